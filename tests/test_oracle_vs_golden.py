@@ -1,0 +1,233 @@
+"""Pins oracle/torch_ref.py (the CPU restatement) against the golden vectors frozen from the imported
+reference (tests/golden/make_goldens.py, groups G1..G16 of SURVEY.md §8c).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import tt
+from oracle import torch_ref as O
+from param_fill import chain_inputs, decoder_feats, fill_params, smooth_images, sparse_gt
+
+RTOL, ATOL = 1e-4, 1e-6           # BASELINE.json north_star: "within 1e-4 rel fp32"
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def test_g01_pose(golden):
+    g = golden("g01_pose")
+    aa, tr = tt(g["axisangle"]), tt(g["translation"])
+    close(O.rot_from_axisangle(aa), g["R"])
+    close(O.transformation_from_parameters(aa, tr, False), g["M"])
+    close(O.transformation_from_parameters(aa, tr, True), g["M_inv"])
+
+
+def test_g02_g03_geometry(golden):
+    g2, g3 = golden("g02_backproject"), golden("g03_project3d")
+    B, H, W = int(g2["B"]), int(g2["H"]), int(g2["W"])
+    d = chain_inputs(int(g2["seed"]), B, H, W)
+    depth = O.upsample_disp(tt(d["disp"]), H, W)
+    assert np.array_equal(depth.numpy(), g2["depth"])
+    cam = O.backproject_depth(depth, tt(d["inv_K"]))
+    assert np.array_equal(cam.numpy(), g2["cam_points"])          # same ATen ops -> bit-exact
+    grid = O.project_3d(cam, tt(d["K"]), tt(g3["T"]), H, W)
+    assert np.array_equal(grid.numpy(), g3["grid"])
+    x0, y0 = O.grid_sample_indices(grid, H, W)
+    assert np.array_equal(x0.numpy(), g3["x0"]) and np.array_equal(y0.numpy(), g3["y0"])
+
+
+def test_g04_grid_sample(golden):
+    g = golden("g04_grid_sample")
+    out = torch.nn.functional.grid_sample(tt(g["img"]), tt(g["grid"]), padding_mode="border", align_corners=True)
+    close(out, g["out"])
+    x0, y0 = O.grid_sample_indices(tt(g["grid"]), 12, 20)
+    assert np.array_equal(x0.numpy(), g["x0"]) and np.array_equal(y0.numpy(), g["y0"])
+
+
+def test_g05_g06_ssim(golden):
+    g = golden("g05_ssim")
+    x = tt(g["x"]).requires_grad_(True)
+    s = O.ssim(x, tt(g["y"]))
+    close(s, g["ssim"])
+    (s * tt(g["w"])).sum().backward()
+    close(x.grad, g["grad_x"], atol=1e-5)
+    g = golden("g06_reprojection")
+    x = tt(g["x"]).requires_grad_(True)
+    r = O.reprojection_loss(x, tt(g["y"]))
+    close(r, g["loss"])
+    (r * tt(g["w"])).sum().backward()
+    close(x.grad, g["grad_pred"], atol=1e-5)
+
+
+def _chain(d, B, H, W, grad=True):
+    disp = tt(d["disp"]).requires_grad_(grad)
+    poses = {f: (tt(d["axisangle_s%d" % i]).requires_grad_(grad), tt(d["translation_s%d" % i]).requires_grad_(grad))
+             for i, f in enumerate((-1, 1))}
+    colors = {0: tt(d["color0"]), -1: tt(d["color_s0"]), 1: tt(d["color_s1"])}
+    out = O.photometric_chain(disp, poses, tt(d["K"]), tt(d["inv_K"]), colors, [0, -1, 1], tt(d["noise"]), H, W)
+    return out, disp, poses
+
+
+@pytest.mark.parametrize("tag", ["a", "b"])
+def test_g07_g08_chain(golden, tag):
+    g7, g8 = golden("g07_generate_images_pred_" + tag), golden("g08_compute_losses_" + tag)
+    B, H, W = int(g7["B"]), int(g7["H"]), int(g7["W"])
+    out, disp, poses = _chain(chain_inputs(int(g7["seed"]), B, H, W), B, H, W)
+    close(out[("depth", 0, 0)], g7["depth"])
+    for f, n in ((-1, "m1"), (1, "p1")):
+        close(out[("sample", f, 0)], g7["sample_" + n], atol=1e-6)
+        close(out[("color", f, 0)], g7["color_" + n], atol=1e-5)
+        x0, y0 = O.grid_sample_indices(out[("sample", f, 0)].detach(), H, W)
+        ok = ~g7["fragile_" + n]
+        assert np.array_equal(x0.numpy()[ok], g7["x0_" + n][ok]) and np.array_equal(y0.numpy()[ok], g7["y0_" + n][ok])
+    close(out["loss"], g8["loss"])
+    assert np.array_equal(out["identity_selection/0"].numpy(), g8["identity_selection"])
+    out["loss"].backward()
+    close(disp.grad, g8["grad_disp"], atol=1e-9)
+    for f, n in ((-1, "m1"), (1, "p1")):
+        close(poses[f][0].grad, g8["grad_axisangle_" + n], atol=1e-7)
+        close(poses[f][1].grad, g8["grad_translation_" + n], atol=1e-7)
+
+
+def test_g09_smooth(golden):
+    g = golden("g09_smooth")
+    d = tt(g["disp"]).requires_grad_(True)
+    loss = O.smooth_loss(d, tt(g["img"]))
+    close(loss, g["loss"])
+    loss.backward()
+    close(d.grad, g["grad_disp"], atol=1e-9)
+
+
+def test_g10_full_query_layer(golden):
+    g = golden("g10_full_query_layer")
+    x, K = tt(g["x"]).requires_grad_(True), tt(g["K"]).requires_grad_(True)
+    y, s = O.full_query_layer(x, K)
+    close(y, g["y"], atol=1e-5)
+    close(s, g["summary"], atol=1e-5)
+    ((y * tt(g["wy"])).sum() + (s * tt(g["ws"])).sum()).backward()
+    close(x.grad, g["grad_x"], atol=1e-5)
+    close(K.grad, g["grad_K"], atol=1e-4)
+
+
+@pytest.mark.parametrize("tag,ff", [("full", 1024), ("lite", 512)])
+def test_g11_qtr(golden, tag, ff):
+    g = golden("g11_qtr_" + tag)
+    kw = {k: (float(v) if "." in v else int(v)) for k, v in g["kw"]}
+    m = O.QueryTrDecoder(dim_feedforward=ff, **kw)
+    fill_params(m, int(g["seed"]))
+    m.eval()
+    x = tt(np.random.RandomState(int(g["x_seed"])).standard_normal((2, 16, 32, 48)).astype(np.float32)).requires_grad_(True)
+    out = m(x)[("disp", 0)]
+    close(out, g["disp"], atol=1e-5)
+    (out * tt(g["w"])).sum().backward()
+    close(x.grad, g["grad_x"], rtol=1e-3, atol=1e-4)
+    P = dict(m.named_parameters())
+    for k in g:
+        if k.startswith("grad__"):
+            close(P[k[6:].replace("__", ".")].grad, g[k], rtol=1e-3, atol=1e-4)
+
+
+def test_g12_posecnn(golden):
+    g = golden("g12_posecnn")
+    m = fill_params(O.PoseCNN(2), int(g["seed"]))
+    x = tt(smooth_images(np.random.RandomState(int(g["x_seed"])), 2, 64, 96, C=6)).requires_grad_(True)
+    aa, tr = m(x)
+    close(aa, g["axisangle"]); close(tr, g["translation"])
+    (aa.sum() * 3 + tr.sum()).backward()
+    close(x.grad, g["grad_x"], atol=1e-7)
+    close(m.net[0].weight.grad, g["grad_w0"], atol=1e-6)
+    close(m.pose_conv.weight.grad, g["grad_pose_conv"], atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,skips,chans", [("res50", (1024, 512, 256, 64), (64, 256, 512, 1024, 2048)),
+                                              ("lite", (256, 128, 64, 64), (64, 64, 128, 256, 512))])
+def test_g13_decoderbn(golden, tag, skips, chans):
+    g = golden("g13_decoderbn_" + tag)
+    dec = fill_params(O.DecoderBN(int(g["nf"]), 8, int(g["bott"]), skips), int(g["seed"]))
+    feats = [tt(f).requires_grad_(True) for f in decoder_feats(int(g["feat_seed"]), chans, 32, 48)]
+    dec.train()
+    out = dec(feats)
+    close(out, g["out_train"], atol=1e-5)
+    out.square().mean().backward()
+    close(dec.up1._net[1].running_mean, g["up1_running_mean_after"])
+    close(feats[0].grad, g["grad_feat0"], rtol=1e-3, atol=1e-7)
+    close(feats[4].grad, g["grad_feat4"], rtol=1e-3, atol=1e-7)
+    close(dec.conv2.weight.grad, g["grad_conv2_w"], rtol=1e-3, atol=1e-7)
+    close(dec.up4._net[1].weight.grad, g["grad_up4_bn_w"], rtol=1e-3, atol=1e-7)
+    dec.eval()
+    close(dec([f.detach() for f in feats]), g["out_eval"], atol=1e-5)
+
+
+def test_g14_depth_errors(golden):
+    g = golden("g14_depth_errors")
+    gt = tt(sparse_gt(int(g["gt_seed"]), 2))
+    m = O.compute_depth_losses(tt(g["pred"]), gt)
+    close(torch.stack([x.double() for x in m]), g["metrics"], rtol=1e-5)
+
+
+def _models(kind):
+    if kind == "res18":
+        enc = O.LiteResnetEncoderDecoder(model_dim=16)
+        dep = O.QueryTrDecoder(16, 16, 8, 4, 12, 24, min_val=0.001, max_val=80.0, dim_feedforward=512, dropout=0.0)
+    else:
+        enc = O.ResnetEncoderDecoder(50, 64, 16)
+        dep = O.QueryTrDecoder(16, 16, 8, 4, 12, 24, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
+    pose = O.PoseCNN(2)
+    fill_params(enc, 1501); fill_params(dep, 1502); fill_params(pose, 1503)
+    for m in (enc, dep, pose):
+        m.train()
+    return enc, dep, pose
+
+
+def batch_inputs(seed, B, H, W):
+    d = chain_inputs(seed, B, H, W)
+    rs = np.random.RandomState(seed + 1)
+    aug = {k: np.clip(d[k] * rs.uniform(0.9, 1.1) + rs.uniform(-0.03, 0.03), 0, 1).astype(np.float32)
+           for k in ("color0", "color_s0", "color_s1")}
+    return {("color", 0, 0): tt(d["color0"]), ("color", -1, 0): tt(d["color_s0"]), ("color", 1, 0): tt(d["color_s1"]),
+            ("color_aug", 0, 0): tt(aug["color0"]), ("color_aug", -1, 0): tt(aug["color_s0"]),
+            ("color_aug", 1, 0): tt(aug["color_s1"]), ("K", 0): tt(d["K"]), ("inv_K", 0): tt(d["inv_K"])}, tt(d["noise"])
+
+
+@pytest.mark.parametrize("kind", ["res18", "res50"])
+def test_g15_g16_train_steps(golden, kind):
+    g15, g16 = golden("g15_process_batch_" + kind), golden("g16_adam_steps_" + kind)
+    B, H, W = int(g15["B"]), int(g15["H"]), int(g15["W"])
+    enc, dep, pose = _models(kind)
+    step = O.RefTrainStep(enc, dep, pose, (0, -1, 1), H, W)
+    traj = []
+    for it in range(3):
+        inputs, noise = batch_inputs(1600 + it, B, H, W)
+        outputs, losses = step.process_batch(inputs, noise)
+        step.optim.zero_grad()
+        losses["loss"].backward()
+        if it == 0:
+            close(outputs[("disp", 0)], g15["disp"], atol=1e-4)
+            close(outputs[("depth", 0, 0)], g15["depth"], atol=1e-4)
+            close(outputs[("axisangle", 0, -1)], g15["axisangle_m1"], atol=1e-7)
+            close(outputs[("translation", 0, 1)], g15["translation_p1"], atol=1e-7)
+            close(outputs[("cam_T_cam", 0, -1)], g15["cam_T_cam_m1"], atol=1e-6)
+            close(outputs[("color", -1, 0)], g15["color_m1"], atol=1e-4)
+            assert (outputs["identity_selection/0"].numpy() != g15["identity_selection"]).mean() < 1e-3
+            close(enc.encoder.encoder.conv1.weight.grad, g15["grad_enc_conv1"], rtol=2e-3, atol=1e-7)
+            close(enc.decoder.conv3.weight.grad, g15["grad_dec_conv3"], rtol=2e-3, atol=1e-7)
+            close(dep.conv3x3.weight.grad, g15["grad_depth_conv3x3"], rtol=2e-3, atol=1e-7)
+            close(pose.pose_conv.weight.grad, g15["grad_pose_conv"], rtol=2e-3, atol=1e-7)
+            assert enc.encoder.encoder.fc.weight.grad is None and bool(g15["fc_grad_is_none"])
+        step.optim.step()
+        traj.append(float(losses["loss"]))
+    np.testing.assert_allclose(traj, g16["losses"], rtol=1e-4)
+    close(enc.encoder.encoder.conv1.weight, g16["enc_conv1_after"], atol=2e-5)
+    close(pose.pose_conv.weight, g16["pose_conv_after"], atol=2e-5)
+    close(dep.conv3x3.weight, g16["depth_conv3x3_after"], atol=2e-5)
+
+
+def test_state_dict_keys(golden):
+    g = golden("g00_state_dict_keys")
+    mods = {"encoder_res50": O.ResnetEncoderDecoder(50, 256, 32), "encoder_res18": O.LiteResnetEncoderDecoder(32),
+            "depth": O.QueryTrDecoder(32, 32, 16, 4, 64, 64), "pose": O.PoseCNN(2)}
+    for n, m in mods.items():
+        mine = ["%s %s" % (k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        assert mine == list(g[n]), n
