@@ -1,0 +1,148 @@
+/* sqd.h — C ABI of libsqd.so, the MI355X (gfx950) implementation of the SQLdepth self-supervised
+ * training hot path (reference: hisfog/SfMNeXt-Impl).
+ *
+ * The reference has no FFI seam (pure Python): each entry point below replaces a run
+ * of ATen dispatches issued by a Python function of the reference, cited per function.  The
+ * reference-side binding a maintainer would add is a ctypes stub — see INTEGRATION.md.
+ *
+ * Contract (all functions):
+ *   - plain C, no C++/torch types; every pointer is a DEVICE pointer unless the name ends in _host;
+ *   - the caller owns all memory (inputs, outputs, workspaces); the library never allocates, frees,
+ *     retains pointers or synchronises; work is enqueued on `stream` (a hipStream_t, passed as void*);
+ *   - tensors are fp32, contiguous, NCHW unless stated; shapes are given as int32;
+ *   - return 0 on success, a negative SQD_E* code otherwise; sqd_last_error() returns a
+ *     thread-local description of the last failure; nothing throws, nothing calls exit();
+ *   - re-entrant: no global mutable state except that thread-local error string.
+ */
+#ifndef SQD_H_
+#define SQD_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SQD_ABI_VERSION 1
+#define SQD_OK 0
+#define SQD_EINVAL (-1)   /* bad shape / null pointer / unsupported configuration */
+#define SQD_ELAUNCH (-2)  /* hipGetLastError() after launch */
+
+#define SQD_MAX_SOURCES 4 /* source frames per target (reference frame_ids[1:], default 2) */
+#define SQD_STRIP_COLS 58 /* output columns per wavefront strip of the column-march kernels */
+
+int sqd_abi_version(void);
+const char *sqd_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * (1) depth upsample + per-image reductions
+ * replaces: F.interpolate(disp,[H,W],bilinear,align_corners=False)  reference trainer.py:395-399
+ *           inv_depth.mean(3).mean(2)                               reference trainer.py:417-418
+ *           disp.mean(2).mean(3)                                    reference trainer.py:535
+ * disp_lr [B,1,h,w] -> depth [B,1,H,W]; part [B, nblk, 2] = per-block (sum 1/depth, sum depth)
+ * with nblk = sqd_depth_up_nblk(H,W).  Deterministic (no atomics).                                  */
+int sqd_depth_up_nblk(int H, int W);
+int sqd_depth_up_fwd(const float *disp_lr, float *depth, float *part, int B, int h, int w, int H, int W,
+                     void *stream);
+/* adjoint: g_depth [B,ng,H,W] = ng gradient planes w.r.t. the full-res depth that are summed on the
+ * fly (photometric per source + smoothness), g_mid [B] = dL/d(mean_inv_depth[b]) (may be NULL)
+ * -> g_disp_lr [B,1,h,w] (overwritten).                                                              */
+int sqd_depth_up_bwd(const float *g_depth, int ng, const float *depth, const float *g_mid, float *g_disp_lr,
+                     int B, int h, int w, int H, int W, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (2) pose -> projection matrices
+ * replaces: transformation_from_parameters / rot_from_axisangle / get_translation_matrix
+ *           (reference layers.py:75-150) called from trainer.py:336-337 and :420-421, and
+ *           P = (K @ T)[:, :3] of Project3D.forward (reference layers.py:248).
+ * axisangle, translation [B,S,3]; invert_host[S] (1 = frame_id < 0); K [B,4,4];
+ * part/nblk from sqd_depth_up_fwd, or part == NULL to use scale 1 (the un-scaled cam_T_cam).
+ * outputs: mid [B] mean inverse depth (may be NULL when part == NULL), T [B,S,4,4], P [B,S,3,4].     */
+int sqd_pose_mats_fwd(const float *axisangle, const float *translation, const int32_t *invert_host,
+                      const float *K, const float *part, int nblk, int HW, float *mid, float *T, float *P,
+                      int B, int S, void *stream);
+/* adjoint: g_P [B,S,3,4] -> g_axisangle, g_translation [B,S,3], g_mid [B] (g_mid may be NULL).       */
+int sqd_pose_mats_bwd(const float *axisangle, const float *translation, const int32_t *invert_host,
+                      const float *K, const float *mid, const float *g_P, float *g_axisangle,
+                      float *g_translation, float *g_mid, int B, int S, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (3) photometric chain
+ * replaces (fused): BackprojectDepth.forward (layers.py:210-215), Project3D.forward (layers.py:247-258),
+ *   F.grid_sample(border, align_corners=True) (trainer.py:431-435), compute_reprojection_loss
+ *   (trainer.py:441-453) with SSIM (layers.py:13-46), the identity losses + tie-break noise, the
+ *   per-pixel min / auto-mask and the mean (trainer.py:474-532).
+ */
+typedef struct sqd_photo_args {
+    /* inputs */
+    const float *depth;     /* [B,1,H,W] from sqd_depth_up_fwd                                       */
+    const float *inv_K;     /* [B,4,4]                                                               */
+    const float *P;         /* [B,S,3,4] from sqd_pose_mats_fwd (or caller-computed)                 */
+    const float *target;    /* [B,3,H,W]  inputs[("color",0,0)]                                      */
+    const float *sources[SQD_MAX_SOURCES]; /* S x [B,3,H,W]  inputs[("color",f,0)], f in frame_ids[1:] */
+    const float *identity;  /* [B,S,H,W] identity reprojection loss + 1e-5*noise (sqd_identity_fwd)  */
+    /* outputs (any of sample[s]/warped[s]/sel/x0y0[s]/coef/reproj may be NULL to skip the store) */
+    float *sample[SQD_MAX_SOURCES];  /* S x [B,H,W,2] outputs[("sample",f,0)]                        */
+    float *warped[SQD_MAX_SOURCES];  /* S x [B,3,H,W] outputs[("color",f,0)]                         */
+    float *sel;             /* [B,H,W]    outputs["identity_selection/0"] (0/1)                      */
+    uint8_t *idx;           /* [B,H,W]    argmin over [identity_0..S-1, reproj_0..S-1]               */
+    int32_t *x0y0[SQD_MAX_SOURCES];  /* S x [B,H,W,2] integer grid_sample taps (x0,y0) — parity instrumentation */
+    float *coef;            /* [B,9,H,W]  d(to_optimise)/d(window stats) of the winning source, for bwd */
+    float *reproj;          /* [B,S,H,W]  reprojection loss maps (debug/parity; may be NULL)         */
+    float *loss_part;       /* [ntasks]   per-wavefront partial sums of to_optimise                  */
+    int32_t B, S, H, W;
+    int32_t rows_per_task;  /* TH: (TH+6) % 7 == 0, e.g. 8, 15, 22, 64; 0 = library default          */
+    void *stream;
+} sqd_photo_args;
+int sqd_photo_ntasks(int B, int H, int W, int rows_per_task);
+int sqd_photo_fwd(const sqd_photo_args *a);
+
+/* identity reprojection losses (trainer.py:480-487) + tie-break noise (trainer.py:514-517).
+ * Depends only on the batch, not on the networks: the trainer enqueues it on a side stream.
+ * target [B,3,H,W], sources_host[S] device pointers to [B,3,H,W], noise [B,S,H,W] (may be NULL)
+ * -> identity [B,S,H,W].                                                                              */
+int sqd_identity_fwd(const float *target, const float *const *sources_host, const float *noise, float *identity,
+                     int B, int S, int H, int W, int rows_per_task, void *stream);
+
+/* backward of sqd_photo_fwd w.r.t. depth and P.  gscale = dL/d(mean to_optimise) / (B*H*W).
+ * One wavefront per (image, source, strip): plane s of g_depth = contribution of source s (fully
+ * overwritten); image b's planes start at g_depth + b*g_depth_img_stride (elements), so the caller
+ * can reserve extra planes (smoothness) behind them for sqd_depth_up_bwd.  g_P_part [ntasks_bwd, 12]
+ * per-wavefront partials, ntasks_bwd = sqd_photo_bwd_ntasks(...) ordered [B][S][tasks_per_image].    */
+typedef struct sqd_photo_bwd_args {
+    const float *depth, *inv_K, *P, *target, *coef;
+    const float *sources[SQD_MAX_SOURCES]; /* S x [B,3,H,W] */
+    const float *sample[SQD_MAX_SOURCES];  /* S x [B,H,W,2] as written by sqd_photo_fwd */
+    const uint8_t *idx;
+    float *g_depth;
+    float *g_P_part;
+    int64_t g_depth_img_stride; /* >= S*H*W */
+    float gscale;
+    int32_t B, S, H, W;
+    int32_t rows_per_task;  /* TH: (TH+6) % 7 == 0; 0 = default */
+    void *stream;
+} sqd_photo_bwd_args;
+int sqd_photo_bwd_ntasks(int B, int S, int H, int W, int rows_per_task);
+int sqd_photo_bwd(const sqd_photo_bwd_args *a);
+/* sums the per-wavefront partials: g_P_part [B,S,tasks_per_image,12] -> g_P [B,S,3,4]                */
+int sqd_photo_bwd_reduce(const float *g_P_part, float *g_P, int ntasks, int tasks_per_image, int B, int S,
+                         void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (4) edge-aware smoothness on the mean-normalised depth
+ * replaces: disp / (disp.mean(2).mean(3) + 1e-7)  (trainer.py:535-536) and get_smooth_loss
+ *           (reference layers.py:267-280).
+ * depth [B,1,H,W], color [B,3,H,W], part from sqd_depth_up_fwd (sum depth) ->
+ * sm_part [B, nblk_s, 2] = per-block (sum of x terms, sum of y terms), nblk_s = sqd_smooth_nblk(H,W);
+ * loss = sum_b,blk sm_part[..,0] / (B*H*(W-1)) + sum sm_part[..,1] / (B*(H-1)*W).                    */
+int sqd_smooth_nblk(int H, int W);
+int sqd_smooth_fwd(const float *depth, const float *color, const float *part, int nblk, float *sm_part,
+                   int B, int H, int W, void *stream);
+/* plane = gout * d(smooth)/d(depth): image b's plane is written at g_depth + b*g_depth_img_stride
+ * (elements) — one of the planes summed by sqd_depth_up_bwd.                                          */
+int sqd_smooth_bwd(const float *depth, const float *color, const float *part, int nblk, const float *sm_part,
+                   float gout, float *g_depth, int64_t g_depth_img_stride, int B, int H, int W, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SQD_H_ */

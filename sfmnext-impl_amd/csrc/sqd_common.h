@@ -1,0 +1,79 @@
+// sqd_common.h — shared helpers for the gfx950 kernels of libsqd.so (wave64, CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <type_traits>
+#include <utility>
+
+#include "../../include/sqd.h"
+
+namespace sqd {
+
+void set_error(const char *fmt, ...);
+
+#define SQD_CHECK_ARG(cond, ...)            \
+    do {                                    \
+        if (!(cond)) {                      \
+            sqd::set_error(__VA_ARGS__);    \
+            return SQD_EINVAL;              \
+        }                                   \
+    } while (0)
+
+#define SQD_CHECK_LAUNCH(name)                                                        \
+    do {                                                                              \
+        hipError_t e_ = hipGetLastError();                                            \
+        if (e_ != hipSuccess) {                                                       \
+            sqd::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));     \
+            return SQD_ELAUNCH;                                                       \
+        }                                                                             \
+    } while (0)
+
+constexpr int WAVE = 64;
+
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(<N-1>) — register arrays indexed by
+// the loop counter stay in VGPRs (a runtime index would send them to scratch).
+template <typename F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// ---- wave64 cross-lane primitives (DPP, no LDS) -------------------------------------------------
+// lane i receives lane i-1 (lane 0 receives 0)
+__device__ __forceinline__ float wave_shr1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x138, 0xf, 0xf, true));
+}
+// lane i receives lane i+1 (lane 63 receives 0)
+__device__ __forceinline__ float wave_shl1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x130, 0xf, 0xf, true));
+}
+// centred 7-tap box sum across lanes: out[i] = v[i-3] + ... + v[i+3] (zero beyond the wave edges).
+// Six v_add_f32_dpp, no LDS traffic: the SSIM window reduction along x.
+__device__ __forceinline__ float box7(float v) {
+    float r = v + wave_shr1(v);          // v[i] + v[i-1]
+    r = v + wave_shr1(r);                // .. + v[i-2]
+    r = v + wave_shr1(r);                // .. + v[i-3]
+    float u = v + wave_shl1(v);          // v[i] + v[i+1]
+    u = v + wave_shl1(u);                // .. + v[i+2]
+    return r + wave_shl1(u);             // + v[i+1] + v[i+2] + v[i+3]
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// reflection index of ReflectionPad2d (pad < n), clamped for lanes far outside the image
+__device__ __forceinline__ int reflect_idx(int p, int n) {
+    p = p < 0 ? -p : p;
+    p = p >= n ? 2 * (n - 1) - p : p;
+    return min(max(p, 0), n - 1);
+}
+
+}  // namespace sqd

@@ -1,0 +1,28 @@
+"""PoseCNN (reference networks/pose_cnn.py:9-45): seven stride-2 conv+ReLU stages, a 1x1 head, spatial
+mean, x0.01, split into axis-angle and translation.  State-dict keys: pose_conv.*, net.{0..6}.* —
+`pose_conv` is registered before `net`, as in the reference."""
+import torch.nn as nn
+
+from sqd import nnops as X
+
+_STAGES = ((16, 7), (32, 5), (64, 3), (128, 3), (256, 3), (256, 3), (256, 3))
+
+
+class PoseCNN(nn.Module):
+    def __init__(self, num_input_frames):
+        super().__init__()
+        self.num_input_frames = num_input_frames
+        convs, cin = [], 3 * num_input_frames
+        for cout, k in _STAGES:
+            convs.append(nn.Conv2d(cin, cout, k, 2, (k - 1) // 2))
+            cin = cout
+        self.pose_conv = nn.Conv2d(cin, 6 * (num_input_frames - 1), 1)
+        self.num_convs = len(convs)
+        self.net = nn.ModuleList(convs)
+
+    def forward(self, out):
+        for conv in self.net:
+            out = X.conv2d(out, conv, "relu")
+        out = X.conv2d(out, self.pose_conv).mean(3).mean(2)
+        out = 0.01 * out.view(-1, self.num_input_frames - 1, 1, 6)
+        return out[..., :3], out[..., 3:]

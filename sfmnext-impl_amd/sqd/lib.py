@@ -1,0 +1,116 @@
+"""ctypes binding of libsqd.so (C ABI declared in include/sqd.h) + the hipcc build recipe.
+
+The product path is HIP-only: `lib()` raises if the library is missing and every wrapper in
+sqd.ops raises on CPU tensors.  There is no CPU fallback (the CPU restatement lives in oracle/ and is
+test infrastructure)."""
+import ctypes
+import glob
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
+SO_PATH = os.path.join(_HERE, "libsqd.so")
+MAX_SOURCES = 4
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
+
+c_float_p = ctypes.POINTER(ctypes.c_float)
+c_void_p = ctypes.c_void_p
+
+
+class PhotoArgs(ctypes.Structure):
+    """struct sqd_photo_args (include/sqd.h)."""
+    _fields_ = [("depth", c_void_p), ("inv_K", c_void_p), ("P", c_void_p), ("target", c_void_p),
+                ("sources", c_void_p * MAX_SOURCES), ("identity", c_void_p),
+                ("sample", c_void_p * MAX_SOURCES), ("warped", c_void_p * MAX_SOURCES),
+                ("sel", c_void_p), ("idx", c_void_p), ("x0y0", c_void_p * MAX_SOURCES),
+                ("coef", c_void_p), ("reproj", c_void_p), ("loss_part", c_void_p),
+                ("B", ctypes.c_int32), ("S", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("rows_per_task", ctypes.c_int32), ("stream", c_void_p)]
+
+
+class PhotoBwdArgs(ctypes.Structure):
+    """struct sqd_photo_bwd_args (include/sqd.h)."""
+    _fields_ = [("depth", c_void_p), ("inv_K", c_void_p), ("P", c_void_p), ("target", c_void_p),
+                ("coef", c_void_p), ("sources", c_void_p * MAX_SOURCES), ("sample", c_void_p * MAX_SOURCES),
+                ("idx", c_void_p), ("g_depth", c_void_p), ("g_P_part", c_void_p), ("g_depth_img_stride", ctypes.c_int64),
+                ("gscale", ctypes.c_float),
+                ("B", ctypes.c_int32), ("S", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+                ("rows_per_task", ctypes.c_int32), ("stream", c_void_p)]
+
+
+def sources():
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def needs_build():
+    if not os.path.exists(SO_PATH):
+        return True
+    t = os.path.getmtime(SO_PATH)
+    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
+        [os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "sqd.h")]
+    return any(os.path.getmtime(f) > t for f in deps)
+
+
+def build(force=False, verbose=False):
+    """hipcc cross-compiles every csrc/*.hip for gfx950 into sqd/libsqd.so (works without a GPU)."""
+    if not force and not needs_build():
+        return SO_PATH
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    cmd = [hipcc] + HIPCC_FLAGS + sources() + ["-o", SO_PATH + ".tmp"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    os.replace(SO_PATH + ".tmp", SO_PATH)
+    global _LIB
+    _LIB = None
+    return SO_PATH
+
+
+_LIB = None
+_I, _F, _P = ctypes.c_int, ctypes.c_float, c_void_p
+_SIGNATURES = {
+    "sqd_abi_version": (ctypes.c_int, []),
+    "sqd_last_error": (ctypes.c_char_p, []),
+    "sqd_depth_up_nblk": (_I, [_I, _I]),
+    "sqd_depth_up_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sqd_depth_up_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sqd_pose_mats_fwd": (_I, [_P, _P, ctypes.POINTER(ctypes.c_int32), _P, _P, _I, _I, _P, _P, _P, _I, _I, _P]),
+    "sqd_pose_mats_bwd": (_I, [_P, _P, ctypes.POINTER(ctypes.c_int32), _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "sqd_photo_ntasks": (_I, [_I, _I, _I, _I]),
+    "sqd_photo_fwd": (_I, [ctypes.POINTER(PhotoArgs)]),
+    "sqd_identity_fwd": (_I, [_P, ctypes.POINTER(c_void_p), _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sqd_photo_bwd_ntasks": (_I, [_I, _I, _I, _I, _I]),
+    "sqd_photo_bwd": (_I, [ctypes.POINTER(PhotoBwdArgs)]),
+    "sqd_photo_bwd_reduce": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "sqd_smooth_nblk": (_I, [_I, _I]),
+    "sqd_smooth_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P]),
+    "sqd_smooth_bwd": (_I, [_P, _P, _P, _I, _P, _F, _P, ctypes.c_int64, _I, _I, _I, _P]),
+}
+
+
+def exported_symbols():
+    """Every entry point include/sqd.h declares (used by the symbol-export test)."""
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(SO_PATH):
+            raise RuntimeError("libsqd.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                               "(hipcc --offload-arch=gfx950). The SQLdepth hot path has no CPU fallback.")
+        L = ctypes.CDLL(SO_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        if L.sqd_abi_version() != 1:
+            raise RuntimeError("libsqd.so ABI version mismatch")
+        _LIB = L
+    return _LIB
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("libsqd %s failed (%d): %s" % (what, rc, lib().sqd_last_error().decode()))

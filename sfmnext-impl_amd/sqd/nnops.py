@@ -1,0 +1,85 @@
+"""Operator dispatch point of the networks (sqd.nnops).
+
+Every tensor operation of the SQLdepth networks is routed through this module so that the
+hand-written gfx950 kernels replace the vendor library one operator at a time without touching the
+module definitions (state-dict keys stay those of the reference).  `BACKEND[name]` records which
+implementation serves each operator:
+
+    "hip"   hand-written kernel in libsqd.so (csrc/*.hip)
+    "aten"  interim: PyTorch-ROCm ATen (MIOpen / rocBLAS) — listed in DESIGN.md §"Kernel coverage"
+            as not yet native; never a CPU fallback: on a GPU box the tensors are device tensors.
+"""
+import torch
+import torch.nn.functional as F
+
+BACKEND = {
+    "conv2d": "aten", "conv_bn_act": "aten", "maxpool3x3s2": "aten", "upsample_concat": "aten",
+    "linear": "aten", "transformer_encoder": "aten", "full_query_layer": "aten", "bins_head": "aten",
+}
+
+
+def _act(y, act):
+    if act is None:
+        return y
+    if act == "relu":
+        return F.relu(y)
+    if act == "leaky_relu":
+        return F.leaky_relu(y, 0.01)
+    raise ValueError(act)
+
+
+def conv2d(x, conv, act=None):
+    """conv (nn.Conv2d holding weight/bias/stride/padding) applied to x, optional activation."""
+    return _act(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), act)
+
+
+def conv_bn_act(x, conv, bn, act, residual=None, input_affine=None):
+    """[input (x-a)/b] -> conv -> BatchNorm2d (batch stats in training, running stats in eval)
+    -> [+ residual] -> activation."""
+    if input_affine is not None:
+        x = (x - input_affine[0]) / input_affine[1]
+    y = bn(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding))
+    if residual is not None:
+        y = y + residual
+    return _act(y, act)
+
+
+def maxpool3x3s2(x):
+    return F.max_pool2d(x, 3, 2, 1)
+
+
+def upsample_concat(x, skip):
+    """bilinear resize of x to skip's size (align_corners=True) and channel concat [up(x), skip]."""
+    up = F.interpolate(x, size=[skip.size(2), skip.size(3)], mode="bilinear", align_corners=True)
+    return torch.cat([up, skip], dim=1)
+
+
+def linear(x, lin, act=None):
+    y = F.linear(x, lin.weight, lin.bias)
+    return F.leaky_relu(y, 0.01) if act == "leaky_relu" else y
+
+
+def transformer_encoder(tokens, encoder):
+    """tokens [T,B,E] through nn.TransformerEncoder (4 post-norm layers, ReLU feed-forward)."""
+    return encoder(tokens)
+
+
+def full_query_layer(x, queries):
+    """Self Query Layer (reference networks/layers.py:7-21): x [B,E,h,w], queries [B,Q,E] ->
+    energy maps [B,Q,h,w] (raw dot products) and summaries [B,Q,E] (softmax over the h*w pixels)."""
+    n, c, h, w = x.shape
+    xt = x.view(n, c, h * w)
+    y = torch.matmul(queries, xt)                              # [B,Q,N]
+    summary = torch.matmul(torch.softmax(y, dim=2), xt.transpose(1, 2))
+    return y.view(n, queries.shape[1], h, w), summary
+
+
+def bins_head(energy_maps, conv1x1, y, min_val, max_val):
+    """1x1 conv + channel softmax over the energy maps, expected value over the adaptive bin centres
+    (reference networks/depth_decoder_QTR.py:61-70).  y [B,dim_out] = normalised bin widths."""
+    out = torch.softmax(F.conv2d(energy_maps, conv1x1.weight, conv1x1.bias), dim=1)
+    widths = (max_val - min_val) * y
+    widths = F.pad(widths, (1, 0), mode="constant", value=min_val)
+    edges = torch.cumsum(widths, dim=1)
+    centers = 0.5 * (edges[:, :-1] + edges[:, 1:])
+    return torch.sum(out * centers.view(centers.shape[0], -1, 1, 1), dim=1, keepdim=True)

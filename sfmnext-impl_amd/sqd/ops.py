@@ -1,0 +1,226 @@
+"""torch-facing wrappers over libsqd.so.  PyTorch supplies device memory and the current HIP stream;
+all arithmetic of the photometric chain happens in the hand-written gfx950 kernels.
+
+Every wrapper requires CUDA(HIP) fp32 contiguous tensors and raises otherwise — no CPU fallback."""
+import ctypes
+
+import torch
+
+from . import lib as _l
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(0)
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _req(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("sqd: tensors must live on the MI355X (HIP) device; the hot path has no CPU fallback")
+        if not t.is_contiguous():
+            raise RuntimeError("sqd: tensor must be contiguous")
+        if t.dtype not in (torch.float32, torch.uint8, torch.int32):
+            raise RuntimeError("sqd: unsupported dtype %s" % t.dtype)
+
+
+def _i32arr(vals):
+    return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
+
+
+# ---------------------------------------------------------------------------------------------------
+def depth_up_fwd(disp_lr, H, W):
+    """F.interpolate(disp,[H,W],bilinear,align_corners=False) + per-block (sum 1/d, sum d).
+    Returns depth [B,1,H,W], part [B,nblk,2]."""
+    _req(disp_lr)
+    B, _, h, w = disp_lr.shape
+    L = _l.lib()
+    nblk = L.sqd_depth_up_nblk(H, W)
+    depth = torch.empty(B, 1, H, W, device=disp_lr.device, dtype=torch.float32)
+    part = torch.empty(B, nblk, 2, device=disp_lr.device, dtype=torch.float32)
+    _l.check(L.sqd_depth_up_fwd(_ptr(disp_lr), _ptr(depth), _ptr(part), B, h, w, H, W, _stream()), "depth_up_fwd")
+    return depth, part
+
+
+def depth_up_bwd(g_depth, depth, g_mid, h, w):
+    _req(g_depth, depth, g_mid)
+    B, ng, H, W = g_depth.shape
+    out = torch.empty(B, 1, h, w, device=depth.device, dtype=torch.float32)
+    _l.check(_l.lib().sqd_depth_up_bwd(_ptr(g_depth), ng, _ptr(depth), _ptr(g_mid), _ptr(out), B, h, w, H, W, _stream()),
+             "depth_up_bwd")
+    return out
+
+
+def pose_mats_fwd(axisangle, translation, invert, K, part=None, HW=0):
+    """axisangle/translation [B,S,3] -> mid [B] (or None), T [B,S,4,4], P [B,S,3,4]."""
+    _req(axisangle, translation, K, part)
+    B, S, _ = axisangle.shape
+    dev = axisangle.device
+    T = torch.empty(B, S, 4, 4, device=dev, dtype=torch.float32)
+    P = torch.empty(B, S, 3, 4, device=dev, dtype=torch.float32)
+    mid = torch.empty(B, device=dev, dtype=torch.float32) if part is not None else None
+    nblk = part.shape[1] if part is not None else 0
+    _l.check(_l.lib().sqd_pose_mats_fwd(_ptr(axisangle), _ptr(translation), _i32arr(invert), _ptr(K), _ptr(part), nblk,
+                                        HW, _ptr(mid), _ptr(T), _ptr(P), B, S, _stream()), "pose_mats_fwd")
+    return mid, T, P
+
+
+def pose_mats_bwd(axisangle, translation, invert, K, mid, g_P):
+    _req(axisangle, translation, K, mid, g_P)
+    B, S, _ = axisangle.shape
+    g_aa = torch.empty_like(axisangle)
+    g_tr = torch.empty_like(translation)
+    g_mid = torch.empty(B, device=axisangle.device, dtype=torch.float32) if mid is not None else None
+    _l.check(_l.lib().sqd_pose_mats_bwd(_ptr(axisangle), _ptr(translation), _i32arr(invert), _ptr(K), _ptr(mid),
+                                        _ptr(g_P), _ptr(g_aa), _ptr(g_tr), _ptr(g_mid), B, S, _stream()), "pose_mats_bwd")
+    return g_aa, g_tr, g_mid
+
+
+def identity_fwd(target, sources, noise=None, rows_per_task=0):
+    """Identity reprojection losses + 1e-5*noise -> [B,S,H,W]  (trainer.py:480-487,514-517)."""
+    _req(target, noise, *sources)
+    B, _, H, W = target.shape
+    S = len(sources)
+    out = torch.empty(B, S, H, W, device=target.device, dtype=torch.float32)
+    arr = (ctypes.c_void_p * S)(*[s.data_ptr() for s in sources])
+    _l.check(_l.lib().sqd_identity_fwd(_ptr(target), arr, _ptr(noise), _ptr(out), B, S, H, W, rows_per_task, _stream()),
+             "identity_fwd")
+    return out
+
+
+def photo_fwd(depth, inv_K, P, target, sources, identity, training=True, want_taps=False, want_reproj=False,
+              rows_per_task=0):
+    """Fused warp + SSIM/L1 + min/auto-mask.  Returns a dict of device tensors."""
+    _req(depth, inv_K, P, target, identity, *sources)
+    B, _, H, W = target.shape
+    S = len(sources)
+    dev = target.device
+    L = _l.lib()
+    nt = L.sqd_photo_ntasks(B, H, W, rows_per_task)
+    f32 = dict(device=dev, dtype=torch.float32)
+    out = {"sample": [torch.empty(B, H, W, 2, **f32) for _ in range(S)],
+           "warped": [torch.empty(B, 3, H, W, **f32) for _ in range(S)],
+           "sel": torch.empty(B, H, W, **f32),
+           "idx": torch.empty(B, H, W, device=dev, dtype=torch.uint8),
+           "loss_part": torch.empty(nt, **f32),
+           "coef": torch.empty(B, 9, H, W, **f32) if training else None,
+           "x0y0": [torch.empty(B, H, W, 2, device=dev, dtype=torch.int32) for _ in range(S)] if want_taps else None,
+           "reproj": torch.empty(B, S, H, W, **f32) if want_reproj else None}
+    a = _l.PhotoArgs()
+    a.depth, a.inv_K, a.P, a.target, a.identity = (t.data_ptr() for t in (depth, inv_K, P, target, identity))
+    for s in range(S):
+        a.sources[s] = sources[s].data_ptr()
+        a.sample[s] = out["sample"][s].data_ptr()
+        a.warped[s] = out["warped"][s].data_ptr()
+        if want_taps:
+            a.x0y0[s] = out["x0y0"][s].data_ptr()
+    a.sel, a.idx, a.loss_part = out["sel"].data_ptr(), out["idx"].data_ptr(), out["loss_part"].data_ptr()
+    a.coef = out["coef"].data_ptr() if training else None
+    a.reproj = out["reproj"].data_ptr() if want_reproj else None
+    a.B, a.S, a.H, a.W, a.rows_per_task = B, S, H, W, rows_per_task
+    a.stream = torch.cuda.current_stream().cuda_stream
+    _l.check(L.sqd_photo_fwd(ctypes.byref(a)), "photo_fwd")
+    return out
+
+
+def photo_bwd(depth, inv_K, P, target, sources, samples, coef, idx, gscale, rows_per_task=0, extra_planes=0):
+    """-> g_depth [B,S+extra_planes,H,W] (plane s = source s; extra planes left unwritten), g_P [B,S,3,4]."""
+    _req(depth, inv_K, P, target, coef, idx, *sources, *samples)
+    B, _, H, W = target.shape
+    S = len(sources)
+    dev = target.device
+    L = _l.lib()
+    nt = L.sqd_photo_bwd_ntasks(B, S, H, W, rows_per_task)
+    g_depth = torch.empty(B, S + extra_planes, H, W, device=dev, dtype=torch.float32)
+    part = torch.empty(nt, 12, device=dev, dtype=torch.float32)
+    a = _l.PhotoBwdArgs()
+    a.depth, a.inv_K, a.P, a.target, a.coef = (t.data_ptr() for t in (depth, inv_K, P, target, coef))
+    for s in range(S):
+        a.sources[s] = sources[s].data_ptr()
+        a.sample[s] = samples[s].data_ptr()
+    a.idx, a.g_depth, a.g_P_part = idx.data_ptr(), g_depth.data_ptr(), part.data_ptr()
+    a.gscale = float(gscale)
+    a.g_depth_img_stride = (S + extra_planes) * H * W
+    a.B, a.S, a.H, a.W, a.rows_per_task = B, S, H, W, rows_per_task
+    a.stream = torch.cuda.current_stream().cuda_stream
+    _l.check(L.sqd_photo_bwd(ctypes.byref(a)), "photo_bwd")
+    g_P = torch.empty(B, S, 3, 4, device=dev, dtype=torch.float32)
+    _l.check(L.sqd_photo_bwd_reduce(_ptr(part), _ptr(g_P), nt, nt // (B * S), B, S, _stream()), "photo_bwd_reduce")
+    return g_depth, g_P
+
+
+def smooth_fwd(depth, color, part):
+    _req(depth, color, part)
+    B, _, H, W = depth.shape
+    L = _l.lib()
+    nb = L.sqd_smooth_nblk(H, W)
+    sm_part = torch.empty(B, nb, 2, device=depth.device, dtype=torch.float32)
+    _l.check(L.sqd_smooth_fwd(_ptr(depth), _ptr(color), _ptr(part), part.shape[1], _ptr(sm_part), B, H, W, _stream()),
+             "smooth_fwd")
+    return sm_part
+
+
+def smooth_bwd(depth, color, part, sm_part, gout, planes=None, plane=0):
+    """writes gout * d(smooth)/d(depth) into planes[:, plane] of a [B,n,H,W] buffer (allocated if None)."""
+    _req(depth, color, part, sm_part, planes)
+    B, _, H, W = depth.shape
+    if planes is None:
+        planes, plane = torch.empty(B, 1, H, W, device=depth.device, dtype=torch.float32), 0
+    n = planes.shape[1]
+    base = planes.data_ptr() + plane * H * W * 4
+    _l.check(_l.lib().sqd_smooth_bwd(_ptr(depth), _ptr(color), _ptr(part), part.shape[1], _ptr(sm_part), float(gout),
+                                     ctypes.c_void_p(base), n * H * W, B, H, W, _stream()), "smooth_bwd")
+    return planes
+
+
+# ---------------------------------------------------------------------------------------------------
+class PhotometricChain(torch.autograd.Function):
+    """generate_images_pred + compute_losses of the reference (trainer.py:386-549) as one autograd node.
+
+    forward(disp_lr [B,1,h,w], axisangle [B,S,3], translation [B,S,3], K, inv_K, target, identity, meta, *sources)
+      -> total loss (differentiable), photo mean, smooth, depth, sel, sample_0.., warped_0.. (non-differentiable)
+    `meta` = dict(H, W, invert=[...], smooth_weight, rows_per_task)."""
+
+    @staticmethod
+    def forward(ctx, disp_lr, axisangle, translation, K, inv_K, target, identity, meta, *sources):
+        H, W = meta["H"], meta["W"]
+        B, S = target.shape[0], len(sources)
+        rows = meta.get("rows_per_task", 0)
+        training = any(ctx.needs_input_grad[:3])
+        depth, part = depth_up_fwd(disp_lr, H, W)
+        mid, T, P = pose_mats_fwd(axisangle, translation, meta["invert"], K, part, H * W)
+        out = photo_fwd(depth, inv_K, P, target, list(sources), identity, training=training, rows_per_task=rows)
+        sm_part = smooth_fwd(depth, target, part)
+        photo = out["loss_part"].sum() / float(B * H * W)
+        smooth = sm_part[..., 0].sum() / float(B * H * (W - 1)) + sm_part[..., 1].sum() / float(B * (H - 1) * W)
+        total = photo + meta["smooth_weight"] * smooth
+        ctx.meta, ctx.S = meta, S
+        ctx.save_for_backward(disp_lr, axisangle, translation, K, inv_K, target, depth, part, mid, P, out["idx"],
+                              out["coef"] if training else depth, sm_part, *sources, *out["sample"])
+        outs = (total, photo, smooth, depth, out["sel"], T, *out["sample"], *out["warped"])
+        ctx.mark_non_differentiable(*outs[1:])
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_total, *_unused):
+        meta, S = ctx.meta, ctx.S
+        saved = ctx.saved_tensors
+        disp_lr, axisangle, translation, K, inv_K, target, depth, part, mid, P, idx, coef, sm_part = saved[:13]
+        sources, samples = list(saved[13:13 + S]), list(saved[13 + S:13 + 2 * S])
+        B, _, H, W = target.shape
+        h, w = disp_lr.shape[2:]
+        rows = meta.get("rows_per_task", 0)
+        # all adjoints are linear in the upstream gradient: run them with 1.0 and scale the three small results
+        planes, g_P = photo_bwd(depth, inv_K, P, target, sources, samples, coef, idx, 1.0 / float(B * H * W), rows,
+                                extra_planes=1)
+        smooth_bwd(depth, target, part, sm_part, meta["smooth_weight"], planes, S)
+        g_aa, g_tr, g_mid = pose_mats_bwd(axisangle, translation, meta["invert"], K, mid, g_P)
+        g_disp = depth_up_bwd(planes, depth, g_mid, h, w)
+        g = g_total
+        return (g_disp * g, g_aa * g, g_tr * g, None, None, None, None, None) + (None,) * S
+
