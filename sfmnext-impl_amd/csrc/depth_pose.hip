@@ -282,6 +282,7 @@ extern "C" int sqd_depth_up_fwd(const float *disp_lr, float *depth, float *part,
     SQD_CHECK_ARG(disp_lr && depth && part, "sqd_depth_up_fwd: null pointer");
     SQD_CHECK_ARG(B > 0 && h > 0 && w > 0 && H >= h && W >= w, "sqd_depth_up_fwd: bad shape B=%d h=%d w=%d H=%d W=%d", B, h, w, H, W);
     int nblk = sqd_depth_up_nblk(H, W);
+    (void)hipGetLastError();   // drop any stale error left by other HIP users of this thread
     hipLaunchKernelGGL(depth_up_fwd_kernel, dim3(nblk, B), dim3(256), 0, (hipStream_t)stream, disp_lr, depth, part, h, w,
                        H, W, nblk);
     SQD_CHECK_LAUNCH("sqd_depth_up_fwd");
@@ -292,6 +293,7 @@ extern "C" int sqd_depth_up_bwd(const float *g_depth, int ng, const float *depth
                                 int B, int h, int w, int H, int W, void *stream) {
     SQD_CHECK_ARG(g_depth && depth && g_disp_lr && ng >= 1, "sqd_depth_up_bwd: null pointer / ng < 1");
     SQD_CHECK_ARG(B > 0 && h > 0 && w > 0 && H >= h && W >= w, "sqd_depth_up_bwd: bad shape");
+    (void)hipGetLastError();   // drop any stale error left by other HIP users of this thread
     hipLaunchKernelGGL(depth_up_bwd_kernel, dim3((h * w + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, g_depth,
                        ng, depth, g_mid, g_disp_lr, h, w, H, W);
     SQD_CHECK_LAUNCH("sqd_depth_up_bwd");
@@ -311,6 +313,7 @@ extern "C" int sqd_pose_mats_fwd(const float *axisangle, const float *translatio
     SQD_CHECK_ARG(axisangle && translation && invert_host && K && T && P, "sqd_pose_mats_fwd: null pointer");
     SQD_CHECK_ARG(B > 0 && S > 0 && S <= SQD_MAX_SOURCES, "sqd_pose_mats_fwd: bad B=%d S=%d", B, S);
     SQD_CHECK_ARG(!part || (nblk > 0 && HW > 0), "sqd_pose_mats_fwd: part given but nblk/HW invalid");
+    (void)hipGetLastError();   // drop any stale error left by other HIP users of this thread
     hipLaunchKernelGGL(pose_mats_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, axisangle, translation,
                        invert_mask_of(invert_host, S), K, part, nblk, HW, mid, T, P, S);
     SQD_CHECK_LAUNCH("sqd_pose_mats_fwd");
@@ -323,6 +326,7 @@ extern "C" int sqd_pose_mats_bwd(const float *axisangle, const float *translatio
     SQD_CHECK_ARG(axisangle && translation && invert_host && K && g_P && g_axisangle && g_translation,
                   "sqd_pose_mats_bwd: null pointer");
     SQD_CHECK_ARG(B > 0 && S > 0 && S <= SQD_MAX_SOURCES, "sqd_pose_mats_bwd: bad B=%d S=%d", B, S);
+    (void)hipGetLastError();   // drop any stale error left by other HIP users of this thread
     hipLaunchKernelGGL(pose_mats_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, axisangle, translation,
                        invert_mask_of(invert_host, S), K, mid, g_P, g_axisangle, g_translation, g_mid, S);
     SQD_CHECK_LAUNCH("sqd_pose_mats_bwd");

@@ -2,10 +2,11 @@
 //
 // Execution shape ("column march"): one wavefront owns a strip of 58 output columns (64 lanes = 58 +
 // a 3-column halo on each side) and marches down TH output rows.  Each lane keeps the last 7 rows of
-// its own column in registers, so the vertical half of the 7x7 SSIM window is a register sum and
-// the horizontal half is a 6-instruction DPP chain across lanes (box7) — no LDS, no barriers.  The
-// image rows arrive as coalesced 256-byte wavefront rows.  ReflectionPad2d(3) is folded in by
-// reflecting the halo coordinates when loading.
+// its own column in a register ring, so the vertical half of the 7x7 SSIM window is a register sum
+// and the horizontal half is a 6-instruction DPP chain across lanes (box7) — no LDS, no barriers.
+// The image rows arrive as coalesced 256-byte wavefront rows.  ReflectionPad2d(3) is folded in by
+// reflecting the halo coordinates when loading.  The row loop is a single rolled loop (the ring is
+// shifted by register moves) so the whole kernel stays resident in the instruction cache.
 //
 // Roofline: HBM.  Algorithmic bytes per target pixel (S = 2): fused forward 93 B (SURVEY.md §8d:
 // reads disp 1 + target 12 + sources 24 + identity/noise 8, writes depth 4 + sample 16 + warped 24 +
@@ -27,16 +28,14 @@ struct Taps {
     float fx0, fy0;        // floor
     int x0, y0;
     bool xin, yin;         // x0+1 < W, y0+1 < H
-    float u, v, z;         // px/z, py/z, pz+eps (for the adjoint)
-    bool mx, my;           // clamp passes gradient
 };
 
 __device__ __forceinline__ void cam_ray(const float *ik, float fx, float fy, float c[3]) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        float acc = ik[i * 4 + 0] * fx;                 // layers.py:211  (FMA chain k = 0..2)
-        acc = fmaf(ik[i * 4 + 1], fy, acc);
-        acc = fmaf(ik[i * 4 + 2], 1.0f, acc);
+        float acc = ik[i * 3 + 0] * fx;                 // layers.py:211  (FMA chain k = 0..2)
+        acc = fmaf(ik[i * 3 + 1], fy, acc);
+        acc = fmaf(ik[i * 3 + 2], 1.0f, acc);
         c[i] = acc;
     }
 }
@@ -52,17 +51,14 @@ __device__ __forceinline__ Taps project(const float *P, const float X[3], float 
         cam[i] = acc;
     }
     Taps t;
-    t.z = cam[2] + 1e-7f;                               // layers.py:252
-    t.u = cam[0] / t.z;
-    t.v = cam[1] / t.z;
-    float un = t.u / wm1, vn = t.v / hm1;               // :255-256
+    const float z = cam[2] + 1e-7f;                     // layers.py:252
+    const float u = cam[0] / z, v = cam[1] / z;
+    const float un = u / wm1, vn = v / hm1;             // :255-256
     t.gx = (un - 0.5f) * 2.0f;                          // :257
     t.gy = (vn - 0.5f) * 2.0f;
-    float ix = ((t.gx + 1.0f) * 0.5f) * wm1;            // grid_sampler_unnormalize (x/2 == x*0.5 exactly)
-    float iy = ((t.gy + 1.0f) * 0.5f) * hm1;
-    t.mx = ix > 0.f && ix < wm1;                        // clip_coordinates_set_grad
-    t.my = iy > 0.f && iy < hm1;
-    t.ix = fminf(wm1, fmaxf(ix, 0.f));
+    const float ix = ((t.gx + 1.0f) * 0.5f) * wm1;      // grid_sampler_unnormalize (x/2 == x*0.5 exactly)
+    const float iy = ((t.gy + 1.0f) * 0.5f) * hm1;
+    t.ix = fminf(wm1, fmaxf(ix, 0.f));                  // clip_coordinates (padding_mode border)
     t.iy = fminf(hm1, fmaxf(iy, 0.f));
     t.fx0 = floorf(t.ix);
     t.fy0 = floorf(t.iy);
@@ -91,34 +87,27 @@ __device__ __forceinline__ Strip strip_of(int task, int nsx, int nsy, int TH, in
     return s;
 }
 
-// SSIM loss of one (pred, target) channel from the 7x7 window sums — layers.py:35-46
-__device__ __forceinline__ float ssim_from_sums(float Sx, float Sy, float Sxx, float Syy, float Sxy) {
-    float mx = Sx * INV49, my = Sy * INV49;
-    float sx = fmaf(-mx, mx, Sxx * INV49), sy = fmaf(-my, my, Syy * INV49), sxy = fmaf(-mx, my, Sxy * INV49);
-    float n = fmaf(2.f * mx, my, C1) * fmaf(2.f, sxy, C2);
-    float d = (fmaf(mx, mx, my * my) + C1) * (sx + sy + C2);
-    float r = (1.f - n * __builtin_amdgcn_rcpf(d)) * 0.5f;
+// SSIM loss of one (pred, target) channel from the 7x7 window sums — layers.py:35-46.
+// When GRAD, also d(ssim_loss)/d(Sx, Sxx, Sxy) (pred-side window sums; zero where the clamp saturates).
+template <bool GRAD>
+__device__ __forceinline__ float ssim_from_sums(float Sx, float Sy, float Sxx, float Syy, float Sxy, float *g) {
+    const float mx = Sx * INV49, my = Sy * INV49;
+    const float sx = fmaf(-mx, mx, Sxx * INV49), sy = fmaf(-my, my, Syy * INV49), sxy = fmaf(-mx, my, Sxy * INV49);
+    const float A1 = fmaf(2.f * mx, my, C1), A2 = fmaf(2.f, sxy, C2);
+    const float B1 = fmaf(mx, mx, my * my) + C1, B2 = sx + sy + C2;
+    const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
+    const float iB = iB1 * iB2;
+    const float Sv = A1 * A2 * iB;
+    const float r = (1.f - Sv) * 0.5f;
+    if (GRAD) {
+        const bool pass = r >= 0.f && r <= 1.f;                       // torch.clamp passes at the bounds
+        const float k = pass ? -0.5f * INV49 : 0.f;                   // d r / d S, and window mean -> sum
+        const float dmu = 2.f * (my * (A2 - A1) * iB + mx * Sv * (iB2 - iB1));
+        g[0] = k * dmu;                                               // d/dSx
+        g[1] = k * (-Sv * iB2);                                       // d/dSxx
+        g[2] = k * (2.f * A1 * iB);                                   // d/dSxy
+    }
     return fminf(fmaxf(r, 0.f), 1.f);
-}
-
-// d(ssim_loss)/d(Sx, Sxx, Sxy) — pred-side window sums; zero where the clamp saturates
-__device__ __forceinline__ void ssim_grad(float Sx, float Sy, float Sxx, float Syy, float Sxy, float &gSx, float &gSxx,
-                                          float &gSxy) {
-    float mx = Sx * INV49, my = Sy * INV49;
-    float sx = fmaf(-mx, mx, Sxx * INV49), sy = fmaf(-my, my, Syy * INV49), sxy = fmaf(-mx, my, Sxy * INV49);
-    float A1 = fmaf(2.f * mx, my, C1), A2 = fmaf(2.f, sxy, C2);
-    float B1 = fmaf(mx, mx, my * my) + C1, B2 = sx + sy + C2;
-    float iB1 = 1.f / B1, iB2 = 1.f / B2;
-    float Sv = A1 * A2 * iB1 * iB2;
-    float r = (1.f - Sv) * 0.5f;
-    bool pass = r >= 0.f && r <= 1.f;                               // torch.clamp passes at the bounds
-    float dmu = (2.f * my * (A2 - A1)) * iB1 * iB2 - 2.f * mx * Sv * iB1 + 2.f * mx * Sv * iB2;
-    float dexx = -Sv * iB2;
-    float dexy = 2.f * A1 * iB1 * iB2;
-    float k = pass ? -0.5f * INV49 : 0.f;                           // d r / d S, and window mean -> sum
-    gSx = k * dmu;
-    gSxx = k * dexx;
-    gSxy = k * dexy;
 }
 
 // ===================================================================================================
@@ -131,168 +120,189 @@ __global__ __launch_bounds__(256) void photo_fwd_kernel(sqd_photo_args a, const 
     const int lane = threadIdx.x & 63;
     const int task = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (task >= ntasks) return;
-    const int H = a.H, W = a.W, B = a.B;
-    const size_t HW = (size_t)H * W;
+    const int H = a.H, W = a.W;
+    const int HW = H * W;
     const Strip st = strip_of(task, nsx, nsy, TH, W, lane);
     const int b = st.b;
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    const bool want_grad = MODE == 1 && a.coef != nullptr;
 
     const float *__restrict__ tgt = a.target + (size_t)b * 3 * HW;
     const float *__restrict__ dep = MODE ? a.depth + (size_t)b * HW : nullptr;
-    float ik[12], P[S][12];
+    const float *__restrict__ src[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) src[s] = a.sources[s] + (size_t)b * 3 * HW;
+    float ik[9], P[S][12];
     if (MODE) {
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
-            for (int k = 0; k < 3; ++k) ik[i * 4 + k] = a.inv_K[(size_t)b * 16 + i * 4 + k];
+            for (int k = 0; k < 3; ++k) ik[i * 3 + k] = a.inv_K[(size_t)b * 16 + i * 4 + k];
 #pragma unroll
         for (int s = 0; s < S; ++s)
 #pragma unroll
             for (int k = 0; k < 12; ++k) P[s][k] = a.P[((size_t)b * S + s) * 12 + k];
     }
 
-    float ring[7][3 + 3 * S];   // per row: target rgb, pred_s rgb
+    constexpr int NV = 3 + 3 * S;
+    float ring[7][NV];   // rows (oldest .. newest) x (target rgb, pred_s rgb)
+#pragma unroll
+    for (int k = 0; k < 7; ++k)
+#pragma unroll
+        for (int c = 0; c < NV; ++c) ring[k][c] = 0.f;
     float loss_acc = 0.f;
     const int nrows = TH + 6;
 
-    for (int j0 = 0; j0 < nrows; j0 += 7) {
-        static_for<7>([&](auto p_) {
-            constexpr int p = decltype(p_)::value;
-            const int j = j0 + p;                  // cell row index; image row (unreflected) y_begin - 3 + j
-            const int ycell = st.y_begin - 3 + j;
-            const int yr = reflect_idx(ycell, H);
-            const size_t off = (size_t)yr * W + st.xr;
-            // this lane owns the *cell* as an output pixel (stores sample / warped for it)
-            const bool own_cell = st.own_col && j >= 3 && j < TH + 3 && ycell < H;
+#pragma nounroll
+    for (int j = 0; j < nrows; ++j) {
+        const int ycell = st.y_begin - 3 + j;          // cell row (unreflected)
+        const int yr = reflect_idx(ycell, H);
+        const int off = yr * W + st.xr;
+        // this lane owns the *cell* as an output pixel (stores sample / warped for it)
+        const bool own_cell = st.own_col && j >= 3 && j < TH + 3 && ycell < H;
+        // shift the ring, newest row goes to slot 6
 #pragma unroll
-            for (int c = 0; c < 3; ++c) ring[p][c] = tgt[c * HW + off];
-            if (MODE == 0) {
+        for (int k = 0; k < 6; ++k)
 #pragma unroll
-                for (int s = 0; s < S; ++s)
+            for (int c = 0; c < NV; ++c) ring[k][c] = ring[k + 1][c];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) ring[p][3 + 3 * s + c] = a.sources[s][((size_t)b * 3 + c) * HW + off];
-            } else {
-                float cr[3], X[3];
-                cam_ray(ik, (float)st.xr, (float)yr, cr);
-                const float d = dep[off];
+        for (int c = 0; c < 3; ++c) ring[6][c] = tgt[c * HW + off];
+        if (MODE == 0) {
 #pragma unroll
-                for (int i = 0; i < 3; ++i) X[i] = d * cr[i];          // layers.py:212
+            for (int s = 0; s < S; ++s)
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    const Taps t = project(P[s], X, wm1, hm1, W, H);
-                    const float fx1 = t.fx0 + 1.f, fy1 = t.fy0 + 1.f;
-                    const float wnw = (fx1 - t.ix) * (fy1 - t.iy), wne = (t.ix - t.fx0) * (fy1 - t.iy);
-                    const float wsw = (fx1 - t.ix) * (t.iy - t.fy0), wse = (t.ix - t.fx0) * (t.iy - t.fy0);
-                    const float *__restrict__ src = a.sources[s] + (size_t)b * 3 * HW;
-                    const int o00 = t.y0 * W + t.x0;
-                    const int o01 = o00 + (t.xin ? 1 : 0), o10 = o00 + (t.yin ? W : 0);
-                    const int o11 = o10 + (t.xin ? 1 : 0);
-                    float wv[3];
+                for (int c = 0; c < 3; ++c) ring[6][3 + 3 * s + c] = src[s][c * HW + off];
+        } else {
+            float cr[3], X[3];
+            cam_ray(ik, (float)st.xr, (float)yr, cr);
+            const float d = dep[off];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        const float *sc = src + c * HW;
-                        float acc = 0.f;
-                        acc = fmaf(sc[o00], wnw, acc);
-                        acc = t.xin ? fmaf(sc[o01], wne, acc) : acc;
-                        acc = t.yin ? fmaf(sc[o10], wsw, acc) : acc;
-                        acc = (t.xin && t.yin) ? fmaf(sc[o11], wse, acc) : acc;
-                        wv[c] = acc;
-                        ring[p][3 + 3 * s + c] = acc;
-                    }
-                    if (own_cell) {
-                        const size_t q = (size_t)b * HW + off;
-                        if (a.sample[s]) *reinterpret_cast<float2 *>(a.sample[s] + q * 2) = make_float2(t.gx, t.gy);
-                        if (a.x0y0[s]) *reinterpret_cast<int2 *>(a.x0y0[s] + q * 2) = make_int2(t.x0, t.y0);
-                        if (a.warped[s]) {
+            for (int i = 0; i < 3; ++i) X[i] = d * cr[i];              // layers.py:212
 #pragma unroll
-                            for (int c = 0; c < 3; ++c) a.warped[s][((size_t)b * 3 + c) * HW + off] = wv[c];
-                        }
-                    }
-                }
-            }
-
-            if (j >= 6) {
-                // output row = cell row j-3 (ring slot (p+4)%7), image row:
-                const int yo = ycell - 3;
-                constexpr int pc = (p + 4) % 7;
-                float St[3], Stt[3];
+            for (int s = 0; s < S; ++s) {
+                const Taps t = project(P[s], X, wm1, hm1, W, H);
+                const float fx1 = t.fx0 + 1.f, fy1 = t.fy0 + 1.f;
+                const float wnw = (fx1 - t.ix) * (fy1 - t.iy), wne = (t.ix - t.fx0) * (fy1 - t.iy);
+                const float wsw = (fx1 - t.ix) * (t.iy - t.fy0), wse = (t.ix - t.fx0) * (t.iy - t.fy0);
+                const int o00 = t.y0 * W + t.x0;
+                const int o01 = o00 + (t.xin ? 1 : 0), o10 = o00 + (t.yin ? W : 0);
+                const int o11 = o10 + (t.xin ? 1 : 0);
+                float wv[3];
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    float s1 = 0.f, s2 = 0.f;
+                    const float *sc = src[s] + c * HW;
+                    // out-of-range taps are skipped by grid_sample; their weight is exactly 0 here and
+                    // the clamped address stays in range, so the FMA contributes +0
+                    float acc = sc[o00] * wnw;
+                    acc = fmaf(sc[o01], t.xin ? wne : 0.f, acc);
+                    acc = fmaf(sc[o10], t.yin ? wsw : 0.f, acc);
+                    acc = fmaf(sc[o11], (t.xin && t.yin) ? wse : 0.f, acc);
+                    wv[c] = acc;
+                    ring[6][3 + 3 * s + c] = acc;
+                }
+                if (own_cell) {
+                    const size_t q = (size_t)b * HW + off;
+                    if (a.sample[s]) *reinterpret_cast<float2 *>(a.sample[s] + q * 2) = make_float2(t.gx, t.gy);
+                    if (a.x0y0[s]) *reinterpret_cast<int2 *>(a.x0y0[s] + q * 2) = make_int2(t.x0, t.y0);
+                    if (a.warped[s]) {
+                        float *wd = a.warped[s] + (size_t)b * 3 * HW + off;
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) {
-                        float v = ring[k][c];
+                        for (int c = 0; c < 3; ++c) wd[c * HW] = wv[c];
+                    }
+                }
+            }
+        }
+
+        if (j >= 6) {
+            // output row = cell row j-3 = ring slot 3
+            const int yo = ycell - 3;
+            float St[3], Stt[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float s1 = ring[0][c], s2 = ring[0][c] * ring[0][c];
+#pragma unroll
+                for (int k = 1; k < 7; ++k) {
+                    const float v = ring[k][c];
+                    s1 += v;
+                    s2 = fmaf(v, v, s2);
+                }
+                St[c] = box7(s1);
+                Stt[c] = box7(s2);
+            }
+            float lossv[S];
+            float gsum[S][9];
+#pragma unroll
+            for (int s = 0; s < S; ++s) {
+                float ssim_sum = 0.f, l1 = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int cc = 3 + 3 * s + c;
+                    float s1 = ring[0][cc], s2 = ring[0][cc] * ring[0][cc], s3 = ring[0][cc] * ring[0][c];
+#pragma unroll
+                    for (int k = 1; k < 7; ++k) {
+                        const float v = ring[k][cc];
                         s1 += v;
                         s2 = fmaf(v, v, s2);
+                        s3 = fmaf(v, ring[k][c], s3);
                     }
-                    St[c] = box7(s1);
-                    Stt[c] = box7(s2);
-                }
-                float lossv[S];
-                float gsum[S][9];
-#pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    float ssim_sum = 0.f, l1 = 0.f;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        float s1 = 0.f, s2 = 0.f, s3 = 0.f;
-#pragma unroll
-                        for (int k = 0; k < 7; ++k) {
-                            float v = ring[k][3 + 3 * s + c];
-                            s1 += v;
-                            s2 = fmaf(v, v, s2);
-                            s3 = fmaf(v, ring[k][c], s3);
-                        }
-                        s1 = box7(s1);
-                        s2 = box7(s2);
-                        s3 = box7(s3);
-                        ssim_sum += ssim_from_sums(s1, St[c], s2, Stt[c], s3);
-                        l1 += fabsf(ring[pc][c] - ring[pc][3 + 3 * s + c]);
-                        if (MODE == 1 && a.coef) ssim_grad(s1, St[c], s2, Stt[c], s3, gsum[s][c], gsum[s][3 + c], gsum[s][6 + c]);
-                    }
-                    // 0.85 * ssim.mean(1) + 0.15 * l1.mean(1)      trainer.py:446-451
-                    lossv[s] = 0.85f * (ssim_sum * (1.f / 3.f)) + 0.15f * (l1 * (1.f / 3.f));
-                }
-                const bool own_out = st.own_col && yo >= 0 && yo < H && yo < st.y_begin + TH;
-                if (own_out) {
-                    const size_t qo = (size_t)yo * W + st.cx;
-                    if (MODE == 0) {
-#pragma unroll
-                        for (int s = 0; s < S; ++s) {
-                            const size_t qi = ((size_t)b * S + s) * HW + qo;
-                            float nz = noise ? noise[qi] : 0.f;
-                            a.sel[qi] = lossv[s] + nz * 0.00001f;          // trainer.py:514-517 (sel aliases the output)
-                        }
+                    s1 = box7(s1);
+                    s2 = box7(s2);
+                    s3 = box7(s3);
+                    float g3[3];
+                    if (want_grad) {
+                        ssim_sum += ssim_from_sums<true>(s1, St[c], s2, Stt[c], s3, g3);
+                        gsum[s][c] = g3[0];
+                        gsum[s][3 + c] = g3[1];
+                        gsum[s][6 + c] = g3[2];
                     } else {
-                        // combined = [identity_0..S-1, reproj_0..S-1]; min over dim 1   trainer.py:519-526
-                        float best = a.identity[((size_t)b * S + 0) * HW + qo];
-                        int bi = 0;
+                        ssim_sum += ssim_from_sums<false>(s1, St[c], s2, Stt[c], s3, g3);
+                    }
+                    l1 += fabsf(ring[3][c] - ring[3][cc]);
+                }
+                // 0.85 * ssim.mean(1) + 0.15 * l1.mean(1)      trainer.py:446-451
+                lossv[s] = 0.85f * (ssim_sum * (1.f / 3.f)) + 0.15f * (l1 * (1.f / 3.f));
+            }
+            const bool own_out = st.own_col && yo >= 0 && yo < H && yo < st.y_begin + TH;
+            if (own_out) {
+                const int qo = yo * W + st.cx;
+                if (MODE == 0) {
 #pragma unroll
-                        for (int s = 1; s < S; ++s) {
-                            float v = a.identity[((size_t)b * S + s) * HW + qo];
-                            if (v < best) { best = v; bi = s; }
-                        }
+                    for (int s = 0; s < S; ++s) {
+                        const size_t qi = ((size_t)b * S + s) * HW + qo;
+                        const float nz = noise ? noise[qi] : 0.f;
+                        a.sel[qi] = lossv[s] + nz * 0.00001f;          // trainer.py:514-517 (sel aliases the output)
+                    }
+                } else {
+                    // combined = [identity_0..S-1, reproj_0..S-1]; min over dim 1   trainer.py:519-526
+                    const float *idm = a.identity + (size_t)b * S * HW + qo;
+                    float best = idm[0];
+                    int bi = 0;
 #pragma unroll
-                        for (int s = 0; s < S; ++s) {
-                            if (lossv[s] < best) { best = lossv[s]; bi = S + s; }
-                            if (a.reproj) a.reproj[((size_t)b * S + s) * HW + qo] = lossv[s];
-                        }
-                        loss_acc += best;
-                        if (a.sel) a.sel[(size_t)b * HW + qo] = bi > S - 1 ? 1.f : 0.f;      // trainer.py:529-530
-                        if (a.idx) a.idx[(size_t)b * HW + qo] = (uint8_t)bi;
-                        if (a.coef && bi >= S) {
-                            float *co = a.coef + (size_t)b * 9 * HW + qo;
+                    for (int s = 1; s < S; ++s) {
+                        const float v = idm[s * HW];
+                        if (v < best) { best = v; bi = s; }
+                    }
 #pragma unroll
-                            for (int s = 0; s < S; ++s)
-                                if (bi == S + s) {
+                    for (int s = 0; s < S; ++s) {
+                        if (lossv[s] < best) { best = lossv[s]; bi = S + s; }
+                        if (a.reproj) a.reproj[((size_t)b * S + s) * HW + qo] = lossv[s];
+                    }
+                    loss_acc += best;
+                    if (a.sel) a.sel[(size_t)b * HW + qo] = bi > S - 1 ? 1.f : 0.f;      // trainer.py:529-530
+                    if (a.idx) a.idx[(size_t)b * HW + qo] = (uint8_t)bi;
+                    if (want_grad && bi >= S) {
+                        float *co = a.coef + (size_t)b * 9 * HW + qo;
 #pragma unroll
-                                    for (int k = 0; k < 9; ++k) co[k * HW] = gsum[s][k] * (0.85f / 3.f);
-                                }
+                        for (int k = 0; k < 9; ++k) {
+                            float v = gsum[0][k];
+#pragma unroll
+                            for (int s = 1; s < S; ++s) v = bi == S + s ? gsum[s][k] : v;
+                            co[k * HW] = v * (0.85f / 3.f);
                         }
                     }
                 }
             }
-        });
+        }
     }
     if (MODE == 1 && a.loss_part) {
         loss_acc = wave_sum(loss_acc);
@@ -319,8 +329,8 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(sqd_photo_bwd_args a, in
     const int lane = threadIdx.x & 63;
     const int task = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (task >= ntasks) return;
-    const int H = a.H, W = a.W, B = a.B;
-    const size_t HW = (size_t)H * W;
+    const int H = a.H, W = a.W;
+    const int HW = H * W;
     // task -> (b, s, sy, sx)
     const int per_img = nsx * nsy;
     const int bs = task / per_img;
@@ -329,11 +339,11 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(sqd_photo_bwd_args a, in
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
     const bool in_img_col = st.cx >= 0 && st.cx < W;
 
-    float ik[12], P[12];
+    float ik[9], P[12];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int k = 0; k < 3; ++k) ik[i * 4 + k] = a.inv_K[(size_t)b * 16 + i * 4 + k];
+        for (int k = 0; k < 3; ++k) ik[i * 3 + k] = a.inv_K[(size_t)b * 16 + i * 4 + k];
 #pragma unroll
     for (int k = 0; k < 12; ++k) P[k] = a.P[((size_t)b * S + s) * 12 + k];
 
@@ -351,7 +361,7 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(sqd_photo_bwd_args a, in
     const bool left_border = lane_c0 >= 0 && lane_c0 + 1 < 64 && lane_c0 <= OWN1;       // strip sees columns 0..3
     const bool right_border = lane_cl <= 63 && lane_cl >= OWN0;                        // strip sees columns W-4..W-1
 
-    float acc[7][9];
+    float acc[7][9];      // acc[i] <-> output row q = r - 3 + i
 #pragma unroll
     for (int k = 0; k < 7; ++k)
 #pragma unroll
@@ -361,113 +371,117 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(sqd_photo_bwd_args a, in
     for (int k = 0; k < 12; ++k) gP[k] = 0.f;
 
     const int nrows = TH + 6;
-    for (int j0 = 0; j0 < nrows; j0 += 7) {
-        static_for<7>([&](auto p_) {
-            constexpr int p = decltype(p_)::value;
-            const int j = j0 + p;
-            const int r = st.y_begin - 3 + j;            // coefficient row (zero outside the image)
-            float g[9];
-            const bool have = r >= 0 && r < H && in_img_col;
-            bool win = false;
-            if (have) win = idx[(size_t)r * W + st.cx] == (uint8_t)(S + s);
+#pragma nounroll
+    for (int j = 0; j < nrows; ++j) {
+        const int r = st.y_begin - 3 + j;            // coefficient row (zero outside the image)
+        float g[9];
+        const bool have = r >= 0 && r < H && in_img_col;
+        bool win = false;
+        if (have) win = idx[r * W + st.cx] == (uint8_t)(S + s);
 #pragma unroll
-            for (int c = 0; c < 9; ++c) {
-                float v = 0.f;
-                if (win) v = coef[c * HW + (size_t)r * W + st.cx];
-                float bx = box7(v);
-                // reflection adjoint along x: columns 1..3 also receive the mirrored window sums
-                if (left_border) {
-                    float c0 = __shfl(v, lane_c0 & 63, 64), c1 = __shfl(v, (lane_c0 + 1) & 63, 64), c2 = __shfl(v, (lane_c0 + 2) & 63, 64);
-                    bx += st.cx == 1 ? (c0 + c1) + c2 : st.cx == 2 ? c0 + c1 : st.cx == 3 ? c0 : 0.f;
-                }
-                if (right_border) {
-                    float c0 = __shfl(v, lane_cl & 63, 64), c1 = __shfl(v, (lane_cl - 1) & 63, 64), c2 = __shfl(v, (lane_cl - 2) & 63, 64);
-                    bx += st.cx == W - 2 ? (c0 + c1) + c2 : st.cx == W - 3 ? c0 + c1 : st.cx == W - 4 ? c0 : 0.f;
-                }
-                g[c] = bx;
+        for (int c = 0; c < 9; ++c) {
+            float v = 0.f;
+            if (win) v = coef[c * HW + r * W + st.cx];
+            float bx = box7(v);
+            // reflection adjoint along x: columns 1..3 / W-4..W-2 also receive the mirrored window sums
+            if (left_border) {
+                const float c0 = __shfl(v, lane_c0 & 63, 64), c1 = __shfl(v, (lane_c0 + 1) & 63, 64),
+                            c2 = __shfl(v, (lane_c0 + 2) & 63, 64);
+                bx += st.cx == 1 ? (c0 + c1) + c2 : st.cx == 2 ? c0 + c1 : st.cx == 3 ? c0 : 0.f;
             }
-            // scatter row r into the 7 accumulator rows q = r+3-k  (slot (p-k) mod 7); slot p is new
-            static_for<7>([&](auto k_) {
-                constexpr int k = decltype(k_)::value;
-                constexpr int slot = (p - k + 7) % 7;
-                const int q = r + 3 - k;
-                float m = 0.f;
-                if (r >= 0 && r < H && q >= 0 && q < H) m = (float)refl_mult(r, q, H);
-#pragma unroll
-                for (int c = 0; c < 9; ++c) acc[slot][c] = (k == 0) ? m * g[c] : fmaf(m, g[c], acc[slot][c]);
-            });
-            // row q = r-3 is complete (slot (p+1)%7)
-            const int qy = r - 3;
-            constexpr int sl = (p + 1) % 7;
-            if (j >= 6 && qy >= st.y_begin && qy < H && qy < st.y_begin + TH && st.own_col) {
-                const size_t qo = (size_t)qy * W + st.cx;
-                const float2 gs = *reinterpret_cast<const float2 *>(smp + qo * 2);
-                // recompute taps from the stored grid exactly as the forward did
-                float ix = ((gs.x + 1.0f) * 0.5f) * wm1, iy = ((gs.y + 1.0f) * 0.5f) * hm1;
-                const bool mx = ix > 0.f && ix < wm1, my = iy > 0.f && iy < hm1;
-                ix = fminf(wm1, fmaxf(ix, 0.f));
-                iy = fminf(hm1, fmaxf(iy, 0.f));
-                const float fx0 = floorf(ix), fy0 = floorf(iy);
-                const int x0 = (int)fx0, y0 = (int)fy0;
-                const bool xin = x0 + 1 < W, yin = y0 + 1 < H;
-                const float ax = ix - fx0, ay = iy - fy0, bxw = (fx0 + 1.f) - ix, byw = (fy0 + 1.f) - iy;
-                const int o00 = y0 * W + x0, o01 = o00 + (xin ? 1 : 0), o10 = o00 + (yin ? W : 0), o11 = o10 + (xin ? 1 : 0);
-                const bool l1on = idx[qo] == (uint8_t)(S + s);
-                float gix = 0.f, giy = 0.f;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float *sc = src + c * HW;
-                    const float vnw = sc[o00], vne = xin ? sc[o01] : 0.f, vsw = yin ? sc[o10] : 0.f,
-                                vse = (xin && yin) ? sc[o11] : 0.f;
-                    float wv = 0.f;
-                    wv = fmaf(vnw, bxw * byw, wv);
-                    wv = fmaf(vne, ax * byw, wv);
-                    wv = fmaf(vsw, bxw * ay, wv);
-                    wv = fmaf(vse, ax * ay, wv);
-                    const float t = tgt[c * HW + qo];
-                    // d to_optimise / d w_c  (window terms + L1 term), trainer.py:441-453
-                    float gw = acc[sl][c] + 2.f * wv * acc[sl][3 + c] + t * acc[sl][6 + c];
-                    if (l1on) {
-                        float df = wv - t;
-                        gw += (0.15f / 3.f) * (df > 0.f ? 1.f : df < 0.f ? -1.f : 0.f);
-                    }
-                    gix += gw * ((vne - vnw) * byw + (vse - vsw) * ay);
-                    giy += gw * ((vsw - vnw) * bxw + (vse - vne) * ax);
-                }
-                // unnormalise + clamp adjoints, then (x - 0.5)*2, / (W-1)
-                float ggx = mx ? gix * (wm1 * 0.5f) : 0.f, ggy = my ? giy * (hm1 * 0.5f) : 0.f;
-                float gu = (ggx * 2.f) / wm1, gv = (ggy * 2.f) / hm1;
-                // recompute the camera point
-                float cr[3], X[3];
-                cam_ray(ik, (float)st.cx, (float)qy, cr);
-                const float d = dep[qo];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) X[i] = d * cr[i];
-                float camz = fmaf(P[11], 1.0f, fmaf(P[10], X[2], fmaf(P[9], X[1], P[8] * X[0])));
-                float z = camz + 1e-7f;
-                float camx = fmaf(P[3], 1.0f, fmaf(P[2], X[2], fmaf(P[1], X[1], P[0] * X[0])));
-                float camy = fmaf(P[7], 1.0f, fmaf(P[6], X[2], fmaf(P[5], X[1], P[4] * X[0])));
-                float iz = 1.f / z;
-                float gpx = gu * iz, gpy = gv * iz;
-                float gpz = -(gu * camx + gv * camy) * iz * iz;
-                gpx *= a.gscale; gpy *= a.gscale; gpz *= a.gscale;
-                float gX[3];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) gX[k] = P[k] * gpx + P[4 + k] * gpy + P[8 + k] * gpz;
-                gdep[qo] = cr[0] * gX[0] + cr[1] * gX[1] + cr[2] * gX[2];
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    gP[k] = fmaf(gpx, X[k], gP[k]);
-                    gP[4 + k] = fmaf(gpy, X[k], gP[4 + k]);
-                    gP[8 + k] = fmaf(gpz, X[k], gP[8 + k]);
-                }
-                gP[3] += gpx; gP[7] += gpy; gP[11] += gpz;
+            if (right_border) {
+                const float c0 = __shfl(v, lane_cl & 63, 64), c1 = __shfl(v, (lane_cl - 1) & 63, 64),
+                            c2 = __shfl(v, (lane_cl - 2) & 63, 64);
+                bx += st.cx == W - 2 ? (c0 + c1) + c2 : st.cx == W - 3 ? c0 + c1 : st.cx == W - 4 ? c0 : 0.f;
             }
-        });
+            g[c] = bx;
+        }
+        // shift the accumulator ring (row r-4 was consumed last iteration), open row q = r+3 in slot 6
+#pragma unroll
+        for (int i = 0; i < 6; ++i)
+#pragma unroll
+            for (int c = 0; c < 9; ++c) acc[i][c] = acc[i + 1][c];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) acc[6][c] = 0.f;
+        // scatter row r into the accumulator rows q = r-3+i with the reflection multiplicity
+        const bool r_in = r >= 0 && r < H;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int q = r - 3 + i;
+            float m = 0.f;
+            if (r_in && q >= 0 && q < H) m = (float)refl_mult(r, q, H);
+#pragma unroll
+            for (int c = 0; c < 9; ++c) acc[i][c] = fmaf(m, g[c], acc[i][c]);
+        }
+        // row q = r-3 (slot 0) is complete
+        const int qy = r - 3;
+        if (j >= 6 && qy >= st.y_begin && qy < H && qy < st.y_begin + TH && st.own_col) {
+            const int qo = qy * W + st.cx;
+            const float2 gs = *reinterpret_cast<const float2 *>(smp + (size_t)qo * 2);
+            // recompute taps from the stored grid exactly as the forward did
+            float ix = ((gs.x + 1.0f) * 0.5f) * wm1, iy = ((gs.y + 1.0f) * 0.5f) * hm1;
+            const bool mx = ix > 0.f && ix < wm1, my = iy > 0.f && iy < hm1;   // clip_coordinates_set_grad
+            ix = fminf(wm1, fmaxf(ix, 0.f));
+            iy = fminf(hm1, fmaxf(iy, 0.f));
+            const float fx0 = floorf(ix), fy0 = floorf(iy);
+            const int x0 = (int)fx0, y0 = (int)fy0;
+            const bool xin = x0 + 1 < W, yin = y0 + 1 < H;
+            const float ax = ix - fx0, ay = iy - fy0, bxw = (fx0 + 1.f) - ix, byw = (fy0 + 1.f) - iy;
+            const int o00 = y0 * W + x0, o01 = o00 + (xin ? 1 : 0), o10 = o00 + (yin ? W : 0), o11 = o10 + (xin ? 1 : 0);
+            const bool l1on = idx[qo] == (uint8_t)(S + s);
+            float gix = 0.f, giy = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float *sc = src + c * HW;
+                const float vnw = sc[o00], vne = xin ? sc[o01] : 0.f, vsw = yin ? sc[o10] : 0.f,
+                            vse = (xin && yin) ? sc[o11] : 0.f;
+                float wv = vnw * (bxw * byw);
+                wv = fmaf(vne, ax * byw, wv);
+                wv = fmaf(vsw, bxw * ay, wv);
+                wv = fmaf(vse, ax * ay, wv);
+                const float t = tgt[c * HW + qo];
+                // d to_optimise / d w_c  (window terms + L1 term), trainer.py:441-453
+                float gw = acc[0][c] + 2.f * wv * acc[0][3 + c] + t * acc[0][6 + c];
+                if (l1on) {
+                    const float df = wv - t;
+                    gw += (0.15f / 3.f) * (df > 0.f ? 1.f : df < 0.f ? -1.f : 0.f);
+                }
+                gix += gw * ((vne - vnw) * byw + (vse - vsw) * ay);
+                giy += gw * ((vsw - vnw) * bxw + (vse - vne) * ax);
+            }
+            // unnormalise + clamp adjoints, then (x - 0.5)*2, / (W-1)
+            const float ggx = mx ? gix * (wm1 * 0.5f) : 0.f, ggy = my ? giy * (hm1 * 0.5f) : 0.f;
+            const float gu = (ggx * 2.f) / wm1, gv = (ggy * 2.f) / hm1;
+            // recompute the camera point
+            float cr[3], X[3];
+            cam_ray(ik, (float)st.cx, (float)qy, cr);
+            const float d = dep[qo];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) X[i] = d * cr[i];
+            const float camz = fmaf(P[11], 1.0f, fmaf(P[10], X[2], fmaf(P[9], X[1], P[8] * X[0])));
+            const float z = camz + 1e-7f;
+            const float camx = fmaf(P[3], 1.0f, fmaf(P[2], X[2], fmaf(P[1], X[1], P[0] * X[0])));
+            const float camy = fmaf(P[7], 1.0f, fmaf(P[6], X[2], fmaf(P[5], X[1], P[4] * X[0])));
+            const float iz = 1.f / z;
+            float gpx = gu * iz, gpy = gv * iz;
+            float gpz = -(gu * camx + gv * camy) * iz * iz;
+            gpx *= a.gscale; gpy *= a.gscale; gpz *= a.gscale;
+            float gX[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) gX[k] = P[k] * gpx + P[4 + k] * gpy + P[8 + k] * gpz;
+            gdep[qo] = cr[0] * gX[0] + cr[1] * gX[1] + cr[2] * gX[2];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                gP[k] = fmaf(gpx, X[k], gP[k]);
+                gP[4 + k] = fmaf(gpy, X[k], gP[4 + k]);
+                gP[8 + k] = fmaf(gpz, X[k], gP[8 + k]);
+            }
+            gP[3] += gpx; gP[7] += gpy; gP[11] += gpz;
+        }
     }
 #pragma unroll
     for (int k = 0; k < 12; ++k) {
-        float v = wave_sum(gP[k]);
+        const float v = wave_sum(gP[k]);
         if (lane == 0) a.g_P_part[(size_t)task * 12 + k] = v;
     }
 }
@@ -484,38 +498,37 @@ __global__ __launch_bounds__(64) void gP_reduce_kernel(const float *__restrict__
 }
 
 int pick_th(int th, int H) {
-    if (th <= 0) th = H >= 128 ? 22 : 15;
+    if (th <= 0) th = H >= 128 ? 16 : 12;
     return th;
+}
+
+int check_shape(const char *who, int B, int S, int H, int W, int TH) {
+    SQD_CHECK_ARG(S == 2, "%s: S=%d unsupported (2 source frames: frame_ids [0,-1,1])", who, S);
+    SQD_CHECK_ARG(B > 0 && H >= 8 && W >= 8, "%s: bad shape B=%d H=%d W=%d", who, B, H, W);
+    SQD_CHECK_ARG((long long)B * 9 * H * W < (1ll << 31), "%s: tensor too large for 32-bit pixel offsets", who);
+    SQD_CHECK_ARG(TH >= 1 && TH <= 4096, "%s: rows_per_task=%d out of range", who, TH);
+    return SQD_OK;
 }
 }  // namespace
 
 extern "C" int sqd_photo_ntasks(int B, int H, int W, int rows_per_task) {
-    int TH = pick_th(rows_per_task, H);
-    int nsx = (W + SQD_STRIP_COLS - 1) / SQD_STRIP_COLS, nsy = (H + TH - 1) / TH;
+    const int TH = pick_th(rows_per_task, H);
+    const int nsx = (W + SQD_STRIP_COLS - 1) / SQD_STRIP_COLS, nsy = (H + TH - 1) / TH;
     return B * nsx * nsy;
 }
 extern "C" int sqd_photo_bwd_ntasks(int B, int S, int H, int W, int rows_per_task) {
     return S * sqd_photo_ntasks(B, H, W, rows_per_task);
 }
 
-static int check_th(int TH, const char *who) {
-    if ((TH + 6) % 7 != 0) {
-        sqd::set_error("%s: rows_per_task=%d must satisfy (TH+6)%%7==0", who, TH);
-        return SQD_EINVAL;
-    }
-    return SQD_OK;
-}
-
 extern "C" int sqd_photo_fwd(const sqd_photo_args *a) {
     SQD_CHECK_ARG(a && a->depth && a->inv_K && a->P && a->target && a->sources[0] && a->sources[1] && a->identity,
                   "sqd_photo_fwd: null input");
-    SQD_CHECK_ARG(a->S == 2, "sqd_photo_fwd: S=%d unsupported (2 source frames: frame_ids [0,-1,1])", a->S);
-    SQD_CHECK_ARG(a->B > 0 && a->H >= 8 && a->W >= 8, "sqd_photo_fwd: bad shape B=%d H=%d W=%d", a->B, a->H, a->W);
     SQD_CHECK_ARG(!a->coef || a->idx, "sqd_photo_fwd: coef requires idx");
     const int TH = pick_th(a->rows_per_task, a->H);
-    if (check_th(TH, "sqd_photo_fwd")) return SQD_EINVAL;
+    if (check_shape("sqd_photo_fwd", a->B, a->S, a->H, a->W, TH)) return SQD_EINVAL;
     const int nsx = (a->W + SQD_STRIP_COLS - 1) / SQD_STRIP_COLS, nsy = (a->H + TH - 1) / TH;
     const int ntasks = a->B * nsx * nsy;
+    (void)hipGetLastError();
     hipLaunchKernelGGL((photo_fwd_kernel<2, 1>), dim3((ntasks + 3) / 4), dim3(256), 0, (hipStream_t)a->stream, *a, nullptr,
                        TH, nsx, nsy, ntasks);
     SQD_CHECK_LAUNCH("sqd_photo_fwd");
@@ -525,10 +538,8 @@ extern "C" int sqd_photo_fwd(const sqd_photo_args *a) {
 extern "C" int sqd_identity_fwd(const float *target, const float *const *sources, const float *noise, float *identity,
                                 int B, int S, int H, int W, int rows_per_task, void *stream) {
     SQD_CHECK_ARG(target && sources && identity, "sqd_identity_fwd: null pointer");
-    SQD_CHECK_ARG(S == 2, "sqd_identity_fwd: S=%d unsupported", S);
-    SQD_CHECK_ARG(B > 0 && H >= 8 && W >= 8, "sqd_identity_fwd: bad shape");
     const int TH = pick_th(rows_per_task, H);
-    if (check_th(TH, "sqd_identity_fwd")) return SQD_EINVAL;
+    if (check_shape("sqd_identity_fwd", B, S, H, W, TH)) return SQD_EINVAL;
     sqd_photo_args a = {};
     a.target = target;
     for (int s = 0; s < S; ++s) {
@@ -539,6 +550,7 @@ extern "C" int sqd_identity_fwd(const float *target, const float *const *sources
     a.B = B; a.S = S; a.H = H; a.W = W;
     const int nsx = (W + SQD_STRIP_COLS - 1) / SQD_STRIP_COLS, nsy = (H + TH - 1) / TH;
     const int ntasks = B * nsx * nsy;
+    (void)hipGetLastError();
     hipLaunchKernelGGL((photo_fwd_kernel<2, 0>), dim3((ntasks + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, noise, TH,
                        nsx, nsy, ntasks);
     SQD_CHECK_LAUNCH("sqd_identity_fwd");
@@ -548,12 +560,12 @@ extern "C" int sqd_identity_fwd(const float *target, const float *const *sources
 extern "C" int sqd_photo_bwd(const sqd_photo_bwd_args *a) {
     SQD_CHECK_ARG(a && a->depth && a->inv_K && a->P && a->target && a->sources[0] && a->sources[1] && a->sample[0] &&
                       a->sample[1] && a->coef && a->idx && a->g_depth && a->g_P_part, "sqd_photo_bwd: null pointer");
-    SQD_CHECK_ARG(a->S == 2, "sqd_photo_bwd: S=%d unsupported", a->S);
-    SQD_CHECK_ARG(a->g_depth_img_stride >= (int64_t)a->S * a->H * a->W, "sqd_photo_bwd: g_depth_img_stride too small");
     const int TH = pick_th(a->rows_per_task, a->H);
-    if (check_th(TH, "sqd_photo_bwd")) return SQD_EINVAL;
+    if (check_shape("sqd_photo_bwd", a->B, a->S, a->H, a->W, TH)) return SQD_EINVAL;
+    SQD_CHECK_ARG(a->g_depth_img_stride >= (int64_t)a->S * a->H * a->W, "sqd_photo_bwd: g_depth_img_stride too small");
     const int nsx = (a->W + SQD_STRIP_COLS - 1) / SQD_STRIP_COLS, nsy = (a->H + TH - 1) / TH;
     const int ntasks = a->B * a->S * nsx * nsy;
+    (void)hipGetLastError();
     hipLaunchKernelGGL((photo_bwd_kernel<2>), dim3((ntasks + 3) / 4), dim3(256), 0, (hipStream_t)a->stream, *a, TH, nsx,
                        nsy, ntasks);
     SQD_CHECK_LAUNCH("sqd_photo_bwd");
@@ -563,6 +575,7 @@ extern "C" int sqd_photo_bwd(const sqd_photo_bwd_args *a) {
 extern "C" int sqd_photo_bwd_reduce(const float *g_P_part, float *g_P, int ntasks, int tasks_per_image, int B, int S,
                                     void *stream) {
     SQD_CHECK_ARG(g_P_part && g_P && ntasks == B * S * tasks_per_image, "sqd_photo_bwd_reduce: bad arguments");
+    (void)hipGetLastError();
     hipLaunchKernelGGL(gP_reduce_kernel, dim3(B * S), dim3(64), 0, (hipStream_t)stream, g_P_part, g_P, tasks_per_image);
     SQD_CHECK_LAUNCH("sqd_photo_bwd_reduce");
     return SQD_OK;

@@ -111,6 +111,7 @@ extern "C" int sqd_smooth_fwd(const float *depth, const float *color, const floa
     SQD_CHECK_ARG(depth && color && part && sm_part, "sqd_smooth_fwd: null pointer");
     SQD_CHECK_ARG(B > 0 && H > 1 && W > 1 && nblk > 0, "sqd_smooth_fwd: bad shape");
     const int nb = sqd_smooth_nblk(H, W);
+    (void)hipGetLastError();   // drop any stale error left by other HIP users of this thread
     hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, depth, color, part, nblk, sm_part,
                        H, W, nb);
     SQD_CHECK_LAUNCH("sqd_smooth_fwd");
@@ -124,6 +125,7 @@ extern "C" int sqd_smooth_bwd(const float *depth, const float *color, const floa
     SQD_CHECK_ARG(g_depth_img_stride >= (int64_t)H * W, "sqd_smooth_bwd: g_depth_img_stride too small");
     SQD_CHECK_ARG(B > 0 && H > 1 && W > 1 && nblk > 0, "sqd_smooth_bwd: bad shape");
     const int nb = sqd_smooth_nblk(H, W);
+    (void)hipGetLastError();   // drop any stale error left by other HIP users of this thread
     hipLaunchKernelGGL(smooth_bwd_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, depth, color, part, nblk, sm_part,
                        nb, gout, g_depth, (long long)g_depth_img_stride, B, H, W);
     SQD_CHECK_LAUNCH("sqd_smooth_bwd");

@@ -1,0 +1,87 @@
+"""Synthetic KITTI-shaped frames with the dict schema of the reference's MonoDataset.__getitem__
+(reference datasets/mono_dataset.py:114-201): ("color", f, 0), ("color_aug", f, 0) for every frame
+id, ("K", 0), ("inv_K", 0), "depth_gt".
+
+Each sample is a smooth random texture (a few low-frequency sinusoids + 5 % white noise); the -1/+1
+frames are the same texture seen through a known small camera motion over a known smooth depth
+field in [2, 60] m, so the photometric loss has a meaningful minimum.  Intrinsics are
+the normalised KITTI K scaled by the image size (reference datasets/kitti_dataset.py:29-32)."""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch.utils.data import Dataset
+
+_K_NORM = np.array([[0.58, 0, 0.5, 0], [0, 1.92, 0.5, 0], [0, 0, 1, 0], [0, 0, 0, 1]], dtype=np.float32)
+
+
+def intrinsics(height, width):
+    K = _K_NORM.copy()
+    K[0, :] *= width
+    K[1, :] *= height
+    return torch.from_numpy(K), torch.from_numpy(np.linalg.pinv(K).astype(np.float32))
+
+
+def _texture(gen, height, width, xs, ys):
+    img = torch.full((3, height, width), 0.5)
+    for c in range(3):
+        for _ in range(5):
+            fx, fy = (torch.rand(2, generator=gen) * 0.23 + 0.02).tolist()
+            ph = float(torch.rand(1, generator=gen)) * 2 * math.pi
+            amp = float(torch.rand(1, generator=gen)) * 0.10 + 0.05
+            img[c] += amp * torch.sin(fx * xs + fy * ys + ph)
+    return img
+
+
+def make_sample(index, height, width, frame_ids=(0, -1, 1), with_gt=True):
+    gen = torch.Generator().manual_seed(1234 + int(index))
+    ys, xs = torch.meshgrid(torch.arange(height, dtype=torch.float32), torch.arange(width, dtype=torch.float32), indexing="ij")
+    # a wider canvas so that the source views stay inside the texture
+    base = _texture(gen, height, width, xs, ys)
+    depth = 31.0 + 29.0 * torch.sin(0.011 * xs + float(torch.rand(1, generator=gen)) * 6) * \
+        torch.cos(0.023 * ys + float(torch.rand(1, generator=gen)) * 6)
+    depth = depth.clamp(2.0, 60.0)
+    K, inv_K = intrinsics(height, width)
+    sample = {("K", 0): K, ("inv_K", 0): inv_K}
+    pix = torch.stack([xs, ys, torch.ones_like(xs)], 0).reshape(3, -1)
+    cam = (inv_K[:3, :3] @ pix) * depth.reshape(1, -1)
+    for f in frame_ids:
+        if f == 0:
+            img = base
+        else:
+            t = (torch.rand(3, generator=gen) - 0.5) * 0.6 * float(f)       # metres
+            w = (torch.rand(3, generator=gen) - 0.5) * 0.02                  # radians (small-angle rotation)
+            R = torch.eye(3) + torch.tensor([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+            p = K[:3, :3] @ (R @ cam + t.reshape(3, 1))
+            u = (p[0] / p[2]).reshape(height, width) / (width - 1) * 2 - 1
+            v = (p[1] / p[2]).reshape(height, width) / (height - 1) * 2 - 1
+            img = F.grid_sample(base[None], torch.stack([u, v], -1)[None], padding_mode="border", align_corners=True)[0]
+        img = (img + 0.05 * (torch.rand(img.shape, generator=gen) - 0.5)).clamp(0, 1)
+        sample[("color", f, 0)] = img
+        gain = 0.9 + 0.2 * float(torch.rand(1, generator=gen))
+        sample[("color_aug", f, 0)] = (img * gain).clamp(0, 1)
+    if with_gt:
+        sample["depth_gt"] = F.interpolate(depth[None, None], [375, 1242], mode="bilinear", align_corners=False)[0]
+    return sample
+
+
+class SyntheticKITTIDataset(Dataset):
+    def __init__(self, height, width, frame_ids=(0, -1, 1), length=240, with_gt=True, offset=0):
+        self.height, self.width, self.frame_ids = height, width, list(frame_ids)
+        self.length, self.with_gt, self.offset = length, with_gt, offset
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, index):
+        return make_sample(index + self.offset, self.height, self.width, [f for f in self.frame_ids if f != "s"], self.with_gt)
+
+
+def synthetic_batch(batch_size, height, width, frame_ids=(0, -1, 1), start=0, device=None, with_gt=False):
+    """A collated batch (dict of stacked tensors) — what the DataLoader would hand to process_batch."""
+    samples = [make_sample(start + i, height, width, frame_ids, with_gt) for i in range(batch_size)]
+    batch = {k: torch.stack([s[k] for s in samples]) for k in samples[0]}
+    if device is not None:
+        batch = {k: v.to(device) for k, v in batch.items()}
+    return batch

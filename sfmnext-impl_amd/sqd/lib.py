@@ -9,6 +9,12 @@ import os
 import shutil
 import subprocess
 
+# Load order matters: PyTorch-ROCm bundles its own libamdhip64.so; libsqd.so must bind to THAT runtime
+# instance (the streams and device pointers it receives belong to it).  Importing torch first puts
+# torch's runtime in the process so the loader resolves libsqd's libamdhip64.so.7 dependency to it;
+# the other order yields two HIP runtimes and "no ROCm-capable device is detected" at the first launch.
+import torch  # noqa: F401  (must precede ctypes.CDLL(libsqd.so))
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(os.path.dirname(_HERE), "csrc")
 SO_PATH = os.path.join(_HERE, "libsqd.so")

@@ -1,0 +1,378 @@
+"""Self-supervised SQLdepth trainer for MI355X — keeps the reference's orchestration surface
+(reference trainer.py:30-687): Trainer(options), train(), run_epoch(), process_batch(inputs) ->
+(outputs, losses), predict_poses(), generate_images_pred(inputs, outputs), compute_losses(inputs,
+outputs), compute_reprojection_loss(), compute_depth_losses(), val(), log(), save_model(),
+load_model(); the same dict keys for inputs / outputs / losses; the same checkpoint layout.
+
+What differs by design (MI355X-first):
+  * one process per GPU; gradients are averaged by sqd.ddp.GradBucketReducer (RCCL all-reduce
+    overlapped with backward) instead of nn.DataParallel scatter/gather (reference trainer.py:74,93);
+    every rank owns encoder, depth head AND pose net, and computes its own loss shard;
+  * generate_images_pred + compute_losses run as ONE autograd node made of hand-written gfx950
+    kernels (sqd.ops.PhotometricChain); the identity-reprojection maps, which depend only on the
+    batch, are computed on a side HIP stream while the networks run;
+  * the data source is synthetic KITTI-shaped frames unless real KITTI is present (no dataset I/O in
+    this build).
+Only the default loss configuration of the reference is implemented (auto-masking on, per-pixel
+minimum, SSIM on, scale 0, posecnn pairs, no stereo) — the configuration every args file of the
+KITTI path uses; other switches raise NotImplementedError instead of silently diverging."""
+import json
+import os
+import time
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+import torch.optim as optim
+from torch.utils.data import DataLoader
+
+import datasets
+import networks
+from layers import compute_depth_errors, transformation_from_parameters
+from sqd import ddp, ops
+from utils import normalize_image, sec_to_hm_str
+
+
+class _NullWriter:
+    def add_scalar(self, *a, **k):
+        pass
+
+    def add_image(self, *a, **k):
+        pass
+
+
+def _make_writer(path):
+    try:
+        from torch.utils.tensorboard.writer import SummaryWriter
+        return SummaryWriter(path)
+    except Exception:          # tensorboard is not installed in this image
+        return _NullWriter()
+
+
+class Trainer:
+    def __init__(self, options):
+        self.opt = options
+        self.log_path = os.path.join(self.opt.log_dir, self.opt.model_name)
+        self._check_supported()
+
+        self.rank, self.world, self.local_rank = ddp.init_from_env()
+        if self.opt.no_cuda or not torch.cuda.is_available():
+            raise RuntimeError("the MI355X build runs the hot path in HIP kernels only (no CPU fallback); "
+                               "the CPU restatement used for parity lives in oracle/ (test infrastructure)")
+        self.device = torch.device("cuda", self.local_rank)
+        torch.cuda.set_device(self.device)
+
+        self.num_scales = len(self.opt.scales)
+        self.num_input_frames = len(self.opt.frame_ids)
+        self.num_pose_frames = 2 if self.opt.pose_model_input == "pairs" else self.num_input_frames
+        assert self.opt.frame_ids[0] == 0, "frame_ids must start with 0"
+        self.use_pose_net = not (self.opt.use_stereo and self.opt.frame_ids == [0])
+
+        self.models = {}
+        self.models["encoder"] = self._build_encoder().to(self.device)
+        self.models["depth"] = self._build_depth_head().to(self.device)
+        self.models["pose"] = networks.PoseCNN(self.num_input_frames if self.opt.pose_model_input == "all" else 2).to(self.device)
+        if self.opt.load_pretrained_model:
+            self._load_pretrained()
+        if self.opt.pretrained_pose:
+            sd = torch.load(os.path.join(self.opt.pose_net_path, "pose.pth"), map_location=self.device)
+            self.models["pose"].load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
+
+        self.parameters_to_train = list(self.models["encoder"].parameters()) + list(self.models["depth"].parameters())
+        if self.opt.diff_lr:
+            self.pose_params = list(self.models["pose"].parameters())
+            groups = [{"params": self.pose_params, "lr": self.opt.learning_rate / 10},
+                      {"params": self.parameters_to_train, "lr": self.opt.learning_rate}]
+            self.model_optimizer = optim.Adam(groups, lr=self.opt.learning_rate)
+        else:
+            self.parameters_to_train += list(self.models["pose"].parameters())
+            self.model_optimizer = optim.Adam(self.parameters_to_train, self.opt.learning_rate)
+        self.model_lr_scheduler = optim.lr_scheduler.StepLR(self.model_optimizer, self.opt.scheduler_step_size, 0.1)
+
+        all_params = [p for m in self.models.values() for p in m.parameters()]
+        self.reducer = ddp.GradBucketReducer(all_params, self.opt.sqd_bucket_mb) if self.world > 1 else None
+        if self.reducer is not None:
+            self.reducer.broadcast_parameters(self.models.values())
+
+        self._side_stream = torch.cuda.Stream(device=self.device)
+        self._build_loaders()
+        self.writers = {m: (_make_writer(os.path.join(self.log_path, m)) if self.rank == 0 else _NullWriter())
+                        for m in ("train", "val")}
+        self.depth_metric_names = ["de/abs_rel", "de/sq_rel", "de/rms", "de/log_rms", "da/a1", "da/a2", "da/a3"]
+        if self.rank == 0:
+            print("Training model named:\n  ", self.opt.model_name)
+            print("Models and tensorboard events files are saved to:\n  ", self.opt.log_dir)
+            print("Training is using:\n  ", self.device, "x", self.world)
+            self.save_opts()
+
+    # ------------------------------------------------------------------------------- construction
+    def _check_supported(self):
+        o = self.opt
+        unsupported = [n for n in ("use_stereo", "v1_multiscale", "predictive_mask", "avg_reprojection", "no_ssim",
+                                   "disable_automasking") if getattr(o, n)]
+        if unsupported or list(o.scales) != [0] or o.pose_model_type != "posecnn" or o.pose_model_input != "pairs":
+            raise NotImplementedError("MI355X hot path implements the reference's KITTI mono configuration "
+                                      "(auto-mask, per-pixel min, SSIM, scale 0, posecnn pairs); got %s scales=%s pose=%s/%s"
+                                      % (unsupported, o.scales, o.pose_model_type, o.pose_model_input))
+        if list(o.frame_ids) != [0, -1, 1]:
+            raise NotImplementedError("frame_ids must be [0, -1, 1] (two source frames)")
+
+    def _build_encoder(self):
+        o = self.opt
+        if o.backbone in ("resnet", "resnet_lite"):
+            return networks.ResnetEncoderDecoder(num_layers=o.num_layers, num_features=o.num_features, model_dim=o.model_dim)
+        if o.backbone == "resnet18_lite":
+            return networks.LiteResnetEncoderDecoder(model_dim=o.model_dim)
+        if o.backbone == "eff_b5":
+            return networks.BaseEncoder.build(num_features=o.num_features, model_dim=o.model_dim)
+        return networks.Unet(pretrained=(not o.load_pretrained_model), backbone=o.backbone, in_channels=3,
+                             num_classes=o.model_dim, decoder_channels=o.dec_channels)
+
+    def _build_depth_head(self):
+        o = self.opt
+        cls = networks.Lite_Depth_Decoder_QueryTr if o.backbone.endswith("_lite") else networks.Depth_Decoder_QueryTr
+        return cls(in_channels=o.model_dim, patch_size=o.patch_size, dim_out=o.dim_out, embedding_dim=o.model_dim,
+                   query_nums=o.query_nums, num_heads=4, min_val=o.min_depth, max_val=o.max_depth)
+
+    def _load_pretrained(self):
+        for name, fname in (("encoder", "encoder.pth"), ("depth", "depth.pth")):
+            sd = torch.load(os.path.join(self.opt.load_pt_folder, fname), map_location=self.device)
+            own = self.models[name].state_dict()
+            self.models[name].load_state_dict({k: v for k, v in sd.items() if k in own})
+
+    def _build_loaders(self):
+        o = self.opt
+        have_kitti = os.path.isdir(o.data_path) and not o.sqd_synthetic
+        if have_kitti:
+            raise NotImplementedError("real KITTI input is outside this build (SURVEY.md §2: datasets are host I/O); "
+                                      "pass --sqd_synthetic")
+        n = o.sqd_synthetic_len
+        train = datasets.SyntheticKITTIDataset(o.height, o.width, o.frame_ids, n, offset=self.rank * n)
+        val = datasets.SyntheticKITTIDataset(o.height, o.width, o.frame_ids, max(o.batch_size, n // 10), offset=10 ** 6)
+        self.num_total_steps = len(train) // o.batch_size * o.num_epochs
+        self.train_loader = DataLoader(train, o.batch_size, True, num_workers=o.num_workers, pin_memory=True, drop_last=True)
+        self.val_loader = DataLoader(val, o.batch_size, True, num_workers=o.num_workers, pin_memory=True, drop_last=True)
+        self.val_iter = iter(self.val_loader)
+
+    def set_train(self):
+        for m in self.models.values():
+            m.train()
+
+    def set_eval(self):
+        for m in self.models.values():
+            m.eval()
+
+    # ------------------------------------------------------------------------------------ epochs
+    def train(self):
+        self.epoch, self.step, self.start_time = 0, 0, time.time()
+        self.save_model()
+        for self.epoch in range(self.opt.num_epochs):
+            self.run_epoch()
+            self.model_lr_scheduler.step()
+            if (self.epoch + 1) % self.opt.save_frequency == 0:
+                self.save_model()
+
+    def train_step(self, inputs):
+        """forward + backward + Adam on one batch (reference trainer.py:240-244)."""
+        outputs, losses = self.process_batch(inputs)
+        if self.reducer is not None:
+            self.reducer.zero_grad()
+        else:
+            self.model_optimizer.zero_grad(set_to_none=True)
+        losses["loss"].backward()
+        if self.reducer is not None:
+            self.reducer.finish()
+        self.model_optimizer.step()
+        return outputs, losses
+
+    def run_epoch(self):
+        if self.rank == 0:
+            print("Training")
+        self.set_train()
+        for batch_idx, inputs in enumerate(self.train_loader):
+            before = time.time()
+            outputs, losses = self.train_step(inputs)
+            early = batch_idx % self.opt.log_frequency == 0 and self.step < 2000
+            late = self.step % 1000 == 0
+            if early or late:
+                loss = losses["loss"].detach().cpu()           # synchronises: duration below is device-true
+                self.log_time(batch_idx, time.time() - before, loss)
+                if "depth_gt" in inputs:
+                    self.compute_depth_losses(inputs, outputs, losses)
+                self.log("train", inputs, outputs, losses)
+                self.val()
+            self.step += 1
+
+    # ----------------------------------------------------------------------------- forward pass
+    def process_batch(self, inputs):
+        """Pass a minibatch through the networks and the photometric chain -> (outputs, losses)."""
+        for key, ipt in inputs.items():
+            inputs[key] = ipt.to(self.device, non_blocking=True)
+        self._launch_identity(inputs)
+        features = self.models["encoder"](inputs["color_aug", 0, 0])
+        outputs = self.models["depth"](features)
+        if self.use_pose_net:
+            outputs.update(self.predict_poses(inputs, features))
+        self.generate_images_pred(inputs, outputs)
+        losses = self.compute_losses(inputs, outputs)
+        return outputs, losses
+
+    def _launch_identity(self, inputs):
+        """Identity-reprojection maps + tie-break noise (reference trainer.py:480-487,514-517) depend only
+        on the batch: compute them on a side stream, overlapped with the encoder forward."""
+        srcs = [inputs[("color", f, 0)] for f in self.opt.frame_ids[1:]]
+        tgt = inputs[("color", 0, 0)]
+        B, _, H, W = tgt.shape
+        if ("noise", 0) in inputs:
+            noise = inputs[("noise", 0)]
+        elif self.opt.sqd_device_noise:
+            noise = torch.randn(B, len(srcs), H, W, device=self.device)
+        else:
+            noise = torch.randn(B, len(srcs), H, W).to(self.device, non_blocking=True)   # CPU RNG, as the reference
+        side = self._side_stream
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._identity = ops.identity_fwd(tgt, srcs, noise)
+            self._identity_done = torch.cuda.Event()
+            self._identity_done.record(side)
+        for t in (tgt, noise, *srcs):
+            t.record_stream(side)
+
+    def predict_poses(self, inputs, features):
+        """Pose of each source frame relative to the target, pairs in temporal order (reference
+        trainer.py:301-337)."""
+        outputs = {}
+        aug = {f: inputs["color_aug", f, 0] for f in self.opt.frame_ids}
+        for f in self.opt.frame_ids[1:]:
+            pair = [aug[f], aug[0]] if f < 0 else [aug[0], aug[f]]
+            axisangle, translation = self.models["pose"](torch.cat(pair, 1))
+            outputs[("axisangle", 0, f)] = axisangle
+            outputs[("translation", 0, f)] = translation
+            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=(f < 0))
+        return outputs
+
+    def generate_images_pred(self, inputs, outputs):
+        """Warps the source frames into the target view (reference trainer.py:386-439) — and, because the
+        whole photometric chain is one fused autograd node here, also evaluates the losses that
+        compute_losses() then reports."""
+        o = self.opt
+        srcs_ids = o.frame_ids[1:]
+        if getattr(self, "_identity", None) is None:
+            self._launch_identity(inputs)
+        torch.cuda.current_stream().wait_event(self._identity_done)
+        identity, self._identity = self._identity, None
+        aa = torch.cat([outputs[("axisangle", 0, f)][:, 0] for f in srcs_ids], 1).contiguous()      # [B,S,3]
+        tr = torch.cat([outputs[("translation", 0, f)][:, 0] for f in srcs_ids], 1).contiguous()
+        meta = dict(H=o.height, W=o.width, invert=[1 if f < 0 else 0 for f in srcs_ids],
+                    smooth_weight=o.disparity_smoothness)
+        srcs = [inputs[("color", f, 0)].contiguous() for f in srcs_ids]
+        res = ops.PhotometricChain.apply(outputs[("disp", 0)].contiguous(), aa, tr, inputs[("K", 0)].contiguous(),
+                                         inputs[("inv_K", 0)].contiguous(), inputs[("color", 0, 0)].contiguous(),
+                                         identity, meta, *srcs)
+        total, photo, smooth, depth, sel, T = res[:6]
+        S = len(srcs)
+        outputs[("depth", 0, 0)] = depth
+        for i, f in enumerate(srcs_ids):
+            outputs[("sample", f, 0)] = res[6 + i]
+            outputs[("color", f, 0)] = res[6 + S + i]
+            outputs[("color_identity", f, 0)] = inputs[("color", f, 0)]
+        outputs[("_chain", 0)] = (total, sel)
+
+    def compute_reprojection_loss(self, pred, target):
+        """0.85*SSIM + 0.15*L1 between a predicted and a target image (reference trainer.py:441-453);
+        stand-alone form for scripts — the training path evaluates it inside the fused kernel."""
+        l1 = torch.abs(target - pred).mean(1, True)
+        return 0.85 * ops.ssim_map(pred, target).mean(1, True) + 0.15 * l1
+
+    def compute_losses(self, inputs, outputs):
+        """Reprojection + smoothness loss of the minibatch (reference trainer.py:455-549)."""
+        if ("_chain", 0) not in outputs:
+            self.generate_images_pred(inputs, outputs)
+        total, sel = outputs.pop(("_chain", 0))
+        outputs["identity_selection/0"] = sel
+        loss = total / self.num_scales
+        return {"loss/0": total, "loss": loss}
+
+    def compute_depth_losses(self, inputs, outputs, losses):
+        """Depth metrics for monitoring (reference trainer.py:551-579): 375x1242, eigen crop, batch-global
+        median scaling."""
+        pred = torch.clamp(F.interpolate(outputs[("depth", 0, 0)].detach(), [375, 1242], mode="bilinear", align_corners=False),
+                           1e-3, 80)
+        gt = inputs["depth_gt"]
+        mask = gt > 0
+        crop = torch.zeros_like(mask)
+        crop[:, :, 153:371, 44:1197] = 1
+        mask = mask * crop
+        gt, pred = gt[mask], pred[mask]
+        pred = torch.clamp(pred * (torch.median(gt) / torch.median(pred)), min=1e-3, max=80)
+        for name, v in zip(self.depth_metric_names, compute_depth_errors(gt, pred)):
+            losses[name] = np.array(v.cpu())
+
+    def val(self):
+        self.set_eval()
+        try:
+            inputs = next(self.val_iter)
+        except StopIteration:
+            self.val_iter = iter(self.val_loader)
+            inputs = next(self.val_iter)
+        with torch.no_grad():
+            outputs, losses = self.process_batch(inputs)
+            if "depth_gt" in inputs:
+                self.compute_depth_losses(inputs, outputs, losses)
+            self.log("val", inputs, outputs, losses)
+        self.set_train()
+
+    # ------------------------------------------------------------------------- logging / state
+    def log_time(self, batch_idx, duration, loss):
+        if self.rank != 0:
+            return
+        sps = self.opt.batch_size * self.world / duration
+        sofar = time.time() - self.start_time
+        left = (self.num_total_steps / self.step - 1.0) * sofar if self.step > 0 else 0
+        print("epoch {:>3} | batch {:>6} | examples/s: {:5.1f} | loss: {:.5f} | time elapsed: {} | time left: {}".format(
+            self.epoch, batch_idx, sps, float(loss), sec_to_hm_str(sofar), sec_to_hm_str(left)))
+
+    def log(self, mode, inputs, outputs, losses):
+        writer = self.writers[mode]
+        for name, v in losses.items():
+            writer.add_scalar(name, float(v), self.step)
+        for j in range(min(4, self.opt.batch_size)):
+            for f in self.opt.frame_ids:
+                writer.add_image("color_{}_0/{}".format(f, j), inputs[("color", f, 0)][j].data, self.step)
+                if f != 0:
+                    writer.add_image("color_pred_{}_0/{}".format(f, j), outputs[("color", f, 0)][j].data, self.step)
+            writer.add_image("disp_0/{}".format(j), normalize_image(outputs[("disp", 0)][j]), self.step)
+            writer.add_image("automask_0/{}".format(j), outputs["identity_selection/0"][j][None, ...], self.step)
+
+    def save_opts(self):
+        models_dir = os.path.join(self.log_path, "models")
+        os.makedirs(models_dir, exist_ok=True)
+        with open(os.path.join(models_dir, "opt.json"), "w") as f:
+            json.dump(self.opt.__dict__.copy(), f, indent=2)
+
+    def save_model(self):
+        """weights_{epoch}/{encoder,depth,pose,adam}.pth with the reference's key names (trainer.py:638-660)."""
+        if self.rank != 0:
+            return
+        folder = os.path.join(self.log_path, "models", "weights_{}".format(self.epoch))
+        os.makedirs(folder, exist_ok=True)
+        for name, model in self.models.items():
+            sd = model.state_dict()
+            if name == "encoder":
+                sd["height"], sd["width"], sd["use_stereo"] = self.opt.height, self.opt.width, self.opt.use_stereo
+            torch.save(sd, os.path.join(folder, "{}.pth".format(name)))
+        torch.save(self.model_optimizer.state_dict(), os.path.join(folder, "adam.pth"))
+
+    def load_model(self):
+        folder = os.path.expanduser(self.opt.load_weights_folder)
+        assert os.path.isdir(folder), "Cannot find folder {}".format(folder)
+        for n in self.opt.models_to_load:
+            if n not in self.models:
+                continue
+            own = self.models[n].state_dict()
+            sd = torch.load(os.path.join(folder, "{}.pth".format(n)), map_location=self.device)
+            own.update({k: v for k, v in sd.items() if k in own})
+            self.models[n].load_state_dict(own)
+        adam = os.path.join(folder, "adam.pth")
+        if os.path.isfile(adam):
+            self.model_optimizer.load_state_dict(torch.load(adam, map_location=self.device))
