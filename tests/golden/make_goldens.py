@@ -406,8 +406,12 @@ def options_spec():
                     args_files[rel] = repr(sorted(vars(ns).items()))
                 except SystemExit:
                     args_files[rel] = "ARGPARSE_ERROR"
+    tokens = {}
+    for rel in args_files:
+        tokens[rel] = " ".join(open(os.path.join(REF, rel)).read().split())     # the flag tokens = parser INPUT
     save("g00_options_spec", rows=np.array(rows), files=np.array(sorted(args_files)),
-         parsed=np.array([args_files[k] for k in sorted(args_files)]))
+         parsed=np.array([args_files[k] for k in sorted(args_files)]),
+         tokens=np.array([tokens[k] for k in sorted(args_files)]))
 
 
 def main():

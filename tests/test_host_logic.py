@@ -1,0 +1,203 @@
+"""CPU-side tests: option parsing against the spec frozen from the reference parser, state-dict key
+compatibility, the C ABI (library loads, exports every symbol include/sqd.h declares, rejects CPU
+tensors), the synthetic data schema, network wiring against the oracle, and the multi-process gradient
+reducer on gloo (world_size 2)."""
+import ast
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import PRODUCT, REPO, tt
+
+
+# ------------------------------------------------------------------------------------------ options
+def test_options_match_reference_spec(golden):
+    from options import MonodepthOptions
+    g = golden("g00_options_spec")
+    parser = MonodepthOptions().parser
+    mine = {a.option_strings[0]: a for a in parser._actions if a.option_strings}
+    for row in g["rows"]:
+        flag, kind, typ, default, nargs, choices = str(row).split("|")
+        if flag == "-h":
+            continue
+        assert flag in mine, flag
+        a = mine[flag]
+        assert type(a).__name__ == kind, flag
+        want_default = ast.literal_eval(default)
+        if flag == "--log_dir":
+            want_default = os.path.join(os.path.expanduser("~"), "tmp")
+        assert a.default == want_default, (flag, a.default, want_default)
+        assert repr(a.nargs) == nargs and repr(a.choices) == choices, flag
+        if kind == "_StoreAction":
+            assert getattr(a.type, "__name__", str(a.type)) == typ, flag
+
+
+def test_reference_args_files_parse_identically(golden):
+    """Every args file of the reference parses to the same namespace (or fails the same way)."""
+    from options import MonodepthOptions
+    g = golden("g00_options_spec")
+    checked = 0
+    for name, parsed, text in zip(g["files"], g["parsed"], g["tokens"]):
+        text = str(text)
+        checked += 1
+        if str(parsed) == "ARGPARSE_ERROR":
+            with pytest.raises(SystemExit):
+                MonodepthOptions().parser.parse_args(text.split())
+            continue
+        ns = vars(MonodepthOptions().parser.parse_args(text.split()))
+        for k, v in ast.literal_eval(str(parsed)):
+            assert ns[k] == v, (name, k, ns[k], v)
+    assert checked >= 30
+
+
+def test_unknown_reference_flag_errors_like_reference():
+    from options import MonodepthOptions
+    with pytest.raises(SystemExit):        # --model_type is not an options.py flag in the reference either
+        MonodepthOptions().parser.parse_args(["--model_type", "hrb5"])
+    assert MonodepthOptions().parser.parse_args([]).png == ".png"     # store_true with a truthy default (App. B-5)
+
+
+# ------------------------------------------------------------------------------- state-dict surface
+def test_state_dict_keys_match_reference(golden):
+    import networks
+    g = golden("g00_state_dict_keys")
+    mods = {"encoder_res50": networks.ResnetEncoderDecoder(num_layers=50, num_features=256, model_dim=32),
+            "encoder_res18": networks.LiteResnetEncoderDecoder(model_dim=32),
+            "depth": networks.Depth_Decoder_QueryTr(in_channels=32, patch_size=16, dim_out=64, embedding_dim=32,
+                                                    query_nums=64, num_heads=4),
+            "pose": networks.PoseCNN(2)}
+    for n, m in mods.items():
+        mine = ["%s %s" % (k, tuple(v.shape)) for k, v in m.state_dict().items()]
+        assert mine == list(g[n]), n
+    assert networks.Lite_Depth_Decoder_QueryTr(in_channels=32, embedding_dim=32).transformer_encoder.layers[0].linear1.out_features == 512
+
+
+def test_networks_match_oracle_on_cpu():
+    """Same weights -> same outputs as the oracle restatement (module wiring; ATen-backed operators)."""
+    import networks
+    from oracle import torch_ref as O
+    from param_fill import fill_params
+    torch.manual_seed(0)
+    x = torch.rand(2, 3, 64, 96)
+    for mine, ref in ((networks.LiteResnetEncoderDecoder(model_dim=16), O.LiteResnetEncoderDecoder(model_dim=16)),
+                      (networks.ResnetEncoderDecoder(50, 64, 16), O.ResnetEncoderDecoder(50, 64, 16))):
+        fill_params(ref, 5)
+        mine.load_state_dict(ref.state_dict())
+        mine.train(); ref.train()
+        np.testing.assert_allclose(mine(x).detach().numpy(), ref(x).detach().numpy(), rtol=1e-4, atol=1e-5)
+    feat = torch.randn(2, 16, 32, 48)
+    mine = networks.Lite_Depth_Decoder_QueryTr(in_channels=16, embedding_dim=16, patch_size=8, query_nums=12, dim_out=24, max_val=80.0)
+    ref = O.QueryTrDecoder(16, 16, 8, 4, 12, 24, max_val=80.0, dim_feedforward=512)
+    fill_params(ref, 6)
+    mine.load_state_dict(ref.state_dict())
+    mine.eval(); ref.eval()
+    np.testing.assert_allclose(mine(feat)[("disp", 0)].detach().numpy(), ref(feat)[("disp", 0)].detach().numpy(), rtol=1e-4, atol=1e-4)
+    pm, pr = networks.PoseCNN(2), O.PoseCNN(2)
+    fill_params(pr, 7)
+    pm.load_state_dict(pr.state_dict())
+    a, b = pm(torch.rand(2, 6, 64, 96)), pr(torch.rand(2, 6, 64, 96).mul(0) + 0.5)
+    assert a[0].shape == b[0].shape == (2, 1, 1, 3)
+
+
+# --------------------------------------------------------------------------------------------- ABI
+def test_abi_exports_every_declared_symbol():
+    from sqd import lib
+    if lib.needs_build():
+        lib.build()
+    L = lib.lib()
+    header = open(os.path.join(REPO, "include", "sqd.h")).read()
+    declared = set(re.findall(r"\b(sqd_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no entry points parsed from include/sqd.h"
+    for name in declared:
+        assert hasattr(L, name), "libsqd.so lacks %s declared in include/sqd.h" % name
+    assert set(lib.exported_symbols()) == declared, set(lib.exported_symbols()) ^ declared
+    assert L.sqd_abi_version() == 1
+
+
+def test_product_ops_refuse_cpu_tensors():
+    from sqd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.identity_fwd(torch.zeros(1, 3, 16, 16), [torch.zeros(1, 3, 16, 16)] * 2)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.pose_mats_fwd(torch.zeros(1, 2, 3), torch.zeros(1, 2, 3), [1, 0], torch.eye(4)[None])
+
+
+def test_product_never_imports_oracle():
+    for root, _, files in os.walk(PRODUCT):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), os.path.join(root, f)
+
+
+# ------------------------------------------------------------------------------------------- data
+def test_synthetic_batch_schema():
+    from datasets import synthetic_batch
+    b = synthetic_batch(2, 64, 96, with_gt=True)
+    for f in (0, -1, 1):
+        assert b[("color", f, 0)].shape == (2, 3, 64, 96) and b[("color_aug", f, 0)].shape == (2, 3, 64, 96)
+        assert 0 <= float(b[("color", f, 0)].min()) and float(b[("color", f, 0)].max()) <= 1
+    K = b[("K", 0)][0]
+    assert abs(float(K[0, 0]) - 0.58 * 96) < 1e-4 and abs(float(K[1, 1]) - 1.92 * 64) < 1e-4
+    np.testing.assert_allclose((b[("K", 0)][0] @ b[("inv_K", 0)][0]).numpy(), np.eye(4), atol=1e-4)
+    assert b["depth_gt"].shape == (2, 1, 375, 1242) and float(b["depth_gt"].min()) > 0
+
+
+# -------------------------------------------------------------------------------- multi-process DDP
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, PRODUCT)
+    from sqd import ddp
+    ddp.init_from_env("gloo")
+    torch.manual_seed(100 + rank)                      # different initial weights per rank on purpose
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 3, padding=1))
+    unused = torch.nn.Linear(4, 4)                     # never receives a gradient (like the trunk's fc)
+    params = list(model.parameters()) + list(unused.parameters())
+    red = ddp.GradBucketReducer(params, bucket_mb=0.0005)     # tiny buckets -> several buckets
+    red.broadcast_parameters([model, unused])
+    torch.manual_seed(7)
+    data = torch.randn(4, 3, 8, 8)
+    shard = data[rank * 2:(rank + 1) * 2]
+    opt = torch.optim.SGD(params, lr=0.1)
+    hist = []
+    for step in range(3):
+        red.zero_grad()
+        model(shard).square().mean().backward()
+        red.finish()
+        hist.append(torch.cat([p.grad.reshape(-1) for p in model.parameters()]).clone())
+        opt.step()
+    q.put((rank, [h.numpy() for h in hist], [p.detach().numpy() for p in model.parameters()], len(red.buckets)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_bucket_reducer_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=180) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    (r0, g0, w0, nb0), (r1, g1, w1, nb1) = res
+    assert nb0 == nb1 and nb0 >= 2
+    for a, b in zip(g0, g1):
+        np.testing.assert_allclose(a, b, rtol=0, atol=0)            # both ranks hold the same averaged gradient
+    for a, b in zip(w0, w1):
+        np.testing.assert_allclose(a, b, rtol=0, atol=1e-7)
+    # single-process reference: full batch of 4 == mean of the two shards of 2
+    torch.manual_seed(100)
+    model = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3, padding=1), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 3, padding=1))
+    torch.manual_seed(7)
+    data = torch.randn(4, 3, 8, 8)
+    (0.5 * (model(data[:2]).square().mean() + model(data[2:]).square().mean())).backward()
+    want = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy()
+    np.testing.assert_allclose(g0[0], want, rtol=1e-5, atol=1e-7)
