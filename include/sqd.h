@@ -142,6 +142,22 @@ int sqd_smooth_fwd(const float *depth, const float *color, const float *part, in
 int sqd_smooth_bwd(const float *depth, const float *color, const float *part, int nblk, const float *sm_part,
                    float gout, float *g_depth, int64_t g_depth_img_stride, int B, int H, int W, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (5) Self Query Layer
+ * replaces: FullQueryLayer.forward (reference networks/layers.py:7-21): y = x^T K^T (:17),
+ *           softmax over the N = h*w pixels (:18), summary = softmax(y)^T x^T (:19).
+ * x [B,E,N] (the [B,E,h,w] feature map), K [B,Q,E] queries -> y [B,Q,N] energy maps (raw dot
+ * products), summary [B,Q,E], lse [B,Q,2] = (max, 1/sum) for the backward.  E in {16,32}, Q <= 128.
+ * part: workspace of sqd_sql_workspace(..).part_floats floats.  fp32 MFMA (v_mfma_f32_16x16x4_f32).  */
+int sqd_sql_workspace(int B, int Q, int E, int N, int64_t *part_floats, int64_t *gk_part_floats);
+int sqd_sql_fwd(const float *x, const float *K, float *y, float *summary, float *lse, float *part, int B, int Q,
+                int E, int N, void *stream);
+/* adjoint: g_y [B,Q,N] (may be NULL), g_summary [B,Q,E] -> g_x [B,E,N], g_K [B,Q,E];
+ * gk_part: workspace of gk_part_floats floats.                                                       */
+int sqd_sql_bwd(const float *x, const float *K, const float *y, const float *g_y, const float *g_summary,
+                const float *summary, const float *lse, float *g_x, float *g_K, float *gk_part, int B, int Q,
+                int E, int N, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,495 @@
+// sql.hip — the Self Query Layer (reference networks/layers.py:7-21, FullQueryLayer.forward) as fp32-MFMA
+// kernels for gfx950:
+//     y[b,q,n]       = sum_e K[b,q,e] * x[b,e,n]                    (energy maps, returned raw)
+//     s[b,q,:]       = softmax over the N = h*w pixels of y[b,q,:]
+//     summary[b,q,e] = sum_n s[b,q,n] * x[b,e,n]
+//
+// Forward: one pass over x.  A wavefront owns a run of pixel tiles; per tile it forms y^T (pixels x
+// queries) with v_mfma_f32_16x16x4_f32, stores y, updates the running (max, sum) of an online softmax
+// per query and feeds p = exp(y - max) — still sitting in the MFMA accumulator registers — straight
+// back in as the B operand of the second MFMA (x * p, contraction over the pixels the accumulator rows
+// index), so the N x Q probability matrix never exists in memory.  Per-workgroup partials
+// (max, sum, unnormalised summary) are merged by a small second kernel, which also emits the
+// log-sum-exp the backward needs.
+//
+// Backward: one pass over (x, y, g_y) in the transposed orientation (queries x pixels) so that the
+// contraction over queries can again consume accumulator registers directly; the only layout change
+// (for dK, a contraction over pixels) goes through a wave-private LDS tile.
+//
+// Roofline: HBM for the y traffic (4*Q B/px written forward, 8*Q B/px read backward), fp32 MFMA
+// (157 TF) for the 4*Q*E flop/px forward — both are ~10-20 us at config B; the kernel exists to
+// replace 5 ATen launches that move y four times.
+#include "sqd_common.h"
+
+namespace {
+using namespace sqd;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+// reduce over the four 16-lane groups (lanes l, l^16, l^32, l^48)
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+
+constexpr int PART_STRIDE_EXTRA = 2;   // per query: max, sum, then E summary values
+
+// ---------------------------------------------------------------------------------------------------
+// forward.  QT = ceil(Q/16) query tiles, ET = E/16 feature tiles (E multiple of 16), NT pixel tiles
+// (of 16) per step; grid (chunks, B), 256 threads; each wave walks `tiles_per_wave` steps.
+// ---------------------------------------------------------------------------------------------------
+template <int QT, int ET, int NT>
+__global__ __launch_bounds__(256) void sql_fwd_kernel(const float *__restrict__ x, const float *__restrict__ K,
+                                                      float *__restrict__ y, float *__restrict__ part, int Q, int N,
+                                                      int steps_per_wave, int nchunks) {
+    constexpr int E = ET * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const float *xb = x + (size_t)b * E * N;
+    const float *Kb = K + (size_t)b * Q * E;
+    float *yb = y + (size_t)b * Q * N;
+    const int PX = NT * 16;                                   // pixels per step
+    const int n_wave0 = (chunk * 4 + wave) * steps_per_wave * PX;
+
+    float m_run[QT], l_run[QT];
+    f32x4 acc[ET][QT];
+#pragma unroll
+    for (int j = 0; j < QT; ++j) {
+        m_run[j] = -INFINITY;
+        l_run[j] = 0.f;
+#pragma unroll
+        for (int t = 0; t < ET; ++t) acc[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    for (int st = 0; st < steps_per_wave; ++st) {
+        const int n0 = n_wave0 + st * PX;
+        if (n0 >= N) break;
+        // ---- y^T tile: D[n][q] = sum_e x[e][n] * K[q][e]   (M = pixels, N = queries, K = features)
+        f32x4 d[NT][QT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < QT; ++j) d[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e0 = 0; e0 < E; e0 += 4) {
+            float bq[QT];
+#pragma unroll
+            for (int j = 0; j < QT; ++j) {
+                const int q = j * 16 + c;
+                bq[j] = q < Q ? Kb[q * E + e0 + g] : 0.f;      // B[k=e][col=q]
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int n = n0 + i * 16 + c;
+                const float a = n < N ? xb[(size_t)(e0 + g) * N + n] : 0.f;   // A[row=n][k=e]
+#pragma unroll
+                for (int j = 0; j < QT; ++j) d[i][j] = mfma16(a, bq[j], d[i][j]);
+            }
+        }
+        // ---- store y (lane holds 4 consecutive pixels n0+i*16+4g.. of query j*16+c) and tile max
+        float tmax[QT];
+#pragma unroll
+        for (int j = 0; j < QT; ++j) tmax[j] = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int n = n0 + i * 16 + 4 * g;
+#pragma unroll
+            for (int j = 0; j < QT; ++j) {
+                const int q = j * 16 + c;
+                f32x4 v = d[i][j];
+                if (q < Q) {
+                    if (n + 3 < N && (N & 3) == 0) {
+                        *reinterpret_cast<f32x4 *>(yb + (size_t)q * N + n) = v;
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (n + r < N) yb[(size_t)q * N + n + r] = v[r];
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (n + r >= N) v[r] = -INFINITY;          // tail pixels take no softmax mass
+                    tmax[j] = fmaxf(tmax[j], v[r]);
+                }
+                d[i][j] = v;
+            }
+        }
+        // ---- online softmax update, p = exp(y - m) left in the accumulator registers
+#pragma unroll
+        for (int j = 0; j < QT; ++j) {
+            const float mt = group_max(tmax[j]);
+            const float mn = fmaxf(m_run[j], mt);
+            const float sc = __expf(m_run[j] - mn);            // exp(-inf) = 0 on the first tile
+            float ls = 0.f;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = __expf(d[i][j][r] - mn);
+                    d[i][j][r] = p;
+                    ls += p;
+                }
+            }
+            l_run[j] = l_run[j] * sc + group_sum(ls);
+            m_run[j] = mn;
+#pragma unroll
+            for (int t = 0; t < ET; ++t) acc[t][j] *= sc;
+        }
+        // ---- summary^T[e][q] += sum_n x[e][n] * p[n][q]: the k-slot (g, r) of pixel tile i is pixel n0+i*16+4g+r
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int n = n0 + i * 16 + 4 * g;
+#pragma unroll
+            for (int t = 0; t < ET; ++t) {
+                const float *xr = xb + (size_t)(t * 16 + c) * N + n;       // A[row=e][k]: 4 consecutive pixels
+                float a4[4];
+                if (n + 3 < N && (N & 3) == 0) {
+                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xr);
+                    a4[0] = v[0]; a4[1] = v[1]; a4[2] = v[2]; a4[3] = v[3];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a4[r] = n + r < N ? xr[r] : 0.f;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int j = 0; j < QT; ++j) acc[t][j] = mfma16(a4[r], d[i][j][r], acc[t][j]);
+            }
+        }
+    }
+
+    // ---- merge the four waves of the workgroup through LDS, one partial record per workgroup
+    constexpr int QP = QT * 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *sm = lds;                                   // [4][QP][2]
+    float *sacc = lds + 4 * QP * 2;                    // [4][E][QP+1]
+    if (g == 0) {
+#pragma unroll
+        for (int j = 0; j < QT; ++j) {
+            sm[(wave * QP + j * 16 + c) * 2] = m_run[j];
+            sm[(wave * QP + j * 16 + c) * 2 + 1] = l_run[j];
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < ET; ++t)
+#pragma unroll
+        for (int j = 0; j < QT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)                 // D: row e = 4g+r, col q = c
+                sacc[((size_t)wave * E + t * 16 + 4 * g + r) * (QP + 1) + j * 16 + c] = acc[t][j][r];
+    __syncthreads();
+    float *po = part + ((size_t)b * nchunks + chunk) * Q * (E + PART_STRIDE_EXTRA);
+    for (int q = threadIdx.x; q < Q; q += 256) {
+        float mk[4], M = -INFINITY, L = 0.f, w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mk[k] = sm[(k * QP + q) * 2];
+            M = fmaxf(M, mk[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            w[k] = mk[k] == -INFINITY ? 0.f : __expf(mk[k] - M);
+            L += sm[(k * QP + q) * 2 + 1] * w[k];
+        }
+        float *o = po + (size_t)q * (E + PART_STRIDE_EXTRA);
+        o[0] = M;
+        o[1] = L;
+        for (int e = 0; e < E; ++e) {
+            float s = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s += sacc[((size_t)k * E + e) * (QP + 1) + q] * w[k];
+            o[2 + e] = s;
+        }
+    }
+}
+
+// merge the per-workgroup partials: summary[b,q,e], lse[b,q,2] = (max, 1/sum)
+__global__ __launch_bounds__(64) void sql_merge_kernel(const float *__restrict__ part, float *__restrict__ summary,
+                                                       float *__restrict__ lse, int Q, int E, int nchunks) {
+    const int b = blockIdx.y, q = blockIdx.x, lane = threadIdx.x;
+    const size_t rec = (size_t)(E + PART_STRIDE_EXTRA);
+    const float *p0 = part + ((size_t)b * nchunks) * Q * rec + (size_t)q * rec;
+    float M = -INFINITY;
+    for (int k = 0; k < nchunks; ++k) M = fmaxf(M, p0[(size_t)k * Q * rec]);
+    float L = 0.f;
+    for (int k = 0; k < nchunks; ++k) {
+        const float *p = p0 + (size_t)k * Q * rec;
+        L += p[1] * (p[0] == -INFINITY ? 0.f : __expf(p[0] - M));
+    }
+    const float iL = 1.f / L;
+    for (int e = lane; e < E; e += 64) {
+        float s = 0.f;
+        for (int k = 0; k < nchunks; ++k) {
+            const float *p = p0 + (size_t)k * Q * rec;
+            s += p[2 + e] * (p[0] == -INFINITY ? 0.f : __expf(p[0] - M));
+        }
+        summary[((size_t)b * Q + q) * E + e] = s * iL;
+    }
+    if (lane == 0) {
+        lse[((size_t)b * Q + q) * 2] = M;
+        lse[((size_t)b * Q + q) * 2 + 1] = iL;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// backward.  Orientation: rows = queries (4g+r within a 16-tile), cols = pixels (c).
+//   t[q][n]   = sum_e gS[q][e] x[e][n]
+//   s[q][n]   = exp(y - max) / sum ;  gyt = g_y + s * (t - dot[q]),  dot[q] = sum_e gS[q][e] * summary[q][e]
+//   g_x[e][n] = sum_q K[q][e] gyt[q][n] + gS[q][e] s[q][n]
+//   g_K[q][e] = sum_n gyt[q][n] x[e][n]                        (through a wave-private LDS transpose)
+// ---------------------------------------------------------------------------------------------------
+template <int QT, int ET, int NT>
+__global__ __launch_bounds__(256) void sql_bwd_kernel(const float *__restrict__ x, const float *__restrict__ K,
+                                                      const float *__restrict__ y, const float *__restrict__ g_y,
+                                                      const float *__restrict__ gS, const float *__restrict__ summary,
+                                                      const float *__restrict__ lse, float *__restrict__ g_x,
+                                                      float *__restrict__ gK_part, int Q, int N, int steps_per_wave,
+                                                      int nchunks) {
+    constexpr int E = ET * 16;
+    constexpr int QP = QT * 16, PX = NT * 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane & 15, g = lane >> 4;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const float *xb = x + (size_t)b * E * N;
+    const float *Kb = K + (size_t)b * Q * E;
+    const float *gSb = gS + (size_t)b * Q * E;
+    const float *yb = y + (size_t)b * Q * N;
+    const float *gyb = g_y ? g_y + (size_t)b * Q * N : nullptr;
+    float *gxb = g_x + (size_t)b * E * N;
+    const int n_wave0 = (chunk * 4 + wave) * steps_per_wave * PX;
+
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *qc = lds;                                              // [QP][4]: max, 1/sum, dot, pad (workgroup-shared)
+    float *tile = lds + QP * 4 + (size_t)wave * QP * (PX + 1);    // wave-private [QP][PX+1]
+    for (int q = threadIdx.x; q < QP; q += 256) {
+        float dsum = 0.f, mx = 0.f, il = 0.f;
+        if (q < Q) {
+            mx = lse[((size_t)b * Q + q) * 2];
+            il = lse[((size_t)b * Q + q) * 2 + 1];
+            for (int e = 0; e < E; ++e) dsum += gSb[q * E + e] * summary[((size_t)b * Q + q) * E + e];
+        }
+        qc[q * 4] = mx; qc[q * 4 + 1] = il; qc[q * 4 + 2] = dsum;
+    }
+    __syncthreads();
+    f32x4 accK[ET][QT];                                            // g_K^T[e][q] accumulators: row e = 4g+r, col q = c
+#pragma unroll
+    for (int t = 0; t < ET; ++t)
+#pragma unroll
+        for (int j = 0; j < QT; ++j) accK[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int st = 0; st < steps_per_wave; ++st) {
+        const int n0 = n_wave0 + st * PX;
+        if (n0 >= N) break;
+        // ---- t[q][n]: M = queries (A = gS[q][e]), N = pixels (B = x[e][n]), K = features
+        f32x4 d[QT][NT];
+#pragma unroll
+        for (int j = 0; j < QT; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) d[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e0 = 0; e0 < E; e0 += 4) {
+            float bx[NT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int n = n0 + i * 16 + c;
+                bx[i] = n < N ? xb[(size_t)(e0 + g) * N + n] : 0.f;           // B[k=e][col=n]
+            }
+#pragma unroll
+            for (int j = 0; j < QT; ++j) {
+                const int q = j * 16 + c;
+                const float a = q < Q ? gSb[q * E + e0 + g] : 0.f;             // A[row=q][k=e]
+#pragma unroll
+                for (int i = 0; i < NT; ++i) d[j][i] = mfma16(a, bx[i], d[j][i]);
+            }
+        }
+        // ---- element-wise: s and gyt (rows q = j*16+4g+r, col n = n0+i*16+c); s kept in sreg
+        f32x4 sreg[QT][NT];
+#pragma unroll
+        for (int j = 0; j < QT; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int n = n0 + i * 16 + c;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int q = j * 16 + 4 * g + r;
+                    float s = 0.f, gyt = 0.f;
+                    if (q < Q && n < N) {
+                        const size_t o = (size_t)q * N + n;
+                        s = __expf(yb[o] - qc[q * 4]) * qc[q * 4 + 1];
+                        gyt = (gyb ? gyb[o] : 0.f) + s * (d[j][i][r] - qc[q * 4 + 2]);
+                    }
+                    sreg[j][i][r] = s;
+                    d[j][i][r] = gyt;
+                    tile[(j * 16 + 4 * g + r) * (PX + 1) + i * 16 + c] = gyt;
+                }
+            }
+        // ---- g_x[e][n] = sum_q K[q][e] gyt[q][n] + gS[q][e] s[q][n]: k-slot (g, r) of query tile j is query j*16+4g+r
+        f32x4 gx[ET][NT];
+#pragma unroll
+        for (int t = 0; t < ET; ++t)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) gx[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < QT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = j * 16 + 4 * g + r;
+#pragma unroll
+                for (int t = 0; t < ET; ++t) {
+                    const float ak = q < Q ? Kb[q * E + t * 16 + c] : 0.f;     // A[row=e][k=q]
+                    const float as = q < Q ? gSb[q * E + t * 16 + c] : 0.f;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        gx[t][i] = mfma16(ak, d[j][i][r], gx[t][i]);
+                        gx[t][i] = mfma16(as, sreg[j][i][r], gx[t][i]);
+                    }
+                }
+            }
+#pragma unroll
+        for (int t = 0; t < ET; ++t)
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int n = n0 + i * 16 + c;
+                if (n < N) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) gxb[(size_t)(t * 16 + 4 * g + r) * N + n] = gx[t][i][r];
+                }
+            }
+        // ---- g_K^T[e][q] += sum_n x[e][n] gyt[q][n]: read gyt transposed from the wave-private tile
+        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes have landed
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int nl = i * 16 + 4 * g + r;     // k-slot (g, r) of pixel tile i
+                const int n = n0 + nl;
+                float bq[QT];
+#pragma unroll
+                for (int j = 0; j < QT; ++j) bq[j] = tile[(j * 16 + c) * (PX + 1) + nl];      // B[k=n][col=q]
+#pragma unroll
+                for (int t = 0; t < ET; ++t) {
+                    const float a = n < N ? xb[(size_t)(t * 16 + c) * N + n] : 0.f;            // A[row=e][k=n]
+#pragma unroll
+                    for (int j = 0; j < QT; ++j) accK[t][j] = mfma16(a, bq[j], accK[t][j]);
+                }
+            }
+    }
+    // ---- workgroup merge of g_K^T through LDS (reuse the tile area after a barrier)
+    __syncthreads();
+    float *red = lds + QP * 4;                          // [4][E][QP+1]
+#pragma unroll
+    for (int t = 0; t < ET; ++t)
+#pragma unroll
+        for (int j = 0; j < QT; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[((size_t)wave * E + t * 16 + 4 * g + r) * (QP + 1) + j * 16 + c] = accK[t][j][r];
+    __syncthreads();
+    float *po = gK_part + ((size_t)b * nchunks + chunk) * Q * E;
+    for (int idx = threadIdx.x; idx < Q * E; idx += 256) {
+        const int q = idx / E, e = idx - q * E;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s += red[((size_t)k * E + e) * (QP + 1) + q];
+        po[idx] = s;
+    }
+}
+
+// g_K[b,q,e] = sum over chunks of gK_part
+__global__ __launch_bounds__(256) void sql_gk_reduce_kernel(const float *__restrict__ part, float *__restrict__ gK, int QE,
+                                                            int nchunks) {
+    const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= QE) return;
+    float s = 0.f;
+    for (int k = 0; k < nchunks; ++k) s += part[((size_t)b * nchunks + k) * QE + idx];
+    gK[(size_t)b * QE + idx] = s;
+}
+
+struct Plan {
+    int QT, ET, NT, steps, nchunks;
+};
+int make_plan(int Q, int E, int N, Plan *p) {
+    if (E % 16 != 0 || E > 32 || E < 16 || Q < 1 || Q > 128 || N < 1) return -1;
+    int QT = (Q + 15) / 16;
+    QT = QT <= 1 ? 1 : QT <= 2 ? 2 : QT <= 4 ? 4 : 8;
+    p->QT = QT;
+    p->ET = E / 16;
+    p->NT = QT >= 8 ? 1 : QT >= 4 ? 2 : 4;
+    const int px = p->NT * 16;
+    // aim at >= ~2048 waves per launch-batch of 12 images: a wave walks `steps` pixel tiles
+    int steps = 2;
+    while (steps < 16 && N / (px * steps * 4) > 64) steps *= 2;
+    p->steps = steps;
+    p->nchunks = (N + px * steps * 4 - 1) / (px * steps * 4);
+    return 0;
+}
+}  // namespace
+
+extern "C" int sqd_sql_workspace(int B, int Q, int E, int N, int64_t *part_floats, int64_t *gk_part_floats) {
+    Plan p;
+    SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql: unsupported Q=%d E=%d N=%d (E in {16,32,48,64}, Q <= 128)", Q, E, N);
+    if (part_floats) *part_floats = (int64_t)B * p.nchunks * Q * (E + PART_STRIDE_EXTRA);
+    if (gk_part_floats) *gk_part_floats = (int64_t)B * p.nchunks * Q * E;
+    return SQD_OK;
+}
+
+#define SQL_DISPATCH(QT_, ET_, NT_, KERNEL, SHMEM, ...)                                                        \
+    if (p.QT == QT_ && p.ET == ET_) {                                                                           \
+        if ((SHMEM) > 48 * 1024)                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&KERNEL<QT_, ET_, NT_>),                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)(SHMEM));                \
+        hipLaunchKernelGGL((KERNEL<QT_, ET_, NT_>), dim3(p.nchunks, B), dim3(256), SHMEM, (hipStream_t)stream, __VA_ARGS__); \
+        launched = true;                                                                                        \
+    }
+
+#define SQL_DISPATCH_ALL(KERNEL, SHMEM, ...)                 \
+    SQL_DISPATCH(1, 1, 4, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(2, 1, 4, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(4, 1, 2, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(8, 1, 1, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(1, 2, 4, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(2, 2, 4, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(4, 2, 2, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(8, 2, 1, KERNEL, SHMEM, __VA_ARGS__)
+
+extern "C" int sqd_sql_fwd(const float *x, const float *K, float *y, float *summary, float *lse, float *part, int B, int Q,
+                           int E, int N, void *stream) {
+    SQD_CHECK_ARG(x && K && y && summary && lse && part, "sqd_sql_fwd: null pointer");
+    Plan p;
+    SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql_fwd: unsupported Q=%d E=%d N=%d", Q, E, N);
+    bool launched = false;
+    const size_t fwd_lds = ((size_t)4 * p.QT * 16 * 2 + (size_t)4 * E * (p.QT * 16 + 1)) * sizeof(float);
+    (void)hipGetLastError();
+    SQL_DISPATCH_ALL(sql_fwd_kernel, fwd_lds, x, K, y, part, Q, N, p.steps, p.nchunks)
+    SQD_CHECK_ARG(launched, "sqd_sql_fwd: no kernel instance for QT=%d ET=%d", p.QT, p.ET);
+    SQD_CHECK_LAUNCH("sqd_sql_fwd");
+    hipLaunchKernelGGL(sql_merge_kernel, dim3(Q, B), dim3(64), 0, (hipStream_t)stream, part, summary, lse, Q, E, p.nchunks);
+    SQD_CHECK_LAUNCH("sqd_sql_fwd(merge)");
+    return SQD_OK;
+}
+
+extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const float *g_y, const float *g_summary,
+                           const float *summary, const float *lse, float *g_x, float *g_K, float *gk_part, int B, int Q,
+                           int E, int N, void *stream) {
+    SQD_CHECK_ARG(x && K && y && g_summary && summary && lse && g_x && g_K && gk_part, "sqd_sql_bwd: null pointer");
+    Plan p;
+    SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql_bwd: unsupported Q=%d E=%d N=%d", Q, E, N);
+    const int QP = p.QT * 16, PX = p.NT * 16;
+    const size_t sh_tile = (size_t)4 * QP * (PX + 1) * sizeof(float), sh_red = (size_t)4 * E * (QP + 1) * sizeof(float);
+    const size_t shmem = (size_t)QP * 4 * sizeof(float) + (sh_tile > sh_red ? sh_tile : sh_red);
+    bool launched = false;
+    (void)hipGetLastError();
+    SQL_DISPATCH_ALL(sql_bwd_kernel, shmem, x, K, y, g_y, g_summary, summary, lse, g_x, gk_part, Q, N, p.steps, p.nchunks)
+    SQD_CHECK_ARG(launched, "sqd_sql_bwd: no kernel instance for QT=%d ET=%d", p.QT, p.ET);
+    SQD_CHECK_LAUNCH("sqd_sql_bwd");
+    hipLaunchKernelGGL(sql_gk_reduce_kernel, dim3((Q * E + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, gk_part, g_K,
+                       Q * E, p.nchunks);
+    SQD_CHECK_LAUNCH("sqd_sql_bwd(reduce)");
+    return SQD_OK;
+}

@@ -90,6 +90,9 @@ _SIGNATURES = {
     "sqd_photo_bwd_ntasks": (_I, [_I, _I, _I, _I, _I]),
     "sqd_photo_bwd": (_I, [ctypes.POINTER(PhotoBwdArgs)]),
     "sqd_photo_bwd_reduce": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "sqd_sql_workspace": (_I, [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
+    "sqd_sql_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sqd_sql_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sqd_smooth_nblk": (_I, [_I, _I]),
     "sqd_smooth_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "sqd_smooth_bwd": (_I, [_P, _P, _P, _I, _P, _F, _P, ctypes.c_int64, _I, _I, _I, _P]),

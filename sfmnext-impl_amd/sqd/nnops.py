@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 BACKEND = {
     "conv2d": "aten", "conv_bn_act": "aten", "maxpool3x3s2": "aten", "upsample_concat": "aten",
-    "linear": "aten", "transformer_encoder": "aten", "full_query_layer": "aten", "bins_head": "aten",
+    "linear": "aten", "transformer_encoder": "aten", "full_query_layer": "hip", "bins_head": "aten",
 }
 
 
@@ -67,8 +67,14 @@ def transformer_encoder(tokens, encoder):
 def full_query_layer(x, queries):
     """Self Query Layer (reference networks/layers.py:7-21): x [B,E,h,w], queries [B,Q,E] ->
     energy maps [B,Q,h,w] (raw dot products) and summaries [B,Q,E] (softmax over the h*w pixels)."""
+    if x.is_cuda:
+        from . import ops
+        if not ops.sql_supported(x.shape[1], queries.shape[1]):
+            raise RuntimeError("sqd: Self Query Layer kernel supports E in {16,32}, Q <= 128; got E=%d Q=%d" % (x.shape[1], queries.shape[1]))
+        return ops.SelfQueryLayer.apply(x, queries)
+    # host tensors: only the CPU wiring tests come here (the training path always runs on the device)
     n, c, h, w = x.shape
-    xt = x.view(n, c, h * w)
+    xt = x.reshape(n, c, h * w)
     y = torch.matmul(queries, xt)                              # [B,Q,N]
     summary = torch.matmul(torch.softmax(y, dim=2), xt.transpose(1, 2))
     return y.view(n, queries.shape[1], h, w), summary

@@ -232,3 +232,52 @@ class PhotometricChain(torch.autograd.Function):
         g = g_total
         return (g_disp * g, g_aa * g, g_tr * g, None, None, None, None, None) + (None,) * S
 
+
+# ---------------------------------------------------------------------------------------------------
+def _sql_workspace(B, Q, E, N):
+    a, b = ctypes.c_int64(0), ctypes.c_int64(0)
+    _l.check(_l.lib().sqd_sql_workspace(B, Q, E, N, ctypes.byref(a), ctypes.byref(b)), "sql_workspace")
+    return a.value, b.value
+
+
+class SelfQueryLayer(torch.autograd.Function):
+    """FullQueryLayer.forward of the reference (networks/layers.py:7-21) as one fp32-MFMA kernel pair.
+    forward(x [B,E,h,w], queries [B,Q,E]) -> (energy maps [B,Q,h,w], summaries [B,Q,E])."""
+
+    @staticmethod
+    def forward(ctx, x, queries):
+        x, queries = x.contiguous(), queries.contiguous()
+        _req(x, queries)
+        B, E, h, w = x.shape
+        Q, N = queries.shape[1], h * w
+        dev = x.device
+        nf, _ = _sql_workspace(B, Q, E, N)
+        y = torch.empty(B, Q, h, w, device=dev, dtype=torch.float32)
+        summary = torch.empty(B, Q, E, device=dev, dtype=torch.float32)
+        lse = torch.empty(B, Q, 2, device=dev, dtype=torch.float32)
+        part = torch.empty(nf, device=dev, dtype=torch.float32)
+        _l.check(_l.lib().sqd_sql_fwd(_ptr(x), _ptr(queries), _ptr(y), _ptr(summary), _ptr(lse), _ptr(part), B, Q, E, N,
+                                      _stream()), "sql_fwd")
+        ctx.save_for_backward(x, queries, y, summary, lse)
+        return y, summary
+
+    @staticmethod
+    def backward(ctx, g_y, g_summary):
+        x, queries, y, summary, lse = ctx.saved_tensors
+        B, E, h, w = x.shape
+        Q, N = queries.shape[1], h * w
+        dev = x.device
+        _, nk = _sql_workspace(B, Q, E, N)
+        g_y = g_y.contiguous() if g_y is not None else None
+        g_summary = g_summary.contiguous() if g_summary is not None else torch.zeros_like(summary)
+        g_x = torch.empty_like(x)
+        g_K = torch.empty_like(queries)
+        part = torch.empty(nk, device=dev, dtype=torch.float32)
+        _l.check(_l.lib().sqd_sql_bwd(_ptr(x), _ptr(queries), _ptr(y), _ptr(g_y), _ptr(g_summary), _ptr(summary), _ptr(lse),
+                                      _ptr(g_x), _ptr(g_K), _ptr(part), B, Q, E, N, _stream()), "sql_bwd")
+        return g_x, g_K
+
+
+def sql_supported(E, Q):
+    return E in (16, 32) and 1 <= Q <= 128
+

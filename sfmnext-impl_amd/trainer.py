@@ -78,6 +78,11 @@ class Trainer:
             sd = torch.load(os.path.join(self.opt.pose_net_path, "pose.pth"), map_location=self.device)
             self.models["pose"].load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
 
+        if self.opt.sqd_miopen_find:
+            torch.backends.cudnn.benchmark = True
+        if self.opt.sqd_channels_last:
+            for m in self.models.values():
+                m.to(memory_format=torch.channels_last)
         self.parameters_to_train = list(self.models["encoder"].parameters()) + list(self.models["depth"].parameters())
         if self.opt.diff_lr:
             self.pose_params = list(self.models["pose"].parameters())
@@ -209,13 +214,16 @@ class Trainer:
         for key, ipt in inputs.items():
             inputs[key] = ipt.to(self.device, non_blocking=True)
         self._launch_identity(inputs)
-        features = self.models["encoder"](inputs["color_aug", 0, 0])
+        features = self.models["encoder"](self._fmt(inputs["color_aug", 0, 0]))
         outputs = self.models["depth"](features)
         if self.use_pose_net:
             outputs.update(self.predict_poses(inputs, features))
         self.generate_images_pred(inputs, outputs)
         losses = self.compute_losses(inputs, outputs)
         return outputs, losses
+
+    def _fmt(self, x):
+        return x.contiguous(memory_format=torch.channels_last) if self.opt.sqd_channels_last else x
 
     def _launch_identity(self, inputs):
         """Identity-reprojection maps + tie-break noise (reference trainer.py:480-487,514-517) depend only
@@ -245,7 +253,7 @@ class Trainer:
         aug = {f: inputs["color_aug", f, 0] for f in self.opt.frame_ids}
         for f in self.opt.frame_ids[1:]:
             pair = [aug[f], aug[0]] if f < 0 else [aug[0], aug[f]]
-            axisangle, translation = self.models["pose"](torch.cat(pair, 1))
+            axisangle, translation = self.models["pose"](self._fmt(torch.cat(pair, 1)))
             outputs[("axisangle", 0, f)] = axisangle
             outputs[("translation", 0, f)] = translation
             outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=(f < 0))

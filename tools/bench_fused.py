@@ -1,0 +1,63 @@
+"""Micro-benchmark of the photometric kernels alone (for rocprofv3 --pmc passes and TH sweeps).
+usage: python tools/bench_fused.py [--rows 8,12,16,24,32] [--iters 200] [--B 12 --H 192 --W 640] [--which fwd,ident,bwd]"""
+import argparse
+import ctypes
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "sfmnext-impl_amd"))
+import torch  # noqa: E402
+from sqd import lib as _l, ops  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", default="0")
+ap.add_argument("--iters", type=int, default=200)
+ap.add_argument("--B", type=int, default=12)
+ap.add_argument("--H", type=int, default=192)
+ap.add_argument("--W", type=int, default=640)
+ap.add_argument("--which", default="fwd,fwd_infer,ident,bwd")
+args = ap.parse_args()
+B, H, W = args.B, args.H, args.W
+dev = torch.device("cuda")
+torch.manual_seed(0)
+K = torch.tensor([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1, 0], [0, 0, 0, 1]], device=dev).repeat(B, 1, 1).contiguous()
+inv_K = torch.linalg.pinv(K).contiguous()
+tgt = torch.rand(B, 3, H, W, device=dev)
+srcs = [torch.rand(B, 3, H, W, device=dev) for _ in range(2)]
+disp = torch.rand(B, 1, H // 2, W // 2, device=dev) * 20 + 1
+depth, part = ops.depth_up_fwd(disp, H, W)
+aa, tr = 0.01 * torch.randn(B, 2, 3, device=dev), 0.5 * torch.randn(B, 2, 3, device=dev)
+mid, T, P = ops.pose_mats_fwd(aa, tr, [1, 0], K, part, H * W)
+noise = torch.randn(B, 2, H, W, device=dev)
+
+
+def timeit(fn, iters):
+    for _ in range(10):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+px = B * H * W
+for rows in [int(r) for r in args.rows.split(",")]:
+    ident = ops.identity_fwd(tgt, srcs, noise, rows)
+    res = {}
+    if "fwd" in args.which.split(","):
+        call, keep = ops.photo_fwd(depth, inv_K, P, tgt, srcs, ident, training=True, rows_per_task=rows, prepared_only=True)
+        res["fwd_train"] = timeit(lambda: ops.photo_fwd_relaunch(call), args.iters)
+    if "fwd_infer" in args.which.split(","):
+        call2, keep2 = ops.photo_fwd(depth, inv_K, P, tgt, srcs, ident, training=False, rows_per_task=rows, prepared_only=True)
+        res["fwd_infer"] = timeit(lambda: ops.photo_fwd_relaunch(call2), args.iters)
+    if "ident" in args.which.split(","):
+        res["identity"] = timeit(lambda: ops.identity_fwd(tgt, srcs, noise, rows), 50)
+    if "bwd" in args.which.split(","):
+        out = ops.photo_fwd(depth, inv_K, P, tgt, srcs, ident, training=True, rows_per_task=rows)
+        res["bwd(+reduce,alloc)"] = timeit(lambda: ops.photo_bwd(depth, inv_K, P, tgt, srcs, out["sample"], out["coef"], out["idx"], 1.0 / px, rows), 50)
+    print("rows_per_task=%d  " % rows + "  ".join("%s %.1f us (%.0f GB/s @93B/px)" % (k, v, 93 * px / v / 1e3) for k, v in res.items()), flush=True)
