@@ -158,6 +158,35 @@ int sqd_sql_bwd(const float *x, const float *K, const float *y, const float *g_y
                 const float *summary, const float *lse, float *g_x, float *g_K, float *gk_part, int B, int Q,
                 int E, int N, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (6) BatchNorm2d fused with activation and residual add, channels-last activations
+ * replaces: nn.BatchNorm2d + nn.ReLU / nn.LeakyReLU (+ the residual add of the ResNet blocks) —
+ *           reference networks/resnet_encoder.py:89-117 (torchvision Bottleneck/BasicBlock, UpSampleBN).
+ * x, res, y: [M = N*H*W, C] row-major (NHWC memory), C % 4 == 0 and C/4 a power of two.
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.01).  part: workspace of sqd_bn_nblk(M,C) * C * 2 floats.
+ * training forward: batch statistics (biased variance for the normalisation, unbiased for the
+ * running estimate, momentum as nn.BatchNorm2d), saves mean / rstd for the backward.               */
+int sqd_bn_nblk(int M, int C);
+int sqd_bn_train_fwd(const float *x, const float *res, const float *gamma, const float *beta, float *running_mean,
+                     float *running_var, float *y, float *save_mean, float *save_rstd, float *part, int M, int C,
+                     float eps, float momentum, int act, void *stream);
+int sqd_bn_eval_fwd(const float *x, const float *res, const float *gamma, const float *beta, const float *running_mean,
+                    const float *running_var, float *y, int M, int C, float eps, int act, void *stream);
+/* dy, x, y -> dx, dres (may be NULL), dgamma [C], dbeta [C]                                          */
+int sqd_bn_train_bwd(const float *dy, const float *x, const float *y, const float *gamma, const float *save_mean,
+                     const float *save_rstd, float *dx, float *dres, float *dgamma, float *dbeta, float *part, int M,
+                     int C, int act, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * (7) bilinear resize (align_corners=True) + channel concat, channels-last activations
+ * replaces: F.interpolate(x, size=skip.shape[2:], bilinear, align_corners=True) + torch.cat([up, skip], 1)
+ *           of UpSampleBN.forward (reference networks/resnet_encoder.py:114-117).
+ * x [N,Hi,Wi,Cx], skip [N,Ho,Wo,Cs] -> out [N,Ho,Wo,Cx+Cs] (NHWC memory; Cx, Cs multiples of 4).      */
+int sqd_upcat_fwd(const float *x, const float *skip, float *out, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs,
+                  void *stream);
+int sqd_upcat_bwd(const float *g_out, float *g_x, float *g_skip, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs,
+                  void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,276 @@
+// bn_act.hip — BatchNorm2d (training and eval) fused with the activation and the residual add, for
+// activations stored channels-last ([N,H,W,C] in memory = a row-major [M = N*H*W, C] matrix).
+//
+// replaces, per conv block of the networks (reference networks/resnet_encoder.py:89-117 through
+// torchvision's Bottleneck/BasicBlock, and UpSampleBN): MIOpenBatchNormFwdTrainSpatial + ReLU/LeakyReLU
+// (+ residual add) forward, MIOpenBatchNormBwdSpatial + threshold_backward (+ add) backward.
+//
+// Forward, training:  stats pass (sum, sum of squares per channel, deterministic two-level reduction)
+//                     -> finalize (mean, rstd, running-stat update: momentum 0.1, unbiased variance)
+//                     -> apply   y = act(gamma * (x - mean) * rstd + beta [+ residual])
+// Backward, training: reduce pass (sum dz, sum dz * xhat with dz = dy * act'(y))
+//                     -> apply   dx = gamma * rstd * (dz - mean(dz) - xhat * mean(dz * xhat)),  dres = dz
+// Roofline: HBM — forward 2 reads + 1 write of x per element (3 with a residual), backward 5 accesses.
+#include "sqd_common.h"
+
+namespace {
+using namespace sqd;
+
+constexpr int ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2;
+constexpr float LEAKY_SLOPE = 0.01f;
+
+__device__ __forceinline__ float act_fwd(float v, int act) {
+    if (act == ACT_RELU) return v > 0.f ? v : 0.f;
+    if (act == ACT_LEAKY) return v > 0.f ? v : v * LEAKY_SLOPE;
+    return v;
+}
+// derivative expressed through the OUTPUT y (what the backward has at hand)
+__device__ __forceinline__ float act_bwd(float y, int act) {
+    if (act == ACT_RELU) return y > 0.f ? 1.f : 0.f;
+    if (act == ACT_LEAKY) return y > 0.f ? 1.f : LEAKY_SLOPE;
+    return 1.f;
+}
+
+struct Geom {
+    int V, TPR, RP, rows_per_block, nblk;
+};
+__host__ __device__ inline Geom geom(int M, int C) {
+    Geom g;
+    g.V = C / 4;
+    g.TPR = g.V < 256 ? g.V : 256;             // threads across one row (each a float4 of channels)
+    g.RP = 256 / g.TPR;                        // rows processed in parallel by a block
+    int rpb = (M + 767) / 768;                 // aim at <= 768 blocks
+    rpb = ((rpb + g.RP - 1) / g.RP) * g.RP;
+    if (rpb < g.RP * 4) rpb = g.RP * 4;
+    g.rows_per_block = rpb;
+    g.nblk = (M + rpb - 1) / rpb;
+    return g;
+}
+
+// per-channel partial sums of two row-wise quantities: MODE 0: (x, x^2);  MODE 1: (dz, dz * xhat)
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy,
+                                                        const float *__restrict__ y, const float *__restrict__ mean,
+                                                        const float *__restrict__ rstd, float *__restrict__ part, int M,
+                                                        int C, int act, Geom g) {
+    const int t = threadIdx.x;
+    const int cg0 = t % g.TPR, rr = t / g.TPR;
+    const int r0 = blockIdx.x * g.rows_per_block, r1 = min(M, r0 + g.rows_per_block);
+    __shared__ float4 sh[2][256];
+    for (int cg = cg0; cg < g.V; cg += g.TPR) {
+        float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+        float4 mu, rs;
+        if (MODE == 1) {
+            mu = *reinterpret_cast<const float4 *>(mean + cg * 4);
+            rs = *reinterpret_cast<const float4 *>(rstd + cg * 4);
+        }
+        for (int row = r0 + rr; row < r1; row += g.RP) {
+            const size_t o = (size_t)row * C + cg * 4;
+            const float4 xv = *reinterpret_cast<const float4 *>(x + o);
+            if (MODE == 0) {
+                a.x += xv.x; a.y += xv.y; a.z += xv.z; a.w += xv.w;
+                b.x = fmaf(xv.x, xv.x, b.x); b.y = fmaf(xv.y, xv.y, b.y); b.z = fmaf(xv.z, xv.z, b.z); b.w = fmaf(xv.w, xv.w, b.w);
+            } else {
+                const float4 gy = *reinterpret_cast<const float4 *>(dy + o);
+                const float4 yv = *reinterpret_cast<const float4 *>(y + o);
+                const float d0 = gy.x * act_bwd(yv.x, act), d1 = gy.y * act_bwd(yv.y, act);
+                const float d2 = gy.z * act_bwd(yv.z, act), d3 = gy.w * act_bwd(yv.w, act);
+                a.x += d0; a.y += d1; a.z += d2; a.w += d3;
+                b.x = fmaf(d0, (xv.x - mu.x) * rs.x, b.x); b.y = fmaf(d1, (xv.y - mu.y) * rs.y, b.y);
+                b.z = fmaf(d2, (xv.z - mu.z) * rs.z, b.z); b.w = fmaf(d3, (xv.w - mu.w) * rs.w, b.w);
+            }
+        }
+        sh[0][t] = a;
+        sh[1][t] = b;
+        __syncthreads();
+        if (rr == 0) {
+            for (int k = 1; k < g.RP; ++k) {
+                const float4 a2 = sh[0][k * g.TPR + cg0], b2 = sh[1][k * g.TPR + cg0];
+                a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+                b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+            }
+            float *o = part + ((size_t)blockIdx.x * C + cg * 4) * 2;
+            o[0] = a.x; o[1] = b.x; o[2] = a.y; o[3] = b.y; o[4] = a.z; o[5] = b.z; o[6] = a.w; o[7] = b.w;
+        }
+        __syncthreads();
+    }
+}
+
+// Sum the per-block partials of FIN_CH channels with a whole 256-thread block: 16 partial-lanes per
+// channel, then a fixed-order LDS tree (deterministic).  A one-thread-per-channel loop over up to 768
+// partials cost 131 us per call and dominated the step (profiles/r01b_*).
+constexpr int FIN_CH = 16, FIN_LANES = 256 / FIN_CH;
+__device__ __forceinline__ bool finalize_sums(const float *__restrict__ part, int nblk, int C, int &c, float &s, float &ss) {
+    __shared__ float sh[2][FIN_LANES][FIN_CH];
+    const int cl = threadIdx.x % FIN_CH, kl = threadIdx.x / FIN_CH;
+    c = blockIdx.x * FIN_CH + cl;
+    float a = 0.f, b = 0.f;
+    if (c < C)
+        for (int k = kl; k < nblk; k += FIN_LANES) {
+            const float2 v = *reinterpret_cast<const float2 *>(part + ((size_t)k * C + c) * 2);
+            a += v.x;
+            b += v.y;
+        }
+    sh[0][kl][cl] = a;
+    sh[1][kl][cl] = b;
+    __syncthreads();
+    if (kl != 0 || c >= C) return false;
+    s = 0.f;
+    ss = 0.f;
+#pragma unroll
+    for (int k = 0; k < FIN_LANES; ++k) {
+        s += sh[0][k][cl];
+        ss += sh[1][k][cl];
+    }
+    return true;
+}
+
+// forward finalize: mean / rstd from the partials + running statistics (nn.BatchNorm2d semantics)
+__global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float *__restrict__ part, int nblk, int M, int C,
+                                                              float eps, float momentum, float *__restrict__ mean,
+                                                              float *__restrict__ rstd, float *__restrict__ rmean,
+                                                              float *__restrict__ rvar) {
+    int c;
+    float s, ss;
+    if (!finalize_sums(part, nblk, C, c, s, ss)) return;
+    const float m = s / (float)M;
+    float var = ss / (float)M - m * m;                    // biased (normalisation) variance
+    var = var < 0.f ? 0.f : var;
+    mean[c] = m;
+    rstd[c] = rsqrtf(var + eps);
+    if (rmean) {
+        const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+    }
+}
+
+// backward finalize: dgamma, dbeta (and the two means the apply pass needs, stored in `red`)
+__global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float *__restrict__ part, int nblk, int M, int C,
+                                                              float *__restrict__ dgamma, float *__restrict__ dbeta) {
+    int c;
+    float s, ss;
+    if (!finalize_sums(part, nblk, C, c, s, ss)) return;
+    dbeta[c] = s;
+    dgamma[c] = ss;
+}
+
+// EVAL: mean/rstd arguments hold running_mean / running_var (rstd computed on the fly)
+template <bool EVAL>
+__global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float *__restrict__ x, const float *__restrict__ res,
+                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                           const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                           float *__restrict__ y, size_t total4, int C, float eps, int act) {
+    const int V = C / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int cg = (int)(i % V);
+        const float4 xv = reinterpret_cast<const float4 *>(x)[i];
+        const float4 ga = reinterpret_cast<const float4 *>(gamma)[cg], be = reinterpret_cast<const float4 *>(beta)[cg];
+        const float4 mu = reinterpret_cast<const float4 *>(mean)[cg];
+        float4 rs = reinterpret_cast<const float4 *>(rstd)[cg];
+        if (EVAL) rs = make_float4(rsqrtf(rs.x + eps), rsqrtf(rs.y + eps), rsqrtf(rs.z + eps), rsqrtf(rs.w + eps));
+        float4 o;
+        o.x = fmaf((xv.x - mu.x) * rs.x, ga.x, be.x);
+        o.y = fmaf((xv.y - mu.y) * rs.y, ga.y, be.y);
+        o.z = fmaf((xv.z - mu.z) * rs.z, ga.z, be.z);
+        o.w = fmaf((xv.w - mu.w) * rs.w, ga.w, be.w);
+        if (res) {
+            const float4 rv = reinterpret_cast<const float4 *>(res)[i];
+            o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+        }
+        o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
+        reinterpret_cast<float4 *>(y)[i] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                           const float *__restrict__ y, const float *__restrict__ gamma,
+                                                           const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                           const float *__restrict__ dgamma, const float *__restrict__ dbeta,
+                                                           float *__restrict__ dx, float *__restrict__ dres, size_t total4,
+                                                           int C, float invM, int act) {
+    const int V = C / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int cg = (int)(i % V);
+        const float4 gy = reinterpret_cast<const float4 *>(dy)[i];
+        const float4 xv = reinterpret_cast<const float4 *>(x)[i];
+        const float4 yv = reinterpret_cast<const float4 *>(y)[i];
+        const float4 ga = reinterpret_cast<const float4 *>(gamma)[cg], mu = reinterpret_cast<const float4 *>(mean)[cg];
+        const float4 rs = reinterpret_cast<const float4 *>(rstd)[cg];
+        const float4 dg = reinterpret_cast<const float4 *>(dgamma)[cg], db = reinterpret_cast<const float4 *>(dbeta)[cg];
+        float4 dz, o;
+        dz.x = gy.x * act_bwd(yv.x, act); dz.y = gy.y * act_bwd(yv.y, act);
+        dz.z = gy.z * act_bwd(yv.z, act); dz.w = gy.w * act_bwd(yv.w, act);
+        o.x = ga.x * rs.x * (dz.x - db.x * invM - (xv.x - mu.x) * rs.x * (dg.x * invM));
+        o.y = ga.y * rs.y * (dz.y - db.y * invM - (xv.y - mu.y) * rs.y * (dg.y * invM));
+        o.z = ga.z * rs.z * (dz.z - db.z * invM - (xv.z - mu.z) * rs.z * (dg.z * invM));
+        o.w = ga.w * rs.w * (dz.w - db.w * invM - (xv.w - mu.w) * rs.w * (dg.w * invM));
+        reinterpret_cast<float4 *>(dx)[i] = o;
+        if (dres) reinterpret_cast<float4 *>(dres)[i] = dz;
+    }
+}
+
+int check(const char *who, int M, int C) {
+    SQD_CHECK_ARG(M > 0 && C >= 4 && C % 4 == 0, "%s: need C %% 4 == 0 (C=%d, M=%d)", who, C, M);
+    const int V = C / 4;
+    SQD_CHECK_ARG((V <= 256 && 256 % V == 0) || V % 256 == 0, "%s: C/4 = %d must divide 256 or be a multiple of it", who, V);
+    return SQD_OK;
+}
+int ew_grid(size_t total4) {
+    size_t b = (total4 + 255) / 256;
+    return (int)(b > 4096 ? 4096 : b);
+}
+}  // namespace
+
+extern "C" int sqd_bn_nblk(int M, int C) {
+    if (C < 4 || C % 4) return -1;
+    return geom(M, C).nblk;
+}
+
+extern "C" int sqd_bn_train_fwd(const float *x, const float *res, const float *gamma, const float *beta, float *running_mean,
+                                float *running_var, float *y, float *save_mean, float *save_rstd, float *part, int M, int C,
+                                float eps, float momentum, int act, void *stream) {
+    SQD_CHECK_ARG(x && gamma && beta && y && save_mean && save_rstd && part, "sqd_bn_train_fwd: null pointer");
+    if (check("sqd_bn_train_fwd", M, C)) return SQD_EINVAL;
+    const Geom g = geom(M, C);
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(g.nblk), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, part, M, C, act, g);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, part, g.nblk, M, C, eps, momentum,
+                       save_mean, save_rstd, running_mean, running_var);
+    const size_t total4 = (size_t)M * C / 4;
+    hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), dim3(ew_grid(total4)), dim3(256), 0, s, x, res, gamma, beta, save_mean,
+                       save_rstd, y, total4, C, eps, act);
+    SQD_CHECK_LAUNCH("sqd_bn_train_fwd");
+    return SQD_OK;
+}
+
+extern "C" int sqd_bn_eval_fwd(const float *x, const float *res, const float *gamma, const float *beta,
+                               const float *running_mean, const float *running_var, float *y, int M, int C, float eps, int act,
+                               void *stream) {
+    SQD_CHECK_ARG(x && gamma && beta && running_mean && running_var && y, "sqd_bn_eval_fwd: null pointer");
+    if (check("sqd_bn_eval_fwd", M, C)) return SQD_EINVAL;
+    const size_t total4 = (size_t)M * C / 4;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,
+                       beta, running_mean, running_var, y, total4, C, eps, act);
+    SQD_CHECK_LAUNCH("sqd_bn_eval_fwd");
+    return SQD_OK;
+}
+
+extern "C" int sqd_bn_train_bwd(const float *dy, const float *x, const float *y, const float *gamma, const float *save_mean,
+                                const float *save_rstd, float *dx, float *dres, float *dgamma, float *dbeta, float *part,
+                                int M, int C, int act, void *stream) {
+    SQD_CHECK_ARG(dy && x && y && gamma && save_mean && save_rstd && dx && dgamma && dbeta && part, "sqd_bn_train_bwd: null pointer");
+    if (check("sqd_bn_train_bwd", M, C)) return SQD_EINVAL;
+    const Geom g = geom(M, C);
+    hipStream_t s = (hipStream_t)stream;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nblk), dim3(256), 0, s, x, dy, y, save_mean, save_rstd, part, M, C, act, g);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, part, g.nblk, M, C, dgamma, dbeta);
+    const size_t total4 = (size_t)M * C / 4;
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, s, dy, x, y, gamma, save_mean, save_rstd, dgamma,
+                       dbeta, dx, dres, total4, C, 1.0f / (float)M, act);
+    SQD_CHECK_LAUNCH("sqd_bn_train_bwd");
+    return SQD_OK;
+}

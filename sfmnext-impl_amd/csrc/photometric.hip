@@ -497,8 +497,17 @@ __global__ __launch_bounds__(64) void gP_reduce_kernel(const float *__restrict__
     }
 }
 
+// development switch: SQD_PHOTO_IMPL=scalar selects the first (unpacked) forward kernel for A/B runs
+bool use_scalar_impl() {
+    static const bool v = [] {
+        const char *e = getenv("SQD_PHOTO_IMPL");
+        return e && e[0] == 's';
+    }();
+    return v;
+}
+
 int pick_th(int th, int H) {
-    if (th <= 0) th = H >= 128 ? 16 : 12;
+    if (th <= 0) th = 8;   // measured at config B: TH=8 94.8 us, 12 99 us, 16 103 us, 24 132 us (more waves beats less halo)
     return th;
 }
 
@@ -529,8 +538,11 @@ extern "C" int sqd_photo_fwd(const sqd_photo_args *a) {
     const int nsx = (a->W + SQD_STRIP_COLS - 1) / SQD_STRIP_COLS, nsy = (a->H + TH - 1) / TH;
     const int ntasks = a->B * nsx * nsy;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((photo_fwd_kernel<2, 1>), dim3((ntasks + 3) / 4), dim3(256), 0, (hipStream_t)a->stream, *a, nullptr,
-                       TH, nsx, nsy, ntasks);
+    if (use_scalar_impl())
+        hipLaunchKernelGGL((photo_fwd_kernel<2, 1>), dim3((ntasks + 3) / 4), dim3(256), 0, (hipStream_t)a->stream, *a,
+                           nullptr, TH, nsx, nsy, ntasks);
+    else
+        sqd::launch_photo_fwd_pk(*a, nullptr, 1, TH, nsx, nsy, ntasks, (hipStream_t)a->stream);
     SQD_CHECK_LAUNCH("sqd_photo_fwd");
     return SQD_OK;
 }
@@ -551,8 +563,11 @@ extern "C" int sqd_identity_fwd(const float *target, const float *const *sources
     const int nsx = (W + SQD_STRIP_COLS - 1) / SQD_STRIP_COLS, nsy = (H + TH - 1) / TH;
     const int ntasks = B * nsx * nsy;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((photo_fwd_kernel<2, 0>), dim3((ntasks + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, noise, TH,
-                       nsx, nsy, ntasks);
+    if (use_scalar_impl())
+        hipLaunchKernelGGL((photo_fwd_kernel<2, 0>), dim3((ntasks + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, noise,
+                           TH, nsx, nsy, ntasks);
+    else
+        sqd::launch_photo_fwd_pk(a, noise, 0, TH, nsx, nsy, ntasks, (hipStream_t)stream);
     SQD_CHECK_LAUNCH("sqd_identity_fwd");
     return SQD_OK;
 }

@@ -13,6 +13,10 @@ namespace sqd {
 
 void set_error(const char *fmt, ...);
 
+// photo_fwd_pk.hip: packed-math fused warp+SSIM forward (mode 1) / identity maps (mode 0)
+void launch_photo_fwd_pk(const sqd_photo_args &a, const float *noise, int mode, int TH, int nsx, int nsy, int ntasks,
+                         hipStream_t stream);
+
 #define SQD_CHECK_ARG(cond, ...)            \
     do {                                    \
         if (!(cond)) {                      \

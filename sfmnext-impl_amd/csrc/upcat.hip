@@ -1,0 +1,127 @@
+// upcat.hip — bilinear resize (align_corners=True) of x to the skip tensor's size, fused with the channel
+// concat [up(x), skip], channels-last activations; and its adjoint.
+// replaces: F.interpolate(x, size=skip.shape[2:], mode='bilinear', align_corners=True) + torch.cat
+//           in UpSampleBN.forward (reference networks/resnet_encoder.py:114-117).
+// Roofline: HBM — forward writes (Cx+Cs)*4 B and reads ~Cx*4/s^2 + Cs*4 B per output pixel; ATen's
+// upsample_bilinear2d took 417 us per call on this shape class, i.e. ~5 % of the whole train step.
+#include "sqd_common.h"
+
+namespace {
+using namespace sqd;
+
+struct Tap {
+    int i0, i1;
+    float l0, l1;
+};
+// ATen area_pixel_compute_source_index(align_corners=True): src = dst * (in-1)/(out-1)
+__device__ __forceinline__ Tap tap_ac(int dst, float scale, int in_size) {
+    const float f = scale * (float)dst;
+    Tap t;
+    t.i0 = (int)f;
+    t.i0 = t.i0 > in_size - 1 ? in_size - 1 : t.i0;
+    t.i1 = t.i0 + (t.i0 < in_size - 1 ? 1 : 0);
+    t.l1 = f - (float)t.i0;
+    t.l0 = 1.f - t.l1;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void upcat_fwd_kernel(const float *__restrict__ x, const float *__restrict__ skip,
+                                                        float *__restrict__ out, int N, int Hi, int Wi, int Cx, int Ho, int Wo,
+                                                        int Cs, float sy, float sx) {
+    const int Ct = Cx + Cs, Vt = Ct / 4, Vx = Cx / 4;
+    const size_t total = (size_t)N * Ho * Wo * Vt;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cv = (int)(i % Vt);
+        const size_t pix = i / Vt;
+        if (cv >= Vx) {
+            reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(skip)[pix * (Cs / 4) + (cv - Vx)];
+            continue;
+        }
+        const int xo = (int)(pix % Wo);
+        const size_t t2 = pix / Wo;
+        const int yo = (int)(t2 % Ho), n = (int)(t2 / Ho);
+        const Tap ty = tap_ac(yo, sy, Hi), tx = tap_ac(xo, sx, Wi);
+        const float4 *xb = reinterpret_cast<const float4 *>(x) + (size_t)n * Hi * Wi * Vx + cv;
+        const float4 v00 = xb[((size_t)ty.i0 * Wi + tx.i0) * Vx], v01 = xb[((size_t)ty.i0 * Wi + tx.i1) * Vx];
+        const float4 v10 = xb[((size_t)ty.i1 * Wi + tx.i0) * Vx], v11 = xb[((size_t)ty.i1 * Wi + tx.i1) * Vx];
+        float4 o;
+        o.x = ty.l0 * (tx.l0 * v00.x + tx.l1 * v01.x) + ty.l1 * (tx.l0 * v10.x + tx.l1 * v11.x);
+        o.y = ty.l0 * (tx.l0 * v00.y + tx.l1 * v01.y) + ty.l1 * (tx.l0 * v10.y + tx.l1 * v11.y);
+        o.z = ty.l0 * (tx.l0 * v00.z + tx.l1 * v01.z) + ty.l1 * (tx.l0 * v10.z + tx.l1 * v11.z);
+        o.w = ty.l0 * (tx.l0 * v00.w + tx.l1 * v01.w) + ty.l1 * (tx.l0 * v10.w + tx.l1 * v11.w);
+        reinterpret_cast<float4 *>(out)[i] = o;
+    }
+}
+
+// adjoint: first N*Hi*Wi*Cx/4 work items gather g_x, the remaining N*Ho*Wo*Cs/4 copy g_skip
+__global__ __launch_bounds__(256) void upcat_bwd_kernel(const float *__restrict__ g_out, float *__restrict__ g_x,
+                                                        float *__restrict__ g_skip, int N, int Hi, int Wi, int Cx, int Ho,
+                                                        int Wo, int Cs, float sy, float sx, float isy, float isx) {
+    const int Ct = Cx + Cs, Vt = Ct / 4, Vx = Cx / 4, Vs = Cs / 4;
+    const size_t nx = (size_t)N * Hi * Wi * Vx, ns = (size_t)N * Ho * Wo * Vs;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nx + ns; i += (size_t)gridDim.x * 256) {
+        if (i >= nx) {
+            const size_t k = i - nx;
+            const size_t pix = k / Vs;
+            reinterpret_cast<float4 *>(g_skip)[k] = reinterpret_cast<const float4 *>(g_out)[pix * Vt + Vx + (k % Vs)];
+            continue;
+        }
+        const int cv = (int)(i % Vx);
+        const size_t pix = i / Vx;
+        const int xi = (int)(pix % Wi);
+        const size_t t2 = pix / Wi;
+        const int yi = (int)(t2 % Hi), n = (int)(t2 / Hi);
+        // destination rows / columns whose taps can touch (yi, xi) — conservative, membership re-tested
+        const int ylo = max(0, (int)floorf(((float)yi - 1.f) * isy) - 1), yhi = min(Ho - 1, (int)ceilf(((float)yi + 1.f) * isy) + 1);
+        const int xlo = max(0, (int)floorf(((float)xi - 1.f) * isx) - 1), xhi = min(Wo - 1, (int)ceilf(((float)xi + 1.f) * isx) + 1);
+        const float4 *gb = reinterpret_cast<const float4 *>(g_out) + (size_t)n * Ho * Wo * Vt + cv;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int y = ylo; y <= yhi; ++y) {
+            const Tap ty = tap_ac(y, sy, Hi);
+            const float wy = (ty.i0 == yi ? ty.l0 : 0.f) + (ty.i1 == yi ? ty.l1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int xq = xlo; xq <= xhi; ++xq) {
+                const Tap tx = tap_ac(xq, sx, Wi);
+                const float w = wy * ((tx.i0 == xi ? tx.l0 : 0.f) + (tx.i1 == xi ? tx.l1 : 0.f));
+                if (w == 0.f) continue;
+                const float4 g = gb[((size_t)y * Wo + xq) * Vt];
+                acc.x = fmaf(w, g.x, acc.x); acc.y = fmaf(w, g.y, acc.y); acc.z = fmaf(w, g.z, acc.z); acc.w = fmaf(w, g.w, acc.w);
+            }
+        }
+        reinterpret_cast<float4 *>(g_x)[i] = acc;
+    }
+}
+
+int grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (int)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+}  // namespace
+
+extern "C" int sqd_upcat_fwd(const float *x, const float *skip, float *out, int N, int Hi, int Wi, int Cx, int Ho, int Wo,
+                             int Cs, void *stream) {
+    SQD_CHECK_ARG(x && skip && out, "sqd_upcat_fwd: null pointer");
+    SQD_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cx % 4 == 0 && Cs % 4 == 0 && Cx > 0 && Cs > 0,
+                  "sqd_upcat_fwd: bad shape (channels must be multiples of 4)");
+    const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(upcat_fwd_kernel, dim3(grid_for((size_t)N * Ho * Wo * (Cx + Cs) / 4)), dim3(256), 0, (hipStream_t)stream, x,
+                       skip, out, N, Hi, Wi, Cx, Ho, Wo, Cs, sy, sx);
+    SQD_CHECK_LAUNCH("sqd_upcat_fwd");
+    return SQD_OK;
+}
+
+extern "C" int sqd_upcat_bwd(const float *g_out, float *g_x, float *g_skip, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs,
+                             void *stream) {
+    SQD_CHECK_ARG(g_out && g_x && g_skip, "sqd_upcat_bwd: null pointer");
+    SQD_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cx % 4 == 0 && Cs % 4 == 0 && Cx > 0 && Cs > 0,
+                  "sqd_upcat_bwd: bad shape (channels must be multiples of 4)");
+    const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
+    const float isy = sy > 0.f ? 1.f / sy : (float)Ho, isx = sx > 0.f ? 1.f / sx : (float)Wo;
+    const size_t total = (size_t)N * Hi * Wi * Cx / 4 + (size_t)N * Ho * Wo * Cs / 4;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(upcat_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g_out, g_x, g_skip, N, Hi, Wi,
+                       Cx, Ho, Wo, Cs, sy, sx, isy, isx);
+    SQD_CHECK_LAUNCH("sqd_upcat_bwd");
+    return SQD_OK;
+}

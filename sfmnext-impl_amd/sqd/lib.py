@@ -93,6 +93,12 @@ _SIGNATURES = {
     "sqd_sql_workspace": (_I, [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "sqd_sql_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sqd_sql_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sqd_bn_nblk": (_I, [_I, _I]),
+    "sqd_bn_train_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P]),
+    "sqd_bn_eval_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
+    "sqd_bn_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "sqd_upcat_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sqd_upcat_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sqd_smooth_nblk": (_I, [_I, _I]),
     "sqd_smooth_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "sqd_smooth_bwd": (_I, [_P, _P, _P, _I, _P, _F, _P, ctypes.c_int64, _I, _I, _I, _P]),

@@ -1,0 +1,111 @@
+"""Autograd nodes of the network operators served by libsqd.so (channels-last activations).
+
+Each Function takes/returns tensors whose logical shape is NCHW and whose memory is NHWC
+(torch.channels_last); the kernels see them as row-major [M = N*H*W, C] matrices."""
+import ctypes
+
+import torch
+
+from . import lib as _l
+from .ops import _ptr, _stream
+
+ACT = {None: 0, "relu": 1, "leaky_relu": 2}
+
+
+def _cl(x):
+    """NHWC-contiguous view/copy of a 4-D tensor."""
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def _require(t, what):
+    if not (t.is_cuda and t.dtype == torch.float32):
+        raise RuntimeError("sqd: %s must be an fp32 tensor on the MI355X device (no CPU fallback)" % what)
+
+
+def bn_supported(C):
+    V = C // 4
+    return C % 4 == 0 and V >= 1 and ((V <= 256 and 256 % V == 0) or V % 256 == 0)
+
+
+class BatchNormAct(torch.autograd.Function):
+    """y = act(BatchNorm2d(x) [+ residual]).  Training: batch statistics + running-stat update
+    (in place on the BatchNorm2d buffers); eval: running statistics."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act):
+        _require(x, "BatchNormAct input")
+        x = _cl(x)
+        N, C, H, W = x.shape
+        M = N * H * W
+        res = _cl(residual) if residual is not None else None
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        L = _l.lib()
+        code = ACT[act]
+        if training:
+            nblk = L.sqd_bn_nblk(M, C)
+            part = torch.empty(nblk * C * 2, device=x.device, dtype=torch.float32)
+            mean = torch.empty(C, device=x.device, dtype=torch.float32)
+            rstd = torch.empty(C, device=x.device, dtype=torch.float32)
+            _l.check(L.sqd_bn_train_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                        _ptr(y), _ptr(mean), _ptr(rstd), _ptr(part), M, C, float(eps), float(momentum), code,
+                                        _stream()), "bn_train_fwd")
+            ctx.save_for_backward(x, y, gamma, mean, rstd)
+            ctx.has_res, ctx.code = residual is not None, code
+        else:
+            _l.check(L.sqd_bn_eval_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                       _ptr(y), M, C, float(eps), code, _stream()), "bn_eval_fwd")
+            ctx.save_for_backward()
+        ctx.training = training
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not ctx.training:
+            raise NotImplementedError("sqd: BatchNormAct backward is implemented for training mode only")
+        x, y, gamma, mean, rstd = ctx.saved_tensors
+        dy = _cl(dy)
+        N, C, H, W = x.shape
+        M = N * H * W
+        L = _l.lib()
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        dres = torch.empty_like(x, memory_format=torch.channels_last) if ctx.has_res else None
+        dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
+        dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
+        part = torch.empty(L.sqd_bn_nblk(M, C) * C * 2, device=x.device, dtype=torch.float32)
+        _l.check(L.sqd_bn_train_bwd(_ptr(dy), _ptr(x), _ptr(y), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
+                                    _ptr(dgamma), _ptr(dbeta), _ptr(part), M, C, ctx.code, _stream()), "bn_train_bwd")
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
+
+
+class UpsampleConcat(torch.autograd.Function):
+    """cat([bilinear_resize(x -> skip's H x W, align_corners=True), skip], dim=1), channels-last."""
+
+    @staticmethod
+    def forward(ctx, x, skip):
+        _require(x, "UpsampleConcat input")
+        x, skip = _cl(x), _cl(skip)
+        N, Cx, Hi, Wi = x.shape
+        _, Cs, Ho, Wo = skip.shape
+        out = torch.empty((N, Cx + Cs, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _l.check(_l.lib().sqd_upcat_fwd(_ptr(x), _ptr(skip), _ptr(out), N, Hi, Wi, Cx, Ho, Wo, Cs, _stream()), "upcat_fwd")
+        ctx.dims = (N, Hi, Wi, Cx, Ho, Wo, Cs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        N, Hi, Wi, Cx, Ho, Wo, Cs = ctx.dims
+        g_out = _cl(g_out)
+        g_x = torch.empty((N, Cx, Hi, Wi), device=g_out.device, dtype=torch.float32, memory_format=torch.channels_last)
+        g_skip = torch.empty((N, Cs, Ho, Wo), device=g_out.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _l.check(_l.lib().sqd_upcat_bwd(_ptr(g_out), _ptr(g_x), _ptr(g_skip), N, Hi, Wi, Cx, Ho, Wo, Cs, _stream()), "upcat_bwd")
+        return g_x, g_skip
+
+
+def batch_norm_act(x, bn, act, residual=None):
+    """nn.BatchNorm2d module `bn` (parameters, running buffers, momentum, eps) applied through the fused
+    kernels; keeps nn.BatchNorm2d's bookkeeping (num_batches_tracked)."""
+    training = bn.training or bn.running_mean is None
+    if training and bn.num_batches_tracked is not None:
+        bn.num_batches_tracked.add_(1)
+    return BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, training,
+                              0.1 if bn.momentum is None else bn.momentum, bn.eps, act)

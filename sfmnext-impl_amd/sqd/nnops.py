@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 BACKEND = {
-    "conv2d": "aten", "conv_bn_act": "aten", "maxpool3x3s2": "aten", "upsample_concat": "aten",
+    "conv2d": "aten", "conv_bn_act": "aten conv + hip bn/act/residual", "maxpool3x3s2": "aten", "upsample_concat": "hip",
     "linear": "aten", "transformer_encoder": "aten", "full_query_layer": "hip", "bins_head": "aten",
 }
 
@@ -38,7 +38,14 @@ def conv_bn_act(x, conv, bn, act, residual=None, input_affine=None):
     -> [+ residual] -> activation."""
     if input_affine is not None:
         x = (x - input_affine[0]) / input_affine[1]
-    y = bn(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding))
+    y = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding)
+    if y.is_cuda:
+        from . import nnkernels
+        if not nnkernels.bn_supported(y.shape[1]):
+            raise RuntimeError("sqd: BatchNorm kernel needs C/4 to be a power of two (C=%d)" % y.shape[1])
+        return nnkernels.batch_norm_act(y, bn, act, residual)
+    # host tensors: only the CPU wiring tests come here
+    y = bn(y)
     if residual is not None:
         y = y + residual
     return _act(y, act)
@@ -50,6 +57,11 @@ def maxpool3x3s2(x):
 
 def upsample_concat(x, skip):
     """bilinear resize of x to skip's size (align_corners=True) and channel concat [up(x), skip]."""
+    if x.is_cuda:
+        from . import nnkernels
+        if x.shape[1] % 4 or skip.shape[1] % 4:
+            raise RuntimeError("sqd: upsample+concat kernel needs channel counts that are multiples of 4")
+        return nnkernels.UpsampleConcat.apply(x, skip)
     up = F.interpolate(x, size=[skip.size(2), skip.size(3)], mode="bilinear", align_corners=True)
     return torch.cat([up, skip], dim=1)
 

@@ -1,0 +1,84 @@
+"""GPU parity of the network-operator kernels (BatchNorm+activation+residual, ...) against PyTorch fp32
+reference implementations of the same operators (the oracle's networks are built from exactly these
+torch modules)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _act(y, act):
+    return F.relu(y) if act == "relu" else F.leaky_relu(y, 0.01) if act == "leaky_relu" else y
+
+
+@pytest.mark.parametrize("N,C,H,W,act,with_res", [(2, 64, 12, 20, "relu", False), (3, 256, 6, 10, "relu", True),
+                                                  (2, 16, 24, 40, "leaky_relu", False), (1, 2048, 3, 5, None, True),
+                                                  (2, 32, 17, 9, "leaky_relu", True), (12, 64, 96, 320, "relu", False)])
+def test_batchnorm_act_train_and_eval(N, C, H, W, act, with_res):
+    from sqd import nnkernels
+    torch.manual_seed(C + H)
+    x = (torch.randn(N, C, H, W) * 1.5 + 0.3)
+    res = torch.randn(N, C, H, W) if with_res else None
+    wgt = torch.randn(N, C, H, W)
+    ref_bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        ref_bn.weight.uniform_(0.5, 1.5); ref_bn.bias.uniform_(-0.2, 0.2)
+        ref_bn.running_mean.uniform_(-0.1, 0.1); ref_bn.running_var.uniform_(0.5, 1.5)
+    my_bn = nn.BatchNorm2d(C).cuda()
+    my_bn.load_state_dict(ref_bn.state_dict())
+    # ---- training step
+    xr = x.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if with_res else None
+    y_ref = ref_bn(xr)
+    if with_res:
+        y_ref = y_ref + rr
+    y_ref = _act(y_ref, act)
+    (y_ref * wgt).sum().backward()
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rg = res.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) if with_res else None
+    y = nnkernels.batch_norm_act(xg, my_bn, act, rg)
+    (y * wgt.cuda()).sum().backward()
+
+    def close(a, b, name, rtol=1e-4):
+        a, b = a.detach().cpu().float(), b.detach().float()
+        err, scale = float((a - b).abs().max()), float(b.abs().max())
+        assert err <= rtol * scale + 1e-5, (name, err, scale)
+    close(y, y_ref, "y")
+    close(xg.grad, xr.grad, "dx", 5e-4)
+    close(my_bn.weight.grad, ref_bn.weight.grad, "dgamma", 5e-4)
+    close(my_bn.bias.grad, ref_bn.bias.grad, "dbeta", 5e-4)
+    if with_res:
+        close(rg.grad, rr.grad, "dres")
+    close(my_bn.running_mean, ref_bn.running_mean, "running_mean")
+    close(my_bn.running_var, ref_bn.running_var, "running_var")
+    assert int(my_bn.num_batches_tracked) == int(ref_bn.num_batches_tracked) == 1
+    # ---- eval
+    ref_bn.eval(); my_bn.eval()
+    with torch.no_grad():
+        ye_ref = ref_bn(x)
+        if with_res:
+            ye_ref = ye_ref + res
+        ye_ref = _act(ye_ref, act)
+        ye = nnkernels.batch_norm_act(x.cuda(), my_bn, act, res.cuda() if with_res else None)
+    close(ye, ye_ref, "y_eval")
+
+
+@pytest.mark.parametrize("N,Cx,Hi,Wi,Cs,Ho,Wo", [(2, 32, 8, 22, 64, 12, 40), (2, 128, 12, 40, 512, 24, 80), (1, 16, 5, 7, 8, 10, 14),
+                                                 (3, 8, 6, 20, 4, 6, 20), (2, 4, 1, 1, 4, 3, 5), (2, 32, 48, 160, 64, 96, 320)])
+def test_upsample_concat(N, Cx, Hi, Wi, Cs, Ho, Wo):
+    from sqd import nnkernels
+    torch.manual_seed(Cx + Ho)
+    x, skip = torch.randn(N, Cx, Hi, Wi), torch.randn(N, Cs, Ho, Wo)
+    wgt = torch.randn(N, Cx + Cs, Ho, Wo)
+    xr, sr = x.clone().requires_grad_(True), skip.clone().requires_grad_(True)
+    ref = torch.cat([F.interpolate(xr, size=[Ho, Wo], mode="bilinear", align_corners=True), sr], 1)
+    (ref * wgt).sum().backward()
+    xg, sg = x.cuda().requires_grad_(True), skip.cuda().requires_grad_(True)
+    out = nnkernels.UpsampleConcat.apply(xg, sg)
+    (out * wgt.cuda()).sum().backward()
+    for a, b, n in ((out, ref, "out"), (xg.grad, xr.grad, "g_x"), (sg.grad, sr.grad, "g_skip")):
+        a, b = a.detach().cpu(), b.detach()
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-5, n
