@@ -187,6 +187,19 @@ int sqd_upcat_fwd(const float *x, const float *skip, float *out, int N, int Hi, 
 int sqd_upcat_bwd(const float *g_out, float *g_x, float *g_skip, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs,
                   void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (8) stand-alone forward kernels behind the reference's layer classes (not used by the training path,
+ * which runs them fused in sqd_photo_fwd):
+ *   BackprojectDepth.forward (layers.py:210-215): depth [B,1,H,W], inv_K [B,4,4] -> cam_points [B,4,HW]
+ *   Project3D.forward (layers.py:247-258): points [B,4,HW], K, T [B,4,4] -> grid [B,H,W,2]
+ *   SSIM.forward (layers.py:31-46): x, y [planes,H,W] -> clamp((1-SSIM)/2,0,1) [planes,H,W]
+ * sqd_smooth_fwd with part == NULL serves get_smooth_loss (layers.py:267-280) on an already
+ * normalised disparity.                                                                              */
+int sqd_backproject_fwd(const float *depth, const float *inv_K, float *cam_points, int B, int H, int W, void *stream);
+int sqd_project3d_fwd(const float *points, const float *K, const float *T, float *grid, int B, int H, int W, float eps,
+                      void *stream);
+int sqd_ssim_fwd(const float *x, const float *y, float *out, int planes, int H, int W, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

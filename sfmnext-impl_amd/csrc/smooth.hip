@@ -30,9 +30,9 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(const float *__restrict
     const int b = blockIdx.y, blk = blockIdx.x;
     const size_t HW = (size_t)H * W;
     __shared__ float s_m;
-    if (threadIdx.x == 0) s_m = image_mean(part, b, nblk, (int)HW);
+    if (threadIdx.x == 0) s_m = part ? image_mean(part, b, nblk, (int)HW) : 0.f;
     __syncthreads();
-    const float im = 1.f / (s_m + 1e-7f);
+    const float im = part ? 1.f / (s_m + 1e-7f) : 1.f;     // part == NULL: caller already normalised (get_smooth_loss)
     const float *d = depth + (size_t)b * HW, *col = color + (size_t)b * 3 * HW;
     float sx = 0.f, sy = 0.f;
     const int q0 = blk * SM_PX_PER_BLOCK + threadIdx.x * 4;
@@ -108,8 +108,8 @@ extern "C" int sqd_smooth_nblk(int H, int W) { return (H * W + SM_PX_PER_BLOCK -
 
 extern "C" int sqd_smooth_fwd(const float *depth, const float *color, const float *part, int nblk, float *sm_part, int B,
                               int H, int W, void *stream) {
-    SQD_CHECK_ARG(depth && color && part && sm_part, "sqd_smooth_fwd: null pointer");
-    SQD_CHECK_ARG(B > 0 && H > 1 && W > 1 && nblk > 0, "sqd_smooth_fwd: bad shape");
+    SQD_CHECK_ARG(depth && color && sm_part, "sqd_smooth_fwd: null pointer");
+    SQD_CHECK_ARG(B > 0 && H > 1 && W > 1 && (!part || nblk > 0), "sqd_smooth_fwd: bad shape");
     const int nb = sqd_smooth_nblk(H, W);
     (void)hipGetLastError();   // drop any stale error left by other HIP users of this thread
     hipLaunchKernelGGL(smooth_fwd_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, depth, color, part, nblk, sm_part,

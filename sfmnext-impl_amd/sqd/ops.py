@@ -186,6 +186,46 @@ def smooth_bwd(depth, color, part, sm_part, gout, planes=None, plane=0):
     return planes
 
 
+# ---- stand-alone forward entries behind the reference's layer classes (no autograd) ------------------
+def backproject(depth, inv_K):
+    depth, inv_K = depth.detach().contiguous().float(), inv_K.detach().contiguous().float()
+    _req(depth, inv_K)
+    B, _, H, W = depth.shape
+    pts = torch.empty(B, 4, H * W, device=depth.device, dtype=torch.float32)
+    _l.check(_l.lib().sqd_backproject_fwd(_ptr(depth), _ptr(inv_K), _ptr(pts), B, H, W, _stream()), "backproject_fwd")
+    return pts
+
+
+def project3d(points, K, T, H, W, eps=1e-7):
+    points, K, T = (t.detach().contiguous().float() for t in (points, K, T))
+    _req(points, K, T)
+    B = points.shape[0]
+    grid = torch.empty(B, H, W, 2, device=points.device, dtype=torch.float32)
+    _l.check(_l.lib().sqd_project3d_fwd(_ptr(points), _ptr(K), _ptr(T), _ptr(grid), B, H, W, float(eps), _stream()),
+             "project3d_fwd")
+    return grid
+
+
+def ssim_map(x, y):
+    x, y = x.detach().contiguous().float(), y.detach().contiguous().float()
+    _req(x, y)
+    B, C, H, W = x.shape
+    out = torch.empty_like(x)
+    _l.check(_l.lib().sqd_ssim_fwd(_ptr(x), _ptr(y), _ptr(out), B * C, H, W, _stream()), "ssim_fwd")
+    return out
+
+
+def smooth_loss_plain(disp, img):
+    disp, img = disp.detach().contiguous().float(), img.detach().contiguous().float()
+    _req(disp, img)
+    B, _, H, W = disp.shape
+    L = _l.lib()
+    nb = L.sqd_smooth_nblk(H, W)
+    sm = torch.empty(B, nb, 2, device=disp.device, dtype=torch.float32)
+    _l.check(L.sqd_smooth_fwd(_ptr(disp), _ptr(img), ctypes.c_void_p(0), 0, _ptr(sm), B, H, W, _stream()), "smooth_fwd")
+    return sm[..., 0].sum() / float(B * H * (W - 1)) + sm[..., 1].sum() / float(B * (H - 1) * W)
+
+
 # ---------------------------------------------------------------------------------------------------
 class PhotometricChain(torch.autograd.Function):
     """generate_images_pred + compute_losses of the reference (trainer.py:386-549) as one autograd node.
