@@ -200,6 +200,16 @@ int sqd_project3d_fwd(const float *points, const float *K, const float *T, float
                       void *stream);
 int sqd_ssim_fwd(const float *x, const float *y, float *out, int planes, int H, int W, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (9) multi-tensor Adam step (one launch per parameter group)
+ * replaces: torch.optim.Adam.step() of reference trainer.py:128-135,244 (default betas/eps, no weight
+ *           decay, no amsgrad).  recs: device array of {float* p, float* exp_avg, float* exp_avg_sq,
+ *           int64 n}; grads: device array of const float*; chunks: device array of int32 pairs
+ *           (tensor index, chunk index), chunk = sqd_adam_chunk_elems() elements; step >= 1.         */
+int sqd_adam_chunk_elems(void);
+int sqd_adam_step(const void *recs, const void *grads, const void *chunks, int nchunks, double lr, double beta1,
+                  double beta2, double eps, int step, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

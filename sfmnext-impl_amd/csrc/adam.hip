@@ -1,0 +1,77 @@
+// adam.hip — one-launch multi-tensor Adam step (reference trainer.py:128-135,244: torch.optim.Adam,
+// default betas/eps, no weight decay, no amsgrad).
+// replaces: the ~30 multi_tensor_apply / foreach launches of torch.optim.Adam.step() per optimiser step.
+// Roofline: HBM — 16 B read + 12 B written per parameter (p, g, m, v -> p, m, v); 33 M parameters at
+// config B = 0.92 GB per step.
+#include "sqd_common.h"
+
+namespace {
+using namespace sqd;
+constexpr int CHUNK = 4096;          // elements per block: 256 threads x 4 float4
+
+struct TensorRec {                   // one parameter tensor (device table, rebuilt only when shapes change)
+    float *p;
+    float *m;
+    float *v;
+    long long n;
+};
+
+__global__ __launch_bounds__(256) void adam_kernel(const TensorRec *__restrict__ recs, const float *const *__restrict__ grads,
+                                                   const int2 *__restrict__ chunks, float step_size, float omb1, float beta2,
+                                                   float omb2, float eps, float inv_bc2_sqrt) {
+    const int2 ch = chunks[blockIdx.x];              // (tensor index, chunk index inside the tensor)
+    const TensorRec r = recs[ch.x];
+    const float *__restrict__ g = grads[ch.x];
+    const long long base = (long long)ch.y * CHUNK;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long i = base + ((long long)k * 256 + threadIdx.x) * 4;
+        if (i >= r.n) break;
+        if (i + 3 < r.n && ((((size_t)r.p | (size_t)g | (size_t)r.m | (size_t)r.v) & 15) == 0)) {
+            float4 pv = *reinterpret_cast<float4 *>(r.p + i), mv = *reinterpret_cast<float4 *>(r.m + i);
+            float4 vv = *reinterpret_cast<float4 *>(r.v + i);
+            const float4 gv = *reinterpret_cast<const float4 *>(g + i);
+            float *pp = &pv.x, *mm = &mv.x, *vq = &vv.x;
+            const float *gg = &gv.x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                mm[e] = fmaf(gg[e] - mm[e], omb1, mm[e]);                     // exp_avg.lerp_(grad, 1 - beta1)
+                vq[e] = fmaf(omb2 * gg[e], gg[e], vq[e] * beta2);             // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
+                const float denom = sqrtf(vq[e]) * inv_bc2_sqrt + eps;
+                pp[e] -= step_size * (mm[e] / denom);                         // param.addcdiv_(exp_avg, denom, -step_size)
+            }
+            *reinterpret_cast<float4 *>(r.p + i) = pv;
+            *reinterpret_cast<float4 *>(r.m + i) = mv;
+            *reinterpret_cast<float4 *>(r.v + i) = vv;
+        } else {
+            for (long long e = i; e < i + 4 && e < r.n; ++e) {
+                const float ge = g[e];
+                float me = r.m[e], ve = r.v[e];
+                me = fmaf(ge - me, omb1, me);
+                ve = fmaf(omb2 * ge, ge, ve * beta2);
+                r.m[e] = me;
+                r.v[e] = ve;
+                r.p[e] -= step_size * (me / (sqrtf(ve) * inv_bc2_sqrt + eps));
+            }
+        }
+    }
+}
+}  // namespace
+
+extern "C" int sqd_adam_chunk_elems(void) { return CHUNK; }
+
+// recs [ntensors] of {p, m, v, n} (device), grads [ntensors] device pointers (device array), chunks [nchunks] int2 (device)
+extern "C" int sqd_adam_step(const void *recs, const void *grads, const void *chunks, int nchunks, double lr, double beta1,
+                             double beta2, double eps, int step, void *stream) {
+    SQD_CHECK_ARG(recs && grads && chunks && nchunks > 0 && step >= 1, "sqd_adam_step: bad arguments");
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    const float step_size = (float)(lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+    // hyper-parameters arrive as doubles: torch.optim does this scalar arithmetic in Python floats
+    // (1.f - 0.999f would be 1.3e-5 off the 1 - beta2 it uses)
+    const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const TensorRec *)recs,
+                       (const float *const *)grads, (const int2 *)chunks, step_size, omb1, (float)beta2, omb2, (float)eps, inv_bc2_sqrt);
+    SQD_CHECK_LAUNCH("sqd_adam_step");
+    return SQD_OK;
+}

@@ -1,0 +1,78 @@
+"""FusedAdam — torch.optim.Adam whose step() is ONE libsqd kernel launch per parameter group.
+
+Keeps torch.optim.Adam's state layout (state[p] = {"step", "exp_avg", "exp_avg_sq"}, param_groups),
+so `optimizer.state_dict()` / `load_state_dict()` and the reference's adam.pth checkpoints
+(trainer.py:659-660, 682-687) stay interchangeable, and StepLR keeps working through param_groups."""
+import ctypes
+
+import torch
+
+from . import lib as _l
+from .ops import _stream
+
+
+class FusedAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
+        if weight_decay != 0 or amsgrad:
+            raise NotImplementedError("FusedAdam implements the reference's configuration: no weight decay, no amsgrad")
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
+        self._tables = {}
+        self._ring = 0
+
+    def _build(self, gi, plist):
+        L = _l.lib()
+        chunk = L.sqd_adam_chunk_elems()
+        dev = plist[0].device
+        recs, chunks = [], []
+        for ti, p in enumerate(plist):
+            st = self.state[p]
+            if len(st) == 0:
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            n = p.numel()
+            recs.append([p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n])
+            chunks += [[ti, c] for c in range((n + chunk - 1) // chunk)]
+        tab = {"params": plist, "keys": [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr()) for p in plist],
+               "recs": torch.tensor(recs, dtype=torch.int64).to(dev), "chunks": torch.tensor(chunks, dtype=torch.int32).to(dev),
+               "nchunks": len(chunks), "gdev": torch.empty(len(plist), dtype=torch.int64, device=dev),
+               "ghost": [torch.empty(len(plist), dtype=torch.int64).pin_memory() for _ in range(4)]}
+        self._tables[gi] = tab
+        return tab
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        L = _l.lib()
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None]
+            if not plist:
+                continue
+            for p in plist:
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous(memory_format=torch.contiguous_format)
+                        or p.is_contiguous(memory_format=torch.channels_last)):
+                    raise RuntimeError("FusedAdam: parameters must be dense fp32 device tensors")
+            tab = self._tables.get(gi)
+            keys = [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr() if len(self.state[p]) else 0) for p in plist]
+            if tab is None or tab["keys"] != keys:
+                tab = self._build(gi, plist)
+            # gradient tensors are re-allocated by every backward: refresh their addresses (one 8*n byte async copy)
+            host = tab["ghost"][self._ring % 4]
+            self._ring += 1
+            for i, p in enumerate(plist):
+                g = p.grad
+                if g.stride() != p.stride():
+                    g = p.grad = g.contiguous(memory_format=torch.channels_last if p.dim() == 4 and
+                                              p.is_contiguous(memory_format=torch.channels_last) and
+                                              not p.is_contiguous() else torch.contiguous_format)
+                host[i] = g.data_ptr()
+            tab["gdev"].copy_(host, non_blocking=True)
+            st0 = self.state[plist[0]]["step"]
+            step = int(st0.item()) + 1
+            for p in plist:
+                self.state[p]["step"] += 1
+            b1, b2 = group["betas"]
+            _l.check(L.sqd_adam_step(ctypes.c_void_p(tab["recs"].data_ptr()), ctypes.c_void_p(tab["gdev"].data_ptr()),
+                                     ctypes.c_void_p(tab["chunks"].data_ptr()), tab["nchunks"], float(group["lr"]), float(b1),
+                                     float(b2), float(group["eps"]), step, _stream()), "adam_step")
+        return loss

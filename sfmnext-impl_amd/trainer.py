@@ -30,6 +30,7 @@ import datasets
 import networks
 from layers import compute_depth_errors, transformation_from_parameters
 from sqd import ddp, ops
+from sqd.optim import FusedAdam
 from utils import normalize_image, sec_to_hm_str
 
 
@@ -88,10 +89,10 @@ class Trainer:
             self.pose_params = list(self.models["pose"].parameters())
             groups = [{"params": self.pose_params, "lr": self.opt.learning_rate / 10},
                       {"params": self.parameters_to_train, "lr": self.opt.learning_rate}]
-            self.model_optimizer = optim.Adam(groups, lr=self.opt.learning_rate)
+            self.model_optimizer = FusedAdam(groups, lr=self.opt.learning_rate)
         else:
             self.parameters_to_train += list(self.models["pose"].parameters())
-            self.model_optimizer = optim.Adam(self.parameters_to_train, self.opt.learning_rate)
+            self.model_optimizer = FusedAdam(self.parameters_to_train, self.opt.learning_rate)
         self.model_lr_scheduler = optim.lr_scheduler.StepLR(self.model_optimizer, self.opt.scheduler_step_size, 0.1)
 
         all_params = [p for m in self.models.values() for p in m.parameters()]

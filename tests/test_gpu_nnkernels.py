@@ -82,3 +82,32 @@ def test_upsample_concat(N, Cx, Hi, Wi, Cs, Ho, Wo):
     for a, b, n in ((out, ref, "out"), (xg.grad, xr.grad, "g_x"), (sg.grad, sr.grad, "g_skip")):
         a, b = a.detach().cpu(), b.detach()
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-5, n
+
+
+def test_fused_adam_matches_torch_adam():
+    from sqd.optim import FusedAdam
+    torch.manual_seed(3)
+    shapes = [(64, 3, 7, 7), (5,), (1000, 33), (4096,), (4097,), (2, 3), (128, 64, 3, 3)]
+    ref_p = [torch.randn(s).cuda().requires_grad_(True) for s in shapes]
+    my_p = [p.detach().clone().requires_grad_(True) for p in ref_p]
+    ref_p[6].data = ref_p[6].data.contiguous(memory_format=torch.channels_last)
+    my_p[6].data = my_p[6].data.contiguous(memory_format=torch.channels_last)
+    unused_ref, unused_my = torch.randn(7).cuda().requires_grad_(True), torch.randn(7).cuda().requires_grad_(True)
+    ref = torch.optim.Adam(ref_p + [unused_ref], lr=1e-2)
+    mine = FusedAdam(my_p + [unused_my], lr=1e-2)
+    for step in range(4):
+        grads = [torch.randn(s).cuda() * (0.1 + step) for s in shapes]
+        for p, q, g in zip(ref_p, my_p, grads):
+            p.grad = g.clone().contiguous(memory_format=torch.channels_last) if p.dim() == 4 and not p.is_contiguous() else g.clone()
+            q.grad = p.grad.clone()
+        if step == 2:
+            for grp in ref.param_groups + mine.param_groups:
+                grp["lr"] = 1e-3                    # StepLR acts through param_groups
+        ref.step(); mine.step()
+        for p, q in zip(ref_p, my_p):
+            assert float((p - q).abs().max()) <= 2e-6 * float(p.abs().max()) + 1e-7, step
+    sd_ref, sd_my = ref.state_dict(), mine.state_dict()
+    assert sd_ref["param_groups"][0]["params"] == sd_my["param_groups"][0]["params"]
+    assert set(sd_ref["state"][0].keys()) == set(sd_my["state"][0].keys())
+    assert float(sd_my["state"][0]["step"]) == 4.0 and 7 not in sd_my["state"]
+    np.testing.assert_allclose(sd_my["state"][3]["exp_avg_sq"].cpu().numpy(), sd_ref["state"][3]["exp_avg_sq"].cpu().numpy(), rtol=1e-5, atol=1e-9)
