@@ -22,7 +22,8 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("SQD_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ     # 1-rank RCCL smoke runs
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"
         if backend == "nccl":
@@ -35,6 +36,9 @@ class GradBucketReducer:
     def __init__(self, params, bucket_mb=32.0, process_group=None):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # exchange whenever a process group exists (a 1-rank group still exercises the RCCL calls)
+        self.active = dist.is_initialized()
+        self._avg = self.active and dist.get_backend(process_group) == "nccl"    # RCCL averages in the collective
         self.params = [p for p in params if p.requires_grad]
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.buckets = None          # built after the first backward (unused-parameter detection)
@@ -44,7 +48,7 @@ class GradBucketReducer:
     # -- start-up ---------------------------------------------------------------------------------
     def broadcast_parameters(self, modules):
         """Rank 0's parameters and buffers become everyone's (one flat broadcast per dtype)."""
-        if self.world == 1:
+        if not self.active:
             return
         tensors = []
         for m in modules:
@@ -102,14 +106,15 @@ class GradBucketReducer:
     def _on_grad(self, p):
         bi = self._bucket_of[p]
         self._pending[bi] -= 1
-        if self._pending[bi] == 0 and self.world > 1:
-            self._works.append(dist.all_reduce(self.flat[bi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self._pending[bi] == 0 and self.active:
+            op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+            self._works.append(dist.all_reduce(self.flat[bi], op=op, group=self.group, async_op=True))
 
     def finish(self):
         """Call after loss.backward(): waits for the in-flight buckets and turns sums into means."""
         if self.buckets is None:
             # first step: no buckets yet — reduce whatever gradients exist, then build the buckets
-            if self.world > 1:
+            if self.active:
                 grads = [p.grad for p in self.params if p.grad is not None]
                 flat = torch.cat([g.reshape(-1) for g in grads])
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
@@ -124,6 +129,6 @@ class GradBucketReducer:
         for w in self._works:
             w.wait()
         self._works = []
-        if self.world > 1:
+        if self.active and not self._avg:
             for flat in self.flat:
                 flat.div_(self.world)

@@ -96,7 +96,8 @@ class Trainer:
         self.model_lr_scheduler = optim.lr_scheduler.StepLR(self.model_optimizer, self.opt.scheduler_step_size, 0.1)
 
         all_params = [p for m in self.models.values() for p in m.parameters()]
-        self.reducer = ddp.GradBucketReducer(all_params, self.opt.sqd_bucket_mb) if self.world > 1 else None
+        import torch.distributed as _dist
+        self.reducer = ddp.GradBucketReducer(all_params, self.opt.sqd_bucket_mb) if _dist.is_initialized() else None
         if self.reducer is not None:
             self.reducer.broadcast_parameters(self.models.values())
 
