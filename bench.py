@@ -65,7 +65,7 @@ def roofline_fused_fwd(trainer, inputs, iters=200):
     px = B * H * W
     t = res["train"]
     achieved = FUSED_FWD_BYTES_PER_PX * px / t / 1e9
-    return {"bound": "hbm", "kernel": "photo_fwd_kernel<2,1> (fused warp+SSIM+L1+automask fwd, training mode)",
+    return {"bound": "hbm", "kernel": "photo_fwd_pk_kernel<1> (fused warp+SSIM+L1+automask fwd, training mode: also writes the 37 B/px coef+argmin maps)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": None, "us_per_launch": round(t * 1e6, 2), "us_per_launch_inference": round(res["infer"] * 1e6, 2),
             "algorithmic_bytes_per_launch": FUSED_FWD_BYTES_PER_PX * px, "pixels_per_launch": px}
