@@ -210,6 +210,27 @@ int sqd_adam_chunk_elems(void);
 int sqd_adam_step(const void *recs, const void *grads, const void *chunks, int nchunks, double lr, double beta1,
                   double beta2, double eps, int step, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (10) convolution as implicit GEMM on the fp32 matrix cores, channels-last
+ * replaces: nn.Conv2d forward / input gradient / weight+bias gradient of the networks' convolutions
+ *           (reference networks/resnet_encoder.py:103-147, pose_cnn.py:14-29, depth_decoder_QTR.py:11-17
+ *           and the torchvision ResNet trunk).
+ * x [N,H,W,C], w [K,R,S,C] (KRSC = torch channels_last weight memory), y [N,Ho,Wo,K];
+ * Ho = (H + 2*pad - R)/stride + 1.  forward needs C % 16 == 0; dgrad K % 16 == 0 and C % 4 == 0;
+ * wgrad C % 4 == 0 and K % 4 == 0.  act (forward epilogue): 0 none, 1 ReLU.                          */
+int sqd_conv_supported(int C, int K);
+/* ws: split-K workspace of sqd_conv_plan(mode 0 = fwd / 1 = dgrad, ...) floats; NULL when the plan says 0 */
+int sqd_conv_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
+                  int64_t *ws_floats);
+int sqd_conv_fwd(const float *x, const float *w, const float *bias, float *y, float *ws, int N, int H, int W, int C, int K,
+                 int R, int S, int stride, int pad, int Ho, int Wo, int act, void *stream);
+int sqd_conv_dgrad(const float *dy, const float *w, float *dx, float *ws, int N, int H, int W, int C, int K, int R, int S,
+                   int stride, int pad, int Ho, int Wo, void *stream);
+/* workspace of the weight gradient: `part_floats` floats (+ ceil(N*Ho*Wo/1024)*K more when dbias is wanted) */
+int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *splits, int64_t *part_floats);
+int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C, int K,
+                   int R, int S, int stride, int pad, int Ho, int Wo, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

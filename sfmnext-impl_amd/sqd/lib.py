@@ -104,6 +104,12 @@ _SIGNATURES = {
     "sqd_ssim_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "sqd_adam_chunk_elems": (_I, []),
     "sqd_adam_step": (_I, [_P, _P, _P, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P]),
+    "sqd_conv_supported": (_I, [_I, _I]),
+    "sqd_conv_plan": (_I, [_I] * 12 + [ctypes.POINTER(ctypes.c_int64)]),
+    "sqd_conv_fwd": (_I, [_P, _P, _P, _P, _P] + [_I] * 12 + [_P]),
+    "sqd_conv_dgrad": (_I, [_P, _P, _P, _P] + [_I] * 11 + [_P]),
+    "sqd_conv_wgrad_plan": (_I, [_I] * 7 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)]),
+    "sqd_conv_wgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
     "sqd_smooth_nblk": (_I, [_I, _I]),
     "sqd_smooth_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "sqd_smooth_bwd": (_I, [_P, _P, _P, _I, _P, _F, _P, ctypes.c_int64, _I, _I, _I, _P]),

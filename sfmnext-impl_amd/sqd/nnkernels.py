@@ -101,6 +101,70 @@ class UpsampleConcat(torch.autograd.Function):
         return g_x, g_skip
 
 
+def conv_supported(C, K):
+    """Both directions of the native implicit-GEMM convolution (forward + dgrad + wgrad)."""
+    return C % 16 == 0 and K % 16 == 0
+
+
+def _conv_ws(mode, geom, device):
+    n = ctypes.c_int64(0)
+    _l.lib().sqd_conv_plan(mode, *geom, ctypes.byref(n))
+    return torch.empty(n.value, device=device, dtype=torch.float32) if n.value else None
+
+
+class Conv2d(torch.autograd.Function):
+    """nn.Conv2d (square stride / padding, dilation 1, groups 1) on the fp32 matrix cores, channels-last.
+    forward(x [N,C,H,W], weight [K,C,R,S], bias [K] | None, stride, pad, act) -> y [N,K,Ho,Wo]"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, act):
+        _require(x, "Conv2d input")
+        x, w = _cl(x), _cl(weight)
+        N, C, H, W = x.shape
+        K, _, R, S = w.shape
+        Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        y = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        ws = _conv_ws(0, (N, H, W, C, K, R, S, stride, pad, Ho, Wo), x.device)
+        _l.check(_l.lib().sqd_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
+                                       ACT[act], _stream()), "conv_fwd")
+        ctx.save_for_backward(x, w, y if act == "relu" else None)
+        ctx.geom = (N, H, W, C, K, R, S, stride, pad, Ho, Wo)
+        ctx.has_bias, ctx.act = bias is not None, act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        N, H, W, C, K, R, S, stride, pad, Ho, Wo = ctx.geom
+        dy = _cl(dy)
+        if ctx.act == "relu":
+            dy = dy * (y > 0)
+        L = _l.lib()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
+            ws = _conv_ws(1, ctx.geom, dy.device)
+            _l.check(L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), N, H, W, C, K, R, S, stride, pad, Ho, Wo, _stream()),
+                     "conv_dgrad")
+        if ctx.needs_input_grad[1]:
+            splits, pf = ctypes.c_int(0), ctypes.c_int64(0)
+            L.sqd_conv_wgrad_plan(N, Ho, Wo, C, K, R, S, ctypes.byref(splits), ctypes.byref(pf))
+            extra = ((N * Ho * Wo + 1023) // 1024) * K if ctx.has_bias else 0
+            part = torch.empty(pf.value + extra, device=dy.device, dtype=torch.float32)
+            dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
+            db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+            _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
+                                      _stream()), "conv_wgrad")
+        return dx, dw, db, None, None, None
+
+
+def conv2d_native(x, conv, act=None):
+    s, p = conv.stride, conv.padding
+    if s[0] != s[1] or p[0] != p[1] or conv.dilation != (1, 1) or conv.groups != 1:
+        raise RuntimeError("sqd: native conv handles square stride/padding, dilation 1, groups 1")
+    return Conv2d.apply(x, conv.weight, conv.bias, s[0], p[0], act)
+
+
 def batch_norm_act(x, bn, act, residual=None):
     """nn.BatchNorm2d module `bn` (parameters, running buffers, momentum, eps) applied through the fused
     kernels; keeps nn.BatchNorm2d's bookkeeping (num_batches_tracked)."""

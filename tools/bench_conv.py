@@ -1,0 +1,71 @@
+"""Per-layer timing of the native implicit-GEMM convolution vs ATen/MIOpen on the config-B layer shapes
+(N=12, 192x640 input).  usage: python tools/bench_conv.py [--iters 20]"""
+import argparse
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, "sfmnext-impl_amd"))
+import torch  # noqa: E402
+import torch.nn as nn  # noqa: E402
+from sqd import nnkernels  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--N", type=int, default=12)
+args = ap.parse_args()
+N = args.N
+L = [  # name, C, H, W, K, R, stride, pad, count (occurrences per forward)
+    ("l1 1x1 64->64", 64, 48, 160, 64, 1, 1, 0, 1), ("l1 3x3 64->64", 64, 48, 160, 64, 3, 1, 1, 3),
+    ("l1 1x1 64->256", 64, 48, 160, 256, 1, 1, 0, 4), ("l1 1x1 256->64", 256, 48, 160, 64, 1, 1, 0, 2),
+    ("l2 1x1 256->128", 256, 48, 160, 128, 1, 1, 0, 1), ("l2 3x3s2 128", 128, 48, 160, 128, 3, 2, 1, 1),
+    ("l2 3x3 128", 128, 24, 80, 128, 3, 1, 1, 3), ("l2 1x1 128->512", 128, 24, 80, 512, 1, 1, 0, 4),
+    ("l2 1x1 512->128", 512, 24, 80, 128, 1, 1, 0, 3), ("l2 ds 256->512 s2", 256, 48, 160, 512, 1, 2, 0, 1),
+    ("l3 1x1 512->256", 512, 24, 80, 256, 1, 1, 0, 1), ("l3 3x3s2 256", 256, 24, 80, 256, 3, 2, 1, 1),
+    ("l3 3x3 256", 256, 12, 40, 256, 3, 1, 1, 5), ("l3 1x1 256->1024", 256, 12, 40, 1024, 1, 1, 0, 6),
+    ("l3 1x1 1024->256", 1024, 12, 40, 256, 1, 1, 0, 5), ("l3 ds 512->1024 s2", 512, 24, 80, 1024, 1, 2, 0, 1),
+    ("l4 1x1 1024->512", 1024, 12, 40, 512, 1, 1, 0, 1), ("l4 3x3s2 512", 512, 12, 40, 512, 3, 2, 1, 1),
+    ("l4 3x3 512", 512, 6, 20, 512, 3, 1, 1, 2), ("l4 1x1 512->2048", 512, 6, 20, 2048, 1, 1, 0, 3),
+    ("l4 1x1 2048->512", 2048, 6, 20, 512, 1, 1, 0, 2), ("l4 ds 1024->2048 s2", 1024, 12, 40, 2048, 1, 2, 0, 1),
+    ("dec conv2 1x1p1", 2048, 6, 20, 256, 1, 1, 1, 1), ("dec up1a 1280->128", 1280, 12, 40, 128, 3, 1, 1, 1),
+    ("dec up1b 128", 128, 12, 40, 128, 3, 1, 1, 1), ("dec up2a 640->64", 640, 24, 80, 64, 3, 1, 1, 1),
+    ("dec up2b 64", 64, 24, 80, 64, 3, 1, 1, 1), ("dec up3a 320->32", 320, 48, 160, 32, 3, 1, 1, 1),
+    ("dec up3b 32", 32, 48, 160, 32, 3, 1, 1, 1), ("dec up4a 96->16", 96, 96, 320, 16, 3, 1, 1, 1),
+    ("dec up4b 16", 16, 96, 320, 16, 3, 1, 1, 1), ("dec conv3 16->32", 16, 96, 320, 32, 3, 1, 1, 1),
+    ("qtr conv3x3 32", 32, 96, 320, 32, 3, 1, 1, 1), ("qtr patch16 32", 32, 96, 320, 32, 16, 16, 0, 1),
+    ("pose 5x5s2 16->32", 16, 96, 320, 32, 5, 2, 2, 2), ("pose 3x3s2 32->64", 32, 48, 160, 64, 3, 2, 1, 2),
+    ("pose 3x3s2 64->128", 64, 24, 80, 128, 3, 2, 1, 2), ("pose 3x3s2 128->256", 128, 12, 40, 256, 3, 2, 1, 2),
+]
+
+
+def timeit(fn, iters):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
+
+
+tot = {"n_f": 0, "n_b": 0, "a_f": 0, "a_b": 0}
+print("%-22s %9s | %8s %8s %6s | %8s %8s %6s" % ("layer", "GFLOP", "nat fwd", "aten fwd", "TF", "nat bwd", "aten bwd", "TF"))
+for name, C, H, W, K, R, st, pad, cnt in L:
+    conv = nn.Conv2d(C, K, R, st, pad, bias=False).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
+    gflop = 2.0 * N * Ho * Wo * K * C * R * R / 1e9
+    y_n = nnkernels.conv2d_native(x, conv)
+    y_a = conv(x)
+    dy = torch.randn_like(y_a)
+    t_nf = timeit(lambda: nnkernels.conv2d_native(x, conv), args.iters)
+    t_af = timeit(lambda: conv(x), args.iters)
+    t_nb = timeit(lambda: torch.autograd.grad(y_n, (x, conv.weight), dy, retain_graph=True), args.iters)
+    t_ab = timeit(lambda: torch.autograd.grad(y_a, (x, conv.weight), dy, retain_graph=True), args.iters)
+    print("%-22s %9.2f | %8.1f %8.1f %6.1f | %8.1f %8.1f %6.1f" % (name, gflop, t_nf, t_af, gflop / t_nf * 1e3 / 1e3, t_nb, t_ab,
+                                                                 2 * gflop / t_nb * 1e3 / 1e3), flush=True)
+    tot["n_f"] += cnt * t_nf; tot["a_f"] += cnt * t_af; tot["n_b"] += cnt * t_nb; tot["a_b"] += cnt * t_ab
+print("weighted totals per step (us): native fwd %.0f bwd %.0f | aten fwd %.0f bwd %.0f" % (tot["n_f"], tot["n_b"], tot["a_f"], tot["a_b"]))
