@@ -17,6 +17,8 @@
 // match a direct fp32 convolution to accumulation-order rounding.
 // Roofline: fp32 MFMA, 157.3 TFLOP/s dense.
 #include "sqd_common.h"
+#include <cstdlib>
+#include <cstring>
 
 namespace {
 using namespace sqd;
@@ -47,13 +49,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm0 = (wave / WGN) * (WTM * 32), wn0 = (wave % WGN) * (WTN * 32);
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    // problem dims seen by the GEMM
-    const int Mrows = MODE == 0 ? g.N * g.Ho * g.Wo : g.N * g.H * g.W;
+    const int n0 = blockIdx.y * BN;
+    // dgrad runs one dense problem per stride class (ph, pw) = (hi % stride, wi % stride): the input pixels of a
+    // class all see the same taps r = r0 + stride*jr, s = s0 + stride*js, with ho = hi' + base_h - jr, so no
+    // slice is spent on taps that do not divide (stride 1: a single class, all taps)
+    const int Hc = (g.H + g.stride - 1) / g.stride, Wc = (g.W + g.stride - 1) / g.stride;
+    const int Mrows = MODE == 0 ? g.N * g.Ho * g.Wo : g.N * Hc * Wc;      // rows of one GEMM (per class for dgrad)
+    const int tiles_m = (Mrows + BM - 1) / BM;
+    const int cls = MODE == 0 ? 0 : blockIdx.x / tiles_m;
+    const int m0 = (MODE == 0 ? blockIdx.x : blockIdx.x - cls * tiles_m) * BM;
+    const int ph = cls / g.stride, pw = cls - ph * g.stride;
+    const int r0 = (ph + g.pad) % g.stride, s0 = (pw + g.pad) % g.stride;
+    const int Rc = MODE == 0 ? g.R : (r0 < g.R ? (g.R - r0 + g.stride - 1) / g.stride : 0);
+    const int Sc = MODE == 0 ? g.S : (s0 < g.S ? (g.S - s0 + g.stride - 1) / g.stride : 0);
     const int Ncols = MODE == 0 ? g.K : g.C;                    // output channels of this GEMM
     const int Cred = MODE == 0 ? g.C : g.K;                     // channels reduced per (r,s)
     const int cchunks = Cred / BK;
-    const int Tall = g.R * g.S * cchunks;
+    const int Tall = Rc * Sc * cchunks;
     // split-K: workgroup z reduces slices [s_beg, s_end) and writes a partial tile (summed by gemm_reduce_kernel)
     const int s_beg = (int)((long long)Tall * blockIdx.z / zsplits), s_end = (int)((long long)Tall * (blockIdx.z + 1) / zsplits);
     const int T = s_end - s_beg;
@@ -73,29 +85,46 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
             ah[i] = (t2 % g.Ho) * g.stride - g.pad;
             aw[i] = wo * g.stride - g.pad;
         } else {
-            const int wi = mm % g.W, t2 = mm / g.W;
-            an[i] = t2 / g.H;
-            ah[i] = (t2 % g.H) + g.pad;
-            aw[i] = wi + g.pad;
+            const int wq = mm % Wc, t2 = mm / Wc, hq = t2 % Hc;
+            an[i] = t2 / Hc;
+            aval[i] = aval[i] && hq * g.stride + ph < g.H && wq * g.stride + pw < g.W;
+            ah[i] = hq + (ph + g.pad - r0) / g.stride;
+            aw[i] = wq + (pw + g.pad - s0) / g.stride;
         }
     }
-    auto load_a = [&](int step, float4 *ra) {
-        const int cc = step % cchunks, rs = step / cchunks;
-        const int r = rs / g.S, s = rs - r * g.S;
+    __shared__ int rowpix[MODE == 1 ? BM : 1];               // dgrad: output pixel index of each tile row (-1 = none)
+    if (MODE == 1 && t < BM) {
+        const int m = m0 + t;
+        const int wq = m % Wc, t2 = m / Wc, hq = t2 % Hc, n = t2 / Hc;
+        const int hi = hq * g.stride + ph, wi = wq * g.stride + pw;
+        rowpix[t] = (m < Mrows && hi < g.H && wi < g.W) ? (n * g.H + hi) * g.W + wi : -1;
+    }
+    // slice counters of the NEXT load: channel chunk cc, tap (r, s) (dgrad: (jr, js) of the class); advanced once per
+    // slice instead of dividing the slice index every step
+    int l_cc = 0, l_r = 0, l_s = 0;
+    if (T > 0) {
+        l_cc = s_beg % cchunks;
+        const int rs = s_beg / cchunks;
+        l_r = rs / Sc;
+        l_s = rs - l_r * Sc;
+    }
+    // element offset of each staging row's pixel at tap (0,0) (32-bit: tensors are checked to stay below 2^31 elements)
+    int apix[A_F4];
+#pragma unroll
+    for (int i = 0; i < A_F4; ++i)
+        apix[i] = MODE == 0 ? (an[i] * g.H + ah[i]) * g.W + aw[i] : (an[i] * g.Ho + ah[i]) * g.Wo + aw[i];
+    auto load_a = [&](float4 *ra) {
+        const int cc = l_cc, r = l_r, s = l_s;
+        const int tapoff = MODE == 0 ? r * g.W + s : -(r * g.Wo + s);
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (MODE == 0) {
-                const int hi = ah[i] + r, wi = aw[i] + s;
-                if (aval[i] && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W)
-                    v = *reinterpret_cast<const float4 *>(a_src + ((size_t)(an[i] * g.H + hi) * g.W + wi) * g.C + cc * BK + c4 * 4);
+                if (aval[i] && (unsigned)(ah[i] + r) < (unsigned)g.H && (unsigned)(aw[i] + s) < (unsigned)g.W)
+                    v = *reinterpret_cast<const float4 *>(a_src + (unsigned)((apix[i] + tapoff) * g.C + cc * BK + c4 * 4));
             } else {
-                const int hn = ah[i] - r, wn = aw[i] - s;              // = ho*stride, wo*stride when divisible
-                if (aval[i] && hn >= 0 && wn >= 0 && hn % g.stride == 0 && wn % g.stride == 0) {
-                    const int ho = hn / g.stride, wo = wn / g.stride;
-                    if (ho < g.Ho && wo < g.Wo)
-                        v = *reinterpret_cast<const float4 *>(a_src + ((size_t)(an[i] * g.Ho + ho) * g.Wo + wo) * g.K + cc * BK + c4 * 4);
-                }
+                if (aval[i] && (unsigned)(ah[i] - r) < (unsigned)g.Ho && (unsigned)(aw[i] - s) < (unsigned)g.Wo)
+                    v = *reinterpret_cast<const float4 *>(a_src + (unsigned)((apix[i] + tapoff) * g.K + cc * BK + c4 * 4));
             }
             ra[i] = v;
         }
@@ -103,8 +132,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
     // ---- B staging.  forward: rows = k, 16 consecutive c of filter tap (r,s): float4 copies.
     //      dgrad: rows = c, 16 k's strided by R*S*C: read float4 along c, transpose into LDS.
     constexpr int B_F4 = (BN * 4 + 255) / 256;
-    auto load_b = [&](int step, float4 *rb) {
-        const int cc = step % cchunks, rs = step / cchunks;
+    auto load_b = [&](float4 *rb) {
+        const int cc = l_cc;
+        const int rs = MODE == 0 ? l_r * g.S + l_s : (r0 + g.stride * l_r) * g.S + s0 + g.stride * l_s;   // filter tap of the slice
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -112,11 +142,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
             if (MODE == 0) {
                 const int row = idx >> 2, q4 = idx & 3;                  // row = out channel, q4 = float4 along c
                 if (row < BN && n0 + row < g.K)
-                    v = *reinterpret_cast<const float4 *>(wgt + ((size_t)(n0 + row) * g.R * g.S + rs) * g.C + cc * BK + q4 * 4);
+                    v = *reinterpret_cast<const float4 *>(wgt + (unsigned)(((n0 + row) * g.R * g.S + rs) * g.C + cc * BK + q4 * 4));
             } else {
                 const int kk = idx & 15, cq = idx >> 4;                  // kk = k inside the slice, cq = float4 of in-channels
                 if (cq * 4 < BN && n0 + cq * 4 < g.C)
-                    v = *reinterpret_cast<const float4 *>(wgt + ((size_t)(cc * BK + kk) * g.R * g.S + rs) * g.C + n0 + cq * 4);
+                    v = *reinterpret_cast<const float4 *>(wgt + (unsigned)(((cc * BK + kk) * g.R * g.S + rs) * g.C + n0 + cq * 4));
             }
             rb[i] = v;
         }
@@ -142,6 +172,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
         }
     };
 
+    if (MODE == 1 && Tall == 0) {               // stride > filter extent: this class receives no gradient
+        __syncthreads();
+        float *dst = out + (size_t)blockIdx.z * g.N * g.H * g.W * Ncols;     // split-K: every partial slot gets its zeros
+        constexpr int QN = BN / 4;                  // float4 per tile row
+        for (int idx = t; idx < BM * QN; idx += 256) {
+            const int ml = idx / QN, c = n0 + (idx % QN) * 4;
+            const int px = rowpix[ml];
+            if (px >= 0 && c < Ncols) *reinterpret_cast<float4 *>(dst + (size_t)px * Ncols + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     f32x16 acc[WTM][WTN];
 #pragma unroll
     for (int i = 0; i < WTM; ++i)
@@ -151,9 +192,16 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     float4 ra[A_F4], rb[B_F4];
+    auto advance = [&]() {
+        if (++l_cc == cchunks) {
+            l_cc = 0;
+            if (++l_s == Sc) { l_s = 0; ++l_r; }
+        }
+    };
     if (T > 0) {
-        load_a(s_beg, ra);
-        load_b(s_beg, rb);
+        load_a(ra);
+        load_b(rb);
+        advance();
         store_ab(0, ra, rb);
     }
     __syncthreads();
@@ -161,8 +209,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
     for (int step = 0; step < T; ++step) {
         const int cur = step & 1;
         if (step + 1 < T) {                       // prefetch the next slice into registers
-            load_a(s_beg + step + 1, ra);
-            load_b(s_beg + step + 1, rb);
+            load_a(ra);
+            load_b(rb);
+            advance();
         }
         float af[WTM][8], bf[WTN][8];
 #pragma unroll
@@ -195,13 +244,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
         const int col = n0 + wn0 + j * 32 + row;
         if (col >= Ncols) continue;
         const float bv = (MODE == 0 && bias && zsplits == 1) ? bias[col] : 0.f;
-        float *dst = out + (size_t)blockIdx.z * Mrows * Ncols;          // zsplits > 1: `out` is the partial workspace
+        const size_t out_rows = MODE == 0 ? (size_t)Mrows : (size_t)g.N * g.H * g.W;
+        float *dst = out + (size_t)blockIdx.z * out_rows * Ncols;       // zsplits > 1: `out` is the partial workspace
 #pragma unroll
         for (int i = 0; i < WTM; ++i)
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int m = m0 + wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (m < Mrows) {
+                const int ml = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int m = MODE == 0 ? m0 + ml : rowpix[ml];
+                if (MODE == 0 ? m < Mrows : m >= 0) {
                     float v = acc[i][j][e] + bv;
                     if (MODE == 0 && act == 1 && zsplits == 1) v = v > 0.f ? v : 0.f;
                     dst[(size_t)m * Ncols + col] = v;
@@ -334,15 +385,136 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     }
 }
 
+// out[i] = sum over splits of part[s][i].  A block owns 16 float4 columns; its 16 thread groups each add the
+// splits s = g, g+16, ... in order, then a fixed-order tree over the groups: deterministic for a given plan.
 __global__ __launch_bounds__(256) void split_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, size_t n,
                                                            int splits) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (size_t)gridDim.x * 256) {
-        float4 a = reinterpret_cast<const float4 *>(part)[i];
-        for (int s = 1; s < splits; ++s) {
+    __shared__ float4 red[16][16];
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + col;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n / 4)
+        for (int s = grp; s < splits; s += 16) {
             const float4 b = reinterpret_cast<const float4 *>(part + (size_t)s * n)[i];
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
         }
-        reinterpret_cast<float4 *>(out)[i] = a;
+    red[grp][col] = a;
+    __syncthreads();
+    for (int w = 8; w >= 1; w >>= 1) {
+        if (grp < w) {
+            const float4 b = red[grp + w][col];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            red[grp][col] = a;
+        }
+        __syncthreads();
+    }
+    if (grp == 0 && i < n / 4) reinterpret_cast<float4 *>(out)[i] = a;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad, operands straight from memory (no LDS staging): v_mfma_f32_16x16x4_f32 takes A[i][p] from lane
+// (i = lane%16, p = lane/16) and B[p][j] likewise, and with channels-last tensors "channel i of pixel p" for
+// 16 x 4 lanes is 4 contiguous 64-byte runs of dy (resp. x) — a coalesced load IS the operand fetch.
+// A lane loads KT (CT) consecutive channels with one dwordxKT load and feeds KT x CT interleaved 16x16 tiles:
+//   tile (q, cq) holds dW[k0 + KT*i + q][c0 + CT*j + cq].
+// One wave = one (k-group, c-group, tap, pixel range); the 4 waves of a workgroup take 4 pixel ranges and add
+// their accumulators through LDS before writing one partial (part[split][k][r][s][c]).
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <int NV> struct VecLoad;
+template <> struct VecLoad<1> {
+    static __device__ __forceinline__ void ld(const float *p, float *v) { v[0] = *p; }
+};
+template <> struct VecLoad<2> {
+    static __device__ __forceinline__ void ld(const float *p, float *v) {
+        const float2 t = *reinterpret_cast<const float2 *>(p);
+        v[0] = t.x; v[1] = t.y;
+    }
+};
+template <> struct VecLoad<4> {
+    static __device__ __forceinline__ void ld(const float *p, float *v) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+};
+
+template <int KT, int CT>
+__global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                float *__restrict__ part, ConvGeom g, int px_per_wave, int kgroups) {
+    constexpr int UB = 4;                                   // MFMA steps (of 4 pixels) per load batch
+    constexpr int NT = KT * CT;
+    __shared__ float red[4][NT * 4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int kg = blockIdx.x % kgroups, cg = blockIdx.x / kgroups;
+    const int rs = blockIdx.z, r = rs / g.S, s = rs - r * g.S;
+    const int M = g.N * g.Ho * g.Wo;
+    const int i16 = lane & 15, pq = lane >> 4;
+    const int kl = kg * 16 * KT + KT * i16, cl = cg * 16 * CT + CT * i16;
+    const int mbeg = (blockIdx.y * 4 + wave) * px_per_wave;
+    const int mend = min(M, mbeg + px_per_wave);
+    // this lane's pixel: m = mbeg + pq, advancing by 4 per step; (n, ho, wo) kept incrementally
+    int m = mbeg + pq;
+    int wo = m % g.Wo, t2 = m / g.Wo, ho = t2 % g.Ho, n = t2 / g.Ho;
+    const float *dyp = dy + (size_t)m * g.K + kl;
+
+    f32x4 acc[KT][CT];
+#pragma unroll
+    for (int q = 0; q < KT; ++q)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[q][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto load_batch = [&](float (*a)[KT], float (*b)[CT]) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+            const bool mv = m < mend;
+            const int hi = ho * g.stride - g.pad + r, wi = wo * g.stride - g.pad + s;
+            const bool xv = mv && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+#pragma unroll
+            for (int q = 0; q < KT; ++q) a[u][q] = 0.f;
+#pragma unroll
+            for (int c = 0; c < CT; ++c) b[u][c] = 0.f;
+            if (mv) VecLoad<KT>::ld(dyp, a[u]);
+            if (xv) VecLoad<CT>::ld(x + ((size_t)(n * g.H + hi) * g.W + wi) * g.C + cl, b[u]);
+            m += 4;
+            dyp += 4 * g.K;
+            wo += 4;
+            while (wo >= g.Wo) {
+                wo -= g.Wo;
+                if (++ho >= g.Ho) { ho = 0; ++n; }
+            }
+        }
+    };
+    auto mma_batch = [&](float (*a)[KT], float (*b)[CT]) {
+#pragma unroll
+        for (int u = 0; u < UB; ++u)
+#pragma unroll
+            for (int q = 0; q < KT; ++q)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q], b[u][c], acc[q][c], 0, 0, 0);
+    };
+    float a0[UB][KT], b0[UB][CT], a1[UB][KT], b1[UB][CT];
+    const int nb = (mend - mbeg + 4 * UB - 1) / (4 * UB);    // batches (loads past mend are masked to zero)
+    if (nb > 0) load_batch(a0, b0);
+    for (int bi = 0; bi < nb; bi += 2) {
+        load_batch(a1, b1);
+        mma_batch(a0, b0);
+        load_batch(a0, b0);
+        mma_batch(a1, b1);
+    }
+    // ---- add the 4 waves' accumulators (fixed order), wave w writes quarter w of the tile registers
+#pragma unroll
+    for (int q = 0; q < KT; ++q)
+#pragma unroll
+        for (int c = 0; c < CT; ++c)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) red[wave][(q * CT + c) * 4 + v][lane] = acc[q][c][v];
+    __syncthreads();
+    float *po = part + (size_t)blockIdx.y * g.K * g.R * g.S * g.C;
+    for (int idx = wave; idx < NT * 4; idx += 4) {
+        const float sum = ((red[0][idx][lane] + red[1][idx][lane]) + red[2][idx][lane]) + red[3][idx][lane];
+        const int v = idx & 3, c = (idx >> 2) % CT, q = (idx >> 2) / CT;
+        const int k = kg * 16 * KT + KT * (4 * pq + v) + q, cc = cg * 16 * CT + CT * i16 + c;
+        po[((size_t)k * g.R * g.S + rs) * g.C + cc] = sum;
     }
 }
 
@@ -366,27 +538,39 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restric
     }
 }
 
-// column sums of a [M, K] matrix (bias gradient), deterministic two-level
-__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ dy, float *__restrict__ part, int M, int K,
-                                                     int rows_per_block) {
-    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
-    for (int k = threadIdx.x; k < K; k += 256) {
-        float s = 0.f;
-        for (int m = r0; m < r1; ++m) s += dy[(size_t)m * K + k];
-        part[(size_t)blockIdx.x * K + k] = s;
+// column sums of a [M, K] matrix (bias gradient), deterministic: block b adds rows [b*rpb, (b+1)*rpb) of a band of up
+// to 256 columns (blockIdx.y): thread (col4 = t % cpb, grp = t / cpb) adds rows grp, grp + 256/cpb, ..., then a
+// fixed-order LDS tree over the groups.  Applied twice: dy -> part [nblk][K] -> out [K].
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ src, float *__restrict__ dst, int M, int K, int rpb,
+                                                     int cpb) {
+    __shared__ float4 red[256];
+    const int t = threadIdx.x, col = t % cpb, grp = t / cpb, ngrp = 256 / cpb;
+    const int c4 = blockIdx.y * 64 + col;                      // float4 column
+    const int r0 = blockIdx.x * rpb, r1 = min(M, r0 + rpb);
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c4 * 4 < K)
+        for (int m = r0 + grp; m < r1; m += ngrp) {
+            const float4 b = *reinterpret_cast<const float4 *>(src + (size_t)m * K + c4 * 4);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+    red[t] = a;
+    __syncthreads();
+    for (int w = ngrp >> 1; w >= 1; w >>= 1) {
+        if (grp < w) {
+            const float4 b = red[t + w * cpb];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            red[t] = a;
+        }
+        __syncthreads();
     }
-}
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float *__restrict__ part, float *__restrict__ out, int nblk, int K) {
-    const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k >= K) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += part[(size_t)b * K + k];
-    out[k] = s;
+    if (grp == 0 && c4 * 4 < K) *reinterpret_cast<float4 *>(dst + (size_t)blockIdx.x * K + c4 * 4) = a;
 }
 
 int check_geom(const char *who, const ConvGeom &g) {
     SQD_CHECK_ARG(g.N > 0 && g.H > 0 && g.W > 0 && g.C > 0 && g.K > 0 && g.R > 0 && g.S > 0 && g.stride > 0 && g.pad >= 0,
                   "%s: bad geometry", who);
+    SQD_CHECK_ARG((long long)g.N * g.H * g.W * g.C < (1ll << 31) && (long long)g.N * g.Ho * g.Wo * g.K < (1ll << 31) &&
+                      (long long)g.K * g.R * g.S * g.C < (1ll << 31), "%s: tensors of 2^31 elements or more are not supported", who);
     SQD_CHECK_ARG(g.Ho == (g.H + 2 * g.pad - g.R) / g.stride + 1 && g.Wo == (g.W + 2 * g.pad - g.S) / g.stride + 1,
                   "%s: Ho/Wo inconsistent with H/W/R/S/stride/pad", who);
     return SQD_OK;
@@ -401,13 +585,24 @@ struct GemmPlan {
 };
 // tile / split-K choice: enough workgroups to cover 256 CUs a few times over, partial workspace <= 64 MB
 static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
-    const int Mrows = mode == 0 ? g.N * g.Ho * g.Wo : g.N * g.H * g.W;
+    int ncls = 1;                                 // stride classes that have at least one tap (the others only zero-fill)
+    if (mode == 1) {
+        int ah = 0, aw = 0;
+        for (int p = 0; p < g.stride; ++p) {
+            ah += (p + g.pad) % g.stride < g.R;
+            aw += (p + g.pad) % g.stride < g.S;
+        }
+        ncls = ah * aw > 0 ? ah * aw : 1;
+    }
+    const int Mcls = mode == 0 ? g.N * g.Ho * g.Wo : g.N * ((g.H + g.stride - 1) / g.stride) * ((g.W + g.stride - 1) / g.stride);
+    const int Mrows = mode == 0 ? g.N * g.Ho * g.Wo : g.N * g.H * g.W;     // output rows (workspace size)
     const int Ncols = mode == 0 ? g.K : g.C;
-    const int T = g.R * g.S * ((mode == 0 ? g.C : g.K) / BK);
+    const int taps = mode == 0 ? g.R * g.S : ((g.R + g.stride - 1) / g.stride) * ((g.S + g.stride - 1) / g.stride);
+    const int T = taps * ((mode == 0 ? g.C : g.K) / BK);
     GemmPlan p;
     p.bn = Ncols >= 128 ? 128 : Ncols >= 64 ? 64 : 32;
     p.bm = 128;
-    auto wgs = [&](int bm, int bn) { return ((Mrows + bm - 1) / bm) * ((Ncols + bn - 1) / bn); };
+    auto wgs = [&](int bm, int bn) { return ncls * ((Mcls + bm - 1) / bm) * ((Ncols + bn - 1) / bn); };
     if (wgs(128, p.bn) < 512 && p.bn >= 64) p.bm = 64;
     if (p.bm == 64 && p.bn == 128 && wgs(64, 128) < 512) p.bn = 64;
     int z = 1;
@@ -424,8 +619,8 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     return p;
 }
 
-#define LAUNCH_GEMM(MODE, BM, BN, WGM, WGN)                                                                               \
-    hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN>), dim3((Mrows + BM - 1) / BM, (Ncols + BN - 1) / BN, p.z), \
+#define LAUNCH_GEMM(MODE, BM, BN, WGM, WGN)                                                                                    \
+    hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN>), dim3(ncls * ((Mcls + BM - 1) / BM), (Ncols + BN - 1) / BN, p.z), \
                        dim3(256), 0, st, a_src, w, bias, dst, g, act, p.z)
 #define DISPATCH_GEMM(MODE)                                          \
     if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM(MODE, 128, 128, 2, 2); \
@@ -436,6 +631,8 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
 
 static int launch_gemm(int mode, const float *a_src, const float *w, const float *bias, float *out, float *ws, const ConvGeom &g,
                        int act, void *stream) {
+    const int ncls = mode == 0 ? 1 : g.stride * g.stride;
+    const int Mcls = mode == 0 ? g.N * g.Ho * g.Wo : g.N * ((g.H + g.stride - 1) / g.stride) * ((g.W + g.stride - 1) / g.stride);
     const int Mrows = mode == 0 ? g.N * g.Ho * g.Wo : g.N * g.H * g.W;
     const int Ncols = mode == 0 ? g.K : g.C;
     const GemmPlan p = plan_gemm(mode, g);
@@ -488,8 +685,49 @@ extern "C" int sqd_conv_dgrad(const float *dy, const float *w, float *dx, float 
     return SQD_OK;
 }
 
+struct WgradPlan {
+    bool direct;
+    int kt, ct, splits, px_per_wave;
+};
+static int wgrad_impl_override() {              // SQD_WGRAD_IMPL=lds|direct forces one kernel (benchmarks); default: heuristic
+    static int v = -1;
+    if (v < 0) {
+        const char *e = getenv("SQD_WGRAD_IMPL");
+        v = !e ? 0 : (!strcmp(e, "lds") ? 1 : (!strcmp(e, "direct") ? 2 : 0));
+    }
+    return v;
+}
+static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, int S) {
+    WgradPlan p;
+    const int M = N * Ho * Wo;
+    const int ov = wgrad_impl_override();
+    // the direct kernel wins where pixels are many and channels few (operand re-reads stay in L2); the LDS-tiled
+    // kernel where K*C is large and the pixel count small
+    p.direct = C % 16 == 0 && K % 16 == 0 && (ov == 2 || (ov == 0 && M >= 2048 && C <= 1024));
+    p.kt = K % 64 == 0 ? 4 : K % 32 == 0 ? 2 : 1;
+    p.ct = C % 64 == 0 ? 4 : C % 32 == 0 ? 2 : 1;
+    const int groups = (K / (16 * p.kt)) * (C / (16 * p.ct)) * R * S;
+    int sp = (1024 + groups - 1) / groups;                       // ~1k workgroups of 4 waves
+    const int max_by_px = (M + 255) / 256;                       // >= 64 pixels per wave
+    if (sp > max_by_px) sp = max_by_px;
+    const int64_t wsz = (int64_t)K * R * S * C;
+    while (sp > 1 && (int64_t)sp * wsz * 4 > (64ll << 20)) --sp;
+    if (sp < 1) sp = 1;
+    int ppw = (M + sp * 4 - 1) / (sp * 4);
+    ppw = (ppw + 3) / 4 * 4;
+    p.splits = sp;
+    p.px_per_wave = ppw;
+    return p;
+}
+
 extern "C" int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *splits, int64_t *part_floats) {
     const int M = N * Ho * Wo;
+    const WgradPlan dp = plan_wgrad_direct(N, Ho, Wo, C, K, R, S);
+    if (dp.direct) {
+        if (splits) *splits = dp.splits;
+        if (part_floats) *part_floats = (int64_t)dp.splits * K * R * S * C;
+        return SQD_OK;
+    }
     const int bm = K >= 128 ? 128 : 64, bn = C >= 128 ? 128 : 64;
     const int tiles = ((K + bm - 1) / bm) * ((C + bn - 1) / bn) * R * S;
     int sp = (1536 + tiles - 1) / tiles;                         // aim at ~1.5k workgroups
@@ -519,21 +757,42 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
     pps = ((pps + BK - 1) / BK) * BK;
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
-    const bool bigk = K >= 128, bigc = C >= 128;
-    const int bm = bigk ? 128 : 64, bn = bigc ? 128 : 64;
-    const dim3 grid(((K + bm - 1) / bm) * ((C + bn - 1) / bn), splits, R * S);
-    if (bigk && bigc) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, dim3(256), 0, st, dy, x, part, g, pps);
-    else if (bigk) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, dim3(256), 0, st, dy, x, part, g, pps);
-    else if (bigc) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, dim3(256), 0, st, dy, x, part, g, pps);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, dy, x, part, g, pps);
+    const WgradPlan dp = plan_wgrad_direct(N, Ho, Wo, C, K, R, S);
+    if (dp.direct) {
+        const int kgroups = K / (16 * dp.kt);
+        const dim3 grid(kgroups * (C / (16 * dp.ct)), dp.splits, R * S);
+#define LAUNCH_WD(KT, CT) \
+    hipLaunchKernelGGL((conv_wgrad_direct_kernel<KT, CT>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, kgroups)
+        switch (dp.kt * 8 + dp.ct) {
+            case 4 * 8 + 4: LAUNCH_WD(4, 4); break;
+            case 4 * 8 + 2: LAUNCH_WD(4, 2); break;
+            case 4 * 8 + 1: LAUNCH_WD(4, 1); break;
+            case 2 * 8 + 4: LAUNCH_WD(2, 4); break;
+            case 2 * 8 + 2: LAUNCH_WD(2, 2); break;
+            case 2 * 8 + 1: LAUNCH_WD(2, 1); break;
+            case 1 * 8 + 4: LAUNCH_WD(1, 4); break;
+            case 1 * 8 + 2: LAUNCH_WD(1, 2); break;
+            default: LAUNCH_WD(1, 1); break;
+        }
+    } else {
+        const bool bigk = K >= 128, bigc = C >= 128;
+        const int bm = bigk ? 128 : 64, bn = bigc ? 128 : 64;
+        const dim3 grid(((K + bm - 1) / bm) * ((C + bn - 1) / bn), splits, R * S);
+        if (bigk && bigc) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, dim3(256), 0, st, dy, x, part, g, pps);
+        else if (bigk) hipLaunchKernelGGL((conv_wgrad_kernel<128, 64>), grid, dim3(256), 0, st, dy, x, part, g, pps);
+        else if (bigc) hipLaunchKernelGGL((conv_wgrad_kernel<64, 128>), grid, dim3(256), 0, st, dy, x, part, g, pps);
+        else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, dy, x, part, g, pps);
+    }
     const size_t wsz = (size_t)K * R * S * C;
-    size_t nb = (wsz / 4 + 255) / 256;
-    hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)(nb > 2048 ? 2048 : nb)), dim3(256), 0, st, part, dw, wsz, splits);
+    hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((wsz / 4 + 15) / 16)), dim3(256), 0, st, part, dw, wsz, splits);
     if (dbias) {
         float *cpart = part + (size_t)splits * wsz;
         const int rpb = 1024, nblk = (M + rpb - 1) / rpb;
-        hipLaunchKernelGGL(colsum_kernel, dim3(nblk), dim3(256), 0, st, dy, cpart, M, K, rpb);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3((K + 255) / 256), dim3(256), 0, st, cpart, dbias, nblk, K);
+        int cpb = 1;
+        while (cpb < 64 && cpb * 4 < K) cpb <<= 1;              // float4 columns per block (power of two <= 64)
+        const int bands = (K / 4 + 63) / 64;
+        hipLaunchKernelGGL(colsum_kernel, dim3(nblk, bands), dim3(256), 0, st, dy, cpart, M, K, rpb, cpb);
+        hipLaunchKernelGGL(colsum_kernel, dim3(1, bands), dim3(256), 0, st, cpart, dbias, nblk, K, nblk, cpb);
     }
     SQD_CHECK_LAUNCH("sqd_conv_wgrad");
     return SQD_OK;

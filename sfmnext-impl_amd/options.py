@@ -114,6 +114,7 @@ EXTRA_FLAGS = [
     ("sqd_bucket_mb", float, 32.0, {"help": "gradient all-reduce bucket size (MB) for multi-GPU runs"}),
     ("sqd_device_noise", _T, False, {"help": "draw the tie-break noise on the device instead of the CPU RNG"}),
     ("sqd_channels_last", _T, False, {"help": "keep network activations NHWC in memory (interim ATen conv backend only)"}),
+    ("sqd_native_conv", _T, False, {"help": "convolutions through the native implicit-GEMM kernels (csrc/conv.hip) instead of ATen/MIOpen"}),
     ("sqd_miopen_find", _T, False, {"help": "let MIOpen benchmark its solvers per layer (interim ATen conv backend only)"}),
 ]
 

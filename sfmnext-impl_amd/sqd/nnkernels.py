@@ -106,10 +106,35 @@ def conv_supported(C, K):
     return C % 16 == 0 and K % 16 == 0
 
 
+_PLAN_CACHE = {}
+
+
 def _conv_ws(mode, geom, device):
-    n = ctypes.c_int64(0)
-    _l.lib().sqd_conv_plan(mode, *geom, ctypes.byref(n))
-    return torch.empty(n.value, device=device, dtype=torch.float32) if n.value else None
+    """split-K workspace of sqd_conv_fwd (mode 0) / sqd_conv_dgrad (mode 1); plan sizes cached per geometry."""
+    key = (mode,) + tuple(geom)
+    n = _PLAN_CACHE.get(key)
+    if n is None:
+        c = ctypes.c_int64(0)
+        _l.lib().sqd_conv_plan(mode, *geom, ctypes.byref(c))
+        n = _PLAN_CACHE[key] = c.value
+    return torch.empty(n, device=device, dtype=torch.float32) if n else None
+
+
+def _wgrad_part_floats(geom):
+    N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
+    key = ("w",) + tuple(geom)
+    n = _PLAN_CACHE.get(key)
+    if n is None:
+        splits, pf = ctypes.c_int(0), ctypes.c_int64(0)
+        _l.lib().sqd_conv_wgrad_plan(N, Ho, Wo, C, K, R, S, ctypes.byref(splits), ctypes.byref(pf))
+        n = _PLAN_CACHE[key] = pf.value
+    return n
+
+
+def conv_module_supported(conv):
+    s, p = conv.stride, conv.padding
+    return (conv.in_channels % 16 == 0 and conv.out_channels % 16 == 0 and s[0] == s[1] and p[0] == p[1]
+            and conv.dilation == (1, 1) and conv.groups == 1 and not isinstance(p, str))
 
 
 class Conv2d(torch.autograd.Function):
@@ -147,10 +172,8 @@ class Conv2d(torch.autograd.Function):
             _l.check(L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), N, H, W, C, K, R, S, stride, pad, Ho, Wo, _stream()),
                      "conv_dgrad")
         if ctx.needs_input_grad[1]:
-            splits, pf = ctypes.c_int(0), ctypes.c_int64(0)
-            L.sqd_conv_wgrad_plan(N, Ho, Wo, C, K, R, S, ctypes.byref(splits), ctypes.byref(pf))
             extra = ((N * Ho * Wo + 1023) // 1024) * K if ctx.has_bias else 0
-            part = torch.empty(pf.value + extra, device=dy.device, dtype=torch.float32)
+            part = torch.empty(_wgrad_part_floats(ctx.geom) + extra, device=dy.device, dtype=torch.float32)
             dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
             db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
             _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,

@@ -28,9 +28,29 @@ def _act(y, act):
     raise ValueError(act)
 
 
+NATIVE_CONV = False          # --sqd_native_conv: implicit-GEMM kernels of csrc/conv.hip instead of ATen/MIOpen
+
+
+def set_native_conv(on):
+    """Route every convolution the native kernels support (C and K multiples of 16, square stride/padding)
+    through libsqd; the 3- and 6-channel stem convolutions stay on ATen."""
+    global NATIVE_CONV
+    NATIVE_CONV = bool(on)
+    BACKEND["conv2d"] = "hip (C,K % 16 == 0) / aten stems" if on else "aten"
+    BACKEND["conv_bn_act"] = ("hip conv" if on else "aten conv") + " + hip bn/act/residual"
+
+
+def _conv(x, conv, act=None):
+    if NATIVE_CONV and x.is_cuda:
+        from . import nnkernels
+        if nnkernels.conv_module_supported(conv):
+            return nnkernels.conv2d_native(x, conv, act)
+    return _act(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), act)
+
+
 def conv2d(x, conv, act=None):
     """conv (nn.Conv2d holding weight/bias/stride/padding) applied to x, optional activation."""
-    return _act(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), act)
+    return _conv(x, conv, act)
 
 
 def conv_bn_act(x, conv, bn, act, residual=None, input_affine=None):
@@ -38,7 +58,7 @@ def conv_bn_act(x, conv, bn, act, residual=None, input_affine=None):
     -> [+ residual] -> activation."""
     if input_affine is not None:
         x = (x - input_affine[0]) / input_affine[1]
-    y = F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding)
+    y = _conv(x, conv)
     if y.is_cuda:
         from . import nnkernels
         if not nnkernels.bn_supported(y.shape[1]):

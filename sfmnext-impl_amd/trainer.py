@@ -81,6 +81,10 @@ class Trainer:
 
         if self.opt.sqd_miopen_find:
             torch.backends.cudnn.benchmark = True
+        from sqd import nnops
+        nnops.set_native_conv(self.opt.sqd_native_conv)
+        if self.opt.sqd_native_conv:
+            self.opt.sqd_channels_last = True          # the native kernels are NHWC / KRSC only
         if self.opt.sqd_channels_last:
             for m in self.models.values():
                 m.to(memory_format=torch.channels_last)

@@ -19,6 +19,8 @@ CASES = [  # N, C, H, W, K, R, stride, pad, bias, act
     (2, 32, 20, 28, 16, 3, 1, 1, True, None),          # K = 16
     (3, 48, 9, 7, 80, 3, 1, 1, True, None),            # channel counts that are not powers of two
     (12, 64, 48, 160, 64, 3, 1, 1, False, None),       # config-B layer1 shape
+    (2, 32, 13, 21, 64, 3, 2, 1, True, None),          # stride 2 on odd sizes (ragged stride classes in dgrad)
+    (1, 512, 6, 20, 512, 3, 1, 1, False, None),        # few pixels, long reduction: split-K path
 ]
 
 

@@ -11,7 +11,7 @@ import torch.nn as nn  # noqa: E402
 from sqd import nnkernels  # noqa: E402
 
 ap = argparse.ArgumentParser()
-ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--N", type=int, default=12)
 args = ap.parse_args()
 N = args.N
@@ -51,21 +51,39 @@ def timeit(fn, iters):
     return e0.elapsed_time(e1) / iters * 1e3
 
 
-tot = {"n_f": 0, "n_b": 0, "a_f": 0, "a_b": 0}
-print("%-22s %9s | %8s %8s %6s | %8s %8s %6s" % ("layer", "GFLOP", "nat fwd", "aten fwd", "TF", "nat bwd", "aten bwd", "TF"))
+import ctypes
+from sqd import lib as _l
+LIB = _l.lib()
+P = lambda t: None if t is None else ctypes.c_void_p(t.data_ptr())
+ST = lambda: ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+tot = {"n_f": 0, "n_d": 0, "n_w": 0, "a_f": 0, "a_d": 0, "a_w": 0}
+print("%-22s %7s | %7s %7s | %7s %7s | %7s %7s   (us per launch, C-ABI called back to back on preallocated buffers)" %
+      ("layer", "GFLOP", "nat fwd", "at fwd", "nat dg", "at dg", "nat wg", "at wg"))
 for name, C, H, W, K, R, st, pad, cnt in L:
     conv = nn.Conv2d(C, K, R, st, pad, bias=False).cuda().to(memory_format=torch.channels_last)
-    x = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    x = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    w = conv.weight.detach()
     Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
     gflop = 2.0 * N * Ho * Wo * K * C * R * R / 1e9
-    y_n = nnkernels.conv2d_native(x, conv)
-    y_a = conv(x)
-    dy = torch.randn_like(y_a)
-    t_nf = timeit(lambda: nnkernels.conv2d_native(x, conv), args.iters)
+    geom = (N, H, W, C, K, R, R, st, pad, Ho, Wo)
+    y = torch.empty(N, K, Ho, Wo, device="cuda").contiguous(memory_format=torch.channels_last)
+    dy = torch.randn_like(y)
+    dx = torch.empty_like(x)
+    dw = torch.empty_like(w)
+    ws0, ws1 = nnkernels._conv_ws(0, geom, x.device), nnkernels._conv_ws(1, geom, x.device)
+    sp, pf = ctypes.c_int(0), ctypes.c_int64(0)
+    LIB.sqd_conv_wgrad_plan(N, Ho, Wo, C, K, R, R, ctypes.byref(sp), ctypes.byref(pf))
+    part = torch.empty(pf.value, device="cuda")
+    t_nf = timeit(lambda: LIB.sqd_conv_fwd(P(x), P(w), None, P(y), P(ws0), *geom, 0, ST()), args.iters)
+    t_nd = timeit(lambda: LIB.sqd_conv_dgrad(P(dy), P(w), P(dx), P(ws1), *geom, ST()), args.iters)
+    t_nw = timeit(lambda: LIB.sqd_conv_wgrad(P(dy), P(x), P(dw), None, P(part), *geom, ST()), args.iters)
+    cb = torch.ops.aten.convolution_backward
+    a = (None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1)
     t_af = timeit(lambda: conv(x), args.iters)
-    t_nb = timeit(lambda: torch.autograd.grad(y_n, (x, conv.weight), dy, retain_graph=True), args.iters)
-    t_ab = timeit(lambda: torch.autograd.grad(y_a, (x, conv.weight), dy, retain_graph=True), args.iters)
-    print("%-22s %9.2f | %8.1f %8.1f %6.1f | %8.1f %8.1f %6.1f" % (name, gflop, t_nf, t_af, gflop / t_nf * 1e3 / 1e3, t_nb, t_ab,
-                                                                 2 * gflop / t_nb * 1e3 / 1e3), flush=True)
-    tot["n_f"] += cnt * t_nf; tot["a_f"] += cnt * t_af; tot["n_b"] += cnt * t_nb; tot["a_b"] += cnt * t_ab
-print("weighted totals per step (us): native fwd %.0f bwd %.0f | aten fwd %.0f bwd %.0f" % (tot["n_f"], tot["n_b"], tot["a_f"], tot["a_b"]))
+    t_ad = timeit(lambda: cb(dy, x, w, *a, [True, False, False]), args.iters)
+    t_aw = timeit(lambda: cb(dy, x, w, *a, [False, True, False]), args.iters)
+    print("%-22s %7.2f | %7.1f %7.1f | %7.1f %7.1f | %7.1f %7.1f" % (name, gflop, t_nf, t_af, t_nd, t_ad, t_nw, t_aw), flush=True)
+    for k, v in (("n_f", t_nf), ("n_d", t_nd), ("n_w", t_nw), ("a_f", t_af), ("a_d", t_ad), ("a_w", t_aw)):
+        tot[k] += cnt * v
+print("weighted totals per step (us): native fwd %.0f dgrad %.0f wgrad %.0f | aten fwd %.0f dgrad %.0f wgrad %.0f" %
+      (tot["n_f"], tot["n_d"], tot["n_w"], tot["a_f"], tot["a_d"], tot["a_w"]))
