@@ -25,7 +25,7 @@ import torch.distributed as dist  # noqa: E402
 CONFIG_B = ["--backbone", "resnet", "--num_layers", "50", "--num_features", "256", "--model_dim", "32",
             "--patch_size", "16", "--query_nums", "64", "--dim_out", "64", "--height", "192", "--width", "640",
             "--batch_size", "12", "--min_depth", "0.001", "--max_depth", "80.0", "--num_workers", "0",
-            "--sqd_synthetic", "--sqd_device_noise", "--sqd_channels_last", "--log_dir", "/tmp/sqd_bench",
+            "--sqd_synthetic", "--sqd_device_noise", "--log_dir", "/tmp/sqd_bench",
             "--model_name", "bench"]
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FUSED_FWD_BYTES_PER_PX = 93      # disp 1 + target 12 + sources 24 + identity/noise 8 | depth 4 + sample 16 + warped 24 + sel 4

@@ -39,7 +39,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 template <int MODE, int BM, int BN, int WGM, int WGN>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
                                                         const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
-                                                        int act, int zsplits) {
+                                                        int act, int zsplits, int order) {
     constexpr int WTM = BM / WGM / 32, WTN = BN / WGN / 32;     // 32x32 MFMA tiles per wave
     static_assert(WGM * WGN == 4 && WTM >= 1 && WTN >= 1, "4 waves per workgroup");
     constexpr int A_F4 = BM * 4 / 256, B_ROWS_PER_PASS = (MODE == 0) ? 64 : 64;
@@ -49,15 +49,27 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm0 = (wave / WGN) * (WTM * 32), wn0 = (wave % WGN) * (WTN * 32);
-    const int n0 = blockIdx.y * BN;
+    // workgroups are dealt round-robin to the 8 XCDs (private L2 each): XCD x gets the contiguous range
+    // [x*G/8, (x+1)*G/8) of the logical tile order, in which the N-tiles of one M-tile are neighbours, so the
+    // activation tile they share is fetched into that L2 once
+    // order bit 0: XCD chunking, bit 1: N-tiles fastest (else M-tiles fastest), bit 2: stride classes interleaved
+    const int tiles_n = (MODE == 0 ? g.K + BN - 1 : g.C + BN - 1) / BN;
+    const int logical = (order & 1) ? (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3) : blockIdx.x;
     // dgrad runs one dense problem per stride class (ph, pw) = (hi % stride, wi % stride): the input pixels of a
     // class all see the same taps r = r0 + stride*jr, s = s0 + stride*js, with ho = hi' + base_h - jr, so no
     // slice is spent on taps that do not divide (stride 1: a single class, all taps)
     const int Hc = (g.H + g.stride - 1) / g.stride, Wc = (g.W + g.stride - 1) / g.stride;
     const int Mrows = MODE == 0 ? g.N * g.Ho * g.Wo : g.N * Hc * Wc;      // rows of one GEMM (per class for dgrad)
     const int tiles_m = (Mrows + BM - 1) / BM;
-    const int cls = MODE == 0 ? 0 : blockIdx.x / tiles_m;
-    const int m0 = (MODE == 0 ? blockIdx.x : blockIdx.x - cls * tiles_m) * BM;
+    // stride classes interleave (class index varies faster than the M-tile) so that every XCD gets its share of the
+    // classes that carry taps
+    const int ncls_all = MODE == 0 ? 1 : g.stride * g.stride;
+    const int tiles_m_all = tiles_m * ncls_all;
+    if (logical >= tiles_m_all * tiles_n) return;                // grid padding (multiple of 8)
+    const int tile_m_all = (order & 2) ? logical / tiles_n : logical % tiles_m_all;
+    const int n0 = ((order & 2) ? logical % tiles_n : logical / tiles_m_all) * BN;
+    const int cls = (order & 4) ? tile_m_all % ncls_all : tile_m_all / tiles_m;
+    const int m0 = ((order & 4) ? tile_m_all / ncls_all : tile_m_all % tiles_m) * BM;
     const int ph = cls / g.stride, pw = cls - ph * g.stride;
     const int r0 = (ph + g.pad) % g.stride, s0 = (pw + g.pad) % g.stride;
     const int Rc = MODE == 0 ? g.R : (r0 < g.R ? (g.R - r0 + g.stride - 1) / g.stride : 0);
@@ -440,17 +452,24 @@ template <> struct VecLoad<4> {
 
 template <int KT, int CT>
 __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__restrict__ dy, const float *__restrict__ x,
-                                                                float *__restrict__ part, ConvGeom g, int px_per_wave, int kgroups) {
+                                                                float *__restrict__ part, ConvGeom g, int px_per_wave, int kgroups,
+                                                                int nsplits) {
     constexpr int UB = 4;                                   // MFMA steps (of 4 pixels) per load batch
     constexpr int NT = KT * CT;
     __shared__ float red[4][NT * 4][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int kg = blockIdx.x % kgroups, cg = blockIdx.x / kgroups;
-    const int rs = blockIdx.z, r = rs / g.S, s = rs - r * g.S;
+    // XCD-aware order (see conv_gemm_kernel): taps fastest, then channel groups, then pixel ranges — the 9 taps of a
+    // 3x3 filter read the same dy rows and overlapping x rows out of one L2
+    const int taps = g.R * g.S, groups = kgroups * (g.C / (16 * CT));
+    const int logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (logical >= taps * groups * nsplits) return;
+    const int rs = logical % taps, lg = logical / taps, grp = lg % groups, split = lg / groups;
+    const int kg = grp % kgroups, cg = grp / kgroups;
+    const int r = rs / g.S, s = rs - r * g.S;
     const int M = g.N * g.Ho * g.Wo;
     const int i16 = lane & 15, pq = lane >> 4;
     const int kl = kg * 16 * KT + KT * i16, cl = cg * 16 * CT + CT * i16;
-    const int mbeg = (blockIdx.y * 4 + wave) * px_per_wave;
+    const int mbeg = (split * 4 + wave) * px_per_wave;
     const int mend = min(M, mbeg + px_per_wave);
     // this lane's pixel: m = mbeg + pq, advancing by 4 per step; (n, ho, wo) kept incrementally
     int m = mbeg + pq;
@@ -509,7 +528,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
 #pragma unroll
             for (int v = 0; v < 4; ++v) red[wave][(q * CT + c) * 4 + v][lane] = acc[q][c][v];
     __syncthreads();
-    float *po = part + (size_t)blockIdx.y * g.K * g.R * g.S * g.C;
+    float *po = part + (size_t)split * g.K * g.R * g.S * g.C;
     for (int idx = wave; idx < NT * 4; idx += 4) {
         const float sum = ((red[0][idx][lane] + red[1][idx][lane]) + red[2][idx][lane]) + red[3][idx][lane];
         const int v = idx & 3, c = (idx >> 2) % CT, q = (idx >> 2) / CT;
@@ -620,8 +639,9 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
 }
 
 #define LAUNCH_GEMM(MODE, BM, BN, WGM, WGN)                                                                                    \
-    hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN>), dim3(ncls * ((Mcls + BM - 1) / BM), (Ncols + BN - 1) / BN, p.z), \
-                       dim3(256), 0, st, a_src, w, bias, dst, g, act, p.z)
+    hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN>),                                                     \
+                       dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(256), 0, st, \
+                       a_src, w, bias, dst, g, act, p.z, order)
 #define DISPATCH_GEMM(MODE)                                          \
     if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM(MODE, 128, 128, 2, 2); \
     else if (p.bm == 128 && p.bn == 64) LAUNCH_GEMM(MODE, 128, 64, 2, 2); \
@@ -641,6 +661,8 @@ static int launch_gemm(int mode, const float *a_src, const float *w, const float
         return SQD_EINVAL;
     }
     hipStream_t st = (hipStream_t)stream;
+    static const int order_env = getenv("SQD_CONV_ORDER") ? atoi(getenv("SQD_CONV_ORDER")) : -1;
+    const int order = order_env >= 0 ? order_env : 2;      // measured best on MI355X (profiles/r01c_conv_layers.md)
     float *dst = p.z > 1 ? ws : out;
     (void)hipGetLastError();
     if (mode == 0) { DISPATCH_GEMM(0) } else { DISPATCH_GEMM(1) }
@@ -760,9 +782,9 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
     const WgradPlan dp = plan_wgrad_direct(N, Ho, Wo, C, K, R, S);
     if (dp.direct) {
         const int kgroups = K / (16 * dp.kt);
-        const dim3 grid(kgroups * (C / (16 * dp.ct)), dp.splits, R * S);
+        const dim3 grid((kgroups * (C / (16 * dp.ct)) * dp.splits * R * S + 7) / 8 * 8);
 #define LAUNCH_WD(KT, CT) \
-    hipLaunchKernelGGL((conv_wgrad_direct_kernel<KT, CT>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, kgroups)
+    hipLaunchKernelGGL((conv_wgrad_direct_kernel<KT, CT>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, kgroups, dp.splits)
         switch (dp.kt * 8 + dp.ct) {
             case 4 * 8 + 4: LAUNCH_WD(4, 4); break;
             case 4 * 8 + 2: LAUNCH_WD(4, 2); break;

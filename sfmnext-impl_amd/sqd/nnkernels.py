@@ -3,6 +3,7 @@
 Each Function takes/returns tensors whose logical shape is NCHW and whose memory is NHWC
 (torch.channels_last); the kernels see them as row-major [M = N*H*W, C] matrices."""
 import ctypes
+import os
 
 import torch
 
@@ -12,8 +13,15 @@ from .ops import _ptr, _stream
 ACT = {None: 0, "relu": 1, "leaky_relu": 2}
 
 
+_DEBUG_COPIES = bool(os.environ.get("SQD_DEBUG_COPIES"))
+
+
 def _cl(x):
     """NHWC-contiguous view/copy of a 4-D tensor."""
+    if _DEBUG_COPIES and not x.is_contiguous(memory_format=torch.channels_last):
+        import traceback
+        fr = traceback.extract_stack(limit=4)[:-1]
+        print("sqd: layout copy", tuple(x.shape), tuple(x.stride()), " <- ".join("%s:%d" % (f.name, f.lineno) for f in reversed(fr)), flush=True)
     return x.contiguous(memory_format=torch.channels_last)
 
 
@@ -188,11 +196,31 @@ def conv2d_native(x, conv, act=None):
     return Conv2d.apply(x, conv.weight, conv.bias, s[0], p[0], act)
 
 
+_DEFER_COUNTERS = False
+_PENDING_COUNTERS = []
+
+
+def defer_bn_counters(on):
+    """Training loops that call flush_bn_counters() once per step set this: the ~60 num_batches_tracked += 1
+    launches of a forward pass become one multi-tensor add."""
+    global _DEFER_COUNTERS
+    _DEFER_COUNTERS = bool(on)
+
+
+def flush_bn_counters():
+    if _PENDING_COUNTERS:
+        torch._foreach_add_(_PENDING_COUNTERS, 1)
+        _PENDING_COUNTERS.clear()
+
+
 def batch_norm_act(x, bn, act, residual=None):
     """nn.BatchNorm2d module `bn` (parameters, running buffers, momentum, eps) applied through the fused
     kernels; keeps nn.BatchNorm2d's bookkeeping (num_batches_tracked)."""
     training = bn.training or bn.running_mean is None
     if training and bn.num_batches_tracked is not None:
-        bn.num_batches_tracked.add_(1)
+        if _DEFER_COUNTERS:
+            _PENDING_COUNTERS.append(bn.num_batches_tracked)
+        else:
+            bn.num_batches_tracked.add_(1)
     return BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, training,
                               0.1 if bn.momentum is None else bn.momentum, bn.eps, act)

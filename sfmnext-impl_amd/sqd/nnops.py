@@ -28,7 +28,7 @@ def _act(y, act):
     raise ValueError(act)
 
 
-NATIVE_CONV = False          # --sqd_native_conv: implicit-GEMM kernels of csrc/conv.hip instead of ATen/MIOpen
+NATIVE_CONV = False          # set by the Trainer (default on; --sqd_aten_conv is the A/B switch back to ATen/MIOpen)
 
 
 def set_native_conv(on):

@@ -29,7 +29,7 @@ from torch.utils.data import DataLoader
 import datasets
 import networks
 from layers import compute_depth_errors, transformation_from_parameters
-from sqd import ddp, ops
+from sqd import ddp, nnkernels, ops
 from sqd.optim import FusedAdam
 from utils import normalize_image, sec_to_hm_str
 
@@ -82,9 +82,10 @@ class Trainer:
         if self.opt.sqd_miopen_find:
             torch.backends.cudnn.benchmark = True
         from sqd import nnops
-        nnops.set_native_conv(self.opt.sqd_native_conv)
-        if self.opt.sqd_native_conv:
+        nnops.set_native_conv(not self.opt.sqd_aten_conv)
+        if not self.opt.sqd_aten_conv:
             self.opt.sqd_channels_last = True          # the native kernels are NHWC / KRSC only
+        nnkernels.defer_bn_counters(True)              # flushed at the end of process_batch
         if self.opt.sqd_channels_last:
             for m in self.models.values():
                 m.to(memory_format=torch.channels_last)
@@ -224,6 +225,7 @@ class Trainer:
         outputs = self.models["depth"](features)
         if self.use_pose_net:
             outputs.update(self.predict_poses(inputs, features))
+        nnkernels.flush_bn_counters()                  # one multi-tensor += 1 for every BatchNorm that ran in training mode
         self.generate_images_pred(inputs, outputs)
         losses = self.compute_losses(inputs, outputs)
         return outputs, losses

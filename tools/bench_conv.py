@@ -13,6 +13,7 @@ from sqd import nnkernels  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--N", type=int, default=12)
+ap.add_argument("--only", default="", help="comma-separated substrings of layer names")
 args = ap.parse_args()
 N = args.N
 L = [  # name, C, H, W, K, R, stride, pad, count (occurrences per forward)
@@ -60,6 +61,8 @@ tot = {"n_f": 0, "n_d": 0, "n_w": 0, "a_f": 0, "a_d": 0, "a_w": 0}
 print("%-22s %7s | %7s %7s | %7s %7s | %7s %7s   (us per launch, C-ABI called back to back on preallocated buffers)" %
       ("layer", "GFLOP", "nat fwd", "at fwd", "nat dg", "at dg", "nat wg", "at wg"))
 for name, C, H, W, K, R, st, pad, cnt in L:
+    if args.only and not any(k in name for k in args.only.split(",")):
+        continue
     conv = nn.Conv2d(C, K, R, st, pad, bias=False).cuda().to(memory_format=torch.channels_last)
     x = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
     w = conv.weight.detach()
