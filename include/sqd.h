@@ -231,6 +231,21 @@ int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *
 int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C, int K,
                    int R, int S, int stride, int pad, int Ho, int Wo, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * (11) adaptive-bins depth head.  replaces reference networks/depth_decoder_QTR.py:61-70 (convert_to_prob =
+ * Conv2d(Q, D, 1) + Softmax(dim=1), then pred = sum_d out[d] * centers[b, d]).
+ * energy [B,Q,N] (the planar energy maps the Self Query Layer writes, N = h*w), weight [D,Q] (the 1x1 filter),
+ * bias [D], centers [B,D] -> pred [B,N].  1 <= Q, D <= 128.  fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * bwd: g_pred [B,N] -> g_energy [B,Q,N], g_weight [D,Q], g_bias [D], g_centers [B,D];
+ *      part: workspace of sqd_bins_workspace floats.  Deterministic (fixed-order partial sums). */
+int sqd_bins_supported(int Q, int D);
+int sqd_bins_workspace(int B, int Q, int D, int N, int64_t *part_floats);
+int sqd_bins_fwd(const float *energy, const float *weight, const float *bias, const float *centers, float *pred, int B, int Q,
+                 int D, int N, void *stream);
+int sqd_bins_bwd(const float *energy, const float *weight, const float *bias, const float *centers, const float *g_pred,
+                 float *g_energy, float *g_weight, float *g_bias, float *g_centers, float *part, int B, int Q, int D, int N,
+                 void *stream);
+
 #ifdef __cplusplus
 }
 #endif

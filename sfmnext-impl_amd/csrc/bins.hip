@@ -1,0 +1,440 @@
+// bins.hip — the adaptive-bins depth head of Depth_Decoder_QueryTr as one kernel pair.
+// replaces: reference networks/depth_decoder_QTR.py:61-70
+//     out  = softmax_d( conv1x1(energy_maps) )            convert_to_prob: [B,Q,h,w] -> [B,D,h,w]
+//     pred = sum_d out[d] * centers[b, d]                  centers = mid-points of the cumulated bin widths
+// (conv 1x1 + channel softmax + expectation: three tensor passes over [B,D,h,w] and, with ATen, four layout copies).
+//
+// forward : per 32-pixel tile  logits[d, p] = W[d, :] . E[:, p] + bias[d]  on v_mfma_f32_32x32x2_f32 with the energy
+//           maps read straight from their planar [B,Q,N] layout as the B operand (lane = pixel: coalesced 128-byte
+//           rows), W held in LDS as the A operand.  The accumulator layout leaves each pixel's logits in one lane
+//           pair (lane, lane^32), so the softmax and the expectation are in-register; only pred [B,N] is written.
+// backward: recomputes the tile's logits, then
+//           dlogit[d,p] = prob[d,p] * g[p] * (c[d] - pred[p])
+//           dE[q,p]     = sum_d W[d,q] dlogit[d,p]     MFMA fed from the accumulator registers (contraction over the
+//                                                      producer's row dimension — no LDS round trip)
+//           dW[d,q]     = sum_p dlogit[d,p] E[q,p]     MFMA, dlogit transposed through a per-wave LDS tile, E re-read
+//                                                      as float4 along the pixels
+//           dbias[d], dcenters[b,d]                    row sums taken while the dW operand is read
+//           per-workgroup partials + one deterministic reduction kernel.
+// Roofline: HBM — forward reads 4*Q B/px, writes 4; backward reads 4*Q (+4*Q from L2), writes 4*Q.
+#include "sqd_common.h"
+
+namespace {
+using namespace sqd;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int PITCH = 36;                        // floats per row of the per-wave [d][32 pixels] tile (16-byte aligned rows)
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+// uniform base + 32-bit byte offset (saddr + voffset addressing: no 64-bit address arithmetic per access)
+__device__ __forceinline__ float ldg(const float *__restrict__ base, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ float4 ldg4(const float *__restrict__ base, unsigned byte_off) {
+    return *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ void stg(float *__restrict__ base, unsigned byte_off, float v) {
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+
+struct BinsDims {
+    int B, Q, D, N;
+};
+
+template <int DT, int QT>
+__device__ __forceinline__ void stage_weights(float *Wl, float *bl, const float *__restrict__ W, const float *__restrict__ bias, int D,
+                                              int Q) {
+    constexpr int QP = QT * 32 + 1;
+    for (int idx = threadIdx.x; idx < DT * 32 * QP; idx += 256) {
+        const int d = idx / QP, q = idx - d * QP;
+        Wl[idx] = (d < D && q < Q) ? W[d * Q + q] : 0.f;
+    }
+    for (int d = threadIdx.x; d < DT * 32; d += 256) bl[d] = d < D ? bias[d] : 0.f;
+}
+
+// logits of the 32 pixels p0..p0+31 of image b: acc[dt][r] = row d = dt*32 + acc_row(r, lane>>5), column = lane & 31
+template <int DT, int QT>
+__device__ __forceinline__ void tile_logits(const float *Wl, const float *__restrict__ Eb, int Q, int N, int p, bool pv, int lane,
+                                            f32x16 (&acc)[DT]) {
+    constexpr int QP = QT * 32 + 1;
+    const int i = lane & 31, kk = lane >> 5;
+    constexpr int G = 8, NG = QT * 16 / G;                 // energy planes are fetched G k-steps (2G planes) at a time
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    const unsigned step = 2u * N * 4u;
+    unsigned off = ((unsigned)kk * N + p) * 4u;
+    auto fetch = [&](int g, float *e) {
+#pragma unroll
+        for (int u = 0; u < G; ++u) {
+            const int q = 2 * (g * G + u) + kk;
+            e[u] = (pv && q < Q) ? ldg(Eb, off) : 0.f;
+            off += step;
+        }
+    };
+    float e0[G], e1[G];
+    fetch(0, e0);
+#pragma unroll 1
+    for (int g = 0; g < NG; g += 2) {
+        fetch(g + 1, e1);                                   // NG is even; planes past Q are masked
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma32(Wl[(dt * 32 + i) * QP + 2 * (g * G + u) + kk], e0[u], acc[dt]);
+        if (g + 2 < NG) fetch(g + 2, e0);
+#pragma unroll
+        for (int u = 0; u < G; ++u)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma32(Wl[(dt * 32 + i) * QP + 2 * ((g + 1) * G + u) + kk], e1[u], acc[dt]);
+    }
+}
+
+// in: acc = raw logits; out: acc = exp(logit - max) (0 for padded d), returns 1/sum and the expectation
+template <int DT>
+__device__ __forceinline__ void tile_softmax(f32x16 (&acc)[DT], const float *bl, const float *cl, int D, int lane, float &inv_sum,
+                                             float &pred) {
+    const int h = lane >> 5;
+    float m = -INFINITY;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = dt * 32 + acc_row(r, h);
+            const float v = d < D ? acc[dt][r] + bl[d] : -INFINITY;
+            acc[dt][r] = v;
+            m = fmaxf(m, v);
+        }
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float se = 0.f, dot = 0.f;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d = dt * 32 + acc_row(r, h);
+            const float ex = __expf(acc[dt][r] - m);
+            acc[dt][r] = ex;
+            se += ex;
+            dot = fmaf(ex, cl[d], dot);
+        }
+    se += __shfl_xor(se, 32, 64);
+    dot += __shfl_xor(dot, 32, 64);
+    inv_sum = 1.f / se;
+    pred = dot * inv_sum;
+}
+
+template <int DT, int QT>
+__global__ __launch_bounds__(256) void bins_fwd_kernel(const float *__restrict__ E, const float *__restrict__ W,
+                                                       const float *__restrict__ bias, const float *__restrict__ centers,
+                                                       float *__restrict__ pred_out, BinsDims dm, int tiles_per_image) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int QP = QT * 32 + 1;
+    float *Wl = smem, *bl = Wl + DT * 32 * QP, *cl = bl + DT * 32;
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    stage_weights<DT, QT>(Wl, bl, W, bias, dm.D, dm.Q);
+    for (int d = threadIdx.x; d < DT * 32; d += 256) cl[d] = d < dm.D ? centers[b * dm.D + d] : 0.f;
+    __syncthreads();
+    const float *Eb = E + (size_t)b * dm.Q * dm.N;
+    for (int tile = blockIdx.x * 4 + wave; tile < tiles_per_image; tile += gridDim.x * 4) {
+        const int p = tile * 32 + (lane & 31);
+        const bool pv = p < dm.N;
+        f32x16 acc[DT];
+        tile_logits<DT, QT>(Wl, Eb, dm.Q, dm.N, p, pv, lane, acc);
+        float inv_sum, pred;
+        tile_softmax<DT>(acc, bl, cl, dm.D, lane, inv_sum, pred);
+        if (pv && lane < 32) pred_out[(size_t)b * dm.N + p] = pred;
+    }
+}
+
+template <int DT, int QT>
+__global__ __launch_bounds__(256) void bins_bwd_kernel(const float *__restrict__ E, const float *__restrict__ W,
+                                                       const float *__restrict__ bias, const float *__restrict__ centers,
+                                                       const float *__restrict__ g_pred, float *__restrict__ dE,
+                                                       float *__restrict__ part_w, float *__restrict__ part_v, BinsDims dm,
+                                                       int tiles_per_image) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int QP = QT * 32 + 1, DP = DT * 32;
+    float *Wl = smem, *bl = Wl + DP * QP, *cl = bl + DP;
+    float *predl = cl + DP;                                   // [4 waves][32]
+    float *tiles = predl + 128;                               // [4 waves][DP][PITCH]: prob*g of the wave's tile, [d][pixel]
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    stage_weights<DT, QT>(Wl, bl, W, bias, dm.D, dm.Q);
+    for (int d = threadIdx.x; d < DP; d += 256) cl[d] = d < dm.D ? centers[b * dm.D + d] : 0.f;
+    __syncthreads();
+    const float *Eb = E + (size_t)b * dm.Q * dm.N;
+    float *dEb = dE + (size_t)b * dm.Q * dm.N;
+    float *tl = tiles + wave * DP * PITCH, *pl = predl + wave * 32;
+    const bool vec_ok = (dm.N & 3) == 0;
+
+    f32x16 accW[DT][QT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accW[dt][qt][r] = 0.f;
+    float dbia[DT], dcen[DT], ci[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        dbia[dt] = 0.f;
+        dcen[dt] = 0.f;
+        ci[dt] = cl[dt * 32 + i];
+    }
+
+    for (int tile = blockIdx.x * 4 + wave; tile < tiles_per_image; tile += gridDim.x * 4) {
+        const int p0 = tile * 32, p = p0 + i;
+        const bool pv = p < dm.N;
+        f32x16 acc[DT];
+        tile_logits<DT, QT>(Wl, Eb, dm.Q, dm.N, p, pv, lane, acc);
+        float inv_sum, pred;
+        tile_softmax<DT>(acc, bl, cl, dm.D, lane, inv_sum, pred);
+        const float g = pv ? g_pred[(size_t)b * dm.N + p] * inv_sum : 0.f;      // g[p] / sum: acc holds un-normalised exp
+        if (lane < 32) pl[i] = pred;
+        // prob*g -> LDS tile [d][pixel] (operand of the dW product); dlogit stays in acc (operand of the dE product)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d = dt * 32 + acc_row(r, h);
+                const float pg = acc[dt][r] * g;
+                tl[d * PITCH + i] = pg;
+                acc[dt][r] = pg * (cl[d] - pred);
+            }
+        // ---- dE[q, p] = sum_d W[d, q] * dlogit[d, p]
+#pragma unroll 1
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x16 accE;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accE[r] = 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    accE = mfma32(Wl[(dt * 32 + acc_row(r, h)) * QP + qt * 32 + i], acc[dt][r], accE);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qt * 32 + acc_row(r, h);
+                if (pv && q < dm.Q) stg(dEb, ((unsigned)q * dm.N + p) * 4u, accE[r]);
+            }
+        }
+        // ---- dW[d, q] += sum_p dlogit[d, p] * E[q, p]; k-step (gq, e): half-wave 0 takes pixel 8gq+e, half-wave 1 pixel 8gq+4+e
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 1
+        for (int gq = 0; gq < 4; ++gq) {
+            const int px = 8 * gq + 4 * h;
+            const float4 pr4 = *reinterpret_cast<const float4 *>(pl + px);
+            const float prv[4] = {pr4.x, pr4.y, pr4.z, pr4.w};
+            float dlg[DT][4], ev[QT][4];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const float4 t4 = *reinterpret_cast<const float4 *>(tl + (dt * 32 + i) * PITCH + px);
+                const float pgv[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dlg[dt][e] = pgv[e] * (ci[dt] - prv[e]);
+                    dcen[dt] += pgv[e];
+                    dbia[dt] += dlg[dt][e];
+                }
+            }
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const int q = qt * 32 + i;
+                const unsigned off = ((unsigned)q * dm.N + p0 + px) * 4u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) ev[qt][e] = 0.f;
+                if (q < dm.Q) {
+                    if (vec_ok && p0 + px + 3 < dm.N) {
+                        const float4 t4 = ldg4(Eb, off);
+                        ev[qt][0] = t4.x; ev[qt][1] = t4.y; ev[qt][2] = t4.z; ev[qt][3] = t4.w;
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (p0 + px + e < dm.N) ev[qt][e] = ldg(Eb, off + 4u * e);
+                    }
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) accW[dt][qt] = mfma32(dlg[dt][e], ev[qt][e], accW[dt][qt]);
+        }
+        __builtin_amdgcn_wave_barrier();                       // the tile is rewritten by the next iteration
+    }
+
+    // ---- workgroup partials: the 4 waves add into one LDS image in a fixed order (wave 0 stores, 1..3 add)
+    __syncthreads();
+    float *red = tiles;                                        // reuse: DP x QT*32 floats <= 4 * DP * PITCH
+    constexpr int QW = QT * 32;
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float *dst = red + (dt * 32 + acc_row(r, h)) * QW + qt * 32 + i;
+                        *dst = (w == 0 ? 0.f : *dst) + accW[dt][qt][r];
+                    }
+        }
+        __syncthreads();
+    }
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    float *pw = part_w + (size_t)wg * dm.D * dm.Q;
+    for (int idx = threadIdx.x; idx < dm.D * dm.Q; idx += 256) {
+        const int d = idx / dm.Q, q = idx - d * dm.Q;
+        pw[idx] = red[d * QW + q];
+    }
+    // dbias / dcenters: lane (d = dt*32 + i, half h) holds the sum over its half of the pixels
+    __syncthreads();
+    float *vred = red;                                         // [4 waves][2][DP]
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const float sb = dbia[dt] + __shfl_xor(dbia[dt], 32, 64), sc = dcen[dt] + __shfl_xor(dcen[dt], 32, 64);
+        if (h == 0) {
+            vred[(wave * 2 + 0) * DP + dt * 32 + i] = sb;
+            vred[(wave * 2 + 1) * DP + dt * 32 + i] = sc;
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * DP; idx += 256) {
+        const int which = idx / DP, d = idx - which * DP;
+        if (d < dm.D) {
+            float s = 0.f;
+            for (int w = 0; w < 4; ++w) s += vred[(w * 2 + which) * DP + d];
+            part_v[((size_t)wg * 2 + which) * dm.D + d] = s;
+        }
+    }
+}
+
+// out[y][i] = sum_{s < splits} part[(y*splits + s)*n + i]: a block owns 32 columns, its 8 thread groups add the
+// partials s = g, g+8, ... in order, then a fixed-order tree over the groups (deterministic)
+__global__ __launch_bounds__(256) void rows_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, int n, int splits) {
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + col;
+    const float *src = part + (size_t)blockIdx.y * splits * n;
+    float a = 0.f;
+    if (i < n)
+        for (int s = grp; s < splits; s += 8) a += src[(size_t)s * n + i];
+    red[grp][col] = a;
+    __syncthreads();
+    for (int w = 4; w >= 1; w >>= 1) {
+        if (grp < w) {
+            a += red[grp + w][col];
+            red[grp][col] = a;
+        }
+        __syncthreads();
+    }
+    if (grp == 0 && i < n) out[(size_t)blockIdx.y * n + i] = a;
+}
+// tmp [B][2][D] (per-image sums of the dbias / dcenters partials) -> dbias [D] (summed over the images), dcenters [B][D]
+__global__ __launch_bounds__(256) void bins_vec_finalize_kernel(const float *__restrict__ tmp, float *__restrict__ dbias,
+                                                                float *__restrict__ dcenters, int B, int D) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx < D) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += tmp[(size_t)b * 2 * D + idx];
+        dbias[idx] = s;
+    } else if (idx < D + B * D) {
+        const int t = idx - D, b = t / D, d = t - b * D;
+        dcenters[t] = tmp[(size_t)b * 2 * D + D + d];
+    }
+}
+
+struct BinsPlan {
+    int dt, wg_per_image, tiles_per_image;
+    size_t smem_fwd, smem_bwd;
+};
+BinsPlan plan_bins(int B, int Q, int D, int N) {
+    BinsPlan p;
+    p.dt = (Q <= 64 && D <= 64) ? 2 : 4;
+    p.tiles_per_image = (N + 31) / 32;
+    // ~3 workgroups per CU overall, at least 2 tiles per wave
+    int wg = (768 + B - 1) / B;
+    const int max_wg = (p.tiles_per_image + 7) / 8;
+    if (wg > max_wg) wg = max_wg;
+    if (wg < 1) wg = 1;
+    p.wg_per_image = wg;
+    const int DP = p.dt * 32, QP = p.dt * 32 + 1;
+    p.smem_fwd = (size_t)(DP * QP + 2 * DP) * 4;
+    p.smem_bwd = (size_t)(DP * QP + 2 * DP + 128 + 4 * DP * PITCH) * 4;
+    return p;
+}
+template <typename K>
+int set_smem(K kernel, size_t bytes) {
+    return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess
+               ? 0
+               : 1;
+}
+}  // namespace
+
+extern "C" int sqd_bins_supported(int Q, int D) { return (Q >= 1 && Q <= 128 && D >= 1 && D <= 128) ? 1 : 0; }
+
+extern "C" int sqd_bins_workspace(int B, int Q, int D, int N, int64_t *part_floats) {
+    SQD_CHECK_ARG(sqd_bins_supported(Q, D), "sqd_bins: Q=%d and D=%d must be in 1..128", Q, D);
+    const BinsPlan p = plan_bins(B, Q, D, N);
+    if (part_floats) *part_floats = (int64_t)p.wg_per_image * B * ((int64_t)D * Q + 2 * D) + (int64_t)B * 2 * D;
+    return SQD_OK;
+}
+
+// energy [B,Q,N], weight [D,Q], bias [D], centers [B,D] -> pred [B,N]
+extern "C" int sqd_bins_fwd(const float *energy, const float *weight, const float *bias, const float *centers, float *pred, int B,
+                            int Q, int D, int N, void *stream) {
+    SQD_CHECK_ARG(energy && weight && bias && centers && pred, "sqd_bins_fwd: null pointer");
+    SQD_CHECK_ARG(B > 0 && N > 0 && (long long)N * 128 * 4 < (1ll << 32) && sqd_bins_supported(Q, D),
+                  "sqd_bins_fwd: unsupported dims B=%d Q=%d D=%d N=%d", B, Q, D, N);
+    const BinsPlan p = plan_bins(B, Q, D, N);
+    const BinsDims dm = {B, Q, D, N};
+    const dim3 grid(p.wg_per_image, B);
+    (void)hipGetLastError();
+    if (p.dt == 2) {
+        hipLaunchKernelGGL((bins_fwd_kernel<2, 2>), grid, dim3(256), p.smem_fwd, (hipStream_t)stream, energy, weight, bias, centers, pred,
+                           dm, p.tiles_per_image);
+    } else {
+        static int once = set_smem(bins_fwd_kernel<4, 4>, plan_bins(1, 128, 128, 32).smem_fwd);
+        SQD_CHECK_ARG(once == 0, "sqd_bins_fwd: cannot reserve %zu bytes of LDS", p.smem_fwd);
+        hipLaunchKernelGGL((bins_fwd_kernel<4, 4>), grid, dim3(256), p.smem_fwd, (hipStream_t)stream, energy, weight, bias, centers, pred,
+                           dm, p.tiles_per_image);
+    }
+    SQD_CHECK_LAUNCH("sqd_bins_fwd");
+    return SQD_OK;
+}
+
+// g_pred [B,N] -> g_energy [B,Q,N], g_weight [D,Q], g_bias [D], g_centers [B,D]; part: sqd_bins_workspace floats
+extern "C" int sqd_bins_bwd(const float *energy, const float *weight, const float *bias, const float *centers, const float *g_pred,
+                            float *g_energy, float *g_weight, float *g_bias, float *g_centers, float *part, int B, int Q, int D,
+                            int N, void *stream) {
+    SQD_CHECK_ARG(energy && weight && bias && centers && g_pred && g_energy && g_weight && g_bias && g_centers && part,
+                  "sqd_bins_bwd: null pointer");
+    SQD_CHECK_ARG(B > 0 && N > 0 && (long long)N * 128 * 4 < (1ll << 32) && sqd_bins_supported(Q, D),
+                  "sqd_bins_bwd: unsupported dims B=%d Q=%d D=%d N=%d", B, Q, D, N);
+    const BinsPlan p = plan_bins(B, Q, D, N);
+    const BinsDims dm = {B, Q, D, N};
+    const dim3 grid(p.wg_per_image, B);
+    float *part_w = part, *part_v = part + (size_t)p.wg_per_image * B * D * Q;
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipGetLastError();
+    if (p.dt == 2) {
+        hipLaunchKernelGGL((bins_bwd_kernel<2, 2>), grid, dim3(256), p.smem_bwd, st, energy, weight, bias, centers, g_pred, g_energy,
+                           part_w, part_v, dm, p.tiles_per_image);
+    } else {
+        static int once = set_smem(bins_bwd_kernel<4, 4>, plan_bins(1, 128, 128, 32).smem_bwd);
+        SQD_CHECK_ARG(once == 0, "sqd_bins_bwd: cannot reserve %zu bytes of LDS", p.smem_bwd);
+        hipLaunchKernelGGL((bins_bwd_kernel<4, 4>), grid, dim3(256), p.smem_bwd, st, energy, weight, bias, centers, g_pred, g_energy,
+                           part_w, part_v, dm, p.tiles_per_image);
+    }
+    float *tmp = part_v + (size_t)p.wg_per_image * B * 2 * D;
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3((D * Q + 31) / 32, 1), dim3(256), 0, st, part_w, g_weight, D * Q, p.wg_per_image * B);
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3((2 * D + 31) / 32, B), dim3(256), 0, st, part_v, tmp, 2 * D, p.wg_per_image);
+    hipLaunchKernelGGL(bins_vec_finalize_kernel, dim3((D + B * D + 255) / 256), dim3(256), 0, st, tmp, g_bias, g_centers, B, D);
+    SQD_CHECK_LAUNCH("sqd_bins_bwd");
+    return SQD_OK;
+}

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 BACKEND = {
     "conv2d": "aten", "conv_bn_act": "aten conv + hip bn/act/residual", "maxpool3x3s2": "aten", "upsample_concat": "hip",
-    "linear": "aten", "transformer_encoder": "aten", "full_query_layer": "hip", "bins_head": "aten",
+    "linear": "aten", "transformer_encoder": "aten", "full_query_layer": "hip", "bins_head": "hip",
 }
 
 
@@ -115,9 +115,16 @@ def full_query_layer(x, queries):
 def bins_head(energy_maps, conv1x1, y, min_val, max_val):
     """1x1 conv + channel softmax over the energy maps, expected value over the adaptive bin centres
     (reference networks/depth_decoder_QTR.py:61-70).  y [B,dim_out] = normalised bin widths."""
-    out = torch.softmax(F.conv2d(energy_maps, conv1x1.weight, conv1x1.bias), dim=1)
     widths = (max_val - min_val) * y
     widths = F.pad(widths, (1, 0), mode="constant", value=min_val)
     edges = torch.cumsum(widths, dim=1)
     centers = 0.5 * (edges[:, :-1] + edges[:, 1:])
+    if energy_maps.is_cuda:
+        from . import ops
+        Q, D = energy_maps.shape[1], conv1x1.weight.shape[0]
+        if not ops.bins_supported(Q, D):
+            raise RuntimeError("sqd: bins head kernel supports Q, dim_out <= 128; got Q=%d dim_out=%d" % (Q, D))
+        return ops.BinsHead.apply(energy_maps, conv1x1.weight, conv1x1.bias, centers)
+    # host tensors: only the CPU wiring tests come here
+    out = torch.softmax(F.conv2d(energy_maps, conv1x1.weight, conv1x1.bias), dim=1)
     return torch.sum(out * centers.view(centers.shape[0], -1, 1, 1), dim=1, keepdim=True)

@@ -318,6 +318,45 @@ class SelfQueryLayer(torch.autograd.Function):
         return g_x, g_K
 
 
+class BinsHead(torch.autograd.Function):
+    """Adaptive-bins head of Depth_Decoder_QueryTr (reference networks/depth_decoder_QTR.py:61-70) as one kernel pair:
+    forward(energy [B,Q,h,w], weight [D,Q,1,1], bias [D], centers [B,D]) -> pred [B,1,h,w]
+        = sum_d softmax_d(conv1x1(energy))[d] * centers[:, d]."""
+
+    @staticmethod
+    def forward(ctx, energy, weight, bias, centers):
+        B, Q, h, w = energy.shape
+        D = weight.shape[0]
+        energy, centers, bias = energy.contiguous(), centers.contiguous(), bias.contiguous()
+        wmat = weight.reshape(D, Q).contiguous()
+        _req(energy, wmat, bias, centers)
+        pred = torch.empty(B, 1, h, w, device=energy.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_bins_fwd(_ptr(energy), _ptr(wmat), _ptr(bias), _ptr(centers), _ptr(pred), B, Q, D, h * w, _stream()),
+                 "bins_fwd")
+        ctx.save_for_backward(energy, wmat, bias, centers)
+        ctx.wshape = weight.shape
+        return pred
+
+    @staticmethod
+    def backward(ctx, g_pred):
+        energy, wmat, bias, centers = ctx.saved_tensors
+        B, Q, h, w = energy.shape
+        D = wmat.shape[0]
+        g_pred = g_pred.contiguous()
+        n = ctypes.c_int64(0)
+        _l.check(_l.lib().sqd_bins_workspace(B, Q, D, h * w, ctypes.byref(n)), "bins_workspace")
+        part = torch.empty(n.value, device=energy.device, dtype=torch.float32)
+        g_e, g_w = torch.empty_like(energy), torch.empty_like(wmat)
+        g_b, g_c = torch.empty_like(bias), torch.empty_like(centers)
+        _l.check(_l.lib().sqd_bins_bwd(_ptr(energy), _ptr(wmat), _ptr(bias), _ptr(centers), _ptr(g_pred), _ptr(g_e), _ptr(g_w),
+                                       _ptr(g_b), _ptr(g_c), _ptr(part), B, Q, D, h * w, _stream()), "bins_bwd")
+        return g_e, g_w.view(ctx.wshape), g_b, g_c
+
+
+def bins_supported(Q, D):
+    return 1 <= Q <= 128 and 1 <= D <= 128
+
+
 def sql_supported(E, Q):
     return E in (16, 32) and 1 <= Q <= 128
 

@@ -1,0 +1,75 @@
+"""GPU parity of the fused adaptive-bins head (csrc/bins.hip) against the torch-fp32 composite the reference
+runs (networks/depth_decoder_QTR.py:61-70): conv1x1 -> softmax(dim=1) -> sum(out * centers)."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+CASES = [  # B, Q, D, h, w
+    (2, 64, 64, 12, 40),       # config B sizes (tile-aligned)
+    (2, 64, 64, 7, 9),         # ragged pixel count (63: not a multiple of 4)
+    (3, 120, 100, 6, 20),      # args_files: query_nums 120, dim_out 100 (padded rows / planes)
+    (1, 128, 128, 8, 16),      # maximum sizes
+    (2, 16, 8, 5, 13),         # tiny Q / D
+    (12, 64, 64, 96, 320),     # full config-B head
+]
+
+
+def composite(energy, weight, bias, centers):
+    out = torch.softmax(F.conv2d(energy, weight, bias), dim=1)
+    return torch.sum(out * centers.view(centers.shape[0], -1, 1, 1), dim=1, keepdim=True)
+
+
+@pytest.mark.parametrize("B,Q,D,h,w", CASES)
+def test_bins_head_fwd_bwd(B, Q, D, h, w):
+    from sqd import ops
+    g = torch.Generator().manual_seed(B * 1000 + Q + D + h)
+    energy = 2.0 * torch.randn(B, Q, h, w, generator=g)
+    weight = 0.3 * torch.randn(D, Q, 1, 1, generator=g)
+    bias = 0.1 * torch.randn(D, generator=g)
+    centers = torch.sort(torch.rand(B, D, generator=g) * 80.0, dim=1).values
+    gout = torch.randn(B, 1, h, w, generator=g)
+    big = B * h * w > 100000
+    dt = torch.float32 if big else torch.float64          # fp64 oracle for the small cases, fp32 CPU composite for the full size
+    ref_in = [t.detach().clone().to(dt).requires_grad_(True) for t in (energy, weight, bias, centers)]
+    ref = composite(*ref_in)
+    ref.backward(gout.to(dt))
+    dev_in = [t.detach().clone().cuda().requires_grad_(True) for t in (energy, weight, bias, centers)]
+    out = ops.BinsHead.apply(*dev_in)
+    out.backward(gout.cuda())
+    torch.cuda.synchronize()
+    assert out.shape == (B, 1, h, w)
+    # tolerance: 1e-4 relative (north_star), fp32 accumulation over Q terms + exp
+    assert torch.allclose(out.cpu().double(), ref.detach().double(), rtol=1e-4, atol=1e-4), float((out.cpu().double() - ref.detach().double()).abs().max())
+    for name, a, r in zip(("energy", "weight", "bias", "centers"), dev_in, ref_in):
+        ga, gr = a.grad.cpu().double(), r.grad.double()
+        scale = float(gr.abs().max()) + 1e-12
+        err = float((ga - gr).abs().max()) / scale
+        # weight / bias / centers gradients are sums over B*h*w pixels: fp32 summation-order noise grows with the count
+        tol = 2e-4 if not big else 2e-3
+        assert err < tol, (name, err)
+
+
+def test_bins_head_rejects():
+    from sqd import ops
+    with pytest.raises(RuntimeError):
+        ops.BinsHead.apply(torch.randn(1, 8, 4, 4), torch.randn(8, 8, 1, 1), torch.randn(8), torch.rand(1, 8))      # host tensors
+    e = torch.randn(1, 130, 4, 4, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.BinsHead.apply(e, torch.randn(8, 130, 1, 1, device="cuda"), torch.randn(8, device="cuda"), torch.rand(1, 8, device="cuda"))
+
+
+def test_bins_head_deterministic():
+    from sqd import ops
+    torch.manual_seed(3)
+    args = [torch.randn(4, 64, 24, 80, device="cuda"), 0.3 * torch.randn(64, 64, 1, 1, device="cuda"), torch.randn(64, device="cuda"),
+            torch.rand(4, 64, device="cuda") * 80]
+    gout = torch.randn(4, 1, 24, 80, device="cuda")
+    res = []
+    for _ in range(2):
+        a = [t.clone().requires_grad_(True) for t in args]
+        ops.BinsHead.apply(*a).backward(gout)
+        res.append([t.grad.clone() for t in a])
+    for x, y in zip(*res):
+        assert torch.equal(x, y)
