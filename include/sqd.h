@@ -209,6 +209,11 @@ int sqd_ssim_fwd(const float *x, const float *y, float *out, int planes, int H, 
 int sqd_adam_chunk_elems(void);
 int sqd_adam_step(const void *recs, const void *grads, const void *chunks, int nchunks, double lr, double beta1,
                   double beta2, double eps, int step, void *stream);
+/* graph-capturable form: the two step-dependent scalars live in device memory (hyper_dev[0] = lr / (1 - beta1^step),
+ * hyper_dev[1] = 1 / sqrt(1 - beta2^step)); sqd_adam_hyper computes them on the host exactly as sqd_adam_step does. */
+int sqd_adam_hyper(double lr, double beta1, double beta2, int step, float *hyper_host);
+int sqd_adam_step_dev(const void *recs, const void *grads, const void *chunks, int nchunks, const float *hyper_dev,
+                      double beta1, double beta2, double eps, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (10) convolution as implicit GEMM on the fp32 matrix cores, channels-last

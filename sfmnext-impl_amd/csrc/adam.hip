@@ -18,7 +18,11 @@ struct TensorRec {                   // one parameter tensor (device table, rebu
 
 __global__ __launch_bounds__(256) void adam_kernel(const TensorRec *__restrict__ recs, const float *const *__restrict__ grads,
                                                    const int2 *__restrict__ chunks, float step_size, float omb1, float beta2,
-                                                   float omb2, float eps, float inv_bc2_sqrt) {
+                                                   float omb2, float eps, float inv_bc2_sqrt, const float *__restrict__ hyper) {
+    if (hyper) {                                     // step-dependent scalars from device memory (graph replay: the launch
+        step_size = hyper[0];                        // arguments are frozen at capture time)
+        inv_bc2_sqrt = hyper[1];
+    }
     const int2 ch = chunks[blockIdx.x];              // (tensor index, chunk index inside the tensor)
     const TensorRec r = recs[ch.x];
     const float *__restrict__ g = grads[ch.x];
@@ -71,7 +75,29 @@ extern "C" int sqd_adam_step(const void *recs, const void *grads, const void *ch
     const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
     (void)hipGetLastError();
     hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const TensorRec *)recs,
-                       (const float *const *)grads, (const int2 *)chunks, step_size, omb1, (float)beta2, omb2, (float)eps, inv_bc2_sqrt);
+                       (const float *const *)grads, (const int2 *)chunks, step_size, omb1, (float)beta2, omb2, (float)eps, inv_bc2_sqrt,
+                       (const float *)nullptr);
     SQD_CHECK_LAUNCH("sqd_adam_step");
+    return SQD_OK;
+}
+
+// host side of the step-dependent scalars: hyper[0] = lr / (1 - beta1^step), hyper[1] = 1 / sqrt(1 - beta2^step)
+extern "C" int sqd_adam_hyper(double lr, double beta1, double beta2, int step, float *hyper_host) {
+    SQD_CHECK_ARG(hyper_host && step >= 1, "sqd_adam_hyper: bad arguments");
+    hyper_host[0] = (float)(lr / (1.0 - pow(beta1, step)));
+    hyper_host[1] = (float)(1.0 / sqrt(1.0 - pow(beta2, step)));
+    return SQD_OK;
+}
+
+// the same step with hyper (2 device floats, see sqd_adam_hyper) read by the kernel: capturable in a hipGraph whose
+// replays only need the two floats refreshed
+extern "C" int sqd_adam_step_dev(const void *recs, const void *grads, const void *chunks, int nchunks, const float *hyper_dev,
+                                 double beta1, double beta2, double eps, void *stream) {
+    SQD_CHECK_ARG(recs && grads && chunks && nchunks > 0 && hyper_dev, "sqd_adam_step_dev: bad arguments");
+    const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const TensorRec *)recs,
+                       (const float *const *)grads, (const int2 *)chunks, 0.f, omb1, (float)beta2, omb2, (float)eps, 0.f, hyper_dev);
+    SQD_CHECK_LAUNCH("sqd_adam_step_dev");
     return SQD_OK;
 }

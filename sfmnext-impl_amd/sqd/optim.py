@@ -18,6 +18,7 @@ class FusedAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
         self._tables = {}
         self._ring = 0
+        self._graph_hyper = None      # set by begin_capture(): {group index: (pinned host [2], device [2])}
 
     def _build(self, gi, plist):
         L = _l.lib()
@@ -40,8 +41,68 @@ class FusedAdam(torch.optim.Adam):
         self._tables[gi] = tab
         return tab
 
+    # ---- hipGraph support: a captured step() launches sqd_adam_step_dev, whose step-dependent scalars are two device
+    # floats per group; refresh_hyper() (outside the graph, before every replay) advances the step counts and rewrites
+    # them, so StepLR and the bias corrections keep working across replays.
+    def begin_capture(self):
+        """Call before torch.cuda.graph(...): allocates what a capturing stream may not (pinned host buffers)."""
+        self._graph_hyper = {}
+        self._graph_ptrs = [torch.empty(max(1, len(g["params"])), dtype=torch.int64).pin_memory() for g in self.param_groups]
+
+    def refresh_hyper(self):
+        L = _l.lib()
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None or "step" in self.state[p]]
+            if not plist:
+                continue
+            if gi not in self._graph_hyper:
+                dev = plist[0].device
+                self._graph_hyper[gi] = (torch.zeros(2, dtype=torch.float32).pin_memory(), torch.zeros(2, dtype=torch.float32, device=dev))
+            host, devt = self._graph_hyper[gi]
+            for p in plist:
+                st = self.state[p]
+                if len(st) == 0:
+                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["step"] += 1
+            step = int(self.state[plist[0]]["step"].item())
+            b1, b2 = group["betas"]
+            _l.check(L.sqd_adam_hyper(float(group["lr"]), float(b1), float(b2), step, ctypes.c_void_p(host.data_ptr())), "adam_hyper")
+            devt.copy_(host, non_blocking=True)
+
+    def _step_captured(self):
+        L = _l.lib()
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None]
+            if not plist:
+                continue
+            tab = self._tables.get(gi)
+            keys = [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr() if "exp_avg" in self.state[p] else 0) for p in plist]
+            # the gradient buffers of a captured backward are fixed: their addresses are written once, from a pinned
+            # buffer that is never touched again (the copy is part of the graph)
+            if tab is None or tab["keys"] != keys:
+                raise RuntimeError("FusedAdam (graph capture): run at least one eager step first (the tensor tables are built there)")
+            host = self._graph_ptrs[gi][:len(plist)]
+            for i, p in enumerate(plist):
+                if p.grad.stride() != p.stride():            # a captured copy into the parameter's layout
+                    p.grad = p.grad.contiguous(memory_format=torch.channels_last if p.dim() == 4 and
+                                               p.is_contiguous(memory_format=torch.channels_last) and
+                                               not p.is_contiguous() else torch.contiguous_format)
+                host[i] = p.grad.data_ptr()
+            tab["graph_host"] = host
+            tab["gdev"].copy_(host, non_blocking=True)
+            b1, b2 = group["betas"]
+            _l.check(L.sqd_adam_step_dev(ctypes.c_void_p(tab["recs"].data_ptr()), ctypes.c_void_p(tab["gdev"].data_ptr()),
+                                         ctypes.c_void_p(tab["chunks"].data_ptr()), tab["nchunks"],
+                                         ctypes.c_void_p(self._graph_hyper[gi][1].data_ptr()), float(b1), float(b2),
+                                         float(group["eps"]), _stream()), "adam_step_dev")
+
     @torch.no_grad()
     def step(self, closure=None):
+        if self._graph_hyper is not None and torch.cuda.is_current_stream_capturing():
+            self._step_captured()
+            return None
         loss = closure() if closure is not None else None
         L = _l.lib()
         for gi, group in enumerate(self.param_groups):

@@ -85,7 +85,6 @@ class Trainer:
         nnops.set_native_conv(not self.opt.sqd_aten_conv)
         if not self.opt.sqd_aten_conv:
             self.opt.sqd_channels_last = True          # the native kernels are NHWC / KRSC only
-        nnkernels.defer_bn_counters(True)              # flushed at the end of process_batch
         if self.opt.sqd_channels_last:
             for m in self.models.values():
                 m.to(memory_format=torch.channels_last)
@@ -100,13 +99,17 @@ class Trainer:
             self.model_optimizer = FusedAdam(self.parameters_to_train, self.opt.learning_rate)
         self.model_lr_scheduler = optim.lr_scheduler.StepLR(self.model_optimizer, self.opt.scheduler_step_size, 0.1)
 
+        self._graph, self._graph_warm, self._capturing = None, 0, False
         all_params = [p for m in self.models.values() for p in m.parameters()]
         import torch.distributed as _dist
         self.reducer = ddp.GradBucketReducer(all_params, self.opt.sqd_bucket_mb) if _dist.is_initialized() else None
         if self.reducer is not None:
             self.reducer.broadcast_parameters(self.models.values())
 
+        self._graph_ok = not self.opt.sqd_no_graph and self.reducer is None and self.device.type == "cuda" and \
+            not self.opt.disable_automasking
         self._side_stream = torch.cuda.Stream(device=self.device)
+        self._graph_stream = torch.cuda.Stream(device=self.device) if self._graph_ok else None
         self._build_loaders()
         self.writers = {m: (_make_writer(os.path.join(self.log_path, m)) if self.rank == 0 else _NullWriter())
                         for m in ("train", "val")}
@@ -185,7 +188,59 @@ class Trainer:
                 self.save_model()
 
     def train_step(self, inputs):
-        """forward + backward + Adam on one batch (reference trainer.py:240-244)."""
+        """forward + backward + Adam on one batch (reference trainer.py:240-244).  On a single device the step is
+        captured into a hipGraph after a few eager steps and replayed from then on (--sqd_no_graph: always eager)."""
+        if self._graph_ok:
+            if self._graph is not None or self._graph_warm >= 3:
+                return self._train_step_graphed(inputs)
+            # the eager warm-up steps run on the stream the capture will use: autograd's AccumulateGrad nodes remember
+            # the stream they were created on, and a capture must not touch the default stream
+            self._graph_warm += 1
+            cur = torch.cuda.current_stream()
+            self._graph_stream.wait_stream(cur)
+            with torch.cuda.stream(self._graph_stream):
+                res = self._train_step_eager(inputs)
+            cur.wait_stream(self._graph_stream)
+            return res
+        return self._train_step_eager(inputs)
+
+    def _train_step_graphed(self, inputs):
+        if not self.opt.sqd_device_noise and ("noise", 0) not in inputs:
+            # host RNG as in the reference (trainer.py:516): drawn outside the graph, handed over as a static input
+            o = self.opt
+            inputs[("noise", 0)] = torch.randn(o.batch_size, len(o.frame_ids) - 1, o.height, o.width)
+        if self._graph is None:
+            self._capture(inputs)
+        for k, v in inputs.items():
+            self._static_in[k].copy_(v, non_blocking=True)
+        self.model_optimizer.refresh_hyper()
+        self._graph.replay()
+        return self._static_out
+
+    def _capture(self, inputs):
+        """One hipGraph for process_batch + backward + Adam.  The ~1200 kernel launches of a step then cost one graph
+        launch on the host (eager: ~23 ms of host time per 26 ms step)."""
+        self._static_in = {k: v.to(self.device).clone() for k, v in inputs.items()}
+        opt = self.model_optimizer
+        opt.zero_grad(set_to_none=True)
+        opt.begin_capture()
+        opt.refresh_hyper()                     # allocates the device scalars; the step counts it adds are undone below
+        for st in opt.state.values():
+            if "step" in st:
+                st["step"] -= 1
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        self._capturing = True
+        try:
+            with torch.cuda.graph(g, stream=self._graph_stream):
+                outputs, losses = self.process_batch(self._static_in)
+                losses["loss"].backward()
+                opt.step()
+        finally:
+            self._capturing = False
+        self._graph, self._static_out = g, (outputs, losses)
+
+    def _train_step_eager(self, inputs):
         outputs, losses = self.process_batch(inputs)
         if self.reducer is not None:
             self.reducer.zero_grad()
@@ -221,11 +276,15 @@ class Trainer:
         for key, ipt in inputs.items():
             inputs[key] = ipt.to(self.device, non_blocking=True)
         self._launch_identity(inputs)
-        features = self.models["encoder"](self._fmt(inputs["color_aug", 0, 0]))
-        outputs = self.models["depth"](features)
-        if self.use_pose_net:
-            outputs.update(self.predict_poses(inputs, features))
-        nnkernels.flush_bn_counters()                  # one multi-tensor += 1 for every BatchNorm that ran in training mode
+        nnkernels.defer_bn_counters(True)
+        try:
+            features = self.models["encoder"](self._fmt(inputs["color_aug", 0, 0]))
+            outputs = self.models["depth"](features)
+            if self.use_pose_net:
+                outputs.update(self.predict_poses(inputs, features))
+        finally:
+            nnkernels.flush_bn_counters()              # one multi-tensor += 1 for every BatchNorm that ran in training mode
+            nnkernels.defer_bn_counters(False)
         self.generate_images_pred(inputs, outputs)
         losses = self.compute_losses(inputs, outputs)
         return outputs, losses
@@ -245,6 +304,9 @@ class Trainer:
             noise = torch.randn(B, len(srcs), H, W, device=self.device)
         else:
             noise = torch.randn(B, len(srcs), H, W).to(self.device, non_blocking=True)   # CPU RNG, as the reference
+        if self._capturing:                    # inside a graph capture everything stays on the capturing stream
+            self._identity, self._identity_done = ops.identity_fwd(tgt, srcs, noise), None
+            return
         side = self._side_stream
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -275,7 +337,8 @@ class Trainer:
         srcs_ids = o.frame_ids[1:]
         if getattr(self, "_identity", None) is None:
             self._launch_identity(inputs)
-        torch.cuda.current_stream().wait_event(self._identity_done)
+        if self._identity_done is not None:
+            torch.cuda.current_stream().wait_event(self._identity_done)
         identity, self._identity = self._identity, None
         aa = torch.cat([outputs[("axisangle", 0, f)][:, 0] for f in srcs_ids], 1).contiguous()      # [B,S,3]
         tr = torch.cat([outputs[("translation", 0, f)][:, 0] for f in srcs_ids], 1).contiguous()

@@ -1,0 +1,54 @@
+"""The hipGraph replay of the training step (Trainer._capture) must train exactly like the eager step:
+same batches, same host-drawn tie-break noise, dropout off -> parameters after 7 steps agree."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ARGS = ["--backbone", "resnet18_lite", "--model_dim", "16", "--patch_size", "8", "--query_nums", "12", "--dim_out", "24",
+        "--height", "64", "--width", "96", "--batch_size", "2", "--num_workers", "0", "--sqd_synthetic",
+        "--log_dir", "/tmp/sqd_graph_test", "--max_depth", "80.0", "--scheduler_step_size", "1"]
+
+
+def run(extra, steps=7):
+    from options import MonodepthOptions
+    from trainer import Trainer
+    from datasets.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    tr = Trainer(MonodepthOptions().parse(ARGS + extra))
+    tr.set_train()
+    for m in tr.models.values():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+    losses = []
+    g = torch.Generator().manual_seed(5)
+    for i in range(steps):
+        inputs = synthetic_batch(2, 64, 96, start=2 * i, device=tr.device)
+        inputs[("noise", 0)] = torch.randn(2, 2, 64, 96, generator=g).cuda()
+        _, ls = tr.train_step(inputs)
+        losses.append(float(ls["loss"]))
+        if i == 4:
+            tr.model_lr_scheduler.step()          # the learning rate changes between replays
+    torch.cuda.synchronize()
+    params = {n + "." + k: v.detach().clone() for n, m in tr.models.items() for k, v in m.state_dict().items()}
+    return tr, losses, params
+
+
+def test_graph_replay_matches_eager():
+    tr_e, loss_e, par_e = run(["--sqd_no_graph"])
+    tr_g, loss_g, par_g = run([])
+    assert tr_e._graph is None and tr_g._graph is not None, "the second run must have replayed a captured graph"
+    for a, b in zip(loss_e, loss_g):
+        assert abs(a - b) <= 1e-5 * abs(a) + 1e-7, (loss_e, loss_g)
+    for k in par_e:
+        a, b = par_e[k].float(), par_g[k].float()
+        # not bit-equal: ATen's max-pool backward accumulates with atomics, and Adam's m/sqrt(v) amplifies the last bit
+        # (an Adam step moves a parameter by ~lr whatever the gradient's magnitude: 5% of the 7 * 1e-4 travelled is the floor)
+        assert float((a - b).abs().max()) <= 5e-4 * float(a.abs().max()) + 3.5e-5, (k, float((a - b).abs().max()))
+    # Adam bookkeeping kept in step: torch.optim state_dict compatibility
+    st_e = tr_e.model_optimizer.state_dict()["state"]
+    st_g = tr_g.model_optimizer.state_dict()["state"]
+    assert [float(v["step"]) for v in st_e.values()] == [float(v["step"]) for v in st_g.values()]
