@@ -52,7 +52,7 @@ class FusedAdam(torch.optim.Adam):
     def refresh_hyper(self):
         L = _l.lib()
         for gi, group in enumerate(self.param_groups):
-            plist = [p for p in group["params"] if p.grad is not None or "step" in self.state[p]]
+            plist = [p for p in group["params"] if p.grad is not None or "step" in self.state.get(p, ())]
             if not plist:
                 continue
             if gi not in self._graph_hyper:
