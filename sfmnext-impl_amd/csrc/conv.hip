@@ -203,6 +203,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+    // (a second register stage — loads issued two slices ahead — was measured and is slower: +3 % fwd, +6 % dgrad over the
+    // config-B layers; HBM latency is not what limits this loop)
     float4 ra[A_F4], rb[B_F4];
     auto advance = [&]() {
         if (++l_cc == cchunks) {
@@ -521,6 +523,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
         mma_batch(a1, b1);
     }
     // ---- add the 4 waves' accumulators (fixed order), wave w writes quarter w of the tile registers
+    // (a slot per wave: a single shared image with the waves adding in turn needs 4x less LDS but serialises the
+    // tail behind 4 barriers — measured 9 % slower over the config-B layers)
 #pragma unroll
     for (int q = 0; q < KT; ++q)
 #pragma unroll
@@ -619,19 +623,45 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     const int taps = mode == 0 ? g.R * g.S : ((g.R + g.stride - 1) / g.stride) * ((g.S + g.stride - 1) / g.stride);
     const int T = taps * ((mode == 0 ? g.C : g.K) / BK);
     GemmPlan p;
-    p.bn = Ncols >= 128 ? 128 : Ncols >= 64 ? 64 : 32;
-    p.bm = 128;
-    auto wgs = [&](int bm, int bn) { return ncls * ((Mcls + bm - 1) / bm) * ((Ncols + bn - 1) / bn); };
-    if (wgs(128, p.bn) < 512 && p.bn >= 64) p.bm = 64;
-    if (p.bm == 64 && p.bn == 128 && wgs(64, 128) < 512) p.bn = 64;
-    int z = 1;
-    const int w = wgs(p.bm, p.bn);
-    if (w < 512) {
-        z = (768 + w - 1) / w;
-        if (z > 16) z = 16;
-        if (z > T / 4) z = T / 4 > 1 ? T / 4 : 1;
-        while (z > 1 && (int64_t)z * Mrows * Ncols * 4 > (64ll << 20)) --z;
-        if (((int64_t)Mrows * Ncols) % 4 != 0) z = 1;
+    // Tile and split-K by a small cost model (cycles on the busiest CU), calibrated on the config-B layers
+    // (profiles/r01c_conv_layers.md): a workgroup-step costs its MFMA cycles (8 x 64 per 32x32 wave tile) and, when too
+    // few workgroups share a CU to hide it, ~400 cycles of load/barrier latency; split-K pays for writing and
+    // re-reading z partial images.
+    static const int cand[5][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 32}};
+    static const int zs[9] = {1, 2, 3, 4, 6, 8, 10, 12, 16};
+    double best = 1e30;
+    p.bm = 128; p.bn = 32; p.z = 1;
+    for (int ci = 0; ci < 5; ++ci) {
+        const int bm = cand[ci][0], bn = cand[ci][1];
+        if (bn > 32 && bn >= 2 * Ncols) continue;                       // a tile wider than twice the channel count
+        if (bn == 32 && Ncols > 32) continue;
+        const long long tiles = (long long)ncls * ((Mcls + bm - 1) / bm) * ((Ncols + bn - 1) / bn);
+        const double mfma = (bm / 32) * (bn / 32) / 4.0 * 512.0;
+        const int occ_max = bm * bn >= 128 * 128 ? 2 : 4;
+        for (int zi = 0; zi < 9; ++zi) {
+            const int z = zs[zi];
+            if (z > 1 && (z > T / 4 || (int64_t)z * Mrows * Ncols * 4 > (64ll << 20) || ((int64_t)Mrows * Ncols) % 4 != 0)) continue;
+            const long long wgs = tiles * z;
+            const long long per_cu = (wgs + 255) / 256;
+            const int occ = per_cu < occ_max ? (int)per_cu : occ_max;
+            const double steps = (double)(T + z - 1) / z;
+            const double rounds = (double)((per_cu + occ - 1) / occ);
+            const double step_cyc = occ * mfma > mfma + 400.0 ? occ * mfma : mfma + 400.0;
+            double cyc = rounds * (steps * step_cyc + 1500.0);         // + prologue / epilogue per round
+            if (z > 1) cyc += 2.4e9 * ((z + 1.0) * Mrows * Ncols * 4.0 / 3.0e12 + 3.0e-6);
+            if (cyc < best) { best = cyc; p.bm = bm; p.bn = bn; p.z = z; }
+        }
+    }
+    int z = p.z;
+    static const char *force = getenv("SQD_CONV_PLAN");          // "bm,bn,z": tuning experiments only
+    if (force) {
+        int fbm, fbn, fz;
+        if (sscanf(force, "%d,%d,%d", &fbm, &fbn, &fz) == 3) {
+            p.bm = fbm;
+            p.bn = fbn < Ncols * 2 ? fbn : p.bn;
+            z = fz < T / 2 ? fz : (T / 2 > 0 ? T / 2 : 1);
+            if (((int64_t)Mrows * Ncols) % 4 != 0) z = 1;
+        }
     }
     p.z = z;
     p.ws_floats = z > 1 ? (int64_t)z * Mrows * Ncols : 0;
