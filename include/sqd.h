@@ -90,7 +90,7 @@ typedef struct sqd_photo_args {
     float *reproj;          /* [B,S,H,W]  reprojection loss maps (debug/parity; may be NULL)         */
     float *loss_part;       /* [ntasks]   per-wavefront partial sums of to_optimise                  */
     int32_t B, S, H, W;
-    int32_t rows_per_task;  /* TH: (TH+6) % 7 == 0, e.g. 8, 15, 22, 64; 0 = library default          */
+    int32_t rows_per_task;  /* TH: output rows per wavefront strip, 1..4096; 0 = library default (8)   */
     void *stream;
 } sqd_photo_args;
 int sqd_photo_ntasks(int B, int H, int W, int rows_per_task);
@@ -118,7 +118,7 @@ typedef struct sqd_photo_bwd_args {
     int64_t g_depth_img_stride; /* >= S*H*W */
     float gscale;
     int32_t B, S, H, W;
-    int32_t rows_per_task;  /* TH: (TH+6) % 7 == 0; 0 = default */
+    int32_t rows_per_task;  /* TH: 1..4096; 0 = default */
     void *stream;
 } sqd_photo_bwd_args;
 int sqd_photo_bwd_ntasks(int B, int S, int H, int W, int rows_per_task);
