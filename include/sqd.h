@@ -225,6 +225,10 @@ int sqd_adam_step_dev(const void *recs, const void *grads, const void *chunks, i
  * wgrad C % 4 == 0 and K % 4 == 0.  act (forward epilogue): 0 none, 1 ReLU.                          */
 int sqd_conv_supported(int C, int K);
 /* ws: split-K workspace of sqd_conv_plan(mode 0 = fwd / 1 = dgrad, ...) floats; NULL when the plan says 0 */
+/* measured plans: see csrc/conv.hip — the library picks tile and split-K by a cost model unless the caller registers
+ * a plan it has timed (bm x bn tile, z split-K factor; bm = 0 clears) */
+int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int bm,
+                      int bn, int z);
 int sqd_conv_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
                   int64_t *ws_floats);
 int sqd_conv_fwd(const float *x, const float *w, const float *bias, float *y, float *ws, int N, int H, int W, int C, int K,

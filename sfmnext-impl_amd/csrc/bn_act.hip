@@ -96,33 +96,33 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict_
     }
 }
 
-// Sum the per-block partials of FIN_CH channels with a whole 256-thread block: 16 partial-lanes per
-// channel, then a fixed-order LDS tree (deterministic).  A one-thread-per-channel loop over up to 768
-// partials cost 131 us per call and dominated the step (profiles/r01b_*).
-constexpr int FIN_CH = 16, FIN_LANES = 256 / FIN_CH;
+// Sum the per-block partials: one wavefront per channel (4 channels per 256-thread block), 64 lanes stride over the
+// partial rows with 4 loads in flight each, then a fixed-order butterfly (deterministic).  History: a
+// one-thread-per-channel loop over up to 768 partials cost 131 us per call; 16 lanes per channel + an LDS tree 12 us.
+constexpr int FIN_CH = 4;
 __device__ __forceinline__ bool finalize_sums(const float *__restrict__ part, int nblk, int C, int &c, float &s, float &ss) {
-    __shared__ float sh[2][FIN_LANES][FIN_CH];
-    const int cl = threadIdx.x % FIN_CH, kl = threadIdx.x / FIN_CH;
-    c = blockIdx.x * FIN_CH + cl;
-    float a = 0.f, b = 0.f;
-    if (c < C)
-        for (int k = kl; k < nblk; k += FIN_LANES) {
-            const float2 v = *reinterpret_cast<const float2 *>(part + ((size_t)k * C + c) * 2);
-            a += v.x;
-            b += v.y;
+    const int lane = threadIdx.x & 63;
+    c = blockIdx.x * FIN_CH + (threadIdx.x >> 6);
+    float a0 = 0.f, b0 = 0.f, a1 = 0.f, b1 = 0.f, a2 = 0.f, b2 = 0.f, a3 = 0.f, b3 = 0.f;
+    if (c < C) {
+        const float *p = part + (size_t)c * 2;
+        const size_t stride = (size_t)C * 2;
+        int k = lane;
+        for (; k + 192 < nblk; k += 256) {
+            const float2 v0 = *reinterpret_cast<const float2 *>(p + (size_t)k * stride);
+            const float2 v1 = *reinterpret_cast<const float2 *>(p + (size_t)(k + 64) * stride);
+            const float2 v2 = *reinterpret_cast<const float2 *>(p + (size_t)(k + 128) * stride);
+            const float2 v3 = *reinterpret_cast<const float2 *>(p + (size_t)(k + 192) * stride);
+            a0 += v0.x; b0 += v0.y; a1 += v1.x; b1 += v1.y; a2 += v2.x; b2 += v2.y; a3 += v3.x; b3 += v3.y;
         }
-    sh[0][kl][cl] = a;
-    sh[1][kl][cl] = b;
-    __syncthreads();
-    if (kl != 0 || c >= C) return false;
-    s = 0.f;
-    ss = 0.f;
-#pragma unroll
-    for (int k = 0; k < FIN_LANES; ++k) {
-        s += sh[0][k][cl];
-        ss += sh[1][k][cl];
+        for (; k < nblk; k += 64) {
+            const float2 v0 = *reinterpret_cast<const float2 *>(p + (size_t)k * stride);
+            a0 += v0.x; b0 += v0.y;
+        }
     }
-    return true;
+    s = wave_sum((a0 + a1) + (a2 + a3));
+    ss = wave_sum((b0 + b1) + (b2 + b3));
+    return lane == 0 && c < C;
 }
 
 // forward finalize: mean / rstd from the partials + running statistics (nn.BatchNorm2d semantics)

@@ -19,6 +19,9 @@
 #include "sqd_common.h"
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 namespace {
 using namespace sqd;
@@ -606,6 +609,19 @@ struct GemmPlan {
     int bm, bn, z;
     int64_t ws_floats;
 };
+// measured plans registered through sqd_conv_set_plan: (mode, geometry) -> (bm, bn, z)
+typedef std::tuple<int, int, int, int, int, int, int, int, int, int> PlanKey;
+static std::map<PlanKey, std::tuple<int, int, int>> &plan_table() {
+    static std::map<PlanKey, std::tuple<int, int, int>> t;
+    return t;
+}
+static std::mutex &plan_mutex() {
+    static std::mutex m;
+    return m;
+}
+static PlanKey plan_key(int mode, const ConvGeom &g) {
+    return PlanKey(mode, g.N, g.H, g.W, g.C, g.K, g.R, g.S, g.stride, g.pad);
+}
 // tile / split-K choice: enough workgroups to cover 256 CUs a few times over, partial workspace <= 64 MB
 static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     int ncls = 1;                                 // stride classes that have at least one tap (the others only zero-fill)
@@ -650,6 +666,15 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
             double cyc = rounds * (steps * step_cyc + 1500.0);         // + prologue / epilogue per round
             if (z > 1) cyc += 2.4e9 * ((z + 1.0) * Mrows * Ncols * 4.0 / 3.0e12 + 3.0e-6);
             if (cyc < best) { best = cyc; p.bm = bm; p.bn = bn; p.z = z; }
+        }
+    }
+    {   // a plan measured by the caller (sqd_conv_set_plan) overrides the model
+        std::lock_guard<std::mutex> lk(plan_mutex());
+        auto it = plan_table().find(plan_key(mode, g));
+        if (it != plan_table().end()) {
+            p.bm = std::get<0>(it->second);
+            p.bn = std::get<1>(it->second);
+            p.z = std::get<2>(it->second);
         }
     }
     int z = p.z;
@@ -702,6 +727,31 @@ static int launch_gemm(int mode, const float *a_src, const float *w, const float
         hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, ws, mode == 0 ? bias : nullptr,
                            out, n, p.z, Ncols, mode == 0 ? act : 0);
     }
+    return SQD_OK;
+}
+
+// Register a measured tile / split-K plan for one geometry (mode 0 = fwd, 1 = dgrad): bm x bn in {128x128, 128x64, 64x128,
+// 64x64, 128x32}, z >= 1 split-K factor; bm = 0 removes the entry.  Returns SQD_EINVAL when the plan cannot run on this
+// geometry (tile wider than twice the channel count, z larger than a quarter of the reduction slices, workspace > 64 MB).
+// The next sqd_conv_plan / sqd_conv_fwd / sqd_conv_dgrad calls of that geometry use it.
+extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
+                                 int bm, int bn, int z) {
+    ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
+    std::lock_guard<std::mutex> lk(plan_mutex());
+    if (bm == 0) {
+        plan_table().erase(plan_key(mode, g));
+        return SQD_OK;
+    }
+    const int Ncols = mode == 0 ? K : C;
+    const int taps = mode == 0 ? R * S : ((R + stride - 1) / stride) * ((S + stride - 1) / stride);
+    const int T = taps * ((mode == 0 ? C : K) / BK);
+    const int64_t out_elems = mode == 0 ? (int64_t)N * Ho * Wo * K : (int64_t)N * H * W * C;
+    const bool tile_ok = (bm == 128 && (bn == 128 || bn == 64 || bn == 32)) || (bm == 64 && (bn == 128 || bn == 64));
+    SQD_CHECK_ARG(tile_ok && z >= 1 && z <= 64, "sqd_conv_set_plan: unsupported plan %dx%d z=%d", bm, bn, z);
+    SQD_CHECK_ARG(!(bn > 32 && bn >= 2 * Ncols) && !(bn == 32 && Ncols > 32), "sqd_conv_set_plan: tile width %d does not fit %d channels", bn, Ncols);
+    SQD_CHECK_ARG(z == 1 || (z <= T / 2 && z * out_elems * 4 <= (64ll << 20) && out_elems % 4 == 0),
+                  "sqd_conv_set_plan: split-K %d not possible here", z);
+    plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z);
     return SQD_OK;
 }
 

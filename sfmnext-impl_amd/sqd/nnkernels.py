@@ -128,6 +128,44 @@ def _conv_ws(mode, geom, device):
     return torch.empty(n, device=device, dtype=torch.float32) if n else None
 
 
+TUNE_CONV = False             # set by the Trainer (--sqd_no_conv_tune switches it off)
+_TUNED = set()
+_TUNE_TILES = ((128, 128), (128, 64), (64, 128), (64, 64), (128, 32))
+_TUNE_Z = (1, 2, 3, 4, 6, 8, 12, 16)
+
+
+def _tune_conv(mode, geom, launch):
+    """Time every tile / split-K plan the library accepts for this geometry (4 launches each, HIP events on the current
+    stream) and register the fastest (sqd_conv_set_plan).  Runs once per geometry, outside graph capture."""
+    key = (mode,) + tuple(geom)
+    if key in _TUNED or torch.cuda.is_current_stream_capturing():
+        return
+    _TUNED.add(key)
+    L = _l.lib()
+    best = None
+    for bm, bn in _TUNE_TILES:
+        for z in _TUNE_Z:
+            if L.sqd_conv_set_plan(mode, *geom, bm, bn, z) != 0:
+                continue
+            _PLAN_CACHE.pop(key, None)
+            ws = _conv_ws(mode, geom, torch.device("cuda", torch.cuda.current_device()))
+            launch(ws)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                launch(ws)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if best is None or t < best[0]:
+                best = (t, bm, bn, z)
+    _PLAN_CACHE.pop(key, None)
+    if best is None:
+        L.sqd_conv_set_plan(mode, *geom, 0, 0, 0)
+    else:
+        L.sqd_conv_set_plan(mode, *geom, best[1], best[2], best[3])
+
+
 def _wgrad_part_floats(geom):
     N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
     key = ("w",) + tuple(geom)
@@ -157,6 +195,10 @@ class Conv2d(torch.autograd.Function):
         K, _, R, S = w.shape
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
         y = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        if TUNE_CONV:
+            _tune_conv(0, (N, H, W, C, K, R, S, stride, pad, Ho, Wo),
+                       lambda ws: _l.lib().sqd_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws), N, H, W, C, K, R, S, stride, pad,
+                                                        Ho, Wo, ACT[act], _stream()))
         ws = _conv_ws(0, (N, H, W, C, K, R, S, stride, pad, Ho, Wo), x.device)
         _l.check(_l.lib().sqd_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
                                        ACT[act], _stream()), "conv_fwd")
@@ -176,6 +218,9 @@ class Conv2d(torch.autograd.Function):
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
+            if TUNE_CONV:
+                _tune_conv(1, ctx.geom, lambda ws: L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), N, H, W, C, K, R, S, stride,
+                                                                    pad, Ho, Wo, _stream()))
             ws = _conv_ws(1, ctx.geom, dy.device)
             _l.check(L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), N, H, W, C, K, R, S, stride, pad, Ho, Wo, _stream()),
                      "conv_dgrad")

@@ -83,6 +83,7 @@ class Trainer:
             torch.backends.cudnn.benchmark = True
         from sqd import nnops
         nnops.set_native_conv(not self.opt.sqd_aten_conv)
+        nnkernels.TUNE_CONV = not self.opt.sqd_no_conv_tune and self.device.type == "cuda"   # first step: ~2 s of plan timing
         if not self.opt.sqd_aten_conv:
             self.opt.sqd_channels_last = True          # the native kernels are NHWC / KRSC only
         if self.opt.sqd_channels_last:

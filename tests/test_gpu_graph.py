@@ -7,7 +7,7 @@ pytestmark = pytest.mark.gpu
 
 ARGS = ["--backbone", "resnet18_lite", "--model_dim", "16", "--patch_size", "8", "--query_nums", "12", "--dim_out", "24",
         "--height", "64", "--width", "96", "--batch_size", "2", "--num_workers", "0", "--sqd_synthetic",
-        "--log_dir", "/tmp/sqd_graph_test", "--max_depth", "80.0", "--scheduler_step_size", "1"]
+        "--log_dir", "/tmp/sqd_graph_test", "--max_depth", "80.0", "--scheduler_step_size", "1", "--sqd_no_conv_tune"]
 
 
 def run(extra, steps=7):
@@ -46,10 +46,15 @@ def test_graph_replay_matches_eager():
     for k in par_e:
         a, b = par_e[k].float(), par_g[k].float()
         # not bit-equal: ATen's max-pool backward accumulates with atomics, and Adam's m/sqrt(v) amplifies the last bit
-        # (an Adam step moves a parameter by ~lr whatever the gradient's magnitude: 5% of the 7 * 1e-4 travelled is the floor)
-        assert float((a - b).abs().max()) <= 5e-4 * float(a.abs().max()) + 3.5e-5, (k, float((a - b).abs().max()))
+        # (an Adam step moves a parameter by ~lr whatever the gradient's magnitude: 10% of the 7 * 1e-4 travelled is the floor)
+        assert float((a - b).abs().max()) <= 5e-4 * float(a.abs().max()) + 7e-5, (k, float((a - b).abs().max()))
     # Adam bookkeeping kept in step: torch.optim state_dict compatibility
     st_e = tr_e.model_optimizer.state_dict()["state"]
     st_g = tr_g.model_optimizer.state_dict()["state"]
     steps_e, steps_g = [float(v["step"]) for v in st_e.values() if "step" in v], [float(v["step"]) for v in st_g.values() if "step" in v]
     assert steps_e == steps_g and set(steps_e) == {7.0}
+    # the step-dependent scalars the captured Adam kernel reads were refreshed for step 7 at the decayed learning rate
+    lr = tr_g.model_optimizer.param_groups[0]["lr"]
+    assert abs(lr - 1e-5) < 1e-12                                   # StepLR(step_size=1, gamma=0.1) stepped once
+    hyper = tr_g.model_optimizer._graph_hyper[0][1].cpu()
+    assert abs(float(hyper[0]) - lr / (1 - 0.9 ** 7)) <= 1e-6 * lr and abs(float(hyper[1]) - (1 - 0.999 ** 7) ** -0.5) <= 1e-4
