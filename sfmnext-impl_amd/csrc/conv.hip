@@ -455,68 +455,96 @@ template <> struct VecLoad<4> {
     }
 };
 
-template <int KT, int CT>
+// TP = filter taps per wave: 1, or the S = 3 taps of one filter row — the wave then fetches dy once for three
+// products (x at wi-1, wi, wi+1: the neighbouring pixel's channels, C floats further) and issues 3x the MFMAs per
+// step of address arithmetic.
+__device__ __forceinline__ void ldv(const float *__restrict__ base, unsigned byte_off, float (&v)[1]) {
+    v[0] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ void ldv(const float *__restrict__ base, unsigned byte_off, float (&v)[2]) {
+    const float2 t = *reinterpret_cast<const float2 *>(reinterpret_cast<const char *>(base) + byte_off);
+    v[0] = t.x; v[1] = t.y;
+}
+__device__ __forceinline__ void ldv(const float *__restrict__ base, unsigned byte_off, float (&v)[4]) {
+    const float4 t = *reinterpret_cast<const float4 *>(reinterpret_cast<const char *>(base) + byte_off);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+
+template <int KT, int CT, int TP>
 __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                                 float *__restrict__ part, ConvGeom g, int px_per_wave, int kgroups,
                                                                 int nsplits) {
-    constexpr int UB = 4;                                   // MFMA steps (of 4 pixels) per load batch
+    constexpr int UB = TP == 3 ? 2 : 4;                     // MFMA steps (of 4 pixels) per load batch
     constexpr int NT = KT * CT;
-    __shared__ float red[4][NT * 4][64];
+    __shared__ float red[4][NT * 4][64];                    // cross-wave add, one tap at a time
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // XCD-aware order (see conv_gemm_kernel): taps fastest, then channel groups, then pixel ranges — the 9 taps of a
-    // 3x3 filter read the same dy rows and overlapping x rows out of one L2
-    const int taps = g.R * g.S, groups = kgroups * (g.C / (16 * CT));
+    // XCD-aware order: tap groups fastest, then channel groups, then pixel ranges — the taps of a 3x3 filter read the
+    // same dy rows and overlapping x rows out of one L2
+    const int tgroups = g.R * g.S / TP, groups = kgroups * (g.C / (16 * CT));
     const int logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
-    if (logical >= taps * groups * nsplits) return;
-    const int rs = logical % taps, lg = logical / taps, grp = lg % groups, split = lg / groups;
+    if (logical >= tgroups * groups * nsplits) return;
+    const int tg = logical % tgroups, lg = logical / tgroups, grp = lg % groups, split = lg / groups;
     const int kg = grp % kgroups, cg = grp / kgroups;
-    const int r = rs / g.S, s = rs - r * g.S;
+    const int rs0 = tg * TP, r = rs0 / g.S, s0 = rs0 - r * g.S;
     const int M = g.N * g.Ho * g.Wo;
     const int i16 = lane & 15, pq = lane >> 4;
     const int kl = kg * 16 * KT + KT * i16, cl = cg * 16 * CT + CT * i16;
     const int mbeg = (split * 4 + wave) * px_per_wave;
     const int mend = min(M, mbeg + px_per_wave);
-    // this lane's pixel: m = mbeg + pq, advancing by 4 per step; (n, ho, wo) kept incrementally
+    // this lane's pixel: m = mbeg + pq, advancing by 4 per step; (n, ho, wo) and the byte offsets kept incrementally
     int m = mbeg + pq;
     int wo = m % g.Wo, t2 = m / g.Wo, ho = t2 % g.Ho, n = t2 / g.Ho;
-    const float *dyp = dy + (size_t)m * g.K + kl;
+    unsigned dyoff = ((unsigned)m * g.K + kl) * 4u;
+    const unsigned dystep = 4u * g.K * 4u;
+    int hi = ho * g.stride - g.pad + r;
+    unsigned xrow = ((unsigned)(n * g.H + hi) * g.W) * (unsigned)g.C;      // element offset of (n, hi, 0, 0); unused when hi is outside
 
-    f32x4 acc[KT][CT];
+    f32x4 acc[TP][KT][CT];
 #pragma unroll
-    for (int q = 0; q < KT; ++q)
+    for (int t = 0; t < TP; ++t)
 #pragma unroll
-        for (int c = 0; c < CT; ++c) acc[q][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < KT; ++q)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) acc[t][q][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    auto load_batch = [&](float (*a)[KT], float (*b)[CT]) {
+    auto load_batch = [&](float (*a)[KT], float (*b)[TP][CT]) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const bool mv = m < mend;
-            const int hi = ho * g.stride - g.pad + r, wi = wo * g.stride - g.pad + s;
-            const bool xv = mv && hi >= 0 && hi < g.H && wi >= 0 && wi < g.W;
+            const bool hv = mv && (unsigned)hi < (unsigned)g.H;
+            const int wi0 = wo * g.stride - g.pad + s0;
 #pragma unroll
             for (int q = 0; q < KT; ++q) a[u][q] = 0.f;
+            if (mv) ldv(dy, dyoff, a[u]);
 #pragma unroll
-            for (int c = 0; c < CT; ++c) b[u][c] = 0.f;
-            if (mv) VecLoad<KT>::ld(dyp, a[u]);
-            if (xv) VecLoad<CT>::ld(x + ((size_t)(n * g.H + hi) * g.W + wi) * g.C + cl, b[u]);
+            for (int t = 0; t < TP; ++t) {
+#pragma unroll
+                for (int c = 0; c < CT; ++c) b[u][t][c] = 0.f;
+                if (hv && (unsigned)(wi0 + t) < (unsigned)g.W) ldv(x, (xrow + (unsigned)(wi0 + t) * g.C + cl) * 4u, b[u][t]);
+            }
             m += 4;
-            dyp += 4 * g.K;
+            dyoff += dystep;
             wo += 4;
-            while (wo >= g.Wo) {
+            while (wo >= g.Wo) {                            // next output row (twice when Wo < 4)
                 wo -= g.Wo;
                 if (++ho >= g.Ho) { ho = 0; ++n; }
+                hi = ho * g.stride - g.pad + r;
+                xrow = ((unsigned)(n * g.H + hi) * g.W) * (unsigned)g.C;
             }
         }
     };
-    auto mma_batch = [&](float (*a)[KT], float (*b)[CT]) {
+    auto mma_batch = [&](float (*a)[KT], float (*b)[TP][CT]) {
 #pragma unroll
         for (int u = 0; u < UB; ++u)
 #pragma unroll
-            for (int q = 0; q < KT; ++q)
+            for (int t = 0; t < TP; ++t)
 #pragma unroll
-                for (int c = 0; c < CT; ++c) acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q], b[u][c], acc[q][c], 0, 0, 0);
+                for (int q = 0; q < KT; ++q)
+#pragma unroll
+                    for (int c = 0; c < CT; ++c)
+                        acc[t][q][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q], b[u][t][c], acc[t][q][c], 0, 0, 0);
     };
-    float a0[UB][KT], b0[UB][CT], a1[UB][KT], b1[UB][CT];
+    float a0[UB][KT], b0[UB][TP][CT], a1[UB][KT], b1[UB][TP][CT];
     const int nb = (mend - mbeg + 4 * UB - 1) / (4 * UB);    // batches (loads past mend are masked to zero)
     if (nb > 0) load_batch(a0, b0);
     for (int bi = 0; bi < nb; bi += 2) {
@@ -525,22 +553,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
         load_batch(a0, b0);
         mma_batch(a1, b1);
     }
-    // ---- add the 4 waves' accumulators (fixed order), wave w writes quarter w of the tile registers
+    // ---- add the 4 waves' accumulators (fixed order), wave w writes quarter w of the tile registers; one tap per round
     // (a slot per wave: a single shared image with the waves adding in turn needs 4x less LDS but serialises the
     // tail behind 4 barriers — measured 9 % slower over the config-B layers)
-#pragma unroll
-    for (int q = 0; q < KT; ++q)
-#pragma unroll
-        for (int c = 0; c < CT; ++c)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) red[wave][(q * CT + c) * 4 + v][lane] = acc[q][c][v];
-    __syncthreads();
     float *po = part + (size_t)split * g.K * g.R * g.S * g.C;
-    for (int idx = wave; idx < NT * 4; idx += 4) {
-        const float sum = ((red[0][idx][lane] + red[1][idx][lane]) + red[2][idx][lane]) + red[3][idx][lane];
-        const int v = idx & 3, c = (idx >> 2) % CT, q = (idx >> 2) / CT;
-        const int k = kg * 16 * KT + KT * (4 * pq + v) + q, cc = cg * 16 * CT + CT * i16 + c;
-        po[((size_t)k * g.R * g.S + rs) * g.C + cc] = sum;
+#pragma unroll
+    for (int t = 0; t < TP; ++t) {
+        if (t > 0) __syncthreads();
+#pragma unroll
+        for (int q = 0; q < KT; ++q)
+#pragma unroll
+            for (int c = 0; c < CT; ++c)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) red[wave][(q * CT + c) * 4 + v][lane] = acc[t][q][c][v];
+        __syncthreads();
+        for (int idx = wave; idx < NT * 4; idx += 4) {
+            const float sum = ((red[0][idx][lane] + red[1][idx][lane]) + red[2][idx][lane]) + red[3][idx][lane];
+            const int v = idx & 3, c = (idx >> 2) % CT, q = (idx >> 2) / CT;
+            const int k = kg * 16 * KT + KT * (4 * pq + v) + q, cc = cg * 16 * CT + CT * i16 + c;
+            po[((size_t)k * g.R * g.S + rs0 + t) * g.C + cc] = sum;
+        }
     }
 }
 
@@ -789,7 +821,7 @@ extern "C" int sqd_conv_dgrad(const float *dy, const float *w, float *dx, float 
 
 struct WgradPlan {
     bool direct;
-    int kt, ct, splits, px_per_wave;
+    int kt, ct, tp, splits, px_per_wave;
 };
 static int wgrad_impl_override() {              // SQD_WGRAD_IMPL=lds|direct forces one kernel (benchmarks); default: heuristic
     static int v = -1;
@@ -808,7 +840,11 @@ static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, i
     p.direct = C % 16 == 0 && K % 16 == 0 && (ov == 2 || (ov == 0 && M >= 2048 && C <= 1024));
     p.kt = K % 64 == 0 ? 4 : K % 32 == 0 ? 2 : 1;
     p.ct = C % 64 == 0 ? 4 : C % 32 == 0 ? 2 : 1;
-    const int groups = (K / (16 * p.kt)) * (C / (16 * p.ct)) * R * S;
+    // a filter row (3 taps) per wave: measured SLOWER on every config-B layer (3x3 64..256 channels: 140 us vs 102 us) — the
+    // 192-256 accumulator registers leave one wave per SIMD and nothing hides the operand latency.  Kept for experiments.
+    static const bool tp3 = getenv("SQD_WGRAD_TP3") != nullptr;
+    p.tp = (tp3 && S == 3 && p.kt * p.ct >= 8) ? 3 : 1;
+    const int groups = (K / (16 * p.kt)) * (C / (16 * p.ct)) * (R * S / p.tp);
     int sp = (1024 + groups - 1) / groups;                       // ~1k workgroups of 4 waves
     const int max_by_px = (M + 255) / 256;                       // >= 64 pixels per wave
     if (sp > max_by_px) sp = max_by_px;
@@ -862,9 +898,18 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
     const WgradPlan dp = plan_wgrad_direct(N, Ho, Wo, C, K, R, S);
     if (dp.direct) {
         const int kgroups = K / (16 * dp.kt);
-        const dim3 grid((kgroups * (C / (16 * dp.ct)) * dp.splits * R * S + 7) / 8 * 8);
+        const dim3 grid((kgroups * (C / (16 * dp.ct)) * dp.splits * (R * S / dp.tp) + 7) / 8 * 8);
+#define LAUNCH_WD3(KT, CT) \
+    hipLaunchKernelGGL((conv_wgrad_direct_kernel<KT, CT, 3>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, kgroups, dp.splits)
 #define LAUNCH_WD(KT, CT) \
-    hipLaunchKernelGGL((conv_wgrad_direct_kernel<KT, CT>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, kgroups, dp.splits)
+    hipLaunchKernelGGL((conv_wgrad_direct_kernel<KT, CT, 1>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, kgroups, dp.splits)
+        if (dp.tp == 3) {
+            switch (dp.kt * 8 + dp.ct) {
+                case 4 * 8 + 4: LAUNCH_WD3(4, 4); break;
+                case 4 * 8 + 2: LAUNCH_WD3(4, 2); break;
+                default: LAUNCH_WD3(2, 4); break;
+            }
+        } else
         switch (dp.kt * 8 + dp.ct) {
             case 4 * 8 + 4: LAUNCH_WD(4, 4); break;
             case 4 * 8 + 2: LAUNCH_WD(4, 2); break;
