@@ -235,7 +235,7 @@ int sqd_conv_fwd(const float *x, const float *w, const float *bias, float *y, fl
                  int R, int S, int stride, int pad, int Ho, int Wo, int act, void *stream);
 int sqd_conv_dgrad(const float *dy, const float *w, float *dx, float *ws, int N, int H, int W, int C, int K, int R, int S,
                    int stride, int pad, int Ho, int Wo, void *stream);
-/* workspace of the weight gradient: `part_floats` floats (+ ceil(N*Ho*Wo/1024)*K more when dbias is wanted) */
+/* workspace of the weight gradient: `part_floats` floats (+ max(ceil(N*Ho*Wo/1024), splits) * K more when dbias is wanted) */
 int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *splits, int64_t *part_floats);
 int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C, int K,
                    int R, int S, int stride, int pad, int Ho, int Wo, void *stream);

@@ -473,7 +473,7 @@ __device__ __forceinline__ void ldv(const float *__restrict__ base, unsigned byt
 template <int KT, int CT, int TP>
 __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                                 float *__restrict__ part, ConvGeom g, int px_per_wave, int kgroups,
-                                                                int nsplits) {
+                                                                int nsplits, float *__restrict__ bias_part) {
     constexpr int UB = TP == 3 ? 2 : 4;                     // MFMA steps (of 4 pixels) per load batch
     constexpr int NT = KT * CT;
     __shared__ float red[4][NT * 4][64];                    // cross-wave add, one tap at a time
@@ -506,6 +506,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
         for (int q = 0; q < KT; ++q)
 #pragma unroll
             for (int c = 0; c < CT; ++c) acc[t][q][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bias gradient = column sums of dy: the workgroups of the first channel group / tap group add up the dy values they
+    // fetch anyway (bias_part [nsplits][K], summed over the splits by the caller)
+    const bool do_bias = bias_part != nullptr && cg == 0 && tg == 0;
+    float bsum[KT];
+#pragma unroll
+    for (int q = 0; q < KT; ++q) bsum[q] = 0.f;
 
     auto load_batch = [&](float (*a)[KT], float (*b)[TP][CT]) {
 #pragma unroll
@@ -543,6 +549,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
 #pragma unroll
                     for (int c = 0; c < CT; ++c)
                         acc[t][q][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][q], b[u][t][c], acc[t][q][c], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+#pragma unroll
+                for (int q = 0; q < KT; ++q) bsum[q] += a[u][q];
+        }
     };
     float a0[UB][KT], b0[UB][TP][CT], a1[UB][KT], b1[UB][TP][CT];
     const int nb = (mend - mbeg + 4 * UB - 1) / (4 * UB);    // batches (loads past mend are masked to zero)
@@ -573,6 +585,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
             const int k = kg * 16 * KT + KT * (4 * pq + v) + q, cc = cg * 16 * CT + CT * i16 + c;
             po[((size_t)k * g.R * g.S + rs0 + t) * g.C + cc] = sum;
         }
+    }
+    if (do_bias) {                                           // workgroup-uniform
+        __shared__ float bred[4][16 * KT];
+#pragma unroll
+        for (int q = 0; q < KT; ++q) {
+            float v = bsum[q];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (pq == 0) bred[wave][i16 * KT + q] = v;
+        }
+        __syncthreads();
+        if (threadIdx.x < 16 * KT)
+            bias_part[(size_t)split * g.K + kg * 16 * KT + threadIdx.x] =
+                ((bred[0][threadIdx.x] + bred[1][threadIdx.x]) + bred[2][threadIdx.x]) + bred[3][threadIdx.x];
     }
 }
 
@@ -880,7 +906,7 @@ extern "C" int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, i
 }
 
 // dy [N,Ho,Wo,K], x [N,H,W,C] -> dw [K,R,S,C]; dbias [K] (may be NULL); part: workspace of sqd_conv_wgrad_plan floats
-// (+ colsum scratch: ceil(M/1024)*K floats appended when dbias is requested)
+// (+ bias scratch appended when dbias is requested: max(ceil(M/1024), splits) * K floats)
 extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C,
                               int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream) {
     SQD_CHECK_ARG(dy && x && dw && part, "sqd_conv_wgrad: null pointer");
@@ -899,10 +925,13 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
     if (dp.direct) {
         const int kgroups = K / (16 * dp.kt);
         const dim3 grid((kgroups * (C / (16 * dp.ct)) * dp.splits * (R * S / dp.tp) + 7) / 8 * 8);
-#define LAUNCH_WD3(KT, CT) \
-    hipLaunchKernelGGL((conv_wgrad_direct_kernel<KT, CT, 3>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, kgroups, dp.splits)
-#define LAUNCH_WD(KT, CT) \
-    hipLaunchKernelGGL((conv_wgrad_direct_kernel<KT, CT, 1>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, kgroups, dp.splits)
+        float *bias_part = dbias ? part + (size_t)dp.splits * K * R * S * C : nullptr;   // [splits][K]
+#define LAUNCH_WD3(KT, CT)                                                                                                      \
+    hipLaunchKernelGGL((conv_wgrad_direct_kernel<KT, CT, 3>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, kgroups, \
+                       dp.splits, bias_part)
+#define LAUNCH_WD(KT, CT)                                                                                                       \
+    hipLaunchKernelGGL((conv_wgrad_direct_kernel<KT, CT, 1>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, kgroups, \
+                       dp.splits, bias_part)
         if (dp.tp == 3) {
             switch (dp.kt * 8 + dp.ct) {
                 case 4 * 8 + 4: LAUNCH_WD3(4, 4); break;
@@ -932,7 +961,10 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
     }
     const size_t wsz = (size_t)K * R * S * C;
     hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((wsz / 4 + 15) / 16)), dim3(256), 0, st, part, dw, wsz, splits);
-    if (dbias) {
+    if (dbias && dp.direct) {
+        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((K / 4 + 15) / 16)), dim3(256), 0, st, part + (size_t)splits * wsz, dbias,
+                           (size_t)K, splits);
+    } else if (dbias) {
         float *cpart = part + (size_t)splits * wsz;
         const int rpb = 1024, nblk = (M + rpb - 1) / rpb;
         int cpb = 1;

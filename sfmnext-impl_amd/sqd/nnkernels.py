@@ -173,7 +173,7 @@ def _wgrad_part_floats(geom):
     if n is None:
         splits, pf = ctypes.c_int(0), ctypes.c_int64(0)
         _l.lib().sqd_conv_wgrad_plan(N, Ho, Wo, C, K, R, S, ctypes.byref(splits), ctypes.byref(pf))
-        n = _PLAN_CACHE[key] = pf.value
+        n = _PLAN_CACHE[key] = (pf.value, splits.value)
     return n
 
 
@@ -225,8 +225,9 @@ class Conv2d(torch.autograd.Function):
             _l.check(L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), N, H, W, C, K, R, S, stride, pad, Ho, Wo, _stream()),
                      "conv_dgrad")
         if ctx.needs_input_grad[1]:
-            extra = ((N * Ho * Wo + 1023) // 1024) * K if ctx.has_bias else 0
-            part = torch.empty(_wgrad_part_floats(ctx.geom) + extra, device=dy.device, dtype=torch.float32)
+            pf, splits = _wgrad_part_floats(ctx.geom)
+            extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if ctx.has_bias else 0
+            part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
             dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
             db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
             _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,

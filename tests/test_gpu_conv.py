@@ -21,6 +21,8 @@ CASES = [  # N, C, H, W, K, R, stride, pad, bias, act
     (12, 64, 48, 160, 64, 3, 1, 1, False, None),       # config-B layer1 shape
     (2, 32, 13, 21, 64, 3, 2, 1, True, None),          # stride 2 on odd sizes (ragged stride classes in dgrad)
     (1, 512, 6, 20, 512, 3, 1, 1, False, None),        # few pixels, long reduction: split-K path
+    (4, 32, 24, 40, 64, 3, 1, 1, True, None),          # direct-operand wgrad with the fused bias gradient
+    (2, 16, 64, 96, 32, 5, 2, 2, True, "relu"),        # same, 5x5 stride 2 + ReLU, K = 32
 ]
 
 
