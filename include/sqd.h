@@ -226,9 +226,9 @@ int sqd_adam_step_dev(const void *recs, const void *grads, const void *chunks, i
 int sqd_conv_supported(int C, int K);
 /* ws: split-K workspace of sqd_conv_plan(mode 0 = fwd / 1 = dgrad, ...) floats; NULL when the plan says 0 */
 /* measured plans: see csrc/conv.hip — the library picks tile and split-K by a cost model unless the caller registers
- * a plan it has timed (bm x bn tile, z split-K factor; bm = 0 clears) */
+ * a plan it has timed (bm x bn tile, z split-K factor, bk = 16 | 32 channels per reduction slice; bm = 0 clears) */
 int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int bm,
-                      int bn, int z);
+                      int bn, int z, int bk);
 int sqd_conv_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
                   int64_t *ws_floats);
 int sqd_conv_fwd(const float *x, const float *w, const float *bias, float *y, float *ws, int N, int H, int W, int C, int K,

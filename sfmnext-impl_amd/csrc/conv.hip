@@ -39,16 +39,19 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 
 // MODE 0: forward (A rows = output pixels, gather x; B rows = out channels k, reduction over (r,s,c))
 // MODE 1: dgrad   (A rows = input pixels, gather dy; B rows = in channels c, reduction over (r,s,k))
-template <int MODE, int BM, int BN, int WGM, int WGN>
+template <int MODE, int BM, int BN, int WGM, int WGN, int BKT>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
                                                         const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
                                                         int act, int zsplits, int order) {
     constexpr int WTM = BM / WGM / 32, WTN = BN / WGN / 32;     // 32x32 MFMA tiles per wave
     static_assert(WGM * WGN == 4 && WTM >= 1 && WTN >= 1, "4 waves per workgroup");
-    constexpr int A_F4 = BM * 4 / 256, B_ROWS_PER_PASS = (MODE == 0) ? 64 : 64;
-    static_assert(A_F4 >= 1, "BM >= 64");
-    __shared__ __attribute__((aligned(16))) float As[2][BM][LDP];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDP];
+    // BKT = reduction slice per step (16 or 32 channels): a wider slice halves the barriers and per-step bookkeeping for
+    // twice the LDS footprint
+    constexpr int NQ = BKT / 4, LDPT = BKT + 4, RPP = 256 / NQ;  // float4 per staged row, LDS row pitch, rows per staging pass
+    constexpr int A_F4 = BM * NQ / 256;
+    static_assert(A_F4 >= 1 && (BKT == 16 || BKT == 32), "BM >= 64, BKT in {16, 32}");
+    __shared__ __attribute__((aligned(16))) float As[2][BM][LDPT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDPT];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm0 = (wave / WGN) * (WTM * 32), wn0 = (wave % WGN) * (WTN * 32);
@@ -79,19 +82,19 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
     const int Sc = MODE == 0 ? g.S : (s0 < g.S ? (g.S - s0 + g.stride - 1) / g.stride : 0);
     const int Ncols = MODE == 0 ? g.K : g.C;                    // output channels of this GEMM
     const int Cred = MODE == 0 ? g.C : g.K;                     // channels reduced per (r,s)
-    const int cchunks = Cred / BK;
+    const int cchunks = Cred / BKT;
     const int Tall = Rc * Sc * cchunks;
     // split-K: workgroup z reduces slices [s_beg, s_end) and writes a partial tile (summed by gemm_reduce_kernel)
     const int s_beg = (int)((long long)Tall * blockIdx.z / zsplits), s_end = (int)((long long)Tall * (blockIdx.z + 1) / zsplits);
     const int T = s_end - s_beg;
 
-    // ---- per-thread A staging rows: float4 column c4 of rows (t>>2) + 64*i
-    const int c4 = t & 3;
+    // ---- per-thread A staging rows: float4 column c4 of rows t / NQ + RPP*i
+    const int c4 = t % NQ, arow = t / NQ;
     int an[A_F4], ah[A_F4], aw[A_F4];
     bool aval[A_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i) {
-        const int m = m0 + (t >> 2) + 64 * i;
+        const int m = m0 + arow + RPP * i;
         aval[i] = m < Mrows;
         const int mm = aval[i] ? m : 0;
         if (MODE == 0) {
@@ -136,17 +139,17 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (MODE == 0) {
                 if (aval[i] && (unsigned)(ah[i] + r) < (unsigned)g.H && (unsigned)(aw[i] + s) < (unsigned)g.W)
-                    v = *reinterpret_cast<const float4 *>(a_src + (unsigned)((apix[i] + tapoff) * g.C + cc * BK + c4 * 4));
+                    v = *reinterpret_cast<const float4 *>(a_src + (unsigned)((apix[i] + tapoff) * g.C + cc * BKT + c4 * 4));
             } else {
                 if (aval[i] && (unsigned)(ah[i] - r) < (unsigned)g.Ho && (unsigned)(aw[i] - s) < (unsigned)g.Wo)
-                    v = *reinterpret_cast<const float4 *>(a_src + (unsigned)((apix[i] + tapoff) * g.K + cc * BK + c4 * 4));
+                    v = *reinterpret_cast<const float4 *>(a_src + (unsigned)((apix[i] + tapoff) * g.K + cc * BKT + c4 * 4));
             }
             ra[i] = v;
         }
     };
     // ---- B staging.  forward: rows = k, 16 consecutive c of filter tap (r,s): float4 copies.
     //      dgrad: rows = c, 16 k's strided by R*S*C: read float4 along c, transpose into LDS.
-    constexpr int B_F4 = (BN * 4 + 255) / 256;
+    constexpr int B_F4 = (BN * NQ + 255) / 256;
     auto load_b = [&](float4 *rb) {
         const int cc = l_cc;
         const int rs = MODE == 0 ? l_r * g.S + l_s : (r0 + g.stride * l_r) * g.S + s0 + g.stride * l_s;   // filter tap of the slice
@@ -155,28 +158,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int idx = t + 256 * i;
             if (MODE == 0) {
-                const int row = idx >> 2, q4 = idx & 3;                  // row = out channel, q4 = float4 along c
+                const int row = idx / NQ, q4 = idx % NQ;                 // row = out channel, q4 = float4 along c
                 if (row < BN && n0 + row < g.K)
-                    v = *reinterpret_cast<const float4 *>(wgt + (unsigned)(((n0 + row) * g.R * g.S + rs) * g.C + cc * BK + q4 * 4));
+                    v = *reinterpret_cast<const float4 *>(wgt + (unsigned)(((n0 + row) * g.R * g.S + rs) * g.C + cc * BKT + q4 * 4));
             } else {
-                const int kk = idx & 15, cq = idx >> 4;                  // kk = k inside the slice, cq = float4 of in-channels
+                const int kk = idx % BKT, cq = idx / BKT;                // kk = k inside the slice, cq = float4 of in-channels
                 if (cq * 4 < BN && n0 + cq * 4 < g.C)
-                    v = *reinterpret_cast<const float4 *>(wgt + (unsigned)(((cc * BK + kk) * g.R * g.S + rs) * g.C + n0 + cq * 4));
+                    v = *reinterpret_cast<const float4 *>(wgt + (unsigned)(((cc * BKT + kk) * g.R * g.S + rs) * g.C + n0 + cq * 4));
             }
             rb[i] = v;
         }
     };
     auto store_ab = [&](int buf, const float4 *ra, const float4 *rb) {
 #pragma unroll
-        for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4 *>(&As[buf][(t >> 2) + 64 * i][c4 * 4]) = ra[i];
+        for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4 *>(&As[buf][arow + RPP * i][c4 * 4]) = ra[i];
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             const int idx = t + 256 * i;
             if (MODE == 0) {
-                const int row = idx >> 2, q4 = idx & 3;
+                const int row = idx / NQ, q4 = idx % NQ;
                 if (row < BN) *reinterpret_cast<float4 *>(&Bs[buf][row][q4 * 4]) = rb[i];
             } else {
-                const int kk = idx & 15, cq = idx >> 4;
+                const int kk = idx % BKT, cq = idx / BKT;
                 if (cq * 4 < BN) {
                     Bs[buf][cq * 4 + 0][kk] = rb[i].x;
                     Bs[buf][cq * 4 + 1][kk] = rb[i].y;
@@ -230,27 +233,32 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
             load_b(rb);
             advance();
         }
-        float af[WTM][8], bf[WTN][8];
+        // half-wave h owns reduction elements [h*BKT/2, (h+1)*BKT/2) of the slice, 8 at a time
 #pragma unroll
-        for (int i = 0; i < WTM; ++i) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(&As[cur][wm0 + i * 32 + row][8 * h]);
-            const float4 v1 = *reinterpret_cast<const float4 *>(&As[cur][wm0 + i * 32 + row][8 * h + 4]);
-            af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
-            af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+        for (int part = 0; part < BKT / 16; ++part) {
+            float af[WTM][8], bf[WTN][8];
+            const int e0 = (BKT / 2) * h + 8 * part;
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(&As[cur][wm0 + i * 32 + row][e0]);
+                const float4 v1 = *reinterpret_cast<const float4 *>(&As[cur][wm0 + i * 32 + row][e0 + 4]);
+                af[i][0] = v0.x; af[i][1] = v0.y; af[i][2] = v0.z; af[i][3] = v0.w;
+                af[i][4] = v1.x; af[i][5] = v1.y; af[i][6] = v1.z; af[i][7] = v1.w;
+            }
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) {
+                const float4 v0 = *reinterpret_cast<const float4 *>(&Bs[cur][wn0 + j * 32 + row][e0]);
+                const float4 v1 = *reinterpret_cast<const float4 *>(&Bs[cur][wn0 + j * 32 + row][e0 + 4]);
+                bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
+                bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+#pragma unroll
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) acc[i][j] = mfma32(af[i][e], bf[j][e], acc[i][j]);
         }
-#pragma unroll
-        for (int j = 0; j < WTN; ++j) {
-            const float4 v0 = *reinterpret_cast<const float4 *>(&Bs[cur][wn0 + j * 32 + row][8 * h]);
-            const float4 v1 = *reinterpret_cast<const float4 *>(&Bs[cur][wn0 + j * 32 + row][8 * h + 4]);
-            bf[j][0] = v0.x; bf[j][1] = v0.y; bf[j][2] = v0.z; bf[j][3] = v0.w;
-            bf[j][4] = v1.x; bf[j][5] = v1.y; bf[j][6] = v1.z; bf[j][7] = v1.w;
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e)
-#pragma unroll
-            for (int i = 0; i < WTM; ++i)
-#pragma unroll
-                for (int j = 0; j < WTN; ++j) acc[i][j] = mfma32(af[i][e], bf[j][e], acc[i][j]);
         if (step + 1 < T) store_ab(cur ^ 1, ra, rb);
         __syncthreads();
     }
@@ -664,13 +672,13 @@ int check_geom(const char *who, const ConvGeom &g) {
 extern "C" int sqd_conv_supported(int C, int K) { return (C % 16 == 0 && K % 16 == 0) ? 1 : 0; }
 
 struct GemmPlan {
-    int bm, bn, z;
+    int bm, bn, z, bk;
     int64_t ws_floats;
 };
 // measured plans registered through sqd_conv_set_plan: (mode, geometry) -> (bm, bn, z)
 typedef std::tuple<int, int, int, int, int, int, int, int, int, int> PlanKey;
-static std::map<PlanKey, std::tuple<int, int, int>> &plan_table() {
-    static std::map<PlanKey, std::tuple<int, int, int>> t;
+static std::map<PlanKey, std::tuple<int, int, int, int>> &plan_table() {
+    static std::map<PlanKey, std::tuple<int, int, int, int>> t;
     return t;
 }
 static std::mutex &plan_mutex() {
@@ -704,7 +712,7 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     static const int cand[5][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {128, 32}};
     static const int zs[9] = {1, 2, 3, 4, 6, 8, 10, 12, 16};
     double best = 1e30;
-    p.bm = 128; p.bn = 32; p.z = 1;
+    p.bm = 128; p.bn = 32; p.z = 1; p.bk = 16;
     for (int ci = 0; ci < 5; ++ci) {
         const int bm = cand[ci][0], bn = cand[ci][1];
         if (bn > 32 && bn >= 2 * Ncols) continue;                       // a tile wider than twice the channel count
@@ -733,9 +741,11 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
             p.bm = std::get<0>(it->second);
             p.bn = std::get<1>(it->second);
             p.z = std::get<2>(it->second);
+            p.bk = std::get<3>(it->second);
         }
     }
     int z = p.z;
+    if (p.bk == 32) z = z <= T / 4 ? z : 1;                      // (slices are twice as wide)
     static const char *force = getenv("SQD_CONV_PLAN");          // "bm,bn,z": tuning experiments only
     if (force) {
         int fbm, fbn, fz;
@@ -751,16 +761,25 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     return p;
 }
 
-#define LAUNCH_GEMM(MODE, BM, BN, WGM, WGN)                                                                                    \
-    hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN>),                                                     \
+#define LAUNCH_GEMM(MODE, BM, BN, WGM, WGN, BKT)                                                                               \
+    hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT>),                                                \
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(256), 0, st, \
                        a_src, w, bias, dst, g, act, p.z, order)
-#define DISPATCH_GEMM(MODE)                                          \
-    if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM(MODE, 128, 128, 2, 2); \
-    else if (p.bm == 128 && p.bn == 64) LAUNCH_GEMM(MODE, 128, 64, 2, 2); \
-    else if (p.bm == 128) LAUNCH_GEMM(MODE, 128, 32, 4, 1);          \
-    else if (p.bn == 128) LAUNCH_GEMM(MODE, 64, 128, 2, 2);          \
-    else LAUNCH_GEMM(MODE, 64, 64, 2, 2);
+#define DISPATCH_GEMM(MODE)                                                      \
+    if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM(MODE, 128, 128, 2, 2, 16);       \
+    else if (p.bm == 128 && p.bn == 64) {                                        \
+        if (p.bk == 32) LAUNCH_GEMM(MODE, 128, 64, 2, 2, 32);                    \
+        else LAUNCH_GEMM(MODE, 128, 64, 2, 2, 16);                               \
+    } else if (p.bm == 128) {                                                    \
+        if (p.bk == 32) LAUNCH_GEMM(MODE, 128, 32, 4, 1, 32);                    \
+        else LAUNCH_GEMM(MODE, 128, 32, 4, 1, 16);                               \
+    } else if (p.bn == 128) {                                                    \
+        if (p.bk == 32) LAUNCH_GEMM(MODE, 64, 128, 2, 2, 32);                    \
+        else LAUNCH_GEMM(MODE, 64, 128, 2, 2, 16);                               \
+    } else {                                                                     \
+        if (p.bk == 32) LAUNCH_GEMM(MODE, 64, 64, 2, 2, 32);                     \
+        else LAUNCH_GEMM(MODE, 64, 64, 2, 2, 16);                                \
+    }
 
 static int launch_gemm(int mode, const float *a_src, const float *w, const float *bias, float *out, float *ws, const ConvGeom &g,
                        int act, void *stream) {
@@ -789,11 +808,11 @@ static int launch_gemm(int mode, const float *a_src, const float *w, const float
 }
 
 // Register a measured tile / split-K plan for one geometry (mode 0 = fwd, 1 = dgrad): bm x bn in {128x128, 128x64, 64x128,
-// 64x64, 128x32}, z >= 1 split-K factor; bm = 0 removes the entry.  Returns SQD_EINVAL when the plan cannot run on this
+// 64x64, 128x32}, z >= 1 split-K factor, bk = 16 | 32 channels per reduction slice; bm = 0 removes the entry.  Returns SQD_EINVAL when the plan cannot run on this
 // geometry (tile wider than twice the channel count, z larger than a quarter of the reduction slices, workspace > 64 MB).
 // The next sqd_conv_plan / sqd_conv_fwd / sqd_conv_dgrad calls of that geometry use it.
 extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
-                                 int bm, int bn, int z) {
+                                 int bm, int bn, int z, int bk) {
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     std::lock_guard<std::mutex> lk(plan_mutex());
     if (bm == 0) {
@@ -802,14 +821,16 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     }
     const int Ncols = mode == 0 ? K : C;
     const int taps = mode == 0 ? R * S : ((R + stride - 1) / stride) * ((S + stride - 1) / stride);
-    const int T = taps * ((mode == 0 ? C : K) / BK);
+    SQD_CHECK_ARG(bk == 16 || (bk == 32 && (mode == 0 ? C : K) % 32 == 0 && bm + bn <= 192),
+                  "sqd_conv_set_plan: slice width %d not possible here (32 needs 32 | reduced channels and bm + bn <= 192)", bk);
+    const int T = taps * ((mode == 0 ? C : K) / bk);
     const int64_t out_elems = mode == 0 ? (int64_t)N * Ho * Wo * K : (int64_t)N * H * W * C;
     const bool tile_ok = (bm == 128 && (bn == 128 || bn == 64 || bn == 32)) || (bm == 64 && (bn == 128 || bn == 64));
     SQD_CHECK_ARG(tile_ok && z >= 1 && z <= 64, "sqd_conv_set_plan: unsupported plan %dx%d z=%d", bm, bn, z);
     SQD_CHECK_ARG(!(bn > 32 && bn >= 2 * Ncols) && !(bn == 32 && Ncols > 32), "sqd_conv_set_plan: tile width %d does not fit %d channels", bn, Ncols);
     SQD_CHECK_ARG(z == 1 || (z <= T / 2 && z * out_elems * 4 <= (64ll << 20) && out_elems % 4 == 0),
                   "sqd_conv_set_plan: split-K %d not possible here", z);
-    plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z);
+    plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, bk);
     return SQD_OK;
 }
 

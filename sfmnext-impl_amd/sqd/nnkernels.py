@@ -143,9 +143,9 @@ def _tune_conv(mode, geom, launch):
     _TUNED.add(key)
     L = _l.lib()
     best = None
-    for bm, bn in _TUNE_TILES:
-        for z in _TUNE_Z:
-            if L.sqd_conv_set_plan(mode, *geom, bm, bn, z) != 0:
+    for bm, bn, z, bk in ((bm, bn, z, bk) for bm, bn in _TUNE_TILES for bk in (16, 32) for z in _TUNE_Z):
+        if True:
+            if L.sqd_conv_set_plan(mode, *geom, bm, bn, z, bk) != 0:
                 continue
             _PLAN_CACHE.pop(key, None)
             ws = _conv_ws(mode, geom, torch.device("cuda", torch.cuda.current_device()))
@@ -158,12 +158,14 @@ def _tune_conv(mode, geom, launch):
             e1.synchronize()
             t = e0.elapsed_time(e1)
             if best is None or t < best[0]:
-                best = (t, bm, bn, z)
+                best = (t, bm, bn, z, bk)
     _PLAN_CACHE.pop(key, None)
     if best is None:
-        L.sqd_conv_set_plan(mode, *geom, 0, 0, 0)
+        L.sqd_conv_set_plan(mode, *geom, 0, 0, 0, 16)
     else:
-        L.sqd_conv_set_plan(mode, *geom, best[1], best[2], best[3])
+        L.sqd_conv_set_plan(mode, *geom, best[1], best[2], best[3], best[4])
+    if os.environ.get("SQD_TUNE_LOG"):
+        print("sqd conv plan", "dgrad" if mode else "fwd", geom, best, flush=True)
 
 
 def _wgrad_part_floats(geom):

@@ -54,3 +54,43 @@ def test_conv_fwd_bwd(N, C, H, W, K, R, stride, pad, bias, act):
     close(conv_g.weight.grad, conv.weight.grad, "dw", 5e-4)
     if bias:
         close(conv_g.bias.grad, conv.bias.grad, "db", 5e-4)
+
+
+@pytest.mark.parametrize("N,C,H,W,K,R,stride,pad", [(2, 64, 24, 40, 128, 3, 2, 1), (2, 128, 12, 20, 64, 1, 1, 0), (1, 256, 9, 11, 32, 3, 1, 1)])
+def test_every_registered_plan_is_exact(N, C, H, W, K, R, stride, pad):
+    """Every tile / split-K / slice-width plan sqd_conv_set_plan accepts must give the same convolution (the first-step
+    tuner picks among them by time alone)."""
+    from sqd import lib, nnkernels
+    L = lib.lib()
+    torch.manual_seed(7)
+    conv = nn.Conv2d(C, K, R, stride, pad, bias=True).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    geom = (N, H, W, C, K, R, R, stride, pad, Ho, Wo)
+    xr = x.clone().requires_grad_(True)
+    yr = conv(xr)
+    gy = torch.randn_like(yr)
+    gxr, = torch.autograd.grad(yr, xr, gy)
+    tried = 0
+    try:
+        for bm, bn in nnkernels._TUNE_TILES:
+            for bk in (16, 32):
+                for z in nnkernels._TUNE_Z:
+                    ok = [L.sqd_conv_set_plan(mode, *geom, bm, bn, z, bk) == 0 for mode in (0, 1)]
+                    if not any(ok):
+                        continue
+                    for mode in (0, 1):
+                        if not ok[mode]:
+                            L.sqd_conv_set_plan(mode, *geom, 0, 0, 0, 16)
+                    nnkernels._PLAN_CACHE.clear()
+                    xg = x.clone().requires_grad_(True)
+                    y = nnkernels.conv2d_native(xg, conv)
+                    gx, = torch.autograd.grad(y, xg, gy)
+                    tried += 1
+                    assert torch.allclose(y, yr, rtol=1e-4, atol=1e-4 * float(yr.abs().max())), (bm, bn, z, bk)
+                    assert torch.allclose(gx, gxr, rtol=1e-4, atol=1e-4 * float(gxr.abs().max())), (bm, bn, z, bk)
+    finally:
+        for mode in (0, 1):
+            L.sqd_conv_set_plan(mode, *geom, 0, 0, 0, 16)
+        nnkernels._PLAN_CACHE.clear()
+    assert tried >= 8
