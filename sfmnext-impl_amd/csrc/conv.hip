@@ -878,13 +878,31 @@ static int wgrad_impl_override() {              // SQD_WGRAD_IMPL=lds|direct for
     }
     return v;
 }
+// measured weight-gradient plans (sqd_conv_wgrad_set_plan): geometry -> (impl 0 = LDS-tiled / 1 = direct-operand, splits)
+typedef std::tuple<int, int, int, int, int, int, int> WPlanKey;
+static std::map<WPlanKey, std::pair<int, int>> &wplan_table() {
+    static std::map<WPlanKey, std::pair<int, int>> t;
+    return t;
+}
+static bool wplan_lookup(int N, int Ho, int Wo, int C, int K, int R, int S, int &impl, int &splits) {
+    std::lock_guard<std::mutex> lk(plan_mutex());
+    auto it = wplan_table().find(WPlanKey(N, Ho, Wo, C, K, R, S));
+    if (it == wplan_table().end()) return false;
+    impl = it->second.first;
+    splits = it->second.second;
+    return true;
+}
+
 static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, int S) {
     WgradPlan p;
     const int M = N * Ho * Wo;
     const int ov = wgrad_impl_override();
+    int m_impl = -1, m_splits = 0;
+    const bool measured = wplan_lookup(N, Ho, Wo, C, K, R, S, m_impl, m_splits);
     // the direct kernel wins where pixels are many and channels few (operand re-reads stay in L2); the LDS-tiled
     // kernel where K*C is large and the pixel count small
     p.direct = C % 16 == 0 && K % 16 == 0 && (ov == 2 || (ov == 0 && M >= 2048 && C <= 1024));
+    if (measured && ov == 0) p.direct = m_impl == 1 && C % 16 == 0 && K % 16 == 0;
     p.kt = K % 64 == 0 ? 4 : K % 32 == 0 ? 2 : 1;
     p.ct = C % 64 == 0 ? 4 : C % 32 == 0 ? 2 : 1;
     // a filter row (3 taps) per wave: measured SLOWER on every config-B layer (3x3 64..256 channels: 140 us vs 102 us) — the
@@ -892,7 +910,9 @@ static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, i
     static const bool tp3 = getenv("SQD_WGRAD_TP3") != nullptr;
     p.tp = (tp3 && S == 3 && p.kt * p.ct >= 8) ? 3 : 1;
     const int groups = (K / (16 * p.kt)) * (C / (16 * p.ct)) * (R * S / p.tp);
-    int sp = (1024 + groups - 1) / groups;                       // ~1k workgroups of 4 waves
+    int sp = (512 + groups - 1) / groups;                        // ~512 workgroups of 4 waves (measured plans mostly land at
+                                                                 // a quarter to a half of the ~1k first assumed)
+    if (measured) sp = m_splits;
     const int max_by_px = (M + 255) / 256;                       // >= 64 pixels per wave
     if (sp > max_by_px) sp = max_by_px;
     const int64_t wsz = (int64_t)K * R * S * C;
@@ -916,6 +936,10 @@ extern "C" int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, i
     const int bm = K >= 128 ? 128 : 64, bn = C >= 128 ? 128 : 64;
     const int tiles = ((K + bm - 1) / bm) * ((C + bn - 1) / bn) * R * S;
     int sp = (1536 + tiles - 1) / tiles;                         // aim at ~1.5k workgroups
+    {
+        int m_impl, m_splits;
+        if (wplan_lookup(N, Ho, Wo, C, K, R, S, m_impl, m_splits)) sp = m_splits;
+    }
     const int max_by_px = (M + 255) / 256;                      // at least 256 pixels per split
     if (sp > max_by_px) sp = max_by_px;
     const int64_t wsz = (int64_t)K * R * S * C;
@@ -923,6 +947,21 @@ extern "C" int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, i
     if (sp < 1) sp = 1;
     if (splits) *splits = sp;
     if (part_floats) *part_floats = (int64_t)sp * wsz;
+    return SQD_OK;
+}
+
+// Register a measured weight-gradient plan: impl 1 = direct-operand kernel, 0 = LDS-tiled kernel, -1 = clear; `splits` pixel
+// ranges (clamped by the library to >= 256 pixels per range and a 64 MB partial buffer).  sqd_conv_wgrad_plan reports the
+// resulting workspace.
+extern "C" int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int impl, int splits) {
+    std::lock_guard<std::mutex> lk(plan_mutex());
+    if (impl < 0) {
+        wplan_table().erase(WPlanKey(N, Ho, Wo, C, K, R, S));
+        return SQD_OK;
+    }
+    SQD_CHECK_ARG(impl <= 1 && splits >= 1 && splits <= 65535, "sqd_conv_wgrad_set_plan: bad plan impl=%d splits=%d", impl, splits);
+    SQD_CHECK_ARG(impl == 0 || (C % 16 == 0 && K % 16 == 0), "sqd_conv_wgrad_set_plan: the direct kernel needs C, K multiples of 16");
+    wplan_table()[WPlanKey(N, Ho, Wo, C, K, R, S)] = std::make_pair(impl, splits);
     return SQD_OK;
 }
 

@@ -112,6 +112,7 @@ _SIGNATURES = {
     "sqd_conv_fwd": (_I, [_P, _P, _P, _P, _P] + [_I] * 12 + [_P]),
     "sqd_conv_dgrad": (_I, [_P, _P, _P, _P] + [_I] * 11 + [_P]),
     "sqd_conv_wgrad_plan": (_I, [_I] * 7 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)]),
+    "sqd_conv_wgrad_set_plan": (_I, [_I] * 9),
     "sqd_conv_wgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
     "sqd_bins_supported": (_I, [_I, _I]),
     "sqd_bins_workspace": (_I, [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64)]),

@@ -168,6 +168,49 @@ def _tune_conv(mode, geom, launch):
         print("sqd conv plan", "dgrad" if mode else "fwd", geom, best, flush=True)
 
 
+def _tune_wgrad(geom, has_bias, launch):
+    """Same for the weight gradient: direct-operand vs LDS-tiled kernel, 1/8x .. 4x the model's pixel splits."""
+    key = ("w",) + tuple(geom)
+    if key in _TUNED or torch.cuda.is_current_stream_capturing():
+        return
+    _TUNED.add(key)
+    N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
+    L = _l.lib()
+    L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, -1, 0)
+    _PLAN_CACHE.pop(key, None)
+    _, base = _wgrad_part_floats(geom)
+    best = None
+    for impl in (1, 0):
+        if impl == 1 and (C % 16 or K % 16):
+            continue
+        tried = set()
+        for mult in (0.125, 0.25, 0.5, 1, 2, 4):
+            sp = max(1, int(base * mult))
+            if sp in tried:
+                continue
+            tried.add(sp)
+            if L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, impl, sp) != 0:
+                continue
+            _PLAN_CACHE.pop(key, None)
+            pf, splits = _wgrad_part_floats(geom)
+            extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if has_bias else 0
+            part = torch.empty(pf + extra, device="cuda", dtype=torch.float32)
+            launch(part)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                launch(part)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if best is None or t < best[0]:
+                best = (t, impl, sp)
+    L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, best[1], best[2])
+    _PLAN_CACHE.pop(key, None)
+    if os.environ.get("SQD_TUNE_LOG"):
+        print("sqd conv plan wgrad", geom, best, "model splits", base, flush=True)
+
+
 def _wgrad_part_floats(geom):
     N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
     key = ("w",) + tuple(geom)
@@ -227,11 +270,15 @@ class Conv2d(torch.autograd.Function):
             _l.check(L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), N, H, W, C, K, R, S, stride, pad, Ho, Wo, _stream()),
                      "conv_dgrad")
         if ctx.needs_input_grad[1]:
+            dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
+            db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+            if TUNE_CONV:
+                _tune_wgrad(ctx.geom, ctx.has_bias,
+                            lambda part: L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride,
+                                                          pad, Ho, Wo, _stream()))
             pf, splits = _wgrad_part_floats(ctx.geom)
             extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if ctx.has_bias else 0
             part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
-            dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
-            db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
             _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
                                       _stream()), "conv_wgrad")
         return dx, dw, db, None, None, None
