@@ -233,8 +233,9 @@ int sqd_conv_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int
                   int64_t *ws_floats);
 int sqd_conv_fwd(const float *x, const float *w, const float *bias, float *y, float *ws, int N, int H, int W, int C, int K,
                  int R, int S, int stride, int pad, int Ho, int Wo, int act, void *stream);
-int sqd_conv_dgrad(const float *dy, const float *w, float *dx, float *ws, int N, int H, int W, int C, int K, int R, int S,
-                   int stride, int pad, int Ho, int Wo, void *stream);
+/* addend [N,H,W,C] or NULL: dx = dgrad + addend (the gradient arriving over a second path, e.g. the residual branch) */
+int sqd_conv_dgrad(const float *dy, const float *w, const float *addend, float *dx, float *ws, int N, int H, int W, int C,
+                   int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream);
 /* workspace of the weight gradient: `part_floats` floats (+ max(ceil(N*Ho*Wo/1024), splits) * K more when dbias is wanted) */
 int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *splits, int64_t *part_floats);
 /* measured plan for the weight gradient: impl 1 = direct-operand kernel, 0 = LDS-tiled kernel, -1 = clear */

@@ -197,7 +197,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
         for (int idx = t; idx < BM * QN; idx += 256) {
             const int ml = idx / QN, c = n0 + (idx % QN) * 4;
             const int px = rowpix[ml];
-            if (px >= 0 && c < Ncols) *reinterpret_cast<float4 *>(dst + (size_t)px * Ncols + c) = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (px >= 0 && c < Ncols)
+                *reinterpret_cast<float4 *>(dst + (size_t)px * Ncols + c) =
+                    (bias && zsplits == 1) ? *reinterpret_cast<const float4 *>(bias + (size_t)px * Ncols + c) : make_float4(0.f, 0.f, 0.f, 0.f);
         }
         return;
     }
@@ -279,6 +281,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
                 const int m = MODE == 0 ? m0 + ml : rowpix[ml];
                 if (MODE == 0 ? m < Mrows : m >= 0) {
                     float v = acc[i][j][e] + bv;
+                    if (MODE == 1 && bias && zsplits == 1) v += bias[(size_t)m * Ncols + col];   // dgrad: `bias` is the [N,H,W,C] addend
                     if (MODE == 0 && act == 1 && zsplits == 1) v = v > 0.f ? v : 0.f;
                     dst[(size_t)m * Ncols + col] = v;
                 }
@@ -612,7 +615,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
 
 // sum of the split-K partial tiles (+ bias, + activation): part [Z][M*Ncols] -> out [M*Ncols]
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias,
-                                                          float *__restrict__ out, size_t n, int Z, int Ncols, int act) {
+                                                          const float *__restrict__ addend, float *__restrict__ out, size_t n, int Z,
+                                                          int Ncols, int act) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (size_t)gridDim.x * 256) {
         float4 a = reinterpret_cast<const float4 *>(part)[i];
         for (int z = 1; z < Z; ++z) {
@@ -621,6 +625,10 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restric
         }
         if (bias) {
             const float4 bv = *reinterpret_cast<const float4 *>(bias + (i * 4) % Ncols);
+            a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
+        }
+        if (addend) {
+            const float4 bv = reinterpret_cast<const float4 *>(addend)[i];
             a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w;
         }
         if (act == 1) {
@@ -801,7 +809,7 @@ static int launch_gemm(int mode, const float *a_src, const float *w, const float
     if (p.z > 1) {
         const size_t n = (size_t)Mrows * Ncols;
         size_t nb = (n / 4 + 255) / 256;
-        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, ws, mode == 0 ? bias : nullptr,
+        hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, ws, mode == 0 ? bias : nullptr, mode == 1 ? bias : nullptr,
                            out, n, p.z, Ncols, mode == 0 ? act : 0);
     }
     return SQD_OK;
@@ -854,14 +862,16 @@ extern "C" int sqd_conv_fwd(const float *x, const float *w, const float *bias, f
     return SQD_OK;
 }
 
-// dy [N,Ho,Wo,K], w [K,R,S,C] -> dx [N,H,W,C]
-extern "C" int sqd_conv_dgrad(const float *dy, const float *w, float *dx, float *ws, int N, int H, int W, int C, int K, int R,
-                              int S, int stride, int pad, int Ho, int Wo, void *stream) {
+// dy [N,Ho,Wo,K], w [K,R,S,C] -> dx [N,H,W,C] (+ addend [N,H,W,C] when not NULL: the gradient arriving over a second path,
+// e.g. the residual branch, is added in the epilogue instead of by a separate pass)
+extern "C" int sqd_conv_dgrad(const float *dy, const float *w, const float *addend, float *dx, float *ws, int N, int H, int W, int C,
+                              int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream) {
     SQD_CHECK_ARG(dy && w && dx, "sqd_conv_dgrad: null pointer");
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     if (check_geom("sqd_conv_dgrad", g)) return SQD_EINVAL;
     SQD_CHECK_ARG(K % 16 == 0 && C % 4 == 0, "sqd_conv_dgrad: K=%d must be a multiple of 16 and C=%d of 4", K, C);
-    if (launch_gemm(1, dy, w, nullptr, dx, ws, g, 0, stream)) return SQD_EINVAL;
+    SQD_CHECK_ARG(addend != dx, "sqd_conv_dgrad: addend must not alias dx");
+    if (launch_gemm(1, dy, w, addend, dx, ws, g, 0, stream)) return SQD_EINVAL;
     SQD_CHECK_LAUNCH("sqd_conv_dgrad");
     return SQD_OK;
 }

@@ -45,8 +45,10 @@ class _Residual(nn.Module):
             self.downsample = nn.Sequential(_conv(cin, cout, 1, stride), nn.BatchNorm2d(cout))
 
     def forward(self, x):
+        # x has two consumers (conv1 and the shortcut): the second one reads the copy handed through conv1's node, so both
+        # gradients meet in conv1's data-gradient kernel (nnops.conv_bn_act, skip=True)
+        y, x = X.conv_bn_act(x, self.conv1, self.bn1, "relu", skip=True)
         shortcut = x if self.downsample is None else X.conv_bn_act(x, self.downsample[0], self.downsample[1], None)
-        y = X.conv_bn_act(x, self.conv1, self.bn1, "relu")
         if self.kind == "bottleneck":
             y = X.conv_bn_act(y, self.conv2, self.bn2, "relu")
             return X.conv_bn_act(y, self.conv3, self.bn3, "relu", residual=shortcut)

@@ -110,7 +110,7 @@ _SIGNATURES = {
     "sqd_conv_set_plan": (_I, [_I] * 16),
     "sqd_conv_plan": (_I, [_I] * 12 + [ctypes.POINTER(ctypes.c_int64)]),
     "sqd_conv_fwd": (_I, [_P, _P, _P, _P, _P] + [_I] * 12 + [_P]),
-    "sqd_conv_dgrad": (_I, [_P, _P, _P, _P] + [_I] * 11 + [_P]),
+    "sqd_conv_dgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
     "sqd_conv_wgrad_plan": (_I, [_I] * 7 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)]),
     "sqd_conv_wgrad_set_plan": (_I, [_I] * 9),
     "sqd_conv_wgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),

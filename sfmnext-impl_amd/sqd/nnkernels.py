@@ -230,10 +230,15 @@ def conv_module_supported(conv):
 
 class Conv2d(torch.autograd.Function):
     """nn.Conv2d (square stride / padding, dilation 1, groups 1) on the fp32 matrix cores, channels-last.
-    forward(x [N,C,H,W], weight [K,C,R,S], bias [K] | None, stride, pad, act) -> y [N,K,Ho,Wo]"""
+    forward(x [N,C,H,W], weight [K,C,R,S], bias [K] | None, stride, pad, act, skip) -> y [N,K,Ho,Wo]  (skip: -> (y, x'))
+
+    With skip=True the node also returns its input as a second output x' (same storage).  A consumer that would have read
+    x a second time (the residual branch, a down-sample convolution) reads x' instead; autograd then hands both
+    gradients to this node, and the data gradient adds the second one in its epilogue (sqd_conv_dgrad's addend) instead
+    of ATen running a separate 3-pass add over the activation."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act):
+    def forward(ctx, x, weight, bias, stride, pad, act, skip=False):
         _require(x, "Conv2d input")
         x, w = _cl(x), _cl(weight)
         N, C, H, W = x.shape
@@ -250,13 +255,18 @@ class Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x, w, y if act == "relu" else None)
         ctx.geom = (N, H, W, C, K, R, S, stride, pad, Ho, Wo)
         ctx.has_bias, ctx.act = bias is not None, act
+        if skip:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_skip=None):
         x, w, y = ctx.saved_tensors
         N, H, W, C, K, R, S, stride, pad, Ho, Wo = ctx.geom
+        if dy is None:                                   # only the pass-through output was used
+            return g_skip, None, None, None, None, None, None
         dy = _cl(dy)
+        g_skip = _cl(g_skip) if g_skip is not None else None
         if ctx.act == "relu":
             dy = dy * (y > 0)
         L = _l.lib()
@@ -264,11 +274,13 @@ class Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
             if TUNE_CONV:
-                _tune_conv(1, ctx.geom, lambda ws: L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), N, H, W, C, K, R, S, stride,
-                                                                    pad, Ho, Wo, _stream()))
+                _tune_conv(1, ctx.geom, lambda ws: L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(g_skip), _ptr(dx), _ptr(ws), N, H, W, C, K, R,
+                                                                    S, stride, pad, Ho, Wo, _stream()))
             ws = _conv_ws(1, ctx.geom, dy.device)
-            _l.check(L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(dx), _ptr(ws), N, H, W, C, K, R, S, stride, pad, Ho, Wo, _stream()),
-                     "conv_dgrad")
+            _l.check(L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(g_skip), _ptr(dx), _ptr(ws), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
+                                      _stream()), "conv_dgrad")
+        elif g_skip is not None:
+            dx = g_skip
         if ctx.needs_input_grad[1]:
             dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
             db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
@@ -281,14 +293,14 @@ class Conv2d(torch.autograd.Function):
             part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
             _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
                                       _stream()), "conv_wgrad")
-        return dx, dw, db, None, None, None
+        return dx, dw, db, None, None, None, None
 
 
-def conv2d_native(x, conv, act=None):
+def conv2d_native(x, conv, act=None, skip=False):
     s, p = conv.stride, conv.padding
     if s[0] != s[1] or p[0] != p[1] or conv.dilation != (1, 1) or conv.groups != 1:
         raise RuntimeError("sqd: native conv handles square stride/padding, dilation 1, groups 1")
-    return Conv2d.apply(x, conv.weight, conv.bias, s[0], p[0], act)
+    return Conv2d.apply(x, conv.weight, conv.bias, s[0], p[0], act, skip)
 
 
 _DEFER_COUNTERS = False

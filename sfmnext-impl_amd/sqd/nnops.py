@@ -40,12 +40,14 @@ def set_native_conv(on):
     BACKEND["conv_bn_act"] = ("hip conv" if on else "aten conv") + " + hip bn/act/residual"
 
 
-def _conv(x, conv, act=None):
+def _conv(x, conv, act=None, skip=False):
+    """skip=True: -> (y, x') with x' the input handed through the convolution node (see nnkernels.Conv2d)."""
     if NATIVE_CONV and x.is_cuda:
         from . import nnkernels
         if nnkernels.conv_module_supported(conv):
-            return nnkernels.conv2d_native(x, conv, act)
-    return _act(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), act)
+            return nnkernels.conv2d_native(x, conv, act, skip)
+    y = _act(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), act)
+    return (y, x) if skip else y
 
 
 def conv2d(x, conv, act=None):
@@ -53,12 +55,21 @@ def conv2d(x, conv, act=None):
     return _conv(x, conv, act)
 
 
-def conv_bn_act(x, conv, bn, act, residual=None, input_affine=None):
+def conv_bn_act(x, conv, bn, act, residual=None, input_affine=None, skip=False):
     """[input (x-a)/b] -> conv -> BatchNorm2d (batch stats in training, running stats in eval)
-    -> [+ residual] -> activation."""
+    -> [+ residual] -> activation.  skip=True: -> (y, x') where x' must replace x for every further consumer of x (the
+    residual branch, the down-sample convolution): their gradient then reaches x through this convolution's data-gradient
+    epilogue instead of a separate accumulation pass."""
     if input_affine is not None:
         x = (x - input_affine[0]) / input_affine[1]
+    if skip:
+        y, x_skip = _conv(x, conv, None, True)
+        return _bn_act(y, bn, act, residual), x_skip
     y = _conv(x, conv)
+    return _bn_act(y, bn, act, residual)
+
+
+def _bn_act(y, bn, act, residual):
     if y.is_cuda:
         from . import nnkernels
         if not nnkernels.bn_supported(y.shape[1]):

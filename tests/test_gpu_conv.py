@@ -56,10 +56,12 @@ def test_conv_fwd_bwd(N, C, H, W, K, R, stride, pad, bias, act):
         close(conv_g.bias.grad, conv.bias.grad, "db", 5e-4)
 
 
-@pytest.mark.parametrize("N,C,H,W,K,R,stride,pad", [(2, 64, 24, 40, 128, 3, 2, 1), (2, 128, 12, 20, 64, 1, 1, 0), (1, 256, 9, 11, 32, 3, 1, 1)])
+@pytest.mark.parametrize("N,C,H,W,K,R,stride,pad", [(2, 64, 24, 40, 128, 3, 2, 1), (2, 128, 12, 20, 64, 1, 1, 0), (1, 256, 9, 11, 32, 3, 1, 1),
+                                                     (2, 64, 12, 20, 128, 1, 2, 0)])
 def test_every_registered_plan_is_exact(N, C, H, W, K, R, stride, pad):
     """Every tile / split-K / slice-width plan sqd_conv_set_plan accepts must give the same convolution (the first-step
-    tuner picks among them by time alone)."""
+    tuner picks among them by time alone).  The node runs with its pass-through output (skip=True), so the data gradient
+    also has to add the second gradient in its epilogue — including the stride classes that are a pure fill."""
     from sqd import lib, nnkernels
     L = lib.lib()
     torch.manual_seed(7)
@@ -71,6 +73,8 @@ def test_every_registered_plan_is_exact(N, C, H, W, K, R, stride, pad):
     yr = conv(xr)
     gy = torch.randn_like(yr)
     gxr, = torch.autograd.grad(yr, xr, gy)
+    gskip = torch.randn_like(x)
+    gxr = gxr + gskip
     tried = 0
     try:
         for bm, bn in nnkernels._TUNE_TILES:
@@ -84,8 +88,9 @@ def test_every_registered_plan_is_exact(N, C, H, W, K, R, stride, pad):
                             L.sqd_conv_set_plan(mode, *geom, 0, 0, 0, 16)
                     nnkernels._PLAN_CACHE.clear()
                     xg = x.clone().requires_grad_(True)
-                    y = nnkernels.conv2d_native(xg, conv)
-                    gx, = torch.autograd.grad(y, xg, gy)
+                    y, xs = nnkernels.conv2d_native(xg, conv, None, True)
+                    assert xs.data_ptr() == xg.data_ptr()
+                    gx, = torch.autograd.grad((y, xs), xg, (gy, gskip))
                     tried += 1
                     assert torch.allclose(y, yr, rtol=1e-4, atol=1e-4 * float(yr.abs().max())), (bm, bn, z, bk)
                     assert torch.allclose(gx, gxr, rtol=1e-4, atol=1e-4 * float(gxr.abs().max())), (bm, bn, z, bk)

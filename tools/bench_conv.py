@@ -78,7 +78,7 @@ for name, C, H, W, K, R, st, pad, cnt in L:
     LIB.sqd_conv_wgrad_plan(N, Ho, Wo, C, K, R, R, ctypes.byref(sp), ctypes.byref(pf))
     part = torch.empty(pf.value, device="cuda")
     t_nf = timeit(lambda: LIB.sqd_conv_fwd(P(x), P(w), None, P(y), P(ws0), *geom, 0, ST()), args.iters)
-    t_nd = timeit(lambda: LIB.sqd_conv_dgrad(P(dy), P(w), P(dx), P(ws1), *geom, ST()), args.iters)
+    t_nd = timeit(lambda: LIB.sqd_conv_dgrad(P(dy), P(w), None, P(dx), P(ws1), *geom, ST()), args.iters)
     t_nw = timeit(lambda: LIB.sqd_conv_wgrad(P(dy), P(x), P(dw), None, P(part), *geom, ST()), args.iters)
     cb = torch.ops.aten.convolution_backward
     a = (None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1)
