@@ -14,6 +14,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--N", type=int, default=12)
 ap.add_argument("--only", default="", help="comma-separated substrings of layer names")
+ap.add_argument("--tune", action="store_true", help="time the registered plans per layer first (what the Trainer's first step does)")
 args = ap.parse_args()
 N = args.N
 L = [  # name, C, H, W, K, R, stride, pad, count (occurrences per forward)
@@ -73,6 +74,10 @@ for name, C, H, W, K, R, st, pad, cnt in L:
     dy = torch.randn_like(y)
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
+    if args.tune:
+        nnkernels._tune_conv(0, geom, lambda ws: LIB.sqd_conv_fwd(P(x), P(w), None, P(y), P(ws), *geom, 0, ST()))
+        nnkernels._tune_conv(1, geom, lambda ws: LIB.sqd_conv_dgrad(P(dy), P(w), None, P(dx), P(ws), *geom, ST()))
+        nnkernels._tune_wgrad(geom, False, lambda part: LIB.sqd_conv_wgrad(P(dy), P(x), P(dw), None, P(part), *geom, ST()))
     ws0, ws1 = nnkernels._conv_ws(0, geom, x.device), nnkernels._conv_ws(1, geom, x.device)
     sp, pf = ctypes.c_int(0), ctypes.c_int64(0)
     LIB.sqd_conv_wgrad_plan(N, Ho, Wo, C, K, R, R, ctypes.byref(sp), ctypes.byref(pf))
