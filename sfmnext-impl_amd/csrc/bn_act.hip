@@ -30,6 +30,25 @@ __device__ __forceinline__ float act_bwd(float y, int act) {
     if (act == ACT_LEAKY) return y > 0.f ? 1.f : LEAKY_SLOPE;
     return 1.f;
 }
+// ... or through the sign bit the forward stored (mask byte of a float4 group: bit j = element j was positive): the
+// backward then reads 1 byte instead of 16 to know the activation's derivative
+__device__ __forceinline__ float act_bwd_bit(unsigned bits, int j, int act) {
+    const bool pos = (bits >> j) & 1u;
+    if (act == ACT_RELU) return pos ? 1.f : 0.f;
+    if (act == ACT_LEAKY) return pos ? 1.f : LEAKY_SLOPE;
+    return 1.f;
+}
+// the four activation derivatives of float4 group `idx`: from the mask when there is one, else from y (not read at all
+// when there is no activation)
+__device__ __forceinline__ float4 act_bwd4(const unsigned char *__restrict__ mask, const float *__restrict__ y, size_t idx, int act) {
+    if (act == ACT_NONE) return make_float4(1.f, 1.f, 1.f, 1.f);
+    if (mask) {
+        const unsigned bits = mask[idx];
+        return make_float4(act_bwd_bit(bits, 0, act), act_bwd_bit(bits, 1, act), act_bwd_bit(bits, 2, act), act_bwd_bit(bits, 3, act));
+    }
+    const float4 yv = reinterpret_cast<const float4 *>(y)[idx];
+    return make_float4(act_bwd(yv.x, act), act_bwd(yv.y, act), act_bwd(yv.z, act), act_bwd(yv.w, act));
+}
 
 struct Geom {
     int V, TPR, RP, rows_per_block, nblk;
@@ -52,7 +71,7 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                         const float *__restrict__ y, const float *__restrict__ mean,
                                                         const float *__restrict__ rstd, float *__restrict__ part, int M,
-                                                        int C, int act, Geom g) {
+                                                        int C, int act, Geom g, const unsigned char *__restrict__ mask) {
     const int t = threadIdx.x;
     const int cg0 = t % g.TPR, rr = t / g.TPR;
     const int r0 = blockIdx.x * g.rows_per_block, r1 = min(M, r0 + g.rows_per_block);
@@ -72,9 +91,8 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict_
                 b.x = fmaf(xv.x, xv.x, b.x); b.y = fmaf(xv.y, xv.y, b.y); b.z = fmaf(xv.z, xv.z, b.z); b.w = fmaf(xv.w, xv.w, b.w);
             } else {
                 const float4 gy = *reinterpret_cast<const float4 *>(dy + o);
-                const float4 yv = *reinterpret_cast<const float4 *>(y + o);
-                const float d0 = gy.x * act_bwd(yv.x, act), d1 = gy.y * act_bwd(yv.y, act);
-                const float d2 = gy.z * act_bwd(yv.z, act), d3 = gy.w * act_bwd(yv.w, act);
+                const float4 da = act_bwd4(mask, y, o / 4, act);
+                const float d0 = gy.x * da.x, d1 = gy.y * da.y, d2 = gy.z * da.z, d3 = gy.w * da.w;
                 a.x += d0; a.y += d1; a.z += d2; a.w += d3;
                 b.x = fmaf(d0, (xv.x - mu.x) * rs.x, b.x); b.y = fmaf(d1, (xv.y - mu.y) * rs.y, b.y);
                 b.z = fmaf(d2, (xv.z - mu.z) * rs.z, b.z); b.w = fmaf(d3, (xv.w - mu.w) * rs.w, b.w);
@@ -160,7 +178,8 @@ template <bool EVAL>
 __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float *__restrict__ x, const float *__restrict__ res,
                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
                                                            const float *__restrict__ mean, const float *__restrict__ rstd,
-                                                           float *__restrict__ y, size_t total4, int C, float eps, int act) {
+                                                           float *__restrict__ y, size_t total4, int C, float eps, int act,
+                                                           unsigned char *__restrict__ mask) {
     const int V = C / 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
         const int cg = (int)(i % V);
@@ -178,6 +197,8 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float *__restri
             const float4 rv = reinterpret_cast<const float4 *>(res)[i];
             o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
         }
+        if (!EVAL && mask)
+            mask[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
         o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
         reinterpret_cast<float4 *>(y)[i] = o;
     }
@@ -188,19 +209,18 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
                                                            const float *__restrict__ mean, const float *__restrict__ rstd,
                                                            const float *__restrict__ dgamma, const float *__restrict__ dbeta,
                                                            float *__restrict__ dx, float *__restrict__ dres, size_t total4,
-                                                           int C, float invM, int act) {
+                                                           int C, float invM, int act, const unsigned char *__restrict__ mask) {
     const int V = C / 4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
         const int cg = (int)(i % V);
         const float4 gy = reinterpret_cast<const float4 *>(dy)[i];
         const float4 xv = reinterpret_cast<const float4 *>(x)[i];
-        const float4 yv = reinterpret_cast<const float4 *>(y)[i];
+        const float4 da = act_bwd4(mask, y, i, act);
         const float4 ga = reinterpret_cast<const float4 *>(gamma)[cg], mu = reinterpret_cast<const float4 *>(mean)[cg];
         const float4 rs = reinterpret_cast<const float4 *>(rstd)[cg];
         const float4 dg = reinterpret_cast<const float4 *>(dgamma)[cg], db = reinterpret_cast<const float4 *>(dbeta)[cg];
         float4 dz, o;
-        dz.x = gy.x * act_bwd(yv.x, act); dz.y = gy.y * act_bwd(yv.y, act);
-        dz.z = gy.z * act_bwd(yv.z, act); dz.w = gy.w * act_bwd(yv.w, act);
+        dz.x = gy.x * da.x; dz.y = gy.y * da.y; dz.z = gy.z * da.z; dz.w = gy.w * da.w;
         o.x = ga.x * rs.x * (dz.x - db.x * invM - (xv.x - mu.x) * rs.x * (dg.x * invM));
         o.y = ga.y * rs.y * (dz.y - db.y * invM - (xv.y - mu.y) * rs.y * (dg.y * invM));
         o.z = ga.z * rs.z * (dz.z - db.z * invM - (xv.z - mu.z) * rs.z * (dg.z * invM));
@@ -228,19 +248,20 @@ extern "C" int sqd_bn_nblk(int M, int C) {
 }
 
 extern "C" int sqd_bn_train_fwd(const float *x, const float *res, const float *gamma, const float *beta, float *running_mean,
-                                float *running_var, float *y, float *save_mean, float *save_rstd, float *part, int M, int C,
-                                float eps, float momentum, int act, void *stream) {
+                                float *running_var, float *y, unsigned char *mask, float *save_mean, float *save_rstd, float *part,
+                                int M, int C, float eps, float momentum, int act, void *stream) {
     SQD_CHECK_ARG(x && gamma && beta && y && save_mean && save_rstd && part, "sqd_bn_train_fwd: null pointer");
     if (check("sqd_bn_train_fwd", M, C)) return SQD_EINVAL;
     const Geom g = geom(M, C);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(g.nblk), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, part, M, C, act, g);
+    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(g.nblk), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, part, M, C, act, g,
+                       (const unsigned char *)nullptr);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, part, g.nblk, M, C, eps, momentum,
                        save_mean, save_rstd, running_mean, running_var);
     const size_t total4 = (size_t)M * C / 4;
     hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), dim3(ew_grid(total4)), dim3(256), 0, s, x, res, gamma, beta, save_mean,
-                       save_rstd, y, total4, C, eps, act);
+                       save_rstd, y, total4, C, eps, act, mask);
     SQD_CHECK_LAUNCH("sqd_bn_train_fwd");
     return SQD_OK;
 }
@@ -253,24 +274,25 @@ extern "C" int sqd_bn_eval_fwd(const float *x, const float *res, const float *ga
     const size_t total4 = (size_t)M * C / 4;
     (void)hipGetLastError();
     hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,
-                       beta, running_mean, running_var, y, total4, C, eps, act);
+                       beta, running_mean, running_var, y, total4, C, eps, act, (unsigned char *)nullptr);
     SQD_CHECK_LAUNCH("sqd_bn_eval_fwd");
     return SQD_OK;
 }
 
-extern "C" int sqd_bn_train_bwd(const float *dy, const float *x, const float *y, const float *gamma, const float *save_mean,
-                                const float *save_rstd, float *dx, float *dres, float *dgamma, float *dbeta, float *part,
-                                int M, int C, int act, void *stream) {
-    SQD_CHECK_ARG(dy && x && y && gamma && save_mean && save_rstd && dx && dgamma && dbeta && part, "sqd_bn_train_bwd: null pointer");
+extern "C" int sqd_bn_train_bwd(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
+                                const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma, float *dbeta,
+                                float *part, int M, int C, int act, void *stream) {
+    SQD_CHECK_ARG(dy && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && part, "sqd_bn_train_bwd: null pointer");
+    SQD_CHECK_ARG(act == ACT_NONE || y || mask, "sqd_bn_train_bwd: an activation needs y or the sign mask of the forward");
     if (check("sqd_bn_train_bwd", M, C)) return SQD_EINVAL;
     const Geom g = geom(M, C);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nblk), dim3(256), 0, s, x, dy, y, save_mean, save_rstd, part, M, C, act, g);
+    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nblk), dim3(256), 0, s, x, dy, y, save_mean, save_rstd, part, M, C, act, g, mask);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, part, g.nblk, M, C, dgamma, dbeta);
     const size_t total4 = (size_t)M * C / 4;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, s, dy, x, y, gamma, save_mean, save_rstd, dgamma,
-                       dbeta, dx, dres, total4, C, 1.0f / (float)M, act);
+                       dbeta, dx, dres, total4, C, 1.0f / (float)M, act, mask);
     SQD_CHECK_LAUNCH("sqd_bn_train_bwd");
     return SQD_OK;
 }

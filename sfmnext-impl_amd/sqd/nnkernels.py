@@ -54,10 +54,12 @@ class BatchNormAct(torch.autograd.Function):
             part = torch.empty(nblk * C * 2, device=x.device, dtype=torch.float32)
             mean = torch.empty(C, device=x.device, dtype=torch.float32)
             rstd = torch.empty(C, device=x.device, dtype=torch.float32)
+            # sign bits of the pre-activation (1 byte per 4 elements): the backward reads them instead of y
+            mask = torch.empty(M * C // 4, device=x.device, dtype=torch.uint8) if code else None
             _l.check(L.sqd_bn_train_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                        _ptr(y), _ptr(mean), _ptr(rstd), _ptr(part), M, C, float(eps), float(momentum), code,
-                                        _stream()), "bn_train_fwd")
-            ctx.save_for_backward(x, y, gamma, mean, rstd)
+                                        _ptr(y), _ptr(mask), _ptr(mean), _ptr(rstd), _ptr(part), M, C, float(eps), float(momentum),
+                                        code, _stream()), "bn_train_fwd")
+            ctx.save_for_backward(x, mask, gamma, mean, rstd)
             ctx.has_res, ctx.code = residual is not None, code
         else:
             _l.check(L.sqd_bn_eval_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
@@ -70,7 +72,7 @@ class BatchNormAct(torch.autograd.Function):
     def backward(ctx, dy):
         if not ctx.training:
             raise NotImplementedError("sqd: BatchNormAct backward is implemented for training mode only")
-        x, y, gamma, mean, rstd = ctx.saved_tensors
+        x, mask, gamma, mean, rstd = ctx.saved_tensors
         dy = _cl(dy)
         N, C, H, W = x.shape
         M = N * H * W
@@ -80,7 +82,7 @@ class BatchNormAct(torch.autograd.Function):
         dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
         part = torch.empty(L.sqd_bn_nblk(M, C) * C * 2, device=x.device, dtype=torch.float32)
-        _l.check(L.sqd_bn_train_bwd(_ptr(dy), _ptr(x), _ptr(y), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
+        _l.check(L.sqd_bn_train_bwd(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
                                     _ptr(dgamma), _ptr(dbeta), _ptr(part), M, C, ctx.code, _stream()), "bn_train_bwd")
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None
 

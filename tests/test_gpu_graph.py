@@ -37,17 +37,30 @@ def run(extra, steps=7):
     return tr, losses, params
 
 
+def _drift(pa, pb):
+    """worst over the state-dict tensors of max|a-b| / (max|a| + 1e-3)"""
+    worst = ("", 0.0)
+    for k in pa:
+        a, b = pa[k].float(), pb[k].float()
+        d = float((a - b).abs().max()) / (float(a.abs().max()) + 1e-3)
+        if d > worst[1]:
+            worst = (k, d)
+    return worst
+
+
 def test_graph_replay_matches_eager():
     tr_e, loss_e, par_e = run(["--sqd_no_graph"])
+    _, loss_e2, par_e2 = run(["--sqd_no_graph"])
     tr_g, loss_g, par_g = run([])
-    assert tr_e._graph is None and tr_g._graph is not None, "the second run must have replayed a captured graph"
+    assert tr_e._graph is None and tr_g._graph is not None, "the third run must have replayed a captured graph"
     for a, b in zip(loss_e, loss_g):
         assert abs(a - b) <= 1e-5 * abs(a) + 1e-7, (loss_e, loss_g)
-    for k in par_e:
-        a, b = par_e[k].float(), par_g[k].float()
-        # not bit-equal: ATen's max-pool backward accumulates with atomics, and Adam's m/sqrt(v) amplifies the last bit
-        # (an Adam step moves a parameter by ~lr whatever the gradient's magnitude: 10% of the 7 * 1e-4 travelled is the floor)
-        assert float((a - b).abs().max()) <= 5e-4 * float(a.abs().max()) + 7e-5, (k, float((a - b).abs().max()))
+    # Two eager runs already differ (ATen's max-pool backward accumulates with atomics, and Adam's m/sqrt(v) turns a
+    # last-bit gradient difference of a zero-initialised bias into a step of ~lr): the replay must stay within that
+    # envelope.  A replay bug (frozen bias correction, stale learning rate) shows up as a drift of ~0.2.
+    k_ee, d_ee = _drift(par_e, par_e2)
+    k_eg, d_eg = _drift(par_e, par_g)
+    assert d_eg <= max(3.0 * d_ee, 5e-3) and d_eg < 0.05, (k_eg, d_eg, k_ee, d_ee)
     # Adam bookkeeping kept in step: torch.optim state_dict compatibility
     st_e = tr_e.model_optimizer.state_dict()["state"]
     st_g = tr_g.model_optimizer.state_dict()["state"]
