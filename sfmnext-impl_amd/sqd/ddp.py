@@ -32,6 +32,11 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def _dense(p):
+    """p occupies numel() contiguous elements in some dimension order (contiguous or channels-last)."""
+    return p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+
+
 class GradBucketReducer:
     def __init__(self, params, bucket_mb=32.0, process_group=None):
         self.group = process_group
@@ -81,7 +86,9 @@ class GradBucketReducer:
             off = 0
             for p in plist:
                 n = p.numel()
-                view = flat[off:off + n].view_as(p)
+                # the view carries the PARAMETER's strides (channels-last filters stay KRSC in the bucket): autograd then
+                # accumulates in place and FusedAdam reads the bucket memory directly, no layout copy in between
+                view = flat.as_strided(p.shape, p.stride(), off) if _dense(p) else flat[off:off + n].view_as(p)
                 view.copy_(p.grad)
                 p.grad = view                      # gradients now accumulate straight into the bucket
                 self._bucket_of[p] = bi
