@@ -49,6 +49,7 @@ class GradBucketReducer:
         self.buckets = None          # built after the first backward (unused-parameter detection)
         self._hooks = []
         self._works = []
+        self.hooks_enabled = True     # False while a hipGraph of forward+backward is captured / replayed (see allreduce_all)
 
     # -- start-up ---------------------------------------------------------------------------------
     def broadcast_parameters(self, modules):
@@ -111,11 +112,36 @@ class GradBucketReducer:
         self._works = []
 
     def _on_grad(self, p):
+        if not self.hooks_enabled:
+            return
         bi = self._bucket_of[p]
         self._pending[bi] -= 1
         if self._pending[bi] == 0 and self.active:
             op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
             self._works.append(dist.all_reduce(self.flat[bi], op=op, group=self.group, async_op=True))
+
+    def detach_grad_views(self):
+        """Graph mode: hand back {parameter: its bucket view} and clear p.grad, so that a captured backward produces fresh
+        gradient tensors which the caller copies into the views (and re-attaches the views afterwards)."""
+        views = {}
+        for plist in self.buckets:
+            for p in plist:
+                views[p] = p.grad
+                p.grad = None
+        return views
+
+    def allreduce_all(self):
+        """Exchange every bucket now (graph mode: forward+backward were replayed as one hipGraph, which leaves no Python
+        hook to overlap with; the 4-5 collectives are issued back to back on RCCL's stream and joined)."""
+        if not self.active or self.buckets is None:
+            return
+        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
+        works = [dist.all_reduce(flat, op=op, group=self.group, async_op=True) for flat in self.flat]
+        for w in works:
+            w.wait()
+        if not self._avg:
+            for flat in self.flat:
+                flat.div_(self.world)
 
     def finish(self):
         """Call after loss.backward(): waits for the in-flight buckets and turns sums into means."""

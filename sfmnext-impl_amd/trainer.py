@@ -107,8 +107,10 @@ class Trainer:
         if self.reducer is not None:
             self.reducer.broadcast_parameters(self.models.values())
 
-        self._graph_ok = not self.opt.sqd_no_graph and self.reducer is None and self.device.type == "cuda" and \
-            not self.opt.disable_automasking
+        # multi-rank runs stay eager unless --sqd_graph_ddp: the forward+backward graph + post all-reduce path is covered by the
+        # 1-rank RCCL device test only (RCCL's watchdog thread must not poll during the capture — see _capture_fwd_bwd)
+        self._graph_ok = not self.opt.sqd_no_graph and self.device.type == "cuda" and not self.opt.disable_automasking and \
+            (self.reducer is None or self.opt.sqd_graph_ddp)
         self._side_stream = torch.cuda.Stream(device=self.device)
         self._graph_stream = torch.cuda.Stream(device=self.device) if self._graph_ok else None
         self._build_loaders()
@@ -214,14 +216,21 @@ class Trainer:
             self._capture(inputs)
         for k, v in inputs.items():
             self._static_in[k].copy_(v, non_blocking=True)
-        self.model_optimizer.refresh_hyper()
-        self._graph.replay()
+        if self.reducer is None:
+            self.model_optimizer.refresh_hyper()
+            self._graph.replay()
+        else:                                   # multi-rank: the graph holds forward + backward; exchange, then Adam
+            self._graph.replay()
+            self.reducer.allreduce_all()
+            self.model_optimizer.step()
         return self._static_out
 
     def _capture(self, inputs):
         """One hipGraph for process_batch + backward + Adam.  The ~1200 kernel launches of a step then cost one graph
         launch on the host (eager: ~23 ms of host time per 26 ms step)."""
         self._static_in = {k: v.to(self.device).clone() for k, v in inputs.items()}
+        if self.reducer is not None:
+            return self._capture_fwd_bwd()
         opt = self.model_optimizer
         opt.zero_grad(set_to_none=True)
         opt.begin_capture()
@@ -239,6 +248,37 @@ class Trainer:
                 opt.step()
         finally:
             self._capturing = False
+        self._graph, self._static_out = g, (outputs, losses)
+
+    def _capture_fwd_bwd(self):
+        """Multi-rank variant: process_batch + the bucket memsets + backward in one hipGraph.  The gradients are the bucket
+        views GradBucketReducer built during the eager warm-up steps, so the replay leaves them ready for the all-reduce;
+        the reducer's autograd hooks stay off (nothing Python-side runs during a replay)."""
+        if self.reducer.buckets is None:
+            raise RuntimeError("graph capture needs one eager step first (the gradient buckets are built there)")
+        self.reducer.hooks_enabled = False
+        views = self.reducer.detach_grad_views()          # {param: bucket view}; p.grad = None for the capture
+        torch.cuda.synchronize()
+        # RCCL's watchdog thread polls (hipEventQuery) the events of the warm-up steps' collectives until it has retired
+        # them; a poll that lands inside the capture aborts the process with hipErrorCapturedEvent.  All of them are
+        # complete after the synchronize above; three polling periods (100 ms each) let the watchdog drop them.
+        time.sleep(0.35)
+        g = torch.cuda.CUDAGraph()
+        self._capturing = True
+        try:
+            # thread_local: RCCL's watchdog thread polls its events while we capture; that is harmless, and under the default
+            # "global" mode it aborts the process (hipErrorCapturedEvent)
+            with torch.cuda.graph(g, stream=self._graph_stream, capture_error_mode="thread_local"):
+                outputs, losses = self.process_batch(self._static_in)
+                losses["loss"].backward()
+                # fresh gradients (assigned, not accumulated: no memsets, no ~170 accumulate launches) -> the buckets, as
+                # a couple of multi-tensor copies
+                params = [p for p in views if p.grad is not None]
+                torch._foreach_copy_([views[p] for p in params], [p.grad for p in params])
+        finally:
+            self._capturing = False
+        for p, v in views.items():                        # the optimiser reads the (all-reduced) bucket memory
+            p.grad = v
         self._graph, self._static_out = g, (outputs, losses)
 
     def _train_step_eager(self, inputs):

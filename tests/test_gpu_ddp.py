@@ -16,8 +16,8 @@ import json, os, sys
 sys.path[:0] = [%(repo)r, os.path.join(%(repo)r, "sfmnext-impl_amd"), os.path.join(%(repo)r, "tests"), os.path.join(%(repo)r, "tests", "golden")]
 import torch
 import test_gpu_graph as T
-tr, losses, params = T.run(["--sqd_no_graph"], steps=5)
-out = {"reducer": tr.reducer is not None, "losses": losses,
+tr, losses, params = T.run(sys.argv[1:], steps=7)
+out = {"reducer": tr.reducer is not None, "graph": tr._graph is not None, "losses": losses,
        "sums": {k: float(v.double().abs().sum()) for k, v in params.items() if v.dtype.is_floating_point}}
 if tr.reducer is not None:
     p = next(p for p in tr.models["encoder"].parameters() if p.dim() == 4 and p.shape[2] == 3)
@@ -26,20 +26,29 @@ print("RESULT " + json.dumps(out))
 """
 
 
-def _run(env_extra):
+DIST = {"SQD_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1"}
+
+
+def _run(env_extra, args=()):
     env = dict(os.environ, **env_extra)
-    r = subprocess.run([sys.executable, "-c", SCRIPT % {"repo": REPO}], env=env, capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, "-c", SCRIPT % {"repo": REPO}, *args], env=env, capture_output=True, text=True, timeout=600)
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
     assert line, r.stdout[-2000:] + r.stderr[-2000:]
     return json.loads(line[-1][7:])
 
 
-def test_one_rank_rccl_reducer_trains_like_single_process():
-    plain = _run({})
-    dist = _run({"SQD_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
-                 "MASTER_PORT": "29541"})
-    assert not plain["reducer"] and dist["reducer"] and dist["grad_is_bucket_view"]
+def _same_training(plain, dist):
     for a, b in zip(plain["losses"], dist["losses"]):
         assert abs(a - b) <= 1e-5 * abs(a) + 1e-7, (plain["losses"], dist["losses"])
     worst = max(abs(plain["sums"][k] - dist["sums"][k]) / (abs(plain["sums"][k]) + 1e-3) for k in plain["sums"])
     assert worst < 2e-2, worst
+
+
+def test_one_rank_rccl_reducer_trains_like_single_process():
+    plain = _run({}, ["--sqd_no_graph"])
+    dist = _run(dict(DIST, MASTER_PORT="29541"), ["--sqd_no_graph"])          # eager: hooks overlap the all-reduces with backward
+    assert not plain["reducer"] and dist["reducer"] and dist["grad_is_bucket_view"] and not dist["graph"]
+    _same_training(plain, dist)
+    graphed = _run(dict(DIST, MASTER_PORT="29542"), ["--sqd_graph_ddp"])                           # forward+backward replayed as a hipGraph, then all-reduce + Adam
+    assert graphed["reducer"] and graphed["graph"] and graphed["grad_is_bucket_view"]
+    _same_training(plain, graphed)
