@@ -34,10 +34,15 @@ class FusedAdam(torch.optim.Adam):
             n = p.numel()
             recs.append([p.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), n])
             chunks += [[ti, c] for c in range((n + chunk - 1) // chunk)]
-        tab = {"params": plist, "keys": [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr()) for p in plist],
+        shared = self.state[plist[0]]["step"]
+        for p in plist:                                # one counter tensor for the whole group
+            self.state[p]["step"] = shared
+        ghost = [torch.empty(len(plist), dtype=torch.int64).pin_memory() for _ in range(4)]
+        tab = {"params": plist, "keys": [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr()) for p in plist], "step": shared,
+               "pstrides": [p.stride() for p in plist], "ptr_scratch": [0] * len(plist), "ghost_np": [h.numpy() for h in ghost],
                "recs": torch.tensor(recs, dtype=torch.int64).to(dev), "chunks": torch.tensor(chunks, dtype=torch.int32).to(dev),
                "nchunks": len(chunks), "gdev": torch.empty(len(plist), dtype=torch.int64, device=dev),
-               "ghost": [torch.empty(len(plist), dtype=torch.int64).pin_memory() for _ in range(4)]}
+               "ghost": ghost}
         self._tables[gi] = tab
         return tab
 
@@ -59,13 +64,16 @@ class FusedAdam(torch.optim.Adam):
                 dev = plist[0].device
                 self._graph_hyper[gi] = (torch.zeros(2, dtype=torch.float32).pin_memory(), torch.zeros(2, dtype=torch.float32, device=dev))
             host, devt = self._graph_hyper[gi]
+            bumped = set()
             for p in plist:
                 st = self.state[p]
                 if len(st) == 0:
                     st["step"] = torch.tensor(0.0, dtype=torch.float32)
                     st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
                     st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
+                if id(st["step"]) not in bumped:           # the group's parameters may share one counter tensor
+                    bumped.add(id(st["step"]))
+                    st["step"] += 1
             step = int(self.state[plist[0]]["step"].item())
             b1, b2 = group["betas"]
             _l.check(L.sqd_adam_hyper(float(group["lr"]), float(b1), float(b2), step, ctypes.c_void_p(host.data_ptr())), "adam_hyper")
@@ -109,29 +117,34 @@ class FusedAdam(torch.optim.Adam):
             plist = [p for p in group["params"] if p.grad is not None]
             if not plist:
                 continue
-            for p in plist:
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous(memory_format=torch.contiguous_format)
-                        or p.is_contiguous(memory_format=torch.channels_last)):
-                    raise RuntimeError("FusedAdam: parameters must be dense fp32 device tensors")
+            # (host time matters: an eager step is launch-bound.  The per-parameter checks run when the table is (re)built;
+            # per step there is one pass over the gradients and one vectorised write of their addresses.)
             tab = self._tables.get(gi)
-            keys = [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr() if len(self.state[p]) else 0) for p in plist]
+            keys = [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr() if "exp_avg" in self.state[p] else 0) for p in plist]
             if tab is None or tab["keys"] != keys:
+                for p in plist:
+                    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous(memory_format=torch.contiguous_format)
+                            or p.is_contiguous(memory_format=torch.channels_last)):
+                        raise RuntimeError("FusedAdam: parameters must be dense fp32 device tensors")
                 tab = self._build(gi, plist)
             # gradient tensors are re-allocated by every backward: refresh their addresses (one 8*n byte async copy)
             host = tab["ghost"][self._ring % 4]
             self._ring += 1
+            ptrs, strides = tab["ptr_scratch"], tab["pstrides"]
             for i, p in enumerate(plist):
                 g = p.grad
-                if g.stride() != p.stride():
+                if g.stride() != strides[i]:
                     g = p.grad = g.contiguous(memory_format=torch.channels_last if p.dim() == 4 and
                                               p.is_contiguous(memory_format=torch.channels_last) and
                                               not p.is_contiguous() else torch.contiguous_format)
-                host[i] = g.data_ptr()
+                ptrs[i] = g.data_ptr()
+            tab["ghost_np"][(self._ring - 1) % 4][:] = ptrs
             tab["gdev"].copy_(host, non_blocking=True)
-            st0 = self.state[plist[0]]["step"]
-            step = int(st0.item()) + 1
-            for p in plist:
-                self.state[p]["step"] += 1
+            # one step counter per group, shared by the states of its parameters (torch.optim.Adam keeps one per parameter;
+            # state_dict() still lists it under every parameter)
+            st0 = tab["step"]
+            st0 += 1
+            step = int(st0.item())
             b1, b2 = group["betas"]
             _l.check(L.sqd_adam_step(ctypes.c_void_p(tab["recs"].data_ptr()), ctypes.c_void_p(tab["gdev"].data_ptr()),
                                      ctypes.c_void_p(tab["chunks"].data_ptr()), tab["nchunks"], float(group["lr"]), float(b1),

@@ -235,8 +235,10 @@ class Trainer:
         opt.zero_grad(set_to_none=True)
         opt.begin_capture()
         opt.refresh_hyper()                     # allocates the device scalars; the step counts it adds are undone below
+        undone = set()
         for st in opt.state.values():
-            if "step" in st:
+            if "step" in st and id(st["step"]) not in undone:      # (a group's parameters may share one counter tensor)
+                undone.add(id(st["step"]))
                 st["step"] -= 1
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
