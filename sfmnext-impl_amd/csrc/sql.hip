@@ -20,6 +20,7 @@
 // (157 TF) for the 4*Q*E flop/px forward — both are ~10-20 us at config B; the kernel exists to
 // replace 5 ATen launches that move y four times.
 #include "sqd_common.h"
+#include <cstdlib>
 
 namespace {
 using namespace sqd;
@@ -401,6 +402,188 @@ __global__ __launch_bounds__(256) void sql_bwd_kernel(const float *__restrict__ 
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// backward, second formulation (the one dispatched): v_mfma_f32_32x32x2_f32 with lane = pixel, so every read of x, y,
+// g_y and every write of g_x is a 128-byte row per half-wave (the 16x16 kernel above moves 64-byte pieces and needs
+// 236-256 VGPRs, i.e. one wave per SIMD: 341 us at config B).  Same mathematics, same g_K partial layout.
+//   t    = gS . x            A = gS [q][e] (LDS), B = x read as planes (lane = pixel)
+//   gyt, s element-wise in the accumulator layout (row q = 32 qt + acc_row(r, h), column = pixel)
+//   g_x  = K^T . gyt + gS^T . s        B operands are the accumulator registers themselves
+//   g_K += gyt . x^T         gyt through a wave-private LDS tile [q][pixel], x re-read as float4 along the pixels
+// ---------------------------------------------------------------------------------------------------
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+constexpr int TP = 36;                                   // floats per row of the wave-private [q][32 pixels] tile
+// uniform base + 32-bit byte offset (saddr + voffset addressing: no 64-bit address registers per access)
+__device__ __forceinline__ float ldg32(const float *__restrict__ base, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ void stg32(float *__restrict__ base, unsigned byte_off, float v) {
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+
+template <int QT>
+__global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict__ x, const float *__restrict__ K,
+                                                        const float *__restrict__ y, const float *__restrict__ g_y,
+                                                        const float *__restrict__ gS, const float *__restrict__ summary,
+                                                        const float *__restrict__ lse, float *__restrict__ g_x,
+                                                        float *__restrict__ gK_part, int Q, int E, int N, int nchunks) {
+    constexpr int QP = QT * 32, EP = 33;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Kl = lds, *Sl = Kl + QP * EP, *qc = Sl + QP * EP;      // K[q][e], gS[q][e], per-query (max, 1/sum, dot, -)
+    float *tiles = qc + QP * 4;                                   // [4 waves][QP][TP]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const float *xb = x + (size_t)b * E * N;
+    const float *yb = y + (size_t)b * Q * N;
+    const float *gyb = g_y ? g_y + (size_t)b * Q * N : nullptr;
+    float *gxb = g_x + (size_t)b * E * N;
+    for (int idx = threadIdx.x; idx < QP * EP; idx += 256) {
+        const int q = idx / EP, e = idx - q * EP;
+        const bool ok = q < Q && e < E;
+        Kl[idx] = ok ? K[((size_t)b * Q + q) * E + e] : 0.f;
+        Sl[idx] = ok ? gS[((size_t)b * Q + q) * E + e] : 0.f;
+    }
+    for (int q = threadIdx.x; q < QP; q += 256) {
+        float dsum = 0.f, mx = 0.f, il = 0.f;
+        if (q < Q) {
+            mx = lse[((size_t)b * Q + q) * 2];
+            il = lse[((size_t)b * Q + q) * 2 + 1];
+            for (int e = 0; e < E; ++e) dsum += gS[((size_t)b * Q + q) * E + e] * summary[((size_t)b * Q + q) * E + e];
+        }
+        qc[q * 4] = mx; qc[q * 4 + 1] = il; qc[q * 4 + 2] = dsum;
+    }
+    __syncthreads();
+    float *tl = tiles + wave * QP * TP;
+    f32x16 accK[QT];                                              // g_K tile: row q, column e = lane & 31
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accK[qt][r] = 0.f;
+    const int ntiles = (N + 31) / 32;
+    const bool vec_ok = (N & 3) == 0;
+
+    for (int tile = chunk * 4 + wave; tile < ntiles; tile += nchunks * 4) {
+        const int p0 = tile * 32, p = p0 + i;
+        const bool pv = p < N;
+        // ---- t[q][p] = sum_e gS[q][e] x[e][p]
+        const unsigned N4 = (unsigned)N * 4u;
+        const unsigned lane_x = ((unsigned)h * N + p) * 4u;           // plane h, pixel p
+        const unsigned lane_q = ((unsigned)(4 * h) * N + p) * 4u;     // row 4h of a 32-row group, pixel p
+        float xe[16];
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int e = 2 * s + h;
+            xe[s] = (pv && e < E) ? ldg32(xb, lane_x + (unsigned)(2 * s) * N4) : 0.f;
+        }
+        // every global read of the tile is issued up front (y, g_y, the float4 pieces of x for the g_K product): the first
+        // product then runs under their latency instead of each phase waiting for its own loads
+        f32x16 yv[QT], gv[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qt * 32 + acc_row(r, h);
+                const unsigned o = lane_q + (unsigned)(qt * 32 + (r & 3) + 8 * (r >> 2)) * N4;
+                const bool ok = q < Q && pv;
+                yv[qt][r] = ok ? ldg32(yb, o) : 0.f;
+                gv[qt][r] = (ok && gyb) ? ldg32(gyb, o) : 0.f;
+            }
+        float xv[4][4];
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int px = 8 * gq + 4 * h;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) xv[gq][j] = 0.f;
+            if (i < E) {
+                const float *src = xb + (size_t)i * N + p0 + px;
+                if (vec_ok && p0 + px + 3 < N) {
+                    const float4 t4 = *reinterpret_cast<const float4 *>(src);
+                    xv[gq][0] = t4.x; xv[gq][1] = t4.y; xv[gq][2] = t4.z; xv[gq][3] = t4.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (p0 + px + j < N) xv[gq][j] = src[j];
+                }
+            }
+        }
+        f32x16 acc[QT], sreg[QT];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[qt][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) acc[qt] = mfma32(Sl[(qt * 32 + i) * EP + 2 * s + h], xe[s], acc[qt]);
+        // ---- s and gyt, element-wise; gyt also to the LDS tile (operand of the g_K product)
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qt * 32 + acc_row(r, h);
+                float sv = 0.f, gyt = 0.f;
+                if (q < Q && pv) {
+                    sv = __expf(yv[qt][r] - qc[q * 4]) * qc[q * 4 + 1];
+                    gyt = gv[qt][r] + sv * (acc[qt][r] - qc[q * 4 + 2]);
+                }
+                sreg[qt][r] = sv;
+                acc[qt][r] = gyt;
+                tl[q * TP + i] = gyt;
+            }
+        // ---- g_x[e][p] = sum_q K[q][e] gyt[q][p] + gS[q][e] s[q][p]
+        f32x16 gx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gx[r] = 0.f;
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qt * 32 + acc_row(r, h);
+                gx = mfma32(Kl[q * EP + i], acc[qt][r], gx);
+                gx = mfma32(Sl[q * EP + i], sreg[qt][r], gx);
+            }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int e = acc_row(r, h);
+            if (pv && e < E) stg32(gxb, lane_q + (unsigned)((r & 3) + 8 * (r >> 2)) * N4, gx[r]);
+        }
+        // ---- g_K[q][e] += sum_p gyt[q][p] x[e][p]; k-step (gq, j): half-wave 0 takes pixel 8gq+j, half-wave 1 pixel 8gq+4+j
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int px = 8 * gq + 4 * h;
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const float4 a4 = *reinterpret_cast<const float4 *>(tl + (qt * 32 + i) * TP + px);
+                const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accK[qt] = mfma32(av[j], xv[gq][j], accK[qt]);
+            }
+        }
+        __builtin_amdgcn_wave_barrier();                           // the tile is rewritten by the next iteration
+    }
+    // ---- workgroup merge of g_K (fixed order) and the partial of this chunk
+    __syncthreads();
+    float *red = tiles;                                            // [4][QP][32]
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((size_t)wave * QP + qt * 32 + acc_row(r, h)) * 32 + i] = accK[qt][r];
+    __syncthreads();
+    float *po = gK_part + ((size_t)b * nchunks + chunk) * Q * E;
+    for (int idx = threadIdx.x; idx < Q * E; idx += 256) {
+        const int q = idx / E, e = idx - q * E;
+        po[idx] = ((red[((size_t)0 * QP + q) * 32 + e] + red[((size_t)1 * QP + q) * 32 + e]) + red[((size_t)2 * QP + q) * 32 + e]) +
+                  red[((size_t)3 * QP + q) * 32 + e];
+    }
+}
+
 // g_K[b,q,e] = sum over chunks of gK_part
 __global__ __launch_bounds__(256) void sql_gk_reduce_kernel(const float *__restrict__ part, float *__restrict__ gK, int QE,
                                                             int nchunks) {
@@ -480,13 +663,29 @@ extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const
     SQD_CHECK_ARG(x && K && y && g_summary && summary && lse && g_x && g_K && gk_part, "sqd_sql_bwd: null pointer");
     Plan p;
     SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql_bwd: unsupported Q=%d E=%d N=%d", Q, E, N);
-    const int QP = p.QT * 16, PX = p.NT * 16;
-    const size_t sh_tile = (size_t)4 * QP * (PX + 1) * sizeof(float), sh_red = (size_t)4 * E * (QP + 1) * sizeof(float);
-    const size_t shmem = (size_t)QP * 4 * sizeof(float) + (sh_tile > sh_red ? sh_tile : sh_red);
-    bool launched = false;
+    SQD_CHECK_ARG((long long)N * 132 * 4 < (1ll << 32), "sqd_sql_bwd: N=%d too large for 32-bit plane offsets", N);
     (void)hipGetLastError();
-    SQL_DISPATCH_ALL(sql_bwd_kernel, shmem, x, K, y, g_y, g_summary, summary, lse, g_x, gk_part, Q, N, p.steps, p.nchunks)
-    SQD_CHECK_ARG(launched, "sqd_sql_bwd: no kernel instance for QT=%d ET=%d", p.QT, p.ET);
+    static const bool legacy = getenv("SQD_SQL_BWD16") != nullptr;          // A/B: the 16x16x4 formulation
+    if (!legacy) {
+        const int qt = Q <= 32 ? 1 : Q <= 64 ? 2 : 4, QP = qt * 32;
+        const size_t shmem = ((size_t)2 * QP * 33 + QP * 4 + (size_t)4 * QP * TP) * sizeof(float);
+#define SQL_BWD32(QT_)                                                                                                          \
+    {                                                                                                                           \
+        if (shmem > 48 * 1024)                                                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sql_bwd32_kernel<QT_>),                                   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                                  \
+        hipLaunchKernelGGL((sql_bwd32_kernel<QT_>), dim3(p.nchunks, B), dim3(256), shmem, (hipStream_t)stream, x, K, y, g_y,   \
+                           g_summary, summary, lse, g_x, gk_part, Q, E, N, p.nchunks);                                          \
+    }
+        if (qt == 1) SQL_BWD32(1) else if (qt == 2) SQL_BWD32(2) else SQL_BWD32(4)
+    } else {
+        const int QP = p.QT * 16, PX = p.NT * 16;
+        const size_t sh_tile = (size_t)4 * QP * (PX + 1) * sizeof(float), sh_red = (size_t)4 * E * (QP + 1) * sizeof(float);
+        const size_t shmem = (size_t)QP * 4 * sizeof(float) + (sh_tile > sh_red ? sh_tile : sh_red);
+        bool launched = false;
+        SQL_DISPATCH_ALL(sql_bwd_kernel, shmem, x, K, y, g_y, g_summary, summary, lse, g_x, gk_part, Q, N, p.steps, p.nchunks)
+        SQD_CHECK_ARG(launched, "sqd_sql_bwd: no kernel instance for QT=%d ET=%d", p.QT, p.ET);
+    }
     SQD_CHECK_LAUNCH("sqd_sql_bwd");
     hipLaunchKernelGGL(sql_gk_reduce_kernel, dim3((Q * E + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, gk_part, g_K,
                        Q * E, p.nchunks);
