@@ -260,6 +260,13 @@ int sqd_bins_bwd(const float *energy, const float *weight, const float *bias, co
                  float *g_energy, float *g_weight, float *g_bias, float *g_centers, float *part, int B, int Q, int D, int N,
                  void *stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * (12) MaxPool2d(3, stride 2, padding 1), channels-last.  replaces: the ResNet stem's maxpool (reference
+ * networks/resnet_encoder.py:96).  x [N,H,W,C] -> y [N,Ho,Wo,C] and idx [N,Ho,Wo,C] (1 byte: window position of the
+ * maximum, ATen's tie rule); Ho = (H-1)/2+1, Wo = (W-1)/2+1; C multiple of 4.  The backward is a gather (no atomics). */
+int sqd_maxpool3x3s2_fwd(const float *x, float *y, unsigned char *idx, int N, int H, int W, int C, void *stream);
+int sqd_maxpool3x3s2_bwd(const float *dy, const unsigned char *idx, float *dx, int N, int H, int W, int C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,105 @@
+// pool.hip — MaxPool2d(kernel 3, stride 2, padding 1) of the ResNet stem, channels-last, forward + backward.
+// replaces: self.encoder.maxpool (torchvision ResNet, called from reference networks/resnet_encoder.py:96).
+// forward : y[n,ho,wo,c] = max over the 3x3 window at (2ho-1, 2wo-1) (positions outside the image are skipped); the window
+//           position of the maximum (0..8, first maximum in row-major scan order — ATen's tie rule) goes to idx (1 byte).
+// backward: gather form — every input pixel looks at the (at most 2x2) windows that contain it and takes dy where idx
+//           names it.  No atomics: deterministic, unlike ATen's scatter (max_pool_backward_nhwc).
+// Roofline: HBM — forward 4 B read + 1.25 B written per input element, backward 1.25 B read + 4 B written.
+#include "sqd_common.h"
+
+namespace {
+using namespace sqd;
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *__restrict__ x, float *__restrict__ y,
+                                                          unsigned char *__restrict__ idx, int N, int H, int W, int C, int Ho, int Wo) {
+    const int V = C / 4;
+    const size_t total = (size_t)N * Ho * Wo * V;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cg = (int)(i % V);
+        size_t t = i / V;
+        const int wo = (int)(t % Wo);
+        t /= Wo;
+        const int ho = (int)(t % Ho), n = (int)(t / Ho);
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        int4 k = make_int4(0, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int hi = 2 * ho - 1 + r;
+            if (hi < 0 || hi >= H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int wi = 2 * wo - 1 + s;
+                if (wi < 0 || wi >= W) continue;
+                const float4 v = *reinterpret_cast<const float4 *>(x + (((size_t)n * H + hi) * W + wi) * C + cg * 4);
+                const int p = r * 3 + s;
+                // ATen: (val > maxval) || isnan(val)
+                if (v.x > m.x || v.x != v.x) { m.x = v.x; k.x = p; }
+                if (v.y > m.y || v.y != v.y) { m.y = v.y; k.y = p; }
+                if (v.z > m.z || v.z != v.z) { m.z = v.z; k.z = p; }
+                if (v.w > m.w || v.w != v.w) { m.w = v.w; k.w = p; }
+            }
+        }
+        reinterpret_cast<float4 *>(y)[i] = m;
+        reinterpret_cast<uchar4 *>(idx)[i] = make_uchar4((unsigned char)k.x, (unsigned char)k.y, (unsigned char)k.z, (unsigned char)k.w);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restrict__ dy, const unsigned char *__restrict__ idx,
+                                                          float *__restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
+    const int V = C / 4;
+    const size_t total = (size_t)N * H * W * V;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int cg = (int)(i % V);
+        size_t t = i / V;
+        const int wi = (int)(t % W);
+        t /= W;
+        const int hi = (int)(t % H), n = (int)(t / H);
+        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        // windows containing row hi: 2ho-1 <= hi <= 2ho+1
+        const int ho0 = hi / 2, ho1 = (hi + 1) / 2, wo0 = wi / 2, wo1 = (wi + 1) / 2;
+        for (int ho = ho0; ho <= ho1; ++ho) {
+            if (ho >= Ho) continue;
+            const int r = hi - (2 * ho - 1);
+            for (int wo = wo0; wo <= wo1; ++wo) {
+                if (wo >= Wo) continue;
+                const int p = r * 3 + wi - (2 * wo - 1);
+                const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * V + cg;
+                const uchar4 k = reinterpret_cast<const uchar4 *>(idx)[o];
+                const float4 v = reinterpret_cast<const float4 *>(dy)[o];
+                if (k.x == p) g.x += v.x;
+                if (k.y == p) g.y += v.y;
+                if (k.z == p) g.z += v.z;
+                if (k.w == p) g.w += v.w;
+            }
+        }
+        reinterpret_cast<float4 *>(dx)[i] = g;
+    }
+}
+
+int grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (int)(b > 8192 ? 8192 : b);
+}
+}  // namespace
+
+// x [N,H,W,C] -> y [N,Ho,Wo,C], idx [N,Ho,Wo,C] bytes; Ho = (H - 1) / 2 + 1, Wo likewise; C multiple of 4
+extern "C" int sqd_maxpool3x3s2_fwd(const float *x, float *y, unsigned char *idx, int N, int H, int W, int C, void *stream) {
+    SQD_CHECK_ARG(x && y && idx && N > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0, "sqd_maxpool3x3s2_fwd: bad arguments (C=%d)", C);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for((size_t)N * Ho * Wo * C / 4)), dim3(256), 0, (hipStream_t)stream, x, y, idx, N, H, W,
+                       C, Ho, Wo);
+    SQD_CHECK_LAUNCH("sqd_maxpool3x3s2_fwd");
+    return SQD_OK;
+}
+
+// dy [N,Ho,Wo,C], idx from the forward -> dx [N,H,W,C] (fully overwritten)
+extern "C" int sqd_maxpool3x3s2_bwd(const float *dy, const unsigned char *idx, float *dx, int N, int H, int W, int C, void *stream) {
+    SQD_CHECK_ARG(dy && idx && dx && N > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0, "sqd_maxpool3x3s2_bwd: bad arguments (C=%d)", C);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((size_t)N * H * W * C / 4)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W,
+                       C, Ho, Wo);
+    SQD_CHECK_LAUNCH("sqd_maxpool3x3s2_bwd");
+    return SQD_OK;
+}

@@ -87,6 +87,32 @@ class BatchNormAct(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None
 
 
+class MaxPool3x3s2(torch.autograd.Function):
+    """nn.MaxPool2d(3, 2, 1) of the ResNet stem, channels-last; the backward is a deterministic gather."""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require(x, "MaxPool3x3s2 input")
+        x = _cl(x)
+        N, C, H, W = x.shape
+        Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+        y = torch.empty((N, C, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        idx = torch.empty(N * Ho * Wo * C, device=x.device, dtype=torch.uint8)
+        _l.check(_l.lib().sqd_maxpool3x3s2_fwd(_ptr(x), _ptr(y), _ptr(idx), N, H, W, C, _stream()), "maxpool_fwd")
+        ctx.save_for_backward(idx)
+        ctx.dims = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        idx, = ctx.saved_tensors
+        N, C, H, W = ctx.dims
+        dy = _cl(dy)
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _l.check(_l.lib().sqd_maxpool3x3s2_bwd(_ptr(dy), _ptr(idx), _ptr(dx), N, H, W, C, _stream()), "maxpool_bwd")
+        return dx
+
+
 class UpsampleConcat(torch.autograd.Function):
     """cat([bilinear_resize(x -> skip's H x W, align_corners=True), skip], dim=1), channels-last."""
 

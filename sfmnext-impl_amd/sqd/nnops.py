@@ -13,7 +13,7 @@ import torch
 import torch.nn.functional as F
 
 BACKEND = {
-    "conv2d": "aten", "conv_bn_act": "aten conv + hip bn/act/residual", "maxpool3x3s2": "aten", "upsample_concat": "hip",
+    "conv2d": "aten", "conv_bn_act": "aten conv + hip bn/act/residual", "maxpool3x3s2": "hip", "upsample_concat": "hip",
     "linear": "aten", "transformer_encoder": "aten", "full_query_layer": "hip", "bins_head": "hip",
 }
 
@@ -83,7 +83,12 @@ def _bn_act(y, bn, act, residual):
 
 
 def maxpool3x3s2(x):
-    return F.max_pool2d(x, 3, 2, 1)
+    if x.is_cuda:
+        from . import nnkernels
+        if x.shape[1] % 4:
+            raise RuntimeError("sqd: max-pool kernel needs a channel count that is a multiple of 4")
+        return nnkernels.MaxPool3x3s2.apply(x)
+    return F.max_pool2d(x, 3, 2, 1)      # host tensors: only the CPU wiring tests come here
 
 
 def upsample_concat(x, skip):

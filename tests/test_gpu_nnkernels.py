@@ -111,3 +111,20 @@ def test_fused_adam_matches_torch_adam():
     assert set(sd_ref["state"][0].keys()) == set(sd_my["state"][0].keys())
     assert float(sd_my["state"][0]["step"]) == 4.0 and 7 not in sd_my["state"]
     np.testing.assert_allclose(sd_my["state"][3]["exp_avg_sq"].cpu().numpy(), sd_ref["state"][3]["exp_avg_sq"].cpu().numpy(), rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 64, 12, 20), (1, 16, 7, 9), (3, 8, 1, 5), (12, 64, 96, 320)])
+def test_maxpool3x3s2_bit_exact(N, C, H, W):
+    """MaxPool2d(3,2,1) forward and (gather-form) backward against ATen on the CPU — including ties (quantised input)."""
+    from sqd import nnkernels
+    g = torch.Generator().manual_seed(N + C + H)
+    x = torch.round(torch.randn(N, C, H, W, generator=g) * 4) / 4        # many exact ties inside the windows
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    gy = torch.randn(yr.shape, generator=g)
+    yr.backward(gy)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = nnkernels.MaxPool3x3s2.apply(xg)
+    y.backward(gy.cuda())
+    assert torch.equal(y.cpu(), yr.detach())
+    assert torch.equal(xg.grad.cpu(), xr.grad)
