@@ -112,6 +112,7 @@ class Trainer:
         self._graph_ok = not self.opt.sqd_no_graph and self.device.type == "cuda" and not self.opt.disable_automasking and \
             (self.reducer is None or self.opt.sqd_graph_ddp)
         self._side_stream = torch.cuda.Stream(device=self.device)
+        self._pose_stream = torch.cuda.Stream(device=self.device)
         self._graph_stream = torch.cuda.Stream(device=self.device) if self._graph_ok else None
         self._build_loaders()
         self.writers = {m: (_make_writer(os.path.join(self.log_path, m)) if self.rank == 0 else _NullWriter())
@@ -321,9 +322,21 @@ class Trainer:
         self._launch_identity(inputs)
         nnkernels.defer_bn_counters(True)
         try:
+            fork = self._capturing and self.use_pose_net and not os.environ.get("SQD_NO_POSE_FORK")
+            if fork:
+                # inside the graph the pose network (which only needs the input frames) is a parallel branch: its small
+                # convolutions — and, through autograd's stream bookkeeping, their backward — fill the gaps the
+                # latency-bound ViT / MLP launches of the depth head leave on the device
+                cur = torch.cuda.current_stream()
+                self._pose_stream.wait_stream(cur)
+                with torch.cuda.stream(self._pose_stream):
+                    pose_outputs = self.predict_poses(inputs, None)
             features = self.models["encoder"](self._fmt(inputs["color_aug", 0, 0]))
             outputs = self.models["depth"](features)
-            if self.use_pose_net:
+            if fork:
+                cur.wait_stream(self._pose_stream)
+                outputs.update(pose_outputs)
+            elif self.use_pose_net:
                 outputs.update(self.predict_poses(inputs, features))
         finally:
             nnkernels.flush_bn_counters()              # one multi-tensor += 1 for every BatchNorm that ran in training mode
@@ -347,7 +360,9 @@ class Trainer:
             noise = torch.randn(B, len(srcs), H, W, device=self.device)
         else:
             noise = torch.randn(B, len(srcs), H, W).to(self.device, non_blocking=True)   # CPU RNG, as the reference
-        if self._capturing:                    # inside a graph capture everything stays on the capturing stream
+        if self._capturing:
+            # inside a graph capture this stays on the capturing stream: as a forked branch it made the replay 1.4 ms SLOWER
+            # (22.28 vs 20.92 ms, same box) — unlike the pose-network branch of process_batch, which gains 0.4 ms
             self._identity, self._identity_done = ops.identity_fwd(tgt, srcs, noise), None
             return
         side = self._side_stream
