@@ -671,7 +671,10 @@ int check_geom(const char *who, const ConvGeom &g) {
                   "%s: bad geometry", who);
     SQD_CHECK_ARG((long long)g.N * g.H * g.W * g.C < (1ll << 31) && (long long)g.N * g.Ho * g.Wo * g.K < (1ll << 31) &&
                       (long long)g.K * g.R * g.S * g.C < (1ll << 31), "%s: tensors of 2^31 elements or more are not supported", who);
-    SQD_CHECK_ARG(g.Ho == (g.H + 2 * g.pad - g.R) / g.stride + 1 && g.Wo == (g.W + 2 * g.pad - g.S) / g.stride + 1,
+    // (Ho, Wo) may be SMALLER than the full output extent: the top-left Ho x Wo outputs are computed (the 7x7/2 stems run as a
+    // 4x4/1 convolution on a space-to-depth input, whose symmetric padding yields one surplus row and column)
+    SQD_CHECK_ARG(g.Ho >= 1 && g.Wo >= 1 && g.Ho <= (g.H + 2 * g.pad - g.R) / g.stride + 1 &&
+                      g.Wo <= (g.W + 2 * g.pad - g.S) / g.stride + 1,
                   "%s: Ho/Wo inconsistent with H/W/R/S/stride/pad", who);
     return SQD_OK;
 }

@@ -103,3 +103,66 @@ extern "C" int sqd_maxpool3x3s2_bwd(const float *dy, const unsigned char *idx, f
     SQD_CHECK_LAUNCH("sqd_maxpool3x3s2_bwd");
     return SQD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// space-to-depth(2) of a channels-last image, channel count padded with zeros:
+//   y[n, h2, w2, c*4 + dy*2 + dx] = x[n, 2*h2 + dy, 2*w2 + dx, c]   (torch.nn.functional.pixel_unshuffle's channel order)
+// feeds the 7x7/2 stems, which run as 4x4/1 convolutions on this layout (nnkernels.conv2d_stem_s2d).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+// one thread = 4 consecutive output channels (one float4 store); reads stay inside two 2C-float runs of the image rows
+__global__ __launch_bounds__(256) void s2d_kernel(const float *__restrict__ x, float *__restrict__ y, int N, int H, int W, int C, int Cp) {
+    const int H2 = H / 2, W2 = W / 2, Q = Cp / 4;
+    const size_t total = (size_t)N * H2 * W2 * Q;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % Q);                       // output channels 4c..4c+3 = input channel c at (dy,dx) = (0,0),(0,1),(1,0),(1,1)
+        size_t t = i / Q;
+        const int w2 = (int)(t % W2);
+        t /= W2;
+        const int h2 = (int)(t % H2), n = (int)(t / H2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) {
+            const float *r0 = x + (((size_t)n * H + 2 * h2) * W + 2 * w2) * C + c, *r1 = r0 + (size_t)W * C;
+            v = make_float4(r0[0], r0[C], r1[0], r1[C]);
+        }
+        reinterpret_cast<float4 *>(y)[i] = v;
+    }
+}
+
+// filter regrouping of the space-to-depth stems and its adjoint:
+//   w [K,C,7,7] (KCRS) <-> ws [K,4,4,Cp] (KRSC', channel c*4 + dy*2 + dx), tap u = 2r' + dy - 1, v = 2s' + dx - 1
+template <bool ADJOINT>
+__global__ __launch_bounds__(256) void stem_regroup_kernel(const float *__restrict__ src, float *__restrict__ dst, int K, int C, int Cp) {
+    const int total = K * 16 * Cp;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int ch = i % Cp, rs = (i / Cp) % 16, k = i / (16 * Cp);
+        const int c = ch >> 2, dy = (ch >> 1) & 1, dx = ch & 1, rp = rs >> 2, sp = rs & 3;
+        const int u = 2 * rp + dy - 1, v = 2 * sp + dx - 1;
+        const bool ok = c < C && u >= 0 && u < 7 && v >= 0 && v < 7;
+        if (!ADJOINT) dst[i] = ok ? src[((k * C + c) * 7 + u) * 7 + v] : 0.f;
+        else if (ok) dst[((k * C + c) * 7 + u) * 7 + v] = src[i];       // every (k,c,u,v) has exactly one (r',dy,s',dx)
+    }
+}
+}  // namespace
+
+// x [N,H,W,C] (H, W even) -> y [N,H/2,W/2,Cp], Cp >= 4*C, channels 4*C..Cp-1 zero
+extern "C" int sqd_space_to_depth2(const float *x, float *y, int N, int H, int W, int C, int Cp, void *stream) {
+    SQD_CHECK_ARG(x && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && Cp >= 4 * C,
+                  "sqd_space_to_depth2: bad arguments (H=%d W=%d C=%d Cp=%d)", H, W, C, Cp);
+    (void)hipGetLastError();
+    SQD_CHECK_ARG(Cp % 4 == 0, "sqd_space_to_depth2: Cp=%d must be a multiple of 4", Cp);
+    hipLaunchKernelGGL(s2d_kernel, dim3(grid_for((size_t)N * (H / 2) * (W / 2) * Cp / 4)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, Cp);
+    SQD_CHECK_LAUNCH("sqd_space_to_depth2");
+    return SQD_OK;
+}
+
+// w [K,C,7,7] contiguous -> ws [K,4,4,Cp] (adjoint = 0) or g_ws [K,4,4,Cp] -> g_w [K,C,7,7] fully overwritten (adjoint = 1)
+extern "C" int sqd_stem_regroup(const float *src, float *dst, int K, int C, int Cp, int adjoint, void *stream) {
+    SQD_CHECK_ARG(src && dst && K > 0 && C > 0 && Cp >= 4 * C, "sqd_stem_regroup: bad arguments");
+    (void)hipGetLastError();
+    const int nb = (K * 16 * Cp + 255) / 256;
+    if (adjoint) hipLaunchKernelGGL((stem_regroup_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, dst, K, C, Cp);
+    else hipLaunchKernelGGL((stem_regroup_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, dst, K, C, Cp);
+    SQD_CHECK_LAUNCH("sqd_stem_regroup");
+    return SQD_OK;
+}

@@ -120,6 +120,8 @@ _SIGNATURES = {
     "sqd_bins_bwd": (_I, [_P] * 10 + [_I] * 4 + [_P]),
     "sqd_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sqd_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "sqd_space_to_depth2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "sqd_stem_regroup": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sqd_smooth_nblk": (_I, [_I, _I]),
     "sqd_smooth_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "sqd_smooth_bwd": (_I, [_P, _P, _P, _I, _P, _F, _P, ctypes.c_int64, _I, _I, _I, _P]),

@@ -266,12 +266,15 @@ class Conv2d(torch.autograd.Function):
     of ATen running a separate 3-pass add over the activation."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, skip=False):
+    def forward(ctx, x, weight, bias, stride, pad, act, skip=False, out_hw=None):
         _require(x, "Conv2d input")
         x, w = _cl(x), _cl(weight)
         N, C, H, W = x.shape
         K, _, R, S = w.shape
         Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - S) // stride + 1
+        if out_hw is not None:                           # only the top-left out_hw outputs (see conv2d_stem_s2d)
+            assert out_hw[0] <= Ho and out_hw[1] <= Wo
+            Ho, Wo = out_hw
         y = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         if TUNE_CONV:
             _tune_conv(0, (N, H, W, C, K, R, S, stride, pad, Ho, Wo),
@@ -292,7 +295,7 @@ class Conv2d(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         N, H, W, C, K, R, S, stride, pad, Ho, Wo = ctx.geom
         if dy is None:                                   # only the pass-through output was used
-            return g_skip, None, None, None, None, None, None
+            return g_skip, None, None, None, None, None, None, None
         dy = _cl(dy)
         g_skip = _cl(g_skip) if g_skip is not None else None
         if ctx.act == "relu":
@@ -321,7 +324,60 @@ class Conv2d(torch.autograd.Function):
             part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
             _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
                                       _stream()), "conv_wgrad")
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
+
+
+def stem_s2d_supported(conv, x):
+    """7x7 / stride 2 / pad 3 convolutions on few input channels (the ResNet and PoseCNN stems)."""
+    return (conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1)
+            and conv.groups == 1 and conv.in_channels % 16 != 0 and conv.out_channels % 16 == 0
+            and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
+
+
+def conv2d_stem_s2d(x, conv, act=None):
+    """A 7x7 stride-2 convolution on C (3 or 6) channels == a 4x4 stride-1 convolution on the space-to-depth(2) image with
+    4C channels (padded to a multiple of 16) and the filter regrouped the same way: tap u = 2r' + dy - 1 of the 7 (u = -1 and
+    u = 7 are zero taps).  That shape runs on the implicit-GEMM kernels (57-77 % of the multiplies are real), so the stems
+    need no vendor convolution; the image needs no gradient, the filter gradient flows back through the regrouping."""
+    N, C, H, W = x.shape
+    K = conv.out_channels
+    Cp = (4 * C + 15) // 16 * 16
+    x = _cl(x.detach())
+    xs = torch.empty((N, Cp, H // 2, W // 2), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    _l.check(_l.lib().sqd_space_to_depth2(_ptr(x), _ptr(xs), N, H, W, C, Cp, _stream()), "space_to_depth2")   # channel c*4 + dy*2 + dx
+    # the regrouped filter is shared by the calls of one step (PoseCNN runs twice per step on the same weights)
+    key = (id(conv.weight), conv.weight._version, torch.is_grad_enabled())
+    cached = _STEM_W.get(id(conv))
+    if cached is not None and cached[0] == key:
+        w = cached[1]
+    else:
+        w = StemRegroup.apply(conv.weight, Cp)
+        _STEM_W[id(conv)] = (key, w)
+    return Conv2d.apply(xs, w, conv.bias, 1, 2, act, False, (H // 2, W // 2))
+
+
+_STEM_W = {}
+
+
+class StemRegroup(torch.autograd.Function):
+    """w [K,C,7,7] -> the 4x4 filter on the space-to-depth channels, [K,Cp,4,4] channels-last (one kernel each way)."""
+
+    @staticmethod
+    def forward(ctx, w, Cp):
+        K, C = w.shape[0], w.shape[1]
+        wc = w.contiguous()
+        ws = torch.empty((K, Cp, 4, 4), device=w.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _l.check(_l.lib().sqd_stem_regroup(_ptr(wc), _ptr(ws), K, C, Cp, 0, _stream()), "stem_regroup")
+        ctx.dims = (K, C, Cp, w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous())
+        return ws
+
+    @staticmethod
+    def backward(ctx, g):
+        K, C, Cp, cl = ctx.dims
+        g = _cl(g)
+        gw = torch.empty((K, C, 7, 7), device=g.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_stem_regroup(_ptr(g), _ptr(gw), K, C, Cp, 1, _stream()), "stem_regroup_adjoint")
+        return (gw.contiguous(memory_format=torch.channels_last) if cl else gw), None
 
 
 def conv2d_native(x, conv, act=None, skip=False):

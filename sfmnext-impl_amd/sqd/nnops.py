@@ -28,6 +28,10 @@ def _act(y, act):
     raise ValueError(act)
 
 
+import os
+
+# 7x7/2 stems as 4x4/1 convolutions on a space-to-depth input (SQD_STEM_ATEN=1: ATen/MIOpen for the stems, A/B runs)
+STEM_S2D = not os.environ.get("SQD_STEM_ATEN")
 NATIVE_CONV = False          # set by the Trainer (default on; --sqd_aten_conv is the A/B switch back to ATen/MIOpen)
 
 
@@ -36,7 +40,7 @@ def set_native_conv(on):
     through libsqd; the 3- and 6-channel stem convolutions stay on ATen."""
     global NATIVE_CONV
     NATIVE_CONV = bool(on)
-    BACKEND["conv2d"] = "hip (C,K % 16 == 0) / aten stems" if on else "aten"
+    BACKEND["conv2d"] = "hip (incl. the 7x7 stems via space-to-depth; K % 16 != 0 heads: aten)" if on else "aten"
     BACKEND["conv_bn_act"] = ("hip conv" if on else "aten conv") + " + hip bn/act/residual"
 
 
@@ -46,6 +50,9 @@ def _conv(x, conv, act=None, skip=False):
         from . import nnkernels
         if nnkernels.conv_module_supported(conv):
             return nnkernels.conv2d_native(x, conv, act, skip)
+        if STEM_S2D and nnkernels.stem_s2d_supported(conv, x):
+            y = nnkernels.conv2d_stem_s2d(x, conv, act)
+            return (y, x) if skip else y
     y = _act(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), act)
     return (y, x) if skip else y
 

@@ -99,3 +99,29 @@ def test_every_registered_plan_is_exact(N, C, H, W, K, R, stride, pad):
             L.sqd_conv_set_plan(mode, *geom, 0, 0, 0, 16)
         nnkernels._PLAN_CACHE.clear()
     assert tried >= 8
+
+
+@pytest.mark.parametrize("N,C,H,W,K,bias,act", [(2, 3, 16, 24, 64, False, None), (2, 6, 32, 20, 16, True, "relu"), (12, 3, 192, 640, 64, False, None)])
+def test_stem_space_to_depth(N, C, H, W, K, bias, act):
+    """7x7/2 stem as a 4x4/1 convolution on the space-to-depth image: output and filter / bias gradients against ATen."""
+    from sqd import nnkernels
+    torch.manual_seed(C + K)
+    conv = nn.Conv2d(C, K, 7, 2, 3, bias=bias)
+    x = torch.randn(N, C, H, W)
+    yr = conv(x)
+    if act == "relu":
+        yr = F.relu(yr)
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    conv_g = nn.Conv2d(C, K, 7, 2, 3, bias=bias).cuda()
+    conv_g.load_state_dict(conv.state_dict())
+    xg = x.cuda().contiguous(memory_format=torch.channels_last)
+    assert nnkernels.stem_s2d_supported(conv_g, xg)
+    y = nnkernels.conv2d_stem_s2d(xg, conv_g, act)
+    y.backward(gy.cuda())
+    assert y.shape == yr.shape
+    assert torch.allclose(y.cpu(), yr.detach(), rtol=1e-4, atol=1e-4 * float(yr.abs().max()))
+    gw, gwr = conv_g.weight.grad.cpu(), conv.weight.grad
+    assert float((gw - gwr).abs().max()) <= 2e-4 * float(gwr.abs().max()), float((gw - gwr).abs().max()) / float(gwr.abs().max())
+    if bias:
+        assert torch.allclose(conv_g.bias.grad.cpu(), conv.bias.grad, rtol=2e-4, atol=2e-4 * float(conv.bias.grad.abs().max()))
