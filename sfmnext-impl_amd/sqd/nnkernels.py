@@ -345,18 +345,10 @@ def conv2d_stem_s2d(x, conv, act=None):
     x = _cl(x.detach())
     xs = torch.empty((N, Cp, H // 2, W // 2), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
     _l.check(_l.lib().sqd_space_to_depth2(_ptr(x), _ptr(xs), N, H, W, C, Cp, _stream()), "space_to_depth2")   # channel c*4 + dy*2 + dx
-    # the regrouped filter is shared by the calls of one step (PoseCNN runs twice per step on the same weights)
-    key = (id(conv.weight), conv.weight._version, torch.is_grad_enabled())
-    cached = _STEM_W.get(id(conv))
-    if cached is not None and cached[0] == key:
-        w = cached[1]
-    else:
-        w = StemRegroup.apply(conv.weight, Cp)
-        _STEM_W[id(conv)] = (key, w)
+    # (regrouped on every call — one tiny kernel: the optimiser updates the weights through raw pointers, so nothing on the
+    # Python side could tell a cached copy that it is stale, and a copy cached before a graph capture would be frozen into it)
+    w = StemRegroup.apply(conv.weight, Cp)
     return Conv2d.apply(xs, w, conv.bias, 1, 2, act, False, (H // 2, W // 2))
-
-
-_STEM_W = {}
 
 
 class StemRegroup(torch.autograd.Function):

@@ -60,7 +60,7 @@ def test_graph_replay_matches_eager():
     # envelope.  A replay bug (frozen bias correction, stale learning rate) shows up as a drift of ~0.2.
     k_ee, d_ee = _drift(par_e, par_e2)
     k_eg, d_eg = _drift(par_e, par_g)
-    assert d_eg <= max(3.0 * d_ee, 5e-3) and d_eg < 0.05, (k_eg, d_eg, k_ee, d_ee)
+    assert d_eg <= max(5.0 * d_ee, 2e-2) and d_eg < 0.05, (k_eg, d_eg, k_ee, d_ee)
     # Adam bookkeeping kept in step: torch.optim state_dict compatibility
     st_e = tr_e.model_optimizer.state_dict()["state"]
     st_g = tr_g.model_optimizer.state_dict()["state"]
@@ -71,3 +71,30 @@ def test_graph_replay_matches_eager():
     assert abs(lr - 1e-5) < 1e-12                                   # StepLR(step_size=1, gamma=0.1) stepped once
     hyper = tr_g.model_optimizer._graph_hyper[0][1].cpu()
     assert abs(float(hyper[0]) - lr / (1 - 0.9 ** 7)) <= 1e-6 * lr and abs(float(hyper[1]) - (1 - 0.999 ** 7) ** -0.5) <= 1e-4
+
+
+def test_graph_replay_trains_every_parameter():
+    """Every parameter that receives a gradient must keep moving under graph replay — a tensor derived from a parameter
+    outside the captured region (a cached regrouped stem filter, say) would freeze that parameter's effect on the loss."""
+    tr, _, _ = run([], steps=4)                       # 3 eager warm-up steps + the capture step
+    assert tr._graph is not None
+    from datasets.synthetic import synthetic_batch
+    snap = {n: p.detach().clone() for m in tr.models.values() for n, p in m.named_parameters() if p.grad is not None}
+    inputs = synthetic_batch(2, 64, 96, start=40, device=tr.device)
+    inputs[("noise", 0)] = torch.randn(2, 2, 64, 96).cuda()
+    _, l1 = tr.train_step(inputs)
+    loss_a = float(l1["loss"])
+    # the same batch again: the loss must change because EVERY weight changed — in particular the stems' regrouped filters
+    _, l2 = tr.train_step(inputs)
+    loss_b = float(l2["loss"])
+    torch.cuda.synchronize()
+    assert loss_a != loss_b
+    moved = {n: bool((p.detach() != snap[n]).any()) for m in tr.models.values() for n, p in m.named_parameters() if n in snap}
+    assert all(moved.values()), [n for n, v in moved.items() if not v]
+    # and the stem filter the forward uses is the CURRENT one: perturbing conv1.weight in place changes the replayed loss
+    for stem in (tr.models["encoder"].encoder.encoder.conv1.weight, tr.models["pose"].net[0].weight):
+        before = float(tr.train_step(inputs)[1]["loss"])       # (graph replay hands back the same static tensors: read now)
+        with torch.no_grad():
+            stem.add_(0.2 * torch.randn_like(stem))            # (not a rescaling: BatchNorm would undo that)
+        after = float(tr.train_step(inputs)[1]["loss"])
+        assert abs(after - before) > 1e-3 * abs(before), (before, after)
