@@ -101,6 +101,7 @@ class Trainer:
         self.model_lr_scheduler = optim.lr_scheduler.StepLR(self.model_optimizer, self.opt.scheduler_step_size, 0.1)
 
         self._graph, self._graph_warm, self._capturing = None, 0, False
+        self.epoch, self.step, self.start_time = 0, 0, time.time()      # (train() resets them, as the reference does)
         all_params = [p for m in self.models.values() for p in m.parameters()]
         import torch.distributed as _dist
         self.reducer = ddp.GradBucketReducer(all_params, self.opt.sqd_bucket_mb) if _dist.is_initialized() else None

@@ -74,3 +74,26 @@ def test_five_steps_follow_the_oracle():
     for tr in (tr_e, tr_g):
         w = tr.models["pose"].net[0].weight.detach().cpu()
         assert float((w - w_ref).abs().max()) <= 0.05 * float((w_ref - state["pose"]["net.0.weight"]).abs().max()) + 1e-6
+
+
+def test_validation_between_graph_replays():
+    """Trainer.val() (eval-mode BatchNorm kernels, no_grad, eager) between replays of the captured training step."""
+    from options import MonodepthOptions
+    from trainer import Trainer
+    from datasets.synthetic import synthetic_batch
+    torch.manual_seed(1)
+    tr = Trainer(MonodepthOptions().parse(ARGS))
+    tr.set_train()
+    losses = []
+    for i in range(7):
+        inputs = synthetic_batch(B, H, W, start=B * i, device=tr.device)
+        losses.append(float(tr.train_step(inputs)[1]["loss"]))
+        if i in (1, 4):
+            rm = tr.models["encoder"].encoder.encoder.bn1.running_mean.clone()
+            tr.val()                                            # eager, eval mode; must leave the training state alone
+            assert all(m.training for m in tr.models.values())
+            assert torch.equal(rm, tr.models["encoder"].encoder.encoder.bn1.running_mean)
+    assert tr._graph is not None
+    assert all(l == l and l < 1.0 for l in losses), losses      # finite, sane
+    nbt = int(tr.models["encoder"].encoder.encoder.bn1.num_batches_tracked)
+    assert nbt == 7, nbt                                        # one count per training step, none from validation
