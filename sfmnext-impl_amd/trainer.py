@@ -218,6 +218,7 @@ class Trainer:
             self._capture(inputs)
         for k, v in inputs.items():
             self._static_in[k].copy_(v, non_blocking=True)
+            inputs[k] = self._static_in[k]        # as process_batch does in eager mode: the caller's dict now holds device tensors
         if self.reducer is None:
             self.model_optimizer.refresh_hyper()
             self._graph.replay()
