@@ -169,9 +169,12 @@ int sqd_sql_bwd(const float *x, const float *K, const float *y, const float *g_y
 int sqd_bn_nblk(int M, int C);
 /* mask (may be NULL): [M*C/4] bytes, bit j of byte i = element 4i+j was positive before the activation; handing it to
  * the backward replaces two full reads of y by two reads of a 16x smaller array                                   */
+/* pre_rows > 0: part already holds pre_rows rows of [C][2] (sum, sum of squares) partials written by the producing
+ * convolution (sqd_conv_fwd's stats / sqd_conv_fwd_stats_rows) and the reduction pass over x is skipped; else part is
+ * scratch of sqd_bn_nblk(M, C) * C * 2 floats                                                                        */
 int sqd_bn_train_fwd(const float *x, const float *res, const float *gamma, const float *beta, float *running_mean,
-                     float *running_var, float *y, unsigned char *mask, float *save_mean, float *save_rstd, float *part, int M,
-                     int C, float eps, float momentum, int act, void *stream);
+                     float *running_var, float *y, unsigned char *mask, float *save_mean, float *save_rstd, float *part,
+                     int pre_rows, int M, int C, float eps, float momentum, int act, void *stream);
 int sqd_bn_eval_fwd(const float *x, const float *res, const float *gamma, const float *beta, const float *running_mean,
                     const float *running_var, float *y, int M, int C, float eps, int act, void *stream);
 /* dy, x, (y | mask: the activation's derivative; neither is read when act = 0) -> dx, dres (may be NULL), dgamma [C], dbeta [C] */
@@ -233,8 +236,11 @@ int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, int R, int S,
                       int bn, int z, int bk);
 int sqd_conv_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
                   int64_t *ws_floats);
-int sqd_conv_fwd(const float *x, const float *w, const float *bias, float *y, float *ws, int N, int H, int W, int C, int K,
-                 int R, int S, int stride, int pad, int Ho, int Wo, int act, void *stream);
+/* stats (may be NULL): [sqd_conv_fwd_stats_rows(...)][K][2] per-channel (sum, sum of squares) partials of y for the BatchNorm that
+ * follows (rows = 0: the current plan splits the reduction and writes none; never more than ceil(N*Ho*Wo / 64) rows)   */
+int sqd_conv_fwd_stats_rows(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo);
+int sqd_conv_fwd(const float *x, const float *w, const float *bias, float *y, float *ws, float *stats, int N, int H, int W,
+                 int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int act, void *stream);
 /* addend [N,H,W,C] or NULL: dx = dgrad + addend (the gradient arriving over a second path, e.g. the residual branch) */
 int sqd_conv_dgrad(const float *dy, const float *w, const float *addend, float *dx, float *ws, int N, int H, int W, int C,
                    int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream);

@@ -249,16 +249,19 @@ extern "C" int sqd_bn_nblk(int M, int C) {
 
 extern "C" int sqd_bn_train_fwd(const float *x, const float *res, const float *gamma, const float *beta, float *running_mean,
                                 float *running_var, float *y, unsigned char *mask, float *save_mean, float *save_rstd, float *part,
-                                int M, int C, float eps, float momentum, int act, void *stream) {
+                                int pre_rows, int M, int C, float eps, float momentum, int act, void *stream) {
     SQD_CHECK_ARG(x && gamma && beta && y && save_mean && save_rstd && part, "sqd_bn_train_fwd: null pointer");
     if (check("sqd_bn_train_fwd", M, C)) return SQD_EINVAL;
     const Geom g = geom(M, C);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(g.nblk), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, part, M, C, act, g,
-                       (const unsigned char *)nullptr);
-    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, part, g.nblk, M, C, eps, momentum,
-                       save_mean, save_rstd, running_mean, running_var);
+    // pre_rows > 0: `part` already holds that many rows of (sum, sum of squares) partials — written by the producing
+    // convolution's epilogue (sqd_conv_fwd's stats) — and the reduction pass over x is skipped
+    if (pre_rows <= 0)
+        hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(g.nblk), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, part, M, C, act, g,
+                           (const unsigned char *)nullptr);
+    hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, part, pre_rows > 0 ? pre_rows : g.nblk, M,
+                       C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
     const size_t total4 = (size_t)M * C / 4;
     hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), dim3(ew_grid(total4)), dim3(256), 0, s, x, res, gamma, beta, save_mean,
                        save_rstd, y, total4, C, eps, act, mask);

@@ -42,7 +42,7 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 template <int MODE, int BM, int BN, int WGM, int WGN, int BKT>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
                                                         const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
-                                                        int act, int zsplits, int order) {
+                                                        int act, int zsplits, int order, float *__restrict__ stats) {
     constexpr int WTM = BM / WGM / 32, WTN = BN / WGN / 32;     // 32x32 MFMA tiles per wave
     static_assert(WGM * WGN == 4 && WTM >= 1 && WTN >= 1, "4 waves per workgroup");
     // BKT = reduction slice per step (16 or 32 channels): a wider slice halves the barriers and per-step bookkeeping for
@@ -266,10 +266,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
     }
 
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    // forward with `stats`: per-channel (sum, sum of squares) of this tile's valid rows, i.e. the partials BatchNorm's first
+    // pass would otherwise re-read the whole output for (stats [tiles_m][K][2], same layout as bn_reduce_kernel's)
+    __shared__ float sred[MODE == 0 ? 4 : 1][MODE == 0 ? WTN * 32 : 1][2];
+    const bool want_stats = MODE == 0 && stats != nullptr && zsplits == 1;
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
         const int col = n0 + wn0 + j * 32 + row;
-        if (col >= Ncols) continue;
+        float s1 = 0.f, s2 = 0.f;
+        if (col < Ncols) {
         const float bv = (MODE == 0 && bias && zsplits == 1) ? bias[col] : 0.f;
         const size_t out_rows = MODE == 0 ? (size_t)Mrows : (size_t)g.N * g.H * g.W;
         float *dst = out + (size_t)blockIdx.z * out_rows * Ncols;       // zsplits > 1: `out` is the partial workspace
@@ -284,8 +289,35 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
                     if (MODE == 1 && bias && zsplits == 1) v += bias[(size_t)m * Ncols + col];   // dgrad: `bias` is the [N,H,W,C] addend
                     if (MODE == 0 && act == 1 && zsplits == 1) v = v > 0.f ? v : 0.f;
                     dst[(size_t)m * Ncols + col] = v;
+                    s1 += v;
+                    s2 = fmaf(v, v, s2);
                 }
             }
+        }
+        if (want_stats) {
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0) {
+                sred[wave][j * 32 + row][0] = s1;
+                sred[wave][j * 32 + row][1] = s2;
+            }
+        }
+    }
+    if (want_stats) {
+        __syncthreads();
+        if (t < BN && n0 + t < Ncols) {
+            // the WGM waves stacked along M that cover column t, in wave order
+            const int wn = t / (WTN * 32), cl = t - wn * (WTN * 32);
+            float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+            for (int wmi = 0; wmi < WGM; ++wmi) {
+                a1 += sred[wmi * WGN + wn][cl][0];
+                a2 += sred[wmi * WGN + wn][cl][1];
+            }
+            float *o = stats + ((size_t)(m0 / BM) * Ncols + n0 + t) * 2;
+            o[0] = a1;
+            o[1] = a2;
+        }
     }
 }
 
@@ -775,7 +807,7 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
 #define LAUNCH_GEMM(MODE, BM, BN, WGM, WGN, BKT)                                                                               \
     hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT>),                                                \
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(256), 0, st, \
-                       a_src, w, bias, dst, g, act, p.z, order)
+                       a_src, w, bias, dst, g, act, p.z, order, stats)
 #define DISPATCH_GEMM(MODE)                                                      \
     if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM(MODE, 128, 128, 2, 2, 16);       \
     else if (p.bm == 128 && p.bn == 64) {                                        \
@@ -793,7 +825,7 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     }
 
 static int launch_gemm(int mode, const float *a_src, const float *w, const float *bias, float *out, float *ws, const ConvGeom &g,
-                       int act, void *stream) {
+                       int act, void *stream, float *stats = nullptr) {
     const int ncls = mode == 0 ? 1 : g.stride * g.stride;
     const int Mcls = mode == 0 ? g.N * g.Ho * g.Wo : g.N * ((g.H + g.stride - 1) / g.stride) * ((g.W + g.stride - 1) / g.stride);
     const int Mrows = mode == 0 ? g.N * g.Ho * g.Wo : g.N * g.H * g.W;
@@ -853,14 +885,25 @@ extern "C" int sqd_conv_plan(int mode, int N, int H, int W, int C, int K, int R,
     return SQD_OK;
 }
 
+// Rows of BatchNorm partials sqd_conv_fwd writes into `stats` for this geometry under the current plan ([rows][K][2] floats:
+// per-channel sum and sum of squares of a tile of output rows, the layout sqd_bn_train_fwd's finalize reads): ceil(M / tile
+// rows), or 0 when the plan splits the reduction (the statistics are then not produced; at most ceil(M/64) rows otherwise).
+extern "C" int sqd_conv_fwd_stats_rows(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo) {
+    ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
+    const GemmPlan p = plan_gemm(0, g);
+    if (p.z > 1) return 0;
+    return (N * Ho * Wo + p.bm - 1) / p.bm;
+}
+
 // x [N,H,W,C], w [K,R,S,C], bias [K] or NULL -> y [N,Ho,Wo,K]; act: 0 none, 1 ReLU.  C, K multiples of 16.
-extern "C" int sqd_conv_fwd(const float *x, const float *w, const float *bias, float *y, float *ws, int N, int H, int W, int C, int K,
-                            int R, int S, int stride, int pad, int Ho, int Wo, int act, void *stream) {
+// stats (may be NULL): see sqd_conv_fwd_stats_rows — per-channel partial sums of y for the BatchNorm that follows.
+extern "C" int sqd_conv_fwd(const float *x, const float *w, const float *bias, float *y, float *ws, float *stats, int N, int H, int W,
+                            int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int act, void *stream) {
     SQD_CHECK_ARG(x && w && y, "sqd_conv_fwd: null pointer");
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     if (check_geom("sqd_conv_fwd", g)) return SQD_EINVAL;
     SQD_CHECK_ARG(C % 16 == 0, "sqd_conv_fwd: C=%d must be a multiple of 16", C);
-    if (launch_gemm(0, x, w, bias, y, ws, g, act, stream)) return SQD_EINVAL;
+    if (launch_gemm(0, x, w, bias, y, ws, g, act, stream, stats)) return SQD_EINVAL;
     SQD_CHECK_LAUNCH("sqd_conv_fwd");
     return SQD_OK;
 }

@@ -94,7 +94,7 @@ _SIGNATURES = {
     "sqd_sql_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sqd_sql_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sqd_bn_nblk": (_I, [_I, _I]),
-    "sqd_bn_train_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _F, _I, _P]),
+    "sqd_bn_train_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),
     "sqd_bn_eval_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
     "sqd_bn_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "sqd_upcat_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
@@ -109,7 +109,8 @@ _SIGNATURES = {
     "sqd_conv_supported": (_I, [_I, _I]),
     "sqd_conv_set_plan": (_I, [_I] * 16),
     "sqd_conv_plan": (_I, [_I] * 12 + [ctypes.POINTER(ctypes.c_int64)]),
-    "sqd_conv_fwd": (_I, [_P, _P, _P, _P, _P] + [_I] * 12 + [_P]),
+    "sqd_conv_fwd_stats_rows": (_I, [_I] * 11),
+    "sqd_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 12 + [_P]),
     "sqd_conv_dgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
     "sqd_conv_wgrad_plan": (_I, [_I] * 7 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)]),
     "sqd_conv_wgrad_set_plan": (_I, [_I] * 9),

@@ -40,7 +40,7 @@ class BatchNormAct(torch.autograd.Function):
     (in place on the BatchNorm2d buffers); eval: running statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, pre_part=None, pre_rows=0):
         _require(x, "BatchNormAct input")
         x = _cl(x)
         N, C, H, W = x.shape
@@ -50,15 +50,18 @@ class BatchNormAct(torch.autograd.Function):
         L = _l.lib()
         code = ACT[act]
         if training:
-            nblk = L.sqd_bn_nblk(M, C)
-            part = torch.empty(nblk * C * 2, device=x.device, dtype=torch.float32)
+            if pre_part is not None and pre_rows > 0:       # statistics partials from the producing convolution's epilogue
+                part = pre_part
+            else:
+                pre_rows = 0
+                part = torch.empty(L.sqd_bn_nblk(M, C) * C * 2, device=x.device, dtype=torch.float32)
             mean = torch.empty(C, device=x.device, dtype=torch.float32)
             rstd = torch.empty(C, device=x.device, dtype=torch.float32)
             # sign bits of the pre-activation (1 byte per 4 elements): the backward reads them instead of y
             mask = torch.empty(M * C // 4, device=x.device, dtype=torch.uint8) if code else None
             _l.check(L.sqd_bn_train_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                        _ptr(y), _ptr(mask), _ptr(mean), _ptr(rstd), _ptr(part), M, C, float(eps), float(momentum),
-                                        code, _stream()), "bn_train_fwd")
+                                        _ptr(y), _ptr(mask), _ptr(mean), _ptr(rstd), _ptr(part), pre_rows, M, C, float(eps),
+                                        float(momentum), code, _stream()), "bn_train_fwd")
             ctx.save_for_backward(x, mask, gamma, mean, rstd)
             ctx.has_res, ctx.code = residual is not None, code
         else:
@@ -84,7 +87,7 @@ class BatchNormAct(torch.autograd.Function):
         part = torch.empty(L.sqd_bn_nblk(M, C) * C * 2, device=x.device, dtype=torch.float32)
         _l.check(L.sqd_bn_train_bwd(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
                                     _ptr(dgamma), _ptr(dbeta), _ptr(part), M, C, ctx.code, _stream()), "bn_train_bwd")
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
 
 
 class MaxPool3x3s2(torch.autograd.Function):
@@ -188,6 +191,7 @@ def _tune_conv(mode, geom, launch):
             if best is None or t < best[0]:
                 best = (t, bm, bn, z, bk)
     _PLAN_CACHE.pop(key, None)
+    _PLAN_CACHE.pop(("s",) + tuple(geom), None)
     if best is None:
         L.sqd_conv_set_plan(mode, *geom, 0, 0, 0, 16)
     else:
@@ -266,7 +270,7 @@ class Conv2d(torch.autograd.Function):
     of ATen running a separate 3-pass add over the activation."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, act, skip=False, out_hw=None):
+    def forward(ctx, x, weight, bias, stride, pad, act, skip=False, out_hw=None, stats=None):
         _require(x, "Conv2d input")
         x, w = _cl(x), _cl(weight)
         N, C, H, W = x.shape
@@ -278,11 +282,11 @@ class Conv2d(torch.autograd.Function):
         y = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
         if TUNE_CONV:
             _tune_conv(0, (N, H, W, C, K, R, S, stride, pad, Ho, Wo),
-                       lambda ws: _l.lib().sqd_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws), N, H, W, C, K, R, S, stride, pad,
-                                                        Ho, Wo, ACT[act], _stream()))
+                       lambda ws: _l.lib().sqd_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws), _ptr(stats), N, H, W, C, K, R, S,
+                                                        stride, pad, Ho, Wo, ACT[act], _stream()))
         ws = _conv_ws(0, (N, H, W, C, K, R, S, stride, pad, Ho, Wo), x.device)
-        _l.check(_l.lib().sqd_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
-                                       ACT[act], _stream()), "conv_fwd")
+        _l.check(_l.lib().sqd_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws), _ptr(stats), N, H, W, C, K, R, S, stride, pad,
+                                       Ho, Wo, ACT[act], _stream()), "conv_fwd")
         ctx.save_for_backward(x, w, y if act == "relu" else None)
         ctx.geom = (N, H, W, C, K, R, S, stride, pad, Ho, Wo)
         ctx.has_bias, ctx.act = bias is not None, act
@@ -295,7 +299,7 @@ class Conv2d(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         N, H, W, C, K, R, S, stride, pad, Ho, Wo = ctx.geom
         if dy is None:                                   # only the pass-through output was used
-            return g_skip, None, None, None, None, None, None, None
+            return g_skip, None, None, None, None, None, None, None, None
         dy = _cl(dy)
         g_skip = _cl(g_skip) if g_skip is not None else None
         if ctx.act == "relu":
@@ -324,7 +328,16 @@ class Conv2d(torch.autograd.Function):
             part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
             _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
                                       _stream()), "conv_wgrad")
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
+
+
+def conv_stats_rows(geom):
+    """rows of BatchNorm partials the forward convolution of this geometry writes under its current plan (0: none)"""
+    key = ("s",) + tuple(geom)
+    n = _PLAN_CACHE.get(key)
+    if n is None:
+        n = _PLAN_CACHE[key] = _l.lib().sqd_conv_fwd_stats_rows(*geom)
+    return n
 
 
 def stem_s2d_supported(conv, x):
@@ -334,7 +347,7 @@ def stem_s2d_supported(conv, x):
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
 
 
-def conv2d_stem_s2d(x, conv, act=None):
+def conv2d_stem_s2d(x, conv, act=None, stats=None):
     """A 7x7 stride-2 convolution on C (3 or 6) channels == a 4x4 stride-1 convolution on the space-to-depth(2) image with
     4C channels (padded to a multiple of 16) and the filter regrouped the same way: tap u = 2r' + dy - 1 of the 7 (u = -1 and
     u = 7 are zero taps).  That shape runs on the implicit-GEMM kernels (57-77 % of the multiplies are real), so the stems
@@ -348,7 +361,7 @@ def conv2d_stem_s2d(x, conv, act=None):
     # (regrouped on every call — one tiny kernel: the optimiser updates the weights through raw pointers, so nothing on the
     # Python side could tell a cached copy that it is stale, and a copy cached before a graph capture would be frozen into it)
     w = StemRegroup.apply(conv.weight, Cp)
-    return Conv2d.apply(xs, w, conv.bias, 1, 2, act, False, (H // 2, W // 2))
+    return Conv2d.apply(xs, w, conv.bias, 1, 2, act, False, (H // 2, W // 2), stats)
 
 
 class StemRegroup(torch.autograd.Function):
@@ -372,11 +385,22 @@ class StemRegroup(torch.autograd.Function):
         return (gw.contiguous(memory_format=torch.channels_last) if cl else gw), None
 
 
-def conv2d_native(x, conv, act=None, skip=False):
+def conv2d_native(x, conv, act=None, skip=False, stats=None):
     s, p = conv.stride, conv.padding
     if s[0] != s[1] or p[0] != p[1] or conv.dilation != (1, 1) or conv.groups != 1:
         raise RuntimeError("sqd: native conv handles square stride/padding, dilation 1, groups 1")
-    return Conv2d.apply(x, conv.weight, conv.bias, s[0], p[0], act, skip)
+    return Conv2d.apply(x, conv.weight, conv.bias, s[0], p[0], act, skip, None, stats)
+
+
+def conv_out_geom(x, conv, s2d=False):
+    """(N,H,W,C,K,R,S,stride,pad,Ho,Wo) of the launch conv2d_native / conv2d_stem_s2d makes for this module and input"""
+    N, C, H, W = x.shape
+    K = conv.out_channels
+    if s2d:
+        Cp = (4 * C + 15) // 16 * 16
+        return (N, H // 2, W // 2, Cp, K, 4, 4, 1, 2, H // 2, W // 2)
+    R, S, st, pd = conv.kernel_size[0], conv.kernel_size[1], conv.stride[0], conv.padding[0]
+    return (N, H, W, C, K, R, S, st, pd, (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1)
 
 
 _DEFER_COUNTERS = False
@@ -396,7 +420,7 @@ def flush_bn_counters():
         _PENDING_COUNTERS.clear()
 
 
-def batch_norm_act(x, bn, act, residual=None):
+def batch_norm_act(x, bn, act, residual=None, pre_part=None, pre_rows=0):
     """nn.BatchNorm2d module `bn` (parameters, running buffers, momentum, eps) applied through the fused
     kernels; keeps nn.BatchNorm2d's bookkeeping (num_batches_tracked)."""
     training = bn.training or bn.running_mean is None
@@ -406,4 +430,5 @@ def batch_norm_act(x, bn, act, residual=None):
         else:
             bn.num_batches_tracked.add_(1)
     return BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, training,
-                              0.1 if bn.momentum is None else bn.momentum, bn.eps, act)
+                              0.1 if bn.momentum is None else bn.momentum, bn.eps, act, pre_part if training else None,
+                              pre_rows if training else 0)

@@ -32,6 +32,8 @@ import os
 
 # 7x7/2 stems as 4x4/1 convolutions on a space-to-depth input (SQD_STEM_ATEN=1: ATen/MIOpen for the stems, A/B runs)
 STEM_S2D = not os.environ.get("SQD_STEM_ATEN")
+# BatchNorm statistics partials from the producing convolution's epilogue (SQD_NO_CONV_BN_STATS=1: BatchNorm's own pass, A/B runs)
+CONV_BN_STATS = not os.environ.get("SQD_NO_CONV_BN_STATS")
 NATIVE_CONV = False          # set by the Trainer (default on; --sqd_aten_conv is the A/B switch back to ATen/MIOpen)
 
 
@@ -44,15 +46,30 @@ def set_native_conv(on):
     BACKEND["conv_bn_act"] = ("hip conv" if on else "aten conv") + " + hip bn/act/residual"
 
 
-def _conv(x, conv, act=None, skip=False):
-    """skip=True: -> (y, x') with x' the input handed through the convolution node (see nnkernels.Conv2d)."""
+def _conv(x, conv, act=None, skip=False, bn_stats=None):
+    """skip=True: -> (y, x') with x' the input handed through the convolution node (see nnkernels.Conv2d).
+    bn_stats: a list that receives (partials, rows) when the convolution's epilogue produced the statistics partials of
+    the BatchNorm that follows (native kernels, training, plan without split-K)."""
     if NATIVE_CONV and x.is_cuda:
         from . import nnkernels
-        if nnkernels.conv_module_supported(conv):
-            return nnkernels.conv2d_native(x, conv, act, skip)
-        if STEM_S2D and nnkernels.stem_s2d_supported(conv, x):
-            y = nnkernels.conv2d_stem_s2d(x, conv, act)
-            return (y, x) if skip else y
+        native = nnkernels.conv_module_supported(conv)
+        s2d = not native and STEM_S2D and nnkernels.stem_s2d_supported(conv, x)
+        stats = geom = None
+        if bn_stats is not None and (native or s2d):
+            geom = nnkernels.conv_out_geom(x, conv, s2d)
+            M, K = geom[0] * geom[9] * geom[10], geom[4]
+            stats = torch.empty(((M + 63) // 64) * K * 2, device=x.device, dtype=torch.float32)    # room for the smallest row tile
+        if native:
+            out = nnkernels.conv2d_native(x, conv, act, skip, stats)
+        elif s2d:
+            y = nnkernels.conv2d_stem_s2d(x, conv, act, stats)
+            out = (y, x) if skip else y
+        if native or s2d:
+            if stats is not None:
+                rows = nnkernels.conv_stats_rows(geom)      # after the call: the first call may have (re)tuned the plan
+                if rows > 0:
+                    bn_stats.append((stats, rows))
+            return out
     y = _act(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), act)
     return (y, x) if skip else y
 
@@ -69,18 +86,22 @@ def conv_bn_act(x, conv, bn, act, residual=None, input_affine=None, skip=False):
     epilogue instead of a separate accumulation pass."""
     if input_affine is not None:
         x = (x - input_affine[0]) / input_affine[1]
+    training = bn.training or bn.running_mean is None
+    pre = [] if (training and CONV_BN_STATS) else None
     if skip:
-        y, x_skip = _conv(x, conv, None, True)
-        return _bn_act(y, bn, act, residual), x_skip
-    y = _conv(x, conv)
-    return _bn_act(y, bn, act, residual)
+        y, x_skip = _conv(x, conv, None, True, pre)
+        return _bn_act(y, bn, act, residual, pre), x_skip
+    y = _conv(x, conv, None, False, pre)
+    return _bn_act(y, bn, act, residual, pre)
 
 
-def _bn_act(y, bn, act, residual):
+def _bn_act(y, bn, act, residual, pre=None):
     if y.is_cuda:
         from . import nnkernels
         if not nnkernels.bn_supported(y.shape[1]):
             raise RuntimeError("sqd: BatchNorm kernel needs C/4 to be a power of two (C=%d)" % y.shape[1])
+        if pre:
+            return nnkernels.batch_norm_act(y, bn, act, residual, pre[0][0], pre[0][1])
         return nnkernels.batch_norm_act(y, bn, act, residual)
     # host tensors: only the CPU wiring tests come here
     y = bn(y)

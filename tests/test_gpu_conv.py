@@ -125,3 +125,47 @@ def test_stem_space_to_depth(N, C, H, W, K, bias, act):
     assert float((gw - gwr).abs().max()) <= 2e-4 * float(gwr.abs().max()), float((gw - gwr).abs().max()) / float(gwr.abs().max())
     if bias:
         assert torch.allclose(conv_g.bias.grad.cpu(), conv.bias.grad, rtol=2e-4, atol=2e-4 * float(conv.bias.grad.abs().max()))
+
+
+@pytest.mark.parametrize("N,C,H,W,K,R,stride,pad,bias", [(6, 32, 45, 61, 64, 3, 1, 1, True), (2, 64, 24, 40, 256, 1, 1, 0, False),
+                                                          (4, 3, 128, 192, 64, 7, 2, 3, False)])
+def test_conv_epilogue_feeds_batchnorm_statistics(N, C, H, W, K, R, stride, pad, bias):
+    """conv -> BatchNorm(train) -> ReLU through nnops.conv_bn_act with the statistics partials taken from the convolution's
+    epilogue: output, running statistics and all gradients against the torch composite."""
+    from sqd import nnkernels, nnops
+    torch.manual_seed(K + R)
+    conv, bn = nn.Conv2d(C, K, R, stride, pad, bias=bias), nn.BatchNorm2d(K)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(N, C, H, W)
+    conv_g, bn_g = nn.Conv2d(C, K, R, stride, pad, bias=bias).cuda(), nn.BatchNorm2d(K).cuda()
+    conv_g.load_state_dict(conv.state_dict())
+    bn_g.load_state_dict(bn.state_dict())
+    conv_g = conv_g.to(memory_format=torch.channels_last)
+    conv, bn = conv.double(), bn.double()                     # fp64 reference: the comparison then measures OUR rounding only
+    xr = x.double().requires_grad_(C > 3)
+    yr = F.relu(bn(conv(xr)))
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    gy = gy.float()
+    nnops.set_native_conv(True)
+    try:
+        assert nnops.CONV_BN_STATS
+        xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(C > 3)
+        y = nnops.conv_bn_act(xg, conv_g, bn_g, "relu")
+        geom = nnkernels.conv_out_geom(xg, conv_g, s2d=(C == 3))
+        assert nnkernels.conv_stats_rows(geom) > 0, "this geometry must take the fused-statistics path"
+        y.backward(gy.cuda())
+    finally:
+        nnops.set_native_conv(False)
+    assert torch.allclose(y.cpu().double(), yr.detach(), rtol=1e-4, atol=2e-4)
+    assert torch.allclose(bn_g.running_mean.cpu().double(), bn.running_mean, rtol=1e-4, atol=1e-5)
+    assert torch.allclose(bn_g.running_var.cpu().double(), bn.running_var, rtol=1e-4, atol=1e-5)
+    # gradients through BatchNorm are differences of large sums (the filter gradient of a conv followed by BN sums to ~0 per
+    # output channel): tolerance relative to the largest entry, fp32 accumulation over N*Ho*Wo pixels
+    for name, a, b in (("dw", conv_g.weight.grad, conv.weight.grad), ("dgamma", bn_g.weight.grad, bn.weight.grad),
+                       ("dbeta", bn_g.bias.grad, bn.bias.grad)):
+        assert float((a.cpu().double() - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-6, name
+    if C > 3:
+        assert float((xg.grad.cpu().double() - xr.grad).abs().max()) <= 1e-3 * float(xr.grad.abs().max())

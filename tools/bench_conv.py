@@ -75,14 +75,14 @@ for name, C, H, W, K, R, st, pad, cnt in L:
     dx = torch.empty_like(x)
     dw = torch.empty_like(w)
     if args.tune:
-        nnkernels._tune_conv(0, geom, lambda ws: LIB.sqd_conv_fwd(P(x), P(w), None, P(y), P(ws), *geom, 0, ST()))
+        nnkernels._tune_conv(0, geom, lambda ws: LIB.sqd_conv_fwd(P(x), P(w), None, P(y), P(ws), None, *geom, 0, ST()))
         nnkernels._tune_conv(1, geom, lambda ws: LIB.sqd_conv_dgrad(P(dy), P(w), None, P(dx), P(ws), *geom, ST()))
         nnkernels._tune_wgrad(geom, False, lambda part: LIB.sqd_conv_wgrad(P(dy), P(x), P(dw), None, P(part), *geom, ST()))
     ws0, ws1 = nnkernels._conv_ws(0, geom, x.device), nnkernels._conv_ws(1, geom, x.device)
     sp, pf = ctypes.c_int(0), ctypes.c_int64(0)
     LIB.sqd_conv_wgrad_plan(N, Ho, Wo, C, K, R, R, ctypes.byref(sp), ctypes.byref(pf))
     part = torch.empty(pf.value, device="cuda")
-    t_nf = timeit(lambda: LIB.sqd_conv_fwd(P(x), P(w), None, P(y), P(ws0), *geom, 0, ST()), args.iters)
+    t_nf = timeit(lambda: LIB.sqd_conv_fwd(P(x), P(w), None, P(y), P(ws0), None, *geom, 0, ST()), args.iters)
     t_nd = timeit(lambda: LIB.sqd_conv_dgrad(P(dy), P(w), None, P(dx), P(ws1), *geom, ST()), args.iters)
     t_nw = timeit(lambda: LIB.sqd_conv_wgrad(P(dy), P(x), P(dw), None, P(part), *geom, ST()), args.iters)
     cb = torch.ops.aten.convolution_backward
