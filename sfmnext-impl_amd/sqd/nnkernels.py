@@ -303,7 +303,7 @@ class Conv2d(torch.autograd.Function):
         dy = _cl(dy)
         g_skip = _cl(g_skip) if g_skip is not None else None
         if ctx.act == "relu":
-            dy = dy * (y > 0)
+            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)         # dy where y > 0 else 0, one launch
         L = _l.lib()
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
