@@ -118,7 +118,7 @@ typedef struct sqd_photo_bwd_args {
     int64_t g_depth_img_stride; /* >= S*H*W */
     float gscale;
     int32_t B, S, H, W;
-    int32_t rows_per_task;  /* TH: 1..4096; 0 = default */
+    int32_t rows_per_task;  /* TH: 1..4096; 0 = default: smallest TH >= 8 whose task count fits one round of wavefronts */
     void *stream;
 } sqd_photo_bwd_args;
 int sqd_photo_bwd_ntasks(int B, int S, int H, int W, int rows_per_task);
