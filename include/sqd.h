@@ -278,6 +278,41 @@ int sqd_space_to_depth2(const float *x, float *y, int N, int H, int W, int C, in
 /* the matching filter regrouping w [K,C,7,7] -> ws [K,4,4,Cp] (tap u = 2r' + dy - 1; adjoint = 1: g_ws -> g_w, fully overwritten) */
 int sqd_stem_regroup(const float *src, float *dst, int K, int C, int Cp, int adjoint, void *stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * (13) token-wise blocks of the post-norm TransformerEncoderLayer over the patch tokens.  replaces: the feed-forward and the
+ * two add+dropout+LayerNorm steps of nn.TransformerEncoderLayer as the reference builds it at
+ * networks/depth_decoder_QTR.py:31-32 (d_model E in {16,32}, 4 heads, dim_feedforward F = 1024 | 512, ReLU, dropout 0.1)
+ * and runs it at :47.  Tokens are the rows of [rows = S*B, E] matrices.  Dropout masks are bytes (1 = keep) drawn by the
+ * caller, NULL = no dropout; scale = 1/(1-p).
+ *   sqd_addln_fwd: out = LayerNorm_E(x + mask*scale*(sum_p y[p] + ybias)) * gamma + beta; y [nparts][rows,E], ybias [E] or
+ *                  NULL; saves xhat [rows,E], rstd [rows]
+ *   sqd_addln_bwd: g = g_out + sum_p g_extra[p] (g_extra [nextra][rows,E]) -> g_x, g_y [rows,E];
+ *                  part: sqd_addln_nblk(rows) x [2][E] partials of (g_gamma, g_beta) for sqd_colsum_multi
+ *   sqd_ffn_fwd:   ypart [G][rows,E], G = sqd_ffn_groups(F) partials over groups of 128 hidden units of
+ *                  W2 . (mask*scale*relu(W1 . x + b1)); W1 [F,E], W2 [E,F], mask [rows,F] (4-byte aligned).  The consumer
+ *                  (sqd_addln_fwd with nparts = G, ybias = b2) adds them.
+ *   sqd_ffn_bwd:   g_y -> gxpart [G][rows,E] (g_x = sum over G; sqd_addln_bwd's g_extra) and per-token-tile partials,
+ *                  T = sqd_ffn_tiles(rows): pW1 [T][F,E], pW2T [T][F,E] (g_W2 transposed), pb1 [T][F], pb2 [T][E].
+ *                  Hidden activations are recomputed.
+ *   sqd_colsum_multi: up to 8 column sums in one launch: dst[s][c] = sum_{r<nrows[s]} src[s][r*ncols[s] + c], ncols % 4 == 0;
+ *                  tr[s] > 0 writes the [ncols/tr][tr] result transposed (pW2T -> g_W2 with tr = E).  The arrays are host arrays.
+ * fp32 MFMA (v_mfma_f32_32x32x2_f32); deterministic (fixed-order partial sums). */
+int sqd_vit_supported(int E, int F);
+int sqd_addln_fwd(const float *x, const float *y, int nparts, const float *ybias, const unsigned char *mask, const float *gamma,
+                  const float *beta, float *out, float *xhat, float *rstd, int rows, int E, float scale, float eps, void *stream);
+int sqd_addln_nblk(int rows);
+int sqd_addln_bwd(const float *g_out, const float *g_extra, int nextra, const float *xhat, const float *rstd,
+                  const unsigned char *mask, const float *gamma, float *g_x, float *g_y, float *part, int rows, int E, float scale,
+                  void *stream);
+int sqd_ffn_groups(int F);
+int sqd_ffn_tiles(int rows);
+int sqd_ffn_fwd(const float *x, const float *W1, const float *b1, const float *W2, const unsigned char *mask, float *ypart, int rows,
+                int E, int F, float scale, void *stream);
+int sqd_ffn_bwd(const float *x, const float *g_y, const float *W1, const float *b1, const float *W2, const unsigned char *mask,
+                float *gxpart, float *pW1, float *pb1, float *pW2T, float *pb2, int rows, int E, int F, float scale, void *stream);
+int sqd_colsum_multi(const float *const *src, float *const *dst, const int *nrows, const int *ncols, const int *tr, int nseg,
+                     void *stream);
+
 #ifdef __cplusplus
 }
 #endif

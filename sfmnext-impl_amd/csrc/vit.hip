@@ -1,0 +1,466 @@
+// vit.hip — the two token-wise blocks of the post-norm TransformerEncoderLayer the depth head runs on its 120 patch tokens
+// (reference networks/depth_decoder_QTR.py:31-32,47: nn.TransformerEncoderLayer(E, 4 heads, dim_feedforward 1024 | 512, ReLU,
+// dropout 0.1), 4 layers), as fused kernels.  Tokens are rows of a [rows = S*B, E] matrix, E in {16, 32}.
+//
+//   add + dropout + LayerNorm :  out = LN(x + mask * scale * y)             (norm1 / norm2 with dropout1 / dropout2)
+//   feed-forward              :  y = W2 . (mask * scale * relu(W1 . x + b1)) + b2   (linear1, ReLU, dropout, linear2)
+//
+// The layer is latency-bound, not throughput-bound (46 K token elements, 190 MFLOP): ATen runs its post-attention half as
+// ~45 launches forward+backward per layer; these kernels make it 3 + 4.  What matters is the length of the dependent chain
+// inside a launch, so the work is cut fine: one wave = 32 tokens x 32 hidden units, every global load it needs issued up
+// front, grid = token tiles x hidden groups (360 workgroups for 1440 tokens, F = 1024).  The feed-forward runs on
+// v_mfma_f32_32x32x2_f32 in the transposed orientation (hidden units x tokens) so that the second product consumes the
+// first one's accumulator registers directly; the hidden activations are never stored — the backward recomputes them.
+// Sums over hidden groups (y, g_x) are left as partials that the consuming add+LayerNorm kernel adds while loading;
+// sums over token tiles (weight gradients) go through one multi-segment column-sum launch.  Everything is fixed-order.
+// Dropout masks are bytes drawn by the caller (torch's generator: graph-safe), so training statistics are torch's.
+#include "sqd_common.h"
+
+namespace {
+using namespace sqd;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >> 2) + 4 * h; }
+
+// ---------------------------------------------------------------------------------------------------
+// out = LayerNorm(x + drop(sum_p y[p] + ybias)) over the last dimension E; one half-wave (32 lanes) per row, lane = feature.
+// saves xhat [rows,E] and rstd [rows] for the backward.
+// ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void addln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ y, int nparts,
+                                                        const float *__restrict__ ybias, const unsigned char *__restrict__ mask,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta,
+                                                        float *__restrict__ out, float *__restrict__ xhat, float *__restrict__ rstd_out,
+                                                        int rows, int E, float scale, float eps) {
+    const int lane = threadIdx.x & 31, row = blockIdx.x * 8 + (threadIdx.x >> 5);
+    if (row >= rows) return;
+    const bool on = lane < E;
+    const size_t o = (size_t)row * E + lane, pstride = (size_t)rows * E;
+    float z = 0.f;
+    if (on) {
+        float yv = ybias ? ybias[lane] : 0.f;
+        for (int p = 0; p < nparts; ++p) yv += y[o + p * pstride];
+        if (mask) yv = mask[o] ? yv * scale : 0.f;
+        z = x[o] + yv;
+    }
+    float s = z;
+#pragma unroll
+    for (int k = 16; k > 0; k >>= 1) s += __shfl_xor(s, k, 32);
+    const float mean = s / (float)E;
+    const float d = on ? z - mean : 0.f;
+    float v = d * d;
+#pragma unroll
+    for (int k = 16; k > 0; k >>= 1) v += __shfl_xor(v, k, 32);
+    const float rstd = rsqrtf(v / (float)E + eps);
+    if (on) {
+        const float xh = d * rstd;
+        xhat[o] = xh;
+        out[o] = fmaf(xh, gamma[lane], beta[lane]);
+    }
+    if (lane == 0) rstd_out[row] = rstd;
+}
+
+// g = g_out + sum_p g_extra[p]  ->  g_x (= dz), g_y (= dz * mask * scale), per-block partials of dgamma / dbeta (part [nblk][2][E])
+constexpr int LN_ROWS = 16;     // rows per block of the backward
+__global__ __launch_bounds__(256) void addln_bwd_kernel(const float *__restrict__ g, const float *__restrict__ g_extra, int nextra,
+                                                        const float *__restrict__ xhat, const float *__restrict__ rstd,
+                                                        const unsigned char *__restrict__ mask, const float *__restrict__ gamma,
+                                                        float *__restrict__ gx, float *__restrict__ gy, float *__restrict__ part,
+                                                        int rows, int E, float scale) {
+    __shared__ float red[2][8][32];
+    const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;
+    const bool on = lane < E;
+    const float ga = on ? gamma[lane] : 0.f;
+    const size_t pstride = (size_t)rows * E;
+    float dg = 0.f, db = 0.f;
+    const int r0 = blockIdx.x * LN_ROWS, r1 = min(rows, r0 + LN_ROWS);
+#pragma unroll
+    for (int k = 0; k < LN_ROWS / 8; ++k) {
+        const int row = r0 + sub + 8 * k;
+        if (row >= r1) break;
+        const size_t o = (size_t)row * E + lane;
+        float gv = on ? g[o] : 0.f;
+        if (on)
+            for (int p = 0; p < nextra; ++p) gv += g_extra[o + p * pstride];
+        const float xh = on ? xhat[o] : 0.f;
+        const float dxh = gv * ga;
+        float s1 = dxh, s2 = dxh * xh;
+#pragma unroll
+        for (int q = 16; q > 0; q >>= 1) {
+            s1 += __shfl_xor(s1, q, 32);
+            s2 += __shfl_xor(s2, q, 32);
+        }
+        const float dz = rstd[row] * (dxh - s1 / (float)E - xh * (s2 / (float)E));
+        if (on) {
+            gx[o] = dz;
+            gy[o] = mask ? (mask[o] ? dz * scale : 0.f) : dz;
+        }
+        dg = fmaf(gv, xh, dg);
+        db += gv;
+    }
+    red[0][sub][lane] = dg;
+    red[1][sub][lane] = db;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int w = threadIdx.x >> 5;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a += red[w][k][lane];
+        if (on) part[((size_t)blockIdx.x * 2 + w) * E + lane] = a;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// several column sums in one launch: segment s: dst[c] = sum_r src[r * ncols + c] (fixed order), ncols % 4 == 0.
+// tr > 0: the columns are a [ncols / tr][tr] matrix written transposed ([tr][ncols / tr]).
+// block = 32 float4 columns x 8 row groups.
+// ---------------------------------------------------------------------------------------------------
+constexpr int CS_MAXSEG = 8;
+struct ColsumSegs {
+    const float *src[CS_MAXSEG];
+    float *dst[CS_MAXSEG];
+    int nrows[CS_MAXSEG], ncols[CS_MAXSEG], tr[CS_MAXSEG], blk0[CS_MAXSEG + 1];
+    int nseg;
+};
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumSegs S) {
+    __shared__ float4 red[8][32];
+    int s = 0;
+    while (s + 1 < S.nseg && (int)blockIdx.x >= S.blk0[s + 1]) ++s;
+    const int c4 = ((int)blockIdx.x - S.blk0[s]) * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+    const int ncols = S.ncols[s], nrows = S.nrows[s];
+    const bool on = c4 * 4 < ncols;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (on) {
+        const float *p = S.src[s] + (size_t)c4 * 4;
+        for (int r = rg; r < nrows; r += 8) {
+            const float4 v = *reinterpret_cast<const float4 *>(p + (size_t)r * ncols);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    }
+    red[rg][threadIdx.x & 31] = a;
+    __syncthreads();
+    if (rg == 0 && on) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k) {
+            const float4 v = red[k][threadIdx.x];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        float *d = S.dst[s];
+        const int tr = S.tr[s];
+        if (tr == 0) *reinterpret_cast<float4 *>(d + (size_t)c4 * 4) = a;
+        else {
+            const int outer = ncols / tr;
+            const float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int c = c4 * 4 + q;
+                d[(size_t)(c % tr) * outer + c / tr] = v[q];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// feed-forward.  Workgroup (tx, gy): tokens [32 tx, 32 tx + 32), hidden units [128 gy, 128 gy + 128): wave w owns the
+// chunk f0 = 128 gy + 32 w.  Orientation: hT[f, t] (rows = hidden units, columns = tokens).  Reduction index of the first
+// product is the feature e, split between the half-waves as e = 16*half + s (16 consecutive floats per lane: float4 loads).
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load16(const float *__restrict__ p, int E, int kk, bool valid, float (&v)[16]) {
+    // 16 consecutive features starting at 16*kk (zeros beyond E)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int e = 16 * kk + 4 * q;
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid && e < E) t = *reinterpret_cast<const float4 *>(p + e);
+        v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
+    }
+}
+
+// per-lane side data of a chunk in accumulator layout: register r <-> hidden unit f0 + acc_row(r, half); r = 4*g4 + j are 4
+// consecutive units, so bias and mask come as one float4 / one dword per g4
+struct ChunkSide {
+    float4 b1[4];
+    unsigned m[4];
+};
+__device__ __forceinline__ void load_side(const float *__restrict__ b1, const unsigned char *__restrict__ mask, int F, int f0, int h,
+                                          size_t tok, bool tv, ChunkSide &sd) {
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        const int f = f0 + 8 * g4 + 4 * h;
+        sd.b1[g4] = f < F ? *reinterpret_cast<const float4 *>(b1 + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sd.m[g4] = 0x01010101u;
+        if (mask) sd.m[g4] = (tv && f < F) ? *reinterpret_cast<const unsigned *>(mask + tok * F + f) : 0u;
+    }
+}
+__device__ __forceinline__ float side_b1(const ChunkSide &sd, int r) {
+    const float4 b = sd.b1[r >> 2];
+    return (r & 3) == 0 ? b.x : (r & 3) == 1 ? b.y : (r & 3) == 2 ? b.z : b.w;
+}
+__device__ __forceinline__ bool side_keep(const ChunkSide &sd, int r) { return (sd.m[r >> 2] >> (8 * (r & 3))) & 0xffu; }
+
+__global__ __launch_bounds__(256) void ffn_fwd_kernel(const float *__restrict__ x, const float *__restrict__ W1,
+                                                      const float *__restrict__ b1, const float *__restrict__ W2,
+                                                      const unsigned char *__restrict__ mask, float *__restrict__ ypart, int rows,
+                                                      int E, int F, float scale) {
+    __shared__ float yred[4][32][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int t0 = blockIdx.x * 32, tok = t0 + i;
+    const bool tv = tok < rows;
+    const int f0 = (blockIdx.y * 4 + wave) * 32;
+    f32x16 yT;                                           // yT[e', t]: rows = output features, columns = tokens
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yT[r] = 0.f;
+    if (f0 < F) {                                        // wave-uniform
+        float xt[16], w1[16];
+        float4 w2[4];
+        ChunkSide sd;
+        load16(x + (size_t)tok * E, E, h, tv, xt);
+        load16(W1 + (size_t)(f0 + i) * E, E, h, f0 + i < F, w1);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            const int f = f0 + 8 * g4 + 4 * h;           // k-slot (r = 4*g4 + j, half) of the second product is hidden unit f + j
+            w2[g4] = (i < E && f < F) ? *reinterpret_cast<const float4 *>(W2 + (size_t)i * F + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        load_side(b1, mask, F, f0, h, (size_t)tok, tv, sd);
+        f32x16 hT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hT[r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 16; ++s) hT = mfma32(w1[s], xt[s], hT);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = hT[r] + side_b1(sd, r);
+            hT[r] = (v > 0.f && side_keep(sd, r)) ? v * scale : 0.f;      // units >= F: W1 row, bias and W2 column are zero
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            yT = mfma32(w2[g4].x, hT[4 * g4 + 0], yT);
+            yT = mfma32(w2[g4].y, hT[4 * g4 + 1], yT);
+            yT = mfma32(w2[g4].z, hT[4 * g4 + 2], yT);
+            yT = mfma32(w2[g4].w, hT[4 * g4 + 3], yT);
+        }
+    }
+    // add the 4 waves (fixed order) -> this hidden group's partial of y
+#pragma unroll
+    for (int r = 0; r < 16; ++r) yred[wave][acc_row(r, h)][i] = yT[r];
+    __syncthreads();
+    float *yo = ypart + (size_t)blockIdx.y * rows * E;
+    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+        const int t = idx >> 5, e = idx & 31;
+        if (t0 + t < rows && e < E) yo[(size_t)(t0 + t) * E + e] = ((yred[0][e][t] + yred[1][e][t]) + yred[2][e][t]) + yred[3][e][t];
+    }
+}
+
+// backward: g_y [rows,E] -> gxpart [G][rows,E] (partials over the hidden groups); per-token-tile partials pW1 [T][F,E],
+// pW2 [T][F,E] (dW2 transposed), pb1 [T][F], pb2 [T][E]
+__global__ __launch_bounds__(256) void ffn_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gy,
+                                                      const float *__restrict__ W1, const float *__restrict__ b1,
+                                                      const float *__restrict__ W2, const unsigned char *__restrict__ mask,
+                                                      float *__restrict__ gxpart, float *__restrict__ pW1, float *__restrict__ pb1,
+                                                      float *__restrict__ pW2, float *__restrict__ pb2, int rows, int E, int F,
+                                                      float scale) {
+    __shared__ float xs[32][33], gs[32][33];             // the token tile: x and g_y, [token][feature], zero padded
+    __shared__ float xred[4][32][33];                    // g_x^T partials of the 4 waves
+    __shared__ float tile[4][2][32][36];                 // per wave: [0] hT (after relu*drop), [1] dhT; [f][token]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int t0 = blockIdx.x * 32, tok = t0 + i;
+    const bool tv = tok < rows;
+    const int f0 = (blockIdx.y * 4 + wave) * 32;
+    const bool active = f0 < F;                          // wave-uniform
+    // global loads of the chunk first (independent of the staging below)
+    float w1row[16], w2col[16], w1col[16];
+    ChunkSide sd;
+    if (active) {
+        load16(W1 + (size_t)(f0 + i) * E, E, h, f0 + i < F, w1row);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            const int e = 16 * h + s;
+            w2col[s] = (f0 + i < F && e < E) ? W2[(size_t)e * F + f0 + i] : 0.f;            // A of dhT: row f = lane, k = e'
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = f0 + acc_row(r, h);
+            w1col[r] = (f < F && i < E) ? W1[(size_t)f * E + i] : 0.f;                     // A of g_x^T: row e = lane, k = f
+        }
+        load_side(b1, mask, F, f0, h, (size_t)tok, tv, sd);
+    }
+    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+        const int t = idx >> 5, e = idx & 31;
+        const bool ok = t0 + t < rows && e < E;
+        xs[t][e] = ok ? x[(size_t)(t0 + t) * E + e] : 0.f;
+        gs[t][e] = ok ? gy[(size_t)(t0 + t) * E + e] : 0.f;
+    }
+    __syncthreads();
+    f32x16 gxT;                                          // g_x^T[e, t]
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gxT[r] = 0.f;
+    if (active) {
+        float(*hs)[36] = tile[wave][0], (*ds)[36] = tile[wave][1];
+        f32x16 hT, dT;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) hT[r] = dT[r] = 0.f;
+        // hT[f, t] = sum_e W1[f, e] x[t, e];  dhT[f, t] = sum_e' W2[e', f] gy[t, e']
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            hT = mfma32(w1row[s], xs[i][16 * h + s], hT);
+            dT = mfma32(w2col[s], gs[i][16 * h + s], dT);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float v = hT[r] + side_b1(sd, r);
+            const bool keep = v > 0.f && side_keep(sd, r);
+            const float hv = keep ? v * scale : 0.f;     // dropped, scaled activation (operand of dW2)
+            const float dv = keep ? dT[r] * scale : 0.f; // gradient w.r.t. the pre-activation
+            dT[r] = dv;
+            hs[acc_row(r, h)][i] = hv;
+            ds[acc_row(r, h)][i] = dv;
+        }
+        // g_x^T[e, t] += sum_f W1[f, e] dhT[f, t] : k-slot (r, half) is hidden unit f0 + acc_row(r, half)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gxT = mfma32(w1col[r], dT[r], gxT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // dW1[f, e] = sum_t dhT[f, t] x[t, e],  dW2[e', f] = sum_t gy[t, e'] hT[f, t] — contraction over the 32 tokens;
+        // k-step (gq, j): half-wave 0 takes token 8gq+j, half-wave 1 token 8gq+4+j
+        f32x16 aW1, aW2T;                                 // aW1: rows f, columns e;  aW2T: rows f, columns e'
+#pragma unroll
+        for (int r = 0; r < 16; ++r) aW1[r] = aW2T[r] = 0.f;
+        float db1 = 0.f;
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int tk = 8 * gq + 4 * h;
+            const float4 d4 = *reinterpret_cast<const float4 *>(&ds[i][tk]);
+            const float4 h4 = *reinterpret_cast<const float4 *>(&hs[i][tk]);
+            const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                aW1 = mfma32(dv[j], xs[tk + j][i], aW1);                  // B[k = token][col = e]
+                aW2T = mfma32(hv[j], gs[tk + j][i], aW2T);
+                db1 += dv[j];
+            }
+        }
+        db1 += __shfl_xor(db1, 32, 64);
+        // each (token tile, hidden unit) is written by exactly one wave: no cross-wave add for dW1 / dW2 / db1
+        float *w1o = pW1 + (size_t)blockIdx.x * F * E, *w2o = pW2 + (size_t)blockIdx.x * F * E;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int f = f0 + acc_row(r, h);
+            if (f < F && i < E) {
+                w1o[(size_t)f * E + i] = aW1[r];
+                w2o[(size_t)f * E + i] = aW2T[r];
+            }
+        }
+        if (h == 0 && f0 + i < F) pb1[(size_t)blockIdx.x * F + f0 + i] = db1;
+    }
+    // g_x: add the 4 waves -> this hidden group's partial; db2 partial = column sums of gy over this tile's tokens
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xred[wave][acc_row(r, h)][i] = gxT[r];
+    __syncthreads();
+    float *go = gxpart + (size_t)blockIdx.y * rows * E;
+    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
+        const int t = idx >> 5, e = idx & 31;
+        if (t0 + t < rows && e < E) go[(size_t)(t0 + t) * E + e] = ((xred[0][e][t] + xred[1][e][t]) + xred[2][e][t]) + xred[3][e][t];
+    }
+    if (blockIdx.y == 0 && threadIdx.x < E) {
+        float s = 0.f;
+#pragma unroll 8
+        for (int t = 0; t < 32; ++t) s += gs[t][threadIdx.x];
+        pb2[(size_t)blockIdx.x * E + threadIdx.x] = s;
+    }
+}
+
+int vit_check(const char *who, int rows, int E) {
+    SQD_CHECK_ARG(rows > 0 && (E == 16 || E == 32), "%s: rows=%d, E=%d (E must be 16 or 32)", who, rows, E);
+    return SQD_OK;
+}
+}  // namespace
+
+extern "C" int sqd_vit_supported(int E, int F) { return ((E == 16 || E == 32) && F >= 4 && F % 4 == 0 && F <= 8192) ? 1 : 0; }
+
+// ---- add + dropout + LayerNorm.  x [rows,E]; y [nparts][rows,E] (summed, + ybias [E] if not NULL); mask [rows,E] bytes
+// (1 = keep) or NULL; scale = 1/(1-p)
+extern "C" int sqd_addln_fwd(const float *x, const float *y, int nparts, const float *ybias, const unsigned char *mask,
+                             const float *gamma, const float *beta, float *out, float *xhat, float *rstd, int rows, int E, float scale,
+                             float eps, void *stream) {
+    SQD_CHECK_ARG(x && y && gamma && beta && out && xhat && rstd && nparts >= 1, "sqd_addln_fwd: null pointer or nparts < 1");
+    if (vit_check("sqd_addln_fwd", rows, E)) return SQD_EINVAL;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(addln_fwd_kernel, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, y, nparts, ybias, mask, gamma, beta, out,
+                       xhat, rstd, rows, E, scale, eps);
+    SQD_CHECK_LAUNCH("sqd_addln_fwd");
+    return SQD_OK;
+}
+
+// g = g_out + sum of nextra tensors g_extra [nextra][rows,E]; part: sqd_addln_nblk(rows) x [2][E] partials of (g_gamma, g_beta),
+// to be column-summed (sqd_colsum_multi)
+extern "C" int sqd_addln_nblk(int rows) { return (rows + LN_ROWS - 1) / LN_ROWS; }
+extern "C" int sqd_addln_bwd(const float *g_out, const float *g_extra, int nextra, const float *xhat, const float *rstd,
+                             const unsigned char *mask, const float *gamma, float *g_x, float *g_y, float *part, int rows, int E,
+                             float scale, void *stream) {
+    SQD_CHECK_ARG(g_out && xhat && rstd && gamma && g_x && g_y && part && nextra >= 0 && (g_extra || nextra == 0),
+                  "sqd_addln_bwd: null pointer");
+    if (vit_check("sqd_addln_bwd", rows, E)) return SQD_EINVAL;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(addln_bwd_kernel, dim3(sqd_addln_nblk(rows)), dim3(256), 0, (hipStream_t)stream, g_out, g_extra, nextra, xhat, rstd,
+                       mask, gamma, g_x, g_y, part, rows, E, scale);
+    SQD_CHECK_LAUNCH("sqd_addln_bwd");
+    return SQD_OK;
+}
+
+// ---- nseg <= 8 column sums in one launch: dst[s][c] = sum_{r < nrows[s]} src[s][r * ncols[s] + c]; ncols % 4 == 0;
+// tr[s] > 0: write the [ncols/tr][tr] result transposed
+extern "C" int sqd_colsum_multi(const float *const *src, float *const *dst, const int *nrows, const int *ncols, const int *tr, int nseg,
+                                void *stream) {
+    SQD_CHECK_ARG(src && dst && nrows && ncols && tr && nseg >= 1 && nseg <= CS_MAXSEG, "sqd_colsum_multi: bad arguments (nseg=%d)", nseg);
+    ColsumSegs S;
+    int blk = 0;
+    for (int s = 0; s < nseg; ++s) {
+        SQD_CHECK_ARG(src[s] && dst[s] && nrows[s] >= 1 && ncols[s] >= 4 && ncols[s] % 4 == 0 && tr[s] >= 0 &&
+                          (tr[s] == 0 || ncols[s] % tr[s] == 0),
+                      "sqd_colsum_multi: segment %d: nrows=%d ncols=%d tr=%d", s, nrows[s], ncols[s], tr[s]);
+        S.src[s] = src[s]; S.dst[s] = dst[s]; S.nrows[s] = nrows[s]; S.ncols[s] = ncols[s]; S.tr[s] = tr[s];
+        S.blk0[s] = blk;
+        blk += (ncols[s] / 4 + 31) / 32;
+    }
+    S.blk0[nseg] = blk;
+    S.nseg = nseg;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(colsum_multi_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, S);
+    SQD_CHECK_LAUNCH("sqd_colsum_multi");
+    return SQD_OK;
+}
+
+// ---- feed-forward.  x [rows,E], W1 [F,E], b1 [F], W2 [E,F]; mask [rows,F] bytes (4-byte aligned) or NULL
+//      -> ypart [G][rows,E] with G = sqd_ffn_groups(F): y = sum_g ypart[g] + b2 (added by the consumer, sqd_addln_fwd)
+extern "C" int sqd_ffn_groups(int F) { return (F + 127) / 128; }
+extern "C" int sqd_ffn_fwd(const float *x, const float *W1, const float *b1, const float *W2, const unsigned char *mask, float *ypart,
+                           int rows, int E, int F, float scale, void *stream) {
+    SQD_CHECK_ARG(x && W1 && b1 && W2 && ypart, "sqd_ffn_fwd: null pointer");
+    SQD_CHECK_ARG(rows > 0 && sqd_vit_supported(E, F), "sqd_ffn_fwd: unsupported dims rows=%d E=%d F=%d", rows, E, F);
+    SQD_CHECK_ARG(((uintptr_t)mask & 3) == 0, "sqd_ffn_fwd: mask must be 4-byte aligned");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(ffn_fwd_kernel, dim3((rows + 31) / 32, sqd_ffn_groups(F)), dim3(256), 0, (hipStream_t)stream, x, W1, b1, W2, mask, ypart,
+                       rows, E, F, scale);
+    SQD_CHECK_LAUNCH("sqd_ffn_fwd");
+    return SQD_OK;
+}
+
+// backward: g_y -> gxpart [G][rows,E] (g_x = sum over G) and per-token-tile partials (T = sqd_ffn_tiles(rows)):
+// pW1 [T][F,E], pW2T [T][F,E] (g_W2 transposed), pb1 [T][F], pb2 [T][E]; column-sum them with sqd_colsum_multi (tr = E for pW2T)
+extern "C" int sqd_ffn_tiles(int rows) { return (rows + 31) / 32; }
+extern "C" int sqd_ffn_bwd(const float *x, const float *g_y, const float *W1, const float *b1, const float *W2,
+                           const unsigned char *mask, float *gxpart, float *pW1, float *pb1, float *pW2T, float *pb2, int rows, int E,
+                           int F, float scale, void *stream) {
+    SQD_CHECK_ARG(x && g_y && W1 && b1 && W2 && gxpart && pW1 && pb1 && pW2T && pb2, "sqd_ffn_bwd: null pointer");
+    SQD_CHECK_ARG(rows > 0 && sqd_vit_supported(E, F), "sqd_ffn_bwd: unsupported dims rows=%d E=%d F=%d", rows, E, F);
+    SQD_CHECK_ARG(((uintptr_t)mask & 3) == 0, "sqd_ffn_bwd: mask must be 4-byte aligned");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(ffn_bwd_kernel, dim3(sqd_ffn_tiles(rows), sqd_ffn_groups(F)), dim3(256), 0, (hipStream_t)stream, x, g_y, W1, b1, W2, mask,
+                       gxpart, pW1, pb1, pW2T, pb2, rows, E, F, scale);
+    SQD_CHECK_LAUNCH("sqd_ffn_bwd");
+    return SQD_OK;
+}

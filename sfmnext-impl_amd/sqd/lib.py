@@ -119,6 +119,15 @@ _SIGNATURES = {
     "sqd_bins_workspace": (_I, [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64)]),
     "sqd_bins_fwd": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "sqd_bins_bwd": (_I, [_P] * 10 + [_I] * 4 + [_P]),
+    "sqd_vit_supported": (_I, [_I, _I]),
+    "sqd_addln_fwd": (_I, [_P, _P, _I] + [_P] * 7 + [_I, _I, _F, _F, _P]),
+    "sqd_addln_nblk": (_I, [_I]),
+    "sqd_addln_bwd": (_I, [_P, _P, _I] + [_P] * 7 + [_I, _I, _F, _P]),
+    "sqd_ffn_groups": (_I, [_I]),
+    "sqd_ffn_tiles": (_I, [_I]),
+    "sqd_ffn_fwd": (_I, [_P] * 6 + [_I, _I, _I, _F, _P]),
+    "sqd_ffn_bwd": (_I, [_P] * 11 + [_I, _I, _I, _F, _P]),
+    "sqd_colsum_multi": (_I, [_P] * 5 + [_I, _P]),
     "sqd_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sqd_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sqd_space_to_depth2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

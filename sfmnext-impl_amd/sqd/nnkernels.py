@@ -432,3 +432,185 @@ def batch_norm_act(x, bn, act, residual=None, pre_part=None, pre_rows=0):
     return BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, training,
                               0.1 if bn.momentum is None else bn.momentum, bn.eps, act, pre_part if training else None,
                               pre_rows if training else 0)
+
+
+# ---------------------------------------------------------------------------------------------------
+# token-wise blocks of the patch-token TransformerEncoderLayer (csrc/vit.hip)
+# ---------------------------------------------------------------------------------------------------
+def _colsum_multi(segs):
+    """segs: [(src [nrows, ncols] partials, dst, tr)] -> one launch of fixed-order column sums."""
+    n = len(segs)
+    PA, IA = ctypes.c_void_p * n, ctypes.c_int * n
+    src = PA(*[t[0].data_ptr() for t in segs])
+    dst = PA(*[t[1].data_ptr() for t in segs])
+    nrows = IA(*[t[0].shape[0] for t in segs])
+    ncols = IA(*[t[0].numel() // t[0].shape[0] for t in segs])
+    tr = IA(*[t[2] for t in segs])
+    _l.check(_l.lib().sqd_colsum_multi(src, dst, nrows, ncols, tr, n, _stream()), "colsum_multi")
+
+
+def _addln_fwd(x, y, nparts, ybias, mask, gamma, beta, scale, eps):
+    E = x.shape[-1]
+    rows = x.numel() // E
+    out, xhat = torch.empty_like(x), torch.empty_like(x)
+    rstd = torch.empty(rows, device=x.device, dtype=torch.float32)
+    _l.check(_l.lib().sqd_addln_fwd(_ptr(x), _ptr(y), nparts, _ptr(ybias), _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(xhat),
+                                    _ptr(rstd), rows, E, float(scale), float(eps), _stream()), "addln_fwd")
+    return out, xhat, rstd
+
+
+def _addln_bwd(g, g_extra, nextra, xhat, rstd, mask, gamma, scale):
+    """-> g_x, g_y, part [nblk, 2E] (partials of g_gamma | g_beta)"""
+    E = xhat.shape[-1]
+    rows = xhat.numel() // E
+    L = _l.lib()
+    gx, gy = torch.empty_like(xhat), torch.empty_like(xhat)
+    part = torch.empty(L.sqd_addln_nblk(rows), 2 * E, device=g.device, dtype=torch.float32)
+    _l.check(L.sqd_addln_bwd(_ptr(g), _ptr(g_extra), nextra, _ptr(xhat), _ptr(rstd), _ptr(mask), _ptr(gamma), _ptr(gx), _ptr(gy),
+                             _ptr(part), rows, E, float(scale), _stream()), "addln_bwd")
+    return gx, gy, part
+
+
+def _ffn_fwd(x, W1, b1, W2, mask, scale):
+    """-> ypart [G, rows, E] (partials over the hidden groups, without b2)"""
+    E, Fh = x.shape[-1], W1.shape[0]
+    rows = x.numel() // E
+    L = _l.lib()
+    ypart = torch.empty(L.sqd_ffn_groups(Fh), rows, E, device=x.device, dtype=torch.float32)
+    _l.check(L.sqd_ffn_fwd(_ptr(x), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(mask), _ptr(ypart), rows, E, Fh, float(scale), _stream()), "ffn_fwd")
+    return ypart
+
+
+def _ffn_bwd(x, gy, W1, b1, W2, mask, scale):
+    """-> gxpart [G, rows, E], pW1 [T, F*E], pb1 [T, F], pW2T [T, F*E], pb2 [T, E]"""
+    E, Fh = x.shape[-1], W1.shape[0]
+    rows = x.numel() // E
+    L = _l.lib()
+    T, G = L.sqd_ffn_tiles(rows), L.sqd_ffn_groups(Fh)
+    buf = torch.empty(G * rows * E + T * (2 * Fh * E + Fh + E), device=x.device, dtype=torch.float32)
+    sizes = [G * rows * E, T * Fh * E, T * Fh, T * Fh * E, T * E]
+    gxpart, pW1, pb1, pW2T, pb2 = torch.split(buf, sizes)
+    _l.check(L.sqd_ffn_bwd(_ptr(x), _ptr(gy), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(mask), _ptr(gxpart), _ptr(pW1), _ptr(pb1), _ptr(pW2T),
+                           _ptr(pb2), rows, E, Fh, float(scale), _stream()), "ffn_bwd")
+    return gxpart.view(G, rows, E), pW1.view(T, Fh * E), pb1.view(T, Fh), pW2T.view(T, Fh * E), pb2.view(T, E)
+
+
+class AddDropLayerNorm(torch.autograd.Function):
+    """LayerNorm(x + dropout(y)) — norm1(x + dropout1(sa)) / norm2(x + dropout2(ff)) of the post-norm encoder layer
+    (reference networks/depth_decoder_QTR.py:31-32 builds nn.TransformerEncoderLayer with its defaults).
+    mask: uint8 keep-mask shaped like y, or None.  (Stand-alone node; the training path uses EncoderTail.)"""
+
+    @staticmethod
+    def forward(ctx, x, y, mask, gamma, beta, scale, eps):
+        x, y = x.contiguous(), y.contiguous()
+        _require(x, "addln x"), _require(y, "addln y")
+        out, xhat, rstd = _addln_fwd(x, y, 1, None, mask, gamma, beta, scale, eps)
+        ctx.save_for_backward(xhat, rstd, gamma)
+        ctx.mask, ctx.scale = mask, float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xhat, rstd, gamma = ctx.saved_tensors
+        gx, gy, part = _addln_bwd(g.contiguous(), None, 0, xhat, rstd, ctx.mask, gamma, ctx.scale)
+        gg = torch.empty(2, gamma.numel(), device=g.device, dtype=torch.float32)
+        _colsum_multi([(part, gg, 0)])
+        return gx, gy, None, gg[0], gg[1], None, None
+
+
+class FeedForward(torch.autograd.Function):
+    """linear2(dropout(relu(linear1(x)))) of the encoder layer; the [rows, F] hidden activations stay in registers
+    (the backward recomputes them).  mask: uint8 keep-mask [rows, F] or None.  (Stand-alone node; the training path uses
+    EncoderTail, which hands the group partials straight to the LayerNorm kernels.)"""
+
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, mask, scale):
+        x = x.contiguous()
+        _require(x, "ffn x")
+        y = _ffn_fwd(x, W1, b1, W2, mask, scale).sum(0).view_as(x) + b2
+        ctx.save_for_backward(x, W1, b1, W2)
+        ctx.mask, ctx.scale = mask, float(scale)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, W1, b1, W2 = ctx.saved_tensors
+        gxpart, pW1, pb1, pW2T, pb2 = _ffn_bwd(x, g.contiguous(), W1, b1, W2, ctx.mask, ctx.scale)
+        gW1, gb1, gW2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2)
+        gb2 = torch.empty(x.shape[-1], device=g.device, dtype=torch.float32)
+        _colsum_multi([(pW1, gW1, 0), (pW2T, gW2, x.shape[-1]), (pb1, gb1, 0), (pb2, gb2, 0)])
+        return gxpart.sum(0).view_as(x), gW1, gb1, gW2, gb2, None, None
+
+
+class EncoderTail(torch.autograd.Function):
+    """Everything of the post-norm encoder layer after self-attention, as one autograd node:
+        x1  = norm1(x + dropout1(sa))
+        out = norm2(x1 + dropout2(linear2(dropout(relu(linear1(x1))))))
+    3 launches forward, 4 backward (ATen: ~45)."""
+
+    @staticmethod
+    def forward(ctx, x, sa, m1, mf, m2, g1, be1, W1, b1, W2, b2, g2, be2, scale, eps1, eps2):
+        x, sa = x.contiguous(), sa.contiguous()
+        _require(x, "encoder tokens"), _require(sa, "attention output")
+        x1, xhat1, rstd1 = _addln_fwd(x, sa, 1, None, m1, g1, be1, scale, eps1)
+        ypart = _ffn_fwd(x1, W1, b1, W2, mf, scale)
+        out, xhat2, rstd2 = _addln_fwd(x1, ypart, ypart.shape[0], b2, m2, g2, be2, scale, eps2)
+        ctx.save_for_backward(xhat1, rstd1, x1, xhat2, rstd2, g1, W1, b1, W2, g2)
+        ctx.masks, ctx.scale = (m1, mf, m2), float(scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        xhat1, rstd1, x1, xhat2, rstd2, g1, W1, b1, W2, g2 = ctx.saved_tensors
+        m1, mf, m2 = ctx.masks
+        E = x1.shape[-1]
+        dz2, gy2, part2 = _addln_bwd(g.contiguous(), None, 0, xhat2, rstd2, m2, g2, ctx.scale)
+        gxpart, pW1, pb1, pW2T, pb2 = _ffn_bwd(x1, gy2, W1, b1, W2, mf, ctx.scale)
+        gx, gsa, part1 = _addln_bwd(dz2, gxpart, gxpart.shape[0], xhat1, rstd1, m1, g1, ctx.scale)
+        gW1, gb1, gW2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2)
+        small = torch.empty(5, E, device=g.device, dtype=torch.float32)     # g_b2 | g_gamma2, g_beta2 | g_gamma1, g_beta1
+        _colsum_multi([(pW1, gW1, 0), (pW2T, gW2, E), (pb1, gb1, 0), (pb2, small[0], 0), (part2, small[1:3], 0), (part1, small[3:5], 0)])
+        return gx, gsa, None, None, None, small[3], small[4], gW1, gb1, gW2, small[0], small[1], small[2], None, None, None
+
+
+def encoder_supported(encoder):
+    """nn.TransformerEncoder as the depth head builds it: post-norm layers, ReLU, no final norm, fp32 dense weights."""
+    import torch.nn.functional as F
+    if getattr(encoder, "norm", None) is not None:
+        return False
+    for layer in encoder.layers:
+        W1, W2 = layer.linear1.weight, layer.linear2.weight
+        if layer.norm_first or layer.activation is not F.relu or layer.linear1.bias is None or layer.linear2.bias is None:
+            return False
+        if not _l.lib().sqd_vit_supported(W1.shape[1], W1.shape[0]) or not (W1.is_contiguous() and W2.is_contiguous()):
+            return False
+        if layer.norm1.weight is None or layer.norm1.bias is None or getattr(layer.self_attn, "batch_first", False):
+            return False
+    return True
+
+
+def transformer_encoder_native(tokens, encoder):
+    """tokens [S,B,E] through the encoder: self-attention stays with torch (in/out projections on rocBLAS, attention core on
+    its fused kernel); everything after it runs as EncoderTail.  One bernoulli launch draws every dropout mask of the pass."""
+    x = tokens.contiguous()
+    S, B, E = x.shape
+    rows = S * B
+    layers = list(encoder.layers)
+    masks, scale = None, 1.0
+    if encoder.training:
+        ps = {p for l in layers for p in (l.dropout1.p, l.dropout.p, l.dropout2.p)}
+        if ps != {0.0}:
+            if len(ps) != 1:
+                raise RuntimeError("sqd: encoder layers with different dropout rates are not supported")
+            p0 = ps.pop()
+            per_layer = [(rows * E, rows * l.linear1.weight.shape[0], rows * E) for l in layers]
+            keep = torch.empty(sum(sum(t) for t in per_layer), device=x.device, dtype=torch.uint8).bernoulli_(1.0 - p0)
+            masks = [torch.split(c, list(t)) for c, t in zip(torch.split(keep, [sum(t) for t in per_layer]), per_layer)]
+            scale = 1.0 / (1.0 - p0)
+    for li, layer in enumerate(layers):
+        m1, mf, m2 = masks[li] if masks is not None else (None, None, None)
+        sa = layer.self_attn(x, x, x, need_weights=False)[0]
+        x = EncoderTail.apply(x, sa, m1, mf, m2, layer.norm1.weight, layer.norm1.bias, layer.linear1.weight, layer.linear1.bias,
+                              layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias, scale,
+                              layer.norm1.eps, layer.norm2.eps)
+    return x

@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 BACKEND = {
     "conv2d": "aten", "conv_bn_act": "aten conv + hip bn/act/residual", "maxpool3x3s2": "hip", "upsample_concat": "hip",
-    "linear": "aten", "transformer_encoder": "aten", "full_query_layer": "hip", "bins_head": "hip",
+    "linear": "aten", "transformer_encoder": "hip feed-forward + add/dropout/layernorm; aten self-attention", "full_query_layer": "hip", "bins_head": "hip",
 }
 
 
@@ -34,6 +34,8 @@ import os
 STEM_S2D = not os.environ.get("SQD_STEM_ATEN")
 # BatchNorm statistics partials from the producing convolution's epilogue (SQD_NO_CONV_BN_STATS=1: BatchNorm's own pass, A/B runs)
 CONV_BN_STATS = not os.environ.get("SQD_NO_CONV_BN_STATS")
+# feed-forward and add+dropout+LayerNorm of the patch-token encoder as fused kernels (SQD_VIT_ATEN=1: nn.TransformerEncoder, A/B runs)
+NATIVE_VIT = not os.environ.get("SQD_VIT_ATEN")
 NATIVE_CONV = False          # set by the Trainer (default on; --sqd_aten_conv is the A/B switch back to ATen/MIOpen)
 
 
@@ -137,6 +139,10 @@ def linear(x, lin, act=None):
 
 def transformer_encoder(tokens, encoder):
     """tokens [T,B,E] through nn.TransformerEncoder (4 post-norm layers, ReLU feed-forward)."""
+    if tokens.is_cuda and NATIVE_VIT:
+        from . import nnkernels
+        if nnkernels.encoder_supported(encoder):
+            return nnkernels.transformer_encoder_native(tokens, encoder)
     return encoder(tokens)
 
 

@@ -1,0 +1,182 @@
+"""GPU parity of the patch-token encoder blocks (csrc/vit.hip) against the torch modules the reference runs
+(networks/depth_decoder_QTR.py:31-32,47: nn.TransformerEncoderLayer defaults — post-norm, ReLU, dropout 0.1):
+add+dropout+LayerNorm, the feed-forward, and the whole 4-layer encoder.  fp64 CPU references; tolerance 1e-4 relative
+to the tensor's scale (north_star's fp32 bar)."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _close(a, b, what, tol=TOL):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    err = (a - b).abs().max().item()
+    scale = max(b.abs().max().item(), 1e-6)
+    assert err <= tol * scale, "%s: max err %.3e vs scale %.3e" % (what, err, scale)
+
+
+def _kink_free(mask, pre, big):
+    """ReLU has a kink at 0: a hidden pre-activation within fp32 rounding of 0 takes different branches in the fp32 kernel and
+    the fp64 reference (seen: one unit of 1.5 M at -2.4e-9, moving g_x of its token by 5e-3).  Those units are dropped through
+    the keep-mask, which is an input of the node (big cases get an all-ones mask with scale 1 when dropout is off)."""
+    near = pre.detach().abs() < 1e-5
+    if mask is None:
+        if not big:
+            assert not near.any()
+            return None
+        mask = torch.ones(pre.shape, dtype=torch.uint8)
+    return (mask.view(pre.shape) * (~near).to(torch.uint8)).reshape(mask.shape)
+
+
+@pytest.mark.parametrize("rows,E,drop", [(1440, 32, True), (1440, 32, False), (77, 16, True), (8, 32, False), (1, 16, True)])
+def test_add_dropout_layernorm(rows, E, drop):
+    from sqd import nnkernels
+    g = torch.Generator().manual_seed(rows + E)
+    x, y = torch.randn(rows, E, generator=g), 2.0 * torch.randn(rows, E, generator=g) + 0.5
+    gamma, beta = 1.0 + 0.2 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)
+    gout = torch.randn(rows, E, generator=g)
+    mask = (torch.rand(rows, E, generator=g) < 0.9).to(torch.uint8) if drop else None
+    scale = 1.0 / 0.9 if drop else 1.0
+    ref_in = [t.clone().double().requires_grad_(True) for t in (x, y, gamma, beta)]
+    yy = ref_in[1] * mask.double() * scale if drop else ref_in[1]
+    ref = F.layer_norm(ref_in[0] + yy, (E,), ref_in[2], ref_in[3], 1e-5)
+    ref.backward(gout.double())
+    dev = [t.clone().cuda().requires_grad_(True) for t in (x, y, gamma, beta)]
+    out = nnkernels.AddDropLayerNorm.apply(dev[0], dev[1], mask.cuda() if drop else None, dev[2], dev[3], scale, 1e-5)
+    out.backward(gout.cuda())
+    _close(out, ref, "out")
+    for name, d, r in zip(("g_x", "g_y", "g_gamma", "g_beta"), dev, ref_in):
+        _close(d.grad, r.grad, name)
+
+
+@pytest.mark.parametrize("rows,E,Fh,drop", [(1440, 32, 1024, True), (1440, 32, 1024, False), (1440, 16, 512, True),
+                                            (77, 32, 36, True), (33, 16, 100, False), (5, 32, 4096, True)])
+def test_feed_forward(rows, E, Fh, drop):
+    from sqd import nnkernels
+    g = torch.Generator().manual_seed(rows + E + Fh)
+    x = torch.randn(rows, E, generator=g)
+    W1, b1 = torch.randn(Fh, E, generator=g) / E ** 0.5, 0.1 * torch.randn(Fh, generator=g)
+    W2, b2 = torch.randn(E, Fh, generator=g) / Fh ** 0.5, 0.1 * torch.randn(E, generator=g)
+    gout = torch.randn(rows, E, generator=g)
+    mask = (torch.rand(rows, Fh, generator=g) < 0.9).to(torch.uint8) if drop else None
+    scale = 1.0 / 0.9 if drop else 1.0
+    ref_in = [t.clone().double().requires_grad_(True) for t in (x, W1, b1, W2, b2)]
+    pre = F.linear(ref_in[0], ref_in[1], ref_in[2])
+    mask = _kink_free(mask, pre, rows * Fh > 100000)
+    h = F.relu(pre)
+    if mask is not None:
+        h = h * mask.double() * scale
+    ref = F.linear(h, ref_in[3], ref_in[4])
+    ref.backward(gout.double())
+    dev = [t.clone().cuda().requires_grad_(True) for t in (x, W1, b1, W2, b2)]
+    drop = mask is not None
+    out = nnkernels.FeedForward.apply(*dev, mask.cuda() if drop else None, scale)
+    out.backward(gout.cuda())
+    _close(out, ref, "y")
+    for name, d, r in zip(("g_x", "g_W1", "g_b1", "g_W2", "g_b2"), dev, ref_in):
+        _close(d.grad, r.grad, name)
+    # deterministic: fixed-order partial sums
+    dev2 = [t.clone().cuda().requires_grad_(True) for t in (x, W1, b1, W2, b2)]
+    nnkernels.FeedForward.apply(*dev2, mask.cuda() if drop else None, scale).backward(gout.cuda())
+    for d, d2 in zip(dev, dev2):
+        assert torch.equal(d.grad, d2.grad)
+
+
+@pytest.mark.parametrize("rows,E,Fh,drop", [(1440, 32, 1024, True), (1440, 16, 512, True), (77, 32, 100, True), (40, 16, 36, False)])
+def test_encoder_tail(rows, E, Fh, drop):
+    """the fused post-attention node (norm1, feed-forward, norm2) with given dropout masks against the fp64 composite"""
+    from sqd import nnkernels
+    g = torch.Generator().manual_seed(rows * 3 + E + Fh)
+    x, sa = torch.randn(rows, E, generator=g), torch.randn(rows, E, generator=g)
+    prm = [1.0 + 0.2 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g),
+           torch.randn(Fh, E, generator=g) / E ** 0.5, 0.1 * torch.randn(Fh, generator=g),
+           torch.randn(E, Fh, generator=g) / Fh ** 0.5, 0.1 * torch.randn(E, generator=g),
+           1.0 + 0.2 * torch.randn(E, generator=g), 0.1 * torch.randn(E, generator=g)]
+    gout = torch.randn(rows, E, generator=g)
+    if drop:
+        keep = (torch.rand(rows * (2 * E + Fh), generator=g) < 0.9).to(torch.uint8)
+        m1, mf, m2 = torch.split(keep, [rows * E, rows * Fh, rows * E])
+        scale = 1.0 / 0.9
+    else:
+        m1 = mf = m2 = None
+        scale = 1.0
+    dm = lambda m, shape: m.view(shape).double() * scale if m is not None else 1.0
+    ref_in = [t.clone().double().requires_grad_(True) for t in [x, sa] + prm]
+    rx, rsa, g1, be1, W1, b1, W2, b2, g2, be2 = ref_in
+    x1 = F.layer_norm(rx + rsa * dm(m1, (rows, E)), (E,), g1, be1, 1e-5)
+    pre = F.linear(x1, W1, b1)
+    mf = _kink_free(mf, pre, False)
+    if drop:
+        keep = torch.cat([m1, mf, m2])
+    ff = F.linear(F.relu(pre) * dm(mf, (rows, Fh)), W2, b2)
+    ref = F.layer_norm(x1 + ff * dm(m2, (rows, E)), (E,), g2, be2, 1e-5)
+    ref.backward(gout.double())
+    dev = [t.clone().cuda().requires_grad_(True) for t in [x, sa] + prm]
+    if drop:
+        keep_d = keep.cuda()
+        m1, mf, m2 = torch.split(keep_d, [rows * E, rows * Fh, rows * E])
+    out = nnkernels.EncoderTail.apply(dev[0], dev[1], m1, mf, m2, *dev[2:], scale, 1e-5, 1e-5)
+    out.backward(gout.cuda())
+    _close(out, ref, "out")
+    names = ("g_x", "g_sa", "g_gamma1", "g_beta1", "g_W1", "g_b1", "g_W2", "g_b2", "g_gamma2", "g_beta2")
+    for name, d, r in zip(names, dev, ref_in):
+        _close(d.grad, r.grad, name, 2e-4)
+
+
+def _encoder(E, Fh, p, seed):
+    torch.manual_seed(seed)
+    layer = nn.TransformerEncoderLayer(E, 4, dim_feedforward=Fh, dropout=p)
+    enc = nn.TransformerEncoder(layer, num_layers=4)
+    for q in enc.parameters():                                  # biases and LayerNorm affine away from their 0 / 1 initial values
+        if q.dim() == 1:
+            q.data.add_(0.1 * torch.randn_like(q))
+    return enc
+
+
+@pytest.mark.parametrize("S,B,E,Fh", [(120, 12, 32, 1024), (120, 2, 16, 512), (15, 3, 32, 1024)])
+def test_encoder_matches_torch(S, B, E, Fh):
+    """dropout 0 in training mode: outputs and every parameter gradient against nn.TransformerEncoder in fp64 on the CPU."""
+    from sqd import nnkernels, nnops
+    enc = _encoder(E, Fh, 0.0, S + B)
+    tokens = torch.randn(S, B, E)
+    gout = torch.randn(S, B, E)
+    ref_enc = _encoder(E, Fh, 0.0, S + B).double()
+    ref_enc.load_state_dict({k: v.double() for k, v in enc.state_dict().items()})
+    tr = tokens.double().requires_grad_(True)
+    ref = ref_enc(tr)
+    ref.backward(gout.double())
+    enc = enc.cuda()
+    assert nnkernels.encoder_supported(enc)
+    td = tokens.cuda().requires_grad_(True)
+    out = nnops.transformer_encoder(td, enc)
+    out.backward(gout.cuda())
+    _close(out, ref, "tokens out", 2e-4)
+    _close(td.grad, tr.grad, "g_tokens", 2e-4)
+    for (name, q), r in zip(enc.named_parameters(), ref_enc.parameters()):
+        _close(q.grad, r.grad, name, 2e-4)
+
+
+def test_encoder_dropout_statistics():
+    """training mode, p = 0.1: masks are fresh per call, keep ~90 %, and eval mode is dropout-free and deterministic."""
+    from sqd import nnops
+    enc = _encoder(32, 1024, 0.1, 7).cuda()
+    x = torch.randn(120, 12, 32, device="cuda")
+    enc.train()
+    a, b = nnops.transformer_encoder(x, enc), nnops.transformer_encoder(x, enc)
+    assert not torch.equal(a, b)
+    keep = torch.empty(1 << 20, device="cuda", dtype=torch.uint8).bernoulli_(0.9)
+    assert abs(keep.float().mean().item() - 0.9) < 5e-3 and int(keep.max()) == 1
+    enc.eval()
+    with torch.no_grad():
+        c, d = nnops.transformer_encoder(x, enc), nnops.transformer_encoder(x, enc)
+        ref = enc(x)
+    assert torch.equal(c, d)
+    _close(c, ref, "eval output", 2e-4)
+    # the training-mode mean over many draws approaches the eval output's neighbourhood (inverted dropout is unbiased to first order)
+    enc.train()
+    with torch.no_grad():
+        acc = sum(nnops.transformer_encoder(x, enc) for _ in range(32)) / 32
+    assert (acc - c).abs().mean().item() < 0.25 * c.abs().mean().item() + 0.05
