@@ -294,7 +294,7 @@ int sqd_stem_regroup(const float *src, float *dst, int K, int C, int Cp, int adj
  *   sqd_ffn_bwd:   g_y -> gxpart [G][rows,E] (g_x = sum over G; sqd_addln_bwd's g_extra) and per-token-tile partials,
  *                  T = sqd_ffn_tiles(rows): pW1 [T][F,E], pW2T [T][F,E] (g_W2 transposed), pb1 [T][F], pb2 [T][E].
  *                  Hidden activations are recomputed.
- *   sqd_colsum_multi: up to 8 column sums in one launch: dst[s][c] = sum_{r<nrows[s]} src[s][r*ncols[s] + c], ncols % 4 == 0;
+ *   sqd_colsum_multi: up to 12 column sums in one launch: dst[s][c] = sum_{r<nrows[s]} src[s][r*ncols[s] + c], ncols % 4 == 0;
  *                  tr[s] > 0 writes the [ncols/tr][tr] result transposed (pW2T -> g_W2 with tr = E).  The arrays are host arrays.
  * fp32 MFMA (v_mfma_f32_32x32x2_f32); deterministic (fixed-order partial sums). */
 int sqd_vit_supported(int E, int F);
@@ -312,6 +312,23 @@ int sqd_ffn_bwd(const float *x, const float *g_y, const float *W1, const float *
                 float *gxpart, float *pW1, float *pb1, float *pW2T, float *pb2, int rows, int E, int F, float scale, void *stream);
 int sqd_colsum_multi(const float *const *src, float *const *dst, const int *nrows, const int *ncols, const int *tr, int nseg,
                      void *stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * (14) multi-head self-attention of the encoder layer for short sequences.  replaces: nn.MultiheadAttention (packed in_proj,
+ * batch_first = False, need_weights = False) inside the nn.TransformerEncoderLayer of reference
+ * networks/depth_decoder_QTR.py:31-32 — in-projection, softmax(q k^T / sqrt(hd)), attention dropout, P v, out-projection.
+ * S <= 128 tokens, E in {16,32}, head dimension E/H in {4,8}.  x [S*B,E], token (s,b) = row s*B+b; Win [3E,E], bin [3E],
+ * Wo [E,E]; mask: keep bytes [B][H][S][SP], SP = S rounded up to 4 (4-byte aligned), or NULL; dscale = 1/(1-p).
+ *   fwd: ypart [H][S*B,E] per-head partials of the block's output without the out-projection bias (the consumer,
+ *        sqd_addln_fwd with nparts = H and ybias = out_proj.bias, adds them); o_save [B][H][S][E/H], ml_save [B][H][S][2]
+ *   bwd: g_sa [S*B,E] -> gxpart [H][S*B,E] (g_x = sum over heads) and per-batch-element partials pWin [B][3E,E], pbin [B][3E],
+ *        pWo [B][E,E], pbo [B][E] for sqd_colsum_multi.  Deterministic. */
+int sqd_mha_supported(int S, int E, int H);
+int sqd_mha_fwd(const float *x, const float *Win, const float *bin, const float *Wo, const unsigned char *mask, float *ypart,
+                float *o_save, float *ml_save, int S, int B, int E, int H, float dscale, void *stream);
+int sqd_mha_bwd(const float *x, const float *g_sa, const float *Win, const float *bin, const float *Wo, const unsigned char *mask,
+                const float *o_save, const float *ml_save, float *gxpart, float *pWin, float *pbin, float *pWo, float *pbo, int S,
+                int B, int E, int H, float dscale, void *stream);
 
 #ifdef __cplusplus
 }

@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256) void addln_bwd_kernel(const float *__restrict_
 // tr > 0: the columns are a [ncols / tr][tr] matrix written transposed ([tr][ncols / tr]).
 // block = 32 float4 columns x 8 row groups.
 // ---------------------------------------------------------------------------------------------------
-constexpr int CS_MAXSEG = 8;
+constexpr int CS_MAXSEG = 12;
 struct ColsumSegs {
     const float *src[CS_MAXSEG];
     float *dst[CS_MAXSEG];
@@ -411,7 +411,7 @@ extern "C" int sqd_addln_bwd(const float *g_out, const float *g_extra, int nextr
     return SQD_OK;
 }
 
-// ---- nseg <= 8 column sums in one launch: dst[s][c] = sum_{r < nrows[s]} src[s][r * ncols[s] + c]; ncols % 4 == 0;
+// ---- nseg <= 12 column sums in one launch: dst[s][c] = sum_{r < nrows[s]} src[s][r * ncols[s] + c]; ncols % 4 == 0;
 // tr[s] > 0: write the [ncols/tr][tr] result transposed
 extern "C" int sqd_colsum_multi(const float *const *src, float *const *dst, const int *nrows, const int *ncols, const int *tr, int nseg,
                                 void *stream) {
@@ -462,5 +462,316 @@ extern "C" int sqd_ffn_bwd(const float *x, const float *g_y, const float *W1, co
     hipLaunchKernelGGL(ffn_bwd_kernel, dim3(sqd_ffn_tiles(rows), sqd_ffn_groups(F)), dim3(256), 0, (hipStream_t)stream, x, g_y, W1, b1, W2, mask,
                        gxpart, pW1, pb1, pW2T, pb2, rows, E, F, scale);
     SQD_CHECK_LAUNCH("sqd_ffn_bwd");
+    return SQD_OK;
+}
+
+// ===================================================================================================
+// multi-head self-attention of the encoder layer (nn.MultiheadAttention, packed in_proj, batch_first = False) for short token
+// sequences: S <= 128 tokens, head dimension HD in {4, 8}.  One workgroup per (batch element, head), one thread per token;
+// the whole head (projections, S x S scores, softmax, attention dropout, P.V, its slice of the out-projection) is VALU
+// work on operands broadcast from LDS — 120 x 120 x 8 per head is far too small for the matrix cores to matter; what
+// counts is that it is ONE launch with no intermediate tensors instead of ~8 (forward) / ~20 (backward).
+// The out-projection is left as per-head partials ypart [H][rows,E] (+ bias added by the consumer, sqd_addln_fwd), the
+// input gradient as per-head partials gxpart [H][rows,E]; weight gradients as per-batch-element partials for sqd_colsum_multi.
+// Token (s, b) is row s*B + b.  Keep-mask of the attention dropout: bytes [B][H][S][SP], SP = S rounded up to 4.
+// ===================================================================================================
+namespace {
+constexpr int MHA_T = 128;
+
+template <int HD, int EE>
+__device__ __forceinline__ void mha_project(const float (&xr)[EE], const float *__restrict__ Win, const float *__restrict__ bin, int h,
+                                            float qscale, float (&q)[HD], float (&k)[HD], float (&v)[HD]) {
+#pragma unroll
+    for (int j = 0; j < HD; ++j) {
+        const float *wq = Win + (size_t)(h * HD + j) * EE, *wk = wq + (size_t)EE * EE, *wv = wk + (size_t)EE * EE;
+        float aq = bin[h * HD + j], ak = bin[EE + h * HD + j], av = bin[2 * EE + h * HD + j];
+#pragma unroll
+        for (int e = 0; e < EE; ++e) {
+            aq = fmaf(xr[e], wq[e], aq);
+            ak = fmaf(xr[e], wk[e], ak);
+            av = fmaf(xr[e], wv[e], av);
+        }
+        q[j] = aq * qscale; k[j] = ak; v[j] = av;
+    }
+}
+
+template <int HD, int EE>
+__global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict__ x, const float *__restrict__ Win,
+                                                        const float *__restrict__ bin, const float *__restrict__ Wo,
+                                                        const unsigned char *__restrict__ mask, float *__restrict__ ypart,
+                                                        float *__restrict__ o_save, float *__restrict__ ml_save, int S, int B, int H,
+                                                        float qscale, float dscale) {
+    __shared__ float Ks[MHA_T][HD], Vs[MHA_T][HD];
+    const int b = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
+    const bool tv = t < S;
+    const int SP = (S + 3) & ~3;
+    const size_t row = (size_t)t * B + b;
+    float xr[EE];
+#pragma unroll
+    for (int e = 0; e < EE; e += 4) {
+        const float4 v4 = tv ? *reinterpret_cast<const float4 *>(x + row * EE + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xr[e] = v4.x; xr[e + 1] = v4.y; xr[e + 2] = v4.z; xr[e + 3] = v4.w;
+    }
+    float q[HD], k[HD], v[HD];
+    mha_project<HD, EE>(xr, Win, bin, h, qscale, q, k, v);
+#pragma unroll
+    for (int d = 0; d < HD; ++d) { Ks[t][d] = k[d]; Vs[t][d] = v[d]; }
+    __syncthreads();
+    float m = -INFINITY;
+    for (int kk = 0; kk < S; ++kk) {
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[kk][d], s);
+        m = fmaxf(m, s);
+    }
+    float l = 0.f, o[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = 0.f;
+    const unsigned char *mrow = mask ? mask + (((size_t)b * H + h) * S + (tv ? t : 0)) * SP : nullptr;
+    for (int k4 = 0; k4 < SP; k4 += 4) {
+        const unsigned mw = mrow ? *reinterpret_cast<const unsigned *>(mrow + k4) : 0x01010101u;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int kk = k4 + j;
+            if (kk < S) {
+                float s = 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[kk][d], s);
+                const float p = __expf(s - m);
+                l += p;
+                const float pd = ((mw >> (8 * j)) & 0xffu) ? p * dscale : 0.f;
+#pragma unroll
+                for (int d = 0; d < HD; ++d) o[d] = fmaf(pd, Vs[kk][d], o[d]);
+            }
+        }
+    }
+    if (!tv) return;
+    const float rl = 1.f / l;
+    const size_t hs = ((size_t)b * H + h) * S + t;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        o[d] *= rl;
+        o_save[hs * HD + d] = o[d];
+    }
+    ml_save[hs * 2] = m;
+    ml_save[hs * 2 + 1] = l;
+    float *yo = ypart + ((size_t)h * S * B + row) * EE;
+#pragma unroll
+    for (int e = 0; e < EE; e += 4) {
+        float y4[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const float *wo = Wo + (size_t)(e + c) * EE + h * HD;
+            float a = 0.f;
+#pragma unroll
+            for (int d = 0; d < HD; ++d) a = fmaf(o[d], wo[d], a);
+            y4[c] = a;
+        }
+        *reinterpret_cast<float4 *>(yo + e) = make_float4(y4[0], y4[1], y4[2], y4[3]);
+    }
+}
+
+template <int HD, int EE>
+__global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gsa,
+                                                        const float *__restrict__ Win, const float *__restrict__ bin,
+                                                        const float *__restrict__ Wo, const unsigned char *__restrict__ mask,
+                                                        const float *__restrict__ o_save, const float *__restrict__ ml_save,
+                                                        float *__restrict__ gxpart, float *__restrict__ pWin, float *__restrict__ pbin,
+                                                        float *__restrict__ pWo, float *__restrict__ pbo, int S, int B, int H,
+                                                        float qscale, float dscale) {
+    __shared__ float xs[MHA_T][EE + 1], gs[MHA_T][EE + 1];
+    __shared__ float qkvd[4][MHA_T][HD];                  // Q (scaled), K, V, dO; later aliased by dqkv [MHA_T][3*HD]
+    __shared__ float os[MHA_T][HD];
+    __shared__ float st[3][MHA_T];                        // m, 1/l, D
+    const int b = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
+    const bool tv = t < S;
+    const int SP = (S + 3) & ~3;
+    const size_t row = (size_t)t * B + b, hs = ((size_t)b * H + h) * S + t;
+    float xr[EE], gr[EE];
+#pragma unroll
+    for (int e = 0; e < EE; e += 4) {
+        const float4 a = tv ? *reinterpret_cast<const float4 *>(x + row * EE + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 g = tv ? *reinterpret_cast<const float4 *>(gsa + row * EE + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+        xr[e] = a.x; xr[e + 1] = a.y; xr[e + 2] = a.z; xr[e + 3] = a.w;
+        gr[e] = g.x; gr[e + 1] = g.y; gr[e + 2] = g.z; gr[e + 3] = g.w;
+    }
+    float q[HD], k[HD], v[HD], dO[HD], o[HD];
+    mha_project<HD, EE>(xr, Win, bin, h, qscale, q, k, v);
+    float D = 0.f;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < EE; ++e) a = fmaf(gr[e], Wo[(size_t)e * EE + h * HD + d], a);
+        dO[d] = a;
+        o[d] = tv ? o_save[hs * HD + d] : 0.f;
+        D = fmaf(a, o[d], D);
+        qkvd[0][t][d] = q[d]; qkvd[1][t][d] = k[d]; qkvd[2][t][d] = v[d]; qkvd[3][t][d] = a;
+        os[t][d] = o[d];
+    }
+#pragma unroll
+    for (int e = 0; e < EE; ++e) { xs[t][e] = xr[e]; gs[t][e] = gr[e]; }
+    const float m = tv ? ml_save[hs * 2] : 0.f, rl = tv ? 1.f / ml_save[hs * 2 + 1] : 0.f;
+    st[0][t] = m; st[1][t] = rl; st[2][t] = D;
+    __syncthreads();
+    const unsigned char *mbase = mask ? mask + ((size_t)b * H + h) * S * SP : nullptr;
+    // pass A: thread = query t, loop over keys -> dq' (gradient of the scaled query)
+    float dq[HD], dk[HD], dv[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) dq[d] = dk[d] = dv[d] = 0.f;
+    {
+        const unsigned char *mrow = mbase ? mbase + (size_t)(tv ? t : 0) * SP : nullptr;
+        for (int k4 = 0; k4 < SP; k4 += 4) {
+            const unsigned mw = mrow ? *reinterpret_cast<const unsigned *>(mrow + k4) : 0x01010101u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kk = k4 + j;
+                if (kk < S) {
+                    float s = 0.f, dpd = 0.f;
+#pragma unroll
+                    for (int d = 0; d < HD; ++d) {
+                        s = fmaf(q[d], qkvd[1][kk][d], s);
+                        dpd = fmaf(dO[d], qkvd[2][kk][d], dpd);
+                    }
+                    const float p = __expf(s - m) * rl;
+                    const float dp = ((mw >> (8 * j)) & 0xffu) ? dpd * dscale : 0.f;
+                    const float ds = p * (dp - D);
+#pragma unroll
+                    for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds, qkvd[1][kk][d], dq[d]);
+                }
+            }
+        }
+    }
+    // pass B: thread = key t, loop over queries -> dk, dv
+    for (int qq = 0; qq < S; ++qq) {
+        float s = 0.f, dpd = 0.f;
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            s = fmaf(qkvd[0][qq][d], k[d], s);
+            dpd = fmaf(qkvd[3][qq][d], v[d], dpd);
+        }
+        const float p = __expf(s - st[0][qq]) * st[1][qq];
+        const bool keep = mbase ? (tv ? mbase[(size_t)qq * SP + t] != 0 : false) : true;
+        const float pd = keep ? p * dscale : 0.f, dp = keep ? dpd * dscale : 0.f;
+        const float ds = p * (dp - st[2][qq]);
+#pragma unroll
+        for (int d = 0; d < HD; ++d) {
+            dv[d] = fmaf(pd, qkvd[3][qq][d], dv[d]);
+            dk[d] = fmaf(ds, qkvd[0][qq][d], dk[d]);
+        }
+    }
+    __syncthreads();                                      // everyone is done with Q, K, V, dO: reuse the area for dqkv
+    float(*dqkv)[3 * HD] = reinterpret_cast<float(*)[3 * HD]>(&qkvd[0][0][0]);
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+        dq[d] = tv ? dq[d] * qscale : 0.f;                // gradient of the unscaled projection
+        dk[d] = tv ? dk[d] : 0.f;
+        dv[d] = tv ? dv[d] : 0.f;
+        dqkv[t][d] = dq[d]; dqkv[t][HD + d] = dk[d]; dqkv[t][2 * HD + d] = dv[d];
+    }
+    // this head's part of the input gradient
+    if (tv) {
+        float *go = gxpart + ((size_t)h * S * B + row) * EE;
+#pragma unroll
+        for (int e = 0; e < EE; e += 4) {
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int j = 0; j < HD; ++j) {
+                const float *wq = Win + (size_t)(h * HD + j) * EE + e, *wk = wq + (size_t)EE * EE, *wv = wk + (size_t)EE * EE;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) a[c] = fmaf(dq[j], wq[c], fmaf(dk[j], wk[c], fmaf(dv[j], wv[c], a[c])));
+            }
+            *reinterpret_cast<float4 *>(go + e) = make_float4(a[0], a[1], a[2], a[3]);
+        }
+    }
+    __syncthreads();
+    // weight-gradient partials of this batch element (rows / columns of head h)
+    for (int idx = t; idx < 3 * HD * EE; idx += MHA_T) {
+        const int j = idx / EE, e = idx % EE;             // j: 0..HD-1 query rows, HD.. key rows, 2HD.. value rows
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a = fmaf(dqkv[s][j], xs[s][e], a);
+        const int wrow = (j / HD) * EE + h * HD + j % HD;
+        pWin[((size_t)b * 3 * EE + wrow) * EE + e] = a;
+    }
+    for (int idx = t; idx < EE * HD; idx += MHA_T) {
+        const int e = idx / HD, d = idx % HD;
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a = fmaf(gs[s][e], os[s][d], a);
+        pWo[((size_t)b * EE + e) * EE + h * HD + d] = a;
+    }
+    if (t < 3 * HD) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += dqkv[s][t];
+        pbin[(size_t)b * 3 * EE + (t / HD) * EE + h * HD + t % HD] = a;
+    }
+    if (h == 0 && t < EE) {
+        float a = 0.f;
+        for (int s = 0; s < S; ++s) a += gs[s][t];
+        pbo[(size_t)b * EE + t] = a;
+    }
+}
+
+template <int HD, int EE>
+void mha_launch_fwd(dim3 grid, hipStream_t st, const float *x, const float *Win, const float *bin, const float *Wo, const unsigned char *mask,
+                    float *ypart, float *o_save, float *ml_save, int S, int B, int H, float qscale, float dscale) {
+    hipLaunchKernelGGL((mha_fwd_kernel<HD, EE>), grid, dim3(MHA_T), 0, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+}
+template <int HD, int EE>
+void mha_launch_bwd(dim3 grid, hipStream_t st, const float *x, const float *gsa, const float *Win, const float *bin, const float *Wo,
+                    const unsigned char *mask, const float *o_save, const float *ml_save, float *gxpart, float *pWin, float *pbin, float *pWo,
+                    float *pbo, int S, int B, int H, float qscale, float dscale) {
+    hipLaunchKernelGGL((mha_bwd_kernel<HD, EE>), grid, dim3(MHA_T), 0, st, x, gsa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin, pbin, pWo,
+                       pbo, S, B, H, qscale, dscale);
+}
+}  // namespace
+
+extern "C" int sqd_mha_supported(int S, int E, int H) {
+    if (!(E == 16 || E == 32) || H < 1 || E % H) return 0;
+    const int hd = E / H;
+    return (S >= 1 && S <= MHA_T && (hd == 4 || hd == 8)) ? 1 : 0;
+}
+
+// x [S*B, E] (token (s,b) = row s*B+b), Win [3E,E], bin [3E], Wo [E,E]; mask [B][H][S][SP] keep bytes (SP = S rounded up to 4)
+// or NULL, dscale = 1/(1-p) -> ypart [H][S*B,E] (attention output through the out-projection, per head, without its bias),
+// o_save [B][H][S][E/H], ml_save [B][H][S][2] (row max, row sum) for the backward
+extern "C" int sqd_mha_fwd(const float *x, const float *Win, const float *bin, const float *Wo, const unsigned char *mask, float *ypart,
+                           float *o_save, float *ml_save, int S, int B, int E, int H, float dscale, void *stream) {
+    SQD_CHECK_ARG(x && Win && bin && Wo && ypart && o_save && ml_save, "sqd_mha_fwd: null pointer");
+    SQD_CHECK_ARG(B >= 1 && sqd_mha_supported(S, E, H), "sqd_mha_fwd: unsupported dims S=%d B=%d E=%d heads=%d", S, B, E, H);
+    SQD_CHECK_ARG(((uintptr_t)mask & 3) == 0, "sqd_mha_fwd: mask must be 4-byte aligned");
+    const int hd = E / H;
+    const float qscale = 1.f / sqrtf((float)hd);
+    const dim3 grid(B, H);
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipGetLastError();
+    if (hd == 8 && E == 32) mha_launch_fwd<8, 32>(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+    else if (hd == 4 && E == 32) mha_launch_fwd<4, 32>(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+    else if (hd == 8 && E == 16) mha_launch_fwd<8, 16>(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+    else mha_launch_fwd<4, 16>(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+    SQD_CHECK_LAUNCH("sqd_mha_fwd");
+    return SQD_OK;
+}
+
+// g_sa [S*B,E] (gradient of the attention block's output, after the out-projection) -> gxpart [H][S*B,E] (g_x = sum over heads)
+// and per-batch-element partials pWin [B][3E,E], pbin [B][3E], pWo [B][E,E], pbo [B][E] for sqd_colsum_multi
+extern "C" int sqd_mha_bwd(const float *x, const float *g_sa, const float *Win, const float *bin, const float *Wo,
+                           const unsigned char *mask, const float *o_save, const float *ml_save, float *gxpart, float *pWin, float *pbin,
+                           float *pWo, float *pbo, int S, int B, int E, int H, float dscale, void *stream) {
+    SQD_CHECK_ARG(x && g_sa && Win && bin && Wo && o_save && ml_save && gxpart && pWin && pbin && pWo && pbo, "sqd_mha_bwd: null pointer");
+    SQD_CHECK_ARG(B >= 1 && sqd_mha_supported(S, E, H), "sqd_mha_bwd: unsupported dims S=%d B=%d E=%d heads=%d", S, B, E, H);
+    SQD_CHECK_ARG(((uintptr_t)mask & 3) == 0, "sqd_mha_bwd: mask must be 4-byte aligned");
+    const int hd = E / H;
+    const float qscale = 1.f / sqrtf((float)hd);
+    const dim3 grid(B, H);
+    hipStream_t st = (hipStream_t)stream;
+    (void)hipGetLastError();
+#define SQD_MHA_BWD(HD_, EE_) \
+    mha_launch_bwd<HD_, EE_>(grid, st, x, g_sa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin, pbin, pWo, pbo, S, B, H, qscale, dscale)
+    if (hd == 8 && E == 32) SQD_MHA_BWD(8, 32);
+    else if (hd == 4 && E == 32) SQD_MHA_BWD(4, 32);
+    else if (hd == 8 && E == 16) SQD_MHA_BWD(8, 16);
+    else SQD_MHA_BWD(4, 16);
+#undef SQD_MHA_BWD
+    SQD_CHECK_LAUNCH("sqd_mha_bwd");
     return SQD_OK;
 }

@@ -573,6 +573,122 @@ class EncoderTail(torch.autograd.Function):
         return gx, gsa, None, None, None, small[3], small[4], gW1, gb1, gW2, small[0], small[1], small[2], None, None, None
 
 
+def _mha_fwd(x, Win, bin_, Wo, mask, S, B, H, scale):
+    """-> ypart [H, rows, E], o_save, ml_save"""
+    E = x.shape[-1]
+    L = _l.lib()
+    ypart = torch.empty(H, S * B, E, device=x.device, dtype=torch.float32)
+    o_save = torch.empty(B * H * S * (E // H), device=x.device, dtype=torch.float32)
+    ml = torch.empty(B * H * S * 2, device=x.device, dtype=torch.float32)
+    _l.check(L.sqd_mha_fwd(_ptr(x), _ptr(Win), _ptr(bin_), _ptr(Wo), _ptr(mask), _ptr(ypart), _ptr(o_save), _ptr(ml), S, B, E, H,
+                           float(scale), _stream()), "mha_fwd")
+    return ypart, o_save, ml
+
+
+def _mha_bwd(x, gsa, Win, bin_, Wo, mask, o_save, ml, S, B, H, scale):
+    """-> gxpart [H, rows, E], pWin [B, 3E*E], pbin [B, 3E], pWo [B, E*E], pbo [B, E]"""
+    E = x.shape[-1]
+    sizes = [H * S * B * E, B * 3 * E * E, B * 3 * E, B * E * E, B * E]
+    gxpart, pWin, pbin, pWo, pbo = torch.split(torch.empty(sum(sizes), device=x.device, dtype=torch.float32), sizes)
+    _l.check(_l.lib().sqd_mha_bwd(_ptr(x), _ptr(gsa), _ptr(Win), _ptr(bin_), _ptr(Wo), _ptr(mask), _ptr(o_save), _ptr(ml), _ptr(gxpart),
+                                  _ptr(pWin), _ptr(pbin), _ptr(pWo), _ptr(pbo), S, B, E, H, float(scale), _stream()), "mha_bwd")
+    return gxpart.view(H, S * B, E), pWin.view(B, 3 * E * E), pbin.view(B, 3 * E), pWo.view(B, E * E), pbo.view(B, E)
+
+
+class SelfAttention(torch.autograd.Function):
+    """nn.MultiheadAttention(x, x, x, need_weights=False)[0] for tokens [S,B,E] as one kernel pair (stand-alone node for
+    tests; the training path uses EncoderStack).  mask: uint8 keep-mask [B,H,S,SP] of the attention dropout, or None."""
+
+    @staticmethod
+    def forward(ctx, x, Win, bin_, Wo, bo, mask, H, scale):
+        x = x.contiguous()
+        _require(x, "attention tokens")
+        S, B, E = x.shape
+        ypart, o_save, ml = _mha_fwd(x, Win, bin_, Wo, mask, S, B, H, scale)
+        ctx.save_for_backward(x, Win, bin_, Wo, o_save, ml)
+        ctx.cfg = (mask, H, float(scale))
+        return ypart.sum(0).view(S, B, E) + bo
+
+    @staticmethod
+    def backward(ctx, g):
+        x, Win, bin_, Wo, o_save, ml = ctx.saved_tensors
+        mask, H, scale = ctx.cfg
+        S, B, E = x.shape
+        gxpart, pWin, pbin, pWo, pbo = _mha_bwd(x, g.contiguous(), Win, bin_, Wo, mask, o_save, ml, S, B, H, scale)
+        gWin, gbin, gWo = torch.empty_like(Win), torch.empty_like(bin_), torch.empty_like(Wo)
+        gbo = torch.empty(E, device=g.device, dtype=torch.float32)
+        _colsum_multi([(pWin, gWin, 0), (pbin, gbin, 0), (pWo, gWo, 0), (pbo, gbo, 0)])
+        return gxpart.sum(0).view(S, B, E), gWin, gbin, gWo, gbo, None, None, None
+
+
+def _layer_params(layer):
+    a = layer.self_attn
+    return [a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, layer.norm1.weight, layer.norm1.bias,
+            layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias]
+
+
+class EncoderStack(torch.autograd.Function):
+    """The whole post-norm encoder (all layers) as one autograd node: 4 launches per layer forward, 5 backward; sums over
+    heads / hidden groups travel between the kernels as partials, so no stand-alone reduction or residual add is launched.
+    cfg: {"H": heads, "eps": [(eps1, eps2)], "masks": [(attn, m1, mf, m2)] | None, "scale": 1/(1-p)}."""
+
+    @staticmethod
+    def forward(ctx, tokens, cfg, *params):
+        x = tokens.contiguous()
+        _require(x, "encoder tokens")
+        S, B, E = x.shape
+        H, scale = cfg["H"], cfg["scale"]
+        saved = []
+        for li in range(len(params) // 12):
+            Win, bin_, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2 = params[12 * li:12 * li + 12]
+            ma, m1, mf, m2 = cfg["masks"][li] if cfg["masks"] is not None else (None,) * 4
+            eps1, eps2 = cfg["eps"][li]
+            apart, o_save, ml = _mha_fwd(x, Win, bin_, Wo, ma, S, B, H, scale)
+            x1, xhat1, rstd1 = _addln_fwd(x, apart, H, bo, m1, g1, be1, scale, eps1)
+            ypart = _ffn_fwd(x1, W1, b1, W2, mf, scale)
+            x2, xhat2, rstd2 = _addln_fwd(x1, ypart, ypart.shape[0], b2, m2, g2, be2, scale, eps2)
+            saved += [x, o_save, ml, xhat1, rstd1, x1, xhat2, rstd2]
+            x = x2
+        ctx.save_for_backward(*saved, *params)
+        ctx.cfg = cfg
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        cfg = ctx.cfg
+        H, scale = cfg["H"], cfg["scale"]
+        nl = len(cfg["eps"])
+        saved, params = ctx.saved_tensors[:8 * nl], ctx.saved_tensors[8 * nl:]
+        S, B, E = saved[0].shape
+        g, extra, nextra = g.contiguous(), None, 0
+        grads = [None] * (12 * nl)
+        for li in reversed(range(nl)):
+            x, o_save, ml, xhat1, rstd1, x1, xhat2, rstd2 = saved[8 * li:8 * li + 8]
+            Win, bin_, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2 = params[12 * li:12 * li + 12]
+            ma, m1, mf, m2 = cfg["masks"][li] if cfg["masks"] is not None else (None,) * 4
+            dz2, gy2, part2 = _addln_bwd(g, extra, nextra, xhat2, rstd2, m2, g2, scale)
+            fpart, pW1, pb1, pW2T, pb2 = _ffn_bwd(x1, gy2, W1, b1, W2, mf, scale)
+            dz1, gsa, part1 = _addln_bwd(dz2, fpart, fpart.shape[0], xhat1, rstd1, m1, g1, scale)
+            apart, pWin, pbin, pWo, pbo = _mha_bwd(x, gsa, Win, bin_, Wo, ma, o_save, ml, S, B, H, scale)
+            gWin, gbin, gWo = torch.empty_like(Win), torch.empty_like(bin_), torch.empty_like(Wo)
+            gW1, gb1, gW2 = torch.empty_like(W1), torch.empty_like(b1), torch.empty_like(W2)
+            small = torch.empty(6, E, device=g.device, dtype=torch.float32)   # g_bo | g_b2 | g_gamma1, g_beta1 | g_gamma2, g_beta2
+            _colsum_multi([(pWin, gWin, 0), (pbin, gbin, 0), (pWo, gWo, 0), (pbo, small[0], 0), (pW1, gW1, 0), (pW2T, gW2, E),
+                           (pb1, gb1, 0), (pb2, small[1], 0), (part1, small[2:4], 0), (part2, small[4:6], 0)])
+            grads[12 * li:12 * li + 12] = [gWin, gbin, gWo, small[0], small[2], small[3], gW1, gb1, gW2, small[1], small[4], small[5]]
+            g, extra, nextra = dz1, apart, H
+        g_tokens = extra.sum(0).view(S, B, E).add_(g)
+        return (g_tokens, None, *grads)
+
+
+def _attention_native_ok(layer, S):
+    a = layer.self_attn
+    E = a.embed_dim
+    return (a._qkv_same_embed_dim and a.in_proj_weight is not None and a.in_proj_bias is not None and a.bias_k is None and
+            not a.add_zero_attn and a.out_proj.bias is not None and
+            bool(_l.lib().sqd_mha_supported(S, E, a.num_heads)))
+
+
 def encoder_supported(encoder):
     """nn.TransformerEncoder as the depth head builds it: post-norm layers, ReLU, no final norm, fp32 dense weights."""
     import torch.nn.functional as F
@@ -590,27 +706,40 @@ def encoder_supported(encoder):
 
 
 def transformer_encoder_native(tokens, encoder):
-    """tokens [S,B,E] through the encoder: self-attention stays with torch (in/out projections on rocBLAS, attention core on
-    its fused kernel); everything after it runs as EncoderTail.  One bernoulli launch draws every dropout mask of the pass."""
+    """tokens [S,B,E] through the encoder.  Short sequences (S <= 128, head dimension 4 | 8): every layer runs on the fused
+    kernels (EncoderStack).  Longer ones: self-attention stays with torch (projections on rocBLAS, attention core on its
+    fused kernel) and everything after it runs as EncoderTail.  One bernoulli launch draws every dropout mask of the pass."""
     x = tokens.contiguous()
     S, B, E = x.shape
     rows = S * B
     layers = list(encoder.layers)
+    H = layers[0].self_attn.num_heads
+    full = NATIVE_MHA and all(_attention_native_ok(l, S) and l.self_attn.num_heads == H for l in layers)
     masks, scale = None, 1.0
     if encoder.training:
-        ps = {p for l in layers for p in (l.dropout1.p, l.dropout.p, l.dropout2.p)}
+        ps = {float(p) for l in layers for p in (l.dropout1.p, l.dropout.p, l.dropout2.p)}
+        if full:
+            ps |= {float(l.self_attn.dropout) for l in layers}
         if ps != {0.0}:
             if len(ps) != 1:
                 raise RuntimeError("sqd: encoder layers with different dropout rates are not supported")
             p0 = ps.pop()
-            per_layer = [(rows * E, rows * l.linear1.weight.shape[0], rows * E) for l in layers]
+            SP = (S + 3) // 4 * 4
+            per_layer = [((B * H * S * SP) if full else 0, rows * E, rows * l.linear1.weight.shape[0], rows * E) for l in layers]
             keep = torch.empty(sum(sum(t) for t in per_layer), device=x.device, dtype=torch.uint8).bernoulli_(1.0 - p0)
             masks = [torch.split(c, list(t)) for c, t in zip(torch.split(keep, [sum(t) for t in per_layer]), per_layer)]
             scale = 1.0 / (1.0 - p0)
+    if full:
+        cfg = {"H": H, "eps": [(l.norm1.eps, l.norm2.eps) for l in layers], "masks": masks, "scale": scale}
+        return EncoderStack.apply(x, cfg, *[p for l in layers for p in _layer_params(l)])
     for li, layer in enumerate(layers):
-        m1, mf, m2 = masks[li] if masks is not None else (None, None, None)
+        _, m1, mf, m2 = masks[li] if masks is not None else (None,) * 4
         sa = layer.self_attn(x, x, x, need_weights=False)[0]
         x = EncoderTail.apply(x, sa, m1, mf, m2, layer.norm1.weight, layer.norm1.bias, layer.linear1.weight, layer.linear1.bias,
                               layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias, scale,
                               layer.norm1.eps, layer.norm2.eps)
     return x
+
+
+# SQD_MHA_ATEN=1: torch's MultiheadAttention inside the encoder (A/B runs)
+NATIVE_MHA = not os.environ.get("SQD_MHA_ATEN")

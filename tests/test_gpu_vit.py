@@ -126,6 +126,93 @@ def test_encoder_tail(rows, E, Fh, drop):
         _close(d.grad, r.grad, name, 2e-4)
 
 
+def _attention_ref(x, Win, bin_, Wo, bo, H, keep, scale):
+    """nn.MultiheadAttention's arithmetic written out (fp64), with an explicit keep-mask on the softmax probabilities"""
+    S, B, E = x.shape
+    hd = E // H
+    qkv = F.linear(x, Win, bin_)
+    q, k, v = [t.reshape(S, B * H, hd).transpose(0, 1) for t in qkv.chunk(3, dim=-1)]
+    p = torch.softmax(q @ k.transpose(1, 2) / hd ** 0.5, dim=-1)
+    if keep is not None:
+        p = p * keep.double() * scale
+    o = (p @ v).transpose(0, 1).reshape(S, B, E)
+    return F.linear(o, Wo, bo)
+
+
+@pytest.mark.parametrize("S,B,E,H,drop", [(120, 12, 32, 4, True), (120, 12, 32, 4, False), (120, 2, 16, 4, True), (37, 3, 32, 8, True),
+                                          (128, 1, 16, 2, False), (1, 2, 32, 4, False), (6, 5, 32, 4, True)])
+def test_self_attention(S, B, E, H, drop):
+    from sqd import nnkernels
+    g = torch.Generator().manual_seed(S * 7 + B + E + H)
+    x = torch.randn(S, B, E, generator=g)
+    Win, bin_ = torch.randn(3 * E, E, generator=g) / E ** 0.5, 0.1 * torch.randn(3 * E, generator=g)
+    Wo, bo = torch.randn(E, E, generator=g) / E ** 0.5, 0.1 * torch.randn(E, generator=g)
+    gout = torch.randn(S, B, E, generator=g)
+    SP = (S + 3) // 4 * 4
+    keep = (torch.rand(B, H, S, SP, generator=g) < 0.9).to(torch.uint8) if drop else None
+    scale = 1.0 / 0.9 if drop else 1.0
+    ref_in = [t.clone().double().requires_grad_(True) for t in (x, Win, bin_, Wo, bo)]
+    ref = _attention_ref(*ref_in, H, keep[..., :S].reshape(B * H, S, S) if drop else None, scale)
+    ref.backward(gout.double())
+    if not drop:                                                # the written-out reference is nn.MultiheadAttention
+        mha = nn.MultiheadAttention(E, H).double()
+        with torch.no_grad():
+            for q, t in zip((mha.in_proj_weight, mha.in_proj_bias, mha.out_proj.weight, mha.out_proj.bias), (Win, bin_, Wo, bo)):
+                q.copy_(t)
+        _close(mha(x.double(), x.double(), x.double(), need_weights=False)[0], ref, "reference vs nn.MultiheadAttention", 1e-9)
+    dev = [t.clone().cuda().requires_grad_(True) for t in (x, Win, bin_, Wo, bo)]
+    out = nnkernels.SelfAttention.apply(*dev, keep.cuda() if drop else None, H, scale)
+    out.backward(gout.cuda())
+    _close(out, ref, "attention out")
+    for name, d, r in zip(("g_x", "g_Win", "g_bin", "g_Wo", "g_bo"), dev, ref_in):
+        _close(d.grad, r.grad, name)
+
+
+def test_encoder_stack_with_masks_matches_node_composition():
+    """all layers in one node with dropout masks == the same masks through the stand-alone nodes (which are checked against
+    fp64 above); only the order of the partial sums differs"""
+    from sqd import nnkernels
+    S, B, E, H, Fh = 120, 12, 32, 4, 1024
+    enc = _encoder(E, Fh, 0.1, 3).cuda()
+    rows, SP = S * B, S
+    x0 = torch.randn(S, B, E, device="cuda")
+    gout = torch.randn(S, B, E, device="cuda")
+    torch.manual_seed(11)
+    sizes = (B * H * S * SP, rows * E, rows * Fh, rows * E)
+    masks = [torch.split(torch.empty(sum(sizes), device="cuda", dtype=torch.uint8).bernoulli_(0.9), sizes) for _ in enc.layers]
+    scale = 1.0 / 0.9
+    params = [p for l in enc.layers for p in nnkernels._layer_params(l)]
+    cfg = {"H": H, "eps": [(1e-5, 1e-5)] * 4, "masks": masks, "scale": scale}
+    xa = x0.clone().requires_grad_(True)
+    out_a = nnkernels.EncoderStack.apply(xa, cfg, *params)
+    out_a.backward(gout)
+    ga = [p.grad.clone() for p in params]
+    for p in params:
+        p.grad = None
+    xb = x0.clone().requires_grad_(True)
+    x = xb
+    for li, l in enumerate(enc.layers):
+        Win, bin_, Wo, bo, g1, be1, W1, b1, W2, b2, g2, be2 = nnkernels._layer_params(l)
+        ma, m1, mf, m2 = masks[li]
+        sa = nnkernels.SelfAttention.apply(x, Win, bin_, Wo, bo, ma, H, scale)
+        x = nnkernels.EncoderTail.apply(x, sa, m1, mf, m2, g1, be1, W1, b1, W2, b2, g2, be2, scale, 1e-5, 1e-5)
+    x.backward(gout)
+    # 6 M hidden pre-activations, two fp32 paths with different partial-sum orders: a handful sit within rounding of the ReLU
+    # kink and take different branches (see _kink_free), each moving one token's / one hidden unit's gradients by ~1e-2 of the
+    # tensor's scale.  So: the whole tensor within 3e-3 in relative L2, and for the large tensors all but a sliver of the elements within 1e-4.
+    def mostly_close(a, b, what):
+        a, b = a.detach().double().cpu(), b.detach().double().cpu()
+        err, scale = (a - b).abs(), max(b.abs().max().item(), 1e-6)
+        frac = (err > 1e-4 * scale).double().mean().item()
+        rel = (a - b).norm().item() / max(b.norm().item(), 1e-12)
+        assert (frac <= 0.02 or a.numel() < 10000) and rel <= 3e-3, "%s: %.2f %% of the elements off, relative L2 %.2e" % (what, 100 * frac, rel)
+    mostly_close(out_a, x, "stack output")
+    mostly_close(xa.grad, xb.grad, "g_tokens")
+    names = [n for l in range(4) for n in ("Win", "bin", "Wo", "bo", "g1", "be1", "W1", "b1", "W2", "b2", "g2", "be2")]
+    for name, a, p in zip(names, ga, params):
+        mostly_close(a, p.grad, name)
+
+
 def _encoder(E, Fh, p, seed):
     torch.manual_seed(seed)
     layer = nn.TransformerEncoderLayer(E, 4, dim_feedforward=Fh, dropout=p)
