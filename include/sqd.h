@@ -269,9 +269,11 @@ int sqd_bins_bwd(const float *energy, const float *weight, const float *bias, co
 /* ---------------------------------------------------------------------------------------------------
  * (12) MaxPool2d(3, stride 2, padding 1), channels-last.  replaces: the ResNet stem's maxpool (reference
  * networks/resnet_encoder.py:96).  x [N,H,W,C] -> y [N,Ho,Wo,C] and idx [N,Ho,Wo,C] (1 byte: window position of the
- * maximum, ATen's tie rule); Ho = (H-1)/2+1, Wo = (W-1)/2+1; C multiple of 4.  The backward is a gather (no atomics). */
+ * maximum, ATen's tie rule); Ho = (H-1)/2+1, Wo = (W-1)/2+1; C multiple of 4.  The backward is a gather (no atomics); addend
+ * [N,H,W,C] (may be NULL) is added to it: the gradient arriving from the input's other consumer (the decoder's skip). */
 int sqd_maxpool3x3s2_fwd(const float *x, float *y, unsigned char *idx, int N, int H, int W, int C, void *stream);
-int sqd_maxpool3x3s2_bwd(const float *dy, const unsigned char *idx, float *dx, int N, int H, int W, int C, void *stream);
+int sqd_maxpool3x3s2_bwd(const float *dy, const unsigned char *idx, const float *addend, float *dx, int N, int H, int W, int C,
+                         void *stream);
 /* space-to-depth(2), channels-last, channels zero-padded to Cp: y[n,h2,w2,c*4+dy*2+dx] = x[n,2h2+dy,2w2+dx,c].  The 7x7/2 stems
  * (reference networks/resnet_encoder.py:94, pose_cnn.py:17) run as 4x4/1 convolutions on this layout (sqd_conv_*).       */
 int sqd_space_to_depth2(const float *x, float *y, int N, int H, int W, int C, int Cp, void *stream);

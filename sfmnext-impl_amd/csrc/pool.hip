@@ -45,7 +45,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *__restric
 }
 
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restrict__ dy, const unsigned char *__restrict__ idx,
-                                                          float *__restrict__ dx, int N, int H, int W, int C, int Ho, int Wo) {
+                                                          const float *__restrict__ addend, float *__restrict__ dx, int N, int H, int W,
+                                                          int C, int Ho, int Wo) {
     const int V = C / 4;
     const size_t total = (size_t)N * H * W * V;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restric
         const int wi = (int)(t % W);
         t /= W;
         const int hi = (int)(t % H), n = (int)(t / H);
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 g = addend ? reinterpret_cast<const float4 *>(addend)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         // windows containing row hi: 2ho-1 <= hi <= 2ho+1
         const int ho0 = hi / 2, ho1 = (hi + 1) / 2, wo0 = wi / 2, wo1 = (wi + 1) / 2;
         for (int ho = ho0; ho <= ho1; ++ho) {
@@ -93,13 +94,15 @@ extern "C" int sqd_maxpool3x3s2_fwd(const float *x, float *y, unsigned char *idx
     return SQD_OK;
 }
 
-// dy [N,Ho,Wo,C], idx from the forward -> dx [N,H,W,C] (fully overwritten)
-extern "C" int sqd_maxpool3x3s2_bwd(const float *dy, const unsigned char *idx, float *dx, int N, int H, int W, int C, void *stream) {
+// dy [N,Ho,Wo,C], idx from the forward -> dx [N,H,W,C] (fully overwritten) = gather(dy) [+ addend [N,H,W,C], may be NULL: the
+// gradient of the input's other consumer, folded in here instead of a separate accumulation pass]
+extern "C" int sqd_maxpool3x3s2_bwd(const float *dy, const unsigned char *idx, const float *addend, float *dx, int N, int H, int W, int C,
+                                    void *stream) {
     SQD_CHECK_ARG(dy && idx && dx && N > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0, "sqd_maxpool3x3s2_bwd: bad arguments (C=%d)", C);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((size_t)N * H * W * C / 4)), dim3(256), 0, (hipStream_t)stream, dy, idx, dx, N, H, W,
-                       C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((size_t)N * H * W * C / 4)), dim3(256), 0, (hipStream_t)stream, dy, idx, addend, dx, N,
+                       H, W, C, Ho, Wo);
     SQD_CHECK_LAUNCH("sqd_maxpool3x3s2_bwd");
     return SQD_OK;
 }

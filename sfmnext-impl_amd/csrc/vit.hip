@@ -467,104 +467,139 @@ extern "C" int sqd_ffn_bwd(const float *x, const float *g_y, const float *W1, co
 
 // ===================================================================================================
 // multi-head self-attention of the encoder layer (nn.MultiheadAttention, packed in_proj, batch_first = False) for short token
-// sequences: S <= 128 tokens, head dimension HD in {4, 8}.  One workgroup per (batch element, head), one thread per token;
-// the whole head (projections, S x S scores, softmax, attention dropout, P.V, its slice of the out-projection) is VALU
-// work on operands broadcast from LDS — 120 x 120 x 8 per head is far too small for the matrix cores to matter; what
+// sequences: S <= 128 tokens, head dimension HD in {4, 8}.  One workgroup per (batch element, head), four threads per token
+// (each takes every 4th key / query and a quarter of the features; quad shuffles combine them); the whole head (projections,
+// S x S scores, softmax, attention dropout, P.V, its slice of the out-projection) is VALU work on operands read from LDS — 120 x 120 x 8 per head is far too small for the matrix cores to matter; what
 // counts is that it is ONE launch with no intermediate tensors instead of ~8 (forward) / ~20 (backward).
 // The out-projection is left as per-head partials ypart [H][rows,E] (+ bias added by the consumer, sqd_addln_fwd), the
 // input gradient as per-head partials gxpart [H][rows,E]; weight gradients as per-batch-element partials for sqd_colsum_multi.
 // Token (s, b) is row s*B + b.  Keep-mask of the attention dropout: bytes [B][H][S][SP], SP = S rounded up to 4.
 // ===================================================================================================
 namespace {
-constexpr int MHA_T = 128;
+constexpr int MHA_T = 128;                               // tokens per workgroup
+constexpr int MHA_P = 4;                                 // threads per token: thread 4*t + p takes every 4th key / query, a
+                                                         // quarter of the projection outputs and of the feature columns
+constexpr int MHA_THREADS = MHA_T * MHA_P;
 
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    return v + __shfl_xor(v, 2, 64);
+}
+__device__ __forceinline__ float quad_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    return fmaxf(v, __shfl_xor(v, 2, 64));
+}
+
+// head h's slices of the packed in-projection (rows q | k | v) and of the out-projection, staged in LDS
 template <int HD, int EE>
-__device__ __forceinline__ void mha_project(const float (&xr)[EE], const float *__restrict__ Win, const float *__restrict__ bin, int h,
-                                            float qscale, float (&q)[HD], float (&k)[HD], float (&v)[HD]) {
+struct MhaWeights {
+    float win[3 * HD][EE + 4];                           // + 4: the 4 parts read rows 2p.. at distinct banks
+    float bin[3 * HD];
+    float wo[EE][HD];                                    // wo[e][d] = Wo[e][h*HD + d]
+};
+template <int HD, int EE>
+__device__ __forceinline__ void mha_stage_weights(MhaWeights<HD, EE> &W, const float *__restrict__ Win, const float *__restrict__ bin,
+                                                  const float *__restrict__ Wo, int h) {
+    for (int idx = threadIdx.x; idx < 3 * HD * EE; idx += MHA_THREADS) {
+        const int j = idx / EE, e = idx % EE;
+        W.win[j][e] = Win[(size_t)((j / HD) * EE + h * HD + j % HD) * EE + e];
+    }
+    for (int idx = threadIdx.x; idx < EE * HD; idx += MHA_THREADS) W.wo[idx / HD][idx % HD] = Wo[(size_t)(idx / HD) * EE + h * HD + idx % HD];
+    if (threadIdx.x < 3 * HD) W.bin[threadIdx.x] = bin[(threadIdx.x / HD) * EE + h * HD + threadIdx.x % HD];
+}
+
+// part p of token t projects HD/4 of the query / key / value features and writes them to LDS
+template <int HD, int EE>
+__device__ __forceinline__ void mha_project(const MhaWeights<HD, EE> &W, const float (&xr)[EE], int t, int p, float qscale,
+                                            float (*Qs)[HD], float (*Ks)[HD], float (*Vs)[HD]) {
+    constexpr int JP = HD / MHA_P;
 #pragma unroll
-    for (int j = 0; j < HD; ++j) {
-        const float *wq = Win + (size_t)(h * HD + j) * EE, *wk = wq + (size_t)EE * EE, *wv = wk + (size_t)EE * EE;
-        float aq = bin[h * HD + j], ak = bin[EE + h * HD + j], av = bin[2 * EE + h * HD + j];
+    for (int jj = 0; jj < JP; ++jj) {
+        const int j = p * JP + jj;
+        float aq = W.bin[j], ak = W.bin[HD + j], av = W.bin[2 * HD + j];
 #pragma unroll
-        for (int e = 0; e < EE; ++e) {
-            aq = fmaf(xr[e], wq[e], aq);
-            ak = fmaf(xr[e], wk[e], ak);
-            av = fmaf(xr[e], wv[e], av);
+        for (int e = 0; e < EE; e += 4) {
+            const float4 wq = *reinterpret_cast<const float4 *>(&W.win[j][e]);
+            const float4 wk = *reinterpret_cast<const float4 *>(&W.win[HD + j][e]);
+            const float4 wv = *reinterpret_cast<const float4 *>(&W.win[2 * HD + j][e]);
+            aq = fmaf(xr[e], wq.x, fmaf(xr[e + 1], wq.y, fmaf(xr[e + 2], wq.z, fmaf(xr[e + 3], wq.w, aq))));
+            ak = fmaf(xr[e], wk.x, fmaf(xr[e + 1], wk.y, fmaf(xr[e + 2], wk.z, fmaf(xr[e + 3], wk.w, ak))));
+            av = fmaf(xr[e], wv.x, fmaf(xr[e + 1], wv.y, fmaf(xr[e + 2], wv.z, fmaf(xr[e + 3], wv.w, av))));
         }
-        q[j] = aq * qscale; k[j] = ak; v[j] = av;
+        Qs[t][j] = aq * qscale; Ks[t][j] = ak; Vs[t][j] = av;
     }
 }
 
 template <int HD, int EE>
-__global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict__ x, const float *__restrict__ Win,
-                                                        const float *__restrict__ bin, const float *__restrict__ Wo,
-                                                        const unsigned char *__restrict__ mask, float *__restrict__ ypart,
-                                                        float *__restrict__ o_save, float *__restrict__ ml_save, int S, int B, int H,
-                                                        float qscale, float dscale) {
-    __shared__ float Ks[MHA_T][HD], Vs[MHA_T][HD];
-    const int b = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
+__global__ __launch_bounds__(MHA_THREADS) void mha_fwd_kernel(const float *__restrict__ x, const float *__restrict__ Win,
+                                                              const float *__restrict__ bin, const float *__restrict__ Wo,
+                                                              const unsigned char *__restrict__ mask, float *__restrict__ ypart,
+                                                              float *__restrict__ o_save, float *__restrict__ ml_save, int S, int B,
+                                                              int H, float qscale, float dscale) {
+    __shared__ MhaWeights<HD, EE> W;
+    __shared__ float Qs[MHA_T][HD], Ks[MHA_T][HD], Vs[MHA_T][HD];
+    const int b = blockIdx.x, h = blockIdx.y, t = threadIdx.x >> 2, p = threadIdx.x & 3;
     const bool tv = t < S;
     const int SP = (S + 3) & ~3;
     const size_t row = (size_t)t * B + b;
+    mha_stage_weights<HD, EE>(W, Win, bin, Wo, h);
     float xr[EE];
 #pragma unroll
     for (int e = 0; e < EE; e += 4) {
         const float4 v4 = tv ? *reinterpret_cast<const float4 *>(x + row * EE + e) : make_float4(0.f, 0.f, 0.f, 0.f);
         xr[e] = v4.x; xr[e + 1] = v4.y; xr[e + 2] = v4.z; xr[e + 3] = v4.w;
     }
-    float q[HD], k[HD], v[HD];
-    mha_project<HD, EE>(xr, Win, bin, h, qscale, q, k, v);
-#pragma unroll
-    for (int d = 0; d < HD; ++d) { Ks[t][d] = k[d]; Vs[t][d] = v[d]; }
     __syncthreads();
+    mha_project<HD, EE>(W, xr, t, p, qscale, Qs, Ks, Vs);
+    __syncthreads();
+    float q[HD];
+#pragma unroll
+    for (int d = 0; d < HD; ++d) q[d] = Qs[t][d];
     float m = -INFINITY;
-    for (int kk = 0; kk < S; ++kk) {
+    for (int kk = p; kk < S; kk += MHA_P) {
         float s = 0.f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[kk][d], s);
         m = fmaxf(m, s);
     }
+    m = quad_max(m);                                     // S >= 1: at least part 0 saw a key
     float l = 0.f, o[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) o[d] = 0.f;
     const unsigned char *mrow = mask ? mask + (((size_t)b * H + h) * S + (tv ? t : 0)) * SP : nullptr;
-    for (int k4 = 0; k4 < SP; k4 += 4) {
-        const unsigned mw = mrow ? *reinterpret_cast<const unsigned *>(mrow + k4) : 0x01010101u;
+    for (int kk = p; kk < S; kk += MHA_P) {
+        float s = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int kk = k4 + j;
-            if (kk < S) {
-                float s = 0.f;
+        for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[kk][d], s);
+        const float pr = __expf(s - m);
+        l += pr;
+        const float pd = (!mrow || mrow[kk]) ? pr * dscale : 0.f;
 #pragma unroll
-                for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[kk][d], s);
-                const float p = __expf(s - m);
-                l += p;
-                const float pd = ((mw >> (8 * j)) & 0xffu) ? p * dscale : 0.f;
-#pragma unroll
-                for (int d = 0; d < HD; ++d) o[d] = fmaf(pd, Vs[kk][d], o[d]);
-            }
-        }
+        for (int d = 0; d < HD; ++d) o[d] = fmaf(pd, Vs[kk][d], o[d]);
     }
-    if (!tv) return;
+    l = quad_sum(l);
     const float rl = 1.f / l;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) o[d] = quad_sum(o[d]) * rl;
+    if (!tv) return;
     const size_t hs = ((size_t)b * H + h) * S + t;
+    if (p == 0) {
 #pragma unroll
-    for (int d = 0; d < HD; ++d) {
-        o[d] *= rl;
-        o_save[hs * HD + d] = o[d];
+        for (int d = 0; d < HD; ++d) o_save[hs * HD + d] = o[d];
+        ml_save[hs * 2] = m;
+        ml_save[hs * 2 + 1] = l;
     }
-    ml_save[hs * 2] = m;
-    ml_save[hs * 2 + 1] = l;
-    float *yo = ypart + ((size_t)h * S * B + row) * EE;
+    // this head's part of the out-projection; part p writes features [p*EE/4, (p+1)*EE/4)
+    constexpr int EP = EE / MHA_P;
+    float *yo = ypart + ((size_t)h * S * B + row) * EE + p * EP;
 #pragma unroll
-    for (int e = 0; e < EE; e += 4) {
+    for (int e = 0; e < EP; e += 4) {
         float y4[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const float *wo = Wo + (size_t)(e + c) * EE + h * HD;
             float a = 0.f;
 #pragma unroll
-            for (int d = 0; d < HD; ++d) a = fmaf(o[d], wo[d], a);
+            for (int d = 0; d < HD; ++d) a = fmaf(o[d], W.wo[p * EP + e + c][d], a);
             y4[c] = a;
         }
         *reinterpret_cast<float4 *>(yo + e) = make_float4(y4[0], y4[1], y4[2], y4[3]);
@@ -572,21 +607,24 @@ __global__ __launch_bounds__(MHA_T) void mha_fwd_kernel(const float *__restrict_
 }
 
 template <int HD, int EE>
-__global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gsa,
-                                                        const float *__restrict__ Win, const float *__restrict__ bin,
-                                                        const float *__restrict__ Wo, const unsigned char *__restrict__ mask,
-                                                        const float *__restrict__ o_save, const float *__restrict__ ml_save,
-                                                        float *__restrict__ gxpart, float *__restrict__ pWin, float *__restrict__ pbin,
-                                                        float *__restrict__ pWo, float *__restrict__ pbo, int S, int B, int H,
-                                                        float qscale, float dscale) {
+__global__ __launch_bounds__(MHA_THREADS) void mha_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gsa,
+                                                              const float *__restrict__ Win, const float *__restrict__ bin,
+                                                              const float *__restrict__ Wo, const unsigned char *__restrict__ mask,
+                                                              const float *__restrict__ o_save, const float *__restrict__ ml_save,
+                                                              float *__restrict__ gxpart, float *__restrict__ pWin,
+                                                              float *__restrict__ pbin, float *__restrict__ pWo, float *__restrict__ pbo,
+                                                              int S, int B, int H, float qscale, float dscale) {
+    __shared__ MhaWeights<HD, EE> W;
     __shared__ float xs[MHA_T][EE + 1], gs[MHA_T][EE + 1];
     __shared__ float qkvd[4][MHA_T][HD];                  // Q (scaled), K, V, dO; later aliased by dqkv [MHA_T][3*HD]
     __shared__ float os[MHA_T][HD];
-    __shared__ float st[3][MHA_T];                        // m, 1/l, D
-    const int b = blockIdx.x, h = blockIdx.y, t = threadIdx.x;
+    __shared__ float st[3][MHA_T];                        // row max, 1 / row sum, D = dO . o
+    constexpr int JP = HD / MHA_P, EP = EE / MHA_P;
+    const int b = blockIdx.x, h = blockIdx.y, t = threadIdx.x >> 2, p = threadIdx.x & 3;
     const bool tv = t < S;
     const int SP = (S + 3) & ~3;
     const size_t row = (size_t)t * B + b, hs = ((size_t)b * H + h) * S + t;
+    mha_stage_weights<HD, EE>(W, Win, bin, Wo, h);
     float xr[EE], gr[EE];
 #pragma unroll
     for (int e = 0; e < EE; e += 4) {
@@ -595,132 +633,140 @@ __global__ __launch_bounds__(MHA_T) void mha_bwd_kernel(const float *__restrict_
         xr[e] = a.x; xr[e + 1] = a.y; xr[e + 2] = a.z; xr[e + 3] = a.w;
         gr[e] = g.x; gr[e + 1] = g.y; gr[e + 2] = g.z; gr[e + 3] = g.w;
     }
-    float q[HD], k[HD], v[HD], dO[HD], o[HD];
-    mha_project<HD, EE>(xr, Win, bin, h, qscale, q, k, v);
+#pragma unroll
+    for (int e = 0; e < EP; ++e) { xs[t][p * EP + e] = xr[p * EP + e]; gs[t][p * EP + e] = gr[p * EP + e]; }
+    __syncthreads();
+    mha_project<HD, EE>(W, xr, t, p, qscale, qkvd[0], qkvd[1], qkvd[2]);
+#pragma unroll
+    for (int jj = 0; jj < JP; ++jj) {
+        const int d = p * JP + jj;
+        float a = 0.f;
+#pragma unroll
+        for (int e = 0; e < EE; ++e) a = fmaf(gr[e], W.wo[e][d], a);
+        qkvd[3][t][d] = a;                                // dO = g_sa . Wo[:, head]
+        os[t][d] = tv ? o_save[hs * HD + d] : 0.f;
+    }
+    __syncthreads();
+    float q[HD], k[HD], v[HD], dO[HD];
     float D = 0.f;
 #pragma unroll
     for (int d = 0; d < HD; ++d) {
-        float a = 0.f;
-#pragma unroll
-        for (int e = 0; e < EE; ++e) a = fmaf(gr[e], Wo[(size_t)e * EE + h * HD + d], a);
-        dO[d] = a;
-        o[d] = tv ? o_save[hs * HD + d] : 0.f;
-        D = fmaf(a, o[d], D);
-        qkvd[0][t][d] = q[d]; qkvd[1][t][d] = k[d]; qkvd[2][t][d] = v[d]; qkvd[3][t][d] = a;
-        os[t][d] = o[d];
+        q[d] = qkvd[0][t][d]; k[d] = qkvd[1][t][d]; v[d] = qkvd[2][t][d]; dO[d] = qkvd[3][t][d];
+        D = fmaf(dO[d], os[t][d], D);
     }
-#pragma unroll
-    for (int e = 0; e < EE; ++e) { xs[t][e] = xr[e]; gs[t][e] = gr[e]; }
     const float m = tv ? ml_save[hs * 2] : 0.f, rl = tv ? 1.f / ml_save[hs * 2 + 1] : 0.f;
-    st[0][t] = m; st[1][t] = rl; st[2][t] = D;
+    if (p == 0) { st[0][t] = m; st[1][t] = rl; st[2][t] = D; }
     __syncthreads();
     const unsigned char *mbase = mask ? mask + ((size_t)b * H + h) * S * SP : nullptr;
-    // pass A: thread = query t, loop over keys -> dq' (gradient of the scaled query)
     float dq[HD], dk[HD], dv[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) dq[d] = dk[d] = dv[d] = 0.f;
+    // pass A: thread = (query t, every 4th key) -> dq' (gradient of the scaled query)
     {
         const unsigned char *mrow = mbase ? mbase + (size_t)(tv ? t : 0) * SP : nullptr;
-        for (int k4 = 0; k4 < SP; k4 += 4) {
-            const unsigned mw = mrow ? *reinterpret_cast<const unsigned *>(mrow + k4) : 0x01010101u;
+        for (int kk = p; kk < S; kk += MHA_P) {
+            float s = 0.f, dpd = 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int kk = k4 + j;
-                if (kk < S) {
-                    float s = 0.f, dpd = 0.f;
-#pragma unroll
-                    for (int d = 0; d < HD; ++d) {
-                        s = fmaf(q[d], qkvd[1][kk][d], s);
-                        dpd = fmaf(dO[d], qkvd[2][kk][d], dpd);
-                    }
-                    const float p = __expf(s - m) * rl;
-                    const float dp = ((mw >> (8 * j)) & 0xffu) ? dpd * dscale : 0.f;
-                    const float ds = p * (dp - D);
-#pragma unroll
-                    for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds, qkvd[1][kk][d], dq[d]);
-                }
+            for (int d = 0; d < HD; ++d) {
+                s = fmaf(q[d], qkvd[1][kk][d], s);
+                dpd = fmaf(dO[d], qkvd[2][kk][d], dpd);
             }
+            const float pr = __expf(s - m) * rl;
+            const float dp = (!mrow || mrow[kk]) ? dpd * dscale : 0.f;
+            const float ds = pr * (dp - D);
+#pragma unroll
+            for (int d = 0; d < HD; ++d) dq[d] = fmaf(ds, qkvd[1][kk][d], dq[d]);
         }
     }
-    // pass B: thread = key t, loop over queries -> dk, dv
-    for (int qq = 0; qq < S; ++qq) {
+    // pass B: thread = (key t, every 4th query) -> dk, dv
+    for (int qq = p; qq < S; qq += MHA_P) {
         float s = 0.f, dpd = 0.f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) {
             s = fmaf(qkvd[0][qq][d], k[d], s);
             dpd = fmaf(qkvd[3][qq][d], v[d], dpd);
         }
-        const float p = __expf(s - st[0][qq]) * st[1][qq];
-        const bool keep = mbase ? (tv ? mbase[(size_t)qq * SP + t] != 0 : false) : true;
-        const float pd = keep ? p * dscale : 0.f, dp = keep ? dpd * dscale : 0.f;
-        const float ds = p * (dp - st[2][qq]);
+        const float pr = __expf(s - st[0][qq]) * st[1][qq];
+        const bool keep = tv && (!mbase || mbase[(size_t)qq * SP + t] != 0);
+        const float pd = keep ? pr * dscale : 0.f, dp = keep ? dpd * dscale : 0.f;
+        const float ds = pr * (dp - st[2][qq]);
 #pragma unroll
         for (int d = 0; d < HD; ++d) {
             dv[d] = fmaf(pd, qkvd[3][qq][d], dv[d]);
             dk[d] = fmaf(ds, qkvd[0][qq][d], dk[d]);
         }
     }
-    __syncthreads();                                      // everyone is done with Q, K, V, dO: reuse the area for dqkv
-    float(*dqkv)[3 * HD] = reinterpret_cast<float(*)[3 * HD]>(&qkvd[0][0][0]);
 #pragma unroll
     for (int d = 0; d < HD; ++d) {
-        dq[d] = tv ? dq[d] * qscale : 0.f;                // gradient of the unscaled projection
-        dk[d] = tv ? dk[d] : 0.f;
-        dv[d] = tv ? dv[d] : 0.f;
-        dqkv[t][d] = dq[d]; dqkv[t][HD + d] = dk[d]; dqkv[t][2 * HD + d] = dv[d];
+        dq[d] = tv ? quad_sum(dq[d]) * qscale : 0.f;      // gradient of the unscaled projection
+        dk[d] = tv ? quad_sum(dk[d]) : 0.f;
+        dv[d] = tv ? quad_sum(dv[d]) : 0.f;
     }
-    // this head's part of the input gradient
-    if (tv) {
-        float *go = gxpart + ((size_t)h * S * B + row) * EE;
+    __syncthreads();                                      // everyone is done with Q, K, V, dO: reuse the area for dqkv
+    float(*dqkv)[3 * HD] = reinterpret_cast<float(*)[3 * HD]>(&qkvd[0][0][0]);
+    if (p == 0) {
 #pragma unroll
-        for (int e = 0; e < EE; e += 4) {
+        for (int d = 0; d < HD; ++d) { dqkv[t][d] = dq[d]; dqkv[t][HD + d] = dk[d]; dqkv[t][2 * HD + d] = dv[d]; }
+    }
+    // this head's part of the input gradient; part p writes features [p*EP, (p+1)*EP)
+    if (tv) {
+        float *go = gxpart + ((size_t)h * S * B + row) * EE + p * EP;
+#pragma unroll
+        for (int e = 0; e < EP; e += 4) {
             float a[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int j = 0; j < HD; ++j) {
-                const float *wq = Win + (size_t)(h * HD + j) * EE + e, *wk = wq + (size_t)EE * EE, *wv = wk + (size_t)EE * EE;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) a[c] = fmaf(dq[j], wq[c], fmaf(dk[j], wk[c], fmaf(dv[j], wv[c], a[c])));
+                const float4 wq = *reinterpret_cast<const float4 *>(&W.win[j][p * EP + e]);
+                const float4 wk = *reinterpret_cast<const float4 *>(&W.win[HD + j][p * EP + e]);
+                const float4 wv = *reinterpret_cast<const float4 *>(&W.win[2 * HD + j][p * EP + e]);
+                a[0] = fmaf(dq[j], wq.x, fmaf(dk[j], wk.x, fmaf(dv[j], wv.x, a[0])));
+                a[1] = fmaf(dq[j], wq.y, fmaf(dk[j], wk.y, fmaf(dv[j], wv.y, a[1])));
+                a[2] = fmaf(dq[j], wq.z, fmaf(dk[j], wk.z, fmaf(dv[j], wv.z, a[2])));
+                a[3] = fmaf(dq[j], wq.w, fmaf(dk[j], wk.w, fmaf(dv[j], wv.w, a[3])));
             }
             *reinterpret_cast<float4 *>(go + e) = make_float4(a[0], a[1], a[2], a[3]);
         }
     }
     __syncthreads();
-    // weight-gradient partials of this batch element (rows / columns of head h)
-    for (int idx = t; idx < 3 * HD * EE; idx += MHA_T) {
+    // weight-gradient partials of this batch element (rows / columns of head h): one output per thread, sums over the tokens
+    for (int idx = threadIdx.x; idx < 3 * HD * EE; idx += MHA_THREADS) {
         const int j = idx / EE, e = idx % EE;             // j: 0..HD-1 query rows, HD.. key rows, 2HD.. value rows
         float a = 0.f;
+#pragma unroll 4
         for (int s = 0; s < S; ++s) a = fmaf(dqkv[s][j], xs[s][e], a);
-        const int wrow = (j / HD) * EE + h * HD + j % HD;
-        pWin[((size_t)b * 3 * EE + wrow) * EE + e] = a;
+        pWin[((size_t)b * 3 * EE + (j / HD) * EE + h * HD + j % HD) * EE + e] = a;
     }
-    for (int idx = t; idx < EE * HD; idx += MHA_T) {
+    for (int idx = threadIdx.x; idx < EE * HD; idx += MHA_THREADS) {
         const int e = idx / HD, d = idx % HD;
         float a = 0.f;
+#pragma unroll 4
         for (int s = 0; s < S; ++s) a = fmaf(gs[s][e], os[s][d], a);
         pWo[((size_t)b * EE + e) * EE + h * HD + d] = a;
     }
-    if (t < 3 * HD) {
+    if (threadIdx.x < 3 * HD) {
+        const int j = threadIdx.x;
         float a = 0.f;
-        for (int s = 0; s < S; ++s) a += dqkv[s][t];
-        pbin[(size_t)b * 3 * EE + (t / HD) * EE + h * HD + t % HD] = a;
+        for (int s = 0; s < S; ++s) a += dqkv[s][j];
+        pbin[(size_t)b * 3 * EE + (j / HD) * EE + h * HD + j % HD] = a;
     }
-    if (h == 0 && t < EE) {
+    if (h == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + EE) {
+        const int e = threadIdx.x - 64;
         float a = 0.f;
-        for (int s = 0; s < S; ++s) a += gs[s][t];
-        pbo[(size_t)b * EE + t] = a;
+        for (int s = 0; s < S; ++s) a += gs[s][e];
+        pbo[(size_t)b * EE + e] = a;
     }
 }
 
 template <int HD, int EE>
 void mha_launch_fwd(dim3 grid, hipStream_t st, const float *x, const float *Win, const float *bin, const float *Wo, const unsigned char *mask,
                     float *ypart, float *o_save, float *ml_save, int S, int B, int H, float qscale, float dscale) {
-    hipLaunchKernelGGL((mha_fwd_kernel<HD, EE>), grid, dim3(MHA_T), 0, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+    hipLaunchKernelGGL((mha_fwd_kernel<HD, EE>), grid, dim3(MHA_THREADS), 0, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
 }
 template <int HD, int EE>
 void mha_launch_bwd(dim3 grid, hipStream_t st, const float *x, const float *gsa, const float *Win, const float *bin, const float *Wo,
                     const unsigned char *mask, const float *o_save, const float *ml_save, float *gxpart, float *pWin, float *pbin, float *pWo,
                     float *pbo, int S, int B, int H, float qscale, float dscale) {
-    hipLaunchKernelGGL((mha_bwd_kernel<HD, EE>), grid, dim3(MHA_T), 0, st, x, gsa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin, pbin, pWo,
+    hipLaunchKernelGGL((mha_bwd_kernel<HD, EE>), grid, dim3(MHA_THREADS), 0, st, x, gsa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin, pbin, pWo,
                        pbo, S, B, H, qscale, dscale);
 }
 }  // namespace

@@ -44,15 +44,25 @@ class _Residual(nn.Module):
         if stride != 1 or cin != cout:
             self.downsample = nn.Sequential(_conv(cin, cout, 1, stride), nn.BatchNorm2d(cout))
 
-    def forward(self, x):
+    def forward(self, x, tap=False):
+        """tap=True (units with a down-sample branch): -> (out, x') where x' is the unit's input handed through both of its
+        consumers' nodes — the encoder exports it as the previous stage's feature tap, so the decoder's skip gradient is
+        added inside the down-sample convolution's data-gradient kernel too."""
         # x has two consumers (conv1 and the shortcut): the second one reads the copy handed through conv1's node, so both
         # gradients meet in conv1's data-gradient kernel (nnops.conv_bn_act, skip=True)
         y, x = X.conv_bn_act(x, self.conv1, self.bn1, "relu", skip=True)
-        shortcut = x if self.downsample is None else X.conv_bn_act(x, self.downsample[0], self.downsample[1], None)
+        if self.downsample is None:
+            shortcut = x
+        elif tap:
+            shortcut, x = X.conv_bn_act(x, self.downsample[0], self.downsample[1], None, skip=True)
+        else:
+            shortcut = X.conv_bn_act(x, self.downsample[0], self.downsample[1], None)
         if self.kind == "bottleneck":
             y = X.conv_bn_act(y, self.conv2, self.bn2, "relu")
-            return X.conv_bn_act(y, self.conv3, self.bn3, "relu", residual=shortcut)
-        return X.conv_bn_act(y, self.conv2, self.bn2, "relu", residual=shortcut)
+            y = X.conv_bn_act(y, self.conv3, self.bn3, "relu", residual=shortcut)
+        else:
+            y = X.conv_bn_act(y, self.conv2, self.bn2, "relu", residual=shortcut)
+        return (y, x) if tap else y
 
 
 class ResNetTrunk(nn.Module):
@@ -91,12 +101,27 @@ class ResnetEncoder(nn.Module):
     def forward(self, input_image):
         e = self.encoder
         f0 = X.conv_bn_act(input_image, e.conv1, e.bn1, "relu", input_affine=(0.45, 0.225))   # (x-0.45)/0.225
-        f1 = e.layer1(X.maxpool3x3s2(f0))
-        f2 = e.layer2(f1)
-        f3 = e.layer3(f2)
-        f4 = e.layer4(f3)
+        # every tap but the last has two consumers (the next stage and the decoder's skip connection); the decoder reads the
+        # copy handed through the next stage's first nodes, so the two gradients meet in a kernel epilogue, not in an add pass
+        pooled, f0 = X.maxpool3x3s2(f0, skip=True)
+        f1 = e.layer1(pooled)
+        f2, f1 = self._stage(e.layer2, f1)
+        f3, f2 = self._stage(e.layer3, f2)
+        f4, f3 = self._stage(e.layer4, f3)
         self.features = [f0, f1, f2, f3, f4]
         return self.features
+
+    @staticmethod
+    def _stage(layer, x):
+        """-> (stage output, the stage input as handed through its first unit)"""
+        units = list(layer)
+        if units[0].downsample is None:
+            y, tap = units[0](x), x
+        else:
+            y, tap = units[0](x, tap=True)
+        for u in units[1:]:
+            y = u(y)
+        return y, tap
 
 
 class UpSampleBN(nn.Module):

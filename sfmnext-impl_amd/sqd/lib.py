@@ -132,7 +132,7 @@ _SIGNATURES = {
     "sqd_mha_fwd": (_I, [_P] * 8 + [_I, _I, _I, _I, _F, _P]),
     "sqd_mha_bwd": (_I, [_P] * 13 + [_I, _I, _I, _I, _F, _P]),
     "sqd_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
-    "sqd_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "sqd_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sqd_space_to_depth2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_stem_regroup": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sqd_smooth_nblk": (_I, [_I, _I]),

@@ -91,10 +91,12 @@ class BatchNormAct(torch.autograd.Function):
 
 
 class MaxPool3x3s2(torch.autograd.Function):
-    """nn.MaxPool2d(3, 2, 1) of the ResNet stem, channels-last; the backward is a deterministic gather."""
+    """nn.MaxPool2d(3, 2, 1) of the ResNet stem, channels-last; the backward is a deterministic gather.
+    skip=True: -> (y, x') with x' the input handed through this node: a second consumer of x (the decoder's skip connection)
+    reads x' instead, and its gradient is added inside the gather kernel instead of a separate accumulation pass."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, skip=False):
         _require(x, "MaxPool3x3s2 input")
         x = _cl(x)
         N, C, H, W = x.shape
@@ -104,16 +106,22 @@ class MaxPool3x3s2(torch.autograd.Function):
         _l.check(_l.lib().sqd_maxpool3x3s2_fwd(_ptr(x), _ptr(y), _ptr(idx), N, H, W, C, _stream()), "maxpool_fwd")
         ctx.save_for_backward(idx)
         ctx.dims = (N, C, H, W)
+        if skip:
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_skip=None):
         idx, = ctx.saved_tensors
         N, C, H, W = ctx.dims
+        if dy is None:
+            return g_skip, None
         dy = _cl(dy)
+        if g_skip is not None:
+            g_skip = _cl(g_skip)
         dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
-        _l.check(_l.lib().sqd_maxpool3x3s2_bwd(_ptr(dy), _ptr(idx), _ptr(dx), N, H, W, C, _stream()), "maxpool_bwd")
-        return dx
+        _l.check(_l.lib().sqd_maxpool3x3s2_bwd(_ptr(dy), _ptr(idx), _ptr(g_skip), _ptr(dx), N, H, W, C, _stream()), "maxpool_bwd")
+        return dx, None
 
 
 class UpsampleConcat(torch.autograd.Function):

@@ -112,13 +112,15 @@ def _bn_act(y, bn, act, residual, pre=None):
     return _act(y, act)
 
 
-def maxpool3x3s2(x):
+def maxpool3x3s2(x, skip=False):
+    """skip=True: -> (y, x') with x' to be read by x's other consumer (see nnkernels.MaxPool3x3s2)."""
     if x.is_cuda:
         from . import nnkernels
         if x.shape[1] % 4:
             raise RuntimeError("sqd: max-pool kernel needs a channel count that is a multiple of 4")
-        return nnkernels.MaxPool3x3s2.apply(x)
-    return F.max_pool2d(x, 3, 2, 1)      # host tensors: only the CPU wiring tests come here
+        return nnkernels.MaxPool3x3s2.apply(x, skip)
+    y = F.max_pool2d(x, 3, 2, 1)         # host tensors: only the CPU wiring tests come here
+    return (y, x) if skip else y
 
 
 def upsample_concat(x, skip):

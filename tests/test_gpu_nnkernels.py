@@ -128,3 +128,62 @@ def test_maxpool3x3s2_bit_exact(N, C, H, W):
     y.backward(gy.cuda())
     assert torch.equal(y.cpu(), yr.detach())
     assert torch.equal(xg.grad.cpu(), xr.grad)
+
+
+def test_maxpool3x3s2_skip_adds_second_consumer_gradient():
+    """skip=True: the input's second consumer reads x'; its gradient is added inside the gather kernel"""
+    from sqd import nnkernels
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 16, 9, 14, generator=g)
+    gy, g2 = torch.randn(2, 16, 5, 7, generator=g), torch.randn(2, 16, 9, 14, generator=g)
+    xr = x.clone().requires_grad_(True)
+    (F.max_pool2d(xr, 3, 2, 1) * gy).sum().backward()
+    ref = xr.grad + g2
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y, x2 = nnkernels.MaxPool3x3s2.apply(xg, True)
+    assert torch.equal(x2, xg)
+    ((y * gy.cuda()).sum() + (x2 * g2.cuda()).sum()).backward()
+    assert torch.allclose(xg.grad.cpu(), ref, rtol=0, atol=1e-6)
+    # only the second consumer carries a gradient
+    xg2 = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y, x2 = nnkernels.MaxPool3x3s2.apply(xg2, True)
+    (x2 * g2.cuda()).sum().backward()
+    assert torch.equal(xg2.grad.cpu(), g2)
+
+
+def test_encoder_taps_carry_the_same_values_and_gradients():
+    """the feature taps handed through the next stage's nodes (resnet_encoder.ResnetEncoder.forward) against the plain wiring:
+    same features, same parameter gradients when both the trunk and a decoder-like consumer use every tap"""
+    from networks.resnet_encoder import ResnetEncoder
+    from sqd import nnops
+    torch.manual_seed(3)
+    enc = ResnetEncoder(18).cuda().train()
+    nnops.set_native_conv(True)
+    try:
+        x = torch.rand(2, 3, 64, 96, device="cuda")
+        ws = [torch.randn(1, c, 1, 1, device="cuda") for c in enc.num_ch_enc]
+
+        def loss(feats):
+            return sum((f * w).mean() for f, w in zip(feats, ws))
+
+        feats = enc(x)
+        loss(feats).backward()
+        got = {n: p.grad.clone() for n, p in enc.named_parameters() if p.grad is not None}
+        vals = [f.detach().clone() for f in feats]
+        enc.zero_grad(set_to_none=True)
+        e = enc.encoder                                             # plain wiring: every tap consumed twice, autograd adds
+        f0 = nnops.conv_bn_act(x, e.conv1, e.bn1, "relu", input_affine=(0.45, 0.225))
+        f1 = e.layer1(nnops.maxpool3x3s2(f0))
+        f2 = e.layer2(f1)
+        f3 = e.layer3(f2)
+        f4 = e.layer4(f3)
+        plain = [f0, f1, f2, f3, f4]
+        loss(plain).backward()
+        for a, b in zip(vals, plain):
+            assert torch.equal(a, b.detach())
+        for n, p in enc.named_parameters():
+            if p.grad is not None:
+                err = (got[n] - p.grad).abs().max().item()
+                assert err <= 1e-5 * max(p.grad.abs().max().item(), 1e-6), (n, err)
+    finally:
+        nnops.set_native_conv(False)

@@ -198,14 +198,13 @@ def test_encoder_stack_with_masks_matches_node_composition():
         x = nnkernels.EncoderTail.apply(x, sa, m1, mf, m2, g1, be1, W1, b1, W2, b2, g2, be2, scale, 1e-5, 1e-5)
     x.backward(gout)
     # 6 M hidden pre-activations, two fp32 paths with different partial-sum orders: a handful sit within rounding of the ReLU
-    # kink and take different branches (see _kink_free), each moving one token's / one hidden unit's gradients by ~1e-2 of the
-    # tensor's scale.  So: the whole tensor within 3e-3 in relative L2, and for the large tensors all but a sliver of the elements within 1e-4.
+    # kink and take different branches (see _kink_free); each flip moves one token's gradient by ~1e-2 of the tensor's scale,
+    # and through the layers below it, many weight-gradient entries by ~1e-4.  So the comparison is in relative L2 (a wrong
+    # mask, a missing term or a mis-indexed head shows up as O(0.1 .. 1) there).
     def mostly_close(a, b, what):
         a, b = a.detach().double().cpu(), b.detach().double().cpu()
-        err, scale = (a - b).abs(), max(b.abs().max().item(), 1e-6)
-        frac = (err > 1e-4 * scale).double().mean().item()
         rel = (a - b).norm().item() / max(b.norm().item(), 1e-12)
-        assert (frac <= 0.02 or a.numel() < 10000) and rel <= 3e-3, "%s: %.2f %% of the elements off, relative L2 %.2e" % (what, 100 * frac, rel)
+        assert rel <= 3e-3, "%s: relative L2 error %.2e" % (what, rel)
     mostly_close(out_a, x, "stack output")
     mostly_close(xa.grad, xb.grad, "g_tokens")
     names = [n for l in range(4) for n in ("Win", "bin", "Wo", "bo", "g1", "be1", "W1", "b1", "W2", "b2", "g2", "be2")]
