@@ -124,6 +124,8 @@ class GradBucketReducer:
         self._pending[bi] -= 1
         if self._pending[bi] == 0:
             plist, views = self.buckets[bi], self.views[bi]
+            from . import nnkernels
+            nnkernels.join_wgrad_stream()                               # the convolutions' weight gradients run on their own stream
             torch._foreach_copy_(views, [q.grad for q in plist])        # gather the bucket: one multi-tensor copy
             for q, v in zip(plist, views):
                 q.grad = v                                              # the optimiser reads the (averaged) bucket memory

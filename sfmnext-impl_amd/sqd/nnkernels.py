@@ -268,6 +268,16 @@ def conv_module_supported(conv):
             and conv.dilation == (1, 1) and conv.groups == 1 and not isinstance(p, str))
 
 
+# stream the weight-gradient kernels run on (None: the caller's stream).  The Trainer sets it; whoever calls backward() must
+# call join_wgrad_stream() before the gradients are read (optimiser, all-reduce).
+WGRAD_STREAM = None
+
+
+def join_wgrad_stream():
+    if WGRAD_STREAM is not None:
+        torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
+
+
 class Conv2d(torch.autograd.Function):
     """nn.Conv2d (square stride / padding, dilation 1, groups 1) on the fp32 matrix cores, channels-last.
     forward(x [N,C,H,W], weight [K,C,R,S], bias [K] | None, stride, pad, act, skip) -> y [N,K,Ho,Wo]  (skip: -> (y, x'))
@@ -314,6 +324,36 @@ class Conv2d(torch.autograd.Function):
             dy = torch.ops.aten.threshold_backward(dy, y, 0.0)         # dy where y > 0 else 0, one launch
         L = _l.lib()
         dx = dw = db = None
+        if ctx.needs_input_grad[1]:
+            if TUNE_CONV:
+                dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
+                db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+                _tune_wgrad(ctx.geom, ctx.has_bias,
+                            lambda part: L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride,
+                                                          pad, Ho, Wo, _stream()))
+            # the weight gradient has no consumer before the optimiser: it runs on its own stream, next to the data gradient
+            # and whatever follows it (two kernels that each leave CUs idle in their ramp and tail fill the chip together)
+            cur, side = torch.cuda.current_stream(), WGRAD_STREAM
+            if side is not None:
+                side.wait_stream(cur)
+                torch.cuda.set_stream(side)
+            try:
+                dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
+                db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+                pf, splits = _wgrad_part_floats(ctx.geom)
+                extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if ctx.has_bias else 0
+                part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
+                _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
+                                          _stream()), "conv_wgrad")
+            finally:
+                if side is not None:
+                    torch.cuda.set_stream(cur)
+            if side is not None:
+                dy.record_stream(side)
+                x.record_stream(side)
+                dw.record_stream(cur)
+                if db is not None:
+                    db.record_stream(cur)
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
             if TUNE_CONV:
@@ -324,18 +364,6 @@ class Conv2d(torch.autograd.Function):
                                       _stream()), "conv_dgrad")
         elif g_skip is not None:
             dx = g_skip
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
-            db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
-            if TUNE_CONV:
-                _tune_wgrad(ctx.geom, ctx.has_bias,
-                            lambda part: L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride,
-                                                          pad, Ho, Wo, _stream()))
-            pf, splits = _wgrad_part_floats(ctx.geom)
-            extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if ctx.has_bias else 0
-            part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
-            _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
-                                      _stream()), "conv_wgrad")
         return dx, dw, db, None, None, None, None, None, None
 
 

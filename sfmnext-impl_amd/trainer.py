@@ -114,6 +114,8 @@ class Trainer:
             (self.reducer is None or self.opt.sqd_graph_ddp)
         self._side_stream = torch.cuda.Stream(device=self.device)
         self._pose_stream = torch.cuda.Stream(device=self.device)
+        # weight-gradient kernels of the convolutions on their own stream (SQD_NO_WGRAD_STREAM=1: A/B runs)
+        self._wgrad_stream = None if os.environ.get("SQD_NO_WGRAD_STREAM") else torch.cuda.Stream(device=self.device)
         self._graph_stream = torch.cuda.Stream(device=self.device) if self._graph_ok else None
         self._build_loaders()
         self.writers = {m: (_make_writer(os.path.join(self.log_path, m)) if self.rank == 0 else _NullWriter())
@@ -249,7 +251,7 @@ class Trainer:
         try:
             with torch.cuda.graph(g, stream=self._graph_stream):
                 outputs, losses = self.process_batch(self._static_in)
-                losses["loss"].backward()
+                self._backward(losses["loss"])
                 opt.step()
         finally:
             self._capturing = False
@@ -275,7 +277,7 @@ class Trainer:
             # "global" mode it aborts the process (hipErrorCapturedEvent)
             with torch.cuda.graph(g, stream=self._graph_stream, capture_error_mode="thread_local"):
                 outputs, losses = self.process_batch(self._static_in)
-                losses["loss"].backward()
+                self._backward(losses["loss"])
                 # fresh gradients (assigned, not accumulated: no memsets, no ~170 accumulate launches) -> the buckets, as
                 # a couple of multi-tensor copies
                 params = [p for p in views if p.grad is not None]
@@ -286,13 +288,23 @@ class Trainer:
             p.grad = v
         self._graph, self._static_out = g, (outputs, losses)
 
+    def _backward(self, loss):
+        # eager steps: the convolutions' weight gradients run on their own stream, next to the data gradients (-0.8 ms per
+        # step).  Not inside a capture: a hipGraph with ~110 extra cross-branch edges replays 1.3 ms slower than the linear one.
+        nnkernels.WGRAD_STREAM = None if getattr(self, "_capturing", False) else self._wgrad_stream
+        try:
+            loss.backward()
+            nnkernels.join_wgrad_stream()                # the caller's stream joins it before anything reads the gradients
+        finally:
+            nnkernels.WGRAD_STREAM = None
+
     def _train_step_eager(self, inputs):
         outputs, losses = self.process_batch(inputs)
         if self.reducer is not None:
             self.reducer.zero_grad()
         else:
             self.model_optimizer.zero_grad(set_to_none=True)
-        losses["loss"].backward()
+        self._backward(losses["loss"])
         if self.reducer is not None:
             self.reducer.finish()
         self.model_optimizer.step()
