@@ -271,10 +271,33 @@ def conv_module_supported(conv):
 # stream the weight-gradient kernels run on (None: the caller's stream).  The Trainer sets it; whoever calls backward() must
 # call join_wgrad_stream() before the gradients are read (optimiser, all-reduce).
 WGRAD_STREAM = None
+WGRAD_BATCH = int(os.environ.get("SQD_WGRAD_BATCH", "1"))
+_PENDING_WGRAD = {}          # raw stream handle -> (stream the operands are produced on, [(launch, tensors)])
+
+
+def flush_wgrads():
+    """launch the queued weight-gradient kernels on WGRAD_STREAM (after everything their producer streams hold so far)"""
+    side = WGRAD_STREAM
+    for key in list(_PENDING_WGRAD):
+        src, q = _PENDING_WGRAD.pop(key)
+        if not q:
+            continue
+        side.wait_stream(src)
+        cur = torch.cuda.current_stream()
+        torch.cuda.set_stream(side)
+        try:
+            for launch, tensors in q:
+                launch()
+                for t in tensors:
+                    if t is not None:
+                        t.record_stream(side)
+        finally:
+            torch.cuda.set_stream(cur)
 
 
 def join_wgrad_stream():
     if WGRAD_STREAM is not None:
+        flush_wgrads()
         torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
 
 
@@ -331,29 +354,26 @@ class Conv2d(torch.autograd.Function):
                 _tune_wgrad(ctx.geom, ctx.has_bias,
                             lambda part: L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride,
                                                           pad, Ho, Wo, _stream()))
-            # the weight gradient has no consumer before the optimiser: it runs on its own stream, next to the data gradient
-            # and whatever follows it (two kernels that each leave CUs idle in their ramp and tail fill the chip together)
-            cur, side = torch.cuda.current_stream(), WGRAD_STREAM
-            if side is not None:
-                side.wait_stream(cur)
-                torch.cuda.set_stream(side)
-            try:
-                dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
-                db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
-                pf, splits = _wgrad_part_floats(ctx.geom)
-                extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if ctx.has_bias else 0
-                part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
+            dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
+            db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+            pf, splits = _wgrad_part_floats(ctx.geom)
+            extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if ctx.has_bias else 0
+            part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
+
+            def launch(dy=dy, x=x, dw=dw, db=db, part=part):
                 _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
                                           _stream()), "conv_wgrad")
-            finally:
-                if side is not None:
-                    torch.cuda.set_stream(cur)
-            if side is not None:
-                dy.record_stream(side)
-                x.record_stream(side)
-                dw.record_stream(cur)
-                if db is not None:
-                    db.record_stream(cur)
+            if WGRAD_STREAM is None:
+                launch()
+            else:
+                # the weight gradient has no consumer before the optimiser: it is queued and runs on its own stream, next to
+                # the data gradients that follow (two kernels that each leave CUs idle in their ramp and tail fill the chip
+                # together).  Queued in batches: one cross-stream dependency per WGRAD_BATCH convolutions.
+                cur = torch.cuda.current_stream()
+                q = _PENDING_WGRAD.setdefault(cur.cuda_stream, (cur, []))[1]
+                q.append((launch, (dy, x, part, dw, db)))
+                if len(q) >= WGRAD_BATCH:
+                    flush_wgrads()
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
             if TUNE_CONV:

@@ -291,7 +291,7 @@ class Trainer:
     def _backward(self, loss):
         # eager steps: the convolutions' weight gradients run on their own stream, next to the data gradients (-0.8 ms per
         # step).  Not inside a capture: a hipGraph with ~110 extra cross-branch edges replays 1.3 ms slower than the linear one.
-        nnkernels.WGRAD_STREAM = None if getattr(self, "_capturing", False) else self._wgrad_stream
+        nnkernels.WGRAD_STREAM = None if (getattr(self, "_capturing", False) and not os.environ.get("SQD_WGRAD_GRAPH")) else self._wgrad_stream
         try:
             loss.backward()
             nnkernels.join_wgrad_stream()                # the caller's stream joins it before anything reads the gradients
@@ -336,7 +336,7 @@ class Trainer:
         self._launch_identity(inputs)
         nnkernels.defer_bn_counters(True)
         try:
-            fork = self._capturing and self.use_pose_net and not os.environ.get("SQD_NO_POSE_FORK")
+            fork = (self._capturing or os.environ.get("SQD_POSE_FORK_EAGER")) and self.use_pose_net and not os.environ.get("SQD_NO_POSE_FORK")
             if fork:
                 # inside the graph the pose network (which only needs the input frames) is a parallel branch: its small
                 # convolutions — and, through autograd's stream bookkeeping, their backward — fill the gaps the
