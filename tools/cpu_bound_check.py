@@ -36,4 +36,4 @@ for _ in range(5):
     tr.train_step(dict(inputs))
 pr.disable()
 torch.cuda.synchronize()
-pstats.Stats(pr).sort_stats("tottime").print_stats(22)
+pstats.Stats(pr).sort_stats("tottime").print_stats(45)
