@@ -119,7 +119,9 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d must be launched with %d ranks (torchrun); WORLD_SIZE=%d" % (args.gpus, args.gpus, world))
     opts = MonodepthOptions().parse(CONFIG_B + os.environ.get("SQD_BENCH_EXTRA", "").split())
-    trainer = Trainer(opts)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):          # the Trainer's banner goes to stderr: stdout carries the one JSON line
+        trainer = Trainer(opts)
     trainer.set_train()
     rank, dev = trainer.rank, trainer.device
     inputs = synthetic_batch(opts.batch_size, opts.height, opts.width, opts.frame_ids, start=rank * opts.batch_size, device=dev)

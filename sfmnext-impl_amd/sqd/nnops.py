@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 BACKEND = {
     "conv2d": "aten", "conv_bn_act": "aten conv + hip bn/act/residual", "maxpool3x3s2": "hip", "upsample_concat": "hip",
-    "linear": "aten", "transformer_encoder": "hip feed-forward + add/dropout/layernorm; aten self-attention", "full_query_layer": "hip", "bins_head": "hip",
+    "linear": "aten", "transformer_encoder": "hip (fused attention, feed-forward, add+dropout+layernorm; > 128 tokens: aten attention)", "full_query_layer": "hip", "bins_head": "hip",
 }
 
 
