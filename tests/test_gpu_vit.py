@@ -222,9 +222,10 @@ def _encoder(E, Fh, p, seed):
     return enc
 
 
-@pytest.mark.parametrize("S,B,E,Fh", [(120, 12, 32, 1024), (120, 2, 16, 512), (15, 3, 32, 1024)])
+@pytest.mark.parametrize("S,B,E,Fh", [(120, 12, 32, 1024), (120, 2, 16, 512), (15, 3, 32, 1024), (200, 2, 32, 1024)])
 def test_encoder_matches_torch(S, B, E, Fh):
-    """dropout 0 in training mode: outputs and every parameter gradient against nn.TransformerEncoder in fp64 on the CPU."""
+    """dropout 0 in training mode: outputs and every parameter gradient against nn.TransformerEncoder in fp64 on the CPU.
+    S = 200 (the 320x1024 configurations) exceeds the fused attention's 128 tokens: torch attention + EncoderTail."""
     from sqd import nnkernels, nnops
     enc = _encoder(E, Fh, 0.0, S + B)
     tokens = torch.randn(S, B, E)
@@ -245,11 +246,13 @@ def test_encoder_matches_torch(S, B, E, Fh):
         _close(q.grad, r.grad, name, 2e-4)
 
 
-def test_encoder_dropout_statistics():
-    """training mode, p = 0.1: masks are fresh per call, keep ~90 %, and eval mode is dropout-free and deterministic."""
+@pytest.mark.parametrize("S", [120, 200])
+def test_encoder_dropout_statistics(S):
+    """training mode, p = 0.1: masks are fresh per call, keep ~90 %, and eval mode is dropout-free and deterministic
+    (S = 200: the torch-attention + EncoderTail path)."""
     from sqd import nnops
     enc = _encoder(32, 1024, 0.1, 7).cuda()
-    x = torch.randn(120, 12, 32, device="cuda")
+    x = torch.randn(S, 12, 32, device="cuda")
     enc.train()
     a, b = nnops.transformer_encoder(x, enc), nnops.transformer_encoder(x, enc)
     assert not torch.equal(a, b)
