@@ -65,9 +65,19 @@ def roofline_fused_fwd(trainer, inputs, iters=200):
     px = B * H * W
     t = res["train"]
     achieved = FUSED_FWD_BYTES_PER_PX * px / t / 1e9
+    # HBM-side bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected separately and corrected with
+    # the dword-access calibration of tools/pmc_calib.py, as the microarchitecture guide prescribes); a committed measurement
+    # of this kernel at this size — PMC counters cannot be read from inside this process
+    traffic = traffic_bytes = None
+    pmc = os.path.join(REPO, "profiles", "r01k_pmc_traffic.json")
+    if os.path.exists(pmc) and (B, H, W) == (12, 192, 640):
+        traffic_bytes = json.load(open(pmc))["kernels"]["photo_fwd_pk_kernel<1>"]["traffic_bytes"]
+        traffic = round(traffic_bytes / t / 1e9, 1)
     return {"bound": "hbm", "kernel": "photo_fwd_pk_kernel<1> (fused warp+SSIM+L1+automask fwd, training mode: also writes the 37 B/px coef+argmin maps)",
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": None, "us_per_launch": round(t * 1e6, 2), "us_per_launch_inference": round(res["infer"] * 1e6, 2),
+            "traffic": traffic, "traffic_bytes_per_launch": traffic_bytes,
+            "traffic_source": "profiles/r01k_pmc_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, dword calibration x2.0 / x1.0)" if traffic else None,
+            "us_per_launch": round(t * 1e6, 2), "us_per_launch_inference": round(res["infer"] * 1e6, 2),
             "algorithmic_bytes_per_launch": FUSED_FWD_BYTES_PER_PX * px, "pixels_per_launch": px}
 
 

@@ -1,0 +1,39 @@
+"""Corrected HBM traffic of the fused warp+SSIM kernel from rocprofv3 PMC passes.
+usage: python tools/pmc_traffic.py <dir with the --pmc FETCH_SIZE / WRITE_SIZE output of pmc_calib.py and bench_fused.py> <out.json>
+FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch.  Correction = known bytes / reported bytes of the calibration
+kernel with the same access width (dword loads / dword stores), as MI355X_MICROARCH.md's HBM section prescribes."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+root, out = sys.argv[1], sys.argv[2]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+
+
+def avg(sub, counter):
+    for k, cs in acc.items():
+        if sub in k and counter in cs:
+            v = cs[counter][len(cs[counter]) // 2:]          # second half of the dispatches: caches and clocks settled
+            return sum(v) / len(v) * 1024.0
+    raise SystemExit("no %s for %s under %s" % (counter, sub, root))
+
+
+GIB = float(1 << 30)
+cal = {"read_dword": GIB / avg("calib_read_dword", "FETCH_SIZE"), "read_f4": GIB / avg("calib_read_f4", "FETCH_SIZE"),
+       "write_dword": GIB / avg("calib_write_dword", "WRITE_SIZE"), "write_f4": GIB / avg("calib_write_f4", "WRITE_SIZE")}
+res = {"calibration_factor": {k: round(v, 4) for k, v in cal.items()}, "kernels": {}}
+for name in ("photo_fwd_pk_kernel<1>", "photo_fwd_pk_kernel<0>", "photo_bwd_kernel"):
+    try:
+        fr, wr = avg(name, "FETCH_SIZE"), avg(name, "WRITE_SIZE")
+    except SystemExit:
+        continue
+    res["kernels"][name] = {"fetch_reported_bytes": round(fr), "write_reported_bytes": round(wr),
+                            "fetch_corrected_bytes": round(fr * cal["read_dword"]), "write_corrected_bytes": round(wr * cal["write_dword"]),
+                            "traffic_bytes": round(fr * cal["read_dword"] + wr * cal["write_dword"])}
+json.dump(res, open(out, "w"), indent=1)
+print(json.dumps(res, indent=1))
