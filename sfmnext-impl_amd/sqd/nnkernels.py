@@ -97,6 +97,7 @@ class MaxPool3x3s2(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, skip=False):
+        ctx.set_materialize_grads(False)
         _require(x, "MaxPool3x3s2 input")
         x = _cl(x)
         N, C, H, W = x.shape
@@ -312,6 +313,7 @@ class Conv2d(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, act, skip=False, out_hw=None, stats=None):
+        ctx.set_materialize_grads(False)                 # an unused output arrives as None in backward, not as a zero tensor
         _require(x, "Conv2d input")
         x, w = _cl(x), _cl(weight)
         N, C, H, W = x.shape

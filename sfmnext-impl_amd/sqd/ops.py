@@ -244,6 +244,7 @@ class PhotometricChain(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, disp_lr, axisangle, translation, K, inv_K, target, identity, meta, *sources):
+        ctx.set_materialize_grads(False)         # 9 of the 10+ outputs never carry a gradient: no zero tensors for them
         H, W = meta["H"], meta["W"]
         B, S = target.shape[0], len(sources)
         rows = meta.get("rows_per_task", 0)
@@ -264,6 +265,8 @@ class PhotometricChain(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_total, *_unused):
+        if g_total is None:
+            return (None,) * (8 + ctx.S)
         meta, S = ctx.meta, ctx.S
         saved = ctx.saved_tensors
         disp_lr, axisangle, translation, K, inv_K, target, depth, part, mid, P, idx, coef, sm_part = saved[:13]
