@@ -1,0 +1,62 @@
+"""End-to-end parity of one training step at BASELINE.json's flagship configurations — ResNet-50 + Depth_Decoder_QueryTr at
+192x640 (configs[1]) and at 320x1024 (configs[2]: 320 patch tokens, the encoder path beyond the fused attention's 128) — against
+the oracle restatement on the host: same weights, same batch, same tie-break noise, dropout off.  Batch 2 / 1 keeps the oracle's
+CPU step in seconds; every kernel still runs at the full image size."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _args(H, W, B, extra):
+    return ["--backbone", "resnet", "--num_layers", "50", "--num_features", "256", "--model_dim", "32", "--patch_size", "16",
+            "--query_nums", "64", "--dim_out", "64", "--height", str(H), "--width", str(W), "--batch_size", str(B),
+            "--min_depth", "0.001", "--max_depth", "80.0", "--num_workers", "0", "--sqd_synthetic",
+            "--log_dir", "/tmp/sqd_full_cfg_test", "--sqd_no_conv_tune"] + extra
+
+
+@pytest.mark.parametrize("H,W,B", [(192, 640, 2), (320, 1024, 1)])
+def test_flagship_step_matches_oracle(H, W, B):
+    sys.path.insert(0, REPO)
+    from oracle import torch_ref as O
+    from options import MonodepthOptions
+    from trainer import Trainer
+    from datasets.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    tr = Trainer(MonodepthOptions().parse(_args(H, W, B, ["--sqd_no_graph"])))
+    tr.set_train()
+    for m in tr.models.values():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+    enc = O.ResnetEncoderDecoder(50, 256, 32)
+    dep = O.QueryTrDecoder(32, 32, 16, 4, 64, 64, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
+    pose = O.PoseCNN(2)
+    for ref, mine in ((enc, tr.models["encoder"]), (dep, tr.models["depth"]), (pose, tr.models["pose"])):
+        ref.load_state_dict({k: v.detach().cpu() for k, v in mine.state_dict().items()})
+        ref.train()
+    cpu_inputs = synthetic_batch(B, H, W)
+    noise = torch.randn(B, 2, H, W)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    ref = O.RefTrainStep(enc, dep, pose, (0, -1, 1), H, W)
+    ref_out, ref_losses = ref.step(dict(cpu_inputs), noise)
+    inputs = {k: v.cuda() for k, v in cpu_inputs.items()}
+    inputs[("noise", 0)] = noise.cuda()
+    outputs, losses = tr.train_step(inputs)
+    torch.cuda.synchronize()
+    got, want = float(losses["loss"]), float(ref_losses["loss"])
+    assert abs(got - want) <= 1e-4 * abs(want), (got, want)
+    disp, disp_ref = outputs[("disp", 0)].detach().cpu(), ref_out[("disp", 0)].detach()
+    assert float((disp - disp_ref).abs().max()) <= 1e-4 * float(disp_ref.abs().max()), "predicted disparity"
+    # the optimiser step: Adam moves every weight by ~lr, so compare the UPDATE of a few tensors (first / last layers of each net)
+    for net, mine, name in ((pose, tr.models["pose"], "pose_conv.weight"), (enc, tr.models["encoder"], "decoder.conv3.weight"),
+                            (dep, tr.models["depth"], "convert_to_prob.0.weight")):
+        w_ref = dict(net.named_parameters())[name].detach()
+        w_got = dict(mine.named_parameters())[name].detach().cpu()
+        assert torch.allclose(w_got, w_ref, atol=5e-5), (name, float((w_got - w_ref).abs().max()))
