@@ -37,9 +37,35 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// ---- split-precision operands (PREC = 1): an fp32 value is the exact sum of three bf16 terms (8 significant bits each:
+// hi = its upper 16 bits, mid = the upper 16 bits of x - hi, lo = the rest), so a product a*b is the sum of 9 bf16 x bf16
+// products, each exact in the fp32 accumulator of v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  The kernel keeps the
+// 6 terms down to 2^-24 relative (drops mid*lo, lo*mid, lo*lo) — fp32-level accuracy at 6/16 of the matrix-core time.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+struct Split4 {
+    uint2 t[3];                       // term -> 4 bf16 (elements 0..3, element 0 in the low half of .x)
+};
+__device__ __forceinline__ unsigned hi16pair(float lo_elem, float hi_elem) {
+    return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
+}
+__device__ __forceinline__ float trunc_bf16(float x) { return __uint_as_float(__float_as_uint(x) & 0xffff0000u); }
+__device__ __forceinline__ Split4 split3(float4 v) {
+    Split4 r;
+    r.t[0] = make_uint2(hi16pair(v.x, v.y), hi16pair(v.z, v.w));
+    const float4 a = make_float4(v.x - trunc_bf16(v.x), v.y - trunc_bf16(v.y), v.z - trunc_bf16(v.z), v.w - trunc_bf16(v.w));
+    r.t[1] = make_uint2(hi16pair(a.x, a.y), hi16pair(a.z, a.w));
+    const float4 b = make_float4(a.x - trunc_bf16(a.x), a.y - trunc_bf16(a.y), a.z - trunc_bf16(a.z), a.w - trunc_bf16(a.w));
+    r.t[2] = make_uint2(hi16pair(b.x, b.y), hi16pair(b.z, b.w));
+    return r;
+}
+__device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
 // MODE 0: forward (A rows = output pixels, gather x; B rows = out channels k, reduction over (r,s,c))
 // MODE 1: dgrad   (A rows = input pixels, gather dy; B rows = in channels c, reduction over (r,s,k))
-template <int MODE, int BM, int BN, int WGM, int WGN, int BKT>
+template <int MODE, int BM, int BN, int WGM, int WGN, int BKT, int PREC = 0>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
                                                         const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
                                                         int act, int zsplits, int order, float *__restrict__ stats) {
@@ -50,8 +76,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
     constexpr int NQ = BKT / 4, LDPT = BKT + 4, RPP = 256 / NQ;  // float4 per staged row, LDS row pitch, rows per staging pass
     constexpr int A_F4 = BM * NQ / 256;
     static_assert(A_F4 >= 1 && (BKT == 16 || BKT == 32), "BM >= 64, BKT in {16, 32}");
-    __shared__ __attribute__((aligned(16))) float As[2][BM][LDPT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN][LDPT];
+    constexpr int LDH = BKT + 8;                                // PREC 1: bf16 row pitch (48 / 80 bytes: conflict-free b128 reads)
+    __shared__ __attribute__((aligned(16))) float As[PREC ? 1 : 2][PREC ? 1 : BM][LDPT];
+    __shared__ __attribute__((aligned(16))) float Bs[PREC ? 1 : 2][PREC ? 1 : BN][LDPT];
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[PREC ? 2 : 1][3][PREC ? BM : 1][LDH];   // [buffer][term][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short Bh[PREC ? 2 : 1][3][PREC ? BN : 1][LDH];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm0 = (wave / WGN) * (WTM * 32), wn0 = (wave % WGN) * (WTN * 32);
@@ -170,6 +199,38 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
         }
     };
     auto store_ab = [&](int buf, const float4 *ra, const float4 *rb) {
+        if (PREC) {
+#pragma unroll
+            for (int i = 0; i < A_F4; ++i) {
+                const Split4 sp = split3(ra[i]);
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<uint2 *>(&Ah[buf][tm][arow + RPP * i][c4 * 4]) = sp.t[tm];
+            }
+#pragma unroll
+            for (int i = 0; i < B_F4; ++i) {
+                const int idx = t + 256 * i;
+                const Split4 sp = split3(rb[i]);
+                if (MODE == 0) {
+                    const int row = idx / NQ, q4 = idx % NQ;
+                    if (row < BN) {
+#pragma unroll
+                        for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<uint2 *>(&Bh[buf][tm][row][q4 * 4]) = sp.t[tm];
+                    }
+                } else {
+                    const int kk = idx % BKT, cq = idx / BKT;
+                    if (cq * 4 < BN) {
+#pragma unroll
+                        for (int tm = 0; tm < 3; ++tm) {
+                            Bh[buf][tm][cq * 4 + 0][kk] = (unsigned short)(sp.t[tm].x & 0xffffu);
+                            Bh[buf][tm][cq * 4 + 1][kk] = (unsigned short)(sp.t[tm].x >> 16);
+                            Bh[buf][tm][cq * 4 + 2][kk] = (unsigned short)(sp.t[tm].y & 0xffffu);
+                            Bh[buf][tm][cq * 4 + 3][kk] = (unsigned short)(sp.t[tm].y >> 16);
+                        }
+                    }
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4 *>(&As[buf][arow + RPP * i][c4 * 4]) = ra[i];
 #pragma unroll
@@ -238,8 +299,33 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
         // half-wave h owns reduction elements [h*BKT/2, (h+1)*BKT/2) of the slice, 8 at a time
 #pragma unroll
         for (int part = 0; part < BKT / 16; ++part) {
-            float af[WTM][8], bf[WTN][8];
             const int e0 = (BKT / 2) * h + 8 * part;
+            if (PREC) {
+                // one 32x32x16 bf16 MFMA consumes the 8 elements of both half-waves; 6 term pairs, smallest first
+                u32x4 ah[WTM][3], bh[WTN][3];
+#pragma unroll
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int tm = 0; tm < 3; ++tm) ah[i][tm] = *reinterpret_cast<const u32x4 *>(&Ah[cur][tm][wm0 + i * 32 + row][e0]);
+#pragma unroll
+                for (int j = 0; j < WTN; ++j)
+#pragma unroll
+                    for (int tm = 0; tm < 3; ++tm) bh[j][tm] = *reinterpret_cast<const u32x4 *>(&Bh[cur][tm][wn0 + j * 32 + row][e0]);
+#pragma unroll
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j) {
+                        f32x16 c = acc[i][j];
+                        c = mfma_bf(ah[i][0], bh[j][2], c);
+                        c = mfma_bf(ah[i][2], bh[j][0], c);
+                        c = mfma_bf(ah[i][1], bh[j][1], c);
+                        c = mfma_bf(ah[i][0], bh[j][1], c);
+                        c = mfma_bf(ah[i][1], bh[j][0], c);
+                        acc[i][j] = mfma_bf(ah[i][0], bh[j][0], c);
+                    }
+                continue;
+            }
+            float af[WTM][8], bf[WTN][8];
 #pragma unroll
             for (int i = 0; i < WTM; ++i) {
                 const float4 v0 = *reinterpret_cast<const float4 *>(&As[cur][wm0 + i * 32 + row][e0]);
@@ -804,10 +890,11 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     return p;
 }
 
-#define LAUNCH_GEMM(MODE, BM, BN, WGM, WGN, BKT)                                                                               \
-    hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT>),                                                \
+#define LAUNCH_GEMM_P(MODE, BM, BN, WGM, WGN, BKT, PREC)                                                                 \
+    hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT, PREC>),                                           \
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(256), 0, st, \
                        a_src, w, bias, dst, g, act, p.z, order, stats)
+#define LAUNCH_GEMM(MODE, BM, BN, WGM, WGN, BKT) LAUNCH_GEMM_P(MODE, BM, BN, WGM, WGN, BKT, 0)
 #define DISPATCH_GEMM(MODE)                                                      \
     if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM(MODE, 128, 128, 2, 2, 16);       \
     else if (p.bm == 128 && p.bn == 64) {                                        \
@@ -823,6 +910,20 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
         if (p.bk == 32) LAUNCH_GEMM(MODE, 64, 64, 2, 2, 32);                     \
         else LAUNCH_GEMM(MODE, 64, 64, 2, 2, 16);                                \
     }
+// split-precision variants: the three bf16 planes need 1.5x the LDS of the fp32 tile, so 128x128 runs as 128x64 and only the
+// 64x64 tile keeps the 32-channel slice
+#define DISPATCH_GEMM_BF(MODE)                                                   \
+    if (p.bm == 128 && p.bn >= 64) LAUNCH_GEMM_P(MODE, 128, 64, 2, 2, 16, 1);    \
+    else if (p.bm == 128) LAUNCH_GEMM_P(MODE, 128, 32, 4, 1, 16, 1);             \
+    else if (p.bn == 128) LAUNCH_GEMM_P(MODE, 64, 128, 2, 2, 16, 1);             \
+    else if (p.bk == 32) LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 32, 1);               \
+    else LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 16, 1);
+
+// 0: fp32 MFMA (default); 1: split-precision bf16 MFMA for forward / data gradient (SQD_CONV_BF16X3=1 or sqd_conv_set_precision)
+static int &conv_precision() {
+    static int prec = getenv("SQD_CONV_BF16X3") ? 1 : 0;
+    return prec;
+}
 
 static int launch_gemm(int mode, const float *a_src, const float *w, const float *bias, float *out, float *ws, const ConvGeom &g,
                        int act, void *stream, float *stats = nullptr) {
@@ -840,7 +941,9 @@ static int launch_gemm(int mode, const float *a_src, const float *w, const float
     const int order = order_env >= 0 ? order_env : 2;      // measured best on MI355X (profiles/r01c_conv_layers.md)
     float *dst = p.z > 1 ? ws : out;
     (void)hipGetLastError();
-    if (mode == 0) { DISPATCH_GEMM(0) } else { DISPATCH_GEMM(1) }
+    if (conv_precision()) {
+        if (mode == 0) { DISPATCH_GEMM_BF(0) } else { DISPATCH_GEMM_BF(1) }
+    } else if (mode == 0) { DISPATCH_GEMM(0) } else { DISPATCH_GEMM(1) }
     if (p.z > 1) {
         const size_t n = (size_t)Mrows * Ncols;
         size_t nb = (n / 4 + 255) / 256;
@@ -876,6 +979,15 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, bk);
     return SQD_OK;
 }
+
+// arithmetic of sqd_conv_fwd / sqd_conv_dgrad: 0 = fp32 MFMA (default), 1 = split-precision bf16 MFMA (3 bf16 terms per fp32
+// operand, 6 products, fp32 accumulation: fp32-level accuracy, experimental)
+extern "C" int sqd_conv_set_precision(int prec) {
+    SQD_CHECK_ARG(prec == 0 || prec == 1, "sqd_conv_set_precision: %d", prec);
+    conv_precision() = prec;
+    return SQD_OK;
+}
+extern "C" int sqd_conv_precision(void) { return conv_precision(); }
 
 // workspace (floats) sqd_conv_fwd (mode 0) / sqd_conv_dgrad (mode 1) need for this geometry (0 = none)
 extern "C" int sqd_conv_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,

@@ -119,6 +119,8 @@ _SIGNATURES = {
     "sqd_bins_workspace": (_I, [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64)]),
     "sqd_bins_fwd": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "sqd_bins_bwd": (_I, [_P] * 10 + [_I] * 4 + [_P]),
+    "sqd_conv_set_precision": (_I, [_I]),
+    "sqd_conv_precision": (_I, []),
     "sqd_vit_supported": (_I, [_I, _I]),
     "sqd_addln_fwd": (_I, [_P, _P, _I] + [_P] * 7 + [_I, _I, _F, _F, _P]),
     "sqd_addln_nblk": (_I, [_I]),

@@ -169,3 +169,37 @@ def test_conv_epilogue_feeds_batchnorm_statistics(N, C, H, W, K, R, stride, pad,
         assert float((a.cpu().double() - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-6, name
     if C > 3:
         assert float((xg.grad.cpu().double() - xr.grad).abs().max()) <= 1e-3 * float(xr.grad.abs().max())
+
+
+@pytest.mark.parametrize("N,C,H,W,K,R,stride,pad,bias,act", [CASES[1], CASES[2], CASES[5], CASES[7], CASES[11], CASES[12]])
+def test_split_precision_variant(N, C, H, W, K, R, stride, pad, bias, act):
+    """opt-in arithmetic of forward / data gradient (sqd_conv_set_precision(1)): every fp32 operand as three bf16 terms on the
+    bf16 matrix cores, 6 partial products, fp32 accumulation.  Must meet the same bar as the fp32 MFMA path — and, being an
+    exact decomposition up to 2^-24, land within a few fp32 roundings of it."""
+    from sqd import lib, nnkernels
+    L = lib.lib()
+    torch.manual_seed(C + K + R)
+    conv = nn.Conv2d(C, K, R, stride, pad, bias=bias).double()
+    x = torch.randn(N, C, H, W)
+    xr = x.double().requires_grad_(True)
+    yr = conv(xr)
+    wgt = torch.randn(yr.shape)
+    (yr * wgt.double()).sum().backward()
+    res = {}
+    try:
+        for prec in (0, 1):
+            assert L.sqd_conv_set_precision(prec) == 0 and L.sqd_conv_precision() == prec
+            conv_g = nn.Conv2d(C, K, R, stride, pad, bias=bias).cuda()
+            conv_g.load_state_dict({k: v.float() for k, v in conv.state_dict().items()})
+            conv_g = conv_g.to(memory_format=torch.channels_last)
+            xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            y = nnkernels.conv2d_native(xg, conv_g, None)
+            (y * wgt.cuda()).sum().backward()
+            res[prec] = (y.detach().cpu().double(), xg.grad.cpu().double())
+    finally:
+        L.sqd_conv_set_precision(0)
+    for name, i, ref in (("y", 0, yr.detach()), ("dx", 1, xr.grad)):
+        scale = float(ref.abs().max())
+        e32, ebf = float((res[0][i] - ref).abs().max()), float((res[1][i] - ref).abs().max())
+        assert ebf <= 1e-4 * scale, (name, ebf, scale)
+        assert ebf <= 4.0 * e32 + 1e-7 * scale, (name, "split precision", ebf, "fp32 MFMA", e32)
