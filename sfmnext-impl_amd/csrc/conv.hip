@@ -66,15 +66,16 @@ __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
 // MODE 0: forward (A rows = output pixels, gather x; B rows = out channels k, reduction over (r,s,c))
 // MODE 1: dgrad   (A rows = input pixels, gather dy; B rows = in channels c, reduction over (r,s,k))
 template <int MODE, int BM, int BN, int WGM, int WGN, int BKT, int PREC = 0>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
+__global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
                                                         const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
                                                         int act, int zsplits, int order, float *__restrict__ stats) {
     constexpr int WTM = BM / WGM / 32, WTN = BN / WGN / 32;     // 32x32 MFMA tiles per wave
-    static_assert(WGM * WGN == 4 && WTM >= 1 && WTN >= 1, "4 waves per workgroup");
+    constexpr int NT = WGM * WGN * 64;                          // 4 or 8 wavefronts per workgroup
+    static_assert((WGM * WGN == 4 || WGM * WGN == 8) && WTM >= 1 && WTN >= 1, "4 or 8 waves per workgroup");
     // BKT = reduction slice per step (16 or 32 channels): a wider slice halves the barriers and per-step bookkeeping for
     // twice the LDS footprint
-    constexpr int NQ = BKT / 4, LDPT = BKT + 4, RPP = 256 / NQ;  // float4 per staged row, LDS row pitch, rows per staging pass
-    constexpr int A_F4 = BM * NQ / 256;
+    constexpr int NQ = BKT / 4, LDPT = BKT + 4, RPP = NT / NQ;  // float4 per staged row, LDS row pitch, rows per staging pass
+    constexpr int A_F4 = BM * NQ / NT;
     static_assert(A_F4 >= 1 && (BKT == 16 || BKT == 32), "BM >= 64, BKT in {16, 32}");
     constexpr int LDH = BKT + 8;                                // PREC 1: bf16 row pitch (48 / 80 bytes: conflict-free b128 reads)
     __shared__ __attribute__((aligned(16))) float As[PREC ? 1 : 2][PREC ? 1 : BM][LDPT];
@@ -178,14 +179,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
     };
     // ---- B staging.  forward: rows = k, 16 consecutive c of filter tap (r,s): float4 copies.
     //      dgrad: rows = c, 16 k's strided by R*S*C: read float4 along c, transpose into LDS.
-    constexpr int B_F4 = (BN * NQ + 255) / 256;
+    constexpr int B_F4 = (BN * NQ + NT - 1) / NT;
     auto load_b = [&](float4 *rb) {
         const int cc = l_cc;
         const int rs = MODE == 0 ? l_r * g.S + l_s : (r0 + g.stride * l_r) * g.S + s0 + g.stride * l_s;   // filter tap of the slice
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int idx = t + 256 * i;
+            const int idx = t + NT * i;
             if (MODE == 0) {
                 const int row = idx / NQ, q4 = idx % NQ;                 // row = out channel, q4 = float4 along c
                 if (row < BN && n0 + row < g.K)
@@ -208,7 +209,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
             }
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
-                const int idx = t + 256 * i;
+                const int idx = t + NT * i;
                 const Split4 sp = split3(rb[i]);
                 if (MODE == 0) {
                     const int row = idx / NQ, q4 = idx % NQ;
@@ -235,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
         for (int i = 0; i < A_F4; ++i) *reinterpret_cast<float4 *>(&As[buf][arow + RPP * i][c4 * 4]) = ra[i];
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
-            const int idx = t + 256 * i;
+            const int idx = t + NT * i;
             if (MODE == 0) {
                 const int row = idx / NQ, q4 = idx % NQ;
                 if (row < BN) *reinterpret_cast<float4 *>(&Bs[buf][row][q4 * 4]) = rb[i];
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
         __syncthreads();
         float *dst = out + (size_t)blockIdx.z * g.N * g.H * g.W * Ncols;     // split-K: every partial slot gets its zeros
         constexpr int QN = BN / 4;                  // float4 per tile row
-        for (int idx = t; idx < BM * QN; idx += 256) {
+        for (int idx = t; idx < BM * QN; idx += NT) {
             const int ml = idx / QN, c = n0 + (idx % QN) * 4;
             const int px = rowpix[ml];
             if (px >= 0 && c < Ncols)
@@ -354,7 +355,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const float *__restrict_
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     // forward with `stats`: per-channel (sum, sum of squares) of this tile's valid rows, i.e. the partials BatchNorm's first
     // pass would otherwise re-read the whole output for (stats [tiles_m][K][2], same layout as bn_reduce_kernel's)
-    __shared__ float sred[MODE == 0 ? 4 : 1][MODE == 0 ? WTN * 32 : 1][2];
+    __shared__ float sred[MODE == 0 ? WGM * WGN : 1][MODE == 0 ? WTN * 32 : 1][2];
     const bool want_stats = MODE == 0 && stats != nullptr && zsplits == 1;
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
@@ -802,6 +803,7 @@ extern "C" int sqd_conv_supported(int C, int K) { return (C % 16 == 0 && K % 16 
 
 struct GemmPlan {
     int bm, bn, z, bk;
+    int waves = 4;                  // wavefronts per workgroup: 4, or 8 on the >= 128x64 tiles (one 32x32 tile per wave)
     int64_t ws_floats;
 };
 // measured plans registered through sqd_conv_set_plan: (mode, geometry) -> (bm, bn, z)
@@ -870,7 +872,8 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
             p.bm = std::get<0>(it->second);
             p.bn = std::get<1>(it->second);
             p.z = std::get<2>(it->second);
-            p.bk = std::get<3>(it->second);
+            p.bk = std::get<3>(it->second) & 255;
+            p.waves = (std::get<3>(it->second) & 256) ? 8 : 4;
         }
     }
     int z = p.z;
@@ -895,8 +898,18 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(256), 0, st, \
                        a_src, w, bias, dst, g, act, p.z, order, stats)
 #define LAUNCH_GEMM(MODE, BM, BN, WGM, WGN, BKT) LAUNCH_GEMM_P(MODE, BM, BN, WGM, WGN, BKT, 0)
+#define LAUNCH_GEMM8(MODE, BM, BN, WGM, WGN, BKT)                                                                       \
+    hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT, 0>),                                              \
+                       dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(512), 0, st, \
+                       a_src, w, bias, dst, g, act, p.z, order, stats)
 #define DISPATCH_GEMM(MODE)                                                      \
-    if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM(MODE, 128, 128, 2, 2, 16);       \
+    if (p.waves == 8 && p.bm == 128 && p.bn == 128) LAUNCH_GEMM8(MODE, 128, 128, 4, 2, 16); \
+    else if (p.waves == 8 && p.bm == 128 && p.bn == 64) {                        \
+        if (p.bk == 32) LAUNCH_GEMM8(MODE, 128, 64, 4, 2, 32);                   \
+        else LAUNCH_GEMM8(MODE, 128, 64, 4, 2, 16);                              \
+    } else if (p.waves == 8 && p.bm == 64 && p.bn == 128 && p.bk == 32) {        \
+        LAUNCH_GEMM8(MODE, 64, 128, 2, 4, 32);                                   \
+    } else if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM(MODE, 128, 128, 2, 2, 16);       \
     else if (p.bm == 128 && p.bn == 64) {                                        \
         if (p.bk == 32) LAUNCH_GEMM(MODE, 128, 64, 2, 2, 32);                    \
         else LAUNCH_GEMM(MODE, 128, 64, 2, 2, 16);                               \
@@ -954,7 +967,8 @@ static int launch_gemm(int mode, const float *a_src, const float *w, const float
 }
 
 // Register a measured tile / split-K plan for one geometry (mode 0 = fwd, 1 = dgrad): bm x bn in {128x128, 128x64, 64x128,
-// 64x64, 128x32}, z >= 1 split-K factor, bk = 16 | 32 channels per reduction slice; bm = 0 removes the entry.  Returns SQD_EINVAL when the plan cannot run on this
+// 64x64, 128x32}, z >= 1 split-K factor, bk = 16 | 32 channels per reduction slice (+ 256: 8-wave workgroups on the 128x128 /
+// 128x64 / 64x128 tiles — twice the resident waves for the same tiles); bm = 0 removes the entry.  Returns SQD_EINVAL when the plan cannot run on this
 // geometry (tile wider than twice the channel count, z larger than a quarter of the reduction slices, workspace > 64 MB).
 // The next sqd_conv_plan / sqd_conv_fwd / sqd_conv_dgrad calls of that geometry use it.
 extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
@@ -967,6 +981,10 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     }
     const int Ncols = mode == 0 ? K : C;
     const int taps = mode == 0 ? R * S : ((R + stride - 1) / stride) * ((S + stride - 1) / stride);
+    const int waves = (bk & 256) ? 8 : 4;                        // bk + 256: 8-wave workgroups (one 32x32 tile per wave)
+    bk &= 255;
+    SQD_CHECK_ARG(waves == 4 || (bm == 128 && bn == 128 && bk == 16) || (bm == 128 && bn == 64) || (bm == 64 && bn == 128 && bk == 32),
+                  "sqd_conv_set_plan: 8-wave workgroups exist for 128x128 (bk 16), 128x64 and 64x128 (bk 32) tiles");
     SQD_CHECK_ARG(bk == 16 || (bk == 32 && (mode == 0 ? C : K) % 32 == 0 && bm + bn <= 192),
                   "sqd_conv_set_plan: slice width %d not possible here (32 needs 32 | reduced channels and bm + bn <= 192)", bk);
     const int T = taps * ((mode == 0 ? C : K) / bk);
@@ -976,7 +994,7 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     SQD_CHECK_ARG(!(bn > 32 && bn >= 2 * Ncols) && !(bn == 32 && Ncols > 32), "sqd_conv_set_plan: tile width %d does not fit %d channels", bn, Ncols);
     SQD_CHECK_ARG(z == 1 || (z <= T / 2 && z * out_elems * 4 <= (64ll << 20) && out_elems % 4 == 0),
                   "sqd_conv_set_plan: split-K %d not possible here", z);
-    plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, bk);
+    plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, bk | (waves == 8 ? 256 : 0));
     return SQD_OK;
 }
 
