@@ -63,6 +63,18 @@ __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// Operand fetches go through raw buffer loads: the descriptor carries the tensor's size, an offset beyond it returns zeros.
+// Padding taps, rows beyond the tile and channels beyond the tensor set the offset to 0xffffffff (one v_cndmask) instead of
+// branching around the load (s_and_saveexec / s_cbranch_execz per float4 in the global_load version).
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0);
+    return make_float4(__int_as_float(v.x), __int_as_float(v.y), __int_as_float(v.z), __int_as_float(v.w));
+}
+
 // MODE 0: forward (A rows = output pixels, gather x; B rows = out channels k, reduction over (r,s,c))
 // MODE 1: dgrad   (A rows = input pixels, gather dy; B rows = in channels c, reduction over (r,s,k))
 template <int MODE, int BM, int BN, int WGM, int WGN, int BKT, int PREC = 0>
@@ -156,25 +168,28 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
         l_r = rs / Sc;
         l_s = rs - l_r * Sc;
     }
-    // element offset of each staging row's pixel at tap (0,0) (32-bit: tensors are checked to stay below 2^31 elements)
+    // element offset of each staging row's pixel at tap (0,0) (32-bit: tensors are checked to stay below 4 GiB)
     int apix[A_F4];
 #pragma unroll
     for (int i = 0; i < A_F4; ++i)
         apix[i] = MODE == 0 ? (an[i] * g.H + ah[i]) * g.W + aw[i] : (an[i] * g.Ho + ah[i]) * g.Wo + aw[i];
+    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_src, (unsigned)(MODE == 0 ? g.N * g.H * g.W * g.C : g.N * g.Ho * g.Wo * g.K) * 4u);
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(wgt, (unsigned)(g.K * g.R * g.S * g.C) * 4u);
     auto load_a = [&](float4 *ra) {
         const int cc = l_cc, r = l_r, s = l_s;
         const int tapoff = MODE == 0 ? r * g.W + s : -(r * g.Wo + s);
 #pragma unroll
         for (int i = 0; i < A_F4; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            bool ok;
+            unsigned off;
             if (MODE == 0) {
-                if (aval[i] && (unsigned)(ah[i] + r) < (unsigned)g.H && (unsigned)(aw[i] + s) < (unsigned)g.W)
-                    v = *reinterpret_cast<const float4 *>(a_src + (unsigned)((apix[i] + tapoff) * g.C + cc * BKT + c4 * 4));
+                ok = aval[i] && (unsigned)(ah[i] + r) < (unsigned)g.H && (unsigned)(aw[i] + s) < (unsigned)g.W;
+                off = (unsigned)((apix[i] + tapoff) * g.C + cc * BKT + c4 * 4) * 4u;
             } else {
-                if (aval[i] && (unsigned)(ah[i] - r) < (unsigned)g.Ho && (unsigned)(aw[i] - s) < (unsigned)g.Wo)
-                    v = *reinterpret_cast<const float4 *>(a_src + (unsigned)((apix[i] + tapoff) * g.K + cc * BKT + c4 * 4));
+                ok = aval[i] && (unsigned)(ah[i] - r) < (unsigned)g.Ho && (unsigned)(aw[i] - s) < (unsigned)g.Wo;
+                off = (unsigned)((apix[i] + tapoff) * g.K + cc * BKT + c4 * 4) * 4u;
             }
-            ra[i] = v;
+            ra[i] = buf_load4(a_rsrc, ok ? off : 0xffffffffu);
         }
     };
     // ---- B staging.  forward: rows = k, 16 consecutive c of filter tap (r,s): float4 copies.
@@ -185,18 +200,19 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
         const int rs = MODE == 0 ? l_r * g.S + l_s : (r0 + g.stride * l_r) * g.S + s0 + g.stride * l_s;   // filter tap of the slice
 #pragma unroll
         for (int i = 0; i < B_F4; ++i) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             const int idx = t + NT * i;
+            bool ok;
+            unsigned off;
             if (MODE == 0) {
                 const int row = idx / NQ, q4 = idx % NQ;                 // row = out channel, q4 = float4 along c
-                if (row < BN && n0 + row < g.K)
-                    v = *reinterpret_cast<const float4 *>(wgt + (unsigned)(((n0 + row) * g.R * g.S + rs) * g.C + cc * BKT + q4 * 4));
+                ok = row < BN && n0 + row < g.K;
+                off = (unsigned)(((n0 + row) * g.R * g.S + rs) * g.C + cc * BKT + q4 * 4) * 4u;
             } else {
                 const int kk = idx % BKT, cq = idx / BKT;                // kk = k inside the slice, cq = float4 of in-channels
-                if (cq * 4 < BN && n0 + cq * 4 < g.C)
-                    v = *reinterpret_cast<const float4 *>(wgt + (unsigned)(((cc * BKT + kk) * g.R * g.S + rs) * g.C + n0 + cq * 4));
+                ok = cq * 4 < BN && n0 + cq * 4 < g.C;
+                off = (unsigned)(((cc * BKT + kk) * g.R * g.S + rs) * g.C + n0 + cq * 4) * 4u;
             }
-            rb[i] = v;
+            rb[i] = buf_load4(w_rsrc, ok ? off : 0xffffffffu);
         }
     };
     auto store_ab = [&](int buf, const float4 *ra, const float4 *rb) {
@@ -788,8 +804,9 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ s
 int check_geom(const char *who, const ConvGeom &g) {
     SQD_CHECK_ARG(g.N > 0 && g.H > 0 && g.W > 0 && g.C > 0 && g.K > 0 && g.R > 0 && g.S > 0 && g.stride > 0 && g.pad >= 0,
                   "%s: bad geometry", who);
-    SQD_CHECK_ARG((long long)g.N * g.H * g.W * g.C < (1ll << 31) && (long long)g.N * g.Ho * g.Wo * g.K < (1ll << 31) &&
-                      (long long)g.K * g.R * g.S * g.C < (1ll << 31), "%s: tensors of 2^31 elements or more are not supported", who);
+    SQD_CHECK_ARG((long long)g.N * g.H * g.W * g.C < (1ll << 30) && (long long)g.N * g.Ho * g.Wo * g.K < (1ll << 30) &&
+                      (long long)g.K * g.R * g.S * g.C < (1ll << 30),
+                  "%s: tensors of 4 GiB or more are not supported (32-bit byte offsets of the buffer loads)", who);
     // (Ho, Wo) may be SMALLER than the full output extent: the top-left Ho x Wo outputs are computed (the 7x7/2 stems run as a
     // 4x4/1 convolution on a space-to-depth input, whose symmetric padding yields one surplus row and column)
     SQD_CHECK_ARG(g.Ho >= 1 && g.Wo >= 1 && g.Ho <= (g.H + 2 * g.pad - g.R) / g.stride + 1 &&
