@@ -616,6 +616,20 @@ __device__ __forceinline__ void ldv(const float *__restrict__ base, unsigned byt
     v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
 }
 
+// the same fetches as raw buffer loads: an offset of 0xffffffff (pixel beyond the range, padding tap) returns zeros, no branch
+__device__ __forceinline__ void ldb(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float (&v)[1]) {
+    v[0] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ void ldb(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float (&v)[2]) {
+    typedef int i32x2 __attribute__((ext_vector_type(2)));
+    const i32x2 t = __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0);
+    v[0] = __int_as_float(t.x); v[1] = __int_as_float(t.y);
+}
+__device__ __forceinline__ void ldb(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float (&v)[4]) {
+    const float4 t = buf_load4(r, byte_off);
+    v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+}
+
 template <int KT, int CT, int TP>
 __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                                 float *__restrict__ part, ConvGeom g, int px_per_wave, int kgroups,
@@ -659,21 +673,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
 #pragma unroll
     for (int q = 0; q < KT; ++q) bsum[q] = 0.f;
 
+    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(dy, (unsigned)(g.N * g.Ho * g.Wo * g.K) * 4u);
+    const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(x, (unsigned)(g.N * g.H * g.W * g.C) * 4u);
     auto load_batch = [&](float (*a)[KT], float (*b)[TP][CT]) {
 #pragma unroll
         for (int u = 0; u < UB; ++u) {
             const bool mv = m < mend;
             const bool hv = mv && (unsigned)hi < (unsigned)g.H;
             const int wi0 = wo * g.stride - g.pad + s0;
+            ldb(dy_rsrc, mv ? dyoff : 0xffffffffu, a[u]);
 #pragma unroll
-            for (int q = 0; q < KT; ++q) a[u][q] = 0.f;
-            if (mv) ldv(dy, dyoff, a[u]);
-#pragma unroll
-            for (int t = 0; t < TP; ++t) {
-#pragma unroll
-                for (int c = 0; c < CT; ++c) b[u][t][c] = 0.f;
-                if (hv && (unsigned)(wi0 + t) < (unsigned)g.W) ldv(x, (xrow + (unsigned)(wi0 + t) * g.C + cl) * 4u, b[u][t]);
-            }
+            for (int t = 0; t < TP; ++t)
+                ldb(x_rsrc, (hv && (unsigned)(wi0 + t) < (unsigned)g.W) ? (xrow + (unsigned)(wi0 + t) * g.C + cl) * 4u : 0xffffffffu, b[u][t]);
             m += 4;
             dyoff += dystep;
             wo += 4;
