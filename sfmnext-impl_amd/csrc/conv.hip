@@ -449,6 +449,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
     // staging: thread -> pixel pp = t & 15 of the slice, float4 group q = t >> 4 (16 groups = 64 channels per pass)
     const int pp = t & 15, q = t >> 4;
     constexpr int A_P = (BM + 63) / 64, B_P = (BN + 63) / 64;
+    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(dy, (unsigned)(g.N * g.Ho * g.Wo * g.K) * 4u);
+    const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(x, (unsigned)(g.N * g.H * g.W * g.C) * 4u);
     auto load = [&](int step, float4 *ra, float4 *rb) {
         const int m = mbeg + step * BK + pp;
         const bool mv = m < mend;
@@ -463,15 +465,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 #pragma unroll
         for (int i = 0; i < A_P; ++i) {
             const int kq = k0 + (q + 16 * i) * 4;
-            ra[i] = (mv && (q + 16 * i) * 4 < BM && kq < g.K) ? *reinterpret_cast<const float4 *>(dy + (size_t)m * g.K + kq)
-                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = mv && (q + 16 * i) * 4 < BM && kq < g.K;
+            ra[i] = buf_load4(dy_rsrc, ok ? (unsigned)(m * g.K + kq) * 4u : 0xffffffffu);
         }
 #pragma unroll
         for (int i = 0; i < B_P; ++i) {
             const int cq = c0 + (q + 16 * i) * 4;
-            rb[i] = (xin && (q + 16 * i) * 4 < BN && cq < g.C)
-                        ? *reinterpret_cast<const float4 *>(x + ((size_t)(n * g.H + hi) * g.W + wi) * g.C + cq)
-                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            const bool ok = xin && (q + 16 * i) * 4 < BN && cq < g.C;
+            rb[i] = buf_load4(x_rsrc, ok ? (unsigned)(((n * g.H + hi) * g.W + wi) * g.C + cq) * 4u : 0xffffffffu);
         }
     };
     auto store = [&](int buf, const float4 *ra, const float4 *rb) {
