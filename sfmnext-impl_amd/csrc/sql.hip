@@ -425,6 +425,21 @@ __device__ __forceinline__ void stg32(float *__restrict__ base, unsigned byte_of
     *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
 
+// raw buffer accesses: the descriptor carries the extent of one image's planes, so a plane index beyond E (or Q) and —
+// through a base offset of 2 GiB for lanes beyond the last pixel — a pixel beyond N read zeros / drop the store without a
+// branch around every access
+typedef int sql_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sql_rsrc(const float *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float ldb32(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ void stb32(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), r, byte_off, 0, 0);
+}
+constexpr unsigned SQL_OOB = 0x80000000u;
+
 template <int QT>
 __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict__ x, const float *__restrict__ K,
                                                         const float *__restrict__ y, const float *__restrict__ g_y,
@@ -442,6 +457,9 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
     const float *yb = y + (size_t)b * Q * N;
     const float *gyb = g_y ? g_y + (size_t)b * Q * N : nullptr;
     float *gxb = g_x + (size_t)b * E * N;
+    const __amdgpu_buffer_rsrc_t x_r = sql_rsrc(xb, (unsigned)(E * N) * 4u), y_r = sql_rsrc(yb, (unsigned)(Q * N) * 4u);
+    const __amdgpu_buffer_rsrc_t gy_r = sql_rsrc(gyb ? gyb : yb, gyb ? (unsigned)(Q * N) * 4u : 0u);      // no g_y: every read is 0
+    const __amdgpu_buffer_rsrc_t gx_r = sql_rsrc(gxb, (unsigned)(E * N) * 4u);
     for (int idx = threadIdx.x; idx < QP * EP; idx += 256) {
         const int q = idx / EP, e = idx - q * EP;
         const bool ok = q < Q && e < E;
@@ -472,14 +490,11 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
         const bool pv = p < N;
         // ---- t[q][p] = sum_e gS[q][e] x[e][p]
         const unsigned N4 = (unsigned)N * 4u;
-        const unsigned lane_x = ((unsigned)h * N + p) * 4u;           // plane h, pixel p
-        const unsigned lane_q = ((unsigned)(4 * h) * N + p) * 4u;     // row 4h of a 32-row group, pixel p
+        const unsigned lane_x = pv ? ((unsigned)h * N + p) * 4u : SQL_OOB;           // plane h, pixel p
+        const unsigned lane_q = pv ? ((unsigned)(4 * h) * N + p) * 4u : SQL_OOB;     // row 4h of a 32-row group, pixel p
         float xe[16];
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int e = 2 * s + h;
-            xe[s] = (pv && e < E) ? ldg32(xb, lane_x + (unsigned)(2 * s) * N4) : 0.f;
-        }
+        for (int s = 0; s < 16; ++s) xe[s] = ldb32(x_r, lane_x + (unsigned)(2 * s) * N4);        // plane 2s+h >= E: beyond the extent
         // every global read of the tile is issued up front (y, g_y, the float4 pieces of x for the g_K product): the first
         // product then runs under their latency instead of each phase waiting for its own loads
         f32x16 yv[QT], gv[QT];
@@ -487,28 +502,23 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int q = qt * 32 + acc_row(r, h);
                 const unsigned o = lane_q + (unsigned)(qt * 32 + (r & 3) + 8 * (r >> 2)) * N4;
-                const bool ok = q < Q && pv;
-                yv[qt][r] = ok ? ldg32(yb, o) : 0.f;
-                gv[qt][r] = (ok && gyb) ? ldg32(gyb, o) : 0.f;
+                yv[qt][r] = ldb32(y_r, o);
+                gv[qt][r] = ldb32(gy_r, o);
             }
         float xv[4][4];
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int px = 8 * gq + 4 * h;
+            if (vec_ok) {                                            // N % 4 == 0: a float4 is inside a plane or beyond it
+                const sql_i32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(
+                    x_r, (i < E && p0 + px < N) ? ((unsigned)i * N + p0 + px) * 4u : SQL_OOB, 0, 0);
+                xv[gq][0] = __int_as_float(t4.x); xv[gq][1] = __int_as_float(t4.y);
+                xv[gq][2] = __int_as_float(t4.z); xv[gq][3] = __int_as_float(t4.w);
+            } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xv[gq][j] = 0.f;
-            if (i < E) {
-                const float *src = xb + (size_t)i * N + p0 + px;
-                if (vec_ok && p0 + px + 3 < N) {
-                    const float4 t4 = *reinterpret_cast<const float4 *>(src);
-                    xv[gq][0] = t4.x; xv[gq][1] = t4.y; xv[gq][2] = t4.z; xv[gq][3] = t4.w;
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (p0 + px + j < N) xv[gq][j] = src[j];
-                }
+                for (int j = 0; j < 4; ++j)
+                    xv[gq][j] = ldb32(x_r, (i < E && p0 + px + j < N) ? ((unsigned)i * N + p0 + px + j) * 4u : SQL_OOB);
             }
         }
         f32x16 acc[QT], sreg[QT];
@@ -549,8 +559,7 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
             }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int e = acc_row(r, h);
-            if (pv && e < E) stg32(gxb, lane_q + (unsigned)((r & 3) + 8 * (r >> 2)) * N4, gx[r]);
+            stb32(gx_r, lane_q + (unsigned)((r & 3) + 8 * (r >> 2)) * N4, gx[r]);       // plane >= E / pixel >= N: dropped
         }
         // ---- g_K[q][e] += sum_p gyt[q][p] x[e][p]; k-step (gq, j): half-wave 0 takes pixel 8gq+j, half-wave 1 pixel 8gq+4+j
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
