@@ -40,6 +40,17 @@ __device__ __forceinline__ void stg(float *__restrict__ base, unsigned byte_off,
     *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
 
+// raw buffer accesses on one image's energy planes [Q][N]: a plane index beyond Q is beyond the descriptor's extent, a lane
+// beyond the last pixel starts from a 2 GiB offset — both read zeros / drop the store, no branch around the access
+typedef int bins_i32x4 __attribute__((ext_vector_type(4)));
+constexpr unsigned BINS_OOB = 0x80000000u;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t bins_rsrc(const float *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float ldb(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+
 struct BinsDims {
     int B, Q, D, N;
 };
@@ -67,12 +78,12 @@ __device__ __forceinline__ void tile_logits(const float *Wl, const float *__rest
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
     const unsigned step = 2u * N * 4u;
-    unsigned off = ((unsigned)kk * N + p) * 4u;
+    const __amdgpu_buffer_rsrc_t e_r = bins_rsrc(Eb, (unsigned)(Q * N) * 4u);
+    unsigned off = pv ? ((unsigned)kk * N + p) * 4u : BINS_OOB;
     auto fetch = [&](int g, float *e) {
 #pragma unroll
         for (int u = 0; u < G; ++u) {
-            const int q = 2 * (g * G + u) + kk;
-            e[u] = (pv && q < Q) ? ldg(Eb, off) : 0.f;
+            e[u] = ldb(e_r, off);                           // plane 2(gG+u)+kk >= Q: beyond the extent
             off += step;
         }
     };
@@ -167,6 +178,7 @@ __global__ __launch_bounds__(256) void bins_bwd_kernel(const float *__restrict__
     __syncthreads();
     const float *Eb = E + (size_t)b * dm.Q * dm.N;
     float *dEb = dE + (size_t)b * dm.Q * dm.N;
+    const __amdgpu_buffer_rsrc_t eb_r = bins_rsrc(Eb, (unsigned)(dm.Q * dm.N) * 4u), de_r = bins_rsrc(dEb, (unsigned)(dm.Q * dm.N) * 4u);
     float *tl = tiles + wave * DP * PITCH, *pl = predl + wave * 32;
     const bool vec_ok = (dm.N & 3) == 0;
 
@@ -218,7 +230,7 @@ __global__ __launch_bounds__(256) void bins_bwd_kernel(const float *__restrict__
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int q = qt * 32 + acc_row(r, h);
-                if (pv && q < dm.Q) stg(dEb, ((unsigned)q * dm.N + p) * 4u, accE[r]);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(accE[r]), de_r, pv ? ((unsigned)q * dm.N + p) * 4u : BINS_OOB, 0, 0);
             }
         }
         // ---- dW[d, q] += sum_p dlogit[d, p] * E[q, p]; k-step (gq, e): half-wave 0 takes pixel 8gq+e, half-wave 1 pixel 8gq+4+e
@@ -245,17 +257,13 @@ __global__ __launch_bounds__(256) void bins_bwd_kernel(const float *__restrict__
             for (int qt = 0; qt < QT; ++qt) {
                 const int q = qt * 32 + i;
                 const unsigned off = ((unsigned)q * dm.N + p0 + px) * 4u;
+                if (vec_ok) {                                   // N % 4 == 0: a float4 lies inside a plane or beyond the last pixel
+                    const bins_i32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(eb_r, p0 + px < dm.N ? off : BINS_OOB, 0, 0);
+                    ev[qt][0] = __int_as_float(t4.x); ev[qt][1] = __int_as_float(t4.y);
+                    ev[qt][2] = __int_as_float(t4.z); ev[qt][3] = __int_as_float(t4.w);
+                } else {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) ev[qt][e] = 0.f;
-                if (q < dm.Q) {
-                    if (vec_ok && p0 + px + 3 < dm.N) {
-                        const float4 t4 = ldg4(Eb, off);
-                        ev[qt][0] = t4.x; ev[qt][1] = t4.y; ev[qt][2] = t4.z; ev[qt][3] = t4.w;
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (p0 + px + e < dm.N) ev[qt][e] = ldg(Eb, off + 4u * e);
-                    }
+                    for (int e = 0; e < 4; ++e) ev[qt][e] = ldb(eb_r, p0 + px + e < dm.N ? off + 4u * e : BINS_OOB);
                 }
             }
 #pragma unroll
