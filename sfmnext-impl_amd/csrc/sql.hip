@@ -39,6 +39,21 @@ __device__ __forceinline__ float group_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
+// raw buffer accesses: the descriptor carries the extent of one image's planes, so a plane index beyond E (or Q) and —
+// through a base offset of 2 GiB for lanes beyond the last pixel — a pixel beyond N read zeros / drop the store without a
+// branch around every access
+typedef int sql_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sql_rsrc(const float *p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float ldb32(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
+}
+__device__ __forceinline__ void stb32(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), r, byte_off, 0, 0);
+}
+constexpr unsigned SQL_OOB = 0x80000000u;
+
 constexpr int PART_STRIDE_EXTRA = 2;   // per query: max, sum, then E summary values
 
 // ---------------------------------------------------------------------------------------------------
@@ -56,6 +71,7 @@ __global__ __launch_bounds__(256) void sql_fwd_kernel(const float *__restrict__ 
     const float *xb = x + (size_t)b * E * N;
     const float *Kb = K + (size_t)b * Q * E;
     float *yb = y + (size_t)b * Q * N;
+    const __amdgpu_buffer_rsrc_t x_r = sql_rsrc(xb, (unsigned)(E * N) * 4u);
     const int PX = NT * 16;                                   // pixels per step
     const int n_wave0 = (chunk * 4 + wave) * steps_per_wave * PX;
 
@@ -89,7 +105,7 @@ __global__ __launch_bounds__(256) void sql_fwd_kernel(const float *__restrict__ 
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int n = n0 + i * 16 + c;
-                const float a = n < N ? xb[(size_t)(e0 + g) * N + n] : 0.f;   // A[row=n][k=e]
+                const float a = ldb32(x_r, n < N ? ((unsigned)(e0 + g) * N + n) * 4u : SQL_OOB);   // A[row=n][k=e]
 #pragma unroll
                 for (int j = 0; j < QT; ++j) d[i][j] = mfma16(a, bq[j], d[i][j]);
             }
@@ -149,14 +165,14 @@ __global__ __launch_bounds__(256) void sql_fwd_kernel(const float *__restrict__ 
             const int n = n0 + i * 16 + 4 * g;
 #pragma unroll
             for (int t = 0; t < ET; ++t) {
-                const float *xr = xb + (size_t)(t * 16 + c) * N + n;       // A[row=e][k]: 4 consecutive pixels
+                const unsigned xo = ((unsigned)(t * 16 + c) * N + n) * 4u;   // A[row=e][k]: 4 consecutive pixels
                 float a4[4];
-                if (n + 3 < N && (N & 3) == 0) {
-                    const f32x4 v = *reinterpret_cast<const f32x4 *>(xr);
-                    a4[0] = v[0]; a4[1] = v[1]; a4[2] = v[2]; a4[3] = v[3];
+                if ((N & 3) == 0) {                                         // a float4 lies inside a plane or beyond the last pixel
+                    const sql_i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(x_r, n < N ? xo : SQL_OOB, 0, 0);
+                    a4[0] = __int_as_float(v.x); a4[1] = __int_as_float(v.y); a4[2] = __int_as_float(v.z); a4[3] = __int_as_float(v.w);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a4[r] = n + r < N ? xr[r] : 0.f;
+                    for (int r = 0; r < 4; ++r) a4[r] = ldb32(x_r, n + r < N ? xo + 4u * r : SQL_OOB);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -424,21 +440,6 @@ __device__ __forceinline__ float ldg32(const float *__restrict__ base, unsigned 
 __device__ __forceinline__ void stg32(float *__restrict__ base, unsigned byte_off, float v) {
     *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
-
-// raw buffer accesses: the descriptor carries the extent of one image's planes, so a plane index beyond E (or Q) and —
-// through a base offset of 2 GiB for lanes beyond the last pixel — a pixel beyond N read zeros / drop the store without a
-// branch around every access
-typedef int sql_i32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t sql_rsrc(const float *p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float ldb32(__amdgpu_buffer_rsrc_t r, unsigned byte_off) {
-    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, byte_off, 0, 0));
-}
-__device__ __forceinline__ void stb32(__amdgpu_buffer_rsrc_t r, unsigned byte_off, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), r, byte_off, 0, 0);
-}
-constexpr unsigned SQL_OOB = 0x80000000u;
 
 template <int QT>
 __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict__ x, const float *__restrict__ K,
