@@ -373,27 +373,45 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
     // pass would otherwise re-read the whole output for (stats [tiles_m][K][2], same layout as bn_reduce_kernel's)
     __shared__ float sred[MODE == 0 ? WGM * WGN : 1][MODE == 0 ? WTN * 32 : 1][2];
     const bool want_stats = MODE == 0 && stats != nullptr && zsplits == 1;
+    // output (and the data gradient's addend) through raw buffer accesses: rows beyond the tile's valid range and columns beyond
+    // the channel count get an offset beyond the descriptor's extent — the store is dropped, the addend reads 0 — so the 16
+    // addend loads of a tile are all in flight at once instead of one load-wait-store sequence per row
+    const unsigned out_rows = MODE == 0 ? (unsigned)Mrows : (unsigned)(g.N * g.H * g.W);
+    const unsigned out_bytes = out_rows * (unsigned)Ncols * 4u;
+    const __amdgpu_buffer_rsrc_t dst_r = make_rsrc(out + (size_t)blockIdx.z * out_rows * Ncols, out_bytes);   // zsplits > 1: partial workspace
+    const bool has_add = MODE == 1 && bias != nullptr && zsplits == 1;                   // dgrad: `bias` is the [N,H,W,C] addend
+    const __amdgpu_buffer_rsrc_t add_r = make_rsrc(has_add ? bias : out, has_add ? out_bytes : 0u);
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
         const int col = n0 + wn0 + j * 32 + row;
         float s1 = 0.f, s2 = 0.f;
-        if (col < Ncols) {
-        const float bv = (MODE == 0 && bias && zsplits == 1) ? bias[col] : 0.f;
-        const size_t out_rows = MODE == 0 ? (size_t)Mrows : (size_t)g.N * g.H * g.W;
-        float *dst = out + (size_t)blockIdx.z * out_rows * Ncols;       // zsplits > 1: `out` is the partial workspace
+        const bool cv = col < Ncols;
+        const float bv = (MODE == 0 && bias && zsplits == 1 && cv) ? bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < WTM; ++i)
+        for (int i = 0; i < WTM; ++i) {
+            unsigned off[16];
+            float addv[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ml = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 const int m = MODE == 0 ? m0 + ml : rowpix[ml];
-                if (MODE == 0 ? m < Mrows : m >= 0) {
-                    float v = acc[i][j][e] + bv;
-                    if (MODE == 1 && bias && zsplits == 1) v += bias[(size_t)m * Ncols + col];   // dgrad: `bias` is the [N,H,W,C] addend
-                    if (MODE == 0 && act == 1 && zsplits == 1) v = v > 0.f ? v : 0.f;
-                    dst[(size_t)m * Ncols + col] = v;
-                    s1 += v;
-                    s2 = fmaf(v, v, s2);
+                const bool ok = cv && (MODE == 0 ? m < Mrows : m >= 0);
+                off[e] = ok ? ((unsigned)m * (unsigned)Ncols + (unsigned)col) * 4u : 0xffffffffu;
+            }
+            if (MODE == 1) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) addv[e] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(add_r, off[e], 0, 0));
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                float v = acc[i][j][e] + bv;
+                if (MODE == 1) v += addv[e];
+                if (MODE == 0 && act == 1 && zsplits == 1) v = v > 0.f ? v : 0.f;
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), dst_r, off[e], 0, 0);
+                if (MODE == 0) {
+                    const float vs = off[e] != 0xffffffffu ? v : 0.f;
+                    s1 += vs;
+                    s2 = fmaf(vs, vs, s2);
                 }
             }
         }
