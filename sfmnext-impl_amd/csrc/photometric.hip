@@ -354,6 +354,8 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(sqd_photo_bwd_args a, in
     const float *__restrict__ smp = (s == 0 ? a.sample[0] : a.sample[1]) + (size_t)b * HW * 2;
     const float *__restrict__ dep = a.depth + (size_t)b * HW;
     float *__restrict__ gdep = a.g_depth + (size_t)b * a.g_depth_img_stride + (size_t)s * HW;
+    const __amdgpu_buffer_rsrc_t coef_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(coef), 0, (unsigned)(9 * HW) * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t idx_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(idx), 0, (unsigned)HW, 0x00020000);
 
     // border-column bookkeeping (wave-uniform): lanes of columns 0 and W-1 in this strip
     const int x_first = st.cx - lane;              // column of lane 0
@@ -376,12 +378,14 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(sqd_photo_bwd_args a, in
         const int r = st.y_begin - 3 + j;            // coefficient row (zero outside the image)
         float g[9];
         const bool have = r >= 0 && r < H && in_img_col;
-        bool win = false;
-        if (have) win = idx[r * W + st.cx] == (uint8_t)(S + s);
+        // raw buffer loads: rows / columns outside the image and pixels another source won read zeros through an offset beyond
+        // the descriptor's extent — no branch around the 10 loads of a row
+        const unsigned pofs = have ? (unsigned)(r * W + st.cx) : 0x80000000u;
+        const bool win = ((int)__builtin_amdgcn_raw_buffer_load_b8(idx_r, pofs, 0, 0) & 0xff) == (S + s);
+        const unsigned cofs = win ? pofs * 4u : 0x80000000u;
 #pragma unroll
         for (int c = 0; c < 9; ++c) {
-            float v = 0.f;
-            if (win) v = coef[c * HW + r * W + st.cx];
+            const float v = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(coef_r, cofs + (unsigned)(c * HW) * 4u, 0, 0));
             float bx = box7(v);
             // reflection adjoint along x: columns 1..3 / W-4..W-2 also receive the mirrored window sums
             if (left_border) {
