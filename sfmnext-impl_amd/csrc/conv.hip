@@ -89,11 +89,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
     constexpr int NQ = BKT / 4, LDPT = BKT + 4, RPP = NT / NQ;  // float4 per staged row, LDS row pitch, rows per staging pass
     constexpr int A_F4 = BM * NQ / NT;
     static_assert(A_F4 >= 1 && (BKT == 16 || BKT == 32), "BM >= 64, BKT in {16, 32}");
+    constexpr bool BF = PREC == 1;                              // split-precision bf16 operands
+    constexpr int NBUF = PREC == 2 ? 1 : 2;                     // PREC 2: single LDS buffer (half the LDS, one more barrier per slice)
     constexpr int LDH = BKT + 8;                                // PREC 1: bf16 row pitch (48 / 80 bytes: conflict-free b128 reads)
-    __shared__ __attribute__((aligned(16))) float As[PREC ? 1 : 2][PREC ? 1 : BM][LDPT];
-    __shared__ __attribute__((aligned(16))) float Bs[PREC ? 1 : 2][PREC ? 1 : BN][LDPT];
-    __shared__ __attribute__((aligned(16))) unsigned short Ah[PREC ? 2 : 1][3][PREC ? BM : 1][LDH];   // [buffer][term][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short Bh[PREC ? 2 : 1][3][PREC ? BN : 1][LDH];
+    __shared__ __attribute__((aligned(16))) float As[BF ? 1 : NBUF][BF ? 1 : BM][LDPT];
+    __shared__ __attribute__((aligned(16))) float Bs[BF ? 1 : NBUF][BF ? 1 : BN][LDPT];
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[BF ? 2 : 1][3][BF ? BM : 1][LDH];   // [buffer][term][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short Bh[BF ? 2 : 1][3][BF ? BN : 1][LDH];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm0 = (wave / WGN) * (WTM * 32), wn0 = (wave % WGN) * (WTN * 32);
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
         }
     };
     auto store_ab = [&](int buf, const float4 *ra, const float4 *rb) {
-        if (PREC) {
+        if (BF) {
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
                 const Split4 sp = split3(ra[i]);
@@ -307,7 +309,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
     __syncthreads();
     const int row = lane & 31, h = lane >> 5;
     for (int step = 0; step < T; ++step) {
-        const int cur = step & 1;
+        const int cur = NBUF == 2 ? (step & 1) : 0;
         if (step + 1 < T) {                       // prefetch the next slice into registers
             load_a(ra);
             load_b(rb);
@@ -317,7 +319,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
 #pragma unroll
         for (int part = 0; part < BKT / 16; ++part) {
             const int e0 = (BKT / 2) * h + 8 * part;
-            if (PREC) {
+            if (BF) {
                 // one 32x32x16 bf16 MFMA consumes the 8 elements of both half-waves; 6 term pairs, smallest first
                 u32x4 ah[WTM][3], bh[WTN][3];
 #pragma unroll
@@ -364,7 +366,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
 #pragma unroll
                     for (int j = 0; j < WTN; ++j) acc[i][j] = mfma32(af[i][e], bf[j][e], acc[i][j]);
         }
-        if (step + 1 < T) store_ab(cur ^ 1, ra, rb);
+        if (NBUF == 1) __syncthreads();           // single buffer: everyone has read the slice before it is overwritten
+        if (step + 1 < T) store_ab(NBUF == 2 ? (cur ^ 1) : 0, ra, rb);
         __syncthreads();
     }
 
@@ -851,6 +854,7 @@ extern "C" int sqd_conv_supported(int C, int K) { return (C % 16 == 0 && K % 16 
 struct GemmPlan {
     int bm, bn, z, bk;
     int waves = 4;                  // wavefronts per workgroup: 4, or 8 on the >= 128x64 tiles (one 32x32 tile per wave)
+    int single = 0;                 // 1: single-buffered LDS variant (bk + 512 in sqd_conv_set_plan)
     int64_t ws_floats;
 };
 // measured plans registered through sqd_conv_set_plan: (mode, geometry) -> (bm, bn, z)
@@ -921,6 +925,7 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
             p.z = std::get<2>(it->second);
             p.bk = std::get<3>(it->second) & 255;
             p.waves = (std::get<3>(it->second) & 256) ? 8 : 4;
+            p.single = (std::get<3>(it->second) & 512) ? 1 : 0;
         }
     }
     int z = p.z;
@@ -950,7 +955,19 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(512), 0, st, \
                        a_src, w, bias, dst, g, act, p.z, order, stats)
 #define DISPATCH_GEMM(MODE)                                                      \
-    if (p.waves == 8 && p.bm == 128 && p.bn == 128) LAUNCH_GEMM8(MODE, 128, 128, 4, 2, 16); \
+    if (p.single && p.bm == 64 && p.bn == 64) {                                  \
+        if (p.bk == 32) LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 32, 2);                \
+        else LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 16, 2);                           \
+    } else if (p.single && p.bm == 128 && p.bn == 64 && p.bk == 32) {            \
+        LAUNCH_GEMM_P(MODE, 128, 64, 2, 2, 32, 2);                               \
+    } else if (p.single && p.bm == 64 && p.bn == 128 && p.bk == 32) {            \
+        LAUNCH_GEMM_P(MODE, 64, 128, 2, 2, 32, 2);                               \
+    } else if (p.single && p.bm == 128 && p.bn == 128) {                         \
+        LAUNCH_GEMM_P(MODE, 128, 128, 2, 2, 16, 2);                              \
+    } else if (p.single && p.bm == 128 && p.bn == 32) {                          \
+        if (p.bk == 32) LAUNCH_GEMM_P(MODE, 128, 32, 4, 1, 32, 2);               \
+        else LAUNCH_GEMM_P(MODE, 128, 32, 4, 1, 16, 2);                          \
+    } else if (p.waves == 8 && p.bm == 128 && p.bn == 128) LAUNCH_GEMM8(MODE, 128, 128, 4, 2, 16); \
     else if (p.waves == 8 && p.bm == 128 && p.bn == 64) {                        \
         if (p.bk == 32) LAUNCH_GEMM8(MODE, 128, 64, 4, 2, 32);                   \
         else LAUNCH_GEMM8(MODE, 128, 64, 4, 2, 16);                              \
@@ -1029,7 +1046,11 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     const int Ncols = mode == 0 ? K : C;
     const int taps = mode == 0 ? R * S : ((R + stride - 1) / stride) * ((S + stride - 1) / stride);
     const int waves = (bk & 256) ? 8 : 4;                        // bk + 256: 8-wave workgroups (one 32x32 tile per wave)
+    const int single = (bk & 512) ? 1 : 0;                       // bk + 512: single-buffered LDS (twice the resident workgroups)
     bk &= 255;
+    SQD_CHECK_ARG(!single || (waves == 4 && ((bm == 64 && bn == 64) || (bm + bn == 192 && bk == 32) || (bm == 128 && bn == 128 && bk == 16) ||
+                                             (bm == 128 && bn == 32))),
+                  "sqd_conv_set_plan: single-buffered variants exist for 64x64, 128x32, 128x64 / 64x128 (bk 32) and 128x128 (bk 16)");
     SQD_CHECK_ARG(waves == 4 || (bm == 128 && bn == 128 && bk == 16) || (bm == 128 && bn == 64) || (bm == 64 && bn == 128 && bk == 32),
                   "sqd_conv_set_plan: 8-wave workgroups exist for 128x128 (bk 16), 128x64 and 64x128 (bk 32) tiles");
     SQD_CHECK_ARG(bk == 16 || (bk == 32 && (mode == 0 ? C : K) % 32 == 0 && bm + bn <= 192),
@@ -1041,7 +1062,7 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     SQD_CHECK_ARG(!(bn > 32 && bn >= 2 * Ncols) && !(bn == 32 && Ncols > 32), "sqd_conv_set_plan: tile width %d does not fit %d channels", bn, Ncols);
     SQD_CHECK_ARG(z == 1 || (z <= T / 2 && z * out_elems * 4 <= (64ll << 20) && out_elems % 4 == 0),
                   "sqd_conv_set_plan: split-K %d not possible here", z);
-    plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, bk | (waves == 8 ? 256 : 0));
+    plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, bk | (waves == 8 ? 256 : 0) | (single ? 512 : 0));
     return SQD_OK;
 }
 

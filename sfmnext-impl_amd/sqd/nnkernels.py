@@ -183,9 +183,11 @@ def _tune_conv(mode, geom, launch):
     _TUNED.add(key)
     L = _l.lib()
     best = None
-    # (bk + 256 = the 8-wave workgroup variants: picked for a third of the config-B layers when offered, each a 1-3 % win, no
+    # bk + 512 = the single-buffered LDS variants (half the LDS per workgroup, twice the resident workgroups, one more barrier
+    # per slice): picked for three quarters of the config-B layers, forward -5 %, data gradient -2 %.
+    # (bk + 256 = the 8-wave workgroup variants: picked for a third of the layers when offered, each a 1-3 % win, no
     # measurable change of the step — left out of the default search, SQD_TUNE_8WAVE=1 adds them)
-    bks = (16, 32, 272, 288) if os.environ.get("SQD_TUNE_8WAVE") else (16, 32)
+    bks = (16, 32, 528, 544) + ((272, 288) if os.environ.get("SQD_TUNE_8WAVE") else ())
     for bm, bn, z, bk in ((bm, bn, z, bk) for bm, bn in _TUNE_TILES for bk in bks for z in _TUNE_Z):
         if True:
             if L.sqd_conv_set_plan(mode, *geom, bm, bn, z, bk) != 0:
