@@ -1153,12 +1153,16 @@ static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, i
     const int ov = wgrad_impl_override();
     int m_impl = -1, m_splits = 0;
     const bool measured = wplan_lookup(N, Ho, Wo, C, K, R, S, m_impl, m_splits);
+    const int fkt = measured ? (m_impl >> 4) & 15 : 0, fct = measured ? (m_impl >> 8) & 15 : 0;   // measured register-tile shape (0: default)
+    if (measured) m_impl &= 1;
     // the direct kernel wins where pixels are many and channels few (operand re-reads stay in L2); the LDS-tiled
     // kernel where K*C is large and the pixel count small
     p.direct = C % 16 == 0 && K % 16 == 0 && (ov == 2 || (ov == 0 && M >= 2048 && C <= 1024));
     if (measured && ov == 0) p.direct = m_impl == 1 && C % 16 == 0 && K % 16 == 0;
     p.kt = K % 64 == 0 ? 4 : K % 32 == 0 ? 2 : 1;
     p.ct = C % 64 == 0 ? 4 : C % 32 == 0 ? 2 : 1;
+    if (fkt) p.kt = fkt;                                         // a smaller register tile = more resident waves (the 4x4 tile's 184
+    if (fct) p.ct = fct;                                         // VGPRs and 66 KB of LDS leave two workgroups per CU)
     // a filter row (3 taps) per wave: measured SLOWER on every config-B layer (3x3 64..256 channels: 140 us vs 102 us) — the
     // 192-256 accumulator registers leave one wave per SIMD and nothing hides the operand latency.  Kept for experiments.
     static const bool tp3 = getenv("SQD_WGRAD_TP3") != nullptr;
@@ -1204,7 +1208,8 @@ extern "C" int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, i
     return SQD_OK;
 }
 
-// Register a measured weight-gradient plan: impl 1 = direct-operand kernel, 0 = LDS-tiled kernel, -1 = clear; `splits` pixel
+// Register a measured weight-gradient plan: impl 1 = direct-operand kernel (+ 16*kt + 256*ct: its register tile covers 16*kt
+// filters x 16*ct channels, kt, ct in {1,2,4}; 0 = the widest that divides), 0 = LDS-tiled kernel, -1 = clear; `splits` pixel
 // ranges (clamped by the library to >= 256 pixels per range and a 64 MB partial buffer).  sqd_conv_wgrad_plan reports the
 // resulting workspace.
 extern "C" int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int impl, int splits) {
@@ -1213,8 +1218,12 @@ extern "C" int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int 
         wplan_table().erase(WPlanKey(N, Ho, Wo, C, K, R, S));
         return SQD_OK;
     }
-    SQD_CHECK_ARG(impl <= 1 && splits >= 1 && splits <= 65535, "sqd_conv_wgrad_set_plan: bad plan impl=%d splits=%d", impl, splits);
-    SQD_CHECK_ARG(impl == 0 || (C % 16 == 0 && K % 16 == 0), "sqd_conv_wgrad_set_plan: the direct kernel needs C, K multiples of 16");
+    const int kt = (impl >> 4) & 15, ct = (impl >> 8) & 15;      // optional register-tile shape of the direct kernel: 16*kt x 16*ct
+    SQD_CHECK_ARG((impl & ~0xff1) == 0 && splits >= 1 && splits <= 65535, "sqd_conv_wgrad_set_plan: bad plan impl=%d splits=%d", impl, splits);
+    SQD_CHECK_ARG((impl & 1) == 0 || (C % 16 == 0 && K % 16 == 0), "sqd_conv_wgrad_set_plan: the direct kernel needs C, K multiples of 16");
+    SQD_CHECK_ARG((kt == 0 && ct == 0) || ((impl & 1) && (kt == 1 || kt == 2 || kt == 4) && (ct == 1 || ct == 2 || ct == 4) &&
+                                          K % (16 * kt) == 0 && C % (16 * ct) == 0),
+                  "sqd_conv_wgrad_set_plan: register tile %dx%d does not fit K=%d, C=%d", kt, ct, K, C);
     wplan_table()[WPlanKey(N, Ho, Wo, C, K, R, S)] = std::make_pair(impl, splits);
     return SQD_OK;
 }

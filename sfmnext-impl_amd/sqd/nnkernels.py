@@ -226,8 +226,15 @@ def _tune_wgrad(geom, has_bias, launch):
     _PLAN_CACHE.pop(key, None)
     _, base = _wgrad_part_floats(geom)
     best = None
-    for impl in (1, 0):
-        if impl == 1 and (C % 16 or K % 16):
+    # direct kernel with its default register tile (the widest that divides: 64 filters x 64 channels), then the LDS-tiled kernel.
+    # (Smaller register tiles — more resident waves, more operand re-reads; impl 1 + 16 kt + 256 ct — win on 7 of the 38 config-B
+    # layers and nothing on the step: SQD_TUNE_WSHAPE=1 adds them to the search.)
+    shapes = [1]
+    if os.environ.get("SQD_TUNE_WSHAPE"):
+        shapes += [1 | (kt << 4) | (ct << 8) for kt, ct in ((2, 4), (4, 2), (2, 2)) if K % (16 * kt) == 0 and C % (16 * ct) == 0
+                   and (K % 64 == 0 or kt < 4) and (C % 64 == 0 or ct < 4)]
+    for impl in shapes + [0]:
+        if impl & 1 and (C % 16 or K % 16):
             continue
         tried = set()
         for mult in (0.125, 0.25, 0.5, 1, 2, 4):

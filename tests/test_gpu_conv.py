@@ -203,3 +203,37 @@ def test_split_precision_variant(N, C, H, W, K, R, stride, pad, bias, act):
         e32, ebf = float((res[0][i] - ref).abs().max()), float((res[1][i] - ref).abs().max())
         assert ebf <= 1e-4 * scale, (name, ebf, scale)
         assert ebf <= 4.0 * e32 + 1e-7 * scale, (name, "split precision", ebf, "fp32 MFMA", e32)
+
+
+@pytest.mark.parametrize("kt,ct", [(2, 4), (4, 2), (2, 2), (1, 1), (4, 4)])
+def test_wgrad_register_tile_shapes(kt, ct):
+    """every register-tile shape of the direct-operand weight-gradient kernel the tuner may register (impl 1 + 16 kt + 256 ct)"""
+    from sqd import lib, nnkernels
+    L = lib.lib()
+    N, C, H, W, K, R, stride, pad = 4, 64, 24, 40, 128, 3, 1, 1
+    torch.manual_seed(kt * 10 + ct)
+    conv = nn.Conv2d(C, K, R, stride, pad, bias=True)
+    x = torch.randn(N, C, H, W)
+    xr = x.double().requires_grad_(True)
+    conv64 = nn.Conv2d(C, K, R, stride, pad, bias=True).double()
+    conv64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    yr = conv64(xr)
+    wgt = torch.randn(yr.shape)
+    (yr * wgt.double()).sum().backward()
+    geom = (N, H, W, C, K, R, R, stride, pad, H, W)
+    try:
+        assert L.sqd_conv_wgrad_set_plan(N, H, W, C, K, R, R, 1 | (kt << 4) | (ct << 8), 6) == 0
+        nnkernels._PLAN_CACHE.clear()
+        conv_g = nn.Conv2d(C, K, R, stride, pad, bias=True).cuda()
+        conv_g.load_state_dict(conv.state_dict())
+        conv_g = conv_g.to(memory_format=torch.channels_last)
+        xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = nnkernels.conv2d_native(xg, conv_g, None)
+        (y * wgt.cuda()).sum().backward()
+    finally:
+        L.sqd_conv_wgrad_set_plan(N, H, W, C, K, R, R, -1, 0)
+        nnkernels._PLAN_CACHE.clear()
+    for name, a, b in (("dw", conv_g.weight.grad, conv64.weight.grad), ("db", conv_g.bias.grad, conv64.bias.grad)):
+        err, scale = float((a.cpu().double() - b).abs().max()), float(b.abs().max())
+        assert err <= 1e-4 * scale, (name, err, scale)
+    assert L.sqd_conv_wgrad_set_plan(N, H, W, C, 48, R, R, 1 | (4 << 4) | (4 << 8), 6) != 0       # 64-filter tile on K = 48: refused
