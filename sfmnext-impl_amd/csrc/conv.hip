@@ -88,7 +88,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
     // twice the LDS footprint
     constexpr int NQ = BKT / 4, LDPT = BKT + 4, RPP = NT / NQ;  // float4 per staged row, LDS row pitch, rows per staging pass
     constexpr int A_F4 = BM * NQ / NT;
-    static_assert(A_F4 >= 1 && (BKT == 16 || BKT == 32), "BM >= 64, BKT in {16, 32}");
+    static_assert(A_F4 >= 1 && (BKT == 16 || BKT == 32 || BKT == 64), "BM >= 64, BKT in {16, 32, 64}");
     constexpr bool BF = PREC == 1;                              // split-precision bf16 operands
     constexpr int NBUF = PREC == 2 ? 1 : 2;                     // PREC 2: single LDS buffer (half the LDS, one more barrier per slice)
     constexpr int LDH = BKT + 8;                                // PREC 1: bf16 row pitch (48 / 80 bytes: conflict-free b128 reads)
@@ -929,7 +929,7 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
         }
     }
     int z = p.z;
-    if (p.bk == 32) z = z <= T / 4 ? z : 1;                      // (slices are twice as wide)
+    if (p.bk >= 32) z = z <= T / (p.bk / 8) ? z : 1;             // (slices are 2x / 4x as wide)
     static const char *force = getenv("SQD_CONV_PLAN");          // "bm,bn,z": tuning experiments only
     if (force) {
         int fbm, fbn, fz;
@@ -956,7 +956,8 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
                        a_src, w, bias, dst, g, act, p.z, order, stats)
 #define DISPATCH_GEMM(MODE)                                                      \
     if (p.single && p.bm == 64 && p.bn == 64) {                                  \
-        if (p.bk == 32) LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 32, 2);                \
+        if (p.bk == 64) LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 64, 2);                \
+        else if (p.bk == 32) LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 32, 2);           \
         else LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 16, 2);                           \
     } else if (p.single && p.bm == 128 && p.bn == 64 && p.bk == 32) {            \
         LAUNCH_GEMM_P(MODE, 128, 64, 2, 2, 32, 2);                               \
@@ -1053,8 +1054,10 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
                   "sqd_conv_set_plan: single-buffered variants exist for 64x64, 128x32, 128x64 / 64x128 (bk 32) and 128x128 (bk 16)");
     SQD_CHECK_ARG(waves == 4 || (bm == 128 && bn == 128 && bk == 16) || (bm == 128 && bn == 64) || (bm == 64 && bn == 128 && bk == 32),
                   "sqd_conv_set_plan: 8-wave workgroups exist for 128x128 (bk 16), 128x64 and 64x128 (bk 32) tiles");
-    SQD_CHECK_ARG(bk == 16 || (bk == 32 && (mode == 0 ? C : K) % 32 == 0 && bm + bn <= 192),
-                  "sqd_conv_set_plan: slice width %d not possible here (32 needs 32 | reduced channels and bm + bn <= 192)", bk);
+    SQD_CHECK_ARG(bk == 16 || (bk == 32 && (mode == 0 ? C : K) % 32 == 0 && bm + bn <= 192) ||
+                      (bk == 64 && single && bm == 64 && bn == 64 && (mode == 0 ? C : K) % 64 == 0),
+                  "sqd_conv_set_plan: slice width %d not possible here (32 needs 32 | reduced channels and bm + bn <= 192; 64 exists "
+                  "for the single-buffered 64x64 tile with 64 | reduced channels)", bk);
     const int T = taps * ((mode == 0 ? C : K) / bk);
     const int64_t out_elems = mode == 0 ? (int64_t)N * Ho * Wo * K : (int64_t)N * H * W * C;
     const bool tile_ok = (bm == 128 && (bn == 128 || bn == 64 || bn == 32)) || (bm == 64 && (bn == 128 || bn == 64));

@@ -187,7 +187,9 @@ def _tune_conv(mode, geom, launch):
     # per slice): picked for three quarters of the config-B layers, forward -5 %, data gradient -2 %.
     # (bk + 256 = the 8-wave workgroup variants: picked for a third of the layers when offered, each a 1-3 % win, no
     # measurable change of the step — left out of the default search, SQD_TUNE_8WAVE=1 adds them)
-    bks = (16, 32, 528, 544) + ((272, 288) if os.environ.get("SQD_TUNE_8WAVE") else ())
+    # (bk 64 + 512 = a 64-channel slice on the single-buffered 64x64 tile: half the barriers again, picked for 11 layer-modes, no
+    # gain on the totals — SQD_TUNE_BK64=1 adds it)
+    bks = (16, 32, 528, 544) + ((576,) if os.environ.get("SQD_TUNE_BK64") else ()) + ((272, 288) if os.environ.get("SQD_TUNE_8WAVE") else ())
     for bm, bn, z, bk in ((bm, bn, z, bk) for bm, bn in _TUNE_TILES for bk in bks for z in _TUNE_Z):
         if True:
             if L.sqd_conv_set_plan(mode, *geom, bm, bn, z, bk) != 0:
