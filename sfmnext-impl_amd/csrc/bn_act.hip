@@ -180,14 +180,24 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float *__restri
                                                            const float *__restrict__ mean, const float *__restrict__ rstd,
                                                            float *__restrict__ y, size_t total4, int C, float eps, int act,
                                                            unsigned char *__restrict__ mask) {
-    const int V = C / 4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const int cg = (int)(i % V);
-        const float4 xv = reinterpret_cast<const float4 *>(x)[i];
-        const float4 ga = reinterpret_cast<const float4 *>(gamma)[cg], be = reinterpret_cast<const float4 *>(beta)[cg];
-        const float4 mu = reinterpret_cast<const float4 *>(mean)[cg];
-        float4 rs = reinterpret_cast<const float4 *>(rstd)[cg];
+    // the channel group of a thread's element advances by (grid stride mod V) per iteration — zero whenever V divides 256, i.e.
+    // for every C <= 1024: the per-channel constants are then loaded once, and no 64-bit modulo runs inside the loop
+    const unsigned V = (unsigned)C / 4u;
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned cg = (unsigned)(i % V);
+    const unsigned cstep = (unsigned)(stride % V);
+    float4 ga, be, mu, rs;
+    auto params = [&]() {
+        ga = reinterpret_cast<const float4 *>(gamma)[cg];
+        be = reinterpret_cast<const float4 *>(beta)[cg];
+        mu = reinterpret_cast<const float4 *>(mean)[cg];
+        rs = reinterpret_cast<const float4 *>(rstd)[cg];
         if (EVAL) rs = make_float4(rsqrtf(rs.x + eps), rsqrtf(rs.y + eps), rsqrtf(rs.z + eps), rsqrtf(rs.w + eps));
+    };
+    params();
+    for (; i < total4; i += stride) {
+        const float4 xv = reinterpret_cast<const float4 *>(x)[i];
         float4 o;
         o.x = fmaf((xv.x - mu.x) * rs.x, ga.x, be.x);
         o.y = fmaf((xv.y - mu.y) * rs.y, ga.y, be.y);
@@ -201,6 +211,11 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float *__restri
             mask[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
         o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
         reinterpret_cast<float4 *>(y)[i] = o;
+        if (cstep) {                                            // uniform
+            cg += cstep;
+            cg -= cg >= V ? V : 0u;
+            params();
+        }
     }
 }
 
@@ -210,23 +225,38 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
                                                            const float *__restrict__ dgamma, const float *__restrict__ dbeta,
                                                            float *__restrict__ dx, float *__restrict__ dres, size_t total4,
                                                            int C, float invM, int act, const unsigned char *__restrict__ mask) {
-    const int V = C / 4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const int cg = (int)(i % V);
+    const unsigned V = (unsigned)C / 4u;
+    const size_t stride = (size_t)gridDim.x * 256;
+    size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    unsigned cg = (unsigned)(i % V);
+    const unsigned cstep = (unsigned)(stride % V);              // 0 whenever V divides 256 (C <= 1024): constants loaded once
+    float4 k0, k1, k2, mu;                                      // dx = k0 * dz - k1 - (x - mu) * k2
+    auto params = [&]() {
+        const float4 ga = reinterpret_cast<const float4 *>(gamma)[cg], rs = reinterpret_cast<const float4 *>(rstd)[cg];
+        const float4 dg = reinterpret_cast<const float4 *>(dgamma)[cg], db = reinterpret_cast<const float4 *>(dbeta)[cg];
+        mu = reinterpret_cast<const float4 *>(mean)[cg];
+        k0 = make_float4(ga.x * rs.x, ga.y * rs.y, ga.z * rs.z, ga.w * rs.w);
+        k1 = make_float4(db.x * invM, db.y * invM, db.z * invM, db.w * invM);
+        k2 = make_float4(rs.x * (dg.x * invM), rs.y * (dg.y * invM), rs.z * (dg.z * invM), rs.w * (dg.w * invM));
+    };
+    params();
+    for (; i < total4; i += stride) {
         const float4 gy = reinterpret_cast<const float4 *>(dy)[i];
         const float4 xv = reinterpret_cast<const float4 *>(x)[i];
         const float4 da = act_bwd4(mask, y, i, act);
-        const float4 ga = reinterpret_cast<const float4 *>(gamma)[cg], mu = reinterpret_cast<const float4 *>(mean)[cg];
-        const float4 rs = reinterpret_cast<const float4 *>(rstd)[cg];
-        const float4 dg = reinterpret_cast<const float4 *>(dgamma)[cg], db = reinterpret_cast<const float4 *>(dbeta)[cg];
         float4 dz, o;
         dz.x = gy.x * da.x; dz.y = gy.y * da.y; dz.z = gy.z * da.z; dz.w = gy.w * da.w;
-        o.x = ga.x * rs.x * (dz.x - db.x * invM - (xv.x - mu.x) * rs.x * (dg.x * invM));
-        o.y = ga.y * rs.y * (dz.y - db.y * invM - (xv.y - mu.y) * rs.y * (dg.y * invM));
-        o.z = ga.z * rs.z * (dz.z - db.z * invM - (xv.z - mu.z) * rs.z * (dg.z * invM));
-        o.w = ga.w * rs.w * (dz.w - db.w * invM - (xv.w - mu.w) * rs.w * (dg.w * invM));
+        o.x = k0.x * (dz.x - k1.x - (xv.x - mu.x) * k2.x);
+        o.y = k0.y * (dz.y - k1.y - (xv.y - mu.y) * k2.y);
+        o.z = k0.z * (dz.z - k1.z - (xv.z - mu.z) * k2.z);
+        o.w = k0.w * (dz.w - k1.w - (xv.w - mu.w) * k2.w);
         reinterpret_cast<float4 *>(dx)[i] = o;
         if (dres) reinterpret_cast<float4 *>(dres)[i] = dz;
+        if (cstep) {                                            // uniform
+            cg += cstep;
+            cg -= cg >= V ? V : 0u;
+            params();
+        }
     }
 }
 
