@@ -28,18 +28,20 @@ __device__ __forceinline__ Tap tap_ac(int dst, float scale, int in_size) {
 __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float *__restrict__ x, const float *__restrict__ skip,
                                                         float *__restrict__ out, int N, int Hi, int Wi, int Cx, int Ho, int Wo,
                                                         int Cs, float sy, float sx) {
-    const int Ct = Cx + Cs, Vt = Ct / 4, Vx = Cx / 4;
-    const size_t total = (size_t)N * Ho * Wo * Vt;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int cv = (int)(i % Vt);
-        const size_t pix = i / Vt;
+    // 32-bit index arithmetic (the host checks that every tensor has fewer than 2^31 float4 groups): the six 64-bit
+    // divisions per element of the size_t version were most of this kernel's instructions
+    const unsigned Ct = Cx + Cs, Vt = Ct / 4, Vx = Cx / 4;
+    const unsigned total = (unsigned)N * Ho * Wo * Vt;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+        const unsigned cv = i % Vt;
+        const unsigned pix = i / Vt;
         if (cv >= Vx) {
             reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(skip)[pix * (Cs / 4) + (cv - Vx)];
             continue;
         }
-        const int xo = (int)(pix % Wo);
-        const size_t t2 = pix / Wo;
-        const int yo = (int)(t2 % Ho), n = (int)(t2 / Ho);
+        const int xo = (int)(pix % (unsigned)Wo);
+        const unsigned t2 = pix / (unsigned)Wo;
+        const int yo = (int)(t2 % (unsigned)Ho), n = (int)(t2 / (unsigned)Ho);
         const Tap ty = tap_ac(yo, sy, Hi), tx = tap_ac(xo, sx, Wi);
         const float4 *xb = reinterpret_cast<const float4 *>(x) + (size_t)n * Hi * Wi * Vx + cv;
         const float4 v00 = xb[((size_t)ty.i0 * Wi + tx.i0) * Vx], v01 = xb[((size_t)ty.i0 * Wi + tx.i1) * Vx];
@@ -57,20 +59,20 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float *__restrict_
 __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float *__restrict__ g_out, float *__restrict__ g_x,
                                                         float *__restrict__ g_skip, int N, int Hi, int Wi, int Cx, int Ho,
                                                         int Wo, int Cs, float sy, float sx, float isy, float isx) {
-    const int Ct = Cx + Cs, Vt = Ct / 4, Vx = Cx / 4, Vs = Cs / 4;
-    const size_t nx = (size_t)N * Hi * Wi * Vx, ns = (size_t)N * Ho * Wo * Vs;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nx + ns; i += (size_t)gridDim.x * 256) {
+    const unsigned Ct = Cx + Cs, Vt = Ct / 4, Vx = Cx / 4, Vs = Cs / 4;
+    const unsigned nx = (unsigned)N * Hi * Wi * Vx, ns = (unsigned)N * Ho * Wo * Vs;
+    for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nx + ns; i += gridDim.x * 256u) {
         if (i >= nx) {
-            const size_t k = i - nx;
-            const size_t pix = k / Vs;
-            reinterpret_cast<float4 *>(g_skip)[k] = reinterpret_cast<const float4 *>(g_out)[pix * Vt + Vx + (k % Vs)];
+            const unsigned k = i - nx;
+            const unsigned pix = k / Vs;
+            reinterpret_cast<float4 *>(g_skip)[k] = reinterpret_cast<const float4 *>(g_out)[(size_t)pix * Vt + Vx + (k % Vs)];
             continue;
         }
-        const int cv = (int)(i % Vx);
-        const size_t pix = i / Vx;
-        const int xi = (int)(pix % Wi);
-        const size_t t2 = pix / Wi;
-        const int yi = (int)(t2 % Hi), n = (int)(t2 / Hi);
+        const unsigned cv = i % Vx;
+        const unsigned pix = i / Vx;
+        const int xi = (int)(pix % (unsigned)Wi);
+        const unsigned t2 = pix / (unsigned)Wi;
+        const int yi = (int)(t2 % (unsigned)Hi), n = (int)(t2 / (unsigned)Hi);
         // destination rows / columns whose taps can touch (yi, xi) — conservative, membership re-tested
         const int ylo = max(0, (int)floorf(((float)yi - 1.f) * isy) - 1), yhi = min(Ho - 1, (int)ceilf(((float)yi + 1.f) * isy) + 1);
         const int xlo = max(0, (int)floorf(((float)xi - 1.f) * isx) - 1), xhi = min(Wo - 1, (int)ceilf(((float)xi + 1.f) * isx) + 1);
@@ -103,6 +105,7 @@ extern "C" int sqd_upcat_fwd(const float *x, const float *skip, float *out, int 
     SQD_CHECK_ARG(x && skip && out, "sqd_upcat_fwd: null pointer");
     SQD_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cx % 4 == 0 && Cs % 4 == 0 && Cx > 0 && Cs > 0,
                   "sqd_upcat_fwd: bad shape (channels must be multiples of 4)");
+    SQD_CHECK_ARG((long long)N * Ho * Wo * (Cx + Cs) / 4 < (1ll << 31), "sqd_upcat_fwd: output of 2^31 float4 groups or more");
     const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
     (void)hipGetLastError();
     hipLaunchKernelGGL(upcat_fwd_kernel, dim3(grid_for((size_t)N * Ho * Wo * (Cx + Cs) / 4)), dim3(256), 0, (hipStream_t)stream, x,
@@ -119,6 +122,7 @@ extern "C" int sqd_upcat_bwd(const float *g_out, float *g_x, float *g_skip, int 
     const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
     const float isy = sy > 0.f ? 1.f / sy : (float)Ho, isx = sx > 0.f ? 1.f / sx : (float)Wo;
     const size_t total = (size_t)N * Hi * Wi * Cx / 4 + (size_t)N * Ho * Wo * Cs / 4;
+    SQD_CHECK_ARG(total < (1ull << 31) && (long long)N * Ho * Wo * (Cx + Cs) / 4 < (1ll << 31), "sqd_upcat_bwd: tensors of 2^31 float4 groups or more");
     (void)hipGetLastError();
     hipLaunchKernelGGL(upcat_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g_out, g_x, g_skip, N, Hi, Wi,
                        Cx, Ho, Wo, Cs, sy, sx, isy, isx);
