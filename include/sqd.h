@@ -270,6 +270,12 @@ int sqd_bins_fwd(const float *energy, const float *weight, const float *bias, co
 int sqd_bins_bwd(const float *energy, const float *weight, const float *bias, const float *centers, const float *g_pred,
                  float *g_energy, float *g_weight, float *g_bias, float *g_centers, float *part, int B, int Q, int D, int N,
                  void *stream);
+/* bin centres from the regressor's raw outputs (norm "linear"; reference networks/depth_decoder_QTR.py:56-66 + the
+ * pad / cumsum / mid-point arithmetic of :62-66): v = relu(y) + 0.1, w = v / sum(v), edges = cumsum([vmin, (vmax-vmin) w]),
+ * centers = mid-points.  y, centers, g_* [B,D], sums [B] (saved for the backward); D <= 128. */
+int sqd_bin_centers_fwd(const float *y, float *centers, float *sums, int B, int D, float vmin, float vmax, void *stream);
+int sqd_bin_centers_bwd(const float *y, const float *sums, const float *g_centers, float *g_y, int B, int D, float vmin, float vmax,
+                        void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * (12) MaxPool2d(3, stride 2, padding 1), channels-last.  replaces: the ResNet stem's maxpool (reference

@@ -446,3 +446,79 @@ extern "C" int sqd_bins_bwd(const float *energy, const float *weight, const floa
     SQD_CHECK_LAUNCH("sqd_bins_bwd");
     return SQD_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// bin centres from the regressor's raw outputs (norm == "linear"; reference networks/depth_decoder_QTR.py:56-66):
+//   v = relu(y) + 0.1;  w = v / sum(v);  widths = (max - min) * w;  edges = cumsum([min, widths]);  centers = midpoints
+// [B, D] numbers, D <= 128: one launch instead of ~8 element-wise / scan launches forward and ~12 backward.  One wavefront
+// per row; the two scans run serially on lane 0 (left to right, the order of torch.cumsum).
+// ---------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(64) void bin_centers_fwd_kernel(const float *__restrict__ y, float *__restrict__ centers,
+                                                             float *__restrict__ sums, int D, float vmin, float vmax) {
+    __shared__ float v[128], c[129];
+    const int b = blockIdx.x, lane = threadIdx.x;
+    for (int d = lane; d < D; d += 64) v[d] = fmaxf(y[(size_t)b * D + d], 0.f) + 0.1f;
+    __syncthreads();
+    if (lane == 0) {
+        float s = 0.f;
+        for (int d = 0; d < D; ++d) s += v[d];
+        sums[b] = s;
+        float e = vmin;                                   // edges[0] = min, edges[d+1] = edges[d] + width[d]
+        c[0] = e;
+        for (int d = 0; d < D; ++d) {
+            e += (vmax - vmin) * (v[d] / s);
+            c[d + 1] = e;
+        }
+    }
+    __syncthreads();
+    for (int d = lane; d < D; d += 64) centers[(size_t)b * D + d] = 0.5f * (c[d] + c[d + 1]);
+}
+
+__global__ __launch_bounds__(64) void bin_centers_bwd_kernel(const float *__restrict__ y, const float *__restrict__ sums,
+                                                             const float *__restrict__ g_centers, float *__restrict__ g_y, int D,
+                                                             float vmin, float vmax) {
+    __shared__ float v[128], gw[128];
+    __shared__ float dot;
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const float s = sums[b], R = vmax - vmin;
+    for (int d = lane; d < D; d += 64) {
+        v[d] = fmaxf(y[(size_t)b * D + d], 0.f) + 0.1f;
+        // d centers / d edges: edge k (k = 1..D) is shared by the centres k-1 and k
+        const float gc0 = g_centers[(size_t)b * D + d], gc1 = d + 1 < D ? g_centers[(size_t)b * D + d + 1] : 0.f;
+        gw[d] = 0.5f * (gc0 + gc1);                        // gradient of edge d+1, before the reverse scan
+    }
+    __syncthreads();
+    if (lane == 0) {
+        float acc = 0.f, dt = 0.f;
+        for (int d = D - 1; d >= 0; --d) {                // width d feeds every edge after it
+            acc += gw[d];
+            gw[d] = acc;
+            dt += acc * v[d];
+        }
+        dot = dt;
+    }
+    __syncthreads();
+    for (int d = lane; d < D; d += 64) {
+        const float gv = R * (gw[d] - dot / s) / s;       // w = v / s
+        g_y[(size_t)b * D + d] = y[(size_t)b * D + d] > 0.f ? gv : 0.f;
+    }
+}
+}  // namespace
+
+// y [B,D] raw regressor outputs -> centers [B,D] (bin mid-points between vmin and vmax), sums [B] (for the backward); D <= 128
+extern "C" int sqd_bin_centers_fwd(const float *y, float *centers, float *sums, int B, int D, float vmin, float vmax, void *stream) {
+    SQD_CHECK_ARG(y && centers && sums && B >= 1 && D >= 1 && D <= 128, "sqd_bin_centers_fwd: bad arguments (B=%d, D=%d)", B, D);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(bin_centers_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, y, centers, sums, D, vmin, vmax);
+    SQD_CHECK_LAUNCH("sqd_bin_centers_fwd");
+    return SQD_OK;
+}
+extern "C" int sqd_bin_centers_bwd(const float *y, const float *sums, const float *g_centers, float *g_y, int B, int D, float vmin,
+                                   float vmax, void *stream) {
+    SQD_CHECK_ARG(y && sums && g_centers && g_y && B >= 1 && D >= 1 && D <= 128, "sqd_bin_centers_bwd: bad arguments (B=%d, D=%d)", B, D);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(bin_centers_bwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, y, sums, g_centers, g_y, D, vmin, vmax);
+    SQD_CHECK_LAUNCH("sqd_bin_centers_bwd");
+    return SQD_OK;
+}

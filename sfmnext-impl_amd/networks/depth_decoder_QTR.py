@@ -54,7 +54,9 @@ class _QueryTrBase(nn.Module):
         y = X.linear(y, self.bins_regressor[2], "leaky_relu")
         y = X.linear(y, self.bins_regressor[4])
         if self.norm == "linear":
-            y = torch.relu(y) + 0.1
+            # relu + 0.1, normalisation, widths, cumsum and mid-points in one kernel (nnops.bins_head, raw_linear)
+            pred = X.bins_head(energy_maps, self.convert_to_prob[0], y, self.min_val, self.max_val, raw_linear=True)
+            return {("disp", 0): pred}
         elif self.norm == "softmax":
             return torch.softmax(y, dim=1), energy_maps
         else:

@@ -133,6 +133,8 @@ _SIGNATURES = {
     "sqd_mha_supported": (_I, [_I, _I, _I]),
     "sqd_mha_fwd": (_I, [_P] * 8 + [_I, _I, _I, _I, _F, _P]),
     "sqd_mha_bwd": (_I, [_P] * 13 + [_I, _I, _I, _I, _F, _P]),
+    "sqd_bin_centers_fwd": (_I, [_P, _P, _P, _I, _I, _F, _F, _P]),
+    "sqd_bin_centers_bwd": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _P]),
     "sqd_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sqd_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
     "sqd_space_to_depth2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

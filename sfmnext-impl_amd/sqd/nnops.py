@@ -164,13 +164,21 @@ def full_query_layer(x, queries):
     return y.view(n, queries.shape[1], h, w), summary
 
 
-def bins_head(energy_maps, conv1x1, y, min_val, max_val):
+def bins_head(energy_maps, conv1x1, y, min_val, max_val, raw_linear=False):
     """1x1 conv + channel softmax over the energy maps, expected value over the adaptive bin centres
-    (reference networks/depth_decoder_QTR.py:61-70).  y [B,dim_out] = normalised bin widths."""
-    widths = (max_val - min_val) * y
-    widths = F.pad(widths, (1, 0), mode="constant", value=min_val)
-    edges = torch.cumsum(widths, dim=1)
-    centers = 0.5 * (edges[:, :-1] + edges[:, 1:])
+    (reference networks/depth_decoder_QTR.py:61-70).  y [B,dim_out] = normalised bin widths — or, with raw_linear=True, the
+    regressor's raw outputs of the norm == "linear" head (:56-60: relu + 0.1, divide by the row sum), normalised here."""
+    if raw_linear and y.is_cuda and y.shape[1] <= 128:
+        from . import ops
+        centers = ops.BinCenters.apply(y, min_val, max_val)
+    else:
+        if raw_linear:
+            y = torch.relu(y) + 0.1
+            y = y / y.sum(dim=1, keepdim=True)
+        widths = (max_val - min_val) * y
+        widths = F.pad(widths, (1, 0), mode="constant", value=min_val)
+        edges = torch.cumsum(widths, dim=1)
+        centers = 0.5 * (edges[:, :-1] + edges[:, 1:])
     if energy_maps.is_cuda:
         from . import ops
         Q, D = energy_maps.shape[1], conv1x1.weight.shape[0]

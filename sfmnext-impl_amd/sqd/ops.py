@@ -364,6 +364,32 @@ class BinsHead(torch.autograd.Function):
         return g_e, g_w.view(ctx.wshape), g_b, g_c
 
 
+class BinCenters(torch.autograd.Function):
+    """Adaptive bin centres from the regressor's raw outputs (norm "linear": relu + 0.1, normalise, widths, cumsum, mid-points —
+    reference networks/depth_decoder_QTR.py:56-66) in one launch each way.  forward(y [B,D], vmin, vmax) -> centers [B,D]."""
+
+    @staticmethod
+    def forward(ctx, y, vmin, vmax):
+        y = y.contiguous()
+        _req(y)
+        B, D = y.shape
+        centers = torch.empty_like(y)
+        sums = torch.empty(B, device=y.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_bin_centers_fwd(_ptr(y), _ptr(centers), _ptr(sums), B, D, float(vmin), float(vmax), _stream()), "bin_centers_fwd")
+        ctx.save_for_backward(y, sums)
+        ctx.range = (float(vmin), float(vmax))
+        return centers
+
+    @staticmethod
+    def backward(ctx, g):
+        y, sums = ctx.saved_tensors
+        B, D = y.shape
+        g_y = torch.empty_like(y)
+        _l.check(_l.lib().sqd_bin_centers_bwd(_ptr(y), _ptr(sums), _ptr(g.contiguous()), _ptr(g_y), B, D, ctx.range[0], ctx.range[1],
+                                              _stream()), "bin_centers_bwd")
+        return g_y, None, None
+
+
 def bins_supported(Q, D):
     return 1 <= Q <= 128 and 1 <= D <= 128
 

@@ -73,3 +73,26 @@ def test_bins_head_deterministic():
         res.append([t.grad.clone() for t in a])
     for x, y in zip(*res):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("B,D", [(12, 64), (2, 100), (3, 128), (1, 1), (5, 24)])
+def test_bin_centers_linear_norm(B, D):
+    """relu + 0.1 -> normalise -> widths -> pad / cumsum -> mid-points (reference depth_decoder_QTR.py:56-66) as one kernel"""
+    from sqd import ops
+    g = torch.Generator().manual_seed(B * 7 + D)
+    y = torch.randn(B, D, generator=g)
+    gout = torch.randn(B, D, generator=g)
+    vmin, vmax = 0.001, 80.0
+    yr = y.double().requires_grad_(True)
+    v = torch.relu(yr) + 0.1
+    v = v / v.sum(dim=1, keepdim=True)
+    widths = F.pad((vmax - vmin) * v, (1, 0), mode="constant", value=vmin)
+    edges = torch.cumsum(widths, dim=1)
+    ref = 0.5 * (edges[:, :-1] + edges[:, 1:])
+    ref.backward(gout.double())
+    yd = y.cuda().requires_grad_(True)
+    out = ops.BinCenters.apply(yd, vmin, vmax)
+    out.backward(gout.cuda())
+    assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= 1e-5 * vmax
+    gs = float(yr.grad.abs().max())
+    assert float((yd.grad.cpu().double() - yr.grad).abs().max()) <= 1e-4 * gs + 1e-9
