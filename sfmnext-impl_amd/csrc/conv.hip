@@ -7,14 +7,17 @@
 //   dgrad   : dx[p, c] = sum_{r,s,k} dy[opix(p; r,s), k] * w[k, r, s, c]      M = N*H*W,   Kgemm = R*S*K
 //   wgrad   : dw[k,r,s,c] = sum_m dy[m, k] * x[pix(m; r,s), c]                split over pixel ranges
 //
-// Tiling: 256 threads = 4 wavefronts per workgroup, BM x BN output tile, BK = 16 reduction slice per
-// step held in LDS as [row][16 (+4 pad)] for both operands — exactly the memory order of NHWC pixels
-// and KRSC filters, so staging is plain 16-byte copies.  A lane feeds the MFMA with 8 consecutive
-// reduction elements of its row (two ds_read_b128, conflict-free with the 20-float row pitch); the two
-// half-waves own reduction elements 0-7 / 8-15 of the slice, so 8 MFMAs consume one slice.  Global
-// loads of slice t+1 are issued before the MFMAs of slice t and written to the other LDS buffer after
-// them (register-staged double buffering).  fp32 MFMA is an exact k-ordered fmaf chain, so results
-// match a direct fp32 convolution to accumulation-order rounding.
+// Tiling: 4 (or 8) wavefronts per workgroup, BM x BN output tile, a reduction slice of 16 / 32 / 64 channels per step held in
+// LDS as [row][slice (+4 pad)] for both operands — exactly the memory order of NHWC pixels and KRSC filters, so staging is
+// plain 16-byte copies.  A lane feeds the MFMA with 8 consecutive reduction elements of its row (two ds_read_b128,
+// conflict-free with the padded row pitch); the two half-waves own the two halves of the slice.  Global loads of slice t+1
+// are issued before the MFMAs of slice t (register staging) and written to the other LDS buffer after them — or, in the
+// single-buffered variants, to the same buffer behind one more barrier: half the LDS per workgroup means twice the resident
+// workgroups, which at batch-12 grid sizes (about two waves per SIMD resident) is worth more than the saved barrier.
+// Every global access is a raw buffer load / store: padding taps, rows beyond the tile and channels beyond the tensor get an
+// offset beyond the descriptor's extent (reads return 0, writes are dropped) instead of a branch.  Which tile, slice width,
+// split-K factor and buffering a layer uses is measured per geometry by the caller (sqd_conv_set_plan).
+// fp32 MFMA is an exact k-ordered fmaf chain, so results match a direct fp32 convolution to accumulation-order rounding.
 // Roofline: fp32 MFMA, 157.3 TFLOP/s dense.
 #include "sqd_common.h"
 #include <cstdlib>
