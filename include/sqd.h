@@ -146,17 +146,18 @@ int sqd_smooth_bwd(const float *depth, const float *color, const float *part, in
  * (5) Self Query Layer
  * replaces: FullQueryLayer.forward (reference networks/layers.py:7-21): y = x^T K^T (:17),
  *           softmax over the N = h*w pixels (:18), summary = softmax(y)^T x^T (:19).
- * x [B,E,N] (the [B,E,h,w] feature map), K [B,Q,E] queries -> y [B,Q,N] energy maps (raw dot
+ * x [B,E,N] (the [B,E,h,w] feature map; x_nhwc = 1: its channels-last memory [B,N,E], the layout the producing
+ * convolution writes — no layout copy), K [B,Q,E] queries -> y [B,Q,N] energy maps (raw dot
  * products), summary [B,Q,E], lse [B,Q,2] = (max, 1/sum) for the backward.  E in {16,32}, Q <= 128.
  * part: workspace of sqd_sql_workspace(..).part_floats floats.  fp32 MFMA (v_mfma_f32_16x16x4_f32).  */
 int sqd_sql_workspace(int B, int Q, int E, int N, int64_t *part_floats, int64_t *gk_part_floats);
 int sqd_sql_fwd(const float *x, const float *K, float *y, float *summary, float *lse, float *part, int B, int Q,
-                int E, int N, void *stream);
-/* adjoint: g_y [B,Q,N] (may be NULL), g_summary [B,Q,E] -> g_x [B,E,N], g_K [B,Q,E];
+                int E, int N, int x_nhwc, void *stream);
+/* adjoint: g_y [B,Q,N] (may be NULL), g_summary [B,Q,E] -> g_x (x's layout), g_K [B,Q,E];
  * gk_part: workspace of gk_part_floats floats.                                                       */
 int sqd_sql_bwd(const float *x, const float *K, const float *y, const float *g_y, const float *g_summary,
                 const float *summary, const float *lse, float *g_x, float *g_K, float *gk_part, int B, int Q,
-                int E, int N, void *stream);
+                int E, int N, int x_nhwc, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (6) BatchNorm2d fused with activation and residual add, channels-last activations

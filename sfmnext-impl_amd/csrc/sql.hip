@@ -63,7 +63,9 @@ constexpr int PART_STRIDE_EXTRA = 2;   // per query: max, sum, then E summary va
 template <int QT, int ET, int NT>
 __global__ __launch_bounds__(256) void sql_fwd_kernel(const float *__restrict__ x, const float *__restrict__ K,
                                                       float *__restrict__ y, float *__restrict__ part, int Q, int N,
-                                                      int steps_per_wave, int nchunks) {
+                                                      int steps_per_wave, int nchunks, int xse, int xsn) {
+    // x[b] is addressed as x[e * xse + n * xsn]: planar [E][N] (xse = N, xsn = 1) or pixel-major / channels-last [N][E]
+    // (xse = 1, xsn = E) — the layout the producing convolution writes, so no layout copy precedes this kernel
     constexpr int E = ET * 16;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int c = lane & 15, g = lane >> 4;
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void sql_fwd_kernel(const float *__restrict__ 
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 const int n = n0 + i * 16 + c;
-                const float a = ldb32(x_r, n < N ? ((unsigned)(e0 + g) * N + n) * 4u : SQL_OOB);   // A[row=n][k=e]
+                const float a = ldb32(x_r, n < N ? ((unsigned)(e0 + g) * xse + (unsigned)n * xsn) * 4u : SQL_OOB);   // A[row=n][k=e]
 #pragma unroll
                 for (int j = 0; j < QT; ++j) d[i][j] = mfma16(a, bq[j], d[i][j]);
             }
@@ -165,14 +167,14 @@ __global__ __launch_bounds__(256) void sql_fwd_kernel(const float *__restrict__ 
             const int n = n0 + i * 16 + 4 * g;
 #pragma unroll
             for (int t = 0; t < ET; ++t) {
-                const unsigned xo = ((unsigned)(t * 16 + c) * N + n) * 4u;   // A[row=e][k]: 4 consecutive pixels
+                const unsigned xo = ((unsigned)(t * 16 + c) * xse + (unsigned)n * xsn) * 4u;   // A[row=e][k]: 4 consecutive pixels
                 float a4[4];
-                if ((N & 3) == 0) {                                         // a float4 lies inside a plane or beyond the last pixel
+                if ((N & 3) == 0 && xsn == 1) {                             // planar: a float4 lies inside a plane or beyond the last pixel
                     const sql_i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(x_r, n < N ? xo : SQL_OOB, 0, 0);
                     a4[0] = __int_as_float(v.x); a4[1] = __int_as_float(v.y); a4[2] = __int_as_float(v.z); a4[3] = __int_as_float(v.w);
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) a4[r] = ldb32(x_r, n + r < N ? xo + 4u * r : SQL_OOB);
+                    for (int r = 0; r < 4; ++r) a4[r] = ldb32(x_r, n + r < N ? xo + 4u * (unsigned)(r * xsn) : SQL_OOB);
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -446,8 +448,9 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
                                                         const float *__restrict__ y, const float *__restrict__ g_y,
                                                         const float *__restrict__ gS, const float *__restrict__ summary,
                                                         const float *__restrict__ lse, float *__restrict__ g_x,
-                                                        float *__restrict__ gK_part, int Q, int E, int N, int nchunks) {
-    constexpr int QP = QT * 32, EP = 33;
+                                                        float *__restrict__ gK_part, int Q, int E, int N, int nchunks, int xse,
+                                                        int xsn) {
+    constexpr int QP = QT * 32, EP = 33;                          // x, g_x: element (e, n) at e * xse + n * xsn (see sql_fwd_kernel)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Kl = lds, *Sl = Kl + QP * EP, *qc = Sl + QP * EP;      // K[q][e], gS[q][e], per-query (max, 1/sum, dot, -)
     float *tiles = qc + QP * 4;                                   // [4 waves][QP][TP]
@@ -491,11 +494,23 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
         const bool pv = p < N;
         // ---- t[q][p] = sum_e gS[q][e] x[e][p]
         const unsigned N4 = (unsigned)N * 4u;
-        const unsigned lane_x = pv ? ((unsigned)h * N + p) * 4u : SQL_OOB;           // plane h, pixel p
-        const unsigned lane_q = pv ? ((unsigned)(4 * h) * N + p) * 4u : SQL_OOB;     // row 4h of a 32-row group, pixel p
+        const unsigned lane_x = pv ? ((unsigned)h * xse + (unsigned)p * xsn) * 4u : SQL_OOB;   // feature h, pixel p
+        const unsigned lane_q = pv ? ((unsigned)(4 * h) * N + p) * 4u : SQL_OOB;     // row 4h of a 32-row group of y / g_y, pixel p
+        const unsigned lane_gx = pv ? ((unsigned)(4 * h) * xse + (unsigned)p * xsn) * 4u : SQL_OOB;
+        const unsigned xse4 = (unsigned)xse * 4u;
         float xe[16];
+        if (xse == 1) {                                      // pixel-major: the lane's 32 features are one 128-byte run — 8 x 16-byte loads
+            const unsigned px_off = pv ? (unsigned)p * (unsigned)xsn * 4u : SQL_OOB;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) xe[s] = ldb32(x_r, lane_x + (unsigned)(2 * s) * N4);        // plane 2s+h >= E: beyond the extent
+            for (int q8 = 0; q8 < 8; ++q8) {
+                const sql_i32x4 f = __builtin_amdgcn_raw_buffer_load_b128(x_r, 4 * q8 < E ? px_off + 16u * q8 : SQL_OOB, 0, 0);
+                xe[2 * q8] = __int_as_float(h ? f.y : f.x);          // feature 4 q8 + h
+                xe[2 * q8 + 1] = __int_as_float(h ? f.w : f.z);      // feature 4 q8 + 2 + h
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; ++s) xe[s] = ldb32(x_r, 2 * s + h < E ? lane_x + (unsigned)(2 * s) * xse4 : SQL_OOB);
+        }
         // every global read of the tile is issued up front (y, g_y, the float4 pieces of x for the g_K product): the first
         // product then runs under their latency instead of each phase waiting for its own loads
         f32x16 yv[QT], gv[QT];
@@ -511,15 +526,15 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
             const int px = 8 * gq + 4 * h;
-            if (vec_ok) {                                            // N % 4 == 0: a float4 is inside a plane or beyond it
+            if (vec_ok && xsn == 1) {                                // planar, N % 4 == 0: a float4 is inside a plane or beyond it
                 const sql_i32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(
-                    x_r, (i < E && p0 + px < N) ? ((unsigned)i * N + p0 + px) * 4u : SQL_OOB, 0, 0);
+                    x_r, (i < E && p0 + px < N) ? ((unsigned)i * xse + p0 + px) * 4u : SQL_OOB, 0, 0);
                 xv[gq][0] = __int_as_float(t4.x); xv[gq][1] = __int_as_float(t4.y);
                 xv[gq][2] = __int_as_float(t4.z); xv[gq][3] = __int_as_float(t4.w);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    xv[gq][j] = ldb32(x_r, (i < E && p0 + px + j < N) ? ((unsigned)i * N + p0 + px + j) * 4u : SQL_OOB);
+                    xv[gq][j] = ldb32(x_r, (i < E && p0 + px + j < N) ? ((unsigned)i * xse + (unsigned)(p0 + px + j) * xsn) * 4u : SQL_OOB);
             }
         }
         f32x16 acc[QT], sreg[QT];
@@ -558,9 +573,19 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
                 gx = mfma32(Kl[q * EP + i], acc[qt][r], gx);
                 gx = mfma32(Sl[q * EP + i], sreg[qt][r], gx);
             }
+        if (xse == 1) {                                      // pixel-major: registers 4g..4g+3 are 4 consecutive features -> one 16-byte store
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            stb32(gx_r, lane_q + (unsigned)((r & 3) + 8 * (r >> 2)) * N4, gx[r]);       // plane >= E / pixel >= N: dropped
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int e0 = 8 * g4 + 4 * h;
+                sql_i32x4 v;
+                v.x = __float_as_int(gx[4 * g4]); v.y = __float_as_int(gx[4 * g4 + 1]);
+                v.z = __float_as_int(gx[4 * g4 + 2]); v.w = __float_as_int(gx[4 * g4 + 3]);
+                __builtin_amdgcn_raw_buffer_store_b128(v, gx_r, (pv && e0 < E) ? ((unsigned)p * (unsigned)xsn + e0) * 4u : SQL_OOB, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                stb32(gx_r, acc_row(r, h) < E ? lane_gx + (unsigned)((r & 3) + 8 * (r >> 2)) * xse4 : SQL_OOB, gx[r]);   // pixel >= N: dropped
         }
         // ---- g_K[q][e] += sum_p gyt[q][p] x[e][p]; k-step (gq, j): half-wave 0 takes pixel 8gq+j, half-wave 1 pixel 8gq+4+j
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -652,14 +677,15 @@ extern "C" int sqd_sql_workspace(int B, int Q, int E, int N, int64_t *part_float
     SQL_DISPATCH(8, 2, 1, KERNEL, SHMEM, __VA_ARGS__)
 
 extern "C" int sqd_sql_fwd(const float *x, const float *K, float *y, float *summary, float *lse, float *part, int B, int Q,
-                           int E, int N, void *stream) {
+                           int E, int N, int x_nhwc, void *stream) {
     SQD_CHECK_ARG(x && K && y && summary && lse && part, "sqd_sql_fwd: null pointer");
+    const int xse = x_nhwc ? 1 : N, xsn = x_nhwc ? E : 1;
     Plan p;
     SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql_fwd: unsupported Q=%d E=%d N=%d", Q, E, N);
     bool launched = false;
     const size_t fwd_lds = ((size_t)4 * p.QT * 16 * 2 + (size_t)4 * E * (p.QT * 16 + 1)) * sizeof(float);
     (void)hipGetLastError();
-    SQL_DISPATCH_ALL(sql_fwd_kernel, fwd_lds, x, K, y, part, Q, N, p.steps, p.nchunks)
+    SQL_DISPATCH_ALL(sql_fwd_kernel, fwd_lds, x, K, y, part, Q, N, p.steps, p.nchunks, xse, xsn)
     SQD_CHECK_ARG(launched, "sqd_sql_fwd: no kernel instance for QT=%d ET=%d", p.QT, p.ET);
     SQD_CHECK_LAUNCH("sqd_sql_fwd");
     hipLaunchKernelGGL(sql_merge_kernel, dim3(Q, B), dim3(64), 0, (hipStream_t)stream, part, summary, lse, Q, E, p.nchunks);
@@ -669,8 +695,9 @@ extern "C" int sqd_sql_fwd(const float *x, const float *K, float *y, float *summ
 
 extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const float *g_y, const float *g_summary,
                            const float *summary, const float *lse, float *g_x, float *g_K, float *gk_part, int B, int Q,
-                           int E, int N, void *stream) {
+                           int E, int N, int x_nhwc, void *stream) {
     SQD_CHECK_ARG(x && K && y && g_summary && summary && lse && g_x && g_K && gk_part, "sqd_sql_bwd: null pointer");
+    const int xse = x_nhwc ? 1 : N, xsn = x_nhwc ? E : 1;
     Plan p;
     SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql_bwd: unsupported Q=%d E=%d N=%d", Q, E, N);
     SQD_CHECK_ARG((long long)N * 132 * 4 < (1ll << 32), "sqd_sql_bwd: N=%d too large for 32-bit plane offsets", N);
@@ -685,10 +712,11 @@ extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sql_bwd32_kernel<QT_>),                                   \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                                  \
         hipLaunchKernelGGL((sql_bwd32_kernel<QT_>), dim3(p.nchunks, B), dim3(256), shmem, (hipStream_t)stream, x, K, y, g_y,   \
-                           g_summary, summary, lse, g_x, gk_part, Q, E, N, p.nchunks);                                          \
+                           g_summary, summary, lse, g_x, gk_part, Q, E, N, p.nchunks, xse, xsn);                                \
     }
         if (qt == 1) SQL_BWD32(1) else if (qt == 2) SQL_BWD32(2) else SQL_BWD32(4)
     } else {
+        SQD_CHECK_ARG(!x_nhwc, "sqd_sql_bwd: the 16x16x4 formulation (SQD_SQL_BWD16) reads planar x only");
         const int QP = p.QT * 16, PX = p.NT * 16;
         const size_t sh_tile = (size_t)4 * QP * (PX + 1) * sizeof(float), sh_red = (size_t)4 * E * (QP + 1) * sizeof(float);
         const size_t shmem = (size_t)QP * 4 * sizeof(float) + (sh_tile > sh_red ? sh_tile : sh_red);

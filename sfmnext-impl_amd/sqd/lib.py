@@ -91,8 +91,8 @@ _SIGNATURES = {
     "sqd_photo_bwd": (_I, [ctypes.POINTER(PhotoBwdArgs)]),
     "sqd_photo_bwd_reduce": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sqd_sql_workspace": (_I, [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
-    "sqd_sql_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
-    "sqd_sql_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sqd_sql_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sqd_sql_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_bn_nblk": (_I, [_I, _I]),
     "sqd_bn_train_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),
     "sqd_bn_eval_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),

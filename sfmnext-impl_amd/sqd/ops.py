@@ -297,8 +297,12 @@ class SelfQueryLayer(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, queries):
-        x, queries = x.contiguous(), queries.contiguous()
-        _req(x, queries)
+        # a channels-last feature map (what the producing convolution writes) is read in place; anything else as planar NCHW
+        nhwc = x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+        if not nhwc:
+            x = x.contiguous()
+        queries = queries.contiguous()
+        _req(x.permute(0, 2, 3, 1) if nhwc else x, queries)       # (the channels-last memory viewed as the dense [B,h,w,E] it is)
         B, E, h, w = x.shape
         Q, N = queries.shape[1], h * w
         dev = x.device
@@ -307,9 +311,10 @@ class SelfQueryLayer(torch.autograd.Function):
         summary = torch.empty(B, Q, E, device=dev, dtype=torch.float32)
         lse = torch.empty(B, Q, 2, device=dev, dtype=torch.float32)
         part = torch.empty(nf, device=dev, dtype=torch.float32)
-        _l.check(_l.lib().sqd_sql_fwd(_ptr(x), _ptr(queries), _ptr(y), _ptr(summary), _ptr(lse), _ptr(part), B, Q, E, N,
+        _l.check(_l.lib().sqd_sql_fwd(_ptr(x), _ptr(queries), _ptr(y), _ptr(summary), _ptr(lse), _ptr(part), B, Q, E, N, int(nhwc),
                                       _stream()), "sql_fwd")
         ctx.save_for_backward(x, queries, y, summary, lse)
+        ctx.nhwc = nhwc
         return y, summary
 
     @staticmethod
@@ -321,11 +326,11 @@ class SelfQueryLayer(torch.autograd.Function):
         _, nk = _sql_workspace(B, Q, E, N)
         g_y = g_y.contiguous() if g_y is not None else None
         g_summary = g_summary.contiguous() if g_summary is not None else torch.zeros_like(summary)
-        g_x = torch.empty_like(x)
+        g_x = torch.empty_like(x)                          # x's layout (preserve_format)
         g_K = torch.empty_like(queries)
         part = torch.empty(nk, device=dev, dtype=torch.float32)
         _l.check(_l.lib().sqd_sql_bwd(_ptr(x), _ptr(queries), _ptr(y), _ptr(g_y), _ptr(g_summary), _ptr(summary), _ptr(lse),
-                                      _ptr(g_x), _ptr(g_K), _ptr(part), B, Q, E, N, _stream()), "sql_bwd")
+                                      _ptr(g_x), _ptr(g_K), _ptr(part), B, Q, E, N, int(ctx.nhwc), _stream()), "sql_bwd")
         return g_x, g_K
 
 

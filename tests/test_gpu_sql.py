@@ -9,11 +9,17 @@ from conftest import tt
 pytestmark = pytest.mark.gpu
 
 
-def _run(x, K, wy, ws):
+def _run(x, K, wy, ws, channels_last=False):
+    """channels_last: x in the layout the producing convolution writes ([B,h,w,E] memory), read and differentiated in place"""
     from sqd import ops
-    xg, Kg = x.cuda().requires_grad_(True), K.cuda().requires_grad_(True)
+    xg = x.cuda()
+    if channels_last:
+        xg = xg.contiguous(memory_format=torch.channels_last)
+    xg, Kg = xg.requires_grad_(True), K.cuda().requires_grad_(True)
     y, s = ops.SelfQueryLayer.apply(xg, Kg)
     ((y * wy.cuda()).sum() + (s * ws.cuda()).sum()).backward()
+    if channels_last and x.shape[1] > 1 and x.shape[2] * x.shape[3] > 1:
+        assert xg.grad.is_contiguous(memory_format=torch.channels_last)      # the gradient comes back in x's layout
     return y.detach().cpu(), s.detach().cpu(), xg.grad.cpu(), Kg.grad.cpu()
 
 
@@ -48,7 +54,9 @@ def test_vs_oracle(B, E, Q, h, w):
     K = 0.5 * torch.randn(B, Q, E)
     K[0, 0] *= 8.0                       # one sharply peaked query: exercises the online-softmax rescale path
     wy, ws = torch.randn(B, Q, h, w), torch.randn(B, Q, E)
-    _check(_run(x, K, wy, ws), _ref(x, K, wy, ws))
+    want = _ref(x, K, wy, ws)
+    _check(_run(x, K, wy, ws), want)
+    _check(_run(x, K, wy, ws, channels_last=True), want)
 
 
 def test_config_b_full_size():
@@ -56,4 +64,6 @@ def test_config_b_full_size():
     torch.manual_seed(5)
     x, K = torch.randn(B, E, h, w), 0.3 * torch.randn(B, Q, E)
     wy, ws = torch.randn(B, Q, h, w) * 1e-3, torch.randn(B, Q, E)
-    _check(_run(x, K, wy, ws), _ref(x, K, wy, ws))
+    want = _ref(x, K, wy, ws)
+    _check(_run(x, K, wy, ws), want)
+    _check(_run(x, K, wy, ws, channels_last=True), want)
