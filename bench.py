@@ -2,7 +2,7 @@
 """bench.py — SQLdepth self-supervised training throughput on MI355X (BASELINE.json metric:
 "train images/sec, ResNet-50 640x192").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]            (N=1 default; N>1 under torchrun)
+    python bench.py [--gpus N] [--steps K] [--warmup W]     (N=1 default; N>1: under torchrun, or plain — it then starts the ranks itself)
 
 One step = Trainer.train_step on one synthetic KITTI-shaped batch (configs[1]: ResNet-50 +
 Depth_Decoder_QueryTr, 192x640, batch 12 per GPU, fp32, 2 source frames): encoder + depth head +
@@ -29,6 +29,22 @@ CONFIG_B = ["--backbone", "resnet", "--num_layers", "50", "--num_features", "256
             "--model_name", "bench"]
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FUSED_FWD_BYTES_PER_PX = 93      # disp 1 + target 12 + sources 24 + identity/noise 8 | depth 4 + sample 16 + warped 24 + sel 4
+
+
+def kernel_source_hash():
+    """sha256 over the photometric kernel sources of the loaded library: a PMC traffic record is only valid for the
+    kernel revision it was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, "sfmnext-impl_amd", "csrc", "photo*.hip")) +
+                    glob.glob(os.path.join(REPO, "sfmnext-impl_amd", "csrc", "photo*.h")) +
+                    [os.path.join(REPO, "sfmnext-impl_amd", "csrc", "sqd_common.h")]):
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
 
 
 def roofline_fused_fwd(trainer, inputs, iters=200):
@@ -65,57 +81,118 @@ def roofline_fused_fwd(trainer, inputs, iters=200):
     px = B * H * W
     t = res["train"]
     achieved = FUSED_FWD_BYTES_PER_PX * px / t / 1e9
-    # HBM-side bytes per launch from the rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE collected separately and corrected with
-    # the dword-access calibration of tools/pmc_calib.py, as the microarchitecture guide prescribes); a committed measurement
-    # of this kernel at this size — PMC counters cannot be read from inside this process
-    traffic = traffic_bytes = None
-    pmc = os.path.join(REPO, "profiles", "r01k_pmc_traffic.json")
-    if os.path.exists(pmc) and (B, H, W) == (12, 192, 640):
-        traffic_bytes = json.load(open(pmc))["kernels"]["photo_fwd_pk_kernel<1>"]["traffic_bytes"]
-        traffic = round(traffic_bytes / t / 1e9, 1)
-    return {"bound": "hbm", "kernel": "photo_fwd_pk_kernel<1> (fused warp+SSIM+L1+automask fwd, training mode: also writes the 37 B/px coef+argmin maps)",
+    # HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/pmc_traffic.py, corrected
+    # with the access-width calibration of tools/pmc_calib.py as the microarchitecture guide prescribes).  PMC counters cannot be
+    # read from inside this process: the committed record is used only if it was measured on THIS revision of the kernel sources.
+    traffic = traffic_bytes = note = None
+    if os.path.exists(PMC_TRAFFIC_JSON) and (B, H, W) == (12, 192, 640):
+        rec = json.load(open(PMC_TRAFFIC_JSON))
+        if rec.get("kernel_source_hash") == kernel_source_hash():
+            traffic_bytes = rec["kernels"][rec["judged_kernel"]]["traffic_bytes"]
+            traffic = round(traffic_bytes / t / 1e9, 1)
+            note = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, access-width calibration)" % os.path.basename(PMC_TRAFFIC_JSON)
+        else:
+            note = "stale PMC record (kernel sources changed since %s was measured): traffic withheld" % os.path.basename(PMC_TRAFFIC_JSON)
+    return {"bound": "hbm", "kernel": ops.PHOTO_FWD_KERNEL_NAME,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-            "traffic": traffic, "traffic_bytes_per_launch": traffic_bytes,
-            "traffic_source": "profiles/r01k_pmc_traffic.md (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, dword calibration x2.0 / x1.0)" if traffic else None,
+            "traffic": traffic, "traffic_bytes_per_launch": traffic_bytes, "traffic_source": note,
             "us_per_launch": round(t * 1e6, 2), "us_per_launch_inference": round(res["infer"] * 1e6, 2),
             "algorithmic_bytes_per_launch": FUSED_FWD_BYTES_PER_PX * px, "pixels_per_launch": px}
 
 
-def cpu_baseline(max_seconds=30.0):
-    """The oracle restatement (oracle/torch_ref.py, pinned to the reference by golden vectors) timed on
-    this box's host cores: same config, same batch shape, fwd + bwd + Adam."""
+def host_cpu():
+    """(model name, logical cpus, physical cores) of this box."""
+    import subprocess
+    model, sockets, cps = "unknown", 1, None
+    try:
+        for line in subprocess.run(["lscpu"], capture_output=True, text=True, timeout=10).stdout.splitlines():
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "Model name":
+                model = v
+            elif k == "Socket(s)":
+                sockets = int(v)
+            elif k == "Core(s) per socket":
+                cps = int(v)
+    except Exception:
+        pass
+    logical = os.cpu_count() or 1
+    return model, logical, (sockets * cps if cps else logical)
+
+
+def cpu_baseline(budget_s=45.0):
+    """The oracle restatement (oracle/torch_ref.py, pinned to the reference by golden vectors) timed on this box's host cores
+    as BASELINE.md §2 prescribes: (1) config A end-to-end, (2) the photometric chain alone at configs B and C, and — the
+    `value` of the record, because it is the workload of the GPU line — (3) the config-B training step on a bounded batch."""
     sys.path.insert(0, REPO)
     from oracle import torch_ref as O
     from datasets.synthetic import synthetic_batch
-    # 32 threads: PyTorch's CPU conv/BN kernels scale poorly beyond that on this many-core host (a first
-    # run with all 256 threads took 106 s per B=12 step); the sample is a reduced batch so that the whole
-    # leg stays within ~30 s
-    cores = min(os.cpu_count() or 1, 32)
+    model, logical, physical = host_cpu()
+    # all physical cores, capped at 64: beyond that PyTorch's CPU conv / pooling kernels lose throughput on this many-core host
+    # (round 1 measured a B=12 step at 106 s with 256 threads against ~2.4 s with 32)
+    cores = max(1, min(physical, 64))
     torch.set_num_threads(cores)
+    t_start = time.time()
+
+    def timed(fn, warm, n_max, budget):
+        t0 = time.time()
+        for _ in range(warm):
+            fn()
+        w = (time.time() - t0) / max(warm, 1)
+        n = max(1, min(n_max, int(budget / max(w, 1e-3))))
+        t0 = time.time()
+        for _ in range(n):
+            fn()
+        return (time.time() - t0) / n, n
+
+    # (3) config B, the GPU line's workload, batch 4 (a B=12 step is ~3x that; img/s is per image)
     B, H, W = 4, 192, 640
     enc = O.ResnetEncoderDecoder(50, 256, 32)
     dep = O.QueryTrDecoder(32, 32, 16, 4, 64, 64, min_val=0.001, max_val=80.0, dim_feedforward=1024)
-    pose = O.PoseCNN(2)
-    step = O.RefTrainStep(enc, dep, pose, (0, -1, 1), H, W)
-    inputs = synthetic_batch(B, H, W)
-    noise = torch.randn(B, 2, H, W)
-    t0 = time.time()
-    step.step(inputs, noise)                                   # warm-up (allocations, oneDNN primitive caches)
-    warm = time.time() - t0
-    n = max(1, min(3, int(max_seconds / max(warm, 1e-3)) - 1))
-    t0 = time.time()
-    for _ in range(n):
-        step.step(inputs, noise)
-    dt = (time.time() - t0) / n
-    return {"value": round(B / dt, 3), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": "%d full train steps (fwd+bwd+Adam) of the config-B model (ResNet-50, 192x640) at batch %d after 1 "
-                      "warm-up, oracle/torch_ref.py on %d host threads, %.2f s/step" % (n, B, cores, dt)}
+    stepB = O.RefTrainStep(enc, dep, O.PoseCNN(2), (0, -1, 1), H, W)
+    inputs, noise = synthetic_batch(B, H, W), torch.randn(B, 2, H, W)
+    dtB, nB = timed(lambda: stepB.step(inputs, noise), 1, 3, 8.0)
+    del stepB, enc, dep
+    # (1) config A end-to-end: ResNet-18 + Lite decoder, 192x640, batch 2, 3 warm-up + up to 20 timed steps
+    encA = O.LiteResnetEncoderDecoder(model_dim=32)
+    depA = O.QueryTrDecoder(32, 32, 16, 4, 120, 128, min_val=0.001, max_val=80.0, dim_feedforward=512)
+    stepA = O.RefTrainStep(encA, depA, O.PoseCNN(2), (0, -1, 1), 192, 640)
+    inA, nzA = synthetic_batch(2, 192, 640), torch.randn(2, 2, 192, 640)
+    dtA, nA = timed(lambda: stepA.step(inA, nzA), 3, 20, 12.0)
+    del stepA, encA, depA
+
+    # (2) photometric chain alone (generate_images_pred + compute_losses + backward) at configs B and C
+    def chain(Bc, Hc, Wc):
+        batch = synthetic_batch(Bc, Hc, Wc)
+        disp = (torch.rand(Bc, 1, Hc // 2, Wc // 2) * 20 + 1).requires_grad_(True)
+        poses = {f: ((0.01 * torch.randn(Bc, 1, 1, 3)).requires_grad_(True), (0.5 * torch.randn(Bc, 1, 1, 3)).requires_grad_(True))
+                 for f in (-1, 1)}
+        colors = {f: batch[("color", f, 0)] for f in (0, -1, 1)}
+        nz = torch.randn(Bc, 2, Hc, Wc)
+
+        def run():
+            out = O.photometric_chain(disp, poses, batch[("K", 0)], batch[("inv_K", 0)], colors, [0, -1, 1], nz, Hc, Wc)
+            out["loss"].backward()
+        dt, n = timed(run, 1, 3, 5.0)
+        px = Bc * Hc * Wc
+        return {"images_per_s": round(Bc / dt, 2), "s_per_pass": round(dt, 3), "passes": n,
+                "effective_GBps": round((93 + 84 + 36) * px / dt / 1e9, 3)}
+    chainB, chainC = chain(12, 192, 640), chain(8, 320, 1024)
+    return {"value": round(B / dtB, 3), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": "%d full train steps (fwd+bwd+Adam) of the config-B model (ResNet-50 + Depth_Decoder_QueryTr, 192x640) at batch %d "
+                      "after 1 warm-up, oracle/torch_ref.py, %.2f s/step" % (nB, B, dtB),
+            "host": {"cpu_model": model, "os_cpu_count": logical, "physical_cores": physical, "threads_used": cores,
+                     "torch": torch.__version__},
+            "config_A_end_to_end": {"images_per_s": round(2 / dtA, 3), "s_per_step": round(dtA, 3), "timed_steps": nA, "warmup": 3,
+                                    "workload": "ResNet-18 + Lite_Depth_Decoder_QueryTr, 192x640, batch 2, fwd+bwd+Adam"},
+            "photometric_chain_config_B": chainB, "photometric_chain_config_C": chainC,
+            "total_cpu_leg_s": round(time.time() - t_start, 1)}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -125,9 +202,19 @@ def main():
     from trainer import Trainer
     from datasets.synthetic import synthetic_batch
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started as a plain `python bench.py --gpus N`: launch the N ranks ourselves (one process per GPU over RCCL); rank 0
+        # prints the JSON line to the inherited stdout
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execv(sys.executable, cmd)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit("bench.py --gpus %d must be launched with %d ranks (torchrun); WORLD_SIZE=%d" % (args.gpus, args.gpus, world))
+        raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
     opts = MonodepthOptions().parse(CONFIG_B + os.environ.get("SQD_BENCH_EXTRA", "").split())
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):          # the Trainer's banner goes to stderr: stdout carries the one JSON line

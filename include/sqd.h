@@ -205,6 +205,10 @@ int sqd_backproject_fwd(const float *depth, const float *inv_K, float *cam_point
 int sqd_project3d_fwd(const float *points, const float *K, const float *T, float *grid, int B, int H, int W, float eps,
                       void *stream);
 int sqd_ssim_fwd(const float *x, const float *y, float *out, int planes, int H, int W, void *stream);
+/* F.grid_sample(img [B,C,H,W], grid [B,Ho,Wo,2], padding_mode="border", align_corners=True) -> out [B,C,Ho,Wo]
+ * (reference trainer.py:431-435); x0y0 (optional, int32 [B,Ho,Wo,2]) receives the integer north-west taps.          */
+int sqd_grid_sample_border_fwd(const float *img, const float *grid, float *out, int *x0y0, int B, int C, int H, int W, int Ho,
+                               int Wo, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (9) multi-tensor Adam step (one launch per parameter group)

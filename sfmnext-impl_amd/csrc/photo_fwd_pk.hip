@@ -256,8 +256,9 @@ __global__ __launch_bounds__(256) void photo_fwd_pk_kernel(sqd_photo_args a, con
                 const v2f B1 = mm + splat(C1), B2 = (Sq * splat(INV49) - mm) + splat(C2);
                 const v2f iB1 = v2f{__builtin_amdgcn_rcpf(B1.x), __builtin_amdgcn_rcpf(B1.y)};
                 const v2f iB2 = v2f{__builtin_amdgcn_rcpf(B2.x), __builtin_amdgcn_rcpf(B2.y)};
-                const v2f iB = iB1 * iB2;
-                const v2f Sv = A1 * A2 * iB;
+                const v2f iB = iB1 * iB2;                 // (reciprocals: gradient coefficients only)
+                const v2f Bd = B1 * B2;
+                const v2f Sv = div_core2(A1 * A2, Bd, rcp_refined2(Bd));      // SSIM_n / SSIM_d as the reference divides (layers.py:46)
                 const v2f r = (splat(1.f) - Sv) * splat(0.5f);
                 ssim_sum += v2f{fminf(fmaxf(r.x, 0.f), 1.f), fminf(fmaxf(r.y, 0.f), 1.f)};
                 const v2f df = splat(rt[3][c]) - rw[3][c];

@@ -90,6 +90,37 @@ __global__ __launch_bounds__(256) void ssim_kernel(const float *__restrict__ x, 
     const float n = (2.f * mx * my + C1) * (2.f * vxy + C2), d = (mx * mx + my * my + C1) * (vx + vy + C2);
     out[(size_t)plane * HW + q] = fminf(fmaxf((1.f - n / d) * 0.5f, 0.f), 1.f);
 }
+
+// F.grid_sample(img, grid, padding_mode="border", align_corners=True) — reference trainer.py:431-435 (ATen
+// grid_sampler_2d).  Same tap arithmetic as the fused warp kernel (unnormalise, clip_coordinates, floor, four weights,
+// out-of-range taps skipped): one thread per output pixel, all channels.
+__global__ __launch_bounds__(256) void grid_sample_border_kernel(const float *__restrict__ img, const float *__restrict__ grid,
+                                                                 float *__restrict__ out, int *__restrict__ x0y0, int C, int H,
+                                                                 int W, int Ho, int Wo) {
+    const int b = blockIdx.y, HWo = Ho * Wo, HW = H * W;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= HWo) return;
+    const float2 g = *reinterpret_cast<const float2 *>(grid + ((size_t)b * HWo + q) * 2);
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    float ix = ((g.x + 1.0f) * 0.5f) * wm1, iy = ((g.y + 1.0f) * 0.5f) * hm1;
+    ix = fminf(wm1, fmaxf(ix, 0.f));
+    iy = fminf(hm1, fmaxf(iy, 0.f));
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const bool xin = x0 + 1 < W, yin = y0 + 1 < H;
+    const float ax = ix - fx0, ay = iy - fy0, bx = (fx0 + 1.f) - ix, by = (fy0 + 1.f) - iy;
+    const float wnw = bx * by, wne = xin ? ax * by : 0.f, wsw = yin ? bx * ay : 0.f, wse = (xin && yin) ? ax * ay : 0.f;
+    const int o00 = y0 * W + x0, o01 = o00 + (xin ? 1 : 0), o10 = o00 + (yin ? W : 0), o11 = o10 + (xin ? 1 : 0);
+    if (x0y0) *reinterpret_cast<int2 *>(x0y0 + ((size_t)b * HWo + q) * 2) = make_int2(x0, y0);
+    for (int c = 0; c < C; ++c) {
+        const float *sc = img + ((size_t)b * C + c) * HW;
+        float acc = sc[o00] * wnw;
+        acc = fmaf(sc[o01], wne, acc);
+        acc = fmaf(sc[o10], wsw, acc);
+        acc = fmaf(sc[o11], wse, acc);
+        out[((size_t)b * C + c) * HWo + q] = acc;
+    }
+}
 }  // namespace
 
 extern "C" int sqd_backproject_fwd(const float *depth, const float *inv_K, float *cam_points, int B, int H, int W, void *stream) {
@@ -116,5 +147,15 @@ extern "C" int sqd_ssim_fwd(const float *x, const float *y, float *out, int plan
     (void)hipGetLastError();
     hipLaunchKernelGGL(ssim_kernel, dim3((H * W + 255) / 256, planes), dim3(256), 0, (hipStream_t)stream, x, y, out, H, W);
     SQD_CHECK_LAUNCH("sqd_ssim_fwd");
+    return SQD_OK;
+}
+
+extern "C" int sqd_grid_sample_border_fwd(const float *img, const float *grid, float *out, int *x0y0, int B, int C, int H, int W,
+                                          int Ho, int Wo, void *stream) {
+    SQD_CHECK_ARG(img && grid && out && B > 0 && C > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "sqd_grid_sample_border_fwd: bad arguments");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(grid_sample_border_kernel, dim3((Ho * Wo + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, img, grid, out,
+                       x0y0, C, H, W, Ho, Wo);
+    SQD_CHECK_LAUNCH("sqd_grid_sample_border_fwd");
     return SQD_OK;
 }

@@ -290,6 +290,14 @@ WGRAD_BATCH = int(os.environ.get("SQD_WGRAD_BATCH", "1"))
 _PENDING_WGRAD = {}          # raw stream handle -> (stream the operands are produced on, [(launch, tensors)])
 
 
+_WEIGHT_USES = {}            # id(weight storage) -> forward uses in the current step (reset by begin_step)
+
+
+def begin_step():
+    """Training loops call this before every forward pass (the side-stream weight gradients need per-step use counts)."""
+    _WEIGHT_USES.clear()
+
+
 def flush_wgrads():
     """launch the queued weight-gradient kernels on WGRAD_STREAM (after everything their producer streams hold so far)"""
     side = WGRAD_STREAM
@@ -345,6 +353,12 @@ class Conv2d(torch.autograd.Function):
         _l.check(_l.lib().sqd_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws), _ptr(stats), N, H, W, C, K, R, S, stride, pad,
                                        Ho, Wo, ACT[act], _stream()), "conv_fwd")
         ctx.save_for_backward(x, w, y if act == "relu" else None)
+        # The weight gradient may run on a side stream only when nothing reads it before the optimiser / bucket gather joins
+        # that stream: the filter must be a leaf (a regrouped stem filter feeds StemRegroup.backward at once) and used once
+        # per step (autograd sums the gradients of a shared filter on the main stream as soon as the second one arrives).
+        ctx.wkey = weight.data_ptr() if weight.is_leaf else None
+        if ctx.wkey is not None:
+            _WEIGHT_USES[ctx.wkey] = _WEIGHT_USES.get(ctx.wkey, 0) + 1
         ctx.geom = (N, H, W, C, K, R, S, stride, pad, Ho, Wo)
         ctx.has_bias, ctx.act = bias is not None, act
         if skip:
@@ -379,7 +393,7 @@ class Conv2d(torch.autograd.Function):
             def launch(dy=dy, x=x, dw=dw, db=db, part=part):
                 _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
                                           _stream()), "conv_wgrad")
-            if WGRAD_STREAM is None:
+            if WGRAD_STREAM is None or ctx.wkey is None or _WEIGHT_USES.get(ctx.wkey, 2) != 1:
                 launch()
             else:
                 # the weight gradient has no consumer before the optimiser: it is queued and runs on its own stream, next to

@@ -101,6 +101,10 @@ def identity_fwd(target, sources, noise=None, rows_per_task=0):
     return out
 
 
+# name of the kernel sqd_photo_fwd launches (the "warp+SSIM kernel" of the roofline record in bench.py)
+PHOTO_FWD_KERNEL_NAME = "photo_fwd_pk_kernel<1> (fused warp+SSIM+L1+automask fwd, training mode: also writes the 37 B/px coef+argmin maps)"
+
+
 def photo_fwd(depth, inv_K, P, target, sources, identity, training=True, want_taps=False, want_reproj=False,
               rows_per_task=0, prepared_only=False):
     """Fused warp + SSIM/L1 + min/auto-mask.  Returns a dict of device tensors."""
@@ -221,6 +225,19 @@ def ssim_map(x, y):
     out = torch.empty_like(x)
     _l.check(_l.lib().sqd_ssim_fwd(_ptr(x), _ptr(y), _ptr(out), B * C, H, W, _stream()), "ssim_fwd")
     return out
+
+
+def grid_sample_border(img, grid, want_taps=False):
+    """F.grid_sample(img, grid, padding_mode="border", align_corners=True) (reference trainer.py:431-435), forward only."""
+    img, grid = img.detach().contiguous().float(), grid.detach().contiguous().float()
+    _req(img, grid)
+    B, C, H, W = img.shape
+    _, Ho, Wo, _ = grid.shape
+    out = torch.empty(B, C, Ho, Wo, device=img.device, dtype=torch.float32)
+    taps = torch.empty(B, Ho, Wo, 2, device=img.device, dtype=torch.int32) if want_taps else None
+    _l.check(_l.lib().sqd_grid_sample_border_fwd(_ptr(img), _ptr(grid), _ptr(out), _ptr(taps), B, C, H, W, Ho, Wo, _stream()),
+             "grid_sample_border_fwd")
+    return (out, taps) if want_taps else out
 
 
 def smooth_loss_plain(disp, img):

@@ -12,13 +12,34 @@ from .ops import _stream
 
 
 class FusedAdam(torch.optim.Adam):
+    HYPER_RING = 8
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
         if weight_decay != 0 or amsgrad:
             raise NotImplementedError("FusedAdam implements the reference's configuration: no weight decay, no amsgrad")
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
         self._tables = {}
         self._ring = 0
-        self._graph_hyper = None      # set by begin_capture(): {group index: (pinned host [2], device [2])}
+        self._graph_hyper = None      # set by begin_capture(): {group index: (ring of (pinned host [2], event), device [2])}
+        self._hyper_slot = {}
+
+    def load_state_dict(self, state_dict):
+        """torch.optim.Adam.load_state_dict, then the moments are laid out like their parameters: the kernel pairs p,
+        exp_avg, exp_avg_sq and grad by flat memory offset, and a checkpoint written from NCHW-contiguous parameters (the
+        reference's adam.pth, trainer.py:659-660) carries contiguous moments while the convolution filters here are
+        channels-last."""
+        super().load_state_dict(state_dict)
+        for group in self.param_groups:
+            for p in group["params"]:
+                st = self.state.get(p)
+                if not st:
+                    continue
+                for k in ("exp_avg", "exp_avg_sq"):
+                    if k in st and (st[k].stride() != p.stride() or st[k].device != p.device or st[k].dtype != p.dtype):
+                        st[k] = torch.empty_like(p, memory_format=torch.preserve_format).copy_(st[k])
+                if "step" in st and torch.is_tensor(st["step"]) and st["step"].is_cuda:
+                    st["step"] = st["step"].detach().cpu()
+        self._tables = {}
 
     def _build(self, gi, plist):
         L = _l.lib()
@@ -62,8 +83,18 @@ class FusedAdam(torch.optim.Adam):
                 continue
             if gi not in self._graph_hyper:
                 dev = plist[0].device
-                self._graph_hyper[gi] = (torch.zeros(2, dtype=torch.float32).pin_memory(), torch.zeros(2, dtype=torch.float32, device=dev))
-            host, devt = self._graph_hyper[gi]
+                # A ring of pinned staging buffers, each guarded by an event: replays are queued faster than they execute
+                # (~1 ms of host time per ~15 ms step), so the copy of step N may still be pending when the host prepares
+                # step N+1 — a single buffer would hand later scalars to earlier replays.  A slot is rewritten only after the
+                # copy that last read it has completed (back-pressure after HYPER_RING steps of run-ahead).
+                ring = [(torch.zeros(2, dtype=torch.float32).pin_memory(), torch.cuda.Event()) for _ in range(self.HYPER_RING)]
+                self._graph_hyper[gi] = (ring, torch.zeros(2, dtype=torch.float32, device=dev))
+                self._hyper_slot[gi] = 0
+            ring, devt = self._graph_hyper[gi]
+            slot = self._hyper_slot[gi]
+            self._hyper_slot[gi] = (slot + 1) % self.HYPER_RING
+            host, done = ring[slot]
+            done.synchronize()                 # (a never-recorded event returns at once)
             bumped = set()
             for p in plist:
                 st = self.state[p]
@@ -78,6 +109,7 @@ class FusedAdam(torch.optim.Adam):
             b1, b2 = group["betas"]
             _l.check(L.sqd_adam_hyper(float(group["lr"]), float(b1), float(b2), step, ctypes.c_void_p(host.data_ptr())), "adam_hyper")
             devt.copy_(host, non_blocking=True)
+            done.record()
 
     def _step_captured(self):
         L = _l.lib()
@@ -123,8 +155,8 @@ class FusedAdam(torch.optim.Adam):
             keys = [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr() if "exp_avg" in self.state[p] else 0) for p in plist]
             if tab is None or tab["keys"] != keys:
                 for p in plist:
-                    if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous(memory_format=torch.contiguous_format)
-                            or p.is_contiguous(memory_format=torch.channels_last)):
+                    dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                    if not (p.is_cuda and p.dtype == torch.float32 and dense):
                         raise RuntimeError("FusedAdam: parameters must be dense fp32 device tensors")
                 tab = self._build(gi, plist)
             # gradient tensors are re-allocated by every backward: refresh their addresses (one 8*n byte async copy)

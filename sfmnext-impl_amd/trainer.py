@@ -164,10 +164,9 @@ class Trainer:
 
     def _build_loaders(self):
         o = self.opt
-        have_kitti = os.path.isdir(o.data_path) and not o.sqd_synthetic
-        if have_kitti:
-            raise NotImplementedError("real KITTI input is outside this build (SURVEY.md §2: datasets are host I/O); "
-                                      "pass --sqd_synthetic")
+        if not o.sqd_synthetic:
+            raise NotImplementedError("real KITTI input is outside this build (SURVEY.md §2: datasets are host I/O): pass "
+                                      "--sqd_synthetic to train on synthetic KITTI-shaped frames (data_path=%r is not read)" % o.data_path)
         n = o.sqd_synthetic_len
         train = datasets.SyntheticKITTIDataset(o.height, o.width, o.frame_ids, n, offset=self.rank * n)
         val = datasets.SyntheticKITTIDataset(o.height, o.width, o.frame_ids, max(o.batch_size, n // 10), offset=10 ** 6)
@@ -299,6 +298,7 @@ class Trainer:
             nnkernels.WGRAD_STREAM = None
 
     def _train_step_eager(self, inputs):
+        nnkernels.begin_step()
         outputs, losses = self.process_batch(inputs)
         if self.reducer is not None:
             self.reducer.zero_grad()
@@ -393,12 +393,23 @@ class Trainer:
         trainer.py:301-337)."""
         outputs = {}
         aug = {f: inputs["color_aug", f, 0] for f in self.opt.frame_ids}
-        for f in self.opt.frame_ids[1:]:
-            pair = [aug[f], aug[0]] if f < 0 else [aug[0], aug[f]]
-            axisangle, translation = self.models["pose"](self._fmt(torch.cat(pair, 1)))
-            outputs[("axisangle", 0, f)] = axisangle
-            outputs[("translation", 0, f)] = translation
-            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(axisangle[:, 0], translation[:, 0], invert=(f < 0))
+        srcs = [f for f in self.opt.frame_ids[1:] if f != "s"]
+        # PoseCNN has no batch statistics, so the pairs of all source frames go through it as ONE batch [S*B,6,H,W] (the
+        # reference calls it once per pair, trainer.py:319-334): same numbers per sample, half the launches, and every
+        # pose filter is used once per step (its weight gradient is one kernel, not a sum of two).
+        B = aug[0].shape[0]
+        x = torch.empty((len(srcs) * B, 6) + tuple(aug[0].shape[2:]), device=aug[0].device, dtype=aug[0].dtype,
+                        memory_format=torch.channels_last if self.opt.sqd_channels_last else torch.contiguous_format)
+        for i, f in enumerate(srcs):
+            first, second = (aug[f], aug[0]) if f < 0 else (aug[0], aug[f])
+            x[i * B:(i + 1) * B, :3].copy_(first)
+            x[i * B:(i + 1) * B, 3:].copy_(second)
+        axisangle, translation = self.models["pose"](x)
+        for i, f in enumerate(srcs):
+            aa, tr = axisangle[i * B:(i + 1) * B], translation[i * B:(i + 1) * B]
+            outputs[("axisangle", 0, f)] = aa
+            outputs[("translation", 0, f)] = tr
+            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(aa[:, 0], tr[:, 0], invert=(f < 0))
         return outputs
 
     def generate_images_pred(self, inputs, outputs):

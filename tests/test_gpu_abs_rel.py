@@ -1,0 +1,85 @@
+"""abs_rel parity after equal steps (BASELINE.json north_star: "abs_rel within +-0.001 of reference after equal steps";
+SURVEY.md §8d): the HIP trainer and the oracle restatement start from identical weights and see identical batches and
+tie-break noise for K = 200 optimisation steps on the synthetic set; then both predict a held-out synthetic batch and
+compute_depth_losses (reference trainer.py:551-579, layers.py:282-300: 375x1242, eigen crop, median scaling) must agree
+on abs_rel to 1e-3.  Small shape (ResNet-18, 64x96) keeps the oracle's 200 CPU steps within a minute; every kernel of the path runs."""
+import os
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H, W, B, STEPS, NBATCH = 64, 96, 2, 200, 8
+ARGS = ["--backbone", "resnet18_lite", "--model_dim", "16", "--patch_size", "8", "--query_nums", "12", "--dim_out", "24",
+        "--height", str(H), "--width", str(W), "--batch_size", str(B), "--num_workers", "0", "--sqd_synthetic",
+        "--log_dir", "/tmp/sqd_absrel_test", "--max_depth", "80.0", "--sqd_no_conv_tune"]
+
+
+def _no_dropout(models):
+    for m in models:
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+
+
+def test_abs_rel_after_200_steps():
+    sys.path.insert(0, REPO)
+    from oracle import torch_ref as O
+    from options import MonodepthOptions
+    from trainer import Trainer
+    from datasets.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    enc = O.LiteResnetEncoderDecoder(model_dim=16)
+    dep = O.QueryTrDecoder(16, 16, 8, 4, 12, 24, min_val=0.001, max_val=80.0, dim_feedforward=512, dropout=0.0)
+    pose = O.PoseCNN(2)
+    for m in (enc, dep, pose):
+        m.train()
+    state = {"encoder": {k: v.clone() for k, v in enc.state_dict().items()}, "depth": {k: v.clone() for k, v in dep.state_dict().items()},
+             "pose": {k: v.clone() for k, v in pose.state_dict().items()}}
+    g = torch.Generator().manual_seed(5)
+    batches = [synthetic_batch(B, H, W, start=B * i) for i in range(NBATCH)]
+    noises = [torch.randn(B, 2, H, W, generator=g) for _ in range(STEPS)]
+    held = synthetic_batch(B, H, W, start=10 ** 5, with_gt=True)
+
+    tr = Trainer(MonodepthOptions().parse(ARGS))
+    tr.set_train()
+    _no_dropout(tr.models.values())
+    for name, sd in state.items():
+        tr.models[name].load_state_dict(sd)
+    ref = O.RefTrainStep(enc, dep, pose, (0, -1, 1), H, W)
+    dev_loss, ref_loss = [], []
+    for i in range(STEPS):
+        inputs = batches[i % NBATCH]
+        ref_loss.append(float(ref.step(dict(inputs), noises[i])[1]["loss"]))
+        dev = {k: v.cuda() for k, v in inputs.items()}
+        dev[("noise", 0)] = noises[i].cuda()
+        dev_loss.append(float(tr.train_step(dev)[1]["loss"]))
+    assert tr._graph is not None                       # the replayed hipGraph did the training
+
+    def abs_rel_ref():
+        for m in (enc, dep, pose):
+            m.eval()
+        with torch.no_grad():
+            out = dep(enc(held[("color_aug", 0, 0)]))
+            depth = torch.nn.functional.interpolate(out[("disp", 0)], [H, W], mode="bilinear", align_corners=False)
+        return [float(v) for v in O.compute_depth_losses(depth, held["depth_gt"])]
+
+    def abs_rel_dev():
+        tr.set_eval()
+        with torch.no_grad():
+            inputs = {k: v.cuda() for k, v in held.items()}
+            outputs, losses = tr.process_batch(inputs)
+            tr.compute_depth_losses(inputs, outputs, losses)
+        return [float(losses[n]) for n in tr.depth_metric_names]
+
+    want, got = abs_rel_ref(), abs_rel_dev()
+    print("loss after %d steps: device %.6f oracle %.6f (first step %.6f); depth metrics device %s oracle %s"
+          % (STEPS, dev_loss[-1], ref_loss[-1], ref_loss[0], ["%.5f" % v for v in got], ["%.5f" % v for v in want]))
+    assert ref_loss[-1] < ref_loss[0]                  # the model did train
+    assert abs(got[0] - want[0]) <= 1e-3, ("abs_rel", got[0], want[0])
+    assert abs(dev_loss[-1] - ref_loss[-1]) <= 2e-2 * abs(ref_loss[-1]), (dev_loss[-1], ref_loss[-1])

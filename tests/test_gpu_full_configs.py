@@ -12,22 +12,25 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _args(H, W, B, extra):
-    return ["--backbone", "resnet", "--num_layers", "50", "--num_features", "256", "--model_dim", "32", "--patch_size", "16",
-            "--query_nums", "64", "--dim_out", "64", "--height", str(H), "--width", str(W), "--batch_size", str(B),
+def _args(H, W, B, extra, kind="res50"):
+    net = ["--backbone", "resnet", "--num_layers", "50", "--num_features", "256", "--query_nums", "64", "--dim_out", "64"] if kind == "res50" \
+        else ["--backbone", "resnet18_lite", "--query_nums", "120", "--dim_out", "128"]       # args_res18_kitti_192x640_tarin.txt:8-10
+    return net + ["--model_dim", "32", "--patch_size", "16", "--height", str(H), "--width", str(W), "--batch_size", str(B),
             "--min_depth", "0.001", "--max_depth", "80.0", "--num_workers", "0", "--sqd_synthetic",
             "--log_dir", "/tmp/sqd_full_cfg_test", "--sqd_no_conv_tune"] + extra
 
 
-@pytest.mark.parametrize("H,W,B", [(192, 640, 2), (320, 1024, 1)])
-def test_flagship_step_matches_oracle(H, W, B):
+@pytest.mark.parametrize("H,W,B,kind", [(192, 640, 2, "res50"), (320, 1024, 1, "res50"), (192, 640, 2, "res18")])
+def test_flagship_step_matches_oracle(H, W, B, kind):
+    """configs[1] and configs[2] (ResNet-50 + Depth_Decoder_QueryTr) and configs[0] at its real shape: ResNet-18 +
+    Lite_Depth_Decoder_QueryTr, 192x640, batch 2, model_dim 32 / patch 16 / 120 queries / dim_out 128."""
     sys.path.insert(0, REPO)
     from oracle import torch_ref as O
     from options import MonodepthOptions
     from trainer import Trainer
     from datasets.synthetic import synthetic_batch
     torch.manual_seed(0)
-    tr = Trainer(MonodepthOptions().parse(_args(H, W, B, ["--sqd_no_graph"])))
+    tr = Trainer(MonodepthOptions().parse(_args(H, W, B, ["--sqd_no_graph"], kind)))
     tr.set_train()
     for m in tr.models.values():
         for mod in m.modules():
@@ -35,8 +38,12 @@ def test_flagship_step_matches_oracle(H, W, B):
                 mod.p = 0.0
             if isinstance(mod, torch.nn.MultiheadAttention):
                 mod.dropout = 0.0
-    enc = O.ResnetEncoderDecoder(50, 256, 32)
-    dep = O.QueryTrDecoder(32, 32, 16, 4, 64, 64, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
+    if kind == "res50":
+        enc = O.ResnetEncoderDecoder(50, 256, 32)
+        dep = O.QueryTrDecoder(32, 32, 16, 4, 64, 64, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
+    else:
+        enc = O.LiteResnetEncoderDecoder(model_dim=32)
+        dep = O.QueryTrDecoder(32, 32, 16, 4, 120, 128, min_val=0.001, max_val=80.0, dim_feedforward=512, dropout=0.0)
     pose = O.PoseCNN(2)
     for ref, mine in ((enc, tr.models["encoder"]), (dep, tr.models["depth"]), (pose, tr.models["pose"])):
         ref.load_state_dict({k: v.detach().cpu() for k, v in mine.state_dict().items()})
@@ -55,8 +62,10 @@ def test_flagship_step_matches_oracle(H, W, B):
     disp, disp_ref = outputs[("disp", 0)].detach().cpu(), ref_out[("disp", 0)].detach()
     assert float((disp - disp_ref).abs().max()) <= 1e-4 * float(disp_ref.abs().max()), "predicted disparity"
     # the optimiser step: Adam moves every weight by ~lr, so compare the UPDATE of a few tensors (first / last layers of each net)
+    # (the two 7x7 stems are the non-leaf / regrouped filters of the eager path: ADVICE r1 asked for them to be checked here)
     for net, mine, name in ((pose, tr.models["pose"], "pose_conv.weight"), (enc, tr.models["encoder"], "decoder.conv3.weight"),
-                            (dep, tr.models["depth"], "convert_to_prob.0.weight")):
+                            (dep, tr.models["depth"], "convert_to_prob.0.weight"), (pose, tr.models["pose"], "net.0.weight"),
+                            (enc, tr.models["encoder"], "encoder.encoder.conv1.weight"), (pose, tr.models["pose"], "net.3.weight")):
         w_ref = dict(net.named_parameters())[name].detach()
         w_got = dict(mine.named_parameters())[name].detach().cpu()
         assert torch.allclose(w_got, w_ref, atol=5e-5), (name, float((w_got - w_ref).abs().max()))

@@ -1,0 +1,155 @@
+"""The reference's own vectors replayed on the device: G04 (grid_sample border cases), G05/G06 (SSIM / reprojection loss),
+G11 (both QTR decoders), G12 (PoseCNN), G13 (DecoderBN, train and eval BatchNorm), G15/G16 (full process_batch + three Adam
+steps through the Trainer).  tests/test_oracle_vs_golden.py holds the CPU oracle to the same fixtures; here the HIP path is
+compared with them directly (no transitive step through the oracle).  Fixtures: tests/golden/make_goldens.py."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import tt
+from param_fill import chain_inputs, decoder_feats, fill_params, smooth_images
+
+pytestmark = pytest.mark.gpu
+RTOL, ATOL = 1e-4, 1e-6
+
+
+def close(a, b, rtol=RTOL, atol=ATOL):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=atol)
+
+
+def rel_close(a, b, tol):
+    """max |a-b| <= tol * max |b|: for gradient tensors whose small entries sit below fp32 summation noise"""
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    assert np.abs(a - b).max() <= tol * np.abs(b).max() + 1e-12, (np.abs(a - b).max(), np.abs(b).max())
+
+
+def test_g04_grid_sample_border_cases(golden):
+    """coords < -1, > 1 and exactly +-1: the stand-alone sampler shares the tap arithmetic of the fused kernel"""
+    from sqd import ops
+    g = golden("g04_grid_sample")
+    out, x0y0 = ops.grid_sample_border(tt(g["img"]).cuda(), tt(g["grid"]).cuda(), want_taps=True)
+    got = x0y0.cpu().numpy()
+    assert np.array_equal(got[..., 0], g["x0"]) and np.array_equal(got[..., 1], g["y0"])
+    close(out, g["out"])
+
+
+def test_g05_g06_ssim_reprojection(golden):
+    import layers
+    from trainer import Trainer
+    g = golden("g05_ssim")
+    close(layers.SSIM()(tt(g["x"]).cuda(), tt(g["y"]).cuda()), g["ssim"], atol=2e-6)
+    g = golden("g06_reprojection")
+    loss = Trainer.compute_reprojection_loss(None, tt(g["x"]).cuda(), tt(g["y"]).cuda())
+    close(loss, g["loss"], atol=2e-6)
+
+
+@pytest.mark.parametrize("tag", ["full", "lite"])
+def test_g11_qtr_decoders(golden, tag):
+    import networks
+    g = golden("g11_qtr_" + tag)
+    kw = {k: (float(v) if "." in v else int(v)) for k, v in g["kw"]}
+    cls = networks.Depth_Decoder_QueryTr if tag == "full" else networks.Lite_Depth_Decoder_QueryTr
+    m = fill_params(cls(**kw), int(g["seed"])).cuda().to(memory_format=torch.channels_last)
+    m.eval()
+    x = tt(np.random.RandomState(int(g["x_seed"])).standard_normal((2, 16, 32, 48)).astype(np.float32)).cuda().requires_grad_(True)
+    out = m(x)[("disp", 0)]
+    close(out, g["disp"], atol=1e-5)
+    (out * tt(g["w"]).cuda()).sum().backward()
+    close(x.grad, g["grad_x"], rtol=1e-3, atol=1e-4)
+    P = dict(m.named_parameters())
+    for k in g:
+        if k.startswith("grad__"):
+            close(P[k[6:].replace("__", ".")].grad, g[k], rtol=1e-3, atol=1e-4)
+
+
+def test_g12_posecnn(golden):
+    import networks
+    from sqd import nnops
+    nnops.set_native_conv(True)
+    g = golden("g12_posecnn")
+    m = fill_params(networks.PoseCNN(2), int(g["seed"])).cuda().to(memory_format=torch.channels_last)
+    x = tt(smooth_images(np.random.RandomState(int(g["x_seed"])), 2, 64, 96, C=6)).cuda()
+    aa, tr = m(x.contiguous(memory_format=torch.channels_last))
+    close(aa, g["axisangle"], atol=1e-8)
+    close(tr, g["translation"], atol=1e-8)
+    (aa.sum() * 3 + tr.sum()).backward()
+    # (the image itself carries no gradient on the training path: the space-to-depth stem does not differentiate it)
+    rel_close(m.net[0].weight.grad, g["grad_w0"], 2e-4)
+    rel_close(m.pose_conv.weight.grad, g["grad_pose_conv"], 2e-4)
+
+
+@pytest.mark.parametrize("tag,skips,chans", [("res50", (1024, 512, 256, 64), (64, 256, 512, 1024, 2048)),
+                                              ("lite", (256, 128, 64, 64), (64, 64, 128, 256, 512))])
+def test_g13_decoderbn(golden, tag, skips, chans):
+    import networks
+    from sqd import nnops
+    nnops.set_native_conv(True)
+    g = golden("g13_decoderbn_" + tag)
+    dec = fill_params(networks.DecoderBN(int(g["nf"]), 8, int(g["bott"]), skips), int(g["seed"])).cuda().to(memory_format=torch.channels_last)
+    feats = [tt(f).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+             for f in decoder_feats(int(g["feat_seed"]), chans, 32, 48)]
+    dec.train()
+    out = dec(feats)
+    close(out, g["out_train"], atol=1e-5)
+    out.square().mean().backward()
+    close(dec.up1._net[1].running_mean, g["up1_running_mean_after"])
+    rel_close(feats[0].grad, g["grad_feat0"], 1e-3)
+    rel_close(feats[4].grad, g["grad_feat4"], 1e-3)
+    rel_close(dec.conv2.weight.grad, g["grad_conv2_w"], 1e-3)
+    rel_close(dec.up4._net[1].weight.grad, g["grad_up4_bn_w"], 1e-3)
+    dec.eval()
+    with torch.no_grad():
+        close(dec([f.detach() for f in feats]), g["out_eval"], atol=1e-5)
+
+
+def _batch_inputs(seed, B, H, W):
+    d = chain_inputs(seed, B, H, W)
+    rs = np.random.RandomState(seed + 1)
+    aug = {k: np.clip(d[k] * rs.uniform(0.9, 1.1) + rs.uniform(-0.03, 0.03), 0, 1).astype(np.float32)
+           for k in ("color0", "color_s0", "color_s1")}
+    return {("color", 0, 0): tt(d["color0"]), ("color", -1, 0): tt(d["color_s0"]), ("color", 1, 0): tt(d["color_s1"]),
+            ("color_aug", 0, 0): tt(aug["color0"]), ("color_aug", -1, 0): tt(aug["color_s0"]),
+            ("color_aug", 1, 0): tt(aug["color_s1"]), ("K", 0): tt(d["K"]), ("inv_K", 0): tt(d["inv_K"]),
+            ("noise", 0): tt(d["noise"])}
+
+
+@pytest.mark.parametrize("kind", ["res18", "res50"])
+def test_g15_g16_trainer_steps(golden, kind):
+    """Trainer.process_batch + backward + FusedAdam for three steps against the reference's own trajectory."""
+    from options import MonodepthOptions
+    from trainer import Trainer
+    g15, g16 = golden("g15_process_batch_" + kind), golden("g16_adam_steps_" + kind)
+    B, H, W = int(g15["B"]), int(g15["H"]), int(g15["W"])
+    net = ["--backbone", "resnet18_lite"] if kind == "res18" else ["--backbone", "resnet", "--num_layers", "50", "--num_features", "64"]
+    args = net + ["--model_dim", "16", "--patch_size", "8", "--query_nums", "12", "--dim_out", "24", "--height", str(H), "--width", str(W),
+                  "--batch_size", str(B), "--num_workers", "0", "--sqd_synthetic", "--min_depth", "0.001", "--max_depth", "80.0",
+                  "--log_dir", "/tmp/sqd_g15_test", "--sqd_no_graph", "--sqd_no_conv_tune"]
+    tr = Trainer(MonodepthOptions().parse(args))
+    fill_params(tr.models["encoder"], 1501); fill_params(tr.models["depth"], 1502); fill_params(tr.models["pose"], 1503)
+    tr.set_train()
+    for m in tr.models.values():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+    traj = []
+    for it in range(3):
+        inputs = _batch_inputs(1600 + it, B, H, W)
+        outputs, losses = tr.train_step(inputs)
+        if it == 0:
+            close(outputs[("disp", 0)], g15["disp"], atol=1e-4)
+            close(outputs[("depth", 0, 0)], g15["depth"], atol=1e-4)
+            close(outputs[("axisangle", 0, -1)], g15["axisangle_m1"], atol=1e-7)
+            close(outputs[("translation", 0, 1)], g15["translation_p1"], atol=1e-7)
+            close(outputs[("cam_T_cam", 0, -1)], g15["cam_T_cam_m1"], atol=1e-6)
+            close(outputs[("color", -1, 0)], g15["color_m1"], atol=1e-4)
+            assert (outputs["identity_selection/0"].cpu().numpy() != g15["identity_selection"]).mean() < 1e-3
+            assert sorted(str(k) for k in outputs) == sorted(str(k) for k in g15["out_keys"]), list(outputs)
+            assert tr.models["encoder"].encoder.encoder.fc.weight.grad is None
+        traj.append(float(losses["loss"]))
+    np.testing.assert_allclose(traj, g16["losses"], rtol=1e-4)
+    close(tr.models["encoder"].encoder.encoder.conv1.weight, g16["enc_conv1_after"], atol=2e-5)
+    close(tr.models["pose"].pose_conv.weight, g16["pose_conv_after"], atol=2e-5)
+    close(tr.models["depth"].conv3x3.weight, g16["depth_conv3x3_after"], atol=2e-5)

@@ -26,12 +26,29 @@ def pose_grad_close(got, want, tol=5e-3):
     assert np.abs(got - want).max() < tol * np.abs(want).max(), (got, want)
 
 
-def grad_close(got, want, frac=1e-2, tol=1e-3, mean_tol=1.5e-3):
+def ties_only(sel_got, want, name, tie_tol=5e-6):
+    """identity_selection is an index output: it may differ from the oracle's only where the two best candidates of
+    trainer.py:526's min tie to within fp32 rounding of the SSIM window sums (|gap| < tie_tol on losses of O(0.1))."""
+    comb = torch.cat((want["identity"], want["reproj"]), 1).detach()
+    top2 = torch.topk(comb, 2, dim=1, largest=False).values
+    gap = (top2[:, 1] - top2[:, 0])
+    # a flip of identity_selection needs the best identity and the best reprojection candidate to tie
+    S = want["identity"].shape[1]
+    gap_ir = (comb[:, :S].min(1).values - comb[:, S:].min(1).values).abs()
+    mism = sel_got.detach().cpu() != want["identity_selection/0"]
+    n = int(mism.sum())
+    worst = float(gap_ir[mism].max()) if n else 0.0
+    print("identity_selection[%s]: %d of %d pixels differ (%.4f %%), largest candidate gap among them %.2e"
+          % (name, n, mism.numel(), 100.0 * n / mism.numel(), worst))
+    assert worst < tie_tol, (n, worst)
+    assert n <= 5e-4 * mism.numel(), n
+
+
+def grad_close(got, want, frac=7.5e-3, tol=1e-3, mean_tol=1e-3):
     """Per-pixel gradient maps: the per-pixel min / auto-mask and sign() make a handful of pixels flip
-    discretely when two candidates tie to within rounding, so require 99 % of pixels within
-    tol*max|want| and a bounded mean error.  Noise floor for calibration: the oracle run in fp32 vs
-    fp64 differs by mean 2.5e-4..4.7e-4 of mean|grad| with 0.02..0.36 % of pixels beyond 1e-3*max
-    (measured on the golden shapes and on B=12 192x640)."""
+    discretely when two candidates tie to within rounding.  Bounds = 2x the noise floor of the oracle
+    itself: run in fp32 vs fp64 it differs by mean 2.5e-4..4.7e-4 of mean|grad| with 0.02..0.36 % of
+    pixels beyond 1e-3*max (measured on the golden shapes and on B=12 192x640)."""
     got = got.detach().cpu().numpy() if isinstance(got, torch.Tensor) else np.asarray(got)
     want = want.detach().cpu().numpy() if isinstance(want, torch.Tensor) else np.asarray(want)
     diff, scale = np.abs(got - want), np.abs(want).max()
@@ -158,7 +175,7 @@ def test_full_chain_vs_oracle(ops, O, B, H, W, rows, seed):
     for s, f in enumerate((-1, 1)):
         close(samples[s], want[("sample", f, 0)], rtol=RTOL, atol=2e-6)
         close(warped[s], want[("color", f, 0)], rtol=RTOL, atol=2e-5)
-    assert (sel.cpu() != want["identity_selection/0"]).float().mean() < 2e-3
+    ties_only(sel, want, "%dx%dx%d" % (B, H, W))
     close(smooth, want["smooth"], rtol=RTOL)
     close(total, want["loss"], rtol=RTOL)
     total.backward()
@@ -182,7 +199,9 @@ def test_golden_g07_g08(ops, golden, tag):
         close(samples[s], g7["sample_" + n], rtol=RTOL, atol=2e-6)
         close(warped[s], g7["color_" + n], rtol=RTOL, atol=2e-5)
     close(total, g8["loss"], rtol=RTOL)
-    assert (sel.cpu().numpy() != g8["identity_selection"]).mean() < 2e-3
+    nm = int((sel.cpu().numpy() != g8["identity_selection"]).sum())
+    print("identity_selection vs golden %s: %d of %d differ" % (tag, nm, sel.numel()))
+    assert nm <= 5e-4 * sel.numel(), nm
     total.backward()
     grad_close(disp.grad, g8["grad_disp"])
     for s, n in enumerate(("m1", "p1")):
@@ -218,7 +237,7 @@ def test_full_size_config_b(ops, O):
     want, wdisp, wposes = oracle_chain(O, d, H, W)
     close(total, want["loss"], rtol=RTOL)
     close(photo, want["to_optimise"].mean(), rtol=RTOL)
-    assert (outs[4].cpu() != want["identity_selection/0"]).float().mean() < 2e-3
+    ties_only(outs[4], want, "config B 12x192x640")
     (2.5 * total).backward()
     grad_close(disp.grad / 2.5, wdisp.grad)
     for s, f in enumerate((-1, 1)):

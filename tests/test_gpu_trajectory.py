@@ -65,9 +65,11 @@ def test_five_steps_follow_the_oracle():
     tr_g, graph = _device_run([], state)
     assert tr_e._graph is None and tr_g._graph is not None
     for name, got in (("eager", eager), ("graph", graph)):
+        print("trajectory[%s] relative loss error per step:" % name, ["%.1e" % (abs(a - b) / abs(b)) for a, b in zip(got, want)])
         for i, (a, b) in enumerate(zip(got, want)):
-            # step 0 agrees to ~1e-6; later steps inherit Adam's amplification of rounding differences in tiny gradients
-            tol = 1e-4 if i == 0 else 5e-3
+            # step 0 agrees to ~1e-6; later steps inherit Adam's amplification (update = lr * sign-like g/sqrt(v)) of rounding
+            # differences in near-zero gradients: measured <= 6e-4 over these six steps, bound = 2x that
+            tol = 1e-4 if i == 0 else 1.2e-3
             assert abs(a - b) <= tol * abs(b), (name, i, got, want)
     # and the weights the oracle ends with are the ones on the device (first pose filter: a 7x7 stem, regrouped each step)
     w_ref = pose.net[0].weight.detach()
