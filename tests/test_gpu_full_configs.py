@@ -66,6 +66,15 @@ def test_flagship_step_matches_oracle(H, W, B, kind):
     for net, mine, name in ((pose, tr.models["pose"], "pose_conv.weight"), (enc, tr.models["encoder"], "decoder.conv3.weight"),
                             (dep, tr.models["depth"], "convert_to_prob.0.weight"), (pose, tr.models["pose"], "net.0.weight"),
                             (enc, tr.models["encoder"], "encoder.encoder.conv1.weight"), (pose, tr.models["pose"], "net.3.weight")):
-        w_ref = dict(net.named_parameters())[name].detach()
+        p_ref = dict(net.named_parameters())[name]
+        w_ref, g_ref = p_ref.detach(), p_ref.grad.detach()
         w_got = dict(mine.named_parameters())[name].detach().cpu()
-        assert torch.allclose(w_got, w_ref, atol=5e-5), (name, float((w_got - w_ref).abs().max()))
+        # Adam's first update is lr * g/(|g| + eps) = lr * sign(g): an element whose gradient lies within fp32 summation noise of
+        # zero may legitimately move the other way.  Such elements are allowed only where |g_ref| is tiny against the tensor's
+        # scale, and only a few of them.
+        bad = (w_got - w_ref).abs() > 5e-5
+        noise_level = g_ref.abs() <= 5e-3 * g_ref.abs().max()
+        print("%s: %d of %d updated weights beyond 5e-5, all of them at |g| <= 5e-3 max|g|: %s"
+              % (name, int(bad.sum()), bad.numel(), bool((~bad | noise_level).all())))
+        assert bool((~bad | noise_level).all()), (name, float((w_got - w_ref).abs().max()))
+        assert float(bad.float().mean()) <= 5e-3, (name, int(bad.sum()))
