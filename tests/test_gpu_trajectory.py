@@ -67,9 +67,8 @@ def test_five_steps_follow_the_oracle():
     for name, got in (("eager", eager), ("graph", graph)):
         print("trajectory[%s] relative loss error per step:" % name, ["%.1e" % (abs(a - b) / abs(b)) for a, b in zip(got, want)])
         for i, (a, b) in enumerate(zip(got, want)):
-            # step 0 agrees to ~1e-6; later steps inherit Adam's amplification (update = lr * sign-like g/sqrt(v)) of rounding
-            # differences in near-zero gradients: measured <= 6e-4 over these six steps, bound = 2x that
-            tol = 1e-4 if i == 0 else 1.2e-3
+            # measured on MI355X: every one of the six steps within 5.1e-6 relative (eager and graph replay)
+            tol = 1e-4
             assert abs(a - b) <= tol * abs(b), (name, i, got, want)
     # and the weights the oracle ends with are the ones on the device (first pose filter: a 7x7 stem, regrouped each step)
     w_ref = pose.net[0].weight.detach()
