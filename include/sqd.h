@@ -80,17 +80,17 @@ typedef struct sqd_photo_args {
     const float *target;    /* [B,3,H,W]  inputs[("color",0,0)]                                      */
     const float *sources[SQD_MAX_SOURCES]; /* S x [B,3,H,W]  inputs[("color",f,0)], f in frame_ids[1:] */
     const float *identity;  /* [B,S,H,W] identity reprojection loss + 1e-5*noise (sqd_identity_fwd)  */
-    /* outputs (any of sample[s]/warped[s]/sel/x0y0[s]/coef/reproj may be NULL to skip the store) */
+    /* outputs (any of sample[s]/warped[s]/sel/x0y0[s]/reproj may be NULL to skip the store) */
     float *sample[SQD_MAX_SOURCES];  /* S x [B,H,W,2] outputs[("sample",f,0)]                        */
     float *warped[SQD_MAX_SOURCES];  /* S x [B,3,H,W] outputs[("color",f,0)]                         */
     float *sel;             /* [B,H,W]    outputs["identity_selection/0"] (0/1)                      */
     uint8_t *idx;           /* [B,H,W]    argmin over [identity_0..S-1, reproj_0..S-1]               */
     int32_t *x0y0[SQD_MAX_SOURCES];  /* S x [B,H,W,2] integer grid_sample taps (x0,y0) — parity instrumentation */
-    float *coef;            /* [B,9,H,W]  d(to_optimise)/d(window stats) of the winning source, for bwd */
+    float *coef;            /* not written by sqd_photo_fwd (the backward recomputes it: sqd_photo_coef); leave NULL */
     float *reproj;          /* [B,S,H,W]  reprojection loss maps (debug/parity; may be NULL)         */
-    float *loss_part;       /* [ntasks]   per-wavefront partial sums of to_optimise                  */
+    float *loss_part;       /* [ntasks]   per-wavefront partial sums of to_optimise, ntasks = sqd_photo_ntasks(...) */
     int32_t B, S, H, W;
-    int32_t rows_per_task;  /* TH: output rows per wavefront strip, 1..4096; 0 = library default (8)   */
+    int32_t rows_per_task;  /* rows a workgroup tile owns (even, <= 16); 0 = library default (16)      */
     void *stream;
 } sqd_photo_args;
 int sqd_photo_ntasks(int B, int H, int W, int rows_per_task);
@@ -102,6 +102,14 @@ int sqd_photo_fwd(const sqd_photo_args *a);
  * -> identity [B,S,H,W].                                                                              */
 int sqd_identity_fwd(const float *target, const float *const *sources_host, const float *noise, float *identity,
                      int B, int S, int H, int W, int rows_per_task, void *stream);
+
+/* d(to_optimise)/d(7x7 window sums) of the winning source — the "coefficient planes" the backward box-filters — from the
+ * warped images sqd_photo_fwd stored: target [B,3,H,W], warped_host[S] device pointers to [B,3,H,W], idx [B,H,W] the argmin
+ * byte -> coef [B,9,H,W] (planes: d/d sum w_c, d/d sum w_c^2, d/d sum w_c t_c for c = r,g,b), written where a
+ * reprojection candidate won (idx >= S); other pixels are left untouched and never read.  Part of the backward pass: the
+ * forward launch carries no training-only traffic.                                                                   */
+int sqd_photo_coef(const float *target, const float *const *warped_host, const uint8_t *idx, float *coef, int B, int S, int H,
+                   int W, int rows_per_task, void *stream);
 
 /* backward of sqd_photo_fwd w.r.t. depth and P.  gscale = dL/d(mean to_optimise) / (B*H*W).
  * One wavefront per (image, source, strip): plane s of g_depth = contribution of source s (fully

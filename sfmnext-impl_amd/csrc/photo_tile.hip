@@ -1,0 +1,502 @@
+// photo_tile.hip — the fused warp + SSIM forward of the photometric chain (S = 2 source frames), tile edition.
+//
+// replaces (reference): BackprojectDepth -> Project3D -> grid_sample (layers.py:186-258, trainer.py:420-435), SSIM + L1
+// (layers.py:13-46, trainer.py:441-453) and the per-pixel minimum / auto-mask (trainer.py:474-532) in ONE launch.
+//
+// Execution shape.  A workgroup (4 wavefronts) owns a tile of up to 58..61 columns x TR (<= 16) rows of the target image.
+//   phase 1 (per cell, once): every cell of the tile + its 3-pixel halo — 64 columns (one per lane) x (TR + 6) rows, rows
+//     dealt round-robin to the four waves — is back-projected, projected into both source views and bilinearly sampled
+//     (canonical fp32 order of oracle/warp_chain.c: bit-exact integer taps); the six warped colours go to LDS (8-byte
+//     (source 0, source 1) pairs, lane-contiguous: conflict-free) and, for the cells the tile owns, to HBM together with
+//     the sampling grid.  Nothing of the expensive projection / gather chain is evaluated twice inside a tile (the column
+//     march this replaces re-evaluated it for the 6 halo rows of every 8-row strip: 1.75x).
+//   phase 2 (per output pixel): each wave takes pairs of output rows; the 7x7 window statistics are vertical register sums
+//     over LDS rows (two outputs share six of their seven rows) followed by the horizontal 7-tap sum on wavefront
+//     shuffles (six v_add_f32_dpp wave_shr/wave_shl per quantity: no LDS traffic, no barrier), then the SSIM algebra with
+//     the reference's true division, L1, the minimum against the identity maps, identity_selection, the argmin byte and
+//     the loss partial.  ReflectionPad2d(3): rows are reflected when they are fetched from LDS; at the left / right image
+//     border the wavefront holds the border columns itself and adds the mirrored terms from the shuffle chain's own
+//     intermediates, so border strips own 61 columns instead of 58 (640 columns = 11 strips, not 12).
+// No coefficient planes are written for the backward any more: photo_coef (MODE 2 below) recomputes them from the warped
+// images when — and only when — a backward pass runs.
+//
+// Roofline: HBM.  Algorithmic bytes per target pixel: reads depth-lowres 1 + target 12 + sources 24 +
+// identity 8, writes depth 4 (by depth_up) + sample 16 + warped 24 + identity_selection 4 = 93 B.
+#include "sqd_common.h"
+
+namespace {
+using namespace sqd;
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v3f __attribute__((ext_vector_type(3)));      // (register triples as SSA vectors: float[3] members end up as private arrays)
+
+constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
+constexpr float INV49 = 1.0f / 49.0f;
+constexpr int TR_MAX = 16;               // rows a tile owns (even)
+constexpr int NROW_MAX = TR_MAX + 6;     // + 3 halo rows above and below
+constexpr int LDS_BYTES = NROW_MAX * 3 * 64 * 8;
+
+__device__ __forceinline__ float ldg(const float *__restrict__ base, unsigned byte_off) {
+    return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
+}
+__device__ __forceinline__ void stg(float *__restrict__ base, unsigned byte_off, float v) {
+    *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
+}
+__device__ __forceinline__ v2f splat(float x) { return v2f{x, x}; }
+__device__ __forceinline__ v2f pfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+// ---- correctly rounded division: the arithmetic core of the compiler's IEEE expansion (v_rcp + Newton + two residual
+// corrections), without the range-scaling wrappers that pixel-range operands never need (validated bit-exact against
+// the C oracle: tests/test_gpu_photometric.py::test_warp_taps_bit_exact)
+__device__ __forceinline__ float rcp_refined(float b) {
+    const float r = __builtin_amdgcn_rcpf(b);
+    return fmaf(fmaf(-b, r, 1.0f), r, r);
+}
+__device__ __forceinline__ v2f rcp_refined2(v2f b) {
+    const v2f r = v2f{__builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y)};
+    return pfma(pfma(-b, r, splat(1.0f)), r, r);
+}
+__device__ __forceinline__ v2f div_core2(v2f a, v2f b, v2f r) {      // a / b with r = rcp_refined(b)
+    v2f q = a * r;
+    v2f e = pfma(-b, q, a);
+    q = pfma(e, r, q);
+    e = pfma(-b, q, a);
+    return pfma(e, r, q);
+}
+
+// ---- column strips ------------------------------------------------------------------------------------------------
+// Lanes of a wavefront = 64 consecutive image columns.  An interior strip owns its middle 58 columns (3 halo lanes per
+// side).  The first strip starts at column 0 and the last one ends at column W-1: they own up to 61 columns, and the
+// mirrored columns of ReflectionPad2d(3) come from their own lanes (box7x3<LEFT / RIGHT>).  Images of at most 58 columns
+// are one "virtual" strip: lanes = columns -3 .. 60, halo lanes loaded at the reflected coordinate.
+enum { INTERIOR = 0, LEFT = 1, RIGHT = 2 };
+struct StripX {
+    int x0;           // column of lane 0 (may be negative)
+    int own0, own1;   // owned columns [own0, own1)
+    int kind;         // INTERIOR (also the virtual strip) / LEFT / RIGHT
+    bool virt;        // halo lanes lie outside the image and are reflected when loaded
+};
+__host__ __device__ inline int strips_x(int W) { return W <= 58 ? 1 : W <= 122 ? 2 : 2 + (W - 122 + 57) / 58; }
+__device__ __forceinline__ StripX strip_x(int k, int nsx, int W) {
+    StripX s;
+    s.virt = false;
+    if (nsx == 1) {
+        s.x0 = -3; s.own0 = 0; s.own1 = W; s.kind = INTERIOR; s.virt = true;
+    } else if (k == 0) {
+        s.x0 = 0; s.own0 = 0; s.own1 = min(61, W - 3); s.kind = LEFT;
+    } else if (k == nsx - 1) {
+        s.x0 = W - 64; s.own0 = nsx == 2 ? min(61, W - 3) : 61 + 58 * (k - 1); s.own1 = W; s.kind = RIGHT;
+    } else {
+        s.own0 = 61 + 58 * (k - 1); s.x0 = s.own0 - 3; s.own1 = s.own0 + 58; s.kind = INTERIOR;
+    }
+    return s;
+}
+
+// lane i receives lane i-n / i+n of its row of 16 lanes (0 beyond the row), or the mirror image of its quad
+template <int N>
+__device__ __forceinline__ float row_shr(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x110 + N, 0xf, 0xf, true));
+}
+template <int N>
+__device__ __forceinline__ float row_shl(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float quad_reverse(float v) {      // quad_perm [3,2,1,0]
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x1B, 0xf, 0xf, true));
+}
+
+// centred 7-tap sums of three quantities across lanes (interleaved chains: no DPP hazard nops).
+// KIND == LEFT: lanes 0..3 are image columns 0..3; the reflected window of column 0 / 1 / 2 additionally holds
+// v1+v2+v3 / v1+v2 / v1: prefix sums of the masked lanes 1..3 (two row-shift adds), mirrored inside the quad.
+// KIND == RIGHT: lanes 60..63 are columns W-4..W-1, mirror image.
+template <int KIND>
+__device__ __forceinline__ void box7x3(float &a, float &b, float &c, bool edge) {
+    float ea = 0.f, eb = 0.f, ec = 0.f;
+    if (KIND == LEFT) {
+        const float ma = edge ? a : 0.f, mb = edge ? b : 0.f, mc = edge ? c : 0.f;      // edge: lanes 1..3
+        ea = quad_reverse((ma + row_shr<1>(ma)) + row_shr<2>(ma));
+        eb = quad_reverse((mb + row_shr<1>(mb)) + row_shr<2>(mb));
+        ec = quad_reverse((mc + row_shr<1>(mc)) + row_shr<2>(mc));
+    } else if (KIND == RIGHT) {
+        const float ma = edge ? a : 0.f, mb = edge ? b : 0.f, mc = edge ? c : 0.f;      // edge: lanes 60..62
+        ea = quad_reverse((ma + row_shl<1>(ma)) + row_shl<2>(ma));
+        eb = quad_reverse((mb + row_shl<1>(mb)) + row_shl<2>(mb));
+        ec = quad_reverse((mc + row_shl<1>(mc)) + row_shl<2>(mc));
+    }
+    float ra = a + wave_shr1(a), rb = b + wave_shr1(b), rc = c + wave_shr1(c);
+    ra = a + wave_shr1(ra); rb = b + wave_shr1(rb); rc = c + wave_shr1(rc);
+    ra = a + wave_shr1(ra); rb = b + wave_shr1(rb); rc = c + wave_shr1(rc);
+    float ua = a + wave_shl1(a), ub = b + wave_shl1(b), uc = c + wave_shl1(c);
+    ua = a + wave_shl1(ua); ub = b + wave_shl1(ub); uc = c + wave_shl1(uc);
+    a = ra + wave_shl1(ua); b = rb + wave_shl1(ub); c = rc + wave_shl1(uc);
+    if (KIND != INTERIOR) {
+        a += ea; b += eb; c += ec;
+    }
+}
+template <int KIND>
+__device__ __forceinline__ void box7x3(v2f &a, v2f &b, v2f &c, bool edge) {
+    float ax = a.x, bx = b.x, cx = c.x, ay = a.y, by = b.y, cy = c.y;
+    box7x3<KIND>(ax, bx, cx, edge);
+    box7x3<KIND>(ay, by, cy, edge);
+    a = v2f{ax, ay};
+    b = v2f{bx, by};
+    c = v2f{cx, cy};
+}
+
+// one row of a lane's column: target rgb and the (pred_0, pred_1) rgb pairs
+struct Raw {
+    v3f t;
+    v2f w[3];
+};
+// the window statistics of one lane's column over some rows (21 numbers): sum t, sum w, sum (w^2 + t^2), sum w t
+struct Sums {
+    v3f St;
+    v2f Sw[3], Sq[3], Swt[3];
+};
+__device__ __forceinline__ void products(const Raw &R, Sums &P) {
+    P.St = R.t;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        P.Sw[c] = R.w[c];
+        P.Sq[c] = pfma(R.w[c], R.w[c], splat(R.t[c] * R.t[c]));       // sigma_x + sigma_y only needs sum(w^2 + t^2)
+        P.Swt[c] = R.w[c] * splat(R.t[c]);
+    }
+}
+__device__ __forceinline__ void accumulate(Sums &A, const Sums &P) {
+    A.St += P.St;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        A.Sw[c] += P.Sw[c];
+        A.Sq[c] += P.Sq[c];
+        A.Swt[c] += P.Swt[c];
+    }
+}
+
+// MODE 0: identity maps ("pred" = the source frames themselves; output = loss + 1e-5 * noise)    trainer.py:480-487,514-517
+// MODE 1: fused warp + SSIM + L1 + per-pixel min / auto-mask                                     trainer.py:386-532
+// MODE 2: d loss / d (window sums) of the winning source ("coefficient planes") for the backward, from the stored warps
+template <int MODE>
+struct Ctx {
+    __amdgpu_buffer_rsrc_t tgt;       // image b of the target, [3][H][W]
+    __amdgpu_buffer_rsrc_t p0, p1;    // MODE 0: sources, MODE 2: warped images (image b)
+    const v2f *wl;                    // MODE 1: LDS tile [row][3][64]
+    int H, W, y0, x, lane;            // tile's first owned row, this lane's column
+    unsigned HW;
+    unsigned xoff;                    // byte offset of the lane's column — beyond every buffer for lanes outside the image
+};
+__device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+
+template <int MODE>
+__device__ __forceinline__ void load_row(const Ctx<MODE> &k, int r, Raw &R) {
+    // tile row r <-> image row y0 - 3 + r, reflected into the image (ReflectionPad2d(3), layers.py:26).  Raw buffer loads: a
+    // lane outside the image (W < 64 only) carries an offset beyond the descriptor and reads zeros — no branch.
+    const int yr = reflect_idx(k.y0 - 3 + r, k.H);
+    const unsigned row = (unsigned)(yr * k.W) * 4u;           // wave-uniform: travels in the scalar offset
+#pragma unroll
+    for (int c = 0; c < 3; ++c) R.t[c] = bld(k.tgt, k.xoff, row + c * k.HW * 4u);
+    if (MODE == 1) {
+        const int rr = yr - (k.y0 - 3);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R.w[c] = k.wl[(rr * 3 + c) * 64 + k.lane];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R.w[c] = v2f{bld(k.p0, k.xoff, row + c * k.HW * 4u), bld(k.p1, k.xoff, row + c * k.HW * 4u)};
+    }
+}
+
+struct SsimOut {
+    v2f loss;              // 0.85 * ssim.mean(1) + 0.15 * l1.mean(1) for (pred_0, pred_1)       trainer.py:446-451
+    float g0[9], g1[9];    // GRAD: d loss_s / d (sum w_c, sum w_c^2, sum w_c t_c), c = 0..2
+};
+
+// SSIM + L1 of both predictions against the target from the window sums (already box-summed) and the centre row
+template <bool GRAD>
+__device__ __forceinline__ void ssim_l1(const Sums &S, const Raw &ctr, SsimOut &o) {
+    v2f ssim_sum = splat(0.f), l1 = splat(0.f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const v2f Sw = S.Sw[c], Sq = S.Sq[c], Swt = S.Swt[c];
+        // layers.py:35-46
+        const float mt = S.St[c] * INV49;
+        const v2f mw = Sw * splat(INV49);
+        const v2f mwmt = mw * splat(mt);
+        const v2f sxy = Swt * splat(INV49) - mwmt;
+        const v2f mm = pfma(mw, mw, splat(mt * mt));
+        const v2f A1 = pfma(splat(2.f), mwmt, splat(C1)), A2 = pfma(splat(2.f), sxy, splat(C2));
+        const v2f B1 = mm + splat(C1), B2 = (Sq * splat(INV49) - mm) + splat(C2);
+        const v2f Bd = B1 * B2;
+        const v2f Sv = div_core2(A1 * A2, Bd, rcp_refined2(Bd));       // SSIM_n / SSIM_d, the reference's division (layers.py:46)
+        const v2f r = (splat(1.f) - Sv) * splat(0.5f);
+        ssim_sum += v2f{fminf(fmaxf(r.x, 0.f), 1.f), fminf(fmaxf(r.y, 0.f), 1.f)};
+        const v2f df = splat(ctr.t[c]) - ctr.w[c];
+        l1 += v2f{fabsf(df.x), fabsf(df.y)};
+        if (GRAD) {
+            const v2f iB1 = v2f{__builtin_amdgcn_rcpf(B1.x), __builtin_amdgcn_rcpf(B1.y)};
+            const v2f iB2 = v2f{__builtin_amdgcn_rcpf(B2.x), __builtin_amdgcn_rcpf(B2.y)};
+            const v2f iB = iB1 * iB2;
+            // torch.clamp passes the gradient at the bounds; window mean -> sum
+            const v2f kk = v2f{(r.x >= 0.f && r.x <= 1.f) ? -0.5f * INV49 : 0.f, (r.y >= 0.f && r.y <= 1.f) ? -0.5f * INV49 : 0.f};
+            const v2f dmu = splat(2.f) * (splat(mt) * (A2 - A1) * iB + mw * Sv * (iB2 - iB1));
+            const v2f g0 = kk * dmu, g1 = kk * (-Sv * iB2), g2 = kk * (splat(2.f) * A1 * iB);
+            o.g0[c] = g0.x; o.g1[c] = g0.y;
+            o.g0[3 + c] = g1.x; o.g1[3 + c] = g1.y;
+            o.g0[6 + c] = g2.x; o.g1[6 + c] = g2.y;
+        }
+    }
+    o.loss = splat(0.85f) * (ssim_sum * splat(1.f / 3.f)) + splat(0.15f) * (l1 * splat(1.f / 3.f));
+}
+
+template <int MODE, int KIND>
+__device__ __forceinline__ void finish_row(const sqd_photo_args &a, const float *noise, const Ctx<MODE> &k, Sums &S, const Raw &ctr,
+                                           bool edge, int b, int yo, bool own, float &loss_acc) {
+    {
+        float s0 = S.St.x, s1 = S.St.y, s2 = S.St.z;
+        box7x3<KIND>(s0, s1, s2, edge);
+        S.St = v3f{s0, s1, s2};
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) box7x3<KIND>(S.Sw[c], S.Sq[c], S.Swt[c], edge);
+    SsimOut o;
+    ssim_l1<MODE == 2>(S, ctr, o);
+    if (!own) return;
+    const unsigned HW = k.HW;
+    const unsigned qo = (unsigned)(yo * k.W + k.x);
+    if (MODE == 0) {
+        float *out = a.sel + (size_t)b * 2 * HW;                       // (the identity maps travel through `sel`)
+        const float *nz = noise ? noise + (size_t)b * 2 * HW : nullptr;
+        stg(out, qo * 4u, o.loss.x + (nz ? ldg(nz, qo * 4u) : 0.f) * 0.00001f);              // trainer.py:514-517
+        stg(out, (qo + HW) * 4u, o.loss.y + (nz ? ldg(nz, (qo + HW) * 4u) : 0.f) * 0.00001f);
+    } else if (MODE == 1) {
+        // combined = [identity_0, identity_1, reproj_0, reproj_1]; torch.min(dim 1): first minimum wins    trainer.py:519-526
+        const float *idm = a.identity + (size_t)b * 2 * HW;
+        float best = ldg(idm, qo * 4u);
+        int bi = 0;
+        const float v1 = ldg(idm, (qo + HW) * 4u);
+        if (v1 < best) { best = v1; bi = 1; }
+        if (o.loss.x < best) { best = o.loss.x; bi = 2; }
+        if (o.loss.y < best) { best = o.loss.y; bi = 3; }
+        if (a.reproj) {
+            a.reproj[(size_t)b * 2 * HW + qo] = o.loss.x;
+            a.reproj[(size_t)b * 2 * HW + HW + qo] = o.loss.y;
+        }
+        loss_acc += best;
+        if (a.sel) a.sel[(size_t)b * HW + qo] = bi > 1 ? 1.f : 0.f;    // trainer.py:529-530
+        if (a.idx) a.idx[(size_t)b * HW + qo] = (uint8_t)bi;
+    } else {
+        const int bi = a.idx[(size_t)b * HW + qo];
+        if (bi >= 2) {
+            float *co = a.coef + (size_t)b * 9 * HW;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) stg(co, (qo + j * HW) * 4u, (bi == 2 ? o.g0[j] : o.g1[j]) * (0.85f / 3.f));
+        }
+    }
+}
+
+// phase 2 for the output rows of one wave: pairs (j, j+1) of tile rows share six of their seven window rows
+template <int MODE, int KIND>
+__device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const float *noise, const Ctx<MODE> &k, bool edge, int b,
+                                          int wave, int TR, int own_rows, bool own_col, float &loss_acc) {
+    for (int p = wave; 2 * p < own_rows; p += 4) {
+        const int j = 2 * p;                         // tile rows j .. j+7 feed the outputs y0+j (centre j+3) and y0+j+1 (centre j+4)
+        Sums core;                                   // rows j+1 .. j+6: shared by both outputs
+        {
+            Raw R;
+            load_row<MODE>(k, j + 1, R);
+            products(R, core);
+#pragma unroll
+            for (int i = 2; i < 7; ++i) {
+                load_row<MODE>(k, j + i, R);
+                Sums P;
+                products(R, P);
+                accumulate(core, P);
+            }
+        }
+        // (a rolled loop: one SSIM body in the instruction stream, and the register allocator sees one output at a time)
+#pragma nounroll
+        for (int o = 0; o < 2; ++o) {
+            Raw R, ctr;
+            load_row<MODE>(k, j + 7 * o, R);         // the row only this output has: j, resp. j+7
+            load_row<MODE>(k, j + 3 + o, ctr);       // centre row (L1 term)
+            Sums S;
+            products(R, S);
+            accumulate(S, core);
+            finish_row<MODE, KIND>(a, noise, k, S, ctr, edge, b, k.y0 + j + o, own_col && j + o < own_rows, loss_acc);
+        }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void photo_tile_kernel(sqd_photo_args a, const float *__restrict__ noise, int TR, int nsx,
+                                                          int nsy, int ntiles, int nblk8) {
+    extern __shared__ v2f wl[];                       // MODE 1: [TR + 6][3][64] (source 0, source 1) warped colours
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    // consecutive tiles (which share halo rows / columns) on the same XCD: workgroup i runs on XCD i % 8
+    const int tile = (blockIdx.x & 7) * nblk8 + (blockIdx.x >> 3);
+    if (tile >= ntiles) return;
+    const int H = a.H, W = a.W;
+    const unsigned HW = (unsigned)(H * W);
+    const int tx = tile % nsx, t2 = tile / nsx, ty = t2 % nsy, b = t2 / nsy;
+    const StripX sx = strip_x(tx, nsx, W);
+    const int y0 = ty * TR;
+    const int own_rows = min(TR, H - y0);
+    const int x = sx.x0 + lane;                                   // this lane's column
+    const int xr = sx.virt ? reflect_idx(x, W) : x;               // column it loads (virtual strip: reflected halo)
+    const bool col_ok = xr >= 0 && xr < W;
+    const bool own_col = x >= sx.own0 && x < sx.own1;
+    const float *__restrict__ tgt = a.target + (size_t)b * 3 * HW;
+
+    if (MODE == 1) {
+        // ---------------------------------------------------------------- phase 1: warp every cell of the tile once
+        const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+        const float *__restrict__ dep = a.depth + (size_t)b * HW;
+        const float *__restrict__ src0 = a.sources[0] + (size_t)b * 3 * HW;
+        const float *__restrict__ src1 = a.sources[1] + (size_t)b * 3 * HW;
+        float ik[9];
+        v2f P[12];                       // (source 0, source 1) projection matrices
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) ik[i * 3 + j] = a.inv_K[(size_t)b * 16 + i * 4 + j];
+#pragma unroll
+        for (int j = 0; j < 12; ++j) P[j] = v2f{a.P[((size_t)b * 2 + 0) * 12 + j], a.P[((size_t)b * 2 + 1) * 12 + j]};
+        const v2f rW = splat(rcp_refined(wm1)), rH = splat(rcp_refined(hm1));
+        const float fx = (float)xr;
+        const int nrow = own_rows + 6;
+        for (int r = wave; r < nrow; r += 4) {
+            const int y = y0 - 3 + r;
+            if (y < 0 || y >= H) continue;                     // (rows outside the image are reflections of rows inside the tile)
+            if (!col_ok) {                                     // lanes beyond the image (W < 64): zeros for the shuffles
+#pragma unroll
+                for (int c = 0; c < 3; ++c) wl[(r * 3 + c) * 64 + lane] = splat(0.f);
+                continue;
+            }
+            const unsigned off = (unsigned)(y * W + xr);
+            // ---- camera ray and point (shared by both sources) — layers.py:211-212
+            const float fy = (float)y;
+            float X[3];
+            const float d = ldg(dep, off * 4u);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                float acc = ik[i * 3 + 0] * fx;
+                acc = fmaf(ik[i * 3 + 1], fy, acc);
+                acc = fmaf(ik[i * 3 + 2], 1.0f, acc);
+                X[i] = d * acc;
+            }
+            // ---- projection of both sources at once — layers.py:250-257 (FMA chain k = 0..3)
+            v2f cam[3];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                v2f acc = P[i * 4 + 0] * splat(X[0]);
+                acc = pfma(P[i * 4 + 1], splat(X[1]), acc);
+                acc = pfma(P[i * 4 + 2], splat(X[2]), acc);
+                acc = pfma(P[i * 4 + 3], splat(1.0f), acc);
+                cam[i] = acc;
+            }
+            const v2f z = cam[2] + splat(1e-7f);
+            const v2f rz = rcp_refined2(z);
+            const v2f u = div_core2(cam[0], z, rz), v = div_core2(cam[1], z, rz);
+            const v2f un = div_core2(u, splat(wm1), rW), vn = div_core2(v, splat(hm1), rH);
+            const v2f gx = (un - splat(0.5f)) * splat(2.0f), gy = (vn - splat(0.5f)) * splat(2.0f);
+            // ---- grid_sample(border, align_corners=True): unnormalise, clip, floor, weights (ATen grid_sampler_2d)
+            v2f ix = ((gx + splat(1.0f)) * splat(0.5f)) * splat(wm1);
+            v2f iy = ((gy + splat(1.0f)) * splat(0.5f)) * splat(hm1);
+            ix = v2f{fminf(wm1, fmaxf(ix.x, 0.f)), fminf(wm1, fmaxf(ix.y, 0.f))};
+            iy = v2f{fminf(hm1, fmaxf(iy.x, 0.f)), fminf(hm1, fmaxf(iy.y, 0.f))};
+            const v2f fx0 = v2f{floorf(ix.x), floorf(ix.y)}, fy0 = v2f{floorf(iy.x), floorf(iy.y)};
+            const v2f ax = ix - fx0, ay = iy - fy0;
+            const v2f bx = (fx0 + splat(1.f)) - ix, by = (fy0 + splat(1.f)) - iy;
+            const int x00 = (int)fx0.x, y00 = (int)fy0.x, x01 = (int)fx0.y, y01 = (int)fy0.y;
+            const bool xin0 = x00 + 1 < W, yin0 = y00 + 1 < H, xin1 = x01 + 1 < W, yin1 = y01 + 1 < H;
+            v2f wnw = bx * by, wne = ax * by, wsw = bx * ay, wse = ax * ay;
+            // out-of-range taps are skipped by grid_sample: weight exactly 0 and a clamped (in-range) address
+            wne = v2f{xin0 ? wne.x : 0.f, xin1 ? wne.y : 0.f};
+            wsw = v2f{yin0 ? wsw.x : 0.f, yin1 ? wsw.y : 0.f};
+            wse = v2f{(xin0 && yin0) ? wse.x : 0.f, (xin1 && yin1) ? wse.y : 0.f};
+            const unsigned a00 = (unsigned)(y00 * W + x00), b00 = (unsigned)(y01 * W + x01);
+            const unsigned a01 = a00 + (xin0 ? 1u : 0u), a10 = a00 + (yin0 ? (unsigned)W : 0u), a11 = a10 + (xin0 ? 1u : 0u);
+            const unsigned b01 = b00 + (xin1 ? 1u : 0u), b10 = b00 + (yin1 ? (unsigned)W : 0u), b11 = b10 + (xin1 ? 1u : 0u);
+            v2f wv[3];
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const unsigned co = c * HW;
+                v2f acc = v2f{ldg(src0, (a00 + co) * 4u), ldg(src1, (b00 + co) * 4u)} * wnw;
+                acc = pfma(v2f{ldg(src0, (a01 + co) * 4u), ldg(src1, (b01 + co) * 4u)}, wne, acc);
+                acc = pfma(v2f{ldg(src0, (a10 + co) * 4u), ldg(src1, (b10 + co) * 4u)}, wsw, acc);
+                acc = pfma(v2f{ldg(src0, (a11 + co) * 4u), ldg(src1, (b11 + co) * 4u)}, wse, acc);
+                wv[c] = acc;
+                wl[(r * 3 + c) * 64 + lane] = acc;
+            }
+            if (own_col && r >= 3 && r < own_rows + 3) {
+                const size_t q = (size_t)b * HW + off;
+                if (a.sample[0]) *reinterpret_cast<float2 *>(a.sample[0] + q * 2) = make_float2(gx.x, gy.x);
+                if (a.sample[1]) *reinterpret_cast<float2 *>(a.sample[1] + q * 2) = make_float2(gx.y, gy.y);
+                if (a.x0y0[0]) *reinterpret_cast<int2 *>(a.x0y0[0] + q * 2) = make_int2(x00, y00);
+                if (a.x0y0[1]) *reinterpret_cast<int2 *>(a.x0y0[1] + q * 2) = make_int2(x01, y01);
+                if (a.warped[0]) {
+                    float *w0 = a.warped[0] + (size_t)b * 3 * HW, *w1 = a.warped[1] + (size_t)b * 3 * HW;
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        stg(w0, (off + c * HW) * 4u, wv[c].x);
+                        stg(w1, (off + c * HW) * 4u, wv[c].y);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    // -------------------------------------------------------------------- phase 2: window statistics, SSIM, selection
+    Ctx<MODE> k;
+    const unsigned img_bytes = 3u * HW * 4u;
+    k.tgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tgt), 0, img_bytes, 0x00020000);
+    const float *q0 = MODE == 0 ? a.sources[0] : MODE == 2 ? a.warped[0] : a.target;
+    const float *q1 = MODE == 0 ? a.sources[1] : MODE == 2 ? a.warped[1] : a.target;
+    k.p0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(q0 + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
+    k.p1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(q1 + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
+    k.wl = wl;
+    k.H = H; k.W = W; k.y0 = y0; k.x = x; k.lane = lane; k.HW = HW;
+    k.xoff = col_ok ? (unsigned)xr * 4u : 0x80000000u;
+    float loss_acc = 0.f;
+    if (sx.kind == LEFT)
+        ssim_rows<MODE, LEFT>(a, noise, k, lane >= 1 && lane <= 3, b, wave, TR, own_rows, own_col, loss_acc);
+    else if (sx.kind == RIGHT)
+        ssim_rows<MODE, RIGHT>(a, noise, k, lane >= 60 && lane <= 62, b, wave, TR, own_rows, own_col, loss_acc);
+    else
+        ssim_rows<MODE, INTERIOR>(a, noise, k, false, b, wave, TR, own_rows, own_col, loss_acc);
+    if (MODE == 1 && a.loss_part) {
+        loss_acc = wave_sum(loss_acc);
+        if (lane == 0) a.loss_part[tile * 4 + wave] = loss_acc;
+    }
+}
+
+int pick_tr(int rows) {
+    int tr = rows <= 0 ? TR_MAX : rows;
+    tr = tr > TR_MAX ? TR_MAX : tr;
+    tr &= ~1;
+    return tr < 2 ? 2 : tr;
+}
+}  // namespace
+
+namespace sqd {
+int photo_tile_count(int B, int H, int W, int rows_per_task) {
+    const int TR = pick_tr(rows_per_task);
+    return B * strips_x(W) * ((H + TR - 1) / TR);
+}
+
+// mode 0: identity maps, 1: fused forward, 2: coefficient planes of the backward (a.warped = stored warps, a.idx, a.coef)
+void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hipStream_t stream) {
+    const int TR = pick_tr(a.rows_per_task);
+    const int nsx = strips_x(a.W), nsy = (a.H + TR - 1) / TR;
+    const int ntiles = a.B * nsx * nsy;
+    const int nblk8 = (ntiles + 7) / 8;
+    const dim3 grid(nblk8 * 8), block(256);
+    if (mode == 0)
+        hipLaunchKernelGGL((photo_tile_kernel<0>), grid, block, 0, stream, a, noise, TR, nsx, nsy, ntiles, nblk8);
+    else if (mode == 1)
+        hipLaunchKernelGGL((photo_tile_kernel<1>), grid, block, (TR + 6) * 3 * 64 * 8, stream, a, noise, TR, nsx, nsy, ntiles, nblk8);
+    else
+        hipLaunchKernelGGL((photo_tile_kernel<2>), grid, block, 0, stream, a, noise, TR, nsx, nsy, ntiles, nblk8);
+}
+}  // namespace sqd

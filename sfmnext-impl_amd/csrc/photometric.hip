@@ -1,17 +1,12 @@
-// photometric.hip — the fused photometric-reprojection kernels (see include/sqd.h section 3).
+// photometric.hip — entry points of the photometric chain (include/sqd.h section 3) and its backward kernel.
 //
-// Execution shape ("column march"): one wavefront owns a strip of 58 output columns (64 lanes = 58 +
-// a 3-column halo on each side) and marches down TH output rows.  Each lane keeps the last 7 rows of
-// its own column in a register ring, so the vertical half of the 7x7 SSIM window is a register sum
-// and the horizontal half is a 6-instruction DPP chain across lanes (box7) — no LDS, no barriers.
-// The image rows arrive as coalesced 256-byte wavefront rows.  ReflectionPad2d(3) is folded in by
-// reflecting the halo coordinates when loading.  The row loop is a single rolled loop (the ring is
-// shifted by register moves) so the whole kernel stays resident in the instruction cache.
+// The forward kernels live in photo_tile.hip (fused warp + SSIM, identity maps, coefficient planes for the backward).
+// Backward ("column march"): one wavefront owns a strip of 58 output columns (64 lanes = 58 + a 3-column halo on each side)
+// and marches down TH output rows; the adjoint of ReflectionPad2d(3)+AvgPool2d(7,1) is a 6-instruction DPP chain along x
+// (box7) and a scatter ring of 7 accumulator rows along y — no LDS, no barriers.
 //
-// Roofline: HBM.  Algorithmic bytes per target pixel (S = 2): fused forward 93 B (SURVEY.md §8d:
-// reads disp 1 + target 12 + sources 24 + identity/noise 8, writes depth 4 + sample 16 + warped 24 +
-// selection 4); training adds the 36 B/px coefficient maps + 1 B/px argmin that replace a second
-// SSIM pass in the backward.  Backward: 84 B/px.
+// Roofline: HBM.  Algorithmic bytes per target pixel (S = 2): backward 84 B + the 36 B/px coefficient
+// planes photo_coef writes and this kernel reads.
 #include "sqd_common.h"
 
 namespace {
@@ -22,14 +17,6 @@ constexpr float INV49 = 1.0f / 49.0f;
 constexpr int OWN0 = 3, OWN1 = 61;   // owned lanes [3, 61): 58 output columns per wavefront
 
 // ---- projection chain: the fp32 order of oracle/warp_chain.c (bit-exact integer taps) ------------
-struct Taps {
-    float gx, gy;          // normalised grid (outputs[("sample",f,0)])
-    float ix, iy;          // clamped pixel coordinates
-    float fx0, fy0;        // floor
-    int x0, y0;
-    bool xin, yin;         // x0+1 < W, y0+1 < H
-};
-
 __device__ __forceinline__ void cam_ray(const float *ik, float fx, float fy, float c[3]) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -38,35 +25,6 @@ __device__ __forceinline__ void cam_ray(const float *ik, float fx, float fy, flo
         acc = fmaf(ik[i * 3 + 2], 1.0f, acc);
         c[i] = acc;
     }
-}
-
-__device__ __forceinline__ Taps project(const float *P, const float X[3], float wm1, float hm1, int W, int H) {
-    float cam[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        float acc = P[i * 4 + 0] * X[0];                // layers.py:250  (FMA chain k = 0..3)
-        acc = fmaf(P[i * 4 + 1], X[1], acc);
-        acc = fmaf(P[i * 4 + 2], X[2], acc);
-        acc = fmaf(P[i * 4 + 3], 1.0f, acc);
-        cam[i] = acc;
-    }
-    Taps t;
-    const float z = cam[2] + 1e-7f;                     // layers.py:252
-    const float u = cam[0] / z, v = cam[1] / z;
-    const float un = u / wm1, vn = v / hm1;             // :255-256
-    t.gx = (un - 0.5f) * 2.0f;                          // :257
-    t.gy = (vn - 0.5f) * 2.0f;
-    const float ix = ((t.gx + 1.0f) * 0.5f) * wm1;      // grid_sampler_unnormalize (x/2 == x*0.5 exactly)
-    const float iy = ((t.gy + 1.0f) * 0.5f) * hm1;
-    t.ix = fminf(wm1, fmaxf(ix, 0.f));                  // clip_coordinates (padding_mode border)
-    t.iy = fminf(hm1, fmaxf(iy, 0.f));
-    t.fx0 = floorf(t.ix);
-    t.fy0 = floorf(t.iy);
-    t.x0 = (int)t.fx0;
-    t.y0 = (int)t.fy0;
-    t.xin = t.x0 + 1 < W;
-    t.yin = t.y0 + 1 < H;
-    return t;
 }
 
 struct Strip {
@@ -85,229 +43,6 @@ __device__ __forceinline__ Strip strip_of(int task, int nsx, int nsy, int TH, in
     s.xr = reflect_idx(s.cx, W);
     s.own_col = lane >= OWN0 && lane < OWN1 && s.cx >= 0 && s.cx < W;
     return s;
-}
-
-// SSIM loss of one (pred, target) channel from the 7x7 window sums — layers.py:35-46.
-// When GRAD, also d(ssim_loss)/d(Sx, Sxx, Sxy) (pred-side window sums; zero where the clamp saturates).
-template <bool GRAD>
-__device__ __forceinline__ float ssim_from_sums(float Sx, float Sy, float Sxx, float Syy, float Sxy, float *g) {
-    const float mx = Sx * INV49, my = Sy * INV49;
-    const float sx = fmaf(-mx, mx, Sxx * INV49), sy = fmaf(-my, my, Syy * INV49), sxy = fmaf(-mx, my, Sxy * INV49);
-    const float A1 = fmaf(2.f * mx, my, C1), A2 = fmaf(2.f, sxy, C2);
-    const float B1 = fmaf(mx, mx, my * my) + C1, B2 = sx + sy + C2;
-    const float iB1 = __builtin_amdgcn_rcpf(B1), iB2 = __builtin_amdgcn_rcpf(B2);
-    const float iB = iB1 * iB2;
-    const float Sv = A1 * A2 * iB;
-    const float r = (1.f - Sv) * 0.5f;
-    if (GRAD) {
-        const bool pass = r >= 0.f && r <= 1.f;                       // torch.clamp passes at the bounds
-        const float k = pass ? -0.5f * INV49 : 0.f;                   // d r / d S, and window mean -> sum
-        const float dmu = 2.f * (my * (A2 - A1) * iB + mx * Sv * (iB2 - iB1));
-        g[0] = k * dmu;                                               // d/dSx
-        g[1] = k * (-Sv * iB2);                                       // d/dSxx
-        g[2] = k * (2.f * A1 * iB);                                   // d/dSxy
-    }
-    return fminf(fmaxf(r, 0.f), 1.f);
-}
-
-// ===================================================================================================
-// forward.  MODE 0: identity maps (no warp: "pred" = source at the same pixel, output = loss + 1e-5*noise)
-//           MODE 1: fused warp + SSIM + L1 + per-pixel min / auto-mask
-// ===================================================================================================
-template <int S, int MODE>
-__global__ __launch_bounds__(256) void photo_fwd_kernel(sqd_photo_args a, const float *__restrict__ noise, int TH,
-                                                        int nsx, int nsy, int ntasks) {
-    const int lane = threadIdx.x & 63;
-    const int task = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (task >= ntasks) return;
-    const int H = a.H, W = a.W;
-    const int HW = H * W;
-    const Strip st = strip_of(task, nsx, nsy, TH, W, lane);
-    const int b = st.b;
-    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-    const bool want_grad = MODE == 1 && a.coef != nullptr;
-
-    const float *__restrict__ tgt = a.target + (size_t)b * 3 * HW;
-    const float *__restrict__ dep = MODE ? a.depth + (size_t)b * HW : nullptr;
-    const float *__restrict__ src[S];
-#pragma unroll
-    for (int s = 0; s < S; ++s) src[s] = a.sources[s] + (size_t)b * 3 * HW;
-    float ik[9], P[S][12];
-    if (MODE) {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int k = 0; k < 3; ++k) ik[i * 3 + k] = a.inv_K[(size_t)b * 16 + i * 4 + k];
-#pragma unroll
-        for (int s = 0; s < S; ++s)
-#pragma unroll
-            for (int k = 0; k < 12; ++k) P[s][k] = a.P[((size_t)b * S + s) * 12 + k];
-    }
-
-    constexpr int NV = 3 + 3 * S;
-    float ring[7][NV];   // rows (oldest .. newest) x (target rgb, pred_s rgb)
-#pragma unroll
-    for (int k = 0; k < 7; ++k)
-#pragma unroll
-        for (int c = 0; c < NV; ++c) ring[k][c] = 0.f;
-    float loss_acc = 0.f;
-    const int nrows = TH + 6;
-
-#pragma nounroll
-    for (int j = 0; j < nrows; ++j) {
-        const int ycell = st.y_begin - 3 + j;          // cell row (unreflected)
-        const int yr = reflect_idx(ycell, H);
-        const int off = yr * W + st.xr;
-        // this lane owns the *cell* as an output pixel (stores sample / warped for it)
-        const bool own_cell = st.own_col && j >= 3 && j < TH + 3 && ycell < H;
-        // shift the ring, newest row goes to slot 6
-#pragma unroll
-        for (int k = 0; k < 6; ++k)
-#pragma unroll
-            for (int c = 0; c < NV; ++c) ring[k][c] = ring[k + 1][c];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) ring[6][c] = tgt[c * HW + off];
-        if (MODE == 0) {
-#pragma unroll
-            for (int s = 0; s < S; ++s)
-#pragma unroll
-                for (int c = 0; c < 3; ++c) ring[6][3 + 3 * s + c] = src[s][c * HW + off];
-        } else {
-            float cr[3], X[3];
-            cam_ray(ik, (float)st.xr, (float)yr, cr);
-            const float d = dep[off];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) X[i] = d * cr[i];              // layers.py:212
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                const Taps t = project(P[s], X, wm1, hm1, W, H);
-                const float fx1 = t.fx0 + 1.f, fy1 = t.fy0 + 1.f;
-                const float wnw = (fx1 - t.ix) * (fy1 - t.iy), wne = (t.ix - t.fx0) * (fy1 - t.iy);
-                const float wsw = (fx1 - t.ix) * (t.iy - t.fy0), wse = (t.ix - t.fx0) * (t.iy - t.fy0);
-                const int o00 = t.y0 * W + t.x0;
-                const int o01 = o00 + (t.xin ? 1 : 0), o10 = o00 + (t.yin ? W : 0);
-                const int o11 = o10 + (t.xin ? 1 : 0);
-                float wv[3];
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float *sc = src[s] + c * HW;
-                    // out-of-range taps are skipped by grid_sample; their weight is exactly 0 here and
-                    // the clamped address stays in range, so the FMA contributes +0
-                    float acc = sc[o00] * wnw;
-                    acc = fmaf(sc[o01], t.xin ? wne : 0.f, acc);
-                    acc = fmaf(sc[o10], t.yin ? wsw : 0.f, acc);
-                    acc = fmaf(sc[o11], (t.xin && t.yin) ? wse : 0.f, acc);
-                    wv[c] = acc;
-                    ring[6][3 + 3 * s + c] = acc;
-                }
-                if (own_cell) {
-                    const size_t q = (size_t)b * HW + off;
-                    if (a.sample[s]) *reinterpret_cast<float2 *>(a.sample[s] + q * 2) = make_float2(t.gx, t.gy);
-                    if (a.x0y0[s]) *reinterpret_cast<int2 *>(a.x0y0[s] + q * 2) = make_int2(t.x0, t.y0);
-                    if (a.warped[s]) {
-                        float *wd = a.warped[s] + (size_t)b * 3 * HW + off;
-#pragma unroll
-                        for (int c = 0; c < 3; ++c) wd[c * HW] = wv[c];
-                    }
-                }
-            }
-        }
-
-        if (j >= 6) {
-            // output row = cell row j-3 = ring slot 3
-            const int yo = ycell - 3;
-            float St[3], Stt[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                float s1 = ring[0][c], s2 = ring[0][c] * ring[0][c];
-#pragma unroll
-                for (int k = 1; k < 7; ++k) {
-                    const float v = ring[k][c];
-                    s1 += v;
-                    s2 = fmaf(v, v, s2);
-                }
-                St[c] = box7(s1);
-                Stt[c] = box7(s2);
-            }
-            float lossv[S];
-            float gsum[S][9];
-#pragma unroll
-            for (int s = 0; s < S; ++s) {
-                float ssim_sum = 0.f, l1 = 0.f;
-#pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const int cc = 3 + 3 * s + c;
-                    float s1 = ring[0][cc], s2 = ring[0][cc] * ring[0][cc], s3 = ring[0][cc] * ring[0][c];
-#pragma unroll
-                    for (int k = 1; k < 7; ++k) {
-                        const float v = ring[k][cc];
-                        s1 += v;
-                        s2 = fmaf(v, v, s2);
-                        s3 = fmaf(v, ring[k][c], s3);
-                    }
-                    s1 = box7(s1);
-                    s2 = box7(s2);
-                    s3 = box7(s3);
-                    float g3[3];
-                    if (want_grad) {
-                        ssim_sum += ssim_from_sums<true>(s1, St[c], s2, Stt[c], s3, g3);
-                        gsum[s][c] = g3[0];
-                        gsum[s][3 + c] = g3[1];
-                        gsum[s][6 + c] = g3[2];
-                    } else {
-                        ssim_sum += ssim_from_sums<false>(s1, St[c], s2, Stt[c], s3, g3);
-                    }
-                    l1 += fabsf(ring[3][c] - ring[3][cc]);
-                }
-                // 0.85 * ssim.mean(1) + 0.15 * l1.mean(1)      trainer.py:446-451
-                lossv[s] = 0.85f * (ssim_sum * (1.f / 3.f)) + 0.15f * (l1 * (1.f / 3.f));
-            }
-            const bool own_out = st.own_col && yo >= 0 && yo < H && yo < st.y_begin + TH;
-            if (own_out) {
-                const int qo = yo * W + st.cx;
-                if (MODE == 0) {
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        const size_t qi = ((size_t)b * S + s) * HW + qo;
-                        const float nz = noise ? noise[qi] : 0.f;
-                        a.sel[qi] = lossv[s] + nz * 0.00001f;          // trainer.py:514-517 (sel aliases the output)
-                    }
-                } else {
-                    // combined = [identity_0..S-1, reproj_0..S-1]; min over dim 1   trainer.py:519-526
-                    const float *idm = a.identity + (size_t)b * S * HW + qo;
-                    float best = idm[0];
-                    int bi = 0;
-#pragma unroll
-                    for (int s = 1; s < S; ++s) {
-                        const float v = idm[s * HW];
-                        if (v < best) { best = v; bi = s; }
-                    }
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        if (lossv[s] < best) { best = lossv[s]; bi = S + s; }
-                        if (a.reproj) a.reproj[((size_t)b * S + s) * HW + qo] = lossv[s];
-                    }
-                    loss_acc += best;
-                    if (a.sel) a.sel[(size_t)b * HW + qo] = bi > S - 1 ? 1.f : 0.f;      // trainer.py:529-530
-                    if (a.idx) a.idx[(size_t)b * HW + qo] = (uint8_t)bi;
-                    if (want_grad && bi >= S) {
-                        float *co = a.coef + (size_t)b * 9 * HW + qo;
-#pragma unroll
-                        for (int k = 0; k < 9; ++k) {
-                            float v = gsum[0][k];
-#pragma unroll
-                            for (int s = 1; s < S; ++s) v = bi == S + s ? gsum[s][k] : v;
-                            co[k * HW] = v * (0.85f / 3.f);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    if (MODE == 1 && a.loss_part) {
-        loss_acc = wave_sum(loss_acc);
-        if (lane == 0) a.loss_part[task] = loss_acc;
-    }
 }
 
 // ===================================================================================================
@@ -501,20 +236,6 @@ __global__ __launch_bounds__(64) void gP_reduce_kernel(const float *__restrict__
     }
 }
 
-// development switch: SQD_PHOTO_IMPL=scalar selects the first (unpacked) forward kernel for A/B runs
-bool use_scalar_impl() {
-    static const bool v = [] {
-        const char *e = getenv("SQD_PHOTO_IMPL");
-        return e && e[0] == 's';
-    }();
-    return v;
-}
-
-int pick_th(int th, int H) {
-    if (th <= 0) th = 8;   // measured at config B: TH=8 94.8 us, 12 99 us, 16 103 us, 24 132 us (more waves beats less halo)
-    return th;
-}
-
 // backward: one wavefront per (image, source, strip); it runs 3 waves per SIMD, i.e. 3072 resident wavefronts on 256 CUs.
 // The default strip height is the smallest one (>= 8 rows) whose task count fits in a single such round — measured at
 // config B: TH = 8 (6912 tasks) 225 us, 12: 208, 16: 246, 20 (2880 tasks): 181, 24: 201, 32: 248.
@@ -536,28 +257,20 @@ int check_shape(const char *who, int B, int S, int H, int W, int TH) {
 }  // namespace
 
 extern "C" int sqd_photo_ntasks(int B, int H, int W, int rows_per_task) {
-    const int TH = pick_th(rows_per_task, H);
-    const int nsx = (W + SQD_STRIP_COLS - 1) / SQD_STRIP_COLS, nsy = (H + TH - 1) / TH;
-    return B * nsx * nsy;
+    return 4 * sqd::photo_tile_count(B, H, W, rows_per_task);       // one loss partial per wavefront of a tile
 }
 extern "C" int sqd_photo_bwd_ntasks(int B, int S, int H, int W, int rows_per_task) {
-    return S * sqd_photo_ntasks(B, H, W, pick_th_bwd(rows_per_task, B, S, H, W));
+    const int TH = pick_th_bwd(rows_per_task, B, S, H, W);
+    const int nsx = (W + SQD_STRIP_COLS - 1) / SQD_STRIP_COLS, nsy = (H + TH - 1) / TH;
+    return S * B * nsx * nsy;
 }
 
 extern "C" int sqd_photo_fwd(const sqd_photo_args *a) {
     SQD_CHECK_ARG(a && a->depth && a->inv_K && a->P && a->target && a->sources[0] && a->sources[1] && a->identity,
                   "sqd_photo_fwd: null input");
-    SQD_CHECK_ARG(!a->coef || a->idx, "sqd_photo_fwd: coef requires idx");
-    const int TH = pick_th(a->rows_per_task, a->H);
-    if (check_shape("sqd_photo_fwd", a->B, a->S, a->H, a->W, TH)) return SQD_EINVAL;
-    const int nsx = (a->W + SQD_STRIP_COLS - 1) / SQD_STRIP_COLS, nsy = (a->H + TH - 1) / TH;
-    const int ntasks = a->B * nsx * nsy;
+    if (check_shape("sqd_photo_fwd", a->B, a->S, a->H, a->W, 8)) return SQD_EINVAL;
     (void)hipGetLastError();
-    if (use_scalar_impl())
-        hipLaunchKernelGGL((photo_fwd_kernel<2, 1>), dim3((ntasks + 3) / 4), dim3(256), 0, (hipStream_t)a->stream, *a,
-                           nullptr, TH, nsx, nsy, ntasks);
-    else
-        sqd::launch_photo_fwd_pk(*a, nullptr, 1, TH, nsx, nsy, ntasks, (hipStream_t)a->stream);
+    sqd::launch_photo_tile(*a, nullptr, 1, (hipStream_t)a->stream);
     SQD_CHECK_LAUNCH("sqd_photo_fwd");
     return SQD_OK;
 }
@@ -565,8 +278,7 @@ extern "C" int sqd_photo_fwd(const sqd_photo_args *a) {
 extern "C" int sqd_identity_fwd(const float *target, const float *const *sources, const float *noise, float *identity,
                                 int B, int S, int H, int W, int rows_per_task, void *stream) {
     SQD_CHECK_ARG(target && sources && identity, "sqd_identity_fwd: null pointer");
-    const int TH = pick_th(rows_per_task, H);
-    if (check_shape("sqd_identity_fwd", B, S, H, W, TH)) return SQD_EINVAL;
+    if (check_shape("sqd_identity_fwd", B, S, H, W, 8)) return SQD_EINVAL;
     sqd_photo_args a = {};
     a.target = target;
     for (int s = 0; s < S; ++s) {
@@ -574,16 +286,29 @@ extern "C" int sqd_identity_fwd(const float *target, const float *const *sources
         a.sources[s] = sources[s];
     }
     a.sel = identity;   // MODE 0 writes its [B,S,H,W] output through `sel`
-    a.B = B; a.S = S; a.H = H; a.W = W;
-    const int nsx = (W + SQD_STRIP_COLS - 1) / SQD_STRIP_COLS, nsy = (H + TH - 1) / TH;
-    const int ntasks = B * nsx * nsy;
+    a.B = B; a.S = S; a.H = H; a.W = W; a.rows_per_task = rows_per_task;
     (void)hipGetLastError();
-    if (use_scalar_impl())
-        hipLaunchKernelGGL((photo_fwd_kernel<2, 0>), dim3((ntasks + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, noise,
-                           TH, nsx, nsy, ntasks);
-    else
-        sqd::launch_photo_fwd_pk(a, noise, 0, TH, nsx, nsy, ntasks, (hipStream_t)stream);
+    sqd::launch_photo_tile(a, noise, 0, (hipStream_t)stream);
     SQD_CHECK_LAUNCH("sqd_identity_fwd");
+    return SQD_OK;
+}
+
+extern "C" int sqd_photo_coef(const float *target, const float *const *warped, const uint8_t *idx, float *coef, int B, int S,
+                              int H, int W, int rows_per_task, void *stream) {
+    SQD_CHECK_ARG(target && warped && idx && coef, "sqd_photo_coef: null pointer");
+    if (check_shape("sqd_photo_coef", B, S, H, W, 8)) return SQD_EINVAL;
+    sqd_photo_args a = {};
+    a.target = target;
+    for (int s = 0; s < S; ++s) {
+        SQD_CHECK_ARG(warped[s], "sqd_photo_coef: null warped image %d", s);
+        a.warped[s] = const_cast<float *>(warped[s]);
+    }
+    a.idx = const_cast<uint8_t *>(idx);
+    a.coef = coef;
+    a.B = B; a.S = S; a.H = H; a.W = W; a.rows_per_task = rows_per_task;
+    (void)hipGetLastError();
+    sqd::launch_photo_tile(a, nullptr, 2, (hipStream_t)stream);
+    SQD_CHECK_LAUNCH("sqd_photo_coef");
     return SQD_OK;
 }
 

@@ -13,9 +13,9 @@ namespace sqd {
 
 void set_error(const char *fmt, ...);
 
-// photo_fwd_pk.hip: packed-math fused warp+SSIM forward (mode 1) / identity maps (mode 0)
-void launch_photo_fwd_pk(const sqd_photo_args &a, const float *noise, int mode, int TH, int nsx, int nsy, int ntasks,
-                         hipStream_t stream);
+// photo_tile.hip: fused warp+SSIM forward (mode 1) / identity maps (mode 0) / coefficient planes for the backward (mode 2)
+void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hipStream_t stream);
+int photo_tile_count(int B, int H, int W, int rows_per_task);
 
 #define SQD_CHECK_ARG(cond, ...)            \
     do {                                    \

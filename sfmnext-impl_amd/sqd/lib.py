@@ -50,21 +50,54 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
 
 
+OBJ_DIR = os.path.join(CSRC, "_build")
+
+
+def _headers():
+    return glob.glob(os.path.join(CSRC, "*.h")) + [os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "sqd.h")]
+
+
+def _obj(src):
+    return os.path.join(OBJ_DIR, os.path.basename(src)[:-4] + ".o")
+
+
+def _stale(src, newest_header):
+    o = _obj(src)
+    return not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(src), newest_header)
+
+
 def needs_build():
     if not os.path.exists(SO_PATH):
         return True
     t = os.path.getmtime(SO_PATH)
-    deps = sources() + glob.glob(os.path.join(CSRC, "*.h")) + \
-        [os.path.join(os.path.dirname(os.path.dirname(_HERE)), "include", "sqd.h")]
-    return any(os.path.getmtime(f) > t for f in deps)
+    return any(os.path.getmtime(f) > t for f in sources() + _headers())
 
 
 def build(force=False, verbose=False):
-    """hipcc cross-compiles every csrc/*.hip for gfx950 into sqd/libsqd.so (works without a GPU)."""
+    """hipcc cross-compiles every csrc/*.hip for gfx950 (works without a GPU): one object per source file, only the stale
+    ones, in parallel; then one link into sqd/libsqd.so."""
     if not force and not needs_build():
         return SO_PATH
+    from concurrent.futures import ThreadPoolExecutor
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + HIPCC_FLAGS + sources() + ["-o", SO_PATH + ".tmp"]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    newest = max(os.path.getmtime(h) for h in _headers())
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    todo = [s for s in sources() if force or _stale(s, newest)]
+
+    def compile_one(src):
+        cmd = [hipcc] + flags + ["-c", src, "-o", _obj(src) + ".tmp"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+        os.replace(_obj(src) + ".tmp", _obj(src))
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        list(ex.map(compile_one, todo))
+    keep = {_obj(s) for s in sources()}
+    for o in glob.glob(os.path.join(OBJ_DIR, "*.o")):       # objects of deleted sources must not be linked
+        if o not in keep:
+            os.remove(o)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + sorted(keep) + ["-o", SO_PATH + ".tmp"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -87,6 +120,7 @@ _SIGNATURES = {
     "sqd_photo_ntasks": (_I, [_I, _I, _I, _I]),
     "sqd_photo_fwd": (_I, [ctypes.POINTER(PhotoArgs)]),
     "sqd_identity_fwd": (_I, [_P, ctypes.POINTER(c_void_p), _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sqd_photo_coef": (_I, [_P, ctypes.POINTER(c_void_p), _P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_photo_bwd_ntasks": (_I, [_I, _I, _I, _I, _I]),
     "sqd_photo_bwd": (_I, [ctypes.POINTER(PhotoBwdArgs)]),
     "sqd_photo_bwd_reduce": (_I, [_P, _P, _I, _I, _I, _I, _P]),

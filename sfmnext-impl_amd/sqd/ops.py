@@ -102,7 +102,7 @@ def identity_fwd(target, sources, noise=None, rows_per_task=0):
 
 
 # name of the kernel sqd_photo_fwd launches (the "warp+SSIM kernel" of the roofline record in bench.py)
-PHOTO_FWD_KERNEL_NAME = "photo_fwd_pk_kernel<1> (fused warp+SSIM+L1+automask fwd, training mode: also writes the 37 B/px coef+argmin maps)"
+PHOTO_FWD_KERNEL_NAME = "photo_tile_kernel<1> (fused warp + SSIM + L1 + min/auto-mask forward; training and inference launches are identical)"
 
 
 def photo_fwd(depth, inv_K, P, target, sources, identity, training=True, want_taps=False, want_reproj=False,
@@ -120,7 +120,6 @@ def photo_fwd(depth, inv_K, P, target, sources, identity, training=True, want_ta
            "sel": torch.empty(B, H, W, **f32),
            "idx": torch.empty(B, H, W, device=dev, dtype=torch.uint8),
            "loss_part": torch.empty(nt, **f32),
-           "coef": torch.empty(B, 9, H, W, **f32) if training else None,
            "x0y0": [torch.empty(B, H, W, 2, device=dev, dtype=torch.int32) for _ in range(S)] if want_taps else None,
            "reproj": torch.empty(B, S, H, W, **f32) if want_reproj else None}
     a = _l.PhotoArgs()
@@ -132,7 +131,7 @@ def photo_fwd(depth, inv_K, P, target, sources, identity, training=True, want_ta
         if want_taps:
             a.x0y0[s] = out["x0y0"][s].data_ptr()
     a.sel, a.idx, a.loss_part = out["sel"].data_ptr(), out["idx"].data_ptr(), out["loss_part"].data_ptr()
-    a.coef = out["coef"].data_ptr() if training else None
+    a.coef = None
     a.reproj = out["reproj"].data_ptr() if want_reproj else None
     a.B, a.S, a.H, a.W, a.rows_per_task = B, S, H, W, rows_per_task
     a.stream = torch.cuda.current_stream().cuda_stream
@@ -148,13 +147,25 @@ def photo_fwd_relaunch(a):
     _l.check(_l.lib().sqd_photo_fwd(ctypes.byref(a)), "photo_fwd")
 
 
-def photo_bwd(depth, inv_K, P, target, sources, samples, coef, idx, gscale, rows_per_task=0, extra_planes=0):
+def photo_coef(target, warped, idx, rows_per_task=0):
+    """d(to_optimise)/d(window sums) of the winning source from the stored warped images -> coef [B,9,H,W]."""
+    _req(target, idx, *warped)
+    B, _, H, W = target.shape
+    S = len(warped)
+    coef = torch.empty(B, 9, H, W, device=target.device, dtype=torch.float32)
+    arr = (ctypes.c_void_p * S)(*[w.data_ptr() for w in warped])
+    _l.check(_l.lib().sqd_photo_coef(_ptr(target), arr, _ptr(idx), _ptr(coef), B, S, H, W, rows_per_task, _stream()), "photo_coef")
+    return coef
+
+
+def photo_bwd(depth, inv_K, P, target, sources, samples, warped, idx, gscale, rows_per_task=0, extra_planes=0):
     """-> g_depth [B,S+extra_planes,H,W] (plane s = source s; extra planes left unwritten), g_P [B,S,3,4]."""
-    _req(depth, inv_K, P, target, coef, idx, *sources, *samples)
+    _req(depth, inv_K, P, target, idx, *sources, *samples, *warped)
     B, _, H, W = target.shape
     S = len(sources)
     dev = target.device
     L = _l.lib()
+    coef = photo_coef(target, warped, idx, rows_per_task)
     nt = L.sqd_photo_bwd_ntasks(B, S, H, W, rows_per_task)
     g_depth = torch.empty(B, S + extra_planes, H, W, device=dev, dtype=torch.float32)
     part = torch.empty(nt, 12, device=dev, dtype=torch.float32)
@@ -275,7 +286,7 @@ class PhotometricChain(torch.autograd.Function):
         total = photo + meta["smooth_weight"] * smooth
         ctx.meta, ctx.S = meta, S
         ctx.save_for_backward(disp_lr, axisangle, translation, K, inv_K, target, depth, part, mid, P, out["idx"],
-                              out["coef"] if training else depth, sm_part, *sources, *out["sample"])
+                              sm_part, *sources, *out["sample"], *out["warped"])
         outs = (total, photo, smooth, depth, out["sel"], T, *out["sample"], *out["warped"])
         ctx.mark_non_differentiable(*outs[1:])
         return outs
@@ -286,13 +297,13 @@ class PhotometricChain(torch.autograd.Function):
             return (None,) * (8 + ctx.S)
         meta, S = ctx.meta, ctx.S
         saved = ctx.saved_tensors
-        disp_lr, axisangle, translation, K, inv_K, target, depth, part, mid, P, idx, coef, sm_part = saved[:13]
-        sources, samples = list(saved[13:13 + S]), list(saved[13 + S:13 + 2 * S])
+        disp_lr, axisangle, translation, K, inv_K, target, depth, part, mid, P, idx, sm_part = saved[:12]
+        sources, samples, warped = list(saved[12:12 + S]), list(saved[12 + S:12 + 2 * S]), list(saved[12 + 2 * S:12 + 3 * S])
         B, _, H, W = target.shape
         h, w = disp_lr.shape[2:]
         rows = meta.get("rows_per_task", 0)
         # all adjoints are linear in the upstream gradient: run them with 1.0 and scale the three small results
-        planes, g_P = photo_bwd(depth, inv_K, P, target, sources, samples, coef, idx, 1.0 / float(B * H * W), rows,
+        planes, g_P = photo_bwd(depth, inv_K, P, target, sources, samples, warped, idx, 1.0 / float(B * H * W), rows,
                                 extra_planes=1)
         smooth_bwd(depth, target, part, sm_part, meta["smooth_weight"], planes, S)
         g_aa, g_tr, g_mid = pose_mats_bwd(axisangle, translation, meta["invert"], K, mid, g_P)

@@ -16,7 +16,7 @@ ap.add_argument("--iters", type=int, default=200)
 ap.add_argument("--B", type=int, default=12)
 ap.add_argument("--H", type=int, default=192)
 ap.add_argument("--W", type=int, default=640)
-ap.add_argument("--which", default="fwd,fwd_infer,ident,bwd")
+ap.add_argument("--which", default="fwd,ident,coef,bwd")
 args = ap.parse_args()
 B, H, W = args.B, args.H, args.W
 dev = torch.device("cuda")
@@ -49,15 +49,16 @@ px = B * H * W
 for rows in [int(r) for r in args.rows.split(",")]:
     ident = ops.identity_fwd(tgt, srcs, noise, rows)
     res = {}
-    if "fwd" in args.which.split(","):
-        call, keep = ops.photo_fwd(depth, inv_K, P, tgt, srcs, ident, training=True, rows_per_task=rows, prepared_only=True)
-        res["fwd_train"] = timeit(lambda: ops.photo_fwd_relaunch(call), args.iters)
-    if "fwd_infer" in args.which.split(","):
-        call2, keep2 = ops.photo_fwd(depth, inv_K, P, tgt, srcs, ident, training=False, rows_per_task=rows, prepared_only=True)
-        res["fwd_infer"] = timeit(lambda: ops.photo_fwd_relaunch(call2), args.iters)
-    if "ident" in args.which.split(","):
+    which = args.which.split(",")
+    if "fwd" in which:
+        call, keep = ops.photo_fwd(depth, inv_K, P, tgt, srcs, ident, rows_per_task=rows, prepared_only=True)
+        res["fwd"] = timeit(lambda: ops.photo_fwd_relaunch(call), args.iters)
+    if "ident" in which:
         res["identity"] = timeit(lambda: ops.identity_fwd(tgt, srcs, noise, rows), 50)
-    if "bwd" in args.which.split(","):
-        out = ops.photo_fwd(depth, inv_K, P, tgt, srcs, ident, training=True, rows_per_task=rows)
-        res["bwd(+reduce,alloc)"] = timeit(lambda: ops.photo_bwd(depth, inv_K, P, tgt, srcs, out["sample"], out["coef"], out["idx"], 1.0 / px, rows), 50)
+    if "coef" in which or "bwd" in which:
+        out = ops.photo_fwd(depth, inv_K, P, tgt, srcs, ident, rows_per_task=rows)
+    if "coef" in which:
+        res["coef"] = timeit(lambda: ops.photo_coef(tgt, out["warped"], out["idx"], rows), 50)
+    if "bwd" in which:
+        res["coef+bwd(+reduce,alloc)"] = timeit(lambda: ops.photo_bwd(depth, inv_K, P, tgt, srcs, out["sample"], out["warped"], out["idx"], 1.0 / px, rows), 50)
     print("rows_per_task=%d  " % rows + "  ".join("%s %.1f us (%.0f GB/s @93B/px)" % (k, v, 93 * px / v / 1e3) for k, v in res.items()), flush=True)

@@ -27,7 +27,7 @@ GIB = float(1 << 30)
 cal = {"read_dword": GIB / avg("calib_read_dword", "FETCH_SIZE"), "read_f4": GIB / avg("calib_read_f4", "FETCH_SIZE"),
        "write_dword": GIB / avg("calib_write_dword", "WRITE_SIZE"), "write_f4": GIB / avg("calib_write_f4", "WRITE_SIZE")}
 res = {"calibration_factor": {k: round(v, 4) for k, v in cal.items()}, "kernels": {}}
-for name in ("photo_fwd_pk_kernel<1>", "photo_fwd_pk_kernel<0>", "photo_bwd_kernel"):
+for name in ("photo_tile_kernel<1>", "photo_tile_kernel<0>", "photo_tile_kernel<2>", "photo_bwd_kernel"):
     try:
         fr, wr = avg(name, "FETCH_SIZE"), avg(name, "WRITE_SIZE")
     except SystemExit:
