@@ -38,6 +38,10 @@ constexpr int LDS_BYTES = NROW_MAX * 3 * 64 * 8;
 __device__ __forceinline__ float ldg(const float *__restrict__ base, unsigned byte_off) {
     return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + byte_off);
 }
+typedef float v2f_ua __attribute__((ext_vector_type(2), aligned(4)));
+__device__ __forceinline__ float __attribute__((ext_vector_type(2))) ldg2(const float *__restrict__ base, unsigned byte_off) {
+    return *reinterpret_cast<const v2f_ua *>(reinterpret_cast<const char *>(base) + byte_off);      // 8 bytes, 4-byte aligned
+}
 __device__ __forceinline__ void stg(float *__restrict__ base, unsigned byte_off, float v) {
     *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
@@ -100,8 +104,10 @@ template <int N>
 __device__ __forceinline__ float row_shl(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x100 + N, 0xf, 0xf, true));
 }
-__device__ __forceinline__ float quad_reverse(float v) {      // quad_perm [3,2,1,0]
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x1B, 0xf, 0xf, true));
+// quad_perm [3,2,1,0] inside ONE quad — row ROW (16 lanes), bank BANK (4 lanes) — zero everywhere else
+template <int ROW, int BANK>
+__device__ __forceinline__ float quad_reverse(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x1B, 1 << ROW, 1 << BANK, true));
 }
 
 // centred 7-tap sums of three quantities across lanes (interleaved chains: no DPP hazard nops).
@@ -113,14 +119,14 @@ __device__ __forceinline__ void box7x3(float &a, float &b, float &c, bool edge) 
     float ea = 0.f, eb = 0.f, ec = 0.f;
     if (KIND == LEFT) {
         const float ma = edge ? a : 0.f, mb = edge ? b : 0.f, mc = edge ? c : 0.f;      // edge: lanes 1..3
-        ea = quad_reverse((ma + row_shr<1>(ma)) + row_shr<2>(ma));
-        eb = quad_reverse((mb + row_shr<1>(mb)) + row_shr<2>(mb));
-        ec = quad_reverse((mc + row_shr<1>(mc)) + row_shr<2>(mc));
+        ea = quad_reverse<0, 0>((ma + row_shr<1>(ma)) + row_shr<2>(ma));      // (the prefix sums spill into lanes 4, 5: only
+        eb = quad_reverse<0, 0>((mb + row_shr<1>(mb)) + row_shr<2>(mb));      //  the first quad is mirrored)
+        ec = quad_reverse<0, 0>((mc + row_shr<1>(mc)) + row_shr<2>(mc));
     } else if (KIND == RIGHT) {
         const float ma = edge ? a : 0.f, mb = edge ? b : 0.f, mc = edge ? c : 0.f;      // edge: lanes 60..62
-        ea = quad_reverse((ma + row_shl<1>(ma)) + row_shl<2>(ma));
-        eb = quad_reverse((mb + row_shl<1>(mb)) + row_shl<2>(mb));
-        ec = quad_reverse((mc + row_shl<1>(mc)) + row_shl<2>(mc));
+        ea = quad_reverse<3, 3>((ma + row_shl<1>(ma)) + row_shl<2>(ma));
+        eb = quad_reverse<3, 3>((mb + row_shl<1>(mb)) + row_shl<2>(mb));
+        ec = quad_reverse<3, 3>((mc + row_shl<1>(mc)) + row_shl<2>(mc));
     }
     float ra = a + wave_shr1(a), rb = b + wave_shr1(b), rc = c + wave_shr1(c);
     ra = a + wave_shr1(ra); rb = b + wave_shr1(rb); rc = c + wave_shr1(rc);
@@ -312,12 +318,11 @@ __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const float *
                 accumulate(core, P);
             }
         }
-        // (a rolled loop: one SSIM body in the instruction stream, and the register allocator sees one output at a time)
 #pragma nounroll
         for (int o = 0; o < 2; ++o) {
             Raw R, ctr;
-            load_row<MODE>(k, j + 7 * o, R);         // the row only this output has: j, resp. j+7
-            load_row<MODE>(k, j + 3 + o, ctr);       // centre row (L1 term)
+            load_row<MODE>(k, j + 7 * o, R);
+            load_row<MODE>(k, j + 3 + o, ctr);
             Sums S;
             products(R, S);
             accumulate(S, core);
@@ -326,8 +331,118 @@ __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const float *
     }
 }
 
+// ---- phase 1 pieces ---------------------------------------------------------------------------------------------
+struct Cell {
+    v2f gx, gy;                      // normalised sampling grid (outputs[("sample", f, 0)]) of (source 0, source 1)
+    v2f wnw, wne, wsw, wse;          // bilinear weights; out-of-range taps carry weight exactly 0
+    unsigned a00, a10;               // offsets of the north and south tap PAIRS in source 0 (clamped into the image)
+    unsigned b00, b10;               // ... in source 1
+    int x00, y00, x01, y01;          // integer north-west taps
+};
+
+// back-projection, projection into both source views and the grid_sample tap arithmetic for one cell — the canonical fp32
+// order of oracle/warp_chain.c (layers.py:211-212,250-257; ATen grid_sampler_2d with border padding, align_corners=True)
+__device__ __forceinline__ void project_cell(Cell &c, float d, float fx, float fy, const float *ik, const v2f *P, v2f rW, v2f rH,
+                                             float wm1, float hm1, int W, int H) {
+    float X[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        float acc = ik[i * 3 + 0] * fx;
+        acc = fmaf(ik[i * 3 + 1], fy, acc);
+        acc = fmaf(ik[i * 3 + 2], 1.0f, acc);
+        X[i] = d * acc;
+    }
+    v2f cam[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v2f acc = P[i * 4 + 0] * splat(X[0]);
+        acc = pfma(P[i * 4 + 1], splat(X[1]), acc);
+        acc = pfma(P[i * 4 + 2], splat(X[2]), acc);
+        acc = pfma(P[i * 4 + 3], splat(1.0f), acc);
+        cam[i] = acc;
+    }
+    const v2f z = cam[2] + splat(1e-7f);
+    const v2f rz = rcp_refined2(z);
+    const v2f u = div_core2(cam[0], z, rz), v = div_core2(cam[1], z, rz);
+    const v2f un = div_core2(u, splat(wm1), rW), vn = div_core2(v, splat(hm1), rH);
+    c.gx = (un - splat(0.5f)) * splat(2.0f);
+    c.gy = (vn - splat(0.5f)) * splat(2.0f);
+    v2f ix = ((c.gx + splat(1.0f)) * splat(0.5f)) * splat(wm1);
+    v2f iy = ((c.gy + splat(1.0f)) * splat(0.5f)) * splat(hm1);
+    ix = v2f{fminf(wm1, fmaxf(ix.x, 0.f)), fminf(wm1, fmaxf(ix.y, 0.f))};
+    iy = v2f{fminf(hm1, fmaxf(iy.x, 0.f)), fminf(hm1, fmaxf(iy.y, 0.f))};
+    const v2f fx0 = v2f{floorf(ix.x), floorf(ix.y)}, fy0 = v2f{floorf(iy.x), floorf(iy.y)};
+    const v2f ax = ix - fx0, ay = iy - fy0;
+    const v2f bx = (fx0 + splat(1.f)) - ix, by = (fy0 + splat(1.f)) - iy;
+    c.x00 = (int)fx0.x; c.y00 = (int)fy0.x; c.x01 = (int)fx0.y; c.y01 = (int)fy0.y;
+    const bool xin0 = c.x00 + 1 < W, yin0 = c.y00 + 1 < H, xin1 = c.x01 + 1 < W, yin1 = c.y01 + 1 < H;
+    c.wnw = bx * by;
+    const v2f wne = ax * by, wsw = bx * ay, wse = ax * ay;
+    // out-of-range taps are skipped by grid_sample: weight exactly 0 and a clamped (in-range) address
+    c.wne = v2f{xin0 ? wne.x : 0.f, xin1 ? wne.y : 0.f};
+    c.wsw = v2f{yin0 ? wsw.x : 0.f, yin1 ? wsw.y : 0.f};
+    c.wse = v2f{(xin0 && yin0) ? wse.x : 0.f, (xin1 && yin1) ? wse.y : 0.f};
+    c.a00 = (unsigned)(c.y00 * W + c.x00);
+    c.b00 = (unsigned)(c.y01 * W + c.x01);
+    // The two taps of a row are 8 contiguous bytes: one load.  Where x0 is the last column (x0 + 1 out of range, its weight
+    // exactly 0) the pair starts one pixel earlier and the weight of x0 moves to the pair's second slot.
+    c.a00 -= xin0 ? 0u : 1u;
+    c.b00 -= xin1 ? 0u : 1u;
+    c.a10 = c.a00 + (yin0 ? (unsigned)W : 0u);
+    c.b10 = c.b00 + (yin1 ? (unsigned)W : 0u);
+    c.wne = v2f{xin0 ? c.wne.x : c.wnw.x, xin1 ? c.wne.y : c.wnw.y};
+    c.wnw = v2f{xin0 ? c.wnw.x : 0.f, xin1 ? c.wnw.y : 0.f};
+    c.wse = v2f{xin0 ? c.wse.x : c.wsw.x, xin1 ? c.wse.y : c.wsw.y};
+    c.wsw = v2f{xin0 ? c.wsw.x : 0.f, xin1 ? c.wsw.y : 0.f};
+}
+
+__device__ __forceinline__ void gather_taps(const Cell &c, const float *__restrict__ src0, const float *__restrict__ src1, unsigned HW,
+                                            v2f t[3][4]) {
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const unsigned co = ch * HW;
+        const v2f n0 = ldg2(src0, (c.a00 + co) * 4u), n1 = ldg2(src1, (c.b00 + co) * 4u);
+        const v2f s0 = ldg2(src0, (c.a10 + co) * 4u), s1 = ldg2(src1, (c.b10 + co) * 4u);
+        t[ch][0] = v2f{n0.x, n1.x};
+        t[ch][1] = v2f{n0.y, n1.y};
+        t[ch][2] = v2f{s0.x, s1.x};
+        t[ch][3] = v2f{s0.y, s1.y};
+    }
+}
+
+// bilinear blend, the tile's LDS row, and — for cells the tile owns — sample / warped / taps in HBM
+__device__ __forceinline__ void finish_cell(const sqd_photo_args &a, const Cell &c, const v2f t[3][4], v2f *wl, int r, int lane,
+                                            bool col_ok, bool own, int b, unsigned HW, unsigned off) {
+    v2f wv[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        v2f acc = t[ch][0] * c.wnw;
+        acc = pfma(t[ch][1], c.wne, acc);
+        acc = pfma(t[ch][2], c.wsw, acc);
+        acc = pfma(t[ch][3], c.wse, acc);
+        wv[ch] = acc;
+        wl[(r * 3 + ch) * 64 + lane] = col_ok ? acc : splat(0.f);      // (lanes beyond a narrow image: zeros for the shuffles)
+    }
+    if (own) {
+        const size_t q = (size_t)b * HW + off;
+        if (a.sample[0]) *reinterpret_cast<float2 *>(a.sample[0] + q * 2) = make_float2(c.gx.x, c.gy.x);
+        if (a.sample[1]) *reinterpret_cast<float2 *>(a.sample[1] + q * 2) = make_float2(c.gx.y, c.gy.y);
+        if (a.x0y0[0]) *reinterpret_cast<int2 *>(a.x0y0[0] + q * 2) = make_int2(c.x00, c.y00);
+        if (a.x0y0[1]) *reinterpret_cast<int2 *>(a.x0y0[1] + q * 2) = make_int2(c.x01, c.y01);
+        if (a.warped[0]) {
+            float *w0 = a.warped[0] + (size_t)b * 3 * HW, *w1 = a.warped[1] + (size_t)b * 3 * HW;
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) {
+                stg(w0, (off + ch * HW) * 4u, wv[ch].x);
+                stg(w1, (off + ch * HW) * 4u, wv[ch].y);
+            }
+        }
+    }
+}
+
+// (4 workgroups of 4 waves per CU: the register allocator is held to 128 VGPRs; the kernel needs 118)
 template <int MODE>
-__global__ __launch_bounds__(256) void photo_tile_kernel(sqd_photo_args a, const float *__restrict__ noise, int TR, int nsx,
+__global__ __launch_bounds__(256, 4) void photo_tile_kernel(sqd_photo_args a, const float *__restrict__ noise, int TR, int nsx,
                                                           int nsy, int ntiles, int nblk8) {
     extern __shared__ v2f wl[];                       // MODE 1: [TR + 6][3][64] (source 0, source 1) warped colours
     const int lane = threadIdx.x & 63;
@@ -362,87 +477,19 @@ __global__ __launch_bounds__(256) void photo_tile_kernel(sqd_photo_args a, const
 #pragma unroll
         for (int j = 0; j < 12; ++j) P[j] = v2f{a.P[((size_t)b * 2 + 0) * 12 + j], a.P[((size_t)b * 2 + 1) * 12 + j]};
         const v2f rW = splat(rcp_refined(wm1)), rH = splat(rcp_refined(hm1));
-        const float fx = (float)xr;
+        const int xc = min(max(xr, 0), W - 1);             // (lanes beyond a narrow image compute a valid column and store zeros)
+        const float fx = (float)xc;
         const int nrow = own_rows + 6;
         for (int r = wave; r < nrow; r += 4) {
-            const int y = y0 - 3 + r;
-            if (y < 0 || y >= H) continue;                     // (rows outside the image are reflections of rows inside the tile)
-            if (!col_ok) {                                     // lanes beyond the image (W < 64): zeros for the shuffles
-#pragma unroll
-                for (int c = 0; c < 3; ++c) wl[(r * 3 + c) * 64 + lane] = splat(0.f);
-                continue;
-            }
-            const unsigned off = (unsigned)(y * W + xr);
-            // ---- camera ray and point (shared by both sources) — layers.py:211-212
-            const float fy = (float)y;
-            float X[3];
-            const float d = ldg(dep, off * 4u);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                float acc = ik[i * 3 + 0] * fx;
-                acc = fmaf(ik[i * 3 + 1], fy, acc);
-                acc = fmaf(ik[i * 3 + 2], 1.0f, acc);
-                X[i] = d * acc;
-            }
-            // ---- projection of both sources at once — layers.py:250-257 (FMA chain k = 0..3)
-            v2f cam[3];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                v2f acc = P[i * 4 + 0] * splat(X[0]);
-                acc = pfma(P[i * 4 + 1], splat(X[1]), acc);
-                acc = pfma(P[i * 4 + 2], splat(X[2]), acc);
-                acc = pfma(P[i * 4 + 3], splat(1.0f), acc);
-                cam[i] = acc;
-            }
-            const v2f z = cam[2] + splat(1e-7f);
-            const v2f rz = rcp_refined2(z);
-            const v2f u = div_core2(cam[0], z, rz), v = div_core2(cam[1], z, rz);
-            const v2f un = div_core2(u, splat(wm1), rW), vn = div_core2(v, splat(hm1), rH);
-            const v2f gx = (un - splat(0.5f)) * splat(2.0f), gy = (vn - splat(0.5f)) * splat(2.0f);
-            // ---- grid_sample(border, align_corners=True): unnormalise, clip, floor, weights (ATen grid_sampler_2d)
-            v2f ix = ((gx + splat(1.0f)) * splat(0.5f)) * splat(wm1);
-            v2f iy = ((gy + splat(1.0f)) * splat(0.5f)) * splat(hm1);
-            ix = v2f{fminf(wm1, fmaxf(ix.x, 0.f)), fminf(wm1, fmaxf(ix.y, 0.f))};
-            iy = v2f{fminf(hm1, fmaxf(iy.x, 0.f)), fminf(hm1, fmaxf(iy.y, 0.f))};
-            const v2f fx0 = v2f{floorf(ix.x), floorf(ix.y)}, fy0 = v2f{floorf(iy.x), floorf(iy.y)};
-            const v2f ax = ix - fx0, ay = iy - fy0;
-            const v2f bx = (fx0 + splat(1.f)) - ix, by = (fy0 + splat(1.f)) - iy;
-            const int x00 = (int)fx0.x, y00 = (int)fy0.x, x01 = (int)fx0.y, y01 = (int)fy0.y;
-            const bool xin0 = x00 + 1 < W, yin0 = y00 + 1 < H, xin1 = x01 + 1 < W, yin1 = y01 + 1 < H;
-            v2f wnw = bx * by, wne = ax * by, wsw = bx * ay, wse = ax * ay;
-            // out-of-range taps are skipped by grid_sample: weight exactly 0 and a clamped (in-range) address
-            wne = v2f{xin0 ? wne.x : 0.f, xin1 ? wne.y : 0.f};
-            wsw = v2f{yin0 ? wsw.x : 0.f, yin1 ? wsw.y : 0.f};
-            wse = v2f{(xin0 && yin0) ? wse.x : 0.f, (xin1 && yin1) ? wse.y : 0.f};
-            const unsigned a00 = (unsigned)(y00 * W + x00), b00 = (unsigned)(y01 * W + x01);
-            const unsigned a01 = a00 + (xin0 ? 1u : 0u), a10 = a00 + (yin0 ? (unsigned)W : 0u), a11 = a10 + (xin0 ? 1u : 0u);
-            const unsigned b01 = b00 + (xin1 ? 1u : 0u), b10 = b00 + (yin1 ? (unsigned)W : 0u), b11 = b10 + (xin1 ? 1u : 0u);
-            v2f wv[3];
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const unsigned co = c * HW;
-                v2f acc = v2f{ldg(src0, (a00 + co) * 4u), ldg(src1, (b00 + co) * 4u)} * wnw;
-                acc = pfma(v2f{ldg(src0, (a01 + co) * 4u), ldg(src1, (b01 + co) * 4u)}, wne, acc);
-                acc = pfma(v2f{ldg(src0, (a10 + co) * 4u), ldg(src1, (b10 + co) * 4u)}, wsw, acc);
-                acc = pfma(v2f{ldg(src0, (a11 + co) * 4u), ldg(src1, (b11 + co) * 4u)}, wse, acc);
-                wv[c] = acc;
-                wl[(r * 3 + c) * 64 + lane] = acc;
-            }
-            if (own_col && r >= 3 && r < own_rows + 3) {
-                const size_t q = (size_t)b * HW + off;
-                if (a.sample[0]) *reinterpret_cast<float2 *>(a.sample[0] + q * 2) = make_float2(gx.x, gy.x);
-                if (a.sample[1]) *reinterpret_cast<float2 *>(a.sample[1] + q * 2) = make_float2(gx.y, gy.y);
-                if (a.x0y0[0]) *reinterpret_cast<int2 *>(a.x0y0[0] + q * 2) = make_int2(x00, y00);
-                if (a.x0y0[1]) *reinterpret_cast<int2 *>(a.x0y0[1] + q * 2) = make_int2(x01, y01);
-                if (a.warped[0]) {
-                    float *w0 = a.warped[0] + (size_t)b * 3 * HW, *w1 = a.warped[1] + (size_t)b * 3 * HW;
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        stg(w0, (off + c * HW) * 4u, wv[c].x);
-                        stg(w1, (off + c * HW) * 4u, wv[c].y);
-                    }
-                }
-            }
+            Cell cA;
+            const int yA = y0 - 3 + r;
+            if (yA < 0 || yA >= H) continue;                 // (rows outside the image are reflections of rows inside the tile)
+            const unsigned offA = (unsigned)(yA * W + xc);
+            const float dA = ldg(dep, offA * 4u);
+            project_cell(cA, dA, fx, (float)yA, ik, P, rW, rH, wm1, hm1, W, H);
+            v2f tA[3][4];
+            gather_taps(cA, src0, src1, HW, tA);
+            finish_cell(a, cA, tA, wl, r, lane, col_ok, own_col && r >= 3 && r < own_rows + 3, b, HW, offA);
         }
         __syncthreads();
     }

@@ -12,6 +12,7 @@
 namespace {
 using namespace sqd;
 
+typedef float f2ua __attribute__((ext_vector_type(2), aligned(4)));      // 8-byte load at 4-byte alignment
 constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
 constexpr float INV49 = 1.0f / 49.0f;
 constexpr int OWN0 = 3, OWN1 = 61;   // owned lanes [3, 61): 58 output columns per wavefront
@@ -166,14 +167,17 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(sqd_photo_bwd_args a, in
             const int x0 = (int)fx0, y0 = (int)fy0;
             const bool xin = x0 + 1 < W, yin = y0 + 1 < H;
             const float ax = ix - fx0, ay = iy - fy0, bxw = (fx0 + 1.f) - ix, byw = (fy0 + 1.f) - iy;
-            const int o00 = y0 * W + x0, o01 = o00 + (xin ? 1 : 0), o10 = o00 + (yin ? W : 0), o11 = o10 + (xin ? 1 : 0);
+            // the two taps of a row are 8 contiguous bytes: one (4-byte aligned) load; at the last column the pair starts one
+            // pixel earlier and the tap is its second element
+            const int o00 = y0 * W + x0 - (xin ? 0 : 1), o10 = o00 + (yin ? W : 0);
             const bool l1on = idx[qo] == (uint8_t)(S + s);
             float gix = 0.f, giy = 0.f;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const float *sc = src + c * HW;
-                const float vnw = sc[o00], vne = xin ? sc[o01] : 0.f, vsw = yin ? sc[o10] : 0.f,
-                            vse = (xin && yin) ? sc[o11] : 0.f;
+                const f2ua pn = *reinterpret_cast<const f2ua *>(sc + o00), ps = *reinterpret_cast<const f2ua *>(sc + o10);
+                const float vnw = xin ? pn.x : pn.y, vne = xin ? pn.y : 0.f, vsw = yin ? (xin ? ps.x : ps.y) : 0.f,
+                            vse = (xin && yin) ? ps.y : 0.f;
                 float wv = vnw * (bxw * byw);
                 wv = fmaf(vne, ax * byw, wv);
                 wv = fmaf(vsw, bxw * ay, wv);

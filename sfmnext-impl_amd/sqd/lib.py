@@ -82,7 +82,7 @@ def build(force=False, verbose=False):
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(OBJ_DIR, exist_ok=True)
     newest = max(os.path.getmtime(h) for h in _headers())
-    flags = [f for f in HIPCC_FLAGS if f != "-shared"]
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + os.environ.get("SQD_HIPCC_EXTRA", "").split()      # (dev knob)
     todo = [s for s in sources() if force or _stale(s, newest)]
 
     def compile_one(src):
