@@ -24,7 +24,7 @@ def rel_close(a, b, tol):
     assert np.abs(a - b).max() <= tol * np.abs(b).max() + 1e-12, (np.abs(a - b).max(), np.abs(b).max())
 
 
-def adam_close(a, b, lr=1e-4, steps=3, atol=2e-5, frac=2e-3):
+def adam_close(a, b, lr=1e-4, steps=3, atol=2e-5, frac=2e-3):  # frac: see the res50 call
     """Weights after `steps` Adam updates: Adam's update is lr * m/(sqrt(v)+eps) ~ lr * sign(g) in the first steps, so an
     element whose gradient is within rounding noise of zero may move the other way (|diff| up to 2*lr per step).  All elements
     within 2*lr*steps, and all but `frac` of them within atol (measured: 4 of 9408 stem weights beyond 2e-5, max 6.2e-5)."""
@@ -161,6 +161,8 @@ def test_g15_g16_trainer_steps(golden, kind):
             assert tr.models["encoder"].encoder.encoder.fc.weight.grad is None
         traj.append(float(losses["loss"]))
     np.testing.assert_allclose(traj, g16["losses"], rtol=1e-4)
-    adam_close(tr.models["encoder"].encoder.encoder.conv1.weight, g16["enc_conv1_after"])
+    # (ResNet-50: 53 layers of BatchNorm'd convolutions between the stem and the loss — 1.1 % of the 9408 stem weights have a
+    #  gradient within fp32 summation noise of zero and take Adam's +-lr step the other way; ResNet-18: 0.04 %)
+    adam_close(tr.models["encoder"].encoder.encoder.conv1.weight, g16["enc_conv1_after"], frac=2e-3 if kind == "res18" else 2.5e-2)
     adam_close(tr.models["pose"].pose_conv.weight, g16["pose_conv_after"])
     adam_close(tr.models["depth"].conv3x3.weight, g16["depth_conv3x3_after"])

@@ -26,7 +26,10 @@ def avg(sub, counter):
 GIB = float(1 << 30)
 cal = {"read_dword": GIB / avg("calib_read_dword", "FETCH_SIZE"), "read_f4": GIB / avg("calib_read_f4", "FETCH_SIZE"),
        "write_dword": GIB / avg("calib_write_dword", "WRITE_SIZE"), "write_f4": GIB / avg("calib_write_f4", "WRITE_SIZE")}
-res = {"calibration_factor": {k: round(v, 4) for k, v in cal.items()}, "kernels": {}}
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_source_hash: the record is valid for this revision of the kernel sources only)
+res = {"kernel_source_hash": bench.kernel_source_hash(), "judged_kernel": "photo_tile_kernel<1>",
+       "calibration_factor": {k: round(v, 4) for k, v in cal.items()}, "kernels": {}}
 for name in ("photo_tile_kernel<1>", "photo_tile_kernel<0>", "photo_tile_kernel<2>", "photo_bwd_kernel"):
     try:
         fr, wr = avg(name, "FETCH_SIZE"), avg(name, "WRITE_SIZE")
@@ -34,6 +37,7 @@ for name in ("photo_tile_kernel<1>", "photo_tile_kernel<0>", "photo_tile_kernel<
         continue
     res["kernels"][name] = {"fetch_reported_bytes": round(fr), "write_reported_bytes": round(wr),
                             "fetch_corrected_bytes": round(fr * cal["read_dword"]), "write_corrected_bytes": round(wr * cal["write_dword"]),
-                            "traffic_bytes": round(fr * cal["read_dword"] + wr * cal["write_dword"])}
+                            "traffic_bytes": round(fr * cal["read_dword"] + wr * cal["write_dword"]),
+                            "note": "dword-width calibration for both directions (the kernels' gathers are 8-byte, their row loads and stores 4-byte)"}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -7,7 +7,7 @@ import sys
 db, out, title = sys.argv[1:4]
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
-pf = [i for i, r in enumerate(rows) if "photo_fwd_kernel<2, 1>" in r[0] or "photo_fwd_pk_kernel<1>" in r[0]]
+pf = [i for i, r in enumerate(rows) if "photo_tile_kernel<1>" in r[0]]
 nsteps_total = next((k for k in range(1, len(pf)) if pf[k] - pf[k - 1] < 5), len(pf))   # train steps precede the roofline loop
 lo, hi = min(3, nsteps_total - 2), nsteps_total - 1
 s0, s1 = rows[pf[lo]][1], rows[pf[hi]][1]
