@@ -260,6 +260,9 @@ int sqd_conv_fwd_stats_rows(int N, int H, int W, int C, int K, int R, int S, int
 int sqd_conv_fwd(const float *x, const float *w, const float *bias, float *y, float *ws, float *stats, int N, int H, int W,
                  int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int act, void *stream);
 /* addend [N,H,W,C] or NULL: dx = dgrad + addend (the gradient arriving over a second path, e.g. the residual branch) */
+/* gradient through the activation the forward applied in its epilogue, from the OUTPUT y: out = g * act'(y) (out may alias
+ * g); act 1 ReLU, 2 LeakyReLU(0.01).  replaces the relu / leaky_relu backward nodes of autograd for these layers.           */
+int sqd_act_bwd(const float *g, const float *y, float *out, int64_t n, int act, void *stream);
 int sqd_conv_dgrad(const float *dy, const float *w, const float *addend, float *dx, float *ws, int N, int H, int W, int C,
                    int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream);
 /* workspace of the weight gradient: `part_floats` floats (+ max(ceil(N*Ho*Wo/1024), splits) * K more when dbias is wanted) */
@@ -355,6 +358,17 @@ int sqd_mha_fwd(const float *x, const float *Win, const float *bin, const float 
 int sqd_mha_bwd(const float *x, const float *g_sa, const float *Win, const float *bin, const float *Wo, const unsigned char *mask,
                 const float *o_save, const float *ml_save, float *gxpart, float *pWin, float *pbin, float *pWo, float *pbo, int S,
                 int B, int E, int H, float dscale, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * PoseCNN tail
+ * replaces: out = self.pose_conv(out); out = out.mean(3).mean(2); out = 0.01 * out.view(...)   reference networks/pose_cnn.py:40-45
+ * x [B,h,w,C] channels-last, W [J,C] (the 1x1 filter), bias [J], J <= 16 -> out [B,J] = scale * (W . mean_hw(x) + bias); mean [B,C]
+ * is kept for the backward.  backward: g [B,J] -> dx [B,h,w,C], per-image partials dWpart [B,J,C], dbpart [B,J] (summed over B by
+ * sqd_colsum_multi).                                                                                                          */
+int sqd_pose_head_fwd(const float *x, const float *W, const float *bias, float *out, float *mean, int B, int h, int w, int C, int J,
+                      float scale, void *stream);
+int sqd_pose_head_bwd(const float *g, const float *W, const float *mean, float *dx, float *dWpart, float *dbpart, int B, int P, int C,
+                      int J, float scale, void *stream);
 
 #ifdef __cplusplus
 }

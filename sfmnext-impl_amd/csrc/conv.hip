@@ -413,6 +413,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
                 float v = acc[i][j][e] + bv;
                 if (MODE == 1) v += addv[e];
                 if (MODE == 0 && act == 1 && zsplits == 1) v = v > 0.f ? v : 0.f;
+                if (MODE == 0 && act == 2 && zsplits == 1) v = v > 0.f ? v : 0.01f * v;      // LeakyReLU(0.01), nn.LeakyReLU's default slope
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), dst_r, off[e], 0, 0);
                 if (MODE == 0) {
                     const float vs = off[e] != 0xffffffffu ? v : 0.f;
@@ -804,9 +805,26 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restric
         }
         if (act == 1) {
             a.x = a.x > 0.f ? a.x : 0.f; a.y = a.y > 0.f ? a.y : 0.f; a.z = a.z > 0.f ? a.z : 0.f; a.w = a.w > 0.f ? a.w : 0.f;
+        } else if (act == 2) {
+            a.x = a.x > 0.f ? a.x : 0.01f * a.x; a.y = a.y > 0.f ? a.y : 0.01f * a.y;
+            a.z = a.z > 0.f ? a.z : 0.01f * a.z; a.w = a.w > 0.f ? a.w : 0.01f * a.w;
         }
         reinterpret_cast<float4 *>(out)[i] = a;
     }
+}
+
+// gradient through the activation a convolution / linear layer applied in its epilogue, from the OUTPUT y (sign(y) == sign(pre-
+// activation) for both): ReLU g * (y > 0), LeakyReLU(0.01) g * (y > 0 ? 1 : 0.01)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ g, const float *__restrict__ y, float *__restrict__ out,
+                                                      size_t n4, size_t n, int act) {
+    const float neg = act == 2 ? 0.01f : 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 a = reinterpret_cast<const float4 *>(g)[i], b = reinterpret_cast<const float4 *>(y)[i];
+        reinterpret_cast<float4 *>(out)[i] = make_float4(b.x > 0.f ? a.x : neg * a.x, b.y > 0.f ? a.y : neg * a.y,
+                                                         b.z > 0.f ? a.z : neg * a.z, b.w > 0.f ? a.w : neg * a.w);
+    }
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = y[i] > 0.f ? g[i] : neg * g[i];
 }
 
 // column sums of a [M, K] matrix (bias gradient), deterministic: block b adds rows [b*rpb, (b+1)*rpb) of a band of up
@@ -1099,7 +1117,7 @@ extern "C" int sqd_conv_fwd_stats_rows(int N, int H, int W, int C, int K, int R,
     return (N * Ho * Wo + p.bm - 1) / p.bm;
 }
 
-// x [N,H,W,C], w [K,R,S,C], bias [K] or NULL -> y [N,Ho,Wo,K]; act: 0 none, 1 ReLU.  C, K multiples of 16.
+// x [N,H,W,C], w [K,R,S,C], bias [K] or NULL -> y [N,Ho,Wo,K]; act: 0 none, 1 ReLU, 2 LeakyReLU(0.01).  C, K multiples of 16.
 // stats (may be NULL): see sqd_conv_fwd_stats_rows — per-channel partial sums of y for the BatchNorm that follows.
 extern "C" int sqd_conv_fwd(const float *x, const float *w, const float *bias, float *y, float *ws, float *stats, int N, int H, int W,
                             int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int act, void *stream) {
@@ -1109,6 +1127,18 @@ extern "C" int sqd_conv_fwd(const float *x, const float *w, const float *bias, f
     SQD_CHECK_ARG(C % 16 == 0, "sqd_conv_fwd: C=%d must be a multiple of 16", C);
     if (launch_gemm(0, x, w, bias, y, ws, g, act, stream, stats)) return SQD_EINVAL;
     SQD_CHECK_LAUNCH("sqd_conv_fwd");
+    return SQD_OK;
+}
+
+// g, y, out: n floats (same memory order; out may alias g) -> out = g * act'(y); act 1 ReLU, 2 LeakyReLU(0.01)
+extern "C" int sqd_act_bwd(const float *g, const float *y, float *out, int64_t n, int act, void *stream) {
+    SQD_CHECK_ARG(g && y && out && n > 0 && (act == 1 || act == 2), "sqd_act_bwd: bad arguments");
+    SQD_CHECK_ARG(((uintptr_t)g & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)out & 15) == 0, "sqd_act_bwd: 16-byte aligned pointers");
+    (void)hipGetLastError();
+    const size_t n4 = (size_t)n / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 1 ? 1 : ((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256));
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, y, out, n4, (size_t)n, act);
+    SQD_CHECK_LAUNCH("sqd_act_bwd");
     return SQD_OK;
 }
 

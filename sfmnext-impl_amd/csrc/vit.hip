@@ -467,7 +467,7 @@ extern "C" int sqd_ffn_bwd(const float *x, const float *g_y, const float *W1, co
 
 // ===================================================================================================
 // multi-head self-attention of the encoder layer (nn.MultiheadAttention, packed in_proj, batch_first = False) for short token
-// sequences: S <= 128 tokens, head dimension HD in {4, 8}.  One workgroup per (batch element, head), four threads per token
+// sequences: S <= 512 tokens, head dimension HD in {4, 8}.  One workgroup per (batch element, head), four (two beyond 256 tokens) threads per token
 // (each takes every 4th key / query and a quarter of the features; quad shuffles combine them); the whole head (projections,
 // S x S scores, softmax, attention dropout, P.V, its slice of the out-projection) is VALU work on operands read from LDS — 120 x 120 x 8 per head is far too small for the matrix cores to matter; what
 // counts is that it is ONE launch with no intermediate tensors instead of ~8 (forward) / ~20 (backward).
@@ -476,18 +476,21 @@ extern "C" int sqd_ffn_bwd(const float *x, const float *g_y, const float *W1, co
 // Token (s, b) is row s*B + b.  Keep-mask of the attention dropout: bytes [B][H][S][SP], SP = S rounded up to 4.
 // ===================================================================================================
 namespace {
-constexpr int MHA_T = 128;                               // tokens per workgroup
-constexpr int MHA_P = 4;                                 // threads per token: thread 4*t + p takes every 4th key / query, a
-                                                         // quarter of the projection outputs and of the feature columns
-constexpr int MHA_THREADS = MHA_T * MHA_P;
-
-__device__ __forceinline__ float quad_sum(float v) {
+// Workgroup shapes: T tokens x P threads per token (thread P*t + p takes every P-th key / query, 1/P of the projection outputs
+// and of the feature columns; shuffles inside the group of P lanes combine them).  S <= 128: 128 x 4; S <= 256: 256 x 4;
+// S <= 512: 512 x 2 (the 1024-thread limit) — and there the backward re-reads x / g_sa from global memory (L2) for the
+// weight-gradient sums instead of staging them in LDS (2 x 67 KB would not fit next to Q, K, V, dO).
+template <int P>
+__device__ __forceinline__ float group_sum(float v) {
     v += __shfl_xor(v, 1, 64);
-    return v + __shfl_xor(v, 2, 64);
+    if (P == 4) v += __shfl_xor(v, 2, 64);
+    return v;
 }
-__device__ __forceinline__ float quad_max(float v) {
+template <int P>
+__device__ __forceinline__ float group_max(float v) {
     v = fmaxf(v, __shfl_xor(v, 1, 64));
-    return fmaxf(v, __shfl_xor(v, 2, 64));
+    if (P == 4) v = fmaxf(v, __shfl_xor(v, 2, 64));
+    return v;
 }
 
 // head h's slices of the packed in-projection (rows q | k | v) and of the out-projection, staged in LDS
@@ -497,22 +500,22 @@ struct MhaWeights {
     float bin[3 * HD];
     float wo[EE][HD];                                    // wo[e][d] = Wo[e][h*HD + d]
 };
-template <int HD, int EE>
+template <int HD, int EE, int NTH>
 __device__ __forceinline__ void mha_stage_weights(MhaWeights<HD, EE> &W, const float *__restrict__ Win, const float *__restrict__ bin,
                                                   const float *__restrict__ Wo, int h) {
-    for (int idx = threadIdx.x; idx < 3 * HD * EE; idx += MHA_THREADS) {
+    for (int idx = threadIdx.x; idx < 3 * HD * EE; idx += NTH) {
         const int j = idx / EE, e = idx % EE;
         W.win[j][e] = Win[(size_t)((j / HD) * EE + h * HD + j % HD) * EE + e];
     }
-    for (int idx = threadIdx.x; idx < EE * HD; idx += MHA_THREADS) W.wo[idx / HD][idx % HD] = Wo[(size_t)(idx / HD) * EE + h * HD + idx % HD];
+    for (int idx = threadIdx.x; idx < EE * HD; idx += NTH) W.wo[idx / HD][idx % HD] = Wo[(size_t)(idx / HD) * EE + h * HD + idx % HD];
     if (threadIdx.x < 3 * HD) W.bin[threadIdx.x] = bin[(threadIdx.x / HD) * EE + h * HD + threadIdx.x % HD];
 }
 
 // part p of token t projects HD/4 of the query / key / value features and writes them to LDS
-template <int HD, int EE>
+template <int HD, int EE, int P>
 __device__ __forceinline__ void mha_project(const MhaWeights<HD, EE> &W, const float (&xr)[EE], int t, int p, float qscale,
                                             float (*Qs)[HD], float (*Ks)[HD], float (*Vs)[HD]) {
-    constexpr int JP = HD / MHA_P;
+    constexpr int JP = HD / P;
 #pragma unroll
     for (int jj = 0; jj < JP; ++jj) {
         const int j = p * JP + jj;
@@ -530,19 +533,19 @@ __device__ __forceinline__ void mha_project(const MhaWeights<HD, EE> &W, const f
     }
 }
 
-template <int HD, int EE>
-__global__ __launch_bounds__(MHA_THREADS) void mha_fwd_kernel(const float *__restrict__ x, const float *__restrict__ Win,
+template <int HD, int EE, int T, int P>
+__global__ __launch_bounds__(T * P) void mha_fwd_kernel(const float *__restrict__ x, const float *__restrict__ Win,
                                                               const float *__restrict__ bin, const float *__restrict__ Wo,
                                                               const unsigned char *__restrict__ mask, float *__restrict__ ypart,
                                                               float *__restrict__ o_save, float *__restrict__ ml_save, int S, int B,
                                                               int H, float qscale, float dscale) {
     __shared__ MhaWeights<HD, EE> W;
-    __shared__ float Qs[MHA_T][HD], Ks[MHA_T][HD], Vs[MHA_T][HD];
-    const int b = blockIdx.x, h = blockIdx.y, t = threadIdx.x >> 2, p = threadIdx.x & 3;
+    __shared__ float Qs[T][HD], Ks[T][HD], Vs[T][HD];
+    const int b = blockIdx.x, h = blockIdx.y, t = threadIdx.x / P, p = threadIdx.x % P;
     const bool tv = t < S;
     const int SP = (S + 3) & ~3;
     const size_t row = (size_t)t * B + b;
-    mha_stage_weights<HD, EE>(W, Win, bin, Wo, h);
+    mha_stage_weights<HD, EE, T * P>(W, Win, bin, Wo, h);
     float xr[EE];
 #pragma unroll
     for (int e = 0; e < EE; e += 4) {
@@ -550,24 +553,24 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_fwd_kernel(const float *__res
         xr[e] = v4.x; xr[e + 1] = v4.y; xr[e + 2] = v4.z; xr[e + 3] = v4.w;
     }
     __syncthreads();
-    mha_project<HD, EE>(W, xr, t, p, qscale, Qs, Ks, Vs);
+    mha_project<HD, EE, P>(W, xr, t, p, qscale, Qs, Ks, Vs);
     __syncthreads();
     float q[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) q[d] = Qs[t][d];
     float m = -INFINITY;
-    for (int kk = p; kk < S; kk += MHA_P) {
+    for (int kk = p; kk < S; kk += P) {
         float s = 0.f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[kk][d], s);
         m = fmaxf(m, s);
     }
-    m = quad_max(m);                                     // S >= 1: at least part 0 saw a key
+    m = group_max<P>(m);                                     // S >= 1: at least part 0 saw a key
     float l = 0.f, o[HD];
 #pragma unroll
     for (int d = 0; d < HD; ++d) o[d] = 0.f;
     const unsigned char *mrow = mask ? mask + (((size_t)b * H + h) * S + (tv ? t : 0)) * SP : nullptr;
-    for (int kk = p; kk < S; kk += MHA_P) {
+    for (int kk = p; kk < S; kk += P) {
         float s = 0.f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) s = fmaf(q[d], Ks[kk][d], s);
@@ -577,10 +580,10 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_fwd_kernel(const float *__res
 #pragma unroll
         for (int d = 0; d < HD; ++d) o[d] = fmaf(pd, Vs[kk][d], o[d]);
     }
-    l = quad_sum(l);
+    l = group_sum<P>(l);
     const float rl = 1.f / l;
 #pragma unroll
-    for (int d = 0; d < HD; ++d) o[d] = quad_sum(o[d]) * rl;
+    for (int d = 0; d < HD; ++d) o[d] = group_sum<P>(o[d]) * rl;
     if (!tv) return;
     const size_t hs = ((size_t)b * H + h) * S + t;
     if (p == 0) {
@@ -590,7 +593,7 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_fwd_kernel(const float *__res
         ml_save[hs * 2 + 1] = l;
     }
     // this head's part of the out-projection; part p writes features [p*EE/4, (p+1)*EE/4)
-    constexpr int EP = EE / MHA_P;
+    constexpr int EP = EE / P;
     float *yo = ypart + ((size_t)h * S * B + row) * EE + p * EP;
 #pragma unroll
     for (int e = 0; e < EP; e += 4) {
@@ -606,8 +609,8 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_fwd_kernel(const float *__res
     }
 }
 
-template <int HD, int EE>
-__global__ __launch_bounds__(MHA_THREADS) void mha_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gsa,
+template <int HD, int EE, int T, int P, bool STAGE>
+__global__ __launch_bounds__(T * P) void mha_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gsa,
                                                               const float *__restrict__ Win, const float *__restrict__ bin,
                                                               const float *__restrict__ Wo, const unsigned char *__restrict__ mask,
                                                               const float *__restrict__ o_save, const float *__restrict__ ml_save,
@@ -615,16 +618,16 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_bwd_kernel(const float *__res
                                                               float *__restrict__ pbin, float *__restrict__ pWo, float *__restrict__ pbo,
                                                               int S, int B, int H, float qscale, float dscale) {
     __shared__ MhaWeights<HD, EE> W;
-    __shared__ float xs[MHA_T][EE + 1], gs[MHA_T][EE + 1];
-    __shared__ float qkvd[4][MHA_T][HD];                  // Q (scaled), K, V, dO; later aliased by dqkv [MHA_T][3*HD]
-    __shared__ float os[MHA_T][HD];
-    __shared__ float st[3][MHA_T];                        // row max, 1 / row sum, D = dO . o
-    constexpr int JP = HD / MHA_P, EP = EE / MHA_P;
-    const int b = blockIdx.x, h = blockIdx.y, t = threadIdx.x >> 2, p = threadIdx.x & 3;
+    __shared__ float xs[STAGE ? T : 1][EE + 1], gs[STAGE ? T : 1][EE + 1];
+    __shared__ float qkvd[4][T][HD];                      // Q (scaled), K, V, dO; later aliased by dqkv [T][3*HD]
+    __shared__ float os[T][HD];
+    __shared__ float st[3][T];                            // row max, 1 / row sum, D = dO . o
+    constexpr int JP = HD / P, EP = EE / P, NTH = T * P;
+    const int b = blockIdx.x, h = blockIdx.y, t = threadIdx.x / P, p = threadIdx.x % P;
     const bool tv = t < S;
     const int SP = (S + 3) & ~3;
     const size_t row = (size_t)t * B + b, hs = ((size_t)b * H + h) * S + t;
-    mha_stage_weights<HD, EE>(W, Win, bin, Wo, h);
+    mha_stage_weights<HD, EE, NTH>(W, Win, bin, Wo, h);
     float xr[EE], gr[EE];
 #pragma unroll
     for (int e = 0; e < EE; e += 4) {
@@ -633,10 +636,12 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_bwd_kernel(const float *__res
         xr[e] = a.x; xr[e + 1] = a.y; xr[e + 2] = a.z; xr[e + 3] = a.w;
         gr[e] = g.x; gr[e + 1] = g.y; gr[e + 2] = g.z; gr[e + 3] = g.w;
     }
+    if (STAGE) {
 #pragma unroll
-    for (int e = 0; e < EP; ++e) { xs[t][p * EP + e] = xr[p * EP + e]; gs[t][p * EP + e] = gr[p * EP + e]; }
+        for (int e = 0; e < EP; ++e) { xs[t][p * EP + e] = xr[p * EP + e]; gs[t][p * EP + e] = gr[p * EP + e]; }
+    }
     __syncthreads();
-    mha_project<HD, EE>(W, xr, t, p, qscale, qkvd[0], qkvd[1], qkvd[2]);
+    mha_project<HD, EE, P>(W, xr, t, p, qscale, qkvd[0], qkvd[1], qkvd[2]);
 #pragma unroll
     for (int jj = 0; jj < JP; ++jj) {
         const int d = p * JP + jj;
@@ -664,7 +669,7 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_bwd_kernel(const float *__res
     // pass A: thread = (query t, every 4th key) -> dq' (gradient of the scaled query)
     {
         const unsigned char *mrow = mbase ? mbase + (size_t)(tv ? t : 0) * SP : nullptr;
-        for (int kk = p; kk < S; kk += MHA_P) {
+        for (int kk = p; kk < S; kk += P) {
             float s = 0.f, dpd = 0.f;
 #pragma unroll
             for (int d = 0; d < HD; ++d) {
@@ -679,7 +684,7 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_bwd_kernel(const float *__res
         }
     }
     // pass B: thread = (key t, every 4th query) -> dk, dv
-    for (int qq = p; qq < S; qq += MHA_P) {
+    for (int qq = p; qq < S; qq += P) {
         float s = 0.f, dpd = 0.f;
 #pragma unroll
         for (int d = 0; d < HD; ++d) {
@@ -698,9 +703,9 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_bwd_kernel(const float *__res
     }
 #pragma unroll
     for (int d = 0; d < HD; ++d) {
-        dq[d] = tv ? quad_sum(dq[d]) * qscale : 0.f;      // gradient of the unscaled projection
-        dk[d] = tv ? quad_sum(dk[d]) : 0.f;
-        dv[d] = tv ? quad_sum(dv[d]) : 0.f;
+        dq[d] = tv ? group_sum<P>(dq[d]) * qscale : 0.f;      // gradient of the unscaled projection
+        dk[d] = tv ? group_sum<P>(dk[d]) : 0.f;
+        dv[d] = tv ? group_sum<P>(dv[d]) : 0.f;
     }
     __syncthreads();                                      // everyone is done with Q, K, V, dO: reuse the area for dqkv
     float(*dqkv)[3 * HD] = reinterpret_cast<float(*)[3 * HD]>(&qkvd[0][0][0]);
@@ -729,18 +734,28 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_bwd_kernel(const float *__res
     }
     __syncthreads();
     // weight-gradient partials of this batch element (rows / columns of head h): one output per thread, sums over the tokens
-    for (int idx = threadIdx.x; idx < 3 * HD * EE; idx += MHA_THREADS) {
+    for (int idx = threadIdx.x; idx < 3 * HD * EE; idx += NTH) {
         const int j = idx / EE, e = idx % EE;             // j: 0..HD-1 query rows, HD.. key rows, 2HD.. value rows
         float a = 0.f;
+        if (STAGE) {
 #pragma unroll 4
-        for (int s = 0; s < S; ++s) a = fmaf(dqkv[s][j], xs[s][e], a);
+            for (int s = 0; s < S; ++s) a = fmaf(dqkv[s][j], xs[s][e], a);
+        } else {
+#pragma unroll 8
+            for (int s = 0; s < S; ++s) a = fmaf(dqkv[s][j], x[((size_t)s * B + b) * EE + e], a);     // 128-byte rows, L2-resident
+        }
         pWin[((size_t)b * 3 * EE + (j / HD) * EE + h * HD + j % HD) * EE + e] = a;
     }
-    for (int idx = threadIdx.x; idx < EE * HD; idx += MHA_THREADS) {
+    for (int idx = threadIdx.x; idx < EE * HD; idx += NTH) {
         const int e = idx / HD, d = idx % HD;
         float a = 0.f;
+        if (STAGE) {
 #pragma unroll 4
-        for (int s = 0; s < S; ++s) a = fmaf(gs[s][e], os[s][d], a);
+            for (int s = 0; s < S; ++s) a = fmaf(gs[s][e], os[s][d], a);
+        } else {
+#pragma unroll 8
+            for (int s = 0; s < S; ++s) a = fmaf(gsa[((size_t)s * B + b) * EE + e], os[s][d], a);
+        }
         pWo[((size_t)b * EE + e) * EE + h * HD + d] = a;
     }
     if (threadIdx.x < 3 * HD) {
@@ -752,7 +767,7 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_bwd_kernel(const float *__res
     if (h == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + EE) {
         const int e = threadIdx.x - 64;
         float a = 0.f;
-        for (int s = 0; s < S; ++s) a += gs[s][e];
+        for (int s = 0; s < S; ++s) a += STAGE ? gs[s][e] : gsa[((size_t)s * B + b) * EE + e];
         pbo[(size_t)b * EE + e] = a;
     }
 }
@@ -760,21 +775,33 @@ __global__ __launch_bounds__(MHA_THREADS) void mha_bwd_kernel(const float *__res
 template <int HD, int EE>
 void mha_launch_fwd(dim3 grid, hipStream_t st, const float *x, const float *Win, const float *bin, const float *Wo, const unsigned char *mask,
                     float *ypart, float *o_save, float *ml_save, int S, int B, int H, float qscale, float dscale) {
-    hipLaunchKernelGGL((mha_fwd_kernel<HD, EE>), grid, dim3(MHA_THREADS), 0, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+    if (S <= 128)
+        hipLaunchKernelGGL((mha_fwd_kernel<HD, EE, 128, 4>), grid, dim3(512), 0, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+    else if (S <= 256)
+        hipLaunchKernelGGL((mha_fwd_kernel<HD, EE, 256, 4>), grid, dim3(1024), 0, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+    else
+        hipLaunchKernelGGL((mha_fwd_kernel<HD, EE, 512, 2>), grid, dim3(1024), 0, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
 }
 template <int HD, int EE>
 void mha_launch_bwd(dim3 grid, hipStream_t st, const float *x, const float *gsa, const float *Win, const float *bin, const float *Wo,
                     const unsigned char *mask, const float *o_save, const float *ml_save, float *gxpart, float *pWin, float *pbin, float *pWo,
                     float *pbo, int S, int B, int H, float qscale, float dscale) {
-    hipLaunchKernelGGL((mha_bwd_kernel<HD, EE>), grid, dim3(MHA_THREADS), 0, st, x, gsa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin, pbin, pWo,
-                       pbo, S, B, H, qscale, dscale);
+    if (S <= 128)
+        hipLaunchKernelGGL((mha_bwd_kernel<HD, EE, 128, 4, true>), grid, dim3(512), 0, st, x, gsa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin,
+                           pbin, pWo, pbo, S, B, H, qscale, dscale);
+    else if (S <= 256)
+        hipLaunchKernelGGL((mha_bwd_kernel<HD, EE, 256, 4, true>), grid, dim3(1024), 0, st, x, gsa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin,
+                           pbin, pWo, pbo, S, B, H, qscale, dscale);
+    else
+        hipLaunchKernelGGL((mha_bwd_kernel<HD, EE, 512, 2, false>), grid, dim3(1024), 0, st, x, gsa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin,
+                           pbin, pWo, pbo, S, B, H, qscale, dscale);
 }
 }  // namespace
 
 extern "C" int sqd_mha_supported(int S, int E, int H) {
     if (!(E == 16 || E == 32) || H < 1 || E % H) return 0;
     const int hd = E / H;
-    return (S >= 1 && S <= MHA_T && (hd == 4 || hd == 8)) ? 1 : 0;
+    return (S >= 1 && S <= 512 && (hd == 4 || hd == 8)) ? 1 : 0;
 }
 
 // x [S*B, E] (token (s,b) = row s*B+b), Win [3E,E], bin [3E], Wo [E,E]; mask [B][H][S][SP] keep bytes (SP = S rounded up to 4)

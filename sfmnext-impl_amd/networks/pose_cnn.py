@@ -23,6 +23,5 @@ class PoseCNN(nn.Module):
     def forward(self, out):
         for conv in self.net:
             out = X.conv2d(out, conv, "relu")
-        out = X.conv2d(out, self.pose_conv).mean(3).mean(2)
-        out = 0.01 * out.view(-1, self.num_input_frames - 1, 1, 6)
+        out = X.pose_head(out, self.pose_conv, 0.01).view(-1, self.num_input_frames - 1, 1, 6)
         return out[..., :3], out[..., 3:]

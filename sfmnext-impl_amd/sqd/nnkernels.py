@@ -277,6 +277,55 @@ def _wgrad_part_floats(geom):
     return n
 
 
+class PoseHead(torch.autograd.Function):
+    """scale * pose_conv(x).mean(3).mean(2) of PoseCNN (reference networks/pose_cnn.py:40-42) as one launch each way.
+    forward(x [B,C,h,w] channels-last, weight [J,C,1,1], bias [J], scale) -> [B,J]"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, scale):
+        _require(x, "PoseHead input")
+        x = _cl(x)
+        B, C, h, w = x.shape
+        J = weight.shape[0]
+        wm = weight.reshape(J, C).contiguous()
+        out = torch.empty(B, J, device=x.device, dtype=torch.float32)
+        mean = torch.empty(B, C, device=x.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_pose_head_fwd(_ptr(x), _ptr(wm), _ptr(bias), _ptr(out), _ptr(mean), B, h, w, C, J, float(scale), _stream()),
+                 "pose_head_fwd")
+        ctx.save_for_backward(wm, mean)
+        ctx.dims = (B, C, h, w, J, float(scale), weight.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        wm, mean = ctx.saved_tensors
+        B, C, h, w, J, scale, wshape = ctx.dims
+        g = g.contiguous()
+        dx = torch.empty((B, C, h, w), device=g.device, dtype=torch.float32, memory_format=torch.channels_last)
+        dWp_c = torch.empty(B, J * C, device=g.device, dtype=torch.float32)
+        dbp_c = torch.empty(B, J, device=g.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_pose_head_bwd(_ptr(g), _ptr(wm), _ptr(mean), _ptr(dx), _ptr(dWp_c), _ptr(dbp_c), B, h * w, C, J, scale, _stream()),
+                 "pose_head_bwd")
+        dW = torch.empty(J, C, device=g.device, dtype=torch.float32)
+        db = torch.empty(J, device=g.device, dtype=torch.float32)
+        _colsum_multi([(dWp_c, dW, 0), (dbp_c, db, 0)])
+        return dx, dW.view(wshape), db, None
+
+
+def linear_native(x, lin, act=None):
+    """nn.Linear on a few rows (the 12-row bins regressor, reference networks/depth_decoder_QTR.py:22-26,49) as a 1x1
+    convolution over rows-as-pixels: the implicit-GEMM kernels with split-K read the weight matrix once, the data / weight
+    gradients come from the same node.  in_features and out_features must be multiples of 16."""
+    rows, K = x.shape[0], lin.out_features
+    x4 = x.reshape(rows, lin.in_features, 1, 1)
+    w4 = lin.weight.view(K, lin.in_features, 1, 1)
+    return Conv2d.apply(x4, w4, lin.bias, 1, 0, act, False, None, None).reshape(rows, K)
+
+
+def linear_supported(lin, x):
+    return x.dim() == 2 and lin.in_features % 16 == 0 and lin.out_features % 16 == 0
+
+
 def conv_module_supported(conv):
     s, p = conv.stride, conv.padding
     return (conv.in_channels % 16 == 0 and conv.out_channels % 16 == 0 and s[0] == s[1] and p[0] == p[1]
@@ -352,7 +401,7 @@ class Conv2d(torch.autograd.Function):
         ws = _conv_ws(0, (N, H, W, C, K, R, S, stride, pad, Ho, Wo), x.device)
         _l.check(_l.lib().sqd_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws), _ptr(stats), N, H, W, C, K, R, S, stride, pad,
                                        Ho, Wo, ACT[act], _stream()), "conv_fwd")
-        ctx.save_for_backward(x, w, y if act == "relu" else None)
+        ctx.save_for_backward(x, w, y if act is not None else None)
         # The weight gradient may run on a side stream only when nothing reads it before the optimiser / bucket gather joins
         # that stream: the filter must be a leaf (a regrouped stem filter feeds StemRegroup.backward at once) and used once
         # per step (autograd sums the gradients of a shared filter on the main stream as soon as the second one arrives).
@@ -373,8 +422,10 @@ class Conv2d(torch.autograd.Function):
             return g_skip, None, None, None, None, None, None, None, None
         dy = _cl(dy)
         g_skip = _cl(g_skip) if g_skip is not None else None
-        if ctx.act == "relu":
-            dy = torch.ops.aten.threshold_backward(dy, y, 0.0)         # dy where y > 0 else 0, one launch
+        if ctx.act is not None:                          # the epilogue's ReLU / LeakyReLU: dy * act'(y), one launch
+            g = torch.empty_like(dy)
+            _l.check(_l.lib().sqd_act_bwd(_ptr(dy), _ptr(y), _ptr(g), dy.numel(), ACT[ctx.act], _stream()), "act_bwd")
+            dy = g
         L = _l.lib()
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
@@ -792,9 +843,9 @@ def encoder_supported(encoder):
 
 
 def transformer_encoder_native(tokens, encoder):
-    """tokens [S,B,E] through the encoder.  Short sequences (S <= 128, head dimension 4 | 8): every layer runs on the fused
-    kernels (EncoderStack).  Longer ones: self-attention stays with torch (projections on rocBLAS, attention core on its
-    fused kernel) and everything after it runs as EncoderTail.  One bernoulli launch draws every dropout mask of the pass."""
+    """tokens [S,B,E] through the encoder.  S <= 512 tokens (the positional table holds 500), head dimension 4 | 8: every layer
+    runs on the fused kernels (EncoderStack).  Anything else: self-attention through torch and everything after it as
+    EncoderTail.  One bernoulli launch draws every dropout mask of the pass."""
     x = tokens.contiguous()
     S, B, E = x.shape
     rows = S * B

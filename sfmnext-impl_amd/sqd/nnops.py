@@ -14,7 +14,7 @@ import torch.nn.functional as F
 
 BACKEND = {
     "conv2d": "aten", "conv_bn_act": "aten conv + hip bn/act/residual", "maxpool3x3s2": "hip", "upsample_concat": "hip",
-    "linear": "aten", "transformer_encoder": "hip (fused attention, feed-forward, add+dropout+layernorm; > 128 tokens: aten attention)", "full_query_layer": "hip", "bins_head": "hip",
+    "pose_head": "hip", "linear": "hip (1x1 implicit GEMM over rows; feature counts not divisible by 16: aten)", "transformer_encoder": "hip (fused attention up to 512 tokens, feed-forward, add+dropout+layernorm)", "full_query_layer": "hip", "bins_head": "hip",
 }
 
 
@@ -44,7 +44,7 @@ def set_native_conv(on):
     through libsqd; the 3- and 6-channel stem convolutions stay on ATen."""
     global NATIVE_CONV
     NATIVE_CONV = bool(on)
-    BACKEND["conv2d"] = "hip (incl. the 7x7 stems via space-to-depth; K % 16 != 0 heads: aten)" if on else "aten"
+    BACKEND["conv2d"] = "hip (incl. the 7x7 stems via space-to-depth; channel counts not divisible by 16: aten)" if on else "aten"
     BACKEND["conv_bn_act"] = ("hip conv" if on else "aten conv") + " + hip bn/act/residual"
 
 
@@ -112,6 +112,14 @@ def _bn_act(y, bn, act, residual, pre=None):
     return _act(y, act)
 
 
+def pose_head(x, conv, scale):
+    """scale * conv(x).mean(3).mean(2) for PoseCNN's 1x1 head (reference networks/pose_cnn.py:40-45) -> [B, J]."""
+    if x.is_cuda and NATIVE_CONV and conv.kernel_size == (1, 1) and conv.out_channels <= 16 and conv.bias is not None:
+        from . import nnkernels
+        return nnkernels.PoseHead.apply(x, conv.weight, conv.bias, scale)
+    return scale * F.conv2d(x, conv.weight, conv.bias).mean(3).mean(2)
+
+
 def maxpool3x3s2(x, skip=False):
     """skip=True: -> (y, x') with x' to be read by x's other consumer (see nnkernels.MaxPool3x3s2)."""
     if x.is_cuda:
@@ -135,7 +143,12 @@ def upsample_concat(x, skip):
 
 
 def linear(x, lin, act=None):
-    y = F.linear(x, lin.weight, lin.bias)
+    """nn.Linear (+ LeakyReLU(0.01)) of the bins regressor."""
+    if x.is_cuda and NATIVE_CONV:
+        from . import nnkernels
+        if nnkernels.linear_supported(lin, x):
+            return nnkernels.linear_native(x, lin, act)
+    y = F.linear(x, lin.weight, lin.bias)      # feature counts that are not multiples of 16 (toy test heads), or host tensors
     return F.leaky_relu(y, 0.01) if act == "leaky_relu" else y
 
 

@@ -187,3 +187,55 @@ def test_encoder_taps_carry_the_same_values_and_gradients():
                 assert err <= 1e-5 * max(p.grad.abs().max().item(), 1e-6), (n, err)
     finally:
         nnops.set_native_conv(False)
+
+
+@pytest.mark.parametrize("rows,K,N,act", [(12, 2048, 1024, "leaky_relu"), (12, 1024, 256, "leaky_relu"), (12, 256, 64, None),
+                                          (2, 3840, 1920, "leaky_relu"), (8, 4096, 2048, "leaky_relu"), (1, 192, 32, None)])
+def test_linear_native(rows, K, N, act):
+    """the bins regressor's nn.Linear (+ LeakyReLU) through the 1x1 implicit-GEMM kernels against fp64"""
+    from sqd import nnops
+    nnops.set_native_conv(True)
+    torch.manual_seed(rows + K)
+    lin = nn.Linear(K, N)
+    x = torch.randn(rows, K)
+    g = torch.randn(rows, N)
+    ref_lin = nn.Linear(K, N).double()
+    ref_lin.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    yr = _act(ref_lin(xr), act)
+    yr.backward(g.double())
+    lin = lin.cuda()
+    xd = x.cuda().requires_grad_(True)
+    y = nnops.linear(xd, lin, act)
+    y.backward(g.cuda())
+    assert "hip" in nnops.BACKEND["linear"]
+
+    def close(a, b, what):
+        a, b = a.detach().cpu().double(), b.detach()
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-7, (what, float((a - b).abs().max()), float(b.abs().max()))
+    close(y, yr, "y")
+    close(xd.grad, xr.grad, "dx")
+    close(lin.weight.grad, ref_lin.weight.grad, "dW")
+    close(lin.bias.grad, ref_lin.bias.grad, "db")
+
+
+@pytest.mark.parametrize("B,C,h,w,J", [(24, 256, 2, 5, 6), (2, 256, 1, 2, 6), (3, 64, 4, 3, 12), (1, 512, 3, 10, 16)])
+def test_pose_head(B, C, h, w, J):
+    """0.01 * pose_conv(x).mean(3).mean(2) (reference networks/pose_cnn.py:40-45) against the fp64 composite"""
+    from sqd import nnops
+    nnops.set_native_conv(True)
+    torch.manual_seed(B + C + J)
+    conv = nn.Conv2d(C, J, 1)
+    x, g = torch.randn(B, C, h, w), torch.randn(B, J)
+    ref = nn.Conv2d(C, J, 1).double()
+    ref.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    yr = 0.01 * ref(xr).mean(3).mean(2)
+    yr.backward(g.double())
+    conv = conv.cuda()
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = nnops.pose_head(xd, conv, 0.01)
+    y.backward(g.cuda())
+    for a, b, what in ((y, yr, "out"), (xd.grad, xr.grad, "dx"), (conv.weight.grad, ref.weight.grad, "dW"), (conv.bias.grad, ref.bias.grad, "db")):
+        a, b = a.detach().cpu().double(), b.detach()
+        assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9, (what, float((a - b).abs().max()))

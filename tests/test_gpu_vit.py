@@ -140,7 +140,11 @@ def _attention_ref(x, Win, bin_, Wo, bo, H, keep, scale):
 
 
 @pytest.mark.parametrize("S,B,E,H,drop", [(120, 12, 32, 4, True), (120, 12, 32, 4, False), (120, 2, 16, 4, True), (37, 3, 32, 8, True),
-                                          (128, 1, 16, 2, False), (1, 2, 32, 4, False), (6, 5, 32, 4, True)])
+                                          (128, 1, 16, 2, False), (1, 2, 32, 4, False), (6, 5, 32, 4, True),
+                                          # the 320x1024 configurations: 200 tokens (patch 20) -> the 256 x 4 workgroup; 320 tokens
+                                          # (patch 16) and 500 (the positional table's limit) -> the 512 x 2 workgroup
+                                          (200, 8, 32, 4, True), (200, 2, 16, 4, False), (129, 1, 32, 8, True), (256, 2, 32, 4, True),
+                                          (320, 8, 32, 4, True), (257, 1, 16, 2, False), (500, 2, 32, 8, True), (320, 2, 16, 4, False)])
 def test_self_attention(S, B, E, H, drop):
     from sqd import nnkernels
     g = torch.Generator().manual_seed(S * 7 + B + E + H)
@@ -222,10 +226,10 @@ def _encoder(E, Fh, p, seed):
     return enc
 
 
-@pytest.mark.parametrize("S,B,E,Fh", [(120, 12, 32, 1024), (120, 2, 16, 512), (15, 3, 32, 1024), (200, 2, 32, 1024)])
+@pytest.mark.parametrize("S,B,E,Fh", [(120, 12, 32, 1024), (120, 2, 16, 512), (15, 3, 32, 1024), (200, 2, 32, 1024), (320, 2, 32, 1024)])
 def test_encoder_matches_torch(S, B, E, Fh):
     """dropout 0 in training mode: outputs and every parameter gradient against nn.TransformerEncoder in fp64 on the CPU.
-    S = 200 (the 320x1024 configurations) exceeds the fused attention's 128 tokens: torch attention + EncoderTail."""
+    S = 200 / 320 (the 320x1024 configurations at patch 20 / 16): the 256- and 512-token attention workgroups."""
     from sqd import nnkernels, nnops
     enc = _encoder(E, Fh, 0.0, S + B)
     tokens = torch.randn(S, B, E)
@@ -246,10 +250,9 @@ def test_encoder_matches_torch(S, B, E, Fh):
         _close(q.grad, r.grad, name, 2e-4)
 
 
-@pytest.mark.parametrize("S", [120, 200])
+@pytest.mark.parametrize("S", [120, 200, 320])
 def test_encoder_dropout_statistics(S):
-    """training mode, p = 0.1: masks are fresh per call, keep ~90 %, and eval mode is dropout-free and deterministic
-    (S = 200: the torch-attention + EncoderTail path)."""
+    """training mode, p = 0.1: masks are fresh per call, keep ~90 %, and eval mode is dropout-free and deterministic."""
     from sqd import nnops
     enc = _encoder(32, 1024, 0.1, 7).cuda()
     x = torch.randn(S, 12, 32, device="cuda")
