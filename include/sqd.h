@@ -363,8 +363,8 @@ int sqd_mha_bwd(const float *x, const float *g_sa, const float *Win, const float
  * PoseCNN tail
  * replaces: out = self.pose_conv(out); out = out.mean(3).mean(2); out = 0.01 * out.view(...)   reference networks/pose_cnn.py:40-45
  * x [B,h,w,C] channels-last, W [J,C] (the 1x1 filter), bias [J], J <= 16 -> out [B,J] = scale * (W . mean_hw(x) + bias); mean [B,C]
- * is kept for the backward.  backward: g [B,J] -> dx [B,h,w,C], per-image partials dWpart [B,J,C], dbpart [B,J] (summed over B by
- * sqd_colsum_multi).                                                                                                          */
+ * is kept for the backward.  backward: g [B,J] -> dx [B,h,w,C], per-image partials dWpart [B,J,C], dbpart [B,J rounded up to a
+ * multiple of 4] (summed over B by sqd_colsum_multi; needs C % 4 == 0).                                                                                                          */
 int sqd_pose_head_fwd(const float *x, const float *W, const float *bias, float *out, float *mean, int B, int h, int w, int C, int J,
                       float scale, void *stream);
 int sqd_pose_head_bwd(const float *g, const float *W, const float *mean, float *dx, float *dWpart, float *dbpart, int B, int P, int C,

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256) void pose_head_fwd_kernel(const float *__restr
     }
 }
 
-// g [B][J] -> dx [B][h][w][C] (every pixel of an image gets the same row), dWpart [B][J][C], dbpart [B][J]
+// g [B][J] -> dx [B][h][w][C] (every pixel of an image gets the same row), dWpart [B][J][C], dbpart [B][J rounded up to 4]
 __global__ __launch_bounds__(256) void pose_head_bwd_kernel(const float *__restrict__ g, const float *__restrict__ W,
                                                             const float *__restrict__ mean, float *__restrict__ dx,
                                                             float *__restrict__ dWpart, float *__restrict__ dbpart, int P, int C, int J,
@@ -53,7 +53,8 @@ __global__ __launch_bounds__(256) void pose_head_bwd_kernel(const float *__restr
     float gj[MAXJ];
 #pragma unroll
     for (int j = 0; j < MAXJ; ++j) gj[j] = j < J ? scale * g[(size_t)b * J + j] : 0.f;
-    if (threadIdx.x < J) dbpart[(size_t)b * J + threadIdx.x] = gj[threadIdx.x];
+    const int JP = (J + 3) & ~3;                    // rows of 4-float groups for sqd_colsum_multi; the padding columns are zero
+    if (threadIdx.x < JP) dbpart[(size_t)b * JP + threadIdx.x] = threadIdx.x < J ? scale * g[(size_t)b * J + threadIdx.x] : 0.f;
     const float ip = 1.f / (float)P;
     for (int c = threadIdx.x; c < C; c += 256) {
         const float m = mean[(size_t)b * C + c];

@@ -115,7 +115,9 @@ EXTRA_FLAGS = [
     ("sqd_device_noise", _T, False, {"help": "draw the tie-break noise on the device instead of the CPU RNG"}),
     ("sqd_channels_last", _T, False, {"help": "keep network activations NHWC in memory (always on with the native convolutions)"}),
     ("sqd_no_graph", _T, False, {"help": "never capture the training step into a hipGraph (single-device runs replay one after 3 eager steps)"}),
-    ("sqd_graph_ddp", _T, False, {"help": "multi-rank runs: replay forward+backward as a hipGraph, then all-reduce the buckets and run Adam (default: eager with overlapped all-reduce)"}),
+    ("sqd_graph_ddp", str, "overlap", {"choices": ["overlap", "post"],
+                                        "help": "multi-rank hipGraph: 'overlap' (default) = the bucketed all-reduces are graph branches next to backward; "
+                                                "'post' = graph of forward+backward, collectives and Adam issued after each replay"}),
     ("sqd_no_conv_tune", _T, False, {"help": "keep the cost-model convolution plans instead of timing tile / split-K plans per layer in the first step"}),
     ("sqd_aten_conv", _T, False, {"help": "A/B switch: ATen/MIOpen convolutions instead of the native implicit-GEMM kernels (csrc/conv.hip)"}),
     ("sqd_miopen_find", _T, False, {"help": "let MIOpen benchmark its solvers per layer (interim ATen conv backend only)"}),

@@ -303,13 +303,14 @@ class PoseHead(torch.autograd.Function):
         g = g.contiguous()
         dx = torch.empty((B, C, h, w), device=g.device, dtype=torch.float32, memory_format=torch.channels_last)
         dWp_c = torch.empty(B, J * C, device=g.device, dtype=torch.float32)
-        dbp_c = torch.empty(B, J, device=g.device, dtype=torch.float32)
+        JP = (J + 3) // 4 * 4
+        dbp_c = torch.empty(B, JP, device=g.device, dtype=torch.float32)
         _l.check(_l.lib().sqd_pose_head_bwd(_ptr(g), _ptr(wm), _ptr(mean), _ptr(dx), _ptr(dWp_c), _ptr(dbp_c), B, h * w, C, J, scale, _stream()),
                  "pose_head_bwd")
         dW = torch.empty(J, C, device=g.device, dtype=torch.float32)
-        db = torch.empty(J, device=g.device, dtype=torch.float32)
+        db = torch.empty(JP, device=g.device, dtype=torch.float32)
         _colsum_multi([(dWp_c, dW, 0), (dbp_c, db, 0)])
-        return dx, dW.view(wshape), db, None
+        return dx, dW.view(wshape), db[:J], None
 
 
 def linear_native(x, lin, act=None):

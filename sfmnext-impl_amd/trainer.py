@@ -108,10 +108,10 @@ class Trainer:
         if self.reducer is not None:
             self.reducer.broadcast_parameters(self.models.values())
 
-        # multi-rank runs stay eager unless --sqd_graph_ddp: the forward+backward graph + post all-reduce path is covered by the
-        # 1-rank RCCL device test only (RCCL's watchdog thread must not poll during the capture — see _capture_fwd_bwd)
-        self._graph_ok = not self.opt.sqd_no_graph and self.device.type == "cuda" and not self.opt.disable_automasking and \
-            (self.reducer is None or self.opt.sqd_graph_ddp)
+        # single- and multi-rank runs replay the whole step as one hipGraph; with a process group the graph also holds the
+        # bucket gathers and the RCCL all-reduces the autograd hooks launch, as branches parallel to the rest of backward
+        # (--sqd_graph_ddp post: the round-1 variant — graph of forward+backward, collectives and Adam issued after the replay)
+        self._graph_ok = not self.opt.sqd_no_graph and self.device.type == "cuda" and not self.opt.disable_automasking
         self._side_stream = torch.cuda.Stream(device=self.device)
         self._pose_stream = torch.cuda.Stream(device=self.device)
         # weight-gradient kernels of the convolutions on their own stream (SQD_NO_WGRAD_STREAM=1: A/B runs)
@@ -220,10 +220,10 @@ class Trainer:
         for k, v in inputs.items():
             self._static_in[k].copy_(v, non_blocking=True)
             inputs[k] = self._static_in[k]        # as process_batch does in eager mode: the caller's dict now holds device tensors
-        if self.reducer is None:
+        if self.reducer is None or self.opt.sqd_graph_ddp != "post":
             self.model_optimizer.refresh_hyper()
-            self._graph.replay()
-        else:                                   # multi-rank: the graph holds forward + backward; exchange, then Adam
+            self._graph.replay()                # forward, backward (+ bucketed all-reduces overlapped with it), Adam
+        else:                                   # the graph holds forward + backward; exchange, then Adam
             self._graph.replay()
             self.reducer.allreduce_all()
             self.model_optimizer.step()
@@ -233,10 +233,15 @@ class Trainer:
         """One hipGraph for process_batch + backward + Adam.  The ~1200 kernel launches of a step then cost one graph
         launch on the host (eager: ~23 ms of host time per 26 ms step)."""
         self._static_in = {k: v.to(self.device).clone() for k, v in inputs.items()}
-        if self.reducer is not None:
+        if self.reducer is not None and self.opt.sqd_graph_ddp == "post":
             return self._capture_fwd_bwd()
         opt = self.model_optimizer
-        opt.zero_grad(set_to_none=True)
+        if self.reducer is not None:
+            if self.reducer.buckets is None:
+                raise RuntimeError("graph capture needs one eager step first (the gradient buckets are built there)")
+            self.reducer.zero_grad()            # p.grad = None, bucket arrival counters reset: the captured backward fills them
+        else:
+            opt.zero_grad(set_to_none=True)
         opt.begin_capture()
         opt.refresh_hyper()                     # allocates the device scalars; the step counts it adds are undone below
         undone = set()
@@ -247,10 +252,18 @@ class Trainer:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         self._capturing = True
+        # with a process group: RCCL's watchdog thread keeps querying the events of the warm-up steps' collectives; under the
+        # default "global" capture mode such a query from another thread aborts the capture (hipErrorCapturedEvent)
+        mode = {} if self.reducer is None else {"capture_error_mode": "thread_local"}
         try:
-            with torch.cuda.graph(g, stream=self._graph_stream):
+            with torch.cuda.graph(g, stream=self._graph_stream, **mode):
                 outputs, losses = self.process_batch(self._static_in)
+                # the reducer's post-accumulate hooks run here, inside the capture: each full bucket is gathered by one
+                # multi-tensor copy and its all-reduce is enqueued on RCCL's stream — a branch of the graph that runs next to
+                # the remaining backward kernels; finish() joins the branches before Adam reads the averaged buckets
                 self._backward(losses["loss"])
+                if self.reducer is not None:
+                    self.reducer.finish()
                 opt.step()
         finally:
             self._capturing = False

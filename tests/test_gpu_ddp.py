@@ -49,6 +49,11 @@ def test_one_rank_rccl_reducer_trains_like_single_process():
     dist = _run(dict(DIST, MASTER_PORT="29541"), ["--sqd_no_graph"])          # eager: hooks overlap the all-reduces with backward
     assert not plain["reducer"] and dist["reducer"] and dist["grad_is_bucket_view"] and not dist["graph"]
     _same_training(plain, dist)
-    graphed = _run(dict(DIST, MASTER_PORT="29542"), ["--sqd_graph_ddp"])                           # forward+backward replayed as a hipGraph, then all-reduce + Adam
+    # default multi-rank mode: ONE hipGraph holding forward, backward, the bucket gathers + RCCL all-reduces launched by the
+    # autograd hooks (graph branches next to the rest of backward) and Adam
+    graphed = _run(dict(DIST, MASTER_PORT="29542"), [])
     assert graphed["reducer"] and graphed["graph"] and graphed["grad_is_bucket_view"]
     _same_training(plain, graphed)
+    post = _run(dict(DIST, MASTER_PORT="29543"), ["--sqd_graph_ddp", "post"])    # forward+backward as a hipGraph, then all-reduce + Adam
+    assert post["reducer"] and post["graph"] and post["grad_is_bucket_view"]
+    _same_training(plain, post)

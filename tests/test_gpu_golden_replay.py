@@ -162,7 +162,7 @@ def test_g15_g16_trainer_steps(golden, kind):
         traj.append(float(losses["loss"]))
     np.testing.assert_allclose(traj, g16["losses"], rtol=1e-4)
     # (ResNet-50: 53 layers of BatchNorm'd convolutions between the stem and the loss — 1.1 % of the 9408 stem weights have a
-    #  gradient within fp32 summation noise of zero and take Adam's +-lr step the other way; ResNet-18: 0.04 %)
-    adam_close(tr.models["encoder"].encoder.encoder.conv1.weight, g16["enc_conv1_after"], frac=2e-3 if kind == "res18" else 2.5e-2)
+    #  gradient within fp32 summation noise of zero and take Adam's +-lr step the other way; ResNet-18: 0.04 - 0.2 %, varying with the summation order of the kernels)
+    adam_close(tr.models["encoder"].encoder.encoder.conv1.weight, g16["enc_conv1_after"], frac=5e-3 if kind == "res18" else 2.5e-2)
     adam_close(tr.models["pose"].pose_conv.weight, g16["pose_conv_after"])
     adam_close(tr.models["depth"].conv3x3.weight, g16["depth_conv3x3_after"])

@@ -201,3 +201,67 @@ def test_grad_bucket_reducer_gloo_world2():
     (0.5 * (model(data[:2]).square().mean() + model(data[2:]).square().mean())).backward()
     want = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).numpy()
     np.testing.assert_allclose(g0[0], want, rtol=1e-5, atol=1e-7)
+
+
+def _trainer_params_worker(rank, world, port, q):
+    """The reducer on the Trainer's own parameter set: ResNet-18 encoder-decoder (with the never-used torchvision `fc`), the QTR
+    head and PoseCNN, filters channels-last as the Trainer keeps them.  Gradients come from a CPU autograd pass over a
+    surrogate loss (the kernels of the hot path need the GPU; the bucket logic does not)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    sys.path.insert(0, PRODUCT)
+    import networks
+    from sqd import ddp
+    ddp.init_from_env("gloo")
+    torch.manual_seed(10 + rank)
+    models = [networks.LiteResnetEncoderDecoder(model_dim=16),
+              networks.Lite_Depth_Decoder_QueryTr(in_channels=16, patch_size=8, dim_out=24, embedding_dim=16, query_nums=12, num_heads=4,
+                                                  min_val=0.001, max_val=80.0),
+              networks.PoseCNN(2)]
+    for m in models:
+        m.to(memory_format=torch.channels_last)
+    params = [p for m in models for p in m.parameters()]
+    names = [n for m in models for n, _ in m.named_parameters()]
+    red = ddp.GradBucketReducer(params, bucket_mb=2.0)
+    red.broadcast_parameters(models)
+    unused = {i for i, n in enumerate(names) if n.startswith("encoder.encoder.fc.")}
+    assert len(unused) == 2
+    coef = [torch.full_like(p, float(rank + 1) * (1 + i % 3)) for i, p in enumerate(params)]
+    hist = []
+    for step in range(3):
+        red.zero_grad()
+        loss = sum((p * c).sum() for i, (p, c) in enumerate(zip(params, coef)) if i not in unused) * (step + 1)
+        loss.backward()
+        red.finish()
+        hist.append([None if p.grad is None else p.grad.clone() for p in params])
+    conv4d = next(i for i, p in enumerate(params) if p.dim() == 4 and p.shape[2] == 3 and p.shape[1] > 1)
+    info = {"nbuckets": len(red.buckets), "in_buckets": sum(len(b) for b in red.buckets), "nparams": len(params),
+            "fc_grad_none": all(hist[-1][i] is None for i in unused),
+            "view_strides_ok": params[conv4d].grad.stride() == params[conv4d].stride() and not params[conv4d].is_contiguous(),
+            "is_view": params[conv4d].grad._base is not None,
+            "w0": float(params[0].detach().double().sum())}
+    vals = [[None if g is None else float(g.double().mean()) for g in h] for h in hist]
+    q.put((rank, info, vals))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reducer_on_trainer_parameter_set_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_trainer_params_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+    (_, i0, v0), (_, i1, v1) = res
+    assert i0 == i1 or {k: v for k, v in i0.items() if k != "w0"} == {k: v for k, v in i1.items() if k != "w0"}
+    assert i0["w0"] == i1["w0"]                                   # rank 0's weights were broadcast
+    assert i0["nbuckets"] >= 2 and i0["in_buckets"] == i0["nparams"] - 2 and i0["fc_grad_none"]     # the unused fc stays out of the buckets
+    assert i0["view_strides_ok"] and i0["is_view"]                # channels-last filters keep their layout inside the bucket
+    for step, (a, b) in enumerate(zip(v0, v1)):
+        assert a == b                                             # both ranks hold the same averaged gradients
+        for i, g in enumerate(a):
+            if g is not None:                                     # mean of rank coefficients 1x and 2x = 1.5x, times the step factor
+                assert abs(g - 1.5 * (1 + i % 3) * (step + 1)) < 1e-5, (step, i, g)
