@@ -124,20 +124,28 @@ def upsample_disp(disp: torch.Tensor, H: int, W: int) -> torch.Tensor:
 
 def generate_images_pred(disp: torch.Tensor, poses: Dict[int, Tuple[torch.Tensor, torch.Tensor]],
                          K: torch.Tensor, inv_K: torch.Tensor, colors: Dict[int, torch.Tensor],
-                         frame_ids: Sequence[int], H: int, W: int) -> Dict:
-    """reference trainer.py:386-439, posecnn / mono branch (scale 0 only).
+                         frame_ids: Sequence[int], H: int, W: int, stereo_T: torch.Tensor = None,
+                         use_stereo: bool = False) -> Dict:
+    """reference trainer.py:386-439, posecnn branch (scale 0 only).
 
-    poses[f] = (axisangle [B,1,1,3], translation [B,1,1,3]).  colors[f] = source image [B,3,H,W].
+    poses[f] = (axisangle [B,1,1,3], translation [B,1,1,3]) for the temporal frames; frame id "s" (the other stereo camera)
+    takes T = stereo_T (:406-407).  use_stereo switches the mean-inverse-depth scaling of the translation off (:412).
+    colors[f] = source image [B,3,H,W].
     Returns dict with ("depth",0,0), ("sample",f,0), ("color",f,0), ("color_identity",f,0), ("T",f)."""
     out = {}
     depth = upsample_disp(disp, H, W)
     out[("depth", 0, 0)] = depth
     for f in frame_ids[1:]:
-        axisangle, translation = poses[f]
-        inv_depth = 1 / depth                                             # :417
-        mean_inv_depth = inv_depth.mean(3, True).mean(2, True)            # :418
-        T = transformation_from_parameters(axisangle[:, 0], translation[:, 0] * mean_inv_depth[:, 0],
-                                           f < 0)                         # :420-421
+        if f == "s":
+            T = stereo_T                                                       # :406-407
+        else:
+            axisangle, translation = poses[f]
+            T = transformation_from_parameters(axisangle[:, 0], translation[:, 0], f < 0)   # cam_T_cam, :336-337 / :409
+            if not use_stereo:                                                 # :412
+                inv_depth = 1 / depth                                          # :417
+                mean_inv_depth = inv_depth.mean(3, True).mean(2, True)         # :418
+                T = transformation_from_parameters(axisangle[:, 0], translation[:, 0] * mean_inv_depth[:, 0],
+                                                   f < 0)                      # :420-421
         cam = backproject_depth(depth, inv_K)                             # :423
         grid = project_3d(cam, K, T, H, W)                                # :425
         out[("T", f)] = T
@@ -215,10 +223,11 @@ def compute_losses(disp: torch.Tensor, target: torch.Tensor, warped: Dict[int, t
             "identity": ident, "idxs": idxs, "to_optimise": to_optimise, "smooth": sm}
 
 
-def photometric_chain(disp, poses, K, inv_K, colors, frame_ids, noise, H, W, disparity_smoothness=1e-3):
+def photometric_chain(disp, poses, K, inv_K, colors, frame_ids, noise, H, W, disparity_smoothness=1e-3, stereo_T=None,
+                      use_stereo=False):
     """generate_images_pred + compute_losses in one call (what process_batch does after the networks,
     reference trainer.py:296-297)."""
-    out = generate_images_pred(disp, poses, K, inv_K, colors, frame_ids, H, W)
+    out = generate_images_pred(disp, poses, K, inv_K, colors, frame_ids, H, W, stereo_T, use_stereo)
     warped = {f: out[("color", f, 0)] for f in frame_ids[1:]}
     sources = {f: colors[f] for f in frame_ids[1:]}
     losses = compute_losses(disp, colors[0], warped, sources, frame_ids, noise, H, W, disparity_smoothness)
@@ -512,17 +521,24 @@ class RefTrainStep:
     on the CPU RNG)."""
 
     def __init__(self, encoder, depth, pose, frame_ids=(0, -1, 1), H=192, W=640, lr=1e-4,
-                 disparity_smoothness=1e-3):
+                 disparity_smoothness=1e-3, use_stereo=False, diff_lr=False):
         self.models = {"encoder": encoder, "depth": depth, "pose": pose}
         self.frame_ids, self.H, self.W = list(frame_ids), H, W
+        self.use_stereo = use_stereo                     # frame_ids then end with "s" (reference trainer.py:52-53)
         self.smooth_w = disparity_smoothness
         params = [p for m in self.models.values() for p in m.parameters()]
-        self.optim = torch.optim.Adam(params, lr)
+        if diff_lr:                                      # reference trainer.py:128-131: the pose network at lr / 10
+            self.optim = torch.optim.Adam([{"params": list(pose.parameters()), "lr": lr / 10},
+                                           {"params": list(encoder.parameters()) + list(depth.parameters()), "lr": lr}], lr)
+        else:
+            self.optim = torch.optim.Adam(params, lr)
 
     def predict_poses(self, inputs):
         """reference trainer.py:301-337 (pairs / posecnn)."""
         poses = {}
         for f in self.frame_ids[1:]:
+            if f == "s":                                                  # :317
+                continue
             pair = [inputs[("color_aug", f, 0)], inputs[("color_aug", 0, 0)]] if f < 0 else \
                    [inputs[("color_aug", 0, 0)], inputs[("color_aug", f, 0)]]
             poses[f] = self.models["pose"](torch.cat(pair, 1))
@@ -534,9 +550,12 @@ class RefTrainStep:
         poses = self.predict_poses(inputs)                               # :294
         colors = {f: inputs[("color", f, 0)] for f in self.frame_ids}
         chain = photometric_chain(outputs[("disp", 0)], poses, inputs[("K", 0)], inputs[("inv_K", 0)],
-                                  colors, self.frame_ids, noise, self.H, self.W, self.smooth_w)
+                                  colors, self.frame_ids, noise, self.H, self.W, self.smooth_w,
+                                  inputs.get("stereo_T"), self.use_stereo)
         outputs.update(chain)
         for f in self.frame_ids[1:]:
+            if f == "s":
+                continue
             outputs[("axisangle", 0, f)], outputs[("translation", 0, f)] = poses[f]
             outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(
                 poses[f][0][:, 0], poses[f][1][:, 0], invert=(f < 0))   # :336-337

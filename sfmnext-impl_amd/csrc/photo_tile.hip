@@ -1,4 +1,4 @@
-// photo_tile.hip — the fused warp + SSIM forward of the photometric chain (S = 2 source frames), tile edition.
+// photo_tile.hip — the fused warp + SSIM forward of the photometric chain (source frames in pairs), tile edition.
 //
 // replaces (reference): BackprojectDepth -> Project3D -> grid_sample (layers.py:186-258, trainer.py:420-435), SSIM + L1
 // (layers.py:13-46, trainer.py:441-453) and the per-pixel minimum / auto-mask (trainer.py:474-532) in ONE launch.
@@ -177,6 +177,16 @@ __device__ __forceinline__ void accumulate(Sums &A, const Sums &P) {
     }
 }
 
+// A launch handles a PAIR of source frames (the two halves of the packed-math registers).  S = 2 (frame_ids [0,-1,1]) is one
+// launch; S = 3 (--use_stereo: frame_ids [0,-1,1,"s"], reference trainer.py:52-53) runs pairs (0,1) and (2,2): the running
+// per-pixel minimum and its argmin travel between the launches through the `sel` / `idx` outputs, in the candidate order of
+// torch.cat + torch.min (identity_0..S-1, reproj_0..S-1 — first minimum wins).
+struct PairPass {
+    int s0, s1;        // source indices of the .x / .y halves (s1 == s0: an odd source count's last pass)
+    int S;             // number of source frames
+    int first, last;   // first pass: start from the identity maps; last pass: emit identity_selection and the loss partial
+};
+
 // MODE 0: identity maps ("pred" = the source frames themselves; output = loss + 1e-5 * noise)    trainer.py:480-487,514-517
 // MODE 1: fused warp + SSIM + L1 + per-pixel min / auto-mask                                     trainer.py:386-532
 // MODE 2: d loss / d (window sums) of the winning source ("coefficient planes") for the backward, from the stored warps
@@ -254,7 +264,7 @@ __device__ __forceinline__ void ssim_l1(const Sums &S, const Raw &ctr, SsimOut &
 }
 
 template <int MODE, int KIND>
-__device__ __forceinline__ void finish_row(const sqd_photo_args &a, const float *noise, const Ctx<MODE> &k, Sums &S, const Raw &ctr,
+__device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPass &pp, const float *noise, const Ctx<MODE> &k, Sums &S, const Raw &ctr,
                                            bool edge, int b, int yo, bool own, float &loss_acc) {
     {
         float s0 = S.St.x, s1 = S.St.y, s2 = S.St.z;
@@ -268,40 +278,58 @@ __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const float 
     if (!own) return;
     const unsigned HW = k.HW;
     const unsigned qo = (unsigned)(yo * k.W + k.x);
+    const int NS = pp.S;
     if (MODE == 0) {
-        float *out = a.sel + (size_t)b * 2 * HW;                       // (the identity maps travel through `sel`)
-        const float *nz = noise ? noise + (size_t)b * 2 * HW : nullptr;
-        stg(out, qo * 4u, o.loss.x + (nz ? ldg(nz, qo * 4u) : 0.f) * 0.00001f);              // trainer.py:514-517
-        stg(out, (qo + HW) * 4u, o.loss.y + (nz ? ldg(nz, (qo + HW) * 4u) : 0.f) * 0.00001f);
+        float *out = a.sel + (size_t)b * NS * HW;                      // (the identity maps travel through `sel`)
+        const float *nz = noise ? noise + (size_t)b * NS * HW : nullptr;
+        const unsigned q0 = qo + (unsigned)pp.s0 * HW, q1 = qo + (unsigned)pp.s1 * HW;
+        stg(out, q0 * 4u, o.loss.x + (nz ? ldg(nz, q0 * 4u) : 0.f) * 0.00001f);              // trainer.py:514-517
+        if (pp.s1 != pp.s0) stg(out, q1 * 4u, o.loss.y + (nz ? ldg(nz, q1 * 4u) : 0.f) * 0.00001f);
     } else if (MODE == 1) {
-        // combined = [identity_0, identity_1, reproj_0, reproj_1]; torch.min(dim 1): first minimum wins    trainer.py:519-526
-        const float *idm = a.identity + (size_t)b * 2 * HW;
-        float best = ldg(idm, qo * 4u);
-        int bi = 0;
-        const float v1 = ldg(idm, (qo + HW) * 4u);
-        if (v1 < best) { best = v1; bi = 1; }
-        if (o.loss.x < best) { best = o.loss.x; bi = 2; }
-        if (o.loss.y < best) { best = o.loss.y; bi = 3; }
-        if (a.reproj) {
-            a.reproj[(size_t)b * 2 * HW + qo] = o.loss.x;
-            a.reproj[(size_t)b * 2 * HW + HW + qo] = o.loss.y;
+        // combined = [identity_0..S-1, reproj_0..S-1]; torch.min(dim 1): first minimum wins            trainer.py:519-526
+        float best;
+        int bi;
+        if (pp.first) {
+            const float *idm = a.identity + (size_t)b * NS * HW;
+            best = ldg(idm, qo * 4u);
+            bi = 0;
+#pragma unroll
+            for (int i = 1; i < SQD_MAX_SOURCES; ++i)
+                if (i < NS) {
+                    const float v = ldg(idm, (qo + i * HW) * 4u);
+                    if (v < best) { best = v; bi = i; }
+                }
+        } else {                                                       // the running minimum of the earlier pairs
+            best = a.sel[(size_t)b * HW + qo];
+            bi = a.idx[(size_t)b * HW + qo];
         }
-        loss_acc += best;
-        if (a.sel) a.sel[(size_t)b * HW + qo] = bi > 1 ? 1.f : 0.f;    // trainer.py:529-530
+        if (o.loss.x < best) { best = o.loss.x; bi = NS + pp.s0; }
+        if (o.loss.y < best) { best = o.loss.y; bi = NS + pp.s1; }
+        if (a.reproj) {
+            a.reproj[((size_t)b * NS + pp.s0) * HW + qo] = o.loss.x;
+            a.reproj[((size_t)b * NS + pp.s1) * HW + qo] = o.loss.y;
+        }
+        if (pp.last) {
+            loss_acc += best;
+            if (a.sel) a.sel[(size_t)b * HW + qo] = bi >= NS ? 1.f : 0.f;   // trainer.py:529-530
+        } else {
+            a.sel[(size_t)b * HW + qo] = best;
+        }
         if (a.idx) a.idx[(size_t)b * HW + qo] = (uint8_t)bi;
     } else {
         const int bi = a.idx[(size_t)b * HW + qo];
-        if (bi >= 2) {
+        if (bi == NS + pp.s0 || bi == NS + pp.s1) {
             float *co = a.coef + (size_t)b * 9 * HW;
+            const bool first = bi == NS + pp.s0;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) stg(co, (qo + j * HW) * 4u, (bi == 2 ? o.g0[j] : o.g1[j]) * (0.85f / 3.f));
+            for (int j = 0; j < 9; ++j) stg(co, (qo + j * HW) * 4u, (first ? o.g0[j] : o.g1[j]) * (0.85f / 3.f));
         }
     }
 }
 
 // phase 2 for the output rows of one wave: pairs (j, j+1) of tile rows share six of their seven window rows
 template <int MODE, int KIND>
-__device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const float *noise, const Ctx<MODE> &k, bool edge, int b,
+__device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const PairPass &pp, const float *noise, const Ctx<MODE> &k, bool edge, int b,
                                           int wave, int TR, int own_rows, bool own_col, float &loss_acc) {
     for (int p = wave; 2 * p < own_rows; p += 4) {
         const int j = 2 * p;                         // tile rows j .. j+7 feed the outputs y0+j (centre j+3) and y0+j+1 (centre j+4)
@@ -326,7 +354,7 @@ __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const float *
             Sums S;
             products(R, S);
             accumulate(S, core);
-            finish_row<MODE, KIND>(a, noise, k, S, ctr, edge, b, k.y0 + j + o, own_col && j + o < own_rows, loss_acc);
+            finish_row<MODE, KIND>(a, pp, noise, k, S, ctr, edge, b, k.y0 + j + o, own_col && j + o < own_rows, loss_acc);
         }
     }
 }
@@ -411,7 +439,7 @@ __device__ __forceinline__ void gather_taps(const Cell &c, const float *__restri
 }
 
 // bilinear blend, the tile's LDS row, and — for cells the tile owns — sample / warped / taps in HBM
-__device__ __forceinline__ void finish_cell(const sqd_photo_args &a, const Cell &c, const v2f t[3][4], v2f *wl, int r, int lane,
+__device__ __forceinline__ void finish_cell(const sqd_photo_args &a, const PairPass &pp, const Cell &c, const v2f t[3][4], v2f *wl, int r, int lane,
                                             bool col_ok, bool own, int b, unsigned HW, unsigned off) {
     v2f wv[3];
 #pragma unroll
@@ -425,16 +453,17 @@ __device__ __forceinline__ void finish_cell(const sqd_photo_args &a, const Cell 
     }
     if (own) {
         const size_t q = (size_t)b * HW + off;
-        if (a.sample[0]) *reinterpret_cast<float2 *>(a.sample[0] + q * 2) = make_float2(c.gx.x, c.gy.x);
-        if (a.sample[1]) *reinterpret_cast<float2 *>(a.sample[1] + q * 2) = make_float2(c.gx.y, c.gy.y);
-        if (a.x0y0[0]) *reinterpret_cast<int2 *>(a.x0y0[0] + q * 2) = make_int2(c.x00, c.y00);
-        if (a.x0y0[1]) *reinterpret_cast<int2 *>(a.x0y0[1] + q * 2) = make_int2(c.x01, c.y01);
-        if (a.warped[0]) {
-            float *w0 = a.warped[0] + (size_t)b * 3 * HW, *w1 = a.warped[1] + (size_t)b * 3 * HW;
+        const bool two = pp.s1 != pp.s0;
+        if (a.sample[pp.s0]) *reinterpret_cast<float2 *>(a.sample[pp.s0] + q * 2) = make_float2(c.gx.x, c.gy.x);
+        if (two && a.sample[pp.s1]) *reinterpret_cast<float2 *>(a.sample[pp.s1] + q * 2) = make_float2(c.gx.y, c.gy.y);
+        if (a.x0y0[pp.s0]) *reinterpret_cast<int2 *>(a.x0y0[pp.s0] + q * 2) = make_int2(c.x00, c.y00);
+        if (two && a.x0y0[pp.s1]) *reinterpret_cast<int2 *>(a.x0y0[pp.s1] + q * 2) = make_int2(c.x01, c.y01);
+        if (a.warped[pp.s0]) {
+            float *w0 = a.warped[pp.s0] + (size_t)b * 3 * HW, *w1 = a.warped[pp.s1] + (size_t)b * 3 * HW;
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) {
                 stg(w0, (off + ch * HW) * 4u, wv[ch].x);
-                stg(w1, (off + ch * HW) * 4u, wv[ch].y);
+                if (two) stg(w1, (off + ch * HW) * 4u, wv[ch].y);
             }
         }
     }
@@ -442,7 +471,7 @@ __device__ __forceinline__ void finish_cell(const sqd_photo_args &a, const Cell 
 
 // (4 workgroups of 4 waves per CU: the register allocator is held to 128 VGPRs; the kernel needs 118)
 template <int MODE>
-__global__ __launch_bounds__(256, 4) void photo_tile_kernel(sqd_photo_args a, const float *__restrict__ noise, int TR, int nsx,
+__global__ __launch_bounds__(256, 4) void photo_tile_kernel(sqd_photo_args a, PairPass pp, const float *__restrict__ noise, int TR, int nsx,
                                                           int nsy, int ntiles, int nblk8) {
     extern __shared__ v2f wl[];                       // MODE 1: [TR + 6][3][64] (source 0, source 1) warped colours
     const int lane = threadIdx.x & 63;
@@ -466,8 +495,8 @@ __global__ __launch_bounds__(256, 4) void photo_tile_kernel(sqd_photo_args a, co
         // ---------------------------------------------------------------- phase 1: warp every cell of the tile once
         const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
         const float *__restrict__ dep = a.depth + (size_t)b * HW;
-        const float *__restrict__ src0 = a.sources[0] + (size_t)b * 3 * HW;
-        const float *__restrict__ src1 = a.sources[1] + (size_t)b * 3 * HW;
+        const float *__restrict__ src0 = a.sources[pp.s0] + (size_t)b * 3 * HW;
+        const float *__restrict__ src1 = a.sources[pp.s1] + (size_t)b * 3 * HW;
         float ik[9];
         v2f P[12];                       // (source 0, source 1) projection matrices
 #pragma unroll
@@ -475,7 +504,7 @@ __global__ __launch_bounds__(256, 4) void photo_tile_kernel(sqd_photo_args a, co
 #pragma unroll
             for (int j = 0; j < 3; ++j) ik[i * 3 + j] = a.inv_K[(size_t)b * 16 + i * 4 + j];
 #pragma unroll
-        for (int j = 0; j < 12; ++j) P[j] = v2f{a.P[((size_t)b * 2 + 0) * 12 + j], a.P[((size_t)b * 2 + 1) * 12 + j]};
+        for (int j = 0; j < 12; ++j) P[j] = v2f{a.P[((size_t)b * pp.S + pp.s0) * 12 + j], a.P[((size_t)b * pp.S + pp.s1) * 12 + j]};
         const v2f rW = splat(rcp_refined(wm1)), rH = splat(rcp_refined(hm1));
         const int xc = min(max(xr, 0), W - 1);             // (lanes beyond a narrow image compute a valid column and store zeros)
         const float fx = (float)xc;
@@ -489,7 +518,7 @@ __global__ __launch_bounds__(256, 4) void photo_tile_kernel(sqd_photo_args a, co
             project_cell(cA, dA, fx, (float)yA, ik, P, rW, rH, wm1, hm1, W, H);
             v2f tA[3][4];
             gather_taps(cA, src0, src1, HW, tA);
-            finish_cell(a, cA, tA, wl, r, lane, col_ok, own_col && r >= 3 && r < own_rows + 3, b, HW, offA);
+            finish_cell(a, pp, cA, tA, wl, r, lane, col_ok, own_col && r >= 3 && r < own_rows + 3, b, HW, offA);
         }
         __syncthreads();
     }
@@ -498,8 +527,8 @@ __global__ __launch_bounds__(256, 4) void photo_tile_kernel(sqd_photo_args a, co
     Ctx<MODE> k;
     const unsigned img_bytes = 3u * HW * 4u;
     k.tgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tgt), 0, img_bytes, 0x00020000);
-    const float *q0 = MODE == 0 ? a.sources[0] : MODE == 2 ? a.warped[0] : a.target;
-    const float *q1 = MODE == 0 ? a.sources[1] : MODE == 2 ? a.warped[1] : a.target;
+    const float *q0 = MODE == 0 ? a.sources[pp.s0] : MODE == 2 ? a.warped[pp.s0] : a.target;
+    const float *q1 = MODE == 0 ? a.sources[pp.s1] : MODE == 2 ? a.warped[pp.s1] : a.target;
     k.p0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(q0 + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
     k.p1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(q1 + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
     k.wl = wl;
@@ -507,12 +536,12 @@ __global__ __launch_bounds__(256, 4) void photo_tile_kernel(sqd_photo_args a, co
     k.xoff = col_ok ? (unsigned)xr * 4u : 0x80000000u;
     float loss_acc = 0.f;
     if (sx.kind == LEFT)
-        ssim_rows<MODE, LEFT>(a, noise, k, lane >= 1 && lane <= 3, b, wave, TR, own_rows, own_col, loss_acc);
+        ssim_rows<MODE, LEFT>(a, pp, noise, k, lane >= 1 && lane <= 3, b, wave, TR, own_rows, own_col, loss_acc);
     else if (sx.kind == RIGHT)
-        ssim_rows<MODE, RIGHT>(a, noise, k, lane >= 60 && lane <= 62, b, wave, TR, own_rows, own_col, loss_acc);
+        ssim_rows<MODE, RIGHT>(a, pp, noise, k, lane >= 60 && lane <= 62, b, wave, TR, own_rows, own_col, loss_acc);
     else
-        ssim_rows<MODE, INTERIOR>(a, noise, k, false, b, wave, TR, own_rows, own_col, loss_acc);
-    if (MODE == 1 && a.loss_part) {
+        ssim_rows<MODE, INTERIOR>(a, pp, noise, k, false, b, wave, TR, own_rows, own_col, loss_acc);
+    if (MODE == 1 && a.loss_part && pp.last) {
         loss_acc = wave_sum(loss_acc);
         if (lane == 0) a.loss_part[tile * 4 + wave] = loss_acc;
     }
@@ -539,11 +568,14 @@ void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hi
     const int ntiles = a.B * nsx * nsy;
     const int nblk8 = (ntiles + 7) / 8;
     const dim3 grid(nblk8 * 8), block(256);
-    if (mode == 0)
-        hipLaunchKernelGGL((photo_tile_kernel<0>), grid, block, 0, stream, a, noise, TR, nsx, nsy, ntiles, nblk8);
-    else if (mode == 1)
-        hipLaunchKernelGGL((photo_tile_kernel<1>), grid, block, (TR + 6) * 3 * 64 * 8, stream, a, noise, TR, nsx, nsy, ntiles, nblk8);
-    else
-        hipLaunchKernelGGL((photo_tile_kernel<2>), grid, block, 0, stream, a, noise, TR, nsx, nsy, ntiles, nblk8);
+    for (int k = 0; 2 * k < a.S; ++k) {                  // one launch per pair of source frames
+        const PairPass pp = {2 * k, 2 * k + 1 < a.S ? 2 * k + 1 : 2 * k, a.S, k == 0, 2 * k + 2 >= a.S};
+        if (mode == 0)
+            hipLaunchKernelGGL((photo_tile_kernel<0>), grid, block, 0, stream, a, pp, noise, TR, nsx, nsy, ntiles, nblk8);
+        else if (mode == 1)
+            hipLaunchKernelGGL((photo_tile_kernel<1>), grid, block, (TR + 6) * 3 * 64 * 8, stream, a, pp, noise, TR, nsx, nsy, ntiles, nblk8);
+        else
+            hipLaunchKernelGGL((photo_tile_kernel<2>), grid, block, 0, stream, a, pp, noise, TR, nsx, nsy, ntiles, nblk8);
+    }
 }
 }  // namespace sqd

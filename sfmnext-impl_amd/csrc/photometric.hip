@@ -60,8 +60,8 @@ __device__ __forceinline__ int refl_mult(int r, int q, int n) {
     return m;
 }
 
-template <int S>
 __global__ __launch_bounds__(256) void photo_bwd_kernel(sqd_photo_bwd_args a, int TH, int nsx, int nsy, int ntasks) {
+    const int S = a.S;
     const int lane = threadIdx.x & 63;
     const int task = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     if (task >= ntasks) return;
@@ -86,8 +86,8 @@ __global__ __launch_bounds__(256) void photo_bwd_kernel(sqd_photo_bwd_args a, in
     const float *__restrict__ coef = a.coef + (size_t)b * 9 * HW;
     const uint8_t *__restrict__ idx = a.idx + (size_t)b * HW;
     const float *__restrict__ tgt = a.target + (size_t)b * 3 * HW;
-    const float *__restrict__ src = (s == 0 ? a.sources[0] : a.sources[1]) + (size_t)b * 3 * HW;
-    const float *__restrict__ smp = (s == 0 ? a.sample[0] : a.sample[1]) + (size_t)b * HW * 2;
+    const float *__restrict__ src = a.sources[s] + (size_t)b * 3 * HW;
+    const float *__restrict__ smp = a.sample[s] + (size_t)b * HW * 2;
     const float *__restrict__ dep = a.depth + (size_t)b * HW;
     float *__restrict__ gdep = a.g_depth + (size_t)b * a.g_depth_img_stride + (size_t)s * HW;
     const __amdgpu_buffer_rsrc_t coef_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(coef), 0, (unsigned)(9 * HW) * 4u, 0x00020000);
@@ -252,7 +252,7 @@ int pick_th_bwd(int th, int B, int S, int H, int W) {
 }
 
 int check_shape(const char *who, int B, int S, int H, int W, int TH) {
-    SQD_CHECK_ARG(S == 2, "%s: S=%d unsupported (2 source frames: frame_ids [0,-1,1])", who, S);
+    SQD_CHECK_ARG(S >= 1 && S <= SQD_MAX_SOURCES, "%s: S=%d source frames unsupported (1..%d)", who, S, SQD_MAX_SOURCES);
     SQD_CHECK_ARG(B > 0 && H >= 8 && W >= 8, "%s: bad shape B=%d H=%d W=%d", who, B, H, W);
     SQD_CHECK_ARG((long long)B * 9 * H * W < (1ll << 31), "%s: tensor too large for 32-bit pixel offsets", who);
     SQD_CHECK_ARG(TH >= 1 && TH <= 4096, "%s: rows_per_task=%d out of range", who, TH);
@@ -270,9 +270,10 @@ extern "C" int sqd_photo_bwd_ntasks(int B, int S, int H, int W, int rows_per_tas
 }
 
 extern "C" int sqd_photo_fwd(const sqd_photo_args *a) {
-    SQD_CHECK_ARG(a && a->depth && a->inv_K && a->P && a->target && a->sources[0] && a->sources[1] && a->identity,
-                  "sqd_photo_fwd: null input");
+    SQD_CHECK_ARG(a && a->depth && a->inv_K && a->P && a->target && a->identity, "sqd_photo_fwd: null input");
     if (check_shape("sqd_photo_fwd", a->B, a->S, a->H, a->W, 8)) return SQD_EINVAL;
+    for (int s = 0; s < a->S; ++s) SQD_CHECK_ARG(a->sources[s], "sqd_photo_fwd: null source %d", s);
+    SQD_CHECK_ARG(a->S <= 2 || (a->sel && a->idx), "sqd_photo_fwd: more than 2 source frames need the sel and idx outputs (running minimum)");
     (void)hipGetLastError();
     sqd::launch_photo_tile(*a, nullptr, 1, (hipStream_t)a->stream);
     SQD_CHECK_LAUNCH("sqd_photo_fwd");
@@ -317,15 +318,15 @@ extern "C" int sqd_photo_coef(const float *target, const float *const *warped, c
 }
 
 extern "C" int sqd_photo_bwd(const sqd_photo_bwd_args *a) {
-    SQD_CHECK_ARG(a && a->depth && a->inv_K && a->P && a->target && a->sources[0] && a->sources[1] && a->sample[0] &&
-                      a->sample[1] && a->coef && a->idx && a->g_depth && a->g_P_part, "sqd_photo_bwd: null pointer");
+    SQD_CHECK_ARG(a && a->depth && a->inv_K && a->P && a->target && a->coef && a->idx && a->g_depth && a->g_P_part, "sqd_photo_bwd: null pointer");
+    for (int s = 0; a->S <= SQD_MAX_SOURCES && s < a->S; ++s) SQD_CHECK_ARG(a->sources[s] && a->sample[s], "sqd_photo_bwd: null source / sample %d", s);
     const int TH = pick_th_bwd(a->rows_per_task, a->B, a->S, a->H, a->W);
     if (check_shape("sqd_photo_bwd", a->B, a->S, a->H, a->W, TH)) return SQD_EINVAL;
     SQD_CHECK_ARG(a->g_depth_img_stride >= (int64_t)a->S * a->H * a->W, "sqd_photo_bwd: g_depth_img_stride too small");
     const int nsx = (a->W + SQD_STRIP_COLS - 1) / SQD_STRIP_COLS, nsy = (a->H + TH - 1) / TH;
     const int ntasks = a->B * a->S * nsx * nsy;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((photo_bwd_kernel<2>), dim3((ntasks + 3) / 4), dim3(256), 0, (hipStream_t)a->stream, *a, TH, nsx,
+    hipLaunchKernelGGL(photo_bwd_kernel, dim3((ntasks + 3) / 4), dim3(256), 0, (hipStream_t)a->stream, *a, TH, nsx,
                        nsy, ntasks);
     SQD_CHECK_LAUNCH("sqd_photo_bwd");
     return SQD_OK;

@@ -1,6 +1,6 @@
 """Synthetic KITTI-shaped frames with the dict schema of the reference's MonoDataset.__getitem__
 (reference datasets/mono_dataset.py:114-201): ("color", f, 0), ("color_aug", f, 0) for every frame
-id, ("K", 0), ("inv_K", 0), "depth_gt".
+id, ("K", 0), ("inv_K", 0), "depth_gt", and — with "s" among the frame ids — "stereo_T".
 
 Each sample is a smooth random texture (a few low-frequency sinusoids + 5 % white noise); the -1/+1
 frames are the same texture seen through a known small camera motion over a known smooth depth
@@ -50,8 +50,14 @@ def make_sample(index, height, width, frame_ids=(0, -1, 1), with_gt=True):
         if f == 0:
             img = base
         else:
-            t = (torch.rand(3, generator=gen) - 0.5) * 0.6 * float(f)       # metres
-            w = (torch.rand(3, generator=gen) - 0.5) * 0.02                  # radians (small-angle rotation)
+            if f == "s":                        # the other camera of the stereo pair: pure baseline shift (mono_dataset.py:193-199, side "l")
+                t, w = torch.tensor([-0.1, 0.0, 0.0]), torch.zeros(3)
+                stereo_T = torch.eye(4)
+                stereo_T[0, 3] = -0.1
+                sample["stereo_T"] = stereo_T
+            else:
+                t = (torch.rand(3, generator=gen) - 0.5) * 0.6 * float(f)       # metres
+                w = (torch.rand(3, generator=gen) - 0.5) * 0.02                  # radians (small-angle rotation)
             R = torch.eye(3) + torch.tensor([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
             p = K[:3, :3] @ (R @ cam + t.reshape(3, 1))
             u = (p[0] / p[2]).reshape(height, width) / (width - 1) * 2 - 1
@@ -75,7 +81,7 @@ class SyntheticKITTIDataset(Dataset):
         return self.length
 
     def __getitem__(self, index):
-        return make_sample(index + self.offset, self.height, self.width, [f for f in self.frame_ids if f != "s"], self.with_gt)
+        return make_sample(index + self.offset, self.height, self.width, self.frame_ids, self.with_gt)
 
 
 def synthetic_batch(batch_size, height, width, frame_ids=(0, -1, 1), start=0, device=None, with_gt=False):

@@ -266,9 +266,10 @@ def smooth_loss_plain(disp, img):
 class PhotometricChain(torch.autograd.Function):
     """generate_images_pred + compute_losses of the reference (trainer.py:386-549) as one autograd node.
 
-    forward(disp_lr [B,1,h,w], axisangle [B,S,3], translation [B,S,3], K, inv_K, target, identity, meta, *sources)
-      -> total loss (differentiable), photo mean, smooth, depth, sel, sample_0.., warped_0.. (non-differentiable)
-    `meta` = dict(H, W, invert=[...], smooth_weight, rows_per_task)."""
+    forward(disp_lr [B,1,h,w], axisangle [B,Sp,3], translation [B,Sp,3], K, inv_K, target, identity [B,S,H,W], meta, *sources)
+      -> total loss (differentiable), photo mean, smooth, depth, sel, T, sample_0.., warped_0.. (non-differentiable)
+    `meta` = dict(H, W, invert=[...] for the Sp pose-net sources, smooth_weight, rows_per_task, use_stereo, stereo_T);
+    with stereo_T the last of the S sources is the other stereo camera (Sp = S - 1)."""
 
     @staticmethod
     def forward(ctx, disp_lr, axisangle, translation, K, inv_K, target, identity, meta, *sources):
@@ -276,17 +277,29 @@ class PhotometricChain(torch.autograd.Function):
         H, W = meta["H"], meta["W"]
         B, S = target.shape[0], len(sources)
         rows = meta.get("rows_per_task", 0)
+        stereo_T = meta.get("stereo_T")           # [B,4,4]: the last source is the other camera of the stereo pair (frame id "s")
+        n_pose = S - (1 if stereo_T is not None else 0)
+        assert axisangle.shape[1] == n_pose and len(meta["invert"]) == n_pose
         training = any(ctx.needs_input_grad[:3])
         depth, part = depth_up_fwd(disp_lr, H, W)
-        mid, T, P = pose_mats_fwd(axisangle, translation, meta["invert"], K, part, H * W)
+        # translation * mean inverse depth (reference trainer.py:412-421) only for the posecnn + mono configuration
+        scaled = not meta.get("use_stereo", False)
+        mid = T = P = None
+        if n_pose:
+            mid, T, P = pose_mats_fwd(axisangle, translation, meta["invert"], K, part if scaled else None, H * W)
+        if stereo_T is not None:                  # T = inputs["stereo_T"] (trainer.py:406-407), P = (K @ T)[:, :3] (layers.py:248)
+            Ts = stereo_T.detach().float().reshape(B, 1, 4, 4)
+            Ps = torch.matmul(K, Ts[:, 0])[:, None, :3, :]
+            T = Ts if T is None else torch.cat([T, Ts], 1)
+            P = (Ps if P is None else torch.cat([P, Ps], 1)).contiguous()
         out = photo_fwd(depth, inv_K, P, target, list(sources), identity, training=training, rows_per_task=rows)
         sm_part = smooth_fwd(depth, target, part)
         photo = out["loss_part"].sum() / float(B * H * W)
         smooth = sm_part[..., 0].sum() / float(B * H * (W - 1)) + sm_part[..., 1].sum() / float(B * (H - 1) * W)
         total = photo + meta["smooth_weight"] * smooth
-        ctx.meta, ctx.S = meta, S
-        ctx.save_for_backward(disp_lr, axisangle, translation, K, inv_K, target, depth, part, mid, P, out["idx"],
-                              sm_part, *sources, *out["sample"], *out["warped"])
+        ctx.meta, ctx.S, ctx.n_pose, ctx.has_mid = meta, S, n_pose, mid is not None
+        ctx.save_for_backward(disp_lr, axisangle, translation, K, inv_K, target, depth, part, mid if mid is not None else depth, P,
+                              out["idx"], sm_part, *sources, *out["sample"], *out["warped"])
         outs = (total, photo, smooth, depth, out["sel"], T, *out["sample"], *out["warped"])
         ctx.mark_non_differentiable(*outs[1:])
         return outs
@@ -295,9 +308,11 @@ class PhotometricChain(torch.autograd.Function):
     def backward(ctx, g_total, *_unused):
         if g_total is None:
             return (None,) * (8 + ctx.S)
-        meta, S = ctx.meta, ctx.S
+        meta, S, n_pose = ctx.meta, ctx.S, ctx.n_pose
         saved = ctx.saved_tensors
         disp_lr, axisangle, translation, K, inv_K, target, depth, part, mid, P, idx, sm_part = saved[:12]
+        if not ctx.has_mid:
+            mid = None
         sources, samples, warped = list(saved[12:12 + S]), list(saved[12 + S:12 + 2 * S]), list(saved[12 + 2 * S:12 + 3 * S])
         B, _, H, W = target.shape
         h, w = disp_lr.shape[2:]
@@ -306,10 +321,13 @@ class PhotometricChain(torch.autograd.Function):
         planes, g_P = photo_bwd(depth, inv_K, P, target, sources, samples, warped, idx, 1.0 / float(B * H * W), rows,
                                 extra_planes=1)
         smooth_bwd(depth, target, part, sm_part, meta["smooth_weight"], planes, S)
-        g_aa, g_tr, g_mid = pose_mats_bwd(axisangle, translation, meta["invert"], K, mid, g_P)
+        g_aa = g_tr = g_mid = None
+        if n_pose:                                # (the stereo source's extrinsics are data: its rows of g_P are dropped)
+            g_aa, g_tr, g_mid = pose_mats_bwd(axisangle, translation, meta["invert"], K, mid,
+                                              g_P if n_pose == S else g_P[:, :n_pose].contiguous())
         g_disp = depth_up_bwd(planes, depth, g_mid, h, w)
         g = g_total
-        return (g_disp * g, g_aa * g, g_tr * g, None, None, None, None, None) + (None,) * S
+        return (g_disp * g, g_aa * g if n_pose else None, g_tr * g if n_pose else None, None, None, None, None, None) + (None,) * S
 
 
 # ---------------------------------------------------------------------------------------------------

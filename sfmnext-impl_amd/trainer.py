@@ -14,8 +14,9 @@ What differs by design (MI355X-first):
   * the data source is synthetic KITTI-shaped frames unless real KITTI is present (no dataset I/O in
     this build).
 Only the default loss configuration of the reference is implemented (auto-masking on, per-pixel
-minimum, SSIM on, scale 0, posecnn pairs, no stereo) — the configuration every args file of the
-KITTI path uses; other switches raise NotImplementedError instead of silently diverging."""
+minimum, SSIM on, scale 0, posecnn pairs; mono, mono+stereo and stereo-only frame sets) — the
+configurations the args files of the KITTI path use; other switches raise NotImplementedError instead
+of silently diverging."""
 import json
 import os
 import time
@@ -68,6 +69,8 @@ class Trainer:
         self.num_pose_frames = 2 if self.opt.pose_model_input == "pairs" else self.num_input_frames
         assert self.opt.frame_ids[0] == 0, "frame_ids must start with 0"
         self.use_pose_net = not (self.opt.use_stereo and self.opt.frame_ids == [0])
+        if self.opt.use_stereo and "s" not in self.opt.frame_ids:
+            self.opt.frame_ids.append("s")          # the other camera of the stereo pair is one more source frame (reference trainer.py:52-53)
 
         self.models = {}
         self.models["encoder"] = self._build_encoder().to(self.device)
@@ -130,14 +133,14 @@ class Trainer:
     # ------------------------------------------------------------------------------- construction
     def _check_supported(self):
         o = self.opt
-        unsupported = [n for n in ("use_stereo", "v1_multiscale", "predictive_mask", "avg_reprojection", "no_ssim",
-                                   "disable_automasking") if getattr(o, n)]
+        unsupported = [n for n in ("v1_multiscale", "predictive_mask", "avg_reprojection", "no_ssim", "disable_automasking") if getattr(o, n)]
         if unsupported or list(o.scales) != [0] or o.pose_model_type != "posecnn" or o.pose_model_input != "pairs":
             raise NotImplementedError("MI355X hot path implements the reference's KITTI mono configuration "
                                       "(auto-mask, per-pixel min, SSIM, scale 0, posecnn pairs); got %s scales=%s pose=%s/%s"
                                       % (unsupported, o.scales, o.pose_model_type, o.pose_model_input))
-        if list(o.frame_ids) != [0, -1, 1]:
-            raise NotImplementedError("frame_ids must be [0, -1, 1] (two source frames)")
+        temporal = [f for f in o.frame_ids if f != "s"]
+        if temporal not in ([0, -1, 1], [0]) or (temporal == [0] and not o.use_stereo):
+            raise NotImplementedError("frame_ids must be [0, -1, 1] (optionally with --use_stereo) or [0] with --use_stereo; got %s" % o.frame_ids)
 
     def _build_encoder(self):
         o = self.opt
@@ -405,7 +408,7 @@ class Trainer:
         """Pose of each source frame relative to the target, pairs in temporal order (reference
         trainer.py:301-337)."""
         outputs = {}
-        aug = {f: inputs["color_aug", f, 0] for f in self.opt.frame_ids}
+        aug = {f: inputs["color_aug", f, 0] for f in self.opt.frame_ids if f != "s"}
         srcs = [f for f in self.opt.frame_ids[1:] if f != "s"]
         # PoseCNN has no batch statistics, so the pairs of all source frames go through it as ONE batch [S*B,6,H,W] (the
         # reference calls it once per pair, trainer.py:319-334): same numbers per sample, half the launches, and every
@@ -436,10 +439,17 @@ class Trainer:
         if self._identity_done is not None:
             torch.cuda.current_stream().wait_event(self._identity_done)
         identity, self._identity = self._identity, None
-        aa = torch.cat([outputs[("axisangle", 0, f)][:, 0] for f in srcs_ids], 1).contiguous()      # [B,S,3]
-        tr = torch.cat([outputs[("translation", 0, f)][:, 0] for f in srcs_ids], 1).contiguous()
-        meta = dict(H=o.height, W=o.width, invert=[1 if f < 0 else 0 for f in srcs_ids],
-                    smooth_weight=o.disparity_smoothness)
+        pose_ids = [f for f in srcs_ids if f != "s"]
+        B = inputs[("color", 0, 0)].shape[0]
+        if pose_ids:
+            aa = torch.cat([outputs[("axisangle", 0, f)][:, 0] for f in pose_ids], 1).contiguous()      # [B,Sp,3]
+            tr = torch.cat([outputs[("translation", 0, f)][:, 0] for f in pose_ids], 1).contiguous()
+        else:
+            aa = tr = torch.zeros(B, 0, 3, device=self.device)
+        # --use_stereo: T of the temporal frames is the un-scaled cam_T_cam, T of "s" is inputs["stereo_T"] (reference
+        # trainer.py:405-421: the mean-inverse-depth scaling of the translation is skipped)
+        meta = dict(H=o.height, W=o.width, invert=[1 if f < 0 else 0 for f in pose_ids], smooth_weight=o.disparity_smoothness,
+                    use_stereo=bool(o.use_stereo), stereo_T=inputs["stereo_T"] if "s" in srcs_ids else None)
         srcs = [inputs[("color", f, 0)].contiguous() for f in srcs_ids]
         res = ops.PhotometricChain.apply(outputs[("disp", 0)].contiguous(), aa, tr, inputs[("K", 0)].contiguous(),
                                          inputs[("inv_K", 0)].contiguous(), inputs[("color", 0, 0)].contiguous(),

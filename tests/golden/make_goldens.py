@@ -226,6 +226,36 @@ def g7_g8_chain(T):
              grad_translation_m1=tr[-1].grad, grad_translation_p1=tr[1].grad)
 
 
+def g17_stereo_chain(T):
+    """--use_stereo: frame_ids [0,-1,1,"s"] (trainer.py:52-53), T of "s" = inputs["stereo_T"] (:406-407), no mean-inverse-depth
+    scaling of the pose translations (:412): generate_images_pred + compute_losses with three source frames."""
+    seed, B, H, W = 1717, 2, 32, 96
+    d = chain_inputs(seed, B, H, W, S=3)
+    shim = make_shim(T, B, H, W, frame_ids=(0, -1, 1, "s"))
+    shim.opt.use_stereo = True
+    disp = tt(d["disp"]).requires_grad_(True)
+    aa = {f: tt(d["axisangle_s%d" % i]).requires_grad_(True) for i, f in enumerate((-1, 1))}
+    tr = {f: tt(d["translation_s%d" % i]).requires_grad_(True) for i, f in enumerate((-1, 1))}
+    stereo_T = torch.eye(4).repeat(B, 1, 1)
+    stereo_T[0, 0, 3], stereo_T[1, 0, 3] = -0.1, 0.1          # left / right target camera (datasets/mono_dataset.py:193-199)
+    inputs = {("color", 0, 0): tt(d["color0"]), ("color", -1, 0): tt(d["color_s0"]), ("color", 1, 0): tt(d["color_s1"]),
+              ("color", "s", 0): tt(d["color_s2"]), ("K", 0): tt(d["K"]), ("inv_K", 0): tt(d["inv_K"]), "stereo_T": stereo_T}
+    outputs = {("disp", 0): disp}
+    for f in (-1, 1):
+        outputs[("axisangle", 0, f)] = aa[f]
+        outputs[("translation", 0, f)] = tr[f]
+        outputs[("cam_T_cam", 0, f)] = T.transformation_from_parameters(aa[f][:, 0], tr[f][:, 0], invert=(f < 0))
+    T.Trainer.generate_images_pred(shim, inputs, outputs)
+    with patched_randn(tt(d["noise"])):
+        losses = T.Trainer.compute_losses(shim, inputs, outputs)
+    losses["loss"].backward()
+    save("g17_stereo_chain", seed=seed, B=B, H=H, W=W, stereo_T=stereo_T, depth=outputs[("depth", 0, 0)],
+         sample_m1=outputs[("sample", -1, 0)], sample_p1=outputs[("sample", 1, 0)], sample_s=outputs[("sample", "s", 0)],
+         color_m1=outputs[("color", -1, 0)], color_p1=outputs[("color", 1, 0)], color_s=outputs[("color", "s", 0)],
+         loss=losses["loss"], identity_selection=outputs["identity_selection/0"], grad_disp=disp.grad,
+         grad_axisangle_m1=aa[-1].grad, grad_axisangle_p1=aa[1].grad, grad_translation_m1=tr[-1].grad, grad_translation_p1=tr[1].grad)
+
+
 def g9_smooth(T):
     rs = np.random.RandomState(909)
     img = smooth_images(rs, 2, 20, 36)
@@ -416,6 +446,11 @@ def options_spec():
 
 def main():
     T, nets = import_reference()
+    if len(sys.argv) > 1:                  # regenerate single groups: python make_goldens.py g17_stereo_chain ...
+        for name in sys.argv[1:]:
+            globals()[name](T)
+        return
+    g17_stereo_chain(T)
     g1_pose(T)
     g2_g3_g4_geometry(T)
     g5_g6_ssim(T)

@@ -251,3 +251,62 @@ def test_full_size_config_b(ops, O):
 def test_cpu_tensors_fail_loudly(ops):
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.depth_up_fwd(torch.zeros(1, 1, 4, 4), 8, 8)
+
+
+def _run_chain_stereo(ops, d, H, W, stereo_T, rows=0):
+    disp = dev(d["disp"]).requires_grad_(True)
+    aa = torch.stack([tt(d["axisangle_s0"])[:, 0, 0], tt(d["axisangle_s1"])[:, 0, 0]], 1).cuda().requires_grad_(True)
+    tr = torch.stack([tt(d["translation_s0"])[:, 0, 0], tt(d["translation_s1"])[:, 0, 0]], 1).cuda().requires_grad_(True)
+    tgt, srcs = dev(d["color0"]), [dev(d["color_s0"]), dev(d["color_s1"]), dev(d["color_s2"])]
+    ident = ops.identity_fwd(tgt, srcs, dev(d["noise"]), rows)
+    meta = dict(H=H, W=W, invert=[1, 0], smooth_weight=1e-3, rows_per_task=rows, use_stereo=True, stereo_T=dev(stereo_T))
+    outs = ops.PhotometricChain.apply(disp, aa, tr, dev(d["K"]), dev(d["inv_K"]), tgt, ident, meta, *srcs)
+    return outs, disp, aa, tr
+
+
+def test_golden_g17_stereo(ops, golden):
+    """three source frames (--use_stereo, reference trainer.py:52-53,405-421) against the reference's own vectors: the pair
+    passes (0,1) + (2,2) of the tile kernel, the running minimum between them, the stereo source through stereo_T"""
+    g = golden("g17_stereo_chain")
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    d = chain_inputs(int(g["seed"]), B, H, W, S=3)
+    outs, disp, aa, tr = _run_chain_stereo(ops, d, H, W, g["stereo_T"])
+    total, photo, smooth, depth, sel, T = outs[:6]
+    samples, warped = outs[6:9], outs[9:12]
+    close(depth, g["depth"], rtol=1e-6)
+    for s, n in enumerate(("m1", "p1", "s")):
+        close(samples[s], g["sample_" + n], rtol=RTOL, atol=2e-6)
+        close(warped[s], g["color_" + n], rtol=RTOL, atol=2e-5)
+    close(total, g["loss"], rtol=RTOL)
+    nm = int((sel.cpu().numpy() != g["identity_selection"]).sum())
+    print("identity_selection vs golden g17: %d of %d differ" % (nm, sel.numel()))
+    assert nm <= 5e-4 * sel.numel(), nm
+    total.backward()
+    grad_close(disp.grad, g["grad_disp"])
+    for s, n in enumerate(("m1", "p1")):
+        pose_grad_close(aa.grad[:, s], g["grad_axisangle_" + n][:, 0, 0])
+        pose_grad_close(tr.grad[:, s], g["grad_translation_" + n][:, 0, 0])
+
+
+@pytest.mark.parametrize("B,H,W,rows,seed", [(2, 48, 160, 0, 81), (1, 40, 70, 8, 82)])
+def test_stereo_chain_vs_oracle(ops, O, B, H, W, rows, seed):
+    d = chain_inputs(seed, B, H, W, S=3)
+    stereo_T = torch.eye(4).repeat(B, 1, 1)
+    stereo_T[:, 0, 3] = -0.1
+    outs, disp, aa, tr = _run_chain_stereo(ops, d, H, W, stereo_T, rows)
+    wdisp = tt(d["disp"]).requires_grad_(True)
+    poses = {f: (tt(d["axisangle_s%d" % i]).requires_grad_(True), tt(d["translation_s%d" % i]).requires_grad_(True))
+             for i, f in enumerate((-1, 1))}
+    colors = {0: tt(d["color0"]), -1: tt(d["color_s0"]), 1: tt(d["color_s1"]), "s": tt(d["color_s2"])}
+    want = O.photometric_chain(wdisp, poses, tt(d["K"]), tt(d["inv_K"]), colors, [0, -1, 1, "s"], tt(d["noise"]), H, W,
+                               stereo_T=stereo_T, use_stereo=True)
+    want["loss"].backward()
+    close(outs[0], want["loss"], rtol=RTOL)
+    for s, f in enumerate((-1, 1, "s")):
+        close(outs[9 + s], want[("color", f, 0)], rtol=RTOL, atol=2e-5)
+    ties_only(outs[4], want, "stereo %dx%dx%d" % (B, H, W))
+    outs[0].backward()
+    grad_close(disp.grad, wdisp.grad)
+    for s, f in enumerate((-1, 1)):
+        pose_grad_close(aa.grad[:, s], poses[f][0].grad[:, 0, 0])
+        pose_grad_close(tr.grad[:, s], poses[f][1].grad[:, 0, 0])

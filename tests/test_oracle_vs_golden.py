@@ -231,3 +231,27 @@ def test_state_dict_keys(golden):
     for n, m in mods.items():
         mine = ["%s %s" % (k, tuple(v.shape)) for k, v in m.state_dict().items()]
         assert mine == list(g[n]), n
+
+
+def test_g17_stereo_chain(golden):
+    """--use_stereo (reference trainer.py:52-53,405-421): three source frames, "s" through stereo_T, un-scaled pose translations."""
+    g = golden("g17_stereo_chain")
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    d = chain_inputs(int(g["seed"]), B, H, W, S=3)
+    disp = tt(d["disp"]).requires_grad_(True)
+    poses = {f: (tt(d["axisangle_s%d" % i]).requires_grad_(True), tt(d["translation_s%d" % i]).requires_grad_(True))
+             for i, f in enumerate((-1, 1))}
+    colors = {0: tt(d["color0"]), -1: tt(d["color_s0"]), 1: tt(d["color_s1"]), "s": tt(d["color_s2"])}
+    out = O.photometric_chain(disp, poses, tt(d["K"]), tt(d["inv_K"]), colors, [0, -1, 1, "s"], tt(d["noise"]), H, W,
+                              stereo_T=tt(g["stereo_T"]), use_stereo=True)
+    close(out[("depth", 0, 0)], g["depth"])
+    for f, n in ((-1, "m1"), (1, "p1"), ("s", "s")):
+        close(out[("sample", f, 0)], g["sample_" + n], atol=1e-6)
+        close(out[("color", f, 0)], g["color_" + n], atol=1e-5)
+    close(out["loss"], g["loss"])
+    assert np.array_equal(out["identity_selection/0"].numpy(), g["identity_selection"])
+    out["loss"].backward()
+    close(disp.grad, g["grad_disp"], atol=1e-9)
+    for f, n in ((-1, "m1"), (1, "p1")):
+        close(poses[f][0].grad, g["grad_axisangle_" + n], atol=1e-7)
+        close(poses[f][1].grad, g["grad_translation_" + n], atol=1e-7)
