@@ -62,7 +62,9 @@ class GradBucketReducer:
         tensors = []
         for m in modules:
             tensors += [p.data for p in m.parameters()] + [b.data for b in m.buffers()]
-        for dtype in {t.dtype for t in tensors}:
+        # (in first-appearance order: a set's iteration order depends on the process's hash seed, and ranks that walk the
+        #  dtypes in different orders issue mismatched broadcasts)
+        for dtype in list(dict.fromkeys(t.dtype for t in tensors)):
             group = [t for t in tensors if t.dtype == dtype]
             flat = torch.cat([t.reshape(-1) for t in group])
             dist.broadcast(flat, 0, group=self.group)
