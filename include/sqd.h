@@ -12,7 +12,10 @@
  *   - tensors are fp32, contiguous, NCHW unless stated; shapes are given as int32;
  *   - return 0 on success, a negative SQD_E* code otherwise; sqd_last_error() returns a
  *     thread-local description of the last failure; nothing throws, nothing calls exit();
- *   - re-entrant: no global mutable state except that thread-local error string.
+ *   - re-entrant; process-wide state is limited to (a) that thread-local error string and (b) configuration the CALLER sets
+ *     through explicit entry points — the measured convolution plans (sqd_conv_set_plan, sqd_conv_wgrad_set_plan: a
+ *     mutex-guarded geometry -> plan table; without a registered plan a cost model decides) and the convolution precision
+ *     mode (sqd_conv_set_precision).  The library reads no environment variables.
  */
 #ifndef SQD_H_
 #define SQD_H_

@@ -951,16 +951,6 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     }
     int z = p.z;
     if (p.bk >= 32) z = z <= T / (p.bk / 8) ? z : 1;             // (slices are 2x / 4x as wide)
-    static const char *force = getenv("SQD_CONV_PLAN");          // "bm,bn,z": tuning experiments only
-    if (force) {
-        int fbm, fbn, fz;
-        if (sscanf(force, "%d,%d,%d", &fbm, &fbn, &fz) == 3) {
-            p.bm = fbm;
-            p.bn = fbn < Ncols * 2 ? fbn : p.bn;
-            z = fz < T / 2 ? fz : (T / 2 > 0 ? T / 2 : 1);
-            if (((int64_t)Mrows * Ncols) % 4 != 0) z = 1;
-        }
-    }
     p.z = z;
     p.ws_floats = z > 1 ? (int64_t)z * Mrows * Ncols : 0;
     return p;
@@ -1018,9 +1008,9 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     else if (p.bk == 32) LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 32, 1);               \
     else LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 16, 1);
 
-// 0: fp32 MFMA (default); 1: split-precision bf16 MFMA for forward / data gradient (SQD_CONV_BF16X3=1 or sqd_conv_set_precision)
+// 0: fp32 MFMA (default); 1: split-precision bf16 MFMA for forward / data gradient (sqd_conv_set_precision)
 static int &conv_precision() {
-    static int prec = getenv("SQD_CONV_BF16X3") ? 1 : 0;
+    static int prec = 0;
     return prec;
 }
 
@@ -1036,8 +1026,7 @@ static int launch_gemm(int mode, const float *a_src, const float *w, const float
         return SQD_EINVAL;
     }
     hipStream_t st = (hipStream_t)stream;
-    static const int order_env = getenv("SQD_CONV_ORDER") ? atoi(getenv("SQD_CONV_ORDER")) : -1;
-    const int order = order_env >= 0 ? order_env : 2;      // measured best on MI355X (profiles/r01c_conv_layers.md)
+    const int order = 2;                                   // N-tiles fastest, no XCD chunking: measured best on MI355X (profiles/r01c_conv_layers.md)
     float *dst = p.z > 1 ? ws : out;
     (void)hipGetLastError();
     if (conv_precision()) {
@@ -1160,14 +1149,6 @@ struct WgradPlan {
     bool direct;
     int kt, ct, tp, splits, px_per_wave;
 };
-static int wgrad_impl_override() {              // SQD_WGRAD_IMPL=lds|direct forces one kernel (benchmarks); default: heuristic
-    static int v = -1;
-    if (v < 0) {
-        const char *e = getenv("SQD_WGRAD_IMPL");
-        v = !e ? 0 : (!strcmp(e, "lds") ? 1 : (!strcmp(e, "direct") ? 2 : 0));
-    }
-    return v;
-}
 // measured weight-gradient plans (sqd_conv_wgrad_set_plan): geometry -> (impl 0 = LDS-tiled / 1 = direct-operand, splits)
 typedef std::tuple<int, int, int, int, int, int, int> WPlanKey;
 static std::map<WPlanKey, std::pair<int, int>> &wplan_table() {
@@ -1186,23 +1167,19 @@ static bool wplan_lookup(int N, int Ho, int Wo, int C, int K, int R, int S, int 
 static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, int S) {
     WgradPlan p;
     const int M = N * Ho * Wo;
-    const int ov = wgrad_impl_override();
     int m_impl = -1, m_splits = 0;
     const bool measured = wplan_lookup(N, Ho, Wo, C, K, R, S, m_impl, m_splits);
     const int fkt = measured ? (m_impl >> 4) & 15 : 0, fct = measured ? (m_impl >> 8) & 15 : 0;   // measured register-tile shape (0: default)
     if (measured) m_impl &= 1;
     // the direct kernel wins where pixels are many and channels few (operand re-reads stay in L2); the LDS-tiled
     // kernel where K*C is large and the pixel count small
-    p.direct = C % 16 == 0 && K % 16 == 0 && (ov == 2 || (ov == 0 && M >= 2048 && C <= 1024));
-    if (measured && ov == 0) p.direct = m_impl == 1 && C % 16 == 0 && K % 16 == 0;
+    p.direct = C % 16 == 0 && K % 16 == 0 && M >= 2048 && C <= 1024;
+    if (measured) p.direct = m_impl == 1 && C % 16 == 0 && K % 16 == 0;
     p.kt = K % 64 == 0 ? 4 : K % 32 == 0 ? 2 : 1;
     p.ct = C % 64 == 0 ? 4 : C % 32 == 0 ? 2 : 1;
     if (fkt) p.kt = fkt;                                         // a smaller register tile = more resident waves (the 4x4 tile's 184
     if (fct) p.ct = fct;                                         // VGPRs and 66 KB of LDS leave two workgroups per CU)
-    // a filter row (3 taps) per wave: measured SLOWER on every config-B layer (3x3 64..256 channels: 140 us vs 102 us) — the
-    // 192-256 accumulator registers leave one wave per SIMD and nothing hides the operand latency.  Kept for experiments.
-    static const bool tp3 = getenv("SQD_WGRAD_TP3") != nullptr;
-    p.tp = (tp3 && S == 3 && p.kt * p.ct >= 8) ? 3 : 1;
+    p.tp = 1;     // (a filter row of 3 taps per wave was measured slower on every config-B layer — 140 us vs 102 us: DESIGN.md §3.4)
     const int groups = (K / (16 * p.kt)) * (C / (16 * p.ct)) * (R * S / p.tp);
     int sp = (512 + groups - 1) / groups;                        // ~512 workgroups of 4 waves (measured plans mostly land at
                                                                  // a quarter to a half of the ~1k first assumed)
@@ -1285,19 +1262,9 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
         const int kgroups = K / (16 * dp.kt);
         const dim3 grid((kgroups * (C / (16 * dp.ct)) * dp.splits * (R * S / dp.tp) + 7) / 8 * 8);
         float *bias_part = dbias ? part + (size_t)dp.splits * K * R * S * C : nullptr;   // [splits][K]
-#define LAUNCH_WD3(KT, CT)                                                                                                      \
-    hipLaunchKernelGGL((conv_wgrad_direct_kernel<KT, CT, 3>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, kgroups, \
-                       dp.splits, bias_part)
 #define LAUNCH_WD(KT, CT)                                                                                                       \
     hipLaunchKernelGGL((conv_wgrad_direct_kernel<KT, CT, 1>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, kgroups, \
                        dp.splits, bias_part)
-        if (dp.tp == 3) {
-            switch (dp.kt * 8 + dp.ct) {
-                case 4 * 8 + 4: LAUNCH_WD3(4, 4); break;
-                case 4 * 8 + 2: LAUNCH_WD3(4, 2); break;
-                default: LAUNCH_WD3(2, 4); break;
-            }
-        } else
         switch (dp.kt * 8 + dp.ct) {
             case 4 * 8 + 4: LAUNCH_WD(4, 4); break;
             case 4 * 8 + 2: LAUNCH_WD(4, 2); break;

@@ -20,7 +20,6 @@
 // (157 TF) for the 4*Q*E flop/px forward — both are ~10-20 us at config B; the kernel exists to
 // replace 5 ATen launches that move y four times.
 #include "sqd_common.h"
-#include <cstdlib>
 
 namespace {
 using namespace sqd;
@@ -257,168 +256,6 @@ __global__ __launch_bounds__(64) void sql_merge_kernel(const float *__restrict__
     }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// backward.  Orientation: rows = queries (4g+r within a 16-tile), cols = pixels (c).
-//   t[q][n]   = sum_e gS[q][e] x[e][n]
-//   s[q][n]   = exp(y - max) / sum ;  gyt = g_y + s * (t - dot[q]),  dot[q] = sum_e gS[q][e] * summary[q][e]
-//   g_x[e][n] = sum_q K[q][e] gyt[q][n] + gS[q][e] s[q][n]
-//   g_K[q][e] = sum_n gyt[q][n] x[e][n]                        (through a wave-private LDS transpose)
-// ---------------------------------------------------------------------------------------------------
-template <int QT, int ET, int NT>
-__global__ __launch_bounds__(256) void sql_bwd_kernel(const float *__restrict__ x, const float *__restrict__ K,
-                                                      const float *__restrict__ y, const float *__restrict__ g_y,
-                                                      const float *__restrict__ gS, const float *__restrict__ summary,
-                                                      const float *__restrict__ lse, float *__restrict__ g_x,
-                                                      float *__restrict__ gK_part, int Q, int N, int steps_per_wave,
-                                                      int nchunks) {
-    constexpr int E = ET * 16;
-    constexpr int QP = QT * 16, PX = NT * 16;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int c = lane & 15, g = lane >> 4;
-    const int b = blockIdx.y, chunk = blockIdx.x;
-    const float *xb = x + (size_t)b * E * N;
-    const float *Kb = K + (size_t)b * Q * E;
-    const float *gSb = gS + (size_t)b * Q * E;
-    const float *yb = y + (size_t)b * Q * N;
-    const float *gyb = g_y ? g_y + (size_t)b * Q * N : nullptr;
-    float *gxb = g_x + (size_t)b * E * N;
-    const int n_wave0 = (chunk * 4 + wave) * steps_per_wave * PX;
-
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *qc = lds;                                              // [QP][4]: max, 1/sum, dot, pad (workgroup-shared)
-    float *tile = lds + QP * 4 + (size_t)wave * QP * (PX + 1);    // wave-private [QP][PX+1]
-    for (int q = threadIdx.x; q < QP; q += 256) {
-        float dsum = 0.f, mx = 0.f, il = 0.f;
-        if (q < Q) {
-            mx = lse[((size_t)b * Q + q) * 2];
-            il = lse[((size_t)b * Q + q) * 2 + 1];
-            for (int e = 0; e < E; ++e) dsum += gSb[q * E + e] * summary[((size_t)b * Q + q) * E + e];
-        }
-        qc[q * 4] = mx; qc[q * 4 + 1] = il; qc[q * 4 + 2] = dsum;
-    }
-    __syncthreads();
-    f32x4 accK[ET][QT];                                            // g_K^T[e][q] accumulators: row e = 4g+r, col q = c
-#pragma unroll
-    for (int t = 0; t < ET; ++t)
-#pragma unroll
-        for (int j = 0; j < QT; ++j) accK[t][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int st = 0; st < steps_per_wave; ++st) {
-        const int n0 = n_wave0 + st * PX;
-        if (n0 >= N) break;
-        // ---- t[q][n]: M = queries (A = gS[q][e]), N = pixels (B = x[e][n]), K = features
-        f32x4 d[QT][NT];
-#pragma unroll
-        for (int j = 0; j < QT; ++j)
-#pragma unroll
-            for (int i = 0; i < NT; ++i) d[j][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int e0 = 0; e0 < E; e0 += 4) {
-            float bx[NT];
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int n = n0 + i * 16 + c;
-                bx[i] = n < N ? xb[(size_t)(e0 + g) * N + n] : 0.f;           // B[k=e][col=n]
-            }
-#pragma unroll
-            for (int j = 0; j < QT; ++j) {
-                const int q = j * 16 + c;
-                const float a = q < Q ? gSb[q * E + e0 + g] : 0.f;             // A[row=q][k=e]
-#pragma unroll
-                for (int i = 0; i < NT; ++i) d[j][i] = mfma16(a, bx[i], d[j][i]);
-            }
-        }
-        // ---- element-wise: s and gyt (rows q = j*16+4g+r, col n = n0+i*16+c); s kept in sreg
-        f32x4 sreg[QT][NT];
-#pragma unroll
-        for (int j = 0; j < QT; ++j)
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int n = n0 + i * 16 + c;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int q = j * 16 + 4 * g + r;
-                    float s = 0.f, gyt = 0.f;
-                    if (q < Q && n < N) {
-                        const size_t o = (size_t)q * N + n;
-                        s = __expf(yb[o] - qc[q * 4]) * qc[q * 4 + 1];
-                        gyt = (gyb ? gyb[o] : 0.f) + s * (d[j][i][r] - qc[q * 4 + 2]);
-                    }
-                    sreg[j][i][r] = s;
-                    d[j][i][r] = gyt;
-                    tile[(j * 16 + 4 * g + r) * (PX + 1) + i * 16 + c] = gyt;
-                }
-            }
-        // ---- g_x[e][n] = sum_q K[q][e] gyt[q][n] + gS[q][e] s[q][n]: k-slot (g, r) of query tile j is query j*16+4g+r
-        f32x4 gx[ET][NT];
-#pragma unroll
-        for (int t = 0; t < ET; ++t)
-#pragma unroll
-            for (int i = 0; i < NT; ++i) gx[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < QT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int q = j * 16 + 4 * g + r;
-#pragma unroll
-                for (int t = 0; t < ET; ++t) {
-                    const float ak = q < Q ? Kb[q * E + t * 16 + c] : 0.f;     // A[row=e][k=q]
-                    const float as = q < Q ? gSb[q * E + t * 16 + c] : 0.f;
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) {
-                        gx[t][i] = mfma16(ak, d[j][i][r], gx[t][i]);
-                        gx[t][i] = mfma16(as, sreg[j][i][r], gx[t][i]);
-                    }
-                }
-            }
-#pragma unroll
-        for (int t = 0; t < ET; ++t)
-#pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int n = n0 + i * 16 + c;
-                if (n < N) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) gxb[(size_t)(t * 16 + 4 * g + r) * N + n] = gx[t][i][r];
-                }
-            }
-        // ---- g_K^T[e][q] += sum_n x[e][n] gyt[q][n]: read gyt transposed from the wave-private tile
-        __builtin_amdgcn_s_waitcnt(0xc07f);            // lgkmcnt(0): this wave's LDS writes have landed
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int nl = i * 16 + 4 * g + r;     // k-slot (g, r) of pixel tile i
-                const int n = n0 + nl;
-                float bq[QT];
-#pragma unroll
-                for (int j = 0; j < QT; ++j) bq[j] = tile[(j * 16 + c) * (PX + 1) + nl];      // B[k=n][col=q]
-#pragma unroll
-                for (int t = 0; t < ET; ++t) {
-                    const float a = n < N ? xb[(size_t)(t * 16 + c) * N + n] : 0.f;            // A[row=e][k=n]
-#pragma unroll
-                    for (int j = 0; j < QT; ++j) accK[t][j] = mfma16(a, bq[j], accK[t][j]);
-                }
-            }
-    }
-    // ---- workgroup merge of g_K^T through LDS (reuse the tile area after a barrier)
-    __syncthreads();
-    float *red = lds + QP * 4;                          // [4][E][QP+1]
-#pragma unroll
-    for (int t = 0; t < ET; ++t)
-#pragma unroll
-        for (int j = 0; j < QT; ++j)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) red[((size_t)wave * E + t * 16 + 4 * g + r) * (QP + 1) + j * 16 + c] = accK[t][j][r];
-    __syncthreads();
-    float *po = gK_part + ((size_t)b * nchunks + chunk) * Q * E;
-    for (int idx = threadIdx.x; idx < Q * E; idx += 256) {
-        const int q = idx / E, e = idx - q * E;
-        float s = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) s += red[((size_t)k * E + e) * (QP + 1) + q];
-        po[idx] = s;
-    }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // backward, second formulation (the one dispatched): v_mfma_f32_32x32x2_f32 with lane = pixel, so every read of x, y,
@@ -651,7 +488,7 @@ int make_plan(int Q, int E, int N, Plan *p) {
 
 extern "C" int sqd_sql_workspace(int B, int Q, int E, int N, int64_t *part_floats, int64_t *gk_part_floats) {
     Plan p;
-    SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql: unsupported Q=%d E=%d N=%d (E in {16,32,48,64}, Q <= 128)", Q, E, N);
+    SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql: unsupported Q=%d E=%d N=%d (E in {16, 32}, Q <= 128)", Q, E, N);
     if (part_floats) *part_floats = (int64_t)B * p.nchunks * Q * (E + PART_STRIDE_EXTRA);
     if (gk_part_floats) *gk_part_floats = (int64_t)B * p.nchunks * Q * E;
     return SQD_OK;
@@ -702,8 +539,7 @@ extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const
     SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql_bwd: unsupported Q=%d E=%d N=%d", Q, E, N);
     SQD_CHECK_ARG((long long)N * 132 * 4 < (1ll << 32), "sqd_sql_bwd: N=%d too large for 32-bit plane offsets", N);
     (void)hipGetLastError();
-    static const bool legacy = getenv("SQD_SQL_BWD16") != nullptr;          // A/B: the 16x16x4 formulation
-    if (!legacy) {
+    {
         const int qt = Q <= 32 ? 1 : Q <= 64 ? 2 : 4, QP = qt * 32;
         const size_t shmem = ((size_t)2 * QP * 33 + QP * 4 + (size_t)4 * QP * TP) * sizeof(float);
 #define SQL_BWD32(QT_)                                                                                                          \
@@ -715,14 +551,6 @@ extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const
                            g_summary, summary, lse, g_x, gk_part, Q, E, N, p.nchunks, xse, xsn);                                \
     }
         if (qt == 1) SQL_BWD32(1) else if (qt == 2) SQL_BWD32(2) else SQL_BWD32(4)
-    } else {
-        SQD_CHECK_ARG(!x_nhwc, "sqd_sql_bwd: the 16x16x4 formulation (SQD_SQL_BWD16) reads planar x only");
-        const int QP = p.QT * 16, PX = p.NT * 16;
-        const size_t sh_tile = (size_t)4 * QP * (PX + 1) * sizeof(float), sh_red = (size_t)4 * E * (QP + 1) * sizeof(float);
-        const size_t shmem = (size_t)QP * 4 * sizeof(float) + (sh_tile > sh_red ? sh_tile : sh_red);
-        bool launched = false;
-        SQL_DISPATCH_ALL(sql_bwd_kernel, shmem, x, K, y, g_y, g_summary, summary, lse, g_x, gk_part, Q, N, p.steps, p.nchunks)
-        SQD_CHECK_ARG(launched, "sqd_sql_bwd: no kernel instance for QT=%d ET=%d", p.QT, p.ET);
     }
     SQD_CHECK_LAUNCH("sqd_sql_bwd");
     hipLaunchKernelGGL(sql_gk_reduce_kernel, dim3((Q * E + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, gk_part, g_K,

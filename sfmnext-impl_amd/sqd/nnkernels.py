@@ -336,7 +336,7 @@ def conv_module_supported(conv):
 # stream the weight-gradient kernels run on (None: the caller's stream).  The Trainer sets it; whoever calls backward() must
 # call join_wgrad_stream() before the gradients are read (optimiser, all-reduce).
 WGRAD_STREAM = None
-WGRAD_BATCH = int(os.environ.get("SQD_WGRAD_BATCH", "1"))
+WGRAD_BATCH = 1              # convolutions per cross-stream dependency of the side-stream weight gradients
 _PENDING_WGRAD = {}          # raw stream handle -> (stream the operands are produced on, [(launch, tensors)])
 
 
@@ -852,7 +852,7 @@ def transformer_encoder_native(tokens, encoder):
     rows = S * B
     layers = list(encoder.layers)
     H = layers[0].self_attn.num_heads
-    full = NATIVE_MHA and all(_attention_native_ok(l, S) and l.self_attn.num_heads == H for l in layers)
+    full = all(_attention_native_ok(l, S) and l.self_attn.num_heads == H for l in layers)
     masks, scale = None, 1.0
     if encoder.training:
         ps = {float(p) for l in layers for p in (l.dropout1.p, l.dropout.p, l.dropout2.p)}
@@ -878,6 +878,3 @@ def transformer_encoder_native(tokens, encoder):
                               layer.norm1.eps, layer.norm2.eps)
     return x
 
-
-# SQD_MHA_ATEN=1: torch's MultiheadAttention inside the encoder (A/B runs)
-NATIVE_MHA = not os.environ.get("SQD_MHA_ATEN")

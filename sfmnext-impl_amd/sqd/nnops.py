@@ -6,8 +6,9 @@ module definitions (state-dict keys stay those of the reference).  `BACKEND[name
 implementation serves each operator:
 
     "hip"   hand-written kernel in libsqd.so (csrc/*.hip)
-    "aten"  interim: PyTorch-ROCm ATen (MIOpen / rocBLAS) — listed in DESIGN.md §"Kernel coverage"
-            as not yet native; never a CPU fallback: on a GPU box the tensors are device tensors.
+    "aten"  PyTorch-ROCm ATen (MIOpen / rocBLAS) for shapes the native kernels do not take (channel / feature counts not
+            divisible by 16) — device tensors only.
+Host tensors are refused: the CPU restatement of these operators is test infrastructure (oracle/, tests/host_ops.py).
 """
 import torch
 import torch.nn.functional as F
@@ -28,14 +29,11 @@ def _act(y, act):
     raise ValueError(act)
 
 
-import os
+def _device_only(x, what):
+    if not x.is_cuda:
+        raise RuntimeError("sqd: %s needs a tensor on the MI355X device — the hot path has no CPU fallback" % what)
 
-# 7x7/2 stems as 4x4/1 convolutions on a space-to-depth input (SQD_STEM_ATEN=1: ATen/MIOpen for the stems, A/B runs)
-STEM_S2D = not os.environ.get("SQD_STEM_ATEN")
-# BatchNorm statistics partials from the producing convolution's epilogue (SQD_NO_CONV_BN_STATS=1: BatchNorm's own pass, A/B runs)
-CONV_BN_STATS = not os.environ.get("SQD_NO_CONV_BN_STATS")
-# feed-forward and add+dropout+LayerNorm of the patch-token encoder as fused kernels (SQD_VIT_ATEN=1: nn.TransformerEncoder, A/B runs)
-NATIVE_VIT = not os.environ.get("SQD_VIT_ATEN")
+
 NATIVE_CONV = False          # set by the Trainer (default on; --sqd_aten_conv is the A/B switch back to ATen/MIOpen)
 
 
@@ -55,7 +53,7 @@ def _conv(x, conv, act=None, skip=False, bn_stats=None):
     if NATIVE_CONV and x.is_cuda:
         from . import nnkernels
         native = nnkernels.conv_module_supported(conv)
-        s2d = not native and STEM_S2D and nnkernels.stem_s2d_supported(conv, x)
+        s2d = not native and nnkernels.stem_s2d_supported(conv, x)
         stats = geom = None
         if bn_stats is not None and (native or s2d):
             geom = nnkernels.conv_out_geom(x, conv, s2d)
@@ -72,7 +70,8 @@ def _conv(x, conv, act=None, skip=False, bn_stats=None):
                 if rows > 0:
                     bn_stats.append((stats, rows))
             return out
-    y = _act(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), act)
+    _device_only(x, "conv2d")
+    y = _act(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), act)      # ATen: channel counts not divisible by 16
     return (y, x) if skip else y
 
 
@@ -89,7 +88,7 @@ def conv_bn_act(x, conv, bn, act, residual=None, input_affine=None, skip=False):
     if input_affine is not None:
         x = (x - input_affine[0]) / input_affine[1]
     training = bn.training or bn.running_mean is None
-    pre = [] if (training and CONV_BN_STATS) else None
+    pre = [] if training else None      # statistics partials from the convolution's epilogue
     if skip:
         y, x_skip = _conv(x, conv, None, True, pre)
         return _bn_act(y, bn, act, residual, pre), x_skip
@@ -98,18 +97,13 @@ def conv_bn_act(x, conv, bn, act, residual=None, input_affine=None, skip=False):
 
 
 def _bn_act(y, bn, act, residual, pre=None):
-    if y.is_cuda:
-        from . import nnkernels
-        if not nnkernels.bn_supported(y.shape[1]):
-            raise RuntimeError("sqd: BatchNorm kernel needs C/4 to be a power of two (C=%d)" % y.shape[1])
-        if pre:
-            return nnkernels.batch_norm_act(y, bn, act, residual, pre[0][0], pre[0][1])
-        return nnkernels.batch_norm_act(y, bn, act, residual)
-    # host tensors: only the CPU wiring tests come here
-    y = bn(y)
-    if residual is not None:
-        y = y + residual
-    return _act(y, act)
+    _device_only(y, "BatchNorm")
+    from . import nnkernels
+    if not nnkernels.bn_supported(y.shape[1]):
+        raise RuntimeError("sqd: BatchNorm kernel needs C/4 to be a power of two (C=%d)" % y.shape[1])
+    if pre:
+        return nnkernels.batch_norm_act(y, bn, act, residual, pre[0][0], pre[0][1])
+    return nnkernels.batch_norm_act(y, bn, act, residual)
 
 
 def pose_head(x, conv, scale):
@@ -117,29 +111,26 @@ def pose_head(x, conv, scale):
     if x.is_cuda and NATIVE_CONV and conv.kernel_size == (1, 1) and conv.out_channels <= 16 and conv.bias is not None:
         from . import nnkernels
         return nnkernels.PoseHead.apply(x, conv.weight, conv.bias, scale)
+    _device_only(x, "pose_head")
     return scale * F.conv2d(x, conv.weight, conv.bias).mean(3).mean(2)
 
 
 def maxpool3x3s2(x, skip=False):
     """skip=True: -> (y, x') with x' to be read by x's other consumer (see nnkernels.MaxPool3x3s2)."""
-    if x.is_cuda:
-        from . import nnkernels
-        if x.shape[1] % 4:
-            raise RuntimeError("sqd: max-pool kernel needs a channel count that is a multiple of 4")
-        return nnkernels.MaxPool3x3s2.apply(x, skip)
-    y = F.max_pool2d(x, 3, 2, 1)         # host tensors: only the CPU wiring tests come here
-    return (y, x) if skip else y
+    _device_only(x, "max-pool")
+    from . import nnkernels
+    if x.shape[1] % 4:
+        raise RuntimeError("sqd: max-pool kernel needs a channel count that is a multiple of 4")
+    return nnkernels.MaxPool3x3s2.apply(x, skip)
 
 
 def upsample_concat(x, skip):
     """bilinear resize of x to skip's size (align_corners=True) and channel concat [up(x), skip]."""
-    if x.is_cuda:
-        from . import nnkernels
-        if x.shape[1] % 4 or skip.shape[1] % 4:
-            raise RuntimeError("sqd: upsample+concat kernel needs channel counts that are multiples of 4")
-        return nnkernels.UpsampleConcat.apply(x, skip)
-    up = F.interpolate(x, size=[skip.size(2), skip.size(3)], mode="bilinear", align_corners=True)
-    return torch.cat([up, skip], dim=1)
+    _device_only(x, "upsample+concat")
+    from . import nnkernels
+    if x.shape[1] % 4 or skip.shape[1] % 4:
+        raise RuntimeError("sqd: upsample+concat kernel needs channel counts that are multiples of 4")
+    return nnkernels.UpsampleConcat.apply(x, skip)
 
 
 def linear(x, lin, act=None):
@@ -148,40 +139,36 @@ def linear(x, lin, act=None):
         from . import nnkernels
         if nnkernels.linear_supported(lin, x):
             return nnkernels.linear_native(x, lin, act)
-    y = F.linear(x, lin.weight, lin.bias)      # feature counts that are not multiples of 16 (toy test heads), or host tensors
+    _device_only(x, "linear")
+    y = F.linear(x, lin.weight, lin.bias)      # ATen: feature counts that are not multiples of 16 (toy test heads)
     return F.leaky_relu(y, 0.01) if act == "leaky_relu" else y
 
 
 def transformer_encoder(tokens, encoder):
     """tokens [T,B,E] through nn.TransformerEncoder (4 post-norm layers, ReLU feed-forward)."""
-    if tokens.is_cuda and NATIVE_VIT:
-        from . import nnkernels
-        if nnkernels.encoder_supported(encoder):
-            return nnkernels.transformer_encoder_native(tokens, encoder)
-    return encoder(tokens)
+    _device_only(tokens, "transformer_encoder")
+    from . import nnkernels
+    if nnkernels.encoder_supported(encoder):
+        return nnkernels.transformer_encoder_native(tokens, encoder)
+    return encoder(tokens)                     # ATen: embedding widths other than 16 / 32
 
 
 def full_query_layer(x, queries):
     """Self Query Layer (reference networks/layers.py:7-21): x [B,E,h,w], queries [B,Q,E] ->
     energy maps [B,Q,h,w] (raw dot products) and summaries [B,Q,E] (softmax over the h*w pixels)."""
-    if x.is_cuda:
-        from . import ops
-        if not ops.sql_supported(x.shape[1], queries.shape[1]):
-            raise RuntimeError("sqd: Self Query Layer kernel supports E in {16,32}, Q <= 128; got E=%d Q=%d" % (x.shape[1], queries.shape[1]))
-        return ops.SelfQueryLayer.apply(x, queries)
-    # host tensors: only the CPU wiring tests come here (the training path always runs on the device)
-    n, c, h, w = x.shape
-    xt = x.reshape(n, c, h * w)
-    y = torch.matmul(queries, xt)                              # [B,Q,N]
-    summary = torch.matmul(torch.softmax(y, dim=2), xt.transpose(1, 2))
-    return y.view(n, queries.shape[1], h, w), summary
+    _device_only(x, "Self Query Layer")
+    from . import ops
+    if not ops.sql_supported(x.shape[1], queries.shape[1]):
+        raise RuntimeError("sqd: Self Query Layer kernel supports E in {16,32}, Q <= 128; got E=%d Q=%d" % (x.shape[1], queries.shape[1]))
+    return ops.SelfQueryLayer.apply(x, queries)
 
 
 def bins_head(energy_maps, conv1x1, y, min_val, max_val, raw_linear=False):
     """1x1 conv + channel softmax over the energy maps, expected value over the adaptive bin centres
     (reference networks/depth_decoder_QTR.py:61-70).  y [B,dim_out] = normalised bin widths — or, with raw_linear=True, the
     regressor's raw outputs of the norm == "linear" head (:56-60: relu + 0.1, divide by the row sum), normalised here."""
-    if raw_linear and y.is_cuda and y.shape[1] <= 128:
+    _device_only(energy_maps, "bins head")
+    if raw_linear and y.shape[1] <= 128:
         from . import ops
         centers = ops.BinCenters.apply(y, min_val, max_val)
     else:
@@ -192,12 +179,8 @@ def bins_head(energy_maps, conv1x1, y, min_val, max_val, raw_linear=False):
         widths = F.pad(widths, (1, 0), mode="constant", value=min_val)
         edges = torch.cumsum(widths, dim=1)
         centers = 0.5 * (edges[:, :-1] + edges[:, 1:])
-    if energy_maps.is_cuda:
-        from . import ops
-        Q, D = energy_maps.shape[1], conv1x1.weight.shape[0]
-        if not ops.bins_supported(Q, D):
-            raise RuntimeError("sqd: bins head kernel supports Q, dim_out <= 128; got Q=%d dim_out=%d" % (Q, D))
-        return ops.BinsHead.apply(energy_maps, conv1x1.weight, conv1x1.bias, centers)
-    # host tensors: only the CPU wiring tests come here
-    out = torch.softmax(F.conv2d(energy_maps, conv1x1.weight, conv1x1.bias), dim=1)
-    return torch.sum(out * centers.view(centers.shape[0], -1, 1, 1), dim=1, keepdim=True)
+    from . import ops
+    Q, D = energy_maps.shape[1], conv1x1.weight.shape[0]
+    if not ops.bins_supported(Q, D):
+        raise RuntimeError("sqd: bins head kernel supports Q, dim_out <= 128; got Q=%d dim_out=%d" % (Q, D))
+    return ops.BinsHead.apply(energy_maps, conv1x1.weight, conv1x1.bias, centers)

@@ -117,8 +117,8 @@ class Trainer:
         self._graph_ok = not self.opt.sqd_no_graph and self.device.type == "cuda" and not self.opt.disable_automasking
         self._side_stream = torch.cuda.Stream(device=self.device)
         self._pose_stream = torch.cuda.Stream(device=self.device)
-        # weight-gradient kernels of the convolutions on their own stream (SQD_NO_WGRAD_STREAM=1: A/B runs)
-        self._wgrad_stream = None if os.environ.get("SQD_NO_WGRAD_STREAM") else torch.cuda.Stream(device=self.device)
+        # weight-gradient kernels of the convolutions on their own stream (eager steps)
+        self._wgrad_stream = torch.cuda.Stream(device=self.device)
         self._graph_stream = torch.cuda.Stream(device=self.device) if self._graph_ok else None
         self._build_loaders()
         self.writers = {m: (_make_writer(os.path.join(self.log_path, m)) if self.rank == 0 else _NullWriter())
@@ -306,7 +306,7 @@ class Trainer:
     def _backward(self, loss):
         # eager steps: the convolutions' weight gradients run on their own stream, next to the data gradients (-0.8 ms per
         # step).  Not inside a capture: a hipGraph with ~110 extra cross-branch edges replays 1.3 ms slower than the linear one.
-        nnkernels.WGRAD_STREAM = None if (getattr(self, "_capturing", False) and not os.environ.get("SQD_WGRAD_GRAPH")) else self._wgrad_stream
+        nnkernels.WGRAD_STREAM = None if getattr(self, "_capturing", False) else self._wgrad_stream
         try:
             loss.backward()
             nnkernels.join_wgrad_stream()                # the caller's stream joins it before anything reads the gradients
@@ -352,7 +352,7 @@ class Trainer:
         self._launch_identity(inputs)
         nnkernels.defer_bn_counters(True)
         try:
-            fork = (self._capturing or os.environ.get("SQD_POSE_FORK_EAGER")) and self.use_pose_net and not os.environ.get("SQD_NO_POSE_FORK")
+            fork = self._capturing and self.use_pose_net
             if fork:
                 # inside the graph the pose network (which only needs the input frames) is a parallel branch: its small
                 # convolutions — and, through autograd's stream bookkeeping, their backward — fill the gaps the

@@ -79,7 +79,20 @@ def test_state_dict_keys_match_reference(golden):
 
 
 def test_networks_match_oracle_on_cpu():
-    """Same weights -> same outputs as the oracle restatement (module wiring; ATen-backed operators)."""
+    """Same weights -> same outputs as the oracle restatement: module wiring and state-dict layout.  The product's operators
+    refuse host tensors; the test patches plain-torch definitions of them (tests/host_ops.py) into the dispatch module."""
+    import host_ops
+    with host_ops.patched():
+        _networks_match_oracle_on_cpu()
+
+
+def test_product_network_ops_refuse_cpu_tensors():
+    import networks
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        networks.PoseCNN(2)(torch.rand(1, 6, 64, 96))
+
+
+def _networks_match_oracle_on_cpu():
     import networks
     from oracle import torch_ref as O
     from param_fill import fill_params
