@@ -70,7 +70,9 @@ class Trainer:
         assert self.opt.frame_ids[0] == 0, "frame_ids must start with 0"
         self.use_pose_net = not (self.opt.use_stereo and self.opt.frame_ids == [0])
         if self.opt.use_stereo and "s" not in self.opt.frame_ids:
-            self.opt.frame_ids.append("s")          # the other camera of the stereo pair is one more source frame (reference trainer.py:52-53)
+            # the other camera of the stereo pair is one more source frame (reference trainer.py:52-53); a new list: the parser's
+            # default is one shared object
+            self.opt.frame_ids = list(self.opt.frame_ids) + ["s"]
 
         self.models = {}
         self.models["encoder"] = self._build_encoder().to(self.device)

@@ -151,7 +151,6 @@ def test_conv_epilogue_feeds_batchnorm_statistics(N, C, H, W, K, R, stride, pad,
     gy = gy.float()
     nnops.set_native_conv(True)
     try:
-        assert nnops.CONV_BN_STATS
         xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(C > 3)
         y = nnops.conv_bn_act(xg, conv_g, bn_g, "relu")
         geom = nnkernels.conv_out_geom(xg, conv_g, s2d=(C == 3))
