@@ -189,10 +189,12 @@ int sqd_bn_train_fwd(const float *x, const float *res, const float *gamma, const
                      int pre_rows, int M, int C, float eps, float momentum, int act, void *stream);
 int sqd_bn_eval_fwd(const float *x, const float *res, const float *gamma, const float *beta, const float *running_mean,
                     const float *running_var, float *y, int M, int C, float eps, int act, void *stream);
-/* dy, x, (y | mask: the activation's derivative; neither is read when act = 0) -> dx, dres (may be NULL), dgamma [C], dbeta [C] */
+/* dy, x, (y | mask: the activation's derivative; neither is read when act = 0) -> dx, dres (may be NULL), dgamma [C], dbeta [C].
+ * act 3 (swish, the EfficientNet trunk): the derivative needs the pre-activation, recomputed from x with gamma and beta (beta may
+ * be NULL for the other activations); no residual.                                                                          */
 int sqd_bn_train_bwd(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
-                     const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma, float *dbeta,
-                     float *part, int M, int C, int act, void *stream);
+                     const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
+                     float *dbeta, float *part, int M, int C, int act, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (7) bilinear resize (align_corners=True) + channel concat, channels-last activations
@@ -361,6 +363,34 @@ int sqd_mha_fwd(const float *x, const float *Win, const float *bin, const float 
 int sqd_mha_bwd(const float *x, const float *g_sa, const float *Win, const float *bin, const float *Wo, const unsigned char *mask,
                 const float *o_save, const float *ml_save, float *gxpart, float *pWin, float *pbin, float *pWo, float *pbo, int S,
                 int B, int E, int H, float dscale, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * EfficientNet-b5 trunk operators (reference networks/base_encoder.py:76-107 loads tf_efficientnet_b5_ap from torch.hub —
+ * third-party; the operators below are what its MBConv blocks add to the ResNet path)
+ * depthwise k x k convolution, k in {3,5}, stride in {1,2}, explicit top / left padding (TensorFlow "SAME": pad_total =
+ * max((ceil(H/stride) - 1) * stride + k - H, 0), top = pad_total / 2), channels-last, C % 4 == 0.  Filters travel tap-major
+ * [k*k][C] (sqd_dw_weight_layout converts from / to torch's [C,1,k,k]).  wgrad leaves partials [chunks][k*k][C]
+ * (chunks = sqd_dw_conv_wgrad_chunks) for sqd_colsum_multi.                                                            */
+int sqd_dw_weight_layout(const float *src, float *dst, int C, int k, int to_taps, void *stream);
+int sqd_dw_conv_fwd(const float *x, const float *w_taps, float *y, int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l,
+                    int Ho, int Wo, void *stream);
+int sqd_dw_conv_dgrad(const float *dy, const float *w_taps, float *dx, int N, int H, int W, int C, int k, int stride, int pad_t,
+                      int pad_l, int Ho, int Wo, void *stream);
+int sqd_dw_conv_wgrad_chunks(int N, int Ho, int Wo);
+int sqd_dw_conv_wgrad(const float *dy, const float *x, float *part, int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l,
+                      int Ho, int Wo, void *stream);
+/* squeeze-and-excite: gate[b,c] = sigmoid(W2 . swish(W1 . mean_hw(x[b]) + b1) + b2), y = x * gate.
+ * sqd_se_pool: per-chunk channel sums of a (or a * b) over the pixels -> part [B][sqd_se_chunks(HW)][C];
+ * sqd_se_gate_fwd: part, W1 [R,C], b1 [R], W2 [C,R], b2 [C] -> s [B,C] (pooled mean), pre1 [B,R], gate [B,C];
+ * sqd_se_gate_bwd: dgpart = sqd_se_pool(dy, x) -> per-image partials dW1part [B,R,C], db1part [B,R rounded up to 4], dW2part [B,C,R], db2part [B,C]
+ * and ds [B,C] (gradient w.r.t. the pooled mean, already divided by HW); sqd_se_scale: y = x * gate (+ ds: the backward).          */
+int sqd_se_chunks(int HW);
+int sqd_se_pool(const float *a, const float *b, float *part, int B, int HW, int C, void *stream);
+int sqd_se_gate_fwd(const float *part, const float *W1, const float *b1, const float *W2, const float *b2, float *s, float *pre1,
+                    float *gate, int B, int HW, int C, int R, void *stream);
+int sqd_se_gate_bwd(const float *dgpart, const float *W1, const float *W2, const float *s, const float *pre1, const float *gate,
+                    float *dW1part, float *db1part, float *dW2part, float *db2part, float *ds, int B, int HW, int C, int R, void *stream);
+int sqd_se_scale(const float *x, const float *gate, const float *ds, float *y, int B, int HW, int C, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * PoseCNN tail

@@ -16,13 +16,19 @@
 namespace {
 using namespace sqd;
 
-constexpr int ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2;
+constexpr int ACT_NONE = 0, ACT_RELU = 1, ACT_LEAKY = 2, ACT_SWISH = 3;      // swish = x * sigmoid(x) (EfficientNet)
 constexpr float LEAKY_SLOPE = 0.01f;
 
 __device__ __forceinline__ float act_fwd(float v, int act) {
     if (act == ACT_RELU) return v > 0.f ? v : 0.f;
     if (act == ACT_LEAKY) return v > 0.f ? v : v * LEAKY_SLOPE;
+    if (act == ACT_SWISH) return v / (1.f + __expf(-v));
     return v;
+}
+// swish has no sign-mask shortcut: its derivative needs the pre-activation v = gamma * xhat + beta, recomputed from x
+__device__ __forceinline__ float swish_bwd(float v) {
+    const float sg = 1.f / (1.f + __expf(-v));
+    return sg * (1.f + v * (1.f - sg));
 }
 // derivative expressed through the OUTPUT y (what the backward has at hand)
 __device__ __forceinline__ float act_bwd(float y, int act) {
@@ -71,17 +77,22 @@ template <int MODE>
 __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict__ x, const float *__restrict__ dy,
                                                         const float *__restrict__ y, const float *__restrict__ mean,
                                                         const float *__restrict__ rstd, float *__restrict__ part, int M,
-                                                        int C, int act, Geom g, const unsigned char *__restrict__ mask) {
+                                                        int C, int act, Geom g, const unsigned char *__restrict__ mask,
+                                                        const float *__restrict__ gamma, const float *__restrict__ beta) {
     const int t = threadIdx.x;
     const int cg0 = t % g.TPR, rr = t / g.TPR;
     const int r0 = blockIdx.x * g.rows_per_block, r1 = min(M, r0 + g.rows_per_block);
     __shared__ float4 sh[2][256];
     for (int cg = cg0; cg < g.V; cg += g.TPR) {
         float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-        float4 mu, rs;
+        float4 mu, rs, ga, be;
         if (MODE == 1) {
             mu = *reinterpret_cast<const float4 *>(mean + cg * 4);
             rs = *reinterpret_cast<const float4 *>(rstd + cg * 4);
+            if (act == ACT_SWISH) {
+                ga = *reinterpret_cast<const float4 *>(gamma + cg * 4);
+                be = *reinterpret_cast<const float4 *>(beta + cg * 4);
+            }
         }
         for (int row = r0 + rr; row < r1; row += g.RP) {
             const size_t o = (size_t)row * C + cg * 4;
@@ -91,7 +102,12 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict_
                 b.x = fmaf(xv.x, xv.x, b.x); b.y = fmaf(xv.y, xv.y, b.y); b.z = fmaf(xv.z, xv.z, b.z); b.w = fmaf(xv.w, xv.w, b.w);
             } else {
                 const float4 gy = *reinterpret_cast<const float4 *>(dy + o);
-                const float4 da = act_bwd4(mask, y, o / 4, act);
+                float4 da;
+                if (act == ACT_SWISH)
+                    da = make_float4(swish_bwd(fmaf((xv.x - mu.x) * rs.x, ga.x, be.x)), swish_bwd(fmaf((xv.y - mu.y) * rs.y, ga.y, be.y)),
+                                     swish_bwd(fmaf((xv.z - mu.z) * rs.z, ga.z, be.z)), swish_bwd(fmaf((xv.w - mu.w) * rs.w, ga.w, be.w)));
+                else
+                    da = act_bwd4(mask, y, o / 4, act);
                 const float d0 = gy.x * da.x, d1 = gy.y * da.y, d2 = gy.z * da.z, d3 = gy.w * da.w;
                 a.x += d0; a.y += d1; a.z += d2; a.w += d3;
                 b.x = fmaf(d0, (xv.x - mu.x) * rs.x, b.x); b.y = fmaf(d1, (xv.y - mu.y) * rs.y, b.y);
@@ -224,15 +240,17 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
                                                            const float *__restrict__ mean, const float *__restrict__ rstd,
                                                            const float *__restrict__ dgamma, const float *__restrict__ dbeta,
                                                            float *__restrict__ dx, float *__restrict__ dres, size_t total4,
-                                                           int C, float invM, int act, const unsigned char *__restrict__ mask) {
+                                                           int C, float invM, int act, const unsigned char *__restrict__ mask,
+                                                           const float *__restrict__ beta) {
     const unsigned V = (unsigned)C / 4u;
     const size_t stride = (size_t)gridDim.x * 256;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     unsigned cg = (unsigned)(i % V);
     const unsigned cstep = (unsigned)(stride % V);              // 0 whenever V divides 256 (C <= 1024): constants loaded once
-    float4 k0, k1, k2, mu;                                      // dx = k0 * dz - k1 - (x - mu) * k2
+    float4 k0, k1, k2, mu, be = make_float4(0.f, 0.f, 0.f, 0.f);   // dx = k0 * dz - k1 - (x - mu) * k2
     auto params = [&]() {
         const float4 ga = reinterpret_cast<const float4 *>(gamma)[cg], rs = reinterpret_cast<const float4 *>(rstd)[cg];
+        if (act == ACT_SWISH) be = reinterpret_cast<const float4 *>(beta)[cg];
         const float4 dg = reinterpret_cast<const float4 *>(dgamma)[cg], db = reinterpret_cast<const float4 *>(dbeta)[cg];
         mu = reinterpret_cast<const float4 *>(mean)[cg];
         k0 = make_float4(ga.x * rs.x, ga.y * rs.y, ga.z * rs.z, ga.w * rs.w);
@@ -243,7 +261,12 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
     for (; i < total4; i += stride) {
         const float4 gy = reinterpret_cast<const float4 *>(dy)[i];
         const float4 xv = reinterpret_cast<const float4 *>(x)[i];
-        const float4 da = act_bwd4(mask, y, i, act);
+        float4 da;
+        if (act == ACT_SWISH)          // pre-activation = gamma * xhat + beta = k0 * (x - mu) + beta
+            da = make_float4(swish_bwd(fmaf(xv.x - mu.x, k0.x, be.x)), swish_bwd(fmaf(xv.y - mu.y, k0.y, be.y)),
+                             swish_bwd(fmaf(xv.z - mu.z, k0.z, be.z)), swish_bwd(fmaf(xv.w - mu.w, k0.w, be.w)));
+        else
+            da = act_bwd4(mask, y, i, act);
         float4 dz, o;
         dz.x = gy.x * da.x; dz.y = gy.y * da.y; dz.z = gy.z * da.z; dz.w = gy.w * da.w;
         o.x = k0.x * (dz.x - k1.x - (xv.x - mu.x) * k2.x);
@@ -281,6 +304,7 @@ extern "C" int sqd_bn_train_fwd(const float *x, const float *res, const float *g
                                 float *running_var, float *y, unsigned char *mask, float *save_mean, float *save_rstd, float *part,
                                 int pre_rows, int M, int C, float eps, float momentum, int act, void *stream) {
     SQD_CHECK_ARG(x && gamma && beta && y && save_mean && save_rstd && part, "sqd_bn_train_fwd: null pointer");
+    SQD_CHECK_ARG(act != ACT_SWISH || !res, "sqd_bn_train_fwd: swish takes no residual (its backward recomputes the pre-activation from x)");
     if (check("sqd_bn_train_fwd", M, C)) return SQD_EINVAL;
     const Geom g = geom(M, C);
     hipStream_t s = (hipStream_t)stream;
@@ -289,7 +313,7 @@ extern "C" int sqd_bn_train_fwd(const float *x, const float *res, const float *g
     // convolution's epilogue (sqd_conv_fwd's stats) — and the reduction pass over x is skipped
     if (pre_rows <= 0)
         hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(g.nblk), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, part, M, C, act, g,
-                           (const unsigned char *)nullptr);
+                           (const unsigned char *)nullptr, (const float *)nullptr, (const float *)nullptr);
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, part, pre_rows > 0 ? pre_rows : g.nblk, M,
                        C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
     const size_t total4 = (size_t)M * C / 4;
@@ -313,19 +337,20 @@ extern "C" int sqd_bn_eval_fwd(const float *x, const float *res, const float *ga
 }
 
 extern "C" int sqd_bn_train_bwd(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
-                                const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma, float *dbeta,
-                                float *part, int M, int C, int act, void *stream) {
+                                const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
+                                float *dbeta, float *part, int M, int C, int act, void *stream) {
     SQD_CHECK_ARG(dy && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && part, "sqd_bn_train_bwd: null pointer");
-    SQD_CHECK_ARG(act == ACT_NONE || y || mask, "sqd_bn_train_bwd: an activation needs y or the sign mask of the forward");
+    SQD_CHECK_ARG(act == ACT_NONE || act == ACT_SWISH || y || mask, "sqd_bn_train_bwd: ReLU / LeakyReLU need y or the sign mask of the forward");
+    SQD_CHECK_ARG(act != ACT_SWISH || (beta && !dres), "sqd_bn_train_bwd: swish needs beta (pre-activation is recomputed) and takes no residual");
     if (check("sqd_bn_train_bwd", M, C)) return SQD_EINVAL;
     const Geom g = geom(M, C);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nblk), dim3(256), 0, s, x, dy, y, save_mean, save_rstd, part, M, C, act, g, mask);
+    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nblk), dim3(256), 0, s, x, dy, y, save_mean, save_rstd, part, M, C, act, g, mask, gamma, beta);
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, part, g.nblk, M, C, dgamma, dbeta);
     const size_t total4 = (size_t)M * C / 4;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, s, dy, x, y, gamma, save_mean, save_rstd, dgamma,
-                       dbeta, dx, dres, total4, C, 1.0f / (float)M, act, mask);
+                       dbeta, dx, dres, total4, C, 1.0f / (float)M, act, mask, beta);
     SQD_CHECK_LAUNCH("sqd_bn_train_bwd");
     return SQD_OK;
 }

@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
     const int Sc = MODE == 0 ? g.S : (s0 < g.S ? (g.S - s0 + g.stride - 1) / g.stride : 0);
     const int Ncols = MODE == 0 ? g.K : g.C;                    // output channels of this GEMM
     const int Cred = MODE == 0 ? g.C : g.K;                     // channels reduced per (r,s)
-    const int cchunks = Cred / BKT;
+    const int cchunks = (Cred + BKT - 1) / BKT;              // the last chunk may be partial (Cred % 4 == 0): its tail is masked
     const int Tall = Rc * Sc * cchunks;
     // split-K: workgroup z reduces slices [s_beg, s_end) and writes a partial tile (summed by gemm_reduce_kernel)
     const int s_beg = (int)((long long)Tall * blockIdx.z / zsplits), s_end = (int)((long long)Tall * (blockIdx.z + 1) / zsplits);
@@ -188,10 +188,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
             bool ok;
             unsigned off;
             if (MODE == 0) {
-                ok = aval[i] && (unsigned)(ah[i] + r) < (unsigned)g.H && (unsigned)(aw[i] + s) < (unsigned)g.W;
+                ok = aval[i] && (unsigned)(ah[i] + r) < (unsigned)g.H && (unsigned)(aw[i] + s) < (unsigned)g.W && cc * BKT + c4 * 4 < g.C;
                 off = (unsigned)((apix[i] + tapoff) * g.C + cc * BKT + c4 * 4) * 4u;
             } else {
-                ok = aval[i] && (unsigned)(ah[i] - r) < (unsigned)g.Ho && (unsigned)(aw[i] - s) < (unsigned)g.Wo;
+                ok = aval[i] && (unsigned)(ah[i] - r) < (unsigned)g.Ho && (unsigned)(aw[i] - s) < (unsigned)g.Wo && cc * BKT + c4 * 4 < g.K;
                 off = (unsigned)((apix[i] + tapoff) * g.K + cc * BKT + c4 * 4) * 4u;
             }
             ra[i] = buf_load4(a_rsrc, ok ? off : 0xffffffffu);
@@ -210,11 +210,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
             unsigned off;
             if (MODE == 0) {
                 const int row = idx / NQ, q4 = idx % NQ;                 // row = out channel, q4 = float4 along c
-                ok = row < BN && n0 + row < g.K;
+                ok = row < BN && n0 + row < g.K && cc * BKT + q4 * 4 < g.C;
                 off = (unsigned)(((n0 + row) * g.R * g.S + rs) * g.C + cc * BKT + q4 * 4) * 4u;
             } else {
                 const int kk = idx % BKT, cq = idx / BKT;                // kk = k inside the slice, cq = float4 of in-channels
-                ok = cq * 4 < BN && n0 + cq * 4 < g.C;
+                ok = cq * 4 < BN && n0 + cq * 4 < g.C && cc * BKT + kk < g.K;
                 off = (unsigned)(((cc * BKT + kk) * g.R * g.S + rs) * g.C + n0 + cq * 4) * 4u;
             }
             rb[i] = buf_load4(w_rsrc, ok ? off : 0xffffffffu);
@@ -870,7 +870,7 @@ int check_geom(const char *who, const ConvGeom &g) {
 }
 }  // namespace
 
-extern "C" int sqd_conv_supported(int C, int K) { return (C % 16 == 0 && K % 16 == 0) ? 1 : 0; }
+extern "C" int sqd_conv_supported(int C, int K) { return (C % 4 == 0 && K % 4 == 0) ? 1 : 0; }
 
 struct GemmPlan {
     int bm, bn, z, bk;
@@ -906,7 +906,7 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     const int Mrows = mode == 0 ? g.N * g.Ho * g.Wo : g.N * g.H * g.W;     // output rows (workspace size)
     const int Ncols = mode == 0 ? g.K : g.C;
     const int taps = mode == 0 ? g.R * g.S : ((g.R + g.stride - 1) / g.stride) * ((g.S + g.stride - 1) / g.stride);
-    const int T = taps * ((mode == 0 ? g.C : g.K) / BK);
+    const int T = taps * (((mode == 0 ? g.C : g.K) + BK - 1) / BK);
     GemmPlan p;
     // Tile and split-K by a small cost model (cycles on the busiest CU), calibrated on the config-B layers
     // (profiles/r01c_conv_layers.md): a workgroup-step costs its MFMA cycles (8 x 64 per 32x32 wave tile) and, when too
@@ -1068,7 +1068,7 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
                       (bk == 64 && single && bm == 64 && bn == 64 && (mode == 0 ? C : K) % 64 == 0),
                   "sqd_conv_set_plan: slice width %d not possible here (32 needs 32 | reduced channels and bm + bn <= 192; 64 exists "
                   "for the single-buffered 64x64 tile with 64 | reduced channels)", bk);
-    const int T = taps * ((mode == 0 ? C : K) / bk);
+    const int T = taps * (((mode == 0 ? C : K) + bk - 1) / bk);
     const int64_t out_elems = mode == 0 ? (int64_t)N * Ho * Wo * K : (int64_t)N * H * W * C;
     const bool tile_ok = (bm == 128 && (bn == 128 || bn == 64 || bn == 32)) || (bm == 64 && (bn == 128 || bn == 64));
     SQD_CHECK_ARG(tile_ok && z >= 1 && z <= 64, "sqd_conv_set_plan: unsupported plan %dx%d z=%d", bm, bn, z);
@@ -1113,7 +1113,7 @@ extern "C" int sqd_conv_fwd(const float *x, const float *w, const float *bias, f
     SQD_CHECK_ARG(x && w && y, "sqd_conv_fwd: null pointer");
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     if (check_geom("sqd_conv_fwd", g)) return SQD_EINVAL;
-    SQD_CHECK_ARG(C % 16 == 0, "sqd_conv_fwd: C=%d must be a multiple of 16", C);
+    SQD_CHECK_ARG(C % 4 == 0 && K % 4 == 0, "sqd_conv_fwd: C=%d and K=%d must be multiples of 4", C, K);
     if (launch_gemm(0, x, w, bias, y, ws, g, act, stream, stats)) return SQD_EINVAL;
     SQD_CHECK_LAUNCH("sqd_conv_fwd");
     return SQD_OK;
@@ -1138,7 +1138,7 @@ extern "C" int sqd_conv_dgrad(const float *dy, const float *w, const float *adde
     SQD_CHECK_ARG(dy && w && dx, "sqd_conv_dgrad: null pointer");
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     if (check_geom("sqd_conv_dgrad", g)) return SQD_EINVAL;
-    SQD_CHECK_ARG(K % 16 == 0 && C % 4 == 0, "sqd_conv_dgrad: K=%d must be a multiple of 16 and C=%d of 4", K, C);
+    SQD_CHECK_ARG(K % 4 == 0 && C % 4 == 0, "sqd_conv_dgrad: K=%d and C=%d must be multiples of 4", K, C);
     SQD_CHECK_ARG(addend != dx, "sqd_conv_dgrad: addend must not alias dx");
     if (launch_gemm(1, dy, w, addend, dx, ws, g, 0, stream)) return SQD_EINVAL;
     SQD_CHECK_LAUNCH("sqd_conv_dgrad");

@@ -130,7 +130,17 @@ _SIGNATURES = {
     "sqd_bn_nblk": (_I, [_I, _I]),
     "sqd_bn_train_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),
     "sqd_bn_eval_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
-    "sqd_bn_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "sqd_bn_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "sqd_dw_weight_layout": (_I, [_P, _P, _I, _I, _I, _P]),
+    "sqd_dw_conv_fwd": (_I, [_P, _P, _P] + [_I] * 10 + [_P]),
+    "sqd_dw_conv_dgrad": (_I, [_P, _P, _P] + [_I] * 10 + [_P]),
+    "sqd_dw_conv_wgrad_chunks": (_I, [_I, _I, _I]),
+    "sqd_dw_conv_wgrad": (_I, [_P, _P, _P] + [_I] * 10 + [_P]),
+    "sqd_se_chunks": (_I, [_I]),
+    "sqd_se_pool": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "sqd_se_gate_fwd": (_I, [_P] * 8 + [_I, _I, _I, _I, _P]),
+    "sqd_se_gate_bwd": (_I, [_P] * 11 + [_I, _I, _I, _I, _P]),
+    "sqd_se_scale": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "sqd_upcat_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sqd_upcat_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sqd_backproject_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),

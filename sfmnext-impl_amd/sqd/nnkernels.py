@@ -10,7 +10,7 @@ import torch
 from . import lib as _l
 from .ops import _ptr, _stream
 
-ACT = {None: 0, "relu": 1, "leaky_relu": 2}
+ACT = {None: 0, "relu": 1, "leaky_relu": 2, "swish": 3}
 
 
 _DEBUG_COPIES = bool(os.environ.get("SQD_DEBUG_COPIES"))
@@ -58,11 +58,11 @@ class BatchNormAct(torch.autograd.Function):
             mean = torch.empty(C, device=x.device, dtype=torch.float32)
             rstd = torch.empty(C, device=x.device, dtype=torch.float32)
             # sign bits of the pre-activation (1 byte per 4 elements): the backward reads them instead of y
-            mask = torch.empty(M * C // 4, device=x.device, dtype=torch.uint8) if code else None
+            mask = torch.empty(M * C // 4, device=x.device, dtype=torch.uint8) if code in (1, 2) else None    # (swish: recomputed from x)
             _l.check(L.sqd_bn_train_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                         _ptr(y), _ptr(mask), _ptr(mean), _ptr(rstd), _ptr(part), pre_rows, M, C, float(eps),
                                         float(momentum), code, _stream()), "bn_train_fwd")
-            ctx.save_for_backward(x, mask, gamma, mean, rstd)
+            ctx.save_for_backward(x, mask, gamma, mean, rstd, beta if code == 3 else None)
             ctx.has_res, ctx.code = residual is not None, code
         else:
             _l.check(L.sqd_bn_eval_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
@@ -75,7 +75,7 @@ class BatchNormAct(torch.autograd.Function):
     def backward(ctx, dy):
         if not ctx.training:
             raise NotImplementedError("sqd: BatchNormAct backward is implemented for training mode only")
-        x, mask, gamma, mean, rstd = ctx.saved_tensors
+        x, mask, gamma, mean, rstd, beta = ctx.saved_tensors
         dy = _cl(dy)
         N, C, H, W = x.shape
         M = N * H * W
@@ -85,7 +85,7 @@ class BatchNormAct(torch.autograd.Function):
         dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
         part = torch.empty(L.sqd_bn_nblk(M, C) * C * 2, device=x.device, dtype=torch.float32)
-        _l.check(L.sqd_bn_train_bwd(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
+        _l.check(L.sqd_bn_train_bwd(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
                                     _ptr(dgamma), _ptr(dbeta), _ptr(part), M, C, ctx.code, _stream()), "bn_train_bwd")
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
 
@@ -151,7 +151,7 @@ class UpsampleConcat(torch.autograd.Function):
 
 def conv_supported(C, K):
     """Both directions of the native implicit-GEMM convolution (forward + dgrad + wgrad)."""
-    return C % 16 == 0 and K % 16 == 0
+    return C % 4 == 0 and K % 4 == 0
 
 
 _PLAN_CACHE = {}
@@ -277,6 +277,104 @@ def _wgrad_part_floats(geom):
     return n
 
 
+def tf_same_pad(size, k, stride):
+    """TensorFlow "SAME" padding of one axis (the tf_efficientnet variants): -> (output size, leading pad)"""
+    out = -(-size // stride)
+    total = max((out - 1) * stride + k - size, 0)
+    return out, total // 2
+
+
+class DepthwiseConv(torch.autograd.Function):
+    """Depthwise k x k convolution (groups == channels), k in {3, 5}, stride in {1, 2}, channels-last.
+    forward(x [N,C,H,W], weight [C,1,k,k], stride, pad) — pad: an int (symmetric) or "same" (TensorFlow SAME, asymmetric)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        _require(x, "DepthwiseConv input")
+        x = _cl(x)
+        N, C, H, W = x.shape
+        k = weight.shape[2]
+        if pad == "same":
+            (Ho, pt), (Wo, pl) = tf_same_pad(H, k, stride), tf_same_pad(W, k, stride)
+        else:
+            pt = pl = int(pad)
+            Ho, Wo = (H + 2 * pt - k) // stride + 1, (W + 2 * pl - k) // stride + 1
+        L = _l.lib()
+        wt = torch.empty(k * k, C, device=x.device, dtype=torch.float32)
+        _l.check(L.sqd_dw_weight_layout(_ptr(weight.contiguous()), _ptr(wt), C, k, 1, _stream()), "dw_weight_layout")
+        y = torch.empty((N, C, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _l.check(L.sqd_dw_conv_fwd(_ptr(x), _ptr(wt), _ptr(y), N, H, W, C, k, stride, pt, pl, Ho, Wo, _stream()), "dw_conv_fwd")
+        ctx.save_for_backward(x, wt)
+        ctx.geom = (N, H, W, C, k, stride, pt, pl, Ho, Wo)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wt = ctx.saved_tensors
+        N, H, W, C, k, stride, pt, pl, Ho, Wo = ctx.geom
+        dy = _cl(dy)
+        L = _l.lib()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
+            _l.check(L.sqd_dw_conv_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), N, H, W, C, k, stride, pt, pl, Ho, Wo, _stream()), "dw_conv_dgrad")
+        if ctx.needs_input_grad[1]:
+            chunks = L.sqd_dw_conv_wgrad_chunks(N, Ho, Wo)
+            part = torch.empty(chunks, k * k * C, device=dy.device, dtype=torch.float32)
+            _l.check(L.sqd_dw_conv_wgrad(_ptr(dy), _ptr(x), _ptr(part), N, H, W, C, k, stride, pt, pl, Ho, Wo, _stream()), "dw_conv_wgrad")
+            dwt = torch.empty(k * k, C, device=dy.device, dtype=torch.float32)
+            _colsum_multi([(part, dwt, 0)])
+            dw = torch.empty(C, 1, k, k, device=dy.device, dtype=torch.float32)
+            _l.check(L.sqd_dw_weight_layout(_ptr(dwt), _ptr(dw), C, k, 0, _stream()), "dw_weight_layout")
+        return dx, dw, None, None
+
+
+class SqueezeExcite(torch.autograd.Function):
+    """x * sigmoid(W2 . swish(W1 . mean_hw(x) + b1) + b2) — the squeeze-and-excite gate of the MBConv blocks.
+    forward(x [B,C,H,W], w1 [R,C,1,1], b1 [R], w2 [C,R,1,1], b2 [C])"""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        _require(x, "SqueezeExcite input")
+        x = _cl(x)
+        B, C, H, W = x.shape
+        R, HW = w1.shape[0], H * W
+        L = _l.lib()
+        W1, W2 = w1.reshape(R, C).contiguous(), w2.reshape(C, R).contiguous()
+        dev = x.device
+        part = torch.empty(B, L.sqd_se_chunks(HW), C, device=dev, dtype=torch.float32)
+        _l.check(L.sqd_se_pool(_ptr(x), None, _ptr(part), B, HW, C, _stream()), "se_pool")
+        s, pre1, gate = (torch.empty(B, n, device=dev, dtype=torch.float32) for n in (C, R, C))
+        _l.check(L.sqd_se_gate_fwd(_ptr(part), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(s), _ptr(pre1), _ptr(gate), B, HW, C, R, _stream()),
+                 "se_gate_fwd")
+        y = torch.empty_like(x, memory_format=torch.channels_last)
+        _l.check(L.sqd_se_scale(_ptr(x), _ptr(gate), None, _ptr(y), B, HW, C, _stream()), "se_scale")
+        ctx.save_for_backward(x, W1, W2, s, pre1, gate)
+        ctx.shapes = (w1.shape, w2.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, W1, W2, s, pre1, gate = ctx.saved_tensors
+        B, C, H, W = x.shape
+        R, HW = W1.shape[0], H * W
+        RP = (R + 3) // 4 * 4
+        dy = _cl(dy)
+        L = _l.lib()
+        dev = dy.device
+        dgpart = torch.empty(B, L.sqd_se_chunks(HW), C, device=dev, dtype=torch.float32)
+        _l.check(L.sqd_se_pool(_ptr(dy), _ptr(x), _ptr(dgpart), B, HW, C, _stream()), "se_pool")
+        dW1p, db1p, dW2p, db2p, ds = (torch.empty(B, n, device=dev, dtype=torch.float32) for n in (R * C, RP, C * R, C, C))
+        _l.check(L.sqd_se_gate_bwd(_ptr(dgpart), _ptr(W1), _ptr(W2), _ptr(s), _ptr(pre1), _ptr(gate), _ptr(dW1p), _ptr(db1p), _ptr(dW2p),
+                                   _ptr(db2p), _ptr(ds), B, HW, C, R, _stream()), "se_gate_bwd")
+        dx = torch.empty_like(x, memory_format=torch.channels_last)
+        _l.check(L.sqd_se_scale(_ptr(dy), _ptr(gate), _ptr(ds), _ptr(dx), B, HW, C, _stream()), "se_scale")
+        dW1, dW2 = torch.empty(R, C, device=dev, dtype=torch.float32), torch.empty(C, R, device=dev, dtype=torch.float32)
+        db1, db2 = torch.empty(RP, device=dev, dtype=torch.float32), torch.empty(C, device=dev, dtype=torch.float32)
+        _colsum_multi([(dW1p, dW1, 0), (db1p, db1, 0), (dW2p, dW2, 0), (db2p, db2, 0)])
+        return dx, dW1.view(ctx.shapes[0]), db1[:R], dW2.view(ctx.shapes[1]), db2
+
+
 class PoseHead(torch.autograd.Function):
     """scale * pose_conv(x).mean(3).mean(2) of PoseCNN (reference networks/pose_cnn.py:40-42) as one launch each way.
     forward(x [B,C,h,w] channels-last, weight [J,C,1,1], bias [J], scale) -> [B,J]"""
@@ -324,12 +422,12 @@ def linear_native(x, lin, act=None):
 
 
 def linear_supported(lin, x):
-    return x.dim() == 2 and lin.in_features % 16 == 0 and lin.out_features % 16 == 0
+    return x.dim() == 2 and lin.in_features % 4 == 0 and lin.out_features % 4 == 0
 
 
 def conv_module_supported(conv):
     s, p = conv.stride, conv.padding
-    return (conv.in_channels % 16 == 0 and conv.out_channels % 16 == 0 and s[0] == s[1] and p[0] == p[1]
+    return (conv.in_channels % 4 == 0 and conv.out_channels % 4 == 0 and s[0] == s[1] and p[0] == p[1]
             and conv.dilation == (1, 1) and conv.groups == 1 and not isinstance(p, str))
 
 
@@ -481,7 +579,7 @@ def conv_stats_rows(geom):
 def stem_s2d_supported(conv, x):
     """7x7 / stride 2 / pad 3 convolutions on few input channels (the ResNet and PoseCNN stems)."""
     return (conv.kernel_size == (7, 7) and conv.stride == (2, 2) and conv.padding == (3, 3) and conv.dilation == (1, 1)
-            and conv.groups == 1 and conv.in_channels % 16 != 0 and conv.out_channels % 16 == 0
+            and conv.groups == 1 and conv.in_channels % 4 != 0 and conv.out_channels % 4 == 0
             and x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0)
 
 

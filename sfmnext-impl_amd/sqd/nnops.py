@@ -7,7 +7,7 @@ implementation serves each operator:
 
     "hip"   hand-written kernel in libsqd.so (csrc/*.hip)
     "aten"  PyTorch-ROCm ATen (MIOpen / rocBLAS) for shapes the native kernels do not take (channel / feature counts not
-            divisible by 16) — device tensors only.
+            divisible by 4) — device tensors only.
 Host tensors are refused: the CPU restatement of these operators is test infrastructure (oracle/, tests/host_ops.py).
 """
 import torch
@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 BACKEND = {
     "conv2d": "aten", "conv_bn_act": "aten conv + hip bn/act/residual", "maxpool3x3s2": "hip", "upsample_concat": "hip",
-    "pose_head": "hip", "linear": "hip (1x1 implicit GEMM over rows; feature counts not divisible by 16: aten)", "transformer_encoder": "hip (fused attention up to 512 tokens, feed-forward, add+dropout+layernorm)", "full_query_layer": "hip", "bins_head": "hip",
+    "pose_head": "hip", "linear": "hip (1x1 implicit GEMM over rows; feature counts not divisible by 4: aten)", "transformer_encoder": "hip (fused attention up to 512 tokens, feed-forward, add+dropout+layernorm)", "full_query_layer": "hip", "bins_head": "hip",
 }
 
 
@@ -42,7 +42,7 @@ def set_native_conv(on):
     through libsqd; the 3- and 6-channel stem convolutions stay on ATen."""
     global NATIVE_CONV
     NATIVE_CONV = bool(on)
-    BACKEND["conv2d"] = "hip (incl. the 7x7 stems via space-to-depth; channel counts not divisible by 16: aten)" if on else "aten"
+    BACKEND["conv2d"] = "hip (incl. the 7x7 stems via space-to-depth; channel counts not divisible by 4: aten)" if on else "aten"
     BACKEND["conv_bn_act"] = ("hip conv" if on else "aten conv") + " + hip bn/act/residual"
 
 
@@ -71,7 +71,7 @@ def _conv(x, conv, act=None, skip=False, bn_stats=None):
                     bn_stats.append((stats, rows))
             return out
     _device_only(x, "conv2d")
-    y = _act(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), act)      # ATen: channel counts not divisible by 16
+    y = _act(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), act)      # ATen: channel counts not divisible by 4
     return (y, x) if skip else y
 
 
@@ -140,7 +140,7 @@ def linear(x, lin, act=None):
         if nnkernels.linear_supported(lin, x):
             return nnkernels.linear_native(x, lin, act)
     _device_only(x, "linear")
-    y = F.linear(x, lin.weight, lin.bias)      # ATen: feature counts that are not multiples of 16 (toy test heads)
+    y = F.linear(x, lin.weight, lin.bias)      # ATen: feature counts that are not multiples of 4
     return F.leaky_relu(y, 0.01) if act == "leaky_relu" else y
 
 

@@ -23,6 +23,12 @@ CASES = [  # N, C, H, W, K, R, stride, pad, bias, act
     (1, 512, 6, 20, 512, 3, 1, 1, False, None),        # few pixels, long reduction: split-K path
     (4, 32, 24, 40, 64, 3, 1, 1, True, None),          # direct-operand wgrad with the fused bias gradient
     (2, 16, 64, 96, 32, 5, 2, 2, True, "relu"),        # same, 5x5 stride 2 + ReLU, K = 32
+    # EfficientNet-b5 widths: 24 / 40 channels are multiples of 4, not of 16 — the last reduction slice is partial
+    (2, 24, 20, 28, 144, 1, 1, 0, False, None),        # MBConv expansion 24 -> 144 (forward reduction over 24)
+    (2, 144, 20, 28, 24, 1, 1, 0, False, None),        # projection 144 -> 24 (data gradient reduces over 24)
+    (2, 40, 10, 14, 240, 1, 1, 0, False, None),
+    (2, 240, 10, 14, 40, 1, 1, 0, True, None),
+    (1, 88, 12, 20, 40, 3, 1, 1, True, None),          # decoder: concat widths such as 64 + 24 = 88
 ]
 
 

@@ -239,3 +239,75 @@ def test_pose_head(B, C, h, w, J):
     for a, b, what in ((y, yr, "out"), (xd.grad, xr.grad, "dx"), (conv.weight.grad, ref.weight.grad, "dW"), (conv.bias.grad, ref.bias.grad, "db")):
         a, b = a.detach().cpu().double(), b.detach()
         assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max()) + 1e-9, (what, float((a - b).abs().max()))
+
+
+@pytest.mark.parametrize("N,C,H,W,k,stride,pad", [(2, 48, 17, 23, 3, 1, "same"), (2, 144, 16, 24, 3, 2, "same"), (2, 240, 15, 21, 5, 2, "same"),
+                                                  (1, 768, 9, 12, 5, 1, "same"), (2, 24, 12, 10, 3, 1, 1), (3, 64, 11, 13, 5, 2, 2)])
+def test_depthwise_conv(N, C, H, W, k, stride, pad):
+    """depthwise k x k convolution (TensorFlow SAME or symmetric padding) against torch's grouped convolution in fp64"""
+    from sqd import nnkernels
+    torch.manual_seed(C + k)
+    x, w = torch.randn(N, C, H, W), torch.randn(C, 1, k, k) / k
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    if pad == "same":
+        (Ho, pt), (Wo, pl) = nnkernels.tf_same_pad(H, k, stride), nnkernels.tf_same_pad(W, k, stride)
+        tot_h, tot_w = max((Ho - 1) * stride + k - H, 0), max((Wo - 1) * stride + k - W, 0)
+        yr = F.conv2d(F.pad(xr, (pl, tot_w - pl, pt, tot_h - pt)), wr, None, stride, 0, 1, C)
+    else:
+        yr = F.conv2d(xr, wr, None, stride, pad, 1, C)
+    g = torch.randn(yr.shape)
+    yr.backward(g.double())
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    wd = w.cuda().requires_grad_(True)
+    y = nnkernels.DepthwiseConv.apply(xd, wd, stride, pad)
+    assert y.shape == yr.shape
+    y.backward(g.cuda())
+    for a, b, what in ((y, yr, "y"), (xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dw")):
+        a, b = a.detach().cpu().double(), b.detach()
+        assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, (what, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.parametrize("B,C,H,W,R", [(2, 144, 12, 20, 6), (3, 48, 7, 9, 12), (1, 1056, 5, 8, 44), (2, 3072, 3, 4, 128), (2, 240, 40, 64, 10)])
+def test_squeeze_excite(B, C, H, W, R):
+    from sqd import nnkernels
+    torch.manual_seed(C + R)
+    x = torch.randn(B, C, H, W)
+    w1, b1 = torch.randn(R, C, 1, 1) / C ** 0.5, 0.1 * torch.randn(R)
+    w2, b2 = torch.randn(C, R, 1, 1) / R ** 0.5, 0.1 * torch.randn(C)
+    g = torch.randn(B, C, H, W)
+    ref = [t.double().requires_grad_(True) for t in (x, w1, b1, w2, b2)]
+    s = ref[0].mean((2, 3), keepdim=True)
+    r = F.conv2d(s, ref[1], ref[2])
+    r = r * torch.sigmoid(r)
+    yr = ref[0] * torch.sigmoid(F.conv2d(r, ref[3], ref[4]))
+    yr.backward(g.double())
+    devs = [x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)] + [t.cuda().requires_grad_(True) for t in (w1, b1, w2, b2)]
+    y = nnkernels.SqueezeExcite.apply(*devs)
+    y.backward(g.cuda())
+    for a, b, what in [(y, yr, "y")] + [(d.grad, q.grad, n) for d, q, n in zip(devs, ref, ("dx", "dw1", "db1", "dw2", "db2"))]:
+        a, b = a.detach().cpu().double(), b.detach()
+        assert float((a - b).abs().max()) <= 5e-5 * float(b.abs().max()) + 1e-7, (what, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.parametrize("N,C,H,W", [(2, 48, 12, 20), (3, 144, 9, 7), (2, 2048, 3, 4), (1, 24, 16, 24)])
+def test_batchnorm_swish(N, C, H, W):
+    """BatchNorm2d (train) + swish / SiLU, the activation of the EfficientNet trunk: forward, input and parameter gradients vs fp64"""
+    from sqd import nnkernels
+    torch.manual_seed(C)
+    x = torch.randn(N, C, H, W) * 1.3 + 0.2
+    g = torch.randn(N, C, H, W)
+    bn_ref = nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).double()
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5); bn_ref.bias.uniform_(-0.3, 0.3)
+    bn = nn.BatchNorm2d(C, eps=1e-3, momentum=0.01).cuda()
+    bn.load_state_dict({k: (v.float() if v.is_floating_point() else v) for k, v in bn_ref.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    yr = F.silu(bn_ref(xr))
+    yr.backward(g.double())
+    xd = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    y = nnkernels.batch_norm_act(xd, bn, "swish")
+    y.backward(g.cuda())
+    for a, b, what in ((y, yr, "y"), (xd.grad, xr.grad, "dx"), (bn.weight.grad, bn_ref.weight.grad, "dgamma"), (bn.bias.grad, bn_ref.bias.grad, "dbeta"),
+                       (bn.running_var, bn_ref.running_var, "running_var")):
+        a, b = a.detach().cpu().double(), b.detach()
+        assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6, (what, float((a - b).abs().max()), float(b.abs().max()))
