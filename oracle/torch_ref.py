@@ -397,6 +397,129 @@ class DecoderBN(nn.Module):
         return self.conv3(x)
 
 
+# --------------------------------------------------------------------------------------
+# EfficientNet-b5 encoder — reference networks/base_encoder.py:58-107.  The trunk itself is torch.hub
+# 'rwightman/gen-efficientnet-pytorch' tf_efficientnet_b5_ap (third-party, absent here: PARITY UNPINNED for its
+# arithmetic); restated from the public architecture: EfficientNet-B0 stage table x width 1.6 / depth 2.2, TF "SAME"
+# padding, BatchNorm eps 1e-3, swish, squeeze-and-excite sized by a quarter of the block's input channels.
+# What is pinned: the DecoderBN around it (golden G18 from the reference's own class) and Encoder.forward's tap order.
+# --------------------------------------------------------------------------------------
+_B5_STAGES = (("ds", 3, 1, 1, 24, 3), ("ir", 3, 2, 6, 40, 5), ("ir", 5, 2, 6, 64, 5), ("ir", 3, 2, 6, 128, 7),
+              ("ir", 5, 1, 6, 176, 7), ("ir", 5, 2, 6, 304, 9), ("ir", 3, 1, 6, 512, 3))
+
+
+def _same_pad(x, k, stride):
+    """TensorFlow SAME padding: total = max((ceil(n/s) - 1) s + k - n, 0), leading = total // 2"""
+    H, W = x.shape[2:]
+    th = max((-(-H // stride) - 1) * stride + k - H, 0)
+    tw = max((-(-W // stride) - 1) * stride + k - W, 0)
+    return F.pad(x, (tw // 2, tw - tw // 2, th // 2, th - th // 2))
+
+
+class _SE(nn.Module):
+    def __init__(self, chs, reduced):
+        super().__init__()
+        self.conv_reduce = nn.Conv2d(chs, reduced, 1)
+        self.conv_expand = nn.Conv2d(reduced, chs, 1)
+
+    def forward(self, x):
+        s = x.mean((2, 3), keepdim=True)
+        return x * torch.sigmoid(self.conv_expand(F.silu(self.conv_reduce(s))))
+
+
+class _DSConv(nn.Module):
+    def __init__(self, cin, cout, k, stride):
+        super().__init__()
+        self.k, self.stride, self.res = k, stride, stride == 1 and cin == cout
+        self.conv_dw = nn.Conv2d(cin, cin, k, stride, 0, groups=cin, bias=False)
+        self.bn1 = nn.BatchNorm2d(cin, eps=1e-3)
+        self.se = _SE(cin, max(1, int(cin * 0.25 + 0.5)))
+        self.conv_pw = nn.Conv2d(cin, cout, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(cout, eps=1e-3)
+
+    def forward(self, x):
+        y = F.silu(self.bn1(self.conv_dw(_same_pad(x, self.k, self.stride))))
+        y = self.bn2(self.conv_pw(self.se(y)))
+        return y + x if self.res else y
+
+
+class _MBConv(nn.Module):
+    def __init__(self, cin, cout, k, stride, expand):
+        super().__init__()
+        mid = cin * expand
+        self.k, self.stride, self.res = k, stride, stride == 1 and cin == cout
+        self.conv_pw = nn.Conv2d(cin, mid, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(mid, eps=1e-3)
+        self.conv_dw = nn.Conv2d(mid, mid, k, stride, 0, groups=mid, bias=False)
+        self.bn2 = nn.BatchNorm2d(mid, eps=1e-3)
+        self.se = _SE(mid, max(1, int(cin * 0.25 + 0.5)))
+        self.conv_pwl = nn.Conv2d(mid, cout, 1, bias=False)
+        self.bn3 = nn.BatchNorm2d(cout, eps=1e-3)
+
+    def forward(self, x):
+        y = F.silu(self.bn1(self.conv_pw(x)))
+        y = F.silu(self.bn2(self.conv_dw(_same_pad(y, self.k, self.stride))))
+        y = self.bn3(self.conv_pwl(self.se(y)))
+        return y + x if self.res else y
+
+
+class EfficientNetB5(nn.Module):
+    """module names of gen-efficientnet's GenEfficientNet (global_pool / classifier = Identity, base_encoder.py:99-100)"""
+
+    def __init__(self, stages=_B5_STAGES, stem=48, head=2048):
+        super().__init__()
+        self.conv_stem = nn.Conv2d(3, stem, 3, 2, 0, bias=False)
+        self.bn1 = nn.BatchNorm2d(stem, eps=1e-3)
+        blocks, cin = [], stem
+        for kind, k, stride, expand, cout, repeats in stages:
+            stage = []
+            for i in range(repeats):
+                st = stride if i == 0 else 1
+                stage.append(_DSConv(cin, cout, k, st) if kind == "ds" else _MBConv(cin, cout, k, st, expand))
+                cin = cout
+            blocks.append(nn.Sequential(*stage))
+        self.blocks = nn.Sequential(*blocks)
+        self.conv_head = nn.Conv2d(cin, head, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(head, eps=1e-3)
+        self.global_pool = nn.Identity()
+        self.classifier = nn.Identity()
+
+    def features(self, x):
+        """reference Encoder.forward (base_encoder.py:63-73): one entry per top-level module, the stages of `blocks` one by one"""
+        f = [x, self.conv_stem(_same_pad(x, 3, 2))]
+        f.append(self.bn1(f[-1]))
+        f.append(F.silu(f[-1]))
+        for stage in self.blocks:
+            f.append(stage(f[-1]))
+        f.append(self.conv_head(f[-1]))
+        f.append(self.bn2(f[-1]))
+        f.append(F.silu(f[-1]))
+        f += [f[-1], f[-1]]                                   # global_pool, classifier (Identity)
+        return f
+
+
+class _B5Encoder(nn.Module):
+    def __init__(self, backend):
+        super().__init__()
+        self.original_model = backend
+
+    def forward(self, x):
+        return self.original_model.features(x)
+
+
+class BaseEncoder(nn.Module):
+    """reference networks/base_encoder.py:76-86"""
+
+    def __init__(self, model_dim=32, num_features=2048, stages=_B5_STAGES):
+        super().__init__()
+        self.encoder = _B5Encoder(EfficientNetB5(stages))
+        self.decoder = DecoderBN(num_features, model_dim, 2048, (176, 64, 40, 24))      # base_encoder.py:31-34
+
+    def forward(self, x):
+        f = self.encoder(x)
+        return self.decoder((f[4], f[5], f[6], f[8], f[11]))                              # base_encoder.py:41
+
+
 class _BasicBlock(nn.Module):
     expansion = 1
 

@@ -1,7 +1,9 @@
 """networks package of the MI355X build — same public names as the reference's networks/__init__.py
-for the models on the KITTI self-supervised path.  EfficientNet-b5 (`BaseEncoder`),
-timm ConvNeXt (`Unet`), PoseDecoder and RectifyNet are outside the round-1 hot path."""
+for the models on the KITTI self-supervised path, including the EfficientNet-b5 `BaseEncoder` (§8f-2).
+The timm ConvNeXt `Unet`, PoseDecoder and RectifyNet are not built yet."""
+from .base_encoder import BaseEncoder
 from .depth_decoder_QTR import Depth_Decoder_QueryTr, Lite_Depth_Decoder_QueryTr
+from .efficientnet import GenEfficientNet
 from .layers import FullQueryLayer
 from .pose_cnn import PoseCNN
 from .resnet_encoder import (DecoderBN, LiteResnetEncoderDecoder, Resnet50EncoderDecoder, ResnetEncoder,
@@ -20,5 +22,4 @@ def _not_in_scope(name, why):
     return _Missing
 
 
-BaseEncoder = _not_in_scope("BaseEncoder", "EfficientNet-b5 trunk comes from torch.hub (SURVEY.md §8f-2)")
 Unet = _not_in_scope("Unet", "ConvNeXt-L trunk comes from timm (SURVEY.md §8f-4)")

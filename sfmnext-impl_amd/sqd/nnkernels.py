@@ -31,8 +31,7 @@ def _require(t, what):
 
 
 def bn_supported(C):
-    V = C // 4
-    return C % 4 == 0 and V >= 1 and ((V <= 256 and 256 % V == 0) or V % 256 == 0)
+    return C % 4 == 0 and C >= 4
 
 
 class BatchNormAct(torch.autograd.Function):

@@ -15,7 +15,7 @@ import torch.nn.functional as F
 
 BACKEND = {
     "conv2d": "aten", "conv_bn_act": "aten conv + hip bn/act/residual", "maxpool3x3s2": "hip", "upsample_concat": "hip",
-    "pose_head": "hip", "linear": "hip (1x1 implicit GEMM over rows; feature counts not divisible by 4: aten)", "transformer_encoder": "hip (fused attention up to 512 tokens, feed-forward, add+dropout+layernorm)", "full_query_layer": "hip", "bins_head": "hip",
+    "pose_head": "hip", "depthwise_conv": "hip", "squeeze_excite": "hip", "linear": "hip (1x1 implicit GEMM over rows; feature counts not divisible by 4: aten)", "transformer_encoder": "hip (fused attention up to 512 tokens, feed-forward, add+dropout+layernorm)", "full_query_layer": "hip", "bins_head": "hip",
 }
 
 
@@ -26,6 +26,8 @@ def _act(y, act):
         return F.relu(y)
     if act == "leaky_relu":
         return F.leaky_relu(y, 0.01)
+    if act == "swish":
+        return F.silu(y)
     raise ValueError(act)
 
 
@@ -100,7 +102,7 @@ def _bn_act(y, bn, act, residual, pre=None):
     _device_only(y, "BatchNorm")
     from . import nnkernels
     if not nnkernels.bn_supported(y.shape[1]):
-        raise RuntimeError("sqd: BatchNorm kernel needs C/4 to be a power of two (C=%d)" % y.shape[1])
+        raise RuntimeError("sqd: BatchNorm kernel needs a channel count that is a multiple of 4 (C=%d)" % y.shape[1])
     if pre:
         return nnkernels.batch_norm_act(y, bn, act, residual, pre[0][0], pre[0][1])
     return nnkernels.batch_norm_act(y, bn, act, residual)
@@ -113,6 +115,33 @@ def pose_head(x, conv, scale):
         return nnkernels.PoseHead.apply(x, conv.weight, conv.bias, scale)
     _device_only(x, "pose_head")
     return scale * F.conv2d(x, conv.weight, conv.bias).mean(3).mean(2)
+
+
+def dw_conv_bn_act(x, conv, bn, act, stride):
+    """depthwise k x k convolution with TensorFlow "SAME" padding -> BatchNorm2d -> activation (EfficientNet blocks)."""
+    _device_only(x, "depthwise convolution")
+    from . import nnkernels
+    y = nnkernels.DepthwiseConv.apply(x, conv.weight, stride, "same")
+    return nnkernels.batch_norm_act(y, bn, act)
+
+
+def squeeze_excite(x, conv_reduce, conv_expand):
+    """x * sigmoid(expand(swish(reduce(mean_hw(x))))) — the squeeze-and-excite gate of the EfficientNet blocks."""
+    _device_only(x, "squeeze-and-excite")
+    from . import nnkernels
+    return nnkernels.SqueezeExcite.apply(x, conv_reduce.weight, conv_reduce.bias, conv_expand.weight, conv_expand.bias)
+
+
+def stem_same_conv_bn_act(x, conv, bn, act):
+    """EfficientNet stem: 3x3 stride-2 convolution on the 3-channel image with TensorFlow "SAME" padding -> BatchNorm -> activation.
+    Three input channels are no shape for the implicit-GEMM kernels: the convolution itself runs on ATen."""
+    _device_only(x, "stem convolution")
+    from . import nnkernels
+    k, st = conv.kernel_size[0], conv.stride[0]
+    (Ho, pt), (Wo, pl) = nnkernels.tf_same_pad(x.shape[2], k, st), nnkernels.tf_same_pad(x.shape[3], k, st)
+    tot_h, tot_w = max((Ho - 1) * st + k - x.shape[2], 0), max((Wo - 1) * st + k - x.shape[3], 0)
+    y = F.conv2d(F.pad(x, (pl, tot_w - pl, pt, tot_h - pt)), conv.weight, None, st)
+    return nnkernels.batch_norm_act(y, bn, act)
 
 
 def maxpool3x3s2(x, skip=False):

@@ -150,7 +150,7 @@ class Trainer:
             return networks.ResnetEncoderDecoder(num_layers=o.num_layers, num_features=o.num_features, model_dim=o.model_dim)
         if o.backbone == "resnet18_lite":
             return networks.LiteResnetEncoderDecoder(model_dim=o.model_dim)
-        if o.backbone == "eff_b5":
+        if o.backbone in ("eff_b5", "tf_efficientnet_b5_ap"):
             return networks.BaseEncoder.build(num_features=o.num_features, model_dim=o.model_dim)
         return networks.Unet(pretrained=(not o.load_pretrained_model), backbone=o.backbone, in_channels=3,
                              num_classes=o.model_dim, decoder_channels=o.dec_channels)

@@ -329,6 +329,33 @@ def g13_decoder(nets):
              grad_conv2_w=dec.conv2.weight.grad, grad_up4_bn_w=dec.up4._net[1].weight.grad)
 
 
+def g18_decoder_b5(T):
+    """DecoderBN of the EfficientNet-b5 encoder (reference networks/base_encoder.py:24-56: skip widths +176, +64, +40, +24, taps
+    features[4,5,6,8,11]) — base_encoder.py imports torch only, so the reference's own class runs here."""
+    sys.path.insert(0, "/root/reference/networks")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_base_encoder", "/root/reference/networks/base_encoder.py")
+    be = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(be)
+    dec = be.DecoderBN(num_features=64, num_classes=8, bottleneck_features=2048)
+    fill_params(dec, 1818)
+    chans = (24, 40, 64, 176, 2048)
+    feats = decoder_feats(1819, chans, 32, 48)
+    fts = [tt(f).requires_grad_(True) for f in feats]
+    flist = [None] * 12
+    for i, f in zip((4, 5, 6, 8, 11), fts):
+        flist[i] = f
+    dec.train()
+    out_tr = dec(flist)
+    out_tr.square().mean().backward()
+    rm = dec.up1._net[1].running_mean.clone()
+    dec.eval()
+    out_ev = dec([None if f is None else f.detach() for f in flist])
+    save("g18_decoderbn_b5", seed=1818, feat_seed=1819, nf=64, bott=2048, out_train=out_tr, out_eval=out_ev,
+         up1_running_mean_after=rm, grad_feat0=fts[0].grad, grad_feat4=fts[4].grad,
+         grad_conv2_w=dec.conv2.weight.grad, grad_up4_bn_w=dec.up4._net[1].weight.grad)
+
+
 def g14_depth_errors(T):
     rs = np.random.RandomState(1414)
     B = 2
@@ -451,6 +478,7 @@ def main():
             globals()[name](T)
         return
     g17_stereo_chain(T)
+    g18_decoder_b5(T)
     g1_pose(T)
     g2_g3_g4_geometry(T)
     g5_g6_ssim(T)

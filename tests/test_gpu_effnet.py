@@ -1,0 +1,111 @@
+"""The EfficientNet-b5 encoder (`--backbone eff_b5`, BASELINE.json configs[3]) on the device against the oracle's plain-torch
+restatement of the same architecture (oracle/torch_ref.py BaseEncoder; the hub trunk itself is third-party and absent:
+parity unpinned for its arithmetic, DecoderBN pinned by golden G18)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import tt
+from param_fill import decoder_feats, fill_params
+
+pytestmark = pytest.mark.gpu
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rel(a, b):
+    a, b = a.detach().cpu().double(), b.detach().double()
+    return float((a - b).abs().max()) / (float(b.abs().max()) + 1e-12)
+
+
+def test_g18_decoderbn_b5_on_device(golden):
+    import networks
+    from sqd import nnops
+    nnops.set_native_conv(True)
+    g = golden("g18_decoderbn_b5")
+    dec = fill_params(networks.DecoderBN(int(g["nf"]), 8, int(g["bott"]), (176, 64, 40, 24)), int(g["seed"])).cuda().to(memory_format=torch.channels_last)
+    feats = [tt(f).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+             for f in decoder_feats(int(g["feat_seed"]), (24, 40, 64, 176, 2048), 32, 48)]
+    dec.train()
+    out = dec(feats)
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g["out_train"], rtol=1e-4, atol=1e-5)
+    out.square().mean().backward()
+    for got, want in ((feats[0].grad, g["grad_feat0"]), (feats[4].grad, g["grad_feat4"]), (dec.conv2.weight.grad, g["grad_conv2_w"])):
+        assert float(np.abs(got.detach().cpu().numpy() - want).max()) <= 1e-3 * float(np.abs(want).max())
+    dec.eval()
+    with torch.no_grad():
+        np.testing.assert_allclose(dec([f.detach() for f in feats]).cpu().numpy(), g["out_eval"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("H,W,B", [(64, 96, 2), (96, 160, 1)])
+def test_base_encoder_matches_oracle(H, W, B):
+    """all 39 MBConv blocks + DecoderBN: output and gradients (stem, a depthwise filter, an SE gate, the last projection, the decoder)"""
+    sys.path.insert(0, REPO)
+    import networks
+    from oracle import torch_ref as O
+    from sqd import nnops
+    nnops.set_native_conv(True)
+    torch.manual_seed(3)
+    ref = O.BaseEncoder(model_dim=32, num_features=512)
+    mine = networks.BaseEncoder.build(model_dim=32, num_features=512)
+    ref.load_state_dict(mine.state_dict())
+    mine = mine.cuda().to(memory_format=torch.channels_last)
+    ref.train(); mine.train()
+    x = torch.rand(B, 3, H, W)
+    g = torch.randn(B, 32, H // 2, W // 2)
+    yr = ref(x)
+    yr.backward(g)
+    y = mine(x.cuda().contiguous(memory_format=torch.channels_last))
+    y.backward(g.cuda())
+    assert _rel(y, yr) < 2e-4, _rel(y, yr)
+    P, R = dict(mine.named_parameters()), dict(ref.named_parameters())
+    for name in ("encoder.original_model.conv_stem.weight", "encoder.original_model.blocks.1.0.conv_dw.weight",
+                 "encoder.original_model.blocks.2.1.se.conv_reduce.weight", "encoder.original_model.blocks.2.1.se.conv_expand.bias",
+                 "encoder.original_model.blocks.6.2.conv_pwl.weight", "encoder.original_model.blocks.4.3.bn2.weight",
+                 "encoder.original_model.conv_head.weight", "decoder.up4._net.0.weight", "decoder.conv3.bias"):
+        e = _rel(P[name].grad, R[name].grad)
+        print("%-64s rel grad err %.2e" % (name, e))
+        assert e < 2e-3, (name, e)
+    rm, rr = mine.encoder.original_model.blocks[3][2].bn1.running_var.cpu(), ref.encoder.original_model.blocks[3][2].bn1.running_var
+    assert _rel(rm, rr) < 1e-4
+
+
+def test_effb5_train_step_matches_oracle():
+    """one optimisation step of the Trainer with --backbone eff_b5 (EfficientNet-b5 + Depth_Decoder_QueryTr) against the oracle"""
+    sys.path.insert(0, REPO)
+    from oracle import torch_ref as O
+    from options import MonodepthOptions
+    from trainer import Trainer
+    from datasets.synthetic import synthetic_batch
+    H, W, B = 64, 128, 2
+    args = ["--backbone", "eff_b5", "--num_features", "256", "--model_dim", "32", "--patch_size", "8", "--query_nums", "16", "--dim_out", "32",
+            "--height", str(H), "--width", str(W), "--batch_size", str(B), "--num_workers", "0", "--sqd_synthetic",
+            "--log_dir", "/tmp/sqd_effb5_test", "--max_depth", "80.0", "--sqd_no_conv_tune", "--sqd_no_graph"]
+    torch.manual_seed(0)
+    tr = Trainer(MonodepthOptions().parse(args))
+    tr.set_train()
+    for m in tr.models.values():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+    enc = O.BaseEncoder(model_dim=32, num_features=256)
+    dep = O.QueryTrDecoder(32, 32, 8, 4, 16, 32, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
+    pose = O.PoseCNN(2)
+    for ref, mine in ((enc, tr.models["encoder"]), (dep, tr.models["depth"]), (pose, tr.models["pose"])):
+        ref.load_state_dict({k: v.detach().cpu() for k, v in mine.state_dict().items()})
+        ref.train()
+    cpu_inputs = synthetic_batch(B, H, W)
+    noise = torch.randn(B, 2, H, W)
+    ref = O.RefTrainStep(enc, dep, pose, (0, -1, 1), H, W)
+    ref_out, ref_losses = ref.step(dict(cpu_inputs), noise)
+    inputs = {k: v.cuda() for k, v in cpu_inputs.items()}
+    inputs[("noise", 0)] = noise.cuda()
+    outputs, losses = tr.train_step(inputs)
+    got, want = float(losses["loss"]), float(ref_losses["loss"])
+    assert abs(got - want) <= 2e-4 * abs(want), (got, want)
+    d, dr = outputs[("disp", 0)].detach().cpu(), ref_out[("disp", 0)].detach()
+    assert float((d - dr).abs().max()) <= 5e-4 * float(dr.abs().max())

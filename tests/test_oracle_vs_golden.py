@@ -255,3 +255,43 @@ def test_g17_stereo_chain(golden):
     for f, n in ((-1, "m1"), (1, "p1")):
         close(poses[f][0].grad, g["grad_axisangle_" + n], atol=1e-7)
         close(poses[f][1].grad, g["grad_translation_" + n], atol=1e-7)
+
+
+def test_g18_decoderbn_b5(golden):
+    """DecoderBN with the EfficientNet-b5 skip widths against the reference's own class (networks/base_encoder.py:24-56)"""
+    g = golden("g18_decoderbn_b5")
+    dec = fill_params(O.DecoderBN(int(g["nf"]), 8, int(g["bott"]), (176, 64, 40, 24)), int(g["seed"]))
+    feats = [tt(f).requires_grad_(True) for f in decoder_feats(int(g["feat_seed"]), (24, 40, 64, 176, 2048), 32, 48)]
+    dec.train()
+    out = dec(feats)
+    close(out, g["out_train"], atol=1e-5)
+    out.square().mean().backward()
+    close(dec.up1._net[1].running_mean, g["up1_running_mean_after"])
+    close(feats[0].grad, g["grad_feat0"], rtol=1e-3, atol=1e-7)
+    close(feats[4].grad, g["grad_feat4"], rtol=1e-3, atol=1e-7)
+    close(dec.conv2.weight.grad, g["grad_conv2_w"], rtol=1e-3, atol=1e-7)
+    close(dec.up4._net[1].weight.grad, g["grad_up4_bn_w"], rtol=1e-3, atol=1e-7)
+    dec.eval()
+    close(dec([f.detach() for f in feats]), g["out_eval"], atol=1e-5)
+
+
+def test_efficientnet_b5_restatement_shapes_and_keys():
+    """the restated trunk: parameter count of EfficientNet-B5 without its classifier (30.39 M - 2.05 M), tap shapes of
+    base_encoder.py:41, and the same state-dict keys in the product module and the oracle"""
+    import sys
+    from conftest import PRODUCT
+    sys.path.insert(0, PRODUCT)
+    import networks
+    ref = O.BaseEncoder(model_dim=32, num_features=512)
+    n = sum(p.numel() for p in ref.encoder.original_model.parameters())
+    assert n == 28340784, n
+    mine = networks.BaseEncoder.build(model_dim=32, num_features=512)
+    assert [(k, tuple(v.shape)) for k, v in mine.state_dict().items()] == [(k, tuple(v.shape)) for k, v in ref.state_dict().items()]
+    small = O.BaseEncoder(model_dim=16, num_features=64, stages=(("ds", 3, 1, 1, 24, 1), ("ir", 3, 2, 6, 40, 1), ("ir", 5, 2, 6, 64, 1),
+                                                                ("ir", 3, 2, 6, 128, 1), ("ir", 5, 1, 6, 176, 1), ("ir", 5, 2, 6, 304, 1),
+                                                                ("ir", 3, 1, 6, 512, 1)))
+    small.eval()
+    x = torch.rand(1, 3, 64, 96)
+    f = small.encoder(x)
+    assert [tuple(f[i].shape[1:]) for i in (4, 5, 6, 8, 11)] == [(24, 32, 48), (40, 16, 24), (64, 8, 12), (176, 4, 6), (2048, 2, 3)]
+    assert small(x).shape == (1, 16, 32, 48)
