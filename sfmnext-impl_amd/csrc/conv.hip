@@ -1175,6 +1175,11 @@ static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, i
     // kernel where K*C is large and the pixel count small
     p.direct = C % 16 == 0 && K % 16 == 0 && M >= 2048 && C <= 1024;
     if (measured) p.direct = m_impl == 1 && C % 16 == 0 && K % 16 == 0;
+    if (!p.direct) {                                             // (channel counts below / not divisible by 16: the LDS-tiled kernel)
+        p.kt = p.ct = p.tp = p.splits = 1;
+        p.px_per_wave = 0;
+        return p;
+    }
     p.kt = K % 64 == 0 ? 4 : K % 32 == 0 ? 2 : 1;
     p.ct = C % 64 == 0 ? 4 : C % 32 == 0 ? 2 : 1;
     if (fkt) p.kt = fkt;                                         // a smaller register tile = more resident waves (the 4x4 tile's 184
