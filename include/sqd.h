@@ -252,9 +252,10 @@ int sqd_conv_supported(int C, int K);
  * a plan it has timed (bm x bn tile, z split-K factor, bk = 16 | 32 channels per reduction slice; bm = 0 clears) */
 int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int bm,
                       int bn, int z, int bk);
-/* arithmetic of sqd_conv_fwd / sqd_conv_dgrad: 0 = fp32 MFMA (default); 1 = split-precision bf16 MFMA — every fp32 operand
- * as the exact sum of three bf16 terms, 6 of the 9 partial products (down to 2^-24 relative), fp32 accumulation.  Experimental
- * (round 2 decides whether it may carry the fp32 label); also enabled by SQD_CONV_BF16X3=1. */
+/* arithmetic of sqd_conv_fwd / sqd_conv_dgrad: 0 = fp32 MFMA (default, the reference's arithmetic); 1 = split-precision bf16
+ * MFMA — every fp32 operand as the exact sum of three bf16 terms, 6 of the 9 partial products (down to 2^-24 relative), fp32
+ * accumulation; 2 = bf16 training arithmetic (BASELINE.json configs[3]): operands rounded to nearest-even bf16 as they are staged,
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation, fp32 tensors in memory, BatchNorm / losses / weight gradients / Adam in fp32. */
 int sqd_conv_set_precision(int prec);
 int sqd_conv_precision(void);
 int sqd_conv_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,

@@ -62,6 +62,19 @@ __device__ __forceinline__ Split4 split3(float4 v) {
     r.t[2] = make_uint2(hi16pair(b.x, b.y), hi16pair(b.z, b.w));
     return r;
 }
+// round-to-nearest-even bf16 of a finite fp32 (PREC 3)
+__device__ __forceinline__ unsigned rne_bf16(float x) {
+    const unsigned u = __float_as_uint(x);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+template <int NTERM>
+__device__ __forceinline__ Split4 splitN(float4 v) {
+    if (NTERM == 3) return split3(v);
+    Split4 r;
+    r.t[0] = make_uint2(rne_bf16(v.x) | (rne_bf16(v.y) << 16), rne_bf16(v.z) | (rne_bf16(v.w) << 16));
+    r.t[1] = r.t[2] = make_uint2(0u, 0u);
+    return r;
+}
 __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
@@ -92,13 +105,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
     constexpr int NQ = BKT / 4, LDPT = BKT + 4, RPP = NT / NQ;  // float4 per staged row, LDS row pitch, rows per staging pass
     constexpr int A_F4 = BM * NQ / NT;
     static_assert(A_F4 >= 1 && (BKT == 16 || BKT == 32 || BKT == 64), "BM >= 64, BKT in {16, 32, 64}");
-    constexpr bool BF = PREC == 1;                              // split-precision bf16 operands
+    constexpr bool BF = PREC == 1 || PREC == 3;                 // bf16 operands: PREC 1 = three-term split (fp32-level accuracy),
+    constexpr int NTERM = PREC == 1 ? 3 : 1;                    // PREC 3 = one round-to-nearest bf16 term (bf16 training arithmetic)
     constexpr int NBUF = PREC == 2 ? 1 : 2;                     // PREC 2: single LDS buffer (half the LDS, one more barrier per slice)
     constexpr int LDH = BKT + 8;                                // PREC 1: bf16 row pitch (48 / 80 bytes: conflict-free b128 reads)
     __shared__ __attribute__((aligned(16))) float As[BF ? 1 : NBUF][BF ? 1 : BM][LDPT];
     __shared__ __attribute__((aligned(16))) float Bs[BF ? 1 : NBUF][BF ? 1 : BN][LDPT];
-    __shared__ __attribute__((aligned(16))) unsigned short Ah[BF ? 2 : 1][3][BF ? BM : 1][LDH];   // [buffer][term][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short Bh[BF ? 2 : 1][3][BF ? BN : 1][LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[BF ? 2 : 1][NTERM][BF ? BM : 1][LDH];   // [buffer][term][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short Bh[BF ? 2 : 1][NTERM][BF ? BN : 1][LDH];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm0 = (wave / WGN) * (WTM * 32), wn0 = (wave % WGN) * (WTN * 32);
@@ -224,25 +238,25 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
         if (BF) {
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
-                const Split4 sp = split3(ra[i]);
+                const Split4 sp = splitN<NTERM>(ra[i]);
 #pragma unroll
-                for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<uint2 *>(&Ah[buf][tm][arow + RPP * i][c4 * 4]) = sp.t[tm];
+                for (int tm = 0; tm < NTERM; ++tm) *reinterpret_cast<uint2 *>(&Ah[buf][tm][arow + RPP * i][c4 * 4]) = sp.t[tm];
             }
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
                 const int idx = t + NT * i;
-                const Split4 sp = split3(rb[i]);
+                const Split4 sp = splitN<NTERM>(rb[i]);
                 if (MODE == 0) {
                     const int row = idx / NQ, q4 = idx % NQ;
                     if (row < BN) {
 #pragma unroll
-                        for (int tm = 0; tm < 3; ++tm) *reinterpret_cast<uint2 *>(&Bh[buf][tm][row][q4 * 4]) = sp.t[tm];
+                        for (int tm = 0; tm < NTERM; ++tm) *reinterpret_cast<uint2 *>(&Bh[buf][tm][row][q4 * 4]) = sp.t[tm];
                     }
                 } else {
                     const int kk = idx % BKT, cq = idx / BKT;
                     if (cq * 4 < BN) {
 #pragma unroll
-                        for (int tm = 0; tm < 3; ++tm) {
+                        for (int tm = 0; tm < NTERM; ++tm) {
                             Bh[buf][tm][cq * 4 + 0][kk] = (unsigned short)(sp.t[tm].x & 0xffffu);
                             Bh[buf][tm][cq * 4 + 1][kk] = (unsigned short)(sp.t[tm].x >> 16);
                             Bh[buf][tm][cq * 4 + 2][kk] = (unsigned short)(sp.t[tm].y & 0xffffu);
@@ -324,25 +338,29 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
             const int e0 = (BKT / 2) * h + 8 * part;
             if (BF) {
                 // one 32x32x16 bf16 MFMA consumes the 8 elements of both half-waves; 6 term pairs, smallest first
-                u32x4 ah[WTM][3], bh[WTN][3];
+                u32x4 ah[WTM][NTERM], bh[WTN][NTERM];
 #pragma unroll
                 for (int i = 0; i < WTM; ++i)
 #pragma unroll
-                    for (int tm = 0; tm < 3; ++tm) ah[i][tm] = *reinterpret_cast<const u32x4 *>(&Ah[cur][tm][wm0 + i * 32 + row][e0]);
+                    for (int tm = 0; tm < NTERM; ++tm) ah[i][tm] = *reinterpret_cast<const u32x4 *>(&Ah[cur][tm][wm0 + i * 32 + row][e0]);
 #pragma unroll
                 for (int j = 0; j < WTN; ++j)
 #pragma unroll
-                    for (int tm = 0; tm < 3; ++tm) bh[j][tm] = *reinterpret_cast<const u32x4 *>(&Bh[cur][tm][wn0 + j * 32 + row][e0]);
+                    for (int tm = 0; tm < NTERM; ++tm) bh[j][tm] = *reinterpret_cast<const u32x4 *>(&Bh[cur][tm][wn0 + j * 32 + row][e0]);
 #pragma unroll
                 for (int i = 0; i < WTM; ++i)
 #pragma unroll
                     for (int j = 0; j < WTN; ++j) {
                         f32x16 c = acc[i][j];
-                        c = mfma_bf(ah[i][0], bh[j][2], c);
-                        c = mfma_bf(ah[i][2], bh[j][0], c);
-                        c = mfma_bf(ah[i][1], bh[j][1], c);
-                        c = mfma_bf(ah[i][0], bh[j][1], c);
-                        c = mfma_bf(ah[i][1], bh[j][0], c);
+                        if (NTERM == 1) {
+                            acc[i][j] = mfma_bf(ah[i][0], bh[j][0], c);
+                            continue;
+                        }
+                        c = mfma_bf(ah[i][0], bh[j][NTERM - 1], c);
+                        c = mfma_bf(ah[i][NTERM - 1], bh[j][0], c);
+                        c = mfma_bf(ah[i][NTERM > 1 ? 1 : 0], bh[j][NTERM > 1 ? 1 : 0], c);
+                        c = mfma_bf(ah[i][0], bh[j][NTERM > 1 ? 1 : 0], c);
+                        c = mfma_bf(ah[i][NTERM > 1 ? 1 : 0], bh[j][0], c);
                         acc[i][j] = mfma_bf(ah[i][0], bh[j][0], c);
                     }
                 continue;
@@ -1001,14 +1019,15 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     }
 // split-precision variants: the three bf16 planes need 1.5x the LDS of the fp32 tile, so 128x128 runs as 128x64 and only the
 // 64x64 tile keeps the 32-channel slice
-#define DISPATCH_GEMM_BF(MODE)                                                   \
-    if (p.bm == 128 && p.bn >= 64) LAUNCH_GEMM_P(MODE, 128, 64, 2, 2, 16, 1);    \
-    else if (p.bm == 128) LAUNCH_GEMM_P(MODE, 128, 32, 4, 1, 16, 1);             \
-    else if (p.bn == 128) LAUNCH_GEMM_P(MODE, 64, 128, 2, 2, 16, 1);             \
-    else if (p.bk == 32) LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 32, 1);               \
-    else LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 16, 1);
+#define DISPATCH_GEMM_BF(MODE, PR)                                               \
+    if (p.bm == 128 && p.bn >= 64) LAUNCH_GEMM_P(MODE, 128, 64, 2, 2, 16, PR);   \
+    else if (p.bm == 128) LAUNCH_GEMM_P(MODE, 128, 32, 4, 1, 16, PR);            \
+    else if (p.bn == 128) LAUNCH_GEMM_P(MODE, 64, 128, 2, 2, 16, PR);            \
+    else if (p.bk == 32) LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 32, PR);              \
+    else LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 16, PR);
 
-// 0: fp32 MFMA (default); 1: split-precision bf16 MFMA for forward / data gradient (sqd_conv_set_precision)
+// 0: fp32 MFMA (default); 1: split-precision bf16 MFMA (three terms, fp32-level accuracy); 2: plain bf16 operands with fp32
+// accumulation — for forward / data gradient (sqd_conv_set_precision); the weight gradient stays on the fp32 MFMA kernels
 static int &conv_precision() {
     static int prec = 0;
     return prec;
@@ -1029,8 +1048,10 @@ static int launch_gemm(int mode, const float *a_src, const float *w, const float
     const int order = 2;                                   // N-tiles fastest, no XCD chunking: measured best on MI355X (profiles/r01c_conv_layers.md)
     float *dst = p.z > 1 ? ws : out;
     (void)hipGetLastError();
-    if (conv_precision()) {
-        if (mode == 0) { DISPATCH_GEMM_BF(0) } else { DISPATCH_GEMM_BF(1) }
+    if (conv_precision() == 1) {
+        if (mode == 0) { DISPATCH_GEMM_BF(0, 1) } else { DISPATCH_GEMM_BF(1, 1) }
+    } else if (conv_precision() == 2) {
+        if (mode == 0) { DISPATCH_GEMM_BF(0, 3) } else { DISPATCH_GEMM_BF(1, 3) }
     } else if (mode == 0) { DISPATCH_GEMM(0) } else { DISPATCH_GEMM(1) }
     if (p.z > 1) {
         const size_t n = (size_t)Mrows * Ncols;
@@ -1082,7 +1103,7 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
 // arithmetic of sqd_conv_fwd / sqd_conv_dgrad: 0 = fp32 MFMA (default), 1 = split-precision bf16 MFMA (3 bf16 terms per fp32
 // operand, 6 products, fp32 accumulation: fp32-level accuracy, experimental)
 extern "C" int sqd_conv_set_precision(int prec) {
-    SQD_CHECK_ARG(prec == 0 || prec == 1, "sqd_conv_set_precision: %d", prec);
+    SQD_CHECK_ARG(prec >= 0 && prec <= 2, "sqd_conv_set_precision: %d (0 fp32, 1 three-term bf16 split, 2 bf16 operands)", prec);
     conv_precision() = prec;
     return SQD_OK;
 }

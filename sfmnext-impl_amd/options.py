@@ -118,6 +118,8 @@ EXTRA_FLAGS = [
     ("sqd_graph_ddp", str, "overlap", {"choices": ["overlap", "post"],
                                         "help": "multi-rank hipGraph: 'overlap' (default) = the bucketed all-reduces are graph branches next to backward; "
                                                 "'post' = graph of forward+backward, collectives and Adam issued after each replay"}),
+    ("sqd_bf16", _T, False, {"help": "bf16 training arithmetic for the convolutions' forward and data gradient (bf16 MFMA, fp32 accumulation; "
+                                      "BatchNorm, losses, weight gradients and Adam stay fp32) — BASELINE.json configs[3]"}),
     ("sqd_no_conv_tune", _T, False, {"help": "keep the cost-model convolution plans instead of timing tile / split-K plans per layer in the first step"}),
     ("sqd_aten_conv", _T, False, {"help": "A/B switch: ATen/MIOpen convolutions instead of the native implicit-GEMM kernels (csrc/conv.hip)"}),
     ("sqd_miopen_find", _T, False, {"help": "let MIOpen benchmark its solvers per layer (interim ATen conv backend only)"}),

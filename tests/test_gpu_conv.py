@@ -242,3 +242,44 @@ def test_wgrad_register_tile_shapes(kt, ct):
         err, scale = float((a.cpu().double() - b).abs().max()), float(b.abs().max())
         assert err <= 1e-4 * scale, (name, err, scale)
     assert L.sqd_conv_wgrad_set_plan(N, H, W, C, 48, R, R, 1 | (4 << 4) | (4 << 8), 6) != 0       # 64-filter tile on K = 48: refused
+
+
+@pytest.mark.parametrize("N,C,H,W,K,R,stride,pad", [(2, 64, 24, 40, 64, 3, 1, 1), (2, 144, 20, 28, 24, 1, 1, 0), (2, 128, 24, 40, 128, 3, 2, 1),
+                                                     (1, 512, 6, 20, 512, 3, 1, 1)])
+def test_conv_bf16_operand_mode(N, C, H, W, K, R, stride, pad):
+    """sqd_conv_set_precision(2) — operands rounded to nearest-even bf16 when staged, fp32 accumulation (BASELINE.json configs[3]):
+    forward and data gradient equal an fp32 convolution of the bf16-rounded operands to accumulation-order rounding; the weight
+    gradient stays fp32"""
+    from sqd import lib, nnkernels
+    torch.manual_seed(C + K)
+    conv = nn.Conv2d(C, K, R, stride, pad, bias=False)
+    x = torch.randn(N, C, H, W)
+    rb = lambda t: t.bfloat16().float()
+    xr = rb(x).requires_grad_(True)
+    wr = rb(conv.weight.detach()).requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, pad)
+    g = torch.randn_like(yr)
+    # the data gradient multiplies bf16(dy) with bf16(w)
+    (dx_ref,) = torch.autograd.grad(F.conv2d(xr, wr, None, stride, pad), xr, rb(g))
+    conv_g = nn.Conv2d(C, K, R, stride, pad, bias=False).cuda()
+    conv_g.load_state_dict(conv.state_dict())
+    conv_g = conv_g.to(memory_format=torch.channels_last)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    L = lib.lib()
+    assert L.sqd_conv_set_precision(2) == 0
+    try:
+        y = nnkernels.conv2d_native(xg, conv_g, None)
+        (y * g.cuda()).sum().backward()
+    finally:
+        L.sqd_conv_set_precision(0)
+
+    def close(a, b, name, rtol):
+        a, b = a.detach().cpu().float(), b.detach().float()
+        err, scale = float((a - b).abs().max()), float(b.abs().max())
+        assert err <= rtol * scale + 1e-6, (name, err, scale)
+    close(y, yr, "y", 2e-5)
+    close(xg.grad, dx_ref, "dx", 2e-5)
+    # weight gradient: full fp32 of the UNROUNDED operands
+    x0 = x.clone().requires_grad_(True)
+    (F.conv2d(x0, conv.weight, None, stride, pad) * g).sum().backward()
+    close(conv_g.weight.grad, conv.weight.grad, "dw", 5e-4)

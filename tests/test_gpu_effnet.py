@@ -109,3 +109,34 @@ def test_effb5_train_step_matches_oracle():
     assert abs(got - want) <= 2e-4 * abs(want), (got, want)
     d, dr = outputs[("disp", 0)].detach().cpu(), ref_out[("disp", 0)].detach()
     assert float((d - dr).abs().max()) <= 5e-4 * float(dr.abs().max())
+
+
+def test_effb5_bf16_training_steps_track_fp32():
+    """--sqd_bf16 (BASELINE.json configs[3]: EfficientNet-b5 in bf16): the same five steps as the fp32 run, loss within bf16 noise"""
+    sys.path.insert(0, REPO)
+    from options import MonodepthOptions
+    from trainer import Trainer
+    from datasets.synthetic import synthetic_batch
+    from sqd import lib
+    H, W, B = 64, 128, 2
+    base = ["--backbone", "eff_b5", "--num_features", "256", "--model_dim", "32", "--patch_size", "8", "--query_nums", "16", "--dim_out", "32",
+            "--height", str(H), "--width", str(W), "--batch_size", str(B), "--num_workers", "0", "--sqd_synthetic",
+            "--log_dir", "/tmp/sqd_effb5_test", "--max_depth", "80.0", "--sqd_no_conv_tune", "--sqd_device_noise"]
+    runs = {}
+    try:
+        for name, extra in (("fp32", []), ("bf16", ["--sqd_bf16"])):
+            torch.manual_seed(0)
+            tr = Trainer(MonodepthOptions().parse(base + extra))
+            tr.set_train()
+            assert lib.lib().sqd_conv_precision() == (2 if extra else 0)
+            losses = []
+            for i in range(5):
+                torch.manual_seed(100 + i)
+                batch = synthetic_batch(B, H, W, start=B * i, device=tr.device)
+                losses.append(float(tr.train_step(batch)[1]["loss"]))
+            runs[name] = losses
+    finally:
+        lib.lib().sqd_conv_set_precision(0)
+    print("eff_b5 losses fp32 %s\n       bf16 %s" % (runs["fp32"], runs["bf16"]))
+    for a, b in zip(runs["fp32"], runs["bf16"]):
+        assert b == b and abs(a - b) <= 0.05 * abs(a), (runs["fp32"], runs["bf16"])
