@@ -382,14 +382,15 @@ int sqd_dw_conv_wgrad(const float *dy, const float *x, float *part, int N, int H
                       int Ho, int Wo, void *stream);
 /* squeeze-and-excite: gate[b,c] = sigmoid(W2 . swish(W1 . mean_hw(x[b]) + b1) + b2), y = x * gate.
  * sqd_se_pool: per-chunk channel sums of a (or a * b) over the pixels -> part [B][sqd_se_chunks(HW)][C];
- * sqd_se_gate_fwd: part, W1 [R,C], b1 [R], W2 [C,R], b2 [C] -> s [B,C] (pooled mean), pre1 [B,R], gate [B,C];
+ * sqd_se_gate_fwd: part, W1 [R,C], b1 [R], W2T [R,C] (the [C,R] expansion filter transposed), b2 [C] -> s [B,C] (pooled mean),
+ * pre1 [B,R], gate [B,C];
  * sqd_se_gate_bwd: dgpart = sqd_se_pool(dy, x) -> per-image partials dW1part [B,R,C], db1part [B,R rounded up to 4], dW2part [B,C,R], db2part [B,C]
  * and ds [B,C] (gradient w.r.t. the pooled mean, already divided by HW); sqd_se_scale: y = x * gate (+ ds: the backward).          */
 int sqd_se_chunks(int HW);
 int sqd_se_pool(const float *a, const float *b, float *part, int B, int HW, int C, void *stream);
-int sqd_se_gate_fwd(const float *part, const float *W1, const float *b1, const float *W2, const float *b2, float *s, float *pre1,
+int sqd_se_gate_fwd(const float *part, const float *W1, const float *b1, const float *W2T, const float *b2, float *s, float *pre1,
                     float *gate, int B, int HW, int C, int R, void *stream);
-int sqd_se_gate_bwd(const float *dgpart, const float *W1, const float *W2, const float *s, const float *pre1, const float *gate,
+int sqd_se_gate_bwd(const float *dgpart, const float *W1, const float *W2T, const float *s, const float *pre1, const float *gate,
                     float *dW1part, float *db1part, float *dW2part, float *db2part, float *ds, int B, int HW, int C, int R, void *stream);
 int sqd_se_scale(const float *x, const float *gate, const float *ds, float *y, int B, int HW, int C, void *stream);
 

@@ -65,39 +65,58 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float *__restrict__ 
     }
 }
 
-// weight gradient: block (chunk, channel band of 64) sums dy * x over its output pixels for every tap; part [nchunk][k*k][C]
-template <int K>
+// weight gradient: block (chunk, channel band of 64) sums dy * x over its share of the output for every tap; part [nchunk][k*k][C].
+// A thread walks RUNS of four consecutive output columns: per filter row it loads the 3*stride + k input columns the run touches
+// once and uses each for up to k taps (a tap-by-tap gather re-reads every input element k^2 times through L1, which — not the
+// arithmetic — bounds this kernel: 16.7 ms of a 75 ms EfficientNet-b5 step before, profiles/r02b).
+template <int K, int ST>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ part,
-                                                       DwGeom g, int px_per_chunk) {
+                                                       DwGeom g, int runs_per_chunk) {
     __shared__ float4 red[16][16];
-    const int cgl = threadIdx.x & 15, pl = threadIdx.x >> 4;          // 16 channel groups (64 channels) x 16 pixel lanes
+    constexpr int P = 4, NC = (P - 1) * ST + K;
+    const int cgl = threadIdx.x & 15, pl = threadIdx.x >> 4;          // 16 channel groups (64 channels) x 16 run lanes
     const int cg = blockIdx.y * 16 + cgl;
     const bool con = cg * 4 < g.C;
-    const size_t M = (size_t)g.N * g.Ho * g.Wo;
-    const size_t p0 = (size_t)blockIdx.x * px_per_chunk, p1 = p0 + px_per_chunk < M ? p0 + px_per_chunk : M;
+    const int wruns = (g.Wo + P - 1) / P;
+    const size_t nruns = (size_t)g.N * g.Ho * wruns;
+    const size_t q0 = (size_t)blockIdx.x * runs_per_chunk, q1 = q0 + runs_per_chunk < nruns ? q0 + runs_per_chunk : nruns;
     float4 acc[K * K];
 #pragma unroll
     for (int t = 0; t < K * K; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     if (con)
-        for (size_t p = p0 + pl; p < p1; p += 16) {
-            const int wo = (int)(p % g.Wo), ho = (int)((p / g.Wo) % g.Ho), n = (int)(p / ((size_t)g.Wo * g.Ho));
-            const float4 gv = *reinterpret_cast<const float4 *>(dy + p * g.C + cg * 4);
-            const int h0 = ho * g.stride - g.pad_t, w0 = wo * g.stride - g.pad_l;
+        for (size_t q = q0 + pl; q < q1; q += 16) {
+            const int wr = (int)(q % wruns), ho = (int)((q / wruns) % g.Ho), n = (int)(q / ((size_t)wruns * g.Ho));
+            const int wo0 = wr * P;
+            float4 gv[P];
+#pragma unroll
+            for (int p = 0; p < P; ++p)
+                gv[p] = wo0 + p < g.Wo ? *reinterpret_cast<const float4 *>(dy + (((size_t)n * g.Ho + ho) * g.Wo + wo0 + p) * g.C + cg * 4) : zero;
+            const int w0 = wo0 * ST - g.pad_l, h0 = ho * ST - g.pad_t;
 #pragma unroll
             for (int r = 0; r < K; ++r) {
                 const int hi = h0 + r;
+                if ((unsigned)hi >= (unsigned)g.H) continue;
+                const float *xrow = x + ((size_t)n * g.H + hi) * g.W * g.C + cg * 4;
+                float4 xv[NC];
 #pragma unroll
-                for (int s = 0; s < K; ++s) {
-                    const int wi = w0 + s;
-                    if ((unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W) {
-                        const float4 xv = *reinterpret_cast<const float4 *>(x + (((size_t)n * g.H + hi) * g.W + wi) * g.C + cg * 4);
-                        float4 &a = acc[r * K + s];
-                        a.x = fmaf(gv.x, xv.x, a.x); a.y = fmaf(gv.y, xv.y, a.y); a.z = fmaf(gv.z, xv.z, a.z); a.w = fmaf(gv.w, xv.w, a.w);
+                for (int c = 0; c < NC; ++c) {
+                    const int wi = w0 + c;
+                    xv[c] = (unsigned)wi < (unsigned)g.W ? *reinterpret_cast<const float4 *>(xrow + (size_t)wi * g.C) : zero;
+                }
+#pragma unroll
+                for (int sx = 0; sx < K; ++sx) {
+                    float4 &a = acc[r * K + sx];
+#pragma unroll
+                    for (int p = 0; p < P; ++p) {
+                        const float4 xq = xv[p * ST + sx];
+                        a.x = fmaf(gv[p].x, xq.x, a.x); a.y = fmaf(gv[p].y, xq.y, a.y);
+                        a.z = fmaf(gv[p].z, xq.z, a.z); a.w = fmaf(gv[p].w, xq.w, a.w);
                     }
                 }
             }
         }
-    // fixed-order sum over the 16 pixel lanes, tap by tap
+    // fixed-order sum over the 16 run lanes, tap by tap
 #pragma unroll
     for (int t = 0; t < K * K; ++t) {
         red[pl][cgl] = acc[t];
@@ -161,15 +180,15 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const float *__restrict__ 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
 
 // one workgroup per image: s = mean over pixels (sum of the chunk partials / HW); r = swish(W1 s + b1); gate = sigmoid(W2 r + b2)
-// W1 [R][C], W2 [C][R].  saves s [B][C], pre1 [B][R] for the backward.
-__global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float *__restrict__ part, int nchunk, const float *__restrict__ W1,
+// W1 [R][C], W2T [R][C] (the expansion filter transposed: lanes run along C in every loop).  saves s [B][C], pre1 [B][R].
+__global__ __launch_bounds__(1024) void se_gate_fwd_kernel(const float *__restrict__ part, int nchunk, const float *__restrict__ W1,
                                                           const float *__restrict__ b1, const float *__restrict__ W2,
                                                           const float *__restrict__ b2, float *__restrict__ s_out,
                                                           float *__restrict__ pre1_out, float *__restrict__ gate, int C, int R, float inv_hw) {
     extern __shared__ float sh[];            // s [C], r [R]
     float *s = sh, *r = sh + C;
     const int img = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += 1024) {
         float a = 0.f;
         for (int k = 0; k < nchunk; ++k) a += part[((size_t)img * nchunk + k) * C + c];
         a *= inv_hw;
@@ -178,7 +197,7 @@ __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float *__restric
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = wave; j < R; j += 4) {      // one wave per reduced channel
+    for (int j = wave; j < R; j += 16) {      // one wave per reduced channel
         float a = 0.f;
         for (int c = lane; c < C; c += 64) a = fmaf(W1[(size_t)j * C + c], s[c], a);
         a = wave_sum(a) + b1[j];
@@ -188,16 +207,16 @@ __global__ __launch_bounds__(256) void se_gate_fwd_kernel(const float *__restric
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += 1024) {
         float a = b2[c];
-        for (int j = 0; j < R; ++j) a = fmaf(W2[(size_t)c * R + j], r[j], a);
+        for (int j = 0; j < R; ++j) a = fmaf(W2[(size_t)j * C + c], r[j], a);
         gate[(size_t)img * C + c] = sigmoidf(a);
     }
 }
 
 // backward of the gate for one image: dgate [C] = sum over pixels of dy * x (chunk partials) ->
 // dW2part [B][C][R], db2part [B][C], dW1part [B][R][C], db1part [B][R rounded up to 4], ds [B][C] (gradient w.r.t. the pooled mean, already / HW)
-__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float *__restrict__ dgpart, int nchunk, const float *__restrict__ W1,
+__global__ __launch_bounds__(1024) void se_gate_bwd_kernel(const float *__restrict__ dgpart, int nchunk, const float *__restrict__ W1,
                                                           const float *__restrict__ W2, const float *__restrict__ s_in,
                                                           const float *__restrict__ pre1_in, const float *__restrict__ gate,
                                                           float *__restrict__ dW1p, float *__restrict__ db1p, float *__restrict__ dW2p,
@@ -205,11 +224,11 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float *__restric
     extern __shared__ float sh[];            // dpre2 [C], r [R], dpre1 [R]
     float *dpre2 = sh, *r = sh + C, *dpre1 = r + R;
     const int img = blockIdx.x, RP = (R + 3) & ~3;
-    for (int j = threadIdx.x; j < R; j += 256) {
+    for (int j = threadIdx.x; j < R; j += 1024) {
         const float a = pre1_in[(size_t)img * R + j];
         r[j] = a * sigmoidf(a);
     }
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int c = threadIdx.x; c < C; c += 1024) {
         float dg = 0.f;
         for (int k = 0; k < nchunk; ++k) dg += dgpart[((size_t)img * nchunk + k) * C + c];
         const float gt = gate[(size_t)img * C + c];
@@ -218,11 +237,11 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float *__restric
         db2p[(size_t)img * C + c] = d;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C * R; i += 256) dW2p[(size_t)img * C * R + i] = dpre2[i / R] * r[i % R];
+    for (int i = threadIdx.x; i < C * R; i += 1024) dW2p[(size_t)img * C * R + i] = dpre2[i / R] * r[i % R];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = wave; j < R; j += 4) {
+    for (int j = wave; j < R; j += 16) {
         float a = 0.f;
-        for (int c = lane; c < C; c += 64) a = fmaf(W2[(size_t)c * R + j], dpre2[c], a);
+        for (int c = lane; c < C; c += 64) a = fmaf(W2[(size_t)j * C + c], dpre2[c], a);
         a = wave_sum(a);
         if (lane == 0) {
             const float p = pre1_in[(size_t)img * R + j], sg = sigmoidf(p);
@@ -233,8 +252,8 @@ __global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float *__restric
     }
     if (threadIdx.x >= R && threadIdx.x < RP) db1p[(size_t)img * RP + threadIdx.x] = 0.f;     // padding columns of the partial rows
     __syncthreads();
-    for (int i = threadIdx.x; i < R * C; i += 256) dW1p[(size_t)img * R * C + i] = dpre1[i / C] * s_in[(size_t)img * C + i % C];
-    for (int c = threadIdx.x; c < C; c += 256) {
+    for (int i = threadIdx.x; i < R * C; i += 1024) dW1p[(size_t)img * R * C + i] = dpre1[i / C] * s_in[(size_t)img * C + i % C];
+    for (int c = threadIdx.x; c < C; c += 1024) {
         float a = 0.f;
         for (int j = 0; j < R; ++j) a = fmaf(W1[(size_t)j * C + c], dpre1[j], a);
         ds[(size_t)img * C + c] = a * inv_hw;
@@ -315,12 +334,15 @@ extern "C" int sqd_dw_conv_wgrad(const float *dy, const float *x, float *part, i
     const DwGeom g = {N, H, W, C, k, stride, pad_t, pad_l, Ho, Wo};
     if (dw_check("sqd_dw_conv_wgrad", g)) return SQD_EINVAL;
     const int chunks = sqd_dw_conv_wgrad_chunks(N, Ho, Wo);
-    const long long M = (long long)N * Ho * Wo;
-    const int ppc = (int)((M + chunks - 1) / chunks);
+    const long long nruns = (long long)N * Ho * ((Wo + 3) / 4);
+    const int rpc = (int)((nruns + chunks - 1) / chunks);
     const dim3 grid(chunks, (C / 4 + 15) / 16);
     (void)hipGetLastError();
-    if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, part, g, ppc);
-    else hipLaunchKernelGGL((dw_wgrad_kernel<5>), grid, dim3(256), 0, (hipStream_t)stream, dy, x, part, g, ppc);
+    hipStream_t st = (hipStream_t)stream;
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<3, 1>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
+    else if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, 2>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
+    else if (stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<5, 1>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
+    else hipLaunchKernelGGL((dw_wgrad_kernel<5, 2>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
     SQD_CHECK_LAUNCH("sqd_dw_conv_wgrad");
     return SQD_OK;
 }
@@ -344,7 +366,7 @@ extern "C" int sqd_se_gate_fwd(const float *part, const float *W1, const float *
     SQD_CHECK_ARG(part && W1 && b1 && W2 && b2 && s && pre1 && gate && B > 0 && C > 0 && R > 0 && (size_t)(C + R) * 4 <= 64 * 1024,
                   "sqd_se_gate_fwd: bad arguments");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(256), (C + R) * sizeof(float), (hipStream_t)stream, part, sqd_se_chunks(HW), W1, b1, W2,
+    hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(1024), (C + R) * sizeof(float), (hipStream_t)stream, part, sqd_se_chunks(HW), W1, b1, W2,
                        b2, s, pre1, gate, C, R, 1.0f / (float)HW);
     SQD_CHECK_LAUNCH("sqd_se_gate_fwd");
     return SQD_OK;
@@ -357,7 +379,7 @@ extern "C" int sqd_se_gate_bwd(const float *dgpart, const float *W1, const float
                       (size_t)(C + 2 * R) * 4 <= 64 * 1024 && R <= 252,
                   "sqd_se_gate_bwd: bad arguments");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(256), (C + 2 * R) * sizeof(float), (hipStream_t)stream, dgpart, sqd_se_chunks(HW), W1, W2,
+    hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(1024), (C + 2 * R) * sizeof(float), (hipStream_t)stream, dgpart, sqd_se_chunks(HW), W1, W2,
                        s, pre1, gate, dW1part, db1part, dW2part, db2part, ds, C, R, 1.0f / (float)HW);
     SQD_CHECK_LAUNCH("sqd_se_gate_bwd");
     return SQD_OK;

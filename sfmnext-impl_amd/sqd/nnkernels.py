@@ -339,7 +339,7 @@ class SqueezeExcite(torch.autograd.Function):
         B, C, H, W = x.shape
         R, HW = w1.shape[0], H * W
         L = _l.lib()
-        W1, W2 = w1.reshape(R, C).contiguous(), w2.reshape(C, R).contiguous()
+        W1, W2 = w1.reshape(R, C).contiguous(), w2.reshape(C, R).t().contiguous()      # W2: [R, C] (transposed: coalesced along C)
         dev = x.device
         part = torch.empty(B, L.sqd_se_chunks(HW), C, device=dev, dtype=torch.float32)
         _l.check(L.sqd_se_pool(_ptr(x), None, _ptr(part), B, HW, C, _stream()), "se_pool")
