@@ -105,14 +105,14 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
     constexpr int NQ = BKT / 4, LDPT = BKT + 4, RPP = NT / NQ;  // float4 per staged row, LDS row pitch, rows per staging pass
     constexpr int A_F4 = BM * NQ / NT;
     static_assert(A_F4 >= 1 && (BKT == 16 || BKT == 32 || BKT == 64), "BM >= 64, BKT in {16, 32, 64}");
-    constexpr bool BF = PREC == 1 || PREC == 3;                 // bf16 operands: PREC 1 = three-term split (fp32-level accuracy),
-    constexpr int NTERM = PREC == 1 ? 3 : 1;                    // PREC 3 = one round-to-nearest bf16 term (bf16 training arithmetic)
-    constexpr int NBUF = PREC == 2 ? 1 : 2;                     // PREC 2: single LDS buffer (half the LDS, one more barrier per slice)
+    constexpr bool BF = PREC == 1 || PREC == 3 || PREC == 4;    // bf16 operands: PREC 1 / 4 = three-term split (fp32-level accuracy),
+    constexpr int NTERM = (PREC == 1 || PREC == 4) ? 3 : 1;     // PREC 3 = one round-to-nearest bf16 term (bf16 training arithmetic)
+    constexpr int NBUF = (PREC == 2 || PREC == 4) ? 1 : 2;      // PREC 2 / 4: single LDS buffer (half the LDS, one more barrier per slice)
     constexpr int LDH = BKT + 8;                                // PREC 1: bf16 row pitch (48 / 80 bytes: conflict-free b128 reads)
     __shared__ __attribute__((aligned(16))) float As[BF ? 1 : NBUF][BF ? 1 : BM][LDPT];
     __shared__ __attribute__((aligned(16))) float Bs[BF ? 1 : NBUF][BF ? 1 : BN][LDPT];
-    __shared__ __attribute__((aligned(16))) unsigned short Ah[BF ? 2 : 1][NTERM][BF ? BM : 1][LDH];   // [buffer][term][row][k]
-    __shared__ __attribute__((aligned(16))) unsigned short Bh[BF ? 2 : 1][NTERM][BF ? BN : 1][LDH];
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[BF ? NBUF : 1][NTERM][BF ? BM : 1][LDH];   // [buffer][term][row][k]
+    __shared__ __attribute__((aligned(16))) unsigned short Bh[BF ? NBUF : 1][NTERM][BF ? BN : 1][LDH];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm0 = (wave / WGN) * (WTM * 32), wn0 = (wave % WGN) * (WTN * 32);
@@ -894,6 +894,7 @@ struct GemmPlan {
     int bm, bn, z, bk;
     int waves = 4;                  // wavefronts per workgroup: 4, or 8 on the >= 128x64 tiles (one 32x32 tile per wave)
     int single = 0;                 // 1: single-buffered LDS variant (bk + 512 in sqd_conv_set_plan)
+    int split3 = 0;                 // 1: three-term bf16 operands on the bf16 matrix cores, single LDS buffer, 32-channel slices (bk + 1024)
     int64_t ws_floats;
 };
 // measured plans registered through sqd_conv_set_plan: (mode, geometry) -> (bm, bn, z)
@@ -965,6 +966,7 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
             p.bk = std::get<3>(it->second) & 255;
             p.waves = (std::get<3>(it->second) & 256) ? 8 : 4;
             p.single = (std::get<3>(it->second) & 512) ? 1 : 0;
+            p.split3 = (std::get<3>(it->second) & 1024) ? 1 : 0;
         }
     }
     int z = p.z;
@@ -984,7 +986,12 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(512), 0, st, \
                        a_src, w, bias, dst, g, act, p.z, order, stats)
 #define DISPATCH_GEMM(MODE)                                                      \
-    if (p.single && p.bm == 64 && p.bn == 64) {                                  \
+    if (p.split3) {                                                              \
+        if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM_P(MODE, 128, 128, 2, 2, 32, 4);      \
+        else if (p.bm == 128) LAUNCH_GEMM_P(MODE, 128, 64, 2, 2, 32, 4);         \
+        else if (p.bn == 128) LAUNCH_GEMM_P(MODE, 64, 128, 2, 2, 32, 4);         \
+        else LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 32, 4);                           \
+    } else if (p.single && p.bm == 64 && p.bn == 64) {                                  \
         if (p.bk == 64) LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 64, 2);                \
         else if (p.bk == 32) LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 32, 2);           \
         else LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 16, 2);                           \
@@ -1079,13 +1086,18 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     const int taps = mode == 0 ? R * S : ((R + stride - 1) / stride) * ((S + stride - 1) / stride);
     const int waves = (bk & 256) ? 8 : 4;                        // bk + 256: 8-wave workgroups (one 32x32 tile per wave)
     const int single = (bk & 512) ? 1 : 0;                       // bk + 512: single-buffered LDS (twice the resident workgroups)
+    const int split3 = (bk & 1024) ? 1 : 0;                      // bk + 1024: three-term bf16 operands (fp32-level accuracy on the bf16 matrix cores)
     bk &= 255;
+    if (split3) {
+        SQD_CHECK_ARG(waves == 4 && !single && bk == 32 && (bm == 128 || bm == 64) && (bn == 128 || bn == 64),
+                      "sqd_conv_set_plan: the three-term bf16 variants are 4-wave 128/64 x 128/64 tiles with 32-channel slices");
+    }
     SQD_CHECK_ARG(!single || (waves == 4 && ((bm == 64 && bn == 64) || (bm + bn == 192 && bk == 32) || (bm == 128 && bn == 128 && bk == 16) ||
                                              (bm == 128 && bn == 32))),
                   "sqd_conv_set_plan: single-buffered variants exist for 64x64, 128x32, 128x64 / 64x128 (bk 32) and 128x128 (bk 16)");
     SQD_CHECK_ARG(waves == 4 || (bm == 128 && bn == 128 && bk == 16) || (bm == 128 && bn == 64) || (bm == 64 && bn == 128 && bk == 32),
                   "sqd_conv_set_plan: 8-wave workgroups exist for 128x128 (bk 16), 128x64 and 64x128 (bk 32) tiles");
-    SQD_CHECK_ARG(bk == 16 || (bk == 32 && (mode == 0 ? C : K) % 32 == 0 && bm + bn <= 192) ||
+    SQD_CHECK_ARG(bk == 16 || split3 || (bk == 32 && (mode == 0 ? C : K) % 32 == 0 && bm + bn <= 192) ||
                       (bk == 64 && single && bm == 64 && bn == 64 && (mode == 0 ? C : K) % 64 == 0),
                   "sqd_conv_set_plan: slice width %d not possible here (32 needs 32 | reduced channels and bm + bn <= 192; 64 exists "
                   "for the single-buffered 64x64 tile with 64 | reduced channels)", bk);
@@ -1096,7 +1108,7 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     SQD_CHECK_ARG(!(bn > 32 && bn >= 2 * Ncols) && !(bn == 32 && Ncols > 32), "sqd_conv_set_plan: tile width %d does not fit %d channels", bn, Ncols);
     SQD_CHECK_ARG(z == 1 || (z <= T / 2 && z * out_elems * 4 <= (64ll << 20) && out_elems % 4 == 0),
                   "sqd_conv_set_plan: split-K %d not possible here", z);
-    plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, bk | (waves == 8 ? 256 : 0) | (single ? 512 : 0));
+    plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, bk | (waves == 8 ? 256 : 0) | (single ? 512 : 0) | (split3 ? 1024 : 0));
     return SQD_OK;
 }
 

@@ -188,7 +188,9 @@ def _tune_conv(mode, geom, launch):
     # measurable change of the step — left out of the default search, SQD_TUNE_8WAVE=1 adds them)
     # (bk 64 + 512 = a 64-channel slice on the single-buffered 64x64 tile: half the barriers again, picked for 11 layer-modes, no
     # gain on the totals — SQD_TUNE_BK64=1 adds it)
-    bks = (16, 32, 528, 544) + ((576,) if os.environ.get("SQD_TUNE_BK64") else ()) + ((272, 288) if os.environ.get("SQD_TUNE_8WAVE") else ())
+    # bk 32 + 1024 = three-term bf16 operands on the bf16 matrix cores (fp32-level accuracy, 6 products per slice at 16x the fp32
+    # MFMA rate, single LDS buffer): 20-30 % faster than the fp32 kernels on most config-B layers (profiles/r02e_conv_split3.md)
+    bks = (16, 32, 528, 544, 1056) + ((576,) if os.environ.get("SQD_TUNE_BK64") else ()) + ((272, 288) if os.environ.get("SQD_TUNE_8WAVE") else ())
     for bm, bn, z, bk in ((bm, bn, z, bk) for bm, bn in _TUNE_TILES for bk in bks for z in _TUNE_Z):
         if True:
             if L.sqd_conv_set_plan(mode, *geom, bm, bn, z, bk) != 0:

@@ -15,6 +15,7 @@ ap.add_argument("--iters", type=int, default=50)
 ap.add_argument("--N", type=int, default=12)
 ap.add_argument("--only", default="", help="comma-separated substrings of layer names")
 ap.add_argument("--tune", action="store_true", help="time the registered plans per layer first (what the Trainer's first step does)")
+ap.add_argument("--split3", action="store_true", help="also time the three-term bf16 plans (bk + 1024) per layer: best tile / split-K")
 args = ap.parse_args()
 N = args.N
 L = [  # name, C, H, W, K, R, stride, pad, count (occurrences per forward)
@@ -85,6 +86,27 @@ for name, C, H, W, K, R, st, pad, cnt in L:
     t_nf = timeit(lambda: LIB.sqd_conv_fwd(P(x), P(w), None, P(y), P(ws0), None, *geom, 0, ST()), args.iters)
     t_nd = timeit(lambda: LIB.sqd_conv_dgrad(P(dy), P(w), None, P(dx), P(ws1), *geom, ST()), args.iters)
     t_nw = timeit(lambda: LIB.sqd_conv_wgrad(P(dy), P(x), P(dw), None, P(part), *geom, ST()), args.iters)
+    if args.split3:
+        res = []
+        for mode, run in ((0, lambda ws: LIB.sqd_conv_fwd(P(x), P(w), None, P(y), P(ws), None, *geom, 0, ST())),
+                          (1, lambda ws: LIB.sqd_conv_dgrad(P(dy), P(w), None, P(dx), P(ws), *geom, ST()))):
+            best = None
+            for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64)):
+                for z in (1, 2, 3, 4, 6, 8):
+                    if LIB.sqd_conv_set_plan(mode, *geom, bm, bn, z, 32 + 1024) != 0:
+                        continue
+                    nnkernels._PLAN_CACHE.pop((mode,) + tuple(geom), None)
+                    ws = nnkernels._conv_ws(mode, geom, x.device)
+                    t = timeit(lambda: run(ws), 10)
+                    if best is None or t < best[0]:
+                        best = (t, bm, bn, z)
+            res.append(best or (float("inf"), 0, 0, 0))
+            LIB.sqd_conv_set_plan(mode, *geom, 0, 0, 0, 16)
+            nnkernels._PLAN_CACHE.pop((mode,) + tuple(geom), None)
+        print("%-22s %7.2f | fwd f32 %7.1f  3xbf16 %7.1f (%dx%d z%d) | dgrad f32 %7.1f  3xbf16 %7.1f (%dx%d z%d)" %
+              (name, gflop, t_nf, res[0][0], res[0][1], res[0][2], res[0][3], t_nd, res[1][0], res[1][1], res[1][2], res[1][3]), flush=True)
+        tot["n_f"] += cnt * t_nf; tot["n_d"] += cnt * t_nd; tot["a_f"] += cnt * min(t_nf, res[0][0]); tot["a_d"] += cnt * min(t_nd, res[1][0])
+        continue
     cb = torch.ops.aten.convolution_backward
     a = (None, [st, st], [pad, pad], [1, 1], False, [0, 0], 1)
     t_af = timeit(lambda: conv(x), args.iters)
