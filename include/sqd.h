@@ -249,7 +249,9 @@ int sqd_adam_step_dev(const void *recs, const void *grads, const void *chunks, i
 int sqd_conv_supported(int C, int K);
 /* ws: split-K workspace of sqd_conv_plan(mode 0 = fwd / 1 = dgrad, ...) floats; NULL when the plan says 0 */
 /* measured plans: see csrc/conv.hip — the library picks tile and split-K by a cost model unless the caller registers
- * a plan it has timed (bm x bn tile, z split-K factor, bk = 16 | 32 channels per reduction slice; bm = 0 clears) */
+ * a plan it has timed (bm x bn tile, z split-K factor, bk = 16 | 32 channels per reduction slice, + 256: 8-wave workgroups,
+ * + 512: single LDS buffer, 32 + 1024: three-term bf16 operands on the bf16 matrix cores — every fp32 operand as the exact sum of
+ * three bf16 terms, 6 of the 9 partial products (down to 2^-24 relative), fp32 accumulation, single LDS buffer; bm = 0 clears) */
 int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int bm,
                       int bn, int z, int bk);
 /* arithmetic of sqd_conv_fwd / sqd_conv_dgrad: 0 = fp32 MFMA (default, the reference's arithmetic); 1 = split-precision bf16

@@ -214,6 +214,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
     // ---- B staging.  forward: rows = k, 16 consecutive c of filter tap (r,s): float4 copies.
     //      dgrad: rows = c, 16 k's strided by R*S*C: read float4 along c, transpose into LDS.
     constexpr int B_F4 = (BN * NQ + NT - 1) / NT;
+    constexpr bool BDW = MODE == 1 && BF && (BN * BKT) % (NT * 8) == 0;      // dgrad, bf16 operands: B staged as groups of 8 k (see load_b)
     auto load_b = [&](float4 *rb) {
         const int cc = l_cc;
         const int rs = MODE == 0 ? l_r * g.S + l_s : (r0 + g.stride * l_r) * g.S + s0 + g.stride * l_s;   // filter tap of the slice
@@ -222,6 +223,21 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
             const int idx = t + NT * i;
             bool ok;
             unsigned off;
+            if (BDW) {
+                // bf16 operands: a thread owns 8 consecutive k of one in-channel (rb[2j], rb[2j+1]) — dword loads, lanes along c
+                // (256 contiguous bytes per wave and load), so that the packed terms go to LDS as one 16-byte write each
+                const int gidx = t + NT * (i >> 1), cl = gidx % BN, kg = gidx / BN;
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = cc * BKT + kg * 8 + (i & 1) * 4 + j;
+                    const bool okk = kg * 8 < BKT && n0 + cl < g.C && k < g.K;
+                    const unsigned o = (unsigned)((k * g.R * g.S + rs) * g.C + n0 + cl) * 4u;
+                    e[j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(w_rsrc, okk ? o : 0xffffffffu, 0, 0));
+                }
+                rb[i] = make_float4(e[0], e[1], e[2], e[3]);
+                continue;
+            }
             if (MODE == 0) {
                 const int row = idx / NQ, q4 = idx % NQ;                 // row = out channel, q4 = float4 along c
                 ok = row < BN && n0 + row < g.K && cc * BKT + q4 * 4 < g.C;
@@ -241,6 +257,22 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
                 const Split4 sp = splitN<NTERM>(ra[i]);
 #pragma unroll
                 for (int tm = 0; tm < NTERM; ++tm) *reinterpret_cast<uint2 *>(&Ah[buf][tm][arow + RPP * i][c4 * 4]) = sp.t[tm];
+            }
+            if (BDW) {
+#pragma unroll
+                for (int i2 = 0; i2 < B_F4 / 2; ++i2) {
+                    const int gidx = t + NT * i2, cl = gidx % BN, kg = gidx / BN;
+                    const Split4 s0 = splitN<NTERM>(rb[2 * i2]), s1 = splitN<NTERM>(rb[2 * i2 + 1]);
+                    if (kg * 8 < BKT) {
+#pragma unroll
+                        for (int tm = 0; tm < NTERM; ++tm) {
+                            u32x4 v;
+                            v.x = s0.t[tm].x; v.y = s0.t[tm].y; v.z = s1.t[tm].x; v.w = s1.t[tm].y;
+                            *reinterpret_cast<u32x4 *>(&Bh[buf][tm][cl][kg * 8]) = v;
+                        }
+                    }
+                }
+                return;
             }
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
