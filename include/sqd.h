@@ -398,14 +398,17 @@ int sqd_se_scale(const float *x, const float *gate, const float *ds, float *y, i
 
 /* ------------------------------------------------------------------------------------------------
  * PoseCNN tail
- * replaces: out = self.pose_conv(out); out = out.mean(3).mean(2); out = 0.01 * out.view(...)   reference networks/pose_cnn.py:40-45
- * x [B,h,w,C] channels-last, W [J,C] (the 1x1 filter), bias [J], J <= 16 -> out [B,J] = scale * (W . mean_hw(x) + bias); mean [B,C]
- * is kept for the backward.  backward: g [B,J] -> dx [B,h,w,C], per-image partials dWpart [B,J,C], dbpart [B,J rounded up to a
- * multiple of 4] (summed over B by sqd_colsum_multi; needs C % 4 == 0).                                                                                                          */
-int sqd_pose_head_fwd(const float *x, const float *W, const float *bias, float *out, float *mean, int B, int h, int w, int C, int J,
-                      float scale, void *stream);
-int sqd_pose_head_bwd(const float *g, const float *W, const float *mean, float *dx, float *dWpart, float *dbpart, int B, int P, int C,
-                      int J, float scale, void *stream);
+ * replaces: out = self.pose_conv(out); out = out.mean(3).mean(2); out = 0.01 * out.view(-1, F, 1, 6); axisangle = out[..., :3];
+ *           translation = out[..., 3:]                                                  reference networks/pose_cnn.py:40-45
+ * x [B,h,w,C] channels-last, W [J,C] (the 1x1 filter), bias [J], J <= 16; mean [B,C] is kept for the backward.
+ * out2 == NULL: out [B,J] = scale * (W . mean_hw(x) + bias).  out2 != NULL (J = 6 F): the same numbers split the reference's way into
+ * two dense tensors, out = axisangle [B,F,3] and out2 = translation [B,F,3] (what sqd_pose_mats_fwd reads).
+ * backward: g (and g2, the forward's layouts) -> dx [B,h,w,C], per-image partials dWpart [B,J,C], dbpart [B,J rounded up to a
+ * multiple of 4] (summed over B by sqd_colsum_multi; needs C % 4 == 0).                                                   */
+int sqd_pose_head_fwd(const float *x, const float *W, const float *bias, float *out, float *out2, float *mean, int B, int h, int w,
+                      int C, int J, float scale, void *stream);
+int sqd_pose_head_bwd(const float *g, const float *g2, const float *W, const float *mean, float *dx, float *dWpart, float *dbpart,
+                      int B, int P, int C, int J, float scale, void *stream);
 
 #ifdef __cplusplus
 }

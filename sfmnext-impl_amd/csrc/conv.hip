@@ -835,6 +835,125 @@ __global__ __launch_bounds__(256) void conv_wgrad_direct_kernel(const float *__r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// wgrad, shared-operand kernel: the four waves of a workgroup own four register tiles of ONE (WK*KT*16) x (WC*CT*16) block of
+// dw[., tap, .] and walk the same pixel range together; the dy / x rows of 32 pixels are staged once per workgroup in LDS in
+// their memory order ([pixel][channel]: the 16x16x4 fp32 MFMA takes one value per lane, rows = channels, k = pixel, so a lane's
+// KT (CT) consecutive channels are one 16-byte LDS read and nothing is transposed).  The direct-operand kernel above gives every
+// wave its own 64 x 64 tile and pixel range, i.e. its own 512 bytes of operands per 4 pixels: at 16 B/clk/wave the L1 path, not
+// the matrix core, sets its pace (43 % MFMA busy).  Here a 128 x 128 block costs 1 KB per 4 pixels for four waves — a quarter of
+// the fetch traffic per multiply — and there is no cross-wave reduction at the end.
+// part[split][k][r][s][c] partial sums as for the other kernels (split_reduce_kernel adds the splits).
+// ---------------------------------------------------------------------------------------------------
+template <int N> struct FVec;
+template <> struct FVec<2> { typedef float2 type; };
+template <> struct FVec<4> { typedef float4 type; };
+template <int WK, int WC, int KT, int CT>
+__global__ __launch_bounds__(256) void conv_wgrad_shared_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                float *__restrict__ part, ConvGeom g, int px_per_split, int nsplits) {
+    static_assert(WK * WC == 4 && (KT == 2 || KT == 4) && (CT == 2 || CT == 4), "4 waves, register tiles of 32 / 64 channels");
+    constexpr int TK = WK * KT * 16, TC = WC * CT * 16, PS = 32;    // block of filters x channels, pixels per slab
+    constexpr int CHA = TK / 4, CHB = TC / 4;                       // float4 per staged pixel row
+    constexpr int PPA = 256 / CHA, PPB = 256 / CHB;                 // pixel rows per staging pass
+    constexpr int NPA = PS / PPA, NPB = PS / PPB;                   // passes per slab
+    static_assert(NPA >= 1 && NPB >= 1, "tile too narrow for 256 staging threads");
+    __shared__ __attribute__((aligned(16))) float sA[PS][TK];
+    __shared__ __attribute__((aligned(16))) float sB[PS][TC];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wk = wave / WC, wc = wave % WC;
+    const int i16 = lane & 15, pq = lane >> 4;
+    const int RS = g.R * g.S, tk = g.K / TK, tc = g.C / TC;
+    const int logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // taps fastest inside an XCD's range
+    if (logical >= RS * tk * tc * nsplits) return;
+    const int tap = logical % RS, lg = logical / RS, grp = lg % (tk * tc), split = lg / (tk * tc);
+    const int k0 = (grp % tk) * TK, c0 = (grp / tk) * TC, r = tap / g.S, s = tap - r * g.S;
+    const int M = g.N * g.Ho * g.Wo;
+    const int mbeg = split * px_per_split, mend = min(M, mbeg + px_per_split);
+    const int chA = t % CHA, ppA = t / CHA, chB = t % CHB, ppB = t / CHB;
+    // x rows: (n, ho, wo) of this thread's pixel of every pass, advanced by PS per slab
+    int wo[NPB], ho[NPB], nn[NPB];
+#pragma unroll
+    for (int i = 0; i < NPB; ++i) {
+        const int m = mbeg + i * PPB + ppB;
+        wo[i] = m % g.Wo;
+        const int t2 = m / g.Wo;
+        ho[i] = t2 % g.Ho;
+        nn[i] = t2 / g.Ho;
+    }
+    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(dy, (unsigned)(g.N * g.Ho * g.Wo * g.K) * 4u);
+    const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(x, (unsigned)(g.N * g.H * g.W * g.C) * 4u);
+    int mslab = mbeg;
+    float4 ra[NPA], rb[NPB];
+    auto load = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) {
+            const int m = mslab + i * PPA + ppA;
+            ra[i] = buf_load4(dy_rsrc, m < mend ? ((unsigned)m * g.K + k0 + chA * 4) * 4u : 0xffffffffu);
+        }
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) {
+            const int m = mslab + i * PPB + ppB;
+            const int hi = ho[i] * g.stride - g.pad + r, wi = wo[i] * g.stride - g.pad + s;
+            const bool ok = m < mend && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+            rb[i] = buf_load4(x_rsrc, ok ? ((unsigned)((nn[i] * g.H + hi) * g.W + wi) * g.C + c0 + chB * 4) * 4u : 0xffffffffu);
+            wo[i] += PS;
+            while (wo[i] >= g.Wo) {
+                wo[i] -= g.Wo;
+                if (++ho[i] >= g.Ho) { ho[i] = 0; ++nn[i]; }
+            }
+        }
+        mslab += PS;
+    };
+    auto store = [&]() {
+#pragma unroll
+        for (int i = 0; i < NPA; ++i) *reinterpret_cast<float4 *>(&sA[i * PPA + ppA][chA * 4]) = ra[i];
+#pragma unroll
+        for (int i = 0; i < NPB; ++i) *reinterpret_cast<float4 *>(&sB[i * PPB + ppB][chB * 4]) = rb[i];
+    };
+    f32x4 acc[KT][CT];
+#pragma unroll
+    for (int q = 0; q < KT; ++q)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[q][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const int nslab = (mend - mbeg + PS - 1) / PS;
+    if (nslab > 0) {
+        load();
+        store();
+    }
+    __syncthreads();
+    typedef typename FVec<KT>::type AV;
+    typedef typename FVec<CT>::type BV;
+    for (int sl = 0; sl < nslab; ++sl) {
+        if (sl + 1 < nslab) load();                     // next slab into registers while this one is multiplied
+#pragma unroll
+        for (int ks = 0; ks < PS / 4; ++ks) {
+            const AV av = *reinterpret_cast<const AV *>(&sA[ks * 4 + pq][wk * KT * 16 + KT * i16]);
+            const BV bv = *reinterpret_cast<const BV *>(&sB[ks * 4 + pq][wc * CT * 16 + CT * i16]);
+            const float *a = reinterpret_cast<const float *>(&av), *b = reinterpret_cast<const float *>(&bv);
+#pragma unroll
+            for (int q = 0; q < KT; ++q)
+#pragma unroll
+                for (int c = 0; c < CT; ++c) acc[q][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], b[c], acc[q][c], 0, 0, 0);
+        }
+        __syncthreads();
+        if (sl + 1 < nslab) store();
+        __syncthreads();
+    }
+    // C/D layout of the 16x16 MFMA: row = 4 * pq + v, column = i16; register tile q / c interleaves the channels (see the loads)
+    float *po = part + (size_t)split * g.K * RS * g.C;
+#pragma unroll
+    for (int q = 0; q < KT; ++q)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int k = k0 + wk * KT * 16 + KT * (4 * pq + v) + q, cc = c0 + wc * CT * 16 + CT * i16;
+            BV o;
+            float *of = reinterpret_cast<float *>(&o);
+#pragma unroll
+            for (int c = 0; c < CT; ++c) of[c] = acc[q][c][v];
+            *reinterpret_cast<BV *>(&po[((size_t)k * RS + tap) * g.C + cc]) = o;
+        }
+}
+
 // sum of the split-K partial tiles (+ bias, + activation): part [Z][M*Ncols] -> out [M*Ncols]
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias,
                                                           const float *__restrict__ addend, float *__restrict__ out, size_t n, int Z,
@@ -1020,6 +1139,7 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
 #define DISPATCH_GEMM(MODE)                                                      \
     if (p.split3) {                                                              \
         if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM_P(MODE, 128, 128, 2, 2, 32, 4);      \
+        else if (p.bm == 128 && p.bn == 32) LAUNCH_GEMM_P(MODE, 128, 32, 4, 1, 32, 4);   \
         else if (p.bm == 128) LAUNCH_GEMM_P(MODE, 128, 64, 2, 2, 32, 4);         \
         else if (p.bn == 128) LAUNCH_GEMM_P(MODE, 64, 128, 2, 2, 32, 4);         \
         else LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 32, 4);                           \
@@ -1121,8 +1241,8 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     const int split3 = (bk & 1024) ? 1 : 0;                      // bk + 1024: three-term bf16 operands (fp32-level accuracy on the bf16 matrix cores)
     bk &= 255;
     if (split3) {
-        SQD_CHECK_ARG(waves == 4 && !single && bk == 32 && (bm == 128 || bm == 64) && (bn == 128 || bn == 64),
-                      "sqd_conv_set_plan: the three-term bf16 variants are 4-wave 128/64 x 128/64 tiles with 32-channel slices");
+        SQD_CHECK_ARG(waves == 4 && !single && bk == 32 && (((bm == 128 || bm == 64) && (bn == 128 || bn == 64)) || (bm == 128 && bn == 32)),
+                      "sqd_conv_set_plan: the three-term bf16 variants are 4-wave 128/64 x 128/64 and 128x32 tiles with 32-channel slices");
     }
     SQD_CHECK_ARG(!single || (waves == 4 && ((bm == 64 && bn == 64) || (bm + bn == 192 && bk == 32) || (bm == 128 && bn == 128 && bk == 16) ||
                                              (bm == 128 && bn == 32))),
@@ -1213,7 +1333,13 @@ extern "C" int sqd_conv_dgrad(const float *dy, const float *w, const float *adde
 struct WgradPlan {
     bool direct;
     int kt, ct, tp, splits, px_per_wave;
+    int shared = 0;                 // 1..4: shared-operand kernel, block 128x128 / 64x128 / 128x64 / 64x64 (filters x channels); 0: not
+    int px_per_split = 0;
 };
+static void shared_block(int variant, int &tk, int &tc) {
+    tk = (variant == 1 || variant == 3) ? 128 : 64;
+    tc = (variant == 1 || variant == 2) ? 128 : 64;
+}
 // measured weight-gradient plans (sqd_conv_wgrad_set_plan): geometry -> (impl 0 = LDS-tiled / 1 = direct-operand, splits)
 typedef std::tuple<int, int, int, int, int, int, int> WPlanKey;
 static std::map<WPlanKey, std::pair<int, int>> &wplan_table() {
@@ -1234,6 +1360,21 @@ static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, i
     const int M = N * Ho * Wo;
     int m_impl = -1, m_splits = 0;
     const bool measured = wplan_lookup(N, Ho, Wo, C, K, R, S, m_impl, m_splits);
+    if (measured && (m_impl & 15) == 2) {                        // shared-operand kernel (measured plans only)
+        p.direct = false;
+        p.kt = p.ct = p.tp = 1;
+        p.px_per_wave = 0;
+        p.shared = ((m_impl >> 4) & 15) + 1;
+        int sp = m_splits;
+        const int max_by_px = (M + 63) / 64;                     // >= 64 pixels per split
+        if (sp > max_by_px) sp = max_by_px;
+        const int64_t wsz = (int64_t)K * R * S * C;
+        while (sp > 1 && (int64_t)sp * wsz * 4 > (64ll << 20)) --sp;
+        if (sp < 1) sp = 1;
+        p.px_per_split = ((M + sp - 1) / sp + 31) / 32 * 32;
+        p.splits = (M + p.px_per_split - 1) / p.px_per_split;
+        return p;
+    }
     const int fkt = measured ? (m_impl >> 4) & 15 : 0, fct = measured ? (m_impl >> 8) & 15 : 0;   // measured register-tile shape (0: default)
     if (measured) m_impl &= 1;
     // the direct kernel wins where pixels are many and channels few (operand re-reads stay in L2); the LDS-tiled
@@ -1269,7 +1410,7 @@ static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, i
 extern "C" int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *splits, int64_t *part_floats) {
     const int M = N * Ho * Wo;
     const WgradPlan dp = plan_wgrad_direct(N, Ho, Wo, C, K, R, S);
-    if (dp.direct) {
+    if (dp.direct || dp.shared) {
         if (splits) *splits = dp.splits;
         if (part_floats) *part_floats = (int64_t)dp.splits * K * R * S * C;
         return SQD_OK;
@@ -1302,6 +1443,15 @@ extern "C" int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int 
         return SQD_OK;
     }
     const int kt = (impl >> 4) & 15, ct = (impl >> 8) & 15;      // optional register-tile shape of the direct kernel: 16*kt x 16*ct
+    if ((impl & 15) == 2) {                                      // shared-operand kernel: impl 2 + 16 * variant
+        const int variant = (impl >> 4) + 1;
+        int tk, tc;
+        shared_block(variant, tk, tc);
+        SQD_CHECK_ARG(variant >= 1 && variant <= 4 && K % tk == 0 && C % tc == 0 && splits >= 1 && splits <= 65535,
+                      "sqd_conv_wgrad_set_plan: shared-operand block %d does not fit K=%d, C=%d", variant, K, C);
+        wplan_table()[WPlanKey(N, Ho, Wo, C, K, R, S)] = std::make_pair(impl, splits);
+        return SQD_OK;
+    }
     SQD_CHECK_ARG((impl & ~0xff1) == 0 && splits >= 1 && splits <= 65535, "sqd_conv_wgrad_set_plan: bad plan impl=%d splits=%d", impl, splits);
     SQD_CHECK_ARG((impl & 1) == 0 || (C % 16 == 0 && K % 16 == 0), "sqd_conv_wgrad_set_plan: the direct kernel needs C, K multiples of 16");
     SQD_CHECK_ARG((kt == 0 && ct == 0) || ((impl & 1) && (kt == 1 || kt == 2 || kt == 4) && (ct == 1 || ct == 2 || ct == 4) &&
@@ -1328,7 +1478,17 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
     const WgradPlan dp = plan_wgrad_direct(N, Ho, Wo, C, K, R, S);
-    if (dp.direct) {
+    if (dp.shared) {
+        int tk, tc;
+        shared_block(dp.shared, tk, tc);
+        const dim3 grid(((K / tk) * (C / tc) * R * S * dp.splits + 7) / 8 * 8);
+#define LAUNCH_WS(WK, WC, KT, CT) \
+    hipLaunchKernelGGL((conv_wgrad_shared_kernel<WK, WC, KT, CT>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_split, dp.splits)
+        if (dp.shared == 1) LAUNCH_WS(2, 2, 4, 4);
+        else if (dp.shared == 2) LAUNCH_WS(1, 4, 4, 2);
+        else if (dp.shared == 3) LAUNCH_WS(4, 1, 2, 4);
+        else LAUNCH_WS(2, 2, 2, 2);
+    } else if (dp.direct) {
         const int kgroups = K / (16 * dp.kt);
         const dim3 grid((kgroups * (C / (16 * dp.ct)) * dp.splits * (R * S / dp.tp) + 7) / 8 * 8);
         float *bias_part = dbias ? part + (size_t)dp.splits * K * R * S * C : nullptr;   // [splits][K]

@@ -23,5 +23,5 @@ class PoseCNN(nn.Module):
     def forward(self, out):
         for conv in self.net:
             out = X.conv2d(out, conv, "relu")
-        out = X.pose_head(out, self.pose_conv, 0.01).view(-1, self.num_input_frames - 1, 1, 6)
-        return out[..., :3], out[..., 3:]
+        # (axisangle, translation) = out.view(-1, F, 1, 6)[..., :3], [..., 3:] of the reference, written as two dense tensors
+        return X.pose_head(out, self.pose_conv, 0.01, split=True)

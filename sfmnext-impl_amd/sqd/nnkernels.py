@@ -261,6 +261,32 @@ def _tune_wgrad(geom, has_bias, launch):
             t = e0.elapsed_time(e1)
             if best is None or t < best[0]:
                 best = (t, impl, sp)
+    # shared-operand kernel (impl 2 + 16 * variant: blocks of 128x128 / 64x128 / 128x64 / 64x64 filters x channels staged once per
+    # workgroup in LDS): pixel splits for ~256 .. 1536 workgroups
+    for v, (tk, tc) in enumerate(((128, 128), (64, 128), (128, 64), (64, 64))):
+        if K % tk or C % tc:
+            continue
+        blocks = (K // tk) * (C // tc) * R * S
+        tried = set()
+        for target in (256, 512, 768, 1024, 1536):
+            sp = max(1, (target + blocks - 1) // blocks)
+            if sp in tried or L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, 2 | (v << 4), sp) != 0:
+                continue
+            tried.add(sp)
+            _PLAN_CACHE.pop(key, None)
+            pf, splits = _wgrad_part_floats(geom)
+            extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if has_bias else 0
+            part = torch.empty(pf + extra, device="cuda", dtype=torch.float32)
+            launch(part)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                launch(part)
+            e1.record()
+            e1.synchronize()
+            t = e0.elapsed_time(e1)
+            if best is None or t < best[0]:
+                best = (t, 2 | (v << 4), sp)
     L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, best[1], best[2])
     _PLAN_CACHE.pop(key, None)
     if os.environ.get("SQD_TUNE_LOG"):
@@ -378,38 +404,48 @@ class SqueezeExcite(torch.autograd.Function):
 
 class PoseHead(torch.autograd.Function):
     """scale * pose_conv(x).mean(3).mean(2) of PoseCNN (reference networks/pose_cnn.py:40-42) as one launch each way.
-    forward(x [B,C,h,w] channels-last, weight [J,C,1,1], bias [J], scale) -> [B,J]"""
+    forward(x [B,C,h,w] channels-last, weight [J,C,1,1], bias [J], scale, split) -> [B,J], or with split=True (J = 6 F) the
+    reference's (axisangle, translation) = (out[..., :3], out[..., 3:]) of out.view(B, F, 1, 6) as two dense [B,F,1,3] tensors
+    (pose_cnn.py:44-45): the photometric chain reads them as they are and their gradients come back as two tensors too."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, scale):
+    def forward(ctx, x, weight, bias, scale, split=False):
         _require(x, "PoseHead input")
         x = _cl(x)
         B, C, h, w = x.shape
         J = weight.shape[0]
         wm = weight.reshape(J, C).contiguous()
-        out = torch.empty(B, J, device=x.device, dtype=torch.float32)
+        if split:
+            out = torch.empty(B, J // 6, 1, 3, device=x.device, dtype=torch.float32)
+            out2 = torch.empty_like(out)
+        else:
+            out, out2 = torch.empty(B, J, device=x.device, dtype=torch.float32), None
         mean = torch.empty(B, C, device=x.device, dtype=torch.float32)
-        _l.check(_l.lib().sqd_pose_head_fwd(_ptr(x), _ptr(wm), _ptr(bias), _ptr(out), _ptr(mean), B, h, w, C, J, float(scale), _stream()),
-                 "pose_head_fwd")
+        _l.check(_l.lib().sqd_pose_head_fwd(_ptr(x), _ptr(wm), _ptr(bias), _ptr(out), _ptr(out2), _ptr(mean), B, h, w, C, J, float(scale),
+                                            _stream()), "pose_head_fwd")
         ctx.save_for_backward(wm, mean)
-        ctx.dims = (B, C, h, w, J, float(scale), weight.shape)
-        return out
+        ctx.dims = (B, C, h, w, J, float(scale), weight.shape, split)
+        return (out, out2) if split else out
 
     @staticmethod
-    def backward(ctx, g):
+    def backward(ctx, g, g2=None):
         wm, mean = ctx.saved_tensors
-        B, C, h, w, J, scale, wshape = ctx.dims
-        g = g.contiguous()
+        B, C, h, w, J, scale, wshape, split = ctx.dims
+        if split:                                        # an unused half arrives as None
+            g = g.contiguous() if g is not None else torch.zeros(B, J // 6, 1, 3, device=wm.device)
+            g2 = g2.contiguous() if g2 is not None else torch.zeros(B, J // 6, 1, 3, device=wm.device)
+        else:
+            g = g.contiguous()
         dx = torch.empty((B, C, h, w), device=g.device, dtype=torch.float32, memory_format=torch.channels_last)
         dWp_c = torch.empty(B, J * C, device=g.device, dtype=torch.float32)
         JP = (J + 3) // 4 * 4
         dbp_c = torch.empty(B, JP, device=g.device, dtype=torch.float32)
-        _l.check(_l.lib().sqd_pose_head_bwd(_ptr(g), _ptr(wm), _ptr(mean), _ptr(dx), _ptr(dWp_c), _ptr(dbp_c), B, h * w, C, J, scale, _stream()),
-                 "pose_head_bwd")
+        _l.check(_l.lib().sqd_pose_head_bwd(_ptr(g), _ptr(g2) if split else None, _ptr(wm), _ptr(mean), _ptr(dx), _ptr(dWp_c), _ptr(dbp_c), B,
+                                            h * w, C, J, scale, _stream()), "pose_head_bwd")
         dW = torch.empty(J, C, device=g.device, dtype=torch.float32)
         db = torch.empty(JP, device=g.device, dtype=torch.float32)
         _colsum_multi([(dWp_c, dW, 0), (dbp_c, db, 0)])
-        return dx, dW.view(wshape), db[:J], None
+        return dx, dW.view(wshape), db[:J], None, None
 
 
 def linear_native(x, lin, act=None):

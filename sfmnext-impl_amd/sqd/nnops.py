@@ -108,13 +108,18 @@ def _bn_act(y, bn, act, residual, pre=None):
     return nnkernels.batch_norm_act(y, bn, act, residual)
 
 
-def pose_head(x, conv, scale):
-    """scale * conv(x).mean(3).mean(2) for PoseCNN's 1x1 head (reference networks/pose_cnn.py:40-45) -> [B, J]."""
+def pose_head(x, conv, scale, split=False):
+    """scale * conv(x).mean(3).mean(2) for PoseCNN's 1x1 head (reference networks/pose_cnn.py:40-45) -> [B, J]; split=True:
+    -> (axisangle, translation), each [B, J/6, 1, 3] — out.view(-1, F, 1, 6)[..., :3] and [..., 3:] as dense tensors."""
     if x.is_cuda and NATIVE_CONV and conv.kernel_size == (1, 1) and conv.out_channels <= 16 and conv.bias is not None:
         from . import nnkernels
-        return nnkernels.PoseHead.apply(x, conv.weight, conv.bias, scale)
+        return nnkernels.PoseHead.apply(x, conv.weight, conv.bias, scale, split)
     _device_only(x, "pose_head")
-    return scale * F.conv2d(x, conv.weight, conv.bias).mean(3).mean(2)
+    out = scale * F.conv2d(x, conv.weight, conv.bias).mean(3).mean(2)
+    if split:
+        out = out.view(out.shape[0], -1, 1, 6)
+        return out[..., :3], out[..., 3:]
+    return out
 
 
 def dw_conv_bn_act(x, conv, bn, act, stride):

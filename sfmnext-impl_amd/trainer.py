@@ -29,7 +29,7 @@ from torch.utils.data import DataLoader
 
 import datasets
 import networks
-from layers import compute_depth_errors, transformation_from_parameters
+from layers import compute_depth_errors
 from sqd import ddp, nnkernels, ops
 from sqd.optim import FusedAdam
 from utils import normalize_image, sec_to_hm_str
@@ -417,19 +417,32 @@ class Trainer:
         # PoseCNN has no batch statistics, so the pairs of all source frames go through it as ONE batch [S*B,6,H,W] (the
         # reference calls it once per pair, trainer.py:319-334): same numbers per sample, half the launches, and every
         # pose filter is used once per step (its weight gradient is one kernel, not a sum of two).
-        B = aug[0].shape[0]
-        x = torch.empty((len(srcs) * B, 6) + tuple(aug[0].shape[2:]), device=aug[0].device, dtype=aug[0].dtype,
+        # Row b*S + i of the batch is pair i of sample b, so that the head's outputs ARE the [B,S,3] axis-angle / translation
+        # arrays the photometric chain reads (no slicing, cat or copies in between, forward or backward).
+        B, S = aug[0].shape[0], len(srcs)
+        x = torch.empty((B * S, 6) + tuple(aug[0].shape[2:]), device=aug[0].device, dtype=aug[0].dtype,
                         memory_format=torch.channels_last if self.opt.sqd_channels_last else torch.contiguous_format)
+        xv = x.view((B, S, 6) + tuple(aug[0].shape[2:]))
         for i, f in enumerate(srcs):
             first, second = (aug[f], aug[0]) if f < 0 else (aug[0], aug[f])
-            x[i * B:(i + 1) * B, :3].copy_(first)
-            x[i * B:(i + 1) * B, 3:].copy_(second)
-        axisangle, translation = self.models["pose"](x)
+            xv[:, i, :3].copy_(first)
+            xv[:, i, 3:].copy_(second)
+        axisangle, translation = self.models["pose"](x)               # [B*S,1,1,3] each
+        if not (axisangle.is_contiguous() and translation.is_contiguous()):
+            axisangle, translation = axisangle.contiguous(), translation.contiguous()
+        aa_all, tr_all = axisangle.view(B, S, 3), translation.view(B, S, 3)
+        # the un-scaled cam_T_cam of every pair (reference trainer.py:336-337) in one launch; detached, as the stand-alone
+        # transformation_from_parameters returns it (the training path differentiates the pose through PhotometricChain)
+        eye = getattr(self, "_eye4", None)
+        if eye is None or eye.shape[0] != B or eye.device != aa_all.device:
+            eye = self._eye4 = torch.eye(4, device=aa_all.device).repeat(B, 1, 1)
+        _, T_all, _ = ops.pose_mats_fwd(aa_all.detach(), tr_all.detach(), [1 if f < 0 else 0 for f in srcs], eye)
         for i, f in enumerate(srcs):
-            aa, tr = axisangle[i * B:(i + 1) * B], translation[i * B:(i + 1) * B]
-            outputs[("axisangle", 0, f)] = aa
-            outputs[("translation", 0, f)] = tr
-            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(aa[:, 0], tr[:, 0], invert=(f < 0))
+            outputs[("axisangle", 0, f)] = aa_all[:, i].view(B, 1, 1, 3)
+            outputs[("translation", 0, f)] = tr_all[:, i].view(B, 1, 1, 3)
+            outputs[("cam_T_cam", 0, f)] = T_all[:, i]
+        # generate_images_pred reads the [B,S,3] arrays as they are when it is handed these very outputs
+        self._pose_all = (aa_all, tr_all, tuple(outputs[("axisangle", 0, f)] for f in srcs))
         return outputs
 
     def generate_images_pred(self, inputs, outputs):
@@ -445,8 +458,12 @@ class Trainer:
         identity, self._identity = self._identity, None
         pose_ids = [f for f in srcs_ids if f != "s"]
         B = inputs[("color", 0, 0)].shape[0]
-        if pose_ids:
-            aa = torch.cat([outputs[("axisangle", 0, f)][:, 0] for f in pose_ids], 1).contiguous()      # [B,Sp,3]
+        cached, self._pose_all = getattr(self, "_pose_all", None), None
+        if pose_ids and cached is not None and len(cached[2]) == len(pose_ids) and \
+                all(outputs[("axisangle", 0, f)] is t for f, t in zip(pose_ids, cached[2])):
+            aa, tr = cached[:2]                                                                          # [B,Sp,3] (predict_poses)
+        elif pose_ids:
+            aa = torch.cat([outputs[("axisangle", 0, f)][:, 0] for f in pose_ids], 1).contiguous()
             tr = torch.cat([outputs[("translation", 0, f)][:, 0] for f in pose_ids], 1).contiguous()
         else:
             aa = tr = torch.zeros(B, 0, 3, device=self.device)

@@ -91,7 +91,7 @@ for name, C, H, W, K, R, st, pad, cnt in L:
         for mode, run in ((0, lambda ws: LIB.sqd_conv_fwd(P(x), P(w), None, P(y), P(ws), None, *geom, 0, ST())),
                           (1, lambda ws: LIB.sqd_conv_dgrad(P(dy), P(w), None, P(dx), P(ws), *geom, ST()))):
             best = None
-            for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64)):
+            for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64), (128, 32)):
                 for z in (1, 2, 3, 4, 6, 8):
                     if LIB.sqd_conv_set_plan(mode, *geom, bm, bn, z, 32 + 1024) != 0:
                         continue
