@@ -30,8 +30,12 @@ def conv_bn_act(x, conv, bn, act, residual=None, input_affine=None, skip=False):
     return (y, x) if skip else y
 
 
-def pose_head(x, conv, scale):
-    return scale * F.conv2d(x, conv.weight, conv.bias).mean(3).mean(2)
+def pose_head(x, conv, scale, split=False):
+    out = scale * F.conv2d(x, conv.weight, conv.bias).mean(3).mean(2)
+    if split:
+        out = out.view(out.shape[0], -1, 1, 6)
+        return out[..., :3], out[..., 3:]
+    return out
 
 
 def maxpool3x3s2(x, skip=False):
