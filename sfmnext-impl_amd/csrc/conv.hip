@@ -150,7 +150,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
     const int T = s_end - s_beg;
 
     // ---- per-thread A staging rows: float4 column c4 of rows t / NQ + RPP*i
-    const int c4 = t % NQ, arow = t / NQ;
+    // bf16 tiles with 32-channel slices (row pitch 80 bytes = 20 banks): the 32 lanes an 8-byte LDS store serves per clock cover
+    // four staging rows, and rows r, r+1, r+2, r+3 wrap onto each other's banks (a third of the LDS cycles were conflicts).  Rows
+    // r, r+4, r+8, r+12 start 16 banks apart: staging row x of a group of 16 is dealt as 4 * (x % 4) + x / 4 (any row order is a
+    // valid one — the rows of a tile are independent).
+    auto srow = [](int x) { return (BF && BKT == 32) ? ((x & ~15) | ((x & 3) << 2) | ((x >> 2) & 3)) : x; };
+    const int c4 = t % NQ, arow = srow(t / NQ);
     int an[A_F4], ah[A_F4], aw[A_F4];
     bool aval[A_F4];
 #pragma unroll
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
                 continue;
             }
             if (MODE == 0) {
-                const int row = idx / NQ, q4 = idx % NQ;                 // row = out channel, q4 = float4 along c
+                const int row = srow(idx / NQ), q4 = idx % NQ;           // row = out channel, q4 = float4 along c
                 ok = row < BN && n0 + row < g.K && cc * BKT + q4 * 4 < g.C;
                 off = (unsigned)(((n0 + row) * g.R * g.S + rs) * g.C + cc * BKT + q4 * 4) * 4u;
             } else {
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
                 const int idx = t + NT * i;
                 const Split4 sp = splitN<NTERM>(rb[i]);
                 if (MODE == 0) {
-                    const int row = idx / NQ, q4 = idx % NQ;
+                    const int row = srow(idx / NQ), q4 = idx % NQ;
                     if (row < BN) {
 #pragma unroll
                         for (int tm = 0; tm < NTERM; ++tm) *reinterpret_cast<uint2 *>(&Bh[buf][tm][row][q4 * 4]) = sp.t[tm];
