@@ -219,11 +219,11 @@ def _tune_conv(mode, geom, launch):
 
 def _tune_wgrad(geom, has_bias, launch):
     """Same for the weight gradient: direct-operand vs LDS-tiled kernel, 1/8x .. 4x the model's pixel splits."""
-    key = ("w",) + tuple(geom)
+    N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
+    key = _wgrad_key(geom)
     if key in _TUNED or torch.cuda.is_current_stream_capturing():
         return
     _TUNED.add(key)
-    N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
     L = _l.lib()
     L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, -1, 0)
     _PLAN_CACHE.pop(key, None)
@@ -293,9 +293,18 @@ def _tune_wgrad(geom, has_bias, launch):
         print("sqd conv plan wgrad", geom, best, "model splits", base, flush=True)
 
 
+def _wgrad_key(geom):
+    """The library keys its weight-gradient plans by (N, Ho, Wo, C, K, R, S): two convolutions that differ only in stride / padding
+    / input size (layer2.0.conv2 at stride 2 and layer2.1.conv2 at stride 1 have the same output) share ONE plan.  The tuner and
+    the cached workspace size use the same key — a per-convolution cache went stale when the second one re-tuned the shared
+    entry to more pixel splits, and the first one's partial buffer was then too small for its own launch."""
+    N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
+    return ("w", N, Ho, Wo, C, K, R, S)
+
+
 def _wgrad_part_floats(geom):
     N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
-    key = ("w",) + tuple(geom)
+    key = _wgrad_key(geom)
     n = _PLAN_CACHE.get(key)
     if n is None:
         splits, pf = ctypes.c_int(0), ctypes.c_int64(0)
