@@ -319,3 +319,31 @@ def test_wgrad_shared_operand_kernel(variant, N, C, H, W, K, R, stride, pad, bia
         err, scale = float((a.cpu().double() - b).abs().max()), float(b.abs().max())
         assert err <= 1e-4 * scale, (name, err, scale)
     assert L.sqd_conv_wgrad_set_plan(N, Ho, Wo, 48, K, R, R, 2, 4) != 0            # 128-channel block on C = 48: refused
+
+
+def test_wgrad_plan_shared_by_output_geometry():
+    """Two convolutions with the same (N, Ho, Wo, C, K, R, S) and different strides share one library plan: tuning the second must
+    not leave the first with a stale workspace size (regression: out-of-bounds partial sums on the side-stream launch)."""
+    import ctypes
+    from sqd import lib, nnkernels
+    L = lib.lib()
+    N, C, K, R = 2, 128, 128, 3
+    gA = (N, 24, 40, C, K, R, R, 1, 1, 24, 40)          # stride 1
+    gB = (N, 48, 80, C, K, R, R, 2, 1, 24, 40)          # stride 2, same output
+    try:
+        for g in (gA, gB):
+            nnkernels._TUNED.discard(nnkernels._wgrad_key(g))
+        for g, H, W, st in ((gA, 24, 40, 1), (gB, 48, 80, 2)):
+            x = torch.randn(N, H, W, C, device="cuda")
+            dy = torch.randn(N, 24, 40, K, device="cuda")
+            dw = torch.empty(K, R, R, C, device="cuda")
+            P = lambda t: ctypes.c_void_p(t.data_ptr())
+            stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+            nnkernels._tune_wgrad(g, False, lambda part: L.sqd_conv_wgrad(P(dy), P(x), P(dw), None, P(part), *g, stream))
+            sp, pf = ctypes.c_int(0), ctypes.c_int64(0)
+            L.sqd_conv_wgrad_plan(N, 24, 40, C, K, R, R, ctypes.byref(sp), ctypes.byref(pf))
+            for g2 in (gA, gB):                           # both see the library's current plan
+                assert nnkernels._wgrad_part_floats(g2) == (pf.value, sp.value)
+    finally:
+        L.sqd_conv_wgrad_set_plan(N, 24, 40, C, K, R, R, -1, 0)
+        nnkernels._PLAN_CACHE.clear()
