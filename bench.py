@@ -189,6 +189,18 @@ def cpu_baseline(budget_s=45.0):
             "total_cpu_leg_s": round(time.time() - t_start, 1)}
 
 
+def workload_name(o):
+    """configs[1] of BASELINE.json by default; SQD_BENCH_EXTRA runs say what they changed"""
+    base = ("configs[1]: ResNet-50 + Depth_Decoder_QueryTr, KITTI 192x640, batch 12 per GPU, fp32, "
+            "2 source frames, fwd+bwd+Adam (num_features 256, model_dim 32, patch 16, Q 64, dim_out 64)")
+    if not os.environ.get("SQD_BENCH_EXTRA"):
+        return base
+    return ("NOT configs[1] (SQD_BENCH_EXTRA=%r): backbone %s, %dx%d, batch %d per GPU, %s convolution operands, frames %s, "
+            "num_features %d, model_dim %d, patch %d, Q %d, dim_out %d" %
+            (os.environ["SQD_BENCH_EXTRA"], o.backbone, o.height, o.width, o.batch_size, "bf16" if o.sqd_bf16 else "fp32",
+             list(o.frame_ids) + (["s"] if o.use_stereo else []), o.num_features, o.model_dim, o.patch_size, o.query_nums, o.dim_out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,8 +266,7 @@ def main():
         out = {"metric": "train images/sec, ResNet-50 640x192", "value": round(world * opts.batch_size / (ms * 1e-3), 2),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "configs[1]: ResNet-50 + Depth_Decoder_QueryTr, KITTI 192x640, batch 12 per GPU, fp32, "
-                                      "2 source frames, fwd+bwd+Adam (num_features 256, model_dim 32, patch 16, Q 64, dim_out 64)",
+               "config": {"workload": workload_name(opts),
                           "global_batch": world * opts.batch_size, "parallelism": "dp%d" % world,
                           "operator_backends": nnops.BACKEND},
                "final_loss": round(loss, 6), "roofline": roof, "cpu_baseline": cpu}

@@ -159,7 +159,7 @@ int sqd_smooth_bwd(const float *depth, const float *color, const float *part, in
  *           softmax over the N = h*w pixels (:18), summary = softmax(y)^T x^T (:19).
  * x [B,E,N] (the [B,E,h,w] feature map; x_nhwc = 1: its channels-last memory [B,N,E], the layout the producing
  * convolution writes — no layout copy), K [B,Q,E] queries -> y [B,Q,N] energy maps (raw dot
- * products), summary [B,Q,E], lse [B,Q,2] = (max, 1/sum) for the backward.  E in {16,32}, Q <= 128.
+ * products), summary [B,Q,E], lse [B,Q,2] = (max, 1/sum) for the backward.  E in {16,32,48,64}, Q <= 128.
  * part: workspace of sqd_sql_workspace(..).part_floats floats.  fp32 MFMA (v_mfma_f32_16x16x4_f32).  */
 int sqd_sql_workspace(int B, int Q, int E, int N, int64_t *part_floats, int64_t *gk_part_floats);
 int sqd_sql_fwd(const float *x, const float *K, float *y, float *summary, float *lse, float *part, int B, int Q,
@@ -354,7 +354,7 @@ int sqd_colsum_multi(const float *const *src, float *const *dst, const int *nrow
  * (14) multi-head self-attention of the encoder layer for short sequences.  replaces: nn.MultiheadAttention (packed in_proj,
  * batch_first = False, need_weights = False) inside the nn.TransformerEncoderLayer of reference
  * networks/depth_decoder_QTR.py:31-32 — in-projection, softmax(q k^T / sqrt(hd)), attention dropout, P v, out-projection.
- * S <= 128 tokens, E in {16,32}, head dimension E/H in {4,8}.  x [S*B,E], token (s,b) = row s*B+b; Win [3E,E], bin [3E],
+ * S <= 512 tokens, E in {16,32}, head dimension E/H in {4,8}.  x [S*B,E], token (s,b) = row s*B+b; Win [3E,E], bin [3E],
  * Wo [E,E]; mask: keep bytes [B][H][S][SP], SP = S rounded up to 4 (4-byte aligned), or NULL; dscale = 1/(1-p).
  *   fwd: ypart [H][S*B,E] per-head partials of the block's output without the out-projection bias (the consumer,
  *        sqd_addln_fwd with nparts = H and ybias = out_proj.bias, adds them); o_save [B][H][S][E/H], ml_save [B][H][S][2]

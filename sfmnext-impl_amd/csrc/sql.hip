@@ -280,14 +280,15 @@ __device__ __forceinline__ void stg32(float *__restrict__ base, unsigned byte_of
     *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
 
-template <int QT>
+// EH = ceil(E / 32) blocks of 32 features (E <= 64): t sums over both blocks, g_x and g_K are produced one block at a time
+template <int QT, int EH>
 __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict__ x, const float *__restrict__ K,
                                                         const float *__restrict__ y, const float *__restrict__ g_y,
                                                         const float *__restrict__ gS, const float *__restrict__ summary,
                                                         const float *__restrict__ lse, float *__restrict__ g_x,
                                                         float *__restrict__ gK_part, int Q, int E, int N, int nchunks, int xse,
                                                         int xsn) {
-    constexpr int QP = QT * 32, EP = 33;                          // x, g_x: element (e, n) at e * xse + n * xsn (see sql_fwd_kernel)
+    constexpr int QP = QT * 32, EP = EH * 32 + 1;                 // x, g_x: element (e, n) at e * xse + n * xsn (see sql_fwd_kernel)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Kl = lds, *Sl = Kl + QP * EP, *qc = Sl + QP * EP;      // K[q][e], gS[q][e], per-query (max, 1/sum, dot, -)
     float *tiles = qc + QP * 4;                                   // [4 waves][QP][TP]
@@ -318,11 +319,13 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
     }
     __syncthreads();
     float *tl = tiles + wave * QP * TP;
-    f32x16 accK[QT];                                              // g_K tile: row q, column e = lane & 31
+    f32x16 accK[EH][QT];                                          // g_K tile: row q, column e = 32 eh + (lane & 31)
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
+    for (int eh = 0; eh < EH; ++eh)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) accK[qt][r] = 0.f;
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) accK[eh][qt][r] = 0.f;
     const int ntiles = (N + 31) / 32;
     const bool vec_ok = (N & 3) == 0;
 
@@ -335,18 +338,22 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
         const unsigned lane_q = pv ? ((unsigned)(4 * h) * N + p) * 4u : SQL_OOB;     // row 4h of a 32-row group of y / g_y, pixel p
         const unsigned lane_gx = pv ? ((unsigned)(4 * h) * xse + (unsigned)p * xsn) * 4u : SQL_OOB;
         const unsigned xse4 = (unsigned)xse * 4u;
-        float xe[16];
-        if (xse == 1) {                                      // pixel-major: the lane's 32 features are one 128-byte run — 8 x 16-byte loads
-            const unsigned px_off = pv ? (unsigned)p * (unsigned)xsn * 4u : SQL_OOB;
+        float xe[EH][16];
 #pragma unroll
-            for (int q8 = 0; q8 < 8; ++q8) {
-                const sql_i32x4 f = __builtin_amdgcn_raw_buffer_load_b128(x_r, 4 * q8 < E ? px_off + 16u * q8 : SQL_OOB, 0, 0);
-                xe[2 * q8] = __int_as_float(h ? f.y : f.x);          // feature 4 q8 + h
-                xe[2 * q8 + 1] = __int_as_float(h ? f.w : f.z);      // feature 4 q8 + 2 + h
+        for (int eh = 0; eh < EH; ++eh) {
+            if (xse == 1) {                                  // pixel-major: 32 features of the lane are one 128-byte run — 8 x 16-byte loads
+                const unsigned px_off = pv ? (unsigned)p * (unsigned)xsn * 4u : SQL_OOB;
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) {
+                    const sql_i32x4 f = __builtin_amdgcn_raw_buffer_load_b128(x_r, eh * 32 + 4 * q8 < E ? px_off + 128u * eh + 16u * q8 : SQL_OOB, 0, 0);
+                    xe[eh][2 * q8] = __int_as_float(h ? f.y : f.x);          // feature 32 eh + 4 q8 + h
+                    xe[eh][2 * q8 + 1] = __int_as_float(h ? f.w : f.z);      // feature 32 eh + 4 q8 + 2 + h
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    xe[eh][s] = ldb32(x_r, eh * 32 + 2 * s + h < E ? lane_x + (unsigned)(eh * 32 + 2 * s) * xse4 : SQL_OOB);
             }
-        } else {
-#pragma unroll
-            for (int s = 0; s < 16; ++s) xe[s] = ldb32(x_r, 2 * s + h < E ? lane_x + (unsigned)(2 * s) * xse4 : SQL_OOB);
         }
         // every global read of the tile is issued up front (y, g_y, the float4 pieces of x for the g_K product): the first
         // product then runs under their latency instead of each phase waiting for its own loads
@@ -359,30 +366,34 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
                 yv[qt][r] = ldb32(y_r, o);
                 gv[qt][r] = ldb32(gy_r, o);
             }
-        float xv[4][4];
+        float xv[EH][4][4];
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const int px = 8 * gq + 4 * h;
-            if (vec_ok && xsn == 1) {                                // planar, N % 4 == 0: a float4 is inside a plane or beyond it
-                const sql_i32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(
-                    x_r, (i < E && p0 + px < N) ? ((unsigned)i * xse + p0 + px) * 4u : SQL_OOB, 0, 0);
-                xv[gq][0] = __int_as_float(t4.x); xv[gq][1] = __int_as_float(t4.y);
-                xv[gq][2] = __int_as_float(t4.z); xv[gq][3] = __int_as_float(t4.w);
-            } else {
+        for (int eh = 0; eh < EH; ++eh)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    xv[gq][j] = ldb32(x_r, (i < E && p0 + px + j < N) ? ((unsigned)i * xse + (unsigned)(p0 + px + j) * xsn) * 4u : SQL_OOB);
+            for (int gq = 0; gq < 4; ++gq) {
+                const int px = 8 * gq + 4 * h, ei = eh * 32 + i;
+                if (vec_ok && xsn == 1) {                            // planar, N % 4 == 0: a float4 is inside a plane or beyond it
+                    const sql_i32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(
+                        x_r, (ei < E && p0 + px < N) ? ((unsigned)ei * xse + p0 + px) * 4u : SQL_OOB, 0, 0);
+                    xv[eh][gq][0] = __int_as_float(t4.x); xv[eh][gq][1] = __int_as_float(t4.y);
+                    xv[eh][gq][2] = __int_as_float(t4.z); xv[eh][gq][3] = __int_as_float(t4.w);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        xv[eh][gq][j] = ldb32(x_r, (ei < E && p0 + px + j < N) ? ((unsigned)ei * xse + (unsigned)(p0 + px + j) * xsn) * 4u : SQL_OOB);
+                }
             }
-        }
         f32x16 acc[QT], sreg[QT];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[qt][r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
+        for (int eh = 0; eh < EH; ++eh)
 #pragma unroll
-            for (int qt = 0; qt < QT; ++qt) acc[qt] = mfma32(Sl[(qt * 32 + i) * EP + 2 * s + h], xe[s], acc[qt]);
+            for (int s = 0; s < 16; ++s)
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) acc[qt] = mfma32(Sl[(qt * 32 + i) * EP + eh * 32 + 2 * s + h], xe[eh][s], acc[qt]);
         // ---- s and gyt, element-wise; gyt also to the LDS tile (operand of the g_K product)
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt)
@@ -399,30 +410,34 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
                 tl[q * TP + i] = gyt;
             }
         // ---- g_x[e][p] = sum_q K[q][e] gyt[q][p] + gS[q][e] s[q][p]
-        f32x16 gx;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gx[r] = 0.f;
+        for (int eh = 0; eh < EH; ++eh) {
+            f32x16 gx;
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
+            for (int r = 0; r < 16; ++r) gx[r] = 0.f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = qt * 32 + acc_row(r, h);
-                gx = mfma32(Kl[q * EP + i], acc[qt][r], gx);
-                gx = mfma32(Sl[q * EP + i], sreg[qt][r], gx);
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = qt * 32 + acc_row(r, h);
+                    gx = mfma32(Kl[q * EP + eh * 32 + i], acc[qt][r], gx);
+                    gx = mfma32(Sl[q * EP + eh * 32 + i], sreg[qt][r], gx);
+                }
+            if (xse == 1) {                                  // pixel-major: registers 4g..4g+3 are 4 consecutive features -> one 16-byte store
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const int e0 = eh * 32 + 8 * g4 + 4 * h;
+                    sql_i32x4 v;
+                    v.x = __float_as_int(gx[4 * g4]); v.y = __float_as_int(gx[4 * g4 + 1]);
+                    v.z = __float_as_int(gx[4 * g4 + 2]); v.w = __float_as_int(gx[4 * g4 + 3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(v, gx_r, (pv && e0 < E) ? ((unsigned)p * (unsigned)xsn + e0) * 4u : SQL_OOB, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stb32(gx_r, eh * 32 + acc_row(r, h) < E ? lane_gx + (unsigned)(eh * 32 + (r & 3) + 8 * (r >> 2)) * xse4 : SQL_OOB,
+                          gx[r]);                                                                           // pixel >= N: dropped
             }
-        if (xse == 1) {                                      // pixel-major: registers 4g..4g+3 are 4 consecutive features -> one 16-byte store
-#pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int e0 = 8 * g4 + 4 * h;
-                sql_i32x4 v;
-                v.x = __float_as_int(gx[4 * g4]); v.y = __float_as_int(gx[4 * g4 + 1]);
-                v.z = __float_as_int(gx[4 * g4 + 2]); v.w = __float_as_int(gx[4 * g4 + 3]);
-                __builtin_amdgcn_raw_buffer_store_b128(v, gx_r, (pv && e0 < E) ? ((unsigned)p * (unsigned)xsn + e0) * 4u : SQL_OOB, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                stb32(gx_r, acc_row(r, h) < E ? lane_gx + (unsigned)((r & 3) + 8 * (r >> 2)) * xse4 : SQL_OOB, gx[r]);   // pixel >= N: dropped
         }
         // ---- g_K[q][e] += sum_p gyt[q][p] x[e][p]; k-step (gq, j): half-wave 0 takes pixel 8gq+j, half-wave 1 pixel 8gq+4+j
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -435,24 +450,30 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
                 const float4 a4 = *reinterpret_cast<const float4 *>(tl + (qt * 32 + i) * TP + px);
                 const float av[4] = {a4.x, a4.y, a4.z, a4.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) accK[qt] = mfma32(av[j], xv[gq][j], accK[qt]);
+                for (int eh = 0; eh < EH; ++eh)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accK[eh][qt] = mfma32(av[j], xv[eh][gq][j], accK[eh][qt]);
             }
         }
         __builtin_amdgcn_wave_barrier();                           // the tile is rewritten by the next iteration
     }
     // ---- workgroup merge of g_K (fixed order) and the partial of this chunk
-    __syncthreads();
     float *red = tiles;                                            // [4][QP][32]
-#pragma unroll
-    for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) red[((size_t)wave * QP + qt * 32 + acc_row(r, h)) * 32 + i] = accK[qt][r];
-    __syncthreads();
     float *po = gK_part + ((size_t)b * nchunks + chunk) * Q * E;
-    for (int idx = threadIdx.x; idx < Q * E; idx += 256) {
-        const int q = idx / E, e = idx - q * E;
-        po[idx] = ((red[((size_t)0 * QP + q) * 32 + e] + red[((size_t)1 * QP + q) * 32 + e]) + red[((size_t)2 * QP + q) * 32 + e]) +
-                  red[((size_t)3 * QP + q) * 32 + e];
+#pragma unroll
+    for (int eh = 0; eh < EH; ++eh) {
+        __syncthreads();
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[((size_t)wave * QP + qt * 32 + acc_row(r, h)) * 32 + i] = accK[eh][qt][r];
+        __syncthreads();
+        const int ew = min(32, E - eh * 32);                       // features of this block
+        for (int idx = threadIdx.x; idx < Q * ew; idx += 256) {
+            const int q = idx / ew, e = idx - q * ew;
+            po[(size_t)q * E + eh * 32 + e] = ((red[((size_t)0 * QP + q) * 32 + e] + red[((size_t)1 * QP + q) * 32 + e]) +
+                                               red[((size_t)2 * QP + q) * 32 + e]) + red[((size_t)3 * QP + q) * 32 + e];
+        }
     }
 }
 
@@ -470,7 +491,7 @@ struct Plan {
     int QT, ET, NT, steps, nchunks;
 };
 int make_plan(int Q, int E, int N, Plan *p) {
-    if (E % 16 != 0 || E > 32 || E < 16 || Q < 1 || Q > 128 || N < 1) return -1;
+    if (E % 16 != 0 || E > 64 || E < 16 || Q < 1 || Q > 128 || N < 1) return -1;
     int QT = (Q + 15) / 16;
     QT = QT <= 1 ? 1 : QT <= 2 ? 2 : QT <= 4 ? 4 : 8;
     p->QT = QT;
@@ -488,7 +509,7 @@ int make_plan(int Q, int E, int N, Plan *p) {
 
 extern "C" int sqd_sql_workspace(int B, int Q, int E, int N, int64_t *part_floats, int64_t *gk_part_floats) {
     Plan p;
-    SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql: unsupported Q=%d E=%d N=%d (E in {16, 32}, Q <= 128)", Q, E, N);
+    SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql: unsupported Q=%d E=%d N=%d (E in {16, 32, 48, 64}, Q <= 128)", Q, E, N);
     if (part_floats) *part_floats = (int64_t)B * p.nchunks * Q * (E + PART_STRIDE_EXTRA);
     if (gk_part_floats) *gk_part_floats = (int64_t)B * p.nchunks * Q * E;
     return SQD_OK;
@@ -511,7 +532,15 @@ extern "C" int sqd_sql_workspace(int B, int Q, int E, int N, int64_t *part_float
     SQL_DISPATCH(1, 2, 4, KERNEL, SHMEM, __VA_ARGS__)        \
     SQL_DISPATCH(2, 2, 4, KERNEL, SHMEM, __VA_ARGS__)        \
     SQL_DISPATCH(4, 2, 2, KERNEL, SHMEM, __VA_ARGS__)        \
-    SQL_DISPATCH(8, 2, 1, KERNEL, SHMEM, __VA_ARGS__)
+    SQL_DISPATCH(8, 2, 1, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(1, 3, 4, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(2, 3, 4, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(4, 3, 2, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(8, 3, 1, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(1, 4, 4, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(2, 4, 4, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(4, 4, 2, KERNEL, SHMEM, __VA_ARGS__)        \
+    SQL_DISPATCH(8, 4, 1, KERNEL, SHMEM, __VA_ARGS__)
 
 extern "C" int sqd_sql_fwd(const float *x, const float *K, float *y, float *summary, float *lse, float *part, int B, int Q,
                            int E, int N, int x_nhwc, void *stream) {
@@ -540,17 +569,21 @@ extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const
     SQD_CHECK_ARG((long long)N * 132 * 4 < (1ll << 32), "sqd_sql_bwd: N=%d too large for 32-bit plane offsets", N);
     (void)hipGetLastError();
     {
-        const int qt = Q <= 32 ? 1 : Q <= 64 ? 2 : 4, QP = qt * 32;
-        const size_t shmem = ((size_t)2 * QP * 33 + QP * 4 + (size_t)4 * QP * TP) * sizeof(float);
-#define SQL_BWD32(QT_)                                                                                                          \
+        const int qt = Q <= 32 ? 1 : Q <= 64 ? 2 : 4, QP = qt * 32, eh = E > 32 ? 2 : 1;
+        const size_t shmem = ((size_t)2 * QP * (eh * 32 + 1) + QP * 4 + (size_t)4 * QP * TP) * sizeof(float);
+#define SQL_BWD32(QT_, EH_)                                                                                                     \
     {                                                                                                                           \
         if (shmem > 48 * 1024)                                                                                                  \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sql_bwd32_kernel<QT_>),                                   \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sql_bwd32_kernel<QT_, EH_>),                              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                                  \
-        hipLaunchKernelGGL((sql_bwd32_kernel<QT_>), dim3(p.nchunks, B), dim3(256), shmem, (hipStream_t)stream, x, K, y, g_y,   \
+        hipLaunchKernelGGL((sql_bwd32_kernel<QT_, EH_>), dim3(p.nchunks, B), dim3(256), shmem, (hipStream_t)stream, x, K, y, g_y, \
                            g_summary, summary, lse, g_x, gk_part, Q, E, N, p.nchunks, xse, xsn);                                \
     }
-        if (qt == 1) SQL_BWD32(1) else if (qt == 2) SQL_BWD32(2) else SQL_BWD32(4)
+        if (eh == 1) {
+            if (qt == 1) SQL_BWD32(1, 1) else if (qt == 2) SQL_BWD32(2, 1) else SQL_BWD32(4, 1)
+        } else {
+            if (qt == 1) SQL_BWD32(1, 2) else if (qt == 2) SQL_BWD32(2, 2) else SQL_BWD32(4, 2)
+        }
     }
     SQD_CHECK_LAUNCH("sqd_sql_bwd");
     hipLaunchKernelGGL(sql_gk_reduce_kernel, dim3((Q * E + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, gk_part, g_K,

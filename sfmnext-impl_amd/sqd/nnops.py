@@ -193,7 +193,7 @@ def full_query_layer(x, queries):
     _device_only(x, "Self Query Layer")
     from . import ops
     if not ops.sql_supported(x.shape[1], queries.shape[1]):
-        raise RuntimeError("sqd: Self Query Layer kernel supports E in {16,32}, Q <= 128; got E=%d Q=%d" % (x.shape[1], queries.shape[1]))
+        raise RuntimeError("sqd: Self Query Layer kernel supports E in {16,32,48,64}, Q <= 128; got E=%d Q=%d" % (x.shape[1], queries.shape[1]))
     return ops.SelfQueryLayer.apply(x, queries)
 
 

@@ -446,5 +446,5 @@ def bins_supported(Q, D):
 
 
 def sql_supported(E, Q):
-    return E in (16, 32) and 1 <= Q <= 128
+    return E in (16, 32, 48, 64) and 1 <= Q <= 128
 

@@ -47,7 +47,9 @@ def test_golden_g10(golden):
 
 
 @pytest.mark.parametrize("B,E,Q,h,w", [(2, 16, 12, 12, 20), (2, 32, 64, 48, 160), (1, 32, 120, 24, 80), (2, 32, 128, 20, 64),
-                                       (1, 16, 5, 13, 17), (3, 32, 33, 7, 9), (2, 16, 24, 96, 320)])
+                                       (1, 16, 5, 13, 17), (3, 32, 33, 7, 9), (2, 16, 24, 96, 320),
+                                       # E = 48 / 64: config B' of the reference (args_res50_kitti_192x640_train.txt: model_dim 64, Q 120)
+                                       (2, 64, 120, 24, 80), (1, 48, 33, 13, 17), (2, 64, 64, 48, 160), (1, 64, 12, 7, 9), (2, 48, 128, 20, 64)])
 def test_vs_oracle(B, E, Q, h, w):
     torch.manual_seed(B * 1000 + Q)
     x = torch.randn(B, E, h, w)
