@@ -223,7 +223,19 @@ class Trainer:
             o = self.opt
             inputs[("noise", 0)] = torch.randn(o.batch_size, len(o.frame_ids) - 1, o.height, o.width)
         if self._graph is None:
-            self._capture(inputs)
+            try:
+                self._capture(inputs)
+            except Exception as e:                  # noqa: BLE001 — any capture failure: keep training, eagerly
+                # (every rank runs the same code on the same shapes, so a capture that cannot be taken fails on all of them;
+                # the eager path needs nothing the capture would have set up)
+                import sys
+                print("sqd: hipGraph capture of the training step failed (%s: %s) — continuing with eager steps" %
+                      (type(e).__name__, str(e).splitlines()[0] if str(e) else ""), file=sys.stderr, flush=True)
+                self._graph, self._graph_ok, self._capturing = None, False, False
+                if self.reducer is not None:
+                    self.reducer.hooks_enabled = True
+                torch.cuda.synchronize()
+                return self._train_step_eager(inputs)
         for k, v in inputs.items():
             self._static_in[k].copy_(v, non_blocking=True)
             inputs[k] = self._static_in[k]        # as process_batch does in eager mode: the caller's dict now holds device tensors

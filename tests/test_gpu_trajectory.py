@@ -98,3 +98,33 @@ def test_validation_between_graph_replays():
     assert all(l == l and l < 1.0 for l in losses), losses      # finite, sane
     nbt = int(tr.models["encoder"].encoder.encoder.bn1.num_batches_tracked)
     assert nbt == 7, nbt                                        # one count per training step, none from validation
+
+
+def test_failed_capture_falls_back_to_eager_steps():
+    """a step graph that cannot be captured (here: forced) must not end the run: the Trainer reports it and keeps stepping eagerly,
+    with the same losses as a run that never tried"""
+    from options import MonodepthOptions
+    from trainer import Trainer
+
+    def run(break_capture):
+        torch.manual_seed(0)
+        tr = Trainer(MonodepthOptions().parse(ARGS))
+        tr.set_train()
+        _no_dropout(tr.models.values())
+        if break_capture:
+            def boom(inputs):
+                raise RuntimeError("capture refused (test)")
+            tr._capture = boom
+        else:
+            tr._graph_ok = False
+        losses = []
+        for inputs, noise in _batches():
+            dev = {k: v.cuda() for k, v in inputs.items()}
+            dev[("noise", 0)] = noise.cuda()
+            losses.append(float(tr.train_step(dev)[1]["loss"]))
+        return tr, losses
+
+    tr, got = run(True)
+    assert tr._graph is None and not tr._graph_ok
+    _, want = run(False)
+    assert len(got) == STEPS and all(abs(a - b) <= 1e-5 * abs(b) + 1e-7 for a, b in zip(got, want)), (got, want)
