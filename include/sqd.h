@@ -410,6 +410,19 @@ int sqd_pose_head_fwd(const float *x, const float *W, const float *bias, float *
 int sqd_pose_head_bwd(const float *g, const float *g2, const float *W, const float *mean, float *dx, float *dWpart, float *dbpart,
                       int B, int P, int C, int J, float scale, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Depth evaluation (not on the training step)
+ * replaces: batch_post_process_disparity (reference evaluate_depth_config.py:50-59) and the per-image body of evaluate()
+ *           (:225-261: cv2.resize to the ground truth's size, Garg / Eigen crop, scale factor, median scaling, clamp,
+ *           compute_errors :30-47), in double precision on the device.
+ * sqd_disp_post_process: disp [2N,h,w] fp32 = outputs of N images followed by those of their flipped copies -> out [N,h,w] fp64.
+ * sqd_depth_eval: pred [h,w] fp64 (the head's depth output), gt [Hg,Wg] fp32 -> out [9] fp64: abs_rel, sq_rel, rmse, rmse_log,
+ *   a1, a2, a3, median-scaling ratio (NaN when disabled), valid pixels (0: the metrics are NaN).  eigen_crop 1: valid =
+ *   min_depth < gt < max_depth inside the crop; 0: gt > 0.  One launch per image (ground-truth sizes differ between images).    */
+int sqd_disp_post_process(const float *disp, double *out, int N, int h, int w, void *stream);
+int sqd_depth_eval(const double *pred, int h, int w, const float *gt, int Hg, int Wg, int eigen_crop, double min_depth,
+                   double max_depth, double pred_scale, int median_scaling, double *out, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -91,3 +91,20 @@ def synthetic_batch(batch_size, height, width, frame_ids=(0, -1, 1), start=0, de
     if device is not None:
         batch = {k: v.to(device) for k, v in batch.items()}
     return batch
+
+
+def synthetic_eval_set(n, height, width, device=None, density=0.05):
+    """n test frames [n,3,H,W] and their ground-truth depth maps as the KITTI eigen split stores them: [375,1242] fp32, sparse
+    (LiDAR-like: `density` of the pixels valid, the rest 0) -> (frames, [gt_0, ..., gt_{n-1}])"""
+    frames, gts = [], []
+    for i in range(n):
+        s = make_sample(10_000 + i, height, width, (0,), with_gt=True)
+        frames.append(s[("color", 0, 0)])
+        gen = torch.Generator().manual_seed(77_000 + i)
+        gt = s["depth_gt"][0].clone()
+        gt[torch.rand(gt.shape, generator=gen) > density] = 0.0
+        gts.append(gt)
+    frames = torch.stack(frames)
+    if device is not None:
+        frames, gts = frames.to(device), [g.to(device) for g in gts]
+    return frames, gts

@@ -448,3 +448,35 @@ def bins_supported(Q, D):
 def sql_supported(E, Q):
     return E in (16, 32, 48, 64) and 1 <= Q <= 128
 
+
+
+# ---------------------------------------------------------------------------------------------------
+# depth evaluation (reference evaluate_depth_config.py) — device tensors in, device tensors out
+def disp_post_process(disp):
+    """batch_post_process_disparity (evaluate_depth_config.py:50-59): disp [2N,h,w] fp32 — the outputs for N images followed by
+    the outputs for their horizontally flipped copies, as the reference batches them (:133-137) — -> [N,h,w] fp64."""
+    _req(disp)
+    assert disp.dim() == 3 and disp.shape[0] % 2 == 0
+    disp = disp.contiguous()
+    N, h, w = disp.shape[0] // 2, disp.shape[1], disp.shape[2]
+    out = torch.empty(N, h, w, device=disp.device, dtype=torch.float64)
+    _l.check(_l.lib().sqd_disp_post_process(_ptr(disp), _ptr(out), N, h, w, _stream()), "disp_post_process")
+    return out
+
+
+EVAL_METRIC_NAMES = ("abs_rel", "sq_rel", "rmse", "rmse_log", "a1", "a2", "a3")
+
+
+def depth_eval(pred, gt, eval_split="eigen", min_depth=1e-3, max_depth=80.0, pred_depth_scale_factor=1.0, median_scaling=True):
+    """the per-image body of the reference's evaluate() (evaluate_depth_config.py:225-261) on the device.
+    pred [h,w] (fp32 or fp64 depth as the head predicts it), gt [Hg,Wg] fp32 -> fp64 tensor [9]: the seven metrics of
+    compute_errors, the median-scaling ratio (NaN when disabled), the number of valid pixels."""
+    if not (pred.is_cuda and gt.is_cuda):
+        raise RuntimeError("sqd: depth_eval takes device tensors (no CPU fallback)")
+    pred = pred.to(torch.float64).contiguous()
+    gt = gt.to(torch.float32).contiguous()
+    out = torch.empty(9, device=pred.device, dtype=torch.float64)
+    _l.check(_l.lib().sqd_depth_eval(_ptr(pred), pred.shape[0], pred.shape[1], _ptr(gt), gt.shape[0], gt.shape[1],
+                                     1 if eval_split == "eigen" else 0, float(min_depth), float(max_depth),
+                                     float(pred_depth_scale_factor), 1 if median_scaling else 0, _ptr(out), _stream()), "depth_eval")
+    return out

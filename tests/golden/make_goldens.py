@@ -368,6 +368,20 @@ def g14_depth_errors(T):
     save("g14_depth_errors", gt_seed=1415, pred=pred, plain_errors=np.array([float(e) for e in errs]), metrics=np.array([float(losses[k]) for k in shim.depth_metric_names], dtype=np.float64))
 
 
+def g19_eval(T):
+    """evaluate_depth_config.py: compute_errors (:30-47) and batch_post_process_disparity (:50-59), the reference's own functions"""
+    import evaluate_depth_config as EV
+    rs = np.random.RandomState(1919)
+    l_disp = rs.uniform(0.5, 60, (3, 24, 80)).astype(np.float32)
+    r_disp = rs.uniform(0.5, 60, (3, 24, 80)).astype(np.float32)
+    post = EV.batch_post_process_disparity(l_disp, r_disp)
+    gt = rs.uniform(1.0, 80.0, 5000).astype(np.float32)
+    pred = np.clip(gt.astype(np.float64) * rs.uniform(0.6, 1.6, 5000), 1e-3, 80.0)
+    errs = np.array(EV.compute_errors(gt, pred), dtype=np.float64)
+    save("g19_eval", l_disp=l_disp, r_disp=r_disp, post=post.astype(np.float64), gt=gt, pred=pred, errors=errs,
+         consts=np.array([1e-3, 80.0, EV.STEREO_SCALE_FACTOR], dtype=np.float64))
+
+
 def build_reference_models(nets, kind):
     if kind == "res18":
         enc = nets["lite_res_encoder"].LiteResnetEncoderDecoder(model_dim=16)
@@ -479,6 +493,7 @@ def main():
         return
     g17_stereo_chain(T)
     g18_decoder_b5(T)
+    g19_eval(T)
     g1_pose(T)
     g2_g3_g4_geometry(T)
     g5_g6_ssim(T)

@@ -295,3 +295,18 @@ def test_efficientnet_b5_restatement_shapes_and_keys():
     f = small.encoder(x)
     assert [tuple(f[i].shape[1:]) for i in (4, 5, 6, 8, 11)] == [(24, 32, 48), (40, 16, 24), (64, 8, 12), (176, 4, 6), (2048, 2, 3)]
     assert small(x).shape == (1, 16, 32, 48)
+
+
+def test_g19_eval_functions(golden):
+    """oracle/eval_ref.py against the reference's compute_errors / batch_post_process_disparity (evaluate_depth_config.py:30-59)"""
+    from oracle import eval_ref as R
+    g = golden("g19_eval")
+    post = R.batch_post_process_disparity(g["l_disp"], g["r_disp"])
+    assert post.dtype == np.float64 and np.array_equal(post, g["post"])
+    errs = np.array(R.compute_errors(g["gt"], g["pred"]), dtype=np.float64)
+    assert np.array_equal(errs, g["errors"])
+    assert (R.MIN_DEPTH, R.MAX_DEPTH, R.STEREO_SCALE_FACTOR) == tuple(g["consts"])
+    # resize_linear: identity at equal size, exact at integer up-scaling of a linear ramp's interior, constant stays constant
+    a = np.random.RandomState(3).uniform(1, 5, (6, 9))
+    assert np.array_equal(R.resize_linear(a, 9, 6), a)
+    assert np.allclose(R.resize_linear(np.full((4, 5), 2.5), 13, 11), 2.5, rtol=0, atol=1e-6)
