@@ -959,6 +959,154 @@ __global__ __launch_bounds__(256) void conv_wgrad_shared_kernel(const float *__r
         }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wgrad on the bf16 matrix cores with three-term operands (the arithmetic of the bk + 1024 forward / data-gradient plans: every
+// fp32 value as the exact sum of three bf16 terms, 6 of the 9 partial products, fp32 accumulation — fp32-level accuracy at 6/16 of
+// the fp32 kernels' matrix-pipe time).  v_mfma_f32_32x32x16_bf16 wants 8 consecutive reduction elements — here: pixels — per lane,
+// while memory has the channels contiguous.  So the staging turns the tile: a wavefront item is 64 channels (one per lane) x 8
+// consecutive pixels, fetched as 8 dword loads of 256 contiguous bytes each; the lane converts its 8 values and writes them as
+// one 16-byte LDS store per term into [term][channel][pixel] (row pitch 80 bytes: conflict-free 16-byte reads and writes).  The
+// pixel arithmetic of an item (row wrap, padding, stride) is wave-uniform, i.e. scalar.  Block / wave tiling, split plan and
+// partial layout as conv_wgrad_shared_kernel.
+// ---------------------------------------------------------------------------------------------------
+template <int WK, int WC, int WTK, int WTC>
+__global__ __launch_bounds__(256) void conv_wgrad_split3_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                float *__restrict__ part, ConvGeom g, int px_per_split, int nsplits) {
+    static_assert(WK * WC == 4 && WTK >= 1 && WTK <= 2 && WTC >= 1 && WTC <= 2, "4 waves, 32 / 64 channels per wave and side");
+    constexpr int TK = WK * WTK * 32, TC = WC * WTC * 32, PS = 32, LDHW = PS + 8;     // block, pixels per slab, bf16 per LDS row
+    constexpr int ITEMS_A = TK / 16, ITEMS = (TK + TC) / 16, NI = ITEMS / 4;            // wave-items (64 channels x 8 pixels) per slab
+    static_assert(TK % 64 == 0 && TC % 64 == 0 && ITEMS % 4 == 0, "blocks of 64 channels");
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[3][TK][LDHW];
+    __shared__ __attribute__((aligned(16))) unsigned short Bh[3][TC][LDHW];
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6), wk = wave / WC, wc = wave % WC;
+    const int row = lane & 31, hh = lane >> 5;
+    const int RS = g.R * g.S, tk = g.K / TK, tc = g.C / TC;
+    const int logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    if (logical >= RS * tk * tc * nsplits) return;
+    const int tap = logical % RS, lg = logical / RS, grp = lg % (tk * tc), split = lg / (tk * tc);
+    const int k0 = (grp % tk) * TK, c0 = (grp / tk) * TC, r = tap / g.S, s = tap - r * g.S;
+    const int M = g.N * g.Ho * g.Wo;
+    const int mbeg = split * px_per_split, mend = min(M, mbeg + px_per_split);
+    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(dy, (unsigned)(g.N * g.Ho * g.Wo * g.K) * 4u);
+    const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(x, (unsigned)(g.N * g.H * g.W * g.C) * 4u);
+    int mslab = mbeg;
+    float vA[NI][8], vB[NI][8];            // two slabs in flight: a slab's loads are issued two multiply phases before it is staged
+    auto load = [&](float (&v)[NI][8]) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int it = wave + 4 * j;                              // wave-uniform
+            const bool isA = it < ITEMS_A;
+            const int idx = isA ? it : it - ITEMS_A, chalf = idx >> 2, pg = idx & 3;
+            const int m0 = mslab + 8 * pg;
+            if (isA) {
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int m = m0 + jj;
+                    v[j][jj] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        dy_rsrc, m < mend ? ((unsigned)m * g.K + k0 + chalf * 64 + lane) * 4u : 0xffffffffu, 0, 0));
+                }
+            } else {
+                int wo = m0 % g.Wo, t2 = m0 / g.Wo, ho = t2 % g.Ho, n = t2 / g.Ho;
+#pragma unroll
+                for (int jj = 0; jj < 8; ++jj) {
+                    const int hi = ho * g.stride - g.pad + r, wi = wo * g.stride - g.pad + s;
+                    const bool ok = m0 + jj < mend && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+                    v[j][jj] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(
+                        x_rsrc, ok ? ((unsigned)((n * g.H + hi) * g.W + wi) * g.C + c0 + chalf * 64 + lane) * 4u : 0xffffffffu, 0, 0));
+                    if (++wo >= g.Wo) {
+                        wo = 0;
+                        if (++ho >= g.Ho) { ho = 0; ++n; }
+                    }
+                }
+            }
+        }
+        mslab += PS;
+    };
+    auto store = [&](const float (&v)[NI][8]) {
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+            const int it = wave + 4 * j;
+            const bool isA = it < ITEMS_A;
+            const int idx = isA ? it : it - ITEMS_A, chalf = idx >> 2, pg = idx & 3;
+            const Split4 s0 = split3(make_float4(v[j][0], v[j][1], v[j][2], v[j][3]));
+            const Split4 s1 = split3(make_float4(v[j][4], v[j][5], v[j][6], v[j][7]));
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) {
+                u32x4 o;
+                o.x = s0.t[tm].x; o.y = s0.t[tm].y; o.z = s1.t[tm].x; o.w = s1.t[tm].y;
+                unsigned short *dst = isA ? &Ah[tm][chalf * 64 + lane][8 * pg] : &Bh[tm][chalf * 64 + lane][8 * pg];
+                *reinterpret_cast<u32x4 *>(dst) = o;
+            }
+        }
+    };
+    f32x16 acc[WTK][WTC];
+#pragma unroll
+    for (int i = 0; i < WTK; ++i)
+#pragma unroll
+        for (int j = 0; j < WTC; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nslab = (mend - mbeg + PS - 1) / PS;
+    if (nslab > 0) {
+        load(vA);
+        store(vA);
+    }
+    __syncthreads();
+    if (nslab > 1) load(vA);                // slab 1
+    if (nslab > 2) load(vB);                // slab 2
+    auto multiply = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < PS / 16; ++ks) {
+            u32x4 a[WTK][3], b[WTC][3];
+#pragma unroll
+            for (int i = 0; i < WTK; ++i)
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm) a[i][tm] = *reinterpret_cast<const u32x4 *>(&Ah[tm][(wk * WTK + i) * 32 + row][ks * 16 + hh * 8]);
+#pragma unroll
+            for (int j = 0; j < WTC; ++j)
+#pragma unroll
+                for (int tm = 0; tm < 3; ++tm) b[j][tm] = *reinterpret_cast<const u32x4 *>(&Bh[tm][(wc * WTC + j) * 32 + row][ks * 16 + hh * 8]);
+#pragma unroll
+            for (int i = 0; i < WTK; ++i)
+#pragma unroll
+                for (int j = 0; j < WTC; ++j) {
+                    f32x16 c = acc[i][j];                            // smallest terms first
+                    c = mfma_bf(a[i][0], b[j][2], c);
+                    c = mfma_bf(a[i][2], b[j][0], c);
+                    c = mfma_bf(a[i][1], b[j][1], c);
+                    c = mfma_bf(a[i][0], b[j][1], c);
+                    c = mfma_bf(a[i][1], b[j][0], c);
+                    acc[i][j] = mfma_bf(a[i][0], b[j][0], c);
+                }
+        }
+    };
+    for (int sl = 0; sl < nslab; sl += 2) {
+        multiply();                                       // slab sl
+        __syncthreads();
+        if (sl + 1 < nslab) store(vA);                    // slab sl + 1
+        __syncthreads();
+        if (sl + 3 < nslab) load(vA);
+        if (sl + 1 < nslab) {
+            multiply();                                   // slab sl + 1
+            __syncthreads();
+            if (sl + 2 < nslab) store(vB);                // slab sl + 2
+            __syncthreads();
+            if (sl + 4 < nslab) load(vB);
+        }
+    }
+    // C/D layout of the 32x32 MFMA: column (c) = lane & 31, row (k) = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+    float *po = part + (size_t)split * g.K * RS * g.C;
+#pragma unroll
+    for (int i = 0; i < WTK; ++i)
+#pragma unroll
+        for (int j = 0; j < WTC; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int k = k0 + (wk * WTK + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh, cc = c0 + (wc * WTC + j) * 32 + row;
+                po[((size_t)k * RS + tap) * g.C + cc] = acc[i][j][e];
+            }
+}
+
 // sum of the split-K partial tiles (+ bias, + activation): part [Z][M*Ncols] -> out [M*Ncols]
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias,
                                                           const float *__restrict__ addend, float *__restrict__ out, size_t n, int Z,
@@ -1339,6 +1487,7 @@ struct WgradPlan {
     bool direct;
     int kt, ct, tp, splits, px_per_wave;
     int shared = 0;                 // 1..4: shared-operand kernel, block 128x128 / 64x128 / 128x64 / 64x64 (filters x channels); 0: not
+    int split3 = 0;                 // with shared != 0: the three-term bf16 kernel on the same blocks (impl 3) instead of fp32 (impl 2)
     int px_per_split = 0;
 };
 static void shared_block(int variant, int &tk, int &tc) {
@@ -1365,7 +1514,8 @@ static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, i
     const int M = N * Ho * Wo;
     int m_impl = -1, m_splits = 0;
     const bool measured = wplan_lookup(N, Ho, Wo, C, K, R, S, m_impl, m_splits);
-    if (measured && (m_impl & 15) == 2) {                        // shared-operand kernel (measured plans only)
+    if (measured && ((m_impl & 15) == 2 || (m_impl & 15) == 3)) {      // shared-operand kernels (measured plans only)
+        p.split3 = (m_impl & 15) == 3;
         p.direct = false;
         p.kt = p.ct = p.tp = 1;
         p.px_per_wave = 0;
@@ -1448,7 +1598,7 @@ extern "C" int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int 
         return SQD_OK;
     }
     const int kt = (impl >> 4) & 15, ct = (impl >> 8) & 15;      // optional register-tile shape of the direct kernel: 16*kt x 16*ct
-    if ((impl & 15) == 2) {                                      // shared-operand kernel: impl 2 + 16 * variant
+    if ((impl & 15) == 2 || (impl & 15) == 3) {                  // shared-operand kernels: impl 2 (fp32) | 3 (three-term bf16) + 16 * variant
         const int variant = (impl >> 4) + 1;
         int tk, tc;
         shared_block(variant, tk, tc);
@@ -1489,7 +1639,14 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
         const dim3 grid(((K / tk) * (C / tc) * R * S * dp.splits + 7) / 8 * 8);
 #define LAUNCH_WS(WK, WC, KT, CT) \
     hipLaunchKernelGGL((conv_wgrad_shared_kernel<WK, WC, KT, CT>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_split, dp.splits)
-        if (dp.shared == 1) LAUNCH_WS(2, 2, 4, 4);
+#define LAUNCH_W3(WK, WC, WTK, WTC) \
+    hipLaunchKernelGGL((conv_wgrad_split3_kernel<WK, WC, WTK, WTC>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_split, dp.splits)
+        if (dp.split3) {
+            if (dp.shared == 1) LAUNCH_W3(2, 2, 2, 2);
+            else if (dp.shared == 2) LAUNCH_W3(1, 4, 2, 1);
+            else if (dp.shared == 3) LAUNCH_W3(4, 1, 1, 2);
+            else LAUNCH_W3(2, 2, 1, 1);
+        } else if (dp.shared == 1) LAUNCH_WS(2, 2, 4, 4);
         else if (dp.shared == 2) LAUNCH_WS(1, 4, 4, 2);
         else if (dp.shared == 3) LAUNCH_WS(4, 1, 2, 4);
         else LAUNCH_WS(2, 2, 2, 2);

@@ -261,16 +261,16 @@ def _tune_wgrad(geom, has_bias, launch):
             t = e0.elapsed_time(e1)
             if best is None or t < best[0]:
                 best = (t, impl, sp)
-    # shared-operand kernel (impl 2 + 16 * variant: blocks of 128x128 / 64x128 / 128x64 / 64x64 filters x channels staged once per
-    # workgroup in LDS): pixel splits for ~256 .. 1536 workgroups
-    for v, (tk, tc) in enumerate(((128, 128), (64, 128), (128, 64), (64, 64))):
+    # shared-operand kernels (impl 2 = fp32 MFMA, 3 = three-term bf16 operands; + 16 * variant: blocks of 128x128 / 64x128 / 128x64 /
+    # 64x64 filters x channels staged once per workgroup in LDS): pixel splits for ~256 .. 1536 workgroups
+    for base_impl, v, (tk, tc) in ((b, v, blk) for b in (2, 3) for v, blk in enumerate(((128, 128), (64, 128), (128, 64), (64, 64)))):
         if K % tk or C % tc:
             continue
         blocks = (K // tk) * (C // tc) * R * S
         tried = set()
         for target in (256, 512, 768, 1024, 1536):
             sp = max(1, (target + blocks - 1) // blocks)
-            if sp in tried or L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, 2 | (v << 4), sp) != 0:
+            if sp in tried or L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, base_impl | (v << 4), sp) != 0:
                 continue
             tried.add(sp)
             _PLAN_CACHE.pop(key, None)
@@ -286,7 +286,7 @@ def _tune_wgrad(geom, has_bias, launch):
             e1.synchronize()
             t = e0.elapsed_time(e1)
             if best is None or t < best[0]:
-                best = (t, 2 | (v << 4), sp)
+                best = (t, base_impl | (v << 4), sp)
     L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, best[1], best[2])
     _PLAN_CACHE.pop(key, None)
     if os.environ.get("SQD_TUNE_LOG"):

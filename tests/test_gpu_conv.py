@@ -288,9 +288,11 @@ def test_conv_bf16_operand_mode(N, C, H, W, K, R, stride, pad):
 @pytest.mark.parametrize("variant,N,C,H,W,K,R,stride,pad,bias,splits", [
     (0, 2, 128, 24, 40, 256, 3, 1, 1, False, 5), (0, 3, 256, 13, 21, 128, 1, 1, 0, True, 3), (1, 2, 128, 24, 40, 64, 3, 2, 1, False, 4),
     (2, 2, 64, 24, 40, 128, 3, 1, 1, True, 7), (3, 2, 64, 23, 37, 64, 5, 2, 2, False, 2), (3, 1, 192, 9, 11, 64, 3, 1, 1, False, 64)])
-def test_wgrad_shared_operand_kernel(variant, N, C, H, W, K, R, stride, pad, bias, splits):
-    """the shared-operand weight-gradient kernel (impl 2 + 16 * variant: dy / x rows of 32 pixels staged once per workgroup, four
-    register tiles of one block) against float64 — ragged pixel ranges, strides, padding, more splits than pixels allow."""
+@pytest.mark.parametrize("impl", [2, 3])
+def test_wgrad_shared_operand_kernel(impl, variant, N, C, H, W, K, R, stride, pad, bias, splits):
+    """the shared-operand weight-gradient kernels (impl 2: fp32 MFMA, dy / x rows of 32 pixels staged once per workgroup; impl 3: the
+    three-term bf16 kernel on the same blocks; + 16 * variant) against float64 — ragged pixel ranges, strides, padding, more
+    splits than pixels allow."""
     from sqd import lib, nnkernels
     L = lib.lib()
     torch.manual_seed(variant + K)
@@ -303,7 +305,7 @@ def test_wgrad_shared_operand_kernel(variant, N, C, H, W, K, R, stride, pad, bia
     (yr * wgt.double()).sum().backward()
     Ho, Wo = yr.shape[2:]
     try:
-        assert L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, R, 2 | (variant << 4), splits) == 0
+        assert L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, R, impl | (variant << 4), splits) == 0
         nnkernels._PLAN_CACHE.clear()
         conv_g = nn.Conv2d(C, K, R, stride, pad, bias=bias).cuda()
         conv_g.load_state_dict(conv.state_dict())
@@ -318,7 +320,7 @@ def test_wgrad_shared_operand_kernel(variant, N, C, H, W, K, R, stride, pad, bia
     for name, a, b in pairs:
         err, scale = float((a.cpu().double() - b).abs().max()), float(b.abs().max())
         assert err <= 1e-4 * scale, (name, err, scale)
-    assert L.sqd_conv_wgrad_set_plan(N, Ho, Wo, 48, K, R, R, 2, 4) != 0            # 128-channel block on C = 48: refused
+    assert L.sqd_conv_wgrad_set_plan(N, Ho, Wo, 48, K, R, R, impl, 4) != 0         # 128-channel block on C = 48: refused
 
 
 def test_wgrad_plan_shared_by_output_geometry():
