@@ -425,6 +425,25 @@ int sqd_disp_post_process(const float *disp, double *out, int N, int h, int w, v
 int sqd_depth_eval(const double *pred, int h, int w, const float *gt, int Hg, int Wg, int eigen_crop, double min_depth,
                    double max_depth, double pred_scale, int median_scaling, double *out, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Device-side input pipeline (not on the training step proper)
+ * replaces: MonoDataset.__getitem__ / preprocess per frame (reference datasets/mono_dataset.py:90-201) — PIL's
+ *           Image.resize(..., ANTIALIAS) (:57,73-78), the left-right flip (:163), torchvision's ColorJitter on PIL images
+ *           (:64-71,179-183) and ToTensor (:107-108) — byte-exact with Pillow's C arithmetic (Resample.c, Blend.c, Convert.c).
+ * Frames are [n,H,W,3] bytes (HWC, as decoded).  Resize = sqd_resample_h_u8 then sqd_resample_v_u8 with the caller's
+ * coefficient tables (Pillow's precompute_coeffs + normalize_coeffs_8bpc for the Lanczos filter: bounds [out,2] int32 = first
+ * source index and tap count, coef [out,ksize] int32 in 22-bit fixed point).  ColorJitter = up to four sqd_color_jitter_step_u8
+ * launches (op[f]: 0 brightness, 1 contrast, 2 saturation, 3 hue, other: copy), the contrast step after sqd_luma_sum_u8 on its
+ * input.  sqd_u8_to_chw_f32: [n,H,W,3] bytes -> [n,3,H,W] float = v / 255.                                                  */
+int sqd_resample_h_u8(const unsigned char *in, unsigned char *out, const int *bounds, const int *coef, int ksize, int n, int H0, int W0,
+                      int W, const unsigned char *flip, void *stream);
+int sqd_resample_v_u8(const unsigned char *in, unsigned char *out, const int *bounds, const int *coef, int ksize, int n, int H0, int H,
+                      int W, void *stream);
+int sqd_luma_sum_u8(const unsigned char *img, unsigned long long *sums, int n, int HW, void *stream);
+int sqd_color_jitter_step_u8(const unsigned char *in, unsigned char *out, const int *op, const float *factor, const int *hshift,
+                             const unsigned long long *lsum, int n, int HW, void *stream);
+int sqd_u8_to_chw_f32(const unsigned char *in, float *out, int n, int HW, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -157,6 +157,11 @@ _SIGNATURES = {
     "sqd_conv_fwd_stats_rows": (_I, [_I] * 11),
     "sqd_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 12 + [_P]),
     "sqd_conv_dgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
+    "sqd_resample_h_u8": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
+    "sqd_resample_v_u8": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sqd_luma_sum_u8": (_I, [_P, _P, _I, _I, _P]),
+    "sqd_color_jitter_step_u8": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "sqd_u8_to_chw_f32": (_I, [_P, _P, _I, _I, _P]),
     "sqd_disp_post_process": (_I, [_P, _P, _I, _I, _I, _P]),
     "sqd_depth_eval": (_I, [_P, _I, _I, _P, _I, _I, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P, _P]),
     "sqd_pose_head_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _F, _P]),
