@@ -444,6 +444,29 @@ int sqd_color_jitter_step_u8(const unsigned char *in, unsigned char *out, const 
                              const unsigned long long *lsum, int n, int HW, void *stream);
 int sqd_u8_to_chw_f32(const unsigned char *in, float *out, int n, int HW, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * ConvNeXt-L trunk + U-Net decoder operators (config E; reference networks/Unet.py:9-312 builds the encoder with
+ * timm.create_model('convnext_large', features_only=True)).  Channels-last activations as rows [M = N*H*W, C], C % 4 == 0.
+ * sqd_ln_rows_*: LayerNorm over the channels of every row (timm LayerNorm2d / the block's nn.LayerNorm, eps 1e-6); pre_bias [C] or
+ *   NULL is added to x first (the bias of the depthwise convolution in front of it).  C <= 2048.  mean, rstd [M] are saved for the
+ *   backward, whose part [sqd_ln_rows_nblk(M)][3][C] holds per-block column sums of dy*xhat, dy, dx (-> dgamma, dbeta, d pre_bias).
+ * sqd_gelu_*: exact (erf) GELU.  sqd_scale_residual_*: out = res + gamma[c] * z (layer scale + shortcut); backward dz = gamma * dy
+ *   and part [sqd_scale_residual_nblk(M)][C] = per-block column sums of dy * z (-> dgamma).
+ * sqd_upsample2x_*: F.interpolate(scale_factor=2, mode='bilinear') (align_corners False) of Unet.py:250, [N,H,W,C] -> [N,2H,2W,C].
+ * The 7x7 depthwise convolution of the block is sqd_dw_conv_* (k in {3,5,7}).                                              */
+int sqd_ln_rows_fwd(const float *x, const float *pre_bias, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                    int M, int C, float eps, void *stream);
+int sqd_ln_rows_nblk(int M);
+int sqd_ln_rows_bwd(const float *dy, const float *x, const float *pre_bias, const float *gamma, const float *mean, const float *rstd,
+                    float *dx, float *part, int M, int C, void *stream);
+int sqd_gelu_fwd(const float *x, float *y, int64_t n, void *stream);
+int sqd_gelu_bwd(const float *x, const float *dy, float *dx, int64_t n, void *stream);
+int sqd_scale_residual_fwd(const float *res, const float *z, const float *gamma, float *out, int M, int C, void *stream);
+int sqd_scale_residual_nblk(int M);
+int sqd_scale_residual_bwd(const float *dy, const float *z, const float *gamma, float *dz, float *part, int M, int C, void *stream);
+int sqd_upsample2x_fwd(const float *x, float *y, int N, int H, int W, int C, void *stream);
+int sqd_upsample2x_bwd(const float *dy, float *dx, int N, int H, int W, int C, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

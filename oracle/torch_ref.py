@@ -520,6 +520,122 @@ class BaseEncoder(nn.Module):
         return self.decoder((f[4], f[5], f[6], f[8], f[11]))                              # base_encoder.py:41
 
 
+# ---------------------------------------------------------------------------------------------------
+# ConvNeXt-L trunk (timm 'convnext_large', features_only — third-party, not in /root/reference: restated from the public
+# definition, parity unpinned) and the reference's U-Net decoder (networks/Unet.py:211-312, pinned by golden G20)
+class _CNBlock(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        self.conv_dw = nn.Conv2d(dim, dim, 7, padding=3, groups=dim)
+        self.norm = nn.LayerNorm(dim, eps=1e-6)
+        self.mlp = nn.Module()
+        self.mlp.fc1, self.mlp.fc2 = nn.Linear(dim, 4 * dim), nn.Linear(4 * dim, dim)
+        self.gamma = nn.Parameter(1e-6 * torch.ones(dim))
+
+    def forward(self, x):
+        z = self.conv_dw(x).permute(0, 2, 3, 1)
+        z = self.mlp.fc2(F.gelu(self.mlp.fc1(self.norm(z)))).permute(0, 3, 1, 2)
+        return x + z * self.gamma.reshape(1, -1, 1, 1)
+
+
+def _ln2d(x, norm):
+    return norm(x.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+
+
+class _CNDown(nn.Sequential):
+    def __init__(self, cin, cout):
+        super().__init__(nn.LayerNorm(cin, eps=1e-6), nn.Conv2d(cin, cout, 2, 2))
+
+    def forward(self, x):
+        return self[1](_ln2d(x, self[0]))
+
+
+class _CNStage(nn.Module):
+    def __init__(self, cin, cout, depth, first):
+        super().__init__()
+        self.downsample = nn.Identity() if first else _CNDown(cin, cout)
+        self.blocks = nn.Sequential(*[_CNBlock(cout) for _ in range(depth)])
+
+    def forward(self, x):
+        return self.blocks(self.downsample(x))
+
+
+class ConvNeXtFeatures(nn.Module):
+    def __init__(self, in_chans=3, depths=(3, 3, 27, 3), dims=(192, 384, 768, 1536)):
+        super().__init__()
+        self.stem_0, self.stem_1 = nn.Conv2d(in_chans, dims[0], 4, 4), nn.LayerNorm(dims[0], eps=1e-6)
+        for i in range(4):
+            setattr(self, "stages_%d" % i, _CNStage(dims[i - 1] if i else dims[0], dims[i], depths[i], i == 0))
+        self.num_chs = list(dims)
+
+    def forward(self, x):
+        x = _ln2d(self.stem_0(x), self.stem_1)
+        feats = []
+        for i in range(4):
+            x = getattr(self, "stages_%d" % i)(x)
+            feats.append(x)
+        return feats
+
+
+class _UConvBnAct(nn.Module):
+    """Unet.py:211-226"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv, self.bn = nn.Conv2d(cin, cout, 3, 1, 1, bias=False), nn.BatchNorm2d(cout)
+
+    def forward(self, x):
+        return F.relu(self.bn(self.conv(x)))
+
+
+class _UDecoderBlock(nn.Module):
+    """Unet.py:229-256"""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1, self.conv2 = _UConvBnAct(cin, cout), _UConvBnAct(cout, cout)
+
+    def forward(self, x, skip=None):
+        if skip is not None:
+            x = F.interpolate(x, size=[skip.size(2), skip.size(3)], mode="bilinear", align_corners=True)
+            x = torch.cat([x, skip], dim=1)
+        else:
+            x = F.interpolate(x, scale_factor=2.0, mode="bilinear")
+        return self.conv2(self.conv1(x))
+
+
+class UnetDecoder(nn.Module):
+    """Unet.py:258-312, center=False"""
+
+    def __init__(self, encoder_channels, decoder_channels, final_channels):
+        super().__init__()
+        ins = [i + s for i, s in zip([encoder_channels[0]] + list(decoder_channels[:-1]), list(encoder_channels[1:]) + [0])]
+        if len(ins) != len(decoder_channels):
+            ins.append(ins[-1] // 2)
+        self.blocks = nn.ModuleList([_UDecoderBlock(i, o) for i, o in zip(ins, decoder_channels)])
+        self.final_conv = nn.Conv2d(decoder_channels[-1], final_channels, 1)
+
+    def forward(self, feats):
+        x, skips = feats[0], feats[1:]
+        for i, b in enumerate(self.blocks):
+            x = b(x, skips[i] if i < len(skips) else None)
+        return self.final_conv(x)
+
+
+class Unet(nn.Module):
+    """Unet.py:82-148 with the convnext_large backbone"""
+
+    def __init__(self, in_channels=3, num_classes=5, decoder_channels=(1024, 512, 256, 128), depths=(3, 3, 27, 3), dims=(192, 384, 768, 1536)):
+        super().__init__()
+        self.encoder = ConvNeXtFeatures(in_channels, depths, dims)
+        self.decoder = UnetDecoder(list(dims)[::-1], tuple(decoder_channels), num_classes)
+
+    def forward(self, x):
+        feats = self.encoder(x)
+        feats.reverse()
+        return self.decoder(feats)
+
+
 class _BasicBlock(nn.Module):
     expansion = 1
 

@@ -12,7 +12,7 @@ using namespace sqd;
 struct DwGeom {
     int N, H, W, C, k, stride, pad_t, pad_l, Ho, Wo;
 };
-constexpr int DW_MAXK = 5;
+constexpr int DW_MAXK = 7;
 
 // ---------------------------------------------------------------------------------------------------
 // depthwise convolution.  w: [k*k][C] (tap-major: sqd_dw_weight_to_taps), y[n,ho,wo,c] = sum_{r,s} x[n,ho*st+r-pt,wo*st+s-pl,c] w[r*k+s][c]
@@ -280,9 +280,9 @@ __global__ __launch_bounds__(256) void se_scale_kernel(const float *__restrict__
 }
 
 int dw_check(const char *who, const DwGeom &g) {
-    SQD_CHECK_ARG(g.N > 0 && g.H > 0 && g.W > 0 && g.C >= 4 && g.C % 4 == 0 && (g.k == 3 || g.k == 5) && (g.stride == 1 || g.stride == 2) &&
+    SQD_CHECK_ARG(g.N > 0 && g.H > 0 && g.W > 0 && g.C >= 4 && g.C % 4 == 0 && (g.k == 3 || g.k == 5 || g.k == 7) && (g.stride == 1 || g.stride == 2) &&
                       g.pad_t >= 0 && g.pad_l >= 0 && g.Ho > 0 && g.Wo > 0,
-                  "%s: unsupported depthwise geometry (C %% 4 == 0, k in {3,5}, stride in {1,2})", who);
+                  "%s: unsupported depthwise geometry (C %% 4 == 0, k in {3,5,7}, stride in {1,2})", who);
     SQD_CHECK_ARG((long long)g.N * g.H * g.W * g.C < (1ll << 31) && (long long)g.N * g.Ho * g.Wo * g.C < (1ll << 31), "%s: tensor too large", who);
     return SQD_OK;
 }
@@ -341,8 +341,10 @@ extern "C" int sqd_dw_conv_wgrad(const float *dy, const float *x, float *part, i
     hipStream_t st = (hipStream_t)stream;
     if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<3, 1>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
     else if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, 2>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
-    else if (stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<5, 1>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
-    else hipLaunchKernelGGL((dw_wgrad_kernel<5, 2>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
+    else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<5, 1>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
+    else if (k == 5) hipLaunchKernelGGL((dw_wgrad_kernel<5, 2>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
+    else if (stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<7, 1>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
+    else hipLaunchKernelGGL((dw_wgrad_kernel<7, 2>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
     SQD_CHECK_LAUNCH("sqd_dw_conv_wgrad");
     return SQD_OK;
 }

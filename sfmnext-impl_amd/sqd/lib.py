@@ -157,6 +157,16 @@ _SIGNATURES = {
     "sqd_conv_fwd_stats_rows": (_I, [_I] * 11),
     "sqd_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 12 + [_P]),
     "sqd_conv_dgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
+    "sqd_ln_rows_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "sqd_ln_rows_nblk": (_I, [_I]),
+    "sqd_ln_rows_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
+    "sqd_gelu_fwd": (_I, [_P, _P, ctypes.c_int64, _P]),
+    "sqd_gelu_bwd": (_I, [_P, _P, _P, ctypes.c_int64, _P]),
+    "sqd_scale_residual_fwd": (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    "sqd_scale_residual_nblk": (_I, [_I]),
+    "sqd_scale_residual_bwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _P]),
+    "sqd_upsample2x_fwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    "sqd_upsample2x_bwd": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sqd_resample_h_u8": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "sqd_resample_v_u8": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_luma_sum_u8": (_I, [_P, _P, _I, _I, _P]),

@@ -321,7 +321,7 @@ def tf_same_pad(size, k, stride):
 
 
 class DepthwiseConv(torch.autograd.Function):
-    """Depthwise k x k convolution (groups == channels), k in {3, 5}, stride in {1, 2}, channels-last.
+    """Depthwise k x k convolution (groups == channels), k in {3, 5, 7}, stride in {1, 2}, channels-last.
     forward(x [N,C,H,W], weight [C,1,k,k], stride, pad) — pad: an int (symmetric) or "same" (TensorFlow SAME, asymmetric)."""
 
     @staticmethod
@@ -363,6 +363,113 @@ class DepthwiseConv(torch.autograd.Function):
             dw = torch.empty(C, 1, k, k, device=dy.device, dtype=torch.float32)
             _l.check(L.sqd_dw_weight_layout(_ptr(dwt), _ptr(dw), C, k, 0, _stream()), "dw_weight_layout")
         return dx, dw, None, None
+
+
+class LayerNormRows(torch.autograd.Function):
+    """LayerNorm over the channels of every pixel of a channels-last map (timm LayerNorm2d; the nn.LayerNorm of a ConvNeXt block
+    between its permutes), eps as given; `pre_bias` [C] or None is added to x first (the depthwise convolution's bias).
+    forward(x [N,C,H,W] channels-last, pre_bias, gamma [C], beta [C], eps) -> [N,C,H,W] channels-last"""
+
+    @staticmethod
+    def forward(ctx, x, pre_bias, gamma, beta, eps):
+        _require(x, "LayerNormRows input")
+        x = _cl(x)
+        N, C, H, W = x.shape
+        M = N * H * W
+        y = torch.empty_like(x)
+        mean, rstd = torch.empty(M, device=x.device, dtype=torch.float32), torch.empty(M, device=x.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_ln_rows_fwd(_ptr(x), _ptr(pre_bias), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), M, C, float(eps),
+                                          _stream()), "ln_rows_fwd")
+        ctx.save_for_backward(x, pre_bias, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pre_bias, gamma, mean, rstd = ctx.saved_tensors
+        N, C, H, W = x.shape
+        M = N * H * W
+        dy = _cl(dy)
+        L = _l.lib()
+        dx = torch.empty_like(x)
+        part = torch.empty(L.sqd_ln_rows_nblk(M), 3 * C, device=x.device, dtype=torch.float32)
+        _l.check(L.sqd_ln_rows_bwd(_ptr(dy), _ptr(x), _ptr(pre_bias), _ptr(gamma), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(part), M, C, _stream()),
+                 "ln_rows_bwd")
+        sums = torch.empty(3 * C, device=x.device, dtype=torch.float32)
+        _colsum_multi([(part, sums, 0)])
+        return dx, (sums[2 * C:] if pre_bias is not None else None), sums[:C], sums[C:2 * C], None
+
+
+class Gelu(torch.autograd.Function):
+    """exact (erf) GELU, element-wise; forward(x) -> gelu(x)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require(x, "Gelu input")
+        if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
+            x = x.contiguous()
+        y = torch.empty_like(x)
+        _l.check(_l.lib().sqd_gelu_fwd(_ptr(x), _ptr(y), x.numel(), _stream()), "gelu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, = ctx.saved_tensors
+        dy = dy.contiguous(memory_format=torch.channels_last) if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) else dy.contiguous()
+        dx = torch.empty_like(x)
+        _l.check(_l.lib().sqd_gelu_bwd(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _stream()), "gelu_bwd")
+        return dx
+
+
+class ScaleResidual(torch.autograd.Function):
+    """shortcut + gamma[c] * z: the layer scale and residual add that close a ConvNeXt block.
+    forward(res [N,C,H,W], z [N,C,H,W], gamma [C]) (channels-last)"""
+
+    @staticmethod
+    def forward(ctx, res, z, gamma):
+        _require(z, "ScaleResidual input")
+        res, z = _cl(res), _cl(z)
+        N, C, H, W = z.shape
+        out = torch.empty_like(z)
+        _l.check(_l.lib().sqd_scale_residual_fwd(_ptr(res), _ptr(z), _ptr(gamma), _ptr(out), N * H * W, C, _stream()), "scale_residual_fwd")
+        ctx.save_for_backward(z, gamma)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        z, gamma = ctx.saved_tensors
+        N, C, H, W = z.shape
+        M = N * H * W
+        dy = _cl(dy)
+        L = _l.lib()
+        dz = torch.empty_like(z)
+        part = torch.empty(L.sqd_scale_residual_nblk(M), C, device=z.device, dtype=torch.float32)
+        _l.check(L.sqd_scale_residual_bwd(_ptr(dy), _ptr(z), _ptr(gamma), _ptr(dz), _ptr(part), M, C, _stream()), "scale_residual_bwd")
+        dgamma = torch.empty(C, device=z.device, dtype=torch.float32)
+        _colsum_multi([(part, dgamma, 0)])
+        return dy, dz, dgamma
+
+
+class Upsample2x(torch.autograd.Function):
+    """F.interpolate(x, scale_factor=2, mode='bilinear') (align_corners False) on a channels-last map (reference Unet.py:250)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        _require(x, "Upsample2x input")
+        x = _cl(x)
+        N, C, H, W = x.shape
+        y = torch.empty((N, C, 2 * H, 2 * W), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _l.check(_l.lib().sqd_upsample2x_fwd(_ptr(x), _ptr(y), N, H, W, C, _stream()), "upsample2x_fwd")
+        ctx.shape = (N, C, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        N, C, H, W = ctx.shape
+        dy = _cl(dy)
+        dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
+        _l.check(_l.lib().sqd_upsample2x_bwd(_ptr(dy), _ptr(dx), N, H, W, C, _stream()), "upsample2x_bwd")
+        return dx
 
 
 class SqueezeExcite(torch.autograd.Function):

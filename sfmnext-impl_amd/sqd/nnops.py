@@ -130,6 +130,63 @@ def dw_conv_bn_act(x, conv, bn, act, stride):
     return nnkernels.batch_norm_act(y, bn, act)
 
 
+def layer_norm_channels(x, norm, pre_bias=None):
+    """LayerNorm over the channel axis of a [N,C,H,W] map (timm's LayerNorm2d, or a ConvNeXt block's nn.LayerNorm applied between
+    its permutes); `pre_bias` [C] is added first (the bias of the depthwise convolution in front)."""
+    _device_only(x, "layer_norm_channels")
+    from . import nnkernels
+    return nnkernels.LayerNormRows.apply(x, pre_bias, norm.weight, norm.bias, norm.eps)
+
+
+def gelu(x):
+    _device_only(x, "gelu")
+    from . import nnkernels
+    return nnkernels.Gelu.apply(x)
+
+
+def scale_residual(shortcut, z, gamma):
+    """shortcut + gamma[c] * z (layer scale + residual of a ConvNeXt block)"""
+    _device_only(z, "scale_residual")
+    from . import nnkernels
+    return nnkernels.ScaleResidual.apply(shortcut, z, gamma)
+
+
+def upsample2x(x):
+    """F.interpolate(x, scale_factor=2, mode='bilinear')"""
+    _device_only(x, "upsample2x")
+    from . import nnkernels
+    return nnkernels.Upsample2x.apply(x)
+
+
+def linear_channels(x, lin, act=None):
+    """nn.Linear applied to the channel axis of a [N,C,H,W] map (what a ConvNeXt block does between its permutes) = a 1x1 convolution"""
+    _device_only(x, "linear_channels")
+    from . import nnkernels
+    K, C = lin.weight.shape
+    return nnkernels.Conv2d.apply(x, lin.weight.view(K, C, 1, 1), lin.bias, 1, 0, act, False, None, None)
+
+
+def dw_conv(x, conv):
+    """depthwise convolution with symmetric padding, WITHOUT its bias (the caller folds conv.bias into the LayerNorm that follows)"""
+    _device_only(x, "depthwise convolution")
+    from . import nnkernels
+    return nnkernels.DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
+
+
+def patchify_conv(x, conv, s):
+    """a k = stride = s convolution (ConvNeXt's 4x4/4 stem on 3 channels, its 2x2/2 down-sampling) = a 1x1 convolution on the
+    space-to-depth(s) image: [N,C,H,W] -> [N, s*s*C, H/s, W/s] rows ordered (dy, dx, c), filter regrouped the same way.  The 3-channel
+    stem's 48 input features are a multiple of 4, so it runs on the implicit-GEMM kernels too."""
+    _device_only(x, "patchify_conv")
+    N, C, H, W = x.shape
+    K = conv.out_channels
+    xs = x.reshape(N, C, H // s, s, W // s, s).permute(0, 3, 5, 1, 2, 4).reshape(N, s * s * C, H // s, W // s)
+    w = conv.weight.permute(0, 2, 3, 1).reshape(K, s * s * C, 1, 1)
+    from . import nnkernels
+    return nnkernels.Conv2d.apply(xs.contiguous(memory_format=torch.channels_last), w.contiguous(memory_format=torch.channels_last),
+                                  conv.bias, 1, 0, None, False, None, None)
+
+
 def squeeze_excite(x, conv_reduce, conv_expand):
     """x * sigmoid(expand(swish(reduce(mean_hw(x))))) — the squeeze-and-excite gate of the EfficientNet blocks."""
     _device_only(x, "squeeze-and-excite")

@@ -382,6 +382,28 @@ def g19_eval(T):
          consts=np.array([1e-3, 80.0, EV.STEREO_SCALE_FACTOR], dtype=np.float64))
 
 
+def g20_unet_decoder(T):
+    """the reference's own UnetDecoder (networks/Unet.py:258-312) on seeded feature maps: output + gradients"""
+    import importlib
+    U = importlib.import_module("networks.Unet")
+    torch.manual_seed(2020)
+    enc_ch, dec_ch = [48, 24, 16, 8], (32, 24, 16, 8)
+    dec = U.UnetDecoder(encoder_channels=enc_ch, decoder_channels=dec_ch, final_channels=4, norm_layer=torch.nn.BatchNorm2d, center=False)
+    fill_params(dec, 2021)
+    dec.train()
+    rs = np.random.RandomState(2022)
+    sizes = [(3, 5), (7, 11), (14, 22), (28, 44)]            # head first; skips need not be exact doublings (interpolate to the skip's size)
+    feats = [(0.5 * rs.standard_normal((2, c, h, w))).astype(np.float32) for c, (h, w) in zip(enc_ch, sizes)]      # (batch 2: BatchNorm statistics)
+    fr = [tt(f).clone().requires_grad_(True) for f in feats]
+    out = dec(fr)
+    w = tt(np.random.RandomState(2023).standard_normal(tuple(out.shape)).astype(np.float32))
+    (out * w).sum().backward()
+    save("g20_unet_decoder", out=out.detach().numpy(), enc_ch=np.array(enc_ch), dec_ch=np.array(dec_ch), seeds=np.array([2021, 2022, 2023]),
+         grad_feat0=fr[0].grad.numpy(), grad_feat3=fr[3].grad.numpy(),
+         grad_final_w=dec.final_conv.weight.grad.numpy(), grad_b0c1=dec.blocks[0].conv1.conv.weight.grad.numpy(),
+         keys=np.array(sorted(dec.state_dict().keys())))
+
+
 def build_reference_models(nets, kind):
     if kind == "res18":
         enc = nets["lite_res_encoder"].LiteResnetEncoderDecoder(model_dim=16)
@@ -494,6 +516,7 @@ def main():
     g17_stereo_chain(T)
     g18_decoder_b5(T)
     g19_eval(T)
+    g20_unet_decoder(T)
     g1_pose(T)
     g2_g3_g4_geometry(T)
     g5_g6_ssim(T)

@@ -76,8 +76,39 @@ def bins_head(energy_maps, conv1x1, y, min_val, max_val, raw_linear=False):
     return torch.sum(out * centers.view(centers.shape[0], -1, 1, 1), dim=1, keepdim=True)
 
 
+def layer_norm_channels(x, norm, pre_bias=None):
+    if pre_bias is not None:
+        x = x + pre_bias.view(1, -1, 1, 1)
+    return F.layer_norm(x.permute(0, 2, 3, 1), (x.shape[1],), norm.weight, norm.bias, norm.eps).permute(0, 3, 1, 2)
+
+
+def gelu(x):
+    return F.gelu(x)
+
+
+def scale_residual(shortcut, z, gamma):
+    return shortcut + z * gamma.view(1, -1, 1, 1)
+
+
+def upsample2x(x):
+    return F.interpolate(x, scale_factor=2.0, mode="bilinear")
+
+
+def dw_conv(x, conv):
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, 1, conv.groups)
+
+
+def linear_channels(x, lin, act=None):
+    return F.linear(x.permute(0, 2, 3, 1), lin.weight, lin.bias).permute(0, 3, 1, 2)
+
+
+def patchify_conv(x, conv, s):
+    return F.conv2d(x, conv.weight, conv.bias, s)
+
+
 NAMES = ("_conv", "conv2d", "conv_bn_act", "pose_head", "maxpool3x3s2", "upsample_concat", "linear", "transformer_encoder",
-         "full_query_layer", "bins_head")
+         "full_query_layer", "bins_head", "layer_norm_channels", "gelu", "scale_residual", "upsample2x", "dw_conv", "linear_channels",
+         "patchify_conv")
 
 
 @contextlib.contextmanager

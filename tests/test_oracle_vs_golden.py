@@ -310,3 +310,29 @@ def test_g19_eval_functions(golden):
     a = np.random.RandomState(3).uniform(1, 5, (6, 9))
     assert np.array_equal(R.resize_linear(a, 9, 6), a)
     assert np.allclose(R.resize_linear(np.full((4, 5), 2.5), 13, 11), 2.5, rtol=0, atol=1e-6)
+
+
+def _g20_inputs(g):
+    rs = np.random.RandomState(int(g["seeds"][1]))
+    sizes = [(3, 5), (7, 11), (14, 22), (28, 44)]
+    feats = [(0.5 * rs.standard_normal((2, int(c), h, w))).astype(np.float32) for c, (h, w) in zip(g["enc_ch"], sizes)]
+    w = np.random.RandomState(int(g["seeds"][2])).standard_normal(g["out"].shape).astype(np.float32)
+    return feats, w
+
+
+def test_g20_unet_decoder(golden):
+    """oracle UnetDecoder against the reference's own (networks/Unet.py:258-312): same state-dict keys, output and gradients"""
+    g = golden("g20_unet_decoder")
+    dec = O.UnetDecoder([int(c) for c in g["enc_ch"]], tuple(int(c) for c in g["dec_ch"]), 4)
+    assert sorted(dec.state_dict().keys()) == list(g["keys"])
+    fill_params(dec, int(g["seeds"][0]))
+    dec.train()
+    feats, w = _g20_inputs(g)
+    fr = [tt(f).clone().requires_grad_(True) for f in feats]
+    out = dec(fr)
+    (out * tt(w)).sum().backward()
+    close(out, g["out"], atol=1e-5)
+    close(fr[0].grad, g["grad_feat0"], atol=1e-5)
+    close(fr[3].grad, g["grad_feat3"], atol=1e-5)
+    close(dec.final_conv.weight.grad, g["grad_final_w"], atol=1e-4)
+    close(dec.blocks[0].conv1.conv.weight.grad, g["grad_b0c1"], atol=1e-4)
