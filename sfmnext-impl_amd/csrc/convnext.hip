@@ -164,18 +164,23 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(const float *__rest
         }
         return;
     }
-    // backward: a = dy.  Thread t owns float4 columns q = t, t + 256, ... of the block's rows
+    // backward: a = dy.  Wave w takes rows r0 + w, r0 + w + 4, ... of the block, lane l the float4 columns l, l + 64, ...; the four
+    // waves' column sums are added through LDS in wave order
+    extern __shared__ float red[];                         // [4][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
-    for (int q = threadIdx.x; q < Q; q += 256) {
+    for (int q = lane; q < Q; q += 64) {
         const float4 g = reinterpret_cast<const float4 *>(gamma)[q];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int row = r0; row < r1; ++row) {
+        for (int row = r0 + wave; row < r1; row += 4) {
             const float4 d = reinterpret_cast<const float4 *>(a + (size_t)row * C)[q], zz = reinterpret_cast<const float4 *>(z + (size_t)row * C)[q];
             reinterpret_cast<float4 *>(out + (size_t)row * C)[q] = make_float4(g.x * d.x, g.y * d.y, g.z * d.z, g.w * d.w);
             acc.x += d.x * zz.x; acc.y += d.y * zz.y; acc.z += d.z * zz.z; acc.w += d.w * zz.w;
         }
-        reinterpret_cast<float4 *>(part + (size_t)blockIdx.x * C)[q] = acc;
+        reinterpret_cast<float4 *>(red + (size_t)wave * C)[q] = acc;
     }
+    __syncthreads();
+    for (int i = threadIdx.x; i < C; i += 256) part[(size_t)blockIdx.x * C + i] = ((red[i] + red[C + i]) + red[2 * C + i]) + red[3 * C + i];
 }
 
 // ATen upsample_bilinear2d, align_corners = False, scale 2: src = max(0.5 * (dst + 0.5) - 0.5, 0)
@@ -301,13 +306,13 @@ extern "C" int sqd_scale_residual_fwd(const float *res, const float *z, const fl
     SQD_CHECK_LAUNCH("sqd_scale_residual_fwd");
     return SQD_OK;
 }
-extern "C" int sqd_scale_residual_nblk(int M) { return (M + 255) / 256; }
+extern "C" int sqd_scale_residual_nblk(int M) { return (M + 63) / 64; }
 // dy, z [M,C] -> dz = gamma * dy; part [sqd_scale_residual_nblk(M)][C] per-block column sums of dy * z (sum over the blocks: dgamma)
 extern "C" int sqd_scale_residual_bwd(const float *dy, const float *z, const float *gamma, float *dz, float *part, int M, int C, void *stream) {
     SQD_CHECK_ARG(dy && z && gamma && dz && part && M > 0 && C >= 4 && C % 4 == 0, "sqd_scale_residual_bwd: bad arguments");
     (void)hipGetLastError();
-    hipLaunchKernelGGL((scale_residual_kernel<1>), dim3(sqd_scale_residual_nblk(M)), dim3(256), 0, (hipStream_t)stream, dy, z, gamma, dz, part, M,
-                       C, 256);
+    hipLaunchKernelGGL((scale_residual_kernel<1>), dim3(sqd_scale_residual_nblk(M)), dim3(256), (size_t)4 * C * sizeof(float),
+                       (hipStream_t)stream, dy, z, gamma, dz, part, M, C, 64);
     SQD_CHECK_LAUNCH("sqd_scale_residual_bwd");
     return SQD_OK;
 }
