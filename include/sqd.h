@@ -467,6 +467,34 @@ int sqd_scale_residual_bwd(const float *dy, const float *z, const float *gamma, 
 int sqd_upsample2x_fwd(const float *x, float *y, int N, int H, int W, int C, void *stream);
 int sqd_upsample2x_bwd(const float *dy, float *dx, int N, int H, int W, int C, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Supervised metric-depth finetune step (config E; not part of the self-supervised step)
+ * replaces: reference finetune/train_ft_SQLdepth.py:219-285 per step — interpolate(pred, depth size, bilinear, align_corners=True)
+ *           (:233), the per-sample median rescale computed with numpy on the host (:234-266), SILogLoss (finetune/loss.py:24-42),
+ *           nn.utils.clip_grad_norm_(params, 0.1) (:281) and optim.AdamW.step() (:184,282).
+ * sqd_resize_ac_*: x [B,1,h,w] -> y [B,1,H,W] and its adjoint (rowscale [B] or NULL multiplies each sample's gradient).
+ * sqd_median_ratio: pred, depth [B,H,W] -> ratio [nscale] = median(depth[valid]) / median(pred[valid]) for the first nscale samples,
+ *   valid = min_eval < depth < max_eval inside the crop (0 none, 1 Garg, 2 Eigen-KITTI); exact medians, float32 as numpy; 1 when
+ *   nothing is valid.
+ * sqd_silog_*: g = log(scale[b] * pred) - log(depth) where depth > min_depth; loss = 10 sqrt(var(g) + 0.15 mean(g)^2), unbiased
+ *   variance; part: 3 * sqd_silog_nblk(B*HW) doubles; stats [4] = (valid pixels, mean, Dg, loss); backward -> d loss / d pred.
+ * sqd_grad_sumsq: part [nchunks] = per-chunk sums of squares of the gradients of an Adam table; sqd_clip_coef: part [n] (of one or
+ *   several tables) -> coef_norm [2] = (min(1, max_norm / (L2 norm + 1e-6)), norm).
+ * sqd_adamw_step: torch.optim.AdamW on the tables of sqd_adam_step; gscale (device float or NULL) multiplies every gradient.   */
+int sqd_resize_ac_fwd(const float *x, float *y, int B, int h, int w, int H, int W, void *stream);
+int sqd_resize_ac_bwd(const float *dy, const float *rowscale, float *dx, int B, int h, int w, int H, int W, void *stream);
+int sqd_median_ratio(const float *pred, const float *depth, float *ratio, int nscale, int H, int W, float min_eval, float max_eval,
+                     int crop, void *stream);
+int sqd_silog_nblk(int64_t total);
+int sqd_silog_fwd(const float *pred, const float *depth, const float *scale, double *part, float *stats, int B, int HW, float min_depth,
+                  void *stream);
+int sqd_silog_bwd(const float *pred, const float *depth, const float *scale, const float *stats, const float *g_loss, float *dpred, int B,
+                  int HW, float min_depth, void *stream);
+int sqd_grad_sumsq(const void *recs, const void *grads, const void *chunks, int nchunks, float *part, void *stream);
+int sqd_clip_coef(const float *part, int n, double max_norm, float *coef_norm, void *stream);
+int sqd_adamw_step(const void *recs, const void *grads, const void *chunks, int nchunks, double lr, double beta1, double beta2,
+                   double eps, double weight_decay, int step, const float *gscale, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,57 @@
+"""TEST INFRASTRUCTURE — CPU restatement (torch fp32 + numpy, as the reference) of the metric-depth finetune step of
+`/root/reference/finetune/train_ft_SQLdepth.py:219-285` and of `SILogLoss` (`finetune/loss.py:24-42`).  Only tests import this module.
+Pinned: SILogLoss against golden G21, frozen from the imported reference class."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+class SILogLoss(nn.Module):
+    """finetune/loss.py:24-42"""
+
+    def forward(self, input, target, mask=None, interpolate=True):
+        if interpolate:
+            input = nn.functional.interpolate(input, target.shape[-2:], mode="bilinear", align_corners=True)
+        if mask is not None:
+            input, target = input[mask], target[mask]
+        g = torch.log(input) - torch.log(target)
+        Dg = torch.var(g) + 0.15 * torch.pow(torch.mean(g), 2)
+        return 10 * torch.sqrt(Dg)
+
+
+def finetune_step(model, optimizer, scheduler, batch, args):
+    """train_ft_SQLdepth.py:222-285 for one batch (model(img) returns the depth map, as SQLdepth.forward does) -> (loss, ratios)"""
+    optimizer.zero_grad()
+    img, depth = batch["image"], batch["depth"]
+    pred = model(img)
+    pred = nn.functional.interpolate(pred, depth.shape[-2:], mode="bilinear", align_corners=True)          # :233
+    ratios = []
+    for i in range(pred.shape[0] // 2):                                                                    # :234
+        pred_np = pred[i].squeeze().detach().cpu().numpy()
+        depth_np = depth[i].squeeze().detach().cpu().numpy()
+        valid_mask = np.logical_and(depth_np > args.min_depth_eval, depth_np < args.max_depth_eval)
+        gt_height, gt_width = depth_np.shape
+        eval_mask = np.zeros(valid_mask.shape)
+        if args.garg_crop:
+            eval_mask[int(0.40810811 * gt_height):int(0.99189189 * gt_height), int(0.03594771 * gt_width):int(0.96405229 * gt_width)] = 1
+        elif args.eigen_crop:
+            eval_mask[int(0.3324324 * gt_height):int(0.91351351 * gt_height), int(0.0359477 * gt_width):int(0.96405229 * gt_width)] = 1
+        else:
+            eval_mask[:] = 1
+        valid_mask = np.logical_and(valid_mask, eval_mask)
+        pred_np, depth_np = pred_np[valid_mask], depth_np[valid_mask]
+        with np.errstate(all="ignore"):
+            import warnings
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                md, mp = np.median(depth_np), np.median(pred_np)
+        ratio = 1 if (np.isnan(md) or np.isnan(mp)) else md / mp                                            # :260-263
+        ratios.append(float(ratio))
+        pred[i] *= ratio                                                                                    # :264
+    mask = depth > args.min_depth                                                                           # :268
+    loss = SILogLoss()(pred, depth, mask=mask.to(torch.bool), interpolate=False)                            # :271
+    loss.backward()
+    nn.utils.clip_grad_norm_(model.parameters(), args.clip_grad_norm)                                       # :281
+    optimizer.step()
+    scheduler.step()
+    return loss.detach(), ratios

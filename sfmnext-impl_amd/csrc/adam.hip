@@ -60,9 +60,100 @@ __global__ __launch_bounds__(256) void adam_kernel(const TensorRec *__restrict__
         }
     }
 }
+
+// AdamW (torch.optim.AdamW: param.mul_(1 - lr * weight_decay) first, then the Adam update) with the gradient optionally scaled by a
+// device scalar — the clip coefficient of clip_grad_norm_, so that clipping costs no pass over the gradients
+__global__ __launch_bounds__(256) void adamw_kernel(const TensorRec *__restrict__ recs, const float *const *__restrict__ grads,
+                                                    const int2 *__restrict__ chunks, float step_size, float omb1, float beta2,
+                                                    float omb2, float eps, float inv_bc2_sqrt, float keep, const float *__restrict__ gscale) {
+    const float gs = gscale ? gscale[0] : 1.0f;
+    const int2 ch = chunks[blockIdx.x];
+    const TensorRec r = recs[ch.x];
+    const float *__restrict__ g = grads[ch.x];
+    const long long base = (long long)ch.y * CHUNK;
+    for (int k = 0; k < 4; ++k) {
+        const long long i0 = base + ((long long)k * 256 + threadIdx.x) * 4;
+        for (long long e = i0; e < i0 + 4 && e < r.n; ++e) {
+            const float ge = g[e] * gs;
+            float me = r.m[e], ve = r.v[e];
+            me = fmaf(ge - me, omb1, me);
+            ve = fmaf(omb2 * ge, ge, ve * beta2);
+            r.m[e] = me;
+            r.v[e] = ve;
+            r.p[e] = r.p[e] * keep - step_size * (me / (sqrtf(ve) * inv_bc2_sqrt + eps));
+        }
+    }
+}
+
+// per-chunk sums of squares of the gradients (the chunks of the Adam table), then their fixed-order total
+__global__ __launch_bounds__(256) void grad_sumsq_kernel(const TensorRec *__restrict__ recs, const float *const *__restrict__ grads,
+                                                         const int2 *__restrict__ chunks, float *__restrict__ part) {
+    __shared__ float red[4];
+    const int2 ch = chunks[blockIdx.x];
+    const long long n = recs[ch.x].n;
+    const float *__restrict__ g = grads[ch.x];
+    const long long base = (long long)ch.y * CHUNK;
+    float s = 0.f;
+    for (int k = 0; k < 4; ++k) {
+        const long long i0 = base + ((long long)k * 256 + threadIdx.x) * 4;
+        for (long long e = i0; e < i0 + 4 && e < n; ++e) s = fmaf(g[e], g[e], s);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
+}
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float *__restrict__ part, int n, float max_norm, float *__restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += (double)part[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(red[0]);
+        const float coef = max_norm / (norm + 1e-6f);          // torch.nn.utils.clip_grad_norm_
+        out[0] = coef < 1.0f ? coef : 1.0f;
+        out[1] = norm;
+    }
+}
 }  // namespace
 
 extern "C" int sqd_adam_chunk_elems(void) { return CHUNK; }
+
+// torch.optim.AdamW step on the tables of sqd_adam_step; gscale: device float multiplying every gradient (NULL: 1)
+extern "C" int sqd_adamw_step(const void *recs, const void *grads, const void *chunks, int nchunks, double lr, double beta1,
+                              double beta2, double eps, double weight_decay, int step, const float *gscale, void *stream) {
+    SQD_CHECK_ARG(recs && grads && chunks && nchunks > 0 && step >= 1 && weight_decay >= 0, "sqd_adamw_step: bad arguments");
+    const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(adamw_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const TensorRec *)recs,
+                       (const float *const *)grads, (const int2 *)chunks, (float)(lr / bc1), (float)(1.0 - beta1), (float)beta2,
+                       (float)(1.0 - beta2), (float)eps, (float)(1.0 / sqrt(bc2)), (float)(1.0 - lr * weight_decay), gscale);
+    SQD_CHECK_LAUNCH("sqd_adamw_step");
+    return SQD_OK;
+}
+// part [nchunks] floats: per-chunk sums of squares of the gradients of one Adam table (several tables may fill one array)
+extern "C" int sqd_grad_sumsq(const void *recs, const void *grads, const void *chunks, int nchunks, float *part, void *stream) {
+    SQD_CHECK_ARG(recs && grads && chunks && nchunks > 0 && part, "sqd_grad_sumsq: bad arguments");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(grad_sumsq_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const TensorRec *)recs,
+                       (const float *const *)grads, (const int2 *)chunks, part);
+    SQD_CHECK_LAUNCH("sqd_grad_sumsq");
+    return SQD_OK;
+}
+// part [n] -> coef_norm [2] device floats: min(1, max_norm / (sqrt(sum part) + 1e-6)) and the norm (torch.nn.utils.clip_grad_norm_
+// over all tensors that contributed); fixed-order sum
+extern "C" int sqd_clip_coef(const float *part, int n, double max_norm, float *coef_norm, void *stream) {
+    SQD_CHECK_ARG(part && n > 0 && coef_norm && max_norm > 0, "sqd_clip_coef: bad arguments");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, n, (float)max_norm, coef_norm);
+    SQD_CHECK_LAUNCH("sqd_clip_coef");
+    return SQD_OK;
+}
 
 // recs [ntensors] of {p, m, v, n} (device), grads [ntensors] device pointers (device array), chunks [nchunks] int2 (device)
 extern "C" int sqd_adam_step(const void *recs, const void *grads, const void *chunks, int nchunks, double lr, double beta1,

@@ -157,6 +157,15 @@ _SIGNATURES = {
     "sqd_conv_fwd_stats_rows": (_I, [_I] * 11),
     "sqd_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 12 + [_P]),
     "sqd_conv_dgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
+    "sqd_resize_ac_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "sqd_resize_ac_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sqd_median_ratio": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),
+    "sqd_silog_nblk": (_I, [ctypes.c_int64]),
+    "sqd_silog_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "sqd_silog_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "sqd_grad_sumsq": (_I, [_P, _P, _P, _I, _P, _P]),
+    "sqd_clip_coef": (_I, [_P, _I, ctypes.c_double, _P, _P]),
+    "sqd_adamw_step": (_I, [_P, _P, _P, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P, _P]),
     "sqd_ln_rows_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "sqd_ln_rows_nblk": (_I, [_I]),
     "sqd_ln_rows_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),

@@ -480,3 +480,65 @@ def depth_eval(pred, gt, eval_split="eigen", min_depth=1e-3, max_depth=80.0, pre
                                      1 if eval_split == "eigen" else 0, float(min_depth), float(max_depth),
                                      float(pred_depth_scale_factor), 1 if median_scaling else 0, _ptr(out), _stream()), "depth_eval")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# supervised metric-depth finetune step (reference finetune/train_ft_SQLdepth.py:219-285)
+class ResizeAlignCorners(torch.autograd.Function):
+    """nn.functional.interpolate(pred, size, mode='bilinear', align_corners=True) for a [B,1,h,w] prediction"""
+
+    @staticmethod
+    def forward(ctx, x, H, W):
+        _req(x)
+        B, _, h, w = x.shape
+        y = torch.empty(B, 1, H, W, device=x.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_resize_ac_fwd(_ptr(x), _ptr(y), B, h, w, H, W, _stream()), "resize_ac_fwd")
+        ctx.dims = (B, h, w, H, W)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, h, w, H, W = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty(B, 1, h, w, device=dy.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_resize_ac_bwd(_ptr(dy), None, _ptr(dx), B, h, w, H, W, _stream()), "resize_ac_bwd")
+        return dx, None, None
+
+
+def median_ratio(pred, depth, nscale, min_eval, max_eval, crop):
+    """ratio [nscale] = median(depth[valid]) / median(pred[valid]) per sample (train_ft_SQLdepth.py:234-263); crop: None, 'garg' or 'eigen'."""
+    B, _, H, W = depth.shape
+    ratio = torch.ones(B, device=pred.device, dtype=torch.float32)
+    if nscale > 0:
+        code = {None: 0, "garg": 1, "eigen": 2}[crop]
+        _l.check(_l.lib().sqd_median_ratio(_ptr(pred.detach().contiguous()), _ptr(depth.contiguous()), _ptr(ratio), nscale, H, W,
+                                           float(min_eval), float(max_eval), code, _stream()), "median_ratio")
+    return ratio
+
+
+class SILog(torch.autograd.Function):
+    """SILogLoss (reference finetune/loss.py:24-42, interpolate=False) of the ratio-scaled prediction over depth > min_depth.
+    forward(pred [B,1,H,W], depth [B,1,H,W], scale [B] (constants), min_depth) -> scalar loss"""
+
+    @staticmethod
+    def forward(ctx, pred, depth, scale, min_depth):
+        _req(pred, depth, scale)
+        pred, depth = pred.contiguous(), depth.contiguous()
+        B, _, H, W = pred.shape
+        L = _l.lib()
+        part = torch.empty(3 * L.sqd_silog_nblk(B * H * W), device=pred.device, dtype=torch.float64)
+        stats = torch.empty(4, device=pred.device, dtype=torch.float32)
+        _l.check(L.sqd_silog_fwd(_ptr(pred), _ptr(depth), _ptr(scale), _ptr(part), _ptr(stats), B, H * W, float(min_depth), _stream()), "silog_fwd")
+        ctx.save_for_backward(pred, depth, scale, stats)
+        ctx.min_depth = float(min_depth)
+        return stats[3].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, depth, scale, stats = ctx.saved_tensors
+        B, _, H, W = pred.shape
+        g = g.contiguous().reshape(1)
+        dpred = torch.empty_like(pred)
+        _l.check(_l.lib().sqd_silog_bwd(_ptr(pred), _ptr(depth), _ptr(scale), _ptr(stats), _ptr(g), _ptr(dpred), B, H * W, ctx.min_depth,
+                                        _stream()), "silog_bwd")
+        return dpred, None, None, None

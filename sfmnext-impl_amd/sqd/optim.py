@@ -138,47 +138,102 @@ class FusedAdam(torch.optim.Adam):
                                          ctypes.c_void_p(self._graph_hyper[gi][1].data_ptr()), float(b1), float(b2),
                                          float(group["eps"]), _stream()), "adam_step_dev")
 
+    def _prepare_group(self, gi, group):
+        """table of the group's parameters with fresh gradient addresses, and the advanced step count -> (tab, step, plist) or None"""
+        plist = [p for p in group["params"] if p.grad is not None]
+        if not plist:
+            return None
+        # (host time matters: an eager step is launch-bound.  The per-parameter checks run when the table is (re)built;
+        # per step there is one pass over the gradients and one vectorised write of their addresses.)
+        tab = self._tables.get(gi)
+        keys = [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr() if "exp_avg" in self.state[p] else 0) for p in plist]
+        if tab is None or tab["keys"] != keys:
+            for p in plist:
+                dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
+                if not (p.is_cuda and p.dtype == torch.float32 and dense):
+                    raise RuntimeError("FusedAdam: parameters must be dense fp32 device tensors")
+            tab = self._build(gi, plist)
+        # gradient tensors are re-allocated by every backward: refresh their addresses (one 8*n byte async copy)
+        host = tab["ghost"][self._ring % 4]
+        self._ring += 1
+        ptrs, strides = tab["ptr_scratch"], tab["pstrides"]
+        for i, p in enumerate(plist):
+            g = p.grad
+            if g.stride() != strides[i]:
+                g = p.grad = g.contiguous(memory_format=torch.channels_last if p.dim() == 4 and
+                                          p.is_contiguous(memory_format=torch.channels_last) and
+                                          not p.is_contiguous() else torch.contiguous_format)
+            ptrs[i] = g.data_ptr()
+        tab["ghost_np"][(self._ring - 1) % 4][:] = ptrs
+        tab["gdev"].copy_(host, non_blocking=True)
+        # one step counter per group, shared by the states of its parameters (torch.optim.Adam keeps one per parameter;
+        # state_dict() still lists it under every parameter)
+        st0 = tab["step"]
+        st0 += 1
+        return tab, int(st0.item()), plist
+
+    def _launch_groups(self, ready):
+        L = _l.lib()
+        for gi, group, tab, step, plist in ready:
+            b1, b2 = group["betas"]
+            _l.check(L.sqd_adam_step(ctypes.c_void_p(tab["recs"].data_ptr()), ctypes.c_void_p(tab["gdev"].data_ptr()),
+                                     ctypes.c_void_p(tab["chunks"].data_ptr()), tab["nchunks"], float(group["lr"]), float(b1),
+                                     float(b2), float(group["eps"]), step, _stream()), "adam_step")
+
     @torch.no_grad()
     def step(self, closure=None):
         if self._graph_hyper is not None and torch.cuda.is_current_stream_capturing():
             self._step_captured()
             return None
         loss = closure() if closure is not None else None
-        L = _l.lib()
+        ready = []
         for gi, group in enumerate(self.param_groups):
-            plist = [p for p in group["params"] if p.grad is not None]
-            if not plist:
-                continue
-            # (host time matters: an eager step is launch-bound.  The per-parameter checks run when the table is (re)built;
-            # per step there is one pass over the gradients and one vectorised write of their addresses.)
-            tab = self._tables.get(gi)
-            keys = [(p.data_ptr(), self.state[p]["exp_avg"].data_ptr() if "exp_avg" in self.state[p] else 0) for p in plist]
-            if tab is None or tab["keys"] != keys:
-                for p in plist:
-                    dense = p.is_contiguous() or (p.dim() == 4 and p.is_contiguous(memory_format=torch.channels_last))
-                    if not (p.is_cuda and p.dtype == torch.float32 and dense):
-                        raise RuntimeError("FusedAdam: parameters must be dense fp32 device tensors")
-                tab = self._build(gi, plist)
-            # gradient tensors are re-allocated by every backward: refresh their addresses (one 8*n byte async copy)
-            host = tab["ghost"][self._ring % 4]
-            self._ring += 1
-            ptrs, strides = tab["ptr_scratch"], tab["pstrides"]
-            for i, p in enumerate(plist):
-                g = p.grad
-                if g.stride() != strides[i]:
-                    g = p.grad = g.contiguous(memory_format=torch.channels_last if p.dim() == 4 and
-                                              p.is_contiguous(memory_format=torch.channels_last) and
-                                              not p.is_contiguous() else torch.contiguous_format)
-                ptrs[i] = g.data_ptr()
-            tab["ghost_np"][(self._ring - 1) % 4][:] = ptrs
-            tab["gdev"].copy_(host, non_blocking=True)
-            # one step counter per group, shared by the states of its parameters (torch.optim.Adam keeps one per parameter;
-            # state_dict() still lists it under every parameter)
-            st0 = tab["step"]
-            st0 += 1
-            step = int(st0.item())
-            b1, b2 = group["betas"]
-            _l.check(L.sqd_adam_step(ctypes.c_void_p(tab["recs"].data_ptr()), ctypes.c_void_p(tab["gdev"].data_ptr()),
-                                     ctypes.c_void_p(tab["chunks"].data_ptr()), tab["nchunks"], float(group["lr"]), float(b1),
-                                     float(b2), float(group["eps"]), step, _stream()), "adam_step")
+            pr = self._prepare_group(gi, group)
+            if pr is not None:
+                ready.append((gi, group) + pr)
+        self._launch_groups(ready)
         return loss
+
+
+class FusedAdamW(FusedAdam):
+    """torch.optim.AdamW (decoupled weight decay) with an optional global gradient-norm clip folded into the step — the optimiser
+    side of the reference's finetune loop (finetune/train_ft_SQLdepth.py:184 `optim.AdamW(params, weight_decay=args.wd, lr=args.lr)`,
+    :281 `nn.utils.clip_grad_norm_(model.parameters(), 0.1)`): one launch pair computes min(1, max_norm / (||g|| + 1e-6)) over the
+    gradients of ALL groups into a device scalar, and the AdamW kernel of every group multiplies its gradients by it on the fly — the
+    gradients are not rewritten (p.grad stays unclipped).  param_groups / state_dict() are torch.optim.Adam's, so
+    torch.optim.lr_scheduler.OneCycleLR (cycle_momentum moves betas[0]) drives it like the reference's optimiser.
+    `clip_info` holds the last (coefficient, norm) as a device tensor."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None):
+        super().__init__(params, lr=lr, betas=betas, eps=eps)
+        self.decoupled_weight_decay = float(weight_decay)
+        self.max_grad_norm = max_grad_norm
+        self.clip_info = None
+
+    def begin_capture(self):
+        raise NotImplementedError("FusedAdamW runs eagerly (the finetune loop is not captured)")
+
+    def _launch_groups(self, ready):
+        if not ready:
+            return
+        L = _l.lib()
+        gscale = None
+        if self.max_grad_norm is not None:
+            dev = ready[0][4][0].device
+            part = torch.empty(sum(r[2]["nchunks"] for r in ready), device=dev, dtype=torch.float32)
+            # per-chunk sums of squares of every group into one partial array, then one fixed-order total
+            off = 0
+            for gi, group, tab, step, plist in ready:
+                _l.check(L.sqd_grad_sumsq(ctypes.c_void_p(tab["recs"].data_ptr()), ctypes.c_void_p(tab["gdev"].data_ptr()),
+                                          ctypes.c_void_p(tab["chunks"].data_ptr()), tab["nchunks"],
+                                          ctypes.c_void_p(part.data_ptr() + 4 * off), _stream()), "grad_sumsq")
+                off += tab["nchunks"]
+            self.clip_info = torch.empty(2, device=dev, dtype=torch.float32)
+            _l.check(L.sqd_clip_coef(ctypes.c_void_p(part.data_ptr()), off, float(self.max_grad_norm), ctypes.c_void_p(self.clip_info.data_ptr()),
+                                     _stream()), "clip_coef")
+            gscale = ctypes.c_void_p(self.clip_info.data_ptr())
+        for gi, group, tab, step, plist in ready:
+            b1, b2 = group["betas"]
+            _l.check(L.sqd_adamw_step(ctypes.c_void_p(tab["recs"].data_ptr()), ctypes.c_void_p(tab["gdev"].data_ptr()),
+                                      ctypes.c_void_p(tab["chunks"].data_ptr()), tab["nchunks"], float(group["lr"]), float(b1), float(b2),
+                                      float(group["eps"]), self.decoupled_weight_decay, step, gscale, _stream()), "adamw_step")

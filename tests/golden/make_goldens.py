@@ -404,6 +404,29 @@ def g20_unet_decoder(T):
          keys=np.array(sorted(dec.state_dict().keys())))
 
 
+def g21_silog(T):
+    """the reference's SILogLoss (finetune/loss.py:24-42): loss and input gradient, with and without interpolation"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_ft_loss", os.path.join(REF, "finetune", "loss.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    crit = mod.SILogLoss()
+    rs = np.random.RandomState(2121)
+    depth = rs.uniform(1.0, 80.0, (2, 1, 24, 40)).astype(np.float32)
+    depth[rs.uniform(size=depth.shape) > 0.4] = 0.0
+    pred_lr = rs.uniform(0.5, 60.0, (2, 1, 12, 20)).astype(np.float32)
+    p = tt(pred_lr).clone().requires_grad_(True)
+    mask = tt(depth) > 1e-3
+    loss = crit(p, tt(depth), mask=mask, interpolate=True)
+    loss.backward()
+    pred_hr = rs.uniform(0.5, 60.0, (2, 1, 24, 40)).astype(np.float32)
+    q = tt(pred_hr).clone().requires_grad_(True)
+    loss2 = crit(q, tt(depth), mask=mask, interpolate=False)
+    loss2.backward()
+    save("g21_silog", depth=depth, pred_lr=pred_lr, pred_hr=pred_hr, loss_interp=np.float32(loss.item()), grad_lr=p.grad.numpy(),
+         loss_plain=np.float32(loss2.item()), grad_hr=q.grad.numpy())
+
+
 def build_reference_models(nets, kind):
     if kind == "res18":
         enc = nets["lite_res_encoder"].LiteResnetEncoderDecoder(model_dim=16)
@@ -517,6 +540,7 @@ def main():
     g18_decoder_b5(T)
     g19_eval(T)
     g20_unet_decoder(T)
+    g21_silog(T)
     g1_pose(T)
     g2_g3_g4_geometry(T)
     g5_g6_ssim(T)

@@ -336,3 +336,21 @@ def test_g20_unet_decoder(golden):
     close(fr[3].grad, g["grad_feat3"], atol=1e-5)
     close(dec.final_conv.weight.grad, g["grad_final_w"], atol=1e-4)
     close(dec.blocks[0].conv1.conv.weight.grad, g["grad_b0c1"], atol=1e-4)
+
+
+def test_g21_silog(golden):
+    """oracle SILogLoss against the reference's own class (finetune/loss.py:24-42)"""
+    from oracle import finetune_ref as FR
+    g = golden("g21_silog")
+    depth = tt(g["depth"])
+    mask = depth > 1e-3
+    p = tt(g["pred_lr"]).clone().requires_grad_(True)
+    loss = FR.SILogLoss()(p, depth, mask=mask, interpolate=True)
+    loss.backward()
+    assert abs(float(loss) - float(g["loss_interp"])) <= 1e-6 * abs(float(g["loss_interp"]))
+    close(p.grad, g["grad_lr"], atol=1e-7)
+    q = tt(g["pred_hr"]).clone().requires_grad_(True)
+    loss2 = FR.SILogLoss()(q, depth, mask=mask, interpolate=False)
+    loss2.backward()
+    assert abs(float(loss2) - float(g["loss_plain"])) <= 1e-6 * abs(float(g["loss_plain"]))
+    close(q.grad, g["grad_hr"], atol=1e-7)
