@@ -71,16 +71,36 @@ __global__ __launch_bounds__(256) void adamw_kernel(const TensorRec *__restrict_
     const TensorRec r = recs[ch.x];
     const float *__restrict__ g = grads[ch.x];
     const long long base = (long long)ch.y * CHUNK;
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
-        const long long i0 = base + ((long long)k * 256 + threadIdx.x) * 4;
-        for (long long e = i0; e < i0 + 4 && e < r.n; ++e) {
-            const float ge = g[e] * gs;
-            float me = r.m[e], ve = r.v[e];
-            me = fmaf(ge - me, omb1, me);
-            ve = fmaf(omb2 * ge, ge, ve * beta2);
-            r.m[e] = me;
-            r.v[e] = ve;
-            r.p[e] = r.p[e] * keep - step_size * (me / (sqrtf(ve) * inv_bc2_sqrt + eps));
+        const long long i = base + ((long long)k * 256 + threadIdx.x) * 4;
+        if (i >= r.n) break;
+        if (i + 3 < r.n && ((((size_t)r.p | (size_t)g | (size_t)r.m | (size_t)r.v) & 15) == 0)) {
+            float4 pv = *reinterpret_cast<float4 *>(r.p + i), mv = *reinterpret_cast<float4 *>(r.m + i);
+            float4 vv = *reinterpret_cast<float4 *>(r.v + i);
+            const float4 gv = *reinterpret_cast<const float4 *>(g + i);
+            float *pp = &pv.x, *mm = &mv.x, *vq = &vv.x;
+            const float *gg = &gv.x;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ge = gg[e] * gs;
+                mm[e] = fmaf(ge - mm[e], omb1, mm[e]);
+                vq[e] = fmaf(omb2 * ge, ge, vq[e] * beta2);
+                pp[e] = pp[e] * keep - step_size * (mm[e] / (sqrtf(vq[e]) * inv_bc2_sqrt + eps));
+            }
+            *reinterpret_cast<float4 *>(r.p + i) = pv;
+            *reinterpret_cast<float4 *>(r.m + i) = mv;
+            *reinterpret_cast<float4 *>(r.v + i) = vv;
+        } else {
+            for (long long e = i; e < i + 4 && e < r.n; ++e) {
+                const float ge = g[e] * gs;
+                float me = r.m[e], ve = r.v[e];
+                me = fmaf(ge - me, omb1, me);
+                ve = fmaf(omb2 * ge, ge, ve * beta2);
+                r.m[e] = me;
+                r.v[e] = ve;
+                r.p[e] = r.p[e] * keep - step_size * (me / (sqrtf(ve) * inv_bc2_sqrt + eps));
+            }
         }
     }
 }
@@ -94,22 +114,33 @@ __global__ __launch_bounds__(256) void grad_sumsq_kernel(const TensorRec *__rest
     const float *__restrict__ g = grads[ch.x];
     const long long base = (long long)ch.y * CHUNK;
     float s = 0.f;
+#pragma unroll
     for (int k = 0; k < 4; ++k) {
         const long long i0 = base + ((long long)k * 256 + threadIdx.x) * 4;
-        for (long long e = i0; e < i0 + 4 && e < n; ++e) s = fmaf(g[e], g[e], s);
+        if (i0 >= n) break;
+        if (i0 + 3 < n && ((size_t)g & 15) == 0) {
+            const float4 gv = *reinterpret_cast<const float4 *>(g + i0);
+            s = fmaf(gv.x, gv.x, s); s = fmaf(gv.y, gv.y, s); s = fmaf(gv.z, gv.z, s); s = fmaf(gv.w, gv.w, s);
+        } else {
+            for (long long e = i0; e < i0 + 4 && e < n; ++e) s = fmaf(g[e], g[e], s);
+        }
     }
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
     if (threadIdx.x == 0) part[blockIdx.x] = ((red[0] + red[1]) + red[2]) + red[3];
 }
-__global__ __launch_bounds__(256) void clip_coef_kernel(const float *__restrict__ part, int n, float max_norm, float *__restrict__ out) {
-    __shared__ double red[256];
-    double s = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) s += (double)part[i];
-    red[threadIdx.x] = s;
+__global__ __launch_bounds__(1024) void clip_coef_kernel(const float *__restrict__ part, int n, float max_norm, float *__restrict__ out) {
+    __shared__ double red[1024];
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;       // four independent chains per thread; fixed order
+    int i = threadIdx.x;
+    for (; i + 3072 < n; i += 4096) {
+        s0 += (double)part[i]; s1 += (double)part[i + 1024]; s2 += (double)part[i + 2048]; s3 += (double)part[i + 3072];
+    }
+    for (; i < n; i += 1024) s0 += (double)part[i];
+    red[threadIdx.x] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
+    for (int o = 512; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
         __syncthreads();
     }
@@ -150,7 +181,7 @@ extern "C" int sqd_grad_sumsq(const void *recs, const void *grads, const void *c
 extern "C" int sqd_clip_coef(const float *part, int n, double max_norm, float *coef_norm, void *stream) {
     SQD_CHECK_ARG(part && n > 0 && coef_norm && max_norm > 0, "sqd_clip_coef: bad arguments");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, n, (float)max_norm, coef_norm);
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, n, (float)max_norm, coef_norm);
     SQD_CHECK_LAUNCH("sqd_clip_coef");
     return SQD_OK;
 }

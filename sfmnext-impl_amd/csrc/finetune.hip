@@ -73,68 +73,111 @@ struct Crop {
 __device__ __forceinline__ bool valid_px(float d, int y, int x, float lo, float hi, const Crop &c) {
     return d > lo && d < hi && y >= c.y0 && y < c.y1 && x >= c.x0 && x < c.x1;
 }
-// element of rank `rank` among the valid pixels of v (WHICH: 0 depth, 1 pred): 3-level radix select on the float bit patterns (> 0)
-template <int WHICH>
-__device__ float select_rank_f32(const float *pred, const float *depth, int H, int W, float lo, float hi, const Crop &c, long long rank,
-                                 unsigned *hist, unsigned *shared) {
-    unsigned prefix = 0;
-    int decided = 0;
-    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
-    const int total = H * W;
-    for (int lvl = 0; lvl < 3; ++lvl) {
-        for (int i = threadIdx.x; i < BINS; i += NT) hist[i] = 0;
-        __syncthreads();
-        for (int p = threadIdx.x; p < total; p += NT) {
-            const float d = depth[p];
-            if (!valid_px(d, p / W, p % W, lo, hi, c)) continue;
-            const unsigned key = __float_as_uint(WHICH == 0 ? d : pred[p]);
-            if (decided && (key >> (32 - decided)) != prefix) continue;
-            atomicAdd(&hist[(key >> shifts[lvl]) & ((1u << widths[lvl]) - 1)], 1u);
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            long long r = rank;
-            unsigned b = 0;
-            for (; b < (1u << widths[lvl]); ++b) {
-                if (r < (long long)hist[b]) break;
-                r -= hist[b];
-            }
-            shared[0] = b;
-            shared[1] = (unsigned)r;
-        }
-        __syncthreads();
-        prefix = (prefix << widths[lvl]) | shared[0];
-        rank = (long long)shared[1];
-        decided += widths[lvl];
-        __syncthreads();
+// One wave finds, in a histogram of nb bins (nb a multiple of 64), the bin holding the element of rank r: -> (bin, rank inside the bin,
+// count of the bin) in out[0..2].  Lane l owns nb/64 consecutive bins; an inclusive scan over the lanes locates the owner.
+__device__ void wave_find_bin(const unsigned *hist, int nb, unsigned r, unsigned *out) {
+    const int lane = threadIdx.x & 63, per = nb >> 6;
+    unsigned s = 0;
+    for (int i = 0; i < per; ++i) s += hist[lane * per + i];
+    unsigned incl = s;
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o, 64);
+        if (lane >= o) incl += t;
     }
-    return __uint_as_float(prefix);
+    const unsigned long long owners = __ballot(incl > r);
+    const int owner = __ffsll((long long)owners) - 1;            // r < total count, so some lane owns it
+    if (lane == owner) {
+        unsigned rr = r - (incl - s);
+        int bin = lane * per;
+        for (;; ++bin) {
+            const unsigned h = hist[bin];
+            if (rr < h) break;
+            rr -= h;
+        }
+        out[0] = (unsigned)bin;
+        out[1] = rr;
+        out[2] = hist[bin];
+    }
 }
 
-// one workgroup per sample b < nscale: ratio[b] = median(depth[valid]) / median(pred[valid]) (1 when a median is NaN / nothing valid)
+// one workgroup per sample b < nscale: ratio[b] = median(depth[valid]) / median(pred[valid]) (1 when nothing is valid).  Exact
+// order statistics by a 3-level radix select (11 + 11 + 10 bits) on the float bit patterns — both arrays are positive, so the bit
+// patterns order as the values do — of the ground truth and of the prediction at once (two histograms per pass over the crop
+// rectangle); for an even count the upper middle element is the lower one again when its value repeats, else the smallest value
+// above it (one more pass).
 __global__ __launch_bounds__(NT) void median_ratio_kernel(const float *__restrict__ pred, const float *__restrict__ depth,
                                                           float *__restrict__ ratio, int H, int W, float lo, float hi, Crop c) {
-    __shared__ unsigned hist[BINS];
-    __shared__ unsigned shared[2];
+    __shared__ unsigned hist[2][BINS];
+    __shared__ unsigned found[2][3];
+    __shared__ unsigned nextkey[2];
     __shared__ int cnt_red[NT / 64];
     const int b = blockIdx.x;
     const float *p = pred + (size_t)b * H * W, *d = depth + (size_t)b * H * W;
+    const int cw = c.x1 - c.x0, npx = (c.y1 - c.y0) * cw;
     int cnt = 0;
-    for (int i = threadIdx.x; i < H * W; i += NT) cnt += valid_px(d[i], i / W, i % W, lo, hi, c) ? 1 : 0;
+    for (int q = threadIdx.x; q < npx; q += NT) {
+        const float dv = d[(size_t)(c.y0 + q / cw) * W + c.x0 + q % cw];
+        cnt += (dv > lo && dv < hi) ? 1 : 0;
+    }
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o, 64);
     if ((threadIdx.x & 63) == 0) cnt_red[threadIdx.x >> 6] = cnt;
     __syncthreads();
     int n = 0;
     for (int i = 0; i < NT / 64; ++i) n += cnt_red[i];
-    __syncthreads();
     if (n == 0) {                                       // np.median of an empty array is NaN -> ratio = 1 (train_ft_SQLdepth.py:261-262)
         if (threadIdx.x == 0) ratio[b] = 1.f;
         return;
     }
-    const long long r1 = (n - 1) / 2, r2 = n / 2;
-    const float g1 = select_rank_f32<0>(p, d, H, W, lo, hi, c, r1, hist, shared), g2 = r2 == r1 ? g1 : select_rank_f32<0>(p, d, H, W, lo, hi, c, r2, hist, shared);
-    const float p1 = select_rank_f32<1>(p, d, H, W, lo, hi, c, r1, hist, shared), p2 = r2 == r1 ? p1 : select_rank_f32<1>(p, d, H, W, lo, hi, c, r2, hist, shared);
-    if (threadIdx.x == 0) ratio[b] = ((g1 + g2) * 0.5f) / ((p1 + p2) * 0.5f);      // np.median(float32): float32 mean of the middle pair
+    const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
+    unsigned prefix[2] = {0, 0}, rank[2] = {(unsigned)((n - 1) / 2), (unsigned)((n - 1) / 2)};
+    int decided = 0;
+    for (int lvl = 0; lvl < 3; ++lvl) {
+        for (int i = threadIdx.x; i < 2 * BINS; i += NT) (&hist[0][0])[i] = 0;
+        __syncthreads();
+        const unsigned mask = (1u << widths[lvl]) - 1;
+        for (int q = threadIdx.x; q < npx; q += NT) {
+            const size_t at = (size_t)(c.y0 + q / cw) * W + c.x0 + q % cw;
+            const float dv = d[at];
+            if (!(dv > lo && dv < hi)) continue;
+            const unsigned kd = __float_as_uint(dv), kp = __float_as_uint(p[at]);
+            if (!decided || (kd >> (32 - decided)) == prefix[0]) atomicAdd(&hist[0][(kd >> shifts[lvl]) & mask], 1u);
+            if (!decided || (kp >> (32 - decided)) == prefix[1]) atomicAdd(&hist[1][(kp >> shifts[lvl]) & mask], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) wave_find_bin(hist[0], 1 << widths[lvl], rank[0], found[0]);
+        else if (threadIdx.x < 128) wave_find_bin(hist[1], 1 << widths[lvl], rank[1], found[1]);
+        __syncthreads();
+        for (int a = 0; a < 2; ++a) {
+            prefix[a] = (prefix[a] << widths[lvl]) | found[a][0];
+            rank[a] = found[a][1];
+        }
+        decided += widths[lvl];
+    }
+    // prefix[] = the elements of rank (n-1)/2; found[a][1..2] = that rank inside the run of equal values and the run's length
+    unsigned upper[2] = {prefix[0], prefix[1]};
+    const bool need[2] = {(n & 1) == 0 && found[0][1] + 1 >= found[0][2], (n & 1) == 0 && found[1][1] + 1 >= found[1][2]};
+    if (need[0] || need[1]) {                           // block-uniform
+        if (threadIdx.x < 2) nextkey[threadIdx.x] = 0xffffffffu;
+        __syncthreads();
+        unsigned best[2] = {0xffffffffu, 0xffffffffu};
+        for (int q = threadIdx.x; q < npx; q += NT) {
+            const size_t at = (size_t)(c.y0 + q / cw) * W + c.x0 + q % cw;
+            const float dv = d[at];
+            if (!(dv > lo && dv < hi)) continue;
+            const unsigned kd = __float_as_uint(dv), kp = __float_as_uint(p[at]);
+            if (kd > prefix[0] && kd < best[0]) best[0] = kd;
+            if (kp > prefix[1] && kp < best[1]) best[1] = kp;
+        }
+        for (int a = 0; a < 2; ++a) {
+            for (int o = 32; o > 0; o >>= 1) best[a] = min(best[a], (unsigned)__shfl_down(best[a], o, 64));
+            if ((threadIdx.x & 63) == 0) atomicMin(&nextkey[a], best[a]);
+        }
+        __syncthreads();
+        for (int a = 0; a < 2; ++a)
+            if (need[a]) upper[a] = nextkey[a];
+    }
+    if (threadIdx.x == 0)                               // np.median(float32): float32 mean of the middle pair
+        ratio[b] = ((__uint_as_float(prefix[0]) + __uint_as_float(upper[0])) * 0.5f) / ((__uint_as_float(prefix[1]) + __uint_as_float(upper[1])) * 0.5f);
 }
 
 // SILog partial sums over chunks: part[blk] = (n, sum g, sum g^2) in double, g = log(scale_b * pred) - log(depth) where depth > min_depth
@@ -156,10 +199,19 @@ __global__ __launch_bounds__(256) void silog_sums_kernel(const float *__restrict
     if (threadIdx.x < 3) part[(size_t)blockIdx.x * 3 + threadIdx.x] = ((red[threadIdx.x][0] + red[threadIdx.x][1]) + red[threadIdx.x][2]) + red[threadIdx.x][3];
 }
 // stats [4] = (n, mean, Dg, loss)
-__global__ __launch_bounds__(64) void silog_finish_kernel(const double *__restrict__ part, int nblk, float *__restrict__ stats) {
-    if (threadIdx.x != 0) return;
+__global__ __launch_bounds__(256) void silog_finish_kernel(const double *__restrict__ part, int nblk, float *__restrict__ stats) {
+    __shared__ double red[3][256];
     double n = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < nblk; ++i) { n += part[3 * i]; s1 += part[3 * i + 1]; s2 += part[3 * i + 2]; }
+    for (int i = threadIdx.x; i < nblk; i += 256) { n += part[3 * i]; s1 += part[3 * i + 1]; s2 += part[3 * i + 2]; }
+    red[0][threadIdx.x] = n; red[1][threadIdx.x] = s1; red[2][threadIdx.x] = s2;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {                 // fixed-order tree: the result does not depend on scheduling
+        if ((int)threadIdx.x < o)
+            for (int a = 0; a < 3; ++a) red[a][threadIdx.x] += red[a][threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    n = red[0][0]; s1 = red[1][0]; s2 = red[2][0];
     const double mean = s1 / n, var = (s2 - s1 * s1 / n) / (n - 1.0);             // torch.var: unbiased
     const double Dg = var + 0.15 * mean * mean;
     stats[0] = (float)n; stats[1] = (float)mean; stats[2] = (float)Dg; stats[3] = (float)(10.0 * sqrt(Dg));
@@ -226,7 +278,7 @@ extern "C" int sqd_silog_fwd(const float *pred, const float *depth, const float 
     const int nblk = sqd_silog_nblk((int64_t)total);
     (void)hipGetLastError();
     hipLaunchKernelGGL(silog_sums_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, pred, depth, scale, part, HW, total, min_depth);
-    hipLaunchKernelGGL(silog_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, nblk, stats);
+    hipLaunchKernelGGL(silog_finish_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nblk, stats);
     SQD_CHECK_LAUNCH("sqd_silog_fwd");
     return SQD_OK;
 }

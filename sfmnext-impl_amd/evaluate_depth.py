@@ -26,6 +26,8 @@ def build_models(opt, device):
     from trainer import Trainer
     shim = Trainer.__new__(Trainer)
     shim.opt = opt
+    from sqd import nnops
+    nnops.configure(opt, device)
     encoder, depth = Trainer._build_encoder(shim).to(device), Trainer._build_depth_head(shim).to(device)
     if opt.load_weights_folder:
         folder = os.path.expanduser(opt.load_weights_folder)

@@ -13,7 +13,7 @@ import torch
 import torch.optim as optim
 
 from SQLdepth import SQLdepth
-from sqd import ops
+from sqd import nnkernels, ops
 from sqd.optim import FusedAdamW
 
 from .loss import SILogLoss
@@ -37,6 +37,8 @@ class FinetuneTrainer:
     def __init__(self, opt, args, steps_per_epoch, device=None):
         self.opt, self.args = opt, args
         self.device = device or torch.device("cuda")
+        from sqd import nnops
+        nnops.configure(opt, self.device)
         self.model = SQLdepth(opt).to(self.device).to(memory_format=torch.channels_last)
         self.model.train()
         if args.same_lr:
@@ -52,6 +54,7 @@ class FinetuneTrainer:
 
     def train_step(self, batch):
         a = self.args
+        nnkernels.begin_step()
         self.optimizer.zero_grad(set_to_none=True)
         img = batch["image"].to(self.device).contiguous(memory_format=torch.channels_last)
         depth = batch["depth"].to(self.device).contiguous()

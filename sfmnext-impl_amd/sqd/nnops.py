@@ -48,6 +48,18 @@ def set_native_conv(on):
     BACKEND["conv_bn_act"] = ("hip conv" if on else "aten conv") + " + hip bn/act/residual"
 
 
+def configure(opt, device):
+    """Backend switches every entry point sets before building its networks (Trainer, evaluate_depth.build_models,
+    finetune.FinetuneTrainer): native convolutions unless --sqd_aten_conv, their operand precision (--sqd_bf16), plan timing on the
+    first call unless --sqd_no_conv_tune.  The native kernels are NHWC / KRSC only, so channels_last is forced with them."""
+    from . import lib as _lib, nnkernels
+    set_native_conv(not opt.sqd_aten_conv)
+    _lib.check(_lib.lib().sqd_conv_set_precision(2 if opt.sqd_bf16 else 0), "conv_set_precision")
+    nnkernels.TUNE_CONV = not opt.sqd_no_conv_tune and torch.device(device).type == "cuda"     # first step: ~2 s of plan timing
+    if not opt.sqd_aten_conv:
+        opt.sqd_channels_last = True
+
+
 def _conv(x, conv, act=None, skip=False, bn_stats=None):
     """skip=True: -> (y, x') with x' the input handed through the convolution node (see nnkernels.Conv2d).
     bn_stats: a list that receives (partials, rows) when the convolution's epilogue produced the statistics partials of

@@ -87,12 +87,7 @@ class Trainer:
         if self.opt.sqd_miopen_find:
             torch.backends.cudnn.benchmark = True
         from sqd import nnops
-        nnops.set_native_conv(not self.opt.sqd_aten_conv)
-        from sqd import lib as _lib
-        _lib.check(_lib.lib().sqd_conv_set_precision(2 if self.opt.sqd_bf16 else 0), "conv_set_precision")
-        nnkernels.TUNE_CONV = not self.opt.sqd_no_conv_tune and self.device.type == "cuda"   # first step: ~2 s of plan timing
-        if not self.opt.sqd_aten_conv:
-            self.opt.sqd_channels_last = True          # the native kernels are NHWC / KRSC only
+        nnops.configure(self.opt, self.device)
         if self.opt.sqd_channels_last:
             for m in self.models.values():
                 m.to(memory_format=torch.channels_last)

@@ -48,15 +48,20 @@ def test_resize_align_corners(h, w, H, W):
     assert float((xg.grad.cpu().double() - xr.grad).abs().max()) <= 1e-4 * float(xr.grad.abs().max()) + 1e-7
 
 
+@pytest.mark.parametrize("quant", [False, True])
 @pytest.mark.parametrize("crop", ["garg", "eigen", None])
-def test_median_ratio_is_exact(crop):
+def test_median_ratio_is_exact(crop, quant):
     from sqd import ops
-    rs = np.random.RandomState(4)
+    rs = np.random.RandomState(4 + quant)
     B, H, W = 5, 88, 304
     depth = rs.uniform(0.5, 90.0, (B, 1, H, W)).astype(np.float32)
+    pred = rs.uniform(1.0, 40.0, (B, 1, H, W)).astype(np.float32)
+    if quant:                                                       # repeated values around the middle (ties inside the middle pair)
+        depth, pred = np.round(depth / 8) * 8 + 1, np.round(pred / 4) * 4 + 1
+        depth, pred = depth.astype(np.float32), pred.astype(np.float32)
     depth[rs.uniform(size=depth.shape) > 0.3] = 0.0
     depth[3] = 0.0                                                  # a sample without measurements: ratio 1
-    pred = rs.uniform(1.0, 40.0, (B, 1, H, W)).astype(np.float32)
+    depth[2, 0, 50, 100] = depth[2, 0, 50, 100] if (np.logical_and(depth[2, 0] > 1e-3, depth[2, 0] < 80).sum() % 2) else 0.0
     got = ops.median_ratio(torch.from_numpy(pred).cuda(), torch.from_numpy(depth).cuda(), 4, 1e-3, 80.0, crop).cpu().numpy()
     for i in range(B):
         if i >= 4:
