@@ -505,6 +505,259 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
 }
 
 // ---------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolutions, three-term bf16 operands ("halo" plans, bk + 2048).  The implicit-GEMM kernel above
+// fetches and converts every input pixel once per filter tap and N-tile (9x for a 3x3 filter); here a workgroup owns a
+// TH x 16 patch of output pixels of one image, stages the (TH+2) x 18 input patch of a 32-channel chunk in LDS ONCE — converted to
+// the three bf16 planes — and all nine taps read their A fragments from it at shifted addresses.  The filter operand does not
+// pass through LDS: a wave owns 32 output channels for all pixels of the patch (wave tile 32*WTM x 32), so its B fragments
+// (8 consecutive reduction channels per lane) are loaded straight from L2 into registers one tap ahead and converted there —
+// no barrier inside a chunk.  WK = 2 (tiles 64 channels wide): two waves share a 32-channel column and split the two 16-channel
+// MFMA steps of a chunk; their accumulators are added through LDS at the end.
+// MODE 0 forward (source x, reduction over c, tap (r,s) reads patch cell (ty+r, tx+s)); MODE 1 data gradient (source dy,
+// reduction over k, tap (r,s) reads (ty+2-r, tx+2-s)).
+// ---------------------------------------------------------------------------------------------------
+template <int MODE, int WTM, int WM, int WN, int WK>
+__global__ __launch_bounds__(WM * WN * WK * 64, (WTM / WM >= 4 ? 2 : 3)) void conv3x3_halo_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
+                                                                    const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
+                                                                    int act, int zsplits, float *__restrict__ stats) {
+    constexpr int TH = 2 * WTM, TW = 16, PW = TW + 2, PH = TH + 2, HP = PH * PW;     // output patch, input patch (+1 on every side)
+    constexpr int NT = WM * WN * WK * 64, BN = WN * 32;
+    constexpr int WS = WTM / WM;                          // 32-pixel sub-tiles per wave
+    constexpr int CK = 32, LDH = CK + 8;                  // channels per chunk, LDS row pitch in bf16 (80 bytes: conflict-free b128 accesses)
+    constexpr int HPP = (HP + 15) / 16 * 16;
+    constexpr int KSW = 2 / WK;                           // 16-channel MFMA steps of a chunk per wave
+    constexpr int A_ITEMS = HPP * 4, A_PASS = (A_ITEMS + NT - 1) / NT;        // item = 8 channels of one patch cell
+    static_assert((WK == 1 || WK == 2) && WTM % WM == 0, "WK, WM");
+    static_assert((WK == 2 ? WN * WTM * 16 * 64 * 4 : 0) + WM * WN * 64 * 4 <= 3 * HPP * LDH * 2, "the accumulator / statistics exchange reuses the patch planes");
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[3][HPP][LDH];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wn = wave % WN, wk = (wave / WN) % WK, wmi = wave / (WN * WK);
+    const int Ncols = MODE == 0 ? g.K : g.C, Cred = MODE == 0 ? g.C : g.K;
+    const int tiles_x = (g.W + TW - 1) / TW, tiles_y = (g.H + TH - 1) / TH;
+    const int tiles_n = (Ncols + BN - 1) / BN;
+    const int tm = blockIdx.x / tiles_n, n0 = (blockIdx.x - tm * tiles_n) * BN;     // N-tiles of a patch are neighbours: they share it in L2
+    const int txi = tm % tiles_x, t2 = tm / tiles_x, tyi = t2 % tiles_y, img = t2 / tiles_y;
+    const int y0 = tyi * TH, x0 = txi * TW;
+    const int cchunks = (Cred + CK - 1) / CK;
+    const int c_beg = (int)((long long)cchunks * blockIdx.z / zsplits), c_end = (int)((long long)cchunks * (blockIdx.z + 1) / zsplits);
+
+    const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_src, (unsigned)(g.N * g.H * g.W * Cred) * 4u);
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(wgt, (unsigned)(g.K * 9 * g.C) * 4u);
+
+    // ---- A staging: thread -> (patch cell, group of 8 channels); cells of a 16-group are dealt 0,4,8,12,1,5,... so that the four
+    // cells a 16-byte LDS store instruction serves per clock start 16 banks apart
+    unsigned a_off[A_PASS];            // byte offset of the cell's channel 0 (0xffffffff: outside the image / no such cell)
+    int a_cell[A_PASS];
+#pragma unroll
+    for (int i = 0; i < A_PASS; ++i) {
+        const int idx = t + NT * i, praw = idx >> 2;
+        const int p = (praw & ~15) | ((praw & 3) << 2) | ((praw >> 2) & 3);
+        const int hy = p / PW, hx = p - hy * PW;
+        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const bool ok = idx < A_ITEMS && p < HP && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
+        a_cell[i] = (idx < A_ITEMS && p < HP) ? p : -1;
+        a_off[i] = ok ? (unsigned)(((img * g.H + iy) * g.W + ix) * Cred) * 4u : 0xffffffffu;
+    }
+    const int c8 = (t & 3) * 8;        // NT is a multiple of 4: the channel group does not depend on the pass
+    float4 ra[A_PASS][2];
+    auto load_a = [&](int cc) {
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            const int c = cc * CK + c8;
+            const bool in = a_off[i] != 0xffffffffu;
+            ra[i][0] = buf_load4(a_rsrc, (in && c < Cred) ? a_off[i] + (unsigned)c * 4u : 0xffffffffu);
+            ra[i][1] = buf_load4(a_rsrc, (in && c + 4 < Cred) ? a_off[i] + (unsigned)(c + 4) * 4u : 0xffffffffu);
+        }
+    };
+    auto store_a = [&]() {
+#pragma unroll
+        for (int i = 0; i < A_PASS; ++i) {
+            if (a_cell[i] < 0) continue;
+            const Split4 s0 = split3(ra[i][0]), s1 = split3(ra[i][1]);
+#pragma unroll
+            for (int tmn = 0; tmn < 3; ++tmn) {
+                u32x4 v;
+                v.x = s0.t[tmn].x; v.y = s0.t[tmn].y; v.z = s1.t[tmn].x; v.w = s1.t[tmn].y;
+                *reinterpret_cast<u32x4 *>(&Ah[tmn][a_cell[i]][c8]) = v;
+            }
+        }
+    };
+
+    // ---- B fragments: lane = (column n = lane & 31, reduction half kg = lane >> 5): 8 consecutive reduction channels.  The
+    // per-lane part of the address is formed once; chunk, tap and step enter as a scalar offset.  No masks along the reduction:
+    // beyond the last channel the A planes hold zeros and the filter values read there are finite (or 0 past the tensor's end).
+    const int col = n0 + wn * 32 + (lane & 31), kg = lane >> 5;
+    const bool colv = col < Ncols;
+    const unsigned b_lane = !colv ? 0xffffffffu : MODE == 0 ? (unsigned)(col * 9 * g.C + kg * 8) * 4u : (unsigned)(kg * 8 * 9 * g.C + col) * 4u;
+    // (fetching a whole filter row ahead instead of one tap was measured: 40-70 more registers, 3 % slower over the config-B layers)
+    float rb[KSW][8];
+    auto load_b = [&](int cc, int rs) {
+#pragma unroll
+        for (int q = 0; q < KSW; ++q) {
+            const int ks = WK == 2 ? wk : q;
+            if (MODE == 0) {
+                const int so = __builtin_amdgcn_readfirstlane((rs * g.C + cc * CK + ks * 16) * 4);
+                const i32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_lane, so, 0);
+                const i32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_lane, so + 16, 0);
+                rb[q][0] = __int_as_float(v0.x); rb[q][1] = __int_as_float(v0.y); rb[q][2] = __int_as_float(v0.z); rb[q][3] = __int_as_float(v0.w);
+                rb[q][4] = __int_as_float(v1.x); rb[q][5] = __int_as_float(v1.y); rb[q][6] = __int_as_float(v1.z); rb[q][7] = __int_as_float(v1.w);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int so = __builtin_amdgcn_readfirstlane((((cc * CK + ks * 16 + j) * 9 + rs) * g.C) * 4);
+                    rb[q][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(w_rsrc, b_lane, so, 0));
+                }
+            }
+        }
+    };
+
+    f32x16 acc[WS];
+#pragma unroll
+    for (int i = 0; i < WS; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    // A fragment of row m = lane & 31 of sub-tile i: patch cell (2i + (m >> 4) + dy, (m & 15) + dx), channels ks*16 + kg*8 ..
+    const int frag_base = ((2 * WS * wmi + ((lane & 31) >> 4)) * PW + (lane & 15)) * LDH + kg * 8;       // in bf16 units
+
+    if (c_beg < c_end) {
+        load_a(c_beg);
+        load_b(c_beg, 0);
+    }
+    for (int cc = c_beg; cc < c_end; ++cc) {
+        __syncthreads();                                  // the previous chunk's fragments have been read
+        store_a();
+        __syncthreads();
+        if (cc + 1 < c_end) load_a(cc + 1);               // in flight during the nine taps
+#pragma unroll 1
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int rs = r * 3 + s;
+                u32x4 bh[KSW][3];
+#pragma unroll
+                for (int q = 0; q < KSW; ++q) {
+                    const Split4 s0 = split3(make_float4(rb[q][0], rb[q][1], rb[q][2], rb[q][3]));
+                    const Split4 s1 = split3(make_float4(rb[q][4], rb[q][5], rb[q][6], rb[q][7]));
+#pragma unroll
+                    for (int tmn = 0; tmn < 3; ++tmn) {
+                        bh[q][tmn].x = s0.t[tmn].x; bh[q][tmn].y = s0.t[tmn].y; bh[q][tmn].z = s1.t[tmn].x; bh[q][tmn].w = s1.t[tmn].y;
+                    }
+                }
+                if (rs < 8) load_b(cc, rs + 1);
+                else if (cc + 1 < c_end) load_b(cc + 1, 0);
+                const int dy = MODE == 0 ? r : 2 - r, dx = MODE == 0 ? s : 2 - s;
+                const unsigned short *tap = &Ah[0][0][0] + frag_base + (dy * PW + dx) * LDH;
+#pragma unroll
+                for (int q = 0; q < KSW; ++q) {
+                    const int ks = WK == 2 ? wk : q;
+#pragma unroll
+                    for (int i = 0; i < WS; ++i) {
+                        const unsigned short *ap = tap + (2 * i * PW) * LDH + ks * 16;
+                        const u32x4 a0 = *reinterpret_cast<const u32x4 *>(ap);
+                        const u32x4 a1 = *reinterpret_cast<const u32x4 *>(ap + HPP * LDH);
+                        const u32x4 a2 = *reinterpret_cast<const u32x4 *>(ap + 2 * HPP * LDH);
+                        f32x16 c = acc[i];
+                        c = mfma_bf(a0, bh[q][2], c);          // smallest terms first
+                        c = mfma_bf(a2, bh[q][0], c);
+                        c = mfma_bf(a1, bh[q][1], c);
+                        c = mfma_bf(a0, bh[q][1], c);
+                        c = mfma_bf(a1, bh[q][0], c);
+                        acc[i] = mfma_bf(a0, bh[q][0], c);
+                    }
+                }
+            }
+        }
+    }
+
+    // ---- WK = 2: the upper waves hand their accumulators over through the (now idle) patch planes
+    if (WK == 2) {
+        float *xch = reinterpret_cast<float *>(&Ah[0][0][0]);
+        __syncthreads();
+        if (wk == 1) {
+#pragma unroll
+            for (int i = 0; i < WS; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) xch[(((wmi * WN + wn) * WS + i) * 16 + e) * 64 + lane] = acc[i][e];
+        }
+        __syncthreads();
+        if (wk == 0) {
+#pragma unroll
+            for (int i = 0; i < WS; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[i][e] += xch[(((wmi * WN + wn) * WS + i) * 16 + e) * 64 + lane];
+        }
+    }
+    const bool writer = WK == 1 || wk == 0;               // (every wave stays for the barriers below)
+
+    // ---- epilogue (C/D layout of the 32x32 MFMA: column = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5))
+    const int h = lane >> 5;
+    const unsigned out_rows = (unsigned)(g.N * g.H * g.W);
+    const unsigned out_bytes = out_rows * (unsigned)Ncols * 4u;
+    const __amdgpu_buffer_rsrc_t dst_r = make_rsrc(out + (size_t)blockIdx.z * out_rows * Ncols, out_bytes);
+    const bool has_add = MODE == 1 && bias != nullptr && zsplits == 1;
+    const __amdgpu_buffer_rsrc_t add_r = make_rsrc(has_add ? bias : out, has_add ? out_bytes : 0u);
+    const float bv = (MODE == 0 && bias && zsplits == 1 && colv) ? bias[col] : 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    if (writer) {
+#pragma unroll
+    for (int i = 0; i < WS; ++i) {
+        unsigned off[16];
+        float addv[16];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int ml = (wmi * WS + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int y = y0 + (ml >> 4), x = x0 + (ml & 15);
+            const bool ok = colv && y < g.H && x < g.W;
+            off[e] = ok ? ((unsigned)((img * g.H + y) * g.W + x) * (unsigned)Ncols + (unsigned)col) * 4u : 0xffffffffu;
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) addv[e] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(add_r, off[e], 0, 0));
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float v = acc[i][e] + bv;
+            if (MODE == 1) v += addv[e];
+            if (MODE == 0 && act == 1 && zsplits == 1) v = v > 0.f ? v : 0.f;
+            if (MODE == 0 && act == 2 && zsplits == 1) v = v > 0.f ? v : 0.01f * v;
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), dst_r, off[e], 0, 0);
+            if (MODE == 0) {
+                const float vs = off[e] != 0xffffffffu ? v : 0.f;
+                s1 += vs;
+                s2 = fmaf(vs, vs, s2);
+            }
+        }
+    }
+    }
+    if (MODE == 0 && stats != nullptr && zsplits == 1) {      // BatchNorm partials of this patch: stats[patch][K][2]
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        if (WM > 1) {                                         // the waves stacked along the pixels add up in wave order
+            float *sx = reinterpret_cast<float *>(&Ah[0][0][0]) + (WK == 2 ? WM * WN * WS * 16 * 64 : 0);
+            __syncthreads();                                  // the patch planes are idle (WK == 1: all fragments have been read)
+            if (writer && h == 0) {
+                sx[((wmi * WN + wn) * 32 + (lane & 31)) * 2] = s1;
+                sx[((wmi * WN + wn) * 32 + (lane & 31)) * 2 + 1] = s2;
+            }
+            __syncthreads();
+            s1 = 0.f; s2 = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WM; ++w2) {
+                s1 += sx[((w2 * WN + wn) * 32 + (lane & 31)) * 2];
+                s2 += sx[((w2 * WN + wn) * 32 + (lane & 31)) * 2 + 1];
+            }
+        }
+        if (writer && wmi == 0 && h == 0 && colv) {
+            float *o = stats + ((size_t)tm * Ncols + col) * 2;
+            o[0] = s1;
+            o[1] = s2;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // wgrad: one workgroup per (k-tile, c-tile, pixel split, filter tap).  Both operands are transposed on
 // their way into LDS (rows = channels, 16 pixels of reduction per slice).
 // part[split][k][r][s][c] partial sums; a second kernel adds the splits (deterministic).
@@ -1199,6 +1452,7 @@ struct GemmPlan {
     int waves = 4;                  // wavefronts per workgroup: 4, or 8 on the >= 128x64 tiles (one 32x32 tile per wave)
     int single = 0;                 // 1: single-buffered LDS variant (bk + 512 in sqd_conv_set_plan)
     int split3 = 0;                 // 1: three-term bf16 operands on the bf16 matrix cores, single LDS buffer, 32-channel slices (bk + 1024)
+    int halo = 0;                   // 1: conv3x3_halo_kernel (bk + 2048; 3x3 / stride 1 / pad 1 only): bm = pixels of a patch, bn = channels of a tile
     int64_t ws_floats;
 };
 // measured plans registered through sqd_conv_set_plan: (mode, geometry) -> (bm, bn, z)
@@ -1271,10 +1525,12 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
             p.waves = (std::get<3>(it->second) & 256) ? 8 : 4;
             p.single = (std::get<3>(it->second) & 512) ? 1 : 0;
             p.split3 = (std::get<3>(it->second) & 1024) ? 1 : 0;
+            p.halo = (std::get<3>(it->second) & 2048) ? 1 : 0;
         }
     }
     int z = p.z;
-    if (p.bk >= 32) z = z <= T / (p.bk / 8) ? z : 1;             // (slices are 2x / 4x as wide)
+    if (p.halo) z = z <= ((mode == 0 ? g.C : g.K) + 31) / 32 ? z : 1;          // split over 32-channel chunks
+    else if (p.bk >= 32) z = z <= T / (p.bk / 8) ? z : 1;        // (slices are 2x / 4x as wide)
     p.z = z;
     p.ws_floats = z > 1 ? (int64_t)z * Mrows * Ncols : 0;
     return p;
@@ -1289,8 +1545,19 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT, 0>),                                              \
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(512), 0, st, \
                        a_src, w, bias, dst, g, act, p.z, order, stats)
+#define LAUNCH_HALO(MODE, WTM, WM, WN, WK)                                                                                 \
+    hipLaunchKernelGGL((conv3x3_halo_kernel<MODE, WTM, WM, WN, WK>),                                                         \
+                       dim3(g.N * ((g.H + 2 * WTM - 1) / (2 * WTM)) * ((g.W + 15) / 16) * ((Ncols + WN * 32 - 1) / (WN * 32)), 1, p.z), \
+                       dim3(WM * WN * WK * 64), 0, st, a_src, w, bias, dst, g, act, p.z, stats)
 #define DISPATCH_GEMM(MODE)                                                      \
-    if (p.split3) {                                                              \
+    if (p.halo) {                                                                \
+        if (p.bm == 128 && p.bn == 128) LAUNCH_HALO(MODE, 4, 1, 4, 1);           \
+        else if (p.bm == 128 && p.bn == 64) LAUNCH_HALO(MODE, 4, 1, 2, 2);       \
+        else if (p.bm == 128) LAUNCH_HALO(MODE, 4, 2, 1, 2);                     \
+        else if (p.bn == 128) LAUNCH_HALO(MODE, 2, 1, 4, 1);                     \
+        else if (p.bn == 64) LAUNCH_HALO(MODE, 2, 1, 2, 2);                      \
+        else LAUNCH_HALO(MODE, 2, 2, 1, 2);                                      \
+    } else if (p.split3) {                                                              \
         if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM_P(MODE, 128, 128, 2, 2, 32, 4);      \
         else if (p.bm == 128 && p.bn == 32) LAUNCH_GEMM_P(MODE, 128, 32, 4, 1, 32, 4);   \
         else if (p.bm == 128) LAUNCH_GEMM_P(MODE, 128, 64, 2, 2, 32, 4);         \
@@ -1392,7 +1659,19 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     const int waves = (bk & 256) ? 8 : 4;                        // bk + 256: 8-wave workgroups (one 32x32 tile per wave)
     const int single = (bk & 512) ? 1 : 0;                       // bk + 512: single-buffered LDS (twice the resident workgroups)
     const int split3 = (bk & 1024) ? 1 : 0;                      // bk + 1024: three-term bf16 operands (fp32-level accuracy on the bf16 matrix cores)
+    const int halo = (bk & 2048) ? 1 : 0;                        // bk + 2048: the input-patch kernel for 3x3 / stride 1 / pad 1 (three-term bf16 operands)
     bk &= 255;
+    if (halo) {
+        const int Cr = mode == 0 ? C : K;
+        SQD_CHECK_ARG(split3 && waves == 4 && !single && bk == 32, "sqd_conv_set_plan: the input-patch plans are bk = 32 + 1024 + 2048");
+        SQD_CHECK_ARG(R == 3 && S == 3 && stride == 1 && pad == 1 && Ho == H && Wo == W, "sqd_conv_set_plan: the input-patch kernel is 3x3 / stride 1 / pad 1 only");
+        SQD_CHECK_ARG((bm == 128 || bm == 64) && (bn == 128 || bn == 64 || bn == 32) && !(bn > 32 && bn >= 2 * Ncols) && !(bn == 32 && Ncols > 32),
+                      "sqd_conv_set_plan: input-patch tiles are 128|64 pixels x 128|64|32 channels");
+        const int64_t oe = (int64_t)N * H * W * Ncols;
+        SQD_CHECK_ARG(z >= 1 && z <= 64 && (z == 1 || (z <= (Cr + 31) / 32 && z * oe * 4 <= (64ll << 20) && oe % 4 == 0)), "sqd_conv_set_plan: split %d not possible here", z);
+        plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, 32 | 1024 | 2048);
+        return SQD_OK;
+    }
     if (split3) {
         SQD_CHECK_ARG(waves == 4 && !single && bk == 32 && (((bm == 128 || bm == 64) && (bn == 128 || bn == 64)) || (bm == 128 && bn == 32)),
                       "sqd_conv_set_plan: the three-term bf16 variants are 4-wave 128/64 x 128/64 and 128x32 tiles with 32-channel slices");
@@ -1441,6 +1720,7 @@ extern "C" int sqd_conv_fwd_stats_rows(int N, int H, int W, int C, int K, int R,
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     const GemmPlan p = plan_gemm(0, g);
     if (p.z > 1) return 0;
+    if (p.halo) return N * ((H + p.bm / 16 - 1) / (p.bm / 16)) * ((W + 15) / 16);     // one row of partials per patch
     return (N * Ho * Wo + p.bm - 1) / p.bm;
 }
 

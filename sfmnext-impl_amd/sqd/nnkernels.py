@@ -190,8 +190,11 @@ def _tune_conv(mode, geom, launch):
     # gain on the totals — SQD_TUNE_BK64=1 adds it)
     # bk 32 + 1024 = three-term bf16 operands on the bf16 matrix cores (fp32-level accuracy, 6 products per slice at 16x the fp32
     # MFMA rate, single LDS buffer): 20-30 % faster than the fp32 kernels on most config-B layers (profiles/r02e_conv_split3.md)
-    bks = (16, 32, 528, 544, 1056) + ((576,) if os.environ.get("SQD_TUNE_BK64") else ()) + ((272, 288) if os.environ.get("SQD_TUNE_8WAVE") else ())
-    for bm, bn, z, bk in ((bm, bn, z, bk) for bm, bn in _TUNE_TILES for bk in bks for z in _TUNE_Z):
+    # bk 32 + 1024 + 2048 = the input-patch kernel for 3x3 / stride 1 / pad 1 (three-term bf16 operands; the input patch of a
+    # 32-channel chunk is converted and staged once for all nine taps, the filter fragments come straight from L2): 20-40 % faster
+    # than the implicit-GEMM plans on the config-B layers above 12x40 pixels (profiles/r02i_conv_input_patch.md)
+    bks = (16, 32, 528, 544, 1056, 3104) + ((576,) if os.environ.get("SQD_TUNE_BK64") else ()) + ((272, 288) if os.environ.get("SQD_TUNE_8WAVE") else ())
+    for bm, bn, z, bk in ((bm, bn, z, bk) for bm, bn in _TUNE_TILES + ((64, 32),) for bk in bks for z in _TUNE_Z):
         if True:
             if L.sqd_conv_set_plan(mode, *geom, bm, bn, z, bk) != 0:
                 continue

@@ -349,3 +349,91 @@ def test_wgrad_plan_shared_by_output_geometry():
     finally:
         L.sqd_conv_wgrad_set_plan(N, 24, 40, C, K, R, R, -1, 0)
         nnkernels._PLAN_CACHE.clear()
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(2, 64, 24, 40, 64), (1, 40, 9, 11, 96), (3, 72, 17, 33, 200), (2, 256, 6, 20, 128), (1, 8, 5, 50, 64), (2, 32, 20, 36, 16),
+                                       (1, 16, 9, 40, 32), (2, 96, 13, 16, 24)])
+def test_input_patch_plans(N, C, H, W, K):
+    """The 3x3 / stride 1 / pad 1 kernel that stages the input patch once per channel chunk (bk = 32 + 1024 + 2048): every patch /
+    channel-tile shape and channel split against float64 — forward with bias, the data gradient with the second gradient added in
+    its epilogue, image sizes that leave partial patches, channel counts that leave partial chunks and partial channel tiles."""
+    from sqd import lib, nnkernels
+    L = lib.lib()
+    torch.manual_seed(C + K)
+    conv = nn.Conv2d(C, K, 3, 1, 1, bias=True).cuda().to(memory_format=torch.channels_last)
+    x = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
+    geom = (N, H, W, C, K, 3, 3, 1, 1, H, W)
+    conv64 = nn.Conv2d(C, K, 3, 1, 1, bias=True).cuda().double()
+    conv64.load_state_dict(conv.state_dict())
+    xr = x.double().requires_grad_(True)
+    yr = conv64(xr)
+    gy = torch.randn_like(yr)
+    gskip = torch.randn_like(xr)
+    gxr, = torch.autograd.grad(yr, xr, gy)
+    gxr = gxr + gskip
+    tried = 0
+    try:
+        for bm in (128, 64):
+            for bn in (128, 64, 32):
+                for z in (1, 2, 3):
+                    ok = [L.sqd_conv_set_plan(mode, *geom, bm, bn, z, 32 + 1024 + 2048) == 0 for mode in (0, 1)]
+                    if not any(ok):
+                        continue
+                    for mode in (0, 1):
+                        if not ok[mode]:
+                            L.sqd_conv_set_plan(mode, *geom, 0, 0, 0, 16)
+                    nnkernels._PLAN_CACHE.clear()
+                    xg = x.clone().requires_grad_(True)
+                    y, xs = nnkernels.conv2d_native(xg, conv, None, True)
+                    gx, = torch.autograd.grad((y, xs), xg, (gy.float(), gskip.float()))
+                    tried += 1
+                    ey = float((y.detach().double() - yr.detach()).abs().max()) / float(yr.abs().max())
+                    ex = float((gx.double() - gxr).abs().max()) / float(gxr.abs().max())
+                    assert ey <= 4e-6 and ex <= 4e-6, (bm, bn, z, ok, ey, ex)
+    finally:
+        for mode in (0, 1):
+            L.sqd_conv_set_plan(mode, *geom, 0, 0, 0, 16)
+        nnkernels._PLAN_CACHE.clear()
+    assert tried >= 2
+    assert L.sqd_conv_set_plan(0, N, H, W, C, K, 3, 3, 2, 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 128, 64, 1, 32 + 1024 + 2048) != 0    # stride 2: refused
+
+
+def test_input_patch_plan_feeds_batchnorm_statistics():
+    """conv -> BatchNorm(train) -> ReLU with the per-patch statistics partials of the input-patch kernel"""
+    from sqd import lib, nnkernels, nnops
+    L = lib.lib()
+    N, C, H, W, K = 3, 64, 21, 37, 96
+    torch.manual_seed(5)
+    conv, bn = nn.Conv2d(C, K, 3, 1, 1, bias=False), nn.BatchNorm2d(K)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(N, C, H, W)
+    conv_g, bn_g = nn.Conv2d(C, K, 3, 1, 1, bias=False).cuda(), nn.BatchNorm2d(K).cuda()
+    conv_g.load_state_dict(conv.state_dict())
+    bn_g.load_state_dict(bn.state_dict())
+    conv_g = conv_g.to(memory_format=torch.channels_last)
+    conv, bn = conv.double(), bn.double()
+    xr = x.double().requires_grad_(True)
+    yr = F.relu(bn(conv(xr)))
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    geom = (N, H, W, C, K, 3, 3, 1, 1, H, W)
+    nnops.set_native_conv(True)
+    try:
+        for bm, bn_t in ((128, 64), (64, 128), (128, 128)):
+            assert L.sqd_conv_set_plan(0, *geom, bm, bn_t, 1, 32 + 1024 + 2048) == 0
+            nnkernels._PLAN_CACHE.clear()
+            bn_g.load_state_dict({k: v.float() for k, v in nn.BatchNorm2d(K).state_dict().items()} | {"weight": bn.weight.float(), "bias": bn.bias.float()})
+            xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            y = nnops.conv_bn_act(xg, conv_g, bn_g, "relu")
+            assert nnkernels.conv_stats_rows(nnkernels.conv_out_geom(xg, conv_g)) == N * ((H + bm // 16 - 1) // (bm // 16)) * ((W + 15) // 16)
+            conv_g.weight.grad = None
+            y.backward(gy.float().cuda())
+            assert torch.allclose(y.cpu().double(), yr.detach(), rtol=1e-4, atol=2e-4)
+            assert torch.allclose(bn_g.running_var.cpu().double(), bn.running_var, rtol=1e-4, atol=1e-5)
+            assert float((xg.grad.cpu().double() - xr.grad).abs().max()) <= 1e-3 * float(xr.grad.abs().max())
+    finally:
+        L.sqd_conv_set_plan(0, *geom, 0, 0, 0, 16)
+        nnkernels._PLAN_CACHE.clear()
+        nnops.set_native_conv(False)

@@ -16,7 +16,11 @@ ap.add_argument("--N", type=int, default=12)
 ap.add_argument("--only", default="", help="comma-separated substrings of layer names")
 ap.add_argument("--tune", action="store_true", help="time the registered plans per layer first (what the Trainer's first step does)")
 ap.add_argument("--split3", action="store_true", help="also time the three-term bf16 plans (bk + 1024) per layer: best tile / split-K")
+ap.add_argument("--halo", action="store_true", help="like --split3 for the input-patch plans (bk + 1024 + 2048; 3x3 / stride 1 / pad 1 layers only)")
 args = ap.parse_args()
+if args.halo:
+    args.split3 = True
+PLAN_FLAG = 32 + 1024 + (2048 if args.halo else 0)
 N = args.N
 L = [  # name, C, H, W, K, R, stride, pad, count (occurrences per forward)
     ("l1 1x1 64->64", 64, 48, 160, 64, 1, 1, 0, 1), ("l1 3x3 64->64", 64, 48, 160, 64, 3, 1, 1, 3),
@@ -65,6 +69,8 @@ print("%-22s %7s | %7s %7s | %7s %7s | %7s %7s   (us per launch, C-ABI called ba
 for name, C, H, W, K, R, st, pad, cnt in L:
     if args.only and not any(k in name for k in args.only.split(",")):
         continue
+    if args.halo and not (R == 3 and st == 1 and pad == 1 and C % 4 == 0 and K % 4 == 0):
+        continue
     conv = nn.Conv2d(C, K, R, st, pad, bias=False).cuda().to(memory_format=torch.channels_last)
     x = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
     w = conv.weight.detach()
@@ -91,9 +97,9 @@ for name, C, H, W, K, R, st, pad, cnt in L:
         for mode, run in ((0, lambda ws: LIB.sqd_conv_fwd(P(x), P(w), None, P(y), P(ws), None, *geom, 0, ST())),
                           (1, lambda ws: LIB.sqd_conv_dgrad(P(dy), P(w), None, P(dx), P(ws), *geom, ST()))):
             best = None
-            for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64), (128, 32)):
+            for bm, bn in ((128, 128), (128, 64), (64, 128), (64, 64), (128, 32), (64, 32)):
                 for z in (1, 2, 3, 4, 6, 8):
-                    if LIB.sqd_conv_set_plan(mode, *geom, bm, bn, z, 32 + 1024) != 0:
+                    if LIB.sqd_conv_set_plan(mode, *geom, bm, bn, z, PLAN_FLAG) != 0:
                         continue
                     nnkernels._PLAN_CACHE.pop((mode,) + tuple(geom), None)
                     ws = nnkernels._conv_ws(mode, geom, x.device)
