@@ -517,7 +517,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
 // reduction over k, tap (r,s) reads (ty+2-r, tx+2-s)).
 // ---------------------------------------------------------------------------------------------------
 template <int MODE, int WTM, int WM, int WN, int WK>
-__global__ __launch_bounds__(WM * WN * WK * 64, (WTM / WM >= 4 ? 2 : 3)) void conv3x3_halo_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
+__global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 2 : 3)) void conv3x3_halo_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
                                                                     const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
                                                                     int act, int zsplits, float *__restrict__ stats) {
     constexpr int TH = 2 * WTM, TW = 16, PW = TW + 2, PH = TH + 2, HP = PH * PW;     // output patch, input patch (+1 on every side)
@@ -585,28 +585,32 @@ __global__ __launch_bounds__(WM * WN * WK * 64, (WTM / WM >= 4 ? 2 : 3)) void co
     };
 
     // ---- B fragments: lane = (column n = lane & 31, reduction half kg = lane >> 5): 8 consecutive reduction channels.  The
-    // per-lane part of the address is formed once; chunk, tap and step enter as a scalar offset.  No masks along the reduction:
-    // beyond the last channel the A planes hold zeros and the filter values read there are finite (or 0 past the tensor's end).
+    // per-lane part of the address is formed once; chunk, tap and step enter as a scalar offset.
     const int col = n0 + wn * 32 + (lane & 31), kg = lane >> 5;
     const bool colv = col < Ncols;
     const unsigned b_lane = !colv ? 0xffffffffu : MODE == 0 ? (unsigned)(col * 9 * g.C + kg * 8) * 4u : (unsigned)(kg * 8 * 9 * g.C + col) * 4u;
-    // (fetching a whole filter row ahead instead of one tap was measured: 40-70 more registers, 3 % slower over the config-B layers)
-    float rb[KSW][8];
-    auto load_b = [&](int cc, int rs) {
+    // Fragments are fetched two taps ahead into a ring of three register sets (a tap is 12-48 MFMAs, 0.2-0.7 us: one tap ahead
+    // leaves most of an L2 round trip exposed — with the loads removed the config-B layers ran 25 % faster; a whole filter row ahead
+    // costs 40-70 more registers and was 3 % slower).
+    float rb[3][KSW][8];
+    auto load_b = [&](float (&dst)[KSW][8], int cc, int rs) {
 #pragma unroll
         for (int q = 0; q < KSW; ++q) {
             const int ks = WK == 2 ? wk : q;
+            // (the scalar offset does not take part in the descriptor's range check: channels beyond the last one — only in a
+            // partial last chunk — are masked per lane; elsewhere the A planes' zeros meet finite filter values)
+            const int c_lane = cc * CK + ks * 16 + kg * 8;
             if (MODE == 0) {
                 const int so = __builtin_amdgcn_readfirstlane((rs * g.C + cc * CK + ks * 16) * 4);
-                const i32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_lane, so, 0);
-                const i32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, b_lane, so + 16, 0);
-                rb[q][0] = __int_as_float(v0.x); rb[q][1] = __int_as_float(v0.y); rb[q][2] = __int_as_float(v0.z); rb[q][3] = __int_as_float(v0.w);
-                rb[q][4] = __int_as_float(v1.x); rb[q][5] = __int_as_float(v1.y); rb[q][6] = __int_as_float(v1.z); rb[q][7] = __int_as_float(v1.w);
+                const i32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, c_lane < Cred ? b_lane : 0xffffffffu, so, 0);
+                const i32x4 v1 = __builtin_amdgcn_raw_buffer_load_b128(w_rsrc, c_lane + 4 < Cred ? b_lane : 0xffffffffu, so + 16, 0);
+                dst[q][0] = __int_as_float(v0.x); dst[q][1] = __int_as_float(v0.y); dst[q][2] = __int_as_float(v0.z); dst[q][3] = __int_as_float(v0.w);
+                dst[q][4] = __int_as_float(v1.x); dst[q][5] = __int_as_float(v1.y); dst[q][6] = __int_as_float(v1.z); dst[q][7] = __int_as_float(v1.w);
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int so = __builtin_amdgcn_readfirstlane((((cc * CK + ks * 16 + j) * 9 + rs) * g.C) * 4);
-                    rb[q][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(w_rsrc, b_lane, so, 0));
+                    dst[q][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(w_rsrc, c_lane + j < Cred ? b_lane : 0xffffffffu, so, 0));
                 }
             }
         }
@@ -623,51 +627,50 @@ __global__ __launch_bounds__(WM * WN * WK * 64, (WTM / WM >= 4 ? 2 : 3)) void co
 
     if (c_beg < c_end) {
         load_a(c_beg);
-        load_b(c_beg, 0);
+        load_b(rb[0], c_beg, 0);
+        load_b(rb[1], c_beg, 1);
     }
     for (int cc = c_beg; cc < c_end; ++cc) {
         __syncthreads();                                  // the previous chunk's fragments have been read
         store_a();
         __syncthreads();
         if (cc + 1 < c_end) load_a(cc + 1);               // in flight during the nine taps
-#pragma unroll 1
-        for (int r = 0; r < 3; ++r) {
 #pragma unroll
-            for (int s = 0; s < 3; ++s) {
-                const int rs = r * 3 + s;
-                u32x4 bh[KSW][3];
+        for (int rs = 0; rs < 9; ++rs) {
+            const int r = rs / 3, s = rs - 3 * r;
+            u32x4 bh[KSW][3];
 #pragma unroll
-                for (int q = 0; q < KSW; ++q) {
-                    const Split4 s0 = split3(make_float4(rb[q][0], rb[q][1], rb[q][2], rb[q][3]));
-                    const Split4 s1 = split3(make_float4(rb[q][4], rb[q][5], rb[q][6], rb[q][7]));
+            for (int q = 0; q < KSW; ++q) {
+                const Split4 s0 = split3(make_float4(rb[rs % 3][q][0], rb[rs % 3][q][1], rb[rs % 3][q][2], rb[rs % 3][q][3]));
+                const Split4 s1 = split3(make_float4(rb[rs % 3][q][4], rb[rs % 3][q][5], rb[rs % 3][q][6], rb[rs % 3][q][7]));
 #pragma unroll
-                    for (int tmn = 0; tmn < 3; ++tmn) {
-                        bh[q][tmn].x = s0.t[tmn].x; bh[q][tmn].y = s0.t[tmn].y; bh[q][tmn].z = s1.t[tmn].x; bh[q][tmn].w = s1.t[tmn].y;
-                    }
-                }
-                if (rs < 8) load_b(cc, rs + 1);
-                else if (cc + 1 < c_end) load_b(cc + 1, 0);
-                const int dy = MODE == 0 ? r : 2 - r, dx = MODE == 0 ? s : 2 - s;
-                const unsigned short *tap = &Ah[0][0][0] + frag_base + (dy * PW + dx) * LDH;
-#pragma unroll
-                for (int q = 0; q < KSW; ++q) {
-                    const int ks = WK == 2 ? wk : q;
-#pragma unroll
-                    for (int i = 0; i < WS; ++i) {
-                        const unsigned short *ap = tap + (2 * i * PW) * LDH + ks * 16;
-                        const u32x4 a0 = *reinterpret_cast<const u32x4 *>(ap);
-                        const u32x4 a1 = *reinterpret_cast<const u32x4 *>(ap + HPP * LDH);
-                        const u32x4 a2 = *reinterpret_cast<const u32x4 *>(ap + 2 * HPP * LDH);
-                        f32x16 c = acc[i];
-                        c = mfma_bf(a0, bh[q][2], c);          // smallest terms first
-                        c = mfma_bf(a2, bh[q][0], c);
-                        c = mfma_bf(a1, bh[q][1], c);
-                        c = mfma_bf(a0, bh[q][1], c);
-                        c = mfma_bf(a1, bh[q][0], c);
-                        acc[i] = mfma_bf(a0, bh[q][0], c);
-                    }
+                for (int tmn = 0; tmn < 3; ++tmn) {
+                    bh[q][tmn].x = s0.t[tmn].x; bh[q][tmn].y = s0.t[tmn].y; bh[q][tmn].z = s1.t[tmn].x; bh[q][tmn].w = s1.t[tmn].y;
                 }
             }
+            if (rs < 7) load_b(rb[(rs + 2) % 3], cc, rs + 2);
+            else if (cc + 1 < c_end) load_b(rb[(rs + 2) % 3], cc + 1, rs - 7);
+            const int dy = MODE == 0 ? r : 2 - r, dx = MODE == 0 ? s : 2 - s;
+            const unsigned short *tap = &Ah[0][0][0] + frag_base + (dy * PW + dx) * LDH;
+#pragma unroll
+            for (int q = 0; q < KSW; ++q) {
+                const int ks = WK == 2 ? wk : q;
+#pragma unroll
+                for (int i = 0; i < WS; ++i) {
+                    const unsigned short *ap = tap + (2 * i * PW) * LDH + ks * 16;
+                    const u32x4 a0 = *reinterpret_cast<const u32x4 *>(ap);
+                    const u32x4 a1 = *reinterpret_cast<const u32x4 *>(ap + HPP * LDH);
+                    const u32x4 a2 = *reinterpret_cast<const u32x4 *>(ap + 2 * HPP * LDH);
+                    f32x16 c = acc[i];
+                    c = mfma_bf(a0, bh[q][2], c);          // smallest terms first
+                    c = mfma_bf(a2, bh[q][0], c);
+                    c = mfma_bf(a1, bh[q][1], c);
+                    c = mfma_bf(a0, bh[q][1], c);
+                    c = mfma_bf(a1, bh[q][0], c);
+                    acc[i] = mfma_bf(a0, bh[q][0], c);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);            // keep the taps apart: hoisting the next tap's reads costs 60+ registers
         }
     }
 
@@ -906,6 +909,43 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(const float *__restri
         __syncthreads();
     }
     if (grp == 0 && i < n / 4) reinterpret_cast<float4 *>(out)[i] = a;
+}
+
+// The same reduction for up to 48 (partials, output) pairs in one launch: the weight gradients of a backward pass have no consumer
+// before the optimiser, so their ~100 reductions (7 us each, mostly launch latency) can run as two or three launches at its end.
+// Per element the order of the additions is split_reduce_kernel's.
+struct ReduceTasks {
+    const float *part[48];
+    float *out[48];
+    unsigned n4[48], splits[48], blk0[49];            // float4 columns, partial count, first workgroup of each task
+    int ntasks;
+};
+__global__ __launch_bounds__(256) void split_reduce_multi_kernel(const ReduceTasks T) {
+    __shared__ float4 red[16][16];
+    int k = 0;
+    while (k + 1 < T.ntasks && blockIdx.x >= T.blk0[k + 1]) ++k;
+    const float *__restrict__ part = T.part[k];
+    const size_t n4 = T.n4[k];
+    const int splits = (int)T.splits[k];
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const size_t i = (size_t)(blockIdx.x - T.blk0[k]) * 16 + col;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4)
+        for (int s = grp; s < splits; s += 16) {
+            const float4 b = reinterpret_cast<const float4 *>(part + (size_t)s * n4 * 4)[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+    red[grp][col] = a;
+    __syncthreads();
+    for (int w = 8; w >= 1; w >>= 1) {
+        if (grp < w) {
+            const float4 b = red[grp + w][col];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            red[grp][col] = a;
+        }
+        __syncthreads();
+    }
+    if (grp == 0 && i < n4) reinterpret_cast<float4 *>(T.out[k])[i] = a;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1715,7 +1755,8 @@ extern "C" int sqd_conv_plan(int mode, int N, int H, int W, int C, int K, int R,
 
 // Rows of BatchNorm partials sqd_conv_fwd writes into `stats` for this geometry under the current plan ([rows][K][2] floats:
 // per-channel sum and sum of squares of a tile of output rows, the layout sqd_bn_train_fwd's finalize reads): ceil(M / tile
-// rows), or 0 when the plan splits the reduction (the statistics are then not produced; at most ceil(M/64) rows otherwise).
+// rows), or 0 when the plan splits the reduction (the statistics are then not produced); the input-patch plans write one row per
+// patch.  Never more than max(ceil(M/64), N * ceil(Ho/4) * ceil(Wo/16)) rows: size `stats` for that when the plan may still change.
 extern "C" int sqd_conv_fwd_stats_rows(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo) {
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     const GemmPlan p = plan_gemm(0, g);
@@ -1898,9 +1939,9 @@ extern "C" int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int 
 
 // dy [N,Ho,Wo,K], x [N,H,W,C] -> dw [K,R,S,C]; dbias [K] (may be NULL); part: workspace of sqd_conv_wgrad_plan floats
 // (+ bias scratch appended when dbias is requested: max(ceil(M/1024), splits) * K floats)
-extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C,
-                              int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream) {
-    SQD_CHECK_ARG(dy && x && dw && part, "sqd_conv_wgrad: null pointer");
+static int wgrad_impl(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C, int K, int R, int S,
+                      int stride, int pad, int Ho, int Wo, void *stream, bool reduce, int *splits_out, int *bias_in_part) {
+    SQD_CHECK_ARG(dy && x && (dw || !reduce) && part, "sqd_conv_wgrad: null pointer");
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     if (check_geom("sqd_conv_wgrad", g)) return SQD_EINVAL;
     SQD_CHECK_ARG(C % 4 == 0 && K % 4 == 0, "sqd_conv_wgrad: C=%d and K=%d must be multiples of 4", C, K);
@@ -1958,9 +1999,11 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
         else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, dy, x, part, g, pps);
     }
     const size_t wsz = (size_t)K * R * S * C;
-    hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((wsz / 4 + 15) / 16)), dim3(256), 0, st, part, dw, wsz, splits);
-    if (dbias && dp.direct) {
-        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((K / 4 + 15) / 16)), dim3(256), 0, st, part + (size_t)splits * wsz, dbias,
+    if (splits_out) *splits_out = splits;
+    if (bias_in_part) *bias_in_part = (dbias && dp.direct && !dp.shared) ? 1 : 0;
+    if (reduce) hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((wsz / 4 + 15) / 16)), dim3(256), 0, st, part, dw, wsz, splits);
+    if (dbias && dp.direct && !dp.shared) {
+        if (reduce) hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((K / 4 + 15) / 16)), dim3(256), 0, st, part + (size_t)splits * wsz, dbias,
                            (size_t)K, splits);
     } else if (dbias) {
         float *cpart = part + (size_t)splits * wsz;
@@ -1972,5 +2015,44 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
         hipLaunchKernelGGL(colsum_kernel, dim3(1, bands), dim3(256), 0, st, cpart, dbias, nblk, K, nblk, cpb);
     }
     SQD_CHECK_LAUNCH("sqd_conv_wgrad");
+    return SQD_OK;
+}
+extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C,
+                              int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream) {
+    return wgrad_impl(dy, x, dw, dbias, part, N, H, W, C, K, R, S, stride, pad, Ho, Wo, stream, true, nullptr, nullptr);
+}
+// sqd_conv_wgrad without the final reduction over the pixel splits: `part` holds [*splits][K][R][S][C] partial filter gradients
+// (followed, when *bias_in_part = 1, by [*splits][K] partial bias gradients; otherwise dbias — if requested — is final on return).
+// The caller adds them later with sqd_split_reduce_multi, many convolutions per launch; `part` must stay untouched until then.
+extern "C" int sqd_conv_wgrad_partials(const float *dy, const float *x, float *dbias, float *part, int N, int H, int W, int C, int K, int R,
+                                       int S, int stride, int pad, int Ho, int Wo, int *splits, int *bias_in_part, void *stream) {
+    SQD_CHECK_ARG(splits && bias_in_part, "sqd_conv_wgrad_partials: null pointer");
+    return wgrad_impl(dy, x, nullptr, dbias, part, N, H, W, C, K, R, S, stride, pad, Ho, Wo, stream, false, splits, bias_in_part);
+}
+// out[t][i] = sum over s < splits[t] of parts[t][s * n[t] + i] for ntasks (host arrays of device pointers / sizes; n[t] multiples of 4,
+// 16-byte aligned pointers): the reductions sqd_conv_wgrad_partials left out, 48 per launch, same order of additions per element.
+extern "C" int sqd_split_reduce_multi(const void *const *parts, void *const *outs, const int64_t *n, const int *splits, int ntasks, void *stream) {
+    SQD_CHECK_ARG(parts && outs && n && splits && ntasks > 0, "sqd_split_reduce_multi: bad arguments");
+    (void)hipGetLastError();
+    for (int t0 = 0; t0 < ntasks; t0 += 48) {
+        ReduceTasks T;
+        T.ntasks = ntasks - t0 < 48 ? ntasks - t0 : 48;
+        unsigned blk = 0;
+        for (int k = 0; k < T.ntasks; ++k) {
+            const int t = t0 + k;
+            SQD_CHECK_ARG(parts[t] && outs[t] && n[t] > 0 && n[t] % 4 == 0 && n[t] / 4 < (1ll << 32) && splits[t] >= 1 &&
+                              ((uintptr_t)parts[t] & 15) == 0 && ((uintptr_t)outs[t] & 15) == 0,
+                          "sqd_split_reduce_multi: task %d is malformed", t);
+            T.part[k] = (const float *)parts[t];
+            T.out[k] = (float *)outs[t];
+            T.n4[k] = (unsigned)(n[t] / 4);
+            T.splits[k] = (unsigned)splits[t];
+            T.blk0[k] = blk;
+            blk += (unsigned)((n[t] / 4 + 15) / 16);
+        }
+        T.blk0[T.ntasks] = blk;
+        hipLaunchKernelGGL(split_reduce_multi_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, T);
+    }
+    SQD_CHECK_LAUNCH("sqd_split_reduce_multi");
     return SQD_OK;
 }

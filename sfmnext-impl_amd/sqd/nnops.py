@@ -72,7 +72,10 @@ def _conv(x, conv, act=None, skip=False, bn_stats=None):
         if bn_stats is not None and (native or s2d):
             geom = nnkernels.conv_out_geom(x, conv, s2d)
             M, K = geom[0] * geom[9] * geom[10], geom[4]
-            stats = torch.empty(((M + 63) // 64) * K * 2, device=x.device, dtype=torch.float32)    # room for the smallest row tile
+            # room for the plan with the most rows of partials: 64-row tiles, or the input-patch kernel's 4 x 16 pixel patches
+            # (partial patches at the right / lower border make that more than M / 64)
+            rows_max = max((M + 63) // 64, geom[0] * ((geom[9] + 3) // 4) * ((geom[10] + 15) // 16))
+            stats = torch.empty(rows_max * K * 2, device=x.device, dtype=torch.float32)
         if native:
             out = nnkernels.conv2d_native(x, conv, act, skip, stats)
         elif s2d:

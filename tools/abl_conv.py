@@ -6,6 +6,16 @@ import torch
 
 L = ctypes.CDLL(sys.argv[1])
 P = lambda t: ctypes.c_void_p(t.data_ptr())
+HALO = [  # the input-patch kernel (bk 32 + 1024 + 2048)
+    ("l1 3x3 64 fwd patch 128x64", (12, 48, 160, 64, 64, 3, 1, 1), 0, (128, 64, 1, 3104)),
+    ("l1 3x3 64 fwd patch 64x64", (12, 48, 160, 64, 64, 3, 1, 1), 0, (64, 64, 1, 3104)),
+    ("l2 3x3 128 fwd patch 64x64", (12, 24, 80, 128, 128, 3, 1, 1), 0, (64, 64, 1, 3104)),
+    ("l2 3x3 128 dgrad patch 64x64", (12, 24, 80, 128, 128, 3, 1, 1), 1, (64, 64, 1, 3104)),
+    ("l3 3x3 256 fwd patch 64x64", (12, 12, 40, 256, 256, 3, 1, 1), 0, (64, 64, 1, 3104)),
+    ("up2a 640->64 fwd patch 128x64 z4", (12, 24, 80, 640, 64, 3, 1, 1), 0, (128, 64, 4, 3104)),
+    ("up3a 320->32 fwd patch 128x32", (12, 48, 160, 320, 32, 3, 1, 1), 0, (128, 32, 1, 3104)),
+    ("qtr 32 fwd patch 128x32", (12, 96, 320, 32, 32, 3, 1, 1), 0, (128, 32, 1, 3104)),
+]
 CASES = [  # name, (N,H,W,C,K,R,stride,pad), mode, (bm,bn,z,bk)
     ("l1 3x3 64 fwd 128x64", (12, 48, 160, 64, 64, 3, 1, 1), 0, (128, 64, 1, 1056)),
     ("l2 3x3 128 fwd 64x128 z2", (12, 24, 80, 128, 128, 3, 1, 1), 0, (64, 128, 2, 1056)),
@@ -16,7 +26,7 @@ CASES = [  # name, (N,H,W,C,K,R,stride,pad), mode, (bm,bn,z,bk)
     ("l2 3x3 128 dgrad 128x64 z2", (12, 24, 80, 128, 128, 3, 1, 1), 1, (128, 64, 2, 1056)),
     ("l2 3x3 128 fwd f32 64x64 bk32 single", (12, 24, 80, 128, 128, 3, 1, 1), 0, (64, 64, 1, 544)),
 ]
-for name, (N, H, W, C, K, R, st, pad), mode, plan in CASES:
+for name, (N, H, W, C, K, R, st, pad), mode, plan in (HALO if len(sys.argv) > 2 and sys.argv[2] == "patch" else CASES):
     Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
     geom = (N, H, W, C, K, R, R, st, pad, Ho, Wo)
     x = torch.randn(N, H, W, C, device="cuda")
