@@ -282,16 +282,6 @@ int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *
 int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int impl, int splits);
 int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C, int K,
                    int R, int S, int stride, int pad, int Ho, int Wo, void *stream);
-/* sqd_conv_wgrad without its final reduction over the pixel splits: `part` holds [*splits][K][R][S][C] partial filter gradients
- * (followed, when *bias_in_part = 1, by [*splits][K] partial bias gradients; otherwise dbias — if requested — is final on return);
- * `part` must stay untouched until sqd_split_reduce_multi has added them.  The weight gradients of a backward pass (autograd's
- * convolution_backward in reference trainer.py:230 `losses["loss"].backward()`) have no consumer before the optimiser, so their
- * ~100 reductions run as two or three launches at the end of the pass.                                                        */
-int sqd_conv_wgrad_partials(const float *dy, const float *x, float *dbias, float *part, int N, int H, int W, int C, int K, int R,
-                            int S, int stride, int pad, int Ho, int Wo, int *splits, int *bias_in_part, void *stream);
-/* out[t][i] = sum over s < splits[t] of parts[t][s * n[t] + i], t < ntasks: host arrays of device pointers (16-byte aligned) and
- * sizes (n[t] multiples of 4); 48 tasks per launch, per element the additions run in sqd_conv_wgrad's order.                   */
-int sqd_split_reduce_multi(const void *const *parts, void *const *outs, const int64_t *n, const int *splits, int ntasks, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * (11) adaptive-bins depth head.  replaces reference networks/depth_decoder_QTR.py:61-70 (convert_to_prob =

@@ -911,43 +911,6 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(const float *__restri
     if (grp == 0 && i < n / 4) reinterpret_cast<float4 *>(out)[i] = a;
 }
 
-// The same reduction for up to 48 (partials, output) pairs in one launch: the weight gradients of a backward pass have no consumer
-// before the optimiser, so their ~100 reductions (7 us each, mostly launch latency) can run as two or three launches at its end.
-// Per element the order of the additions is split_reduce_kernel's.
-struct ReduceTasks {
-    const float *part[48];
-    float *out[48];
-    unsigned n4[48], splits[48], blk0[49];            // float4 columns, partial count, first workgroup of each task
-    int ntasks;
-};
-__global__ __launch_bounds__(256) void split_reduce_multi_kernel(const ReduceTasks T) {
-    __shared__ float4 red[16][16];
-    int k = 0;
-    while (k + 1 < T.ntasks && blockIdx.x >= T.blk0[k + 1]) ++k;
-    const float *__restrict__ part = T.part[k];
-    const size_t n4 = T.n4[k];
-    const int splits = (int)T.splits[k];
-    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const size_t i = (size_t)(blockIdx.x - T.blk0[k]) * 16 + col;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n4)
-        for (int s = grp; s < splits; s += 16) {
-            const float4 b = reinterpret_cast<const float4 *>(part + (size_t)s * n4 * 4)[i];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        }
-    red[grp][col] = a;
-    __syncthreads();
-    for (int w = 8; w >= 1; w >>= 1) {
-        if (grp < w) {
-            const float4 b = red[grp + w][col];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-            red[grp][col] = a;
-        }
-        __syncthreads();
-    }
-    if (grp == 0 && i < n4) reinterpret_cast<float4 *>(T.out[k])[i] = a;
-}
-
 // ---------------------------------------------------------------------------------------------------
 // wgrad, operands straight from memory (no LDS staging): v_mfma_f32_16x16x4_f32 takes A[i][p] from lane
 // (i = lane%16, p = lane/16) and B[p][j] likewise, and with channels-last tensors "channel i of pixel p" for
@@ -1939,9 +1902,9 @@ extern "C" int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int 
 
 // dy [N,Ho,Wo,K], x [N,H,W,C] -> dw [K,R,S,C]; dbias [K] (may be NULL); part: workspace of sqd_conv_wgrad_plan floats
 // (+ bias scratch appended when dbias is requested: max(ceil(M/1024), splits) * K floats)
-static int wgrad_impl(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C, int K, int R, int S,
-                      int stride, int pad, int Ho, int Wo, void *stream, bool reduce, int *splits_out, int *bias_in_part) {
-    SQD_CHECK_ARG(dy && x && (dw || !reduce) && part, "sqd_conv_wgrad: null pointer");
+extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C,
+                              int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream) {
+    SQD_CHECK_ARG(dy && x && dw && part, "sqd_conv_wgrad: null pointer");
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     if (check_geom("sqd_conv_wgrad", g)) return SQD_EINVAL;
     SQD_CHECK_ARG(C % 4 == 0 && K % 4 == 0, "sqd_conv_wgrad: C=%d and K=%d must be multiples of 4", C, K);
@@ -1999,11 +1962,11 @@ static int wgrad_impl(const float *dy, const float *x, float *dw, float *dbias, 
         else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, dim3(256), 0, st, dy, x, part, g, pps);
     }
     const size_t wsz = (size_t)K * R * S * C;
-    if (splits_out) *splits_out = splits;
-    if (bias_in_part) *bias_in_part = (dbias && dp.direct && !dp.shared) ? 1 : 0;
-    if (reduce) hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((wsz / 4 + 15) / 16)), dim3(256), 0, st, part, dw, wsz, splits);
+    // (leaving the ~100 reductions of a backward pass to two or three multi-task launches at its end was measured: bit-identical and
+    // 0.7 ms SLOWER per step — reduced on the spot the partials of most layers are still in the 256 MB Infinity Cache)
+    hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((wsz / 4 + 15) / 16)), dim3(256), 0, st, part, dw, wsz, splits);
     if (dbias && dp.direct && !dp.shared) {
-        if (reduce) hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((K / 4 + 15) / 16)), dim3(256), 0, st, part + (size_t)splits * wsz, dbias,
+        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((K / 4 + 15) / 16)), dim3(256), 0, st, part + (size_t)splits * wsz, dbias,
                            (size_t)K, splits);
     } else if (dbias) {
         float *cpart = part + (size_t)splits * wsz;
@@ -2017,42 +1980,4 @@ static int wgrad_impl(const float *dy, const float *x, float *dw, float *dbias, 
     SQD_CHECK_LAUNCH("sqd_conv_wgrad");
     return SQD_OK;
 }
-extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C,
-                              int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream) {
-    return wgrad_impl(dy, x, dw, dbias, part, N, H, W, C, K, R, S, stride, pad, Ho, Wo, stream, true, nullptr, nullptr);
-}
-// sqd_conv_wgrad without the final reduction over the pixel splits: `part` holds [*splits][K][R][S][C] partial filter gradients
-// (followed, when *bias_in_part = 1, by [*splits][K] partial bias gradients; otherwise dbias — if requested — is final on return).
-// The caller adds them later with sqd_split_reduce_multi, many convolutions per launch; `part` must stay untouched until then.
-extern "C" int sqd_conv_wgrad_partials(const float *dy, const float *x, float *dbias, float *part, int N, int H, int W, int C, int K, int R,
-                                       int S, int stride, int pad, int Ho, int Wo, int *splits, int *bias_in_part, void *stream) {
-    SQD_CHECK_ARG(splits && bias_in_part, "sqd_conv_wgrad_partials: null pointer");
-    return wgrad_impl(dy, x, nullptr, dbias, part, N, H, W, C, K, R, S, stride, pad, Ho, Wo, stream, false, splits, bias_in_part);
-}
-// out[t][i] = sum over s < splits[t] of parts[t][s * n[t] + i] for ntasks (host arrays of device pointers / sizes; n[t] multiples of 4,
-// 16-byte aligned pointers): the reductions sqd_conv_wgrad_partials left out, 48 per launch, same order of additions per element.
-extern "C" int sqd_split_reduce_multi(const void *const *parts, void *const *outs, const int64_t *n, const int *splits, int ntasks, void *stream) {
-    SQD_CHECK_ARG(parts && outs && n && splits && ntasks > 0, "sqd_split_reduce_multi: bad arguments");
-    (void)hipGetLastError();
-    for (int t0 = 0; t0 < ntasks; t0 += 48) {
-        ReduceTasks T;
-        T.ntasks = ntasks - t0 < 48 ? ntasks - t0 : 48;
-        unsigned blk = 0;
-        for (int k = 0; k < T.ntasks; ++k) {
-            const int t = t0 + k;
-            SQD_CHECK_ARG(parts[t] && outs[t] && n[t] > 0 && n[t] % 4 == 0 && n[t] / 4 < (1ll << 32) && splits[t] >= 1 &&
-                              ((uintptr_t)parts[t] & 15) == 0 && ((uintptr_t)outs[t] & 15) == 0,
-                          "sqd_split_reduce_multi: task %d is malformed", t);
-            T.part[k] = (const float *)parts[t];
-            T.out[k] = (float *)outs[t];
-            T.n4[k] = (unsigned)(n[t] / 4);
-            T.splits[k] = (unsigned)splits[t];
-            T.blk0[k] = blk;
-            blk += (unsigned)((n[t] / 4 + 15) / 16);
-        }
-        T.blk0[T.ntasks] = blk;
-        hipLaunchKernelGGL(split_reduce_multi_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, T);
-    }
-    SQD_CHECK_LAUNCH("sqd_split_reduce_multi");
-    return SQD_OK;
-}
+

@@ -63,13 +63,7 @@ class FinetuneTrainer:
         crop = "garg" if a.garg_crop else "eigen" if a.eigen_crop else None
         ratio = ops.median_ratio(pred, depth, pred.shape[0] // 2, a.min_depth_eval, a.max_depth_eval, crop)
         loss = self.criterion(pred, depth, a.min_depth, scale=ratio, interpolate=False)
-        nnkernels.DEFER_WGRAD_REDUCE = True               # the weight gradients' split reductions: a few launches after the pass
-        try:
-            loss.backward()
-            nnkernels.flush_wgrad_reduces()
-        finally:
-            nnkernels.DEFER_WGRAD_REDUCE = False
-            nnkernels._DEFERRED_REDUCES.clear()
+        loss.backward()
         self.optimizer.step()                                  # gradient clipping is folded into the step (FusedAdamW)
         self.scheduler.step()
         return loss.detach(), ratio

@@ -189,9 +189,6 @@ _SIGNATURES = {
     "sqd_conv_wgrad_plan": (_I, [_I] * 7 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)]),
     "sqd_conv_wgrad_set_plan": (_I, [_I] * 9),
     "sqd_conv_wgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
-    "sqd_conv_wgrad_partials": (_I, [_P, _P, _P, _P] + [_I] * 11 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), _P]),
-    "sqd_split_reduce_multi": (_I, [ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_int64),
-                                    ctypes.POINTER(ctypes.c_int), _I, _P]),
     "sqd_bins_supported": (_I, [_I, _I]),
     "sqd_bins_workspace": (_I, [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64)]),
     "sqd_bins_fwd": (_I, [_P] * 5 + [_I] * 4 + [_P]),

@@ -602,27 +602,6 @@ def begin_step():
     _WEIGHT_USES.clear()
 
 
-DEFER_WGRAD_REDUCE = False    # set by the training loops around loss.backward(): the reductions over the weight gradients' pixel
-_DEFERRED_REDUCES = []        # splits are collected — (partials, offset, output storage, output pointer, floats, splits) — and run by flush_wgrad_reduces()
-
-
-def flush_wgrad_reduces():
-    """One sqd_split_reduce_multi call (48 reductions per launch) for the weight gradients sqd_conv_wgrad_partials left as partial
-    sums during this backward pass; call after loss.backward() (and join_wgrad_stream) and before anything reads the gradients."""
-    if not _DEFERRED_REDUCES:
-        return
-    n = len(_DEFERRED_REDUCES)
-    parts = (ctypes.c_void_p * n)(*[t[0].data_ptr() + 4 * t[1] for t in _DEFERRED_REDUCES])
-    outs = (ctypes.c_void_p * n)(*[t[3] for t in _DEFERRED_REDUCES])
-    ns = (ctypes.c_int64 * n)(*[t[4] for t in _DEFERRED_REDUCES])
-    sps = (ctypes.c_int * n)(*[t[5] for t in _DEFERRED_REDUCES])
-    _l.check(_l.lib().sqd_split_reduce_multi(parts, outs, ns, sps, n, _stream()), "split_reduce_multi")
-    cur = torch.cuda.current_stream()
-    for t in _DEFERRED_REDUCES:
-        t[0].record_stream(cur)
-    _DEFERRED_REDUCES.clear()
-
-
 def flush_wgrads():
     """launch the queued weight-gradient kernels on WGRAD_STREAM (after everything their producer streams hold so far)"""
     side = WGRAD_STREAM
@@ -717,24 +696,10 @@ class Conv2d(torch.autograd.Function):
             extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if ctx.has_bias else 0
             part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
 
-            single_use = ctx.wkey is not None and _WEIGHT_USES.get(ctx.wkey, 2) == 1
-            defer = DEFER_WGRAD_REDUCE and single_use and splits > 1      # (a weight used twice: autograd adds the two gradients at once)
-
-            def launch(dy=dy, x=x, dw=dw, db=db, part=part, defer=defer):     # (dw, db: see the note on references below)
-                if not defer:
-                    _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
-                                              _stream()), "conv_wgrad")
-                    return
-                sp, bip = ctypes.c_int(0), ctypes.c_int(0)
-                _l.check(L.sqd_conv_wgrad_partials(_ptr(dy), _ptr(x), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
-                                                   ctypes.byref(sp), ctypes.byref(bip), _stream()), "conv_wgrad_partials")
-                # (the outputs are remembered as storages, not as the tensors handed to autograd: AccumulateGrad takes a gradient
-                # over as .grad only while nobody else refers to it — with a second reference it stores a COPY, made before the
-                # reduction has run)
-                _DEFERRED_REDUCES.append((part, 0, dw.untyped_storage(), dw.data_ptr(), dw.numel(), sp.value))
-                if bip.value:
-                    _DEFERRED_REDUCES.append((part, sp.value * dw.numel(), db.untyped_storage(), db.data_ptr(), K, sp.value))
-            if WGRAD_STREAM is None or not single_use:
+            def launch(dy=dy, x=x, dw=dw, db=db, part=part):
+                _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
+                                          _stream()), "conv_wgrad")
+            if WGRAD_STREAM is None or ctx.wkey is None or _WEIGHT_USES.get(ctx.wkey, 2) != 1:
                 launch()
             else:
                 # the weight gradient has no consumer before the optimiser: it is queued and runs on its own stream, next to

@@ -318,17 +318,11 @@ class Trainer:
         # eager steps: the convolutions' weight gradients run on their own stream, next to the data gradients (-0.8 ms per
         # step).  Not inside a capture: a hipGraph with ~110 extra cross-branch edges replays 1.3 ms slower than the linear one.
         nnkernels.WGRAD_STREAM = None if getattr(self, "_capturing", False) else self._wgrad_stream
-        # the reductions over the weight gradients' pixel splits (~100 launches of a few us) run as two or three launches after the
-        # pass — unless the reducer's hooks consume gradients while the pass is still running
-        nnkernels.DEFER_WGRAD_REDUCE = self.reducer is None or not self.reducer.hooks_enabled
         try:
             loss.backward()
             nnkernels.join_wgrad_stream()                # the caller's stream joins it before anything reads the gradients
-            nnkernels.flush_wgrad_reduces()
         finally:
             nnkernels.WGRAD_STREAM = None
-            nnkernels.DEFER_WGRAD_REDUCE = False
-            nnkernels._DEFERRED_REDUCES.clear()
 
     def _train_step_eager(self, inputs):
         nnkernels.begin_step()

@@ -438,32 +438,3 @@ def test_input_patch_plan_feeds_batchnorm_statistics():
         L.sqd_conv_set_plan(0, *geom, 0, 0, 0, 16)
         nnkernels._PLAN_CACHE.clear()
         nnops.set_native_conv(False)
-
-
-@pytest.mark.parametrize("N,C,H,W,K,R,stride,pad,bias", [(4, 64, 24, 40, 128, 3, 1, 1, True), (2, 256, 12, 20, 64, 1, 1, 0, False), (2, 16, 33, 47, 32, 3, 2, 1, True)])
-def test_deferred_weight_gradient_reduction_is_bit_identical(N, C, H, W, K, R, stride, pad, bias):
-    """sqd_conv_wgrad_partials + one sqd_split_reduce_multi call at the end of the backward pass against sqd_conv_wgrad's own
-    reduction: same bits (the additions per element run in the same order)."""
-    from sqd import nnkernels
-    torch.manual_seed(N + K)
-    convs = [nn.Conv2d(C, K, R, stride, pad, bias=bias).cuda().to(memory_format=torch.channels_last) for _ in range(3)]
-    x = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=torch.channels_last)
-
-    def run(defer):
-        nnkernels.begin_step()
-        ys = [nnkernels.conv2d_native(x, c, None) for c in convs]
-        gys = [torch.ones_like(y) * (i + 1) + torch.arange(y.shape[1], device="cuda").view(1, -1, 1, 1) * 0.01 for i, y in enumerate(ys)]
-        params = [p for c in convs for p in c.parameters()]
-        nnkernels.DEFER_WGRAD_REDUCE = defer
-        try:
-            grads = torch.autograd.grad(ys, params, gys)
-            if defer:
-                assert len(nnkernels._DEFERRED_REDUCES) >= 3
-            nnkernels.flush_wgrad_reduces()
-        finally:
-            nnkernels.DEFER_WGRAD_REDUCE = False
-            nnkernels._DEFERRED_REDUCES.clear()
-        return [g.clone() for g in grads]
-    a, b = run(False), run(True)
-    for ga, gb in zip(a, b):
-        assert torch.equal(ga, gb)
