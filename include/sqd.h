@@ -251,7 +251,9 @@ int sqd_conv_supported(int C, int K);
 /* measured plans: see csrc/conv.hip — the library picks tile and split-K by a cost model unless the caller registers
  * a plan it has timed (bm x bn tile, z split-K factor, bk = 16 | 32 channels per reduction slice, + 256: 8-wave workgroups,
  * + 512: single LDS buffer, 32 + 1024: three-term bf16 operands on the bf16 matrix cores — every fp32 operand as the exact sum of
- * three bf16 terms, 6 of the 9 partial products (down to 2^-24 relative), fp32 accumulation, single LDS buffer; bm = 0 clears) */
+ * three bf16 terms, 6 of the 9 partial products (down to 2^-24 relative), fp32 accumulation, single LDS buffer;
+ * 32 + 1024 + 2048: the input-patch kernel of that arithmetic for R = S = 3, stride 1, pad 1 — bm = 128 | 64 pixels of a patch
+ * (8x16 | 4x16), bn = 128 | 64 | 32 output channels per workgroup, z = split over 32-channel chunks; bm = 0 clears) */
 int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int bm,
                       int bn, int z, int bk);
 /* arithmetic of sqd_conv_fwd / sqd_conv_dgrad: 0 = fp32 MFMA (default, the reference's arithmetic); 1 = split-precision bf16

@@ -193,7 +193,9 @@ def _tune_conv(mode, geom, launch):
     # bk 32 + 1024 + 2048 = the input-patch kernel for 3x3 / stride 1 / pad 1 (three-term bf16 operands; the input patch of a
     # 32-channel chunk is converted and staged once for all nine taps, the filter fragments come straight from L2): 20-40 % faster
     # than the implicit-GEMM plans on the config-B layers above 12x40 pixels (profiles/r02i_conv_input_patch.md)
-    bks = (16, 32, 528, 544, 1056, 3104) + ((576,) if os.environ.get("SQD_TUNE_BK64") else ()) + ((272, 288) if os.environ.get("SQD_TUNE_8WAVE") else ())
+    # (bk 64 + 1024, the three-term 64x64 tile with 64-channel slices, was tried for the few-pixel / many-channel 1x1 layers of layer 3 / 4:
+    # no change of the step in a same-box A/B — not kept)
+    bks = (16, 32, 528, 544, 1056) + (() if os.environ.get("SQD_TUNE_NO_PATCH") else (3104,)) + ((576,) if os.environ.get("SQD_TUNE_BK64") else ()) + ((272, 288) if os.environ.get("SQD_TUNE_8WAVE") else ())
     for bm, bn, z, bk in ((bm, bn, z, bk) for bm, bn in _TUNE_TILES + ((64, 32),) for bk in bks for z in _TUNE_Z):
         if True:
             if L.sqd_conv_set_plan(mode, *geom, bm, bn, z, bk) != 0:

@@ -16,6 +16,17 @@ HALO = [  # the input-patch kernel (bk 32 + 1024 + 2048)
     ("up3a 320->32 fwd patch 128x32", (12, 48, 160, 320, 32, 3, 1, 1), 0, (128, 32, 1, 3104)),
     ("qtr 32 fwd patch 128x32", (12, 96, 320, 32, 32, 3, 1, 1), 0, (128, 32, 1, 3104)),
 ]
+ONE = [  # 1x1 layers with few pixels and many channels
+    ("l3 1x1 256->1024 fwd 64x128", (12, 12, 40, 256, 1024, 1, 1, 0), 0, (64, 128, 1, 1056)),
+    ("l3 1x1 256->1024 fwd 64x64", (12, 12, 40, 256, 1024, 1, 1, 0), 0, (64, 64, 1, 1056)),
+    ("l3 1x1 256->1024 fwd 128x128", (12, 12, 40, 256, 1024, 1, 1, 0), 0, (128, 128, 1, 1056)),
+    ("l3 1x1 1024->256 fwd 64x64", (12, 12, 40, 1024, 256, 1, 1, 0), 0, (64, 64, 1, 1056)),
+    ("l3 1x1 1024->256 fwd 64x64 z2", (12, 12, 40, 1024, 256, 1, 1, 0), 0, (64, 64, 2, 1056)),
+    ("l4 1x1 512->2048 fwd 64x128", (12, 6, 20, 512, 2048, 1, 1, 0), 0, (64, 128, 1, 1056)),
+    ("l4 1x1 512->2048 fwd 64x64", (12, 6, 20, 512, 2048, 1, 1, 0), 0, (64, 64, 1, 1056)),
+    ("l3 1x1 256->1024 dgrad 64x64", (12, 12, 40, 256, 1024, 1, 1, 0), 1, (64, 64, 1, 1056)),
+    ("l1 1x1 64->256 fwd 64x128", (12, 48, 160, 64, 256, 1, 1, 0), 0, (64, 128, 1, 1056)),
+]
 CASES = [  # name, (N,H,W,C,K,R,stride,pad), mode, (bm,bn,z,bk)
     ("l1 3x3 64 fwd 128x64", (12, 48, 160, 64, 64, 3, 1, 1), 0, (128, 64, 1, 1056)),
     ("l2 3x3 128 fwd 64x128 z2", (12, 24, 80, 128, 128, 3, 1, 1), 0, (64, 128, 2, 1056)),
@@ -26,7 +37,7 @@ CASES = [  # name, (N,H,W,C,K,R,stride,pad), mode, (bm,bn,z,bk)
     ("l2 3x3 128 dgrad 128x64 z2", (12, 24, 80, 128, 128, 3, 1, 1), 1, (128, 64, 2, 1056)),
     ("l2 3x3 128 fwd f32 64x64 bk32 single", (12, 24, 80, 128, 128, 3, 1, 1), 0, (64, 64, 1, 544)),
 ]
-for name, (N, H, W, C, K, R, st, pad), mode, plan in (HALO if len(sys.argv) > 2 and sys.argv[2] == "patch" else CASES):
+for name, (N, H, W, C, K, R, st, pad), mode, plan in (HALO if len(sys.argv) > 2 and sys.argv[2] == "patch" else ONE if len(sys.argv) > 2 and sys.argv[2] == "1x1" else CASES):
     Ho, Wo = (H + 2 * pad - R) // st + 1, (W + 2 * pad - R) // st + 1
     geom = (N, H, W, C, K, R, R, st, pad, Ho, Wo)
     x = torch.randn(N, H, W, C, device="cuda")
