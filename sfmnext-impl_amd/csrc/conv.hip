@@ -671,6 +671,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
                 }
             }
             __builtin_amdgcn_sched_barrier(0);            // keep the taps apart: hoisting the next tap's reads costs 60+ registers
+                                                          // (reading the A fragments one tap ahead by hand: +30-90 registers, spills, no gain)
         }
     }
 
