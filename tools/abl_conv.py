@@ -26,6 +26,7 @@ ONE = [  # 1x1 layers with few pixels and many channels
     ("l4 1x1 512->2048 fwd 64x64", (12, 6, 20, 512, 2048, 1, 1, 0), 0, (64, 64, 1, 1056)),
     ("l3 1x1 256->1024 dgrad 64x64", (12, 12, 40, 256, 1024, 1, 1, 0), 1, (64, 64, 1, 1056)),
     ("l1 1x1 64->256 fwd 64x128", (12, 48, 160, 64, 256, 1, 1, 0), 0, (64, 128, 1, 1056)),
+    ("l2 1x1 128->512 fwd 64x128", (12, 24, 80, 128, 512, 1, 1, 0), 0, (64, 128, 1, 1056)),
 ]
 CASES = [  # name, (N,H,W,C,K,R,stride,pad), mode, (bm,bn,z,bk)
     ("l1 3x3 64 fwd 128x64", (12, 48, 160, 64, 64, 3, 1, 1), 0, (128, 64, 1, 1056)),
