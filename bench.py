@@ -268,7 +268,7 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": workload_name(opts),
                           "global_batch": world * opts.batch_size, "parallelism": "dp%d" % world,
-                          "operator_backends": nnops.BACKEND},
+                          "operator_backends": nnops.backend_report()},
                "final_loss": round(loss, 6), "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
     if world > 1:

@@ -317,6 +317,12 @@ int sqd_maxpool3x3s2_bwd(const float *dy, const unsigned char *idx, const float 
 /* space-to-depth(2), channels-last, channels zero-padded to Cp: y[n,h2,w2,c*4+dy*2+dx] = x[n,2h2+dy,2w2+dx,c].  The 7x7/2 stems
  * (reference networks/resnet_encoder.py:94, pose_cnn.py:17) run as 4x4/1 convolutions on this layout (sqd_conv_*).       */
 int sqd_space_to_depth2(const float *x, float *y, int N, int H, int W, int C, int Cp, void *stream);
+/* the same from planar sources x0 [N,C0,H,W], x1 [N,C1,H,W] (or NULL), with the frame staging of the two stems folded in: channel
+ * concatenation (x0, x1) (the pose network's torch.cat of a frame pair, reference trainer.py:319-326), every value
+ * (v - sub) * (1.0f / div) — the encoder's (x - 0.45) / 0.225 (reference networks/resnet_encoder.py:93) as ATen evaluates a tensor
+ * divided by a scalar on the device: bit-identical to the reference's normalised frame; sample n is written at y + n * y_stride floats */
+int sqd_space_to_depth2_planar(const float *x0, const float *x1, float *y, int N, int H, int W, int C0, int C1, int Cp,
+                               int64_t y_stride, float sub, float div, void *stream);
 /* the matching filter regrouping w [K,C,7,7] -> ws [K,4,4,Cp] (tap u = 2r' + dy - 1; adjoint = 1: g_ws -> g_w, fully overwritten) */
 int sqd_stem_regroup(const float *src, float *dst, int K, int C, int Cp, int adjoint, void *stream);
 

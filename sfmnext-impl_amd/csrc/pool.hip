@@ -132,6 +132,32 @@ __global__ __launch_bounds__(256) void s2d_kernel(const float *__restrict__ x, f
     }
 }
 
+// the same from planar (NCHW) sources, with the input normalisation and the channel concatenation of two frames folded in:
+//   channel c < C0 from x0[n, c], c >= C0 from x1[n, c - C0];  value (v - sub) * (1 / div) — a tensor divided by a scalar is a
+//   multiplication by the scalar's float reciprocal in ATen's CUDA/HIP kernels, which is what the reference runs;  sample n lands at
+//   y + n * y_stride
+__global__ __launch_bounds__(256) void s2d_planar_kernel(const float *__restrict__ x0, const float *__restrict__ x1, float *__restrict__ y,
+                                                         int N, int H, int W, int C0, int C1, int Cp, long long y_stride, float sub, float inv_div) {
+    const int H2 = H / 2, W2 = W / 2, Q = Cp / 4, C = C0 + C1;
+    const size_t per = (size_t)H2 * W2 * Q, total = (size_t)N * per;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        // pixels fastest inside a (sample, channel) plane pair: a wave reads two runs of 128 consecutive source floats
+        const int w2 = (int)(i % W2);
+        size_t t = i / W2;
+        const int c = (int)(t % Q);
+        t /= Q;
+        const int h2 = (int)(t % H2), n = (int)(t / H2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < C) {
+            const float *pl = c < C0 ? x0 + ((size_t)n * C0 + c) * H * W : x1 + ((size_t)n * C1 + (c - C0)) * H * W;
+            const float2 a = *reinterpret_cast<const float2 *>(pl + (size_t)(2 * h2) * W + 2 * w2);
+            const float2 b = *reinterpret_cast<const float2 *>(pl + (size_t)(2 * h2 + 1) * W + 2 * w2);
+            v = make_float4((a.x - sub) * inv_div, (a.y - sub) * inv_div, (b.x - sub) * inv_div, (b.y - sub) * inv_div);
+        }
+        reinterpret_cast<float4 *>(y + (size_t)n * y_stride)[((size_t)h2 * W2 + w2) * Q + c] = v;
+    }
+}
+
 // filter regrouping of the space-to-depth stems and its adjoint:
 //   w [K,C,7,7] (KCRS) <-> ws [K,4,4,Cp] (KRSC', channel c*4 + dy*2 + dx), tap u = 2r' + dy - 1, v = 2s' + dx - 1
 template <bool ADJOINT>
@@ -156,6 +182,23 @@ extern "C" int sqd_space_to_depth2(const float *x, float *y, int N, int H, int W
     SQD_CHECK_ARG(Cp % 4 == 0, "sqd_space_to_depth2: Cp=%d must be a multiple of 4", Cp);
     hipLaunchKernelGGL(s2d_kernel, dim3(grid_for((size_t)N * (H / 2) * (W / 2) * Cp / 4)), dim3(256), 0, (hipStream_t)stream, x, y, N, H, W, C, Cp);
     SQD_CHECK_LAUNCH("sqd_space_to_depth2");
+    return SQD_OK;
+}
+
+// x0 [N,C0,H,W], x1 [N,C1,H,W] or NULL (planar, dense) -> y[n] = y + n * y_stride floats, each [H/2,W/2,Cp] as sqd_space_to_depth2 of the
+// channel concatenation (x0, x1), every value (v - sub) / div: the frame staging of the two stems in one pass — the encoder's
+// (x - 0.45) / 0.225 (reference networks/resnet_encoder.py:93) and the pose network's torch.cat of a frame pair
+// (reference trainer.py:319-326); y_stride lets the pairs of one sample interleave along the batch
+extern "C" int sqd_space_to_depth2_planar(const float *x0, const float *x1, float *y, int N, int H, int W, int C0, int C1, int Cp,
+                                          int64_t y_stride, float sub, float div, void *stream) {
+    SQD_CHECK_ARG(x0 && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C0 > 0 && C1 >= 0 && (x1 || C1 == 0) &&
+                      Cp >= 4 * (C0 + C1) && Cp % 4 == 0 && div != 0.f && y_stride >= (int64_t)(H / 2) * (W / 2) * Cp && y_stride % 4 == 0,
+                  "sqd_space_to_depth2_planar: bad arguments (H=%d W=%d C0=%d C1=%d Cp=%d)", H, W, C0, C1, Cp);
+    SQD_CHECK_ARG(((uintptr_t)x0 & 7) == 0 && ((uintptr_t)x1 & 7) == 0 && ((uintptr_t)y & 15) == 0, "sqd_space_to_depth2_planar: alignment");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(s2d_planar_kernel, dim3(grid_for((size_t)N * (H / 2) * (W / 2) * Cp / 4)), dim3(256), 0, (hipStream_t)stream, x0, x1, y,
+                       N, H, W, C0, C1, Cp, (long long)y_stride, sub, 1.0f / div);
+    SQD_CHECK_LAUNCH("sqd_space_to_depth2_planar");
     return SQD_OK;
 }
 

@@ -21,7 +21,15 @@ class PoseCNN(nn.Module):
         self.net = nn.ModuleList(convs)
 
     def forward(self, out):
-        for conv in self.net:
+        return self._trunk(X.conv2d(out, self.net[0], "relu"))
+
+    def forward_pairs(self, pairs):
+        """pairs = [(first frame, second frame), ...], each [B,3,H,W] -> the outputs of forward(x) for the batch x [B * len(pairs), 6,
+        H, W] whose row b * len(pairs) + i is torch.cat(pairs[i], 1)[b] (reference trainer.py:319-326), without building x"""
+        return self._trunk(X.stem_pairs(pairs, self.net[0], "relu"))
+
+    def _trunk(self, out):
+        for conv in list(self.net)[1:]:
             out = X.conv2d(out, conv, "relu")
         # (axisangle, translation) = out.view(-1, F, 1, 6)[..., :3], [..., 3:] of the reference, written as two dense tensors
         return X.pose_head(out, self.pose_conv, 0.01, split=True)

@@ -98,6 +98,8 @@ class ResnetEncoder(nn.Module):
         self.num_ch_enc = [64, 64, 128, 256, 512] if num_layers <= 34 else [64, 256, 512, 1024, 2048]
         self.encoder = ResNetTrunk(num_layers)
 
+    planar_input = True      # the stem takes the frame as it comes (dense NCHW): no channels-last copy before the call
+
     def forward(self, input_image):
         e = self.encoder
         f0 = X.conv_bn_act(input_image, e.conv1, e.bn1, "relu", input_affine=(0.45, 0.225))   # (x-0.45)/0.225
@@ -163,6 +165,8 @@ class DecoderBN(nn.Module):
 
 
 class ResnetEncoderDecoder(nn.Module):
+    planar_input = True
+
     def __init__(self, num_layers=50, num_features=512, model_dim=32):
         super().__init__()
         if num_layers < 50:
@@ -181,6 +185,8 @@ class Resnet50EncoderDecoder(ResnetEncoderDecoder):
 
 
 class LiteResnetEncoderDecoder(nn.Module):
+    planar_input = True
+
     def __init__(self, model_dim=128):
         super().__init__()
         self.encoder = ResnetEncoder(num_layers=18, pretrained=True, num_input_images=1)

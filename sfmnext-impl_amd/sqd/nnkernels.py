@@ -758,6 +758,34 @@ def conv2d_stem_s2d(x, conv, act=None, stats=None):
     return Conv2d.apply(xs, w, conv.bias, 1, 2, act, False, (H // 2, W // 2), stats)
 
 
+def conv2d_stem_s2d_planar(pairs, conv, act=None, stats=None, affine=(0.0, 1.0)):
+    """conv2d_stem_s2d on frames that are still planar (NCHW, dense): pairs = [(x0, x1 | None), ...], each x [B,C,H,W]; the batch of
+    the convolution is [B * len(pairs)] with row b * len(pairs) + i = pair i of sample b, its channels the concatenation (x0, x1),
+    every value (v - affine[0]) / affine[1].  One sqd_space_to_depth2_planar launch per pair replaces the layout conversion, the
+    normalisation (two element-wise passes) and the torch.cat / slice copies of the frame staging."""
+    x0 = pairs[0][0]
+    B, C0, H, W = x0.shape
+    C1 = 0 if pairs[0][1] is None else pairs[0][1].shape[1]
+    S, K = len(pairs), conv.out_channels
+    Cp = (4 * (C0 + C1) + 15) // 16 * 16
+    xs = torch.empty((B * S, Cp, H // 2, W // 2), device=x0.device, dtype=torch.float32, memory_format=torch.channels_last)
+    per = (H // 2) * (W // 2) * Cp
+    for i, (a, b) in enumerate(pairs):
+        a = a.detach()
+        b = None if b is None else b.detach()
+        if not (a.is_contiguous() and (b is None or b.is_contiguous()) and a.dtype == torch.float32):
+            raise RuntimeError("sqd: conv2d_stem_s2d_planar needs dense NCHW float32 frames")
+        _l.check(_l.lib().sqd_space_to_depth2_planar(_ptr(a), _ptr(b), ctypes.c_void_p(xs.data_ptr() + 4 * per * i), B, H, W, C0, C1, Cp,
+                                                     per * S, float(affine[0]), float(affine[1]), _stream()), "space_to_depth2_planar")
+    w = StemRegroup.apply(conv.weight, Cp)
+    return Conv2d.apply(xs, w, conv.bias, 1, 2, act, False, (H // 2, W // 2), stats)
+
+
+def stem_s2d_planar_supported(conv, x):
+    """a 7x7 / stride 2 / pad 3 stem on a dense NCHW float32 frame (see stem_s2d_supported)"""
+    return stem_s2d_supported(conv, x) and x.is_contiguous() and x.dtype == torch.float32 and x.dim() == 4 and x.shape[1] > 1
+
+
 class StemRegroup(torch.autograd.Function):
     """w [K,C,7,7] -> the 4x4 filter on the space-to-depth channels, [K,Cp,4,4] channels-last (one kernel each way)."""
 

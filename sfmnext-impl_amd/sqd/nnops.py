@@ -19,6 +19,21 @@ BACKEND = {
 }
 
 
+ATEN_FALLBACKS = {}           # operator -> calls that ran on ATen because the native kernel does not take the shape (this process)
+
+
+def backend_report():
+    """BACKEND with the two operators that can fall back per call (conv2d, linear: channel / feature counts not divisible by 4)
+    reported by what actually ran: plain "hip" when no call of this process went to ATen."""
+    rep = dict(BACKEND)
+    for op in ("conv2d", "linear"):
+        if rep[op].startswith("hip"):
+            n = ATEN_FALLBACKS.get(op, 0)
+            rep[op] = rep[op].split(";")[0].rstrip(")") + (")" if "(" in rep[op].split(";")[0] else "")
+            rep[op] += " — no call fell back to ATen" if n == 0 else " — %d calls fell back to ATen (channel counts not divisible by 4)" % n
+    return rep
+
+
 def _act(y, act):
     if act is None:
         return y
@@ -60,7 +75,7 @@ def configure(opt, device):
         opt.sqd_channels_last = True
 
 
-def _conv(x, conv, act=None, skip=False, bn_stats=None):
+def _conv(x, conv, act=None, skip=False, bn_stats=None, input_affine=None):
     """skip=True: -> (y, x') with x' the input handed through the convolution node (see nnkernels.Conv2d).
     bn_stats: a list that receives (partials, rows) when the convolution's epilogue produced the statistics partials of
     the BatchNorm that follows (native kernels, training, plan without split-K)."""
@@ -68,6 +83,10 @@ def _conv(x, conv, act=None, skip=False, bn_stats=None):
         from . import nnkernels
         native = nnkernels.conv_module_supported(conv)
         s2d = not native and nnkernels.stem_s2d_supported(conv, x)
+        # a dense NCHW frame into a 7x7 stem: layout conversion and (x - a) / b happen inside the space-to-depth pass
+        planar = s2d and not skip and nnkernels.stem_s2d_planar_supported(conv, x)
+        if input_affine is not None and not planar:
+            x = (x - input_affine[0]) / input_affine[1]
         stats = geom = None
         if bn_stats is not None and (native or s2d):
             geom = nnkernels.conv_out_geom(x, conv, s2d)
@@ -78,6 +97,8 @@ def _conv(x, conv, act=None, skip=False, bn_stats=None):
             stats = torch.empty(rows_max * K * 2, device=x.device, dtype=torch.float32)
         if native:
             out = nnkernels.conv2d_native(x, conv, act, skip, stats)
+        elif planar:
+            out = nnkernels.conv2d_stem_s2d_planar([(x, None)], conv, act, stats, input_affine or (0.0, 1.0))
         elif s2d:
             y = nnkernels.conv2d_stem_s2d(x, conv, act, stats)
             out = (y, x) if skip else y
@@ -88,6 +109,9 @@ def _conv(x, conv, act=None, skip=False, bn_stats=None):
                     bn_stats.append((stats, rows))
             return out
     _device_only(x, "conv2d")
+    ATEN_FALLBACKS["conv2d"] = ATEN_FALLBACKS.get("conv2d", 0) + 1
+    if input_affine is not None:
+        x = (x - input_affine[0]) / input_affine[1]
     y = _act(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), act)      # ATen: channel counts not divisible by 4
     return (y, x) if skip else y
 
@@ -97,19 +121,31 @@ def conv2d(x, conv, act=None):
     return _conv(x, conv, act)
 
 
+def stem_pairs(pairs, conv, act=None):
+    """conv applied to the channel concatenation of frame pairs: pairs = [(x0, x1), ...] -> [B * len(pairs), K, H', W'] with row
+    b * len(pairs) + i = pair i of sample b (the pose network's input assembly, reference trainer.py:319-326, without the copies)."""
+    x0 = pairs[0][0]
+    if NATIVE_CONV and x0.is_cuda:
+        from . import nnkernels
+        probe = torch.empty((1, conv.in_channels, x0.shape[2], x0.shape[3]), device="meta")
+        if nnkernels.stem_s2d_supported(conv, probe) and all(a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float32 for a, b in pairs):
+            return nnkernels.conv2d_stem_s2d_planar(pairs, conv, act)
+    B, S = x0.shape[0], len(pairs)
+    x = torch.stack([torch.cat(p, 1) for p in pairs], 1).reshape((B * S, -1) + tuple(x0.shape[2:]))
+    return conv2d(x.contiguous(memory_format=torch.channels_last) if x.is_cuda else x, conv, act)
+
+
 def conv_bn_act(x, conv, bn, act, residual=None, input_affine=None, skip=False):
     """[input (x-a)/b] -> conv -> BatchNorm2d (batch stats in training, running stats in eval)
     -> [+ residual] -> activation.  skip=True: -> (y, x') where x' must replace x for every further consumer of x (the
     residual branch, the down-sample convolution): their gradient then reaches x through this convolution's data-gradient
     epilogue instead of a separate accumulation pass."""
-    if input_affine is not None:
-        x = (x - input_affine[0]) / input_affine[1]
     training = bn.training or bn.running_mean is None
     pre = [] if training else None      # statistics partials from the convolution's epilogue
     if skip:
-        y, x_skip = _conv(x, conv, None, True, pre)
+        y, x_skip = _conv(x, conv, None, True, pre, input_affine)
         return _bn_act(y, bn, act, residual, pre), x_skip
-    y = _conv(x, conv, None, False, pre)
+    y = _conv(x, conv, None, False, pre, input_affine)
     return _bn_act(y, bn, act, residual, pre)
 
 
@@ -246,6 +282,7 @@ def linear(x, lin, act=None):
         if nnkernels.linear_supported(lin, x):
             return nnkernels.linear_native(x, lin, act)
     _device_only(x, "linear")
+    ATEN_FALLBACKS["linear"] = ATEN_FALLBACKS.get("linear", 0) + 1
     y = F.linear(x, lin.weight, lin.bias)      # ATen: feature counts that are not multiples of 4
     return F.leaky_relu(y, 0.01) if act == "leaky_relu" else y
 

@@ -372,7 +372,10 @@ class Trainer:
                 self._pose_stream.wait_stream(cur)
                 with torch.cuda.stream(self._pose_stream):
                     pose_outputs = self.predict_poses(inputs, None)
-            features = self.models["encoder"](self._fmt(inputs["color_aug", 0, 0]))
+            enc = self.models["encoder"]
+            frame = inputs["color_aug", 0, 0]
+            # (the ResNet stems take the dense NCHW frame: layout conversion and normalisation happen in their space-to-depth pass)
+            features = enc(frame if getattr(enc, "planar_input", False) and frame.is_contiguous() else self._fmt(frame))
             outputs = self.models["depth"](features)
             if fork:
                 cur.wait_stream(self._pose_stream)
@@ -427,14 +430,8 @@ class Trainer:
         # Row b*S + i of the batch is pair i of sample b, so that the head's outputs ARE the [B,S,3] axis-angle / translation
         # arrays the photometric chain reads (no slicing, cat or copies in between, forward or backward).
         B, S = aug[0].shape[0], len(srcs)
-        x = torch.empty((B * S, 6) + tuple(aug[0].shape[2:]), device=aug[0].device, dtype=aug[0].dtype,
-                        memory_format=torch.channels_last if self.opt.sqd_channels_last else torch.contiguous_format)
-        xv = x.view((B, S, 6) + tuple(aug[0].shape[2:]))
-        for i, f in enumerate(srcs):
-            first, second = (aug[f], aug[0]) if f < 0 else (aug[0], aug[f])
-            xv[:, i, :3].copy_(first)
-            xv[:, i, 3:].copy_(second)
-        axisangle, translation = self.models["pose"](x)               # [B*S,1,1,3] each
+        pairs = [((aug[f], aug[0]) if f < 0 else (aug[0], aug[f])) for f in srcs]
+        axisangle, translation = self.models["pose"].forward_pairs(pairs)      # [B*S,1,1,3] each; the 6-channel batch is never built
         if not (axisangle.is_contiguous() and translation.is_contiguous()):
             axisangle, translation = axisangle.contiguous(), translation.contiguous()
         aa_all, tr_all = axisangle.view(B, S, 3), translation.view(B, S, 3)

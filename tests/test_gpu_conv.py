@@ -438,3 +438,32 @@ def test_input_patch_plan_feeds_batchnorm_statistics():
         L.sqd_conv_set_plan(0, *geom, 0, 0, 0, 16)
         nnkernels._PLAN_CACHE.clear()
         nnops.set_native_conv(False)
+
+
+def test_planar_frame_staging_matches_the_copies():
+    """sqd_space_to_depth2_planar (frame pairs, normalisation and layout conversion inside the stem's space-to-depth pass) against the
+    staged path it replaces — torch.cat + channels-last copy + (x - a) / b + sqd_space_to_depth2: same bits, forward and filter gradient."""
+    from sqd import nnkernels, nnops
+    from networks.pose_cnn import PoseCNN
+    torch.manual_seed(3)
+    B, H, W = 3, 32, 48
+    f = [torch.rand(B, 3, H, W, device="cuda") for _ in range(3)]
+    conv = nn.Conv2d(3, 64, 7, 2, 3, bias=False).cuda()
+    xn = ((f[0] - 0.45) / 0.225).contiguous(memory_format=torch.channels_last)
+    y_ref = nnkernels.conv2d_stem_s2d(xn, conv, "relu")
+    y = nnkernels.conv2d_stem_s2d_planar([(f[0], None)], conv, "relu", None, (0.45, 0.225))
+    assert torch.equal(y, y_ref)
+    g = torch.randn_like(y)
+    gw_ref, = torch.autograd.grad(y_ref, conv.weight, g)
+    gw, = torch.autograd.grad(y, conv.weight, g)
+    assert torch.equal(gw, gw_ref)
+    pose = PoseCNN(2).cuda().to(memory_format=torch.channels_last)
+    pairs = [(f[1], f[0]), (f[0], f[2])]
+    x = torch.stack([torch.cat(p, 1) for p in pairs], 1).reshape(B * 2, 6, H, W).contiguous(memory_format=torch.channels_last)
+    nnops.set_native_conv(True)
+    try:
+        a_ref, t_ref = pose(x)
+        a, t = pose.forward_pairs(pairs)
+    finally:
+        nnops.set_native_conv(False)
+    assert torch.equal(a, a_ref) and torch.equal(t, t_ref)

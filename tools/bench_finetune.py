@@ -44,7 +44,7 @@ def main():
     print(json.dumps({"metric": "finetune images/sec, ConvNeXt-L U-Net %dx%d" % (a.width, a.height), "value": round(a.bs / ms * 1e3, 2),
                       "unit": "images/s", "ms_per_step": round(ms, 2), "batch": a.bs, "dtype": "f32", "data": "synthetic",
                       "final_loss": round(float(loss), 5), "peak_mem_GB": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2),
-                      "operator_backends": nnops.BACKEND}))
+                      "operator_backends": nnops.backend_report()}))
 
 
 if __name__ == "__main__":
