@@ -516,11 +516,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
 // MODE 0 forward (source x, reduction over c, tap (r,s) reads patch cell (ty+r, tx+s)); MODE 1 data gradient (source dy,
 // reduction over k, tap (r,s) reads (ty+2-r, tx+2-s)).
 // ---------------------------------------------------------------------------------------------------
-template <int MODE, int WTM, int WM, int WN, int WK>
+template <int MODE, int WTM, int WM, int WN, int WK, int R = 3>
 __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 2 : 3)) void conv3x3_halo_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
                                                                     const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
                                                                     int act, int zsplits, float *__restrict__ stats) {
-    constexpr int TH = 2 * WTM, TW = 16, PW = TW + 2, PH = TH + 2, HP = PH * PW;     // output patch, input patch (+1 on every side)
+    constexpr int TH = 2 * WTM, TW = 16, PW = TW + R - 1, PH = TH + R - 1, HP = PH * PW;   // output patch, input patch (R x R taps)
+    constexpr int RS = R * R, RING = RS % 3 == 0 ? 3 : 4;                          // filter-fragment ring: its size divides the taps of a chunk
+    static_assert((R == 3 || R == 4) && (R == 3 || MODE == 0) && RS % RING == 0, "3x3, or 4x4 forward (the space-to-depth stems)");
     constexpr int NT = WM * WN * WK * 64, BN = WN * 32;
     constexpr int WS = WTM / WM;                          // 32-pixel sub-tiles per wave
     constexpr int CK = 32, LDH = CK + 8;                  // channels per chunk, LDS row pitch in bf16 (80 bytes: conflict-free b128 accesses)
@@ -543,7 +545,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
     const int c_beg = (int)((long long)cchunks * blockIdx.z / zsplits), c_end = (int)((long long)cchunks * (blockIdx.z + 1) / zsplits);
 
     const __amdgpu_buffer_rsrc_t a_rsrc = make_rsrc(a_src, (unsigned)(g.N * g.H * g.W * Cred) * 4u);
-    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(wgt, (unsigned)(g.K * 9 * g.C) * 4u);
+    const __amdgpu_buffer_rsrc_t w_rsrc = make_rsrc(wgt, (unsigned)(g.K * RS * g.C) * 4u);
 
     // ---- A staging: thread -> (patch cell, group of 8 channels); cells of a 16-group are dealt 0,4,8,12,1,5,... so that the four
     // cells a 16-byte LDS store instruction serves per clock start 16 banks apart
@@ -554,7 +556,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
         const int idx = t + NT * i, praw = idx >> 2;
         const int p = (praw & ~15) | ((praw & 3) << 2) | ((praw >> 2) & 3);
         const int hy = p / PW, hx = p - hy * PW;
-        const int iy = y0 - 1 + hy, ix = x0 - 1 + hx;
+        const int iy = y0 - g.pad + hy, ix = x0 - g.pad + hx;
         const bool ok = idx < A_ITEMS && p < HP && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
         a_cell[i] = (idx < A_ITEMS && p < HP) ? p : -1;
         a_off[i] = ok ? (unsigned)(((img * g.H + iy) * g.W + ix) * Cred) * 4u : 0xffffffffu;
@@ -588,11 +590,11 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
     // per-lane part of the address is formed once; chunk, tap and step enter as a scalar offset.
     const int col = n0 + wn * 32 + (lane & 31), kg = lane >> 5;
     const bool colv = col < Ncols;
-    const unsigned b_lane = !colv ? 0xffffffffu : MODE == 0 ? (unsigned)(col * 9 * g.C + kg * 8) * 4u : (unsigned)(kg * 8 * 9 * g.C + col) * 4u;
+    const unsigned b_lane = !colv ? 0xffffffffu : MODE == 0 ? (unsigned)(col * RS * g.C + kg * 8) * 4u : (unsigned)(kg * 8 * RS * g.C + col) * 4u;
     // Fragments are fetched two taps ahead into a ring of three register sets (a tap is 12-48 MFMAs, 0.2-0.7 us: one tap ahead
     // leaves most of an L2 round trip exposed — with the loads removed the config-B layers ran 25 % faster; a whole filter row ahead
     // costs 40-70 more registers and was 3 % slower).
-    float rb[3][KSW][8];
+    float rb[RING][KSW][8];
     auto load_b = [&](float (&dst)[KSW][8], int cc, int rs) {
 #pragma unroll
         for (int q = 0; q < KSW; ++q) {
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
             } else {
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const int so = __builtin_amdgcn_readfirstlane((((cc * CK + ks * 16 + j) * 9 + rs) * g.C) * 4);
+                    const int so = __builtin_amdgcn_readfirstlane((((cc * CK + ks * 16 + j) * RS + rs) * g.C) * 4);
                     dst[q][j] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(w_rsrc, c_lane + j < Cred ? b_lane : 0xffffffffu, so, 0));
                 }
             }
@@ -636,25 +638,26 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
         __syncthreads();
         if (cc + 1 < c_end) load_a(cc + 1);               // in flight during the nine taps
 #pragma unroll
-        for (int rs = 0; rs < 9; ++rs) {
-            const int r = rs / 3, s = rs - 3 * r;
+        for (int rs = 0; rs < RS; ++rs) {
+            const int r = rs / R, s = rs - R * r;
             u32x4 bh[KSW][3];
 #pragma unroll
             for (int q = 0; q < KSW; ++q) {
-                const Split4 s0 = split3(make_float4(rb[rs % 3][q][0], rb[rs % 3][q][1], rb[rs % 3][q][2], rb[rs % 3][q][3]));
-                const Split4 s1 = split3(make_float4(rb[rs % 3][q][4], rb[rs % 3][q][5], rb[rs % 3][q][6], rb[rs % 3][q][7]));
+                const Split4 s0 = split3(make_float4(rb[rs % RING][q][0], rb[rs % RING][q][1], rb[rs % RING][q][2], rb[rs % RING][q][3]));
+                const Split4 s1 = split3(make_float4(rb[rs % RING][q][4], rb[rs % RING][q][5], rb[rs % RING][q][6], rb[rs % RING][q][7]));
 #pragma unroll
                 for (int tmn = 0; tmn < 3; ++tmn) {
                     bh[q][tmn].x = s0.t[tmn].x; bh[q][tmn].y = s0.t[tmn].y; bh[q][tmn].z = s1.t[tmn].x; bh[q][tmn].w = s1.t[tmn].y;
                 }
             }
-            if (rs < 7) load_b(rb[(rs + 2) % 3], cc, rs + 2);
-            else if (cc + 1 < c_end) load_b(rb[(rs + 2) % 3], cc + 1, rs - 7);
-            const int dy = MODE == 0 ? r : 2 - r, dx = MODE == 0 ? s : 2 - s;
+            if (rs + 2 < RS) load_b(rb[(rs + 2) % RING], cc, rs + 2);
+            else if (cc + 1 < c_end) load_b(rb[(rs + 2) % RING], cc + 1, rs + 2 - RS);
+            const int dy = MODE == 0 ? r : R - 1 - r, dx = MODE == 0 ? s : R - 1 - s;
             const unsigned short *tap = &Ah[0][0][0] + frag_base + (dy * PW + dx) * LDH;
 #pragma unroll
             for (int q = 0; q < KSW; ++q) {
                 const int ks = WK == 2 ? wk : q;
+                if (cc * CK + ks * 16 >= Cred) continue;      // (uniform) a step beyond the last channel: the 16-channel stems
 #pragma unroll
                 for (int i = 0; i < WS; ++i) {
                     const unsigned short *ap = tap + (2 * i * PW) * LDH + ks * 16;
@@ -1549,12 +1552,23 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT, 0>),                                              \
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(512), 0, st, \
                        a_src, w, bias, dst, g, act, p.z, order, stats)
+#define LAUNCH_HALO4(WTM, WM, WN, WK)                                                                                      \
+    hipLaunchKernelGGL((conv3x3_halo_kernel<0, WTM, WM, WN, WK, 4>),                                                         \
+                       dim3(g.N * ((g.H + 2 * WTM - 1) / (2 * WTM)) * ((g.W + 15) / 16) * ((Ncols + WN * 32 - 1) / (WN * 32)), 1, p.z), \
+                       dim3(WM * WN * WK * 64), 0, st, a_src, w, bias, dst, g, act, p.z, stats)
 #define LAUNCH_HALO(MODE, WTM, WM, WN, WK)                                                                                 \
     hipLaunchKernelGGL((conv3x3_halo_kernel<MODE, WTM, WM, WN, WK>),                                                         \
                        dim3(g.N * ((g.H + 2 * WTM - 1) / (2 * WTM)) * ((g.W + 15) / 16) * ((Ncols + WN * 32 - 1) / (WN * 32)), 1, p.z), \
                        dim3(WM * WN * WK * 64), 0, st, a_src, w, bias, dst, g, act, p.z, stats)
 #define DISPATCH_GEMM(MODE)                                                      \
-    if (p.halo) {                                                                \
+    if (p.halo && g.R == 4) {                /* 4x4 taps: the space-to-depth stems (forward only); few input channels: waves split pixels */ \
+        if (MODE == 0) {                                                         \
+            if (p.bm == 128 && p.bn == 64) LAUNCH_HALO4(4, 2, 2, 1);             \
+            else if (p.bm == 128) LAUNCH_HALO4(4, 4, 1, 1);                      \
+            else if (p.bn == 64) LAUNCH_HALO4(2, 2, 2, 1);                       \
+            else LAUNCH_HALO4(2, 2, 1, 2);                                       \
+        }                                                                        \
+    } else if (p.halo) {                                                         \
         if (p.bm == 128 && p.bn == 128) LAUNCH_HALO(MODE, 4, 1, 4, 1);           \
         else if (p.bm == 128 && p.bn == 64) LAUNCH_HALO(MODE, 4, 1, 2, 2);       \
         else if (p.bm == 128) LAUNCH_HALO(MODE, 4, 2, 1, 2);                     \
@@ -1668,9 +1682,11 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     if (halo) {
         const int Cr = mode == 0 ? C : K;
         SQD_CHECK_ARG(split3 && waves == 4 && !single && bk == 32, "sqd_conv_set_plan: the input-patch plans are bk = 32 + 1024 + 2048");
-        SQD_CHECK_ARG(R == 3 && S == 3 && stride == 1 && pad == 1 && Ho == H && Wo == W, "sqd_conv_set_plan: the input-patch kernel is 3x3 / stride 1 / pad 1 only");
-        SQD_CHECK_ARG((bm == 128 || bm == 64) && (bn == 128 || bn == 64 || bn == 32) && !(bn > 32 && bn >= 2 * Ncols) && !(bn == 32 && Ncols > 32),
-                      "sqd_conv_set_plan: input-patch tiles are 128|64 pixels x 128|64|32 channels");
+        SQD_CHECK_ARG(((R == 3 && S == 3 && pad == 1) || (R == 4 && S == 4 && pad == 2 && mode == 0)) && stride == 1 && Ho == H && Wo == W,
+                      "sqd_conv_set_plan: the input-patch kernel is 3x3 / stride 1 / pad 1, or the forward 4x4 / stride 1 / pad 2 of the space-to-depth stems");
+        SQD_CHECK_ARG((bm == 128 || bm == 64) && (bn == 128 || bn == 64 || bn == 32) && !(bn > 32 && bn >= 2 * Ncols) && !(bn == 32 && Ncols > 32) &&
+                          !(R == 4 && bn == 128),
+                      "sqd_conv_set_plan: input-patch tiles are 128|64 pixels x 128|64|32 channels (4x4: 64|32 channels)");
         const int64_t oe = (int64_t)N * H * W * Ncols;
         SQD_CHECK_ARG(z >= 1 && z <= 64 && (z == 1 || (z <= (Cr + 31) / 32 && z * oe * 4 <= (64ll << 20) && oe % 4 == 0)), "sqd_conv_set_plan: split %d not possible here", z);
         plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, 32 | 1024 | 2048);

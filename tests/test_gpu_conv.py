@@ -467,3 +467,34 @@ def test_planar_frame_staging_matches_the_copies():
     finally:
         nnops.set_native_conv(False)
     assert torch.equal(a, a_ref) and torch.equal(t, t_ref)
+
+
+@pytest.mark.parametrize("N,C,H,W,K", [(2, 3, 32, 48, 64), (3, 6, 30, 44, 16), (1, 3, 18, 34, 32)])
+def test_input_patch_plans_on_the_stems(N, C, H, W, K):
+    """The 7x7 / stride 2 stems run as 4x4 / stride 1 / pad 2 convolutions on the space-to-depth image; with the input-patch plans
+    (16 taps read from one staged patch) against float64, bias + ReLU, every accepted patch / channel-tile shape."""
+    from sqd import lib, nnkernels
+    L = lib.lib()
+    torch.manual_seed(C * K)
+    conv = nn.Conv2d(C, K, 7, 2, 3, bias=True).cuda()
+    x = torch.randn(N, C, H, W, device="cuda")
+    yr = F.relu(F.conv2d(x.double(), conv.weight.double(), conv.bias.double(), 2, 3))
+    Cp = (4 * C + 15) // 16 * 16
+    geom = (N, H // 2, W // 2, Cp, K, 4, 4, 1, 2, H // 2, W // 2)
+    tried = 0
+    try:
+        for bm in (128, 64):
+            for bn in (64, 32):
+                if L.sqd_conv_set_plan(0, *geom, bm, bn, 1, 32 + 1024 + 2048) != 0:
+                    continue
+                nnkernels._PLAN_CACHE.clear()
+                for y in (nnkernels.conv2d_stem_s2d(x.contiguous(memory_format=torch.channels_last), conv, "relu"),
+                          nnkernels.conv2d_stem_s2d_planar([(x, None)], conv, "relu")):
+                    err = float((y.detach().double() - yr).abs().max()) / float(yr.abs().max())
+                    assert err <= 4e-6, (bm, bn, err)
+                tried += 1
+    finally:
+        L.sqd_conv_set_plan(0, *geom, 0, 0, 0, 16)
+        nnkernels._PLAN_CACHE.clear()
+    assert tried >= 2
+    assert L.sqd_conv_set_plan(1, *geom, 64, 32, 1, 32 + 1024 + 2048) != 0         # no data gradient for the 4x4 form
