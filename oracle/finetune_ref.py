@@ -55,3 +55,46 @@ def finetune_step(model, optimizer, scheduler, batch, args):
     optimizer.step()
     scheduler.step()
     return loss.detach(), ratios
+
+
+def compute_errors(gt, pred):
+    """finetune/utils.py:76-96 (numpy, in the arrays' own precision: float32 in the reference's validation loop)"""
+    import numpy as np
+    thresh = np.maximum((gt / pred), (pred / gt))
+    a1, a2, a3 = (thresh < 1.25).mean(), (thresh < 1.25 ** 2).mean(), (thresh < 1.25 ** 3).mean()
+    abs_rel = np.mean(np.abs(gt - pred) / gt)
+    sq_rel = np.mean(((gt - pred) ** 2) / gt)
+    rmse = np.sqrt(((gt - pred) ** 2).mean())
+    rmse_log = np.sqrt(((np.log(gt) - np.log(pred)) ** 2).mean())
+    err = np.log(pred) - np.log(gt)
+    silog = np.sqrt(np.mean(err ** 2) - np.mean(err) ** 2) * 100
+    log_10 = (np.abs(np.log10(gt) - np.log10(pred))).mean()
+    return dict(a1=a1, a2=a2, a3=a3, abs_rel=abs_rel, rmse=rmse, log_10=log_10, rmse_log=rmse_log, silog=silog, sq_rel=sq_rel)
+
+
+def validate_image(pred, gt_depth, min_depth_eval, max_depth_eval, garg_crop=True, eigen_crop=False, dataset="kitti"):
+    """the per-image body of validate() (train_ft_SQLdepth.py:347-375): pred, gt_depth [H,W] float32 numpy arrays (the prediction
+    already resized) -> (metrics dict, ratio, number of valid pixels) or None when no pixel is valid"""
+    import numpy as np
+    valid_mask = np.logical_and(gt_depth > min_depth_eval, gt_depth < max_depth_eval)
+    if garg_crop or eigen_crop:
+        gt_height, gt_width = gt_depth.shape
+        eval_mask = np.zeros(valid_mask.shape)
+        if garg_crop:
+            eval_mask[int(0.40810811 * gt_height):int(0.99189189 * gt_height), int(0.03594771 * gt_width):int(0.96405229 * gt_width)] = 1
+        elif dataset == "kitti":
+            eval_mask[int(0.3324324 * gt_height):int(0.91351351 * gt_height), int(0.0359477 * gt_width):int(0.96405229 * gt_width)] = 1
+        else:
+            eval_mask[45:471, 41:601] = 1
+        valid_mask = np.logical_and(valid_mask, eval_mask)
+    if valid_mask.sum() == 0:
+        return None
+    pred = pred[valid_mask].copy()
+    gt = gt_depth[valid_mask]
+    ratio = np.median(gt) / np.median(pred)
+    pred *= ratio
+    pred[pred < min_depth_eval] = min_depth_eval
+    pred[pred > max_depth_eval] = max_depth_eval
+    pred[np.isinf(pred)] = max_depth_eval
+    pred[np.isnan(pred)] = min_depth_eval
+    return compute_errors(gt, pred), float(ratio), int(valid_mask.sum())

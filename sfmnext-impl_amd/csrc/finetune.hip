@@ -105,14 +105,11 @@ __device__ void wave_find_bin(const unsigned *hist, int nb, unsigned r, unsigned
 // patterns order as the values do — of the ground truth and of the prediction at once (two histograms per pass over the crop
 // rectangle); for an even count the upper middle element is the lower one again when its value repeats, else the smallest value
 // above it (one more pass).
-__global__ __launch_bounds__(NT) void median_ratio_kernel(const float *__restrict__ pred, const float *__restrict__ depth,
-                                                          float *__restrict__ ratio, int H, int W, float lo, float hi, Crop c) {
-    __shared__ unsigned hist[2][BINS];
-    __shared__ unsigned found[2][3];
-    __shared__ unsigned nextkey[2];
-    __shared__ int cnt_red[NT / 64];
-    const int b = blockIdx.x;
-    const float *p = pred + (size_t)b * H * W, *d = depth + (size_t)b * H * W;
+// the two medians (ground truth, prediction) over the valid pixels of the crop rectangle; false when nothing is valid.  Block-wide
+// (NT threads); uses hist / found / nextkey / cnt_red in LDS; n_out = number of valid pixels
+__device__ bool joint_medians(const float *__restrict__ p, const float *__restrict__ d, int W, float lo, float hi, const Crop &c,
+                              unsigned (*hist)[BINS], unsigned (*found)[3], unsigned *nextkey, int *cnt_red, float &med_gt, float &med_pred,
+                              int &n_out) {
     const int cw = c.x1 - c.x0, npx = (c.y1 - c.y0) * cw;
     int cnt = 0;
     for (int q = threadIdx.x; q < npx; q += NT) {
@@ -124,10 +121,8 @@ __global__ __launch_bounds__(NT) void median_ratio_kernel(const float *__restric
     __syncthreads();
     int n = 0;
     for (int i = 0; i < NT / 64; ++i) n += cnt_red[i];
-    if (n == 0) {                                       // np.median of an empty array is NaN -> ratio = 1 (train_ft_SQLdepth.py:261-262)
-        if (threadIdx.x == 0) ratio[b] = 1.f;
-        return;
-    }
+    n_out = n;
+    if (n == 0) return false;
     const int shifts[3] = {21, 10, 0}, widths[3] = {11, 11, 10};
     unsigned prefix[2] = {0, 0}, rank[2] = {(unsigned)((n - 1) / 2), (unsigned)((n - 1) / 2)};
     int decided = 0;
@@ -176,8 +171,85 @@ __global__ __launch_bounds__(NT) void median_ratio_kernel(const float *__restric
         for (int a = 0; a < 2; ++a)
             if (need[a]) upper[a] = nextkey[a];
     }
-    if (threadIdx.x == 0)                               // np.median(float32): float32 mean of the middle pair
-        ratio[b] = ((__uint_as_float(prefix[0]) + __uint_as_float(upper[0])) * 0.5f) / ((__uint_as_float(prefix[1]) + __uint_as_float(upper[1])) * 0.5f);
+    // np.median(float32): float32 mean of the middle pair
+    med_gt = (__uint_as_float(prefix[0]) + __uint_as_float(upper[0])) * 0.5f;
+    med_pred = (__uint_as_float(prefix[1]) + __uint_as_float(upper[1])) * 0.5f;
+    return true;
+}
+
+__global__ __launch_bounds__(NT) void median_ratio_kernel(const float *__restrict__ pred, const float *__restrict__ depth,
+                                                          float *__restrict__ ratio, int H, int W, float lo, float hi, Crop c) {
+    __shared__ unsigned hist[2][BINS];
+    __shared__ unsigned found[2][3];
+    __shared__ unsigned nextkey[2];
+    __shared__ int cnt_red[NT / 64];
+    const int b = blockIdx.x;
+    float mg, mp;
+    int n;
+    const bool any = joint_medians(pred + (size_t)b * H * W, depth + (size_t)b * H * W, W, lo, hi, c, hist, found, nextkey, cnt_red, mg, mp, n);
+    if (threadIdx.x == 0) ratio[b] = any ? mg / mp : 1.f;      // np.median of an empty array is NaN -> ratio = 1 (train_ft_SQLdepth.py:261-262)
+}
+
+// validation metrics of one image (train_ft_SQLdepth.py:347-375 + utils.py:76-96): median-scaled, clamped prediction against the ground
+// truth over the valid pixels of the crop; the per-pixel terms in float32 as numpy evaluates them on float32 arrays, their sums in
+// float64.  out[b] = a1, a2, a3, abs_rel, rmse, log_10, rmse_log, silog, sq_rel, ratio, valid pixels (metrics NaN when none)
+__global__ __launch_bounds__(NT) void metric_eval_kernel(const float *__restrict__ pred, const float *__restrict__ depth,
+                                                         double *__restrict__ out, int H, int W, float lo, float hi, Crop c) {
+    __shared__ unsigned hist[2][BINS];
+    __shared__ unsigned found[2][3];
+    __shared__ unsigned nextkey[2];
+    __shared__ int cnt_red[NT / 64];
+    __shared__ double red[9][NT / 64];
+    const int b = blockIdx.x;
+    const float *p = pred + (size_t)b * H * W, *d = depth + (size_t)b * H * W;
+    double *o = out + (size_t)b * 11;
+    float mg, mp;
+    int n;
+    if (!joint_medians(p, d, W, lo, hi, c, hist, found, nextkey, cnt_red, mg, mp, n)) {
+        if (threadIdx.x < 11) o[threadIdx.x] = threadIdx.x == 10 ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
+        return;
+    }
+    const float ratio = mg / mp;
+    const int cw = c.x1 - c.x0, npx = (c.y1 - c.y0) * cw;
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};           // a1 a2 a3 |d|/g d^2 |log10| dlog^2 err err^2... (see below)
+    const float t1 = 1.25f, t2 = 1.25f * 1.25f, t3 = 1.25f * 1.25f * 1.25f;
+    for (int q = threadIdx.x; q < npx; q += NT) {
+        const size_t at = (size_t)(c.y0 + q / cw) * W + c.x0 + q % cw;
+        const float g = d[at];
+        if (!(g > lo && g < hi)) continue;
+        float v = p[at] * ratio;                           // pred *= ratio; clamps; inf -> max, nan -> min  (:370-374)
+        v = v < lo ? lo : v;
+        v = v > hi ? hi : v;
+        if (isinf(v)) v = hi;
+        if (isnan(v)) v = lo;
+        const float th = fmaxf(g / v, v / g), df = g - v;
+        const float lg = logf(g) - logf(v), l10 = fabsf(log10f(g) - log10f(v));
+        s[0] += th < t1 ? 1.0 : 0.0; s[1] += th < t2 ? 1.0 : 0.0; s[2] += th < t3 ? 1.0 : 0.0;
+        s[3] += (double)(fabsf(df) / g);
+        s[4] += (double)(df * df);
+        s[5] += (double)l10;
+        s[6] += (double)(lg * lg);
+        s[7] += (double)(-lg);                             // err = log(pred) - log(gt)
+        s[8] += (double)(df * df / g);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        double v = s[k];
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+        if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double r[9];
+        for (int k = 0; k < 9; ++k) {
+            r[k] = 0.0;
+            for (int w = 0; w < NT / 64; ++w) r[k] += red[k][w];
+        }
+        const double dn = (double)n, me = r[7] / dn;
+        o[0] = r[0] / dn; o[1] = r[1] / dn; o[2] = r[2] / dn; o[3] = r[3] / dn; o[4] = sqrt(r[4] / dn); o[5] = r[5] / dn;
+        o[6] = sqrt(r[6] / dn); o[7] = sqrt(fmax(r[6] / dn - me * me, 0.0)) * 100.0; o[8] = r[8] / dn;
+        o[9] = (double)ratio; o[10] = dn;
+    }
 }
 
 // SILog partial sums over chunks: part[blk] = (n, sum g, sum g^2) in double, g = log(scale_b * pred) - log(depth) where depth > min_depth
@@ -266,6 +338,21 @@ extern "C" int sqd_median_ratio(const float *pred, const float *depth, float *ra
     (void)hipGetLastError();
     hipLaunchKernelGGL(median_ratio_kernel, dim3(nscale), dim3(NT), 0, (hipStream_t)stream, pred, depth, ratio, H, W, min_eval, max_eval, c);
     SQD_CHECK_LAUNCH("sqd_median_ratio");
+    return SQD_OK;
+}
+// pred, depth [B,H,W] float32 (the prediction already at the ground truth's size) -> out [B][11] doubles: a1, a2, a3, abs_rel, rmse, log_10,
+// rmse_log, silog, sq_rel, median ratio, valid pixels — the per-image body of the reference's validate() (train_ft_SQLdepth.py:347-375,
+// utils.py:76-96); crop: 0 none, 1 Garg, 2 Eigen (KITTI), 3 Eigen (NYU: rows 45..470, columns 41..600)
+extern "C" int sqd_metric_depth_eval(const float *pred, const float *depth, double *out, int B, int H, int W, float min_eval, float max_eval,
+                                     int crop, void *stream) {
+    SQD_CHECK_ARG(pred && depth && out && B > 0 && H > 0 && W > 0 && crop >= 0 && crop <= 3 && max_eval > min_eval, "sqd_metric_depth_eval: bad arguments");
+    Crop c = {0, H, 0, W};
+    if (crop == 1) c = Crop{(int)(0.40810811 * H), (int)(0.99189189 * H), (int)(0.03594771 * W), (int)(0.96405229 * W)};
+    if (crop == 2) c = Crop{(int)(0.3324324 * H), (int)(0.91351351 * H), (int)(0.0359477 * W), (int)(0.96405229 * W)};
+    if (crop == 3) c = Crop{45 < H ? 45 : H, 471 < H ? 471 : H, 41 < W ? 41 : W, 601 < W ? 601 : W};
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(metric_eval_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, pred, depth, out, H, W, min_eval, max_eval, c);
+    SQD_CHECK_LAUNCH("sqd_metric_depth_eval");
     return SQD_OK;
 }
 extern "C" int sqd_silog_nblk(int64_t total) { return ew_grid((size_t)total, 1024); }

@@ -69,6 +69,35 @@ class FinetuneTrainer:
         return loss.detach(), ratio
 
 
+@torch.no_grad()
+def validate(trainer, batches):
+    """The reference's validate() (train_ft_SQLdepth.py:323-378) on the device: per batch the model's prediction resized to the ground
+    truth (align_corners), the dense SILog loss of every image, median-scaled and clamped error metrics over the Garg / Eigen crop — one
+    [B,11] table per batch, everything transferred to the host once at the end.  -> (dict of the nine metric means, mean SILog loss).
+    Images without a valid pixel are skipped, as `has_valid_depth` does in the reference's loader."""
+    a, model = trainer.args, trainer.model
+    was_training = model.training
+    model.eval()
+    tables, losses = [], []
+    crop = "garg" if a.garg_crop else ("eigen" if a.dataset == "kitti" else "eigen_nyu") if a.eigen_crop else None
+    try:
+        for batch in batches:
+            img = batch["image"].to(trainer.device)
+            depth = batch["depth"].to(trainer.device).contiguous()
+            frame = img if getattr(model.encoder, "planar_input", False) and img.is_contiguous() else img.contiguous(memory_format=torch.channels_last)
+            pred = ops.ResizeAlignCorners.apply(model(frame).contiguous(), depth.shape[-2], depth.shape[-1])
+            for i in range(pred.shape[0]):                      # the reference validates image by image (batch size 1): one loss per image
+                losses.append(trainer.criterion(pred[i:i + 1], depth[i:i + 1], a.min_depth, interpolate=False))
+            tables.append(ops.metric_depth_eval(pred, depth, a.min_depth_eval, a.max_depth_eval, crop))
+    finally:
+        model.train(was_training)
+    table = torch.cat(tables).cpu().numpy()                     # the only device -> host transfers
+    loss = torch.stack(losses).cpu().numpy()
+    ok = table[:, 10] > 0
+    means = {k: float(table[ok, j].mean()) for j, k in enumerate(ops.METRIC_DEPTH_NAMES)} if ok.any() else {}
+    return means, float(loss[ok].mean()) if ok.any() else float("nan")
+
+
 def synthetic_batch(bs, H, W, Hd=None, Wd=None, seed=0, density=0.3):
     """{"image": [bs,3,H,W] in [0,1], "depth": [bs,1,Hd,Wd] sparse metric depth (0 = no measurement)}"""
     g = torch.Generator().manual_seed(seed)

@@ -505,6 +505,27 @@ class ResizeAlignCorners(torch.autograd.Function):
         return dx, None, None
 
 
+METRIC_DEPTH_NAMES = ("a1", "a2", "a3", "abs_rel", "rmse", "log_10", "rmse_log", "silog", "sq_rel")     # reference finetune/utils.py:95-96
+_CROPS = {None: 0, "garg": 1, "eigen": 2, "eigen_nyu": 3}
+
+
+def metric_depth_eval(pred, depth, min_eval, max_eval, crop=None):
+    """pred, depth [B,1,H,W] or [B,H,W] float32 (prediction at the ground truth's size) -> [B,11] float64 on the device: the nine metrics
+    of METRIC_DEPTH_NAMES, the median-scaling ratio, the number of valid pixels — the per-image body of the reference's validate()
+    (finetune/train_ft_SQLdepth.py:347-375) without the trip through numpy."""
+    if not pred.is_cuda:
+        raise RuntimeError("sqd: metric_depth_eval needs tensors on the MI355X device — there is no CPU fallback")
+    H, W = pred.shape[-2:]
+    B = pred.numel() // (H * W)
+    pred, depth = pred.detach().contiguous().float(), depth.contiguous().float()
+    if depth.numel() != pred.numel():
+        raise ValueError("metric_depth_eval: prediction and ground truth differ in size")
+    out = torch.empty(B, 11, device=pred.device, dtype=torch.float64)
+    _l.check(_l.lib().sqd_metric_depth_eval(_ptr(pred), _ptr(depth), _ptr(out), B, H, W, float(min_eval), float(max_eval), _CROPS[crop],
+                                            _stream()), "metric_depth_eval")
+    return out
+
+
 def median_ratio(pred, depth, nscale, min_eval, max_eval, crop):
     """ratio [nscale] = median(depth[valid]) / median(pred[valid]) per sample (train_ft_SQLdepth.py:234-263); crop: None, 'garg' or 'eigen'."""
     B, _, H, W = depth.shape

@@ -427,6 +427,20 @@ def g21_silog(T):
          loss_plain=np.float32(loss2.item()), grad_hr=q.grad.numpy())
 
 
+def g22_metric_errors(T):
+    """the reference's compute_errors (finetune/utils.py:76-96) on float32 arrays, as its validation loop calls it"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("ref_ft_utils", os.path.join(REF, "finetune", "utils.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rs = np.random.RandomState(2222)
+    gt = rs.uniform(1.0, 80.0, 5000).astype(np.float32)
+    pred = (gt * np.exp(rs.normal(0.0, 0.25, 5000))).astype(np.float32)
+    pred = np.clip(pred, 1e-3, 80.0).astype(np.float32)
+    e = mod.compute_errors(gt, pred)
+    save("g22_metric_errors", gt=gt, pred=pred, **{k: np.float64(v) for k, v in e.items()})
+
+
 def build_reference_models(nets, kind):
     if kind == "res18":
         enc = nets["lite_res_encoder"].LiteResnetEncoderDecoder(model_dim=16)
@@ -541,6 +555,7 @@ def main():
     g19_eval(T)
     g20_unet_decoder(T)
     g21_silog(T)
+    g22_metric_errors(T)
     g1_pose(T)
     g2_g3_g4_geometry(T)
     g5_g6_ssim(T)

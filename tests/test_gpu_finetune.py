@@ -161,3 +161,65 @@ def test_finetune_step_matches_oracle():
             continue
         d = (mine[kk].detach().cpu() - v).abs()
         assert float((d > 3e-5 + 1e-3 * v.abs()).float().mean()) < 2e-2, (kk, float(d.max()))
+
+
+@pytest.mark.parametrize("crop", ["garg", "eigen", "eigen_nyu", None])
+def test_metric_depth_eval(crop):
+    """sqd_metric_depth_eval against the oracle's restatement of validate()'s per-image body (numpy float32, as the reference; its
+    compute_errors is pinned to the reference's own by G22): the nine metrics within 2e-5 relative (numpy sums float32 pairwise, the
+    kernel in float64), ratio and valid count exact."""
+    from oracle import finetune_ref as FR
+    from sqd import ops
+    rs = np.random.RandomState(9)
+    B, H, W = 4, 480, 640
+    depth = rs.uniform(0.5, 90.0, (B, H, W)).astype(np.float32)
+    depth[rs.uniform(size=depth.shape) > 0.25] = 0.0
+    depth[2] = 0.0                                                   # an image without ground truth: NaN metrics, 0 valid pixels
+    pred = (np.abs(depth + rs.normal(0, 3.0, depth.shape)) * 1.7 + 0.05 + (depth == 0) * rs.uniform(1, 50, depth.shape)).astype(np.float32)
+    got = ops.metric_depth_eval(torch.from_numpy(pred).cuda(), torch.from_numpy(depth).cuda(), 1e-3, 80.0, crop).cpu().numpy()
+    for i in range(B):
+        want = FR.validate_image(pred[i], depth[i], 1e-3, 80.0, garg_crop=crop == "garg", eigen_crop=crop in ("eigen", "eigen_nyu"),
+                                 dataset="nyu" if crop == "eigen_nyu" else "kitti")
+        if want is None:
+            assert got[i, 10] == 0 and np.isnan(got[i, :10]).all()
+            continue
+        e, ratio, n = want
+        assert got[i, 10] == n and np.float32(got[i, 9]) == np.float32(ratio)
+        for j, k in enumerate(ops.METRIC_DEPTH_NAMES):
+            assert abs(got[i, j] - float(e[k])) <= 2e-5 * abs(float(e[k])) + 1e-7, (i, k, got[i, j], float(e[k]))
+    if crop is None:
+        # a prediction that is the ground truth at half scale: the median ratio undoes it — a1..a3 = 1, errors 0
+        gt = rs.uniform(1.0, 70.0, (1, 50, 100)).astype(np.float32)
+        t = ops.metric_depth_eval(torch.from_numpy(gt * np.float32(0.5)).cuda(), torch.from_numpy(gt).cuda(), 1e-3, 80.0, None).cpu().numpy()[0]
+        assert t[0] == 1 and t[1] == 1 and t[2] == 1 and abs(t[3]) < 1e-6 and abs(t[9] - 2.0) < 1e-6 and t[10] == 5000
+
+
+def test_finetune_validate_matches_oracle():
+    """validate() of the finetune loop on a narrow ConvNeXt U-Net: mean metrics and mean SILog against the oracle's image-by-image numpy loop"""
+    from finetune.train_ft_SQLdepth import FinetuneArgs, FinetuneTrainer, synthetic_batch, validate
+    from finetune.loss import SILogLoss
+    from options import MonodepthOptions
+    from oracle import finetune_ref as FR
+    from sqd import ops
+    torch.manual_seed(1)
+    opt = MonodepthOptions().parse(["--backbone", "convnext_large", "--model_dim", "16", "--patch_size", "8", "--query_nums", "12", "--dim_out", "24",
+                                    "--dec_channels", "64", "32", "16", "8", "--height", "64", "--width", "96", "--max_depth", "80.0",
+                                    "--sqd_no_conv_tune", "--sqd_synthetic"])
+    opt.sqd_convnext_depths, opt.sqd_convnext_dims = (1, 1, 2, 1), (16, 32, 64, 128)
+    args = FinetuneArgs(bs=2, lr=1e-4, epochs=1)
+    tr = FinetuneTrainer(opt, args, steps_per_epoch=2)
+    batches = [synthetic_batch(2, 64, 96, 88, 120, seed=s) for s in (5, 6)]
+    means, si = validate(tr, batches)
+    tr.model.eval()
+    want, losses = [], []
+    with torch.no_grad():
+        for b in batches:
+            pred = ops.ResizeAlignCorners.apply(tr.model(b["image"].cuda()).contiguous(), 88, 120).cpu()
+            for i in range(2):
+                r = FR.validate_image(pred[i, 0].numpy(), b["depth"][i, 0].numpy(), args.min_depth_eval, args.max_depth_eval, garg_crop=True)
+                want.append(r[0])
+                losses.append(float(FR.SILogLoss()(pred[i:i + 1], b["depth"][i:i + 1], mask=b["depth"][i:i + 1] > args.min_depth, interpolate=False)))
+    for k in ops.METRIC_DEPTH_NAMES:
+        w = float(np.mean([float(e[k]) for e in want]))
+        assert abs(means[k] - w) <= 5e-5 * abs(w) + 1e-6, (k, means[k], w)
+    assert abs(si - float(np.mean(losses))) <= 1e-4 * abs(float(np.mean(losses)))

@@ -354,3 +354,12 @@ def test_g21_silog(golden):
     loss2.backward()
     assert abs(float(loss2) - float(g["loss_plain"])) <= 1e-6 * abs(float(g["loss_plain"]))
     close(q.grad, g["grad_hr"], atol=1e-7)
+
+
+def test_g22_metric_errors(golden):
+    """oracle compute_errors against the reference's own function (finetune/utils.py:76-96), float32 arrays as in its validation loop"""
+    from oracle import finetune_ref as FR
+    g = golden("g22_metric_errors")
+    e = FR.compute_errors(g["gt"], g["pred"])
+    for k, v in e.items():
+        assert float(v) == float(g[k]), k
