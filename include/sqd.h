@@ -499,9 +499,10 @@ int sqd_median_ratio(const float *pred, const float *depth, float *ratio, int ns
  * rmse_log, silog, sq_rel, median ratio, valid pixels (metrics NaN when 0): the per-image body of the reference's validation loop
  * (finetune/train_ft_SQLdepth.py:347-375: valid = min_eval < depth < max_eval inside the crop, pred *= median(gt) / median(pred) with exact
  * float32 medians, clamp to [min_eval, max_eval]; finetune/utils.py:76-96 compute_errors — per-pixel terms in float32 as numpy forms them,
- * sums in float64).  crop: 0 none, 1 Garg, 2 Eigen (KITTI), 3 Eigen (NYU, rows 45..470 x columns 41..600).                          */
+ * sums in float64).  crop: 0 none, 1 Garg, 2 Eigen (KITTI), 3 Eigen (NYU, rows 45..470 x columns 41..600).  median_scaling = 0: the
+ * body of finetune/evaluate_metric_depth.py:65-141 instead (no scaling, no clamps, inf -> max_eval, nan -> min_eval, ratio = 1).  */
 int sqd_metric_depth_eval(const float *pred, const float *depth, double *out, int B, int H, int W, float min_eval, float max_eval,
-                          int crop, void *stream);
+                          int crop, int median_scaling, void *stream);
 int sqd_silog_nblk(int64_t total);
 int sqd_silog_fwd(const float *pred, const float *depth, const float *scale, double *part, float *stats, int B, int HW, float min_depth,
                   void *stream);

@@ -98,3 +98,25 @@ def validate_image(pred, gt_depth, min_depth_eval, max_depth_eval, garg_crop=Tru
     pred[np.isinf(pred)] = max_depth_eval
     pred[np.isnan(pred)] = min_depth_eval
     return compute_errors(gt, pred), float(ratio), int(valid_mask.sum())
+
+
+def eval_image(final, gt, min_depth, max_depth, garg_crop=True, eigen_crop=False, dataset="kitti"):
+    """the per-image body of evaluate_metric_depth.py's eval() (:84-139): no median scaling, no clamps"""
+    import numpy as np
+    final = final.copy()
+    final[np.isinf(final)] = max_depth
+    final[np.isnan(final)] = min_depth
+    valid_mask = np.logical_and(gt > min_depth, gt < max_depth)
+    if garg_crop or eigen_crop:
+        gt_height, gt_width = gt.shape
+        eval_mask = np.zeros(valid_mask.shape)
+        if garg_crop:
+            eval_mask[int(0.40810811 * gt_height):int(0.99189189 * gt_height), int(0.03594771 * gt_width):int(0.96405229 * gt_width)] = 1
+        elif dataset == "kitti":
+            eval_mask[int(0.3324324 * gt_height):int(0.91351351 * gt_height), int(0.0359477 * gt_width):int(0.96405229 * gt_width)] = 1
+        else:
+            eval_mask[45:471, 41:601] = 1
+        valid_mask = np.logical_and(valid_mask, eval_mask)
+    if valid_mask.sum() == 0:
+        return None
+    return compute_errors(gt[valid_mask], final[valid_mask])

@@ -193,6 +193,7 @@ __global__ __launch_bounds__(NT) void median_ratio_kernel(const float *__restric
 // validation metrics of one image (train_ft_SQLdepth.py:347-375 + utils.py:76-96): median-scaled, clamped prediction against the ground
 // truth over the valid pixels of the crop; the per-pixel terms in float32 as numpy evaluates them on float32 arrays, their sums in
 // float64.  out[b] = a1, a2, a3, abs_rel, rmse, log_10, rmse_log, silog, sq_rel, ratio, valid pixels (metrics NaN when none)
+template <bool SCALE>
 __global__ __launch_bounds__(NT) void metric_eval_kernel(const float *__restrict__ pred, const float *__restrict__ depth,
                                                          double *__restrict__ out, int H, int W, float lo, float hi, Crop c) {
     __shared__ unsigned hist[2][BINS];
@@ -209,17 +210,20 @@ __global__ __launch_bounds__(NT) void metric_eval_kernel(const float *__restrict
         if (threadIdx.x < 11) o[threadIdx.x] = threadIdx.x == 10 ? 0.0 : __longlong_as_double(0x7ff8000000000000ll);
         return;
     }
-    const float ratio = mg / mp;
+    // SCALE: validate() (median scaling, clamps); else evaluate_metric_depth.py's eval(): the prediction as it is, only inf / nan replaced
+    const float ratio = SCALE ? mg / mp : 1.f;
     const int cw = c.x1 - c.x0, npx = (c.y1 - c.y0) * cw;
-    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};           // a1 a2 a3 |d|/g d^2 |log10| dlog^2 err err^2... (see below)
+    double s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     const float t1 = 1.25f, t2 = 1.25f * 1.25f, t3 = 1.25f * 1.25f * 1.25f;
     for (int q = threadIdx.x; q < npx; q += NT) {
         const size_t at = (size_t)(c.y0 + q / cw) * W + c.x0 + q % cw;
         const float g = d[at];
         if (!(g > lo && g < hi)) continue;
-        float v = p[at] * ratio;                           // pred *= ratio; clamps; inf -> max, nan -> min  (:370-374)
-        v = v < lo ? lo : v;
-        v = v > hi ? hi : v;
+        float v = SCALE ? p[at] * ratio : p[at];           // pred *= ratio; clamps; inf -> max, nan -> min  (:370-374)
+        if (SCALE) {
+            v = v < lo ? lo : v;
+            v = v > hi ? hi : v;
+        }
         if (isinf(v)) v = hi;
         if (isnan(v)) v = lo;
         const float th = fmaxf(g / v, v / g), df = g - v;
@@ -342,16 +346,18 @@ extern "C" int sqd_median_ratio(const float *pred, const float *depth, float *ra
 }
 // pred, depth [B,H,W] float32 (the prediction already at the ground truth's size) -> out [B][11] doubles: a1, a2, a3, abs_rel, rmse, log_10,
 // rmse_log, silog, sq_rel, median ratio, valid pixels — the per-image body of the reference's validate() (train_ft_SQLdepth.py:347-375,
-// utils.py:76-96); crop: 0 none, 1 Garg, 2 Eigen (KITTI), 3 Eigen (NYU: rows 45..470, columns 41..600)
+// utils.py:76-96); crop: 0 none, 1 Garg, 2 Eigen (KITTI), 3 Eigen (NYU: rows 45..470, columns 41..600).  median_scaling = 0: the body of
+// evaluate_metric_depth.py:65-141 instead — the prediction unscaled and unclamped (inf -> max_eval, nan -> min_eval), ratio reported as 1
 extern "C" int sqd_metric_depth_eval(const float *pred, const float *depth, double *out, int B, int H, int W, float min_eval, float max_eval,
-                                     int crop, void *stream) {
+                                     int crop, int median_scaling, void *stream) {
     SQD_CHECK_ARG(pred && depth && out && B > 0 && H > 0 && W > 0 && crop >= 0 && crop <= 3 && max_eval > min_eval, "sqd_metric_depth_eval: bad arguments");
     Crop c = {0, H, 0, W};
     if (crop == 1) c = Crop{(int)(0.40810811 * H), (int)(0.99189189 * H), (int)(0.03594771 * W), (int)(0.96405229 * W)};
     if (crop == 2) c = Crop{(int)(0.3324324 * H), (int)(0.91351351 * H), (int)(0.0359477 * W), (int)(0.96405229 * W)};
     if (crop == 3) c = Crop{45 < H ? 45 : H, 471 < H ? 471 : H, 41 < W ? 41 : W, 601 < W ? 601 : W};
     (void)hipGetLastError();
-    hipLaunchKernelGGL(metric_eval_kernel, dim3(B), dim3(NT), 0, (hipStream_t)stream, pred, depth, out, H, W, min_eval, max_eval, c);
+    if (median_scaling) hipLaunchKernelGGL(metric_eval_kernel<true>, dim3(B), dim3(NT), 0, (hipStream_t)stream, pred, depth, out, H, W, min_eval, max_eval, c);
+    else hipLaunchKernelGGL(metric_eval_kernel<false>, dim3(B), dim3(NT), 0, (hipStream_t)stream, pred, depth, out, H, W, min_eval, max_eval, c);
     SQD_CHECK_LAUNCH("sqd_metric_depth_eval");
     return SQD_OK;
 }

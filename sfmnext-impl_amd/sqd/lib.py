@@ -160,7 +160,7 @@ _SIGNATURES = {
     "sqd_resize_ac_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_resize_ac_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_median_ratio": (_I, [_P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),
-    "sqd_metric_depth_eval": (_I, [_P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _P]),
+    "sqd_metric_depth_eval": (_I, [_P, _P, _P, _I, _I, _I, ctypes.c_float, ctypes.c_float, _I, _I, _P]),
     "sqd_silog_nblk": (_I, [ctypes.c_int64]),
     "sqd_silog_fwd": (_I, [_P, _P, _P, _P, _P, _I, _I, _F, _P]),
     "sqd_silog_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),

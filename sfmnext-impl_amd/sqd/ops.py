@@ -509,10 +509,11 @@ METRIC_DEPTH_NAMES = ("a1", "a2", "a3", "abs_rel", "rmse", "log_10", "rmse_log",
 _CROPS = {None: 0, "garg": 1, "eigen": 2, "eigen_nyu": 3}
 
 
-def metric_depth_eval(pred, depth, min_eval, max_eval, crop=None):
+def metric_depth_eval(pred, depth, min_eval, max_eval, crop=None, median_scaling=True):
     """pred, depth [B,1,H,W] or [B,H,W] float32 (prediction at the ground truth's size) -> [B,11] float64 on the device: the nine metrics
     of METRIC_DEPTH_NAMES, the median-scaling ratio, the number of valid pixels — the per-image body of the reference's validate()
-    (finetune/train_ft_SQLdepth.py:347-375) without the trip through numpy."""
+    (finetune/train_ft_SQLdepth.py:347-375) without the trip through numpy; median_scaling=False: that of evaluate_metric_depth.py's
+    eval() (:65-141: the prediction unscaled and unclamped)."""
     if not pred.is_cuda:
         raise RuntimeError("sqd: metric_depth_eval needs tensors on the MI355X device — there is no CPU fallback")
     H, W = pred.shape[-2:]
@@ -522,7 +523,7 @@ def metric_depth_eval(pred, depth, min_eval, max_eval, crop=None):
         raise ValueError("metric_depth_eval: prediction and ground truth differ in size")
     out = torch.empty(B, 11, device=pred.device, dtype=torch.float64)
     _l.check(_l.lib().sqd_metric_depth_eval(_ptr(pred), _ptr(depth), _ptr(out), B, H, W, float(min_eval), float(max_eval), _CROPS[crop],
-                                            _stream()), "metric_depth_eval")
+                                            1 if median_scaling else 0, _stream()), "metric_depth_eval")
     return out
 
 

@@ -223,3 +223,51 @@ def test_finetune_validate_matches_oracle():
         w = float(np.mean([float(e[k]) for e in want]))
         assert abs(means[k] - w) <= 5e-5 * abs(w) + 1e-6, (k, means[k], w)
     assert abs(si - float(np.mean(losses))) <= 1e-4 * abs(float(np.mean(losses)))
+
+
+def test_metric_depth_eval_without_median_scaling():
+    """evaluate_metric_depth.py's eval() body: unscaled, unclamped prediction (inf / nan replaced) against the oracle"""
+    from oracle import finetune_ref as FR
+    from sqd import ops
+    rs = np.random.RandomState(11)
+    B, H, W = 3, 352, 1216
+    depth = rs.uniform(0.5, 90.0, (B, H, W)).astype(np.float32)
+    depth[rs.uniform(size=depth.shape) > 0.2] = 0.0
+    pred = (np.abs(depth + rs.normal(0, 2.0, depth.shape)) + 0.05 + (depth == 0) * rs.uniform(1, 50, depth.shape)).astype(np.float32)
+    pred[0, 200, 300], pred[1, 210, 400] = np.inf, np.nan
+    depth[0, 200, 300], depth[1, 210, 400] = 30.0, 20.0
+    got = ops.metric_depth_eval(torch.from_numpy(pred).cuda(), torch.from_numpy(depth).cuda(), 1e-3, 80.0, "garg", median_scaling=False).cpu().numpy()
+    for i in range(B):
+        e = FR.eval_image(pred[i], depth[i], 1e-3, 80.0, garg_crop=True)
+        assert got[i, 9] == 1.0
+        for j, k in enumerate(ops.METRIC_DEPTH_NAMES):
+            assert abs(got[i, j] - float(e[k])) <= 2e-5 * abs(float(e[k])) + 1e-7, (i, k, got[i, j], float(e[k]))
+
+
+def test_predict_tta_and_evaluate():
+    """flip test-time augmentation + evaluate() on a narrow model against the same composition on the host"""
+    from finetune.evaluate_metric_depth import evaluate, predict_tta
+    from finetune.train_ft_SQLdepth import FinetuneArgs, FinetuneTrainer, synthetic_batch
+    from options import MonodepthOptions
+    from oracle import finetune_ref as FR
+    torch.manual_seed(2)
+    opt = MonodepthOptions().parse(["--backbone", "convnext_large", "--model_dim", "16", "--patch_size", "8", "--query_nums", "12", "--dim_out", "24",
+                                    "--dec_channels", "64", "32", "16", "8", "--height", "64", "--width", "96", "--max_depth", "80.0",
+                                    "--sqd_no_conv_tune", "--sqd_synthetic"])
+    opt.sqd_convnext_depths, opt.sqd_convnext_dims = (1, 1, 2, 1), (16, 32, 64, 128)
+    args = FinetuneArgs(bs=2)
+    tr = FinetuneTrainer(opt, args, steps_per_epoch=2)
+    tr.model.eval()
+    b = synthetic_batch(2, 64, 96, 64, 96, seed=3)
+    img = b["image"].cuda()
+    with torch.no_grad():
+        p0 = tr.model(img.contiguous(memory_format=torch.channels_last))
+        p1 = torch.flip(tr.model(torch.flip(img, [3]).contiguous(memory_format=torch.channels_last)), [3])
+        want = F.interpolate(0.5 * (p0 + p1), (64, 96), mode="bilinear", align_corners=True)
+    got = predict_tta(tr.model, img)
+    assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max())
+    metrics, invalid = evaluate(tr.model, [b], args)
+    e = [FR.eval_image(want[i, 0].cpu().numpy(), b["depth"][i, 0].numpy(), args.min_depth, args.max_depth, garg_crop=True) for i in range(2)]
+    assert invalid == 0
+    for k, v in metrics.items():
+        assert abs(v - round(float(np.mean([float(x[k]) for x in e])), 3)) <= 1.1e-3, k
