@@ -29,6 +29,14 @@ print("RESULT " + json.dumps(out))
 DIST = {"SQD_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1"}
 
 
+def _free_port():
+    """a port nobody listens on right now (fixed ports collide with the TIME_WAIT sockets of a previous run of this test)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return str(sk.getsockname()[1])
+
+
 def _run(env_extra, args=()):
     env = dict(os.environ, **env_extra)
     r = subprocess.run([sys.executable, "-c", SCRIPT % {"repo": REPO}, *args], env=env, capture_output=True, text=True, timeout=600)
@@ -46,14 +54,14 @@ def _same_training(plain, dist):
 
 def test_one_rank_rccl_reducer_trains_like_single_process():
     plain = _run({}, ["--sqd_no_graph"])
-    dist = _run(dict(DIST, MASTER_PORT="29541"), ["--sqd_no_graph"])          # eager: hooks overlap the all-reduces with backward
+    dist = _run(dict(DIST, MASTER_PORT=_free_port()), ["--sqd_no_graph"])          # eager: hooks overlap the all-reduces with backward
     assert not plain["reducer"] and dist["reducer"] and dist["grad_is_bucket_view"] and not dist["graph"]
     _same_training(plain, dist)
     # default multi-rank mode: ONE hipGraph holding forward, backward, the bucket gathers + RCCL all-reduces launched by the
     # autograd hooks (graph branches next to the rest of backward) and Adam
-    graphed = _run(dict(DIST, MASTER_PORT="29542"), [])
+    graphed = _run(dict(DIST, MASTER_PORT=_free_port()), [])
     assert graphed["reducer"] and graphed["graph"] and graphed["grad_is_bucket_view"]
     _same_training(plain, graphed)
-    post = _run(dict(DIST, MASTER_PORT="29543"), ["--sqd_graph_ddp", "post"])    # forward+backward as a hipGraph, then all-reduce + Adam
+    post = _run(dict(DIST, MASTER_PORT=_free_port()), ["--sqd_graph_ddp", "post"])    # forward+backward as a hipGraph, then all-reduce + Adam
     assert post["reducer"] and post["graph"] and post["grad_is_bucket_view"]
     _same_training(plain, post)

@@ -190,10 +190,17 @@ def _ddp_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_grad_bucket_reducer_gloo_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -261,7 +268,7 @@ def _trainer_params_worker(rank, world, port, q):
 def test_reducer_on_trainer_parameter_set_gloo_world2():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
+    port = _free_port()
     procs = [ctx.Process(target=_trainer_params_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
