@@ -398,11 +398,13 @@ def test_input_patch_plans(N, C, H, W, K):
     assert L.sqd_conv_set_plan(0, N, H, W, C, K, 3, 3, 2, 1, (H - 1) // 2 + 1, (W - 1) // 2 + 1, 128, 64, 1, 32 + 1024 + 2048) != 0    # stride 2: refused
 
 
-def test_input_patch_plan_feeds_batchnorm_statistics():
-    """conv -> BatchNorm(train) -> ReLU with the per-patch statistics partials of the input-patch kernel"""
+@pytest.mark.parametrize("K,plans", [(96, ((128, 64), (64, 128), (128, 128))), (32, ((128, 32), (64, 32))), (16, ((128, 32), (64, 32)))])
+def test_input_patch_plan_feeds_batchnorm_statistics(K, plans):
+    """conv -> BatchNorm(train) -> ReLU with the per-patch statistics partials of the input-patch kernel (32-channel tiles: the waves
+    that split the patch rows add their column sums through LDS)"""
     from sqd import lib, nnkernels, nnops
     L = lib.lib()
-    N, C, H, W, K = 3, 64, 21, 37, 96
+    N, C, H, W = 3, 64, 21, 37
     torch.manual_seed(5)
     conv, bn = nn.Conv2d(C, K, 3, 1, 1, bias=False), nn.BatchNorm2d(K)
     with torch.no_grad():
@@ -421,7 +423,7 @@ def test_input_patch_plan_feeds_batchnorm_statistics():
     geom = (N, H, W, C, K, 3, 3, 1, 1, H, W)
     nnops.set_native_conv(True)
     try:
-        for bm, bn_t in ((128, 64), (64, 128), (128, 128)):
+        for bm, bn_t in plans:
             assert L.sqd_conv_set_plan(0, *geom, bm, bn_t, 1, 32 + 1024 + 2048) == 0
             nnkernels._PLAN_CACHE.clear()
             bn_g.load_state_dict({k: v.float() for k, v in nn.BatchNorm2d(K).state_dict().items()} | {"weight": bn.weight.float(), "bias": bn.bias.float()})
@@ -498,3 +500,36 @@ def test_input_patch_plans_on_the_stems(N, C, H, W, K):
         nnkernels._PLAN_CACHE.clear()
     assert tried >= 2
     assert L.sqd_conv_set_plan(1, *geom, 64, 32, 1, 32 + 1024 + 2048) != 0         # no data gradient for the 4x4 form
+
+
+@pytest.mark.parametrize("bm,bn_t", [(128, 64), (64, 64), (128, 32), (64, 32)])
+def test_stem_with_input_patch_plan_feeds_batchnorm_statistics(bm, bn_t):
+    """the encoder stem as the Trainer runs it: planar frame -> (x - 0.45) / 0.225 -> 7x7/2 convolution (4x4 input-patch plan on the
+    space-to-depth image, waves splitting the patch rows) -> BatchNorm(train) from the epilogue's per-patch partials -> ReLU"""
+    from sqd import lib, nnkernels, nnops
+    L = lib.lib()
+    N, H, W, K = 3, 44, 72, 64 if bn_t == 64 else 32
+    torch.manual_seed(bm + bn_t)
+    conv, bn = nn.Conv2d(3, K, 7, 2, 3, bias=False), nn.BatchNorm2d(K)
+    x = torch.rand(N, 3, H, W)
+    conv_g, bn_g = nn.Conv2d(3, K, 7, 2, 3, bias=False).cuda(), nn.BatchNorm2d(K).cuda()
+    conv_g.load_state_dict(conv.state_dict())
+    conv, bn = conv.double(), bn.double()
+    yr = F.relu(bn(conv((x.double() - 0.45) / 0.225)))
+    gy = torch.randn_like(yr)
+    gwr, = torch.autograd.grad(yr, conv.weight, gy)
+    geom = (N, H // 2, W // 2, 16, K, 4, 4, 1, 2, H // 2, W // 2)
+    nnops.set_native_conv(True)
+    try:
+        assert L.sqd_conv_set_plan(0, *geom, bm, bn_t, 1, 32 + 1024 + 2048) == 0
+        nnkernels._PLAN_CACHE.clear()
+        y = nnops.conv_bn_act(x.cuda(), conv_g, bn_g, "relu", input_affine=(0.45, 0.225))
+        assert nnkernels.conv_stats_rows(geom) == N * (((H // 2) + bm // 16 - 1) // (bm // 16)) * (((W // 2) + 15) // 16)
+        gw, = torch.autograd.grad(y, conv_g.weight, gy.float().cuda())
+    finally:
+        L.sqd_conv_set_plan(0, *geom, 0, 0, 0, 16)
+        nnkernels._PLAN_CACHE.clear()
+        nnops.set_native_conv(False)
+    assert torch.allclose(y.detach().cpu().double(), yr.detach(), rtol=1e-4, atol=2e-4)
+    assert torch.allclose(bn_g.running_var.cpu().double(), bn.running_var, rtol=1e-4, atol=1e-5)
+    assert float((gw.cpu().double() - gwr).abs().max()) <= 1e-3 * float(gwr.abs().max())
