@@ -98,3 +98,68 @@ def test_graph_replay_trains_every_parameter():
             stem.add_(0.2 * torch.randn_like(stem))            # (not a rescaling: BatchNorm would undo that)
         after = float(tr.train_step(inputs)[1]["loss"])
         assert abs(after - before) > 1e-3 * abs(before), (before, after)
+
+
+def test_tuned_plans_train_like_the_default_plans():
+    """The configuration that is benchmarked — first-step plan timing on: per layer the fastest of the fp32, three-term bf16,
+    input-patch (3x3 and stems) and weight-gradient variants — must train like the library's default plans: every plan is an fp32-level
+    evaluation of the same convolution, so the losses of 7 steps agree to 1e-4 and the parameters stay inside the run-to-run envelope.
+    ResNet-50 at 96x160 (every stage keeps at least 3x5 pixels), batch 3."""
+    global ARGS
+    saved = ARGS
+    base = [a for a in ARGS if a != "--sqd_no_conv_tune"]
+    for key, val in (("--backbone", "resnet"), ("--height", "96"), ("--width", "160"), ("--batch_size", "2")):
+        base[base.index(key) + 1] = val
+    base += ["--num_layers", "50", "--num_features", "64"]
+
+    def run50(extra, nsteps=5):
+        from options import MonodepthOptions
+        from trainer import Trainer
+        from datasets.synthetic import synthetic_batch
+        from sqd import nnkernels
+        torch.manual_seed(0)
+        tr = Trainer(MonodepthOptions().parse(base + extra))
+        tr.set_train()
+        for m in tr.models.values():
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+                if isinstance(mod, torch.nn.MultiheadAttention):
+                    mod.dropout = 0.0
+        losses = []
+        g = torch.Generator().manual_seed(5)
+        for i in range(nsteps):
+            inputs = synthetic_batch(2, 96, 160, start=2 * i, device=tr.device)
+            inputs[("noise", 0)] = torch.randn(2, 2, 96, 160, generator=g).cuda()
+            _, ls = tr.train_step(inputs)
+            losses.append(float(ls["loss"]))
+        torch.cuda.synchronize()
+        params = {n + "." + k: v.detach().clone() for n, m in tr.models.items() for k, v in m.state_dict().items()}
+        return losses, params, set(nnkernels._TUNED)
+    try:
+        loss_d, par_d, _ = run50(["--sqd_no_graph", "--sqd_no_conv_tune"])
+        loss_d2, par_d2, _ = run50(["--sqd_no_graph", "--sqd_no_conv_tune"])
+        _, par1_d, _ = run50(["--sqd_no_graph", "--sqd_no_conv_tune"], 1)
+        loss_t, par_t, tuned = run50(["--sqd_no_graph"])
+        _, par1_t, _ = run50(["--sqd_no_graph"], 1)              # (plans stay registered from the run above)
+    finally:
+        ARGS = saved
+        from sqd import lib, nnkernels
+        for key in list(nnkernels._TUNED):                 # leave no measured plan behind for the tests that follow
+            if key[0] in (0, 1):
+                lib.lib().sqd_conv_set_plan(key[0], *key[1:], 0, 0, 0, 16)
+            elif key[0] == "w":
+                lib.lib().sqd_conv_wgrad_set_plan(*key[1:], -1, 0)
+        nnkernels._TUNED.clear()
+        nnkernels._PLAN_CACHE.clear()
+    assert len(tuned) > 40, "the tuned run must have timed its layers"
+    for a, b in zip(loss_d, loss_t):
+        assert abs(a - b) <= 1e-4 * abs(a) + 1e-6, (loss_d, loss_t)
+    assert _drift(par_d, par_d2)[1] <= 1e-6                      # the default plans are deterministic
+    # The state after ONE step separates a wrong kernel from amplification (after a few steps Adam's m / sqrt(v) has turned last-bit
+    # gradient differences on zero-initialised biases into whole steps of lr, and the 3x5-pixel BatchNorm statistics of layer 4 follow):
+    # the BatchNorm running statistics of the first forward pass depend on the forward kernels alone
+    for k in par1_d:
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            a, b = par1_d[k].double(), par1_t[k].double()
+            assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-7, k       # fp32 rounding through up to 53 layers
