@@ -210,6 +210,11 @@ def _tune_conv(mode, geom, launch):
             e1.record()
             e1.synchronize()
             t = e0.elapsed_time(e1)
+            if mode == 0 and z > 1 and not os.environ.get("SQD_TUNE_NO_STATS_PENALTY"):
+                # a forward plan that splits the reduction writes no BatchNorm partials: the BatchNorm that follows (nearly every
+                # convolution of these networks has one) then reads the output once more for its statistics — charge that pass
+                # (output bytes at ~4 TB/s + a launch) for the 3 timed launches
+                t += 3.0 * (geom[0] * geom[9] * geom[10] * geom[4] * 4 / 4.0e12 + 3.0e-6) * 1e3
             if best is None or t < best[0]:
                 best = (t, bm, bn, z, bk)
     _PLAN_CACHE.pop(key, None)
