@@ -20,7 +20,6 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(REPO, "sfmnext-impl_amd"))
 
 import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
 
 CONFIG_B = ["--backbone", "resnet", "--num_layers", "50", "--num_features", "256", "--model_dim", "32",
             "--patch_size", "16", "--query_nums", "64", "--dim_out", "64", "--height", "192", "--width", "640",
@@ -235,9 +234,12 @@ def main():
     rank, dev = trainer.rank, trainer.device
     inputs = synthetic_batch(opts.batch_size, opts.height, opts.width, opts.frame_ids, start=rank * opts.batch_size, device=dev)
 
+    from sqd import ddp
+
     def sync():
-        if world > 1:
-            dist.barrier()
+        torch.cuda.synchronize()
+        if ddp.COMM is not None:
+            ddp.COMM.barrier()          # an all-reduce over RCCL + a stream synchronize: every rank's device work is done
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -248,9 +250,9 @@ def main():
         _, losses = trainer.train_step(dict(inputs))
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if ddp.COMM is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ddp.COMM.all_reduce(t, "max")
         elapsed = float(t.item())
     loss = float(losses["loss"].detach().cpu())
 
@@ -268,12 +270,16 @@ def main():
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": workload_name(opts),
                           "global_batch": world * opts.batch_size, "parallelism": "dp%d" % world,
+                          "exchange": None if trainer.reducer is None else {
+                              "communicator": type(trainer.reducer.comm).__name__, "ranks": trainer.reducer.comm.world,
+                              "buckets": len(trainer.reducer.buckets or ()), "bucket_mb": opts.sqd_bucket_mb,
+                              "mode": ("eager hooks" if trainer._graph is None else
+                                       "all-reduces captured in the step graph" if opts.sqd_graph_ddp != "post" else
+                                       "graph of forward+backward, then all-reduce + Adam")},
                           "operator_backends": nnops.backend_report()},
                "final_loss": round(loss, 6), "roofline": roof, "cpu_baseline": cpu}
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ddp.shutdown()
 
 
 if __name__ == "__main__":

@@ -513,6 +513,31 @@ int sqd_clip_coef(const float *part, int n, double max_norm, float *coef_norm, v
 int sqd_adamw_step(const void *recs, const void *grads, const void *chunks, int nchunks, double lr, double beta1, double beta2,
                    double eps, double weight_decay, int step, const float *gscale, void *stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * (19) gradient exchange across the GPUs of a node: a RCCL communicator owned by the library
+ * replaces: nn.DataParallel's gather of the replicas' gradients onto GPU 0       reference trainer.py:73-74,92-93
+ *           (one process per GPU, bucketed all-reduce overlapped with backward)
+ * The collectives are plain stream operations on the caller's stream: they order like kernels, they can be
+ * captured into a hipGraph like kernels, and no helper thread ever touches the caller's events.
+ * librccl is bound at run time (dlopen): sqd_comm_load(path) picks the instance — a PyTorch process passes
+ * torch/lib/librccl.so so that RCCL and the caller share ONE HIP runtime; NULL means "librccl.so" on the
+ * loader's search path.  Everything else in this header works without RCCL present.
+ * Rendezvous stays with the caller: rank 0 calls sqd_comm_unique_id, ships the SQD_COMM_ID_BYTES to the
+ * other ranks over whatever channel the job already has (torchrun's store here), then every rank calls
+ * sqd_comm_init (collective; the calling thread's current HIP device is the rank's GPU).
+ * dtype: 0 = f32, 1 = f64, 2 = i32, 3 = u8;  op: 0 = sum, 1 = average, 2 = max, 3 = min.                 */
+#define SQD_COMM_ID_BYTES 128
+#define SQD_ECOMM (-3)    /* RCCL returned an error (text in sqd_last_error) or librccl could not be bound */
+typedef struct sqd_comm sqd_comm;
+int sqd_comm_load(const char *librccl_path_host);
+int sqd_comm_unique_id(void *id_host);
+int sqd_comm_init(const void *id_host, int rank, int world, sqd_comm **comm_host);
+int sqd_comm_rank(const sqd_comm *comm);
+int sqd_comm_world(const sqd_comm *comm);
+int sqd_comm_allreduce(sqd_comm *comm, void *buf, int64_t count, int dtype, int op, void *stream);
+int sqd_comm_broadcast(sqd_comm *comm, void *buf, int64_t count, int dtype, int root, void *stream);
+int sqd_comm_destroy(sqd_comm *comm);
+
 #ifdef __cplusplus
 }
 #endif

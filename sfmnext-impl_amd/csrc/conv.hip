@@ -1454,6 +1454,13 @@ int check_geom(const char *who, const ConvGeom &g) {
 
 extern "C" int sqd_conv_supported(int C, int K) { return (C % 4 == 0 && K % 4 == 0) ? 1 : 0; }
 
+// 0: fp32 MFMA (default); 1: split-precision bf16 MFMA (three terms, fp32-level accuracy); 2: plain bf16 operands with fp32
+// accumulation — for forward / data gradient (sqd_conv_set_precision); the weight gradient stays on the fp32 MFMA kernels
+static int &conv_precision() {
+    static int prec = 0;
+    return prec;
+}
+
 struct GemmPlan {
     int bm, bn, z, bk;
     int waves = 4;                  // wavefronts per workgroup: 4, or 8 on the >= 128x64 tiles (one 32x32 tile per wave)
@@ -1534,6 +1541,17 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
             p.split3 = (std::get<3>(it->second) & 1024) ? 1 : 0;
             p.halo = (std::get<3>(it->second) & 2048) ? 1 : 0;
         }
+    }
+    if (conv_precision() != 0) {
+        // the operand-precision modes run ONE kernel family (DISPATCH_GEMM_BF): the plan describes the tile that is launched,
+        // so that the BatchNorm partial rows sqd_conv_fwd_stats_rows reports are the rows the kernel writes
+        p.halo = p.split3 = p.single = 0;
+        p.waves = 4;
+        if (p.bm == 128 && p.bn >= 64) p.bn = 64;
+        else if (p.bm == 128) p.bn = 32;
+        else if (p.bn == 128) p.bm = 64;
+        else { p.bm = 64; p.bn = 64; }
+        if (!(p.bm == 64 && p.bn == 64 && p.bk == 32)) p.bk = 16;
     }
     int z = p.z;
     if (p.halo) z = z <= ((mode == 0 ? g.C : g.K) + 31) / 32 ? z : 1;          // split over 32-channel chunks
@@ -1623,13 +1641,6 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     else if (p.bk == 32) LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 32, PR);              \
     else LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 16, PR);
 
-// 0: fp32 MFMA (default); 1: split-precision bf16 MFMA (three terms, fp32-level accuracy); 2: plain bf16 operands with fp32
-// accumulation — for forward / data gradient (sqd_conv_set_precision); the weight gradient stays on the fp32 MFMA kernels
-static int &conv_precision() {
-    static int prec = 0;
-    return prec;
-}
-
 static int launch_gemm(int mode, const float *a_src, const float *w, const float *bias, float *out, float *ws, const ConvGeom &g,
                        int act, void *stream, float *stats = nullptr) {
     const int ncls = mode == 0 ? 1 : g.stride * g.stride;
@@ -1679,6 +1690,9 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     const int split3 = (bk & 1024) ? 1 : 0;                      // bk + 1024: three-term bf16 operands (fp32-level accuracy on the bf16 matrix cores)
     const int halo = (bk & 2048) ? 1 : 0;                        // bk + 2048: the input-patch kernel for 3x3 / stride 1 / pad 1 (three-term bf16 operands)
     bk &= 255;
+    SQD_CHECK_ARG(conv_precision() == 0 || !(halo || split3 || single || waves == 8),
+                  "sqd_conv_set_plan: the single-buffered / 8-wave / three-term / input-patch variants exist for the fp32 arithmetic only "
+                  "(sqd_conv_set_precision is %d)", conv_precision());
     if (halo) {
         const int Cr = mode == 0 ? C : K;
         SQD_CHECK_ARG(split3 && waves == 4 && !single && bk == 32, "sqd_conv_set_plan: the input-patch plans are bk = 32 + 1024 + 2048");
@@ -1720,6 +1734,11 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
 // operand, 6 products, fp32 accumulation: fp32-level accuracy, experimental)
 extern "C" int sqd_conv_set_precision(int prec) {
     SQD_CHECK_ARG(prec >= 0 && prec <= 2, "sqd_conv_set_precision: %d (0 fp32, 1 three-term bf16 split, 2 bf16 operands)", prec);
+    if (prec != conv_precision()) {
+        // plans are measured per arithmetic: a table filled under another mode would name kernels this mode does not have
+        std::lock_guard<std::mutex> lk(plan_mutex());
+        plan_table().clear();
+    }
     conv_precision() = prec;
     return SQD_OK;
 }

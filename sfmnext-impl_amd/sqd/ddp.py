@@ -1,5 +1,5 @@
-"""Data-parallel gradient exchange for one-process-per-GPU training (RCCL over xGMI through
-torch.distributed backend "nccl"; "gloo" on CPU for tests).
+"""Data-parallel gradient exchange for one-process-per-GPU training: RCCL over xGMI through the library's own
+communicator (include/sqd.h §19; torch.distributed "gloo" carries the rendezvous and, on CPU, the tests).
 
 Design: every rank owns a full replica and a shard of the batch; after backward the
 gradients are averaged with a small number of large all-reduces.  Parameters are grouped into a few
@@ -14,25 +14,126 @@ large enough to run at link bandwidth, small enough that the last bucket's tail 
 
 Parameters that never receive a gradient (the torchvision-compatible `fc` of the ResNet trunk —
 SURVEY App. B-11) are detected on the first step and left out of the buckets."""
+import ctypes
 import os
 
 import torch
 import torch.distributed as dist
 
+COMM = None          # the data-plane communicator of this process (RcclComm on a GPU, GlooComm in the CPU tests), set by init_from_env
+
+
+class RcclComm:
+    """RCCL communicator owned by libsqd.so (include/sqd.h §19, csrc/comm.hip): collectives are plain operations on the
+    stream they are given — they overlap and capture into a hipGraph like kernels, and nothing polls events from a helper
+    thread (ProcessGroupNCCL's watchdog did, and aborted in-capture exchanges)."""
+    _DT = {torch.float32: 0, torch.float64: 1, torch.int32: 2, torch.uint8: 3}
+    _OP = {"sum": 0, "avg": 1, "max": 2, "min": 3}
+    device_averages = True
+
+    def __init__(self, rank, world, exchange_id):
+        """exchange_id(bytes_or_None) -> bytes: ships rank 0's unique id to every rank (the job's existing control channel)."""
+        from .lib import lib
+        self._lib = lib()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self._check(self._lib.sqd_comm_load(path.encode() if os.path.exists(path) else None))
+        buf = ctypes.create_string_buffer(128)
+        if rank == 0:
+            self._check(self._lib.sqd_comm_unique_id(buf))
+        uid = exchange_id(buf.raw if rank == 0 else None)
+        assert len(uid) == 128
+        handle = ctypes.c_void_p()
+        self._check(self._lib.sqd_comm_init(uid, rank, world, ctypes.byref(handle)))
+        self._h, self.rank, self.world = handle, rank, world
+        self.stream = torch.cuda.Stream()        # the exchange runs here, next to the backward kernels
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError("sqd_comm: %s" % self._lib.sqd_last_error().decode())
+
+    def all_reduce(self, t, op="avg", stream=None):
+        """in place, on `stream` (default: the caller's current stream)"""
+        assert t.is_cuda and t.is_contiguous()
+        st = torch.cuda.current_stream() if stream is None else stream
+        self._check(self._lib.sqd_comm_allreduce(self._h, t.data_ptr(), t.numel(), self._DT[t.dtype], self._OP[op], st.cuda_stream))
+
+    def broadcast(self, t, root=0, stream=None):
+        assert t.is_cuda and t.is_contiguous()
+        st = torch.cuda.current_stream() if stream is None else stream
+        self._check(self._lib.sqd_comm_broadcast(self._h, t.data_ptr(), t.numel(), self._DT[t.dtype], root, st.cuda_stream))
+
+    def barrier(self):
+        t = torch.zeros(1, device="cuda")
+        self.all_reduce(t, "sum")
+        torch.cuda.current_stream().synchronize()
+
+    def close(self):
+        if self._h is not None:
+            torch.cuda.synchronize()
+            self._lib.sqd_comm_destroy(self._h)
+            self._h = None
+
+
+class GlooComm:
+    """torch.distributed (gloo) behind the same five calls: the CPU tests of the bucket logic (world size 2, no GPU)."""
+    device_averages = False
+    stream = None
+
+    def __init__(self, group=None):
+        self.group, self.rank, self.world = group, dist.get_rank(group), dist.get_world_size(group)
+
+    def all_reduce(self, t, op="avg", stream=None):
+        dist.all_reduce(t, op={"sum": dist.ReduceOp.SUM, "avg": dist.ReduceOp.SUM, "max": dist.ReduceOp.MAX,
+                               "min": dist.ReduceOp.MIN}[op], group=self.group)
+        if op == "avg":
+            t.div_(self.world)
+
+    def broadcast(self, t, root=0, stream=None):
+        dist.broadcast(t, root, group=self.group)
+
+    def barrier(self):
+        dist.barrier(group=self.group)
+
+    def close(self):
+        pass
+
 
 def init_from_env(backend=None):
-    """Initialise torch.distributed from torchrun's environment. Returns (rank, world, local_rank)."""
+    """Join the job torchrun's environment describes.  Returns (rank, world, local_rank) and sets ddp.COMM.
+    Control plane (rendezvous, shipping RCCL's unique id, CPU-side barriers): a gloo process group over 127.0.0.1 / the
+    job's store.  Data plane on a GPU: RcclComm (the library's own communicator) — ProcessGroupNCCL is never created."""
+    global COMM
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    force = os.environ.get("SQD_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ     # 1-rank RCCL smoke runs
-    if (world > 1 or force) and not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+    force = os.environ.get("SQD_FORCE_DIST") == "1" and "MASTER_ADDR" in os.environ     # 1-rank RCCL runs (tests)
+    if (world > 1 or force) and COMM is None:
+        gpu = backend != "gloo" and torch.cuda.is_available()
+        if gpu:
+            # the host driver supports dmabuf IPC only: RCCL's peer mappings need this before the HIP runtime starts
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if not dist.is_initialized():
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        if gpu:
+            def exchange(uid):
+                box = [uid]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            COMM = RcclComm(rank, world, exchange)
+        else:
+            COMM = GlooComm()
     return rank, world, local
+
+
+def shutdown():
+    global COMM
+    if COMM is not None:
+        COMM.close()
+        COMM = None
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def _dense(p):
@@ -41,17 +142,16 @@ def _dense(p):
 
 
 class GradBucketReducer:
-    def __init__(self, params, bucket_mb=32.0, process_group=None):
-        self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        # exchange whenever a process group exists (a 1-rank group still exercises the RCCL calls)
-        self.active = dist.is_initialized()
-        self._avg = self.active and dist.get_backend(process_group) == "nccl"    # RCCL averages in the collective
+    def __init__(self, params, bucket_mb=32.0, comm=None):
+        self.comm = COMM if comm is None else comm
+        # exchange whenever a communicator exists (a 1-rank communicator still exercises the RCCL calls)
+        self.active = self.comm is not None
+        self.world = self.comm.world if self.active else 1
         self.params = [p for p in params if p.requires_grad]
         self.bucket_bytes = int(bucket_mb * (1 << 20))
         self.buckets = None          # built after the first backward (unused-parameter detection)
         self._hooks = []
-        self._works = []
+        self._inflight = False        # collectives queued on the communicator's stream since the last finish()
         self.hooks_enabled = True     # False while a hipGraph of forward+backward is captured / replayed (see allreduce_all)
 
     # -- start-up ---------------------------------------------------------------------------------
@@ -67,7 +167,12 @@ class GradBucketReducer:
         for dtype in list(dict.fromkeys(t.dtype for t in tensors)):
             group = [t for t in tensors if t.dtype == dtype]
             flat = torch.cat([t.reshape(-1) for t in group])
-            dist.broadcast(flat, 0, group=self.group)
+            if dtype == torch.int64 and flat.is_cuda:        # (BatchNorm's num_batches_tracked) the ABI moves i32
+                wire = flat.to(torch.int32)
+                self.comm.broadcast(wire, 0)
+                flat = wire.to(torch.int64)
+            else:
+                self.comm.broadcast(flat, 0)
             off = 0
             for t in group:
                 n = t.numel()
@@ -106,6 +211,24 @@ class GradBucketReducer:
         for p in used:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
+    # -- the exchange -----------------------------------------------------------------------------
+    def _exchange(self, flat):
+        """Average one bucket across the ranks, asynchronously: on a GPU the collective goes onto the communicator's stream
+        behind everything the current stream has queued (an event edge — inside a hipGraph capture: a graph branch);
+        finish() joins it."""
+        side = self.comm.stream
+        if side is None:                                   # CPU (gloo): synchronous
+            self.comm.all_reduce(flat, "avg")
+            return
+        side.wait_stream(torch.cuda.current_stream())
+        self.comm.all_reduce(flat, "avg", stream=side)
+        self._inflight = True
+
+    def _join(self):
+        if self._inflight:
+            torch.cuda.current_stream().wait_stream(self.comm.stream)
+            self._inflight = False
+
     # -- per step ---------------------------------------------------------------------------------
     def zero_grad(self):
         """Replaces optimizer.zero_grad(set_to_none=True): backward then produces fresh gradient tensors, which the hook
@@ -115,7 +238,6 @@ class GradBucketReducer:
         if self.buckets is not None:
             for bi in range(len(self.buckets)):
                 self._pending[bi] = len(self.buckets[bi])
-        self._works = []
 
     def _on_grad(self, p):
         if not self.hooks_enabled:
@@ -132,8 +254,7 @@ class GradBucketReducer:
             for q, v in zip(plist, views):
                 q.grad = v                                              # the optimiser reads the (averaged) bucket memory
             if self.active:
-                op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-                self._works.append(dist.all_reduce(self.flat[bi], op=op, group=self.group, async_op=True))
+                self._exchange(self.flat[bi])
 
     def detach_grad_views(self):
         """Graph mode: hand back {parameter: its bucket view} and clear p.grad, so that a captured backward produces fresh
@@ -146,27 +267,22 @@ class GradBucketReducer:
         return views
 
     def allreduce_all(self):
-        """Exchange every bucket now (graph mode: forward+backward were replayed as one hipGraph, which leaves no Python
-        hook to overlap with; the 4-5 collectives are issued back to back on RCCL's stream and joined)."""
+        """Exchange every bucket now (--sqd_graph_ddp post: forward+backward were replayed as one hipGraph, which leaves no
+        Python hook to overlap with; the 4-5 collectives are issued back to back on the communicator's stream and joined)."""
         if not self.active or self.buckets is None:
             return
-        op = dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM
-        works = [dist.all_reduce(flat, op=op, group=self.group, async_op=True) for flat in self.flat]
-        for w in works:
-            w.wait()
-        if not self._avg:
-            for flat in self.flat:
-                flat.div_(self.world)
+        for flat in self.flat:
+            self._exchange(flat)
+        self._join()
 
     def finish(self):
-        """Call after loss.backward(): waits for the in-flight buckets and turns sums into means."""
+        """Call after loss.backward(): the current stream waits for the in-flight buckets."""
         if self.buckets is None:
             # first step: no buckets yet — reduce whatever gradients exist, then build the buckets
             if self.active:
                 grads = [p.grad for p in self.params if p.grad is not None]
                 flat = torch.cat([g.reshape(-1) for g in grads])
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-                flat.div_(self.world)
+                self.comm.all_reduce(flat, "avg")
                 off = 0
                 for g in grads:
                     n = g.numel()
@@ -174,9 +290,4 @@ class GradBucketReducer:
                     off += n
             self._build()
             return
-        for w in self._works:
-            w.wait()
-        self._works = []
-        if self.active and not self._avg:
-            for flat in self.flat:
-                flat.div_(self.world)
+        self._join()

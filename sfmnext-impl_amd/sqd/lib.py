@@ -112,6 +112,14 @@ _I, _F, _P = ctypes.c_int, ctypes.c_float, c_void_p
 _SIGNATURES = {
     "sqd_abi_version": (ctypes.c_int, []),
     "sqd_last_error": (ctypes.c_char_p, []),
+    "sqd_comm_load": (_I, [ctypes.c_char_p]),
+    "sqd_comm_unique_id": (_I, [ctypes.c_char_p]),
+    "sqd_comm_init": (_I, [ctypes.c_char_p, _I, _I, ctypes.POINTER(c_void_p)]),
+    "sqd_comm_rank": (_I, [_P]),
+    "sqd_comm_world": (_I, [_P]),
+    "sqd_comm_allreduce": (_I, [_P, _P, ctypes.c_int64, _I, _I, _P]),
+    "sqd_comm_broadcast": (_I, [_P, _P, ctypes.c_int64, _I, _I, _P]),
+    "sqd_comm_destroy": (_I, [_P]),
     "sqd_depth_up_nblk": (_I, [_I, _I]),
     "sqd_depth_up_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_depth_up_bwd": (_I, [_P, _I, _P, _P, _P, _I, _I, _I, _I, _I, _P]),

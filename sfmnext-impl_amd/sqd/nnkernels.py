@@ -169,6 +169,21 @@ def _conv_ws(mode, geom, device):
 
 TUNE_CONV = False             # set by the Trainer (--sqd_no_conv_tune switches it off)
 _TUNED = set()
+
+
+def set_conv_precision(prec):
+    """sqd_conv_set_precision + everything this module remembers about plans: the library drops its measured plans when the
+    arithmetic changes (they name kernels of the other mode), so the cached workspace / partial-row counts and the "already
+    tuned" marks go with them."""
+    L = _l.lib()
+    if L.sqd_conv_precision() != prec:
+        _PLAN_CACHE.clear()
+        _TUNED.clear()
+        CHOSEN_PLANS.clear()
+    _l.check(L.sqd_conv_set_precision(prec), "conv_set_precision")
+
+
+CHOSEN_PLANS = {}             # ("fwd" | "dgrad", geom) -> (bm, bn, z, bk);  ("wgrad", N, Ho, Wo, C, K, R, S) -> (impl, splits)
 _TUNE_TILES = ((128, 128), (128, 64), (64, 128), (64, 64), (128, 32))
 _TUNE_Z = (1, 2, 3, 4, 6, 8, 12, 16)
 

@@ -69,7 +69,7 @@ def configure(opt, device):
     first call unless --sqd_no_conv_tune.  The native kernels are NHWC / KRSC only, so channels_last is forced with them."""
     from . import lib as _lib, nnkernels
     set_native_conv(not opt.sqd_aten_conv)
-    _lib.check(_lib.lib().sqd_conv_set_precision(2 if opt.sqd_bf16 else 0), "conv_set_precision")
+    nnkernels.set_conv_precision(2 if opt.sqd_bf16 else 0)
     nnkernels.TUNE_CONV = not opt.sqd_no_conv_tune and torch.device(device).type == "cuda"     # first step: ~2 s of plan timing
     if not opt.sqd_aten_conv:
         opt.sqd_channels_last = True

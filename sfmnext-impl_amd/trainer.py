@@ -105,8 +105,7 @@ class Trainer:
         self._graph, self._graph_warm, self._capturing = None, 0, False
         self.epoch, self.step, self.start_time = 0, 0, time.time()      # (train() resets them, as the reference does)
         all_params = [p for m in self.models.values() for p in m.parameters()]
-        import torch.distributed as _dist
-        self.reducer = ddp.GradBucketReducer(all_params, self.opt.sqd_bucket_mb) if _dist.is_initialized() else None
+        self.reducer = ddp.GradBucketReducer(all_params, self.opt.sqd_bucket_mb) if ddp.COMM is not None else None
         if self.reducer is not None:
             self.reducer.broadcast_parameters(self.models.values())
 
@@ -266,15 +265,16 @@ class Trainer:
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         self._capturing = True
-        # with a process group: RCCL's watchdog thread keeps querying the events of the warm-up steps' collectives; under the
-        # default "global" capture mode such a query from another thread aborts the capture (hipErrorCapturedEvent)
+        # with a communicator: RCCL's own helper threads may call into the HIP runtime while this thread captures; only
+        # this thread's calls are part of the capture ("thread_local"), theirs are none of its business
         mode = {} if self.reducer is None else {"capture_error_mode": "thread_local"}
         try:
             with torch.cuda.graph(g, stream=self._graph_stream, **mode):
                 outputs, losses = self.process_batch(self._static_in)
                 # the reducer's post-accumulate hooks run here, inside the capture: each full bucket is gathered by one
-                # multi-tensor copy and its all-reduce is enqueued on RCCL's stream — a branch of the graph that runs next to
-                # the remaining backward kernels; finish() joins the branches before Adam reads the averaged buckets
+                # multi-tensor copy and its all-reduce (sqd_comm_allreduce, a plain stream operation) is enqueued on the
+                # communicator's stream — a branch of the graph that runs next to the remaining backward kernels; finish()
+                # joins the branches before Adam reads the averaged buckets
                 self._backward(losses["loss"])
                 if self.reducer is not None:
                     self.reducer.finish()
@@ -292,15 +292,9 @@ class Trainer:
         self.reducer.hooks_enabled = False
         views = self.reducer.detach_grad_views()          # {param: bucket view}; p.grad = None for the capture
         torch.cuda.synchronize()
-        # RCCL's watchdog thread polls (hipEventQuery) the events of the warm-up steps' collectives until it has retired
-        # them; a poll that lands inside the capture aborts the process with hipErrorCapturedEvent.  All of them are
-        # complete after the synchronize above; three polling periods (100 ms each) let the watchdog drop them.
-        time.sleep(0.35)
         g = torch.cuda.CUDAGraph()
         self._capturing = True
         try:
-            # thread_local: RCCL's watchdog thread polls its events while we capture; that is harmless, and under the default
-            # "global" mode it aborts the process (hipErrorCapturedEvent)
             with torch.cuda.graph(g, stream=self._graph_stream, capture_error_mode="thread_local"):
                 outputs, losses = self.process_batch(self._static_in)
                 self._backward(losses["loss"])

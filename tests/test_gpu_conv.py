@@ -193,7 +193,8 @@ def test_split_precision_variant(N, C, H, W, K, R, stride, pad, bias, act):
     res = {}
     try:
         for prec in (0, 1):
-            assert L.sqd_conv_set_precision(prec) == 0 and L.sqd_conv_precision() == prec
+            nnkernels.set_conv_precision(prec)
+            assert L.sqd_conv_precision() == prec
             conv_g = nn.Conv2d(C, K, R, stride, pad, bias=bias).cuda()
             conv_g.load_state_dict({k: v.float() for k, v in conv.state_dict().items()})
             conv_g = conv_g.to(memory_format=torch.channels_last)
@@ -202,7 +203,7 @@ def test_split_precision_variant(N, C, H, W, K, R, stride, pad, bias, act):
             (y * wgt.cuda()).sum().backward()
             res[prec] = (y.detach().cpu().double(), xg.grad.cpu().double())
     finally:
-        L.sqd_conv_set_precision(0)
+        nnkernels.set_conv_precision(0)
     for name, i, ref in (("y", 0, yr.detach()), ("dx", 1, xr.grad)):
         scale = float(ref.abs().max())
         e32, ebf = float((res[0][i] - ref).abs().max()), float((res[1][i] - ref).abs().max())
@@ -266,12 +267,12 @@ def test_conv_bf16_operand_mode(N, C, H, W, K, R, stride, pad):
     conv_g = conv_g.to(memory_format=torch.channels_last)
     xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
     L = lib.lib()
-    assert L.sqd_conv_set_precision(2) == 0
+    nnkernels.set_conv_precision(2)
     try:
         y = nnkernels.conv2d_native(xg, conv_g, None)
         (y * g.cuda()).sum().backward()
     finally:
-        L.sqd_conv_set_precision(0)
+        nnkernels.set_conv_precision(0)
 
     def close(a, b, name, rtol):
         a, b = a.detach().cpu().float(), b.detach().float()

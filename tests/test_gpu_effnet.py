@@ -117,7 +117,7 @@ def test_effb5_bf16_training_steps_track_fp32():
     from options import MonodepthOptions
     from trainer import Trainer
     from datasets.synthetic import synthetic_batch
-    from sqd import lib
+    from sqd import lib, nnkernels
     H, W, B = 64, 128, 2
     base = ["--backbone", "eff_b5", "--num_features", "256", "--model_dim", "32", "--patch_size", "8", "--query_nums", "16", "--dim_out", "32",
             "--height", str(H), "--width", str(W), "--batch_size", str(B), "--num_workers", "0", "--sqd_synthetic",
@@ -136,7 +136,7 @@ def test_effb5_bf16_training_steps_track_fp32():
                 losses.append(float(tr.train_step(batch)[1]["loss"]))
             runs[name] = losses
     finally:
-        lib.lib().sqd_conv_set_precision(0)
+        nnkernels.set_conv_precision(0)
     print("eff_b5 losses fp32 %s\n       bf16 %s" % (runs["fp32"], runs["bf16"]))
     for a, b in zip(runs["fp32"], runs["bf16"]):
         assert b == b and abs(a - b) <= 0.05 * abs(a), (runs["fp32"], runs["bf16"])
