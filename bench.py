@@ -265,11 +265,26 @@ def main():
     if rank == 0:
         from sqd import nnops
         ms = elapsed / args.steps * 1e3
-        out = {"metric": "train images/sec, ResNet-50 640x192", "value": round(world * opts.batch_size / (ms * 1e-3), 2),
+        from sqd import nnkernels
+        default_cfg = not os.environ.get("SQD_BENCH_EXTRA")
+        backbone = {"resnet": "ResNet-%d" % opts.num_layers, "resnet_lite": "ResNet-%d" % opts.num_layers, "resnet18_lite": "ResNet-18",
+                    "eff_b5": "EfficientNet-b5", "tf_efficientnet_b5_ap": "EfficientNet-b5"}.get(opts.backbone, opts.backbone)
+        out = {"metric": "train images/sec, ResNet-50 640x192" if default_cfg else "train images/sec, %s %dx%d" % (backbone, opts.width, opts.height),
+               "value": round(world * opts.batch_size / (ms * 1e-3), 2),
                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               # the type the path computes in: fp32 tensors, fp32 accumulation everywhere; per layer the convolutions multiply either
+               # fp32 operands or their exact three-term bf16 split (fp32-level accuracy) — config.conv_arith counts which; --sqd_bf16
+               # rounds the convolution operands to ONE bf16 term instead
+               "dtype": "bf16" if opts.sqd_bf16 else "f32", "data": "synthetic",
                "config": {"workload": workload_name(opts),
                           "global_batch": world * opts.batch_size, "parallelism": "dp%d" % world,
+                          "conv_arith": {"note": "layer geometries per pass by the kernel family their measured plan runs; 'bf16x3' = every fp32 "
+                                                 "operand as the exact sum of three bf16 terms, 6 of 9 partial products on the bf16 matrix cores, "
+                                                 "fp32 accumulation (error <= 4x the fp32-MFMA kernel's against fp64: tests/test_gpu_conv.py)",
+                                         "plans": "measured in step 1" if nnkernels.TUNE_CONV and not opts.sqd_conv_plans else
+                                                  ("pinned: " + opts.sqd_conv_plans) if opts.sqd_conv_plans else "cost model (fp32 MFMA)",
+                                         **nnkernels.plan_mix()},
                           "exchange": None if trainer.reducer is None else {
                               "communicator": type(trainer.reducer.comm).__name__, "ranks": trainer.reducer.comm.world,
                               "buckets": len(trainer.reducer.buckets or ()), "bucket_mb": opts.sqd_bucket_mb,

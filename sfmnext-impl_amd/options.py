@@ -121,8 +121,9 @@ EXTRA_FLAGS = [
     ("sqd_bf16", _T, False, {"help": "bf16 training arithmetic for the convolutions' forward and data gradient (bf16 MFMA, fp32 accumulation; "
                                       "BatchNorm, losses, weight gradients and Adam stay fp32) — BASELINE.json configs[3]"}),
     ("sqd_no_conv_tune", _T, False, {"help": "keep the cost-model convolution plans instead of timing tile / split-K plans per layer in the first step"}),
-    ("sqd_aten_conv", _T, False, {"help": "A/B switch: ATen/MIOpen convolutions instead of the native implicit-GEMM kernels (csrc/conv.hip)"}),
-    ("sqd_miopen_find", _T, False, {"help": "let MIOpen benchmark its solvers per layer (interim ATen conv backend only)"}),
+    ("sqd_conv_plans", str, None, {"help": "JSON file of convolution plans (written by --sqd_save_conv_plans): pins every listed layer's kernel, "
+                                        "tile and split instead of timing them in the first step — last-bit reproducible across boxes"}),
+    ("sqd_save_conv_plans", str, None, {"help": "write the convolution plans this run measured (or loaded) to this JSON file after the first steps"}),
 ]
 
 

@@ -3,7 +3,6 @@
 Each Function takes/returns tensors whose logical shape is NCHW and whose memory is NHWC
 (torch.channels_last); the kernels see them as row-major [M = N*H*W, C] matrices."""
 import ctypes
-import os
 
 import torch
 
@@ -13,7 +12,7 @@ from .ops import _ptr, _stream
 ACT = {None: 0, "relu": 1, "leaky_relu": 2, "swish": 3}
 
 
-_DEBUG_COPIES = bool(os.environ.get("SQD_DEBUG_COPIES"))
+_DEBUG_COPIES = False          # tools/ set it: report activations that reach a kernel in the wrong memory format
 
 
 def _cl(x):
@@ -188,9 +187,32 @@ _TUNE_TILES = ((128, 128), (128, 64), (64, 128), (64, 64), (128, 32))
 _TUNE_Z = (1, 2, 3, 4, 6, 8, 12, 16)
 
 
+# Search-space switches of the plan timing.  Defaults are what the product runs; tools/ (A/B scripts) may flip them.
+TUNE_SPACE = {
+    "input_patch": True,       # bk 32+1024+2048: the input-patch kernel for 3x3 / stride 1 (three-term bf16 operands)
+    "bk64": False,             # bk 64+512 on the single-buffered 64x64 tile: picked for 11 layer-modes, no gain on the totals
+    "eight_wave": False,       # bk +256: 8-wave workgroups — 1-3 % on a third of the layers, nothing on the step
+    "wgrad_shapes": False,     # smaller register tiles of the direct weight gradient: 7 of 38 layers, nothing on the step
+    "stats_penalty": True,     # charge split-K forward plans the BatchNorm statistics pass they force
+    "log": False,
+}
+
+
+def _time_launch(launch, arg):
+    launch(arg)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        launch(arg)
+    e1.record()
+    e1.synchronize()
+    return e0.elapsed_time(e1)
+
+
 def _tune_conv(mode, geom, launch):
     """Time every tile / split-K plan the library accepts for this geometry (4 launches each, HIP events on the current
-    stream) and register the fastest (sqd_conv_set_plan).  Runs once per geometry, outside graph capture."""
+    stream) and register the fastest (sqd_conv_set_plan).  Runs once per geometry, outside graph capture; geometries with a
+    pinned plan (load_plans) are not timed."""
     key = (mode,) + tuple(geom)
     if key in _TUNED or torch.cuda.is_current_stream_capturing():
         return
@@ -199,10 +221,6 @@ def _tune_conv(mode, geom, launch):
     best = None
     # bk + 512 = the single-buffered LDS variants (half the LDS per workgroup, twice the resident workgroups, one more barrier
     # per slice): picked for three quarters of the config-B layers, forward -5 %, data gradient -2 %.
-    # (bk + 256 = the 8-wave workgroup variants: picked for a third of the layers when offered, each a 1-3 % win, no
-    # measurable change of the step — left out of the default search, SQD_TUNE_8WAVE=1 adds them)
-    # (bk 64 + 512 = a 64-channel slice on the single-buffered 64x64 tile: half the barriers again, picked for 11 layer-modes, no
-    # gain on the totals — SQD_TUNE_BK64=1 adds it)
     # bk 32 + 1024 = three-term bf16 operands on the bf16 matrix cores (fp32-level accuracy, 6 products per slice at 16x the fp32
     # MFMA rate, single LDS buffer): 20-30 % faster than the fp32 kernels on most config-B layers (profiles/r02e_conv_split3.md)
     # bk 32 + 1024 + 2048 = the input-patch kernel for 3x3 / stride 1 / pad 1 (three-term bf16 operands; the input patch of a
@@ -210,36 +228,36 @@ def _tune_conv(mode, geom, launch):
     # than the implicit-GEMM plans on the config-B layers above 12x40 pixels (profiles/r02i_conv_input_patch.md)
     # (bk 64 + 1024, the three-term 64x64 tile with 64-channel slices, was tried for the few-pixel / many-channel 1x1 layers of layer 3 / 4:
     # no change of the step in a same-box A/B — not kept)
-    bks = (16, 32, 528, 544, 1056) + (() if os.environ.get("SQD_TUNE_NO_PATCH") else (3104,)) + ((576,) if os.environ.get("SQD_TUNE_BK64") else ()) + ((272, 288) if os.environ.get("SQD_TUNE_8WAVE") else ())
+    if L.sqd_conv_precision() != 0:
+        bks = (16, 32)             # --sqd_bf16 runs one kernel family: tile and split-K are all there is to choose
+    else:
+        bks = (16, 32, 528, 544, 1056) + ((3104,) if TUNE_SPACE["input_patch"] else ()) + ((576,) if TUNE_SPACE["bk64"] else ()) + \
+            ((272, 288) if TUNE_SPACE["eight_wave"] else ())
     for bm, bn, z, bk in ((bm, bn, z, bk) for bm, bn in _TUNE_TILES + ((64, 32),) for bk in bks for z in _TUNE_Z):
-        if True:
-            if L.sqd_conv_set_plan(mode, *geom, bm, bn, z, bk) != 0:
-                continue
-            _PLAN_CACHE.pop(key, None)
-            ws = _conv_ws(mode, geom, torch.device("cuda", torch.cuda.current_device()))
-            launch(ws)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                launch(ws)
-            e1.record()
-            e1.synchronize()
-            t = e0.elapsed_time(e1)
-            if mode == 0 and z > 1 and not os.environ.get("SQD_TUNE_NO_STATS_PENALTY"):
-                # a forward plan that splits the reduction writes no BatchNorm partials: the BatchNorm that follows (nearly every
-                # convolution of these networks has one) then reads the output once more for its statistics — charge that pass
-                # (output bytes at ~4 TB/s + a launch) for the 3 timed launches
-                t += 3.0 * (geom[0] * geom[9] * geom[10] * geom[4] * 4 / 4.0e12 + 3.0e-6) * 1e3
-            if best is None or t < best[0]:
-                best = (t, bm, bn, z, bk)
+        if L.sqd_conv_set_plan(mode, *geom, bm, bn, z, bk) != 0:
+            continue
+        _PLAN_CACHE.pop(key, None)
+        ws = _conv_ws(mode, geom, torch.device("cuda", torch.cuda.current_device()))
+        t = _time_launch(launch, ws)
+        if mode == 0 and z > 1 and TUNE_SPACE["stats_penalty"]:
+            # a forward plan that splits the reduction writes no BatchNorm partials: the BatchNorm that follows (nearly every
+            # convolution of these networks has one) then reads the output once more for its statistics — charge that pass
+            # (output bytes at ~4 TB/s + a launch) for the 3 timed launches
+            t += 3.0 * (geom[0] * geom[9] * geom[10] * geom[4] * 4 / 4.0e12 + 3.0e-6) * 1e3
+        if best is None or t < best[0]:
+            best = (t, bm, bn, z, bk)
+    plan = (0, 0, 0, 16) if best is None else best[1:]
+    _register_conv_plan(mode, geom, plan)
+    if TUNE_SPACE["log"]:
+        print("sqd conv plan", "dgrad" if mode else "fwd", geom, best, flush=True)
+
+
+def _register_conv_plan(mode, geom, plan):
+    key = (mode,) + tuple(geom)
     _PLAN_CACHE.pop(key, None)
     _PLAN_CACHE.pop(("s",) + tuple(geom), None)
-    if best is None:
-        L.sqd_conv_set_plan(mode, *geom, 0, 0, 0, 16)
-    else:
-        L.sqd_conv_set_plan(mode, *geom, best[1], best[2], best[3], best[4])
-    if os.environ.get("SQD_TUNE_LOG"):
-        print("sqd conv plan", "dgrad" if mode else "fwd", geom, best, flush=True)
+    _l.check(_l.lib().sqd_conv_set_plan(mode, *geom, *plan), "conv_set_plan")
+    CHOSEN_PLANS[("dgrad" if mode else "fwd",) + tuple(geom)] = tuple(plan)
 
 
 def _tune_wgrad(geom, has_bias, launch):
@@ -254,11 +272,21 @@ def _tune_wgrad(geom, has_bias, launch):
     _PLAN_CACHE.pop(key, None)
     _, base = _wgrad_part_floats(geom)
     best = None
-    # direct kernel with its default register tile (the widest that divides: 64 filters x 64 channels), then the LDS-tiled kernel.
-    # (Smaller register tiles — more resident waves, more operand re-reads; impl 1 + 16 kt + 256 ct — win on 7 of the 38 config-B
-    # layers and nothing on the step: SQD_TUNE_WSHAPE=1 adds them to the search.)
+
+    def trial(impl, sp):
+        nonlocal best
+        if L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, impl, sp) != 0:
+            return False
+        _PLAN_CACHE.pop(key, None)
+        pf, splits = _wgrad_part_floats(geom)
+        extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if has_bias else 0
+        t = _time_launch(launch, torch.empty(pf + extra, device="cuda", dtype=torch.float32))
+        if best is None or t < best[0]:
+            best = (t, impl, sp)
+        return True
+    # direct kernel with its default register tile (the widest that divides: 64 filters x 64 channels), then the LDS-tiled kernel
     shapes = [1]
-    if os.environ.get("SQD_TUNE_WSHAPE"):
+    if TUNE_SPACE["wgrad_shapes"]:
         shapes += [1 | (kt << 4) | (ct << 8) for kt, ct in ((2, 4), (4, 2), (2, 2)) if K % (16 * kt) == 0 and C % (16 * ct) == 0
                    and (K % 64 == 0 or kt < 4) and (C % 64 == 0 or ct < 4)]
     for impl in shapes + [0]:
@@ -267,25 +295,9 @@ def _tune_wgrad(geom, has_bias, launch):
         tried = set()
         for mult in (0.125, 0.25, 0.5, 1, 2, 4):
             sp = max(1, int(base * mult))
-            if sp in tried:
-                continue
-            tried.add(sp)
-            if L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, impl, sp) != 0:
-                continue
-            _PLAN_CACHE.pop(key, None)
-            pf, splits = _wgrad_part_floats(geom)
-            extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if has_bias else 0
-            part = torch.empty(pf + extra, device="cuda", dtype=torch.float32)
-            launch(part)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                launch(part)
-            e1.record()
-            e1.synchronize()
-            t = e0.elapsed_time(e1)
-            if best is None or t < best[0]:
-                best = (t, impl, sp)
+            if sp not in tried:
+                tried.add(sp)
+                trial(impl, sp)
     # shared-operand kernels (impl 2 = fp32 MFMA, 3 = three-term bf16 operands; + 16 * variant: blocks of 128x128 / 64x128 / 128x64 /
     # 64x64 filters x channels staged once per workgroup in LDS): pixel splits for ~256 .. 1536 workgroups
     for base_impl, v, (tk, tc) in ((b, v, blk) for b in (2, 3) for v, blk in enumerate(((128, 128), (64, 128), (128, 64), (64, 64)))):
@@ -295,27 +307,72 @@ def _tune_wgrad(geom, has_bias, launch):
         tried = set()
         for target in (256, 512, 768, 1024, 1536):
             sp = max(1, (target + blocks - 1) // blocks)
-            if sp in tried or L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, base_impl | (v << 4), sp) != 0:
-                continue
-            tried.add(sp)
-            _PLAN_CACHE.pop(key, None)
-            pf, splits = _wgrad_part_floats(geom)
-            extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if has_bias else 0
-            part = torch.empty(pf + extra, device="cuda", dtype=torch.float32)
-            launch(part)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(3):
-                launch(part)
-            e1.record()
-            e1.synchronize()
-            t = e0.elapsed_time(e1)
-            if best is None or t < best[0]:
-                best = (t, base_impl | (v << 4), sp)
-    L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, best[1], best[2])
-    _PLAN_CACHE.pop(key, None)
-    if os.environ.get("SQD_TUNE_LOG"):
+            if sp not in tried and trial(base_impl | (v << 4), sp):
+                tried.add(sp)
+    _register_wgrad_plan((N, Ho, Wo, C, K, R, S), best[1:])
+    if TUNE_SPACE["log"]:
         print("sqd conv plan wgrad", geom, best, "model splits", base, flush=True)
+
+
+def _register_wgrad_plan(wkey, plan):
+    _PLAN_CACHE.pop(("w",) + tuple(wkey), None)
+    _l.check(_l.lib().sqd_conv_wgrad_set_plan(*wkey, *plan), "conv_wgrad_set_plan")
+    CHOSEN_PLANS[("wgrad",) + tuple(wkey)] = tuple(plan)
+
+
+def export_plans():
+    """The measured plan set of this process as a JSON-able record: a run loaded from it (load_plans, --sqd_conv_plans) executes
+    the same kernels on the same tiles and splits — last-bit reproducible across boxes, where first-step timing is not."""
+    return {"abi": _l.lib().sqd_abi_version(), "precision": _l.lib().sqd_conv_precision(),
+            "plans": [{"pass": k[0], "geom": list(k[1:]), "plan": list(v)} for k, v in sorted(CHOSEN_PLANS.items(), key=repr)]}
+
+
+def load_plans(rec):
+    """Register a plan set written by export_plans; the geometries it names are not timed again."""
+    if rec.get("precision", 0) != _l.lib().sqd_conv_precision():
+        raise RuntimeError("sqd: the plan file was measured with convolution precision %s, this run uses %s"
+                           % (rec.get("precision"), _l.lib().sqd_conv_precision()))
+    for e in rec["plans"]:
+        geom, plan = tuple(e["geom"]), tuple(e["plan"])
+        if e["pass"] == "wgrad":
+            _register_wgrad_plan(geom, plan)
+            _TUNED.add(("w",) + geom)
+        else:
+            mode = 1 if e["pass"] == "dgrad" else 0
+            _register_conv_plan(mode, geom, plan)
+            _TUNED.add((mode,) + geom)
+
+
+def reset_plans():
+    """Forget every measured / pinned plan (library table and this module's caches) and stop timing plans: the cost-model plans
+    apply again."""
+    L = _l.lib()
+    for k in list(CHOSEN_PLANS):
+        if k[0] == "wgrad":
+            L.sqd_conv_wgrad_set_plan(*k[1:], -1, 0)
+        else:
+            L.sqd_conv_set_plan(1 if k[0] == "dgrad" else 0, *k[1:], 0, 0, 0, 16)
+    CHOSEN_PLANS.clear()
+    _TUNED.clear()
+    _PLAN_CACHE.clear()
+    global TUNE_CONV
+    TUNE_CONV = False             # (nnops.configure switches plan timing on again for the next Trainer that wants it)
+
+
+def plan_mix():
+    """How many geometries of each pass run which arithmetic / kernel family under the registered plans (bench line)."""
+    mix = {}
+    for k, v in CHOSEN_PLANS.items():
+        if k[0] == "wgrad":
+            name = {0: "fp32 lds-tiled", 1: "fp32 direct", 2: "fp32 shared-operand", 3: "bf16x3 shared-operand"}[v[0] & 15]
+        else:
+            bk = v[3]
+            name = "bf16x3 input-patch" if bk & 2048 else "bf16x3 implicit-gemm" if bk & 1024 else "fp32 implicit-gemm"
+            if _l.lib().sqd_conv_precision() == 2:
+                name = "bf16 implicit-gemm"
+        mix.setdefault(k[0], {})
+        mix[k[0]][name] = mix[k[0]].get(name, 0) + 1
+    return mix
 
 
 def _wgrad_key(geom):
@@ -825,6 +882,36 @@ class StemRegroup(torch.autograd.Function):
         gw = torch.empty((K, C, 7, 7), device=g.device, dtype=torch.float32)
         _l.check(_l.lib().sqd_stem_regroup(_ptr(g), _ptr(gw), K, C, Cp, 1, _stream()), "stem_regroup_adjoint")
         return (gw.contiguous(memory_format=torch.channels_last) if cl else gw), None
+
+
+_STEM3_INDEX = {}
+
+
+def conv2d_stem3_same_s2d(x, conv):
+    """EfficientNet's stem — a 3x3 / stride 2 convolution with TensorFlow "SAME" padding on the 3-channel frame (reference
+    networks/base_encoder.py:41,94: tf_efficientnet_b5_ap.conv_stem) — as a 3x3 / stride 1 / pad 1 convolution on the
+    space-to-depth(2) image: for even H, W "SAME" pads one row below and one column right only, so output row i reads input rows
+    2i, 2i+1, 2i+2 = (block i, dy 0), (block i, dy 1), (block i+1, dy 0); the filter is scattered accordingly into [K, 16, 3, 3]
+    (block offsets -1 and the (block i+1, dy 1) taps are zero).  Runs on the implicit-GEMM / input-patch kernels like every
+    other convolution; the frame needs no gradient, the filter gradient comes back through the scatter's adjoint (a gather)."""
+    N, C, H, W = x.shape
+    K = conv.out_channels
+    if not (conv.kernel_size == (3, 3) and conv.stride == (2, 2) and H % 2 == 0 and W % 2 == 0 and conv.groups == 1 and conv.bias is None):
+        raise RuntimeError("sqd: the SAME-padded stem kernel takes a bias-free 3x3 / stride 2 convolution on an even-sized frame; got "
+                           "kernel %s stride %s on %dx%d" % (tuple(conv.kernel_size), tuple(conv.stride), H, W))
+    Cp = (4 * C + 15) // 16 * 16
+    xc = _cl(x.detach())
+    xs = torch.empty((N, Cp, H // 2, W // 2), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+    _l.check(_l.lib().sqd_space_to_depth2(_ptr(xc), _ptr(xs), N, H, W, C, Cp, _stream()), "space_to_depth2")   # channel c*4 + dy*2 + dx
+    key = (C, Cp, x.device)
+    idx = _STEM3_INDEX.get(key)
+    if idx is None:
+        # position of w[k, c, r, s] inside the KRSC memory of the [K, Cp, 3, 3] filter: ((R' * 3) + S') * Cp + c*4 + dy*2 + dx
+        pos = [(((r // 2 + 1) * 3 + (s_ // 2 + 1)) * Cp + c * 4 + (r % 2) * 2 + (s_ % 2)) for c in range(C) for r in range(3) for s_ in range(3)]
+        idx = _STEM3_INDEX[key] = torch.tensor(pos, device=x.device, dtype=torch.int64)
+    flat = torch.zeros((K, 9 * Cp), device=x.device, dtype=torch.float32).index_copy(1, idx, conv.weight.reshape(K, C * 9))
+    ws = flat.view(K, 3, 3, Cp).permute(0, 3, 1, 2)          # logical [K, Cp, 3, 3], channels-last memory
+    return Conv2d.apply(xs, ws, None, 1, 1, None, False, (H // 2, W // 2), None)
 
 
 def conv2d_native(x, conv, act=None, skip=False, stats=None):

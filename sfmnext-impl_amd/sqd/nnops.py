@@ -1,49 +1,32 @@
-"""Operator dispatch point of the networks (sqd.nnops).
+"""Operator entry point of the networks (sqd.nnops).
 
-Every tensor operation of the SQLdepth networks is routed through this module so that the
-hand-written gfx950 kernels replace the vendor library one operator at a time without touching the
-module definitions (state-dict keys stay those of the reference).  `BACKEND[name]` records which
-implementation serves each operator:
-
-    "hip"   hand-written kernel in libsqd.so (csrc/*.hip)
-    "aten"  PyTorch-ROCm ATen (MIOpen / rocBLAS) for shapes the native kernels do not take (channel / feature counts not
-            divisible by 4) — device tensors only.
-Host tensors are refused: the CPU restatement of these operators is test infrastructure (oracle/, tests/host_ops.py).
-"""
+Every tensor operation of the SQLdepth networks goes through this module, so that the module definitions keep the
+reference's structure (state-dict keys stay those of the reference) while the arithmetic runs in the hand-written gfx950
+kernels of libsqd.so (csrc/*.hip).  There is ONE implementation per operator: a shape the kernels do not take (channel /
+feature counts that are not multiples of 4) is an error that names the operator and the shape, not a detour through another
+library; host tensors are refused (the CPU restatement of these operators is test infrastructure: oracle/, tests/host_ops.py).
+The one operator still served by ATen is listed in BACKEND with its reason."""
 import torch
 import torch.nn.functional as F
 
 BACKEND = {
-    "conv2d": "aten", "conv_bn_act": "aten conv + hip bn/act/residual", "maxpool3x3s2": "hip", "upsample_concat": "hip",
-    "pose_head": "hip", "depthwise_conv": "hip", "squeeze_excite": "hip", "linear": "hip (1x1 implicit GEMM over rows; feature counts not divisible by 4: aten)", "transformer_encoder": "hip (fused attention up to 512 tokens, feed-forward, add+dropout+layernorm)", "full_query_layer": "hip", "bins_head": "hip",
+    "conv2d": "hip (implicit GEMM / input-patch kernels; 7x7 and 3x3 stride-2 stems via space-to-depth)",
+    "conv_bn_act": "hip conv + hip bn/act/residual", "maxpool3x3s2": "hip", "upsample_concat": "hip",
+    "pose_head": "hip", "depthwise_conv": "hip", "squeeze_excite": "hip", "linear": "hip (1x1 implicit GEMM over rows)",
+    "transformer_encoder": "hip (fused attention up to 512 tokens, feed-forward, add+dropout+layernorm; embedding width 64: aten nn.TransformerEncoder)",
+    "full_query_layer": "hip", "bins_head": "hip",
 }
 
-
-ATEN_FALLBACKS = {}           # operator -> calls that ran on ATen because the native kernel does not take the shape (this process)
+ATEN_CALLS = {}               # operator -> calls of this process that ran on ATen (only transformer_encoder can)
 
 
 def backend_report():
-    """BACKEND with the two operators that can fall back per call (conv2d, linear: channel / feature counts not divisible by 4)
-    reported by what actually ran: plain "hip" when no call of this process went to ATen."""
+    """BACKEND, with the transformer encoder reported by what actually ran in this process."""
     rep = dict(BACKEND)
-    for op in ("conv2d", "linear"):
-        if rep[op].startswith("hip"):
-            n = ATEN_FALLBACKS.get(op, 0)
-            rep[op] = rep[op].split(";")[0].rstrip(")") + (")" if "(" in rep[op].split(";")[0] else "")
-            rep[op] += " — no call fell back to ATen" if n == 0 else " — %d calls fell back to ATen (channel counts not divisible by 4)" % n
+    n = ATEN_CALLS.get("transformer_encoder", 0)
+    rep["transformer_encoder"] = ("hip (fused attention up to 512 tokens, feed-forward, add+dropout+layernorm)" if n == 0 else
+                                  "aten nn.TransformerEncoder (%d calls: embedding width 64)" % n)
     return rep
-
-
-def _act(y, act):
-    if act is None:
-        return y
-    if act == "relu":
-        return F.relu(y)
-    if act == "leaky_relu":
-        return F.leaky_relu(y, 0.01)
-    if act == "swish":
-        return F.silu(y)
-    raise ValueError(act)
 
 
 def _device_only(x, what):
@@ -51,69 +34,56 @@ def _device_only(x, what):
         raise RuntimeError("sqd: %s needs a tensor on the MI355X device — the hot path has no CPU fallback" % what)
 
 
-NATIVE_CONV = False          # set by the Trainer (default on; --sqd_aten_conv is the A/B switch back to ATen/MIOpen)
-
-
-def set_native_conv(on):
-    """Route every convolution the native kernels support (C and K multiples of 16, square stride/padding)
-    through libsqd; the 3- and 6-channel stem convolutions stay on ATen."""
-    global NATIVE_CONV
-    NATIVE_CONV = bool(on)
-    BACKEND["conv2d"] = "hip (incl. the 7x7 stems via space-to-depth; channel counts not divisible by 4: aten)" if on else "aten"
-    BACKEND["conv_bn_act"] = ("hip conv" if on else "aten conv") + " + hip bn/act/residual"
-
-
 def configure(opt, device):
-    """Backend switches every entry point sets before building its networks (Trainer, evaluate_depth.build_models,
-    finetune.FinetuneTrainer): native convolutions unless --sqd_aten_conv, their operand precision (--sqd_bf16), plan timing on the
-    first call unless --sqd_no_conv_tune.  The native kernels are NHWC / KRSC only, so channels_last is forced with them."""
-    from . import lib as _lib, nnkernels
-    set_native_conv(not opt.sqd_aten_conv)
+    """What every entry point sets before building its networks (Trainer, evaluate_depth.build_models,
+    finetune.FinetuneTrainer): the convolutions' operand precision (--sqd_bf16), a pinned plan set (--sqd_conv_plans) or plan
+    timing on the first call unless --sqd_no_conv_tune.  The kernels are NHWC / KRSC only, so channels_last is forced."""
+    from . import nnkernels
     nnkernels.set_conv_precision(2 if opt.sqd_bf16 else 0)
     nnkernels.TUNE_CONV = not opt.sqd_no_conv_tune and torch.device(device).type == "cuda"     # first step: ~2 s of plan timing
-    if not opt.sqd_aten_conv:
-        opt.sqd_channels_last = True
+    if getattr(opt, "sqd_conv_plans", None):
+        import json
+        with open(opt.sqd_conv_plans) as f:
+            nnkernels.load_plans(json.load(f))
+    opt.sqd_channels_last = True
 
 
 def _conv(x, conv, act=None, skip=False, bn_stats=None, input_affine=None):
     """skip=True: -> (y, x') with x' the input handed through the convolution node (see nnkernels.Conv2d).
     bn_stats: a list that receives (partials, rows) when the convolution's epilogue produced the statistics partials of
-    the BatchNorm that follows (native kernels, training, plan without split-K)."""
-    if NATIVE_CONV and x.is_cuda:
-        from . import nnkernels
-        native = nnkernels.conv_module_supported(conv)
-        s2d = not native and nnkernels.stem_s2d_supported(conv, x)
-        # a dense NCHW frame into a 7x7 stem: layout conversion and (x - a) / b happen inside the space-to-depth pass
-        planar = s2d and not skip and nnkernels.stem_s2d_planar_supported(conv, x)
-        if input_affine is not None and not planar:
-            x = (x - input_affine[0]) / input_affine[1]
-        stats = geom = None
-        if bn_stats is not None and (native or s2d):
-            geom = nnkernels.conv_out_geom(x, conv, s2d)
-            M, K = geom[0] * geom[9] * geom[10], geom[4]
-            # room for the plan with the most rows of partials: 64-row tiles, or the input-patch kernel's 4 x 16 pixel patches
-            # (partial patches at the right / lower border make that more than M / 64)
-            rows_max = max((M + 63) // 64, geom[0] * ((geom[9] + 3) // 4) * ((geom[10] + 15) // 16))
-            stats = torch.empty(rows_max * K * 2, device=x.device, dtype=torch.float32)
-        if native:
-            out = nnkernels.conv2d_native(x, conv, act, skip, stats)
-        elif planar:
-            out = nnkernels.conv2d_stem_s2d_planar([(x, None)], conv, act, stats, input_affine or (0.0, 1.0))
-        elif s2d:
-            y = nnkernels.conv2d_stem_s2d(x, conv, act, stats)
-            out = (y, x) if skip else y
-        if native or s2d:
-            if stats is not None:
-                rows = nnkernels.conv_stats_rows(geom)      # after the call: the first call may have (re)tuned the plan
-                if rows > 0:
-                    bn_stats.append((stats, rows))
-            return out
+    the BatchNorm that follows (training, plan without split-K)."""
     _device_only(x, "conv2d")
-    ATEN_FALLBACKS["conv2d"] = ATEN_FALLBACKS.get("conv2d", 0) + 1
-    if input_affine is not None:
+    from . import nnkernels
+    native = nnkernels.conv_module_supported(conv)
+    s2d = not native and nnkernels.stem_s2d_supported(conv, x)
+    if not (native or s2d):
+        raise RuntimeError("sqd: conv2d %d -> %d channels, kernel %s, stride %s, padding %s: the implicit-GEMM kernels take channel "
+                           "counts that are multiples of 4 (3- / 6-channel frames: the 7x7 stride-2 stems only)"
+                           % (conv.in_channels, conv.out_channels, tuple(conv.kernel_size), tuple(conv.stride), tuple(conv.padding)))
+    # a dense NCHW frame into a 7x7 stem: layout conversion and (x - a) / b happen inside the space-to-depth pass
+    planar = s2d and not skip and nnkernels.stem_s2d_planar_supported(conv, x)
+    if input_affine is not None and not planar:
         x = (x - input_affine[0]) / input_affine[1]
-    y = _act(F.conv2d(x, conv.weight, conv.bias, conv.stride, conv.padding), act)      # ATen: channel counts not divisible by 4
-    return (y, x) if skip else y
+    stats = geom = None
+    if bn_stats is not None:
+        geom = nnkernels.conv_out_geom(x, conv, s2d)
+        M, K = geom[0] * geom[9] * geom[10], geom[4]
+        # room for the plan with the most rows of partials: 64-row tiles, or the input-patch kernel's 4 x 16 pixel patches
+        # (partial patches at the right / lower border make that more than M / 64)
+        rows_max = max((M + 63) // 64, geom[0] * ((geom[9] + 3) // 4) * ((geom[10] + 15) // 16))
+        stats = torch.empty(rows_max * K * 2, device=x.device, dtype=torch.float32)
+    if native:
+        out = nnkernels.conv2d_native(x, conv, act, skip, stats)
+    elif planar:
+        out = nnkernels.conv2d_stem_s2d_planar([(x, None)], conv, act, stats, input_affine or (0.0, 1.0))
+    else:
+        y = nnkernels.conv2d_stem_s2d(x, conv, act, stats)
+        out = (y, x) if skip else y
+    if stats is not None:
+        rows = nnkernels.conv_stats_rows(geom)      # after the call: the first call may have (re)tuned the plan
+        if rows > 0:
+            bn_stats.append((stats, rows))
+    return out
 
 
 def conv2d(x, conv, act=None):
@@ -125,14 +95,14 @@ def stem_pairs(pairs, conv, act=None):
     """conv applied to the channel concatenation of frame pairs: pairs = [(x0, x1), ...] -> [B * len(pairs), K, H', W'] with row
     b * len(pairs) + i = pair i of sample b (the pose network's input assembly, reference trainer.py:319-326, without the copies)."""
     x0 = pairs[0][0]
-    if NATIVE_CONV and x0.is_cuda:
-        from . import nnkernels
-        probe = torch.empty((1, conv.in_channels, x0.shape[2], x0.shape[3]), device="meta")
-        if nnkernels.stem_s2d_supported(conv, probe) and all(a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float32 for a, b in pairs):
-            return nnkernels.conv2d_stem_s2d_planar(pairs, conv, act)
+    _device_only(x0, "stem_pairs")
+    from . import nnkernels
+    probe = torch.empty((1, conv.in_channels, x0.shape[2], x0.shape[3]), device="meta")
+    if nnkernels.stem_s2d_supported(conv, probe) and all(a.is_contiguous() and b.is_contiguous() and a.dtype == torch.float32 for a, b in pairs):
+        return nnkernels.conv2d_stem_s2d_planar(pairs, conv, act)
     B, S = x0.shape[0], len(pairs)
     x = torch.stack([torch.cat(p, 1) for p in pairs], 1).reshape((B * S, -1) + tuple(x0.shape[2:]))
-    return conv2d(x.contiguous(memory_format=torch.channels_last) if x.is_cuda else x, conv, act)
+    return conv2d(x.contiguous(memory_format=torch.channels_last), conv, act)
 
 
 def conv_bn_act(x, conv, bn, act, residual=None, input_affine=None, skip=False):
@@ -162,15 +132,12 @@ def _bn_act(y, bn, act, residual, pre=None):
 def pose_head(x, conv, scale, split=False):
     """scale * conv(x).mean(3).mean(2) for PoseCNN's 1x1 head (reference networks/pose_cnn.py:40-45) -> [B, J]; split=True:
     -> (axisangle, translation), each [B, J/6, 1, 3] — out.view(-1, F, 1, 6)[..., :3] and [..., 3:] as dense tensors."""
-    if x.is_cuda and NATIVE_CONV and conv.kernel_size == (1, 1) and conv.out_channels <= 16 and conv.bias is not None:
-        from . import nnkernels
-        return nnkernels.PoseHead.apply(x, conv.weight, conv.bias, scale, split)
     _device_only(x, "pose_head")
-    out = scale * F.conv2d(x, conv.weight, conv.bias).mean(3).mean(2)
-    if split:
-        out = out.view(out.shape[0], -1, 1, 6)
-        return out[..., :3], out[..., 3:]
-    return out
+    if not (conv.kernel_size == (1, 1) and conv.out_channels <= 16 and conv.bias is not None):
+        raise RuntimeError("sqd: pose_head is a 1x1 convolution with bias onto <= 16 channels; got kernel %s, %d channels, bias %s"
+                           % (tuple(conv.kernel_size), conv.out_channels, conv.bias is not None))
+    from . import nnkernels
+    return nnkernels.PoseHead.apply(x, conv.weight, conv.bias, scale, split)
 
 
 def dw_conv_bn_act(x, conv, bn, act, stride):
@@ -246,15 +213,11 @@ def squeeze_excite(x, conv_reduce, conv_expand):
 
 
 def stem_same_conv_bn_act(x, conv, bn, act):
-    """EfficientNet stem: 3x3 stride-2 convolution on the 3-channel image with TensorFlow "SAME" padding -> BatchNorm -> activation.
-    Three input channels are no shape for the implicit-GEMM kernels: the convolution itself runs on ATen."""
+    """EfficientNet stem: 3x3 stride-2 convolution on the 3-channel image with TensorFlow "SAME" padding -> BatchNorm -> activation
+    (the convolution runs as a 3x3 / stride 1 one on the space-to-depth image: nnkernels.conv2d_stem3_same_s2d)."""
     _device_only(x, "stem convolution")
     from . import nnkernels
-    k, st = conv.kernel_size[0], conv.stride[0]
-    (Ho, pt), (Wo, pl) = nnkernels.tf_same_pad(x.shape[2], k, st), nnkernels.tf_same_pad(x.shape[3], k, st)
-    tot_h, tot_w = max((Ho - 1) * st + k - x.shape[2], 0), max((Wo - 1) * st + k - x.shape[3], 0)
-    y = F.conv2d(F.pad(x, (pl, tot_w - pl, pt, tot_h - pt)), conv.weight, None, st)
-    return nnkernels.batch_norm_act(y, bn, act)
+    return nnkernels.batch_norm_act(nnkernels.conv2d_stem3_same_s2d(x, conv), bn, act)
 
 
 def maxpool3x3s2(x, skip=False):
@@ -277,14 +240,12 @@ def upsample_concat(x, skip):
 
 def linear(x, lin, act=None):
     """nn.Linear (+ LeakyReLU(0.01)) of the bins regressor."""
-    if x.is_cuda and NATIVE_CONV:
-        from . import nnkernels
-        if nnkernels.linear_supported(lin, x):
-            return nnkernels.linear_native(x, lin, act)
     _device_only(x, "linear")
-    ATEN_FALLBACKS["linear"] = ATEN_FALLBACKS.get("linear", 0) + 1
-    y = F.linear(x, lin.weight, lin.bias)      # ATen: feature counts that are not multiples of 4
-    return F.leaky_relu(y, 0.01) if act == "leaky_relu" else y
+    from . import nnkernels
+    if not nnkernels.linear_supported(lin, x):
+        raise RuntimeError("sqd: linear %d -> %d features on input %s: the kernel takes feature counts that are multiples of 4"
+                           % (lin.in_features, lin.out_features, tuple(x.shape)))
+    return nnkernels.linear_native(x, lin, act)
 
 
 def transformer_encoder(tokens, encoder):
@@ -293,7 +254,8 @@ def transformer_encoder(tokens, encoder):
     from . import nnkernels
     if nnkernels.encoder_supported(encoder):
         return nnkernels.transformer_encoder_native(tokens, encoder)
-    return encoder(tokens)                     # ATen: embedding widths other than 16 / 32
+    ATEN_CALLS["transformer_encoder"] = ATEN_CALLS.get("transformer_encoder", 0) + 1
+    return encoder(tokens)                     # ATen: embedding widths other than 16 / 32 (config B' of the old args files)
 
 
 def full_query_layer(x, queries):

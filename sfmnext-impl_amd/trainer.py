@@ -84,8 +84,6 @@ class Trainer:
             sd = torch.load(os.path.join(self.opt.pose_net_path, "pose.pth"), map_location=self.device)
             self.models["pose"].load_state_dict({k.replace("module.", ""): v for k, v in sd.items()})
 
-        if self.opt.sqd_miopen_find:
-            torch.backends.cudnn.benchmark = True
         from sqd import nnops
         nnops.configure(self.opt, self.device)
         if self.opt.sqd_channels_last:
@@ -197,6 +195,12 @@ class Trainer:
     def train_step(self, inputs):
         """forward + backward + Adam on one batch (reference trainer.py:240-244).  On a single device the step is
         captured into a hipGraph after a few eager steps and replayed from then on (--sqd_no_graph: always eager)."""
+        self._steps_run = getattr(self, "_steps_run", 0) + 1
+        if self._steps_run == 5 and self.opt.sqd_save_conv_plans and self.rank == 0:
+            # every layer's forward / data-gradient / weight-gradient plan has been timed (step 1) and, in graph mode, frozen
+            # into the capture (step 4): the file pins this exact kernel set for a later run (--sqd_conv_plans)
+            with open(self.opt.sqd_save_conv_plans, "w") as f:
+                json.dump(nnkernels.export_plans(), f)
         if self._graph_ok:
             if self._graph is not None or self._graph_warm >= 3:
                 return self._train_step_graphed(inputs)

@@ -26,11 +26,11 @@ def _no_dropout(models):
                 mod.dropout = 0.0
 
 
-def test_abs_rel_after_200_steps():
+@pytest.fixture(scope="module")
+def oracle_run():
+    """the oracle's 200 steps (CPU), once for both device runs"""
     sys.path.insert(0, REPO)
     from oracle import torch_ref as O
-    from options import MonodepthOptions
-    from trainer import Trainer
     from datasets.synthetic import synthetic_batch
     torch.manual_seed(0)
     torch.set_num_threads(min(16, os.cpu_count() or 1))
@@ -45,43 +45,57 @@ def test_abs_rel_after_200_steps():
     batches = [synthetic_batch(B, H, W, start=B * i) for i in range(NBATCH)]
     noises = [torch.randn(B, 2, H, W, generator=g) for _ in range(STEPS)]
     held = synthetic_batch(B, H, W, start=10 ** 5, with_gt=True)
+    ref = O.RefTrainStep(enc, dep, pose, (0, -1, 1), H, W)
+    ref_loss = [float(ref.step(dict(batches[i % NBATCH]), noises[i])[1]["loss"].detach()) for i in range(STEPS)]
+    for m in (enc, dep, pose):
+        m.eval()
+    with torch.no_grad():
+        out = dep(enc(held[("color_aug", 0, 0)]))
+        depth = torch.nn.functional.interpolate(out[("disp", 0)], [H, W], mode="bilinear", align_corners=False)
+    want = [float(v) for v in O.compute_depth_losses(depth, held["depth_gt"])]
+    return {"state": state, "batches": batches, "noises": noises, "held": held, "ref_loss": ref_loss, "want": want}
 
-    tr = Trainer(MonodepthOptions().parse(ARGS))
+
+@pytest.mark.parametrize("plans", ["default_plans", "tuned_plans"])
+def test_abs_rel_after_200_steps(oracle_run, plans):
+    """default_plans: the library's cost-model (fp32 MFMA) plans; tuned_plans: first-step plan timing on, as benchmarked
+    (three-term bf16 / input-patch kernels where they are faster)"""
+    from options import MonodepthOptions
+    from trainer import Trainer
+    from sqd import nnkernels
+    R = oracle_run
+    nnkernels.reset_plans()
+    tr = Trainer(MonodepthOptions().parse(ARGS if plans == "default_plans" else [a for a in ARGS if a != "--sqd_no_conv_tune"]))
     tr.set_train()
     _no_dropout(tr.models.values())
-    for name, sd in state.items():
+    for name, sd in R["state"].items():
         tr.models[name].load_state_dict(sd)
-    ref = O.RefTrainStep(enc, dep, pose, (0, -1, 1), H, W)
-    dev_loss, ref_loss = [], []
-    for i in range(STEPS):
-        inputs = batches[i % NBATCH]
-        ref_loss.append(float(ref.step(dict(inputs), noises[i])[1]["loss"]))
-        dev = {k: v.cuda() for k, v in inputs.items()}
-        dev[("noise", 0)] = noises[i].cuda()
-        dev_loss.append(float(tr.train_step(dev)[1]["loss"]))
-    assert tr._graph is not None                       # the replayed hipGraph did the training
-
-    def abs_rel_ref():
-        for m in (enc, dep, pose):
-            m.eval()
-        with torch.no_grad():
-            out = dep(enc(held[("color_aug", 0, 0)]))
-            depth = torch.nn.functional.interpolate(out[("disp", 0)], [H, W], mode="bilinear", align_corners=False)
-        return [float(v) for v in O.compute_depth_losses(depth, held["depth_gt"])]
-
-    def abs_rel_dev():
+    dev_loss = []
+    try:
+        for i in range(STEPS):
+            dev = {k: v.cuda() for k, v in R["batches"][i % NBATCH].items()}
+            dev[("noise", 0)] = R["noises"][i].cuda()
+            dev_loss.append(float(tr.train_step(dev)[1]["loss"].detach()))
+        assert tr._graph is not None                       # the replayed hipGraph did the training
+        mix = nnkernels.plan_mix()
         tr.set_eval()
         with torch.no_grad():
-            inputs = {k: v.cuda() for k, v in held.items()}
+            inputs = {k: v.cuda() for k, v in R["held"].items()}
             outputs, losses = tr.process_batch(inputs)
             tr.compute_depth_losses(inputs, outputs, losses)
-        return [float(losses[n]) for n in tr.depth_metric_names]
-
-    want, got = abs_rel_ref(), abs_rel_dev()
-    print("loss after %d steps: device %.6f oracle %.6f (first step %.6f); depth metrics device %s oracle %s"
-          % (STEPS, dev_loss[-1], ref_loss[-1], ref_loss[0], ["%.5f" % v for v in got], ["%.5f" % v for v in want]))
+        got = [float(losses[n]) for n in tr.depth_metric_names]
+    finally:
+        nnkernels.reset_plans()
+    ref_loss, want = R["ref_loss"], R["want"]
+    worst = max(abs(a - b) / abs(b) for a, b in zip(dev_loss, ref_loss))
+    print("%s: loss after %d steps: device %.6f oracle %.6f (first step %.6f), worst per-step relative difference %.2e; depth metrics device %s oracle %s; plans %s"
+          % (plans, STEPS, dev_loss[-1], ref_loss[-1], ref_loss[0], worst, ["%.5f" % v for v in got], ["%.5f" % v for v in want], mix))
     first, last = sum(ref_loss[:NBATCH]) / NBATCH, sum(ref_loss[-NBATCH:]) / NBATCH
-    print("mean loss over the %d batches: first pass %.6f, last pass %.6f" % (NBATCH, first, last))
     assert last < first                                # the model did train (same batches, 25 passes later)
+    if plans == "tuned_plans":
+        assert sum(mix.get("fwd", {}).values()) > 10, mix
     assert abs(got[0] - want[0]) <= 1e-3, ("abs_rel", got[0], want[0])
-    assert abs(dev_loss[-1] - ref_loss[-1]) <= 2e-2 * abs(ref_loss[-1]), (dev_loss[-1], ref_loss[-1])
+    # measured on MI355X (profiles/r03c): worst per-step relative loss difference over the 200 steps 9.6e-4 (default plans) / 3.1e-4
+    # (measured plans), final loss equal to 1e-5, |d abs_rel| 2.3e-4 / 0.9e-4 — the bars are ~3x that
+    assert worst <= 3e-3, worst
+    assert abs(dev_loss[-1] - ref_loss[-1]) <= 5e-4 * abs(ref_loss[-1]), (dev_loss[-1], ref_loss[-1])

@@ -155,7 +155,6 @@ def test_conv_epilogue_feeds_batchnorm_statistics(N, C, H, W, K, R, stride, pad,
     gy = torch.randn_like(yr)
     yr.backward(gy)
     gy = gy.float()
-    nnops.set_native_conv(True)
     try:
         xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(C > 3)
         y = nnops.conv_bn_act(xg, conv_g, bn_g, "relu")
@@ -163,7 +162,7 @@ def test_conv_epilogue_feeds_batchnorm_statistics(N, C, H, W, K, R, stride, pad,
         assert nnkernels.conv_stats_rows(geom) > 0, "this geometry must take the fused-statistics path"
         y.backward(gy.cuda())
     finally:
-        nnops.set_native_conv(False)
+        pass
     assert torch.allclose(y.cpu().double(), yr.detach(), rtol=1e-4, atol=2e-4)
     assert torch.allclose(bn_g.running_mean.cpu().double(), bn.running_mean, rtol=1e-4, atol=1e-5)
     assert torch.allclose(bn_g.running_var.cpu().double(), bn.running_var, rtol=1e-4, atol=1e-5)
@@ -422,7 +421,6 @@ def test_input_patch_plan_feeds_batchnorm_statistics(K, plans):
     gy = torch.randn_like(yr)
     yr.backward(gy)
     geom = (N, H, W, C, K, 3, 3, 1, 1, H, W)
-    nnops.set_native_conv(True)
     try:
         for bm, bn_t in plans:
             assert L.sqd_conv_set_plan(0, *geom, bm, bn_t, 1, 32 + 1024 + 2048) == 0
@@ -440,7 +438,6 @@ def test_input_patch_plan_feeds_batchnorm_statistics(K, plans):
     finally:
         L.sqd_conv_set_plan(0, *geom, 0, 0, 0, 16)
         nnkernels._PLAN_CACHE.clear()
-        nnops.set_native_conv(False)
 
 
 def test_planar_frame_staging_matches_the_copies():
@@ -463,12 +460,11 @@ def test_planar_frame_staging_matches_the_copies():
     pose = PoseCNN(2).cuda().to(memory_format=torch.channels_last)
     pairs = [(f[1], f[0]), (f[0], f[2])]
     x = torch.stack([torch.cat(p, 1) for p in pairs], 1).reshape(B * 2, 6, H, W).contiguous(memory_format=torch.channels_last)
-    nnops.set_native_conv(True)
     try:
         a_ref, t_ref = pose(x)
         a, t = pose.forward_pairs(pairs)
     finally:
-        nnops.set_native_conv(False)
+        pass
     assert torch.equal(a, a_ref) and torch.equal(t, t_ref)
 
 
@@ -520,7 +516,6 @@ def test_stem_with_input_patch_plan_feeds_batchnorm_statistics(bm, bn_t):
     gy = torch.randn_like(yr)
     gwr, = torch.autograd.grad(yr, conv.weight, gy)
     geom = (N, H // 2, W // 2, 16, K, 4, 4, 1, 2, H // 2, W // 2)
-    nnops.set_native_conv(True)
     try:
         assert L.sqd_conv_set_plan(0, *geom, bm, bn_t, 1, 32 + 1024 + 2048) == 0
         nnkernels._PLAN_CACHE.clear()
@@ -530,7 +525,6 @@ def test_stem_with_input_patch_plan_feeds_batchnorm_statistics(bm, bn_t):
     finally:
         L.sqd_conv_set_plan(0, *geom, 0, 0, 0, 16)
         nnkernels._PLAN_CACHE.clear()
-        nnops.set_native_conv(False)
     assert torch.allclose(y.detach().cpu().double(), yr.detach(), rtol=1e-4, atol=2e-4)
     assert torch.allclose(bn_g.running_var.cpu().double(), bn.running_var, rtol=1e-4, atol=1e-5)
     assert float((gw.cpu().double() - gwr).abs().max()) <= 1e-3 * float(gwr.abs().max())

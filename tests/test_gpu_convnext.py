@@ -10,6 +10,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+# bars of the full-trunk step: set from the figures the test prints on MI355X (see below)
+LOSS_RTOL, DISP_RTOL, WRONG_SIGN_FRACTION = 2e-4, 5e-4, 2e-2
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
 
@@ -216,12 +218,17 @@ def test_convnext_large_train_step_matches_oracle():
     inputs[("noise", 0)] = noise.cuda()
     outputs, losses = tr.train_step(inputs)
     got, want = float(losses["loss"]), float(ref_losses["loss"])
-    assert abs(got - want) <= 2e-4 * abs(want), (got, want)
     d, dr = outputs[("disp", 0)].detach().cpu(), ref_out[("disp", 0)].detach()
-    assert float((d - dr).abs().max()) <= 5e-4 * float(dr.abs().max())
-    # updated weights (Adam step of 1e-4: a wrong-signed gradient moves a weight by 2e-4)
+    d_err = float((d - dr).abs().max()) / float(dr.abs().max())
     mine = tr.models["encoder"].state_dict()
+    off = {}
     for k, v in enc.state_dict().items():
         if k.endswith(("stem_0.weight", "stages_2.blocks.5.mlp.fc2.weight", "stages_3.blocks.0.conv_dw.weight", "decoder.blocks.1.conv2.conv.weight")):
-            diff = (mine[k].detach().cpu() - v).abs()
-            assert float((diff > 1.2e-4).float().mean()) < 2e-2, (k, float(diff.max()))
+            off[k] = float(((mine[k].detach().cpu() - v).abs() > 1.2e-4).float().mean())
+    print("convnext_large 64x128: loss %.7f oracle %.7f (rel %.2e); disparity max err %.2e of max; fraction of weights updated the other way %s"
+          % (got, want, abs(got - want) / abs(want), d_err, {k.split(".", 2)[-1]: "%.1e" % v for k, v in off.items()}))
+    assert abs(got - want) <= LOSS_RTOL * abs(want), (got, want)
+    assert d_err <= DISP_RTOL
+    # updated weights (Adam step of 1e-4: a wrong-signed gradient moves a weight by 2e-4; only gradients within rounding of zero may)
+    for k, v in off.items():
+        assert v < WRONG_SIGN_FRACTION, (k, v)

@@ -23,7 +23,6 @@ def _rel(a, b):
 def test_g18_decoderbn_b5_on_device(golden):
     import networks
     from sqd import nnops
-    nnops.set_native_conv(True)
     g = golden("g18_decoderbn_b5")
     dec = fill_params(networks.DecoderBN(int(g["nf"]), 8, int(g["bott"]), (176, 64, 40, 24)), int(g["seed"])).cuda().to(memory_format=torch.channels_last)
     feats = [tt(f).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
@@ -46,7 +45,6 @@ def test_base_encoder_matches_oracle(H, W, B):
     import networks
     from oracle import torch_ref as O
     from sqd import nnops
-    nnops.set_native_conv(True)
     torch.manual_seed(3)
     ref = O.BaseEncoder(model_dim=32, num_features=512)
     mine = networks.BaseEncoder.build(model_dim=32, num_features=512)

@@ -12,25 +12,40 @@ pytestmark = pytest.mark.gpu
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+HEADS = {
+    # kind: (network flags, oracle decoder arguments (patch, Q, dim_out, ff, min_depth))
+    "res50": (["--backbone", "resnet", "--num_layers", "50", "--num_features", "256", "--query_nums", "64", "--dim_out", "64",
+               "--patch_size", "16", "--min_depth", "0.001"], (16, 64, 64, 1024, 0.001)),
+    # configs[2] with the head of the reference's own 320x1024 file (args_files/hisfog/kitti/resnet_320x1024.txt:6,12-19):
+    # backbone resnet_lite (=> Lite_Depth_Decoder_QueryTr, feed-forward 512), patch 20, 128 queries, dim_out 128, min_depth 0.01
+    "res50_c": (["--backbone", "resnet_lite", "--num_layers", "50", "--num_features", "256", "--query_nums", "128", "--dim_out", "128",
+                 "--patch_size", "20", "--min_depth", "0.01"], (20, 128, 128, 512, 0.01)),
+    "res18": (["--backbone", "resnet18_lite", "--query_nums", "120", "--dim_out", "128", "--patch_size", "16", "--min_depth", "0.001"],
+              (16, 120, 128, 512, 0.001)),       # args_res18_kitti_192x640_tarin.txt:8-10
+}
+
+
 def _args(H, W, B, extra, kind="res50"):
-    net = ["--backbone", "resnet", "--num_layers", "50", "--num_features", "256", "--query_nums", "64", "--dim_out", "64"] if kind == "res50" \
-        else ["--backbone", "resnet18_lite", "--query_nums", "120", "--dim_out", "128"]       # args_res18_kitti_192x640_tarin.txt:8-10
-    return net + ["--model_dim", "32", "--patch_size", "16", "--height", str(H), "--width", str(W), "--batch_size", str(B),
-            "--min_depth", "0.001", "--max_depth", "80.0", "--num_workers", "0", "--sqd_synthetic",
-            "--log_dir", "/tmp/sqd_full_cfg_test", "--sqd_no_conv_tune"] + extra
+    return HEADS[kind][0] + ["--model_dim", "32", "--height", str(H), "--width", str(W), "--batch_size", str(B),
+                             "--max_depth", "80.0", "--num_workers", "0", "--sqd_synthetic", "--log_dir", "/tmp/sqd_full_cfg_test"] + extra
 
 
-@pytest.mark.parametrize("H,W,B,kind", [(192, 640, 2, "res50"), (320, 1024, 1, "res50"), (192, 640, 2, "res18")])
-def test_flagship_step_matches_oracle(H, W, B, kind):
-    """configs[1] and configs[2] (ResNet-50 + Depth_Decoder_QueryTr) and configs[0] at its real shape: ResNet-18 +
-    Lite_Depth_Decoder_QueryTr, 192x640, batch 2, model_dim 32 / patch 16 / 120 queries / dim_out 128."""
+@pytest.mark.parametrize("plans", ["default_plans", "tuned_plans"])
+@pytest.mark.parametrize("H,W,B,kind", [(192, 640, 2, "res50"), (320, 1024, 1, "res50_c"), (192, 640, 2, "res18")])
+def test_flagship_step_matches_oracle(H, W, B, kind, plans):
+    """configs[1] and configs[2] (ResNet-50 + [Lite_]Depth_Decoder_QueryTr) and configs[0] at its real shape (ResNet-18 +
+    Lite_Depth_Decoder_QueryTr, 192x640, batch 2, model_dim 32 / patch 16 / 120 queries / dim_out 128), each under the
+    library's default (fp32 MFMA) plans and under first-step plan timing — the benchmarked arithmetic: per layer the fastest of the
+    fp32, three-term bf16 and input-patch kernels — against the same oracle step at the same 1e-4."""
     sys.path.insert(0, REPO)
     from oracle import torch_ref as O
     from options import MonodepthOptions
     from trainer import Trainer
     from datasets.synthetic import synthetic_batch
     torch.manual_seed(0)
-    tr = Trainer(MonodepthOptions().parse(_args(H, W, B, ["--sqd_no_graph"], kind)))
+    from sqd import nnkernels
+    nnkernels.reset_plans()
+    tr = Trainer(MonodepthOptions().parse(_args(H, W, B, ["--sqd_no_graph"] + ([] if plans == "tuned_plans" else ["--sqd_no_conv_tune"]), kind)))
     tr.set_train()
     for m in tr.models.values():
         for mod in m.modules():
@@ -38,12 +53,9 @@ def test_flagship_step_matches_oracle(H, W, B, kind):
                 mod.p = 0.0
             if isinstance(mod, torch.nn.MultiheadAttention):
                 mod.dropout = 0.0
-    if kind == "res50":
-        enc = O.ResnetEncoderDecoder(50, 256, 32)
-        dep = O.QueryTrDecoder(32, 32, 16, 4, 64, 64, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
-    else:
-        enc = O.LiteResnetEncoderDecoder(model_dim=32)
-        dep = O.QueryTrDecoder(32, 32, 16, 4, 120, 128, min_val=0.001, max_val=80.0, dim_feedforward=512, dropout=0.0)
+    patch, Q, dim_out, ff, min_depth = HEADS[kind][1]
+    enc = O.LiteResnetEncoderDecoder(model_dim=32) if kind == "res18" else O.ResnetEncoderDecoder(50, 256, 32)
+    dep = O.QueryTrDecoder(32, 32, patch, 4, Q, dim_out, min_val=min_depth, max_val=80.0, dim_feedforward=ff, dropout=0.0)
     pose = O.PoseCNN(2)
     for ref, mine in ((enc, tr.models["encoder"]), (dep, tr.models["depth"]), (pose, tr.models["pose"])):
         ref.load_state_dict({k: v.detach().cpu() for k, v in mine.state_dict().items()})
@@ -55,12 +67,22 @@ def test_flagship_step_matches_oracle(H, W, B, kind):
     ref_out, ref_losses = ref.step(dict(cpu_inputs), noise)
     inputs = {k: v.cuda() for k, v in cpu_inputs.items()}
     inputs[("noise", 0)] = noise.cuda()
-    outputs, losses = tr.train_step(inputs)
-    torch.cuda.synchronize()
+    try:
+        outputs, losses = tr.train_step(inputs)
+        torch.cuda.synchronize()
+        mix = nnkernels.plan_mix()
+    finally:
+        nnkernels.reset_plans()
+    if plans == "tuned_plans":
+        assert sum(mix.get("fwd", {}).values()) > 20 and sum(mix.get("wgrad", {}).values()) > 20, mix      # the layers were timed
     got, want = float(losses["loss"]), float(ref_losses["loss"])
-    assert abs(got - want) <= 1e-4 * abs(want), (got, want)
     disp, disp_ref = outputs[("disp", 0)].detach().cpu(), ref_out[("disp", 0)].detach()
-    assert float((disp - disp_ref).abs().max()) <= 1e-4 * float(disp_ref.abs().max()), "predicted disparity"
+    d_err = float((disp - disp_ref).abs().max()) / float(disp_ref.abs().max())
+    print("%s %dx%d %s: loss %.7f oracle %.7f (rel %.2e), disparity max err %.2e of max; plans %s"
+          % (kind, H, W, plans, got, want, abs(got - want) / abs(want), d_err, mix))
+    # north_star: 1e-4 relative; measured on MI355X 1-2e-6 for loss and 1.4-2.4e-6 for the disparity, default and measured plans alike
+    assert abs(got - want) <= 2e-5 * abs(want), (got, want)
+    assert d_err <= 2e-5, "predicted disparity"
     # the optimiser step: Adam moves every weight by ~lr, so compare the UPDATE of a few tensors (first / last layers of each net)
     # (the two 7x7 stems are the non-leaf / regrouped filters of the eager path: ADVICE r1 asked for them to be checked here)
     for net, mine, name in ((pose, tr.models["pose"], "pose_conv.weight"), (enc, tr.models["encoder"], "decoder.conv3.weight"),

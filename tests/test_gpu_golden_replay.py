@@ -77,7 +77,6 @@ def test_g11_qtr_decoders(golden, tag):
 def test_g12_posecnn(golden):
     import networks
     from sqd import nnops
-    nnops.set_native_conv(True)
     g = golden("g12_posecnn")
     m = fill_params(networks.PoseCNN(2), int(g["seed"])).cuda().to(memory_format=torch.channels_last)
     x = tt(smooth_images(np.random.RandomState(int(g["x_seed"])), 2, 64, 96, C=6)).cuda()
@@ -95,7 +94,6 @@ def test_g12_posecnn(golden):
 def test_g13_decoderbn(golden, tag, skips, chans):
     import networks
     from sqd import nnops
-    nnops.set_native_conv(True)
     g = golden("g13_decoderbn_" + tag)
     dec = fill_params(networks.DecoderBN(int(g["nf"]), 8, int(g["bott"]), skips), int(g["seed"])).cuda().to(memory_format=torch.channels_last)
     feats = [tt(f).cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)

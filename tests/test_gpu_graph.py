@@ -144,14 +144,8 @@ def test_tuned_plans_train_like_the_default_plans():
         _, par1_t, _ = run50(["--sqd_no_graph"], 1)              # (plans stay registered from the run above)
     finally:
         ARGS = saved
-        from sqd import lib, nnkernels
-        for key in list(nnkernels._TUNED):                 # leave no measured plan behind for the tests that follow
-            if key[0] in (0, 1):
-                lib.lib().sqd_conv_set_plan(key[0], *key[1:], 0, 0, 0, 16)
-            elif key[0] == "w":
-                lib.lib().sqd_conv_wgrad_set_plan(*key[1:], -1, 0)
-        nnkernels._TUNED.clear()
-        nnkernels._PLAN_CACHE.clear()
+        from sqd import nnkernels
+        nnkernels.reset_plans()                            # leave no measured plan behind for the tests that follow
     assert len(tuned) > 40, "the tuned run must have timed its layers"
     for a, b in zip(loss_d, loss_t):
         assert abs(a - b) <= 1e-4 * abs(a) + 1e-6, (loss_d, loss_t)

@@ -158,7 +158,6 @@ def test_encoder_taps_carry_the_same_values_and_gradients():
     from sqd import nnops
     torch.manual_seed(3)
     enc = ResnetEncoder(18).cuda().train()
-    nnops.set_native_conv(True)
     try:
         x = torch.rand(2, 3, 64, 96, device="cuda")
         ws = [torch.randn(1, c, 1, 1, device="cuda") for c in enc.num_ch_enc]
@@ -186,7 +185,7 @@ def test_encoder_taps_carry_the_same_values_and_gradients():
                 err = (got[n] - p.grad).abs().max().item()
                 assert err <= 1e-5 * max(p.grad.abs().max().item(), 1e-6), (n, err)
     finally:
-        nnops.set_native_conv(False)
+        pass
 
 
 @pytest.mark.parametrize("rows,K,N,act", [(12, 2048, 1024, "leaky_relu"), (12, 1024, 256, "leaky_relu"), (12, 256, 64, None),
@@ -194,7 +193,6 @@ def test_encoder_taps_carry_the_same_values_and_gradients():
 def test_linear_native(rows, K, N, act):
     """the bins regressor's nn.Linear (+ LeakyReLU) through the 1x1 implicit-GEMM kernels against fp64"""
     from sqd import nnops
-    nnops.set_native_conv(True)
     torch.manual_seed(rows + K)
     lin = nn.Linear(K, N)
     x = torch.randn(rows, K)
@@ -223,7 +221,6 @@ def test_linear_native(rows, K, N, act):
 def test_pose_head(B, C, h, w, J):
     """0.01 * pose_conv(x).mean(3).mean(2) (reference networks/pose_cnn.py:40-45) against the fp64 composite"""
     from sqd import nnops
-    nnops.set_native_conv(True)
     torch.manual_seed(B + C + J)
     conv = nn.Conv2d(C, J, 1)
     x, g = torch.randn(B, C, h, w), torch.randn(B, J)
