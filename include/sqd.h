@@ -108,17 +108,19 @@ int sqd_identity_fwd(const float *target, const float *const *sources_host, cons
 
 /* d(to_optimise)/d(7x7 window sums) of the winning source — the "coefficient planes" the backward box-filters — from the
  * warped images sqd_photo_fwd stored: target [B,3,H,W], warped_host[S] device pointers to [B,3,H,W], idx [B,H,W] the argmin
- * byte -> coef [B,9,H,W] (planes: d/d sum w_c, d/d sum w_c^2, d/d sum w_c t_c for c = r,g,b), written where a
- * reprojection candidate won (idx >= S); other pixels are left untouched and never read.  Part of the backward pass: the
- * forward launch carries no training-only traffic.                                                                   */
+ * byte -> coef [B,9,H,W] (planes: d/d sum w_c, d/d sum w_c^2, d/d sum w_c t_c for c = r,g,b) where a reprojection
+ * candidate won (idx >= S), zeros elsewhere (fully written).  Part of the backward pass: the forward launch carries no
+ * training-only traffic.                                                                                                */
 int sqd_photo_coef(const float *target, const float *const *warped_host, const uint8_t *idx, float *coef, int B, int S, int H,
                    int W, int rows_per_task, void *stream);
 
 /* backward of sqd_photo_fwd w.r.t. depth and P.  gscale = dL/d(mean to_optimise) / (B*H*W).
- * One wavefront per (image, source, strip): plane s of g_depth = contribution of source s (fully
- * overwritten); image b's planes start at g_depth + b*g_depth_img_stride (elements), so the caller
- * can reserve extra planes (smoothness) behind them for sqd_depth_up_bwd.  g_P_part [ntasks_bwd, 12]
- * per-wavefront partials, ntasks_bwd = sqd_photo_bwd_ntasks(...) ordered [B][S][tasks_per_image].    */
+ * Tile kernel (same tiles as the forward), both sources of a pair in one pass, one launch per pair of source frames:
+ * plane k of g_depth = contribution of sources 2k and 2k+1 (fully overwritten); image b's planes start at
+ * g_depth + b*g_depth_img_stride (elements), so the caller can reserve extra planes (smoothness) behind the
+ * ceil(S/2) pair planes for sqd_depth_up_bwd.  coef: the planes sqd_photo_coef wrote (fully written; zero where an identity
+ * candidate won).  g_P_part [ntasks_bwd, 12] per-wavefront partials, ntasks_bwd = sqd_photo_bwd_ntasks(...)
+ * ordered [B][S][tasks_per_image] (tasks_per_image = 4 wavefronts x tiles per image).                 */
 typedef struct sqd_photo_bwd_args {
     const float *depth, *inv_K, *P, *target, *coef;
     const float *sources[SQD_MAX_SOURCES]; /* S x [B,3,H,W] */
@@ -126,10 +128,10 @@ typedef struct sqd_photo_bwd_args {
     const uint8_t *idx;
     float *g_depth;
     float *g_P_part;
-    int64_t g_depth_img_stride; /* >= S*H*W */
+    int64_t g_depth_img_stride; /* >= ceil(S/2)*H*W */
     float gscale;
     int32_t B, S, H, W;
-    int32_t rows_per_task;  /* TH: 1..4096; 0 = default: smallest TH >= 8 whose task count fits one round of wavefronts */
+    int32_t rows_per_task;  /* rows a workgroup tile owns (even, <= 16); 0 = library default (16) — as sqd_photo_args */
     void *stream;
 } sqd_photo_bwd_args;
 int sqd_photo_bwd_ntasks(int B, int S, int H, int W, int rows_per_task);

@@ -317,12 +317,15 @@ __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPa
         }
         if (a.idx) a.idx[(size_t)b * HW + qo] = (uint8_t)bi;
     } else {
+        // the planes are fully written: zeros where an identity candidate won (the first pass lays them down; a later pass
+        // of a 3- or 4-source run only overwrites the pixels its own sources won), so the backward reads them unmasked
         const int bi = a.idx[(size_t)b * HW + qo];
-        if (bi == NS + pp.s0 || bi == NS + pp.s1) {
+        const bool won = bi == NS + pp.s0 || bi == NS + pp.s1;
+        if (won || pp.first) {
             float *co = a.coef + (size_t)b * 9 * HW;
             const bool first = bi == NS + pp.s0;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) stg(co, (qo + j * HW) * 4u, (first ? o.g0[j] : o.g1[j]) * (0.85f / 3.f));
+            for (int j = 0; j < 9; ++j) stg(co, (qo + j * HW) * 4u, won ? (first ? o.g0[j] : o.g1[j]) * (0.85f / 3.f) : 0.f);
         }
     }
 }
@@ -547,6 +550,267 @@ __global__ __launch_bounds__(256, 4) void photo_tile_kernel(sqd_photo_args a, Pa
     }
 }
 
+// =====================================================================================================================
+// backward of the fused forward w.r.t. depth and the projection matrices, tile edition (both sources of a pair in one pass).
+//
+// d loss / d warped_s(q) collects the coefficient planes (photo_coef) of every window that contains q and was won by source s:
+// the adjoint of ReflectionPad2d(3) + AvgPool2d(7,1) in gather form — a zero-padded 7x7 box sum plus the mirrored terms at the
+// image border (rows / columns 1..3 receive the windows of rows / columns 0..3-q once more).  Vertically that is a sum over the
+// <= 7 rows around q with a wave-uniform multiplicity (refl_mult), taken straight from L2 (the rows of a tile are shared by its
+// four waves and by the neighbouring tiles of the same XCD); horizontally the same six-DPP chain as the forward plus the border
+// prefix sums mirrored inside the border quad.  Then, per owned pixel and source: the bilinear adjoint w.r.t. the sampling
+// position (clamp masks as ATen's clip_coordinates_set_grad; taps as 8-byte pair loads), the adjoints of Project3D and
+// BackprojectDepth; g_depth of both sources is written as ONE plane, the 12 entries of g_P per source are reduced per wave.
+// Replaces round 2's column march (one wave per image x source x strip, seven accumulator rows in registers, 172 us at config B).
+__device__ __forceinline__ int refl_mult(int r, int q, int n) {
+    // number of offsets d in [-3,3] with reflect(r+d) == q, for r,q in [0,n), |r-q| <= 3
+    return 1 + (int)(q >= 1 & q + r <= 3) + (int)(q <= n - 2 & (n - 1 - q) + (n - 1 - r) <= 3);
+}
+
+// adjoint of the reflected 7-tap window sum along x for three quantities: the zero-padded box7 plus, in a LEFT strip, columns
+// 1..3 += g0+g1+g2 / g0+g1 / g0 (prefix sums of lanes 0..2, mirrored inside the first quad; esrc = lanes 0..2, ekill = lane 0,
+// which the mirror hands the spill-over of the prefix chain) — RIGHT strips mirror-image (esrc = lanes 61..63, ekill = lane 63).
+__device__ __forceinline__ void box7x3_adj(int kind, float &a, float &b, float &c, bool esrc, bool ekill) {
+    float ea = 0.f, eb = 0.f, ec = 0.f;
+    if (kind != INTERIOR) {                                                   // (wave-uniform)
+        const float ma = esrc ? a : 0.f, mb = esrc ? b : 0.f, mc = esrc ? c : 0.f;
+        if (kind == LEFT) {
+            ea = quad_reverse<0, 0>((ma + row_shr<1>(ma)) + row_shr<2>(ma));
+            eb = quad_reverse<0, 0>((mb + row_shr<1>(mb)) + row_shr<2>(mb));
+            ec = quad_reverse<0, 0>((mc + row_shr<1>(mc)) + row_shr<2>(mc));
+        } else {
+            ea = quad_reverse<3, 3>((ma + row_shl<1>(ma)) + row_shl<2>(ma));
+            eb = quad_reverse<3, 3>((mb + row_shl<1>(mb)) + row_shl<2>(mb));
+            ec = quad_reverse<3, 3>((mc + row_shl<1>(mc)) + row_shl<2>(mc));
+        }
+        ea = ekill ? 0.f : ea; eb = ekill ? 0.f : eb; ec = ekill ? 0.f : ec;
+    }
+    float ra = a + wave_shr1(a), rb = b + wave_shr1(b), rc = c + wave_shr1(c);
+    ra = a + wave_shr1(ra); rb = b + wave_shr1(rb); rc = c + wave_shr1(rc);
+    ra = a + wave_shr1(ra); rb = b + wave_shr1(rb); rc = c + wave_shr1(rc);
+    float ua = a + wave_shl1(a), ub = b + wave_shl1(b), uc = c + wave_shl1(c);
+    ua = a + wave_shl1(ua); ub = b + wave_shl1(ub); uc = c + wave_shl1(uc);
+    a = (ra + wave_shl1(ua)) + ea; b = (rb + wave_shl1(ub)) + eb; c = (rc + wave_shl1(uc)) + ec;
+}
+
+// images of at most 64 columns: BOTH image borders lie inside the wavefront (column 0 in lane `lane0`), and a border's mirrored
+// terms may land on columns the other strip owns; they come from three lanes read with bpermute (tiny images only — tests)
+__device__ __forceinline__ float virt_border_adj(float v, int x, int W, int lane0) {
+    const float l0 = __shfl(v, lane0, 64), l1 = __shfl(v, lane0 + 1, 64), l2 = __shfl(v, lane0 + 2, 64);
+    const float r0 = __shfl(v, (lane0 + W - 1) & 63, 64), r1 = __shfl(v, (lane0 + W - 2) & 63, 64), r2 = __shfl(v, (lane0 + W - 3) & 63, 64);
+    float e = x == 1 ? (l0 + l1) + l2 : x == 2 ? l0 + l1 : x == 3 ? l0 : 0.f;
+    e += x == W - 2 ? (r0 + r1) + r2 : x == W - 3 ? r0 + r1 : x == W - 4 ? r0 : 0.f;
+    return e;
+}
+
+// total of v over the wavefront, delivered in lane 63: quad / half-row / row butterflies, then the two row broadcasts (six DPP adds)
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+#define SQD_DPP_ADD(ctrl, rmask, bc) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, bc))
+    SQD_DPP_ADD(0xB1, 0xf, true);      // quad_perm [1,0,3,2]
+    SQD_DPP_ADD(0x4E, 0xf, true);      // quad_perm [2,3,0,1]
+    SQD_DPP_ADD(0x141, 0xf, true);     // row_half_mirror
+    SQD_DPP_ADD(0x140, 0xf, true);     // row_mirror
+    SQD_DPP_ADD(0x142, 0xa, false);    // row_bcast:15 into rows 1, 3
+    SQD_DPP_ADD(0x143, 0xc, false);    // row_bcast:31 into rows 2, 3
+#undef SQD_DPP_ADD
+    return v;
+}
+
+struct BwdPix {
+    float wm1, hm1, gscale;
+    int W, H;
+    unsigned HW;
+};
+
+// per pixel and source: d loss / d warped (window terms G + the L1 term where this source won the pixel itself) pulled back
+// through grid_sample, Project3D and BackprojectDepth (reference layers.py:186-258; ATen grid_sampler_2d_backward).
+// Returns the contribution to g_depth; accumulates the 12 entries of g_P.
+__device__ __forceinline__ float pixel_adjoint(const BwdPix &k, const float *__restrict__ src, const float *__restrict__ smp, const float *P,
+                                               const float G[9], const float t[3], const float cr[3], const float X[3], bool l1on, unsigned qo,
+                                               float gP[12]) {
+    const int W = k.W, H = k.H;
+    const float wm1 = k.wm1, hm1 = k.hm1;
+    const float2 gs = *reinterpret_cast<const float2 *>(smp + (size_t)qo * 2);
+    // recompute taps from the stored grid exactly as the forward did
+    float ix = ((gs.x + 1.0f) * 0.5f) * wm1, iy = ((gs.y + 1.0f) * 0.5f) * hm1;
+    const bool mx = ix > 0.f && ix < wm1, my = iy > 0.f && iy < hm1;   // clip_coordinates_set_grad
+    ix = fminf(wm1, fmaxf(ix, 0.f));
+    iy = fminf(hm1, fmaxf(iy, 0.f));
+    const float fx0 = floorf(ix), fy0 = floorf(iy);
+    const int x0 = (int)fx0, y0 = (int)fy0;
+    const bool xin = x0 + 1 < W, yin = y0 + 1 < H;
+    const float ax = ix - fx0, ay = iy - fy0, bxw = (fx0 + 1.f) - ix, byw = (fy0 + 1.f) - iy;
+    // the two taps of a row are 8 contiguous bytes: one (4-byte aligned) load; at the last column the pair starts one pixel
+    // earlier and the tap is its second element
+    const unsigned o00 = (unsigned)(y0 * W + x0 - (xin ? 0 : 1)), o10 = o00 + (yin ? (unsigned)W : 0u);
+    float gix = 0.f, giy = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const v2f pn = ldg2(src, (o00 + c * k.HW) * 4u), ps = ldg2(src, (o10 + c * k.HW) * 4u);
+        const float vnw = xin ? pn.x : pn.y, vne = xin ? pn.y : 0.f, vsw = yin ? (xin ? ps.x : ps.y) : 0.f, vse = (xin && yin) ? ps.y : 0.f;
+        float wv = vnw * (bxw * byw);
+        wv = fmaf(vne, ax * byw, wv);
+        wv = fmaf(vsw, bxw * ay, wv);
+        wv = fmaf(vse, ax * ay, wv);
+        // d to_optimise / d w_c  (window terms + L1 term), trainer.py:441-453
+        float gw = G[c] + 2.f * wv * G[3 + c] + t[c] * G[6 + c];
+        if (l1on) {
+            const float df = wv - t[c];
+            gw += (0.15f / 3.f) * (df > 0.f ? 1.f : df < 0.f ? -1.f : 0.f);
+        }
+        gix += gw * ((vne - vnw) * byw + (vse - vsw) * ay);
+        giy += gw * ((vsw - vnw) * bxw + (vse - vne) * ax);
+    }
+    // unnormalise + clamp adjoints, then (x - 0.5)*2, / (W-1)
+    const float ggx = mx ? gix * (wm1 * 0.5f) : 0.f, ggy = my ? giy * (hm1 * 0.5f) : 0.f;
+    const float gu = (ggx * 2.f) / wm1, gv = (ggy * 2.f) / hm1;
+    const float camz = fmaf(P[11], 1.0f, fmaf(P[10], X[2], fmaf(P[9], X[1], P[8] * X[0])));
+    const float z = camz + 1e-7f;
+    const float camx = fmaf(P[3], 1.0f, fmaf(P[2], X[2], fmaf(P[1], X[1], P[0] * X[0])));
+    const float camy = fmaf(P[7], 1.0f, fmaf(P[6], X[2], fmaf(P[5], X[1], P[4] * X[0])));
+    const float iz = 1.f / z;
+    float gpx = gu * iz, gpy = gv * iz;
+    float gpz = -(gu * camx + gv * camy) * iz * iz;
+    gpx *= k.gscale; gpy *= k.gscale; gpz *= k.gscale;
+    float gX[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) gX[i] = P[i] * gpx + P[4 + i] * gpy + P[8 + i] * gpz;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        gP[i] = fmaf(gpx, X[i], gP[i]);
+        gP[4 + i] = fmaf(gpy, X[i], gP[4 + i]);
+        gP[8 + i] = fmaf(gpz, X[i], gP[8 + i]);
+    }
+    gP[3] += gpx; gP[7] += gpy; gP[11] += gpz;
+    return cr[0] * gX[0] + cr[1] * gX[1] + cr[2] * gX[2];
+}
+
+__device__ __forceinline__ void bwd_rows(int KIND, const sqd_photo_bwd_args &a, const PairPass &pp, const BwdPix &k, __amdgpu_buffer_rsrc_t coef_r,
+                                         __amdgpu_buffer_rsrc_t idx_r, int lane0, int b, int wave, int y0, int own_rows, int x, bool in_col, bool own_col,
+                                         int lane, float *gdep, float gP0[12], float gP1[12]) {
+    const int W = k.W, H = k.H, NS = pp.S;
+    const unsigned HW = k.HW;
+    const bool two = pp.s1 != pp.s0;
+    const unsigned xoff = in_col ? (unsigned)x * 4u : 0x80000000u, xoffb = in_col ? (unsigned)x : 0x80000000u;
+    const bool esrc = KIND == LEFT ? lane <= 2 : lane >= 61, ekill = KIND == LEFT ? lane == 0 : lane == 63;
+    float ik[9], P0[12], P1[12];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ik[i * 3 + j] = a.inv_K[(size_t)b * 16 + i * 4 + j];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        P0[j] = a.P[((size_t)b * NS + pp.s0) * 12 + j];
+        P1[j] = a.P[((size_t)b * NS + pp.s1) * 12 + j];
+    }
+    const float *__restrict__ tgt = a.target + (size_t)b * 3 * HW;
+    const float *__restrict__ dep = a.depth + (size_t)b * HW;
+    const float *__restrict__ src0 = a.sources[pp.s0] + (size_t)b * 3 * HW, *__restrict__ src1 = a.sources[pp.s1] + (size_t)b * 3 * HW;
+    const float *__restrict__ smp0 = a.sample[pp.s0] + (size_t)b * HW * 2, *__restrict__ smp1 = a.sample[pp.s1] + (size_t)b * HW * 2;
+    const int id0 = NS + pp.s0, id1 = two ? NS + pp.s1 : -1;                  // argmin codes of the pair's reprojection candidates
+    for (int j = wave; j < own_rows; j += 4) {
+        const int q = y0 + j;
+        float G0[9], G1[9];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) G0[c] = G1[c] = 0.f;
+        int idc = 0;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int r = q - 3 + i;
+            // branch-free: a row outside the image reads zeros (offset beyond the descriptor) with multiplicity 0, so that the
+            // loads of all rows are one straight-line batch
+            // (pure arithmetic on purpose: a select on the wave-uniform row test becomes a branch, and a branch per row keeps the
+            //  scheduler from batching the loads of the seven rows)
+            const int ok = (int)((unsigned)r < (unsigned)H);
+            const int rc = min(max(r, 0), H - 1);
+            const float m = (float)(refl_mult(rc, q, H) * ok);
+            const unsigned row = (unsigned)(rc * W);
+            const unsigned oob = (unsigned)(ok - 1) & 0x80000000u;
+            const unsigned vo = xoff | oob, vob = xoffb | oob;
+            const int id = (int)__builtin_amdgcn_raw_buffer_load_b8(idx_r, vob, row, 0) & 0xff;       // 0 beyond the image
+            if (i == 3) idc = id;
+            const float w0 = id == id0 ? m : 0.f, w1 = id == id1 ? m : 0.f;
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const float v = bld(coef_r, vo, (row + (unsigned)c * HW) * 4u);
+                G0[c] = fmaf(w0, v, G0[c]);
+                G1[c] = fmaf(w1, v, G1[c]);
+            }
+        }
+        if (lane0 >= 0) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                const float e0 = virt_border_adj(G0[c], x, W, lane0), e1 = virt_border_adj(G1[c], x, W, lane0);
+                G0[c] = box7(G0[c]) + e0;
+                G1[c] = box7(G1[c]) + e1;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 9; c += 3) {
+                box7x3_adj(KIND, G0[c], G0[c + 1], G0[c + 2], esrc, ekill);
+                box7x3_adj(KIND, G1[c], G1[c + 1], G1[c + 2], esrc, ekill);
+            }
+        }
+        if (!own_col) continue;
+        const unsigned qo = (unsigned)(q * W + x);
+        float t[3], cr[3], X[3];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[c] = ldg(tgt, (qo + c * HW) * 4u);
+        const float d = ldg(dep, qo * 4u);
+        const float fx = (float)x, fy = (float)q;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            float acc = ik[i * 3 + 0] * fx;                 // layers.py:211  (FMA chain k = 0..2)
+            acc = fmaf(ik[i * 3 + 1], fy, acc);
+            acc = fmaf(ik[i * 3 + 2], 1.0f, acc);
+            cr[i] = acc;
+            X[i] = d * acc;
+        }
+        float g = pixel_adjoint(k, src0, smp0, P0, G0, t, cr, X, idc == id0, qo, gP0);
+        if (two) g += pixel_adjoint(k, src1, smp1, P1, G1, t, cr, X, idc == id1, qo, gP1);
+        gdep[qo] = g;
+    }
+}
+
+// Two workgroups (8 waves) per CU: the scheduler is left free to batch the 70 coefficient loads of a row and both sources' tap
+// gathers (140 VGPRs).  Measured at config B (profiles/r03h_photo_bwd_variants.md): 4 waves per SIMD with the loads fenced into
+// 128 registers 95 us, 3 waves 98 us, 2 waves 74 us; tile heights 6..16 within 10 % of each other, 16 best.
+__global__ __launch_bounds__(256, 2) void photo_bwd_tile_kernel(sqd_photo_bwd_args a, PairPass pp, int pass, int TR, int nsx, int nsy, int ntiles, int nblk8) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = (blockIdx.x & 7) * nblk8 + (blockIdx.x >> 3);          // neighbouring tiles (shared rows / columns) on one XCD
+    if (tile >= ntiles) return;
+    const int H = a.H, W = a.W;
+    const unsigned HW = (unsigned)(H * W);
+    const int tx = tile % nsx, t2 = tile / nsx, ty = t2 % nsy, b = t2 / nsy;
+    const StripX sx = strip_x(tx, nsx, W);
+    const int y0 = ty * TR;
+    const int own_rows = min(TR, H - y0);
+    const int x = sx.x0 + lane;
+    const bool in_col = x >= 0 && x < W;
+    const bool own_col = x >= sx.own0 && x < sx.own1 && in_col;
+    const __amdgpu_buffer_rsrc_t coef_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.coef + (size_t)b * 9 * HW), 0, 9u * HW * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t idx_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.idx + (size_t)b * HW), 0, HW, 0x00020000);
+    BwdPix k;
+    k.wm1 = (float)(W - 1); k.hm1 = (float)(H - 1); k.gscale = a.gscale; k.W = W; k.H = H; k.HW = HW;
+    float *gdep = a.g_depth + (size_t)b * a.g_depth_img_stride + (size_t)pass * HW;
+    float gP0[12], gP1[12];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) gP0[j] = gP1[j] = 0.f;
+    const int lane0 = W <= 64 ? -sx.x0 : -1;                                  // >= 0: both borders inside the wavefront (generic border path)
+    bwd_rows(lane0 >= 0 ? (int)INTERIOR : sx.kind, a, pp, k, coef_r, idx_r, lane0, b, wave, y0, own_rows, x, in_col, own_col, lane, gdep, gP0, gP1);
+    // per-wavefront partials of g_P: [B][S][tiles per image * 4][12]
+    const int tpi = nsx * nsy * 4, slot = (ty * nsx + tx) * 4 + wave;
+#pragma unroll
+    for (int j = 0; j < 12; ++j) {
+        const float v0 = wave_sum_to_lane63(gP0[j]), v1 = wave_sum_to_lane63(gP1[j]);
+        if (lane == 63) {
+            a.g_P_part[(((size_t)b * pp.S + pp.s0) * tpi + slot) * 12 + j] = v0;
+            if (pp.s1 != pp.s0) a.g_P_part[(((size_t)b * pp.S + pp.s1) * tpi + slot) * 12 + j] = v1;
+        }
+    }
+}
+
 int pick_tr(int rows) {
     int tr = rows <= 0 ? TR_MAX : rows;
     tr = tr > TR_MAX ? TR_MAX : tr;
@@ -576,6 +840,18 @@ void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hi
             hipLaunchKernelGGL((photo_tile_kernel<1>), grid, block, (TR + 6) * 3 * 64 * 8, stream, a, pp, noise, TR, nsx, nsy, ntiles, nblk8);
         else
             hipLaunchKernelGGL((photo_tile_kernel<2>), grid, block, 0, stream, a, pp, noise, TR, nsx, nsy, ntiles, nblk8);
+    }
+}
+
+// backward: one launch per pair of source frames; plane `pass` of g_depth receives the pair's contribution
+void launch_photo_bwd_tile(const sqd_photo_bwd_args &a, hipStream_t stream) {
+    const int TR = pick_tr(a.rows_per_task);
+    const int nsx = strips_x(a.W), nsy = (a.H + TR - 1) / TR;
+    const int ntiles = a.B * nsx * nsy;
+    const int nblk8 = (ntiles + 7) / 8;
+    for (int k = 0; 2 * k < a.S; ++k) {
+        const PairPass pp = {2 * k, 2 * k + 1 < a.S ? 2 * k + 1 : 2 * k, a.S, k == 0, 2 * k + 2 >= a.S};
+        hipLaunchKernelGGL(photo_bwd_tile_kernel, dim3(nblk8 * 8), dim3(256), 0, stream, a, pp, k, TR, nsx, nsy, ntiles, nblk8);
     }
 }
 }  // namespace sqd

@@ -159,7 +159,7 @@ def photo_coef(target, warped, idx, rows_per_task=0):
 
 
 def photo_bwd(depth, inv_K, P, target, sources, samples, warped, idx, gscale, rows_per_task=0, extra_planes=0):
-    """-> g_depth [B,S+extra_planes,H,W] (plane s = source s; extra planes left unwritten), g_P [B,S,3,4]."""
+    """-> g_depth [B,ceil(S/2)+extra_planes,H,W] (plane k = the pair of sources 2k, 2k+1; extra planes left unwritten), g_P [B,S,3,4]."""
     _req(depth, inv_K, P, target, idx, *sources, *samples, *warped)
     B, _, H, W = target.shape
     S = len(sources)
@@ -167,7 +167,7 @@ def photo_bwd(depth, inv_K, P, target, sources, samples, warped, idx, gscale, ro
     L = _l.lib()
     coef = photo_coef(target, warped, idx, rows_per_task)
     nt = L.sqd_photo_bwd_ntasks(B, S, H, W, rows_per_task)
-    g_depth = torch.empty(B, S + extra_planes, H, W, device=dev, dtype=torch.float32)
+    g_depth = torch.empty(B, (S + 1) // 2 + extra_planes, H, W, device=dev, dtype=torch.float32)
     part = torch.empty(nt, 12, device=dev, dtype=torch.float32)
     a = _l.PhotoBwdArgs()
     a.depth, a.inv_K, a.P, a.target, a.coef = (t.data_ptr() for t in (depth, inv_K, P, target, coef))
@@ -176,7 +176,7 @@ def photo_bwd(depth, inv_K, P, target, sources, samples, warped, idx, gscale, ro
         a.sample[s] = samples[s].data_ptr()
     a.idx, a.g_depth, a.g_P_part = idx.data_ptr(), g_depth.data_ptr(), part.data_ptr()
     a.gscale = float(gscale)
-    a.g_depth_img_stride = (S + extra_planes) * H * W
+    a.g_depth_img_stride = ((S + 1) // 2 + extra_planes) * H * W
     a.B, a.S, a.H, a.W, a.rows_per_task = B, S, H, W, rows_per_task
     a.stream = torch.cuda.current_stream().cuda_stream
     _l.check(L.sqd_photo_bwd(ctypes.byref(a)), "photo_bwd")
@@ -320,7 +320,7 @@ class PhotometricChain(torch.autograd.Function):
         # all adjoints are linear in the upstream gradient: run them with 1.0 and scale the three small results
         planes, g_P = photo_bwd(depth, inv_K, P, target, sources, samples, warped, idx, 1.0 / float(B * H * W), rows,
                                 extra_planes=1)
-        smooth_bwd(depth, target, part, sm_part, meta["smooth_weight"], planes, S)
+        smooth_bwd(depth, target, part, sm_part, meta["smooth_weight"], planes, (S + 1) // 2)
         g_aa = g_tr = g_mid = None
         if n_pose:                                # (the stereo source's extrinsics are data: its rows of g_P are dropped)
             g_aa, g_tr, g_mid = pose_mats_bwd(axisangle, translation, meta["invert"], K, mid,
