@@ -153,27 +153,28 @@ struct Raw {
     v3f t;
     v2f w[3];
 };
-// the window statistics of one lane's column over some rows (21 numbers): sum t, sum w, sum (w^2 + t^2), sum w t
+// the window statistics of one lane's column over some rows: sum t, sum t^2, sum w, sum w^2, sum w t (24 numbers; sum t^2 joins
+// sum w^2 before the horizontal pass — sigma_x + sigma_y only needs their sum — so 21 quantities cross the lanes)
 struct Sums {
-    v3f St;
+    v3f St, Stt;
     v2f Sw[3], Sq[3], Swt[3];
 };
-__device__ __forceinline__ void products(const Raw &R, Sums &P) {
-    P.St = R.t;
+__device__ __forceinline__ void clear(Sums &A) {
+    A.St = v3f{0.f, 0.f, 0.f};
+    A.Stt = v3f{0.f, 0.f, 0.f};
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        P.Sw[c] = R.w[c];
-        P.Sq[c] = pfma(R.w[c], R.w[c], splat(R.t[c] * R.t[c]));       // sigma_x + sigma_y only needs sum(w^2 + t^2)
-        P.Swt[c] = R.w[c] * splat(R.t[c]);
-    }
+    for (int c = 0; c < 3; ++c) A.Sw[c] = A.Sq[c] = A.Swt[c] = splat(0.f);
 }
-__device__ __forceinline__ void accumulate(Sums &A, const Sums &P) {
-    A.St += P.St;
+// A += the products of one row: five instructions per colour (add, fma, packed add, two packed fma) — the products are never
+// formed on their own (a packed multiply costs what two scalar ones do on gfx950; a packed fma 1.45x one scalar fma)
+__device__ __forceinline__ void accumulate_row(Sums &A, const Raw &R) {
+    A.St += R.t;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        A.Sw[c] += P.Sw[c];
-        A.Sq[c] += P.Sq[c];
-        A.Swt[c] += P.Swt[c];
+        A.Stt[c] = fmaf(R.t[c], R.t[c], A.Stt[c]);
+        A.Sw[c] += R.w[c];
+        A.Sq[c] = pfma(R.w[c], R.w[c], A.Sq[c]);
+        A.Swt[c] = pfma(R.w[c], splat(R.t[c]), A.Swt[c]);
     }
 }
 
@@ -244,7 +245,7 @@ __device__ __forceinline__ void ssim_l1(const Sums &S, const Raw &ctr, SsimOut &
         const v2f Bd = B1 * B2;
         const v2f Sv = div_core2(A1 * A2, Bd, rcp_refined2(Bd));       // SSIM_n / SSIM_d, the reference's division (layers.py:46)
         const v2f r = (splat(1.f) - Sv) * splat(0.5f);
-        ssim_sum += v2f{fminf(fmaxf(r.x, 0.f), 1.f), fminf(fmaxf(r.y, 0.f), 1.f)};
+        ssim_sum += v2f{__builtin_amdgcn_fmed3f(r.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(r.y, 0.f, 1.f)};      // torch.clamp(., 0, 1)
         const v2f df = splat(ctr.t[c]) - ctr.w[c];
         l1 += v2f{fabsf(df.x), fabsf(df.y)};
         if (GRAD) {
@@ -337,16 +338,13 @@ __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const PairPas
     for (int p = wave; 2 * p < own_rows; p += 4) {
         const int j = 2 * p;                         // tile rows j .. j+7 feed the outputs y0+j (centre j+3) and y0+j+1 (centre j+4)
         Sums core;                                   // rows j+1 .. j+6: shared by both outputs
+        clear(core);
         {
             Raw R;
-            load_row<MODE>(k, j + 1, R);
-            products(R, core);
 #pragma unroll
-            for (int i = 2; i < 7; ++i) {
+            for (int i = 1; i < 7; ++i) {
                 load_row<MODE>(k, j + i, R);
-                Sums P;
-                products(R, P);
-                accumulate(core, P);
+                accumulate_row(core, R);
             }
         }
 #pragma nounroll
@@ -354,9 +352,10 @@ __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const PairPas
             Raw R, ctr;
             load_row<MODE>(k, j + 7 * o, R);
             load_row<MODE>(k, j + 3 + o, ctr);
-            Sums S;
-            products(R, S);
-            accumulate(S, core);
+            Sums S = core;
+            accumulate_row(S, R);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) S.Sq[c] += splat(S.Stt[c]);
             finish_row<MODE, KIND>(a, pp, noise, k, S, ctr, edge, b, k.y0 + j + o, own_col && j + o < own_rows, loss_acc);
         }
     }
@@ -601,19 +600,6 @@ __device__ __forceinline__ float virt_border_adj(float v, int x, int W, int lane
     float e = x == 1 ? (l0 + l1) + l2 : x == 2 ? l0 + l1 : x == 3 ? l0 : 0.f;
     e += x == W - 2 ? (r0 + r1) + r2 : x == W - 3 ? r0 + r1 : x == W - 4 ? r0 : 0.f;
     return e;
-}
-
-// total of v over the wavefront, delivered in lane 63: quad / half-row / row butterflies, then the two row broadcasts (six DPP adds)
-__device__ __forceinline__ float wave_sum_to_lane63(float v) {
-#define SQD_DPP_ADD(ctrl, rmask, bc) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, bc))
-    SQD_DPP_ADD(0xB1, 0xf, true);      // quad_perm [1,0,3,2]
-    SQD_DPP_ADD(0x4E, 0xf, true);      // quad_perm [2,3,0,1]
-    SQD_DPP_ADD(0x141, 0xf, true);     // row_half_mirror
-    SQD_DPP_ADD(0x140, 0xf, true);     // row_mirror
-    SQD_DPP_ADD(0x142, 0xa, false);    // row_bcast:15 into rows 1, 3
-    SQD_DPP_ADD(0x143, 0xc, false);    // row_bcast:31 into rows 2, 3
-#undef SQD_DPP_ADD
-    return v;
 }
 
 struct BwdPix {

@@ -74,6 +74,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// total of v over the wavefront, delivered in lane 63: quad / half-row / row butterflies, then the two row broadcasts (six DPP adds)
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+#define SQD_DPP_ADD(ctrl, rmask, bc) v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), ctrl, rmask, 0xf, bc))
+    SQD_DPP_ADD(0xB1, 0xf, true);      // quad_perm [1,0,3,2]
+    SQD_DPP_ADD(0x4E, 0xf, true);      // quad_perm [2,3,0,1]
+    SQD_DPP_ADD(0x141, 0xf, true);     // row_half_mirror
+    SQD_DPP_ADD(0x140, 0xf, true);     // row_mirror
+    SQD_DPP_ADD(0x142, 0xa, false);    // row_bcast:15 into rows 1, 3
+    SQD_DPP_ADD(0x143, 0xc, false);    // row_bcast:31 into rows 2, 3
+#undef SQD_DPP_ADD
+    return v;
+}
+
 // reflection index of ReflectionPad2d (pad < n), clamped for lanes far outside the image
 __device__ __forceinline__ int reflect_idx(int p, int n) {
     p = p < 0 ? -p : p;

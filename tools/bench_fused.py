@@ -17,7 +17,13 @@ ap.add_argument("--B", type=int, default=12)
 ap.add_argument("--H", type=int, default=192)
 ap.add_argument("--W", type=int, default=640)
 ap.add_argument("--which", default="fwd,ident,coef,bwd")
+ap.add_argument("--cold", action="store_true", help="evict L2 and the Infinity Cache before every timed call (a 1 GB fill): what the kernels see "
+                                                     "inside the training step, where their inputs were produced milliseconds earlier")
+ap.add_argument("--lib", default=None, help="another build of libsqd.so (tools/build_alt_lib.sh) for same-box A/B runs")
 args = ap.parse_args()
+if args.lib:
+    _l.SO_PATH = os.path.abspath(args.lib)
+    _l.needs_build = lambda: False
 B, H, W = args.B, args.H, args.W
 dev = torch.device("cuda")
 torch.manual_seed(0)
@@ -32,10 +38,27 @@ mid, T, P = ops.pose_mats_fwd(aa, tr, [1, 0], K, part, H * W)
 noise = torch.randn(B, 2, H, W, device=dev)
 
 
+_evict = None
+
+
 def timeit(fn, iters):
     for _ in range(10):
         fn()
     torch.cuda.synchronize()
+    if args.cold:
+        global _evict
+        if _evict is None:
+            _evict = torch.empty(256 << 20, device=dev, dtype=torch.float32)
+        tot, n = 0.0, min(iters, 20)
+        for i in range(n):
+            _evict.fill_(float(i))
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            torch.cuda.synchronize()
+            tot += e0.elapsed_time(e1)
+        return tot / n * 1e3
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(iters):
