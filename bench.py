@@ -99,6 +99,82 @@ def roofline_fused_fwd(trainer, inputs, iters=200):
             "algorithmic_bytes_per_launch": FUSED_FWD_BYTES_PER_PX * px, "pixels_per_launch": px}
 
 
+def _time_calls(fn, iters=100, warm=10):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e-3
+
+
+def roofline_depthwise(trainer):
+    """Config D (EfficientNet-b5): the dominant kernel family is the depthwise k x k convolution (HBM-bound: one read and one
+    write of the activation, 8 B per element) — timed on the layer of the trunk that moves the most bytes, through the C ABI
+    on the launch stream."""
+    from sqd import lib as _l, nnkernels
+    o = trainer.opt
+    dev = trainer.device
+    best = None
+    H, W = o.height // 2, o.width // 2                       # after the stride-2 stem
+    for stage in trainer.models["encoder"].encoder.original_model.blocks:
+        for blk in stage:
+            conv = blk.conv_dw
+            k, st, C = conv.kernel_size[0], conv.stride[0], conv.in_channels
+            (Ho, pt), (Wo, pl) = nnkernels.tf_same_pad(H, k, st), nnkernels.tf_same_pad(W, k, st)
+            elems = o.batch_size * C * (H * W + Ho * Wo)
+            if best is None or elems > best[0]:
+                best = (elems, C, k, st, H, W, Ho, Wo, pt, pl)
+            H, W = Ho, Wo
+    elems, C, k, st, H, W, Ho, Wo, pt, pl = best
+    N = o.batch_size
+    x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    wt = torch.randn(k * k, C, device=dev)
+    y = torch.empty((N, C, Ho, Wo), device=dev).contiguous(memory_format=torch.channels_last)
+    L, st_ = _l.lib(), torch.cuda.current_stream().cuda_stream
+    t = _time_calls(lambda: _l.check(L.sqd_dw_conv_fwd(x.data_ptr(), wt.data_ptr(), y.data_ptr(), N, H, W, C, k, st, pt, pl, Ho, Wo, st_), "dw_conv_fwd"))
+    nbytes = 4 * elems
+    return {"bound": "hbm", "kernel": "dw_conv_kernel (depthwise %dx%d / stride %d forward, [%d,%d,%d,%d] -> %dx%d: the trunk's largest)" % (k, k, st, N, C, H, W, Ho, Wo),
+            "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
+            "traffic": None, "traffic_source": "no PMC record for this kernel", "us_per_launch": round(t * 1e6, 2),
+            "algorithmic_bytes_per_launch": nbytes, "note": "8 B per element: one read of the input, one write of the output; filters are %d floats" % (k * k * C)}
+
+
+def roofline_mlp_gemm(trainer):
+    """Config E (ConvNeXt-L): the dominant kernels are the 1x1 convolutions of the block MLPs (Linear C -> 4C -> C) — timed on
+    stage 2's expansion (27 of the 36 blocks) under the plan the tuner registered for it, priced against the fp32 MFMA peak
+    (the arithmetic is fp32-equivalent whichever plan runs)."""
+    from sqd import lib as _l, nnkernels
+    o = trainer.opt
+    dev = trainer.device
+    N, H, W, C, K = o.batch_size, o.height // 16, o.width // 16, 768, 3072
+    geom = (N, H, W, C, K, 1, 1, 1, 0, H, W)
+    x = torch.randn(N, C, H, W, device=dev).contiguous(memory_format=torch.channels_last)
+    w = torch.randn(K, C, 1, 1, device=dev).contiguous(memory_format=torch.channels_last)
+    b = torch.zeros(K, device=dev)
+    y = torch.empty((N, K, H, W), device=dev).contiguous(memory_format=torch.channels_last)
+    ws = nnkernels._conv_ws(0, geom, dev)
+    L, st_ = _l.lib(), torch.cuda.current_stream().cuda_stream
+    t = _time_calls(lambda: _l.check(L.sqd_conv_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None if ws is None else ws.data_ptr(), None,
+                                                    N, H, W, C, K, 1, 1, 1, 0, H, W, 0, st_), "conv_fwd"))
+    flops = 2.0 * N * H * W * C * K
+    plan = nnkernels.CHOSEN_PLANS.get(("fwd",) + geom)
+    split3 = bool(plan and plan[3] & 1024)
+    # the bound of the arithmetic the registered plan runs: fp32 MFMA 157.3 TFLOP/s; a three-term bf16 plan issues 6 bf16 products per
+    # fp32 product on the 2500 TFLOP/s dense bf16 pipe (MI355X_MICROARCH.md) = 416.7 TFLOP/s of fp32-equivalent work
+    peak = 2500.0 / 6.0 if split3 else 157.3
+    return {"bound": "mfma", "kernel": "conv_gemm_kernel (1x1 convolution %d -> %d on [%d,%d,%d]: stage-2 MLP expansion; plan (bm, bn, split, bk flags) %s = %s)"
+                                       % (C, K, N, H, W, plan, "three-term bf16 operands" if split3 else "fp32 MFMA"),
+            "achieved": round(flops / t / 1e12, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(flops / t / 1e12 / peak, 4),
+            "frac_of_fp32_mfma_peak": round(flops / t / 1e12 / 157.3, 4),
+            "traffic": None, "us_per_launch": round(t * 1e6, 2), "algorithmic_flops_per_launch": flops,
+            "note": "achieved = fp32-equivalent FLOP (2 M C K) per second; peak = the matrix-pipe bound of the plan's arithmetic"}
+
+
 def host_cpu():
     """(model name, logical cpus, physical cores) of this box."""
     import subprocess
@@ -258,7 +334,14 @@ def main():
 
     roof = None
     if rank == 0 and not args.no_roofline:
-        roof = roofline_fused_fwd(trainer, inputs)
+        # the dominant kernel of the configuration that ran: the fused warp+SSIM forward (the kernel BASELINE.json's target names)
+        # for the ResNet configurations, the depthwise convolution for EfficientNet-b5, the block-MLP GEMM for ConvNeXt-L
+        if opts.backbone in ("eff_b5", "tf_efficientnet_b5_ap"):
+            roof = roofline_depthwise(trainer)
+        elif opts.backbone.startswith("convnext"):
+            roof = roofline_mlp_gemm(trainer)
+        else:
+            roof = roofline_fused_fwd(trainer, inputs)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
