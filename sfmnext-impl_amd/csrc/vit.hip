@@ -1,6 +1,6 @@
 // vit.hip — the two token-wise blocks of the post-norm TransformerEncoderLayer the depth head runs on its 120 patch tokens
 // (reference networks/depth_decoder_QTR.py:31-32,47: nn.TransformerEncoderLayer(E, 4 heads, dim_feedforward 1024 | 512, ReLU,
-// dropout 0.1), 4 layers), as fused kernels.  Tokens are rows of a [rows = S*B, E] matrix, E in {16, 32}.
+// dropout 0.1), 4 layers), as fused kernels.  Tokens are rows of a [rows = S*B, E] matrix, E in {16, 32, 64}.
 //
 //   add + dropout + LayerNorm :  out = LN(x + mask * scale * y)             (norm1 / norm2 with dropout1 / dropout2)
 //   feed-forward              :  y = W2 . (mask * scale * relu(W1 . x + b1)) + b2   (linear1, ReLU, dropout, linear2)
@@ -29,12 +29,13 @@ __device__ __forceinline__ int acc_row(int r, int h) { return (r & 3) + 8 * (r >
 // out = LayerNorm(x + drop(sum_p y[p] + ybias)) over the last dimension E; one half-wave (32 lanes) per row, lane = feature.
 // saves xhat [rows,E] and rstd [rows] for the backward.
 // ---------------------------------------------------------------------------------------------------
+template <int LW>                                      // lanes per row: 32 (E <= 32: one half-wave per row) or 64 (E <= 64)
 __global__ __launch_bounds__(256) void addln_fwd_kernel(const float *__restrict__ x, const float *__restrict__ y, int nparts,
                                                         const float *__restrict__ ybias, const unsigned char *__restrict__ mask,
                                                         const float *__restrict__ gamma, const float *__restrict__ beta,
                                                         float *__restrict__ out, float *__restrict__ xhat, float *__restrict__ rstd_out,
                                                         int rows, int E, float scale, float eps) {
-    const int lane = threadIdx.x & 31, row = blockIdx.x * 8 + (threadIdx.x >> 5);
+    const int lane = threadIdx.x & (LW - 1), row = blockIdx.x * (256 / LW) + threadIdx.x / LW;
     if (row >= rows) return;
     const bool on = lane < E;
     const size_t o = (size_t)row * E + lane, pstride = (size_t)rows * E;
@@ -47,12 +48,12 @@ __global__ __launch_bounds__(256) void addln_fwd_kernel(const float *__restrict_
     }
     float s = z;
 #pragma unroll
-    for (int k = 16; k > 0; k >>= 1) s += __shfl_xor(s, k, 32);
+    for (int k = LW / 2; k > 0; k >>= 1) s += __shfl_xor(s, k, LW);
     const float mean = s / (float)E;
     const float d = on ? z - mean : 0.f;
     float v = d * d;
 #pragma unroll
-    for (int k = 16; k > 0; k >>= 1) v += __shfl_xor(v, k, 32);
+    for (int k = LW / 2; k > 0; k >>= 1) v += __shfl_xor(v, k, LW);
     const float rstd = rsqrtf(v / (float)E + eps);
     if (on) {
         const float xh = d * rstd;
@@ -64,21 +65,23 @@ __global__ __launch_bounds__(256) void addln_fwd_kernel(const float *__restrict_
 
 // g = g_out + sum_p g_extra[p]  ->  g_x (= dz), g_y (= dz * mask * scale), per-block partials of dgamma / dbeta (part [nblk][2][E])
 constexpr int LN_ROWS = 16;     // rows per block of the backward
+template <int LW>
 __global__ __launch_bounds__(256) void addln_bwd_kernel(const float *__restrict__ g, const float *__restrict__ g_extra, int nextra,
                                                         const float *__restrict__ xhat, const float *__restrict__ rstd,
                                                         const unsigned char *__restrict__ mask, const float *__restrict__ gamma,
                                                         float *__restrict__ gx, float *__restrict__ gy, float *__restrict__ part,
                                                         int rows, int E, float scale) {
-    __shared__ float red[2][8][32];
-    const int lane = threadIdx.x & 31, sub = threadIdx.x >> 5;
+    constexpr int RP = 256 / LW;                        // rows in flight per block
+    __shared__ float red[2][RP][LW];
+    const int lane = threadIdx.x & (LW - 1), sub = threadIdx.x / LW;
     const bool on = lane < E;
     const float ga = on ? gamma[lane] : 0.f;
     const size_t pstride = (size_t)rows * E;
     float dg = 0.f, db = 0.f;
     const int r0 = blockIdx.x * LN_ROWS, r1 = min(rows, r0 + LN_ROWS);
 #pragma unroll
-    for (int k = 0; k < LN_ROWS / 8; ++k) {
-        const int row = r0 + sub + 8 * k;
+    for (int k = 0; k < LN_ROWS / RP; ++k) {
+        const int row = r0 + sub + RP * k;
         if (row >= r1) break;
         const size_t o = (size_t)row * E + lane;
         float gv = on ? g[o] : 0.f;
@@ -88,9 +91,9 @@ __global__ __launch_bounds__(256) void addln_bwd_kernel(const float *__restrict_
         const float dxh = gv * ga;
         float s1 = dxh, s2 = dxh * xh;
 #pragma unroll
-        for (int q = 16; q > 0; q >>= 1) {
-            s1 += __shfl_xor(s1, q, 32);
-            s2 += __shfl_xor(s2, q, 32);
+        for (int q = LW / 2; q > 0; q >>= 1) {
+            s1 += __shfl_xor(s1, q, LW);
+            s2 += __shfl_xor(s2, q, LW);
         }
         const float dz = rstd[row] * (dxh - s1 / (float)E - xh * (s2 / (float)E));
         if (on) {
@@ -103,11 +106,11 @@ __global__ __launch_bounds__(256) void addln_bwd_kernel(const float *__restrict_
     red[0][sub][lane] = dg;
     red[1][sub][lane] = db;
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int w = threadIdx.x >> 5;
+    if (threadIdx.x < 2 * LW) {
+        const int w = threadIdx.x / LW;
         float a = 0.f;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a += red[w][k][lane];
+        for (int k = 0; k < RP; ++k) a += red[w][k][lane];
         if (on) part[((size_t)blockIdx.x * 2 + w) * E + lane] = a;
     }
 }
@@ -167,11 +170,12 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumSegs S) {
 // chunk f0 = 128 gy + 32 w.  Orientation: hT[f, t] (rows = hidden units, columns = tokens).  Reduction index of the first
 // product is the feature e, split between the half-waves as e = 16*half + s (16 consecutive floats per lane: float4 loads).
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void load16(const float *__restrict__ p, int E, int kk, bool valid, float (&v)[16]) {
-    // 16 consecutive features starting at 16*kk (zeros beyond E)
+template <int N>
+__device__ __forceinline__ void loadn(const float *__restrict__ p, int E, int kk, bool valid, float (&v)[N]) {
+    // N consecutive features starting at N*kk (zeros beyond E)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int e = 16 * kk + 4 * q;
+    for (int q = 0; q < N / 4; ++q) {
+        const int e = N * kk + 4 * q;
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (valid && e < E) t = *reinterpret_cast<const float4 *>(p + e);
         v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w;
@@ -200,70 +204,84 @@ __device__ __forceinline__ float side_b1(const ChunkSide &sd, int r) {
 }
 __device__ __forceinline__ bool side_keep(const ChunkSide &sd, int r) { return (sd.m[r >> 2] >> (8 * (r & 3))) & 0xffu; }
 
+// EB = blocks of 32 features: E <= 32 EB (1: the 16 / 32-wide heads of the published configurations; 2: model_dim 64).  The first
+// product reduces over 32 EB features (16 EB per half-wave), the second one writes EB accumulator tiles of 32 output features.
+template <int EB>
 __global__ __launch_bounds__(256) void ffn_fwd_kernel(const float *__restrict__ x, const float *__restrict__ W1,
                                                       const float *__restrict__ b1, const float *__restrict__ W2,
                                                       const unsigned char *__restrict__ mask, float *__restrict__ ypart, int rows,
                                                       int E, int F, float scale) {
-    __shared__ float yred[4][32][33];
+    constexpr int KE = 16 * EB, EW = 32 * EB;
+    __shared__ float yred[4][EW][33];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int t0 = blockIdx.x * 32, tok = t0 + i;
     const bool tv = tok < rows;
     const int f0 = (blockIdx.y * 4 + wave) * 32;
-    f32x16 yT;                                           // yT[e', t]: rows = output features, columns = tokens
+    f32x16 yT[EB];                                       // yT[eb][e', t]: rows = output features 32 eb + e', columns = tokens
 #pragma unroll
-    for (int r = 0; r < 16; ++r) yT[r] = 0.f;
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yT[eb][r] = 0.f;
     if (f0 < F) {                                        // wave-uniform
-        float xt[16], w1[16];
-        float4 w2[4];
+        float xt[KE], w1[KE];
+        float4 w2[EB][4];
         ChunkSide sd;
-        load16(x + (size_t)tok * E, E, h, tv, xt);
-        load16(W1 + (size_t)(f0 + i) * E, E, h, f0 + i < F, w1);
+        loadn<KE>(x + (size_t)tok * E, E, h, tv, xt);
+        loadn<KE>(W1 + (size_t)(f0 + i) * E, E, h, f0 + i < F, w1);
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            const int f = f0 + 8 * g4 + 4 * h;           // k-slot (r = 4*g4 + j, half) of the second product is hidden unit f + j
-            w2[g4] = (i < E && f < F) ? *reinterpret_cast<const float4 *>(W2 + (size_t)i * F + f) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int f = f0 + 8 * g4 + 4 * h;       // k-slot (r = 4*g4 + j, half) of the second product is hidden unit f + j
+                w2[eb][g4] = (32 * eb + i < E && f < F) ? *reinterpret_cast<const float4 *>(W2 + (size_t)(32 * eb + i) * F + f) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         load_side(b1, mask, F, f0, h, (size_t)tok, tv, sd);
         f32x16 hT;
 #pragma unroll
         for (int r = 0; r < 16; ++r) hT[r] = 0.f;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) hT = mfma32(w1[s], xt[s], hT);
+        for (int s = 0; s < KE; ++s) hT = mfma32(w1[s], xt[s], hT);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const float v = hT[r] + side_b1(sd, r);
             hT[r] = (v > 0.f && side_keep(sd, r)) ? v * scale : 0.f;      // units >= F: W1 row, bias and W2 column are zero
         }
 #pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-            yT = mfma32(w2[g4].x, hT[4 * g4 + 0], yT);
-            yT = mfma32(w2[g4].y, hT[4 * g4 + 1], yT);
-            yT = mfma32(w2[g4].z, hT[4 * g4 + 2], yT);
-            yT = mfma32(w2[g4].w, hT[4 * g4 + 3], yT);
-        }
+        for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                yT[eb] = mfma32(w2[eb][g4].x, hT[4 * g4 + 0], yT[eb]);
+                yT[eb] = mfma32(w2[eb][g4].y, hT[4 * g4 + 1], yT[eb]);
+                yT[eb] = mfma32(w2[eb][g4].z, hT[4 * g4 + 2], yT[eb]);
+                yT[eb] = mfma32(w2[eb][g4].w, hT[4 * g4 + 3], yT[eb]);
+            }
     }
     // add the 4 waves (fixed order) -> this hidden group's partial of y
 #pragma unroll
-    for (int r = 0; r < 16; ++r) yred[wave][acc_row(r, h)][i] = yT[r];
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) yred[wave][32 * eb + acc_row(r, h)][i] = yT[eb][r];
     __syncthreads();
     float *yo = ypart + (size_t)blockIdx.y * rows * E;
-    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
-        const int t = idx >> 5, e = idx & 31;
+    for (int idx = threadIdx.x; idx < 32 * EW; idx += 256) {
+        const int t = idx / EW, e = idx % EW;
         if (t0 + t < rows && e < E) yo[(size_t)(t0 + t) * E + e] = ((yred[0][e][t] + yred[1][e][t]) + yred[2][e][t]) + yred[3][e][t];
     }
 }
 
 // backward: g_y [rows,E] -> gxpart [G][rows,E] (partials over the hidden groups); per-token-tile partials pW1 [T][F,E],
 // pW2 [T][F,E] (dW2 transposed), pb1 [T][F], pb2 [T][E]
+template <int EB>
 __global__ __launch_bounds__(256) void ffn_bwd_kernel(const float *__restrict__ x, const float *__restrict__ gy,
                                                       const float *__restrict__ W1, const float *__restrict__ b1,
                                                       const float *__restrict__ W2, const unsigned char *__restrict__ mask,
                                                       float *__restrict__ gxpart, float *__restrict__ pW1, float *__restrict__ pb1,
                                                       float *__restrict__ pW2, float *__restrict__ pb2, int rows, int E, int F,
                                                       float scale) {
-    __shared__ float xs[32][33], gs[32][33];             // the token tile: x and g_y, [token][feature], zero padded
-    __shared__ float xred[4][32][33];                    // g_x^T partials of the 4 waves
+    constexpr int KE = 16 * EB, EW = 32 * EB;
+    __shared__ float xs[32][EW + 1], gs[32][EW + 1];     // the token tile: x and g_y, [token][feature], zero padded
+    __shared__ float xred[4][EW][33];                    // g_x^T partials of the 4 waves
     __shared__ float tile[4][2][32][36];                 // per wave: [0] hT (after relu*drop), [1] dhT; [f][token]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
@@ -272,32 +290,36 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(const float *__restrict__ 
     const int f0 = (blockIdx.y * 4 + wave) * 32;
     const bool active = f0 < F;                          // wave-uniform
     // global loads of the chunk first (independent of the staging below)
-    float w1row[16], w2col[16], w1col[16];
+    float w1row[KE], w2col[KE], w1col[EB][16];
     ChunkSide sd;
     if (active) {
-        load16(W1 + (size_t)(f0 + i) * E, E, h, f0 + i < F, w1row);
+        loadn<KE>(W1 + (size_t)(f0 + i) * E, E, h, f0 + i < F, w1row);
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int e = 16 * h + s;
+        for (int s = 0; s < KE; ++s) {
+            const int e = KE * h + s;
             w2col[s] = (f0 + i < F && e < E) ? W2[(size_t)e * F + f0 + i] : 0.f;            // A of dhT: row f = lane, k = e'
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = f0 + acc_row(r, h);
-            w1col[r] = (f < F && i < E) ? W1[(size_t)f * E + i] : 0.f;                     // A of g_x^T: row e = lane, k = f
-        }
+        for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = f0 + acc_row(r, h);
+                w1col[eb][r] = (f < F && 32 * eb + i < E) ? W1[(size_t)f * E + 32 * eb + i] : 0.f;     // A of g_x^T tile eb: row e = 32 eb + lane, k = f
+            }
         load_side(b1, mask, F, f0, h, (size_t)tok, tv, sd);
     }
-    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
-        const int t = idx >> 5, e = idx & 31;
+    for (int idx = threadIdx.x; idx < 32 * EW; idx += 256) {
+        const int t = idx / EW, e = idx % EW;
         const bool ok = t0 + t < rows && e < E;
         xs[t][e] = ok ? x[(size_t)(t0 + t) * E + e] : 0.f;
         gs[t][e] = ok ? gy[(size_t)(t0 + t) * E + e] : 0.f;
     }
     __syncthreads();
-    f32x16 gxT;                                          // g_x^T[e, t]
+    f32x16 gxT[EB];                                      // g_x^T[32 eb + e, t]
 #pragma unroll
-    for (int r = 0; r < 16; ++r) gxT[r] = 0.f;
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) gxT[eb][r] = 0.f;
     if (active) {
         float(*hs)[36] = tile[wave][0], (*ds)[36] = tile[wave][1];
         f32x16 hT, dT;
@@ -305,9 +327,9 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(const float *__restrict__ 
         for (int r = 0; r < 16; ++r) hT[r] = dT[r] = 0.f;
         // hT[f, t] = sum_e W1[f, e] x[t, e];  dhT[f, t] = sum_e' W2[e', f] gy[t, e']
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            hT = mfma32(w1row[s], xs[i][16 * h + s], hT);
-            dT = mfma32(w2col[s], gs[i][16 * h + s], dT);
+        for (int s = 0; s < KE; ++s) {
+            hT = mfma32(w1row[s], xs[i][KE * h + s], hT);
+            dT = mfma32(w2col[s], gs[i][KE * h + s], dT);
         }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -321,14 +343,18 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(const float *__restrict__ 
         }
         // g_x^T[e, t] += sum_f W1[f, e] dhT[f, t] : k-slot (r, half) is hidden unit f0 + acc_row(r, half)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) gxT = mfma32(w1col[r], dT[r], gxT);
+        for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gxT[eb] = mfma32(w1col[eb][r], dT[r], gxT[eb]);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // dW1[f, e] = sum_t dhT[f, t] x[t, e],  dW2[e', f] = sum_t gy[t, e'] hT[f, t] — contraction over the 32 tokens;
         // k-step (gq, j): half-wave 0 takes token 8gq+j, half-wave 1 token 8gq+4+j
-        f32x16 aW1, aW2T;                                 // aW1: rows f, columns e;  aW2T: rows f, columns e'
+        f32x16 aW1[EB], aW2T[EB];                         // aW1: rows f, columns e;  aW2T: rows f, columns e'
 #pragma unroll
-        for (int r = 0; r < 16; ++r) aW1[r] = aW2T[r] = 0.f;
+        for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) aW1[eb][r] = aW2T[eb][r] = 0.f;
         float db1 = 0.f;
 #pragma unroll
         for (int gq = 0; gq < 4; ++gq) {
@@ -338,8 +364,11 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(const float *__restrict__ 
             const float dv[4] = {d4.x, d4.y, d4.z, d4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                aW1 = mfma32(dv[j], xs[tk + j][i], aW1);                  // B[k = token][col = e]
-                aW2T = mfma32(hv[j], gs[tk + j][i], aW2T);
+#pragma unroll
+                for (int eb = 0; eb < EB; ++eb) {
+                    aW1[eb] = mfma32(dv[j], xs[tk + j][32 * eb + i], aW1[eb]);                  // B[k = token][col = e]
+                    aW2T[eb] = mfma32(hv[j], gs[tk + j][32 * eb + i], aW2T[eb]);
+                }
                 db1 += dv[j];
             }
         }
@@ -347,22 +376,26 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(const float *__restrict__ 
         // each (token tile, hidden unit) is written by exactly one wave: no cross-wave add for dW1 / dW2 / db1
         float *w1o = pW1 + (size_t)blockIdx.x * F * E, *w2o = pW2 + (size_t)blockIdx.x * F * E;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int f = f0 + acc_row(r, h);
-            if (f < F && i < E) {
-                w1o[(size_t)f * E + i] = aW1[r];
-                w2o[(size_t)f * E + i] = aW2T[r];
+        for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int f = f0 + acc_row(r, h);
+                if (f < F && 32 * eb + i < E) {
+                    w1o[(size_t)f * E + 32 * eb + i] = aW1[eb][r];
+                    w2o[(size_t)f * E + 32 * eb + i] = aW2T[eb][r];
+                }
             }
-        }
         if (h == 0 && f0 + i < F) pb1[(size_t)blockIdx.x * F + f0 + i] = db1;
     }
     // g_x: add the 4 waves -> this hidden group's partial; db2 partial = column sums of gy over this tile's tokens
 #pragma unroll
-    for (int r = 0; r < 16; ++r) xred[wave][acc_row(r, h)][i] = gxT[r];
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xred[wave][32 * eb + acc_row(r, h)][i] = gxT[eb][r];
     __syncthreads();
     float *go = gxpart + (size_t)blockIdx.y * rows * E;
-    for (int idx = threadIdx.x; idx < 32 * 32; idx += 256) {
-        const int t = idx >> 5, e = idx & 31;
+    for (int idx = threadIdx.x; idx < 32 * EW; idx += 256) {
+        const int t = idx / EW, e = idx % EW;
         if (t0 + t < rows && e < E) go[(size_t)(t0 + t) * E + e] = ((xred[0][e][t] + xred[1][e][t]) + xred[2][e][t]) + xred[3][e][t];
     }
     if (blockIdx.y == 0 && threadIdx.x < E) {
@@ -374,12 +407,12 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(const float *__restrict__ 
 }
 
 int vit_check(const char *who, int rows, int E) {
-    SQD_CHECK_ARG(rows > 0 && (E == 16 || E == 32), "%s: rows=%d, E=%d (E must be 16 or 32)", who, rows, E);
+    SQD_CHECK_ARG(rows > 0 && (E == 16 || E == 32 || E == 64), "%s: rows=%d, E=%d (E must be 16, 32 or 64)", who, rows, E);
     return SQD_OK;
 }
 }  // namespace
 
-extern "C" int sqd_vit_supported(int E, int F) { return ((E == 16 || E == 32) && F >= 4 && F % 4 == 0 && F <= 8192) ? 1 : 0; }
+extern "C" int sqd_vit_supported(int E, int F) { return ((E == 16 || E == 32 || E == 64) && F >= 4 && F % 4 == 0 && F <= 8192) ? 1 : 0; }
 
 // ---- add + dropout + LayerNorm.  x [rows,E]; y [nparts][rows,E] (summed, + ybias [E] if not NULL); mask [rows,E] bytes
 // (1 = keep) or NULL; scale = 1/(1-p)
@@ -389,8 +422,12 @@ extern "C" int sqd_addln_fwd(const float *x, const float *y, int nparts, const f
     SQD_CHECK_ARG(x && y && gamma && beta && out && xhat && rstd && nparts >= 1, "sqd_addln_fwd: null pointer or nparts < 1");
     if (vit_check("sqd_addln_fwd", rows, E)) return SQD_EINVAL;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(addln_fwd_kernel, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, y, nparts, ybias, mask, gamma, beta, out,
-                       xhat, rstd, rows, E, scale, eps);
+    if (E <= 32)
+        hipLaunchKernelGGL(addln_fwd_kernel<32>, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, x, y, nparts, ybias, mask, gamma, beta, out,
+                           xhat, rstd, rows, E, scale, eps);
+    else
+        hipLaunchKernelGGL(addln_fwd_kernel<64>, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, nparts, ybias, mask, gamma, beta, out,
+                           xhat, rstd, rows, E, scale, eps);
     SQD_CHECK_LAUNCH("sqd_addln_fwd");
     return SQD_OK;
 }
@@ -405,8 +442,12 @@ extern "C" int sqd_addln_bwd(const float *g_out, const float *g_extra, int nextr
                   "sqd_addln_bwd: null pointer");
     if (vit_check("sqd_addln_bwd", rows, E)) return SQD_EINVAL;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(addln_bwd_kernel, dim3(sqd_addln_nblk(rows)), dim3(256), 0, (hipStream_t)stream, g_out, g_extra, nextra, xhat, rstd,
-                       mask, gamma, g_x, g_y, part, rows, E, scale);
+    if (E <= 32)
+        hipLaunchKernelGGL(addln_bwd_kernel<32>, dim3(sqd_addln_nblk(rows)), dim3(256), 0, (hipStream_t)stream, g_out, g_extra, nextra, xhat, rstd,
+                           mask, gamma, g_x, g_y, part, rows, E, scale);
+    else
+        hipLaunchKernelGGL(addln_bwd_kernel<64>, dim3(sqd_addln_nblk(rows)), dim3(256), 0, (hipStream_t)stream, g_out, g_extra, nextra, xhat, rstd,
+                           mask, gamma, g_x, g_y, part, rows, E, scale);
     SQD_CHECK_LAUNCH("sqd_addln_bwd");
     return SQD_OK;
 }
@@ -443,8 +484,12 @@ extern "C" int sqd_ffn_fwd(const float *x, const float *W1, const float *b1, con
     SQD_CHECK_ARG(rows > 0 && sqd_vit_supported(E, F), "sqd_ffn_fwd: unsupported dims rows=%d E=%d F=%d", rows, E, F);
     SQD_CHECK_ARG(((uintptr_t)mask & 3) == 0, "sqd_ffn_fwd: mask must be 4-byte aligned");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(ffn_fwd_kernel, dim3((rows + 31) / 32, sqd_ffn_groups(F)), dim3(256), 0, (hipStream_t)stream, x, W1, b1, W2, mask, ypart,
-                       rows, E, F, scale);
+    if (E <= 32)
+        hipLaunchKernelGGL(ffn_fwd_kernel<1>, dim3((rows + 31) / 32, sqd_ffn_groups(F)), dim3(256), 0, (hipStream_t)stream, x, W1, b1, W2, mask, ypart,
+                           rows, E, F, scale);
+    else
+        hipLaunchKernelGGL(ffn_fwd_kernel<2>, dim3((rows + 31) / 32, sqd_ffn_groups(F)), dim3(256), 0, (hipStream_t)stream, x, W1, b1, W2, mask, ypart,
+                           rows, E, F, scale);
     SQD_CHECK_LAUNCH("sqd_ffn_fwd");
     return SQD_OK;
 }
@@ -459,15 +504,19 @@ extern "C" int sqd_ffn_bwd(const float *x, const float *g_y, const float *W1, co
     SQD_CHECK_ARG(rows > 0 && sqd_vit_supported(E, F), "sqd_ffn_bwd: unsupported dims rows=%d E=%d F=%d", rows, E, F);
     SQD_CHECK_ARG(((uintptr_t)mask & 3) == 0, "sqd_ffn_bwd: mask must be 4-byte aligned");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(ffn_bwd_kernel, dim3(sqd_ffn_tiles(rows), sqd_ffn_groups(F)), dim3(256), 0, (hipStream_t)stream, x, g_y, W1, b1, W2, mask,
-                       gxpart, pW1, pb1, pW2T, pb2, rows, E, F, scale);
+    if (E <= 32)
+        hipLaunchKernelGGL(ffn_bwd_kernel<1>, dim3(sqd_ffn_tiles(rows), sqd_ffn_groups(F)), dim3(256), 0, (hipStream_t)stream, x, g_y, W1, b1, W2, mask,
+                           gxpart, pW1, pb1, pW2T, pb2, rows, E, F, scale);
+    else
+        hipLaunchKernelGGL(ffn_bwd_kernel<2>, dim3(sqd_ffn_tiles(rows), sqd_ffn_groups(F)), dim3(256), 0, (hipStream_t)stream, x, g_y, W1, b1, W2, mask,
+                           gxpart, pW1, pb1, pW2T, pb2, rows, E, F, scale);
     SQD_CHECK_LAUNCH("sqd_ffn_bwd");
     return SQD_OK;
 }
 
 // ===================================================================================================
 // multi-head self-attention of the encoder layer (nn.MultiheadAttention, packed in_proj, batch_first = False) for short token
-// sequences: S <= 512 tokens, head dimension HD in {4, 8}.  One workgroup per (batch element, head), four (two beyond 256 tokens) threads per token
+// sequences: S <= 512 tokens, head dimension HD in {4, 8} (E = 64: HD = 16, S <= 256).  One workgroup per (batch element, head), four (two beyond 256 tokens) threads per token
 // (each takes every 4th key / query and a quarter of the features; quad shuffles combine them); the whole head (projections,
 // S x S scores, softmax, attention dropout, P.V, its slice of the out-projection) is VALU work on operands read from LDS — 120 x 120 x 8 per head is far too small for the matrix cores to matter; what
 // counts is that it is ONE launch with no intermediate tensors instead of ~8 (forward) / ~20 (backward).
@@ -772,6 +821,25 @@ __global__ __launch_bounds__(T * P) void mha_bwd_kernel(const float *__restrict_
     }
 }
 
+// model_dim 64 (head dimension 16): 128 tokens x 4 threads, or 256 tokens x 2 threads (512 threads: the 64 + 64 row registers of the
+// backward need the 256-register budget); the backward stages x / g_sa in LDS only for the 128-token shape
+void mha_launch_fwd64(dim3 grid, hipStream_t st, const float *x, const float *Win, const float *bin, const float *Wo, const unsigned char *mask,
+                      float *ypart, float *o_save, float *ml_save, int S, int B, int H, float qscale, float dscale) {
+    if (S <= 128)
+        hipLaunchKernelGGL((mha_fwd_kernel<16, 64, 128, 4>), grid, dim3(512), 0, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+    else
+        hipLaunchKernelGGL((mha_fwd_kernel<16, 64, 256, 2>), grid, dim3(512), 0, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+}
+void mha_launch_bwd64(dim3 grid, hipStream_t st, const float *x, const float *gsa, const float *Win, const float *bin, const float *Wo,
+                      const unsigned char *mask, const float *o_save, const float *ml_save, float *gxpart, float *pWin, float *pbin, float *pWo,
+                      float *pbo, int S, int B, int H, float qscale, float dscale) {
+    if (S <= 128)
+        hipLaunchKernelGGL((mha_bwd_kernel<16, 64, 128, 4, true>), grid, dim3(512), 0, st, x, gsa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin,
+                           pbin, pWo, pbo, S, B, H, qscale, dscale);
+    else
+        hipLaunchKernelGGL((mha_bwd_kernel<16, 64, 256, 2, false>), grid, dim3(512), 0, st, x, gsa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin,
+                           pbin, pWo, pbo, S, B, H, qscale, dscale);
+}
 template <int HD, int EE>
 void mha_launch_fwd(dim3 grid, hipStream_t st, const float *x, const float *Win, const float *bin, const float *Wo, const unsigned char *mask,
                     float *ypart, float *o_save, float *ml_save, int S, int B, int H, float qscale, float dscale) {
@@ -799,8 +867,9 @@ void mha_launch_bwd(dim3 grid, hipStream_t st, const float *x, const float *gsa,
 }  // namespace
 
 extern "C" int sqd_mha_supported(int S, int E, int H) {
-    if (!(E == 16 || E == 32) || H < 1 || E % H) return 0;
+    if (!(E == 16 || E == 32 || E == 64) || H < 1 || E % H) return 0;
     const int hd = E / H;
+    if (E == 64) return (S >= 1 && S <= 256 && hd == 16) ? 1 : 0;          // model_dim 64 with its 4 heads
     return (S >= 1 && S <= 512 && (hd == 4 || hd == 8)) ? 1 : 0;
 }
 
@@ -817,7 +886,8 @@ extern "C" int sqd_mha_fwd(const float *x, const float *Win, const float *bin, c
     const dim3 grid(B, H);
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
-    if (hd == 8 && E == 32) mha_launch_fwd<8, 32>(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+    if (E == 64) mha_launch_fwd64(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+    else if (hd == 8 && E == 32) mha_launch_fwd<8, 32>(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
     else if (hd == 4 && E == 32) mha_launch_fwd<4, 32>(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
     else if (hd == 8 && E == 16) mha_launch_fwd<8, 16>(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
     else mha_launch_fwd<4, 16>(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
@@ -840,7 +910,8 @@ extern "C" int sqd_mha_bwd(const float *x, const float *g_sa, const float *Win, 
     (void)hipGetLastError();
 #define SQD_MHA_BWD(HD_, EE_) \
     mha_launch_bwd<HD_, EE_>(grid, st, x, g_sa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin, pbin, pWo, pbo, S, B, H, qscale, dscale)
-    if (hd == 8 && E == 32) SQD_MHA_BWD(8, 32);
+    if (E == 64) mha_launch_bwd64(grid, st, x, g_sa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin, pbin, pWo, pbo, S, B, H, qscale, dscale);
+    else if (hd == 8 && E == 32) SQD_MHA_BWD(8, 32);
     else if (hd == 4 && E == 32) SQD_MHA_BWD(4, 32);
     else if (hd == 8 && E == 16) SQD_MHA_BWD(8, 16);
     else SQD_MHA_BWD(4, 16);

@@ -5,7 +5,8 @@ reference's structure (state-dict keys stay those of the reference) while the ar
 kernels of libsqd.so (csrc/*.hip).  There is ONE implementation per operator: a shape the kernels do not take (channel /
 feature counts that are not multiples of 4) is an error that names the operator and the shape, not a detour through another
 library; host tensors are refused (the CPU restatement of these operators is test infrastructure: oracle/, tests/host_ops.py).
-The one operator still served by ATen is listed in BACKEND with its reason."""
+A transformer encoder the kernels do not take (an embedding width other than 16 / 32 / 64, more than 512 tokens) would run on ATen and
+is counted in ATEN_CALLS; no args file of the reference builds one."""
 import torch
 import torch.nn.functional as F
 
@@ -13,7 +14,7 @@ BACKEND = {
     "conv2d": "hip (implicit GEMM / input-patch kernels; 7x7 and 3x3 stride-2 stems via space-to-depth)",
     "conv_bn_act": "hip conv + hip bn/act/residual", "maxpool3x3s2": "hip", "upsample_concat": "hip",
     "pose_head": "hip", "depthwise_conv": "hip", "squeeze_excite": "hip", "linear": "hip (1x1 implicit GEMM over rows)",
-    "transformer_encoder": "hip (fused attention up to 512 tokens, feed-forward, add+dropout+layernorm; embedding width 64: aten nn.TransformerEncoder)",
+    "transformer_encoder": "hip (fused attention up to 512 tokens — 256 at embedding width 64 —, feed-forward, add+dropout+layernorm)",
     "full_query_layer": "hip", "bins_head": "hip",
 }
 
@@ -24,8 +25,8 @@ def backend_report():
     """BACKEND, with the transformer encoder reported by what actually ran in this process."""
     rep = dict(BACKEND)
     n = ATEN_CALLS.get("transformer_encoder", 0)
-    rep["transformer_encoder"] = ("hip (fused attention up to 512 tokens, feed-forward, add+dropout+layernorm)" if n == 0 else
-                                  "aten nn.TransformerEncoder (%d calls: embedding width 64)" % n)
+    if n:
+        rep["transformer_encoder"] = "aten nn.TransformerEncoder (%d calls: a shape the kernels do not take)" % n
     return rep
 
 
@@ -255,7 +256,7 @@ def transformer_encoder(tokens, encoder):
     if nnkernels.encoder_supported(encoder):
         return nnkernels.transformer_encoder_native(tokens, encoder)
     ATEN_CALLS["transformer_encoder"] = ATEN_CALLS.get("transformer_encoder", 0) + 1
-    return encoder(tokens)                     # ATen: embedding widths other than 16 / 32 (config B' of the old args files)
+    return encoder(tokens)                     # ATen: embedding widths other than 16 / 32 / 64
 
 
 def full_query_layer(x, queries):

@@ -20,18 +20,22 @@ HEADS = {
     # backbone resnet_lite (=> Lite_Depth_Decoder_QueryTr, feed-forward 512), patch 20, 128 queries, dim_out 128, min_depth 0.01
     "res50_c": (["--backbone", "resnet_lite", "--num_layers", "50", "--num_features", "256", "--query_nums", "128", "--dim_out", "128",
                  "--patch_size", "20", "--min_depth", "0.01"], (20, 128, 128, 512, 0.01)),
+    # config B' = the old args_files/args_res50_kitti_192x640_train.txt:8-10 (model_dim 64, patch 16, 120 queries; num_features 512 and
+    # dim_out 128 are the parser's defaults): the 64-wide patch-token encoder and Self Query Layer
+    "res50_bp": (["--backbone", "resnet", "--num_layers", "50", "--num_features", "512", "--query_nums", "120", "--dim_out", "128",
+                  "--patch_size", "16", "--min_depth", "0.001"], (16, 120, 128, 1024, 0.001)),
     "res18": (["--backbone", "resnet18_lite", "--query_nums", "120", "--dim_out", "128", "--patch_size", "16", "--min_depth", "0.001"],
               (16, 120, 128, 512, 0.001)),       # args_res18_kitti_192x640_tarin.txt:8-10
 }
 
 
 def _args(H, W, B, extra, kind="res50"):
-    return HEADS[kind][0] + ["--model_dim", "32", "--height", str(H), "--width", str(W), "--batch_size", str(B),
+    return HEADS[kind][0] + ["--model_dim", "64" if kind == "res50_bp" else "32", "--height", str(H), "--width", str(W), "--batch_size", str(B),
                              "--max_depth", "80.0", "--num_workers", "0", "--sqd_synthetic", "--log_dir", "/tmp/sqd_full_cfg_test"] + extra
 
 
 @pytest.mark.parametrize("plans", ["default_plans", "tuned_plans"])
-@pytest.mark.parametrize("H,W,B,kind", [(192, 640, 2, "res50"), (320, 1024, 1, "res50_c"), (192, 640, 2, "res18")])
+@pytest.mark.parametrize("H,W,B,kind", [(192, 640, 2, "res50"), (320, 1024, 1, "res50_c"), (192, 640, 2, "res18"), (192, 640, 2, "res50_bp")])
 def test_flagship_step_matches_oracle(H, W, B, kind, plans):
     """configs[1] and configs[2] (ResNet-50 + [Lite_]Depth_Decoder_QueryTr) and configs[0] at its real shape (ResNet-18 +
     Lite_Depth_Decoder_QueryTr, 192x640, batch 2, model_dim 32 / patch 16 / 120 queries / dim_out 128), each under the
@@ -54,8 +58,9 @@ def test_flagship_step_matches_oracle(H, W, B, kind, plans):
             if isinstance(mod, torch.nn.MultiheadAttention):
                 mod.dropout = 0.0
     patch, Q, dim_out, ff, min_depth = HEADS[kind][1]
-    enc = O.LiteResnetEncoderDecoder(model_dim=32) if kind == "res18" else O.ResnetEncoderDecoder(50, 256, 32)
-    dep = O.QueryTrDecoder(32, 32, patch, 4, Q, dim_out, min_val=min_depth, max_val=80.0, dim_feedforward=ff, dropout=0.0)
+    md = 64 if kind == "res50_bp" else 32
+    enc = O.LiteResnetEncoderDecoder(model_dim=32) if kind == "res18" else O.ResnetEncoderDecoder(50, 512 if kind == "res50_bp" else 256, md)
+    dep = O.QueryTrDecoder(md, md, patch, 4, Q, dim_out, min_val=min_depth, max_val=80.0, dim_feedforward=ff, dropout=0.0)
     pose = O.PoseCNN(2)
     for ref, mine in ((enc, tr.models["encoder"]), (dep, tr.models["depth"]), (pose, tr.models["pose"])):
         ref.load_state_dict({k: v.detach().cpu() for k, v in mine.state_dict().items()})
@@ -67,10 +72,13 @@ def test_flagship_step_matches_oracle(H, W, B, kind, plans):
     ref_out, ref_losses = ref.step(dict(cpu_inputs), noise)
     inputs = {k: v.cuda() for k, v in cpu_inputs.items()}
     inputs[("noise", 0)] = noise.cuda()
+    from sqd import nnops
+    nnops.ATEN_CALLS.clear()
     try:
         outputs, losses = tr.train_step(inputs)
         torch.cuda.synchronize()
         mix = nnkernels.plan_mix()
+        assert not nnops.ATEN_CALLS, nnops.ATEN_CALLS          # every operator of the step ran in libsqd (model_dim 64 included)
     finally:
         nnkernels.reset_plans()
     if plans == "tuned_plans":

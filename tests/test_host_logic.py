@@ -285,3 +285,48 @@ def test_reducer_on_trainer_parameter_set_gloo_world2():
         for i, g in enumerate(a):
             if g is not None:                                     # mean of rank coefficients 1x and 2x = 1.5x, times the step factor
                 assert abs(g - 1.5 * (1 + i % 3) * (step + 1)) < 1e-5, (step, i, g)
+
+
+_TORCHRUN_SCRIPT = r"""
+import os, sys
+sys.path.insert(0, %(product)r)
+import torch
+from sqd import ddp
+rank, world, local = ddp.init_from_env("gloo")          # the launcher's environment: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*
+assert world == 2 and rank == int(os.environ["RANK"]) and type(ddp.COMM).__name__ == "GlooComm"
+torch.manual_seed(rank)
+model = torch.nn.Sequential(torch.nn.Linear(8, 16), torch.nn.ReLU(), torch.nn.Linear(16, 4))
+red = ddp.GradBucketReducer(list(model.parameters()), bucket_mb=0.0002)
+red.broadcast_parameters([model])
+w0 = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+for step in range(3):
+    red.zero_grad()
+    torch.manual_seed(10 * step + rank)
+    model(torch.randn(5, 8)).square().mean().backward()
+    red.finish()
+g = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+both = [torch.zeros_like(g) for _ in range(2)]
+torch.distributed.all_gather(both, g)
+ws = [torch.zeros_like(w0) for _ in range(2)]
+torch.distributed.all_gather(ws, w0)
+assert torch.equal(both[0], both[1]) and torch.equal(ws[0], ws[1]) and len(red.buckets) >= 2
+t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+ddp.COMM.all_reduce(t, "max")
+assert float(t) == 2.0
+ddp.COMM.barrier()
+ddp.shutdown()
+print("RANK_OK %%d" %% rank, flush=True)
+"""
+
+
+def test_reducer_under_the_drivers_launcher_gloo_world2(tmp_path):
+    """python -m torch.distributed.run --nproc-per-node 2 (the route the driver takes for bench.py --gpus N): the environment it
+    hands the ranks, the control-plane process group over its store, the bucket reducer, the max-reduce bench.py uses for the
+    step time, shutdown"""
+    import subprocess
+    script = tmp_path / "rank.py"
+    script.write_text(_TORCHRUN_SCRIPT % {"product": PRODUCT})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), str(script)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
+    assert r.returncode == 0 and "RANK_OK 0" in r.stdout and "RANK_OK 1" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
