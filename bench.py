@@ -43,7 +43,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r02_pmc_traffic.json")
+PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
 
 
 def roofline_fused_fwd(trainer, inputs, iters=200):

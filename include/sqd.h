@@ -93,7 +93,8 @@ typedef struct sqd_photo_args {
     float *reproj;          /* [B,S,H,W]  reprojection loss maps (debug/parity; may be NULL)         */
     float *loss_part;       /* [ntasks]   per-wavefront partial sums of to_optimise, ntasks = sqd_photo_ntasks(...) */
     int32_t B, S, H, W;
-    int32_t rows_per_task;  /* rows a workgroup tile owns (even, <= 16); 0 = library default (16)      */
+    int32_t rows_per_task;  /* rows a workgroup tile owns (even; <= 32 for sqd_photo_fwd — above 16: 8-wave workgroups —, <= 16 elsewhere);
+                               0 = the kernel family's measured default (fused forward 28, identity / coefficient maps 12, backward 16) */
     void *stream;
 } sqd_photo_args;
 int sqd_photo_ntasks(int B, int H, int W, int rows_per_task);
@@ -131,7 +132,7 @@ typedef struct sqd_photo_bwd_args {
     int64_t g_depth_img_stride; /* >= ceil(S/2)*H*W */
     float gscale;
     int32_t B, S, H, W;
-    int32_t rows_per_task;  /* rows a workgroup tile owns (even, <= 16); 0 = library default (16) — as sqd_photo_args */
+    int32_t rows_per_task;  /* rows a workgroup tile owns (even, <= 16); 0 = library default (16) */
     void *stream;
 } sqd_photo_bwd_args;
 int sqd_photo_bwd_ntasks(int B, int S, int H, int W, int rows_per_task);

@@ -334,8 +334,8 @@ __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPa
 // phase 2 for the output rows of one wave: pairs (j, j+1) of tile rows share six of their seven window rows
 template <int MODE, int KIND>
 __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const PairPass &pp, const float *noise, const Ctx<MODE> &k, bool edge, int b,
-                                          int wave, int TR, int own_rows, bool own_col, float &loss_acc) {
-    for (int p = wave; 2 * p < own_rows; p += 4) {
+                                          int wave, int nwaves, int own_rows, bool own_col, float &loss_acc) {
+    for (int p = wave; 2 * p < own_rows; p += nwaves) {
         const int j = 2 * p;                         // tile rows j .. j+7 feed the outputs y0+j (centre j+3) and y0+j+1 (centre j+4)
         Sums core;                                   // rows j+1 .. j+6: shared by both outputs
         clear(core);
@@ -471,9 +471,10 @@ __device__ __forceinline__ void finish_cell(const sqd_photo_args &a, const PairP
     }
 }
 
-// (4 workgroups of 4 waves per CU: the register allocator is held to 128 VGPRs; the kernel needs 118)
-template <int MODE>
-__global__ __launch_bounds__(256, 4) void photo_tile_kernel(sqd_photo_args a, PairPass pp, const float *__restrict__ noise, int TR, int nsx,
+// (4 workgroups of 4 waves per CU: the register allocator is held to 128 VGPRs; the kernel needs 118.  NW = 8: two workgroups of 8
+//  waves on tiles of up to 32 rows — the same waves per SIMD, 38 instead of 2 x 22 warped rows per 32 output rows)
+template <int MODE, int NW = 4>
+__global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_args a, PairPass pp, const float *__restrict__ noise, int TR, int nsx,
                                                           int nsy, int ntiles, int nblk8) {
     extern __shared__ v2f wl[];                       // MODE 1: [TR + 6][3][64] (source 0, source 1) warped colours
     const int lane = threadIdx.x & 63;
@@ -511,7 +512,7 @@ __global__ __launch_bounds__(256, 4) void photo_tile_kernel(sqd_photo_args a, Pa
         const int xc = min(max(xr, 0), W - 1);             // (lanes beyond a narrow image compute a valid column and store zeros)
         const float fx = (float)xc;
         const int nrow = own_rows + 6;
-        for (int r = wave; r < nrow; r += 4) {
+        for (int r = wave; r < nrow; r += NW) {
             Cell cA;
             const int yA = y0 - 3 + r;
             if (yA < 0 || yA >= H) continue;                 // (rows outside the image are reflections of rows inside the tile)
@@ -538,14 +539,14 @@ __global__ __launch_bounds__(256, 4) void photo_tile_kernel(sqd_photo_args a, Pa
     k.xoff = col_ok ? (unsigned)xr * 4u : 0x80000000u;
     float loss_acc = 0.f;
     if (sx.kind == LEFT)
-        ssim_rows<MODE, LEFT>(a, pp, noise, k, lane >= 1 && lane <= 3, b, wave, TR, own_rows, own_col, loss_acc);
+        ssim_rows<MODE, LEFT>(a, pp, noise, k, lane >= 1 && lane <= 3, b, wave, NW, own_rows, own_col, loss_acc);
     else if (sx.kind == RIGHT)
-        ssim_rows<MODE, RIGHT>(a, pp, noise, k, lane >= 60 && lane <= 62, b, wave, TR, own_rows, own_col, loss_acc);
+        ssim_rows<MODE, RIGHT>(a, pp, noise, k, lane >= 60 && lane <= 62, b, wave, NW, own_rows, own_col, loss_acc);
     else
-        ssim_rows<MODE, INTERIOR>(a, pp, noise, k, false, b, wave, TR, own_rows, own_col, loss_acc);
+        ssim_rows<MODE, INTERIOR>(a, pp, noise, k, false, b, wave, NW, own_rows, own_col, loss_acc);
     if (MODE == 1 && a.loss_part && pp.last) {
         loss_acc = wave_sum(loss_acc);
-        if (lane == 0) a.loss_part[tile * 4 + wave] = loss_acc;
+        if (lane == 0) a.loss_part[tile * NW + wave] = loss_acc;
     }
 }
 
@@ -797,31 +798,42 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_tile_kernel(sqd_photo_bwd_ar
     }
 }
 
-int pick_tr(int rows) {
-    int tr = rows <= 0 ? TR_MAX : rows;
-    tr = tr > TR_MAX ? TR_MAX : tr;
+// rows a workgroup tile owns: the caller's rows_per_task (even, clamped), or the measured default of the kernel family — at config B
+// (B 12, 192x640; profiles/r03m_photo_tile_heights.md): fused forward 8 waves x 28 rows 51.0 us (4 x 16: 56.8, 4 x 14: 53.5, 8 x 32:
+// 56.4, 8 x 30: 52.0 — tiles per CU and their halo both count), identity / coefficient kernels 12 rows (31.4 / 33.2 us against 33.1 /
+// 37.2 at 16), backward 16 (flat)
+enum { FAMILY_FWD = 1, FAMILY_ROWS = 0, FAMILY_BWD = 2 };
+int pick_tr(int rows, int family, int H) {
+    const int cap = family == FAMILY_FWD && (rows > TR_MAX || (rows <= 0 && H >= 56)) ? 2 * TR_MAX : TR_MAX;
+    int tr = rows > 0 ? rows : family == FAMILY_FWD ? (H >= 56 ? 28 : TR_MAX) : family == FAMILY_ROWS ? 12 : TR_MAX;
+    tr = tr > cap ? cap : tr;
     tr &= ~1;
     return tr < 2 ? 2 : tr;
 }
 }  // namespace
 
 namespace sqd {
-int photo_tile_count(int B, int H, int W, int rows_per_task) {
-    const int TR = pick_tr(rows_per_task);
+// the fused forward takes tiles of up to 32 rows with 8 waves (its default above; rows_per_task 17..32), everything else 4 waves
+int photo_fwd_waves(int rows_per_task, int H) { return pick_tr(rows_per_task, FAMILY_FWD, H) > TR_MAX ? 8 : 4; }
+int photo_tile_count(int B, int H, int W, int rows_per_task, int family) {
+    const int TR = pick_tr(rows_per_task, family, H);
     return B * strips_x(W) * ((H + TR - 1) / TR);
 }
 
 // mode 0: identity maps, 1: fused forward, 2: coefficient planes of the backward (a.warped = stored warps, a.idx, a.coef)
 void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hipStream_t stream) {
-    const int TR = pick_tr(a.rows_per_task);
+    const int TR = pick_tr(a.rows_per_task, mode == 1 ? FAMILY_FWD : FAMILY_ROWS, a.H);
+    const int NW = mode == 1 && TR > TR_MAX ? 8 : 4;
     const int nsx = strips_x(a.W), nsy = (a.H + TR - 1) / TR;
     const int ntiles = a.B * nsx * nsy;
     const int nblk8 = (ntiles + 7) / 8;
-    const dim3 grid(nblk8 * 8), block(256);
+    const dim3 grid(nblk8 * 8), block(NW * 64);
     for (int k = 0; 2 * k < a.S; ++k) {                  // one launch per pair of source frames
         const PairPass pp = {2 * k, 2 * k + 1 < a.S ? 2 * k + 1 : 2 * k, a.S, k == 0, 2 * k + 2 >= a.S};
         if (mode == 0)
             hipLaunchKernelGGL((photo_tile_kernel<0>), grid, block, 0, stream, a, pp, noise, TR, nsx, nsy, ntiles, nblk8);
+        else if (mode == 1 && NW == 8)
+            hipLaunchKernelGGL((photo_tile_kernel<1, 8>), grid, block, (TR + 6) * 3 * 64 * 8, stream, a, pp, noise, TR, nsx, nsy, ntiles, nblk8);
         else if (mode == 1)
             hipLaunchKernelGGL((photo_tile_kernel<1>), grid, block, (TR + 6) * 3 * 64 * 8, stream, a, pp, noise, TR, nsx, nsy, ntiles, nblk8);
         else
@@ -831,7 +843,7 @@ void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hi
 
 // backward: one launch per pair of source frames; plane `pass` of g_depth receives the pair's contribution
 void launch_photo_bwd_tile(const sqd_photo_bwd_args &a, hipStream_t stream) {
-    const int TR = pick_tr(a.rows_per_task);
+    const int TR = pick_tr(a.rows_per_task, FAMILY_BWD, a.H);
     const int nsx = strips_x(a.W), nsy = (a.H + TR - 1) / TR;
     const int ntiles = a.B * nsx * nsy;
     const int nblk8 = (ntiles + 7) / 8;

@@ -30,7 +30,7 @@ sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(_
 import bench  # noqa: E402  (kernel_source_hash: the record is valid for this revision of the kernel sources only)
 res = {"kernel_source_hash": bench.kernel_source_hash(), "judged_kernel": "photo_tile_kernel<1>",
        "calibration_factor": {k: round(v, 4) for k, v in cal.items()}, "kernels": {}}
-for name in ("photo_tile_kernel<1>", "photo_tile_kernel<0>", "photo_tile_kernel<2>", "photo_bwd_kernel"):
+for name in ("photo_tile_kernel<1>", "photo_tile_kernel<0>", "photo_tile_kernel<2>", "photo_bwd_tile_kernel"):
     try:
         fr, wr = avg(name, "FETCH_SIZE"), avg(name, "WRITE_SIZE")
     except SystemExit:

@@ -13,5 +13,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc/fused_$c -- python $R/tools/bench_fused.py --iters 30 --which fwd,ident,coef,bwd > /dev/null 2>&1
 done
 python $R/tools/pmc_traffic.py $out/pmc $out/${tag}_pmc_traffic.json > $out/pmc_traffic.log 2>&1
+rm -rf $out/trace $out/pmc          # (raw traces: tens of MB; gpurun copies at most 64 MB back)
 tail -c 1500 $out/${tag}_pmc_traffic.json
 head -60 $out/${tag}_bench_kernel_trace_stats.md
