@@ -136,25 +136,34 @@ __global__ __launch_bounds__(256) void s2d_kernel(const float *__restrict__ x, f
 //   channel c < C0 from x0[n, c], c >= C0 from x1[n, c - C0];  value (v - sub) * (1 / div) — a tensor divided by a scalar is a
 //   multiplication by the scalar's float reciprocal in ATen's CUDA/HIP kernels, which is what the reference runs;  sample n lands at
 //   y + n * y_stride
+//   One thread per OUTPUT pixel: its Cp floats are Cp/4 consecutive float4 stores (a wave writes 64 x Cp x 4 contiguous bytes) and
+//   every plane is read as two runs of 128 consecutive floats per wave.  (Round 2's version gave a thread one (pixel, channel): a
+//   wave's stores were 16 bytes out of every Cp x 4 — 40 us per call for 41 MB at config B.)
+template <int QMAX>                                      // Cp / 4 <= QMAX float4 per pixel
 __global__ __launch_bounds__(256) void s2d_planar_kernel(const float *__restrict__ x0, const float *__restrict__ x1, float *__restrict__ y,
                                                          int N, int H, int W, int C0, int C1, int Cp, long long y_stride, float sub, float inv_div) {
     const int H2 = H / 2, W2 = W / 2, Q = Cp / 4, C = C0 + C1;
-    const size_t per = (size_t)H2 * W2 * Q, total = (size_t)N * per;
+    const size_t per = (size_t)H2 * W2, total = (size_t)N * per;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        // pixels fastest inside a (sample, channel) plane pair: a wave reads two runs of 128 consecutive source floats
         const int w2 = (int)(i % W2);
-        size_t t = i / W2;
-        const int c = (int)(t % Q);
-        t /= Q;
+        const size_t t = i / W2;
         const int h2 = (int)(t % H2), n = (int)(t / H2);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < C) {
-            const float *pl = c < C0 ? x0 + ((size_t)n * C0 + c) * H * W : x1 + ((size_t)n * C1 + (c - C0)) * H * W;
-            const float2 a = *reinterpret_cast<const float2 *>(pl + (size_t)(2 * h2) * W + 2 * w2);
-            const float2 b = *reinterpret_cast<const float2 *>(pl + (size_t)(2 * h2 + 1) * W + 2 * w2);
-            v = make_float4((a.x - sub) * inv_div, (a.y - sub) * inv_div, (b.x - sub) * inv_div, (b.y - sub) * inv_div);
+        const size_t o = (size_t)(2 * h2) * W + 2 * w2;
+        float4 v[QMAX];
+#pragma unroll
+        for (int c = 0; c < QMAX; ++c) {
+            v[c] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < C) {
+                const float *pl = c < C0 ? x0 + ((size_t)n * C0 + c) * H * W : x1 + ((size_t)n * C1 + (c - C0)) * H * W;
+                const float2 a = *reinterpret_cast<const float2 *>(pl + o);
+                const float2 b = *reinterpret_cast<const float2 *>(pl + o + W);
+                v[c] = make_float4((a.x - sub) * inv_div, (a.y - sub) * inv_div, (b.x - sub) * inv_div, (b.y - sub) * inv_div);
+            }
         }
-        reinterpret_cast<float4 *>(y + (size_t)n * y_stride)[((size_t)h2 * W2 + w2) * Q + c] = v;
+        float4 *dst = reinterpret_cast<float4 *>(y + (size_t)n * y_stride) + ((size_t)h2 * W2 + w2) * Q;
+#pragma unroll
+        for (int c = 0; c < QMAX; ++c)
+            if (c < Q) dst[c] = v[c];
     }
 }
 
@@ -196,8 +205,14 @@ extern "C" int sqd_space_to_depth2_planar(const float *x0, const float *x1, floa
                   "sqd_space_to_depth2_planar: bad arguments (H=%d W=%d C0=%d C1=%d Cp=%d)", H, W, C0, C1, Cp);
     SQD_CHECK_ARG(((uintptr_t)x0 & 7) == 0 && ((uintptr_t)x1 & 7) == 0 && ((uintptr_t)y & 15) == 0, "sqd_space_to_depth2_planar: alignment");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(s2d_planar_kernel, dim3(grid_for((size_t)N * (H / 2) * (W / 2) * Cp / 4)), dim3(256), 0, (hipStream_t)stream, x0, x1, y,
-                       N, H, W, C0, C1, Cp, (long long)y_stride, sub, 1.0f / div);
+    SQD_CHECK_ARG(Cp <= 64, "sqd_space_to_depth2_planar: Cp=%d (at most 64: frames of up to 16 channels)", Cp);
+    const dim3 grid(grid_for((size_t)N * (H / 2) * (W / 2)));
+    if (Cp <= 16)
+        hipLaunchKernelGGL(s2d_planar_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x0, x1, y, N, H, W, C0, C1, Cp, (long long)y_stride, sub, 1.0f / div);
+    else if (Cp <= 32)
+        hipLaunchKernelGGL(s2d_planar_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x0, x1, y, N, H, W, C0, C1, Cp, (long long)y_stride, sub, 1.0f / div);
+    else
+        hipLaunchKernelGGL(s2d_planar_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x0, x1, y, N, H, W, C0, C1, Cp, (long long)y_stride, sub, 1.0f / div);
     SQD_CHECK_LAUNCH("sqd_space_to_depth2_planar");
     return SQD_OK;
 }
