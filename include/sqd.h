@@ -198,6 +198,11 @@ int sqd_bn_eval_fwd(const float *x, const float *res, const float *gamma, const 
 int sqd_bn_train_bwd(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
                      const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
                      float *dbeta, float *part, int M, int C, int act, void *stream);
+/* the same with the reduction pass replaced by partials the producing data gradient wrote (sqd_conv_dgrad_bn): part holds pre_rows rows of
+ * [C][2] = (sum dz, sum dz * xhat); pre_rows = 0: as sqd_bn_train_bwd                                                                  */
+int sqd_bn_train_bwd_pre(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
+                         const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
+                         float *dbeta, float *part, int pre_rows, int M, int C, int act, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (7) bilinear resize (align_corners=True) + channel concat, channels-last activations
@@ -280,6 +285,14 @@ int sqd_conv_fwd(const float *x, const float *w, const float *bias, float *y, fl
 int sqd_act_bwd(const float *g, const float *y, float *out, int64_t n, int act, void *stream);
 int sqd_conv_dgrad(const float *dy, const float *w, const float *addend, float *dx, float *ws, int N, int H, int W, int C,
                    int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream);
+/* data gradient + the partial sums of the BatchNorm backward whose output act(BN(bn_x)) this convolution differentiates — replaces the
+ * reduction pass of torch's batch_norm_backward over dy and x (dx = dgrad + addend must be the complete gradient of that output).
+ * bn_x [N,H,W,C], bn_mask [N*H*W*C/4] sign bytes of the forward (NULL: no activation), bn_mean / bn_rstd [C], bn_act 0 | 1 | 2
+ * -> stats [sqd_conv_dgrad_stats_rows(...)][C][2] for sqd_bn_train_bwd_pre (0 rows: the plan splits the reduction, nothing is written). */
+int sqd_conv_dgrad_stats_rows(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo);
+int sqd_conv_dgrad_bn(const float *dy, const float *w, const float *addend, float *dx, float *ws, const float *bn_x,
+                      const unsigned char *bn_mask, const float *bn_mean, const float *bn_rstd, int bn_act, float *stats, int N, int H,
+                      int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream);
 /* workspace of the weight gradient: `part_floats` floats (+ max(ceil(N*Ho*Wo/1024), splits) * K more when dbias is wanted) */
 int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *splits, int64_t *part_floats);
 /* measured plan for the weight gradient: impl 1 (+ 16 kt + 256 ct: register tile) = direct-operand kernel, 0 = LDS-tiled kernel,

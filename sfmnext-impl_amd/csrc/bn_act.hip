@@ -349,15 +349,25 @@ extern "C" int sqd_bn_eval_fwd(const float *x, const float *res, const float *ga
 extern "C" int sqd_bn_train_bwd(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
                                 const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
                                 float *dbeta, float *part, int M, int C, int act, void *stream) {
+    return sqd_bn_train_bwd_pre(dy, x, y, mask, gamma, beta, save_mean, save_rstd, dx, dres, dgamma, dbeta, part, 0, M, C, act, stream);
+}
+
+// pre_rows > 0: `part` already holds that many rows of (sum dz, sum dz * xhat) partials — written by the epilogue of the data gradient
+// that produced dy (sqd_conv_dgrad_bn) — and the reduction pass over dy and x is skipped
+extern "C" int sqd_bn_train_bwd_pre(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
+                                    const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
+                                    float *dbeta, float *part, int pre_rows, int M, int C, int act, void *stream) {
     SQD_CHECK_ARG(dy && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && part, "sqd_bn_train_bwd: null pointer");
+    SQD_CHECK_ARG(pre_rows >= 0 && (pre_rows == 0 || act != ACT_SWISH), "sqd_bn_train_bwd_pre: pre_rows=%d (no precomputed partials with swish)", pre_rows);
     SQD_CHECK_ARG(act == ACT_NONE || act == ACT_SWISH || y || mask, "sqd_bn_train_bwd: ReLU / LeakyReLU need y or the sign mask of the forward");
     SQD_CHECK_ARG(act != ACT_SWISH || (beta && !dres), "sqd_bn_train_bwd: swish needs beta (pre-activation is recomputed) and takes no residual");
     if (check("sqd_bn_train_bwd", M, C)) return SQD_EINVAL;
     const Geom g = geom(M, C);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
-    hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nblk), dim3(256), 0, s, x, dy, y, save_mean, save_rstd, part, M, C, act, g, mask, gamma, beta);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, part, g.nblk, M, C, dgamma, dbeta);
+    if (pre_rows <= 0)
+        hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nblk), dim3(256), 0, s, x, dy, y, save_mean, save_rstd, part, M, C, act, g, mask, gamma, beta);
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, part, pre_rows > 0 ? pre_rows : g.nblk, M, C, dgamma, dbeta);
     const size_t total4 = (size_t)M * C / 4;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, s, dy, x, y, gamma, save_mean, save_rstd, dgamma,
                        dbeta, dx, dres, total4, C, 1.0f / (float)M, act, mask, beta);

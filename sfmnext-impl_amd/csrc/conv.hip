@@ -32,6 +32,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16, LDP = 20;     // reduction slice, LDS row pitch (floats)
 
+// BatchNorm-backward statistics in the data-gradient epilogue (sqd_conv_dgrad_bn): the tensor this convolution differentiates is
+// the output act(BN(x_bn) [+ res]) of a training-mode BatchNorm; its backward needs per channel  sum dz  and  sum dz * xhat
+// (dz = dx * act'(.), xhat = (x_bn - mean) * rstd) — sums over exactly the elements the epilogue holds.  x == NULL: off.
+struct BnBwdSrc {
+    const float *x;                 // the BatchNorm's input [N,H,W,C] (the producing convolution's output)
+    const unsigned char *mask;      // sign bits of its pre-activation, 1 byte per 4 channels (ReLU / LeakyReLU); NULL: no activation
+    const float *mean, *rstd;       // [C] batch statistics of the forward
+    int act;                        // 0 none, 1 ReLU, 2 LeakyReLU(0.01)
+};
+__device__ __forceinline__ float bn_bwd_act(unsigned bits, int j, int act) {
+    const bool pos = (bits >> j) & 1u;
+    return act == 1 ? (pos ? 1.f : 0.f) : act == 2 ? (pos ? 1.f : 0.01f) : 1.f;
+}
+
 struct ConvGeom {
     int N, H, W, C, K, R, S, stride, pad, Ho, Wo;
 };
@@ -96,7 +110,7 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned b
 template <int MODE, int BM, int BN, int WGM, int WGN, int BKT, int PREC = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
                                                         const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
-                                                        int act, int zsplits, int order, float *__restrict__ stats) {
+                                                        int act, int zsplits, int order, float *__restrict__ stats, BnBwdSrc bnb) {
     constexpr int WTM = BM / WGM / 32, WTN = BN / WGN / 32;     // 32x32 MFMA tiles per wave
     constexpr int NT = WGM * WGN * 64;                          // 4 or 8 wavefronts per workgroup
     static_assert((WGM * WGN == 4 || WGM * WGN == 8) && WTM >= 1 && WTN >= 1, "4 or 8 waves per workgroup");
@@ -432,8 +446,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
     // ---- epilogue: C/D layout of 32x32 MFMA: col = lane & 31, row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
     // forward with `stats`: per-channel (sum, sum of squares) of this tile's valid rows, i.e. the partials BatchNorm's first
     // pass would otherwise re-read the whole output for (stats [tiles_m][K][2], same layout as bn_reduce_kernel's)
-    __shared__ float sred[MODE == 0 ? WGM * WGN : 1][MODE == 0 ? WTN * 32 : 1][2];
-    const bool want_stats = MODE == 0 && stats != nullptr && zsplits == 1;
+    // data gradient with `stats` + bnb: per-channel (sum dz, sum dz * xhat) of the tile — the partials of the BatchNorm backward whose
+    // output this convolution differentiates (same layout; rows = M-tiles x stride classes)
+    __shared__ float sred[WGM * WGN][WTN * 32][2];
+    const bool want_stats = stats != nullptr && zsplits == 1 && (MODE == 0 || bnb.x != nullptr);
+    const __amdgpu_buffer_rsrc_t bx_r = make_rsrc(MODE == 1 && want_stats ? bnb.x : out, MODE == 1 && want_stats ? (unsigned)(g.N * g.H * g.W) * (unsigned)Ncols * 4u : 0u);
+    const bool has_mask = MODE == 1 && want_stats && bnb.mask != nullptr;
+    const __amdgpu_buffer_rsrc_t bm_r = make_rsrc(has_mask ? (const float *)bnb.mask : out, has_mask ? (unsigned)(g.N * g.H * g.W) * (unsigned)Ncols / 4u : 0u);
     // output (and the data gradient's addend) through raw buffer accesses: rows beyond the tile's valid range and columns beyond
     // the channel count get an offset beyond the descriptor's extent — the store is dropped, the addend reads 0 — so the 16
     // addend loads of a tile are all in flight at once instead of one load-wait-store sequence per row
@@ -448,10 +467,12 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
         float s1 = 0.f, s2 = 0.f;
         const bool cv = col < Ncols;
         const float bv = (MODE == 0 && bias && zsplits == 1 && cv) ? bias[col] : 0.f;
+        const float bmu = (MODE == 1 && want_stats && cv) ? bnb.mean[col] : 0.f, brs = (MODE == 1 && want_stats && cv) ? bnb.rstd[col] : 0.f;
 #pragma unroll
         for (int i = 0; i < WTM; ++i) {
             unsigned off[16];
-            float addv[16];
+            float addv[16], bxv[16];
+            unsigned bmb[16];
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int ml = wm0 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -462,6 +483,13 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
             if (MODE == 1) {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) addv[e] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(add_r, off[e], 0, 0));
+                if (want_stats) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        bxv[e] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(bx_r, off[e], 0, 0));
+                        bmb[e] = has_mask ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(bm_r, off[e] >> 4, 0, 0) & 0xffu : 0xffu;
+                    }
+                }
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
@@ -474,6 +502,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
                     const float vs = off[e] != 0xffffffffu ? v : 0.f;
                     s1 += vs;
                     s2 = fmaf(vs, vs, s2);
+                } else if (want_stats) {
+                    const float dz = off[e] != 0xffffffffu ? v * bn_bwd_act(bmb[e], col & 3, bnb.act) : 0.f;
+                    s1 += dz;
+                    s2 = fmaf(dz, (bxv[e] - bmu) * brs, s2);
                 }
             }
         }
@@ -497,7 +529,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
                 a1 += sred[wmi * WGN + wn][cl][0];
                 a2 += sred[wmi * WGN + wn][cl][1];
             }
-            float *o = stats + ((size_t)(m0 / BM) * Ncols + n0 + t) * 2;
+            float *o = stats + ((size_t)(MODE == 0 ? m0 / BM : tile_m_all) * Ncols + n0 + t) * 2;
             o[0] = a1;
             o[1] = a2;
         }
@@ -519,7 +551,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
 template <int MODE, int WTM, int WM, int WN, int WK, int R = 3>
 __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 2 : 3)) void conv3x3_halo_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
                                                                     const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
-                                                                    int act, int zsplits, float *__restrict__ stats) {
+                                                                    int act, int zsplits, float *__restrict__ stats, BnBwdSrc bnb) {
     constexpr int TH = 2 * WTM, TW = 16, PW = TW + R - 1, PH = TH + R - 1, HP = PH * PW;   // output patch, input patch (R x R taps)
     constexpr int RS = R * R, RING = RS % 3 == 0 ? 3 : 4;                          // filter-fragment ring: its size divides the taps of a chunk
     static_assert((R == 3 || R == 4) && (R == 3 || MODE == 0) && RS % RING == 0, "3x3, or 4x4 forward (the space-to-depth stems)");
@@ -706,12 +738,18 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
     const bool has_add = MODE == 1 && bias != nullptr && zsplits == 1;
     const __amdgpu_buffer_rsrc_t add_r = make_rsrc(has_add ? bias : out, has_add ? out_bytes : 0u);
     const float bv = (MODE == 0 && bias && zsplits == 1 && colv) ? bias[col] : 0.f;
+    const bool want_stats = stats != nullptr && zsplits == 1 && (MODE == 0 || bnb.x != nullptr);
+    const bool bstats = MODE == 1 && want_stats, has_mask = bstats && bnb.mask != nullptr;
+    const __amdgpu_buffer_rsrc_t bx_r = make_rsrc(bstats ? bnb.x : out, bstats ? out_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t bm_r = make_rsrc(has_mask ? (const float *)bnb.mask : out, has_mask ? out_rows * (unsigned)Ncols / 4u : 0u);
+    const float bmu = (bstats && colv) ? bnb.mean[col] : 0.f, brs = (bstats && colv) ? bnb.rstd[col] : 0.f;
     float s1 = 0.f, s2 = 0.f;
     if (writer) {
 #pragma unroll
     for (int i = 0; i < WS; ++i) {
         unsigned off[16];
-        float addv[16];
+        float addv[16], bxv[16];
+        unsigned bmb[16];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int ml = (wmi * WS + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -722,6 +760,13 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
         if (MODE == 1) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) addv[e] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(add_r, off[e], 0, 0));
+            if (bstats) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    bxv[e] = __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(bx_r, off[e], 0, 0));
+                    bmb[e] = has_mask ? (unsigned)__builtin_amdgcn_raw_buffer_load_b8(bm_r, off[e] >> 4, 0, 0) & 0xffu : 0xffu;
+                }
+            }
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -734,11 +779,15 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
                 const float vs = off[e] != 0xffffffffu ? v : 0.f;
                 s1 += vs;
                 s2 = fmaf(vs, vs, s2);
+            } else if (bstats) {
+                const float dz = off[e] != 0xffffffffu ? v * bn_bwd_act(bmb[e], col & 3, bnb.act) : 0.f;
+                s1 += dz;
+                s2 = fmaf(dz, (bxv[e] - bmu) * brs, s2);
             }
         }
     }
     }
-    if (MODE == 0 && stats != nullptr && zsplits == 1) {      // BatchNorm partials of this patch: stats[patch][K][2]
+    if (want_stats) {      // BatchNorm partials of this patch: stats[patch][channels][2] (forward: of y; data gradient: of the BatchNorm backward)
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
         if (WM > 1) {                                         // the waves stacked along the pixels add up in wave order
@@ -1564,20 +1613,20 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
 #define LAUNCH_GEMM_P(MODE, BM, BN, WGM, WGN, BKT, PREC)                                                                 \
     hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT, PREC>),                                           \
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(256), 0, st, \
-                       a_src, w, bias, dst, g, act, p.z, order, stats)
+                       a_src, w, bias, dst, g, act, p.z, order, stats, bnb)
 #define LAUNCH_GEMM(MODE, BM, BN, WGM, WGN, BKT) LAUNCH_GEMM_P(MODE, BM, BN, WGM, WGN, BKT, 0)
 #define LAUNCH_GEMM8(MODE, BM, BN, WGM, WGN, BKT)                                                                       \
     hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT, 0>),                                              \
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(512), 0, st, \
-                       a_src, w, bias, dst, g, act, p.z, order, stats)
+                       a_src, w, bias, dst, g, act, p.z, order, stats, bnb)
 #define LAUNCH_HALO4(WTM, WM, WN, WK)                                                                                      \
     hipLaunchKernelGGL((conv3x3_halo_kernel<0, WTM, WM, WN, WK, 4>),                                                         \
                        dim3(g.N * ((g.H + 2 * WTM - 1) / (2 * WTM)) * ((g.W + 15) / 16) * ((Ncols + WN * 32 - 1) / (WN * 32)), 1, p.z), \
-                       dim3(WM * WN * WK * 64), 0, st, a_src, w, bias, dst, g, act, p.z, stats)
+                       dim3(WM * WN * WK * 64), 0, st, a_src, w, bias, dst, g, act, p.z, stats, bnb)
 #define LAUNCH_HALO(MODE, WTM, WM, WN, WK)                                                                                 \
     hipLaunchKernelGGL((conv3x3_halo_kernel<MODE, WTM, WM, WN, WK>),                                                         \
                        dim3(g.N * ((g.H + 2 * WTM - 1) / (2 * WTM)) * ((g.W + 15) / 16) * ((Ncols + WN * 32 - 1) / (WN * 32)), 1, p.z), \
-                       dim3(WM * WN * WK * 64), 0, st, a_src, w, bias, dst, g, act, p.z, stats)
+                       dim3(WM * WN * WK * 64), 0, st, a_src, w, bias, dst, g, act, p.z, stats, bnb)
 #define DISPATCH_GEMM(MODE)                                                      \
     if (p.halo && g.R == 4) {                /* 4x4 taps: the space-to-depth stems (forward only); few input channels: waves split pixels */ \
         if (MODE == 0) {                                                         \
@@ -1642,7 +1691,7 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     else LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 16, PR);
 
 static int launch_gemm(int mode, const float *a_src, const float *w, const float *bias, float *out, float *ws, const ConvGeom &g,
-                       int act, void *stream, float *stats = nullptr) {
+                       int act, void *stream, float *stats = nullptr, BnBwdSrc bnb = BnBwdSrc{nullptr, nullptr, nullptr, nullptr, 0}) {
     const int ncls = mode == 0 ? 1 : g.stride * g.stride;
     const int Mcls = mode == 0 ? g.N * g.Ho * g.Wo : g.N * ((g.H + g.stride - 1) / g.stride) * ((g.W + g.stride - 1) / g.stride);
     const int Mrows = mode == 0 ? g.N * g.Ho * g.Wo : g.N * g.H * g.W;
@@ -1800,6 +1849,38 @@ extern "C" int sqd_conv_dgrad(const float *dy, const float *w, const float *adde
     SQD_CHECK_ARG(addend != dx, "sqd_conv_dgrad: addend must not alias dx");
     if (launch_gemm(1, dy, w, addend, dx, ws, g, 0, stream)) return SQD_EINVAL;
     SQD_CHECK_LAUNCH("sqd_conv_dgrad");
+    return SQD_OK;
+}
+
+// Rows of BatchNorm-backward partials sqd_conv_dgrad_bn writes for this geometry under the current plan ([rows][C][2] floats: per-channel
+// sum dz and sum dz * xhat of a tile of input pixels): M-tiles x stride classes, one row per patch for the input-patch plans, 0 when the
+// plan splits the reduction (the partials are then not produced: run the BatchNorm backward's own reduction).
+extern "C" int sqd_conv_dgrad_stats_rows(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo) {
+    ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
+    const GemmPlan p = plan_gemm(1, g);
+    if (p.z > 1) return 0;
+    if (p.halo) return N * ((H + p.bm / 16 - 1) / (p.bm / 16)) * ((W + 15) / 16);
+    const int Mcls = N * ((H + stride - 1) / stride) * ((W + stride - 1) / stride);
+    return stride * stride * ((Mcls + p.bm - 1) / p.bm);
+}
+
+// sqd_conv_dgrad + the partial sums of the BatchNorm backward whose output act(BN(bn_x)) this convolution differentiates (dx, i.e.
+// dgrad + addend, must be the COMPLETE gradient of that output): bn_x [N,H,W,C] the BatchNorm's input, bn_mask its sign bytes
+// ([N*H*W*C/4], NULL without activation), bn_mean / bn_rstd [C], bn_act 0 | 1 (ReLU) | 2 (LeakyReLU 0.01)
+// -> stats [sqd_conv_dgrad_stats_rows][C][2], consumed by sqd_bn_train_bwd_pre.  stats == NULL: plain sqd_conv_dgrad.
+extern "C" int sqd_conv_dgrad_bn(const float *dy, const float *w, const float *addend, float *dx, float *ws, const float *bn_x,
+                                 const unsigned char *bn_mask, const float *bn_mean, const float *bn_rstd, int bn_act, float *stats, int N,
+                                 int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream) {
+    SQD_CHECK_ARG(dy && w && dx, "sqd_conv_dgrad_bn: null pointer");
+    SQD_CHECK_ARG(!stats || (bn_x && bn_mean && bn_rstd && bn_act >= 0 && bn_act <= 2 && (bn_mask || bn_act == 0)),
+                  "sqd_conv_dgrad_bn: the statistics need bn_x, bn_mean, bn_rstd and (for ReLU / LeakyReLU) bn_mask");
+    ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
+    if (check_geom("sqd_conv_dgrad_bn", g)) return SQD_EINVAL;
+    SQD_CHECK_ARG(K % 4 == 0 && C % 4 == 0, "sqd_conv_dgrad_bn: K=%d and C=%d must be multiples of 4", K, C);
+    SQD_CHECK_ARG(addend != dx, "sqd_conv_dgrad_bn: addend must not alias dx");
+    const BnBwdSrc bnb = {stats ? bn_x : nullptr, bn_mask, bn_mean, bn_rstd, bn_act};
+    if (launch_gemm(1, dy, w, addend, dx, ws, g, 0, stream, stats, bnb)) return SQD_EINVAL;
+    SQD_CHECK_LAUNCH("sqd_conv_dgrad_bn");
     return SQD_OK;
 }
 

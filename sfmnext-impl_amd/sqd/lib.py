@@ -164,6 +164,9 @@ _SIGNATURES = {
     "sqd_conv_plan": (_I, [_I] * 12 + [ctypes.POINTER(ctypes.c_int64)]),
     "sqd_conv_fwd_stats_rows": (_I, [_I] * 11),
     "sqd_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 12 + [_P]),
+    "sqd_conv_dgrad_stats_rows": (_I, [_I] * 11),
+    "sqd_conv_dgrad_bn": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P] + [_I] * 11 + [_P]),
+    "sqd_bn_train_bwd_pre": (_I, [_P] * 13 + [_I, _I, _I, _I, _P]),
     "sqd_conv_dgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
     "sqd_resize_ac_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_resize_ac_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),

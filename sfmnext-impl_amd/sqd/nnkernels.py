@@ -38,7 +38,7 @@ class BatchNormAct(torch.autograd.Function):
     (in place on the BatchNorm2d buffers); eval: running statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, pre_part=None, pre_rows=0):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, pre_part=None, pre_rows=0, shared=None):
         _require(x, "BatchNormAct input")
         x = _cl(x)
         N, C, H, W = x.shape
@@ -62,6 +62,11 @@ class BatchNormAct(torch.autograd.Function):
                                         float(momentum), code, _stream()), "bn_train_fwd")
             ctx.save_for_backward(x, mask, gamma, mean, rstd, beta if code == 3 else None)
             ctx.has_res, ctx.code = residual is not None, code
+            # what the convolution that consumes y needs to deliver this node's backward statistics from its data-gradient epilogue
+            # (sqd_conv_dgrad_bn): filled here, read by Conv2d.backward, answered through "dx" / "part" / "rows" (see batch_norm_act)
+            ctx.shared = shared if code != 3 else None
+            if ctx.shared is not None:
+                shared.update(x=x, mask=mask, mean=mean, rstd=rstd, code=code, dx=None, part=None, rows=0)
         else:
             _l.check(L.sqd_bn_eval_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                        _ptr(y), M, C, float(eps), code, _stream()), "bn_eval_fwd")
@@ -74,6 +79,12 @@ class BatchNormAct(torch.autograd.Function):
         if not ctx.training:
             raise NotImplementedError("sqd: BatchNormAct backward is implemented for training mode only")
         x, mask, gamma, mean, rstd, beta = ctx.saved_tensors
+        # the gradient that arrives is the very tensor a data-gradient epilogue wrote together with this node's two sums: skip the
+        # reduction pass (a gradient summed from several consumers is another tensor: the ordinary path)
+        sh = getattr(ctx, "shared", None)
+        pre_part, pre_rows = (sh["part"], sh["rows"]) if sh is not None and sh.get("dx") is dy and sh.get("rows", 0) > 0 else (None, 0)
+        if sh is not None:
+            sh.update(dx=None, part=None, rows=0)
         dy = _cl(dy)
         N, C, H, W = x.shape
         M = N * H * W
@@ -82,10 +93,10 @@ class BatchNormAct(torch.autograd.Function):
         dres = torch.empty_like(x, memory_format=torch.channels_last) if ctx.has_res else None
         dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
-        part = torch.empty(L.sqd_bn_nblk(M, C) * C * 2, device=x.device, dtype=torch.float32)
-        _l.check(L.sqd_bn_train_bwd(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
-                                    _ptr(dgamma), _ptr(dbeta), _ptr(part), M, C, ctx.code, _stream()), "bn_train_bwd")
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None
+        part = pre_part if pre_rows > 0 else torch.empty(L.sqd_bn_nblk(M, C) * C * 2, device=x.device, dtype=torch.float32)
+        _l.check(L.sqd_bn_train_bwd_pre(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
+                                        _ptr(dgamma), _ptr(dbeta), _ptr(part), pre_rows, M, C, ctx.code, _stream()), "bn_train_bwd")
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 
 
 class MaxPool3x3s2(torch.autograd.Function):
@@ -256,6 +267,7 @@ def _register_conv_plan(mode, geom, plan):
     key = (mode,) + tuple(geom)
     _PLAN_CACHE.pop(key, None)
     _PLAN_CACHE.pop(("s",) + tuple(geom), None)
+    _PLAN_CACHE.pop(("sd",) + tuple(geom), None)
     _l.check(_l.lib().sqd_conv_set_plan(mode, *geom, *plan), "conv_set_plan")
     CHOSEN_PLANS[("dgrad" if mode else "fwd",) + tuple(geom)] = tuple(plan)
 
@@ -744,6 +756,7 @@ class Conv2d(torch.autograd.Function):
             _WEIGHT_USES[ctx.wkey] = _WEIGHT_USES.get(ctx.wkey, 0) + 1
         ctx.geom = (N, H, W, C, K, R, S, stride, pad, Ho, Wo)
         ctx.has_bias, ctx.act = bias is not None, act
+        ctx.bn_src = getattr(x, "_sqd_bn_src", None)     # x is the output of a training-mode BatchNormAct: see backward
         if skip:
             return y, x.view_as(x)
         return y
@@ -795,11 +808,31 @@ class Conv2d(torch.autograd.Function):
                 _tune_conv(1, ctx.geom, lambda ws: L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(g_skip), _ptr(dx), _ptr(ws), N, H, W, C, K, R,
                                                                     S, stride, pad, Ho, Wo, _stream()))
             ws = _conv_ws(1, ctx.geom, dy.device)
-            _l.check(L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(g_skip), _ptr(dx), _ptr(ws), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
-                                      _stream()), "conv_dgrad")
+            src = ctx.bn_src
+            rows = conv_dgrad_stats_rows(ctx.geom) if src is not None and src.get("x") is not None else 0
+            if rows > 0:
+                # dx (= data gradient + the second path's gradient) is the complete gradient of a BatchNorm's output: the epilogue
+                # also writes that BatchNorm backward's per-channel partial sums, and the node finds them through `src`
+                stats = torch.empty(rows * C * 2, device=dy.device, dtype=torch.float32)
+                _l.check(L.sqd_conv_dgrad_bn(_ptr(dy), _ptr(w), _ptr(g_skip), _ptr(dx), _ptr(ws), _ptr(src["x"]), _ptr(src["mask"]),
+                                             _ptr(src["mean"]), _ptr(src["rstd"]), src["code"], _ptr(stats), N, H, W, C, K, R, S, stride, pad,
+                                             Ho, Wo, _stream()), "conv_dgrad_bn")
+                src.update(dx=dx, part=stats, rows=rows)
+            else:
+                _l.check(L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(g_skip), _ptr(dx), _ptr(ws), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
+                                          _stream()), "conv_dgrad")
         elif g_skip is not None:
             dx = g_skip
         return dx, dw, db, None, None, None, None, None, None
+
+
+def conv_dgrad_stats_rows(geom):
+    """rows of BatchNorm-backward partials the data gradient of this geometry writes under its current plan (0: none)"""
+    key = ("sd",) + tuple(geom)
+    n = _PLAN_CACHE.get(key)
+    if n is None:
+        n = _PLAN_CACHE[key] = _l.lib().sqd_conv_dgrad_stats_rows(*geom)
+    return n
 
 
 def conv_stats_rows(geom):
@@ -932,6 +965,7 @@ def conv_out_geom(x, conv, s2d=False):
     return (N, H, W, C, K, R, S, st, pd, (H + 2 * pd - R) // st + 1, (W + 2 * pd - S) // st + 1)
 
 
+FUSE_BN_BWD_STATS = True      # BatchNorm-backward sums from the consuming convolution's data-gradient epilogue (tools may switch it off)
 _DEFER_COUNTERS = False
 _PENDING_COUNTERS = []
 
@@ -958,9 +992,13 @@ def batch_norm_act(x, bn, act, residual=None, pre_part=None, pre_rows=0):
             _PENDING_COUNTERS.append(bn.num_batches_tracked)
         else:
             bn.num_batches_tracked.add_(1)
-    return BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, training,
-                              0.1 if bn.momentum is None else bn.momentum, bn.eps, act, pre_part if training else None,
-                              pre_rows if training else 0)
+    shared = {} if training and FUSE_BN_BWD_STATS else None
+    out = BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, training,
+                             0.1 if bn.momentum is None else bn.momentum, bn.eps, act, pre_part if training else None,
+                             pre_rows if training else 0, shared)
+    if shared:
+        out._sqd_bn_src = shared          # read by the Conv2d node that takes `out` as its input
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -1,0 +1,105 @@
+"""BatchNorm-backward statistics from the consuming convolution's data-gradient epilogue (sqd_conv_dgrad_bn + sqd_bn_train_bwd_pre):
+the fused path must be TAKEN where it applies, must agree with the unfused path and with float64, and must step aside when the
+gradient of the BatchNorm output is a sum over several consumers."""
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _chain(conv1, bn, conv2, x, act, res=None, double=False):
+    y = conv1(x)
+    z = bn(y) if res is None else bn(y) + res
+    z = F.relu(z) if act == "relu" else F.leaky_relu(z, 0.01) if act == "leaky_relu" else z
+    return conv2(z)
+
+
+@pytest.mark.parametrize("N,C,H,W,Cm,K,R2,stride2,act,with_res,plan2", [
+    (3, 32, 20, 28, 64, 48, 1, 1, "relu", False, (64, 64, 1, 16)),            # 1x1 consumer
+    (2, 32, 21, 37, 64, 32, 3, 1, "relu", False, (128, 64, 1, 16)),           # 3x3 consumer, ragged tiles
+    (2, 32, 24, 40, 64, 64, 3, 1, "leaky_relu", False, (64, 64, 1, 32 + 1024 + 2048)),      # the input-patch data gradient
+    (2, 64, 24, 40, 64, 128, 3, 2, "relu", True, (64, 64, 1, 16)),            # stride-2 consumer (4 stride classes), residual into the BatchNorm
+    (2, 64, 24, 40, 64, 128, 3, 2, "relu", False, None),                      # whatever the cost model picks
+    (2, 32, 16, 24, 64, 32, 1, 1, None, False, (64, 64, 1, 32 + 1024)),                      # no activation, three-term plan
+    (2, 64, 12, 20, 256, 64, 1, 1, "relu", False, (128, 64, 2, 16)),                        # split reduction: no partials, ordinary path
+])
+def test_bn_backward_statistics_from_the_dgrad_epilogue(N, C, H, W, Cm, K, R2, stride2, act, with_res, plan2):
+    from sqd import lib, nnkernels, nnops
+    L = lib.lib()
+    torch.manual_seed(C + K + H)
+    conv1, bn, conv2 = nn.Conv2d(C, Cm, 1, bias=False), nn.BatchNorm2d(Cm), nn.Conv2d(Cm, K, R2, stride2, R2 // 2, bias=False)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(N, C, H, W)
+    res = torch.randn(N, Cm, H, W) if with_res else None
+    # float64 reference
+    import copy
+    c1, b1, c2 = copy.deepcopy(conv1).double(), copy.deepcopy(bn).double(), copy.deepcopy(conv2).double()
+    xr = x.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if with_res else None
+    out_r = _chain(c1, b1, c2, xr, act, rr)
+    g = torch.randn_like(out_r)
+    out_r.backward(g)
+    geom2 = (N, H, W, Cm, K, R2, R2, stride2, R2 // 2, out_r.shape[2], out_r.shape[3])
+    nnkernels.reset_plans()
+    results = {}
+    try:
+        for fused in (True, False):
+            nnkernels.FUSE_BN_BWD_STATS = fused
+            nnkernels._PLAN_CACHE.clear()
+            if plan2 is not None:
+                assert L.sqd_conv_set_plan(1, *geom2, *plan2) == 0, L.sqd_last_error()
+            m1, mb, m2 = copy.deepcopy(conv1).cuda().to(memory_format=torch.channels_last), copy.deepcopy(bn).cuda(), \
+                copy.deepcopy(conv2).cuda().to(memory_format=torch.channels_last)
+            xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            rg = res.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) if with_res else None
+            z = nnops.conv_bn_act(xg, m1, mb, act, residual=rg)
+            assert (getattr(z, "_sqd_bn_src", None) is not None) == fused
+            out = nnops.conv2d(z, m2)
+            rows = nnkernels.conv_dgrad_stats_rows(geom2)
+            out.backward(g.float().cuda())
+            results[fused] = (out.detach().cpu().double(), xg.grad.cpu().double(), m1.weight.grad.cpu().double(), mb.weight.grad.cpu().double(),
+                              mb.bias.grad.cpu().double(), rg.grad.cpu().double() if with_res else None, rows)
+    finally:
+        nnkernels.FUSE_BN_BWD_STATS = True
+        L.sqd_conv_set_plan(1, *geom2, 0, 0, 0, 16)
+        nnkernels.reset_plans()
+    if plan2 is not None:
+        assert (results[True][6] > 0) == (plan2[2] == 1), results[True][6]          # the fused path ran exactly where the plan allows it
+    refs = (out_r.detach(), xr.grad, c1.weight.grad, b1.weight.grad, b1.bias.grad, rr.grad if with_res else None)
+    for name, i in (("out", 0), ("dx", 1), ("dW1", 2), ("dgamma", 3), ("dbeta", 4), ("dres", 5)):
+        if refs[i] is None:
+            continue
+        scale = float(refs[i].abs().max())
+        ef, eu = float((results[True][i] - refs[i]).abs().max()) / scale, float((results[False][i] - refs[i]).abs().max()) / scale
+        # gradients through BatchNorm are differences of large sums: both paths sit at the same fp32 level against float64
+        assert ef <= 2e-4 and ef <= 4.0 * eu + 2e-6, (name, "fused", ef, "unfused", eu)
+
+
+def test_summed_gradient_takes_the_ordinary_path():
+    """the BatchNorm output feeds the convolution AND a second consumer directly (no skip hand-over): autograd sums the two gradients,
+    the tensor the BatchNorm node receives is not the data gradient's, and the node must run its own reduction — results as float64"""
+    from sqd import nnkernels, nnops
+    import copy
+    torch.manual_seed(4)
+    N, C, H, W, Cm = 2, 32, 16, 24, 32
+    conv1, bn, conv2 = nn.Conv2d(C, Cm, 1, bias=False), nn.BatchNorm2d(Cm), nn.Conv2d(Cm, Cm, 3, 1, 1, bias=False)
+    x = torch.randn(N, C, H, W)
+    c1, b1, c2 = copy.deepcopy(conv1).double(), copy.deepcopy(bn).double(), copy.deepcopy(conv2).double()
+    xr = x.double().requires_grad_(True)
+    zr = F.relu(b1(c1(xr)))
+    out_r = c2(zr) + 0.5 * zr
+    g = torch.randn_like(out_r)
+    out_r.backward(g)
+    m1, mb, m2 = conv1.cuda().to(memory_format=torch.channels_last), bn.cuda(), conv2.cuda().to(memory_format=torch.channels_last)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    z = nnops.conv_bn_act(xg, m1, mb, "relu")
+    out = nnops.conv2d(z, m2) + 0.5 * z
+    out.backward(g.float().cuda())
+    assert z._sqd_bn_src["dx"] is None and z._sqd_bn_src["rows"] == 0           # consumed / reset by the BatchNorm node
+    for got, ref, name in ((xg.grad, xr.grad, "dx"), (mb.weight.grad, b1.weight.grad, "dgamma"), (mb.bias.grad, b1.bias.grad, "dbeta")):
+        err = float((got.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 2e-4, (name, err)
