@@ -32,7 +32,8 @@ res = {"kernel_source_hash": bench.kernel_source_hash(), "judged_kernel": "photo
        "calibration_factor": {k: round(v, 4) for k, v in cal.items()}, "kernels": {}}
 for name in ("photo_tile_kernel<1>", "photo_tile_kernel<0>", "photo_tile_kernel<2>", "photo_bwd_tile_kernel"):
     try:
-        fr, wr = avg(name, "FETCH_SIZE"), avg(name, "WRITE_SIZE")
+        sub = name.rstrip(">")                  # (the kernels carry a second template argument — waves per workgroup — in their names)
+        fr, wr = avg(sub, "FETCH_SIZE"), avg(sub, "WRITE_SIZE")
     except SystemExit:
         continue
     res["kernels"][name] = {"fetch_reported_bytes": round(fr), "write_reported_bytes": round(wr),

@@ -5,7 +5,7 @@ import sqlite3
 import sys
 
 db, out, title = sys.argv[1:4]
-marker = sys.argv[4] if len(sys.argv) > 4 else "photo_tile_kernel<1>"
+marker = sys.argv[4] if len(sys.argv) > 4 else "photo_tile_kernel<1"
 workload = sys.argv[5] if len(sys.argv) > 5 else "config B (ResNet-50, B=12, 192x640, fp32, 1 x MI355X)"
 c = sqlite3.connect(db)
 rows = c.execute("select name, start, end from kernels order by start").fetchall()
@@ -27,7 +27,7 @@ with open(out, "w") as f:
     f.write("| us/step | calls/step | avg us | kernel |\n|---:|---:|---:|---|\n")
     for name, t in tot.most_common(70):
         f.write("| %.1f | %.1f | %.1f | `%s` |\n" % (t / n / 1e3, cnt[name] / n, t / cnt[name] / 1e3, name[:120].replace("|", "/")))
-    for key in ("photo_fwd_kernel<2, 1>", "photo_tile_kernel<1>", "photo_tile_kernel<0>", "photo_tile_kernel<2>", "photo_bwd_tile_kernel", "sql_fwd_kernel", "sql_bwd_kernel"):
+    for key in ("photo_tile_kernel<1", "photo_tile_kernel<0", "photo_tile_kernel<2", "photo_bwd_tile_kernel", "sql_fwd_kernel", "sql_bwd"):
         pk = [(e - s) / 1e3 for name, s, e in rows if key in name]
         if pk:
             f.write("\n`%s`: %d dispatches in the whole run, avg %.2f us, min %.2f us\n" % (key, len(pk), sum(pk) / len(pk), min(pk)))
