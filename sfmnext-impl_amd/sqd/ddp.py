@@ -20,6 +20,10 @@ import os
 import torch
 import torch.distributed as dist
 
+# the host driver supports dmabuf IPC only: RCCL's peer mappings need this in the environment before the HIP runtime starts (it is exported
+# on the pool's boxes already; set here at import, long before the first device call, for launchers that scrub the environment)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 COMM = None          # the data-plane communicator of this process (RcclComm on a GPU, GlooComm in the CPU tests), set by init_from_env
 
 
@@ -110,8 +114,6 @@ def init_from_env(backend=None):
     if (world > 1 or force) and COMM is None:
         gpu = backend != "gloo" and torch.cuda.is_available()
         if gpu:
-            # the host driver supports dmabuf IPC only: RCCL's peer mappings need this before the HIP runtime starts
-            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             torch.cuda.set_device(local)
         if not dist.is_initialized():
             dist.init_process_group(backend="gloo", rank=rank, world_size=world)
