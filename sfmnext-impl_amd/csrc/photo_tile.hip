@@ -182,6 +182,34 @@ __device__ __forceinline__ void accumulate_row(Sums &A, const Raw &R) {
 // launch; S = 3 (--use_stereo: frame_ids [0,-1,1,"s"], reference trainer.py:52-53) runs pairs (0,1) and (2,2): the running
 // per-pixel minimum and its argmin travel between the launches through the `sel` / `idx` outputs, in the candidate order of
 // torch.cat + torch.min (identity_0..S-1, reproj_0..S-1 — first minimum wins).
+// Tiling of a launch.  Uniform: every (image, column strip) is cut into nsy tiles of TR rows.  Balanced (n_lo > 0; the fused forward's
+// default where it applies): the first n_hi_cols of the B * nsx image columns are cut into n_lo + 1 nearly equal tiles, the others into
+// n_lo, so that the launch has a whole number of tiles per CU — all of (nearly) the same cost: 1024 tiles of 24..28 rows at config B
+// instead of 1584 of 16 (6.19 per CU) or 924 of 28 (3.61 per CU): -3 % (49.6 against 51.2 us).
+struct Tiling {
+    int TR, nsx, nsy, ntiles, nblk8;
+    int n_lo, n_hi_cols;
+};
+__device__ __forceinline__ void tile_of(const Tiling &tl, int tile, int H, int &b, int &tx, int &y0, int &own_rows) {
+    if (tl.n_lo <= 0) {
+        tx = tile % tl.nsx;
+        const int t2 = tile / tl.nsx, ty = t2 % tl.nsy;
+        b = t2 / tl.nsy;
+        y0 = ty * tl.TR;
+        own_rows = min(tl.TR, H - y0);
+        return;
+    }
+    const int nhi = tl.n_hi_cols * (tl.n_lo + 1);
+    int col, k, n;
+    if (tile < nhi) { n = tl.n_lo + 1; col = tile / n; k = tile - col * n; }
+    else { n = tl.n_lo; const int t2 = tile - nhi; col = tl.n_hi_cols + t2 / n; k = t2 - (t2 / n) * n; }
+    b = col / tl.nsx;
+    tx = col - b * tl.nsx;
+    const int Hh = (H + 1) / 2;                          // tiles start on even rows (phase 2 works on row pairs)
+    y0 = 2 * ((k * Hh) / n);
+    own_rows = min(H, 2 * (((k + 1) * Hh) / n)) - y0;
+}
+
 struct PairPass {
     int s0, s1;        // source indices of the .x / .y halves (s1 == s0: an odd source count's last pass)
     int S;             // number of source frames
@@ -474,20 +502,18 @@ __device__ __forceinline__ void finish_cell(const sqd_photo_args &a, const PairP
 // (4 workgroups of 4 waves per CU: the register allocator is held to 128 VGPRs; the kernel needs 118.  NW = 8: two workgroups of 8
 //  waves on tiles of up to 32 rows — the same waves per SIMD, 38 instead of 2 x 22 warped rows per 32 output rows)
 template <int MODE, int NW = 4>
-__global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_args a, PairPass pp, const float *__restrict__ noise, int TR, int nsx,
-                                                          int nsy, int ntiles, int nblk8) {
+__global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_args a, PairPass pp, const float *__restrict__ noise, Tiling tl) {
     extern __shared__ v2f wl[];                       // MODE 1: [TR + 6][3][64] (source 0, source 1) warped colours
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // consecutive tiles (which share halo rows / columns) on the same XCD: workgroup i runs on XCD i % 8
-    const int tile = (blockIdx.x & 7) * nblk8 + (blockIdx.x >> 3);
-    if (tile >= ntiles) return;
-    const int H = a.H, W = a.W;
+    const int tile = (blockIdx.x & 7) * tl.nblk8 + (blockIdx.x >> 3);
+    if (tile >= tl.ntiles) return;
+    const int H = a.H, W = a.W, nsx = tl.nsx;
     const unsigned HW = (unsigned)(H * W);
-    const int tx = tile % nsx, t2 = tile / nsx, ty = t2 % nsy, b = t2 / nsy;
+    int tx, b, y0, own_rows;
+    tile_of(tl, tile, H, b, tx, y0, own_rows);
     const StripX sx = strip_x(tx, nsx, W);
-    const int y0 = ty * TR;
-    const int own_rows = min(TR, H - y0);
     const int x = sx.x0 + lane;                                   // this lane's column
     const int xr = sx.virt ? reflect_idx(x, W) : x;               // column it loads (virtual strip: reflected halo)
     const bool col_ok = xr >= 0 && xr < W;
@@ -798,10 +824,10 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_tile_kernel(sqd_photo_bwd_ar
     }
 }
 
-// rows a workgroup tile owns: the caller's rows_per_task (even, clamped), or the measured default of the kernel family — at config B
-// (B 12, 192x640; profiles/r03m_photo_tile_heights.md): fused forward 8 waves x 28 rows 51.0 us (4 x 16: 56.8, 4 x 14: 53.5, 8 x 32:
-// 56.4, 8 x 30: 52.0 — tiles per CU and their halo both count), identity / coefficient kernels 12 rows (31.4 / 33.2 us against 33.1 /
-// 37.2 at 16), backward 16 (flat)
+// rows a workgroup tile owns: the caller's rows_per_task (even, clamped), or the default of the kernel family.  Measured at config B
+// after a proper warm-up (profiles/r03m_photo_tile_heights.md): every uniform shape of the fused forward within 1.5 % of the others
+// (4 x 16: 51.2 us, 8 x 28: 50.7), identity / coefficient / backward kernels flat in the tile height — what does count is a whole number
+// of tiles per CU (make_tiling's balanced cut: 49.6 us)
 enum { FAMILY_FWD = 1, FAMILY_ROWS = 0, FAMILY_BWD = 2 };
 int pick_tr(int rows, int family, int H) {
     const int cap = family == FAMILY_FWD && (rows > TR_MAX || (rows <= 0 && H >= 56)) ? 2 * TR_MAX : TR_MAX;
@@ -810,34 +836,68 @@ int pick_tr(int rows, int family, int H) {
     tr &= ~1;
     return tr < 2 ? 2 : tr;
 }
+
+// the tiling of a launch: family FAMILY_FWD with rows_per_task == 0 -> balanced (a whole number of equal-cost tiles per CU, 8 waves),
+// when the image leaves tiles of 12..32 rows for that; otherwise uniform tiles of pick_tr rows
+Tiling make_tiling(int B, int H, int W, int rows_per_task, int family) {
+    Tiling tl = {};
+    tl.nsx = strips_x(W);
+    const int cols = B * tl.nsx;
+    // (only where 28-row tiles leave the last round of tiles more than 6 % empty: at config C — 1728 tiles, 6.75 per CU — the
+    //  balanced cut measured no better than the uniform one, within that shape's +-8 % run-to-run spread)
+    const int tu = cols * ((H + 27) / 28);
+    const double fill = (double)tu / 256.0, imbalance = (double)((tu + 255) / 256) / fill;
+    if (family == FAMILY_FWD && rows_per_task <= 0 && H >= 56 && imbalance > 1.06) {
+        // 256 CUs x 2 resident 8-wave workgroups: tiles in multiples of 512, as close to 26 rows each as that allows
+        const long long rows_total = (long long)cols * H;
+        int best = 0;
+        for (int t = 512; t <= 512 * 64; t += 512) {
+            const double r = (double)rows_total / t;
+            if (r < 12.0) break;
+            if (r <= 30.0 && best == 0) best = t;            // the fewest tiles (least halo) that fit the 32-row LDS tile
+        }
+        const int n_lo = best / cols, n_hi_cols = best - n_lo * cols;
+        // tallest tile of the launch: a column with n_lo tiles, cut on even rows
+        if (best > 0 && n_lo >= 1 && 2 * (((H + 1) / 2 + n_lo - 1) / n_lo) <= 2 * TR_MAX) {
+            tl.n_lo = n_lo;
+            tl.n_hi_cols = n_hi_cols;
+            tl.ntiles = best;
+            tl.TR = 2 * (((H + 1) / 2 + n_lo - 1) / n_lo);
+            tl.nsy = 0;
+            tl.nblk8 = (tl.ntiles + 7) / 8;
+            return tl;
+        }
+    }
+    tl.TR = pick_tr(rows_per_task, family, H);
+    tl.nsy = (H + tl.TR - 1) / tl.TR;
+    tl.ntiles = cols * tl.nsy;
+    tl.nblk8 = (tl.ntiles + 7) / 8;
+    return tl;
+}
 }  // namespace
 
 namespace sqd {
-// the fused forward takes tiles of up to 32 rows with 8 waves (its default above; rows_per_task 17..32), everything else 4 waves
-int photo_fwd_waves(int rows_per_task, int H) { return pick_tr(rows_per_task, FAMILY_FWD, H) > TR_MAX ? 8 : 4; }
-int photo_tile_count(int B, int H, int W, int rows_per_task, int family) {
-    const int TR = pick_tr(rows_per_task, family, H);
-    return B * strips_x(W) * ((H + TR - 1) / TR);
+int photo_fwd_waves(int B, int H, int W, int rows_per_task) {
+    const Tiling tl = make_tiling(B, H, W, rows_per_task, FAMILY_FWD);
+    return tl.TR > TR_MAX ? 8 : 4;
 }
+int photo_tile_count(int B, int H, int W, int rows_per_task, int family) { return make_tiling(B, H, W, rows_per_task, family).ntiles; }
 
 // mode 0: identity maps, 1: fused forward, 2: coefficient planes of the backward (a.warped = stored warps, a.idx, a.coef)
 void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hipStream_t stream) {
-    const int TR = pick_tr(a.rows_per_task, mode == 1 ? FAMILY_FWD : FAMILY_ROWS, a.H);
-    const int NW = mode == 1 && TR > TR_MAX ? 8 : 4;
-    const int nsx = strips_x(a.W), nsy = (a.H + TR - 1) / TR;
-    const int ntiles = a.B * nsx * nsy;
-    const int nblk8 = (ntiles + 7) / 8;
-    const dim3 grid(nblk8 * 8), block(NW * 64);
+    const Tiling tl = make_tiling(a.B, a.H, a.W, a.rows_per_task, mode == 1 ? FAMILY_FWD : FAMILY_ROWS);
+    const int NW = mode == 1 && tl.TR > TR_MAX ? 8 : 4;
+    const dim3 grid(tl.nblk8 * 8), block(NW * 64);
     for (int k = 0; 2 * k < a.S; ++k) {                  // one launch per pair of source frames
         const PairPass pp = {2 * k, 2 * k + 1 < a.S ? 2 * k + 1 : 2 * k, a.S, k == 0, 2 * k + 2 >= a.S};
         if (mode == 0)
-            hipLaunchKernelGGL((photo_tile_kernel<0>), grid, block, 0, stream, a, pp, noise, TR, nsx, nsy, ntiles, nblk8);
+            hipLaunchKernelGGL((photo_tile_kernel<0>), grid, block, 0, stream, a, pp, noise, tl);
         else if (mode == 1 && NW == 8)
-            hipLaunchKernelGGL((photo_tile_kernel<1, 8>), grid, block, (TR + 6) * 3 * 64 * 8, stream, a, pp, noise, TR, nsx, nsy, ntiles, nblk8);
+            hipLaunchKernelGGL((photo_tile_kernel<1, 8>), grid, block, (tl.TR + 6) * 3 * 64 * 8, stream, a, pp, noise, tl);
         else if (mode == 1)
-            hipLaunchKernelGGL((photo_tile_kernel<1>), grid, block, (TR + 6) * 3 * 64 * 8, stream, a, pp, noise, TR, nsx, nsy, ntiles, nblk8);
+            hipLaunchKernelGGL((photo_tile_kernel<1>), grid, block, (tl.TR + 6) * 3 * 64 * 8, stream, a, pp, noise, tl);
         else
-            hipLaunchKernelGGL((photo_tile_kernel<2>), grid, block, 0, stream, a, pp, noise, TR, nsx, nsy, ntiles, nblk8);
+            hipLaunchKernelGGL((photo_tile_kernel<2>), grid, block, 0, stream, a, pp, noise, tl);
     }
 }
 

@@ -36,7 +36,7 @@ int check_shape(const char *who, int B, int S, int H, int W, int TH) {
 }  // namespace
 
 extern "C" int sqd_photo_ntasks(int B, int H, int W, int rows_per_task) {
-    return sqd::photo_fwd_waves(rows_per_task, H) * sqd::photo_tile_count(B, H, W, rows_per_task, 1);       // one loss partial per wavefront of a tile
+    return sqd::photo_fwd_waves(B, H, W, rows_per_task) * sqd::photo_tile_count(B, H, W, rows_per_task, 1);       // one loss partial per wavefront of a tile
 }
 extern "C" int sqd_photo_bwd_ntasks(int B, int S, int H, int W, int rows_per_task) {
     return S * 4 * sqd::photo_tile_count(B, H, W, rows_per_task, 2);      // one g_P partial per wavefront of a tile and source

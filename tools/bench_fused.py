@@ -69,6 +69,12 @@ def timeit(fn, iters):
 
 
 px = B * H * W
+# the first measurement of a process reads 5-10 % slow (clocks / caches settle over the first ~100 ms of work): burn that here, or the
+# first entry of a sweep is penalised (round 3's first tile-height sweeps were: profiles/r03m_photo_tile_heights.md)
+_w = ops.identity_fwd(tgt, srcs, noise, 0)
+for _ in range(300):
+    ops.identity_fwd(tgt, srcs, noise, 0)
+torch.cuda.synchronize()
 for rows in [int(r) for r in args.rows.split(",")]:
     ident = ops.identity_fwd(tgt, srcs, noise, rows)
     res = {}
