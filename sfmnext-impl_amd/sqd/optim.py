@@ -14,10 +14,12 @@ from .ops import _stream
 class FusedAdam(torch.optim.Adam):
     HYPER_RING = 8
 
+    DECOUPLED_DECAY = False       # FusedAdamW: param_groups carry a (decoupled) weight decay
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False):
-        if weight_decay != 0 or amsgrad:
+        if (weight_decay != 0 and not self.DECOUPLED_DECAY) or amsgrad:
             raise NotImplementedError("FusedAdam implements the reference's configuration: no weight decay, no amsgrad")
-        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0, amsgrad=False, foreach=False, fused=False)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=False, foreach=False, fused=False)
         self._tables = {}
         self._ring = 0
         self._graph_hyper = None      # set by begin_capture(): {group index: (ring of (pinned host [2], event), device [2])}
@@ -196,6 +198,8 @@ class FusedAdam(torch.optim.Adam):
 
 
 class FusedAdamW(FusedAdam):
+    DECOUPLED_DECAY = True
+
     """torch.optim.AdamW (decoupled weight decay) with an optional global gradient-norm clip folded into the step — the optimiser
     side of the reference's finetune loop (finetune/train_ft_SQLdepth.py:184 `optim.AdamW(params, weight_decay=args.wd, lr=args.lr)`,
     :281 `nn.utils.clip_grad_norm_(model.parameters(), 0.1)`): one launch pair computes min(1, max_norm / (||g|| + 1e-6)) over the
@@ -205,8 +209,9 @@ class FusedAdamW(FusedAdam):
     `clip_info` holds the last (coefficient, norm) as a device tensor."""
 
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None):
-        super().__init__(params, lr=lr, betas=betas, eps=eps)
-        self.decoupled_weight_decay = float(weight_decay)
+        # the decay lives where torch.optim.AdamW keeps it — in every param_group (default from the constructor, per-group values from the
+        # caller's dicts) — so that state_dict() reports it and a reference AdamW checkpoint's value takes effect when loaded
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay)
         self.max_grad_norm = max_grad_norm
         self.clip_info = None
 
@@ -236,4 +241,4 @@ class FusedAdamW(FusedAdam):
             b1, b2 = group["betas"]
             _l.check(L.sqd_adamw_step(ctypes.c_void_p(tab["recs"].data_ptr()), ctypes.c_void_p(tab["gdev"].data_ptr()),
                                       ctypes.c_void_p(tab["chunks"].data_ptr()), tab["nchunks"], float(group["lr"]), float(b1), float(b2),
-                                      float(group["eps"]), self.decoupled_weight_decay, step, gscale, _stream()), "adamw_step")
+                                      float(group["eps"]), float(group["weight_decay"]), step, gscale, _stream()), "adamw_step")

@@ -105,6 +105,31 @@ def test_adamw_with_clipping_matches_torch():
             assert float((a.detach().cpu().double() - b.detach()).abs().max()) <= 2e-6 * float(b.detach().abs().max()) + 1e-8, step
 
 
+def test_adamw_weight_decay_lives_in_the_param_groups():
+    """the decay must be what state_dict() reports and what a loaded (reference AdamW) state dict sets — per group"""
+    from sqd.optim import FusedAdamW
+    torch.manual_seed(3)
+    ps = [torch.randn(40, 8), torch.randn(16)]
+    ref = [p.clone().double().requires_grad_(True) for p in ps]
+    mine = [p.clone().cuda().requires_grad_(True) for p in ps]
+    o_ref = torch.optim.AdamW([{"params": ref[:1], "weight_decay": 0.3}, {"params": ref[1:]}], lr=1e-2, weight_decay=0.05)
+    o_mine = FusedAdamW([{"params": mine[:1]}, {"params": mine[1:]}], lr=1e-2, weight_decay=0.0)
+    assert [g["weight_decay"] for g in o_mine.state_dict()["param_groups"]] == [0.0, 0.0]
+    sd = o_ref.state_dict()                                   # no steps taken yet: hyper-parameters only
+    o_mine.load_state_dict(sd)
+    assert [g["weight_decay"] for g in o_mine.param_groups] == [0.3, 0.05]
+    for step in range(3):
+        grads = [torch.randn_like(p) for p in ps]
+        for p, g in zip(ref, grads):
+            p.grad = g.double()
+        for p, g in zip(mine, grads):
+            p.grad = g.cuda()
+        o_ref.step()
+        o_mine.step()
+    for a, b in zip(mine, ref):
+        assert float((a.detach().cpu().double() - b.detach()).abs().max()) <= 2e-6 * float(b.detach().abs().max()) + 1e-8
+
+
 def test_finetune_step_matches_oracle():
     """two steps of FinetuneTrainer (narrow ConvNeXt U-Net + Self-Query head, median rescale, SILog, clipping, AdamW, OneCycle) against
     the oracle's restatement of train_ft_SQLdepth.py:222-285 with torch.optim.AdamW on the host"""
