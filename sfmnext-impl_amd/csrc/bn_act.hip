@@ -135,8 +135,11 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float *__restrict_
 // are 32 contiguous bytes of a partial row, so each of the 256 threads strides over the rows with two 16-byte loads per row (four
 // rows in flight), then a fixed-order reduction: DPP butterflies inside each wave, the four waves through LDS (deterministic).
 // History: one thread per channel over up to 768 partials 131 us per call; 16 lanes per channel + an LDS tree 12 us; one wave per
-// channel with 8-byte loads 5.2 us (x 120 calls per step = 0.63 ms of a 15.9 ms step: latency-bound, 11 dependent rounds of loads
-// for the 2880 partial rows of the 96x320 layers); all 256 threads on the four channels: 3 rounds.
+// channel with 8-byte loads 5.2 us.  Round 3 put all 256 threads on the four channels and eight rows in flight per thread (2880
+// partial rows = two rounds of loads instead of eleven): the in-step average stayed at 5.0 us per call — the kernel is not bound by
+// its load rounds (a replayed graph's chain of EMPTY kernels costs 1.5 us per node, tools/ubench_graph_nodes.py; the rest is this
+// kernel's launch ramp over C / 4 workgroups, its first touch of partials another XCD's L2 wrote, two barriers and the running-stat
+// read-modify-write).  120 calls x 5 us per step remain: only fewer launches remove them.
 constexpr int FIN_CH = 4;
 __device__ __forceinline__ bool finalize_sums(const float *__restrict__ part, int nblk, int C, int &c, float &s, float &ss) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -144,16 +147,25 @@ __device__ __forceinline__ bool finalize_sums(const float *__restrict__ part, in
     float4 a0 = make_float4(0.f, 0.f, 0.f, 0.f), b0 = a0, a1 = a0, b1 = a0;
     const float *p = part + (size_t)c0 * 2;
     const size_t stride = (size_t)C * 2;
-    int k = threadIdx.x;
-    for (; k + 256 < nblk; k += 512) {
-        const float4 u0 = *reinterpret_cast<const float4 *>(p + (size_t)k * stride), v0 = *reinterpret_cast<const float4 *>(p + (size_t)k * stride + 4);
-        const float4 u1 = *reinterpret_cast<const float4 *>(p + (size_t)(k + 256) * stride), v1 = *reinterpret_cast<const float4 *>(p + (size_t)(k + 256) * stride + 4);
-        a0.x += u0.x; a0.y += u0.y; a0.z += u0.z; a0.w += u0.w; b0.x += v0.x; b0.y += v0.y; b0.z += v0.z; b0.w += v0.w;
-        a1.x += u1.x; a1.y += u1.y; a1.z += u1.z; a1.w += u1.w; b1.x += v1.x; b1.y += v1.y; b1.z += v1.z; b1.w += v1.w;
-    }
-    if (k < nblk) {
-        const float4 u0 = *reinterpret_cast<const float4 *>(p + (size_t)k * stride), v0 = *reinterpret_cast<const float4 *>(p + (size_t)k * stride + 4);
-        a0.x += u0.x; a0.y += u0.y; a0.z += u0.z; a0.w += u0.w; b0.x += v0.x; b0.y += v0.y; b0.z += v0.z; b0.w += v0.w;
+    // eight rows (sixteen 16-byte loads) in flight per thread and round
+    constexpr int DEPTH = 8;
+    for (int k0 = threadIdx.x; k0 < nblk; k0 += 256 * DEPTH) {
+        float4 u[DEPTH], v[DEPTH];
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            const int k = k0 + 256 * d;
+            u[d] = v[d] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (k < nblk) {
+                u[d] = *reinterpret_cast<const float4 *>(p + (size_t)k * stride);
+                v[d] = *reinterpret_cast<const float4 *>(p + (size_t)k * stride + 4);
+            }
+        }
+#pragma unroll
+        for (int d = 0; d < DEPTH; d += 2) {
+            a0.x += u[d].x; a0.y += u[d].y; a0.z += u[d].z; a0.w += u[d].w; b0.x += v[d].x; b0.y += v[d].y; b0.z += v[d].z; b0.w += v[d].w;
+            a1.x += u[d + 1].x; a1.y += u[d + 1].y; a1.z += u[d + 1].z; a1.w += u[d + 1].w;
+            b1.x += v[d + 1].x; b1.y += v[d + 1].y; b1.z += v[d + 1].z; b1.w += v[d + 1].w;
+        }
     }
     // (sum, sum of squares) of channels c0 .. c0+3 in this thread: a = (s0, ss0, s1, ss1), b = (s2, ss2, s3, ss3)
     float v[8] = {a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w, b0.x + b1.x, b0.y + b1.y, b0.z + b1.z, b0.w + b1.w};
