@@ -25,11 +25,15 @@
 extern "C" {
 #endif
 
-#define SQD_ABI_VERSION 1
+#define SQD_ABI_VERSION 2   /* 2: loss_flags in sqd_photo_args / sqd_photo_bwd_args */
 #define SQD_OK 0
 #define SQD_EINVAL (-1)   /* bad shape / null pointer / unsupported configuration */
 #define SQD_ELAUNCH (-2)  /* hipGetLastError() after launch */
 
+/* the reference's loss options (options.py --no_ssim / --avg_reprojection / --disable_automasking; trainer.py:447-451, 480-524) */
+#define SQD_LOSS_NO_SSIM 1           /* reprojection loss = L1 alone                                                             */
+#define SQD_LOSS_AVG_REPROJECTION 2  /* mean over the source frames instead of the per-pixel minimum (two source frames)          */
+#define SQD_LOSS_NO_AUTOMASK 4       /* no identity candidates: the minimum runs over the reprojection losses only                */
 #define SQD_MAX_SOURCES 4 /* source frames per target (reference frame_ids[1:], default 2) */
 #define SQD_STRIP_COLS 58 /* output columns per wavefront strip of the column-march kernels */
 
@@ -93,6 +97,7 @@ typedef struct sqd_photo_args {
     float *reproj;          /* [B,S,H,W]  reprojection loss maps (debug/parity; may be NULL)         */
     float *loss_part;       /* [ntasks]   per-wavefront partial sums of to_optimise, ntasks = sqd_photo_ntasks(...) */
     int32_t B, S, H, W;
+    int32_t loss_flags;     /* SQD_LOSS_* bits: the reference's loss options (0 = its defaults)                  */
     int32_t rows_per_task;  /* rows a workgroup tile owns (even; <= 32 for sqd_photo_fwd — above 16: 8-wave workgroups —, <= 16 elsewhere);
                                0 = the kernel family's measured default (fused forward 28, identity / coefficient maps 12, backward 16) */
     void *stream;
@@ -106,6 +111,10 @@ int sqd_photo_fwd(const sqd_photo_args *a);
  * -> identity [B,S,H,W].                                                                              */
 int sqd_identity_fwd(const float *target, const float *const *sources_host, const float *noise, float *identity,
                      int B, int S, int H, int W, int rows_per_task, void *stream);
+/* the same under loss options: SQD_LOSS_NO_SSIM -> L1 maps; SQD_LOSS_AVG_REPROJECTION -> identity and noise are [B,1,H,W]: ONE map per
+ * image, the mean over the two sources + 1e-5 * noise (sqd_photo_fwd reads identity in that layout under the same flag)        */
+int sqd_identity_fwd_ex(const float *target, const float *const *sources_host, const float *noise, float *identity,
+                        int B, int S, int H, int W, int rows_per_task, int loss_flags, void *stream);
 
 /* d(to_optimise)/d(7x7 window sums) of the winning source — the "coefficient planes" the backward box-filters — from the
  * warped images sqd_photo_fwd stored: target [B,3,H,W], warped_host[S] device pointers to [B,3,H,W], idx [B,H,W] the argmin
@@ -114,6 +123,10 @@ int sqd_identity_fwd(const float *target, const float *const *sources_host, cons
  * training-only traffic.                                                                                                */
 int sqd_photo_coef(const float *target, const float *const *warped_host, const uint8_t *idx, float *coef, int B, int S, int H,
                    int W, int rows_per_task, void *stream);
+/* under loss options: SQD_LOSS_NO_SSIM -> zeros; SQD_LOSS_AVG_REPROJECTION -> coef [B,18,H,W]: planes 0..8 source 0, 9..17 source 1, each
+ * with weight 1/2 where the mean reprojection won                                                                               */
+int sqd_photo_coef_ex(const float *target, const float *const *warped_host, const uint8_t *idx, float *coef, int B, int S, int H,
+                      int W, int rows_per_task, int loss_flags, void *stream);
 
 /* backward of sqd_photo_fwd w.r.t. depth and P.  gscale = dL/d(mean to_optimise) / (B*H*W).
  * Tile kernel (same tiles as the forward), both sources of a pair in one pass, one launch per pair of source frames:
@@ -132,6 +145,7 @@ typedef struct sqd_photo_bwd_args {
     int64_t g_depth_img_stride; /* >= ceil(S/2)*H*W */
     float gscale;
     int32_t B, S, H, W;
+    int32_t loss_flags;     /* SQD_LOSS_* bits, as given to sqd_photo_fwd / sqd_photo_coef_ex                                   */
     int32_t rows_per_task;  /* rows a workgroup tile owns (even, <= 16); 0 = library default (16) */
     void *stream;
 } sqd_photo_bwd_args;

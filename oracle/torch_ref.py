@@ -199,38 +199,53 @@ def smooth_loss(disp: torch.Tensor, img: torch.Tensor) -> torch.Tensor:
 
 def compute_losses(disp: torch.Tensor, target: torch.Tensor, warped: Dict[int, torch.Tensor],
                    sources: Dict[int, torch.Tensor], frame_ids: Sequence[int], noise: torch.Tensor,
-                   H: int, W: int, disparity_smoothness: float = 1e-3) -> Dict:
-    """reference trainer.py:455-549 at the default options (automasking on, min-reprojection, scale 0).
+                   H: int, W: int, disparity_smoothness: float = 1e-3, no_ssim: bool = False,
+                   avg_reprojection: bool = False, disable_automasking: bool = False) -> Dict:
+    """reference trainer.py:455-549 at scale 0, with its three loss options (defaults: automasking on, per-pixel minimum, SSIM on).
 
-    `noise` [B,S,H,W] stands for `torch.randn(shape)` of trainer.py:516 (already un-scaled; the 1e-5
-    factor is applied here).  Returns loss, loss/0, identity_selection/0, and the intermediate maps."""
+    `noise` stands for `torch.randn(identity_reprojection_loss.shape)` of trainer.py:516 — [B,S,H,W], or [B,1,H,W] under
+    avg_reprojection (already un-scaled; the 1e-5 factor is applied here); unused without automasking.  Returns loss, loss/0,
+    identity_selection/0 (automasking only, :528-530) and the intermediate maps."""
     srcs = list(frame_ids[1:])
-    reproj = torch.cat([reprojection_loss(warped[f], target) for f in srcs], 1)       # :474-478
-    ident = torch.cat([reprojection_loss(sources[f], target) for f in srcs], 1)       # :480-487
-    ident = ident + noise * 0.00001                                                   # :514-517
-    combined = torch.cat((ident, reproj), dim=1)                                      # :519
-    to_optimise, idxs = torch.min(combined, dim=1)                                    # :526
-    sel = (idxs > ident.shape[1] - 1).float()                                         # :529-530
-    loss = to_optimise.mean()                                                         # :532
+    reproj = torch.cat([reprojection_loss(warped[f], target, no_ssim) for f in srcs], 1)       # :474-478 (:447-451)
+    ident = None
+    if not disable_automasking:
+        ident = torch.cat([reprojection_loss(sources[f], target, no_ssim) for f in srcs], 1)   # :480-487
+        if avg_reprojection:
+            ident = ident.mean(1, keepdim=True)                                               # :489-490
+    reproj_c = reproj.mean(1, keepdim=True) if avg_reprojection else reproj                   # :508-511
+    if not disable_automasking:
+        ident = ident + noise * 0.00001                                                       # :514-517
+        combined = torch.cat((ident, reproj_c), dim=1)                                        # :519
+    else:
+        combined = reproj_c                                                                   # :521
+    if combined.shape[1] == 1:
+        to_optimise, idxs = combined, None                                                    # :523-524
+    else:
+        to_optimise, idxs = torch.min(combined, dim=1)                                        # :526
+    out = {}
+    if not disable_automasking:
+        out["identity_selection/0"] = (idxs > ident.shape[1] - 1).float()                     # :528-530
+    loss = to_optimise.mean()                                                                 # :532
     d = disp
     if d.shape[-2:] != target.shape[-2:]:
-        d = F.interpolate(d, [H, W], mode="bilinear", align_corners=False)            # :533-534
-    mean_disp = d.mean(2, True).mean(3, True)                                         # :535
-    norm_disp = d / (mean_disp + 1e-7)                                                # :536
-    sm = smooth_loss(norm_disp, target)                                               # :540
-    loss = loss + disparity_smoothness * sm / (2 ** 0)                                # :542
-    return {"loss": loss, "loss/0": loss, "identity_selection/0": sel, "reproj": reproj,
-            "identity": ident, "idxs": idxs, "to_optimise": to_optimise, "smooth": sm}
+        d = F.interpolate(d, [H, W], mode="bilinear", align_corners=False)                    # :533-534
+    mean_disp = d.mean(2, True).mean(3, True)                                                 # :535
+    norm_disp = d / (mean_disp + 1e-7)                                                        # :536
+    sm = smooth_loss(norm_disp, target)                                                       # :540
+    loss = loss + disparity_smoothness * sm / (2 ** 0)                                        # :542
+    out.update({"loss": loss, "loss/0": loss, "reproj": reproj, "identity": ident, "idxs": idxs, "to_optimise": to_optimise, "smooth": sm})
+    return out
 
 
 def photometric_chain(disp, poses, K, inv_K, colors, frame_ids, noise, H, W, disparity_smoothness=1e-3, stereo_T=None,
-                      use_stereo=False):
+                      use_stereo=False, **loss_options):
     """generate_images_pred + compute_losses in one call (what process_batch does after the networks,
     reference trainer.py:296-297)."""
     out = generate_images_pred(disp, poses, K, inv_K, colors, frame_ids, H, W, stereo_T, use_stereo)
     warped = {f: out[("color", f, 0)] for f in frame_ids[1:]}
     sources = {f: colors[f] for f in frame_ids[1:]}
-    losses = compute_losses(disp, colors[0], warped, sources, frame_ids, noise, H, W, disparity_smoothness)
+    losses = compute_losses(disp, colors[0], warped, sources, frame_ids, noise, H, W, disparity_smoothness, **loss_options)
     out.update(losses)
     return out
 

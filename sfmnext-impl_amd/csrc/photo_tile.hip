@@ -257,7 +257,7 @@ struct SsimOut {
 
 // SSIM + L1 of both predictions against the target from the window sums (already box-summed) and the centre row
 template <bool GRAD>
-__device__ __forceinline__ void ssim_l1(const Sums &S, const Raw &ctr, SsimOut &o) {
+__device__ __forceinline__ void ssim_l1(const Sums &S, const Raw &ctr, SsimOut &o, int flags) {
     v2f ssim_sum = splat(0.f), l1 = splat(0.f);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -290,6 +290,7 @@ __device__ __forceinline__ void ssim_l1(const Sums &S, const Raw &ctr, SsimOut &
         }
     }
     o.loss = splat(0.85f) * (ssim_sum * splat(1.f / 3.f)) + splat(0.15f) * (l1 * splat(1.f / 3.f));
+    if (flags & SQD_LOSS_NO_SSIM) o.loss = l1 * splat(1.f / 3.f);          // --no_ssim: the L1 term alone (trainer.py:447-448)
 }
 
 template <int MODE, int KIND>
@@ -303,37 +304,55 @@ __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPa
 #pragma unroll
     for (int c = 0; c < 3; ++c) box7x3<KIND>(S.Sw[c], S.Sq[c], S.Swt[c], edge);
     SsimOut o;
-    ssim_l1<MODE == 2>(S, ctr, o);
+    const int flags = a.loss_flags;
+    const bool avg = flags & SQD_LOSS_AVG_REPROJECTION;
+    ssim_l1<MODE == 2>(S, ctr, o, flags);
     if (!own) return;
     const unsigned HW = k.HW;
     const unsigned qo = (unsigned)(yo * k.W + k.x);
     const int NS = pp.S;
     if (MODE == 0) {
-        float *out = a.sel + (size_t)b * NS * HW;                      // (the identity maps travel through `sel`)
-        const float *nz = noise ? noise + (size_t)b * NS * HW : nullptr;
+        const int NI = avg ? 1 : NS;                                   // identity maps (and noise planes) per image
+        float *out = a.sel + (size_t)b * NI * HW;                      // (the identity maps travel through `sel`)
+        const float *nz = noise ? noise + (size_t)b * NI * HW : nullptr;
         const unsigned q0 = qo + (unsigned)pp.s0 * HW, q1 = qo + (unsigned)pp.s1 * HW;
-        stg(out, q0 * 4u, o.loss.x + (nz ? ldg(nz, q0 * 4u) : 0.f) * 0.00001f);              // trainer.py:514-517
-        if (pp.s1 != pp.s0) stg(out, q1 * 4u, o.loss.y + (nz ? ldg(nz, q1 * 4u) : 0.f) * 0.00001f);
+        if (avg) {       // --avg_reprojection: ONE identity map per image, the mean over the two sources (trainer.py:489-490)
+            stg(out, q0 * 4u, (o.loss.x + o.loss.y) * 0.5f + (nz ? ldg(nz, q0 * 4u) : 0.f) * 0.00001f);
+        } else {
+            stg(out, q0 * 4u, o.loss.x + (nz ? ldg(nz, q0 * 4u) : 0.f) * 0.00001f);              // trainer.py:514-517
+            if (pp.s1 != pp.s0) stg(out, q1 * 4u, o.loss.y + (nz ? ldg(nz, q1 * 4u) : 0.f) * 0.00001f);
+        }
     } else if (MODE == 1) {
         // combined = [identity_0..S-1, reproj_0..S-1]; torch.min(dim 1): first minimum wins            trainer.py:519-526
+        // the argmin byte: < NS an identity map won (auto-mask: no gradient), NS + s reprojection of source s won; under
+        // --avg_reprojection NS stands for "the mean of all reprojections" (every source, weight 1 / S)
         float best;
         int bi;
+        const bool automask = !(flags & SQD_LOSS_NO_AUTOMASK);
         if (pp.first) {
-            const float *idm = a.identity + (size_t)b * NS * HW;
-            best = ldg(idm, qo * 4u);
+            best = INFINITY;                                           // --disable_automasking: no identity candidates (trainer.py:520-521)
             bi = 0;
+            if (automask) {
+                const float *idm = a.identity + (size_t)b * (avg ? 1 : NS) * HW;
+                best = ldg(idm, qo * 4u);
 #pragma unroll
-            for (int i = 1; i < SQD_MAX_SOURCES; ++i)
-                if (i < NS) {
-                    const float v = ldg(idm, (qo + i * HW) * 4u);
-                    if (v < best) { best = v; bi = i; }
-                }
+                for (int i = 1; i < SQD_MAX_SOURCES; ++i)
+                    if (i < NS && !avg) {
+                        const float v = ldg(idm, (qo + i * HW) * 4u);
+                        if (v < best) { best = v; bi = i; }
+                    }
+            }
         } else {                                                       // the running minimum of the earlier pairs
             best = a.sel[(size_t)b * HW + qo];
             bi = a.idx[(size_t)b * HW + qo];
         }
-        if (o.loss.x < best) { best = o.loss.x; bi = NS + pp.s0; }
-        if (o.loss.y < best) { best = o.loss.y; bi = NS + pp.s1; }
+        if (avg) {
+            const float m = (o.loss.x + o.loss.y) * 0.5f;              // trainer.py:508-509 (S = 2: one pair pass)
+            if (m < best) { best = m; bi = NS; }
+        } else {
+            if (o.loss.x < best) { best = o.loss.x; bi = NS + pp.s0; }
+            if (o.loss.y < best) { best = o.loss.y; bi = NS + pp.s1; }
+        }
         if (a.reproj) {
             a.reproj[((size_t)b * NS + pp.s0) * HW + qo] = o.loss.x;
             a.reproj[((size_t)b * NS + pp.s1) * HW + qo] = o.loss.y;
@@ -349,12 +368,23 @@ __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPa
         // the planes are fully written: zeros where an identity candidate won (the first pass lays them down; a later pass
         // of a 3- or 4-source run only overwrites the pixels its own sources won), so the backward reads them unmasked
         const int bi = a.idx[(size_t)b * HW + qo];
+        const float scale = (flags & SQD_LOSS_NO_SSIM) ? 0.f : 0.85f / 3.f;          // --no_ssim: no window terms at all
+        if (avg) {                         // both sources carry half of the gradient wherever the mean reprojection won: 18 planes
+            const bool won = bi == NS;
+            float *co = a.coef + (size_t)b * 18 * HW;
+#pragma unroll
+            for (int j = 0; j < 9; ++j) {
+                stg(co, (qo + j * HW) * 4u, won ? o.g0[j] * (scale * 0.5f) : 0.f);
+                stg(co, (qo + (9 + j) * HW) * 4u, won ? o.g1[j] * (scale * 0.5f) : 0.f);
+            }
+            return;
+        }
         const bool won = bi == NS + pp.s0 || bi == NS + pp.s1;
         if (won || pp.first) {
             float *co = a.coef + (size_t)b * 9 * HW;
             const bool first = bi == NS + pp.s0;
 #pragma unroll
-            for (int j = 0; j < 9; ++j) stg(co, (qo + j * HW) * 4u, won ? (first ? o.g0[j] : o.g1[j]) * (0.85f / 3.f) : 0.f);
+            for (int j = 0; j < 9; ++j) stg(co, (qo + j * HW) * 4u, won ? (first ? o.g0[j] : o.g1[j]) * scale : 0.f);
         }
     }
 }
@@ -630,7 +660,7 @@ __device__ __forceinline__ float virt_border_adj(float v, int x, int W, int lane
 }
 
 struct BwdPix {
-    float wm1, hm1, gscale;
+    float wm1, hm1, gscale, l1w;            // l1w: weight of the L1 term's sign in d loss / d warped
     int W, H;
     unsigned HW;
 };
@@ -669,7 +699,7 @@ __device__ __forceinline__ float pixel_adjoint(const BwdPix &k, const float *__r
         float gw = G[c] + 2.f * wv * G[3 + c] + t[c] * G[6 + c];
         if (l1on) {
             const float df = wv - t[c];
-            gw += (0.15f / 3.f) * (df > 0.f ? 1.f : df < 0.f ? -1.f : 0.f);
+            gw += k.l1w * (df > 0.f ? 1.f : df < 0.f ? -1.f : 0.f);
         }
         gix += gw * ((vne - vnw) * byw + (vse - vsw) * ay);
         giy += gw * ((vsw - vnw) * bxw + (vse - vne) * ax);
@@ -698,6 +728,7 @@ __device__ __forceinline__ float pixel_adjoint(const BwdPix &k, const float *__r
     return cr[0] * gX[0] + cr[1] * gX[1] + cr[2] * gX[2];
 }
 
+template <bool AVG>
 __device__ __forceinline__ void bwd_rows(int KIND, const sqd_photo_bwd_args &a, const PairPass &pp, const BwdPix &k, __amdgpu_buffer_rsrc_t coef_r,
                                          __amdgpu_buffer_rsrc_t idx_r, int lane0, int b, int wave, int y0, int own_rows, int x, bool in_col, bool own_col,
                                          int lane, float *gdep, float gP0[12], float gP1[12]) {
@@ -720,7 +751,11 @@ __device__ __forceinline__ void bwd_rows(int KIND, const sqd_photo_bwd_args &a, 
     const float *__restrict__ dep = a.depth + (size_t)b * HW;
     const float *__restrict__ src0 = a.sources[pp.s0] + (size_t)b * 3 * HW, *__restrict__ src1 = a.sources[pp.s1] + (size_t)b * 3 * HW;
     const float *__restrict__ smp0 = a.sample[pp.s0] + (size_t)b * HW * 2, *__restrict__ smp1 = a.sample[pp.s1] + (size_t)b * HW * 2;
-    const int id0 = NS + pp.s0, id1 = two ? NS + pp.s1 : -1;                  // argmin codes of the pair's reprojection candidates
+    constexpr bool avg = AVG;
+    // argmin codes of the pair's reprojection candidates (--avg_reprojection: NS = the mean of both: the two sources read their own
+    // nine planes of the 18 sqd_photo_coef wrote)
+    const int id0 = avg ? NS : NS + pp.s0, id1 = avg ? NS : two ? NS + pp.s1 : -1;
+    const unsigned c1off = 9u * HW;
     for (int j = wave; j < own_rows; j += 4) {
         const int q = y0 + j;
         float G0[9], G1[9];
@@ -747,7 +782,8 @@ __device__ __forceinline__ void bwd_rows(int KIND, const sqd_photo_bwd_args &a, 
             for (int c = 0; c < 9; ++c) {
                 const float v = bld(coef_r, vo, (row + (unsigned)c * HW) * 4u);
                 G0[c] = fmaf(w0, v, G0[c]);
-                G1[c] = fmaf(w1, v, G1[c]);
+                if constexpr (avg) G1[c] = fmaf(w1, bld(coef_r, vo, (row + (unsigned)c * HW + c1off) * 4u), G1[c]);
+                else G1[c] = fmaf(w1, v, G1[c]);
             }
         }
         if (lane0 >= 0) {
@@ -788,6 +824,7 @@ __device__ __forceinline__ void bwd_rows(int KIND, const sqd_photo_bwd_args &a, 
 // Two workgroups (8 waves) per CU: the scheduler is left free to batch the 70 coefficient loads of a row and both sources' tap
 // gathers (140 VGPRs).  Measured at config B (profiles/r03h_photo_bwd_variants.md): 4 waves per SIMD with the loads fenced into
 // 128 registers 95 us, 3 waves 98 us, 2 waves 74 us; tile heights 6..16 within 10 % of each other, 16 best.
+template <bool AVG>
 __global__ __launch_bounds__(256, 2) void photo_bwd_tile_kernel(sqd_photo_bwd_args a, PairPass pp, int pass, int TR, int nsx, int nsy, int ntiles, int nblk8) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -802,16 +839,18 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_tile_kernel(sqd_photo_bwd_ar
     const int x = sx.x0 + lane;
     const bool in_col = x >= 0 && x < W;
     const bool own_col = x >= sx.own0 && x < sx.own1 && in_col;
-    const __amdgpu_buffer_rsrc_t coef_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.coef + (size_t)b * 9 * HW), 0, 9u * HW * 4u, 0x00020000);
+    constexpr unsigned ncoef = AVG ? 18u : 9u;
+    const __amdgpu_buffer_rsrc_t coef_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.coef + (size_t)b * ncoef * HW), 0, ncoef * HW * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t idx_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.idx + (size_t)b * HW), 0, HW, 0x00020000);
     BwdPix k;
     k.wm1 = (float)(W - 1); k.hm1 = (float)(H - 1); k.gscale = a.gscale; k.W = W; k.H = H; k.HW = HW;
+    k.l1w = ((a.loss_flags & SQD_LOSS_NO_SSIM) ? 1.f / 3.f : 0.15f / 3.f) * (AVG ? 0.5f : 1.f);
     float *gdep = a.g_depth + (size_t)b * a.g_depth_img_stride + (size_t)pass * HW;
     float gP0[12], gP1[12];
 #pragma unroll
     for (int j = 0; j < 12; ++j) gP0[j] = gP1[j] = 0.f;
     const int lane0 = W <= 64 ? -sx.x0 : -1;                                  // >= 0: both borders inside the wavefront (generic border path)
-    bwd_rows(lane0 >= 0 ? (int)INTERIOR : sx.kind, a, pp, k, coef_r, idx_r, lane0, b, wave, y0, own_rows, x, in_col, own_col, lane, gdep, gP0, gP1);
+    bwd_rows<AVG>(lane0 >= 0 ? (int)INTERIOR : sx.kind, a, pp, k, coef_r, idx_r, lane0, b, wave, y0, own_rows, x, in_col, own_col, lane, gdep, gP0, gP1);
     // per-wavefront partials of g_P: [B][S][tiles per image * 4][12]
     const int tpi = nsx * nsy * 4, slot = (ty * nsx + tx) * 4 + wave;
 #pragma unroll
@@ -909,7 +948,10 @@ void launch_photo_bwd_tile(const sqd_photo_bwd_args &a, hipStream_t stream) {
     const int nblk8 = (ntiles + 7) / 8;
     for (int k = 0; 2 * k < a.S; ++k) {
         const PairPass pp = {2 * k, 2 * k + 1 < a.S ? 2 * k + 1 : 2 * k, a.S, k == 0, 2 * k + 2 >= a.S};
-        hipLaunchKernelGGL(photo_bwd_tile_kernel, dim3(nblk8 * 8), dim3(256), 0, stream, a, pp, k, TR, nsx, nsy, ntiles, nblk8);
+        if (a.loss_flags & SQD_LOSS_AVG_REPROJECTION)
+            hipLaunchKernelGGL(photo_bwd_tile_kernel<true>, dim3(nblk8 * 8), dim3(256), 0, stream, a, pp, k, TR, nsx, nsy, ntiles, nblk8);
+        else
+            hipLaunchKernelGGL(photo_bwd_tile_kernel<false>, dim3(nblk8 * 8), dim3(256), 0, stream, a, pp, k, TR, nsx, nsy, ntiles, nblk8);
     }
 }
 }  // namespace sqd

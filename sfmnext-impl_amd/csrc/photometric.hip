@@ -42,8 +42,15 @@ extern "C" int sqd_photo_bwd_ntasks(int B, int S, int H, int W, int rows_per_tas
     return S * 4 * sqd::photo_tile_count(B, H, W, rows_per_task, 2);      // one g_P partial per wavefront of a tile and source
 }
 
+static int check_loss_flags(const char *who, int flags, int S) {
+    SQD_CHECK_ARG((flags & ~7) == 0, "%s: unknown loss_flags %d", who, flags);
+    SQD_CHECK_ARG(!(flags & SQD_LOSS_AVG_REPROJECTION) || S == 2, "%s: avg_reprojection is implemented for two source frames (S=%d)", who, S);
+    return SQD_OK;
+}
+
 extern "C" int sqd_photo_fwd(const sqd_photo_args *a) {
-    SQD_CHECK_ARG(a && a->depth && a->inv_K && a->P && a->target && a->identity, "sqd_photo_fwd: null input");
+    SQD_CHECK_ARG(a && a->depth && a->inv_K && a->P && a->target && (a->identity || (a->loss_flags & SQD_LOSS_NO_AUTOMASK)), "sqd_photo_fwd: null input");
+    if (check_loss_flags("sqd_photo_fwd", a->loss_flags, a->S)) return SQD_EINVAL;
     if (check_shape("sqd_photo_fwd", a->B, a->S, a->H, a->W, 8)) return SQD_EINVAL;
     for (int s = 0; s < a->S; ++s) SQD_CHECK_ARG(a->sources[s], "sqd_photo_fwd: null source %d", s);
     SQD_CHECK_ARG(a->S <= 2 || (a->sel && a->idx), "sqd_photo_fwd: more than 2 source frames need the sel and idx outputs (running minimum)");
@@ -55,7 +62,13 @@ extern "C" int sqd_photo_fwd(const sqd_photo_args *a) {
 
 extern "C" int sqd_identity_fwd(const float *target, const float *const *sources, const float *noise, float *identity,
                                 int B, int S, int H, int W, int rows_per_task, void *stream) {
+    return sqd_identity_fwd_ex(target, sources, noise, identity, B, S, H, W, rows_per_task, 0, stream);
+}
+
+extern "C" int sqd_identity_fwd_ex(const float *target, const float *const *sources, const float *noise, float *identity,
+                                   int B, int S, int H, int W, int rows_per_task, int loss_flags, void *stream) {
     SQD_CHECK_ARG(target && sources && identity, "sqd_identity_fwd: null pointer");
+    if (check_loss_flags("sqd_identity_fwd", loss_flags, S)) return SQD_EINVAL;
     if (check_shape("sqd_identity_fwd", B, S, H, W, 8)) return SQD_EINVAL;
     sqd_photo_args a = {};
     a.target = target;
@@ -64,7 +77,7 @@ extern "C" int sqd_identity_fwd(const float *target, const float *const *sources
         a.sources[s] = sources[s];
     }
     a.sel = identity;   // MODE 0 writes its [B,S,H,W] output through `sel`
-    a.B = B; a.S = S; a.H = H; a.W = W; a.rows_per_task = rows_per_task;
+    a.B = B; a.S = S; a.H = H; a.W = W; a.rows_per_task = rows_per_task; a.loss_flags = loss_flags;
     (void)hipGetLastError();
     sqd::launch_photo_tile(a, noise, 0, (hipStream_t)stream);
     SQD_CHECK_LAUNCH("sqd_identity_fwd");
@@ -73,7 +86,13 @@ extern "C" int sqd_identity_fwd(const float *target, const float *const *sources
 
 extern "C" int sqd_photo_coef(const float *target, const float *const *warped, const uint8_t *idx, float *coef, int B, int S,
                               int H, int W, int rows_per_task, void *stream) {
+    return sqd_photo_coef_ex(target, warped, idx, coef, B, S, H, W, rows_per_task, 0, stream);
+}
+
+extern "C" int sqd_photo_coef_ex(const float *target, const float *const *warped, const uint8_t *idx, float *coef, int B, int S,
+                                 int H, int W, int rows_per_task, int loss_flags, void *stream) {
     SQD_CHECK_ARG(target && warped && idx && coef, "sqd_photo_coef: null pointer");
+    if (check_loss_flags("sqd_photo_coef", loss_flags, S)) return SQD_EINVAL;
     if (check_shape("sqd_photo_coef", B, S, H, W, 8)) return SQD_EINVAL;
     sqd_photo_args a = {};
     a.target = target;
@@ -83,7 +102,7 @@ extern "C" int sqd_photo_coef(const float *target, const float *const *warped, c
     }
     a.idx = const_cast<uint8_t *>(idx);
     a.coef = coef;
-    a.B = B; a.S = S; a.H = H; a.W = W; a.rows_per_task = rows_per_task;
+    a.B = B; a.S = S; a.H = H; a.W = W; a.rows_per_task = rows_per_task; a.loss_flags = loss_flags;
     (void)hipGetLastError();
     sqd::launch_photo_tile(a, nullptr, 2, (hipStream_t)stream);
     SQD_CHECK_LAUNCH("sqd_photo_coef");
@@ -95,6 +114,7 @@ extern "C" int sqd_photo_bwd(const sqd_photo_bwd_args *a) {
     SQD_CHECK_ARG(a->S >= 1 && a->S <= SQD_MAX_SOURCES, "sqd_photo_bwd: S=%d source frames unsupported (1..%d)", a->S, SQD_MAX_SOURCES);
     for (int s = 0; s < a->S; ++s) SQD_CHECK_ARG(a->sources[s] && a->sample[s], "sqd_photo_bwd: null source / sample %d", s);
     if (check_shape("sqd_photo_bwd", a->B, a->S, a->H, a->W, 8)) return SQD_EINVAL;
+    if (check_loss_flags("sqd_photo_bwd", a->loss_flags, a->S)) return SQD_EINVAL;
     SQD_CHECK_ARG(a->rows_per_task >= 0, "sqd_photo_bwd: rows_per_task=%d", a->rows_per_task);
     SQD_CHECK_ARG(a->g_depth_img_stride >= (int64_t)((a->S + 1) / 2) * a->H * a->W, "sqd_photo_bwd: g_depth_img_stride too small");
     (void)hipGetLastError();

@@ -23,6 +23,13 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_void_p = ctypes.c_void_p
+ABI_VERSION = 2   # SQD_ABI_VERSION of include/sqd.h this binding was written against
+# SQD_LOSS_* (include/sqd.h): the reference's --no_ssim / --avg_reprojection / --disable_automasking
+LOSS_NO_SSIM, LOSS_AVG_REPROJECTION, LOSS_NO_AUTOMASK = 1, 2, 4
+
+
+def loss_flags(no_ssim=False, avg_reprojection=False, disable_automasking=False):
+    return (LOSS_NO_SSIM if no_ssim else 0) | (LOSS_AVG_REPROJECTION if avg_reprojection else 0) | (LOSS_NO_AUTOMASK if disable_automasking else 0)
 
 
 class PhotoArgs(ctypes.Structure):
@@ -33,7 +40,7 @@ class PhotoArgs(ctypes.Structure):
                 ("sel", c_void_p), ("idx", c_void_p), ("x0y0", c_void_p * MAX_SOURCES),
                 ("coef", c_void_p), ("reproj", c_void_p), ("loss_part", c_void_p),
                 ("B", ctypes.c_int32), ("S", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
-                ("rows_per_task", ctypes.c_int32), ("stream", c_void_p)]
+                ("loss_flags", ctypes.c_int32), ("rows_per_task", ctypes.c_int32), ("stream", c_void_p)]
 
 
 class PhotoBwdArgs(ctypes.Structure):
@@ -43,7 +50,7 @@ class PhotoBwdArgs(ctypes.Structure):
                 ("idx", c_void_p), ("g_depth", c_void_p), ("g_P_part", c_void_p), ("g_depth_img_stride", ctypes.c_int64),
                 ("gscale", ctypes.c_float),
                 ("B", ctypes.c_int32), ("S", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
-                ("rows_per_task", ctypes.c_int32), ("stream", c_void_p)]
+                ("loss_flags", ctypes.c_int32), ("rows_per_task", ctypes.c_int32), ("stream", c_void_p)]
 
 
 def sources():
@@ -129,6 +136,8 @@ _SIGNATURES = {
     "sqd_photo_fwd": (_I, [ctypes.POINTER(PhotoArgs)]),
     "sqd_identity_fwd": (_I, [_P, ctypes.POINTER(c_void_p), _P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_photo_coef": (_I, [_P, ctypes.POINTER(c_void_p), _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sqd_identity_fwd_ex": (_I, [_P, ctypes.POINTER(c_void_p), _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    "sqd_photo_coef_ex": (_I, [_P, ctypes.POINTER(c_void_p), _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sqd_photo_bwd_ntasks": (_I, [_I, _I, _I, _I, _I]),
     "sqd_photo_bwd": (_I, [ctypes.POINTER(PhotoBwdArgs)]),
     "sqd_photo_bwd_reduce": (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -247,7 +256,7 @@ def lib():
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(L, name)
             fn.restype, fn.argtypes = res, args
-        if L.sqd_abi_version() != 1:
+        if L.sqd_abi_version() != ABI_VERSION:
             raise RuntimeError("libsqd.so ABI version mismatch")
         _LIB = L
     return _LIB

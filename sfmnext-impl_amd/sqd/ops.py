@@ -89,14 +89,18 @@ def pose_mats_bwd(axisangle, translation, invert, K, mid, g_P):
     return g_aa, g_tr, g_mid
 
 
-def identity_fwd(target, sources, noise=None, rows_per_task=0):
-    """Identity reprojection losses + 1e-5*noise -> [B,S,H,W]  (trainer.py:480-487,514-517)."""
+def identity_fwd(target, sources, noise=None, rows_per_task=0, loss_flags=0):
+    """Identity reprojection losses + 1e-5*noise -> [B,S,H,W]  (trainer.py:480-487,514-517).  Under LOSS_AVG_REPROJECTION the result is
+    [B,1,H,W]: the mean over the sources + 1e-5 * noise [B,1,H,W] (trainer.py:489-490)."""
     _req(target, noise, *sources)
     B, _, H, W = target.shape
     S = len(sources)
-    out = torch.empty(B, S, H, W, device=target.device, dtype=torch.float32)
+    NI = 1 if loss_flags & _l.LOSS_AVG_REPROJECTION else S
+    if noise is not None and tuple(noise.shape) != (B, NI, H, W):
+        raise ValueError("identity_fwd: noise must be [B,%d,H,W], got %s" % (NI, tuple(noise.shape)))
+    out = torch.empty(B, NI, H, W, device=target.device, dtype=torch.float32)
     arr = (ctypes.c_void_p * S)(*[s.data_ptr() for s in sources])
-    _l.check(_l.lib().sqd_identity_fwd(_ptr(target), arr, _ptr(noise), _ptr(out), B, S, H, W, rows_per_task, _stream()),
+    _l.check(_l.lib().sqd_identity_fwd_ex(_ptr(target), arr, _ptr(noise), _ptr(out), B, S, H, W, rows_per_task, loss_flags, _stream()),
              "identity_fwd")
     return out
 
@@ -106,9 +110,11 @@ PHOTO_FWD_KERNEL_NAME = "photo_tile_kernel<1> (fused warp + SSIM + L1 + min/auto
 
 
 def photo_fwd(depth, inv_K, P, target, sources, identity, training=True, want_taps=False, want_reproj=False,
-              rows_per_task=0, prepared_only=False):
-    """Fused warp + SSIM/L1 + min/auto-mask.  Returns a dict of device tensors."""
-    _req(depth, inv_K, P, target, identity, *sources)
+              rows_per_task=0, prepared_only=False, loss_flags=0):
+    """Fused warp + SSIM/L1 + min/auto-mask.  Returns a dict of device tensors.  `identity` may be None under LOSS_NO_AUTOMASK."""
+    _req(depth, inv_K, P, target, *sources)
+    if identity is not None:
+        _req(identity)
     B, _, H, W = target.shape
     S = len(sources)
     dev = target.device
@@ -123,7 +129,9 @@ def photo_fwd(depth, inv_K, P, target, sources, identity, training=True, want_ta
            "x0y0": [torch.empty(B, H, W, 2, device=dev, dtype=torch.int32) for _ in range(S)] if want_taps else None,
            "reproj": torch.empty(B, S, H, W, **f32) if want_reproj else None}
     a = _l.PhotoArgs()
-    a.depth, a.inv_K, a.P, a.target, a.identity = (t.data_ptr() for t in (depth, inv_K, P, target, identity))
+    a.depth, a.inv_K, a.P, a.target = (t.data_ptr() for t in (depth, inv_K, P, target))
+    a.identity = identity.data_ptr() if identity is not None else None
+    a.loss_flags = loss_flags
     for s in range(S):
         a.sources[s] = sources[s].data_ptr()
         a.sample[s] = out["sample"][s].data_ptr()
@@ -147,25 +155,27 @@ def photo_fwd_relaunch(a):
     _l.check(_l.lib().sqd_photo_fwd(ctypes.byref(a)), "photo_fwd")
 
 
-def photo_coef(target, warped, idx, rows_per_task=0):
-    """d(to_optimise)/d(window sums) of the winning source from the stored warped images -> coef [B,9,H,W]."""
+def photo_coef(target, warped, idx, rows_per_task=0, loss_flags=0):
+    """d(to_optimise)/d(window sums) of the winning source from the stored warped images -> coef [B,9,H,W]
+    ([B,18,H,W] under LOSS_AVG_REPROJECTION: nine planes per source)."""
     _req(target, idx, *warped)
     B, _, H, W = target.shape
     S = len(warped)
-    coef = torch.empty(B, 9, H, W, device=target.device, dtype=torch.float32)
+    coef = torch.empty(B, 18 if loss_flags & _l.LOSS_AVG_REPROJECTION else 9, H, W, device=target.device, dtype=torch.float32)
     arr = (ctypes.c_void_p * S)(*[w.data_ptr() for w in warped])
-    _l.check(_l.lib().sqd_photo_coef(_ptr(target), arr, _ptr(idx), _ptr(coef), B, S, H, W, rows_per_task, _stream()), "photo_coef")
+    _l.check(_l.lib().sqd_photo_coef_ex(_ptr(target), arr, _ptr(idx), _ptr(coef), B, S, H, W, rows_per_task, loss_flags, _stream()),
+             "photo_coef")
     return coef
 
 
-def photo_bwd(depth, inv_K, P, target, sources, samples, warped, idx, gscale, rows_per_task=0, extra_planes=0):
+def photo_bwd(depth, inv_K, P, target, sources, samples, warped, idx, gscale, rows_per_task=0, extra_planes=0, loss_flags=0):
     """-> g_depth [B,ceil(S/2)+extra_planes,H,W] (plane k = the pair of sources 2k, 2k+1; extra planes left unwritten), g_P [B,S,3,4]."""
     _req(depth, inv_K, P, target, idx, *sources, *samples, *warped)
     B, _, H, W = target.shape
     S = len(sources)
     dev = target.device
     L = _l.lib()
-    coef = photo_coef(target, warped, idx, rows_per_task)
+    coef = photo_coef(target, warped, idx, rows_per_task, loss_flags)
     nt = L.sqd_photo_bwd_ntasks(B, S, H, W, rows_per_task)
     g_depth = torch.empty(B, (S + 1) // 2 + extra_planes, H, W, device=dev, dtype=torch.float32)
     part = torch.empty(nt, 12, device=dev, dtype=torch.float32)
@@ -176,6 +186,7 @@ def photo_bwd(depth, inv_K, P, target, sources, samples, warped, idx, gscale, ro
         a.sample[s] = samples[s].data_ptr()
     a.idx, a.g_depth, a.g_P_part = idx.data_ptr(), g_depth.data_ptr(), part.data_ptr()
     a.gscale = float(gscale)
+    a.loss_flags = loss_flags
     a.g_depth_img_stride = ((S + 1) // 2 + extra_planes) * H * W
     a.B, a.S, a.H, a.W, a.rows_per_task = B, S, H, W, rows_per_task
     a.stream = torch.cuda.current_stream().cuda_stream
@@ -268,7 +279,9 @@ class PhotometricChain(torch.autograd.Function):
 
     forward(disp_lr [B,1,h,w], axisangle [B,Sp,3], translation [B,Sp,3], K, inv_K, target, identity [B,S,H,W], meta, *sources)
       -> total loss (differentiable), photo mean, smooth, depth, sel, T, sample_0.., warped_0.. (non-differentiable)
-    `meta` = dict(H, W, invert=[...] for the Sp pose-net sources, smooth_weight, rows_per_task, use_stereo, stereo_T);
+    `meta` = dict(H, W, invert=[...] for the Sp pose-net sources, smooth_weight, rows_per_task, use_stereo, stereo_T, loss_flags);
+    loss_flags = lib.loss_flags(no_ssim, avg_reprojection, disable_automasking) (`identity` is then built with the same flags; it
+    is ignored under disable_automasking);
     with stereo_T the last of the S sources is the other stereo camera (Sp = S - 1)."""
 
     @staticmethod
@@ -292,7 +305,8 @@ class PhotometricChain(torch.autograd.Function):
             Ps = torch.matmul(K, Ts[:, 0])[:, None, :3, :]
             T = Ts if T is None else torch.cat([T, Ts], 1)
             P = (Ps if P is None else torch.cat([P, Ps], 1)).contiguous()
-        out = photo_fwd(depth, inv_K, P, target, list(sources), identity, training=training, rows_per_task=rows)
+        out = photo_fwd(depth, inv_K, P, target, list(sources), identity, training=training, rows_per_task=rows,
+                        loss_flags=meta.get("loss_flags", 0))
         sm_part = smooth_fwd(depth, target, part)
         photo = out["loss_part"].sum() / float(B * H * W)
         smooth = sm_part[..., 0].sum() / float(B * H * (W - 1)) + sm_part[..., 1].sum() / float(B * (H - 1) * W)
@@ -319,7 +333,7 @@ class PhotometricChain(torch.autograd.Function):
         rows = meta.get("rows_per_task", 0)
         # all adjoints are linear in the upstream gradient: run them with 1.0 and scale the three small results
         planes, g_P = photo_bwd(depth, inv_K, P, target, sources, samples, warped, idx, 1.0 / float(B * H * W), rows,
-                                extra_planes=1)
+                                extra_planes=1, loss_flags=meta.get("loss_flags", 0))
         smooth_bwd(depth, target, part, sm_part, meta["smooth_weight"], planes, (S + 1) // 2)
         g_aa = g_tr = g_mid = None
         if n_pose:                                # (the stereo source's extrinsics are data: its rows of g_P are dropped)

@@ -31,6 +31,7 @@ import datasets
 import networks
 from layers import compute_depth_errors
 from sqd import ddp, nnkernels, ops
+from sqd import lib as _sqd_lib
 from sqd.optim import FusedAdam
 from utils import normalize_image, sec_to_hm_str
 
@@ -110,7 +111,7 @@ class Trainer:
         # single- and multi-rank runs replay the whole step as one hipGraph; with a process group the graph also holds the
         # bucket gathers and the RCCL all-reduces the autograd hooks launch, as branches parallel to the rest of backward
         # (--sqd_graph_ddp post: the round-1 variant — graph of forward+backward, collectives and Adam issued after the replay)
-        self._graph_ok = not self.opt.sqd_no_graph and self.device.type == "cuda" and not self.opt.disable_automasking
+        self._graph_ok = not self.opt.sqd_no_graph and self.device.type == "cuda"
         self._side_stream = torch.cuda.Stream(device=self.device)
         self._pose_stream = torch.cuda.Stream(device=self.device)
         # weight-gradient kernels of the convolutions on their own stream (eager steps)
@@ -129,10 +130,12 @@ class Trainer:
     # ------------------------------------------------------------------------------- construction
     def _check_supported(self):
         o = self.opt
-        unsupported = [n for n in ("v1_multiscale", "predictive_mask", "avg_reprojection", "no_ssim", "disable_automasking") if getattr(o, n)]
+        unsupported = [n for n in ("v1_multiscale", "predictive_mask") if getattr(o, n)]
+        if o.avg_reprojection and len(o.frame_ids) - 1 > 2:
+            unsupported.append("avg_reprojection with %d source frames" % (len(o.frame_ids) - 1))
         if unsupported or list(o.scales) != [0] or o.pose_model_type != "posecnn" or o.pose_model_input != "pairs":
             raise NotImplementedError("MI355X hot path implements the reference's KITTI mono configuration "
-                                      "(auto-mask, per-pixel min, SSIM, scale 0, posecnn pairs); got %s scales=%s pose=%s/%s"
+                                      "(scale 0, posecnn pairs; --no_ssim / --avg_reprojection / --disable_automasking included); got %s scales=%s pose=%s/%s"
                                       % (unsupported, o.scales, o.pose_model_type, o.pose_model_input))
         temporal = [f for f in o.frame_ids if f != "s"]
         if temporal not in ([0, -1, 1], [0]) or (temporal == [0] and not o.use_stereo):
@@ -219,7 +222,7 @@ class Trainer:
         if not self.opt.sqd_device_noise and ("noise", 0) not in inputs:
             # host RNG as in the reference (trainer.py:516): drawn outside the graph, handed over as a static input
             o = self.opt
-            inputs[("noise", 0)] = torch.randn(o.batch_size, len(o.frame_ids) - 1, o.height, o.width)
+            inputs[("noise", 0)] = torch.randn(o.batch_size, self._identity_planes(), o.height, o.width)
         if self._graph is None:
             try:
                 self._capture(inputs)
@@ -390,27 +393,39 @@ class Trainer:
     def _fmt(self, x):
         return x.contiguous(memory_format=torch.channels_last) if self.opt.sqd_channels_last else x
 
+    def _loss_flags(self):
+        """SQD_LOSS_* bits of the reference's loss options (trainer.py:447-451, 480-524); the mean over ONE source frame is that frame."""
+        o = self.opt
+        return _sqd_lib.loss_flags(o.no_ssim, o.avg_reprojection and len(o.frame_ids) - 1 > 1, o.disable_automasking)
+
+    def _identity_planes(self):
+        return 1 if self._loss_flags() & _sqd_lib.LOSS_AVG_REPROJECTION else len(self.opt.frame_ids) - 1
+
     def _launch_identity(self, inputs):
         """Identity-reprojection maps + tie-break noise (reference trainer.py:480-487,514-517) depend only
         on the batch: compute them on a side stream, overlapped with the encoder forward."""
         srcs = [inputs[("color", f, 0)] for f in self.opt.frame_ids[1:]]
         tgt = inputs[("color", 0, 0)]
         B, _, H, W = tgt.shape
+        flags, NI = self._loss_flags(), self._identity_planes()
+        if flags & _sqd_lib.LOSS_NO_AUTOMASK:           # no identity candidates (trainer.py:520-521): nothing to compute, no noise drawn
+            self._identity, self._identity_done = False, None
+            return
         if ("noise", 0) in inputs:
             noise = inputs[("noise", 0)]
         elif self.opt.sqd_device_noise:
-            noise = torch.randn(B, len(srcs), H, W, device=self.device)
+            noise = torch.randn(B, NI, H, W, device=self.device)
         else:
-            noise = torch.randn(B, len(srcs), H, W).to(self.device, non_blocking=True)   # CPU RNG, as the reference
+            noise = torch.randn(B, NI, H, W).to(self.device, non_blocking=True)   # CPU RNG, as the reference
         if self._capturing:
             # inside a graph capture this stays on the capturing stream: as a forked branch it made the replay 1.4 ms SLOWER
             # (22.28 vs 20.92 ms, same box) — unlike the pose-network branch of process_batch, which gains 0.4 ms
-            self._identity, self._identity_done = ops.identity_fwd(tgt, srcs, noise), None
+            self._identity, self._identity_done = ops.identity_fwd(tgt, srcs, noise, loss_flags=flags), None
             return
         side = self._side_stream
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            self._identity = ops.identity_fwd(tgt, srcs, noise)
+            self._identity = ops.identity_fwd(tgt, srcs, noise, loss_flags=flags)
             self._identity_done = torch.cuda.Event()
             self._identity_done.record(side)
         for t in (tgt, noise, *srcs):
@@ -458,6 +473,8 @@ class Trainer:
         if self._identity_done is not None:
             torch.cuda.current_stream().wait_event(self._identity_done)
         identity, self._identity = self._identity, None
+        if identity is False:
+            identity = None
         pose_ids = [f for f in srcs_ids if f != "s"]
         B = inputs[("color", 0, 0)].shape[0]
         cached, self._pose_all = getattr(self, "_pose_all", None), None
@@ -472,7 +489,8 @@ class Trainer:
         # --use_stereo: T of the temporal frames is the un-scaled cam_T_cam, T of "s" is inputs["stereo_T"] (reference
         # trainer.py:405-421: the mean-inverse-depth scaling of the translation is skipped)
         meta = dict(H=o.height, W=o.width, invert=[1 if f < 0 else 0 for f in pose_ids], smooth_weight=o.disparity_smoothness,
-                    use_stereo=bool(o.use_stereo), stereo_T=inputs["stereo_T"] if "s" in srcs_ids else None)
+                    use_stereo=bool(o.use_stereo), stereo_T=inputs["stereo_T"] if "s" in srcs_ids else None,
+                    loss_flags=self._loss_flags())
         srcs = [inputs[("color", f, 0)].contiguous() for f in srcs_ids]
         res = ops.PhotometricChain.apply(outputs[("disp", 0)].contiguous(), aa, tr, inputs[("K", 0)].contiguous(),
                                          inputs[("inv_K", 0)].contiguous(), inputs[("color", 0, 0)].contiguous(),
@@ -497,7 +515,8 @@ class Trainer:
         if ("_chain", 0) not in outputs:
             self.generate_images_pred(inputs, outputs)
         total, sel = outputs.pop(("_chain", 0))
-        outputs["identity_selection/0"] = sel
+        if not self.opt.disable_automasking:             # (trainer.py:523-525)
+            outputs["identity_selection/0"] = sel
         loss = total / self.num_scales
         return {"loss/0": total, "loss": loss}
 
@@ -550,7 +569,8 @@ class Trainer:
                 if f != 0:
                     writer.add_image("color_pred_{}_0/{}".format(f, j), outputs[("color", f, 0)][j].data, self.step)
             writer.add_image("disp_0/{}".format(j), normalize_image(outputs[("disp", 0)][j]), self.step)
-            writer.add_image("automask_0/{}".format(j), outputs["identity_selection/0"][j][None, ...], self.step)
+            if not self.opt.disable_automasking:
+                writer.add_image("automask_0/{}".format(j), outputs["identity_selection/0"][j][None, ...], self.step)
 
     def save_opts(self):
         models_dir = os.path.join(self.log_path, "models")

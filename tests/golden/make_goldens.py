@@ -186,8 +186,11 @@ def g5_g6_ssim(T):
     save("g06_reprojection", x=x, y=y, loss=r, w=w2, grad_pred=xt2.grad)
 
 
-def run_chain(T, d, B, H, W, with_grad=True):
+def run_chain(T, d, B, H, W, with_grad=True, **opt_flags):
     shim = make_shim(T, B, H, W)
+    for k, v in opt_flags.items():          # the reference's loss options: no_ssim, avg_reprojection, disable_automasking
+        assert hasattr(shim.opt, k)
+        setattr(shim.opt, k, v)
     disp = tt(d["disp"]).requires_grad_(with_grad)
     aa = {f: tt(d["axisangle_s%d" % i]).requires_grad_(with_grad) for i, f in enumerate((-1, 1))}
     tr = {f: tt(d["translation_s%d" % i]).requires_grad_(with_grad) for i, f in enumerate((-1, 1))}
@@ -199,9 +202,29 @@ def run_chain(T, d, B, H, W, with_grad=True):
         outputs[("translation", 0, f)] = tr[f]
         outputs[("cam_T_cam", 0, f)] = T.transformation_from_parameters(aa[f][:, 0], tr[f][:, 0], invert=(f < 0))
     T.Trainer.generate_images_pred(shim, inputs, outputs)
-    with patched_randn(tt(d["noise"])):
+    noise = tt(d["noise"])
+    if shim.opt.avg_reprojection:
+        noise = noise[:, :1].contiguous()     # torch.randn(identity_reprojection_loss.shape): one channel under avg_reprojection (:490,:516)
+    with patched_randn(noise):
         losses = T.Trainer.compute_losses(shim, inputs, outputs)
     return shim, inputs, outputs, losses, disp, aa, tr
+
+
+def g23_loss_options(T):
+    """the reference's loss options (trainer.py:447-451, 480-524) through its own compute_losses: loss, identity_selection (with
+    automasking) and the gradients w.r.t. disparity and poses, per option set"""
+    B, H, W = 2, 24, 80
+    d = chain_inputs(723, B, H, W)
+    for tag, flags in (("no_ssim", dict(no_ssim=True)), ("avg", dict(avg_reprojection=True)), ("no_automask", dict(disable_automasking=True)),
+                       ("avg_no_automask", dict(avg_reprojection=True, disable_automasking=True)),
+                       ("no_ssim_avg", dict(no_ssim=True, avg_reprojection=True))):
+        shim, inputs, outputs, losses, disp, aa, tr = run_chain(T, d, B, H, W, **flags)
+        losses["loss"].backward()
+        extra = {} if flags.get("disable_automasking") else {"identity_selection": outputs["identity_selection/0"]}
+        save("g23_loss_options_" + tag, seed=723, B=B, H=H, W=W, loss=losses["loss"], grad_disp=disp.grad,
+             grad_axisangle_m1=aa[-1].grad, grad_axisangle_p1=aa[1].grad, grad_translation_m1=tr[-1].grad, grad_translation_p1=tr[1].grad,
+             flags=np.array([int(flags.get("no_ssim", False)), int(flags.get("avg_reprojection", False)), int(flags.get("disable_automasking", False))]),
+             **extra)
 
 
 def g7_g8_chain(T):
@@ -556,6 +579,7 @@ def main():
     g20_unet_decoder(T)
     g21_silog(T)
     g22_metric_errors(T)
+    g23_loss_options(T)
     g1_pose(T)
     g2_g3_g4_geometry(T)
     g5_g6_ssim(T)

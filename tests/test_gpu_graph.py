@@ -27,7 +27,7 @@ def run(extra, steps=7):
     g = torch.Generator().manual_seed(5)
     for i in range(steps):
         inputs = synthetic_batch(2, 64, 96, start=2 * i, device=tr.device)
-        inputs[("noise", 0)] = torch.randn(2, 2, 64, 96, generator=g).cuda()
+        inputs[("noise", 0)] = torch.randn(2, tr._identity_planes(), 64, 96, generator=g).cuda()
         _, ls = tr.train_step(inputs)
         losses.append(float(ls["loss"]))
         if i == 4:
@@ -157,3 +157,33 @@ def test_tuned_plans_train_like_the_default_plans():
         if k.endswith("running_mean") or k.endswith("running_var"):
             a, b = par1_d[k].double(), par1_t[k].double()
             assert float((a - b).abs().max()) <= 2e-4 * float(a.abs().max()) + 1e-7, k       # fp32 rounding through up to 53 layers
+
+
+@pytest.mark.parametrize("flags", [["--no_ssim"], ["--avg_reprojection"], ["--disable_automasking"],
+                                   ["--no_ssim", "--avg_reprojection", "--disable_automasking"]])
+def test_loss_options_train_and_match_the_oracle(flags):
+    """--no_ssim / --avg_reprojection / --disable_automasking (reference options.py, trainer.py:447-451, 480-524) at Trainer level:
+    the graph replay follows the eager step, and the loss the step reports is the oracle's compute_losses of the step's own
+    disparity and warped images under the same options."""
+    from oracle import torch_ref as O
+    from datasets.synthetic import synthetic_batch
+    tr_e, loss_e, _ = run(["--sqd_no_graph"] + flags, steps=5)
+    tr_g, loss_g, _ = run(flags, steps=5)
+    assert tr_e._graph is None and tr_g._graph is not None
+    for a, b in zip(loss_e, loss_g):
+        assert abs(a - b) <= 1e-5 * abs(a) + 1e-7, (loss_e, loss_g)
+    avg, noauto = "--avg_reprojection" in flags, "--disable_automasking" in flags
+    inputs = synthetic_batch(2, 64, 96, start=40, device=tr_e.device)
+    noise = torch.randn(2, 1 if avg else 2, 64, 96, generator=torch.Generator().manual_seed(9))
+    inputs[("noise", 0)] = noise.cuda()
+    tr_e.set_eval()
+    with torch.no_grad():
+        outputs, losses = tr_e.process_batch(inputs)
+    assert ("identity_selection/0" in outputs) == (not noauto)
+    cpu = lambda t: t.detach().float().cpu()
+    want = O.compute_losses(cpu(outputs[("disp", 0)]), cpu(inputs[("color", 0, 0)]), {f: cpu(outputs[("color", f, 0)]) for f in (-1, 1)},
+                            {f: cpu(inputs[("color", f, 0)]) for f in (-1, 1)}, [0, -1, 1], noise, 64, 96,
+                            disparity_smoothness=tr_e.opt.disparity_smoothness, no_ssim="--no_ssim" in flags, avg_reprojection=avg,
+                            disable_automasking=noauto)
+    got, ref = float(losses["loss"]), float(want["loss"])
+    assert abs(got - ref) <= 1e-4 * abs(ref), (got, ref)

@@ -310,3 +310,89 @@ def test_stereo_chain_vs_oracle(ops, O, B, H, W, rows, seed):
     for s, f in enumerate((-1, 1)):
         pose_grad_close(aa.grad[:, s], poses[f][0].grad[:, 0, 0])
         pose_grad_close(tr.grad[:, s], poses[f][1].grad[:, 0, 0])
+
+
+# ---------------------------------------------------------------------------------------------------
+# the reference's loss options: --no_ssim / --avg_reprojection / --disable_automasking (trainer.py:447-451, 480-524)
+LOSS_OPTION_SETS = {"no_ssim": dict(no_ssim=True), "avg": dict(avg_reprojection=True), "no_automask": dict(disable_automasking=True),
+                    "avg_no_automask": dict(avg_reprojection=True, disable_automasking=True),
+                    "no_ssim_avg": dict(no_ssim=True, avg_reprojection=True),
+                    "all": dict(no_ssim=True, avg_reprojection=True, disable_automasking=True)}
+
+
+def run_chain_options(ops, d, H, W, options, rows=0):
+    from sqd import lib
+    flags = lib.loss_flags(**options)
+    disp = dev(d["disp"]).requires_grad_(True)
+    aa = torch.stack([tt(d["axisangle_s0"])[:, 0, 0], tt(d["axisangle_s1"])[:, 0, 0]], 1).cuda().requires_grad_(True)
+    tr = torch.stack([tt(d["translation_s0"])[:, 0, 0], tt(d["translation_s1"])[:, 0, 0]], 1).cuda().requires_grad_(True)
+    tgt, srcs = dev(d["color0"]), [dev(d["color_s0"]), dev(d["color_s1"])]
+    noise = dev(d["noise"][:, :1] if options.get("avg_reprojection") else d["noise"])
+    ident = None if options.get("disable_automasking") else ops.identity_fwd(tgt, srcs, noise, rows, loss_flags=flags)
+    meta = dict(H=H, W=W, invert=[1, 0], smooth_weight=1e-3, rows_per_task=rows, loss_flags=flags)
+    outs = ops.PhotometricChain.apply(disp, aa, tr, dev(d["K"]), dev(d["inv_K"]), tgt, ident, meta, *srcs)
+    return outs, disp, aa, tr, ident
+
+
+def oracle_chain_options(O, d, H, W, options):
+    disp = tt(d["disp"]).requires_grad_(True)
+    poses = {f: (tt(d["axisangle_s%d" % i]).requires_grad_(True), tt(d["translation_s%d" % i]).requires_grad_(True))
+             for i, f in enumerate((-1, 1))}
+    colors = {0: tt(d["color0"]), -1: tt(d["color_s0"]), 1: tt(d["color_s1"])}
+    noise = tt(d["noise"][:, :1] if options.get("avg_reprojection") else d["noise"])
+    out = O.photometric_chain(disp, poses, tt(d["K"]), tt(d["inv_K"]), colors, [0, -1, 1], noise, H, W, **options)
+    out["loss"].backward()
+    return out, disp, poses
+
+
+@pytest.mark.parametrize("name", sorted(LOSS_OPTION_SETS))
+@pytest.mark.parametrize("B,H,W,rows,seed", [(2, 24, 80, 8, 61), (2, 48, 160, 0, 62), (1, 31, 59, 8, 63)])
+def test_loss_options_vs_oracle(ops, O, name, B, H, W, rows, seed):
+    """The fused HIP chain under each set of the reference's loss options against the oracle's compute_losses on the same inputs:
+    identity maps, loss, identity_selection (ties only) and the gradients of disparity and poses."""
+    options = LOSS_OPTION_SETS[name]
+    d = chain_inputs(seed, B, H, W)
+    outs, disp, aa, tr, ident = run_chain_options(ops, d, H, W, options, rows)
+    total, photo, smooth, depth, sel, T = outs[:6]
+    want, wdisp, wposes = oracle_chain_options(O, d, H, W, options)
+    if ident is not None:
+        close(ident, want["identity"], rtol=RTOL, atol=2e-6)
+        ties_only(sel, want, "%s %dx%dx%d" % (name, B, H, W))
+    close(smooth, want["smooth"], rtol=RTOL)
+    close(total, want["loss"], rtol=RTOL)
+    total.backward()
+    grad_close(disp.grad, wdisp.grad)
+    for s, f in enumerate((-1, 1)):
+        pose_grad_close(aa.grad[:, s], wposes[f][0].grad[:, 0, 0])
+        pose_grad_close(tr.grad[:, s], wposes[f][1].grad[:, 0, 0])
+
+
+@pytest.mark.parametrize("tag", ["no_ssim", "avg", "no_automask", "avg_no_automask", "no_ssim_avg"])
+def test_golden_g23_loss_options(ops, golden, tag):
+    """... and against vectors frozen from the imported reference's own compute_losses under those options."""
+    g = golden("g23_loss_options_" + tag)
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    fl = [bool(v) for v in g["flags"]]
+    options = dict(no_ssim=fl[0], avg_reprojection=fl[1], disable_automasking=fl[2])
+    d = chain_inputs(int(g["seed"]), B, H, W)
+    outs, disp, aa, tr, _ = run_chain_options(ops, d, H, W, options)
+    total, sel = outs[0], outs[4]
+    close(total, g["loss"], rtol=RTOL)
+    if not fl[2]:
+        nm = int((sel.cpu().numpy() != g["identity_selection"]).sum())
+        print("identity_selection vs golden %s: %d of %d differ" % (tag, nm, sel.numel()))
+        assert nm <= 5e-4 * sel.numel(), nm
+    total.backward()
+    grad_close(disp.grad, g["grad_disp"])
+    for s, n in enumerate(("m1", "p1")):
+        pose_grad_close(aa.grad[:, s], g["grad_axisangle_" + n][:, 0, 0])
+        pose_grad_close(tr.grad[:, s], g["grad_translation_" + n][:, 0, 0])
+
+
+def test_loss_options_argument_errors(ops):
+    from sqd import lib
+    t = torch.zeros(1, 3, 16, 64, device="cuda")
+    with pytest.raises(RuntimeError, match="two source frames"):
+        ops.identity_fwd(t, [t, t, t], None, loss_flags=lib.LOSS_AVG_REPROJECTION)
+    with pytest.raises(RuntimeError, match="unknown loss_flags"):
+        ops.identity_fwd(t, [t, t], None, loss_flags=8)

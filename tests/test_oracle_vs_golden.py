@@ -61,13 +61,35 @@ def test_g05_g06_ssim(golden):
     close(x.grad, g["grad_pred"], atol=1e-5)
 
 
-def _chain(d, B, H, W, grad=True):
+def _chain(d, B, H, W, grad=True, **loss_options):
     disp = tt(d["disp"]).requires_grad_(grad)
     poses = {f: (tt(d["axisangle_s%d" % i]).requires_grad_(grad), tt(d["translation_s%d" % i]).requires_grad_(grad))
              for i, f in enumerate((-1, 1))}
     colors = {0: tt(d["color0"]), -1: tt(d["color_s0"]), 1: tt(d["color_s1"])}
-    out = O.photometric_chain(disp, poses, tt(d["K"]), tt(d["inv_K"]), colors, [0, -1, 1], tt(d["noise"]), H, W)
+    noise = tt(d["noise"])
+    if loss_options.get("avg_reprojection"):
+        noise = noise[:, :1].contiguous()
+    out = O.photometric_chain(disp, poses, tt(d["K"]), tt(d["inv_K"]), colors, [0, -1, 1], noise, H, W, **loss_options)
     return out, disp, poses
+
+
+@pytest.mark.parametrize("tag", ["no_ssim", "avg", "no_automask", "avg_no_automask", "no_ssim_avg"])
+def test_g23_loss_options(golden, tag):
+    """the oracle's restatement of trainer.py:447-451,480-524 against the reference's own compute_losses under each option set"""
+    g = golden("g23_loss_options_" + tag)
+    B, H, W = int(g["B"]), int(g["H"]), int(g["W"])
+    no_ssim, avg, no_mask = (bool(v) for v in g["flags"])
+    out, disp, poses = _chain(chain_inputs(int(g["seed"]), B, H, W), B, H, W, no_ssim=no_ssim, avg_reprojection=avg, disable_automasking=no_mask)
+    close(out["loss"], g["loss"])
+    if not no_mask:
+        assert np.array_equal(out["identity_selection/0"].numpy(), g["identity_selection"])
+    else:
+        assert "identity_selection/0" not in out
+    out["loss"].backward()
+    close(disp.grad, g["grad_disp"], atol=1e-9)
+    for f, n in ((-1, "m1"), (1, "p1")):
+        close(poses[f][0].grad, g["grad_axisangle_" + n], atol=1e-7)
+        close(poses[f][1].grad, g["grad_translation_" + n], atol=1e-7)
 
 
 @pytest.mark.parametrize("tag", ["a", "b"])
