@@ -311,7 +311,9 @@ int sqd_conv_dgrad_bn(const float *dy, const float *w, const float *addend, floa
 int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *splits, int64_t *part_floats);
 /* measured plan for the weight gradient: impl 1 (+ 16 kt + 256 ct: register tile) = direct-operand kernel, 0 = LDS-tiled kernel,
  * 2 / 3 + 16 * v = shared-operand kernel in fp32 MFMA / three-term bf16 arithmetic on blocks v = 0..3 of 128x128, 64x128, 128x64,
- * 64x64 filters x channels (K, C divisible by the block), -1 = clear.  Plans are keyed by (N, Ho, Wo, C, K, R, S).            */
+ * 64x64 filters x channels (K, C divisible by the block), 4 = row-window kernel (stride 1; K in {16,32,64} filters x C in {16,32,96}
+ * channels x 3x3 / 4x4 taps as instantiated — others are refused; `splits` = workgroups, each holding the whole filter bank),
+ * -1 = clear.  Plans are keyed by (N, Ho, Wo, C, K, R, S); a strided convolution of that key under an impl-4 plan runs impl 1. */
 int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int impl, int splits);
 int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C, int K,
                    int R, int S, int stride, int pad, int Ho, int Wo, void *stream);

@@ -1269,6 +1269,205 @@ __global__ __launch_bounds__(256) void conv_wgrad_shared_kernel(const float *__r
 }
 
 // ---------------------------------------------------------------------------------------------------
+// wgrad, row-window kernel (impl 4): for the high-resolution layers with FEW channels (K = 16 KT <= 64 filters, C = 16 CT channels,
+// R x R taps, stride 1) the kernels above spend their time fetching: every tap re-reads the x rows (9 - 16 times), and with 16
+// filters a dy fetch feeds one or two MFMAs.  Here a workgroup holds the WHOLE dw [K][R][R][C] in the accumulators of its waves and
+// walks output rows in chunks of PXW pixels: the R input rows of the window (PXW + R - 1 pixels, all channels) sit in an LDS ring of
+// R + 1 slots in memory order, one new row per step (fetched into registers while the current step multiplies), the dy row in a
+// double buffer; every tap is a shifted read of the same rows.  The IG x PG waves split the (tap, channel tile) items IG ways (wave
+// ig owns items ig, ig + IG, ... for all KT filter tiles: per 4 pixels KT + NB LDS reads feed KT * NB MFMAs) and the 4-pixel groups
+// of a step PG ways; the PG pixel groups add their accumulators through LDS once, at the end.  Row strides are = 16 (mod 32) floats
+// so that the pixel groups of a read fall on disjoint banks.  Steps (image, column chunk, row) are dealt to the workgroups as equal
+// contiguous ranges; part[split = workgroup][k][r][s][c] as for the other kernels.
+// ---------------------------------------------------------------------------------------------------
+template <int KT, int CT, int R, int IG, int PG, int PXW>
+__global__ __launch_bounds__(IG * PG * 64, IG * PG == 8 ? 1 : 2) void conv_wgrad_rows_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                                             float *__restrict__ part, ConvGeom g, int steps_per_wg,
+                                                                                             int nchunks, int nsplits, float *__restrict__ bias_part) {
+    constexpr int NTH = IG * PG * 64, K = 16 * KT, C = 16 * CT, XW = PXW + R - 1;
+    constexpr int KS = K + (K % 32 == 16 ? 0 : 16), CS = C + (C % 32 == 16 ? 0 : 16);     // LDS row strides (floats)
+    constexpr int NI = CT * R * R, NB = (NI + IG - 1) / IG;                                // (tap, channel tile) items; per wave
+    constexpr int XV = (XW * C / 4 + NTH - 1) / NTH, DV = (PXW * K / 4 + NTH - 1) / NTH;   // float4 fetches per thread and row
+    constexpr int NKS = PXW / 4 / PG;                                                      // 4-pixel groups per wave and step
+    static_assert(PXW % (4 * PG) == 0 && (IG * PG == 4 || IG * PG == 8), "wave grid");
+    constexpr int RING = (R + 1) * XW * CS, DYB = 2 * PXW * KS, RED = IG * NB * KT * 256;
+    constexpr int LDSF = (RING + DYB > RED ? RING + DYB : RED) + PG * K;
+    __shared__ __attribute__((aligned(16))) float lds[LDSF];
+    float *xs = lds, *dys = lds + RING, *red = lds, *bred = lds + LDSF - PG * K;
+    const int t = threadIdx.x, lane = t & 63, wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int ig = wave % IG, pg = wave / IG;
+    const int i16 = lane & 15, pq = lane >> 4;
+    const int split = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);             // neighbouring step ranges on one XCD
+    if (split >= nsplits) return;
+    const int total = g.N * nchunks * g.Ho;
+    const int s_beg = split * steps_per_wg, s_end = min(total, s_beg + steps_per_wg);
+    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(dy, (unsigned)(g.N * g.Ho * g.Wo * g.K) * 4u);
+    const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(x, (unsigned)(g.N * g.H * g.W * g.C) * 4u);
+
+    // this wave's items: LDS offset of (tap column s, channel tile) inside a row slot, and the tap row
+    int ioff[NB], irow[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int it = min(ig + IG * b, NI - 1);                // (a missing last item repeats the previous one and is not stored)
+        const int ct = it % CT, tap = it / CT, r = tap / R, sx = tap - r * R;
+        ioff[b] = sx * CS + ct * 16;
+        irow[b] = r;
+    }
+    float4 rx[XV], rd[DV];
+    auto fetch_x = [&](int n, int hi, int w0) {                // input row hi of image n, pixels w0 - pad .. + XW
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int idx = t + i * NTH, px = idx / (C / 4), c4 = idx - px * (C / 4);
+            const int wi = w0 - g.pad + px;
+            const bool ok = idx < XW * C / 4 && (unsigned)hi < (unsigned)g.H && (unsigned)wi < (unsigned)g.W;
+            rx[i] = buf_load4(x_rsrc, ok ? ((unsigned)((n * g.H + hi) * g.W + wi) * C + c4 * 4) * 4u : 0xffffffffu);
+        }
+    };
+    auto store_x = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < XV; ++i) {
+            const int idx = t + i * NTH, px = idx / (C / 4), c4 = idx - px * (C / 4);
+            if (idx < XW * C / 4) *reinterpret_cast<float4 *>(&xs[slot * (XW * CS) + px * CS + c4 * 4]) = rx[i];
+        }
+    };
+    auto fetch_dy = [&](int n, int ho, int w0) {
+#pragma unroll
+        for (int i = 0; i < DV; ++i) {
+            const int idx = t + i * NTH, px = idx / (K / 4), k4 = idx - px * (K / 4);
+            const bool ok = idx < PXW * K / 4 && w0 + px < g.Wo;
+            rd[i] = buf_load4(dy_rsrc, ok ? ((unsigned)((n * g.Ho + ho) * g.Wo + w0 + px) * K + k4 * 4) * 4u : 0xffffffffu);
+        }
+    };
+    auto store_dy = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < DV; ++i) {
+            const int idx = t + i * NTH, px = idx / (K / 4), k4 = idx - px * (K / 4);
+            if (idx < PXW * K / 4) *reinterpret_cast<float4 *>(&dys[buf * (PXW * KS) + px * KS + k4 * 4]) = rd[i];
+        }
+    };
+    auto slot_of = [&](int hi) { return (hi + g.pad) % (R + 1); };     // ring slot of input row hi (hi >= -pad)
+
+    f32x4 acc[NB][KT];
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int q = 0; q < KT; ++q) acc[b][q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float bsum[KT];
+#pragma unroll
+    for (int q = 0; q < KT; ++q) bsum[q] = 0.f;
+
+    int step = s_beg;
+    while (step < s_end) {
+        // ---- a column run: (n, chunk) fixed, rows ho0 .. ho1 - 1
+        const int ho0 = step % g.Ho, col = step / g.Ho, chunk = col % nchunks, n = col / nchunks;
+        const int ho1 = min(g.Ho, ho0 + (s_end - step));
+        const int w0 = chunk * PXW;
+        __syncthreads();                                       // the previous run's last step still reads the ring
+        for (int r = 0; r < R; ++r) {                          // the first window, row by row through the fetch registers
+            const int hi = ho0 - g.pad + r;
+            fetch_x(n, hi, w0);
+            if (r == 0) fetch_dy(n, ho0, w0);
+            store_x(slot_of(hi));
+        }
+        store_dy(ho0 & 1);
+        __syncthreads();
+        for (int ho = ho0; ho < ho1; ++ho) {
+            const bool more = ho + 1 < ho1;
+            if (more) {                                        // next step's new row and dy row into registers
+                fetch_x(n, ho + 1 - g.pad + R - 1, w0);
+                fetch_dy(n, ho + 1, w0);
+            }
+            int rowbase[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) rowbase[r] = slot_of(ho - g.pad + r) * (XW * CS);
+            int bbase[NB];
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                int rb = rowbase[0];
+#pragma unroll
+                for (int r = 1; r < R; ++r) rb = irow[b] == r ? rowbase[r] : rb;
+                bbase[b] = rb + ioff[b] + (pg * NKS * 4 + pq) * CS + i16;
+            }
+            const float *dl = &dys[(ho & 1) * (PXW * KS) + (pg * NKS * 4 + pq) * KS + i16];
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                float a[KT];
+#pragma unroll
+                for (int q = 0; q < KT; ++q) a[q] = dl[ks * 4 * KS + q * 16];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const float bv = xs[bbase[b] + ks * 4 * CS];
+#pragma unroll
+                    for (int q = 0; q < KT; ++q) acc[b][q] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q], bv, acc[b][q], 0, 0, 0);
+                }
+                if (bias_part != nullptr) {
+#pragma unroll
+                    for (int q = 0; q < KT; ++q) bsum[q] += a[q];
+                }
+                // half way through: the next step's rows have arrived; their LDS stores run under the remaining MFMAs (the slots
+                // written are not read by this step: ring of R + 1, dy double buffer)
+                if (ks == (NKS - 1) / 2 && more) {
+                    store_x(slot_of(ho + 1 - g.pad + R - 1));
+                    store_dy((ho + 1) & 1);
+                }
+            }
+            __syncthreads();
+        }
+        step += ho1 - ho0;
+    }
+    // ---- the PG pixel groups add up (fixed order: pg = PG - 1 first) through LDS; the pg = 0 waves then hold the sums
+    if (bias_part != nullptr && ig == 0) {
+#pragma unroll
+        for (int q = 0; q < KT; ++q) {
+            float v = bsum[q];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            if (pq == 0) bred[pg * K + q * 16 + i16] = v;
+        }
+    }
+#pragma unroll 1
+    for (int p = PG - 1; p >= 1; --p) {
+        __syncthreads();                                       // (first round: the last step's reads of the ring are done)
+        if (pg == p) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < KT; ++q)
+                    *reinterpret_cast<f32x4 *>(&red[((ig * NB + b) * KT + q) * 256 + lane * 4]) = acc[b][q];
+        }
+        __syncthreads();
+        if (pg == 0) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int q = 0; q < KT; ++q) acc[b][q] += *reinterpret_cast<const f32x4 *>(&red[((ig * NB + b) * KT + q) * 256 + lane * 4]);
+        }
+    }
+    if (PG == 1) __syncthreads();
+    // ---- C/D layout of the 16x16 MFMA: row (filter) = 4 * pq + v, column (channel) = i16
+    if (pg == 0) {
+        float *po = part + (size_t)split * K * R * R * C;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int it = ig + IG * b;
+            if (it < NI) {
+                const int ct = it % CT, tap = it / CT;
+#pragma unroll
+                for (int q = 0; q < KT; ++q)
+#pragma unroll
+                    for (int v = 0; v < 4; ++v) po[((size_t)(q * 16 + 4 * pq + v) * R * R + tap) * C + ct * 16 + i16] = acc[b][q][v];
+            }
+        }
+    }
+    if (bias_part != nullptr && t < K) {                       // column sums of dy (every item group read all of it: group 0 reports)
+        float v = bred[t];
+#pragma unroll
+        for (int p = 1; p < PG; ++p) v += bred[p * K + t];
+        bias_part[(size_t)split * K + t] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // wgrad on the bf16 matrix cores with three-term operands (the arithmetic of the bk + 1024 forward / data-gradient plans: every
 // fp32 value as the exact sum of three bf16 terms, 6 of the 9 partial products, fp32 accumulation — fp32-level accuracy at 6/16 of
 // the fp32 kernels' matrix-pipe time).  v_mfma_f32_32x32x16_bf16 wants 8 consecutive reduction elements — here: pixels — per lane,
@@ -1890,7 +2089,18 @@ struct WgradPlan {
     int shared = 0;                 // 1..4: shared-operand kernel, block 128x128 / 64x128 / 128x64 / 64x64 (filters x channels); 0: not
     int split3 = 0;                 // with shared != 0: the three-term bf16 kernel on the same blocks (impl 3) instead of fp32 (impl 2)
     int px_per_split = 0;
+    int rows = 0;                   // row-window kernel (impl 4): `splits` workgroups of `steps_per_wg` (image, column chunk, row) steps
+    int steps_per_wg = 0, nchunks = 0;
 };
+// (filters, channels, taps) the row-window kernel is instantiated for
+static bool rows_shape(int C, int K, int R, int S) {
+    if (R != S || C % 16 || K % 16) return false;
+    const int kt = K / 16, ct = C / 16;
+    if (R == 3) return (kt == 1 && (ct == 6 || ct == 2 || ct == 1)) || (kt == 2 && (ct == 2 || ct == 1)) || (kt == 4 && ct == 1);
+    if (R == 4) return (kt == 1 && ct == 2) || (kt == 4 && ct == 1);
+    return false;
+}
+static int rows_pxw(int) { return 64; }                       // pixels per step of the row-window kernel's instantiations
 static void shared_block(int variant, int &tk, int &tc) {
     tk = (variant == 1 || variant == 3) ? 128 : 64;
     tc = (variant == 1 || variant == 2) ? 128 : 64;
@@ -1910,11 +2120,28 @@ static bool wplan_lookup(int N, int Ho, int Wo, int C, int K, int R, int S, int 
     return true;
 }
 
-static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, int S) {
+static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, int S, int stride = 1) {
     WgradPlan p;
     const int M = N * Ho * Wo;
     int m_impl = -1, m_splits = 0;
     const bool measured = wplan_lookup(N, Ho, Wo, C, K, R, S, m_impl, m_splits);
+    if (measured && (m_impl & 15) == 4) {
+        if (stride == 1) {                                       // row-window kernel: `m_splits` workgroups
+            p.direct = false;
+            p.kt = p.ct = p.tp = 1;
+            p.px_per_wave = 0;
+            p.rows = 1;
+            p.nchunks = (Wo + rows_pxw(C) - 1) / rows_pxw(C);
+            const int total = N * p.nchunks * Ho;
+            int sp = std::min(std::max(m_splits, 1), total);
+            const int64_t wsz = (int64_t)K * R * S * C;
+            while (sp > 1 && (int64_t)sp * wsz * 4 > (64ll << 20)) --sp;
+            p.steps_per_wg = (total + sp - 1) / sp;
+            p.splits = (total + p.steps_per_wg - 1) / p.steps_per_wg;
+            return p;
+        }
+        m_impl = 1;             // the plan table does not key on the stride: a strided convolution of the same output geometry runs the
+    }                           // direct kernel on (at most) the same number of splits, inside the workspace the plan query reported
     if (measured && ((m_impl & 15) == 2 || (m_impl & 15) == 3)) {      // shared-operand kernels (measured plans only)
         p.split3 = (m_impl & 15) == 3;
         p.direct = false;
@@ -1966,7 +2193,7 @@ static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, i
 extern "C" int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *splits, int64_t *part_floats) {
     const int M = N * Ho * Wo;
     const WgradPlan dp = plan_wgrad_direct(N, Ho, Wo, C, K, R, S);
-    if (dp.direct || dp.shared) {
+    if (dp.direct || dp.shared || dp.rows) {
         if (splits) *splits = dp.splits;
         if (part_floats) *part_floats = (int64_t)dp.splits * K * R * S * C;
         return SQD_OK;
@@ -1999,6 +2226,12 @@ extern "C" int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int 
         return SQD_OK;
     }
     const int kt = (impl >> 4) & 15, ct = (impl >> 8) & 15;      // optional register-tile shape of the direct kernel: 16*kt x 16*ct
+    if ((impl & 15) == 4) {                                      // row-window kernel (stride 1; few channels): `splits` workgroups
+        SQD_CHECK_ARG(impl == 4 && rows_shape(C, K, R, S) && splits >= 1 && splits <= 65535,
+                      "sqd_conv_wgrad_set_plan: the row-window kernel is not built for C=%d K=%d %dx%d", C, K, R, S);
+        wplan_table()[WPlanKey(N, Ho, Wo, C, K, R, S)] = std::make_pair(impl, splits);
+        return SQD_OK;
+    }
     if ((impl & 15) == 2 || (impl & 15) == 3) {                  // shared-operand kernels: impl 2 (fp32) | 3 (three-term bf16) + 16 * variant
         const int variant = (impl >> 4) + 1;
         int tk, tc;
@@ -2033,8 +2266,23 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
     pps = ((pps + BK - 1) / BK) * BK;
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
-    const WgradPlan dp = plan_wgrad_direct(N, Ho, Wo, C, K, R, S);
-    if (dp.shared) {
+    const WgradPlan dp = plan_wgrad_direct(N, Ho, Wo, C, K, R, S, stride);
+    if (dp.rows) {
+        const dim3 grid((dp.splits + 7) / 8 * 8);
+        float *bias_part = dbias ? part + (size_t)dp.splits * K * R * S * C : nullptr;   // [splits][K]
+#define LAUNCH_WR(KT, CT, RR, IG, PG, PXW)                                                                                     \
+    hipLaunchKernelGGL((conv_wgrad_rows_kernel<KT, CT, RR, IG, PG, PXW>), grid, dim3(IG * PG * 64), 0, st, dy, x, part, g,         \
+                       dp.steps_per_wg, dp.nchunks, dp.splits, bias_part)
+        const int kt = K / 16, ct = C / 16;
+        if (R == 3 && kt == 1 && ct == 6) LAUNCH_WR(1, 6, 3, 4, 2, 64);
+        else if (R == 3 && kt == 1 && ct == 2) LAUNCH_WR(1, 2, 3, 2, 4, 64);
+        else if (R == 3 && kt == 1 && ct == 1) LAUNCH_WR(1, 1, 3, 1, 8, 64);
+        else if (R == 3 && kt == 2 && ct == 2) LAUNCH_WR(2, 2, 3, 2, 4, 64);
+        else if (R == 3 && kt == 2 && ct == 1) LAUNCH_WR(2, 1, 3, 1, 8, 64);
+        else if (R == 3 && kt == 4 && ct == 1) LAUNCH_WR(4, 1, 3, 1, 8, 64);
+        else if (R == 4 && kt == 1 && ct == 2) LAUNCH_WR(1, 2, 4, 4, 2, 64);
+        else LAUNCH_WR(4, 1, 4, 4, 2, 64);
+    } else if (dp.shared) {
         int tk, tc;
         shared_block(dp.shared, tk, tc);
         const dim3 grid(((K / tk) * (C / tc) * R * S * dp.splits + 7) / 8 * 8);
@@ -2081,8 +2329,9 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
     const size_t wsz = (size_t)K * R * S * C;
     // (leaving the ~100 reductions of a backward pass to two or three multi-task launches at its end was measured: bit-identical and
     // 0.7 ms SLOWER per step — reduced on the spot the partials of most layers are still in the 256 MB Infinity Cache)
+    if (dp.direct || dp.shared || dp.rows) splits = dp.splits;    // (a strided convolution under a row-window plan: see plan_wgrad_direct)
     hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((wsz / 4 + 15) / 16)), dim3(256), 0, st, part, dw, wsz, splits);
-    if (dbias && dp.direct && !dp.shared) {
+    if (dbias && ((dp.direct && !dp.shared) || dp.rows)) {
         hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((K / 4 + 15) / 16)), dim3(256), 0, st, part + (size_t)splits * wsz, dbias,
                            (size_t)K, splits);
     } else if (dbias) {

@@ -204,6 +204,7 @@ TUNE_SPACE = {
     "bk64": False,             # bk 64+512 on the single-buffered 64x64 tile: picked for 11 layer-modes, no gain on the totals
     "eight_wave": False,       # bk +256: 8-wave workgroups — 1-3 % on a third of the layers, nothing on the step
     "wgrad_shapes": False,     # smaller register tiles of the direct weight gradient: 7 of 38 layers, nothing on the step
+    "wgrad_rows": True,        # impl 4: the row-window weight gradient of the few-channel / high-resolution layers
     "stats_penalty": True,     # charge split-K forward plans the BatchNorm statistics pass they force
     "log": False,
 }
@@ -321,6 +322,12 @@ def _tune_wgrad(geom, has_bias, launch):
             sp = max(1, (target + blocks - 1) // blocks)
             if sp not in tried and trial(base_impl | (v << 4), sp):
                 tried.add(sp)
+    # row-window kernel (impl 4): few channels, stride 1 — the whole filter bank in one workgroup's accumulators, `sp` workgroups
+    # (the library refuses the shapes it is not built for)
+    if stride == 1 and R == S and TUNE_SPACE["wgrad_rows"]:
+        for sp in (256, 384, 512, 768, 1024):
+            if not trial(4, sp):
+                break
     _register_wgrad_plan((N, Ho, Wo, C, K, R, S), best[1:])
     if TUNE_SPACE["log"]:
         print("sqd conv plan wgrad", geom, best, "model splits", base, flush=True)
@@ -376,7 +383,7 @@ def plan_mix():
     mix = {}
     for k, v in CHOSEN_PLANS.items():
         if k[0] == "wgrad":
-            name = {0: "fp32 lds-tiled", 1: "fp32 direct", 2: "fp32 shared-operand", 3: "bf16x3 shared-operand"}[v[0] & 15]
+            name = {0: "fp32 lds-tiled", 1: "fp32 direct", 2: "fp32 shared-operand", 3: "bf16x3 shared-operand", 4: "fp32 row-window"}[v[0] & 15]
         else:
             bk = v[3]
             name = "bf16x3 input-patch" if bk & 2048 else "bf16x3 implicit-gemm" if bk & 1024 else "fp32 implicit-gemm"

@@ -528,3 +528,53 @@ def test_stem_with_input_patch_plan_feeds_batchnorm_statistics(bm, bn_t):
     assert torch.allclose(y.detach().cpu().double(), yr.detach(), rtol=1e-4, atol=2e-4)
     assert torch.allclose(bn_g.running_var.cpu().double(), bn.running_var, rtol=1e-4, atol=1e-5)
     assert float((gw.cpu().double() - gwr).abs().max()) <= 1e-3 * float(gwr.abs().max())
+
+
+@pytest.mark.parametrize("N,C,H,W,K,R,pad,bias,splits", [
+    (2, 96, 24, 80, 16, 3, 1, True, 40), (1, 32, 17, 45, 16, 4, 2, False, 7), (2, 16, 33, 70, 64, 4, 2, True, 1000),
+    (2, 32, 24, 40, 32, 3, 1, True, 16), (1, 16, 9, 31, 32, 3, 1, False, 3), (3, 16, 12, 64, 16, 3, 1, True, 5),
+    (1, 16, 20, 33, 64, 3, 0, False, 9), (2, 32, 8, 100, 16, 3, 1, False, 1)])
+def test_wgrad_row_window_kernel(N, C, H, W, K, R, pad, bias, splits):
+    """the row-window weight-gradient kernel (impl 4: whole filter bank per workgroup, x rows in an LDS ring) against float64 —
+    ragged column chunks, column runs that start mid-image, more workgroups than steps, padding 0 / 1 / 2, 3x3 and 4x4 taps."""
+    from sqd import lib, nnkernels
+    L = lib.lib()
+    torch.manual_seed(C + K + R)
+    conv = nn.Conv2d(C, K, R, 1, pad, bias=bias)
+    x = torch.randn(N, C, H, W)
+    conv64 = nn.Conv2d(C, K, R, 1, pad, bias=bias).double()
+    conv64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    yr = conv64(x.double())
+    wgt = torch.randn(yr.shape)
+    (yr * wgt.double()).sum().backward()
+    Ho, Wo = yr.shape[2:]
+    try:
+        assert L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, R, 4, splits) == 0
+        nnkernels._PLAN_CACHE.clear()
+        conv_g = nn.Conv2d(C, K, R, 1, pad, bias=bias).cuda()
+        conv_g.load_state_dict(conv.state_dict())
+        conv_g = conv_g.to(memory_format=torch.channels_last)
+        xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = nnkernels.conv2d_native(xg, conv_g, None)
+        (y * wgt.cuda()).sum().backward()
+        if R == 3:           # a strided convolution that shares the plan key runs the direct kernel inside the same workspace
+            conv_s = nn.Conv2d(C, K, R, 2, pad, bias=bias).cuda().to(memory_format=torch.channels_last)
+            conv_s.load_state_dict(conv.state_dict())
+            xs = torch.randn(N, C, 2 * Ho + R - 2 * pad - 2, 2 * Wo + R - 2 * pad - 2)
+            ys64 = F.conv2d(xs.double(), conv64.weight.detach(), None, 2, pad)
+            assert tuple(ys64.shape[2:]) == (Ho, Wo)
+            w64 = conv64.weight.detach().clone().requires_grad_(True)
+            (F.conv2d(xs.double(), w64, None, 2, pad) * wgt.double()).sum().backward()
+            ysg = nnkernels.conv2d_native(xs.cuda().contiguous(memory_format=torch.channels_last), conv_s, None)
+            (ysg * wgt.cuda()).sum().backward()
+            err, scale = float((conv_s.weight.grad.cpu().double() - w64.grad).abs().max()), float(w64.grad.abs().max())
+            assert err <= 1e-4 * scale, ("strided dw", err, scale)
+    finally:
+        L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, R, -1, 0)
+        nnkernels._PLAN_CACHE.clear()
+    pairs = [("dw", conv_g.weight.grad, conv64.weight.grad)] + ([("db", conv_g.bias.grad, conv64.bias.grad)] if bias else [])
+    for name, a, b in pairs:
+        err, scale = float((a.cpu().double() - b).abs().max()), float(b.abs().max())
+        assert err <= 1e-4 * scale, (name, err, scale)
+    assert L.sqd_conv_wgrad_set_plan(N, Ho, Wo, 64, 64, 3, 3, 4, 4) != 0          # 64 x 64 x 9: not instantiated, refused
+    assert L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, 5, 5, 4, 4) != 0            # 5x5 taps: refused

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Same-box A/B of bench.py with a product module attribute flipped (dev tool): alternates the two settings in fresh processes.
-usage: python tools/ab_bench.py nnkernels.FUSE_BN_BWD_STATS=False [--rounds 3] [bench.py arguments ...]"""
+usage: python tools/ab_bench.py nnkernels.FUSE_BN_BWD_STATS=False | "nnkernels.TUNE_SPACE[wgrad_rows]=False" [--rounds 3] [bench.py arguments ...]"""
 import json
 import os
 import subprocess
@@ -16,7 +16,11 @@ if setting:
     name, _, val = rest.partition("=")
     import importlib
     m = importlib.import_module("sqd." + mod)
-    setattr(m, name, eval(val))
+    if "[" in name:                                   # nnkernels.TUNE_SPACE[wgrad_rows]=False
+        name, _, key = name.partition("[")
+        getattr(m, name)[key.rstrip("]")] = eval(val)
+    else:
+        setattr(m, name, eval(val))
 import bench
 sys.argv = ["bench.py"] + %(args)r
 bench.main()

@@ -20,11 +20,11 @@ dw = torch.empty(K, R, R, C, device="cuda")
 P = lambda t: ctypes.c_void_p(t.data_ptr())
 S = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 gflop = 2.0 * N * Ho * Wo * K * C * R * R / 1e9
-names = {0: "lds-tiled fp32", 1: "direct fp32", 2: "shared fp32", 3: "shared 3xbf16"}
-for impl, variants in ((1, [0]), (0, [0]), (2, range(4)), (3, range(4))):
+names = {0: "lds-tiled fp32", 1: "direct fp32", 2: "shared fp32", 3: "shared 3xbf16", 4: "row-window fp32"}
+for impl, variants in ((1, [0]), (0, [0]), (2, range(4)), (3, range(4)), (4, [0])):
     for v in variants:
         best = None
-        for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128):
+        for sp in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128) + ((192, 256, 384, 512, 768, 1024, 1536) if impl == 4 else ()):
             code = impl | (v << 4) if impl >= 2 else impl
             if L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, R, code, sp) != 0:
                 continue
