@@ -228,27 +228,41 @@ __global__ __launch_bounds__(256) void sql_fwd_kernel(const float *__restrict__ 
     }
 }
 
-// merge the per-workgroup partials: summary[b,q,e], lse[b,q,2] = (max, 1/sum)
+// merge the per-workgroup partials: summary[b,q,e], lse[b,q,2] = (max, 1/sum).  One wavefront per (b, q): the lanes take the
+// chunks in parallel for the maximum and the sum (fixed-order butterflies), leave the chunk weights in LDS, and then take the features
+// — every load of a pass is independent of the others (the first version chained three serial loops over the chunks: 32-44 us).
 __global__ __launch_bounds__(64) void sql_merge_kernel(const float *__restrict__ part, float *__restrict__ summary,
                                                        float *__restrict__ lse, int Q, int E, int nchunks) {
+    extern __shared__ float wl[];                        // [nchunks] weight exp(max_k - max) of every chunk
     const int b = blockIdx.y, q = blockIdx.x, lane = threadIdx.x;
-    const size_t rec = (size_t)(E + PART_STRIDE_EXTRA);
-    const float *p0 = part + ((size_t)b * nchunks) * Q * rec + (size_t)q * rec;
+    const size_t rec = (size_t)(E + PART_STRIDE_EXTRA), cs = (size_t)Q * rec;
+    const float *p0 = part + ((size_t)b * nchunks) * cs + (size_t)q * rec;
     float M = -INFINITY;
-    for (int k = 0; k < nchunks; ++k) M = fmaxf(M, p0[(size_t)k * Q * rec]);
+    for (int k = lane; k < nchunks; k += 64) M = fmaxf(M, p0[(size_t)k * cs]);
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) M = fmaxf(M, __shfl_xor(M, o, 64));
     float L = 0.f;
-    for (int k = 0; k < nchunks; ++k) {
-        const float *p = p0 + (size_t)k * Q * rec;
-        L += p[1] * (p[0] == -INFINITY ? 0.f : __expf(p[0] - M));
+    for (int k = lane; k < nchunks; k += 64) {
+        const float mk = p0[(size_t)k * cs];
+        const float w = mk == -INFINITY ? 0.f : __expf(mk - M);
+        wl[k] = w;
+        L += p0[(size_t)k * cs + 1] * w;
     }
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) L += __shfl_xor(L, o, 64);
+    __syncthreads();
     const float iL = 1.f / L;
     for (int e = lane; e < E; e += 64) {
-        float s = 0.f;
-        for (int k = 0; k < nchunks; ++k) {
-            const float *p = p0 + (size_t)k * Q * rec;
-            s += p[2 + e] * (p[0] == -INFINITY ? 0.f : __expf(p[0] - M));
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int k = 0;
+        for (; k + 3 < nchunks; k += 4) {
+            s0 += p0[(size_t)k * cs + 2 + e] * wl[k];
+            s1 += p0[(size_t)(k + 1) * cs + 2 + e] * wl[k + 1];
+            s2 += p0[(size_t)(k + 2) * cs + 2 + e] * wl[k + 2];
+            s3 += p0[(size_t)(k + 3) * cs + 2 + e] * wl[k + 3];
         }
-        summary[((size_t)b * Q + q) * E + e] = s * iL;
+        for (; k < nchunks; ++k) s0 += p0[(size_t)k * cs + 2 + e] * wl[k];
+        summary[((size_t)b * Q + q) * E + e] = ((s0 + s1) + (s2 + s3)) * iL;
     }
     if (lane == 0) {
         lse[((size_t)b * Q + q) * 2] = M;
@@ -477,18 +491,229 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
     }
 }
 
-// g_K[b,q,e] = sum over chunks of gK_part
+// g_K[b,q,e] = sum over chunks of gK_part: 64 outputs per workgroup, the chunks dealt to its four waves (fixed order), added through LDS
 __global__ __launch_bounds__(256) void sql_gk_reduce_kernel(const float *__restrict__ part, float *__restrict__ gK, int QE,
                                                             int nchunks) {
-    const int b = blockIdx.y, idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= QE) return;
-    float s = 0.f;
-    for (int k = 0; k < nchunks; ++k) s += part[((size_t)b * nchunks + k) * QE + idx];
-    gK[(size_t)b * QE + idx] = s;
+    __shared__ float red[4][64];
+    const int b = blockIdx.y, lane = threadIdx.x & 63, grp = threadIdx.x >> 6, idx = blockIdx.x * 64 + lane;
+    float s0 = 0.f, s1 = 0.f;
+    if (idx < QE) {
+        int k = grp;
+        for (; k + 4 < nchunks; k += 8) {
+            s0 += part[((size_t)b * nchunks + k) * QE + idx];
+            s1 += part[((size_t)b * nchunks + k + 4) * QE + idx];
+        }
+        if (k < nchunks) s0 += part[((size_t)b * nchunks + k) * QE + idx];
+    }
+    red[grp][lane] = s0 + s1;
+    __syncthreads();
+    if (grp == 0 && idx < QE) gK[(size_t)b * QE + idx] = ((red[0][lane] + red[1][lane]) + red[2][lane]) + red[3][lane];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// forward, second formulation (the one dispatched for pixel-major x with 32 or 64 features): v_mfma_f32_32x32x2_f32 in the
+// orientation of the backward — D[q][pixel], lane = pixel — so that every store of y is a 128-byte row per half-wave and x is read
+// as 64-byte runs per lane / 128-byte rows per half-wave (the 16x16 kernel above fetches x and K as 16-byte pieces of 16 lines per
+// instruction and re-reads K from memory every step: 111 us at config B against 28 us of y traffic).
+//   y^T tile   D[q][n]  = sum_e K[q][e] x[n][e]        A = K from LDS, B = the lane's own 16 features (k-slot (s, h) = feature 16 h + s)
+//   p          = exp(D - ref[q])                        ref[q]: the row maximum of the wave's FIRST tile; softmax does not care which
+//                                                       reference is used as long as nothing overflows, so later tiles only test
+//                                                       D - ref <= 60 (one ballot) and take the rescale path when the test fails
+//   summary    D2[q][e] += sum_n p[q][n] x[n][e]        A = p through a wave-private LDS tile [q][pixel], B = x rows (lane = feature)
+// Per-lane partial row sums of p (lane = pixel class mod 32) are added across lanes once, at the end; the four waves of a workgroup
+// are merged through LDS into one (max, sum, unnormalised summary) record of the layout sql_merge_kernel reads.
+// ---------------------------------------------------------------------------------------------------
+constexpr int PT = 33;                                   // floats per row of the wave-private [q][32 pixels] probability tile
+__device__ __forceinline__ float half_max(float v) {     // over the 32 lanes of a half-wave
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    v = fmaxf(v, __shfl_xor(v, 2, 64));
+    v = fmaxf(v, __shfl_xor(v, 4, 64));
+    v = fmaxf(v, __shfl_xor(v, 8, 64));
+    return fmaxf(v, __shfl_xor(v, 16, 64));
+}
+__device__ __forceinline__ float half_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v + __shfl_xor(v, 16, 64);
+}
+
+template <int QT, int EH>
+__global__ __launch_bounds__(256) void sql_fwd32_kernel(const float *__restrict__ x, const float *__restrict__ K, float *__restrict__ y,
+                                                        float *__restrict__ part, int Qall, int N, int tiles_per_wave, int nchunks) {
+    // blockIdx.z selects a group of 32 QT queries (Q of them valid, Qall in total): E = 64 with more than 64 queries runs as two groups
+    constexpr int E = 32 * EH, QP = 32 * QT, EP = E + 1;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Kl = lds;                                     // [QP][EP]
+    float *refl = Kl + QP * EP;                          // [4 waves][QP]
+    float *ptile = refl + 4 * QP;                        // [4 waves][32][PT]
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, chunk = blockIdx.x, q0 = blockIdx.z * QP, Q = min(QP, Qall - q0);
+    const float *xb = x + (size_t)b * E * N;
+    float *yb = y + ((size_t)b * Qall + q0) * N;
+    const __amdgpu_buffer_rsrc_t x_r = sql_rsrc(xb, (unsigned)(E * N) * 4u);
+    const __amdgpu_buffer_rsrc_t y_r = sql_rsrc(yb, (unsigned)(Q * N) * 4u);
+    for (int idx = threadIdx.x; idx < QP * EP; idx += 256) {
+        const int q = idx / EP, e = idx - q * EP;
+        Kl[idx] = (q < Q && e < E) ? K[((size_t)b * Qall + q0 + q) * E + e] : 0.f;
+    }
+    __syncthreads();
+    float *rl = refl + wave * QP, *pt = ptile + wave * 32 * PT;
+
+    f32x16 acc2[QT][EH];
+    float lsum[QT][16];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+#pragma unroll
+        for (int eh = 0; eh < EH; ++eh)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[qt][eh][r] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lsum[qt][r] = 0.f;
+    }
+    const int tile0 = (chunk * 4 + wave) * tiles_per_wave, ntiles = (N + 31) / 32;
+    bool first = true;
+    for (int tl = tile0; tl < min(ntiles, tile0 + tiles_per_wave); ++tl) {
+        const int n0 = tl * 32, n = n0 + i;
+        const bool pv = n < N;
+        // ---- x in the two operand layouts: the lane's pixel (16 features per half, 4 x 16-byte loads per 32 features) and, for the
+        // summary product, rows of pixels (lane = feature, k-slot (s, h) = pixel 2 s + h)
+        float xr[EH][16], xc[EH][16];
+        const unsigned po = pv ? ((unsigned)n * E + 16u * h) * 4u : SQL_OOB;
+#pragma unroll
+        for (int eh = 0; eh < EH; ++eh)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) {
+                const sql_i32x4 f = __builtin_amdgcn_raw_buffer_load_b128(x_r, pv ? po + 128u * eh + 16u * v : SQL_OOB, 0, 0);
+                xr[eh][4 * v] = __int_as_float(f.x); xr[eh][4 * v + 1] = __int_as_float(f.y);
+                xr[eh][4 * v + 2] = __int_as_float(f.z); xr[eh][4 * v + 3] = __int_as_float(f.w);
+            }
+#pragma unroll
+        for (int eh = 0; eh < EH; ++eh)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int pn = n0 + 2 * s + h;
+                xc[eh][s] = ldb32(x_r, pn < N ? ((unsigned)pn * E + 32u * eh + i) * 4u : SQL_OOB);
+            }
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            f32x16 d;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) d[r] = 0.f;
+#pragma unroll
+            for (int eh = 0; eh < EH; ++eh)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) d = mfma32(Kl[(qt * 32 + i) * EP + eh * 32 + 16 * h + s], xr[eh][s], d);
+            // ---- y out: row q = qt * 32 + acc_row(r, h), 32 consecutive pixels per half-wave
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int q = qt * 32 + acc_row(r, h);
+                stb32(y_r, (pv && q < Q) ? ((unsigned)q * N + n) * 4u : SQL_OOB, d[r]);
+                if (!pv) d[r] = -INFINITY;                   // tail pixels take no softmax mass
+            }
+            if (first) {                                      // the reference of this wave: row maxima of its first tile
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float m = half_max(d[r]);
+                    if (i == 0) rl[qt * 32 + acc_row(r, h)] = m;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+            float ref[16];
+            bool over = false;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                ref[r] = rl[qt * 32 + acc_row(r, h)];
+                over |= d[r] - ref[r] > 60.f;
+            }
+            if (__any(over)) {                                // rare: move the reference up and rescale what was accumulated under the old one
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float m = fmaxf(ref[r], half_max(d[r]));
+                    const float sc = __expf(ref[r] - m);
+                    lsum[qt][r] *= sc;
+#pragma unroll
+                    for (int eh = 0; eh < EH; ++eh) acc2[qt][eh][r] *= sc;
+                    ref[r] = m;
+                    if (i == 0) rl[qt * 32 + acc_row(r, h)] = m;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                  // the previous tile's reads of the probability tile are done
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float pr = __expf(d[r] - ref[r]);
+                lsum[qt][r] += pr;
+                pt[acc_row(r, h) * PT + i] = pr;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const float a = pt[i * PT + 2 * s + h];
+#pragma unroll
+                for (int eh = 0; eh < EH; ++eh) acc2[qt][eh] = mfma32(a, xc[eh][s], acc2[qt][eh]);
+            }
+        }
+        first = false;
+    }
+    // ---- one record per workgroup: the four waves' (reference, sum, summary) through LDS
+    __syncthreads();
+    float *sm = lds;                                         // [4][QP][2]
+    float *sacc = lds + 4 * QP * 2;                          // [4][QP][EP]
+    float rv[QT][16];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rv[qt][r] = first ? -INFINITY : rl[qt * 32 + acc_row(r, h)];      // (a wave without tiles: no mass)
+    __syncthreads();
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int q = qt * 32 + acc_row(r, h);
+            const float l = half_sum(lsum[qt][r]);
+            if (i == 0) {
+                sm[(wave * QP + q) * 2] = rv[qt][r];
+                sm[(wave * QP + q) * 2 + 1] = l;
+            }
+#pragma unroll
+            for (int eh = 0; eh < EH; ++eh) sacc[(wave * QP + q) * EP + eh * 32 + i] = acc2[qt][eh][r];
+        }
+    __syncthreads();
+    float *po = part + (((size_t)b * nchunks + chunk) * Qall + q0) * (E + PART_STRIDE_EXTRA);
+    for (int idx = threadIdx.x; idx < Q * 4; idx += 256) {          // 4 threads per query: a quarter of the features each
+        const int q = idx >> 2, eq = idx & 3;
+        float mk[4], M = -INFINITY, L = 0.f, w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            mk[k] = sm[(k * QP + q) * 2];
+            M = fmaxf(M, mk[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            w[k] = mk[k] == -INFINITY ? 0.f : __expf(mk[k] - M);
+            L += sm[(k * QP + q) * 2 + 1] * w[k];
+        }
+        float *o = po + (size_t)q * (E + PART_STRIDE_EXTRA);
+        if (eq == 0) {
+            o[0] = M;
+            o[1] = L;
+        }
+        for (int e = eq * (E / 4); e < (eq + 1) * (E / 4); ++e) {
+            float sv = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) sv += sacc[(k * QP + q) * EP + e] * w[k];
+            o[2 + e] = sv;
+        }
+    }
 }
 
 struct Plan {
     int QT, ET, NT, steps, nchunks;
+    int tiles32, nchunks32;          // sql_fwd32_kernel (E = 32 | 64, pixel-major x): 32-pixel tiles per wave, workgroups per image; 0: not built
 };
 int make_plan(int Q, int E, int N, Plan *p) {
     if (E % 16 != 0 || E > 64 || E < 16 || Q < 1 || Q > 128 || N < 1) return -1;
@@ -503,6 +728,14 @@ int make_plan(int Q, int E, int N, Plan *p) {
     while (steps < 16 && N / (px * steps * 4) > 64) steps *= 2;
     p->steps = steps;
     p->nchunks = (N + px * steps * 4 - 1) / (px * steps * 4);
+    p->tiles32 = p->nchunks32 = 0;
+    if (E == 32 || E == 64) {                                   // ~256 workgroups per image batch of a few: 64 per image
+        const int ntiles = (N + 31) / 32;
+        int tpw = (ntiles + 255) / 256;
+        tpw = tpw < 1 ? 1 : tpw > 16 ? 16 : tpw;
+        p->tiles32 = tpw;
+        p->nchunks32 = (ntiles + 4 * tpw - 1) / (4 * tpw);
+    }
     return 0;
 }
 }  // namespace
@@ -510,7 +743,7 @@ int make_plan(int Q, int E, int N, Plan *p) {
 extern "C" int sqd_sql_workspace(int B, int Q, int E, int N, int64_t *part_floats, int64_t *gk_part_floats) {
     Plan p;
     SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql: unsupported Q=%d E=%d N=%d (E in {16, 32, 48, 64}, Q <= 128)", Q, E, N);
-    if (part_floats) *part_floats = (int64_t)B * p.nchunks * Q * (E + PART_STRIDE_EXTRA);
+    if (part_floats) *part_floats = (int64_t)B * (p.nchunks > p.nchunks32 ? p.nchunks : p.nchunks32) * Q * (E + PART_STRIDE_EXTRA);
     if (gk_part_floats) *gk_part_floats = (int64_t)B * p.nchunks * Q * E;
     return SQD_OK;
 }
@@ -549,12 +782,37 @@ extern "C" int sqd_sql_fwd(const float *x, const float *K, float *y, float *summ
     Plan p;
     SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql_fwd: unsupported Q=%d E=%d N=%d", Q, E, N);
     bool launched = false;
-    const size_t fwd_lds = ((size_t)4 * p.QT * 16 * 2 + (size_t)4 * E * (p.QT * 16 + 1)) * sizeof(float);
     (void)hipGetLastError();
-    SQL_DISPATCH_ALL(sql_fwd_kernel, fwd_lds, x, K, y, part, Q, N, p.steps, p.nchunks, xse, xsn)
+    const bool fwd32 = x_nhwc && p.nchunks32 > 0;
+    if (fwd32) {                     // pixel-major x, 32 or 64 features: the 32x32 formulation (lane = pixel)
+        // one group of 32 queries per workgroup (grid.z): 132 registers = 3 waves per SIMD whose load / MFMA / exp / LDS phases overlap;
+        // with 64 or 128 queries per wave (227 - 256 registers, one or two waves per SIMD) the phases of a tile ran one after the other
+        const int eh = E / 32, groups = (Q + 31) / 32;
+        const int qt = 1, QP = qt * 32, EP = E + 1;
+        const size_t a = (size_t)QP * EP + 4 * QP + (size_t)4 * 32 * PT, m = (size_t)4 * QP * 2 + (size_t)4 * QP * EP;
+        const size_t shmem = (a > m ? a : m) * sizeof(float);
+#define SQL_FWD32(QT_, EH_)                                                                                                     \
+    {                                                                                                                           \
+        if (shmem > 48 * 1024)                                                                                                  \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sql_fwd32_kernel<QT_, EH_>),                              \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                                  \
+        hipLaunchKernelGGL((sql_fwd32_kernel<QT_, EH_>), dim3(p.nchunks32, B, groups), dim3(256), shmem, (hipStream_t)stream,  \
+                           x, K, y, part, Q, N, p.tiles32, p.nchunks32);                                                        \
+    }
+        if (eh == 1) {
+            if (qt == 1) SQL_FWD32(1, 1) else if (qt == 2) SQL_FWD32(2, 1) else SQL_FWD32(4, 1)
+        } else {
+            if (qt == 1) SQL_FWD32(1, 2) else SQL_FWD32(2, 2)
+        }
+        launched = true;
+    } else {
+        const size_t fwd_lds = ((size_t)4 * p.QT * 16 * 2 + (size_t)4 * E * (p.QT * 16 + 1)) * sizeof(float);
+        SQL_DISPATCH_ALL(sql_fwd_kernel, fwd_lds, x, K, y, part, Q, N, p.steps, p.nchunks, xse, xsn)
+    }
     SQD_CHECK_ARG(launched, "sqd_sql_fwd: no kernel instance for QT=%d ET=%d", p.QT, p.ET);
     SQD_CHECK_LAUNCH("sqd_sql_fwd");
-    hipLaunchKernelGGL(sql_merge_kernel, dim3(Q, B), dim3(64), 0, (hipStream_t)stream, part, summary, lse, Q, E, p.nchunks);
+    const int nch = fwd32 ? p.nchunks32 : p.nchunks;
+    hipLaunchKernelGGL(sql_merge_kernel, dim3(Q, B), dim3(64), (size_t)nch * sizeof(float), (hipStream_t)stream, part, summary, lse, Q, E, nch);
     SQD_CHECK_LAUNCH("sqd_sql_fwd(merge)");
     return SQD_OK;
 }
@@ -586,7 +844,7 @@ extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const
         }
     }
     SQD_CHECK_LAUNCH("sqd_sql_bwd");
-    hipLaunchKernelGGL(sql_gk_reduce_kernel, dim3((Q * E + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, gk_part, g_K,
+    hipLaunchKernelGGL(sql_gk_reduce_kernel, dim3((Q * E + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, gk_part, g_K,
                        Q * E, p.nchunks);
     SQD_CHECK_LAUNCH("sqd_sql_bwd(reduce)");
     return SQD_OK;

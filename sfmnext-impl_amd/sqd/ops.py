@@ -109,6 +109,9 @@ def identity_fwd(target, sources, noise=None, rows_per_task=0, loss_flags=0):
 PHOTO_FWD_KERNEL_NAME = "photo_tile_kernel<1> (fused warp + SSIM + L1 + min/auto-mask forward; training and inference launches are identical)"
 
 
+PHOTO_FWD_EVENTS = None      # a list: photo_fwd brackets its launch with HIP events on the launch stream and appends the pair
+
+
 def photo_fwd(depth, inv_K, P, target, sources, identity, training=True, want_taps=False, want_reproj=False,
               rows_per_task=0, prepared_only=False, loss_flags=0):
     """Fused warp + SSIM/L1 + min/auto-mask.  Returns a dict of device tensors.  `identity` may be None under LOSS_NO_AUTOMASK."""
@@ -145,6 +148,13 @@ def photo_fwd(depth, inv_K, P, target, sources, identity, training=True, want_ta
     a.stream = torch.cuda.current_stream().cuda_stream
     if prepared_only:
         return a, out
+    if PHOTO_FWD_EVENTS is not None:          # bench.py: duration of this launch inside a (non-captured) training step
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        _l.check(L.sqd_photo_fwd(ctypes.byref(a)), "photo_fwd")
+        ev[1].record()
+        PHOTO_FWD_EVENTS.append(ev)
+        return out
     _l.check(L.sqd_photo_fwd(ctypes.byref(a)), "photo_fwd")
     return out
 

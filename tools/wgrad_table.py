@@ -41,6 +41,24 @@ for m_ in tr.models.values():
     for mod in m_.modules():
         if hasattr(mod, "weight") and mod.weight is not None and mod.weight.dim() == 4:
             uses[tuple(mod.weight.shape)] = uses.get(tuple(mod.weight.shape), 0) + 1
+for mode in ("fwd", "dgrad"):
+    rows2 = []
+    for line in buf.getvalue().splitlines():
+        m = re.match(r"sqd conv plan %s (\(.*?\)) (\(.*?\))$" % mode, line)
+        if m:
+            geom, best = ast.literal_eval(m.group(1)), ast.literal_eval(m.group(2))
+            N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
+            gflop = 2.0 * N * Ho * Wo * K * C * R * S / 1e9
+            rows2.append((best[0] / 3 * 1e3, geom, best[1:], gflop))
+    print("\n## %s\n\n| us (1 call) | TFLOP/s | of 157.3 | plan (bm, bn, z, bk) | N Ho Wo C K RxS stride |\n|---:|---:|---:|---|---|" % mode)
+    tu = tg = 0.0
+    for us, geom, plan, gflop in sorted(rows2, reverse=True):
+        N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
+        print("| %.1f | %.1f | %.2f | %s | %d %d %d %d %d %dx%d s%d |" % (us, gflop / us * 1e3, gflop / us * 1e3 / 157.3, plan, N, Ho, Wo, C, K, R, S, stride))
+        tu += us
+        tg += gflop
+    print("\nsum over distinct geometries: %.0f us, %.1f GFLOP, %.1f TFLOP/s" % (tu, tg, tg / max(tu, 1e-9) * 1e3))
+print("\n## wgrad\n")
 tot_us = tot_gf = 0.0
 print("| us (1 call) | TFLOP/s | of 157.3 | plan (impl, splits) | N Ho Wo C K RxS stride |")
 print("|---:|---:|---:|---|---|")
