@@ -491,6 +491,219 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// backward, third formulation (dispatched for Q > 32): the SAME products, but a wave owns ONE group of 32 queries.  With all QT
+// groups in one wave the kernel above needs 239 - 256 registers (+ 396 bytes of scratch at Q = 120 / E = 64), i.e. one wave per
+// SIMD, and the load / product / exp / LDS phases of a tile run one after the other.  Here the four waves of a workgroup are QT
+// query-group waves x 4 / QT pixel tiles; g_x — the only product that contracts over the queries — is formed per group and the QT
+// partial tiles are added through LDS (fixed order), each wave storing its share of the feature rows; g_K needs no exchange until
+// the final merge.  ~130 - 180 registers: two to three waves per SIMD.
+// ---------------------------------------------------------------------------------------------------
+template <int QT, int EH>
+__global__ __launch_bounds__(256) void sql_bwd32q_kernel(const float *__restrict__ x, const float *__restrict__ K,
+                                                         const float *__restrict__ y, const float *__restrict__ g_y,
+                                                         const float *__restrict__ gS, const float *__restrict__ summary,
+                                                         const float *__restrict__ lse, float *__restrict__ g_x,
+                                                         float *__restrict__ gK_part, int Q, int E, int N, int nchunks, int xse,
+                                                         int xsn) {
+    static_assert(QT == 2 || QT == 4, "query-group waves per pixel tile");
+    constexpr int QP = QT * 32, EP = EH * 32 + 1, PTW = 4 / QT;   // pixel tiles per workgroup iteration
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float *Kl = lds, *Sl = Kl + QP * EP, *qc = Sl + QP * EP;      // K[q][e], gS[q][e], per-query (max, 1/sum, dot, -)
+    float *tiles = qc + QP * 4;                                   // [4 waves][32][TP]: gyt of the wave's query group
+    // [4 waves][EH][16][64]: partial g_x tiles — with one feature block they reuse the wave's gyt tile (dead once the g_K product is
+    // issued), which keeps the workgroup at 37 KB of LDS: three workgroups per CU (the register file's limit) instead of two
+    constexpr int GXW = EH == 1 ? 32 * TP : EH * 16 * 64;         // floats per wave
+    float *gxs = EH == 1 ? tiles : tiles + 4 * 32 * TP;
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wq = wave % QT, wp = wave / QT;
+    const int i = lane & 31, h = lane >> 5;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const float *xb = x + (size_t)b * E * N;
+    const float *yb = y + (size_t)b * Q * N;
+    const float *gyb = g_y ? g_y + (size_t)b * Q * N : nullptr;
+    float *gxb = g_x + (size_t)b * E * N;
+    const __amdgpu_buffer_rsrc_t x_r = sql_rsrc(xb, (unsigned)(E * N) * 4u), y_r = sql_rsrc(yb, (unsigned)(Q * N) * 4u);
+    const __amdgpu_buffer_rsrc_t gy_r = sql_rsrc(gyb ? gyb : yb, gyb ? (unsigned)(Q * N) * 4u : 0u);      // no g_y: every read is 0
+    const __amdgpu_buffer_rsrc_t gx_r = sql_rsrc(gxb, (unsigned)(E * N) * 4u);
+    for (int idx = threadIdx.x; idx < QP * EP; idx += 256) {
+        const int q = idx / EP, e = idx - q * EP;
+        const bool ok = q < Q && e < E;
+        Kl[idx] = ok ? K[((size_t)b * Q + q) * E + e] : 0.f;
+        Sl[idx] = ok ? gS[((size_t)b * Q + q) * E + e] : 0.f;
+    }
+    for (int q = threadIdx.x; q < QP; q += 256) {
+        float dsum = 0.f, mx = 0.f, il = 0.f;
+        if (q < Q) {
+            mx = lse[((size_t)b * Q + q) * 2];
+            il = lse[((size_t)b * Q + q) * 2 + 1];
+            for (int e = 0; e < E; ++e) dsum += gS[((size_t)b * Q + q) * E + e] * summary[((size_t)b * Q + q) * E + e];
+        }
+        qc[q * 4] = mx; qc[q * 4 + 1] = il; qc[q * 4 + 2] = dsum;
+    }
+    __syncthreads();
+    float *tl = tiles + wave * 32 * TP;
+    const float *Kq = Kl + wq * 32 * EP, *Sq = Sl + wq * 32 * EP, *qcq = qc + wq * 32 * 4;
+    f32x16 accK[EH];                                              // g_K tile of the wave's group: row q, column e = 32 eh + (lane & 31)
+#pragma unroll
+    for (int eh = 0; eh < EH; ++eh)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accK[eh][r] = 0.f;
+    const int ntiles = (N + 31) / 32;
+    const bool vec_ok = (N & 3) == 0;
+    const int iters = (ntiles + nchunks * PTW - 1) / (nchunks * PTW);
+
+    for (int it = 0; it < iters; ++it) {                          // (uniform trip count: the loop holds workgroup barriers)
+        const int tile = (it * nchunks + chunk) * PTW + wp;
+        const int p0 = tile * 32, p = p0 + i;
+        const bool pv = p < N;                                    // (a tile beyond the image: every access masked)
+        const unsigned N4 = (unsigned)N * 4u;
+        const unsigned lane_x = pv ? ((unsigned)h * xse + (unsigned)p * xsn) * 4u : SQL_OOB;
+        const unsigned lane_q = pv ? ((unsigned)(wq * 32 + 4 * h) * N + p) * 4u : SQL_OOB;   // row 4h of the group's rows of y / g_y, pixel p
+        const unsigned lane_gx = pv ? ((unsigned)(4 * h) * xse + (unsigned)p * xsn) * 4u : SQL_OOB;
+        const unsigned xse4 = (unsigned)xse * 4u;
+        float xe[EH][16];
+#pragma unroll
+        for (int eh = 0; eh < EH; ++eh) {
+            if (xse == 1) {                                  // pixel-major: 32 features of the lane are one 128-byte run — 8 x 16-byte loads
+                const unsigned px_off = pv ? (unsigned)p * (unsigned)xsn * 4u : SQL_OOB;
+#pragma unroll
+                for (int q8 = 0; q8 < 8; ++q8) {
+                    const sql_i32x4 f = __builtin_amdgcn_raw_buffer_load_b128(x_r, eh * 32 + 4 * q8 < E ? px_off + 128u * eh + 16u * q8 : SQL_OOB, 0, 0);
+                    xe[eh][2 * q8] = __int_as_float(h ? f.y : f.x);          // feature 32 eh + 4 q8 + h
+                    xe[eh][2 * q8 + 1] = __int_as_float(h ? f.w : f.z);      // feature 32 eh + 4 q8 + 2 + h
+                }
+            } else {
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    xe[eh][s] = ldb32(x_r, eh * 32 + 2 * s + h < E ? lane_x + (unsigned)(eh * 32 + 2 * s) * xse4 : SQL_OOB);
+            }
+        }
+        f32x16 yv, gv;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const bool qv = wq * 32 + acc_row(r, h) < Q;
+            const unsigned o = qv ? lane_q + (unsigned)((r & 3) + 8 * (r >> 2)) * N4 : SQL_OOB;
+            yv[r] = ldb32(y_r, o);
+            gv[r] = ldb32(gy_r, o);
+        }
+        float xv[EH][4][4];
+#pragma unroll
+        for (int eh = 0; eh < EH; ++eh)
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int px = 8 * gq + 4 * h, ei = eh * 32 + i;
+                if (vec_ok && xsn == 1) {                            // planar, N % 4 == 0: a float4 is inside a plane or beyond it
+                    const sql_i32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(
+                        x_r, (ei < E && p0 + px < N) ? ((unsigned)ei * xse + p0 + px) * 4u : SQL_OOB, 0, 0);
+                    xv[eh][gq][0] = __int_as_float(t4.x); xv[eh][gq][1] = __int_as_float(t4.y);
+                    xv[eh][gq][2] = __int_as_float(t4.z); xv[eh][gq][3] = __int_as_float(t4.w);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        xv[eh][gq][j] = ldb32(x_r, (ei < E && p0 + px + j < N) ? ((unsigned)ei * xse + (unsigned)(p0 + px + j) * xsn) * 4u : SQL_OOB);
+                }
+            }
+        // ---- t[q][p] = sum_e gS[q][e] x[e][p]
+        f32x16 acc, sreg;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int eh = 0; eh < EH; ++eh)
+#pragma unroll
+            for (int s = 0; s < 16; ++s) acc = mfma32(Sq[i * EP + eh * 32 + 2 * s + h], xe[eh][s], acc);
+        // ---- s and gyt, element-wise; gyt also to the LDS tile (operand of the g_K product)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ql = acc_row(r, h);
+            float sv = 0.f, gyt = 0.f;
+            if (wq * 32 + ql < Q && pv) {
+                sv = __expf(yv[r] - qcq[ql * 4]) * qcq[ql * 4 + 1];
+                gyt = gv[r] + sv * (acc[r] - qcq[ql * 4 + 2]);
+            }
+            sreg[r] = sv;
+            acc[r] = gyt;
+            tl[ql * TP + i] = gyt;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- g_K[q][e] += sum_p gyt[q][p] x[e][p]; k-step (gq, j): half-wave 0 takes pixel 8gq+j, half-wave 1 pixel 8gq+4+j
+#pragma unroll
+        for (int gq = 0; gq < 4; ++gq) {
+            const int px = 8 * gq + 4 * h;
+            const float4 a4 = *reinterpret_cast<const float4 *>(tl + i * TP + px);
+            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+#pragma unroll
+            for (int eh = 0; eh < EH; ++eh)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) accK[eh] = mfma32(av[j], xv[eh][gq][j], accK[eh]);
+        }
+        __builtin_amdgcn_wave_barrier();                           // (the tile's reads are issued before it is overwritten below)
+        // ---- the group's part of g_x[e][p] = sum_q K[q][e] gyt[q][p] + gS[q][e] s[q][p]
+#pragma unroll
+        for (int eh = 0; eh < EH; ++eh) {
+            f32x16 gx;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gx[r] = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = acc_row(r, h);
+                gx = mfma32(Kq[ql * EP + eh * 32 + i], acc[r], gx);
+                gx = mfma32(Sq[ql * EP + eh * 32 + i], sreg[r], gx);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gxs[wave * GXW + (eh * 16 + r) * 64 + lane] = gx[r];
+        }
+        __syncthreads();
+        // ---- add the QT groups (fixed order); wave wq stores register groups g4 = wq * 4 / QT .. of every feature block
+#pragma unroll
+        for (int eh = 0; eh < EH; ++eh)
+#pragma unroll
+            for (int gg = 0; gg < 4 / QT; ++gg) {
+                const int g4 = wq * (4 / QT) + gg;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float sum = gxs[(wp * QT) * GXW + (eh * 16 + 4 * g4 + j) * 64 + lane];
+#pragma unroll
+                    for (int k = 1; k < QT; ++k) sum += gxs[(wp * QT + k) * GXW + (eh * 16 + 4 * g4 + j) * 64 + lane];
+                    v[j] = sum;
+                }
+                if (xse == 1) {                              // pixel-major: registers 4 g4 .. + 3 are 4 consecutive features -> one 16-byte store
+                    const int e0 = eh * 32 + 8 * g4 + 4 * h;
+                    sql_i32x4 o;
+                    o.x = __float_as_int(v[0]); o.y = __float_as_int(v[1]); o.z = __float_as_int(v[2]); o.w = __float_as_int(v[3]);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, gx_r, (pv && e0 < E) ? ((unsigned)p * (unsigned)xsn + e0) * 4u : SQL_OOB, 0, 0);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int r = 4 * g4 + j;
+                        stb32(gx_r, eh * 32 + acc_row(r, h) < E ? lane_gx + (unsigned)(eh * 32 + (r & 3) + 8 * (r >> 2)) * xse4 : SQL_OOB, v[j]);
+                    }
+                }
+            }
+        __syncthreads();                                           // gxs and the gyt tiles are rewritten by the next iteration
+    }
+    // ---- workgroup merge of g_K (fixed order over the pixel-tile waves of a group) and the partial of this chunk
+    float *red = tiles;                                            // [4][32][32] (TP = 36 >= 32)
+    float *po = gK_part + ((size_t)b * nchunks + chunk) * Q * E;
+#pragma unroll
+    for (int eh = 0; eh < EH; ++eh) {
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((size_t)wave * 32 + acc_row(r, h)) * 32 + i] = accK[eh][r];
+        __syncthreads();
+        const int ew = min(32, E - eh * 32);                       // features of this block
+        for (int idx = threadIdx.x; idx < Q * ew; idx += 256) {
+            const int q = idx / ew, e = idx - q * ew, g = q >> 5, ql = q & 31;
+            float sum = red[((size_t)g * 32 + ql) * 32 + e];
+#pragma unroll
+            for (int k = 1; k < PTW; ++k) sum += red[((size_t)(k * QT + g) * 32 + ql) * 32 + e];
+            po[(size_t)q * E + eh * 32 + e] = sum;
+        }
+    }
+}
+
 // g_K[b,q,e] = sum over chunks of gK_part: 64 outputs per workgroup, the chunks dealt to its four waves (fixed order), added through LDS
 __global__ __launch_bounds__(256) void sql_gk_reduce_kernel(const float *__restrict__ part, float *__restrict__ gK, int QE,
                                                             int nchunks) {
@@ -714,8 +927,9 @@ __global__ __launch_bounds__(256) void sql_fwd32_kernel(const float *__restrict_
 struct Plan {
     int QT, ET, NT, steps, nchunks;
     int tiles32, nchunks32;          // sql_fwd32_kernel (E = 32 | 64, pixel-major x): 32-pixel tiles per wave, workgroups per image; 0: not built
+    int nchunks_bwd;                 // workgroups per image of the backward: B * nchunks_bwd = one resident round (3 or 2 workgroups per CU)
 };
-int make_plan(int Q, int E, int N, Plan *p) {
+int make_plan(int Q, int E, int N, Plan *p, int B = 12) {
     if (E % 16 != 0 || E > 64 || E < 16 || Q < 1 || Q > 128 || N < 1) return -1;
     int QT = (Q + 15) / 16;
     QT = QT <= 1 ? 1 : QT <= 2 ? 2 : QT <= 4 ? 4 : 8;
@@ -729,6 +943,12 @@ int make_plan(int Q, int E, int N, Plan *p) {
     p->steps = steps;
     p->nchunks = (N + px * steps * 4 - 1) / (px * steps * 4);
     p->tiles32 = p->nchunks32 = 0;
+    {
+        const int slots = E > 32 ? 512 : 768, ntiles = (N + 31) / 32;
+        int nb = slots / (B < 1 ? 1 : B);
+        nb = nb < 1 ? 1 : nb > ntiles ? ntiles : nb;
+        p->nchunks_bwd = Q > 32 ? nb : p->nchunks;              // (Q <= 32: the one-group kernel keeps its plan)
+    }
     if (E == 32 || E == 64) {                                   // ~256 workgroups per image batch of a few: 64 per image
         const int ntiles = (N + 31) / 32;
         int tpw = (ntiles + 255) / 256;
@@ -742,9 +962,9 @@ int make_plan(int Q, int E, int N, Plan *p) {
 
 extern "C" int sqd_sql_workspace(int B, int Q, int E, int N, int64_t *part_floats, int64_t *gk_part_floats) {
     Plan p;
-    SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql: unsupported Q=%d E=%d N=%d (E in {16, 32, 48, 64}, Q <= 128)", Q, E, N);
+    SQD_CHECK_ARG(make_plan(Q, E, N, &p, B) == 0, "sqd_sql: unsupported Q=%d E=%d N=%d (E in {16, 32, 48, 64}, Q <= 128)", Q, E, N);
     if (part_floats) *part_floats = (int64_t)B * (p.nchunks > p.nchunks32 ? p.nchunks : p.nchunks32) * Q * (E + PART_STRIDE_EXTRA);
-    if (gk_part_floats) *gk_part_floats = (int64_t)B * p.nchunks * Q * E;
+    if (gk_part_floats) *gk_part_floats = (int64_t)B * p.nchunks_bwd * Q * E;
     return SQD_OK;
 }
 
@@ -823,7 +1043,7 @@ extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const
     SQD_CHECK_ARG(x && K && y && g_summary && summary && lse && g_x && g_K && gk_part, "sqd_sql_bwd: null pointer");
     const int xse = x_nhwc ? 1 : N, xsn = x_nhwc ? E : 1;
     Plan p;
-    SQD_CHECK_ARG(make_plan(Q, E, N, &p) == 0, "sqd_sql_bwd: unsupported Q=%d E=%d N=%d", Q, E, N);
+    SQD_CHECK_ARG(make_plan(Q, E, N, &p, B) == 0, "sqd_sql_bwd: unsupported Q=%d E=%d N=%d", Q, E, N);
     SQD_CHECK_ARG((long long)N * 132 * 4 < (1ll << 32), "sqd_sql_bwd: N=%d too large for 32-bit plane offsets", N);
     (void)hipGetLastError();
     {
@@ -834,18 +1054,27 @@ extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const
         if (shmem > 48 * 1024)                                                                                                  \
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sql_bwd32_kernel<QT_, EH_>),                              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                                  \
-        hipLaunchKernelGGL((sql_bwd32_kernel<QT_, EH_>), dim3(p.nchunks, B), dim3(256), shmem, (hipStream_t)stream, x, K, y, g_y, \
-                           g_summary, summary, lse, g_x, gk_part, Q, E, N, p.nchunks, xse, xsn);                                \
+        hipLaunchKernelGGL((sql_bwd32_kernel<QT_, EH_>), dim3(p.nchunks_bwd, B), dim3(256), shmem, (hipStream_t)stream, x, K, y, g_y, \
+                           g_summary, summary, lse, g_x, gk_part, Q, E, N, p.nchunks_bwd, xse, xsn);                                \
+    }
+        const size_t shmem_q = ((size_t)2 * QP * (eh * 32 + 1) + QP * 4 + (size_t)4 * 32 * TP + (eh == 1 ? 0 : (size_t)4 * eh * 16 * 64)) * sizeof(float);
+#define SQL_BWD32Q(QT_, EH_)                                                                                                    \
+    {                                                                                                                           \
+        if (shmem_q > 48 * 1024)                                                                                                \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sql_bwd32q_kernel<QT_, EH_>),                             \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_q);                                \
+        hipLaunchKernelGGL((sql_bwd32q_kernel<QT_, EH_>), dim3(p.nchunks_bwd, B), dim3(256), shmem_q, (hipStream_t)stream, x, K, y, g_y, \
+                           g_summary, summary, lse, g_x, gk_part, Q, E, N, p.nchunks_bwd, xse, xsn);                                \
     }
         if (eh == 1) {
-            if (qt == 1) SQL_BWD32(1, 1) else if (qt == 2) SQL_BWD32(2, 1) else SQL_BWD32(4, 1)
+            if (qt == 1) SQL_BWD32(1, 1) else if (qt == 2) SQL_BWD32Q(2, 1) else SQL_BWD32Q(4, 1)
         } else {
-            if (qt == 1) SQL_BWD32(1, 2) else if (qt == 2) SQL_BWD32(2, 2) else SQL_BWD32(4, 2)
+            if (qt == 1) SQL_BWD32(1, 2) else if (qt == 2) SQL_BWD32Q(2, 2) else SQL_BWD32Q(4, 2)
         }
     }
     SQD_CHECK_LAUNCH("sqd_sql_bwd");
     hipLaunchKernelGGL(sql_gk_reduce_kernel, dim3((Q * E + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, gk_part, g_K,
-                       Q * E, p.nchunks);
+                       Q * E, p.nchunks_bwd);
     SQD_CHECK_LAUNCH("sqd_sql_bwd(reduce)");
     return SQD_OK;
 }
