@@ -169,6 +169,11 @@ int sqd_smooth_fwd(const float *depth, const float *color, const float *part, in
  * (elements) — one of the planes summed by sqd_depth_up_bwd.                                          */
 int sqd_smooth_bwd(const float *depth, const float *color, const float *part, int nblk, const float *sm_part,
                    float gout, float *g_depth, int64_t g_depth_img_stride, int B, int H, int W, void *stream);
+/* the scalars of compute_losses (trainer.py:531-545) from the partial sums of sqd_photo_fwd and sqd_smooth_fwd, in one launch:
+ * photo = sum(loss_part[0..n_loss)) * w_photo, smooth = sum(sm_part[.., 0]) * w_x + sum(sm_part[.., 1]) * w_y (n_sm pairs),
+ * out[3] = (photo + smooth_weight * smooth, photo, smooth).  Fixed summation order.                                          */
+int sqd_chain_loss(const float *loss_part, int n_loss, const float *sm_part, int n_sm, float w_photo, float w_x, float w_y,
+                   float smooth_weight, float *out, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (5) Self Query Layer

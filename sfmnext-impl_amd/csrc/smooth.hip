@@ -106,6 +106,49 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const float *__restrict
 
 extern "C" int sqd_smooth_nblk(int H, int W) { return (H * W + SM_PX_PER_BLOCK - 1) / SM_PX_PER_BLOCK; }
 
+namespace {
+// the three scalars of compute_losses from the kernels' partial sums, one workgroup, fixed order:
+//   photo = sum(loss_part) * w_photo;  smooth = sum(sm_part[.., 0]) * w_x + sum(sm_part[.., 1]) * w_y;  out = (photo + smooth_weight * smooth, photo, smooth)
+__global__ __launch_bounds__(256) void chain_loss_kernel(const float *__restrict__ loss_part, int n_loss, const float *__restrict__ sm_part,
+                                                         int n_sm, float w_photo, float w_x, float w_y, float smooth_weight,
+                                                         float *__restrict__ out) {
+    __shared__ float red[3][4];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    float a0 = 0.f, a1 = 0.f, sx = 0.f, sy = 0.f;
+    int i = t;
+    for (; i + 256 < n_loss; i += 512) {
+        a0 += loss_part[i];
+        a1 += loss_part[i + 256];
+    }
+    if (i < n_loss) a0 += loss_part[i];
+    for (int j = t; j < n_sm; j += 256) {
+        const float2 v = reinterpret_cast<const float2 *>(sm_part)[j];
+        sx += v.x;
+        sy += v.y;
+    }
+    float v0 = sqd::wave_sum_to_lane63(a0 + a1), v1 = sqd::wave_sum_to_lane63(sx), v2 = sqd::wave_sum_to_lane63(sy);
+    if (lane == 63) { red[0][wave] = v0; red[1][wave] = v1; red[2][wave] = v2; }
+    __syncthreads();
+    if (t == 0) {
+        const float photo = (((red[0][0] + red[0][1]) + red[0][2]) + red[0][3]) * w_photo;
+        const float smooth = (((red[1][0] + red[1][1]) + red[1][2]) + red[1][3]) * w_x + (((red[2][0] + red[2][1]) + red[2][2]) + red[2][3]) * w_y;
+        out[0] = photo + smooth_weight * smooth;
+        out[1] = photo;
+        out[2] = smooth;
+    }
+}
+}  // namespace
+
+extern "C" int sqd_chain_loss(const float *loss_part, int n_loss, const float *sm_part, int n_sm, float w_photo, float w_x, float w_y,
+                              float smooth_weight, float *out, void *stream) {
+    SQD_CHECK_ARG(loss_part && sm_part && out && n_loss > 0 && n_sm > 0, "sqd_chain_loss: bad arguments");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(chain_loss_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, loss_part, n_loss, sm_part, n_sm, w_photo, w_x, w_y,
+                       smooth_weight, out);
+    SQD_CHECK_LAUNCH("sqd_chain_loss");
+    return SQD_OK;
+}
+
 extern "C" int sqd_smooth_fwd(const float *depth, const float *color, const float *part, int nblk, float *sm_part, int B,
                               int H, int W, void *stream) {
     SQD_CHECK_ARG(depth && color && sm_part, "sqd_smooth_fwd: null pointer");

@@ -238,6 +238,7 @@ _SIGNATURES = {
     "sqd_smooth_nblk": (_I, [_I, _I]),
     "sqd_smooth_fwd": (_I, [_P, _P, _P, _I, _P, _I, _I, _I, _P]),
     "sqd_smooth_bwd": (_I, [_P, _P, _P, _I, _P, _F, _P, ctypes.c_int64, _I, _I, _I, _P]),
+    "sqd_chain_loss": (_I, [_P, _I, _P, _I, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, _P, _P]),
 }
 
 

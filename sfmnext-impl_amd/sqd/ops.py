@@ -318,9 +318,11 @@ class PhotometricChain(torch.autograd.Function):
         out = photo_fwd(depth, inv_K, P, target, list(sources), identity, training=training, rows_per_task=rows,
                         loss_flags=meta.get("loss_flags", 0))
         sm_part = smooth_fwd(depth, target, part)
-        photo = out["loss_part"].sum() / float(B * H * W)
-        smooth = sm_part[..., 0].sum() / float(B * H * (W - 1)) + sm_part[..., 1].sum() / float(B * (H - 1) * W)
-        total = photo + meta["smooth_weight"] * smooth
+        scal = torch.empty(3, device=depth.device, dtype=torch.float32)           # total, photometric mean, smoothness: one launch
+        _l.check(_l.lib().sqd_chain_loss(_ptr(out["loss_part"]), out["loss_part"].numel(), _ptr(sm_part), sm_part.numel() // 2,
+                                         1.0 / float(B * H * W), 1.0 / float(B * H * (W - 1)), 1.0 / float(B * (H - 1) * W),
+                                         float(meta["smooth_weight"]), _ptr(scal), _stream()), "chain_loss")
+        total, photo, smooth = scal[0], scal[1], scal[2]
         ctx.meta, ctx.S, ctx.n_pose, ctx.has_mid = meta, S, n_pose, mid is not None
         ctx.save_for_backward(disp_lr, axisangle, translation, K, inv_K, target, depth, part, mid if mid is not None else depth, P,
                               out["idx"], sm_part, *sources, *out["sample"], *out["warped"])

@@ -517,7 +517,7 @@ class Trainer:
         total, sel = outputs.pop(("_chain", 0))
         if not self.opt.disable_automasking:             # (trainer.py:523-525)
             outputs["identity_selection/0"] = sel
-        loss = total / self.num_scales
+        loss = total / self.num_scales if self.num_scales != 1 else total          # (scale 0 only: no division kernel)
         return {"loss/0": total, "loss": loss}
 
     def compute_depth_losses(self, inputs, outputs, losses):
