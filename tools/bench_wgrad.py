@@ -9,6 +9,11 @@ sys.path.insert(0, os.path.join(REPO, "sfmnext-impl_amd"))
 import torch  # noqa: E402
 from sqd import lib as _l  # noqa: E402
 
+if "--lib" in sys.argv:                       # another build of libsqd.so (tools/build_alt_lib.sh) for same-box A/B runs
+    i = sys.argv.index("--lib")
+    _l.SO_PATH = os.path.abspath(sys.argv[i + 1])
+    _l.needs_build = lambda: False
+    del sys.argv[i:i + 2]
 N, H, W, C, K, R = (int(v) for v in sys.argv[1:7])
 st, pad = (int(sys.argv[7]), int(sys.argv[8])) if len(sys.argv) > 8 else (1, (R - 1) // 2)
 L = _l.lib()
