@@ -182,115 +182,115 @@ __global__ __launch_bounds__(256) void bins_bwd_kernel(const float *__restrict__
     float *tl = tiles + wave * DP * PITCH, *pl = predl + wave * 32;
     const bool vec_ok = (dm.N & 3) == 0;
 
-    f32x16 accW[DT][QT];
+    // The dW accumulator of a whole [D][Q] tile is DT * QT * 16 registers — all 256 at D = Q = 128 (round 2: 512 registers + 340 B
+    // of scratch, 1.27 ms).  So the waves share it: wave w owns the 32 filters of d-tile wd = w % DT (QT * 16 registers) and, after
+    // a workgroup barrier, accumulates them over the pixel tiles of its group of DT waves (wg = w / DT) from the prob*g tiles those
+    // waves left in LDS; logits, softmax and the dE product stay per wave on its own pixel tile.
+    const int wd = wave % DT, wgp = wave / DT;
+    f32x16 accW[QT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-        for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accW[dt][qt][r] = 0.f;
-    float dbia[DT], dcen[DT], ci[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        dbia[dt] = 0.f;
-        dcen[dt] = 0.f;
-        ci[dt] = cl[dt * 32 + i];
-    }
+        for (int r = 0; r < 16; ++r) accW[qt][r] = 0.f;
+    float dbia = 0.f, dcen = 0.f;
+    const float ci = cl[wd * 32 + i];
+    const int iters = (tiles_per_image + gridDim.x * 4 - 1) / (gridDim.x * 4);
 
-    for (int tile = blockIdx.x * 4 + wave; tile < tiles_per_image; tile += gridDim.x * 4) {
+    for (int it = 0; it < iters; ++it) {                       // (uniform trip count: the loop holds workgroup barriers)
+        const int tile0 = (it * gridDim.x + blockIdx.x) * 4, tile = tile0 + wave;
         const int p0 = tile * 32, p = p0 + i;
-        const bool pv = p < dm.N;
-        f32x16 acc[DT];
-        tile_logits<DT, QT>(Wl, Eb, dm.Q, dm.N, p, pv, lane, acc);
-        float inv_sum, pred;
-        tile_softmax<DT>(acc, bl, cl, dm.D, lane, inv_sum, pred);
-        const float g = pv ? g_pred[(size_t)b * dm.N + p] * inv_sum : 0.f;      // g[p] / sum: acc holds un-normalised exp
-        if (lane < 32) pl[i] = pred;
-        // prob*g -> LDS tile [d][pixel] (operand of the dW product); dlogit stays in acc (operand of the dE product)
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d = dt * 32 + acc_row(r, h);
-                const float pg = acc[dt][r] * g;
-                tl[d * PITCH + i] = pg;
-                acc[dt][r] = pg * (cl[d] - pred);
-            }
-        // ---- dE[q, p] = sum_d W[d, q] * dlogit[d, p]
-#pragma unroll 1
-        for (int qt = 0; qt < QT; ++qt) {
-            f32x16 accE;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) accE[r] = 0.f;
+        const bool pv = p < dm.N;                               // (a tile beyond the image: every access masked, zero contributions)
+        {
+            f32x16 acc[DT];
+            tile_logits<DT, QT>(Wl, Eb, dm.Q, dm.N, p, pv, lane, acc);
+            float inv_sum, pred;
+            tile_softmax<DT>(acc, bl, cl, dm.D, lane, inv_sum, pred);
+            const float g = pv ? g_pred[(size_t)b * dm.N + p] * inv_sum : 0.f;      // g[p] / sum: acc holds un-normalised exp
+            if (lane < 32) pl[i] = pred;
+            // prob*g -> LDS tile [d][pixel] (operand of the dW product); dlogit stays in acc (operand of the dE product)
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    accE = mfma32(Wl[(dt * 32 + acc_row(r, h)) * QP + qt * 32 + i], acc[dt][r], accE);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int q = qt * 32 + acc_row(r, h);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(accE[r]), de_r, pv ? ((unsigned)q * dm.N + p) * 4u : BINS_OOB, 0, 0);
-            }
-        }
-        // ---- dW[d, q] += sum_p dlogit[d, p] * E[q, p]; k-step (gq, e): half-wave 0 takes pixel 8gq+e, half-wave 1 pixel 8gq+4+e
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
+                for (int r = 0; r < 16; ++r) {
+                    const int d = dt * 32 + acc_row(r, h);
+                    const float pg = acc[dt][r] * g;
+                    tl[d * PITCH + i] = pg;
+                    acc[dt][r] = pg * (cl[d] - pred);
+                }
+            // ---- dE[q, p] = sum_d W[d, q] * dlogit[d, p]
 #pragma unroll 1
-        for (int gq = 0; gq < 4; ++gq) {
-            const int px = 8 * gq + 4 * h;
-            const float4 pr4 = *reinterpret_cast<const float4 *>(pl + px);
-            const float prv[4] = {pr4.x, pr4.y, pr4.z, pr4.w};
-            float dlg[DT][4], ev[QT][4];
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const float4 t4 = *reinterpret_cast<const float4 *>(tl + (dt * 32 + i) * PITCH + px);
-                const float pgv[4] = {t4.x, t4.y, t4.z, t4.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    dlg[dt][e] = pgv[e] * (ci[dt] - prv[e]);
-                    dcen[dt] += pgv[e];
-                    dbia[dt] += dlg[dt][e];
-                }
-            }
-#pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
-                const int q = qt * 32 + i;
-                const unsigned off = ((unsigned)q * dm.N + p0 + px) * 4u;
-                if (vec_ok) {                                   // N % 4 == 0: a float4 lies inside a plane or beyond the last pixel
-                    const bins_i32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(eb_r, p0 + px < dm.N ? off : BINS_OOB, 0, 0);
-                    ev[qt][0] = __int_as_float(t4.x); ev[qt][1] = __int_as_float(t4.y);
-                    ev[qt][2] = __int_as_float(t4.z); ev[qt][3] = __int_as_float(t4.w);
-                } else {
+                f32x16 accE;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) ev[qt][e] = ldb(eb_r, p0 + px + e < dm.N ? off + 4u * e : BINS_OOB);
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
+                for (int r = 0; r < 16; ++r) accE[r] = 0.f;
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                    for (int qt = 0; qt < QT; ++qt) accW[dt][qt] = mfma32(dlg[dt][e], ev[qt][e], accW[dt][qt]);
+                    for (int r = 0; r < 16; ++r)
+                        accE = mfma32(Wl[(dt * 32 + acc_row(r, h)) * QP + qt * 32 + i], acc[dt][r], accE);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = qt * 32 + acc_row(r, h);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(accE[r]), de_r, pv ? ((unsigned)q * dm.N + p) * 4u : BINS_OOB, 0, 0);
+                }
+            }
         }
-        __builtin_amdgcn_wave_barrier();                       // the tile is rewritten by the next iteration
+        __syncthreads();                                        // every wave's prob*g tile and pred row are in LDS
+        // ---- dW[d, q] += sum_p dlogit[d, p] * E[q, p] for d-tile wd over the group's DT pixel tiles; k-step (gq, e): half-wave 0 takes
+        // pixel 8gq+e, half-wave 1 pixel 8gq+4+e
+#pragma unroll 1
+        for (int tt = 0; tt < DT; ++tt) {
+            const int wsrc = wgp * DT + tt;                     // the wave whose pixel tile this is
+            const int q0 = (tile0 + wsrc) * 32;
+            const float *tls = tiles + wsrc * DP * PITCH, *pls = predl + wsrc * 32;
+#pragma unroll 1
+            for (int gq = 0; gq < 4; ++gq) {
+                const int px = 8 * gq + 4 * h;
+                const float4 pr4 = *reinterpret_cast<const float4 *>(pls + px);
+                const float prv[4] = {pr4.x, pr4.y, pr4.z, pr4.w};
+                float dlg[4], ev[QT][4];
+                const float4 t4 = *reinterpret_cast<const float4 *>(tls + (wd * 32 + i) * PITCH + px);
+                const float pgv[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dlg[e] = pgv[e] * (ci - prv[e]);
+                    dcen += pgv[e];
+                    dbia += dlg[e];
+                }
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const int q = qt * 32 + i;
+                    const unsigned off = ((unsigned)q * dm.N + q0 + px) * 4u;
+                    if (vec_ok) {                               // N % 4 == 0: a float4 lies inside a plane or beyond the last pixel
+                        const bins_i32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(eb_r, q0 + px < dm.N ? off : BINS_OOB, 0, 0);
+                        ev[qt][0] = __int_as_float(v4.x); ev[qt][1] = __int_as_float(v4.y);
+                        ev[qt][2] = __int_as_float(v4.z); ev[qt][3] = __int_as_float(v4.w);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ev[qt][e] = ldb(eb_r, q0 + px + e < dm.N ? off + 4u * e : BINS_OOB);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) accW[qt] = mfma32(dlg[e], ev[qt][e], accW[qt]);
+            }
+        }
+        __syncthreads();                                        // the tiles are rewritten by the next iteration
     }
 
-    // ---- workgroup partials: the 4 waves add into one LDS image in a fixed order (wave 0 stores, 1..3 add)
-    __syncthreads();
+    // ---- workgroup partials: the 4 / DT groups add their d-tiles into one LDS image in a fixed order (group 0 stores, the others add)
     float *red = tiles;                                        // reuse: DP x QT*32 floats <= 4 * DP * PITCH
     constexpr int QW = QT * 32;
-    for (int w = 0; w < 4; ++w) {
-        if (wave == w) {
+    for (int gsel = 0; gsel < 4 / DT; ++gsel) {
+        if (wgp == gsel) {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+            for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
-                for (int qt = 0; qt < QT; ++qt)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        float *dst = red + (dt * 32 + acc_row(r, h)) * QW + qt * 32 + i;
-                        *dst = (w == 0 ? 0.f : *dst) + accW[dt][qt][r];
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    float *dst = red + (wd * 32 + acc_row(r, h)) * QW + qt * 32 + i;
+                    *dst = (gsel == 0 ? 0.f : *dst) + accW[qt][r];
+                }
         }
         __syncthreads();
     }
@@ -300,24 +300,23 @@ __global__ __launch_bounds__(256) void bins_bwd_kernel(const float *__restrict__
         const int d = idx / dm.Q, q = idx - d * dm.Q;
         pw[idx] = red[d * QW + q];
     }
-    // dbias / dcenters: lane (d = dt*32 + i, half h) holds the sum over its half of the pixels
+    // dbias / dcenters: lane (d = wd*32 + i, half h) holds the sum over its half of the pixels of its group's tiles
     __syncthreads();
-    float *vred = red;                                         // [4 waves][2][DP]
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        const float sb = dbia[dt] + __shfl_xor(dbia[dt], 32, 64), sc = dcen[dt] + __shfl_xor(dcen[dt], 32, 64);
+    float *vred = red;                                         // [4 / DT groups][2][DP]
+    {
+        const float sb = dbia + __shfl_xor(dbia, 32, 64), sc = dcen + __shfl_xor(dcen, 32, 64);
         if (h == 0) {
-            vred[(wave * 2 + 0) * DP + dt * 32 + i] = sb;
-            vred[(wave * 2 + 1) * DP + dt * 32 + i] = sc;
+            vred[(wgp * 2 + 0) * DP + wd * 32 + i] = sb;
+            vred[(wgp * 2 + 1) * DP + wd * 32 + i] = sc;
         }
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < 2 * DP; idx += 256) {
         const int which = idx / DP, d = idx - which * DP;
         if (d < dm.D) {
-            float s = 0.f;
-            for (int w = 0; w < 4; ++w) s += vred[(w * 2 + which) * DP + d];
-            part_v[((size_t)wg * 2 + which) * dm.D + d] = s;
+            float sum = 0.f;
+            for (int w = 0; w < 4 / DT; ++w) sum += vred[(w * 2 + which) * DP + d];
+            part_v[((size_t)wg * 2 + which) * dm.D + d] = sum;
         }
     }
 }

@@ -5,7 +5,7 @@ R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, "sfmnext-impl_amd"))
 import torch
 from sqd import ops
-B, Q, D, h, w = 12, 64, 64, 96, 320
+B, Q, D, h, w = (int(v) for v in sys.argv[1:6]) if len(sys.argv) > 5 else (12, 64, 64, 96, 320)      # config C: 8 128 128 160 512
 torch.manual_seed(0)
 a = [torch.randn(B, Q, h, w, device="cuda").requires_grad_(True), (0.3 * torch.randn(D, Q, 1, 1, device="cuda")).requires_grad_(True),
      torch.randn(D, device="cuda").requires_grad_(True), (torch.rand(B, D, device="cuda") * 80).requires_grad_(True)]
