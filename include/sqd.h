@@ -222,6 +222,12 @@ int sqd_bn_train_bwd(const float *dy, const float *x, const float *y, const unsi
 int sqd_bn_train_bwd_pre(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
                          const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
                          float *dbeta, float *part, int pre_rows, int M, int C, int act, void *stream);
+/* ... and red_out[i] = sum_{s < red_splits} red_part[s * red_n + i] (sqd_split_reduce's arithmetic) as extra workgroups of the
+ * finalize launch; red_part == NULL: none                                                                                        */
+int sqd_bn_train_bwd_pre_red(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
+                             const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
+                             float *dbeta, float *part, int pre_rows, int M, int C, int act, const float *red_part, float *red_out,
+                             int64_t red_n, int red_splits, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (7) bilinear resize (align_corners=True) + channel concat, channels-last activations
@@ -322,6 +328,13 @@ int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *
 int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int impl, int splits);
 int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C, int K,
                    int R, int S, int stride, int pad, int Ho, int Wo, void *stream);
+/* sqd_conv_wgrad without the final sum over the pixel splits: part[0 .. *splits)[K*R*S*C] holds the partial filter gradients and dw
+ * is NOT written (dbias is).  The caller adds them later on the same stream: sqd_split_reduce(part, dw, K*R*S*C, *splits), or as extra
+ * workgroups of the next BatchNorm-backward finalize launch (sqd_bn_train_bwd_pre_red) — one launch less per layer, the same bits. */
+int sqd_conv_wgrad_partials(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C, int K,
+                            int R, int S, int stride, int pad, int Ho, int Wo, int *splits, void *stream);
+/* out[i] = sum_{s < splits} part[s * n + i], i < n (n a multiple of 4); fixed summation order                                      */
+int sqd_split_reduce(const float *part, float *out, int64_t n, int splits, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * (11) adaptive-bins depth head.  replaces reference networks/depth_decoder_QTR.py:61-70 (convert_to_prob =

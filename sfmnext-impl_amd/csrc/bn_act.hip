@@ -204,8 +204,17 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float *__res
 }
 
 // backward finalize: dgamma, dbeta (and the two means the apply pass needs, stored in `red`)
+// Workgroups beyond the nfin finalize ones carry a pending split reduction along (a weight gradient's pixel splits: one launch less
+// per layer; red_part == NULL: none).
 __global__ __launch_bounds__(256) void bn_finalize_bwd_kernel(const float *__restrict__ part, int nblk, int M, int C,
-                                                              float *__restrict__ dgamma, float *__restrict__ dbeta) {
+                                                              float *__restrict__ dgamma, float *__restrict__ dbeta, int nfin,
+                                                              const float *__restrict__ red_part, float *__restrict__ red_out, size_t red_n,
+                                                              int red_splits) {
+    if ((int)blockIdx.x >= nfin) {                  // (workgroup-uniform)
+        __shared__ float4 red[16][16];
+        sqd::split_reduce_block(red_part, red_out, red_n, red_splits, (int)blockIdx.x - nfin, red);
+        return;
+    }
     int c;
     float s, ss;
     if (!finalize_sums(part, nblk, C, c, s, ss)) return;
@@ -369,6 +378,17 @@ extern "C" int sqd_bn_train_bwd(const float *dy, const float *x, const float *y,
 extern "C" int sqd_bn_train_bwd_pre(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
                                     const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
                                     float *dbeta, float *part, int pre_rows, int M, int C, int act, void *stream) {
+    return sqd_bn_train_bwd_pre_red(dy, x, y, mask, gamma, beta, save_mean, save_rstd, dx, dres, dgamma, dbeta, part, pre_rows, M, C, act, nullptr,
+                                    nullptr, 0, 0, stream);
+}
+
+// ... and red_out[i] = sum_{s < red_splits} red_part[s * red_n + i] (sqd_split_reduce's arithmetic) as extra workgroups of the finalize
+// launch: the pending sum of a weight gradient's pixel splits (sqd_conv_wgrad_partials) rides along.  red_part == NULL: none.
+extern "C" int sqd_bn_train_bwd_pre_red(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
+                                        const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
+                                        float *dbeta, float *part, int pre_rows, int M, int C, int act, const float *red_part, float *red_out,
+                                        int64_t red_n, int red_splits, void *stream) {
+    SQD_CHECK_ARG(!red_part || (red_out && red_n > 0 && red_n % 4 == 0 && red_splits >= 1), "sqd_bn_train_bwd_pre_red: bad pending reduction");
     SQD_CHECK_ARG(dy && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && part, "sqd_bn_train_bwd: null pointer");
     SQD_CHECK_ARG(pre_rows >= 0 && (pre_rows == 0 || act != ACT_SWISH), "sqd_bn_train_bwd_pre: pre_rows=%d (no precomputed partials with swish)", pre_rows);
     SQD_CHECK_ARG(act == ACT_NONE || act == ACT_SWISH || y || mask, "sqd_bn_train_bwd: ReLU / LeakyReLU need y or the sign mask of the forward");
@@ -379,7 +399,9 @@ extern "C" int sqd_bn_train_bwd_pre(const float *dy, const float *x, const float
     (void)hipGetLastError();
     if (pre_rows <= 0)
         hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nblk), dim3(256), 0, s, x, dy, y, save_mean, save_rstd, part, M, C, act, g, mask, gamma, beta);
-    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, part, pre_rows > 0 ? pre_rows : g.nblk, M, C, dgamma, dbeta);
+    const int nfin = (C + FIN_CH - 1) / FIN_CH, nred = red_part ? (int)((red_n / 4 + 15) / 16) : 0;
+    hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(nfin + nred), dim3(256), 0, s, part, pre_rows > 0 ? pre_rows : g.nblk, M, C, dgamma, dbeta, nfin,
+                       red_part, red_out, (size_t)red_n, red_splits);
     const size_t total4 = (size_t)M * C / 4;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, s, dy, x, y, gamma, save_mean, save_rstd, dgamma,
                        dbeta, dx, dres, total4, C, 1.0f / (float)M, act, mask, beta);

@@ -943,25 +943,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float *__restrict
 __global__ __launch_bounds__(256) void split_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, size_t n,
                                                            int splits) {
     __shared__ float4 red[16][16];
-    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    const size_t i = (size_t)blockIdx.x * 16 + col;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n / 4)
-        for (int s = grp; s < splits; s += 16) {
-            const float4 b = reinterpret_cast<const float4 *>(part + (size_t)s * n)[i];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-        }
-    red[grp][col] = a;
-    __syncthreads();
-    for (int w = 8; w >= 1; w >>= 1) {
-        if (grp < w) {
-            const float4 b = red[grp + w][col];
-            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-            red[grp][col] = a;
-        }
-        __syncthreads();
-    }
-    if (grp == 0 && i < n / 4) reinterpret_cast<float4 *>(out)[i] = a;
+    sqd::split_reduce_block(part, out, n, splits, blockIdx.x, red);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2252,8 +2234,8 @@ extern "C" int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int 
 
 // dy [N,Ho,Wo,K], x [N,H,W,C] -> dw [K,R,S,C]; dbias [K] (may be NULL); part: workspace of sqd_conv_wgrad_plan floats
 // (+ bias scratch appended when dbias is requested: max(ceil(M/1024), splits) * K floats)
-extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C,
-                              int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream) {
+static int conv_wgrad_impl(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C,
+                           int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream, bool reduce_dw, int *splits_out) {
     SQD_CHECK_ARG(dy && x && dw && part, "sqd_conv_wgrad: null pointer");
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     if (check_geom("sqd_conv_wgrad", g)) return SQD_EINVAL;
@@ -2330,7 +2312,8 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
     // (leaving the ~100 reductions of a backward pass to two or three multi-task launches at its end was measured: bit-identical and
     // 0.7 ms SLOWER per step — reduced on the spot the partials of most layers are still in the 256 MB Infinity Cache)
     if (dp.direct || dp.shared || dp.rows) splits = dp.splits;    // (a strided convolution under a row-window plan: see plan_wgrad_direct)
-    hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((wsz / 4 + 15) / 16)), dim3(256), 0, st, part, dw, wsz, splits);
+    if (splits_out) *splits_out = splits;
+    if (reduce_dw) hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((wsz / 4 + 15) / 16)), dim3(256), 0, st, part, dw, wsz, splits);
     if (dbias && ((dp.direct && !dp.shared) || dp.rows)) {
         hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((K / 4 + 15) / 16)), dim3(256), 0, st, part + (size_t)splits * wsz, dbias,
                            (size_t)K, splits);
@@ -2344,6 +2327,29 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
         hipLaunchKernelGGL(colsum_kernel, dim3(1, bands), dim3(256), 0, st, cpart, dbias, nblk, K, nblk, cpb);
     }
     SQD_CHECK_LAUNCH("sqd_conv_wgrad");
+    return SQD_OK;
+}
+
+extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C,
+                              int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream) {
+    return conv_wgrad_impl(dy, x, dw, dbias, part, N, H, W, C, K, R, S, stride, pad, Ho, Wo, stream, true, nullptr);
+}
+
+// The same without the final sum over the pixel splits: part[0 .. *splits)[K*R*S*C] holds the partial filter gradients, dw is NOT
+// written (dbias is).  The caller adds them later on the same stream — sqd_split_reduce, or as extra workgroups of the next
+// BatchNorm-backward finalize launch (sqd_bn_train_bwd_pre_red): one launch less per layer, the same bits.
+extern "C" int sqd_conv_wgrad_partials(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C,
+                                       int K, int R, int S, int stride, int pad, int Ho, int Wo, int *splits, void *stream) {
+    SQD_CHECK_ARG(splits, "sqd_conv_wgrad_partials: null pointer");
+    return conv_wgrad_impl(dy, x, dw, dbias, part, N, H, W, C, K, R, S, stride, pad, Ho, Wo, stream, false, splits);
+}
+
+// out[i] = sum_{s < splits} part[s * n + i], i < n (n a multiple of 4; fixed summation order)
+extern "C" int sqd_split_reduce(const float *part, float *out, int64_t n, int splits, void *stream) {
+    SQD_CHECK_ARG(part && out && n > 0 && n % 4 == 0 && splits >= 1, "sqd_split_reduce: bad arguments");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((n / 4 + 15) / 16)), dim3(256), 0, (hipStream_t)stream, part, out, (size_t)n, splits);
+    SQD_CHECK_LAUNCH("sqd_split_reduce");
     return SQD_OK;
 }
 

@@ -95,4 +95,29 @@ __device__ __forceinline__ int reflect_idx(int p, int n) {
     return min(max(p, 0), n - 1);
 }
 
+// out[i] = sum over splits of part[s][i] for the 16 float4 columns of block `block` (256 threads): its 16 thread groups each add the
+// splits s = g, g + 16, ... in order, then a fixed-order tree over the groups — deterministic for a given split count.  Shared by
+// conv.hip's split_reduce_kernel and by the kernels that carry a pending reduction along (bn_finalize_bwd_kernel).
+__device__ __forceinline__ void split_reduce_block(const float *__restrict__ part, float *__restrict__ out, size_t n, int splits, int block,
+                                                   float4 (*red)[16]) {
+    const int col = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const size_t i = (size_t)block * 16 + col;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n / 4)
+        for (int s = grp; s < splits; s += 16) {
+            const float4 b = reinterpret_cast<const float4 *>(part + (size_t)s * n)[i];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+    red[grp][col] = a;
+    __syncthreads();
+    for (int w = 8; w >= 1; w >>= 1) {
+        if (grp < w) {
+            const float4 b = red[grp + w][col];
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+            red[grp][col] = a;
+        }
+        __syncthreads();
+    }
+    if (grp == 0 && i < n / 4) reinterpret_cast<float4 *>(out)[i] = a;
+}
 }  // namespace sqd

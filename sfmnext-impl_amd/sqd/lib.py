@@ -176,6 +176,7 @@ _SIGNATURES = {
     "sqd_conv_dgrad_stats_rows": (_I, [_I] * 11),
     "sqd_conv_dgrad_bn": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P] + [_I] * 11 + [_P]),
     "sqd_bn_train_bwd_pre": (_I, [_P] * 13 + [_I, _I, _I, _I, _P]),
+    "sqd_bn_train_bwd_pre_red": (_I, [_P] * 13 + [_I, _I, _I, _I, _P, _P, ctypes.c_int64, _I, _P]),
     "sqd_conv_dgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
     "sqd_resize_ac_fwd": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_resize_ac_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _P]),
@@ -210,6 +211,8 @@ _SIGNATURES = {
     "sqd_conv_wgrad_plan": (_I, [_I] * 7 + [ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int64)]),
     "sqd_conv_wgrad_set_plan": (_I, [_I] * 9),
     "sqd_conv_wgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
+    "sqd_conv_wgrad_partials": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [ctypes.POINTER(ctypes.c_int), _P]),
+    "sqd_split_reduce": (_I, [_P, _P, ctypes.c_int64, _I, _P]),
     "sqd_bins_supported": (_I, [_I, _I]),
     "sqd_bins_workspace": (_I, [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64)]),
     "sqd_bins_fwd": (_I, [_P] * 5 + [_I] * 4 + [_P]),

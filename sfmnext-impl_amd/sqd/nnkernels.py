@@ -94,8 +94,13 @@ class BatchNormAct(torch.autograd.Function):
         dgamma = torch.empty(C, device=x.device, dtype=torch.float32)
         dbeta = torch.empty(C, device=x.device, dtype=torch.float32)
         part = pre_part if pre_rows > 0 else torch.empty(L.sqd_bn_nblk(M, C) * C * 2, device=x.device, dtype=torch.float32)
-        _l.check(L.sqd_bn_train_bwd_pre(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
-                                        _ptr(dgamma), _ptr(dbeta), _ptr(part), pre_rows, M, C, ctx.code, _stream()), "bn_train_bwd")
+        # a weight gradient whose pixel splits are not summed yet (Conv2d.backward under DEFER_WGRAD_REDUCE): the sum rides along as extra
+        # workgroups of this node's finalize launch
+        pend = _take_pending_reduce()
+        rp, ro, rn, rs = pend if pend is not None else (None, None, 0, 0)
+        _l.check(L.sqd_bn_train_bwd_pre_red(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
+                                            _ptr(dgamma), _ptr(dbeta), _ptr(part), pre_rows, M, C, ctx.code, _ptr(rp), _ptr(ro), rn, rs, _stream()),
+                 "bn_train_bwd")
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
 
 
@@ -688,6 +693,37 @@ def conv_module_supported(conv):
 # stream the weight-gradient kernels run on (None: the caller's stream).  The Trainer sets it; whoever calls backward() must
 # call join_wgrad_stream() before the gradients are read (optimiser, all-reduce).
 WGRAD_STREAM = None
+
+# Sum of a weight gradient's pixel splits as part of the next BatchNorm-backward launch instead of a launch of its own (the Trainer turns
+# this on for single-rank runs: one launch less per convolution + BatchNorm layer, the same bits).  While it is on, a filter gradient is
+# valid once the backward pass has returned (an end-of-pass callback sums whatever is still pending) — as with WGRAD_STREAM.  Off by
+# default: a multi-rank reducer's hooks read the gradients as they are accumulated.
+DEFER_WGRAD_REDUCE = False
+_PENDING_REDUCE = {}          # stream handle -> (part, dw, n, splits)
+
+
+def _flush_pending_reduce(stream_handle=None):
+    keys = [stream_handle] if stream_handle is not None else list(_PENDING_REDUCE)
+    for k in keys:
+        rec = _PENDING_REDUCE.pop(k, None)
+        if rec is not None:
+            part, dw, n, splits = rec
+            _l.check(_l.lib().sqd_split_reduce(_ptr(part), _ptr(dw), n, splits, ctypes.c_void_p(k)), "split_reduce")
+
+
+def _end_of_backward_reduce():
+    _flush_pending_reduce()
+
+
+def _set_pending_reduce(part, dw, n, splits):
+    h = torch.cuda.current_stream().cuda_stream
+    _flush_pending_reduce(h)                    # two convolutions in a row without a BatchNorm between them: the first sum runs now
+    _PENDING_REDUCE[h] = (part, dw, n, splits)
+    torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_reduce)      # (idempotent: nothing pending, nothing launched)
+
+
+def _take_pending_reduce():
+    return _PENDING_REDUCE.pop(torch.cuda.current_stream().cuda_stream, None)
 WGRAD_BATCH = 1              # convolutions per cross-stream dependency of the side-stream weight gradients
 _PENDING_WGRAD = {}          # raw stream handle -> (stream the operands are produced on, [(launch, tensors)])
 
@@ -798,7 +834,19 @@ class Conv2d(torch.autograd.Function):
             def launch(dy=dy, x=x, dw=dw, db=db, part=part):
                 _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
                                           _stream()), "conv_wgrad")
-            if WGRAD_STREAM is None or ctx.wkey is None or _WEIGHT_USES.get(ctx.wkey, 2) != 1:
+            if DEFER_WGRAD_REDUCE and WGRAD_STREAM is None and ctx.wkey is not None and _WEIGHT_USES.get(ctx.wkey, 2) == 1 and \
+                    ctx.bn_src is not None and w.grad is None:
+                # the partial filter gradients now; x is the output of a training-mode BatchNorm, whose backward is the next node of this
+                # stream: its finalize launch carries the sum (the end-of-pass callback is only the safety net).  The tensor is handed to
+                # the parameter directly (autograd gets None for it: an AccumulateGrad that decided to copy would copy it before it is
+                # written): valid when the backward pass has returned.
+                sp = ctypes.c_int(0)
+                _l.check(L.sqd_conv_wgrad_partials(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
+                                                   ctypes.byref(sp), _stream()), "conv_wgrad_partials")
+                _set_pending_reduce(part, dw, K * R * S * C, sp.value)
+                w.grad = dw
+                dw = None
+            elif WGRAD_STREAM is None or ctx.wkey is None or _WEIGHT_USES.get(ctx.wkey, 2) != 1:
                 launch()
             else:
                 # the weight gradient has no consumer before the optimiser: it is queued and runs on its own stream, next to

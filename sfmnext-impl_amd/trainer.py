@@ -107,6 +107,9 @@ class Trainer:
         self.reducer = ddp.GradBucketReducer(all_params, self.opt.sqd_bucket_mb) if ddp.COMM is not None else None
         if self.reducer is not None:
             self.reducer.broadcast_parameters(self.models.values())
+        # single rank: the sum of a weight gradient's pixel splits rides on the next BatchNorm-backward launch (a reducer's hooks would read
+        # the gradient before that)
+        self._defer_wgrad_reduce = self.reducer is None and not self.opt.sqd_no_defer_wgrad_reduce
 
         # single- and multi-rank runs replay the whole step as one hipGraph; with a process group the graph also holds the
         # bucket gathers and the RCCL all-reduces the autograd hooks launch, as branches parallel to the rest of backward
@@ -277,6 +280,7 @@ class Trainer:
         mode = {} if self.reducer is None else {"capture_error_mode": "thread_local"}
         try:
             with torch.cuda.graph(g, stream=self._graph_stream, **mode):
+                nnkernels.begin_step()          # per-step use counts of the filters (a filter used once may defer its gradient's split sum)
                 outputs, losses = self.process_batch(self._static_in)
                 # the reducer's post-accumulate hooks run here, inside the capture: each full bucket is gathered by one
                 # multi-tensor copy and its all-reduce (sqd_comm_allreduce, a plain stream operation) is enqueued on the
@@ -303,6 +307,7 @@ class Trainer:
         self._capturing = True
         try:
             with torch.cuda.graph(g, stream=self._graph_stream, capture_error_mode="thread_local"):
+                nnkernels.begin_step()
                 outputs, losses = self.process_batch(self._static_in)
                 self._backward(losses["loss"])
                 # fresh gradients (assigned, not accumulated: no memsets, no ~170 accumulate launches) -> the buckets, as
@@ -319,11 +324,13 @@ class Trainer:
         # eager steps: the convolutions' weight gradients run on their own stream, next to the data gradients (-0.8 ms per
         # step).  Not inside a capture: a hipGraph with ~110 extra cross-branch edges replays 1.3 ms slower than the linear one.
         nnkernels.WGRAD_STREAM = None if getattr(self, "_capturing", False) else self._wgrad_stream
+        nnkernels.DEFER_WGRAD_REDUCE = self._defer_wgrad_reduce
         try:
             loss.backward()
             nnkernels.join_wgrad_stream()                # the caller's stream joins it before anything reads the gradients
         finally:
             nnkernels.WGRAD_STREAM = None
+            nnkernels.DEFER_WGRAD_REDUCE = False
 
     def _train_step_eager(self, inputs):
         nnkernels.begin_step()

@@ -103,3 +103,36 @@ def test_summed_gradient_takes_the_ordinary_path():
     for got, ref, name in ((xg.grad, xr.grad, "dx"), (mb.weight.grad, b1.weight.grad, "dgamma"), (mb.bias.grad, b1.bias.grad, "dbeta")):
         err = float((got.cpu().double() - ref).abs().max()) / float(ref.abs().max())
         assert err <= 2e-4, (name, err)
+
+
+def test_deferred_wgrad_reduce_rides_on_the_batchnorm_backward():
+    """DEFER_WGRAD_REDUCE: the sum of a weight gradient's pixel splits is carried by the finalize launch of the next BatchNorm backward
+    (sqd_conv_wgrad_partials + sqd_bn_train_bwd_pre_red) — same bits as the launch of its own, for every filter of a conv/BN stack incl.
+    the last convolution (no BatchNorm backward follows it: the end-of-pass callback sums it)."""
+    from sqd import nnkernels, nnops
+    torch.manual_seed(11)
+    convs = [nn.Conv2d(16, 64, 3, 1, 1, bias=False), nn.Conv2d(64, 32, 1, 1, 0, bias=False), nn.Conv2d(32, 64, 3, 2, 1, bias=True)]
+    bns = [nn.BatchNorm2d(64), nn.BatchNorm2d(32), nn.BatchNorm2d(64)]
+    convs = [c.cuda().to(memory_format=torch.channels_last) for c in convs]
+    bns = [b.cuda() for b in bns]
+    x = torch.randn(3, 16, 40, 72, device="cuda").contiguous(memory_format=torch.channels_last)
+    gy = torch.randn(3, 64, 20, 36, device="cuda").contiguous(memory_format=torch.channels_last)
+
+    def run(defer):
+        nnkernels.DEFER_WGRAD_REDUCE = defer
+        try:
+            for m in convs + bns:
+                m.zero_grad(set_to_none=True)
+            for b in bns:
+                b.reset_running_stats()
+            h = x
+            for c, b in zip(convs, bns):
+                h = nnops.conv_bn_act(h, c, b, "relu")
+            h.backward(gy)
+            assert not nnkernels._PENDING_REDUCE
+            return [c.weight.grad.clone() for c in convs] + [convs[2].bias.grad.clone()] + [b.weight.grad.clone() for b in bns]
+        finally:
+            nnkernels.DEFER_WGRAD_REDUCE = False
+    ref, got = run(False), run(True)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
