@@ -17,11 +17,21 @@ __device__ __forceinline__ float edge_w(const float *__restrict__ col, size_t HW
     return __expf(-(g * (1.f / 3.f)));
 }
 
-__device__ __forceinline__ float image_mean(const float *__restrict__ part, int b, int nblk, int HW) {
-    // every thread re-sums the per-block depth sums of sqd_depth_up_fwd in a fixed order (deterministic)
+// sum over k < n of src[k * stride], by the whole workgroup of 256 threads in a fixed order (thread t takes k = t, t + 256, ...; lanes, then
+// waves): every workgroup of the forward and of the backward kernel gets the same bits.  (Round 1 let thread 0 walk the partials alone
+// while 255 threads waited — 240 serial loads per workgroup were 30 of smooth_bwd's 46 us.)
+__device__ __forceinline__ float block_sum_strided(const float *__restrict__ src, int n, int stride, float *red4) {
     float s = 0.f;
-    for (int k = 0; k < nblk; ++k) s += part[((size_t)b * nblk + k) * 2 + 1];
-    return s / (float)HW;
+    for (int k = threadIdx.x; k < n; k += 256) s += src[(size_t)k * stride];
+    s = wave_sum(s);
+    __syncthreads();                                 // (red4 may still be read from a previous call)
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = s;
+    __syncthreads();
+    return (red4[0] + red4[1]) + (red4[2] + red4[3]);
+}
+__device__ __forceinline__ float image_mean(const float *__restrict__ part, int b, int nblk, int HW, float *red4) {
+    // the per-block depth sums of sqd_depth_up_fwd
+    return block_sum_strided(part + (size_t)b * nblk * 2 + 1, nblk, 2, red4) / (float)HW;
 }
 
 __global__ __launch_bounds__(256) void smooth_fwd_kernel(const float *__restrict__ depth, const float *__restrict__ color,
@@ -29,9 +39,8 @@ __global__ __launch_bounds__(256) void smooth_fwd_kernel(const float *__restrict
                                                          float *__restrict__ sm_part, int H, int W, int nblk_s) {
     const int b = blockIdx.y, blk = blockIdx.x;
     const size_t HW = (size_t)H * W;
-    __shared__ float s_m;
-    if (threadIdx.x == 0) s_m = part ? image_mean(part, b, nblk, (int)HW) : 0.f;
-    __syncthreads();
+    __shared__ float red4[4];
+    const float s_m = part ? image_mean(part, b, nblk, (int)HW, red4) : 0.f;      // (workgroup-uniform branch)
     const float im = part ? 1.f / (s_m + 1e-7f) : 1.f;     // part == NULL: caller already normalised (get_smooth_loss)
     const float *d = depth + (size_t)b * HW, *col = color + (size_t)b * 3 * HW;
     float sx = 0.f, sy = 0.f;
@@ -71,18 +80,12 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const float *__restrict
                                                          int W) {
     const int b = blockIdx.y, blk = blockIdx.x;
     const size_t HW = (size_t)H * W;
-    __shared__ float s_m, s_Lb;
+    __shared__ float red4[4];
     const float inx = 1.f / ((float)B * (float)H * (float)(W - 1)), iny = 1.f / ((float)B * (float)(H - 1) * (float)W);
-    if (threadIdx.x == 0) {
-        s_m = image_mean(part, b, nblk, (int)HW);
-        float ax = 0.f, ay = 0.f;
-        for (int k = 0; k < nblk_s; ++k) {
-            ax += sm_part[((size_t)b * nblk_s + k) * 2];
-            ay += sm_part[((size_t)b * nblk_s + k) * 2 + 1];
-        }
-        s_Lb = ax * inx + ay * iny;
-    }
-    __syncthreads();
+    const float s_m = image_mean(part, b, nblk, (int)HW, red4);
+    const float ax = block_sum_strided(sm_part + (size_t)b * nblk_s * 2, nblk_s, 2, red4);
+    const float ay = block_sum_strided(sm_part + (size_t)b * nblk_s * 2 + 1, nblk_s, 2, red4);
+    const float s_Lb = ax * inx + ay * iny;
     const float mp = s_m + 1e-7f, im = 1.f / mp;
     const float mean_term = -s_Lb * im / (float)HW;
     const float *d = depth + (size_t)b * HW, *col = color + (size_t)b * 3 * HW;
