@@ -949,9 +949,9 @@ int make_plan(int Q, int E, int N, Plan *p, int B = 12) {
         nb = nb < 1 ? 1 : nb > ntiles ? ntiles : nb;
         p->nchunks_bwd = Q > 32 ? nb : p->nchunks;              // (Q <= 32: the one-group kernel keeps its plan)
     }
-    if (E == 32 || E == 64) {                                   // ~256 workgroups per image batch of a few: 64 per image
+    if (E == 32 || E == 64) {                                   // 32 workgroups of 4 waves per image and query group
         const int ntiles = (N + 31) / 32;
-        int tpw = (ntiles + 255) / 256;
+        int tpw = (ntiles + 127) / 128;                          // (8 tiles per wave at config B: 60.5 -> 56 us against 4; the merge 8 -> 6 us)
         tpw = tpw < 1 ? 1 : tpw > 16 ? 16 : tpw;
         p->tiles32 = tpw;
         p->nchunks32 = (ntiles + 4 * tpw - 1) / (4 * tpw);
