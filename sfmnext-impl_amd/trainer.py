@@ -240,9 +240,16 @@ class Trainer:
                     self.reducer.hooks_enabled = True
                 torch.cuda.synchronize()
                 return self._train_step_eager(inputs)
+        src = self.__dict__.setdefault("_static_src", {})
         for k, v in inputs.items():
-            self._static_in[k].copy_(v, non_blocking=True)
-            inputs[k] = self._static_in[k]        # as process_batch does in eager mode: the caller's dict now holds device tensors
+            st = self._static_in[k]
+            last = src.get(k)
+            # the very tensor object that was copied last time, unchanged since (same autograd version counter; the reference held here
+            # keeps its storage from being recycled): the static copy is current — a resident batch fed again costs no copies
+            if not (v is st or (last is not None and last[0] is v and last[1] == v._version and v.is_cuda)):
+                st.copy_(v, non_blocking=True)
+                src[k] = (v, v._version)
+            inputs[k] = st                        # as process_batch does in eager mode: the caller's dict now holds device tensors
         if self.reducer is None or self.opt.sqd_graph_ddp != "post":
             self.model_optimizer.refresh_hyper()
             self._graph.replay()                # forward, backward (+ bucketed all-reduces overlapped with it), Adam

@@ -187,3 +187,34 @@ def test_loss_options_train_and_match_the_oracle(flags):
                             disable_automasking=noauto)
     got, ref = float(losses["loss"]), float(want["loss"])
     assert abs(got - ref) <= 1e-4 * abs(ref), (got, ref)
+
+
+def test_replay_skips_the_copy_of_an_unchanged_resident_batch_only():
+    """A device tensor fed again unchanged is not copied into the graph's static input again; a tensor changed in place (or another
+    tensor) is."""
+    from datasets.synthetic import synthetic_batch
+    tr, _, _ = run([], steps=4)                        # captured
+    assert tr._graph is not None
+    a = synthetic_batch(2, 64, 96, start=100, device=tr.device)
+    a[("noise", 0)] = torch.randn(2, 2, 64, 96, device=tr.device)
+    b = synthetic_batch(2, 64, 96, start=200, device=tr.device)
+    b[("noise", 0)] = a[("noise", 0)].clone()
+    key = ("color", 0, 0)
+    tr.train_step(dict(a))
+    assert torch.equal(tr._static_in[key], a[key])
+    calls = []
+    orig = torch.Tensor.copy_
+    torch.Tensor.copy_ = lambda self, *x, **kw: (calls.append(1), orig(self, *x, **kw))[1]
+    try:
+        tr.train_step(dict(a))                         # same objects, unchanged: no copies
+        n_same = len(calls)
+        a[key].mul_(0.5)                               # in place: that one tensor is copied again
+        tr.train_step(dict(a))
+        n_changed = len(calls) - n_same
+        tr.train_step(dict(b))                         # other tensors: all copied
+        n_other = len(calls) - n_same - n_changed
+    finally:
+        torch.Tensor.copy_ = orig
+    # (n_same counts the copies a step makes anyway: the optimiser's refreshed step scalars)
+    assert n_same <= 1 and n_changed == n_same + 1 and n_other == n_same + len(b), (n_same, n_changed, n_other)
+    assert torch.equal(tr._static_in[key], b[key])
