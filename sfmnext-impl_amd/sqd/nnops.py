@@ -87,9 +87,11 @@ def _conv(x, conv, act=None, skip=False, bn_stats=None, input_affine=None):
     return out
 
 
-def conv2d(x, conv, act=None):
-    """conv (nn.Conv2d holding weight/bias/stride/padding) applied to x, optional activation."""
-    return _conv(x, conv, act)
+def conv2d(x, conv, act=None, skip=False):
+    """conv (nn.Conv2d holding weight/bias/stride/padding) applied to x, optional activation.  skip=True: -> (y, x') where x' must replace
+    x for x's other consumer: that consumer's gradient is then added in this convolution's data-gradient epilogue instead of by a
+    separate accumulation pass over the whole tensor."""
+    return _conv(x, conv, act, skip)
 
 
 def stem_pairs(pairs, conv, act=None):
