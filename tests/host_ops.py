@@ -16,8 +16,9 @@ def _conv(x, conv, act=None, skip=False, bn_stats=None):
     return (y, x) if skip else y
 
 
-def conv2d(x, conv, act=None):
-    return _conv(x, conv, act)
+def conv2d(x, conv, act=None, skip=False):
+    y = _conv(x, conv, act)
+    return (y, x) if skip else y
 
 
 def conv_bn_act(x, conv, bn, act, residual=None, input_affine=None, skip=False):
