@@ -299,7 +299,7 @@ int sqd_conv_precision(void);
 int sqd_conv_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
                   int64_t *ws_floats);
 /* stats (may be NULL): [sqd_conv_fwd_stats_rows(...)][K][2] per-channel (sum, sum of squares) partials of y for the BatchNorm that
- * follows (rows = 0: the current plan splits the reduction and writes none; never more than
+ * follows (a plan that splits the reduction takes them in the sum over its splits: ceil(N*Ho*Wo / 64) rows; never more than
  * max(ceil(N*Ho*Wo / 64), N * ceil(Ho/4) * ceil(Wo/16)) rows — the second term: one row per patch of the input-patch plans)   */
 int sqd_conv_fwd_stats_rows(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo);
 int sqd_conv_fwd(const float *x, const float *w, const float *bias, float *y, float *ws, float *stats, int N, int H, int W,
@@ -313,7 +313,7 @@ int sqd_conv_dgrad(const float *dy, const float *w, const float *addend, float *
 /* data gradient + the partial sums of the BatchNorm backward whose output act(BN(bn_x)) this convolution differentiates — replaces the
  * reduction pass of torch's batch_norm_backward over dy and x (dx = dgrad + addend must be the complete gradient of that output).
  * bn_x [N,H,W,C], bn_mask [N*H*W*C/4] sign bytes of the forward (NULL: no activation), bn_mean / bn_rstd [C], bn_act 0 | 1 | 2
- * -> stats [sqd_conv_dgrad_stats_rows(...)][C][2] for sqd_bn_train_bwd_pre (0 rows: the plan splits the reduction, nothing is written). */
+ * -> stats [sqd_conv_dgrad_stats_rows(...)][C][2] for sqd_bn_train_bwd_pre (split plans: ceil(N*H*W / 64) rows, written by the sum over the splits). */
 int sqd_conv_dgrad_stats_rows(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo);
 int sqd_conv_dgrad_bn(const float *dy, const float *w, const float *addend, float *dx, float *ws, const float *bn_x,
                       const unsigned char *bn_mask, const float *bn_mean, const float *bn_rstd, int bn_act, float *stats, int N, int H,

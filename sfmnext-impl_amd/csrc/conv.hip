@@ -1625,6 +1625,82 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restric
     }
 }
 
+// The same sum for a convolution whose output feeds a BatchNorm (forward, MODE 0) or whose data gradient is a BatchNorm's complete
+// output gradient (MODE 1) — with that BatchNorm's per-channel partial sums taken on the way, as the unsplit kernels' epilogues do:
+// a split-K plan no longer costs the BatchNorm a reduction pass of its own over the tensor (bn_reduce_kernel, one launch and one
+// more read of the output).  A workgroup owns RED_ROWS rows x CH channels: thread (cg = t % TPR, rr = t / TPR) walks rows
+// rr, rr + RP, ...; fixed-order LDS sum over the row groups; stats[row block][channel][2] (bn_reduce_kernel's layout).
+// MODE 0: (sum y, sum y^2), y = sum_z part + bias.   MODE 1: (sum dz, sum dz * xhat), dx = sum_z part + addend, dz = dx * act'(mask).
+constexpr int RED_ROWS = 64;
+template <int MODE>
+__global__ __launch_bounds__(256) void gemm_reduce_stats_kernel(const float *__restrict__ part, const float *__restrict__ bias,
+                                                                const float *__restrict__ addend, float *__restrict__ out, int M, int Z,
+                                                                int Ncols, int act, float *__restrict__ stats, BnBwdSrc bnb, int CH) {
+    __shared__ float4 sh[2][256];
+    const int t = threadIdx.x;
+    const int chunk = min(CH, Ncols - (int)blockIdx.y * CH);            // channels of this workgroup (multiple of 4; CH = 256 .. 32)
+    const int TPR = chunk / 4, RP = 256 / TPR;
+    const int cg0 = t % TPR, rr = t / TPR;
+    const int c = blockIdx.y * CH + cg0 * 4;
+    const int r0 = blockIdx.x * RED_ROWS, r1 = min(M, r0 + RED_ROWS);
+    const size_t n = (size_t)M * Ncols;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (rr < RP) {
+        float4 bv = a, mu = a, rs = a;
+        if (MODE == 0 && bias) bv = *reinterpret_cast<const float4 *>(bias + c);
+        if (MODE == 1) {
+            mu = *reinterpret_cast<const float4 *>(bnb.mean + c);
+            rs = *reinterpret_cast<const float4 *>(bnb.rstd + c);
+        }
+        for (int row = r0 + rr; row < r1; row += RP) {
+            const size_t o = (size_t)row * Ncols + c;
+            float4 v = *reinterpret_cast<const float4 *>(part + o);
+            for (int z = 1; z < Z; ++z) {
+                const float4 w = *reinterpret_cast<const float4 *>(part + (size_t)z * n + o);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            if (MODE == 0) {
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                if (act == 1) {
+                    v.x = v.x > 0.f ? v.x : 0.f; v.y = v.y > 0.f ? v.y : 0.f; v.z = v.z > 0.f ? v.z : 0.f; v.w = v.w > 0.f ? v.w : 0.f;
+                } else if (act == 2) {
+                    v.x = v.x > 0.f ? v.x : 0.01f * v.x; v.y = v.y > 0.f ? v.y : 0.01f * v.y;
+                    v.z = v.z > 0.f ? v.z : 0.01f * v.z; v.w = v.w > 0.f ? v.w : 0.01f * v.w;
+                }
+            } else if (addend) {
+                const float4 w = *reinterpret_cast<const float4 *>(addend + o);
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            *reinterpret_cast<float4 *>(out + o) = v;
+            if (MODE == 0) {
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                b.x = fmaf(v.x, v.x, b.x); b.y = fmaf(v.y, v.y, b.y); b.z = fmaf(v.z, v.z, b.z); b.w = fmaf(v.w, v.w, b.w);
+            } else {
+                const float4 xv = *reinterpret_cast<const float4 *>(bnb.x + o);
+                const unsigned bits = bnb.mask ? bnb.mask[o / 4] : 0xfu;
+                const float d0 = v.x * bn_bwd_act(bits, 0, bnb.act), d1 = v.y * bn_bwd_act(bits, 1, bnb.act);
+                const float d2 = v.z * bn_bwd_act(bits, 2, bnb.act), d3 = v.w * bn_bwd_act(bits, 3, bnb.act);
+                a.x += d0; a.y += d1; a.z += d2; a.w += d3;
+                b.x = fmaf(d0, (xv.x - mu.x) * rs.x, b.x); b.y = fmaf(d1, (xv.y - mu.y) * rs.y, b.y);
+                b.z = fmaf(d2, (xv.z - mu.z) * rs.z, b.z); b.w = fmaf(d3, (xv.w - mu.w) * rs.w, b.w);
+            }
+        }
+    }
+    sh[0][t] = a;
+    sh[1][t] = b;
+    __syncthreads();
+    if (rr == 0) {
+        for (int k = 1; k < RP; ++k) {
+            const float4 a2 = sh[0][k * TPR + cg0], b2 = sh[1][k * TPR + cg0];
+            a.x += a2.x; a.y += a2.y; a.z += a2.z; a.w += a2.w;
+            b.x += b2.x; b.y += b2.y; b.z += b2.z; b.w += b2.w;
+        }
+        float *o = stats + ((size_t)blockIdx.x * Ncols + c) * 2;
+        reinterpret_cast<float4 *>(o)[0] = make_float4(a.x, b.x, a.y, b.y);
+        reinterpret_cast<float4 *>(o)[1] = make_float4(a.z, b.z, a.w, b.w);
+    }
+}
+
 // gradient through the activation a convolution / linear layer applied in its epilogue, from the OUTPUT y (sign(y) == sign(pre-
 // activation) for both): ReLU g * (y > 0), LeakyReLU(0.01) g * (y > 0 ? 1 : 0.01)
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ g, const float *__restrict__ y, float *__restrict__ out,
@@ -1891,7 +1967,19 @@ static int launch_gemm(int mode, const float *a_src, const float *w, const float
     } else if (conv_precision() == 2) {
         if (mode == 0) { DISPATCH_GEMM_BF(0, 3) } else { DISPATCH_GEMM_BF(1, 3) }
     } else if (mode == 0) { DISPATCH_GEMM(0) } else { DISPATCH_GEMM(1) }
-    if (p.z > 1) {
+    if (p.z > 1 && stats && (mode == 0 || bnb.x != nullptr)) {
+        // split reduction + the following BatchNorm's partial sums in one pass: stats [ceil(Mrows / RED_ROWS)][Ncols][2]
+        // the channels of a row block are cut into chunks of 256 .. 32 until the launch has ~1000 workgroups (split plans are the
+        // few-pixel layers: 1440 or 5760 rows)
+        const int mb = (Mrows + RED_ROWS - 1) / RED_ROWS;
+        int CH = 256;
+        while (CH > 32 && mb * ((Ncols + CH - 1) / CH) < 1024) CH >>= 1;
+        const dim3 grid(mb, (Ncols + CH - 1) / CH);
+        if (mode == 0)
+            hipLaunchKernelGGL((gemm_reduce_stats_kernel<0>), grid, dim3(256), 0, st, ws, bias, (const float *)nullptr, out, Mrows, p.z, Ncols, act, stats, bnb, CH);
+        else
+            hipLaunchKernelGGL((gemm_reduce_stats_kernel<1>), grid, dim3(256), 0, st, ws, (const float *)nullptr, bias, out, Mrows, p.z, Ncols, 0, stats, bnb, CH);
+    } else if (p.z > 1) {
         const size_t n = (size_t)Mrows * Ncols;
         size_t nb = (n / 4 + 255) / 256;
         hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, ws, mode == 0 ? bias : nullptr, mode == 1 ? bias : nullptr,
@@ -1984,12 +2072,12 @@ extern "C" int sqd_conv_plan(int mode, int N, int H, int W, int C, int K, int R,
 
 // Rows of BatchNorm partials sqd_conv_fwd writes into `stats` for this geometry under the current plan ([rows][K][2] floats:
 // per-channel sum and sum of squares of a tile of output rows, the layout sqd_bn_train_fwd's finalize reads): ceil(M / tile
-// rows), or 0 when the plan splits the reduction (the statistics are then not produced); the input-patch plans write one row per
-// patch.  Never more than max(ceil(M/64), N * ceil(Ho/4) * ceil(Wo/16)) rows: size `stats` for that when the plan may still change.
+// rows) — ceil(M / 64) when the plan splits the reduction (the sum over the splits takes the statistics); the input-patch plans
+// write one row per patch.  Never more than max(ceil(M/64), N * ceil(Ho/4) * ceil(Wo/16)) rows: size `stats` for that when the plan may still change.
 extern "C" int sqd_conv_fwd_stats_rows(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo) {
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     const GemmPlan p = plan_gemm(0, g);
-    if (p.z > 1) return 0;
+    if (p.z > 1) return (N * Ho * Wo + RED_ROWS - 1) / RED_ROWS;                      // taken by the split-K sum (gemm_reduce_stats_kernel)
     if (p.halo) return N * ((H + p.bm / 16 - 1) / (p.bm / 16)) * ((W + 15) / 16);     // one row of partials per patch
     return (N * Ho * Wo + p.bm - 1) / p.bm;
 }
@@ -2034,12 +2122,12 @@ extern "C" int sqd_conv_dgrad(const float *dy, const float *w, const float *adde
 }
 
 // Rows of BatchNorm-backward partials sqd_conv_dgrad_bn writes for this geometry under the current plan ([rows][C][2] floats: per-channel
-// sum dz and sum dz * xhat of a tile of input pixels): M-tiles x stride classes, one row per patch for the input-patch plans, 0 when the
-// plan splits the reduction (the partials are then not produced: run the BatchNorm backward's own reduction).
+// sum dz and sum dz * xhat of a tile of input pixels): M-tiles x stride classes, one row per patch for the input-patch plans, ceil(N*H*W / 64) when the
+// plan splits the reduction (the sum over the splits takes them: gemm_reduce_stats_kernel).
 extern "C" int sqd_conv_dgrad_stats_rows(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo) {
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     const GemmPlan p = plan_gemm(1, g);
-    if (p.z > 1) return 0;
+    if (p.z > 1) return (N * H * W + RED_ROWS - 1) / RED_ROWS;
     if (p.halo) return N * ((H + p.bm / 16 - 1) / (p.bm / 16)) * ((W + 15) / 16);
     const int Mcls = N * ((H + stride - 1) / stride) * ((W + stride - 1) / stride);
     return stride * stride * ((Mcls + p.bm - 1) / p.bm);

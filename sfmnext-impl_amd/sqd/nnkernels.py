@@ -210,7 +210,7 @@ TUNE_SPACE = {
     "eight_wave": False,       # bk +256: 8-wave workgroups — 1-3 % on a third of the layers, nothing on the step
     "wgrad_shapes": False,     # smaller register tiles of the direct weight gradient: 7 of 38 layers, nothing on the step
     "wgrad_rows": True,        # impl 4: the row-window weight gradient of the few-channel / high-resolution layers
-    "stats_penalty": True,     # charge split-K forward plans the BatchNorm statistics pass they force
+    "stats_penalty": False,    # (history: split-K forward plans used to force a BatchNorm statistics pass; their sum takes the partials now)
     "log": False,
 }
 

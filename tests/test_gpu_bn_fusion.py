@@ -23,7 +23,9 @@ def _chain(conv1, bn, conv2, x, act, res=None, double=False):
     (2, 64, 24, 40, 64, 128, 3, 2, "relu", True, (64, 64, 1, 16)),            # stride-2 consumer (4 stride classes), residual into the BatchNorm
     (2, 64, 24, 40, 64, 128, 3, 2, "relu", False, None),                      # whatever the cost model picks
     (2, 32, 16, 24, 64, 32, 1, 1, None, False, (64, 64, 1, 32 + 1024)),                      # no activation, three-term plan
-    (2, 64, 12, 20, 256, 64, 1, 1, "relu", False, (128, 64, 2, 16)),                        # split reduction: no partials, ordinary path
+    (2, 64, 12, 20, 256, 64, 1, 1, "relu", False, (128, 64, 2, 16)),                        # split reduction: the sum over the splits takes the partials
+    (3, 64, 12, 20, 320, 64, 3, 1, "leaky_relu", True, (64, 64, 4, 32 + 1024)),             # ... 4 splits, three-term plan, residual, 320 channels = two channel chunks
+    (2, 32, 9, 13, 72, 64, 3, 2, "relu", False, (64, 64, 2, 16)),                           # ... stride classes, ragged rows, 72 channels (18 threads per row)
 ])
 def test_bn_backward_statistics_from_the_dgrad_epilogue(N, C, H, W, Cm, K, R2, stride2, act, with_res, plan2):
     from sqd import lib, nnkernels, nnops
@@ -68,7 +70,9 @@ def test_bn_backward_statistics_from_the_dgrad_epilogue(N, C, H, W, Cm, K, R2, s
         L.sqd_conv_set_plan(1, *geom2, 0, 0, 0, 16)
         nnkernels.reset_plans()
     if plan2 is not None:
-        assert (results[True][6] > 0) == (plan2[2] == 1), results[True][6]          # the fused path ran exactly where the plan allows it
+        assert results[True][6] > 0, results[True][6]                               # the fused path ran (split plans: through gemm_reduce_stats_kernel)
+        if plan2[2] > 1:
+            assert results[True][6] == (N * H * W + 63) // 64
     refs = (out_r.detach(), xr.grad, c1.weight.grad, b1.weight.grad, b1.bias.grad, rr.grad if with_res else None)
     for name, i in (("out", 0), ("dx", 1), ("dW1", 2), ("dgamma", 3), ("dbeta", 4), ("dres", 5)):
         if refs[i] is None:

@@ -1,5 +1,7 @@
 """GPU parity of the native implicit-GEMM convolution (csrc/conv.hip through the C ABI: forward, input
 gradient, weight + bias gradient) against torch's fp32 convolution on the same inputs."""
+import copy
+
 import pytest
 import torch
 import torch.nn as nn
@@ -173,6 +175,48 @@ def test_conv_epilogue_feeds_batchnorm_statistics(N, C, H, W, K, R, stride, pad,
         assert float((a.cpu().double() - b).abs().max()) <= 1e-3 * float(b.abs().max()) + 1e-6, name
     if C > 3:
         assert float((xg.grad.cpu().double() - xr.grad).abs().max()) <= 1e-3 * float(xr.grad.abs().max())
+
+
+@pytest.mark.parametrize("N,C,H,W,K,R,z,bk", [(2, 512, 6, 20, 512, 3, 4, 16), (3, 256, 9, 13, 72, 1, 2, 16), (2, 512, 12, 20, 320, 1, 2, 32 + 1024)])
+def test_split_plan_takes_the_batchnorm_statistics_in_its_sum(N, C, H, W, K, R, z, bk):
+    """A forward plan that splits the reduction: the sum over its splits (gemm_reduce_stats_kernel) writes the BatchNorm partials —
+    ceil(M / 64) rows — and conv -> BatchNorm -> ReLU gives what the unsplit plan gives (same fp32 level against float64)."""
+    from sqd import lib, nnkernels, nnops
+    L = lib.lib()
+    torch.manual_seed(K + z)
+    conv, bn = nn.Conv2d(C, K, R, 1, R // 2, bias=False), nn.BatchNorm2d(K)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.5, 0.5)
+    x = torch.randn(N, C, H, W)
+    cr, br = copy.deepcopy(conv).double(), copy.deepcopy(bn).double()
+    xr = x.double().requires_grad_(True)
+    yr = F.relu(br(cr(xr)))
+    gy = torch.randn_like(yr)
+    yr.backward(gy)
+    geom = (N, H, W, C, K, R, R, 1, R // 2, H, W)
+    nnkernels.reset_plans()
+    got = {}
+    try:
+        for zz in (z, 1):
+            nnkernels._PLAN_CACHE.clear()
+            assert L.sqd_conv_set_plan(0, *geom, 64, 64, zz, bk) == 0, L.sqd_last_error()
+            cg, bg = copy.deepcopy(conv).cuda().to(memory_format=torch.channels_last), copy.deepcopy(bn).cuda()
+            xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            y = nnops.conv_bn_act(xg, cg, bg, "relu")
+            rows = nnkernels.conv_stats_rows(geom)
+            assert rows == ((N * H * W + 63) // 64 if zz > 1 else (N * H * W + 63) // 64), rows
+            y.backward(gy.float().cuda())
+            got[zz] = (y.detach().cpu().double(), bg.running_mean.cpu().double(), bg.running_var.cpu().double(), xg.grad.cpu().double(),
+                       bg.weight.grad.cpu().double(), bg.bias.grad.cpu().double())
+    finally:
+        L.sqd_conv_set_plan(0, *geom, 0, 0, 0, 16)
+        nnkernels.reset_plans()
+    refs = (yr.detach(), br.running_mean, br.running_var, xr.grad, br.weight.grad, br.bias.grad)
+    for i, name in enumerate(("y", "running_mean", "running_var", "dx", "dgamma", "dbeta")):
+        scale = float(refs[i].abs().max())
+        es, eu = float((got[z][i] - refs[i]).abs().max()) / scale, float((got[1][i] - refs[i]).abs().max()) / scale
+        assert es <= 2e-4 and es <= 4.0 * eu + 2e-6, (name, "split", es, "unsplit", eu)
 
 
 @pytest.mark.parametrize("N,C,H,W,K,R,stride,pad,bias,act", [CASES[1], CASES[2], CASES[5], CASES[7], CASES[11], CASES[12]])
