@@ -190,6 +190,13 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float *__res
                                                               float *__restrict__ rvar) {
     int c;
     float s, ss;
+    // the running statistics are fetched before the partials are summed, not after: one dependent memory latency less at the end of a
+    // kernel that is nothing but a latency chain
+    float rm = 0.f, rv = 0.f;
+    if (rmean && threadIdx.x < FIN_CH && (int)(blockIdx.x * FIN_CH + threadIdx.x) < C) {
+        rm = rmean[blockIdx.x * FIN_CH + threadIdx.x];
+        rv = rvar[blockIdx.x * FIN_CH + threadIdx.x];
+    }
     if (!finalize_sums(part, nblk, C, c, s, ss)) return;
     const float m = s / (float)M;
     float var = ss / (float)M - m * m;                    // biased (normalisation) variance
@@ -198,8 +205,8 @@ __global__ __launch_bounds__(256) void bn_finalize_fwd_kernel(const float *__res
     rstd[c] = rsqrtf(var + eps);
     if (rmean) {
         const float unbiased = M > 1 ? var * ((float)M / (float)(M - 1)) : var;
-        rmean[c] = (1.f - momentum) * rmean[c] + momentum * m;
-        rvar[c] = (1.f - momentum) * rvar[c] + momentum * unbiased;
+        rmean[c] = (1.f - momentum) * rm + momentum * m;
+        rvar[c] = (1.f - momentum) * rv + momentum * unbiased;
     }
 }
 

@@ -124,6 +124,8 @@ EXTRA_FLAGS = [
     ("sqd_conv_plans", str, None, {"help": "JSON file of convolution plans (written by --sqd_save_conv_plans): pins every listed layer's kernel, "
                                         "tile and split instead of timing them in the first step — last-bit reproducible across boxes"}),
     ("sqd_save_conv_plans", str, None, {"help": "write the convolution plans this run measured (or loaded) to this JSON file after the first steps"}),
+    ("sqd_early_identity", _T, False, {"help": "captured step: evaluate the identity-reprojection maps at the start of the step (as the eager steps do "
+                                                "on their side stream) instead of right before the fused warp + SSIM kernel"}),
     ("sqd_no_defer_wgrad_reduce", _T, False, {"help": "sum every weight gradient's pixel splits in a launch of its own instead of letting the sum ride "
                                                        "on the next BatchNorm-backward launch (single-rank default: it rides)"}),
 ]

@@ -375,7 +375,11 @@ class Trainer:
         """Pass a minibatch through the networks and the photometric chain -> (outputs, losses)."""
         for key, ipt in inputs.items():
             inputs[key] = ipt.to(self.device, non_blocking=True)
-        self._launch_identity(inputs)
+        if not self._capturing or self.opt.sqd_early_identity:
+            self._launch_identity(inputs)
+        # (inside the captured step the identity maps are evaluated right before the fused warp + SSIM kernel instead — see
+        #  generate_images_pred: a side stream buys nothing in the graph, and the pass over the target and source frames leaves them
+        #  in the Infinity Cache for the kernel that gathers from them next, 15 ms of convolution traffic after the stems read them)
         nnkernels.defer_bn_counters(True)
         try:
             fork = self._capturing and self.use_pose_net

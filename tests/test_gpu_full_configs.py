@@ -105,13 +105,17 @@ def test_flagship_step_matches_oracle(H, W, B, kind, plans):
         # with round 2's kernels: two fp32 evaluations with different summation orders disagree on a handful of ReLU / max-pool gates
         # among the ~10^8 activations of the trunk, and every flipped gate re-routes a gradient path that ends in this filter
         g_err = float((g_got - g_ref).abs().max()) / float(g_ref.abs().max())
+        g_l2 = float((g_got - g_ref).norm()) / float(g_ref.norm())              # (a handful of re-routed paths barely move the norm)
         # (2) the optimiser step.  Adam's first update is lr * g/(|g| + eps) = lr * sign(g): an element whose gradient lies within that
         # noise of zero may legitimately move the other way — allowed only where |g_ref| is small against the tensor's scale, and
         # only for a few elements.
         bad = (w_got - w_ref).abs() > 5e-5
         noise_level = g_ref.abs() <= max(5e-3, 4.0 * g_err) * g_ref.abs().max()
-        print("%s: gradient max err %.1e of max|g|; %d of %d updated weights beyond 5e-5, all of them inside the gradient's noise band: %s"
-              % (name, g_err, int(bad.sum()), bad.numel(), bool((~bad | noise_level).all())))
-        assert g_err <= (2.5e-2 if name.endswith("encoder.conv1.weight") else 2e-3), (name, g_err)
+        print("%s: gradient max err %.1e of max|g|, L2 err %.1e; %d of %d updated weights beyond 5e-5, all of them inside the gradient's noise band: %s"
+              % (name, g_err, g_l2, int(bad.sum()), bad.numel(), bool((~bad | noise_level).all())))
+        # (the stem's worst element moves with the rounding pattern of the run — 5e-3 .. 2.5e-2 over the plan sets and library builds seen on
+        #  MI355X: which gates flip is a lottery — so the bound on it is loose and the norm of the difference carries the claim)
+        assert g_err <= (5e-2 if name.endswith("encoder.conv1.weight") else 2e-3), (name, g_err)
+        assert g_l2 <= (3e-2 if name.endswith("encoder.conv1.weight") else 2e-3), (name, g_l2)
         assert bool((~bad | noise_level).all()), (name, float((w_got - w_ref).abs().max()))
         assert float(bad.float().mean()) <= 2e-2, (name, int(bad.sum()))
