@@ -179,67 +179,85 @@ __global__ __launch_bounds__(256) void se_pool_kernel(const float *__restrict__ 
 
 __device__ __forceinline__ float sigmoidf(float v) { return 1.f / (1.f + __expf(-v)); }
 
-// one workgroup per image: s = mean over pixels (sum of the chunk partials / HW); r = swish(W1 s + b1); gate = sigmoid(W2 r + b2)
+// The gate of one image: s = mean over pixels (sum of the chunk partials / HW); r = swish(W1 s + b1); gate = sigmoid(W2 r + b2).
 // W1 [R][C], W2T [R][C] (the expansion filter transposed: lanes run along C in every loop).  saves s [B][C], pre1 [B][R].
-__global__ __launch_bounds__(1024) void se_gate_fwd_kernel(const float *__restrict__ part, int nchunk, const float *__restrict__ W1,
-                                                          const float *__restrict__ b1, const float *__restrict__ W2,
-                                                          const float *__restrict__ b2, float *__restrict__ s_out,
-                                                          float *__restrict__ pre1_out, float *__restrict__ gate, int C, int R, float inv_hw) {
-    extern __shared__ float sh[];            // s [C], r [R]
-    float *s = sh, *r = sh + C;
-    const int img = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += 1024) {
+// Two launches, both spread over the chip (one workgroup per image — 8 of 256 CUs, each reading its 1.5 MB of W1 alone — took 39 us per
+// block of the trunk): (1) SE_SPLIT workgroups per image share the R squeeze dots (one wave per reduced channel; every workgroup forms
+// s itself — the partials are small —, the first one stores it); (2) one thread per channel for the excite dots.  Same order of every
+// sum as the one-workgroup kernel: the same bits.
+constexpr int SE_SPLIT = 16;
+__global__ __launch_bounds__(256) void se_squeeze_kernel(const float *__restrict__ part, int nchunk, const float *__restrict__ W1,
+                                                         const float *__restrict__ b1, float *__restrict__ s_out, float *__restrict__ pre1_out,
+                                                         int C, int R, float inv_hw) {
+    extern __shared__ float sh[];            // s [C]
+    float *s = sh;
+    const int img = blockIdx.y, blk = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
         float a = 0.f;
         for (int k = 0; k < nchunk; ++k) a += part[((size_t)img * nchunk + k) * C + c];
         a *= inv_hw;
         s[c] = a;
-        s_out[(size_t)img * C + c] = a;
+        if (blk == 0) s_out[(size_t)img * C + c] = a;
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = wave; j < R; j += 16) {      // one wave per reduced channel
+    const int per = (R + SE_SPLIT - 1) / SE_SPLIT, j0 = blk * per, j1 = min(R, j0 + per);
+    for (int j = j0 + wave; j < j1; j += 4) {      // one wave per reduced channel
         float a = 0.f;
         for (int c = lane; c < C; c += 64) a = fmaf(W1[(size_t)j * C + c], s[c], a);
         a = wave_sum(a) + b1[j];
-        if (lane == 0) {
-            pre1_out[(size_t)img * R + j] = a;
-            r[j] = a * sigmoidf(a);
-        }
+        if (lane == 0) pre1_out[(size_t)img * R + j] = a;
+    }
+}
+__global__ __launch_bounds__(256) void se_excite_kernel(const float *__restrict__ pre1, const float *__restrict__ W2, const float *__restrict__ b2,
+                                                        float *__restrict__ gate, int C, int R) {
+    __shared__ float r[256];                 // R <= 252
+    const int img = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if ((int)threadIdx.x < R) {
+        const float a = pre1[(size_t)img * R + threadIdx.x];
+        r[threadIdx.x] = a * sigmoidf(a);
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 1024) {
-        float a = b2[c];
-        for (int j = 0; j < R; ++j) a = fmaf(W2[(size_t)j * C + c], r[j], a);
-        gate[(size_t)img * C + c] = sigmoidf(a);
-    }
+    if (c >= C) return;
+    float a = b2[c];
+    for (int j = 0; j < R; ++j) a = fmaf(W2[(size_t)j * C + c], r[j], a);
+    gate[(size_t)img * C + c] = sigmoidf(a);
 }
 
 // backward of the gate for one image: dgate [C] = sum over pixels of dy * x (chunk partials) ->
 // dW2part [B][C][R], db2part [B][C], dW1part [B][R][C], db1part [B][R rounded up to 4], ds [B][C] (gradient w.r.t. the pooled mean, already / HW)
-__global__ __launch_bounds__(1024) void se_gate_bwd_kernel(const float *__restrict__ dgpart, int nchunk, const float *__restrict__ W1,
-                                                          const float *__restrict__ W2, const float *__restrict__ s_in,
-                                                          const float *__restrict__ pre1_in, const float *__restrict__ gate,
-                                                          float *__restrict__ dW1p, float *__restrict__ db1p, float *__restrict__ dW2p,
-                                                          float *__restrict__ db2p, float *__restrict__ ds, int C, int R, float inv_hw) {
+// Two launches, as the forward (one workgroup of 1024 threads per image took 64 us per block of the trunk): (1) SE_SPLIT workgroups per
+// image: every one forms dpre2 [C] and r [R] itself, writes its slice of channels of dW2part / db2part, then the dpre1 of its slice of
+// reduced channels (one wave per dot over C) -> db1part and its rows of dW1part; (2) one thread per channel for ds, reading dpre1 back
+// from db1part.  The same order of every sum as before: the same bits.
+__global__ __launch_bounds__(256) void se_gate_bwd_kernel(const float *__restrict__ dgpart, int nchunk, const float *__restrict__ W2,
+                                                         const float *__restrict__ s_in, const float *__restrict__ pre1_in,
+                                                         const float *__restrict__ gate, float *__restrict__ dW1p, float *__restrict__ db1p,
+                                                         float *__restrict__ dW2p, float *__restrict__ db2p, int C, int R) {
     extern __shared__ float sh[];            // dpre2 [C], r [R], dpre1 [R]
     float *dpre2 = sh, *r = sh + C, *dpre1 = r + R;
-    const int img = blockIdx.x, RP = (R + 3) & ~3;
-    for (int j = threadIdx.x; j < R; j += 1024) {
+    const int img = blockIdx.y, blk = blockIdx.x, RP = (R + 3) & ~3;
+    const int cper = (C + SE_SPLIT - 1) / SE_SPLIT, c0 = blk * cper, c1 = min(C, c0 + cper);
+    const int jper = (R + SE_SPLIT - 1) / SE_SPLIT, j0 = blk * jper, j1 = min(R, j0 + jper);
+    for (int j = threadIdx.x; j < R; j += 256) {
         const float a = pre1_in[(size_t)img * R + j];
         r[j] = a * sigmoidf(a);
     }
-    for (int c = threadIdx.x; c < C; c += 1024) {
+    for (int c = threadIdx.x; c < C; c += 256) {
         float dg = 0.f;
         for (int k = 0; k < nchunk; ++k) dg += dgpart[((size_t)img * nchunk + k) * C + c];
         const float gt = gate[(size_t)img * C + c];
         const float d = dg * gt * (1.f - gt);
         dpre2[c] = d;
-        db2p[(size_t)img * C + c] = d;
+        if (c >= c0 && c < c1) db2p[(size_t)img * C + c] = d;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C * R; i += 1024) dW2p[(size_t)img * C * R + i] = dpre2[i / R] * r[i % R];
+    for (int i = threadIdx.x; i < (c1 - c0) * R; i += 256) {
+        const int c = c0 + i / R, j = i % R;
+        dW2p[((size_t)img * C + c) * R + j] = dpre2[c] * r[j];
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = wave; j < R; j += 16) {
+    for (int j = j0 + wave; j < j1; j += 4) {
         float a = 0.f;
         for (int c = lane; c < C; c += 64) a = fmaf(W2[(size_t)j * C + c], dpre2[c], a);
         a = wave_sum(a);
@@ -250,14 +268,23 @@ __global__ __launch_bounds__(1024) void se_gate_bwd_kernel(const float *__restri
             db1p[(size_t)img * RP + j] = d;
         }
     }
-    if (threadIdx.x >= R && threadIdx.x < RP) db1p[(size_t)img * RP + threadIdx.x] = 0.f;     // padding columns of the partial rows
+    if (blk == 0 && (int)threadIdx.x >= R && (int)threadIdx.x < RP) db1p[(size_t)img * RP + threadIdx.x] = 0.f;     // padding columns of the partial rows
     __syncthreads();
-    for (int i = threadIdx.x; i < R * C; i += 1024) dW1p[(size_t)img * R * C + i] = dpre1[i / C] * s_in[(size_t)img * C + i % C];
-    for (int c = threadIdx.x; c < C; c += 1024) {
-        float a = 0.f;
-        for (int j = 0; j < R; ++j) a = fmaf(W1[(size_t)j * C + c], dpre1[j], a);
-        ds[(size_t)img * C + c] = a * inv_hw;
+    for (int i = threadIdx.x; i < (j1 - j0) * C; i += 256) {
+        const int j = j0 + i / C, c = i % C;
+        dW1p[((size_t)img * R + j) * C + c] = dpre1[j] * s_in[(size_t)img * C + c];
     }
+}
+__global__ __launch_bounds__(256) void se_gate_bwd_ds_kernel(const float *__restrict__ W1, const float *__restrict__ db1p, float *__restrict__ ds,
+                                                            int C, int R, float inv_hw) {
+    __shared__ float dpre1[256];
+    const int img = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x, RP = (R + 3) & ~3;
+    if ((int)threadIdx.x < R) dpre1[threadIdx.x] = db1p[(size_t)img * RP + threadIdx.x];
+    __syncthreads();
+    if (c >= C) return;
+    float a = 0.f;
+    for (int j = 0; j < R; ++j) a = fmaf(W1[(size_t)j * C + c], dpre1[j], a);
+    ds[(size_t)img * C + c] = a * inv_hw;
 }
 
 // y = x * gate[img, c]   |   backward: dx = dy * gate + ds[img, c]
@@ -368,8 +395,10 @@ extern "C" int sqd_se_gate_fwd(const float *part, const float *W1, const float *
     SQD_CHECK_ARG(part && W1 && b1 && W2 && b2 && s && pre1 && gate && B > 0 && C > 0 && R > 0 && (size_t)(C + R) * 4 <= 64 * 1024,
                   "sqd_se_gate_fwd: bad arguments");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(se_gate_fwd_kernel, dim3(B), dim3(1024), (C + R) * sizeof(float), (hipStream_t)stream, part, sqd_se_chunks(HW), W1, b1, W2,
-                       b2, s, pre1, gate, C, R, 1.0f / (float)HW);
+    SQD_CHECK_ARG(R <= 252, "sqd_se_gate_fwd: R=%d (at most 252 reduced channels)", R);
+    hipLaunchKernelGGL(se_squeeze_kernel, dim3(SE_SPLIT, B), dim3(256), C * sizeof(float), (hipStream_t)stream, part, sqd_se_chunks(HW), W1, b1, s,
+                       pre1, C, R, 1.0f / (float)HW);
+    hipLaunchKernelGGL(se_excite_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, pre1, W2, b2, gate, C, R);
     SQD_CHECK_LAUNCH("sqd_se_gate_fwd");
     return SQD_OK;
 }
@@ -381,8 +410,9 @@ extern "C" int sqd_se_gate_bwd(const float *dgpart, const float *W1, const float
                       (size_t)(C + 2 * R) * 4 <= 64 * 1024 && R <= 252,
                   "sqd_se_gate_bwd: bad arguments");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(B), dim3(1024), (C + 2 * R) * sizeof(float), (hipStream_t)stream, dgpart, sqd_se_chunks(HW), W1, W2,
-                       s, pre1, gate, dW1part, db1part, dW2part, db2part, ds, C, R, 1.0f / (float)HW);
+    hipLaunchKernelGGL(se_gate_bwd_kernel, dim3(SE_SPLIT, B), dim3(256), (C + 2 * R) * sizeof(float), (hipStream_t)stream, dgpart, sqd_se_chunks(HW), W2,
+                       s, pre1, gate, dW1part, db1part, dW2part, db2part, C, R);
+    hipLaunchKernelGGL(se_gate_bwd_ds_kernel, dim3((C + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, W1, db1part, ds, C, R, 1.0f / (float)HW);
     SQD_CHECK_LAUNCH("sqd_se_gate_bwd");
     return SQD_OK;
 }
