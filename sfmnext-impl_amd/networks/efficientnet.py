@@ -73,7 +73,13 @@ class InvertedResidual(nn.Module):
         self.bn3 = nn.BatchNorm2d(out_chs, eps=BN_EPS)
 
     def forward(self, x):
-        y = X.conv_bn_act(x, self.conv_pw, self.bn1, "swish")
+        if self.has_residual:
+            # x has two consumers: the expansion hands it through, so that the residual branch's gradient is added in the expansion's
+            # data-gradient epilogue (no accumulation pass over [B,C,H,W]) and — the sum being the complete gradient of the previous
+            # block's bn3 output — that BatchNorm's backward sums come from the same epilogue (nnops.conv_bn_act, skip=True)
+            y, x = X.conv_bn_act(x, self.conv_pw, self.bn1, "swish", skip=True)
+        else:
+            y = X.conv_bn_act(x, self.conv_pw, self.bn1, "swish")
         y = X.dw_conv_bn_act(y, self.conv_dw, self.bn2, "swish", self.stride)
         y = self.se(y)
         return X.conv_bn_act(y, self.conv_pwl, self.bn3, None, residual=x if self.has_residual else None)
