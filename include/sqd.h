@@ -328,6 +328,10 @@ int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *
 int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int impl, int splits);
 int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C, int K,
                    int R, int S, int stride, int pad, int Ho, int Wo, void *stream);
+/* src [rows][cols] -> dst [cols][rows] (fp32); colsum (may be NULL): [ceil(rows/64)][cols] column sums of each 64-row tile.  The wide
+ * 1x1 layers' weight gradient dW[k][c] = sum_m dY[m][k] X[m][c] as a FORWARD problem on transposed operands:
+ * sqd_conv_fwd(x = dY^T as [1,1,K,M], w = X^T [C][M]) -> dW [K][C] on the three-term kernels; dbias from colsum. */
+int sqd_transpose2d(const float *src, float *dst, int rows, int cols, float *colsum, void *stream);
 /* sqd_conv_wgrad without the final sum over the pixel splits: part[0 .. *splits)[K*R*S*C] holds the partial filter gradients and dw
  * is NOT written (dbias is).  The caller adds them later on the same stream: sqd_split_reduce(part, dw, K*R*S*C, *splits), or as extra
  * workgroups of the next BatchNorm-backward finalize launch (sqd_bn_train_bwd_pre_red) — one launch less per layer, the same bits. */

@@ -2441,3 +2441,43 @@ extern "C" int sqd_split_reduce(const float *part, float *out, int64_t n, int sp
     return SQD_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// [rows][cols] -> [cols][rows] (fp32, 64 x 64 tiles through LDS, both sides coalesced), optionally with the column sums of each row
+// tile on the way (colsum [ceil(rows / 64)][cols]: the bias gradient's partials).  Feeds the weight gradient of the wide 1x1 layers
+// as a forward GEMM on transposed operands (nnkernels._wgrad_transposed): dW [K][C] = sum_m dY[m][k] X[m][c] reduces over the slow
+// axis of both tensors; transposed, it is the forward problem "K pixels, M channels, C filters" and runs the three-term kernels.
+// ---------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void transpose2d_kernel(const float *__restrict__ src, float *__restrict__ dst, int rows, int cols,
+                                                          float *__restrict__ colsum) {
+    __shared__ float tile[64][65];
+    __shared__ float cs[4][64];
+    const int c = threadIdx.x & 63, r0 = threadIdx.x >> 6;
+    const int R0 = blockIdx.y * 64, C0 = blockIdx.x * 64;
+    float acc = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + 4 * i;
+        const float v = (R0 + r < rows && C0 + c < cols) ? src[(size_t)(R0 + r) * cols + C0 + c] : 0.f;
+        tile[r][c] = v;
+        acc += v;
+    }
+    if (colsum) cs[r0][c] = acc;
+    __syncthreads();
+    if (colsum && r0 == 0 && C0 + c < cols) colsum[(size_t)blockIdx.y * cols + C0 + c] = ((cs[0][c] + cs[1][c]) + cs[2][c]) + cs[3][c];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int r = r0 + 4 * i;                       // column C0 + r of src = row of dst; c runs along the source rows
+        if (C0 + r < cols && R0 + c < rows) dst[(size_t)(C0 + r) * rows + R0 + c] = tile[c][r];
+    }
+}
+}  // namespace
+
+// src [rows][cols] -> dst [cols][rows]; colsum (may be NULL): [ceil(rows / 64)][cols] partial column sums (sum them with sqd_colsum_multi)
+extern "C" int sqd_transpose2d(const float *src, float *dst, int rows, int cols, float *colsum, void *stream) {
+    SQD_CHECK_ARG(src && dst && src != dst && rows > 0 && cols > 0, "sqd_transpose2d: bad arguments");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(transpose2d_kernel, dim3((cols + 63) / 64, (rows + 63) / 64), dim3(256), 0, (hipStream_t)stream, src, dst, rows, cols, colsum);
+    SQD_CHECK_LAUNCH("sqd_transpose2d");
+    return SQD_OK;
+}

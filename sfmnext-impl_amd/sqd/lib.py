@@ -171,6 +171,7 @@ _SIGNATURES = {
     "sqd_conv_supported": (_I, [_I, _I]),
     "sqd_conv_set_plan": (_I, [_I] * 16),
     "sqd_conv_plan": (_I, [_I] * 12 + [ctypes.POINTER(ctypes.c_int64)]),
+    "sqd_transpose2d": (_I, [_P, _P, _I, _I, _P, _P]),
     "sqd_conv_fwd_stats_rows": (_I, [_I] * 11),
     "sqd_conv_fwd": (_I, [_P, _P, _P, _P, _P, _P] + [_I] * 12 + [_P]),
     "sqd_conv_dgrad_stats_rows": (_I, [_I] * 11),

@@ -211,6 +211,7 @@ TUNE_SPACE = {
     "wgrad_shapes": False,     # smaller register tiles of the direct weight gradient: 7 of 38 layers, nothing on the step
     "wgrad_rows": True,        # impl 4: the row-window weight gradient of the few-channel / high-resolution layers
     "stats_penalty": False,    # (history: split-K forward plans used to force a BatchNorm statistics pass; their sum takes the partials now)
+    "wgrad_transposed": True,  # impl 5: the wide 1x1 layers' weight gradient as a forward GEMM on transposed operands
     "rounds": 1,               # measurements (of 3 launches each) per candidate plan; the fastest counts
     "log": False,
 }
@@ -283,8 +284,9 @@ def _register_conv_plan(mode, geom, plan):
     CHOSEN_PLANS[("dgrad" if mode else "fwd",) + tuple(geom)] = tuple(plan)
 
 
-def _tune_wgrad(geom, has_bias, launch):
-    """Same for the weight gradient: direct-operand vs LDS-tiled kernel, 1/8x .. 4x the model's pixel splits."""
+def _tune_wgrad(geom, has_bias, launch, launch_t=None):
+    """Same for the weight gradient: direct-operand vs LDS-tiled kernel, 1/8x .. 4x the model's pixel splits; launch_t (wide 1x1 layers):
+    the forward GEMM on transposed operands."""
     N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
     key = _wgrad_key(geom)
     if key in _TUNED or torch.cuda.is_current_stream_capturing():
@@ -338,15 +340,57 @@ def _tune_wgrad(geom, has_bias, launch):
         for sp in (256, 384, 512, 768, 1024):
             if not trial(4, sp):
                 break
+    if launch_t is not None and TUNE_SPACE["wgrad_transposed"]:
+        launch_t(None)                                # (times the forward plans of the transposed problem first)
+        t = _time_launch(launch_t, None)
+        if t < best[0]:
+            best = (t, WGRAD_TRANSPOSED, 0)
     _register_wgrad_plan((N, Ho, Wo, C, K, R, S), best[1:])
     if TUNE_SPACE["log"]:
         print("sqd conv plan wgrad", geom, best, "model splits", base, flush=True)
 
 
+WGRAD_TRANSPOSED = 5          # plan impl handled here, not in the library: the wide 1x1 layers' weight gradient as a forward GEMM on
+                              # transposed operands (_wgrad_transposed)
+
+
 def _register_wgrad_plan(wkey, plan):
     _PLAN_CACHE.pop(("w",) + tuple(wkey), None)
-    _l.check(_l.lib().sqd_conv_wgrad_set_plan(*wkey, *plan), "conv_wgrad_set_plan")
+    if plan[0] == WGRAD_TRANSPOSED:
+        _l.lib().sqd_conv_wgrad_set_plan(*wkey, -1, 0)
+    else:
+        _l.check(_l.lib().sqd_conv_wgrad_set_plan(*wkey, *plan), "conv_wgrad_set_plan")
     CHOSEN_PLANS[("wgrad",) + tuple(wkey)] = tuple(plan)
+
+
+def wgrad_transposed_applies(geom):
+    """1x1, stride 1, unpadded, a reduction (pixel count) that the GEMM kernels take as a channel count, filters and channels wide
+    enough that the two transposes are small against the product"""
+    N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
+    M = N * Ho * Wo
+    return R == 1 and S == 1 and stride == 1 and pad == 0 and M % 4 == 0 and M >= 256 and C >= 128 and K >= 128 and C % 4 == 0 and K % 4 == 0
+
+
+def _wgrad_transposed(dy, x, dw, db, geom):
+    """dW [K][C] = sum_m dY[m][k] X[m][c] reduces over the slow axis of both operands — the layout the fp32 weight-gradient kernels are
+    built around and the reason they end at ~95 TFLOP/s.  Transposed (two HBM-rate passes, sqd_transpose2d), it is the FORWARD problem
+    "K pixels x M channels -> C filters": sqd_conv_fwd on its measured plan (three-term bf16 operands at ~175 TFLOP/s effective on the
+    ConvNeXt-L block MLPs).  The bias gradient comes from the column sums the transpose of dY takes on the way."""
+    N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
+    M = N * Ho * Wo
+    L = _l.lib()
+    dyT = torch.empty(K * M, device=dy.device, dtype=torch.float32)
+    xT = torch.empty(C * M, device=dy.device, dtype=torch.float32)
+    cs = torch.empty(((M + 63) // 64, K), device=dy.device, dtype=torch.float32) if db is not None else None
+    _l.check(L.sqd_transpose2d(_ptr(dy), _ptr(dyT), M, K, _ptr(cs), _stream()), "transpose2d")
+    _l.check(L.sqd_transpose2d(_ptr(x), _ptr(xT), M, C, None, _stream()), "transpose2d")
+    gT = (1, 1, K, M, C, 1, 1, 1, 0, 1, K)           # N, H, W, "channels" = M, "filters" = C, 1x1 -> [1, 1, K] pixels x C
+    if TUNE_CONV:
+        _tune_conv(0, gT, lambda ws: L.sqd_conv_fwd(_ptr(dyT), _ptr(xT), None, _ptr(dw), _ptr(ws), None, *gT, 0, _stream()))
+    ws = _conv_ws(0, gT, dy.device)
+    _l.check(L.sqd_conv_fwd(_ptr(dyT), _ptr(xT), None, _ptr(dw), _ptr(ws), None, *gT, 0, _stream()), "conv_fwd (transposed weight gradient)")
+    if db is not None:
+        _colsum_multi([(cs, db, 0)])
 
 
 def export_plans():
@@ -393,7 +437,7 @@ def plan_mix():
     mix = {}
     for k, v in CHOSEN_PLANS.items():
         if k[0] == "wgrad":
-            name = {0: "fp32 lds-tiled", 1: "fp32 direct", 2: "fp32 shared-operand", 3: "bf16x3 shared-operand", 4: "fp32 row-window"}[v[0] & 15]
+            name = {0: "fp32 lds-tiled", 1: "fp32 direct", 2: "fp32 shared-operand", 3: "bf16x3 shared-operand", 4: "fp32 row-window", 5: "bf16x3 transposed-gemm"}[v[0] & 15]
         else:
             bk = v[3]
             name = "bf16x3 input-patch" if bk & 2048 else "bf16x3 implicit-gemm" if bk & 1024 else "fp32 implicit-gemm"
@@ -829,17 +873,25 @@ class Conv2d(torch.autograd.Function):
                 db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
                 _tune_wgrad(ctx.geom, ctx.has_bias,
                             lambda part: L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride,
-                                                          pad, Ho, Wo, _stream()))
+                                                          pad, Ho, Wo, _stream()),
+                            (lambda _: _wgrad_transposed(dy, x, dw, db, ctx.geom)) if wgrad_transposed_applies(ctx.geom) else None)
             dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
             db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
-            pf, splits = _wgrad_part_floats(ctx.geom)
-            extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if ctx.has_bias else 0
-            part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
+            transposed = CHOSEN_PLANS.get(("wgrad", N, Ho, Wo, C, K, R, S), (0,))[0] == WGRAD_TRANSPOSED
+            if transposed:
+                part = None
 
-            def launch(dy=dy, x=x, dw=dw, db=db, part=part):
-                _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
-                                          _stream()), "conv_wgrad")
-            if DEFER_WGRAD_REDUCE and WGRAD_STREAM is None and ctx.wkey is not None and _WEIGHT_USES.get(ctx.wkey, 2) == 1 and \
+                def launch(dy=dy, x=x, dw=dw, db=db, geom=ctx.geom):
+                    _wgrad_transposed(dy, x, dw, db, geom)
+            else:
+                pf, splits = _wgrad_part_floats(ctx.geom)
+                extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if ctx.has_bias else 0
+                part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
+
+                def launch(dy=dy, x=x, dw=dw, db=db, part=part):
+                    _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
+                                              _stream()), "conv_wgrad")
+            if not transposed and DEFER_WGRAD_REDUCE and WGRAD_STREAM is None and ctx.wkey is not None and _WEIGHT_USES.get(ctx.wkey, 2) == 1 and \
                     ctx.bn_src is not None and w.grad is None:
                 # the partial filter gradients now; x is the output of a training-mode BatchNorm, whose backward is the next node of this
                 # stream: its finalize launch carries the sum (the end-of-pass callback is only the safety net).  The tensor is handed to

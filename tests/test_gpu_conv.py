@@ -177,6 +177,45 @@ def test_conv_epilogue_feeds_batchnorm_statistics(N, C, H, W, K, R, stride, pad,
         assert float((xg.grad.cpu().double() - xr.grad).abs().max()) <= 1e-3 * float(xr.grad.abs().max())
 
 
+@pytest.mark.parametrize("M,C,K,bias", [(5120, 768, 3072, True), (1284, 3072, 768, True), (600, 136, 200, False)])
+def test_weight_gradient_as_forward_gemm_on_transposed_operands(M, C, K, bias):
+    """Plan impl 5 (nnkernels._wgrad_transposed): dW = dY^T X through sqd_transpose2d x 2 + sqd_conv_fwd, the bias gradient from the column
+    sums the transpose takes on the way — against float64 and against the direct fp32 kernel (same error level), row counts that are
+    no multiples of the 64 x 64 transpose tiles included."""
+    from sqd import nnkernels
+    torch.manual_seed(M + K)
+    x = torch.randn(M, C, 1, 1)
+    w = torch.randn(K, C, 1, 1) * 0.05
+    b = torch.randn(K) if bias else None
+    g = torch.randn(M, K, 1, 1)
+    xr, wr = x.double(), w.double().requires_grad_(True)
+    br = b.double().requires_grad_(True) if bias else None
+    F.conv2d(xr, wr, br).backward(g.double())
+    geom = (M, 1, 1, C, K, 1, 1, 1, 0, 1, 1)
+    assert nnkernels.wgrad_transposed_applies(geom)
+    got = {}
+    nnkernels.reset_plans()
+    try:
+        direct = 1 if C % 16 == 0 and K % 16 == 0 else 0          # (the direct-operand kernel wants multiples of 16: else the LDS-tiled one)
+        for impl in (nnkernels.WGRAD_TRANSPOSED, 1):
+            nnkernels._register_wgrad_plan((M, 1, 1, C, K, 1, 1), (impl, 0) if impl == nnkernels.WGRAD_TRANSPOSED else (direct, 8))
+            xg = x.cuda().contiguous(memory_format=torch.channels_last)
+            wg = w.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            bg = b.cuda().requires_grad_(True) if bias else None
+            y = nnkernels.Conv2d.apply(xg, wg, bg, 1, 0, None, False, None, None)
+            y.backward(g.cuda())
+            got[impl] = (wg.grad.cpu().double(), bg.grad.cpu().double() if bias else None)
+    finally:
+        nnkernels.reset_plans()
+    for i, (name, ref) in enumerate((("dw", wr.grad), ("db", br.grad if bias else None))):
+        if ref is None:
+            continue
+        scale = float(ref.abs().max())
+        et = float((got[nnkernels.WGRAD_TRANSPOSED][i] - ref).abs().max()) / scale
+        ed = float((got[1][i] - ref).abs().max()) / scale
+        assert et <= 2e-5 and et <= 4.0 * ed + 1e-6, (name, "transposed", et, "direct", ed)
+
+
 @pytest.mark.parametrize("N,C,H,W,K,R,z,bk", [(2, 512, 6, 20, 512, 3, 4, 16), (3, 256, 9, 13, 72, 1, 2, 16), (2, 512, 12, 20, 320, 1, 2, 32 + 1024)])
 def test_split_plan_takes_the_batchnorm_statistics_in_its_sum(N, C, H, W, K, R, z, bk):
     """A forward plan that splits the reduction: the sum over its splits (gemm_reduce_stats_kernel) writes the BatchNorm partials —
