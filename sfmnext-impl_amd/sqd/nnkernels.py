@@ -345,6 +345,11 @@ def _tune_wgrad(geom, has_bias, launch, launch_t=None):
         t = _time_launch(launch_t, None)
         if t < best[0]:
             best = (t, WGRAD_TRANSPOSED, 0)
+        else:                                         # not taken: the transposed problem's forward plan is nobody's plan
+            gT = (1, 1, K, N * Ho * Wo, C, 1, 1, 1, 0, 1, K)
+            if CHOSEN_PLANS.pop(("fwd",) + gT, None) is not None:
+                L.sqd_conv_set_plan(0, *gT, 0, 0, 0, 16)
+                _PLAN_CACHE.pop((0,) + gT, None)
     _register_wgrad_plan((N, Ho, Wo, C, K, R, S), best[1:])
     if TUNE_SPACE["log"]:
         print("sqd conv plan wgrad", geom, best, "model splits", base, flush=True)
@@ -368,7 +373,10 @@ def wgrad_transposed_applies(geom):
     enough that the two transposes are small against the product"""
     N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
     M = N * Ho * Wo
-    return R == 1 and S == 1 and stride == 1 and pad == 0 and M % 4 == 0 and M >= 256 and C >= 128 and K >= 128 and C % 4 == 0 and K % 4 == 0
+    # (measured: taken for the ConvNeXt-L stage 3 / 4 MLPs — 5120 and 1280 rows, 768..6144 features —, never at 20480+ rows, where the
+    #  two transposes outweigh the faster product, nor for ResNet-50's 1x1 layers)
+    return (R == 1 and S == 1 and stride == 1 and pad == 0 and M % 4 == 0 and 256 <= M <= 8192 and min(C, K) >= 256 and C * K >= 512 * 1024
+            and C % 4 == 0 and K % 4 == 0)
 
 
 def _wgrad_transposed(dy, x, dw, db, geom):
