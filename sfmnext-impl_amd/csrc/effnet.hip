@@ -69,20 +69,25 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float *__restrict__ 
 // A thread walks RUNS of four consecutive output columns: per filter row it loads the 3*stride + k input columns the run touches
 // once and uses each for up to k taps (a tap-by-tap gather re-reads every input element k^2 times through L1, which — not the
 // arithmetic — bounds this kernel: 16.7 ms of a 75 ms EfficientNet-b5 step before, profiles/r02b).
-template <int K, int ST>
+// RS (row split, the 5x5 and 7x7 filters): a workgroup takes ONE filter row (blockIdx.z) — K accumulators per thread instead of K^2
+// (the 49 float4 accumulators of a 7x7 filter are 196 registers: one wave per SIMD, 177 us per ConvNeXt-L block where the tensors
+// move in 25); dy is read once per filter row, from L2.  Every tap is still summed over the same runs in the same order: same bits.
+template <int K, int ST, bool RS>
 __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ part,
                                                        DwGeom g, int runs_per_chunk) {
     __shared__ float4 red[16][16];
     constexpr int P = 4, NC = (P - 1) * ST + K;
+    constexpr int KR = RS ? 1 : K;                        // filter rows of this workgroup
+    const int rbase = RS ? (int)blockIdx.z : 0;
     const int cgl = threadIdx.x & 15, pl = threadIdx.x >> 4;          // 16 channel groups (64 channels) x 16 run lanes
     const int cg = blockIdx.y * 16 + cgl;
     const bool con = cg * 4 < g.C;
     const int wruns = (g.Wo + P - 1) / P;
     const size_t nruns = (size_t)g.N * g.Ho * wruns;
     const size_t q0 = (size_t)blockIdx.x * runs_per_chunk, q1 = q0 + runs_per_chunk < nruns ? q0 + runs_per_chunk : nruns;
-    float4 acc[K * K];
+    float4 acc[KR * K];
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < KR * K; ++t) acc[t] = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     if (con)
         for (size_t q = q0 + pl; q < q1; q += 16) {
@@ -94,7 +99,8 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float *__restrict__
                 gv[p] = wo0 + p < g.Wo ? *reinterpret_cast<const float4 *>(dy + (((size_t)n * g.Ho + ho) * g.Wo + wo0 + p) * g.C + cg * 4) : zero;
             const int w0 = wo0 * ST - g.pad_l, h0 = ho * ST - g.pad_t;
 #pragma unroll
-            for (int r = 0; r < K; ++r) {
+            for (int rl = 0; rl < KR; ++rl) {
+                const int r = rbase + rl;
                 const int hi = h0 + r;
                 if ((unsigned)hi >= (unsigned)g.H) continue;
                 const float *xrow = x + ((size_t)n * g.H + hi) * g.W * g.C + cg * 4;
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float *__restrict__
                 }
 #pragma unroll
                 for (int sx = 0; sx < K; ++sx) {
-                    float4 &a = acc[r * K + sx];
+                    float4 &a = acc[rl * K + sx];
 #pragma unroll
                     for (int p = 0; p < P; ++p) {
                         const float4 xq = xv[p * ST + sx];
@@ -118,7 +124,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float *__restrict__
         }
     // fixed-order sum over the 16 run lanes, tap by tap
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) {
+    for (int t = 0; t < KR * K; ++t) {
         red[pl][cgl] = acc[t];
         __syncthreads();
         if (pl == 0 && con) {
@@ -127,7 +133,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_kernel(const float *__restrict__
                 const float4 b = red[q][cgl];
                 a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
             }
-            *reinterpret_cast<float4 *>(part + ((size_t)blockIdx.x * K * K + t) * g.C + cg * 4) = a;
+            *reinterpret_cast<float4 *>(part + ((size_t)blockIdx.x * K * K + rbase * K + t) * g.C + cg * 4) = a;
         }
         __syncthreads();
     }
@@ -363,15 +369,15 @@ extern "C" int sqd_dw_conv_wgrad(const float *dy, const float *x, float *part, i
     const int chunks = sqd_dw_conv_wgrad_chunks(N, Ho, Wo);
     const long long nruns = (long long)N * Ho * ((Wo + 3) / 4);
     const int rpc = (int)((nruns + chunks - 1) / chunks);
-    const dim3 grid(chunks, (C / 4 + 15) / 16);
+    const dim3 grid(chunks, (C / 4 + 15) / 16), grid_rs(chunks, (C / 4 + 15) / 16, k);      // (row split: one filter row per workgroup)
     (void)hipGetLastError();
     hipStream_t st = (hipStream_t)stream;
-    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<3, 1>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
-    else if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, 2>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
-    else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<5, 1>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
-    else if (k == 5) hipLaunchKernelGGL((dw_wgrad_kernel<5, 2>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
-    else if (stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<7, 1>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
-    else hipLaunchKernelGGL((dw_wgrad_kernel<7, 2>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<3, 1, false>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
+    else if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, 2, false>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
+    else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<5, 1, true>), grid_rs, dim3(256), 0, st, dy, x, part, g, rpc);
+    else if (k == 5) hipLaunchKernelGGL((dw_wgrad_kernel<5, 2, true>), grid_rs, dim3(256), 0, st, dy, x, part, g, rpc);
+    else if (stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<7, 1, true>), grid_rs, dim3(256), 0, st, dy, x, part, g, rpc);
+    else hipLaunchKernelGGL((dw_wgrad_kernel<7, 2, true>), grid_rs, dim3(256), 0, st, dy, x, part, g, rpc);
     SQD_CHECK_LAUNCH("sqd_dw_conv_wgrad");
     return SQD_OK;
 }
