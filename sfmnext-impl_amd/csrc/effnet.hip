@@ -436,8 +436,8 @@ extern "C" int sqd_dw_conv_wgrad(const float *dy, const float *x, float *part, i
     const dim3 grid(chunks, (C / 4 + 15) / 16), grid_rs(chunks, (C / 4 + 15) / 16, k);      // (row split: one filter row per workgroup)
     (void)hipGetLastError();
     hipStream_t st = (hipStream_t)stream;
-    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<3, 1, false>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
-    else if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, 2, false>), grid, dim3(256), 0, st, dy, x, part, g, rpc);
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<3, 1, true>), grid_rs, dim3(256), 0, st, dy, x, part, g, rpc);
+    else if (k == 3) hipLaunchKernelGGL((dw_wgrad_kernel<3, 2, true>), grid_rs, dim3(256), 0, st, dy, x, part, g, rpc);
     else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<5, 1, true>), grid_rs, dim3(256), 0, st, dy, x, part, g, rpc);
     else if (k == 5) hipLaunchKernelGGL((dw_wgrad_kernel<5, 2, true>), grid_rs, dim3(256), 0, st, dy, x, part, g, rpc);
     else if (stride == 1) hipLaunchKernelGGL((dw_wgrad_kernel<7, 1, true>), grid_rs, dim3(256), 0, st, dy, x, part, g, rpc);
