@@ -209,6 +209,11 @@ int sqd_bn_nblk(int M, int C);
 int sqd_bn_train_fwd(const float *x, const float *res, const float *gamma, const float *beta, float *running_mean,
                      float *running_var, float *y, unsigned char *mask, float *save_mean, float *save_rstd, float *part,
                      int pre_rows, int M, int C, float eps, float momentum, int act, void *stream);
+/* ... and, for a BatchNorm that feeds a squeeze-and-excite gate (B images of M / B pixels, res == NULL): pool_part
+ * [B][sqd_se_chunks(M / B)][C] = the per-image channel sums of y, bit-identical to sqd_se_pool(y) — the gate need not read y again */
+int sqd_bn_train_fwd_pool(const float *x, const float *res, const float *gamma, const float *beta, float *running_mean,
+                          float *running_var, float *y, unsigned char *mask, float *save_mean, float *save_rstd, float *part,
+                          int pre_rows, int M, int C, float eps, float momentum, int act, float *pool_part, int B, void *stream);
 int sqd_bn_eval_fwd(const float *x, const float *res, const float *gamma, const float *beta, const float *running_mean,
                     const float *running_var, float *y, int M, int C, float eps, int act, void *stream);
 /* dy, x, (y | mask: the activation's derivative; neither is read when act = 0) -> dx, dres (may be NULL), dgamma [C], dbeta [C].

@@ -323,6 +323,51 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
     }
 }
 
+// bn_apply_fwd_kernel for a BatchNorm whose output goes into a squeeze-and-excite gate: the same values, and on the way the per-image
+// channel sums the gate's pooled mean needs (part [B][nchunk][C], the layout, chunking and summation order of se_pool_kernel in
+// effnet.hip: bit-identical to pooling y afterwards) — the gate does not read the activation a second time.
+// grid (nchunk, ceil(C / 64), B): thread (channel group t & 15, pixel lane t >> 4) walks pixels p0 + lane, + 16, ... of its chunk.
+__global__ __launch_bounds__(256) void bn_apply_pool_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma,
+                                                                const float *__restrict__ beta, const float *__restrict__ mean,
+                                                                const float *__restrict__ rstd, float *__restrict__ y,
+                                                                unsigned char *__restrict__ mask, float *__restrict__ part, int HW, int C,
+                                                                int act, int px_per_chunk, int nchunk) {
+    __shared__ float4 red[16][16];
+    const int cgl = threadIdx.x & 15, pl = threadIdx.x >> 4;
+    const int cg = blockIdx.y * 16 + cgl, img = blockIdx.z, chunk = blockIdx.x;
+    const bool con = cg * 4 < C;
+    const int p0 = chunk * px_per_chunk, p1 = min(HW, p0 + px_per_chunk);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (con) {
+        const float4 ga = reinterpret_cast<const float4 *>(gamma)[cg], be = reinterpret_cast<const float4 *>(beta)[cg];
+        const float4 mu = reinterpret_cast<const float4 *>(mean)[cg], rs = reinterpret_cast<const float4 *>(rstd)[cg];
+#pragma unroll 4
+        for (int p = p0 + pl; p < p1; p += 16) {
+            const size_t i4 = (((size_t)img * HW + p) * C) / 4 + cg;
+            const float4 xv = reinterpret_cast<const float4 *>(x)[i4];
+            float4 o;
+            o.x = fmaf((xv.x - mu.x) * rs.x, ga.x, be.x);
+            o.y = fmaf((xv.y - mu.y) * rs.y, ga.y, be.y);
+            o.z = fmaf((xv.z - mu.z) * rs.z, ga.z, be.z);
+            o.w = fmaf((xv.w - mu.w) * rs.w, ga.w, be.w);
+            if (mask) mask[i4] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
+            o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
+            reinterpret_cast<float4 *>(y)[i4] = o;
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+    }
+    red[pl][cgl] = acc;
+    __syncthreads();
+    if (pl == 0 && con) {
+        float4 s = red[0][cgl];
+        for (int q = 1; q < 16; ++q) {
+            const float4 v = red[q][cgl];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4 *>(part + ((size_t)img * nchunk + chunk) * C + cg * 4) = s;
+    }
+}
+
 int check(const char *who, int M, int C) {
     SQD_CHECK_ARG(M > 0 && C >= 4 && C % 4 == 0, "%s: need C %% 4 == 0 (C=%d, M=%d)", who, C, M);
     return SQD_OK;
@@ -341,7 +386,17 @@ extern "C" int sqd_bn_nblk(int M, int C) {
 extern "C" int sqd_bn_train_fwd(const float *x, const float *res, const float *gamma, const float *beta, float *running_mean,
                                 float *running_var, float *y, unsigned char *mask, float *save_mean, float *save_rstd, float *part,
                                 int pre_rows, int M, int C, float eps, float momentum, int act, void *stream) {
+    return sqd_bn_train_fwd_pool(x, res, gamma, beta, running_mean, running_var, y, mask, save_mean, save_rstd, part, pre_rows, M, C, eps, momentum,
+                                 act, nullptr, 0, stream);
+}
+
+// pool_part != NULL (B images of M / B pixels, no residual): the element-wise pass also writes the per-image channel sums of y,
+// pool_part [B][sqd_se_chunks(M / B)][C] — what sqd_se_pool(y) would compute, for sqd_se_gate_fwd
+extern "C" int sqd_bn_train_fwd_pool(const float *x, const float *res, const float *gamma, const float *beta, float *running_mean,
+                                     float *running_var, float *y, unsigned char *mask, float *save_mean, float *save_rstd, float *part,
+                                     int pre_rows, int M, int C, float eps, float momentum, int act, float *pool_part, int B, void *stream) {
     SQD_CHECK_ARG(x && gamma && beta && y && save_mean && save_rstd && part, "sqd_bn_train_fwd: null pointer");
+    SQD_CHECK_ARG(!pool_part || (B > 0 && M % B == 0 && !res), "sqd_bn_train_fwd_pool: B=%d must divide M=%d; no residual", B, M);
     SQD_CHECK_ARG(act != ACT_SWISH || !res, "sqd_bn_train_fwd: swish takes no residual (its backward recomputes the pre-activation from x)");
     if (check("sqd_bn_train_fwd", M, C)) return SQD_EINVAL;
     const Geom g = geom(M, C);
@@ -355,8 +410,14 @@ extern "C" int sqd_bn_train_fwd(const float *x, const float *res, const float *g
     hipLaunchKernelGGL(bn_finalize_fwd_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, part, pre_rows > 0 ? pre_rows : g.nblk, M,
                        C, eps, momentum, save_mean, save_rstd, running_mean, running_var);
     const size_t total4 = (size_t)M * C / 4;
-    hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), dim3(ew_grid(total4)), dim3(256), 0, s, x, res, gamma, beta, save_mean,
-                       save_rstd, y, total4, C, eps, act, mask);
+    if (pool_part) {
+        const int HW = M / B, nchunk = sqd_se_chunks(HW), ppc = (HW + nchunk - 1) / nchunk;
+        hipLaunchKernelGGL(bn_apply_pool_fwd_kernel, dim3(nchunk, (C / 4 + 15) / 16, B), dim3(256), 0, s, x, gamma, beta, save_mean, save_rstd, y, mask,
+                           pool_part, HW, C, act, ppc, nchunk);
+    } else {
+        hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), dim3(ew_grid(total4)), dim3(256), 0, s, x, res, gamma, beta, save_mean,
+                           save_rstd, y, total4, C, eps, act, mask);
+    }
     SQD_CHECK_LAUNCH("sqd_bn_train_fwd");
     return SQD_OK;
 }

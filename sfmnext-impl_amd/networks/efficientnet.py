@@ -51,7 +51,7 @@ class DepthwiseSeparableConv(nn.Module):
         self.bn2 = nn.BatchNorm2d(out_chs, eps=BN_EPS)
 
     def forward(self, x):
-        y = X.dw_conv_bn_act(x, self.conv_dw, self.bn1, "swish", self.stride)
+        y = X.dw_conv_bn_act(x, self.conv_dw, self.bn1, "swish", self.stride, pool=True)      # (pooled sums for the gate on the way)
         y = self.se(y)
         return X.conv_bn_act(y, self.conv_pw, self.bn2, None, residual=x if self.has_residual else None)
 
@@ -80,7 +80,7 @@ class InvertedResidual(nn.Module):
             y, x = X.conv_bn_act(x, self.conv_pw, self.bn1, "swish", skip=True)
         else:
             y = X.conv_bn_act(x, self.conv_pw, self.bn1, "swish")
-        y = X.dw_conv_bn_act(y, self.conv_dw, self.bn2, "swish", self.stride)
+        y = X.dw_conv_bn_act(y, self.conv_dw, self.bn2, "swish", self.stride, pool=True)      # (pooled sums for the gate on the way)
         y = self.se(y)
         return X.conv_bn_act(y, self.conv_pwl, self.bn3, None, residual=x if self.has_residual else None)
 

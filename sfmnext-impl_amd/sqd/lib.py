@@ -147,6 +147,7 @@ _SIGNATURES = {
     "sqd_bn_nblk": (_I, [_I, _I]),
     "sqd_bn_train_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),
     "sqd_bn_eval_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
+    "sqd_bn_train_fwd_pool": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _I, _P]),
     "sqd_bn_train_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
     "sqd_dw_weight_layout": (_I, [_P, _P, _I, _I, _I, _P]),
     "sqd_dw_conv_fwd": (_I, [_P, _P, _P] + [_I] * 10 + [_P]),

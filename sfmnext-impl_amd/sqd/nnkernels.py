@@ -38,7 +38,8 @@ class BatchNormAct(torch.autograd.Function):
     (in place on the BatchNorm2d buffers); eval: running statistics."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, pre_part=None, pre_rows=0, shared=None):
+    def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, pre_part=None, pre_rows=0, shared=None,
+                pool_part=None):
         _require(x, "BatchNormAct input")
         x = _cl(x)
         N, C, H, W = x.shape
@@ -57,9 +58,11 @@ class BatchNormAct(torch.autograd.Function):
             rstd = torch.empty(C, device=x.device, dtype=torch.float32)
             # sign bits of the pre-activation (1 byte per 4 elements): the backward reads them instead of y
             mask = torch.empty(M * C // 4, device=x.device, dtype=torch.uint8) if code in (1, 2) else None    # (swish: recomputed from x)
-            _l.check(L.sqd_bn_train_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
-                                        _ptr(y), _ptr(mask), _ptr(mean), _ptr(rstd), _ptr(part), pre_rows, M, C, float(eps),
-                                        float(momentum), code, _stream()), "bn_train_fwd")
+            # pool_part [B, chunks, C] (batch_norm_act(pool=True)): the element-wise pass also takes the per-image channel sums of y for the
+            # squeeze-and-excite gate that follows
+            _l.check(L.sqd_bn_train_fwd_pool(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+                                             _ptr(y), _ptr(mask), _ptr(mean), _ptr(rstd), _ptr(part), pre_rows, M, C, float(eps),
+                                             float(momentum), code, _ptr(pool_part), N, _stream()), "bn_train_fwd")
             ctx.save_for_backward(x, mask, gamma, mean, rstd, beta if code == 3 else None)
             ctx.has_res, ctx.code = residual is not None, code
             # what the convolution that consumes y needs to deliver this node's backward statistics from its data-gradient epilogue
@@ -101,7 +104,7 @@ class BatchNormAct(torch.autograd.Function):
         _l.check(L.sqd_bn_train_bwd_pre_red(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
                                             _ptr(dgamma), _ptr(dbeta), _ptr(part), pre_rows, M, C, ctx.code, _ptr(rp), _ptr(ro), rn, rs, _stream()),
                  "bn_train_bwd")
-        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
 
 
 class MaxPool3x3s2(torch.autograd.Function):
@@ -642,14 +645,17 @@ class SqueezeExcite(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2):
         _require(x, "SqueezeExcite input")
+        pooled = getattr(x, "_sqd_pool_part", None) if x.is_contiguous(memory_format=torch.channels_last) else None
         x = _cl(x)
         B, C, H, W = x.shape
         R, HW = w1.shape[0], H * W
         L = _l.lib()
         W1, W2 = w1.reshape(R, C).contiguous(), w2.reshape(C, R).t().contiguous()      # W2: [R, C] (transposed: coalesced along C)
         dev = x.device
-        part = torch.empty(B, L.sqd_se_chunks(HW), C, device=dev, dtype=torch.float32)
-        _l.check(L.sqd_se_pool(_ptr(x), None, _ptr(part), B, HW, C, _stream()), "se_pool")
+        part = pooled                                   # the producing BatchNorm's element-wise pass took the sums already
+        if part is None or tuple(part.shape) != (B, L.sqd_se_chunks(HW), C):
+            part = torch.empty(B, L.sqd_se_chunks(HW), C, device=dev, dtype=torch.float32)
+            _l.check(L.sqd_se_pool(_ptr(x), None, _ptr(part), B, HW, C, _stream()), "se_pool")
         s, pre1, gate = (torch.empty(B, n, device=dev, dtype=torch.float32) for n in (C, R, C))
         _l.check(L.sqd_se_gate_fwd(_ptr(part), _ptr(W1), _ptr(b1), _ptr(W2), _ptr(b2), _ptr(s), _ptr(pre1), _ptr(gate), B, HW, C, R, _stream()),
                  "se_gate_fwd")
@@ -1103,9 +1109,10 @@ def flush_bn_counters():
         _PENDING_COUNTERS.clear()
 
 
-def batch_norm_act(x, bn, act, residual=None, pre_part=None, pre_rows=0):
+def batch_norm_act(x, bn, act, residual=None, pre_part=None, pre_rows=0, pool=False):
     """nn.BatchNorm2d module `bn` (parameters, running buffers, momentum, eps) applied through the fused
-    kernels; keeps nn.BatchNorm2d's bookkeeping (num_batches_tracked)."""
+    kernels; keeps nn.BatchNorm2d's bookkeeping (num_batches_tracked).  pool=True (training, no residual): the output carries the
+    per-image channel sums of itself (`_sqd_pool_part`) for the squeeze-and-excite gate that reads it next."""
     training = bn.training or bn.running_mean is None
     if training and bn.num_batches_tracked is not None:
         if _DEFER_COUNTERS:
@@ -1113,11 +1120,17 @@ def batch_norm_act(x, bn, act, residual=None, pre_part=None, pre_rows=0):
         else:
             bn.num_batches_tracked.add_(1)
     shared = {} if training and FUSE_BN_BWD_STATS else None
+    pool_part = None
+    if pool and training and residual is None:
+        B, C, H, W = x.shape
+        pool_part = torch.empty(B, _l.lib().sqd_se_chunks(H * W), C, device=x.device, dtype=torch.float32)
     out = BatchNormAct.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, residual, training,
                              0.1 if bn.momentum is None else bn.momentum, bn.eps, act, pre_part if training else None,
-                             pre_rows if training else 0, shared)
+                             pre_rows if training else 0, shared, pool_part)
     if shared:
         out._sqd_bn_src = shared          # read by the Conv2d node that takes `out` as its input
+    if pool_part is not None:
+        out._sqd_pool_part = pool_part    # read by the SqueezeExcite node that takes `out` as its input
     return out
 
 

@@ -143,12 +143,13 @@ def pose_head(x, conv, scale, split=False):
     return nnkernels.PoseHead.apply(x, conv.weight, conv.bias, scale, split)
 
 
-def dw_conv_bn_act(x, conv, bn, act, stride):
-    """depthwise k x k convolution with TensorFlow "SAME" padding -> BatchNorm2d -> activation (EfficientNet blocks)."""
+def dw_conv_bn_act(x, conv, bn, act, stride, pool=False):
+    """depthwise k x k convolution with TensorFlow "SAME" padding -> BatchNorm2d -> activation (EfficientNet blocks).
+    pool=True: a squeeze-and-excite gate reads the result next — the BatchNorm's element-wise pass takes its pooled sums on the way."""
     _device_only(x, "depthwise convolution")
     from . import nnkernels
     y = nnkernels.DepthwiseConv.apply(x, conv.weight, stride, "same")
-    return nnkernels.batch_norm_act(y, bn, act)
+    return nnkernels.batch_norm_act(y, bn, act, pool=pool)
 
 
 def layer_norm_channels(x, norm, pre_bias=None):
