@@ -13,7 +13,13 @@
 namespace {
 using namespace sqd;
 constexpr int LN_MAXQ = 8;            // float4 per lane: C <= 64 * 4 * 8 = 2048
-constexpr int LN_RPW = 16;            // rows per wave in the backward (partial column sums stay in registers that long)
+constexpr int LN_RPW = 16;            // rows per wave in the backward, at most (partial column sums stay in registers that long)
+// ... fewer where the tensor has few rows: stage 3 of ConvNeXt-L is 27 of the 36 blocks at 5120 rows — 80 workgroups of 64 rows each
+// left two thirds of the chip idle (65 us per call where the bytes move in 10).  Aim at >= 1024 workgroups.
+__host__ __device__ inline int ln_rpw(int M) {
+    int r = M / (4 * 1024);
+    return r < 2 ? 2 : r > LN_RPW ? LN_RPW : r;
+}
 
 // one wave per row; lane holds float4 q = lane + 64 j of the row
 __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float *__restrict__ x, const float *__restrict__ pre_bias,
@@ -76,8 +82,9 @@ __global__ __launch_bounds__(256) void ln_rows_bwd_kernel(const float *__restric
     float4 ag[LN_MAXQ], ab[LN_MAXQ], ax[LN_MAXQ];
 #pragma unroll
     for (int j = 0; j < LN_MAXQ; ++j) ag[j] = ab[j] = ax[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int row0 = (blockIdx.x * 4 + wave) * LN_RPW;
-    for (int r = 0; r < LN_RPW; ++r) {
+    const int rpw = ln_rpw(M);
+    const int row0 = (blockIdx.x * 4 + wave) * rpw;
+    for (int r = 0; r < rpw; ++r) {
         const int row = row0 + r;
         if (row >= M) break;
         const float mean = mean_in[row], rstd = rstd_in[row];
@@ -266,7 +273,7 @@ extern "C" int sqd_ln_rows_fwd(const float *x, const float *pre_bias, const floa
     SQD_CHECK_LAUNCH("sqd_ln_rows_fwd");
     return SQD_OK;
 }
-extern "C" int sqd_ln_rows_nblk(int M) { return (M + 4 * LN_RPW - 1) / (4 * LN_RPW); }
+extern "C" int sqd_ln_rows_nblk(int M) { return (M + 4 * ln_rpw(M) - 1) / (4 * ln_rpw(M)); }
 // dy, x [M,C] -> dx [M,C]; part [sqd_ln_rows_nblk(M)][3][C]: per-block column sums of dy*xhat, dy, dx (sum them over the blocks:
 // dgamma, dbeta, gradient of pre_bias)
 extern "C" int sqd_ln_rows_bwd(const float *dy, const float *x, const float *pre_bias, const float *gamma, const float *mean,
@@ -306,13 +313,19 @@ extern "C" int sqd_scale_residual_fwd(const float *res, const float *z, const fl
     SQD_CHECK_LAUNCH("sqd_scale_residual_fwd");
     return SQD_OK;
 }
-extern "C" int sqd_scale_residual_nblk(int M) { return (M + 63) / 64; }
+// rows per workgroup of the backward: 64, fewer for tensors of few rows (>= 1024 workgroups where the rows allow, at least 8 rows each)
+static int scale_residual_rows(int M) {
+    int r = M / 1024;
+    r = (r + 3) & ~3;
+    return r < 8 ? 8 : r > 64 ? 64 : r;
+}
+extern "C" int sqd_scale_residual_nblk(int M) { return (M + scale_residual_rows(M) - 1) / scale_residual_rows(M); }
 // dy, z [M,C] -> dz = gamma * dy; part [sqd_scale_residual_nblk(M)][C] per-block column sums of dy * z (sum over the blocks: dgamma)
 extern "C" int sqd_scale_residual_bwd(const float *dy, const float *z, const float *gamma, float *dz, float *part, int M, int C, void *stream) {
     SQD_CHECK_ARG(dy && z && gamma && dz && part && M > 0 && C >= 4 && C % 4 == 0, "sqd_scale_residual_bwd: bad arguments");
     (void)hipGetLastError();
     hipLaunchKernelGGL((scale_residual_kernel<1>), dim3(sqd_scale_residual_nblk(M)), dim3(256), (size_t)4 * C * sizeof(float),
-                       (hipStream_t)stream, dy, z, gamma, dz, part, M, C, 64);
+                       (hipStream_t)stream, dy, z, gamma, dz, part, M, C, scale_residual_rows(M));
     SQD_CHECK_LAUNCH("sqd_scale_residual_bwd");
     return SQD_OK;
 }

@@ -127,27 +127,33 @@ struct ColsumSegs {
     int nrows[CS_MAXSEG], ncols[CS_MAXSEG], tr[CS_MAXSEG], blk0[CS_MAXSEG + 1];
     int nseg;
 };
+// CW float4 columns x 256 / CW row groups per workgroup: 32 x 8 for the few partial rows the token-wise blocks produce, 8 x 32 when
+// a segment has hundreds of rows (the ConvNeXt LayerNorm backward at 640 partial rows: 18 workgroups of 80 sequential loads per thread
+// took 15 us; 72 workgroups of 20 take 8)
+template <int CW>
 __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumSegs S) {
-    __shared__ float4 red[8][32];
+    constexpr int RG = 256 / CW;
+    __shared__ float4 red[RG][CW];
     int s = 0;
     while (s + 1 < S.nseg && (int)blockIdx.x >= S.blk0[s + 1]) ++s;
-    const int c4 = ((int)blockIdx.x - S.blk0[s]) * 32 + (threadIdx.x & 31), rg = threadIdx.x >> 5;
+    const int cl = threadIdx.x % CW, rg = threadIdx.x / CW;
+    const int c4 = ((int)blockIdx.x - S.blk0[s]) * CW + cl;
     const int ncols = S.ncols[s], nrows = S.nrows[s];
     const bool on = c4 * 4 < ncols;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
     if (on) {
         const float *p = S.src[s] + (size_t)c4 * 4;
-        for (int r = rg; r < nrows; r += 8) {
+        for (int r = rg; r < nrows; r += RG) {
             const float4 v = *reinterpret_cast<const float4 *>(p + (size_t)r * ncols);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
     }
-    red[rg][threadIdx.x & 31] = a;
+    red[rg][cl] = a;
     __syncthreads();
     if (rg == 0 && on) {
 #pragma unroll
-        for (int k = 1; k < 8; ++k) {
-            const float4 v = red[k][threadIdx.x];
+        for (int k = 1; k < RG; ++k) {
+            const float4 v = red[k][cl];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
         float *d = S.dst[s];
@@ -458,19 +464,22 @@ extern "C" int sqd_colsum_multi(const float *const *src, float *const *dst, cons
                                 void *stream) {
     SQD_CHECK_ARG(src && dst && nrows && ncols && tr && nseg >= 1 && nseg <= CS_MAXSEG, "sqd_colsum_multi: bad arguments (nseg=%d)", nseg);
     ColsumSegs S;
-    int blk = 0;
+    int blk = 0, max_rows = 0;
+    for (int s = 0; s < nseg; ++s) max_rows = nrows[s] > max_rows ? nrows[s] : max_rows;
+    const int CW = max_rows >= 256 ? 8 : 32;
     for (int s = 0; s < nseg; ++s) {
         SQD_CHECK_ARG(src[s] && dst[s] && nrows[s] >= 1 && ncols[s] >= 4 && ncols[s] % 4 == 0 && tr[s] >= 0 &&
                           (tr[s] == 0 || ncols[s] % tr[s] == 0),
                       "sqd_colsum_multi: segment %d: nrows=%d ncols=%d tr=%d", s, nrows[s], ncols[s], tr[s]);
         S.src[s] = src[s]; S.dst[s] = dst[s]; S.nrows[s] = nrows[s]; S.ncols[s] = ncols[s]; S.tr[s] = tr[s];
         S.blk0[s] = blk;
-        blk += (ncols[s] / 4 + 31) / 32;
+        blk += (ncols[s] / 4 + CW - 1) / CW;
     }
     S.blk0[nseg] = blk;
     S.nseg = nseg;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(colsum_multi_kernel, dim3(blk), dim3(256), 0, (hipStream_t)stream, S);
+    if (CW == 8) hipLaunchKernelGGL(colsum_multi_kernel<8>, dim3(blk), dim3(256), 0, (hipStream_t)stream, S);
+    else hipLaunchKernelGGL(colsum_multi_kernel<32>, dim3(blk), dim3(256), 0, (hipStream_t)stream, S);
     SQD_CHECK_LAUNCH("sqd_colsum_multi");
     return SQD_OK;
 }
