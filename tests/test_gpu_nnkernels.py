@@ -264,6 +264,31 @@ def test_depthwise_conv(N, C, H, W, k, stride, pad):
         assert float((a - b).abs().max()) <= 2e-5 * float(b.abs().max()) + 1e-7, (what, float((a - b).abs().max()), float(b.abs().max()))
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 144, 40, 64), (3, 40, 7, 9), (1, 1056, 33, 35)])
+def test_batchnorm_takes_the_gate_pool_on_the_way(B, C, H, W):
+    """batch_norm_act(pool=True) (sqd_bn_train_fwd_pool): the same output as the plain element-wise pass, and the per-image channel sums
+    it attaches are bit-identical to sqd_se_pool of that output — the squeeze-and-excite node then skips its own pooling pass."""
+    import ctypes
+    from sqd import lib, nnkernels
+    L = lib.lib()
+    torch.manual_seed(C)
+    x = torch.randn(B, C, H, W).cuda().contiguous(memory_format=torch.channels_last)
+    bn_a, bn_b = nn.BatchNorm2d(C).cuda(), nn.BatchNorm2d(C).cuda()
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5)
+        bn_a.bias.uniform_(-0.5, 0.5)
+    bn_b.load_state_dict(bn_a.state_dict())
+    y_plain = nnkernels.batch_norm_act(x, bn_a, "swish")
+    y_pool = nnkernels.batch_norm_act(x, bn_b, "swish", pool=True)
+    assert torch.equal(y_plain, y_pool) and torch.equal(bn_a.running_var, bn_b.running_var)
+    part = y_pool._sqd_pool_part
+    want = torch.empty_like(part)
+    lib.check(L.sqd_se_pool(ctypes.c_void_p(y_plain.data_ptr()), None, ctypes.c_void_p(want.data_ptr()), B, H * W, C,
+                            ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)), "se_pool")
+    assert part.shape == (B, L.sqd_se_chunks(H * W), C) and torch.equal(part, want)
+    assert getattr(y_plain, "_sqd_pool_part", None) is None
+
+
 @pytest.mark.parametrize("B,C,H,W,R", [(2, 144, 12, 20, 6), (3, 48, 7, 9, 12), (1, 1056, 5, 8, 44), (2, 3072, 3, 4, 128), (2, 240, 40, 64, 10)])
 def test_squeeze_excite(B, C, H, W, R):
     from sqd import nnkernels
