@@ -450,6 +450,9 @@ int sqd_dw_conv_fwd(const float *x, const float *w_taps, float *y, int N, int H,
                     int Ho, int Wo, void *stream);
 int sqd_dw_conv_dgrad(const float *dy, const float *w_taps, float *dx, int N, int H, int W, int C, int k, int stride, int pad_t,
                       int pad_l, int Ho, int Wo, void *stream);
+/* ... + addend [N,H,W,C] (NULL: none; stride 1): the gradient arriving over the input's other path (a block's shortcut) added in the kernel */
+int sqd_dw_conv_dgrad_add(const float *dy, const float *w_taps, const float *addend, float *dx, int N, int H, int W, int C, int k, int stride,
+                          int pad_t, int pad_l, int Ho, int Wo, void *stream);
 int sqd_dw_conv_wgrad_chunks(int N, int Ho, int Wo);
 int sqd_dw_conv_wgrad(const float *dy, const float *x, float *part, int N, int H, int W, int C, int k, int stride, int pad_t, int pad_l,
                       int Ho, int Wo, void *stream);

@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void dw_conv_kernel(const float *__restrict__ 
 // of the k^2 additions of an output is that of the one-pixel kernel in both modes: the same bits.
 template <int K, int ST, bool DGRAD>
 __global__ __launch_bounds__(256) void dw_conv_run_kernel(const float *__restrict__ in, const float *__restrict__ w, float *__restrict__ out,
-                                                          DwGeom g) {
+                                                          DwGeom g, const float *__restrict__ addend = nullptr) {
     constexpr int P = 4, NC = (P - 1) * ST + K;
     const int V = g.C / 4;
     const int OH = DGRAD ? g.H : g.Ho, OW = DGRAD ? g.W : g.Wo, IH = DGRAD ? g.Ho : g.H, IW = DGRAD ? g.Wo : g.W;
@@ -112,7 +112,14 @@ __global__ __launch_bounds__(256) void dw_conv_run_kernel(const float *__restric
         }
 #pragma unroll
         for (int p = 0; p < P; ++p)
-            if (ow0 + p < OW) *reinterpret_cast<float4 *>(out + (((size_t)n * OH + oh) * OW + ow0 + p) * g.C + cg * 4) = acc[p];
+            if (ow0 + p < OW) {
+                const size_t o = (((size_t)n * OH + oh) * OW + ow0 + p) * g.C + cg * 4;
+                if (DGRAD && addend) {          // the gradient that reaches the input over its other path (the block's shortcut)
+                    const float4 u = *reinterpret_cast<const float4 *>(addend + o);
+                    acc[p].x += u.x; acc[p].y += u.y; acc[p].z += u.z; acc[p].w += u.w;
+                }
+                *reinterpret_cast<float4 *>(out + o) = acc[p];
+            }
     }
 }
 
@@ -392,27 +399,35 @@ extern "C" int sqd_dw_conv_fwd(const float *x, const float *w_taps, float *y, in
     (void)hipGetLastError();
     const dim3 grid(ew_blocks((size_t)N * Ho * ((Wo + 3) / 4) * C / 4));
     hipStream_t st = (hipStream_t)stream;
-    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_conv_run_kernel<3, 1, false>), grid, dim3(256), 0, st, x, w_taps, y, g);
-    else if (k == 3) hipLaunchKernelGGL((dw_conv_run_kernel<3, 2, false>), grid, dim3(256), 0, st, x, w_taps, y, g);
-    else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_conv_run_kernel<5, 1, false>), grid, dim3(256), 0, st, x, w_taps, y, g);
-    else if (k == 5) hipLaunchKernelGGL((dw_conv_run_kernel<5, 2, false>), grid, dim3(256), 0, st, x, w_taps, y, g);
-    else if (stride == 1) hipLaunchKernelGGL((dw_conv_run_kernel<7, 1, false>), grid, dim3(256), 0, st, x, w_taps, y, g);
-    else hipLaunchKernelGGL((dw_conv_run_kernel<7, 2, false>), grid, dim3(256), 0, st, x, w_taps, y, g);
+    if (k == 3 && stride == 1) hipLaunchKernelGGL((dw_conv_run_kernel<3, 1, false>), grid, dim3(256), 0, st, x, w_taps, y, g, (const float *)nullptr);
+    else if (k == 3) hipLaunchKernelGGL((dw_conv_run_kernel<3, 2, false>), grid, dim3(256), 0, st, x, w_taps, y, g, (const float *)nullptr);
+    else if (k == 5 && stride == 1) hipLaunchKernelGGL((dw_conv_run_kernel<5, 1, false>), grid, dim3(256), 0, st, x, w_taps, y, g, (const float *)nullptr);
+    else if (k == 5) hipLaunchKernelGGL((dw_conv_run_kernel<5, 2, false>), grid, dim3(256), 0, st, x, w_taps, y, g, (const float *)nullptr);
+    else if (stride == 1) hipLaunchKernelGGL((dw_conv_run_kernel<7, 1, false>), grid, dim3(256), 0, st, x, w_taps, y, g, (const float *)nullptr);
+    else hipLaunchKernelGGL((dw_conv_run_kernel<7, 2, false>), grid, dim3(256), 0, st, x, w_taps, y, g, (const float *)nullptr);
     SQD_CHECK_LAUNCH("sqd_dw_conv_fwd");
     return SQD_OK;
 }
 
 extern "C" int sqd_dw_conv_dgrad(const float *dy, const float *w_taps, float *dx, int N, int H, int W, int C, int k, int stride, int pad_t,
                                  int pad_l, int Ho, int Wo, void *stream) {
+    return sqd_dw_conv_dgrad_add(dy, w_taps, nullptr, dx, N, H, W, C, k, stride, pad_t, pad_l, Ho, Wo, stream);
+}
+
+// dx = data gradient + addend [N,H,W,C] (NULL: none; stride 1 only): the gradient arriving over the input's second path — a block's
+// shortcut — is added here instead of by a separate accumulation pass
+extern "C" int sqd_dw_conv_dgrad_add(const float *dy, const float *w_taps, const float *addend, float *dx, int N, int H, int W, int C, int k,
+                                     int stride, int pad_t, int pad_l, int Ho, int Wo, void *stream) {
     SQD_CHECK_ARG(dy && w_taps && dx, "sqd_dw_conv_dgrad: null pointer");
+    SQD_CHECK_ARG(!addend || (stride == 1 && addend != dx), "sqd_dw_conv_dgrad_add: the addend needs stride 1 and must not alias dx");
     const DwGeom g = {N, H, W, C, k, stride, pad_t, pad_l, Ho, Wo};
     if (dw_check("sqd_dw_conv_dgrad", g)) return SQD_EINVAL;
     (void)hipGetLastError();
     hipStream_t st = (hipStream_t)stream;
     const dim3 grid(ew_blocks((size_t)N * H * ((W + 3) / 4) * C / 4));
-    if (stride == 1 && k == 3) hipLaunchKernelGGL((dw_conv_run_kernel<3, 1, true>), grid, dim3(256), 0, st, dy, w_taps, dx, g);
-    else if (stride == 1 && k == 5) hipLaunchKernelGGL((dw_conv_run_kernel<5, 1, true>), grid, dim3(256), 0, st, dy, w_taps, dx, g);
-    else if (stride == 1) hipLaunchKernelGGL((dw_conv_run_kernel<7, 1, true>), grid, dim3(256), 0, st, dy, w_taps, dx, g);
+    if (stride == 1 && k == 3) hipLaunchKernelGGL((dw_conv_run_kernel<3, 1, true>), grid, dim3(256), 0, st, dy, w_taps, dx, g, addend);
+    else if (stride == 1 && k == 5) hipLaunchKernelGGL((dw_conv_run_kernel<5, 1, true>), grid, dim3(256), 0, st, dy, w_taps, dx, g, addend);
+    else if (stride == 1) hipLaunchKernelGGL((dw_conv_run_kernel<7, 1, true>), grid, dim3(256), 0, st, dy, w_taps, dx, g, addend);
     else     // stride 2: the taps of an input pixel depend on its stride phase — the one-pixel gather
         hipLaunchKernelGGL((dw_conv_kernel<1>), dim3(ew_blocks((size_t)N * H * W * C / 4)), dim3(256), 0, st, dy, w_taps, dx, g);
     SQD_CHECK_LAUNCH("sqd_dw_conv_dgrad");

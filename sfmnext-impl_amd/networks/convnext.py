@@ -29,7 +29,9 @@ class ConvNeXtBlock(nn.Module):
         self.gamma = nn.Parameter(ls_init_value * torch.ones(dim))
 
     def forward(self, x):
-        z = X.dw_conv(x, self.conv_dw)                                           # (its bias is added inside the LayerNorm kernel)
+        # x has two consumers (the depthwise convolution and the shortcut): the convolution hands it through, the shortcut's gradient is
+        # added inside the depthwise data-gradient kernel instead of by an accumulation pass over [N,C,H,W]
+        z, x = X.dw_conv(x, self.conv_dw, skip=True)                             # (its bias is added inside the LayerNorm kernel)
         z = X.layer_norm_channels(z, self.norm, pre_bias=self.conv_dw.bias)
         z = X.gelu(X.linear_channels(z, self.mlp.fc1))
         z = X.linear_channels(z, self.mlp.fc2)

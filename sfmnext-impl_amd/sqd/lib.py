@@ -152,6 +152,7 @@ _SIGNATURES = {
     "sqd_dw_weight_layout": (_I, [_P, _P, _I, _I, _I, _P]),
     "sqd_dw_conv_fwd": (_I, [_P, _P, _P] + [_I] * 10 + [_P]),
     "sqd_dw_conv_dgrad": (_I, [_P, _P, _P] + [_I] * 10 + [_P]),
+    "sqd_dw_conv_dgrad_add": (_I, [_P, _P, _P, _P] + [_I] * 10 + [_P]),
     "sqd_dw_conv_wgrad_chunks": (_I, [_I, _I, _I]),
     "sqd_dw_conv_wgrad": (_I, [_P, _P, _P] + [_I] * 10 + [_P]),
     "sqd_se_chunks": (_I, [_I]),

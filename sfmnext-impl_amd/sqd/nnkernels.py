@@ -488,10 +488,13 @@ def tf_same_pad(size, k, stride):
 
 class DepthwiseConv(torch.autograd.Function):
     """Depthwise k x k convolution (groups == channels), k in {3, 5, 7}, stride in {1, 2}, channels-last.
-    forward(x [N,C,H,W], weight [C,1,k,k], stride, pad) — pad: an int (symmetric) or "same" (TensorFlow SAME, asymmetric)."""
+    forward(x [N,C,H,W], weight [C,1,k,k], stride, pad) — pad: an int (symmetric) or "same" (TensorFlow SAME, asymmetric).
+    skip=True (stride 1): -> (y, x') with x' the input handed through this node: the input's other consumer (a block's shortcut) reads
+    x' instead, and its gradient is added inside the data-gradient kernel instead of by a separate accumulation pass."""
 
     @staticmethod
-    def forward(ctx, x, weight, stride, pad):
+    def forward(ctx, x, weight, stride, pad, skip=False):
+        ctx.set_materialize_grads(False)
         _require(x, "DepthwiseConv input")
         x = _cl(x)
         N, C, H, W = x.shape
@@ -508,18 +511,27 @@ class DepthwiseConv(torch.autograd.Function):
         _l.check(L.sqd_dw_conv_fwd(_ptr(x), _ptr(wt), _ptr(y), N, H, W, C, k, stride, pt, pl, Ho, Wo, _stream()), "dw_conv_fwd")
         ctx.save_for_backward(x, wt)
         ctx.geom = (N, H, W, C, k, stride, pt, pl, Ho, Wo)
+        if skip:
+            assert stride == 1, "DepthwiseConv: the hand-over needs stride 1"
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, g_skip=None):
         x, wt = ctx.saved_tensors
         N, H, W, C, k, stride, pt, pl, Ho, Wo = ctx.geom
+        if dy is None:                                   # only the pass-through output was used
+            return g_skip, None, None, None, None
         dy = _cl(dy)
+        g_skip = _cl(g_skip) if g_skip is not None else None
         L = _l.lib()
         dx = dw = None
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
-            _l.check(L.sqd_dw_conv_dgrad(_ptr(dy), _ptr(wt), _ptr(dx), N, H, W, C, k, stride, pt, pl, Ho, Wo, _stream()), "dw_conv_dgrad")
+            _l.check(L.sqd_dw_conv_dgrad_add(_ptr(dy), _ptr(wt), _ptr(g_skip), _ptr(dx), N, H, W, C, k, stride, pt, pl, Ho, Wo, _stream()),
+                     "dw_conv_dgrad")
+        elif g_skip is not None:
+            dx = g_skip
         if ctx.needs_input_grad[1]:
             chunks = L.sqd_dw_conv_wgrad_chunks(N, Ho, Wo)
             part = torch.empty(chunks, k * k * C, device=dy.device, dtype=torch.float32)
@@ -528,7 +540,7 @@ class DepthwiseConv(torch.autograd.Function):
             _colsum_multi([(part, dwt, 0)])
             dw = torch.empty(C, 1, k, k, device=dy.device, dtype=torch.float32)
             _l.check(L.sqd_dw_weight_layout(_ptr(dwt), _ptr(dw), C, k, 0, _stream()), "dw_weight_layout")
-        return dx, dw, None, None
+        return dx, dw, None, None, None
 
 
 class LayerNormRows(torch.autograd.Function):

@@ -188,11 +188,13 @@ def linear_channels(x, lin, act=None):
     return nnkernels.Conv2d.apply(x, lin.weight.view(K, C, 1, 1), lin.bias, 1, 0, act, False, None, None)
 
 
-def dw_conv(x, conv):
-    """depthwise convolution with symmetric padding, WITHOUT its bias (the caller folds conv.bias into the LayerNorm that follows)"""
+def dw_conv(x, conv, skip=False):
+    """depthwise convolution with symmetric padding, WITHOUT its bias (the caller folds conv.bias into the LayerNorm that follows).
+    skip=True (stride 1): -> (y, x') where x' must replace x for x's other consumer (the block's shortcut): that consumer's gradient is
+    then added inside the depthwise data-gradient kernel instead of by a separate accumulation pass over [N,C,H,W]."""
     _device_only(x, "depthwise convolution")
     from . import nnkernels
-    return nnkernels.DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0])
+    return nnkernels.DepthwiseConv.apply(x, conv.weight, conv.stride[0], conv.padding[0], skip)
 
 
 def patchify_conv(x, conv, s):

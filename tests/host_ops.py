@@ -95,8 +95,9 @@ def upsample2x(x):
     return F.interpolate(x, scale_factor=2.0, mode="bilinear")
 
 
-def dw_conv(x, conv):
-    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, 1, conv.groups)
+def dw_conv(x, conv, skip=False):
+    y = F.conv2d(x, conv.weight, None, conv.stride, conv.padding, 1, conv.groups)
+    return (y, x) if skip else y
 
 
 def linear_channels(x, lin, act=None):
