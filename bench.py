@@ -163,7 +163,7 @@ def roofline_depthwise(trainer):
     L, st_ = _l.lib(), torch.cuda.current_stream().cuda_stream
     t = _time_calls(lambda: _l.check(L.sqd_dw_conv_fwd(x.data_ptr(), wt.data_ptr(), y.data_ptr(), N, H, W, C, k, st, pt, pl, Ho, Wo, st_), "dw_conv_fwd"))
     nbytes = 4 * elems
-    return {"bound": "hbm", "kernel": "dw_conv_kernel (depthwise %dx%d / stride %d forward, [%d,%d,%d,%d] -> %dx%d: the trunk's largest)" % (k, k, st, N, C, H, W, Ho, Wo),
+    return {"bound": "hbm", "kernel": "dw_conv_run_kernel (depthwise %dx%d / stride %d forward, [%d,%d,%d,%d] -> %dx%d: the trunk's largest)" % (k, k, st, N, C, H, W, Ho, Wo),
             "achieved": round(nbytes / t / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(nbytes / t / 1e9 / HBM_PEAK_GBS, 4),
             "traffic": None, "traffic_source": "no PMC record for this kernel", "us_per_launch": round(t * 1e6, 2),
             "algorithmic_bytes_per_launch": nbytes, "note": "8 B per element: one read of the input, one write of the output; filters are %d floats" % (k * k * C)}
