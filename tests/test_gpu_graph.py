@@ -73,6 +73,16 @@ def test_graph_replay_matches_eager():
     assert abs(float(hyper[0]) - lr / (1 - 0.9 ** 7)) <= 1e-6 * lr and abs(float(hyper[1]) - (1 - 0.999 ** 7) ** -0.5) <= 1e-4
 
 
+def test_identity_maps_late_or_early_in_the_captured_step():
+    """The captured step evaluates the identity-reprojection maps right before the fused warp + SSIM kernel (default) or at the start of
+    the step (--sqd_early_identity): the same kernels on the same inputs in another order — the same losses and parameters, bit for bit."""
+    tr_l, loss_l, par_l = run([])
+    tr_e, loss_e, par_e = run(["--sqd_early_identity"])
+    assert tr_l._graph is not None and tr_e._graph is not None
+    assert loss_l == loss_e, (loss_l, loss_e)
+    assert _drift(par_l, par_e)[1] == 0.0, _drift(par_l, par_e)
+
+
 def test_graph_replay_trains_every_parameter():
     """Every parameter that receives a gradient must keep moving under graph replay — a tensor derived from a parameter
     outside the captured region (a cached regrouped stem filter, say) would freeze that parameter's effect on the loss."""
