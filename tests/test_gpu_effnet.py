@@ -70,17 +70,22 @@ def test_base_encoder_matches_oracle(H, W, B):
     assert _rel(rm, rr) < 1e-4
 
 
-def test_effb5_train_step_matches_oracle():
-    """one optimisation step of the Trainer with --backbone eff_b5 (EfficientNet-b5 + Depth_Decoder_QueryTr) against the oracle"""
+@pytest.mark.parametrize("H,W,B,nf,patch,Q,dout,tune", [(64, 128, 2, 256, 8, 16, 32, False), (320, 1024, 1, 512, 20, 128, 128, True)])
+def test_effb5_train_step_matches_oracle(H, W, B, nf, patch, Q, dout, tune):
+    """one optimisation step of the Trainer with --backbone eff_b5 (EfficientNet-b5 + Depth_Decoder_QueryTr) against the oracle: a small
+    shape under the default plans, and configs[3]'s workload shape (320x1024, the parser's head: num_features 512, patch 20, 128 queries,
+    dim_out 128; batch 1 keeps the oracle's CPU step short; fp32 operands — the bf16 mode is tracked against fp32 below) with the plans
+    measured in the step, as the benchmark runs"""
     sys.path.insert(0, REPO)
     from oracle import torch_ref as O
     from options import MonodepthOptions
     from trainer import Trainer
     from datasets.synthetic import synthetic_batch
-    H, W, B = 64, 128, 2
-    args = ["--backbone", "eff_b5", "--num_features", "256", "--model_dim", "32", "--patch_size", "8", "--query_nums", "16", "--dim_out", "32",
-            "--height", str(H), "--width", str(W), "--batch_size", str(B), "--num_workers", "0", "--sqd_synthetic",
-            "--log_dir", "/tmp/sqd_effb5_test", "--max_depth", "80.0", "--sqd_no_conv_tune", "--sqd_no_graph"]
+    from sqd import nnkernels
+    nnkernels.reset_plans()
+    args = ["--backbone", "eff_b5", "--num_features", str(nf), "--model_dim", "32", "--patch_size", str(patch), "--query_nums", str(Q),
+            "--dim_out", str(dout), "--height", str(H), "--width", str(W), "--batch_size", str(B), "--num_workers", "0", "--sqd_synthetic",
+            "--log_dir", "/tmp/sqd_effb5_test", "--max_depth", "80.0", "--sqd_no_graph"] + ([] if tune else ["--sqd_no_conv_tune"])
     torch.manual_seed(0)
     tr = Trainer(MonodepthOptions().parse(args))
     tr.set_train()
@@ -90,8 +95,8 @@ def test_effb5_train_step_matches_oracle():
                 mod.p = 0.0
             if isinstance(mod, torch.nn.MultiheadAttention):
                 mod.dropout = 0.0
-    enc = O.BaseEncoder(model_dim=32, num_features=256)
-    dep = O.QueryTrDecoder(32, 32, 8, 4, 16, 32, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
+    enc = O.BaseEncoder(model_dim=32, num_features=nf)
+    dep = O.QueryTrDecoder(32, 32, patch, 4, Q, dout, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
     pose = O.PoseCNN(2)
     for ref, mine in ((enc, tr.models["encoder"]), (dep, tr.models["depth"]), (pose, tr.models["pose"])):
         ref.load_state_dict({k: v.detach().cpu() for k, v in mine.state_dict().items()})
@@ -102,8 +107,13 @@ def test_effb5_train_step_matches_oracle():
     ref_out, ref_losses = ref.step(dict(cpu_inputs), noise)
     inputs = {k: v.cuda() for k, v in cpu_inputs.items()}
     inputs[("noise", 0)] = noise.cuda()
-    outputs, losses = tr.train_step(inputs)
+    try:
+        outputs, losses = tr.train_step(inputs)
+        torch.cuda.synchronize()
+    finally:
+        nnkernels.reset_plans()
     got, want = float(losses["loss"]), float(ref_losses["loss"])
+    print("eff_b5 %dx%d: loss %.7f oracle %.7f (rel %.2e)" % (H, W, got, want, abs(got - want) / abs(want)))
     assert abs(got - want) <= 2e-4 * abs(want), (got, want)
     d, dr = outputs[("disp", 0)].detach().cpu(), ref_out[("disp", 0)].detach()
     assert float((d - dr).abs().max()) <= 5e-4 * float(dr.abs().max())
