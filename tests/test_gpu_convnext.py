@@ -181,17 +181,21 @@ def test_unet_matches_oracle():
             close(grads[n].grad, p.grad, 2e-3, n)
 
 
-def test_convnext_large_train_step_matches_oracle():
+@pytest.mark.parametrize("H,W,B,patch,Q,dout,tune", [(64, 128, 2, 8, 16, 32, False), (320, 1024, 1, 32, 64, 64, True)])
+def test_convnext_large_train_step_matches_oracle(H, W, B, patch, Q, dout, tune):
     """one optimisation step of the Trainer with --backbone convnext_large (the full ConvNeXt-L U-Net, 238 M encoder parameters,
-    + Depth_Decoder_QueryTr + PoseCNN; BASELINE.json configs[4]'s trunk) against the oracle, at a small image size"""
+    + Depth_Decoder_QueryTr + PoseCNN; BASELINE.json configs[4]'s trunk) against the oracle: at a small image size under the default
+    plans, and at the workload shape (320x1024, patch 32, 64 queries, dim_out 64 as bench.py runs it; batch 1 for the oracle's CPU step) with the plans
+    measured in the step — the benchmarked arithmetic, the transposed-GEMM weight gradient of the stage 3 / 4 MLPs included"""
     from oracle import torch_ref as O
     from options import MonodepthOptions
     from trainer import Trainer
     from datasets.synthetic import synthetic_batch
-    H, W, B = 64, 128, 2
-    args = ["--backbone", "convnext_large", "--model_dim", "32", "--patch_size", "8", "--query_nums", "16", "--dim_out", "32",
+    from sqd import nnkernels
+    nnkernels.reset_plans()
+    args = ["--backbone", "convnext_large", "--model_dim", "32", "--patch_size", str(patch), "--query_nums", str(Q), "--dim_out", str(dout),
             "--height", str(H), "--width", str(W), "--batch_size", str(B), "--num_workers", "0", "--sqd_synthetic",
-            "--log_dir", "/tmp/sqd_convnext_test", "--max_depth", "80.0", "--sqd_no_conv_tune", "--sqd_no_graph"]
+            "--log_dir", "/tmp/sqd_convnext_test", "--max_depth", "80.0", "--sqd_no_graph"] + ([] if tune else ["--sqd_no_conv_tune"])
     torch.manual_seed(0)
     tr = Trainer(MonodepthOptions().parse(args))
     tr.set_train()
@@ -205,18 +209,26 @@ def test_convnext_large_train_step_matches_oracle():
         if n.endswith("gamma"):
             p.data.fill_(0.3)                     # (at the 1e-6 initial layer scale the blocks would not show in the loss)
     enc = O.Unet(3, 32, (1024, 512, 256, 128))
-    dep = O.QueryTrDecoder(32, 32, 8, 4, 16, 32, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
+    dep = O.QueryTrDecoder(32, 32, patch, 4, Q, dout, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
     pose = O.PoseCNN(2)
     for ref, mine in ((enc, tr.models["encoder"]), (dep, tr.models["depth"]), (pose, tr.models["pose"])):
         ref.load_state_dict({k: v.detach().cpu() for k, v in mine.state_dict().items()})
         ref.train()
     cpu_inputs = synthetic_batch(B, H, W)
     noise = torch.randn(B, 2, H, W)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     ref = O.RefTrainStep(enc, dep, pose, (0, -1, 1), H, W)
     ref_out, ref_losses = ref.step(dict(cpu_inputs), noise)
     inputs = {k: v.cuda() for k, v in cpu_inputs.items()}
     inputs[("noise", 0)] = noise.cuda()
-    outputs, losses = tr.train_step(inputs)
+    try:
+        outputs, losses = tr.train_step(inputs)
+        torch.cuda.synchronize()
+        mix = nnkernels.plan_mix()
+    finally:
+        nnkernels.reset_plans()
+    if tune:
+        assert mix.get("wgrad", {}).get("bf16x3 transposed-gemm", 0) >= 1, mix          # the stage 3 / 4 MLPs took plan 5
     got, want = float(losses["loss"]), float(ref_losses["loss"])
     d, dr = outputs[("disp", 0)].detach().cpu(), ref_out[("disp", 0)].detach()
     d_err = float((d - dr).abs().max()) / float(dr.abs().max())
@@ -225,8 +237,8 @@ def test_convnext_large_train_step_matches_oracle():
     for k, v in enc.state_dict().items():
         if k.endswith(("stem_0.weight", "stages_2.blocks.5.mlp.fc2.weight", "stages_3.blocks.0.conv_dw.weight", "decoder.blocks.1.conv2.conv.weight")):
             off[k] = float(((mine[k].detach().cpu() - v).abs() > 1.2e-4).float().mean())
-    print("convnext_large 64x128: loss %.7f oracle %.7f (rel %.2e); disparity max err %.2e of max; fraction of weights updated the other way %s"
-          % (got, want, abs(got - want) / abs(want), d_err, {k.split(".", 2)[-1]: "%.1e" % v for k, v in off.items()}))
+    print("convnext_large %dx%d: loss %.7f oracle %.7f (rel %.2e); disparity max err %.2e of max; fraction of weights updated the other way %s"
+          % (H, W, got, want, abs(got - want) / abs(want), d_err, {k.split(".", 2)[-1]: "%.1e" % v for k, v in off.items()}))
     assert abs(got - want) <= LOSS_RTOL * abs(want), (got, want)
     assert d_err <= DISP_RTOL
     # updated weights (Adam step of 1e-4: a wrong-signed gradient moves a weight by 2e-4; only gradients within rounding of zero may)
