@@ -330,3 +330,28 @@ def test_reducer_under_the_drivers_launcher_gloo_world2(tmp_path):
            "--master-port", str(_free_port()), str(script)]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=dict(os.environ, OMP_NUM_THREADS="1"))
     assert r.returncode == 0 and "RANK_OK 0" in r.stdout and "RANK_OK 1" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_transposed_weight_gradient_plan_round_trips_through_the_plan_file():
+    """plan impl 5 (the wide 1x1 layers' weight gradient as a forward GEMM on transposed operands) lives in the host module, not in the
+    library's table: export -> reset -> load must bring it back; its applicability rule is what DESIGN 3.8 states"""
+    from sqd import nnkernels
+    nnkernels.reset_plans()
+    try:
+        wkey = (5120, 1, 1, 768, 3072, 1, 1)
+        nnkernels._register_wgrad_plan(wkey, (nnkernels.WGRAD_TRANSPOSED, 0))
+        nnkernels._register_wgrad_plan((12, 48, 160, 64, 64, 3, 3), (1, 28))
+        rec = nnkernels.export_plans()
+        assert {"pass": "wgrad", "geom": list(wkey), "plan": [5, 0]} in rec["plans"]
+        nnkernels.reset_plans()
+        assert not nnkernels.CHOSEN_PLANS
+        nnkernels.load_plans(rec)
+        assert nnkernels.CHOSEN_PLANS[("wgrad",) + wkey] == (5, 0) and nnkernels.CHOSEN_PLANS[("wgrad", 12, 48, 160, 64, 64, 3, 3)] == (1, 28)
+        assert nnkernels.plan_mix()["wgrad"] == {"bf16x3 transposed-gemm": 1, "fp32 direct": 1}
+    finally:
+        nnkernels.reset_plans()
+    ok = nnkernels.wgrad_transposed_applies
+    assert ok((5120, 1, 1, 768, 3072, 1, 1, 1, 0, 1, 1)) and ok((4, 10, 32, 6144, 1536, 1, 1, 1, 0, 10, 32))
+    assert not ok((20480, 1, 1, 384, 1536, 1, 1, 1, 0, 1, 1))            # too many rows: the transposes outweigh the product
+    assert not ok((12, 12, 40, 256, 1024, 1, 1, 1, 0, 12, 40))           # ResNet-50 layer 3: too narrow
+    assert not ok((4, 20, 64, 768, 768, 3, 3, 1, 1, 20, 64))             # not a 1x1 layer
