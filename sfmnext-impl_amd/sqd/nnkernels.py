@@ -378,8 +378,10 @@ def wgrad_transposed_applies(geom):
     M = N * Ho * Wo
     # (measured: taken for the ConvNeXt-L stage 3 / 4 MLPs — 5120 and 1280 rows, 768..6144 features —, never at 20480+ rows, where the
     #  two transposes outweigh the faster product, nor for ResNet-50's 1x1 layers)
+    # fp32 arithmetic only: under --sqd_bf16 the forward kernels round their operands to ONE bf16 term, and the weight gradients of that
+    # mode stay fp32 — the product on transposed operands would silently compute them in bf16
     return (R == 1 and S == 1 and stride == 1 and pad == 0 and M % 4 == 0 and 256 <= M <= 8192 and min(C, K) >= 256 and C * K >= 512 * 1024
-            and C % 4 == 0 and K % 4 == 0)
+            and C % 4 == 0 and K % 4 == 0 and _l.lib().sqd_conv_precision() == 0)
 
 
 def _wgrad_transposed(dy, x, dw, db, geom):

@@ -355,3 +355,8 @@ def test_transposed_weight_gradient_plan_round_trips_through_the_plan_file():
     assert not ok((20480, 1, 1, 384, 1536, 1, 1, 1, 0, 1, 1))            # too many rows: the transposes outweigh the product
     assert not ok((12, 12, 40, 256, 1024, 1, 1, 1, 0, 12, 40))           # ResNet-50 layer 3: too narrow
     assert not ok((4, 20, 64, 768, 768, 3, 3, 1, 1, 20, 64))             # not a 1x1 layer
+    nnkernels.set_conv_precision(2)                                       # --sqd_bf16: weight gradients stay fp32, the transposed product would not
+    try:
+        assert not ok((5120, 1, 1, 768, 3072, 1, 1, 1, 0, 1, 1))
+    finally:
+        nnkernels.set_conv_precision(0)
