@@ -450,7 +450,7 @@ def plan_mix():
     mix = {}
     for k, v in CHOSEN_PLANS.items():
         if k[0] == "wgrad":
-            name = {0: "fp32 lds-tiled", 1: "fp32 direct", 2: "fp32 shared-operand", 3: "bf16x3 shared-operand", 4: "fp32 row-window", 5: "bf16x3 transposed-gemm"}[v[0] & 15]
+            name = {0: "fp32 lds-tiled", 1: "fp32 direct", 2: "fp32 shared-operand", 3: "bf16x3 shared-operand", 4: "fp32 row-window", 5: "transposed forward-gemm (its own fwd plan)"}[v[0] & 15]
         else:
             bk = v[3]
             name = "bf16x3 input-patch" if bk & 2048 else "bf16x3 implicit-gemm" if bk & 1024 else "fp32 implicit-gemm"

@@ -228,7 +228,7 @@ def test_convnext_large_train_step_matches_oracle(H, W, B, patch, Q, dout, tune)
     finally:
         nnkernels.reset_plans()
     if tune:
-        assert mix.get("wgrad", {}).get("bf16x3 transposed-gemm", 0) >= 1, mix          # the stage 3 / 4 MLPs took plan 5
+        assert mix.get("wgrad", {}).get("transposed forward-gemm (its own fwd plan)", 0) >= 1, mix          # the stage 3 / 4 MLPs took plan 5
     got, want = float(losses["loss"]), float(ref_losses["loss"])
     d, dr = outputs[("disp", 0)].detach().cpu(), ref_out[("disp", 0)].detach()
     d_err = float((d - dr).abs().max()) / float(dr.abs().max())

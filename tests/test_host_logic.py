@@ -347,7 +347,7 @@ def test_transposed_weight_gradient_plan_round_trips_through_the_plan_file():
         assert not nnkernels.CHOSEN_PLANS
         nnkernels.load_plans(rec)
         assert nnkernels.CHOSEN_PLANS[("wgrad",) + wkey] == (5, 0) and nnkernels.CHOSEN_PLANS[("wgrad", 12, 48, 160, 64, 64, 3, 3)] == (1, 28)
-        assert nnkernels.plan_mix()["wgrad"] == {"bf16x3 transposed-gemm": 1, "fp32 direct": 1}
+        assert nnkernels.plan_mix()["wgrad"] == {"transposed forward-gemm (its own fwd plan)": 1, "fp32 direct": 1}
     finally:
         nnkernels.reset_plans()
     ok = nnkernels.wgrad_transposed_applies
