@@ -7,9 +7,13 @@
 One step = Trainer.train_step on one synthetic KITTI-shaped batch (configs[1]: ResNet-50 +
 Depth_Decoder_QueryTr, 192x640, batch 12 per GPU, fp32, 2 source frames): encoder + depth head +
 2 x PoseCNN forward, the fused photometric chain, full backward, gradient all-reduce (N>1), Adam.
-Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line with the job-wide
-images/s, the roofline record of the fused warp+SSIM forward kernel (live HIP-event timing on the
-launch stream) and — at N=1 — a host-CPU baseline of the oracle restatement on a bounded sample."""
+Inputs are resident in HBM before the timed region: NBATCH different batches, fed in rotation, each copied
+into the replayed graph's input tensors inside the timed region (a run never sees the same batch twice in a
+row).  The convolution plans are the pinned set shipped for configs[1] (plans/): every box runs the same
+kernels; the line says whether this box's own plan timing would have chosen differently.  Rank 0 prints ONE
+JSON line with the job-wide images/s, the roofline record of the fused warp+SSIM forward kernel (live
+HIP-event timing on the launch stream, inside training steps) and — at N=1 — a host-CPU baseline of the
+oracle restatement on a bounded sample."""
 import argparse
 import contextlib
 import json
@@ -27,6 +31,8 @@ CONFIG_B = ["--backbone", "resnet", "--num_layers", "50", "--num_features", "256
             "--batch_size", "12", "--min_depth", "0.001", "--max_depth", "80.0", "--num_workers", "0",
             "--sqd_synthetic", "--sqd_device_noise", "--log_dir", "/tmp/sqd_bench",
             "--model_name", "bench"]
+NBATCH = 3                       # resident batches fed in rotation
+PINNED_PLANS = os.path.join(REPO, "sfmnext-impl_amd", "plans", "configB_resnet50_192x640_b12.json")
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FUSED_FWD_BYTES_PER_PX = 93      # disp 1 + target 12 + sources 24 + identity/noise 8 | depth 4 + sample 16 + warped 24 + sel 4
 
@@ -47,12 +53,13 @@ def kernel_source_hash():
 PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
 
 
-def roofline_fused_fwd(trainer, inputs, iters=200):
+def roofline_fused_fwd(trainer, batches, iters=200):
     """Average duration of the fused warp+SSIM forward launch, HIP events on the launch stream."""
     from sqd import ops
     o = trainer.opt
     B, H, W = o.batch_size, o.height, o.width
     dev = trainer.device
+    inputs = batches[0]
     with torch.no_grad():
         disp = torch.rand(B, 1, H // 2, W // 2, device=dev) * 20 + 1
         depth, part = ops.depth_up_fwd(disp, H, W)
@@ -86,19 +93,23 @@ def roofline_fused_fwd(trainer, inputs, iters=200):
         from options import MonodepthOptions
         from trainer import Trainer
         with contextlib.redirect_stdout(sys.stderr):
-            eager = Trainer(MonodepthOptions().parse(CONFIG_B + os.environ.get("SQD_BENCH_EXTRA", "").split() + ["--sqd_no_graph"]))
+            eager = Trainer(MonodepthOptions().parse(bench_args() + ["--sqd_no_graph"]))
         eager.set_train()
         ops.PHOTO_FWD_EVENTS = []
         try:
-            for _ in range(12):
-                eager.train_step(dict(inputs))
+            for i in range(12):
+                eager.train_step(dict(batches[i % len(batches)]))
             torch.cuda.synchronize()
             ts = sorted(e0.elapsed_time(e1) * 1e-3 for e0, e1 in ops.PHOTO_FWD_EVENTS[2:])
             in_step = ts[len(ts) // 2]
         finally:
             ops.PHOTO_FWD_EVENTS = None
     px = B * H * W
-    t = res["train"]
+    hot = res["train"]
+    # THE figure of the record (frac / achieved / us_per_launch) is the launch inside training steps; the back-to-back relaunch of one
+    # Infinity-Cache-resident working set is reported beside it as cache_resident.  (Multi-rank runs have no eager in-step probe:
+    # there the cache-resident figure stands in and `timing` says so.)
+    t = in_step if in_step is not None else hot
     achieved = FUSED_FWD_BYTES_PER_PX * px / t / 1e9
     # HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/pmc_traffic.py, corrected
     # with the access-width calibration of tools/pmc_calib.py as the microarchitecture guide prescribes).  PMC counters cannot be
@@ -115,12 +126,16 @@ def roofline_fused_fwd(trainer, inputs, iters=200):
     return {"bound": "hbm", "kernel": ops.PHOTO_FWD_KERNEL_NAME,
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_bytes_per_launch": traffic_bytes, "traffic_source": note,
-            "us_per_launch": round(t * 1e6, 2), "us_per_launch_inference": round(res["infer"] * 1e6, 2),
-            "timing": "HIP events on the launch stream around %d back-to-back launches of one working set (Infinity-Cache resident)" % iters,
-            "in_step": None if in_step is None else {
-                "us_per_launch": round(in_step * 1e6, 2), "achieved": round(FUSED_FWD_BYTES_PER_PX * px / in_step / 1e9, 1),
-                "frac": round(FUSED_FWD_BYTES_PER_PX * px / in_step / 1e9 / HBM_PEAK_GBS, 4),
-                "timing": "median of 10 launches, HIP events around the launch inside eager training steps"},
+            "us_per_launch": round(t * 1e6, 2),
+            "timing": ("median of 10 launches, HIP events on the launch stream around the launch inside eager training steps (rotating batches)"
+                       if in_step is not None else
+                       "no in-step probe in a multi-rank run: HIP events around %d back-to-back launches of one working set" % iters),
+            "cache_resident": {
+                "us_per_launch": round(hot * 1e6, 2), "us_per_launch_inference": round(res["infer"] * 1e6, 2),
+                "achieved": round(FUSED_FWD_BYTES_PER_PX * px / hot / 1e9, 1),
+                "frac_cache_resident": round(FUSED_FWD_BYTES_PER_PX * px / hot / 1e9 / HBM_PEAK_GBS, 4),
+                "timing": "HIP events on the launch stream around %d back-to-back launches of one 137 MB working set (Infinity-Cache resident: "
+                          "an upper bound, not the figure of a training step)" % iters},
             "algorithmic_bytes_per_launch": FUSED_FWD_BYTES_PER_PX * px, "pixels_per_launch": px}
 
 
@@ -301,6 +316,105 @@ def workload_name(o):
              list(o.frame_ids) + (["s"] if o.use_stereo else []), o.num_features, o.model_dim, o.patch_size, o.query_nums, o.dim_out))
 
 
+def conv_source_hash():
+    """sha256 over the convolution kernel sources: a pinned plan set names kernels of THIS revision"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("conv.hip", "sqd_common.h"):
+        h.update(open(os.path.join(REPO, "sfmnext-impl_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pinned_plans():
+    """(path or None, note): the plan set shipped for configs[1], if it was measured on this revision of the convolution kernels"""
+    if os.environ.get("SQD_BENCH_EXTRA") or os.environ.get("SQD_BENCH_LIVE_PLANS"):
+        return None, "not configs[1] / live plan timing requested: plans measured in step 1"
+    if not os.path.exists(PINNED_PLANS):
+        return None, "no pinned plan file: plans measured in step 1"
+    rec = json.load(open(PINNED_PLANS))
+    if rec.get("conv_source_hash") != conv_source_hash():
+        return None, "pinned plan file is stale (convolution kernel sources changed since it was measured): plans measured in step 1"
+    return PINNED_PLANS, "pinned: %s (measured %s)" % (os.path.relpath(PINNED_PLANS, REPO), rec.get("measured_on", "?"))
+
+
+def bench_args():
+    path, _ = pinned_plans()
+    return CONFIG_B + os.environ.get("SQD_BENCH_EXTRA", "").split() + (["--sqd_conv_plans", path] if path else [])
+
+
+def gpu_state(index=0):
+    """shader / memory clock, power draw and cap of the device as rocm-smi reports them (None where it does not)"""
+    import subprocess
+    out = {}
+    try:
+        r = subprocess.run(["rocm-smi", "-d", str(index), "-c", "-P", "-M", "--json"], capture_output=True, text=True, timeout=20)
+        rec = json.loads(r.stdout)
+        card = rec.get("card%d" % index) or next(iter(rec.values()))
+        for k, v in card.items():
+            kl = k.lower()
+            if "sclk" in kl:
+                out["gpu_sclk_mhz"] = int("".join(ch for ch in str(v).split("Mhz")[0].split("(")[-1] if ch.isdigit()) or 0) or str(v)
+            elif "mclk" in kl:
+                out["gpu_mclk_mhz"] = int("".join(ch for ch in str(v).split("Mhz")[0].split("(")[-1] if ch.isdigit()) or 0) or str(v)
+            elif "max" in kl and "power" in kl:
+                out["power_cap_w"] = float(v) if str(v).replace(".", "", 1).isdigit() else str(v)
+            elif "power" in kl and "w" in kl:
+                out["power_w"] = float(v) if str(v).replace(".", "", 1).isdigit() else str(v)
+    except Exception as e:                              # noqa: BLE001 — reporting only
+        out["error"] = "%s: %s" % (type(e).__name__, e)
+    return out
+
+
+def kernel_time_per_step(timeout_s=240):
+    """Sum of the kernel durations of one replayed step (torch.profiler's device activity over 4 steps of the same configuration), in a
+    child process: a profiler problem must not cost the bench line."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--kernel-sum-child"], capture_output=True, text=True, timeout=timeout_s,
+                           env=dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+        for line in r.stdout.splitlines():
+            if line.startswith("{") and "kernel_ms_per_step" in line:
+                return json.loads(line)
+        return {"error": "child printed no record (rc %d): %s" % (r.returncode, (r.stderr or "").strip().splitlines()[-1:] or "")}
+    except Exception as e:                              # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def kernel_sum_child():
+    from options import MonodepthOptions
+    from trainer import Trainer
+    from datasets.synthetic import synthetic_batch
+    from torch.profiler import profile, ProfilerActivity
+    opts = MonodepthOptions().parse(bench_args())
+    with contextlib.redirect_stdout(sys.stderr):
+        tr = Trainer(opts)
+    tr.set_train()
+    batches = [synthetic_batch(opts.batch_size, opts.height, opts.width, opts.frame_ids, start=i * opts.batch_size, device=tr.device) for i in range(NBATCH)]
+    for i in range(8):
+        tr.train_step(dict(batches[i % NBATCH]))
+    torch.cuda.synchronize()
+    n = 4
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for i in range(n):
+            tr.train_step(dict(batches[i % NBATCH]))
+        torch.cuda.synchronize()
+    evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    total_us = sum(e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total for e in evs)
+    print(json.dumps({"kernel_ms_per_step": round(total_us / n / 1e3, 3), "device_events_per_step": round(len(evs) / n, 1),
+                      "source": "torch.profiler device activity over %d replayed steps (kernels + copies), separate process" % n}))
+
+
+def time_steps(trainer, batches, steps, warmup, sync):
+    for i in range(warmup):
+        trainer.train_step(dict(batches[i % len(batches)]))
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        _, losses = trainer.train_step(dict(batches[i % len(batches)]))
+    sync()
+    return time.perf_counter() - t0, losses
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -308,7 +422,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-diagnostics", action="store_true", help="skip the kernel-time sum and the live plan-timing comparison")
+    ap.add_argument("--kernel-sum-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.kernel_sum_child:
+        return kernel_sum_child()
 
     from options import MonodepthOptions
     from trainer import Trainer
@@ -327,15 +445,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py --gpus %d was launched with WORLD_SIZE=%d" % (args.gpus, world))
-    opts = MonodepthOptions().parse(CONFIG_B + os.environ.get("SQD_BENCH_EXTRA", "").split())
-    import contextlib
+    plan_path, plan_note = pinned_plans()
+    opts = MonodepthOptions().parse(bench_args())
     with contextlib.redirect_stdout(sys.stderr):          # the Trainer's banner goes to stderr: stdout carries the one JSON line
         trainer = Trainer(opts)
     trainer.set_train()
     rank, dev = trainer.rank, trainer.device
-    inputs = synthetic_batch(opts.batch_size, opts.height, opts.width, opts.frame_ids, start=rank * opts.batch_size, device=dev)
+    # NBATCH different resident batches per rank, fed in rotation: every step copies its batch into the graph's input tensors
+    # inside the timed region, as a loader-fed run does
+    batches = [synthetic_batch(opts.batch_size, opts.height, opts.width, opts.frame_ids,
+                               start=(i * world + rank) * opts.batch_size, device=dev) for i in range(NBATCH)]
 
-    from sqd import ddp
+    from sqd import ddp, nnkernels
 
     def sync():
         torch.cuda.synchronize()
@@ -343,19 +464,27 @@ def main():
             ddp.COMM.barrier()          # an all-reduce over RCCL + a stream synchronize: every rank's device work is done
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.train_step(dict(inputs))
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        _, losses = trainer.train_step(dict(inputs))
-    sync()
-    elapsed = time.perf_counter() - t0
+    state0 = gpu_state(trainer.local_rank) if rank == 0 else None
+    elapsed, losses = time_steps(trainer, batches, args.steps, args.warmup, sync)
+    state1 = gpu_state(trainer.local_rank) if rank == 0 else None
     if ddp.COMM is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         ddp.COMM.all_reduce(t, "max")
         elapsed = float(t.item())
     loss = float(losses["loss"].detach().cpu())
+    mix, plans_used = nnkernels.plan_mix(), nnkernels.export_plans()
+    exchange = None
+    if trainer.reducer is not None:
+        comm = trainer.reducer.comm
+        exchange = {"communicator": type(comm).__name__, "ranks": comm.world,
+                    "ranks_joined": comm.joined() if hasattr(comm, "joined") else comm.world,
+                    "rccl_version": comm.rccl_version() if hasattr(comm, "rccl_version") else None,
+                    "buckets": len(trainer.reducer.buckets or ()), "bucket_mb": opts.sqd_bucket_mb,
+                    "bucket_bytes": trainer.reducer.bucket_bytes_list(),
+                    "defer_wgrad_reduce": bool(trainer._defer_wgrad_reduce),
+                    "graph_mode": trainer.graph_mode(), "capture_failures": getattr(trainer, "capture_failures", []),
+                    "mode": {"eager": "eager hooks", "overlap": "all-reduces captured in the step graph",
+                             "post": "graph of forward+backward, then all-reduce + Adam"}.get(trainer.graph_mode(), trainer.graph_mode())}
 
     roof = None
     if rank == 0 and not args.no_roofline:
@@ -366,14 +495,31 @@ def main():
         elif opts.backbone.startswith("convnext"):
             roof = roofline_mlp_gemm(trainer)
         else:
-            roof = roofline_fused_fwd(trainer, inputs)
+            roof = roofline_fused_fwd(trainer, batches)
+    diag = None
+    if rank == 0 and world == 1 and not args.no_diagnostics:
+        diag = {"gpu_before": state0, "gpu_after_timed_loop": state1, "kernel_time": kernel_time_per_step()}
+        if plan_path is not None:
+            # what this box's own plan timing would have chosen, and what that is worth here: a second Trainer without the pinned set
+            del trainer
+            nnkernels.reset_plans()
+            with contextlib.redirect_stdout(sys.stderr):
+                live = Trainer(MonodepthOptions().parse(CONFIG_B))
+            live.set_train()
+            el, _ = time_steps(live, batches, 20, 6, sync)
+            mine = {(e["pass"], tuple(e["geom"])): tuple(e["plan"]) for e in nnkernels.export_plans()["plans"]}
+            pinned = {(e["pass"], tuple(e["geom"])): tuple(e["plan"]) for e in plans_used["plans"]}
+            differ = sorted(k for k in pinned if k in mine and mine[k] != pinned[k])
+            diag["live_plan_timing"] = {"ms_per_step": round(el / 20 * 1e3, 3), "geometries": len(pinned), "disagreed_on": len(differ),
+                                        "passes_of_disagreements": {p: sum(1 for k in differ if k[0] == p) for p in ("fwd", "dgrad", "wgrad")},
+                                        "note": "plans timed in this process's first step, 20 timed steps after 6 warm-ups; the headline value runs the pinned set"}
+            del live
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
     if rank == 0:
         from sqd import nnops
         ms = elapsed / args.steps * 1e3
-        from sqd import nnkernels
         default_cfg = not os.environ.get("SQD_BENCH_EXTRA")
         backbone = {"resnet": "ResNet-%d" % opts.num_layers, "resnet_lite": "ResNet-%d" % opts.num_layers, "resnet18_lite": "ResNet-18",
                     "eff_b5": "EfficientNet-b5", "tf_efficientnet_b5_ap": "EfficientNet-b5"}.get(opts.backbone, opts.backbone)
@@ -384,23 +530,17 @@ def main():
                # the type the path computes in: fp32 tensors, fp32 accumulation everywhere; per layer the convolutions multiply either
                # fp32 operands or their exact three-term bf16 split (fp32-level accuracy) — config.conv_arith counts which; --sqd_bf16
                # rounds the convolution operands to ONE bf16 term instead
-               "dtype": "bf16" if opts.sqd_bf16 else "f32", "data": "synthetic",
+               "dtype": "bf16" if opts.sqd_bf16 else "f32",
+               "data": "synthetic (%d resident batches in rotation, copied into the step's input tensors inside the timed region)" % NBATCH,
                "config": {"workload": workload_name(opts),
                           "global_batch": world * opts.batch_size, "parallelism": "dp%d" % world,
-                          "conv_arith": {"note": "layer geometries per pass by the kernel family their measured plan runs; 'bf16x3' = every fp32 "
+                          "conv_arith": {"note": "layer geometries per pass by the kernel family their plan runs; 'bf16x3' = every fp32 "
                                                  "operand as the exact sum of three bf16 terms, 6 of 9 partial products on the bf16 matrix cores, "
                                                  "fp32 accumulation (error <= 4x the fp32-MFMA kernel's against fp64: tests/test_gpu_conv.py)",
-                                         "plans": "measured in step 1" if nnkernels.TUNE_CONV and not opts.sqd_conv_plans else
-                                                  ("pinned: " + opts.sqd_conv_plans) if opts.sqd_conv_plans else "cost model (fp32 MFMA)",
-                                         **nnkernels.plan_mix()},
-                          "exchange": None if trainer.reducer is None else {
-                              "communicator": type(trainer.reducer.comm).__name__, "ranks": trainer.reducer.comm.world,
-                              "buckets": len(trainer.reducer.buckets or ()), "bucket_mb": opts.sqd_bucket_mb,
-                              "mode": ("eager hooks" if trainer._graph is None else
-                                       "all-reduces captured in the step graph" if opts.sqd_graph_ddp != "post" else
-                                       "graph of forward+backward, then all-reduce + Adam")},
+                                         "plans": plan_note if not opts.sqd_no_conv_tune else "cost model (fp32 MFMA)", **mix},
+                          "exchange": exchange,
                           "operator_backends": nnops.backend_report()},
-               "final_loss": round(loss, 6), "roofline": roof, "cpu_baseline": cpu}
+               "final_loss": round(loss, 6), "roofline": roof, "cpu_baseline": cpu, "diagnostics": diag}
         print(json.dumps(out))
     ddp.shutdown()
 

@@ -596,6 +596,10 @@ int sqd_comm_unique_id(void *id_host);
 int sqd_comm_init(const void *id_host, int rank, int world, sqd_comm **comm_host);
 int sqd_comm_rank(const sqd_comm *comm);
 int sqd_comm_world(const sqd_comm *comm);
+/* reporting only (bench line): NCCL-style version code of the bound librccl (22703 = 2.27.3; 0 = not exported by it), and the
+ * number of ranks RCCL itself counts in the communicator (ncclCommCount)                                                     */
+int sqd_comm_rccl_version(int *version_host);
+int sqd_comm_joined(const sqd_comm *comm, int *count_host);
 int sqd_comm_allreduce(sqd_comm *comm, void *buf, int64_t count, int dtype, int op, void *stream);
 int sqd_comm_broadcast(sqd_comm *comm, void *buf, int64_t count, int dtype, int root, void *stream);
 int sqd_comm_destroy(sqd_comm *comm);

@@ -75,18 +75,19 @@ def transformation_from_parameters(axisangle, translation, invert=False):
 # --------------------------------------------------------------------------------------
 
 
-def pixel_grid(B: int, H: int, W: int, device=None) -> torch.Tensor:
-    """Homogeneous pixel coordinates (x, y, 1) row-major, reference layers.py:196-208 -> [B,3,HW]."""
-    ys, xs = torch.meshgrid(torch.arange(H, dtype=torch.float32, device=device),
-                            torch.arange(W, dtype=torch.float32, device=device), indexing="ij")
-    pix = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(H * W, device=device)], 0)
+def pixel_grid(B: int, H: int, W: int, device=None, dtype=torch.float32) -> torch.Tensor:
+    """Homogeneous pixel coordinates (x, y, 1) row-major, reference layers.py:196-208 -> [B,3,HW].
+    (dtype: float32 as the reference; the tests' float64 runs of the oracle measure its own rounding noise)"""
+    ys, xs = torch.meshgrid(torch.arange(H, dtype=dtype, device=device),
+                            torch.arange(W, dtype=dtype, device=device), indexing="ij")
+    pix = torch.stack([xs.reshape(-1), ys.reshape(-1), torch.ones(H * W, dtype=dtype, device=device)], 0)
     return pix.unsqueeze(0).repeat(B, 1, 1)
 
 
 def backproject_depth(depth: torch.Tensor, inv_K: torch.Tensor) -> torch.Tensor:
     """reference layers.py:210-215.  depth [B,1,H,W], inv_K [B,4,4] -> cam points [B,4,HW]."""
     B, _, H, W = depth.shape
-    pix = pixel_grid(B, H, W, depth.device)
+    pix = pixel_grid(B, H, W, depth.device, depth.dtype)
     cam = torch.matmul(inv_K[:, :3, :3], pix)                 # :211
     cam = depth.view(B, 1, -1) * cam                          # :212
     ones = torch.ones(B, 1, H * W, dtype=depth.dtype, device=depth.device)

@@ -35,6 +35,8 @@ struct Rccl {
     int (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     const char *(*GetErrorString)(int) = nullptr;
     const char *(*GetLastError)(ncclComm_t) = nullptr;
+    int (*GetVersion)(int *) = nullptr;
+    int (*CommCount)(const ncclComm_t, int *) = nullptr;
 };
 Rccl g_rccl;
 std::mutex g_rccl_mutex;
@@ -68,6 +70,8 @@ int bind_rccl(const char *path) {
     SQD_BIND(GetErrorString, "ncclGetErrorString");
 #undef SQD_BIND
     *(void **)(&r.GetLastError) = dlsym(h, "ncclGetLastError");      // optional (absent before NCCL 2.13)
+    *(void **)(&r.GetVersion) = dlsym(h, "ncclGetVersion");          // optional: only reported (sqd_comm_rccl_version)
+    *(void **)(&r.CommCount) = dlsym(h, "ncclCommCount");            // optional: only reported (sqd_comm_joined)
     g_rccl = r;
     return SQD_OK;
 }
@@ -124,6 +128,23 @@ extern "C" int sqd_comm_init(const void *id_host, int rank, int world, sqd_comm 
 
 extern "C" int sqd_comm_rank(const sqd_comm *comm) { return comm ? comm->rank : SQD_EINVAL; }
 extern "C" int sqd_comm_world(const sqd_comm *comm) { return comm ? comm->world : SQD_EINVAL; }
+
+// NCCL-style version code of the bound librccl (e.g. 22703 = 2.27.3); 0 if the library does not export ncclGetVersion
+extern "C" int sqd_comm_rccl_version(int *version_host) {
+    SQD_CHECK_ARG(version_host, "sqd_comm_rccl_version: null argument");
+    if (int rc = bind_rccl(nullptr)) return rc;
+    *version_host = 0;
+    if (g_rccl.GetVersion) SQD_CHECK_RCCL(g_rccl.GetVersion(version_host), "sqd_comm_rccl_version", nullptr);
+    return SQD_OK;
+}
+
+// ranks RCCL itself counts in the communicator (ncclCommCount): what a bench line records as "ranks joined"
+extern "C" int sqd_comm_joined(const sqd_comm *comm, int *count_host) {
+    SQD_CHECK_ARG(comm && count_host, "sqd_comm_joined: null argument");
+    *count_host = comm->world;
+    if (g_rccl.CommCount) SQD_CHECK_RCCL(g_rccl.CommCount(comm->nccl, count_host), "sqd_comm_joined", comm->nccl);
+    return SQD_OK;
+}
 
 extern "C" int sqd_comm_allreduce(sqd_comm *comm, void *buf, int64_t count, int dtype, int op, void *stream) {
     SQD_CHECK_ARG(comm && (buf || count == 0) && count >= 0, "sqd_comm_allreduce: null argument");

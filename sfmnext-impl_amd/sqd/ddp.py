@@ -71,6 +71,19 @@ class RcclComm:
         self.all_reduce(t, "sum")
         torch.cuda.current_stream().synchronize()
 
+    def rccl_version(self):
+        """NCCL-style version code of the bound librccl as "major.minor.patch" (reporting only)"""
+        v = ctypes.c_int(0)
+        self._check(self._lib.sqd_comm_rccl_version(ctypes.byref(v)))
+        v = v.value
+        return "%d.%d.%d" % (v // 10000, (v // 100) % 100, v % 100) if v >= 10000 else str(v)
+
+    def joined(self):
+        """ranks RCCL itself counts in this communicator"""
+        n = ctypes.c_int(0)
+        self._check(self._lib.sqd_comm_joined(self._h, ctypes.byref(n)))
+        return n.value
+
     def close(self):
         if self._h is not None:
             torch.cuda.synchronize()
@@ -155,6 +168,7 @@ class GradBucketReducer:
         self._hooks = []
         self._inflight = False        # collectives queued on the communicator's stream since the last finish()
         self.hooks_enabled = True     # False while a hipGraph of forward+backward is captured / replayed (see allreduce_all)
+        self._bucket_of, self._by_ptr = {}, {}
 
     # -- start-up ---------------------------------------------------------------------------------
     def broadcast_parameters(self, modules):
@@ -210,6 +224,7 @@ class GradBucketReducer:
             self.flat.append(flat)
             self.views.append(views)
             self._pending.append(len(plist))
+        self._by_ptr = {p.data_ptr(): p for p in used}
         for p in used:
             self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
 
@@ -258,6 +273,13 @@ class GradBucketReducer:
             if self.active:
                 self._exchange(self.flat[bi])
 
+    def on_deferred_grad(self, w):
+        """nnkernels.DEFERRED_GRAD_HOOK: a filter whose gradient was handed to it directly (its split sum rides on a BatchNorm-backward
+        launch that has just been enqueued) arrives like any accumulated gradient."""
+        p = w if w in self._bucket_of else self._by_ptr.get(w.data_ptr())
+        if p is not None:
+            self._on_grad(p)
+
     def detach_grad_views(self):
         """Graph mode: hand back {parameter: its bucket view} and clear p.grad, so that a captured backward produces fresh
         gradient tensors which the caller copies into the views (and re-attaches the views afterwards)."""
@@ -267,6 +289,19 @@ class GradBucketReducer:
                 views[p] = p.grad
                 p.grad = None
         return views
+
+    def reattach_grad_views(self):
+        """every bucketed parameter's .grad is its bucket view again (after a capture attempt that left them half-way)"""
+        if self.buckets is None:
+            return
+        for bi, plist in enumerate(self.buckets):
+            for p, v in zip(plist, self.views[bi]):
+                p.grad = v
+            self._pending[bi] = len(plist)
+        self._inflight = False
+
+    def bucket_bytes_list(self):
+        return [int(f.numel() * f.element_size()) for f in getattr(self, "flat", [])]
 
     def allreduce_all(self):
         """Exchange every bucket now (--sqd_graph_ddp post: forward+backward were replayed as one hipGraph, which leaves no

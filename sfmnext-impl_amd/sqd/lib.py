@@ -124,6 +124,8 @@ _SIGNATURES = {
     "sqd_comm_init": (_I, [ctypes.c_char_p, _I, _I, ctypes.POINTER(c_void_p)]),
     "sqd_comm_rank": (_I, [_P]),
     "sqd_comm_world": (_I, [_P]),
+    "sqd_comm_rccl_version": (_I, [ctypes.POINTER(ctypes.c_int)]),
+    "sqd_comm_joined": (_I, [_P, ctypes.POINTER(ctypes.c_int)]),
     "sqd_comm_allreduce": (_I, [_P, _P, ctypes.c_int64, _I, _I, _P]),
     "sqd_comm_broadcast": (_I, [_P, _P, ctypes.c_int64, _I, _I, _P]),
     "sqd_comm_destroy": (_I, [_P]),

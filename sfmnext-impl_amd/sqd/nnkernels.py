@@ -100,10 +100,12 @@ class BatchNormAct(torch.autograd.Function):
         # a weight gradient whose pixel splits are not summed yet (Conv2d.backward under DEFER_WGRAD_REDUCE): the sum rides along as extra
         # workgroups of this node's finalize launch
         pend = _take_pending_reduce()
-        rp, ro, rn, rs = pend if pend is not None else (None, None, 0, 0)
+        rp, ro, rn, rs = pend[:4] if pend is not None else (None, None, 0, 0)
         _l.check(L.sqd_bn_train_bwd_pre_red(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
                                             _ptr(dgamma), _ptr(dbeta), _ptr(part), pre_rows, M, C, ctx.code, _ptr(rp), _ptr(ro), rn, rs, _stream()),
                  "bn_train_bwd")
+        if pend is not None:
+            _deferred_grad_done(pend[5])
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
 
 
@@ -776,7 +778,16 @@ WGRAD_STREAM = None
 # valid once the backward pass has returned (an end-of-pass callback sums whatever is still pending) — as with WGRAD_STREAM.  Off by
 # default: a multi-rank reducer's hooks read the gradients as they are accumulated.
 DEFER_WGRAD_REDUCE = False
-_PENDING_REDUCE = {}          # stream handle -> (part, dw, n, splits)
+_PENDING_REDUCE = {}          # stream handle -> (part, dw, n, splits, stream, filter)
+# Multi-rank runs: a deferred filter gradient never passes through autograd's AccumulateGrad, so the reducer's post-accumulate hook
+# does not see it; the reducer registers this callable instead (called with the filter tensor once the launch that carries the sum
+# of its splits has been enqueued — from then on the gradient is stream-ordered like any other).
+DEFERRED_GRAD_HOOK = None
+
+
+def _deferred_grad_done(w):
+    if DEFERRED_GRAD_HOOK is not None and w is not None:
+        DEFERRED_GRAD_HOOK(w)
 
 
 def _flush_pending_reduce(stream_handle=None):
@@ -784,18 +795,29 @@ def _flush_pending_reduce(stream_handle=None):
     for k in keys:
         rec = _PENDING_REDUCE.pop(k, None)
         if rec is not None:
-            part, dw, n, splits = rec
+            part, dw, n, splits, stream, w = rec
             _l.check(_l.lib().sqd_split_reduce(_ptr(part), _ptr(dw), n, splits, ctypes.c_void_p(k)), "split_reduce")
+            cur = torch.cuda.current_stream()
+            if stream is not None and stream.cuda_stream != cur.cuda_stream:
+                # the sum ran on the stream its partials were produced on; whoever reads the gradient next does so on the caller's
+                # stream (inside a capture an unjoined branch would otherwise be left behind)
+                cur.wait_stream(stream)
+            _deferred_grad_done(w)
 
 
 def _end_of_backward_reduce():
     _flush_pending_reduce()
 
 
-def _set_pending_reduce(part, dw, n, splits):
+def drop_pending_reduce():
+    """a backward pass that raised leaves its pending sums behind: the next step must not flush them into a stale gradient"""
+    _PENDING_REDUCE.clear()
+
+
+def _set_pending_reduce(part, dw, n, splits, w=None):
     h = torch.cuda.current_stream().cuda_stream
     _flush_pending_reduce(h)                    # two convolutions in a row without a BatchNorm between them: the first sum runs now
-    _PENDING_REDUCE[h] = (part, dw, n, splits)
+    _PENDING_REDUCE[h] = (part, dw, n, splits, torch.cuda.current_stream(), w)
     torch.autograd.Variable._execution_engine.queue_callback(_end_of_backward_reduce)      # (idempotent: nothing pending, nothing launched)
 
 
@@ -905,7 +927,9 @@ class Conv2d(torch.autograd.Function):
                             (lambda _: _wgrad_transposed(dy, x, dw, db, ctx.geom)) if wgrad_transposed_applies(ctx.geom) else None)
             dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
             db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
-            transposed = CHOSEN_PLANS.get(("wgrad", N, Ho, Wo, C, K, R, S), (0,))[0] == WGRAD_TRANSPOSED
+            # (the plan table keys on the OUTPUT geometry: a strided or padded 1x1 that shares it with a stride-1 layer — or a plan file —
+            #  must not take the transposed product, which reads x as [N*Ho*Wo][C] rows)
+            transposed = CHOSEN_PLANS.get(("wgrad", N, Ho, Wo, C, K, R, S), (0,))[0] == WGRAD_TRANSPOSED and wgrad_transposed_applies(ctx.geom)
             if transposed:
                 part = None
 
@@ -920,16 +944,19 @@ class Conv2d(torch.autograd.Function):
                     _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
                                               _stream()), "conv_wgrad")
             if not transposed and DEFER_WGRAD_REDUCE and WGRAD_STREAM is None and ctx.wkey is not None and _WEIGHT_USES.get(ctx.wkey, 2) == 1 and \
-                    ctx.bn_src is not None and w.grad is None:
+                    ctx.bn_src is not None and w.grad is None and w.is_leaf and w.requires_grad and w.data_ptr() == ctx.wkey and \
+                    not w._backward_hooks and (DEFERRED_GRAD_HOOK is not None or not getattr(w, "_post_accumulate_grad_hooks", None)):
                 # the partial filter gradients now; x is the output of a training-mode BatchNorm, whose backward is the next node of this
                 # stream: its finalize launch carries the sum (the end-of-pass callback is only the safety net).  The tensor is handed to
                 # the parameter directly (autograd gets None for it: an AccumulateGrad that decided to copy would copy it before it is
-                # written): valid when the backward pass has returned.
+                # written): valid when the backward pass has returned.  Only for the original leaf filter without tensor hooks (a
+                # channels-last copy would receive the gradient instead of the parameter; hooks would be skipped) — post-accumulate
+                # hooks only when their owner registered DEFERRED_GRAD_HOOK (the multi-rank reducer).
                 sp = ctypes.c_int(0)
                 _l.check(L.sqd_conv_wgrad_partials(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
                                                    ctypes.byref(sp), _stream()), "conv_wgrad_partials")
-                _set_pending_reduce(part, dw, K * R * S * C, sp.value)
                 w.grad = dw
+                _set_pending_reduce(part, dw, K * R * S * C, sp.value, w)
                 dw = None
             elif WGRAD_STREAM is None or ctx.wkey is None or _WEIGHT_USES.get(ctx.wkey, 2) != 1:
                 launch()
@@ -1420,37 +1447,31 @@ def encoder_supported(encoder):
 
 
 def transformer_encoder_native(tokens, encoder):
-    """tokens [S,B,E] through the encoder.  S <= 512 tokens (the positional table holds 500), head dimension 4 | 8: every layer
-    runs on the fused kernels (EncoderStack).  Anything else: self-attention through torch and everything after it as
-    EncoderTail.  One bernoulli launch draws every dropout mask of the pass."""
+    """tokens [S,B,E] through the encoder on the fused kernels (EncoderStack): S <= 512 tokens (the positional table holds 500; 256 at
+    width 64), head dimension 4 | 8 | 16.  A token count or head dimension the attention kernel does not take raises — self-attention never
+    runs through torch.  One bernoulli launch draws every dropout mask of the pass."""
     x = tokens.contiguous()
     S, B, E = x.shape
     rows = S * B
     layers = list(encoder.layers)
     H = layers[0].self_attn.num_heads
-    full = all(_attention_native_ok(l, S) and l.self_attn.num_heads == H for l in layers)
+    if not all(_attention_native_ok(l, S) and l.self_attn.num_heads == H for l in layers):
+        raise RuntimeError("sqd: self-attention over %d tokens of width %d with %d heads: the fused attention kernel takes up to 512 tokens "
+                           "with head dimension 4 | 8 (width 16 / 32) and up to 256 tokens with head dimension 16 (width 64); there is no "
+                           "ATen fallback" % (S, E, H))
     masks, scale = None, 1.0
     if encoder.training:
         ps = {float(p) for l in layers for p in (l.dropout1.p, l.dropout.p, l.dropout2.p)}
-        if full:
-            ps |= {float(l.self_attn.dropout) for l in layers}
+        ps |= {float(l.self_attn.dropout) for l in layers}
         if ps != {0.0}:
             if len(ps) != 1:
                 raise RuntimeError("sqd: encoder layers with different dropout rates are not supported")
             p0 = ps.pop()
             SP = (S + 3) // 4 * 4
-            per_layer = [((B * H * S * SP) if full else 0, rows * E, rows * l.linear1.weight.shape[0], rows * E) for l in layers]
+            per_layer = [(B * H * S * SP, rows * E, rows * l.linear1.weight.shape[0], rows * E) for l in layers]
             keep = torch.empty(sum(sum(t) for t in per_layer), device=x.device, dtype=torch.uint8).bernoulli_(1.0 - p0)
             masks = [torch.split(c, list(t)) for c, t in zip(torch.split(keep, [sum(t) for t in per_layer]), per_layer)]
             scale = 1.0 / (1.0 - p0)
-    if full:
-        cfg = {"H": H, "eps": [(l.norm1.eps, l.norm2.eps) for l in layers], "masks": masks, "scale": scale}
-        return EncoderStack.apply(x, cfg, *[p for l in layers for p in _layer_params(l)])
-    for li, layer in enumerate(layers):
-        _, m1, mf, m2 = masks[li] if masks is not None else (None,) * 4
-        sa = layer.self_attn(x, x, x, need_weights=False)[0]
-        x = EncoderTail.apply(x, sa, m1, mf, m2, layer.norm1.weight, layer.norm1.bias, layer.linear1.weight, layer.linear1.bias,
-                              layer.linear2.weight, layer.linear2.bias, layer.norm2.weight, layer.norm2.bias, scale,
-                              layer.norm1.eps, layer.norm2.eps)
-    return x
+    cfg = {"H": H, "eps": [(l.norm1.eps, l.norm2.eps) for l in layers], "masks": masks, "scale": scale}
+    return EncoderStack.apply(x, cfg, *[p for l in layers for p in _layer_params(l)])
 

@@ -5,8 +5,8 @@ reference's structure (state-dict keys stay those of the reference) while the ar
 kernels of libsqd.so (csrc/*.hip).  There is ONE implementation per operator: a shape the kernels do not take (channel /
 feature counts that are not multiples of 4) is an error that names the operator and the shape, not a detour through another
 library; host tensors are refused (the CPU restatement of these operators is test infrastructure: oracle/, tests/host_ops.py).
-A transformer encoder the kernels do not take (an embedding width other than 16 / 32 / 64, more than 512 tokens) would run on ATen and
-is counted in ATEN_CALLS; no args file of the reference builds one."""
+That includes the patch-token transformer encoder: an embedding width other than 16 / 32 / 64 or more than 512 tokens (256 at
+width 64) raises — no args file of the reference builds one, and nothing in the step runs on ATen's nn.TransformerEncoder."""
 import torch
 import torch.nn.functional as F
 
@@ -18,16 +18,12 @@ BACKEND = {
     "full_query_layer": "hip", "bins_head": "hip",
 }
 
-ATEN_CALLS = {}               # operator -> calls of this process that ran on ATen (only transformer_encoder can)
+ATEN_CALLS = {}               # operator -> calls that ran on ATen: nothing writes to it any more (kept so that tests can assert it stays empty)
 
 
 def backend_report():
-    """BACKEND, with the transformer encoder reported by what actually ran in this process."""
-    rep = dict(BACKEND)
-    n = ATEN_CALLS.get("transformer_encoder", 0)
-    if n:
-        rep["transformer_encoder"] = "aten nn.TransformerEncoder (%d calls: a shape the kernels do not take)" % n
-    return rep
+    """BACKEND: one implementation per operator — there is nothing to report per process."""
+    return dict(BACKEND)
 
 
 def _device_only(x, what):
@@ -258,10 +254,13 @@ def transformer_encoder(tokens, encoder):
     """tokens [T,B,E] through nn.TransformerEncoder (4 post-norm layers, ReLU feed-forward)."""
     _device_only(tokens, "transformer_encoder")
     from . import nnkernels
-    if nnkernels.encoder_supported(encoder):
-        return nnkernels.transformer_encoder_native(tokens, encoder)
-    ATEN_CALLS["transformer_encoder"] = ATEN_CALLS.get("transformer_encoder", 0) + 1
-    return encoder(tokens)                     # ATen: embedding widths other than 16 / 32 / 64
+    if not nnkernels.encoder_supported(encoder):
+        l0 = encoder.layers[0]
+        raise RuntimeError("sqd: transformer_encoder with embedding width %d, feed-forward %d, norm_first=%s: the patch-token encoder kernels "
+                           "take post-norm ReLU layers of width 16 / 32 / 64 (reference networks/depth_decoder_QTR.py:14-16 with the "
+                           "model_dim of every args file); there is no ATen fallback"
+                           % (l0.linear1.weight.shape[1], l0.linear1.weight.shape[0], l0.norm_first))
+    return nnkernels.transformer_encoder_native(tokens, encoder)
 
 
 def full_query_layer(x, queries):

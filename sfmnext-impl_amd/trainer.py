@@ -107,9 +107,10 @@ class Trainer:
         self.reducer = ddp.GradBucketReducer(all_params, self.opt.sqd_bucket_mb) if ddp.COMM is not None else None
         if self.reducer is not None:
             self.reducer.broadcast_parameters(self.models.values())
-        # single rank: the sum of a weight gradient's pixel splits rides on the next BatchNorm-backward launch (a reducer's hooks would read
-        # the gradient before that)
-        self._defer_wgrad_reduce = self.reducer is None and not self.opt.sqd_no_defer_wgrad_reduce
+        # the sum of a weight gradient's pixel splits rides on the next BatchNorm-backward launch; with a reducer the filter is announced to
+        # it by nnkernels.DEFERRED_GRAD_HOOK once that launch is enqueued (its post-accumulate hook never sees a directly assigned gradient),
+        # so that N > 1 runs the kernels N = 1 is measured with
+        self._defer_wgrad_reduce = not self.opt.sqd_no_defer_wgrad_reduce
 
         # single- and multi-rank runs replay the whole step as one hipGraph; with a process group the graph also holds the
         # bucket gathers and the RCCL all-reduces the autograd hooks launch, as branches parallel to the rest of backward
@@ -227,28 +228,27 @@ class Trainer:
             o = self.opt
             inputs[("noise", 0)] = torch.randn(o.batch_size, self._identity_planes(), o.height, o.width)
         if self._graph is None:
-            try:
-                self._capture(inputs)
-            except Exception as e:                  # noqa: BLE001 — any capture failure: keep training, eagerly
-                # (every rank runs the same code on the same shapes, so a capture that cannot be taken fails on all of them;
-                # the eager path needs nothing the capture would have set up)
-                import sys
-                print("sqd: hipGraph capture of the training step failed (%s: %s) — continuing with eager steps" %
-                      (type(e).__name__, str(e).splitlines()[0] if str(e) else ""), file=sys.stderr, flush=True)
-                self._graph, self._graph_ok, self._capturing = None, False, False
+            err = self._try_capture(inputs)
+            if err is not None and self.reducer is not None and self.opt.sqd_graph_ddp != "post":
+                # multi-rank: the capture with the all-reduces inside could not be taken — fall back to the graph of forward + backward with
+                # the exchange and Adam after the replay (every rank runs the same code on the same shapes: all of them land here)
+                self._note_capture_failure("overlap", err, "retrying as --sqd_graph_ddp post")
+                self.opt.sqd_graph_ddp = "post"
+                self._graph_ok = True
+                self.reducer.hooks_enabled = True
+                self.reducer.reattach_grad_views()
+                err = self._try_capture(inputs)
+            if err is not None:
+                # (the eager path needs nothing the capture would have set up)
+                self._note_capture_failure(self.graph_mode(), err, "continuing with eager steps")
+                self._graph, self._graph_ok = None, False
                 if self.reducer is not None:
                     self.reducer.hooks_enabled = True
-                torch.cuda.synchronize()
                 return self._train_step_eager(inputs)
-        src = self.__dict__.setdefault("_static_src", {})
         for k, v in inputs.items():
             st = self._static_in[k]
-            last = src.get(k)
-            # the very tensor object that was copied last time, unchanged since (same autograd version counter; the reference held here
-            # keeps its storage from being recycled): the static copy is current — a resident batch fed again costs no copies
-            if not (v is st or (last is not None and last[0] is v and last[1] == v._version and v.is_cuda)):
+            if v is not st:                       # every batch is copied into the graph's input tensors (a loader never feeds one twice)
                 st.copy_(v, non_blocking=True)
-                src[k] = (v, v._version)
             inputs[k] = st                        # as process_batch does in eager mode: the caller's dict now holds device tensors
         if self.reducer is None or self.opt.sqd_graph_ddp != "post":
             self.model_optimizer.refresh_hyper()
@@ -258,6 +258,31 @@ class Trainer:
             self.reducer.allreduce_all()
             self.model_optimizer.step()
         return self._static_out
+
+    def _try_capture(self, inputs):
+        """-> None, or the exception that kept the step from being captured (the device is idle again when it returns)"""
+        try:
+            self._capture(inputs)
+            return None
+        except Exception as e:                  # noqa: BLE001 — any capture failure: the caller decides how to keep training
+            self._graph, self._capturing = None, False
+            torch.cuda.synchronize()
+            return e
+
+    def _note_capture_failure(self, mode, e, then):
+        import sys
+        self.capture_failures = getattr(self, "capture_failures", []) + ["%s: %s: %s" % (mode, type(e).__name__, (str(e).splitlines() or [""])[0])]
+        print("sqd: hipGraph capture of the training step (%s) failed (%s: %s) — %s" %
+              (mode, type(e).__name__, (str(e).splitlines() or [""])[0], then), file=sys.stderr, flush=True)
+
+    def graph_mode(self):
+        """what a step runs as right now: 'eager', 'graph' (single rank), 'overlap' (all-reduces captured in the step graph) or
+        'post' (graph of forward + backward, then all-reduce + Adam) — bench lines and logs quote it"""
+        if not self._graph_ok:
+            return "eager"
+        if self.reducer is None:
+            return "graph"
+        return "post" if self.opt.sqd_graph_ddp == "post" else "overlap"
 
     def _capture(self, inputs):
         """One hipGraph for process_batch + backward + Adam.  The ~1200 kernel launches of a step then cost one graph
@@ -332,12 +357,18 @@ class Trainer:
         # step).  Not inside a capture: a hipGraph with ~110 extra cross-branch edges replays 1.3 ms slower than the linear one.
         nnkernels.WGRAD_STREAM = None if getattr(self, "_capturing", False) else self._wgrad_stream
         nnkernels.DEFER_WGRAD_REDUCE = self._defer_wgrad_reduce
+        # (the first multi-rank step builds the buckets from whatever gradients exist: nothing to announce yet)
+        nnkernels.DEFERRED_GRAD_HOOK = self.reducer.on_deferred_grad if self.reducer is not None and self.reducer.buckets is not None else None
+        if self.reducer is not None and self.reducer.buckets is None:
+            nnkernels.DEFER_WGRAD_REDUCE = False         # (its parameters have no hooks yet, but finish() reads every gradient right after)
         try:
             loss.backward()
             nnkernels.join_wgrad_stream()                # the caller's stream joins it before anything reads the gradients
         finally:
             nnkernels.WGRAD_STREAM = None
             nnkernels.DEFER_WGRAD_REDUCE = False
+            nnkernels.DEFERRED_GRAD_HOOK = None
+            nnkernels.drop_pending_reduce()              # (empty after a pass that returned; a pass that raised must not leak its sums)
 
     def _train_step_eager(self, inputs):
         nnkernels.begin_step()

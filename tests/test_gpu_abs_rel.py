@@ -99,3 +99,82 @@ def test_abs_rel_after_200_steps(oracle_run, plans):
     # (measured plans), final loss equal to 1e-5, |d abs_rel| 2.3e-4 / 0.9e-4 — the bars are ~3x that
     assert worst <= 3e-3, worst
     assert abs(dev_loss[-1] - ref_loss[-1]) <= 5e-4 * abs(ref_loss[-1]), (dev_loss[-1], ref_loss[-1])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# The same claim on the metric's own model (BASELINE.json: "KITTI 640x192 ResNet-50 ... abs_rel within +-0.001 of reference after equal
+# steps"; reference trainer.py:551-579, layers.py:282-300): ResNet-50 + Depth_Decoder_QueryTr at 192x640 — configs[1]'s networks and
+# image size; batch 2 keeps the oracle's CPU steps at ~1 s each — 50 optimisation steps through the replayed hipGraph with the plans
+# measured in the first step (the benchmarked arithmetic), then compute_depth_losses on a held-out batch.
+R50_H, R50_W, R50_B, R50_STEPS, R50_NBATCH = 192, 640, 2, 50, 5
+R50_ARGS = ["--backbone", "resnet", "--num_layers", "50", "--num_features", "256", "--model_dim", "32", "--patch_size", "16",
+            "--query_nums", "64", "--dim_out", "64", "--height", str(R50_H), "--width", str(R50_W), "--batch_size", str(R50_B),
+            "--min_depth", "0.001", "--max_depth", "80.0", "--num_workers", "0", "--sqd_synthetic", "--log_dir", "/tmp/sqd_absrel_test"]
+
+
+@pytest.fixture(scope="module")
+def oracle_run_res50():
+    sys.path.insert(0, REPO)
+    from oracle import torch_ref as O
+    from datasets.synthetic import synthetic_batch
+    torch.manual_seed(0)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    enc = O.ResnetEncoderDecoder(50, 256, 32)
+    dep = O.QueryTrDecoder(32, 32, 16, 4, 64, 64, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
+    pose = O.PoseCNN(2)
+    for m in (enc, dep, pose):
+        m.train()
+    state = {"encoder": {k: v.clone() for k, v in enc.state_dict().items()}, "depth": {k: v.clone() for k, v in dep.state_dict().items()},
+             "pose": {k: v.clone() for k, v in pose.state_dict().items()}}
+    g = torch.Generator().manual_seed(7)
+    batches = [synthetic_batch(R50_B, R50_H, R50_W, start=R50_B * i) for i in range(R50_NBATCH)]
+    noises = [torch.randn(R50_B, 2, R50_H, R50_W, generator=g) for _ in range(R50_STEPS)]
+    held = synthetic_batch(R50_B, R50_H, R50_W, start=10 ** 5, with_gt=True)
+    ref = O.RefTrainStep(enc, dep, pose, (0, -1, 1), R50_H, R50_W)
+    ref_loss = [float(ref.step(dict(batches[i % R50_NBATCH]), noises[i])[1]["loss"].detach()) for i in range(R50_STEPS)]
+    for m in (enc, dep, pose):
+        m.eval()
+    with torch.no_grad():
+        out = dep(enc(held[("color_aug", 0, 0)]))
+        depth = torch.nn.functional.interpolate(out[("disp", 0)], [R50_H, R50_W], mode="bilinear", align_corners=False)
+    want = [float(v) for v in O.compute_depth_losses(depth, held["depth_gt"])]
+    return {"state": state, "batches": batches, "noises": noises, "held": held, "ref_loss": ref_loss, "want": want}
+
+
+def test_abs_rel_resnet50_192x640_after_50_steps(oracle_run_res50):
+    from options import MonodepthOptions
+    from trainer import Trainer
+    from sqd import nnkernels
+    R = oracle_run_res50
+    nnkernels.reset_plans()
+    tr = Trainer(MonodepthOptions().parse(R50_ARGS))            # plan timing ON, graph replay ON: what bench.py runs
+    tr.set_train()
+    _no_dropout(tr.models.values())
+    for name, sd in R["state"].items():
+        tr.models[name].load_state_dict(sd)
+    dev_loss = []
+    try:
+        for i in range(R50_STEPS):
+            dev = {k: v.cuda() for k, v in R["batches"][i % R50_NBATCH].items()}
+            dev[("noise", 0)] = R["noises"][i].cuda()
+            dev_loss.append(float(tr.train_step(dev)[1]["loss"].detach()))
+        assert tr._graph is not None                       # the replayed hipGraph did the training
+        mix = nnkernels.plan_mix()
+        tr.set_eval()
+        with torch.no_grad():
+            inputs = {k: v.cuda() for k, v in R["held"].items()}
+            outputs, losses = tr.process_batch(inputs)
+            tr.compute_depth_losses(inputs, outputs, losses)
+        got = [float(losses[n]) for n in tr.depth_metric_names]
+    finally:
+        nnkernels.reset_plans()
+    ref_loss, want = R["ref_loss"], R["want"]
+    worst = max(abs(a - b) / abs(b) for a, b in zip(dev_loss, ref_loss))
+    print("ResNet-50 192x640: loss after %d steps: device %.6f oracle %.6f (first step %.6f), worst per-step relative difference %.2e; "
+          "depth metrics device %s oracle %s; plans %s"
+          % (R50_STEPS, dev_loss[-1], ref_loss[-1], ref_loss[0], worst, ["%.5f" % v for v in got], ["%.5f" % v for v in want], mix))
+    assert sum(mix.get("fwd", {}).values()) > 20 and sum(mix.get("wgrad", {}).values()) > 20, mix      # the layers were timed
+    first, last = sum(ref_loss[:R50_NBATCH]) / R50_NBATCH, sum(ref_loss[-R50_NBATCH:]) / R50_NBATCH
+    assert last < first                                # the model did train
+    assert abs(got[0] - want[0]) <= 1e-3, ("abs_rel", got[0], want[0])          # BASELINE.json north_star
+    assert worst <= 1e-2, worst

@@ -122,8 +122,18 @@ def test_deferred_wgrad_reduce_rides_on_the_batchnorm_backward():
     x = torch.randn(3, 16, 40, 72, device="cuda").contiguous(memory_format=torch.channels_last)
     gy = torch.randn(3, 64, 20, 36, device="cuda").contiguous(memory_format=torch.channels_last)
 
+    deferred = []
+    real_set = nnkernels._set_pending_reduce
+
+    def counting_set(part, dw, n, splits, w=None):
+        deferred.append(dw)
+        return real_set(part, dw, n, splits, w)
+
     def run(defer):
+        nnkernels.begin_step()                  # per-step use counts of the filters: a filter is deferred only when used once
         nnkernels.DEFER_WGRAD_REDUCE = defer
+        nnkernels._set_pending_reduce = counting_set
+        del deferred[:]
         try:
             for m in convs + bns:
                 m.zero_grad(set_to_none=True)
@@ -134,9 +144,18 @@ def test_deferred_wgrad_reduce_rides_on_the_batchnorm_backward():
                 h = nnops.conv_bn_act(h, c, b, "relu")
             h.backward(gy)
             assert not nnkernels._PENDING_REDUCE
+            if defer:
+                # the deferred path ran: the second and third convolutions read a training-mode BatchNorm's output (the first reads the
+                # plain input: no BatchNorm backward follows its weight gradient, it takes the launch of its own), and their filters
+                # hold the very tensors handed over by the node
+                assert len(deferred) == 2, len(deferred)
+                assert all(any(c.weight.grad.data_ptr() == d.data_ptr() for d in deferred) for c in convs[1:])
+            else:
+                assert not deferred
             return [c.weight.grad.clone() for c in convs] + [convs[2].bias.grad.clone()] + [b.weight.grad.clone() for b in bns]
         finally:
             nnkernels.DEFER_WGRAD_REDUCE = False
+            nnkernels._set_pending_reduce = real_set
     ref, got = run(False), run(True)
     for a, b in zip(ref, got):
         assert torch.equal(a, b)

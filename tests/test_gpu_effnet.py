@@ -148,3 +148,95 @@ def test_effb5_bf16_training_steps_track_fp32():
     print("eff_b5 losses fp32 %s\n       bf16 %s" % (runs["fp32"], runs["bf16"]))
     for a, b in zip(runs["fp32"], runs["bf16"]):
         assert b == b and abs(a - b) <= 0.05 * abs(a), (runs["fp32"], runs["bf16"])
+
+
+@pytest.mark.parametrize("H,W,B,nf,patch,Q,dout", [(160, 416, 2, 256, 16, 16, 32), (320, 1024, 1, 512, 20, 128, 128)])
+def test_effb5_bf16_step_matches_bf16_oracle(H, W, B, nf, patch, Q, dout):
+    """configs[3] in the arithmetic it names: one optimisation step of EfficientNet-b5 + Depth_Decoder_QueryTr under --sqd_bf16 with the
+    plans measured in the step, at the workload shape (320x1024; batch 1 keeps the oracle's CPU steps short) and at a geometry whose maps
+    are no multiples of 16 (160x416: 5x13 at stride 32, ADVICE r02's BatchNorm-partial-rows case) — against the ORACLE evaluated in the same
+    arithmetic (oracle/bf16_mode.py: the fp32 oracle with both operands of every implicit-GEMM product rounded to bf16, RNE, fp32
+    accumulation; fp32 weight gradients).
+
+    The bound.  Device and oracle round the same values with the same rule, so they differ only where an operand that differs by the
+    fp32 accumulation-order noise e ~ 1e-6 straddles a bf16 rounding boundary: probability e / 2^-8 per operand, error 2^-8 when it
+    happens, i.e. an rms contribution sqrt(e 2^-8) per operand and sqrt(e 2^-8 / K) on a K-term product; iterated over the layers this
+    settles at e* ~ 2^-8 / K ~ 1e-5 .. 1e-4 for K = 50 .. 500 reduction terms.  The bars — loss 1e-4, disparity 1e-3 of its maximum —
+    are 10x that and 10x BELOW the distance between the bf16 and fp32 arithmetics themselves (printed: disparity ~1e-2), so a wrong
+    BatchNorm statistic, a dropped bias or an unrounded operand cannot hide in them.  The fp32 oracle is evaluated too: the device's
+    distance to it must equal the bf16 oracle's distance to it within the same bars."""
+    sys.path.insert(0, REPO)
+    from oracle import torch_ref as O, bf16_mode as BM
+    from options import MonodepthOptions
+    from trainer import Trainer
+    from datasets.synthetic import synthetic_batch
+    from sqd import lib, nnkernels
+    nnkernels.reset_plans()
+    args = ["--backbone", "eff_b5", "--num_features", str(nf), "--model_dim", "32", "--patch_size", str(patch), "--query_nums", str(Q),
+            "--dim_out", str(dout), "--height", str(H), "--width", str(W), "--batch_size", str(B), "--num_workers", "0", "--sqd_synthetic",
+            "--log_dir", "/tmp/sqd_effb5_test", "--max_depth", "80.0", "--sqd_no_graph", "--sqd_bf16"]          # plan timing ON
+    torch.manual_seed(0)
+    try:
+        tr = Trainer(MonodepthOptions().parse(args))
+        tr.set_train()
+        assert lib.lib().sqd_conv_precision() == 2
+        for m in tr.models.values():
+            for mod in m.modules():
+                if isinstance(mod, torch.nn.Dropout):
+                    mod.p = 0.0
+                if isinstance(mod, torch.nn.MultiheadAttention):
+                    mod.dropout = 0.0
+        cpu_inputs = synthetic_batch(B, H, W)
+        noise = torch.randn(B, 2, H, W)
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        runs = {}
+        for mode in ("fp32", "bf16"):
+            enc = O.BaseEncoder(model_dim=32, num_features=nf)
+            dep = O.QueryTrDecoder(32, 32, patch, 4, Q, dout, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
+            pose = O.PoseCNN(2)
+            for ref, mine in ((enc, tr.models["encoder"]), (dep, tr.models["depth"]), (pose, tr.models["pose"])):
+                ref.load_state_dict({k: v.detach().cpu() for k, v in mine.state_dict().items()})
+                ref.train()
+            step = O.RefTrainStep(enc, dep, pose, (0, -1, 1), H, W)
+            if mode == "bf16":
+                with BM.bf16_operands(BM.gemm_modules(enc, dep, pose)):
+                    out, losses = step.step(dict(cpu_inputs), noise)
+            else:
+                out, losses = step.step(dict(cpu_inputs), noise)
+            runs[mode] = (float(losses["loss"]), out[("disp", 0)].detach(), {"encoder": enc, "depth": dep, "pose": pose})
+        inputs = {k: v.cuda() for k, v in cpu_inputs.items()}
+        inputs[("noise", 0)] = noise.cuda()
+        outputs, losses = tr.train_step(inputs)
+        torch.cuda.synchronize()
+        mix = nnkernels.plan_mix()
+    finally:
+        nnkernels.reset_plans()
+        nnkernels.set_conv_precision(0)
+    got = float(losses["loss"])
+    d = outputs[("disp", 0)].detach().cpu()
+    (l32, d32, _), (l16, d16, nets16) = runs["fp32"], runs["bf16"]
+    dmax = float(d16.abs().max())
+    e_loss, e_disp = abs(got - l16) / abs(l16), float((d - d16).abs().max()) / dmax
+    gap_loss, gap_disp = abs(l16 - l32) / abs(l32), float((d16 - d32).abs().max()) / dmax
+    dev_gap = float((d - d32).abs().max()) / dmax
+    print("eff_b5 bf16 %dx%d: loss %.7f, bf16 oracle %.7f (rel %.2e), fp32 oracle %.7f; disparity vs bf16 oracle %.2e of max; "
+          "bf16 oracle vs fp32 oracle: loss %.2e, disparity %.2e (device vs fp32 oracle %.2e); plans %s"
+          % (H, W, got, l16, e_loss, l32, e_disp, gap_loss, gap_disp, dev_gap, mix))
+    assert sum(mix.get("fwd", {}).values()) > 20, mix                       # the layers were timed
+    assert e_loss <= 1e-4, (got, l16)
+    assert e_disp <= 1e-3, e_disp
+    assert gap_disp >= 10 * e_disp or gap_disp <= 1e-3, (gap_disp, e_disp)   # the test resolves the two arithmetics
+    assert abs(dev_gap - gap_disp) <= 1e-3 + 0.2 * gap_disp, (dev_gap, gap_disp)
+    # gradients and BatchNorm state after the step (fp32 weight gradients of bf16-rounded data gradients): first / middle / last layers
+    for net, name in (("encoder", "encoder.original_model.conv_stem.weight"), ("encoder", "encoder.original_model.blocks.2.1.conv_pw.weight"),
+                      ("encoder", "encoder.original_model.blocks.4.3.bn2.weight"), ("encoder", "encoder.original_model.blocks.6.2.conv_pwl.weight"),
+                      ("encoder", "encoder.original_model.conv_head.weight"), ("encoder", "decoder.up4._net.0.weight"), ("encoder", "decoder.conv3.bias"),
+                      ("depth", "bins_regressor.0.weight"), ("depth", "conv3x3.weight"), ("pose", "net.3.weight")):
+        g_ref = dict(nets16[net].named_parameters())[name].grad
+        g_got = dict(tr.models[net].named_parameters())[name].grad.detach().cpu()
+        g_l2 = float((g_got - g_ref).norm() / g_ref.norm())
+        print("%-60s gradient L2 err vs bf16 oracle %.2e" % (name, g_l2))
+        assert g_l2 <= 2e-2, (name, g_l2)
+    rm = tr.models["encoder"].encoder.original_model.blocks[3][2].bn1.running_var.cpu()
+    rr = nets16["encoder"].encoder.original_model.blocks[3][2].bn1.running_var
+    assert float((rm - rr).abs().max() / rr.abs().max()) < 1e-3

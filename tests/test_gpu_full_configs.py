@@ -29,6 +29,40 @@ HEADS = {
 }
 
 
+_STEM_REF = {}        # (H, W, B, kind) -> (float64 gradient of the encoder's stem filter, the oracle's own fp32 error against it)
+
+
+def _stem_noise_floor(key, nets, cpu_inputs, noise, H, W):
+    """The stem filter's gradient is the end of every gradient path of the trunk: two correct evaluations that round differently
+    disagree on a handful of ReLU / max-pool gates among ~10^8 activations, and each flipped gate re-routes a path that ends here.
+    How much that is gets MEASURED, per configuration: the oracle step in float64 (the reference value), and two float32 evaluations
+    of the same oracle — as it is, and with every weight perturbed by 1e-7 relative (another draw of the rounding lottery).  Returns
+    (g64, floor_max, floor_l2) with floor_* the larger of the two fp32 errors against float64 (relative to max|g| / to ||g||)."""
+    if key in _STEM_REF:
+        return _STEM_REF[key]
+    import copy
+    from oracle import torch_ref as O
+
+    def grad(dtype, perturb):
+        e, d, p = [copy.deepcopy(m).to(dtype) for m in nets]
+        if perturb:
+            g = torch.Generator().manual_seed(1)
+            with torch.no_grad():
+                for q in list(e.parameters()) + list(d.parameters()) + list(p.parameters()):
+                    q.mul_(1 + perturb * torch.randn(q.shape, generator=g).to(dtype))
+        step = O.RefTrainStep(e, d, p, (0, -1, 1), H, W)
+        step.step({k: (v.to(dtype) if v.is_floating_point() else v) for k, v in cpu_inputs.items()}, noise.to(dtype))
+        name = "encoder.encoder.conv1.weight"
+        return dict(e.named_parameters())[name].grad.double()
+    g64 = grad(torch.float64, 0.0)
+    errs = []
+    for perturb in (0.0, 1e-7):
+        g32 = grad(torch.float32, perturb)
+        errs.append((float((g32 - g64).abs().max() / g64.abs().max()), float((g32 - g64).norm() / g64.norm())))
+    _STEM_REF[key] = (g64, max(e[0] for e in errs), max(e[1] for e in errs), errs)
+    return _STEM_REF[key]
+
+
 def _args(H, W, B, extra, kind="res50"):
     return HEADS[kind][0] + ["--model_dim", "64" if kind == "res50_bp" else "32", "--height", str(H), "--width", str(W), "--batch_size", str(B),
                              "--max_depth", "80.0", "--num_workers", "0", "--sqd_synthetic", "--log_dir", "/tmp/sqd_full_cfg_test"] + extra
@@ -68,6 +102,7 @@ def test_flagship_step_matches_oracle(H, W, B, kind, plans):
     cpu_inputs = synthetic_batch(B, H, W)
     noise = torch.randn(B, 2, H, W)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
+    stem64, floor_max, floor_l2, floor_samples = _stem_noise_floor((H, W, B, kind), (enc, dep, pose), cpu_inputs, noise, H, W)
     ref = O.RefTrainStep(enc, dep, pose, (0, -1, 1), H, W)
     ref_out, ref_losses = ref.step(dict(cpu_inputs), noise)
     inputs = {k: v.cuda() for k, v in cpu_inputs.items()}
@@ -113,9 +148,18 @@ def test_flagship_step_matches_oracle(H, W, B, kind, plans):
         noise_level = g_ref.abs() <= max(5e-3, 4.0 * g_err) * g_ref.abs().max()
         print("%s: gradient max err %.1e of max|g|, L2 err %.1e; %d of %d updated weights beyond 5e-5, all of them inside the gradient's noise band: %s"
               % (name, g_err, g_l2, int(bad.sum()), bad.numel(), bool((~bad | noise_level).all())))
-        # (the stem's worst element moves with the rounding pattern of the run — 5e-3 .. 2.5e-2 over the plan sets and library builds seen on
-        #  MI355X: which gates flip is a lottery — so the bound on it is loose and the norm of the difference carries the claim)
-        assert g_err <= (5e-2 if name.endswith("encoder.conv1.weight") else 2e-3), (name, g_err)
-        assert g_l2 <= (3e-2 if name.endswith("encoder.conv1.weight") else 2e-3), (name, g_l2)
+        if name.endswith("encoder.conv1.weight"):
+            # the encoder's stem: held to the float64 value of the oracle step at twice the oracle's OWN measured fp32 noise there
+            # (_stem_noise_floor; measured on the host in the build container for res50 192x640: fp32 oracle vs float64 1.26e-2 of max /
+            # 1.31e-2 in norm, a float64 run with weights perturbed by 1e-7 still 0.73e-2 — the filter sits at the end of a chaotic map)
+            e64 = float((g_got.double() - stem64).abs().max() / stem64.abs().max())
+            l64 = float((g_got.double() - stem64).norm() / stem64.norm())
+            print("%s: against float64: device max err %.2e / L2 %.2e; the oracle's fp32 evaluations (as is, weights * (1 + 1e-7 n)): %s"
+                  % (name, e64, l64, ["max %.2e / L2 %.2e" % e for e in floor_samples]))
+            assert e64 <= 2.0 * floor_max, (name, e64, floor_max)
+            assert l64 <= 2.0 * floor_l2, (name, l64, floor_l2)
+        else:
+            assert g_err <= 2e-3, (name, g_err)
+            assert g_l2 <= 2e-3, (name, g_l2)
         assert bool((~bad | noise_level).all()), (name, float((w_got - w_ref).abs().max()))
         assert float(bad.float().mean()) <= 2e-2, (name, int(bad.sum()))
