@@ -158,13 +158,15 @@ def test_effb5_bf16_step_matches_bf16_oracle(H, W, B, nf, patch, Q, dout):
     arithmetic (oracle/bf16_mode.py: the fp32 oracle with both operands of every implicit-GEMM product rounded to bf16, RNE, fp32
     accumulation; fp32 weight gradients).
 
-    The bound.  Device and oracle round the same values with the same rule, so they differ only where an operand that differs by the
-    fp32 accumulation-order noise e ~ 1e-6 straddles a bf16 rounding boundary: probability e / 2^-8 per operand, error 2^-8 when it
-    happens, i.e. an rms contribution sqrt(e 2^-8) per operand and sqrt(e 2^-8 / K) on a K-term product; iterated over the layers this
-    settles at e* ~ 2^-8 / K ~ 1e-5 .. 1e-4 for K = 50 .. 500 reduction terms.  The bars — loss 1e-4, disparity 1e-3 of its maximum —
-    are 10x that and 10x BELOW the distance between the bf16 and fp32 arithmetics themselves (printed: disparity ~1e-2), so a wrong
-    BatchNorm statistic, a dropped bias or an unrounded operand cannot hide in them.  The fp32 oracle is evaluated too: the device's
-    distance to it must equal the bf16 oracle's distance to it within the same bars."""
+    The bound is MEASURED, not assumed.  Device and oracle round the same values with the same rule, so they differ only where an operand
+    that differs by fp32 accumulation-order noise (~1e-6) straddles a bf16 rounding boundary — but every such flip is a 2^-8 jump, and
+    a hundred layers amplify it: two evaluations of the bf16 oracle ITSELF whose weights differ by 1e-7 relative end 6e-3 .. 8e-3 apart in
+    the worst pixel of the predicted depth (5e-4 on average; measured on the host: 160x416), where two such evaluations of the fp32 oracle
+    end 3e-6 apart.  So the oracle is evaluated three times in bf16 arithmetic (as is, and twice with every weight times 1 + 1e-7 n):
+    the larger of the two distances is the arithmetic's own noise floor, and the device must lie within 2x of it in the maximum AND in the
+    mean.  That floor is ~5x (max) / ~8x (mean) BELOW the distance between the bf16 and the fp32 arithmetic (printed; asserted >= 3x in
+    the mean), so a wrong BatchNorm statistic, a dropped bias or an operand left unrounded cannot hide in it; the loss, an average over
+    all pixels, is held to 1e-4 (measured 1e-6 .. 2e-6)."""
     sys.path.insert(0, REPO)
     from oracle import torch_ref as O, bf16_mode as BM
     from options import MonodepthOptions
@@ -190,15 +192,20 @@ def test_effb5_bf16_step_matches_bf16_oracle(H, W, B, nf, patch, Q, dout):
         noise = torch.randn(B, 2, H, W)
         torch.set_num_threads(min(32, os.cpu_count() or 1))
         runs = {}
-        for mode in ("fp32", "bf16"):
+        for mode in ("fp32", "bf16", "bf16+1", "bf16+2"):
             enc = O.BaseEncoder(model_dim=32, num_features=nf)
             dep = O.QueryTrDecoder(32, 32, patch, 4, Q, dout, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
             pose = O.PoseCNN(2)
             for ref, mine in ((enc, tr.models["encoder"]), (dep, tr.models["depth"]), (pose, tr.models["pose"])):
                 ref.load_state_dict({k: v.detach().cpu() for k, v in mine.state_dict().items()})
                 ref.train()
+            if "+" in mode:                     # another draw of the rounding lottery: every weight times (1 + 1e-7 n)
+                g = torch.Generator().manual_seed(int(mode[-1]))
+                with torch.no_grad():
+                    for q in list(enc.parameters()) + list(dep.parameters()) + list(pose.parameters()):
+                        q.mul_(1 + 1e-7 * torch.randn(q.shape, generator=g))
             step = O.RefTrainStep(enc, dep, pose, (0, -1, 1), H, W)
-            if mode == "bf16":
+            if mode.startswith("bf16"):
                 with BM.bf16_operands(BM.gemm_modules(enc, dep, pose)):
                     out, losses = step.step(dict(cpu_inputs), noise)
             else:
@@ -215,18 +222,21 @@ def test_effb5_bf16_step_matches_bf16_oracle(H, W, B, nf, patch, Q, dout):
     got = float(losses["loss"])
     d = outputs[("disp", 0)].detach().cpu()
     (l32, d32, _), (l16, d16, nets16) = runs["fp32"], runs["bf16"]
-    dmax = float(d16.abs().max())
-    e_loss, e_disp = abs(got - l16) / abs(l16), float((d - d16).abs().max()) / dmax
-    gap_loss, gap_disp = abs(l16 - l32) / abs(l32), float((d16 - d32).abs().max()) / dmax
-    dev_gap = float((d - d32).abs().max()) / dmax
-    print("eff_b5 bf16 %dx%d: loss %.7f, bf16 oracle %.7f (rel %.2e), fp32 oracle %.7f; disparity vs bf16 oracle %.2e of max; "
-          "bf16 oracle vs fp32 oracle: loss %.2e, disparity %.2e (device vs fp32 oracle %.2e); plans %s"
-          % (H, W, got, l16, e_loss, l32, e_disp, gap_loss, gap_disp, dev_gap, mix))
+    dmax, dmean = float(d16.abs().max()), float(d16.abs().mean())
+
+    def dist(a, b):
+        return float((a - b).abs().max()) / dmax, float((a - b).abs().mean()) / dmean
+    e_loss = abs(got - l16) / abs(l16)
+    e_max, e_mean = dist(d, d16)
+    floor_max, floor_mean = [max(v) for v in zip(dist(runs["bf16+1"][1], d16), dist(runs["bf16+2"][1], d16))]
+    gap_max, gap_mean = dist(d16, d32)
+    print("eff_b5 bf16 %dx%d: loss %.7f, bf16 oracle %.7f (rel %.2e), fp32 oracle %.7f; disparity vs bf16 oracle: max %.2e / mean %.2e; "
+          "the bf16 oracle's own noise (weights * (1 + 1e-7 n), two draws): max %.2e / mean %.2e; bf16 oracle vs fp32 oracle: max %.2e / mean %.2e; plans %s"
+          % (H, W, got, l16, e_loss, l32, e_max, e_mean, floor_max, floor_mean, gap_max, gap_mean, mix))
     assert sum(mix.get("fwd", {}).values()) > 20, mix                       # the layers were timed
     assert e_loss <= 1e-4, (got, l16)
-    assert e_disp <= 1e-3, e_disp
-    assert gap_disp >= 10 * e_disp or gap_disp <= 1e-3, (gap_disp, e_disp)   # the test resolves the two arithmetics
-    assert abs(dev_gap - gap_disp) <= 1e-3 + 0.2 * gap_disp, (dev_gap, gap_disp)
+    assert e_max <= 2.0 * floor_max and e_mean <= 2.0 * floor_mean, (e_max, floor_max, e_mean, floor_mean)
+    assert gap_mean >= 3.0 * e_mean, (gap_mean, e_mean)                     # the test resolves the two arithmetics
     # gradients and BatchNorm state after the step (fp32 weight gradients of bf16-rounded data gradients): first / middle / last layers
     for net, name in (("encoder", "encoder.original_model.conv_stem.weight"), ("encoder", "encoder.original_model.blocks.2.1.conv_pw.weight"),
                       ("encoder", "encoder.original_model.blocks.4.3.bn2.weight"), ("encoder", "encoder.original_model.blocks.6.2.conv_pwl.weight"),
