@@ -45,6 +45,12 @@ __device__ __forceinline__ float __attribute__((ext_vector_type(2))) ldg2(const 
 __device__ __forceinline__ void stg(float *__restrict__ base, unsigned byte_off, float v) {
     *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
 }
+__device__ __forceinline__ void stg2(void *__restrict__ base, unsigned byte_off, float x, float y) {      // (32-bit byte offsets: the
+    *reinterpret_cast<float2 *>(reinterpret_cast<char *>(base) + byte_off) = make_float2(x, y);           //  scalar-base store forms)
+}
+__device__ __forceinline__ void stg2i(void *__restrict__ base, unsigned byte_off, int x, int y) {
+    *reinterpret_cast<int2 *>(reinterpret_cast<char *>(base) + byte_off) = make_int2(x, y);
+}
 __device__ __forceinline__ v2f splat(float x) { return v2f{x, x}; }
 __device__ __forceinline__ v2f pfma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 
@@ -256,8 +262,42 @@ struct SsimOut {
 };
 
 // SSIM + L1 of both predictions against the target from the window sums (already box-summed) and the centre row
+// Forward paths (identity maps, fused forward): the same quotient on the RAW window sums.  With mu = S / 49 every factor of
+// SSIM_n / SSIM_d carries 49^-2, which cancels: A1' = 2 Sw St + 49^2 C1, A2' = 2 (49 Swt - Sw St) + 49^2 C2, B1' = Sw^2 + St^2 + 49^2 C1,
+// B2' = 49 (Sww + Stt) - (Sw^2 + St^2) + 49^2 C2 — 11 packed instructions per colour instead of 18 (no means are formed), the
+// quotient as v_rcp + one Newton step on the quotient (<= 1 ulp of the correctly rounded value; the conditioning of the sigma
+// terms, 49 Sww - Sw^2 against 49^2 C2, is that of layers.py:35-46's own mu / sigma form).
+__device__ __forceinline__ v2f ssim_l1_fwd(const Sums &S, const Raw &ctr, int flags) {
+    constexpr float K1 = C1 * 2401.f, K2 = C2 * 2401.f;
+    v2f ssim_sum = splat(0.f), l1 = splat(0.f);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const float St = S.St[c];
+        const v2f Sw = S.Sw[c];
+        const v2f p = Sw * splat(St);
+        const v2f A1 = pfma(splat(2.f), p, splat(K1));
+        const v2f A2 = pfma(splat(2.f), pfma(splat(49.f), S.Swt[c], -p), splat(K2));
+        const v2f q = pfma(Sw, Sw, splat(St * St));
+        const v2f B1 = q + splat(K1), B2 = pfma(splat(49.f), S.Sq[c], splat(K2) - q);
+        const v2f num = A1 * A2, den = B1 * B2;
+        const v2f rd = v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+        const v2f q0 = num * rd;
+        const v2f Sv = pfma(pfma(-den, q0, num), rd, q0);
+        const v2f r = pfma(splat(-0.5f), Sv, splat(0.5f));
+        ssim_sum += v2f{__builtin_amdgcn_fmed3f(r.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(r.y, 0.f, 1.f)};      // torch.clamp(., 0, 1)
+        const v2f df = splat(ctr.t[c]) - ctr.w[c];
+        l1 += v2f{fabsf(df.x), fabsf(df.y)};
+    }
+    if (flags & SQD_LOSS_NO_SSIM) return l1 * splat(1.f / 3.f);          // --no_ssim: the L1 term alone (trainer.py:447-448)
+    return splat(0.85f) * (ssim_sum * splat(1.f / 3.f)) + splat(0.15f) * (l1 * splat(1.f / 3.f));
+}
+
 template <bool GRAD>
 __device__ __forceinline__ void ssim_l1(const Sums &S, const Raw &ctr, SsimOut &o, int flags) {
+    if constexpr (!GRAD) {
+        o.loss = ssim_l1_fwd(S, ctr, flags);
+        return;
+    }
     v2f ssim_sum = splat(0.f), l1 = splat(0.f);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -293,6 +333,53 @@ __device__ __forceinline__ void ssim_l1(const Sums &S, const Raw &ctr, SsimOut &
     if (flags & SQD_LOSS_NO_SSIM) o.loss = l1 * splat(1.f / 3.f);          // --no_ssim: the L1 term alone (trainer.py:447-448)
 }
 
+// the per-pixel minimum over [identity_0..S-1, reproj_0..S-1] (torch.cat + torch.min, first minimum wins: trainer.py:519-526) for the
+// pair's two reprojection losses, identity_selection, the argmin byte and the loss partial.
+// The argmin byte: < NS an identity map won (auto-mask: no gradient), NS + s reprojection of source s won; under --avg_reprojection NS
+// stands for "the mean of all reprojections" (every source, weight 1 / S)
+__device__ __forceinline__ void select_store(const sqd_photo_args &a, const PairPass &pp, v2f loss, int b, unsigned qo, unsigned HW, float &loss_acc) {
+    const int flags = a.loss_flags, NS = pp.S;
+    const bool avg = flags & SQD_LOSS_AVG_REPROJECTION;
+    float best;
+    int bi;
+    const bool automask = !(flags & SQD_LOSS_NO_AUTOMASK);
+    if (pp.first) {
+        best = INFINITY;                                           // --disable_automasking: no identity candidates (trainer.py:520-521)
+        bi = 0;
+        if (automask) {
+            const float *idm = a.identity + (size_t)b * (avg ? 1 : NS) * HW;
+            best = ldg(idm, qo * 4u);
+#pragma unroll
+            for (int i = 1; i < SQD_MAX_SOURCES; ++i)
+                if (i < NS && !avg) {
+                    const float v = ldg(idm, (qo + i * HW) * 4u);
+                    if (v < best) { best = v; bi = i; }
+                }
+        }
+    } else {                                                       // the running minimum of the earlier pairs
+        best = a.sel[(size_t)b * HW + qo];
+        bi = a.idx[(size_t)b * HW + qo];
+    }
+    if (avg) {
+        const float m = (loss.x + loss.y) * 0.5f;                  // trainer.py:508-509 (S = 2: one pair pass)
+        if (m < best) { best = m; bi = NS; }
+    } else {
+        if (loss.x < best) { best = loss.x; bi = NS + pp.s0; }
+        if (loss.y < best) { best = loss.y; bi = NS + pp.s1; }
+    }
+    if (a.reproj) {
+        a.reproj[((size_t)b * NS + pp.s0) * HW + qo] = loss.x;
+        a.reproj[((size_t)b * NS + pp.s1) * HW + qo] = loss.y;
+    }
+    if (pp.last) {
+        loss_acc += best;
+        if (a.sel) a.sel[(size_t)b * HW + qo] = bi >= NS ? 1.f : 0.f;   // trainer.py:529-530
+    } else {
+        a.sel[(size_t)b * HW + qo] = best;
+    }
+    if (a.idx) a.idx[(size_t)b * HW + qo] = (uint8_t)bi;
+}
+
 template <int MODE, int KIND>
 __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPass &pp, const float *noise, const Ctx<MODE> &k, Sums &S, const Raw &ctr,
                                            bool edge, int b, int yo, bool own, float &loss_acc) {
@@ -323,47 +410,7 @@ __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPa
             if (pp.s1 != pp.s0) stg(out, q1 * 4u, o.loss.y + (nz ? ldg(nz, q1 * 4u) : 0.f) * 0.00001f);
         }
     } else if (MODE == 1) {
-        // combined = [identity_0..S-1, reproj_0..S-1]; torch.min(dim 1): first minimum wins            trainer.py:519-526
-        // the argmin byte: < NS an identity map won (auto-mask: no gradient), NS + s reprojection of source s won; under
-        // --avg_reprojection NS stands for "the mean of all reprojections" (every source, weight 1 / S)
-        float best;
-        int bi;
-        const bool automask = !(flags & SQD_LOSS_NO_AUTOMASK);
-        if (pp.first) {
-            best = INFINITY;                                           // --disable_automasking: no identity candidates (trainer.py:520-521)
-            bi = 0;
-            if (automask) {
-                const float *idm = a.identity + (size_t)b * (avg ? 1 : NS) * HW;
-                best = ldg(idm, qo * 4u);
-#pragma unroll
-                for (int i = 1; i < SQD_MAX_SOURCES; ++i)
-                    if (i < NS && !avg) {
-                        const float v = ldg(idm, (qo + i * HW) * 4u);
-                        if (v < best) { best = v; bi = i; }
-                    }
-            }
-        } else {                                                       // the running minimum of the earlier pairs
-            best = a.sel[(size_t)b * HW + qo];
-            bi = a.idx[(size_t)b * HW + qo];
-        }
-        if (avg) {
-            const float m = (o.loss.x + o.loss.y) * 0.5f;              // trainer.py:508-509 (S = 2: one pair pass)
-            if (m < best) { best = m; bi = NS; }
-        } else {
-            if (o.loss.x < best) { best = o.loss.x; bi = NS + pp.s0; }
-            if (o.loss.y < best) { best = o.loss.y; bi = NS + pp.s1; }
-        }
-        if (a.reproj) {
-            a.reproj[((size_t)b * NS + pp.s0) * HW + qo] = o.loss.x;
-            a.reproj[((size_t)b * NS + pp.s1) * HW + qo] = o.loss.y;
-        }
-        if (pp.last) {
-            loss_acc += best;
-            if (a.sel) a.sel[(size_t)b * HW + qo] = bi >= NS ? 1.f : 0.f;   // trainer.py:529-530
-        } else {
-            a.sel[(size_t)b * HW + qo] = best;
-        }
-        if (a.idx) a.idx[(size_t)b * HW + qo] = (uint8_t)bi;
+        select_store(a, pp, o.loss, b, qo, HW, loss_acc);
     } else {
         // the planes are fully written: zeros where an identity candidate won (the first pass lays them down; a later pass
         // of a 3- or 4-source run only overwrites the pixels its own sources won), so the backward reads them unmasked
@@ -419,19 +466,33 @@ __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const PairPas
     }
 }
 
+
 // ---- phase 1 pieces ---------------------------------------------------------------------------------------------
+// One warped cell = one target pixel seen in both source views.  Round 4 layout of the arithmetic:
+//  * the projection / normalisation chain is the canonical fp32 order of oracle/warp_chain.c (layers.py:211-212,250-257), with two
+//    identities that leave every bit where it was: (gx + 1) * 0.5 * (W - 1) = fl(fl(2 t + 1) * (0.5 (W - 1))) for t = un - 0.5 (a product
+//    by 0.5 is exact, 0.5 (W - 1) is representable), and gx = t + t;
+//  * grid_sample's border rules need NO masks: the coordinate is clamped into [0, W - 1], so x0 + 1 can only leave the image when
+//    ix == W - 1 exactly, where ax = ix - floor(ix) is exactly 0 and with it the weights of both out-of-range taps (ATen skips those
+//    taps: adding 0 * finite is the same sum); likewise y.  The tap pairs are fetched through RAW BUFFER loads whose descriptor
+//    spans image b of the source: the pair (W - 1, W) of a row reads the first pixel of the next row or plane (finite image data,
+//    weight 0), the one pair that would leave the image reads 0 — no address clamp, no weight shift (round 3: 22 selects + 8 compares
+//    per cell);
+//  * the two taps of a row arrive in consecutive registers, so the blend multiplies PAIRS (nw, ne) * (wnw, wne) and adds the halves —
+//    2 packed + 1 scalar instruction per colour and source, no register shuffling (round 3 packed (source 0, source 1): 16 moves).
 struct Cell {
     v2f gx, gy;                      // normalised sampling grid (outputs[("sample", f, 0)]) of (source 0, source 1)
-    v2f wnw, wne, wsw, wse;          // bilinear weights; out-of-range taps carry weight exactly 0
-    unsigned a00, a10;               // offsets of the north and south tap PAIRS in source 0 (clamped into the image)
-    unsigned b00, b10;               // ... in source 1
+    v2f wn0, ws0, wn1, ws1;          // (west, east) bilinear weights of the north / south tap pair, source 0 and source 1
+    unsigned o0, o1;                 // byte offset of the north pair inside image b of source 0 / source 1
     int x00, y00, x01, y01;          // integer north-west taps
 };
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f bld2(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));      // 8 bytes, 4-byte aligned
+}
 
-// back-projection, projection into both source views and the grid_sample tap arithmetic for one cell — the canonical fp32
-// order of oracle/warp_chain.c (layers.py:211-212,250-257; ATen grid_sampler_2d with border padding, align_corners=True)
 __device__ __forceinline__ void project_cell(Cell &c, float d, float fx, float fy, const float *ik, const v2f *P, v2f rW, v2f rH,
-                                             float wm1, float hm1, int W, int H) {
+                                             float wm1, float hm1, int W) {
     float X[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -452,80 +513,134 @@ __device__ __forceinline__ void project_cell(Cell &c, float d, float fx, float f
     const v2f z = cam[2] + splat(1e-7f);
     const v2f rz = rcp_refined2(z);
     const v2f u = div_core2(cam[0], z, rz), v = div_core2(cam[1], z, rz);
-    const v2f un = div_core2(u, splat(wm1), rW), vn = div_core2(v, splat(hm1), rH);
-    c.gx = (un - splat(0.5f)) * splat(2.0f);
-    c.gy = (vn - splat(0.5f)) * splat(2.0f);
-    v2f ix = ((c.gx + splat(1.0f)) * splat(0.5f)) * splat(wm1);
-    v2f iy = ((c.gy + splat(1.0f)) * splat(0.5f)) * splat(hm1);
-    ix = v2f{fminf(wm1, fmaxf(ix.x, 0.f)), fminf(wm1, fmaxf(ix.y, 0.f))};
-    iy = v2f{fminf(hm1, fmaxf(iy.x, 0.f)), fminf(hm1, fmaxf(iy.y, 0.f))};
+    const v2f tx = div_core2(u, splat(wm1), rW) - splat(0.5f), ty = div_core2(v, splat(hm1), rH) - splat(0.5f);
+    c.gx = tx + tx;                                                     // (un - 0.5) * 2
+    c.gy = ty + ty;
+    v2f ix = pfma(splat(2.0f), tx, splat(1.0f)) * splat(0.5f * wm1);   // ((gx + 1) * 0.5) * (W - 1), bit for bit
+    v2f iy = pfma(splat(2.0f), ty, splat(1.0f)) * splat(0.5f * hm1);
+    ix = v2f{__builtin_amdgcn_fmed3f(ix.x, 0.f, wm1), __builtin_amdgcn_fmed3f(ix.y, 0.f, wm1)};      // border padding: clamp
+    iy = v2f{__builtin_amdgcn_fmed3f(iy.x, 0.f, hm1), __builtin_amdgcn_fmed3f(iy.y, 0.f, hm1)};
     const v2f fx0 = v2f{floorf(ix.x), floorf(ix.y)}, fy0 = v2f{floorf(iy.x), floorf(iy.y)};
     const v2f ax = ix - fx0, ay = iy - fy0;
     const v2f bx = (fx0 + splat(1.f)) - ix, by = (fy0 + splat(1.f)) - iy;
     c.x00 = (int)fx0.x; c.y00 = (int)fy0.x; c.x01 = (int)fx0.y; c.y01 = (int)fy0.y;
-    const bool xin0 = c.x00 + 1 < W, yin0 = c.y00 + 1 < H, xin1 = c.x01 + 1 < W, yin1 = c.y01 + 1 < H;
-    c.wnw = bx * by;
-    const v2f wne = ax * by, wsw = bx * ay, wse = ax * ay;
-    // out-of-range taps are skipped by grid_sample: weight exactly 0 and a clamped (in-range) address
-    c.wne = v2f{xin0 ? wne.x : 0.f, xin1 ? wne.y : 0.f};
-    c.wsw = v2f{yin0 ? wsw.x : 0.f, yin1 ? wsw.y : 0.f};
-    c.wse = v2f{(xin0 && yin0) ? wse.x : 0.f, (xin1 && yin1) ? wse.y : 0.f};
-    c.a00 = (unsigned)(c.y00 * W + c.x00);
-    c.b00 = (unsigned)(c.y01 * W + c.x01);
-    // The two taps of a row are 8 contiguous bytes: one load.  Where x0 is the last column (x0 + 1 out of range, its weight
-    // exactly 0) the pair starts one pixel earlier and the weight of x0 moves to the pair's second slot.
-    c.a00 -= xin0 ? 0u : 1u;
-    c.b00 -= xin1 ? 0u : 1u;
-    c.a10 = c.a00 + (yin0 ? (unsigned)W : 0u);
-    c.b10 = c.b00 + (yin1 ? (unsigned)W : 0u);
-    c.wne = v2f{xin0 ? c.wne.x : c.wnw.x, xin1 ? c.wne.y : c.wnw.y};
-    c.wnw = v2f{xin0 ? c.wnw.x : 0.f, xin1 ? c.wnw.y : 0.f};
-    c.wse = v2f{xin0 ? c.wse.x : c.wsw.x, xin1 ? c.wse.y : c.wsw.y};
-    c.wsw = v2f{xin0 ? c.wsw.x : 0.f, xin1 ? c.wsw.y : 0.f};
+    const v2f h0 = v2f{bx.x, ax.x}, h1 = v2f{bx.y, ax.y};             // (west, east) of source 0 / source 1
+    c.wn0 = h0 * splat(by.x); c.ws0 = h0 * splat(ay.x);
+    c.wn1 = h1 * splat(by.y); c.ws1 = h1 * splat(ay.y);
+    c.o0 = (unsigned)(c.y00 * W + c.x00) * 4u;
+    c.o1 = (unsigned)(c.y01 * W + c.x01) * 4u;
 }
 
-__device__ __forceinline__ void gather_taps(const Cell &c, const float *__restrict__ src0, const float *__restrict__ src1, unsigned HW,
-                                            v2f t[3][4]) {
+// the twelve tap pairs of a cell (2 sources x 3 colours x north / south), issued back to back
+__device__ __forceinline__ void gather_taps(const Cell &c, __amdgpu_buffer_rsrc_t r0, __amdgpu_buffer_rsrc_t r1, unsigned HW4, unsigned W4,
+                                            v2f t0[3][2], v2f t1[3][2]) {
+    const unsigned s0 = c.o0 + W4, s1 = c.o1 + W4;
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        const unsigned co = ch * HW;
-        const v2f n0 = ldg2(src0, (c.a00 + co) * 4u), n1 = ldg2(src1, (c.b00 + co) * 4u);
-        const v2f s0 = ldg2(src0, (c.a10 + co) * 4u), s1 = ldg2(src1, (c.b10 + co) * 4u);
-        t[ch][0] = v2f{n0.x, n1.x};
-        t[ch][1] = v2f{n0.y, n1.y};
-        t[ch][2] = v2f{s0.x, s1.x};
-        t[ch][3] = v2f{s0.y, s1.y};
+        t0[ch][0] = bld2(r0, c.o0, ch * HW4);
+        t1[ch][0] = bld2(r1, c.o1, ch * HW4);
+        t0[ch][1] = bld2(r0, s0, ch * HW4);
+        t1[ch][1] = bld2(r1, s1, ch * HW4);
     }
 }
 
+// west + east half of a blended pair: a plain v_add_f32 (kept out of the SLP vectorizer's reach — it would pair the six adds of a cell
+// into three packed ones behind nine register moves)
+__device__ __forceinline__ float hadd(v2f a) {
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a.x), "v"(a.y));
+    return r;
+}
+__device__ __forceinline__ v2f blend_taps(const Cell &c, const v2f t0[2], const v2f t1[2]) {
+    const v2f a = pfma(t0[1], c.ws0, t0[0] * c.wn0), b = pfma(t1[1], c.ws1, t1[0] * c.wn1);
+    return v2f{hadd(a), hadd(b)};
+}
+
+// what phase 1 stores to HBM for the cells a tile owns; resolved once per tile (round 3 re-read six pointers from the kernel
+// arguments for every row, an s_load + wait each)
+struct WarpOut {
+    float2 *smp0, *smp1;             // image b of sample[s0] / sample[s1] (nullptr: not stored)
+    int2 *tap0, *tap1;
+    float *w0, *w1;                  // image b of warped[s0] / warped[s1]
+};
+
 // bilinear blend, the tile's LDS row, and — for cells the tile owns — sample / warped / taps in HBM
-__device__ __forceinline__ void finish_cell(const sqd_photo_args &a, const PairPass &pp, const Cell &c, const v2f t[3][4], v2f *wl, int r, int lane,
-                                            bool col_ok, bool own, int b, unsigned HW, unsigned off) {
+template <bool VIRT>
+__device__ __forceinline__ void finish_cell(const WarpOut &o, const Cell &c, const v2f t0[3][2], const v2f t1[3][2], v2f *wl, int r, int lane,
+                                            bool col_ok, bool own, unsigned HW, unsigned off) {
     v2f wv[3];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
-        v2f acc = t[ch][0] * c.wnw;
-        acc = pfma(t[ch][1], c.wne, acc);
-        acc = pfma(t[ch][2], c.wsw, acc);
-        acc = pfma(t[ch][3], c.wse, acc);
-        wv[ch] = acc;
-        wl[(r * 3 + ch) * 64 + lane] = col_ok ? acc : splat(0.f);      // (lanes beyond a narrow image: zeros for the shuffles)
+        wv[ch] = blend_taps(c, t0[ch], t1[ch]);
+        // (lanes beyond a narrow image carry zeros for the shuffles)
+        wl[(r * 3 + ch) * 64 + lane] = (!VIRT || col_ok) ? wv[ch] : splat(0.f);
     }
     if (own) {
-        const size_t q = (size_t)b * HW + off;
-        const bool two = pp.s1 != pp.s0;
-        if (a.sample[pp.s0]) *reinterpret_cast<float2 *>(a.sample[pp.s0] + q * 2) = make_float2(c.gx.x, c.gy.x);
-        if (two && a.sample[pp.s1]) *reinterpret_cast<float2 *>(a.sample[pp.s1] + q * 2) = make_float2(c.gx.y, c.gy.y);
-        if (a.x0y0[pp.s0]) *reinterpret_cast<int2 *>(a.x0y0[pp.s0] + q * 2) = make_int2(c.x00, c.y00);
-        if (two && a.x0y0[pp.s1]) *reinterpret_cast<int2 *>(a.x0y0[pp.s1] + q * 2) = make_int2(c.x01, c.y01);
-        if (a.warped[pp.s0]) {
-            float *w0 = a.warped[pp.s0] + (size_t)b * 3 * HW, *w1 = a.warped[pp.s1] + (size_t)b * 3 * HW;
+        if (o.smp0) stg2(o.smp0, off * 8u, c.gx.x, c.gy.x);
+        if (o.smp1) stg2(o.smp1, off * 8u, c.gx.y, c.gy.y);
+        if (o.tap0) stg2i(o.tap0, off * 8u, c.x00, c.y00);
+        if (o.tap1) stg2i(o.tap1, off * 8u, c.x01, c.y01);
+        if (o.w0) {
 #pragma unroll
-            for (int ch = 0; ch < 3; ++ch) {
-                stg(w0, (off + ch * HW) * 4u, wv[ch].x);
-                if (two) stg(w1, (off + ch * HW) * 4u, wv[ch].y);
-            }
+            for (int ch = 0; ch < 3; ++ch) stg(o.w0, (off + ch * HW) * 4u, wv[ch].x);
         }
+        if (o.w1) {
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) stg(o.w1, (off + ch * HW) * 4u, wv[ch].y);
+        }
+    }
+}
+
+// phase 1 of a tile: every cell of the tile + halo is warped once, rows dealt round-robin to the NW waves; the depth of a wave's next
+// row is fetched under the current row's projection
+template <int NW, bool VIRT>
+__device__ __forceinline__ void warp_tile(const sqd_photo_args &a, const PairPass &pp, v2f *wl, int b, int y0, int own_rows, int xr, bool col_ok,
+                                          bool own_col, int lane, int wave) {
+    const int H = a.H, W = a.W;
+    const unsigned HW = (unsigned)(H * W);
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    const float *__restrict__ dep = a.depth + (size_t)b * HW;
+    const unsigned img_bytes = 3u * HW * 4u;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sources[pp.s0] + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sources[pp.s1] + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
+    const bool two = pp.s1 != pp.s0;
+    WarpOut o;
+    o.smp0 = a.sample[pp.s0] ? reinterpret_cast<float2 *>(a.sample[pp.s0]) + (size_t)b * HW : nullptr;
+    o.smp1 = two && a.sample[pp.s1] ? reinterpret_cast<float2 *>(a.sample[pp.s1]) + (size_t)b * HW : nullptr;
+    o.tap0 = a.x0y0[pp.s0] ? reinterpret_cast<int2 *>(a.x0y0[pp.s0]) + (size_t)b * HW : nullptr;
+    o.tap1 = two && a.x0y0[pp.s1] ? reinterpret_cast<int2 *>(a.x0y0[pp.s1]) + (size_t)b * HW : nullptr;
+    o.w0 = a.warped[pp.s0] ? a.warped[pp.s0] + (size_t)b * 3 * HW : nullptr;
+    o.w1 = two && a.warped[pp.s0] ? a.warped[pp.s1] + (size_t)b * 3 * HW : nullptr;
+    float ik[9];
+    v2f P[12];                       // (source 0, source 1) projection matrices
+    // (read through the constant address space: wave-uniform, never written by this launch — scalar loads into SGPRs whatever the
+    //  compiler can or cannot prove about the output pointers)
+    typedef const __attribute__((address_space(4))) float *cfp;
+    const cfp ikp = (cfp)(a.inv_K + (size_t)b * 16);
+    const cfp p0 = (cfp)(a.P + ((size_t)b * pp.S + pp.s0) * 12), p1 = (cfp)(a.P + ((size_t)b * pp.S + pp.s1) * 12);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ik[i * 3 + j] = ikp[i * 4 + j];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) P[j] = v2f{p0[j], p1[j]};
+    const v2f rW = splat(rcp_refined(wm1)), rH = splat(rcp_refined(hm1));
+    const int xc = VIRT ? min(max(xr, 0), W - 1) : xr;      // (lanes beyond a narrow image compute a valid column and store zeros)
+    const float fx = (float)xc;
+    // rows of the tile + halo that lie inside the image (rows outside are reflections of rows inside the tile): r_lo .. r_hi
+    const int r_lo = max(0, 3 - y0), r_hi = min(own_rows + 6, H - y0 + 3);
+    int r = r_lo + wave;
+    float d_next = r < r_hi ? ldg(dep, (unsigned)((y0 - 3 + r) * W + xc) * 4u) : 0.f;
+    for (; r < r_hi; r += NW) {
+        const int yA = y0 - 3 + r;
+        const unsigned off = (unsigned)(yA * W + xc);
+        const float d = d_next;
+        if (r + NW < r_hi) d_next = ldg(dep, (off + (unsigned)(NW * W)) * 4u);
+        Cell c;
+        project_cell(c, d, fx, (float)yA, ik, P, rW, rH, wm1, hm1, W);
+        v2f t0[3][2], t1[3][2];
+        gather_taps(c, r0, r1, HW * 4u, (unsigned)W * 4u, t0, t1);
+        finish_cell<VIRT>(o, c, t0, t1, wl, r, lane, col_ok, own_col && r >= 3 && r < own_rows + 3, HW, off);
     }
 }
 
@@ -552,33 +667,9 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_
 
     if (MODE == 1) {
         // ---------------------------------------------------------------- phase 1: warp every cell of the tile once
-        const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
-        const float *__restrict__ dep = a.depth + (size_t)b * HW;
-        const float *__restrict__ src0 = a.sources[pp.s0] + (size_t)b * 3 * HW;
-        const float *__restrict__ src1 = a.sources[pp.s1] + (size_t)b * 3 * HW;
-        float ik[9];
-        v2f P[12];                       // (source 0, source 1) projection matrices
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 3; ++j) ik[i * 3 + j] = a.inv_K[(size_t)b * 16 + i * 4 + j];
-#pragma unroll
-        for (int j = 0; j < 12; ++j) P[j] = v2f{a.P[((size_t)b * pp.S + pp.s0) * 12 + j], a.P[((size_t)b * pp.S + pp.s1) * 12 + j]};
-        const v2f rW = splat(rcp_refined(wm1)), rH = splat(rcp_refined(hm1));
-        const int xc = min(max(xr, 0), W - 1);             // (lanes beyond a narrow image compute a valid column and store zeros)
-        const float fx = (float)xc;
-        const int nrow = own_rows + 6;
-        for (int r = wave; r < nrow; r += NW) {
-            Cell cA;
-            const int yA = y0 - 3 + r;
-            if (yA < 0 || yA >= H) continue;                 // (rows outside the image are reflections of rows inside the tile)
-            const unsigned offA = (unsigned)(yA * W + xc);
-            const float dA = ldg(dep, offA * 4u);
-            project_cell(cA, dA, fx, (float)yA, ik, P, rW, rH, wm1, hm1, W, H);
-            v2f tA[3][4];
-            gather_taps(cA, src0, src1, HW, tA);
-            finish_cell(a, pp, cA, tA, wl, r, lane, col_ok, own_col && r >= 3 && r < own_rows + 3, b, HW, offA);
-        }
+        // (images of fewer than 64 columns: lanes of a strip lie outside the image — they compute a clamped column and store zeros)
+        if (W < 64) warp_tile<NW, true>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
+        else warp_tile<NW, false>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
         __syncthreads();
     }
 
