@@ -245,8 +245,11 @@ def test_effb5_bf16_step_matches_bf16_oracle(H, W, B, nf, patch, Q, dout):
         g_ref = dict(nets16[net].named_parameters())[name].grad
         g_got = dict(tr.models[net].named_parameters())[name].grad.detach().cpu()
         g_l2 = float((g_got - g_ref).norm() / g_ref.norm())
-        print("%-60s gradient L2 err vs bf16 oracle %.2e" % (name, g_l2))
-        assert g_l2 <= 2e-2, (name, g_l2)
+        # the same yardstick as for the disparity: how far the bf16 oracle's own gradient moves under the 1e-7 weight perturbations (the
+        # trunk's first layers sit at the end of the longest chain of rounded products: the stem's gradient moves by ~10 %)
+        floor = max(float((dict(runs[m][2][net].named_parameters())[name].grad - g_ref).norm() / g_ref.norm()) for m in ("bf16+1", "bf16+2"))
+        print("%-60s gradient L2 err vs bf16 oracle %.2e (the oracle's own noise %.2e)" % (name, g_l2, floor))
+        assert g_l2 <= max(2.0 * floor, 2e-3), (name, g_l2, floor)
     rm = tr.models["encoder"].encoder.original_model.blocks[3][2].bn1.running_var.cpu()
     rr = nets16["encoder"].encoder.original_model.blocks[3][2].bn1.running_var
     assert float((rm - rr).abs().max() / rr.abs().max()) < 1e-3
