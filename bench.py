@@ -50,10 +50,10 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r03_pmc_traffic.json")
+PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r04_pmc_traffic.json")
 
 
-def roofline_fused_fwd(trainer, batches, iters=200):
+def roofline_fused_fwd(trainer, batches, iters=200, graph_us=None):
     """Average duration of the fused warp+SSIM forward launch, HIP events on the launch stream."""
     from sqd import ops
     o = trainer.opt
@@ -109,6 +109,11 @@ def roofline_fused_fwd(trainer, batches, iters=200):
     # THE figure of the record (frac / achieved / us_per_launch) is the launch inside training steps; the back-to-back relaunch of one
     # Infinity-Cache-resident working set is reported beside it as cache_resident.  (Multi-rank runs have no eager in-step probe:
     # there the cache-resident figure stands in and `timing` says so.)
+    # (best: the kernel's duration inside the REPLAYED graph steps — what a kernel trace of the timed loop shows; eager steps leave the
+    #  device idle half of the time and its clocks lower: the eager probe reads 10-30 % slow and is only the fallback)
+    eager_us = None if in_step is None else round(in_step * 1e6, 2)
+    if graph_us:
+        in_step = graph_us * 1e-6
     t = in_step if in_step is not None else hot
     achieved = FUSED_FWD_BYTES_PER_PX * px / t / 1e9
     # HBM-side bytes per launch from separate rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE passes (tools/pmc_traffic.py, corrected
@@ -127,7 +132,10 @@ def roofline_fused_fwd(trainer, batches, iters=200):
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_bytes_per_launch": traffic_bytes, "traffic_source": note,
             "us_per_launch": round(t * 1e6, 2),
-            "timing": ("median of 10 launches, HIP events on the launch stream around the launch inside eager training steps (rotating batches)"
+            "us_per_launch_eager_steps": eager_us,
+            "timing": ("average duration of the launch inside replayed hipGraph training steps (device activity records of 4 steps, child process); "
+                       "us_per_launch_eager_steps = median of 10 launches bracketed by HIP events on the launch stream inside EAGER steps" if graph_us else
+                       "median of 10 launches, HIP events on the launch stream around the launch inside eager training steps (rotating batches)"
                        if in_step is not None else
                        "no in-step probe in a multi-rank run: HIP events around %d back-to-back launches of one working set" % iters),
             "cache_resident": {
@@ -350,15 +358,18 @@ def gpu_state(index=0):
         r = subprocess.run(["rocm-smi", "-d", str(index), "-c", "-P", "-M", "--json"], capture_output=True, text=True, timeout=20)
         rec = json.loads(r.stdout)
         card = rec.get("card%d" % index) or next(iter(rec.values()))
+        def mhz(v):
+            digits = "".join(ch for ch in str(v) if ch.isdigit())
+            return int(digits) if digits else str(v)
         for k, v in card.items():
             kl = k.lower()
-            if "sclk" in kl:
-                out["gpu_sclk_mhz"] = int("".join(ch for ch in str(v).split("Mhz")[0].split("(")[-1] if ch.isdigit()) or 0) or str(v)
-            elif "mclk" in kl:
-                out["gpu_mclk_mhz"] = int("".join(ch for ch in str(v).split("Mhz")[0].split("(")[-1] if ch.isdigit()) or 0) or str(v)
+            if "sclk clock speed" in kl:
+                out["gpu_sclk_mhz"] = mhz(v)
+            elif "mclk clock speed" in kl:
+                out["gpu_mclk_mhz"] = mhz(v)
             elif "max" in kl and "power" in kl:
                 out["power_cap_w"] = float(v) if str(v).replace(".", "", 1).isdigit() else str(v)
-            elif "power" in kl and "w" in kl:
+            elif "power" in kl and "(w)" in kl:
                 out["power_w"] = float(v) if str(v).replace(".", "", 1).isdigit() else str(v)
     except Exception as e:                              # noqa: BLE001 — reporting only
         out["error"] = "%s: %s" % (type(e).__name__, e)
@@ -399,8 +410,13 @@ def kernel_sum_child():
             tr.train_step(dict(batches[i % NBATCH]))
         torch.cuda.synchronize()
     evs = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
-    total_us = sum(e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total for e in evs)
+
+    def dur(e):
+        return e.device_time_total if hasattr(e, "device_time_total") else e.cuda_time_total
+    total_us = sum(dur(e) for e in evs)
+    judged = [dur(e) for e in evs if "photo_tile_kernel<1" in e.name]
     print(json.dumps({"kernel_ms_per_step": round(total_us / n / 1e3, 3), "device_events_per_step": round(len(evs) / n, 1),
+                      "fused_fwd_us_in_graph": round(sum(judged) / len(judged), 2) if judged else None, "fused_fwd_launches": len(judged),
                       "source": "torch.profiler device activity over %d replayed steps (kernels + copies), separate process" % n}))
 
 
@@ -466,7 +482,32 @@ def main():
 
     state0 = gpu_state(trainer.local_rank) if rank == 0 else None
     elapsed, losses = time_steps(trainer, batches, args.steps, args.warmup, sync)
-    state1 = gpu_state(trainer.local_rank) if rank == 0 else None
+    state1 = None
+    if rank == 0 and world == 1 and not args.no_diagnostics:
+        # shader clock and power UNDER LOAD: rocm-smi polled from a thread while the same steps keep running (outside the timed region)
+        import threading
+        samples, stop = [], threading.Event()
+
+        def poll():
+            while not stop.is_set():
+                samples.append(gpu_state(trainer.local_rank))
+        th = threading.Thread(target=poll, daemon=True)
+        th.start()
+        t_end = time.perf_counter() + 2.5
+        i = 0
+        while time.perf_counter() < t_end:
+            trainer.train_step(dict(batches[i % len(batches)]))
+            i += 1
+            if i % 20 == 0:
+                torch.cuda.synchronize()
+        torch.cuda.synchronize()
+        stop.set()
+        th.join(timeout=10)
+        clk = sorted(x["gpu_sclk_mhz"] for x in samples if isinstance(x.get("gpu_sclk_mhz"), int))
+        pw = sorted(x["power_w"] for x in samples if isinstance(x.get("power_w"), float))
+        state1 = {"samples": len(samples), "gpu_sclk_mhz_median": clk[len(clk) // 2] if clk else None, "gpu_sclk_mhz_min": clk[0] if clk else None,
+                  "gpu_sclk_mhz_max": clk[-1] if clk else None, "power_w_median": pw[len(pw) // 2] if pw else None,
+                  "power_cap_w": next((x.get("power_cap_w") for x in samples if "power_cap_w" in x), None)}
     if ddp.COMM is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         ddp.COMM.all_reduce(t, "max")
@@ -486,6 +527,9 @@ def main():
                     "mode": {"eager": "eager hooks", "overlap": "all-reduces captured in the step graph",
                              "post": "graph of forward+backward, then all-reduce + Adam"}.get(trainer.graph_mode(), trainer.graph_mode())}
 
+    ktime = None
+    if rank == 0 and world == 1 and not args.no_diagnostics:
+        ktime = kernel_time_per_step()
     roof = None
     if rank == 0 and not args.no_roofline:
         # the dominant kernel of the configuration that ran: the fused warp+SSIM forward (the kernel BASELINE.json's target names)
@@ -495,10 +539,10 @@ def main():
         elif opts.backbone.startswith("convnext"):
             roof = roofline_mlp_gemm(trainer)
         else:
-            roof = roofline_fused_fwd(trainer, batches)
+            roof = roofline_fused_fwd(trainer, batches, graph_us=(ktime or {}).get("fused_fwd_us_in_graph"))
     diag = None
     if rank == 0 and world == 1 and not args.no_diagnostics:
-        diag = {"gpu_before": state0, "gpu_after_timed_loop": state1, "kernel_time": kernel_time_per_step()}
+        diag = {"gpu_idle_before": state0, "gpu_under_load": state1, "kernel_time": ktime}
         if plan_path is not None:
             # what this box's own plan timing would have chosen, and what that is worth here: a second Trainer without the pinned set
             del trainer

@@ -32,7 +32,7 @@ extern "C" {
 
 /* the reference's loss options (options.py --no_ssim / --avg_reprojection / --disable_automasking; trainer.py:447-451, 480-524) */
 #define SQD_LOSS_NO_SSIM 1           /* reprojection loss = L1 alone                                                             */
-#define SQD_LOSS_AVG_REPROJECTION 2  /* mean over the source frames instead of the per-pixel minimum (two source frames)          */
+#define SQD_LOSS_AVG_REPROJECTION 2  /* mean over the S >= 2 source frames instead of the per-pixel minimum                       */
 #define SQD_LOSS_NO_AUTOMASK 4       /* no identity candidates: the minimum runs over the reprojection losses only                */
 #define SQD_MAX_SOURCES 4 /* source frames per target (reference frame_ids[1:], default 2) */
 #define SQD_STRIP_COLS 58 /* output columns per wavefront strip of the column-march kernels */
@@ -112,7 +112,7 @@ int sqd_photo_fwd(const sqd_photo_args *a);
 int sqd_identity_fwd(const float *target, const float *const *sources_host, const float *noise, float *identity,
                      int B, int S, int H, int W, int rows_per_task, void *stream);
 /* the same under loss options: SQD_LOSS_NO_SSIM -> L1 maps; SQD_LOSS_AVG_REPROJECTION -> identity and noise are [B,1,H,W]: ONE map per
- * image, the mean over the two sources + 1e-5 * noise (sqd_photo_fwd reads identity in that layout under the same flag)        */
+ * image, the mean over the S sources + 1e-5 * noise (sqd_photo_fwd reads identity in that layout under the same flag)          */
 int sqd_identity_fwd_ex(const float *target, const float *const *sources_host, const float *noise, float *identity,
                         int B, int S, int H, int W, int rows_per_task, int loss_flags, void *stream);
 
@@ -123,8 +123,8 @@ int sqd_identity_fwd_ex(const float *target, const float *const *sources_host, c
  * training-only traffic.                                                                                                */
 int sqd_photo_coef(const float *target, const float *const *warped_host, const uint8_t *idx, float *coef, int B, int S, int H,
                    int W, int rows_per_task, void *stream);
-/* under loss options: SQD_LOSS_NO_SSIM -> zeros; SQD_LOSS_AVG_REPROJECTION -> coef [B,18,H,W]: planes 0..8 source 0, 9..17 source 1, each
- * with weight 1/2 where the mean reprojection won                                                                               */
+/* under loss options: SQD_LOSS_NO_SSIM -> zeros; SQD_LOSS_AVG_REPROJECTION -> coef [B,9 S,H,W]: planes 9 s .. 9 s + 8 belong to source s,
+ * each with weight 1/S where the mean reprojection won (sqd_photo_bwd reads them in that layout under the same flag)            */
 int sqd_photo_coef_ex(const float *target, const float *const *warped_host, const uint8_t *idx, float *coef, int B, int S, int H,
                       int W, int rows_per_task, int loss_flags, void *stream);
 

@@ -343,7 +343,10 @@ __device__ __forceinline__ void select_store(const sqd_photo_args &a, const Pair
     float best;
     int bi;
     const bool automask = !(flags & SQD_LOSS_NO_AUTOMASK);
-    if (pp.first) {
+    if (avg) {
+        best = INFINITY;                                           // (set below, by the last pair pass)
+        bi = 0;
+    } else if (pp.first) {
         best = INFINITY;                                           // --disable_automasking: no identity candidates (trainer.py:520-521)
         bi = 0;
         if (automask) {
@@ -361,7 +364,22 @@ __device__ __forceinline__ void select_store(const sqd_photo_args &a, const Pair
         bi = a.idx[(size_t)b * HW + qo];
     }
     if (avg) {
-        const float m = (loss.x + loss.y) * 0.5f;                  // trainer.py:508-509 (S = 2: one pair pass)
+        // trainer.py:508-509: the mean over the S reprojection losses is the one reprojection candidate.  More than two sources: the sum
+        // travels through `sel` between the pair passes, the identity candidate is only looked at by the last one
+        float sum = pp.s1 != pp.s0 ? loss.x + loss.y : loss.x;
+        if (!pp.first) sum += a.sel[(size_t)b * HW + qo];
+        if (!pp.last) {
+            if (a.reproj) {
+                a.reproj[((size_t)b * NS + pp.s0) * HW + qo] = loss.x;
+                a.reproj[((size_t)b * NS + pp.s1) * HW + qo] = loss.y;
+            }
+            a.sel[(size_t)b * HW + qo] = sum;
+            return;
+        }
+        const float m = NS == 2 ? sum * 0.5f : sum / (float)NS;
+        best = INFINITY;
+        bi = 0;
+        if (automask) best = ldg(a.identity + (size_t)b * HW, qo * 4u);
         if (m < best) { best = m; bi = NS; }
     } else {
         if (loss.x < best) { best = loss.x; bi = NS + pp.s0; }
@@ -403,8 +421,12 @@ __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPa
         float *out = a.sel + (size_t)b * NI * HW;                      // (the identity maps travel through `sel`)
         const float *nz = noise ? noise + (size_t)b * NI * HW : nullptr;
         const unsigned q0 = qo + (unsigned)pp.s0 * HW, q1 = qo + (unsigned)pp.s1 * HW;
-        if (avg) {       // --avg_reprojection: ONE identity map per image, the mean over the two sources (trainer.py:489-490)
-            stg(out, q0 * 4u, (o.loss.x + o.loss.y) * 0.5f + (nz ? ldg(nz, q0 * 4u) : 0.f) * 0.00001f);
+        if (avg) {       // --avg_reprojection: ONE identity map per image, the mean over the S sources (trainer.py:489-490); more than
+            //              two sources: the sum travels through the output plane from pair pass to pair pass
+            float sum = pp.s1 != pp.s0 ? o.loss.x + o.loss.y : o.loss.x;
+            if (!pp.first) sum += ldg(out, qo * 4u);
+            if (pp.last) sum = (NS == 2 ? sum * 0.5f : sum / (float)NS) + (nz ? ldg(nz, qo * 4u) : 0.f) * 0.00001f;
+            stg(out, qo * 4u, sum);
         } else {
             stg(out, q0 * 4u, o.loss.x + (nz ? ldg(nz, q0 * 4u) : 0.f) * 0.00001f);              // trainer.py:514-517
             if (pp.s1 != pp.s0) stg(out, q1 * 4u, o.loss.y + (nz ? ldg(nz, q1 * 4u) : 0.f) * 0.00001f);
@@ -416,13 +438,14 @@ __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPa
         // of a 3- or 4-source run only overwrites the pixels its own sources won), so the backward reads them unmasked
         const int bi = a.idx[(size_t)b * HW + qo];
         const float scale = (flags & SQD_LOSS_NO_SSIM) ? 0.f : 0.85f / 3.f;          // --no_ssim: no window terms at all
-        if (avg) {                         // both sources carry half of the gradient wherever the mean reprojection won: 18 planes
+        if (avg) {                         // every source carries 1 / S of the gradient wherever the mean reprojection won: 9 S planes
             const bool won = bi == NS;
-            float *co = a.coef + (size_t)b * 18 * HW;
+            float *co = a.coef + (size_t)b * 9 * NS * HW;
+            const float sc = scale / (float)NS;
 #pragma unroll
             for (int j = 0; j < 9; ++j) {
-                stg(co, (qo + j * HW) * 4u, won ? o.g0[j] * (scale * 0.5f) : 0.f);
-                stg(co, (qo + (9 + j) * HW) * 4u, won ? o.g1[j] * (scale * 0.5f) : 0.f);
+                stg(co, (qo + (9 * pp.s0 + j) * HW) * 4u, won ? o.g0[j] * sc : 0.f);
+                if (pp.s1 != pp.s0) stg(co, (qo + (9 * pp.s1 + j) * HW) * 4u, won ? o.g1[j] * sc : 0.f);
             }
             return;
         }
@@ -846,7 +869,8 @@ __device__ __forceinline__ void bwd_rows(int KIND, const sqd_photo_bwd_args &a, 
     // argmin codes of the pair's reprojection candidates (--avg_reprojection: NS = the mean of both: the two sources read their own
     // nine planes of the 18 sqd_photo_coef wrote)
     const int id0 = avg ? NS : NS + pp.s0, id1 = avg ? NS : two ? NS + pp.s1 : -1;
-    const unsigned c1off = 9u * HW;
+    // --avg_reprojection: the planes of source s start at 9 s HW (sqd_photo_coef wrote 9 S of them)
+    const unsigned c0off = avg ? 9u * (unsigned)pp.s0 * HW : 0u, c1off = avg ? 9u * (unsigned)pp.s1 * HW : 0u;
     for (int j = wave; j < own_rows; j += 4) {
         const int q = y0 + j;
         float G0[9], G1[9];
@@ -871,7 +895,7 @@ __device__ __forceinline__ void bwd_rows(int KIND, const sqd_photo_bwd_args &a, 
             const float w0 = id == id0 ? m : 0.f, w1 = id == id1 ? m : 0.f;
 #pragma unroll
             for (int c = 0; c < 9; ++c) {
-                const float v = bld(coef_r, vo, (row + (unsigned)c * HW) * 4u);
+                const float v = bld(coef_r, vo, (row + (unsigned)c * HW + c0off) * 4u);
                 G0[c] = fmaf(w0, v, G0[c]);
                 if constexpr (avg) G1[c] = fmaf(w1, bld(coef_r, vo, (row + (unsigned)c * HW + c1off) * 4u), G1[c]);
                 else G1[c] = fmaf(w1, v, G1[c]);
@@ -930,12 +954,12 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_tile_kernel(sqd_photo_bwd_ar
     const int x = sx.x0 + lane;
     const bool in_col = x >= 0 && x < W;
     const bool own_col = x >= sx.own0 && x < sx.own1 && in_col;
-    constexpr unsigned ncoef = AVG ? 18u : 9u;
+    const unsigned ncoef = AVG ? 9u * (unsigned)pp.S : 9u;
     const __amdgpu_buffer_rsrc_t coef_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.coef + (size_t)b * ncoef * HW), 0, ncoef * HW * 4u, 0x00020000);
     const __amdgpu_buffer_rsrc_t idx_r = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(a.idx + (size_t)b * HW), 0, HW, 0x00020000);
     BwdPix k;
     k.wm1 = (float)(W - 1); k.hm1 = (float)(H - 1); k.gscale = a.gscale; k.W = W; k.H = H; k.HW = HW;
-    k.l1w = ((a.loss_flags & SQD_LOSS_NO_SSIM) ? 1.f / 3.f : 0.15f / 3.f) * (AVG ? 0.5f : 1.f);
+    k.l1w = ((a.loss_flags & SQD_LOSS_NO_SSIM) ? 1.f / 3.f : 0.15f / 3.f) * (AVG ? 1.f / (float)pp.S : 1.f);
     float *gdep = a.g_depth + (size_t)b * a.g_depth_img_stride + (size_t)pass * HW;
     float gP0[12], gP1[12];
 #pragma unroll

@@ -44,7 +44,7 @@ extern "C" int sqd_photo_bwd_ntasks(int B, int S, int H, int W, int rows_per_tas
 
 static int check_loss_flags(const char *who, int flags, int S) {
     SQD_CHECK_ARG((flags & ~7) == 0, "%s: unknown loss_flags %d", who, flags);
-    SQD_CHECK_ARG(!(flags & SQD_LOSS_AVG_REPROJECTION) || S == 2, "%s: avg_reprojection is implemented for two source frames (S=%d)", who, S);
+    SQD_CHECK_ARG(!(flags & SQD_LOSS_AVG_REPROJECTION) || S >= 2, "%s: avg_reprojection needs at least two source frames (the mean over one is that frame: drop the flag; S=%d)", who, S);
     return SQD_OK;
 }
 

@@ -167,11 +167,11 @@ def photo_fwd_relaunch(a):
 
 def photo_coef(target, warped, idx, rows_per_task=0, loss_flags=0):
     """d(to_optimise)/d(window sums) of the winning source from the stored warped images -> coef [B,9,H,W]
-    ([B,18,H,W] under LOSS_AVG_REPROJECTION: nine planes per source)."""
+    ([B,9 S,H,W] under LOSS_AVG_REPROJECTION: nine planes per source)."""
     _req(target, idx, *warped)
     B, _, H, W = target.shape
     S = len(warped)
-    coef = torch.empty(B, 18 if loss_flags & _l.LOSS_AVG_REPROJECTION else 9, H, W, device=target.device, dtype=torch.float32)
+    coef = torch.empty(B, 9 * S if loss_flags & _l.LOSS_AVG_REPROJECTION else 9, H, W, device=target.device, dtype=torch.float32)
     arr = (ctypes.c_void_p * S)(*[w.data_ptr() for w in warped])
     _l.check(_l.lib().sqd_photo_coef_ex(_ptr(target), arr, _ptr(idx), _ptr(coef), B, S, H, W, rows_per_task, loss_flags, _stream()),
              "photo_coef")

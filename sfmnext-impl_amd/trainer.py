@@ -135,8 +135,6 @@ class Trainer:
     def _check_supported(self):
         o = self.opt
         unsupported = [n for n in ("v1_multiscale", "predictive_mask") if getattr(o, n)]
-        if o.avg_reprojection and len(o.frame_ids) - 1 > 2:
-            unsupported.append("avg_reprojection with %d source frames" % (len(o.frame_ids) - 1))
         if unsupported or list(o.scales) != [0] or o.pose_model_type != "posecnn" or o.pose_model_input != "pairs":
             raise NotImplementedError("MI355X hot path implements the reference's KITTI mono configuration "
                                       "(scale 0, posecnn pairs; --no_ssim / --avg_reprojection / --disable_automasking included); got %s scales=%s pose=%s/%s"

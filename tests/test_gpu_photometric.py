@@ -26,13 +26,14 @@ def pose_grad_close(got, want, tol=5e-3):
     assert np.abs(got - want).max() < tol * np.abs(want).max(), (got, want)
 
 
-def ties_only(sel_got, want, name, tie_tol=2.5e-5):
+def ties_only(sel_got, want, name, tie_tol=2.5e-5, avg=False):
     """identity_selection is an index output: it may differ from the oracle's only where the two best candidates of
     trainer.py:526's min tie to within fp32 rounding of the SSIM window sums.  SSIM = n/d is ill-conditioned in flat
     regions (d = (mu_x^2+mu_y^2+C1)(sigma_x+sigma_y+C2) ~ 1e-3 from variances that are differences of O(0.3) sums), so two
     exact-division fp32 implementations with different summation orders differ by ~1e-5 there: measured worst gap among
     the flipped pixels 1.25e-5 (29 of 1 474 560 pixels at config B, 0.002 %); bound = 2x that."""
-    comb = torch.cat((want["identity"], want["reproj"]), 1).detach()
+    # (--avg_reprojection: the one reprojection candidate is the mean over the sources, trainer.py:508-509)
+    comb = torch.cat((want["identity"], want["reproj"].mean(1, keepdim=True) if avg else want["reproj"]), 1).detach()
     top2 = torch.topk(comb, 2, dim=1, largest=False).values
     gap = (top2[:, 1] - top2[:, 0])
     # a flip of identity_selection needs the best identity and the best reprojection candidate to tie
@@ -357,7 +358,7 @@ def test_loss_options_vs_oracle(ops, O, name, B, H, W, rows, seed):
     want, wdisp, wposes = oracle_chain_options(O, d, H, W, options)
     if ident is not None:
         close(ident, want["identity"], rtol=RTOL, atol=2e-6)
-        ties_only(sel, want, "%s %dx%dx%d" % (name, B, H, W))
+        ties_only(sel, want, "%s %dx%dx%d" % (name, B, H, W), avg=bool(options.get("avg_reprojection")))
     close(smooth, want["smooth"], rtol=RTOL)
     close(total, want["loss"], rtol=RTOL)
     total.backward()
@@ -365,6 +366,43 @@ def test_loss_options_vs_oracle(ops, O, name, B, H, W, rows, seed):
     for s, f in enumerate((-1, 1)):
         pose_grad_close(aa.grad[:, s], wposes[f][0].grad[:, 0, 0])
         pose_grad_close(tr.grad[:, s], wposes[f][1].grad[:, 0, 0])
+
+
+@pytest.mark.parametrize("name", ["avg", "avg_no_automask", "no_ssim_avg"])
+@pytest.mark.parametrize("B,H,W,rows,seed", [(2, 24, 80, 8, 71), (1, 48, 160, 0, 72)])
+def test_avg_reprojection_three_sources_vs_oracle(ops, O, name, B, H, W, rows, seed):
+    """--avg_reprojection with --use_stereo (three source frames: reference trainer.py:52-53 + 489-490, 508-509 take any S): the mean over
+    three identity / reprojection maps travels through the pair passes (0,1) + (2,2); loss, selection and every gradient against the oracle."""
+    from sqd import lib
+    options = LOSS_OPTION_SETS[name]
+    flags = lib.loss_flags(**options)
+    d = chain_inputs(seed, B, H, W, S=3)
+    stereo_T = torch.eye(4).repeat(B, 1, 1)
+    stereo_T[:, 0, 3] = -0.1
+    disp = dev(d["disp"]).requires_grad_(True)
+    aa = torch.stack([tt(d["axisangle_s0"])[:, 0, 0], tt(d["axisangle_s1"])[:, 0, 0]], 1).cuda().requires_grad_(True)
+    tr = torch.stack([tt(d["translation_s0"])[:, 0, 0], tt(d["translation_s1"])[:, 0, 0]], 1).cuda().requires_grad_(True)
+    tgt, srcs = dev(d["color0"]), [dev(d["color_s0"]), dev(d["color_s1"]), dev(d["color_s2"])]
+    noise1 = d["noise"][:, :1]
+    ident = None if options.get("disable_automasking") else ops.identity_fwd(tgt, srcs, dev(noise1), rows, loss_flags=flags)
+    meta = dict(H=H, W=W, invert=[1, 0], smooth_weight=1e-3, rows_per_task=rows, use_stereo=True, stereo_T=dev(stereo_T), loss_flags=flags)
+    outs = ops.PhotometricChain.apply(disp, aa, tr, dev(d["K"]), dev(d["inv_K"]), tgt, ident, meta, *srcs)
+    total, sel = outs[0], outs[4]
+    wdisp = tt(d["disp"]).requires_grad_(True)
+    poses = {f: (tt(d["axisangle_s%d" % i]).requires_grad_(True), tt(d["translation_s%d" % i]).requires_grad_(True)) for i, f in enumerate((-1, 1))}
+    colors = {0: tt(d["color0"]), -1: tt(d["color_s0"]), 1: tt(d["color_s1"]), "s": tt(d["color_s2"])}
+    want = O.photometric_chain(wdisp, poses, tt(d["K"]), tt(d["inv_K"]), colors, [0, -1, 1, "s"], tt(noise1), H, W, stereo_T=stereo_T, use_stereo=True,
+                               **options)
+    want["loss"].backward()
+    if ident is not None:
+        close(ident, want["identity"], rtol=RTOL, atol=2e-6)
+        ties_only(sel, want, "%s S=3 %dx%dx%d" % (name, B, H, W), avg=True)
+    close(total, want["loss"], rtol=RTOL)
+    total.backward()
+    grad_close(disp.grad, wdisp.grad)
+    for s_, f in enumerate((-1, 1)):
+        pose_grad_close(aa.grad[:, s_], poses[f][0].grad[:, 0, 0])
+        pose_grad_close(tr.grad[:, s_], poses[f][1].grad[:, 0, 0])
 
 
 @pytest.mark.parametrize("tag", ["no_ssim", "avg", "no_automask", "avg_no_automask", "no_ssim_avg"])
@@ -392,7 +430,7 @@ def test_golden_g23_loss_options(ops, golden, tag):
 def test_loss_options_argument_errors(ops):
     from sqd import lib
     t = torch.zeros(1, 3, 16, 64, device="cuda")
-    with pytest.raises(RuntimeError, match="two source frames"):
-        ops.identity_fwd(t, [t, t, t], None, loss_flags=lib.LOSS_AVG_REPROJECTION)
+    with pytest.raises(RuntimeError, match="at least two source frames"):
+        ops.identity_fwd(t, [t], None, loss_flags=lib.LOSS_AVG_REPROJECTION)
     with pytest.raises(RuntimeError, match="unknown loss_flags"):
         ops.identity_fwd(t, [t, t], None, loss_flags=8)

@@ -5,9 +5,9 @@
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}; out=$R/$1; tag=$2
 mkdir -p $out; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $out/trace -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline > $out/${tag}_bench_line.json 2> $out/trace.err
+rocprofv3 --kernel-trace --stats -d $out/trace -- python $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-diagnostics > $out/${tag}_bench_line.json 2> $out/trace.err
 db=$(find $out/trace -name "*.db" | head -1)
-python $R/tools/prof_summary.py $db $out/${tag}_bench_kernel_trace_stats.md "Round 3 ($tag): bench.py step (rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline)" > /dev/null
+python $R/tools/prof_summary.py $db $out/${tag}_bench_kernel_trace_stats.md "Round ${tag:1:2} ($tag): bench.py step (rocprofv3 --kernel-trace --stats -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-diagnostics)" > /dev/null
 for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc/calib_$c -- python $R/tools/pmc_calib.py > /dev/null 2>&1
   rocprofv3 --pmc $c --kernel-trace --output-format csv -d $out/pmc/fused_$c -- python $R/tools/bench_fused.py --iters 30 --which fwd,ident,coef,bwd > /dev/null 2>&1
