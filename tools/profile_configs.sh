@@ -6,10 +6,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; out=$R/$1; tag=$2
 mkdir -p $out; cd /tmp; export TMPDIR=/tmp
 run() {   # name, SQD_BENCH_EXTRA, workload line
   export SQD_BENCH_EXTRA="$2"
-  python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $out/${tag}_$1_bench_line.json 2> $out/$1.err
-  rocprofv3 --kernel-trace --stats -d $out/trace_$1 -- python $R/bench.py --steps 12 --warmup 5 --no-cpu-baseline --no-roofline > /dev/null 2> $out/$1.trace.err
+  python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-diagnostics > $out/${tag}_$1_bench_line.json 2> $out/$1.err
+  rocprofv3 --kernel-trace --stats -d $out/trace_$1 -- python $R/bench.py --steps 12 --warmup 5 --no-cpu-baseline --no-roofline --no-diagnostics > /dev/null 2> $out/$1.trace.err
   db=$(find $out/trace_$1 -name "*.db" | head -1)
-  python $R/tools/prof_summary.py $db $out/${tag}_$1_kernel_trace_stats.md "Round 3 ($tag): $3 — rocprofv3 --kernel-trace --stats -- SQD_BENCH_EXTRA='$2' python bench.py --steps 12 --warmup 5" "photo_tile_kernel<1" "$3" > /dev/null
+  python $R/tools/prof_summary.py $db $out/${tag}_$1_kernel_trace_stats.md "Round ${tag:1:2} ($tag): $3 — rocprofv3 --kernel-trace --stats -- SQD_BENCH_EXTRA='$2' python bench.py --steps 12 --warmup 5" "photo_tile_kernel<1" "$3" > /dev/null
   unset SQD_BENCH_EXTRA
   rm -rf $out/trace_$1          # (the raw trace is ~30 MB per run; gpurun copies at most 64 MB back)
   head -c 700 $out/${tag}_$1_bench_line.json; echo; sed -n 3,14p $out/${tag}_$1_kernel_trace_stats.md | cut -c1-150
