@@ -243,11 +243,20 @@ class Trainer:
                 if self.reducer is not None:
                     self.reducer.hooks_enabled = True
                 return self._train_step_eager(inputs)
+        # every batch is copied into the graph's input tensors (a loader never feeds one twice): device-resident tensors of the static
+        # tensors' dtype in ONE multi-tensor launch, whatever else (host tensors: a loader's pinned batch) one by one
+        dst, src = [], []
         for k, v in inputs.items():
             st = self._static_in[k]
-            if v is not st:                       # every batch is copied into the graph's input tensors (a loader never feeds one twice)
-                st.copy_(v, non_blocking=True)
+            if v is not st:
+                if v.is_cuda and v.dtype == st.dtype and v.shape == st.shape:
+                    dst.append(st)
+                    src.append(v)
+                else:
+                    st.copy_(v, non_blocking=True)
             inputs[k] = st                        # as process_batch does in eager mode: the caller's dict now holds device tensors
+        if dst:
+            torch._foreach_copy_(dst, src)
         if self.reducer is None or self.opt.sqd_graph_ddp != "post":
             self.model_optimizer.refresh_hyper()
             self._graph.replay()                # forward, backward (+ bucketed all-reduces overlapped with it), Adam

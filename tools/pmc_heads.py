@@ -56,5 +56,5 @@ for sub, (what, alg) in ALG.items():
         continue
     traffic = f * 1024.0 * fr + wv * 1024.0 * fw
     print("| `%s` (%s) | %.1f | %.1f | %.1f (%.2f) | %.2f (%.3f) | %.1f | %.1f | %.1f |"
-          % (name.split("(")[0].replace("void (anonymous namespace)::", ""), what, t, alg / 1e6, traffic / 1e6, traffic / alg, alg / t / 1e6, alg / t / 1e6 / 8.0,
+          % (name.replace("void (anonymous namespace)::", "").replace("(anonymous namespace)::", "").split("(")[0], what, t, alg / 1e6, traffic / 1e6, traffic / alg, alg / t / 1e6, alg / t / 1e6 / 8.0,
              alg / 8e6, FLOP[sub] / 157.3e6, FLOP[sub] / t / 1e6))
