@@ -253,8 +253,23 @@ def _trainer_params_worker(rank, world, port, q):
         loss.backward()
         red.finish()
         hist.append([None if p.grad is None else p.grad.clone() for p in params])
+    # a step in which some filters' gradients are DEFERRED (round 4: handed to the parameter directly by Conv2d.backward and announced
+    # through nnkernels.DEFERRED_GRAD_HOOK = reducer.on_deferred_grad instead of passing through AccumulateGrad): every fourth 4-D
+    # parameter is detached from the autograd loss and gets its gradient assigned by hand, in the middle of the backward pass' hooks
+    deferred = [i for i, p in enumerate(params) if p.dim() == 4 and i not in unused][::4]
+    red.zero_grad()
+    loss = sum((p * c).sum() for i, (p, c) in enumerate(zip(params, coef)) if i not in unused and i not in deferred) * 4.0
+    for i in deferred[: len(deferred) // 2]:                     # (some before, some after the autograd pass: arrival order is free)
+        params[i].grad = (coef[i] * 4.0).contiguous(memory_format=torch.channels_last)
+        red.on_deferred_grad(params[i])
+    loss.backward()
+    for i in deferred[len(deferred) // 2:]:
+        params[i].grad = (coef[i] * 4.0).contiguous(memory_format=torch.channels_last)
+        red.on_deferred_grad(params[i].detach().requires_grad_())        # (found by storage when it is not the parameter object itself)
+    red.finish()
+    hist.append([None if p.grad is None else p.grad.clone() for p in params])
     conv4d = next(i for i, p in enumerate(params) if p.dim() == 4 and p.shape[2] == 3 and p.shape[1] > 1)
-    info = {"nbuckets": len(red.buckets), "in_buckets": sum(len(b) for b in red.buckets), "nparams": len(params),
+    info = {"nbuckets": len(red.buckets), "ndeferred": len(deferred), "in_buckets": sum(len(b) for b in red.buckets), "nparams": len(params),
             "fc_grad_none": all(hist[-1][i] is None for i in unused),
             "view_strides_ok": params[conv4d].grad.stride() == params[conv4d].stride() and not params[conv4d].is_contiguous(),
             "is_view": params[conv4d].grad._base is not None,
@@ -280,6 +295,7 @@ def test_reducer_on_trainer_parameter_set_gloo_world2():
     assert i0["w0"] == i1["w0"]                                   # rank 0's weights were broadcast
     assert i0["nbuckets"] >= 2 and i0["in_buckets"] == i0["nparams"] - 2 and i0["fc_grad_none"]     # the unused fc stays out of the buckets
     assert i0["view_strides_ok"] and i0["is_view"]                # channels-last filters keep their layout inside the bucket
+    assert i0["ndeferred"] >= 4 and len(v0) == 4                  # (the fourth step: deferred gradients announced by hand)
     for step, (a, b) in enumerate(zip(v0, v1)):
         assert a == b                                             # both ranks hold the same averaged gradients
         for i, g in enumerate(a):
