@@ -978,70 +978,6 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_tile_kernel(sqd_photo_bwd_ar
     }
 }
 
-        __syncthreads();
-    }
-}
-
-__global__ __launch_bounds__(SNW * 64, 4) void photo_stream_kernel(sqd_photo_args a, PairPass pp, StreamPlan plan) {
-    extern __shared__ v2f wl[];                       // ring: [RING][3][64] warped pairs, then [RING][3][64] target floats
-    float *tl = reinterpret_cast<float *>(wl + RING_W);
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // consecutive ranges (which share halo rows) on the same XCD: workgroup i runs on XCD i % 8
-    const int wg = (blockIdx.x & 7) * plan.nblk8 + (blockIdx.x >> 3);
-    if (wg >= plan.nwg) return;
-    const int nsx = strips_x(a.W);
-    int g = plan.start[wg];
-    const int g1 = plan.start[wg + 1];
-    float loss_acc = 0.f;
-    while (g < g1) {                                  // (a range that crosses into the next column: two segments)
-        const int col = g / plan.cpc, c0 = g - col * plan.cpc;
-        const int c1 = min(plan.cpc, c0 + (g1 - g));
-        const int b = col / nsx, tx = col - b * nsx;
-        const StripX sx = strip_x(tx, nsx, a.W);
-        const int ya = c0 * SNW, yb = min(a.H, c1 * SNW);
-        // (images of fewer than 64 columns: lanes of a strip lie outside the image — one generic instance with the lane masks)
-        if (a.W < 64) {
-            if (sx.kind == LEFT) stream_segment<true, LEFT>(a, pp, wl, tl, b, sx, ya, yb, lane, wave, loss_acc);
-            else if (sx.kind == RIGHT) stream_segment<true, RIGHT>(a, pp, wl, tl, b, sx, ya, yb, lane, wave, loss_acc);
-            else stream_segment<true, INTERIOR>(a, pp, wl, tl, b, sx, ya, yb, lane, wave, loss_acc);
-        } else if (sx.kind == LEFT) stream_segment<false, LEFT>(a, pp, wl, tl, b, sx, ya, yb, lane, wave, loss_acc);
-        else if (sx.kind == RIGHT) stream_segment<false, RIGHT>(a, pp, wl, tl, b, sx, ya, yb, lane, wave, loss_acc);
-        else stream_segment<false, INTERIOR>(a, pp, wl, tl, b, sx, ya, yb, lane, wave, loss_acc);
-        g += c1 - c0;
-    }
-    if (a.loss_part && pp.last) {
-        loss_acc = wave_sum(loss_acc);
-        if (lane == 0) a.loss_part[wg * SNW + wave] = loss_acc;
-    }
-}
-
-// the work split of a streaming launch: contiguous chunk ranges, as many as fit the chip; ranges get total / nwg chunks, the remainder
-// goes — one chunk each — to ranges that do not cross a column boundary where there is a choice (a crossing costs a warm-up)
-bool make_stream_plan(StreamPlan &pl, int B, int H, int W) {
-    const int cols = B * strips_x(W);
-    pl.cpc = (H + SNW - 1) / SNW;
-    const long long total = (long long)cols * pl.cpc;
-    if (total >= 65536) return false;                 // (16-bit table: larger launches run the tile kernel)
-    int nwg = (int)(total < STREAM_MAX_WG ? total : STREAM_MAX_WG);
-    if (total < 3LL * STREAM_MAX_WG) nwg = (int)((total + 2) / 3);      // small problems: at least ~3 chunks per workgroup (halo 1.25)
-    nwg = nwg < 1 ? 1 : nwg;
-    const int base = (int)(total / nwg);
-    int extra = (int)(total - (long long)base * nwg), g = 0;
-    for (int i = 0; i < nwg; ++i) {
-        const int left = nwg - i;
-        int len = base;
-        if (extra > 0 && (extra >= left || (g % pl.cpc) + base + 1 <= pl.cpc)) { ++len; --extra; }
-        pl.start[i] = (unsigned short)g;
-        g += len;
-    }
-    pl.start[nwg] = (unsigned short)g;
-    pl.nwg = nwg;
-    pl.nblk8 = (nwg + 7) / 8;
-    return g == total && extra == 0;
-}
-
-#endif
 // rows a workgroup tile owns: the caller's rows_per_task (even, clamped), or the default of the kernel family.  Measured at config B
 // after a proper warm-up (profiles/r03m_photo_tile_heights.md): every uniform shape of the fused forward within 1.5 % of the others
 // (4 x 16: 51.2 us, 8 x 28: 50.7), identity / coefficient / backward kernels flat in the tile height — what does count is a whole number
