@@ -2322,12 +2322,59 @@ extern "C" int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int 
 
 // dy [N,Ho,Wo,K], x [N,H,W,C] -> dw [K,R,S,C]; dbias [K] (may be NULL); part: workspace of sqd_conv_wgrad_plan floats
 // (+ bias scratch appended when dbias is requested: max(ceil(M/1024), splits) * K floats)
+// ---------------------------------------------------------------------------------------------------
+// Weight gradient of a 1x1 convolution over a HANDFUL of rows (M <= 32): the bins regressor's Linear layers run as 1x1 convolutions
+// whose "pixels" are the batch's 12 rows (reference networks/depth_decoder_QTR.py:22-26,49), so dW [K][C] = sum_m dy[m][k] x[m][c] is
+// M outer products and 4 K C bytes of output — 8.4 MB for the 2048 -> 1024 layer, which the pixel-split MFMA kernels above wrote in
+// 30 us (1.7 TFLOP/s: a tile of 64 x 64 filters for 12 pixels).  Here a thread owns a float4 of input channels for KB filters: x is read
+// once per block of KB filters (coalesced), dy[m][k] is wave-uniform (scalar loads), dW leaves as coalesced 16-byte stores; the bias
+// gradient is the column sum of dy.  Fixed summation order over m.
+// ---------------------------------------------------------------------------------------------------
+template <int KB>
+__global__ __launch_bounds__(256) void conv_wgrad_fewrows_kernel(const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ dw,
+                                                                 float *__restrict__ dbias, int M, int C, int K) {
+    const int c4 = blockIdx.x * 256 + threadIdx.x, k0 = blockIdx.y * KB;
+    if (dbias && blockIdx.x == 0 && threadIdx.x < KB && k0 + (int)threadIdx.x < K) {
+        float sb = 0.f;
+        for (int m = 0; m < M; ++m) sb += dy[(size_t)m * K + k0 + threadIdx.x];
+        dbias[k0 + threadIdx.x] = sb;
+    }
+    if (c4 * 4 >= C) return;
+    float4 acc[KB];
+#pragma unroll
+    for (int q = 0; q < KB; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int m = 0; m < M; ++m) {
+        const float4 xv = reinterpret_cast<const float4 *>(x + (size_t)m * C)[c4];
+        const float *__restrict__ dr = dy + (size_t)m * K + k0;          // wave-uniform: scalar loads
+#pragma unroll
+        for (int q = 0; q < KB; ++q) {
+            const float d = k0 + q < K ? dr[q] : 0.f;
+            acc[q].x = fmaf(d, xv.x, acc[q].x); acc[q].y = fmaf(d, xv.y, acc[q].y);
+            acc[q].z = fmaf(d, xv.z, acc[q].z); acc[q].w = fmaf(d, xv.w, acc[q].w);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < KB; ++q)
+        if (k0 + q < K) reinterpret_cast<float4 *>(dw + (size_t)(k0 + q) * C)[c4] = acc[q];
+}
+constexpr int FEWROWS_MAX = 32;
+
 static int conv_wgrad_impl(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C,
                            int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream, bool reduce_dw, int *splits_out) {
     SQD_CHECK_ARG(dy && x && dw && part, "sqd_conv_wgrad: null pointer");
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     if (check_geom("sqd_conv_wgrad", g)) return SQD_EINVAL;
     SQD_CHECK_ARG(C % 4 == 0 && K % 4 == 0, "sqd_conv_wgrad: C=%d and K=%d must be multiples of 4", C, K);
+    if (R == 1 && S == 1 && stride == 1 && pad == 0 && N * Ho * Wo <= FEWROWS_MAX) {
+        // a handful of rows (the bins regressor's Linear layers): M outer products, no pixel splits — whatever plan is registered
+        float *out = reduce_dw ? dw : part;
+        if (splits_out) *splits_out = 1;
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(conv_wgrad_fewrows_kernel<8>, dim3((C / 4 + 255) / 256, (K + 7) / 8), dim3(256), 0, (hipStream_t)stream, dy, x, out, dbias,
+                           N * Ho * Wo, C, K);
+        SQD_CHECK_LAUNCH("sqd_conv_wgrad");
+        return SQD_OK;
+    }
     int splits;
     int64_t pf;
     sqd_conv_wgrad_plan(N, Ho, Wo, C, K, R, S, &splits, &pf);
