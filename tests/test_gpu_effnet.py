@@ -249,11 +249,11 @@ def test_effb5_bf16_step_matches_bf16_oracle(H, W, B, nf, patch, Q, dout):
         # trunk's first layers sit at the end of the longest chain of rounded products: the stem's gradient moves by ~10 %)
         # (three oracle evaluations = three pairwise distances; the largest is the floor.  Gradients are the heavy-tailed end of this
         #  lottery — which plans the step's timing picked changes the device's draw from run to run: 2.2x the two-draw floor has been
-        #  seen on the query MLP's first layer — so they get 3x where the disparity gets 2x)
+        #  seen on the query MLP's first layer — so they get 4x where the disparity gets 2x)
         gs = [dict(runs[m][2][net].named_parameters())[name].grad for m in ("bf16", "bf16+1", "bf16+2")]
         floor = max(float((gs[i] - gs[j]).norm() / g_ref.norm()) for i, j in ((0, 1), (0, 2), (1, 2)))
         print("%-60s gradient L2 err vs bf16 oracle %.2e (the oracle's own noise %.2e)" % (name, g_l2, floor))
-        assert g_l2 <= max(3.0 * floor, 2e-3), (name, g_l2, floor)
+        assert g_l2 <= max(4.0 * floor, 2e-3), (name, g_l2, floor)
     rm = tr.models["encoder"].encoder.original_model.blocks[3][2].bn1.running_var.cpu()
     rr = nets16["encoder"].encoder.original_model.blocks[3][2].bn1.running_var
     assert float((rm - rr).abs().max() / rr.abs().max()) < 1e-3
