@@ -256,9 +256,16 @@ class GradBucketReducer:
             for bi in range(len(self.buckets)):
                 self._pending[bi] = len(self.buckets[bi])
 
-    def _on_grad(self, p):
+    def _on_grad(self, p, announced=False):
         if not self.hooks_enabled:
             return
+        if not announced:
+            # (torch fires a post-accumulate hook even when the node received no gradient: a filter whose gradient Conv2d.backward
+            #  handed over directly gets here right after that backward, before the launch carrying the sum of its pixel splits is
+            #  enqueued — it counts when nnkernels announces it, not now)
+            from . import nnkernels
+            if p.data_ptr() in nnkernels.DEFERRED_FILTERS:
+                return
         bi = self._bucket_of.get(p)
         if bi is None:
             return
@@ -278,7 +285,7 @@ class GradBucketReducer:
         launch that has just been enqueued) arrives like any accumulated gradient."""
         p = w if w in self._bucket_of else self._by_ptr.get(w.data_ptr())
         if p is not None:
-            self._on_grad(p)
+            self._on_grad(p, announced=True)
 
     def detach_grad_views(self):
         """Graph mode: hand back {parameter: its bucket view} and clear p.grad, so that a captured backward produces fresh

@@ -783,6 +783,11 @@ _PENDING_REDUCE = {}          # stream handle -> (part, dw, n, splits, stream, f
 # does not see it; the reducer registers this callable instead (called with the filter tensor once the launch that carries the sum
 # of its splits has been enqueued — from then on the gradient is stream-ordered like any other).
 DEFERRED_GRAD_HOOK = None
+# ... and the filters (by data pointer) whose gradient was handed over directly in the current pass: autograd still runs their
+# AccumulateGrad node with an undefined gradient, and torch fires the post-accumulate hooks of such a node — right after
+# Conv2d.backward, BEFORE the launch that carries the sum of the splits is enqueued.  The reducer must not count (or gather) on that
+# call; it counts the announcement.  Cleared by begin_step().
+DEFERRED_FILTERS = set()
 
 
 def _deferred_grad_done(w):
@@ -833,6 +838,7 @@ _WEIGHT_USES = {}            # id(weight storage) -> forward uses in the current
 def begin_step():
     """Training loops call this before every forward pass (the side-stream weight gradients need per-step use counts)."""
     _WEIGHT_USES.clear()
+    DEFERRED_FILTERS.clear()
 
 
 def flush_wgrads():
@@ -956,6 +962,7 @@ class Conv2d(torch.autograd.Function):
                 _l.check(L.sqd_conv_wgrad_partials(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
                                                    ctypes.byref(sp), _stream()), "conv_wgrad_partials")
                 w.grad = dw
+                DEFERRED_FILTERS.add(w.data_ptr())
                 _set_pending_reduce(part, dw, K * R * S * C, sp.value, w)
                 dw = None
             elif WGRAD_STREAM is None or ctx.wkey is None or _WEIGHT_USES.get(ctx.wkey, 2) != 1:

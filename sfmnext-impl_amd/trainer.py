@@ -319,19 +319,44 @@ class Trainer:
         mode = {} if self.reducer is None else {"capture_error_mode": "thread_local"}
         try:
             with torch.cuda.graph(g, stream=self._graph_stream, **mode):
-                nnkernels.begin_step()          # per-step use counts of the filters (a filter used once may defer its gradient's split sum)
-                outputs, losses = self.process_batch(self._static_in)
-                # the reducer's post-accumulate hooks run here, inside the capture: each full bucket is gathered by one
-                # multi-tensor copy and its all-reduce (sqd_comm_allreduce, a plain stream operation) is enqueued on the
-                # communicator's stream — a branch of the graph that runs next to the remaining backward kernels; finish()
-                # joins the branches before Adam reads the averaged buckets
-                self._backward(losses["loss"])
-                if self.reducer is not None:
-                    self.reducer.finish()
-                opt.step()
+                try:
+                    nnkernels.begin_step()      # per-step use counts of the filters (a filter used once may defer its gradient's split sum)
+                    outputs, losses = self.process_batch(self._static_in)
+                    # the reducer's post-accumulate hooks run here, inside the capture: each full bucket is gathered by one
+                    # multi-tensor copy and its all-reduce (sqd_comm_allreduce, a plain stream operation) is enqueued on the
+                    # communicator's stream — a branch of the graph that runs next to the remaining backward kernels; finish()
+                    # joins the branches before Adam reads the averaged buckets
+                    self._backward(losses["loss"])
+                    if self.reducer is not None:
+                        self.reducer.finish()
+                    opt.step()
+                except BaseException:
+                    self._join_captured_branches()
+                    raise
         finally:
             self._capturing = False
         self._graph, self._static_out = g, (outputs, losses)
+
+    def _join_captured_branches(self):
+        """A step that raises in the middle of a capture leaves its forked branches (pose network, weight gradients, the communicator's
+        stream) un-joined, and a capture with un-joined work cannot be ended: every stream of it would stay in capturing state and the
+        next capture attempt — the fallback — would die with it.  Join whatever is still capturing, so that the context manager can end
+        (and discard) the capture cleanly."""
+        cur = torch.cuda.current_stream()
+        streams = [self._pose_stream, self._side_stream, self._wgrad_stream]
+        if self.reducer is not None and getattr(self.reducer.comm, "stream", None) is not None:
+            streams.append(self.reducer.comm.stream)
+            self.reducer._inflight = False
+        for s in streams:
+            try:
+                with torch.cuda.stream(s):
+                    branch = torch.cuda.is_current_stream_capturing()
+                if branch and s.cuda_stream != cur.cuda_stream:
+                    cur.wait_stream(s)
+            except Exception:                    # noqa: BLE001 — best effort: the original exception is what gets reported
+                pass
+        nnkernels.WGRAD_STREAM = None
+        nnkernels._PENDING_WGRAD.clear()
 
     def _capture_fwd_bwd(self):
         """Multi-rank variant: process_batch + the bucket memsets + backward in one hipGraph.  The gradients are the bucket
@@ -346,13 +371,17 @@ class Trainer:
         self._capturing = True
         try:
             with torch.cuda.graph(g, stream=self._graph_stream, capture_error_mode="thread_local"):
-                nnkernels.begin_step()
-                outputs, losses = self.process_batch(self._static_in)
-                self._backward(losses["loss"])
-                # fresh gradients (assigned, not accumulated: no memsets, no ~170 accumulate launches) -> the buckets, as
-                # a couple of multi-tensor copies
-                params = [p for p in views if p.grad is not None]
-                torch._foreach_copy_([views[p] for p in params], [p.grad for p in params])
+                try:
+                    nnkernels.begin_step()
+                    outputs, losses = self.process_batch(self._static_in)
+                    self._backward(losses["loss"])
+                    # fresh gradients (assigned, not accumulated: no memsets, no ~170 accumulate launches) -> the buckets, as
+                    # a couple of multi-tensor copies
+                    params = [p for p in views if p.grad is not None]
+                    torch._foreach_copy_([views[p] for p in params], [p.grad for p in params])
+                except BaseException:
+                    self._join_captured_branches()
+                    raise
         finally:
             self._capturing = False
         for p, v in views.items():                        # the optimiser reads the (all-reduced) bucket memory

@@ -21,8 +21,23 @@ import json, os, sys
 sys.path[:0] = [%(repo)r, os.path.join(%(repo)r, "sfmnext-impl_amd"), os.path.join(%(repo)r, "tests"), os.path.join(%(repo)r, "tests", "golden")]
 import torch
 import test_gpu_graph as T
-tr, losses, params = T.run(sys.argv[1:], steps=7)
-out = {"reducer": tr.reducer is not None, "graph": tr._graph is not None, "losses": losses,
+from sqd import ddp as _ddp
+_announced = []
+_orig_announce = _ddp.GradBucketReducer.on_deferred_grad
+_ddp.GradBucketReducer.on_deferred_grad = lambda self, w: (_announced.append(1), _orig_announce(self, w))[1]
+if os.environ.get("SQD_TEST_FAIL_OVERLAP_CAPTURE"):
+    # the first capture attempt (all-reduces inside the step graph) dies in the reducer's join: the Trainer must fall back to "post"
+    _orig_finish = _ddp.GradBucketReducer.finish
+    def _finish(self):
+        if torch.cuda.is_current_stream_capturing() and not getattr(self, "_failed_once", False):
+            self._failed_once = True
+            raise RuntimeError("injected capture failure")
+        return _orig_finish(self)
+    _ddp.GradBucketReducer.finish = _finish
+args = [a for a in sys.argv[1:]]
+tr, losses, params = T.run(args, steps=7)
+out = {"reducer": tr.reducer is not None, "graph": tr._graph is not None, "losses": losses, "announced": len(_announced),
+       "graph_mode": tr.graph_mode(), "capture_failures": getattr(tr, "capture_failures", []),
        "sums": {k: float(v.double().abs().sum()) for k, v in params.items() if v.dtype.is_floating_point}}
 if tr.reducer is not None:
     p = next(p for p in tr.models["encoder"].parameters() if p.dim() == 4 and p.shape[2] == 3)
@@ -135,6 +150,18 @@ def test_step_graph_with_captured_allreduces_leg(plain, attempt):
     graphed = _run(_dist_env(), [], "graph-overlap leg, attempt %d" % attempt)
     _check_dist(graphed, graph=True)
     _same_training(plain, graphed)
+    # round 4: the multi-rank step runs the kernels the single-rank step is measured with — the sums of the weight gradients' pixel
+    # splits ride on the BatchNorm-backward launches and the filters are announced to the reducer by hand
+    assert graphed["graph_mode"] == "overlap" and graphed["announced"] > 0 and not graphed["capture_failures"], graphed
+
+
+def test_overlap_capture_failure_falls_back_to_post(plain):
+    """a step graph with the all-reduces inside that cannot be captured must not end the run: the Trainer retries as
+    --sqd_graph_ddp post (graph of forward + backward, exchange and Adam after the replay) and says so"""
+    res = _run(dict(_dist_env(), SQD_TEST_FAIL_OVERLAP_CAPTURE="1"), [], "overlap capture failure -> post")
+    _check_dist(res, graph=True)
+    assert res["graph_mode"] == "post" and len(res["capture_failures"]) == 1 and "injected" in res["capture_failures"][0], res
+    _same_training(plain, res)
 
 
 def test_graph_then_allreduce_leg(plain):
@@ -155,4 +182,8 @@ def test_bench_under_torchrun_one_rank():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert r.returncode == 0 and lines, "rc %d\n%s\n%s" % (r.returncode, r.stdout[-3000:], r.stderr[-12000:])
     rec = json.loads(lines[-1])
-    assert rec["n_gpus"] == 1 and rec["value"] > 0 and rec["config"]["exchange"]["communicator"] == "RcclComm"
+    ex = rec["config"]["exchange"]
+    assert rec["n_gpus"] == 1 and rec["value"] > 0 and ex["communicator"] == "RcclComm"
+    # what a multi-GPU line must say about itself
+    assert ex["ranks_joined"] == 1 and ex["rccl_version"] and ex["rccl_version"][0].isdigit() and ex["defer_wgrad_reduce"] is True
+    assert ex["graph_mode"] == "overlap" and ex["buckets"] == len(ex["bucket_bytes"]) >= 1 and not ex["capture_failures"]
