@@ -368,6 +368,144 @@ __global__ __launch_bounds__(256) void bn_apply_pool_fwd_kernel(const float *__r
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Finalize + element-wise pass in ONE launch, for layers whose statistics arrive as FEW partial rows (the 12x40 and 6x20 maps of
+// layer3 / layer4: 90 / 23 rows from the convolution's epilogue).  No cross-workgroup dependency: a workgroup owns 64 channels x a
+// block of rows and sums the partial rows of ITS 64 channels itself, in its prologue (rows x 512 bytes out of L2, fixed order — every
+// workgroup of a channel chunk computes the same bits); the workgroup of row block 0 publishes mean / rstd (or dgamma / dbeta) and the
+// running statistics.  Redundant L2 reads instead of a 5 us launch + a kernel boundary per layer and direction.  Not for
+// many partial rows (360 at 24x80: 184 KB per workgroup — more than its slice of the tensor) and not with a cross-workgroup wait
+// (round 3 measured that: 1.4 - 3.7 x slower steps).
+// ---------------------------------------------------------------------------------------------------
+constexpr int FUSE_MAX_ROWS = 160;
+// (sum, sum2) of the thread's 4 channels over all partial rows -> s[0..3], q[0..3]; thread = (channel group t & 15, row lane t >> 4)
+__device__ __forceinline__ void chunk_sums(const float *__restrict__ part, int rows, int C, int c0, float4 &s, float4 &q, float4 (*red)[16][2]) {
+    const int cgl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;        // a = (s0, q0, s1, q1), b = (s2, q2, s3, q3)
+    const float *p = part + ((size_t)c0 + cgl * 4) * 2;
+    for (int r = rl; r < rows; r += 16) {
+        const float4 u = *reinterpret_cast<const float4 *>(p + (size_t)r * C * 2), v = *reinterpret_cast<const float4 *>(p + (size_t)r * C * 2 + 4);
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    red[rl][cgl][0] = a;
+    red[rl][cgl][1] = b;
+    __syncthreads();
+    a = red[0][cgl][0];
+    b = red[0][cgl][1];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) {
+        const float4 u = red[k][cgl][0], v = red[k][cgl][1];
+        a.x += u.x; a.y += u.y; a.z += u.z; a.w += u.w;
+        b.x += v.x; b.y += v.y; b.z += v.z; b.w += v.w;
+    }
+    s = make_float4(a.x, a.z, b.x, b.z);
+    q = make_float4(a.y, a.w, b.y, b.w);
+}
+
+__global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ gamma,
+                                                           const float *__restrict__ beta, const float *__restrict__ part, int rows,
+                                                           float *__restrict__ mean_out, float *__restrict__ rstd_out, float *__restrict__ rmean,
+                                                           float *__restrict__ rvar, float *__restrict__ y, unsigned char *__restrict__ mask, int M,
+                                                           int C, float eps, float momentum, int act, int rows_per_block) {
+    __shared__ float4 red[16][16][2];
+    const int cgl = threadIdx.x & 15, rl = threadIdx.x >> 4, c0 = blockIdx.y * 64, c = c0 + cgl * 4;
+    float4 s, q;
+    chunk_sums(part, rows, C, c0, s, q, red);
+    float4 mu, rs;
+    {
+        const float m0 = s.x / (float)M, m1 = s.y / (float)M, m2 = s.z / (float)M, m3 = s.w / (float)M;
+        float v0 = q.x / (float)M - m0 * m0, v1 = q.y / (float)M - m1 * m1, v2 = q.z / (float)M - m2 * m2, v3 = q.w / (float)M - m3 * m3;
+        v0 = v0 < 0.f ? 0.f : v0; v1 = v1 < 0.f ? 0.f : v1; v2 = v2 < 0.f ? 0.f : v2; v3 = v3 < 0.f ? 0.f : v3;
+        mu = make_float4(m0, m1, m2, m3);
+        rs = make_float4(rsqrtf(v0 + eps), rsqrtf(v1 + eps), rsqrtf(v2 + eps), rsqrtf(v3 + eps));
+        if (blockIdx.x == 0 && rl == 0) {
+            *reinterpret_cast<float4 *>(mean_out + c) = mu;
+            *reinterpret_cast<float4 *>(rstd_out + c) = rs;
+            if (rmean) {
+                const float ub = M > 1 ? (float)M / (float)(M - 1) : 1.f;
+                const float4 rm = *reinterpret_cast<const float4 *>(rmean + c), rv = *reinterpret_cast<const float4 *>(rvar + c);
+                *reinterpret_cast<float4 *>(rmean + c) = make_float4((1.f - momentum) * rm.x + momentum * m0, (1.f - momentum) * rm.y + momentum * m1,
+                                                                      (1.f - momentum) * rm.z + momentum * m2, (1.f - momentum) * rm.w + momentum * m3);
+                *reinterpret_cast<float4 *>(rvar + c) = make_float4((1.f - momentum) * rv.x + momentum * (v0 * ub), (1.f - momentum) * rv.y + momentum * (v1 * ub),
+                                                                     (1.f - momentum) * rv.z + momentum * (v2 * ub), (1.f - momentum) * rv.w + momentum * (v3 * ub));
+            }
+        }
+    }
+    const float4 ga = *reinterpret_cast<const float4 *>(gamma + c), be = *reinterpret_cast<const float4 *>(beta + c);
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int r = r0 + rl; r < r1; r += 16) {
+        const size_t i = ((size_t)r * C + c) / 4;
+        const float4 xv = reinterpret_cast<const float4 *>(x)[i];
+        float4 o;
+        o.x = fmaf((xv.x - mu.x) * rs.x, ga.x, be.x);
+        o.y = fmaf((xv.y - mu.y) * rs.y, ga.y, be.y);
+        o.z = fmaf((xv.z - mu.z) * rs.z, ga.z, be.z);
+        o.w = fmaf((xv.w - mu.w) * rs.w, ga.w, be.w);
+        if (res) {
+            const float4 rv = reinterpret_cast<const float4 *>(res)[i];
+            o.x += rv.x; o.y += rv.y; o.z += rv.z; o.w += rv.w;
+        }
+        if (mask) mask[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
+        o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
+        reinterpret_cast<float4 *>(y)[i] = o;
+    }
+}
+
+// backward: dgamma / dbeta from the partial rows (sum dz, sum dz * xhat), then dx = gamma rstd (dz - mean(dz) - xhat mean(dz xhat)), dres = dz.
+// Workgroups with blockIdx.y >= nchunks carry a pending split reduction along (as bn_finalize_bwd_kernel does).
+__global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x, const float *__restrict__ y,
+                                                           const float *__restrict__ gamma, const float *__restrict__ mean, const float *__restrict__ rstd,
+                                                           const float *__restrict__ part, int rows, float *__restrict__ dgamma, float *__restrict__ dbeta,
+                                                           float *__restrict__ dx, float *__restrict__ dres, int M, int C, int act,
+                                                           const unsigned char *__restrict__ mask, int rows_per_block, int nchunks, int nrb,
+                                                           const float *__restrict__ red_part, float *__restrict__ red_out, size_t red_n, int red_splits) {
+    __shared__ float4 red[16][16][2];
+    if ((int)blockIdx.y >= nchunks) {              // (workgroup-uniform) the pending sum of a weight gradient's pixel splits
+        sqd::split_reduce_block(red_part, red_out, red_n, red_splits, ((int)blockIdx.y - nchunks) * nrb + (int)blockIdx.x,
+                                reinterpret_cast<float4(*)[16]>(&red[0][0][0]));
+        return;
+    }
+    const int cgl = threadIdx.x & 15, rl = threadIdx.x >> 4, c0 = blockIdx.y * 64, c = c0 + cgl * 4;
+    float4 db, dg;
+    chunk_sums(part, rows, C, c0, db, dg, red);
+    if (blockIdx.x == 0 && rl == 0) {
+        *reinterpret_cast<float4 *>(dbeta + c) = db;
+        *reinterpret_cast<float4 *>(dgamma + c) = dg;
+    }
+    const float invM = 1.0f / (float)M;
+    const float4 ga = *reinterpret_cast<const float4 *>(gamma + c), rs = *reinterpret_cast<const float4 *>(rstd + c);
+    const float4 mu = *reinterpret_cast<const float4 *>(mean + c);
+    const float4 k0 = make_float4(ga.x * rs.x, ga.y * rs.y, ga.z * rs.z, ga.w * rs.w);
+    const float4 k1 = make_float4(db.x * invM, db.y * invM, db.z * invM, db.w * invM);
+    const float4 k2 = make_float4(rs.x * (dg.x * invM), rs.y * (dg.y * invM), rs.z * (dg.z * invM), rs.w * (dg.w * invM));
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int r = r0 + rl; r < r1; r += 16) {
+        const size_t i = ((size_t)r * C + c) / 4;
+        const float4 gy = reinterpret_cast<const float4 *>(dy)[i];
+        const float4 xv = reinterpret_cast<const float4 *>(x)[i];
+        const float4 da = act_bwd4(mask, y, i, act);
+        float4 dz, o;
+        dz.x = gy.x * da.x; dz.y = gy.y * da.y; dz.z = gy.z * da.z; dz.w = gy.w * da.w;
+        o.x = k0.x * (dz.x - k1.x - (xv.x - mu.x) * k2.x);
+        o.y = k0.y * (dz.y - k1.y - (xv.y - mu.y) * k2.y);
+        o.z = k0.z * (dz.z - k1.z - (xv.z - mu.z) * k2.z);
+        o.w = k0.w * (dz.w - k1.w - (xv.w - mu.w) * k2.w);
+        reinterpret_cast<float4 *>(dx)[i] = o;
+        if (dres) reinterpret_cast<float4 *>(dres)[i] = dz;
+    }
+}
+// rows a workgroup of the fused kernels owns: ~1024 workgroups per launch, at least 64 rows each and at least as many as there are
+// partial rows (the prologue — `prows` x 512 bytes — is paid per workgroup: it stays below the workgroup's own slice of the tensor)
+inline int fused_rows_per_block(int M, int C, int prows) {
+    const int chunks = C / 64;
+    int nrb = (1024 + chunks - 1) / chunks;
+    int rpb = (M + nrb - 1) / nrb;
+    rpb = rpb < 64 ? 64 : rpb;
+    rpb = rpb < prows ? prows : rpb;
+    return (rpb + 15) / 16 * 16;
+}
+
 int check(const char *who, int M, int C) {
     SQD_CHECK_ARG(M > 0 && C >= 4 && C % 4 == 0, "%s: need C %% 4 == 0 (C=%d, M=%d)", who, C, M);
     return SQD_OK;
@@ -404,6 +542,14 @@ extern "C" int sqd_bn_train_fwd_pool(const float *x, const float *res, const flo
     (void)hipGetLastError();
     // pre_rows > 0: `part` already holds that many rows of (sum, sum of squares) partials — written by the producing
     // convolution's epilogue (sqd_conv_fwd's stats) — and the reduction pass over x is skipped
+    if (pre_rows > 0 && pre_rows <= FUSE_MAX_ROWS && C % 64 == 0 && !pool_part && act != ACT_SWISH) {
+        // few partial rows from the producing convolution: finalize + element-wise pass in one launch
+        const int rpb = fused_rows_per_block(M, C, pre_rows);
+        hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3((M + rpb - 1) / rpb, C / 64), dim3(256), 0, s, x, res, gamma, beta, part, pre_rows, save_mean, save_rstd,
+                           running_mean, running_var, y, mask, M, C, eps, momentum, act, rpb);
+        SQD_CHECK_LAUNCH("sqd_bn_train_fwd");
+        return SQD_OK;
+    }
     if (pre_rows <= 0)
         hipLaunchKernelGGL((bn_reduce_kernel<0>), dim3(g.nblk), dim3(256), 0, s, x, nullptr, nullptr, nullptr, nullptr, part, M, C, act, g,
                            (const unsigned char *)nullptr, (const float *)nullptr, (const float *)nullptr);
@@ -465,6 +611,14 @@ extern "C" int sqd_bn_train_bwd_pre_red(const float *dy, const float *x, const f
     const Geom g = geom(M, C);
     hipStream_t s = (hipStream_t)stream;
     (void)hipGetLastError();
+    if (pre_rows > 0 && pre_rows <= FUSE_MAX_ROWS && C % 64 == 0 && act != ACT_SWISH) {
+        const int rpb = fused_rows_per_block(M, C, pre_rows), nrb = (M + rpb - 1) / rpb, nchunks = C / 64;
+        const int nredb = red_part ? (int)((red_n / 4 + 15) / 16) : 0;             // blocks of the pending split reduction, nrb per grid row
+        hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3(nrb, nchunks + (nredb + nrb - 1) / nrb), dim3(256), 0, s, dy, x, y, gamma, save_mean, save_rstd, part,
+                           pre_rows, dgamma, dbeta, dx, dres, M, C, act, mask, rpb, nchunks, nrb, red_part, red_out, (size_t)red_n, red_splits);
+        SQD_CHECK_LAUNCH("sqd_bn_train_bwd");
+        return SQD_OK;
+    }
     if (pre_rows <= 0)
         hipLaunchKernelGGL((bn_reduce_kernel<1>), dim3(g.nblk), dim3(256), 0, s, x, dy, y, save_mean, save_rstd, part, M, C, act, g, mask, gamma, beta);
     const int nfin = (C + FIN_CH - 1) / FIN_CH, nred = red_part ? (int)((red_n / 4 + 15) / 16) : 0;

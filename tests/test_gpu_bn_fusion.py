@@ -159,3 +159,48 @@ def test_deferred_wgrad_reduce_rides_on_the_batchnorm_backward():
     ref, got = run(False), run(True)
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("N,C,H,W,Cm,act,with_res", [(12, 128, 6, 20, 512, "relu", True), (12, 64, 12, 40, 256, "relu", False),
+                                                     (8, 64, 20, 64, 128, "leaky_relu", False), (2, 32, 9, 13, 64, None, False)])
+def test_finalize_and_elementwise_pass_in_one_launch(N, C, H, W, Cm, act, with_res):
+    """Round 4: with few partial rows from the producing convolution (<= 160: the 12x40 / 6x20 maps of layer3 / layer4, 20x64 at configs[2]) and a
+    channel count that is a multiple of 64, BatchNorm's finalize and element-wise pass are ONE launch, forward and backward — every workgroup sums
+    the partial rows of its own 64 channels.  Output, batch statistics, running statistics and every gradient against float64."""
+    import copy
+    from sqd import lib, nnkernels, nnops
+    torch.manual_seed(N + Cm)
+    conv1, bn, conv2 = nn.Conv2d(C, Cm, 1, bias=False), nn.BatchNorm2d(Cm), nn.Conv2d(Cm, 64, 1, bias=False)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+    x, res = torch.randn(N, C, H, W), (torch.randn(N, Cm, H, W) if with_res else None)
+    c1, b1, c2 = copy.deepcopy(conv1).double(), copy.deepcopy(bn).double(), copy.deepcopy(conv2).double()
+    xr = x.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if with_res else None
+    out_r = _chain(c1, b1, c2, xr, act, rr)
+    g = torch.randn_like(out_r)
+    out_r.backward(g)
+    nnkernels.reset_plans()
+    m1, mb, m2 = conv1.cuda().to(memory_format=torch.channels_last), bn.cuda(), conv2.cuda().to(memory_format=torch.channels_last)
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    rg = res.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True) if with_res else None
+    geom1 = (N, H, W, C, Cm, 1, 1, 1, 0, H, W)
+    rows = nnkernels.conv_stats_rows(geom1)
+    assert 0 < rows <= 160 and Cm % 64 == 0, rows                 # the shape takes the one-launch path (csrc/bn_act.hip FUSE_MAX_ROWS)
+    z = nnops.conv_bn_act(xg, m1, mb, act, residual=rg)
+    out = nnops.conv2d(z, m2)
+    out.backward(g.float().cuda())
+
+    def close(a, b, what, tol=2e-4):
+        a, b = a.detach().cpu().double(), b.detach()
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max()) + 1e-7, (what, float((a - b).abs().max()), float(b.abs().max()))
+    close(out, out_r, "out")
+    close(mb.running_mean, b1.running_mean, "running_mean", 1e-5)
+    close(mb.running_var, b1.running_var, "running_var", 1e-5)
+    close(xg.grad, xr.grad, "dx")
+    close(mb.weight.grad, b1.weight.grad, "dgamma")
+    close(mb.bias.grad, b1.bias.grad, "dbeta")
+    close(m1.weight.grad, c1.weight.grad, "dW1")
+    if with_res:
+        close(rg.grad, rr.grad, "dres")
