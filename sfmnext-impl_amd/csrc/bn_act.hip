@@ -377,7 +377,10 @@ __global__ __launch_bounds__(256) void bn_apply_pool_fwd_kernel(const float *__r
 // many partial rows (360 at 24x80: 184 KB per workgroup — more than its slice of the tensor) and not with a cross-workgroup wait
 // (round 3 measured that: 1.4 - 3.7 x slower steps).
 // ---------------------------------------------------------------------------------------------------
-constexpr int FUSE_MAX_ROWS = 160;
+#ifndef SQD_BN_FUSE_MAX_ROWS
+#define SQD_BN_FUSE_MAX_ROWS 160
+#endif
+constexpr int FUSE_MAX_ROWS = SQD_BN_FUSE_MAX_ROWS;
 // (sum, sum2) of the thread's 4 channels over all partial rows -> s[0..3], q[0..3]; thread = (channel group t & 15, row lane t >> 4)
 __device__ __forceinline__ void chunk_sums(const float *__restrict__ part, int rows, int C, int c0, float4 &s, float4 &q, float4 (*red)[16][2]) {
     const int cgl = threadIdx.x & 15, rl = threadIdx.x >> 4;

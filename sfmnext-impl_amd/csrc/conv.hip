@@ -1597,6 +1597,166 @@ __global__ __launch_bounds__(256) void conv_wgrad_split3_kernel(const float *__r
             }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// wgrad, three-term bf16 operands straight from memory (impl 6, round 4).  The two kernels above that run on the bf16 matrix cores
+// turn the tile in LDS (pixels must be the 8 consecutive reduction elements of a lane, memory has the channels contiguous) and pay
+// for it with two barriers per 32 pixels and a workgroup-wide staging phase the matrix pipe waits behind.  But the MFMA only asks
+// that A and B agree on WHICH pixel sits in reduction slot kk, and that the 32 rows of a tile are 32 different channels — not which:
+//   * slot kk = 8 h + j (h = lane / 32) holds pixel p0 + 2 j + h: the two halves of the wave read the even / the odd pixel of a
+//     pair, so every pixel quantity is wave-uniform (scalar unit) and the odd half's address is the even one + a lane constant;
+//   * row i of tile ta holds filter k0 + KT i + ta (tile tb: channel c0 + CT i + tb): lane i fetches its KT (CT) consecutive
+//     channels of a pixel as ONE 8 / 16-byte load (256 / 512 contiguous bytes per half wave), and the value it needs for tile ta
+//     is element ta of that load — nothing is transposed, nothing goes through LDS, no barrier until the epilogue.
+// A step = 16 pixels = 8 loads of dy + 8 of x per lane, 5.5 VALU instructions per value for the exact split into three bf16 terms,
+// 6 x KT x CT v_mfma_f32_32x32x16_bf16 (smallest terms first).  The four waves of a workgroup walk four pixel ranges of one
+// (filters, channels, tap) tile and add their accumulators through LDS in a fixed order.  Needs an even Wo (a pair never straddles
+// an output row) unless the convolution is a plain 1x1 (x pixel = output pixel).  part[split][k][r][s][c] as for the others.
+// ---------------------------------------------------------------------------------------------------
+template <int KT, int CT, bool FLAT>
+__global__ __launch_bounds__(256, (KT * CT <= 4 ? 2 : 1)) void conv_wgrad_direct3_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                                       float *__restrict__ part, ConvGeom g, int px_per_wave,
+                                                                                       int nsplits) {
+    constexpr int NR = KT * CT * 16;                        // accumulator registers per lane
+    constexpr int PR = NR < 64 ? NR : 64;                   // ... of which one pass of the final cross-wave sum takes PR (64 KB of LDS)
+    constexpr bool TWO_RAW = KT * CT <= 4;                  // small tiles: two steps of loads in flight; large ones: the converted terms are the second buffer
+    __shared__ float red[4][PR][64];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i32 = lane & 31, h = lane >> 5;
+    const int RS = g.R * g.S, tk = g.K / (32 * KT), tc = g.C / (32 * CT);
+    const int logical = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);      // taps fastest inside an XCD's range
+    if (logical >= RS * tk * tc * nsplits) return;
+    const int tap = logical % RS, lg = logical / RS, grp = lg % (tk * tc), split = lg / (tk * tc);
+    const int k0 = (grp % tk) * 32 * KT, c0 = (grp / tk) * 32 * CT, r = tap / g.S, s = tap - r * g.S;
+    const int M = g.N * g.Ho * g.Wo;
+    const int mbeg = (split * 4 + wave) * px_per_wave, mend = min(M, mbeg + px_per_wave);
+    const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(dy, (unsigned)(g.N * g.Ho * g.Wo * g.K) * 4u);
+    const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(x, (unsigned)(g.N * g.H * g.W * g.C) * 4u);
+    // lane constants: its channels, + one pixel for the odd half
+    const unsigned dyl = (unsigned)(k0 + KT * i32) * 4u + (h ? (unsigned)g.K * 4u : 0u);
+    const unsigned xl = (unsigned)(c0 + CT * i32) * 4u + (h ? (unsigned)(FLAT ? g.C : g.stride * g.C) * 4u : 0u);
+    // the even pixel of the next pair (wave-uniform)
+    int m = mbeg;
+    int wo = 0, ho = 0, n = 0;
+    if (!FLAT) {
+        wo = m % g.Wo;
+        const int t2 = m / g.Wo;
+        ho = t2 % g.Ho;
+        n = t2 / g.Ho;
+    }
+    f32x16 acc[KT][CT];
+#pragma unroll
+    for (int a = 0; a < KT; ++a)
+#pragma unroll
+        for (int b = 0; b < CT; ++b)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
+
+    auto load_step = [&](float (*a)[KT], float (*b)[CT]) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ev = m < mend, od = m + 1 < mend;
+            ldb(dy_rsrc, (h ? od : ev) ? dyl + (unsigned)m * (unsigned)g.K * 4u : 0xffffffffu, a[j]);
+            if (FLAT) {
+                ldb(x_rsrc, (h ? od : ev) ? xl + (unsigned)m * (unsigned)g.C * 4u : 0xffffffffu, b[j]);
+            } else {
+                const int hi = ho * g.stride - g.pad + r, wi = wo * g.stride - g.pad + s;
+                const bool row = (unsigned)hi < (unsigned)g.H;
+                const bool xe = ev && row && (unsigned)wi < (unsigned)g.W, xo = od && row && (unsigned)(wi + g.stride) < (unsigned)g.W;
+                const unsigned so = (unsigned)(((n * g.H + hi) * g.W + wi) * g.C) * 4u;      // (may wrap below 0 for wi = -1: only the odd half adds to it)
+                ldb(x_rsrc, (h ? xo : xe) ? xl + so : 0xffffffffu, b[j]);
+                wo += 2;
+                if (wo >= g.Wo) {
+                    wo -= g.Wo;
+                    if (++ho >= g.Ho) { ho = 0; ++n; }
+                }
+            }
+            m += 2;
+        }
+    };
+    auto convert = [&](float (*a)[KT], float (*b)[CT], u32x4 (*A)[3], u32x4 (*B)[3]) {
+#pragma unroll
+        for (int q = 0; q < KT; ++q) {
+            const Split4 s0 = split3(make_float4(a[0][q], a[1][q], a[2][q], a[3][q])), s1 = split3(make_float4(a[4][q], a[5][q], a[6][q], a[7][q]));
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) A[q][tm] = (u32x4){s0.t[tm].x, s0.t[tm].y, s1.t[tm].x, s1.t[tm].y};
+        }
+#pragma unroll
+        for (int q = 0; q < CT; ++q) {
+            const Split4 s0 = split3(make_float4(b[0][q], b[1][q], b[2][q], b[3][q])), s1 = split3(make_float4(b[4][q], b[5][q], b[6][q], b[7][q]));
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm) B[q][tm] = (u32x4){s0.t[tm].x, s0.t[tm].y, s1.t[tm].x, s1.t[tm].y};
+        }
+    };
+    auto multiply = [&](u32x4 (*A)[3], u32x4 (*B)[3]) {
+#pragma unroll
+        for (int q = 0; q < KT; ++q)
+#pragma unroll
+            for (int c = 0; c < CT; ++c) {
+                f32x16 v = acc[q][c];                               // smallest terms first
+                v = mfma_bf(A[q][0], B[c][2], v);
+                v = mfma_bf(A[q][2], B[c][0], v);
+                v = mfma_bf(A[q][1], B[c][1], v);
+                v = mfma_bf(A[q][0], B[c][1], v);
+                v = mfma_bf(A[q][1], B[c][0], v);
+                acc[q][c] = mfma_bf(A[q][0], B[c][0], v);
+            }
+    };
+    auto mma_step = [&](float (*a)[KT], float (*b)[CT]) {
+        u32x4 A[KT][3], B[CT][3];
+        convert(a, b, A, B);
+        multiply(A, B);
+    };
+    const int nst = (mend - mbeg + 15) / 16;                  // steps (loads past mend return zeros)
+    if constexpr (TWO_RAW) {
+        float a0[8][KT], b0[8][CT], a1[8][KT], b1[8][CT];
+        if (nst > 0) load_step(a0, b0);
+        for (int st = 0; st < nst; st += 2) {
+            load_step(a1, b1);
+            mma_step(a0, b0);
+            load_step(a0, b0);
+            mma_step(a1, b1);
+        }
+    } else {
+        float a0[8][KT], b0[8][CT];
+        if (nst > 0) load_step(a0, b0);
+        for (int st = 0; st < nst; ++st) {
+            u32x4 A[KT][3], B[CT][3];
+            convert(a0, b0, A, B);
+            load_step(a0, b0);                                // the next step's values arrive under this step's products
+            multiply(A, B);
+        }
+    }
+    // ---- the four waves' accumulators added in a fixed order, PR registers per pass; register q = (ta * 16 + e) * CT + tb, wave w sums
+    // q in [w PR/4, (w+1) PR/4) of a pass: CT consecutive channels per store.  C/D layout of the 32x32 MFMA: column = lane & 31,
+    // row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
+    float *po = part + (size_t)split * g.K * RS * g.C;
+#pragma unroll
+    for (int pass = 0; pass < NR / PR; ++pass) {
+        if (pass > 0) __syncthreads();
+#pragma unroll
+        for (int a = 0; a < KT; ++a)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+#pragma unroll
+                for (int b = 0; b < CT; ++b) {
+                    const int q = (a * 16 + e) * CT + b;
+                    if (q / PR == pass) red[wave][q % PR][lane] = acc[a][b][e];
+                }
+        __syncthreads();
+        for (int q0 = wave * (PR / 4); q0 < (wave + 1) * (PR / 4); q0 += CT) {
+            float v[CT];
+#pragma unroll
+            for (int b = 0; b < CT; ++b) v[b] = ((red[0][q0 + b][lane] + red[1][q0 + b][lane]) + red[2][q0 + b][lane]) + red[3][q0 + b][lane];
+            const int ae = (pass * PR + q0) / CT, a = ae >> 4, e = ae & 15;
+            const int k = k0 + KT * ((e & 3) + 8 * (e >> 2) + 4 * h) + a, cc = c0 + CT * i32;
+            float *dst = po + ((size_t)k * RS + tap) * g.C + cc;
+            if (CT == 2) *reinterpret_cast<float2 *>(dst) = make_float2(v[0], v[1 % CT]);
+            else if (CT == 4) *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1 % CT], v[2 % CT], v[3 % CT]);
+            else dst[0] = v[0];
+        }
+    }
+}
+
 // sum of the split-K partial tiles (+ bias, + activation): part [Z][M*Ncols] -> out [M*Ncols]
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias,
                                                           const float *__restrict__ addend, float *__restrict__ out, size_t n, int Z,
@@ -2159,6 +2319,7 @@ struct WgradPlan {
     int shared = 0;                 // 1..4: shared-operand kernel, block 128x128 / 64x128 / 128x64 / 64x64 (filters x channels); 0: not
     int split3 = 0;                 // with shared != 0: the three-term bf16 kernel on the same blocks (impl 3) instead of fp32 (impl 2)
     int px_per_split = 0;
+    int direct3 = 0;                // 1..: three-term bf16 operands straight from memory (impl 6), register tile variant
     int rows = 0;                   // row-window kernel (impl 4): `splits` workgroups of `steps_per_wg` (image, column chunk, row) steps
     int steps_per_wg = 0, nchunks = 0;
 };
@@ -2190,7 +2351,14 @@ static bool wplan_lookup(int N, int Ho, int Wo, int C, int K, int R, int S, int 
     return true;
 }
 
-static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, int S, int stride = 1) {
+// register tile (x 32 filters, x 32 channels per lane-row) of the impl-6 kernel's variants
+static void direct3_tile(int variant, int &kt, int &ct) {
+    static const int T[6][2] = {{2, 2}, {2, 1}, {1, 2}, {4, 2}, {2, 4}, {4, 4}};
+    kt = T[variant - 1][0];
+    ct = T[variant - 1][1];
+}
+constexpr int DIRECT3_VARIANTS = 6;
+static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, int S, int stride = 1, bool pairs_ok = true) {
     WgradPlan p;
     const int M = N * Ho * Wo;
     int m_impl = -1, m_splits = 0;
@@ -2212,6 +2380,25 @@ static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, i
         }
         m_impl = 1;             // the plan table does not key on the stride: a strided convolution of the same output geometry runs the
     }                           // direct kernel on (at most) the same number of splits, inside the workspace the plan query reported
+    if (measured && (m_impl & 15) == 6) {
+        int kt3, ct3;
+        direct3_tile(((m_impl >> 4) & 15) + 1, kt3, ct3);
+        if (pairs_ok && K % (32 * kt3) == 0 && C % (32 * ct3) == 0) {
+            p.direct = false;
+            p.kt = p.ct = p.tp = 1;
+            p.direct3 = ((m_impl >> 4) & 15) + 1;
+            int sp = m_splits;
+            const int max_by_px = (M + 255) / 256;                   // >= 64 pixels per wave
+            if (sp > max_by_px) sp = max_by_px;
+            const int64_t wsz = (int64_t)K * R * S * C;
+            while (sp > 1 && (int64_t)sp * wsz * 4 > (64ll << 20)) --sp;
+            if (sp < 1) sp = 1;
+            p.splits = sp;
+            p.px_per_wave = ((M + sp * 4 - 1) / (sp * 4) + 15) / 16 * 16;
+            return p;
+        }
+        m_impl = 1;             // an odd Wo under a strided / padded convolution of the same output geometry: the fp32 direct kernel, same splits
+    }
     if (measured && ((m_impl & 15) == 2 || (m_impl & 15) == 3)) {      // shared-operand kernels (measured plans only)
         p.split3 = (m_impl & 15) == 3;
         p.direct = false;
@@ -2263,7 +2450,7 @@ static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, i
 extern "C" int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *splits, int64_t *part_floats) {
     const int M = N * Ho * Wo;
     const WgradPlan dp = plan_wgrad_direct(N, Ho, Wo, C, K, R, S);
-    if (dp.direct || dp.shared || dp.rows) {
+    if (dp.direct || dp.shared || dp.rows || dp.direct3) {
         if (splits) *splits = dp.splits;
         if (part_floats) *part_floats = (int64_t)dp.splits * K * R * S * C;
         return SQD_OK;
@@ -2299,6 +2486,16 @@ extern "C" int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int 
     if ((impl & 15) == 4) {                                      // row-window kernel (stride 1; few channels): `splits` workgroups
         SQD_CHECK_ARG(impl == 4 && rows_shape(C, K, R, S) && splits >= 1 && splits <= 65535,
                       "sqd_conv_wgrad_set_plan: the row-window kernel is not built for C=%d K=%d %dx%d", C, K, R, S);
+        wplan_table()[WPlanKey(N, Ho, Wo, C, K, R, S)] = std::make_pair(impl, splits);
+        return SQD_OK;
+    }
+    if ((impl & 15) == 6) {                                      // three-term bf16 operands straight from memory: 6 + 16 * variant
+        const int variant = (impl >> 4) + 1;
+        int kt3 = 0, ct3 = 0;
+        if (variant >= 1 && variant <= DIRECT3_VARIANTS) direct3_tile(variant, kt3, ct3);
+        SQD_CHECK_ARG(variant >= 1 && variant <= DIRECT3_VARIANTS && K % (32 * kt3) == 0 && C % (32 * ct3) == 0 && splits >= 1 && splits <= 65535 &&
+                          (Wo % 2 == 0 || (R == 1 && S == 1)),
+                      "sqd_conv_wgrad_set_plan: the three-term direct kernel (variant %d) does not fit K=%d, C=%d, Wo=%d", variant, K, C, Wo);
         wplan_table()[WPlanKey(N, Ho, Wo, C, K, R, S)] = std::make_pair(impl, splits);
         return SQD_OK;
     }
@@ -2383,8 +2580,26 @@ static int conv_wgrad_impl(const float *dy, const float *x, float *dw, float *db
     pps = ((pps + BK - 1) / BK) * BK;
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
-    const WgradPlan dp = plan_wgrad_direct(N, Ho, Wo, C, K, R, S, stride);
-    if (dp.rows) {
+    const bool flat = R == 1 && S == 1 && stride == 1 && pad == 0;
+    const WgradPlan dp = plan_wgrad_direct(N, Ho, Wo, C, K, R, S, stride, flat || Wo % 2 == 0);
+    if (dp.direct3) {
+        int kt3, ct3;
+        direct3_tile(dp.direct3, kt3, ct3);
+        const dim3 grid(((K / (32 * kt3)) * (C / (32 * ct3)) * R * S * dp.splits + 7) / 8 * 8);
+#define LAUNCH_W6(KT, CT)                                                                                                              \
+    do {                                                                                                                               \
+        if (flat) hipLaunchKernelGGL((conv_wgrad_direct3_kernel<KT, CT, true>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, dp.splits); \
+        else hipLaunchKernelGGL((conv_wgrad_direct3_kernel<KT, CT, false>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, dp.splits);    \
+    } while (0)
+        switch (dp.direct3) {
+            case 1: LAUNCH_W6(2, 2); break;
+            case 2: LAUNCH_W6(2, 1); break;
+            case 3: LAUNCH_W6(1, 2); break;
+            case 4: LAUNCH_W6(4, 2); break;
+            case 5: LAUNCH_W6(2, 4); break;
+            default: LAUNCH_W6(4, 4); break;
+        }
+    } else if (dp.rows) {
         const dim3 grid((dp.splits + 7) / 8 * 8);
         float *bias_part = dbias ? part + (size_t)dp.splits * K * R * S * C : nullptr;   // [splits][K]
 #define LAUNCH_WR(KT, CT, RR, IG, PG, PXW)                                                                                     \
@@ -2446,7 +2661,7 @@ static int conv_wgrad_impl(const float *dy, const float *x, float *dw, float *db
     const size_t wsz = (size_t)K * R * S * C;
     // (leaving the ~100 reductions of a backward pass to two or three multi-task launches at its end was measured: bit-identical and
     // 0.7 ms SLOWER per step — reduced on the spot the partials of most layers are still in the 256 MB Infinity Cache)
-    if (dp.direct || dp.shared || dp.rows) splits = dp.splits;    // (a strided convolution under a row-window plan: see plan_wgrad_direct)
+    if (dp.direct || dp.shared || dp.rows || dp.direct3) splits = dp.splits;    // (a strided convolution under a row-window plan: see plan_wgrad_direct)
     if (splits_out) *splits_out = splits;
     if (reduce_dw) hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((wsz / 4 + 15) / 16)), dim3(256), 0, st, part, dw, wsz, splits);
     if (dbias && ((dp.direct && !dp.shared) || dp.rows)) {

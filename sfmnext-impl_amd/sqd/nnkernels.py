@@ -214,6 +214,7 @@ TUNE_SPACE = {
     "bk64": False,             # bk 64+512 on the single-buffered 64x64 tile: picked for 11 layer-modes, no gain on the totals
     "eight_wave": False,       # bk +256: 8-wave workgroups — 1-3 % on a third of the layers, nothing on the step
     "wgrad_shapes": False,     # smaller register tiles of the direct weight gradient: 7 of 38 layers, nothing on the step
+    "wgrad_direct3": True,     # impl 6: three-term bf16 operands straight from memory (even / odd pixel per half wave)
     "wgrad_rows": True,        # impl 4: the row-window weight gradient of the few-channel / high-resolution layers
     "stats_penalty": False,    # (history: split-K forward plans used to force a BatchNorm statistics pass; their sum takes the partials now)
     "wgrad_transposed": True,  # impl 5: the wide 1x1 layers' weight gradient as a forward GEMM on transposed operands
@@ -339,6 +340,22 @@ def _tune_wgrad(geom, has_bias, launch, launch_t=None):
             sp = max(1, (target + blocks - 1) // blocks)
             if sp not in tried and trial(base_impl | (v << 4), sp):
                 tried.add(sp)
+    # three-term bf16 operands straight from memory (impl 6 + 16 * variant; round 4): register tiles of 64x64, 128x64, 64x128, 128x128
+    # (filters x channels) per wave — the wider the tile, the more pixel splits it takes to fill the chip
+    if TUNE_SPACE["wgrad_direct3"]:
+        # pixel splits for a whole number of workgroup rounds: the 64x64 and 128x64 tiles keep two workgroups per CU resident, the
+        # 64x128 and 128x128 ones one
+        for v, (tk, tc), per_cu in ((0, (64, 64), 2), (3, (128, 64), 2), (4, (64, 128), 1), (5, (128, 128), 1)):
+            if K % tk or C % tc:
+                continue
+            tiles = (K // tk) * (C // tc) * R * S
+            tried = set()
+            for target in (128, 192, 256, 384, 512, 768, 1024):
+                sp = max(1, (target * per_cu) // tiles)
+                if sp not in tried:
+                    tried.add(sp)
+                    if not trial(6 | (v << 4), sp):
+                        break
     # row-window kernel (impl 4): few channels, stride 1 — the whole filter bank in one workgroup's accumulators, `sp` workgroups
     # (the library refuses the shapes it is not built for)
     if stride == 1 and R == S and TUNE_SPACE["wgrad_rows"]:
@@ -452,7 +469,8 @@ def plan_mix():
     mix = {}
     for k, v in CHOSEN_PLANS.items():
         if k[0] == "wgrad":
-            name = {0: "fp32 lds-tiled", 1: "fp32 direct", 2: "fp32 shared-operand", 3: "bf16x3 shared-operand", 4: "fp32 row-window", 5: "transposed forward-gemm (its own fwd plan)"}[v[0] & 15]
+            name = {0: "fp32 lds-tiled", 1: "fp32 direct", 2: "fp32 shared-operand", 3: "bf16x3 shared-operand", 4: "fp32 row-window", 5: "transposed forward-gemm (its own fwd plan)",
+                    6: "bf16x3 direct-operand"}[v[0] & 15]
         else:
             bk = v[3]
             name = "bf16x3 input-patch" if bk & 2048 else "bf16x3 implicit-gemm" if bk & 1024 else "fp32 implicit-gemm"

@@ -406,6 +406,47 @@ def test_wgrad_shared_operand_kernel(impl, variant, N, C, H, W, K, R, stride, pa
     assert L.sqd_conv_wgrad_set_plan(N, Ho, Wo, 48, K, R, R, impl, 4) != 0         # 128-channel block on C = 48: refused
 
 
+@pytest.mark.parametrize("variant,N,C,H,W,K,R,stride,pad,bias,splits", [
+    (0, 2, 128, 24, 40, 256, 3, 1, 1, False, 5), (0, 3, 256, 13, 21, 128, 1, 1, 0, True, 3), (0, 2, 128, 24, 40, 64, 3, 2, 1, False, 4),
+    (1, 2, 32, 24, 40, 128, 3, 1, 1, True, 7), (2, 2, 64, 24, 36, 32, 5, 2, 2, False, 2), (0, 1, 192, 9, 12, 64, 3, 1, 1, False, 64),
+    (0, 2, 64, 12, 40, 128, 1, 2, 0, False, 2), (2, 1, 64, 7, 9, 96, 1, 1, 0, False, 1),
+    (3, 2, 64, 24, 40, 128, 3, 1, 1, False, 3), (4, 2, 128, 13, 21, 64, 1, 1, 0, True, 2), (5, 2, 128, 12, 20, 256, 3, 2, 1, False, 2),
+    (5, 1, 256, 9, 11, 128, 1, 1, 0, False, 5)])
+def test_wgrad_three_term_direct_kernel(variant, N, C, H, W, K, R, stride, pad, bias, splits):
+    """impl 6 (round 4): three-term bf16 operands straight from memory — the wave's halves take the even / odd pixel of a pair, a lane
+    its consecutive channels of one pixel as one load — against float64: 3x3 / 5x5 / 1x1, strides, padding (the pair that straddles the
+    image border), a ragged last pixel range, an odd pixel count (plain 1x1), more splits than the pixels allow."""
+    from sqd import lib, nnkernels
+    L = lib.lib()
+    torch.manual_seed(variant + K)
+    conv = nn.Conv2d(C, K, R, stride, pad, bias=bias)
+    x = torch.randn(N, C, H, W)
+    conv64 = nn.Conv2d(C, K, R, stride, pad, bias=bias).double()
+    conv64.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+    yr = conv64(x.double())
+    wgt = torch.randn(yr.shape)
+    (yr * wgt.double()).sum().backward()
+    Ho, Wo = yr.shape[2:]
+    try:
+        assert L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, R, 6 | (variant << 4), splits) == 0
+        nnkernels._PLAN_CACHE.clear()
+        conv_g = nn.Conv2d(C, K, R, stride, pad, bias=bias).cuda()
+        conv_g.load_state_dict(conv.state_dict())
+        conv_g = conv_g.to(memory_format=torch.channels_last)
+        xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        y = nnkernels.conv2d_native(xg, conv_g, None)
+        (y * wgt.cuda()).sum().backward()
+    finally:
+        L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, R, -1, 0)
+        nnkernels._PLAN_CACHE.clear()
+    pairs = [("dw", conv_g.weight.grad, conv64.weight.grad)] + ([("db", conv_g.bias.grad, conv64.bias.grad)] if bias else [])
+    for name, a, b in pairs:
+        err, scale = float((a.cpu().double() - b).abs().max()), float(b.abs().max())
+        assert err <= 1e-4 * scale, (name, err, scale)
+    assert L.sqd_conv_wgrad_set_plan(N, Ho, Wo, 48, K, R, R, 6, 4) != 0            # 64-channel tile on C = 48: refused
+    assert L.sqd_conv_wgrad_set_plan(N, 7, 9, C, K, 3, 3, 6 | (variant << 4), 4) != 0     # odd Wo under a 3x3: pairs would straddle rows, refused
+
+
 def test_wgrad_plan_shared_by_output_geometry():
     """Two convolutions with the same (N, Ho, Wo, C, K, R, S) and different strides share one library plan: tuning the second must
     not leave the first with a stale workspace size (regression: out-of-bounds partial sums on the side-stream launch)."""
