@@ -215,6 +215,7 @@ TUNE_SPACE = {
     "eight_wave": False,       # bk +256: 8-wave workgroups — 1-3 % on a third of the layers, nothing on the step
     "wgrad_shapes": False,     # smaller register tiles of the direct weight gradient: 7 of 38 layers, nothing on the step
     "wgrad_direct3": True,     # impl 6: three-term bf16 operands straight from memory (even / odd pixel per half wave)
+    "wgrad_direct3_wide": True,  # ... its one-wave-per-SIMD tiles (64x128, 128x128)
     "wgrad_rows": True,        # impl 4: the row-window weight gradient of the few-channel / high-resolution layers
     "stats_penalty": False,    # (history: split-K forward plans used to force a BatchNorm statistics pass; their sum takes the partials now)
     "wgrad_transposed": True,  # impl 5: the wide 1x1 layers' weight gradient as a forward GEMM on transposed operands
@@ -346,7 +347,7 @@ def _tune_wgrad(geom, has_bias, launch, launch_t=None):
         # pixel splits for a whole number of workgroup rounds: the 64x64 and 128x64 tiles keep two workgroups per CU resident, the
         # 64x128 and 128x128 ones one
         for v, (tk, tc), per_cu in ((0, (64, 64), 2), (3, (128, 64), 2), (4, (64, 128), 1), (5, (128, 128), 1)):
-            if K % tk or C % tc:
+            if K % tk or C % tc or (per_cu == 1 and not TUNE_SPACE["wgrad_direct3_wide"]):
                 continue
             tiles = (K // tk) * (C // tc) * R * S
             tried = set()
