@@ -329,7 +329,10 @@ int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *
  * 2 / 3 + 16 * v = shared-operand kernel in fp32 MFMA / three-term bf16 arithmetic on blocks v = 0..3 of 128x128, 64x128, 128x64,
  * 64x64 filters x channels (K, C divisible by the block), 4 = row-window kernel (stride 1; K in {16,32,64} filters x C in {16,32,96}
  * channels x 3x3 / 4x4 taps as instantiated — others are refused; `splits` = workgroups, each holding the whole filter bank),
- * -1 = clear.  Plans are keyed by (N, Ho, Wo, C, K, R, S); a strided convolution of that key under an impl-4 plan runs impl 1. */
+ * 6 + 16 * v = three-term bf16 operands straight from memory (the wave's halves take the even / odd pixel of a pair; register tiles
+ * v = 0..5 of 64x64, 64x32, 32x64, 128x64, 64x128, 128x128 filters x channels; even Wo unless R = S = 1),
+ * -1 = clear.  Plans are keyed by (N, Ho, Wo, C, K, R, S); a strided convolution of that key under an impl-4 / impl-6 plan it cannot run
+ * takes impl 1 with the same splits. */
 int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int impl, int splits);
 int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C, int K,
                    int R, int S, int stride, int pad, int Ho, int Wo, void *stream);
