@@ -1612,14 +1612,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_split3_kernel(const float *__r
 // (filters, channels, tap) tile and add their accumulators through LDS in a fixed order.  Needs an even Wo (a pair never straddles
 // an output row) unless the convolution is a plain 1x1 (x pixel = output pixel).  part[split][k][r][s][c] as for the others.
 // ---------------------------------------------------------------------------------------------------
-template <int KT, int CT, bool FLAT>
-__global__ __launch_bounds__(256, (KT * CT <= 4 ? 2 : 1)) void conv_wgrad_direct3_kernel(const float *__restrict__ dy, const float *__restrict__ x,
-                                                                                       float *__restrict__ part, ConvGeom g, int px_per_wave,
-                                                                                       int nsplits) {
+template <int KT, int CT, bool FLAT, int NW = 4>
+__global__ __launch_bounds__(NW * 64, (KT * CT <= 4 || NW == 8 ? 2 : 1)) void conv_wgrad_direct3_kernel(const float *__restrict__ dy,
+                                                                                                      const float *__restrict__ x,
+                                                                                                      float *__restrict__ part, ConvGeom g,
+                                                                                                      int px_per_wave, int nsplits) {
+#ifdef SQD_WGRAD_TRACE
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int NR = KT * CT * 16;                        // accumulator registers per lane
-    constexpr int PR = NR < 64 ? NR : 64;                   // ... of which one pass of the final cross-wave sum takes PR (64 KB of LDS)
+    static_assert((NW == 4 || NW == 8) && (256 / NW) % CT == 0 && (256 / NW / NW) % CT == 0, "4 or 8 waves");
+    constexpr int PR = (NR < 256 / NW ? NR : 256 / NW);     // ... of which one pass of the final cross-wave sum takes PR (64 KB of LDS)
     constexpr bool TWO_RAW = KT * CT <= 4;                  // small tiles: two steps of loads in flight; large ones: the converted terms are the second buffer
-    __shared__ float red[4][PR][64];
+    __shared__ float red[NW][PR][64];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i32 = lane & 31, h = lane >> 5;
     const int RS = g.R * g.S, tk = g.K / (32 * KT), tc = g.C / (32 * CT);
@@ -1628,7 +1633,7 @@ __global__ __launch_bounds__(256, (KT * CT <= 4 ? 2 : 1)) void conv_wgrad_direct
     const int tap = logical % RS, lg = logical / RS, grp = lg % (tk * tc), split = lg / (tk * tc);
     const int k0 = (grp % tk) * 32 * KT, c0 = (grp / tk) * 32 * CT, r = tap / g.S, s = tap - r * g.S;
     const int M = g.N * g.Ho * g.Wo;
-    const int mbeg = (split * 4 + wave) * px_per_wave, mend = min(M, mbeg + px_per_wave);
+    const int mbeg = (split * NW + wave) * px_per_wave, mend = min(M, mbeg + px_per_wave);
     const __amdgpu_buffer_rsrc_t dy_rsrc = make_rsrc(dy, (unsigned)(g.N * g.Ho * g.Wo * g.K) * 4u);
     const __amdgpu_buffer_rsrc_t x_rsrc = make_rsrc(x, (unsigned)(g.N * g.H * g.W * g.C) * 4u);
     // lane constants: its channels, + one pixel for the odd half
@@ -1652,6 +1657,19 @@ __global__ __launch_bounds__(256, (KT * CT <= 4 ? 2 : 1)) void conv_wgrad_direct
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
     auto load_step = [&](float (*a)[KT], float (*b)[CT]) {
+#ifdef SQD_WG_NOLOAD
+        if (m > mbeg) {
+            m += 16;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int q = 0; q < KT; ++q) asm volatile("" : "+v"(a[j][q]));
+#pragma unroll
+                for (int q = 0; q < CT; ++q) asm volatile("" : "+v"(b[j][q]));
+            }
+            return;
+        }
+#endif
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool ev = m < mend, od = m + 1 < mend;
@@ -1674,6 +1692,19 @@ __global__ __launch_bounds__(256, (KT * CT <= 4 ? 2 : 1)) void conv_wgrad_direct
         }
     };
     auto convert = [&](float (*a)[KT], float (*b)[CT], u32x4 (*A)[3], u32x4 (*B)[3]) {
+#ifdef SQD_WG_NOCVT
+#pragma unroll
+        for (int q = 0; q < KT; ++q)
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm)
+                A[q][tm] = (u32x4){__float_as_uint(a[0 + tm][q]), __float_as_uint(a[1 + tm][q]), __float_as_uint(a[2 + tm][q]), __float_as_uint(a[3 + tm][q])};
+#pragma unroll
+        for (int q = 0; q < CT; ++q)
+#pragma unroll
+            for (int tm = 0; tm < 3; ++tm)
+                B[q][tm] = (u32x4){__float_as_uint(b[0 + tm][q]), __float_as_uint(b[1 + tm][q]), __float_as_uint(b[2 + tm][q]), __float_as_uint(b[3 + tm][q])};
+        return;
+#endif
 #pragma unroll
         for (int q = 0; q < KT; ++q) {
             const Split4 s0 = split3(make_float4(a[0][q], a[1][q], a[2][q], a[3][q])), s1 = split3(make_float4(a[4][q], a[5][q], a[6][q], a[7][q]));
@@ -1726,6 +1757,9 @@ __global__ __launch_bounds__(256, (KT * CT <= 4 ? 2 : 1)) void conv_wgrad_direct
             multiply(A, B);
         }
     }
+#ifdef SQD_WGRAD_TRACE
+    const unsigned long long t_loop = __builtin_amdgcn_s_memtime();
+#endif
     // ---- the four waves' accumulators added in a fixed order, PR registers per pass; register q = (ta * 16 + e) * CT + tb, wave w sums
     // q in [w PR/4, (w+1) PR/4) of a pass: CT consecutive channels per store.  C/D layout of the 32x32 MFMA: column = lane & 31,
     // row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
@@ -1743,10 +1777,13 @@ __global__ __launch_bounds__(256, (KT * CT <= 4 ? 2 : 1)) void conv_wgrad_direct
                     if (q / PR == pass) red[wave][q % PR][lane] = acc[a][b][e];
                 }
         __syncthreads();
-        for (int q0 = wave * (PR / 4); q0 < (wave + 1) * (PR / 4); q0 += CT) {
+        for (int q0 = wave * (PR / NW); q0 < (wave + 1) * (PR / NW); q0 += CT) {
             float v[CT];
 #pragma unroll
-            for (int b = 0; b < CT; ++b) v[b] = ((red[0][q0 + b][lane] + red[1][q0 + b][lane]) + red[2][q0 + b][lane]) + red[3][q0 + b][lane];
+            for (int b = 0; b < CT; ++b) {
+                v[b] = ((red[0][q0 + b][lane] + red[1][q0 + b][lane]) + red[2][q0 + b][lane]) + red[3][q0 + b][lane];
+                if (NW == 8) v[b] += ((red[4 % NW][q0 + b][lane] + red[5 % NW][q0 + b][lane]) + red[6 % NW][q0 + b][lane]) + red[7 % NW][q0 + b][lane];
+            }
             const int ae = (pass * PR + q0) / CT, a = ae >> 4, e = ae & 15;
             const int k = k0 + KT * ((e & 3) + 8 * (e >> 2) + 4 * h) + a, cc = c0 + CT * i32;
             float *dst = po + ((size_t)k * RS + tap) * g.C + cc;
@@ -1755,6 +1792,12 @@ __global__ __launch_bounds__(256, (KT * CT <= 4 ? 2 : 1)) void conv_wgrad_direct
             else dst[0] = v[0];
         }
     }
+#ifdef SQD_WGRAD_TRACE
+    if (lane == 0) {
+        unsigned long long *tr = reinterpret_cast<unsigned long long *>(part + (size_t)nsplits * g.K * RS * g.C) + ((size_t)blockIdx.x * NW + wave) * 4;
+        tr[0] = t_entry; tr[1] = t_loop; tr[2] = __builtin_amdgcn_s_memtime(); tr[3] = (unsigned long long)logical;
+    }
+#endif
 }
 
 // sum of the split-K partial tiles (+ bias, + activation): part [Z][M*Ncols] -> out [M*Ncols]
@@ -2353,11 +2396,12 @@ static bool wplan_lookup(int N, int Ho, int Wo, int C, int K, int R, int S, int 
 
 // register tile (x 32 filters, x 32 channels per lane-row) of the impl-6 kernel's variants
 static void direct3_tile(int variant, int &kt, int &ct) {
-    static const int T[6][2] = {{2, 2}, {2, 1}, {1, 2}, {4, 2}, {2, 4}, {4, 4}};
+    static const int T[8][2] = {{2, 2}, {2, 1}, {1, 2}, {4, 2}, {2, 4}, {4, 4}, {4, 2}, {2, 2}};     // variants 7, 8: 8-wave workgroups
     kt = T[variant - 1][0];
     ct = T[variant - 1][1];
 }
-constexpr int DIRECT3_VARIANTS = 6;
+constexpr int DIRECT3_VARIANTS = 8;
+static int direct3_waves(int variant) { return variant >= 7 ? 8 : 4; }
 static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, int S, int stride = 1, bool pairs_ok = true) {
     WgradPlan p;
     const int M = N * Ho * Wo;
@@ -2394,7 +2438,8 @@ static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, i
             while (sp > 1 && (int64_t)sp * wsz * 4 > (64ll << 20)) --sp;
             if (sp < 1) sp = 1;
             p.splits = sp;
-            p.px_per_wave = ((M + sp * 4 - 1) / (sp * 4) + 15) / 16 * 16;
+            const int nw = direct3_waves(p.direct3);
+            p.px_per_wave = ((M + sp * nw - 1) / (sp * nw) + 15) / 16 * 16;
             return p;
         }
         m_impl = 1;             // an odd Wo under a strided / padded convolution of the same output geometry: the fp32 direct kernel, same splits
@@ -2586,18 +2631,20 @@ static int conv_wgrad_impl(const float *dy, const float *x, float *dw, float *db
         int kt3, ct3;
         direct3_tile(dp.direct3, kt3, ct3);
         const dim3 grid(((K / (32 * kt3)) * (C / (32 * ct3)) * R * S * dp.splits + 7) / 8 * 8);
-#define LAUNCH_W6(KT, CT)                                                                                                              \
+#define LAUNCH_W6(KT, CT, NW)                                                                                                          \
     do {                                                                                                                               \
-        if (flat) hipLaunchKernelGGL((conv_wgrad_direct3_kernel<KT, CT, true>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, dp.splits); \
-        else hipLaunchKernelGGL((conv_wgrad_direct3_kernel<KT, CT, false>), grid, dim3(256), 0, st, dy, x, part, g, dp.px_per_wave, dp.splits);    \
+        if (flat) hipLaunchKernelGGL((conv_wgrad_direct3_kernel<KT, CT, true, NW>), grid, dim3(NW * 64), 0, st, dy, x, part, g, dp.px_per_wave, dp.splits); \
+        else hipLaunchKernelGGL((conv_wgrad_direct3_kernel<KT, CT, false, NW>), grid, dim3(NW * 64), 0, st, dy, x, part, g, dp.px_per_wave, dp.splits);    \
     } while (0)
         switch (dp.direct3) {
-            case 1: LAUNCH_W6(2, 2); break;
-            case 2: LAUNCH_W6(2, 1); break;
-            case 3: LAUNCH_W6(1, 2); break;
-            case 4: LAUNCH_W6(4, 2); break;
-            case 5: LAUNCH_W6(2, 4); break;
-            default: LAUNCH_W6(4, 4); break;
+            case 1: LAUNCH_W6(2, 2, 4); break;
+            case 2: LAUNCH_W6(2, 1, 4); break;
+            case 3: LAUNCH_W6(1, 2, 4); break;
+            case 4: LAUNCH_W6(4, 2, 4); break;
+            case 5: LAUNCH_W6(2, 4, 4); break;
+            case 6: LAUNCH_W6(4, 4, 4); break;
+            case 7: LAUNCH_W6(4, 2, 8); break;
+            default: LAUNCH_W6(2, 2, 8); break;
         }
     } else if (dp.rows) {
         const dim3 grid((dp.splits + 7) / 8 * 8);

@@ -215,6 +215,7 @@ TUNE_SPACE = {
     "eight_wave": False,       # bk +256: 8-wave workgroups — 1-3 % on a third of the layers, nothing on the step
     "wgrad_shapes": False,     # smaller register tiles of the direct weight gradient: 7 of 38 layers, nothing on the step
     "wgrad_direct3": True,     # impl 6: three-term bf16 operands straight from memory (even / odd pixel per half wave)
+    "wgrad_direct3_8w": True,    # ... its eight-wave workgroups (two waves per SIMD on one tile: conversions of one wave under the MFMAs of the other)
     "wgrad_direct3_wide": True,  # ... its one-wave-per-SIMD tiles (64x128, 128x128)
     "wgrad_rows": True,        # impl 4: the row-window weight gradient of the few-channel / high-resolution layers
     "stats_penalty": False,    # (history: split-K forward plans used to force a BatchNorm statistics pass; their sum takes the partials now)
@@ -346,8 +347,8 @@ def _tune_wgrad(geom, has_bias, launch, launch_t=None):
     if TUNE_SPACE["wgrad_direct3"]:
         # pixel splits for a whole number of workgroup rounds: the 64x64 and 128x64 tiles keep two workgroups per CU resident, the
         # 64x128 and 128x128 ones one
-        for v, (tk, tc), per_cu in ((0, (64, 64), 2), (3, (128, 64), 2), (4, (64, 128), 1), (5, (128, 128), 1)):
-            if K % tk or C % tc or (per_cu == 1 and not TUNE_SPACE["wgrad_direct3_wide"]):
+        for v, (tk, tc), per_cu in ((0, (64, 64), 2), (3, (128, 64), 2), (4, (64, 128), 1), (5, (128, 128), 1), (6, (128, 64), 1), (7, (64, 64), 1)):
+            if K % tk or C % tc or (per_cu == 1 and v < 6 and not TUNE_SPACE["wgrad_direct3_wide"]) or (v >= 6 and not TUNE_SPACE["wgrad_direct3_8w"]):
                 continue
             tiles = (K // tk) * (C // tc) * R * S
             tried = set()

@@ -411,11 +411,12 @@ def test_wgrad_shared_operand_kernel(impl, variant, N, C, H, W, K, R, stride, pa
     (1, 2, 32, 24, 40, 128, 3, 1, 1, True, 7), (2, 2, 64, 24, 36, 32, 5, 2, 2, False, 2), (0, 1, 192, 9, 12, 64, 3, 1, 1, False, 64),
     (0, 2, 64, 12, 40, 128, 1, 2, 0, False, 2), (2, 1, 64, 7, 9, 96, 1, 1, 0, False, 1),
     (3, 2, 64, 24, 40, 128, 3, 1, 1, False, 3), (4, 2, 128, 13, 21, 64, 1, 1, 0, True, 2), (5, 2, 128, 12, 20, 256, 3, 2, 1, False, 2),
-    (5, 1, 256, 9, 11, 128, 1, 1, 0, False, 5)])
+    (5, 1, 256, 9, 11, 128, 1, 1, 0, False, 5), (6, 2, 64, 24, 40, 128, 3, 1, 1, False, 3), (6, 3, 128, 13, 21, 256, 1, 1, 0, True, 2),
+    (7, 2, 64, 23, 36, 64, 3, 2, 1, False, 2), (7, 1, 64, 9, 11, 64, 1, 1, 0, False, 1)])
 def test_wgrad_three_term_direct_kernel(variant, N, C, H, W, K, R, stride, pad, bias, splits):
     """impl 6 (round 4): three-term bf16 operands straight from memory — the wave's halves take the even / odd pixel of a pair, a lane
     its consecutive channels of one pixel as one load — against float64: 3x3 / 5x5 / 1x1, strides, padding (the pair that straddles the
-    image border), a ragged last pixel range, an odd pixel count (plain 1x1), more splits than the pixels allow."""
+    image border), a ragged last pixel range, an odd pixel count (plain 1x1), more splits than the pixels allow; variants 6 / 7: eight waves per workgroup."""
     from sqd import lib, nnkernels
     L = lib.lib()
     torch.manual_seed(variant + K)

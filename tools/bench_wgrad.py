@@ -27,7 +27,7 @@ S = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 gflop = 2.0 * N * Ho * Wo * K * C * R * R / 1e9
 names = {0: "lds-tiled fp32", 1: "direct fp32", 2: "shared fp32", 3: "shared 3xbf16", 4: "row-window fp32", 6: "direct 3xbf16"}
 only = [int(v) for v in os.environ.get('BENCH_WGRAD_IMPLS', '').split(',') if v]
-for impl, variants in ((1, [0]), (0, [0]), (2, range(4)), (3, range(4)), (4, [0]), (6, range(6))):
+for impl, variants in ((1, [0]), (0, [0]), (2, range(4)), (3, range(4)), (4, [0]), (6, range(8))):
     if only and impl not in only:
         continue
     for v in variants:
