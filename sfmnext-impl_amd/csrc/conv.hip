@@ -2079,6 +2079,10 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT, 0>),                                              \
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(512), 0, st, \
                        a_src, w, bias, dst, g, act, p.z, order, stats, bnb)
+#define LAUNCH_GEMM8_P(MODE, BM, BN, WGM, WGN, BKT, PREC)                                                                \
+    hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT, PREC>),                                           \
+                       dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(512), 0, st, \
+                       a_src, w, bias, dst, g, act, p.z, order, stats, bnb)
 #define LAUNCH_HALO4(WTM, WM, WN, WK)                                                                                      \
     hipLaunchKernelGGL((conv3x3_halo_kernel<0, WTM, WM, WN, WK, 4>),                                                         \
                        dim3(g.N * ((g.H + 2 * WTM - 1) / (2 * WTM)) * ((g.W + 15) / 16) * ((Ncols + WN * 32 - 1) / (WN * 32)), 1, p.z), \
@@ -2102,6 +2106,10 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
         else if (p.bn == 128) LAUNCH_HALO(MODE, 2, 1, 4, 1);                     \
         else if (p.bn == 64) LAUNCH_HALO(MODE, 2, 1, 2, 2);                      \
         else LAUNCH_HALO(MODE, 2, 2, 1, 2);                                      \
+    } else if (p.split3 && p.waves == 8) {                                             \
+        if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM8_P(MODE, 128, 128, 4, 2, 32, 4);     \
+        else if (p.bm == 128) LAUNCH_GEMM8_P(MODE, 128, 64, 4, 2, 32, 4);               \
+        else LAUNCH_GEMM8_P(MODE, 64, 128, 2, 4, 32, 4);                                \
     } else if (p.split3) {                                                              \
         if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM_P(MODE, 128, 128, 2, 2, 32, 4);      \
         else if (p.bm == 128 && p.bn == 32) LAUNCH_GEMM_P(MODE, 128, 32, 4, 1, 32, 4);   \
@@ -2227,14 +2235,17 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
         plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, 32 | 1024 | 2048);
         return SQD_OK;
     }
-    if (split3) {
+    if (split3 && waves == 8) {
+        SQD_CHECK_ARG(!single && bk == 32 && ((bm == 128 && (bn == 128 || (bn == 64 && mode == 0))) || (bm == 64 && bn == 128)),
+                      "sqd_conv_set_plan: the 8-wave three-term variants are 128x128, 64x128 and (forward) 128x64 tiles with 32-channel slices");
+    } else if (split3) {
         SQD_CHECK_ARG(waves == 4 && !single && bk == 32 && (((bm == 128 || bm == 64) && (bn == 128 || bn == 64)) || (bm == 128 && bn == 32)),
                       "sqd_conv_set_plan: the three-term bf16 variants are 4-wave 128/64 x 128/64 and 128x32 tiles with 32-channel slices");
     }
     SQD_CHECK_ARG(!single || (waves == 4 && ((bm == 64 && bn == 64) || (bm + bn == 192 && bk == 32) || (bm == 128 && bn == 128 && bk == 16) ||
                                              (bm == 128 && bn == 32))),
                   "sqd_conv_set_plan: single-buffered variants exist for 64x64, 128x32, 128x64 / 64x128 (bk 32) and 128x128 (bk 16)");
-    SQD_CHECK_ARG(waves == 4 || (bm == 128 && bn == 128 && bk == 16) || (bm == 128 && bn == 64) || (bm == 64 && bn == 128 && bk == 32),
+    SQD_CHECK_ARG(waves == 4 || split3 || (bm == 128 && bn == 128 && bk == 16) || (bm == 128 && bn == 64) || (bm == 64 && bn == 128 && bk == 32),
                   "sqd_conv_set_plan: 8-wave workgroups exist for 128x128 (bk 16), 128x64 and 64x128 (bk 32) tiles");
     SQD_CHECK_ARG(bk == 16 || split3 || (bk == 32 && (mode == 0 ? C : K) % 32 == 0 && bm + bn <= 192) ||
                       (bk == 64 && single && bm == 64 && bn == 64 && (mode == 0 ? C : K) % 64 == 0),

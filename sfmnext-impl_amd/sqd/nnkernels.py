@@ -213,6 +213,7 @@ TUNE_SPACE = {
     "input_patch": True,       # bk 32+1024+2048: the input-patch kernel for 3x3 / stride 1 (three-term bf16 operands)
     "bk64": False,             # bk 64+512 on the single-buffered 64x64 tile: picked for 11 layer-modes, no gain on the totals
     "eight_wave": False,       # bk +256: 8-wave workgroups — 1-3 % on a third of the layers, nothing on the step
+    "eight_wave_split3": True, # bk 32 + 256 + 1024: the three-term tiles on 8-wave workgroups (conversions of some waves under the MFMAs of others)
     "wgrad_shapes": False,     # smaller register tiles of the direct weight gradient: 7 of 38 layers, nothing on the step
     "wgrad_direct3": True,     # impl 6: three-term bf16 operands straight from memory (even / odd pixel per half wave)
     "wgrad_direct3_8w": True,    # ... its eight-wave workgroups (two waves per SIMD on one tile: conversions of one wave under the MFMAs of the other)
@@ -263,7 +264,7 @@ def _tune_conv(mode, geom, launch):
         bks = (16, 32)             # --sqd_bf16 runs one kernel family: tile and split-K are all there is to choose
     else:
         bks = (16, 32, 528, 544, 1056) + ((3104,) if TUNE_SPACE["input_patch"] else ()) + ((576,) if TUNE_SPACE["bk64"] else ()) + \
-            ((272, 288) if TUNE_SPACE["eight_wave"] else ())
+            ((272, 288) if TUNE_SPACE["eight_wave"] else ()) + ((1312,) if TUNE_SPACE["eight_wave_split3"] else ())
     for bm, bn, z, bk in ((bm, bn, z, bk) for bm, bn in _TUNE_TILES + ((64, 32),) for bk in bks for z in _TUNE_Z):
         if L.sqd_conv_set_plan(mode, *geom, bm, bn, z, bk) != 0:
             continue

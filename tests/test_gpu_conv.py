@@ -86,7 +86,7 @@ def test_every_registered_plan_is_exact(N, C, H, W, K, R, stride, pad):
     tried = 0
     try:
         for bm, bn in nnkernels._TUNE_TILES:
-            for bk in (16, 32, 272, 288, 528, 544, 576, 1056):  # + 256: 8-wave workgroups, + 512: single-buffered LDS (also 64-wide slices), 32 + 1024: three-term bf16 operands
+            for bk in (16, 32, 272, 288, 528, 544, 576, 1056, 1312):  # + 256: 8-wave workgroups, + 512: single-buffered LDS (also 64-wide slices), 32 + 1024: three-term bf16 operands
                 for z in nnkernels._TUNE_Z:
                     ok = [L.sqd_conv_set_plan(mode, *geom, bm, bn, z, bk) == 0 for mode in (0, 1)]
                     if not any(ok):
