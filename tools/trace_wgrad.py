@@ -1,5 +1,7 @@
 """Phase timestamps of conv_wgrad_direct3_kernel (dev tool; needs a library built with -DSQD_WGRAD_TRACE: tools/build_variant.sh trace conv.hip -DSQD_WGRAD_TRACE):
-python tools/trace_wgrad.py --lib tools/bin/libsqd_trace.so N H W C K R impl splits"""
+python tools/trace_wgrad.py --lib tools/bin/libsqd_trace.so N H W C K R impl splits
+Ablations: add -DSQD_WG_NOCVT (operands packed without the three-term split) and / or -DSQD_WG_NOLOAD (only the first step's loads are issued) to the
+variant build: loop length with the MFMAs alone / + conversions / + loads."""
 import ctypes
 import os
 import sys
@@ -41,8 +43,5 @@ t0 = int(tr[:, 0].min())
 ent, loop, end = (tr[:, 0] - t0).double(), (tr[:, 1] - t0).double(), (tr[:, 2] - t0).double()
 q = lambda v: "min %.0f  p10 %.0f  med %.0f  p90 %.0f  max %.0f" % tuple(float(torch.quantile(v, p)) for p in (0.0, 0.1, 0.5, 0.9, 1.0))
 print("splits %d, waves traced %d, launch+reduce %.1f us by events (ticks below: s_memtime)" % (spl.value, tr.shape[0], e0.elapsed_time(e1) * 1e3))
-pass
-pass
-pass
 print("loop length:", q(loop - ent))
 print("epilogue   :", q(end - loop))
