@@ -24,6 +24,7 @@ def main():
     from trainer import Trainer
     from datasets.synthetic import synthetic_batch
     from sqd import nnkernels
+    nnkernels.TUNE_SPACE["rounds"] = int(os.environ.get("SQD_TUNE_ROUNDS", "1"))      # measurements per candidate plan (3 rounds measured no better set: tools/ab_plans.sh)
     opts = MonodepthOptions().parse(bench.CONFIG_B)
     with contextlib.redirect_stdout(sys.stderr):
         tr = Trainer(opts)
