@@ -2099,6 +2099,11 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
             else if (p.bn == 64) LAUNCH_HALO4(2, 2, 2, 1);                       \
             else LAUNCH_HALO4(2, 2, 1, 2);                                       \
         }                                                                        \
+    } else if (p.halo && p.waves == 8) {                                         \
+        if (p.bm == 128 && p.bn == 128) LAUNCH_HALO(MODE, 4, 2, 4, 1);           \
+        else if (p.bm == 128 && p.bn == 64) LAUNCH_HALO(MODE, 4, 2, 2, 2);       \
+        else if (p.bn == 128) LAUNCH_HALO(MODE, 2, 2, 4, 1);                     \
+        else LAUNCH_HALO(MODE, 2, 2, 2, 2);                                      \
     } else if (p.halo) {                                                         \
         if (p.bm == 128 && p.bn == 128) LAUNCH_HALO(MODE, 4, 1, 4, 1);           \
         else if (p.bm == 128 && p.bn == 64) LAUNCH_HALO(MODE, 4, 1, 2, 2);       \
@@ -2224,7 +2229,8 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
                   "(sqd_conv_set_precision is %d)", conv_precision());
     if (halo) {
         const int Cr = mode == 0 ? C : K;
-        SQD_CHECK_ARG(split3 && waves == 4 && !single && bk == 32, "sqd_conv_set_plan: the input-patch plans are bk = 32 + 1024 + 2048");
+        SQD_CHECK_ARG(split3 && !single && bk == 32 && (waves == 4 || (R == 3 && bn >= 64)),
+                      "sqd_conv_set_plan: the input-patch plans are bk = 32 + 1024 + 2048 (+ 256: 8-wave workgroups, 3x3 with >= 64-channel tiles)");
         SQD_CHECK_ARG(((R == 3 && S == 3 && pad == 1) || (R == 4 && S == 4 && pad == 2 && mode == 0)) && stride == 1 && Ho == H && Wo == W,
                       "sqd_conv_set_plan: the input-patch kernel is 3x3 / stride 1 / pad 1, or the forward 4x4 / stride 1 / pad 2 of the space-to-depth stems");
         SQD_CHECK_ARG((bm == 128 || bm == 64) && (bn == 128 || bn == 64 || bn == 32) && !(bn > 32 && bn >= 2 * Ncols) && !(bn == 32 && Ncols > 32) &&
@@ -2232,7 +2238,7 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
                       "sqd_conv_set_plan: input-patch tiles are 128|64 pixels x 128|64|32 channels (4x4: 64|32 channels)");
         const int64_t oe = (int64_t)N * H * W * Ncols;
         SQD_CHECK_ARG(z >= 1 && z <= 64 && (z == 1 || (z <= (Cr + 31) / 32 && z * oe * 4 <= (64ll << 20) && oe % 4 == 0)), "sqd_conv_set_plan: split %d not possible here", z);
-        plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, 32 | 1024 | 2048);
+        plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, 32 | 1024 | 2048 | (waves == 8 ? 256 : 0));
         return SQD_OK;
     }
     if (split3 && waves == 8) {

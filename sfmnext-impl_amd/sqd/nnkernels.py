@@ -264,7 +264,7 @@ def _tune_conv(mode, geom, launch):
         bks = (16, 32)             # --sqd_bf16 runs one kernel family: tile and split-K are all there is to choose
     else:
         bks = (16, 32, 528, 544, 1056) + ((3104,) if TUNE_SPACE["input_patch"] else ()) + ((576,) if TUNE_SPACE["bk64"] else ()) + \
-            ((272, 288) if TUNE_SPACE["eight_wave"] else ()) + ((1312,) if TUNE_SPACE["eight_wave_split3"] else ())
+            ((272, 288) if TUNE_SPACE["eight_wave"] else ()) + ((1312,) + ((3360,) if TUNE_SPACE["input_patch"] else ()) if TUNE_SPACE["eight_wave_split3"] else ())
     for bm, bn, z, bk in ((bm, bn, z, bk) for bm, bn in _TUNE_TILES + ((64, 32),) for bk in bks for z in _TUNE_Z):
         if L.sqd_conv_set_plan(mode, *geom, bm, bn, z, bk) != 0:
             continue

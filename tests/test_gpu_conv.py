@@ -498,10 +498,10 @@ def test_input_patch_plans(N, C, H, W, K):
     gxr = gxr + gskip
     tried = 0
     try:
-        for bm in (128, 64):
-            for bn in (128, 64, 32):
-                for z in (1, 2, 3):
-                    ok = [L.sqd_conv_set_plan(mode, *geom, bm, bn, z, 32 + 1024 + 2048) == 0 for mode in (0, 1)]
+        for bm, bn, z, w8 in ((bm, bn, z, w8) for bm in (128, 64) for bn in (128, 64, 32) for z in (1, 2, 3) for w8 in (0, 256)):
+            if True:
+                if True:                                             # (+ 256: the 8-wave workgroups of the same tiles)
+                    ok = [L.sqd_conv_set_plan(mode, *geom, bm, bn, z, 32 + 1024 + 2048 + w8) == 0 for mode in (0, 1)]
                     if not any(ok):
                         continue
                     for mode in (0, 1):
