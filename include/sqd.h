@@ -292,7 +292,8 @@ int sqd_conv_supported(int C, int K);
  * three bf16 terms, 6 of the 9 partial products (down to 2^-24 relative), fp32 accumulation, single LDS buffer;
  * 32 + 1024 + 2048: the input-patch kernel of that arithmetic for R = S = 3, stride 1, pad 1 (and the forward of R = S = 4, stride 1,
  * pad 2: the space-to-depth stems) — bm = 128 | 64 pixels of a patch
- * (8x16 | 4x16), bn = 128 | 64 | 32 output channels per workgroup, z = split over 32-channel chunks; bm = 0 clears) */
+ * (8x16 | 4x16), bn = 128 | 64 | 32 output channels per workgroup, z = split over 32-channel chunks; + 256 on the three-term plans:
+ * 8-wave workgroups (128x128, 64x128, forward 128x64 GEMM tiles; 3x3 input-patch tiles of >= 64 channels); bm = 0 clears) */
 int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int bm,
                       int bn, int z, int bk);
 /* arithmetic of sqd_conv_fwd / sqd_conv_dgrad: 0 = fp32 MFMA (default, the reference's arithmetic); 1 = split-precision bf16
