@@ -499,22 +499,21 @@ def test_input_patch_plans(N, C, H, W, K):
     tried = 0
     try:
         for bm, bn, z, w8 in ((bm, bn, z, w8) for bm in (128, 64) for bn in (128, 64, 32) for z in (1, 2, 3) for w8 in (0, 256)):
-            if True:
-                if True:                                             # (+ 256: the 8-wave workgroups of the same tiles)
-                    ok = [L.sqd_conv_set_plan(mode, *geom, bm, bn, z, 32 + 1024 + 2048 + w8) == 0 for mode in (0, 1)]
-                    if not any(ok):
-                        continue
-                    for mode in (0, 1):
-                        if not ok[mode]:
-                            L.sqd_conv_set_plan(mode, *geom, 0, 0, 0, 16)
-                    nnkernels._PLAN_CACHE.clear()
-                    xg = x.clone().requires_grad_(True)
-                    y, xs = nnkernels.conv2d_native(xg, conv, None, True)
-                    gx, = torch.autograd.grad((y, xs), xg, (gy.float(), gskip.float()))
-                    tried += 1
-                    ey = float((y.detach().double() - yr.detach()).abs().max()) / float(yr.abs().max())
-                    ex = float((gx.double() - gxr).abs().max()) / float(gxr.abs().max())
-                    assert ey <= 4e-6 and ex <= 4e-6, (bm, bn, z, ok, ey, ex)
+            # (+ 256: the 8-wave workgroups of the same tiles)
+            ok = [L.sqd_conv_set_plan(mode, *geom, bm, bn, z, 32 + 1024 + 2048 + w8) == 0 for mode in (0, 1)]
+            if not any(ok):
+                continue
+            for mode in (0, 1):
+                if not ok[mode]:
+                    L.sqd_conv_set_plan(mode, *geom, 0, 0, 0, 16)
+            nnkernels._PLAN_CACHE.clear()
+            xg = x.clone().requires_grad_(True)
+            y, xs = nnkernels.conv2d_native(xg, conv, None, True)
+            gx, = torch.autograd.grad((y, xs), xg, (gy.float(), gskip.float()))
+            tried += 1
+            ey = float((y.detach().double() - yr.detach()).abs().max()) / float(yr.abs().max())
+            ex = float((gx.double() - gxr).abs().max()) / float(gxr.abs().max())
+            assert ey <= 4e-6 and ex <= 4e-6, (bm, bn, z, w8, ok, ey, ex)
     finally:
         for mode in (0, 1):
             L.sqd_conv_set_plan(mode, *geom, 0, 0, 0, 16)
