@@ -349,6 +349,31 @@ int sqd_conv_wgrad_partials(const float *dy, const float *x, float *dw, float *d
 /* out[i] = sum_{s < splits} part[s * n + i], i < n (n a multiple of 4); fixed summation order                                      */
 int sqd_split_reduce(const float *part, float *out, int64_t n, int splits, void *stream);
 
+/* ---- (10b) two-term fp16 operands ("f16x2", round 5): plans bk = 32 + 1024 + 4096 (+ 2048, + 256) of sqd_conv_set_plan and impl
+ * 7 + 16 * v of sqd_conv_wgrad_set_plan are the three-term plans / impl 6 with every fp32 operand staged as s^-1 (h + l): s a power of
+ * two that puts the tensor's largest magnitude into [2^14, 2^15), h and l fp16 (round-to-nearest), products h h + h l + l h on
+ * v_mfma_f32_32x32x16_f16 with fp32 accumulation — half the matrix and conversion instructions of the three-term bf16 split at the
+ * accuracy of the fp32 MFMA chain (csrc/conv.hip; tests/test_gpu_conv.py).  Such a plan needs max |.| of both operand tensors:
+ * `amax_*` = device scalars holding the bit pattern of a non-negative float (any upper bound is safe), written before the call on the
+ * same stream — by sqd_amax / sqd_amax_multi or by the `amax` outputs of the producing kernels.  The *_scaled entry points are the
+ * plain ones + those scalars; plans of the other arithmetics ignore them (NULL allowed), a two-term plan without them is SQD_EINVAL.
+ * replaces: nothing in the reference — its convolutions multiply in fp32 (networks/resnet_encoder.py:89-147). */
+int sqd_amax(const float *x, int64_t n, float *amax, void *stream);
+/* one scalar per parameter tensor of an optimiser table (recs / chunks of sqd_adam_step): amax[t] = bits of max |p_t| */
+int sqd_amax_multi(const void *recs, const void *chunks, int nchunks, int ntensors, float *amax, void *stream);
+int sqd_conv_fwd_scaled(const float *x, const float *w, const float *bias, float *y, float *ws, float *stats, const float *amax_x,
+                        const float *amax_w, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int act,
+                        void *stream);
+/* sqd_conv_dgrad_bn (stats == NULL: sqd_conv_dgrad) + the operand scalars */
+int sqd_conv_dgrad_scaled(const float *dy, const float *w, const float *addend, float *dx, float *ws, const float *bn_x,
+                          const unsigned char *bn_mask, const float *bn_mean, const float *bn_rstd, int bn_act, float *stats,
+                          const float *amax_dy, const float *amax_w, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
+                          int Ho, int Wo, void *stream);
+/* sqd_conv_wgrad (splits == NULL) / sqd_conv_wgrad_partials (splits != NULL) + the operand scalars */
+int sqd_conv_wgrad_scaled(const float *dy, const float *x, float *dw, float *dbias, float *part, const float *amax_dy,
+                          const float *amax_x, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
+                          int *splits, void *stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * (11) adaptive-bins depth head.  replaces reference networks/depth_decoder_QTR.py:61-70 (convert_to_prob =
  * Conv2d(Q, D, 1) + Softmax(dim=1), then pred = sum_d out[d] * centers[b, d]).

@@ -93,6 +93,99 @@ __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
+// ---- two-term fp16 operands (PREC 5, "f16x2", round 5).  Three bf16 terms cost 5.5 VALU instructions per staged element and six
+// matrix instructions per product; an fp32 value is just as well the sum  s^-1 (h + l)  of two fp16 terms (11 significant bits each,
+// round-to-nearest: |x s - h - l| <= 2^-22 |x s|, rms 2^-24.8 — the size of ONE fp32 rounding) once the tensor has been scaled by
+// a power of two s that puts its largest magnitude into [2^14, 2^15): h never overflows fp16 and the low term of every element
+// within 2^18 of the maximum is a normal number (smaller elements keep an absolute accuracy of 2^-40 of the maximum: fp16
+// subnormals, which v_cvt_pk_f16_f32 produces and v_mfma_f32_32x32x16_f16 consumes — tools/ubench_f16x2.hip).  The kernel keeps
+// h_a h_b + h_a l_b + l_a h_b (drops l_a l_b <= 2^-22), every product exact in the fp32 accumulator: three matrix instructions and
+// 3-4 conversion instructions per element instead of six and 5.5, two LDS planes instead of three.  Against float64 the result is
+// as close as the fp32 MFMA chain's (tests/test_gpu_conv.py::test_f16x2_*; oracle/f16x2_model.py).  The scale comes from the
+// tensor's max |.|, which the producing kernel leaves in device memory (sqd_amax_* / the `amax` outputs of the producers): a
+// device scalar holding the bit pattern of a non-negative float.  s = 2^(141 - biased exponent), clamped to a normal float.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
+struct OpScale {
+    const float *amax_a, *amax_b;     // max |.| of the A operand (x / dy) and of the B operand (w; x for the weight gradient); NULL: unscaled plans
+};
+__device__ __forceinline__ unsigned scale_exp(const float *amax) {        // biased exponent of s
+    const int e = (int)((__float_as_uint(*amax) >> 23) & 0xffu);
+    return (unsigned)min(max(268 - e, 1), 253);
+}
+__device__ __forceinline__ float scale_from_exp(unsigned be) { return __uint_as_float(be << 23); }
+__device__ __forceinline__ float inv_scale_from_exp(unsigned be) { return __uint_as_float((254u - be) << 23); }
+struct Split4h {
+    uint2 t[2];                       // t[0] = four high terms, t[1] = four low terms (element 0 in the low half of .x)
+};
+#ifndef SQD_F16X2_PLAIN
+// x s - h in one instruction: v_fma_mix_f32 reads src2 as the (negated) fp16 half of the packed high terms; exact (the result is
+// representable), identical bits to the convert-and-subtract form (tools/ubench_f16x2.hip checks 2^18 values)
+__device__ __forceinline__ float resid_lo(float x, float s, unsigned hpk) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s), "v"(hpk));
+    return r;
+}
+__device__ __forceinline__ float resid_hi(float x, float s, unsigned hpk) {
+    float r;
+    asm("v_fma_mix_f32 %0, %1, %2, -%3 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "=v"(r) : "v"(x), "v"(s), "v"(hpk));
+    return r;
+}
+#endif
+__device__ __forceinline__ Split4h split2h(float4 v, float s) {
+    Split4h r;
+    const f16x2v a = __builtin_convertvector((f32x2v){v.x * s, v.y * s}, f16x2v), b = __builtin_convertvector((f32x2v){v.z * s, v.w * s}, f16x2v);
+    const unsigned ua = __builtin_bit_cast(unsigned, a), ub = __builtin_bit_cast(unsigned, b);
+#ifdef SQD_F16X2_PLAIN
+    const f16x2v c = __builtin_convertvector((f32x2v){v.x * s - (float)a[0], v.y * s - (float)a[1]}, f16x2v);
+    const f16x2v d = __builtin_convertvector((f32x2v){v.z * s - (float)b[0], v.w * s - (float)b[1]}, f16x2v);
+#else
+    const f16x2v c = __builtin_convertvector((f32x2v){resid_lo(v.x, s, ua), resid_hi(v.y, s, ua)}, f16x2v);
+    const f16x2v d = __builtin_convertvector((f32x2v){resid_lo(v.z, s, ub), resid_hi(v.w, s, ub)}, f16x2v);
+#endif
+    r.t[0] = make_uint2(ua, ub);
+    r.t[1] = make_uint2(__builtin_bit_cast(unsigned, c), __builtin_bit_cast(unsigned, d));
+    return r;
+}
+__device__ __forceinline__ f32x16 mfma_h(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// the staged terms of either arithmetic behind one interface: NT terms of four elements
+template <int NT> struct SplitT { uint2 t[NT]; };
+template <int NT, bool H2>
+__device__ __forceinline__ SplitT<NT> split_terms(float4 v, float s) {
+    SplitT<NT> r;
+    if constexpr (H2) {
+        const Split4h h = split2h(v, s);
+        r.t[0] = h.t[0];
+        r.t[1 % NT] = h.t[1];
+    } else {
+        const Split4 b = splitN<NT>(v);
+#pragma unroll
+        for (int i = 0; i < NT; ++i) r.t[i] = b.t[i];
+    }
+    return r;
+}
+// acc += A B over the kept term pairs, smallest first: 6 of 9 (three bf16 terms), 3 of 4 (two fp16 terms), 1 (one bf16 term)
+template <int NT, bool H2>
+__device__ __forceinline__ f32x16 mma_terms(const u32x4 *a, const u32x4 *b, f32x16 c) {
+    if constexpr (H2) {
+        c = mfma_h(a[0], b[1], c);
+        c = mfma_h(a[1], b[0], c);
+        return mfma_h(a[0], b[0], c);
+    } else if constexpr (NT == 1) {
+        return mfma_bf(a[0], b[0], c);
+    } else {
+        c = mfma_bf(a[0], b[2], c);
+        c = mfma_bf(a[2], b[0], c);
+        c = mfma_bf(a[1], b[1], c);
+        c = mfma_bf(a[0], b[1], c);
+        c = mfma_bf(a[1], b[0], c);
+        return mfma_bf(a[0], b[0], c);
+    }
+}
+
 // Operand fetches go through raw buffer loads: the descriptor carries the tensor's size, an offset beyond it returns zeros.
 // Padding taps, rows beyond the tile and channels beyond the tensor set the offset to 0xffffffff (one v_cndmask) instead of
 // branching around the load (s_and_saveexec / s_cbranch_execz per float4 in the global_load version).
@@ -110,7 +203,8 @@ __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned b
 template <int MODE, int BM, int BN, int WGM, int WGN, int BKT, int PREC = 0>
 __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
                                                         const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
-                                                        int act, int zsplits, int order, float *__restrict__ stats, BnBwdSrc bnb) {
+                                                        int act, int zsplits, int order, float *__restrict__ stats, BnBwdSrc bnb,
+                                                        OpScale sc) {
     constexpr int WTM = BM / WGM / 32, WTN = BN / WGN / 32;     // 32x32 MFMA tiles per wave
     constexpr int NT = WGM * WGN * 64;                          // 4 or 8 wavefronts per workgroup
     static_assert((WGM * WGN == 4 || WGM * WGN == 8) && WTM >= 1 && WTN >= 1, "4 or 8 waves per workgroup");
@@ -119,9 +213,10 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
     constexpr int NQ = BKT / 4, LDPT = BKT + 4, RPP = NT / NQ;  // float4 per staged row, LDS row pitch, rows per staging pass
     constexpr int A_F4 = BM * NQ / NT;
     static_assert(A_F4 >= 1 && (BKT == 16 || BKT == 32 || BKT == 64), "BM >= 64, BKT in {16, 32, 64}");
-    constexpr bool BF = PREC == 1 || PREC == 3 || PREC == 4;    // bf16 operands: PREC 1 / 4 = three-term split (fp32-level accuracy),
-    constexpr int NTERM = (PREC == 1 || PREC == 4) ? 3 : 1;     // PREC 3 = one round-to-nearest bf16 term (bf16 training arithmetic)
-    constexpr int NBUF = (PREC == 2 || PREC == 4) ? 1 : 2;      // PREC 2 / 4: single LDS buffer (half the LDS, one more barrier per slice)
+    constexpr bool H2 = PREC == 5;                              // PREC 5: two fp16 terms of the power-of-two scaled operands (f16x2, see above)
+    constexpr bool BF = PREC == 1 || PREC == 3 || PREC == 4 || H2;   // 16-bit operands: PREC 1 / 4 = three-term bf16 split (fp32-level accuracy),
+    constexpr int NTERM = (PREC == 1 || PREC == 4) ? 3 : H2 ? 2 : 1; // PREC 3 = one round-to-nearest bf16 term (bf16 training arithmetic)
+    constexpr int NBUF = (PREC == 2 || PREC == 4 || H2) ? 1 : 2;     // PREC 2 / 4 / 5: single LDS buffer (half the LDS, one more barrier per slice)
     constexpr int LDH = BKT + 8;                                // PREC 1: bf16 row pitch (48 / 80 bytes: conflict-free b128 reads)
     __shared__ __attribute__((aligned(16))) float As[BF ? 1 : NBUF][BF ? 1 : BM][LDPT];
     __shared__ __attribute__((aligned(16))) float Bs[BF ? 1 : NBUF][BF ? 1 : BN][LDPT];
@@ -130,6 +225,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm0 = (wave / WGN) * (WTM * 32), wn0 = (wave % WGN) * (WTN * 32);
+    const unsigned bea = H2 ? scale_exp(sc.amax_a) : 127u, beb = H2 ? scale_exp(sc.amax_b) : 127u;      // (scalar loads, wave-uniform)
+    const float sca = scale_from_exp(bea), scb = scale_from_exp(beb);
     // workgroups are dealt round-robin to the 8 XCDs (private L2 each): XCD x gets the contiguous range
     // [x*G/8, (x+1)*G/8) of the logical tile order, in which the N-tiles of one M-tile are neighbours, so the
     // activation tile they share is fetched into that L2 once
@@ -273,7 +370,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
         if (BF) {
 #pragma unroll
             for (int i = 0; i < A_F4; ++i) {
-                const Split4 sp = splitN<NTERM>(ra[i]);
+                const SplitT<NTERM> sp = split_terms<NTERM, H2>(ra[i], sca);
 #pragma unroll
                 for (int tm = 0; tm < NTERM; ++tm) *reinterpret_cast<uint2 *>(&Ah[buf][tm][arow + RPP * i][c4 * 4]) = sp.t[tm];
             }
@@ -281,7 +378,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
 #pragma unroll
                 for (int i2 = 0; i2 < B_F4 / 2; ++i2) {
                     const int gidx = t + NT * i2, cl = gidx % BN, kg = gidx / BN;
-                    const Split4 s0 = splitN<NTERM>(rb[2 * i2]), s1 = splitN<NTERM>(rb[2 * i2 + 1]);
+                    const SplitT<NTERM> s0 = split_terms<NTERM, H2>(rb[2 * i2], scb), s1 = split_terms<NTERM, H2>(rb[2 * i2 + 1], scb);
                     if (kg * 8 < BKT) {
 #pragma unroll
                         for (int tm = 0; tm < NTERM; ++tm) {
@@ -296,7 +393,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
 #pragma unroll
             for (int i = 0; i < B_F4; ++i) {
                 const int idx = t + NT * i;
-                const Split4 sp = splitN<NTERM>(rb[i]);
+                const SplitT<NTERM> sp = split_terms<NTERM, H2>(rb[i], scb);
                 if (MODE == 0) {
                     const int row = srow(idx / NQ), q4 = idx % NQ;
                     if (row < BN) {
@@ -388,7 +485,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
         for (int part = 0; part < BKT / 16; ++part) {
             const int e0 = (BKT / 2) * h + 8 * part;
             if (BF) {
-                // one 32x32x16 bf16 MFMA consumes the 8 elements of both half-waves; 6 term pairs, smallest first
+                // one 32x32x16 bf16 / fp16 MFMA consumes the 8 elements of both half-waves; 6 (3) term pairs, smallest first
                 u32x4 ah[WTM][NTERM], bh[WTN][NTERM];
 #pragma unroll
                 for (int i = 0; i < WTM; ++i)
@@ -402,17 +499,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
                 for (int i = 0; i < WTM; ++i)
 #pragma unroll
                     for (int j = 0; j < WTN; ++j) {
-                        f32x16 c = acc[i][j];
-                        if (NTERM == 1) {
-                            acc[i][j] = mfma_bf(ah[i][0], bh[j][0], c);
-                            continue;
-                        }
-                        c = mfma_bf(ah[i][0], bh[j][NTERM - 1], c);
-                        c = mfma_bf(ah[i][NTERM - 1], bh[j][0], c);
-                        c = mfma_bf(ah[i][NTERM > 1 ? 1 : 0], bh[j][NTERM > 1 ? 1 : 0], c);
-                        c = mfma_bf(ah[i][0], bh[j][NTERM > 1 ? 1 : 0], c);
-                        c = mfma_bf(ah[i][NTERM > 1 ? 1 : 0], bh[j][0], c);
-                        acc[i][j] = mfma_bf(ah[i][0], bh[j][0], c);
+                        acc[i][j] = mma_terms<NTERM, H2>(ah[i], bh[j], acc[i][j]);
                     }
                 continue;
             }
@@ -461,6 +548,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
     const __amdgpu_buffer_rsrc_t dst_r = make_rsrc(out + (size_t)blockIdx.z * out_rows * Ncols, out_bytes);   // zsplits > 1: partial workspace
     const bool has_add = MODE == 1 && bias != nullptr && zsplits == 1;                   // dgrad: `bias` is the [N,H,W,C] addend
     const __amdgpu_buffer_rsrc_t add_r = make_rsrc(has_add ? bias : out, has_add ? out_bytes : 0u);
+    const float isa = inv_scale_from_exp(bea), isb = inv_scale_from_exp(beb);     // f16x2: the accumulators hold s_a s_b times the result
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
         const int col = n0 + wn0 + j * 32 + row;
@@ -493,7 +581,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
             }
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                float v = acc[i][j][e] + bv;
+                float v = (H2 ? acc[i][j][e] * isa * isb : acc[i][j][e]) + bv;
                 if (MODE == 1) v += addv[e];
                 if (MODE == 0 && act == 1 && zsplits == 1) v = v > 0.f ? v : 0.f;
                 if (MODE == 0 && act == 2 && zsplits == 1) v = v > 0.f ? v : 0.01f * v;      // LeakyReLU(0.01), nn.LeakyReLU's default slope
@@ -548,10 +636,11 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
 // MODE 0 forward (source x, reduction over c, tap (r,s) reads patch cell (ty+r, tx+s)); MODE 1 data gradient (source dy,
 // reduction over k, tap (r,s) reads (ty+2-r, tx+2-s)).
 // ---------------------------------------------------------------------------------------------------
-template <int MODE, int WTM, int WM, int WN, int WK, int R = 3>
+template <int MODE, int WTM, int WM, int WN, int WK, int R = 3, bool H2 = false>
 __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 2 : 3)) void conv3x3_halo_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
                                                                     const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
-                                                                    int act, int zsplits, float *__restrict__ stats, BnBwdSrc bnb) {
+                                                                    int act, int zsplits, float *__restrict__ stats, BnBwdSrc bnb, OpScale sc) {
+    constexpr int NTM = H2 ? 2 : 3;                       // operand terms: three bf16 (truncating split) or two fp16 of the scaled operand (H2)
     constexpr int TH = 2 * WTM, TW = 16, PW = TW + R - 1, PH = TH + R - 1, HP = PH * PW;   // output patch, input patch (R x R taps)
     constexpr int RS = R * R, RING = RS % 3 == 0 ? 3 : 4;                          // filter-fragment ring: its size divides the taps of a chunk
     static_assert((R == 3 || R == 4) && (R == 3 || MODE == 0) && RS % RING == 0, "3x3, or 4x4 forward (the space-to-depth stems)");
@@ -562,8 +651,12 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
     constexpr int KSW = 2 / WK;                           // 16-channel MFMA steps of a chunk per wave
     constexpr int A_ITEMS = HPP * 4, A_PASS = (A_ITEMS + NT - 1) / NT;        // item = 8 channels of one patch cell
     static_assert((WK == 1 || WK == 2) && WTM % WM == 0, "WK, WM");
-    static_assert((WK == 2 ? WN * WTM * 16 * 64 * 4 : 0) + WM * WN * 64 * 4 <= 3 * HPP * LDH * 2, "the accumulator / statistics exchange reuses the patch planes");
-    __shared__ __attribute__((aligned(16))) unsigned short Ah[3][HPP][LDH];
+    constexpr int XCH_BYTES = (WK == 2 ? WN * WTM * 16 * 64 * 4 : 0) + WM * WN * 64 * 4;      // the accumulator / statistics exchange reuses the patch planes
+    constexpr int NPL = XCH_BYTES <= NTM * HPP * LDH * 2 ? NTM : 3;
+    static_assert(XCH_BYTES <= NPL * HPP * LDH * 2, "the accumulator / statistics exchange reuses the patch planes");
+    __shared__ __attribute__((aligned(16))) unsigned short Ah[NPL][HPP][LDH];
+    const unsigned bea = H2 ? scale_exp(sc.amax_a) : 127u, beb = H2 ? scale_exp(sc.amax_b) : 127u;
+    const float sca = scale_from_exp(bea), scb = scale_from_exp(beb);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wn = wave % WN, wk = (wave / WN) % WK, wmi = wave / (WN * WK);
@@ -608,9 +701,9 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
 #pragma unroll
         for (int i = 0; i < A_PASS; ++i) {
             if (a_cell[i] < 0) continue;
-            const Split4 s0 = split3(ra[i][0]), s1 = split3(ra[i][1]);
+            const SplitT<NTM> s0 = split_terms<NTM, H2>(ra[i][0], sca), s1 = split_terms<NTM, H2>(ra[i][1], sca);
 #pragma unroll
-            for (int tmn = 0; tmn < 3; ++tmn) {
+            for (int tmn = 0; tmn < NTM; ++tmn) {
                 u32x4 v;
                 v.x = s0.t[tmn].x; v.y = s0.t[tmn].y; v.z = s1.t[tmn].x; v.w = s1.t[tmn].y;
                 *reinterpret_cast<u32x4 *>(&Ah[tmn][a_cell[i]][c8]) = v;
@@ -672,13 +765,13 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
 #pragma unroll
         for (int rs = 0; rs < RS; ++rs) {
             const int r = rs / R, s = rs - R * r;
-            u32x4 bh[KSW][3];
+            u32x4 bh[KSW][NTM];
 #pragma unroll
             for (int q = 0; q < KSW; ++q) {
-                const Split4 s0 = split3(make_float4(rb[rs % RING][q][0], rb[rs % RING][q][1], rb[rs % RING][q][2], rb[rs % RING][q][3]));
-                const Split4 s1 = split3(make_float4(rb[rs % RING][q][4], rb[rs % RING][q][5], rb[rs % RING][q][6], rb[rs % RING][q][7]));
+                const SplitT<NTM> s0 = split_terms<NTM, H2>(make_float4(rb[rs % RING][q][0], rb[rs % RING][q][1], rb[rs % RING][q][2], rb[rs % RING][q][3]), scb);
+                const SplitT<NTM> s1 = split_terms<NTM, H2>(make_float4(rb[rs % RING][q][4], rb[rs % RING][q][5], rb[rs % RING][q][6], rb[rs % RING][q][7]), scb);
 #pragma unroll
-                for (int tmn = 0; tmn < 3; ++tmn) {
+                for (int tmn = 0; tmn < NTM; ++tmn) {
                     bh[q][tmn].x = s0.t[tmn].x; bh[q][tmn].y = s0.t[tmn].y; bh[q][tmn].z = s1.t[tmn].x; bh[q][tmn].w = s1.t[tmn].y;
                 }
             }
@@ -693,16 +786,10 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
 #pragma unroll
                 for (int i = 0; i < WS; ++i) {
                     const unsigned short *ap = tap + (2 * i * PW) * LDH + ks * 16;
-                    const u32x4 a0 = *reinterpret_cast<const u32x4 *>(ap);
-                    const u32x4 a1 = *reinterpret_cast<const u32x4 *>(ap + HPP * LDH);
-                    const u32x4 a2 = *reinterpret_cast<const u32x4 *>(ap + 2 * HPP * LDH);
-                    f32x16 c = acc[i];
-                    c = mfma_bf(a0, bh[q][2], c);          // smallest terms first
-                    c = mfma_bf(a2, bh[q][0], c);
-                    c = mfma_bf(a1, bh[q][1], c);
-                    c = mfma_bf(a0, bh[q][1], c);
-                    c = mfma_bf(a1, bh[q][0], c);
-                    acc[i] = mfma_bf(a0, bh[q][0], c);
+                    u32x4 at[NTM];
+#pragma unroll
+                    for (int tmn = 0; tmn < NTM; ++tmn) at[tmn] = *reinterpret_cast<const u32x4 *>(ap + tmn * HPP * LDH);
+                    acc[i] = mma_terms<NTM, H2>(at, bh[q], acc[i]);          // smallest terms first
                 }
             }
             __builtin_amdgcn_sched_barrier(0);            // keep the taps apart: hoisting the next tap's reads costs 60+ registers
@@ -744,6 +831,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
     const __amdgpu_buffer_rsrc_t bm_r = make_rsrc(has_mask ? (const float *)bnb.mask : out, has_mask ? out_rows * (unsigned)Ncols / 4u : 0u);
     const float bmu = (bstats && colv) ? bnb.mean[col] : 0.f, brs = (bstats && colv) ? bnb.rstd[col] : 0.f;
     float s1 = 0.f, s2 = 0.f;
+    const float isa = inv_scale_from_exp(bea), isb = inv_scale_from_exp(beb);
     if (writer) {
 #pragma unroll
     for (int i = 0; i < WS; ++i) {
@@ -770,7 +858,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
         }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-            float v = acc[i][e] + bv;
+            float v = (H2 ? acc[i][e] * isa * isb : acc[i][e]) + bv;
             if (MODE == 1) v += addv[e];
             if (MODE == 0 && act == 1 && zsplits == 1) v = v > 0.f ? v : 0.f;
             if (MODE == 0 && act == 2 && zsplits == 1) v = v > 0.f ? v : 0.01f * v;
@@ -1612,11 +1700,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_split3_kernel(const float *__r
 // (filters, channels, tap) tile and add their accumulators through LDS in a fixed order.  Needs an even Wo (a pair never straddles
 // an output row) unless the convolution is a plain 1x1 (x pixel = output pixel).  part[split][k][r][s][c] as for the others.
 // ---------------------------------------------------------------------------------------------------
-template <int KT, int CT, bool FLAT, int NW = 4>
+template <int KT, int CT, bool FLAT, int NW = 4, bool H2 = false>
 __global__ __launch_bounds__(NW * 64, (KT * CT <= 4 || NW == 8 ? 2 : 1)) void conv_wgrad_direct3_kernel(const float *__restrict__ dy,
                                                                                                       const float *__restrict__ x,
                                                                                                       float *__restrict__ part, ConvGeom g,
-                                                                                                      int px_per_wave, int nsplits) {
+                                                                                                      int px_per_wave, int nsplits, OpScale sc) {
+    constexpr int NTM = H2 ? 2 : 3;                         // operand terms: three bf16, or (H2, impl 7) two fp16 of the scaled operands
+    const unsigned bea = H2 ? scale_exp(sc.amax_a) : 127u, beb = H2 ? scale_exp(sc.amax_b) : 127u;
+    const float sca = scale_from_exp(bea), scb = scale_from_exp(beb);
 #ifdef SQD_WGRAD_TRACE
     const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
 #endif
@@ -1691,49 +1782,43 @@ __global__ __launch_bounds__(NW * 64, (KT * CT <= 4 || NW == 8 ? 2 : 1)) void co
             m += 2;
         }
     };
-    auto convert = [&](float (*a)[KT], float (*b)[CT], u32x4 (*A)[3], u32x4 (*B)[3]) {
+    auto convert = [&](float (*a)[KT], float (*b)[CT], u32x4 (*A)[NTM], u32x4 (*B)[NTM]) {
 #ifdef SQD_WG_NOCVT
 #pragma unroll
         for (int q = 0; q < KT; ++q)
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm)
+            for (int tm = 0; tm < NTM; ++tm)
                 A[q][tm] = (u32x4){__float_as_uint(a[0 + tm][q]), __float_as_uint(a[1 + tm][q]), __float_as_uint(a[2 + tm][q]), __float_as_uint(a[3 + tm][q])};
 #pragma unroll
         for (int q = 0; q < CT; ++q)
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm)
+            for (int tm = 0; tm < NTM; ++tm)
                 B[q][tm] = (u32x4){__float_as_uint(b[0 + tm][q]), __float_as_uint(b[1 + tm][q]), __float_as_uint(b[2 + tm][q]), __float_as_uint(b[3 + tm][q])};
         return;
 #endif
 #pragma unroll
         for (int q = 0; q < KT; ++q) {
-            const Split4 s0 = split3(make_float4(a[0][q], a[1][q], a[2][q], a[3][q])), s1 = split3(make_float4(a[4][q], a[5][q], a[6][q], a[7][q]));
+            const SplitT<NTM> s0 = split_terms<NTM, H2>(make_float4(a[0][q], a[1][q], a[2][q], a[3][q]), sca),
+                              s1 = split_terms<NTM, H2>(make_float4(a[4][q], a[5][q], a[6][q], a[7][q]), sca);
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm) A[q][tm] = (u32x4){s0.t[tm].x, s0.t[tm].y, s1.t[tm].x, s1.t[tm].y};
+            for (int tm = 0; tm < NTM; ++tm) A[q][tm] = (u32x4){s0.t[tm].x, s0.t[tm].y, s1.t[tm].x, s1.t[tm].y};
         }
 #pragma unroll
         for (int q = 0; q < CT; ++q) {
-            const Split4 s0 = split3(make_float4(b[0][q], b[1][q], b[2][q], b[3][q])), s1 = split3(make_float4(b[4][q], b[5][q], b[6][q], b[7][q]));
+            const SplitT<NTM> s0 = split_terms<NTM, H2>(make_float4(b[0][q], b[1][q], b[2][q], b[3][q]), scb),
+                              s1 = split_terms<NTM, H2>(make_float4(b[4][q], b[5][q], b[6][q], b[7][q]), scb);
 #pragma unroll
-            for (int tm = 0; tm < 3; ++tm) B[q][tm] = (u32x4){s0.t[tm].x, s0.t[tm].y, s1.t[tm].x, s1.t[tm].y};
+            for (int tm = 0; tm < NTM; ++tm) B[q][tm] = (u32x4){s0.t[tm].x, s0.t[tm].y, s1.t[tm].x, s1.t[tm].y};
         }
     };
-    auto multiply = [&](u32x4 (*A)[3], u32x4 (*B)[3]) {
+    auto multiply = [&](u32x4 (*A)[NTM], u32x4 (*B)[NTM]) {
 #pragma unroll
         for (int q = 0; q < KT; ++q)
 #pragma unroll
-            for (int c = 0; c < CT; ++c) {
-                f32x16 v = acc[q][c];                               // smallest terms first
-                v = mfma_bf(A[q][0], B[c][2], v);
-                v = mfma_bf(A[q][2], B[c][0], v);
-                v = mfma_bf(A[q][1], B[c][1], v);
-                v = mfma_bf(A[q][0], B[c][1], v);
-                v = mfma_bf(A[q][1], B[c][0], v);
-                acc[q][c] = mfma_bf(A[q][0], B[c][0], v);
-            }
+            for (int c = 0; c < CT; ++c) acc[q][c] = mma_terms<NTM, H2>(A[q], B[c], acc[q][c]);      // smallest terms first
     };
     auto mma_step = [&](float (*a)[KT], float (*b)[CT]) {
-        u32x4 A[KT][3], B[CT][3];
+        u32x4 A[KT][NTM], B[CT][NTM];
         convert(a, b, A, B);
         multiply(A, B);
     };
@@ -1751,7 +1836,7 @@ __global__ __launch_bounds__(NW * 64, (KT * CT <= 4 || NW == 8 ? 2 : 1)) void co
         float a0[8][KT], b0[8][CT];
         if (nst > 0) load_step(a0, b0);
         for (int st = 0; st < nst; ++st) {
-            u32x4 A[KT][3], B[CT][3];
+            u32x4 A[KT][NTM], B[CT][NTM];
             convert(a0, b0, A, B);
             load_step(a0, b0);                                // the next step's values arrive under this step's products
             multiply(A, B);
@@ -1764,6 +1849,7 @@ __global__ __launch_bounds__(NW * 64, (KT * CT <= 4 || NW == 8 ? 2 : 1)) void co
     // q in [w PR/4, (w+1) PR/4) of a pass: CT consecutive channels per store.  C/D layout of the 32x32 MFMA: column = lane & 31,
     // row = (e & 3) + 8 (e >> 2) + 4 (lane >> 5)
     float *po = part + (size_t)split * g.K * RS * g.C;
+    const float isa = inv_scale_from_exp(bea), isb = inv_scale_from_exp(beb);     // H2: the accumulators hold s_dy s_x times the partial sums
 #pragma unroll
     for (int pass = 0; pass < NR / PR; ++pass) {
         if (pass > 0) __syncthreads();
@@ -1783,6 +1869,7 @@ __global__ __launch_bounds__(NW * 64, (KT * CT <= 4 || NW == 8 ? 2 : 1)) void co
             for (int b = 0; b < CT; ++b) {
                 v[b] = ((red[0][q0 + b][lane] + red[1][q0 + b][lane]) + red[2][q0 + b][lane]) + red[3][q0 + b][lane];
                 if (NW == 8) v[b] += ((red[4 % NW][q0 + b][lane] + red[5 % NW][q0 + b][lane]) + red[6 % NW][q0 + b][lane]) + red[7 % NW][q0 + b][lane];
+                if (H2) v[b] = v[b] * isa * isb;
             }
             const int ae = (pass * PR + q0) / CT, a = ae >> 4, e = ae & 15;
             const int k = k0 + KT * ((e & 3) + 8 * (e >> 2) + 4 * h) + a, cc = c0 + CT * i32;
@@ -1976,6 +2063,7 @@ struct GemmPlan {
     int single = 0;                 // 1: single-buffered LDS variant (bk + 512 in sqd_conv_set_plan)
     int split3 = 0;                 // 1: three-term bf16 operands on the bf16 matrix cores, single LDS buffer, 32-channel slices (bk + 1024)
     int halo = 0;                   // 1: conv3x3_halo_kernel (bk + 2048; 3x3 / stride 1 / pad 1 only): bm = pixels of a patch, bn = channels of a tile
+    int h2 = 0;                     // 1: with split3 (and halo): two fp16 terms of the scaled operands instead of three bf16 terms (bk + 4096); needs the operands' max |.|
     int64_t ws_floats;
 };
 // measured plans registered through sqd_conv_set_plan: (mode, geometry) -> (bm, bn, z)
@@ -2049,12 +2137,13 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
             p.single = (std::get<3>(it->second) & 512) ? 1 : 0;
             p.split3 = (std::get<3>(it->second) & 1024) ? 1 : 0;
             p.halo = (std::get<3>(it->second) & 2048) ? 1 : 0;
+            p.h2 = (std::get<3>(it->second) & 4096) ? 1 : 0;
         }
     }
     if (conv_precision() != 0) {
         // the operand-precision modes run ONE kernel family (DISPATCH_GEMM_BF): the plan describes the tile that is launched,
         // so that the BatchNorm partial rows sqd_conv_fwd_stats_rows reports are the rows the kernel writes
-        p.halo = p.split3 = p.single = 0;
+        p.halo = p.split3 = p.single = p.h2 = 0;
         p.waves = 4;
         if (p.bm == 128 && p.bn >= 64) p.bn = 64;
         else if (p.bm == 128) p.bn = 32;
@@ -2073,24 +2162,34 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
 #define LAUNCH_GEMM_P(MODE, BM, BN, WGM, WGN, BKT, PREC)                                                                 \
     hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT, PREC>),                                           \
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(256), 0, st, \
-                       a_src, w, bias, dst, g, act, p.z, order, stats, bnb)
+                       a_src, w, bias, dst, g, act, p.z, order, stats, bnb, sc)
 #define LAUNCH_GEMM(MODE, BM, BN, WGM, WGN, BKT) LAUNCH_GEMM_P(MODE, BM, BN, WGM, WGN, BKT, 0)
 #define LAUNCH_GEMM8(MODE, BM, BN, WGM, WGN, BKT)                                                                       \
     hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT, 0>),                                              \
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(512), 0, st, \
-                       a_src, w, bias, dst, g, act, p.z, order, stats, bnb)
+                       a_src, w, bias, dst, g, act, p.z, order, stats, bnb, sc)
 #define LAUNCH_GEMM8_P(MODE, BM, BN, WGM, WGN, BKT, PREC)                                                                \
     hipLaunchKernelGGL((conv_gemm_kernel<MODE, BM, BN, WGM, WGN, BKT, PREC>),                                           \
                        dim3((ncls * ((Mcls + BM - 1) / BM) * ((Ncols + BN - 1) / BN) + 7) / 8 * 8, 1, p.z), dim3(512), 0, st, \
-                       a_src, w, bias, dst, g, act, p.z, order, stats, bnb)
+                       a_src, w, bias, dst, g, act, p.z, order, stats, bnb, sc)
 #define LAUNCH_HALO4(WTM, WM, WN, WK)                                                                                      \
+    if (p.h2)                                                                                                              \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<0, WTM, WM, WN, WK, 4, true>),                                                   \
+                       dim3(g.N * ((g.H + 2 * WTM - 1) / (2 * WTM)) * ((g.W + 15) / 16) * ((Ncols + WN * 32 - 1) / (WN * 32)), 1, p.z), \
+                       dim3(WM * WN * WK * 64), 0, st, a_src, w, bias, dst, g, act, p.z, stats, bnb, sc);                          \
+    else                                                                                                                   \
     hipLaunchKernelGGL((conv3x3_halo_kernel<0, WTM, WM, WN, WK, 4>),                                                         \
                        dim3(g.N * ((g.H + 2 * WTM - 1) / (2 * WTM)) * ((g.W + 15) / 16) * ((Ncols + WN * 32 - 1) / (WN * 32)), 1, p.z), \
-                       dim3(WM * WN * WK * 64), 0, st, a_src, w, bias, dst, g, act, p.z, stats, bnb)
+                       dim3(WM * WN * WK * 64), 0, st, a_src, w, bias, dst, g, act, p.z, stats, bnb, sc)
 #define LAUNCH_HALO(MODE, WTM, WM, WN, WK)                                                                                 \
+    if (p.h2)                                                                                                              \
+        hipLaunchKernelGGL((conv3x3_halo_kernel<MODE, WTM, WM, WN, WK, 3, true>),                                                \
+                       dim3(g.N * ((g.H + 2 * WTM - 1) / (2 * WTM)) * ((g.W + 15) / 16) * ((Ncols + WN * 32 - 1) / (WN * 32)), 1, p.z), \
+                       dim3(WM * WN * WK * 64), 0, st, a_src, w, bias, dst, g, act, p.z, stats, bnb, sc);                          \
+    else                                                                                                                   \
     hipLaunchKernelGGL((conv3x3_halo_kernel<MODE, WTM, WM, WN, WK>),                                                         \
                        dim3(g.N * ((g.H + 2 * WTM - 1) / (2 * WTM)) * ((g.W + 15) / 16) * ((Ncols + WN * 32 - 1) / (WN * 32)), 1, p.z), \
-                       dim3(WM * WN * WK * 64), 0, st, a_src, w, bias, dst, g, act, p.z, stats, bnb)
+                       dim3(WM * WN * WK * 64), 0, st, a_src, w, bias, dst, g, act, p.z, stats, bnb, sc)
 #define DISPATCH_GEMM(MODE)                                                      \
     if (p.halo && g.R == 4) {                /* 4x4 taps: the space-to-depth stems (forward only); few input channels: waves split pixels */ \
         if (MODE == 0) {                                                         \
@@ -2111,6 +2210,16 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
         else if (p.bn == 128) LAUNCH_HALO(MODE, 2, 1, 4, 1);                     \
         else if (p.bn == 64) LAUNCH_HALO(MODE, 2, 1, 2, 2);                      \
         else LAUNCH_HALO(MODE, 2, 2, 1, 2);                                      \
+    } else if (p.split3 && p.h2 && p.waves == 8) {                                     \
+        if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM8_P(MODE, 128, 128, 4, 2, 32, 5);     \
+        else if (p.bm == 128) LAUNCH_GEMM8_P(MODE, 128, 64, 4, 2, 32, 5);               \
+        else LAUNCH_GEMM8_P(MODE, 64, 128, 2, 4, 32, 5);                                \
+    } else if (p.split3 && p.h2) {                                                      \
+        if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM_P(MODE, 128, 128, 2, 2, 32, 5);      \
+        else if (p.bm == 128 && p.bn == 32) LAUNCH_GEMM_P(MODE, 128, 32, 4, 1, 32, 5);   \
+        else if (p.bm == 128) LAUNCH_GEMM_P(MODE, 128, 64, 2, 2, 32, 5);         \
+        else if (p.bn == 128) LAUNCH_GEMM_P(MODE, 64, 128, 2, 2, 32, 5);         \
+        else LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 32, 5);                           \
     } else if (p.split3 && p.waves == 8) {                                             \
         if (p.bm == 128 && p.bn == 128) LAUNCH_GEMM8_P(MODE, 128, 128, 4, 2, 32, 4);     \
         else if (p.bm == 128) LAUNCH_GEMM8_P(MODE, 128, 64, 4, 2, 32, 4);               \
@@ -2164,7 +2273,8 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
     else LAUNCH_GEMM_P(MODE, 64, 64, 2, 2, 16, PR);
 
 static int launch_gemm(int mode, const float *a_src, const float *w, const float *bias, float *out, float *ws, const ConvGeom &g,
-                       int act, void *stream, float *stats = nullptr, BnBwdSrc bnb = BnBwdSrc{nullptr, nullptr, nullptr, nullptr, 0}) {
+                       int act, void *stream, float *stats = nullptr, BnBwdSrc bnb = BnBwdSrc{nullptr, nullptr, nullptr, nullptr, 0},
+                       OpScale sc = OpScale{nullptr, nullptr}) {
     const int ncls = mode == 0 ? 1 : g.stride * g.stride;
     const int Mcls = mode == 0 ? g.N * g.Ho * g.Wo : g.N * ((g.H + g.stride - 1) / g.stride) * ((g.W + g.stride - 1) / g.stride);
     const int Mrows = mode == 0 ? g.N * g.Ho * g.Wo : g.N * g.H * g.W;
@@ -2172,6 +2282,11 @@ static int launch_gemm(int mode, const float *a_src, const float *w, const float
     const GemmPlan p = plan_gemm(mode, g);
     if (p.z > 1 && !ws) {
         sqd::set_error("sqd_conv: this shape needs a split-K workspace of %lld floats (sqd_conv_plan)", (long long)p.ws_floats);
+        return SQD_EINVAL;
+    }
+    if (p.h2 && !(sc.amax_a && sc.amax_b)) {
+        sqd::set_error("sqd_conv: the plan registered for this geometry runs on two-term fp16 operands and needs the max |.| of both operands "
+                       "(sqd_conv_fwd_scaled / sqd_conv_dgrad_scaled; sqd_amax)");
         return SQD_EINVAL;
     }
     hipStream_t st = (hipStream_t)stream;
@@ -2223,7 +2338,9 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     const int single = (bk & 512) ? 1 : 0;                       // bk + 512: single-buffered LDS (twice the resident workgroups)
     const int split3 = (bk & 1024) ? 1 : 0;                      // bk + 1024: three-term bf16 operands (fp32-level accuracy on the bf16 matrix cores)
     const int halo = (bk & 2048) ? 1 : 0;                        // bk + 2048: the input-patch kernel for 3x3 / stride 1 / pad 1 (three-term bf16 operands)
+    const int h2 = (bk & 4096) ? 4096 : 0;                       // bk + 4096 (with + 1024): two fp16 terms of the scaled operands instead of three bf16 terms
     bk &= 255;
+    SQD_CHECK_ARG(!h2 || split3, "sqd_conv_set_plan: + 4096 (two-term fp16 operands) modifies the + 1024 plans");
     SQD_CHECK_ARG(conv_precision() == 0 || !(halo || split3 || single || waves == 8),
                   "sqd_conv_set_plan: the single-buffered / 8-wave / three-term / input-patch variants exist for the fp32 arithmetic only "
                   "(sqd_conv_set_precision is %d)", conv_precision());
@@ -2238,7 +2355,7 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
                       "sqd_conv_set_plan: input-patch tiles are 128|64 pixels x 128|64|32 channels (4x4: 64|32 channels)");
         const int64_t oe = (int64_t)N * H * W * Ncols;
         SQD_CHECK_ARG(z >= 1 && z <= 64 && (z == 1 || (z <= (Cr + 31) / 32 && z * oe * 4 <= (64ll << 20) && oe % 4 == 0)), "sqd_conv_set_plan: split %d not possible here", z);
-        plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, 32 | 1024 | 2048 | (waves == 8 ? 256 : 0));
+        plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, 32 | 1024 | 2048 | h2 | (waves == 8 ? 256 : 0));
         return SQD_OK;
     }
     if (split3 && waves == 8) {
@@ -2264,7 +2381,7 @@ extern "C" int sqd_conv_set_plan(int mode, int N, int H, int W, int C, int K, in
     SQD_CHECK_ARG(!(bn > 32 && bn >= 2 * Ncols) && !(bn == 32 && Ncols > 32), "sqd_conv_set_plan: tile width %d does not fit %d channels", bn, Ncols);
     SQD_CHECK_ARG(z == 1 || (z <= T / 2 && z * out_elems * 4 <= (64ll << 20) && out_elems % 4 == 0),
                   "sqd_conv_set_plan: split-K %d not possible here", z);
-    plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, bk | (waves == 8 ? 256 : 0) | (single ? 512 : 0) | (split3 ? 1024 : 0));
+    plan_table()[plan_key(mode, g)] = std::make_tuple(bm, bn, z, bk | (waves == 8 ? 256 : 0) | (single ? 512 : 0) | (split3 ? 1024 : 0) | h2);
     return SQD_OK;
 }
 
@@ -2312,6 +2429,21 @@ extern "C" int sqd_conv_fwd(const float *x, const float *w, const float *bias, f
     SQD_CHECK_ARG(C % 4 == 0 && K % 4 == 0, "sqd_conv_fwd: C=%d and K=%d must be multiples of 4", C, K);
     if (launch_gemm(0, x, w, bias, y, ws, g, act, stream, stats)) return SQD_EINVAL;
     SQD_CHECK_LAUNCH("sqd_conv_fwd");
+    return SQD_OK;
+}
+
+// sqd_conv_fwd for plans on two-term fp16 operands (sqd_conv_set_plan bk + 4096): amax_x / amax_w = device scalars holding max |x| / max |w|
+// (bit pattern of a non-negative float; any upper bound is safe, a tighter one is more accurate) — written by the producer of the tensor
+// (the `amax` outputs of the BatchNorm / element-wise kernels, sqd_amax, sqd_amax_multi).  Other plans ignore them (NULL allowed).
+extern "C" int sqd_conv_fwd_scaled(const float *x, const float *w, const float *bias, float *y, float *ws, float *stats, const float *amax_x,
+                                   const float *amax_w, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
+                                   int act, void *stream) {
+    SQD_CHECK_ARG(x && w && y, "sqd_conv_fwd_scaled: null pointer");
+    ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
+    if (check_geom("sqd_conv_fwd_scaled", g)) return SQD_EINVAL;
+    SQD_CHECK_ARG(C % 4 == 0 && K % 4 == 0, "sqd_conv_fwd_scaled: C=%d and K=%d must be multiples of 4", C, K);
+    if (launch_gemm(0, x, w, bias, y, ws, g, act, stream, stats, BnBwdSrc{nullptr, nullptr, nullptr, nullptr, 0}, OpScale{amax_x, amax_w})) return SQD_EINVAL;
+    SQD_CHECK_LAUNCH("sqd_conv_fwd_scaled");
     return SQD_OK;
 }
 
@@ -2373,6 +2505,24 @@ extern "C" int sqd_conv_dgrad_bn(const float *dy, const float *w, const float *a
     return SQD_OK;
 }
 
+// sqd_conv_dgrad_bn for plans on two-term fp16 operands: amax_dy / amax_w as in sqd_conv_fwd_scaled.
+extern "C" int sqd_conv_dgrad_scaled(const float *dy, const float *w, const float *addend, float *dx, float *ws, const float *bn_x,
+                                     const unsigned char *bn_mask, const float *bn_mean, const float *bn_rstd, int bn_act, float *stats,
+                                     const float *amax_dy, const float *amax_w, int N, int H, int W, int C, int K, int R, int S, int stride,
+                                     int pad, int Ho, int Wo, void *stream) {
+    SQD_CHECK_ARG(dy && w && dx, "sqd_conv_dgrad_scaled: null pointer");
+    SQD_CHECK_ARG(!stats || (bn_x && bn_mean && bn_rstd && bn_act >= 0 && bn_act <= 2 && (bn_mask || bn_act == 0)),
+                  "sqd_conv_dgrad_scaled: the statistics need bn_x, bn_mean, bn_rstd and (for ReLU / LeakyReLU) bn_mask");
+    ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
+    if (check_geom("sqd_conv_dgrad_scaled", g)) return SQD_EINVAL;
+    SQD_CHECK_ARG(K % 4 == 0 && C % 4 == 0, "sqd_conv_dgrad_scaled: K=%d and C=%d must be multiples of 4", K, C);
+    SQD_CHECK_ARG(addend != dx, "sqd_conv_dgrad_scaled: addend must not alias dx");
+    const BnBwdSrc bnb = {stats ? bn_x : nullptr, bn_mask, bn_mean, bn_rstd, bn_act};
+    if (launch_gemm(1, dy, w, addend, dx, ws, g, 0, stream, stats, bnb, OpScale{amax_dy, amax_w})) return SQD_EINVAL;
+    SQD_CHECK_LAUNCH("sqd_conv_dgrad_scaled");
+    return SQD_OK;
+}
+
 struct WgradPlan {
     bool direct;
     int kt, ct, tp, splits, px_per_wave;
@@ -2380,6 +2530,7 @@ struct WgradPlan {
     int split3 = 0;                 // with shared != 0: the three-term bf16 kernel on the same blocks (impl 3) instead of fp32 (impl 2)
     int px_per_split = 0;
     int direct3 = 0;                // 1..: three-term bf16 operands straight from memory (impl 6), register tile variant
+    int h2 = 0;                     // with direct3: two fp16 terms of the scaled operands (impl 7) instead of three bf16 terms
     int rows = 0;                   // row-window kernel (impl 4): `splits` workgroups of `steps_per_wg` (image, column chunk, row) steps
     int steps_per_wg = 0, nchunks = 0;
 };
@@ -2441,8 +2592,9 @@ static WgradPlan plan_wgrad_direct(int N, int Ho, int Wo, int C, int K, int R, i
         }
         m_impl = 1;             // the plan table does not key on the stride: a strided convolution of the same output geometry runs the
     }                           // direct kernel on (at most) the same number of splits, inside the workspace the plan query reported
-    if (measured && (m_impl & 15) == 6) {
+    if (measured && ((m_impl & 15) == 6 || (m_impl & 15) == 7)) {
         int kt3, ct3;
+        p.h2 = (m_impl & 15) == 7;
         direct3_tile(((m_impl >> 4) & 15) + 1, kt3, ct3);
         if (pairs_ok && K % (32 * kt3) == 0 && C % (32 * ct3) == 0) {
             p.direct = false;
@@ -2551,7 +2703,7 @@ extern "C" int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int 
         wplan_table()[WPlanKey(N, Ho, Wo, C, K, R, S)] = std::make_pair(impl, splits);
         return SQD_OK;
     }
-    if ((impl & 15) == 6) {                                      // three-term bf16 operands straight from memory: 6 + 16 * variant
+    if ((impl & 15) == 6 || (impl & 15) == 7) {                  // three-term bf16 (6) / two-term fp16 (7) operands straight from memory: + 16 * variant
         const int variant = (impl >> 4) + 1;
         int kt3 = 0, ct3 = 0;
         if (variant >= 1 && variant <= DIRECT3_VARIANTS) direct3_tile(variant, kt3, ct3);
@@ -2619,7 +2771,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_fewrows_kernel(const float *__
 constexpr int FEWROWS_MAX = 32;
 
 static int conv_wgrad_impl(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C,
-                           int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream, bool reduce_dw, int *splits_out) {
+                           int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream, bool reduce_dw, int *splits_out,
+                           OpScale sc = OpScale{nullptr, nullptr}) {
     SQD_CHECK_ARG(dy && x && dw && part, "sqd_conv_wgrad: null pointer");
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     if (check_geom("sqd_conv_wgrad", g)) return SQD_EINVAL;
@@ -2648,10 +2801,15 @@ static int conv_wgrad_impl(const float *dy, const float *x, float *dw, float *db
         int kt3, ct3;
         direct3_tile(dp.direct3, kt3, ct3);
         const dim3 grid(((K / (32 * kt3)) * (C / (32 * ct3)) * R * S * dp.splits + 7) / 8 * 8);
+        // (an fp32 fallback of a two-term plan — odd Wo under a strided layer of the same output geometry — never reaches this branch)
+        SQD_CHECK_ARG(!dp.h2 || (sc.amax_a && sc.amax_b), "sqd_conv_wgrad: the plan registered for this geometry runs on two-term fp16 operands and "
+                      "needs the max |.| of dy and x (sqd_conv_wgrad_scaled)");
 #define LAUNCH_W6(KT, CT, NW)                                                                                                          \
     do {                                                                                                                               \
-        if (flat) hipLaunchKernelGGL((conv_wgrad_direct3_kernel<KT, CT, true, NW>), grid, dim3(NW * 64), 0, st, dy, x, part, g, dp.px_per_wave, dp.splits); \
-        else hipLaunchKernelGGL((conv_wgrad_direct3_kernel<KT, CT, false, NW>), grid, dim3(NW * 64), 0, st, dy, x, part, g, dp.px_per_wave, dp.splits);    \
+        if (dp.h2 && flat) hipLaunchKernelGGL((conv_wgrad_direct3_kernel<KT, CT, true, NW, true>), grid, dim3(NW * 64), 0, st, dy, x, part, g, dp.px_per_wave, dp.splits, sc); \
+        else if (dp.h2) hipLaunchKernelGGL((conv_wgrad_direct3_kernel<KT, CT, false, NW, true>), grid, dim3(NW * 64), 0, st, dy, x, part, g, dp.px_per_wave, dp.splits, sc);  \
+        else if (flat) hipLaunchKernelGGL((conv_wgrad_direct3_kernel<KT, CT, true, NW>), grid, dim3(NW * 64), 0, st, dy, x, part, g, dp.px_per_wave, dp.splits, sc); \
+        else hipLaunchKernelGGL((conv_wgrad_direct3_kernel<KT, CT, false, NW>), grid, dim3(NW * 64), 0, st, dy, x, part, g, dp.px_per_wave, dp.splits, sc);    \
     } while (0)
         switch (dp.direct3) {
             case 1: LAUNCH_W6(2, 2, 4); break;
@@ -2747,6 +2905,14 @@ static int conv_wgrad_impl(const float *dy, const float *x, float *dw, float *db
 extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C,
                               int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream) {
     return conv_wgrad_impl(dy, x, dw, dbias, part, N, H, W, C, K, R, S, stride, pad, Ho, Wo, stream, true, nullptr);
+}
+
+// sqd_conv_wgrad / sqd_conv_wgrad_partials (splits != NULL: no final sum, see below) for plans on two-term fp16 operands (impl 7):
+// amax_dy / amax_x as in sqd_conv_fwd_scaled.  Other plans ignore them.
+extern "C" int sqd_conv_wgrad_scaled(const float *dy, const float *x, float *dw, float *dbias, float *part, const float *amax_dy,
+                                     const float *amax_x, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
+                                     int *splits, void *stream) {
+    return conv_wgrad_impl(dy, x, dw, dbias, part, N, H, W, C, K, R, S, stride, pad, Ho, Wo, stream, splits == nullptr, splits, OpScale{amax_dy, amax_x});
 }
 
 // The same without the final sum over the pixel splits: part[0 .. *splits)[K*R*S*C] holds the partial filter gradients, dw is NOT

@@ -88,6 +88,20 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     return v;
 }
 
+// ---- max |x| bookkeeping for the two-term fp16 convolution operands (amax.hip, conv.hip "f16x2") ----------------------
+// bit pattern of |x|: unsigned order == order of the magnitudes (NaN patterns sort above everything: a NaN poisons the scale like it
+// would poison an fp32 product)
+__device__ __forceinline__ unsigned abs_bits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
+// wave-wide max of the per-lane candidates, then ONE device-scope atomic per wave — and only when it would raise the scalar (the first
+// waves of a launch establish the maximum; the plain pre-check may read a stale smaller value, which costs an atomic, never a miss).
+// amax == NULL: nothing recorded.  The scalar must have been cleared on the stream before the launch.
+__device__ __forceinline__ void amax_commit(unsigned m, unsigned *__restrict__ amax) {
+    if (!amax) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > __builtin_nontemporal_load(amax)) atomicMax(amax, m);
+}
+
 // reflection index of ReflectionPad2d (pad < n), clamped for lanes far outside the image
 __device__ __forceinline__ int reflect_idx(int p, int n) {
     p = p < 0 ? -p : p;
