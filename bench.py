@@ -514,6 +514,10 @@ def main():
         elapsed = float(t.item())
     loss = float(losses["loss"].detach().cpu())
     mix, plans_used = nnkernels.plan_mix(), nnkernels.export_plans()
+    # operand scales of the two-term fp16 plans: how many max |.| scalars came out of producer kernels ("fused") and how many needed a
+    # pass of their own, by call site — Python-side counts of every step that ran eagerly or was captured (replays add nothing)
+    scales = {"recorded_by_producers": nnkernels.AMAX_STATS["fused"], "standalone_passes": nnkernels.AMAX_STATS["standalone"],
+              "standalone_by_site": dict(nnkernels.AMAX_STATS["sites"])}
     exchange = None
     if trainer.reducer is not None:
         comm = trainer.reducer.comm
@@ -580,8 +584,12 @@ def main():
                           "global_batch": world * opts.batch_size, "parallelism": "dp%d" % world,
                           "conv_arith": {"note": "layer geometries per pass by the kernel family their plan runs; 'bf16x3' = every fp32 "
                                                  "operand as the exact sum of three bf16 terms, 6 of 9 partial products on the bf16 matrix cores, "
-                                                 "fp32 accumulation (error <= 4x the fp32-MFMA kernel's against fp64: tests/test_gpu_conv.py)",
-                                         "plans": plan_note if not opts.sqd_no_conv_tune else "cost model (fp32 MFMA)", **mix},
+                                                 "fp32 accumulation (error <= 4x the fp32-MFMA kernel's against fp64: tests/test_gpu_conv.py)"
+                                                 "; 'f16x2' = every fp32 operand as two fp16 terms of the tensor scaled by a power of two, 3 of 4 partial "
+                                                 "products on the fp16 matrix cores, fp32 accumulation (error <= the fp32-MFMA kernel's against fp64: "
+                                                 "tests/test_gpu_f16x2.py)",
+                                         "plans": plan_note if not opts.sqd_no_conv_tune else "cost model (fp32 MFMA)", **mix,
+                                         "operand_scales": scales},
                           "exchange": exchange,
                           "operator_backends": nnops.backend_report()},
                "final_loss": round(loss, 6), "roofline": roof, "cpu_baseline": cpu, "diagnostics": diag}

@@ -214,6 +214,12 @@ int sqd_bn_train_fwd(const float *x, const float *res, const float *gamma, const
 int sqd_bn_train_fwd_pool(const float *x, const float *res, const float *gamma, const float *beta, float *running_mean,
                           float *running_var, float *y, unsigned char *mask, float *save_mean, float *save_rstd, float *part,
                           int pre_rows, int M, int C, float eps, float momentum, int act, float *pool_part, int B, void *stream);
+/* ... and amax_y (may be NULL; a device scalar the caller cleared on the stream): the element-wise pass records the bit pattern of max |y| —
+ * the operand scale of a convolution that reads y on two-term fp16 operands (section 10b).  Not together with pool_part. */
+int sqd_bn_train_fwd_amax(const float *x, const float *res, const float *gamma, const float *beta, float *running_mean,
+                          float *running_var, float *y, unsigned char *mask, float *save_mean, float *save_rstd, float *part,
+                          int pre_rows, int M, int C, float eps, float momentum, int act, float *pool_part, int B, float *amax_y,
+                          void *stream);
 int sqd_bn_eval_fwd(const float *x, const float *res, const float *gamma, const float *beta, const float *running_mean,
                     const float *running_var, float *y, int M, int C, float eps, int act, void *stream);
 /* dy, x, (y | mask: the activation's derivative; neither is read when act = 0) -> dx, dres (may be NULL), dgamma [C], dbeta [C].
@@ -233,6 +239,11 @@ int sqd_bn_train_bwd_pre_red(const float *dy, const float *x, const float *y, co
                              const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
                              float *dbeta, float *part, int pre_rows, int M, int C, int act, const float *red_part, float *red_out,
                              int64_t red_n, int red_splits, void *stream);
+/* ... and amax_dx / amax_dres (may be NULL; cleared by the caller): the bit patterns of max |dx| / max |dres| (section 10b) */
+int sqd_bn_train_bwd_amax(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
+                          const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
+                          float *dbeta, float *part, int pre_rows, int M, int C, int act, const float *red_part, float *red_out,
+                          int64_t red_n, int red_splits, float *amax_dx, float *amax_dres, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (7) bilinear resize (align_corners=True) + channel concat, channels-last activations
@@ -241,6 +252,9 @@ int sqd_bn_train_bwd_pre_red(const float *dy, const float *x, const float *y, co
  * x [N,Hi,Wi,Cx], skip [N,Ho,Wo,Cs] -> out [N,Ho,Wo,Cx+Cs] (NHWC memory; Cx, Cs multiples of 4).      */
 int sqd_upcat_fwd(const float *x, const float *skip, float *out, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs,
                   void *stream);
+/* ... and amax_out (may be NULL; cleared by the caller): the bit pattern of max |out| (section 10b) */
+int sqd_upcat_fwd_amax(const float *x, const float *skip, float *out, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs,
+                       float *amax_out, void *stream);
 int sqd_upcat_bwd(const float *g_out, float *g_x, float *g_skip, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs,
                   void *stream);
 
@@ -337,6 +351,9 @@ int sqd_conv_wgrad_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int *
 int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int R, int S, int impl, int splits);
 int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C, int K,
                    int R, int S, int stride, int pad, int Ho, int Wo, void *stream);
+/* impl & 15 of the kernel sqd_conv_wgrad launches for THIS convolution under the registered plan (a strided / padded layer that shares
+ * the plan's output-geometry key may fall back to impl 1, see sqd_conv_wgrad_set_plan) — the plan timing discards such candidates */
+int sqd_conv_wgrad_effective_impl(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo);
 /* src [rows][cols] -> dst [cols][rows] (fp32); colsum (may be NULL): [ceil(rows/64)][cols] column sums of each 64-row tile.  The wide
  * 1x1 layers' weight gradient dW[k][c] = sum_m dY[m][k] X[m][c] as a FORWARD problem on transposed operands:
  * sqd_conv_fwd(x = dY^T as [1,1,K,M], w = X^T [C][M]) -> dW [K][C] on the three-term kernels; dbias from colsum. */
@@ -354,21 +371,27 @@ int sqd_split_reduce(const float *part, float *out, int64_t n, int splits, void 
  * two that puts the tensor's largest magnitude into [2^14, 2^15), h and l fp16 (round-to-nearest), products h h + h l + l h on
  * v_mfma_f32_32x32x16_f16 with fp32 accumulation — half the matrix and conversion instructions of the three-term bf16 split at the
  * accuracy of the fp32 MFMA chain (csrc/conv.hip; tests/test_gpu_conv.py).  Such a plan needs max |.| of both operand tensors:
- * `amax_*` = device scalars holding the bit pattern of a non-negative float (any upper bound is safe), written before the call on the
- * same stream — by sqd_amax / sqd_amax_multi or by the `amax` outputs of the producing kernels.  The *_scaled entry points are the
+ * `amax_*` = device RECORDS of SQD_AMAX_RECORD_FLOATS floats whose words 0, 16, 32, .. hold bit patterns of non-negative floats, the tensor's
+ * max |.| being their maximum (any upper bound is safe), written before the call on the same stream — by sqd_amax / sqd_amax_multi or by the `amax` outputs of the producing kernels.  The *_scaled entry points are the
  * plain ones + those scalars; plans of the other arithmetics ignore them (NULL allowed), a two-term plan without them is SQD_EINVAL.
  * replaces: nothing in the reference — its convolutions multiply in fp32 (networks/resnet_encoder.py:89-147). */
+#define SQD_AMAX_WAYS 64            /* a max |.| record: 64 words, one per 64-byte line — the recording kernels spread their atomics over them  */
+#define SQD_AMAX_RECORD_FLOATS 1024 /* ... = 4 KB; the value of the record is the maximum of words 0, 16, 32, ..., 1008 (csrc/sqd_common.h)        */
 int sqd_amax(const float *x, int64_t n, float *amax, void *stream);
-/* one scalar per parameter tensor of an optimiser table (recs / chunks of sqd_adam_step): amax[t] = bits of max |p_t| */
+/* one record per parameter tensor of an optimiser table (recs / chunks of sqd_adam_step): amax + t * SQD_AMAX_RECORD_FLOATS = max |p_t| */
 int sqd_amax_multi(const void *recs, const void *chunks, int nchunks, int ntensors, float *amax, void *stream);
+/* amax_y / amax_dx (every plan; may be NULL; a scalar the caller cleared on the stream): the epilogue (or the sum over the splits) records the bit
+ * pattern of max |output| there — the operand scale of the next convolution in a chain without BatchNorm (PoseCNN, the decoder's plain layers) */
 int sqd_conv_fwd_scaled(const float *x, const float *w, const float *bias, float *y, float *ws, float *stats, const float *amax_x,
-                        const float *amax_w, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo, int act,
-                        void *stream);
+                        const float *amax_w, float *amax_y, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho,
+                        int Wo, int act, void *stream);
 /* sqd_conv_dgrad_bn (stats == NULL: sqd_conv_dgrad) + the operand scalars */
 int sqd_conv_dgrad_scaled(const float *dy, const float *w, const float *addend, float *dx, float *ws, const float *bn_x,
                           const unsigned char *bn_mask, const float *bn_mean, const float *bn_rstd, int bn_act, float *stats,
-                          const float *amax_dy, const float *amax_w, int N, int H, int W, int C, int K, int R, int S, int stride, int pad,
-                          int Ho, int Wo, void *stream);
+                          const float *amax_dy, const float *amax_w, float *amax_dx, int N, int H, int W, int C, int K, int R, int S,
+                          int stride, int pad, int Ho, int Wo, void *stream);
+/* sqd_act_bwd + amax_out (may be NULL; cleared by the caller): the bit pattern of max |out| */
+int sqd_act_bwd_amax(const float *g, const float *y, float *out, int64_t n, int act, float *amax_out, void *stream);
 /* sqd_conv_wgrad (splits == NULL) / sqd_conv_wgrad_partials (splits != NULL) + the operand scalars */
 int sqd_conv_wgrad_scaled(const float *dy, const float *x, float *dw, float *dbias, float *part, const float *amax_dy,
                           const float *amax_x, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
@@ -412,6 +435,9 @@ int sqd_space_to_depth2(const float *x, float *y, int N, int H, int W, int C, in
  * divided by a scalar on the device: bit-identical to the reference's normalised frame; sample n is written at y + n * y_stride floats */
 int sqd_space_to_depth2_planar(const float *x0, const float *x1, float *y, int N, int H, int W, int C0, int C1, int Cp,
                                int64_t y_stride, float sub, float div, void *stream);
+/* ... and amax_y (may be NULL; cleared by the caller, once for all launches that fill one batch): the bit pattern of max |y| (section 10b) */
+int sqd_space_to_depth2_planar_amax(const float *x0, const float *x1, float *y, int N, int H, int W, int C0, int C1, int Cp,
+                                    int64_t y_stride, float sub, float div, float *amax_y, void *stream);
 /* the matching filter regrouping w [K,C,7,7] -> ws [K,4,4,Cp] (tap u = 2r' + dy - 1; adjoint = 1: g_ws -> g_w, fully overwritten) */
 int sqd_stem_regroup(const float *src, float *dst, int K, int C, int Cp, int adjoint, void *stream);
 

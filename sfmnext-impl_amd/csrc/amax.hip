@@ -1,8 +1,9 @@
 // amax.hip — max |x| of a tensor as a device scalar: the power-of-two operand scale of the two-term fp16 convolution
 // arithmetic (conv.hip, "f16x2") is derived from it.  No reference counterpart: the reference multiplies in fp32 on cuDNN
 // (networks/resnet_encoder.py:89-147); this is bookkeeping of the build's own operand format.
-// The scalar holds the BIT PATTERN of a non-negative float (an unsigned max of |x|'s bits is the max of |x|; a NaN anywhere
-// yields a NaN pattern, which the consumer turns into NaN results like fp32 arithmetic would).  Producers that already touch every
+// A record (SQD_AMAX_RECORD_FLOATS floats, sqd_common.h) holds BIT PATTERNS of non-negative floats in 16 of its words, the tensor's max |x|
+// being their maximum (an unsigned max of |x|'s bits is the max of |x|; a NaN anywhere yields a NaN pattern, which the consumer turns
+// into NaN results like fp32 arithmetic would).  Producers that already touch every
 // element (BatchNorm / activation / up-sampling kernels, convolution epilogues, the optimiser) record it on the way — the
 // `amax` arguments of their entry points, amax_commit() of sqd_common.h; these kernels serve tensors that have no such producer.
 // Roofline: HBM, 4 B read per element.
@@ -49,15 +50,15 @@ __global__ __launch_bounds__(256) void amax_multi_kernel(const TensorRec *__rest
             for (long long e = i; e < i + 4 && e < r.n; ++e) m = max(m, abs_bits(r.p[e]));
         }
     }
-    amax_commit(m, amax + ch.x);
+    amax_commit(m, amax + (size_t)ch.x * SQD_AMAX_RECORD_FLOATS);
 }
 }  // namespace
 
-// amax[0] = bits of max |x[i]|, i < n (the scalar is cleared on the stream first: two graph nodes)
+// record `amax` (SQD_AMAX_RECORD_FLOATS floats) = max |x[i]|, i < n (the record is cleared on the stream first: two graph nodes)
 extern "C" int sqd_amax(const float *x, int64_t n, float *amax, void *stream) {
     SQD_CHECK_ARG(x && amax && n > 0 && ((uintptr_t)x & 15) == 0, "sqd_amax: bad arguments (x 16-byte aligned, n > 0)");
     (void)hipGetLastError();
-    if (hipMemsetAsync(amax, 0, 4, (hipStream_t)stream) != hipSuccess) {
+    if (hipMemsetAsync(amax, 0, SQD_AMAX_RECORD_FLOATS * 4, (hipStream_t)stream) != hipSuccess) {
         sqd::set_error("sqd_amax: hipMemsetAsync failed");
         return SQD_ELAUNCH;
     }
@@ -67,12 +68,12 @@ extern "C" int sqd_amax(const float *x, int64_t n, float *amax, void *stream) {
     return SQD_OK;
 }
 
-// amax[t] = bits of max |p_t| for every parameter tensor t of an optimiser table (recs / chunks as for sqd_adam_step; ntensors entries
-// of amax are cleared first).  One launch for all filters of the networks.
+// record amax + t * SQD_AMAX_RECORD_FLOATS = max |p_t| for every parameter tensor t of an optimiser table (recs / chunks as for
+// sqd_adam_step; the ntensors records are cleared first).  One launch for all filters of the networks.
 extern "C" int sqd_amax_multi(const void *recs, const void *chunks, int nchunks, int ntensors, float *amax, void *stream) {
     SQD_CHECK_ARG(recs && chunks && nchunks > 0 && ntensors > 0 && amax, "sqd_amax_multi: bad arguments");
     (void)hipGetLastError();
-    if (hipMemsetAsync(amax, 0, (size_t)ntensors * 4, (hipStream_t)stream) != hipSuccess) {
+    if (hipMemsetAsync(amax, 0, (size_t)ntensors * SQD_AMAX_RECORD_FLOATS * 4, (hipStream_t)stream) != hipSuccess) {
         sqd::set_error("sqd_amax_multi: hipMemsetAsync failed");
         return SQD_ELAUNCH;
     }

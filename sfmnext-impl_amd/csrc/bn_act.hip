@@ -235,7 +235,8 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float *__restri
                                                            const float *__restrict__ gamma, const float *__restrict__ beta,
                                                            const float *__restrict__ mean, const float *__restrict__ rstd,
                                                            float *__restrict__ y, size_t total4, int C, float eps, int act,
-                                                           unsigned char *__restrict__ mask) {
+                                                           unsigned char *__restrict__ mask, unsigned *__restrict__ amax_y) {
+    unsigned am = 0u;                                           // max |y| of this thread's elements (amax_y == NULL: not recorded)
     // the channel group of a thread's element advances by (grid stride mod V) per iteration — zero whenever V divides 256, i.e.
     // for every C <= 1024: the per-channel constants are then loaded once, and no 64-bit modulo runs inside the loop
     const unsigned V = (unsigned)C / 4u;
@@ -267,12 +268,14 @@ __global__ __launch_bounds__(256) void bn_apply_fwd_kernel(const float *__restri
             mask[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
         o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
         reinterpret_cast<float4 *>(y)[i] = o;
+        am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
         if (cstep) {                                            // uniform
             cg += cstep;
             cg -= cg >= V ? V : 0u;
             params();
         }
     }
+    amax_commit(am, amax_y);
 }
 
 __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
@@ -281,7 +284,9 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
                                                            const float *__restrict__ dgamma, const float *__restrict__ dbeta,
                                                            float *__restrict__ dx, float *__restrict__ dres, size_t total4,
                                                            int C, float invM, int act, const unsigned char *__restrict__ mask,
-                                                           const float *__restrict__ beta) {
+                                                           const float *__restrict__ beta, unsigned *__restrict__ amax_dx,
+                                                           unsigned *__restrict__ amax_dres) {
+    unsigned am = 0u, amr = 0u;
     const unsigned V = (unsigned)C / 4u;
     const size_t stride = (size_t)gridDim.x * 256;
     size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -315,12 +320,16 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
         o.w = k0.w * (dz.w - k1.w - (xv.w - mu.w) * k2.w);
         reinterpret_cast<float4 *>(dx)[i] = o;
         if (dres) reinterpret_cast<float4 *>(dres)[i] = dz;
+        am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
+        amr = max(max(amr, abs_bits(dz.x)), max(abs_bits(dz.y), max(abs_bits(dz.z), abs_bits(dz.w))));
         if (cstep) {                                            // uniform
             cg += cstep;
             cg -= cg >= V ? V : 0u;
             params();
         }
     }
+    amax_commit(am, amax_dx);
+    if (dres) amax_commit(amr, amax_dres, 1);
 }
 
 // bn_apply_fwd_kernel for a BatchNorm whose output goes into a squeeze-and-excite gate: the same values, and on the way the per-image
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const float *__restri
                                                            const float *__restrict__ beta, const float *__restrict__ part, int rows,
                                                            float *__restrict__ mean_out, float *__restrict__ rstd_out, float *__restrict__ rmean,
                                                            float *__restrict__ rvar, float *__restrict__ y, unsigned char *__restrict__ mask, int M,
-                                                           int C, float eps, float momentum, int act, int rows_per_block) {
+                                                           int C, float eps, float momentum, int act, int rows_per_block, unsigned *__restrict__ amax_y) {
     __shared__ float4 red[16][16][2];
     const int cgl = threadIdx.x & 15, rl = threadIdx.x >> 4, c0 = blockIdx.y * 64, c = c0 + cgl * 4;
     float4 s, q;
@@ -437,6 +446,7 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const float *__restri
     }
     const float4 ga = *reinterpret_cast<const float4 *>(gamma + c), be = *reinterpret_cast<const float4 *>(beta + c);
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    unsigned am = 0u;
     for (int r = r0 + rl; r < r1; r += 16) {
         const size_t i = ((size_t)r * C + c) / 4;
         const float4 xv = reinterpret_cast<const float4 *>(x)[i];
@@ -452,7 +462,9 @@ __global__ __launch_bounds__(256) void bn_fused_fwd_kernel(const float *__restri
         if (mask) mask[i] = (unsigned char)((o.x > 0.f ? 1 : 0) | (o.y > 0.f ? 2 : 0) | (o.z > 0.f ? 4 : 0) | (o.w > 0.f ? 8 : 0));
         o.x = act_fwd(o.x, act); o.y = act_fwd(o.y, act); o.z = act_fwd(o.z, act); o.w = act_fwd(o.w, act);
         reinterpret_cast<float4 *>(y)[i] = o;
+        am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
     }
+    amax_commit(am, amax_y);
 }
 
 // backward: dgamma / dbeta from the partial rows (sum dz, sum dz * xhat), then dx = gamma rstd (dz - mean(dz) - xhat mean(dz xhat)), dres = dz.
@@ -462,7 +474,8 @@ __global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const float *__restri
                                                            const float *__restrict__ part, int rows, float *__restrict__ dgamma, float *__restrict__ dbeta,
                                                            float *__restrict__ dx, float *__restrict__ dres, int M, int C, int act,
                                                            const unsigned char *__restrict__ mask, int rows_per_block, int nchunks, int nrb,
-                                                           const float *__restrict__ red_part, float *__restrict__ red_out, size_t red_n, int red_splits) {
+                                                           const float *__restrict__ red_part, float *__restrict__ red_out, size_t red_n, int red_splits,
+                                                           unsigned *__restrict__ amax_dx, unsigned *__restrict__ amax_dres) {
     __shared__ float4 red[16][16][2];
     if ((int)blockIdx.y >= nchunks) {              // (workgroup-uniform) the pending sum of a weight gradient's pixel splits
         sqd::split_reduce_block(red_part, red_out, red_n, red_splits, ((int)blockIdx.y - nchunks) * nrb + (int)blockIdx.x,
@@ -483,6 +496,7 @@ __global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const float *__restri
     const float4 k1 = make_float4(db.x * invM, db.y * invM, db.z * invM, db.w * invM);
     const float4 k2 = make_float4(rs.x * (dg.x * invM), rs.y * (dg.y * invM), rs.z * (dg.z * invM), rs.w * (dg.w * invM));
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    unsigned am = 0u, amr = 0u;
     for (int r = r0 + rl; r < r1; r += 16) {
         const size_t i = ((size_t)r * C + c) / 4;
         const float4 gy = reinterpret_cast<const float4 *>(dy)[i];
@@ -496,7 +510,11 @@ __global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const float *__restri
         o.w = k0.w * (dz.w - k1.w - (xv.w - mu.w) * k2.w);
         reinterpret_cast<float4 *>(dx)[i] = o;
         if (dres) reinterpret_cast<float4 *>(dres)[i] = dz;
+        am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
+        amr = max(max(amr, abs_bits(dz.x)), max(abs_bits(dz.y), max(abs_bits(dz.z), abs_bits(dz.w))));
     }
+    amax_commit(am, amax_dx);
+    if (dres) amax_commit(amr, amax_dres, 1);
 }
 // rows a workgroup of the fused kernels owns: ~1024 workgroups per launch, at least 64 rows each and at least as many as there are
 // partial rows (the prologue — `prows` x 512 bytes — is paid per workgroup: it stays below the workgroup's own slice of the tensor)
@@ -536,6 +554,17 @@ extern "C" int sqd_bn_train_fwd(const float *x, const float *res, const float *g
 extern "C" int sqd_bn_train_fwd_pool(const float *x, const float *res, const float *gamma, const float *beta, float *running_mean,
                                      float *running_var, float *y, unsigned char *mask, float *save_mean, float *save_rstd, float *part,
                                      int pre_rows, int M, int C, float eps, float momentum, int act, float *pool_part, int B, void *stream) {
+    return sqd_bn_train_fwd_amax(x, res, gamma, beta, running_mean, running_var, y, mask, save_mean, save_rstd, part, pre_rows, M, C, eps, momentum,
+                                 act, pool_part, B, nullptr, stream);
+}
+
+// ... and amax_y (may be NULL; cleared by the caller on the stream before the call): the element-wise pass records the bit pattern of
+// max |y| there — the operand scale of a convolution that reads y on two-term fp16 operands (sqd_conv_fwd_scaled).  Not with pool_part.
+extern "C" int sqd_bn_train_fwd_amax(const float *x, const float *res, const float *gamma, const float *beta, float *running_mean,
+                                     float *running_var, float *y, unsigned char *mask, float *save_mean, float *save_rstd, float *part,
+                                     int pre_rows, int M, int C, float eps, float momentum, int act, float *pool_part, int B, float *amax_y,
+                                     void *stream) {
+    SQD_CHECK_ARG(!(amax_y && pool_part), "sqd_bn_train_fwd_amax: the pooled variant records no max |y|");
     SQD_CHECK_ARG(x && gamma && beta && y && save_mean && save_rstd && part, "sqd_bn_train_fwd: null pointer");
     SQD_CHECK_ARG(!pool_part || (B > 0 && M % B == 0 && !res), "sqd_bn_train_fwd_pool: B=%d must divide M=%d; no residual", B, M);
     SQD_CHECK_ARG(act != ACT_SWISH || !res, "sqd_bn_train_fwd: swish takes no residual (its backward recomputes the pre-activation from x)");
@@ -549,7 +578,7 @@ extern "C" int sqd_bn_train_fwd_pool(const float *x, const float *res, const flo
         // few partial rows from the producing convolution: finalize + element-wise pass in one launch
         const int rpb = fused_rows_per_block(M, C, pre_rows);
         hipLaunchKernelGGL(bn_fused_fwd_kernel, dim3((M + rpb - 1) / rpb, C / 64), dim3(256), 0, s, x, res, gamma, beta, part, pre_rows, save_mean, save_rstd,
-                           running_mean, running_var, y, mask, M, C, eps, momentum, act, rpb);
+                           running_mean, running_var, y, mask, M, C, eps, momentum, act, rpb, (unsigned *)amax_y);
         SQD_CHECK_LAUNCH("sqd_bn_train_fwd");
         return SQD_OK;
     }
@@ -565,7 +594,7 @@ extern "C" int sqd_bn_train_fwd_pool(const float *x, const float *res, const flo
                            pool_part, HW, C, act, ppc, nchunk);
     } else {
         hipLaunchKernelGGL((bn_apply_fwd_kernel<false>), dim3(ew_grid(total4)), dim3(256), 0, s, x, res, gamma, beta, save_mean,
-                           save_rstd, y, total4, C, eps, act, mask);
+                           save_rstd, y, total4, C, eps, act, mask, (unsigned *)amax_y);
     }
     SQD_CHECK_LAUNCH("sqd_bn_train_fwd");
     return SQD_OK;
@@ -579,7 +608,7 @@ extern "C" int sqd_bn_eval_fwd(const float *x, const float *res, const float *ga
     const size_t total4 = (size_t)M * C / 4;
     (void)hipGetLastError();
     hipLaunchKernelGGL((bn_apply_fwd_kernel<true>), dim3(ew_grid(total4)), dim3(256), 0, (hipStream_t)stream, x, res, gamma,
-                       beta, running_mean, running_var, y, total4, C, eps, act, (unsigned char *)nullptr);
+                       beta, running_mean, running_var, y, total4, C, eps, act, (unsigned char *)nullptr, (unsigned *)nullptr);
     SQD_CHECK_LAUNCH("sqd_bn_eval_fwd");
     return SQD_OK;
 }
@@ -605,6 +634,16 @@ extern "C" int sqd_bn_train_bwd_pre_red(const float *dy, const float *x, const f
                                         const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
                                         float *dbeta, float *part, int pre_rows, int M, int C, int act, const float *red_part, float *red_out,
                                         int64_t red_n, int red_splits, void *stream) {
+    return sqd_bn_train_bwd_amax(dy, x, y, mask, gamma, beta, save_mean, save_rstd, dx, dres, dgamma, dbeta, part, pre_rows, M, C, act, red_part, red_out,
+                                 red_n, red_splits, nullptr, nullptr, stream);
+}
+
+// ... and amax_dx / amax_dres (may be NULL; cleared by the caller): bit patterns of max |dx| and max |dres|, for the data / weight gradients
+// that read them on two-term fp16 operands
+extern "C" int sqd_bn_train_bwd_amax(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
+                                     const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
+                                     float *dbeta, float *part, int pre_rows, int M, int C, int act, const float *red_part, float *red_out,
+                                     int64_t red_n, int red_splits, float *amax_dx, float *amax_dres, void *stream) {
     SQD_CHECK_ARG(!red_part || (red_out && red_n > 0 && red_n % 4 == 0 && red_splits >= 1), "sqd_bn_train_bwd_pre_red: bad pending reduction");
     SQD_CHECK_ARG(dy && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && part, "sqd_bn_train_bwd: null pointer");
     SQD_CHECK_ARG(pre_rows >= 0 && (pre_rows == 0 || act != ACT_SWISH), "sqd_bn_train_bwd_pre: pre_rows=%d (no precomputed partials with swish)", pre_rows);
@@ -618,7 +657,8 @@ extern "C" int sqd_bn_train_bwd_pre_red(const float *dy, const float *x, const f
         const int rpb = fused_rows_per_block(M, C, pre_rows), nrb = (M + rpb - 1) / rpb, nchunks = C / 64;
         const int nredb = red_part ? (int)((red_n / 4 + 15) / 16) : 0;             // blocks of the pending split reduction, nrb per grid row
         hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3(nrb, nchunks + (nredb + nrb - 1) / nrb), dim3(256), 0, s, dy, x, y, gamma, save_mean, save_rstd, part,
-                           pre_rows, dgamma, dbeta, dx, dres, M, C, act, mask, rpb, nchunks, nrb, red_part, red_out, (size_t)red_n, red_splits);
+                           pre_rows, dgamma, dbeta, dx, dres, M, C, act, mask, rpb, nchunks, nrb, red_part, red_out, (size_t)red_n, red_splits,
+                           (unsigned *)amax_dx, (unsigned *)amax_dres);
         SQD_CHECK_LAUNCH("sqd_bn_train_bwd");
         return SQD_OK;
     }
@@ -629,7 +669,7 @@ extern "C" int sqd_bn_train_bwd_pre_red(const float *dy, const float *x, const f
                        red_part, red_out, (size_t)red_n, red_splits);
     const size_t total4 = (size_t)M * C / 4;
     hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, s, dy, x, y, gamma, save_mean, save_rstd, dgamma,
-                       dbeta, dx, dres, total4, C, 1.0f / (float)M, act, mask, beta);
+                       dbeta, dx, dres, total4, C, 1.0f / (float)M, act, mask, beta, (unsigned *)amax_dx, (unsigned *)amax_dres);
     SQD_CHECK_LAUNCH("sqd_bn_train_bwd");
     return SQD_OK;
 }

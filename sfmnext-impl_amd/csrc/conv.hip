@@ -103,15 +103,16 @@ __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
 // 3-4 conversion instructions per element instead of six and 5.5, two LDS planes instead of three.  Against float64 the result is
 // as close as the fp32 MFMA chain's (tests/test_gpu_conv.py::test_f16x2_*; oracle/f16x2_model.py).  The scale comes from the
 // tensor's max |.|, which the producing kernel leaves in device memory (sqd_amax_* / the `amax` outputs of the producers): a
-// device scalar holding the bit pattern of a non-negative float.  s = 2^(141 - biased exponent), clamped to a normal float.
+// record of 16 words in 16 cache lines (sqd_common.h) holding bit patterns of non-negative floats.  s = 2^(141 - biased exponent), clamped to a normal float.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 struct OpScale {
     const float *amax_a, *amax_b;     // max |.| of the A operand (x / dy) and of the B operand (w; x for the weight gradient); NULL: unscaled plans
+    unsigned *amax_out;               // may be NULL: where the epilogue records max |output| (for the convolution that reads the output next)
 };
 __device__ __forceinline__ unsigned scale_exp(const float *amax) {        // biased exponent of s
-    const int e = (int)((__float_as_uint(*amax) >> 23) & 0xffu);
+    const int e = (int)((amax_record_bits(amax) >> 23) & 0xffu);
     return (unsigned)min(max(268 - e, 1), 253);
 }
 __device__ __forceinline__ float scale_from_exp(unsigned be) { return __uint_as_float(be << 23); }
@@ -439,13 +440,17 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
         __syncthreads();
         float *dst = out + (size_t)blockIdx.z * g.N * g.H * g.W * Ncols;     // split-K: every partial slot gets its zeros
         constexpr int QN = BN / 4;                  // float4 per tile row
+        unsigned am0 = 0u;
         for (int idx = t; idx < BM * QN; idx += NT) {
             const int ml = idx / QN, c = n0 + (idx % QN) * 4;
             const int px = rowpix[ml];
-            if (px >= 0 && c < Ncols)
-                *reinterpret_cast<float4 *>(dst + (size_t)px * Ncols + c) =
-                    (bias && zsplits == 1) ? *reinterpret_cast<const float4 *>(bias + (size_t)px * Ncols + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (px >= 0 && c < Ncols) {
+                const float4 v = (bias && zsplits == 1) ? *reinterpret_cast<const float4 *>(bias + (size_t)px * Ncols + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4 *>(dst + (size_t)px * Ncols + c) = v;
+                am0 = max(max(am0, abs_bits(v.x)), max(abs_bits(v.y), max(abs_bits(v.z), abs_bits(v.w))));
+            }
         }
+        if (sc.amax_out != nullptr && zsplits == 1) amax_commit(am0, sc.amax_out);
         return;
     }
     f32x16 acc[WTM][WTN];
@@ -549,6 +554,8 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
     const bool has_add = MODE == 1 && bias != nullptr && zsplits == 1;                   // dgrad: `bias` is the [N,H,W,C] addend
     const __amdgpu_buffer_rsrc_t add_r = make_rsrc(has_add ? bias : out, has_add ? out_bytes : 0u);
     const float isa = inv_scale_from_exp(bea), isb = inv_scale_from_exp(beb);     // f16x2: the accumulators hold s_a s_b times the result
+    const bool want_amax = sc.amax_out != nullptr && zsplits == 1;                // (split plans: the sum over the splits records it)
+    unsigned am = 0u;
 #pragma unroll
     for (int j = 0; j < WTN; ++j) {
         const int col = n0 + wn0 + j * 32 + row;
@@ -586,6 +593,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
                 if (MODE == 0 && act == 1 && zsplits == 1) v = v > 0.f ? v : 0.f;
                 if (MODE == 0 && act == 2 && zsplits == 1) v = v > 0.f ? v : 0.01f * v;      // LeakyReLU(0.01), nn.LeakyReLU's default slope
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), dst_r, off[e], 0, 0);
+                if (want_amax) am = max(am, off[e] != 0xffffffffu ? abs_bits(v) : 0u);
                 if (MODE == 0) {
                     const float vs = off[e] != 0xffffffffu ? v : 0.f;
                     s1 += vs;
@@ -606,6 +614,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
             }
         }
     }
+    if (want_amax) amax_commit(am, sc.amax_out);
     if (want_stats) {
         __syncthreads();
         if (t < BN && n0 + t < Ncols) {
@@ -832,6 +841,8 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
     const float bmu = (bstats && colv) ? bnb.mean[col] : 0.f, brs = (bstats && colv) ? bnb.rstd[col] : 0.f;
     float s1 = 0.f, s2 = 0.f;
     const float isa = inv_scale_from_exp(bea), isb = inv_scale_from_exp(beb);
+    const bool want_amax = sc.amax_out != nullptr && zsplits == 1;
+    unsigned am = 0u;
     if (writer) {
 #pragma unroll
     for (int i = 0; i < WS; ++i) {
@@ -863,6 +874,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
             if (MODE == 0 && act == 1 && zsplits == 1) v = v > 0.f ? v : 0.f;
             if (MODE == 0 && act == 2 && zsplits == 1) v = v > 0.f ? v : 0.01f * v;
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(v), dst_r, off[e], 0, 0);
+            if (want_amax) am = max(am, off[e] != 0xffffffffu ? abs_bits(v) : 0u);
             if (MODE == 0) {
                 const float vs = off[e] != 0xffffffffu ? v : 0.f;
                 s1 += vs;
@@ -875,6 +887,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
         }
     }
     }
+    if (want_amax) amax_commit(am, sc.amax_out);
     if (want_stats) {      // BatchNorm partials of this patch: stats[patch][channels][2] (forward: of y; data gradient: of the BatchNorm backward)
         s1 += __shfl_xor(s1, 32, 64);
         s2 += __shfl_xor(s2, 32, 64);
@@ -1890,7 +1903,8 @@ __global__ __launch_bounds__(NW * 64, (KT * CT <= 4 || NW == 8 ? 2 : 1)) void co
 // sum of the split-K partial tiles (+ bias, + activation): part [Z][M*Ncols] -> out [M*Ncols]
 __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restrict__ part, const float *__restrict__ bias,
                                                           const float *__restrict__ addend, float *__restrict__ out, size_t n, int Z,
-                                                          int Ncols, int act) {
+                                                          int Ncols, int act, unsigned *__restrict__ amax_out) {
+    unsigned am = 0u;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n / 4; i += (size_t)gridDim.x * 256) {
         float4 a = reinterpret_cast<const float4 *>(part)[i];
         for (int z = 1; z < Z; ++z) {
@@ -1912,7 +1926,9 @@ __global__ __launch_bounds__(256) void gemm_reduce_kernel(const float *__restric
             a.z = a.z > 0.f ? a.z : 0.01f * a.z; a.w = a.w > 0.f ? a.w : 0.01f * a.w;
         }
         reinterpret_cast<float4 *>(out)[i] = a;
+        am = max(max(am, abs_bits(a.x)), max(abs_bits(a.y), max(abs_bits(a.z), abs_bits(a.w))));
     }
+    amax_commit(am, amax_out);
 }
 
 // The same sum for a convolution whose output feeds a BatchNorm (forward, MODE 0) or whose data gradient is a BatchNorm's complete
@@ -1925,8 +1941,10 @@ constexpr int RED_ROWS = 64;
 template <int MODE>
 __global__ __launch_bounds__(256) void gemm_reduce_stats_kernel(const float *__restrict__ part, const float *__restrict__ bias,
                                                                 const float *__restrict__ addend, float *__restrict__ out, int M, int Z,
-                                                                int Ncols, int act, float *__restrict__ stats, BnBwdSrc bnb, int CH) {
+                                                                int Ncols, int act, float *__restrict__ stats, BnBwdSrc bnb, int CH,
+                                                                unsigned *__restrict__ amax_out) {
     __shared__ float4 sh[2][256];
+    unsigned am = 0u;
     const int t = threadIdx.x;
     const int chunk = min(CH, Ncols - (int)blockIdx.y * CH);            // channels of this workgroup (multiple of 4; CH = 256 .. 32)
     const int TPR = chunk / 4, RP = 256 / TPR;
@@ -1962,6 +1980,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_stats_kernel(const float *__r
                 v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
             }
             *reinterpret_cast<float4 *>(out + o) = v;
+            am = max(max(am, abs_bits(v.x)), max(abs_bits(v.y), max(abs_bits(v.z), abs_bits(v.w))));
             if (MODE == 0) {
                 a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
                 b.x = fmaf(v.x, v.x, b.x); b.y = fmaf(v.y, v.y, b.y); b.z = fmaf(v.z, v.z, b.z); b.w = fmaf(v.w, v.w, b.w);
@@ -1976,6 +1995,7 @@ __global__ __launch_bounds__(256) void gemm_reduce_stats_kernel(const float *__r
             }
         }
     }
+    amax_commit(am, amax_out);
     sh[0][t] = a;
     sh[1][t] = b;
     __syncthreads();
@@ -1994,15 +2014,21 @@ __global__ __launch_bounds__(256) void gemm_reduce_stats_kernel(const float *__r
 // gradient through the activation a convolution / linear layer applied in its epilogue, from the OUTPUT y (sign(y) == sign(pre-
 // activation) for both): ReLU g * (y > 0), LeakyReLU(0.01) g * (y > 0 ? 1 : 0.01)
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float *__restrict__ g, const float *__restrict__ y, float *__restrict__ out,
-                                                      size_t n4, size_t n, int act) {
+                                                      size_t n4, size_t n, int act, unsigned *__restrict__ amax_out) {
     const float neg = act == 2 ? 0.01f : 0.f;
+    unsigned am = 0u;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const float4 a = reinterpret_cast<const float4 *>(g)[i], b = reinterpret_cast<const float4 *>(y)[i];
-        reinterpret_cast<float4 *>(out)[i] = make_float4(b.x > 0.f ? a.x : neg * a.x, b.y > 0.f ? a.y : neg * a.y,
-                                                         b.z > 0.f ? a.z : neg * a.z, b.w > 0.f ? a.w : neg * a.w);
+        const float4 o = make_float4(b.x > 0.f ? a.x : neg * a.x, b.y > 0.f ? a.y : neg * a.y, b.z > 0.f ? a.z : neg * a.z, b.w > 0.f ? a.w : neg * a.w);
+        reinterpret_cast<float4 *>(out)[i] = o;
+        am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
     }
-    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
-        out[i] = y[i] > 0.f ? g[i] : neg * g[i];
+    for (size_t i = n4 * 4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float o = y[i] > 0.f ? g[i] : neg * g[i];
+        out[i] = o;
+        am = max(am, abs_bits(o));
+    }
+    amax_commit(am, amax_out);
 }
 
 // column sums of a [M, K] matrix (bias gradient), deterministic: block b adds rows [b*rpb, (b+1)*rpb) of a band of up
@@ -2274,7 +2300,7 @@ static GemmPlan plan_gemm(int mode, const ConvGeom &g) {
 
 static int launch_gemm(int mode, const float *a_src, const float *w, const float *bias, float *out, float *ws, const ConvGeom &g,
                        int act, void *stream, float *stats = nullptr, BnBwdSrc bnb = BnBwdSrc{nullptr, nullptr, nullptr, nullptr, 0},
-                       OpScale sc = OpScale{nullptr, nullptr}) {
+                       OpScale sc = OpScale{nullptr, nullptr, nullptr}) {
     const int ncls = mode == 0 ? 1 : g.stride * g.stride;
     const int Mcls = mode == 0 ? g.N * g.Ho * g.Wo : g.N * ((g.H + g.stride - 1) / g.stride) * ((g.W + g.stride - 1) / g.stride);
     const int Mrows = mode == 0 ? g.N * g.Ho * g.Wo : g.N * g.H * g.W;
@@ -2307,14 +2333,14 @@ static int launch_gemm(int mode, const float *a_src, const float *w, const float
         while (CH > 32 && mb * ((Ncols + CH - 1) / CH) < 1024) CH >>= 1;
         const dim3 grid(mb, (Ncols + CH - 1) / CH);
         if (mode == 0)
-            hipLaunchKernelGGL((gemm_reduce_stats_kernel<0>), grid, dim3(256), 0, st, ws, bias, (const float *)nullptr, out, Mrows, p.z, Ncols, act, stats, bnb, CH);
+            hipLaunchKernelGGL((gemm_reduce_stats_kernel<0>), grid, dim3(256), 0, st, ws, bias, (const float *)nullptr, out, Mrows, p.z, Ncols, act, stats, bnb, CH, sc.amax_out);
         else
-            hipLaunchKernelGGL((gemm_reduce_stats_kernel<1>), grid, dim3(256), 0, st, ws, (const float *)nullptr, bias, out, Mrows, p.z, Ncols, 0, stats, bnb, CH);
+            hipLaunchKernelGGL((gemm_reduce_stats_kernel<1>), grid, dim3(256), 0, st, ws, (const float *)nullptr, bias, out, Mrows, p.z, Ncols, 0, stats, bnb, CH, sc.amax_out);
     } else if (p.z > 1) {
         const size_t n = (size_t)Mrows * Ncols;
         size_t nb = (n / 4 + 255) / 256;
         hipLaunchKernelGGL(gemm_reduce_kernel, dim3((unsigned)(nb > 4096 ? 4096 : nb)), dim3(256), 0, st, ws, mode == 0 ? bias : nullptr, mode == 1 ? bias : nullptr,
-                           out, n, p.z, Ncols, mode == 0 ? act : 0);
+                           out, n, p.z, Ncols, mode == 0 ? act : 0, sc.amax_out);
     }
     return SQD_OK;
 }
@@ -2435,26 +2461,31 @@ extern "C" int sqd_conv_fwd(const float *x, const float *w, const float *bias, f
 // sqd_conv_fwd for plans on two-term fp16 operands (sqd_conv_set_plan bk + 4096): amax_x / amax_w = device scalars holding max |x| / max |w|
 // (bit pattern of a non-negative float; any upper bound is safe, a tighter one is more accurate) — written by the producer of the tensor
 // (the `amax` outputs of the BatchNorm / element-wise kernels, sqd_amax, sqd_amax_multi).  Other plans ignore them (NULL allowed).
+// amax_y (any plan; may be NULL; cleared by the caller): the epilogue records max |y| for the next convolution.
 extern "C" int sqd_conv_fwd_scaled(const float *x, const float *w, const float *bias, float *y, float *ws, float *stats, const float *amax_x,
-                                   const float *amax_w, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
-                                   int act, void *stream) {
+                                   const float *amax_w, float *amax_y, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho,
+                                   int Wo, int act, void *stream) {
     SQD_CHECK_ARG(x && w && y, "sqd_conv_fwd_scaled: null pointer");
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     if (check_geom("sqd_conv_fwd_scaled", g)) return SQD_EINVAL;
     SQD_CHECK_ARG(C % 4 == 0 && K % 4 == 0, "sqd_conv_fwd_scaled: C=%d and K=%d must be multiples of 4", C, K);
-    if (launch_gemm(0, x, w, bias, y, ws, g, act, stream, stats, BnBwdSrc{nullptr, nullptr, nullptr, nullptr, 0}, OpScale{amax_x, amax_w})) return SQD_EINVAL;
+    if (launch_gemm(0, x, w, bias, y, ws, g, act, stream, stats, BnBwdSrc{nullptr, nullptr, nullptr, nullptr, 0}, OpScale{amax_x, amax_w, (unsigned *)amax_y})) return SQD_EINVAL;
     SQD_CHECK_LAUNCH("sqd_conv_fwd_scaled");
     return SQD_OK;
 }
 
 // g, y, out: n floats (same memory order; out may alias g) -> out = g * act'(y); act 1 ReLU, 2 LeakyReLU(0.01)
 extern "C" int sqd_act_bwd(const float *g, const float *y, float *out, int64_t n, int act, void *stream) {
+    return sqd_act_bwd_amax(g, y, out, n, act, nullptr, stream);
+}
+// ... and amax_out (may be NULL; cleared by the caller): the bit pattern of max |out|
+extern "C" int sqd_act_bwd_amax(const float *g, const float *y, float *out, int64_t n, int act, float *amax_out, void *stream) {
     SQD_CHECK_ARG(g && y && out && n > 0 && (act == 1 || act == 2), "sqd_act_bwd: bad arguments");
     SQD_CHECK_ARG(((uintptr_t)g & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)out & 15) == 0, "sqd_act_bwd: 16-byte aligned pointers");
     (void)hipGetLastError();
     const size_t n4 = (size_t)n / 4;
     const int blocks = (int)((n4 + 255) / 256 < 1 ? 1 : ((n4 + 255) / 256 > 2048 ? 2048 : (n4 + 255) / 256));
-    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, y, out, n4, (size_t)n, act);
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, y, out, n4, (size_t)n, act, (unsigned *)amax_out);
     SQD_CHECK_LAUNCH("sqd_act_bwd");
     return SQD_OK;
 }
@@ -2508,8 +2539,8 @@ extern "C" int sqd_conv_dgrad_bn(const float *dy, const float *w, const float *a
 // sqd_conv_dgrad_bn for plans on two-term fp16 operands: amax_dy / amax_w as in sqd_conv_fwd_scaled.
 extern "C" int sqd_conv_dgrad_scaled(const float *dy, const float *w, const float *addend, float *dx, float *ws, const float *bn_x,
                                      const unsigned char *bn_mask, const float *bn_mean, const float *bn_rstd, int bn_act, float *stats,
-                                     const float *amax_dy, const float *amax_w, int N, int H, int W, int C, int K, int R, int S, int stride,
-                                     int pad, int Ho, int Wo, void *stream) {
+                                     const float *amax_dy, const float *amax_w, float *amax_dx, int N, int H, int W, int C, int K, int R, int S,
+                                     int stride, int pad, int Ho, int Wo, void *stream) {
     SQD_CHECK_ARG(dy && w && dx, "sqd_conv_dgrad_scaled: null pointer");
     SQD_CHECK_ARG(!stats || (bn_x && bn_mean && bn_rstd && bn_act >= 0 && bn_act <= 2 && (bn_mask || bn_act == 0)),
                   "sqd_conv_dgrad_scaled: the statistics need bn_x, bn_mean, bn_rstd and (for ReLU / LeakyReLU) bn_mask");
@@ -2518,7 +2549,7 @@ extern "C" int sqd_conv_dgrad_scaled(const float *dy, const float *w, const floa
     SQD_CHECK_ARG(K % 4 == 0 && C % 4 == 0, "sqd_conv_dgrad_scaled: K=%d and C=%d must be multiples of 4", K, C);
     SQD_CHECK_ARG(addend != dx, "sqd_conv_dgrad_scaled: addend must not alias dx");
     const BnBwdSrc bnb = {stats ? bn_x : nullptr, bn_mask, bn_mean, bn_rstd, bn_act};
-    if (launch_gemm(1, dy, w, addend, dx, ws, g, 0, stream, stats, bnb, OpScale{amax_dy, amax_w})) return SQD_EINVAL;
+    if (launch_gemm(1, dy, w, addend, dx, ws, g, 0, stream, stats, bnb, OpScale{amax_dy, amax_w, (unsigned *)amax_dx})) return SQD_EINVAL;
     SQD_CHECK_LAUNCH("sqd_conv_dgrad_scaled");
     return SQD_OK;
 }
@@ -2731,6 +2762,21 @@ extern "C" int sqd_conv_wgrad_set_plan(int N, int Ho, int Wo, int C, int K, int 
     return SQD_OK;
 }
 
+// The kernel family sqd_conv_wgrad launches for this convolution under the registered plan: the plan table keys on the OUTPUT geometry, so a
+// strided / padded layer that shares a key with a stride-1 layer may not be able to run the registered kernel (the row-window kernel is
+// stride 1 only; the direct-operand split kernels need an even Wo unless the convolution is a plain 1x1) and falls back to the fp32
+// direct kernel (1) inside the same workspace.  Returns impl & 15 of what runs: 0 LDS-tiled, 1 direct fp32, 2 / 3 shared-operand,
+// 4 row-window, 6 three-term direct, 7 two-term direct.  The plan timing uses it to discard candidates that would not run as named.
+extern "C" int sqd_conv_wgrad_effective_impl(int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo) {
+    (void)H; (void)W;
+    const bool flat = R == 1 && S == 1 && stride == 1 && pad == 0;
+    const WgradPlan dp = plan_wgrad_direct(N, Ho, Wo, C, K, R, S, stride, flat || Wo % 2 == 0);
+    if (dp.direct3) return dp.h2 ? 7 : 6;
+    if (dp.rows) return 4;
+    if (dp.shared) return dp.split3 ? 3 : 2;
+    return dp.direct ? 1 : 0;
+}
+
 // dy [N,Ho,Wo,K], x [N,H,W,C] -> dw [K,R,S,C]; dbias [K] (may be NULL); part: workspace of sqd_conv_wgrad_plan floats
 // (+ bias scratch appended when dbias is requested: max(ceil(M/1024), splits) * K floats)
 // ---------------------------------------------------------------------------------------------------
@@ -2772,7 +2818,7 @@ constexpr int FEWROWS_MAX = 32;
 
 static int conv_wgrad_impl(const float *dy, const float *x, float *dw, float *dbias, float *part, int N, int H, int W, int C,
                            int K, int R, int S, int stride, int pad, int Ho, int Wo, void *stream, bool reduce_dw, int *splits_out,
-                           OpScale sc = OpScale{nullptr, nullptr}) {
+                           OpScale sc = OpScale{nullptr, nullptr, nullptr}) {
     SQD_CHECK_ARG(dy && x && dw && part, "sqd_conv_wgrad: null pointer");
     ConvGeom g = {N, H, W, C, K, R, S, stride, pad, Ho, Wo};
     if (check_geom("sqd_conv_wgrad", g)) return SQD_EINVAL;
@@ -2912,7 +2958,7 @@ extern "C" int sqd_conv_wgrad(const float *dy, const float *x, float *dw, float 
 extern "C" int sqd_conv_wgrad_scaled(const float *dy, const float *x, float *dw, float *dbias, float *part, const float *amax_dy,
                                      const float *amax_x, int N, int H, int W, int C, int K, int R, int S, int stride, int pad, int Ho, int Wo,
                                      int *splits, void *stream) {
-    return conv_wgrad_impl(dy, x, dw, dbias, part, N, H, W, C, K, R, S, stride, pad, Ho, Wo, stream, splits == nullptr, splits, OpScale{amax_dy, amax_x});
+    return conv_wgrad_impl(dy, x, dw, dbias, part, N, H, W, C, K, R, S, stride, pad, Ho, Wo, stream, splits == nullptr, splits, OpScale{amax_dy, amax_x, nullptr});
 }
 
 // The same without the final sum over the pixel splits: part[0 .. *splits)[K*R*S*C] holds the partial filter gradients, dw is NOT

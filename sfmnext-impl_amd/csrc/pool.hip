@@ -141,7 +141,9 @@ __global__ __launch_bounds__(256) void s2d_kernel(const float *__restrict__ x, f
 //   wave's stores were 16 bytes out of every Cp x 4 — 40 us per call for 41 MB at config B.)
 template <int QMAX>                                      // Cp / 4 <= QMAX float4 per pixel
 __global__ __launch_bounds__(256) void s2d_planar_kernel(const float *__restrict__ x0, const float *__restrict__ x1, float *__restrict__ y,
-                                                         int N, int H, int W, int C0, int C1, int Cp, long long y_stride, float sub, float inv_div) {
+                                                         int N, int H, int W, int C0, int C1, int Cp, long long y_stride, float sub, float inv_div,
+                                                         unsigned *__restrict__ amax_y) {
+    unsigned am = 0u;                                    // max |y| over this thread's values (amax_y == NULL: not recorded)
     const int H2 = H / 2, W2 = W / 2, Q = Cp / 4, C = C0 + C1;
     const size_t per = (size_t)H2 * W2, total = (size_t)N * per;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(256) void s2d_planar_kernel(const float *__restrict
                 const float2 a = *reinterpret_cast<const float2 *>(pl + o);
                 const float2 b = *reinterpret_cast<const float2 *>(pl + o + W);
                 v[c] = make_float4((a.x - sub) * inv_div, (a.y - sub) * inv_div, (b.x - sub) * inv_div, (b.y - sub) * inv_div);
+                am = max(max(am, abs_bits(v[c].x)), max(abs_bits(v[c].y), max(abs_bits(v[c].z), abs_bits(v[c].w))));
             }
         }
         float4 *dst = reinterpret_cast<float4 *>(y + (size_t)n * y_stride) + ((size_t)h2 * W2 + w2) * Q;
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(256) void s2d_planar_kernel(const float *__restrict
         for (int c = 0; c < QMAX; ++c)
             if (c < Q) dst[c] = v[c];
     }
+    amax_commit(am, amax_y);
 }
 
 // filter regrouping of the space-to-depth stems and its adjoint:
@@ -200,6 +204,11 @@ extern "C" int sqd_space_to_depth2(const float *x, float *y, int N, int H, int W
 // (reference trainer.py:319-326); y_stride lets the pairs of one sample interleave along the batch
 extern "C" int sqd_space_to_depth2_planar(const float *x0, const float *x1, float *y, int N, int H, int W, int C0, int C1, int Cp,
                                           int64_t y_stride, float sub, float div, void *stream) {
+    return sqd_space_to_depth2_planar_amax(x0, x1, y, N, H, W, C0, C1, Cp, y_stride, sub, div, nullptr, stream);
+}
+// ... and amax_y (may be NULL; cleared by the caller — once for all the launches that fill one batch): the bit pattern of max |y| (sqd.h 10b)
+extern "C" int sqd_space_to_depth2_planar_amax(const float *x0, const float *x1, float *y, int N, int H, int W, int C0, int C1, int Cp,
+                                               int64_t y_stride, float sub, float div, float *amax_y, void *stream) {
     SQD_CHECK_ARG(x0 && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C0 > 0 && C1 >= 0 && (x1 || C1 == 0) &&
                       Cp >= 4 * (C0 + C1) && Cp % 4 == 0 && div != 0.f && y_stride >= (int64_t)(H / 2) * (W / 2) * Cp && y_stride % 4 == 0,
                   "sqd_space_to_depth2_planar: bad arguments (H=%d W=%d C0=%d C1=%d Cp=%d)", H, W, C0, C1, Cp);
@@ -208,11 +217,11 @@ extern "C" int sqd_space_to_depth2_planar(const float *x0, const float *x1, floa
     SQD_CHECK_ARG(Cp <= 64, "sqd_space_to_depth2_planar: Cp=%d (at most 64: frames of up to 16 channels)", Cp);
     const dim3 grid(grid_for((size_t)N * (H / 2) * (W / 2)));
     if (Cp <= 16)
-        hipLaunchKernelGGL(s2d_planar_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x0, x1, y, N, H, W, C0, C1, Cp, (long long)y_stride, sub, 1.0f / div);
+        hipLaunchKernelGGL(s2d_planar_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, x0, x1, y, N, H, W, C0, C1, Cp, (long long)y_stride, sub, 1.0f / div, (unsigned *)amax_y);
     else if (Cp <= 32)
-        hipLaunchKernelGGL(s2d_planar_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x0, x1, y, N, H, W, C0, C1, Cp, (long long)y_stride, sub, 1.0f / div);
+        hipLaunchKernelGGL(s2d_planar_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, x0, x1, y, N, H, W, C0, C1, Cp, (long long)y_stride, sub, 1.0f / div, (unsigned *)amax_y);
     else
-        hipLaunchKernelGGL(s2d_planar_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x0, x1, y, N, H, W, C0, C1, Cp, (long long)y_stride, sub, 1.0f / div);
+        hipLaunchKernelGGL(s2d_planar_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, x0, x1, y, N, H, W, C0, C1, Cp, (long long)y_stride, sub, 1.0f / div, (unsigned *)amax_y);
     SQD_CHECK_LAUNCH("sqd_space_to_depth2_planar");
     return SQD_OK;
 }

@@ -92,14 +92,37 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
 // bit pattern of |x|: unsigned order == order of the magnitudes (NaN patterns sort above everything: a NaN poisons the scale like it
 // would poison an fp32 product)
 __device__ __forceinline__ unsigned abs_bits(float x) { return __float_as_uint(x) & 0x7fffffffu; }
-// wave-wide max of the per-lane candidates, then ONE device-scope atomic per wave — and only when it would raise the scalar (the first
-// waves of a launch establish the maximum; the plain pre-check may read a stale smaller value, which costs an atomic, never a miss).
-// amax == NULL: nothing recorded.  The scalar must have been cleared on the stream before the launch.
-__device__ __forceinline__ void amax_commit(unsigned m, unsigned *__restrict__ amax) {
+// A max |x| RECORD is SQD_AMAX_WAYS words, one per 64-byte line (SQD_AMAX_RECORD_FLOATS floats = 4 KB): device-scope atomics serialise per
+// cache line at ~8 ns each (tools/ubench_atomic_max.hip: 4096 workgroups ending with one atomicMax on one word — or on 16 words of one
+// line — turn a 23 us element-wise pass into 55 us; on 16 words in 16 lines into 23.5 us, on 64 into 23.1; a pre-check load costs more than
+// it saves; in the training step 16 ways still cost the BatchNorm passes 2 us each, profiles/r05f).  A workgroup combines its waves
+// through LDS and issues ONE atomic to way (blockIdx mod 64); the reader takes the max over the ways (amax_record_bits: scalar loads).  EVERY thread of the workgroup must call amax_commit (it contains a barrier); amax == NULL:
+// nothing recorded (uniform: no barrier either).  The record must have been cleared on the stream before the launch.  `which` (0 / 1): a
+// kernel that records two maxima back to back gives them different staging rows (no barrier between the first one's read and the second
+// one's write).
+constexpr int AMAX_WAYS = SQD_AMAX_WAYS, AMAX_WAY_STRIDE = SQD_AMAX_RECORD_FLOATS / SQD_AMAX_WAYS;      // words
+__device__ __forceinline__ void amax_commit(unsigned m, unsigned *__restrict__ amax, int which = 0) {
     if (!amax) return;
+    __shared__ unsigned amax_stage[2][16];
+    unsigned *amax_wave_max = amax_stage[which];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
-    if ((threadIdx.x & 63) == 0 && m > __builtin_nontemporal_load(amax)) atomicMax(amax, m);
+    const int nw = (int)((blockDim.x * blockDim.y * blockDim.z + 63u) >> 6);
+    const int tid = (int)(threadIdx.x + blockDim.x * (threadIdx.y + blockDim.y * threadIdx.z));
+    if (nw > 1) {
+        if ((tid & 63) == 0) amax_wave_max[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0)
+            for (int w = 1; w < nw; ++w) m = max(m, amax_wave_max[w]);
+    }
+    if (tid == 0 && m != 0u) atomicMax(amax + ((blockIdx.x + 5u * blockIdx.y + 3u * blockIdx.z) & (AMAX_WAYS - 1)) * AMAX_WAY_STRIDE, m);
+}
+// the maximum a record holds (wave-uniform pointer: scalar loads)
+__device__ __forceinline__ unsigned amax_record_bits(const float *__restrict__ rec) {
+    unsigned m = 0u;
+#pragma unroll
+    for (int e = 0; e < AMAX_WAYS; ++e) m = max(m, __float_as_uint(rec[e * AMAX_WAY_STRIDE]));
+    return m;
 }
 
 // reflection index of ReflectionPad2d (pad < n), clamped for lanes far outside the image

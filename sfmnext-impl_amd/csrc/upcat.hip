@@ -27,7 +27,8 @@ __device__ __forceinline__ Tap tap_ac(int dst, float scale, int in_size) {
 
 __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float *__restrict__ x, const float *__restrict__ skip,
                                                         float *__restrict__ out, int N, int Hi, int Wi, int Cx, int Ho, int Wo,
-                                                        int Cs, float sy, float sx) {
+                                                        int Cs, float sy, float sx, unsigned *__restrict__ amax_out) {
+    unsigned am = 0u;                                       // max |out| over this thread's elements (amax_out == NULL: not recorded)
     // 32-bit index arithmetic (the host checks that every tensor has fewer than 2^31 float4 groups): the six 64-bit
     // divisions per element of the size_t version were most of this kernel's instructions
     const unsigned Ct = Cx + Cs, Vt = Ct / 4, Vx = Cx / 4;
@@ -36,7 +37,9 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float *__restrict_
         const unsigned cv = i % Vt;
         const unsigned pix = i / Vt;
         if (cv >= Vx) {
-            reinterpret_cast<float4 *>(out)[i] = reinterpret_cast<const float4 *>(skip)[pix * (Cs / 4) + (cv - Vx)];
+            const float4 v = reinterpret_cast<const float4 *>(skip)[pix * (Cs / 4) + (cv - Vx)];
+            reinterpret_cast<float4 *>(out)[i] = v;
+            am = max(max(am, abs_bits(v.x)), max(abs_bits(v.y), max(abs_bits(v.z), abs_bits(v.w))));
             continue;
         }
         const int xo = (int)(pix % (unsigned)Wo);
@@ -52,7 +55,9 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float *__restrict_
         o.z = ty.l0 * (tx.l0 * v00.z + tx.l1 * v01.z) + ty.l1 * (tx.l0 * v10.z + tx.l1 * v11.z);
         o.w = ty.l0 * (tx.l0 * v00.w + tx.l1 * v01.w) + ty.l1 * (tx.l0 * v10.w + tx.l1 * v11.w);
         reinterpret_cast<float4 *>(out)[i] = o;
+        am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
     }
+    amax_commit(am, amax_out);
 }
 
 // adjoint: first N*Hi*Wi*Cx/4 work items gather g_x, the remaining N*Ho*Wo*Cs/4 copy g_skip
@@ -102,6 +107,12 @@ int grid_for(size_t total) {
 
 extern "C" int sqd_upcat_fwd(const float *x, const float *skip, float *out, int N, int Hi, int Wi, int Cx, int Ho, int Wo,
                              int Cs, void *stream) {
+    return sqd_upcat_fwd_amax(x, skip, out, N, Hi, Wi, Cx, Ho, Wo, Cs, nullptr, stream);
+}
+// ... and amax_out (may be NULL; cleared by the caller): the bit pattern of max |out|, for the convolution that reads `out` on two-term
+// fp16 operands (sqd.h section 10b)
+extern "C" int sqd_upcat_fwd_amax(const float *x, const float *skip, float *out, int N, int Hi, int Wi, int Cx, int Ho, int Wo,
+                                  int Cs, float *amax_out, void *stream) {
     SQD_CHECK_ARG(x && skip && out, "sqd_upcat_fwd: null pointer");
     SQD_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cx % 4 == 0 && Cs % 4 == 0 && Cx > 0 && Cs > 0,
                   "sqd_upcat_fwd: bad shape (channels must be multiples of 4)");
@@ -109,7 +120,7 @@ extern "C" int sqd_upcat_fwd(const float *x, const float *skip, float *out, int 
     const float sy = Ho > 1 ? (float)(Hi - 1) / (float)(Ho - 1) : 0.f, sx = Wo > 1 ? (float)(Wi - 1) / (float)(Wo - 1) : 0.f;
     (void)hipGetLastError();
     hipLaunchKernelGGL(upcat_fwd_kernel, dim3(grid_for((size_t)N * Ho * Wo * (Cx + Cs) / 4)), dim3(256), 0, (hipStream_t)stream, x,
-                       skip, out, N, Hi, Wi, Cx, Ho, Wo, Cs, sy, sx);
+                       skip, out, N, Hi, Wi, Cx, Ho, Wo, Cs, sy, sx, (unsigned *)amax_out);
     SQD_CHECK_LAUNCH("sqd_upcat_fwd");
     return SQD_OK;
 }

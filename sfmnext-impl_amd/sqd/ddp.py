@@ -255,6 +255,16 @@ class GradBucketReducer:
         if self.buckets is not None:
             for bi in range(len(self.buckets)):
                 self._pending[bi] = len(self.buckets[bi])
+        self._forget_deferred()
+
+    @staticmethod
+    def _forget_deferred():
+        """the filters whose gradient the previous backward pass handed over directly: a pass that raised after Conv2d.backward had
+        added its filters, or a loop that drives this reducer without nnkernels.begin_step(), would otherwise leave entries behind that
+        make a later, genuinely accumulated gradient of the same filter go uncounted (the bucket would never complete)"""
+        from . import nnkernels
+        nnkernels.DEFERRED_FILTERS.clear()
+        nnkernels.drop_pending_reduce()
 
     def _on_grad(self, p, announced=False):
         if not self.hooks_enabled:
@@ -306,6 +316,7 @@ class GradBucketReducer:
                 p.grad = v
             self._pending[bi] = len(plist)
         self._inflight = False
+        self._forget_deferred()
 
     def bucket_bytes_list(self):
         return [int(f.numel() * f.element_size()) for f in getattr(self, "flat", [])]
@@ -335,3 +346,11 @@ class GradBucketReducer:
             self._build()
             return
         self._join()
+        # every bucket either completed (and was exchanged) or saw no gradient at all this pass: anything in between means an arrival was
+        # lost (a stale DEFERRED_FILTERS entry, a hook that did not fire) and the ranks would silently diverge
+        if self.hooks_enabled:
+            stuck = [bi for bi, plist in enumerate(self.buckets) if 0 < self._pending[bi] < len(plist)]
+            if stuck:
+                raise RuntimeError("sqd.ddp: gradient bucket(s) %s received only part of their gradients in this backward pass "
+                                   "(%s of %s arrivals missing): no all-reduce ran for them" %
+                                   (stuck, [self._pending[bi] for bi in stuck], [len(self.buckets[bi]) for bi in stuck]))

@@ -217,10 +217,16 @@ _SIGNATURES = {
     "sqd_conv_wgrad_set_plan": (_I, [_I] * 9),
     "sqd_conv_wgrad": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [_P]),
     "sqd_conv_wgrad_partials": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [ctypes.POINTER(ctypes.c_int), _P]),
+    "sqd_bn_train_fwd_amax": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _I, _P, _P]),
+    "sqd_bn_train_bwd_amax": (_I, [_P] * 13 + [_I, _I, _I, _I, _P, _P, ctypes.c_int64, _I, _P, _P, _P]),
+    "sqd_upcat_fwd_amax": (_I, [_P, _P, _P] + [_I] * 7 + [_P, _P]),
+    "sqd_space_to_depth2_planar_amax": (_I, [_P, _P, _P] + [_I] * 6 + [ctypes.c_int64, ctypes.c_float, ctypes.c_float, _P, _P]),
+    "sqd_conv_wgrad_effective_impl": (_I, [_I] * 11),
     "sqd_amax": (_I, [_P, ctypes.c_int64, _P, _P]),
     "sqd_amax_multi": (_I, [_P, _P, _I, _I, _P, _P]),
-    "sqd_conv_fwd_scaled": (_I, [_P] * 8 + [_I] * 12 + [_P]),
-    "sqd_conv_dgrad_scaled": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P] + [_I] * 11 + [_P]),
+    "sqd_conv_fwd_scaled": (_I, [_P] * 9 + [_I] * 12 + [_P]),
+    "sqd_conv_dgrad_scaled": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P] + [_I] * 11 + [_P]),
+    "sqd_act_bwd_amax": (_I, [_P, _P, _P, ctypes.c_int64, _I, _P, _P]),
     "sqd_conv_wgrad_scaled": (_I, [_P] * 7 + [_I] * 11 + [ctypes.POINTER(ctypes.c_int), _P]),
     "sqd_split_reduce": (_I, [_P, _P, ctypes.c_int64, _I, _P]),
     "sqd_bins_supported": (_I, [_I, _I]),

@@ -33,6 +33,158 @@ def bn_supported(C):
     return C % 4 == 0 and C >= 4
 
 
+# ---------------------------------------------------------------------------------------------------
+# Operand scales of the two-term fp16 convolution plans (csrc/conv.hip "f16x2", include/sqd.h section 10b).  Such a plan needs max |.| of
+# both operand tensors as device scalars.  Producers record it on the way (the `amax` outputs of the BatchNorm / convolution-epilogue /
+# up-sampling / frame-staging kernels): a tensor carries `_sqd_amax = (slot, epoch)`, slot = one 1 KB record of a pool that begin_step() clears
+# at the start of every step (inside the captured graph).  A tensor without a valid tag (a gradient summed by autograd, the output of an
+# operator that does not record it) gets a standalone pass (sqd_amax) — counted per call site in AMAX_STATS, so that a missing producer
+# shows up as a number instead of as a slow step.  Filters: one persistent table, refreshed by ONE multi-tensor launch per step
+# (sqd_amax_multi) — they change once per step, in the optimiser.
+# ---------------------------------------------------------------------------------------------------
+AMAX_ON = True                 # producers record max |output| (nnops.configure: off under --sqd_no_f16x2 / --sqd_bf16)
+AMAX_STATS = {"fused": 0, "standalone": 0, "sites": {}}
+AMAX_REC = 1024                # SQD_AMAX_RECORD_FLOATS: a record is 64 words in 64 cache lines (the recording kernels spread their atomics over them)
+_AM = {"buf": None, "n": 0, "epoch": 0, "size": 1024}
+_WAM = {"buf": None, "index": {}, "refs": [], "dirty": True, "recs": None, "chunks": None, "nchunks": 0, "fresh": set()}
+
+
+def amax_enable(on):
+    global AMAX_ON
+    AMAX_ON = bool(on)
+
+
+def _amax_new(device):
+    """a cleared record of the per-step pool (AMAX_REC floats)"""
+    if _AM["buf"] is None or _AM["buf"].device != device:
+        _AM["buf"] = torch.zeros(_AM["size"] * AMAX_REC, device=device, dtype=torch.float32)
+        _AM["n"] = 0
+        _AM["epoch"] += 1
+    if _AM["n"] >= _AM["size"]:
+        # a loop that never calls begin_step (evaluation): start over — stream-ordered behind every consumer of the old values
+        _AM["buf"].zero_()
+        _AM["n"] = 0
+        _AM["epoch"] += 1
+    i = _AM["n"]
+    _AM["n"] = i + 1
+    return _AM["buf"][i * AMAX_REC:(i + 1) * AMAX_REC]
+
+
+def amax_value(rec):
+    """the number a record holds (host read-back: tests and tools)"""
+    return float(rec.view(-1, 16)[:, 0].max())
+
+
+def _amax_tag(t, slot):
+    if t is not None and slot is not None:
+        t._sqd_amax = (slot, _AM["epoch"])
+    return t
+
+
+def _amax_get(t):
+    tag = getattr(t, "_sqd_amax", None)
+    return tag[0] if tag is not None and tag[1] == _AM["epoch"] else None
+
+
+def _amax_out(device):
+    """slot for a producer's `amax` output (None when recording is off)"""
+    if not AMAX_ON:
+        return None
+    AMAX_STATS["fused"] += 1
+    return _amax_new(device)
+
+
+def amax_of(t, site):
+    """device scalar holding the bits of max |t| — the tensor's tag, or a standalone pass"""
+    a = _amax_get(t)
+    if a is None:
+        a = _amax_new(t.device)
+        _l.check(_l.lib().sqd_amax(_ptr(t), t.numel(), _ptr(a), _stream()), "amax")
+        AMAX_STATS["standalone"] += 1
+        AMAX_STATS["sites"][site] = AMAX_STATS["sites"].get(site, 0) + 1
+        _amax_tag(t, a)
+    return a
+
+
+def _wam_slot(w):
+    """slot of a leaf filter in the persistent table (registered on first use)"""
+    import weakref
+    dev = w.device
+    if _WAM["buf"] is None or _WAM["buf"].device != dev:
+        _WAM.update(buf=torch.zeros(1024 * AMAX_REC, device=dev, dtype=torch.float32), index={}, refs=[], dirty=True, fresh=set())
+    key = w.data_ptr()
+    ent = _WAM["index"].get(key)
+    if ent is not None and (ent[1]() is None or ent[2] != w.numel()):
+        ent = None                                   # another tensor lives at that address now
+    if ent is None:
+        live = {k: e for k, e in _WAM["index"].items() if e[1]() is not None and k != key}
+        used = {e[0] for e in live.values()}
+        idx = next(i for i in range(1024) if i not in used)
+        ent = (idx, weakref.ref(w), w.numel(), [-1])
+        live[key] = ent
+        _WAM["index"] = live
+        _WAM["dirty"] = True
+    return ent
+
+
+def _weight_source(w):
+    """the leaf parameter a filter tensor was rearranged from (`_sqd_w_src`: regrouped stem filters, Linear weights viewed as 1x1 filters —
+    the same values, so the same max |.|), the tensor itself when it is a leaf, else None"""
+    src = getattr(w, "_sqd_w_src", None)
+    if src is not None:
+        return src
+    return w if w.is_leaf else None
+
+
+def amax_of_weight(w):
+    """filters: the persistent table for a leaf parameter (or the leaf a rearranged filter came from), a standalone pass otherwise"""
+    src = _weight_source(w)
+    if src is None:
+        return amax_of(w, "filter (not a leaf)")
+    w = src
+    ent = _wam_slot(w)
+    slot = _WAM["buf"][ent[0] * AMAX_REC:(ent[0] + 1) * AMAX_REC]
+    # valid when this step's multi-tensor launch covered it and nothing wrote the parameter through torch since
+    if ent[3][0] != w._version or ent[0] not in _WAM["fresh"]:
+        _l.check(_l.lib().sqd_amax(_ptr(w), w.numel(), _ptr(slot), _stream()), "amax (filter)")
+        ent[3][0] = w._version
+        _WAM["fresh"].add(ent[0])
+        AMAX_STATS["standalone"] += 1
+        AMAX_STATS["sites"]["filter (first use)"] = AMAX_STATS["sites"].get("filter (first use)", 0) + 1
+    return slot
+
+
+def weights_changed():
+    """an optimiser wrote the parameters through raw pointers: the filter table is stale until the next begin_step()"""
+    _WAM["fresh"] = set()
+
+
+def _wam_refresh():
+    """one launch: max |w| of every registered filter (begin_step)"""
+    live = [(k, e) for k, e in _WAM["index"].items() if e[1]() is not None]
+    if not live:
+        return
+    if _WAM["dirty"] or _WAM["recs"] is None:
+        chunk = _l.lib().sqd_adam_chunk_elems()
+        live.sort(key=lambda ke: ke[1][0])
+        n_slots = max(e[0] for _, e in live) + 1
+        recs = [[0, 0, 0, 0] for _ in range(n_slots)]            # table index == slot index (unused slots: empty tensors)
+        chunks = []
+        for k, e in live:
+            recs[e[0]] = [k, 0, 0, e[2]]
+            chunks += [[e[0], c] for c in range((e[2] + chunk - 1) // chunk)]
+        dev = _WAM["buf"].device
+        _WAM.update(recs=torch.tensor(recs, dtype=torch.int64).to(dev), chunks=torch.tensor(chunks, dtype=torch.int32).to(dev),
+                    nchunks=len(chunks), nslots=n_slots, index=dict(live), dirty=False)
+    _l.check(_l.lib().sqd_amax_multi(_ptr(_WAM["recs"]), _ptr(_WAM["chunks"]), _WAM["nchunks"], _WAM["nslots"], _ptr(_WAM["buf"]), _stream()),
+             "amax_multi")
+    _WAM["fresh"] = {e[0] for _, e in live}
+    for _, e in live:
+        w = e[1]()
+        if w is not None:
+            e[3][0] = w._version
+
+
 class BatchNormAct(torch.autograd.Function):
     """y = act(BatchNorm2d(x) [+ residual]).  Training: batch statistics + running-stat update
     (in place on the BatchNorm2d buffers); eval: running statistics."""
@@ -60,9 +212,11 @@ class BatchNormAct(torch.autograd.Function):
             mask = torch.empty(M * C // 4, device=x.device, dtype=torch.uint8) if code in (1, 2) else None    # (swish: recomputed from x)
             # pool_part [B, chunks, C] (batch_norm_act(pool=True)): the element-wise pass also takes the per-image channel sums of y for the
             # squeeze-and-excite gate that follows
-            _l.check(L.sqd_bn_train_fwd_pool(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
+            ay = _amax_out(x.device) if pool_part is None else None
+            _l.check(L.sqd_bn_train_fwd_amax(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                              _ptr(y), _ptr(mask), _ptr(mean), _ptr(rstd), _ptr(part), pre_rows, M, C, float(eps),
-                                             float(momentum), code, _ptr(pool_part), N, _stream()), "bn_train_fwd")
+                                             float(momentum), code, _ptr(pool_part), N, _ptr(ay), _stream()), "bn_train_fwd")
+            _amax_tag(y, ay)
             ctx.save_for_backward(x, mask, gamma, mean, rstd, beta if code == 3 else None)
             ctx.has_res, ctx.code = residual is not None, code
             # what the convolution that consumes y needs to deliver this node's backward statistics from its data-gradient epilogue
@@ -101,9 +255,13 @@ class BatchNormAct(torch.autograd.Function):
         # workgroups of this node's finalize launch
         pend = _take_pending_reduce()
         rp, ro, rn, rs = pend[:4] if pend is not None else (None, None, 0, 0)
-        _l.check(L.sqd_bn_train_bwd_pre_red(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
-                                            _ptr(dgamma), _ptr(dbeta), _ptr(part), pre_rows, M, C, ctx.code, _ptr(rp), _ptr(ro), rn, rs, _stream()),
-                 "bn_train_bwd")
+        adx = _amax_out(x.device)
+        adr = _amax_out(x.device) if dres is not None else None
+        _l.check(L.sqd_bn_train_bwd_amax(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
+                                         _ptr(dgamma), _ptr(dbeta), _ptr(part), pre_rows, M, C, ctx.code, _ptr(rp), _ptr(ro), rn, rs,
+                                         _ptr(adx), _ptr(adr), _stream()), "bn_train_bwd")
+        _amax_tag(dx, adx)
+        _amax_tag(dres, adr)
         if pend is not None:
             _deferred_grad_done(pend[5])
         return dx, dgamma, dbeta, None, None, dres, None, None, None, None, None, None, None, None
@@ -126,8 +284,10 @@ class MaxPool3x3s2(torch.autograd.Function):
         _l.check(_l.lib().sqd_maxpool3x3s2_fwd(_ptr(x), _ptr(y), _ptr(idx), N, H, W, C, _stream()), "maxpool_fwd")
         ctx.save_for_backward(idx)
         ctx.dims = (N, C, H, W)
+        ax = _amax_get(x)
+        _amax_tag(y, ax)                         # the outputs are a subset of the inputs: max |x| bounds max |y|
         if skip:
-            return y, x.view_as(x)
+            return y, _amax_tag(x.view_as(x), ax)
         return y
 
     @staticmethod
@@ -154,9 +314,10 @@ class UpsampleConcat(torch.autograd.Function):
         N, Cx, Hi, Wi = x.shape
         _, Cs, Ho, Wo = skip.shape
         out = torch.empty((N, Cx + Cs, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
-        _l.check(_l.lib().sqd_upcat_fwd(_ptr(x), _ptr(skip), _ptr(out), N, Hi, Wi, Cx, Ho, Wo, Cs, _stream()), "upcat_fwd")
+        ao = _amax_out(x.device)
+        _l.check(_l.lib().sqd_upcat_fwd_amax(_ptr(x), _ptr(skip), _ptr(out), N, Hi, Wi, Cx, Ho, Wo, Cs, _ptr(ao), _stream()), "upcat_fwd")
         ctx.dims = (N, Hi, Wi, Cx, Ho, Wo, Cs)
-        return out
+        return _amax_tag(out, ao)
 
     @staticmethod
     def backward(ctx, g_out):
@@ -221,6 +382,7 @@ TUNE_SPACE = {
     "wgrad_rows": True,        # impl 4: the row-window weight gradient of the few-channel / high-resolution layers
     "stats_penalty": False,    # (history: split-K forward plans used to force a BatchNorm statistics pass; their sum takes the partials now)
     "wgrad_transposed": True,  # impl 5: the wide 1x1 layers' weight gradient as a forward GEMM on transposed operands
+    "f16x2": True,             # bk + 4096 / impl 7: two-term fp16 operands of the power-of-two scaled tensors (round 5) next to the three-term bf16 plans
     "rounds": 1,               # measurements (of 3 launches each) per candidate plan; the fastest counts
     "log": False,
 }
@@ -241,7 +403,7 @@ def _time_launch(launch, arg):
     return best
 
 
-def _tune_conv(mode, geom, launch):
+def _tune_conv(mode, geom, launch, scaled=False):
     """Time every tile / split-K plan the library accepts for this geometry (4 launches each, HIP events on the current
     stream) and register the fastest (sqd_conv_set_plan).  Runs once per geometry, outside graph capture; geometries with a
     pinned plan (load_plans) are not timed."""
@@ -265,6 +427,10 @@ def _tune_conv(mode, geom, launch):
     else:
         bks = (16, 32, 528, 544, 1056) + ((3104,) if TUNE_SPACE["input_patch"] else ()) + ((576,) if TUNE_SPACE["bk64"] else ()) + \
             ((272, 288) if TUNE_SPACE["eight_wave"] else ()) + ((1312,) + ((3360,) if TUNE_SPACE["input_patch"] else ()) if TUNE_SPACE["eight_wave_split3"] else ())
+        if scaled and TUNE_SPACE["f16x2"]:
+            # + 4096: the same tiles on two-term fp16 operands (the launch carries the operands' max |.|): half the matrix and conversion
+            # instructions of the three-term plans (profiles/r05a_f16x2_layers.txt: forward -23 %, data gradient -21 %)
+            bks += tuple(b + 4096 for b in bks if b & 1024)
     for bm, bn, z, bk in ((bm, bn, z, bk) for bm, bn in _TUNE_TILES + ((64, 32),) for bk in bks for z in _TUNE_Z):
         if L.sqd_conv_set_plan(mode, *geom, bm, bn, z, bk) != 0:
             continue
@@ -293,7 +459,7 @@ def _register_conv_plan(mode, geom, plan):
     CHOSEN_PLANS[("dgrad" if mode else "fwd",) + tuple(geom)] = tuple(plan)
 
 
-def _tune_wgrad(geom, has_bias, launch, launch_t=None):
+def _tune_wgrad(geom, has_bias, launch, launch_t=None, scaled=False):
     """Same for the weight gradient: direct-operand vs LDS-tiled kernel, 1/8x .. 4x the model's pixel splits; launch_t (wide 1x1 layers):
     the forward GEMM on transposed operands."""
     N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
@@ -310,6 +476,10 @@ def _tune_wgrad(geom, has_bias, launch, launch_t=None):
     def trial(impl, sp):
         nonlocal best
         if L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, R, S, impl, sp) != 0:
+            return False
+        if L.sqd_conv_wgrad_effective_impl(*geom) != ((impl & 15) if impl & 15 else 0) and (impl & 15) in (4, 6, 7):
+            # the table keys on the output geometry: THIS convolution (strided / padded, odd Wo) would run the fp32 direct kernel under
+            # that entry — timing it under the candidate's name would rank and report a kernel that did not run
             return False
         _PLAN_CACHE.pop(key, None)
         pf, splits = _wgrad_part_floats(geom)
@@ -352,13 +522,14 @@ def _tune_wgrad(geom, has_bias, launch, launch_t=None):
             if K % tk or C % tc or (per_cu == 1 and v < 6 and not TUNE_SPACE["wgrad_direct3_wide"]) or (v >= 6 and not TUNE_SPACE["wgrad_direct3_8w"]):
                 continue
             tiles = (K // tk) * (C // tc) * R * S
-            tried = set()
-            for target in (128, 192, 256, 384, 512, 768, 1024):
-                sp = max(1, (target * per_cu) // tiles)
-                if sp not in tried:
-                    tried.add(sp)
-                    if not trial(6 | (v << 4), sp):
-                        break
+            for impl in (6, 7) if scaled and TUNE_SPACE["f16x2"] else (6,):          # 7: the same tiles on two-term fp16 operands
+                tried = set()
+                for target in (128, 192, 256, 384, 512, 768, 1024):
+                    sp = max(1, (target * per_cu) // tiles)
+                    if sp not in tried:
+                        tried.add(sp)
+                        if not trial(impl | (v << 4), sp):
+                            break
     # row-window kernel (impl 4): few channels, stride 1 — the whole filter bank in one workgroup's accumulators, `sp` workgroups
     # (the library refuses the shapes it is not built for)
     if stride == 1 and R == S and TUNE_SPACE["wgrad_rows"]:
@@ -406,7 +577,7 @@ def wgrad_transposed_applies(geom):
             and C % 4 == 0 and K % 4 == 0 and _l.lib().sqd_conv_precision() == 0)
 
 
-def _wgrad_transposed(dy, x, dw, db, geom):
+def _wgrad_transposed(dy, x, dw, db, geom, ady=None, ax=None):
     """dW [K][C] = sum_m dY[m][k] X[m][c] reduces over the slow axis of both operands — the layout the fp32 weight-gradient kernels are
     built around and the reason they end at ~95 TFLOP/s.  Transposed (two HBM-rate passes, sqd_transpose2d), it is the FORWARD problem
     "K pixels x M channels -> C filters": sqd_conv_fwd on its measured plan (three-term bf16 operands at ~175 TFLOP/s effective on the
@@ -420,10 +591,12 @@ def _wgrad_transposed(dy, x, dw, db, geom):
     _l.check(L.sqd_transpose2d(_ptr(dy), _ptr(dyT), M, K, _ptr(cs), _stream()), "transpose2d")
     _l.check(L.sqd_transpose2d(_ptr(x), _ptr(xT), M, C, None, _stream()), "transpose2d")
     gT = (1, 1, K, M, C, 1, 1, 1, 0, 1, K)           # N, H, W, "channels" = M, "filters" = C, 1x1 -> [1, 1, K] pixels x C
+    # (a transpose moves values, it does not change them: the operands' max |.| are those of dy and x)
+    run = lambda ws: L.sqd_conv_fwd_scaled(_ptr(dyT), _ptr(xT), None, _ptr(dw), _ptr(ws), None, _ptr(ady), _ptr(ax), None, *gT, 0, _stream())
     if TUNE_CONV:
-        _tune_conv(0, gT, lambda ws: L.sqd_conv_fwd(_ptr(dyT), _ptr(xT), None, _ptr(dw), _ptr(ws), None, *gT, 0, _stream()))
+        _tune_conv(0, gT, run, ady is not None and ax is not None)
     ws = _conv_ws(0, gT, dy.device)
-    _l.check(L.sqd_conv_fwd(_ptr(dyT), _ptr(xT), None, _ptr(dw), _ptr(ws), None, *gT, 0, _stream()), "conv_fwd (transposed weight gradient)")
+    _l.check(run(ws), "conv_fwd (transposed weight gradient)")
     if db is not None:
         _colsum_multi([(cs, db, 0)])
 
@@ -473,10 +646,11 @@ def plan_mix():
     for k, v in CHOSEN_PLANS.items():
         if k[0] == "wgrad":
             name = {0: "fp32 lds-tiled", 1: "fp32 direct", 2: "fp32 shared-operand", 3: "bf16x3 shared-operand", 4: "fp32 row-window", 5: "transposed forward-gemm (its own fwd plan)",
-                    6: "bf16x3 direct-operand"}[v[0] & 15]
+                    6: "bf16x3 direct-operand", 7: "f16x2 direct-operand"}[v[0] & 15]
         else:
             bk = v[3]
-            name = "bf16x3 input-patch" if bk & 2048 else "bf16x3 implicit-gemm" if bk & 1024 else "fp32 implicit-gemm"
+            arith = "f16x2" if bk & 4096 else "bf16x3"
+            name = arith + " input-patch" if bk & 2048 else arith + " implicit-gemm" if bk & 1024 else "fp32 implicit-gemm"
             if _l.lib().sqd_conv_precision() == 2:
                 name = "bf16 implicit-gemm"
         mix.setdefault(k[0], {})
@@ -777,6 +951,7 @@ def linear_native(x, lin, act=None):
     rows, K = x.shape[0], lin.out_features
     x4 = x.reshape(rows, lin.in_features, 1, 1)
     w4 = lin.weight.view(K, lin.in_features, 1, 1)
+    w4._sqd_w_src = lin.weight
     return Conv2d.apply(x4, w4, lin.bias, 1, 0, act, False, None, None).reshape(rows, K)
 
 
@@ -857,9 +1032,16 @@ _WEIGHT_USES = {}            # id(weight storage) -> forward uses in the current
 
 
 def begin_step():
-    """Training loops call this before every forward pass (the side-stream weight gradients need per-step use counts)."""
+    """Training loops call this before every forward pass (the side-stream weight gradients need per-step use counts; the operand
+    scales of the two-term fp16 plans live in a per-step pool, and the filters' are refreshed here)."""
     _WEIGHT_USES.clear()
     DEFERRED_FILTERS.clear()
+    if _AM["buf"] is not None:
+        _AM["buf"].zero_()                       # (a memset node of the captured step)
+        _AM["n"] = 0
+        _AM["epoch"] += 1
+    if AMAX_ON and _WAM["buf"] is not None:
+        _wam_refresh()
 
 
 def flush_wgrads():
@@ -888,19 +1070,43 @@ def join_wgrad_stream():
         torch.cuda.current_stream().wait_stream(WGRAD_STREAM)
 
 
+def _scaled_plan(kind, geom):
+    """does the registered plan of this geometry run on two-term fp16 operands (and so need the operands' max |.|)?"""
+    if kind == "wgrad":
+        N, H, W, C, K, R, S, stride, pad, Ho, Wo = geom
+        v = CHOSEN_PLANS.get(("wgrad", N, Ho, Wo, C, K, R, S))
+        return v is not None and (v[0] & 15) == 7
+    v = CHOSEN_PLANS.get((kind,) + tuple(geom))
+    return v is not None and bool(v[3] & 4096)
+
+
+def _scales_wanted(kind, geom, tune_key):
+    """operand scales are fetched when the plan needs them, or when the plans of this geometry are about to be timed (the two-term
+    plans are among the candidates).  Convolutions over a handful of rows (the Linear layers of the bins regressor) stay unscaled."""
+    if not AMAX_ON or _l.lib().sqd_conv_precision() != 0 or geom[0] * geom[9] * geom[10] < 256:
+        return False
+    if _scaled_plan(kind, geom):
+        return True
+    return TUNE_CONV and TUNE_SPACE["f16x2"] and tune_key not in _TUNED and not torch.cuda.is_current_stream_capturing()
+
+
 class Conv2d(torch.autograd.Function):
-    """nn.Conv2d (square stride / padding, dilation 1, groups 1) on the fp32 matrix cores, channels-last.
+    """nn.Conv2d (square stride / padding, dilation 1, groups 1) on the matrix cores, channels-last.
     forward(x [N,C,H,W], weight [K,C,R,S], bias [K] | None, stride, pad, act, skip) -> y [N,K,Ho,Wo]  (skip: -> (y, x'))
 
     With skip=True the node also returns its input as a second output x' (same storage).  A consumer that would have read
     x a second time (the residual branch, a down-sample convolution) reads x' instead; autograd then hands both
     gradients to this node, and the data gradient adds the second one in its epilogue (sqd_conv_dgrad's addend) instead
-    of ATen running a separate 3-pass add over the activation."""
+    of ATen running a separate 3-pass add over the activation.
+
+    Plans on two-term fp16 operands (sqd.h section 10b) take the operands' max |.| from the tensors' tags (amax_of); every launch
+    records max |output| for the next convolution of a chain."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, pad, act, skip=False, out_hw=None, stats=None):
         ctx.set_materialize_grads(False)                 # an unused output arrives as None in backward, not as a zero tensor
         _require(x, "Conv2d input")
+        x_in = x
         x, w = _cl(x), _cl(weight)
         N, C, H, W = x.shape
         K, _, R, S = w.shape
@@ -909,13 +1115,22 @@ class Conv2d(torch.autograd.Function):
             assert out_hw[0] <= Ho and out_hw[1] <= Wo
             Ho, Wo = out_hw
         y = torch.empty((N, K, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
+        geom = (N, H, W, C, K, R, S, stride, pad, Ho, Wo)
+        L = _l.lib()
+        ax, aw = _amax_get(x_in), None
+        if _scales_wanted("fwd", geom, (0,) + geom):
+            if ax is None:
+                ax = amax_of(x, "conv forward: input")
+            aw = amax_of_weight(weight)
+        ay = _amax_out(x.device)
+
+        def run(ws):
+            return L.sqd_conv_fwd_scaled(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws), _ptr(stats), _ptr(ax), _ptr(aw), _ptr(ay), N, H, W, C, K,
+                                         R, S, stride, pad, Ho, Wo, ACT[act], _stream())
         if TUNE_CONV:
-            _tune_conv(0, (N, H, W, C, K, R, S, stride, pad, Ho, Wo),
-                       lambda ws: _l.lib().sqd_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws), _ptr(stats), N, H, W, C, K, R, S,
-                                                        stride, pad, Ho, Wo, ACT[act], _stream()))
-        ws = _conv_ws(0, (N, H, W, C, K, R, S, stride, pad, Ho, Wo), x.device)
-        _l.check(_l.lib().sqd_conv_fwd(_ptr(x), _ptr(w), _ptr(bias), _ptr(y), _ptr(ws), _ptr(stats), N, H, W, C, K, R, S, stride, pad,
-                                       Ho, Wo, ACT[act], _stream()), "conv_fwd")
+            _tune_conv(0, geom, run, aw is not None)
+        _l.check(run(_conv_ws(0, geom, x.device)), "conv_fwd")
+        _amax_tag(y, ay)
         ctx.save_for_backward(x, w, y if act is not None else None)
         # The weight gradient may run on a side stream only when nothing reads it before the optimiser / bucket gather joins
         # that stream: the filter must be a leaf (a regrouped stem filter feeds StemRegroup.backward at once) and used once
@@ -923,11 +1138,13 @@ class Conv2d(torch.autograd.Function):
         ctx.wkey = weight.data_ptr() if weight.is_leaf else None
         if ctx.wkey is not None:
             _WEIGHT_USES[ctx.wkey] = _WEIGHT_USES.get(ctx.wkey, 0) + 1
-        ctx.geom = (N, H, W, C, K, R, S, stride, pad, Ho, Wo)
+        ctx.geom = geom
         ctx.has_bias, ctx.act = bias is not None, act
-        ctx.bn_src = getattr(x, "_sqd_bn_src", None)     # x is the output of a training-mode BatchNormAct: see backward
+        ctx.bn_src = getattr(x_in, "_sqd_bn_src", None)  # x is the output of a training-mode BatchNormAct: see backward
+        # what the backward pass may need of this step's scales (saved tensors come back as other Python objects: the tags would be lost)
+        ctx.am = (ax, aw, _weight_source(weight), _AM["epoch"])
         if skip:
-            return y, x.view_as(x)
+            return y, _amax_tag(x.view_as(x), ax)
         return y
 
     @staticmethod
@@ -936,22 +1153,50 @@ class Conv2d(torch.autograd.Function):
         N, H, W, C, K, R, S, stride, pad, Ho, Wo = ctx.geom
         if dy is None:                                   # only the pass-through output was used
             return g_skip, None, None, None, None, None, None, None, None
+        L = _l.lib()
+        dy_in = dy
         dy = _cl(dy)
+        if dy is not dy_in:
+            _amax_tag(dy, _amax_get(dy_in))
         g_skip = _cl(g_skip) if g_skip is not None else None
         if ctx.act is not None:                          # the epilogue's ReLU / LeakyReLU: dy * act'(y), one launch
             g = torch.empty_like(dy)
-            _l.check(_l.lib().sqd_act_bwd(_ptr(dy), _ptr(y), _ptr(g), dy.numel(), ACT[ctx.act], _stream()), "act_bwd")
-            dy = g
-        L = _l.lib()
+            ag = _amax_out(dy.device)
+            _l.check(L.sqd_act_bwd_amax(_ptr(dy), _ptr(y), _ptr(g), dy.numel(), ACT[ctx.act], _ptr(ag), _stream()), "act_bwd")
+            dy = _amax_tag(g, ag)
+        sx, sw, wt, epoch = ctx.am
+        if epoch != _AM["epoch"]:                        # (a backward pass of another step: the pool has been cleared since)
+            sx = sw = None
+        scales = {}
+
+        def a_dy():
+            if "dy" not in scales:
+                scales["dy"] = amax_of(dy, "conv backward: output gradient")
+            return scales["dy"]
+
+        def a_x():
+            if "x" not in scales:
+                scales["x"] = sx if sx is not None else amax_of(x, "conv backward: saved input")
+            return scales["x"]
+
+        def a_w():
+            if "w" not in scales:
+                scales["w"] = sw if sw is not None else amax_of_weight(wt) if wt is not None else amax_of(w, "conv backward: filter (not a leaf)")
+            return scales["w"]
         dx = dw = db = None
         if ctx.needs_input_grad[1]:
+            wkey = _wgrad_key(ctx.geom)
+            w_sc = _scales_wanted("wgrad", ctx.geom, wkey)
+            ady, axx = (a_dy(), a_x()) if w_sc else (None, None)
             if TUNE_CONV:
                 dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
                 db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
                 _tune_wgrad(ctx.geom, ctx.has_bias,
-                            lambda part: L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride,
-                                                          pad, Ho, Wo, _stream()),
-                            (lambda _: _wgrad_transposed(dy, x, dw, db, ctx.geom)) if wgrad_transposed_applies(ctx.geom) else None)
+                            lambda part: L.sqd_conv_wgrad_scaled(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), _ptr(ady), _ptr(axx), N, H, W, C, K,
+                                                                 R, S, stride, pad, Ho, Wo, None, _stream()),
+                            (lambda _: _wgrad_transposed(dy, x, dw, db, ctx.geom, ady, axx)) if wgrad_transposed_applies(ctx.geom) else None, w_sc)
+                if not w_sc and _scaled_plan("wgrad", ctx.geom):      # (cannot happen: a two-term plan is only timed with scales at hand)
+                    ady, axx = a_dy(), a_x()
             dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
             db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
             # (the plan table keys on the OUTPUT geometry: a strided or padded 1x1 that shares it with a stride-1 layer — or a plan file —
@@ -959,17 +1204,20 @@ class Conv2d(torch.autograd.Function):
             transposed = CHOSEN_PLANS.get(("wgrad", N, Ho, Wo, C, K, R, S), (0,))[0] == WGRAD_TRANSPOSED and wgrad_transposed_applies(ctx.geom)
             if transposed:
                 part = None
+                gT = (1, 1, K, N * Ho * Wo, C, 1, 1, 1, 0, 1, K)
+                if ady is None and _scales_wanted("fwd", gT, (0,) + gT):
+                    ady, axx = a_dy(), a_x()
 
-                def launch(dy=dy, x=x, dw=dw, db=db, geom=ctx.geom):
-                    _wgrad_transposed(dy, x, dw, db, geom)
+                def launch(dy=dy, x=x, dw=dw, db=db, geom=ctx.geom, ady=ady, axx=axx):
+                    _wgrad_transposed(dy, x, dw, db, geom, ady, axx)
             else:
                 pf, splits = _wgrad_part_floats(ctx.geom)
                 extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if ctx.has_bias else 0
                 part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
 
-                def launch(dy=dy, x=x, dw=dw, db=db, part=part):
-                    _l.check(L.sqd_conv_wgrad(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
-                                              _stream()), "conv_wgrad")
+                def launch(dy=dy, x=x, dw=dw, db=db, part=part, ady=ady, axx=axx):
+                    _l.check(L.sqd_conv_wgrad_scaled(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), _ptr(ady), _ptr(axx), N, H, W, C, K, R, S,
+                                                     stride, pad, Ho, Wo, None, _stream()), "conv_wgrad")
             if not transposed and DEFER_WGRAD_REDUCE and WGRAD_STREAM is None and ctx.wkey is not None and _WEIGHT_USES.get(ctx.wkey, 2) == 1 and \
                     ctx.bn_src is not None and w.grad is None and w.is_leaf and w.requires_grad and w.data_ptr() == ctx.wkey and \
                     not w._backward_hooks and (DEFERRED_GRAD_HOOK is not None or not getattr(w, "_post_accumulate_grad_hooks", None)):
@@ -980,8 +1228,8 @@ class Conv2d(torch.autograd.Function):
                 # channels-last copy would receive the gradient instead of the parameter; hooks would be skipped) — post-accumulate
                 # hooks only when their owner registered DEFERRED_GRAD_HOOK (the multi-rank reducer).
                 sp = ctypes.c_int(0)
-                _l.check(L.sqd_conv_wgrad_partials(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
-                                                   ctypes.byref(sp), _stream()), "conv_wgrad_partials")
+                _l.check(L.sqd_conv_wgrad_scaled(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), _ptr(ady), _ptr(axx), N, H, W, C, K, R, S, stride,
+                                                 pad, Ho, Wo, ctypes.byref(sp), _stream()), "conv_wgrad_partials")
                 w.grad = dw
                 DEFERRED_FILTERS.add(w.data_ptr())
                 _set_pending_reduce(part, dw, K * R * S * C, sp.value, w)
@@ -999,23 +1247,29 @@ class Conv2d(torch.autograd.Function):
                     flush_wgrads()
         if ctx.needs_input_grad[0]:
             dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
-            if TUNE_CONV:
-                _tune_conv(1, ctx.geom, lambda ws: L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(g_skip), _ptr(dx), _ptr(ws), N, H, W, C, K, R,
-                                                                    S, stride, pad, Ho, Wo, _stream()))
-            ws = _conv_ws(1, ctx.geom, dy.device)
+            d_sc = _scales_wanted("dgrad", ctx.geom, (1,) + tuple(ctx.geom))
+            ady, aww = (a_dy(), a_w()) if d_sc else (None, None)
+            adx = _amax_out(dy.device)
             src = ctx.bn_src
+
+            def run_d(ws, stats=None):
+                bn = src if stats is not None else {}
+                return L.sqd_conv_dgrad_scaled(_ptr(dy), _ptr(w), _ptr(g_skip), _ptr(dx), _ptr(ws), _ptr(bn.get("x")), _ptr(bn.get("mask")),
+                                               _ptr(bn.get("mean")), _ptr(bn.get("rstd")), bn.get("code", 0), _ptr(stats), _ptr(ady), _ptr(aww), _ptr(adx),
+                                               N, H, W, C, K, R, S, stride, pad, Ho, Wo, _stream())
+            if TUNE_CONV:
+                _tune_conv(1, ctx.geom, run_d, d_sc)
+            ws = _conv_ws(1, ctx.geom, dy.device)
             rows = conv_dgrad_stats_rows(ctx.geom) if src is not None and src.get("x") is not None else 0
             if rows > 0:
                 # dx (= data gradient + the second path's gradient) is the complete gradient of a BatchNorm's output: the epilogue
                 # also writes that BatchNorm backward's per-channel partial sums, and the node finds them through `src`
                 stats = torch.empty(rows * C * 2, device=dy.device, dtype=torch.float32)
-                _l.check(L.sqd_conv_dgrad_bn(_ptr(dy), _ptr(w), _ptr(g_skip), _ptr(dx), _ptr(ws), _ptr(src["x"]), _ptr(src["mask"]),
-                                             _ptr(src["mean"]), _ptr(src["rstd"]), src["code"], _ptr(stats), N, H, W, C, K, R, S, stride, pad,
-                                             Ho, Wo, _stream()), "conv_dgrad_bn")
+                _l.check(run_d(ws, stats), "conv_dgrad_bn")
                 src.update(dx=dx, part=stats, rows=rows)
             else:
-                _l.check(L.sqd_conv_dgrad(_ptr(dy), _ptr(w), _ptr(g_skip), _ptr(dx), _ptr(ws), N, H, W, C, K, R, S, stride, pad, Ho, Wo,
-                                          _stream()), "conv_dgrad")
+                _l.check(run_d(ws), "conv_dgrad")
+            _amax_tag(dx, adx)
         elif g_skip is not None:
             dx = g_skip
         return dx, dw, db, None, None, None, None, None, None
@@ -1060,6 +1314,7 @@ def conv2d_stem_s2d(x, conv, act=None, stats=None):
     # (regrouped on every call — one tiny kernel: the optimiser updates the weights through raw pointers, so nothing on the
     # Python side could tell a cached copy that it is stale, and a copy cached before a graph capture would be frozen into it)
     w = StemRegroup.apply(conv.weight, Cp)
+    w._sqd_w_src = conv.weight                   # (regrouped values + zero taps: max |w| is the parameter's)
     return Conv2d.apply(xs, w, conv.bias, 1, 2, act, False, (H // 2, W // 2), stats)
 
 
@@ -1075,14 +1330,17 @@ def conv2d_stem_s2d_planar(pairs, conv, act=None, stats=None, affine=(0.0, 1.0))
     Cp = (4 * (C0 + C1) + 15) // 16 * 16
     xs = torch.empty((B * S, Cp, H // 2, W // 2), device=x0.device, dtype=torch.float32, memory_format=torch.channels_last)
     per = (H // 2) * (W // 2) * Cp
+    axs = _amax_out(x0.device)                   # one scalar for the whole batch: every launch below raises it
     for i, (a, b) in enumerate(pairs):
         a = a.detach()
         b = None if b is None else b.detach()
         if not (a.is_contiguous() and (b is None or b.is_contiguous()) and a.dtype == torch.float32):
             raise RuntimeError("sqd: conv2d_stem_s2d_planar needs dense NCHW float32 frames")
-        _l.check(_l.lib().sqd_space_to_depth2_planar(_ptr(a), _ptr(b), ctypes.c_void_p(xs.data_ptr() + 4 * per * i), B, H, W, C0, C1, Cp,
-                                                     per * S, float(affine[0]), float(affine[1]), _stream()), "space_to_depth2_planar")
+        _l.check(_l.lib().sqd_space_to_depth2_planar_amax(_ptr(a), _ptr(b), ctypes.c_void_p(xs.data_ptr() + 4 * per * i), B, H, W, C0, C1, Cp,
+                                                          per * S, float(affine[0]), float(affine[1]), _ptr(axs), _stream()), "space_to_depth2_planar")
+    _amax_tag(xs, axs)
     w = StemRegroup.apply(conv.weight, Cp)
+    w._sqd_w_src = conv.weight
     return Conv2d.apply(xs, w, conv.bias, 1, 2, act, False, (H // 2, W // 2), stats)
 
 
@@ -1139,6 +1397,7 @@ def conv2d_stem3_same_s2d(x, conv):
         idx = _STEM3_INDEX[key] = torch.tensor(pos, device=x.device, dtype=torch.int64)
     flat = torch.zeros((K, 9 * Cp), device=x.device, dtype=torch.float32).index_copy(1, idx, conv.weight.reshape(K, C * 9))
     ws = flat.view(K, 3, 3, Cp).permute(0, 3, 1, 2)          # logical [K, Cp, 3, 3], channels-last memory
+    ws._sqd_w_src = conv.weight
     return Conv2d.apply(xs, ws, None, 1, 1, None, False, (H // 2, W // 2), None)
 
 

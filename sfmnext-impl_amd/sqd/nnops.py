@@ -37,6 +37,9 @@ def configure(opt, device):
     timing on the first call unless --sqd_no_conv_tune.  The kernels are NHWC / KRSC only, so channels_last is forced."""
     from . import nnkernels
     nnkernels.set_conv_precision(2 if opt.sqd_bf16 else 0)
+    # two-term fp16 operands (f16x2) are plans of the fp32-equivalent arithmetic; --sqd_no_f16x2 keeps the round-4 plan space
+    nnkernels.amax_enable(not opt.sqd_bf16 and not getattr(opt, "sqd_no_f16x2", False))
+    nnkernels.TUNE_SPACE["f16x2"] = not getattr(opt, "sqd_no_f16x2", False)
     nnkernels.TUNE_CONV = not opt.sqd_no_conv_tune and torch.device(device).type == "cuda"     # first step: ~2 s of plan timing
     if getattr(opt, "sqd_conv_plans", None):
         import json
@@ -181,7 +184,9 @@ def linear_channels(x, lin, act=None):
     _device_only(x, "linear_channels")
     from . import nnkernels
     K, C = lin.weight.shape
-    return nnkernels.Conv2d.apply(x, lin.weight.view(K, C, 1, 1), lin.bias, 1, 0, act, False, None, None)
+    w4 = lin.weight.view(K, C, 1, 1)
+    w4._sqd_w_src = lin.weight                   # (the same values: the filter's max |.| is the parameter's, see nnkernels.amax_of_weight)
+    return nnkernels.Conv2d.apply(x, w4, lin.bias, 1, 0, act, False, None, None)
 
 
 def dw_conv(x, conv, skip=False):
@@ -201,10 +206,10 @@ def patchify_conv(x, conv, s):
     N, C, H, W = x.shape
     K = conv.out_channels
     xs = x.reshape(N, C, H // s, s, W // s, s).permute(0, 3, 5, 1, 2, 4).reshape(N, s * s * C, H // s, W // s)
-    w = conv.weight.permute(0, 2, 3, 1).reshape(K, s * s * C, 1, 1)
+    w = conv.weight.permute(0, 2, 3, 1).reshape(K, s * s * C, 1, 1).contiguous(memory_format=torch.channels_last)
+    w._sqd_w_src = conv.weight                   # (a permutation of the parameter's values)
     from . import nnkernels
-    return nnkernels.Conv2d.apply(xs.contiguous(memory_format=torch.channels_last), w.contiguous(memory_format=torch.channels_last),
-                                  conv.bias, 1, 0, None, False, None, None)
+    return nnkernels.Conv2d.apply(xs.contiguous(memory_format=torch.channels_last), w, conv.bias, 1, 0, None, False, None, None)
 
 
 def squeeze_excite(x, conv_reduce, conv_expand):

@@ -184,6 +184,10 @@ class FusedAdam(torch.optim.Adam):
 
     @torch.no_grad()
     def step(self, closure=None):
+        # the kernels below write the parameters through raw pointers: the filters' max |.| table of the two-term fp16 convolution
+        # plans is stale until the next nnkernels.begin_step() recomputes it (one launch)
+        from . import nnkernels
+        nnkernels.weights_changed()
         if self._graph_hyper is not None and torch.cuda.is_current_stream_capturing():
             self._step_captured()
             return None

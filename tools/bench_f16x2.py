@@ -61,7 +61,7 @@ def timeit(fn, iters):
 
 
 def amax_of(t):
-    a = torch.zeros(1, device="cuda")
+    a = torch.zeros(nnkernels.AMAX_REC, device="cuda")
     _l.check(LIB.sqd_amax(P(t), t.numel(), P(a), ST()), "amax")
     return a
 
@@ -129,8 +129,8 @@ for name, C, H, W, K, R, st, pad, cnt in LAYERS:
     halo = R == 3 and st == 1 and pad == 1
     f3 = [32 + 1024, 32 + 1024 + 256] + ([32 + 1024 + 2048, 32 + 1024 + 2048 + 256] if halo else [])
     f2 = [f + 4096 for f in f3]
-    run_f = lambda ws: LIB.sqd_conv_fwd_scaled(P(x), P(w), None, P(y), P(ws), None, P(ax), P(aw), *geom, 0, ST())
-    run_d = lambda ws: LIB.sqd_conv_dgrad_scaled(P(dy), P(w), None, P(dx), P(ws), None, None, None, None, 0, None, P(ady), P(aw), *geom, ST())
+    run_f = lambda ws: LIB.sqd_conv_fwd_scaled(P(x), P(w), None, P(y), P(ws), None, P(ax), P(aw), None, *geom, 0, ST())
+    run_d = lambda ws: LIB.sqd_conv_dgrad_scaled(P(dy), P(w), None, P(dx), P(ws), None, None, None, None, 0, None, P(ady), P(aw), None, *geom, ST())
     run_w = lambda part: LIB.sqd_conv_wgrad_scaled(P(dy), P(x), P(dw), None, P(part), P(ady), P(ax), *geom, None, ST())
     bf3, bf2 = best_gemm(0, geom, run_f, f3), best_gemm(0, geom, run_f, f2)
     bd3, bd2 = best_gemm(1, geom, run_d, f3), best_gemm(1, geom, run_d, f2)
@@ -166,10 +166,10 @@ for name, C, H, W, K, R, st, pad, cnt in LAYERS:
                     e.append((float("nan"),) * 2)
                     continue
                 if mode == 0:
-                    _l.check(LIB.sqd_conv_fwd_scaled(P(xs), P(w), None, P(ys), None, None, P(a_x), P(aw), *g2, 0, ST()), "fwd")
+                    _l.check(LIB.sqd_conv_fwd_scaled(P(xs), P(w), None, P(ys), None, None, P(a_x), P(aw), None, *g2, 0, ST()), "fwd")
                     e.append(rel_err(ys.permute(0, 3, 1, 2), yr))
                 else:
-                    _l.check(LIB.sqd_conv_dgrad_scaled(P(dys), P(w), None, P(dxs), None, None, None, None, None, 0, None, P(a_dy), P(aw), *g2, ST()), "dgrad")
+                    _l.check(LIB.sqd_conv_dgrad_scaled(P(dys), P(w), None, P(dxs), None, None, None, None, None, 0, None, P(a_dy), P(aw), None, *g2, ST()), "dgrad")
                     e.append(rel_err(dxs.permute(0, 3, 1, 2), dxr))
                 LIB.sqd_conv_set_plan(mode, *g2, 0, 0, 0, 16)
             if wimpl == 1 or LIB.sqd_conv_wgrad_set_plan(nb, Ho, Wo, C, K, R, R, wimpl | (1 << 4) if C % 64 or K % 64 else wimpl, 2) == 0:

@@ -19,13 +19,13 @@ def zg(self):
     return oz(self)
 _ddp.GradBucketReducer.zero_grad = zg
 dups = [0]
-def on_grad(self, p):
+def on_grad(self, p, announced=False):
     bi = self._bucket_of.get(p)
     if id(p) in seen and dups[0] < 2:
         dups[0] += 1
         print("DUPLICATE arrival of", names.get(id(p)), "\nFIRST:\n", seen[id(p)], "\nSECOND:\n", "".join(traceback.format_stack(limit=8)), flush=True)
     seen[id(p)] = "".join(traceback.format_stack(limit=8))
-    log.append((names.get(id(p), "?"), bi, None if bi is None else self._pending[bi], p.grad is None))
+    log.append((names.get(id(p), "?") + (" [announced]" if announced else ""), bi, None if bi is None else self._pending[bi], p.grad is None))
     if bi is not None and self._pending[bi] == 1:
         missing = [names.get(id(q), "?") for q in self.buckets[bi] if q.grad is None]
         if missing:
@@ -34,7 +34,7 @@ def on_grad(self, p):
             for n, b, pend, gn in log:
                 if b == bi: cnt[n] = cnt.get(n, 0) + 1
             print("announce counts >1:", {k: v for k, v in cnt.items() if v > 1}, flush=True)
-    return orig(self, p)
+    return orig(self, p, announced=announced)
 _ddp.GradBucketReducer._on_grad = on_grad
 from trainer import Trainer
 oi = Trainer.__init__
