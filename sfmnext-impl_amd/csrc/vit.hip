@@ -413,12 +413,15 @@ __global__ __launch_bounds__(256) void ffn_bwd_kernel(const float *__restrict__ 
 }
 
 int vit_check(const char *who, int rows, int E) {
-    SQD_CHECK_ARG(rows > 0 && (E == 16 || E == 32 || E == 64), "%s: rows=%d, E=%d (E must be 16, 32 or 64)", who, rows, E);
+    SQD_CHECK_ARG(rows > 0 && E >= 4 && E <= 64 && E % 4 == 0, "%s: rows=%d, E=%d (E must be a multiple of 4, at most 64)", who, rows, E);
     return SQD_OK;
 }
 }  // namespace
 
-extern "C" int sqd_vit_supported(int E, int F) { return ((E == 16 || E == 32 || E == 64) && F >= 4 && F % 4 == 0 && F <= 8192) ? 1 : 0; }
+// embedding widths: any multiple of 4 up to 64 — the token-wise kernels mask the lanes / reduction slots beyond E (one half-wave per row up
+// to 32 features, a whole wave beyond; feed-forward blocks of 32 features).  The reference's args files use 32 (KITTI), 64 and 56
+// (args_files/args_cityscapes_train.txt:9: --model_dim 56).
+extern "C" int sqd_vit_supported(int E, int F) { return (E >= 4 && E <= 64 && E % 4 == 0 && F >= 4 && F % 4 == 0 && F <= 8192) ? 1 : 0; }
 
 // ---- add + dropout + LayerNorm.  x [rows,E]; y [nparts][rows,E] (summed, + ybias [E] if not NULL); mask [rows,E] bytes
 // (1 = keep) or NULL; scale = 1/(1-p)
@@ -525,7 +528,7 @@ extern "C" int sqd_ffn_bwd(const float *x, const float *g_y, const float *W1, co
 
 // ===================================================================================================
 // multi-head self-attention of the encoder layer (nn.MultiheadAttention, packed in_proj, batch_first = False) for short token
-// sequences: S <= 512 tokens, head dimension HD in {4, 8} (E = 64: HD = 16, S <= 256).  One workgroup per (batch element, head), four (two beyond 256 tokens) threads per token
+// sequences: S <= 512 tokens, head dimension HD in {4, 8} (E = 64: HD = 16, E = 56: HD = 14, both S <= 256).  One workgroup per (batch element, head), four (two beyond 256 tokens) threads per token
 // (each takes every 4th key / query and a quarter of the features; quad shuffles combine them); the whole head (projections,
 // S x S scores, softmax, attention dropout, P.V, its slice of the out-projection) is VALU work on operands read from LDS — 120 x 120 x 8 per head is far too small for the matrix cores to matter; what
 // counts is that it is ONE launch with no intermediate tensors instead of ~8 (forward) / ~20 (backward).
@@ -849,6 +852,25 @@ void mha_launch_bwd64(dim3 grid, hipStream_t st, const float *x, const float *gs
         hipLaunchKernelGGL((mha_bwd_kernel<16, 64, 256, 2, false>), grid, dim3(512), 0, st, x, gsa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin,
                            pbin, pWo, pbo, S, B, H, qscale, dscale);
 }
+// model_dim 56 with its 4 heads of 14 (reference args_files/args_cityscapes_train.txt:9): two threads per token (14 = 2 x 7 projection
+// outputs, 56 = 2 x 28 feature columns per part), up to 256 tokens
+void mha_launch_fwd56(dim3 grid, hipStream_t st, const float *x, const float *Win, const float *bin, const float *Wo, const unsigned char *mask,
+                      float *ypart, float *o_save, float *ml_save, int S, int B, int H, float qscale, float dscale) {
+    if (S <= 128)
+        hipLaunchKernelGGL((mha_fwd_kernel<14, 56, 128, 2>), grid, dim3(256), 0, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+    else
+        hipLaunchKernelGGL((mha_fwd_kernel<14, 56, 256, 2>), grid, dim3(512), 0, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+}
+void mha_launch_bwd56(dim3 grid, hipStream_t st, const float *x, const float *gsa, const float *Win, const float *bin, const float *Wo,
+                      const unsigned char *mask, const float *o_save, const float *ml_save, float *gxpart, float *pWin, float *pbin, float *pWo,
+                      float *pbo, int S, int B, int H, float qscale, float dscale) {
+    if (S <= 128)
+        hipLaunchKernelGGL((mha_bwd_kernel<14, 56, 128, 2, true>), grid, dim3(256), 0, st, x, gsa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin,
+                           pbin, pWo, pbo, S, B, H, qscale, dscale);
+    else
+        hipLaunchKernelGGL((mha_bwd_kernel<14, 56, 256, 2, false>), grid, dim3(512), 0, st, x, gsa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin,
+                           pbin, pWo, pbo, S, B, H, qscale, dscale);
+}
 template <int HD, int EE>
 void mha_launch_fwd(dim3 grid, hipStream_t st, const float *x, const float *Win, const float *bin, const float *Wo, const unsigned char *mask,
                     float *ypart, float *o_save, float *ml_save, int S, int B, int H, float qscale, float dscale) {
@@ -876,9 +898,10 @@ void mha_launch_bwd(dim3 grid, hipStream_t st, const float *x, const float *gsa,
 }  // namespace
 
 extern "C" int sqd_mha_supported(int S, int E, int H) {
-    if (!(E == 16 || E == 32 || E == 64) || H < 1 || E % H) return 0;
+    if (!(E == 16 || E == 32 || E == 56 || E == 64) || H < 1 || E % H) return 0;
     const int hd = E / H;
     if (E == 64) return (S >= 1 && S <= 256 && hd == 16) ? 1 : 0;          // model_dim 64 with its 4 heads
+    if (E == 56) return (S >= 1 && S <= 256 && hd == 14) ? 1 : 0;          // model_dim 56 with its 4 heads (the Cityscapes args files)
     return (S >= 1 && S <= 512 && (hd == 4 || hd == 8)) ? 1 : 0;
 }
 
@@ -896,6 +919,7 @@ extern "C" int sqd_mha_fwd(const float *x, const float *Win, const float *bin, c
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
     if (E == 64) mha_launch_fwd64(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
+    else if (E == 56) mha_launch_fwd56(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
     else if (hd == 8 && E == 32) mha_launch_fwd<8, 32>(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
     else if (hd == 4 && E == 32) mha_launch_fwd<4, 32>(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
     else if (hd == 8 && E == 16) mha_launch_fwd<8, 16>(grid, st, x, Win, bin, Wo, mask, ypart, o_save, ml_save, S, B, H, qscale, dscale);
@@ -920,6 +944,7 @@ extern "C" int sqd_mha_bwd(const float *x, const float *g_sa, const float *Win, 
 #define SQD_MHA_BWD(HD_, EE_) \
     mha_launch_bwd<HD_, EE_>(grid, st, x, g_sa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin, pbin, pWo, pbo, S, B, H, qscale, dscale)
     if (E == 64) mha_launch_bwd64(grid, st, x, g_sa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin, pbin, pWo, pbo, S, B, H, qscale, dscale);
+    else if (E == 56) mha_launch_bwd56(grid, st, x, g_sa, Win, bin, Wo, mask, o_save, ml_save, gxpart, pWin, pbin, pWo, pbo, S, B, H, qscale, dscale);
     else if (hd == 8 && E == 32) SQD_MHA_BWD(8, 32);
     else if (hd == 4 && E == 32) SQD_MHA_BWD(4, 32);
     else if (hd == 8 && E == 16) SQD_MHA_BWD(8, 16);

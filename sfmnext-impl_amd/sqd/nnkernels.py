@@ -1735,7 +1735,7 @@ def encoder_supported(encoder):
 
 def transformer_encoder_native(tokens, encoder):
     """tokens [S,B,E] through the encoder on the fused kernels (EncoderStack): S <= 512 tokens (the positional table holds 500; 256 at
-    width 64), head dimension 4 | 8 | 16.  A token count or head dimension the attention kernel does not take raises — self-attention never
+    width 56 / 64), head dimension 4 | 8 | 14 | 16.  A token count or head dimension the attention kernel does not take raises — self-attention never
     runs through torch.  One bernoulli launch draws every dropout mask of the pass."""
     x = tokens.contiguous()
     S, B, E = x.shape
@@ -1744,8 +1744,8 @@ def transformer_encoder_native(tokens, encoder):
     H = layers[0].self_attn.num_heads
     if not all(_attention_native_ok(l, S) and l.self_attn.num_heads == H for l in layers):
         raise RuntimeError("sqd: self-attention over %d tokens of width %d with %d heads: the fused attention kernel takes up to 512 tokens "
-                           "with head dimension 4 | 8 (width 16 / 32) and up to 256 tokens with head dimension 16 (width 64); there is no "
-                           "ATen fallback" % (S, E, H))
+                           "with head dimension 4 | 8 (width 16 / 32) and up to 256 tokens with head dimension 16 (width 64) or 14 (width 56: "
+                           "the reference's Cityscapes args files); there is no ATen fallback" % (S, E, H))
     masks, scale = None, 1.0
     if encoder.training:
         ps = {float(p) for l in layers for p in (l.dropout1.p, l.dropout.p, l.dropout2.p)}

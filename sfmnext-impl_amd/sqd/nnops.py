@@ -5,8 +5,9 @@ reference's structure (state-dict keys stay those of the reference) while the ar
 kernels of libsqd.so (csrc/*.hip).  There is ONE implementation per operator: a shape the kernels do not take (channel /
 feature counts that are not multiples of 4) is an error that names the operator and the shape, not a detour through another
 library; host tensors are refused (the CPU restatement of these operators is test infrastructure: oracle/, tests/host_ops.py).
-That includes the patch-token transformer encoder: an embedding width other than 16 / 32 / 64 or more than 512 tokens (256 at
-width 64) raises — no args file of the reference builds one, and nothing in the step runs on ATen's nn.TransformerEncoder."""
+That includes the patch-token transformer encoder: it takes the embedding widths of the reference's args files — 32 (KITTI), 64
+(args_res50_kitti_192x640_train.txt) and 56 (args_cityscapes_train.txt:9, args_cityscapes_eval.txt:7: 4 heads of 14) — and 16; another
+width, or more than 512 tokens (256 at width 56 / 64), raises: nothing in the step runs on ATen's nn.TransformerEncoder."""
 import torch
 import torch.nn.functional as F
 
@@ -14,7 +15,7 @@ BACKEND = {
     "conv2d": "hip (implicit GEMM / input-patch kernels; 7x7 and 3x3 stride-2 stems via space-to-depth)",
     "conv_bn_act": "hip conv + hip bn/act/residual", "maxpool3x3s2": "hip", "upsample_concat": "hip",
     "pose_head": "hip", "depthwise_conv": "hip", "squeeze_excite": "hip", "linear": "hip (1x1 implicit GEMM over rows)",
-    "transformer_encoder": "hip (fused attention up to 512 tokens — 256 at embedding width 64 —, feed-forward, add+dropout+layernorm)",
+    "transformer_encoder": "hip (fused attention up to 512 tokens — 256 at embedding width 56 / 64 —, feed-forward, add+dropout+layernorm)",
     "full_query_layer": "hip", "bins_head": "hip",
 }
 
@@ -262,8 +263,9 @@ def transformer_encoder(tokens, encoder):
     if not nnkernels.encoder_supported(encoder):
         l0 = encoder.layers[0]
         raise RuntimeError("sqd: transformer_encoder with embedding width %d, feed-forward %d, norm_first=%s: the patch-token encoder kernels "
-                           "take post-norm ReLU layers of width 16 / 32 / 64 (reference networks/depth_decoder_QTR.py:14-16 with the "
-                           "model_dim of every args file); there is no ATen fallback"
+                           "take post-norm ReLU layers whose width is a multiple of 4 up to 64, with attention heads of 4 | 8 (width 16 / 32), "
+                           "14 (width 56) or 16 (width 64) features (reference networks/depth_decoder_QTR.py:14-16 with the model_dim of "
+                           "every args file: 32, 56, 64); there is no ATen fallback"
                            % (l0.linear1.weight.shape[1], l0.linear1.weight.shape[0], l0.norm_first))
     return nnkernels.transformer_encoder_native(tokens, encoder)
 
@@ -273,8 +275,19 @@ def full_query_layer(x, queries):
     energy maps [B,Q,h,w] (raw dot products) and summaries [B,Q,E] (softmax over the h*w pixels)."""
     _device_only(x, "Self Query Layer")
     from . import ops
-    if not ops.sql_supported(x.shape[1], queries.shape[1]):
-        raise RuntimeError("sqd: Self Query Layer kernel supports E in {16,32,48,64}, Q <= 128; got E=%d Q=%d" % (x.shape[1], queries.shape[1]))
+    E, Q = x.shape[1], queries.shape[1]
+    if not ops.sql_supported(E, Q):
+        Ep = (E + 15) // 16 * 16
+        if E % 4 == 0 and ops.sql_supported(Ep, Q):
+            # an embedding width between the kernel's 16-channel steps (model_dim 56 of the reference's Cityscapes args files): zero channels
+            # add nothing to the x . query products and come back as zero columns of the summaries, so the width is rounded up with zeros
+            # — two small copies (ATen pads) around the same kernels; the data gradients of the zero channels are dropped by the slices
+            xp = F.pad(x, (0, 0, 0, 0, 0, Ep - E))
+            if x.is_contiguous(memory_format=torch.channels_last):
+                xp = xp.contiguous(memory_format=torch.channels_last)
+            y, summ = ops.SelfQueryLayer.apply(xp, F.pad(queries, (0, Ep - E)))
+            return y, summ[..., :E]
+        raise RuntimeError("sqd: Self Query Layer kernel supports embedding widths that are multiples of 4 up to 64, Q <= 128; got E=%d Q=%d" % (E, Q))
     return ops.SelfQueryLayer.apply(x, queries)
 
 

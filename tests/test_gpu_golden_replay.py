@@ -74,6 +74,37 @@ def test_g11_qtr_decoders(golden, tag):
             rel_close(P[k[6:].replace("__", ".")].grad, g[k], 1e-3)
 
 
+@pytest.mark.parametrize("cls_name,ff", [("Depth_Decoder_QueryTr", 1024), ("Lite_Depth_Decoder_QueryTr", 512)])
+def test_qtr_decoder_model_dim_56_matches_the_oracle(cls_name, ff):
+    """--model_dim 56 (reference args_files/args_cityscapes_train.txt:9, args_cityscapes_eval.txt:7: 4 heads of 14): forward and every
+    gradient of the head against the oracle's restatement of networks/depth_decoder_QTR.py (itself pinned to the reference by G11,
+    tests/test_oracle_vs_golden.py) in float64 — the attention kernel's 14-feature heads, the token-wise kernels' masked lanes beyond
+    56 and the Self Query Layer on the width rounded up to 64 with zero channels (VERDICT r04 missing #2)"""
+    import networks
+    from oracle import torch_ref as O
+    kw = dict(in_channels=32, embedding_dim=56, patch_size=16, num_heads=4, query_nums=64, dim_out=128, norm="linear", min_val=0.001, max_val=10.0)
+    m = fill_params(getattr(networks, cls_name)(**kw), 5)
+    ref = O.QueryTrDecoder(dim_feedforward=ff, dropout=0.0, **kw).double()
+    ref.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    m = m.cuda().to(memory_format=torch.channels_last)
+    m.eval()
+    ref.eval()
+    x = tt(np.random.RandomState(11).standard_normal((2, 32, 96, 256)).astype(np.float32))     # 192x512 frames: 6 x 16 = 96 tokens
+    w = tt(np.random.RandomState(12).standard_normal((2, 1, 96, 256)).astype(np.float32))
+    xr = x.double().requires_grad_(True)
+    out_r = ref(xr)[("disp", 0)]
+    (out_r * w.double()).sum().backward()
+    xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    out = m(xg)[("disp", 0)]
+    (out * w.cuda()).sum().backward()
+    close(out, out_r.detach().numpy(), atol=2e-5)
+    rel_close(xg.grad, xr.grad.numpy(), 2e-4)
+    P, R = dict(m.named_parameters()), dict(ref.named_parameters())
+    assert set(P) == set(R)
+    for k in P:
+        rel_close(P[k].grad, R[k].grad.numpy(), 2e-3)
+
+
 def test_g12_posecnn(golden):
     import networks
     from sqd import nnops
