@@ -96,7 +96,7 @@ __device__ __forceinline__ unsigned abs_bits(float x) { return __float_as_uint(x
 // cache line at ~8 ns each (tools/ubench_atomic_max.hip: 4096 workgroups ending with one atomicMax on one word — or on 16 words of one
 // line — turn a 23 us element-wise pass into 55 us; on 16 words in 16 lines into 23.5 us, on 64 into 23.1; a pre-check load costs more than
 // it saves; in the training step 16 ways still cost the BatchNorm passes 2 us each, profiles/r05f).  A workgroup combines its waves
-// through LDS and issues ONE atomic to way (blockIdx mod 64); the reader takes the max over the ways (amax_record_bits: scalar loads).  EVERY thread of the workgroup must call amax_commit (it contains a barrier); amax == NULL:
+// through LDS and issues ONE atomic to way (blockIdx mod 64); the reader takes the max over the ways (amax_record_bits: one vector load).  EVERY thread of the workgroup must call amax_commit (it contains a barrier); amax == NULL:
 // nothing recorded (uniform: no barrier either).  The record must have been cleared on the stream before the launch.  `which` (0 / 1): a
 // kernel that records two maxima back to back gives them different staging rows (no barrier between the first one's read and the second
 // one's write).
@@ -117,12 +117,15 @@ __device__ __forceinline__ void amax_commit(unsigned m, unsigned *__restrict__ a
     }
     if (tid == 0 && m != 0u) atomicMax(amax + ((blockIdx.x + 5u * blockIdx.y + 3u * blockIdx.z) & (AMAX_WAYS - 1)) * AMAX_WAY_STRIDE, m);
 }
-// the maximum a record holds (wave-uniform pointer: scalar loads)
+// the maximum a record holds: ONE vector load (lane e reads way e; 64 scalar loads from 64 cache lines per operand cost a two-term
+// kernel ~10 us at its start — round 5's first in-step measurement, where those plans lost to the three-term ones they beat by 20 % in
+// isolation) and a wave-wide maximum; the result is wave-uniform (SGPR)
 __device__ __forceinline__ unsigned amax_record_bits(const float *__restrict__ rec) {
-    unsigned m = 0u;
+    static_assert(AMAX_WAYS == 64, "one way per lane");
+    unsigned m = __float_as_uint(rec[(__lane_id() & (AMAX_WAYS - 1)) * AMAX_WAY_STRIDE]);
 #pragma unroll
-    for (int e = 0; e < AMAX_WAYS; ++e) m = max(m, __float_as_uint(rec[e * AMAX_WAY_STRIDE]));
-    return m;
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    return (unsigned)__builtin_amdgcn_readfirstlane((int)m);
 }
 
 // reflection index of ReflectionPad2d (pad < n), clamped for lanes far outside the image

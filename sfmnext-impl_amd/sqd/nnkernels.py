@@ -413,6 +413,7 @@ def _tune_conv(mode, geom, launch, scaled=False):
     _TUNED.add(key)
     L = _l.lib()
     best = None
+    by_class = {}                  # (log) the fastest plan of each arithmetic
     # bk + 512 = the single-buffered LDS variants (half the LDS per workgroup, twice the resident workgroups, one more barrier
     # per slice): picked for three quarters of the config-B layers, forward -5 %, data gradient -2 %.
     # bk 32 + 1024 = three-term bf16 operands on the bf16 matrix cores (fp32-level accuracy, 6 products per slice at 16x the fp32
@@ -444,10 +445,13 @@ def _tune_conv(mode, geom, launch, scaled=False):
             t += 3.0 * (geom[0] * geom[9] * geom[10] * geom[4] * 4 / 4.0e12 + 3.0e-6) * 1e3
         if best is None or t < best[0]:
             best = (t, bm, bn, z, bk)
+        cls = "f16x2" if bk & 4096 else "bf16x3" if bk & 1024 else "fp32"
+        if cls not in by_class or t / 3 * 1e3 < by_class[cls][0]:
+            by_class[cls] = (round(t / 3 * 1e3, 1), bm, bn, z, bk)
     plan = (0, 0, 0, 16) if best is None else best[1:]
     _register_conv_plan(mode, geom, plan)
     if TUNE_SPACE["log"]:
-        print("sqd conv plan", "dgrad" if mode else "fwd", geom, best, flush=True)
+        print("sqd conv plan", "dgrad" if mode else "fwd", geom, best, "us per launch by arithmetic:", by_class, "scaled" if scaled else "unscaled", flush=True)
 
 
 def _register_conv_plan(mode, geom, plan):
@@ -472,6 +476,7 @@ def _tune_wgrad(geom, has_bias, launch, launch_t=None, scaled=False):
     _PLAN_CACHE.pop(key, None)
     _, base = _wgrad_part_floats(geom)
     best = None
+    by_impl = {}                   # (log) the fastest plan of each kernel family
 
     def trial(impl, sp):
         nonlocal best
@@ -487,6 +492,8 @@ def _tune_wgrad(geom, has_bias, launch, launch_t=None, scaled=False):
         t = _time_launch(launch, torch.empty(pf + extra, device="cuda", dtype=torch.float32))
         if best is None or t < best[0]:
             best = (t, impl, sp)
+        if (impl & 15) not in by_impl or t / 3 * 1e3 < by_impl[impl & 15][0]:
+            by_impl[impl & 15] = (round(t / 3 * 1e3, 1), impl, sp)
         return True
     # direct kernel with its default register tile (the widest that divides: 64 filters x 64 channels), then the LDS-tiled kernel
     shapes = [1]
@@ -548,7 +555,7 @@ def _tune_wgrad(geom, has_bias, launch, launch_t=None, scaled=False):
                 _PLAN_CACHE.pop((0,) + gT, None)
     _register_wgrad_plan((N, Ho, Wo, C, K, R, S), best[1:])
     if TUNE_SPACE["log"]:
-        print("sqd conv plan wgrad", geom, best, "model splits", base, flush=True)
+        print("sqd conv plan wgrad", geom, best, "model splits", base, "us per launch by kernel family:", by_impl, "scaled" if scaled else "unscaled", flush=True)
 
 
 WGRAD_TRANSPOSED = 5          # plan impl handled here, not in the library: the wide 1x1 layers' weight gradient as a forward GEMM on
@@ -1083,10 +1090,10 @@ def _scaled_plan(kind, geom):
 def _scales_wanted(kind, geom, tune_key):
     """operand scales are fetched when the plan needs them, or when the plans of this geometry are about to be timed (the two-term
     plans are among the candidates).  Convolutions over a handful of rows (the Linear layers of the bins regressor) stay unscaled."""
-    if not AMAX_ON or _l.lib().sqd_conv_precision() != 0 or geom[0] * geom[9] * geom[10] < 256:
-        return False
     if _scaled_plan(kind, geom):
         return True
+    if not AMAX_ON or _l.lib().sqd_conv_precision() != 0 or geom[0] * geom[9] * geom[10] < 256:
+        return False
     return TUNE_CONV and TUNE_SPACE["f16x2"] and tune_key not in _TUNED and not torch.cuda.is_current_stream_capturing()
 
 
