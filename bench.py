@@ -128,7 +128,11 @@ def roofline_fused_fwd(trainer, batches, iters=200, graph_us=None):
             note = "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, access-width calibration)" % os.path.basename(PMC_TRAFFIC_JSON)
         else:
             note = "stale PMC record (kernel sources changed since %s was measured): traffic withheld" % os.path.basename(PMC_TRAFFIC_JSON)
-    return {"bound": "hbm", "kernel": ops.PHOTO_FWD_KERNEL_NAME,
+    n_src = len([f for f in trainer.opt.frame_ids if f != 0]) + (1 if trainer.opt.use_stereo and "s" not in trainer.opt.frame_ids else 0)
+    caveat = None if n_src == 2 else ("%d source frames: the sources are processed in pairs, %d launches per step (the last one with a single source and the running "
+                                      "minimum carried in); us_per_launch averages them and is priced with the two-source launch's 93 B/px — not comparable "
+                                      "with configs[1]'s figure" % (n_src, (n_src + 1) // 2))
+    return {"bound": "hbm", "kernel": ops.PHOTO_FWD_KERNEL_NAME, **({"caveat": caveat} if caveat else {}),
             "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
             "traffic": traffic, "traffic_bytes_per_launch": traffic_bytes, "traffic_source": note,
             "us_per_launch": round(t * 1e6, 2),
@@ -169,7 +173,8 @@ def roofline_depthwise(trainer):
     dev = trainer.device
     best = None
     H, W = o.height // 2, o.width // 2                       # after the stride-2 stem
-    for stage in trainer.models["encoder"].encoder.original_model.blocks:
+    trunk = trainer.models["encoder"].encoder              # BaseEncoder: .original_model is the trunk; Unet: the features_only trunk itself
+    for stage in getattr(trunk, "original_model", trunk).blocks:
         for blk in stage:
             conv = blk.conv_dw
             k, st, C = conv.kernel_size[0], conv.stride[0], conv.in_channels
@@ -207,16 +212,24 @@ def roofline_mlp_gemm(trainer):
     y = torch.empty((N, K, H, W), device=dev).contiguous(memory_format=torch.channels_last)
     ws = nnkernels._conv_ws(0, geom, dev)
     L, st_ = _l.lib(), torch.cuda.current_stream().cuda_stream
-    t = _time_calls(lambda: _l.check(L.sqd_conv_fwd(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None if ws is None else ws.data_ptr(), None,
-                                                    N, H, W, C, K, 1, 1, 1, 0, H, W, 0, st_), "conv_fwd"))
-    flops = 2.0 * N * H * W * C * K
     plan = nnkernels.CHOSEN_PLANS.get(("fwd",) + geom)
-    split3 = bool(plan and plan[3] & 1024)
+    split3, h2 = bool(plan and plan[3] & 1024), bool(plan and plan[3] & 4096)
+    ax = aw = None
+    if h2:                                     # a two-term fp16 plan takes the operands' max |.| (device scalars)
+        ax, aw = (torch.zeros(nnkernels.AMAX_REC, device=dev) for _ in range(2))
+        for t_, a_ in ((x, ax), (w, aw)):
+            _l.check(L.sqd_amax(t_.data_ptr(), t_.numel(), a_.data_ptr(), st_), "amax")
+    t = _time_calls(lambda: _l.check(L.sqd_conv_fwd_scaled(x.data_ptr(), w.data_ptr(), b.data_ptr(), y.data_ptr(), None if ws is None else ws.data_ptr(), None,
+                                                           None if ax is None else ax.data_ptr(), None if aw is None else aw.data_ptr(), None,
+                                                           N, H, W, C, K, 1, 1, 1, 0, H, W, 0, st_), "conv_fwd"))
+    flops = 2.0 * N * H * W * C * K
     # the bound of the arithmetic the registered plan runs: fp32 MFMA 157.3 TFLOP/s; a three-term bf16 plan issues 6 bf16 products per
-    # fp32 product on the 2500 TFLOP/s dense bf16 pipe (MI355X_MICROARCH.md) = 416.7 TFLOP/s of fp32-equivalent work
-    peak = 2500.0 / 6.0 if split3 else 157.3
+    # fp32 product on the 2500 TFLOP/s dense bf16 pipe (MI355X_MICROARCH.md) = 416.7 TFLOP/s of fp32-equivalent work; a two-term fp16
+    # plan 3 products on the fp16 pipe (same dense peak) = 833.3
+    peak = 2500.0 / 3.0 if h2 else 2500.0 / 6.0 if split3 else 157.3
+    arith = "two-term fp16 operands" if h2 else "three-term bf16 operands" if split3 else "fp32 MFMA"
     return {"bound": "mfma", "kernel": "conv_gemm_kernel (1x1 convolution %d -> %d on [%d,%d,%d]: stage-2 MLP expansion; plan (bm, bn, split, bk flags) %s = %s)"
-                                       % (C, K, N, H, W, plan, "three-term bf16 operands" if split3 else "fp32 MFMA"),
+                                       % (C, K, N, H, W, plan, arith),
             "achieved": round(flops / t / 1e12, 1), "peak": round(peak, 1), "unit": "TFLOP/s", "frac": round(flops / t / 1e12 / peak, 4),
             "frac_of_fp32_mfma_peak": round(flops / t / 1e12 / 157.3, 4),
             "traffic": None, "us_per_launch": round(t * 1e6, 2), "algorithmic_flops_per_launch": flops,
@@ -318,7 +331,8 @@ def workload_name(o):
             "2 source frames, fwd+bwd+Adam (num_features 256, model_dim 32, patch 16, Q 64, dim_out 64)")
     if not os.environ.get("SQD_BENCH_EXTRA"):
         return base
-    return ("NOT configs[1] (SQD_BENCH_EXTRA=%r): backbone %s, %dx%d, batch %d per GPU, %s convolution operands, frames %s, "
+    return (os.environ.get("SQD_BENCH_WORKLOAD", "") + " " if os.environ.get("SQD_BENCH_WORKLOAD") else "") + \
+           ("NOT configs[1] (SQD_BENCH_EXTRA=%r): backbone %s, %dx%d, batch %d per GPU, %s convolution operands, frames %s, "
             "num_features %d, model_dim %d, patch %d, Q %d, dim_out %d" %
             (os.environ["SQD_BENCH_EXTRA"], o.backbone, o.height, o.width, o.batch_size, "bf16" if o.sqd_bf16 else "fp32",
              list(o.frame_ids) + (["s"] if o.use_stereo else []), o.num_features, o.model_dim, o.patch_size, o.query_nums, o.dim_out))

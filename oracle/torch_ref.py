@@ -495,10 +495,21 @@ class EfficientNetB5(nn.Module):
                 cin = cout
             blocks.append(nn.Sequential(*stage))
         self.blocks = nn.Sequential(*blocks)
-        self.conv_head = nn.Conv2d(cin, head, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(head, eps=1e-3)
-        self.global_pool = nn.Identity()
-        self.classifier = nn.Identity()
+        if head is not None:
+            self.conv_head = nn.Conv2d(cin, head, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(head, eps=1e-3)
+            self.global_pool = nn.Identity()
+            self.classifier = nn.Identity()
+
+    def stride_features(self, x):
+        """timm features_only (Unet.py:114-118 for --backbone tf_efficientnet_b5_ap): the last map of every stride = stages 0, 1, 2, 4, 6"""
+        f = F.silu(self.bn1(self.conv_stem(_same_pad(x, 3, 2))))
+        out = []
+        for i, stage in enumerate(self.blocks):
+            f = stage(f)
+            if i in (0, 1, 2, 4, 6):
+                out.append(f)
+        return out
 
     def features(self, x):
         """reference Encoder.forward (base_encoder.py:63-73): one entry per top-level module, the stages of `blocks` one by one"""
@@ -645,6 +656,29 @@ class Unet(nn.Module):
         super().__init__()
         self.encoder = ConvNeXtFeatures(in_channels, depths, dims)
         self.decoder = UnetDecoder(list(dims)[::-1], tuple(decoder_channels), num_classes)
+
+    def forward(self, x):
+        feats = self.encoder(x)
+        feats.reverse()
+        return self.decoder(feats)
+
+
+class _B5Features(EfficientNetB5):
+    def __init__(self, stages=_B5_STAGES):
+        super().__init__(stages, head=None)
+
+    def forward(self, x):
+        return self.stride_features(x)
+
+
+class UnetB5(nn.Module):
+    """Unet.py:82-148 with the tf_efficientnet_b5_ap backbone (trainer.py:64 under args_files/hisfog/kitti/effb5_320x1024.txt)"""
+
+    def __init__(self, num_classes=32, decoder_channels=(512, 256, 128, 64, 32), stages=_B5_STAGES):
+        super().__init__()
+        self.encoder = _B5Features(stages)
+        chs = [stages[i][4] for i in (0, 1, 2, 4, 6)]
+        self.decoder = UnetDecoder(chs[::-1], tuple(decoder_channels), num_classes)
 
     def forward(self, x):
         feats = self.encoder(x)

@@ -5,7 +5,13 @@ id, ("K", 0), ("inv_K", 0), "depth_gt", and — with "s" among the frame ids —
 Each sample is a smooth random texture (a few low-frequency sinusoids + 5 % white noise); the -1/+1
 frames are the same texture seen through a known small camera motion over a known smooth depth
 field in [2, 60] m, so the photometric loss has a meaningful minimum.  Intrinsics are
-the normalised KITTI K scaled by the image size (reference datasets/kitti_dataset.py:29-32)."""
+the normalised KITTI K scaled by the image size (reference datasets/kitti_dataset.py:29-32).
+
+scene="waves" (default): the depth field has random phases and nothing in the image tells them — a network cannot learn it, abs_rel stays
+at what a constant prediction gets (~0.9).  scene="road": a driving-scene layout the image does tell — a ground plane below a horizon row
+that varies per sample (camera 1.65 m above it, as on KITTI's car) and a far wall above it, the region above the horizon brighter and the
+ground carrying a depth-scaled stripe pattern — so that self-supervised training brings abs_rel down (tests/test_gpu_abs_rel.py's
+comparison from trained weights)."""
 import math
 
 import numpy as np
@@ -34,14 +40,25 @@ def _texture(gen, height, width, xs, ys):
     return img
 
 
-def make_sample(index, height, width, frame_ids=(0, -1, 1), with_gt=True):
+def make_sample(index, height, width, frame_ids=(0, -1, 1), with_gt=True, scene="waves"):
     gen = torch.Generator().manual_seed(1234 + int(index))
     ys, xs = torch.meshgrid(torch.arange(height, dtype=torch.float32), torch.arange(width, dtype=torch.float32), indexing="ij")
     # a wider canvas so that the source views stay inside the texture
     base = _texture(gen, height, width, xs, ys)
-    depth = 31.0 + 29.0 * torch.sin(0.011 * xs + float(torch.rand(1, generator=gen)) * 6) * \
-        torch.cos(0.023 * ys + float(torch.rand(1, generator=gen)) * 6)
-    depth = depth.clamp(2.0, 60.0)
+    if scene == "road":
+        v = (ys + 0.5) / height
+        v0 = 0.30 + 0.12 * float(torch.rand(1, generator=gen))                 # horizon row (fraction of the height)
+        tilt = (float(torch.rand(1, generator=gen)) - 0.5) * 0.08              # the horizon is not quite level
+        below = v - v0 - tilt * ((xs + 0.5) / width - 0.5)
+        depth = (1.65 * _K_NORM[1, 1] / below.clamp(min=1e-3)).clamp(2.0, 60.0)      # z = h f_y / (y - y_horizon)
+        sky = (below <= 0).float()
+        depth = depth * (1 - sky) + 55.0 * sky
+        stripes = 0.08 * torch.sin(40.0 / depth * 6.0 + 0.05 * xs)             # ground markings: their spacing shrinks with distance
+        base = (base * (0.75 + 0.35 * sky) + stripes * (1 - sky)).clamp(0, 1)
+    else:
+        depth = 31.0 + 29.0 * torch.sin(0.011 * xs + float(torch.rand(1, generator=gen)) * 6) * \
+            torch.cos(0.023 * ys + float(torch.rand(1, generator=gen)) * 6)
+        depth = depth.clamp(2.0, 60.0)
     K, inv_K = intrinsics(height, width)
     sample = {("K", 0): K, ("inv_K", 0): inv_K}
     pix = torch.stack([xs, ys, torch.ones_like(xs)], 0).reshape(3, -1)
@@ -84,9 +101,9 @@ class SyntheticKITTIDataset(Dataset):
         return make_sample(index + self.offset, self.height, self.width, self.frame_ids, self.with_gt)
 
 
-def synthetic_batch(batch_size, height, width, frame_ids=(0, -1, 1), start=0, device=None, with_gt=False):
+def synthetic_batch(batch_size, height, width, frame_ids=(0, -1, 1), start=0, device=None, with_gt=False, scene="waves"):
     """A collated batch (dict of stacked tensors) — what the DataLoader would hand to process_batch."""
-    samples = [make_sample(start + i, height, width, frame_ids, with_gt) for i in range(batch_size)]
+    samples = [make_sample(start + i, height, width, frame_ids, with_gt, scene) for i in range(batch_size)]
     batch = {k: torch.stack([s[k] for s in samples]) for k in samples[0]}
     if device is not None:
         batch = {k: v.to(device) for k, v in batch.items()}

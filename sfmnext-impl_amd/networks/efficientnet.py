@@ -90,6 +90,7 @@ class GenEfficientNet(nn.Module):
     feature list reference Encoder.forward builds (base_encoder.py:63-73) — entries the decoder never reads are None."""
 
     def __init__(self, stages=B5_STAGES, stem=B5_STEM, head=B5_HEAD):
+        """head=None: no conv_head / bn2 (the features_only trunk of `EfficientNetFeatures`)"""
         super().__init__()
         self.conv_stem = nn.Conv2d(3, stem, 3, 2, 0, bias=False)
         self.bn1 = nn.BatchNorm2d(stem, eps=BN_EPS)
@@ -102,10 +103,11 @@ class GenEfficientNet(nn.Module):
                 cin = cout
             blocks.append(nn.Sequential(*stage))
         self.blocks = nn.Sequential(*blocks)
-        self.conv_head = nn.Conv2d(cin, head, 1, bias=False)
-        self.bn2 = nn.BatchNorm2d(head, eps=BN_EPS)
-        self.global_pool = nn.Identity()
-        self.classifier = nn.Identity()
+        if head is not None:
+            self.conv_head = nn.Conv2d(cin, head, 1, bias=False)
+            self.bn2 = nn.BatchNorm2d(head, eps=BN_EPS)
+            self.global_pool = nn.Identity()
+            self.classifier = nn.Identity()
         for m in self.modules():                     # (gen-efficientnet's initialisation: fan-out normal for the convolutions)
             if isinstance(m, nn.Conv2d):
                 fan_out = m.kernel_size[0] * m.kernel_size[1] * m.out_channels // m.groups
@@ -117,6 +119,26 @@ class GenEfficientNet(nn.Module):
         feats = [x, None, None, X.stem_same_conv_bn_act(x, self.conv_stem, self.bn1, "swish")]      # conv_stem, bn1, act1
         for stage in self.blocks:
             feats.append(stage(feats[-1]))
+        if not hasattr(self, "conv_head"):
+            return feats
         feats.append(X.conv2d(feats[-1], self.conv_head))                                           # features[11]
         feats += [None, None, None, None]                    # bn2, act2, global_pool, classifier: never read by the decoder
         return feats
+
+
+class EfficientNetFeatures(GenEfficientNet):
+    """`timm.create_model('tf_efficientnet_b5_ap', features_only=True)` as the reference's `Unet` builds it for
+    `--backbone tf_efficientnet_b5_ap` (reference trainer.py:64, networks/Unet.py:114-118; args_files/hisfog/kitti/effb5_320x1024.txt):
+    the trunk without conv_head, returning the last feature map of every stride — stages 0, 1, 2, 4, 6 = 24 @ /2, 40 @ /4, 64 @ /8,
+    176 @ /16, 512 @ /32 (timm's default out_indices for this family).  timm is not part of the reference tree: restated, parity of
+    the trunk arithmetic UNPINNED like the hub trunk above; state-dict keys conv_stem, bn1, blocks.*"""
+    TAPS = (0, 1, 2, 4, 6)
+
+    def __init__(self, in_channels=3, stages=B5_STAGES, stem=B5_STEM):
+        assert in_channels == 3
+        super().__init__(stages, stem, head=None)
+        self.num_chs = [stages[i][4] for i in self.TAPS]
+
+    def forward(self, x):
+        feats = super().forward(x)                   # [x, None, None, stem, stage 0 .. 6]
+        return [feats[4 + i] for i in self.TAPS]

@@ -1,8 +1,10 @@
 """`Unet` of the reference (networks/Unet.py:9-312): a timm backbone as the encoder of a U-Net whose decoder blocks are
 [bilinear up (to the skip's size, align_corners=True; x2 without a skip, Unet.py:244-251) -> concat -> (conv3x3 -> BN -> ReLU) x 2]
 (Unet.py:211-256) and a final 1x1 convolution (Unet.py:293).  With decoder_channels (1024, 512, 256, 128) on ConvNeXt-L the fourth
-block has no skip and brings stride 4 to stride 2 — the resolution the SQLdepth head works at.  Only the `convnext_large`
-backbone of the reference's configuration (config E) is built: `networks.convnext.ConvNeXtFeatures`.
+block has no skip and brings stride 4 to stride 2 — the resolution the SQLdepth head works at.  Two backbones are built, the ones the
+reference's KITTI args files name: `convnext_large` (`networks.convnext.ConvNeXtFeatures`, config E) and `tf_efficientnet_b5_ap`
+(`networks.efficientnet.EfficientNetFeatures`: five features, decoder_channels (512, 256, 128, 64, 32) — the fifth block has no skip
+and brings stride 2 to the full resolution; args_files/hisfog/kitti/effb5_320x1024.txt).
 State-dict keys as in the reference: encoder.*, decoder.blocks.{i}.conv{1,2}.{conv,bn}.*, decoder.final_conv.*."""
 import torch
 import torch.nn as nn
@@ -10,6 +12,7 @@ import torch.nn as nn
 from sqd import nnops as X
 
 from .convnext import LARGE, ConvNeXtFeatures
+from .efficientnet import EfficientNetFeatures
 
 
 class Conv2dBnAct(nn.Module):
@@ -72,10 +75,13 @@ class Unet(nn.Module):
     def __init__(self, backbone="convnext_large", pretrained=True, in_channels=3, num_classes=5, decoder_channels=(1024, 512, 256, 128),
                  depths=None, dims=None, **_ignored):
         super().__init__()
-        if backbone != "convnext_large":
-            raise NotImplementedError("Unet: only the convnext_large backbone of the reference's configuration is built (got %r)" % backbone)
+        if backbone not in ("convnext_large", "tf_efficientnet_b5_ap"):
+            raise NotImplementedError("Unet: the backbones of the reference's args files are built — convnext_large, tf_efficientnet_b5_ap (got %r)" % backbone)
         # (pretrained=True would download ImageNet weights through timm in the reference; there is no network here: random init)
-        self.encoder = ConvNeXtFeatures(in_channels, depths or LARGE["depths"], dims or LARGE["dims"])
+        if backbone == "tf_efficientnet_b5_ap":
+            self.encoder = EfficientNetFeatures(in_channels, **({"stages": _ignored["stages"]} if "stages" in _ignored else {}))
+        else:
+            self.encoder = ConvNeXtFeatures(in_channels, depths or LARGE["depths"], dims or LARGE["dims"])
         self.decoder = UnetDecoder(self.encoder.num_chs[::-1], tuple(decoder_channels), num_classes)
 
     def forward(self, x):

@@ -122,6 +122,9 @@ EXTRA_FLAGS = [
                                       "BatchNorm, losses, weight gradients and Adam stay fp32) — BASELINE.json configs[3]"}),
     ("sqd_no_f16x2", _T, False, {"help": "keep the convolutions off the two-term fp16 operand plans (power-of-two scaled operands, three products on the fp16 "
                                           "matrix cores, fp32 accumulation: fp32-level accuracy) — the plan space of round 4: three-term bf16 and fp32 MFMA"}),
+    ("sqd_graph_wgrad_batch", int, 0, {"help": "inside the captured step, run the weight gradients of once-used filters on a side branch, one cross-branch "
+                                                "dependency per this many convolutions (0: on the capturing stream, with their split sums riding on the next "
+                                                "BatchNorm-backward launch)"}),
     ("sqd_no_conv_tune", _T, False, {"help": "keep the cost-model convolution plans instead of timing tile / split-K plans per layer in the first step"}),
     ("sqd_conv_plans", str, None, {"help": "JSON file of convolution plans (written by --sqd_save_conv_plans): pins every listed layer's kernel, "
                                         "tile and split instead of timing them in the first step — last-bit reproducible across boxes"}),

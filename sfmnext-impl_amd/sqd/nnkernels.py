@@ -525,7 +525,9 @@ def _tune_wgrad(geom, has_bias, launch, launch_t=None, scaled=False):
     if TUNE_SPACE["wgrad_direct3"]:
         # pixel splits for a whole number of workgroup rounds: the 64x64 and 128x64 tiles keep two workgroups per CU resident, the
         # 64x128 and 128x128 ones one
-        for v, (tk, tc), per_cu in ((0, (64, 64), 2), (3, (128, 64), 2), (4, (64, 128), 1), (5, (128, 128), 1), (6, (128, 64), 1), (7, (64, 64), 1)):
+        for v, (tk, tc), per_cu in ((0, (64, 64), 2), (1, (64, 32), 2), (2, (32, 64), 2), (3, (128, 64), 2), (4, (64, 128), 1), (5, (128, 128), 1), (6, (128, 64), 1), (7, (64, 64), 1)):
+            if v in (1, 2) and K % 64 == 0 and C % 64 == 0:     # (the half-width tiles are for the 32-filter / 32-channel layers the 64x64 tile does not divide)
+                continue
             if K % tk or C % tc or (per_cu == 1 and v < 6 and not TUNE_SPACE["wgrad_direct3_wide"]) or (v >= 6 and not TUNE_SPACE["wgrad_direct3_8w"]):
                 continue
             tiles = (K // tk) * (C // tc) * R * S

@@ -149,8 +149,9 @@ class Trainer:
             return networks.ResnetEncoderDecoder(num_layers=o.num_layers, num_features=o.num_features, model_dim=o.model_dim)
         if o.backbone == "resnet18_lite":
             return networks.LiteResnetEncoderDecoder(model_dim=o.model_dim)
-        if o.backbone in ("eff_b5", "tf_efficientnet_b5_ap"):
+        if o.backbone == "eff_b5":
             return networks.BaseEncoder.build(num_features=o.num_features, model_dim=o.model_dim)
+        # every other name is a timm backbone under the U-Net decoder (reference trainer.py:63-64): convnext_large, tf_efficientnet_b5_ap
         return networks.Unet(pretrained=(not o.load_pretrained_model), backbone=o.backbone, in_channels=3,
                              num_classes=o.model_dim, decoder_channels=o.dec_channels)
 
@@ -391,7 +392,9 @@ class Trainer:
     def _backward(self, loss):
         # eager steps: the convolutions' weight gradients run on their own stream, next to the data gradients (-0.8 ms per
         # step).  Not inside a capture: a hipGraph with ~110 extra cross-branch edges replays 1.3 ms slower than the linear one.
-        nnkernels.WGRAD_STREAM = None if getattr(self, "_capturing", False) else self._wgrad_stream
+        gb = int(getattr(self.opt, "sqd_graph_wgrad_batch", 0) or 0)
+        nnkernels.WGRAD_STREAM = None if getattr(self, "_capturing", False) and gb <= 0 else self._wgrad_stream
+        nnkernels.WGRAD_BATCH = gb if getattr(self, "_capturing", False) and gb > 0 else 1
         nnkernels.DEFER_WGRAD_REDUCE = self._defer_wgrad_reduce
         # (the first multi-rank step builds the buckets from whatever gradients exist: nothing to announce yet)
         nnkernels.DEFERRED_GRAD_HOOK = self.reducer.on_deferred_grad if self.reducer is not None and self.reducer.buckets is not None else None

@@ -262,3 +262,90 @@ def test_effb5_bf16_step_matches_bf16_oracle(H, W, B, nf, patch, Q, dout):
     rm = tr.models["encoder"].encoder.original_model.blocks[3][2].bn1.running_var.cpu()
     rr = nets16["encoder"].encoder.original_model.blocks[3][2].bn1.running_var
     assert float((rm - rr).abs().max() / rr.abs().max()) < 1e-3
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# `--backbone tf_efficientnet_b5_ap` (args_files/hisfog/kitti/effb5_320x1024.txt): the reference's trainer.py:63-64 builds networks.Unet
+# on timm's features_only trunk — five features, decoder_channels (512, 256, 128, 64, 32), output at the full image resolution.
+def test_unet_b5_matches_oracle():
+    """networks.Unet(backbone='tf_efficientnet_b5_ap') — the full 39-block trunk without conv_head under the reference's U-Net decoder —
+    against the oracle: output at full resolution, gradients of the stem, a mid-trunk depthwise filter, the last stage, the skip-less
+    fifth decoder block and the final 1x1"""
+    sys.path.insert(0, REPO)
+    import networks
+    from oracle import torch_ref as O
+    torch.manual_seed(5)
+    ref = O.UnetB5(num_classes=32, decoder_channels=(128, 64, 32, 16, 16))
+    mine = networks.Unet(backbone="tf_efficientnet_b5_ap", num_classes=32, decoder_channels=(128, 64, 32, 16, 16))
+    assert sorted(mine.state_dict().keys()) == sorted(ref.state_dict().keys())
+    ref.load_state_dict(mine.state_dict())
+    mine = mine.cuda().to(memory_format=torch.channels_last)
+    ref.train(); mine.train()
+    B, H, W = 2, 64, 96
+    x = torch.rand(B, 3, H, W)
+    g = torch.randn(B, 32, H, W)
+    yr = ref(x)
+    assert yr.shape == (B, 32, H, W)
+    yr.backward(g)
+    y = mine(x.cuda().contiguous(memory_format=torch.channels_last))
+    assert y.shape == (B, 32, H, W)
+    y.backward(g.cuda())
+    assert _rel(y, yr) < 2e-4, _rel(y, yr)
+    P, R = dict(mine.named_parameters()), dict(ref.named_parameters())
+    for name in ("encoder.conv_stem.weight", "encoder.blocks.2.1.conv_dw.weight", "encoder.blocks.6.2.conv_pwl.weight", "encoder.blocks.4.3.bn2.weight",
+                 "decoder.blocks.0.conv1.conv.weight", "decoder.blocks.4.conv1.conv.weight", "decoder.blocks.4.conv2.bn.weight", "decoder.final_conv.bias"):
+        e = _rel(P[name].grad, R[name].grad)
+        print("%-48s rel grad err %.2e" % (name, e))
+        assert e < 2e-3, (name, e)
+
+
+def test_effb5_unet_train_step_matches_oracle():
+    """one optimisation step of the Trainer under the flags of args_files/hisfog/kitti/effb5_320x1024.txt (backbone tf_efficientnet_b5_ap,
+    dec_channels 512 256 128 64 32, model_dim 32, patch 32, 128 queries, dim_out 128, --use_stereo --diff_lr: three source frames) at 160x512 —
+    the smallest size at which a 32-pixel patch grid still yields the 128 queries the head slices (reference depth_decoder_QTR.py:46) —
+    batch 1, against the oracle; plans measured in the step"""
+    sys.path.insert(0, REPO)
+    from oracle import torch_ref as O
+    from options import MonodepthOptions
+    from trainer import Trainer
+    from datasets.synthetic import synthetic_batch
+    from sqd import nnkernels
+    nnkernels.reset_plans()
+    H, W, B, patch, Q, dout = 192, 704, 1, 32, 128, 128           # 6 x 22 = 132 tokens >= 128 queries
+    args = ["--backbone", "tf_efficientnet_b5_ap", "--dec_channels", "512", "256", "128", "64", "32", "--model_dim", "32", "--patch_size", str(patch),
+            "--query_nums", str(Q), "--dim_out", str(dout), "--height", str(H), "--width", str(W), "--batch_size", str(B), "--num_workers", "0",
+            "--sqd_synthetic", "--log_dir", "/tmp/sqd_effb5_unet_test", "--min_depth", "0.001", "--max_depth", "80.0", "--use_stereo", "--diff_lr",
+            "--sqd_no_graph"]
+    torch.manual_seed(0)
+    tr = Trainer(MonodepthOptions().parse(args))
+    tr.set_train()
+    for m in tr.models.values():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+    enc = O.UnetB5(num_classes=32, decoder_channels=(512, 256, 128, 64, 32))
+    dep = O.QueryTrDecoder(32, 32, patch, 4, Q, dout, min_val=0.001, max_val=80.0, dim_feedforward=1024, dropout=0.0)
+    pose = O.PoseCNN(2)
+    for ref, mine in ((enc, tr.models["encoder"]), (dep, tr.models["depth"]), (pose, tr.models["pose"])):
+        ref.load_state_dict({k: v.detach().cpu() for k, v in mine.state_dict().items()})
+        ref.train()
+    frames = (0, -1, 1, "s")
+    cpu_inputs = synthetic_batch(B, H, W, frame_ids=frames)
+    noise = torch.randn(B, 3, H, W)
+    ref = O.RefTrainStep(enc, dep, pose, frames, H, W, use_stereo=True, diff_lr=True)
+    ref_out, ref_losses = ref.step(dict(cpu_inputs), noise)
+    inputs = {k: v.cuda() for k, v in cpu_inputs.items()}
+    inputs[("noise", 0)] = noise.cuda()
+    try:
+        outputs, losses = tr.train_step(inputs)
+        torch.cuda.synchronize()
+    finally:
+        nnkernels.reset_plans()
+    got, want = float(losses["loss"]), float(ref_losses["loss"])
+    print("tf_efficientnet_b5_ap U-Net %dx%d: loss %.7f oracle %.7f (rel %.2e)" % (H, W, got, want, abs(got - want) / abs(want)))
+    assert abs(got - want) <= 2e-4 * abs(want), (got, want)
+    d, dr = outputs[("disp", 0)].detach().cpu(), ref_out[("disp", 0)].detach()
+    assert d.shape[-2:] == (H, W)                        # the head works at the full resolution under this encoder
+    assert float((d - dr).abs().max()) <= 5e-4 * float(dr.abs().max())

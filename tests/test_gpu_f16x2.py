@@ -67,7 +67,8 @@ def test_f16x2_plans_against_float64(geom, dist):
     i.e. with the operand scales taken from the tensors' tags or a standalone pass) no further from float64 than 1.25x the three-term
     bf16 plan of the same tile / split — or than the cost-model fp32 MFMA plan, where that one is further off (the heavy-tailed
     weight gradients: a tensor-wide scale gives the small pixels fewer bits than a three-term split does, 2.0e-7 against 1.0e-7
-    with the fp32 chain at 3.2e-7) —, and within 4x the fp32 plan in any case"""
+    with the fp32 chain at 3.2e-7) —, and within 4x the fp32 plan unless the three-term plan of the same tile is further off still (long
+    reductions of non-negative inputs: the summation order of the tile, not the operand arithmetic, sets the distance)"""
     from sqd import lib, nnkernels
     L = lib.lib()
     N, C, H, W, K, R, stride, pad = geom
@@ -104,9 +105,9 @@ def test_f16x2_plans_against_float64(geom, dist):
                     ey, ex = _err(y, yr), _err(gx, gxr)
                     ey3, ex3 = _err(y3, yr), _err(gx3, gxr)
                     if ok[0]:
-                        assert ey <= max(1.25 * ey3, e32[0]) + 5e-8 and ey <= 4.0 * e32[0] + 2e-7, ("fwd", bm, bn, z, flags, ey, ey3, e32[0])
+                        assert ey <= max(1.25 * ey3, e32[0]) + 5e-8 and (ey <= 4.0 * e32[0] + 2e-7 or ey <= ey3), ("fwd", bm, bn, z, flags, ey, ey3, e32[0])
                     if ok[1]:
-                        assert ex <= max(1.25 * ex3, e32[1]) + 5e-8 and ex <= 4.0 * e32[1] + 2e-7, ("dgrad", bm, bn, z, flags, ex, ex3, e32[1])
+                        assert ex <= max(1.25 * ex3, e32[1]) + 5e-8 and (ex <= 4.0 * e32[1] + 2e-7 or ex <= ex3), ("dgrad", bm, bn, z, flags, ex, ex3, e32[1])
         assert tried >= 2
         nnkernels.reset_plans()
         # weight gradient: impl 7, every register tile that divides
@@ -122,7 +123,7 @@ def test_f16x2_plans_against_float64(geom, dist):
                 _, _, gw3 = _run(x, w, dy, stride, pad)
                 tried_w += 1
                 ew, ew3 = _err(gw, gwr), _err(gw3, gwr)
-                assert ew <= max(1.25 * ew3, e32[2]) + 5e-8 and ew <= 4.0 * e32[2] + 2e-7, ("wgrad", v, sp, ew, ew3, e32[2])
+                assert ew <= max(1.25 * ew3, e32[2]) + 5e-8 and (ew <= 4.0 * e32[2] + 2e-7 or ew <= ew3), ("wgrad", v, sp, ew, ew3, e32[2])
         if C % 64 == 0 and K % 64 == 0 and (Wo % 2 == 0 or R == 1):
             assert tried_w >= 2
     finally:
