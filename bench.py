@@ -50,7 +50,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r04_pmc_traffic.json")
+PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r05_pmc_traffic.json")
 
 
 def roofline_fused_fwd(trainer, batches, iters=200, graph_us=None):
