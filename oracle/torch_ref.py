@@ -126,7 +126,7 @@ def upsample_disp(disp: torch.Tensor, H: int, W: int) -> torch.Tensor:
 def generate_images_pred(disp: torch.Tensor, poses: Dict[int, Tuple[torch.Tensor, torch.Tensor]],
                          K: torch.Tensor, inv_K: torch.Tensor, colors: Dict[int, torch.Tensor],
                          frame_ids: Sequence[int], H: int, W: int, stereo_T: torch.Tensor = None,
-                         use_stereo: bool = False) -> Dict:
+                         use_stereo: bool = False, cam_T_cam: Dict = None) -> Dict:
     """reference trainer.py:386-439, posecnn branch (scale 0 only).
 
     poses[f] = (axisangle [B,1,1,3], translation [B,1,1,3]) for the temporal frames; frame id "s" (the other stereo camera)
@@ -141,7 +141,10 @@ def generate_images_pred(disp: torch.Tensor, poses: Dict[int, Tuple[torch.Tensor
             T = stereo_T                                                       # :406-407
         else:
             axisangle, translation = poses[f]
-            T = transformation_from_parameters(axisangle[:, 0], translation[:, 0], f < 0)   # cam_T_cam, :336-337 / :409
+            if cam_T_cam is not None:                                          # :409 (predict_poses' matrix: --pose_model_input all, :358-359)
+                T = cam_T_cam[f]
+            else:
+                T = transformation_from_parameters(axisangle[:, 0], translation[:, 0], f < 0)   # cam_T_cam, :336-337 / :409
             if not use_stereo:                                                 # :412
                 inv_depth = 1 / depth                                          # :417
                 mean_inv_depth = inv_depth.mean(3, True).mean(2, True)         # :418
@@ -240,10 +243,10 @@ def compute_losses(disp: torch.Tensor, target: torch.Tensor, warped: Dict[int, t
 
 
 def photometric_chain(disp, poses, K, inv_K, colors, frame_ids, noise, H, W, disparity_smoothness=1e-3, stereo_T=None,
-                      use_stereo=False, **loss_options):
+                      use_stereo=False, cam_T_cam=None, **loss_options):
     """generate_images_pred + compute_losses in one call (what process_batch does after the networks,
     reference trainer.py:296-297)."""
-    out = generate_images_pred(disp, poses, K, inv_K, colors, frame_ids, H, W, stereo_T, use_stereo)
+    out = generate_images_pred(disp, poses, K, inv_K, colors, frame_ids, H, W, stereo_T, use_stereo, cam_T_cam)
     warped = {f: out[("color", f, 0)] for f in frame_ids[1:]}
     sources = {f: colors[f] for f in frame_ids[1:]}
     losses = compute_losses(disp, colors[0], warped, sources, frame_ids, noise, H, W, disparity_smoothness, **loss_options)
@@ -810,8 +813,9 @@ class RefTrainStep:
     on the CPU RNG)."""
 
     def __init__(self, encoder, depth, pose, frame_ids=(0, -1, 1), H=192, W=640, lr=1e-4,
-                 disparity_smoothness=1e-3, use_stereo=False, diff_lr=False):
+                 disparity_smoothness=1e-3, use_stereo=False, diff_lr=False, pose_model_input="pairs"):
         self.models = {"encoder": encoder, "depth": depth, "pose": pose}
+        self.pose_model_input = pose_model_input
         self.frame_ids, self.H, self.W = list(frame_ids), H, W
         self.use_stereo = use_stereo                     # frame_ids then end with "s" (reference trainer.py:52-53)
         self.smooth_w = disparity_smoothness
@@ -825,6 +829,10 @@ class RefTrainStep:
     def predict_poses(self, inputs):
         """reference trainer.py:301-337 (pairs / posecnn)."""
         poses = {}
+        if self.pose_model_input == "all":                                # :339-361: every temporal frame through ONE pass
+            x = torch.cat([inputs[("color_aug", f, 0)] for f in self.frame_ids if f != "s"], 1)
+            axisangle, translation = self.models["pose"](x)
+            return {f: (axisangle, translation) for f in self.frame_ids[1:] if f != "s"}
         for f in self.frame_ids[1:]:
             if f == "s":                                                  # :317
                 continue
@@ -838,15 +846,19 @@ class RefTrainStep:
         outputs = self.models["depth"](feats)                            # :288
         poses = self.predict_poses(inputs)                               # :294
         colors = {f: inputs[("color", f, 0)] for f in self.frame_ids}
+        cam_T_cam = None
+        if self.pose_model_input == "all":                               # :355-359: pose i of the shared tensors, not inverted
+            cam_T_cam = {f: transformation_from_parameters(poses[f][0][:, i], poses[f][1][:, i])
+                         for i, f in enumerate(self.frame_ids[1:]) if f != "s"}
         chain = photometric_chain(outputs[("disp", 0)], poses, inputs[("K", 0)], inputs[("inv_K", 0)],
                                   colors, self.frame_ids, noise, self.H, self.W, self.smooth_w,
-                                  inputs.get("stereo_T"), self.use_stereo)
+                                  inputs.get("stereo_T"), self.use_stereo, cam_T_cam)
         outputs.update(chain)
         for f in self.frame_ids[1:]:
             if f == "s":
                 continue
             outputs[("axisangle", 0, f)], outputs[("translation", 0, f)] = poses[f]
-            outputs[("cam_T_cam", 0, f)] = transformation_from_parameters(
+            outputs[("cam_T_cam", 0, f)] = cam_T_cam[f] if cam_T_cam is not None else transformation_from_parameters(
                 poses[f][0][:, 0], poses[f][1][:, 0], invert=(f < 0))   # :336-337
         return outputs, {"loss": chain["loss"], "loss/0": chain["loss/0"]}
 

@@ -135,13 +135,22 @@ class Trainer:
     def _check_supported(self):
         o = self.opt
         unsupported = [n for n in ("v1_multiscale", "predictive_mask") if getattr(o, n)]
-        if unsupported or list(o.scales) != [0] or o.pose_model_type != "posecnn" or o.pose_model_input != "pairs":
+        if unsupported or list(o.scales) != [0] or o.pose_model_type != "posecnn" or o.pose_model_input not in ("pairs", "all"):
             raise NotImplementedError("MI355X hot path implements the reference's KITTI mono configuration "
-                                      "(scale 0, posecnn pairs; --no_ssim / --avg_reprojection / --disable_automasking included); got %s scales=%s pose=%s/%s"
-                                      % (unsupported, o.scales, o.pose_model_type, o.pose_model_input))
+                                      "(scale 0, posecnn on pairs or on all frames; --no_ssim / --avg_reprojection / --disable_automasking included); "
+                                      "got %s scales=%s pose=%s/%s" % (unsupported, o.scales, o.pose_model_type, o.pose_model_input))
+        # any temporal neighbours (reference trainer.py:315-337 loops over frame_ids[1:]; args_files/hisfog/mc and nyu train on 0 -8 8 and
+        # 0 -16 16), optionally with the stereo frame; the photometric kernels take up to SQD_MAX_SOURCES source frames
         temporal = [f for f in o.frame_ids if f != "s"]
-        if temporal not in ([0, -1, 1], [0]) or (temporal == [0] and not o.use_stereo):
-            raise NotImplementedError("frame_ids must be [0, -1, 1] (optionally with --use_stereo) or [0] with --use_stereo; got %s" % o.frame_ids)
+        if any(not isinstance(f, int) for f in temporal) or temporal[0] != 0 or len(set(temporal)) != len(temporal) or \
+                (temporal == [0] and not o.use_stereo):
+            raise NotImplementedError("frame_ids must be 0 followed by distinct temporal offsets (optionally with --use_stereo), or [0] with "
+                                      "--use_stereo; got %s" % o.frame_ids)
+        if len(temporal) - 1 + (1 if (o.use_stereo or "s" in o.frame_ids) else 0) > _sqd_lib.MAX_SOURCES:
+            raise NotImplementedError("the photometric kernels take at most %d source frames (SQD_MAX_SOURCES); got frame_ids %s"
+                                      % (_sqd_lib.MAX_SOURCES, o.frame_ids))
+        if o.pose_model_input == "all" and 6 * (len(temporal) - 1) > 16:
+            raise NotImplementedError("--pose_model_input all: the pose head kernel writes at most 16 channels (3 temporal frames); got %s" % o.frame_ids)
 
     def _build_encoder(self):
         o = self.opt
@@ -531,6 +540,8 @@ class Trainer:
         # Row b*S + i of the batch is pair i of sample b, so that the head's outputs ARE the [B,S,3] axis-angle / translation
         # arrays the photometric chain reads (no slicing, cat or copies in between, forward or backward).
         B, S = aug[0].shape[0], len(srcs)
+        if self.num_pose_frames != 2:
+            return self._predict_poses_all(aug, srcs)
         pairs = [((aug[f], aug[0]) if f < 0 else (aug[0], aug[f])) for f in srcs]
         axisangle, translation = self.models["pose"].forward_pairs(pairs)      # [B*S,1,1,3] each; the 6-channel batch is never built
         if not (axisangle.is_contiguous() and translation.is_contiguous()):
@@ -548,6 +559,26 @@ class Trainer:
             outputs[("cam_T_cam", 0, f)] = T_all[:, i]
         # generate_images_pred reads the [B,S,3] arrays as they are when it is handed these very outputs
         self._pose_all = (aa_all, tr_all, tuple(outputs[("axisangle", 0, f)] for f in srcs))
+        return outputs
+
+    def _predict_poses_all(self, aug, srcs):
+        """--pose_model_input all (reference trainer.py:339-361): ONE pass of the pose network over the channel concatenation of every
+        temporal frame, in frame_ids order; pose i of its [B, F-1, 1, 3] outputs belongs to frame_ids[1 + i], none is inverted, and every
+        frame's ("axisangle", 0, f) / ("translation", 0, f) entry is the whole tensor."""
+        outputs = {}
+        x = torch.cat([aug[f] for f in [0] + srcs], 1).contiguous()                      # [B, 3 F, H, W]
+        axisangle, translation = self.models["pose"](x)                                   # [B, F-1, 1, 3] each
+        B, S = x.shape[0], len(srcs)
+        aa_all, tr_all = axisangle.reshape(B, S, 3), translation.reshape(B, S, 3)
+        eye = getattr(self, "_eye4", None)
+        if eye is None or eye.shape[0] != B or eye.device != aa_all.device:
+            eye = self._eye4 = torch.eye(4, device=aa_all.device).repeat(B, 1, 1)
+        _, T_all, _ = ops.pose_mats_fwd(aa_all.detach().contiguous(), tr_all.detach().contiguous(), [0] * S, eye)
+        for i, f in enumerate(srcs):
+            outputs[("axisangle", 0, f)] = axisangle
+            outputs[("translation", 0, f)] = translation
+            outputs[("cam_T_cam", 0, f)] = T_all[:, i]
+        self._pose_all = None
         return outputs
 
     def generate_images_pred(self, inputs, outputs):
@@ -569,14 +600,21 @@ class Trainer:
         if pose_ids and cached is not None and len(cached[2]) == len(pose_ids) and \
                 all(outputs[("axisangle", 0, f)] is t for f, t in zip(pose_ids, cached[2])):
             aa, tr = cached[:2]                                                                          # [B,Sp,3] (predict_poses)
+        elif pose_ids and self.num_pose_frames != 2 and o.use_stereo:
+            # --pose_model_input all with --use_stereo: T is cam_T_cam of predict_poses (reference trainer.py:408, 412): pose i, not inverted
+            aa = outputs[("axisangle", 0, pose_ids[0])][:, :len(pose_ids), 0].contiguous()
+            tr = outputs[("translation", 0, pose_ids[0])][:, :len(pose_ids), 0].contiguous()
         elif pose_ids:
+            # (with --pose_model_input all and no stereo frame the reference rebuilds T from axisangle[:, 0] / translation[:, 0] of the
+            # shared [B, F-1, 1, 3] tensors for EVERY frame, inverted for negative ids — trainer.py:414-421 — and so does this)
             aa = torch.cat([outputs[("axisangle", 0, f)][:, 0] for f in pose_ids], 1).contiguous()
             tr = torch.cat([outputs[("translation", 0, f)][:, 0] for f in pose_ids], 1).contiguous()
         else:
             aa = tr = torch.zeros(B, 0, 3, device=self.device)
         # --use_stereo: T of the temporal frames is the un-scaled cam_T_cam, T of "s" is inputs["stereo_T"] (reference
         # trainer.py:405-421: the mean-inverse-depth scaling of the translation is skipped)
-        meta = dict(H=o.height, W=o.width, invert=[1 if f < 0 else 0 for f in pose_ids], smooth_weight=o.disparity_smoothness,
+        all_stereo = self.num_pose_frames != 2 and o.use_stereo
+        meta = dict(H=o.height, W=o.width, invert=[1 if (f < 0 and not all_stereo) else 0 for f in pose_ids], smooth_weight=o.disparity_smoothness,
                     use_stereo=bool(o.use_stereo), stereo_T=inputs["stereo_T"] if "s" in srcs_ids else None,
                     loss_flags=self._loss_flags())
         srcs = [inputs[("color", f, 0)].contiguous() for f in srcs_ids]

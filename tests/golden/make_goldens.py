@@ -25,7 +25,7 @@ REPO = os.path.dirname(os.path.dirname(HERE))
 REF = "/root/reference"
 sys.path.insert(0, HERE)
 sys.path.insert(0, REPO)
-from param_fill import chain_inputs, decoder_feats, fill_params, kitti_K, smooth_images, sparse_gt  # noqa: E402
+from param_fill import chain_inputs, decoder_feats, fill_params, kitti_K, pose_input_case, smooth_images, sparse_gt  # noqa: E402
 
 from oracle import torch_ref as O  # noqa: E402  (only for the build's ResNet trunk plugged into G15)
 
@@ -277,6 +277,41 @@ def g17_stereo_chain(T):
          color_m1=outputs[("color", -1, 0)], color_p1=outputs[("color", 1, 0)], color_s=outputs[("color", "s", 0)],
          loss=losses["loss"], identity_selection=outputs["identity_selection/0"], grad_disp=disp.grad,
          grad_axisangle_m1=aa[-1].grad, grad_axisangle_p1=aa[1].grad, grad_translation_m1=tr[-1].grad, grad_translation_p1=tr[1].grad)
+
+
+def g24_pose_inputs(T):
+    """predict_poses -> generate_images_pred -> compute_losses of the reference itself for the pose-input variants of trainer.py:301-361:
+    "all" (ONE pass of PoseCNN(3) over the concatenated frames; without a stereo frame :414-421 rebuild T of EVERY frame from pose 0 of the
+    shared tensors, with --use_stereo T = cam_T_cam of pose i) and pairs on temporal offsets other than +-1 (frame_ids 0 -2 1)."""
+    nets = {"pose_cnn": importlib.import_module("networks.pose_cnn")}
+    B, H, W = 2, 64, 96
+    for name, frame_ids, mode, stereo in (("all", (0, -1, 1), "all", False), ("all_stereo", (0, -1, 1), "all", True),
+                                          ("pairs_m2_p1", (0, -2, 1), "pairs", False)):
+        seed = 2400 + len(name)
+        fids, np_inputs, np_disp, np_noise = pose_input_case(seed, B, H, W, frame_ids, stereo)
+        shim = make_shim(T, B, H, W, frame_ids=fids)
+        shim.opt.use_stereo, shim.opt.pose_model_input = stereo, mode
+        shim.num_pose_frames = 2 if mode == "pairs" else len(frame_ids)
+        pose = fill_params(nets["pose_cnn"].PoseCNN(shim.num_pose_frames), seed + 2)
+        shim.models = {"pose": pose}
+        inputs = {k: tt(v) for k, v in np_inputs.items()}
+        stereo_T = tt(np_inputs["stereo_T"]) if stereo else torch.eye(4).repeat(B, 1, 1)
+        disp = tt(np_disp).requires_grad_(True)
+        outputs = {("disp", 0): disp}
+        outputs.update(T.Trainer.predict_poses(shim, inputs, None))
+        T.Trainer.generate_images_pred(shim, inputs, outputs)
+        with patched_randn(tt(np_noise)):
+            losses = T.Trainer.compute_losses(shim, inputs, outputs)
+        losses["loss"].backward()
+        f1, f2 = frame_ids[1], frame_ids[2]
+        save("g24_pose_inputs_" + name, seed=seed, B=B, H=H, W=W, stereo=np.array(stereo), mode=np.array(mode),
+             frame_ids=np.array([str(f) for f in fids]), stereo_T=stereo_T,
+             axisangle_f1=outputs[("axisangle", 0, f1)], translation_f2=outputs[("translation", 0, f2)],
+             cam_T_cam_f1=outputs[("cam_T_cam", 0, f1)], cam_T_cam_f2=outputs[("cam_T_cam", 0, f2)],
+             sample_f1=outputs[("sample", f1, 0)], sample_f2=outputs[("sample", f2, 0)],
+             color_f1=outputs[("color", f1, 0)], color_f2=outputs[("color", f2, 0)], loss=losses["loss"],
+             identity_selection=outputs["identity_selection/0"], grad_disp=disp.grad,
+             grad_pose_conv=pose.pose_conv.weight.grad, grad_pose_w0=pose.net[0].weight.grad)
 
 
 def g9_smooth(T):
@@ -580,6 +615,7 @@ def main():
     g21_silog(T)
     g22_metric_errors(T)
     g23_loss_options(T)
+    g24_pose_inputs(T)
     g1_pose(T)
     g2_g3_g4_geometry(T)
     g5_g6_ssim(T)

@@ -93,3 +93,21 @@ def sparse_gt(seed: int, B: int):
     gt = rs.uniform(0.5, 80, (B, 1, 375, 1242)).astype(np.float32)
     gt[rs.uniform(size=gt.shape) < 0.7] = 0
     return gt
+
+
+def pose_input_case(seed: int, B: int, H: int, W: int, frame_ids, stereo: bool):
+    """Inputs of fixture group G24 (predict_poses -> generate_images_pred -> compute_losses under the pose-input variants): the frames
+    of chain_inputs() keyed as the trainer's inputs dict (numpy arrays), colour-augmented copies, stereo_T, disp, noise."""
+    fids = list(frame_ids) + (["s"] if stereo else [])
+    d = chain_inputs(seed, B, H, W, S=len(fids) - 1)
+    rs = np.random.RandomState(seed + 1)
+    inputs = {("K", 0): d["K"], ("inv_K", 0): d["inv_K"]}
+    for i, f in enumerate(fids):
+        img = d["color0"] if f == 0 else d["color_s%d" % (i - 1)]
+        inputs[("color", f, 0)] = img
+        inputs[("color_aug", f, 0)] = np.clip(img * rs.uniform(0.9, 1.1) + rs.uniform(-0.03, 0.03), 0, 1).astype(np.float32)
+    stereo_T = np.repeat(np.eye(4, dtype=np.float32)[None], B, 0)
+    stereo_T[0, 0, 3], stereo_T[1, 0, 3] = -0.1, 0.1
+    if stereo:
+        inputs["stereo_T"] = stereo_T
+    return fids, inputs, d["disp"], d["noise"]

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from conftest import tt
-from param_fill import chain_inputs, decoder_feats, fill_params, smooth_images
+from param_fill import chain_inputs, decoder_feats, fill_params, pose_input_case, smooth_images
 
 pytestmark = pytest.mark.gpu
 RTOL, ATOL = 1e-4, 1e-6
@@ -195,3 +195,59 @@ def test_g15_g16_trainer_steps(golden, kind):
     adam_close(tr.models["encoder"].encoder.encoder.conv1.weight, g16["enc_conv1_after"], frac=5e-3 if kind == "res18" else 2.5e-2)
     adam_close(tr.models["pose"].pose_conv.weight, g16["pose_conv_after"])
     adam_close(tr.models["depth"].conv3x3.weight, g16["depth_conv3x3_after"])
+
+
+@pytest.mark.parametrize("name", ["all", "all_stereo", "pairs_m2_p1"])
+def test_g24_pose_input_variants(golden, name):
+    """Trainer.predict_poses -> generate_images_pred -> compute_losses (+ backward) with --pose_model_input all, with and without --use_stereo,
+    and with pairs on frame_ids 0 -2 1 (reference trainer.py:301-361, 404-421) against the reference's own run of the same methods."""
+    from options import MonodepthOptions
+    from trainer import Trainer
+    g = golden("g24_pose_inputs_" + name)
+    B, H, W, seed, stereo, mode = int(g["B"]), int(g["H"]), int(g["W"]), int(g["seed"]), bool(g["stereo"]), str(g["mode"])
+    fids = [f if f == "s" else int(f) for f in g["frame_ids"]]
+    temporal = [f for f in fids if f != "s"]
+    _, np_inputs, np_disp, np_noise = pose_input_case(seed, B, H, W, temporal, stereo)
+    args = ["--backbone", "resnet18_lite", "--model_dim", "16", "--patch_size", "8", "--query_nums", "12", "--dim_out", "24", "--height", str(H),
+            "--width", str(W), "--batch_size", str(B), "--num_workers", "0", "--sqd_synthetic", "--min_depth", "0.001", "--max_depth", "80.0",
+            "--log_dir", "/tmp/sqd_g24_test", "--sqd_no_graph", "--sqd_no_conv_tune", "--pose_model_input", mode,
+            "--frame_ids"] + [str(f) for f in temporal] + (["--use_stereo"] if stereo else [])
+    tr = Trainer(MonodepthOptions().parse(args))
+    assert tr.opt.frame_ids == fids
+    fill_params(tr.models["pose"], seed + 2)
+    tr.set_train()
+    inputs = {k: tt(v).cuda() for k, v in np_inputs.items()}
+    inputs[("noise", 0)] = tt(np_noise).cuda()
+    disp = tt(np_disp).cuda().requires_grad_(True)
+    outputs = {("disp", 0): disp}
+    outputs.update(tr.predict_poses(inputs, None))
+    tr.generate_images_pred(inputs, outputs)
+    losses = tr.compute_losses(inputs, outputs)
+    f1, f2 = temporal[1], temporal[2]
+    assert tuple(outputs[("axisangle", 0, f1)].shape) == tuple(g["axisangle_f1"].shape)
+    close(outputs[("axisangle", 0, f1)], g["axisangle_f1"], atol=1e-7)
+    close(outputs[("translation", 0, f2)], g["translation_f2"], atol=1e-7)
+    close(outputs[("cam_T_cam", 0, f1)], g["cam_T_cam_f1"], atol=1e-6)
+    close(outputs[("cam_T_cam", 0, f2)], g["cam_T_cam_f2"], atol=1e-6)
+    for f, n in ((f1, "f1"), (f2, "f2")):
+        close(outputs[("sample", f, 0)], g["sample_" + n], atol=2e-6)
+        close(outputs[("color", f, 0)], g["color_" + n], atol=2e-5)
+    close(losses["loss"], g["loss"])
+    assert (outputs["identity_selection/0"].cpu().numpy() != g["identity_selection"]).mean() < 1e-3
+    losses["loss"].backward()
+    rel_close(disp.grad, g["grad_disp"], 1e-3)
+    rel_close(tr.models["pose"].pose_conv.weight.grad, g["grad_pose_conv"], 1e-3)
+    rel_close(tr.models["pose"].net[0].weight.grad, g["grad_pose_w0"], 1e-3)
+
+
+def test_frame_ids_the_kernels_do_not_take_raise():
+    """more source frames than SQD_MAX_SOURCES, repeated offsets, [0] without a stereo frame: refused at construction, with the reason"""
+    from options import MonodepthOptions
+    from trainer import Trainer
+    base = ["--backbone", "resnet18_lite", "--model_dim", "16", "--patch_size", "8", "--query_nums", "12", "--dim_out", "24", "--height", "64",
+            "--width", "96", "--batch_size", "2", "--num_workers", "0", "--sqd_synthetic", "--log_dir", "/tmp/sqd_g24_test"]
+    for extra in (["--frame_ids", "0", "-2", "-1", "1", "2", "--use_stereo"], ["--frame_ids", "0", "1", "1"], ["--frame_ids", "0"],
+                  ["--frame_ids", "0", "-2", "-1", "1", "--pose_model_input", "all"]):
+        with pytest.raises(NotImplementedError):
+            Trainer(MonodepthOptions().parse(base + extra))
+

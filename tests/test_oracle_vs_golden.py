@@ -6,7 +6,7 @@ import torch
 
 from conftest import tt
 from oracle import torch_ref as O
-from param_fill import chain_inputs, decoder_feats, fill_params, smooth_images, sparse_gt
+from param_fill import chain_inputs, decoder_feats, fill_params, pose_input_case, smooth_images, sparse_gt
 
 RTOL, ATOL = 1e-4, 1e-6           # BASELINE.json north_star: "within 1e-4 rel fp32"
 
@@ -385,3 +385,41 @@ def test_g22_metric_errors(golden):
     e = FR.compute_errors(g["gt"], g["pred"])
     for k, v in e.items():
         assert float(v) == float(g[k]), k
+
+
+@pytest.mark.parametrize("name", ["all", "all_stereo", "pairs_m2_p1"])
+def test_g24_pose_input_variants(golden, name):
+    """predict_poses -> generate_images_pred -> compute_losses with --pose_model_input all (with and without --use_stereo) and with pairs on
+    frame_ids 0 -2 1 (reference trainer.py:301-361, 404-421), against the reference's own run."""
+    g = golden("g24_pose_inputs_" + name)
+    B, H, W, seed, stereo, mode = int(g["B"]), int(g["H"]), int(g["W"]), int(g["seed"]), bool(g["stereo"]), str(g["mode"])
+    fids = [f if f == "s" else int(f) for f in g["frame_ids"]]
+    temporal = [f for f in fids if f != "s"]
+    _, np_inputs, np_disp, np_noise = pose_input_case(seed, B, H, W, temporal, stereo)
+    inputs = {k: tt(v) for k, v in np_inputs.items()}
+    pose = fill_params(O.PoseCNN(2 if mode == "pairs" else len(temporal)), seed + 2)
+
+    class _Feed(torch.nn.Module):                          # encoder / depth stand-ins: the fixture feeds disp directly
+        def __init__(self, out):
+            super().__init__()
+            self.out = out
+
+        def forward(self, x):
+            return self.out
+    disp = tt(np_disp).requires_grad_(True)
+    ref = O.RefTrainStep(_Feed(None), _Feed({("disp", 0): disp}), pose, fids, H, W, use_stereo=stereo, pose_model_input=mode)
+    out, losses = ref.process_batch(inputs, tt(np_noise))
+    f1, f2 = temporal[1], temporal[2]
+    close(out[("axisangle", 0, f1)], g["axisangle_f1"], atol=1e-7)
+    close(out[("translation", 0, f2)], g["translation_f2"], atol=1e-7)
+    close(out[("cam_T_cam", 0, f1)], g["cam_T_cam_f1"])
+    close(out[("cam_T_cam", 0, f2)], g["cam_T_cam_f2"])
+    for f, n in ((f1, "f1"), (f2, "f2")):
+        close(out[("sample", f, 0)], g["sample_" + n], atol=1e-6)
+        close(out[("color", f, 0)], g["color_" + n], atol=1e-5)
+    close(losses["loss"], g["loss"])
+    assert np.array_equal(out["identity_selection/0"].numpy(), g["identity_selection"])
+    losses["loss"].backward()
+    close(disp.grad, g["grad_disp"], atol=1e-9)
+    close(pose.pose_conv.weight.grad, g["grad_pose_conv"], rtol=1e-3, atol=1e-8)
+    close(pose.net[0].weight.grad, g["grad_pose_w0"], rtol=1e-3, atol=1e-8)
