@@ -401,10 +401,14 @@ int sqd_conv_wgrad_scaled(const float *dy, const float *x, float *dw, float *dbi
  * (11) adaptive-bins depth head.  replaces reference networks/depth_decoder_QTR.py:61-70 (convert_to_prob =
  * Conv2d(Q, D, 1) + Softmax(dim=1), then pred = sum_d out[d] * centers[b, d]).
  * energy [B,Q,N] (the planar energy maps the Self Query Layer writes, N = h*w), weight [D,Q] (the 1x1 filter),
- * bias [D], centers [B,D] -> pred [B,N].  1 <= Q, D <= 128.  fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ * bias [D], centers [B,D] -> pred [B,N].  1 <= Q, D <= 128.
  * bwd: g_pred [B,N] -> g_energy [B,Q,N], g_weight [D,Q], g_bias [D], g_centers [B,D];
- *      part: workspace of sqd_bins_workspace floats.  Deterministic (fixed-order partial sums). */
+ *      part: workspace of sqd_bins_workspace floats.  Deterministic (fixed-order partial sums).
+ * Arithmetic (sqd_bins_set_arith, process-wide, default 1): 1 = the logits and the g_energy product on two-term fp16 operands
+ * (v_mfma_f32_32x32x16_f16, three instructions per product, fp32 accumulation: csrc/sqd_f16x2.h — error against float64 at the level of
+ * the fp32 instruction's), the g_weight product on v_mfma_f32_32x32x2_f32; 0 = the fp32 matrix instruction throughout (rounds 1-4). */
 int sqd_bins_supported(int Q, int D);
+int sqd_bins_set_arith(int arith);
 int sqd_bins_workspace(int B, int Q, int D, int N, int64_t *part_floats);
 int sqd_bins_fwd(const float *energy, const float *weight, const float *bias, const float *centers, float *pred, int B, int Q,
                  int D, int N, void *stream);

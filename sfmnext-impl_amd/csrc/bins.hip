@@ -18,6 +18,7 @@
 //           per-workgroup partials + one deterministic reduction kernel.
 // Roofline: HBM — forward reads 4*Q B/px, writes 4; backward reads 4*Q (+4*Q from L2), writes 4*Q.
 #include "sqd_common.h"
+#include "sqd_f16x2.h"
 
 namespace {
 using namespace sqd;
@@ -63,7 +64,7 @@ __device__ __forceinline__ void stage_weights(float *Wl, float *bl, const float 
         const int d = idx / QP, q = idx - d * QP;
         Wl[idx] = (d < D && q < Q) ? W[d * Q + q] : 0.f;
     }
-    for (int d = threadIdx.x; d < DT * 32; d += 256) bl[d] = d < D ? bias[d] : 0.f;
+    for (int d = threadIdx.x; d < DT * 32; d += 256) bl[d] = d < D ? bias[d] : -INFINITY;      // (see tile_softmax)
 }
 
 // logits of the 32 pixels p0..p0+31 of image b: acc[dt][r] = row d = dt*32 + acc_row(r, lane>>5), column = lane & 31
@@ -104,32 +105,43 @@ __device__ __forceinline__ void tile_logits(const float *Wl, const float *__rest
     }
 }
 
-// in: acc = raw logits; out: acc = exp(logit - max) (0 for padded d), returns 1/sum and the expectation
+// in: acc * scale = the products W.E; out: acc = exp(logit - max) (0 for padded d), returns 1/sum and the expectation.  bl[d] = bias[d], -inf
+// for padded rows (their products are 0: the logit of a padded row is -inf and its exponential 0, no compare needed); the four rows of a
+// register group r = 4 g .. 4 g + 3 are consecutive d: bias and centres come as 16-byte LDS reads.  (Round 5: the per-row `d < D ? acc + bl[d]
+// : -inf` of rounds 1-4 compiled to 64 exec-masked branches, each around one ds_read_b32 and its wait — ~10 000 cycles per tile.)
 template <int DT>
-__device__ __forceinline__ void tile_softmax(f32x16 (&acc)[DT], const float *bl, const float *cl, int D, int lane, float &inv_sum,
+__device__ __forceinline__ void tile_softmax(f32x16 (&acc)[DT], const float *bl, const float *cl, int lane, float scale, float &inv_sum,
                                              float &pred) {
     const int h = lane >> 5;
     float m = -INFINITY;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int d = dt * 32 + acc_row(r, h);
-            const float v = d < D ? acc[dt][r] + bl[d] : -INFINITY;
-            acc[dt][r] = v;
-            m = fmaxf(m, v);
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4 *>(bl + dt * 32 + 8 * g + 4 * h);
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = fmaf(acc[dt][4 * g + j], scale, bv[j]);      // (scale is a power of two: the same bits as mul + add)
+                acc[dt][4 * g + j] = v;
+                m = fmaxf(m, v);
+            }
         }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float se = 0.f, dot = 0.f;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int d = dt * 32 + acc_row(r, h);
-            const float ex = __expf(acc[dt][r] - m);
-            acc[dt][r] = ex;
-            se += ex;
-            dot = fmaf(ex, cl[d], dot);
+        for (int g = 0; g < 4; ++g) {
+            const float4 c4 = *reinterpret_cast<const float4 *>(cl + dt * 32 + 8 * g + 4 * h);
+            const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float ex = __expf(acc[dt][4 * g + j] - m);
+                acc[dt][4 * g + j] = ex;
+                se += ex;
+                dot = fmaf(ex, cv[j], dot);
+            }
         }
     se += __shfl_xor(se, 32, 64);
     dot += __shfl_xor(dot, 32, 64);
@@ -155,7 +167,7 @@ __global__ __launch_bounds__(256) void bins_fwd_kernel(const float *__restrict__
         f32x16 acc[DT];
         tile_logits<DT, QT>(Wl, Eb, dm.Q, dm.N, p, pv, lane, acc);
         float inv_sum, pred;
-        tile_softmax<DT>(acc, bl, cl, dm.D, lane, inv_sum, pred);
+        tile_softmax<DT>(acc, bl, cl, lane, 1.f, inv_sum, pred);
         if (pv && lane < 32) pred_out[(size_t)b * dm.N + p] = pred;
     }
 }
@@ -204,7 +216,7 @@ __global__ __launch_bounds__(256) void bins_bwd_kernel(const float *__restrict__
             f32x16 acc[DT];
             tile_logits<DT, QT>(Wl, Eb, dm.Q, dm.N, p, pv, lane, acc);
             float inv_sum, pred;
-            tile_softmax<DT>(acc, bl, cl, dm.D, lane, inv_sum, pred);
+            tile_softmax<DT>(acc, bl, cl, lane, 1.f, inv_sum, pred);
             const float g = pv ? g_pred[(size_t)b * dm.N + p] * inv_sum : 0.f;      // g[p] / sum: acc holds un-normalised exp
             if (lane < 32) pl[i] = pred;
             // prob*g -> LDS tile [d][pixel] (operand of the dW product); dlogit stays in acc (operand of the dE product)
@@ -321,6 +333,296 @@ __global__ __launch_bounds__(256) void bins_bwd_kernel(const float *__restrict__
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Round 5: the same kernels on two-term fp16 operands (sqd_f16x2.h).  The fp32 kernels above spend DT * QT * 16 matrix instructions of
+// 64 cycles on a tile's logits (16 384 cycles at D = Q = 128: bins_fwd ran at 0.43, bins_bwd at 0.48 of the fp32 matrix peak, three
+// rounds without movement); v_mfma_f32_32x32x16_f16 does 8x the work of v_mfma_f32_32x32x2_f32 in half its cycles, so three of them per
+// product (h h + h l + l h) are 5.3x less matrix time and the kernels become what their header says: HBM-bound.
+//   W      d-major in LDS as fp16 high / low planes [DP][QH] (row pitch 16 bytes beyond a multiple of 64: ds_read_b128 of 16 consecutive rows
+//          is conflict-free), scaled by one power of two from max |W| (taken while staging);
+//   logits A = W rows (ds_read_b128: 8 consecutive q), B = energy planes read straight from [B,Q,N] — k-slot (h, j) of step ks is plane
+//          16 ks + 8 h + j — split in registers with a PER-PIXEL scale (the scale of B may vary along its columns);
+//   dE     contraction over d: B = dlogit from the accumulator registers of the logits (k-slot (h, j) of step (dt, u) is row
+//          dt 32 + 16 u + 4 h + (j & 3) + 8 (j >> 2): the lane's own registers 8 u .. 8 u + 7), per-pixel scale again; A = W^T, which the
+//          d-major LDS image yields through ds_read_b64_tr_b16 (the LDS transpose read: a 16-lane group reads a [4 d][16 q] block, each lane
+//          receives one q column) — one LDS image serves both contractions;
+//   dW     contraction over the pixels, accumulated over all tiles of the workgroup: stays on the fp32 instruction (its operand scales
+//          would have to be uniform over the whole launch), a third of the old matrix time.
+constexpr unsigned BINS_H_MAX_BYTES = 0x7fffffffu;             // Q N 4 must stay below 2 GiB (masked lanes start at BINS_OOB and add plane steps)
+
+template <int DT, int QT>
+__device__ __forceinline__ unsigned stage_weights_h(unsigned short *Wh, unsigned short *Wlo, float *bl, unsigned *red4,
+                                                    const float *__restrict__ W, const float *__restrict__ bias, int D, int Q) {
+    constexpr int QH = QT * 32 + 8, DP = DT * 32;
+    unsigned m = 0u;
+    for (int idx = threadIdx.x; idx < D * Q; idx += 256) m = max(m, abs_bits(W[idx]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+    if ((threadIdx.x & 63) == 0) red4[threadIdx.x >> 6] = m;
+    __syncthreads();
+    m = max(max(red4[0], red4[1]), max(red4[2], red4[3]));
+    const unsigned be = h2_scale_exp(m);
+    const float s = h2_scale(be);
+    for (int idx = threadIdx.x; idx < DP * QT * 8; idx += 256) {
+        const int d = idx / (QT * 8), q0 = 4 * (idx - d * (QT * 8));
+        float v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = (d < D && q0 + k < Q) ? W[d * Q + q0 + k] : 0.f;
+        unsigned h0, h1, l0, l1;
+        h2_split2(v[0], v[1], s, h0, l0);
+        h2_split2(v[2], v[3], s, h1, l1);
+        *reinterpret_cast<uint2 *>(Wh + d * QH + q0) = make_uint2(h0, h1);
+        *reinterpret_cast<uint2 *>(Wlo + d * QH + q0) = make_uint2(l0, l1);
+    }
+    for (int d = threadIdx.x; d < DP; d += 256) bl[d] = d < D ? bias[d] : -INFINITY;      // (see tile_softmax)
+    return be;
+}
+
+// logits of the 32 pixels p0..p0+31 of one image, as tile_logits (acc[dt][r] = row dt*32 + acc_row(r, lane>>5), column lane & 31)
+template <int DT, int QT>
+__device__ __forceinline__ float tile_logits_h(const unsigned short *Wh, const unsigned short *Wlo, unsigned beW, __amdgpu_buffer_rsrc_t e_r, int N, int p,
+                                              bool pv, int lane, f32x16 (&acc)[DT]) {
+    constexpr int QH = QT * 32 + 8, KS = QT * 2;
+    const int i = lane & 31, h = lane >> 5;
+    const unsigned step = (unsigned)N * 4u;
+    float e[KS][8];
+    unsigned off = pv ? ((unsigned)(8 * h) * N + p) * 4u : BINS_OOB;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[ks][j] = ldb(e_r, off + (unsigned)j * step);       // plane 16 ks + 8 h + j >= Q: beyond the extent
+        off += 16u * step;
+    }
+    unsigned m = 0u;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) m = max(m, abs_bits(e[ks][j]));
+    m = max(m, (unsigned)__shfl_xor((int)m, 32, 64));
+    const unsigned beP = h2_scale_exp(m);
+    const float sp = h2_scale(beP);
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        u32x4 bh, bl_;
+        h2_split8(e[ks], sp, bh, bl_);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const u32x4 ah = *reinterpret_cast<const u32x4 *>(Wh + (dt * 32 + i) * QH + ks * 16 + 8 * h);
+            const u32x4 al = *reinterpret_cast<const u32x4 *>(Wlo + (dt * 32 + i) * QH + ks * 16 + 8 * h);
+            acc[dt] = mfma_h16x2(ah, al, bh, bl_, acc[dt]);
+        }
+    }
+    return h2_inv_scale(beW) * h2_inv_scale(beP);              // acc holds s_W s_p times the products
+}
+
+template <int DT, int QT>
+__global__ __launch_bounds__(256, 2) void bins_fwd_h_kernel(const float *__restrict__ E, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, const float *__restrict__ centers,
+                                                         float *__restrict__ pred_out, BinsDims dm, int tiles_per_image) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int QH = QT * 32 + 8, DP = DT * 32;
+    unsigned short *Wh = reinterpret_cast<unsigned short *>(smem), *Wlo = Wh + DP * QH;
+    float *bl = reinterpret_cast<float *>(Wlo + DP * QH), *cl = bl + DP;
+    unsigned *red4 = reinterpret_cast<unsigned *>(cl + DP);
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned beW = stage_weights_h<DT, QT>(Wh, Wlo, bl, red4, W, bias, dm.D, dm.Q);
+    for (int d = threadIdx.x; d < DP; d += 256) cl[d] = d < dm.D ? centers[b * dm.D + d] : 0.f;
+    __syncthreads();
+    const float *Eb = E + (size_t)b * dm.Q * dm.N;
+    const __amdgpu_buffer_rsrc_t e_r = bins_rsrc(Eb, (unsigned)(dm.Q * dm.N) * 4u);
+    for (int tile = blockIdx.x * 4 + wave; tile < tiles_per_image; tile += gridDim.x * 4) {
+        const int p = tile * 32 + (lane & 31);
+        const bool pv = p < dm.N;
+        f32x16 acc[DT];
+        const float lscale = tile_logits_h<DT, QT>(Wh, Wlo, beW, e_r, dm.N, p, pv, lane, acc);
+        float inv_sum, pred;
+        tile_softmax<DT>(acc, bl, cl, lane, lscale, inv_sum, pred);
+        if (pv && lane < 32) pred_out[(size_t)b * dm.N + p] = pred;
+    }
+}
+
+template <int DT, int QT>
+__global__ __launch_bounds__(256) void bins_bwd_h_kernel(const float *__restrict__ E, const float *__restrict__ W,
+                                                         const float *__restrict__ bias, const float *__restrict__ centers,
+                                                         const float *__restrict__ g_pred, float *__restrict__ dE,
+                                                         float *__restrict__ part_w, float *__restrict__ part_v, BinsDims dm,
+                                                         int tiles_per_image) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int QH = QT * 32 + 8, DP = DT * 32;
+    unsigned short *Wh = reinterpret_cast<unsigned short *>(smem), *Wlo = Wh + DP * QH;
+    float *bl = reinterpret_cast<float *>(Wlo + DP * QH), *cl = bl + DP;
+    float *predl = cl + DP;                                   // [4 waves][32]
+    float *tiles = predl + 128;                               // [4 waves][DP][PITCH]: prob*g of the wave's tile, [d][pixel]
+    unsigned *red4 = reinterpret_cast<unsigned *>(tiles);     // (staging only)
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const unsigned beW = stage_weights_h<DT, QT>(Wh, Wlo, bl, red4, W, bias, dm.D, dm.Q);
+    for (int d = threadIdx.x; d < DP; d += 256) cl[d] = d < dm.D ? centers[b * dm.D + d] : 0.f;
+    __syncthreads();
+    const float *Eb = E + (size_t)b * dm.Q * dm.N;
+    float *dEb = dE + (size_t)b * dm.Q * dm.N;
+    const __amdgpu_buffer_rsrc_t eb_r = bins_rsrc(Eb, (unsigned)(dm.Q * dm.N) * 4u), de_r = bins_rsrc(dEb, (unsigned)(dm.Q * dm.N) * 4u);
+    float *tl = tiles + wave * DP * PITCH, *pl = predl + wave * 32;
+    const bool vec_ok = (dm.N & 3) == 0;
+    const int wd = wave % DT, wgp = wave / DT;
+    f32x16 accW[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) accW[qt][r] = 0.f;
+    float dbia = 0.f, dcen = 0.f;
+    const float ci = cl[wd * 32 + i];
+    const int iters = (tiles_per_image + gridDim.x * 4 - 1) / (gridDim.x * 4);
+    // the transpose reads of the dE product: lane t of a 16-lane group addresses row t / 4, columns 4 (t % 4).. of the group's [4 d][16 q]
+    // block; the group's 16 lanes are the q columns 16 ((lane >> 4) & 1) .. + 15 of the 32-wide q tile, its d rows start at 4 h
+    const int tr_off = (4 * h + ((lane & 15) >> 2)) * QH + 16 * ((lane >> 4) & 1) + 4 * (lane & 3);
+
+    for (int it = 0; it < iters; ++it) {                       // (uniform trip count: the loop holds workgroup barriers)
+        const int tile0 = (it * gridDim.x + blockIdx.x) * 4, tile = tile0 + wave;
+        const int p0 = tile * 32, p = p0 + i;
+        const bool pv = p < dm.N;
+        {
+            f32x16 acc[DT];
+            const float lscale = tile_logits_h<DT, QT>(Wh, Wlo, beW, eb_r, dm.N, p, pv, lane, acc);
+            float inv_sum, pred;
+            tile_softmax<DT>(acc, bl, cl, lane, lscale, inv_sum, pred);
+            const float g = pv ? g_pred[(size_t)b * dm.N + p] * inv_sum : 0.f;
+            if (lane < 32) pl[i] = pred;
+            unsigned m = 0u;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int d = dt * 32 + acc_row(r, h);
+                    const float pg = acc[dt][r] * g;
+                    tl[d * PITCH + i] = pg;
+                    const float dl = pg * (cl[d] - pred);
+                    acc[dt][r] = dl;
+                    m = max(m, abs_bits(dl));
+                }
+            // ---- dE[q, p] = sum_d W[d, q] * dlogit[d, p]: the B operand is the lane's own accumulator registers
+            m = max(m, (unsigned)__shfl_xor((int)m, 32, 64));
+            const unsigned beL = h2_scale_exp(m);
+            const float sl = h2_scale(beL), invE = h2_inv_scale(beW) * h2_inv_scale(beL);
+            u32x4 bh[DT][2], blo[DT][2];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = acc[dt][8 * u + j];
+                    h2_split8(v, sl, bh[dt][u], blo[dt][u]);
+                }
+#pragma unroll 1
+            for (int qt = 0; qt < QT; ++qt) {
+                f32x16 accE;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) accE[r] = 0.f;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int o = tr_off + (dt * 32 + 16 * u) * QH + qt * 32;
+                        const uint2 h0 = lds_read_tr16(Wh + o), h1 = lds_read_tr16(Wh + o + 8 * QH);
+                        const uint2 l0 = lds_read_tr16(Wlo + o), l1 = lds_read_tr16(Wlo + o + 8 * QH);
+                        accE = mfma_h16x2((u32x4){h0.x, h0.y, h1.x, h1.y}, (u32x4){l0.x, l0.y, l1.x, l1.y}, bh[dt][u], blo[dt][u], accE);
+                    }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int q = qt * 32 + acc_row(r, h);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_int(accE[r] * invE), de_r, pv ? ((unsigned)q * dm.N + p) * 4u : BINS_OOB, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                                        // every wave's prob*g tile and pred row are in LDS
+        // ---- dW[d, q] += sum_p dlogit[d, p] * E[q, p] (fp32 instruction, see the header of this section)
+#pragma unroll 1
+        for (int tt = 0; tt < DT; ++tt) {
+            const int wsrc = wgp * DT + tt;
+            const int q0 = (tile0 + wsrc) * 32;
+            const float *tls = tiles + wsrc * DP * PITCH, *pls = predl + wsrc * 32;
+#pragma unroll 1
+            for (int gq = 0; gq < 4; ++gq) {
+                const int px = 8 * gq + 4 * h;
+                const float4 pr4 = *reinterpret_cast<const float4 *>(pls + px);
+                const float prv[4] = {pr4.x, pr4.y, pr4.z, pr4.w};
+                float dlg[4], ev[QT][4];
+                const float4 t4 = *reinterpret_cast<const float4 *>(tls + (wd * 32 + i) * PITCH + px);
+                const float pgv[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    dlg[e] = pgv[e] * (ci - prv[e]);
+                    dcen += pgv[e];
+                    dbia += dlg[e];
+                }
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    const int q = qt * 32 + i;
+                    const unsigned off = ((unsigned)q * dm.N + q0 + px) * 4u;
+                    if (vec_ok) {
+                        const bins_i32x4 v4 = __builtin_amdgcn_raw_buffer_load_b128(eb_r, q0 + px < dm.N ? off : BINS_OOB, 0, 0);
+                        ev[qt][0] = __int_as_float(v4.x); ev[qt][1] = __int_as_float(v4.y);
+                        ev[qt][2] = __int_as_float(v4.z); ev[qt][3] = __int_as_float(v4.w);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) ev[qt][e] = ldb(eb_r, q0 + px + e < dm.N ? off + 4u * e : BINS_OOB);
+                    }
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) accW[qt] = mfma32(dlg[e], ev[qt][e], accW[qt]);
+            }
+        }
+        __syncthreads();                                        // the tiles are rewritten by the next iteration
+    }
+
+    // ---- workgroup partials, as bins_bwd_kernel
+    float *red = tiles;
+    constexpr int QW = QT * 32;
+    for (int gsel = 0; gsel < 4 / DT; ++gsel) {
+        if (wgp == gsel) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float *dst = red + (wd * 32 + acc_row(r, h)) * QW + qt * 32 + i;
+                    *dst = (gsel == 0 ? 0.f : *dst) + accW[qt][r];
+                }
+        }
+        __syncthreads();
+    }
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    float *pw = part_w + (size_t)wg * dm.D * dm.Q;
+    for (int idx = threadIdx.x; idx < dm.D * dm.Q; idx += 256) {
+        const int d = idx / dm.Q, q = idx - d * dm.Q;
+        pw[idx] = red[d * QW + q];
+    }
+    __syncthreads();
+    float *vred = red;
+    {
+        const float sb = dbia + __shfl_xor(dbia, 32, 64), sc = dcen + __shfl_xor(dcen, 32, 64);
+        if (h == 0) {
+            vred[(wgp * 2 + 0) * DP + wd * 32 + i] = sb;
+            vred[(wgp * 2 + 1) * DP + wd * 32 + i] = sc;
+        }
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 2 * DP; idx += 256) {
+        const int which = idx / DP, d = idx - which * DP;
+        if (d < dm.D) {
+            float sum = 0.f;
+            for (int w = 0; w < 4 / DT; ++w) sum += vred[(w * 2 + which) * DP + d];
+            part_v[((size_t)wg * 2 + which) * dm.D + d] = sum;
+        }
+    }
+}
+
 // out[y][i] = sum_{s < splits} part[(y*splits + s)*n + i]: a block owns 32 columns, its 8 thread groups add the
 // partials s = g, g+8, ... in order, then a fixed-order tree over the groups (deterministic)
 __global__ __launch_bounds__(256) void rows_reduce_kernel(const float *__restrict__ part, float *__restrict__ out, int n, int splits) {
@@ -358,7 +660,7 @@ __global__ __launch_bounds__(256) void bins_vec_finalize_kernel(const float *__r
 
 struct BinsPlan {
     int dt, wg_per_image, tiles_per_image;
-    size_t smem_fwd, smem_bwd;
+    size_t smem_fwd, smem_bwd, smem_fwd_h, smem_bwd_h;
 };
 BinsPlan plan_bins(int B, int Q, int D, int N) {
     BinsPlan p;
@@ -370,11 +672,16 @@ BinsPlan plan_bins(int B, int Q, int D, int N) {
     if (wg > max_wg) wg = max_wg;
     if (wg < 1) wg = 1;
     p.wg_per_image = wg;
-    const int DP = p.dt * 32, QP = p.dt * 32 + 1;
+    const int DP = p.dt * 32, QP = p.dt * 32 + 1, QH = p.dt * 32 + 8;
     p.smem_fwd = (size_t)(DP * QP + 2 * DP) * 4;
     p.smem_bwd = (size_t)(DP * QP + 2 * DP + 128 + 4 * DP * PITCH) * 4;
+    p.smem_fwd_h = (size_t)2 * DP * QH * 2 + (size_t)(2 * DP + 4) * 4;
+    p.smem_bwd_h = (size_t)2 * DP * QH * 2 + (size_t)(2 * DP + 128 + 4 * DP * PITCH) * 4;
     return p;
 }
+// 1 (default): two-term fp16 operands for the logits and the dE product (bins_*_h_kernel); 0: the fp32 matrix instruction throughout
+int g_bins_arith = 1;
+bool bins_h_ok(int Q, int N) { return g_bins_arith == 1 && (long long)Q * N * 4 <= (long long)BINS_H_MAX_BYTES; }
 template <typename K>
 int set_smem(K kernel, size_t bytes) {
     return hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess
@@ -384,6 +691,12 @@ int set_smem(K kernel, size_t bytes) {
 }  // namespace
 
 extern "C" int sqd_bins_supported(int Q, int D) { return (Q >= 1 && Q <= 128 && D >= 1 && D <= 128) ? 1 : 0; }
+
+extern "C" int sqd_bins_set_arith(int arith) {
+    SQD_CHECK_ARG(arith == 0 || arith == 1, "sqd_bins_set_arith: 0 (fp32 matrix instruction) or 1 (two-term fp16 operands), got %d", arith);
+    g_bins_arith = arith;
+    return SQD_OK;
+}
 
 extern "C" int sqd_bins_workspace(int B, int Q, int D, int N, int64_t *part_floats) {
     SQD_CHECK_ARG(sqd_bins_supported(Q, D), "sqd_bins: Q=%d and D=%d must be in 1..128", Q, D);
@@ -402,7 +715,19 @@ extern "C" int sqd_bins_fwd(const float *energy, const float *weight, const floa
     const BinsDims dm = {B, Q, D, N};
     const dim3 grid(p.wg_per_image, B);
     (void)hipGetLastError();
-    if (p.dt == 2) {
+    if (bins_h_ok(Q, N)) {
+        if (p.dt == 2) {
+            static int once = set_smem(bins_fwd_h_kernel<2, 2>, plan_bins(1, 64, 64, 32).smem_fwd_h);
+            SQD_CHECK_ARG(once == 0, "sqd_bins_fwd: cannot reserve %zu bytes of LDS", p.smem_fwd_h);
+            hipLaunchKernelGGL((bins_fwd_h_kernel<2, 2>), grid, dim3(256), p.smem_fwd_h, (hipStream_t)stream, energy, weight, bias, centers, pred,
+                               dm, p.tiles_per_image);
+        } else {
+            static int once = set_smem(bins_fwd_h_kernel<4, 4>, plan_bins(1, 128, 128, 32).smem_fwd_h);
+            SQD_CHECK_ARG(once == 0, "sqd_bins_fwd: cannot reserve %zu bytes of LDS", p.smem_fwd_h);
+            hipLaunchKernelGGL((bins_fwd_h_kernel<4, 4>), grid, dim3(256), p.smem_fwd_h, (hipStream_t)stream, energy, weight, bias, centers, pred,
+                               dm, p.tiles_per_image);
+        }
+    } else if (p.dt == 2) {
         hipLaunchKernelGGL((bins_fwd_kernel<2, 2>), grid, dim3(256), p.smem_fwd, (hipStream_t)stream, energy, weight, bias, centers, pred,
                            dm, p.tiles_per_image);
     } else {
@@ -429,7 +754,19 @@ extern "C" int sqd_bins_bwd(const float *energy, const float *weight, const floa
     float *part_w = part, *part_v = part + (size_t)p.wg_per_image * B * D * Q;
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
-    if (p.dt == 2) {
+    if (bins_h_ok(Q, N)) {
+        if (p.dt == 2) {
+            static int once = set_smem(bins_bwd_h_kernel<2, 2>, plan_bins(1, 64, 64, 32).smem_bwd_h);
+            SQD_CHECK_ARG(once == 0, "sqd_bins_bwd: cannot reserve %zu bytes of LDS", p.smem_bwd_h);
+            hipLaunchKernelGGL((bins_bwd_h_kernel<2, 2>), grid, dim3(256), p.smem_bwd_h, st, energy, weight, bias, centers, g_pred, g_energy,
+                               part_w, part_v, dm, p.tiles_per_image);
+        } else {
+            static int once = set_smem(bins_bwd_h_kernel<4, 4>, plan_bins(1, 128, 128, 32).smem_bwd_h);
+            SQD_CHECK_ARG(once == 0, "sqd_bins_bwd: cannot reserve %zu bytes of LDS", p.smem_bwd_h);
+            hipLaunchKernelGGL((bins_bwd_h_kernel<4, 4>), grid, dim3(256), p.smem_bwd_h, st, energy, weight, bias, centers, g_pred, g_energy,
+                               part_w, part_v, dm, p.tiles_per_image);
+        }
+    } else if (p.dt == 2) {
         hipLaunchKernelGGL((bins_bwd_kernel<2, 2>), grid, dim3(256), p.smem_bwd, st, energy, weight, bias, centers, g_pred, g_energy,
                            part_w, part_v, dm, p.tiles_per_image);
     } else {

@@ -230,6 +230,7 @@ _SIGNATURES = {
     "sqd_conv_wgrad_scaled": (_I, [_P] * 7 + [_I] * 11 + [ctypes.POINTER(ctypes.c_int), _P]),
     "sqd_split_reduce": (_I, [_P, _P, ctypes.c_int64, _I, _P]),
     "sqd_bins_supported": (_I, [_I, _I]),
+    "sqd_bins_set_arith": (_I, [_I]),
     "sqd_bins_workspace": (_I, [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64)]),
     "sqd_bins_fwd": (_I, [_P] * 5 + [_I] * 4 + [_P]),
     "sqd_bins_bwd": (_I, [_P] * 10 + [_I] * 4 + [_P]),

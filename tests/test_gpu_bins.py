@@ -13,6 +13,7 @@ CASES = [  # B, Q, D, h, w
     (1, 128, 128, 8, 16),      # maximum sizes
     (2, 16, 8, 5, 13),         # tiny Q / D
     (12, 64, 64, 96, 320),     # full config-B head
+    (2, 128, 128, 160, 512),   # configs[2]'s head (Q = dim_out = 128) at its map size, two images
 ]
 
 
@@ -21,8 +22,17 @@ def composite(energy, weight, bias, centers):
     return torch.sum(out * centers.view(centers.shape[0], -1, 1, 1), dim=1, keepdim=True)
 
 
+@pytest.fixture(params=[1, 0], ids=["f16x2", "fp32mfma"])
+def arith(request):
+    """both arithmetics of csrc/bins.hip (sqd_bins_set_arith): two-term fp16 operands (the default) and the fp32 matrix instruction"""
+    from sqd import lib
+    lib.check(lib.lib().sqd_bins_set_arith(request.param), "bins_set_arith")
+    yield request.param
+    lib.check(lib.lib().sqd_bins_set_arith(1), "bins_set_arith")
+
+
 @pytest.mark.parametrize("B,Q,D,h,w", CASES)
-def test_bins_head_fwd_bwd(B, Q, D, h, w):
+def test_bins_head_fwd_bwd(B, Q, D, h, w, arith):
     from sqd import ops
     g = torch.Generator().manual_seed(B * 1000 + Q + D + h)
     energy = 2.0 * torch.randn(B, Q, h, w, generator=g)
@@ -96,3 +106,27 @@ def test_bin_centers_linear_norm(B, D):
     assert float((out.detach().cpu().double() - ref.detach()).abs().max()) <= 1e-5 * vmax
     gs = float(yr.grad.abs().max())
     assert float((yd.grad.cpu().double() - yr.grad).abs().max()) <= 1e-4 * gs + 1e-9
+
+
+def test_bins_head_f16x2_wide_dynamic_range():
+    """two-term fp16 operands with per-pixel scales: energies whose magnitude varies by 2^28 across the pixels (and by 2^12 inside a pixel's
+    Q values): the logits must come out at fp32 accuracy for every pixel, not only for the loudest ones"""
+    from sqd import lib, ops
+    lib.check(lib.lib().sqd_bins_set_arith(1), "bins_set_arith")
+    g = torch.Generator().manual_seed(77)
+    B, Q, D, h, w = 2, 64, 64, 9, 32
+    mag = torch.exp2(torch.randint(-24, 5, (B, 1, h, w), generator=g).float())
+    energy = torch.randn(B, Q, h, w, generator=g) * mag * torch.exp2(torch.randint(-12, 1, (B, Q, h, w), generator=g).float())
+    weight = 0.05 * torch.randn(D, Q, 1, 1, generator=g)
+    bias = 0.1 * torch.randn(D, generator=g)
+    centers = torch.sort(torch.rand(B, D, generator=g) * 80.0, dim=1).values
+    ref = composite(energy.double(), weight.double(), bias.double(), centers.double())
+    out = ops.BinsHead.apply(energy.cuda(), weight.cuda(), bias.cuda(), centers.cuda())
+    lib.check(lib.lib().sqd_bins_set_arith(0), "bins_set_arith")
+    out32 = ops.BinsHead.apply(energy.cuda(), weight.cuda(), bias.cuda(), centers.cuda())
+    lib.check(lib.lib().sqd_bins_set_arith(1), "bins_set_arith")
+    e16 = float((out.cpu().double() - ref).abs().max())
+    e32 = float((out32.cpu().double() - ref).abs().max())
+    print("max |pred - float64|: f16x2 %.3e, fp32 MFMA %.3e" % (e16, e32))
+    assert e16 <= max(4 * e32, 1e-4), (e16, e32)
+

@@ -18,5 +18,10 @@ def t(fn, n=50):
     for _ in range(n): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3
-y = ops.BinsHead.apply(*a)
-print("fwd %.1f us  fwd+bwd %.1f us" % (t(lambda: ops.BinsHead.apply(*a)), t(lambda: torch.autograd.grad(ops.BinsHead.apply(*a), a, g))))
+from sqd import lib
+for arith, name in ((1, "f16x2"), (0, "fp32 MFMA")):
+    lib.check(lib.lib().sqd_bins_set_arith(arith), "bins_set_arith")
+    print(name, end=": ")
+    _bench = True
+    print("fwd %.1f us  fwd+bwd %.1f us" % (t(lambda: ops.BinsHead.apply(*a)), t(lambda: torch.autograd.grad(ops.BinsHead.apply(*a), a, g))))
+lib.check(lib.lib().sqd_bins_set_arith(1), "bins_set_arith")
