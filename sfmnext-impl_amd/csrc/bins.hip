@@ -405,22 +405,39 @@ __device__ __forceinline__ float tile_logits_h(const unsigned short *Wh, const u
     for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[dt][r] = 0.f;
+    // the A operands of step ks + 1 are fetched from LDS while the matrix instructions of step ks run (left to itself the compiler
+    // emits read - wait - multiply 64 times per tile: the waves of round 5's first version spent half of their life at those waits)
+    u32x4 ah[2][DT], al[2][DT];
+    const unsigned short *wh_lane = Wh + i * QH + 8 * h, *wl_lane = Wlo + i * QH + 8 * h;
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        ah[0][dt] = *reinterpret_cast<const u32x4 *>(wh_lane + dt * 32 * QH);
+        al[0][dt] = *reinterpret_cast<const u32x4 *>(wl_lane + dt * 32 * QH);
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
+        if (ks + 1 < KS) {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                ah[(ks + 1) & 1][dt] = *reinterpret_cast<const u32x4 *>(wh_lane + dt * 32 * QH + (ks + 1) * 16);
+                al[(ks + 1) & 1][dt] = *reinterpret_cast<const u32x4 *>(wl_lane + dt * 32 * QH + (ks + 1) * 16);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                   // (the reads stay above the step's arithmetic)
         u32x4 bh, bl_;
         h2_split8(e[ks], sp, bh, bl_);
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-            const u32x4 ah = *reinterpret_cast<const u32x4 *>(Wh + (dt * 32 + i) * QH + ks * 16 + 8 * h);
-            const u32x4 al = *reinterpret_cast<const u32x4 *>(Wlo + (dt * 32 + i) * QH + ks * 16 + 8 * h);
-            acc[dt] = mfma_h16x2(ah, al, bh, bl_, acc[dt]);
-        }
+        for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma_h16(ah[ks & 1][dt], bh, acc[dt]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma_h16(ah[ks & 1][dt], bl_, acc[dt]);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma_h16(al[ks & 1][dt], bh, acc[dt]);
     }
     return h2_inv_scale(beW) * h2_inv_scale(beP);              // acc holds s_W s_p times the products
 }
 
 template <int DT, int QT>
-__global__ __launch_bounds__(256, 2) void bins_fwd_h_kernel(const float *__restrict__ E, const float *__restrict__ W,
+__global__ __launch_bounds__(256, 2) __attribute__((amdgpu_waves_per_eu(2, 2))) void bins_fwd_h_kernel(const float *__restrict__ E, const float *__restrict__ W,
                                                          const float *__restrict__ bias, const float *__restrict__ centers,
                                                          float *__restrict__ pred_out, BinsDims dm, int tiles_per_image) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -434,9 +451,14 @@ __global__ __launch_bounds__(256, 2) void bins_fwd_h_kernel(const float *__restr
     __syncthreads();
     const float *Eb = E + (size_t)b * dm.Q * dm.N;
     const __amdgpu_buffer_rsrc_t e_r = bins_rsrc(Eb, (unsigned)(dm.Q * dm.N) * 4u);
-    for (int tile = blockIdx.x * 4 + wave; tile < tiles_per_image; tile += gridDim.x * 4) {
+    const int iters = (tiles_per_image + gridDim.x * 4 - 1) / (gridDim.x * 4);
+    for (int it = 0; it < iters; ++it) {
+        const int tile = (it * gridDim.x + blockIdx.x) * 4 + wave;
         const int p = tile * 32 + (lane & 31);
         const bool pv = p < dm.N;
+#ifdef SQD_BINS_FWD_BARRIER
+        __syncthreads();          // the four waves issue their 4 x 128 bytes of every plane together
+#endif
         f32x16 acc[DT];
         const float lscale = tile_logits_h<DT, QT>(Wh, Wlo, beW, e_r, dm.N, p, pv, lane, acc);
         float inv_sum, pred;
@@ -523,15 +545,22 @@ __global__ __launch_bounds__(256) void bins_bwd_h_kernel(const float *__restrict
                 f32x16 accE;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) accE[r] = 0.f;
+                // step st = (dt, u): 16 d rows; the transpose reads of step st + 1 are issued before the matrix instructions of step st
+                u32x4 ath[2], atl[2];
+                auto fetch = [&](int st, u32x4 &ah_, u32x4 &al_) {
+                    const int o = tr_off + (16 * st) * QH + qt * 32;
+                    const uint2 h0 = lds_read_tr16(Wh + o), h1 = lds_read_tr16(Wh + o + 8 * QH);
+                    const uint2 l0 = lds_read_tr16(Wlo + o), l1 = lds_read_tr16(Wlo + o + 8 * QH);
+                    ah_ = (u32x4){h0.x, h0.y, h1.x, h1.y};
+                    al_ = (u32x4){l0.x, l0.y, l1.x, l1.y};
+                };
+                fetch(0, ath[0], atl[0]);
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                    for (int u = 0; u < 2; ++u) {
-                        const int o = tr_off + (dt * 32 + 16 * u) * QH + qt * 32;
-                        const uint2 h0 = lds_read_tr16(Wh + o), h1 = lds_read_tr16(Wh + o + 8 * QH);
-                        const uint2 l0 = lds_read_tr16(Wlo + o), l1 = lds_read_tr16(Wlo + o + 8 * QH);
-                        accE = mfma_h16x2((u32x4){h0.x, h0.y, h1.x, h1.y}, (u32x4){l0.x, l0.y, l1.x, l1.y}, bh[dt][u], blo[dt][u], accE);
-                    }
+                for (int st = 0; st < 2 * DT; ++st) {
+                    if (st + 1 < 2 * DT) fetch(st + 1, ath[(st + 1) & 1], atl[(st + 1) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    accE = mfma_h16x2(ath[st & 1], atl[st & 1], bh[st >> 1][st & 1], blo[st >> 1][st & 1], accE);
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int q = qt * 32 + acc_row(r, h);
@@ -659,7 +688,7 @@ __global__ __launch_bounds__(256) void bins_vec_finalize_kernel(const float *__r
 }
 
 struct BinsPlan {
-    int dt, wg_per_image, tiles_per_image;
+    int dt, wg_per_image, tiles_per_image, wg_fwd_h, wg_bwd_h;
     size_t smem_fwd, smem_bwd, smem_fwd_h, smem_bwd_h;
 };
 BinsPlan plan_bins(int B, int Q, int D, int N) {
@@ -672,6 +701,15 @@ BinsPlan plan_bins(int B, int Q, int D, int N) {
     if (wg > max_wg) wg = max_wg;
     if (wg < 1) wg = 1;
     p.wg_per_image = wg;
+    // the two-term kernels: ONE round of resident workgroups (every workgroup stages W once, 768 workgroups on 512 slots were 1.5 rounds) —
+    // forward 2 (D, Q > 64: 72 KB of LDS) or 4 per CU, backward 1 or 2 (its fp32 tiles)
+    auto one_round = [&](int per_cu) {
+        int w = (256 * per_cu) / B;
+        if (w > (p.tiles_per_image + 3) / 4) w = (p.tiles_per_image + 3) / 4;
+        return w < 1 ? 1 : w;
+    };
+    p.wg_fwd_h = one_round(p.dt == 2 ? 4 : 2);
+    p.wg_bwd_h = one_round(p.dt == 2 ? 2 : 1);
     const int DP = p.dt * 32, QP = p.dt * 32 + 1, QH = p.dt * 32 + 8;
     p.smem_fwd = (size_t)(DP * QP + 2 * DP) * 4;
     p.smem_bwd = (size_t)(DP * QP + 2 * DP + 128 + 4 * DP * PITCH) * 4;
@@ -701,7 +739,8 @@ extern "C" int sqd_bins_set_arith(int arith) {
 extern "C" int sqd_bins_workspace(int B, int Q, int D, int N, int64_t *part_floats) {
     SQD_CHECK_ARG(sqd_bins_supported(Q, D), "sqd_bins: Q=%d and D=%d must be in 1..128", Q, D);
     const BinsPlan p = plan_bins(B, Q, D, N);
-    if (part_floats) *part_floats = (int64_t)p.wg_per_image * B * ((int64_t)D * Q + 2 * D) + (int64_t)B * 2 * D;
+    const int wg = p.wg_per_image > p.wg_bwd_h ? p.wg_per_image : p.wg_bwd_h;          // (either arithmetic may run: sqd_bins_set_arith)
+    if (part_floats) *part_floats = (int64_t)wg * B * ((int64_t)D * Q + 2 * D) + (int64_t)B * 2 * D;
     return SQD_OK;
 }
 
@@ -713,18 +752,18 @@ extern "C" int sqd_bins_fwd(const float *energy, const float *weight, const floa
                   "sqd_bins_fwd: unsupported dims B=%d Q=%d D=%d N=%d", B, Q, D, N);
     const BinsPlan p = plan_bins(B, Q, D, N);
     const BinsDims dm = {B, Q, D, N};
-    const dim3 grid(p.wg_per_image, B);
+    const dim3 grid(p.wg_per_image, B), grid_h(p.wg_fwd_h, B);
     (void)hipGetLastError();
     if (bins_h_ok(Q, N)) {
         if (p.dt == 2) {
             static int once = set_smem(bins_fwd_h_kernel<2, 2>, plan_bins(1, 64, 64, 32).smem_fwd_h);
             SQD_CHECK_ARG(once == 0, "sqd_bins_fwd: cannot reserve %zu bytes of LDS", p.smem_fwd_h);
-            hipLaunchKernelGGL((bins_fwd_h_kernel<2, 2>), grid, dim3(256), p.smem_fwd_h, (hipStream_t)stream, energy, weight, bias, centers, pred,
+            hipLaunchKernelGGL((bins_fwd_h_kernel<2, 2>), grid_h, dim3(256), p.smem_fwd_h, (hipStream_t)stream, energy, weight, bias, centers, pred,
                                dm, p.tiles_per_image);
         } else {
             static int once = set_smem(bins_fwd_h_kernel<4, 4>, plan_bins(1, 128, 128, 32).smem_fwd_h);
             SQD_CHECK_ARG(once == 0, "sqd_bins_fwd: cannot reserve %zu bytes of LDS", p.smem_fwd_h);
-            hipLaunchKernelGGL((bins_fwd_h_kernel<4, 4>), grid, dim3(256), p.smem_fwd_h, (hipStream_t)stream, energy, weight, bias, centers, pred,
+            hipLaunchKernelGGL((bins_fwd_h_kernel<4, 4>), grid_h, dim3(256), p.smem_fwd_h, (hipStream_t)stream, energy, weight, bias, centers, pred,
                                dm, p.tiles_per_image);
         }
     } else if (p.dt == 2) {
@@ -750,8 +789,9 @@ extern "C" int sqd_bins_bwd(const float *energy, const float *weight, const floa
                   "sqd_bins_bwd: unsupported dims B=%d Q=%d D=%d N=%d", B, Q, D, N);
     const BinsPlan p = plan_bins(B, Q, D, N);
     const BinsDims dm = {B, Q, D, N};
-    const dim3 grid(p.wg_per_image, B);
-    float *part_w = part, *part_v = part + (size_t)p.wg_per_image * B * D * Q;
+    const int wgi = bins_h_ok(Q, N) ? p.wg_bwd_h : p.wg_per_image;
+    const dim3 grid(wgi, B);
+    float *part_w = part, *part_v = part + (size_t)wgi * B * D * Q;
     hipStream_t st = (hipStream_t)stream;
     (void)hipGetLastError();
     if (bins_h_ok(Q, N)) {
@@ -775,9 +815,9 @@ extern "C" int sqd_bins_bwd(const float *energy, const float *weight, const floa
         hipLaunchKernelGGL((bins_bwd_kernel<4, 4>), grid, dim3(256), p.smem_bwd, st, energy, weight, bias, centers, g_pred, g_energy,
                            part_w, part_v, dm, p.tiles_per_image);
     }
-    float *tmp = part_v + (size_t)p.wg_per_image * B * 2 * D;
-    hipLaunchKernelGGL(rows_reduce_kernel, dim3((D * Q + 31) / 32, 1), dim3(256), 0, st, part_w, g_weight, D * Q, p.wg_per_image * B);
-    hipLaunchKernelGGL(rows_reduce_kernel, dim3((2 * D + 31) / 32, B), dim3(256), 0, st, part_v, tmp, 2 * D, p.wg_per_image);
+    float *tmp = part_v + (size_t)wgi * B * 2 * D;
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3((D * Q + 31) / 32, 1), dim3(256), 0, st, part_w, g_weight, D * Q, wgi * B);
+    hipLaunchKernelGGL(rows_reduce_kernel, dim3((2 * D + 31) / 32, B), dim3(256), 0, st, part_v, tmp, 2 * D, wgi);
     hipLaunchKernelGGL(bins_vec_finalize_kernel, dim3((D + B * D + 255) / 256), dim3(256), 0, st, tmp, g_bias, g_centers, B, D);
     SQD_CHECK_LAUNCH("sqd_bins_bwd");
     return SQD_OK;

@@ -608,35 +608,56 @@ __global__ __launch_bounds__(256) void sql_bwd32q_kernel(const float *__restrict
         f32x16 acc, sreg;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        // (round 5: every LDS operand of a product is fetched BEFORE its matrix instructions, behind a scheduling fence — left to itself the
+        //  compiler emitted read - wait - multiply per instruction, and the two waves of a SIMD spent their time at those waits: the matrix
+        //  pipe was busy 32 % of the launch)
+        {
+            float sa[EH][16];
 #pragma unroll
-        for (int eh = 0; eh < EH; ++eh)
+            for (int eh = 0; eh < EH; ++eh)
 #pragma unroll
-            for (int s = 0; s < 16; ++s) acc = mfma32(Sq[i * EP + eh * 32 + 2 * s + h], xe[eh][s], acc);
+                for (int s = 0; s < 16; ++s) sa[eh][s] = Sq[i * EP + eh * 32 + 2 * s + h];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int eh = 0; eh < EH; ++eh)
+#pragma unroll
+                for (int s = 0; s < 16; ++s) acc = mfma32(sa[eh][s], xe[eh][s], acc);
+        }
         // ---- s and gyt, element-wise; gyt also to the LDS tile (operand of the g_K product)
+        {
+            float4 qv4[16];                                           // (max, 1/sum, dot, -) of the lane's 16 query rows: 16-byte reads, issued together
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ql = acc_row(r, h);
-            float sv = 0.f, gyt = 0.f;
-            if (wq * 32 + ql < Q && pv) {
-                sv = __expf(yv[r] - qcq[ql * 4]) * qcq[ql * 4 + 1];
-                gyt = gv[r] + sv * (acc[r] - qcq[ql * 4 + 2]);
+            for (int r = 0; r < 16; ++r) qv4[r] = *reinterpret_cast<const float4 *>(qcq + acc_row(r, h) * 4);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ql = acc_row(r, h);
+                float sv = 0.f, gyt = 0.f;
+                if (wq * 32 + ql < Q && pv) {
+                    sv = __expf(yv[r] - qv4[r].x) * qv4[r].y;
+                    gyt = gv[r] + sv * (acc[r] - qv4[r].z);
+                }
+                sreg[r] = sv;
+                acc[r] = gyt;
+                tl[ql * TP + i] = gyt;
             }
-            sreg[r] = sv;
-            acc[r] = gyt;
-            tl[ql * TP + i] = gyt;
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         // ---- g_K[q][e] += sum_p gyt[q][p] x[e][p]; k-step (gq, j): half-wave 0 takes pixel 8gq+j, half-wave 1 pixel 8gq+4+j
+        {
+            float4 a4[4];
 #pragma unroll
-        for (int gq = 0; gq < 4; ++gq) {
-            const int px = 8 * gq + 4 * h;
-            const float4 a4 = *reinterpret_cast<const float4 *>(tl + i * TP + px);
-            const float av[4] = {a4.x, a4.y, a4.z, a4.w};
+            for (int gq = 0; gq < 4; ++gq) a4[gq] = *reinterpret_cast<const float4 *>(tl + i * TP + 8 * gq + 4 * h);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int eh = 0; eh < EH; ++eh)
+            for (int gq = 0; gq < 4; ++gq) {
+                const float av[4] = {a4[gq].x, a4[gq].y, a4[gq].z, a4[gq].w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) accK[eh] = mfma32(av[j], xv[eh][gq][j], accK[eh]);
+                for (int eh = 0; eh < EH; ++eh)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) accK[eh] = mfma32(av[j], xv[eh][gq][j], accK[eh]);
+            }
         }
         __builtin_amdgcn_wave_barrier();                           // (the tile's reads are issued before it is overwritten below)
         // ---- the group's part of g_x[e][p] = sum_q K[q][e] gyt[q][p] + gS[q][e] s[q][p]
@@ -645,12 +666,19 @@ __global__ __launch_bounds__(256) void sql_bwd32q_kernel(const float *__restrict
             f32x16 gx;
 #pragma unroll
             for (int r = 0; r < 16; ++r) gx[r] = 0.f;
+            float ka[16], sb[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int ql = acc_row(r, h);
-                gx = mfma32(Kq[ql * EP + eh * 32 + i], acc[r], gx);
-                gx = mfma32(Sq[ql * EP + eh * 32 + i], sreg[r], gx);
+                ka[r] = Kq[acc_row(r, h) * EP + eh * 32 + i];
+                sb[r] = Sq[acc_row(r, h) * EP + eh * 32 + i];
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                gx = mfma32(ka[r], acc[r], gx);
+                gx = mfma32(sb[r], sreg[r], gx);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int r = 0; r < 16; ++r) gxs[wave * GXW + (eh * 16 + r) * 64 + lane] = gx[r];
         }
@@ -815,10 +843,18 @@ __global__ __launch_bounds__(256) void sql_fwd32_kernel(const float *__restrict_
             f32x16 d;
 #pragma unroll
             for (int r = 0; r < 16; ++r) d[r] = 0.f;
+            {                                                 // (operands first, then the products: see sql_bwd32q_kernel)
+                float ka[EH][16];
 #pragma unroll
-            for (int eh = 0; eh < EH; ++eh)
+                for (int eh = 0; eh < EH; ++eh)
 #pragma unroll
-                for (int s = 0; s < 16; ++s) d = mfma32(Kl[(qt * 32 + i) * EP + eh * 32 + 16 * h + s], xr[eh][s], d);
+                    for (int s = 0; s < 16; ++s) ka[eh][s] = Kl[(qt * 32 + i) * EP + eh * 32 + 16 * h + s];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int eh = 0; eh < EH; ++eh)
+#pragma unroll
+                    for (int s = 0; s < 16; ++s) d = mfma32(ka[eh][s], xr[eh][s], d);
+            }
             // ---- y out: row q = qt * 32 + acc_row(r, h), 32 consecutive pixels per half-wave
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -863,11 +899,15 @@ __global__ __launch_bounds__(256) void sql_fwd32_kernel(const float *__restrict_
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            {
+                float pa[16];
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const float a = pt[i * PT + 2 * s + h];
+                for (int s = 0; s < 16; ++s) pa[s] = pt[i * PT + 2 * s + h];
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int eh = 0; eh < EH; ++eh) acc2[qt][eh] = mfma32(a, xc[eh][s], acc2[qt][eh]);
+                for (int s = 0; s < 16; ++s)
+#pragma unroll
+                    for (int eh = 0; eh < EH; ++eh) acc2[qt][eh] = mfma32(pa[s], xc[eh][s], acc2[qt][eh]);
             }
         }
         first = false;

@@ -3,6 +3,9 @@ import os, sys
 R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(R, "sfmnext-impl_amd"))
 import torch
+from sqd import lib as _l
+if os.environ.get('SQD_LIB'):
+    _l.SO_PATH = os.path.abspath(os.environ['SQD_LIB']); _l.needs_build = lambda: False      # another build (tools/build_variant.sh)
 from sqd import ops
 B, E, Q, h, w = (int(v) for v in sys.argv[1:6]) if len(sys.argv) > 5 else (12, 32, 64, 96, 320)
 torch.manual_seed(0)

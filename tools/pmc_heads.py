@@ -39,8 +39,10 @@ ALG = {"sql_fwd32_kernel": ("Self Query Layer forward: read x 4E, write y 4Q per
        "sql_bwd32q_kernel": ("Self Query Layer backward: read x 4E, g_y 4Q (+ y recomputed), write g_x 4E", px * 4 * (2 * E + Q)),
        "sql_bwd32_kernel": ("Self Query Layer backward: read x 4E, g_y 4Q (+ y recomputed), write g_x 4E", px * 4 * (2 * E + Q)),
        "bins_fwd_kernel": ("bins head forward: read the energy maps 4Q, write pred 4 per pixel", px * 4 * (Q + 1)),
-       "bins_bwd_kernel": ("bins head backward: read the energy maps 4Q, g 4, write dE 4Q per pixel", px * 4 * (2 * Q + 1))}
-FLOP = {"bins_fwd_kernel": 2.0 * px * Q * D, "bins_bwd_kernel": 6.0 * px * Q * D, "sql_fwd32_kernel": 4.0 * px * Q * E,
+       "bins_bwd_kernel": ("bins head backward: read the energy maps 4Q, g 4, write dE 4Q per pixel", px * 4 * (2 * Q + 1)),
+       "bins_fwd_h_kernel": ("bins head forward on two-term fp16 operands (round 5)", px * 4 * (Q + 1)),
+       "bins_bwd_h_kernel": ("bins head backward, logits and dE on two-term fp16 operands (round 5)", px * 4 * (2 * Q + 1))}
+FLOP = {"bins_fwd_kernel": 2.0 * px * Q * D, "bins_bwd_kernel": 6.0 * px * Q * D, "bins_fwd_h_kernel": 2.0 * px * Q * D, "bins_bwd_h_kernel": 6.0 * px * Q * D, "sql_fwd32_kernel": 4.0 * px * Q * E,
         "sql_bwd32q_kernel": 8.0 * px * Q * E, "sql_bwd32_kernel": 8.0 * px * Q * E}
 print("# Depth-head kernels at B=%d Q=%d D=%d E=%d on %dx%d maps: PMC traffic and durations (one MI355X)\n" % (B, Q, D, E, h, w))
 print("`tools/pmc_heads.sh`: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over tools/bench_bins.py / tools/bench_sql.py, corrected by the "
