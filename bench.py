@@ -137,6 +137,10 @@ def roofline_fused_fwd(trainer, batches, iters=200, graph_us=None):
             "traffic": traffic, "traffic_bytes_per_launch": traffic_bytes, "traffic_source": note,
             "us_per_launch": round(t * 1e6, 2),
             "us_per_launch_eager_steps": eager_us,
+            "clock": ("torch.profiler device activity (roctracer) — the ONE clock of frac / achieved / us_per_launch in this line; the record kept under "
+                      "profiles/ is rocprofv3 --kernel-trace of the same command (profiles/r05*_bench_kernel_trace_stats.md), which reads the same launch "
+                      "5-6 % shorter (51.7 against 53.0-54.5 us in round 5): compare a line with a line and a trace with a trace" if graph_us else
+                      "HIP events on the launch stream (eager steps)"),
             "timing": ("average duration of the launch inside replayed hipGraph training steps (device activity records of 4 steps, child process); "
                        "us_per_launch_eager_steps = median of 10 launches bracketed by HIP events on the launch stream inside EAGER steps" if graph_us else
                        "median of 10 launches, HIP events on the launch stream around the launch inside eager training steps (rotating batches)"
