@@ -25,7 +25,7 @@ with open(out, "w") as f:
     f.write("Steady-state window = %d train steps (after warm-up), %s.\n\n" % (n, workload))
     f.write("wall %.2f ms/step under the profiler, GPU busy %.2f ms/step, %d kernel launches/step\n\n" % ((s1 - s0) / n / 1e6, T / n / 1e6, len(sel) // n))
     f.write("| us/step | calls/step | avg us | kernel |\n|---:|---:|---:|---|\n")
-    for name, t in tot.most_common(70):
+    for name, t in tot.most_common(160):
         f.write("| %.1f | %.1f | %.1f | `%s` |\n" % (t / n / 1e3, cnt[name] / n, t / cnt[name] / 1e3, name[:120].replace("|", "/")))
     for key in ("photo_tile_kernel<1", "photo_tile_kernel<0", "photo_tile_kernel<2", "photo_bwd_tile_kernel", "sql_fwd_kernel", "sql_bwd"):
         pk = [(e - s) / 1e3 for name, s, e in rows if key in name]
