@@ -61,6 +61,58 @@ def test_stereo_step_matches_oracle():
     assert torch.allclose(w_got, w_ref, atol=1e-5), float((w_got - w_ref).abs().max())
 
 
+@pytest.mark.parametrize("frame_ids,stereo,mode", [
+    ((0, -8, 8), False, "pairs"),              # args_files/hisfog/mc/ssl_eff78M_submit.txt
+    ((0, -2, -1, 1), True, "pairs"),           # four source frames with the stereo one: SQD_MAX_SOURCES, two pair passes
+    ((0, -1, 1), False, "all"),                # --pose_model_input all (reference trainer.py:339-361)
+    ((0, -1, 1), True, "all"),
+])
+def test_frame_id_and_pose_input_variants_step_matches_oracle(frame_ids, stereo, mode):
+    """two training steps of the Trainer (the second one of the three through the replayed graph) against the oracle for the frame-id /
+    pose-input variants round 5 added; G24 pins the oracle's handling of them to the reference"""
+    sys.path.insert(0, REPO)
+    from oracle import torch_ref as O
+    from options import MonodepthOptions
+    from trainer import Trainer
+    from datasets.synthetic import synthetic_batch
+    H, W, B = 64, 96, 2
+    args = ["--backbone", "resnet18_lite", "--model_dim", "16", "--patch_size", "8", "--query_nums", "12", "--dim_out", "24",
+            "--height", str(H), "--width", str(W), "--batch_size", str(B), "--num_workers", "0", "--sqd_synthetic",
+            "--log_dir", "/tmp/sqd_variants_test", "--max_depth", "80.0", "--sqd_no_conv_tune", "--pose_model_input", mode,
+            "--frame_ids"] + [str(f) for f in frame_ids] + (["--use_stereo"] if stereo else [])
+    torch.manual_seed(0)
+    tr = Trainer(MonodepthOptions().parse(args))
+    fids = list(frame_ids) + (["s"] if stereo else [])
+    assert tr.opt.frame_ids == fids
+    tr.set_train()
+    _no_dropout(tr.models.values())
+    enc = O.LiteResnetEncoderDecoder(model_dim=16)
+    dep = O.QueryTrDecoder(16, 16, 8, 4, 12, 24, min_val=0.001, max_val=80.0, dim_feedforward=512, dropout=0.0)
+    pose = O.PoseCNN(2 if mode == "pairs" else len(frame_ids))
+    for ref, mine in ((enc, tr.models["encoder"]), (dep, tr.models["depth"]), (pose, tr.models["pose"])):
+        ref.load_state_dict({k: v.detach().cpu() for k, v in mine.state_dict().items()})
+        ref.train()
+    ref = O.RefTrainStep(enc, dep, pose, fids, H, W, use_stereo=stereo, pose_model_input=mode)
+    S = len(fids) - 1
+    g = torch.Generator().manual_seed(3)
+    for step in range(5):                      # three eager steps, then the captured graph (steps 4 and 5 replay it)
+        cpu_inputs = synthetic_batch(B, H, W, frame_ids=fids, start=step * B)
+        noise = torch.randn(B, S, H, W, generator=g)
+        ref_out, ref_losses = ref.step(dict(cpu_inputs), noise)
+        inputs = {k: v.cuda() for k, v in cpu_inputs.items()}
+        inputs[("noise", 0)] = noise.cuda()
+        outputs, losses = tr.train_step(inputs)
+        got, want = float(losses["loss"].detach()), float(ref_losses["loss"].detach())
+        assert abs(got - want) <= 2e-4 * abs(want), (step, got, want)
+        if step == 0:                          # (before the two trainings drift apart by their rounding)
+            for f in fids[1:]:
+                assert float((outputs[("color", f, 0)].cpu() - ref_out[("color", f, 0)].detach()).abs().max()) < 5e-5, f
+    assert tr._graph is not None
+    assert set(k[1] for k in outputs if isinstance(k, tuple) and k[0] == "sample") == set(fids[1:])
+    w_ref, w_got = pose.pose_conv.weight.detach(), tr.models["pose"].pose_conv.weight.detach().cpu()
+    assert torch.allclose(w_got, w_ref, atol=2e-5), float((w_got - w_ref).abs().max())
+
+
 def test_train_py_runs_the_published_resnet_192x640_args(golden, tmp_path):
     """`python train.py args_files/hisfog/kitti/resnet_192x640.txt` of the reference (its tokens are frozen in the options
     fixture): --backbone resnet_lite, 50 layers, --use_stereo, --diff_lr, ... — minus the checkpoint paths that do not exist
