@@ -515,6 +515,11 @@ __global__ __launch_bounds__(256) void sql_bwd32q_kernel(const float *__restrict
     // issued), which keeps the workgroup at 37 KB of LDS: three workgroups per CU (the register file's limit) instead of two
     constexpr int GXW = EH == 1 ? 32 * TP : EH * 16 * 64;         // floats per wave
     float *gxs = EH == 1 ? tiles : tiles + 4 * 32 * TP;
+    // round 5: the x tile(s) of an iteration — 32 pixels x E features each, needed by all QT query-group waves of a pixel tile in two operand
+    // layouts — are fetched ONCE per workgroup (one 16-byte load per thread and 1024 floats, fully coalesced) into [PTW][32][XP] and read from
+    // there; before, every wave fetched them itself: 8 loads of 32 cache lines + 16 loads per wave and tile, 4x over (pixel-major x only)
+    constexpr int XP = EH * 32 + 4;                               // row pitch: 16-byte reads of 16 consecutive rows are conflict-free
+    float *xs = gxs + (EH == 1 ? 0 : 4 * GXW) + (EH == 1 ? 4 * 32 * TP : 0);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wq = wave % QT, wp = wave / QT;
     const int i = lane & 31, h = lane >> 5;
@@ -562,16 +567,28 @@ __global__ __launch_bounds__(256) void sql_bwd32q_kernel(const float *__restrict
         const unsigned lane_q = pv ? ((unsigned)(wq * 32 + 4 * h) * N + p) * 4u : SQL_OOB;   // row 4h of the group's rows of y / g_y, pixel p
         const unsigned lane_gx = pv ? ((unsigned)(4 * h) * xse + (unsigned)p * xsn) * 4u : SQL_OOB;
         const unsigned xse4 = (unsigned)xse * 4u;
+        const bool shared_x = xse == 1;                          // (wave-uniform)
+        if (shared_x) {
+            constexpr int F4 = EH * 8;                           // 16-byte pieces per pixel row
+#pragma unroll
+            for (int v = 0; v < PTW * 32 * F4 / 256; ++v) {
+                const int idx = threadIdx.x + 256 * v, pt = idx / (32 * F4), rem = idx - pt * (32 * F4), px = rem / F4, f4 = rem - px * F4;
+                const int pg = ((it * nchunks + chunk) * PTW + pt) * 32 + px;
+                const sql_i32x4 f = __builtin_amdgcn_raw_buffer_load_b128(x_r, (pg < N && 4 * f4 < E) ? ((unsigned)pg * (unsigned)xsn + 4u * f4) * 4u : SQL_OOB, 0, 0);
+                *reinterpret_cast<sql_i32x4 *>(xs + (pt * 32 + px) * XP + 4 * f4) = f;
+            }
+            __syncthreads();
+        }
+        const float *xt = xs + wp * 32 * XP;                      // this wave's pixel tile
         float xe[EH][16];
 #pragma unroll
         for (int eh = 0; eh < EH; ++eh) {
-            if (xse == 1) {                                  // pixel-major: 32 features of the lane are one 128-byte run — 8 x 16-byte loads
-                const unsigned px_off = pv ? (unsigned)p * (unsigned)xsn * 4u : SQL_OOB;
+            if (shared_x) {                                  // the lane's pixel row: 8 x 16-byte LDS reads per 32 features
 #pragma unroll
                 for (int q8 = 0; q8 < 8; ++q8) {
-                    const sql_i32x4 f = __builtin_amdgcn_raw_buffer_load_b128(x_r, eh * 32 + 4 * q8 < E ? px_off + 128u * eh + 16u * q8 : SQL_OOB, 0, 0);
-                    xe[eh][2 * q8] = __int_as_float(h ? f.y : f.x);          // feature 32 eh + 4 q8 + h
-                    xe[eh][2 * q8 + 1] = __int_as_float(h ? f.w : f.z);      // feature 32 eh + 4 q8 + 2 + h
+                    const float4 f = *reinterpret_cast<const float4 *>(xt + i * XP + eh * 32 + 4 * q8);
+                    xe[eh][2 * q8] = h ? f.y : f.x;          // feature 32 eh + 4 q8 + h
+                    xe[eh][2 * q8 + 1] = h ? f.w : f.z;      // feature 32 eh + 4 q8 + 2 + h
                 }
             } else {
 #pragma unroll
@@ -593,7 +610,10 @@ __global__ __launch_bounds__(256) void sql_bwd32q_kernel(const float *__restrict
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int px = 8 * gq + 4 * h, ei = eh * 32 + i;
-                if (vec_ok && xsn == 1) {                            // planar, N % 4 == 0: a float4 is inside a plane or beyond it
+                if (shared_x) {                                      // lane = feature: four pixels of the shared tile
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) xv[eh][gq][j] = xt[(px + j) * XP + ei];
+                } else if (vec_ok && xsn == 1) {                     // planar, N % 4 == 0: a float4 is inside a plane or beyond it
                     const sql_i32x4 t4 = __builtin_amdgcn_raw_buffer_load_b128(
                         x_r, (ei < E && p0 + px < N) ? ((unsigned)ei * xse + p0 + px) * 4u : SQL_OOB, 0, 0);
                     xv[eh][gq][0] = __int_as_float(t4.x); xv[eh][gq][1] = __int_as_float(t4.y);
@@ -1097,7 +1117,8 @@ extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const
         hipLaunchKernelGGL((sql_bwd32_kernel<QT_, EH_>), dim3(p.nchunks_bwd, B), dim3(256), shmem, (hipStream_t)stream, x, K, y, g_y, \
                            g_summary, summary, lse, g_x, gk_part, Q, E, N, p.nchunks_bwd, xse, xsn);                                \
     }
-        const size_t shmem_q = ((size_t)2 * QP * (eh * 32 + 1) + QP * 4 + (size_t)4 * 32 * TP + (eh == 1 ? 0 : (size_t)4 * eh * 16 * 64)) * sizeof(float);
+        const size_t shmem_q = ((size_t)2 * QP * (eh * 32 + 1) + QP * 4 + (size_t)4 * 32 * TP + (eh == 1 ? 0 : (size_t)4 * eh * 16 * 64) +
+                                (size_t)(4 / qt) * 32 * (eh * 32 + 4)) * sizeof(float);      // (+ the shared x tiles of an iteration)
 #define SQL_BWD32Q(QT_, EH_)                                                                                                    \
     {                                                                                                                           \
         if (shmem_q > 48 * 1024)                                                                                                \
