@@ -130,3 +130,32 @@ def test_bins_head_f16x2_wide_dynamic_range():
     print("max |pred - float64|: f16x2 %.3e, fp32 MFMA %.3e" % (e16, e32))
     assert e16 <= max(4 * e32, 1e-4), (e16, e32)
 
+
+def test_bins_head_f16x2_gradients_wide_range_along_the_image():
+    """gradients under a wide dynamic range ALONG the image: the upstream gradient grows by 2^24 and the energies by 2^6 from the first to the
+    last pixel, so that every per-pixel operand scale of the dE product differs and the weight gradient sums terms 2^30 apart — all four
+    gradients must match float64 at the fp32 instruction's accuracy (the test that held round 5's running-scale fp16 weight-gradient
+    product, tools/experiments/bins_bwd_dw_f16_running_scale_r05.diff: parity-green, no faster, not kept)"""
+    from sqd import lib, ops
+    g = torch.Generator().manual_seed(91)
+    B, Q, D, h, w = 2, 64, 64, 48, 64
+    ramp = torch.exp2(torch.linspace(0, 1, h * w).view(1, 1, h, w) * 24.0)
+    energy = torch.randn(B, Q, h, w, generator=g) * torch.exp2(torch.linspace(-3, 3, h * w).view(1, 1, h, w))
+    weight = 0.05 * torch.randn(D, Q, 1, 1, generator=g)
+    bias = 0.1 * torch.randn(D, generator=g)
+    centers = torch.sort(torch.rand(B, D, generator=g) * 80.0, dim=1).values
+    gout = torch.randn(B, 1, h, w, generator=g) * ramp * 2.0 ** -20
+    ref_in = [t.detach().clone().double().requires_grad_(True) for t in (energy, weight, bias, centers)]
+    composite(*ref_in).backward(gout.double())
+    errs = {}
+    for arith in (1, 0):
+        lib.check(lib.lib().sqd_bins_set_arith(arith), "bins_set_arith")
+        dev_in = [t.detach().clone().cuda().requires_grad_(True) for t in (energy, weight, bias, centers)]
+        ops.BinsHead.apply(*dev_in).backward(gout.cuda())
+        for name, a, r in zip(("energy", "weight", "bias", "centers"), dev_in, ref_in):
+            errs[(arith, name)] = float((a.grad.cpu().double() - r.grad).abs().max()) / (float(r.grad.abs().max()) + 1e-30)
+    lib.check(lib.lib().sqd_bins_set_arith(1), "bins_set_arith")
+    print({k: "%.2e" % v for k, v in errs.items()})
+    for name in ("energy", "weight", "bias", "centers"):
+        assert errs[(1, name)] <= max(4 * errs[(0, name)], 2e-5), (name, errs[(1, name)], errs[(0, name)])
+
