@@ -12,7 +12,7 @@ run() {   # name, SQD_BENCH_EXTRA, workload line
   timeout 900 python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-diagnostics > $out/${tag}_$1_bench_line.json 2> $out/$1.err
   timeout 900 rocprofv3 --kernel-trace --stats -d $out/trace_$1 -- python $R/bench.py --steps 12 --warmup 5 --no-cpu-baseline --no-roofline --no-diagnostics > /dev/null 2> $out/$1.trace.err
   db=$(find $out/trace_$1 -name "*.db" | head -1)
-  [ -n "$db" ] && python $R/tools/prof_summary.py $db $out/${tag}_$1_kernel_trace_stats.md "Round ${tag:1:2} ($tag): $3 — rocprofv3 --kernel-trace --stats -- SQD_BENCH_EXTRA='$2' python bench.py --steps 12 --warmup 5" "bins_fwd_kernel" "$3" > /dev/null
+  [ -n "$db" ] && python $R/tools/prof_summary.py $db $out/${tag}_$1_kernel_trace_stats.md "Round ${tag:1:2} ($tag): $3 — rocprofv3 --kernel-trace --stats -- SQD_BENCH_EXTRA='$2' python bench.py --steps 12 --warmup 5" "bins_fwd_" "$3" > /dev/null
   unset SQD_BENCH_EXTRA SQD_BENCH_WORKLOAD
   rm -rf $out/trace_$1          # (the raw trace is ~30 MB per run; gpurun copies at most 64 MB back)
   head -c 500 $out/${tag}_$1_bench_line.json; echo; sed -n 3,8p $out/${tag}_$1_kernel_trace_stats.md | cut -c1-150
