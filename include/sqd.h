@@ -444,6 +444,8 @@ int sqd_space_to_depth2_planar_amax(const float *x0, const float *x1, float *y, 
                                     int64_t y_stride, float sub, float div, float *amax_y, void *stream);
 /* the matching filter regrouping w [K,C,7,7] -> ws [K,4,4,Cp] (tap u = 2r' + dy - 1; adjoint = 1: g_ws -> g_w, fully overwritten) */
 int sqd_stem_regroup(const float *src, float *dst, int K, int C, int Cp, int adjoint, void *stream);
+/* ... with the 7x7 filter (adjoint: its gradient) in channels-last memory [K,7,7,C] when w_channels_last != 0 — no layout copy on either side */
+int sqd_stem_regroup_ex(const float *src, float *dst, int K, int C, int Cp, int adjoint, int w_channels_last, void *stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * (13) token-wise blocks of the post-norm TransformerEncoderLayer over the patch tokens.  replaces: the feed-forward and the

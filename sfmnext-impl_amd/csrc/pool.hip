@@ -173,16 +173,19 @@ __global__ __launch_bounds__(256) void s2d_planar_kernel(const float *__restrict
 
 // filter regrouping of the space-to-depth stems and its adjoint:
 //   w [K,C,7,7] (KCRS) <-> ws [K,4,4,Cp] (KRSC', channel c*4 + dy*2 + dx), tap u = 2r' + dy - 1, v = 2s' + dx - 1
+// (wcl: the 7x7 filter / its gradient lives in channels-last memory [K,7,7,C] — what torch keeps behind a channels_last parameter —
+//  instead of [K,C,7,7]: read / written in place, no layout copy on either side)
 template <bool ADJOINT>
-__global__ __launch_bounds__(256) void stem_regroup_kernel(const float *__restrict__ src, float *__restrict__ dst, int K, int C, int Cp) {
+__global__ __launch_bounds__(256) void stem_regroup_kernel(const float *__restrict__ src, float *__restrict__ dst, int K, int C, int Cp, int wcl) {
     const int total = K * 16 * Cp;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
         const int ch = i % Cp, rs = (i / Cp) % 16, k = i / (16 * Cp);
         const int c = ch >> 2, dy = (ch >> 1) & 1, dx = ch & 1, rp = rs >> 2, sp = rs & 3;
         const int u = 2 * rp + dy - 1, v = 2 * sp + dx - 1;
         const bool ok = c < C && u >= 0 && u < 7 && v >= 0 && v < 7;
-        if (!ADJOINT) dst[i] = ok ? src[((k * C + c) * 7 + u) * 7 + v] : 0.f;
-        else if (ok) dst[((k * C + c) * 7 + u) * 7 + v] = src[i];       // every (k,c,u,v) has exactly one (r',dy,s',dx)
+        const int wi = wcl ? ((k * 7 + u) * 7 + v) * C + c : ((k * C + c) * 7 + u) * 7 + v;
+        if (!ADJOINT) dst[i] = ok ? src[wi] : 0.f;
+        else if (ok) dst[wi] = src[i];                                  // every (k,c,u,v) has exactly one (r',dy,s',dx)
     }
 }
 }  // namespace
@@ -227,12 +230,15 @@ extern "C" int sqd_space_to_depth2_planar_amax(const float *x0, const float *x1,
 }
 
 // w [K,C,7,7] contiguous -> ws [K,4,4,Cp] (adjoint = 0) or g_ws [K,4,4,Cp] -> g_w [K,C,7,7] fully overwritten (adjoint = 1)
-extern "C" int sqd_stem_regroup(const float *src, float *dst, int K, int C, int Cp, int adjoint, void *stream) {
+extern "C" int sqd_stem_regroup_ex(const float *src, float *dst, int K, int C, int Cp, int adjoint, int w_channels_last, void *stream) {
     SQD_CHECK_ARG(src && dst && K > 0 && C > 0 && Cp >= 4 * C, "sqd_stem_regroup: bad arguments");
     (void)hipGetLastError();
     const int nb = (K * 16 * Cp + 255) / 256;
-    if (adjoint) hipLaunchKernelGGL((stem_regroup_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, dst, K, C, Cp);
-    else hipLaunchKernelGGL((stem_regroup_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, dst, K, C, Cp);
+    if (adjoint) hipLaunchKernelGGL((stem_regroup_kernel<true>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, dst, K, C, Cp, w_channels_last);
+    else hipLaunchKernelGGL((stem_regroup_kernel<false>), dim3(nb), dim3(256), 0, (hipStream_t)stream, src, dst, K, C, Cp, w_channels_last);
     SQD_CHECK_LAUNCH("sqd_stem_regroup");
     return SQD_OK;
+}
+extern "C" int sqd_stem_regroup(const float *src, float *dst, int K, int C, int Cp, int adjoint, void *stream) {
+    return sqd_stem_regroup_ex(src, dst, K, C, Cp, adjoint, 0, stream);
 }

@@ -1364,19 +1364,20 @@ class StemRegroup(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w, Cp):
         K, C = w.shape[0], w.shape[1]
-        wc = w.contiguous()
+        cl = w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous()
+        wc = w if cl else w.contiguous()                 # (a channels-last parameter is read in place: no layout copy)
         ws = torch.empty((K, Cp, 4, 4), device=w.device, dtype=torch.float32, memory_format=torch.channels_last)
-        _l.check(_l.lib().sqd_stem_regroup(_ptr(wc), _ptr(ws), K, C, Cp, 0, _stream()), "stem_regroup")
-        ctx.dims = (K, C, Cp, w.is_contiguous(memory_format=torch.channels_last) and not w.is_contiguous())
+        _l.check(_l.lib().sqd_stem_regroup_ex(_ptr(wc), _ptr(ws), K, C, Cp, 0, 1 if cl else 0, _stream()), "stem_regroup")
+        ctx.dims = (K, C, Cp, cl)
         return ws
 
     @staticmethod
     def backward(ctx, g):
         K, C, Cp, cl = ctx.dims
         g = _cl(g)
-        gw = torch.empty((K, C, 7, 7), device=g.device, dtype=torch.float32)
-        _l.check(_l.lib().sqd_stem_regroup(_ptr(g), _ptr(gw), K, C, Cp, 1, _stream()), "stem_regroup_adjoint")
-        return (gw.contiguous(memory_format=torch.channels_last) if cl else gw), None
+        gw = torch.empty((K, C, 7, 7), device=g.device, dtype=torch.float32, memory_format=torch.channels_last if cl else torch.contiguous_format)
+        _l.check(_l.lib().sqd_stem_regroup_ex(_ptr(g), _ptr(gw), K, C, Cp, 1, 1 if cl else 0, _stream()), "stem_regroup_adjoint")
+        return gw, None
 
 
 _STEM3_INDEX = {}

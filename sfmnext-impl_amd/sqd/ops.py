@@ -284,6 +284,11 @@ def smooth_loss_plain(disp, img):
 
 
 # ---------------------------------------------------------------------------------------------------
+# set by Trainer._backward for the duration of loss.backward() when the loss IS the chain's total (one scale): the upstream gradient is the
+# unit seed, and the three element-wise products by it are skipped
+UNIT_UPSTREAM = False
+
+
 class PhotometricChain(torch.autograd.Function):
     """generate_images_pred + compute_losses of the reference (trainer.py:386-549) as one autograd node.
 
@@ -352,6 +357,8 @@ class PhotometricChain(torch.autograd.Function):
             g_aa, g_tr, g_mid = pose_mats_bwd(axisangle, translation, meta["invert"], K, mid,
                                               g_P if n_pose == S else g_P[:, :n_pose].contiguous())
         g_disp = depth_up_bwd(planes, depth, g_mid, h, w)
+        if UNIT_UPSTREAM:                         # (the Trainer differentiates the chain's total itself: the seed is exactly 1 — no scaling launches)
+            return (g_disp, g_aa if n_pose else None, g_tr if n_pose else None, None, None, None, None, None) + (None,) * S
         g = g_total
         return (g_disp * g, g_aa * g if n_pose else None, g_tr * g if n_pose else None, None, None, None, None, None) + (None,) * S
 

@@ -409,10 +409,13 @@ class Trainer:
         nnkernels.DEFERRED_GRAD_HOOK = self.reducer.on_deferred_grad if self.reducer is not None and self.reducer.buckets is not None else None
         if self.reducer is not None and self.reducer.buckets is None:
             nnkernels.DEFER_WGRAD_REDUCE = False         # (its parameters have no hooks yet, but finish() reads every gradient right after)
+        ops.UNIT_UPSTREAM = loss is getattr(self, "_chain_total", None)      # (one scale: the loss is the chain's total itself, its seed is 1)
         try:
             loss.backward()
             nnkernels.join_wgrad_stream()                # the caller's stream joins it before anything reads the gradients
         finally:
+            ops.UNIT_UPSTREAM = False
+            self._chain_total = None
             nnkernels.WGRAD_STREAM = None
             nnkernels.DEFER_WGRAD_REDUCE = False
             nnkernels.DEFERRED_GRAD_HOOK = None
@@ -641,6 +644,7 @@ class Trainer:
         if ("_chain", 0) not in outputs:
             self.generate_images_pred(inputs, outputs)
         total, sel = outputs.pop(("_chain", 0))
+        self._chain_total = total
         if not self.opt.disable_automasking:             # (trainer.py:523-525)
             outputs["identity_selection/0"] = sel
         loss = total / self.num_scales if self.num_scales != 1 else total          # (scale 0 only: no division kernel)
