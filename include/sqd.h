@@ -447,6 +447,10 @@ int sqd_stem_regroup(const float *src, float *dst, int K, int C, int Cp, int adj
 /* ... with the 7x7 filter (adjoint: its gradient) in channels-last memory [K,7,7,C] when w_channels_last != 0 — no layout copy on either side */
 int sqd_stem_regroup_ex(const float *src, float *dst, int K, int C, int Cp, int adjoint, int w_channels_last, void *stream);
 
+/* patch tokens + positional encodings (reference networks/depth_decoder_QTR.py:49-51): emb [B,T,E] (the embedding convolution's channels-last
+ * output), pos [Tmax,E] -> out [T,B,E] = emb + pos[:T]; backward: g [T,B,E] -> g_emb [B,T,E], g_pos [Tmax,E] (rows >= T zero) */
+int sqd_tokens_pos_fwd(const float *emb, const float *pos, float *out, int B, int T, int E, void *stream);
+int sqd_tokens_pos_bwd(const float *g, float *g_emb, float *g_pos, int B, int T, int E, int Tmax, void *stream);
 /* ---------------------------------------------------------------------------------------------------
  * (13) token-wise blocks of the post-norm TransformerEncoderLayer over the patch tokens.  replaces: the feed-forward and the
  * two add+dropout+LayerNorm steps of nn.TransformerEncoderLayer as the reference builds it at

@@ -421,6 +421,52 @@ int vit_check(const char *who, int rows, int E) {
 // embedding widths: any multiple of 4 up to 64 — the token-wise kernels mask the lanes / reduction slots beyond E (one half-wave per row up
 // to 32 features, a whole wave beyond; feed-forward blocks of 32 features).  The reference's args files use 32 (KITTI), 64 and 56
 // (args_files/args_cityscapes_train.txt:9: --model_dim 56).
+// ---------------------------------------------------------------------------------------------------------------------------------
+// patch tokens + positional encodings (reference networks/depth_decoder_QTR.py:49-51: embedding.flatten(2) + positional_encodings[:T].T,
+// then .permute(2, 0, 1)): the embedding convolution's output is channels-last memory [B][T][E]; the encoder wants [T][B][E].  One launch
+// each way instead of add + layout copy forward and sum + zero-fill + slice copy + layout copy backward.
+//   fwd: out[t][b][e] = emb[b][t][e] + pos[t][e]
+//   bwd: g_emb[b][t][e] = g[t][b][e];  g_pos[t][e] = sum_b g[t][b][e] for t < T, 0 for the rows of the table the step did not use
+namespace {
+__global__ __launch_bounds__(256) void tokens_pos_fwd_kernel(const float *__restrict__ emb, const float *__restrict__ pos, float *__restrict__ out,
+                                                             int B, int T, int E) {
+    const int n = B * T * E;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+        const int e = idx % E, b = (idx / E) % B, t = idx / (E * B);
+        out[idx] = emb[((size_t)b * T + t) * E + e] + pos[(size_t)t * E + e];
+    }
+}
+__global__ __launch_bounds__(256) void tokens_pos_bwd_kernel(const float *__restrict__ g, float *__restrict__ g_emb, float *__restrict__ g_pos,
+                                                             int B, int T, int E, int Tmax) {
+    const int n = Tmax * E;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+        const int e = idx % E, t = idx / E;
+        float s = 0.f;
+        if (t < T)
+            for (int b = 0; b < B; ++b) {                       // (fixed order: deterministic)
+                const float v = g[((size_t)t * B + b) * E + e];
+                g_emb[((size_t)b * T + t) * E + e] = v;
+                s += v;
+            }
+        g_pos[idx] = s;
+    }
+}
+}  // namespace
+extern "C" int sqd_tokens_pos_fwd(const float *emb, const float *pos, float *out, int B, int T, int E, void *stream) {
+    SQD_CHECK_ARG(emb && pos && out && B > 0 && T > 0 && E > 0, "sqd_tokens_pos_fwd: bad arguments");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(tokens_pos_fwd_kernel, dim3((B * T * E + 255) / 256), dim3(256), 0, (hipStream_t)stream, emb, pos, out, B, T, E);
+    SQD_CHECK_LAUNCH("sqd_tokens_pos_fwd");
+    return SQD_OK;
+}
+extern "C" int sqd_tokens_pos_bwd(const float *g, float *g_emb, float *g_pos, int B, int T, int E, int Tmax, void *stream) {
+    SQD_CHECK_ARG(g && g_emb && g_pos && B > 0 && T > 0 && E > 0 && Tmax >= T, "sqd_tokens_pos_bwd: bad arguments");
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(tokens_pos_bwd_kernel, dim3((Tmax * E + 255) / 256), dim3(256), 0, (hipStream_t)stream, g, g_emb, g_pos, B, T, E, Tmax);
+    SQD_CHECK_LAUNCH("sqd_tokens_pos_bwd");
+    return SQD_OK;
+}
+
 extern "C" int sqd_vit_supported(int E, int F) { return (E >= 4 && E <= 64 && E % 4 == 0 && F >= 4 && F % 4 == 0 && F <= 8192) ? 1 : 0; }
 
 // ---- add + dropout + LayerNorm.  x [rows,E]; y [nparts][rows,E] (summed, + ybias [E] if not NULL); mask [rows,E] bytes

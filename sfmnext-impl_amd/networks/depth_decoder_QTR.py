@@ -46,9 +46,9 @@ class _QueryTrBase(nn.Module):
         # 3x3 data gradient's epilogue instead of by a pass of its own over [B,C,h,w] (same forward values: the order of two independent
         # convolutions)
         feat, x0p = X.conv2d(x0, self.conv3x3, skip=True)
-        tokens = X.conv2d(x0p, self.embedding_convPxP).flatten(2)                      # [B,E,T]
-        tokens = tokens + self.positional_encodings[:tokens.shape[2], :].T.unsqueeze(0)
-        tokens = X.transformer_encoder(tokens.permute(2, 0, 1), self.transformer_encoder)   # [T,B,E]
+        # embedding.flatten(2) + positional_encodings[:T].T, permuted to [T,B,E] (reference :49-51), one launch
+        tokens = X.tokens_with_positions(X.conv2d(x0p, self.embedding_convPxP), self.positional_encodings)
+        tokens = X.transformer_encoder(tokens, self.transformer_encoder)               # [T,B,E]
         queries = tokens[:self.query_nums, ...].permute(1, 0, 2).contiguous()          # first Q tokens, [B,Q,E]
         energy_maps, summaries = self.full_query_layer(feat, queries)
         bs, Q, E = summaries.shape

@@ -1743,6 +1743,30 @@ def encoder_supported(encoder):
     return True
 
 
+class TokensWithPos(torch.autograd.Function):
+    """emb [B,E,h,w] (channels-last memory = [B][T][E]) + pos[:T] -> tokens [T,B,E]: reference networks/depth_decoder_QTR.py:49-51 in one launch
+    each way (the gradient of the positional table arrives whole, zero rows included)"""
+
+    @staticmethod
+    def forward(ctx, emb, pos):
+        B, E, h, w = emb.shape
+        T = h * w
+        embc = _cl(emb)
+        out = torch.empty((T, B, E), device=emb.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_tokens_pos_fwd(_ptr(embc), _ptr(pos), _ptr(out), B, T, E, _stream()), "tokens_pos_fwd")
+        ctx.dims = (B, E, h, w, pos.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        B, E, h, w, Tmax = ctx.dims
+        g = g.contiguous()
+        g_emb = torch.empty((B, E, h, w), device=g.device, dtype=torch.float32, memory_format=torch.channels_last)
+        g_pos = torch.empty((Tmax, E), device=g.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_tokens_pos_bwd(_ptr(g), _ptr(g_emb), _ptr(g_pos), B, h * w, E, Tmax, _stream()), "tokens_pos_bwd")
+        return g_emb, g_pos
+
+
 def transformer_encoder_native(tokens, encoder):
     """tokens [S,B,E] through the encoder on the fused kernels (EncoderStack): S <= 512 tokens (the positional table holds 500; 256 at
     width 56 / 64), head dimension 4 | 8 | 14 | 16.  A token count or head dimension the attention kernel does not take raises — self-attention never

@@ -256,6 +256,16 @@ def linear(x, lin, act=None):
     return nnkernels.linear_native(x, lin, act)
 
 
+def tokens_with_positions(emb, pos):
+    """the patch embedding [B,E,h,w] plus the first h*w rows of the positional table [Tmax,E], as the [T,B,E] sequence the encoder reads
+    (reference networks/depth_decoder_QTR.py:49-51: flatten(2) + positional_encodings[:T].T, permute(2, 0, 1))"""
+    _device_only(emb, "tokens_with_positions")
+    from . import nnkernels
+    if emb.shape[2] * emb.shape[3] > pos.shape[0] or pos.shape[1] != emb.shape[1] or not pos.is_contiguous():
+        raise RuntimeError("sqd: %d patch tokens of width %d against a positional table %s" % (emb.shape[2] * emb.shape[3], emb.shape[1], tuple(pos.shape)))
+    return nnkernels.TokensWithPos.apply(emb, pos)
+
+
 def transformer_encoder(tokens, encoder):
     """tokens [T,B,E] through nn.TransformerEncoder (4 post-norm layers, ReLU feed-forward)."""
     _device_only(tokens, "transformer_encoder")

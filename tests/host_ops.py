@@ -108,7 +108,12 @@ def patchify_conv(x, conv, s):
     return F.conv2d(x, conv.weight, conv.bias, s)
 
 
-NAMES = ("_conv", "conv2d", "conv_bn_act", "pose_head", "maxpool3x3s2", "upsample_concat", "linear", "transformer_encoder",
+def tokens_with_positions(emb, pos):
+    tokens = emb.flatten(2)                                     # reference networks/depth_decoder_QTR.py:49-51
+    return (tokens + pos[:tokens.shape[2], :].T.unsqueeze(0)).permute(2, 0, 1)
+
+
+NAMES = ("_conv", "conv2d", "conv_bn_act", "pose_head", "maxpool3x3s2", "upsample_concat", "linear", "transformer_encoder", "tokens_with_positions",
          "full_query_layer", "bins_head", "layer_norm_channels", "gelu", "scale_residual", "upsample2x", "dw_conv", "linear_channels",
          "patchify_conv")
 

@@ -313,3 +313,27 @@ def test_encoder_width_the_kernels_do_not_take_raises():
     with pytest.raises(RuntimeError, match="no ATen fallback"):
         nnops.transformer_encoder(torch.randn(600, 1, 32, device="cuda"), enc)
     assert not nnops.ATEN_CALLS
+
+
+@pytest.mark.parametrize("B,E,h,w", [(2, 32, 6, 20), (3, 56, 5, 7), (1, 16, 1, 1)])
+def test_tokens_with_positions(B, E, h, w):
+    """embedding.flatten(2) + positional_encodings[:T].T, permuted to [T,B,E] (reference networks/depth_decoder_QTR.py:49-51) as one launch each
+    way: values and both gradients equal the torch composite bit for bit (sums over the batch in index order); unused table rows get zeros"""
+    from sqd import nnops
+    torch.manual_seed(B * 100 + E)
+    emb = torch.randn(B, E, h, w, device="cuda").contiguous(memory_format=torch.channels_last).requires_grad_(True)
+    pos = torch.rand(500, E, device="cuda").requires_grad_(True)
+    g = torch.randn(h * w, B, E, device="cuda")
+    out = nnops.tokens_with_positions(emb, pos)
+    out.backward(g)
+    emb2, pos2 = emb.detach().clone().requires_grad_(True), pos.detach().clone().requires_grad_(True)
+    tok = emb2.flatten(2)
+    ref = (tok + pos2[:tok.shape[2], :].T.unsqueeze(0)).permute(2, 0, 1)
+    ref.backward(g)
+    assert out.shape == (h * w, B, E) and out.is_contiguous()
+    assert torch.equal(out, ref)
+    assert torch.equal(emb.grad, emb2.grad)
+    assert torch.allclose(pos.grad, pos2.grad, rtol=0, atol=1e-6) and float(pos.grad[h * w:].abs().max() if h * w < 500 else 0) == 0.0
+    with pytest.raises(RuntimeError):
+        nnops.tokens_with_positions(torch.randn(1, E, 30, 20, device="cuda"), pos)      # 600 tokens against 500 rows
+
