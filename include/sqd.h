@@ -451,6 +451,11 @@ int sqd_stem_regroup_ex(const float *src, float *dst, int K, int C, int Cp, int 
  * output), pos [Tmax,E] -> out [T,B,E] = emb + pos[:T]; backward: g [T,B,E] -> g_emb [B,T,E], g_pos [Tmax,E] (rows >= T zero) */
 int sqd_tokens_pos_fwd(const float *emb, const float *pos, float *out, int B, int T, int E, void *stream);
 int sqd_tokens_pos_bwd(const float *g, float *g_emb, float *g_pos, int B, int T, int E, int Tmax, void *stream);
+/* the first Q tokens as the query matrix (reference networks/depth_decoder_QTR.py:52): src [T,B,E] -> dst [B,Q,E]; adjoint != 0: src [B,Q,E] ->
+ * dst [T,B,E] with zero rows for t >= Q */
+int sqd_first_queries(const float *src, float *dst, int T, int B, int Q, int E, int adjoint, void *stream);
+/* out [n] = (add ? add[n] : 0) + sum_k parts[k][n] in index order (n a multiple of 4) */
+int sqd_sum_parts(const float *parts, const float *add, float *out, int nparts, int64_t n, void *stream);
 /* ---------------------------------------------------------------------------------------------------
  * (13) token-wise blocks of the post-norm TransformerEncoderLayer over the patch tokens.  replaces: the feed-forward and the
  * two add+dropout+LayerNorm steps of nn.TransformerEncoderLayer as the reference builds it at

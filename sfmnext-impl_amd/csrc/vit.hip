@@ -467,6 +467,51 @@ extern "C" int sqd_tokens_pos_bwd(const float *g, float *g_emb, float *g_pos, in
     return SQD_OK;
 }
 
+// the first Q tokens of the encoder's output as the query matrix [B,Q,E] (reference networks/depth_decoder_QTR.py:52:
+// tokens[:Q].permute(1, 0, 2)) and its adjoint (zero rows for the tokens that are not queries); out = (add ? add : 0) + sum_k parts[k]
+namespace {
+__global__ __launch_bounds__(256) void first_queries_kernel(const float *__restrict__ src, float *__restrict__ dst, int T, int B, int Q, int E, int adjoint) {
+    const int n = adjoint ? T * B * E : B * Q * E;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n; idx += gridDim.x * 256) {
+        if (!adjoint) {
+            const int e = idx % E, q = (idx / E) % Q, b = idx / (E * Q);
+            dst[idx] = src[((size_t)q * B + b) * E + e];
+        } else {
+            const int e = idx % E, b = (idx / E) % B, t = idx / (E * B);
+            dst[idx] = t < Q ? src[((size_t)b * Q + t) * E + e] : 0.f;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void sum_parts_kernel(const float *__restrict__ parts, const float *__restrict__ add, float *__restrict__ out, int nparts,
+                                                        int n4) {
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < n4; idx += gridDim.x * 256) {
+        float4 a = add ? reinterpret_cast<const float4 *>(add)[idx] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 s = reinterpret_cast<const float4 *>(parts)[idx];
+        for (int k = 1; k < nparts; ++k) {                      // (torch's sum over dim 0 adds in index order too)
+            const float4 v = reinterpret_cast<const float4 *>(parts)[(size_t)k * n4 + idx];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        reinterpret_cast<float4 *>(out)[idx] = make_float4(s.x + a.x, s.y + a.y, s.z + a.z, s.w + a.w);
+    }
+}
+}  // namespace
+extern "C" int sqd_first_queries(const float *src, float *dst, int T, int B, int Q, int E, int adjoint, void *stream) {
+    SQD_CHECK_ARG(src && dst && T > 0 && B > 0 && Q > 0 && Q <= T && E > 0, "sqd_first_queries: bad arguments");
+    (void)hipGetLastError();
+    const int n = adjoint ? T * B * E : B * Q * E;
+    hipLaunchKernelGGL(first_queries_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, dst, T, B, Q, E, adjoint);
+    SQD_CHECK_LAUNCH("sqd_first_queries");
+    return SQD_OK;
+}
+extern "C" int sqd_sum_parts(const float *parts, const float *add, float *out, int nparts, int64_t n, void *stream) {
+    SQD_CHECK_ARG(parts && out && nparts >= 1 && n > 0 && n % 4 == 0 && n / 4 < (1ll << 31), "sqd_sum_parts: bad arguments (n must be a multiple of 4)");
+    (void)hipGetLastError();
+    const int n4 = (int)(n / 4);
+    hipLaunchKernelGGL(sum_parts_kernel, dim3((n4 + 255) / 256), dim3(256), 0, (hipStream_t)stream, parts, add, out, nparts, n4);
+    SQD_CHECK_LAUNCH("sqd_sum_parts");
+    return SQD_OK;
+}
+
 extern "C" int sqd_vit_supported(int E, int F) { return (E >= 4 && E <= 64 && E % 4 == 0 && F >= 4 && F % 4 == 0 && F <= 8192) ? 1 : 0; }
 
 // ---- add + dropout + LayerNorm.  x [rows,E]; y [nparts][rows,E] (summed, + ybias [E] if not NULL); mask [rows,E] bytes

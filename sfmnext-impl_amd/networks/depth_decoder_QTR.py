@@ -49,7 +49,7 @@ class _QueryTrBase(nn.Module):
         # embedding.flatten(2) + positional_encodings[:T].T, permuted to [T,B,E] (reference :49-51), one launch
         tokens = X.tokens_with_positions(X.conv2d(x0p, self.embedding_convPxP), self.positional_encodings)
         tokens = X.transformer_encoder(tokens, self.transformer_encoder)               # [T,B,E]
-        queries = tokens[:self.query_nums, ...].permute(1, 0, 2).contiguous()          # first Q tokens, [B,Q,E]
+        queries = X.first_queries(tokens, self.query_nums)                             # first Q tokens, [B,Q,E]
         energy_maps, summaries = self.full_query_layer(feat, queries)
         bs, Q, E = summaries.shape
         y = summaries.reshape(bs, Q * E)

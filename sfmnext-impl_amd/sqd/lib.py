@@ -256,6 +256,8 @@ _SIGNATURES = {
     "sqd_space_to_depth2_planar": (_I, [_P, _P, _P] + [_I] * 6 + [ctypes.c_int64, ctypes.c_float, ctypes.c_float, _P]),
     "sqd_tokens_pos_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "sqd_tokens_pos_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
+    "sqd_first_queries": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    "sqd_sum_parts": (_I, [_P, _P, _P, _I, ctypes.c_int64, _P]),
     "sqd_stem_regroup": (_I, [_P, _P, _I, _I, _I, _I, _P]),
     "sqd_stem_regroup_ex": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_smooth_nblk": (_I, [_I, _I]),

@@ -1715,7 +1715,11 @@ class EncoderStack(torch.autograd.Function):
                            (pb1, gb1, 0), (pb2, small[1], 0), (part1, small[2:4], 0), (part2, small[4:6], 0)])
             grads[12 * li:12 * li + 12] = [gWin, gbin, gWo, small[0], small[2], small[3], gW1, gb1, gW2, small[1], small[4], small[5]]
             g, extra, nextra = dz1, apart, H
-        g_tokens = extra.sum(0).view(S, B, E).add_(g)
+        g_tokens = torch.empty((S, B, E), device=g.device, dtype=torch.float32)       # sum of the attention partials + g, one launch
+        if (S * B * E) % 4 == 0 and extra.is_contiguous() and g.is_contiguous():
+            _l.check(_l.lib().sqd_sum_parts(_ptr(extra), _ptr(g), _ptr(g_tokens), extra.shape[0], S * B * E, _stream()), "sum_parts")
+        else:
+            g_tokens = extra.sum(0).view(S, B, E).add_(g)
         return (g_tokens, None, *grads)
 
 
@@ -1765,6 +1769,27 @@ class TokensWithPos(torch.autograd.Function):
         g_pos = torch.empty((Tmax, E), device=g.device, dtype=torch.float32)
         _l.check(_l.lib().sqd_tokens_pos_bwd(_ptr(g), _ptr(g_emb), _ptr(g_pos), B, h * w, E, Tmax, _stream()), "tokens_pos_bwd")
         return g_emb, g_pos
+
+
+class FirstQueries(torch.autograd.Function):
+    """tokens [T,B,E] -> tokens[:Q].permute(1, 0, 2) as a dense [B,Q,E] (reference networks/depth_decoder_QTR.py:52), one launch each way"""
+
+    @staticmethod
+    def forward(ctx, tokens, Q):
+        T, B, E = tokens.shape
+        tokens = tokens.contiguous()
+        out = torch.empty((B, Q, E), device=tokens.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_first_queries(_ptr(tokens), _ptr(out), T, B, Q, E, 0, _stream()), "first_queries")
+        ctx.dims = (T, B, Q, E)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        T, B, Q, E = ctx.dims
+        g = g.contiguous()
+        gt = torch.empty((T, B, E), device=g.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_first_queries(_ptr(g), _ptr(gt), T, B, Q, E, 1, _stream()), "first_queries_adjoint")
+        return gt, None
 
 
 def transformer_encoder_native(tokens, encoder):

@@ -266,6 +266,15 @@ def tokens_with_positions(emb, pos):
     return nnkernels.TokensWithPos.apply(emb, pos)
 
 
+def first_queries(tokens, Q):
+    """tokens [T,B,E] -> the first Q of them as [B,Q,E] (reference networks/depth_decoder_QTR.py:52)"""
+    _device_only(tokens, "first_queries")
+    from . import nnkernels
+    if Q > tokens.shape[0]:
+        raise RuntimeError("sqd: %d queries out of %d tokens" % (Q, tokens.shape[0]))
+    return nnkernels.FirstQueries.apply(tokens, Q)
+
+
 def transformer_encoder(tokens, encoder):
     """tokens [T,B,E] through nn.TransformerEncoder (4 post-norm layers, ReLU feed-forward)."""
     _device_only(tokens, "transformer_encoder")

@@ -113,7 +113,12 @@ def tokens_with_positions(emb, pos):
     return (tokens + pos[:tokens.shape[2], :].T.unsqueeze(0)).permute(2, 0, 1)
 
 
+def first_queries(tokens, Q):
+    return tokens[:Q, ...].permute(1, 0, 2).contiguous()
+
+
 NAMES = ("_conv", "conv2d", "conv_bn_act", "pose_head", "maxpool3x3s2", "upsample_concat", "linear", "transformer_encoder", "tokens_with_positions",
+         "first_queries",
          "full_query_layer", "bins_head", "layer_norm_channels", "gelu", "scale_residual", "upsample2x", "dw_conv", "linear_channels",
          "patchify_conv")
 

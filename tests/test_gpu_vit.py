@@ -337,3 +337,25 @@ def test_tokens_with_positions(B, E, h, w):
     with pytest.raises(RuntimeError):
         nnops.tokens_with_positions(torch.randn(1, E, 30, 20, device="cuda"), pos)      # 600 tokens against 500 rows
 
+
+def test_first_queries_and_sum_parts():
+    """tokens[:Q].permute(1, 0, 2) as one launch each way (zero rows for the tokens that are not queries in the adjoint) and the encoder's
+    final  sum of the attention partials + g  as one launch: bit-equal to the torch composites"""
+    from sqd import lib, nnops, ops
+    torch.manual_seed(5)
+    T, B, Q, E = 120, 3, 64, 32
+    tok = torch.randn(T, B, E, device="cuda").requires_grad_(True)
+    g = torch.randn(B, Q, E, device="cuda")
+    out = nnops.first_queries(tok, Q)
+    out.backward(g)
+    tok2 = tok.detach().clone().requires_grad_(True)
+    ref = tok2[:Q, ...].permute(1, 0, 2).contiguous()
+    ref.backward(g)
+    assert torch.equal(out, ref) and torch.equal(tok.grad, tok2.grad)
+    with pytest.raises(RuntimeError):
+        nnops.first_queries(tok, T + 1)
+    parts, add = torch.randn(4, T * B, E, device="cuda"), torch.randn(T, B, E, device="cuda")
+    res = torch.empty(T, B, E, device="cuda")
+    lib.check(lib.lib().sqd_sum_parts(parts.data_ptr(), add.data_ptr(), res.data_ptr(), 4, T * B * E, torch.cuda.current_stream().cuda_stream), "sum_parts")
+    assert torch.equal(res, parts.sum(0).view(T, B, E).add_(add))
+
