@@ -357,5 +357,5 @@ def test_first_queries_and_sum_parts():
     parts, add = torch.randn(4, T * B, E, device="cuda"), torch.randn(T, B, E, device="cuda")
     res = torch.empty(T, B, E, device="cuda")
     lib.check(lib.lib().sqd_sum_parts(parts.data_ptr(), add.data_ptr(), res.data_ptr(), 4, T * B * E, torch.cuda.current_stream().cuda_stream), "sum_parts")
-    assert torch.equal(res, parts.sum(0).view(T, B, E).add_(add))
+    assert torch.allclose(res, parts.sum(0).view(T, B, E).add_(add), rtol=0, atol=2e-6)       # (torch's reduction may pair the four terms differently)
 
