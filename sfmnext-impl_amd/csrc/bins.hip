@@ -673,6 +673,48 @@ __global__ __launch_bounds__(256) void rows_reduce_kernel(const float *__restric
     }
     if (grp == 0 && i < n) out[(size_t)blockIdx.y * n + i] = a;
 }
+// the backward's three tail sums in ONE launch (round 5; three launches before, same bits): blocks [0, nbw) sum the g_weight partials over
+// all workgroups (rows_reduce's arithmetic); a block of the rest owns 32 of the 2 D vector columns and walks the images in order — per image
+// the sum over its workgroups' partials (same arithmetic), columns < D added up over the images into g_bias, columns >= D written to
+// g_centers[b]
+__global__ __launch_bounds__(256) void bins_tail_kernel(const float *__restrict__ part_w, float *__restrict__ g_weight, int nw, int splits_w, int nbw,
+                                                        const float *__restrict__ part_v, float *__restrict__ g_bias, float *__restrict__ g_centers,
+                                                        int B, int D, int splits_v) {
+    __shared__ float red[8][32];
+    const int col = threadIdx.x & 31, grp = threadIdx.x >> 5;
+    auto reduce = [&](const float *src, int n, int i, int splits) {
+        float a = 0.f;
+        if (i < n)
+            for (int s = grp; s < splits; s += 8) a += src[(size_t)s * n + i];
+        red[grp][col] = a;
+        __syncthreads();
+        for (int w = 4; w >= 1; w >>= 1) {
+            if (grp < w) {
+                a += red[grp + w][col];
+                red[grp][col] = a;
+            }
+            __syncthreads();
+        }
+        return a;                                              // (valid in group 0)
+    };
+    if ((int)blockIdx.x < nbw) {
+        const int i = blockIdx.x * 32 + col;
+        const float a = reduce(part_w, nw, i, splits_w);
+        if (grp == 0 && i < nw) g_weight[i] = a;
+        return;
+    }
+    const int n = 2 * D, i = ((int)blockIdx.x - nbw) * 32 + col;
+    float bias_acc = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float a = reduce(part_v + (size_t)b * splits_v * n, n, i, splits_v);
+        if (grp == 0 && i < n) {
+            if (i < D) bias_acc += a;
+            else g_centers[(size_t)b * D + (i - D)] = a;
+        }
+        __syncthreads();
+    }
+    if (grp == 0 && i < D) g_bias[i] = bias_acc;
+}
 // tmp [B][2][D] (per-image sums of the dbias / dcenters partials) -> dbias [D] (summed over the images), dcenters [B][D]
 __global__ __launch_bounds__(256) void bins_vec_finalize_kernel(const float *__restrict__ tmp, float *__restrict__ dbias,
                                                                 float *__restrict__ dcenters, int B, int D) {
@@ -815,10 +857,9 @@ extern "C" int sqd_bins_bwd(const float *energy, const float *weight, const floa
         hipLaunchKernelGGL((bins_bwd_kernel<4, 4>), grid, dim3(256), p.smem_bwd, st, energy, weight, bias, centers, g_pred, g_energy,
                            part_w, part_v, dm, p.tiles_per_image);
     }
-    float *tmp = part_v + (size_t)wgi * B * 2 * D;
-    hipLaunchKernelGGL(rows_reduce_kernel, dim3((D * Q + 31) / 32, 1), dim3(256), 0, st, part_w, g_weight, D * Q, wgi * B);
-    hipLaunchKernelGGL(rows_reduce_kernel, dim3((2 * D + 31) / 32, B), dim3(256), 0, st, part_v, tmp, 2 * D, wgi);
-    hipLaunchKernelGGL(bins_vec_finalize_kernel, dim3((D + B * D + 255) / 256), dim3(256), 0, st, tmp, g_bias, g_centers, B, D);
+    const int nbw = (D * Q + 31) / 32;
+    hipLaunchKernelGGL(bins_tail_kernel, dim3(nbw + (2 * D + 31) / 32), dim3(256), 0, st, part_w, g_weight, D * Q, wgi * B, nbw, part_v, g_bias,
+                       g_centers, B, D, wgi);
     SQD_CHECK_LAUNCH("sqd_bins_bwd");
     return SQD_OK;
 }
