@@ -1,6 +1,6 @@
 #!/bin/bash
 # Same-box A/B of the training step between the tree's libsqd.so and a variant (tools/build_variant.sh): alternating fresh processes.
-#   tools/ab_lib_bench.sh <variant name> [rounds]
+#   tools/ab_lib_bench.sh "<variant name> [<variant name> ...]" [rounds]
 R=$(cd $(dirname $0)/.. && pwd); v=$1; n=${2:-3}
 run() { python - "$1" <<'PY'
 import json, os, runpy, sys, io, contextlib
@@ -18,4 +18,4 @@ print(sys.argv[1] if False else "", d["ms_per_step"], d["value"])
 PY
 }
 cd $R
-for i in $(seq $n); do echo -n "tree: "; run tree; echo -n "$v: "; run tools/bin/libsqd_$v.so; done
+for i in $(seq $n); do echo -n "tree: "; run tree; for w in $v; do echo -n "$w: "; run tools/bin/libsqd_$w.so; done; done
