@@ -1046,6 +1046,15 @@ __global__ __launch_bounds__(256) void split_reduce_kernel(const float *__restri
     __shared__ float4 red[16][16];
     sqd::split_reduce_block(part, out, n, splits, blockIdx.x, red);
 }
+// ... and a second sum over the same splits in the same launch (a weight gradient's filter and bias partials): blocks [0, nb1) own the
+// first, the others the second — the arithmetic of two split_reduce_kernel launches
+__global__ __launch_bounds__(256) void split_reduce2_kernel(const float *__restrict__ part, float *__restrict__ out, size_t n,
+                                                            const float *__restrict__ part2, float *__restrict__ out2, size_t n2, int splits,
+                                                            int nb1) {
+    __shared__ float4 red[16][16];
+    if ((int)blockIdx.x < nb1) sqd::split_reduce_block(part, out, n, splits, blockIdx.x, red);       // (workgroup-uniform)
+    else sqd::split_reduce_block(part2, out2, n2, splits, (int)blockIdx.x - nb1, red);
+}
 
 // ---------------------------------------------------------------------------------------------------
 // wgrad, operands straight from memory (no LDS staging): v_mfma_f32_16x16x4_f32 takes A[i][p] from lane
@@ -2931,11 +2940,18 @@ static int conv_wgrad_impl(const float *dy, const float *x, float *dw, float *db
     // 0.7 ms SLOWER per step — reduced on the spot the partials of most layers are still in the 256 MB Infinity Cache)
     if (dp.direct || dp.shared || dp.rows || dp.direct3) splits = dp.splits;    // (a strided convolution under a row-window plan: see plan_wgrad_direct)
     if (splits_out) *splits_out = splits;
-    if (reduce_dw) hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((wsz / 4 + 15) / 16)), dim3(256), 0, st, part, dw, wsz, splits);
-    if (dbias && ((dp.direct && !dp.shared) || dp.rows)) {
+    const bool bias_splits = dbias && ((dp.direct && !dp.shared) || dp.rows);       // the kernel left [splits][K] bias partials behind the filter partials
+    if (reduce_dw && bias_splits) {
+        const unsigned nb1 = (unsigned)((wsz / 4 + 15) / 16);
+        hipLaunchKernelGGL(split_reduce2_kernel, dim3(nb1 + (unsigned)((K / 4 + 15) / 16)), dim3(256), 0, st, part, dw, wsz,
+                           part + (size_t)splits * wsz, dbias, (size_t)K, splits, (int)nb1);
+    } else if (reduce_dw) {
+        hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((wsz / 4 + 15) / 16)), dim3(256), 0, st, part, dw, wsz, splits);
+    }
+    if (bias_splits && !reduce_dw) {
         hipLaunchKernelGGL(split_reduce_kernel, dim3((unsigned)((K / 4 + 15) / 16)), dim3(256), 0, st, part + (size_t)splits * wsz, dbias,
                            (size_t)K, splits);
-    } else if (dbias) {
+    } else if (dbias && !bias_splits) {
         float *cpart = part + (size_t)splits * wsz;
         const int rpb = 1024, nblk = (M + rpb - 1) / rpb;
         int cpb = 1;

@@ -702,3 +702,39 @@ def test_wgrad_row_window_kernel(N, C, H, W, K, R, pad, bias, splits):
         assert err <= 1e-4 * scale, (name, err, scale)
     assert L.sqd_conv_wgrad_set_plan(N, Ho, Wo, 64, 64, 3, 3, 4, 4) != 0          # 64 x 64 x 9: not instantiated, refused
     assert L.sqd_conv_wgrad_set_plan(N, Ho, Wo, C, K, 5, 5, 4, 4) != 0            # 5x5 taps: refused
+
+
+@pytest.mark.parametrize("N,C,H,W,K,R,stride,pad", [(4, 32, 24, 40, 64, 3, 1, 1), (12, 8, 48, 160, 16, 7, 2, 3), (2, 64, 24, 40, 128, 1, 1, 0),
+                                                     (12, 256, 6, 20, 256, 3, 2, 1)])
+def test_filter_and_bias_split_sums_in_one_launch_are_the_same_bits(N, C, H, W, K, R, stride, pad):
+    """sqd_conv_wgrad sums the filter partials and (where the plan left bias partials behind them) the bias partials in ONE launch;
+    sqd_conv_wgrad_partials + sqd_split_reduce is the two-launch form of the same arithmetic: equal bits, filter and bias."""
+    import ctypes
+    from sqd import lib, nnkernels
+    L = lib.lib()
+    torch.manual_seed(N + K)
+    Ho, Wo = (H + 2 * pad - R) // stride + 1, (W + 2 * pad - R) // stride + 1
+    x = torch.randn(N, H, W, C, device="cuda")
+    dy = torch.randn(N, Ho, Wo, K, device="cuda")
+    geom = (N, H, W, C, K, R, R, stride, pad, Ho, Wo)
+    pf, splits = nnkernels._wgrad_part_floats(geom)                       # the workspace Conv2d.backward allocates: filter partials + bias rows
+    nfl = pf + max((N * Ho * Wo + 1023) // 1024, splits) * K
+    st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    P = lambda t: ctypes.c_void_p(t.data_ptr())
+    outs = []
+    for partial in (False, True):
+        part = torch.zeros(nfl, device="cuda")
+        dw = torch.full((K, R, R, C), float("nan"), device="cuda")
+        db = torch.full((K,), float("nan"), device="cuda")
+        if partial:
+            sp = ctypes.c_int(0)
+            lib.check(L.sqd_conv_wgrad_partials(P(dy), P(x), P(dw), P(db), P(part), *geom, ctypes.byref(sp), st), "wgrad_partials")
+            lib.check(L.sqd_split_reduce(P(part), P(dw), K * R * R * C, sp.value, st), "split_reduce")
+        else:
+            lib.check(L.sqd_conv_wgrad(P(dy), P(x), P(dw), P(db), P(part), *geom, st), "wgrad")
+        torch.cuda.synchronize()
+        outs.append((dw, db))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    ref = torch.nn.grad.conv2d_weight(x.permute(0, 3, 1, 2), (K, C, R, R), dy.permute(0, 3, 1, 2), stride=stride, padding=pad).permute(0, 2, 3, 1)
+    assert torch.allclose(outs[0][0], ref, rtol=1e-3, atol=1e-3 * float(ref.abs().max()))
+    assert torch.allclose(outs[0][1], dy.sum((0, 1, 2)), rtol=1e-4, atol=1e-4 * float(dy.sum((0, 1, 2)).abs().max()))
