@@ -608,6 +608,16 @@ int sqd_scale_residual_nblk(int M);
 int sqd_scale_residual_bwd(const float *dy, const float *z, const float *gamma, float *dz, float *part, int M, int C, void *stream);
 int sqd_upsample2x_fwd(const float *x, float *y, int N, int H, int W, int C, void *stream);
 int sqd_upsample2x_bwd(const float *dy, float *dx, int N, int H, int W, int C, void *stream);
+/* The same with the bit pattern of max |output| recorded by the pass that writes the tensor (amax_* may be NULL; a record of section 10b,
+ * cleared by the caller on the stream before the call): the operand scales of the block's two Linear layers when they run on two-term fp16
+ * operands (sqd_conv_fwd_scaled / _dgrad_scaled / _wgrad_scaled) — LayerNorm output and GELU output forward, GELU's dx and the layer
+ * scale's dz backward — without a sqd_amax pass over each tensor.                                                            */
+int sqd_ln_rows_fwd_amax(const float *x, const float *pre_bias, const float *gamma, const float *beta, float *y, float *mean, float *rstd,
+                         int M, int C, float eps, float *amax_y, void *stream);
+int sqd_gelu_fwd_amax(const float *x, float *y, int64_t n, float *amax_y, void *stream);
+int sqd_gelu_bwd_amax(const float *x, const float *dy, float *dx, int64_t n, float *amax_dx, void *stream);
+int sqd_scale_residual_bwd_amax(const float *dy, const float *z, const float *gamma, float *dz, float *part, int M, int C, float *amax_dz,
+                                void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Supervised metric-depth finetune step (config E; not part of the self-supervised step)

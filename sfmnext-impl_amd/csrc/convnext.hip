@@ -25,8 +25,9 @@ __host__ __device__ inline int ln_rpw(int M) {
 __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float *__restrict__ x, const float *__restrict__ pre_bias,
                                                           const float *__restrict__ gamma, const float *__restrict__ beta,
                                                           float *__restrict__ y, float *__restrict__ mean_out, float *__restrict__ rstd_out,
-                                                          int M, int C, float eps) {
+                                                          int M, int C, float eps, unsigned *__restrict__ amax_y) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, Q = C / 4;
+    unsigned am = 0u;                                      // max |y| of this thread's elements (amax_y == NULL: not recorded)
     for (int row = blockIdx.x * 4 + wave; row < M; row += gridDim.x * 4) {
         float4 v[LN_MAXQ];
         float s = 0.f;
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float *__restric
                 o.x = (v[j].x - mean) * rstd * g.x + b.x; o.y = (v[j].y - mean) * rstd * g.y + b.y;
                 o.z = (v[j].z - mean) * rstd * g.z + b.z; o.w = (v[j].w - mean) * rstd * g.w + b.w;
                 reinterpret_cast<float4 *>(y + (size_t)row * C)[q] = o;
+                am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
             }
         }
         if (lane == 0) {
@@ -69,6 +71,7 @@ __global__ __launch_bounds__(256) void ln_rows_fwd_kernel(const float *__restric
             rstd_out[row] = rstd;
         }
     }
+    amax_commit(am, amax_y);
 }
 
 // dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma; partial column sums per workgroup:
@@ -142,7 +145,9 @@ __device__ __forceinline__ float gelu_d(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * __expf(-0.5f * x * x);
 }
 template <bool BWD>
-__global__ __launch_bounds__(256) void gelu_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ out, size_t n4) {
+__global__ __launch_bounds__(256) void gelu_kernel(const float *__restrict__ x, const float *__restrict__ dy, float *__restrict__ out, size_t n4,
+                                                   unsigned *__restrict__ amax_out) {
+    unsigned am = 0u;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
         const float4 v = reinterpret_cast<const float4 *>(x)[i];
         float4 o;
@@ -153,14 +158,17 @@ __global__ __launch_bounds__(256) void gelu_kernel(const float *__restrict__ x, 
             o = make_float4(gelu_f(v.x), gelu_f(v.y), gelu_f(v.z), gelu_f(v.w));
         }
         reinterpret_cast<float4 *>(out)[i] = o;
+        am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
     }
+    amax_commit(am, amax_out);
 }
 
 // MODE 0: out = res + gamma * z.   MODE 1: dz = gamma * dy, and per-workgroup partial column sums of dy * z (dgamma) -> part[blk][C]
 template <int MODE>
 __global__ __launch_bounds__(256) void scale_residual_kernel(const float *__restrict__ a, const float *__restrict__ z,
                                                              const float *__restrict__ gamma, float *__restrict__ out,
-                                                             float *__restrict__ part, int M, int C, int rows_per_blk) {
+                                                             float *__restrict__ part, int M, int C, int rows_per_blk,
+                                                             unsigned *__restrict__ amax_out) {
     const int Q = C / 4;
     if (MODE == 0) {
         const size_t total = (size_t)M * Q;
@@ -176,18 +184,22 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(const float *__rest
     extern __shared__ float red[];                         // [4][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
+    unsigned am = 0u;                                      // max |dz| (amax_out == NULL: not recorded)
     for (int q = lane; q < Q; q += 64) {
         const float4 g = reinterpret_cast<const float4 *>(gamma)[q];
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int row = r0 + wave; row < r1; row += 4) {
             const float4 d = reinterpret_cast<const float4 *>(a + (size_t)row * C)[q], zz = reinterpret_cast<const float4 *>(z + (size_t)row * C)[q];
-            reinterpret_cast<float4 *>(out + (size_t)row * C)[q] = make_float4(g.x * d.x, g.y * d.y, g.z * d.z, g.w * d.w);
+            const float4 o = make_float4(g.x * d.x, g.y * d.y, g.z * d.z, g.w * d.w);
+            reinterpret_cast<float4 *>(out + (size_t)row * C)[q] = o;
+            am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
             acc.x += d.x * zz.x; acc.y += d.y * zz.y; acc.z += d.z * zz.z; acc.w += d.w * zz.w;
         }
         reinterpret_cast<float4 *>(red + (size_t)wave * C)[q] = acc;
     }
     __syncthreads();
     for (int i = threadIdx.x; i < C; i += 256) part[(size_t)blockIdx.x * C + i] = ((red[i] + red[C + i]) + red[2 * C + i]) + red[3 * C + i];
+    amax_commit(am, amax_out);
 }
 
 // ATen upsample_bilinear2d, align_corners = False, scale 2: src = max(0.5 * (dst + 0.5) - 0.5, 0)
@@ -265,11 +277,18 @@ int ln_check(const char *who, int M, int C) {
 // x, y [M,C]; pre_bias [C] or NULL (added to x first); gamma, beta [C]; mean, rstd [M] (saved for the backward)
 extern "C" int sqd_ln_rows_fwd(const float *x, const float *pre_bias, const float *gamma, const float *beta, float *y, float *mean,
                                float *rstd, int M, int C, float eps, void *stream) {
+    return sqd_ln_rows_fwd_amax(x, pre_bias, gamma, beta, y, mean, rstd, M, C, eps, nullptr, stream);
+}
+// ... and amax_y (may be NULL; a record cleared by the caller on the stream before the call, include/sqd.h section 10b): the bit pattern of
+// max |y| — the operand scale of the block's first Linear layer when it runs on two-term fp16 operands (no sqd_amax pass over y)
+extern "C" int sqd_ln_rows_fwd_amax(const float *x, const float *pre_bias, const float *gamma, const float *beta, float *y, float *mean,
+                                    float *rstd, int M, int C, float eps, float *amax_y, void *stream) {
     SQD_CHECK_ARG(x && gamma && beta && y && mean && rstd, "sqd_ln_rows_fwd: null pointer");
     if (ln_check("sqd_ln_rows_fwd", M, C)) return SQD_EINVAL;
     const int blocks = (M + 3) / 4 > 8192 ? 8192 : (M + 3) / 4;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, pre_bias, gamma, beta, y, mean, rstd, M, C, eps);
+    hipLaunchKernelGGL(ln_rows_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, pre_bias, gamma, beta, y, mean, rstd, M, C, eps,
+                       (unsigned *)amax_y);
     SQD_CHECK_LAUNCH("sqd_ln_rows_fwd");
     return SQD_OK;
 }
@@ -290,17 +309,24 @@ extern "C" int sqd_ln_rows_bwd(const float *dy, const float *x, const float *pre
     return SQD_OK;
 }
 // exact (erf) GELU: y = gelu(x);  backward: dx = dy * gelu'(x).  n a multiple of 4, 16-byte aligned pointers
-extern "C" int sqd_gelu_fwd(const float *x, float *y, int64_t n, void *stream) {
+extern "C" int sqd_gelu_fwd(const float *x, float *y, int64_t n, void *stream) { return sqd_gelu_fwd_amax(x, y, n, nullptr, stream); }
+extern "C" int sqd_gelu_bwd(const float *x, const float *dy, float *dx, int64_t n, void *stream) {
+    return sqd_gelu_bwd_amax(x, dy, dx, n, nullptr, stream);
+}
+// ... and amax_y / amax_dx (may be NULL; cleared records): max |y| for the second Linear layer's forward, max |dx| for the first one's
+// gradients, recorded by the pass that writes the tensor
+extern "C" int sqd_gelu_fwd_amax(const float *x, float *y, int64_t n, float *amax_y, void *stream) {
     SQD_CHECK_ARG(x && y && n > 0 && n % 4 == 0, "sqd_gelu_fwd: bad arguments");
     (void)hipGetLastError();
-    hipLaunchKernelGGL((gelu_kernel<false>), dim3(ew_grid((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, x, (const float *)nullptr, y, (size_t)n / 4);
+    hipLaunchKernelGGL((gelu_kernel<false>), dim3(ew_grid((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, x, (const float *)nullptr, y, (size_t)n / 4,
+                       (unsigned *)amax_y);
     SQD_CHECK_LAUNCH("sqd_gelu_fwd");
     return SQD_OK;
 }
-extern "C" int sqd_gelu_bwd(const float *x, const float *dy, float *dx, int64_t n, void *stream) {
+extern "C" int sqd_gelu_bwd_amax(const float *x, const float *dy, float *dx, int64_t n, float *amax_dx, void *stream) {
     SQD_CHECK_ARG(x && dy && dx && n > 0 && n % 4 == 0, "sqd_gelu_bwd: bad arguments");
     (void)hipGetLastError();
-    hipLaunchKernelGGL((gelu_kernel<true>), dim3(ew_grid((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (size_t)n / 4);
+    hipLaunchKernelGGL((gelu_kernel<true>), dim3(ew_grid((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, (size_t)n / 4, (unsigned *)amax_dx);
     SQD_CHECK_LAUNCH("sqd_gelu_bwd");
     return SQD_OK;
 }
@@ -309,7 +335,7 @@ extern "C" int sqd_scale_residual_fwd(const float *res, const float *z, const fl
     SQD_CHECK_ARG(res && z && gamma && out && M > 0 && C >= 4 && C % 4 == 0, "sqd_scale_residual_fwd: bad arguments");
     (void)hipGetLastError();
     hipLaunchKernelGGL((scale_residual_kernel<0>), dim3(ew_grid((size_t)M * C / 4)), dim3(256), 0, (hipStream_t)stream, res, z, gamma, out,
-                       (float *)nullptr, M, C, 0);
+                       (float *)nullptr, M, C, 0, (unsigned *)nullptr);
     SQD_CHECK_LAUNCH("sqd_scale_residual_fwd");
     return SQD_OK;
 }
@@ -322,10 +348,15 @@ static int scale_residual_rows(int M) {
 extern "C" int sqd_scale_residual_nblk(int M) { return (M + scale_residual_rows(M) - 1) / scale_residual_rows(M); }
 // dy, z [M,C] -> dz = gamma * dy; part [sqd_scale_residual_nblk(M)][C] per-block column sums of dy * z (sum over the blocks: dgamma)
 extern "C" int sqd_scale_residual_bwd(const float *dy, const float *z, const float *gamma, float *dz, float *part, int M, int C, void *stream) {
+    return sqd_scale_residual_bwd_amax(dy, z, gamma, dz, part, M, C, nullptr, stream);
+}
+// ... and amax_dz (may be NULL; a cleared record): max |dz| for the second Linear layer's gradients
+extern "C" int sqd_scale_residual_bwd_amax(const float *dy, const float *z, const float *gamma, float *dz, float *part, int M, int C, float *amax_dz,
+                                           void *stream) {
     SQD_CHECK_ARG(dy && z && gamma && dz && part && M > 0 && C >= 4 && C % 4 == 0, "sqd_scale_residual_bwd: bad arguments");
     (void)hipGetLastError();
     hipLaunchKernelGGL((scale_residual_kernel<1>), dim3(sqd_scale_residual_nblk(M)), dim3(256), (size_t)4 * C * sizeof(float),
-                       (hipStream_t)stream, dy, z, gamma, dz, part, M, C, scale_residual_rows(M));
+                       (hipStream_t)stream, dy, z, gamma, dz, part, M, C, scale_residual_rows(M), (unsigned *)amax_dz);
     SQD_CHECK_LAUNCH("sqd_scale_residual_bwd");
     return SQD_OK;
 }

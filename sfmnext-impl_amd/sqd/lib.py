@@ -194,6 +194,10 @@ _SIGNATURES = {
     "sqd_clip_coef": (_I, [_P, _I, ctypes.c_double, _P, _P]),
     "sqd_adamw_step": (_I, [_P, _P, _P, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P, _P]),
     "sqd_ln_rows_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P]),
+    "sqd_ln_rows_fwd_amax": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _P, _P]),
+    "sqd_gelu_fwd_amax": (_I, [_P, _P, ctypes.c_int64, _P, _P]),
+    "sqd_gelu_bwd_amax": (_I, [_P, _P, _P, ctypes.c_int64, _P, _P]),
+    "sqd_scale_residual_bwd_amax": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
     "sqd_ln_rows_nblk": (_I, [_I]),
     "sqd_ln_rows_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sqd_gelu_fwd": (_I, [_P, _P, ctypes.c_int64, _P]),

@@ -764,8 +764,10 @@ class LayerNormRows(torch.autograd.Function):
         M = N * H * W
         y = torch.empty_like(x)
         mean, rstd = torch.empty(M, device=x.device, dtype=torch.float32), torch.empty(M, device=x.device, dtype=torch.float32)
-        _l.check(_l.lib().sqd_ln_rows_fwd(_ptr(x), _ptr(pre_bias), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), M, C, float(eps),
-                                          _stream()), "ln_rows_fwd")
+        ay = _amax_out(x.device)                 # max |y| for the Linear layer that reads y on two-term fp16 operands (no pass of its own)
+        _l.check(_l.lib().sqd_ln_rows_fwd_amax(_ptr(x), _ptr(pre_bias), _ptr(gamma), _ptr(beta), _ptr(y), _ptr(mean), _ptr(rstd), M, C, float(eps),
+                                               _ptr(ay), _stream()), "ln_rows_fwd")
+        _amax_tag(y, ay)
         ctx.save_for_backward(x, pre_bias, gamma, mean, rstd)
         return y
 
@@ -794,7 +796,9 @@ class Gelu(torch.autograd.Function):
         if not (x.is_contiguous() or x.is_contiguous(memory_format=torch.channels_last)):
             x = x.contiguous()
         y = torch.empty_like(x)
-        _l.check(_l.lib().sqd_gelu_fwd(_ptr(x), _ptr(y), x.numel(), _stream()), "gelu_fwd")
+        ay = _amax_out(x.device)
+        _l.check(_l.lib().sqd_gelu_fwd_amax(_ptr(x), _ptr(y), x.numel(), _ptr(ay), _stream()), "gelu_fwd")
+        _amax_tag(y, ay)
         ctx.save_for_backward(x)
         return y
 
@@ -803,8 +807,9 @@ class Gelu(torch.autograd.Function):
         x, = ctx.saved_tensors
         dy = dy.contiguous(memory_format=torch.channels_last) if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) else dy.contiguous()
         dx = torch.empty_like(x)
-        _l.check(_l.lib().sqd_gelu_bwd(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _stream()), "gelu_bwd")
-        return dx
+        ad = _amax_out(x.device)
+        _l.check(_l.lib().sqd_gelu_bwd_amax(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _ptr(ad), _stream()), "gelu_bwd")
+        return _amax_tag(dx, ad)
 
 
 class ScaleResidual(torch.autograd.Function):
@@ -830,10 +835,11 @@ class ScaleResidual(torch.autograd.Function):
         L = _l.lib()
         dz = torch.empty_like(z)
         part = torch.empty(L.sqd_scale_residual_nblk(M), C, device=z.device, dtype=torch.float32)
-        _l.check(L.sqd_scale_residual_bwd(_ptr(dy), _ptr(z), _ptr(gamma), _ptr(dz), _ptr(part), M, C, _stream()), "scale_residual_bwd")
+        ad = _amax_out(z.device)
+        _l.check(L.sqd_scale_residual_bwd_amax(_ptr(dy), _ptr(z), _ptr(gamma), _ptr(dz), _ptr(part), M, C, _ptr(ad), _stream()), "scale_residual_bwd")
         dgamma = torch.empty(C, device=z.device, dtype=torch.float32)
         _colsum_multi([(part, dgamma, 0)])
-        return dy, dz, dgamma
+        return dy, _amax_tag(dz, ad), dgamma
 
 
 class Upsample2x(torch.autograd.Function):

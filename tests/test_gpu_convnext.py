@@ -244,3 +244,46 @@ def test_convnext_large_train_step_matches_oracle(H, W, B, patch, Q, dout, tune)
     # updated weights (Adam step of 1e-4: a wrong-signed gradient moves a weight by 2e-4; only gradients within rounding of zero may)
     for k, v in off.items():
         assert v < WRONG_SIGN_FRACTION, (k, v)
+
+
+def test_block_operators_record_the_maximum_of_what_they_write():
+    """LayerNorm over channels and GELU tag their outputs, GELU's and the layer scale's backward their gradients, with max |tensor| — equal to
+    torch's maximum bit for bit — so that the block's two Linear layers take their two-term fp16 operand scales without a pass of their own"""
+    from sqd import nnkernels, nnops
+    was = nnkernels.AMAX_ON
+    nnkernels.amax_enable(True)
+    try:
+        torch.manual_seed(3)
+        cl = torch.channels_last
+
+        def tag_value(t):
+            a = nnkernels._amax_get(t)
+            assert a is not None, "no tag"
+            return nnkernels.amax_value(a)
+        nnkernels.begin_step()
+        for N, C, H, W in ((2, 192, 20, 64), (1, 1536, 5, 8), (3, 96, 7, 9)):
+            norm = nn.LayerNorm(C, eps=1e-6).cuda()
+            with torch.no_grad():
+                norm.weight.uniform_(0.5, 2.0); norm.bias.uniform_(-1.0, 1.0)
+            x = (torch.randn(N, C, H, W, device="cuda") * 4).contiguous(memory_format=cl).requires_grad_(True)
+            y = nnops.layer_norm_channels(x, norm, torch.randn(C, device="cuda"))
+            assert tag_value(y) == float(y.abs().max())
+            u = (torch.randn(N, C, H, W, device="cuda") * 3).contiguous(memory_format=cl).requires_grad_(True)
+            v = nnops.gelu(u)
+            assert tag_value(v) == float(v.abs().max())
+            z = (torch.randn(N, C, H, W, device="cuda")).contiguous(memory_format=cl).requires_grad_(True)
+            gamma = (torch.rand(C, device="cuda") * 1e-3).requires_grad_(True)
+            out = nnops.scale_residual(x.detach(), z, gamma)
+            seen = {}
+
+            def grab(name):
+                def hook(g):
+                    seen[name] = (None if nnkernels._amax_get(g) is None else nnkernels.amax_value(nnkernels._amax_get(g)), float(g.abs().max()))
+                return hook
+            u.register_hook(grab("gelu dx"))
+            z.register_hook(grab("scale dz"))
+            v.backward(torch.randn_like(v) * 1e-5)
+            out.backward(torch.randn_like(out) * 1e-5)
+            assert seen["gelu dx"][0] == seen["gelu dx"][1] and seen["scale dz"][0] == seen["scale dz"][1], seen
+    finally:
+        nnkernels.amax_enable(was)
