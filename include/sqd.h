@@ -618,6 +618,12 @@ int sqd_gelu_fwd_amax(const float *x, float *y, int64_t n, float *amax_y, void *
 int sqd_gelu_bwd_amax(const float *x, const float *dy, float *dx, int64_t n, float *amax_dx, void *stream);
 int sqd_scale_residual_bwd_amax(const float *dy, const float *z, const float *gamma, float *dz, float *part, int M, int C, float *amax_dz,
                                 void *stream);
+/* ... and the bias gradients of the block's two Linear layers from the passes that write their output gradients: part2 / part
+ * [sqd_scale_residual_nblk(M)][C] = per-block column sums of dz (layer scale backward; part2 may be NULL) and of dx (GELU backward on rows
+ * [M,C]); summed over the blocks (sqd_colsum_multi) they are dbias, and the Linear layer's weight-gradient call takes dbias = NULL. */
+int sqd_scale_residual_bwd_sums(const float *dy, const float *z, const float *gamma, float *dz, float *part, float *part2, int M, int C,
+                                float *amax_dz, void *stream);
+int sqd_gelu_bwd_rows(const float *x, const float *dy, float *dx, float *part, int M, int C, float *amax_dx, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Supervised metric-depth finetune step (config E; not part of the self-supervised step)

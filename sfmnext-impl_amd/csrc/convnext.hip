@@ -164,11 +164,14 @@ __global__ __launch_bounds__(256) void gelu_kernel(const float *__restrict__ x, 
 }
 
 // MODE 0: out = res + gamma * z.   MODE 1: dz = gamma * dy, and per-workgroup partial column sums of dy * z (dgamma) -> part[blk][C]
+// and (part2 != NULL) of dz -> part2[blk][C]: the bias gradient of the Linear layer whose output z is, taken by the pass that writes dz.
+// MODE 2 (a = dy, z = x, no gamma): dx = dy * gelu'(x) and partial column sums of dx -> part[blk][C] (the bias gradient of the Linear
+// layer in front of the GELU).
 template <int MODE>
 __global__ __launch_bounds__(256) void scale_residual_kernel(const float *__restrict__ a, const float *__restrict__ z,
                                                              const float *__restrict__ gamma, float *__restrict__ out,
                                                              float *__restrict__ part, int M, int C, int rows_per_blk,
-                                                             unsigned *__restrict__ amax_out) {
+                                                             unsigned *__restrict__ amax_out, float *__restrict__ part2) {
     const int Q = C / 4;
     if (MODE == 0) {
         const size_t total = (size_t)M * Q;
@@ -181,24 +184,48 @@ __global__ __launch_bounds__(256) void scale_residual_kernel(const float *__rest
     }
     // backward: a = dy.  Wave w takes rows r0 + w, r0 + w + 4, ... of the block, lane l the float4 columns l, l + 64, ...; the four
     // waves' column sums are added through LDS in wave order
-    extern __shared__ float red[];                         // [4][C]
+    extern __shared__ float red[];                         // [4][C] (MODE 1 with part2: [8][C])
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r0 = blockIdx.x * rows_per_blk, r1 = min(M, r0 + rows_per_blk);
-    unsigned am = 0u;                                      // max |dz| (amax_out == NULL: not recorded)
+    const bool two = MODE == 1 && part2 != nullptr;
+    unsigned am = 0u;                                      // max |out| (amax_out == NULL: not recorded)
     for (int q = lane; q < Q; q += 64) {
-        const float4 g = reinterpret_cast<const float4 *>(gamma)[q];
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int row = r0 + wave; row < r1; row += 4) {
-            const float4 d = reinterpret_cast<const float4 *>(a + (size_t)row * C)[q], zz = reinterpret_cast<const float4 *>(z + (size_t)row * C)[q];
-            const float4 o = make_float4(g.x * d.x, g.y * d.y, g.z * d.z, g.w * d.w);
-            reinterpret_cast<float4 *>(out + (size_t)row * C)[q] = o;
-            am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
-            acc.x += d.x * zz.x; acc.y += d.y * zz.y; acc.z += d.z * zz.z; acc.w += d.w * zz.w;
+        const float4 g = MODE == 1 ? reinterpret_cast<const float4 *>(gamma)[q] : make_float4(1.f, 1.f, 1.f, 1.f);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f), acc2 = acc;
+        // four rows of the wave per step: their eight loads are in flight together (rows beyond the block read row r1 - 1 again and are
+        // not stored or summed); the sums run over the rows in order
+        for (int row = r0 + wave; row < r1; row += 16) {
+            float4 d[4], zz[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = min(row + 4 * u, r1 - 1);
+                d[u] = reinterpret_cast<const float4 *>(a + (size_t)rr * C)[q];
+                zz[u] = reinterpret_cast<const float4 *>(z + (size_t)rr * C)[q];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (row + 4 * u >= r1) break;
+                float4 o;
+                if (MODE == 1) o = make_float4(g.x * d[u].x, g.y * d[u].y, g.z * d[u].z, g.w * d[u].w);
+                else o = make_float4(d[u].x * gelu_d(zz[u].x), d[u].y * gelu_d(zz[u].y), d[u].z * gelu_d(zz[u].z), d[u].w * gelu_d(zz[u].w));
+                reinterpret_cast<float4 *>(out + (size_t)(row + 4 * u) * C)[q] = o;
+                am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
+                if (MODE == 1) {
+                    acc.x += d[u].x * zz[u].x; acc.y += d[u].y * zz[u].y; acc.z += d[u].z * zz[u].z; acc.w += d[u].w * zz[u].w;
+                    acc2.x += o.x; acc2.y += o.y; acc2.z += o.z; acc2.w += o.w;
+                } else {
+                    acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+                }
+            }
         }
         reinterpret_cast<float4 *>(red + (size_t)wave * C)[q] = acc;
+        if (two) reinterpret_cast<float4 *>(red + (size_t)(4 + wave) * C)[q] = acc2;
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < C; i += 256) part[(size_t)blockIdx.x * C + i] = ((red[i] + red[C + i]) + red[2 * C + i]) + red[3 * C + i];
+    for (int i = threadIdx.x; i < C; i += 256) {
+        part[(size_t)blockIdx.x * C + i] = ((red[i] + red[C + i]) + red[2 * C + i]) + red[3 * C + i];
+        if (two) part2[(size_t)blockIdx.x * C + i] = ((red[4 * C + i] + red[5 * C + i]) + red[6 * C + i]) + red[7 * C + i];
+    }
     amax_commit(am, amax_out);
 }
 
@@ -335,15 +362,16 @@ extern "C" int sqd_scale_residual_fwd(const float *res, const float *z, const fl
     SQD_CHECK_ARG(res && z && gamma && out && M > 0 && C >= 4 && C % 4 == 0, "sqd_scale_residual_fwd: bad arguments");
     (void)hipGetLastError();
     hipLaunchKernelGGL((scale_residual_kernel<0>), dim3(ew_grid((size_t)M * C / 4)), dim3(256), 0, (hipStream_t)stream, res, z, gamma, out,
-                       (float *)nullptr, M, C, 0, (unsigned *)nullptr);
+                       (float *)nullptr, M, C, 0, (unsigned *)nullptr, (float *)nullptr);
     SQD_CHECK_LAUNCH("sqd_scale_residual_fwd");
     return SQD_OK;
 }
-// rows per workgroup of the backward: 64, fewer for tensors of few rows (>= 1024 workgroups where the rows allow, at least 8 rows each)
+// rows per workgroup of the backward: >= 1024 workgroups where the rows allow, 8 .. 256 rows each (the partial rows a launch leaves are
+// summed by sqd_colsum_multi: at 64 rows the 327 680-row maps of stage 1 left 5120 of them per tensor)
 static int scale_residual_rows(int M) {
     int r = M / 1024;
     r = (r + 3) & ~3;
-    return r < 8 ? 8 : r > 64 ? 64 : r;
+    return r < 8 ? 8 : r > 256 ? 256 : r;
 }
 extern "C" int sqd_scale_residual_nblk(int M) { return (M + scale_residual_rows(M) - 1) / scale_residual_rows(M); }
 // dy, z [M,C] -> dz = gamma * dy; part [sqd_scale_residual_nblk(M)][C] per-block column sums of dy * z (sum over the blocks: dgamma)
@@ -353,11 +381,35 @@ extern "C" int sqd_scale_residual_bwd(const float *dy, const float *z, const flo
 // ... and amax_dz (may be NULL; a cleared record): max |dz| for the second Linear layer's gradients
 extern "C" int sqd_scale_residual_bwd_amax(const float *dy, const float *z, const float *gamma, float *dz, float *part, int M, int C, float *amax_dz,
                                            void *stream) {
+    return sqd_scale_residual_bwd_sums(dy, z, gamma, dz, part, nullptr, M, C, amax_dz, stream);
+}
+// ... and part2 [sqd_scale_residual_nblk(M)][C] (may be NULL): per-block column sums of dz — summed over the blocks, the bias gradient of
+// the Linear layer that produced z (its weight-gradient call then takes dbias = NULL: no column-sum pass over dz of its own)
+extern "C" int sqd_scale_residual_bwd_sums(const float *dy, const float *z, const float *gamma, float *dz, float *part, float *part2, int M, int C,
+                                           float *amax_dz, void *stream) {
     SQD_CHECK_ARG(dy && z && gamma && dz && part && M > 0 && C >= 4 && C % 4 == 0, "sqd_scale_residual_bwd: bad arguments");
+    const size_t shmem = (size_t)(part2 ? 8 : 4) * C * sizeof(float);
+    SQD_CHECK_ARG(shmem <= 160 * 1024, "sqd_scale_residual_bwd: C=%d needs more LDS than a workgroup has", C);
     (void)hipGetLastError();
-    hipLaunchKernelGGL((scale_residual_kernel<1>), dim3(sqd_scale_residual_nblk(M)), dim3(256), (size_t)4 * C * sizeof(float),
-                       (hipStream_t)stream, dy, z, gamma, dz, part, M, C, scale_residual_rows(M), (unsigned *)amax_dz);
+    if (shmem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scale_residual_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL((scale_residual_kernel<1>), dim3(sqd_scale_residual_nblk(M)), dim3(256), shmem, (hipStream_t)stream, dy, z, gamma, dz, part, M, C,
+                       scale_residual_rows(M), (unsigned *)amax_dz, part2);
     SQD_CHECK_LAUNCH("sqd_scale_residual_bwd");
+    return SQD_OK;
+}
+// GELU backward on rows: x, dy, dx [M,C]; part [sqd_scale_residual_nblk(M)][C] = per-block column sums of dx (summed over the blocks: the bias
+// gradient of the Linear layer in front of the GELU); amax_dx as in sqd_gelu_bwd_amax.  The values of sqd_gelu_bwd.
+extern "C" int sqd_gelu_bwd_rows(const float *x, const float *dy, float *dx, float *part, int M, int C, float *amax_dx, void *stream) {
+    SQD_CHECK_ARG(x && dy && dx && part && M > 0 && C >= 4 && C % 4 == 0, "sqd_gelu_bwd_rows: bad arguments");
+    const size_t shmem = (size_t)4 * C * sizeof(float);
+    SQD_CHECK_ARG(shmem <= 160 * 1024, "sqd_gelu_bwd_rows: C=%d needs more LDS than a workgroup has", C);
+    (void)hipGetLastError();
+    if (shmem > 48 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&scale_residual_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    hipLaunchKernelGGL((scale_residual_kernel<2>), dim3(sqd_scale_residual_nblk(M)), dim3(256), shmem, (hipStream_t)stream, dy, x, (const float *)nullptr, dx,
+                       part, M, C, scale_residual_rows(M), (unsigned *)amax_dx, (float *)nullptr);
+    SQD_CHECK_LAUNCH("sqd_gelu_bwd_rows");
     return SQD_OK;
 }
 // x [N,H,W,C] -> y [N,2H,2W,C], bilinear, align_corners = False;  backward: dy [N,2H,2W,C] -> dx [N,H,W,C]

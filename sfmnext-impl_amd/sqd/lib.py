@@ -198,6 +198,8 @@ _SIGNATURES = {
     "sqd_gelu_fwd_amax": (_I, [_P, _P, ctypes.c_int64, _P, _P]),
     "sqd_gelu_bwd_amax": (_I, [_P, _P, _P, ctypes.c_int64, _P, _P]),
     "sqd_scale_residual_bwd_amax": (_I, [_P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "sqd_scale_residual_bwd_sums": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _P, _P]),
+    "sqd_gelu_bwd_rows": (_I, [_P, _P, _P, _P, _I, _I, _P, _P]),
     "sqd_ln_rows_nblk": (_I, [_I]),
     "sqd_ln_rows_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sqd_gelu_fwd": (_I, [_P, _P, ctypes.c_int64, _P]),

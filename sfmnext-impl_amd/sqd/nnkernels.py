@@ -808,7 +808,18 @@ class Gelu(torch.autograd.Function):
         dy = dy.contiguous(memory_format=torch.channels_last) if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) else dy.contiguous()
         dx = torch.empty_like(x)
         ad = _amax_out(x.device)
-        _l.check(_l.lib().sqd_gelu_bwd_amax(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _ptr(ad), _stream()), "gelu_bwd")
+        L = _l.lib()
+        if x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 4 == 0 and x.shape[1] * 16 <= 160 * 1024:
+            # rows [N*H*W, C]: the pass also leaves the per-block column sums of dx — the bias gradient of the Linear layer in front
+            N, C, H, W = x.shape
+            M = N * H * W
+            part = torch.empty(L.sqd_scale_residual_nblk(M), C, device=x.device, dtype=torch.float32)
+            _l.check(L.sqd_gelu_bwd_rows(_ptr(x), _ptr(dy), _ptr(dx), _ptr(part), M, C, _ptr(ad), _stream()), "gelu_bwd_rows")
+            cs = torch.empty(C, device=x.device, dtype=torch.float32)
+            _colsum_multi([(part, cs, 0)])
+            dx._sqd_colsum = cs                          # column sums of dx [C]: Conv2d.backward takes them as its bias gradient
+        else:
+            _l.check(L.sqd_gelu_bwd_amax(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _ptr(ad), _stream()), "gelu_bwd")
         return _amax_tag(dx, ad)
 
 
@@ -836,9 +847,16 @@ class ScaleResidual(torch.autograd.Function):
         dz = torch.empty_like(z)
         part = torch.empty(L.sqd_scale_residual_nblk(M), C, device=z.device, dtype=torch.float32)
         ad = _amax_out(z.device)
-        _l.check(L.sqd_scale_residual_bwd_amax(_ptr(dy), _ptr(z), _ptr(gamma), _ptr(dz), _ptr(part), M, C, _ptr(ad), _stream()), "scale_residual_bwd")
+        part2 = torch.empty_like(part) if C * 32 <= 160 * 1024 else None       # column sums of dz: the bias gradient of the Linear layer that wrote z
+        _l.check(L.sqd_scale_residual_bwd_sums(_ptr(dy), _ptr(z), _ptr(gamma), _ptr(dz), _ptr(part), _ptr(part2), M, C, _ptr(ad), _stream()),
+                 "scale_residual_bwd")
         dgamma = torch.empty(C, device=z.device, dtype=torch.float32)
-        _colsum_multi([(part, dgamma, 0)])
+        if part2 is not None:
+            cs = torch.empty(C, device=z.device, dtype=torch.float32)
+            _colsum_multi([(part, dgamma, 0), (part2, cs, 0)])
+            dz._sqd_colsum = cs                          # column sums of dz [C]
+        else:
+            _colsum_multi([(part, dgamma, 0)])
         return dy, _amax_tag(dz, ad), dgamma
 
 
@@ -1173,6 +1191,9 @@ class Conv2d(torch.autograd.Function):
         dy = _cl(dy)
         if dy is not dy_in:
             _amax_tag(dy, _amax_get(dy_in))
+        # column sums of dy from the pass that wrote it (the bias gradient without a pass of its own): only when this node has no activation
+        # of its own (its gradient would come between dy and the sums)
+        pre_db = getattr(dy_in, "_sqd_colsum", None) if ctx.act is None else None
         g_skip = _cl(g_skip) if g_skip is not None else None
         if ctx.act is not None:                          # the epilogue's ReLU / LeakyReLU: dy * act'(y), one launch
             g = torch.empty_like(dy)
@@ -1214,6 +1235,10 @@ class Conv2d(torch.autograd.Function):
                     ady, axx = a_dy(), a_x()
             dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
             db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
+            db_k = db                                    # what the weight-gradient kernels are asked to fill
+            if db is not None and pre_db is not None and pre_db.numel() == K:
+                # the pass that wrote dy also summed its columns (GELU / layer-scale backward): that IS dbias
+                db, db_k = pre_db, None
             # (the plan table keys on the OUTPUT geometry: a strided or padded 1x1 that shares it with a stride-1 layer — or a plan file —
             #  must not take the transposed product, which reads x as [N*Ho*Wo][C] rows)
             transposed = CHOSEN_PLANS.get(("wgrad", N, Ho, Wo, C, K, R, S), (0,))[0] == WGRAD_TRANSPOSED and wgrad_transposed_applies(ctx.geom)
@@ -1223,14 +1248,14 @@ class Conv2d(torch.autograd.Function):
                 if ady is None and _scales_wanted("fwd", gT, (0,) + gT):
                     ady, axx = a_dy(), a_x()
 
-                def launch(dy=dy, x=x, dw=dw, db=db, geom=ctx.geom, ady=ady, axx=axx):
+                def launch(dy=dy, x=x, dw=dw, db=db_k, geom=ctx.geom, ady=ady, axx=axx):
                     _wgrad_transposed(dy, x, dw, db, geom, ady, axx)
             else:
                 pf, splits = _wgrad_part_floats(ctx.geom)
                 extra = max((N * Ho * Wo + 1023) // 1024, splits) * K if ctx.has_bias else 0
                 part = torch.empty(pf + extra, device=dy.device, dtype=torch.float32)
 
-                def launch(dy=dy, x=x, dw=dw, db=db, part=part, ady=ady, axx=axx):
+                def launch(dy=dy, x=x, dw=dw, db=db_k, part=part, ady=ady, axx=axx):
                     _l.check(L.sqd_conv_wgrad_scaled(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), _ptr(ady), _ptr(axx), N, H, W, C, K, R, S,
                                                      stride, pad, Ho, Wo, None, _stream()), "conv_wgrad")
             if not transposed and DEFER_WGRAD_REDUCE and WGRAD_STREAM is None and ctx.wkey is not None and _WEIGHT_USES.get(ctx.wkey, 2) == 1 and \
@@ -1243,7 +1268,7 @@ class Conv2d(torch.autograd.Function):
                 # channels-last copy would receive the gradient instead of the parameter; hooks would be skipped) — post-accumulate
                 # hooks only when their owner registered DEFERRED_GRAD_HOOK (the multi-rank reducer).
                 sp = ctypes.c_int(0)
-                _l.check(L.sqd_conv_wgrad_scaled(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db), _ptr(part), _ptr(ady), _ptr(axx), N, H, W, C, K, R, S, stride,
+                _l.check(L.sqd_conv_wgrad_scaled(_ptr(dy), _ptr(x), _ptr(dw), _ptr(db_k), _ptr(part), _ptr(ady), _ptr(axx), N, H, W, C, K, R, S, stride,
                                                  pad, Ho, Wo, ctypes.byref(sp), _stream()), "conv_wgrad_partials")
                 w.grad = dw
                 DEFERRED_FILTERS.add(w.data_ptr())

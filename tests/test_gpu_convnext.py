@@ -177,7 +177,8 @@ def test_unet_matches_oracle():
     for n, p in ref.named_parameters():
         if any(s in n for s in ("stem_0.weight", "stages_0.blocks.0.gamma", "stages_2.blocks.1.conv_dw.weight", "stages_1.downsample.1.weight",
                                 "stages_3.blocks.0.mlp.fc1.weight", "stages_2.blocks.0.norm.weight", "decoder.blocks.3.conv1.conv.weight",
-                                "decoder.final_conv.bias", "stages_0.blocks.0.conv_dw.bias")):
+                                "decoder.final_conv.bias", "stages_0.blocks.0.conv_dw.bias", "stages_3.blocks.0.mlp.fc1.bias",
+                                "stages_1.blocks.0.mlp.fc2.bias", "stages_2.blocks.1.mlp.fc2.bias")):
             close(grads[n].grad, p.grad, 2e-3, n)
 
 
@@ -279,11 +280,20 @@ def test_block_operators_record_the_maximum_of_what_they_write():
             def grab(name):
                 def hook(g):
                     seen[name] = (None if nnkernels._amax_get(g) is None else nnkernels.amax_value(nnkernels._amax_get(g)), float(g.abs().max()))
+                    # ... and the per-block column sums of what they wrote (the bias gradient of the Linear layer in front of them)
+                    cs = getattr(g, "_sqd_colsum", None)
+                    assert cs is not None and cs.shape == (C,), name
+                    want = g.double().sum((0, 2, 3))
+                    assert torch.allclose(cs.double(), want, rtol=1e-4, atol=1e-4 * float(want.abs().max())), name
                 return hook
             u.register_hook(grab("gelu dx"))
             z.register_hook(grab("scale dz"))
-            v.backward(torch.randn_like(v) * 1e-5)
+            gv = torch.randn_like(v) * 1e-5
+            v.backward(gv)
             out.backward(torch.randn_like(out) * 1e-5)
             assert seen["gelu dx"][0] == seen["gelu dx"][1] and seen["scale dz"][0] == seen["scale dz"][1], seen
+            ur = u.detach().clone().requires_grad_(True)
+            F.gelu(ur).backward(gv)
+            assert torch.allclose(u.grad, ur.grad, rtol=1e-5, atol=1e-5 * float(ur.grad.abs().max()))
     finally:
         nnkernels.amax_enable(was)
