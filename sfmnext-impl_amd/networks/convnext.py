@@ -43,7 +43,9 @@ class _Downsample(nn.Sequential):
         super().__init__(nn.LayerNorm(cin, eps=1e-6), nn.Conv2d(cin, cout, kernel_size=2, stride=2))
 
     def forward(self, x):
-        return X.patchify_conv(X.layer_norm_channels(x, self[0]), self[1], 2)
+        # (the 2x2 / 2 convolution runs on the implicit-GEMM kernels as it is — taps (r, s) of the strided input — with the LayerNorm's
+        #  operand-scale record; the space-to-depth form costs a layout copy each way)
+        return X.conv2d(X.layer_norm_channels(x, self[0]), self[1])
 
 
 class _Stage(nn.Module):
