@@ -104,6 +104,9 @@ typedef struct sqd_photo_args {
 } sqd_photo_args;
 int sqd_photo_ntasks(int B, int H, int W, int rows_per_task);
 int sqd_photo_fwd(const sqd_photo_args *a);
+/* which kernel sqd_photo_fwd launches on 8-wave tiles (process-wide, default 0): 0 = the colour-serial kernel (64 registers, eight
+ * waves per SIMD), 1 = round 5's all-colours kernel (126 registers, four waves per SIMD).  Same outputs bit for bit; kept for A/B runs. */
+int sqd_photo_set_fwd_variant(int variant);
 
 /* identity reprojection losses (trainer.py:480-487) + tie-break noise (trainer.py:514-517).
  * Depends only on the batch, not on the networks: the trainer enqueues it on a side stream.

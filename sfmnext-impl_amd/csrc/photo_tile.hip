@@ -31,6 +31,16 @@ typedef float v3f __attribute__((ext_vector_type(3)));      // (register triples
 
 constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
 constexpr float INV49 = 1.0f / 49.0f;
+#ifdef SQD_PHOTO_TRACE      // developer build (tools/build_variant.sh trace photo_tile.hip -DSQD_PHOTO_TRACE): per-wave s_memtime stamps of the forward's phases
+__device__ unsigned long long *g_photo_trace;      // [tile][wave][8]
+#define PHOTO_STAMP(i)                                                                                              \
+    do {                                                                                                            \
+        if (g_photo_trace && (threadIdx.x & 63) == 0)                                                               \
+            g_photo_trace[((size_t)tile * NW + wave) * 8 + (i)] = (i) == 7 ? (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) : __builtin_amdgcn_s_memtime(); \
+    } while (0)
+#else
+#define PHOTO_STAMP(i) do { } while (0)
+#endif
 constexpr int TR_MAX = 16;               // rows a tile owns (even)
 constexpr int NROW_MAX = TR_MAX + 6;     // + 3 halo rows above and below
 constexpr int LDS_BYTES = NROW_MAX * 3 * 64 * 8;
@@ -195,6 +205,7 @@ __device__ __forceinline__ void accumulate_row(Sums &A, const Raw &R) {
 struct Tiling {
     int TR, nsx, nsy, ntiles, nblk8;
     int n_lo, n_hi_cols;
+    int skew;          // fused forward: cycles the second workgroup of a CU waits at its start (0: none)
 };
 __device__ __forceinline__ void tile_of(const Tiling &tl, int tile, int H, int &b, int &tx, int &y0, int &own_rows) {
     if (tl.n_lo <= 0) {
@@ -230,6 +241,9 @@ struct Ctx {
     __amdgpu_buffer_rsrc_t tgt;       // image b of the target, [3][H][W]
     __amdgpu_buffer_rsrc_t p0, p1;    // MODE 0: sources, MODE 2: warped images (image b)
     const v2f *wl;                    // MODE 1: LDS tile [row][3][64]
+    const float *tt;                  // MODE 1, wide edition: the target rows of the tile in LDS, [row][3][64] (nullptr: from memory)
+    float *selp;                      // MODE 1, fast edition: image b of identity_selection / argmin (p0 = descriptor of its identity maps)
+    uint8_t *idxp;
     int H, W, y0, x, lane;            // tile's first owned row, this lane's column
     unsigned HW;
     unsigned xoff;                    // byte offset of the lane's column — beyond every buffer for lanes outside the image
@@ -238,14 +252,21 @@ __device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned voff, un
     return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-template <int MODE>
+template <int MODE, bool WIDE = false, bool NOREFL = false>
 __device__ __forceinline__ void load_row(const Ctx<MODE> &k, int r, Raw &R) {
     // tile row r <-> image row y0 - 3 + r, reflected into the image (ReflectionPad2d(3), layers.py:26).  Raw buffer loads: a
     // lane outside the image (W < 64 only) carries an offset beyond the descriptor and reads zeros — no branch.
-    const int yr = reflect_idx(k.y0 - 3 + r, k.H);
+    // (NOREFL: a tile whose halo rows all lie inside the image — no reflection arithmetic, row offsets are compile-time multiples)
+    const int yr = NOREFL ? k.y0 - 3 + r : reflect_idx(k.y0 - 3 + r, k.H);
     const unsigned row = (unsigned)(yr * k.W) * 4u;           // wave-uniform: travels in the scalar offset
+    if (MODE == 1 && WIDE) {
+        const int rr = yr - (k.y0 - 3);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) R.t[c] = bld(k.tgt, k.xoff, row + c * k.HW * 4u);
+        for (int c = 0; c < 3; ++c) R.t[c] = k.tt[(rr * 3 + c) * 64 + k.lane];
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R.t[c] = bld(k.tgt, k.xoff, row + c * k.HW * 4u);
+    }
     if (MODE == 1) {
         const int rr = yr - (k.y0 - 3);
 #pragma unroll
@@ -398,7 +419,24 @@ __device__ __forceinline__ void select_store(const sqd_photo_args &a, const Pair
     if (a.idx) a.idx[(size_t)b * HW + qo] = (uint8_t)bi;
 }
 
-template <int MODE, int KIND>
+// select_store for the configuration every training step of the reference's default options runs (two source frames in one pair pass, auto-mask
+// on, per-pixel minimum, no reprojection dump): the ~150 instructions select_store spends per output row on wave-uniform option tests (exec
+// mask bookkeeping, 64-bit pointer arithmetic per candidate) become 2 loads, 3 compare / select pairs and 2 stores.  `ident`: descriptor of
+// image b of the identity maps ([2][H][W]); `selp` / `idxp`: image b of the outputs.
+__device__ __forceinline__ void select_store_fast(__amdgpu_buffer_rsrc_t ident, float *__restrict__ selp, uint8_t *__restrict__ idxp, v2f loss, unsigned qo, unsigned HW,
+                                                  float &loss_acc) {
+    float best = bld(ident, qo * 4u, 0);
+    const float v1 = bld(ident, qo * 4u, HW * 4u);
+    int bi = 0;
+    if (v1 < best) { best = v1; bi = 1; }
+    if (loss.x < best) { best = loss.x; bi = 2; }
+    if (loss.y < best) { best = loss.y; bi = 3; }
+    loss_acc += best;
+    selp[qo] = bi >= 2 ? 1.f : 0.f;                                   // trainer.py:529-530
+    idxp[qo] = (uint8_t)bi;
+}
+
+template <int MODE, int KIND, bool FAST = false>
 __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPass &pp, const float *noise, const Ctx<MODE> &k, Sums &S, const Raw &ctr,
                                            bool edge, int b, int yo, bool own, float &loss_acc) {
     {
@@ -409,7 +447,7 @@ __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPa
 #pragma unroll
     for (int c = 0; c < 3; ++c) box7x3<KIND>(S.Sw[c], S.Sq[c], S.Swt[c], edge);
     SsimOut o;
-    const int flags = a.loss_flags;
+    const int flags = FAST ? 0 : a.loss_flags;
     const bool avg = flags & SQD_LOSS_AVG_REPROJECTION;
     ssim_l1<MODE == 2>(S, ctr, o, flags);
     if (!own) return;
@@ -432,7 +470,8 @@ __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPa
             if (pp.s1 != pp.s0) stg(out, q1 * 4u, o.loss.y + (nz ? ldg(nz, q1 * 4u) : 0.f) * 0.00001f);
         }
     } else if (MODE == 1) {
-        select_store(a, pp, o.loss, b, qo, HW, loss_acc);
+        if constexpr (FAST) select_store_fast(k.p0, k.selp, k.idxp, o.loss, qo, HW, loss_acc);
+        else select_store(a, pp, o.loss, b, qo, HW, loss_acc);
     } else {
         // the planes are fully written: zeros where an identity candidate won (the first pass lays them down; a later pass
         // of a 3- or 4-source run only overwrites the pixels its own sources won), so the backward reads them unmasked
@@ -460,7 +499,7 @@ __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPa
 }
 
 // phase 2 for the output rows of one wave: pairs (j, j+1) of tile rows share six of their seven window rows
-template <int MODE, int KIND>
+template <int MODE, int KIND, bool WIDE = false, bool FAST = false, bool NOREFL = false>
 __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const PairPass &pp, const float *noise, const Ctx<MODE> &k, bool edge, int b,
                                           int wave, int nwaves, int own_rows, bool own_col, float &loss_acc) {
     for (int p = wave; 2 * p < own_rows; p += nwaves) {
@@ -471,20 +510,20 @@ __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const PairPas
             Raw R;
 #pragma unroll
             for (int i = 1; i < 7; ++i) {
-                load_row<MODE>(k, j + i, R);
+                load_row<MODE, WIDE, NOREFL>(k, j + i, R);
                 accumulate_row(core, R);
             }
         }
 #pragma nounroll
         for (int o = 0; o < 2; ++o) {
             Raw R, ctr;
-            load_row<MODE>(k, j + 7 * o, R);
-            load_row<MODE>(k, j + 3 + o, ctr);
+            load_row<MODE, WIDE, NOREFL>(k, j + 7 * o, R);
+            load_row<MODE, WIDE, NOREFL>(k, j + 3 + o, ctr);
             Sums S = core;
             accumulate_row(S, R);
 #pragma unroll
             for (int c = 0; c < 3; ++c) S.Sq[c] += splat(S.Stt[c]);
-            finish_row<MODE, KIND>(a, pp, noise, k, S, ctr, edge, b, k.y0 + j + o, own_col && j + o < own_rows, loss_acc);
+            finish_row<MODE, KIND, FAST>(a, pp, noise, k, S, ctr, edge, b, k.y0 + j + o, own_col && j + o < own_rows, loss_acc);
         }
     }
 }
@@ -588,7 +627,7 @@ struct WarpOut {
 };
 
 // bilinear blend, the tile's LDS row, and — for cells the tile owns — sample / warped / taps in HBM
-template <bool VIRT>
+template <bool VIRT, bool WIDE = false, bool FAST = false>
 __device__ __forceinline__ void finish_cell(const WarpOut &o, const Cell &c, const v2f t0[3][2], const v2f t1[3][2], v2f *wl, int r, int lane,
                                             bool col_ok, bool own, unsigned HW, unsigned off) {
     v2f wv[3];
@@ -599,15 +638,15 @@ __device__ __forceinline__ void finish_cell(const WarpOut &o, const Cell &c, con
         wl[(r * 3 + ch) * 64 + lane] = (!VIRT || col_ok) ? wv[ch] : splat(0.f);
     }
     if (own) {
-        if (o.smp0) stg2(o.smp0, off * 8u, c.gx.x, c.gy.x);
-        if (o.smp1) stg2(o.smp1, off * 8u, c.gx.y, c.gy.y);
-        if (o.tap0) stg2i(o.tap0, off * 8u, c.x00, c.y00);
-        if (o.tap1) stg2i(o.tap1, off * 8u, c.x01, c.y01);
-        if (o.w0) {
+        if (FAST || o.smp0) stg2(o.smp0, off * 8u, c.gx.x, c.gy.x);
+        if (FAST || o.smp1) stg2(o.smp1, off * 8u, c.gx.y, c.gy.y);
+        if (!FAST && o.tap0) stg2i(o.tap0, off * 8u, c.x00, c.y00);
+        if (!FAST && o.tap1) stg2i(o.tap1, off * 8u, c.x01, c.y01);
+        if (!WIDE && o.w0) {       // (wide edition: the warped colours leave from the LDS tile, 16 bytes per lane — store_warped_wide)
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) stg(o.w0, (off + ch * HW) * 4u, wv[ch].x);
         }
-        if (o.w1) {
+        if (!WIDE && o.w1) {
 #pragma unroll
             for (int ch = 0; ch < 3; ++ch) stg(o.w1, (off + ch * HW) * 4u, wv[ch].y);
         }
@@ -616,7 +655,7 @@ __device__ __forceinline__ void finish_cell(const WarpOut &o, const Cell &c, con
 
 // phase 1 of a tile: every cell of the tile + halo is warped once, rows dealt round-robin to the NW waves; the depth of a wave's next
 // row is fetched under the current row's projection
-template <int NW, bool VIRT>
+template <int NW, bool VIRT, bool WIDE = false, bool FAST = false>
 __device__ __forceinline__ void warp_tile(const sqd_photo_args &a, const PairPass &pp, v2f *wl, int b, int y0, int own_rows, int xr, bool col_ok,
                                           bool own_col, int lane, int wave) {
     const int H = a.H, W = a.W;
@@ -663,15 +702,88 @@ __device__ __forceinline__ void warp_tile(const sqd_photo_args &a, const PairPas
         project_cell(c, d, fx, (float)yA, ik, P, rW, rH, wm1, hm1, W);
         v2f t0[3][2], t1[3][2];
         gather_taps(c, r0, r1, HW * 4u, (unsigned)W * 4u, t0, t1);
-        finish_cell<VIRT>(o, c, t0, t1, wl, r, lane, col_ok, own_col && r >= 3 && r < own_rows + 3, HW, off);
+        finish_cell<VIRT, WIDE, FAST>(o, c, t0, t1, wl, r, lane, col_ok, own_col && r >= 3 && r < own_rows + 3, HW, off);
+    }
+}
+
+// ---- wide edition (round 6): every vector-memory instruction of a wave costs the CU's address path 16 clocks whatever it moves (4 lanes
+// per clock), and the round-5 kernel issued 43 of them per 64-pixel output row — 30 us of the launch's 51 before any arithmetic, the two
+// adding up rather than overlapping.  Two families of 4-byte accesses become 16-byte ones that go through LDS:
+//  * the TARGET rows of the tile + halo are staged once, a lane fetching four consecutive pixels of one of four rows (one instruction
+//    = 4 rows x 64 columns; 26 per tile instead of phase 2's 15 dword loads per output row), and phase 2 reads them from LDS;
+//  * the WARPED colours, which phase 1 has put into the LDS tile anyway, leave from there as 16-byte stores (all 64 columns of the
+//    strip: the three halo columns on either side are the neighbouring tile's own cells, warped to the same bits — the two tiles sit
+//    on the same XCD and the duplicates merge in its L2).
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// the same in two halves, for at most 4 units per wave (tiles of up to 36 rows + halo on 8 waves): the loads leave before phase 1's row loop
+// and land in LDS after it — their round trip (4 800 cycles in the first wide build's trace) runs under the warps
+struct StagedRows { u32x4 v[4]; };
+template <int NW>
+__device__ __forceinline__ void stage_target_issue(StagedRows &sr, const float *__restrict__ tgt, int H, int W, int y0, int x0, int r_lo, int r_hi, int lane, int wave) {
+    const unsigned HW = (unsigned)(H * W);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tgt), 0, 3u * HW * 4u, 0x00020000);
+    const int rsub = lane >> 4, c4 = (lane & 15) * 4;
+    const int ngrp = (r_hi - r_lo + 3) >> 2;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int it = wave + NW * u;
+        const int p = it / ngrp, g = it - p * ngrp;
+        const int r = r_lo + 4 * g + rsub;
+        const unsigned voff = it < 3 * ngrp && r < r_hi ? (unsigned)((y0 - 3 + r) * W + x0 + c4) * 4u : 0x80000000u;
+        sr.v[u] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)p * HW * 4u, 0);
+    }
+}
+template <int NW>
+__device__ __forceinline__ void stage_target_commit(const StagedRows &sr, float *tt, int r_lo, int r_hi, int lane, int wave) {
+    const int rsub = lane >> 4, c4 = (lane & 15) * 4;
+    const int ngrp = (r_hi - r_lo + 3) >> 2;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int it = wave + NW * u;
+        const int p = it / ngrp, g = it - p * ngrp;
+        const int r = r_lo + 4 * g + rsub;
+        if (it < 3 * ngrp && r < r_hi) *reinterpret_cast<u32x4 *>(tt + (r * 3 + p) * 64 + c4) = sr.v[u];
+    }
+}
+template <int NW>
+__device__ __forceinline__ void stage_target_wide(float *tt, const float *__restrict__ tgt, int H, int W, int y0, int x0, int r_lo, int r_hi, int lane, int wave) {
+    const unsigned HW = (unsigned)(H * W);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(tgt), 0, 3u * HW * 4u, 0x00020000);
+    const int rsub = lane >> 4, c4 = (lane & 15) * 4;
+    const int ngrp = (r_hi - r_lo + 3) >> 2;
+    for (int it = wave; it < 3 * ngrp; it += NW) {
+        const int p = it / ngrp, g = it - p * ngrp;
+        const int r = r_lo + 4 * g + rsub;
+        const unsigned voff = r < r_hi ? (unsigned)((y0 - 3 + r) * W + x0 + c4) * 4u : 0x80000000u;
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)p * HW * 4u, 0);
+        if (r < r_hi) *reinterpret_cast<u32x4 *>(tt + (r * 3 + p) * 64 + c4) = v;
+    }
+}
+template <int NW>
+__device__ __forceinline__ void store_warped_wide(const v2f *wl, float *__restrict__ w0, float *__restrict__ w1, int H, int W, int y0, int x0, int own_rows,
+                                                  int lane, int wave) {
+    const unsigned HW = (unsigned)(H * W);
+    const int rsub = lane >> 4, c4 = (lane & 15) * 4;
+    const int ngrp = (own_rows + 3) >> 2;
+    for (int it = wave; it < 3 * ngrp; it += NW) {
+        const int ch = it / ngrp, g = it - ch * ngrp;
+        const int j = 4 * g + rsub;                          // owned row j of the tile = tile row j + 3
+        if (j < own_rows) {
+            const v4f lo = *reinterpret_cast<const v4f *>(wl + ((j + 3) * 3 + ch) * 64 + c4), hi = *reinterpret_cast<const v4f *>(wl + ((j + 3) * 3 + ch) * 64 + c4 + 2);
+            const size_t off = (size_t)ch * HW + (size_t)(y0 + j) * W + x0 + c4;
+            typedef float v4f_ua __attribute__((ext_vector_type(4), aligned(4)));
+            if (w0) *reinterpret_cast<v4f_ua *>(w0 + off) = v4f{lo.x, lo.z, hi.x, hi.z};
+            if (w1) *reinterpret_cast<v4f_ua *>(w1 + off) = v4f{lo.y, lo.w, hi.y, hi.w};
+        }
     }
 }
 
 // (4 workgroups of 4 waves per CU: the register allocator is held to 128 VGPRs; the kernel needs 118.  NW = 8: two workgroups of 8
 //  waves on tiles of up to 32 rows — the same waves per SIMD, 38 instead of 2 x 22 warped rows per 32 output rows)
-template <int MODE, int NW = 4>
+template <int MODE, int NW = 4, bool WIDE = false, bool FAST = false>
 __global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_args a, PairPass pp, const float *__restrict__ noise, Tiling tl) {
-    extern __shared__ v2f wl[];                       // MODE 1: [TR + 6][3][64] (source 0, source 1) warped colours
+    extern __shared__ v2f wl[];                       // MODE 1: [TR + 6][3][64] (source 0, source 1) warped colours (+ WIDE: [TR + 6][3][64] target)
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     // consecutive tiles (which share halo rows / columns) on the same XCD: workgroup i runs on XCD i % 8
@@ -688,12 +800,49 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_
     const bool own_col = x >= sx.own0 && x < sx.own1;
     const float *__restrict__ tgt = a.target + (size_t)b * 3 * HW;
 
+    if (MODE == 1 && tl.skew > 0 && (((blockIdx.x >> 3) >> 5) & 1)) {
+        // the two workgroups that start together on a CU are blocks 8 i + x and 8 (i + 32) + x of XCD x (profiles/r06a): the second one
+        // waits out `skew` cycles so that its address-bound phase 1 runs beside the first one's issue-bound phase 2 from then on
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)tl.skew) __builtin_amdgcn_s_sleep(32);
+    }
+    PHOTO_STAMP(0);
+    PHOTO_STAMP(7);                                                                 // HW_ID: which CU / SIMD the wave runs on
+#ifdef SQD_PHOTO_TRACE
+    if (g_photo_trace && lane == 0) g_photo_trace[((size_t)tile * NW + wave) * 8 + 6] = (unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11));      // XCC_ID
+#endif
     if (MODE == 1) {
         // ---------------------------------------------------------------- phase 1: warp every cell of the tile once
         // (images of fewer than 64 columns: lanes of a strip lie outside the image — they compute a clamped column and store zeros)
-        if (W < 64) warp_tile<NW, true>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
-        else warp_tile<NW, false>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
-        __syncthreads();
+        if (WIDE) {                                   // (launched for W >= 64 only)
+            float *tt = reinterpret_cast<float *>(wl + (tl.TR + 6) * 192);
+            const int r_lo = max(0, 3 - y0), r_hi = min(own_rows + 6, H - y0 + 3);
+            if constexpr (FAST) {
+                StagedRows sr;
+                stage_target_issue<NW>(sr, tgt, H, W, y0, sx.x0, r_lo, r_hi, lane, wave);
+                PHOTO_STAMP(1);
+                warp_tile<NW, false, true, true>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
+                stage_target_commit<NW>(sr, tt, r_lo, r_hi, lane, wave);
+            } else {
+                stage_target_wide<NW>(tt, tgt, H, W, y0, sx.x0, r_lo, r_hi, lane, wave);
+                PHOTO_STAMP(1);
+                warp_tile<NW, false, true>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
+            }
+            PHOTO_STAMP(2);
+            __syncthreads();
+            PHOTO_STAMP(3);
+            const bool two = pp.s1 != pp.s0;
+            store_warped_wide<NW>(wl, a.warped[pp.s0] ? a.warped[pp.s0] + (size_t)b * 3 * HW : nullptr,
+                                  two && a.warped[pp.s0] ? a.warped[pp.s1] + (size_t)b * 3 * HW : nullptr, H, W, y0, sx.x0, own_rows, lane, wave);
+        } else {
+            PHOTO_STAMP(1);
+            if (W < 64) warp_tile<NW, true>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
+            else warp_tile<NW, false>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
+            PHOTO_STAMP(2);
+            __syncthreads();
+            PHOTO_STAMP(3);
+        }
+        PHOTO_STAMP(4);
     }
 
     // -------------------------------------------------------------------- phase 2: window statistics, SSIM, selection
@@ -704,20 +853,597 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_
     const float *q1 = MODE == 0 ? a.sources[pp.s1] : MODE == 2 ? a.warped[pp.s1] : a.target;
     k.p0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(q0 + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
     k.p1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(q1 + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
+    if constexpr (FAST) {
+        k.p0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.identity + (size_t)b * 2 * HW), 0, 2u * HW * 4u, 0x00020000);
+        k.selp = a.sel + (size_t)b * HW;
+        k.idxp = a.idx + (size_t)b * HW;
+    }
     k.wl = wl;
+    k.tt = MODE == 1 && WIDE ? reinterpret_cast<const float *>(wl + (tl.TR + 6) * 192) : nullptr;
+    k.H = H; k.W = W; k.y0 = y0; k.x = x; k.lane = lane; k.HW = HW;
+    k.xoff = col_ok ? (unsigned)xr * 4u : 0x80000000u;
+    float loss_acc = 0.f;
+    if (FAST && y0 >= 3 && y0 + own_rows + 3 <= H) {       // every row of the tile + halo inside the image: the reflection-free row addressing
+        if (sx.kind == LEFT)
+            ssim_rows<MODE, LEFT, WIDE, FAST, true>(a, pp, noise, k, lane >= 1 && lane <= 3, b, wave, NW, own_rows, own_col, loss_acc);
+        else if (sx.kind == RIGHT)
+            ssim_rows<MODE, RIGHT, WIDE, FAST, true>(a, pp, noise, k, lane >= 60 && lane <= 62, b, wave, NW, own_rows, own_col, loss_acc);
+        else
+            ssim_rows<MODE, INTERIOR, WIDE, FAST, true>(a, pp, noise, k, false, b, wave, NW, own_rows, own_col, loss_acc);
+    } else if (sx.kind == LEFT)
+        ssim_rows<MODE, LEFT, WIDE, FAST>(a, pp, noise, k, lane >= 1 && lane <= 3, b, wave, NW, own_rows, own_col, loss_acc);
+    else if (sx.kind == RIGHT)
+        ssim_rows<MODE, RIGHT, WIDE, FAST>(a, pp, noise, k, lane >= 60 && lane <= 62, b, wave, NW, own_rows, own_col, loss_acc);
+    else
+        ssim_rows<MODE, INTERIOR, WIDE, FAST>(a, pp, noise, k, false, b, wave, NW, own_rows, own_col, loss_acc);
+    PHOTO_STAMP(5);
+    if (MODE == 1 && a.loss_part && pp.last) {       // (8-wave tilings: 16 partials per tile — the stream kernel's one per row pair)
+        loss_acc = wave_sum(loss_acc);
+        if (lane == 0) {
+            a.loss_part[tile * (NW == 8 ? 16 : NW) + wave] = loss_acc;
+            if (NW == 8) a.loss_part[tile * 16 + 8 + wave] = 0.f;
+        }
+    }
+}
+
+// =====================================================================================================================
+// Round 6: the fused forward, COLOUR-SERIAL phase 2 (photo_fwd_c_kernel).  Same tiles, same phase 1, same arithmetic in the same
+// order as photo_tile_kernel<1, 8> (the two kernels' outputs are equal bit for bit: tests/test_gpu_photometric.py) — what changes
+// is what a wave holds at a time.  SSIM is separable over the colour planes until the final mean, so phase 2 walks the three
+// colours one after the other: one colour's window sums are 8 registers (St, Stt, and (source 0, source 1) pairs of Sw, Sq, Swt)
+// instead of 24, its eight window rows 24 registers loaded as ONE batch (8 LDS reads + 8 target loads in flight), the horizontal
+// pass 7 shuffle chains (4 + 3 interleaved), and only the running (ssim, l1) sums of the row pair's two outputs (8 registers)
+// survive a colour.  The kernel fits 64 VGPRs: EIGHT waves per SIMD = four 8-wave workgroups per CU (4 x 34 KB of LDS), i.e. all
+// 1024 tiles of configs[1] resident at once — the records of rounds 3-5 say the forward follows its resident waves (3 waves per
+// SIMD 65.8 us, 4 waves 51 us) and that both of its phases are per-wave dependent chains, not pipe-bound.
+// phase 1 of the colour-serial kernel: warp_tile with the stores that do not depend on the gathers (sampling grid, integer taps)
+// issued BEFORE the gathers — eight registers less across the tap round trip
+template <int NW, bool VIRT>
+__device__ __forceinline__ void warp_tile_c(const sqd_photo_args &a, const PairPass &pp, v2f *wl, int b, int y0, int own_rows, int xr, bool col_ok,
+                                            bool own_col, int lane, int wave) {
+    const int H = a.H, W = a.W;
+    const unsigned HW = (unsigned)(H * W);
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    const float *__restrict__ dep = a.depth + (size_t)b * HW;
+    const unsigned img_bytes = 3u * HW * 4u;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sources[pp.s0] + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sources[pp.s1] + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
+    const bool two = pp.s1 != pp.s0;
+    WarpOut o;
+    o.smp0 = a.sample[pp.s0] ? reinterpret_cast<float2 *>(a.sample[pp.s0]) + (size_t)b * HW : nullptr;
+    o.smp1 = two && a.sample[pp.s1] ? reinterpret_cast<float2 *>(a.sample[pp.s1]) + (size_t)b * HW : nullptr;
+    o.tap0 = a.x0y0[pp.s0] ? reinterpret_cast<int2 *>(a.x0y0[pp.s0]) + (size_t)b * HW : nullptr;
+    o.tap1 = two && a.x0y0[pp.s1] ? reinterpret_cast<int2 *>(a.x0y0[pp.s1]) + (size_t)b * HW : nullptr;
+    o.w0 = a.warped[pp.s0] ? a.warped[pp.s0] + (size_t)b * 3 * HW : nullptr;
+    o.w1 = two && a.warped[pp.s0] ? a.warped[pp.s1] + (size_t)b * 3 * HW : nullptr;
+    float ik[9];
+    v2f P[12];
+    typedef const __attribute__((address_space(4))) float *cfp;
+    const cfp ikp = (cfp)(a.inv_K + (size_t)b * 16);
+    const cfp p0 = (cfp)(a.P + ((size_t)b * pp.S + pp.s0) * 12), p1 = (cfp)(a.P + ((size_t)b * pp.S + pp.s1) * 12);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ik[i * 3 + j] = ikp[i * 4 + j];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) P[j] = v2f{p0[j], p1[j]};
+    const v2f rW = splat(rcp_refined(wm1)), rH = splat(rcp_refined(hm1));
+    const int xc = VIRT ? min(max(xr, 0), W - 1) : xr;
+    const float fx = (float)xc;
+    const int r_lo = max(0, 3 - y0), r_hi = min(own_rows + 6, H - y0 + 3);
+    int r = r_lo + wave;
+    float d_next = r < r_hi ? ldg(dep, (unsigned)((y0 - 3 + r) * W + xc) * 4u) : 0.f;
+    for (; r < r_hi; r += NW) {
+        const int yA = y0 - 3 + r;
+        const unsigned off = (unsigned)(yA * W + xc);
+        const float d = d_next;
+        if (r + NW < r_hi) d_next = ldg(dep, (off + (unsigned)(NW * W)) * 4u);
+        const bool own = own_col && r >= 3 && r < own_rows + 3;
+        v2f wn0, ws0, wn1, ws1;
+        unsigned o0, o1;
+        {
+            Cell c;
+            project_cell(c, d, fx, (float)yA, ik, P, rW, rH, wm1, hm1, W);
+            if (own) {
+                if (o.smp0) stg2(o.smp0, off * 8u, c.gx.x, c.gy.x);
+                if (o.smp1) stg2(o.smp1, off * 8u, c.gx.y, c.gy.y);
+                if (o.tap0) stg2i(o.tap0, off * 8u, c.x00, c.y00);
+                if (o.tap1) stg2i(o.tap1, off * 8u, c.x01, c.y01);
+            }
+            wn0 = c.wn0; ws0 = c.ws0; wn1 = c.wn1; ws1 = c.ws1; o0 = c.o0; o1 = c.o1;
+        }
+        const unsigned HW4 = HW * 4u, s0 = o0 + (unsigned)W * 4u, s1 = o1 + (unsigned)W * 4u;
+        v2f t0[3][2], t1[3][2];
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            t0[ch][0] = bld2(r0, o0, ch * HW4);
+            t1[ch][0] = bld2(r1, o1, ch * HW4);
+            t0[ch][1] = bld2(r0, s0, ch * HW4);
+            t1[ch][1] = bld2(r1, s1, ch * HW4);
+        }
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const v2f ea = pfma(t0[ch][1], ws0, t0[ch][0] * wn0), eb = pfma(t1[ch][1], ws1, t1[ch][0] * wn1);
+            const v2f wv = v2f{hadd(ea), hadd(eb)};
+            wl[(r * 3 + ch) * 64 + lane] = (!VIRT || col_ok) ? wv : splat(0.f);
+            if (own) {
+                if (o.w0) stg(o.w0, (off + ch * HW) * 4u, wv.x);
+                if (o.w1) stg(o.w1, (off + ch * HW) * 4u, wv.y);
+            }
+        }
+    }
+}
+
+struct CSum {
+    float St, Stt;
+    v2f Sw, Sq, Swt;
+};
+// centred 7-tap sums of FOUR quantities across lanes (box7x3's chains, four interleaved)
+template <int KIND>
+__device__ __forceinline__ void box7x4(float &a, float &b, float &c, float &d, bool edge) {
+    float ea = 0.f, eb = 0.f, ec = 0.f, ed = 0.f;
+    if (KIND == LEFT) {
+        const float ma = edge ? a : 0.f, mb = edge ? b : 0.f, mc = edge ? c : 0.f, md = edge ? d : 0.f;
+        ea = quad_reverse<0, 0>((ma + row_shr<1>(ma)) + row_shr<2>(ma));
+        eb = quad_reverse<0, 0>((mb + row_shr<1>(mb)) + row_shr<2>(mb));
+        ec = quad_reverse<0, 0>((mc + row_shr<1>(mc)) + row_shr<2>(mc));
+        ed = quad_reverse<0, 0>((md + row_shr<1>(md)) + row_shr<2>(md));
+    } else if (KIND == RIGHT) {
+        const float ma = edge ? a : 0.f, mb = edge ? b : 0.f, mc = edge ? c : 0.f, md = edge ? d : 0.f;
+        ea = quad_reverse<3, 3>((ma + row_shl<1>(ma)) + row_shl<2>(ma));
+        eb = quad_reverse<3, 3>((mb + row_shl<1>(mb)) + row_shl<2>(mb));
+        ec = quad_reverse<3, 3>((mc + row_shl<1>(mc)) + row_shl<2>(mc));
+        ed = quad_reverse<3, 3>((md + row_shl<1>(md)) + row_shl<2>(md));
+    }
+    float ra = a + wave_shr1(a), rb = b + wave_shr1(b), rc = c + wave_shr1(c), rd = d + wave_shr1(d);
+    ra = a + wave_shr1(ra); rb = b + wave_shr1(rb); rc = c + wave_shr1(rc); rd = d + wave_shr1(rd);
+    ra = a + wave_shr1(ra); rb = b + wave_shr1(rb); rc = c + wave_shr1(rc); rd = d + wave_shr1(rd);
+    float ua = a + wave_shl1(a), ub = b + wave_shl1(b), uc = c + wave_shl1(c), ud = d + wave_shl1(d);
+    ua = a + wave_shl1(ua); ub = b + wave_shl1(ub); uc = c + wave_shl1(uc); ud = d + wave_shl1(ud);
+    a = ra + wave_shl1(ua); b = rb + wave_shl1(ub); c = rc + wave_shl1(uc); d = rd + wave_shl1(ud);
+    if (KIND != INTERIOR) {
+        a += ea; b += eb; c += ec; d += ed;
+    }
+}
+// one colour's term of ssim_l1_fwd (same instructions, same order)
+__device__ __forceinline__ void ssim_colour(float St, v2f Sw, v2f Sq, v2f Swt, float tc, v2f wc, v2f &ssim_sum, v2f &l1) {
+    constexpr float K1 = C1 * 2401.f, K2 = C2 * 2401.f;
+    const v2f p = Sw * splat(St);
+    const v2f A1 = pfma(splat(2.f), p, splat(K1));
+    const v2f A2 = pfma(splat(2.f), pfma(splat(49.f), Swt, -p), splat(K2));
+    const v2f q = pfma(Sw, Sw, splat(St * St));
+    const v2f B1 = q + splat(K1), B2 = pfma(splat(49.f), Sq, splat(K2) - q);
+    const v2f num = A1 * A2, den = B1 * B2;
+    const v2f rd = v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const v2f q0 = num * rd;
+    const v2f Sv = pfma(pfma(-den, q0, num), rd, q0);
+    const v2f r = pfma(splat(-0.5f), Sv, splat(0.5f));
+    ssim_sum += v2f{__builtin_amdgcn_fmed3f(r.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(r.y, 0.f, 1.f)};      // torch.clamp(., 0, 1)
+    const v2f df = splat(tc) - wc;
+    l1 += v2f{fabsf(df.x), fabsf(df.y)};
+}
+// S = core + one more row, Sigma t^2 folded into Sigma w^2, the horizontal pass, the colour's SSIM / L1 terms
+template <int KIND>
+__device__ __forceinline__ void finish_colour(const CSum &core, float t, v2f w, float tc, v2f wc, bool edge, v2f &ssim_sum, v2f &l1) {
+    float St = core.St + t;
+    const float Stt = fmaf(t, t, core.Stt);
+    v2f Sw = core.Sw + w;
+    v2f Sq = pfma(w, w, core.Sq);
+    v2f Swt = pfma(w, splat(t), core.Swt);
+    Sq += splat(Stt);
+    float swx = Sw.x, sqx = Sq.x, stx = Swt.x, swy = Sw.y, sqy = Sq.y, sty = Swt.y;
+    box7x4<KIND>(St, swx, sqx, stx, edge);
+    box7x3<KIND>(swy, sqy, sty, edge);
+    ssim_colour(St, v2f{swx, swy}, v2f{sqx, sqy}, v2f{stx, sty}, tc, wc, ssim_sum, l1);
+}
+
+template <int KIND>
+__device__ __forceinline__ void ssim_rows_c(const sqd_photo_args &a, const PairPass &pp, const Ctx<1> &k, bool edge, int b, int wave, int nwaves,
+                                            int own_rows, bool own_col, float &loss_acc) {
+    const int flags = a.loss_flags;
+    for (int p = wave; 2 * p < own_rows; p += nwaves) {
+        const int j = 2 * p;                         // tile rows j .. j+7 feed the outputs y0+j (centre j+3) and y0+j+1 (centre j+4)
+        v2f ss0 = splat(0.f), ss1 = splat(0.f), la0 = splat(0.f), la1 = splat(0.f);
+        // rows of the window in the image / in the LDS tile (wave-uniform; ReflectionPad2d(3): layers.py:26)
+        unsigned trow[8];
+        int lrow[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int yr = reflect_idx(k.y0 - 3 + j + i, k.H);
+            trow[i] = (unsigned)(yr * k.W) * 4u;
+            lrow[i] = (yr - (k.y0 - 3)) * 3 * 64;
+        }
+#pragma nounroll
+        for (int c = 0; c < 3; ++c) {
+            float t[8];
+            v2f w[8];
+            const unsigned plane = (unsigned)c * k.HW * 4u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                t[i] = bld(k.tgt, k.xoff, trow[i] + plane);
+                w[i] = k.wl[lrow[i] + c * 64 + k.lane];
+            }
+            CSum core;                               // rows j+1 .. j+6: shared by both outputs
+            core.St = 0.f; core.Stt = 0.f; core.Sw = core.Sq = core.Swt = splat(0.f);
+#pragma unroll
+            for (int i = 1; i < 7; ++i) {
+                core.St += t[i];
+                core.Stt = fmaf(t[i], t[i], core.Stt);
+                core.Sw += w[i];
+                core.Sq = pfma(w[i], w[i], core.Sq);
+                core.Swt = pfma(w[i], splat(t[i]), core.Swt);
+            }
+            finish_colour<KIND>(core, t[0], w[0], t[3], w[3], edge, ss0, la0);
+            finish_colour<KIND>(core, t[7], w[7], t[4], w[4], edge, ss1, la1);
+        }
+        const unsigned HW = k.HW;
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            const v2f ssim_sum = o ? ss1 : ss0, l1 = o ? la1 : la0;
+            v2f loss = splat(0.85f) * (ssim_sum * splat(1.f / 3.f)) + splat(0.15f) * (l1 * splat(1.f / 3.f));
+            if (flags & SQD_LOSS_NO_SSIM) loss = l1 * splat(1.f / 3.f);
+            if (own_col && j + o < own_rows) select_store(a, pp, loss, b, (unsigned)((k.y0 + j + o) * k.W + k.x), HW, loss_acc);
+        }
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 8) void photo_fwd_c_kernel(sqd_photo_args a, PairPass pp, Tiling tl) {
+    extern __shared__ v2f wl[];                       // [TR + 6][3][64] (source 0, source 1) warped colours
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = (blockIdx.x & 7) * tl.nblk8 + (blockIdx.x >> 3);      // consecutive tiles (shared halo rows / columns) on one XCD
+    if (tile >= tl.ntiles) return;
+    const int H = a.H, W = a.W, nsx = tl.nsx;
+    const unsigned HW = (unsigned)(H * W);
+    int tx, b, y0, own_rows;
+    tile_of(tl, tile, H, b, tx, y0, own_rows);
+    const StripX sx = strip_x(tx, nsx, W);
+    const int x = sx.x0 + lane;
+    const int xr = sx.virt ? reflect_idx(x, W) : x;
+    const bool col_ok = xr >= 0 && xr < W;
+    const bool own_col = x >= sx.own0 && x < sx.own1;
+    if (W < 64) warp_tile_c<NW, true>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
+    else warp_tile_c<NW, false>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
+    __syncthreads();
+    Ctx<1> k;
+    k.tgt = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.target + (size_t)b * 3 * HW), 0, 3u * HW * 4u, 0x00020000);
+    k.p0 = k.p1 = k.tgt;
+    k.wl = wl;
+    k.tt = nullptr;
     k.H = H; k.W = W; k.y0 = y0; k.x = x; k.lane = lane; k.HW = HW;
     k.xoff = col_ok ? (unsigned)xr * 4u : 0x80000000u;
     float loss_acc = 0.f;
     if (sx.kind == LEFT)
-        ssim_rows<MODE, LEFT>(a, pp, noise, k, lane >= 1 && lane <= 3, b, wave, NW, own_rows, own_col, loss_acc);
+        ssim_rows_c<LEFT>(a, pp, k, lane >= 1 && lane <= 3, b, wave, NW, own_rows, own_col, loss_acc);
     else if (sx.kind == RIGHT)
-        ssim_rows<MODE, RIGHT>(a, pp, noise, k, lane >= 60 && lane <= 62, b, wave, NW, own_rows, own_col, loss_acc);
+        ssim_rows_c<RIGHT>(a, pp, k, lane >= 60 && lane <= 62, b, wave, NW, own_rows, own_col, loss_acc);
     else
-        ssim_rows<MODE, INTERIOR>(a, pp, noise, k, false, b, wave, NW, own_rows, own_col, loss_acc);
-    if (MODE == 1 && a.loss_part && pp.last) {
+        ssim_rows_c<INTERIOR>(a, pp, k, false, b, wave, NW, own_rows, own_col, loss_acc);
+    if (a.loss_part && pp.last) {
         loss_acc = wave_sum(loss_acc);
-        if (lane == 0) a.loss_part[tile * NW + wave] = loss_acc;
+        if (lane == 0) {
+            a.loss_part[tile * 16 + wave] = loss_acc;
+            a.loss_part[tile * 16 + 8 + wave] = 0.f;
+        }
     }
+}
+
+// =====================================================================================================================
+// Round 6: the fused forward with DYNAMIC WAVE ROLES and a row in flight under every SSIM step (photo_fwd_s_kernel).
+//
+// What the per-wave s_memtime traces of round 6 say about photo_tile_kernel<1, 8> (profiles/r06a_photo_fwd_phase_trace.md): a wave alone
+// needs 3 400 cycles per warped row — 209 instructions, 950 cycles of issue, the rest is the tap round trip it stands at — and 9 600 per
+// row pair; two resident workgroups finish a tile every 25 000 cycles, three every 22 000, one every 38 000: the launch follows the
+// waves in flight, the VALU is busy 42 % and the address path 60 %, and the barrier between the phases plus 34 rows / 13 pairs dealt to
+// 8 waves leave 15..25 % of the wave slots idle.  Neither more resident waves (colour-serial, 6 per SIMD: 50.7 us) nor fewer memory
+// instructions (wide edition, 43 -> 25 per output row: 50.4 us) moves it while a wave still waits out every row's gathers.
+// Here the tile's work is three LDS queues of UNITS that the eight waves claim in order whenever a unit's inputs are ready (per-unit
+// done flags + a done prefix per queue; a claim is a compare-and-swap AFTER the readiness test, so no wave holds a unit it cannot run):
+//   stage: 4 rows of target + depth into LDS, 16 bytes per lane (phase 2 reads no memory; depth waits in the row's own warped slot);
+//   row:   warp one row of cells (phase 1's loop body) from the staged depth -> warped colours into LDS, grid + colours to HBM;
+//   pair:  two output rows, colour by colour (one colour's window sums are 8 registers) — and BETWEEN the colours of its pair the wave
+//          claims a row, projects it and issues its twelve gathers, runs the next colour's ~500 instructions while they fly, then blends:
+//          the tap round trip of a row is covered by its own wave's SSIM arithmetic, not by hoping for another wave.
+// No workgroup barrier after the prologue.  The loss partial is one slot per PAIR (16 per tile): the sum order does not depend on which
+// wave ran what, results are run-to-run identical.
+constexpr int ROW_WL = 3 * 64;                 // v2f per LDS row
+struct DynCtl {                                // (volatile ints in LDS)
+    int stage_next, stage_done, row_next, row_done, pair_next, pair_done, pad0, pad1;
+    int stage_flag[16], row_flag[48], pair_flag[24];
+};
+__device__ __forceinline__ int ldu(const volatile int *p) { return __builtin_amdgcn_readfirstlane(*p); }
+// claim unit `expect` of a queue (all lanes call; true for the whole wave if this wave got it)
+__device__ __forceinline__ bool claim_unit(volatile int *next, int expect, int lane) {
+    int got = expect + 1;
+    if (lane == 0) got = atomicCAS(const_cast<int *>(next), expect, expect + 1);
+    return __builtin_amdgcn_readfirstlane(got) == expect;
+}
+// unit i of a queue is complete: set its flag, then push the queue's done prefix over every leading complete unit (whoever finishes a unit
+// re-reads the flags after writing its own, so the prefix never stops short of a complete run)
+__device__ __forceinline__ void unit_done(volatile int *flag, volatile int *prefix, int i, int n, int lane) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (lane == 0) {
+        flag[i] = 1;
+        for (;;) {
+            const int p = *prefix;
+            if (p < n && flag[p]) atomicCAS(const_cast<int *>(prefix), p, p + 1);
+            else break;
+        }
+    }
+    asm volatile("" ::: "memory");
+}
+
+struct StreamTile {
+    int b, y0, own_rows, x0, x, lane;
+    int r_lo, r_hi, npairs, nstage, nrows;
+    bool own_col;
+    unsigned HW;
+};
+
+typedef const __attribute__((address_space(4))) float *cfp;
+typedef const __attribute__((address_space(4))) sqd_photo_args *argp;
+// The launch arguments are re-read from the kernel-argument segment (scalar loads) by every unit that needs them, through a pointer the
+// compiler cannot see through: the ~60 SGPRs of pointers a row unit uses would otherwise be loaded in the prologue, stay live through
+// the pair units and spill (first build: 287 SGPR + 44 VGPR spills).
+__device__ __forceinline__ const sqd_photo_args &fresh_args(argp ap) {
+    asm volatile("" : "+s"(ap));
+    return *(const sqd_photo_args *)ap;
+}
+
+// stage unit g: tile rows r_lo + 4 g .. + 3 (target planes + depth), one 16-byte load per lane and plane
+__device__ __forceinline__ void stage_unit(argp ap, const StreamTile &t, v2f *wl, float *tt, int g) {
+    const sqd_photo_args &a = fresh_args(ap);
+    const int W = a.W;
+    const int rsub = t.lane >> 4, c4 = (t.lane & 15) * 4;
+    const int r = t.r_lo + 4 * g + rsub;
+    const bool ok = r < t.r_hi;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.target + (size_t)t.b * 3 * t.HW), 0, 3u * t.HW * 4u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.depth + (size_t)t.b * t.HW), 0, t.HW * 4u, 0x00020000);
+    const unsigned voff = ok ? (unsigned)((t.y0 - 3 + r) * W + t.x0 + c4) * 4u : 0x80000000u;
+    u32x4 v[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) v[p] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, (unsigned)p * t.HW * 4u, 0);
+    const u32x4 d = __builtin_amdgcn_raw_buffer_load_b128(rd, voff, 0, 0);
+    if (ok) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) *reinterpret_cast<u32x4 *>(tt + (r * 3 + p) * 64 + c4) = v[p];
+        unsigned *dw = reinterpret_cast<unsigned *>(wl + r * ROW_WL + c4);       // the depth of column c waits in .x of the row's first colour slot
+        dw[0] = d.x; dw[2] = d.y; dw[4] = d.z; dw[6] = d.w;
+    }
+}
+
+struct RowInFlight {                 // a warped row between the issue of its gathers and its blend
+    v2f t0[3][2], t1[3][2];
+    v2f wn0, ws0, wn1, ws1;
+    unsigned off;
+    int r;
+    bool own;
+};
+
+// row unit, first half: projection, grid / tap stores, the twelve gathers (phase 1's loop body up to the tap round trip)
+__device__ __forceinline__ void row_issue(argp ap, const PairPass &pp, const StreamTile &t, const v2f *wl, int r, RowInFlight &f) {
+    const sqd_photo_args &a = fresh_args(ap);
+    const int W = a.W, H = a.H;
+    const unsigned HW = t.HW;
+    const int yA = t.y0 - 3 + r;
+    f.r = r;
+    f.off = (unsigned)(yA * W + t.x);
+    const float d = reinterpret_cast<const float *>(wl + r * ROW_WL + t.lane)[0];
+    f.own = t.own_col && r >= 3 && r < t.own_rows + 3;
+    const bool two = pp.s1 != pp.s0;
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    unsigned o0, o1;
+    {
+        const cfp ikp = (cfp)(a.inv_K + (size_t)t.b * 16);
+        const cfp p0 = (cfp)(a.P + ((size_t)t.b * pp.S + pp.s0) * 12), p1 = (cfp)(a.P + ((size_t)t.b * pp.S + pp.s1) * 12);
+        float ik[9];
+        v2f P[12];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) ik[i * 3 + jj] = ikp[i * 4 + jj];
+#pragma unroll
+        for (int jj = 0; jj < 12; ++jj) P[jj] = v2f{p0[jj], p1[jj]};
+        const v2f rW = splat(rcp_refined(wm1)), rH = splat(rcp_refined(hm1));
+        Cell c;
+        project_cell(c, d, (float)t.x, (float)yA, ik, P, rW, rH, wm1, hm1, W);
+        if (f.own) {
+            if (a.sample[pp.s0]) stg2(reinterpret_cast<float2 *>(a.sample[pp.s0]) + (size_t)t.b * HW, f.off * 8u, c.gx.x, c.gy.x);
+            if (two && a.sample[pp.s1]) stg2(reinterpret_cast<float2 *>(a.sample[pp.s1]) + (size_t)t.b * HW, f.off * 8u, c.gx.y, c.gy.y);
+            if (a.x0y0[pp.s0]) stg2i(reinterpret_cast<int2 *>(a.x0y0[pp.s0]) + (size_t)t.b * HW, f.off * 8u, c.x00, c.y00);
+            if (two && a.x0y0[pp.s1]) stg2i(reinterpret_cast<int2 *>(a.x0y0[pp.s1]) + (size_t)t.b * HW, f.off * 8u, c.x01, c.y01);
+        }
+        f.wn0 = c.wn0; f.ws0 = c.ws0; f.wn1 = c.wn1; f.ws1 = c.ws1; o0 = c.o0; o1 = c.o1;
+    }
+    const unsigned img_bytes = 3u * HW * 4u;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sources[pp.s0] + (size_t)t.b * 3 * HW), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sources[pp.s1] + (size_t)t.b * 3 * HW), 0, img_bytes, 0x00020000);
+    const unsigned HW4 = HW * 4u, s0 = o0 + (unsigned)W * 4u, s1 = o1 + (unsigned)W * 4u;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        f.t0[ch][0] = bld2(r0, o0, ch * HW4);
+        f.t1[ch][0] = bld2(r1, o1, ch * HW4);
+        f.t0[ch][1] = bld2(r0, s0, ch * HW4);
+        f.t1[ch][1] = bld2(r1, s1, ch * HW4);
+    }
+}
+// second half: blend, LDS row, warped colours to HBM
+__device__ __forceinline__ void row_finish(argp ap, const PairPass &pp, const StreamTile &t, v2f *wl, const RowInFlight &f) {
+    const sqd_photo_args &a = fresh_args(ap);
+    v2f *row = wl + f.r * ROW_WL;
+    float *w0 = a.warped[pp.s0] ? a.warped[pp.s0] + (size_t)t.b * 3 * t.HW : nullptr;
+    float *w1 = pp.s1 != pp.s0 && a.warped[pp.s0] ? a.warped[pp.s1] + (size_t)t.b * 3 * t.HW : nullptr;
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const v2f ea = pfma(f.t0[ch][1], f.ws0, f.t0[ch][0] * f.wn0), eb = pfma(f.t1[ch][1], f.ws1, f.t1[ch][0] * f.wn1);
+        const v2f wv = v2f{hadd(ea), hadd(eb)};
+        row[ch * 64 + t.lane] = wv;
+        if (f.own) {
+            if (w0) stg(w0, (f.off + ch * t.HW) * 4u, wv.x);
+            if (w1) stg(w1, (f.off + ch * t.HW) * 4u, wv.y);
+        }
+    }
+}
+
+// the next row of the queue, if its depth is staged: claimed (true) or not
+__device__ __forceinline__ bool claim_row(volatile DynCtl *q, const StreamTile &t, int &r) {
+    r = ldu(&q->row_next);
+    if (r < t.nrows && r < 4 * ldu(&q->stage_done)) return claim_unit(&q->row_next, r, t.lane);
+    return false;
+}
+
+// pair unit p: output rows y0 + 2 p, + 1 (ssim_rows_c's loop body), with a row unit in flight under every colour
+template <int KIND>
+__device__ __forceinline__ void pair_unit(argp ap, const PairPass &pp, const StreamTile &t, v2f *wl, const float *tt,
+                                          volatile DynCtl *q, bool edge, int tile, int p, int H) {
+    const int j = 2 * p;
+    v2f ss0 = splat(0.f), ss1 = splat(0.f), la0 = splat(0.f), la1 = splat(0.f);
+    int slot[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) slot[i] = (reflect_idx(t.y0 - 3 + j + i, H) - (t.y0 - 3)) * ROW_WL;
+#pragma nounroll
+    for (int c = 0; c < 3; ++c) {
+        RowInFlight f;
+        int r;
+        const bool have = claim_row(q, t, r);
+        if (have) row_issue(ap, pp, t, wl, t.r_lo + r, f);
+        {
+            float tv[8];
+            v2f w[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                tv[i] = tt[slot[i] + c * 64 + t.lane];
+                w[i] = wl[slot[i] + c * 64 + t.lane];
+            }
+            CSum core;
+            core.St = 0.f; core.Stt = 0.f; core.Sw = core.Sq = core.Swt = splat(0.f);
+#pragma unroll
+            for (int i = 1; i < 7; ++i) {
+                core.St += tv[i];
+                core.Stt = fmaf(tv[i], tv[i], core.Stt);
+                core.Sw += w[i];
+                core.Sq = pfma(w[i], w[i], core.Sq);
+                core.Swt = pfma(w[i], splat(tv[i]), core.Swt);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            finish_colour<KIND>(core, tv[0], w[0], tv[3], w[3], edge, ss0, la0);
+            __builtin_amdgcn_sched_barrier(0);
+            finish_colour<KIND>(core, tv[7], w[7], tv[4], w[4], edge, ss1, la1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (have) {
+            row_finish(ap, pp, t, wl, f);
+            unit_done(q->row_flag, &q->row_done, r, t.nrows, t.lane);
+        }
+    }
+    const sqd_photo_args &a = fresh_args(ap);
+    const int W = a.W, flags = a.loss_flags;
+    float loss_acc = 0.f;
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+        const v2f ssim_sum = o ? ss1 : ss0, l1 = o ? la1 : la0;
+        v2f loss = splat(0.85f) * (ssim_sum * splat(1.f / 3.f)) + splat(0.15f) * (l1 * splat(1.f / 3.f));
+        if (flags & SQD_LOSS_NO_SSIM) loss = l1 * splat(1.f / 3.f);
+        if (t.own_col && j + o < t.own_rows) select_store(a, pp, loss, t.b, (unsigned)((t.y0 + j + o) * W + t.x), t.HW, loss_acc);
+    }
+    if (a.loss_part && pp.last) {
+        loss_acc = wave_sum_to_lane63(loss_acc);
+        if (t.lane == 63) a.loss_part[tile * 16 + p] = loss_acc;
+    }
+}
+
+#ifdef SQD_PHOTO_TRACE      // unit log of the stream kernel: per tile 128 records of (type << 8 | index, wave, start, end), slot 0 = the record count
+#define STREAM_T0() const unsigned long long t0_ = __builtin_amdgcn_s_memtime()
+#define STREAM_T1(type, idx)                                                                          \
+    do {                                                                                              \
+        if (g_photo_trace && lane == 0) {                                                             \
+            unsigned long long *tb = g_photo_trace + (size_t)tile * 512;                               \
+            const int n = (int)atomicAdd(reinterpret_cast<unsigned long long *>(tb), 1ull) + 1;       \
+            if (n < 128) {                                                                            \
+                tb[n * 4 + 0] = ((type) << 8) | (idx);                                                \
+                tb[n * 4 + 1] = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);                     \
+                tb[n * 4 + 2] = t0_;                                                                  \
+                tb[n * 4 + 3] = __builtin_amdgcn_s_memtime();                                         \
+            }                                                                                         \
+        }                                                                                             \
+    } while (0)
+#else
+#define STREAM_T0() do { } while (0)
+#define STREAM_T1(type, idx) do { } while (0)
+#endif
+template <int NW, int KIND>
+__device__ __forceinline__ void stream_tile(argp ap, const PairPass &pp, const StreamTile &t, v2f *wl, float *tt, volatile DynCtl *q, bool edge,
+                                            int tile, int H) {
+    const int lane = t.lane;
+    for (;;) {
+        asm volatile("" ::: "memory");
+        // ---- a stage unit
+        const int g = ldu(&q->stage_next);
+        if (g < t.nstage) {
+            if (claim_unit(&q->stage_next, g, lane)) {
+                STREAM_T0();
+                stage_unit(ap, t, wl, tt, g);
+                unit_done(q->stage_flag, &q->stage_done, g, t.nstage, lane);
+                STREAM_T1(0, g);
+            }
+            continue;
+        }
+        // ---- a pair whose eight rows are warped
+        const int p = ldu(&q->pair_next);
+        if (p < t.npairs && ldu(&q->row_done) >= min(2 * p + 8 - t.r_lo, t.nrows)) {
+            if (claim_unit(&q->pair_next, p, lane)) {
+                STREAM_T0();
+                pair_unit<KIND>(ap, pp, t, wl, tt, q, edge, tile, p, H);
+                unit_done(q->pair_flag, &q->pair_done, p, t.npairs, lane);
+                STREAM_T1(2, p);
+            }
+            continue;
+        }
+        // ---- a row whose depth is staged (no pair ready: nothing to run under its gathers)
+        int r;
+        if (claim_row(q, t, r)) {
+            STREAM_T0();
+            RowInFlight f;
+            row_issue(ap, pp, t, wl, t.r_lo + r, f);
+            row_finish(ap, pp, t, wl, f);
+            unit_done(q->row_flag, &q->row_done, r, t.nrows, lane);
+            STREAM_T1(1, r);
+            continue;
+        }
+        if (p >= t.npairs) break;
+        __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+template <int NW, int WPE>
+__global__ __launch_bounds__(NW * 64, WPE) void photo_fwd_s_kernel(sqd_photo_args a, PairPass pp, Tiling tl) {
+    extern __shared__ v2f wl[];                       // [TR + 6][3][64] warped (source 0, source 1) | [TR + 6][3][64] target | DynCtl
+    float *tt = reinterpret_cast<float *>(wl + (tl.TR + 6) * ROW_WL);
+    volatile DynCtl *q = reinterpret_cast<volatile DynCtl *>(tt + (tl.TR + 6) * 3 * 64);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int tile = (blockIdx.x & 7) * tl.nblk8 + (blockIdx.x >> 3);
+    if (tile >= tl.ntiles) return;
+    const int H = a.H, W = a.W;
+    StreamTile t;
+    int tx;
+    tile_of(tl, tile, H, t.b, tx, t.y0, t.own_rows);
+    const StripX sx = strip_x(tx, tl.nsx, W);
+    t.x0 = sx.x0; t.lane = lane; t.x = sx.x0 + lane;
+    t.own_col = t.x >= sx.own0 && t.x < sx.own1;
+    t.HW = (unsigned)(H * W);
+    t.r_lo = max(0, 3 - t.y0); t.r_hi = min(t.own_rows + 6, H - t.y0 + 3);
+    t.nrows = t.r_hi - t.r_lo;
+    t.npairs = (t.own_rows + 1) >> 1;
+    t.nstage = (t.nrows + 3) >> 2;
+    for (int i = threadIdx.x; i < (int)(sizeof(DynCtl) / sizeof(int)); i += NW * 64) reinterpret_cast<volatile int *>(q)[i] = 0;
+    if (a.loss_part && pp.last && wave == 0 && lane < 16 && lane >= t.npairs) a.loss_part[tile * 16 + lane] = 0.f;
+    const argp ap = (argp)__builtin_amdgcn_kernarg_segment_ptr();      // (`a` is the first kernel argument)
+    __syncthreads();
+    if (sx.kind == LEFT) stream_tile<NW, LEFT>(ap, pp, t, wl, tt, q, lane >= 1 && lane <= 3, tile, H);
+    else if (sx.kind == RIGHT) stream_tile<NW, RIGHT>(ap, pp, t, wl, tt, q, lane >= 60 && lane <= 62, tile, H);
+    else stream_tile<NW, INTERIOR>(ap, pp, t, wl, tt, q, false, tile, H);
 }
 
 // =====================================================================================================================
@@ -1030,24 +1756,67 @@ Tiling make_tiling(int B, int H, int W, int rows_per_task, int family) {
 }
 }  // namespace
 
+#ifdef SQD_PHOTO_TRACE
+extern "C" int sqd_photo_trace(void *buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_photo_trace), &buf, sizeof(buf)); }
+#endif
 namespace sqd {
-int photo_fwd_waves(int B, int H, int W, int rows_per_task) {
+static int g_fwd_variant = 0;      // 0: default (stream kernel on 8-wave tilings), 1: round 5's kernel, 2: colour-serial phase 2, 4: wide edition
+static int g_fwd_skew = 0;
+void photo_set_fwd_variant(int v) { g_fwd_variant = v & 0xff; g_fwd_skew = (v >> 8) * 256; }
+int photo_fwd_waves(int B, int H, int W, int rows_per_task) {      // loss partials per tile
     const Tiling tl = make_tiling(B, H, W, rows_per_task, FAMILY_FWD);
-    return tl.TR > TR_MAX ? 8 : 4;
+    return tl.TR > TR_MAX ? 16 : 4;
 }
 int photo_tile_count(int B, int H, int W, int rows_per_task, int family) { return make_tiling(B, H, W, rows_per_task, family).ntiles; }
 
 // mode 0: identity maps, 1: fused forward, 2: coefficient planes of the backward (a.warped = stored warps, a.idx, a.coef)
 void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hipStream_t stream) {
-    const Tiling tl = make_tiling(a.B, a.H, a.W, a.rows_per_task, mode == 1 ? FAMILY_FWD : FAMILY_ROWS);
+    Tiling tl = make_tiling(a.B, a.H, a.W, a.rows_per_task, mode == 1 ? FAMILY_FWD : FAMILY_ROWS);
+    tl.skew = mode == 1 ? g_fwd_skew : 0;
     const int NW = mode == 1 && tl.TR > TR_MAX ? 8 : 4;
     const dim3 grid(tl.nblk8 * 8), block(NW * 64);
     for (int k = 0; 2 * k < a.S; ++k) {                  // one launch per pair of source frames
         const PairPass pp = {2 * k, 2 * k + 1 < a.S ? 2 * k + 1 : 2 * k, a.S, k == 0, 2 * k + 2 >= a.S};
         if (mode == 0)
             hipLaunchKernelGGL((photo_tile_kernel<0>), grid, block, 0, stream, a, pp, noise, tl);
-        else if (mode == 1 && NW == 8)
+        else if (mode == 1 && NW == 8 && g_fwd_variant == 2)
+            hipLaunchKernelGGL((photo_fwd_c_kernel<8>), grid, block, (tl.TR + 6) * 3 * 64 * 8, stream, a, pp, tl);
+        else if (mode == 1 && NW == 8 && g_fwd_variant == 0 && a.W >= 64 && a.S == 2 && a.loss_flags == 0 && !a.reproj && !a.x0y0[0] && !a.x0y0[1] && a.sel && a.idx &&
+                 a.sample[0] && a.sample[1] && a.warped[0] && a.warped[1] && a.identity && tl.TR <= 36) {
+            const int lds = (tl.TR + 6) * 3 * 64 * 12;
+            static int lds_ok = 0;                   // (dynamic LDS beyond 64 KB is an opt-in of the function)
+            if (!lds_ok) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photo_tile_kernel<1, 8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                lds_ok = 1;
+            }
+            hipLaunchKernelGGL((photo_tile_kernel<1, 8, true, true>), grid, block, lds, stream, a, pp, noise, tl);
+        } else if (mode == 1 && NW == 8 && g_fwd_variant == 5 && a.W >= 64) {
+            const int lds = (tl.TR + 6) * 3 * 64 * 12 + (int)sizeof(DynCtl);
+            static int lds_ok = 0;                   // (dynamic LDS beyond 64 KB is an opt-in of the function)
+            if (!lds_ok) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photo_fwd_s_kernel<8, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                lds_ok = 1;
+            }
+            hipLaunchKernelGGL((photo_fwd_s_kernel<8, 4>), grid, block, lds, stream, a, pp, tl);
+        } else if (mode == 1 && NW == 8 && g_fwd_variant == 4 && a.W >= 64) {
+            const int lds = (tl.TR + 6) * 3 * 64 * 12;
+            static int lds_ok = 0;                   // (dynamic LDS beyond 64 KB is an opt-in of the function)
+            if (lds > lds_ok) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photo_tile_kernel<1, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                lds_ok = 160 * 1024;
+            }
+            hipLaunchKernelGGL((photo_tile_kernel<1, 8, true>), grid, block, lds, stream, a, pp, noise, tl);
+        }
+        else if (mode == 1 && NW == 8) {
+#ifdef SQD_PHOTO_TRACE
+            if (g_fwd_variant == 3) {                  // developer experiment: ONE workgroup per CU (LDS padded to 100 KB)
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photo_tile_kernel<1, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                hipLaunchKernelGGL((photo_tile_kernel<1, 8>), grid, block, 100 * 1024, stream, a, pp, noise, tl);
+                continue;
+            }
+#endif
             hipLaunchKernelGGL((photo_tile_kernel<1, 8>), grid, block, (tl.TR + 6) * 3 * 64 * 8, stream, a, pp, noise, tl);
+        }
         else if (mode == 1)
             hipLaunchKernelGGL((photo_tile_kernel<1>), grid, block, (tl.TR + 6) * 3 * 64 * 8, stream, a, pp, noise, tl);
         else

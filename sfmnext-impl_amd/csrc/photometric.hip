@@ -48,6 +48,13 @@ static int check_loss_flags(const char *who, int flags, int S) {
     return SQD_OK;
 }
 
+namespace sqd { void photo_set_fwd_variant(int v); }
+extern "C" int sqd_photo_set_fwd_variant(int variant) {
+    SQD_CHECK_ARG((variant & 0xff) <= 5 && variant >= 0, "sqd_photo_set_fwd_variant: 0 (wide), 1 (round 5) or 2 (colour-serial), got %d", variant);
+    sqd::photo_set_fwd_variant(variant);
+    return SQD_OK;
+}
+
 extern "C" int sqd_photo_fwd(const sqd_photo_args *a) {
     SQD_CHECK_ARG(a && a->depth && a->inv_K && a->P && a->target && (a->identity || (a->loss_flags & SQD_LOSS_NO_AUTOMASK)), "sqd_photo_fwd: null input");
     if (check_loss_flags("sqd_photo_fwd", a->loss_flags, a->S)) return SQD_EINVAL;

@@ -136,6 +136,7 @@ _SIGNATURES = {
     "sqd_pose_mats_bwd": (_I, [_P, _P, ctypes.POINTER(ctypes.c_int32), _P, _P, _P, _P, _P, _P, _I, _I, _P]),
     "sqd_photo_ntasks": (_I, [_I, _I, _I, _I]),
     "sqd_photo_fwd": (_I, [ctypes.POINTER(PhotoArgs)]),
+    "sqd_photo_set_fwd_variant": (_I, [_I]),
     "sqd_identity_fwd": (_I, [_P, ctypes.POINTER(c_void_p), _P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_photo_coef": (_I, [_P, ctypes.POINTER(c_void_p), _P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_identity_fwd_ex": (_I, [_P, ctypes.POINTER(c_void_p), _P, _P, _I, _I, _I, _I, _I, _I, _P]),
