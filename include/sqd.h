@@ -169,7 +169,8 @@ int sqd_smooth_nblk(int H, int W);
 int sqd_smooth_fwd(const float *depth, const float *color, const float *part, int nblk, float *sm_part,
                    int B, int H, int W, void *stream);
 /* plane = gout * d(smooth)/d(depth): image b's plane is written at g_depth + b*g_depth_img_stride
- * (elements) — one of the planes summed by sqd_depth_up_bwd.                                          */
+ * (elements) — one of the planes summed by sqd_depth_up_bwd.  part == NULL (sm_part ignored): the adjoint of the
+ * stand-alone get_smooth_loss (sqd_smooth_fwd with part == NULL: no mean normalisation).               */
 int sqd_smooth_bwd(const float *depth, const float *color, const float *part, int nblk, const float *sm_part,
                    float gout, float *g_depth, int64_t g_depth_img_stride, int B, int H, int W, void *stream);
 /* the scalars of compute_losses (trainer.py:531-545) from the partial sums of sqd_photo_fwd and sqd_smooth_fwd, in one launch:

@@ -83,6 +83,14 @@ __device__ __forceinline__ v2f div_core2(v2f a, v2f b, v2f r) {      // a / b wi
     return pfma(e, r, q);
 }
 
+__device__ __forceinline__ void div_core2x2(v2f a0, v2f a1, v2f b0, v2f b1, v2f r0, v2f r1, v2f &o0, v2f &o1) {      // o_i = a_i / b_i, r_i = rcp_refined(b_i)
+    v2f q0 = a0 * r0, q1 = a1 * r1;
+    v2f e0 = pfma(-b0, q0, a0), e1 = pfma(-b1, q1, a1);
+    q0 = pfma(e0, r0, q0); q1 = pfma(e1, r1, q1);
+    e0 = pfma(-b0, q0, a0); e1 = pfma(-b1, q1, a1);
+    o0 = pfma(e0, r0, q0); o1 = pfma(e1, r1, q1);
+}
+
 // ---- column strips ------------------------------------------------------------------------------------------------
 // Lanes of a wavefront = 64 consecutive image columns.  An interior strip owns its middle 58 columns (3 halo lanes per
 // side).  The first strip starts at column 0 and the last one ends at column W-1: they own up to 61 columns, and the
@@ -162,6 +170,45 @@ __device__ __forceinline__ void box7x3(v2f &a, v2f &b, v2f &c, bool edge) {
     a = v2f{ax, ay};
     b = v2f{bx, by};
     c = v2f{cx, cy};
+}
+
+// centred 7-tap sums of SEVEN quantities (one colour's St, Sw, Sq, Swt of both sources) as ONE block of 42 v_add_f32_dpp in a fixed
+// interleaved order (box7x3's six steps, every step across the seven chains: a chain's shuffle reads a register written seven
+// instructions earlier — no hazard nops; the leading s_nop covers a producer right in front of the block).  Round 6: left to the
+// compiler, the last two steps of a chain came out as v_mov_b32_dpp + (SLP-paired) v_pk_add_f32 — 7 instructions per quantity and 21
+// hazard nops per output row instead of 6 and none.  Same sums in the same order as box7x3.
+#define SQD_DPP_SHR " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+#define SQD_DPP_SHL " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+template <int KIND>
+__device__ __forceinline__ void box7x7(float (&v)[7], bool edge) {
+    float e[7];
+    if (KIND != INTERIOR) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const float m = edge ? v[i] : 0.f;
+            e[i] = KIND == LEFT ? quad_reverse<0, 0>((m + row_shr<1>(m)) + row_shr<2>(m)) : quad_reverse<3, 3>((m + row_shl<1>(m)) + row_shl<2>(m));
+        }
+    }
+    float r0, r1, r2, r3, r4, r5, r6, u0, u1, u2, u3, u4, u5, u6;
+    asm("s_nop 1\n"
+        "v_add_f32_dpp %7, %0, %0" SQD_DPP_SHR "v_add_f32_dpp %8, %1, %1" SQD_DPP_SHR "v_add_f32_dpp %9, %2, %2" SQD_DPP_SHR "v_add_f32_dpp %10, %3, %3" SQD_DPP_SHR
+        "v_add_f32_dpp %11, %4, %4" SQD_DPP_SHR "v_add_f32_dpp %12, %5, %5" SQD_DPP_SHR "v_add_f32_dpp %13, %6, %6" SQD_DPP_SHR
+        "v_add_f32_dpp %7, %7, %0" SQD_DPP_SHR "v_add_f32_dpp %8, %8, %1" SQD_DPP_SHR "v_add_f32_dpp %9, %9, %2" SQD_DPP_SHR "v_add_f32_dpp %10, %10, %3" SQD_DPP_SHR
+        "v_add_f32_dpp %11, %11, %4" SQD_DPP_SHR "v_add_f32_dpp %12, %12, %5" SQD_DPP_SHR "v_add_f32_dpp %13, %13, %6" SQD_DPP_SHR
+        "v_add_f32_dpp %7, %7, %0" SQD_DPP_SHR "v_add_f32_dpp %8, %8, %1" SQD_DPP_SHR "v_add_f32_dpp %9, %9, %2" SQD_DPP_SHR "v_add_f32_dpp %10, %10, %3" SQD_DPP_SHR
+        "v_add_f32_dpp %11, %11, %4" SQD_DPP_SHR "v_add_f32_dpp %12, %12, %5" SQD_DPP_SHR "v_add_f32_dpp %13, %13, %6" SQD_DPP_SHR
+        "v_add_f32_dpp %14, %0, %0" SQD_DPP_SHL "v_add_f32_dpp %15, %1, %1" SQD_DPP_SHL "v_add_f32_dpp %16, %2, %2" SQD_DPP_SHL "v_add_f32_dpp %17, %3, %3" SQD_DPP_SHL
+        "v_add_f32_dpp %18, %4, %4" SQD_DPP_SHL "v_add_f32_dpp %19, %5, %5" SQD_DPP_SHL "v_add_f32_dpp %20, %6, %6" SQD_DPP_SHL
+        "v_add_f32_dpp %14, %14, %0" SQD_DPP_SHL "v_add_f32_dpp %15, %15, %1" SQD_DPP_SHL "v_add_f32_dpp %16, %16, %2" SQD_DPP_SHL "v_add_f32_dpp %17, %17, %3" SQD_DPP_SHL
+        "v_add_f32_dpp %18, %18, %4" SQD_DPP_SHL "v_add_f32_dpp %19, %19, %5" SQD_DPP_SHL "v_add_f32_dpp %20, %20, %6" SQD_DPP_SHL
+        "v_add_f32_dpp %0, %14, %7" SQD_DPP_SHL "v_add_f32_dpp %1, %15, %8" SQD_DPP_SHL "v_add_f32_dpp %2, %16, %9" SQD_DPP_SHL "v_add_f32_dpp %3, %17, %10" SQD_DPP_SHL
+        "v_add_f32_dpp %4, %18, %11" SQD_DPP_SHL "v_add_f32_dpp %5, %19, %12" SQD_DPP_SHL "v_add_f32_dpp %6, %20, %13" SQD_DPP_SHL
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&v"(r4), "=&v"(r5),
+          "=&v"(r6), "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3), "=&v"(u4), "=&v"(u5), "=&v"(u6));
+    if (KIND != INTERIOR) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) v[i] += e[i];
+    }
 }
 
 // one row of a lane's column: target rgb and the (pred_0, pred_1) rgb pairs
@@ -244,6 +291,7 @@ struct Ctx {
     const float *tt;                  // MODE 1, wide edition: the target rows of the tile in LDS, [row][3][64] (nullptr: from memory)
     float *selp;                      // MODE 1, fast edition: image b of identity_selection / argmin (p0 = descriptor of its identity maps)
     uint8_t *idxp;
+    float *w0, *w1;                   //   and of the warped outputs
     int H, W, y0, x, lane;            // tile's first owned row, this lane's column
     unsigned HW;
     unsigned xoff;                    // byte offset of the lane's column — beyond every buffer for lanes outside the image
@@ -290,24 +338,60 @@ struct SsimOut {
 // terms, 49 Sww - Sw^2 against 49^2 C2, is that of layers.py:35-46's own mu / sigma form).
 __device__ __forceinline__ v2f ssim_l1_fwd(const Sums &S, const Raw &ctr, int flags) {
     constexpr float K1 = C1 * 2401.f, K2 = C2 * 2401.f;
+    // (every step for the three colours before the next step: a packed instruction that reads the previous one's result costs an s_nop
+    //  on gfx950, and the compiler left the third colour's chain — 20 of them per output row — alone at the end)
+    v2f p[3], A1[3], A2[3], q[3], B1[3], B2[3], num[3], den[3], rd[3], q0[3], Sv[3], r[3], df[3];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) p[c] = S.Sw[c] * splat(S.St[c]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q[c] = pfma(S.Sw[c], S.Sw[c], splat(S.St[c] * S.St[c]));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) A1[c] = pfma(splat(2.f), p[c], splat(K1));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) A2[c] = pfma(splat(49.f), S.Swt[c], -p[c]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) B1[c] = q[c] + splat(K1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) B2[c] = pfma(splat(49.f), S.Sq[c], splat(K2) - q[c]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) A2[c] = pfma(splat(2.f), A2[c], splat(K2));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) den[c] = B1[c] * B2[c];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) num[c] = A1[c] * A2[c];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rd[c] = v2f{__builtin_amdgcn_rcpf(den[c].x), __builtin_amdgcn_rcpf(den[c].y)};
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) df[c] = splat(ctr.t[c]) - ctr.w[c];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) q0[c] = num[c] * rd[c];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Sv[c] = pfma(-den[c], q0[c], num[c]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) Sv[c] = pfma(Sv[c], rd[c], q0[c]);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) r[c] = pfma(splat(-0.5f), Sv[c], splat(0.5f));
+    __builtin_amdgcn_sched_barrier(0);
     v2f ssim_sum = splat(0.f), l1 = splat(0.f);
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const float St = S.St[c];
-        const v2f Sw = S.Sw[c];
-        const v2f p = Sw * splat(St);
-        const v2f A1 = pfma(splat(2.f), p, splat(K1));
-        const v2f A2 = pfma(splat(2.f), pfma(splat(49.f), S.Swt[c], -p), splat(K2));
-        const v2f q = pfma(Sw, Sw, splat(St * St));
-        const v2f B1 = q + splat(K1), B2 = pfma(splat(49.f), S.Sq[c], splat(K2) - q);
-        const v2f num = A1 * A2, den = B1 * B2;
-        const v2f rd = v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
-        const v2f q0 = num * rd;
-        const v2f Sv = pfma(pfma(-den, q0, num), rd, q0);
-        const v2f r = pfma(splat(-0.5f), Sv, splat(0.5f));
-        ssim_sum += v2f{__builtin_amdgcn_fmed3f(r.x, 0.f, 1.f), __builtin_amdgcn_fmed3f(r.y, 0.f, 1.f)};      // torch.clamp(., 0, 1)
-        const v2f df = splat(ctr.t[c]) - ctr.w[c];
-        l1 += v2f{fabsf(df.x), fabsf(df.y)};
+        ssim_sum += v2f{__builtin_amdgcn_fmed3f(r[c].x, 0.f, 1.f), __builtin_amdgcn_fmed3f(r[c].y, 0.f, 1.f)};      // torch.clamp(., 0, 1)
+        l1 += v2f{fabsf(df[c].x), fabsf(df[c].y)};
     }
     if (flags & SQD_LOSS_NO_SSIM) return l1 * splat(1.f / 3.f);          // --no_ssim: the L1 term alone (trainer.py:447-448)
     return splat(0.85f) * (ssim_sum * splat(1.f / 3.f)) + splat(0.15f) * (l1 * splat(1.f / 3.f));
@@ -439,13 +523,23 @@ __device__ __forceinline__ void select_store_fast(__amdgpu_buffer_rsrc_t ident, 
 template <int MODE, int KIND, bool FAST = false>
 __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPass &pp, const float *noise, const Ctx<MODE> &k, Sums &S, const Raw &ctr,
                                            bool edge, int b, int yo, bool own, float &loss_acc) {
-    {
-        float s0 = S.St.x, s1 = S.St.y, s2 = S.St.z;
-        box7x3<KIND>(s0, s1, s2, edge);
-        S.St = v3f{s0, s1, s2};
-    }
+    if constexpr (FAST) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) box7x3<KIND>(S.Sw[c], S.Sq[c], S.Swt[c], edge);
+        for (int c = 0; c < 3; ++c) {
+            float q[7] = {S.St[c], S.Sw[c].x, S.Sw[c].y, S.Sq[c].x, S.Sq[c].y, S.Swt[c].x, S.Swt[c].y};
+            box7x7<KIND>(q, edge);
+            S.St[c] = q[0];
+            S.Sw[c] = v2f{q[1], q[2]}; S.Sq[c] = v2f{q[3], q[4]}; S.Swt[c] = v2f{q[5], q[6]};
+        }
+    } else {
+        {
+            float s0 = S.St.x, s1 = S.St.y, s2 = S.St.z;
+            box7x3<KIND>(s0, s1, s2, edge);
+            S.St = v3f{s0, s1, s2};
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) box7x3<KIND>(S.Sw[c], S.Sq[c], S.Swt[c], edge);
+    }
     SsimOut o;
     const int flags = FAST ? 0 : a.loss_flags;
     const bool avg = flags & SQD_LOSS_AVG_REPROJECTION;
@@ -498,12 +592,20 @@ __device__ __forceinline__ void finish_row(const sqd_photo_args &a, const PairPa
     }
 }
 
+template <int NW>
+__device__ __forceinline__ void store_warped_wide(const v2f *wl, float *__restrict__ w0, float *__restrict__ w1, int H, int W, int y0, int x0, int own_rows,
+                                                  int lane, int wave, int k0 = 0, int k1 = 1 << 20);
 // phase 2 for the output rows of one wave: pairs (j, j+1) of tile rows share six of their seven window rows
 template <int MODE, int KIND, bool WIDE = false, bool FAST = false, bool NOREFL = false>
 __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const PairPass &pp, const float *noise, const Ctx<MODE> &k, bool edge, int b,
                                           int wave, int nwaves, int own_rows, bool own_col, float &loss_acc) {
+    int kst = 0;
     for (int p = wave; 2 * p < own_rows; p += nwaves) {
         const int j = 2 * p;                         // tile rows j .. j+7 feed the outputs y0+j (centre j+3) and y0+j+1 (centre j+4)
+        if constexpr (MODE == 1 && FAST) {           // three of the wave's 16-byte warped-store iterations per row pair (<= 6 in all: tiles of <= 64 rows)
+            store_warped_wide<8>(k.wl, k.w0, k.w1, k.H, k.W, k.y0, k.x - k.lane, own_rows, k.lane, wave, kst, kst + 3);
+            kst += 3;
+        }
         Sums core;                                   // rows j+1 .. j+6: shared by both outputs
         clear(core);
         {
@@ -526,6 +628,7 @@ __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const PairPas
             finish_row<MODE, KIND, FAST>(a, pp, noise, k, S, ctr, edge, b, k.y0 + j + o, own_col && j + o < own_rows, loss_acc);
         }
     }
+    if constexpr (MODE == 1 && FAST) store_warped_wide<8>(k.wl, k.w0, k.w1, k.H, k.W, k.y0, k.x - k.lane, own_rows, k.lane, wave, kst);
 }
 
 
@@ -574,8 +677,13 @@ __device__ __forceinline__ void project_cell(Cell &c, float d, float fx, float f
     }
     const v2f z = cam[2] + splat(1e-7f);
     const v2f rz = rcp_refined2(z);
-    const v2f u = div_core2(cam[0], z, rz), v = div_core2(cam[1], z, rz);
-    const v2f tx = div_core2(u, splat(wm1), rW) - splat(0.5f), ty = div_core2(v, splat(hm1), rH) - splat(0.5f);
+    // the x and y quotients as two interleaved chains (div_core2's steps, statement by statement): a packed instruction that reads the
+    // previous one's result costs an s_nop on gfx950 — the serial form carried 20 of them per row of cells
+    v2f u, v, tx, ty;
+    div_core2x2(cam[0], cam[1], z, z, rz, rz, u, v);
+    div_core2x2(u, v, splat(wm1), splat(hm1), rW, rH, tx, ty);
+    tx -= splat(0.5f);
+    ty -= splat(0.5f);
     c.gx = tx + tx;                                                     // (un - 0.5) * 2
     c.gy = ty + ty;
     v2f ix = pfma(splat(2.0f), tx, splat(1.0f)) * splat(0.5f * wm1);   // ((gx + 1) * 0.5) * (W - 1), bit for bit
@@ -762,11 +870,11 @@ __device__ __forceinline__ void stage_target_wide(float *tt, const float *__rest
 }
 template <int NW>
 __device__ __forceinline__ void store_warped_wide(const v2f *wl, float *__restrict__ w0, float *__restrict__ w1, int H, int W, int y0, int x0, int own_rows,
-                                                  int lane, int wave) {
+                                                  int lane, int wave, int k0, int k1) {      // (the wave's iterations k0 .. k1 - 1)
     const unsigned HW = (unsigned)(H * W);
     const int rsub = lane >> 4, c4 = (lane & 15) * 4;
     const int ngrp = (own_rows + 3) >> 2;
-    for (int it = wave; it < 3 * ngrp; it += NW) {
+    for (int it = wave + NW * k0; it < 3 * ngrp && it < wave + NW * k1; it += NW) {
         const int ch = it / ngrp, g = it - ch * ngrp;
         const int j = 4 * g + rsub;                          // owned row j of the tile = tile row j + 3
         if (j < own_rows) {
@@ -781,14 +889,10 @@ __device__ __forceinline__ void store_warped_wide(const v2f *wl, float *__restri
 
 // (4 workgroups of 4 waves per CU: the register allocator is held to 128 VGPRs; the kernel needs 118.  NW = 8: two workgroups of 8
 //  waves on tiles of up to 32 rows — the same waves per SIMD, 38 instead of 2 x 22 warped rows per 32 output rows)
-template <int MODE, int NW = 4, bool WIDE = false, bool FAST = false>
-__global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_args a, PairPass pp, const float *__restrict__ noise, Tiling tl) {
-    extern __shared__ v2f wl[];                       // MODE 1: [TR + 6][3][64] (source 0, source 1) warped colours (+ WIDE: [TR + 6][3][64] target)
+template <int MODE, int NW, bool WIDE, bool FAST>
+__device__ __forceinline__ void photo_tile_body(const sqd_photo_args &a, const PairPass &pp, const float *__restrict__ noise, const Tiling &tl, v2f *wl, int tile) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // consecutive tiles (which share halo rows / columns) on the same XCD: workgroup i runs on XCD i % 8
-    const int tile = (blockIdx.x & 7) * tl.nblk8 + (blockIdx.x >> 3);
-    if (tile >= tl.ntiles) return;
     const int H = a.H, W = a.W, nsx = tl.nsx;
     const unsigned HW = (unsigned)(H * W);
     int tx, b, y0, own_rows;
@@ -832,8 +936,9 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_
             __syncthreads();
             PHOTO_STAMP(3);
             const bool two = pp.s1 != pp.s0;
-            store_warped_wide<NW>(wl, a.warped[pp.s0] ? a.warped[pp.s0] + (size_t)b * 3 * HW : nullptr,
-                                  two && a.warped[pp.s0] ? a.warped[pp.s1] + (size_t)b * 3 * HW : nullptr, H, W, y0, sx.x0, own_rows, lane, wave);
+            if (!FAST)      // (fast edition: the stores leave between the wave's row pairs — ssim_rows —, under the other waves' arithmetic)
+                store_warped_wide<NW>(wl, a.warped[pp.s0] ? a.warped[pp.s0] + (size_t)b * 3 * HW : nullptr,
+                                      two && a.warped[pp.s0] ? a.warped[pp.s1] + (size_t)b * 3 * HW : nullptr, H, W, y0, sx.x0, own_rows, lane, wave);
         } else {
             PHOTO_STAMP(1);
             if (W < 64) warp_tile<NW, true>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
@@ -857,6 +962,8 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_
         k.p0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.identity + (size_t)b * 2 * HW), 0, 2u * HW * 4u, 0x00020000);
         k.selp = a.sel + (size_t)b * HW;
         k.idxp = a.idx + (size_t)b * HW;
+        k.w0 = a.warped[pp.s0] + (size_t)b * 3 * HW;
+        k.w1 = a.warped[pp.s1] + (size_t)b * 3 * HW;
     }
     k.wl = wl;
     k.tt = MODE == 1 && WIDE ? reinterpret_cast<const float *>(wl + (tl.TR + 6) * 192) : nullptr;
@@ -883,6 +990,25 @@ __global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_
             a.loss_part[tile * (NW == 8 ? 16 : NW) + wave] = loss_acc;
             if (NW == 8) a.loss_part[tile * 16 + 8 + wave] = 0.f;
         }
+    }
+}
+template <int MODE, int NW = 4, bool WIDE = false, bool FAST = false>
+__global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_args a, PairPass pp, const float *__restrict__ noise, Tiling tl) {
+    extern __shared__ v2f wl[];                       // MODE 1: [TR + 6][3][64] (source 0, source 1) warped colours (+ WIDE: [TR + 6][3][64] target)
+    // consecutive tiles (which share halo rows / columns) on the same XCD: workgroup i runs on XCD i % 8
+    const int tile = (blockIdx.x & 7) * tl.nblk8 + (blockIdx.x >> 3);
+    if (tile >= tl.ntiles) return;
+    photo_tile_body<MODE, NW, WIDE, FAST>(a, pp, noise, tl, wl, tile);
+}
+// the lean forward as RESIDENT workgroups (two per CU = 64 per XCD), each walking its XCD's tile list with stride 64: the per-CU traces of
+// round 6 show a freed workgroup slot idle for ~5 000 cycles (2 us of a 45 us launch) before its successor starts
+template <int NW>
+__global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_resident_kernel(sqd_photo_args a, PairPass pp, Tiling tl, int per_xcd) {
+    extern __shared__ v2f wl[];
+    for (int j = blockIdx.x >> 3; j < tl.nblk8; j += per_xcd) {
+        const int tile = (blockIdx.x & 7) * tl.nblk8 + j;
+        if (tile < tl.ntiles) photo_tile_body<1, NW, true, true>(a, pp, nullptr, tl, wl, tile);
+        __syncthreads();
     }
 }
 
@@ -1761,8 +1887,8 @@ extern "C" int sqd_photo_trace(void *buf) { return (int)hipMemcpyToSymbol(HIP_SY
 #endif
 namespace sqd {
 static int g_fwd_variant = 0;      // 0: default (stream kernel on 8-wave tilings), 1: round 5's kernel, 2: colour-serial phase 2, 4: wide edition
-static int g_fwd_skew = 0;
-void photo_set_fwd_variant(int v) { g_fwd_variant = v & 0xff; g_fwd_skew = (v >> 8) * 256; }
+static int g_fwd_skew = 0, g_fwd_resident = 0;
+void photo_set_fwd_variant(int v) { g_fwd_variant = v & 0x7f; g_fwd_resident = (v & 0x80) != 0; g_fwd_skew = (v >> 8) * 256; }
 int photo_fwd_waves(int B, int H, int W, int rows_per_task) {      // loss partials per tile
     const Tiling tl = make_tiling(B, H, W, rows_per_task, FAMILY_FWD);
     return tl.TR > TR_MAX ? 16 : 4;
@@ -1789,7 +1915,16 @@ void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hi
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photo_tile_kernel<1, 8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                 lds_ok = 1;
             }
-            hipLaunchKernelGGL((photo_tile_kernel<1, 8, true, true>), grid, block, lds, stream, a, pp, noise, tl);
+            static int lds_ok2 = 0;
+            if (!lds_ok2) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photo_tile_resident_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                lds_ok2 = 1;
+            }
+            const int per_xcd = tl.nblk8 < 64 ? tl.nblk8 : 64;            // 256 CUs x 2 resident workgroups = 64 per XCD
+            if (g_fwd_resident && tl.nblk8 > 64)
+                hipLaunchKernelGGL((photo_tile_resident_kernel<8>), dim3(per_xcd * 8), block, lds, stream, a, pp, tl, per_xcd);
+            else
+                hipLaunchKernelGGL((photo_tile_kernel<1, 8, true, true>), grid, block, lds, stream, a, pp, noise, tl);
         } else if (mode == 1 && NW == 8 && g_fwd_variant == 5 && a.W >= 64) {
             const int lds = (tl.TR + 6) * 3 * 64 * 12 + (int)sizeof(DynCtl);
             static int lds_ok = 0;                   // (dynamic LDS beyond 64 KB is an opt-in of the function)

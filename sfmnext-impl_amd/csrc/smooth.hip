@@ -82,12 +82,13 @@ __global__ __launch_bounds__(256) void smooth_bwd_kernel(const float *__restrict
     const size_t HW = (size_t)H * W;
     __shared__ float red4[4];
     const float inx = 1.f / ((float)B * (float)H * (float)(W - 1)), iny = 1.f / ((float)B * (float)(H - 1) * (float)W);
-    const float s_m = image_mean(part, b, nblk, (int)HW, red4);
-    const float ax = block_sum_strided(sm_part + (size_t)b * nblk_s * 2, nblk_s, 2, red4);
-    const float ay = block_sum_strided(sm_part + (size_t)b * nblk_s * 2 + 1, nblk_s, 2, red4);
+    // part == NULL (workgroup-uniform): the stand-alone get_smooth_loss on an already normalised disparity — no mean-normalisation term
+    const float s_m = part ? image_mean(part, b, nblk, (int)HW, red4) : 0.f;
+    const float ax = part ? block_sum_strided(sm_part + (size_t)b * nblk_s * 2, nblk_s, 2, red4) : 0.f;
+    const float ay = part ? block_sum_strided(sm_part + (size_t)b * nblk_s * 2 + 1, nblk_s, 2, red4) : 0.f;
     const float s_Lb = ax * inx + ay * iny;
-    const float mp = s_m + 1e-7f, im = 1.f / mp;
-    const float mean_term = -s_Lb * im / (float)HW;
+    const float mp = s_m + 1e-7f, im = part ? 1.f / mp : 1.f;
+    const float mean_term = part ? -s_Lb * im / (float)HW : 0.f;
     const float *d = depth + (size_t)b * HW, *col = color + (size_t)b * 3 * HW;
     float *g = g_depth + (size_t)b * gstride;
     const int q0 = blk * SM_PX_PER_BLOCK + threadIdx.x * 4;
@@ -167,9 +168,9 @@ extern "C" int sqd_smooth_fwd(const float *depth, const float *color, const floa
 extern "C" int sqd_smooth_bwd(const float *depth, const float *color, const float *part, int nblk, const float *sm_part,
                               float gout, float *g_depth, int64_t g_depth_img_stride, int B, int H, int W,
                               void *stream) {
-    SQD_CHECK_ARG(depth && color && part && sm_part && g_depth, "sqd_smooth_bwd: null pointer");
+    SQD_CHECK_ARG(depth && color && (sm_part || !part) && g_depth, "sqd_smooth_bwd: null pointer");
     SQD_CHECK_ARG(g_depth_img_stride >= (int64_t)H * W, "sqd_smooth_bwd: g_depth_img_stride too small");
-    SQD_CHECK_ARG(B > 0 && H > 1 && W > 1 && nblk > 0, "sqd_smooth_bwd: bad shape");
+    SQD_CHECK_ARG(B > 0 && H > 1 && W > 1 && (nblk > 0 || !part), "sqd_smooth_bwd: bad shape");
     const int nb = sqd_smooth_nblk(H, W);
     (void)hipGetLastError();   // drop any stale error left by other HIP users of this thread
     hipLaunchKernelGGL(smooth_bwd_kernel, dim3(nb, B), dim3(256), 0, (hipStream_t)stream, depth, color, part, nblk, sm_part,

@@ -4,7 +4,9 @@ On the training path these are not called one by one: `Trainer.generate_images_p
 `compute_losses` run them fused in sqd.ops.PhotometricChain (depth upsample -> BackprojectDepth ->
 Project3D -> grid_sample -> SSIM + L1 -> min/auto-mask -> smoothness).  The stand-alone names below
 keep the reference's call signatures for scripts that use them directly; each is served by a kernel
-of libsqd.so.  Device tensors only — there is no CPU fallback."""
+of libsqd.so.  Device tensors only — there is no CPU fallback.  get_smooth_loss and the pose-matrix
+functions are autograd nodes; SSIM / BackprojectDepth / Project3D are forward-only and RAISE when an input requires a
+gradient (the reference's are differentiable: layers.py:13-46,186-258) — nothing detaches silently."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -20,18 +22,12 @@ def disp_to_depth(disp, min_depth, max_depth):
 
 
 def _pose(axisangle, translation, invert):
-    B = axisangle.shape[0]
-    aa = axisangle.reshape(B, 1, 3).contiguous().float()
-    tr = translation.reshape(B, 1, 3).contiguous().float()
-    K = torch.eye(4, device=aa.device).repeat(B, 1, 1)
-    _, T, _ = ops.pose_mats_fwd(aa.detach(), tr.detach(), [1 if invert else 0], K)
-    return T[:, 0]
+    return ops.pose_matrix(axisangle, translation, invert)
 
 
 def transformation_from_parameters(axisangle, translation, invert=False):
     """(axisangle [B,1,3], translation [B,1,3]) -> 4x4 (reference layers.py:75-92).  One kernel launch
-    instead of ~40 ATen ops; the result is detached (the training path differentiates the pose through
-    PhotometricChain, not through this matrix)."""
+    instead of ~40 ATen ops, differentiable w.r.t. both vectors (sqd_pose_mats_bwd)."""
     return _pose(axisangle, translation, invert)
 
 

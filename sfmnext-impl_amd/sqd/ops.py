@@ -230,8 +230,20 @@ def smooth_bwd(depth, color, part, sm_part, gout, planes=None, plane=0):
     return planes
 
 
-# ---- stand-alone forward entries behind the reference's layer classes (no autograd) ------------------
+# ---- stand-alone entries behind the reference's layer classes ----------------------------------------------------------
+# The reference's SSIM / BackprojectDepth / Project3D / get_smooth_loss / transformation_from_parameters are ordinary autograd modules
+# (layers.py:13-46,75-92,186-258,267-280).  Here the training path differentiates the fused chain (PhotometricChain); of the stand-alone
+# forms, get_smooth_loss (w.r.t. the disparity) and transformation_from_parameters (w.r.t. both pose vectors) are autograd nodes over the
+# adjoint kernels the chain uses, and the FORWARD-ONLY ones refuse an input that requires a gradient — none of them detaches silently.
+def _forward_only(who, *tensors):
+    if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
+        raise RuntimeError("%s is a forward-only stand-alone entry of libsqd: an input requires a gradient, and no gradient would flow "
+                           "through it.  Differentiate through the fused chain (Trainer.generate_images_pred / compute_losses, "
+                           "sqd.ops.PhotometricChain) or call it under torch.no_grad() / on detached tensors." % who)
+
+
 def backproject(depth, inv_K):
+    _forward_only("BackprojectDepth", depth, inv_K)
     depth, inv_K = depth.detach().contiguous().float(), inv_K.detach().contiguous().float()
     _req(depth, inv_K)
     B, _, H, W = depth.shape
@@ -241,6 +253,7 @@ def backproject(depth, inv_K):
 
 
 def project3d(points, K, T, H, W, eps=1e-7):
+    _forward_only("Project3D", points, K, T)
     points, K, T = (t.detach().contiguous().float() for t in (points, K, T))
     _req(points, K, T)
     B = points.shape[0]
@@ -251,6 +264,7 @@ def project3d(points, K, T, H, W, eps=1e-7):
 
 
 def ssim_map(x, y):
+    _forward_only("SSIM", x, y)
     x, y = x.detach().contiguous().float(), y.detach().contiguous().float()
     _req(x, y)
     B, C, H, W = x.shape
@@ -261,6 +275,7 @@ def ssim_map(x, y):
 
 def grid_sample_border(img, grid, want_taps=False):
     """F.grid_sample(img, grid, padding_mode="border", align_corners=True) (reference trainer.py:431-435), forward only."""
+    _forward_only("grid_sample_border", img, grid)
     img, grid = img.detach().contiguous().float(), grid.detach().contiguous().float()
     _req(img, grid)
     B, C, H, W = img.shape
@@ -272,15 +287,61 @@ def grid_sample_border(img, grid, want_taps=False):
     return (out, taps) if want_taps else out
 
 
+class _SmoothLossPlain(torch.autograd.Function):
+    """get_smooth_loss (reference layers.py:267-280) on an already normalised disparity: sqd_smooth_fwd / sqd_smooth_bwd with part == NULL."""
+
+    @staticmethod
+    def forward(ctx, disp, img):
+        disp, img = disp.detach().contiguous().float(), img.detach().contiguous().float()
+        _req(disp, img)
+        B, _, H, W = disp.shape
+        L = _l.lib()
+        nb = L.sqd_smooth_nblk(H, W)
+        sm = torch.empty(B, nb, 2, device=disp.device, dtype=torch.float32)
+        _l.check(L.sqd_smooth_fwd(_ptr(disp), _ptr(img), ctypes.c_void_p(0), 0, _ptr(sm), B, H, W, _stream()), "smooth_fwd")
+        ctx.save_for_backward(disp, img)
+        return sm[..., 0].sum() / float(B * H * (W - 1)) + sm[..., 1].sum() / float(B * (H - 1) * W)
+
+    @staticmethod
+    def backward(ctx, gout):
+        disp, img = ctx.saved_tensors
+        B, _, H, W = disp.shape
+        g = torch.empty(B, 1, H, W, device=disp.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_smooth_bwd(_ptr(disp), _ptr(img), ctypes.c_void_p(0), 0, ctypes.c_void_p(0), 1.0, _ptr(g), H * W, B, H, W,
+                                         _stream()), "smooth_bwd")
+        return g * gout, None            # (the adjoint is linear in the upstream gradient: no host synchronisation)
+
+
 def smooth_loss_plain(disp, img):
-    disp, img = disp.detach().contiguous().float(), img.detach().contiguous().float()
-    _req(disp, img)
-    B, _, H, W = disp.shape
-    L = _l.lib()
-    nb = L.sqd_smooth_nblk(H, W)
-    sm = torch.empty(B, nb, 2, device=disp.device, dtype=torch.float32)
-    _l.check(L.sqd_smooth_fwd(_ptr(disp), _ptr(img), ctypes.c_void_p(0), 0, _ptr(sm), B, H, W, _stream()), "smooth_fwd")
-    return sm[..., 0].sum() / float(B * H * (W - 1)) + sm[..., 1].sum() / float(B * (H - 1) * W)
+    if torch.is_grad_enabled() and img.requires_grad:
+        raise RuntimeError("get_smooth_loss: the image argument is data here — no gradient is computed w.r.t. it (detach it)")
+    return _SmoothLossPlain.apply(disp, img)
+
+
+class _PoseMatrix(torch.autograd.Function):
+    """transformation_from_parameters (reference layers.py:75-92): sqd_pose_mats_fwd / sqd_pose_mats_bwd with K = I, no translation scale."""
+
+    @staticmethod
+    def forward(ctx, axisangle, translation, invert):
+        B = axisangle.shape[0]
+        aa = axisangle.detach().reshape(B, 1, 3).contiguous().float()
+        tr = translation.detach().reshape(B, 1, 3).contiguous().float()
+        K = torch.eye(4, device=aa.device).repeat(B, 1, 1).contiguous()
+        _, T, _ = pose_mats_fwd(aa, tr, [1 if invert else 0], K)
+        ctx.save_for_backward(aa, tr, K)
+        ctx.invert, ctx.shapes = bool(invert), (axisangle.shape, translation.shape)
+        return T[:, 0]
+
+    @staticmethod
+    def backward(ctx, g_T):
+        aa, tr, K = ctx.saved_tensors
+        g_P = g_T[:, :3, :].reshape(-1, 1, 3, 4).contiguous().float()          # P = (K T)[:3] with K = I: the last row of T is constant
+        g_aa, g_tr, _ = pose_mats_bwd(aa, tr, [1 if ctx.invert else 0], K, None, g_P)
+        return g_aa.reshape(ctx.shapes[0]), g_tr.reshape(ctx.shapes[1]), None
+
+
+def pose_matrix(axisangle, translation, invert=False):
+    return _PoseMatrix.apply(axisangle, translation, invert)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -51,3 +51,50 @@ def test_depth_errors_g14(golden):
     pred = rs.uniform(1, 80, int((gt > 0).sum())).astype(np.float32)
     errs = layers.compute_depth_errors(tt(gt[gt > 0]).cuda(), tt(pred).cuda())
     np.testing.assert_allclose([float(e) for e in errs], g["plain_errors"], rtol=1e-4)
+
+
+def test_standalone_layers_gradients_or_refusal():
+    """The reference's stand-alone layers are autograd modules (layers.py:13-46,75-92,186-258,267-280).  Here get_smooth_loss and
+    transformation_from_parameters are differentiable (checked against the oracle's autograd); SSIM / BackprojectDepth / Project3D /
+    Trainer.compute_reprojection_loss are forward-only and must REFUSE an input that requires a gradient — never detach it silently."""
+    import layers
+    from oracle import torch_ref as O
+    torch.manual_seed(0)
+    B, H, W = 2, 24, 40
+    # get_smooth_loss w.r.t. the disparity
+    disp = (torch.rand(B, 1, H, W) + 0.5)
+    img = torch.rand(B, 3, H, W)
+    d_dev = disp.cuda().requires_grad_(True)
+    loss = layers.get_smooth_loss(d_dev, img.cuda())
+    (3.0 * loss).backward()
+    d_ref = disp.clone().requires_grad_(True)
+    (3.0 * O.smooth_loss(d_ref, img)).backward()
+    np.testing.assert_allclose(float(loss), float(O.smooth_loss(disp, img)), rtol=1e-5)
+    np.testing.assert_allclose(d_dev.grad.cpu().numpy(), d_ref.grad.numpy(), rtol=1e-4, atol=1e-8)
+    with pytest.raises(RuntimeError, match="no gradient is computed"):
+        layers.get_smooth_loss(d_dev, img.cuda().requires_grad_(True))
+    # transformation_from_parameters w.r.t. both pose vectors, both directions
+    for invert in (False, True):
+        aa, tr = 0.3 * torch.randn(B, 1, 3), torch.randn(B, 1, 3)
+        w = torch.randn(B, 4, 4)
+        a_dev, t_dev = aa.cuda().requires_grad_(True), tr.cuda().requires_grad_(True)
+        (layers.transformation_from_parameters(a_dev, t_dev, invert) * w.cuda()).sum().backward()
+        a_ref, t_ref = aa.clone().requires_grad_(True), tr.clone().requires_grad_(True)
+        (O.transformation_from_parameters(a_ref, t_ref, invert) * w).sum().backward()
+        np.testing.assert_allclose(a_dev.grad.cpu().numpy(), a_ref.grad.numpy(), rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(t_dev.grad.cpu().numpy(), t_ref.grad.numpy(), rtol=1e-4, atol=1e-5)
+    # the forward-only entries
+    x, y = torch.rand(B, 3, H, W).cuda(), torch.rand(B, 3, H, W).cuda()
+    xg = x.clone().requires_grad_(True)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        layers.SSIM()(xg, y)
+    with pytest.raises(RuntimeError, match="forward-only"):
+        layers.BackprojectDepth(B, H, W)(torch.rand(B, 1, H, W).cuda().requires_grad_(True), torch.eye(4).repeat(B, 1, 1).cuda())
+    pts = layers.BackprojectDepth(B, H, W)(torch.rand(B, 1, H, W).cuda() + 1, torch.eye(4).repeat(B, 1, 1).cuda())
+    with pytest.raises(RuntimeError, match="forward-only"):
+        layers.Project3D(B, H, W)(pts.requires_grad_(True), torch.eye(4).repeat(B, 1, 1).cuda(), torch.eye(4).repeat(B, 1, 1).cuda())
+    with torch.no_grad():                      # under no_grad (evaluation scripts) the same calls are fine
+        layers.SSIM()(xg, y)
+    from trainer import Trainer
+    with pytest.raises(RuntimeError, match="forward-only"):
+        Trainer.compute_reprojection_loss(None, xg, y)

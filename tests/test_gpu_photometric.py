@@ -119,6 +119,75 @@ def test_warp_taps_bit_exact(ops, O, B, H, W, rows):
         close(out["warped"][s], warped, rtol=1e-6, atol=1e-7)
 
 
+def _full_size_P(B, S, seed):
+    """plausible KITTI-scale motions for the full-size tap tests: small rotations, translations up to ~0.5 m"""
+    g = torch.Generator().manual_seed(seed)
+    aa = 0.02 * torch.randn(B, S, 3, generator=g)
+    tr = 0.3 * torch.randn(B, S, 3, generator=g)
+    return aa, tr
+
+
+@pytest.mark.parametrize("B,H,W,S", [(12, 192, 640, 2), (8, 320, 1024, 2), (4, 192, 640, 3)])
+def test_warp_taps_bit_exact_full_size(ops, O, B, H, W, S):
+    """BASELINE.json image sizes with the launch's DEFAULT tile cut (configs[1]: the balanced 1024-tile cut, 11 column strips x 24..28 rows
+    on 8-wave workgroups; configs[2]: 18 strips, uniform 28-row tiles; S = 3: the stereo pair passes (0,1) + (2,2)): sampling grid and
+    integer taps equal the C chain's bit for bit, for the kernel that dumps taps AND for the production call (the lean kernel of the
+    default loss options, which stores no taps: its grid is compared bit for bit, and its warped colours equal the tap-dumping call's
+    bit for bit — the same taps were read)."""
+    from oracle import c_chain
+    d = chain_inputs(23, B, H, W, S=S)
+    depth_np = c_chain.depth_up(d["disp"], H, W)
+    aa, tr = _full_size_P(B, S, 5)
+    mid = (1.0 / tt(depth_np)).mean(3, True).mean(2, True)
+    Ps = []
+    for s in range(S):
+        T = O.transformation_from_parameters(aa[:, s:s + 1], tr[:, s:s + 1] * mid[:, 0], s == 0)
+        Ps.append(torch.matmul(tt(d["K"]), T)[:, :3, :])
+    P = torch.stack(Ps, 1).contiguous()
+    srcs = [dev(d["color_s%d" % s]) for s in range(S)]
+    ident = ops.identity_fwd(dev(d["color0"]), srcs, dev(d["noise"]), 0)
+    full = ops.photo_fwd(dev(depth_np), dev(d["inv_K"]), dev(P), dev(d["color0"]), srcs, ident, want_taps=True)
+    prod = ops.photo_fwd(dev(depth_np), dev(d["inv_K"]), dev(P), dev(d["color0"]), srcs, ident)
+    for s in range(S):
+        grid, x0, y0, warped = c_chain.warp(depth_np, d["inv_K"], P[:, s].numpy(), d["color_s%d" % s])
+        got = full["x0y0"][s].cpu().numpy()
+        assert np.array_equal(got[..., 0], x0) and np.array_equal(got[..., 1], y0)
+        assert np.array_equal(full["sample"][s].cpu().numpy(), grid)
+        assert np.array_equal(prod["sample"][s].cpu().numpy(), grid)
+        assert torch.equal(prod["warped"][s], full["warped"][s])
+        close(full["warped"][s], warped, rtol=1e-6, atol=1e-7)
+    assert torch.equal(prod["idx"], full["idx"]) and torch.equal(prod["sel"], full["sel"])
+
+
+@pytest.mark.parametrize("B,H,W", [(12, 192, 640), (3, 96, 320), (2, 320, 1024)])
+def test_forward_kernel_variants_agree(ops, B, H, W):
+    """every kernel sqd_photo_set_fwd_variant can select (0 lean = the default, 1 round 5's, 2 colour-serial, 4 wide, 5 dynamic wave
+    roles, 0x80: resident workgroups) writes the same sampling grid, warped colours, identity_selection and argmin, bit for bit; the
+    loss partials sum to the same loss (their partition differs: per wave / per row pair)."""
+    from sqd import lib as _l
+    d = chain_inputs(29, B, H, W)
+    depth, part = ops.depth_up_fwd(dev(d["disp"]), H, W)
+    aa, tr = _full_size_P(B, 2, 7)
+    mid, T, P = ops.pose_mats_fwd(aa.cuda(), tr.cuda(), [1, 0], dev(d["K"]), part, H * W)
+    srcs = [dev(d["color_s0"]), dev(d["color_s1"])]
+    ident = ops.identity_fwd(dev(d["color0"]), srcs, dev(d["noise"]), 0)
+    L = _l.lib()
+    outs = {}
+    try:
+        for v in (1, 0, 2, 4, 5, 0x80):
+            _l.check(L.sqd_photo_set_fwd_variant(v), "variant")
+            outs[v] = ops.photo_fwd(depth, dev(d["inv_K"]), P, dev(d["color0"]), srcs, ident)
+    finally:
+        _l.check(L.sqd_photo_set_fwd_variant(0), "variant")
+    ref = outs[1]
+    for v, o in outs.items():
+        assert torch.equal(o["sel"], ref["sel"]) and torch.equal(o["idx"], ref["idx"]), v
+        for k in ("sample", "warped"):
+            assert all(torch.equal(x, y) for x, y in zip(o[k], ref[k])), (v, k)
+        a, b = o["loss_part"].double().sum().item(), ref["loss_part"].double().sum().item()
+        assert abs(a - b) <= 1e-6 * abs(b), (v, a, b)
+
+
 def test_pose_mats(ops, O):
     B, H, W = 3, 24, 80
     d = chain_inputs(31, B, H, W)

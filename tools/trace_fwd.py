@@ -79,6 +79,6 @@ cnt = np.array([len(v) for v in per.values()])
 print("CUs seen %d; tiles per CU: min %d max %d; histogram %s" % (len(per), cnt.min(), cnt.max(), dict(zip(*np.unique(cnt, return_counts=True)))))
 ends = np.array([max(e for _, e, _ in v) for v in per.values()])
 print("per-CU finish time: min %d median %d max %d" % (ends.min(), np.median(ends), ends.max()))
-for key in list(per.keys())[:10]:
+for key in list(per.keys())[:3]:
     base = min(s for s, _, _ in per[key])
     print("  CU %d: " % key + "  ".join("tile %d [%d..%d]" % (ti, s - base, e - base) for s, e, ti in sorted(per[key])))
