@@ -50,7 +50,7 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r05_pmc_traffic.json")
+PMC_TRAFFIC_JSON = os.path.join(REPO, "profiles", "r06_pmc_traffic.json")
 
 
 def roofline_fused_fwd(trainer, batches, iters=200, graph_us=None):
@@ -138,8 +138,8 @@ def roofline_fused_fwd(trainer, batches, iters=200, graph_us=None):
             "us_per_launch": round(t * 1e6, 2),
             "us_per_launch_eager_steps": eager_us,
             "clock": ("torch.profiler device activity (roctracer) — the ONE clock of frac / achieved / us_per_launch in this line; the record kept under "
-                      "profiles/ is rocprofv3 --kernel-trace of the same command (profiles/r05*_bench_kernel_trace_stats.md), which reads the same launch "
-                      "5-6 % shorter (51.7 against 53.0-54.5 us in round 5): compare a line with a line and a trace with a trace" if graph_us else
+                      "profiles/ is rocprofv3 --kernel-trace of the same command (profiles/r06*_bench_kernel_trace_stats.md), which reads the same launch "
+                      "3-6 % shorter (44.1 against 45.6 us in round 6): compare a line with a line and a trace with a trace" if graph_us else
                       "HIP events on the launch stream (eager steps)"),
             "timing": ("average duration of the launch inside replayed hipGraph training steps (device activity records of 4 steps, child process); "
                        "us_per_launch_eager_steps = median of 10 launches bracketed by HIP events on the launch stream inside EAGER steps" if graph_us else
@@ -320,7 +320,9 @@ def cpu_baseline(budget_s=45.0):
     chainB, chainC = chain(12, 192, 640), chain(8, 320, 1024)
     return {"value": round(B / dtB, 3), "unit": "images/s", "cores": cores, "kind": "port",
             "sample": "%d full train steps (fwd+bwd+Adam) of the config-B model (ResNet-50 + Depth_Decoder_QueryTr, 192x640) at batch %d "
-                      "after 1 warm-up, oracle/torch_ref.py, %.2f s/step" % (nB, B, dtB),
+                      "after 1 warm-up, oracle/torch_ref.py, %.2f s/step, on %d threads (%s)" % (
+                          nB, B, dtB, cores, "capped from %d physical cores: PyTorch's CPU convolutions lose throughput beyond 64 threads on this host"
+                          % physical if cores < physical else "all physical cores"),
             "host": {"cpu_model": model, "os_cpu_count": logical, "physical_cores": physical, "threads_used": cores,
                      "torch": torch.__version__},
             "config_A_end_to_end": {"images_per_s": round(2 / dtA, 3), "s_per_step": round(dtA, 3), "timed_steps": nA, "warmup": 3,
@@ -604,8 +606,9 @@ def main():
                                                  "operand as the exact sum of three bf16 terms, 6 of 9 partial products on the bf16 matrix cores, "
                                                  "fp32 accumulation (error <= 4x the fp32-MFMA kernel's against fp64: tests/test_gpu_conv.py)"
                                                  "; 'f16x2' = every fp32 operand as two fp16 terms of the tensor scaled by a power of two, 3 of 4 partial "
-                                                 "products on the fp16 matrix cores, fp32 accumulation (error <= the fp32-MFMA kernel's against fp64: "
-                                                 "tests/test_gpu_f16x2.py)",
+                                                 "products on the fp16 matrix cores, fp32 accumulation (tested per plan against fp64, tests/test_gpu_f16x2.py: error <= "
+                                                 "max(1.25 x the bf16x3 kernel's, the fp32-MFMA kernel's) + 5e-8 and <= 4 x the fp32-MFMA kernel's + 2e-7, "
+                                                 "relative to the largest output)",
                                          "plans": plan_note if not opts.sqd_no_conv_tune else "cost model (fp32 MFMA)", **mix,
                                          "operand_scales": scales},
                           "exchange": exchange,

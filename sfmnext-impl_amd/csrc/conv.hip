@@ -103,7 +103,7 @@ __device__ __forceinline__ f32x16 mfma_bf(u32x4 a, u32x4 b, f32x16 c) {
 // 3-4 conversion instructions per element instead of six and 5.5, two LDS planes instead of three.  Against float64 the result is
 // as close as the fp32 MFMA chain's (tests/test_gpu_conv.py::test_f16x2_*; oracle/f16x2_model.py).  The scale comes from the
 // tensor's max |.|, which the producing kernel leaves in device memory (sqd_amax_* / the `amax` outputs of the producers): a
-// record of 16 words in 16 cache lines (sqd_common.h) holding bit patterns of non-negative floats.  s = 2^(141 - biased exponent), clamped to a normal float.
+// record of 64 words in 64 cache lines (SQD_AMAX_WAYS, sqd_common.h) holding bit patterns of non-negative floats.  s = 2^(141 - biased exponent), clamped to a normal float.
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2v __attribute__((ext_vector_type(2)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(WGM * WGN * 64) void conv_gemm_kernel(const float *
 // reduction over k, tap (r,s) reads (ty+2-r, tx+2-s)).
 // ---------------------------------------------------------------------------------------------------
 template <int MODE, int WTM, int WM, int WN, int WK, int R = 3, bool H2 = false>
-__global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 2 : 3)) void conv3x3_halo_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
+__global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1 || R == 4) ? 2 : 3)) void conv3x3_halo_kernel(const float *__restrict__ a_src, const float *__restrict__ wgt,
                                                                     const float *__restrict__ bias, float *__restrict__ out, ConvGeom g,
                                                                     int act, int zsplits, float *__restrict__ stats, BnBwdSrc bnb, OpScale sc) {
     constexpr int NTM = H2 ? 2 : 3;                       // operand terms: three bf16 (truncating split) or two fp16 of the scaled operand (H2)
@@ -655,10 +655,17 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
     static_assert((R == 3 || R == 4) && (R == 3 || MODE == 0) && RS % RING == 0, "3x3, or 4x4 forward (the space-to-depth stems)");
     constexpr int NT = WM * WN * WK * 64, BN = WN * 32;
     constexpr int WS = WTM / WM;                          // 32-pixel sub-tiles per wave
-    constexpr int CK = 32, LDH = CK + 8;                  // channels per chunk, LDS row pitch in bf16 (80 bytes: conflict-free b128 accesses)
-    constexpr int HPP = (HP + 15) / 16 * 16;
+    constexpr int CK = 32, LDH = CK + 8;                  // channels per chunk, pitch of a patch cell in bf16 (80 bytes)
+    // Pitch of a patch ROW: a multiple of 256 bytes.  ds_read_b128 serves a wave in four groups of 16 lanes — {0-3, 12-15, 20-27},
+    // {4-11, 16-19, 28-31} and the same two for the upper half-wave —, i.e. eight cells of fragment row m >> 4 = 0 and eight of row 1,
+    // and a group is conflict-free when its 16 lanes hit 16 different 16-byte slots of the 256-byte bank row.  Cell pitch 80 bytes puts
+    // column x at slot 5 x mod 16; with the rows a multiple of 256 bytes apart the two rows' column sets {0-3, 12-15} and {4-11} fill the
+    // 16 slots exactly.  Round 5's dense rows (PW * 80 = 1440 bytes: slot 10 row + 5 x) put two lanes of every group on an occupied
+    // slot — the 34-44 % bank-conflict cycles of profiles/r05p_conv_sq_counters.md, every instantiation of this kernel.
+    constexpr int RPH = (PW * LDH * 2 + 255) / 256 * 128; // row pitch in bf16
+    constexpr int HPP = (PH * RPH + LDH - 1) / LDH;       // cells' worth of LDS per plane (plane = PH rows)
     constexpr int KSW = 2 / WK;                           // 16-channel MFMA steps of a chunk per wave
-    constexpr int A_ITEMS = HPP * 4, A_PASS = (A_ITEMS + NT - 1) / NT;        // item = 8 channels of one patch cell
+    constexpr int A_ITEMS = (HP + 15) / 16 * 16 * 4, A_PASS = (A_ITEMS + NT - 1) / NT;        // item = 8 channels of one patch cell
     static_assert((WK == 1 || WK == 2) && WTM % WM == 0, "WK, WM");
     constexpr int XCH_BYTES = (WK == 2 ? WN * WTM * 16 * 64 * 4 : 0) + WM * WN * 64 * 4;      // the accumulator / statistics exchange reuses the patch planes
     constexpr int NPL = XCH_BYTES <= NTM * HPP * LDH * 2 ? NTM : 3;
@@ -684,7 +691,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
     // ---- A staging: thread -> (patch cell, group of 8 channels); cells of a 16-group are dealt 0,4,8,12,1,5,... so that the four
     // cells a 16-byte LDS store instruction serves per clock start 16 banks apart
     unsigned a_off[A_PASS];            // byte offset of the cell's channel 0 (0xffffffff: outside the image / no such cell)
-    int a_cell[A_PASS];
+    int a_cell[A_PASS];                // the cell's place in a patch plane (bf16 units), -1: none
 #pragma unroll
     for (int i = 0; i < A_PASS; ++i) {
         const int idx = t + NT * i, praw = idx >> 2;
@@ -692,7 +699,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
         const int hy = p / PW, hx = p - hy * PW;
         const int iy = y0 - g.pad + hy, ix = x0 - g.pad + hx;
         const bool ok = idx < A_ITEMS && p < HP && (unsigned)iy < (unsigned)g.H && (unsigned)ix < (unsigned)g.W;
-        a_cell[i] = (idx < A_ITEMS && p < HP) ? p : -1;
+        a_cell[i] = (idx < A_ITEMS && p < HP) ? hy * RPH + hx * LDH : -1;
         a_off[i] = ok ? (unsigned)(((img * g.H + iy) * g.W + ix) * Cred) * 4u : 0xffffffffu;
     }
     const int c8 = (t & 3) * 8;        // NT is a multiple of 4: the channel group does not depend on the pass
@@ -715,7 +722,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
             for (int tmn = 0; tmn < NTM; ++tmn) {
                 u32x4 v;
                 v.x = s0.t[tmn].x; v.y = s0.t[tmn].y; v.z = s1.t[tmn].x; v.w = s1.t[tmn].y;
-                *reinterpret_cast<u32x4 *>(&Ah[tmn][a_cell[i]][c8]) = v;
+                *reinterpret_cast<u32x4 *>(&Ah[tmn][0][0] + a_cell[i] + c8) = v;
             }
         }
     };
@@ -759,7 +766,7 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
     // A fragment of row m = lane & 31 of sub-tile i: patch cell (2i + (m >> 4) + dy, (m & 15) + dx), channels ks*16 + kg*8 ..
-    const int frag_base = ((2 * WS * wmi + ((lane & 31) >> 4)) * PW + (lane & 15)) * LDH + kg * 8;       // in bf16 units
+    const int frag_base = (2 * WS * wmi + ((lane & 31) >> 4)) * RPH + (lane & 15) * LDH + kg * 8;       // in bf16 units
 
     if (c_beg < c_end) {
         load_a(c_beg);
@@ -787,14 +794,14 @@ __global__ __launch_bounds__(WM * WN * WK * 64, ((WTM / WM >= 4 || MODE == 1) ? 
             if (rs + 2 < RS) load_b(rb[(rs + 2) % RING], cc, rs + 2);
             else if (cc + 1 < c_end) load_b(rb[(rs + 2) % RING], cc + 1, rs + 2 - RS);
             const int dy = MODE == 0 ? r : R - 1 - r, dx = MODE == 0 ? s : R - 1 - s;
-            const unsigned short *tap = &Ah[0][0][0] + frag_base + (dy * PW + dx) * LDH;
+            const unsigned short *tap = &Ah[0][0][0] + frag_base + dy * RPH + dx * LDH;
 #pragma unroll
             for (int q = 0; q < KSW; ++q) {
                 const int ks = WK == 2 ? wk : q;
                 if (cc * CK + ks * 16 >= Cred) continue;      // (uniform) a step beyond the last channel: the 16-channel stems
 #pragma unroll
                 for (int i = 0; i < WS; ++i) {
-                    const unsigned short *ap = tap + (2 * i * PW) * LDH + ks * 16;
+                    const unsigned short *ap = tap + 2 * i * RPH + ks * 16;
                     u32x4 at[NTM];
 #pragma unroll
                     for (int tmn = 0; tmn < NTM; ++tmn) at[tmn] = *reinterpret_cast<const u32x4 *>(ap + tmn * HPP * LDH);

@@ -3,20 +3,28 @@
 // replaces (reference): BackprojectDepth -> Project3D -> grid_sample (layers.py:186-258, trainer.py:420-435), SSIM + L1
 // (layers.py:13-46, trainer.py:441-453) and the per-pixel minimum / auto-mask (trainer.py:474-532) in ONE launch.
 //
-// Execution shape.  A workgroup (4 wavefronts) owns a tile of up to 58..61 columns x TR (<= 16) rows of the target image.
-//   phase 1 (per cell, once): every cell of the tile + its 3-pixel halo — 64 columns (one per lane) x (TR + 6) rows, rows
-//     dealt round-robin to the four waves — is back-projected, projected into both source views and bilinearly sampled
-//     (canonical fp32 order of oracle/warp_chain.c: bit-exact integer taps); the six warped colours go to LDS (8-byte
-//     (source 0, source 1) pairs, lane-contiguous: conflict-free) and, for the cells the tile owns, to HBM together with
-//     the sampling grid.  Nothing of the expensive projection / gather chain is evaluated twice inside a tile (the column
-//     march this replaces re-evaluated it for the 6 halo rows of every 8-row strip: 1.75x).
-//   phase 2 (per output pixel): each wave takes pairs of output rows; the 7x7 window statistics are vertical register sums
-//     over LDS rows (two outputs share six of their seven rows) followed by the horizontal 7-tap sum on wavefront
-//     shuffles (six v_add_f32_dpp wave_shr/wave_shl per quantity: no LDS traffic, no barrier), then the SSIM algebra with
-//     the reference's true division, L1, the minimum against the identity maps, identity_selection, the argmin byte and
-//     the loss partial.  ReflectionPad2d(3): rows are reflected when they are fetched from LDS; at the left / right image
-//     border the wavefront holds the border columns itself and adds the mirrored terms from the shuffle chain's own
-//     intermediates, so border strips own 61 columns instead of 58 (640 columns = 11 strips, not 12).
+// Execution shape.  A workgroup of 8 wavefronts (4 on images of fewer than 56 rows) owns a tile of 58..61 columns x 24..28 rows of
+// the target image (make_tiling: a balanced cut — 1024 tiles = 4 per CU at configs[1]).
+//   phase 1 (per cell, once): every cell of the tile + its 3-pixel halo — 64 columns (one per lane) x (rows + 6), rows dealt
+//     round-robin to the waves — is back-projected, projected into both source views and bilinearly sampled (canonical fp32 order of
+//     oracle/warp_chain.c: bit-exact integer taps); the six warped colours go to LDS (8-byte (source 0, source 1) pairs,
+//     lane-contiguous: conflict-free); grid and colours of the cells the tile owns go to HBM.
+//   phase 2 (per output pixel): each wave takes pairs of output rows; the 7x7 window statistics are vertical register sums over LDS
+//     rows (two outputs share six of their seven rows) followed by the horizontal 7-tap sum on wavefront shuffles (six
+//     v_add_f32_dpp per quantity: no LDS traffic, no barrier), then the SSIM algebra, L1, the minimum against the identity maps,
+//     identity_selection, the argmin byte and the loss partial.  ReflectionPad2d(3): rows are reflected when they are fetched
+//     from LDS; at the left / right image border the wavefront holds the border columns itself and adds the mirrored terms from
+//     the shuffle chain's own intermediates, so border strips own 61 columns instead of 58 (640 columns = 11 strips, not 12).
+// Kernels of the forward (sqd_photo_set_fwd_variant; all of them write the same bits):
+//   photo_tile_kernel<1, 8, true, true>  the LEAN edition — what a training step of the default loss options runs (round 6): target
+//                                        rows staged into LDS by 16-byte loads whose round trip runs under the warps, warped colours
+//                                        stored from LDS 16 bytes per lane between the row pairs, option-free selection, reflection-
+//                                        free row addressing for tiles inside the image, hand-scheduled shuffle blocks (box7x7);
+//   photo_tile_kernel<1, 8> / <1, 4>     round 5's kernel: every option set, tap dumps, images narrower than 64 columns;
+//   photo_fwd_c_kernel, photo_tile_kernel<1, 8, true, false>, photo_fwd_s_kernel, photo_tile_resident_kernel
+//                                        round 6's measured experiments (colour-serial phase 2 at 6 waves per SIMD, wide accesses
+//                                        alone, dynamic wave roles with a row in flight under every SSIM step, resident workgroups):
+//                                        parity-green and no faster — DESIGN.md 3.1 has the per-wave traces that say why.
 // No coefficient planes are written for the backward any more: photo_coef (MODE 2 below) recomputes them from the warped
 // images when — and only when — a backward pass runs.
 //

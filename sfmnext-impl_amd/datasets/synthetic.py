@@ -90,15 +90,15 @@ def make_sample(index, height, width, frame_ids=(0, -1, 1), with_gt=True, scene=
 
 
 class SyntheticKITTIDataset(Dataset):
-    def __init__(self, height, width, frame_ids=(0, -1, 1), length=240, with_gt=True, offset=0):
+    def __init__(self, height, width, frame_ids=(0, -1, 1), length=240, with_gt=True, offset=0, scene="waves"):
         self.height, self.width, self.frame_ids = height, width, list(frame_ids)
-        self.length, self.with_gt, self.offset = length, with_gt, offset
+        self.length, self.with_gt, self.offset, self.scene = length, with_gt, offset, scene
 
     def __len__(self):
         return self.length
 
     def __getitem__(self, index):
-        return make_sample(index + self.offset, self.height, self.width, self.frame_ids, self.with_gt)
+        return make_sample(index + self.offset, self.height, self.width, self.frame_ids, self.with_gt, self.scene)
 
 
 def synthetic_batch(batch_size, height, width, frame_ids=(0, -1, 1), start=0, device=None, with_gt=False, scene="waves"):

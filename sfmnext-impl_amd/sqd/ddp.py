@@ -335,6 +335,17 @@ class GradBucketReducer:
         if self.buckets is None:
             # first step: no buckets yet — reduce whatever gradients exist, then build the buckets
             if self.active:
+                # the buckets are built from the parameters that received a gradient in THIS backward pass: every rank must have seen the
+                # same set, or the ranks would bucket — and from then on exchange — different tensors.  One small max / min exchange.
+                dev = self.params[0].device
+                mask = torch.tensor([1.0 if p.grad is not None else 0.0 for p in self.params], device=dev, dtype=torch.float32)
+                lo, hi = mask.clone(), mask.clone()
+                self.comm.all_reduce(lo, "min")
+                self.comm.all_reduce(hi, "max")
+                if not torch.equal(lo.cpu(), hi.cpu()):
+                    differ = [i for i, (a, b) in enumerate(zip(lo.cpu().tolist(), hi.cpu().tolist())) if a != b]
+                    raise RuntimeError("sqd.ddp: the ranks disagree on which parameters received a gradient in the first backward pass "
+                                       "(parameter indices %s...): their gradient buckets would not line up" % differ[:8])
                 grads = [p.grad for p in self.params if p.grad is not None]
                 flat = torch.cat([g.reshape(-1) for g in grads])
                 self.comm.all_reduce(flat, "avg")

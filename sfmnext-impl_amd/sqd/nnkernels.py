@@ -36,7 +36,7 @@ def bn_supported(C):
 # ---------------------------------------------------------------------------------------------------
 # Operand scales of the two-term fp16 convolution plans (csrc/conv.hip "f16x2", include/sqd.h section 10b).  Such a plan needs max |.| of
 # both operand tensors as device scalars.  Producers record it on the way (the `amax` outputs of the BatchNorm / convolution-epilogue /
-# up-sampling / frame-staging kernels): a tensor carries `_sqd_amax = (slot, epoch)`, slot = one 1 KB record of a pool that begin_step() clears
+# up-sampling / frame-staging kernels): a tensor carries `_sqd_amax = (slot, epoch, tensor version)`, slot = one 4 KB record (64 words in 64 cache lines) of a pool that begin_step() clears
 # at the start of every step (inside the captured graph).  A tensor without a valid tag (a gradient summed by autograd, the output of an
 # operator that does not record it) gets a standalone pass (sqd_amax) — counted per call site in AMAX_STATS, so that a missing producer
 # shows up as a number instead of as a slow step.  Filters: one persistent table, refreshed by ONE multi-tensor launch per step
@@ -61,10 +61,12 @@ def _amax_new(device):
         _AM["n"] = 0
         _AM["epoch"] += 1
     if _AM["n"] >= _AM["size"]:
-        # a loop that never calls begin_step (evaluation): start over — stream-ordered behind every consumer of the old values
-        _AM["buf"].zero_()
+        # the pool is used up inside one step (a deeper model than any shipped one — they use 500-750 records — or a loop that never calls
+        # begin_step): a FRESH pool, never a clear of the old one — records handed out earlier in this step may still be read by a pending
+        # data gradient or a deferred side-stream weight gradient.  The old pool stays alive until the next begin_step.
+        _AM.setdefault("retired", []).append(_AM["buf"])
+        _AM["buf"] = torch.zeros(_AM["size"] * AMAX_REC, device=device, dtype=torch.float32)
         _AM["n"] = 0
-        _AM["epoch"] += 1
     i = _AM["n"]
     _AM["n"] = i + 1
     return _AM["buf"][i * AMAX_REC:(i + 1) * AMAX_REC]
@@ -76,14 +78,26 @@ def amax_value(rec):
 
 
 def _amax_tag(t, slot):
+    # the tag names the tensor's CONTENT: it carries the tensor's version counter, because autograd's InputBuffer accumulates a second
+    # gradient IN PLACE into a tensor whose last reference it holds — the Python attribute survives that sum, the maximum does not
     if t is not None and slot is not None:
-        t._sqd_amax = (slot, _AM["epoch"])
+        t._sqd_amax = (slot, _AM["epoch"], t._version)
     return t
 
 
 def _amax_get(t):
     tag = getattr(t, "_sqd_amax", None)
-    return tag[0] if tag is not None and tag[1] == _AM["epoch"] else None
+    return tag[0] if tag is not None and tag[1] == _AM["epoch"] and tag[2] == t._version else None
+
+
+def _colsum_tag(t, cs):
+    """column sums of a gradient its producer leaves for the next Conv2d.backward's bias gradient — valid for this content only"""
+    t._sqd_colsum = (cs, t._version)
+
+
+def _colsum_get(t):
+    tag = getattr(t, "_sqd_colsum", None)
+    return tag[0] if tag is not None and tag[1] == t._version else None
 
 
 def _amax_out(device):
@@ -119,7 +133,10 @@ def _wam_slot(w):
     if ent is None:
         live = {k: e for k, e in _WAM["index"].items() if e[1]() is not None and k != key}
         used = {e[0] for e in live.values()}
-        idx = next(i for i in range(1024) if i not in used)
+        idx = next((i for i in range(1024) if i not in used), None)
+        if idx is None:
+            raise RuntimeError("sqd.nnkernels: more than 1024 live convolution filters in the operand-scale table (register parameters, not "
+                               "per-call derived tensors: a derived filter should carry _sqd_w_src)")
         ent = (idx, weakref.ref(w), w.numel(), [-1])
         live[key] = ent
         _WAM["index"] = live
@@ -817,7 +834,7 @@ class Gelu(torch.autograd.Function):
             _l.check(L.sqd_gelu_bwd_rows(_ptr(x), _ptr(dy), _ptr(dx), _ptr(part), M, C, _ptr(ad), _stream()), "gelu_bwd_rows")
             cs = torch.empty(C, device=x.device, dtype=torch.float32)
             _colsum_multi([(part, cs, 0)])
-            dx._sqd_colsum = cs                          # column sums of dx [C]: Conv2d.backward takes them as its bias gradient
+            _colsum_tag(dx, cs)                          # column sums of dx [C]: Conv2d.backward takes them as its bias gradient
         else:
             _l.check(L.sqd_gelu_bwd_amax(_ptr(x), _ptr(dy), _ptr(dx), x.numel(), _ptr(ad), _stream()), "gelu_bwd")
         return _amax_tag(dx, ad)
@@ -854,7 +871,7 @@ class ScaleResidual(torch.autograd.Function):
         if part2 is not None:
             cs = torch.empty(C, device=z.device, dtype=torch.float32)
             _colsum_multi([(part, dgamma, 0), (part2, cs, 0)])
-            dz._sqd_colsum = cs                          # column sums of dz [C]
+            _colsum_tag(dz, cs)                          # column sums of dz [C]
         else:
             _colsum_multi([(part, dgamma, 0)])
         return dy, _amax_tag(dz, ad), dgamma
@@ -1073,6 +1090,9 @@ def begin_step():
         _AM["buf"].zero_()                       # (a memset node of the captured step)
         _AM["n"] = 0
         _AM["epoch"] += 1
+        # pools an over-long step retired (_amax_new) are dropped one step late: side-stream weight gradients of the step that retired
+        # them may still be reading
+        _AM["retired_prev"], _AM["retired"] = _AM.get("retired", []), []
     if AMAX_ON and _WAM["buf"] is not None:
         _wam_refresh()
 
@@ -1193,7 +1213,7 @@ class Conv2d(torch.autograd.Function):
             _amax_tag(dy, _amax_get(dy_in))
         # column sums of dy from the pass that wrote it (the bias gradient without a pass of its own): only when this node has no activation
         # of its own (its gradient would come between dy and the sums)
-        pre_db = getattr(dy_in, "_sqd_colsum", None) if ctx.act is None else None
+        pre_db = _colsum_get(dy_in) if ctx.act is None else None
         g_skip = _cl(g_skip) if g_skip is not None else None
         if ctx.act is not None:                          # the epilogue's ReLU / LeakyReLU: dy * act'(y), one launch
             g = torch.empty_like(dy)

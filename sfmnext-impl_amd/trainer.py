@@ -13,10 +13,11 @@ What differs by design (MI355X-first):
     batch, are computed on a side HIP stream while the networks run;
   * the data source is synthetic KITTI-shaped frames unless real KITTI is present (no dataset I/O in
     this build).
-Only the default loss configuration of the reference is implemented (auto-masking on, per-pixel
-minimum, SSIM on, scale 0, posecnn pairs; mono, mono+stereo and stereo-only frame sets) — the
-configurations the args files of the KITTI path use; other switches raise NotImplementedError instead
-of silently diverging."""
+Implemented: scale 0, PoseCNN on frame pairs or on all frames (--pose_model_input all), any temporal
+frame_ids (0 -1 1, 0 -8 8, ...), mono / mono+stereo / stereo-only frame sets, and the reference's loss
+options --no_ssim, --avg_reprojection, --disable_automasking (five option sets pinned by fixture G23);
+--v1_multiscale / --predictive_mask and other scales raise NotImplementedError instead of silently
+diverging (_check_supported)."""
 import json
 import os
 import time
@@ -142,7 +143,10 @@ class Trainer:
         # any temporal neighbours (reference trainer.py:315-337 loops over frame_ids[1:]; args_files/hisfog/mc and nyu train on 0 -8 8 and
         # 0 -16 16), optionally with the stereo frame; the photometric kernels take up to SQD_MAX_SOURCES source frames
         temporal = [f for f in o.frame_ids if f != "s"]
-        if any(not isinstance(f, int) for f in temporal) or temporal[0] != 0 or len(set(temporal)) != len(temporal) or \
+        if "s" in o.frame_ids and o.frame_ids[-1] != "s":
+            raise NotImplementedError("the stereo frame \"s\" must be the last entry of frame_ids (the pose bookkeeping indexes the temporal "
+                                      "frames by position, as reference trainer.py:52-53 appends it); got %s" % o.frame_ids)
+        if not temporal or any(not isinstance(f, int) for f in temporal) or temporal[0] != 0 or len(set(temporal)) != len(temporal) or \
                 (temporal == [0] and not o.use_stereo):
             raise NotImplementedError("frame_ids must be 0 followed by distinct temporal offsets (optionally with --use_stereo), or [0] with "
                                       "--use_stereo; got %s" % o.frame_ids)

@@ -259,3 +259,34 @@ def test_first_step_plan_timing_offers_the_two_term_plans():
     finally:
         nnkernels.TUNE_CONV = old_tune
         nnkernels.reset_plans()
+
+
+def test_tagged_gradient_summed_in_place_is_not_trusted():
+    """a Conv2d output with TWO consumers, one of which returns a gradient tagged with its max |.| (the data gradient of the
+    next convolution).  Autograd's input buffer adds the second consumer's gradient IN PLACE into that tensor: the Python tag survives, the
+    maximum it names does not — a 64x louder second gradient would overflow the two-term fp16 high part to inf if the stale tag were used.
+    The tag carries the tensor's version counter; the summed gradient gets a stand-alone pass.  Gradients against float64."""
+    from sqd import nnkernels
+    torch.manual_seed(0)
+    N, C, H, W = 2, 64, 24, 40
+    cl = torch.channels_last
+    c1 = nn.Conv2d(C, C, 3, 1, 1, bias=False).cuda().to(memory_format=cl)
+    c2 = nn.Conv2d(C, C, 3, 1, 1, bias=False).cuda().to(memory_format=cl)
+    x = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=cl).requires_grad_(True)
+    dy2 = torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=cl)
+    w_side = 64.0 * torch.randn(N, C, H, W, device="cuda").contiguous(memory_format=cl)          # the second consumer: y * w_side
+    nnkernels.begin_step()
+    y = nnkernels.conv2d_native(x, c1, None)
+    z = nnkernels.conv2d_native(y, c2, None)                      # consumer 1: its backward hands back a TAGGED d y
+    loss = (z * dy2).sum() + (y * w_side).sum()                   # consumer 2: an untagged, much louder gradient w.r.t. y
+    loss.backward()
+    xr = x.detach().double().cpu().requires_grad_(True)
+    w1, w2 = c1.weight.detach().double().cpu().requires_grad_(True), c2.weight.detach().double().cpu().requires_grad_(True)
+    yr = F.conv2d(xr, w1, None, 1, 1)
+    lr = (F.conv2d(yr, w2, None, 1, 1) * dy2.double().cpu()).sum() + (yr * w_side.double().cpu()).sum()
+    lr.backward()
+    for name, got, want in (("dx", x.grad, xr.grad), ("dw1", c1.weight.grad, w1.grad), ("dw2", c2.weight.grad, w2.grad)):
+        assert torch.isfinite(got).all(), name
+        e = _err(got, want)
+        print("two consumers, %s: error against float64 %.2e of max" % (name, e))
+        assert e <= 5e-6, (name, e)
