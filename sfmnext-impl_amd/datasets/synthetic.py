@@ -11,7 +11,11 @@ scene="waves" (default): the depth field has random phases and nothing in the im
 at what a constant prediction gets (~0.9).  scene="road": a driving-scene layout the image does tell — a ground plane below a horizon row
 that varies per sample (camera 1.65 m above it, as on KITTI's car) and a far wall above it, the region above the horizon brighter and the
 ground carrying a depth-scaled stripe pattern — so that self-supervised training brings abs_rel down (tests/test_gpu_abs_rel.py's
-comparison from trained weights)."""
+comparison from trained weights).  scene="drive" (round 6): the CONSISTENT scene — texture and depth are analytic functions of the continuous
+target coordinates, and a source frame's pixel y shows the texture of the target point x whose 3-D point projects to y (x found by
+fixed-point iteration; round 5 sampled the target texture at the FORWARD projection, which is consistent to first order only), rotations are
+exact, nothing is added after the warp.  The photometric loss of the reference then has its minimum at the true depth and the true motion up to
+the bilinear interpolation error of a smooth function: a trained model stays trained under the default learning rate."""
 import math
 
 import numpy as np
@@ -40,7 +44,98 @@ def _texture(gen, height, width, xs, ys):
     return img
 
 
+def _rodrigues(w):
+    """exact rotation matrix of the axis-angle vector w (float64)"""
+    th = float(w.norm())
+    Kx = torch.tensor([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]], dtype=torch.float64)
+    if th < 1e-12:
+        return torch.eye(3, dtype=torch.float64) + Kx
+    return torch.eye(3, dtype=torch.float64) + math.sin(th) / th * Kx + (1 - math.cos(th)) / (th * th) * (Kx @ Kx)
+
+
+def drive_motion(index, f):
+    """the camera motion target -> source frame f of sample `index` of the "drive" scene: (axis-angle w, translation t), X_src = R(w) X_tgt + t"""
+    gen = torch.Generator().manual_seed(977 + 31 * int(index) + (int(f) if f != "s" else 7))
+    if f == "s":
+        return torch.zeros(3, dtype=torch.float64), torch.tensor([-0.1, 0.0, 0.0], dtype=torch.float64)
+    r = torch.rand(6, generator=gen, dtype=torch.float64)
+    t = torch.stack([(r[0] - 0.5) * 0.10, (r[1] - 0.5) * 0.04, -(0.25 + 0.25 * r[2])]) * float(f)     # driving forward: frame -1 lies behind, +1 ahead
+    w = (r[3:6] - 0.5) * 0.012 * float(f)
+    return w, t
+
+
+def _drive_sample(index, height, width, frame_ids, with_gt):
+    gen = torch.Generator().manual_seed(1234 + int(index))
+    dd = torch.float64
+    r = torch.rand(40, generator=gen, dtype=dd)
+    v0 = 0.30 + 0.10 * float(r[0])                                   # horizon (fraction of the height)
+    tilt = (float(r[1]) - 0.5) * 0.06
+    fy_n, cam_h = float(_K_NORM[1, 1]), 1.65
+    bumps = [(float(r[2 + 4 * i]), 0.45 + 0.4 * float(r[3 + 4 * i]), 0.04 + 0.05 * float(r[4 + 4 * i]), 0.02 + 0.05 * float(r[5 + 4 * i])) for i in range(3)]
+    fr = [(0.02 + 0.2 * float(r[14 + 4 * i]), 0.02 + 0.2 * float(r[15 + 4 * i]), 6.283 * float(r[16 + 4 * i]), 0.04 + 0.07 * float(r[17 + 4 * i])) for i in range(6)]
+
+    def inv_depth(x, y):                                             # smooth in the continuous pixel coordinates, defined everywhere
+        u, v = (x + 0.5) / width, (y + 0.5) / height
+        below = v - v0 - tilt * (u - 0.5)
+        ground = torch.nn.functional.softplus(below * 40.0) / 40.0 / (cam_h * fy_n)      # 1 / z of the ground plane, -> 0 above the horizon
+        inv = 1.0 / 55.0 + ground
+        for (bu, bv, su, amp) in bumps:                              # a few nearer "objects": smooth bumps of inverse depth
+            inv = inv + amp * torch.exp(-((u - bu) ** 2) / (2 * su * su) - ((v - bv) ** 2) / (2 * (1.6 * su) ** 2))
+        return inv.clamp(1.0 / 60.0, 1.0 / 2.0)
+
+    def texture(x, y):                                               # [3, ...] analytic colours: the image tells the layout (sky brighter, stripes ~ 1/z)
+        inv = inv_depth(x, y)
+        u, v = (x + 0.5) / width, (y + 0.5) / height
+        sky = torch.sigmoid(-(v - v0 - tilt * (u - 0.5)) * 60.0)
+        out = []
+        for c in range(3):
+            img = 0.45 + 0.0 * x
+            for i, (fx, fyq, ph, amp) in enumerate(fr):
+                img = img + amp * torch.sin(fx * x * (1 + 0.13 * c) + fyq * y + ph + 0.7 * c)
+            img = img * (0.8 + 0.3 * sky) + 0.07 * torch.sin(inv * 150.0 + 0.04 * x) * (1 - sky)
+            out.append(img)
+        return torch.stack(out, 0).clamp(0.02, 0.98)
+
+    ys, xs = torch.meshgrid(torch.arange(height, dtype=dd), torch.arange(width, dtype=dd), indexing="ij")
+    K, inv_K = intrinsics(height, width)
+    K3, iK3 = K[:3, :3].to(dd), inv_K[:3, :3].to(dd)
+
+    def project(x, y, R, t):                                         # target pixel (x, y) -> its pixel in the source view
+        z = 1.0 / inv_depth(x, y)
+        ray = torch.stack([iK3[0, 0] * x + iK3[0, 1] * y + iK3[0, 2], iK3[1, 0] * x + iK3[1, 1] * y + iK3[1, 2], torch.ones_like(x)], 0)
+        X = ray * z
+        p = torch.einsum("ij,j...->i...", K3 @ R, X) + (K3 @ t).reshape(3, *([1] * x.dim()))
+        return p[0] / p[2], p[1] / p[2]
+
+    sample = {("K", 0): K, ("inv_K", 0): inv_K}
+    for f in frame_ids:
+        if f == 0:
+            img = texture(xs, ys)
+        else:
+            w, t = drive_motion(index, f)
+            R = _rodrigues(w)
+            if f == "s":
+                stereo_T = torch.eye(4)
+                stereo_T[0, 3] = -0.1
+                sample["stereo_T"] = stereo_T
+            x, y = xs.clone(), ys.clone()
+            for _ in range(6):                                       # the target point whose projection is this source pixel (contraction ~0.05 per step)
+                px, py = project(x, y, R, t)
+                x, y = x - (px - xs), y - (py - ys)
+            img = texture(x, y)
+        img = img.to(torch.float32)
+        sample[("color", f, 0)] = img
+        gain = 0.9 + 0.2 * float(torch.rand(1, generator=gen))
+        sample[("color_aug", f, 0)] = (img * gain).clamp(0, 1)
+    if with_gt:
+        depth = (1.0 / inv_depth(xs, ys)).to(torch.float32)
+        sample["depth_gt"] = F.interpolate(depth[None, None], [375, 1242], mode="bilinear", align_corners=False)[0]
+    return sample
+
+
 def make_sample(index, height, width, frame_ids=(0, -1, 1), with_gt=True, scene="waves"):
+    if scene == "drive":
+        return _drive_sample(index, height, width, frame_ids, with_gt)
     gen = torch.Generator().manual_seed(1234 + int(index))
     ys, xs = torch.meshgrid(torch.arange(height, dtype=torch.float32), torch.arange(width, dtype=torch.float32), indexing="ij")
     # a wider canvas so that the source views stay inside the texture
