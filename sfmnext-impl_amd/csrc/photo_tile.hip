@@ -261,6 +261,7 @@ struct Tiling {
     int TR, nsx, nsy, ntiles, nblk8;
     int n_lo, n_hi_cols;
     int skew;          // fused forward: cycles the second workgroup of a CU waits at its start (0: none)
+    int pipe;          // lean forward: two rows of a wave in flight in phase 1 (warp_tile_pipe)
 };
 __device__ __forceinline__ void tile_of(const Tiling &tl, int tile, int H, int &b, int &tx, int &y0, int &own_rows) {
     if (tl.n_lo <= 0) {
@@ -822,6 +823,86 @@ __device__ __forceinline__ void warp_tile(const sqd_photo_args &a, const PairPas
     }
 }
 
+// phase 1 of the lean forward with TWO rows of a wave in flight: the gathers of the wave's next row leave before the current row is
+// blended, so that a workgroup alone on its CU's address path (the other one busy in phase 2: Tiling::skew) keeps it fed with its eight
+// waves — with one row in flight eight waves reach 57 % of the path's rate (profiles/r06a: phase 1 takes 14 300 cycles with one workgroup
+// per CU, 16 000 with two).  Grid stores before the gathers, warped colours to LDS only (store_warped_wide).
+struct WarpRow {
+    v2f t0[3][2], t1[3][2];
+    v2f wn0, ws0, wn1, ws1;
+};
+template <int NW>
+__device__ __forceinline__ void warp_tile_pipe(const sqd_photo_args &a, const PairPass &pp, v2f *wl, int b, int y0, int own_rows, int x, bool own_col, int lane,
+                                               int wave) {
+    const int H = a.H, W = a.W;
+    const unsigned HW = (unsigned)(H * W);
+    const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
+    const float *__restrict__ dep = a.depth + (size_t)b * HW;
+    const unsigned img_bytes = 3u * HW * 4u;
+    const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sources[pp.s0] + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sources[pp.s1] + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
+    float2 *smp0 = reinterpret_cast<float2 *>(a.sample[pp.s0]) + (size_t)b * HW, *smp1 = reinterpret_cast<float2 *>(a.sample[pp.s1]) + (size_t)b * HW;
+    float ik[9];
+    v2f P[12];
+    typedef const __attribute__((address_space(4))) float *cfp;
+    const cfp ikp = (cfp)(a.inv_K + (size_t)b * 16);
+    const cfp p0 = (cfp)(a.P + ((size_t)b * pp.S + pp.s0) * 12), p1 = (cfp)(a.P + ((size_t)b * pp.S + pp.s1) * 12);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) ik[i * 3 + j] = ikp[i * 4 + j];
+#pragma unroll
+    for (int j = 0; j < 12; ++j) P[j] = v2f{p0[j], p1[j]};
+    const v2f rW = splat(rcp_refined(wm1)), rH = splat(rcp_refined(hm1));
+    const float fx = (float)x;
+    const unsigned HW4 = HW * 4u, W4 = (unsigned)W * 4u;
+    const int r_lo = max(0, 3 - y0), r_hi = min(own_rows + 6, H - y0 + 3);
+    auto issue = [&](WarpRow &f, int r, float d) {
+        const int yA = y0 - 3 + r;
+        const unsigned off = (unsigned)(yA * W + x);
+        Cell c;
+        project_cell(c, d, fx, (float)yA, ik, P, rW, rH, wm1, hm1, W);
+        if (own_col && r >= 3 && r < own_rows + 3) {
+            stg2(smp0, off * 8u, c.gx.x, c.gy.x);
+            stg2(smp1, off * 8u, c.gx.y, c.gy.y);
+        }
+        f.wn0 = c.wn0; f.ws0 = c.ws0; f.wn1 = c.wn1; f.ws1 = c.ws1;
+        const unsigned s0 = c.o0 + W4, s1 = c.o1 + W4;
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            f.t0[ch][0] = bld2(r0, c.o0, ch * HW4);
+            f.t1[ch][0] = bld2(r1, c.o1, ch * HW4);
+            f.t0[ch][1] = bld2(r0, s0, ch * HW4);
+            f.t1[ch][1] = bld2(r1, s1, ch * HW4);
+        }
+    };
+    auto finish = [&](const WarpRow &f, int r) {
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const v2f ea = pfma(f.t0[ch][1], f.ws0, f.t0[ch][0] * f.wn0), eb = pfma(f.t1[ch][1], f.ws1, f.t1[ch][0] * f.wn1);
+            wl[(r * 3 + ch) * 64 + lane] = v2f{hadd(ea), hadd(eb)};
+        }
+    };
+    auto depth_of = [&](int r) { return r < r_hi ? ldg(dep, (unsigned)((y0 - 3 + r) * W + x) * 4u) : 0.f; };
+    int r = r_lo + wave;
+    if (r >= r_hi) return;
+    WarpRow A, B;
+    float d1 = depth_of(r + NW);
+    issue(A, r, depth_of(r));
+    for (;;) {
+        float d2 = depth_of(r + 2 * NW);
+        if (r + NW < r_hi) issue(B, r + NW, d1);
+        finish(A, r);
+        r += NW;
+        if (r >= r_hi) break;
+        d1 = depth_of(r + 2 * NW);
+        if (r + NW < r_hi) issue(A, r + NW, d2);
+        finish(B, r);
+        r += NW;
+        if (r >= r_hi) break;
+    }
+}
+
 // ---- wide edition (round 6): every vector-memory instruction of a wave costs the CU's address path 16 clocks whatever it moves (4 lanes
 // per clock), and the round-5 kernel issued 43 of them per 64-pixel output row — 30 us of the launch's 51 before any arithmetic, the two
 // adding up rather than overlapping.  Two families of 4-byte accesses become 16-byte ones that go through LDS:
@@ -933,7 +1014,8 @@ __device__ __forceinline__ void photo_tile_body(const sqd_photo_args &a, const P
                 StagedRows sr;
                 stage_target_issue<NW>(sr, tgt, H, W, y0, sx.x0, r_lo, r_hi, lane, wave);
                 PHOTO_STAMP(1);
-                warp_tile<NW, false, true, true>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
+                if (tl.pipe) warp_tile_pipe<NW>(a, pp, wl, b, y0, own_rows, x, own_col, lane, wave);
+                else warp_tile<NW, false, true, true>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
                 stage_target_commit<NW>(sr, tt, r_lo, r_hi, lane, wave);
             } else {
                 stage_target_wide<NW>(tt, tgt, H, W, y0, sx.x0, r_lo, r_hi, lane, wave);
@@ -1895,8 +1977,8 @@ extern "C" int sqd_photo_trace(void *buf) { return (int)hipMemcpyToSymbol(HIP_SY
 #endif
 namespace sqd {
 static int g_fwd_variant = 0;      // 0: default (stream kernel on 8-wave tilings), 1: round 5's kernel, 2: colour-serial phase 2, 4: wide edition
-static int g_fwd_skew = 0, g_fwd_resident = 0;
-void photo_set_fwd_variant(int v) { g_fwd_variant = v & 0x7f; g_fwd_resident = (v & 0x80) != 0; g_fwd_skew = (v >> 8) * 256; }
+static int g_fwd_skew = 0, g_fwd_resident = 0, g_fwd_pipe = 0;
+void photo_set_fwd_variant(int v) { g_fwd_variant = v & 0x3f; g_fwd_pipe = (v & 0x40) != 0; g_fwd_resident = (v & 0x80) != 0; g_fwd_skew = (v >> 8) * 256; }
 int photo_fwd_waves(int B, int H, int W, int rows_per_task) {      // loss partials per tile
     const Tiling tl = make_tiling(B, H, W, rows_per_task, FAMILY_FWD);
     return tl.TR > TR_MAX ? 16 : 4;
@@ -1907,6 +1989,7 @@ int photo_tile_count(int B, int H, int W, int rows_per_task, int family) { retur
 void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hipStream_t stream) {
     Tiling tl = make_tiling(a.B, a.H, a.W, a.rows_per_task, mode == 1 ? FAMILY_FWD : FAMILY_ROWS);
     tl.skew = mode == 1 ? g_fwd_skew : 0;
+    tl.pipe = g_fwd_pipe;
     const int NW = mode == 1 && tl.TR > TR_MAX ? 8 : 4;
     const dim3 grid(tl.nblk8 * 8), block(NW * 64);
     for (int k = 0; 2 * k < a.S; ++k) {                  // one launch per pair of source frames
