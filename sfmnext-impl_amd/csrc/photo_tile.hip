@@ -978,7 +978,7 @@ __device__ __forceinline__ void store_warped_wide(const v2f *wl, float *__restri
 
 // (4 workgroups of 4 waves per CU: the register allocator is held to 128 VGPRs; the kernel needs 118.  NW = 8: two workgroups of 8
 //  waves on tiles of up to 32 rows — the same waves per SIMD, 38 instead of 2 x 22 warped rows per 32 output rows)
-template <int MODE, int NW, bool WIDE, bool FAST>
+template <int MODE, int NW, bool WIDE, bool FAST, bool PIPE = false>
 __device__ __forceinline__ void photo_tile_body(const sqd_photo_args &a, const PairPass &pp, const float *__restrict__ noise, const Tiling &tl, v2f *wl, int tile) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1014,7 +1014,7 @@ __device__ __forceinline__ void photo_tile_body(const sqd_photo_args &a, const P
                 StagedRows sr;
                 stage_target_issue<NW>(sr, tgt, H, W, y0, sx.x0, r_lo, r_hi, lane, wave);
                 PHOTO_STAMP(1);
-                if (tl.pipe) warp_tile_pipe<NW>(a, pp, wl, b, y0, own_rows, x, own_col, lane, wave);
+                if constexpr (PIPE) warp_tile_pipe<NW>(a, pp, wl, b, y0, own_rows, x, own_col, lane, wave);
                 else warp_tile<NW, false, true, true>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
                 stage_target_commit<NW>(sr, tt, r_lo, r_hi, lane, wave);
             } else {
@@ -1082,22 +1082,27 @@ __device__ __forceinline__ void photo_tile_body(const sqd_photo_args &a, const P
         }
     }
 }
-template <int MODE, int NW = 4, bool WIDE = false, bool FAST = false>
+template <int MODE, int NW = 4, bool WIDE = false, bool FAST = false, bool PIPE = false>
 __global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_args a, PairPass pp, const float *__restrict__ noise, Tiling tl) {
     extern __shared__ v2f wl[];                       // MODE 1: [TR + 6][3][64] (source 0, source 1) warped colours (+ WIDE: [TR + 6][3][64] target)
     // consecutive tiles (which share halo rows / columns) on the same XCD: workgroup i runs on XCD i % 8
     const int tile = (blockIdx.x & 7) * tl.nblk8 + (blockIdx.x >> 3);
     if (tile >= tl.ntiles) return;
-    photo_tile_body<MODE, NW, WIDE, FAST>(a, pp, noise, tl, wl, tile);
+    photo_tile_body<MODE, NW, WIDE, FAST, PIPE>(a, pp, noise, tl, wl, tile);
 }
 // the lean forward as RESIDENT workgroups (two per CU = 64 per XCD), each walking its XCD's tile list with stride 64: the per-CU traces of
 // round 6 show a freed workgroup slot idle for ~5 000 cycles (2 us of a 45 us launch) before its successor starts
 template <int NW>
 __global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_resident_kernel(sqd_photo_args a, PairPass pp, Tiling tl, int per_xcd) {
     extern __shared__ v2f wl[];
+    // (the launch arguments are re-read per tile through a pointer the compiler cannot see through: with `a` inlined the tile loop kept
+    //  every tile-independent address live across iterations — 122 registers and 92 SGPR spills, 49.0 against 44.7 us)
+    typedef const __attribute__((address_space(4))) sqd_photo_args *argp_t;
+    argp_t ap = (argp_t)__builtin_amdgcn_kernarg_segment_ptr();
     for (int j = blockIdx.x >> 3; j < tl.nblk8; j += per_xcd) {
         const int tile = (blockIdx.x & 7) * tl.nblk8 + j;
-        if (tile < tl.ntiles) photo_tile_body<1, NW, true, true>(a, pp, nullptr, tl, wl, tile);
+        asm volatile("" : "+s"(ap));
+        if (tile < tl.ntiles) photo_tile_body<1, NW, true, true>(*(const sqd_photo_args *)ap, pp, nullptr, tl, wl, tile);
         __syncthreads();
     }
 }
@@ -2014,7 +2019,14 @@ void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hi
             const int per_xcd = tl.nblk8 < 64 ? tl.nblk8 : 64;            // 256 CUs x 2 resident workgroups = 64 per XCD
             if (g_fwd_resident && tl.nblk8 > 64)
                 hipLaunchKernelGGL((photo_tile_resident_kernel<8>), dim3(per_xcd * 8), block, lds, stream, a, pp, tl, per_xcd);
-            else
+            else if (g_fwd_pipe) {
+                static int lds_ok3 = 0;
+                if (!lds_ok3) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photo_tile_kernel<1, 8, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    lds_ok3 = 1;
+                }
+                hipLaunchKernelGGL((photo_tile_kernel<1, 8, true, true, true>), grid, block, lds, stream, a, pp, noise, tl);
+            } else
                 hipLaunchKernelGGL((photo_tile_kernel<1, 8, true, true>), grid, block, lds, stream, a, pp, noise, tl);
         } else if (mode == 1 && NW == 8 && g_fwd_variant == 5 && a.W >= 64) {
             const int lds = (tl.TR + 6) * 3 * 64 * 12 + (int)sizeof(DynCtl);
