@@ -361,7 +361,27 @@ class GradBucketReducer:
         # lost (a stale DEFERRED_FILTERS entry, a hook that did not fire) and the ranks would silently diverge
         if self.hooks_enabled:
             stuck = [bi for bi, plist in enumerate(self.buckets) if 0 < self._pending[bi] < len(plist)]
-            if stuck:
+            # a bucket whose missing arrivals are exactly its parameters WITHOUT a gradient in this pass (a frozen or conditionally unused
+            # branch that shares the bucket with used parameters) is exchanged with zeros in their place — torch DDP's treatment of unused
+            # parameters; as there, every rank must leave the same parameters unused in a step.  Missing arrivals of parameters that DO hold
+            # a gradient are lost ones: no exchange may silently skip them.
+            lost = [bi for bi in stuck if self._pending[bi] != sum(1 for q in self.buckets[bi] if q.grad is None)]
+            if lost:
                 raise RuntimeError("sqd.ddp: gradient bucket(s) %s received only part of their gradients in this backward pass "
-                                   "(%s of %s arrivals missing): no all-reduce ran for them" %
-                                   (stuck, [self._pending[bi] for bi in stuck], [len(self.buckets[bi]) for bi in stuck]))
+                                   "(%s of %s arrivals missing, parameters without a gradient: %s): no all-reduce ran for them" %
+                                   (lost, [self._pending[bi] for bi in lost], [len(self.buckets[bi]) for bi in lost],
+                                    [sum(1 for q in self.buckets[bi] if q.grad is None) for bi in lost]))
+            for bi in stuck:
+                from . import nnkernels
+                nnkernels.join_wgrad_stream()
+                for q, v in zip(self.buckets[bi], self.views[bi]):
+                    if q.grad is None:
+                        v.zero_()
+                    elif q.grad is not v:
+                        v.copy_(q.grad)
+                    q.grad = v
+                self._pending[bi] = 0
+                if self.active:
+                    self._exchange(self.flat[bi])
+            if stuck:
+                self._join()

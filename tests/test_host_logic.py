@@ -268,11 +268,20 @@ def _trainer_params_worker(rank, world, port, q):
         red.on_deferred_grad(params[i].detach().requires_grad_())        # (found by storage when it is not the parameter object itself)
     red.finish()
     hist.append([None if p.grad is None else p.grad.clone() for p in params])
+    # a step in which a few bucketed parameters legitimately receive NO gradient (a frozen branch; the same ones on every rank): their
+    # buckets are exchanged with zeros in their place — the used parameters of those buckets still get the averaged gradient
+    skipped = [i for i in range(len(params)) if i not in unused][3::11]
+    red.zero_grad()
+    loss = sum((p * c).sum() for i, (p, c) in enumerate(zip(params, coef)) if i not in unused and i not in skipped) * 5.0
+    loss.backward()
+    red.finish()
+    hist.append([None if p.grad is None else p.grad.clone() for p in params])
+    zero_filled = all(float(hist[-1][i].abs().max()) == 0.0 for i in skipped)
     conv4d = next(i for i, p in enumerate(params) if p.dim() == 4 and p.shape[2] == 3 and p.shape[1] > 1)
     info = {"nbuckets": len(red.buckets), "ndeferred": len(deferred), "in_buckets": sum(len(b) for b in red.buckets), "nparams": len(params),
             "fc_grad_none": all(hist[-1][i] is None for i in unused),
             "view_strides_ok": params[conv4d].grad.stride() == params[conv4d].stride() and not params[conv4d].is_contiguous(),
-            "is_view": params[conv4d].grad._base is not None,
+            "is_view": params[conv4d].grad._base is not None, "zero_filled": zero_filled, "nskipped": len(skipped),
             "w0": float(params[0].detach().double().sum())}
     vals = [[None if g is None else float(g.double().mean()) for g in h] for h in hist]
     q.put((rank, info, vals))
@@ -295,7 +304,11 @@ def test_reducer_on_trainer_parameter_set_gloo_world2():
     assert i0["w0"] == i1["w0"]                                   # rank 0's weights were broadcast
     assert i0["nbuckets"] >= 2 and i0["in_buckets"] == i0["nparams"] - 2 and i0["fc_grad_none"]     # the unused fc stays out of the buckets
     assert i0["view_strides_ok"] and i0["is_view"]                # channels-last filters keep their layout inside the bucket
-    assert i0["ndeferred"] >= 4 and len(v0) == 4                  # (the fourth step: deferred gradients announced by hand)
+    assert i0["ndeferred"] >= 4 and len(v0) == 5                  # (the fourth step: deferred gradients announced by hand)
+    assert i0["nskipped"] >= 3 and i0["zero_filled"]              # (the fifth: parameters without a gradient exchanged as zeros)
+    # the used parameters of the fifth step: mean of (rank + 1) * (1 + i % 3) * 5 over the two ranks = 7.5 * (1 + i % 3)
+    used5 = [(i, m) for i, m in enumerate(v0[4]) if m is not None and m != 0.0]
+    assert len(used5) > 20 and all(abs(m - 7.5 * (1 + i % 3)) < 1e-4 for i, m in used5), used5[:5]
     for step, (a, b) in enumerate(zip(v0, v1)):
         assert a == b                                             # both ranks hold the same averaged gradients
         for i, g in enumerate(a):
