@@ -312,7 +312,7 @@ def test_reducer_on_trainer_parameter_set_gloo_world2():
     for step, (a, b) in enumerate(zip(v0, v1)):
         assert a == b                                             # both ranks hold the same averaged gradients
         for i, g in enumerate(a):
-            if g is not None:                                     # mean of rank coefficients 1x and 2x = 1.5x, times the step factor
+            if g is not None and not (step == 4 and g == 0.0):   # mean of rank coefficients 1x and 2x = 1.5x, times the step factor (fifth step: zeros for the skipped parameters)
                 assert abs(g - 1.5 * (1 + i % 3) * (step + 1)) < 1e-5, (step, i, g)
 
 
