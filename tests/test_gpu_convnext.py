@@ -281,7 +281,7 @@ def test_block_operators_record_the_maximum_of_what_they_write():
                 def hook(g):
                     seen[name] = (None if nnkernels._amax_get(g) is None else nnkernels.amax_value(nnkernels._amax_get(g)), float(g.abs().max()))
                     # ... and the per-block column sums of what they wrote (the bias gradient of the Linear layer in front of them)
-                    cs = getattr(g, "_sqd_colsum", None)
+                    cs = nnkernels._colsum_get(g)               # (valid for this content of the tensor only: it carries the version counter)
                     assert cs is not None and cs.shape == (C,), name
                     want = g.double().sum((0, 2, 3))
                     assert torch.allclose(cs.double(), want, rtol=1e-4, atol=1e-4 * float(want.abs().max())), name
