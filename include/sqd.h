@@ -277,6 +277,17 @@ int sqd_backproject_fwd(const float *depth, const float *inv_K, float *cam_point
 int sqd_project3d_fwd(const float *points, const float *K, const float *T, float *grid, int B, int H, int W, float eps,
                       void *stream);
 int sqd_ssim_fwd(const float *x, const float *y, float *out, int planes, int H, int W, void *stream);
+/* adjoints (the reference's modules are differentiable: layers.py:13-46,186-258).
+ *   sqd_ssim_bwd: g [planes,H,W] upstream -> g_x, g_y [planes,H,W] (either may be NULL); coef_ws: 4*planes*H*W floats of workspace
+ *   sqd_backproject_bwd: g_points [B,4,HW] -> g_depth [B,1,H,W] (inv_K is data)
+ *   sqd_project3d_bwd: g_grid [B,H,W,2] -> g_points [B,4,HW], g_T [B,4,4] (K is data); gP_part: B * sqd_project3d_bwd_nblk(H,W) * 12
+ *   floats of workspace (per-workgroup partials, summed in a fixed order)                                                           */
+int sqd_ssim_bwd(const float *x, const float *y, const float *g, float *coef_ws, float *g_x, float *g_y, int planes, int H, int W,
+                 void *stream);
+int sqd_backproject_bwd(const float *g_points, const float *inv_K, float *g_depth, int B, int H, int W, void *stream);
+int sqd_project3d_bwd_nblk(int H, int W);
+int sqd_project3d_bwd(const float *points, const float *K, const float *T, const float *g_grid, float *g_points, float *gP_part,
+                      float *g_T, int B, int H, int W, float eps, void *stream);
 /* F.grid_sample(img [B,C,H,W], grid [B,Ho,Wo,2], padding_mode="border", align_corners=True) -> out [B,C,Ho,Wo]
  * (reference trainer.py:431-435); x0y0 (optional, int32 [B,Ho,Wo,2]) receives the integer north-west taps.          */
 int sqd_grid_sample_border_fwd(const float *img, const float *grid, float *out, int *x0y0, int B, int C, int H, int W, int Ho,

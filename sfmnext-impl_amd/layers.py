@@ -4,9 +4,11 @@ On the training path these are not called one by one: `Trainer.generate_images_p
 `compute_losses` run them fused in sqd.ops.PhotometricChain (depth upsample -> BackprojectDepth ->
 Project3D -> grid_sample -> SSIM + L1 -> min/auto-mask -> smoothness).  The stand-alone names below
 keep the reference's call signatures for scripts that use them directly; each is served by a kernel
-of libsqd.so.  Device tensors only — there is no CPU fallback.  get_smooth_loss and the pose-matrix
-functions are autograd nodes; SSIM / BackprojectDepth / Project3D are forward-only and RAISE when an input requires a
-gradient (the reference's are differentiable: layers.py:13-46,186-258) — nothing detaches silently."""
+of libsqd.so.  Device tensors only — there is no CPU fallback.  Like the reference's modules (layers.py:13-46,75-92,186-258,267-280)
+they are differentiable: SSIM w.r.t. both images, BackprojectDepth w.r.t. the depth, Project3D w.r.t. the points and T,
+get_smooth_loss w.r.t. the disparity, the pose-matrix functions w.r.t. both vectors — each through an adjoint kernel of
+libsqd.so.  Arguments that are data in the reference's training graph (K, inv_K, the smoothness term's image) RAISE when
+they require a gradient; nothing detaches silently."""
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -55,7 +57,7 @@ def compute_depth_errors(gt, pred):
 
 class SSIM(nn.Module):
     """SSIM loss map between two images, 7x7 window over a 3-px reflection pad (reference
-    layers.py:13-46).  Stand-alone entry served by the identity/SSIM kernel of libsqd.so."""
+    layers.py:13-46).  Stand-alone entry (sqd_ssim_fwd / sqd_ssim_bwd)."""
 
     def forward(self, x, y):
         return ops.ssim_map(x, y)

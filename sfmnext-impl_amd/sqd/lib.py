@@ -168,6 +168,10 @@ _SIGNATURES = {
     "sqd_backproject_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "sqd_project3d_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "sqd_ssim_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "sqd_ssim_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _P]),
+    "sqd_backproject_bwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "sqd_project3d_bwd_nblk": (_I, [_I, _I]),
+    "sqd_project3d_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "sqd_grid_sample_border_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     "sqd_adam_chunk_elems": (_I, []),
     "sqd_adam_step": (_I, [_P, _P, _P, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P]),

@@ -232,45 +232,101 @@ def smooth_bwd(depth, color, part, sm_part, gout, planes=None, plane=0):
 
 # ---- stand-alone entries behind the reference's layer classes ----------------------------------------------------------
 # The reference's SSIM / BackprojectDepth / Project3D / get_smooth_loss / transformation_from_parameters are ordinary autograd modules
-# (layers.py:13-46,75-92,186-258,267-280).  Here the training path differentiates the fused chain (PhotometricChain); of the stand-alone
-# forms, get_smooth_loss (w.r.t. the disparity) and transformation_from_parameters (w.r.t. both pose vectors) are autograd nodes over the
-# adjoint kernels the chain uses, and the FORWARD-ONLY ones refuse an input that requires a gradient — none of them detaches silently.
+# (layers.py:13-46,75-92,186-258,267-280).  Here the training path differentiates the fused chain (PhotometricChain); the stand-alone
+# forms are autograd nodes over adjoint kernels of their own (sqd_ssim_bwd, sqd_backproject_bwd, sqd_project3d_bwd, sqd_smooth_bwd,
+# sqd_pose_mats_bwd) w.r.t. the arguments the reference's training graph differentiates — images, depth, points, T, disparity, pose
+# vectors.  An argument that is DATA there (intrinsics, the smoothness term's image) or an entry without an adjoint (grid_sample_border)
+# refuses a tensor that requires a gradient — nothing detaches silently.
 def _forward_only(who, *tensors):
     if torch.is_grad_enabled() and any(isinstance(t, torch.Tensor) and t.requires_grad for t in tensors):
-        raise RuntimeError("%s is a forward-only stand-alone entry of libsqd: an input requires a gradient, and no gradient would flow "
-                           "through it.  Differentiate through the fused chain (Trainer.generate_images_pred / compute_losses, "
-                           "sqd.ops.PhotometricChain) or call it under torch.no_grad() / on detached tensors." % who)
+        raise RuntimeError("%s: no gradient is computed w.r.t. this argument (a forward-only stand-alone entry of libsqd, or an argument "
+                           "that is data in the reference's training graph), and it requires one.  Differentiate through the fused "
+                           "chain (Trainer.generate_images_pred / compute_losses) or pass a detached tensor." % who)
+
+
+class _Backproject(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, depth, inv_K):
+        depth, inv_K = depth.detach().contiguous().float(), inv_K.detach().contiguous().float()
+        _req(depth, inv_K)
+        B, _, H, W = depth.shape
+        pts = torch.empty(B, 4, H * W, device=depth.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_backproject_fwd(_ptr(depth), _ptr(inv_K), _ptr(pts), B, H, W, _stream()), "backproject_fwd")
+        ctx.save_for_backward(inv_K)
+        ctx.shape = (B, H, W)
+        return pts
+
+    @staticmethod
+    def backward(ctx, g_pts):
+        (inv_K,) = ctx.saved_tensors
+        B, H, W = ctx.shape
+        g_pts = g_pts.contiguous().float()
+        g_depth = torch.empty(B, 1, H, W, device=g_pts.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_backproject_bwd(_ptr(g_pts), _ptr(inv_K), _ptr(g_depth), B, H, W, _stream()), "backproject_bwd")
+        return g_depth, None
 
 
 def backproject(depth, inv_K):
-    _forward_only("BackprojectDepth", depth, inv_K)
-    depth, inv_K = depth.detach().contiguous().float(), inv_K.detach().contiguous().float()
-    _req(depth, inv_K)
-    B, _, H, W = depth.shape
-    pts = torch.empty(B, 4, H * W, device=depth.device, dtype=torch.float32)
-    _l.check(_l.lib().sqd_backproject_fwd(_ptr(depth), _ptr(inv_K), _ptr(pts), B, H, W, _stream()), "backproject_fwd")
-    return pts
+    _forward_only("BackprojectDepth (inv_K)", inv_K)
+    return _Backproject.apply(depth, inv_K)
+
+
+class _Project3D(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, points, K, T, H, W, eps):
+        points, K, T = (t.detach().contiguous().float() for t in (points, K, T))
+        _req(points, K, T)
+        B = points.shape[0]
+        grid = torch.empty(B, H, W, 2, device=points.device, dtype=torch.float32)
+        _l.check(_l.lib().sqd_project3d_fwd(_ptr(points), _ptr(K), _ptr(T), _ptr(grid), B, H, W, float(eps), _stream()), "project3d_fwd")
+        ctx.save_for_backward(points, K, T)
+        ctx.geom = (B, H, W, float(eps))
+        return grid
+
+    @staticmethod
+    def backward(ctx, g_grid):
+        points, K, T = ctx.saved_tensors
+        B, H, W, eps = ctx.geom
+        L = _l.lib()
+        g_grid = g_grid.contiguous().float()
+        g_pts = torch.empty_like(points)
+        part = torch.empty(B * L.sqd_project3d_bwd_nblk(H, W) * 12, device=points.device, dtype=torch.float32)
+        g_T = torch.empty(B, 4, 4, device=points.device, dtype=torch.float32)
+        _l.check(L.sqd_project3d_bwd(_ptr(points), _ptr(K), _ptr(T), _ptr(g_grid), _ptr(g_pts), _ptr(part), _ptr(g_T), B, H, W, eps, _stream()),
+                 "project3d_bwd")
+        return g_pts, None, g_T, None, None, None
 
 
 def project3d(points, K, T, H, W, eps=1e-7):
-    _forward_only("Project3D", points, K, T)
-    points, K, T = (t.detach().contiguous().float() for t in (points, K, T))
-    _req(points, K, T)
-    B = points.shape[0]
-    grid = torch.empty(B, H, W, 2, device=points.device, dtype=torch.float32)
-    _l.check(_l.lib().sqd_project3d_fwd(_ptr(points), _ptr(K), _ptr(T), _ptr(grid), B, H, W, float(eps), _stream()),
-             "project3d_fwd")
-    return grid
+    _forward_only("Project3D (K)", K)
+    return _Project3D.apply(points, K, T, H, W, eps)
+
+
+class _Ssim(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        x, y = x.detach().contiguous().float(), y.detach().contiguous().float()
+        _req(x, y)
+        B, C, H, W = x.shape
+        out = torch.empty_like(x)
+        _l.check(_l.lib().sqd_ssim_fwd(_ptr(x), _ptr(y), _ptr(out), B * C, H, W, _stream()), "ssim_fwd")
+        ctx.save_for_backward(x, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        B, C, H, W = x.shape
+        g = g.contiguous().float()
+        ws = torch.empty(B * C * 4, H, W, device=x.device, dtype=torch.float32)
+        gx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        gy = torch.empty_like(y) if ctx.needs_input_grad[1] else None
+        _l.check(_l.lib().sqd_ssim_bwd(_ptr(x), _ptr(y), _ptr(g), _ptr(ws), _ptr(gx), _ptr(gy), B * C, H, W, _stream()), "ssim_bwd")
+        return gx, gy
 
 
 def ssim_map(x, y):
-    _forward_only("SSIM", x, y)
-    x, y = x.detach().contiguous().float(), y.detach().contiguous().float()
-    _req(x, y)
-    B, C, H, W = x.shape
-    out = torch.empty_like(x)
-    _l.check(_l.lib().sqd_ssim_fwd(_ptr(x), _ptr(y), _ptr(out), B * C, H, W, _stream()), "ssim_fwd")
-    return out
+    return _Ssim.apply(x, y)
 
 
 def grid_sample_border(img, grid, want_taps=False):

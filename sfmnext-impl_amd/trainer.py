@@ -639,8 +639,8 @@ class Trainer:
 
     def compute_reprojection_loss(self, pred, target):
         """0.85*SSIM + 0.15*L1 between a predicted and a target image (reference trainer.py:441-453);
-        stand-alone form for scripts — the training path evaluates it inside the fused kernel.  Forward only: sqd.ops.ssim_map raises
-        if `pred` or `target` requires a gradient (the reference differentiates this function; the build differentiates the fused chain)."""
+        stand-alone form for scripts — the training path evaluates it inside the fused kernel.  Differentiable w.r.t. both images
+        (sqd_ssim_bwd + autograd's own abs / mean), as the reference's is."""
         l1 = torch.abs(target - pred).mean(1, True)
         return 0.85 * ops.ssim_map(pred, target).mean(1, True) + 0.15 * l1
 

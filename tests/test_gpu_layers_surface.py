@@ -54,9 +54,9 @@ def test_depth_errors_g14(golden):
 
 
 def test_standalone_layers_gradients_or_refusal():
-    """The reference's stand-alone layers are autograd modules (layers.py:13-46,75-92,186-258,267-280).  Here get_smooth_loss and
-    transformation_from_parameters are differentiable (checked against the oracle's autograd); SSIM / BackprojectDepth / Project3D /
-    Trainer.compute_reprojection_loss are forward-only and must REFUSE an input that requires a gradient — never detach it silently."""
+    """The reference's stand-alone layers are autograd modules (layers.py:13-46,75-92,186-258,267-280).  So are these: get_smooth_loss,
+    transformation_from_parameters, SSIM, BackprojectDepth, Project3D and Trainer.compute_reprojection_loss against the oracle's autograd
+    (float64); arguments that are data in the reference's graph must REFUSE a tensor that requires a gradient — never detach it silently."""
     import layers
     from oracle import torch_ref as O
     torch.manual_seed(0)
@@ -83,18 +83,45 @@ def test_standalone_layers_gradients_or_refusal():
         (O.transformation_from_parameters(a_ref, t_ref, invert) * w).sum().backward()
         np.testing.assert_allclose(a_dev.grad.cpu().numpy(), a_ref.grad.numpy(), rtol=1e-4, atol=1e-5)
         np.testing.assert_allclose(t_dev.grad.cpu().numpy(), t_ref.grad.numpy(), rtol=1e-4, atol=1e-5)
-    # the forward-only entries
-    x, y = torch.rand(B, 3, H, W).cuda(), torch.rand(B, 3, H, W).cuda()
-    xg = x.clone().requires_grad_(True)
-    with pytest.raises(RuntimeError, match="forward-only"):
-        layers.SSIM()(xg, y)
-    with pytest.raises(RuntimeError, match="forward-only"):
-        layers.BackprojectDepth(B, H, W)(torch.rand(B, 1, H, W).cuda().requires_grad_(True), torch.eye(4).repeat(B, 1, 1).cuda())
-    pts = layers.BackprojectDepth(B, H, W)(torch.rand(B, 1, H, W).cuda() + 1, torch.eye(4).repeat(B, 1, 1).cuda())
-    with pytest.raises(RuntimeError, match="forward-only"):
-        layers.Project3D(B, H, W)(pts.requires_grad_(True), torch.eye(4).repeat(B, 1, 1).cuda(), torch.eye(4).repeat(B, 1, 1).cuda())
-    with torch.no_grad():                      # under no_grad (evaluation scripts) the same calls are fine
-        layers.SSIM()(xg, y)
+    # SSIM w.r.t. both images (interior and reflected borders), and Trainer.compute_reprojection_loss through it
+    x, y = torch.rand(B, 3, H, W), torch.rand(B, 3, H, W)
+    x[:, :, :6, :8] *= 0.02                       # a dark flat corner: the ill-conditioned end of the quotient
+    y[:, :, :6, :8] *= 0.02
+    gup = torch.randn(B, 3, H, W)
+    xd, yd = x.cuda().requires_grad_(True), y.cuda().requires_grad_(True)
+    (layers.SSIM()(xd, yd) * gup.cuda()).sum().backward()
+    xr, yr = x.double().requires_grad_(True), y.double().requires_grad_(True)
+    (O.ssim(xr, yr) * gup.double()).sum().backward()
+    for got, want, name in ((xd.grad, xr.grad, "d ssim / d x"), (yd.grad, yr.grad, "d ssim / d y")):
+        err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+        print("%s: max error %.2e of max |gradient| against float64" % (name, err))
+        assert err <= 2e-4, (name, err)
     from trainer import Trainer
-    with pytest.raises(RuntimeError, match="forward-only"):
-        Trainer.compute_reprojection_loss(None, xg, y)
+    xd2 = x.cuda().requires_grad_(True)
+    Trainer.compute_reprojection_loss(None, xd2, y.cuda()).sum().backward()
+    xr2 = x.double().requires_grad_(True)
+    (0.85 * O.ssim(xr2, y.double()).mean(1, True) + 0.15 * (y.double() - xr2).abs().mean(1, True)).sum().backward()
+    assert float((xd2.grad.double().cpu() - xr2.grad).abs().max() / xr2.grad.abs().max()) <= 2e-4
+    # BackprojectDepth w.r.t. the depth, Project3D w.r.t. the points and T
+    d = chain_inputs(41, B, H, W)
+    K, invK = tt(d["K"]), tt(d["inv_K"])
+    depth = torch.rand(B, 1, H, W) * 10 + 2
+    Tm = O.transformation_from_parameters(0.05 * torch.randn(B, 1, 3), 0.3 * torch.randn(B, 1, 3), False)
+    gg = torch.randn(B, H, W, 2)
+    dd, Td = depth.cuda().requires_grad_(True), Tm.cuda().requires_grad_(True)
+    pts = layers.BackprojectDepth(B, H, W)(dd, invK.cuda())
+    (layers.Project3D(B, H, W)(pts, K.cuda(), Td) * gg.cuda()).sum().backward()
+    dr, Tr = depth.double().requires_grad_(True), Tm.double().requires_grad_(True)
+    (O.project_3d(O.backproject_depth(dr, invK.double()), K.double(), Tr, H, W) * gg.double()).sum().backward()
+    for got, want, name in ((dd.grad, dr.grad, "d grid / d depth"), (Td.grad, Tr.grad, "d grid / d T")):
+        err = float((got.double().cpu() - want).abs().max() / want.abs().max())
+        print("%s: max error %.2e of max |gradient| against float64" % (name, err))
+        assert err <= 2e-4, (name, err)
+    # arguments that are data in the reference's graph, and the entry without an adjoint
+    with pytest.raises(RuntimeError, match="no gradient is computed"):
+        layers.BackprojectDepth(B, H, W)(depth.cuda(), invK.cuda().requires_grad_(True))
+    with pytest.raises(RuntimeError, match="no gradient is computed"):
+        layers.Project3D(B, H, W)(pts.detach(), K.cuda().requires_grad_(True), Tm.cuda())
+    from sqd import ops as sqd_ops
+    with pytest.raises(RuntimeError, match="no gradient is computed"):
+        sqd_ops.grid_sample_border(x.cuda().requires_grad_(True), torch.zeros(B, H, W, 2).cuda())
