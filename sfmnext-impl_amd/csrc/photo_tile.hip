@@ -1048,7 +1048,7 @@ __device__ __forceinline__ void photo_tile_body(const sqd_photo_args &a, const P
     const float *q1 = MODE == 0 ? a.sources[pp.s1] : MODE == 2 ? a.warped[pp.s1] : a.target;
     k.p0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(q0 + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
     k.p1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(q1 + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
-    if constexpr (FAST) {
+    if constexpr (FAST && MODE == 1) {
         k.p0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.identity + (size_t)b * 2 * HW), 0, 2u * HW * 4u, 0x00020000);
         k.selp = a.sel + (size_t)b * HW;
         k.idxp = a.idx + (size_t)b * HW;
@@ -1710,6 +1710,33 @@ __device__ __forceinline__ void box7x3_adj(int kind, float &a, float &b, float &
     a = (ra + wave_shl1(ua)) + ea; b = (rb + wave_shl1(ub)) + eb; c = (rc + wave_shl1(uc)) + ec;
 }
 
+// the adjoint window sums of NINE planes (one source's coefficients) as one hand-scheduled block of 54 v_add_f32_dpp — box7x7's scheme; the
+// compiler's own code for box7x3_adj carried one v_mov_b32_dpp per two adds and hazard nops between the three-chain groups
+__device__ __forceinline__ void box7x9_adj(int kind, float (&v)[9], bool esrc, bool ekill) {
+    float e[9];
+    if (kind != INTERIOR) {                                                   // (wave-uniform)
+#pragma unroll
+        for (int i = 0; i < 9; ++i) {
+            const float m = esrc ? v[i] : 0.f;
+            const float t = kind == LEFT ? quad_reverse<0, 0>((m + row_shr<1>(m)) + row_shr<2>(m)) : quad_reverse<3, 3>((m + row_shl<1>(m)) + row_shl<2>(m));
+            e[i] = ekill ? 0.f : t;
+        }
+    }
+    float r[9], u[9];
+    asm("s_nop 1\n"
+        "v_add_f32_dpp %9, %0, %0" SQD_DPP_SHR "v_add_f32_dpp %10, %1, %1" SQD_DPP_SHR "v_add_f32_dpp %11, %2, %2" SQD_DPP_SHR "v_add_f32_dpp %12, %3, %3" SQD_DPP_SHR "v_add_f32_dpp %13, %4, %4" SQD_DPP_SHR "v_add_f32_dpp %14, %5, %5" SQD_DPP_SHR "v_add_f32_dpp %15, %6, %6" SQD_DPP_SHR "v_add_f32_dpp %16, %7, %7" SQD_DPP_SHR "v_add_f32_dpp %17, %8, %8" SQD_DPP_SHR
+        "v_add_f32_dpp %9, %9, %0" SQD_DPP_SHR "v_add_f32_dpp %10, %10, %1" SQD_DPP_SHR "v_add_f32_dpp %11, %11, %2" SQD_DPP_SHR "v_add_f32_dpp %12, %12, %3" SQD_DPP_SHR "v_add_f32_dpp %13, %13, %4" SQD_DPP_SHR "v_add_f32_dpp %14, %14, %5" SQD_DPP_SHR "v_add_f32_dpp %15, %15, %6" SQD_DPP_SHR "v_add_f32_dpp %16, %16, %7" SQD_DPP_SHR "v_add_f32_dpp %17, %17, %8" SQD_DPP_SHR
+        "v_add_f32_dpp %9, %9, %0" SQD_DPP_SHR "v_add_f32_dpp %10, %10, %1" SQD_DPP_SHR "v_add_f32_dpp %11, %11, %2" SQD_DPP_SHR "v_add_f32_dpp %12, %12, %3" SQD_DPP_SHR "v_add_f32_dpp %13, %13, %4" SQD_DPP_SHR "v_add_f32_dpp %14, %14, %5" SQD_DPP_SHR "v_add_f32_dpp %15, %15, %6" SQD_DPP_SHR "v_add_f32_dpp %16, %16, %7" SQD_DPP_SHR "v_add_f32_dpp %17, %17, %8" SQD_DPP_SHR
+        "v_add_f32_dpp %18, %0, %0" SQD_DPP_SHL "v_add_f32_dpp %19, %1, %1" SQD_DPP_SHL "v_add_f32_dpp %20, %2, %2" SQD_DPP_SHL "v_add_f32_dpp %21, %3, %3" SQD_DPP_SHL "v_add_f32_dpp %22, %4, %4" SQD_DPP_SHL "v_add_f32_dpp %23, %5, %5" SQD_DPP_SHL "v_add_f32_dpp %24, %6, %6" SQD_DPP_SHL "v_add_f32_dpp %25, %7, %7" SQD_DPP_SHL "v_add_f32_dpp %26, %8, %8" SQD_DPP_SHL
+        "v_add_f32_dpp %18, %18, %0" SQD_DPP_SHL "v_add_f32_dpp %19, %19, %1" SQD_DPP_SHL "v_add_f32_dpp %20, %20, %2" SQD_DPP_SHL "v_add_f32_dpp %21, %21, %3" SQD_DPP_SHL "v_add_f32_dpp %22, %22, %4" SQD_DPP_SHL "v_add_f32_dpp %23, %23, %5" SQD_DPP_SHL "v_add_f32_dpp %24, %24, %6" SQD_DPP_SHL "v_add_f32_dpp %25, %25, %7" SQD_DPP_SHL "v_add_f32_dpp %26, %26, %8" SQD_DPP_SHL
+        "v_add_f32_dpp %0, %18, %9" SQD_DPP_SHL "v_add_f32_dpp %1, %19, %10" SQD_DPP_SHL "v_add_f32_dpp %2, %20, %11" SQD_DPP_SHL "v_add_f32_dpp %3, %21, %12" SQD_DPP_SHL "v_add_f32_dpp %4, %22, %13" SQD_DPP_SHL "v_add_f32_dpp %5, %23, %14" SQD_DPP_SHL "v_add_f32_dpp %6, %24, %15" SQD_DPP_SHL "v_add_f32_dpp %7, %25, %16" SQD_DPP_SHL "v_add_f32_dpp %8, %26, %17" SQD_DPP_SHL
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]), "=&v"(r[5]), "=&v"(r[6]), "=&v"(r[7]), "=&v"(r[8]), "=&v"(u[0]), "=&v"(u[1]), "=&v"(u[2]), "=&v"(u[3]), "=&v"(u[4]), "=&v"(u[5]), "=&v"(u[6]), "=&v"(u[7]), "=&v"(u[8]));
+    if (kind != INTERIOR) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) v[i] += e[i];
+    }
+}
+
 // images of at most 64 columns: BOTH image borders lie inside the wavefront (column 0 in lane `lane0`), and a border's mirrored
 // terms may land on columns the other strip owns; they come from three lanes read with bpermute (tiny images only — tests)
 __device__ __forceinline__ float virt_border_adj(float v, int x, int W, int lane0) {
@@ -1856,11 +1883,8 @@ __device__ __forceinline__ void bwd_rows(int KIND, const sqd_photo_bwd_args &a, 
                 G1[c] = box7(G1[c]) + e1;
             }
         } else {
-#pragma unroll
-            for (int c = 0; c < 9; c += 3) {
-                box7x3_adj(KIND, G0[c], G0[c + 1], G0[c + 2], esrc, ekill);
-                box7x3_adj(KIND, G1[c], G1[c + 1], G1[c + 2], esrc, ekill);
-            }
+            box7x9_adj(KIND, G0, esrc, ekill);
+            box7x9_adj(KIND, G1, esrc, ekill);
         }
         if (!own_col) continue;
         const unsigned qo = (unsigned)(q * W + x);
@@ -2000,7 +2024,9 @@ void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hi
     for (int k = 0; 2 * k < a.S; ++k) {                  // one launch per pair of source frames
         const PairPass pp = {2 * k, 2 * k + 1 < a.S ? 2 * k + 1 : 2 * k, a.S, k == 0, 2 * k + 2 >= a.S};
         if (mode == 0)
-            hipLaunchKernelGGL((photo_tile_kernel<0>), grid, block, 0, stream, a, pp, noise, tl);
+            // (default loss options, one pair pass: the option-free / reflection-free / hand-scheduled-shuffle paths of the lean forward)
+            if (a.loss_flags == 0 && a.S == 2 && !g_fwd_variant) hipLaunchKernelGGL((photo_tile_kernel<0, 4, false, true>), grid, block, 0, stream, a, pp, noise, tl);
+            else hipLaunchKernelGGL((photo_tile_kernel<0>), grid, block, 0, stream, a, pp, noise, tl);
         else if (mode == 1 && NW == 8 && g_fwd_variant == 2)
             hipLaunchKernelGGL((photo_fwd_c_kernel<8>), grid, block, (tl.TR + 6) * 3 * 64 * 8, stream, a, pp, tl);
         else if (mode == 1 && NW == 8 && g_fwd_variant == 0 && a.W >= 64 && a.S == 2 && a.loss_flags == 0 && !a.reproj && !a.x0y0[0] && !a.x0y0[1] && a.sel && a.idx &&
@@ -2058,7 +2084,8 @@ void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hi
         else if (mode == 1)
             hipLaunchKernelGGL((photo_tile_kernel<1>), grid, block, (tl.TR + 6) * 3 * 64 * 8, stream, a, pp, noise, tl);
         else
-            hipLaunchKernelGGL((photo_tile_kernel<2>), grid, block, 0, stream, a, pp, noise, tl);
+            if (a.loss_flags == 0 && a.S == 2 && !g_fwd_variant) hipLaunchKernelGGL((photo_tile_kernel<2, 4, false, true>), grid, block, 0, stream, a, pp, noise, tl);
+            else hipLaunchKernelGGL((photo_tile_kernel<2>), grid, block, 0, stream, a, pp, noise, tl);
     }
 }
 
