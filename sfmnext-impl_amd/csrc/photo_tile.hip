@@ -1883,8 +1883,16 @@ __device__ __forceinline__ void bwd_rows(int KIND, const sqd_photo_bwd_args &a, 
                 G1[c] = box7(G1[c]) + e1;
             }
         } else {
+#ifdef SQD_BWD_ADJ3                                                               // (A/B builds: the compiler-scheduled three-plane sums)
+#pragma unroll
+            for (int c = 0; c < 9; c += 3) {
+                box7x3_adj(KIND, G0[c], G0[c + 1], G0[c + 2], esrc, ekill);
+                box7x3_adj(KIND, G1[c], G1[c + 1], G1[c + 2], esrc, ekill);
+            }
+#else
             box7x9_adj(KIND, G0, esrc, ekill);
             box7x9_adj(KIND, G1, esrc, ekill);
+#endif
         }
         if (!own_col) continue;
         const unsigned qo = (unsigned)(q * W + x);

@@ -19,6 +19,7 @@ ap.add_argument("--W", type=int, default=640)
 ap.add_argument("--which", default="fwd,ident,coef,bwd")
 ap.add_argument("--cold", action="store_true", help="evict L2 and the Infinity Cache before every timed call (a 1 GB fill): what the kernels see "
                                                      "inside the training step, where their inputs were produced milliseconds earlier")
+ap.add_argument("--dump", default=None, help="save the backward's outputs here (bit-compare two builds)")
 ap.add_argument("--lib", default=None, help="another build of libsqd.so (tools/build_alt_lib.sh) for same-box A/B runs")
 args = ap.parse_args()
 if args.lib:
@@ -90,4 +91,7 @@ for rows in [int(r) for r in args.rows.split(",")]:
         res["coef"] = timeit(lambda: ops.photo_coef(tgt, out["warped"], out["idx"], rows), 50)
     if "bwd" in which:
         res["coef+bwd(+reduce,alloc)"] = timeit(lambda: ops.photo_bwd(depth, inv_K, P, tgt, srcs, out["sample"], out["warped"], out["idx"], 1.0 / px, rows), 50)
+    if args.dump and "bwd" in which:
+        g = ops.photo_bwd(depth, inv_K, P, tgt, srcs, out["sample"], out["warped"], out["idx"], 1.0 / px, rows)
+        torch.save([x.cpu() for x in (g if isinstance(g, (tuple, list)) else [g]) if torch.is_tensor(x)], args.dump)
     print("rows_per_task=%d  " % rows + "  ".join("%s %.1f us (%.0f GB/s @93B/px)" % (k, v, 93 * px / v / 1e3) for k, v in res.items()), flush=True)
