@@ -67,6 +67,9 @@ def roofline_fused_fwd(trainer, batches, iters=200, graph_us=None):
         tr = 0.5 * torch.randn(B, 2, 3, device=dev)
         _, _, P = ops.pose_mats_fwd(aa, tr, [1, 0], inputs[("K", 0)].contiguous(), part, H * W)
         srcs = [inputs[("color", f, 0)].contiguous() for f in (-1, 1)]
+        hwc = bool(getattr(trainer, "_hwc_keys", None))
+        if hwc:      # the replayed step keeps its source frames in [B,H,W,3] memory (trainer._capture): time the kernel on what it reads there
+            srcs = ops.pack_pixels(srcs)
         tgt = inputs[("color", 0, 0)].contiguous()
         ident = ops.identity_fwd(tgt, srcs, torch.randn(B, 2, H, W, device=dev))
         inv_K = inputs[("inv_K", 0)].contiguous()
@@ -97,8 +100,13 @@ def roofline_fused_fwd(trainer, batches, iters=200, graph_us=None):
         eager.set_train()
         ops.PHOTO_FWD_EVENTS = []
         try:
+            ebatches = [dict(b) for b in batches]
+            if hwc:
+                for b in ebatches:
+                    for f in (-1, 1):
+                        b[("color", f, 0)] = b[("color", f, 0)].contiguous(memory_format=torch.channels_last)
             for i in range(12):
-                eager.train_step(dict(batches[i % len(batches)]))
+                eager.train_step(dict(ebatches[i % len(ebatches)]))
             torch.cuda.synchronize()
             ts = sorted(e0.elapsed_time(e1) * 1e-3 for e0, e1 in ops.PHOTO_FWD_EVENTS[2:])
             in_step = ts[len(ts) // 2]

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define SQD_ABI_VERSION 2   /* 2: loss_flags in sqd_photo_args / sqd_photo_bwd_args */
+#define SQD_ABI_VERSION 3   /* 2: loss_flags in sqd_photo_args / sqd_photo_bwd_args; 3: SQD_SOURCES_HWC, sqd_pack_pixels */
 #define SQD_OK 0
 #define SQD_EINVAL (-1)   /* bad shape / null pointer / unsupported configuration */
 #define SQD_ELAUNCH (-2)  /* hipGetLastError() after launch */
@@ -34,6 +34,12 @@ extern "C" {
 #define SQD_LOSS_NO_SSIM 1           /* reprojection loss = L1 alone                                                             */
 #define SQD_LOSS_AVG_REPROJECTION 2  /* mean over the S >= 2 source frames instead of the per-pixel minimum                       */
 #define SQD_LOSS_NO_AUTOMASK 4       /* no identity candidates: the minimum runs over the reprojection losses only                */
+/* a LAYOUT bit that travels with the loss options: sources[] point at pixel-interleaved frames [B,H,W,3] (torch: channels_last; sqd_pack_pixels
+ * makes them) instead of [B,3,H,W].  The 2 x 2 taps of a warped pixel are then two runs of 24 bytes — eight gathers per pixel and source pair
+ * instead of twelve in sqd_photo_fwd and sqd_photo_bwd, whose outputs do not change by a bit.  Served for two source frames,
+ * the default loss options, W >= 64, by sqd_identity_fwd_ex, sqd_photo_fwd (all outputs but the tap / reprojection dumps requested) and
+ * sqd_photo_bwd; SQD_EINVAL elsewhere.  sqd_photo_coef_ex ignores it (it reads no source frame).                                        */
+#define SQD_SOURCES_HWC 256
 #define SQD_MAX_SOURCES 4 /* source frames per target (reference frame_ids[1:], default 2) */
 #define SQD_STRIP_COLS 58 /* output columns per wavefront strip of the column-march kernels */
 
@@ -102,6 +108,13 @@ typedef struct sqd_photo_args {
                                0 = the kernel family's measured default (fused forward 28, identity / coefficient maps 12, backward 16) */
     void *stream;
 } sqd_photo_args;
+/* the pixel-interleaved frames SQD_SOURCES_HWC announces: planar_host[n] device pointers to [B,3,H,W] -> px_host[n] device pointers to
+ * [B,H,W,3] (n <= SQD_MAX_SOURCES frames in one launch; H*W a multiple of 4).  No reference counterpart: the layout a batch is copied
+ * into where the photometric kernels are its only readers (trainer.py here: the static source frames of the captured step).     */
+/* 1 if sqd_identity_fwd_ex, sqd_photo_fwd (training outputs) and sqd_photo_bwd all serve SQD_SOURCES_HWC at this shape and these loss options
+ * (what a caller asks before it lays its source frames out that way), else 0.                                                   */
+int sqd_photo_sources_hwc_ok(int B, int S, int H, int W, int rows_per_task, int loss_flags);
+int sqd_pack_pixels(const float *const *planar_host, float *const *px_host, int n, int B, int H, int W, void *stream);
 int sqd_photo_ntasks(int B, int H, int W, int rows_per_task);
 int sqd_photo_fwd(const sqd_photo_args *a);
 /* which kernel sqd_photo_fwd launches on 8-wave tilings (process-wide, default 0; every choice writes the same bits — kept for

@@ -30,11 +30,12 @@
 //
 // Roofline: HBM.  Algorithmic bytes per target pixel: reads depth-lowres 1 + target 12 + sources 24 +
 // identity 8, writes depth 4 (by depth_up) + sample 16 + warped 24 + identity_selection 4 = 93 B.
-#include "sqd_common.h"
+#include "photo_launch.h"
 
 namespace {
 using namespace sqd;
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float v3f __attribute__((ext_vector_type(3)));      // (register triples as SSA vectors: float[3] members end up as private arrays)
 
 constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;
@@ -59,6 +60,10 @@ __device__ __forceinline__ float ldg(const float *__restrict__ base, unsigned by
 typedef float v2f_ua __attribute__((ext_vector_type(2), aligned(4)));
 __device__ __forceinline__ float __attribute__((ext_vector_type(2))) ldg2(const float *__restrict__ base, unsigned byte_off) {
     return *reinterpret_cast<const v2f_ua *>(reinterpret_cast<const char *>(base) + byte_off);      // 8 bytes, 4-byte aligned
+}
+typedef float v4f_ua __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ float __attribute__((ext_vector_type(4))) ldg4(const float *__restrict__ base, unsigned byte_off) {
+    return *reinterpret_cast<const v4f_ua *>(reinterpret_cast<const char *>(base) + byte_off);      // 16 bytes, 4-byte aligned
 }
 __device__ __forceinline__ void stg(float *__restrict__ base, unsigned byte_off, float v) {
     *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + byte_off) = v;
@@ -309,7 +314,7 @@ __device__ __forceinline__ float bld(__amdgpu_buffer_rsrc_t r, unsigned voff, un
     return __int_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
 
-template <int MODE, bool WIDE = false, bool NOREFL = false>
+template <int MODE, bool WIDE = false, bool NOREFL = false, bool PX = false>
 __device__ __forceinline__ void load_row(const Ctx<MODE> &k, int r, Raw &R) {
     // tile row r <-> image row y0 - 3 + r, reflected into the image (ReflectionPad2d(3), layers.py:26).  Raw buffer loads: a
     // lane outside the image (W < 64 only) carries an offset beyond the descriptor and reads zeros — no branch.
@@ -328,6 +333,11 @@ __device__ __forceinline__ void load_row(const Ctx<MODE> &k, int r, Raw &R) {
         const int rr = yr - (k.y0 - 3);
 #pragma unroll
         for (int c = 0; c < 3; ++c) R.w[c] = k.wl[(rr * 3 + c) * 64 + k.lane];
+    } else if (MODE == 0 && PX) {       // pixel-interleaved sources: the lane's three colours are 12 consecutive bytes
+        typedef unsigned u32x3 __attribute__((ext_vector_type(3)));
+        const u32x3 s0 = __builtin_amdgcn_raw_buffer_load_b96(k.p0, k.xoff * 3u, row * 3u, 0), s1 = __builtin_amdgcn_raw_buffer_load_b96(k.p1, k.xoff * 3u, row * 3u, 0);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) R.w[c] = v2f{__uint_as_float(s0[c]), __uint_as_float(s1[c])};
     } else {
 #pragma unroll
         for (int c = 0; c < 3; ++c) R.w[c] = v2f{bld(k.p0, k.xoff, row + c * k.HW * 4u), bld(k.p1, k.xoff, row + c * k.HW * 4u)};
@@ -605,7 +615,7 @@ template <int NW>
 __device__ __forceinline__ void store_warped_wide(const v2f *wl, float *__restrict__ w0, float *__restrict__ w1, int H, int W, int y0, int x0, int own_rows,
                                                   int lane, int wave, int k0 = 0, int k1 = 1 << 20);
 // phase 2 for the output rows of one wave: pairs (j, j+1) of tile rows share six of their seven window rows
-template <int MODE, int KIND, bool WIDE = false, bool FAST = false, bool NOREFL = false>
+template <int MODE, int KIND, bool WIDE = false, bool FAST = false, bool NOREFL = false, bool PX = false>
 __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const PairPass &pp, const float *noise, const Ctx<MODE> &k, bool edge, int b,
                                           int wave, int nwaves, int own_rows, bool own_col, float &loss_acc) {
     int kst = 0;
@@ -621,15 +631,15 @@ __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const PairPas
             Raw R;
 #pragma unroll
             for (int i = 1; i < 7; ++i) {
-                load_row<MODE, WIDE, NOREFL>(k, j + i, R);
+                load_row<MODE, WIDE, NOREFL, PX>(k, j + i, R);
                 accumulate_row(core, R);
             }
         }
 #pragma nounroll
         for (int o = 0; o < 2; ++o) {
             Raw R, ctr;
-            load_row<MODE, WIDE, NOREFL>(k, j + 7 * o, R);
-            load_row<MODE, WIDE, NOREFL>(k, j + 3 + o, ctr);
+            load_row<MODE, WIDE, NOREFL, PX>(k, j + 7 * o, R);
+            load_row<MODE, WIDE, NOREFL, PX>(k, j + 3 + o, ctr);
             Sums S = core;
             accumulate_row(S, R);
 #pragma unroll
@@ -745,15 +755,11 @@ struct WarpOut {
 
 // bilinear blend, the tile's LDS row, and — for cells the tile owns — sample / warped / taps in HBM
 template <bool VIRT, bool WIDE = false, bool FAST = false>
-__device__ __forceinline__ void finish_cell(const WarpOut &o, const Cell &c, const v2f t0[3][2], const v2f t1[3][2], v2f *wl, int r, int lane,
-                                            bool col_ok, bool own, unsigned HW, unsigned off) {
-    v2f wv[3];
+__device__ __forceinline__ void store_cell(const WarpOut &o, const Cell &c, const v2f wv[3], v2f *wl, int r, int lane, bool col_ok, bool own,
+                                           unsigned HW, unsigned off) {
 #pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        wv[ch] = blend_taps(c, t0[ch], t1[ch]);
-        // (lanes beyond a narrow image carry zeros for the shuffles)
+    for (int ch = 0; ch < 3; ++ch)      // (lanes beyond a narrow image carry zeros for the shuffles)
         wl[(r * 3 + ch) * 64 + lane] = (!VIRT || col_ok) ? wv[ch] : splat(0.f);
-    }
     if (own) {
         if (FAST || o.smp0) stg2(o.smp0, off * 8u, c.gx.x, c.gy.x);
         if (FAST || o.smp1) stg2(o.smp1, off * 8u, c.gx.y, c.gy.y);
@@ -769,10 +775,66 @@ __device__ __forceinline__ void finish_cell(const WarpOut &o, const Cell &c, con
         }
     }
 }
+template <bool VIRT, bool WIDE = false, bool FAST = false>
+__device__ __forceinline__ void finish_cell(const WarpOut &o, const Cell &c, const v2f t0[3][2], const v2f t1[3][2], v2f *wl, int r, int lane,
+                                            bool col_ok, bool own, unsigned HW, unsigned off) {
+    v2f wv[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) wv[ch] = blend_taps(c, t0[ch], t1[ch]);
+    store_cell<VIRT, WIDE, FAST>(o, c, wv, wl, r, lane, col_ok, own, HW, off);
+}
+
+// ---- pixel-interleaved sources (SQD_SOURCES_HWC: the frames as [B,H,W,3]) ---------------------------------------------------------------
+// The (west, east) taps of a row are 24 consecutive bytes there — R0 G0 B0 R1 | G1 B1 —: one 16-byte and one 8-byte gather per row and
+// source, EIGHT vector-memory instructions per cell instead of the planar layout's twelve (phase 1 sits on the address path at 16 clocks
+// per gather: DESIGN.md 3.1).  The blend multiplies the register pairs as they arrive — (R0, G0) by the west weights, (B0, R1) by
+// (west, east), (G1, B1) by the east weights — and adds the halves across pairs: every product and sum is the planar blend's own
+// (west = fma(s, w_sw, n * w_nw), east likewise, colour = west + east), so the two layouts give the same bits.
+struct PxTaps {
+    v4f n4, s4;                      // R0 G0 B0 R1 of the north / south row
+    v2f n2, s2;                      // G1 B1
+};
+__device__ __forceinline__ v4f bld4(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));     // 16 bytes, 4-byte aligned
+}
+__device__ __forceinline__ void gather_taps_px(const Cell &c, __amdgpu_buffer_rsrc_t r0, __amdgpu_buffer_rsrc_t r1, unsigned W12, PxTaps &t0,
+                                               PxTaps &t1) {
+    const unsigned n0 = c.o0 * 3u, n1 = c.o1 * 3u, s0 = n0 + W12, s1 = n1 + W12;
+    t0.n4 = bld4(r0, n0, 0);
+    t1.n4 = bld4(r1, n1, 0);
+    t0.s4 = bld4(r0, s0, 0);
+    t1.s4 = bld4(r1, s1, 0);
+    t0.n2 = bld2(r0, n0 + 16u, 0);
+    t1.n2 = bld2(r1, n1 + 16u, 0);
+    t0.s2 = bld2(r0, s0 + 16u, 0);
+    t1.s2 = bld2(r1, s1 + 16u, 0);
+}
+__device__ __forceinline__ float add_f32(float a, float b) {      // (out of the SLP vectorizer's reach, as hadd)
+    float r;
+    asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ void blend_px(const PxTaps &t, v2f wn, v2f ws, float &R, float &G, float &B) {
+    const v2f a = pfma(v2f{t.s4.x, t.s4.y}, splat(ws.x), v2f{t.n4.x, t.n4.y} * splat(wn.x));      // (R, G) west halves
+    const v2f b = pfma(v2f{t.s4.z, t.s4.w}, ws, v2f{t.n4.z, t.n4.w} * wn);                        // (B west, R east)
+    const v2f e = pfma(t.s2, splat(ws.y), t.n2 * splat(wn.y));                                    // (G, B) east halves
+    R = add_f32(a.x, b.y);
+    G = add_f32(a.y, e.x);
+    B = add_f32(b.x, e.y);
+}
+template <bool VIRT, bool WIDE = false, bool FAST = false>
+__device__ __forceinline__ void finish_cell_px(const WarpOut &o, const Cell &c, const PxTaps &t0, const PxTaps &t1, v2f *wl, int r, int lane,
+                                               bool col_ok, bool own, unsigned HW, unsigned off) {
+    float p[3], q[3];
+    blend_px(t0, c.wn0, c.ws0, p[0], p[1], p[2]);
+    blend_px(t1, c.wn1, c.ws1, q[0], q[1], q[2]);
+    const v2f wv[3] = {v2f{p[0], q[0]}, v2f{p[1], q[1]}, v2f{p[2], q[2]}};
+    store_cell<VIRT, WIDE, FAST>(o, c, wv, wl, r, lane, col_ok, own, HW, off);
+}
 
 // phase 1 of a tile: every cell of the tile + halo is warped once, rows dealt round-robin to the NW waves; the depth of a wave's next
 // row is fetched under the current row's projection
-template <int NW, bool VIRT, bool WIDE = false, bool FAST = false>
+template <int NW, bool VIRT, bool WIDE = false, bool FAST = false, bool PX = false>
 __device__ __forceinline__ void warp_tile(const sqd_photo_args &a, const PairPass &pp, v2f *wl, int b, int y0, int own_rows, int xr, bool col_ok,
                                           bool own_col, int lane, int wave) {
     const int H = a.H, W = a.W;
@@ -780,6 +842,7 @@ __device__ __forceinline__ void warp_tile(const sqd_photo_args &a, const PairPas
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
     const float *__restrict__ dep = a.depth + (size_t)b * HW;
     const unsigned img_bytes = 3u * HW * 4u;
+    // (PX: the same bytes per image, laid out [H,W,3])
     const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sources[pp.s0] + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t r1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.sources[pp.s1] + (size_t)b * 3 * HW), 0, img_bytes, 0x00020000);
     const bool two = pp.s1 != pp.s0;
@@ -817,9 +880,15 @@ __device__ __forceinline__ void warp_tile(const sqd_photo_args &a, const PairPas
         if (r + NW < r_hi) d_next = ldg(dep, (off + (unsigned)(NW * W)) * 4u);
         Cell c;
         project_cell(c, d, fx, (float)yA, ik, P, rW, rH, wm1, hm1, W);
-        v2f t0[3][2], t1[3][2];
-        gather_taps(c, r0, r1, HW * 4u, (unsigned)W * 4u, t0, t1);
-        finish_cell<VIRT, WIDE, FAST>(o, c, t0, t1, wl, r, lane, col_ok, own_col && r >= 3 && r < own_rows + 3, HW, off);
+        if constexpr (PX) {
+            PxTaps t0, t1;
+            gather_taps_px(c, r0, r1, (unsigned)W * 12u, t0, t1);
+            finish_cell_px<VIRT, WIDE, FAST>(o, c, t0, t1, wl, r, lane, col_ok, own_col && r >= 3 && r < own_rows + 3, HW, off);
+        } else {
+            v2f t0[3][2], t1[3][2];
+            gather_taps(c, r0, r1, HW * 4u, (unsigned)W * 4u, t0, t1);
+            finish_cell<VIRT, WIDE, FAST>(o, c, t0, t1, wl, r, lane, col_ok, own_col && r >= 3 && r < own_rows + 3, HW, off);
+        }
     }
 }
 
@@ -911,7 +980,6 @@ __device__ __forceinline__ void warp_tile_pipe(const sqd_photo_args &a, const Pa
 //  * the WARPED colours, which phase 1 has put into the LDS tile anyway, leave from there as 16-byte stores (all 64 columns of the
 //    strip: the three halo columns on either side are the neighbouring tile's own cells, warped to the same bits — the two tiles sit
 //    on the same XCD and the duplicates merge in its L2).
-typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // the same in two halves, for at most 4 units per wave (tiles of up to 36 rows + halo on 8 waves): the loads leave before phase 1's row loop
 // and land in LDS after it — their round trip (4 800 cycles in the first wide build's trace) runs under the warps
@@ -978,7 +1046,7 @@ __device__ __forceinline__ void store_warped_wide(const v2f *wl, float *__restri
 
 // (4 workgroups of 4 waves per CU: the register allocator is held to 128 VGPRs; the kernel needs 118.  NW = 8: two workgroups of 8
 //  waves on tiles of up to 32 rows — the same waves per SIMD, 38 instead of 2 x 22 warped rows per 32 output rows)
-template <int MODE, int NW, bool WIDE, bool FAST, bool PIPE = false>
+template <int MODE, int NW, bool WIDE, bool FAST, bool PIPE = false, bool PX = false>
 __device__ __forceinline__ void photo_tile_body(const sqd_photo_args &a, const PairPass &pp, const float *__restrict__ noise, const Tiling &tl, v2f *wl, int tile) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1015,7 +1083,7 @@ __device__ __forceinline__ void photo_tile_body(const sqd_photo_args &a, const P
                 stage_target_issue<NW>(sr, tgt, H, W, y0, sx.x0, r_lo, r_hi, lane, wave);
                 PHOTO_STAMP(1);
                 if constexpr (PIPE) warp_tile_pipe<NW>(a, pp, wl, b, y0, own_rows, x, own_col, lane, wave);
-                else warp_tile<NW, false, true, true>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
+                else warp_tile<NW, false, true, true, PX>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
                 stage_target_commit<NW>(sr, tt, r_lo, r_hi, lane, wave);
             } else {
                 stage_target_wide<NW>(tt, tgt, H, W, y0, sx.x0, r_lo, r_hi, lane, wave);
@@ -1062,17 +1130,17 @@ __device__ __forceinline__ void photo_tile_body(const sqd_photo_args &a, const P
     float loss_acc = 0.f;
     if (FAST && y0 >= 3 && y0 + own_rows + 3 <= H) {       // every row of the tile + halo inside the image: the reflection-free row addressing
         if (sx.kind == LEFT)
-            ssim_rows<MODE, LEFT, WIDE, FAST, true>(a, pp, noise, k, lane >= 1 && lane <= 3, b, wave, NW, own_rows, own_col, loss_acc);
+            ssim_rows<MODE, LEFT, WIDE, FAST, true, PX>(a, pp, noise, k, lane >= 1 && lane <= 3, b, wave, NW, own_rows, own_col, loss_acc);
         else if (sx.kind == RIGHT)
-            ssim_rows<MODE, RIGHT, WIDE, FAST, true>(a, pp, noise, k, lane >= 60 && lane <= 62, b, wave, NW, own_rows, own_col, loss_acc);
+            ssim_rows<MODE, RIGHT, WIDE, FAST, true, PX>(a, pp, noise, k, lane >= 60 && lane <= 62, b, wave, NW, own_rows, own_col, loss_acc);
         else
-            ssim_rows<MODE, INTERIOR, WIDE, FAST, true>(a, pp, noise, k, false, b, wave, NW, own_rows, own_col, loss_acc);
+            ssim_rows<MODE, INTERIOR, WIDE, FAST, true, PX>(a, pp, noise, k, false, b, wave, NW, own_rows, own_col, loss_acc);
     } else if (sx.kind == LEFT)
-        ssim_rows<MODE, LEFT, WIDE, FAST>(a, pp, noise, k, lane >= 1 && lane <= 3, b, wave, NW, own_rows, own_col, loss_acc);
+        ssim_rows<MODE, LEFT, WIDE, FAST, false, PX>(a, pp, noise, k, lane >= 1 && lane <= 3, b, wave, NW, own_rows, own_col, loss_acc);
     else if (sx.kind == RIGHT)
-        ssim_rows<MODE, RIGHT, WIDE, FAST>(a, pp, noise, k, lane >= 60 && lane <= 62, b, wave, NW, own_rows, own_col, loss_acc);
+        ssim_rows<MODE, RIGHT, WIDE, FAST, false, PX>(a, pp, noise, k, lane >= 60 && lane <= 62, b, wave, NW, own_rows, own_col, loss_acc);
     else
-        ssim_rows<MODE, INTERIOR, WIDE, FAST>(a, pp, noise, k, false, b, wave, NW, own_rows, own_col, loss_acc);
+        ssim_rows<MODE, INTERIOR, WIDE, FAST, false, PX>(a, pp, noise, k, false, b, wave, NW, own_rows, own_col, loss_acc);
     PHOTO_STAMP(5);
     if (MODE == 1 && a.loss_part && pp.last) {       // (8-wave tilings: 16 partials per tile — the stream kernel's one per row pair)
         loss_acc = wave_sum(loss_acc);
@@ -1082,13 +1150,13 @@ __device__ __forceinline__ void photo_tile_body(const sqd_photo_args &a, const P
         }
     }
 }
-template <int MODE, int NW = 4, bool WIDE = false, bool FAST = false, bool PIPE = false>
+template <int MODE, int NW = 4, bool WIDE = false, bool FAST = false, bool PIPE = false, bool PX = false>
 __global__ __launch_bounds__(NW * 64, 16 / NW) void photo_tile_kernel(sqd_photo_args a, PairPass pp, const float *__restrict__ noise, Tiling tl) {
     extern __shared__ v2f wl[];                       // MODE 1: [TR + 6][3][64] (source 0, source 1) warped colours (+ WIDE: [TR + 6][3][64] target)
     // consecutive tiles (which share halo rows / columns) on the same XCD: workgroup i runs on XCD i % 8
     const int tile = (blockIdx.x & 7) * tl.nblk8 + (blockIdx.x >> 3);
     if (tile >= tl.ntiles) return;
-    photo_tile_body<MODE, NW, WIDE, FAST, PIPE>(a, pp, noise, tl, wl, tile);
+    photo_tile_body<MODE, NW, WIDE, FAST, PIPE, PX>(a, pp, noise, tl, wl, tile);
 }
 // the lean forward as RESIDENT workgroups (two per CU = 64 per XCD), each walking its XCD's tile list with stride 64: the per-CU traces of
 // round 6 show a freed workgroup slot idle for ~5 000 cycles (2 us of a 45 us launch) before its successor starts
@@ -1756,6 +1824,7 @@ struct BwdPix {
 // per pixel and source: d loss / d warped (window terms G + the L1 term where this source won the pixel itself) pulled back
 // through grid_sample, Project3D and BackprojectDepth (reference layers.py:186-258; ATen grid_sampler_2d_backward).
 // Returns the contribution to g_depth; accumulates the 12 entries of g_P.
+template <bool PX = false>
 __device__ __forceinline__ float pixel_adjoint(const BwdPix &k, const float *__restrict__ src, const float *__restrict__ smp, const float *P,
                                                const float G[9], const float t[3], const float cr[3], const float X[3], bool l1on, unsigned qo,
                                                float gP[12]) {
@@ -1775,9 +1844,22 @@ __device__ __forceinline__ float pixel_adjoint(const BwdPix &k, const float *__r
     // earlier and the tap is its second element
     const unsigned o00 = (unsigned)(y0 * W + x0 - (xin ? 0 : 1)), o10 = o00 + (yin ? (unsigned)W : 0u);
     float gix = 0.f, giy = 0.f;
+    v2f pnc[3], psc[3];
+    if constexpr (PX) {      // pixel-interleaved source: the pair of a row is R0 G0 B0 R1 | G1 B1 — a 16-byte and an 8-byte gather
+        const v4f n4 = ldg4(src, o00 * 12u), s4 = ldg4(src, o10 * 12u);
+        const v2f n2 = ldg2(src, o00 * 12u + 16u), s2 = ldg2(src, o10 * 12u + 16u);
+        pnc[0] = v2f{n4.x, n4.w}; pnc[1] = v2f{n4.y, n2.x}; pnc[2] = v2f{n4.z, n2.y};
+        psc[0] = v2f{s4.x, s4.w}; psc[1] = v2f{s4.y, s2.x}; psc[2] = v2f{s4.z, s2.y};
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            pnc[c] = ldg2(src, (o00 + c * k.HW) * 4u);
+            psc[c] = ldg2(src, (o10 + c * k.HW) * 4u);
+        }
+    }
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        const v2f pn = ldg2(src, (o00 + c * k.HW) * 4u), ps = ldg2(src, (o10 + c * k.HW) * 4u);
+        const v2f pn = pnc[c], ps = psc[c];
         const float vnw = xin ? pn.x : pn.y, vne = xin ? pn.y : 0.f, vsw = yin ? (xin ? ps.x : ps.y) : 0.f, vse = (xin && yin) ? ps.y : 0.f;
         float wv = vnw * (bxw * byw);
         wv = fmaf(vne, ax * byw, wv);
@@ -1816,7 +1898,7 @@ __device__ __forceinline__ float pixel_adjoint(const BwdPix &k, const float *__r
     return cr[0] * gX[0] + cr[1] * gX[1] + cr[2] * gX[2];
 }
 
-template <bool AVG>
+template <bool AVG, bool PX = false>
 __device__ __forceinline__ void bwd_rows(int KIND, const sqd_photo_bwd_args &a, const PairPass &pp, const BwdPix &k, __amdgpu_buffer_rsrc_t coef_r,
                                          __amdgpu_buffer_rsrc_t idx_r, int lane0, int b, int wave, int y0, int own_rows, int x, bool in_col, bool own_col,
                                          int lane, float *gdep, float gP0[12], float gP1[12]) {
@@ -1909,8 +1991,8 @@ __device__ __forceinline__ void bwd_rows(int KIND, const sqd_photo_bwd_args &a, 
             cr[i] = acc;
             X[i] = d * acc;
         }
-        float g = pixel_adjoint(k, src0, smp0, P0, G0, t, cr, X, idc == id0, qo, gP0);
-        if (two) g += pixel_adjoint(k, src1, smp1, P1, G1, t, cr, X, idc == id1, qo, gP1);
+        float g = pixel_adjoint<PX>(k, src0, smp0, P0, G0, t, cr, X, idc == id0, qo, gP0);
+        if (two) g += pixel_adjoint<PX>(k, src1, smp1, P1, G1, t, cr, X, idc == id1, qo, gP1);
         gdep[qo] = g;
     }
 }
@@ -1918,7 +2000,7 @@ __device__ __forceinline__ void bwd_rows(int KIND, const sqd_photo_bwd_args &a, 
 // Two workgroups (8 waves) per CU: the scheduler is left free to batch the 70 coefficient loads of a row and both sources' tap
 // gathers (140 VGPRs).  Measured at config B (profiles/r03h_photo_bwd_variants.md): 4 waves per SIMD with the loads fenced into
 // 128 registers 95 us, 3 waves 98 us, 2 waves 74 us; tile heights 6..16 within 10 % of each other, 16 best.
-template <bool AVG>
+template <bool AVG, bool PX = false>
 __global__ __launch_bounds__(256, 2) void photo_bwd_tile_kernel(sqd_photo_bwd_args a, PairPass pp, int pass, int TR, int nsx, int nsy, int ntiles, int nblk8) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1944,7 +2026,7 @@ __global__ __launch_bounds__(256, 2) void photo_bwd_tile_kernel(sqd_photo_bwd_ar
 #pragma unroll
     for (int j = 0; j < 12; ++j) gP0[j] = gP1[j] = 0.f;
     const int lane0 = W <= 64 ? -sx.x0 : -1;                                  // >= 0: both borders inside the wavefront (generic border path)
-    bwd_rows<AVG>(lane0 >= 0 ? (int)INTERIOR : sx.kind, a, pp, k, coef_r, idx_r, lane0, b, wave, y0, own_rows, x, in_col, own_col, lane, gdep, gP0, gP1);
+    bwd_rows<AVG, PX>(lane0 >= 0 ? (int)INTERIOR : sx.kind, a, pp, k, coef_r, idx_r, lane0, b, wave, y0, own_rows, x, in_col, own_col, lane, gdep, gP0, gP1);
     // per-wavefront partials of g_P: [B][S][tiles per image * 4][12]
     const int tpi = nsx * nsy * 4, slot = (ty * nsx + tx) * 4 + wave;
 #pragma unroll
@@ -2020,25 +2102,41 @@ int photo_fwd_waves(int B, int H, int W, int rows_per_task) {      // loss parti
     const Tiling tl = make_tiling(B, H, W, rows_per_task, FAMILY_FWD);
     return tl.TR > TR_MAX ? 16 : 4;
 }
+// do the kernels of a training step (identity maps, lean forward with every training output, default backward) read [B,H,W,3] sources at this shape?
+bool photo_sources_hwc_ok(int B, int S, int H, int W, int rows_per_task, int loss_flags) {
+    const Tiling tl = make_tiling(B, H, W, rows_per_task, FAMILY_FWD);
+    return S == 2 && (loss_flags & ~SQD_SOURCES_HWC) == 0 && W >= 64 && (size_t)H * W % 4 == 0 && !g_fwd_variant && tl.TR > TR_MAX && tl.TR <= 36;
+}
 int photo_tile_count(int B, int H, int W, int rows_per_task, int family) { return make_tiling(B, H, W, rows_per_task, family).ntiles; }
 
 // mode 0: identity maps, 1: fused forward, 2: coefficient planes of the backward (a.warped = stored warps, a.idx, a.coef)
-void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hipStream_t stream) {
+int launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hipStream_t stream) {
     Tiling tl = make_tiling(a.B, a.H, a.W, a.rows_per_task, mode == 1 ? FAMILY_FWD : FAMILY_ROWS);
     tl.skew = mode == 1 ? g_fwd_skew : 0;
     tl.pipe = g_fwd_pipe;
     const int NW = mode == 1 && tl.TR > TR_MAX ? 8 : 4;
     const dim3 grid(tl.nblk8 * 8), block(NW * 64);
+    // (SQD_SOURCES_HWC travels in loss_flags)
+    const bool hwc = (a.loss_flags & SQD_SOURCES_HWC) != 0;
+    const int opts = a.loss_flags & ~SQD_SOURCES_HWC;
+    const bool lean = mode == 1 && NW == 8 && g_fwd_variant == 0 && a.W >= 64 && a.S == 2 && opts == 0 && !a.reproj && !a.x0y0[0] && !a.x0y0[1] && a.sel && a.idx &&
+                      a.sample[0] && a.sample[1] && a.warped[0] && a.warped[1] && a.identity && tl.TR <= 36;
+    if (hwc && mode != 2 && !(a.W >= 64 && a.S == 2 && opts == 0 && !g_fwd_variant && (mode == 0 || lean))) {
+        // (the kernels that read [B,H,W,3] sources: the lean forward, the option-free identity maps, the default backward)
+        set_error("SQD_SOURCES_HWC: only with two source frames, the default loss options, W >= 64, every output of the forward requested except the tap / "
+                  "reprojection dumps, and the default kernel variant");
+        return SQD_EINVAL;
+    }
     for (int k = 0; 2 * k < a.S; ++k) {                  // one launch per pair of source frames
         const PairPass pp = {2 * k, 2 * k + 1 < a.S ? 2 * k + 1 : 2 * k, a.S, k == 0, 2 * k + 2 >= a.S};
         if (mode == 0)
             // (default loss options, one pair pass: the option-free / reflection-free / hand-scheduled-shuffle paths of the lean forward)
-            if (a.loss_flags == 0 && a.S == 2 && !g_fwd_variant) hipLaunchKernelGGL((photo_tile_kernel<0, 4, false, true>), grid, block, 0, stream, a, pp, noise, tl);
+            if (hwc) hipLaunchKernelGGL((photo_tile_kernel<0, 4, false, true, false, true>), grid, block, 0, stream, a, pp, noise, tl);
+            else if (opts == 0 && a.S == 2 && !g_fwd_variant) hipLaunchKernelGGL((photo_tile_kernel<0, 4, false, true>), grid, block, 0, stream, a, pp, noise, tl);
             else hipLaunchKernelGGL((photo_tile_kernel<0>), grid, block, 0, stream, a, pp, noise, tl);
         else if (mode == 1 && NW == 8 && g_fwd_variant == 2)
             hipLaunchKernelGGL((photo_fwd_c_kernel<8>), grid, block, (tl.TR + 6) * 3 * 64 * 8, stream, a, pp, tl);
-        else if (mode == 1 && NW == 8 && g_fwd_variant == 0 && a.W >= 64 && a.S == 2 && a.loss_flags == 0 && !a.reproj && !a.x0y0[0] && !a.x0y0[1] && a.sel && a.idx &&
-                 a.sample[0] && a.sample[1] && a.warped[0] && a.warped[1] && a.identity && tl.TR <= 36) {
+        else if (lean) {
             const int lds = (tl.TR + 6) * 3 * 64 * 12;
             static int lds_ok = 0;                   // (dynamic LDS beyond 64 KB is an opt-in of the function)
             if (!lds_ok) {
@@ -2060,6 +2158,13 @@ void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hi
                     lds_ok3 = 1;
                 }
                 hipLaunchKernelGGL((photo_tile_kernel<1, 8, true, true, true>), grid, block, lds, stream, a, pp, noise, tl);
+            } else if (hwc) {                                     // pixel-interleaved sources: eight gathers per cell instead of twelve
+                static int lds_ok4 = 0;
+                if (!lds_ok4) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photo_tile_kernel<1, 8, true, true, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    lds_ok4 = 1;
+                }
+                hipLaunchKernelGGL((photo_tile_kernel<1, 8, true, true, false, true>), grid, block, lds, stream, a, pp, noise, tl);
             } else
                 hipLaunchKernelGGL((photo_tile_kernel<1, 8, true, true>), grid, block, lds, stream, a, pp, noise, tl);
         } else if (mode == 1 && NW == 8 && g_fwd_variant == 5 && a.W >= 64) {
@@ -2092,9 +2197,10 @@ void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hi
         else if (mode == 1)
             hipLaunchKernelGGL((photo_tile_kernel<1>), grid, block, (tl.TR + 6) * 3 * 64 * 8, stream, a, pp, noise, tl);
         else
-            if (a.loss_flags == 0 && a.S == 2 && !g_fwd_variant) hipLaunchKernelGGL((photo_tile_kernel<2, 4, false, true>), grid, block, 0, stream, a, pp, noise, tl);
+            if (opts == 0 && a.S == 2 && !g_fwd_variant) hipLaunchKernelGGL((photo_tile_kernel<2, 4, false, true>), grid, block, 0, stream, a, pp, noise, tl);
             else hipLaunchKernelGGL((photo_tile_kernel<2>), grid, block, 0, stream, a, pp, noise, tl);
     }
+    return SQD_OK;
 }
 
 // backward: one launch per pair of source frames; plane `pass` of g_depth receives the pair's contribution
@@ -2105,7 +2211,9 @@ void launch_photo_bwd_tile(const sqd_photo_bwd_args &a, hipStream_t stream) {
     const int nblk8 = (ntiles + 7) / 8;
     for (int k = 0; 2 * k < a.S; ++k) {
         const PairPass pp = {2 * k, 2 * k + 1 < a.S ? 2 * k + 1 : 2 * k, a.S, k == 0, 2 * k + 2 >= a.S};
-        if (a.loss_flags & SQD_LOSS_AVG_REPROJECTION)
+        if (a.loss_flags & SQD_SOURCES_HWC)      // (default loss options only: photometric.hip)
+            hipLaunchKernelGGL((photo_bwd_tile_kernel<false, true>), dim3(nblk8 * 8), dim3(256), 0, stream, a, pp, k, TR, nsx, nsy, ntiles, nblk8);
+        else if (a.loss_flags & SQD_LOSS_AVG_REPROJECTION)
             hipLaunchKernelGGL(photo_bwd_tile_kernel<true>, dim3(nblk8 * 8), dim3(256), 0, stream, a, pp, k, TR, nsx, nsy, ntiles, nblk8);
         else
             hipLaunchKernelGGL(photo_bwd_tile_kernel<false>, dim3(nblk8 * 8), dim3(256), 0, stream, a, pp, k, TR, nsx, nsy, ntiles, nblk8);

@@ -5,7 +5,7 @@
 //
 // Roofline: HBM.  Algorithmic bytes per target pixel (S = 2): backward 84 B + the 36 B/px coefficient
 // planes photo_coef writes and the backward kernel reads.
-#include "sqd_common.h"
+#include "photo_launch.h"
 
 namespace {
 using namespace sqd;
@@ -43,7 +43,8 @@ extern "C" int sqd_photo_bwd_ntasks(int B, int S, int H, int W, int rows_per_tas
 }
 
 static int check_loss_flags(const char *who, int flags, int S) {
-    SQD_CHECK_ARG((flags & ~7) == 0, "%s: unknown loss_flags %d", who, flags);
+    SQD_CHECK_ARG((flags & ~(7 | SQD_SOURCES_HWC)) == 0, "%s: unknown loss_flags %d", who, flags);
+    SQD_CHECK_ARG(!(flags & SQD_SOURCES_HWC) || ((flags & 7) == 0 && S == 2), "%s: SQD_SOURCES_HWC goes with the default loss options and two source frames (loss_flags %d, S=%d)", who, flags, S);
     SQD_CHECK_ARG(!(flags & SQD_LOSS_AVG_REPROJECTION) || S >= 2, "%s: avg_reprojection needs at least two source frames (the mean over one is that frame: drop the flag; S=%d)", who, S);
     return SQD_OK;
 }
@@ -62,7 +63,7 @@ extern "C" int sqd_photo_fwd(const sqd_photo_args *a) {
     for (int s = 0; s < a->S; ++s) SQD_CHECK_ARG(a->sources[s], "sqd_photo_fwd: null source %d", s);
     SQD_CHECK_ARG(a->S <= 2 || (a->sel && a->idx), "sqd_photo_fwd: more than 2 source frames need the sel and idx outputs (running minimum)");
     (void)hipGetLastError();
-    sqd::launch_photo_tile(*a, nullptr, 1, (hipStream_t)a->stream);
+    if (sqd::launch_photo_tile(*a, nullptr, 1, (hipStream_t)a->stream)) return SQD_EINVAL;
     SQD_CHECK_LAUNCH("sqd_photo_fwd");
     return SQD_OK;
 }
@@ -86,8 +87,55 @@ extern "C" int sqd_identity_fwd_ex(const float *target, const float *const *sour
     a.sel = identity;   // MODE 0 writes its [B,S,H,W] output through `sel`
     a.B = B; a.S = S; a.H = H; a.W = W; a.rows_per_task = rows_per_task; a.loss_flags = loss_flags;
     (void)hipGetLastError();
-    sqd::launch_photo_tile(a, noise, 0, (hipStream_t)stream);
+    if (sqd::launch_photo_tile(a, noise, 0, (hipStream_t)stream)) return SQD_EINVAL;
     SQD_CHECK_LAUNCH("sqd_identity_fwd");
+    return SQD_OK;
+}
+
+// ---- pixel-interleaved copies of the source frames (SQD_SOURCES_HWC) -------------------------------------------------------------------
+// [B,3,H,W] -> [B,H,W,3]: a thread takes four pixels — one 16-byte load per colour plane, three 16-byte stores (48 consecutive bytes).  HBM:
+// 24 bytes per pixel and frame.  n frames per launch (blockIdx.y).
+namespace {
+struct PackPtrs {
+    const float *in[SQD_MAX_SOURCES];
+    float *out[SQD_MAX_SOURCES];
+};
+__global__ __launch_bounds__(256) void pack_pixels_kernel(PackPtrs p, int HW4, int B) {
+    const float *__restrict__ in = p.in[blockIdx.y];
+    float *__restrict__ out = p.out[blockIdx.y];
+    const size_t n = (size_t)B * HW4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const size_t b = i / HW4, q = i - b * HW4;
+        const float4 *src = reinterpret_cast<const float4 *>(in + b * 3 * 4 * (size_t)HW4) + q;
+        const float4 r = src[0], g = src[HW4], bl = src[2 * (size_t)HW4];
+        float4 *dst = reinterpret_cast<float4 *>(out) + i * 3;
+        dst[0] = make_float4(r.x, g.x, bl.x, r.y);
+        dst[1] = make_float4(g.y, bl.y, r.z, g.z);
+        dst[2] = make_float4(bl.z, r.w, g.w, bl.w);
+    }
+}
+}  // namespace
+
+extern "C" int sqd_photo_sources_hwc_ok(int B, int S, int H, int W, int rows_per_task, int loss_flags) {
+    return B > 0 && H > 0 && W > 0 && sqd::photo_sources_hwc_ok(B, S, H, W, rows_per_task, loss_flags) ? 1 : 0;
+}
+
+extern "C" int sqd_pack_pixels(const float *const *planar, float *const *px, int n, int B, int H, int W, void *stream) {
+    SQD_CHECK_ARG(planar && px, "sqd_pack_pixels: null pointer");
+    SQD_CHECK_ARG(n >= 1 && n <= SQD_MAX_SOURCES, "sqd_pack_pixels: %d frames (1..%d)", n, SQD_MAX_SOURCES);
+    SQD_CHECK_ARG(B > 0 && H > 0 && W > 0 && (size_t)H * W % 4 == 0 && (size_t)B * 3 * H * W < (1ull << 31), "sqd_pack_pixels: bad shape %dx3x%dx%d (H*W a multiple of 4)", B, H, W);
+    PackPtrs p = {};
+    for (int i = 0; i < n; ++i) {
+        SQD_CHECK_ARG(planar[i] && px[i], "sqd_pack_pixels: null frame %d", i);
+        p.in[i] = planar[i];
+        p.out[i] = px[i];
+    }
+    const int HW4 = H * W / 4;
+    const size_t total = (size_t)B * HW4;
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(pack_pixels_kernel, dim3(blocks, n), dim3(256), 0, (hipStream_t)stream, p, HW4, B);
+    SQD_CHECK_LAUNCH("sqd_pack_pixels");
     return SQD_OK;
 }
 
@@ -111,7 +159,7 @@ extern "C" int sqd_photo_coef_ex(const float *target, const float *const *warped
     a.coef = coef;
     a.B = B; a.S = S; a.H = H; a.W = W; a.rows_per_task = rows_per_task; a.loss_flags = loss_flags;
     (void)hipGetLastError();
-    sqd::launch_photo_tile(a, nullptr, 2, (hipStream_t)stream);
+    if (sqd::launch_photo_tile(a, nullptr, 2, (hipStream_t)stream)) return SQD_EINVAL;
     SQD_CHECK_LAUNCH("sqd_photo_coef");
     return SQD_OK;
 }
@@ -123,6 +171,7 @@ extern "C" int sqd_photo_bwd(const sqd_photo_bwd_args *a) {
     if (check_shape("sqd_photo_bwd", a->B, a->S, a->H, a->W, 8)) return SQD_EINVAL;
     if (check_loss_flags("sqd_photo_bwd", a->loss_flags, a->S)) return SQD_EINVAL;
     SQD_CHECK_ARG(a->rows_per_task >= 0, "sqd_photo_bwd: rows_per_task=%d", a->rows_per_task);
+    SQD_CHECK_ARG(!(a->loss_flags & SQD_SOURCES_HWC) || a->W >= 64, "sqd_photo_bwd: SQD_SOURCES_HWC needs W >= 64 (W=%d)", a->W);
     SQD_CHECK_ARG(a->g_depth_img_stride >= (int64_t)((a->S + 1) / 2) * a->H * a->W, "sqd_photo_bwd: g_depth_img_stride too small");
     (void)hipGetLastError();
     sqd::launch_photo_bwd_tile(*a, (hipStream_t)a->stream);

@@ -13,12 +13,6 @@ namespace sqd {
 
 void set_error(const char *fmt, ...);
 
-// photo_tile.hip: fused warp+SSIM forward (mode 1) / identity maps (mode 0) / coefficient planes for the backward (mode 2)
-void launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hipStream_t stream);
-int photo_tile_count(int B, int H, int W, int rows_per_task, int family);      // family: 1 fused forward, 0 identity / coefficients, 2 backward
-int photo_fwd_waves(int B, int H, int W, int rows_per_task);
-void launch_photo_bwd_tile(const sqd_photo_bwd_args &a, hipStream_t stream);
-
 #define SQD_CHECK_ARG(cond, ...)            \
     do {                                    \
         if (!(cond)) {                      \

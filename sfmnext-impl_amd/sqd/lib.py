@@ -23,9 +23,10 @@ HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"
 
 c_float_p = ctypes.POINTER(ctypes.c_float)
 c_void_p = ctypes.c_void_p
-ABI_VERSION = 2   # SQD_ABI_VERSION of include/sqd.h this binding was written against
+ABI_VERSION = 3   # SQD_ABI_VERSION of include/sqd.h this binding was written against
 # SQD_LOSS_* (include/sqd.h): the reference's --no_ssim / --avg_reprojection / --disable_automasking
 LOSS_NO_SSIM, LOSS_AVG_REPROJECTION, LOSS_NO_AUTOMASK = 1, 2, 4
+SOURCES_HWC = 256       # SQD_SOURCES_HWC: the layout bit that travels with the loss options (source frames in [B,H,W,3] memory)
 
 
 def loss_flags(no_ssim=False, avg_reprojection=False, disable_automasking=False):
@@ -137,6 +138,8 @@ _SIGNATURES = {
     "sqd_photo_ntasks": (_I, [_I, _I, _I, _I]),
     "sqd_photo_fwd": (_I, [ctypes.POINTER(PhotoArgs)]),
     "sqd_photo_set_fwd_variant": (_I, [_I]),
+    "sqd_photo_sources_hwc_ok": (_I, [_I, _I, _I, _I, _I, _I]),
+    "sqd_pack_pixels": (_I, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p), _I, _I, _I, _I, _P]),
     "sqd_identity_fwd": (_I, [_P, ctypes.POINTER(c_void_p), _P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_photo_coef": (_I, [_P, ctypes.POINTER(c_void_p), _P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_identity_fwd_ex": (_I, [_P, ctypes.POINTER(c_void_p), _P, _P, _I, _I, _I, _I, _I, _I, _P]),

@@ -37,6 +37,20 @@ def _req(*ts):
             raise RuntimeError("sqd: unsupported dtype %s" % t.dtype)
 
 
+def _sources_layout(sources):
+    """0 for [B,3,H,W] frames in planar memory, lib.SOURCES_HWC for frames whose MEMORY is [B,H,W,3] (torch.channels_last tensors of the same
+    shape: pack_pixels, or the static source frames of the captured step) — all frames of a call in the same layout."""
+    hwc = [not f.is_contiguous() and f.dim() == 4 and f.is_contiguous(memory_format=torch.channels_last) for f in sources]
+    for f, h in zip(sources, hwc):
+        if not h:
+            _req(f)
+        elif not f.is_cuda or f.dtype != torch.float32:
+            raise RuntimeError("sqd: source frames must be float32 tensors on the device")
+    if any(hwc) and not all(hwc):
+        raise RuntimeError("sqd: the source frames of a call must share a memory layout (planar or channels_last)")
+    return _l.SOURCES_HWC if hwc and all(hwc) else 0
+
+
 def _i32arr(vals):
     return (ctypes.c_int32 * len(vals))(*[int(v) for v in vals])
 
@@ -92,7 +106,8 @@ def pose_mats_bwd(axisangle, translation, invert, K, mid, g_P):
 def identity_fwd(target, sources, noise=None, rows_per_task=0, loss_flags=0):
     """Identity reprojection losses + 1e-5*noise -> [B,S,H,W]  (trainer.py:480-487,514-517).  Under LOSS_AVG_REPROJECTION the result is
     [B,1,H,W]: the mean over the sources + 1e-5 * noise [B,1,H,W] (trainer.py:489-490)."""
-    _req(target, noise, *sources)
+    _req(target, noise)
+    loss_flags |= _sources_layout(sources)
     B, _, H, W = target.shape
     S = len(sources)
     NI = 1 if loss_flags & _l.LOSS_AVG_REPROJECTION else S
@@ -112,10 +127,34 @@ PHOTO_FWD_KERNEL_NAME = "photo_tile_kernel<1> (fused warp + SSIM + L1 + min/auto
 PHOTO_FWD_EVENTS = None      # a list: photo_fwd brackets its launch with HIP events on the launch stream and appends the pair
 
 
+def sources_hwc_ok(B, S, H, W, rows_per_task=0, loss_flags=0):
+    """do the photometric kernels of a training step read channels_last source frames at this shape / these loss options?"""
+    return bool(_l.lib().sqd_photo_sources_hwc_ok(B, S, H, W, rows_per_task, loss_flags))
+
+
+def pack_pixels(frames, out=None):
+    """Planar [B,3,H,W] frames -> the same frames as channels_last tensors (memory [B,H,W,3]; one launch for up to MAX_SOURCES frames):
+    the layout identity_fwd / photo_fwd / photo_bwd read with fewer gathers (SQD_SOURCES_HWC; they recognise it by the strides)."""
+    _req(*frames)
+    B, _, H, W = frames[0].shape
+    if out is None:
+        out = [torch.empty(B, 3, H, W, device=f.device, dtype=torch.float32, memory_format=torch.channels_last) for f in frames]
+    for o in out:
+        if tuple(o.shape) != (B, 3, H, W) or not o.is_contiguous(memory_format=torch.channels_last) or o.dtype != torch.float32 or not o.is_cuda:
+            raise ValueError("pack_pixels: outputs must be float32 channels_last device tensors of the frames' shape")
+    n = len(frames)
+    src = (ctypes.c_void_p * n)(*[f.data_ptr() for f in frames])
+    dst = (ctypes.c_void_p * n)(*[o.data_ptr() for o in out])
+    _l.check(_l.lib().sqd_pack_pixels(src, dst, n, B, H, W, _stream()), "pack_pixels")
+    return out
+
+
 def photo_fwd(depth, inv_K, P, target, sources, identity, training=True, want_taps=False, want_reproj=False,
               rows_per_task=0, prepared_only=False, loss_flags=0):
-    """Fused warp + SSIM/L1 + min/auto-mask.  Returns a dict of device tensors.  `identity` may be None under LOSS_NO_AUTOMASK."""
-    _req(depth, inv_K, P, target, *sources)
+    """Fused warp + SSIM/L1 + min/auto-mask.  Returns a dict of device tensors.  `identity` may be None under LOSS_NO_AUTOMASK.
+    Source frames in channels_last memory (pack_pixels) are read as such: fewer gathers, same bits."""
+    _req(depth, inv_K, P, target)
+    loss_flags |= _sources_layout(sources)
     if identity is not None:
         _req(identity)
     B, _, H, W = target.shape
@@ -180,12 +219,13 @@ def photo_coef(target, warped, idx, rows_per_task=0, loss_flags=0):
 
 def photo_bwd(depth, inv_K, P, target, sources, samples, warped, idx, gscale, rows_per_task=0, extra_planes=0, loss_flags=0):
     """-> g_depth [B,ceil(S/2)+extra_planes,H,W] (plane k = the pair of sources 2k, 2k+1; extra planes left unwritten), g_P [B,S,3,4]."""
-    _req(depth, inv_K, P, target, idx, *sources, *samples, *warped)
+    _req(depth, inv_K, P, target, idx, *samples, *warped)
     B, _, H, W = target.shape
     S = len(sources)
     dev = target.device
     L = _l.lib()
     coef = photo_coef(target, warped, idx, rows_per_task, loss_flags)
+    loss_flags |= _sources_layout(sources)
     nt = L.sqd_photo_bwd_ntasks(B, S, H, W, rows_per_task)
     g_depth = torch.empty(B, (S + 1) // 2 + extra_planes, H, W, device=dev, dtype=torch.float32)
     part = torch.empty(nt, 12, device=dev, dtype=torch.float32)

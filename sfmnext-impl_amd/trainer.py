@@ -259,11 +259,14 @@ class Trainer:
                 return self._train_step_eager(inputs)
         # every batch is copied into the graph's input tensors (a loader never feeds one twice): device-resident tensors of the static
         # tensors' dtype in ONE multi-tensor launch, whatever else (host tensors: a loader's pinned batch) one by one
-        dst, src = [], []
+        dst, src, pk_dst, pk_src = [], [], [], []
         for k, v in inputs.items():
             st = self._static_in[k]
             if v is not st:
-                if v.is_cuda and v.dtype == st.dtype and v.shape == st.shape:
+                if v.is_cuda and v.dtype == st.dtype and v.shape == st.shape and k in self._hwc_keys and v.is_contiguous():
+                    pk_dst.append(st)             # planar batch -> the channels_last static frame: one transposing launch for all of them
+                    pk_src.append(v)
+                elif v.is_cuda and v.dtype == st.dtype and v.shape == st.shape and k not in self._hwc_keys:
                     dst.append(st)
                     src.append(v)
                 else:
@@ -271,6 +274,8 @@ class Trainer:
             inputs[k] = st                        # as process_batch does in eager mode: the caller's dict now holds device tensors
         if dst:
             torch._foreach_copy_(dst, src)
+        if pk_dst:
+            ops.pack_pixels(pk_src, out=pk_dst)
         if self.reducer is None or self.opt.sqd_graph_ddp != "post":
             self.model_optimizer.refresh_hyper()
             self._graph.replay()                # forward, backward (+ bucketed all-reduces overlapped with it), Adam
@@ -309,6 +314,16 @@ class Trainer:
         """One hipGraph for process_batch + backward + Adam.  The ~1200 kernel launches of a step then cost one graph
         launch on the host (eager: ~23 ms of host time per 26 ms step)."""
         self._static_in = {k: v.to(self.device).clone() for k, v in inputs.items()}
+        # the full-resolution source frames have the photometric kernels as their only readers, and those fetch a pixel's taps with fewer
+        # gathers from [B,H,W,3] memory: the step's static copies of these frames are channels_last tensors (same shape, same values — the
+        # copy-in of a batch transposes instead of copying, sqd_pack_pixels), where every kernel of the chain reads that layout
+        self._hwc_keys = []
+        o = self.opt
+        src_ids = [f for f in o.frame_ids[1:]]
+        if "s" not in src_ids and ops.sources_hwc_ok(o.batch_size, len(src_ids), o.height, o.width, 0, self._loss_flags()):
+            self._hwc_keys = [("color", f, 0) for f in src_ids if ("color", f, 0) in self._static_in]
+            for k in self._hwc_keys:
+                self._static_in[k] = self._static_in[k].contiguous(memory_format=torch.channels_last)
         if self.reducer is not None and self.opt.sqd_graph_ddp == "post":
             return self._capture_fwd_bwd()
         opt = self.model_optimizer
@@ -624,7 +639,8 @@ class Trainer:
         meta = dict(H=o.height, W=o.width, invert=[1 if (f < 0 and not all_stereo) else 0 for f in pose_ids], smooth_weight=o.disparity_smoothness,
                     use_stereo=bool(o.use_stereo), stereo_T=inputs["stereo_T"] if "s" in srcs_ids else None,
                     loss_flags=self._loss_flags())
-        srcs = [inputs[("color", f, 0)].contiguous() for f in srcs_ids]
+        # (channels_last frames — the captured step's static source frames — go through as they are: the chain's kernels read that layout)
+        srcs = [t if t.is_contiguous(memory_format=torch.channels_last) else t.contiguous() for t in (inputs[("color", f, 0)] for f in srcs_ids)]
         res = ops.PhotometricChain.apply(outputs[("disp", 0)].contiguous(), aa, tr, inputs[("K", 0)].contiguous(),
                                          inputs[("inv_K", 0)].contiguous(), inputs[("color", 0, 0)].contiguous(),
                                          identity, meta, *srcs)

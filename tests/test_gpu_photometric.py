@@ -188,6 +188,57 @@ def test_forward_kernel_variants_agree(ops, B, H, W):
         assert abs(a - b) <= 1e-6 * abs(b), (v, a, b)
 
 
+@pytest.mark.parametrize("B,H,W", [(12, 192, 640), (3, 96, 320), (2, 320, 1024), (1, 64, 64)])
+def test_channels_last_sources_same_bits(ops, B, H, W):
+    """source frames in [B,H,W,3] memory (SQD_SOURCES_HWC: ops recognise channels_last tensors by their strides; pack_pixels makes them):
+    identity maps, every output of the fused forward and both gradients of the backward are those of the planar frames, bit for bit —
+    the 2 x 2 taps are fetched as 16 + 8 bytes per row instead of three pairs, every product and sum is the same."""
+    d = chain_inputs(53, B, H, W)
+    depth, part = ops.depth_up_fwd(dev(d["disp"]), H, W)
+    aa, tr = _full_size_P(B, 2, 11)
+    mid, T, P = ops.pose_mats_fwd(aa.cuda(), tr.cuda(), [1, 0], dev(d["K"]), part, H * W)
+    tgt, srcs = dev(d["color0"]), [dev(d["color_s0"]), dev(d["color_s1"])]
+    px = ops.pack_pixels(srcs)
+    for p, f in zip(px, srcs):
+        assert p.shape == f.shape and p.is_contiguous(memory_format=torch.channels_last) and torch.equal(p, f)
+    noise = dev(d["noise"])
+    ident = ops.identity_fwd(tgt, srcs, noise, 0)
+    assert torch.equal(ops.identity_fwd(tgt, px, noise, 0), ident)
+    a = ops.photo_fwd(depth, dev(d["inv_K"]), P, tgt, srcs, ident)
+    b = ops.photo_fwd(depth, dev(d["inv_K"]), P, tgt, px, ident)
+    assert torch.equal(a["sel"], b["sel"]) and torch.equal(a["idx"], b["idx"]) and torch.equal(a["loss_part"], b["loss_part"])
+    for k in ("sample", "warped"):
+        assert all(torch.equal(x, y) for x, y in zip(a[k], b[k])), k
+    ga = ops.photo_bwd(depth, dev(d["inv_K"]), P, tgt, srcs, a["sample"], a["warped"], a["idx"], 1.0 / (B * H * W))
+    gb = ops.photo_bwd(depth, dev(d["inv_K"]), P, tgt, px, a["sample"], a["warped"], a["idx"], 1.0 / (B * H * W))
+    assert torch.equal(ga[0], gb[0]) and torch.equal(ga[1], gb[1])
+
+
+def test_channels_last_sources_refused_where_no_kernel_reads_them(ops):
+    """launches only the planar kernels serve (loss options, tap dumps, three sources, narrow images, mixed layouts) raise instead of
+    reading [B,H,W,3] memory as planes."""
+    from sqd import lib as _l
+    B, H, W = 2, 64, 96
+    d = chain_inputs(59, B, H, W)
+    depth, part = ops.depth_up_fwd(dev(d["disp"]), H, W)
+    aa, tr = _full_size_P(B, 2, 13)
+    mid, T, P = ops.pose_mats_fwd(aa.cuda(), tr.cuda(), [1, 0], dev(d["K"]), part, H * W)
+    tgt, srcs = dev(d["color0"]), [dev(d["color_s0"]), dev(d["color_s1"])]
+    px = ops.pack_pixels(srcs)
+    ident = ops.identity_fwd(tgt, px, dev(d["noise"]), 0)
+    with pytest.raises(RuntimeError, match="SQD_SOURCES_HWC"):
+        ops.photo_fwd(depth, dev(d["inv_K"]), P, tgt, px, ident, want_taps=True)
+    with pytest.raises(RuntimeError, match="SQD_SOURCES_HWC"):
+        ops.photo_fwd(depth, dev(d["inv_K"]), P, tgt, px, ident, loss_flags=_l.LOSS_NO_SSIM)
+    with pytest.raises(RuntimeError, match="SQD_SOURCES_HWC"):
+        ops.identity_fwd(tgt, px + px[:1], None, 0)
+    with pytest.raises(RuntimeError, match="share a memory layout"):
+        ops.photo_fwd(depth, dev(d["inv_K"]), P, tgt, [px[0], srcs[1]], ident)
+    small = [torch.rand(1, 3, 16, 32, device="cuda") for _ in range(3)]
+    with pytest.raises(RuntimeError, match="SQD_SOURCES_HWC"):
+        ops.identity_fwd(small[0], ops.pack_pixels(small[1:]), None, 0)
+
+
 def test_pose_mats(ops, O):
     B, H, W = 3, 24, 80
     d = chain_inputs(31, B, H, W)

@@ -130,7 +130,7 @@ def test_abi_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(L, name), "libsqd.so lacks %s declared in include/sqd.h" % name
     assert set(lib.exported_symbols()) == declared, set(lib.exported_symbols()) ^ declared
-    assert L.sqd_abi_version() == 2
+    assert L.sqd_abi_version() == lib.ABI_VERSION == 3
 
 
 def test_product_ops_refuse_cpu_tensors():
