@@ -120,7 +120,7 @@ int sqd_photo_fwd(const sqd_photo_args *a);
 /* which kernel sqd_photo_fwd launches on 8-wave tilings (process-wide, default 0; every choice writes the same bits — kept for
  * same-box A/B runs and tests/test_gpu_photometric.py::test_forward_kernel_variants_agree).  Bits 0-5: 0 = the lean kernel where the launch
  * qualifies (S = 2, loss_flags 0, no tap / reprojection dumps, W >= 64), round 5's kernel otherwise; 1 = round 5's kernel; 2 = colour-serial
- * phase 2; 4 = wide accesses only; 5 = dynamic wave roles.  Bit 6 (0x40): lean kernel with two rows of a wave in flight in phase 1;
+ * phase 2; 4 = wide accesses only; 5 = dynamic wave roles; 6 = lean kernel with the rows that do not fill a round of its waves warped behind the barrier.  Bit 6 (0x40): lean kernel with two rows of a wave in flight in phase 1;
  * bit 7 (0x80): lean kernel as resident workgroups; bits 8..: cycles / 256 the second workgroup of a CU waits at its start.  DESIGN.md 3.1. */
 int sqd_photo_set_fwd_variant(int variant);
 

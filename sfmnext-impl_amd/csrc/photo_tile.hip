@@ -267,6 +267,7 @@ struct Tiling {
     int n_lo, n_hi_cols;
     int skew;          // fused forward: cycles the second workgroup of a CU waits at its start (0: none)
     int pipe;          // lean forward: two rows of a wave in flight in phase 1 (warp_tile_pipe)
+    int late;          // lean forward: the rows that do not fill a round of the waves are warped after the barrier (warp_tile)
 };
 __device__ __forceinline__ void tile_of(const Tiling &tl, int tile, int H, int &b, int &tx, int &y0, int &own_rows) {
     if (tl.n_lo <= 0) {
@@ -307,6 +308,8 @@ struct Ctx {
     uint8_t *idxp;
     float *w0, *w1;                   //   and of the warped outputs
     int H, W, y0, x, lane;            // tile's first owned row, this lane's column
+    const int *late_ctr = nullptr;    // MODE 1, fast edition: LDS count of the late rows warped so far, the first late tile row, their number (warp_tile)
+    int late_r0 = 1 << 20, late_n = 0;
     unsigned HW;
     unsigned xoff;                    // byte offset of the lane's column — beyond every buffer for lanes outside the image
 };
@@ -619,8 +622,15 @@ template <int MODE, int KIND, bool WIDE = false, bool FAST = false, bool NOREFL 
 __device__ __forceinline__ void ssim_rows(const sqd_photo_args &a, const PairPass &pp, const float *noise, const Ctx<MODE> &k, bool edge, int b,
                                           int wave, int nwaves, int own_rows, bool own_col, float &loss_acc) {
     int kst = 0;
+    bool late_seen = !(MODE == 1 && FAST) || k.late_n == 0;
     for (int p = wave; 2 * p < own_rows; p += nwaves) {
         const int j = 2 * p;                         // tile rows j .. j+7 feed the outputs y0+j (centre j+3) and y0+j+1 (centre j+4)
+        if constexpr (MODE == 1 && FAST) {
+            if (!late_seen && (!NOREFL || j + 8 > k.late_r0)) {      // this pair's window reaches a row warped after the barrier (warp_tile)
+                while (__hip_atomic_load(k.late_ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < k.late_n) __builtin_amdgcn_s_sleep(2);
+                late_seen = true;
+            }
+        }
         if constexpr (MODE == 1 && FAST) {           // three of the wave's 16-byte warped-store iterations per row pair (<= 6 in all: tiles of <= 64 rows)
             store_warped_wide<8>(k.wl, k.w0, k.w1, k.H, k.W, k.y0, k.x - k.lane, own_rows, k.lane, wave, kst, kst + 3);
             kst += 3;
@@ -834,9 +844,23 @@ __device__ __forceinline__ void finish_cell_px(const WarpOut &o, const Cell &c, 
 
 // phase 1 of a tile: every cell of the tile + halo is warped once, rows dealt round-robin to the NW waves; the depth of a wave's next
 // row is fetched under the current row's projection
-template <int NW, bool VIRT, bool WIDE = false, bool FAST = false, bool PX = false>
+// LATE ROWS (lean forward, Tiling::late — sqd_photo_set_fwd_variant(6); off by default): a 28-row tile warps 34 rows — four rounds of the
+// eight waves and two rows more, a fifth round of waves 0 and 1 with the other six waiting at the barrier, in front of a phase 2 in which
+// those same two waves own two row pairs and waves 6 and 7 one.  With late rows the rounds that fill all waves run before the barrier; the
+// rows left over go to the LAST waves (the ones with a row pair less), which warp them AFTER the barrier while the others are in phase 2,
+// and count them done in an LDS word; a row pair whose window reaches a late row (the tile's last pairs; every pair of a tile that
+// reflects rows) waits for that count first — by then it has long been reached.  Measured (profiles/r06h): the same bits, the same
+// 40.5 us, and still 2 900 cycles of a wave's median at the barrier — the waves of a round do not finish together whatever their row
+// counts; the launch follows the CU's VALU issue (phase 2's 126 half-rate shuffles per row), not a wave's critical path.  `mid` = what
+// the caller does between the phases (target staging commit, barrier).  Hands back the first late tile row (LATE_NONE: none) and their number.
+struct NoMid {
+    __device__ __forceinline__ void operator()() const {}
+};
+constexpr int LATE_NONE = 1 << 20;
+template <int NW, bool VIRT, bool WIDE = false, bool FAST = false, bool PX = false, typename Mid = NoMid>
 __device__ __forceinline__ void warp_tile(const sqd_photo_args &a, const PairPass &pp, v2f *wl, int b, int y0, int own_rows, int xr, bool col_ok,
-                                          bool own_col, int lane, int wave) {
+                                          bool own_col, int lane, int wave, int *late_ctr = nullptr, int *late_r0 = nullptr, int *late_n = nullptr,
+                                          Mid mid = Mid()) {
     const int H = a.H, W = a.W;
     const unsigned HW = (unsigned)(H * W);
     const float wm1 = (float)(W - 1), hm1 = (float)(H - 1);
@@ -871,13 +895,18 @@ __device__ __forceinline__ void warp_tile(const sqd_photo_args &a, const PairPas
     const float fx = (float)xc;
     // rows of the tile + halo that lie inside the image (rows outside are reflections of rows inside the tile): r_lo .. r_hi
     const int r_lo = max(0, 3 - y0), r_hi = min(own_rows + 6, H - y0 + 3);
-    int r = r_lo + wave;
-    float d_next = r < r_hi ? ldg(dep, (unsigned)((y0 - 3 + r) * W + xc) * 4u) : 0.f;
-    for (; r < r_hi; r += NW) {
+    // late rows: what is left after the rounds that fill all waves, if the owned rows (whose warped colours the waves store from LDS
+    // right after the barrier) are not among them
+    int n_late = 0;
+    if (FAST && late_ctr) {
+        const int n = (r_hi - r_lo) % NW;
+        if (n > 0 && r_hi - r_lo > NW && own_rows + 3 <= r_hi - n) n_late = n;
+    }
+    const int r_main = r_hi - n_late;
+    const int r_mine = n_late && wave >= NW - n_late ? r_main + (NW - 1 - wave) : -1;      // the last wave takes the first late row
+    auto warp_row = [&](int r, float d) {
         const int yA = y0 - 3 + r;
         const unsigned off = (unsigned)(yA * W + xc);
-        const float d = d_next;
-        if (r + NW < r_hi) d_next = ldg(dep, (off + (unsigned)(NW * W)) * 4u);
         Cell c;
         project_cell(c, d, fx, (float)yA, ik, P, rW, rH, wm1, hm1, W);
         if constexpr (PX) {
@@ -889,6 +918,27 @@ __device__ __forceinline__ void warp_tile(const sqd_photo_args &a, const PairPas
             gather_taps(c, r0, r1, HW * 4u, (unsigned)W * 4u, t0, t1);
             finish_cell<VIRT, WIDE, FAST>(o, c, t0, t1, wl, r, lane, col_ok, own_col && r >= 3 && r < own_rows + 3, HW, off);
         }
+    };
+    int r = r_lo + wave;
+    float d_next = r < r_main ? ldg(dep, (unsigned)((y0 - 3 + r) * W + xc) * 4u) : 0.f;
+    const float d_late = r_mine >= 0 ? ldg(dep, (unsigned)((y0 - 3 + r_mine) * W + xc) * 4u) : 0.f;
+    for (; r < r_main; r += NW) {
+        const float d = d_next;
+        if (r + NW < r_main) d_next = ldg(dep, (unsigned)((y0 - 3 + r + NW) * W + xc) * 4u);
+        warp_row(r, d);
+    }
+    if constexpr (FAST) {
+        if (late_ctr && threadIdx.x == 0) *late_ctr = 0;
+        mid();
+        if (r_mine >= 0) {
+            warp_row(r_mine, d_late);
+            // (the row's LDS writes and this increment are DS operations of one wave: they execute in order)
+            if (lane == 0) __hip_atomic_fetch_add(late_ctr, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        if (late_r0) {
+            *late_r0 = n_late ? r_main : LATE_NONE;
+            *late_n = n_late;
+        }
     }
 }
 
@@ -898,9 +948,10 @@ __device__ __forceinline__ void warp_tile(const sqd_photo_args &a, const PairPas
 // per CU, 16 000 with two).  Grid stores before the gathers, warped colours to LDS only (store_warped_wide).
 struct WarpRow {
     v2f t0[3][2], t1[3][2];
+    PxTaps p0, p1;                   // (pixel-interleaved sources)
     v2f wn0, ws0, wn1, ws1;
 };
-template <int NW>
+template <int NW, bool PX = false>
 __device__ __forceinline__ void warp_tile_pipe(const sqd_photo_args &a, const PairPass &pp, v2f *wl, int b, int y0, int own_rows, int x, bool own_col, int lane,
                                                int wave) {
     const int H = a.H, W = a.W;
@@ -936,6 +987,10 @@ __device__ __forceinline__ void warp_tile_pipe(const sqd_photo_args &a, const Pa
             stg2(smp1, off * 8u, c.gx.y, c.gy.y);
         }
         f.wn0 = c.wn0; f.ws0 = c.ws0; f.wn1 = c.wn1; f.ws1 = c.ws1;
+        if constexpr (PX) {
+            gather_taps_px(c, r0, r1, (unsigned)W * 12u, f.p0, f.p1);
+            return;
+        }
         const unsigned s0 = c.o0 + W4, s1 = c.o1 + W4;
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
@@ -946,6 +1001,14 @@ __device__ __forceinline__ void warp_tile_pipe(const sqd_photo_args &a, const Pa
         }
     };
     auto finish = [&](const WarpRow &f, int r) {
+        if constexpr (PX) {
+            float p[3], q[3];
+            blend_px(f.p0, f.wn0, f.ws0, p[0], p[1], p[2]);
+            blend_px(f.p1, f.wn1, f.ws1, q[0], q[1], q[2]);
+#pragma unroll
+            for (int ch = 0; ch < 3; ++ch) wl[(r * 3 + ch) * 64 + lane] = v2f{p[ch], q[ch]};
+            return;
+        }
 #pragma unroll
         for (int ch = 0; ch < 3; ++ch) {
             const v2f ea = pfma(f.t0[ch][1], f.ws0, f.t0[ch][0] * f.wn0), eb = pfma(f.t1[ch][1], f.ws1, f.t1[ch][0] * f.wn1);
@@ -1067,6 +1130,8 @@ __device__ __forceinline__ void photo_tile_body(const sqd_photo_args &a, const P
         const unsigned long long t0 = __builtin_amdgcn_s_memtime();
         while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)tl.skew) __builtin_amdgcn_s_sleep(32);
     }
+    int *late_ctr = nullptr;
+    int late_r0 = LATE_NONE, late_n = 0;
     PHOTO_STAMP(0);
     PHOTO_STAMP(7);                                                                 // HW_ID: which CU / SIMD the wave runs on
 #ifdef SQD_PHOTO_TRACE
@@ -1082,17 +1147,30 @@ __device__ __forceinline__ void photo_tile_body(const sqd_photo_args &a, const P
                 StagedRows sr;
                 stage_target_issue<NW>(sr, tgt, H, W, y0, sx.x0, r_lo, r_hi, lane, wave);
                 PHOTO_STAMP(1);
-                if constexpr (PIPE) warp_tile_pipe<NW>(a, pp, wl, b, y0, own_rows, x, own_col, lane, wave);
-                else warp_tile<NW, false, true, true, PX>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
-                stage_target_commit<NW>(sr, tt, r_lo, r_hi, lane, wave);
+                if constexpr (PIPE) {
+                    warp_tile_pipe<NW, PX>(a, pp, wl, b, y0, own_rows, x, own_col, lane, wave);
+                    stage_target_commit<NW>(sr, tt, r_lo, r_hi, lane, wave);
+                    PHOTO_STAMP(2);
+                    __syncthreads();
+                    PHOTO_STAMP(3);
+                } else {
+                    auto mid = [&]() {
+                        stage_target_commit<NW>(sr, tt, r_lo, r_hi, lane, wave);
+                        PHOTO_STAMP(2);
+                        __syncthreads();
+                        PHOTO_STAMP(3);
+                    };
+                    late_ctr = reinterpret_cast<int *>(wl + (tl.TR + 6) * 288);      // (the word behind the warped + target rows)
+                    warp_tile<NW, false, true, true, PX>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave, tl.late ? late_ctr : nullptr, &late_r0, &late_n, mid);
+                }
             } else {
                 stage_target_wide<NW>(tt, tgt, H, W, y0, sx.x0, r_lo, r_hi, lane, wave);
                 PHOTO_STAMP(1);
                 warp_tile<NW, false, true>(a, pp, wl, b, y0, own_rows, xr, col_ok, own_col, lane, wave);
+                PHOTO_STAMP(2);
+                __syncthreads();
+                PHOTO_STAMP(3);
             }
-            PHOTO_STAMP(2);
-            __syncthreads();
-            PHOTO_STAMP(3);
             const bool two = pp.s1 != pp.s0;
             if (!FAST)      // (fast edition: the stores leave between the wave's row pairs — ssim_rows —, under the other waves' arithmetic)
                 store_warped_wide<NW>(wl, a.warped[pp.s0] ? a.warped[pp.s0] + (size_t)b * 3 * HW : nullptr,
@@ -1126,6 +1204,7 @@ __device__ __forceinline__ void photo_tile_body(const sqd_photo_args &a, const P
     k.wl = wl;
     k.tt = MODE == 1 && WIDE ? reinterpret_cast<const float *>(wl + (tl.TR + 6) * 192) : nullptr;
     k.H = H; k.W = W; k.y0 = y0; k.x = x; k.lane = lane; k.HW = HW;
+    k.late_ctr = late_ctr; k.late_r0 = late_r0; k.late_n = late_n;
     k.xoff = col_ok ? (unsigned)xr * 4u : 0x80000000u;
     float loss_acc = 0.f;
     if (FAST && y0 >= 3 && y0 + own_rows + 3 <= H) {       // every row of the tile + halo inside the image: the reflection-free row addressing
@@ -2096,8 +2175,13 @@ extern "C" int sqd_photo_trace(void *buf) { return (int)hipMemcpyToSymbol(HIP_SY
 #endif
 namespace sqd {
 static int g_fwd_variant = 0;      // 0: default (stream kernel on 8-wave tilings), 1: round 5's kernel, 2: colour-serial phase 2, 4: wide edition
-static int g_fwd_skew = 0, g_fwd_resident = 0, g_fwd_pipe = 0;
-void photo_set_fwd_variant(int v) { g_fwd_variant = v & 0x3f; g_fwd_pipe = (v & 0x40) != 0; g_fwd_resident = (v & 0x80) != 0; g_fwd_skew = (v >> 8) * 256; }
+static int g_fwd_skew = 0, g_fwd_resident = 0, g_fwd_pipe = 0, g_fwd_late = 0;
+void photo_set_fwd_variant(int v) {
+    g_fwd_variant = v & 0x3f;
+    g_fwd_late = g_fwd_variant == 6;      // 6: the lean kernel with its late rows warped behind the barrier (warp_tile; measured: no faster)
+    if (g_fwd_variant == 6) g_fwd_variant = 0;
+    g_fwd_pipe = (v & 0x40) != 0; g_fwd_resident = (v & 0x80) != 0; g_fwd_skew = (v >> 8) * 256;
+}
 int photo_fwd_waves(int B, int H, int W, int rows_per_task) {      // loss partials per tile
     const Tiling tl = make_tiling(B, H, W, rows_per_task, FAMILY_FWD);
     return tl.TR > TR_MAX ? 16 : 4;
@@ -2114,6 +2198,7 @@ int launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hip
     Tiling tl = make_tiling(a.B, a.H, a.W, a.rows_per_task, mode == 1 ? FAMILY_FWD : FAMILY_ROWS);
     tl.skew = mode == 1 ? g_fwd_skew : 0;
     tl.pipe = g_fwd_pipe;
+    tl.late = g_fwd_late && !g_fwd_resident;
     const int NW = mode == 1 && tl.TR > TR_MAX ? 8 : 4;
     const dim3 grid(tl.nblk8 * 8), block(NW * 64);
     // (SQD_SOURCES_HWC travels in loss_flags)
@@ -2121,7 +2206,7 @@ int launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hip
     const int opts = a.loss_flags & ~SQD_SOURCES_HWC;
     const bool lean = mode == 1 && NW == 8 && g_fwd_variant == 0 && a.W >= 64 && a.S == 2 && opts == 0 && !a.reproj && !a.x0y0[0] && !a.x0y0[1] && a.sel && a.idx &&
                       a.sample[0] && a.sample[1] && a.warped[0] && a.warped[1] && a.identity && tl.TR <= 36;
-    if (hwc && mode != 2 && !(a.W >= 64 && a.S == 2 && opts == 0 && !g_fwd_variant && (mode == 0 || lean))) {
+    if (hwc && mode != 2 && !(a.W >= 64 && a.S == 2 && opts == 0 && !g_fwd_variant && !g_fwd_resident && (mode == 0 || lean))) {
         // (the kernels that read [B,H,W,3] sources: the lean forward, the option-free identity maps, the default backward)
         set_error("SQD_SOURCES_HWC: only with two source frames, the default loss options, W >= 64, every output of the forward requested except the tap / "
                   "reprojection dumps, and the default kernel variant");
@@ -2137,7 +2222,7 @@ int launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hip
         else if (mode == 1 && NW == 8 && g_fwd_variant == 2)
             hipLaunchKernelGGL((photo_fwd_c_kernel<8>), grid, block, (tl.TR + 6) * 3 * 64 * 8, stream, a, pp, tl);
         else if (lean) {
-            const int lds = (tl.TR + 6) * 3 * 64 * 12;
+            const int lds = (tl.TR + 6) * 3 * 64 * 12 + 16;      // warped rows (8 bytes per cell and colour), target rows (4), the late-row count
             static int lds_ok = 0;                   // (dynamic LDS beyond 64 KB is an opt-in of the function)
             if (!lds_ok) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photo_tile_kernel<1, 8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -2155,9 +2240,11 @@ int launch_photo_tile(const sqd_photo_args &a, const float *noise, int mode, hip
                 static int lds_ok3 = 0;
                 if (!lds_ok3) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photo_tile_kernel<1, 8, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&photo_tile_kernel<1, 8, true, true, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                     lds_ok3 = 1;
                 }
-                hipLaunchKernelGGL((photo_tile_kernel<1, 8, true, true, true>), grid, block, lds, stream, a, pp, noise, tl);
+                if (hwc) hipLaunchKernelGGL((photo_tile_kernel<1, 8, true, true, true, true>), grid, block, lds, stream, a, pp, noise, tl);
+                else hipLaunchKernelGGL((photo_tile_kernel<1, 8, true, true, true>), grid, block, lds, stream, a, pp, noise, tl);
             } else if (hwc) {                                     // pixel-interleaved sources: eight gathers per cell instead of twelve
                 static int lds_ok4 = 0;
                 if (!lds_ok4) {

@@ -51,7 +51,7 @@ static int check_loss_flags(const char *who, int flags, int S) {
 
 namespace sqd { void photo_set_fwd_variant(int v); }
 extern "C" int sqd_photo_set_fwd_variant(int variant) {
-    SQD_CHECK_ARG((variant & 0x3f) <= 5 && variant >= 0, "sqd_photo_set_fwd_variant: 0 (wide), 1 (round 5) or 2 (colour-serial), got %d", variant);
+    SQD_CHECK_ARG((variant & 0x3f) <= 6 && variant >= 0, "sqd_photo_set_fwd_variant: bits 0-5 take 0 .. 6 (include/sqd.h), got %d", variant);
     sqd::photo_set_fwd_variant(variant);
     return SQD_OK;
 }

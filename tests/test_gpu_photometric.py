@@ -161,8 +161,8 @@ def test_warp_taps_bit_exact_full_size(ops, O, B, H, W, S):
 
 @pytest.mark.parametrize("B,H,W", [(12, 192, 640), (3, 96, 320), (2, 320, 1024)])
 def test_forward_kernel_variants_agree(ops, B, H, W):
-    """every kernel sqd_photo_set_fwd_variant can select (0 lean = the default, 1 round 5's, 2 colour-serial, 4 wide, 5 dynamic wave
-    roles; 0x40: two rows of a wave in flight in phase 1, 0x80: resident workgroups) writes the same sampling grid, warped colours, identity_selection and argmin, bit for bit; the
+    """every kernel sqd_photo_set_fwd_variant can select (0 lean = the default, 6 lean with its late rows warped behind the barrier, 1 round 5's,
+    2 colour-serial, 4 wide, 5 dynamic wave roles; 0x40: two rows of a wave in flight in phase 1, 0x80: resident workgroups) writes the same sampling grid, warped colours, identity_selection and argmin, bit for bit; the
     loss partials sum to the same loss (their partition differs: per wave / per row pair)."""
     from sqd import lib as _l
     d = chain_inputs(29, B, H, W)
@@ -174,7 +174,7 @@ def test_forward_kernel_variants_agree(ops, B, H, W):
     L = _l.lib()
     outs = {}
     try:
-        for v in (1, 0, 2, 4, 5, 0x40, 0x80):
+        for v in (1, 0, 6, 2, 4, 5, 0x40, 0x80):
             _l.check(L.sqd_photo_set_fwd_variant(v), "variant")
             outs[v] = ops.photo_fwd(depth, dev(d["inv_K"]), P, dev(d["color0"]), srcs, ident)
     finally:

@@ -33,6 +33,21 @@ def t(fn, n=200):
     e1.record(); torch.cuda.synchronize(); return e0.elapsed_time(e1) / n * 1e3
 c0, _k0 = ops.photo_fwd(depth, inv_K, P, tgt, srcs, ident, prepared_only=True)
 c1, _k1 = ops.photo_fwd(depth, inv_K, P, tgt, px, ident, prepared_only=True)
+def with_variant(v, fn):
+    _l.check(L.sqd_photo_set_fwd_variant(v), "variant")
+    try:
+        return fn()
+    finally:
+        _l.check(L.sqd_photo_set_fwd_variant(0), "variant")
+o6 = with_variant(6, lambda: ops.photo_fwd(depth, inv_K, P, tgt, px, ident))
+print("late rows behind the barrier (variant 6), same bits as the default:", all((all(torch.equal(a, b) for a, b in zip(o6[k], o1[k])) if isinstance(o1[k], list) else torch.equal(o6[k], o1[k])) for k in o1 if o1[k] is not None and k != "loss_part"),
+      " loss:", float(o6["loss_part"].double().sum()), float(o1["loss_part"].double().sum()))
+for r in range(3):
+    print("forward, late rows behind the barrier (variant 6): planar %.1f us, pixel-interleaved %.1f us" % (with_variant(6, lambda: t(lambda: ops.photo_fwd_relaunch(c0))), with_variant(6, lambda: t(lambda: ops.photo_fwd_relaunch(c1)))))
+o40 = with_variant(0x40, lambda: ops.photo_fwd(depth, inv_K, P, tgt, px, ident))
+print("two rows in flight (0x40) on pixel-interleaved sources, same bits:", all((all(torch.equal(a, b) for a, b in zip(o40[k], o1[k])) if isinstance(o1[k], list) else torch.equal(o40[k], o1[k])) for k in o1 if o1[k] is not None))
+for r in range(3):
+    print("forward, two rows of a wave in flight (variant 0x40): planar %.1f us, pixel-interleaved %.1f us" % (with_variant(0x40, lambda: t(lambda: ops.photo_fwd_relaunch(c0))), with_variant(0x40, lambda: t(lambda: ops.photo_fwd_relaunch(c1)))))
 for r in range(4):
     print("forward: planar %.1f us, pixel-interleaved %.1f us   identity: %.1f / %.1f us   coef + backward (+reduce, alloc): %.1f / %.1f us   pack (2 frames) %.1f us" % (
         t(lambda: ops.photo_fwd_relaunch(c0)), t(lambda: ops.photo_fwd_relaunch(c1)), t(lambda: ops.identity_fwd(tgt, srcs, noise, 0), 50), t(lambda: ops.identity_fwd(tgt, px, noise, 0), 50),

@@ -19,6 +19,8 @@ ap.add_argument("--W", type=int, default=640)
 ap.add_argument("--which", default="fwd,ident,coef,bwd")
 ap.add_argument("--cold", action="store_true", help="evict L2 and the Infinity Cache before every timed call (a 1 GB fill): what the kernels see "
                                                      "inside the training step, where their inputs were produced milliseconds earlier")
+ap.add_argument("--layout", default="hwc", choices=("hwc", "planar"), help="memory layout of the source frames: hwc = channels_last, what the captured "
+                "training step keeps them in (trainer._capture) — the default, so that the kernels profiled here are the step's; planar = [B,3,H,W]")
 ap.add_argument("--dump", default=None, help="save the backward's outputs here (bit-compare two builds)")
 ap.add_argument("--lib", default=None, help="another build of libsqd.so (tools/build_alt_lib.sh) for same-box A/B runs")
 args = ap.parse_args()
@@ -32,6 +34,8 @@ K = torch.tensor([[0.58 * W, 0, 0.5 * W, 0], [0, 1.92 * H, 0.5 * H, 0], [0, 0, 1
 inv_K = torch.linalg.pinv(K).contiguous()
 tgt = torch.rand(B, 3, H, W, device=dev)
 srcs = [torch.rand(B, 3, H, W, device=dev) for _ in range(2)]
+if args.layout == "hwc" and ops.sources_hwc_ok(B, 2, H, W):
+    srcs = ops.pack_pixels(srcs)
 disp = torch.rand(B, 1, H // 2, W // 2, device=dev) * 20 + 1
 depth, part = ops.depth_up_fwd(disp, H, W)
 aa, tr = 0.01 * torch.randn(B, 2, 3, device=dev), 0.5 * torch.randn(B, 2, 3, device=dev)

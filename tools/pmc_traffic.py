@@ -15,10 +15,14 @@ for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         acc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 
 
+matched = {}
+
+
 def avg(sub, counter):
     for k, cs in acc.items():
         if sub in k and counter in cs:
             v = cs[counter][len(cs[counter]) // 2:]          # second half of the dispatches: caches and clocks settled
+            matched[sub] = k.split("(")[0]
             return sum(v) / len(v) * 1024.0
     raise SystemExit("no %s for %s under %s" % (counter, sub, root))
 
@@ -36,9 +40,9 @@ for name in ("photo_tile_kernel<1>", "photo_tile_kernel<0>", "photo_tile_kernel<
         fr, wr = avg(sub, "FETCH_SIZE"), avg(sub, "WRITE_SIZE")
     except SystemExit:
         continue
-    res["kernels"][name] = {"fetch_reported_bytes": round(fr), "write_reported_bytes": round(wr),
+    res["kernels"][name] = {"instantiation": matched.get(sub), "fetch_reported_bytes": round(fr), "write_reported_bytes": round(wr),
                             "fetch_corrected_bytes": round(fr * cal["read_dword"]), "write_corrected_bytes": round(wr * cal["write_dword"]),
                             "traffic_bytes": round(fr * cal["read_dword"] + wr * cal["write_dword"]),
-                            "note": "dword-width calibration for both directions (the kernels' gathers are 8-byte, their row loads and stores 4-byte)"}
+                            "note": "dword-width calibration for both directions (the kernels' gathers are 8- and 16-byte, their row loads and stores 4- to 16-byte)"}
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -17,6 +17,7 @@ ap.add_argument("--variant", type=int, default=0)
 ap.add_argument("--B", type=int, default=12)
 ap.add_argument("--H", type=int, default=192)
 ap.add_argument("--W", type=int, default=640)
+ap.add_argument("--layout", default="hwc", choices=("hwc", "planar"))
 args = ap.parse_args()
 _l.SO_PATH = os.path.abspath(args.lib)
 _l.needs_build = lambda: False
@@ -34,6 +35,8 @@ depth, part = ops.depth_up_fwd(disp, H, W)
 aa, tr = 0.01 * torch.randn(B, S, 3, device=dev), 0.5 * torch.randn(B, S, 3, device=dev)
 mid, T, P = ops.pose_mats_fwd(aa, tr, [1, 0], K, part, H * W)
 noise = torch.randn(B, S, H, W, device=dev)
+if args.layout == "hwc":
+    srcs = ops.pack_pixels(srcs)
 ident = ops.identity_fwd(tgt, srcs, noise, 0)
 _l.check(L.sqd_photo_set_fwd_variant(args.variant), "variant")
 call, keep = ops.photo_fwd(depth, inv_K, P, tgt, srcs, ident, prepared_only=True)
