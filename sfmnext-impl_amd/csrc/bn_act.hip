@@ -285,7 +285,14 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
                                                            float *__restrict__ dx, float *__restrict__ dres, size_t total4,
                                                            int C, float invM, int act, const unsigned char *__restrict__ mask,
                                                            const float *__restrict__ beta, unsigned *__restrict__ amax_dx,
-                                                           unsigned *__restrict__ amax_dres) {
+                                                           unsigned *__restrict__ amax_dres, const float *__restrict__ x2 = nullptr,
+                                                           const float *__restrict__ mean2 = nullptr, const float *__restrict__ rstd2 = nullptr,
+                                                           float *__restrict__ part2 = nullptr) {
+    // x2 != NULL (launched with 256 % (C / 4) == 0: a thread keeps its channel group): dres = dz is ALSO the whole gradient of the BatchNorm that
+    // produced the residual branch (a bottleneck's down-sample BatchNorm: no activation, one consumer) — its two backward sums
+    // (sum dz, sum dz * xhat2) are taken here, one partial row per workgroup, instead of by a pass of its own over dres and x2
+    __shared__ float4 red2[2][256];
+    float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f), q2 = s2, mu2 = s2, rs2 = s2;
     unsigned am = 0u, amr = 0u;
     const unsigned V = (unsigned)C / 4u;
     const size_t stride = (size_t)gridDim.x * 256;
@@ -303,6 +310,10 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
         k2 = make_float4(rs.x * (dg.x * invM), rs.y * (dg.y * invM), rs.z * (dg.z * invM), rs.w * (dg.w * invM));
     };
     params();
+    if (x2) {
+        mu2 = reinterpret_cast<const float4 *>(mean2)[cg];
+        rs2 = reinterpret_cast<const float4 *>(rstd2)[cg];
+    }
     for (; i < total4; i += stride) {
         const float4 gy = reinterpret_cast<const float4 *>(dy)[i];
         const float4 xv = reinterpret_cast<const float4 *>(x)[i];
@@ -320,12 +331,33 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
         o.w = k0.w * (dz.w - k1.w - (xv.w - mu.w) * k2.w);
         reinterpret_cast<float4 *>(dx)[i] = o;
         if (dres) reinterpret_cast<float4 *>(dres)[i] = dz;
+        if (x2) {
+            const float4 xw = reinterpret_cast<const float4 *>(x2)[i];
+            s2.x += dz.x; s2.y += dz.y; s2.z += dz.z; s2.w += dz.w;
+            q2.x = fmaf(dz.x, (xw.x - mu2.x) * rs2.x, q2.x); q2.y = fmaf(dz.y, (xw.y - mu2.y) * rs2.y, q2.y);
+            q2.z = fmaf(dz.z, (xw.z - mu2.z) * rs2.z, q2.z); q2.w = fmaf(dz.w, (xw.w - mu2.w) * rs2.w, q2.w);
+        }
         am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
         amr = max(max(amr, abs_bits(dz.x)), max(abs_bits(dz.y), max(abs_bits(dz.z), abs_bits(dz.w))));
         if (cstep) {                                            // uniform
             cg += cstep;
             cg -= cg >= V ? V : 0u;
             params();
+        }
+    }
+    if (x2) {      // (uniform) the workgroup's partial row: the threads of a channel group added in a fixed order
+        red2[0][threadIdx.x] = s2;
+        red2[1][threadIdx.x] = q2;
+        __syncthreads();
+        if (threadIdx.x < V) {
+            for (unsigned k = threadIdx.x + V; k < 256u; k += V) {
+                const float4 u = red2[0][k], v = red2[1][k];
+                s2.x += u.x; s2.y += u.y; s2.z += u.z; s2.w += u.w;
+                q2.x += v.x; q2.y += v.y; q2.z += v.z; q2.w += v.w;
+            }
+            float *o = part2 + ((size_t)blockIdx.x * C + threadIdx.x * 4) * 2;
+            reinterpret_cast<float4 *>(o)[0] = make_float4(s2.x, q2.x, s2.y, q2.y);
+            reinterpret_cast<float4 *>(o)[1] = make_float4(s2.z, q2.z, s2.w, q2.w);
         }
     }
     amax_commit(am, amax_dx);
@@ -475,7 +507,9 @@ __global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const float *__restri
                                                            float *__restrict__ dx, float *__restrict__ dres, int M, int C, int act,
                                                            const unsigned char *__restrict__ mask, int rows_per_block, int nchunks, int nrb,
                                                            const float *__restrict__ red_part, float *__restrict__ red_out, size_t red_n, int red_splits,
-                                                           unsigned *__restrict__ amax_dx, unsigned *__restrict__ amax_dres) {
+                                                           unsigned *__restrict__ amax_dx, unsigned *__restrict__ amax_dres,
+                                                           const float *__restrict__ x2 = nullptr, const float *__restrict__ mean2 = nullptr,
+                                                           const float *__restrict__ rstd2 = nullptr, float *__restrict__ part2 = nullptr) {
     __shared__ float4 red[16][16][2];
     if ((int)blockIdx.y >= nchunks) {              // (workgroup-uniform) the pending sum of a weight gradient's pixel splits
         sqd::split_reduce_block(red_part, red_out, red_n, red_splits, ((int)blockIdx.y - nchunks) * nrb + (int)blockIdx.x,
@@ -497,6 +531,12 @@ __global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const float *__restri
     const float4 k2 = make_float4(rs.x * (dg.x * invM), rs.y * (dg.y * invM), rs.z * (dg.z * invM), rs.w * (dg.w * invM));
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     unsigned am = 0u, amr = 0u;
+    // x2 != NULL: the backward sums of the BatchNorm behind the residual branch, one partial row per row block (bn_apply_bwd_kernel)
+    float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f), q2 = s2, mu2 = s2, rs2 = s2;
+    if (x2) {
+        mu2 = *reinterpret_cast<const float4 *>(mean2 + c);
+        rs2 = *reinterpret_cast<const float4 *>(rstd2 + c);
+    }
     for (int r = r0 + rl; r < r1; r += 16) {
         const size_t i = ((size_t)r * C + c) / 4;
         const float4 gy = reinterpret_cast<const float4 *>(dy)[i];
@@ -510,8 +550,31 @@ __global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const float *__restri
         o.w = k0.w * (dz.w - k1.w - (xv.w - mu.w) * k2.w);
         reinterpret_cast<float4 *>(dx)[i] = o;
         if (dres) reinterpret_cast<float4 *>(dres)[i] = dz;
+        if (x2) {
+            const float4 xw = reinterpret_cast<const float4 *>(x2)[i];
+            s2.x += dz.x; s2.y += dz.y; s2.z += dz.z; s2.w += dz.w;
+            q2.x = fmaf(dz.x, (xw.x - mu2.x) * rs2.x, q2.x); q2.y = fmaf(dz.y, (xw.y - mu2.y) * rs2.y, q2.y);
+            q2.z = fmaf(dz.z, (xw.z - mu2.z) * rs2.z, q2.z); q2.w = fmaf(dz.w, (xw.w - mu2.w) * rs2.w, q2.w);
+        }
         am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
         amr = max(max(amr, abs_bits(dz.x)), max(abs_bits(dz.y), max(abs_bits(dz.z), abs_bits(dz.w))));
+    }
+    if (x2) {      // (uniform; chunk_sums is done with `red`: every thread has passed its barrier and read its sums)
+        __syncthreads();
+        red[rl][cgl][0] = s2;
+        red[rl][cgl][1] = q2;
+        __syncthreads();
+        if (rl == 0) {
+#pragma unroll
+            for (int k = 1; k < 16; ++k) {
+                const float4 u = red[k][cgl][0], v = red[k][cgl][1];
+                s2.x += u.x; s2.y += u.y; s2.z += u.z; s2.w += u.w;
+                q2.x += v.x; q2.y += v.y; q2.z += v.z; q2.w += v.w;
+            }
+            float *o = part2 + ((size_t)blockIdx.x * C + c) * 2;
+            reinterpret_cast<float4 *>(o)[0] = make_float4(s2.x, q2.x, s2.y, q2.y);
+            reinterpret_cast<float4 *>(o)[1] = make_float4(s2.z, q2.z, s2.w, q2.w);
+        }
     }
     amax_commit(am, amax_dx);
     if (dres) amax_commit(amr, amax_dres, 1);
@@ -644,6 +707,33 @@ extern "C" int sqd_bn_train_bwd_amax(const float *dy, const float *x, const floa
                                      const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
                                      float *dbeta, float *part, int pre_rows, int M, int C, int act, const float *red_part, float *red_out,
                                      int64_t red_n, int red_splits, float *amax_dx, float *amax_dres, void *stream) {
+    return sqd_bn_train_bwd_res(dy, x, y, mask, gamma, beta, save_mean, save_rstd, dx, dres, dgamma, dbeta, part, pre_rows, M, C, act, red_part, red_out,
+                                red_n, red_splits, amax_dx, amax_dres, nullptr, nullptr, nullptr, nullptr, stream);
+}
+
+// the partial rows sqd_bn_train_bwd_res writes for the residual branch's BatchNorm at this shape (0: this shape does not take them)
+extern "C" int sqd_bn_bwd_res_rows(int M, int C, int pre_rows, int act) {
+    if (M <= 0 || C < 4 || C % 4 || act == ACT_SWISH) return 0;
+    if (pre_rows > 0 && pre_rows <= FUSE_MAX_ROWS && C % 64 == 0) {
+        const int rpb = fused_rows_per_block(M, C, pre_rows);
+        return (M + rpb - 1) / rpb;
+    }
+    if (256 % (C / 4)) return 0;                        // (the element-wise kernel's threads keep their channel group)
+    const int g = ew_grid((size_t)M * C / 4);
+    return g < 2048 ? g : 2048;
+}
+
+// ... and, with x2 / mean2 / rstd2 / part2 (all or none; dres required), the two backward sums of the BatchNorm that produced the residual branch
+// (no activation, this node its only consumer: dres IS its incoming gradient): x2 [M,C] that BatchNorm's input, mean2 / rstd2 its saved
+// statistics -> part2 [sqd_bn_bwd_res_rows(M, C, pre_rows, act)][C][2] = (sum dres, sum dres * xhat2), to be handed to its own backward as
+// precomputed partials (sqd_bn_train_bwd_pre) — the pass over dres and x2 that would take them is not run
+extern "C" int sqd_bn_train_bwd_res(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
+                                    const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
+                                    float *dbeta, float *part, int pre_rows, int M, int C, int act, const float *red_part, float *red_out,
+                                    int64_t red_n, int red_splits, float *amax_dx, float *amax_dres, const float *x2, const float *mean2,
+                                    const float *rstd2, float *part2, void *stream) {
+    SQD_CHECK_ARG((!x2 && !mean2 && !rstd2 && !part2) || (x2 && mean2 && rstd2 && part2 && dres && sqd_bn_bwd_res_rows(M, C, pre_rows, act) > 0),
+                  "sqd_bn_train_bwd_res: the residual branch's sums need x2, mean2, rstd2, part2, dres and a shape sqd_bn_bwd_res_rows accepts");
     SQD_CHECK_ARG(!red_part || (red_out && red_n > 0 && red_n % 4 == 0 && red_splits >= 1), "sqd_bn_train_bwd_pre_red: bad pending reduction");
     SQD_CHECK_ARG(dy && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && part, "sqd_bn_train_bwd: null pointer");
     SQD_CHECK_ARG(pre_rows >= 0 && (pre_rows == 0 || act != ACT_SWISH), "sqd_bn_train_bwd_pre: pre_rows=%d (no precomputed partials with swish)", pre_rows);
@@ -658,7 +748,7 @@ extern "C" int sqd_bn_train_bwd_amax(const float *dy, const float *x, const floa
         const int nredb = red_part ? (int)((red_n / 4 + 15) / 16) : 0;             // blocks of the pending split reduction, nrb per grid row
         hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3(nrb, nchunks + (nredb + nrb - 1) / nrb), dim3(256), 0, s, dy, x, y, gamma, save_mean, save_rstd, part,
                            pre_rows, dgamma, dbeta, dx, dres, M, C, act, mask, rpb, nchunks, nrb, red_part, red_out, (size_t)red_n, red_splits,
-                           (unsigned *)amax_dx, (unsigned *)amax_dres);
+                           (unsigned *)amax_dx, (unsigned *)amax_dres, x2, mean2, rstd2, part2);
         SQD_CHECK_LAUNCH("sqd_bn_train_bwd");
         return SQD_OK;
     }
@@ -668,8 +758,9 @@ extern "C" int sqd_bn_train_bwd_amax(const float *dy, const float *x, const floa
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(nfin + nred), dim3(256), 0, s, part, pre_rows > 0 ? pre_rows : g.nblk, M, C, dgamma, dbeta, nfin,
                        red_part, red_out, (size_t)red_n, red_splits);
     const size_t total4 = (size_t)M * C / 4;
-    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(ew_grid(total4)), dim3(256), 0, s, dy, x, y, gamma, save_mean, save_rstd, dgamma,
-                       dbeta, dx, dres, total4, C, 1.0f / (float)M, act, mask, beta, (unsigned *)amax_dx, (unsigned *)amax_dres);
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(x2 ? sqd_bn_bwd_res_rows(M, C, pre_rows, act) : ew_grid(total4)), dim3(256), 0, s, dy, x, y, gamma, save_mean,
+                       save_rstd, dgamma, dbeta, dx, dres, total4, C, 1.0f / (float)M, act, mask, beta, (unsigned *)amax_dx, (unsigned *)amax_dres, x2, mean2, rstd2,
+                       part2);
     SQD_CHECK_LAUNCH("sqd_bn_train_bwd");
     return SQD_OK;
 }

@@ -241,6 +241,11 @@ class BatchNormAct(torch.autograd.Function):
             ctx.shared = shared if code != 3 else None
             if ctx.shared is not None:
                 shared.update(x=x, mask=mask, mean=mean, rstd=rstd, code=code, dx=None, part=None, rows=0)
+            # the residual branch is itself the output of a training-mode BatchNorm without activation (a bottleneck's down-sample branch):
+            # this node's backward can take that node's two sums on the way (dres is its whole gradient if this node is its only consumer —
+            # its backward checks that the tensor that arrives is the dres written here)
+            rs = getattr(residual, "_sqd_bn_src", None) if FUSE_BN_BWD_STATS else None
+            ctx.res_src = rs if rs is not None and rs.get("code") == 0 and rs["x"].shape == x.shape else None
         else:
             _l.check(L.sqd_bn_eval_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
                                        _ptr(y), M, C, float(eps), code, _stream()), "bn_eval_fwd")
@@ -274,9 +279,18 @@ class BatchNormAct(torch.autograd.Function):
         rp, ro, rn, rs = pend[:4] if pend is not None else (None, None, 0, 0)
         adx = _amax_out(x.device)
         adr = _amax_out(x.device) if dres is not None else None
-        _l.check(L.sqd_bn_train_bwd_amax(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
-                                         _ptr(dgamma), _ptr(dbeta), _ptr(part), pre_rows, M, C, ctx.code, _ptr(rp), _ptr(ro), rn, rs,
-                                         _ptr(adx), _ptr(adr), _stream()), "bn_train_bwd")
+        src2 = getattr(ctx, "res_src", None) if dres is not None else None
+        rows2 = L.sqd_bn_bwd_res_rows(M, C, pre_rows, ctx.code) if src2 is not None else 0
+        if rows2 > 0:
+            part2 = torch.empty(rows2 * C * 2, device=x.device, dtype=torch.float32)
+            _l.check(L.sqd_bn_train_bwd_res(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
+                                            _ptr(dgamma), _ptr(dbeta), _ptr(part), pre_rows, M, C, ctx.code, _ptr(rp), _ptr(ro), rn, rs,
+                                            _ptr(adx), _ptr(adr), _ptr(src2["x"]), _ptr(src2["mean"]), _ptr(src2["rstd"]), _ptr(part2), _stream()), "bn_train_bwd_res")
+            src2.update(dx=dres, part=part2, rows=rows2)
+        else:
+            _l.check(L.sqd_bn_train_bwd_amax(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
+                                             _ptr(dgamma), _ptr(dbeta), _ptr(part), pre_rows, M, C, ctx.code, _ptr(rp), _ptr(ro), rn, rs,
+                                             _ptr(adx), _ptr(adr), _stream()), "bn_train_bwd")
         _amax_tag(dx, adx)
         _amax_tag(dres, adr)
         if pend is not None:

@@ -83,6 +83,72 @@ def test_bn_backward_statistics_from_the_dgrad_epilogue(N, C, H, W, Cm, K, R2, s
         assert ef <= 2e-4 and ef <= 4.0 * eu + 2e-6, (name, "fused", ef, "unfused", eu)
 
 
+@pytest.mark.parametrize("N,C,H,W,Cm,shared_res,expect_ds", [
+    (2, 32, 12, 20, 64, False, True),        # few partial rows: finalize + element-wise pass in one launch (bn_fused_bwd_kernel)
+    (4, 32, 48, 80, 128, False, True),       # many partial rows: the three-launch path (bn_apply_bwd_kernel takes the sums)
+    (8, 32, 96, 160, 256, False, True),      # ... more elements than the 2048 workgroups of that pass take in one sweep
+    (2, 32, 12, 20, 72, False, False),       # 18 channel groups: not a multiple of 64 channels, not a divisor of 256 threads — not served
+    (2, 32, 12, 20, 64, True, False),        # the down-sample output has a SECOND consumer: its gradient is a sum, the ordinary path must run
+])
+def test_residual_branch_batchnorm_sums_ride_on_the_main_branch(N, C, H, W, Cm, shared_res, expect_ds):
+    """a bottleneck's tail, out = relu(bn3(conv3(x)) + bn_ds(conv_ds(x))) -> conv: the backward of bn3 writes dres, which is the whole gradient
+    of bn_ds — its two sums are taken in that same pass (sqd_bn_train_bwd_res), bn_ds runs no reduction of its own, and every gradient is
+    what float64 and the unfused path give"""
+    from sqd import nnkernels, nnops
+    import copy
+    torch.manual_seed(N * H + Cm)
+    conv3, bn3, convd, bnd, conv4 = nn.Conv2d(C, Cm, 1, bias=False), nn.BatchNorm2d(Cm), nn.Conv2d(C, Cm, 1, bias=False), nn.BatchNorm2d(Cm), \
+        nn.Conv2d(Cm, 32, 1, bias=False)
+    with torch.no_grad():
+        for b in (bn3, bnd):
+            b.weight.uniform_(0.5, 1.5)
+            b.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(N, C, H, W)
+    mods = [conv3, bn3, convd, bnd, conv4]
+    r = [copy.deepcopy(m).double() for m in mods]
+    xr = x.double().requires_grad_(True)
+    ds_r = r[3](r[2](xr))
+    z_r = F.relu(r[1](r[0](xr)) + ds_r)
+    out_r = r[4](z_r) + (0.25 * ds_r.mean() if shared_res else 0.0)
+    g = torch.randn_like(out_r)
+    out_r.backward(g)
+    results, took = {}, {}
+    orig = nnkernels.BatchNormAct.backward
+    try:
+        for fused in (True, False):
+            nnkernels.FUSE_BN_BWD_STATS = fused
+            m = [copy.deepcopy(q).cuda() for q in mods]
+            for q in (m[0], m[2], m[4]):
+                q.to(memory_format=torch.channels_last)
+            xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            pre = []
+
+            def backward(ctx, dy, _pre=pre):
+                sh = getattr(ctx, "shared", None)
+                _pre.append(bool(sh is not None and sh.get("dx") is dy and sh.get("rows", 0) > 0))
+                return orig(ctx, dy)
+            nnkernels.BatchNormAct.backward = staticmethod(backward)
+            ds = nnops.conv_bn_act(xg, m[2], m[3], None)
+            z = nnops.conv_bn_act(xg, m[0], m[1], "relu", residual=ds)
+            out = nnops.conv2d(z, m[4])
+            if shared_res:
+                out = out + 0.25 * ds.mean()
+            out.backward(g.float().cuda())
+            took[fused] = list(pre)          # backward order: bn3 first (sums from conv4's epilogue when fused), then bn_ds
+            results[fused] = [xg.grad] + [q.weight.grad for q in m[:4]] + [m[1].bias.grad, m[3].bias.grad]
+    finally:
+        nnkernels.FUSE_BN_BWD_STATS = True
+        nnkernels.BatchNormAct.backward = orig
+    assert len(took[True]) == 2 and took[True][0], took                      # bn3: from the data-gradient epilogue of conv4
+    assert took[True][1] == expect_ds, took                                  # bn_ds: from bn3's pass, unless its gradient is a sum of two / the shape is not served
+    assert took[False] == [False, False], took
+    refs = [xr.grad] + [q.weight.grad for q in r[:4]] + [r[1].bias.grad, r[3].bias.grad]
+    for name, a, b, ref in zip(("dx", "dW3", "dgamma3", "dWd", "dgamma_ds", "dbeta3", "dbeta_ds"), results[True], results[False], refs):
+        scale = float(ref.abs().max())
+        ef, eu = float((a.cpu().double() - ref).abs().max()) / scale, float((b.cpu().double() - ref).abs().max()) / scale
+        assert ef <= 2e-4 and ef <= 4.0 * eu + 2e-6, (name, "fused", ef, "unfused", eu)
+
+
 def test_summed_gradient_takes_the_ordinary_path():
     """the BatchNorm output feeds the convolution AND a second consumer directly (no skip hand-over): autograd sums the two gradients,
     the tensor the BatchNorm node receives is not the data gradient's, and the node must run its own reduction — results as float64"""
