@@ -287,6 +287,12 @@ int sqd_upcat_fwd_amax(const float *x, const float *skip, float *out, int N, int
                        float *amax_out, void *stream);
 int sqd_upcat_bwd(const float *g_out, float *g_x, float *g_skip, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs,
                   void *stream);
+/* ... and, on the way, the two BatchNorm-backward sums of the node that produced x = act(BatchNorm(xb)) (a decoder stage's output: g_x is its whole
+ * incoming gradient): xb [N,Hi,Wi,Cx], maskb its sign bits (NULL with act 0), meanb / rstdb [Cx], act 0 none / 1 ReLU / 2 LeakyReLU(0.01) ->
+ * partb [sqd_upcat_bwd_bn_rows(...)][Cx][2] for its sqd_bn_train_bwd_pre (rows 0: shape not served).  xb = NULL: sqd_upcat_bwd.            */
+int sqd_upcat_bwd_bn_rows(int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs);
+int sqd_upcat_bwd_bn(const float *g_out, float *g_x, float *g_skip, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs, const float *xb,
+                     const unsigned char *maskb, const float *meanb, const float *rstdb, int act, float *partb, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (8) stand-alone forward kernels behind the reference's layer classes (not used by the training path,
@@ -471,6 +477,13 @@ int sqd_bin_centers_bwd(const float *y, const float *sums, const float *g_center
 int sqd_maxpool3x3s2_fwd(const float *x, float *y, unsigned char *idx, int N, int H, int W, int C, void *stream);
 int sqd_maxpool3x3s2_bwd(const float *dy, const unsigned char *idx, const float *addend, float *dx, int N, int H, int W, int C,
                          void *stream);
+/* ... and, on the way, the two BatchNorm-backward sums of the node that produced the pooled tensor x = act(BatchNorm(xb)) (the stem's bn1 + ReLU:
+ * dx is its whole incoming gradient): xb [N,H,W,C], maskb the sign bits its forward stored (NULL with act 0), meanb / rstdb [C], act 0 none /
+ * 1 ReLU / 2 LeakyReLU(0.01) -> partb [sqd_maxpool3x3s2_bwd_bn_rows(N,H,W,C)][C][2] for its sqd_bn_train_bwd_pre (rows 0: shape not served). */
+int sqd_maxpool3x3s2_bwd_bn_rows(int N, int H, int W, int C);
+int sqd_maxpool3x3s2_bwd_bn(const float *dy, const unsigned char *idx, const float *addend, float *dx, int N, int H, int W, int C,
+                            const float *xb, const unsigned char *maskb, const float *meanb, const float *rstdb, int act, float *partb,
+                            void *stream);
 /* space-to-depth(2), channels-last, channels zero-padded to Cp: y[n,h2,w2,c*4+dy*2+dx] = x[n,2h2+dy,2w2+dx,c].  The 7x7/2 stems
  * (reference networks/resnet_encoder.py:94, pose_cnn.py:17) run as 4x4/1 convolutions on this layout (sqd_conv_*).       */
 int sqd_space_to_depth2(const float *x, float *y, int N, int H, int W, int C, int Cp, void *stream);

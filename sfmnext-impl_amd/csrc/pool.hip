@@ -44,11 +44,24 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float *__restric
     }
 }
 
+// xb != NULL (launched with 256 % (C / 4) == 0: a thread keeps its channel group): dx is the whole gradient of the BatchNorm + activation that
+// produced the pooled tensor (the ResNet stem's bn1 + ReLU; its other consumer's gradient arrives as `addend`) — that node's two backward sums,
+// (sum dz, sum dz * xhat) with dz = dx * act'(.), are taken here, one partial row [C][2] per workgroup, instead of by a reduction pass of their
+// own over dx and xb: xb [N,H,W,C] the BatchNorm's input, maskb the sign bits of its pre-activation (1 byte per 4 elements; NULL: no activation),
+// slope = the activation's derivative on the negative side (ReLU 0, LeakyReLU 0.01)
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restrict__ dy, const unsigned char *__restrict__ idx,
                                                           const float *__restrict__ addend, float *__restrict__ dx, int N, int H, int W,
-                                                          int C, int Ho, int Wo) {
+                                                          int C, int Ho, int Wo, const float *__restrict__ xb = nullptr,
+                                                          const unsigned char *__restrict__ maskb = nullptr, const float *__restrict__ meanb = nullptr,
+                                                          const float *__restrict__ rstdb = nullptr, float slope = 0.f, float *__restrict__ partb = nullptr) {
+    __shared__ float4 red[2][256];
     const int V = C / 4;
     const size_t total = (size_t)N * H * W * V;
+    float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), qb = sb, mub = sb, rsb = sb;
+    if (xb) {
+        mub = reinterpret_cast<const float4 *>(meanb)[threadIdx.x % V];
+        rsb = reinterpret_cast<const float4 *>(rstdb)[threadIdx.x % V];
+    }
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
         const int cg = (int)(i % V);
         size_t t = i / V;
@@ -74,6 +87,30 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restric
             }
         }
         reinterpret_cast<float4 *>(dx)[i] = g;
+        if (xb) {
+            const unsigned bits = maskb ? maskb[i] : 0xfu;
+            const float4 xv = reinterpret_cast<const float4 *>(xb)[i];
+            const float d0 = g.x * ((bits & 1u) ? 1.f : slope), d1 = g.y * ((bits & 2u) ? 1.f : slope), d2 = g.z * ((bits & 4u) ? 1.f : slope),
+                        d3 = g.w * ((bits & 8u) ? 1.f : slope);
+            sb.x += d0; sb.y += d1; sb.z += d2; sb.w += d3;
+            qb.x = fmaf(d0, (xv.x - mub.x) * rsb.x, qb.x); qb.y = fmaf(d1, (xv.y - mub.y) * rsb.y, qb.y);
+            qb.z = fmaf(d2, (xv.z - mub.z) * rsb.z, qb.z); qb.w = fmaf(d3, (xv.w - mub.w) * rsb.w, qb.w);
+        }
+    }
+    if (xb) {      // (uniform) the workgroup's partial row: the threads of a channel group added in a fixed order
+        red[0][threadIdx.x] = sb;
+        red[1][threadIdx.x] = qb;
+        __syncthreads();
+        if ((int)threadIdx.x < V) {
+            for (int k = threadIdx.x + V; k < 256; k += V) {
+                const float4 u = red[0][k], v = red[1][k];
+                sb.x += u.x; sb.y += u.y; sb.z += u.z; sb.w += u.w;
+                qb.x += v.x; qb.y += v.y; qb.z += v.z; qb.w += v.w;
+            }
+            float *o = partb + ((size_t)blockIdx.x * C + threadIdx.x * 4) * 2;
+            reinterpret_cast<float4 *>(o)[0] = make_float4(sb.x, qb.x, sb.y, qb.y);
+            reinterpret_cast<float4 *>(o)[1] = make_float4(sb.z, qb.z, sb.w, qb.w);
+        }
     }
 }
 
@@ -104,6 +141,32 @@ extern "C" int sqd_maxpool3x3s2_bwd(const float *dy, const unsigned char *idx, c
     hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((size_t)N * H * W * C / 4)), dim3(256), 0, (hipStream_t)stream, dy, idx, addend, dx, N,
                        H, W, C, Ho, Wo);
     SQD_CHECK_LAUNCH("sqd_maxpool3x3s2_bwd");
+    return SQD_OK;
+}
+
+// the partial rows sqd_maxpool3x3s2_bwd_bn writes at this shape (0: not served — the channel groups must divide a workgroup's 256 threads)
+extern "C" int sqd_maxpool3x3s2_bwd_bn_rows(int N, int H, int W, int C) {
+    if (N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 || 256 % (C / 4)) return 0;
+    const int g = grid_for((size_t)N * H * W * C / 4);
+    return g < 2048 ? g : 2048;
+}
+
+// sqd_maxpool3x3s2_bwd that also takes the two BatchNorm-backward sums of the node that produced the pooled tensor x = act(BatchNorm(xb)): dx is
+// that node's whole incoming gradient.  xb [N,H,W,C], maskb (may be NULL with act 0) the sign bits its forward stored, meanb / rstdb [C] its saved
+// statistics, act 0 none / 1 ReLU / 2 LeakyReLU(0.01) -> partb [sqd_maxpool3x3s2_bwd_bn_rows(N,H,W,C)][C][2] = (sum dz, sum dz * xhat), the
+// precomputed partials of its sqd_bn_train_bwd_pre
+extern "C" int sqd_maxpool3x3s2_bwd_bn(const float *dy, const unsigned char *idx, const float *addend, float *dx, int N, int H, int W, int C,
+                                       const float *xb, const unsigned char *maskb, const float *meanb, const float *rstdb, int act, float *partb,
+                                       void *stream) {
+    SQD_CHECK_ARG(dy && idx && dx && xb && meanb && rstdb && partb, "sqd_maxpool3x3s2_bwd_bn: null pointer");
+    SQD_CHECK_ARG(act == 0 || ((act == 1 || act == 2) && maskb), "sqd_maxpool3x3s2_bwd_bn: act %d (0 none, 1 ReLU, 2 LeakyReLU: these with the sign mask)", act);
+    const int rows = sqd_maxpool3x3s2_bwd_bn_rows(N, H, W, C);
+    SQD_CHECK_ARG(rows > 0, "sqd_maxpool3x3s2_bwd_bn: shape %dx%dx%dx%d not served (C / 4 must divide 256)", N, H, W, C);
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, dy, idx, addend, dx, N, H, W, C, Ho, Wo, xb, act ? maskb : nullptr,
+                       meanb, rstdb, act == 2 ? 0.01f : 0.f, partb);
+    SQD_CHECK_LAUNCH("sqd_maxpool3x3s2_bwd_bn");
     return SQD_OK;
 }
 

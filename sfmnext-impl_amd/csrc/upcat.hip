@@ -61,11 +61,23 @@ __global__ __launch_bounds__(256) void upcat_fwd_kernel(const float *__restrict_
 }
 
 // adjoint: first N*Hi*Wi*Cx/4 work items gather g_x, the remaining N*Ho*Wo*Cs/4 copy g_skip
+// xb != NULL (launched with 256 % (Cx / 4) == 0: a thread keeps its channel group over the g_x items): g_x is the whole gradient of the
+// BatchNorm + activation that produced x (a decoder stage's output) — that node's two backward sums (sum dz, sum dz * xhat), dz = g_x * act'(.),
+// are taken here, one partial row [Cx][2] per workgroup (pool.hip's maxpool_bwd_kernel does the same for the stem): xb [N,Hi,Wi,Cx] the
+// BatchNorm's input, maskb its sign bits (NULL: no activation), slope the activation's derivative on the negative side
 __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float *__restrict__ g_out, float *__restrict__ g_x,
                                                         float *__restrict__ g_skip, int N, int Hi, int Wi, int Cx, int Ho,
-                                                        int Wo, int Cs, float sy, float sx, float isy, float isx) {
+                                                        int Wo, int Cs, float sy, float sx, float isy, float isx, const float *__restrict__ xb = nullptr,
+                                                        const unsigned char *__restrict__ maskb = nullptr, const float *__restrict__ meanb = nullptr,
+                                                        const float *__restrict__ rstdb = nullptr, float slope = 0.f, float *__restrict__ partb = nullptr) {
+    __shared__ float4 red[2][256];
     const unsigned Ct = Cx + Cs, Vt = Ct / 4, Vx = Cx / 4, Vs = Cs / 4;
     const unsigned nx = (unsigned)N * Hi * Wi * Vx, ns = (unsigned)N * Ho * Wo * Vs;
+    float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), qb = sb, mub = sb, rsb = sb;
+    if (xb) {
+        mub = reinterpret_cast<const float4 *>(meanb)[threadIdx.x % Vx];
+        rsb = reinterpret_cast<const float4 *>(rstdb)[threadIdx.x % Vx];
+    }
     for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nx + ns; i += gridDim.x * 256u) {
         if (i >= nx) {
             const unsigned k = i - nx;
@@ -96,6 +108,30 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float *__restrict_
             }
         }
         reinterpret_cast<float4 *>(g_x)[i] = acc;
+        if (xb) {
+            const unsigned bits = maskb ? maskb[i] : 0xfu;
+            const float4 xv = reinterpret_cast<const float4 *>(xb)[i];
+            const float d0 = acc.x * ((bits & 1u) ? 1.f : slope), d1 = acc.y * ((bits & 2u) ? 1.f : slope), d2 = acc.z * ((bits & 4u) ? 1.f : slope),
+                        d3 = acc.w * ((bits & 8u) ? 1.f : slope);
+            sb.x += d0; sb.y += d1; sb.z += d2; sb.w += d3;
+            qb.x = fmaf(d0, (xv.x - mub.x) * rsb.x, qb.x); qb.y = fmaf(d1, (xv.y - mub.y) * rsb.y, qb.y);
+            qb.z = fmaf(d2, (xv.z - mub.z) * rsb.z, qb.z); qb.w = fmaf(d3, (xv.w - mub.w) * rsb.w, qb.w);
+        }
+    }
+    if (xb) {      // (uniform) the workgroup's partial row: the threads of a channel group added in a fixed order
+        red[0][threadIdx.x] = sb;
+        red[1][threadIdx.x] = qb;
+        __syncthreads();
+        if (threadIdx.x < Vx) {
+            for (unsigned k = threadIdx.x + Vx; k < 256u; k += Vx) {
+                const float4 u = red[0][k], v = red[1][k];
+                sb.x += u.x; sb.y += u.y; sb.z += u.z; sb.w += u.w;
+                qb.x += v.x; qb.y += v.y; qb.z += v.z; qb.w += v.w;
+            }
+            float *o = partb + ((size_t)blockIdx.x * Cx + threadIdx.x * 4) * 2;
+            reinterpret_cast<float4 *>(o)[0] = make_float4(sb.x, qb.x, sb.y, qb.y);
+            reinterpret_cast<float4 *>(o)[1] = make_float4(sb.z, qb.z, sb.w, qb.w);
+        }
     }
 }
 
@@ -127,6 +163,21 @@ extern "C" int sqd_upcat_fwd_amax(const float *x, const float *skip, float *out,
 
 extern "C" int sqd_upcat_bwd(const float *g_out, float *g_x, float *g_skip, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs,
                              void *stream) {
+    return sqd_upcat_bwd_bn(g_out, g_x, g_skip, N, Hi, Wi, Cx, Ho, Wo, Cs, nullptr, nullptr, nullptr, nullptr, 0, nullptr, stream);
+}
+// the partial rows sqd_upcat_bwd_bn writes at this shape (0: not served — the channel groups of x must divide a workgroup's 256 threads)
+extern "C" int sqd_upcat_bwd_bn_rows(int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs) {
+    if (N <= 0 || Hi <= 0 || Wi <= 0 || Ho <= 0 || Wo <= 0 || Cx < 4 || Cx % 4 || Cs < 4 || Cs % 4 || 256 % (Cx / 4)) return 0;
+    const int g = grid_for((size_t)N * Hi * Wi * Cx / 4 + (size_t)N * Ho * Wo * Cs / 4);
+    return g < 2048 ? g : 2048;
+}
+// sqd_upcat_bwd that also takes the two BatchNorm-backward sums of the node that produced x = act(BatchNorm(xb)) (g_x is its whole incoming
+// gradient): xb [N,Hi,Wi,Cx], maskb the sign bits its forward stored (NULL with act 0), meanb / rstdb [Cx], act 0 none / 1 ReLU / 2 LeakyReLU(0.01)
+// -> partb [sqd_upcat_bwd_bn_rows(...)][Cx][2] for its sqd_bn_train_bwd_pre.  xb = NULL: sqd_upcat_bwd.
+extern "C" int sqd_upcat_bwd_bn(const float *g_out, float *g_x, float *g_skip, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs, const float *xb,
+                                const unsigned char *maskb, const float *meanb, const float *rstdb, int act, float *partb, void *stream) {
+    SQD_CHECK_ARG(!xb || (meanb && rstdb && partb && (act == 0 || ((act == 1 || act == 2) && maskb)) && sqd_upcat_bwd_bn_rows(N, Hi, Wi, Cx, Ho, Wo, Cs) > 0),
+                  "sqd_upcat_bwd_bn: the BatchNorm sums need meanb, rstdb, partb, the sign mask with ReLU / LeakyReLU, and Cx / 4 dividing 256");
     SQD_CHECK_ARG(g_out && g_x && g_skip, "sqd_upcat_bwd: null pointer");
     SQD_CHECK_ARG(N > 0 && Hi > 0 && Wi > 0 && Ho > 0 && Wo > 0 && Cx % 4 == 0 && Cs % 4 == 0 && Cx > 0 && Cs > 0,
                   "sqd_upcat_bwd: bad shape (channels must be multiples of 4)");
@@ -135,8 +186,8 @@ extern "C" int sqd_upcat_bwd(const float *g_out, float *g_x, float *g_skip, int 
     const size_t total = (size_t)N * Hi * Wi * Cx / 4 + (size_t)N * Ho * Wo * Cs / 4;
     SQD_CHECK_ARG(total < (1ull << 31) && (long long)N * Ho * Wo * (Cx + Cs) / 4 < (1ll << 31), "sqd_upcat_bwd: tensors of 2^31 float4 groups or more");
     (void)hipGetLastError();
-    hipLaunchKernelGGL(upcat_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, g_out, g_x, g_skip, N, Hi, Wi,
-                       Cx, Ho, Wo, Cs, sy, sx, isy, isx);
+    hipLaunchKernelGGL(upcat_bwd_kernel, dim3(xb ? sqd_upcat_bwd_bn_rows(N, Hi, Wi, Cx, Ho, Wo, Cs) : grid_for(total)), dim3(256), 0, (hipStream_t)stream, g_out,
+                       g_x, g_skip, N, Hi, Wi, Cx, Ho, Wo, Cs, sy, sx, isy, isx, xb, act ? maskb : nullptr, meanb, rstdb, act == 2 ? 0.01f : 0.f, partb);
     SQD_CHECK_LAUNCH("sqd_upcat_bwd");
     return SQD_OK;
 }

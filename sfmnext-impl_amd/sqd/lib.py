@@ -168,6 +168,8 @@ _SIGNATURES = {
     "sqd_se_scale": (_I, [_P, _P, _P, _P, _I, _I, _I, _P]),
     "sqd_upcat_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sqd_upcat_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    "sqd_upcat_bwd_bn_rows": (_I, [_I, _I, _I, _I, _I, _I, _I]),
+    "sqd_upcat_bwd_bn": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "sqd_backproject_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "sqd_project3d_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "sqd_ssim_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
@@ -268,6 +270,8 @@ _SIGNATURES = {
     "sqd_bin_centers_bwd": (_I, [_P, _P, _P, _P, _I, _I, _F, _F, _P]),
     "sqd_maxpool3x3s2_fwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     "sqd_maxpool3x3s2_bwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P]),
+    "sqd_maxpool3x3s2_bwd_bn_rows": (_I, [_I, _I, _I, _I]),
+    "sqd_maxpool3x3s2_bwd_bn": (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
     "sqd_space_to_depth2": (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_space_to_depth2_planar": (_I, [_P, _P, _P] + [_I] * 6 + [ctypes.c_int64, ctypes.c_float, ctypes.c_float, _P]),
     "sqd_tokens_pos_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),

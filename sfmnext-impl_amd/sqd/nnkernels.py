@@ -307,6 +307,7 @@ class MaxPool3x3s2(torch.autograd.Function):
     def forward(ctx, x, skip=False):
         ctx.set_materialize_grads(False)
         _require(x, "MaxPool3x3s2 input")
+        x_in = x
         x = _cl(x)
         N, C, H, W = x.shape
         Ho, Wo = (H - 1) // 2 + 1, (W - 1) // 2 + 1
@@ -315,6 +316,9 @@ class MaxPool3x3s2(torch.autograd.Function):
         _l.check(_l.lib().sqd_maxpool3x3s2_fwd(_ptr(x), _ptr(y), _ptr(idx), N, H, W, C, _stream()), "maxpool_fwd")
         ctx.save_for_backward(idx)
         ctx.dims = (N, C, H, W)
+        # x is the output of a training-mode BatchNorm + activation (the stem's bn1): the gather of the backward writes that node's whole
+        # gradient (skip=True brings the other consumer's in) and can take its two sums on the way — see backward
+        ctx.bn_src = getattr(x_in, "_sqd_bn_src", None) if FUSE_BN_BWD_STATS and x is x_in else None
         ax = _amax_get(x)
         _amax_tag(y, ax)                         # the outputs are a subset of the inputs: max |x| bounds max |y|
         if skip:
@@ -331,7 +335,16 @@ class MaxPool3x3s2(torch.autograd.Function):
         if g_skip is not None:
             g_skip = _cl(g_skip)
         dx = torch.empty((N, C, H, W), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
-        _l.check(_l.lib().sqd_maxpool3x3s2_bwd(_ptr(dy), _ptr(idx), _ptr(g_skip), _ptr(dx), N, H, W, C, _stream()), "maxpool_bwd")
+        L = _l.lib()
+        src = ctx.bn_src
+        rows = L.sqd_maxpool3x3s2_bwd_bn_rows(N, H, W, C) if src is not None and src.get("code") in (0, 1, 2) and tuple(src["x"].shape) == (N, C, H, W) else 0
+        if rows > 0:
+            part = torch.empty(rows * C * 2, device=dy.device, dtype=torch.float32)
+            _l.check(L.sqd_maxpool3x3s2_bwd_bn(_ptr(dy), _ptr(idx), _ptr(g_skip), _ptr(dx), N, H, W, C, _ptr(src["x"]), _ptr(src["mask"]), _ptr(src["mean"]),
+                                               _ptr(src["rstd"]), src["code"], _ptr(part), _stream()), "maxpool_bwd_bn")
+            src.update(dx=dx, part=part, rows=rows)
+        else:
+            _l.check(L.sqd_maxpool3x3s2_bwd(_ptr(dy), _ptr(idx), _ptr(g_skip), _ptr(dx), N, H, W, C, _stream()), "maxpool_bwd")
         return dx, None
 
 
@@ -341,7 +354,11 @@ class UpsampleConcat(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, skip):
         _require(x, "UpsampleConcat input")
+        x_in = x
         x, skip = _cl(x), _cl(skip)
+        # x is the output of a training-mode BatchNorm + activation (a decoder stage): the backward's gather writes that node's whole gradient and
+        # can take its two sums on the way — see backward
+        ctx.bn_src = getattr(x_in, "_sqd_bn_src", None) if FUSE_BN_BWD_STATS and x is x_in else None
         N, Cx, Hi, Wi = x.shape
         _, Cs, Ho, Wo = skip.shape
         out = torch.empty((N, Cx + Cs, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
@@ -356,7 +373,16 @@ class UpsampleConcat(torch.autograd.Function):
         g_out = _cl(g_out)
         g_x = torch.empty((N, Cx, Hi, Wi), device=g_out.device, dtype=torch.float32, memory_format=torch.channels_last)
         g_skip = torch.empty((N, Cs, Ho, Wo), device=g_out.device, dtype=torch.float32, memory_format=torch.channels_last)
-        _l.check(_l.lib().sqd_upcat_bwd(_ptr(g_out), _ptr(g_x), _ptr(g_skip), N, Hi, Wi, Cx, Ho, Wo, Cs, _stream()), "upcat_bwd")
+        L = _l.lib()
+        src = getattr(ctx, "bn_src", None)
+        rows = L.sqd_upcat_bwd_bn_rows(N, Hi, Wi, Cx, Ho, Wo, Cs) if src is not None and src.get("code") in (0, 1, 2) and tuple(src["x"].shape) == (N, Cx, Hi, Wi) else 0
+        if rows > 0:
+            part = torch.empty(rows * Cx * 2, device=g_out.device, dtype=torch.float32)
+            _l.check(L.sqd_upcat_bwd_bn(_ptr(g_out), _ptr(g_x), _ptr(g_skip), N, Hi, Wi, Cx, Ho, Wo, Cs, _ptr(src["x"]), _ptr(src["mask"]), _ptr(src["mean"]),
+                                        _ptr(src["rstd"]), src["code"], _ptr(part), _stream()), "upcat_bwd_bn")
+            src.update(dx=g_x, part=part, rows=rows)
+        else:
+            _l.check(L.sqd_upcat_bwd(_ptr(g_out), _ptr(g_x), _ptr(g_skip), N, Hi, Wi, Cx, Ho, Wo, Cs, _stream()), "upcat_bwd")
         return g_x, g_skip
 
 

@@ -149,6 +149,120 @@ def test_residual_branch_batchnorm_sums_ride_on_the_main_branch(N, C, H, W, Cm, 
         assert ef <= 2e-4 and ef <= 4.0 * eu + 2e-6, (name, "fused", ef, "unfused", eu)
 
 
+@pytest.mark.parametrize("N,H,W,C,act,direct_use", [
+    (2, 24, 40, 64, "relu", False),            # the ResNet stem: bn1 + ReLU -> max-pool, the decoder's skip through the pool node
+    (3, 17, 23, 32, "leaky_relu", False),      # odd sizes, LeakyReLU
+    (2, 24, 40, 64, "relu", True),             # a consumer that bypasses the pool node: the gradient is a sum, the ordinary path must run
+])
+def test_stem_batchnorm_sums_ride_on_the_maxpool_backward(N, H, W, C, act, direct_use):
+    """x -> conv -> bn + act -> max-pool(3, 2, 1) -> conv, with the pooled tensor's input also feeding a skip convolution (handed through the pool
+    node): the pool's backward gather writes bn's whole gradient and takes its two sums on the way (sqd_maxpool3x3s2_bwd_bn)"""
+    from sqd import nnkernels, nnops
+    import copy
+    torch.manual_seed(H * W + C)
+    conv1, bn, conv2, convs = nn.Conv2d(16, C, 1, bias=False), nn.BatchNorm2d(C), nn.Conv2d(C, 32, 1, bias=False), nn.Conv2d(C, 8, 1, bias=False)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(N, 16, H, W)
+    mods = [conv1, bn, conv2, convs]
+    r = [copy.deepcopy(m).double() for m in mods]
+    xr = x.double().requires_grad_(True)
+    zr = r[1](r[0](xr))
+    zr = F.relu(zr) if act == "relu" else F.leaky_relu(zr, 0.01)
+    out_r = r[2](F.max_pool2d(zr, 3, 2, 1)).sum() * 0.0 + (r[2](F.max_pool2d(zr, 3, 2, 1)) ** 2).sum() + (r[3](zr) ** 2).sum() + (zr.sum() if direct_use else 0.0)
+    out_r.backward()
+    results, took = {}, {}
+    orig = nnkernels.BatchNormAct.backward
+    try:
+        for fused in (True, False):
+            nnkernels.FUSE_BN_BWD_STATS = fused
+            m = [copy.deepcopy(q).cuda() for q in mods]
+            for q in (m[0], m[2], m[3]):
+                q.to(memory_format=torch.channels_last)
+            xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            pre = []
+
+            def backward(ctx, dy, _pre=pre):
+                sh = getattr(ctx, "shared", None)
+                _pre.append(bool(sh is not None and sh.get("dx") is dy and sh.get("rows", 0) > 0))
+                return orig(ctx, dy)
+            nnkernels.BatchNormAct.backward = staticmethod(backward)
+            z = nnops.conv_bn_act(xg, m[0], m[1], act)
+            p, zs = nnops.maxpool3x3s2(z, skip=True)
+            out = (nnops.conv2d(p, m[2]) ** 2).sum() + (nnops.conv2d(zs, m[3]) ** 2).sum()
+            if direct_use:
+                out = out + z.sum()
+            out.backward()
+            took[fused] = list(pre)
+            results[fused] = [xg.grad, m[0].weight.grad, m[1].weight.grad, m[1].bias.grad]
+    finally:
+        nnkernels.FUSE_BN_BWD_STATS = True
+        nnkernels.BatchNormAct.backward = orig
+    assert took[True] == [not direct_use] and took[False] == [False], took
+    refs = [xr.grad, r[0].weight.grad, r[1].weight.grad, r[1].bias.grad]
+    for name, a, b, ref in zip(("dx", "dW1", "dgamma", "dbeta"), results[True], results[False], refs):
+        scale = float(ref.abs().max())
+        ef, eu = float((a.cpu().double() - ref).abs().max()) / scale, float((b.cpu().double() - ref).abs().max()) / scale
+        assert ef <= 2e-4 and ef <= 4.0 * eu + 2e-6, (name, "fused", ef, "unfused", eu)
+
+
+@pytest.mark.parametrize("N,Hi,Wi,Ho,Wo,C,Cs,act", [
+    (2, 12, 20, 24, 40, 64, 32, "leaky_relu"),       # a decoder stage: BatchNorm + LeakyReLU -> up-sample x2 + concat with the skip
+    (3, 6, 10, 13, 21, 32, 16, "relu"),              # odd target size
+    (2, 12, 20, 24, 40, 72, 32, "leaky_relu"),       # 18 channel groups do not divide 256: not served, ordinary path
+])
+def test_decoder_batchnorm_sums_ride_on_the_upsample_concat_backward(N, Hi, Wi, Ho, Wo, C, Cs, act):
+    """x -> conv -> bn + act -> bilinear up-sample + concat(skip) -> conv: the adjoint of the up-sampling writes bn's whole gradient and takes its
+    two sums on the way (sqd_upcat_bwd_bn)"""
+    from sqd import nnkernels, nnops
+    import copy
+    torch.manual_seed(Hi * Wo + C)
+    conv1, bn, conv2 = nn.Conv2d(16, C, 1, bias=False), nn.BatchNorm2d(C), nn.Conv2d(C + Cs, 32, 1, bias=False)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+    x, skip = torch.randn(N, 16, Hi, Wi), torch.randn(N, Cs, Ho, Wo)
+    mods = [conv1, bn, conv2]
+    r = [copy.deepcopy(m).double() for m in mods]
+    xr, sr = x.double().requires_grad_(True), skip.double().requires_grad_(True)
+    zr = r[1](r[0](xr))
+    zr = F.relu(zr) if act == "relu" else F.leaky_relu(zr, 0.01)
+    out_r = (r[2](torch.cat([F.interpolate(zr, size=(Ho, Wo), mode="bilinear", align_corners=True), sr], 1)) ** 2).sum()
+    out_r.backward()
+    results, took = {}, {}
+    orig = nnkernels.BatchNormAct.backward
+    try:
+        for fused in (True, False):
+            nnkernels.FUSE_BN_BWD_STATS = fused
+            m = [copy.deepcopy(q).cuda() for q in mods]
+            for q in (m[0], m[2]):
+                q.to(memory_format=torch.channels_last)
+            xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            sg = skip.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+            pre = []
+
+            def backward(ctx, dy, _pre=pre):
+                sh = getattr(ctx, "shared", None)
+                _pre.append(bool(sh is not None and sh.get("dx") is dy and sh.get("rows", 0) > 0))
+                return orig(ctx, dy)
+            nnkernels.BatchNormAct.backward = staticmethod(backward)
+            z = nnops.conv_bn_act(xg, m[0], m[1], act)
+            out = (nnops.conv2d(nnops.upsample_concat(z, sg), m[2]) ** 2).sum()
+            out.backward()
+            took[fused] = list(pre)
+            results[fused] = [xg.grad, sg.grad, m[0].weight.grad, m[1].weight.grad, m[1].bias.grad]
+    finally:
+        nnkernels.FUSE_BN_BWD_STATS = True
+        nnkernels.BatchNormAct.backward = orig
+    assert took[True] == [256 % (C // 4) == 0] and took[False] == [False], took
+    refs = [xr.grad, sr.grad, r[0].weight.grad, r[1].weight.grad, r[1].bias.grad]
+    for name, a, b, ref in zip(("dx", "dskip", "dW1", "dgamma", "dbeta"), results[True], results[False], refs):
+        scale = float(ref.abs().max())
+        ef, eu = float((a.cpu().double() - ref).abs().max()) / scale, float((b.cpu().double() - ref).abs().max()) / scale
+        assert ef <= 2e-4 and ef <= 4.0 * eu + 2e-6, (name, "fused", ef, "unfused", eu)
+
+
 def test_summed_gradient_takes_the_ordinary_path():
     """the BatchNorm output feeds the convolution AND a second consumer directly (no skip hand-over): autograd sums the two gradients,
     the tensor the BatchNorm node receives is not the data gradient's, and the node must run its own reduction — results as float64"""
