@@ -244,7 +244,7 @@ class BatchNormAct(torch.autograd.Function):
             # the residual branch is itself the output of a training-mode BatchNorm without activation (a bottleneck's down-sample branch):
             # this node's backward can take that node's two sums on the way (dres is its whole gradient if this node is its only consumer —
             # its backward checks that the tensor that arrives is the dres written here)
-            rs = getattr(residual, "_sqd_bn_src", None) if FUSE_BN_BWD_STATS else None
+            rs = getattr(residual, "_sqd_bn_src", None) if FUSE_BN_BWD_STATS and FUSE_BN_SIDE_SUMS["res"] else None
             ctx.res_src = rs if rs is not None and rs.get("code") == 0 and rs["x"].shape == x.shape else None
         else:
             _l.check(L.sqd_bn_eval_fwd(_ptr(x), _ptr(res), _ptr(gamma), _ptr(beta), _ptr(running_mean), _ptr(running_var),
@@ -318,7 +318,7 @@ class MaxPool3x3s2(torch.autograd.Function):
         ctx.dims = (N, C, H, W)
         # x is the output of a training-mode BatchNorm + activation (the stem's bn1): the gather of the backward writes that node's whole
         # gradient (skip=True brings the other consumer's in) and can take its two sums on the way — see backward
-        ctx.bn_src = getattr(x_in, "_sqd_bn_src", None) if FUSE_BN_BWD_STATS and x is x_in else None
+        ctx.bn_src = getattr(x_in, "_sqd_bn_src", None) if FUSE_BN_BWD_STATS and FUSE_BN_SIDE_SUMS["pool"] and x is x_in else None
         ax = _amax_get(x)
         _amax_tag(y, ax)                         # the outputs are a subset of the inputs: max |x| bounds max |y|
         if skip:
@@ -358,7 +358,7 @@ class UpsampleConcat(torch.autograd.Function):
         x, skip = _cl(x), _cl(skip)
         # x is the output of a training-mode BatchNorm + activation (a decoder stage): the backward's gather writes that node's whole gradient and
         # can take its two sums on the way — see backward
-        ctx.bn_src = getattr(x_in, "_sqd_bn_src", None) if FUSE_BN_BWD_STATS and x is x_in else None
+        ctx.bn_src = getattr(x_in, "_sqd_bn_src", None) if FUSE_BN_BWD_STATS and FUSE_BN_SIDE_SUMS["upcat"] and x is x_in else None
         N, Cx, Hi, Wi = x.shape
         _, Cs, Ho, Wo = skip.shape
         out = torch.empty((N, Cx + Cs, Ho, Wo), device=x.device, dtype=torch.float32, memory_format=torch.channels_last)
@@ -1521,6 +1521,9 @@ def conv_out_geom(x, conv, s2d=False):
 
 
 FUSE_BN_BWD_STATS = True      # BatchNorm-backward sums from the consuming convolution's data-gradient epilogue (tools may switch it off)
+# ... and from the other passes that write a BatchNorm's whole gradient: "res" the main branch's element-wise pass (down-sample BatchNorms),
+# "pool" the max-pool backward gather (the stem), "upcat" the adjoint of the decoder's up-sampling (tools/ab_bench.py switches them one by one)
+FUSE_BN_SIDE_SUMS = {"res": True, "pool": True, "upcat": True}
 _DEFER_COUNTERS = False
 _PENDING_COUNTERS = []
 

@@ -22,7 +22,7 @@ def avg(sub, counter):
     for k, cs in acc.items():
         if sub in k and counter in cs:
             v = cs[counter][len(cs[counter]) // 2:]          # second half of the dispatches: caches and clocks settled
-            matched[sub] = k.split("(")[0]
+            matched[sub] = k[:k.index(">(") + 1] if ">(" in k else k[:100]
             return sum(v) / len(v) * 1024.0
     raise SystemExit("no %s for %s under %s" % (counter, sub, root))
 
