@@ -147,7 +147,7 @@ def roofline_fused_fwd(trainer, batches, iters=200, graph_us=None):
             "us_per_launch_eager_steps": eager_us,
             "clock": ("torch.profiler device activity (roctracer) — the ONE clock of frac / achieved / us_per_launch in this line; the record kept under "
                       "profiles/ is rocprofv3 --kernel-trace of the same command (profiles/r06*_bench_kernel_trace_stats.md), which reads the same launch "
-                      "3-6 % shorter (44.1 against 45.6 us in round 6): compare a line with a line and a trace with a trace" if graph_us else
+                      "a few per cent apart (round 6: 44.1 against 45.6 us on planar source frames, 42.9 against 42.4 on channels_last ones): compare a line with a line and a trace with a trace" if graph_us else
                       "HIP events on the launch stream (eager steps)"),
             "timing": ("average duration of the launch inside replayed hipGraph training steps (device activity records of 4 steps, child process); "
                        "us_per_launch_eager_steps = median of 10 launches bracketed by HIP events on the launch stream inside EAGER steps" if graph_us else
