@@ -263,13 +263,15 @@ int sqd_bn_train_bwd_pre_red(const float *dy, const float *x, const float *y, co
 /* sqd_bn_train_bwd_amax that also takes the backward sums of the BatchNorm behind the residual branch (a bottleneck's down-sample BatchNorm: no
  * activation, this node its only consumer, so dres is its whole incoming gradient): x2 [M,C] its input, mean2 / rstd2 its saved statistics ->
  * part2 [sqd_bn_bwd_res_rows(M, C, pre_rows, act)][C][2] = (sum dres, sum dres * xhat2), precomputed partials for ITS sqd_bn_train_bwd_pre.
- * x2 = mean2 = rstd2 = part2 = NULL: sqd_bn_train_bwd_amax.  sqd_bn_bwd_res_rows = 0: the shape is not served (C / 4 must divide 256 on the
- * three-launch path).                                                                                                                        */
+ * x2 = mean2 = rstd2 = part2 = NULL: none taken.  dx_colsum_part (may be NULL, independent of x2): [rows][C] partial column sums of dx — their sum
+ * over the rows is the bias gradient of the convolution that produced x (for weight-gradient plans that leave none behind).
+ * sqd_bn_bwd_res_rows = 0: the shape is not served (C / 4 must divide 256 on the three-launch path).                                                                                                                        */
 int sqd_bn_bwd_res_rows(int M, int C, int pre_rows, int act);
 int sqd_bn_train_bwd_res(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma, const float *beta,
                          const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma, float *dbeta, float *part,
                          int pre_rows, int M, int C, int act, const float *red_part, float *red_out, int64_t red_n, int red_splits,
-                         float *amax_dx, float *amax_dres, const float *x2, const float *mean2, const float *rstd2, float *part2, void *stream);
+                         float *amax_dx, float *amax_dres, const float *x2, const float *mean2, const float *rstd2, float *part2, float *dx_colsum_part,
+                         void *stream);
 int sqd_bn_train_bwd_amax(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
                           const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
                           float *dbeta, float *part, int pre_rows, int M, int C, int act, const float *red_part, float *red_out,

@@ -287,7 +287,10 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
                                                            const float *__restrict__ beta, unsigned *__restrict__ amax_dx,
                                                            unsigned *__restrict__ amax_dres, const float *__restrict__ x2 = nullptr,
                                                            const float *__restrict__ mean2 = nullptr, const float *__restrict__ rstd2 = nullptr,
-                                                           float *__restrict__ part2 = nullptr) {
+                                                           float *__restrict__ part2 = nullptr, float *__restrict__ cpart = nullptr) {
+    // cpart != NULL (same launch rule): the column sums of dx, one partial row [C] per workgroup — the bias gradient of the convolution that
+    // produced x, when its weight-gradient kernel leaves none behind (a pass over dx of its own otherwise: colsum_kernel, two launches)
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
     // x2 != NULL (launched with 256 % (C / 4) == 0: a thread keeps its channel group): dres = dz is ALSO the whole gradient of the BatchNorm that
     // produced the residual branch (a bottleneck's down-sample BatchNorm: no activation, one consumer) — its two backward sums
     // (sum dz, sum dz * xhat2) are taken here, one partial row per workgroup, instead of by a pass of its own over dres and x2
@@ -337,6 +340,7 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
             q2.x = fmaf(dz.x, (xw.x - mu2.x) * rs2.x, q2.x); q2.y = fmaf(dz.y, (xw.y - mu2.y) * rs2.y, q2.y);
             q2.z = fmaf(dz.z, (xw.z - mu2.z) * rs2.z, q2.z); q2.w = fmaf(dz.w, (xw.w - mu2.w) * rs2.w, q2.w);
         }
+        cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
         am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
         amr = max(max(amr, abs_bits(dz.x)), max(abs_bits(dz.y), max(abs_bits(dz.z), abs_bits(dz.w))));
         if (cstep) {                                            // uniform
@@ -358,6 +362,18 @@ __global__ __launch_bounds__(256) void bn_apply_bwd_kernel(const float *__restri
             float *o = part2 + ((size_t)blockIdx.x * C + threadIdx.x * 4) * 2;
             reinterpret_cast<float4 *>(o)[0] = make_float4(s2.x, q2.x, s2.y, q2.y);
             reinterpret_cast<float4 *>(o)[1] = make_float4(s2.z, q2.z, s2.w, q2.w);
+        }
+    }
+    if (cpart) {   // (uniform)
+        __syncthreads();
+        red2[0][threadIdx.x] = cs;
+        __syncthreads();
+        if (threadIdx.x < V) {
+            for (unsigned k = threadIdx.x + V; k < 256u; k += V) {
+                const float4 u = red2[0][k];
+                cs.x += u.x; cs.y += u.y; cs.z += u.z; cs.w += u.w;
+            }
+            reinterpret_cast<float4 *>(cpart + (size_t)blockIdx.x * C)[threadIdx.x] = cs;
         }
     }
     amax_commit(am, amax_dx);
@@ -509,7 +525,8 @@ __global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const float *__restri
                                                            const float *__restrict__ red_part, float *__restrict__ red_out, size_t red_n, int red_splits,
                                                            unsigned *__restrict__ amax_dx, unsigned *__restrict__ amax_dres,
                                                            const float *__restrict__ x2 = nullptr, const float *__restrict__ mean2 = nullptr,
-                                                           const float *__restrict__ rstd2 = nullptr, float *__restrict__ part2 = nullptr) {
+                                                           const float *__restrict__ rstd2 = nullptr, float *__restrict__ part2 = nullptr,
+                                                           float *__restrict__ cpart = nullptr) {
     __shared__ float4 red[16][16][2];
     if ((int)blockIdx.y >= nchunks) {              // (workgroup-uniform) the pending sum of a weight gradient's pixel splits
         sqd::split_reduce_block(red_part, red_out, red_n, red_splits, ((int)blockIdx.y - nchunks) * nrb + (int)blockIdx.x,
@@ -532,7 +549,7 @@ __global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const float *__restri
     const int r0 = blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
     unsigned am = 0u, amr = 0u;
     // x2 != NULL: the backward sums of the BatchNorm behind the residual branch, one partial row per row block (bn_apply_bwd_kernel)
-    float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f), q2 = s2, mu2 = s2, rs2 = s2;
+    float4 s2 = make_float4(0.f, 0.f, 0.f, 0.f), q2 = s2, mu2 = s2, rs2 = s2, cs = s2;
     if (x2) {
         mu2 = *reinterpret_cast<const float4 *>(mean2 + c);
         rs2 = *reinterpret_cast<const float4 *>(rstd2 + c);
@@ -556,8 +573,22 @@ __global__ __launch_bounds__(256) void bn_fused_bwd_kernel(const float *__restri
             q2.x = fmaf(dz.x, (xw.x - mu2.x) * rs2.x, q2.x); q2.y = fmaf(dz.y, (xw.y - mu2.y) * rs2.y, q2.y);
             q2.z = fmaf(dz.z, (xw.z - mu2.z) * rs2.z, q2.z); q2.w = fmaf(dz.w, (xw.w - mu2.w) * rs2.w, q2.w);
         }
+        cs.x += o.x; cs.y += o.y; cs.z += o.z; cs.w += o.w;
         am = max(max(am, abs_bits(o.x)), max(abs_bits(o.y), max(abs_bits(o.z), abs_bits(o.w))));
         amr = max(max(amr, abs_bits(dz.x)), max(abs_bits(dz.y), max(abs_bits(dz.z), abs_bits(dz.w))));
+    }
+    if (cpart) {   // (uniform) column sums of dx, one partial row per row block (bn_apply_bwd_kernel)
+        __syncthreads();
+        red[rl][cgl][0] = cs;
+        __syncthreads();
+        if (rl == 0) {
+#pragma unroll
+            for (int k = 1; k < 16; ++k) {
+                const float4 u = red[k][cgl][0];
+                cs.x += u.x; cs.y += u.y; cs.z += u.z; cs.w += u.w;
+            }
+            *reinterpret_cast<float4 *>(cpart + (size_t)blockIdx.x * C + c) = cs;
+        }
     }
     if (x2) {      // (uniform; chunk_sums is done with `red`: every thread has passed its barrier and read its sums)
         __syncthreads();
@@ -708,10 +739,11 @@ extern "C" int sqd_bn_train_bwd_amax(const float *dy, const float *x, const floa
                                      float *dbeta, float *part, int pre_rows, int M, int C, int act, const float *red_part, float *red_out,
                                      int64_t red_n, int red_splits, float *amax_dx, float *amax_dres, void *stream) {
     return sqd_bn_train_bwd_res(dy, x, y, mask, gamma, beta, save_mean, save_rstd, dx, dres, dgamma, dbeta, part, pre_rows, M, C, act, red_part, red_out,
-                                red_n, red_splits, amax_dx, amax_dres, nullptr, nullptr, nullptr, nullptr, stream);
+                                red_n, red_splits, amax_dx, amax_dres, nullptr, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
-// the partial rows sqd_bn_train_bwd_res writes for the residual branch's BatchNorm at this shape (0: this shape does not take them)
+// the partial rows sqd_bn_train_bwd_res writes — for the residual branch's BatchNorm and for the column sums of dx — at this shape (0: this shape
+// does not take them)
 extern "C" int sqd_bn_bwd_res_rows(int M, int C, int pre_rows, int act) {
     if (M <= 0 || C < 4 || C % 4 || act == ACT_SWISH) return 0;
     if (pre_rows > 0 && pre_rows <= FUSE_MAX_ROWS && C % 64 == 0) {
@@ -726,14 +758,17 @@ extern "C" int sqd_bn_bwd_res_rows(int M, int C, int pre_rows, int act) {
 // ... and, with x2 / mean2 / rstd2 / part2 (all or none; dres required), the two backward sums of the BatchNorm that produced the residual branch
 // (no activation, this node its only consumer: dres IS its incoming gradient): x2 [M,C] that BatchNorm's input, mean2 / rstd2 its saved
 // statistics -> part2 [sqd_bn_bwd_res_rows(M, C, pre_rows, act)][C][2] = (sum dres, sum dres * xhat2), to be handed to its own backward as
-// precomputed partials (sqd_bn_train_bwd_pre) — the pass over dres and x2 that would take them is not run
+// precomputed partials (sqd_bn_train_bwd_pre) — the pass over dres and x2 that would take them is not run.
+// dx_colsum_part (may be NULL, independent of x2): [sqd_bn_bwd_res_rows(...)][C] partial column sums of dx — summed over the rows they are the bias
+// gradient of the convolution that produced x
 extern "C" int sqd_bn_train_bwd_res(const float *dy, const float *x, const float *y, const unsigned char *mask, const float *gamma,
                                     const float *beta, const float *save_mean, const float *save_rstd, float *dx, float *dres, float *dgamma,
                                     float *dbeta, float *part, int pre_rows, int M, int C, int act, const float *red_part, float *red_out,
                                     int64_t red_n, int red_splits, float *amax_dx, float *amax_dres, const float *x2, const float *mean2,
-                                    const float *rstd2, float *part2, void *stream) {
+                                    const float *rstd2, float *part2, float *dx_colsum_part, void *stream) {
     SQD_CHECK_ARG((!x2 && !mean2 && !rstd2 && !part2) || (x2 && mean2 && rstd2 && part2 && dres && sqd_bn_bwd_res_rows(M, C, pre_rows, act) > 0),
                   "sqd_bn_train_bwd_res: the residual branch's sums need x2, mean2, rstd2, part2, dres and a shape sqd_bn_bwd_res_rows accepts");
+    SQD_CHECK_ARG(!dx_colsum_part || sqd_bn_bwd_res_rows(M, C, pre_rows, act) > 0, "sqd_bn_train_bwd_res: dx_colsum_part at a shape sqd_bn_bwd_res_rows does not accept");
     SQD_CHECK_ARG(!red_part || (red_out && red_n > 0 && red_n % 4 == 0 && red_splits >= 1), "sqd_bn_train_bwd_pre_red: bad pending reduction");
     SQD_CHECK_ARG(dy && x && gamma && save_mean && save_rstd && dx && dgamma && dbeta && part, "sqd_bn_train_bwd: null pointer");
     SQD_CHECK_ARG(pre_rows >= 0 && (pre_rows == 0 || act != ACT_SWISH), "sqd_bn_train_bwd_pre: pre_rows=%d (no precomputed partials with swish)", pre_rows);
@@ -748,7 +783,7 @@ extern "C" int sqd_bn_train_bwd_res(const float *dy, const float *x, const float
         const int nredb = red_part ? (int)((red_n / 4 + 15) / 16) : 0;             // blocks of the pending split reduction, nrb per grid row
         hipLaunchKernelGGL(bn_fused_bwd_kernel, dim3(nrb, nchunks + (nredb + nrb - 1) / nrb), dim3(256), 0, s, dy, x, y, gamma, save_mean, save_rstd, part,
                            pre_rows, dgamma, dbeta, dx, dres, M, C, act, mask, rpb, nchunks, nrb, red_part, red_out, (size_t)red_n, red_splits,
-                           (unsigned *)amax_dx, (unsigned *)amax_dres, x2, mean2, rstd2, part2);
+                           (unsigned *)amax_dx, (unsigned *)amax_dres, x2, mean2, rstd2, part2, dx_colsum_part);
         SQD_CHECK_LAUNCH("sqd_bn_train_bwd");
         return SQD_OK;
     }
@@ -758,9 +793,9 @@ extern "C" int sqd_bn_train_bwd_res(const float *dy, const float *x, const float
     hipLaunchKernelGGL(bn_finalize_bwd_kernel, dim3(nfin + nred), dim3(256), 0, s, part, pre_rows > 0 ? pre_rows : g.nblk, M, C, dgamma, dbeta, nfin,
                        red_part, red_out, (size_t)red_n, red_splits);
     const size_t total4 = (size_t)M * C / 4;
-    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(x2 ? sqd_bn_bwd_res_rows(M, C, pre_rows, act) : ew_grid(total4)), dim3(256), 0, s, dy, x, y, gamma, save_mean,
-                       save_rstd, dgamma, dbeta, dx, dres, total4, C, 1.0f / (float)M, act, mask, beta, (unsigned *)amax_dx, (unsigned *)amax_dres, x2, mean2, rstd2,
-                       part2);
+    hipLaunchKernelGGL(bn_apply_bwd_kernel, dim3(x2 || dx_colsum_part ? sqd_bn_bwd_res_rows(M, C, pre_rows, act) : ew_grid(total4)), dim3(256), 0, s, dy, x, y, gamma,
+                       save_mean, save_rstd, dgamma, dbeta, dx, dres, total4, C, 1.0f / (float)M, act, mask, beta, (unsigned *)amax_dx, (unsigned *)amax_dres, x2, mean2,
+                       rstd2, part2, dx_colsum_part);
     SQD_CHECK_LAUNCH("sqd_bn_train_bwd");
     return SQD_OK;
 }

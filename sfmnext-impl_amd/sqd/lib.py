@@ -235,7 +235,7 @@ _SIGNATURES = {
     "sqd_conv_wgrad_partials": (_I, [_P, _P, _P, _P, _P] + [_I] * 11 + [ctypes.POINTER(ctypes.c_int), _P]),
     "sqd_bn_train_fwd_amax": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P, _I, _P, _P]),
     "sqd_bn_train_bwd_amax": (_I, [_P] * 13 + [_I, _I, _I, _I, _P, _P, ctypes.c_int64, _I, _P, _P, _P]),
-    "sqd_bn_train_bwd_res": (_I, [_P] * 13 + [_I, _I, _I, _I, _P, _P, ctypes.c_int64, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "sqd_bn_train_bwd_res": (_I, [_P] * 13 + [_I, _I, _I, _I, _P, _P, ctypes.c_int64, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "sqd_bn_bwd_res_rows": (_I, [_I, _I, _I, _I]),
     "sqd_upcat_fwd_amax": (_I, [_P, _P, _P] + [_I] * 7 + [_P, _P]),
     "sqd_space_to_depth2_planar_amax": (_I, [_P, _P, _P] + [_I] * 6 + [ctypes.c_int64, ctypes.c_float, ctypes.c_float, _P, _P]),

@@ -210,6 +210,7 @@ class BatchNormAct(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, running_mean, running_var, residual, training, momentum, eps, act, pre_part=None, pre_rows=0, shared=None,
                 pool_part=None):
         _require(x, "BatchNormAct input")
+        x_in = x
         x = _cl(x)
         N, C, H, W = x.shape
         M = N * H * W
@@ -244,6 +245,10 @@ class BatchNormAct(torch.autograd.Function):
             # the residual branch is itself the output of a training-mode BatchNorm without activation (a bottleneck's down-sample branch):
             # this node's backward can take that node's two sums on the way (dres is its whole gradient if this node is its only consumer —
             # its backward checks that the tensor that arrives is the dres written here)
+            # x is the output of a convolution with a bias whose weight-gradient plan leaves no bias partials behind: this node's backward writes
+            # dx, whose column sums ARE that bias gradient — it takes them on the way (Conv2d.backward finds them tagged on dx: _colsum_get)
+            bg = getattr(x_in, "_sqd_bias_geom", None) if FUSE_BN_SIDE_SUMS["bias"] and x is x_in else None
+            ctx.want_dxsum = bg is not None and (L.sqd_conv_wgrad_effective_impl(*bg) & 15) not in (1, 4)
             rs = getattr(residual, "_sqd_bn_src", None) if FUSE_BN_BWD_STATS and FUSE_BN_SIDE_SUMS["res"] else None
             ctx.res_src = rs if rs is not None and rs.get("code") == 0 and rs["x"].shape == x.shape else None
         else:
@@ -280,13 +285,21 @@ class BatchNormAct(torch.autograd.Function):
         adx = _amax_out(x.device)
         adr = _amax_out(x.device) if dres is not None else None
         src2 = getattr(ctx, "res_src", None) if dres is not None else None
-        rows2 = L.sqd_bn_bwd_res_rows(M, C, pre_rows, ctx.code) if src2 is not None else 0
+        want_cs = getattr(ctx, "want_dxsum", False)
+        rows2 = L.sqd_bn_bwd_res_rows(M, C, pre_rows, ctx.code) if src2 is not None or want_cs else 0
         if rows2 > 0:
-            part2 = torch.empty(rows2 * C * 2, device=x.device, dtype=torch.float32)
+            part2 = torch.empty(rows2 * C * 2, device=x.device, dtype=torch.float32) if src2 is not None else None
+            cpart = torch.empty(rows2, C, device=x.device, dtype=torch.float32) if want_cs else None
             _l.check(L.sqd_bn_train_bwd_res(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
                                             _ptr(dgamma), _ptr(dbeta), _ptr(part), pre_rows, M, C, ctx.code, _ptr(rp), _ptr(ro), rn, rs,
-                                            _ptr(adx), _ptr(adr), _ptr(src2["x"]), _ptr(src2["mean"]), _ptr(src2["rstd"]), _ptr(part2), _stream()), "bn_train_bwd_res")
-            src2.update(dx=dres, part=part2, rows=rows2)
+                                            _ptr(adx), _ptr(adr), _ptr(src2["x"]) if src2 is not None else None, _ptr(src2["mean"]) if src2 is not None else None,
+                                            _ptr(src2["rstd"]) if src2 is not None else None, _ptr(part2), _ptr(cpart), _stream()), "bn_train_bwd_res")
+            if src2 is not None:
+                src2.update(dx=dres, part=part2, rows=rows2)
+            if cpart is not None:
+                cs = torch.empty(C, device=x.device, dtype=torch.float32)
+                _colsum_multi([(cpart, cs, 0)])
+                _colsum_tag(dx, cs)                      # column sums of dx [C]: Conv2d.backward takes them as its bias gradient
         else:
             _l.check(L.sqd_bn_train_bwd_amax(_ptr(dy), _ptr(x), None, _ptr(mask), _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(rstd), _ptr(dx), _ptr(dres),
                                              _ptr(dgamma), _ptr(dbeta), _ptr(part), pre_rows, M, C, ctx.code, _ptr(rp), _ptr(ro), rn, rs,
@@ -1233,6 +1246,8 @@ class Conv2d(torch.autograd.Function):
             _WEIGHT_USES[ctx.wkey] = _WEIGHT_USES.get(ctx.wkey, 0) + 1
         ctx.geom = geom
         ctx.has_bias, ctx.act = bias is not None, act
+        if bias is not None and act is None:
+            y._sqd_bias_geom = geom          # (read by a BatchNormAct node that takes y: its backward can deliver this node's bias gradient)
         ctx.bn_src = getattr(x_in, "_sqd_bn_src", None)  # x is the output of a training-mode BatchNormAct: see backward
         # what the backward pass may need of this step's scales (saved tensors come back as other Python objects: the tags would be lost)
         ctx.am = (ax, aw, _weight_source(weight), _AM["epoch"])
@@ -1523,7 +1538,8 @@ def conv_out_geom(x, conv, s2d=False):
 FUSE_BN_BWD_STATS = True      # BatchNorm-backward sums from the consuming convolution's data-gradient epilogue (tools may switch it off)
 # ... and from the other passes that write a BatchNorm's whole gradient: "res" the main branch's element-wise pass (down-sample BatchNorms),
 # "pool" the max-pool backward gather (the stem), "upcat" the adjoint of the decoder's up-sampling (tools/ab_bench.py switches them one by one)
-FUSE_BN_SIDE_SUMS = {"res": True, "pool": True, "upcat": True}
+# "bias": the column sums of a BatchNorm backward's dx = the bias gradient of the convolution in front of it, where its weight-gradient kernel leaves none
+FUSE_BN_SIDE_SUMS = {"res": True, "pool": True, "upcat": True, "bias": True}
 _DEFER_COUNTERS = False
 _PENDING_COUNTERS = []
 

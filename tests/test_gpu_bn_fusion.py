@@ -263,6 +263,62 @@ def test_decoder_batchnorm_sums_ride_on_the_upsample_concat_backward(N, Hi, Wi, 
         assert ef <= 2e-4 and ef <= 4.0 * eu + 2e-6, (name, "fused", ef, "unfused", eu)
 
 
+@pytest.mark.parametrize("N,C,H,W,K,impl,splits,expect", [
+    (2, 64, 24, 40, 128, 2 | (2 << 4), 7, True),      # fp32 shared-operand weight gradient: leaves no bias partials -> the BatchNorm backward delivers dbias
+    (8, 64, 48, 80, 64, 3 | (3 << 4), 8, True),       # three-term shared-operand plan; 240 partial rows: the three-launch BatchNorm path
+    (2, 64, 24, 40, 32, 1, 3, False),                 # fp32 direct plan: leaves bias partials, nothing to take over
+])
+def test_bias_gradient_from_the_batchnorm_backward(N, C, H, W, K, impl, splits, expect):
+    """x -> conv(bias) -> bn + act -> conv: the column sums of the BatchNorm backward's dx are the first convolution's bias gradient; where its
+    weight-gradient plan leaves no bias partials behind, the BatchNorm's element-wise pass takes them (sqd_bn_train_bwd_res's dx_colsum_part)
+    instead of two colsum launches over dx"""
+    from sqd import lib, nnkernels, nnops
+    import copy
+    L = lib.lib()
+    torch.manual_seed(C + K)
+    conv1, bn, conv2 = nn.Conv2d(C, K, 3, 1, 1, bias=True), nn.BatchNorm2d(K), nn.Conv2d(K, 16, 1, bias=False)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5)
+        bn.bias.uniform_(-0.3, 0.3)
+    x = torch.randn(N, C, H, W)
+    r = [copy.deepcopy(m).double() for m in (conv1, bn, conv2)]
+    xr = x.double().requires_grad_(True)
+    out_r = (r[2](F.leaky_relu(r[1](r[0](xr)), 0.01)) ** 2).sum()
+    out_r.backward()
+    tagged = []
+    orig_tag = nnkernels._colsum_tag
+    nnkernels.reset_plans()
+    try:
+        nnkernels._PLAN_CACHE.clear()
+        assert L.sqd_conv_wgrad_set_plan(N, H, W, C, K, 3, 3, impl, splits) == 0, L.sqd_last_error()
+
+        def tag(t, cs):
+            tagged.append(tuple(t.shape))
+            return orig_tag(t, cs)
+        nnkernels._colsum_tag = tag
+        m = [copy.deepcopy(q).cuda() for q in (conv1, bn, conv2)]
+        for q in (m[0], m[2]):
+            q.to(memory_format=torch.channels_last)
+        xg = x.cuda().contiguous(memory_format=torch.channels_last).requires_grad_(True)
+        z = nnops.conv_bn_act(xg, m[0], m[1], "leaky_relu")
+        out = (nnops.conv2d(z, m[2]) ** 2).sum()
+        out.backward()
+    finally:
+        nnkernels._colsum_tag = orig_tag
+        L.sqd_conv_wgrad_set_plan(N, H, W, C, K, 3, 3, -1, 0)
+        nnkernels.reset_plans()
+    assert ((N, K, H, W) in tagged) == expect, tagged
+    # the bias gradient of a convolution in front of a BatchNorm is a sum that cancels analytically: compare on the scale of the terms that cancel
+    # (sum |dx| per channel), as for every fp32 path
+    for name, got, ref in (("dx", xg.grad, xr.grad), ("dW1", m[0].weight.grad, r[0].weight.grad), ("dgamma", m[1].weight.grad, r[1].weight.grad)):
+        err = float((got.cpu().double() - ref).abs().max()) / float(ref.abs().max())
+        assert err <= 2e-4, (name, err)
+    zr = r[0](xr.detach()).detach().requires_grad_(True)
+    (r[2](F.leaky_relu(r[1](zr), 0.01)) ** 2).sum().backward()
+    scale = float(zr.grad.abs().sum((0, 2, 3)).max())
+    assert float((m[0].bias.grad.cpu().double() - r[0].bias.grad).abs().max()) <= 2e-6 * scale, (m[0].bias.grad, r[0].bias.grad, scale)
+
+
 def test_summed_gradient_takes_the_ordinary_path():
     """the BatchNorm output feeds the convolution AND a second consumer directly (no skip hand-over): autograd sums the two gradients,
     the tensor the BatchNorm node receives is not the data gradient's, and the node must run its own reduction — results as float64"""

@@ -31,7 +31,9 @@ for c in cls:
 
     def backward(ctx, *a, _o=o, _c=c):
         if a[0] is not None and (getattr(ctx, "act", None) is not None or getattr(ctx, "has_bias", False)):
-            log.append((_c.__name__, names.get(getattr(ctx, "wkey", None), "?"), tuple(ctx.geom), ctx.act, ctx.has_bias, nnkernels._colsum_get(a[0]) is not None))
+            N, H, W, C, K, R, S, stride, pad, Ho, Wo = ctx.geom
+            log.append((_c.__name__, names.get(getattr(ctx, "wkey", None), "?"), tuple(ctx.geom), ctx.act, ctx.has_bias, nnkernels._colsum_get(a[0]) is not None,
+                        nnkernels.CHOSEN_PLANS.get(("wgrad", N, Ho, Wo, C, K, R, S))))
         return _o(ctx, *a)
     c.backward = staticmethod(backward)
 batch = synthetic_batch(opts.batch_size, opts.height, opts.width, opts.frame_ids, device=tr.device)
@@ -41,4 +43,4 @@ for i in range(2):
 print("%d convolution backward nodes with an activation or a bias:" % len(log))
 for l in log:
     N, H, W, C, K, R, S, stride, pad, Ho, Wo = l[2]
-    print("  %-14s %-44s x [%d,%d,%d,%d] -> K %d %dx%d/%d  dy %.1f MB  act %s  bias %s  colsum tag on dy %s" % (l[0], l[1], N, C, H, W, K, R, S, stride, N * Ho * Wo * K * 4 / 1e6, l[3], l[4], l[5]))
+    print("  %-14s %-44s x [%d,%d,%d,%d] -> K %d %dx%d/%d  dy %.1f MB  act %s  bias %s  colsum tag on dy %s  wgrad plan %s" % (l[0], l[1], N, C, H, W, K, R, S, stride, N * Ho * Wo * K * 4 / 1e6, l[3], l[4], l[5], l[6]))
