@@ -248,7 +248,7 @@ class BatchNormAct(torch.autograd.Function):
             # x is the output of a convolution with a bias whose weight-gradient plan leaves no bias partials behind: this node's backward writes
             # dx, whose column sums ARE that bias gradient — it takes them on the way (Conv2d.backward finds them tagged on dx: _colsum_get)
             bg = getattr(x_in, "_sqd_bias_geom", None) if FUSE_BN_SIDE_SUMS["bias"] and x is x_in else None
-            ctx.want_dxsum = bg is not None and (L.sqd_conv_wgrad_effective_impl(*bg) & 15) not in (1, 4)
+            ctx.want_dxsum = bg is not None and _wgrad_key(bg) in _WGRAD_SETTLED and (L.sqd_conv_wgrad_effective_impl(*bg) & 15) not in (1, 4)
             rs = getattr(residual, "_sqd_bn_src", None) if FUSE_BN_BWD_STATS and FUSE_BN_SIDE_SUMS["res"] else None
             ctx.res_src = rs if rs is not None and rs.get("code") == 0 and rs["x"].shape == x.shape else None
         else:
@@ -703,6 +703,13 @@ def load_plans(rec):
             _TUNED.add((mode,) + geom)
 
 
+# weight-gradient geometries (output-geometry keys) whose backward has run at least once in this process: their plan is settled — timed in that
+# first backward, or pinned from a file — so a decision taken from it (BatchNormAct.forward: who delivers the bias gradient) is the same in the run
+# that timed the plans and in a run that loads them: both decide from their second step on, both from the same plan (the plan-pinning contract of
+# tests/test_gpu_plans.py: a pinned run trains to the bits of the run that wrote the file)
+_WGRAD_SETTLED = set()
+
+
 def reset_plans():
     """Forget every measured / pinned plan (library table and this module's caches) and stop timing plans: the cost-model plans
     apply again."""
@@ -715,6 +722,7 @@ def reset_plans():
     CHOSEN_PLANS.clear()
     _TUNED.clear()
     _PLAN_CACHE.clear()
+    _WGRAD_SETTLED.clear()
     global TUNE_CONV
     TUNE_CONV = False             # (nnops.configure switches plan timing on again for the next Trainer that wants it)
 
@@ -1311,6 +1319,7 @@ class Conv2d(torch.autograd.Function):
             dw = torch.empty((K, C, R, S), device=dy.device, dtype=torch.float32, memory_format=torch.channels_last)
             db = torch.empty(K, device=dy.device, dtype=torch.float32) if ctx.has_bias else None
             db_k = db                                    # what the weight-gradient kernels are asked to fill
+            _WGRAD_SETTLED.add(_wgrad_key(ctx.geom))
             if db is not None and pre_db is not None and pre_db.numel() == K:
                 # the pass that wrote dy also summed its columns (GELU / layer-scale backward): that IS dbias
                 db, db_k = pre_db, None
