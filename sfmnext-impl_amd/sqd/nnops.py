@@ -42,6 +42,7 @@ def configure(opt, device):
     nnkernels.amax_enable(not opt.sqd_bf16 and not getattr(opt, "sqd_no_f16x2", False))
     nnkernels.TUNE_SPACE["f16x2"] = not getattr(opt, "sqd_no_f16x2", False)
     nnkernels.TUNE_CONV = not opt.sqd_no_conv_tune and torch.device(device).type == "cuda"     # first step: ~2 s of plan timing
+    nnkernels._WGRAD_SETTLED.clear()     # (a run decides from settled weight-gradient plans from ITS second step on, whatever ran in the process before)
     if getattr(opt, "sqd_conv_plans", None):
         import json
         with open(opt.sqd_conv_plans) as f:
