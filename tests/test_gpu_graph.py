@@ -110,6 +110,33 @@ def test_graph_replay_trains_every_parameter():
         assert abs(after - before) > 1e-3 * abs(before), (before, after)
 
 
+def test_captured_step_keeps_its_source_frames_channels_last():
+    """the static source frames of the captured step are channels_last tensors (the photometric kernels' cheaper layout, trainer._capture):
+    same shape and values for a reader of `inputs` / `outputs`, written by the copy-in of every batch; the eager run keeps planar frames; the two
+    train alike (test_graph_replay_matches_eager), and configurations the channels_last kernels do not serve keep planar frames in the graph too"""
+    from datasets.synthetic import synthetic_batch
+    tr, _, _ = run([], steps=5)
+    assert tr._graph is not None and sorted(tr._hwc_keys) == [("color", -1, 0), ("color", 1, 0)]
+    batch = synthetic_batch(2, 64, 96, tr.opt.frame_ids, start=77, device=tr.device)
+    batch[("noise", 0)] = torch.randn(2, 2, 64, 96).cuda()
+    want = {k: v.clone() for k, v in batch.items()}
+    outputs, _ = tr.train_step(batch)
+    for k, v in want.items():
+        st = tr._static_in[k]
+        assert batch[k] is st and st.shape == v.shape and torch.equal(st, v), k
+        cl = not st.is_contiguous() and st.is_contiguous(memory_format=torch.channels_last)
+        assert cl == (k in tr._hwc_keys), (k, st.stride())
+    for f in (-1, 1):
+        assert torch.equal(outputs[("color_identity", f, 0)], want[("color", f, 0)])
+    # a host batch (a loader's) takes the same route
+    host = {k: v.cpu() for k, v in want.items()}
+    tr.train_step(host)
+    assert all(torch.equal(tr._static_in[k], want[k]) for k in want)
+    tr_s, _, _ = run(["--no_ssim"], steps=5)          # a loss option: round 5's forward kernel, planar frames
+    assert tr_s._graph is not None and tr_s._hwc_keys == []
+    assert all(t.is_contiguous() for k, t in tr_s._static_in.items() if k[0] == "color")
+
+
 def test_tuned_plans_train_like_the_default_plans():
     """The configuration that is benchmarked — first-step plan timing on: per layer the fastest of the fp32, three-term bf16,
     input-patch (3x3 and stems) and weight-gradient variants — must train like the library's default plans: every plan is an fp32-level
