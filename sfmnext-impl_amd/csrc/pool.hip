@@ -62,40 +62,68 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float *__restric
         mub = reinterpret_cast<const float4 *>(meanb)[threadIdx.x % V];
         rsb = reinterpret_cast<const float4 *>(rstdb)[threadIdx.x % V];
     }
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int cg = (int)(i % V);
-        size_t t = i / V;
-        const int wi = (int)(t % W);
-        t /= W;
-        const int hi = (int)(t % H), n = (int)(t / H);
-        float4 g = addend ? reinterpret_cast<const float4 *>(addend)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-        // windows containing row hi: 2ho-1 <= hi <= 2ho+1
-        const int ho0 = hi / 2, ho1 = (hi + 1) / 2, wo0 = wi / 2, wo1 = (wi + 1) / 2;
-        for (int ho = ho0; ho <= ho1; ++ho) {
-            if (ho >= Ho) continue;
-            const int r = hi - (2 * ho - 1);
-            for (int wo = wo0; wo <= wo1; ++wo) {
-                if (wo >= Wo) continue;
-                const int p = r * 3 + wi - (2 * wo - 1);
-                const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * V + cg;
-                const uchar4 k = reinterpret_cast<const uchar4 *>(idx)[o];
-                const float4 v = reinterpret_cast<const float4 *>(dy)[o];
-                if (k.x == p) g.x += v.x;
-                if (k.y == p) g.y += v.y;
-                if (k.z == p) g.z += v.z;
-                if (k.w == p) g.w += v.w;
+    // a thread takes a 2 x 2 quad of input pixels (rows 2a, 2a+1, columns 2b, 2b+1) of one channel group: the four windows that can hold them —
+    // (a, b) all four, (a, b+1) the odd column, (a+1, b) the odd row, (a+1, b+1) the odd-odd pixel — are fetched ONCE (until round 6: per pixel, nine
+    // window fetches per quad: 40.5 / 44.3 / 68.3 us without / with the skip gradient / with the BatchNorm sums at 12 x 64 x 96 x 320 against 24.0 /
+    // 37.1 / 58.0 now, tools/bench_pool.py); per pixel the same terms in the same order as before (the other consumer's gradient, then the windows
+    // by row, column)
+    const int H2 = (H + 1) / 2, W2 = (W + 1) / 2;
+    const size_t quads = (size_t)N * H2 * W2 * V;
+    (void)total;
+    for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < quads; q += (size_t)gridDim.x * 256) {
+        const int cg = (int)(q % V);
+        size_t t = q / V;
+        const int b2 = (int)(t % W2);
+        t /= W2;
+        const int a2 = (int)(t % H2), n = (int)(t / H2);
+        uchar4 k[2][2];
+        float4 v[2][2];
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+            for (int dw = 0; dw < 2; ++dw) {
+                const int ho = a2 + dh, wo = b2 + dw;
+                if (ho < Ho && wo < Wo) {
+                    const size_t o = (((size_t)n * Ho + ho) * Wo + wo) * V + cg;
+                    k[dh][dw] = reinterpret_cast<const uchar4 *>(idx)[o];
+                    v[dh][dw] = reinterpret_cast<const float4 *>(dy)[o];
+                } else {
+                    k[dh][dw] = make_uchar4(255, 255, 255, 255);        // (no window: matches no position)
+                    v[dh][dw] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
             }
-        }
-        reinterpret_cast<float4 *>(dx)[i] = g;
-        if (xb) {
-            const unsigned bits = maskb ? maskb[i] : 0xfu;
-            const float4 xv = reinterpret_cast<const float4 *>(xb)[i];
-            const float d0 = g.x * ((bits & 1u) ? 1.f : slope), d1 = g.y * ((bits & 2u) ? 1.f : slope), d2 = g.z * ((bits & 4u) ? 1.f : slope),
-                        d3 = g.w * ((bits & 8u) ? 1.f : slope);
-            sb.x += d0; sb.y += d1; sb.z += d2; sb.w += d3;
-            qb.x = fmaf(d0, (xv.x - mub.x) * rsb.x, qb.x); qb.y = fmaf(d1, (xv.y - mub.y) * rsb.y, qb.y);
-            qb.z = fmaf(d2, (xv.z - mub.z) * rsb.z, qb.z); qb.w = fmaf(d3, (xv.w - mub.w) * rsb.w, qb.w);
-        }
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int pw = 0; pw < 2; ++pw) {
+                const int hi = 2 * a2 + ph, wi = 2 * b2 + pw;
+                if (hi >= H || wi >= W) continue;
+                const size_t i = (((size_t)n * H + hi) * W + wi) * V + cg;
+                float4 g = addend ? reinterpret_cast<const float4 *>(addend)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+                // windows holding row hi: ho = a (position row 1 for an even row, 2 for an odd one) and, for an odd row, ho = a + 1 (position row 0)
+#pragma unroll
+                for (int dh = 0; dh <= ph; ++dh)
+#pragma unroll
+                    for (int dw = 0; dw <= pw; ++dw) {
+                        const int p = (ph + 1 - 2 * dh) * 3 + (pw + 1 - 2 * dw);
+                        const uchar4 kk = k[dh][dw];
+                        const float4 vv = v[dh][dw];
+                        if (kk.x == p) g.x += vv.x;
+                        if (kk.y == p) g.y += vv.y;
+                        if (kk.z == p) g.z += vv.z;
+                        if (kk.w == p) g.w += vv.w;
+                    }
+                reinterpret_cast<float4 *>(dx)[i] = g;
+                if (xb) {
+                    const unsigned bits = maskb ? maskb[i] : 0xfu;
+                    const float4 xv = reinterpret_cast<const float4 *>(xb)[i];
+                    const float d0 = g.x * ((bits & 1u) ? 1.f : slope), d1 = g.y * ((bits & 2u) ? 1.f : slope), d2 = g.z * ((bits & 4u) ? 1.f : slope),
+                                d3 = g.w * ((bits & 8u) ? 1.f : slope);
+                    sb.x += d0; sb.y += d1; sb.z += d2; sb.w += d3;
+                    qb.x = fmaf(d0, (xv.x - mub.x) * rsb.x, qb.x); qb.y = fmaf(d1, (xv.y - mub.y) * rsb.y, qb.y);
+                    qb.z = fmaf(d2, (xv.z - mub.z) * rsb.z, qb.z); qb.w = fmaf(d3, (xv.w - mub.w) * rsb.w, qb.w);
+                }
+            }
     }
     if (xb) {      // (uniform) the workgroup's partial row: the threads of a channel group added in a fixed order
         red[0][threadIdx.x] = sb;
@@ -138,8 +166,8 @@ extern "C" int sqd_maxpool3x3s2_bwd(const float *dy, const unsigned char *idx, c
     SQD_CHECK_ARG(dy && idx && dx && N > 0 && H > 0 && W > 0 && C >= 4 && C % 4 == 0, "sqd_maxpool3x3s2_bwd: bad arguments (C=%d)", C);
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     (void)hipGetLastError();
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((size_t)N * H * W * C / 4)), dim3(256), 0, (hipStream_t)stream, dy, idx, addend, dx, N,
-                       H, W, C, Ho, Wo);
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for((size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C / 4)), dim3(256), 0, (hipStream_t)stream, dy, idx, addend,
+                       dx, N, H, W, C, Ho, Wo);                 // (a thread per 2 x 2 quad of input pixels and channel group)
     SQD_CHECK_LAUNCH("sqd_maxpool3x3s2_bwd");
     return SQD_OK;
 }
@@ -147,7 +175,7 @@ extern "C" int sqd_maxpool3x3s2_bwd(const float *dy, const unsigned char *idx, c
 // the partial rows sqd_maxpool3x3s2_bwd_bn writes at this shape (0: not served — the channel groups must divide a workgroup's 256 threads)
 extern "C" int sqd_maxpool3x3s2_bwd_bn_rows(int N, int H, int W, int C) {
     if (N <= 0 || H <= 0 || W <= 0 || C < 4 || C % 4 || 256 % (C / 4)) return 0;
-    const int g = grid_for((size_t)N * H * W * C / 4);
+    const int g = grid_for((size_t)N * ((H + 1) / 2) * ((W + 1) / 2) * C / 4);
     return g < 2048 ? g : 2048;
 }
 
