@@ -150,9 +150,19 @@ __global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumSegs S) {
     }
     red[rg][cl] = a;
     __syncthreads();
+    if (RG > 32) {      // (many row groups: a fixed-order tree down to 32 of them before the serial tail)
+        for (int w = RG / 2; w >= 32; w >>= 1) {
+            if (rg < w) {
+                const float4 v = red[rg + w][cl];
+                a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+                red[rg][cl] = a;
+            }
+            __syncthreads();
+        }
+    }
     if (rg == 0 && on) {
 #pragma unroll
-        for (int k = 1; k < RG; ++k) {
+        for (int k = 1; k < (RG > 32 ? 32 : RG); ++k) {
             const float4 v = red[k][cl];
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
@@ -560,7 +570,9 @@ extern "C" int sqd_colsum_multi(const float *const *src, float *const *dst, cons
     ColsumSegs S;
     int blk = 0, max_rows = 0;
     for (int s = 0; s < nseg; ++s) max_rows = nrows[s] > max_rows ? nrows[s] : max_rows;
-    const int CW = max_rows >= 256 ? 8 : 32;
+    // (thousands of partial rows over a few dozen columns — the column sums the BatchNorm backward passes leave for a bias gradient, nnkernels.py —:
+    //  2 columns x 128 row groups, 16 sequential loads per thread at 2048 rows; with 8 x 32 one workgroup walked 64 and took 16 us)
+    const int CW = max_rows >= 1024 ? 2 : max_rows >= 256 ? 8 : 32;
     for (int s = 0; s < nseg; ++s) {
         SQD_CHECK_ARG(src[s] && dst[s] && nrows[s] >= 1 && ncols[s] >= 4 && ncols[s] % 4 == 0 && tr[s] >= 0 &&
                           (tr[s] == 0 || ncols[s] % tr[s] == 0),
@@ -572,7 +584,8 @@ extern "C" int sqd_colsum_multi(const float *const *src, float *const *dst, cons
     S.blk0[nseg] = blk;
     S.nseg = nseg;
     (void)hipGetLastError();
-    if (CW == 8) hipLaunchKernelGGL(colsum_multi_kernel<8>, dim3(blk), dim3(256), 0, (hipStream_t)stream, S);
+    if (CW == 2) hipLaunchKernelGGL(colsum_multi_kernel<2>, dim3(blk), dim3(256), 0, (hipStream_t)stream, S);
+    else if (CW == 8) hipLaunchKernelGGL(colsum_multi_kernel<8>, dim3(blk), dim3(256), 0, (hipStream_t)stream, S);
     else hipLaunchKernelGGL(colsum_multi_kernel<32>, dim3(blk), dim3(256), 0, (hipStream_t)stream, S);
     SQD_CHECK_LAUNCH("sqd_colsum_multi");
     return SQD_OK;

@@ -333,3 +333,18 @@ def test_batchnorm_swish(N, C, H, W):
                        (bn.running_var, bn_ref.running_var, "running_var")):
         a, b = a.detach().cpu().double(), b.detach()
         assert float((a - b).abs().max()) <= 1e-4 * float(b.abs().max()) + 1e-6, (what, float((a - b).abs().max()), float(b.abs().max()))
+
+
+@pytest.mark.parametrize("rows,cols", [(2048, 32), (1920, 64), (1024, 128), (300, 32), (7, 256)])
+def test_colsum_multi_row_counts(rows, cols):
+    """sqd_colsum_multi over few and over thousands of partial rows (2 / 8 / 32 float4 columns per workgroup by row count): fixed-order sums against
+    float64, run-to-run identical"""
+    from sqd import nnkernels
+    g = torch.Generator().manual_seed(rows + cols)
+    part = torch.randn(rows, cols, generator=g).cuda()
+    out = [torch.empty(cols, device="cuda") for _ in range(2)]
+    for o in out:
+        nnkernels._colsum_multi([(part, o, 0)])
+    ref = part.double().sum(0)
+    assert torch.equal(out[0], out[1])
+    assert float((out[0].double() - ref).abs().max()) <= 1e-5 * float(part.double().abs().sum(0).max())
