@@ -103,6 +103,7 @@ class Trainer:
         self.model_lr_scheduler = optim.lr_scheduler.StepLR(self.model_optimizer, self.opt.scheduler_step_size, 0.1)
 
         self._graph, self._graph_warm, self._capturing = None, 0, False
+        self._hwc_keys = []                     # static source frames the captured step keeps channels_last (_capture)
         self.epoch, self.step, self.start_time = 0, 0, time.time()      # (train() resets them, as the reference does)
         all_params = [p for m in self.models.values() for p in m.parameters()]
         self.reducer = ddp.GradBucketReducer(all_params, self.opt.sqd_bucket_mb) if ddp.COMM is not None else None
