@@ -338,6 +338,13 @@ int sqd_adam_step(const void *recs, const void *grads, const void *chunks, int n
 int sqd_adam_hyper(double lr, double beta1, double beta2, int step, float *hyper_host);
 int sqd_adam_step_dev(const void *recs, const void *grads, const void *chunks, int nchunks, const float *hyper_dev,
                       double beta1, double beta2, double eps, void *stream);
+/* ... that also leave max |p| of the updated tensors behind: amax_recs (may be NULL) = device array [ntensors] of pointers to
+ * SQD_AMAX_RECORD_FLOATS-float records (section 10b), NULL per tensor that needs none; the records must have been cleared on the stream.
+ * The filters' operand scales of the next step's two-term fp16 convolutions then need no pass over the weights (sqd_amax_multi).      */
+int sqd_adam_step_amax(const void *recs, const void *grads, const void *chunks, int nchunks, double lr, double beta1,
+                       double beta2, double eps, int step, const void *amax_recs, void *stream);
+int sqd_adam_step_dev_amax(const void *recs, const void *grads, const void *chunks, int nchunks, const float *hyper_dev,
+                           double beta1, double beta2, double eps, const void *amax_recs, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (10) convolution as implicit GEMM on the fp32 matrix cores, channels-last

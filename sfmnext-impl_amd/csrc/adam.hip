@@ -16,9 +16,13 @@ struct TensorRec {                   // one parameter tensor (device table, rebu
     long long n;
 };
 
+// amax_recs != NULL: [ntensors] device pointers to max |x| records (sqd_common.h: amax_commit; cleared on the stream by the caller) or NULL per
+// tensor — the kernel leaves max |p_new| of every listed tensor behind, so that the convolutions that read those filters on two-term fp16
+// operands in the next step need no pass of their own over the weights (amax.hip: sqd_amax_multi, 131 MB per step at configs[1])
 __global__ __launch_bounds__(256) void adam_kernel(const TensorRec *__restrict__ recs, const float *const *__restrict__ grads,
                                                    const int2 *__restrict__ chunks, float step_size, float omb1, float beta2,
-                                                   float omb2, float eps, float inv_bc2_sqrt, const float *__restrict__ hyper) {
+                                                   float omb2, float eps, float inv_bc2_sqrt, const float *__restrict__ hyper,
+                                                   unsigned *const *__restrict__ amax_recs = nullptr) {
     if (hyper) {                                     // step-dependent scalars from device memory (graph replay: the launch
         step_size = hyper[0];                        // arguments are frozen at capture time)
         inv_bc2_sqrt = hyper[1];
@@ -27,6 +31,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const TensorRec *__restrict__
     const TensorRec r = recs[ch.x];
     const float *__restrict__ g = grads[ch.x];
     const long long base = (long long)ch.y * CHUNK;
+    unsigned am = 0u;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const long long i = base + ((long long)k * 256 + threadIdx.x) * 4;
@@ -43,6 +48,7 @@ __global__ __launch_bounds__(256) void adam_kernel(const TensorRec *__restrict__
                 vq[e] = fmaf(omb2 * gg[e], gg[e], vq[e] * beta2);             // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
                 const float denom = sqrtf(vq[e]) * inv_bc2_sqrt + eps;
                 pp[e] -= step_size * (mm[e] / denom);                         // param.addcdiv_(exp_avg, denom, -step_size)
+                am = max(am, abs_bits(pp[e]));
             }
             *reinterpret_cast<float4 *>(r.p + i) = pv;
             *reinterpret_cast<float4 *>(r.m + i) = mv;
@@ -55,10 +61,13 @@ __global__ __launch_bounds__(256) void adam_kernel(const TensorRec *__restrict__
                 ve = fmaf(omb2 * ge, ge, ve * beta2);
                 r.m[e] = me;
                 r.v[e] = ve;
-                r.p[e] -= step_size * (me / (sqrtf(ve) * inv_bc2_sqrt + eps));
+                const float pn = r.p[e] - step_size * (me / (sqrtf(ve) * inv_bc2_sqrt + eps));
+                r.p[e] = pn;
+                am = max(am, abs_bits(pn));
             }
         }
     }
+    if (amax_recs) amax_commit(am, amax_recs[ch.x]);      // (workgroup-uniform: one tensor per workgroup; NULL entry: nothing recorded)
 }
 
 // AdamW (torch.optim.AdamW: param.mul_(1 - lr * weight_decay) first, then the Adam update) with the gradient optionally scaled by a
@@ -189,6 +198,12 @@ extern "C" int sqd_clip_coef(const float *part, int n, double max_norm, float *c
 // recs [ntensors] of {p, m, v, n} (device), grads [ntensors] device pointers (device array), chunks [nchunks] int2 (device)
 extern "C" int sqd_adam_step(const void *recs, const void *grads, const void *chunks, int nchunks, double lr, double beta1,
                              double beta2, double eps, int step, void *stream) {
+    return sqd_adam_step_amax(recs, grads, chunks, nchunks, lr, beta1, beta2, eps, step, nullptr, stream);
+}
+// ... and amax_recs (may be NULL): [ntensors] device pointers (device array) to SQD_AMAX_RECORD_FLOATS-float records, or NULL per tensor; the
+// records must have been cleared on the stream: the step leaves the bit pattern of max |p| of each listed tensor in its record
+extern "C" int sqd_adam_step_amax(const void *recs, const void *grads, const void *chunks, int nchunks, double lr, double beta1,
+                                  double beta2, double eps, int step, const void *amax_recs, void *stream) {
     SQD_CHECK_ARG(recs && grads && chunks && nchunks > 0 && step >= 1, "sqd_adam_step: bad arguments");
     const double bc1 = 1.0 - pow(beta1, step), bc2 = 1.0 - pow(beta2, step);
     const float step_size = (float)(lr / bc1), inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
@@ -198,7 +213,7 @@ extern "C" int sqd_adam_step(const void *recs, const void *grads, const void *ch
     (void)hipGetLastError();
     hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const TensorRec *)recs,
                        (const float *const *)grads, (const int2 *)chunks, step_size, omb1, (float)beta2, omb2, (float)eps, inv_bc2_sqrt,
-                       (const float *)nullptr);
+                       (const float *)nullptr, (unsigned *const *)amax_recs);
     SQD_CHECK_LAUNCH("sqd_adam_step");
     return SQD_OK;
 }
@@ -215,11 +230,16 @@ extern "C" int sqd_adam_hyper(double lr, double beta1, double beta2, int step, f
 // replays only need the two floats refreshed
 extern "C" int sqd_adam_step_dev(const void *recs, const void *grads, const void *chunks, int nchunks, const float *hyper_dev,
                                  double beta1, double beta2, double eps, void *stream) {
+    return sqd_adam_step_dev_amax(recs, grads, chunks, nchunks, hyper_dev, beta1, beta2, eps, nullptr, stream);
+}
+extern "C" int sqd_adam_step_dev_amax(const void *recs, const void *grads, const void *chunks, int nchunks, const float *hyper_dev,
+                                      double beta1, double beta2, double eps, const void *amax_recs, void *stream) {
     SQD_CHECK_ARG(recs && grads && chunks && nchunks > 0 && hyper_dev, "sqd_adam_step_dev: bad arguments");
     const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
     (void)hipGetLastError();
     hipLaunchKernelGGL(adam_kernel, dim3(nchunks), dim3(256), 0, (hipStream_t)stream, (const TensorRec *)recs,
-                       (const float *const *)grads, (const int2 *)chunks, 0.f, omb1, (float)beta2, omb2, (float)eps, 0.f, hyper_dev);
+                       (const float *const *)grads, (const int2 *)chunks, 0.f, omb1, (float)beta2, omb2, (float)eps, 0.f, hyper_dev,
+                       (unsigned *const *)amax_recs);
     SQD_CHECK_LAUNCH("sqd_adam_step_dev");
     return SQD_OK;
 }

@@ -182,6 +182,8 @@ _SIGNATURES = {
     "sqd_adam_step": (_I, [_P, _P, _P, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P]),
     "sqd_adam_hyper": (_I, [ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P]),
     "sqd_adam_step_dev": (_I, [_P, _P, _P, _I, _P, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P]),
+    "sqd_adam_step_amax": (_I, [_P, _P, _P, _I, ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.c_double, _I, _P, _P]),
+    "sqd_adam_step_dev_amax": (_I, [_P, _P, _P, _I, _P, ctypes.c_double, ctypes.c_double, ctypes.c_double, _P, _P]),
     "sqd_conv_supported": (_I, [_I, _I]),
     "sqd_conv_set_plan": (_I, [_I] * 16),
     "sqd_conv_plan": (_I, [_I] * 12 + [ctypes.POINTER(ctypes.c_int64)]),

@@ -46,7 +46,7 @@ AMAX_ON = True                 # producers record max |output| (nnops.configure:
 AMAX_STATS = {"fused": 0, "standalone": 0, "sites": {}}
 AMAX_REC = 1024                # SQD_AMAX_RECORD_FLOATS: a record is 64 words in 64 cache lines (the recording kernels spread their atomics over them)
 _AM = {"buf": None, "n": 0, "epoch": 0, "size": 1024}
-_WAM = {"buf": None, "index": {}, "refs": [], "dirty": True, "recs": None, "chunks": None, "nchunks": 0, "fresh": set()}
+_WAM = {"buf": None, "index": {}, "refs": [], "dirty": True, "recs": None, "chunks": None, "nchunks": 0, "fresh": set(), "gen": 0}
 
 
 def amax_enable(on):
@@ -141,6 +141,7 @@ def _wam_slot(w):
         live[key] = ent
         _WAM["index"] = live
         _WAM["dirty"] = True
+        _WAM["gen"] += 1                                # (optimisers cache record addresses per generation of the table)
     return ent
 
 
@@ -174,6 +175,61 @@ def amax_of_weight(w):
 def weights_changed():
     """an optimiser wrote the parameters through raw pointers: the filter table is stale until the next begin_step()"""
     _WAM["fresh"] = set()
+
+
+def filter_records_stale():
+    """has anything written a registered filter through torch (load_state_dict, an initialiser) since its record was taken — or was it never taken?"""
+    for e in _WAM["index"].values():
+        w = e[1]()
+        if w is not None and (e[0] not in _WAM["fresh"] or e[3][0] != w._version):
+            return True
+    return False
+
+
+def refresh_filter_records_if_stale():
+    """Before the replay of a captured step whose graph relies on the previous step's optimiser launch for the filter records (no pass of its
+    own at its start): one eager sqd_amax_multi when something else has written the weights in between."""
+    if AMAX_ON and _WAM["buf"] is not None and filter_records_stale():
+        _wam_refresh()
+
+
+FUSE_ADAM_AMAX = True          # the optimiser's kernel leaves the filters' max |w| records behind (tools may switch it off: tools/ab_bench.py)
+
+
+def wam_records_for(params):
+    """For an optimiser about to update `params` through its own kernel: (generation, {param data_ptr: record address}) if that kernel can
+    leave the filter table's records behind — every live registered filter is among `params` (a filter the step does not touch would lose its
+    record to the clearing) — else None.  The caller clears the records (wam_clear_records) on the stream before its launches and reports
+    wam_records_written(params) after them."""
+    if not (AMAX_ON and FUSE_ADAM_AMAX) or _WAM["buf"] is None:
+        return None
+    live = {k: e for k, e in _WAM["index"].items() if e[1]() is not None}
+    if not live:
+        return None
+    ptrs = {p.data_ptr(): p for p in params}
+    for k, e in live.items():
+        p = ptrs.get(k)
+        if p is None or p.numel() != e[2] or p is not e[1]():
+            return None
+    base = _WAM["buf"].data_ptr()
+    return _WAM["gen"], {k: base + e[0] * AMAX_REC * 4 for k, e in live.items()}
+
+
+def wam_clear_records():
+    """the whole table of filter records, one fill on the stream (slots without a live filter hold nothing anyone reads)"""
+    n = max(e[0] for e in _WAM["index"].values()) + 1
+    _WAM["buf"][:n * AMAX_REC].zero_()
+
+
+def wam_records_written(params):
+    """the optimiser's launches have left max |w| of every live filter in its record: valid until something else writes the parameters"""
+    fresh = set()
+    for e in _WAM["index"].values():
+        w = e[1]()
+        if w is not None:
+            e[3][0] = w._version
+            fresh.add(e[0])
+    _WAM["fresh"] = fresh
 
 
 def _wam_refresh():
@@ -1144,7 +1200,8 @@ _WEIGHT_USES = {}            # id(weight storage) -> forward uses in the current
 
 def begin_step():
     """Training loops call this before every forward pass (the side-stream weight gradients need per-step use counts; the operand
-    scales of the two-term fp16 plans live in a per-step pool, and the filters' are refreshed here)."""
+    scales of the two-term fp16 plans live in a per-step pool, and the filters' are refreshed here).  -> True when the filters' records were
+    refreshed by a pass of this call (a captured step then carries that pass), False when the optimiser's launch had left them valid."""
     _WEIGHT_USES.clear()
     DEFERRED_FILTERS.clear()
     if _AM["buf"] is not None:
@@ -1155,7 +1212,11 @@ def begin_step():
         # them may still be reading
         _AM["retired_prev"], _AM["retired"] = _AM.get("retired", []), []
     if AMAX_ON and _WAM["buf"] is not None:
-        _wam_refresh()
+        # (no pass when the optimiser's kernel left every record behind — wam_records_written — and nothing has written a filter through torch since)
+        if not _WAM["index"] or filter_records_stale() or not FUSE_ADAM_AMAX:
+            _wam_refresh()
+            return True
+    return False
 
 
 def flush_wgrads():

@@ -115,6 +115,12 @@ class FusedAdam(torch.optim.Adam):
 
     def _step_captured(self):
         L = _l.lib()
+        todo = []
+        for gi, group in enumerate(self.param_groups):
+            plist = [p for p in group["params"] if p.grad is not None]
+            if plist and self._tables.get(gi) is not None:
+                todo.append((self._tables[gi], plist))
+        fused = self._amax_tables(todo) if todo else False
         for gi, group in enumerate(self.param_groups):
             plist = [p for p in group["params"] if p.grad is not None]
             if not plist:
@@ -135,10 +141,14 @@ class FusedAdam(torch.optim.Adam):
             tab["graph_host"] = host
             tab["gdev"].copy_(host, non_blocking=True)
             b1, b2 = group["betas"]
-            _l.check(L.sqd_adam_step_dev(ctypes.c_void_p(tab["recs"].data_ptr()), ctypes.c_void_p(tab["gdev"].data_ptr()),
-                                         ctypes.c_void_p(tab["chunks"].data_ptr()), tab["nchunks"],
-                                         ctypes.c_void_p(self._graph_hyper[gi][1].data_ptr()), float(b1), float(b2),
-                                         float(group["eps"]), _stream()), "adam_step_dev")
+            _l.check(L.sqd_adam_step_dev_amax(ctypes.c_void_p(tab["recs"].data_ptr()), ctypes.c_void_p(tab["gdev"].data_ptr()),
+                                              ctypes.c_void_p(tab["chunks"].data_ptr()), tab["nchunks"],
+                                              ctypes.c_void_p(self._graph_hyper[gi][1].data_ptr()), float(b1), float(b2),
+                                              float(group["eps"]), ctypes.c_void_p(tab["amax_dev"].data_ptr()) if fused else None,
+                                              _stream()), "adam_step_dev")
+        if fused:
+            from . import nnkernels
+            nnkernels.wam_records_written([p for _, plist in todo for p in plist])
 
     def _prepare_group(self, gi, group):
         """table of the group's parameters with fresh gradient addresses, and the advanced step count -> (tab, step, plist) or None"""
@@ -174,13 +184,42 @@ class FusedAdam(torch.optim.Adam):
         st0 += 1
         return tab, int(st0.item()), plist
 
+    def _amax_tables(self, tabs_plists):
+        """[(tab, plist)] of one step -> True when the launches of this step leave the convolution filters' max |w| records behind (every live
+        registered filter is updated by them: nnkernels.wam_records_for); fills tab["amax_dev"] (device array of record addresses, 0 = none)
+        and clears the records on the stream."""
+        from . import nnkernels
+        info = nnkernels.wam_records_for([p for _, plist in tabs_plists for p in plist])
+        if info is None:
+            for tab, _ in tabs_plists:
+                tab["amax_on"] = False
+            return False
+        gen, addr = info
+        for tab, plist in tabs_plists:
+            if tab.get("amax_gen") != gen:
+                if torch.cuda.is_current_stream_capturing():
+                    # (a table that changed between the warm-up steps and the capture: leave the records to nnkernels.begin_step)
+                    for t, _ in tabs_plists:
+                        t["amax_on"] = False
+                    return False
+                tab["amax_dev"] = torch.tensor([addr.get(p.data_ptr(), 0) for p in plist], dtype=torch.int64).to(plist[0].device)
+                tab["amax_gen"] = gen
+            tab["amax_on"] = True
+        nnkernels.wam_clear_records()
+        return True
+
     def _launch_groups(self, ready):
         L = _l.lib()
+        fused = self._amax_tables([(tab, plist) for _, _, tab, _, plist in ready]) if ready else False
         for gi, group, tab, step, plist in ready:
             b1, b2 = group["betas"]
-            _l.check(L.sqd_adam_step(ctypes.c_void_p(tab["recs"].data_ptr()), ctypes.c_void_p(tab["gdev"].data_ptr()),
-                                     ctypes.c_void_p(tab["chunks"].data_ptr()), tab["nchunks"], float(group["lr"]), float(b1),
-                                     float(b2), float(group["eps"]), step, _stream()), "adam_step")
+            _l.check(L.sqd_adam_step_amax(ctypes.c_void_p(tab["recs"].data_ptr()), ctypes.c_void_p(tab["gdev"].data_ptr()),
+                                          ctypes.c_void_p(tab["chunks"].data_ptr()), tab["nchunks"], float(group["lr"]), float(b1),
+                                          float(b2), float(group["eps"]), step,
+                                          ctypes.c_void_p(tab["amax_dev"].data_ptr()) if fused else None, _stream()), "adam_step")
+        if fused:
+            from . import nnkernels
+            nnkernels.wam_records_written([p for _, _, _, _, plist in ready for p in plist])
 
     @torch.no_grad()
     def step(self, closure=None):

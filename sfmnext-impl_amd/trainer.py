@@ -277,6 +277,10 @@ class Trainer:
             torch._foreach_copy_(dst, src)
         if pk_dst:
             ops.pack_pixels(pk_src, out=pk_dst)
+        # (the captured step takes the convolution filters' operand-scale records from the previous step's Adam launch: refresh them here if
+        #  something else — load_model, an initialiser — has written the weights since)
+        if not getattr(self, "_graph_refreshes_records", True):
+            nnkernels.refresh_filter_records_if_stale()
         if self.reducer is None or self.opt.sqd_graph_ddp != "post":
             self.model_optimizer.refresh_hyper()
             self._graph.replay()                # forward, backward (+ bucketed all-reduces overlapped with it), Adam
@@ -350,7 +354,9 @@ class Trainer:
         try:
             with torch.cuda.graph(g, stream=self._graph_stream, **mode):
                 try:
-                    nnkernels.begin_step()      # per-step use counts of the filters (a filter used once may defer its gradient's split sum)
+                    # per-step use counts of the filters (a filter used once may defer its gradient's split sum); does the captured step
+                    # refresh the filters' operand-scale records itself, or does it rely on the previous step's Adam launch for them?
+                    self._graph_refreshes_records = nnkernels.begin_step()
                     outputs, losses = self.process_batch(self._static_in)
                     # the reducer's post-accumulate hooks run here, inside the capture: each full bucket is gathered by one
                     # multi-tensor copy and its all-reduce (sqd_comm_allreduce, a plain stream operation) is enqueued on the
@@ -402,7 +408,7 @@ class Trainer:
         try:
             with torch.cuda.graph(g, stream=self._graph_stream, capture_error_mode="thread_local"):
                 try:
-                    nnkernels.begin_step()
+                    self._graph_refreshes_records = nnkernels.begin_step()
                     outputs, losses = self.process_batch(self._static_in)
                     self._backward(losses["loss"])
                     # fresh gradients (assigned, not accumulated: no memsets, no ~170 accumulate launches) -> the buckets, as

@@ -348,3 +348,49 @@ def test_colsum_multi_row_counts(rows, cols):
     ref = part.double().sum(0)
     assert torch.equal(out[0], out[1])
     assert float((out[0].double() - ref).abs().max()) <= 1e-5 * float(part.double().abs().sum(0).max())
+
+
+def test_adam_step_leaves_the_filter_records_behind():
+    """FusedAdam's launch leaves max |w| of every registered convolution filter in its operand-scale record (sqd_adam_step_amax): the next
+    step's begin_step runs no pass over the weights; a filter written through torch in between is noticed (version) and the pass runs again"""
+    import torch.nn as nn
+    from sqd import nnkernels, nnops, optim
+    nnkernels.amax_enable(True)
+    torch.manual_seed(3)
+    convs = [nn.Conv2d(32, 64, 3, 1, 1).cuda().to(memory_format=torch.channels_last), nn.Conv2d(64, 32, 1).cuda().to(memory_format=torch.channels_last)]
+    params = [p for c in convs for p in c.parameters()]
+    opt = optim.FusedAdam(params, lr=1e-2)
+    x = torch.randn(2, 32, 12, 20, device="cuda").contiguous(memory_format=torch.channels_last)
+
+    passes = []
+    orig = nnkernels._wam_refresh
+    nnkernels._wam_refresh = lambda: (passes.append(1), orig())[1]
+    for c in convs:
+        nnkernels.amax_of_weight(c.weight)            # (what a two-term fp16 plan of these layers does on its first use: the filters join the table)
+    try:
+        for step in range(3):
+            refreshed = nnkernels.begin_step()
+            y = nnops.conv2d(nnops.conv2d(x, convs[0]), convs[1])
+            (y ** 2).mean().backward()
+            standalone = nnkernels.AMAX_STATS["sites"].get("filter (first use)", 0)
+            opt.step()
+            opt.zero_grad(set_to_none=True)
+            assert not nnkernels.filter_records_stale(), step
+            for c in convs:
+                ent = nnkernels._wam_slot(c.weight)
+                rec = nnkernels._WAM["buf"][ent[0] * nnkernels.AMAX_REC:(ent[0] + 1) * nnkernels.AMAX_REC]
+                got = rec.view(torch.int32).max().view(torch.float32)
+                assert float(got) == float(c.weight.detach().abs().max()), (step, float(got), float(c.weight.detach().abs().max()))
+            if step > 0:
+                assert refreshed is False, step                        # the previous step's Adam launch had left the records valid
+        n = len(passes)
+        assert nnkernels.begin_step() is False and len(passes) == n
+        with torch.no_grad():
+            convs[0].weight.mul_(3.0)                                  # written through torch: the version moves
+        assert nnkernels.filter_records_stale()
+        assert nnkernels.begin_step() is True and len(passes) == n + 1
+        ent = nnkernels._wam_slot(convs[0].weight)
+        rec = nnkernels._WAM["buf"][ent[0] * nnkernels.AMAX_REC:(ent[0] + 1) * nnkernels.AMAX_REC]
+        assert float(rec.view(torch.int32).max().view(torch.float32)) == float(convs[0].weight.detach().abs().max())
+    finally:
+        nnkernels._wam_refresh = orig
