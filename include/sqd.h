@@ -211,6 +211,10 @@ int sqd_sql_fwd(const float *x, const float *K, float *y, float *summary, float 
 int sqd_sql_bwd(const float *x, const float *K, const float *y, const float *g_y, const float *g_summary,
                 const float *summary, const float *lse, float *g_x, float *g_K, float *gk_part, int B, int Q,
                 int E, int N, int x_nhwc, void *stream);
+/* ... and amax_gx (may be NULL; cleared by the caller): the bit pattern of max |g_x| — g_x is the output gradient of the convolution that produced the
+ * features; that node reads it on two-term fp16 operands (section 10b) and needs no pass of its own for the scale */
+int sqd_sql_bwd_amax(const float *x, const float *K, const float *y, const float *g_y, const float *g_summary, const float *summary,
+                     const float *lse, float *g_x, float *g_K, float *gk_part, int B, int Q, int E, int N, int x_nhwc, float *amax_gx, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (6) BatchNorm2d fused with activation and residual add, channels-last activations
@@ -295,6 +299,9 @@ int sqd_upcat_bwd(const float *g_out, float *g_x, float *g_skip, int N, int Hi, 
 int sqd_upcat_bwd_bn_rows(int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs);
 int sqd_upcat_bwd_bn(const float *g_out, float *g_x, float *g_skip, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs, const float *xb,
                      const unsigned char *maskb, const float *meanb, const float *rstdb, int act, float *partb, void *stream);
+/* ... and amax_gx (may be NULL; cleared by the caller): the bit pattern of max |g_x|, for the convolution backward that reads g_x on two-term fp16 operands */
+int sqd_upcat_bwd_bn_amax(const float *g_out, float *g_x, float *g_skip, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs, const float *xb,
+                          const unsigned char *maskb, const float *meanb, const float *rstdb, int act, float *partb, float *amax_gx, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * (8) stand-alone forward kernels behind the reference's layer classes (not used by the training path,

@@ -301,7 +301,10 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
                                                         const float *__restrict__ gS, const float *__restrict__ summary,
                                                         const float *__restrict__ lse, float *__restrict__ g_x,
                                                         float *__restrict__ gK_part, int Q, int E, int N, int nchunks, int xse,
-                                                        int xsn) {
+                                                        int xsn, unsigned *__restrict__ amax_gx) {
+    // amax_gx (may be NULL; cleared by the caller): the bit pattern of max |g_x| — g_x is the output gradient of the convolution that produced the
+    // features, which reads it on two-term fp16 operands (sqd.h section 10b)
+    unsigned am = 0u;
     constexpr int QP = QT * 32, EP = EH * 32 + 1;                 // x, g_x: element (e, n) at e * xse + n * xsn (see sql_fwd_kernel)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Kl = lds, *Sl = Kl + QP * EP, *qc = Sl + QP * EP;      // K[q][e], gS[q][e], per-query (max, 1/sum, dot, -)
@@ -445,12 +448,16 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
                     v.x = __float_as_int(gx[4 * g4]); v.y = __float_as_int(gx[4 * g4 + 1]);
                     v.z = __float_as_int(gx[4 * g4 + 2]); v.w = __float_as_int(gx[4 * g4 + 3]);
                     __builtin_amdgcn_raw_buffer_store_b128(v, gx_r, (pv && e0 < E) ? ((unsigned)p * (unsigned)xsn + e0) * 4u : SQL_OOB, 0, 0);
+                    if (pv && e0 < E)
+                        am = max(max(am, abs_bits(gx[4 * g4])), max(abs_bits(gx[4 * g4 + 1]), max(abs_bits(gx[4 * g4 + 2]), abs_bits(gx[4 * g4 + 3]))));
                 }
             } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
+                for (int r = 0; r < 16; ++r) {
                     stb32(gx_r, eh * 32 + acc_row(r, h) < E ? lane_gx + (unsigned)(eh * 32 + (r & 3) + 8 * (r >> 2)) * xse4 : SQL_OOB,
                           gx[r]);                                                                           // pixel >= N: dropped
+                    if (pv && eh * 32 + acc_row(r, h) < E) am = max(am, abs_bits(gx[r]));
+                }
             }
         }
         // ---- g_K[q][e] += sum_p gyt[q][p] x[e][p]; k-step (gq, j): half-wave 0 takes pixel 8gq+j, half-wave 1 pixel 8gq+4+j
@@ -489,6 +496,7 @@ __global__ __launch_bounds__(256) void sql_bwd32_kernel(const float *__restrict_
                                                red[((size_t)2 * QP + q) * 32 + e]) + red[((size_t)3 * QP + q) * 32 + e];
         }
     }
+    amax_commit(am, amax_gx);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -505,8 +513,9 @@ __global__ __launch_bounds__(256) void sql_bwd32q_kernel(const float *__restrict
                                                          const float *__restrict__ gS, const float *__restrict__ summary,
                                                          const float *__restrict__ lse, float *__restrict__ g_x,
                                                          float *__restrict__ gK_part, int Q, int E, int N, int nchunks, int xse,
-                                                         int xsn) {
+                                                         int xsn, unsigned *__restrict__ amax_gx) {
     static_assert(QT == 2 || QT == 4, "query-group waves per pixel tile");
+    unsigned am = 0u;                                             // (max |g_x| over this thread's stores: sql_bwd32_kernel)
     constexpr int QP = QT * 32, EP = EH * 32 + 1, PTW = 4 / QT;   // pixel tiles per workgroup iteration
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *Kl = lds, *Sl = Kl + QP * EP, *qc = Sl + QP * EP;      // K[q][e], gS[q][e], per-query (max, 1/sum, dot, -)
@@ -722,11 +731,13 @@ __global__ __launch_bounds__(256) void sql_bwd32q_kernel(const float *__restrict
                     sql_i32x4 o;
                     o.x = __float_as_int(v[0]); o.y = __float_as_int(v[1]); o.z = __float_as_int(v[2]); o.w = __float_as_int(v[3]);
                     __builtin_amdgcn_raw_buffer_store_b128(o, gx_r, (pv && e0 < E) ? ((unsigned)p * (unsigned)xsn + e0) * 4u : SQL_OOB, 0, 0);
+                    if (pv && e0 < E) am = max(max(am, abs_bits(v[0])), max(abs_bits(v[1]), max(abs_bits(v[2]), abs_bits(v[3]))));
                 } else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int r = 4 * g4 + j;
                         stb32(gx_r, eh * 32 + acc_row(r, h) < E ? lane_gx + (unsigned)(eh * 32 + (r & 3) + 8 * (r >> 2)) * xse4 : SQL_OOB, v[j]);
+                        if (pv && eh * 32 + acc_row(r, h) < E) am = max(am, abs_bits(v[j]));
                     }
                 }
             }
@@ -750,6 +761,7 @@ __global__ __launch_bounds__(256) void sql_bwd32q_kernel(const float *__restrict
             po[(size_t)q * E + eh * 32 + e] = sum;
         }
     }
+    amax_commit(am, amax_gx);
 }
 
 // g_K[b,q,e] = sum over chunks of gK_part: 64 outputs per workgroup, the chunks dealt to its four waves (fixed order), added through LDS
@@ -1100,6 +1112,12 @@ extern "C" int sqd_sql_fwd(const float *x, const float *K, float *y, float *summ
 extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const float *g_y, const float *g_summary,
                            const float *summary, const float *lse, float *g_x, float *g_K, float *gk_part, int B, int Q,
                            int E, int N, int x_nhwc, void *stream) {
+    return sqd_sql_bwd_amax(x, K, y, g_y, g_summary, summary, lse, g_x, g_K, gk_part, B, Q, E, N, x_nhwc, nullptr, stream);
+}
+// ... and amax_gx (may be NULL; cleared by the caller): the bit pattern of max |g_x| (sqd.h section 10b)
+extern "C" int sqd_sql_bwd_amax(const float *x, const float *K, const float *y, const float *g_y, const float *g_summary,
+                                const float *summary, const float *lse, float *g_x, float *g_K, float *gk_part, int B, int Q,
+                                int E, int N, int x_nhwc, float *amax_gx, void *stream) {
     SQD_CHECK_ARG(x && K && y && g_summary && summary && lse && g_x && g_K && gk_part, "sqd_sql_bwd: null pointer");
     const int xse = x_nhwc ? 1 : N, xsn = x_nhwc ? E : 1;
     Plan p;
@@ -1115,7 +1133,7 @@ extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sql_bwd32_kernel<QT_, EH_>),                              \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                                  \
         hipLaunchKernelGGL((sql_bwd32_kernel<QT_, EH_>), dim3(p.nchunks_bwd, B), dim3(256), shmem, (hipStream_t)stream, x, K, y, g_y, \
-                           g_summary, summary, lse, g_x, gk_part, Q, E, N, p.nchunks_bwd, xse, xsn);                                \
+                           g_summary, summary, lse, g_x, gk_part, Q, E, N, p.nchunks_bwd, xse, xsn, (unsigned *)amax_gx);               \
     }
         const size_t shmem_q = ((size_t)2 * QP * (eh * 32 + 1) + QP * 4 + (size_t)4 * 32 * TP + (eh == 1 ? 0 : (size_t)4 * eh * 16 * 64) +
                                 (size_t)(4 / qt) * 32 * (eh * 32 + 4)) * sizeof(float);      // (+ the shared x tiles of an iteration)
@@ -1125,7 +1143,7 @@ extern "C" int sqd_sql_bwd(const float *x, const float *K, const float *y, const
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&sql_bwd32q_kernel<QT_, EH_>),                             \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem_q);                                \
         hipLaunchKernelGGL((sql_bwd32q_kernel<QT_, EH_>), dim3(p.nchunks_bwd, B), dim3(256), shmem_q, (hipStream_t)stream, x, K, y, g_y, \
-                           g_summary, summary, lse, g_x, gk_part, Q, E, N, p.nchunks_bwd, xse, xsn);                                \
+                           g_summary, summary, lse, g_x, gk_part, Q, E, N, p.nchunks_bwd, xse, xsn, (unsigned *)amax_gx);               \
     }
         if (eh == 1) {
             if (qt == 1) SQL_BWD32(1, 1) else if (qt == 2) SQL_BWD32Q(2, 1) else SQL_BWD32Q(4, 1)

@@ -69,8 +69,12 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float *__restrict_
                                                         float *__restrict__ g_skip, int N, int Hi, int Wi, int Cx, int Ho,
                                                         int Wo, int Cs, float sy, float sx, float isy, float isx, const float *__restrict__ xb = nullptr,
                                                         const unsigned char *__restrict__ maskb = nullptr, const float *__restrict__ meanb = nullptr,
-                                                        const float *__restrict__ rstdb = nullptr, float slope = 0.f, float *__restrict__ partb = nullptr) {
+                                                        const float *__restrict__ rstdb = nullptr, float slope = 0.f, float *__restrict__ partb = nullptr,
+                                                        unsigned *__restrict__ amax_gx = nullptr) {
+    // amax_gx (may be NULL; cleared by the caller): the bit pattern of max |g_x| — the operand scale of a convolution backward that reads g_x on
+    // two-term fp16 operands (the decoder's first 1x1 layer has no BatchNorm behind it: g_x is its output gradient)
     __shared__ float4 red[2][256];
+    unsigned am = 0u;
     const unsigned Ct = Cx + Cs, Vt = Ct / 4, Vx = Cx / 4, Vs = Cs / 4;
     const unsigned nx = (unsigned)N * Hi * Wi * Vx, ns = (unsigned)N * Ho * Wo * Vs;
     float4 sb = make_float4(0.f, 0.f, 0.f, 0.f), qb = sb, mub = sb, rsb = sb;
@@ -108,6 +112,7 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float *__restrict_
             }
         }
         reinterpret_cast<float4 *>(g_x)[i] = acc;
+        am = max(max(am, abs_bits(acc.x)), max(abs_bits(acc.y), max(abs_bits(acc.z), abs_bits(acc.w))));
         if (xb) {
             const unsigned bits = maskb ? maskb[i] : 0xfu;
             const float4 xv = reinterpret_cast<const float4 *>(xb)[i];
@@ -133,6 +138,7 @@ __global__ __launch_bounds__(256) void upcat_bwd_kernel(const float *__restrict_
             reinterpret_cast<float4 *>(o)[1] = make_float4(sb.z, qb.z, sb.w, qb.w);
         }
     }
+    amax_commit(am, amax_gx);
 }
 
 int grid_for(size_t total) {
@@ -176,6 +182,12 @@ extern "C" int sqd_upcat_bwd_bn_rows(int N, int Hi, int Wi, int Cx, int Ho, int 
 // -> partb [sqd_upcat_bwd_bn_rows(...)][Cx][2] for its sqd_bn_train_bwd_pre.  xb = NULL: sqd_upcat_bwd.
 extern "C" int sqd_upcat_bwd_bn(const float *g_out, float *g_x, float *g_skip, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs, const float *xb,
                                 const unsigned char *maskb, const float *meanb, const float *rstdb, int act, float *partb, void *stream) {
+    return sqd_upcat_bwd_bn_amax(g_out, g_x, g_skip, N, Hi, Wi, Cx, Ho, Wo, Cs, xb, maskb, meanb, rstdb, act, partb, nullptr, stream);
+}
+// ... and amax_gx (may be NULL; cleared by the caller): the bit pattern of max |g_x| (sqd.h section 10b)
+extern "C" int sqd_upcat_bwd_bn_amax(const float *g_out, float *g_x, float *g_skip, int N, int Hi, int Wi, int Cx, int Ho, int Wo, int Cs, const float *xb,
+                                     const unsigned char *maskb, const float *meanb, const float *rstdb, int act, float *partb, float *amax_gx,
+                                     void *stream) {
     SQD_CHECK_ARG(!xb || (meanb && rstdb && partb && (act == 0 || ((act == 1 || act == 2) && maskb)) && sqd_upcat_bwd_bn_rows(N, Hi, Wi, Cx, Ho, Wo, Cs) > 0),
                   "sqd_upcat_bwd_bn: the BatchNorm sums need meanb, rstdb, partb, the sign mask with ReLU / LeakyReLU, and Cx / 4 dividing 256");
     SQD_CHECK_ARG(g_out && g_x && g_skip, "sqd_upcat_bwd: null pointer");
@@ -187,7 +199,8 @@ extern "C" int sqd_upcat_bwd_bn(const float *g_out, float *g_x, float *g_skip, i
     SQD_CHECK_ARG(total < (1ull << 31) && (long long)N * Ho * Wo * (Cx + Cs) / 4 < (1ll << 31), "sqd_upcat_bwd: tensors of 2^31 float4 groups or more");
     (void)hipGetLastError();
     hipLaunchKernelGGL(upcat_bwd_kernel, dim3(xb ? sqd_upcat_bwd_bn_rows(N, Hi, Wi, Cx, Ho, Wo, Cs) : grid_for(total)), dim3(256), 0, (hipStream_t)stream, g_out,
-                       g_x, g_skip, N, Hi, Wi, Cx, Ho, Wo, Cs, sy, sx, isy, isx, xb, act ? maskb : nullptr, meanb, rstdb, act == 2 ? 0.01f : 0.f, partb);
+                       g_x, g_skip, N, Hi, Wi, Cx, Ho, Wo, Cs, sy, sx, isy, isx, xb, act ? maskb : nullptr, meanb, rstdb, act == 2 ? 0.01f : 0.f, partb,
+                       (unsigned *)amax_gx);
     SQD_CHECK_LAUNCH("sqd_upcat_bwd");
     return SQD_OK;
 }

@@ -150,6 +150,7 @@ _SIGNATURES = {
     "sqd_sql_workspace": (_I, [_I, _I, _I, _I, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]),
     "sqd_sql_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
     "sqd_sql_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P]),
+    "sqd_sql_bwd_amax": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P]),
     "sqd_bn_nblk": (_I, [_I, _I]),
     "sqd_bn_train_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _F, _I, _P]),
     "sqd_bn_eval_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _F, _I, _P]),
@@ -170,6 +171,7 @@ _SIGNATURES = {
     "sqd_upcat_bwd": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     "sqd_upcat_bwd_bn_rows": (_I, [_I, _I, _I, _I, _I, _I, _I]),
     "sqd_upcat_bwd_bn": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P]),
+    "sqd_upcat_bwd_bn_amax": (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P, _I, _P, _P, _P]),
     "sqd_backproject_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),
     "sqd_project3d_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _F, _P]),
     "sqd_ssim_fwd": (_I, [_P, _P, _P, _I, _I, _I, _P]),

@@ -451,7 +451,12 @@ class UpsampleConcat(torch.autograd.Function):
                                         _ptr(src["rstd"]), src["code"], _ptr(part), _stream()), "upcat_bwd_bn")
             src.update(dx=g_x, part=part, rows=rows)
         else:
-            _l.check(L.sqd_upcat_bwd(_ptr(g_out), _ptr(g_x), _ptr(g_skip), N, Hi, Wi, Cx, Ho, Wo, Cs, _stream()), "upcat_bwd")
+            # (no BatchNorm behind x — the decoder's first 1x1 convolution —: g_x is a convolution's output gradient, and the gather records its
+            #  max |.| for that node's two-term fp16 operands instead of a pass of its own)
+            agx = _amax_out(g_out.device)
+            _l.check(L.sqd_upcat_bwd_bn_amax(_ptr(g_out), _ptr(g_x), _ptr(g_skip), N, Hi, Wi, Cx, Ho, Wo, Cs, None, None, None, None, 0, None, _ptr(agx),
+                                             _stream()), "upcat_bwd")
+            _amax_tag(g_x, agx)
         return g_x, g_skip
 
 

@@ -565,8 +565,13 @@ class SelfQueryLayer(torch.autograd.Function):
         g_x = torch.empty_like(x)                          # x's layout (preserve_format)
         g_K = torch.empty_like(queries)
         part = torch.empty(nk, device=dev, dtype=torch.float32)
-        _l.check(_l.lib().sqd_sql_bwd(_ptr(x), _ptr(queries), _ptr(y), _ptr(g_y), _ptr(g_summary), _ptr(summary), _ptr(lse),
-                                      _ptr(g_x), _ptr(g_K), _ptr(part), B, Q, E, N, int(ctx.nhwc), _stream()), "sql_bwd")
+        # (g_x is the output gradient of the convolution that produced the features: the kernel records its max |.| for that node's two-term
+        #  fp16 operands — a 47 MB pass of its own at configs[1] otherwise)
+        from . import nnkernels
+        agx = nnkernels._amax_out(dev)
+        _l.check(_l.lib().sqd_sql_bwd_amax(_ptr(x), _ptr(queries), _ptr(y), _ptr(g_y), _ptr(g_summary), _ptr(summary), _ptr(lse),
+                                           _ptr(g_x), _ptr(g_K), _ptr(part), B, Q, E, N, int(ctx.nhwc), _ptr(agx), _stream()), "sql_bwd")
+        nnkernels._amax_tag(g_x, agx)
         return g_x, g_K
 
 

@@ -69,3 +69,23 @@ def test_config_b_full_size():
     want = _ref(x, K, wy, ws)
     _check(_run(x, K, wy, ws), want)
     _check(_run(x, K, wy, ws, channels_last=True), want)
+
+
+@pytest.mark.parametrize("B,E,Q,h,w,cl", [(2, 32, 64, 24, 40, True), (2, 32, 24, 12, 20, False), (1, 64, 128, 16, 24, True), (2, 48, 64, 9, 13, True)])
+def test_backward_records_max_abs_of_the_feature_gradient(B, E, Q, h, w, cl):
+    """sqd_sql_bwd_amax: the backward kernels (both formulations, both layouts, ragged tiles) leave the bit pattern of max |g_x| in the record the
+    feature gradient is tagged with — the operand scale of the convolution backward that reads it"""
+    from sqd import nnkernels, ops
+    nnkernels.amax_enable(True)
+    nnkernels.begin_step()
+    g = torch.Generator().manual_seed(B * E + Q + h)
+    x = torch.randn(B, E, h, w, generator=g).cuda()
+    if cl:
+        x = x.contiguous(memory_format=torch.channels_last)
+    x.requires_grad_(True)
+    K = torch.randn(B, Q, E, generator=g).cuda().requires_grad_(True)
+    y, s = ops.SelfQueryLayer.apply(x, K)
+    gx, = torch.autograd.grad((y * torch.randn(y.shape, generator=g).cuda()).sum() + (s * torch.randn(s.shape, generator=g).cuda()).sum(), x)
+    rec = nnkernels._amax_get(gx)
+    assert rec is not None
+    assert float(rec.view(torch.int32).max().view(torch.float32)) == float(gx.abs().max())
