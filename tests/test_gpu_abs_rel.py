@@ -310,9 +310,21 @@ def _oracle_stretch(O, T, noises, perturb):
 
 
 _ABSREL_RUNS = {}
+_ABSREL_SEEDS = [11, 12, 13]
+_ORACLE_STRETCH = {}
 
 
-@pytest.mark.parametrize("seed", [11, 12, 13])
+def _oracle_pair(O, T, seed):
+    """the oracle's stretch from the trained state under the seed's tie-break noise, and the same from weights perturbed by 1e-7 (its own
+    sensitivity) — CPU only, deterministic, computed once per seed"""
+    if seed not in _ORACLE_STRETCH:
+        g = torch.Generator().manual_seed(seed)
+        noises = [torch.randn(R50_B, 2, R50_H, R50_W, generator=g) for _ in range(CMP_STEPS)]
+        _ORACLE_STRETCH[seed] = (noises, _oracle_stretch(O, T, noises, 0.0), _oracle_stretch(O, T, noises, 1e-7))
+    return _ORACLE_STRETCH[seed]
+
+
+@pytest.mark.parametrize("seed", _ABSREL_SEEDS)
 def test_abs_rel_resnet50_from_trained_weights(trained_state, seed):
     sys.path.insert(0, REPO)
     from oracle import torch_ref as O
@@ -321,11 +333,12 @@ def test_abs_rel_resnet50_from_trained_weights(trained_state, seed):
     from sqd import nnkernels
     T = trained_state
     torch.set_num_threads(min(32, os.cpu_count() or 1))
-    g = torch.Generator().manual_seed(seed)
-    noises = [torch.randn(R50_B, 2, R50_H, R50_W, generator=g) for _ in range(CMP_STEPS)]
-    start, want, ref_loss = _oracle_stretch(O, T, noises, 0.0)
-    _, want_p, ref_loss_p = _oracle_stretch(O, T, noises, 1e-7)
+    noises, (start, want, ref_loss), (_, want_p, ref_loss_p) = _oracle_pair(O, T, seed)
     floor = abs(want[0] - want_p[0])
+    # the bound of EVERY seed is three times the oracle's worst sensitivity over ALL seeds (known before any device run: whichever seed runs
+    # first is held to the same bound; until round 6's last session the first seed was held to its own floor alone, and a box whose plan
+    # timing picked another arithmetic for a few layers — the device trajectory follows the plans — could leave it)
+    worst_floor = max(abs(w[0] - wp[0]) for _, (_, w, _), (_, wp, _) in (_oracle_pair(O, T, sd) for sd in _ABSREL_SEEDS))
     assert start[0] < 0.25, start                       # the pre-fit and the warm-up left a trained model
     nnkernels.reset_plans()
     tr = Trainer(MonodepthOptions().parse(R50_ARGS))    # --learning_rate at its default 1e-4; plan timing ON, graph replay ON: what bench.py runs
@@ -359,5 +372,4 @@ def test_abs_rel_resnet50_from_trained_weights(trained_state, seed):
     # per-pixel (1 - SSIM) / 2 and |difference| terms that are differences of O(1) numbers: fp32 leaves ~1e-6 of absolute error in it
     # (measured 8e-7; 3e-7 at the loss ~0.1 of the untrained full-step tests)
     assert abs(dev_loss[0] - ref_loss[0]) <= max(2e-5 * abs(ref_loss[0]), 2e-6), (dev_loss[0], ref_loss[0])
-    worst_floor = max(f for _, f in _ABSREL_RUNS.values())
-    assert abs(got[0] - want[0]) <= max(1e-3, 3.0 * worst_floor), ("abs_rel", got[0], want[0], want_p[0])
+    assert abs(got[0] - want[0]) <= max(1e-3, 3.0 * worst_floor), ("abs_rel", got[0], want[0], want_p[0], worst_floor)
